@@ -1,0 +1,174 @@
+"""ctypes binding of the C ABI declared in include/copra_hip.h (libcopra_hip.so).
+
+The library is hand-written HIP for gfx950; there is NO CPU fallback: if the shared object is missing or no HIP
+device is usable, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcopra_hip.so")
+
+COPRA_OK, COPRA_ERR_DOMAIN, COPRA_ERR_RUNTIME, COPRA_ERR_HIP, COPRA_ERR_UNSUPPORTED, COPRA_ERR_ARG = range(6)
+
+COST_KINDS = {"trajectory": 0, "target": 1, "control": 2, "mixed": 3}
+CSTR_KINDS = {"trajectory": 0, "control": 1, "mixed": 2, "trajectory_bound": 3, "control_bound": 4}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class CostDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("m_cols", C.c_int), ("n_cols", C.c_int),
+                ("M", _dp), ("N", _dp), ("p", _dp), ("weights", _dp)]
+
+
+class CstrDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("e_cols", C.c_int), ("g_cols", C.c_int),
+                ("is_inequality", C.c_int), ("E", _dp), ("G", _dp), ("f", _dp), ("lower", _dp), ("upper", _dp)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int), ("batch", C.c_int)]
+
+
+class CopraDomainError(ValueError):
+    """std::domain_error of the reference (include/debugUtils.h:32-36)"""
+
+
+class CopraRuntimeError(RuntimeError):
+    """std::runtime_error of the reference (include/debugUtils.h:38-42)"""
+
+
+class CopraUnsupported(NotImplementedError):
+    pass
+
+
+def fcol(a):
+    """column-major contiguous float64"""
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else _dp()
+
+
+def pack_costs(costs, keep):
+    """costs: list of dicts {kind, M, N, p, weights}.  `keep` collects the numpy buffers the structs point into."""
+    arr = (CostDesc * max(1, len(costs)))()
+    for i, c in enumerate(costs):
+        M = fcol(np.atleast_2d(c["M"])) if c.get("M") is not None else None
+        Nm = fcol(np.atleast_2d(c["N"])) if c.get("N") is not None else None
+        p = fcol(np.atleast_1d(c["p"]))
+        rows = p.shape[0]
+        w = c.get("weights")
+        w = np.ones(rows) if w is None else np.atleast_1d(np.asarray(w, dtype=np.float64))
+        if w.shape[0] != rows:  # CostFunction::weights (include/costFunctions.h:54-67)
+            if w.shape[0] == 0 or rows % w.shape[0] != 0:
+                raise CopraDomainError("weights: bad dimension")
+            w = np.tile(w, rows // w.shape[0])
+        w = fcol(w)
+        for m, nm in ((M, "M"), (Nm, "N")):
+            if m is not None and m.shape[0] != rows:  # costFunctions.cpp:47-49
+                raise CopraDomainError("%s and p must have the same number of rows (try autoSpan)" % nm)
+        keep.extend([M, Nm, p, w])
+        arr[i].kind = COST_KINDS[c["kind"]]
+        arr[i].rows = rows
+        arr[i].m_cols = M.shape[1] if M is not None else 0
+        arr[i].n_cols = Nm.shape[1] if Nm is not None else 0
+        arr[i].M, arr[i].N, arr[i].p, arr[i].weights = dptr(M), dptr(Nm), dptr(p), dptr(w)
+    return arr
+
+
+def pack_cstrs(cstrs, keep):
+    arr = (CstrDesc * max(1, len(cstrs)))()
+    for i, c in enumerate(cstrs):
+        kind = CSTR_KINDS[c["kind"]]
+        arr[i].kind = kind
+        arr[i].is_inequality = 1 if c.get("ineq", True) else 0
+        if kind in (3, 4):
+            lo = fcol(np.atleast_1d(c["lower"]))
+            up = fcol(np.atleast_1d(c["upper"]))
+            if lo.shape[0] != up.shape[0]:  # constraints.cpp:265-267, 339-341
+                raise CopraDomainError("lower and upper must have the same number of rows (try autoSpan)")
+            keep.extend([lo, up])
+            arr[i].rows = lo.shape[0]
+            arr[i].lower, arr[i].upper = dptr(lo), dptr(up)
+        else:
+            E = fcol(np.atleast_2d(c["E"])) if c.get("E") is not None else None
+            G = fcol(np.atleast_2d(c["G"])) if c.get("G") is not None else None
+            f = fcol(np.atleast_1d(c["f"]))
+            for m, nm in ((E, "E"), (G, "G")):
+                if m is not None and m.shape[0] != f.shape[0]:  # constraints.cpp:47-49, 112-114, 173-178
+                    raise CopraDomainError("%s and f must have the same number of rows (try autoSpan)" % nm)
+            keep.extend([E, G, f])
+            arr[i].rows = f.shape[0]
+            arr[i].e_cols = E.shape[1] if E is not None else 0
+            arr[i].g_cols = G.shape[1] if G is not None else 0
+            arr[i].E, arr[i].G, arr[i].f = dptr(E), dptr(G), dptr(f)
+    return arr
+
+
+_lib = None
+
+
+def lib():
+    """Load libcopra_hip.so; raises (no fallback) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "copra_amd: %s is missing -- build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C copra_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.copra_batch_create.restype = C.c_int
+        L.copra_batch_create.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc), C.c_int,
+                                         C.POINTER(CstrDesc)]
+        L.copra_batch_destroy.restype = None
+        L.copra_batch_destroy.argtypes = [vp]
+        L.copra_batch_set_system.restype = C.c_int
+        L.copra_batch_set_system.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+        L.copra_batch_set_x0.restype = C.c_int
+        L.copra_batch_set_x0.argtypes = [vp, vp, C.c_int]
+        L.copra_batch_solve.restype = C.c_int
+        L.copra_batch_solve.argtypes = [vp, vp]
+        L.copra_batch_synchronize.restype = C.c_int
+        L.copra_batch_synchronize.argtypes = [vp]
+        for nm in ("copra_batch_control_device", "copra_batch_trajectory_device", "copra_batch_status_device",
+                   "copra_batch_iter_device"):
+            getattr(L, nm).restype = vp
+            getattr(L, nm).argtypes = [vp]
+        L.copra_batch_get_results.restype = C.c_int
+        L.copra_batch_get_results.argtypes = [vp, vp, vp, vp, vp]
+        L.copra_batch_qp_sizes.restype = C.c_int
+        L.copra_batch_qp_sizes.argtypes = [vp, _ip, _ip, _ip]
+        L.copra_batch_dump_qp.restype = C.c_int
+        L.copra_batch_dump_qp.argtypes = [vp, C.c_int] + [vp] * 8
+        L.copra_batch_last_solve_seconds.restype = C.c_int
+        L.copra_batch_last_solve_seconds.argtypes = [vp, _dp]
+        L.copra_qp_solve_dense_batch.restype = C.c_int
+        L.copra_qp_solve_dense_batch.argtypes = [C.c_int] * 4 + [vp] * 11 + [C.c_int, vp]
+        L.copra_last_error.restype = C.c_char_p
+        L.copra_device_info.restype = C.c_int
+        L.copra_device_info.argtypes = [_ip, _ip, C.c_char_p, C.c_int]
+        L.copra_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == COPRA_OK:
+        return
+    msg = lib().copra_last_error().decode("utf-8", "replace")
+    if rc == COPRA_ERR_DOMAIN:
+        raise CopraDomainError(msg)
+    if rc == COPRA_ERR_RUNTIME:
+        raise CopraRuntimeError(msg)
+    if rc == COPRA_ERR_UNSUPPORTED:
+        raise CopraUnsupported(msg)
+    if rc == COPRA_ERR_HIP:
+        raise RuntimeError("HIP: " + msg)
+    raise ValueError("copra_hip: bad argument: " + msg)

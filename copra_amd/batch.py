@@ -1,0 +1,155 @@
+"""BatchLMPC -- host-side handle of one batched LMPC controller (thin ctypes layer over include/copra_hip.h).
+
+Mirrors the call sequence of the reference controller (src/LMPC.cpp): construct with the preview-system dimensions,
+costs and constraints (LMPC::LMPC / addCost / addConstraint), hand over A, B, d, x0 for every instance
+(PreviewSystem::system), solve() (LMPC::solve), then control() / trajectory() (LMPC.h:108-110).
+
+Arrays given as numpy use natural indexing (A[b] is the nx x nx state matrix of instance b) and are converted to
+the ABI layout (column-major per instance).  torch CUDA tensors are used in place and must already be in ABI layout
+(i.e. A_abi[b] = A[b].T contiguous); see to_abi_layout().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def to_abi_layout(A, B, d, x0):
+    """numpy (b,nx,nx),(b,nx,nu),(b,nx),(b,nx) natural indexing -> contiguous per-instance column-major arrays"""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    Ab = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    Bb = np.ascontiguousarray(np.transpose(B, (0, 2, 1)))
+    return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
+
+
+def _is_torch(t):
+    return type(t).__module__.startswith("torch")
+
+
+class BatchLMPC:
+    def __init__(self, nx, nu, N, batch, costs, cstrs):
+        self._lib = _capi.lib()
+        self.nx, self.nu, self.N, self.batch = int(nx), int(nu), int(N), int(batch)
+        self.n = self.nu * self.N
+        self.X = self.nx * (self.N + 1)
+        self._keep = []
+        cc = _capi.pack_costs(costs, self._keep)
+        kk = _capi.pack_cstrs(cstrs, self._keep)
+        dims = _capi.Dims(self.nx, self.nu, self.N, self.batch)
+        self._h = C.c_void_p()
+        _capi.check(self._lib.copra_batch_create(C.byref(self._h), C.byref(dims), len(costs), cc, len(cstrs), kk))
+        self._sys = None
+        self._outs = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.copra_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # PreviewSystem::system for every instance
+    def set_system(self, A, B, d, x0):
+        if _is_torch(A):
+            self._sys = (A, B, d, x0)  # keep alive; used in place
+            for t in self._sys:
+                assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float64"
+            _capi.check(self._lib.copra_batch_set_system(self._h, A.data_ptr(), B.data_ptr(), d.data_ptr(),
+                                                         x0.data_ptr(), 1))
+        else:
+            Ab, Bb, db, xb = to_abi_layout(A, B, d, x0)
+            assert Ab.shape == (self.batch, self.nx, self.nx) and Bb.shape == (self.batch, self.nu, self.nx)
+            assert db.shape == (self.batch, self.nx) and xb.shape == (self.batch, self.nx)
+            _capi.check(self._lib.copra_batch_set_system(self._h, Ab.ctypes.data, Bb.ctypes.data, db.ctypes.data,
+                                                         xb.ctypes.data, 0))
+
+    # PreviewSystem::xInit for every instance
+    def set_x0(self, x0):
+        if _is_torch(x0):
+            self._x0 = x0
+            _capi.check(self._lib.copra_batch_set_x0(self._h, x0.data_ptr(), 1))
+        else:
+            xb = np.ascontiguousarray(x0, dtype=np.float64)
+            _capi.check(self._lib.copra_batch_set_x0(self._h, xb.ctypes.data, 0))
+
+    def set_outputs(self, control, trajectory, status, iters):
+        """torch CUDA tensors (float64 [b,n], float64 [b,X], int32 [b], int32 [b,2]) that receive the results"""
+        self._outs = (control, trajectory, status, iters)
+        _capi.check(self._lib.copra_batch_set_outputs(self._h, control.data_ptr(), trajectory.data_ptr(),
+                                                      status.data_ptr(), iters.data_ptr()))
+
+    def solve(self, stream=None):
+        """LMPC::solve for the whole batch; asynchronous on `stream` (an integer hipStream_t handle or None)"""
+        _capi.check(self._lib.copra_batch_solve(self._h, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        _capi.check(self._lib.copra_batch_synchronize(self._h))
+
+    def last_solve_seconds(self):
+        s = C.c_double()
+        _capi.check(self._lib.copra_batch_last_solve_seconds(self._h, C.byref(s)))
+        return s.value
+
+    def results(self):
+        u = np.empty((self.batch, self.n))
+        tr = np.empty((self.batch, self.X))
+        st = np.empty(self.batch, dtype=np.int32)
+        it = np.empty((self.batch, 2), dtype=np.int32)
+        _capi.check(self._lib.copra_batch_get_results(self._h, u.ctypes.data, tr.ctypes.data, st.ctypes.data,
+                                                      it.ctypes.data))
+        return dict(control=u, trajectory=tr, status=st, iter=it)
+
+    def qp_sizes(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _capi.check(self._lib.copra_batch_qp_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def dump_qp(self, instance):
+        """The dense QP of one instance as LMPC exposes it (LMPC.h:112-127), condensed on the device."""
+        n, neq, nineq = self.qp_sizes()
+        Q = np.zeros((n, n), order="F")
+        c = np.zeros(n)
+        Aeq = np.zeros((neq, n), order="F")
+        beq = np.zeros(neq)
+        Aineq = np.zeros((nineq, n), order="F")
+        bineq = np.zeros(nineq)
+        lb, ub = np.zeros(n), np.zeros(n)
+        _capi.check(self._lib.copra_batch_dump_qp(self._h, instance, Q.ctypes.data, c.ctypes.data, Aeq.ctypes.data,
+                                                  beq.ctypes.data, Aineq.ctypes.data, bineq.ctypes.data,
+                                                  lb.ctypes.data, ub.ctypes.data))
+        return dict(Q=np.array(Q), c=c, Aeq=np.array(Aeq), beq=beq, Aineq=np.array(Aineq), bineq=bineq, lb=lb, ub=ub)
+
+
+def qp_solve_dense_batch(Q, c, Aeq, beq, Aineq, bineq, XL, XU):
+    """Batched QuadProgDenseSolver::SI_solve (src/QuadProgSolver.cpp:54-72) on the GPU; numpy, natural indexing:
+    Q (b,n,n), c (b,n), Aeq (b,meq,n) or None, ...  Returns x (b,n), fail (b,), iter (b,2)."""
+    L = _capi.lib()
+    Q = np.asarray(Q, dtype=np.float64)
+    b, n = Q.shape[0], Q.shape[1]
+    Aeq = np.zeros((b, 0, n)) if Aeq is None else np.asarray(Aeq, dtype=np.float64).reshape(b, -1, n)
+    Aineq = np.zeros((b, 0, n)) if Aineq is None else np.asarray(Aineq, dtype=np.float64).reshape(b, -1, n)
+    beq = np.zeros((b, 0)) if beq is None else np.asarray(beq, dtype=np.float64).reshape(b, -1)
+    bineq = np.zeros((b, 0)) if bineq is None else np.asarray(bineq, dtype=np.float64).reshape(b, -1)
+    neq, nineq = Aeq.shape[1], Aineq.shape[1]
+
+    def cm(a):
+        return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+
+    Qb, Aeqb, Aineqb = cm(Q), cm(Aeq), cm(Aineq)
+    cb = np.ascontiguousarray(c, dtype=np.float64)
+    beqb, bineqb = np.ascontiguousarray(beq), np.ascontiguousarray(bineq)
+    XLb, XUb = np.ascontiguousarray(XL, dtype=np.float64), np.ascontiguousarray(XU, dtype=np.float64)
+    x = np.full((b, n), np.nan)
+    fail = np.full(b, -1, dtype=np.int32)
+    it = np.zeros((b, 2), dtype=np.int32)
+    _capi.check(L.copra_qp_solve_dense_batch(b, n, neq, nineq, Qb.ctypes.data, cb.ctypes.data, Aeqb.ctypes.data,
+                                             beqb.ctypes.data, Aineqb.ctypes.data, bineqb.ctypes.data,
+                                             XLb.ctypes.data, XUb.ctypes.data, x.ctypes.data, fail.ctypes.data,
+                                             it.ctypes.data, 0, None))
+    return x, fail, it

@@ -1,0 +1,478 @@
+// copra_hip.hip -- kernels + C ABI (include/copra_hip.h) of the MI355X-native batched linear-MPC engine.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared copra_hip.hip -o libcopra_hip.so  (see Makefile)
+#include <hip/hip_runtime.h>
+
+#include "../../include/copra_hip.h"
+#include "lmpc_fused.hpp"
+#include "plan_builder.hpp"
+#include "qp_dense.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace copra_hip;
+
+// ------------------------------------------------------------------------------------------------
+// kernels: one 64-lane wavefront (= one workgroup) per MPC instance.  The hardware workgroup dispatcher is the
+// work queue: instances with long active-set loops simply hold their CU slot longer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
+{
+    lmpc_fused_body(P, P.inst_offset + (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+copra_status_t fail(copra_status_t code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                                 \
+    do {                                                                                                              \
+        hipError_t e_ = (expr);                                                                                       \
+        if (e_ != hipSuccess) return fail(COPRA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T>
+hipError_t upload(T** dst, const std::vector<T>& src)
+{
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    hipError_t e = hipMalloc((void**)dst, bytes);
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+} // namespace
+
+struct copra_batch {
+    HostPlan hp;
+    // device copies of the plan tables
+    int *d_row_step = nullptr, *d_row_ekind = nullptr, *d_row_eoff = nullptr, *d_row_gkind = nullptr,
+        *d_row_goff = nullptr;
+    double *d_row_f = nullptr, *d_params = nullptr, *d_lb = nullptr, *d_ub = nullptr;
+    // system (owned copies, or borrowed device pointers)
+    double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
+    const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
+    // results
+    double *d_control = nullptr, *d_traj = nullptr;
+    int *d_status = nullptr, *d_iter = nullptr;
+    // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
+    double *ext_control = nullptr, *ext_traj = nullptr;
+    int *ext_status = nullptr, *ext_iter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool timed = false;
+    bool lds_attr_set = false;
+};
+
+static FusedPlan device_plan(const copra_batch* h)
+{
+    FusedPlan P = h->hp.plan;
+    P.row_step = h->d_row_step;
+    P.row_ekind = h->d_row_ekind;
+    P.row_eoff = h->d_row_eoff;
+    P.row_gkind = h->d_row_gkind;
+    P.row_goff = h->d_row_goff;
+    P.row_f = h->d_row_f;
+    P.params = h->d_params;
+    P.lb = h->d_lb;
+    P.ub = h->d_ub;
+    P.A = h->A;
+    P.B = h->B;
+    P.d = h->d;
+    P.x0 = h->x0;
+    P.control = h->ext_control ? h->ext_control : h->d_control;
+    P.trajectory = h->ext_traj ? h->ext_traj : h->d_traj;
+    P.status = h->ext_status ? h->ext_status : h->d_status;
+    P.iter = h->ext_iter ? h->ext_iter : h->d_iter;
+    P.inst_offset = 0;
+    P.dump_instance = -1;
+    P.dump_only = 0;
+    P.dumpQ = P.dumpc = P.dumpA = P.dumpb = nullptr;
+    return P;
+}
+
+static copra_status_t ensure_lds_attr(copra_batch* h)
+{
+    if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_lmpc_fused_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
+    }
+    h->lds_attr_set = true;
+    return COPRA_OK;
+}
+
+extern "C" {
+
+int copra_abi_version(void) { return 1; }
+
+const char* copra_last_error(void) { return g_err.c_str(); }
+
+copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len)
+{
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n_devices) *n_devices = n;
+    if (n > 0) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (cu_count) *cu_count = prop.multiProcessorCount;
+        if (arch_name && arch_name_len > 0) {
+            strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1);
+            arch_name[arch_name_len - 1] = 0;
+        }
+    }
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs)
+{
+    if (!out || !dims || n_costs < 0 || n_cstrs < 0 || (n_costs > 0 && !costs) || (n_cstrs > 0 && !cstrs))
+        return fail(COPRA_ERR_ARG, "copra_batch_create: null / negative argument");
+    *out = nullptr;
+    copra_batch* h = new copra_batch();
+    copra_status_t rc = build_plan(h->hp, *dims, n_costs, costs, n_cstrs, cstrs);
+    if (rc != COPRA_OK) {
+        g_err = h->hp.error;
+        delete h;
+        return rc;
+    }
+    const FusedPlan& P = h->hp.plan;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    chk(upload(&h->d_row_step, h->hp.row_step));
+    chk(upload(&h->d_row_ekind, h->hp.row_ekind));
+    chk(upload(&h->d_row_eoff, h->hp.row_eoff));
+    chk(upload(&h->d_row_gkind, h->hp.row_gkind));
+    chk(upload(&h->d_row_goff, h->hp.row_goff));
+    chk(upload(&h->d_row_f, h->hp.row_f));
+    chk(upload(&h->d_params, h->hp.params));
+    chk(upload(&h->d_lb, h->hp.lb));
+    chk(upload(&h->d_ub, h->hp.ub));
+    const size_t b = (size_t)(P.batch > 0 ? P.batch : 1);
+    chk(hipMalloc((void**)&h->d_control, b * P.n * sizeof(double)));
+    chk(hipMalloc((void**)&h->d_traj, b * P.X * sizeof(double)));
+    chk(hipMalloc((void**)&h->d_status, b * sizeof(int)));
+    chk(hipMalloc((void**)&h->d_iter, b * 2 * sizeof(int)));
+    chk(hipEventCreate(&h->ev0));
+    chk(hipEventCreate(&h->ev1));
+    if (e != hipSuccess) {
+        g_err = std::string("copra_batch_create: ") + hipGetErrorString(e);
+        copra_batch_destroy(h);
+        return COPRA_ERR_HIP;
+    }
+    *out = h;
+    return COPRA_OK;
+}
+
+void copra_batch_destroy(copra_batch_t* h)
+{
+    if (!h) return;
+    (void)hipFree(h->d_row_step);
+    (void)hipFree(h->d_row_ekind);
+    (void)hipFree(h->d_row_eoff);
+    (void)hipFree(h->d_row_gkind);
+    (void)hipFree(h->d_row_goff);
+    (void)hipFree(h->d_row_f);
+    (void)hipFree(h->d_params);
+    (void)hipFree(h->d_lb);
+    (void)hipFree(h->d_ub);
+    (void)hipFree(h->own_A);
+    (void)hipFree(h->own_B);
+    (void)hipFree(h->own_d);
+    (void)hipFree(h->own_x0);
+    (void)hipFree(h->d_control);
+    (void)hipFree(h->d_traj);
+    (void)hipFree(h->d_status);
+    (void)hipFree(h->d_iter);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const double* B, const double* d,
+    const double* x0, int on_device)
+{
+    if (!h || !A || !B || !d || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_system: null argument");
+    const FusedPlan& P = h->hp.plan;
+    const size_t b = (size_t)P.batch;
+    if (on_device) {
+        h->A = A;
+        h->B = B;
+        h->d = d;
+        h->x0 = x0;
+        return COPRA_OK;
+    }
+    const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
+    if (!h->own_A) {
+        HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->own_d, (nd ? nd : 1) * sizeof(double)));
+    }
+    if (!h->own_x0) HIP_TRY(hipMalloc((void**)&h->own_x0, (nd ? nd : 1) * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->own_A, A, nA * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->own_B, B, nB * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->own_d, d, nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->own_x0, x0, nd * sizeof(double), hipMemcpyHostToDevice));
+    h->A = h->own_A;
+    h->B = h->own_B;
+    h->d = h->own_d;
+    h->x0 = h->own_x0;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device)
+{
+    if (!h || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_x0: null argument");
+    const FusedPlan& P = h->hp.plan;
+    if (on_device) {
+        h->x0 = x0;
+        return COPRA_OK;
+    }
+    const size_t nd = (size_t)P.batch * P.nx;
+    if (!h->own_x0) HIP_TRY(hipMalloc((void**)&h->own_x0, (nd ? nd : 1) * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->own_x0, x0, nd * sizeof(double), hipMemcpyHostToDevice));
+    h->x0 = h->own_x0;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter)
+{
+    if (!h || !control || !trajectory || !status || !iter)
+        return fail(COPRA_ERR_ARG, "copra_batch_set_outputs: null argument");
+    h->ext_control = control;
+    h->ext_traj = trajectory;
+    h->ext_status = status;
+    h->ext_iter = iter;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
+    if (!h->A || !h->B || !h->d || !h->x0)
+        return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
+    const FusedPlan P = device_plan(h);
+    hipStream_t s = (hipStream_t)hip_stream;
+    h->last_stream = s;
+    if (P.batch == 0) return COPRA_OK;
+    copra_status_t rc = ensure_lds_attr(h);
+    if (rc != COPRA_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(copra_lmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_synchronize(copra_batch_t* h)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_synchronize: null handle");
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    return COPRA_OK;
+}
+
+const double* copra_batch_control_device(const copra_batch_t* h)
+{
+    return h ? (h->ext_control ? h->ext_control : h->d_control) : nullptr;
+}
+const double* copra_batch_trajectory_device(const copra_batch_t* h)
+{
+    return h ? (h->ext_traj ? h->ext_traj : h->d_traj) : nullptr;
+}
+const int* copra_batch_status_device(const copra_batch_t* h)
+{
+    return h ? (h->ext_status ? h->ext_status : h->d_status) : nullptr;
+}
+const int* copra_batch_iter_device(const copra_batch_t* h)
+{
+    return h ? (h->ext_iter ? h->ext_iter : h->d_iter) : nullptr;
+}
+
+copra_status_t copra_batch_get_results(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_get_results: null handle");
+    const FusedPlan& P = h->hp.plan;
+    const size_t b = (size_t)P.batch;
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    if (control) HIP_TRY(hipMemcpy(control, copra_batch_control_device(h), b * P.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (trajectory) HIP_TRY(hipMemcpy(trajectory, copra_batch_trajectory_device(h), b * P.X * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, copra_batch_status_device(h), b * sizeof(int), hipMemcpyDeviceToHost));
+    if (iter) HIP_TRY(hipMemcpy(iter, copra_batch_iter_device(h), b * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_qp_sizes(const copra_batch_t* h, int* nvar, int* neq, int* nineq)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_qp_sizes: null handle");
+    if (nvar) *nvar = h->hp.plan.n;
+    if (neq) *neq = h->hp.plan.meq;
+    if (nineq) *nineq = h->hp.plan.mineq;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, double* c, double* Aeq, double* beq,
+    double* Aineq, double* bineq, double* lb, double* ub)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_dump_qp: null handle");
+    const FusedPlan& HP = h->hp.plan;
+    if (instance < 0 || instance >= HP.batch) return fail(COPRA_ERR_ARG, "copra_batch_dump_qp: bad instance");
+    if (!h->A) return fail(COPRA_ERR_RUNTIME, "copra_batch_dump_qp: no preview system set");
+    const int n = HP.n, mg = HP.mgen;
+    double *dQ = nullptr, *dc = nullptr, *dA = nullptr, *db = nullptr;
+    HIP_TRY(hipMalloc((void**)&dQ, (size_t)n * n * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&dc, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&dA, (size_t)(mg ? mg : 1) * n * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&db, (size_t)(mg ? mg : 1) * sizeof(double)));
+    FusedPlan P = device_plan(h);
+    P.inst_offset = instance;
+    P.dump_instance = instance;
+    P.dump_only = 1;
+    P.dumpQ = dQ;
+    P.dumpc = dc;
+    P.dumpA = dA;
+    P.dumpb = db;
+    copra_status_t rc = ensure_lds_attr(h);
+    if (rc != COPRA_OK) return rc;
+    hipLaunchKernelGGL(copra_lmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_bytes, h->last_stream, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    std::vector<double> hA((size_t)(mg ? mg : 1) * n), hb((size_t)(mg ? mg : 1));
+    if (Q) HIP_TRY(hipMemcpy(Q, dQ, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (c) HIP_TRY(hipMemcpy(c, dc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hA.data(), dA, hA.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hb.data(), db, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // split the stacked rows (leading dimension mgen) into Aeq (ld meq) and Aineq (ld mineq)
+    for (int j = 0; j < n; ++j) {
+        for (int i = 0; i < HP.meq; ++i)
+            if (Aeq) Aeq[(size_t)j * HP.meq + i] = hA[(size_t)j * mg + i];
+        for (int i = 0; i < HP.mineq; ++i)
+            if (Aineq) Aineq[(size_t)j * HP.mineq + i] = hA[(size_t)j * mg + HP.meq + i];
+    }
+    for (int i = 0; i < HP.meq; ++i)
+        if (beq) beq[i] = hb[(size_t)i];
+    for (int i = 0; i < HP.mineq; ++i)
+        if (bineq) bineq[i] = hb[(size_t)HP.meq + i];
+    if (lb) memcpy(lb, h->hp.lb.data(), (size_t)n * sizeof(double));
+    if (ub) memcpy(ub, h->hp.ub.data(), (size_t)n * sizeof(double));
+    (void)hipFree(dQ);
+    (void)hipFree(dc);
+    (void)hipFree(dA);
+    (void)hipFree(db);
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds)
+{
+    if (!h || !seconds) return fail(COPRA_ERR_ARG, "copra_batch_last_solve_seconds: null argument");
+    if (!h->timed) return fail(COPRA_ERR_RUNTIME, "copra_batch_last_solve_seconds: no solve has been launched");
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *seconds = (double)ms * 1e-3;
+    return COPRA_OK;
+}
+
+copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, const double* Q, const double* c,
+    const double* Aeq, const double* beq, const double* Aineq, const double* bineq, const double* XL,
+    const double* XU, double* x, int* failv, int* iter, int on_device, void* hip_stream)
+{
+    if (batch < 0 || n <= 0 || neq < 0 || nineq < 0) // SI_problem(nrVar, nrEq, nrInEq)
+        return fail(COPRA_ERR_DOMAIN, "copra_qp_solve_dense_batch: bad problem sizes");
+    if (!Q || !c || !XL || !XU || !x || !failv || (neq > 0 && (!Aeq || !beq)) || (nineq > 0 && (!Aineq || !bineq)))
+        return fail(COPRA_ERR_ARG, "copra_qp_solve_dense_batch: null argument");
+    if (n > kWave) return fail(COPRA_ERR_UNSUPPORTED, "dense QP with more than 64 variables is not covered yet");
+    if (batch == 0) return COPRA_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    DensePlan P {};
+    P.n = n;
+    P.meq = neq;
+    P.mineq = nineq;
+    P.mgen = neq + nineq;
+    P.mtotal = P.mgen + 2 * n; // QuadProgSolver.cpp:51
+    P.batch = batch;
+    P.vsmall = qpgen2_vsmall();
+    P.max_iter = 50 * (n + P.mtotal) + 100;
+    layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
+    const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
+    if (lds_bytes > 160u * 1024u) return fail(COPRA_ERR_UNSUPPORTED, "dense QP does not fit LDS");
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_qp_dense_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const size_t b = (size_t)batch;
+    std::vector<void*> owned;
+    auto release = [&]() {
+        for (void* p : owned) (void)hipFree(p);
+    };
+    hipError_t e = hipSuccess;
+    auto to_dev = [&](const double* src, size_t count) -> const double* {
+        if (on_device) return src;
+        double* dptr = nullptr;
+        hipError_t r = hipMalloc((void**)&dptr, (count ? count : 1) * sizeof(double));
+        if (r == hipSuccess && count) r = hipMemcpyAsync(dptr, src, count * sizeof(double), hipMemcpyHostToDevice, s);
+        if (r != hipSuccess && e == hipSuccess) e = r;
+        owned.push_back(dptr);
+        return dptr;
+    };
+    P.Q = to_dev(Q, b * n * n);
+    P.c = to_dev(c, b * n);
+    P.Aeq = to_dev(Aeq, b * neq * n);
+    P.beq = to_dev(beq, b * neq);
+    P.Aineq = to_dev(Aineq, b * nineq * n);
+    P.bineq = to_dev(bineq, b * nineq);
+    P.XL = to_dev(XL, b * n);
+    P.XU = to_dev(XU, b * n);
+    double* dx = x;
+    int *dfail = failv, *diter = iter;
+    if (!on_device) {
+        hipError_t r = hipMalloc((void**)&dx, b * n * sizeof(double));
+        if (r == hipSuccess) r = hipMalloc((void**)&dfail, b * sizeof(int));
+        if (r == hipSuccess) r = hipMalloc((void**)&diter, b * 2 * sizeof(int));
+        if (r != hipSuccess && e == hipSuccess) e = r;
+        owned.push_back(dx);
+        owned.push_back(dfail);
+        owned.push_back(diter);
+    } else if (!diter) {
+        hipError_t r = hipMalloc((void**)&diter, b * 2 * sizeof(int));
+        if (r != hipSuccess && e == hipSuccess) e = r;
+        owned.push_back(diter);
+    }
+    if (e != hipSuccess) {
+        release();
+        return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
+    }
+    P.x = dx;
+    P.fail = dfail;
+    P.iter = diter;
+    hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
+    e = hipGetLastError();
+    if (e == hipSuccess && !on_device) {
+        e = hipMemcpyAsync(x, dx, b * n * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(failv, dfail, b * sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && iter) e = hipMemcpyAsync(iter, diter, b * 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess && !owned.empty()) e = hipStreamSynchronize(s);
+    release();
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
+    return COPRA_OK;
+}
+
+} // extern "C"

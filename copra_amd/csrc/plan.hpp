@@ -1,0 +1,125 @@
+// plan.hpp -- the "compiled" form of one batched LMPC controller, shared by host and device code.
+//
+// copra_batch_create() turns the user's cost / constraint descriptors (the arguments of LMPC::addCost /
+// addConstraint, reference src/LMPC.cpp:118-128) into
+//   * a parameter blob (doubles) holding every M / N / p / w / E / G matrix, column-major,
+//   * a list of cost terms (offsets into the blob),
+//   * a table of constraint ROWS in the order LMPC::makeQPForm stacks them (reference src/LMPC.cpp:257-271:
+//     equalities in insertion order, then inequalities in insertion order), each row being
+//         E_row . x_k  (+ full-horizon E_row . X)  +  G_row . u_k  (+ full-horizon G_row . U)   <=|=   f
+//     so that A = E Psi + G never has to be materialised (reference src/constraints.cpp:66-84, 137-148, 197-226,
+//     284-315 all reduce to this form),
+//   * lb / ub (reference src/constraints.cpp:359-367, src/LMPC.cpp:274-279).
+// The device kernel interprets this plan once per instance; control flow over the plan is wave-uniform.
+#pragma once
+
+namespace copra_hip {
+
+constexpr int kMaxCosts = 8;
+constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
+constexpr int kWave = 64;
+
+// cost kinds (== copra_cost_kind_t)
+enum { kCostTrajectory = 0, kCostTarget = 1, kCostControl = 2, kCostMixed = 3 };
+
+// state part of a constraint row
+enum {
+    kENone = 0, // no state term
+    kEDense = 1, // nx coefficients at params[eoff..] applied to x_step
+    kEOneHot = 2, // coefficient 1 on component `eoff` of x_step (rows of Psi: TrajectoryBoundConstraint)
+    kEFull = 3 // fullXDim coefficients at params[eoff..] applied to the whole trajectory X (full-size entry)
+};
+// control part of a constraint row
+enum {
+    kGNone = 0,
+    kGStep = 1, // nu coefficients at params[goff..] applied to u_step
+    kGFull = 2 // fullUDim coefficients at params[goff..] applied to U (full-size entry)
+};
+
+struct CostTerm {
+    int kind;
+    int rows; // r
+    int offM; // r x nx   (column-major)  or -1
+    int offN; // r x nu                   or -1
+    int offP; // r
+    int offW; // r
+};
+
+// LDS carve-up, offsets in doubles from the dynamic-LDS base (all multiples of 2 doubles = 16 bytes)
+struct LdsLayout {
+    int A, B, D, X0; // system matrices of this instance
+    int G; // N blocks G_k = A^k B (nx x nu, column-major): Psi_{i,j} = G_{i-1-j}  (PreviewSystem.cpp:57-74)
+    int Xbar; // free response  Phi x0 + xi               (fullXDim)
+    int Xcur; // current trajectory Xbar + Psi U          (fullXDim)
+    int J, ldj; // n x ldj: Hessian (upper) -> Cholesky factor -> J = R^-1 (row i at J + i*ldj)
+    int R; // packed upper-triangular R of the active set, n(n+1)/2; ALIASED during the build phase (see Bld*)
+    int xs, dv, zv, uv, ap, coef, cvec; // solver vectors (n; uv n+1; coef 4n)
+    int nb; // norms of the general rows (m_gen)
+    int eqsgn; // current orientation of each equality row (meq)
+    int scal; // 8 scalars
+    int act; // int[m_total] active flags   (offset in doubles; cast to int*)
+    int iact; // int[n+1]
+    // build-phase scratch (aliases R and beyond; sized on the host)
+    int BldPhi; // (N+1) blocks nx x nx
+    int BldXi; // fullXDim
+    int BldY; // N blocks r x nu   (M G_k)
+    int BldWe; // (N+1) blocks r    (w .* (M xbar_k - p))
+    int total; // total doubles
+};
+
+struct FusedPlan {
+    // dimensions
+    int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
+    int batch;
+    // costs
+    int ncost;
+    CostTerm cost[kMaxCosts];
+    int rmax; // max rows over the stage costs
+    // constraint rows
+    int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
+    int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)
+    const int* row_step; // [mgen]
+    const int* row_ekind; // [mgen]
+    const int* row_eoff; // [mgen]
+    const int* row_gkind; // [mgen]
+    const int* row_goff; // [mgen]
+    const double* row_f; // [mgen]
+    const double* params; // blob
+    const double* lb; // [n]
+    const double* ub; // [n]
+    // solver constants
+    double vsmall; // qpgen2's machine-precision guard
+    int max_iter;
+    // batch I/O (device pointers in the product, host pointers in the CPU emulator)
+    const double* A; // [batch][nx*nx]
+    const double* B; // [batch][nx*nu]
+    const double* d; // [batch][nx]
+    const double* x0; // [batch][nx]
+    double* control; // [batch][n]
+    double* trajectory; // [batch][X]
+    int* status; // [batch]
+    int* iter; // [batch][2]
+    int inst_offset; // instance handled by workgroup 0 (normally 0)
+    // optional parity dump (dump_instance >= 0): the dense QP of ONE instance written by the condense code
+    int dump_instance;
+    int dump_only; // 1: stop after the dump (no solve, no result stores)
+    double* dumpQ; // n x n (symmetric, both triangles written)
+    double* dumpc; // n
+    double* dumpA; // mgen x n  (rows in stacking order, <= / = orientation of the reference)
+    double* dumpb; // mgen
+    LdsLayout lds;
+};
+
+// dense batched QP kernel (plug-in point 1): plain SolverInterface::SI_solve arguments, batch-major
+struct DensePlan {
+    int n, meq, mineq, mgen, mtotal, batch;
+    const double *Q, *c, *Aeq, *beq, *Aineq, *bineq, *XL, *XU;
+    double* x;
+    int* fail;
+    int* iter;
+    double vsmall;
+    int max_iter;
+    LdsLayout lds;
+};
+
+} // namespace copra_hip

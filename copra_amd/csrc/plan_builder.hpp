@@ -1,0 +1,364 @@
+// plan_builder.hpp -- host-side compilation of copra cost / constraint descriptors into a FusedPlan.
+// Pure C++ (no HIP): used by the C-ABI library and by the CPU wave-emulator harness under tests/emu/.
+//
+// Mirrors the dimension checks of the reference's initializeCost / initializeConstraint
+// (src/costFunctions.cpp:44-61, 88-98, 122-137, 173-193; src/constraints.cpp:45-64, 106-135, 171-195, 263-282,
+// 333-357) -> COPRA_ERR_DOMAIN, and the stacking order of LMPC::makeQPForm (src/LMPC.cpp:250-280).
+#pragma once
+
+#include "../../include/copra_hip.h"
+#include "plan.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace copra_hip {
+
+struct HostPlan {
+    FusedPlan plan {}; // pointers refer to the vectors below (host addresses)
+    std::vector<double> params;
+    std::vector<int> row_step, row_ekind, row_eoff, row_gkind, row_goff;
+    std::vector<double> row_f;
+    std::vector<double> lb, ub;
+    std::string error;
+    size_t lds_bytes = 0;
+};
+
+// qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
+inline double qpgen2_vsmall()
+{
+    volatile double vsmall = 1.0e-60, ta, tb;
+    do {
+        vsmall = vsmall + vsmall;
+        ta = 1.0 + 0.1 * vsmall;
+        tb = 1.0 + 0.2 * vsmall;
+    } while (ta <= 1.0 || tb <= 1.0);
+    return vsmall;
+}
+
+inline int align2(int v) { return (v + 1) & ~1; }
+
+// LDS carve-up for a solver working on nvar variables with mgen general rows.
+inline void layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
+    bool fused)
+{
+    int o = 0;
+    auto take = [&](int count) {
+        int at = o;
+        o += align2(count);
+        return at;
+    };
+    if (fused) {
+        L.A = take(nx * nx);
+        L.B = take(nx * nu);
+        L.D = take(nx);
+        L.X0 = take(nx);
+        L.G = take(N * nx * nu);
+        L.Xbar = take(X);
+        L.Xcur = take(X);
+    } else {
+        L.A = L.B = L.D = L.X0 = L.G = L.Xbar = L.Xcur = 0;
+    }
+    L.ldj = (n % 2 == 0) ? n + 1 : n; // odd leading dimension: row-per-lane and column-per-lane reads conflict-free
+    L.J = take(n * L.ldj);
+    // R region, aliased by the build scratch
+    int rsize = n * (n + 1) / 2 + 2;
+    int bld = 0;
+    if (fused) {
+        L.BldPhi = 0;
+        L.BldXi = L.BldPhi + align2((N + 1) * nx * nx);
+        L.BldY = L.BldXi + align2(X);
+        L.BldWe = L.BldY + align2(N * rmax * nu);
+        bld = L.BldWe + align2((N + 1) * rmax);
+    }
+    L.R = take(rsize > bld ? rsize : bld);
+    if (fused) {
+        L.BldPhi += L.R;
+        L.BldXi += L.R;
+        L.BldY += L.R;
+        L.BldWe += L.R;
+    }
+    L.xs = take(n);
+    L.dv = take(n);
+    L.zv = take(n);
+    L.uv = take(n + 2);
+    L.ap = take(n);
+    L.coef = take(4 * n);
+    L.cvec = take(n);
+    L.nb = take(mgen > 0 ? mgen : 1);
+    L.eqsgn = take(meq > 0 ? meq : 1);
+    L.scal = take(8);
+    L.act = take((mtotal + 1) / 2 + 1);
+    L.iact = take((n + 2) / 2 + 1);
+    L.total = o;
+}
+
+inline bool is_neg_inf(double v) { return std::isinf(v) && v < 0; }
+inline bool is_pos_inf(double v) { return std::isinf(v) && v > 0; }
+
+inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_costs, const copra_cost_desc_t* costs,
+    int n_cstrs, const copra_cstr_desc_t* cstrs)
+{
+    FusedPlan& P = hp.plan;
+    const int nx = dims.nx, nu = dims.nu, N = dims.N;
+    if (nx <= 0 || nu <= 0 || N <= 0 || dims.batch < 0) { // PreviewSystem.cpp:19-33
+        hp.error = "PreviewSystem: dimensions and number of steps must be positive";
+        return COPRA_ERR_DOMAIN;
+    }
+    const int X = nx * (N + 1), U = nu * N;
+    P.nx = nx;
+    P.nu = nu;
+    P.N = N;
+    P.n = U;
+    P.X = X;
+    P.batch = dims.batch;
+    P.dump_instance = -1;
+    if (n_costs > kMaxCosts) {
+        hp.error = "too many cost functions for the fused kernel";
+        return COPRA_ERR_UNSUPPORTED;
+    }
+    auto push = [&](const double* src, int count) {
+        int at = (int)hp.params.size();
+        hp.params.insert(hp.params.end(), src, src + count);
+        if (hp.params.size() & 1) hp.params.push_back(0.0);
+        return at;
+    };
+
+    // ---------------- costs ----------------
+    P.ncost = n_costs;
+    P.rmax = 1;
+    for (int k = 0; k < n_costs; ++k) {
+        const copra_cost_desc_t& c = costs[k];
+        CostTerm& t = P.cost[k];
+        t.kind = c.kind;
+        t.rows = c.rows;
+        t.offM = t.offN = -1;
+        if (c.rows <= 0 || !c.p || !c.weights) {
+            hp.error = "cost: empty p / weights";
+            return COPRA_ERR_DOMAIN;
+        }
+        bool full = false;
+        switch (c.kind) {
+        case COPRA_COST_TRAJECTORY: // costFunctions.cpp:44-61
+            if (!c.M) return hp.error = "TrajectoryCost: M missing", COPRA_ERR_DOMAIN;
+            if (c.m_cols == nx)
+                full = false;
+            else if (c.m_cols == X)
+                full = true;
+            else
+                return hp.error = "TrajectoryCost: M has neither xDim nor fullXDim columns", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_COST_TARGET: // costFunctions.cpp:88-98
+            if (!c.M) return hp.error = "TargetCost: M missing", COPRA_ERR_DOMAIN;
+            if (c.m_cols != nx) return hp.error = "TargetCost: M must have xDim columns", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_COST_CONTROL: // costFunctions.cpp:122-137
+            if (!c.N) return hp.error = "ControlCost: N missing", COPRA_ERR_DOMAIN;
+            if (c.n_cols == nu)
+                full = false;
+            else if (c.n_cols == U)
+                full = true;
+            else
+                return hp.error = "ControlCost: N has neither uDim nor fullUDim columns", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_COST_MIXED: // costFunctions.cpp:173-193
+            if (!c.M || !c.N) return hp.error = "MixedCost: M / N missing", COPRA_ERR_DOMAIN;
+            if (c.m_cols == nx && c.n_cols == nu)
+                full = false;
+            else if (c.m_cols == X && c.n_cols == U)
+                full = true;
+            else
+                return hp.error = "MixedCost: M / N column mismatch", COPRA_ERR_DOMAIN;
+            break;
+        default:
+            return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
+        }
+        if (full) {
+            hp.error = "full-size cost entries are not yet covered by the fused HIP path";
+            return COPRA_ERR_UNSUPPORTED;
+        }
+        if (c.kind != COPRA_COST_CONTROL) t.offM = push(c.M, c.rows * nx);
+        if (c.kind == COPRA_COST_CONTROL || c.kind == COPRA_COST_MIXED) t.offN = push(c.N, c.rows * nu);
+        t.offP = push(c.p, c.rows);
+        t.offW = push(c.weights, c.rows);
+        if (c.rows > P.rmax) P.rmax = c.rows;
+    }
+
+    // ---------------- constraints: two passes (equalities first, then inequalities) ----------------
+    hp.lb.assign(U, -DBL_MAX); // LMPC.cpp:207-208
+    hp.ub.assign(U, DBL_MAX);
+    int bound_line = 0;
+    P.any_state_rows = 0;
+    // validate + bounds
+    for (int k = 0; k < n_cstrs; ++k) {
+        const copra_cstr_desc_t& c = cstrs[k];
+        if (c.rows <= 0) return hp.error = "constraint: no rows", COPRA_ERR_DOMAIN;
+        switch (c.kind) {
+        case COPRA_CSTR_TRAJECTORY:
+            if (!c.E || !c.f) return hp.error = "TrajectoryConstraint: E / f missing", COPRA_ERR_DOMAIN;
+            if (c.e_cols != nx && c.e_cols != X)
+                return hp.error = "TrajectoryConstraint: E has neither xDim nor fullXDim columns", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_CSTR_CONTROL:
+            if (!c.G || !c.f) return hp.error = "ControlConstraint: G / f missing", COPRA_ERR_DOMAIN;
+            if (c.g_cols != nu && c.g_cols != U)
+                return hp.error = "ControlConstraint: G has neither uDim nor fullUDim columns", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_CSTR_MIXED:
+            if (!c.E || !c.G || !c.f) return hp.error = "MixedConstraint: E / G / f missing", COPRA_ERR_DOMAIN;
+            if (!((c.e_cols == nx && c.g_cols == nu) || (c.e_cols == X && c.g_cols == U)))
+                return hp.error = "MixedConstraint: E / G column mismatch", COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_CSTR_TRAJECTORY_BOUND:
+            if (!c.lower || !c.upper) return hp.error = "TrajectoryBoundConstraint: bounds missing", COPRA_ERR_DOMAIN;
+            if (c.rows != nx && c.rows != X)
+                return hp.error = "TrajectoryBoundConstraint: bounds have neither xDim nor fullXDim rows",
+                       COPRA_ERR_DOMAIN;
+            break;
+        case COPRA_CSTR_CONTROL_BOUND: {
+            if (!c.lower || !c.upper) return hp.error = "ControlBoundConstraint: bounds missing", COPRA_ERR_DOMAIN;
+            if (c.rows != nu && c.rows != U)
+                return hp.error = "ControlBoundConstraint: bounds have neither uDim nor fullUDim rows",
+                       COPRA_ERR_DOMAIN;
+            if (bound_line + U > U) // LMPC.cpp:274-279 writes consecutively: a second bound constraint overflows
+                return hp.error = "more than one ControlBoundConstraint does not fit lb/ub", COPRA_ERR_RUNTIME;
+            for (int i = 0; i < U; ++i) { // constraints.cpp:359-367
+                const int src = (c.rows == nu) ? (i % nu) : i;
+                hp.lb[bound_line + i] = c.lower[src];
+                hp.ub[bound_line + i] = c.upper[src];
+            }
+            bound_line += U;
+            break;
+        }
+        default:
+            return hp.error = "unknown constraint kind", COPRA_ERR_DOMAIN;
+        }
+    }
+    auto add_row = [&](int step, int ekind, int eoff, int gkind, int goff, double f) {
+        hp.row_step.push_back(step);
+        hp.row_ekind.push_back(ekind);
+        hp.row_eoff.push_back(eoff);
+        hp.row_gkind.push_back(gkind);
+        hp.row_goff.push_back(goff);
+        hp.row_f.push_back(f);
+        if (ekind != kENone) P.any_state_rows = 1;
+    };
+    // row-major copy of one row of a column-major (rows x cols) matrix into the blob
+    auto push_row = [&](const double* Mx, int rows, int cols, int r) {
+        std::vector<double> tmp((size_t)cols);
+        for (int j = 0; j < cols; ++j) tmp[(size_t)j] = Mx[(size_t)j * rows + r];
+        return push(tmp.data(), cols);
+    };
+    P.meq = P.mineq = 0;
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: equalities, pass 1: inequalities (LMPC.cpp:257-271)
+        for (int k = 0; k < n_cstrs; ++k) {
+            const copra_cstr_desc_t& c = cstrs[k];
+            if (c.kind == COPRA_CSTR_CONTROL_BOUND) continue;
+            const bool ineq = (c.kind == COPRA_CSTR_TRAJECTORY_BOUND) || c.is_inequality;
+            if ((pass == 1) != ineq) continue;
+            const int before = (int)hp.row_f.size();
+            const int r = c.rows;
+            switch (c.kind) {
+            case COPRA_CSTR_TRAJECTORY: // constraints.cpp:66-84
+                if (c.e_cols == nx) {
+                    std::vector<int> eo((size_t)r);
+                    for (int i = 0; i < r; ++i) eo[(size_t)i] = push_row(c.E, r, nx, i);
+                    for (int s = 0; s <= N; ++s)
+                        for (int i = 0; i < r; ++i) add_row(s, kEDense, eo[(size_t)i], kGNone, -1, c.f[i]);
+                } else {
+                    for (int i = 0; i < r; ++i) add_row(0, kEFull, push_row(c.E, r, X, i), kGNone, -1, c.f[i]);
+                }
+                break;
+            case COPRA_CSTR_CONTROL: // constraints.cpp:137-148
+                if (c.g_cols == nu) {
+                    std::vector<int> go((size_t)r);
+                    for (int i = 0; i < r; ++i) go[(size_t)i] = push_row(c.G, r, nu, i);
+                    for (int s = 0; s < N; ++s)
+                        for (int i = 0; i < r; ++i) add_row(s, kENone, -1, kGStep, go[(size_t)i], c.f[i]);
+                } else {
+                    for (int i = 0; i < r; ++i) add_row(0, kENone, -1, kGFull, push_row(c.G, r, U, i), c.f[i]);
+                }
+                break;
+            case COPRA_CSTR_MIXED: // constraints.cpp:197-226
+                if (c.e_cols == nx) {
+                    std::vector<int> eo((size_t)r), go((size_t)r);
+                    for (int i = 0; i < r; ++i) {
+                        eo[(size_t)i] = push_row(c.E, r, nx, i);
+                        go[(size_t)i] = push_row(c.G, r, nu, i);
+                    }
+                    for (int s = 0; s < N; ++s)
+                        for (int i = 0; i < r; ++i) add_row(s, kEDense, eo[(size_t)i], kGStep, go[(size_t)i], c.f[i]);
+                } else {
+                    for (int i = 0; i < r; ++i)
+                        add_row(0, kEFull, push_row(c.E, r, X, i), kGFull, push_row(c.G, r, U, i), c.f[i]);
+                }
+                break;
+            case COPRA_CSTR_TRAJECTORY_BOUND: { // constraints.h:248-255, constraints.cpp:284-315
+                // reference quirk Q1 reproduced: lower rows keep the SAME orientation as upper rows (x <= lower)
+                const bool full = (c.rows == X);
+                for (int bpass = 0; bpass < 2; ++bpass) {
+                    const double* bound = bpass == 0 ? c.lower : c.upper;
+                    for (int s = 0; s <= N; ++s) {
+                        for (int line = 0; line < c.rows; ++line) {
+                            if (bpass == 0 ? is_neg_inf(bound[line]) : is_pos_inf(bound[line])) continue;
+                            const int row = line + nx * s;
+                            add_row(row / nx, kEOneHot, row % nx, kGNone, -1, bound[line]);
+                        }
+                        if (full) break;
+                    }
+                }
+                break;
+            }
+            default:
+                break;
+            }
+            const int added = (int)hp.row_f.size() - before;
+            if (ineq)
+                P.mineq += added;
+            else
+                P.meq += added;
+        }
+    }
+    P.mgen = P.meq + P.mineq;
+    P.mtotal = P.mgen + 2 * U; // QuadProgSolver.cpp:51
+    if (hp.params.empty()) hp.params.assign(2, 0.0);
+
+    P.vsmall = qpgen2_vsmall();
+    P.max_iter = 50 * (U + P.mtotal) + 100;
+
+    // fused-kernel limits
+    if (U > kWave) {
+        hp.error = "fullUDim > 64 is not covered by the one-wave fused kernel";
+        return COPRA_ERR_UNSUPPORTED;
+    }
+    if (nu > kMaxNu) {
+        hp.error = "uDim > 8 is not covered by the one-wave fused kernel";
+        return COPRA_ERR_UNSUPPORTED;
+    }
+    layout_lds(P.lds, nx, nu, N, U, X, P.rmax, P.mgen, P.meq, P.mtotal, true);
+    hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
+    if (hp.lds_bytes > 160u * 1024u) {
+        hp.error = "problem does not fit the 160 KiB LDS of one CU";
+        return COPRA_ERR_UNSUPPORTED;
+    }
+    return COPRA_OK;
+}
+
+// fix up the pointers of hp.plan to the host vectors (emulator) -- the product path re-points them to HBM copies
+inline void point_plan_to_host(HostPlan& hp)
+{
+    FusedPlan& P = hp.plan;
+    P.row_step = hp.row_step.data();
+    P.row_ekind = hp.row_ekind.data();
+    P.row_eoff = hp.row_eoff.data();
+    P.row_gkind = hp.row_gkind.data();
+    P.row_goff = hp.row_goff.data();
+    P.row_f = hp.row_f.data();
+    P.params = hp.params.data();
+    P.lb = hp.lb.data();
+    P.ub = hp.ub.data();
+}
+
+} // namespace copra_hip

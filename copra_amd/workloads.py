@@ -1,0 +1,92 @@
+"""Synthetic workloads for the BASELINE.json configs.
+
+All random draws come from splitmix64 (vectorised in numpy, trivially reproducible in C) so that the same inputs
+can be regenerated anywhere.  System matrices follow the reference's own fixtures:
+  * double integrator "falling mass": tests/systems.h:63-83 (T = 0.005, m = 5, gravity bias)
+  * CoM preview system: binding/python/tests/pyTests.py:342-359 (A, B, x_init, x_goal, T = 0.117)
+Arrays use natural numpy indexing: A[b] is the (nx, nx) state matrix of instance b.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.state = np.uint64(seed)
+
+    def next_u64(self, count):
+        with np.errstate(over="ignore"):
+            inc = np.uint64(0x9E3779B97F4A7C15)
+            idx = np.arange(1, count + 1, dtype=np.uint64)
+            z = self.state + idx * inc
+            self.state = self.state + np.uint64(count) * inc
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        return z
+
+    def uniform(self, count, lo=0.0, hi=1.0):
+        u = (self.next_u64(count) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return lo + (hi - lo) * u
+
+    def normal(self, count, sigma=1.0):
+        u1 = self.uniform(count)
+        u2 = self.uniform(count)
+        u1 = np.maximum(u1, 1e-300)
+        return sigma * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# pyTests.py:358-359
+COM_X_INIT = np.array([1.5842778860957882, 0.3422260214935311, 2.289067474385933, 0.0, 0.0, 0.0])
+COM_X_GOAL = np.array([1.627772868473883, 0.4156386515475985, 2.3984423755527136,
+                       0.06745225960685897, 0.3882830795737303, 0.06845759848745198])
+
+
+def double_integrator(batch, N=10, seed=0):
+    """BASELINE config 2: batch of falling-mass double integrators (nx=2, nu=1) with a control bound.
+    Per-instance mass m ~ U(3,7) (changes B) and x0 = [U(-1,1), U(-6,-4)]; shared costs / bound (systems.h:63-83)."""
+    rng = SplitMix64(seed)
+    T = 0.005
+    m = rng.uniform(batch, 3.0, 7.0)
+    A = np.tile(np.array([[1.0, T], [0.0, 1.0]]), (batch, 1, 1))
+    B = np.zeros((batch, 2, 1))
+    B[:, 0, 0] = 0.5 * T * T / m
+    B[:, 1, 0] = T / m
+    d = np.tile(np.array([(-9.81 / 2.0) * T * T, -9.81 * T]), (batch, 1))
+    x0 = np.stack([rng.uniform(batch, -1.0, 1.0), rng.uniform(batch, -6.0, -4.0)], axis=1)
+    costs = [dict(kind="target", M=np.eye(2), p=[0.0, -1.0], weights=[10.0, 10000.0]),
+             dict(kind="control", N=[[1.0]], p=[2.0], weights=[1e-4])]
+    cstrs = [dict(kind="control_bound", lower=[-np.inf], upper=[200.0])]
+    return dict(name="double-integrator (nx=2,nu=1,N=%d) + control bound" % N, A=A, B=B, d=d, x0=x0, N=N,
+                costs=costs, cstrs=cstrs)
+
+
+def com_preview(batch, N=20, seed=1, v_max=0.6, u_max=3.0):
+    """BASELINE configs 3/4 (headline): CoM double integrator in 3-D (nx=6, nu=3), per-instance sampling period
+    T ~ U(0.08, 0.15) so A and B differ per instance; x0 = x_init + noise; trajectory cost towards x_goal + small
+    control cost; 2 inequality objects: upper velocity bound (TrajectoryBoundConstraint, 63 rows; upper-only because
+    of reference quirk Q1) and symmetric control bound.  The defaults v_max=0.6, u_max=3.0 leave ~55 % of the
+    instances with at least one active constraint (SURVEY.md 8d asks for 30-60 %); v_max=0.25, u_max=1.2 makes every
+    instance hit 3..22 constraints (used by the parity tests to stress the active-set loop)."""
+    rng = SplitMix64(seed)
+    T = rng.uniform(batch, 0.08, 0.15)
+    I3 = np.eye(3)
+    A = np.zeros((batch, 6, 6))
+    B = np.zeros((batch, 6, 3))
+    A[:, :3, :3] = I3
+    A[:, 3:, 3:] = I3
+    A[:, :3, 3:] = T[:, None, None] * I3
+    B[:, :3, :] = (0.5 * T * T)[:, None, None] * I3
+    B[:, 3:, :] = T[:, None, None] * I3
+    d = np.zeros((batch, 6))
+    x0 = np.tile(COM_X_INIT, (batch, 1))
+    x0[:, :3] += rng.normal(batch * 3, 0.05).reshape(batch, 3)
+    x0[:, 3:] += rng.uniform(batch * 3, -0.2, 0.2).reshape(batch, 3)
+    inf = np.inf
+    costs = [dict(kind="trajectory", M=np.eye(6), p=COM_X_GOAL, weights=[10.0, 10.0, 10.0, 1.0, 1.0, 1.0]),
+             dict(kind="control", N=np.eye(3), p=np.zeros(3), weights=[1e-3] * 3)]
+    cstrs = [dict(kind="trajectory_bound", lower=[-inf] * 6, upper=[inf, inf, inf, v_max, v_max, v_max]),
+             dict(kind="control_bound", lower=[-u_max] * 3, upper=[u_max] * 3)]
+    return dict(name="CoM preview (nx=6,nu=3,N=%d) + trajectory & control bounds" % N, A=A, B=B, d=d, x0=x0, N=N,
+                costs=costs, cstrs=cstrs)

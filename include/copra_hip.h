@@ -1,0 +1,157 @@
+/*
+ * copra_hip.h -- C ABI of the MI355X-native batched condensed linear-MPC engine (libcopra_hip.so).
+ *
+ * This is the drop-in boundary BENEATH copra's C++ classes.  The reference (jrl-umi3218/copra v1.3.3) has no C
+ * ABI of its own; each entry point below names the reference interface it replaces (file:line relative to the
+ * reference tree).  Plain pointers and sizes only -- no torch / Eigen types.  All matrices are FP64 and
+ * column-major per instance (Eigen's default layout, include/PreviewSystem.h:56-62); batched arrays are
+ * batch-major: element (b, i, j) of a [batch][rows x cols] array lives at  ptr[b*rows*cols + j*rows + i].
+ *
+ * Error convention: every function returns a copra_status_t; COPRA_ERR_DOMAIN corresponds to the reference's
+ * std::domain_error (include/debugUtils.h:32-36), COPRA_ERR_RUNTIME to std::runtime_error (:38-42).  No C++
+ * exception crosses this boundary; the C++ wrappers (copra_amd/cpp) translate codes back into those exceptions.
+ * copra_last_error() returns a thread-local message.
+ *
+ * The library REQUIRES a HIP device (gfx950).  There is no CPU fallback: without a usable device every compute
+ * entry point returns COPRA_ERR_HIP.
+ */
+#ifndef COPRA_HIP_H
+#define COPRA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    COPRA_OK = 0,
+    COPRA_ERR_DOMAIN = 1, /* std::domain_error: dimension mismatch (debugUtils.h:32-36) */
+    COPRA_ERR_RUNTIME = 2, /* std::runtime_error (debugUtils.h:38-42) */
+    COPRA_ERR_HIP = 3, /* HIP runtime failure / no device */
+    COPRA_ERR_UNSUPPORTED = 4, /* valid copra problem that this build of the engine does not cover */
+    COPRA_ERR_ARG = 5 /* NULL / negative argument */
+} copra_status_t;
+
+/* Cost kinds: include/costFunctions.h:103 (TrajectoryCost), :134 (TargetCost), :165 (ControlCost), :196 (MixedCost) */
+typedef enum { COPRA_COST_TRAJECTORY = 0, COPRA_COST_TARGET = 1, COPRA_COST_CONTROL = 2, COPRA_COST_MIXED = 3 } copra_cost_kind_t;
+
+/* Constraint kinds: include/constraints.h:114, :153, :193, :234, :284 */
+typedef enum {
+    COPRA_CSTR_TRAJECTORY = 0,
+    COPRA_CSTR_CONTROL = 1,
+    COPRA_CSTR_MIXED = 2,
+    COPRA_CSTR_TRAJECTORY_BOUND = 3,
+    COPRA_CSTR_CONTROL_BOUND = 4
+} copra_cstr_kind_t;
+
+/* Per-instance solver status == SolverInterface::SI_fail() of QuadProgDenseSolver (include/QuadProgSolver.h:21-27),
+ * plus one engine-specific code. */
+typedef enum {
+    COPRA_QP_OK = 0, /* "No problems" */
+    COPRA_QP_INFEASIBLE = 1, /* "The minimization problem has no solution" */
+    COPRA_QP_NOT_PD = 2, /* "Problems with the decomposition of Q" */
+    COPRA_QP_ITER_LIMIT = 3 /* engine safety cap on active-set iterations (never hit by a well-posed QP) */
+} copra_qp_status_t;
+
+/* A cost function exactly as handed to LMPC::addCost (src/LMPC.cpp:118-122), i.e. the constructor arguments of
+ * include/costFunctions.h:112-118 / :142-148 / :171-177 / :203-210 plus CostFunction::weights (:54-67).
+ * Host pointers; copied at copra_batch_create.  The parameters are shared by every instance of the batch. */
+typedef struct {
+    int kind; /* copra_cost_kind_t */
+    int rows; /* rows of M / N / p / weights */
+    int m_cols; /* cols of M: xDim (per-step entry) or fullXDim (full-size entry); 0 if unused */
+    int n_cols; /* cols of N: uDim or fullUDim; 0 if unused */
+    const double* M; /* rows x m_cols */
+    const double* N; /* rows x n_cols */
+    const double* p; /* rows */
+    const double* weights; /* rows */
+} copra_cost_desc_t;
+
+/* A constraint exactly as handed to LMPC::addConstraint (src/LMPC.cpp:124-128): constructor arguments of
+ * include/constraints.h:125-132 / :165-172 / :209-217 / :242-255 / :296-303. */
+typedef struct {
+    int kind; /* copra_cstr_kind_t */
+    int rows; /* rows of E / G / f, or length of lower / upper */
+    int e_cols; /* cols of E (xDim | fullXDim), 0 if unused */
+    int g_cols; /* cols of G (uDim | fullUDim), 0 if unused */
+    int is_inequality; /* isInequalityConstraint (constraints.h:126); ignored by the bound kinds */
+    const double* E;
+    const double* G;
+    const double* f;
+    const double* lower;
+    const double* upper;
+} copra_cstr_desc_t;
+
+/* Dimensions of the preview systems of one batch: PreviewSystem::system(state, control, bias, xInit, numberOfSteps)
+ * (src/PreviewSystem.cpp:16-55). */
+typedef struct {
+    int nx; /* xDim */
+    int nu; /* uDim */
+    int N; /* nrUStep */
+    int batch; /* number of independent preview systems (instances) */
+} copra_dims_t;
+
+typedef struct copra_batch copra_batch_t; /* opaque handle == one batched LMPC controller */
+
+/* ---- controller life cycle (replaces LMPC::LMPC / initializeController / addCost / addConstraint,
+ *      src/LMPC.cpp:56-77, 118-128; dimension checks of costFunctions.cpp:44-61,88-98,122-137,173-193 and
+ *      constraints.cpp:45-64,106-135,171-195,263-282,333-357 -> COPRA_ERR_DOMAIN) ---- */
+copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs);
+void copra_batch_destroy(copra_batch_t* h);
+
+/* ---- PreviewSystem::system / xInit for every instance (src/PreviewSystem.cpp:16-55, include/PreviewSystem.h:52).
+ *      A [batch][nx x nx], B [batch][nx x nu], d [batch][nx], x0 [batch][nx].
+ *      on_device != 0: the pointers are device pointers and are USED IN PLACE (they must stay valid until the next
+ *      call); on_device == 0: host pointers, copied H2D into engine-owned HBM buffers. ---- */
+copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const double* B, const double* d,
+    const double* x0, int on_device);
+copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device);
+
+/* ---- optional: let the caller own the result buffers (device pointers, e.g. torch tensors that are later handed to
+ *      an RCCL gather); must be called before copra_batch_solve and stay valid.  Sizes as in the results block. ---- */
+copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter);
+
+/* ---- LMPC::solve for every instance (src/LMPC.cpp:79-101): condensed-QP build + Goldfarb-Idnani solve +
+ *      updateResults, one launch on `hip_stream` (a hipStream_t, may be NULL = default stream).  Asynchronous. ---- */
+copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream);
+copra_status_t copra_batch_synchronize(copra_batch_t* h);
+
+/* ---- results: LMPC::control() / trajectory() (include/LMPC.h:108-110), SI_fail / SI_iter
+ *      (src/QuadProgSolver.cpp:14-22).  control [batch][nu*N], trajectory [batch][nx*(N+1)], status [batch],
+ *      iter [batch][2] (main iterations, constraint drops).  Device-resident accessors return engine-owned HBM
+ *      pointers valid for the lifetime of the handle.  A failed instance keeps NaN in control/trajectory. ---- */
+const double* copra_batch_control_device(const copra_batch_t* h);
+const double* copra_batch_trajectory_device(const copra_batch_t* h);
+const int* copra_batch_status_device(const copra_batch_t* h);
+const int* copra_batch_iter_device(const copra_batch_t* h);
+copra_status_t copra_batch_get_results(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter);
+
+/* ---- parity hooks: the dense QP of one instance as LMPC exposes it (include/LMPC.h:112-127: Q c Aineq bineq Aeq
+ *      beq lb ub), rebuilt ON THE DEVICE by the same condense code the solver runs.  Any pointer may be NULL.
+ *      Q [n x n], c [n], Aeq [neq x n], beq [neq], Aineq [nineq x n], bineq [nineq], lb [n], ub [n]. ---- */
+copra_status_t copra_batch_qp_sizes(const copra_batch_t* h, int* nvar, int* neq, int* nineq);
+copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, double* c, double* Aeq, double* beq,
+    double* Aineq, double* bineq, double* lb, double* ub);
+
+/* ---- timing contract of LMPC::solveTime()/solveAndBuildTime() (src/LMPC.cpp:82-99, 108-116): device time of the
+ *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch. ---- */
+copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds);
+
+/* ---- plug-in point 1, batched: QuadProgDenseSolver::SI_problem + SI_solve (src/QuadProgSolver.cpp:45-72) for
+ *      `batch` independent dense QPs  min 1/2 x'Qx + c'x  s.t. Aeq x = beq, Aineq x <= bineq, XL <= x <= XU.
+ *      Q [batch][n x n] (upper triangle read), c [batch][n], Aeq [batch][neq x n], beq [batch][neq],
+ *      Aineq [batch][nineq x n], bineq [batch][nineq], XL/XU [batch][n]; outputs x [batch][n], fail [batch]
+ *      (SI_fail), iter [batch][2].  on_device selects host or device pointers for ALL arrays. ---- */
+copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, const double* Q, const double* c,
+    const double* Aeq, const double* beq, const double* Aineq, const double* bineq, const double* XL,
+    const double* XU, double* x, int* fail, int* iter, int on_device, void* hip_stream);
+
+/* ---- misc ---- */
+const char* copra_last_error(void);
+copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len);
+int copra_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COPRA_HIP_H */

@@ -48,12 +48,28 @@ class OrQp(C.Structure):
 _lib = None
 
 
+def _cpu_tag():
+    """-march=native objects must not travel between hosts: tag them with a hash of this host's CPU flags"""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            txt = "".join(l for l in fh if l.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        txt = "unknown"
+    return hashlib.sha1(txt.encode()).hexdigest()[:10]
+
+
 def build(native=False):
-    target = "libcopra_oracle_native.so" if native else "libcopra_oracle.so"
-    path = os.path.join(_HERE, target)
     src = os.path.join(_HERE, "copra_oracle.c")
+    if native:
+        path = os.path.join(_HERE, "libcopra_oracle_native_%s.so" % _cpu_tag())
+        if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c99", "-fPIC", "-ffp-contract=off",
+                                   "-fno-fast-math", "-pthread", "-shared", "-o", path, src, "-lm", "-lpthread"])
+        return path
+    path = os.path.join(_HERE, "libcopra_oracle.so")
     if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "libcopra_oracle.so"], stdout=subprocess.DEVNULL)
     return path
 
 

@@ -1,0 +1,161 @@
+// tests/emu/emu_harness.cpp -- runs the HIP kernel BODIES on the CPU, one fiber per lane (TEST INFRASTRUCTURE ONLY).
+// See wave_prims.hpp in this directory.  Exposes a tiny C interface for ctypes.
+#include "wave_prims.hpp" // must come first: shadows copra_amd/csrc/wave_prims.hpp (same include guard name)
+
+#include "../../copra_amd/csrc/lmpc_fused.hpp"
+#include "../../copra_amd/csrc/plan_builder.hpp"
+#include "../../copra_amd/csrc/qp_dense.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <ucontext.h>
+#include <vector>
+
+namespace copra_hip {
+namespace emu {
+    WaveState g_wave;
+    static ucontext_t g_sched;
+    static ucontext_t g_fiber[64];
+    static bool g_done[64];
+    static std::function<void()>* g_body;
+
+    void yield() { swapcontext(&g_fiber[g_wave.lane], &g_sched); }
+
+    static void fiber_main()
+    {
+        (*g_body)();
+        g_done[g_wave.lane] = true;
+        swapcontext(&g_fiber[g_wave.lane], &g_sched);
+    }
+
+    // run one 64-lane wave to completion
+    static int run_wave(std::function<void()> body, size_t lds_bytes, int inst, int ninst)
+    {
+        static std::vector<char> stacks;
+        const size_t stack_sz = 256 * 1024;
+        if (stacks.size() < 64 * stack_sz) stacks.resize(64 * stack_sz);
+        std::vector<double> lds(lds_bytes / sizeof(double) + 2, __builtin_nan(""));
+        g_wave.lds = lds.data();
+        g_wave.inst = inst;
+        g_wave.ninst = ninst;
+        g_body = &body;
+        for (int l = 0; l < 64; ++l) {
+            g_done[l] = false;
+            getcontext(&g_fiber[l]);
+            g_fiber[l].uc_stack.ss_sp = stacks.data() + l * stack_sz;
+            g_fiber[l].uc_stack.ss_size = stack_sz;
+            g_fiber[l].uc_link = &g_sched;
+            makecontext(&g_fiber[l], fiber_main, 0);
+        }
+        for (;;) {
+            int ndone = 0;
+            for (int l = 0; l < 64; ++l) {
+                if (g_done[l]) {
+                    ++ndone;
+                    continue;
+                }
+                g_wave.lane = l;
+                swapcontext(&g_sched, &g_fiber[l]);
+            }
+            int after = 0;
+            for (int l = 0; l < 64; ++l) after += g_done[l] ? 1 : 0;
+            if (after == 64) return 0;
+            if (after != 0 && after != ndone && after != 64) {
+                // some lanes finished while others wait at a barrier: divergent exit
+                bool all = true;
+                for (int l = 0; l < 64; ++l) all = all && g_done[l];
+                if (!all && after > 0) {
+                    // allow: lanes finish in the same round only
+                    int pending = 64 - after;
+                    if (pending > 0 && ndone == 0) {
+                        fprintf(stderr, "emu: divergent wave exit (%d lanes done, %d waiting)\n", after, pending);
+                        return -1;
+                    }
+                }
+            }
+        }
+    }
+} // namespace emu
+} // namespace copra_hip
+
+using namespace copra_hip;
+
+extern "C" {
+
+// Build the plan exactly as copra_batch_create does and run the fused kernel body for every instance.
+int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
+    const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
+    double* control, double* trajectory, int* status, int* iter, int dump_instance, double* dumpQ, double* dumpc,
+    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes */)
+{
+    HostPlan hp;
+    copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs);
+    if (rc != COPRA_OK) {
+        fprintf(stderr, "emu: %s\n", hp.error.c_str());
+        return (int)rc;
+    }
+    point_plan_to_host(hp);
+    FusedPlan& P = hp.plan;
+    P.A = A;
+    P.B = B;
+    P.d = d;
+    P.x0 = x0;
+    P.control = control;
+    P.trajectory = trajectory;
+    P.status = status;
+    P.iter = iter;
+    P.dump_instance = dump_instance;
+    P.dumpQ = dumpQ;
+    P.dumpc = dumpc;
+    P.dumpA = dumpA;
+    P.dumpb = dumpb;
+    if (sizes) {
+        sizes[0] = P.n;
+        sizes[1] = P.meq;
+        sizes[2] = P.mineq;
+        sizes[3] = (int)hp.lds_bytes;
+    }
+    if (!A) return 0; // size query only
+    for (int b = 0; b < dims->batch; ++b) {
+        int r = emu::run_wave([&]() { lmpc_fused_body(P, b); }, hp.lds_bytes, b, dims->batch);
+        if (r != 0) return -100;
+    }
+    return 0;
+}
+
+int emu_qp_dense(int batch, int n, int neq, int nineq, const double* Q, const double* c, const double* Aeq,
+    const double* beq, const double* Aineq, const double* bineq, const double* XL, const double* XU, double* x,
+    int* fail, int* iter)
+{
+    DensePlan P {};
+    P.n = n;
+    P.meq = neq;
+    P.mineq = nineq;
+    P.mgen = neq + nineq;
+    P.mtotal = P.mgen + 2 * n;
+    P.batch = batch;
+    P.Q = Q;
+    P.c = c;
+    P.Aeq = Aeq;
+    P.beq = beq;
+    P.Aineq = Aineq;
+    P.bineq = bineq;
+    P.XL = XL;
+    P.XU = XU;
+    P.x = x;
+    P.fail = fail;
+    P.iter = iter;
+    P.vsmall = qpgen2_vsmall();
+    P.max_iter = 50 * (n + P.mtotal) + 100;
+    if (n > 64) return (int)COPRA_ERR_UNSUPPORTED;
+    layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
+    const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
+    for (int b = 0; b < batch; ++b) {
+        int r = emu::run_wave([&]() { qp_dense_body(P, b); }, lds_bytes, b, batch);
+        if (r != 0) return -100;
+    }
+    return 0;
+}
+}

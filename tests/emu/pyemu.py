@@ -1,0 +1,111 @@
+"""ctypes front-end of the CPU wave emulator (tests/emu/emu_harness.cpp) -- TEST INFRASTRUCTURE ONLY.
+
+Runs the HIP kernel BODIES (copra_amd/csrc/*.hpp) lane-by-lane on the CPU so that `pytest -m "not gpu"` can compare
+the kernel logic with the oracle without a GPU.  Never used by the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "..", ".."))
+from copra_amd import _capi  # noqa: E402  (struct definitions only; does not load the HIP library)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE, "libcopra_emu.so"], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(os.path.join(_HERE, "libcopra_emu.so"))
+        _lib.emu_lmpc_solve.restype = C.c_int
+        _lib.emu_qp_dense.restype = C.c_int
+    return _lib
+
+
+def _batchify(A, B, d, x0):
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    if A.ndim == 2:
+        A, B = A[None], B[None]
+        d, x0 = np.asarray(d, dtype=np.float64)[None], np.asarray(x0, dtype=np.float64)[None]
+    # per-instance column-major
+    Ab = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    Bb = np.ascontiguousarray(np.transpose(B, (0, 2, 1)))
+    return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
+
+
+def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1):
+    Ab, Bb, db, xb = _batchify(A, B, d, x0)
+    batch, nu, nx = Bb.shape[0], Bb.shape[1], Bb.shape[2]
+    keep = []
+    cc = _capi.pack_costs(costs, keep)
+    kk = _capi.pack_cstrs(cstrs, keep)
+    dims = _capi.Dims(nx, nu, N, batch)
+    sizes = (C.c_int * 4)()
+    vp = C.c_void_p
+    rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, vp(), vp(), vp(), vp(), vp(), vp(), vp(),
+                              vp(), -1, vp(), vp(), vp(), vp(), sizes)
+    if rc == _capi.COPRA_ERR_DOMAIN:
+        raise _capi.CopraDomainError("emu")
+    if rc == _capi.COPRA_ERR_RUNTIME:
+        raise _capi.CopraRuntimeError("emu")
+    if rc == _capi.COPRA_ERR_UNSUPPORTED:
+        raise _capi.CopraUnsupported("emu")
+    n, neq, nineq = sizes[0], sizes[1], sizes[2]
+    mgen = neq + nineq
+    X = nx * (N + 1)
+    u = np.full((batch, n), np.nan)
+    tr = np.full((batch, X), np.nan)
+    st = np.full(batch, -1, dtype=np.int32)
+    it = np.zeros((batch, 2), dtype=np.int32)
+    dQ = np.zeros((n, n), order="F")
+    dc = np.zeros(n)
+    dA = np.zeros((max(mgen, 1), n), order="F")
+    db_ = np.zeros(max(mgen, 1))
+    p = _capi.dptr
+    rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ab), p(Bb), p(db), p(xb), p(u), p(tr),
+                              st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)),
+                              dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes)
+    if rc != 0:
+        raise RuntimeError("emulator failed rc=%d" % rc)
+    out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3])
+    if dump_instance >= 0:
+        out.update(Q=np.array(dQ), c=dc, Aeq=np.array(dA[:neq]), beq=db_[:neq], Aineq=np.array(dA[neq:mgen]),
+                   bineq=db_[neq:mgen])
+    return out
+
+
+def qp_dense(Q, c, Aeq, beq, Aineq, bineq, XL, XU):
+    """batched: Q (b,n,n), c (b,n), Aeq (b,meq,n) ... natural numpy indexing"""
+    Q = np.asarray(Q, dtype=np.float64)
+    if Q.ndim == 2:
+        Q, c, XL, XU = Q[None], np.asarray(c)[None], np.asarray(XL)[None], np.asarray(XU)[None]
+        Aeq = None if Aeq is None else np.asarray(Aeq)[None]
+        beq = None if beq is None else np.asarray(beq)[None]
+        Aineq = None if Aineq is None else np.asarray(Aineq)[None]
+        bineq = None if bineq is None else np.asarray(bineq)[None]
+    b, n = Q.shape[0], Q.shape[1]
+    Aeq = np.zeros((b, 0, n)) if Aeq is None else np.asarray(Aeq, dtype=np.float64).reshape(b, -1, n)
+    Aineq = np.zeros((b, 0, n)) if Aineq is None else np.asarray(Aineq, dtype=np.float64).reshape(b, -1, n)
+    beq = np.zeros((b, 0)) if beq is None else np.asarray(beq, dtype=np.float64).reshape(b, -1)
+    bineq = np.zeros((b, 0)) if bineq is None else np.asarray(bineq, dtype=np.float64).reshape(b, -1)
+    neq, nineq = Aeq.shape[1], Aineq.shape[1]
+    cm = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 1)))  # per-instance column-major
+    Qb, Aeqb, Aineqb = cm(Q), cm(Aeq), cm(Aineq)
+    cb = np.ascontiguousarray(c, dtype=np.float64)
+    beqb, bineqb = np.ascontiguousarray(beq), np.ascontiguousarray(bineq)
+    XLb, XUb = np.ascontiguousarray(XL, dtype=np.float64), np.ascontiguousarray(XU, dtype=np.float64)
+    x = np.full((b, n), np.nan)
+    fail = np.full(b, -1, dtype=np.int32)
+    it = np.zeros((b, 2), dtype=np.int32)
+    p = _capi.dptr
+    rc = lib().emu_qp_dense(b, n, neq, nineq, p(Qb), p(cb), p(Aeqb), p(beqb), p(Aineqb), p(bineqb), p(XLb), p(XUb),
+                            p(x), fail.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc != 0:
+        raise RuntimeError("emulator failed rc=%d" % rc)
+    return x, fail, it

@@ -1,0 +1,86 @@
+// tests/emu/wave_prims.hpp -- CPU stand-in for copra_amd/csrc/wave_prims.hpp (TEST INFRASTRUCTURE ONLY).
+//
+// The kernel bodies (lmpc_fused.hpp, qp_dense.hpp, gi_core.hpp) are written against a handful of wave primitives.
+// This header re-implements them with 64 cooperative fibers (ucontext), one per lane, that run in lock-step
+// BETWEEN barriers: a lane runs until its next wave_sync()/shuffle and then yields.  Consequences:
+//   * a missing wave_sync() between an LDS write and a cross-lane read shows up as a wrong result here (the fibers
+//     do not execute instruction-by-instruction in lock-step like the hardware does, so this is stricter);
+//   * the same source can be built with -fsanitize=undefined on the CPU (GPU sanitizers are not available);
+//   * `pytest -m "not gpu"` can check the kernel logic against the oracle without a GPU.
+// It is never linked into libcopra_hip.so and never used by the product path.
+#ifndef COPRA_WAVE_PRIMS_HPP
+#define COPRA_WAVE_PRIMS_HPP
+#include <cmath>
+#include <cstddef>
+
+#define COPRA_DEV inline
+
+namespace copra_hip {
+
+namespace emu {
+    struct WaveState {
+        int lane; // current fiber
+        int inst;
+        int ninst;
+        double* lds;
+        double xf[64]; // shuffle staging
+        int xi[64];
+    };
+    extern WaveState g_wave;
+    void yield(); // implemented in emu_harness.cpp: switch back to the scheduler (== barrier)
+} // namespace emu
+
+COPRA_DEV int lane_id() { return emu::g_wave.lane; }
+COPRA_DEV int instance_id() { return emu::g_wave.inst; }
+COPRA_DEV int instance_stride() { return emu::g_wave.ninst; }
+COPRA_DEV void wave_sync() { emu::yield(); }
+COPRA_DEV double* lds_base() { return emu::g_wave.lds; }
+
+COPRA_DEV double emu_xchg_f64(double v, int src)
+{
+    const int me = emu::g_wave.lane;
+    emu::g_wave.xf[me] = v;
+    emu::yield();
+    const double r = (src >= 0 && src < 64) ? emu::g_wave.xf[src] : emu::g_wave.xf[me];
+    emu::yield();
+    return r;
+}
+COPRA_DEV int emu_xchg_i32(int v, int src)
+{
+    const int me = emu::g_wave.lane;
+    emu::g_wave.xi[me] = v;
+    emu::yield();
+    const int r = (src >= 0 && src < 64) ? emu::g_wave.xi[src] : emu::g_wave.xi[me];
+    emu::yield();
+    return r;
+}
+
+COPRA_DEV double shfl_xor_f64(double v, int mask) { return emu_xchg_f64(v, lane_id() ^ mask); }
+COPRA_DEV int shfl_xor_i32(int v, int mask) { return emu_xchg_i32(v, lane_id() ^ mask); }
+COPRA_DEV double shfl_f64(double v, int src) { return emu_xchg_f64(v, src); }
+COPRA_DEV int shfl_i32(int v, int src) { return emu_xchg_i32(v, src); }
+COPRA_DEV double shfl_down0_f64(double v, int delta)
+{
+    const int src = lane_id() + delta;
+    const double t = emu_xchg_f64(v, src);
+    return (src < 64) ? t : 0.0;
+}
+COPRA_DEV double shfl_up0_f64(double v, int delta)
+{
+    const int src = lane_id() - delta;
+    const double t = emu_xchg_f64(v, src);
+    return (src >= 0) ? t : 0.0;
+}
+COPRA_DEV double wave_sum(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
+COPRA_DEV double wave_max(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_f64(v, m));
+    return v;
+}
+
+} // namespace copra_hip
+#endif // COPRA_WAVE_PRIMS_HPP

