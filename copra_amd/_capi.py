@@ -133,6 +133,8 @@ def lib():
         L.copra_batch_set_system.argtypes = [vp, vp, vp, vp, vp, C.c_int]
         L.copra_batch_set_x0.restype = C.c_int
         L.copra_batch_set_x0.argtypes = [vp, vp, C.c_int]
+        L.copra_batch_set_outputs.restype = C.c_int
+        L.copra_batch_set_outputs.argtypes = [vp, vp, vp, vp, vp]
         L.copra_batch_solve.restype = C.c_int
         L.copra_batch_solve.argtypes = [vp, vp]
         L.copra_batch_synchronize.restype = C.c_int
