@@ -96,6 +96,17 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_last_solve_seconds(self._h, C.byref(s)))
         return s.value
 
+    PHASES = ("preview", "costs", "norms", "cholesky", "inverse_x0", "active_set", "results", "total")
+
+    def enable_phase_profile(self, on=True):
+        _capi.check(self._lib.copra_batch_phase_profile(self._h, 1 if on else 0, None))
+
+    def phase_profile(self):
+        """per-instance shader-clock cycles of the kernel phases, shape (batch, 8) -- see PHASES"""
+        out = np.zeros((self.batch, 8), dtype=np.int64)
+        _capi.check(self._lib.copra_batch_phase_profile(self._h, 1, out.ctypes.data))
+        return out
+
     def results(self):
         u = np.empty((self.batch, self.n))
         tr = np.empty((self.batch, self.X))

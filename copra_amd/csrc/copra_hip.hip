@@ -18,10 +18,24 @@ using namespace copra_hip;
 // kernels: one 64-lane wavefront (= one workgroup) per MPC instance.  The hardware workgroup dispatcher is the
 // work queue: instances with long active-set loops simply hold their CU slot longer.
 // ------------------------------------------------------------------------------------------------
+// <NX, NU, N, RP> = compile-time (xDim, uDim, nrUStep, padded cost rows); <0,0,0,0> is the generic (run-time
+// shape) instantiation.
+template <int NX, int NU, int NH, int RP>
 __global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
 {
-    lmpc_fused_body(P, P.inst_offset + (int)blockIdx.x);
+    lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
 }
+
+namespace {
+using fused_kernel_t = void (*)(const FusedPlan);
+// the BASELINE.json shapes get their own instantiation
+fused_kernel_t select_fused_kernel(const FusedPlan& P)
+{
+    if (P.nx == 6 && P.nu == 3 && P.N == 20 && P.rmax <= 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
+    if (P.nx == 2 && P.nu == 1 && P.N == 10 && P.rmax <= 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
+    return copra_lmpc_fused_kernel<0, 0, 0, 0>;
+}
+} // namespace
 
 __global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
 
@@ -71,6 +85,7 @@ struct copra_batch {
     // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
+    long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -101,13 +116,14 @@ static FusedPlan device_plan(const copra_batch* h)
     P.dump_instance = -1;
     P.dump_only = 0;
     P.dumpQ = P.dumpc = P.dumpA = P.dumpb = nullptr;
+    P.prof = h->d_prof;
     return P;
 }
 
 static copra_status_t ensure_lds_attr(copra_batch* h)
 {
     if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_lmpc_fused_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_fused_kernel(h->hp.plan)),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
     }
     h->lds_attr_set = true;
@@ -202,6 +218,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_traj);
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_iter);
+    (void)hipFree(h->d_prof);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -276,7 +293,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(copra_lmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+    hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev1, s));
     h->timed = true;
@@ -352,7 +369,7 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     P.dumpb = db;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    hipLaunchKernelGGL(copra_lmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_bytes, h->last_stream, P);
+    hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_bytes, h->last_stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     std::vector<double> hA((size_t)(mg ? mg : 1) * n), hb((size_t)(mg ? mg : 1));
@@ -377,6 +394,26 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     (void)hipFree(dc);
     (void)hipFree(dA);
     (void)hipFree(db);
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long* cycles_out)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_phase_profile: null handle");
+    const size_t b = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1);
+    if (enable && !h->d_prof) {
+        HIP_TRY(hipMalloc((void**)&h->d_prof, b * 8 * sizeof(long long)));
+        HIP_TRY(hipMemset(h->d_prof, 0, b * 8 * sizeof(long long)));
+    }
+    if (cycles_out) {
+        if (!h->d_prof) return fail(COPRA_ERR_RUNTIME, "copra_batch_phase_profile: profiling was not enabled");
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+        HIP_TRY(hipMemcpy(cycles_out, h->d_prof, b * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    if (!enable && h->d_prof) {
+        (void)hipFree(h->d_prof);
+        h->d_prof = nullptr;
+    }
     return COPRA_OK;
 }
 

@@ -9,16 +9,23 @@
 // Wave mapping (lane l <-> index l):
 //   * J lives in LDS with an odd leading dimension, so "lane = column" reads (d = J'n) and "lane = row" reads
 //     (z = J2 d2, Givens sweeps) are both bank-conflict free;
+//   * Cholesky and the triangular inverse are LEFT-LOOKING and blocked by 4 rows: one lane-private LDS read feeds
+//     four FMAs whose second operands are wave-uniform (broadcast) LDS reads -- 0.75 LDS reads per FMA instead of 2,
+//     no read-modify-write traffic, and the pivots use a Newton-refined v_rsq_f64 instead of sqrt + divide;
 //   * the (n - nact) Givens rotations of a constraint addition are NOT computed one after the other as in qpgen2:
 //     all rotation coefficients follow from a suffix scan of d^2 (|h_q| = sqrt(sum_{k>=q} d_k^2)), so lanes compute
-//     them in parallel and only the O(n) column sweep stays sequential;
+//     them in parallel and only the O(n) column sweep stays sequential (branch-free, reflection form);
 //   * constraints are never materialised: a Rows policy evaluates slacks / normals / norms on the fly.
+// NV > 0 fixes the number of variables at compile time (loops unroll, LDS reads batch); NV == 0 is the generic path.
 //
-// Rows policy interface (all members are wave-collective unless noted):
+// Rows policy interface for the mgen GENERAL rows (the 2n bound rows [I; -I] of QuadProgSolver.cpp:59-69 are handled
+// here, from per-lane register copies of XU_j / XL_j):
 //   void   begin_scan(const double* xs)            refresh whatever slack() needs (e.g. the trajectory); syncs
-//   double slack(int i, const double* xs)          per-lane: qpgen2's  a_i'x - b_i  in the ORIGINAL orientation
+//   double slack(int i, const double* xs)          per-lane (i = 64c + lane): qpgen2's a_i'x - b_i, ORIGINAL orientation
+//   double slack_uniform(int p, const double* xs)  the same for a wave-uniform row index
 //   double norm(int i)                             per-lane: ||a_i||
 //   void   load_normal(int p, double sgn, double* ap)   lane j writes ap[j] = sgn-oriented normal of row p; no sync
+//   double ub(int j), lb(int j)                    per-lane: XU_j, XL_j
 #pragma once
 
 #include "plan.hpp"
@@ -57,58 +64,145 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
 // ------------------------------------------------------------------------------------------------
 // Factorisation: S.J holds the Hessian (upper triangle), S.cvec the linear term c.
 // On exit S.J = J = R^-1 (upper triangular, strict lower part zero), S.xs = -Q^-1 c.  Returns 0 or 2.
+// S.coef is used as scratch (1/R(i,i)).
 // ------------------------------------------------------------------------------------------------
-COPRA_DEV int gi_factorize(const SolverLds& S, int n)
+template <int NV>
+COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol = nullptr)
 {
     const int lane = lane_id();
+    const int n = NV ? NV : n_rt;
+    const int ld = NV ? (NV | 1) : S.ldj;
+    const int lj = (lane < n) ? lane : n - 1; // clamped lane: idle lanes re-read column n-1, never store
     double* J = S.J;
-    const int ld = S.ldj;
-
-    // right-looking Cholesky, lane = column (qpgen2: dpofa)
-    for (int k = 0; k < n; ++k) {
-        wave_sync();
-        const double piv = J[k * ld + k];
-        if (!(piv > 0.0)) return 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
-        const double rkk = sqrt(piv);
-        double rkj = 0.0;
-        if (lane > k && lane < n) rkj = J[k * ld + lane] / rkk;
-        wave_sync();
-        if (lane > k && lane < n) J[k * ld + lane] = rkj;
-        if (lane == k) J[k * ld + k] = rkk;
-        wave_sync();
-        for (int i = k + 1; i < n; ++i) {
-            if (lane >= i && lane < n) J[i * ld + lane] -= J[k * ld + i] * rkj;
-        }
-    }
+    double* rinvd = S.coef;
     wave_sync();
-    // in-place inverse of the upper-triangular factor, lane = column, rows from the bottom up (qpgen2: dpori)
-    for (int i = n - 1; i >= 0; --i) {
-        const double rii = J[i * ld + i];
-        double v = 0.0;
-        if (lane >= i && lane < n) {
-            double acc = (lane == i) ? 1.0 : 0.0;
-            for (int k = i + 1; k <= lane; ++k) acc -= J[i * ld + k] * J[k * ld + lane];
-            v = acc / rii;
+    // ---- blocked left-looking Cholesky Q = R'R, lane = column (qpgen2: dpofa) ----
+#pragma unroll 1
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        const int pw = (n - k0 < 4) ? n - k0 : 4;
+        double acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = (p < pw) ? J[(k0 + p) * ld + lj] : 0.0;
+#pragma unroll 2
+        for (int t = 0; t < k0; t += 4) { // k0 is a multiple of 4: no remainder
+            double rt[4], bb[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rt[u] = J[(t + u) * ld + lj]; // R(t+u, lane)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bb[u][p] = (p < pw) ? J[(t + u) * ld + k0 + p] : 0.0; // wave-uniform address
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] -= bb[u][p] * rt[u];
         }
-        wave_sync(); // every lane has read row i
-        if (lane >= i && lane < n) J[i * ld + lane] = v;
+        // The 4x4 diagonal block of the panel (entries acc[p] of lanes k0+p..k0+3) is broadcast to every lane and
+        // factorised redundantly (wave-uniform arithmetic, no cross-lane dependency inside the chain).
+        double Dg[4][4], Rd[4][4], ri[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = p; q < 4; ++q) Dg[p][q] = (q < pw) ? bcast_f64(acc[p], k0 + q) : ((p == q) ? 1.0 : 0.0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double dpp = Dg[p][p];
+#pragma unroll
+            for (int t = 0; t < p; ++t) dpp -= Rd[t][p] * Rd[t][p];
+            if (p < pw && !(dpp > 0.0)) return 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
+            ri[p] = fast_rsqrt(dpp);
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double v = Dg[p][q];
+#pragma unroll
+                for (int t = 0; t < p; ++t) v -= Rd[t][p] * Rd[t][q];
+                Rd[p][q] = v * ri[p];
+            }
+        }
+        // this lane's entries of the four new rows of R
+        double rp[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double v = acc[p];
+#pragma unroll
+            for (int t = 0; t < p; ++t) v -= Rd[t][p] * rp[t];
+            rp[p] = v * ri[p]; // R(k0+p, lane); the diagonal lane gets sqrt(pivot)
+            if (p < pw && lane >= k0 + p && lane < n) J[(k0 + p) * ld + lane] = rp[p];
+            if (p < pw && lane == 0) rinvd[k0 + p] = ri[p];
+        }
         wave_sync();
     }
+    if (t_chol) *t_chol = cycle_counter();
     // zero the strict lower triangle (qpgen2 does the same before the first rotation)
-    if (lane < n)
-        for (int i = lane + 1; i < n; ++i) J[i * ld + lane] = 0.0;
+    for (int i = 1; i < n; ++i)
+        if (i > lane) J[i * ld + lane] = 0.0;
     wave_sync();
-    // unconstrained minimiser x = -J J' c   (qpgen2: dposl on dvec = -c)
-    double t = 0.0;
-    if (lane < n)
-        for (int i = 0; i <= lane; ++i) t += J[i * ld + lane] * S.cvec[i];
-    if (lane < n) S.dv[lane] = t;
-    wave_sync();
-    double x = 0.0;
-    if (lane < n)
-        for (int j = lane; j < n; ++j) x += J[lane * ld + j] * S.dv[j];
-    if (lane < n) S.xs[lane] = -x;
-    wave_sync();
+    // ---- in-place inverse of the upper-triangular factor, 4 rows at a time from the bottom (qpgen2: dpori) ----
+#pragma unroll 1
+    for (int i0 = ((n - 1) / 4) * 4; i0 >= 0; i0 -= 4) {
+        const int pw = (n - i0 < 4) ? n - i0 : 4;
+        double acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = (lane == i0 + p) ? 1.0 : 0.0;
+        int k = i0 + pw;
+#pragma unroll 2
+        for (; k + 4 <= n; k += 4) {
+            double vk[4], bb[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vk[u] = J[(k + u) * ld + lj]; // V(k+u, lane), zero below the diagonal
+#pragma unroll
+                for (int p = 0; p < 4; ++p) bb[u][p] = (p < pw) ? J[(i0 + p) * ld + k + u] : 0.0; // wave-uniform address
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] -= bb[u][p] * vk[u];
+        }
+        for (; k < n; ++k) {
+            const double vk = J[k * ld + lj];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p < pw) acc[p] -= J[(i0 + p) * ld + k] * vk;
+        }
+        double v[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int p = 3; p >= 0; --p) {
+            if (p < pw) {
+                double a = acc[p];
+#pragma unroll
+                for (int q = p + 1; q < 4; ++q)
+                    if (q < pw) a -= J[(i0 + p) * ld + i0 + q] * v[q];
+                v[p] = a * rinvd[i0 + p];
+            }
+        }
+        wave_sync(); // every lane has read the panel rows
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p < pw && lane < n) J[(i0 + p) * ld + lane] = v[p];
+        wave_sync();
+    }
+    // ---- unconstrained minimiser x = -J J' c   (qpgen2: dposl on dvec = -c) ----
+    {
+        double t0 = 0.0, t1 = 0.0;
+        int i = 0;
+        for (; i + 1 < n; i += 2) {
+            t0 += J[i * ld + lj] * S.cvec[i];
+            t1 += J[(i + 1) * ld + lj] * S.cvec[i + 1];
+        }
+        if (i < n) t0 += J[i * ld + lj] * S.cvec[i];
+        if (lane < n) S.dv[lane] = t0 + t1;
+        wave_sync();
+        double x0 = 0.0, x1 = 0.0;
+        int j = 0;
+        for (; j + 1 < n; j += 2) {
+            x0 += J[lj * ld + j] * S.dv[j];
+            x1 += J[lj * ld + j + 1] * S.dv[j + 1];
+        }
+        if (j < n) x0 += J[lj * ld + j] * S.dv[j];
+        if (lane < n) S.xs[lane] = -(x0 + x1);
+        wave_sync();
+    }
     return 0;
 }
 
@@ -117,19 +211,24 @@ COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
 // ------------------------------------------------------------------------------------------------
 // Active-set iterations.  Returns qpgen2's ierr (0 ok, 1 infeasible) or 3 (iteration cap).
 // ------------------------------------------------------------------------------------------------
-template <class Rows>
-COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows& rows, double vsmall, int max_iter,
+template <int NV, class Rows>
+COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
     int& iter_main, int& iter_drop)
 {
     const int lane = lane_id();
+    const int n = NV ? NV : n_rt;
+    const int ld = NV ? (NV | 1) : S.ldj;
+    const int lj = (lane < n) ? lane : n - 1;
+    const int mtotal = mgen + 2 * n; // QuadProgSolver.cpp:51: the bounds are 2n more inequality rows
     double* J = S.J;
-    const int ld = S.ldj;
     int nact = 0;
     iter_main = 0;
     iter_drop = 0;
     for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;
     for (int i = lane; i < meq; i += kWave) S.eqsgn[i] = 1.0;
     for (int i = lane; i <= n + 1; i += kWave) S.uv[i] = 0.0;
+    // rows [I; -I] with right-hand sides [XU; -XL] (QuadProgSolver.cpp:61-69): lane j keeps XU_j, XL_j
+    const double ubj = rows.ub(lj), lbj = rows.lb(lj);
     wave_sync();
 
     for (;;) {
@@ -139,9 +238,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
         rows.begin_scan(S.xs);
         double best = 0.0, best_s = 0.0;
         int best_i = -1;
-        for (int base = 0; base < mtotal; base += kWave) {
+        for (int base = 0; base < mgen; base += kWave) { // general rows (equalities first)
             const int i = base + lane;
-            if (i < mtotal) {
+            if (i < mgen) {
                 double s = rows.slack(i, S.xs);
                 if (i < meq) {
                     const double sg = S.eqsgn[i];
@@ -161,18 +260,26 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
                 }
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double ob = shfl_xor_f64(best, m);
-            const double os = shfl_xor_f64(best_s, m);
-            const int oi = shfl_xor_i32(best_i, m);
-            const bool take = (oi >= 0) && (best_i < 0 || ob < best || (ob == best && oi < best_i));
-            if (take) {
-                best = ob;
-                best_s = os;
-                best_i = oi;
+        if (lane < n) { // bound rows: unit norm; an infinite / DBL_MAX bound gives a slack that is never negative
+            const double xj = S.xs[lane];
+            double s = ubj - xj; // row mgen + j of [I]
+            if (fabs(s) < vsmall) s = 0.0;
+            if (S.act[mgen + lane]) s = 0.0;
+            if (s < best) {
+                best = s;
+                best_i = mgen + lane;
+                best_s = s;
+            }
+            s = xj - lbj; // row mgen + n + j of [-I]
+            if (fabs(s) < vsmall) s = 0.0;
+            if (S.act[mgen + n + lane]) s = 0.0;
+            if (s < best) {
+                best = s;
+                best_i = mgen + n + lane;
+                best_s = s;
             }
         }
+        wave_argmin(best, best_i, best_s);
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
         double sv_nvl = best_s;
@@ -180,27 +287,47 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
 
         // ---------------- step 2 ----------------
         for (;;) {
-            const double sgn = (nvl < meq) ? S.eqsgn[nvl] : 1.0;
-            rows.load_normal(nvl, sgn, S.ap);
-            wave_sync();
-            // d = J' n+   (lane = column)
-            double dj = 0.0;
-            if (lane < n) {
-                for (int i = 0; i < n; ++i) dj += J[i * ld + lane] * S.ap[i];
-                S.dv[lane] = dj;
+            if (nvl < mgen) {
+                const double sgn = (nvl < meq) ? S.eqsgn[nvl] : 1.0;
+                rows.load_normal(nvl, sgn, S.ap);
+            } else if (lane < n) { // rows of -[I; -I]: -e_j for an upper bound, +e_j for a lower bound
+                const int q = nvl - mgen;
+                S.ap[lane] = (q < n) ? ((lane == q) ? -1.0 : 0.0) : ((lane == q - n) ? 1.0 : 0.0);
             }
             wave_sync();
-            // z = J2 d2   (lane = row)
-            double zi = 0.0;
-            if (lane < n)
-                for (int j = nact; j < n; ++j) zi += J[lane * ld + j] * S.dv[j];
+            // d = J' n+   (lane = column)
+            double dj;
+            {
+                double d0 = 0.0, d1 = 0.0;
+                int i = 0;
+                for (; i + 1 < n; i += 2) {
+                    d0 += J[i * ld + lj] * S.ap[i];
+                    d1 += J[(i + 1) * ld + lj] * S.ap[i + 1];
+                }
+                if (i < n) d0 += J[i * ld + lj] * S.ap[i];
+                dj = (lane < n) ? d0 + d1 : 0.0;
+            }
+            if (lane < n) S.dv[lane] = (lane >= nact) ? dj : 0.0; // d2 (d1 stays in registers)
+            wave_sync();
+            // z = J2 d2   (lane = row; the d1 part of dv is zero)
+            double zi;
+            {
+                double z0 = 0.0, z1 = 0.0;
+                int j = 0;
+                for (; j + 1 < n; j += 2) {
+                    z0 += J[lj * ld + j] * S.dv[j];
+                    z1 += J[lj * ld + j + 1] * S.dv[j + 1];
+                }
+                if (j < n) z0 += J[lj * ld + j] * S.dv[j];
+                zi = (lane < n) ? z0 + z1 : 0.0;
+            }
             // r = R^-1 d1 : column-oriented back substitution, r_c broadcast from lane c
             double acc = (lane < nact) ? dj : 0.0;
             double ri = 0.0;
             for (int c = nact - 1; c >= 0; --c) {
                 double rc = 0.0;
                 if (lane == c) rc = acc / S.R[rcol(c) + c];
-                rc = shfl_f64(rc, c);
+                rc = bcast_f64(rc, c);
                 if (lane == c) ri = rc;
                 if (lane < c) acc -= S.R[rcol(c) + lane] * rc;
             }
@@ -211,15 +338,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
                 t1 = S.uv[lane] / ri;
                 it1 = lane;
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const double ot = shfl_xor_f64(t1, m);
-                const int oi = shfl_xor_i32(it1, m);
-                const bool take = (oi >= 0) && (it1 < 0 || ot < t1 || (ot == t1 && oi < it1));
-                if (take) {
-                    t1 = ot;
-                    it1 = oi;
-                }
+            if (nact > 0) {
+                double dummy = 0.0;
+                wave_argmin(t1, it1, dummy);
             }
             const bool t1inf = (it1 < 0);
             const double zz = wave_sum(zi * zi);
@@ -255,21 +376,25 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
                     if (!in_tail) h = 0.0;
                     const double h_prev = shfl_up0_f64(h, 1); // h_{q-1}
                     const double d_prev = shfl_up0_f64(dj, 1); // d_{q-1}
-                    // rotation q acts on columns (q-1, q), q = nact+1 .. n-1
-                    if (lane > nact && lane < n) {
-                        double gc = 1.0, gs = 0.0, nu_ = 0.0, skip = 1.0;
-                        if (h != 0.0) {
-                            gc = d_prev / h_prev;
-                            gs = h / h_prev;
+                    // rotation q acts on columns (q-1, q), q = nact+1 .. n-1, as the reflection
+                    //   col_{q-1}' = gc col_{q-1} + gs col_q ,  col_q' = gs col_{q-1} - gc col_q
+                    // (qpgen2's "nu" form is the same map); identity where qpgen2 skips (h_q == 0 or gc == 1)
+                    if (lane >= 1 && lane < n) {
+                        double c0 = 1.0, c1 = 0.0, c2 = 0.0, c3 = 1.0;
+                        if (lane > nact && h != 0.0) {
+                            const double gc = d_prev / h_prev;
+                            const double gs = h / h_prev;
                             if (gc != 1.0) {
-                                nu_ = gs / (1.0 + gc);
-                                skip = 0.0;
+                                c0 = gc;
+                                c1 = gs;
+                                c2 = gs;
+                                c3 = -gc;
                             }
                         }
-                        S.coef[4 * lane + 0] = gc;
-                        S.coef[4 * lane + 1] = gs;
-                        S.coef[4 * lane + 2] = nu_;
-                        S.coef[4 * lane + 3] = skip;
+                        S.coef[4 * lane + 0] = c0;
+                        S.coef[4 * lane + 1] = c1;
+                        S.coef[4 * lane + 2] = c2;
+                        S.coef[4 * lane + 3] = c3;
                     }
                     if (lane == nact) {
                         S.R[rcol(nact) + nact] = h; // new diagonal element of R
@@ -277,21 +402,20 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
                         S.act[nvl] = 1;
                     }
                     wave_sync();
-                    if (lane < n && nact + 1 < n) {
-                        double carry = J[lane * ld + (n - 1)];
-                        for (int q = n - 1; q > nact; --q) {
-                            const double a = J[lane * ld + q - 1];
-                            if (S.coef[4 * q + 3] != 0.0) {
-                                J[lane * ld + q] = carry;
-                                carry = a;
-                            } else {
-                                const double gc = S.coef[4 * q + 0], gs = S.coef[4 * q + 1], nu_ = S.coef[4 * q + 2];
-                                const double t = gc * a + gs * carry;
-                                J[lane * ld + q] = nu_ * (a + t) - carry;
-                                carry = t;
-                            }
+                    if (nact + 1 < n) {
+                        double carry = J[lj * ld + (n - 1)];
+                        const int qlo = NV ? 0 : nact; // compile-time shape: sweep everything (identity below nact)
+#pragma unroll 4
+                        for (int q = n - 1; q > qlo; --q) {
+                            const double a = J[lj * ld + q - 1];
+                            const double c0 = S.coef[4 * q + 0], c1 = S.coef[4 * q + 1];
+                            const double c2 = S.coef[4 * q + 2], c3 = S.coef[4 * q + 3];
+                            const double t = c0 * a + c1 * carry;
+                            const double w = c2 * a + c3 * carry;
+                            if (lane < n) J[lane * ld + q] = w;
+                            carry = t;
                         }
-                        J[lane * ld + nact] = carry;
+                        if (lane < n) J[lane * ld + qlo] = carry;
                     }
                     nact += 1;
                     wave_sync();
@@ -299,8 +423,15 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n, int meq, int mtotal, Rows
                 } else {
                     // ---- partial step: recompute the slack of nvl, then drop the blocking constraint ----
                     wave_sync();
-                    rows.begin_scan(S.xs);
-                    double s = rows.slack(nvl, S.xs); // wave-uniform argument: every lane computes the same value
+                    double s;
+                    if (nvl < mgen) {
+                        rows.begin_scan(S.xs);
+                        s = rows.slack_uniform(nvl, S.xs); // every lane computes the same value
+                    } else {
+                        const int q = nvl - mgen;
+                        const double sl = (q < n) ? ubj - S.xs[lj] : S.xs[lj] - lbj;
+                        s = bcast_f64(sl, (q < n) ? q : q - n);
+                    }
                     if (nvl < meq) {
                         const double sg = S.eqsgn[nvl];
                         s = sg * s;

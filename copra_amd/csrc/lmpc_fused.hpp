@@ -4,77 +4,136 @@
 //   0. coalesced load of A, B, d, x0 (66 doubles at (6,3)) into LDS;
 //   1. PreviewSystem::updateSystem (src/PreviewSystem.cpp:57-74) WITHOUT the O(N^2) Toeplitz fill: only the first
 //      block column G_k = A^k B of Psi (Psi_{i,j} = G_{i-1-j}), Phi_k = A^k and xi_k are formed, by the same
-//      left-multiplication recursion as the reference;
+//      left-multiplication recursion as the reference; the three recursions are ONE stacked product
+//      [Phi_s | G_{s-1} | xi_s] = A [Phi_{s-1} | G_{s-2} | xi_{s-1}] (+ d on the last column), one element per lane;
 //   2. cost functions (src/costFunctions.cpp:63-215) summed as LMPC::makeQPForm does (src/LMPC.cpp:228-230,
-//      252-255): the Hessian uses the block recursion  Q_{a,b} = Q_{a+1,b+1} + (M G_{K-1-a})' W (M G_{K-1-b}),
-//      which adds the per-step terms of the reference's loop in the same (ascending step) order but skips its
-//      "lot of sums of zero" (costFunctions.cpp:73);
+//      252-255).  The Hessian block (a,b), a <= b, of a per-step cost is the prefix sum
+//          Q_{a,b} = sum_{s=0}^{K-1-b} (M G_{s+b-a})' W (M G_s)
+//      along block diagonal delta = b-a, so lane (delta, ic) walks its diagonal once: the per-step terms of the
+//      reference's loop are added in the same (ascending step) order but its "lot of sums of zero"
+//      (costFunctions.cpp:73) is skipped -- 11 k MACs instead of 453 k at (6,3,20);
 //   3. constraints (src/constraints.cpp) stay implicit rows (plan.hpp); only their norms are computed;
 //   4. QuadProgDenseSolver::SI_solve (src/QuadProgSolver.cpp:54-72): bounds become the 2n implicit rows [I; -I];
 //      Goldfarb-Idnani in gi_core.hpp;
 //   5. LMPC::updateResults (src/LMPC.cpp:282-286): control = U, trajectory = Phi x0 + Psi U + xi.
+//
+// Template parameters fix (xDim, uDim, nrUStep) at compile time (0 = take them from the plan at run time): the
+// launcher instantiates the BASELINE shapes and falls back to the generic instantiation for everything else.
 #pragma once
 
 #include "gi_core.hpp"
 
 namespace copra_hip {
 
+// One constraint row of the plan (see plan.hpp), held in registers.
+struct RowDesc {
+    int k, ek, eo, gk, go;
+    double f;
+};
+
 // Implicit constraint rows of an LMPC problem.
+template <int NX_, int NU_, int NH_>
 struct StageRows {
     const FusedPlan& P;
     const double* G; // LDS
     const double* Xbar; // LDS
     double* Xcur; // LDS
     const double* nb; // LDS
+    RowDesc mine; // descriptor of row `lane` (rows 0..63 are scanned as i == lane): no table look-ups in the loop
 
-    // coefficient j of row i in the reference's orientation (row i of Aeq / Aineq), i < mgen
-    COPRA_DEV double coeff(int i, int j) const
+    COPRA_DEV int nx() const { return NX_ ? NX_ : P.nx; }
+    COPRA_DEV int nu() const { return NU_ ? NU_ : P.nu; }
+    COPRA_DEV int nh() const { return NH_ ? NH_ : P.N; }
+    COPRA_DEV int nvar() const { return (NU_ && NH_) ? NU_ * NH_ : P.n; }
+    COPRA_DEV int xdim() const { return (NX_ && NH_) ? NX_ * (NH_ + 1) : P.X; }
+
+    COPRA_DEV RowDesc load_desc(int i) const
     {
-        const int nx = P.nx, nu = P.nu;
-        const int k = P.row_step[i], ek = P.row_ekind[i], eo = P.row_eoff[i];
-        const int gk = P.row_gkind[i], go = P.row_goff[i];
-        const int jb = j / nu, jc = j - jb * nu;
+        RowDesc d;
+        d.k = P.row_step[i];
+        d.ek = P.row_ekind[i];
+        d.eo = P.row_eoff[i];
+        d.gk = P.row_gkind[i];
+        d.go = P.row_goff[i];
+        d.f = P.row_f[i];
+        return d;
+    }
+    COPRA_DEV void cache_own_row()
+    {
+        const int i = lane_id();
+        if (i < P.mgen)
+            mine = load_desc(i);
+        else
+            mine = RowDesc { 0, kENone, 0, kGNone, 0, 0.0 };
+    }
+    COPRA_DEV RowDesc desc(int i) const { return (i < kWave) ? mine : load_desc(i); }
+
+    // coefficient j of a row in the reference's orientation (row of Aeq / Aineq)
+    COPRA_DEV double coeff(const RowDesc& d, int j) const
+    {
+        const int k = d.k, eo = d.eo, go = d.go;
+        const int jb = j / nu(), jc = j - jb * nu();
         double v = 0.0;
-        if (ek == kEDense) {
+        if (d.ek == kEOneHot) {
+            if (jb < k) v = G[(k - 1 - jb) * nx() * nu() + nx() * jc + eo];
+        } else if (d.ek == kEDense) {
             if (jb < k) {
-                const double* Gk = G + (k - 1 - jb) * nx * nu + nx * jc;
-                for (int c = 0; c < nx; ++c) v += P.params[eo + c] * Gk[c];
+                const double* Gk = G + (k - 1 - jb) * nx() * nu() + nx() * jc;
+                for (int c = 0; c < nx(); ++c) v += P.params[eo + c] * Gk[c];
             }
-        } else if (ek == kEOneHot) {
-            if (jb < k) v = G[(k - 1 - jb) * nx * nu + nx * jc + eo];
-        } else if (ek == kEFull) {
-            for (int s = jb + 1; s <= P.N; ++s) {
-                const double* Gk = G + (s - 1 - jb) * nx * nu + nx * jc;
-                for (int c = 0; c < nx; ++c) v += P.params[eo + s * nx + c] * Gk[c];
+        } else if (d.ek == kEFull) {
+            for (int s = jb + 1; s <= nh(); ++s) {
+                const double* Gk = G + (s - 1 - jb) * nx() * nu() + nx() * jc;
+                for (int c = 0; c < nx(); ++c) v += P.params[eo + s * nx() + c] * Gk[c];
             }
         }
-        if (gk == kGStep) {
+        if (d.gk == kGStep) {
             if (jb == k) v += P.params[go + jc];
-        } else if (gk == kGFull) {
+        } else if (d.gk == kGFull) {
             v += P.params[go + j];
         }
         return v;
     }
 
-    // E_row . Xv (+ G_row . u when u != nullptr)
-    COPRA_DEV double lhs(int i, const double* Xv, const double* u) const
+    // squared norm of a row: sum_j coeff(j)^2
+    COPRA_DEV double norm2(const RowDesc& d) const
     {
-        const int nx = P.nx, nu = P.nu;
-        const int k = P.row_step[i], ek = P.row_ekind[i], eo = P.row_eoff[i];
-        const int gk = P.row_gkind[i], go = P.row_goff[i];
+        if (d.ek == kEOneHot && d.gk == kGNone) { // rows of Psi: sum over the blocks G_0 .. G_{k-1}
+            double s0 = 0.0;
+            const double* g = G + d.eo;
+            for (int t = 0; t < d.k; ++t) {
+                for (int jc = 0; jc < nu(); ++jc) {
+                    const double a = g[t * nx() * nu() + nx() * jc];
+                    s0 += a * a;
+                }
+            }
+            return s0;
+        }
+        double s = 0.0;
+        for (int j = 0; j < nvar(); ++j) {
+            const double a = coeff(d, j);
+            s += a * a;
+        }
+        return s;
+    }
+
+    // E_row . Xv (+ G_row . u when u != nullptr)
+    COPRA_DEV double lhs(const RowDesc& d, const double* Xv, const double* u) const
+    {
+        const int k = d.k, eo = d.eo, go = d.go;
         double ax = 0.0;
-        if (ek == kEDense) {
-            for (int c = 0; c < nx; ++c) ax += P.params[eo + c] * Xv[k * nx + c];
-        } else if (ek == kEOneHot) {
-            ax = Xv[k * nx + eo];
-        } else if (ek == kEFull) {
-            for (int r = 0; r < P.X; ++r) ax += P.params[eo + r] * Xv[r];
+        if (d.ek == kEOneHot) {
+            ax = Xv[k * nx() + eo];
+        } else if (d.ek == kEDense) {
+            for (int c = 0; c < nx(); ++c) ax += P.params[eo + c] * Xv[k * nx() + c];
+        } else if (d.ek == kEFull) {
+            for (int r = 0; r < xdim(); ++r) ax += P.params[eo + r] * Xv[r];
         }
         if (u) {
-            if (gk == kGStep) {
-                for (int c = 0; c < nu; ++c) ax += P.params[go + c] * u[k * nu + c];
-            } else if (gk == kGFull) {
-                for (int j = 0; j < P.n; ++j) ax += P.params[go + j] * u[j];
+            if (d.gk == kGStep) {
+                for (int c = 0; c < nu(); ++c) ax += P.params[go + c] * u[k * nu() + c];
+            } else if (d.gk == kGFull) {
+                for (int j = 0; j < nvar(); ++j) ax += P.params[go + j] * u[j];
             }
         }
         return ax;
@@ -83,15 +142,14 @@ struct StageRows {
     // trajectory at the current iterate: Xcur = Xbar + Psi U  (Psi implicit)
     COPRA_DEV void refresh_trajectory(const double* xs) const
     {
-        const int nx = P.nx, nu = P.nu;
-        for (int row = lane_id(); row < P.X; row += kWave) {
-            const int k = row / nx, comp = row - k * nx;
-            double acc = 0.0;
+        for (int row = lane_id(); row < xdim(); row += kWave) {
+            const int k = row / nx(), comp = row - k * nx();
+            double a0 = 0.0;
+            const double* g = G + comp + (k - 1) * nx() * nu(); // block G_{k-1-jb}
             for (int jb = 0; jb < k; ++jb) {
-                const double* Gk = G + (k - 1 - jb) * nx * nu + comp;
-                for (int jc = 0; jc < nu; ++jc) acc += Gk[nx * jc] * xs[jb * nu + jc];
+                for (int jc = 0; jc < nu(); ++jc) a0 += g[-jb * nx() * nu() + nx() * jc] * xs[jb * nu() + jc];
             }
-            Xcur[row] = Xbar[row] + acc;
+            Xcur[row] = Xbar[row] + a0;
         }
     }
 
@@ -101,45 +159,45 @@ struct StageRows {
         wave_sync();
     }
 
+    // i == base + lane in the scan (rows < 64 come from registers), or a wave-uniform row index otherwise
     COPRA_DEV double slack(int i, const double* xs) const
     {
-        if (i < P.mgen) {
-            const double ax = lhs(i, Xcur, xs);
-            const double f = P.row_f[i];
-            return (i < P.meq) ? (ax - f) : (f - ax);
-        }
-        const int j = i - P.mgen;
-        if (j < P.n) return P.ub[j] - xs[j]; // row of [I]:  x_j <= XU_j   (QuadProgSolver.cpp:64,67)
-        return xs[j - P.n] - P.lb[j - P.n]; // row of [-I]: -x_j <= -XL_j (QuadProgSolver.cpp:65,68)
+        const RowDesc d = desc(i);
+        const double ax = lhs(d, Xcur, xs);
+        return (i < P.meq) ? (ax - d.f) : (d.f - ax);
+    }
+    COPRA_DEV double slack_uniform(int p, const double* xs) const
+    {
+        const RowDesc d = load_desc(uniform_i32(p));
+        const double ax = lhs(d, Xcur, xs);
+        return (p < P.meq) ? (ax - d.f) : (d.f - ax);
     }
 
-    COPRA_DEV double norm(int i) const { return (i < P.mgen) ? nb[i] : 1.0; }
+    COPRA_DEV double norm(int i) const { return nb[i]; }
+    COPRA_DEV double ub(int j) const { return P.ub[j]; }
+    COPRA_DEV double lb(int j) const { return P.lb[j]; }
 
     COPRA_DEV void load_normal(int p, double sgn, double* ap) const
     {
         const int j = lane_id();
-        if (j >= P.n) return;
-        double v;
-        if (p < P.mgen) {
-            v = coeff(p, j);
-            v = (p < P.meq) ? sgn * v : -v;
-        } else {
-            const int q = p - P.mgen;
-            if (q < P.n)
-                v = (j == q) ? -1.0 : 0.0;
-            else
-                v = (j == q - P.n) ? 1.0 : 0.0;
-        }
-        ap[j] = v;
+        if (j >= nvar()) return;
+        const RowDesc d = load_desc(uniform_i32(p));
+        const double v = coeff(d, j);
+        ap[j] = (p < P.meq) ? sgn * v : -v;
     }
 };
 
+// RP_ > 0: every cost term is padded to RP_ rows (zero M / N / p / w rows add exact zeros), so the inner products
+// over the cost rows unroll; RP_ == 0 uses the run-time row count of each term.
+template <int NX_, int NU_, int NH_, int RP_>
 COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
 {
     double* lds = lds_base();
     const LdsLayout& L = P.lds;
     const int lane = lane_id();
-    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X;
+    const int nx = NX_ ? NX_ : P.nx, nu = NU_ ? NU_ : P.nu, N = NH_ ? NH_ : P.N;
+    const int n = nu * N, X = nx * (N + 1);
+    constexpr int NV = NU_ * NH_;
     double* A = lds + L.A;
     double* B = lds + L.B;
     double* D = lds + L.D;
@@ -149,8 +207,10 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     double* Xcur = lds + L.Xcur;
     double* nb = lds + L.nb;
     SolverLds S = carve_solver(lds, L);
-    const int ld = S.ldj;
+    const int ld = NV ? (NV | 1) : S.ldj;
 
+    long long stamp[8];
+    stamp[0] = cycle_counter();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];
     for (int e = lane; e < nx * nu; e += kWave) B[e] = P.B[(size_t)inst * nx * nu + e];
@@ -174,30 +234,29 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             Xi[e] = 0.0;
             Xi[nx + e] = D[e]; // xi_1 = d (:61)
         }
-        const int per_step = nPhi + nG + nx;
+        // stacked step: element (r, c) of [Phi_s | G_{s-1} | xi_s], c in [0, nx + nu + 1)
+        const int per_step = nx * (nx + nu + 1);
         for (int s = 2; s <= N; ++s) {
             wave_sync();
             for (int e = lane; e < per_step; e += kWave) {
-                if (e < nPhi) { // Phi_s = A Phi_{s-1} (:64)
-                    const int r = e % nx, c = e / nx;
-                    const double* prev = Phi + (s - 1) * nPhi + c * nx;
-                    double acc = 0.0;
-                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * prev[t];
-                    Phi[s * nPhi + e] = acc;
-                } else if (e < nPhi + nG) { // Psi_{s,0} = A Psi_{s-1,0}, i.e. G_{s-1} = A G_{s-2} (:65)
-                    const int g = e - nPhi;
-                    const int r = g % nx, c = g / nx;
-                    const double* prev = G + (s - 2) * nG + c * nx;
-                    double acc = 0.0;
-                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * prev[t];
-                    G[(s - 1) * nG + g] = acc;
+                const int c = e / nx, r = e - c * nx;
+                const double* src;
+                double* dst;
+                double add = 0.0;
+                if (c < nx) { // Phi_s = A Phi_{s-1} (:64)
+                    src = Phi + (s - 1) * nPhi + c * nx;
+                    dst = Phi + s * nPhi + c * nx + r;
+                } else if (c < nx + nu) { // Psi_{s,0} = A Psi_{s-1,0}, i.e. G_{s-1} = A G_{s-2} (:65)
+                    src = G + (s - 2) * nG + (c - nx) * nx;
+                    dst = G + (s - 1) * nG + (c - nx) * nx + r;
                 } else { // xi_s = A xi_{s-1} + d (:70)
-                    const int r = e - nPhi - nG;
-                    const double* prev = Xi + (s - 1) * nx;
-                    double acc = 0.0;
-                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * prev[t];
-                    Xi[s * nx + r] = acc + D[r];
+                    src = Xi + (s - 1) * nx;
+                    dst = Xi + s * nx + r;
+                    add = D[r];
                 }
+                double acc = 0.0;
+                for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * src[t];
+                *dst = acc + add;
             }
         }
         wave_sync();
@@ -210,6 +269,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             Xbar[row] = acc + Xi[row];
         }
     }
+    stamp[1] = cycle_counter();
     // ---- 2. Hessian and gradient: Q = 1e-6 I + sum Q_k, c = sum c_k (LMPC.cpp:228-230, 252-255) ----
     {
         double* Q = S.J;
@@ -223,96 +283,113 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         double cj = 0.0; // lane j accumulates c_j
         double* Y = lds + L.BldY;
         double* We = lds + L.BldWe;
-        const int a_blk = lane / nu, ic = lane - a_blk * nu; // lane as row index i = (a, ic) / column j = (b, jc)
+        double* Cp = lds + L.BldCp; // this cost's parameters: M (r x nx) | N (r x nu) | p (r) | w (r)
+        const int blk = lane / nu, sub = lane - blk * nu; // lane as (block, component)
         for (int t = 0; t < P.ncost; ++t) {
             const CostTerm& ct = P.cost[t];
-            const int r = ct.rows;
-            const double* w = P.params + ct.offW;
-            const double* p = P.params + ct.offP;
+            const int rc = ct.rows; // rows of this term as given
+            const int r = RP_ ? RP_ : rc; // rows it is processed with (zero padded)
+            wave_sync();
+            double* Mx = Cp;
+            double* Nm = Cp + r * nx;
+            double* p = Nm + r * nu;
+            double* w = p + r;
+            for (int e = lane; e < r * nx; e += kWave) {
+                const int row = e % r, c = e / r;
+                Mx[e] = (ct.offM >= 0 && row < rc) ? P.params[ct.offM + row + rc * c] : 0.0;
+            }
+            for (int e = lane; e < r * nu; e += kWave) {
+                const int row = e % r, c = e / r;
+                Nm[e] = (ct.offN >= 0 && row < rc) ? P.params[ct.offN + row + rc * c] : 0.0;
+            }
+            for (int e = lane; e < r; e += kWave) {
+                p[e] = (e < rc) ? P.params[ct.offP + e] : 0.0;
+                w[e] = (e < rc) ? P.params[ct.offW + e] : 0.0;
+            }
             wave_sync();
             if (ct.kind == kCostControl) {
                 // ControlCost::update (costFunctions.cpp:148-156): block-diagonal N'WN, c = -p'WN
-                const double* Nm = P.params + ct.offN; // r x nu
                 if (lane < n) {
-                    const int jc = ic, b = a_blk;
                     for (int i2 = 0; i2 < nu; ++i2) {
                         double acc = 0.0;
-                        for (int k = 0; k < r; ++k) acc += (Nm[k + r * i2] * w[k]) * Nm[k + r * jc];
-                        Q[(b * nu + i2) * ld + lane] += acc;
+                        for (int k = 0; k < r; ++k) acc += (Nm[k + r * i2] * w[k]) * Nm[k + r * sub];
+                        Q[(blk * nu + i2) * ld + lane] += acc;
                     }
                     double acc = 0.0;
-                    for (int k = 0; k < r; ++k) acc += ((-p[k]) * w[k]) * Nm[k + r * jc];
+                    for (int k = 0; k < r; ++k) acc += ((-p[k]) * w[k]) * Nm[k + r * sub];
                     cj += acc;
                 }
                 continue;
             }
-            const double* M = P.params + ct.offM; // r x nx
-            const double* Nm = (ct.kind == kCostMixed) ? P.params + ct.offN : nullptr;
+            const bool mixed = (ct.kind == kCostMixed);
             // Y_k = M G_k (the block  M * Psi_{i, j}  with k = i-1-j), We_k = w .* (M xbar_k - p)
             for (int e = lane; e < N * r * nu; e += kWave) {
                 const int k = e / (r * nu), rem = e - k * r * nu;
                 const int jc = rem / r, row = rem - jc * r;
                 const double* Gk = G + k * nx * nu + nx * jc;
                 double acc = 0.0;
-                for (int c = 0; c < nx; ++c) acc += M[row + r * c] * Gk[c];
+                for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Gk[c];
                 Y[e] = acc; // Y[k][row + r*jc]
             }
             for (int e = lane; e < (N + 1) * r; e += kWave) {
                 const int k = e / r, row = e - k * r;
                 double acc = 0.0;
-                for (int c = 0; c < nx; ++c) acc += M[row + r * c] * Xbar[k * nx + c];
+                for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Xbar[k * nx + c];
                 We[e] = (acc - p[row]) * w[row];
             }
             wave_sync();
             // last state index K that enters the sum: trajectory K = N, mixed K = N-1, target only K = N
-            const int K = (ct.kind == kCostMixed) ? N - 1 : N;
-            const bool recur = (ct.kind != kCostTarget);
-            double val[kMaxNu];
-#pragma unroll
-            for (int jc = 0; jc < kMaxNu; ++jc) val[jc] = 0.0;
-            for (int b = N - 1; b >= 0; --b) {
-                const int ka = K - 1 - a_blk, kb = K - 1 - b;
-                const bool have = (lane < n) && ka >= 0 && kb >= 0;
+            const int K = mixed ? N - 1 : N;
+            const bool accumulate = (ct.kind != kCostTarget);
+            if (lane < n) {
+                // lane = (delta, ic): walk block diagonal delta from the bottom-right corner upwards
+                const int delta = blk, ic = sub;
+                double val[kMaxNu], cross[kMaxNu];
 #pragma unroll
                 for (int jc = 0; jc < kMaxNu; ++jc) {
-                    if (jc < nu) {
-                        double pterm = 0.0;
-                        if (have) {
-                            const double* Ya = Y + ka * r * nu + r * ic;
-                            const double* Yb = Y + kb * r * nu + r * jc;
-                            for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
-                        }
-                        const double carried = recur ? shfl_down0_f64(val[jc], nu) : 0.0;
-                        val[jc] = (lane < n) ? carried + pterm : 0.0;
-                        if (lane < n) {
-                            double add = val[jc];
-                            if (Nm) { // MixedCost cross terms of step k = b (costFunctions.cpp:207)
-                                double cross = 0.0;
-                                bool has_cross = false;
-                                if (a_blk < b) { // (M G_{b-1-a})' W N
-                                    const double* Ya = Y + (b - 1 - a_blk) * r * nu + r * ic;
-                                    for (int k = 0; k < r; ++k) cross += (Ya[k] * w[k]) * Nm[k + r * jc];
-                                    has_cross = true;
-                                } else if (a_blk == b) { // N' W N
-                                    for (int k = 0; k < r; ++k) cross += (Nm[k + r * ic] * w[k]) * Nm[k + r * jc];
-                                    has_cross = true;
-                                }
-                                if (has_cross) add += cross;
+                    val[jc] = 0.0;
+                    cross[jc] = 0.0;
+                }
+                if (mixed) { // step k = b of MixedCost (costFunctions.cpp:207): (M G_{delta-1})' W N  or  N' W N
+#pragma unroll
+                    for (int jc = 0; jc < kMaxNu; ++jc) {
+                        if (jc < nu) {
+                            double acc = 0.0;
+                            if (delta > 0) {
+                                const double* Ya = Y + (delta - 1) * r * nu + r * ic;
+                                for (int k = 0; k < r; ++k) acc += (Ya[k] * w[k]) * Nm[k + r * jc];
+                            } else {
+                                for (int k = 0; k < r; ++k) acc += (Nm[k + r * ic] * w[k]) * Nm[k + r * jc];
                             }
-                            Q[lane * ld + b * nu + jc] += add;
+                            cross[jc] = acc;
                         }
                     }
                 }
-            }
-            // gradient: c_j = sum_k tmp_k(:,j)' We_k  (ascending step order, costFunctions.cpp:78,80 / :106 / :211)
-            if (lane < n) {
-                const int b = a_blk, jc = ic;
+                for (int b = N - 1; b >= delta; --b) {
+                    const int a = b - delta;
+                    const int m = K - 1 - b; // P_{m+delta, m}
+#pragma unroll
+                    for (int jc = 0; jc < kMaxNu; ++jc) {
+                        if (jc < nu) {
+                            double pterm = 0.0;
+                            if (m >= 0) {
+                                const double* Ya = Y + (m + delta) * r * nu + r * ic;
+                                const double* Yb = Y + m * r * nu + r * jc;
+                                for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
+                            }
+                            val[jc] = accumulate ? val[jc] + pterm : pterm;
+                            Q[(a * nu + ic) * ld + b * nu + jc] += mixed ? val[jc] + cross[jc] : val[jc];
+                        }
+                    }
+                }
+                // gradient: c_j = sum_k tmp_k(:,j)' We_k  (ascending step order, costFunctions.cpp:78,80 / :106 / :211)
+                const int b = blk, jc = sub;
                 double acc = 0.0;
                 if (ct.kind == kCostTarget) {
                     const double* Yb = Y + (N - 1 - b) * r * nu + r * jc;
                     for (int k = 0; k < r; ++k) acc += We[N * r + k] * Yb[k];
                 } else {
-                    if (Nm) { // step k = b of MixedCost: tmp_b(:, j) = N
+                    if (mixed) { // step k = b of MixedCost: tmp_b(:, j) = N
                         double s0 = 0.0;
                         for (int k = 0; k < r; ++k) s0 += We[b * r + k] * Nm[k + r * jc];
                         acc += s0;
@@ -341,29 +418,30 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             }
         }
     }
+    stamp[2] = cycle_counter();
     // ---- 3. implicit rows: norms (qpgen2: column norms of amat) ----
-    StageRows rows { P, G, Xbar, Xcur, nb };
-    for (int i = lane; i < P.mgen; i += kWave) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double a = rows.coeff(i, j);
-            s += a * a;
-        }
-        nb[i] = sqrt(s);
-    }
+    StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {} };
+    rows.cache_own_row();
+    for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(rows.desc(i)));
     if (inst == P.dump_instance && P.dumpA) { // parity hook (LMPC::Aeq/beq/Aineq/bineq; LMPC.h:116-123)
         for (int i = lane; i < P.mgen; i += kWave) {
-            for (int j = 0; j < n; ++j) P.dumpA[(size_t)j * P.mgen + i] = rows.coeff(i, j);
-            P.dumpb[i] = P.row_f[i] - rows.lhs(i, Xbar, nullptr); // b = z - Y x0 (constraints.cpp:81)
+            const RowDesc d = rows.desc(i);
+            for (int j = 0; j < n; ++j) P.dumpA[(size_t)j * P.mgen + i] = rows.coeff(d, j);
+            P.dumpb[i] = d.f - rows.lhs(d, Xbar, nullptr); // b = z - Y x0 (constraints.cpp:81)
         }
     }
     wave_sync();
     if (P.dump_only) return;
+    stamp[3] = cycle_counter();
     // ---- 4. + 5. solve ----
-    int status = gi_factorize(S, n);
+    stamp[4] = stamp[3];
+    int status = gi_factorize<NV>(S, n, &stamp[4]);
+    stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
-    if (status == 0) status = gi_active_set(S, n, P.meq, P.mtotal, rows, P.vsmall, P.max_iter, it_main, it_drop);
+    if (status == 0)
+        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
     wave_sync();
+    stamp[6] = cycle_counter();
     // ---- 6. results (LMPC.cpp:95-97: outputs only on success; failures are flagged with NaN) ----
     if (status == 0) {
         rows.refresh_trajectory(S.xs);
@@ -379,6 +457,12 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         P.status[inst] = status;
         P.iter[2 * (size_t)inst] = it_main;
         P.iter[2 * (size_t)inst + 1] = it_drop;
+        if (P.prof) {
+            stamp[7] = cycle_counter();
+            long long* pr = P.prof + 8 * (size_t)inst;
+            for (int k = 0; k < 7; ++k) pr[k] = stamp[k + 1] - stamp[k]; // preview, costs, norms, chol, inv, set, out
+            pr[7] = stamp[7] - stamp[0];
+        }
     }
 }
 

@@ -64,6 +64,7 @@ struct LdsLayout {
     int BldXi; // fullXDim
     int BldY; // N blocks r x nu   (M G_k)
     int BldWe; // (N+1) blocks r    (w .* (M xbar_k - p))
+    int BldCp; // parameters of the cost being processed: M (r x nx) | N (r x nu) | p (r) | w (r)
     int total; // total doubles
 };
 
@@ -107,6 +108,9 @@ struct FusedPlan {
     double* dumpc; // n
     double* dumpA; // mgen x n  (rows in stacking order, <= / = orientation of the reference)
     double* dumpb; // mgen
+    // optional phase profile: 8 shader-clock stamps per instance (preview, costs, norms, cholesky, inverse+x0,
+    // active set, results, total) -- the device-side analogue of LMPC::solveTime()/solveAndBuildTime()
+    long long* prof;
     LdsLayout lds;
 };
 

@@ -71,7 +71,8 @@ inline void layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
         L.BldXi = L.BldPhi + align2((N + 1) * nx * nx);
         L.BldY = L.BldXi + align2(X);
         L.BldWe = L.BldY + align2(N * rmax * nu);
-        bld = L.BldWe + align2((N + 1) * rmax);
+        L.BldCp = L.BldWe + align2((N + 1) * rmax);
+        bld = L.BldCp + align2(rmax * (nx + nu + 2));
     }
     L.R = take(rsize > bld ? rsize : bld);
     if (fused) {
@@ -79,6 +80,7 @@ inline void layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
         L.BldXi += L.R;
         L.BldY += L.R;
         L.BldWe += L.R;
+        L.BldCp += L.R;
     }
     L.xs = take(n);
     L.dv = take(n);

@@ -24,18 +24,16 @@ struct DenseRows {
             for (int j = 0; j < n; ++j) ax += Aeq[(size_t)j * P.meq + i] * xs[j];
             return ax - beq[i];
         }
-        if (i < P.mgen) {
-            const int r = i - P.meq;
-            double ax = 0.0;
-            for (int j = 0; j < n; ++j) ax += Aineq[(size_t)j * P.mineq + r] * xs[j];
-            return bineq[r] - ax;
-        }
-        const int j = i - P.mgen;
-        if (j < n) return XU[j] - xs[j];
-        return xs[j - n] - XL[j - n];
+        const int r = i - P.meq;
+        double ax = 0.0;
+        for (int j = 0; j < n; ++j) ax += Aineq[(size_t)j * P.mineq + r] * xs[j];
+        return bineq[r] - ax;
     }
 
-    COPRA_DEV double norm(int i) const { return (i < P.mgen) ? nb[i] : 1.0; }
+    COPRA_DEV double slack_uniform(int p, const double* xs) const { return slack(p, xs); }
+    COPRA_DEV double norm(int i) const { return nb[i]; }
+    COPRA_DEV double ub(int j) const { return XU[j]; }
+    COPRA_DEV double lb(int j) const { return XL[j]; }
 
     COPRA_DEV double coeff(int i, int j) const
     {
@@ -46,16 +44,7 @@ struct DenseRows {
     {
         const int j = lane_id();
         if (j >= P.n) return;
-        double v;
-        if (p < P.meq)
-            v = sgn * Aeq[(size_t)j * P.meq + p];
-        else if (p < P.mgen)
-            v = -Aineq[(size_t)j * P.mineq + (p - P.meq)];
-        else {
-            const int q = p - P.mgen;
-            v = (q < P.n) ? ((j == q) ? -1.0 : 0.0) : ((j == q - P.n) ? 1.0 : 0.0);
-        }
-        ap[j] = v;
+        ap[j] = (p < P.meq) ? sgn * Aeq[(size_t)j * P.meq + p] : -Aineq[(size_t)j * P.mineq + (p - P.meq)];
     }
 };
 
@@ -86,9 +75,9 @@ COPRA_DEV void qp_dense_body(const DensePlan& P, int inst)
         nb[i] = sqrt(s);
     }
     wave_sync();
-    int status = gi_factorize(S, n);
+    int status = gi_factorize<0>(S, n);
     int it_main = 0, it_drop = 0;
-    if (status == 0) status = gi_active_set(S, n, P.meq, P.mtotal, rows, P.vsmall, P.max_iter, it_main, it_drop);
+    if (status == 0) status = gi_active_set<0>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
     wave_sync();
     const double qnan = __builtin_nan("");
     for (int e = lane; e < n; e += kWave) P.x[(size_t)inst * n + e] = (status == 0) ? S.xs[e] : qnan;

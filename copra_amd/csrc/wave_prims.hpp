@@ -17,6 +17,8 @@ COPRA_DEV int instance_stride() { return (int)gridDim.x; }
 // workgroup == one wave: the barrier only has to order LDS traffic
 COPRA_DEV void wave_sync() { __syncthreads(); }
 
+COPRA_DEV long long cycle_counter() { return (long long)__builtin_readcyclecounter(); } // s_memtime
+
 COPRA_DEV double* lds_base()
 {
     extern __shared__ __attribute__((aligned(16))) double copra_lds[];
@@ -40,17 +42,98 @@ COPRA_DEV double shfl_up0_f64(double v, int delta)
     return ((int)threadIdx.x - delta >= 0) ? t : 0.0;
 }
 
+// value of lane `src` (src wave-uniform): v_readlane_b32 x2, no LDS round trip
+COPRA_DEV double bcast_f64(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps (full double precision to ~1 ulp, no divide)
+COPRA_DEV double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    return y;
+}
+
+// make a wave-uniform value provably uniform (SGPR) so that table look-ups become scalar loads
+COPRA_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- DPP cross-lane moves (no LDS round trip).  ctrl: quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140
+template <int CTRL>
+COPRA_DEV double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+COPRA_DEV int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+// Butterfly inside each 16-lane row: xor 1, xor 2 (quad_perm), then mirror inside 8 and inside 16 (valid for
+// commutative reductions once the smaller groups already agree).  Afterwards every lane of a row holds the row
+// result; the four row results are combined through v_readlane.
+#define COPRA_DPP_XOR1 0xB1 /* quad_perm [1,0,3,2] */
+#define COPRA_DPP_XOR2 0x4E /* quad_perm [2,3,0,1] */
+#define COPRA_DPP_HMIRROR 0x141
+#define COPRA_DPP_MIRROR 0x140
+
 COPRA_DEV double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
-    return v;
+    v += dpp_f64<COPRA_DPP_XOR1>(v);
+    v += dpp_f64<COPRA_DPP_XOR2>(v);
+    v += dpp_f64<COPRA_DPP_HMIRROR>(v);
+    v += dpp_f64<COPRA_DPP_MIRROR>(v);
+    return (bcast_f64(v, 0) + bcast_f64(v, 16)) + (bcast_f64(v, 32) + bcast_f64(v, 48));
 }
 COPRA_DEV double wave_max(double v)
 {
+    v = fmax(v, dpp_f64<COPRA_DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<COPRA_DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<COPRA_DPP_HMIRROR>(v));
+    v = fmax(v, dpp_f64<COPRA_DPP_MIRROR>(v));
+    return fmax(fmax(bcast_f64(v, 0), bcast_f64(v, 16)), fmax(bcast_f64(v, 32), bcast_f64(v, 48)));
+}
+// argmin of (key, idx) over the wave: smallest key, ties -> smallest idx; lanes without a candidate pass idx < 0.
+// `payload` travels with the winner.  Result is wave-uniform.
+COPRA_DEV void wave_argmin(double& key, int& idx, double& payload)
+{
+#define COPRA_ARGMIN_STEP(CTRL)                                                                                       \
+    {                                                                                                                 \
+        const double ok = dpp_f64<CTRL>(key);                                                                         \
+        const double op = dpp_f64<CTRL>(payload);                                                                     \
+        const int oi = dpp_i32<CTRL>(idx);                                                                            \
+        const bool take = (oi >= 0) && (idx < 0 || ok < key || (ok == key && oi < idx));                              \
+        key = take ? ok : key;                                                                                        \
+        payload = take ? op : payload;                                                                                \
+        idx = take ? oi : idx;                                                                                        \
+    }
+    COPRA_ARGMIN_STEP(COPRA_DPP_XOR1)
+    COPRA_ARGMIN_STEP(COPRA_DPP_XOR2)
+    COPRA_ARGMIN_STEP(COPRA_DPP_HMIRROR)
+    COPRA_ARGMIN_STEP(COPRA_DPP_MIRROR)
+#undef COPRA_ARGMIN_STEP
+    // combine the four rows (lanes 0, 16, 32, 48 hold the row winners)
+    double bk = bcast_f64(key, 0), bp = bcast_f64(payload, 0);
+    int bi = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_f64(v, m));
-    return v;
+    for (int r = 16; r < 64; r += 16) {
+        const double ok = bcast_f64(key, r), op = bcast_f64(payload, r);
+        const int oi = __builtin_amdgcn_readlane(idx, r);
+        const bool take = (oi >= 0) && (bi < 0 || ok < bk || (ok == bk && oi < bi));
+        bk = take ? ok : bk;
+        bp = take ? op : bp;
+        bi = take ? oi : bi;
+    }
+    key = bk;
+    payload = bp;
+    idx = bi;
 }
 
 } // namespace copra_hip

@@ -137,6 +137,11 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
  *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch. ---- */
 copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds);
 
+/* ---- device-side split of that time: per-instance shader-clock cycles of the 7 phases of the fused kernel
+ *      (preview, costs, norms, cholesky, inverse+x0, active set, result stores) + total; 8 values per instance.
+ *      enable != 0 turns the stamps on for subsequent solves; cycles_out (host, [batch][8]) may be NULL. ---- */
+copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long* cycles_out);
+
 /* ---- plug-in point 1, batched: QuadProgDenseSolver::SI_problem + SI_solve (src/QuadProgSolver.cpp:45-72) for
  *      `batch` independent dense QPs  min 1/2 x'Qx + c'x  s.t. Aeq x = beq, Aineq x <= bineq, XL <= x <= XU.
  *      Q [batch][n x n] (upper triangle read), c [batch][n], Aeq [batch][neq x n], beq [batch][neq],

@@ -88,7 +88,7 @@ extern "C" {
 int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
     const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
     double* control, double* trajectory, int* status, int* iter, int dump_instance, double* dumpQ, double* dumpc,
-    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes */)
+    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes */, int use_specialised)
 {
     HostPlan hp;
     copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs);
@@ -118,8 +118,20 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[3] = (int)hp.lds_bytes;
     }
     if (!A) return 0; // size query only
+    // same dispatch as the HIP launcher (select_fused_kernel): compile-time shapes for the BASELINE configs
+    const bool s6 = use_specialised && P.nx == 6 && P.nu == 3 && P.N == 20 && P.rmax <= 6;
+    const bool s2 = use_specialised && P.nx == 2 && P.nu == 1 && P.N == 10 && P.rmax <= 2;
     for (int b = 0; b < dims->batch; ++b) {
-        int r = emu::run_wave([&]() { lmpc_fused_body(P, b); }, hp.lds_bytes, b, dims->batch);
+        int r = emu::run_wave(
+            [&]() {
+                if (s6)
+                    lmpc_fused_body<6, 3, 20, 6>(P, b);
+                else if (s2)
+                    lmpc_fused_body<2, 1, 10, 2>(P, b);
+                else
+                    lmpc_fused_body<0, 0, 0, 0>(P, b);
+            },
+            hp.lds_bytes, b, dims->batch);
         if (r != 0) return -100;
     }
     return 0;

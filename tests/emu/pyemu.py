@@ -39,7 +39,7 @@ def _batchify(A, B, d, x0):
     return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
 
 
-def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1):
+def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True):
     Ab, Bb, db, xb = _batchify(A, B, d, x0)
     batch, nu, nx = Bb.shape[0], Bb.shape[1], Bb.shape[2]
     keep = []
@@ -49,7 +49,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1):
     sizes = (C.c_int * 4)()
     vp = C.c_void_p
     rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, vp(), vp(), vp(), vp(), vp(), vp(), vp(),
-                              vp(), -1, vp(), vp(), vp(), vp(), sizes)
+                              vp(), -1, vp(), vp(), vp(), vp(), sizes, 0)
     if rc == _capi.COPRA_ERR_DOMAIN:
         raise _capi.CopraDomainError("emu")
     if rc == _capi.COPRA_ERR_RUNTIME:
@@ -70,7 +70,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1):
     p = _capi.dptr
     rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ab), p(Bb), p(db), p(xb), p(u), p(tr),
                               st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)),
-                              dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes)
+                              dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes, 1 if specialised else 0)
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
     out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3])

@@ -35,6 +35,7 @@ COPRA_DEV int instance_id() { return emu::g_wave.inst; }
 COPRA_DEV int instance_stride() { return emu::g_wave.ninst; }
 COPRA_DEV void wave_sync() { emu::yield(); }
 COPRA_DEV double* lds_base() { return emu::g_wave.lds; }
+COPRA_DEV long long cycle_counter() { return 0; }
 
 COPRA_DEV double emu_xchg_f64(double v, int src)
 {
@@ -71,6 +72,25 @@ COPRA_DEV double shfl_up0_f64(double v, int delta)
     const double t = emu_xchg_f64(v, src);
     return (src >= 0) ? t : 0.0;
 }
+COPRA_DEV double bcast_f64(double v, int src) { return emu_xchg_f64(v, src); }
+COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+
+COPRA_DEV int uniform_i32(int v) { return v; }
+COPRA_DEV void wave_argmin(double& key, int& idx, double& payload)
+{
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ok = shfl_xor_f64(key, m);
+        const double op = shfl_xor_f64(payload, m);
+        const int oi = shfl_xor_i32(idx, m);
+        const bool take = (oi >= 0) && (idx < 0 || ok < key || (ok == key && oi < idx));
+        if (take) {
+            key = ok;
+            payload = op;
+            idx = oi;
+        }
+    }
+}
+
 COPRA_DEV double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);

@@ -1,0 +1,26 @@
+"""Per-phase shader-clock profile of the fused kernel on the headline workload (run on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from copra_amd import BatchLMPC, workloads  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+wl = workloads.com_preview(batch)
+eng = BatchLMPC(6, 3, wl["N"], batch, wl["costs"], wl["cstrs"])
+eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+eng.enable_phase_profile(True)
+eng.solve()
+eng.solve()
+pr = eng.phase_profile()
+res = eng.results()
+print("kernel ms", eng.last_solve_seconds() * 1e3, "batch", batch)
+for k, name in enumerate(BatchLMPC.PHASES):
+    print("%-12s mean %10.0f  p50 %10.0f  max %10.0f cycles" % (name, pr[:, k].mean(), np.median(pr[:, k]), pr[:, k].max()))
+it = res["iter"][:, 0]
+for v in range(1, int(it.max()) + 1):
+    sel = it == v
+    if sel.any():
+        print("iters=%d: %6d instances, active_set mean %8.0f cycles" % (v, sel.sum(), pr[sel, 5].mean()))
