@@ -31,8 +31,9 @@ using fused_kernel_t = void (*)(const FusedPlan);
 // the BASELINE.json shapes get their own instantiation
 fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
-    if (P.nx == 6 && P.nu == 3 && P.N == 20 && P.rmax <= 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
-    if (P.nx == 2 && P.nu == 1 && P.N == 10 && P.rmax <= 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax);
+    if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
+    if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;
 }
 } // namespace

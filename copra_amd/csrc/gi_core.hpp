@@ -1,7 +1,7 @@
 // gi_core.hpp -- Goldfarb-Idnani dual active-set QP solver, ONE problem per 64-lane wavefront, n <= 64.
 //
 // Replaces the eigen-quadprog call of the reference (src/QuadProgSolver.cpp:71 -> Eigen::QuadProgDense::solve ->
-// qpgen2).  Same algorithm and the same decisions as qpgen2 (see oracle/copra_oracle.c:gi_qpgen2 for the scalar
+// qpgen2).  Same algorithm and the same decisions as qpgen2 (the test oracle holds a scalar
 // restatement): Cholesky Q = R'R, J = R^-1, unconstrained minimiser, then repeatedly pick the most violated
 // constraint normalised by its row norm (lowest index wins ties), compute d = J'n, z = J2 d2, r = R^-1 d1, take
 // the min of the dual (t1) and primal (t2) step, add the constraint (Givens on J) or drop the blocking one.

@@ -36,6 +36,16 @@ enum {
     kGFull = 2 // fullUDim coefficients at params[goff..] applied to U (full-size entry)
 };
 
+// Shapes that get their own compile-time instantiation of the fused kernel (the BASELINE.json configs).  Returns the
+// padded cost-row count RP of the specialisation, or 0 when (nx, nu, N, rmax) runs on the generic instantiation.
+// Used by the plan builder (LDS sizing), the HIP launcher and the CPU emulator so that all three agree.
+inline int specialised_cost_rows(int nx, int nu, int N, int rmax)
+{
+    if (nx == 6 && nu == 3 && N == 20 && rmax <= 6) return 6;
+    if (nx == 2 && nu == 1 && N == 10 && rmax <= 2) return 2;
+    return 0;
+}
+
 struct CostTerm {
     int kind;
     int rows; // r

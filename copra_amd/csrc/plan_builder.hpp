@@ -339,7 +339,10 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.error = "uDim > 8 is not covered by the one-wave fused kernel";
         return COPRA_ERR_UNSUPPORTED;
     }
-    layout_lds(P.lds, nx, nu, N, U, X, P.rmax, P.mgen, P.meq, P.mtotal, true);
+    {
+        const int rp = specialised_cost_rows(nx, nu, N, P.rmax); // the specialised kernels pad every cost to rp rows
+        layout_lds(P.lds, nx, nu, N, U, X, rp > P.rmax ? rp : P.rmax, P.mgen, P.meq, P.mtotal, true);
+    }
     hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
     if (hp.lds_bytes > 160u * 1024u) {
         hp.error = "problem does not fit the 160 KiB LDS of one CU";

@@ -8,6 +8,7 @@
 #include "copra_oracle.h"
 
 #include <float.h>
+#include <malloc.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -1183,6 +1184,12 @@ int or_lmpc_solve_batch(int batch, int nthreads, int nx, int nu, int N, const do
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > batch) nthreads = batch > 0 ? batch : 1;
+    /* The restatement allocates per solve like the reference does (Eigen temporaries).  Keep glibc from returning
+     * that memory to the kernel after every solve: with many threads the mmap/munmap/page-fault traffic serialises
+     * on the process-wide mm lock and the "all cores" baseline would measure the allocator, not the algorithm. */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 16 << 20);
     batch_job_t* jobs = (batch_job_t*)calloc((size_t)nthreads, sizeof(batch_job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     int err = 0;

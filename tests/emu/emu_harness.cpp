@@ -119,8 +119,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     }
     if (!A) return 0; // size query only
     // same dispatch as the HIP launcher (select_fused_kernel): compile-time shapes for the BASELINE configs
-    const bool s6 = use_specialised && P.nx == 6 && P.nu == 3 && P.N == 20 && P.rmax <= 6;
-    const bool s2 = use_specialised && P.nx == 2 && P.nu == 1 && P.N == 10 && P.rmax <= 2;
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax);
+    const bool s6 = use_specialised && P.nx == 6 && rp == 6;
+    const bool s2 = use_specialised && P.nx == 2 && rp == 2;
     for (int b = 0; b < dims->batch; ++b) {
         int r = emu::run_wave(
             [&]() {

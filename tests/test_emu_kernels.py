@@ -1,0 +1,168 @@
+"""The HIP kernel BODIES (copra_amd/csrc/*.hpp) executed lane-by-lane on the CPU by the fiber emulator under
+tests/emu/ and compared with the oracle.  This is how the kernel logic is covered without a GPU; the same bodies,
+compiled by hipcc, are what `-m gpu` tests run on the MI355X.  (The emulator is test infrastructure: see
+tests/emu/wave_prims.hpp.)"""
+import numpy as np
+import pytest
+
+import fixtures as F
+
+RTOL = 1e-6  # BASELINE.json north_star tolerance
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import pyemu
+    pyemu.lib()
+    return pyemu
+
+
+def _rel(a, b):
+    return np.nanmax(np.abs(a - b) / (1.0 + np.abs(b)))
+
+
+def _compare(emu, oracle, A, B, d, x0, N, costs, cstrs, specialised=True, same_iters=True):
+    re = emu.lmpc_solve(A, B, d, x0, N, costs, cstrs, specialised=specialised)
+    ro = oracle.lmpc_solve_batch(np.atleast_3d(A) if np.ndim(A) == 3 else A[None], B if np.ndim(B) == 3 else B[None],
+                                 d if np.ndim(d) == 2 else d[None], x0 if np.ndim(x0) == 2 else x0[None], N, costs,
+                                 cstrs)
+    assert (re["status"] == ro["status"]).all()
+    ok = ro["status"] == 0
+    if ok.any():
+        assert _rel(re["control"][ok], ro["control"][ok]) <= RTOL
+        assert _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= RTOL
+    if same_iters:
+        assert (re["iter"] == ro["iter"]).all()
+    return re, ro
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+def test_config2_double_integrator(emu, oracle, specialised):
+    from copra_amd import workloads
+    wl = workloads.double_integrator(12)
+    _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], specialised)
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+@pytest.mark.parametrize("vmax,umax", [(0.6, 3.0), (0.25, 1.2)])
+def test_config3_com_preview(emu, oracle, specialised, vmax, umax):
+    from copra_amd import workloads
+    wl = workloads.com_preview(10, v_max=vmax, u_max=umax, seed=7)
+    _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], specialised)
+
+
+def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
+    """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(3)
+    for spec in (True, False):
+        re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], dump_instance=2,
+                            specialised=spec)
+        qp = oracle.lmpc_build(wl["A"][2], wl["B"][2], wl["d"][2], wl["x0"][2], wl["N"], wl["costs"], wl["cstrs"])
+        assert np.abs(re["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+        assert np.abs(re["c"] - qp["c"]).max() <= 1e-12 * max(1.0, np.abs(qp["c"]).max())
+        assert np.abs(re["Aineq"] - qp["Aineq"]).max() <= 1e-13
+        assert np.abs(re["bineq"] - qp["bineq"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("system", ["bounded", "ineq", "mixed", "eq"])
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_reference_fixtures_short_horizon(emu, oracle, system, xcost):
+    """The twelve {cost} x {constraint} combinations of tests/TestLMPC.cpp on the systems.h matrices with a horizon
+    that fits the one-wave kernel (N = 12): every cost class and every constraint class goes through the generic
+    instantiation of the fused kernel; the QP dump and the solution must match the oracle."""
+    pb = getattr(F, system + "_system")(xcost, N=12)
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], dump_instance=0)
+    qp = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    scale = np.abs(qp["Q"]).max()
+    assert np.abs(re["Q"] - qp["Q"]).max() <= 1e-12 * scale
+    assert np.abs(re["c"] - qp["c"]).max() <= 1e-11 * max(1.0, np.abs(qp["c"]).max())
+    for k in ("Aeq", "Aineq"):
+        if qp[k].size:
+            assert np.abs(re[k] - qp[k]).max() <= 1e-12 * max(1.0, np.abs(qp[k]).max())
+    for k in ("beq", "bineq"):
+        if qp[k].size:
+            assert np.abs(re[k] - qp[k]).max() <= 1e-10 * max(1.0, np.abs(qp[k]).max())
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert re["status"][0] == ro["status"]
+    if ro["status"] == 0:
+        assert _rel(re["control"][0], ro["control"]) <= RTOL
+        assert _rel(re["trajectory"][0], ro["trajectory"]) <= RTOL
+
+
+@pytest.mark.parametrize("full_size", [False])
+def test_all_nine_classes_at_once(emu, oracle, full_size):
+    """tests/TestLMPC_InitialState.cpp:29-130 problem (per-step entries): four cost classes + five constraint
+    classes in one controller"""
+    pb = F.initial_state_problem(full_size)
+    _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+
+
+def test_full_size_constraint_entries(emu, oracle):
+    """full-size (autoSpan'ed) constraint entries run on the fused path: E (R x fullXDim), G (R x fullUDim)"""
+    from copra_amd.autospan import autospan_cstr
+    pb = F.ineq_system("target", N=12)
+    pb["cstrs"] = [autospan_cstr(dict(c, f=np.tile(np.atleast_1d(c["f"]), 13 if c["kind"] == "trajectory" else 12)))
+                   for c in pb["cstrs"]]
+    _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    pb = F.com_walk_problem()  # 66 x 30 full-size ControlConstraint polytope
+    _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], same_iters=False)
+
+
+def test_status_codes(emu, oracle):
+    pb = F.bounded_system("target", N=10)
+    pb["x0"] = np.array([0.0, 1.0])
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert re["status"][0] == 1 and np.isnan(re["control"]).all()
+    pb = F.bounded_system("target", N=10)
+    pb["costs"][0]["weights"] = [-1e9, -1e9]
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert re["status"][0] == 2
+
+
+def test_dense_qp_kernel_body(emu, oracle):
+    """qp_dense.hpp == QuadProgDenseSolver::SI_solve on the Scilab problem and on random strictly convex QPs with
+    equalities, inequalities and partly infinite bounds"""
+    P = F.scilab_problem()
+    x, fail, it = emu.qp_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+    assert fail[0] == 0 and np.abs(x[0] - P["x_star"]).max() < 1e-9
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        n, meq, mi = int(rng.integers(3, 20)), int(rng.integers(0, 3)), int(rng.integers(0, 12))
+        Mx = rng.standard_normal((n, n))
+        Q = Mx @ Mx.T + 0.1 * np.eye(n)
+        c = rng.standard_normal(n)
+        Aeq, beq = rng.standard_normal((meq, n)), rng.standard_normal(meq)
+        Ai, bi = rng.standard_normal((mi, n)), rng.standard_normal(mi) + 1.0
+        XL, XU = -np.abs(rng.standard_normal(n)) - 0.2, np.abs(rng.standard_normal(n)) + 0.2
+        XL[::3] = -np.inf
+        XU[1::4] = np.finfo(float).max
+        xo, fo, ito = oracle.quadprog_dense(Q, c, Aeq, beq, Ai, bi, XL, XU)
+        x, fail, it = emu.qp_dense(Q, c, Aeq if meq else None, beq if meq else None, Ai if mi else None,
+                                   bi if mi else None, XL, XU)
+        assert fail[0] == fo
+        if fo == 0:
+            assert np.abs(x[0] - xo).max() <= 1e-8 * (1 + np.abs(xo).max())
+
+
+def test_host_plan_errors(emu):
+    """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
+    from copra_amd import _capi
+    pb = F.ineq_system("target", N=10)
+    I5 = np.eye(5)
+    bad = [([dict(kind="trajectory", M=I5, p=np.ones(5))], []), ([dict(kind="target", M=I5, p=np.ones(5))], []),
+           ([dict(kind="control", N=I5, p=np.ones(5))], []), ([dict(kind="mixed", M=I5, N=I5, p=np.ones(5))], []),
+           ([], [dict(kind="trajectory", E=I5, f=np.ones(5))]), ([], [dict(kind="control", G=I5, f=np.ones(5))]),
+           ([], [dict(kind="mixed", E=I5, G=I5, f=np.ones(5))]),
+           ([], [dict(kind="trajectory_bound", lower=np.ones(3), upper=np.ones(3))]),
+           ([], [dict(kind="control_bound", lower=np.ones(3), upper=np.ones(3))])]
+    for costs, cstrs in bad:
+        with pytest.raises(_capi.CopraDomainError):
+            emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], costs, cstrs)
+    for costs, cstrs in [([dict(kind="trajectory", M=I5, p=np.ones(2))], []),
+                         ([], [dict(kind="control_bound", lower=np.ones(3), upper=np.ones(2))])]:
+        with pytest.raises(_capi.CopraDomainError):  # rows mismatch (try autoSpan)
+            emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], costs, cstrs)
+    two_bounds = [dict(kind="control_bound", lower=[-1.0], upper=[1.0])] * 2  # TestLMPC.cpp:1084-1086
+    with pytest.raises(_capi.CopraRuntimeError):
+        emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], [], two_bounds)

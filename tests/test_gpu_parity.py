@@ -142,3 +142,85 @@ def test_status_codes_infeasible_and_not_pd(oracle):
     eng2, res2 = _solve_gpu(wl2, 4)
     ref2 = oracle.lmpc_solve_batch(wl2["A"], wl2["B"], wl2["d"], wl2["x0"], wl2["N"], wl2["costs"], wl2["cstrs"])
     assert (ref2["status"] == 2).all() and (res2["status"] == 2).all()
+
+
+@pytest.mark.parametrize("system", ["bounded", "ineq", "mixed", "eq"])
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_reference_fixtures_on_the_generic_kernel(oracle, system, xcost):
+    """tests/TestLMPC.cpp's twelve {cost} x {constraint} combinations (systems.h matrices, horizon 12 so that they fit
+    the one-wave kernel) through the generic <0,0,0,0> instantiation, batch of 33 perturbed initial states."""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    pb = getattr(F, system + "_system")(xcost, N=12)
+    b = 33
+    rng = np.random.default_rng(5)
+    x0 = np.tile(pb["x0"], (b, 1))
+    if system != "eq":
+        x0[:, 1] += rng.uniform(-1.0, 0.5, b)
+    A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+    eng = BatchLMPC(2, 1, 12, b, pb["costs"], pb["cstrs"])
+    eng.set_system(A, B, d, x0)
+    eng.solve()
+    res = eng.results()
+    ref = oracle.lmpc_solve_batch(A, B, d, x0, 12, pb["costs"], pb["cstrs"])
+    assert (res["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.any()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
+    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+
+
+def test_all_nine_classes_and_full_size_constraints(oracle):
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    from copra_amd.autospan import autospan_cstr
+    pb = F.initial_state_problem(False)
+    eng = BatchLMPC(2, 1, pb["N"], 1, pb["costs"], pb["cstrs"])
+    eng.set_system(pb["A"][None], pb["B"][None], pb["d"][None], pb["x0"][None])
+    eng.solve()
+    res = eng.results()
+    ref = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert res["status"][0] == ref["status"] == 0
+    assert _rel(res["control"][0], ref["control"]) <= RTOL
+    pb = F.com_walk_problem()  # 66 x 30 full-size ControlConstraint (pyTests.py:361-435)
+    eng = BatchLMPC(6, 3, pb["N"], 1, pb["costs"], pb["cstrs"])
+    eng.set_system(pb["A"][None], pb["B"][None], pb["d"][None], pb["x0"][None])
+    eng.solve()
+    res = eng.results()
+    ref = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert res["status"][0] == ref["status"] == 0
+    assert _rel(res["control"][0], ref["control"]) <= RTOL
+    assert _rel(res["trajectory"][0], ref["trajectory"]) <= RTOL
+
+
+def test_receding_horizon_x0_update(oracle):
+    """PreviewSystem::xInit between solves (PreviewSystem.h:52): only x0 changes, A/B stay resident"""
+    from copra_amd import BatchLMPC, workloads
+    wl = workloads.com_preview(128)
+    eng = BatchLMPC(6, 3, wl["N"], 128, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    r1 = eng.results()
+    # apply u_0, move to x_1 and solve again
+    x1 = r1["trajectory"][:, 6:12].copy()
+    eng.set_x0(x1)
+    eng.solve()
+    r2 = eng.results()
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], x1, wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert (r2["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert _rel(r2["control"][ok], ref["control"][ok]) <= RTOL
+
+
+def test_error_codes_through_the_c_abi():
+    """std::domain_error / std::runtime_error equivalents (TestLMPC.cpp:949-1087) out of copra_batch_create"""
+    from copra_amd import BatchLMPC, CopraDomainError, CopraRuntimeError
+    I5 = np.eye(5)
+    with pytest.raises(CopraDomainError):
+        BatchLMPC(2, 1, 10, 4, [dict(kind="trajectory", M=I5, p=np.ones(5))], [])
+    with pytest.raises(CopraDomainError):
+        BatchLMPC(2, 1, 10, 4, [], [dict(kind="mixed", E=I5, G=I5, f=np.ones(5))])
+    with pytest.raises(CopraDomainError):
+        BatchLMPC(2, 1, -1, 4, [], [])
+    with pytest.raises(CopraRuntimeError):
+        BatchLMPC(2, 1, 10, 4, [], [dict(kind="control_bound", lower=[-1.0], upper=[1.0])] * 2)

@@ -1,0 +1,181 @@
+"""Pins the CPU oracle (oracle/copra_oracle.c) against everything the reference offers for this path:
+known answers, the analytic EqSystem solution, and every property check of tests/TestLMPC.cpp /
+tests/TestLMPC_InitialState.cpp replayed at the reference's own sizes (N = 300 / N = 10).
+The reference holds NO numeric golden vectors, so this is what "pinned" can mean here.
+"""
+import numpy as np
+import pytest
+
+import fixtures as F
+
+
+def _solve(oracle, pb, **kw):
+    return oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], **kw)
+
+
+def test_scilab_known_answer(oracle):
+    """tests/TestSolvers.cpp:25-33 (SI_solve true, SI_fail 0) + the known minimiser of tests/systems.h:11-38"""
+    P = F.scilab_problem()
+    x, fail, it = oracle.quadprog_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+    assert fail == 0
+    assert np.abs(x - P["x_star"]).max() < 5e-10
+    fval = 0.5 * x @ P["Q"] @ x + P["c"] @ x
+    assert abs(fval - P["f_star"]) < 1e-7
+    assert np.abs(P["Aeq"] @ x - P["beq"]).max() < 1e-12
+    assert (P["Aineq"] @ x <= P["bineq"] + 1e-12).all()
+
+
+def test_preview_closed_form(oracle):
+    """Psi_{i,j} = A^{i-1-j} B, Phi_i = A^i, xi_i = sum_{k<i} A^k d (src/PreviewSystem.cpp:57-74)"""
+    rng = np.random.default_rng(0)
+    nx, nu, N = 3, 2, 6
+    A, B, d = rng.standard_normal((nx, nx)), rng.standard_normal((nx, nu)), rng.standard_normal(nx)
+    Phi, Psi, xi = oracle.preview(A, B, d, N)
+    for i in range(N + 1):
+        assert np.allclose(Phi[i * nx:(i + 1) * nx], np.linalg.matrix_power(A, i), rtol=1e-12, atol=1e-12)
+        acc = np.zeros(nx)
+        for k in range(i):
+            acc += np.linalg.matrix_power(A, k) @ d
+        assert np.allclose(xi[i * nx:(i + 1) * nx], acc, rtol=1e-12, atol=1e-12)
+        for j in range(N):
+            blk = Psi[i * nx:(i + 1) * nx, j * nu:(j + 1) * nu]
+            ref = np.linalg.matrix_power(A, i - 1 - j) @ B if j < i else np.zeros((nx, nu))
+            assert np.allclose(blk, ref, rtol=1e-12, atol=1e-12)
+
+
+def _traj(res):
+    tr = res["trajectory"]
+    return tr[0::2], tr[1::2]
+
+
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_bound_constraints_properties(oracle, xcost):
+    """TestLMPC.cpp:36-217 (MPC_*_COST_WITH_BOUND_CONSTRAINTS), N = 300"""
+    pb = F.bounded_system(xcost)
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    pos, vel = _traj(res)
+    tail = vel[-1] if xcost != "mixed" else vel[-2]  # TestLMPC.cpp:207: X_N is not evaluated by MixedCost
+    assert abs(pb["xd"][1] - tail) <= 1e-3
+    assert pos.max() <= pb["x0"][0]
+    assert vel.max() <= pb["v_upper"] + 1e-6
+    assert res["control"].max() <= pb["u_upper"] + 1e-6
+
+
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_inequality_constraints_properties(oracle, xcost):
+    """TestLMPC.cpp:219-409"""
+    pb = F.ineq_system(xcost)
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    pos, vel = _traj(res)
+    tail = vel[-1] if xcost != "mixed" else vel[-2]
+    assert abs(pb["xd"][1] - tail) <= 1e-3
+    assert pos.max() <= pb["x0"][0]
+    assert vel.max() <= pb["v_upper"] + 1e-6
+    assert res["control"].max() <= pb["u_upper"] + 1e-6  # "QuadProg allows to exceeds the constrain of a small amount"
+
+
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_mixed_constraints_properties(oracle, xcost):
+    """TestLMPC.cpp:415-587: E x_k + G u_k <= p for every step"""
+    pb = F.mixed_system(xcost)
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    pos, vel = _traj(res)
+    tail = vel[-1] if xcost != "mixed" else vel[-2]
+    assert abs(pb["xd"][1] - tail) <= 1e-3
+    assert pos.max() <= pb["x0"][0]
+    x = res["trajectory"].reshape(-1, 2)
+    for i in range(pb["N"]):
+        r = pb["E"] @ x[i] + pb["G"] @ res["control"][i:i + 1]
+        assert r[0] <= pb["p"] + 1e-6
+
+
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_equality_constraints_properties_and_analytic_answer(oracle, xcost):
+    """TestLMPC.cpp:593-771 + the analytic answer u_k = m g (602 equality rows, 302 of them identically zero)"""
+    pb = F.eq_system(xcost)
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    pos, vel = _traj(res)
+    assert abs(pb["xd"][1] - vel[-1]) <= 1e-3
+    assert pos.max() <= pb["x0"][0] + 1e-6
+    assert vel.max() <= 0.0 + 1e-6
+    assert np.abs(res["control"] - pb["u_expected"]).max() < 1e-5
+    assert np.abs(res["trajectory"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("full_size", [False, True])
+def test_lmpc_vs_initial_state_lmpc_blocks(oracle, full_size):
+    """TestLMPC_InitialState.cpp:29-260: trailing blocks of the InitialStateLMPC QP equal the LMPC QP (<= 1e-6),
+    all nine cost / constraint classes, per-step and full-size entries."""
+    pb = F.initial_state_problem(full_size)
+    nx, U = 2, 10
+    a = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    ist = dict(R=np.zeros((nx, nx)), r=np.zeros(nx), x0lb=pb["x0"], x0ub=pb["x0"])  # InitialStateLMPC.cpp:20-28
+    b = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist)
+    assert a["neq"] == b["neq"] and a["nineq"] == b["nineq"]
+    assert np.abs(a["Q"] - b["Q"][nx:, nx:]).max() <= 1e-6
+    assert np.abs(a["c"] - b["c"][nx:]).max() <= 1e-6
+    assert np.abs(a["lb"] - b["lb"][nx:]).max() <= 1e-6
+    assert np.abs(a["ub"] - b["ub"][nx:]).max() <= 1e-6
+    assert np.abs(a["Aineq"] - b["Aineq"][:, nx:]).max() <= 1e-6
+    assert np.abs(a["bineq"] - b["bineq"]).max() <= 1e-6
+    # LMPC itself solves and keeps x0 (TestLMPC_InitialState.cpp:242-252)
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    assert np.abs(res["trajectory"][:nx] - pb["x0"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("full_size", [False, True])
+def test_initial_state_optimisation(oracle, full_size):
+    """TestLMPC_InitialState.cpp:266-403: x0 free in [-1, 1], R = 1e-6 I: solve succeeds, x0* within bounds"""
+    pb = F.initial_state_problem(full_size)
+    nx = 2
+    ist = dict(R=1e-6 * np.eye(nx), r=np.zeros(nx), x0lb=-np.ones(nx), x0ub=np.ones(nx))
+    res = _solve(oracle, pb, initial_state=ist)
+    assert res["status"] == 0
+    x0s = res["trajectory"][:nx]
+    assert (x0s <= 1 + 1e-6).all() and (x0s >= -1 - 1e-6).all()
+    assert np.abs(x0s - res["x0_opt"]).max() < 1e-12
+
+
+def test_com_walk_runs(oracle):
+    """binding/python/tests/pyTests.py:341-443 only checks that the CoM problem runs; we also check feasibility"""
+    pb = F.com_walk_problem()
+    res = _solve(oracle, pb)
+    assert res["status"] == 0
+    G, h = pb["cstrs"][0]["G"], pb["cstrs"][0]["f"]
+    assert (G @ res["control"] <= h + 1e-6).all()
+
+
+def test_error_paths(oracle):
+    """TestLMPC.cpp:949-1087: std::domain_error on every bad dimension"""
+    pb = F.ineq_system("target", N=10)
+    I5 = np.eye(5)
+    bad_costs = [dict(kind="trajectory", M=I5, p=np.ones(5)), dict(kind="target", M=I5, p=np.ones(5)),
+                 dict(kind="control", N=I5, p=np.ones(5)),
+                 dict(kind="mixed", M=I5, N=I5, p=np.ones(5))]
+    for c in bad_costs:
+        with pytest.raises(ValueError):
+            oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], [c], [])
+    bad_cstrs = [dict(kind="trajectory", E=I5, f=np.ones(5)), dict(kind="control", G=I5, f=np.ones(5)),
+                 dict(kind="mixed", E=I5, G=I5, f=np.ones(5)),
+                 dict(kind="trajectory_bound", lower=np.ones(3), upper=np.ones(3)),
+                 dict(kind="control_bound", lower=np.ones(3), upper=np.ones(3))]
+    for c in bad_cstrs:
+        with pytest.raises(ValueError):
+            oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], [], [c])
+    with pytest.raises(ValueError):  # rows mismatch caught while packing (costFunctions.cpp:47-49)
+        oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], [dict(kind="trajectory", M=I5, p=np.ones(2))], [])
+
+
+def test_status_codes(oracle):
+    """SI_fail (QuadProgSolver.h:21-27): 1 = no solution (x0 violates a step-0 row, quirk Q5), 2 = Q not PD"""
+    pb = F.bounded_system("target", N=10)
+    pb["x0"] = np.array([0.0, 1.0])  # velocity above the bound at step 0
+    assert _solve(oracle, pb)["status"] == 1
+    pb = F.bounded_system("target", N=10)
+    pb["costs"][0]["weights"] = [-1e9, -1e9]
+    assert _solve(oracle, pb)["status"] == 2
