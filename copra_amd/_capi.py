@@ -112,12 +112,49 @@ def pack_cstrs(cstrs, keep):
 
 
 _lib = None
+_SRC_EXT = (".hip", ".hpp", ".h")
+
+
+def source_hash():
+    """sha1 over the HIP sources + the ABI header: recorded next to the .so at build time"""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(_SRC_EXT) or f == "Makefile")
+    for f in files:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(_HERE, "..", "include", "copra_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_library(force=False):
+    """(Re)build libcopra_hip.so with hipcc when the sources changed since the last build.  Never falls back to
+    anything else: without hipcc a stale or missing library is an error the caller sees."""
+    import subprocess
+    stamp = LIB_PATH + ".srchash"
+    want = source_hash()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if os.path.exists(LIB_PATH) and have == want and not force:
+        return False
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIB_PATH):
+            raise ImportError("copra_amd: libcopra_hip.so is older than its sources and hipcc is not available")
+        raise ImportError("copra_amd: libcopra_hip.so has not been built and hipcc is not available")
+    subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
+                          stdout=subprocess.DEVNULL)
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
+    return True
 
 
 def lib():
-    """Load libcopra_hip.so; raises (no fallback) when it has not been built."""
+    """Load libcopra_hip.so (rebuilding it first if its sources changed); raises -- no fallback -- otherwise."""
     global _lib
     if _lib is None:
+        build_library()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "copra_amd: %s is missing -- build the HIP extension first (python -c 'import __graft_entry__ as g; "
