@@ -86,6 +86,7 @@ struct copra_batch {
     // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
+    long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
@@ -118,6 +119,7 @@ static FusedPlan device_plan(const copra_batch* h)
     P.dump_only = 0;
     P.dumpQ = P.dumpc = P.dumpA = P.dumpb = nullptr;
     P.prof = h->d_prof;
+    P.prof_fine = h->d_prof_fine;
     return P;
 }
 
@@ -417,6 +419,24 @@ copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long
     }
     return COPRA_OK;
 }
+
+#ifdef COPRA_FINE_PROFILE
+// profiling builds only (libcopra_hip_prof.so): 32 raw shader-clock stamps per instance, -1 = unused
+copra_status_t copra_batch_fine_profile(copra_batch_t* h, long long* out)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_fine_profile: null handle");
+    const size_t b = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1);
+    if (!h->d_prof_fine) {
+        HIP_TRY(hipMalloc((void**)&h->d_prof_fine, b * 32 * sizeof(long long)));
+        HIP_TRY(hipMemset(h->d_prof_fine, 0xff, b * 32 * sizeof(long long)));
+    }
+    if (out) {
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+        HIP_TRY(hipMemcpy(out, h->d_prof_fine, b * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    return COPRA_OK;
+}
+#endif
 
 copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds)
 {

@@ -31,7 +31,27 @@
 #include "plan.hpp"
 #include "wave_prims.hpp"
 
+// Fine-grained stamps for profiling builds (make libcopra_hip_prof.so); compiled out of the product library.
+#ifdef COPRA_FINE_PROFILE
+#define COPRA_FINE(tag)                                                                                               \
+    do {                                                                                                              \
+        if (copra_fine_n < 32) copra_fine[copra_fine_n++] = cycle_counter();                                         \
+    } while (0)
+#define COPRA_FINE_DECL long long copra_fine[32]; int copra_fine_n = 0
+#define COPRA_FINE_ARGS , long long* copra_fine, int& copra_fine_n
+#define COPRA_FINE_PASS , copra_fine, copra_fine_n
+#else
+#define COPRA_FINE(tag) do { } while (0)
+#define COPRA_FINE_DECL
+#define COPRA_FINE_ARGS
+#define COPRA_FINE_PASS
+#endif
+
 namespace copra_hip {
+
+struct alignas(16) f64x2 { // one 16-byte LDS access
+    double lo, hi;
+};
 
 struct SolverLds {
     double* J;
@@ -67,7 +87,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
 // S.coef is used as scratch (1/R(i,i)).
 // ------------------------------------------------------------------------------------------------
 template <int NV>
-COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol = nullptr)
+COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA_FINE_ARGS)
 {
     const int lane = lane_id();
     const int n = NV ? NV : n_rt;
@@ -97,6 +117,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol = nul
 #pragma unroll
                 for (int p = 0; p < 4; ++p) acc[p] -= bb[u][p] * rt[u];
         }
+        if (k0 == 28 || k0 == 56) COPRA_FINE("chol:tloop");
         // The 4x4 diagonal block of the panel (entries acc[p] of lanes k0+p..k0+3) is broadcast to every lane and
         // factorised redundantly (wave-uniform arithmetic, no cross-lane dependency inside the chain).
         double Dg[4][4], Rd[4][4], ri[4];
@@ -131,6 +152,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol = nul
             if (p < pw && lane == 0) rinvd[k0 + p] = ri[p];
         }
         wave_sync();
+        if (k0 == 24 || k0 == 28 || k0 == 52 || k0 == 56) COPRA_FINE("chol:panel");
     }
     if (t_chol) *t_chol = cycle_counter();
     // zero the strict lower triangle (qpgen2 does the same before the first rotation)

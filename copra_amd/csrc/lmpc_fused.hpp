@@ -210,6 +210,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     const int ld = NV ? (NV | 1) : S.ldj;
 
     long long stamp[8];
+    COPRA_FINE_DECL;
     stamp[0] = cycle_counter();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];
@@ -236,6 +237,29 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         }
         // stacked step: element (r, c) of [Phi_s | G_{s-1} | xi_s], c in [0, nx + nu + 1)
         const int per_step = nx * (nx + nu + 1);
+        if constexpr (NX_ > 0 && NU_ > 0 && NX_ * (NX_ + NU_ + 1) <= kWave) {
+            // one element per lane for the whole recursion: keep row r of A in registers, only 'src' is re-read
+            const int e = (lane < per_step) ? lane : 0;
+            const int c = e / NX_, r = e - c * NX_;
+            double ar[NX_];
+#pragma unroll
+            for (int t = 0; t < NX_; ++t) ar[t] = A[r + NX_ * t];
+            const double add = (c == NX_ + NU_) ? D[r] : 0.0;
+            for (int s = 2; s <= N; ++s) {
+                wave_sync();
+                const double* src = (c < NX_) ? Phi + (s - 1) * nPhi + c * NX_
+                                              : (c < NX_ + NU_) ? G + (s - 2) * nG + (c - NX_) * NX_ : Xi + (s - 1) * NX_;
+                double* dst = (c < NX_) ? Phi + s * nPhi + c * NX_ + r
+                                        : (c < NX_ + NU_) ? G + (s - 1) * nG + (c - NX_) * NX_ + r : Xi + s * NX_ + r;
+                double sv[NX_];
+#pragma unroll
+                for (int t = 0; t < NX_; ++t) sv[t] = src[t];
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < NX_; ++t) acc += ar[t] * sv[t];
+                if (lane < per_step) *dst = acc + add;
+            }
+        } else
         for (int s = 2; s <= N; ++s) {
             wave_sync();
             for (int e = lane; e < per_step; e += kWave) {
@@ -273,8 +297,15 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     // ---- 2. Hessian and gradient: Q = 1e-6 I + sum Q_k, c = sum c_k (LMPC.cpp:228-230, 252-255) ----
     {
         double* Q = S.J;
-        for (int e = lane; e < n * ld; e += kWave) Q[e] = 0.0;
+        COPRA_FINE("costs:start");
+        { // the J region starts 16-byte aligned (plan_builder.hpp: even offsets): clear two doubles per store
+            f64x2* Q2 = reinterpret_cast<f64x2*>(Q);
+            const int n2 = (n * ld + 1) / 2;
+#pragma unroll 8
+            for (int e = lane; e < n2; e += kWave) Q2[e] = f64x2 { 0.0, 0.0 };
+        }
         wave_sync();
+        COPRA_FINE("costs:zeroed");
         if (lane < n) {
             double one = 1.0;
             one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;
@@ -307,6 +338,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                 w[e] = (e < rc) ? P.params[ct.offW + e] : 0.0;
             }
             wave_sync();
+            COPRA_FINE("cost:params");
             if (ct.kind == kCostControl) {
                 // ControlCost::update (costFunctions.cpp:148-156): block-diagonal N'WN, c = -p'WN
                 if (lane < n) {
@@ -338,6 +370,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                 We[e] = (acc - p[row]) * w[row];
             }
             wave_sync();
+            COPRA_FINE("cost:YWe");
             // last state index K that enters the sum: trajectory K = N, mixed K = N-1, target only K = N
             const int K = mixed ? N - 1 : N;
             const bool accumulate = (ct.kind != kCostTarget);
@@ -365,23 +398,54 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                         }
                     }
                 }
-                for (int b = N - 1; b >= delta; --b) {
-                    const int a = b - delta;
-                    const int m = K - 1 - b; // P_{m+delta, m}
+                if constexpr (RP_ > 0 && NU_ > 0) {
+                    // compile-time rows: every operand of a step is loaded before the first FMA so the LDS reads batch
+                    double wr[RP_];
 #pragma unroll
-                    for (int jc = 0; jc < kMaxNu; ++jc) {
-                        if (jc < nu) {
+                    for (int k = 0; k < RP_; ++k) wr[k] = w[k];
+                    for (int b = N - 1; b >= delta; --b) {
+                        const int a = b - delta;
+                        const int m = K - 1 - b; // P_{m+delta, m}
+                        const int ma = (m >= 0) ? m + delta : 0, mb = (m >= 0) ? m : 0;
+                        double ya[RP_], yb[NU_][RP_], qv[NU_];
+#pragma unroll
+                        for (int k = 0; k < RP_; ++k) ya[k] = Y[ma * RP_ * NU_ + RP_ * ic + k] * wr[k];
+#pragma unroll
+                        for (int jc = 0; jc < NU_; ++jc)
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) yb[jc][k] = Y[mb * RP_ * NU_ + RP_ * jc + k];
+#pragma unroll
+                        for (int jc = 0; jc < NU_; ++jc) qv[jc] = Q[(a * NU_ + ic) * ld + b * NU_ + jc];
+#pragma unroll
+                        for (int jc = 0; jc < NU_; ++jc) {
                             double pterm = 0.0;
-                            if (m >= 0) {
-                                const double* Ya = Y + (m + delta) * r * nu + r * ic;
-                                const double* Yb = Y + m * r * nu + r * jc;
-                                for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
-                            }
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) pterm += ya[k] * yb[jc][k];
+                            if (m < 0) pterm = 0.0;
                             val[jc] = accumulate ? val[jc] + pterm : pterm;
-                            Q[(a * nu + ic) * ld + b * nu + jc] += mixed ? val[jc] + cross[jc] : val[jc];
+                            Q[(a * NU_ + ic) * ld + b * NU_ + jc] = qv[jc] + (mixed ? val[jc] + cross[jc] : val[jc]);
+                        }
+                    }
+                } else {
+                    for (int b = N - 1; b >= delta; --b) {
+                        const int a = b - delta;
+                        const int m = K - 1 - b; // P_{m+delta, m}
+#pragma unroll
+                        for (int jc = 0; jc < kMaxNu; ++jc) {
+                            if (jc < nu) {
+                                double pterm = 0.0;
+                                if (m >= 0) {
+                                    const double* Ya = Y + (m + delta) * r * nu + r * ic;
+                                    const double* Yb = Y + m * r * nu + r * jc;
+                                    for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
+                                }
+                                val[jc] = accumulate ? val[jc] + pterm : pterm;
+                                Q[(a * nu + ic) * ld + b * nu + jc] += mixed ? val[jc] + cross[jc] : val[jc];
+                            }
                         }
                     }
                 }
+                COPRA_FINE("cost:chain");
                 // gradient: c_j = sum_k tmp_k(:,j)' We_k  (ascending step order, costFunctions.cpp:78,80 / :106 / :211)
                 const int b = blk, jc = sub;
                 double acc = 0.0;
@@ -394,17 +458,33 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                         for (int k = 0; k < r; ++k) s0 += We[b * r + k] * Nm[k + r * jc];
                         acc += s0;
                     }
-                    for (int s = b + 1; s <= K; ++s) {
-                        const double* Yb = Y + (s - 1 - b) * r * nu + r * jc;
-                        const double* Ws = We + s * r;
-                        double sk = 0.0;
-                        for (int k = 0; k < r; ++k) sk += Ws[k] * Yb[k];
-                        acc += sk;
+                    if constexpr (RP_ > 0 && NU_ > 0) {
+                        for (int s = b + 1; s <= K; ++s) {
+                            double yv[RP_], wv[RP_];
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) {
+                                yv[k] = Y[(s - 1 - b) * RP_ * NU_ + RP_ * jc + k];
+                                wv[k] = We[s * RP_ + k];
+                            }
+                            double sk = 0.0;
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) sk += wv[k] * yv[k];
+                            acc += sk;
+                        }
+                    } else {
+                        for (int s = b + 1; s <= K; ++s) {
+                            const double* Yb = Y + (s - 1 - b) * r * nu + r * jc;
+                            const double* Ws = We + s * r;
+                            double sk = 0.0;
+                            for (int k = 0; k < r; ++k) sk += Ws[k] * Yb[k];
+                            acc += sk;
+                        }
                     }
                 }
                 cj += acc;
             }
         }
+        COPRA_FINE("costs:grad");
         wave_sync();
         if (lane < n) S.cvec[lane] = cj;
         wave_sync();
@@ -435,7 +515,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     stamp[3] = cycle_counter();
     // ---- 4. + 5. solve ----
     stamp[4] = stamp[3];
-    int status = gi_factorize<NV>(S, n, &stamp[4]);
+    int status = gi_factorize<NV>(S, n, &stamp[4] COPRA_FINE_PASS);
     stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
     if (status == 0)
@@ -457,6 +537,12 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         P.status[inst] = status;
         P.iter[2 * (size_t)inst] = it_main;
         P.iter[2 * (size_t)inst + 1] = it_drop;
+#ifdef COPRA_FINE_PROFILE
+        if (P.prof_fine) {
+            long long* pf = P.prof_fine + 32 * (size_t)inst;
+            for (int k = 0; k < 32; ++k) pf[k] = (k < copra_fine_n) ? copra_fine[k] - stamp[0] : -1;
+        }
+#endif
         if (P.prof) {
             stamp[7] = cycle_counter();
             long long* pr = P.prof + 8 * (size_t)inst;

@@ -121,6 +121,7 @@ struct FusedPlan {
     // optional phase profile: 8 shader-clock stamps per instance (preview, costs, norms, cholesky, inverse+x0,
     // active set, results, total) -- the device-side analogue of LMPC::solveTime()/solveAndBuildTime()
     long long* prof;
+    long long* prof_fine; // profiling builds only (-DCOPRA_FINE_PROFILE): 32 raw stamps per instance
     LdsLayout lds;
 };
 

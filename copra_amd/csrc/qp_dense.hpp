@@ -75,7 +75,8 @@ COPRA_DEV void qp_dense_body(const DensePlan& P, int inst)
         nb[i] = sqrt(s);
     }
     wave_sync();
-    int status = gi_factorize<0>(S, n);
+    COPRA_FINE_DECL;
+    int status = gi_factorize<0>(S, n, nullptr COPRA_FINE_PASS);
     int it_main = 0, it_drop = 0;
     if (status == 0) status = gi_active_set<0>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
     wave_sync();
