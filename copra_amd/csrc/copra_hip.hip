@@ -23,7 +23,15 @@ using namespace copra_hip;
 template <int NX, int NU, int NH, int RP>
 __global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
 {
-    lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
+    if (!P.from_list) {
+        lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
+    } else { // second tier: the instances the compact layout could not finish
+        const int count = *P.ovf_count;
+        for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+            lmpc_fused_body<NX, NU, NH, RP>(P, P.ovf_list[k]);
+            __syncthreads();
+        }
+    }
 }
 
 namespace {
@@ -86,6 +94,7 @@ struct copra_batch {
     // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
+    int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
     long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -120,14 +129,18 @@ static FusedPlan device_plan(const copra_batch* h)
     P.dumpQ = P.dumpc = P.dumpA = P.dumpb = nullptr;
     P.prof = h->d_prof;
     P.prof_fine = h->d_prof_fine;
+    P.ovf_count = h->d_ovf_count;
+    P.ovf_list = h->d_ovf_list;
+    P.from_list = 0;
     return P;
 }
 
 static copra_status_t ensure_lds_attr(copra_batch* h)
 {
-    if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024) {
+    const size_t need = h->hp.lds_full_bytes > h->hp.lds_bytes ? h->hp.lds_full_bytes : h->hp.lds_bytes;
+    if (!h->lds_attr_set && need > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_fused_kernel(h->hp.plan)),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     h->lds_attr_set = true;
     return COPRA_OK;
@@ -190,6 +203,8 @@ copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims,
     chk(hipMalloc((void**)&h->d_traj, b * P.X * sizeof(double)));
     chk(hipMalloc((void**)&h->d_status, b * sizeof(int)));
     chk(hipMalloc((void**)&h->d_iter, b * 2 * sizeof(int)));
+    chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
+    chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
     chk(hipEventCreate(&h->ev1));
     if (e != hipSuccess) {
@@ -222,6 +237,8 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_iter);
     (void)hipFree(h->d_prof);
+    (void)hipFree(h->d_ovf_count);
+    (void)hipFree(h->d_ovf_list);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -296,8 +313,18 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
+    if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
     hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
     HIP_TRY(hipGetLastError());
+    if (h->hp.two_tier) {
+        // second tier: same kernel, full LDS layout, instances taken from the overflow queue (usually empty)
+        FusedPlan P2 = P;
+        P2.lds = h->hp.lds_full;
+        P2.from_list = 1;
+        const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+        hipLaunchKernelGGL(select_fused_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(h->ev1, s));
     h->timed = true;
     return COPRA_OK;
@@ -370,9 +397,10 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     P.dumpc = dc;
     P.dumpA = dA;
     P.dumpb = db;
+    P.lds = h->hp.lds_full;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_bytes, h->last_stream, P);
+    hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     std::vector<double> hA((size_t)(mg ? mg : 1) * n), hb((size_t)(mg ? mg : 1));
@@ -469,7 +497,7 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.batch = batch;
     P.vsmall = qpgen2_vsmall();
     P.max_iter = 50 * (n + P.mtotal) + 100;
-    layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
+    (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
     const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
     if (lds_bytes > 160u * 1024u) return fail(COPRA_ERR_UNSUPPORTED, "dense QP does not fit LDS");
     if (lds_bytes > 48 * 1024)

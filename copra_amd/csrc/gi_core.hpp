@@ -57,6 +57,7 @@ struct SolverLds {
     double* J;
     int ldj;
     double* R; // packed upper triangular: R(i,c) at R[c(c+1)/2 + i]
+    int rcap; // columns R has room for (LdsLayout::rcap)
     double *xs, *dv, *zv, *uv, *ap, *coef, *cvec, *eqsgn, *scal;
     int *act, *iact;
 };
@@ -67,6 +68,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.J = lds + L.J;
     S.ldj = L.ldj;
     S.R = lds + L.R;
+    S.rcap = L.rcap;
     S.xs = lds + L.xs;
     S.dv = lds + L.dv;
     S.zv = lds + L.zv;
@@ -231,7 +233,8 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
 
 // ------------------------------------------------------------------------------------------------
-// Active-set iterations.  Returns qpgen2's ierr (0 ok, 1 infeasible) or 3 (iteration cap).
+// Active-set iterations.  Returns qpgen2's ierr (0 ok, 1 infeasible), 3 (iteration cap) or 4 (internal: the
+// compact layout's R is full; the caller queues the instance for the full-layout launch).
 // ------------------------------------------------------------------------------------------------
 template <int NV, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
@@ -386,6 +389,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if (lane == 0) S.uv[nact] += tt;
                 if (t2min) {
                     // ---- full step: constraint nvl becomes active; update R and J ----
+                    if (nact >= S.rcap) return 4; // compact layout: R is full -> the instance is redone with the full one
                     if (lane < nact) S.R[rcol(nact) + lane] = dj;
                     const bool in_tail = (lane >= nact && lane < n);
                     // |h_q| = sqrt(sum_{k>=q} d_k^2) by a suffix scan, scaled by max|d| against under/overflow

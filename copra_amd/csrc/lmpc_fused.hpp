@@ -292,6 +292,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             for (int c = 0; c < nx; ++c) acc += Pk[nx * c] * X0[c];
             Xbar[row] = acc + Xi[row];
         }
+        wave_sync(); // the compact layout lends the J region to the preview tables: done with them before Q is built
     }
     stamp[1] = cycle_counter();
     // ---- 2. Hessian and gradient: Q = 1e-6 I + sum Q_k, c = sum c_k (LMPC.cpp:228-230, 252-255) ----
@@ -522,6 +523,14 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
     wave_sync();
     stamp[6] = cycle_counter();
+    if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else
+        if (lane == 0) {
+            const int slot = atomic_append(P.ovf_count);
+            P.ovf_list[slot] = inst;
+            P.status[inst] = 4;
+        }
+        return;
+    }
     // ---- 6. results (LMPC.cpp:95-97: outputs only on success; failures are flagged with NaN) ----
     if (status == 0) {
         rows.refresh_trajectory(S.xs);

@@ -62,7 +62,8 @@ struct LdsLayout {
     int Xbar; // free response  Phi x0 + xi               (fullXDim)
     int Xcur; // current trajectory Xbar + Psi U          (fullXDim)
     int J, ldj; // n x ldj: Hessian (upper) -> Cholesky factor -> J = R^-1 (row i at J + i*ldj)
-    int R; // packed upper-triangular R of the active set, n(n+1)/2; ALIASED during the build phase (see Bld*)
+    int R; // packed upper-triangular R of the active set (rcap columns)
+    int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one
     int xs, dv, zv, uv, ap, coef, cvec; // solver vectors (n; uv n+1; coef 4n)
     int nb; // norms of the general rows (m_gen)
     int eqsgn; // current orientation of each equality row (meq)
@@ -120,6 +121,10 @@ struct FusedPlan {
     double* dumpb; // mgen
     // optional phase profile: 8 shader-clock stamps per instance (preview, costs, norms, cholesky, inverse+x0,
     // active set, results, total) -- the device-side analogue of LMPC::solveTime()/solveAndBuildTime()
+    // two-tier execution: instances whose active set outgrows lds.rcap in the compact layout are queued ...
+    int* ovf_count; // device counter (reset before every solve)
+    int* ovf_list; // [batch] instance ids
+    int from_list; // ... and the second launch (full layout) takes its instances from that queue
     long long* prof;
     long long* prof_fine; // profiling builds only (-DCOPRA_FINE_PROFILE): 32 raw stamps per instance
     LdsLayout lds;

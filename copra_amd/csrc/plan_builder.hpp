@@ -23,7 +23,12 @@ struct HostPlan {
     std::vector<double> row_f;
     std::vector<double> lb, ub;
     std::string error;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0; // of plan.lds (the layout of the first launch)
+    // two-tier execution: plan.lds is the compact layout (4 waves per CU) when it fits, lds_full the always-sufficient
+    // one used by the second launch for the instances that overflowed R
+    bool two_tier = false;
+    LdsLayout lds_full {};
+    size_t lds_full_bytes = 0;
 };
 
 // qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
@@ -40,9 +45,13 @@ inline double qpgen2_vsmall()
 
 inline int align2(int v) { return (v + 1) & ~1; }
 
-// LDS carve-up for a solver working on nvar variables with mgen general rows.
-inline void layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused)
+// LDS carve-up for a solver working on n variables with mgen general rows.
+//   compact == false: every region has its own space, R holds n columns (always sufficient).
+//   compact == true : the preview-phase tables (A, B, d, x0, Phi, xi) borrow the not-yet-used J region, the cost-phase
+//                     tables (Y, We, cost parameters) borrow the not-yet-used solver vectors, and R gets whatever is
+//                     left of `budget` doubles (at least 1 column).  Returns false if even that does not fit.
+inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
+    bool fused, bool compact = false, int budget = 0)
 {
     int o = 0;
     auto take = [&](int count) {
@@ -50,51 +59,69 @@ inline void layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
         o += align2(count);
         return at;
     };
+    L.ldj = (n % 2 == 0) ? n + 1 : n; // odd leading dimension: row-per-lane and column-per-lane reads conflict-free
+    const int sizeJ = align2(n * L.ldj);
+    const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
+    const int sizeCost = fused ? align2(N * rmax * nu) + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) : 0;
     if (fused) {
-        L.A = take(nx * nx);
-        L.B = take(nx * nu);
-        L.D = take(nx);
-        L.X0 = take(nx);
         L.G = take(N * nx * nu);
         L.Xbar = take(X);
         L.Xcur = take(X);
     } else {
-        L.A = L.B = L.D = L.X0 = L.G = L.Xbar = L.Xcur = 0;
+        L.G = L.Xbar = L.Xcur = 0;
     }
-    L.ldj = (n % 2 == 0) ? n + 1 : n; // odd leading dimension: row-per-lane and column-per-lane reads conflict-free
-    L.J = take(n * L.ldj);
-    // R region, aliased by the build scratch
-    int rsize = n * (n + 1) / 2 + 2;
-    int bld = 0;
+    L.J = take(sizeJ > 0 ? sizeJ : 2);
+    if (compact && sizePrev > sizeJ) take(sizePrev - sizeJ); // (never for the shapes of interest)
+    int prev0 = L.J; // preview tables alias J in the compact layout
+    if (fused && !compact) prev0 = take(sizePrev);
     if (fused) {
-        L.BldPhi = 0;
-        L.BldXi = L.BldPhi + align2((N + 1) * nx * nx);
-        L.BldY = L.BldXi + align2(X);
-        L.BldWe = L.BldY + align2(N * rmax * nu);
-        L.BldCp = L.BldWe + align2((N + 1) * rmax);
-        bld = L.BldCp + align2(rmax * (nx + nu + 2));
+        int q = prev0;
+        L.A = q, q += align2(nx * nx);
+        L.B = q, q += align2(nx * nu);
+        L.D = q, q += align2(nx);
+        L.X0 = q, q += align2(nx);
+        L.BldPhi = q, q += align2((N + 1) * nx * nx);
+        L.BldXi = q, q += align2(X);
+    } else {
+        L.A = L.B = L.D = L.X0 = L.BldPhi = L.BldXi = 0;
     }
-    L.R = take(rsize > bld ? rsize : bld);
-    if (fused) {
-        L.BldPhi += L.R;
-        L.BldXi += L.R;
-        L.BldY += L.R;
-        L.BldWe += L.R;
-        L.BldCp += L.R;
-    }
+    // solver vectors (the cost tables alias them in the compact layout)
+    const int vec0 = o;
     L.xs = take(n);
     L.dv = take(n);
-    L.zv = take(n);
+    L.zv = L.dv; // (unused scratch name kept for the carve helper)
     L.uv = take(n + 2);
     L.ap = take(n);
+    L.cvec = compact ? L.ap : take(n); // c is consumed by the factorisation before ap is first written
     L.coef = take(4 * n);
-    L.cvec = take(n);
     L.nb = take(mgen > 0 ? mgen : 1);
     L.eqsgn = take(meq > 0 ? meq : 1);
-    L.scal = take(8);
+    L.scal = take(2);
     L.act = take((mtotal + 1) / 2 + 1);
     L.iact = take((n + 2) / 2 + 1);
+    if (compact && sizeCost > o - vec0) take(sizeCost - (o - vec0));
+    int cost0 = vec0;
+    if (fused && !compact) cost0 = take(sizeCost);
+    if (fused) {
+        int q = cost0;
+        L.BldY = q, q += align2(N * rmax * nu);
+        L.BldWe = q, q += align2((N + 1) * rmax);
+        L.BldCp = q;
+    } else {
+        L.BldY = L.BldWe = L.BldCp = 0;
+    }
+    // R: n columns, or what the budget leaves
+    int rcap = n;
+    if (compact) {
+        const int left = budget - o - 2;
+        rcap = 0;
+        while (rcap < n && (rcap + 1) * (rcap + 2) / 2 <= left) ++rcap;
+        if (rcap < 1) return false;
+    }
+    L.rcap = rcap;
+    L.R = take(rcap * (rcap + 1) / 2 + 2);
     L.total = o;
+    return true;
 }
 
 inline bool is_neg_inf(double v) { return std::isinf(v) && v < 0; }
@@ -341,12 +368,26 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     }
     {
         const int rp = specialised_cost_rows(nx, nu, N, P.rmax); // the specialised kernels pad every cost to rp rows
-        layout_lds(P.lds, nx, nu, N, U, X, rp > P.rmax ? rp : P.rmax, P.mgen, P.meq, P.mtotal, true);
-    }
-    hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
-    if (hp.lds_bytes > 160u * 1024u) {
-        hp.error = "problem does not fit the 160 KiB LDS of one CU";
-        return COPRA_ERR_UNSUPPORTED;
+        const int rows = rp > P.rmax ? rp : P.rmax;
+        layout_lds(hp.lds_full, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true);
+        hp.lds_full_bytes = (size_t)hp.lds_full.total * sizeof(double);
+        if (hp.lds_full_bytes > 160u * 1024u) {
+            hp.error = "problem does not fit the 160 KiB LDS of one CU";
+            return COPRA_ERR_UNSUPPORTED;
+        }
+        // Occupancy: the 160 KiB of a CU admit 4 waves (one per SIMD) at <= 40 KiB each.  If the full layout does not
+        // reach that but a compact one (aliased build tables, R capped) does, run two-tier.
+        const int quarter = (160 * 1024 / 4) / (int)sizeof(double);
+        LdsLayout compact {};
+        hp.two_tier = false;
+        P.lds = hp.lds_full;
+        if (hp.lds_full.total > quarter
+            && layout_lds(compact, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, quarter)
+            && compact.total <= quarter && compact.rcap >= 8 && compact.rcap < U) {
+            hp.two_tier = true;
+            P.lds = compact;
+        }
+        hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
     }
     return COPRA_OK;
 }

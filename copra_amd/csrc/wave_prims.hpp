@@ -17,6 +17,7 @@ COPRA_DEV int instance_stride() { return (int)gridDim.x; }
 // workgroup == one wave: the barrier only has to order LDS traffic
 COPRA_DEV void wave_sync() { __syncthreads(); }
 
+COPRA_DEV int atomic_append(int* counter) { return atomicAdd(counter, 1); }
 COPRA_DEV long long cycle_counter() { return (long long)__builtin_readcyclecounter(); } // s_memtime
 
 COPRA_DEV double* lds_base()

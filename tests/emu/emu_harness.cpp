@@ -88,7 +88,7 @@ extern "C" {
 int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
     const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
     double* control, double* trajectory, int* status, int* iter, int dump_instance, double* dumpQ, double* dumpc,
-    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes */, int use_specialised)
+    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes, overflowed, rcap */, int use_specialised)
 {
     HostPlan hp;
     copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs);
@@ -116,24 +116,43 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[1] = P.meq;
         sizes[2] = P.mineq;
         sizes[3] = (int)hp.lds_bytes;
+        sizes[4] = 0;
+        sizes[5] = P.lds.rcap;
     }
     if (!A) return 0; // size query only
     // same dispatch as the HIP launcher (select_fused_kernel): compile-time shapes for the BASELINE configs
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax);
     const bool s6 = use_specialised && P.nx == 6 && rp == 6;
     const bool s2 = use_specialised && P.nx == 2 && rp == 2;
+    // two-tier execution exactly as copra_batch_solve does it: compact layout first, overflow queue, full layout
+    int ovf_count = 0;
+    std::vector<int> ovf_list((size_t)(dims->batch > 0 ? dims->batch : 1));
+    P.ovf_count = &ovf_count;
+    P.ovf_list = ovf_list.data();
+    P.from_list = 0;
+    if (dump_instance >= 0) P.lds = hp.lds_full;
+    auto body = [&](const FusedPlan& PP, int b) {
+        if (s6)
+            lmpc_fused_body<6, 3, 20, 6>(PP, b);
+        else if (s2)
+            lmpc_fused_body<2, 1, 10, 2>(PP, b);
+        else
+            lmpc_fused_body<0, 0, 0, 0>(PP, b);
+    };
+    const size_t bytes1 = (size_t)P.lds.total * sizeof(double);
     for (int b = 0; b < dims->batch; ++b) {
-        int r = emu::run_wave(
-            [&]() {
-                if (s6)
-                    lmpc_fused_body<6, 3, 20, 6>(P, b);
-                else if (s2)
-                    lmpc_fused_body<2, 1, 10, 2>(P, b);
-                else
-                    lmpc_fused_body<0, 0, 0, 0>(P, b);
-            },
-            hp.lds_bytes, b, dims->batch);
+        int r = emu::run_wave([&]() { body(P, b); }, bytes1, b, dims->batch);
         if (r != 0) return -100;
+    }
+    if (sizes) sizes[4] = ovf_count;
+    if (ovf_count > 0) {
+        FusedPlan P2 = P;
+        P2.lds = hp.lds_full;
+        for (int k = 0; k < ovf_count; ++k) {
+            const int b = ovf_list[(size_t)k];
+            int r = emu::run_wave([&]() { body(P2, b); }, hp.lds_full_bytes, b, dims->batch);
+            if (r != 0) return -100;
+        }
     }
     return 0;
 }
@@ -163,7 +182,7 @@ int emu_qp_dense(int batch, int n, int neq, int nineq, const double* Q, const do
     P.vsmall = qpgen2_vsmall();
     P.max_iter = 50 * (n + P.mtotal) + 100;
     if (n > 64) return (int)COPRA_ERR_UNSUPPORTED;
-    layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
+    (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
     const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
     for (int b = 0; b < batch; ++b) {
         int r = emu::run_wave([&]() { qp_dense_body(P, b); }, lds_bytes, b, batch);

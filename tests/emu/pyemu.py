@@ -46,7 +46,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True)
     cc = _capi.pack_costs(costs, keep)
     kk = _capi.pack_cstrs(cstrs, keep)
     dims = _capi.Dims(nx, nu, N, batch)
-    sizes = (C.c_int * 4)()
+    sizes = (C.c_int * 6)()
     vp = C.c_void_p
     rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, vp(), vp(), vp(), vp(), vp(), vp(), vp(),
                               vp(), -1, vp(), vp(), vp(), vp(), sizes, 0)
@@ -73,7 +73,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True)
                               dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes, 1 if specialised else 0)
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
-    out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3])
+    out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3], overflowed=sizes[4], rcap=sizes[5])
     if dump_instance >= 0:
         out.update(Q=np.array(dQ), c=dc, Aeq=np.array(dA[:neq]), beq=db_[:neq], Aineq=np.array(dA[neq:mgen]),
                    bineq=db_[neq:mgen])

@@ -36,6 +36,7 @@ COPRA_DEV int instance_stride() { return emu::g_wave.ninst; }
 COPRA_DEV void wave_sync() { emu::yield(); }
 COPRA_DEV double* lds_base() { return emu::g_wave.lds; }
 COPRA_DEV long long cycle_counter() { return 0; }
+COPRA_DEV int atomic_append(int* counter) { return (*counter)++; }
 
 COPRA_DEV double emu_xchg_f64(double v, int src)
 {

@@ -166,3 +166,18 @@ def test_host_plan_errors(emu):
     two_bounds = [dict(kind="control_bound", lower=[-1.0], upper=[1.0])] * 2  # TestLMPC.cpp:1084-1086
     with pytest.raises(_capi.CopraRuntimeError):
         emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], [], two_bounds)
+
+
+def test_two_tier_execution_overflow_queue(emu, oracle):
+    """Occupancy design: the first launch uses a compact <= 40 KiB LDS layout whose R holds `rcap` < n active
+    constraints; instances that need more are queued and redone by a second launch with the full layout.  A workload
+    with very tight bounds forces that path; results must still match the oracle (incl. infeasible instances)."""
+    from copra_amd import workloads
+    wl = workloads.com_preview(24, v_max=0.12, u_max=0.8, seed=9)
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    ro = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert re["lds_bytes"] <= 40 * 1024 and re["rcap"] < 60
+    assert re["overflowed"] > 0  # the second tier really ran
+    assert (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
+    ok = ro["status"] == 0
+    assert ok.any() and _rel(re["control"][ok], ro["control"][ok]) <= RTOL

@@ -224,3 +224,18 @@ def test_error_codes_through_the_c_abi():
         BatchLMPC(2, 1, -1, 4, [], [])
     with pytest.raises(CopraRuntimeError):
         BatchLMPC(2, 1, 10, 4, [], [dict(kind="control_bound", lower=[-1.0], upper=[1.0])] * 2)
+
+
+def test_two_tier_overflow_on_gpu(oracle):
+    """very tight bounds: many instances outgrow the compact layout's R and go through the second (full-LDS) launch;
+    some are infeasible.  Everything must still agree with the CPU path."""
+    from copra_amd import workloads
+    wl = workloads.com_preview(1024, v_max=0.12, u_max=0.8, seed=9)
+    eng, res = _solve_gpu(wl, 1024)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert (res["status"] == ref["status"]).all()
+    assert (ref["iter"][:, 0] > 18).any()  # active sets beyond the compact capacity really occur
+    ok = ref["status"] == 0
+    assert ok.any() and (~ok).any()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
+    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
