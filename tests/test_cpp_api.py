@@ -1,0 +1,37 @@
+"""The C++ API mirror (copra_amd/cpp/include/copra/copra.h) compiled with g++ against libcopra_hip.so and driven by
+tests written like the reference's doctest cases (tests/cpp/test_api.cpp)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_api")
+
+
+def _build():
+    from copra_amd import _capi
+    _capi.build_library()
+    src = os.path.join(ROOT, "tests", "cpp", "test_api.cpp")
+    hdr = os.path.join(ROOT, "copra_amd", "cpp", "include", "copra", "copra.h")
+    newest = max(os.path.getmtime(p) for p in (src, hdr, _capi.LIB_PATH))
+    if os.path.exists(EXE) and os.path.getmtime(EXE) >= newest:
+        return
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "copra_amd", "cpp", "include"),
+                           src, "-o", EXE, "-L", libdir, "-lcopra_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_error_handlers_like_TestLMPC():
+    """TestLMPC.cpp:949-1087: std::domain_error / std::runtime_error from system/addCost/addConstraint/weights"""
+    _build()
+    r = subprocess.run([EXE, "errors"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_solve_cases_like_TestLMPC():
+    _build()
+    r = subprocess.run([EXE, "solve"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
