@@ -39,7 +39,7 @@ using fused_kernel_t = void (*)(const FusedPlan);
 // the BASELINE.json shapes get their own instantiation
 fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
-    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax);
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;

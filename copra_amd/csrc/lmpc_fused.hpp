@@ -187,6 +187,94 @@ struct StageRows {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Full-size cost entry (costFunctions.cpp:65-71 TrajectoryCost, :141-146 ControlCost, :197-203 MixedCost):
+//     tmp = M Psi (+ N)   (R x n, dense, no Toeplitz structure),   Q += tmp' W tmp,   c += tmp' W (M xbar - p).
+// This is the dense Psi' W Psi contraction of the reference.  It runs on the matrix cores: four rows of tmp at a
+// time are staged through LDS into the operand layout of v_mfma_f64_16x16x4_f64 (K = 4 cost rows per instruction)
+// and accumulated into the 10 upper 16x16 tiles of Q; the weights ride on the A operand ((tmp' W) tmp as in Eigen).
+// ------------------------------------------------------------------------------------------------
+template <int NX_, int NU_, int NH_>
+COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const double* G, const double* Xbar,
+    double* Q, int ld, double* scratch, double& cj)
+{
+    const int lane = lane_id();
+    const int nx = NX_ ? NX_ : P.nx, nu = NU_ ? NU_ : P.nu, N = NH_ ? NH_ : P.N;
+    const int n = nu * N, X = nx * (N + 1);
+    const int R = ct.rows;
+    const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
+    const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
+    const double* p = P.params + ct.offP;
+    const double* w = P.params + ct.offW;
+    double* We = scratch; // R weighted residuals
+    double* stage = scratch + ((R + 1) & ~1); // 4 x 64 tile of tmp rows
+    // weighted residuals  We_r = (M_r . xbar - p_r) w_r   (ControlCost: -p_r w_r)
+    for (int r = lane; r < R; r += kWave) {
+        double acc = 0.0;
+        if (Mr)
+            for (int col = 0; col < X; ++col) acc += Mr[(size_t)r * X + col] * Xbar[col];
+        We[r] = (acc - p[r]) * w[r];
+    }
+    wave_sync();
+    mfma_acc acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t].v[0] = acc[t].v[1] = acc[t].v[2] = acc[t].v[3] = 0.0;
+    const int jb = lane / nu, jc = lane - jb * nu;
+    const int kk = lane >> 4, col = lane & 15;
+    for (int r0 = 0; r0 < R; r0 += 4) {
+        double y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            double v = 0.0;
+            if (r < R && lane < n) {
+                if (Mr) { // row r of M times column `lane` of Psi: Psi_{s, jb} = G_{s-1-jb} for s > jb
+                    const double* mrow = Mr + (size_t)r * X;
+                    for (int s = jb + 1; s <= N; ++s) {
+                        const double* Gk = G + (s - 1 - jb) * nx * nu + nx * jc;
+                        for (int c = 0; c < nx; ++c) v += mrow[s * nx + c] * Gk[c];
+                    }
+                }
+                if (Nr) v += Nr[(size_t)r * n + lane];
+            }
+            y[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u < R) cj += We[r0 + u] * y[u]; // c += (resid' W) tmp, rows in ascending order
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stage[u * kWave + lane] = y[u];
+        wave_sync();
+        const double wk = (r0 + kk < R) ? w[r0 + kk] : 0.0;
+        double a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = stage[kk * kWave + 16 * t + col]; // tmp(r0 + kk, 16 t + col)
+        int idx = 0;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < 4; ++tj) {
+                mfma_f64_16x16x4(a[ti] * wk, a[tj], acc[idx]); // (tmp' W) tmp
+                ++idx;
+            }
+    }
+    wave_sync();
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < 4; ++tj) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = 16 * ti + kk + 4 * reg, j = 16 * tj + col;
+                if (i < n && j < n) Q[i * ld + j] += acc[idx].v[reg];
+            }
+            ++idx;
+        }
+    wave_sync();
+}
+
 // RP_ > 0: every cost term is padded to RP_ rows (zero M / N / p / w rows add exact zeros), so the inner products
 // over the cost rows unroll; RP_ == 0 uses the run-time row count of each term.
 template <int NX_, int NU_, int NH_, int RP_>
@@ -319,6 +407,13 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         const int blk = lane / nu, sub = lane - blk * nu; // lane as (block, component)
         for (int t = 0; t < P.ncost; ++t) {
             const CostTerm& ct = P.cost[t];
+            if constexpr (RP_ == 0) { // plans with full-size entries always run the generic instantiation (plan.hpp)
+                if (ct.full) {
+                    wave_sync();
+                    full_size_cost_term<NX_, NU_, NH_>(P, ct, G, Xbar, Q, ld, lds + L.BldFull, cj);
+                    continue;
+                }
+            }
             const int rc = ct.rows; // rows of this term as given
             const int r = RP_ ? RP_ : rc; // rows it is processed with (zero padded)
             wave_sync();

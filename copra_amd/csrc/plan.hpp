@@ -39,8 +39,9 @@ enum {
 // Shapes that get their own compile-time instantiation of the fused kernel (the BASELINE.json configs).  Returns the
 // padded cost-row count RP of the specialisation, or 0 when (nx, nu, N, rmax) runs on the generic instantiation.
 // Used by the plan builder (LDS sizing), the HIP launcher and the CPU emulator so that all three agree.
-inline int specialised_cost_rows(int nx, int nu, int N, int rmax)
+inline int specialised_cost_rows(int nx, int nu, int N, int rmax, int rfull = 0)
 {
+    if (rfull > 0) return 0; // full-size cost entries run on the generic instantiation
     if (nx == 6 && nu == 3 && N == 20 && rmax <= 6) return 6;
     if (nx == 2 && nu == 1 && N == 10 && rmax <= 2) return 2;
     return 0;
@@ -49,10 +50,11 @@ inline int specialised_cost_rows(int nx, int nu, int N, int rmax)
 struct CostTerm {
     int kind;
     int rows; // r
-    int offM; // r x nx   (column-major)  or -1
-    int offN; // r x nu                   or -1
+    int offM; // per-step: r x nx column-major; full-size: r x fullXDim ROW-major (one contiguous row per cost row); or -1
+    int offN; // per-step: r x nu column-major; full-size: r x fullUDim ROW-major; or -1
     int offP; // r
     int offW; // r
+    int full; // 1: full-size entry (costFunctions.cpp:65-71, 141-146, 197-203) -> dense MFMA contraction
 };
 
 // LDS carve-up, offsets in doubles from the dynamic-LDS base (all multiples of 2 doubles = 16 bytes)
@@ -76,6 +78,7 @@ struct LdsLayout {
     int BldY; // N blocks r x nu   (M G_k)
     int BldWe; // (N+1) blocks r    (w .* (M xbar_k - p))
     int BldCp; // parameters of the cost being processed: M (r x nx) | N (r x nu) | p (r) | w (r)
+    int BldFull; // full-size costs: weighted residuals (rfull) | 4 x 64 staging tile of Y rows for the MFMA operands
     int total; // total doubles
 };
 
@@ -86,7 +89,8 @@ struct FusedPlan {
     // costs
     int ncost;
     CostTerm cost[kMaxCosts];
-    int rmax; // max rows over the stage costs
+    int rmax; // max rows over the per-step costs
+    int rfull; // max rows over the full-size costs (0 if none)
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)

@@ -51,7 +51,7 @@ inline int align2(int v) { return (v + 1) & ~1; }
 //                     tables (Y, We, cost parameters) borrow the not-yet-used solver vectors, and R gets whatever is
 //                     left of `budget` doubles (at least 1 column).  Returns false if even that does not fit.
 inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused, bool compact = false, int budget = 0)
+    bool fused, bool compact = false, int budget = 0, int rfull = 0)
 {
     int o = 0;
     auto take = [&](int count) {
@@ -62,7 +62,9 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     L.ldj = (n % 2 == 0) ? n + 1 : n; // odd leading dimension: row-per-lane and column-per-lane reads conflict-free
     const int sizeJ = align2(n * L.ldj);
     const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
-    const int sizeCost = fused ? align2(N * rmax * nu) + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) : 0;
+    const int sizeFull = rfull > 0 ? align2(rfull) + 4 * kWave : 0;
+    const int sizeCost
+        = fused ? align2(N * rmax * nu) + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) + sizeFull : 0;
     if (fused) {
         L.G = take(N * nx * nu);
         L.Xbar = take(X);
@@ -106,9 +108,10 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
         int q = cost0;
         L.BldY = q, q += align2(N * rmax * nu);
         L.BldWe = q, q += align2((N + 1) * rmax);
-        L.BldCp = q;
+        L.BldCp = q, q += align2(rmax * (nx + nu + 2));
+        L.BldFull = q;
     } else {
-        L.BldY = L.BldWe = L.BldCp = 0;
+        L.BldY = L.BldWe = L.BldCp = L.BldFull = 0;
     }
     // R: n columns, or what the budget leaves
     int rcap = n;
@@ -158,6 +161,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     // ---------------- costs ----------------
     P.ncost = n_costs;
     P.rmax = 1;
+    P.rfull = 0;
     for (int k = 0; k < n_costs; ++k) {
         const copra_cost_desc_t& c = costs[k];
         CostTerm& t = P.cost[k];
@@ -204,15 +208,25 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         default:
             return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
         }
+        t.full = full ? 1 : 0;
         if (full) {
-            hp.error = "full-size cost entries are not yet covered by the fused HIP path";
-            return COPRA_ERR_UNSUPPORTED;
+            // full-size entry: keep M (rows x fullXDim) and N (rows x fullUDim) ROW-major, one contiguous row per cost row
+            auto push_rowmajor = [&](const double* Mx, int rows, int cols) {
+                std::vector<double> tmp((size_t)rows * cols);
+                for (int i = 0; i < rows; ++i)
+                    for (int j = 0; j < cols; ++j) tmp[(size_t)i * cols + j] = Mx[(size_t)j * rows + i];
+                return push(tmp.data(), rows * cols);
+            };
+            if (c.kind != COPRA_COST_CONTROL) t.offM = push_rowmajor(c.M, c.rows, X);
+            if (c.kind != COPRA_COST_TRAJECTORY) t.offN = push_rowmajor(c.N, c.rows, U);
+            if (c.rows > P.rfull) P.rfull = c.rows;
+        } else {
+            if (c.kind != COPRA_COST_CONTROL) t.offM = push(c.M, c.rows * nx);
+            if (c.kind == COPRA_COST_CONTROL || c.kind == COPRA_COST_MIXED) t.offN = push(c.N, c.rows * nu);
+            if (c.rows > P.rmax) P.rmax = c.rows;
         }
-        if (c.kind != COPRA_COST_CONTROL) t.offM = push(c.M, c.rows * nx);
-        if (c.kind == COPRA_COST_CONTROL || c.kind == COPRA_COST_MIXED) t.offN = push(c.N, c.rows * nu);
         t.offP = push(c.p, c.rows);
         t.offW = push(c.weights, c.rows);
-        if (c.rows > P.rmax) P.rmax = c.rows;
     }
 
     // ---------------- constraints: two passes (equalities first, then inequalities) ----------------
@@ -367,9 +381,9 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         return COPRA_ERR_UNSUPPORTED;
     }
     {
-        const int rp = specialised_cost_rows(nx, nu, N, P.rmax); // the specialised kernels pad every cost to rp rows
+        const int rp = specialised_cost_rows(nx, nu, N, P.rmax, P.rfull); // the specialised kernels pad every cost to rp rows
         const int rows = rp > P.rmax ? rp : P.rmax;
-        layout_lds(hp.lds_full, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true);
+        layout_lds(hp.lds_full, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, false, 0, P.rfull);
         hp.lds_full_bytes = (size_t)hp.lds_full.total * sizeof(double);
         if (hp.lds_full_bytes > 160u * 1024u) {
             hp.error = "problem does not fit the 160 KiB LDS of one CU";
@@ -382,7 +396,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.two_tier = false;
         P.lds = hp.lds_full;
         if (hp.lds_full.total > quarter
-            && layout_lds(compact, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, quarter)
+            && layout_lds(compact, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, quarter, P.rfull)
             && compact.total <= quarter && compact.rcap >= 8 && compact.rcap < U) {
             hp.two_tier = true;
             P.lds = compact;

@@ -61,6 +61,23 @@ COPRA_DEV double fast_rsqrt(double x)
     return y;
 }
 
+// D = A(16x4) * B(4x16) + C on the matrix cores, FP64 (v_mfma_f64_16x16x4_f64).  Operand layout (one double per
+// lane): A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15];  C/D: four doubles per lane,
+// element `reg` is D[row = (lane >> 4) + 4 * reg][col = lane & 15]  (the f64 map, NOT the f32 one).
+struct mfma_acc {
+    double v[4];
+};
+COPRA_DEV void mfma_f64_16x16x4(double a, double b, mfma_acc& c)
+{
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    v4f64 cc = { c.v[0], c.v[1], c.v[2], c.v[3] };
+    cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cc, 0, 0, 0);
+    c.v[0] = cc[0];
+    c.v[1] = cc[1];
+    c.v[2] = cc[2];
+    c.v[3] = cc[3];
+}
+
 // make a wave-uniform value provably uniform (SGPR) so that table look-ups become scalar loads
 COPRA_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -16,6 +16,7 @@
 namespace copra_hip {
 namespace emu {
     WaveState g_wave;
+    double g_mfma_a[64], g_mfma_b[64];
     static ucontext_t g_sched;
     static ucontext_t g_fiber[64];
     static bool g_done[64];
@@ -121,7 +122,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     }
     if (!A) return 0; // size query only
     // same dispatch as the HIP launcher (select_fused_kernel): compile-time shapes for the BASELINE configs
-    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax);
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const bool s6 = use_specialised && P.nx == 6 && rp == 6;
     const bool s2 = use_specialised && P.nx == 2 && rp == 2;
     // two-tier execution exactly as copra_batch_solve does it: compact layout first, overflow queue, full layout

@@ -77,6 +77,29 @@ COPRA_DEV double bcast_f64(double v, int src) { return emu_xchg_f64(v, src); }
 COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 COPRA_DEV int uniform_i32(int v) { return v; }
+
+// v_mfma_f64_16x16x4_f64 stand-in with the same operand / result layout as the hardware instruction
+struct mfma_acc {
+    double v[4];
+};
+namespace emu {
+    extern double g_mfma_a[64], g_mfma_b[64];
+}
+COPRA_DEV void mfma_f64_16x16x4(double a, double b, mfma_acc& c)
+{
+    const int l = emu::g_wave.lane;
+    emu::g_mfma_a[l] = a; // A[i = l & 15][k = l >> 4]
+    emu::g_mfma_b[l] = b; // B[k = l >> 4][j = l & 15]
+    emu::yield();
+    const int j = l & 15;
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = (l >> 4) + 4 * reg;
+        double acc = c.v[reg];
+        for (int k = 0; k < 4; ++k) acc += emu::g_mfma_a[i + 16 * k] * emu::g_mfma_b[j + 16 * k];
+        c.v[reg] = acc;
+    }
+    emu::yield();
+}
 COPRA_DEV void wave_argmin(double& key, int& idx, double& payload)
 {
     for (int m = 32; m >= 1; m >>= 1) {

@@ -90,10 +90,11 @@ def test_reference_fixtures_short_horizon(emu, oracle, system, xcost):
         assert _rel(re["trajectory"][0], ro["trajectory"]) <= RTOL
 
 
-@pytest.mark.parametrize("full_size", [False])
+@pytest.mark.parametrize("full_size", [False, True])
 def test_all_nine_classes_at_once(emu, oracle, full_size):
-    """tests/TestLMPC_InitialState.cpp:29-130 problem (per-step entries): four cost classes + five constraint
-    classes in one controller"""
+    """tests/TestLMPC_InitialState.cpp:29-130 problem: four cost classes + five constraint classes in one controller,
+    with per-step entries and with the full-size entries autoSpan() produces (the latter go through the dense MFMA
+    Psi' W Psi contraction)"""
     pb = F.initial_state_problem(full_size)
     _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
 
@@ -181,3 +182,20 @@ def test_two_tier_execution_overflow_queue(emu, oracle):
     assert (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
     ok = ro["status"] == 0
     assert ok.any() and _rel(re["control"][ok], ro["control"][ok]) <= RTOL
+
+
+def test_dense_mfma_hessian_equals_structured_path(emu, oracle):
+    """The headline TrajectoryCost handed over as a full-size entry (M = blockdiag, 126 x 126) must give the same QP
+    as the per-step entry: dense v_mfma_f64_16x16x4 contraction vs block-diagonal prefix sums vs the oracle."""
+    from copra_amd import workloads
+    from copra_amd.autospan import autospan_cost
+    wl = workloads.com_preview(3)
+    dense = [autospan_cost(dict(wl["costs"][0], p=np.tile(wl["costs"][0]["p"], 21))), wl["costs"][1]]
+    rd = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], dense, wl["cstrs"], dump_instance=1)
+    rs = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], dump_instance=1)
+    qp = oracle.lmpc_build(wl["A"][1], wl["B"][1], wl["d"][1], wl["x0"][1], wl["N"], dense, wl["cstrs"])
+    scale = np.abs(qp["Q"]).max()
+    assert np.abs(rd["Q"] - qp["Q"]).max() <= 1e-12 * scale
+    assert np.abs(rd["Q"] - rs["Q"]).max() <= 1e-12 * scale
+    assert np.abs(rd["c"] - qp["c"]).max() <= 1e-11 * max(1.0, np.abs(qp["c"]).max())
+    assert _rel(rd["control"], rs["control"]) <= 1e-9

@@ -239,3 +239,38 @@ def test_two_tier_overflow_on_gpu(oracle):
     assert ok.any() and (~ok).any()
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
     assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+
+
+def test_full_size_cost_entries_mfma_contraction(oracle):
+    """Full-size cost entries (costFunctions.cpp:65-71,141-146,197-203) run the dense Psi' W Psi contraction on
+    v_mfma_f64_16x16x4_f64: (a) all nine classes with autoSpan'ed full-size entries (TestLMPC_InitialState.cpp,
+    fullSizeEntry = true), (b) the headline cost as a 126 x 126 full-size entry vs the structured path."""
+    import fixtures as F
+    from copra_amd import BatchLMPC, workloads
+    from copra_amd.autospan import autospan_cost
+    pb = F.initial_state_problem(True)
+    eng = BatchLMPC(2, 1, pb["N"], 1, pb["costs"], pb["cstrs"])
+    eng.set_system(pb["A"][None], pb["B"][None], pb["d"][None], pb["x0"][None])
+    eng.solve()
+    res = eng.results()
+    ref = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert res["status"][0] == ref["status"] == 0
+    assert _rel(res["control"][0], ref["control"]) <= RTOL
+    qp = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    got = eng.dump_qp(0)
+    assert np.abs(got["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+    assert np.abs(got["c"] - qp["c"]).max() <= 1e-12 * np.abs(qp["c"]).max()
+
+    b = 512
+    wl = workloads.com_preview(b)
+    dense = [autospan_cost(dict(wl["costs"][0], p=np.tile(wl["costs"][0]["p"], 21))), wl["costs"][1]]
+    e1 = BatchLMPC(6, 3, 20, b, dense, wl["cstrs"])
+    e1.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    e1.solve()
+    r1 = e1.results()
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], 20, wl["costs"], wl["cstrs"], nthreads=8)
+    assert (r1["status"] == ref["status"]).all()
+    assert _rel(r1["control"], ref["control"]) <= RTOL
+    got = e1.dump_qp(5)
+    qp = oracle.lmpc_build(wl["A"][5], wl["B"][5], wl["d"][5], wl["x0"][5], 20, wl["costs"], wl["cstrs"])
+    assert np.abs(got["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
