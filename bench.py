@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-hessian", action="store_true",
+                    help="hand the TrajectoryCost over as a full-size entry (126x126 M): the Hessian is then built by "
+                         "the dense v_mfma_f64_16x16x4 Psi'WPsi contraction instead of the block-diagonal prefix sums")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     args = ap.parse_args()
 
@@ -68,6 +71,10 @@ def main():
     n, X = nu * N, nx * (N + 1)
     # weak scaling: every rank owns `batch` instances; seeds differ per rank (rank 0 == BASELINE config 3, seed 1)
     wl = workloads.com_preview(batch, N=N, seed=1 + rank)
+    if args.dense_hessian:
+        from copra_amd.autospan import autospan_cost
+        c0 = wl["costs"][0]
+        wl["costs"] = [autospan_cost(dict(c0, p=np.tile(c0["p"], N + 1))), wl["costs"][1]]
     Ab, Bb, db, xb = to_abi_layout(wl["A"], wl["B"], wl["d"], wl["x0"])
     tA, tB = torch.from_numpy(Ab).to(dev), torch.from_numpy(Bb).to(dev)
     td, tx0 = torch.from_numpy(db).to(dev), torch.from_numpy(xb).to(dev)
@@ -142,6 +149,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "CoM preview LMPC nx=6 nu=3 N=20, TrajectoryCost+ControlCost, "
                                    "TrajectoryBound(63 rows)+ControlBound (BASELINE configs[2])",
+                       "hessian": "dense MFMA f64 contraction (full-size cost entry)" if args.dense_hessian
+                       else "block-diagonal prefix sums (per-step cost entry)",
                        "batch_per_gpu": batch, "global_batch": batch * world, "nvar": n, "ineq_rows": 63,
                        "bound_rows": 2 * n, "parallelism": "batch-shard x%d + 1 RCCL gather/step" % world
                        if world > 1 else "single GPU"},

@@ -40,6 +40,7 @@ struct StageRows {
     double* Xcur; // LDS
     const double* nb; // LDS
     RowDesc mine; // descriptor of row `lane` (rows 0..63 are scanned as i == lane): no table look-ups in the loop
+    double ub_mine, lb_mine; // XU_lane, XL_lane
 
     COPRA_DEV int nx() const { return NX_ ? NX_ : P.nx; }
     COPRA_DEV int nu() const { return NU_ ? NU_ : P.nu; }
@@ -65,6 +66,9 @@ struct StageRows {
             mine = load_desc(i);
         else
             mine = RowDesc { 0, kENone, 0, kGNone, 0, 0.0 };
+        const int j = (i < nvar()) ? i : nvar() - 1;
+        ub_mine = P.ub[j];
+        lb_mine = P.lb[j];
     }
     COPRA_DEV RowDesc desc(int i) const { return (i < kWave) ? mine : load_desc(i); }
 
@@ -174,8 +178,8 @@ struct StageRows {
     }
 
     COPRA_DEV double norm(int i) const { return nb[i]; }
-    COPRA_DEV double ub(int j) const { return P.ub[j]; }
-    COPRA_DEV double lb(int j) const { return P.lb[j]; }
+    COPRA_DEV double ub(int) const { return ub_mine; } // asked for j == min(lane, n-1) only
+    COPRA_DEV double lb(int) const { return lb_mine; }
 
     COPRA_DEV void load_normal(int p, double sgn, double* ap) const
     {
@@ -300,6 +304,10 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     long long stamp[8];
     COPRA_FINE_DECL;
     stamp[0] = cycle_counter();
+    // plan look-ups this lane needs much later (its constraint row, its bounds): issue the global loads now so that
+    // their latency hides under the preview / cost phases
+    StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
+    rows.cache_own_row();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];
     for (int e = lane; e < nx * nu; e += kWave) B[e] = P.B[(size_t)inst * nx * nu + e];
@@ -596,8 +604,6 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     }
     stamp[2] = cycle_counter();
     // ---- 3. implicit rows: norms (qpgen2: column norms of amat) ----
-    StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {} };
-    rows.cache_own_row();
     for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(rows.desc(i)));
     if (inst == P.dump_instance && P.dumpA) { // parity hook (LMPC::Aeq/beq/Aineq/bineq; LMPC.h:116-123)
         for (int i = lane; i < P.mgen; i += kWave) {
