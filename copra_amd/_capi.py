@@ -34,6 +34,10 @@ class Dims(C.Structure):
     _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int), ("batch", C.c_int)]
 
 
+class InitialStateDesc(C.Structure):
+    _fields_ = [("R", _dp), ("r", _dp)]
+
+
 class CopraDomainError(ValueError):
     """std::domain_error of the reference (include/debugUtils.h:32-36)"""
 
@@ -164,6 +168,13 @@ def lib():
         L.copra_batch_create.restype = C.c_int
         L.copra_batch_create.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc), C.c_int,
                                          C.POINTER(CstrDesc)]
+        L.copra_batch_create_initial_state.restype = C.c_int
+        L.copra_batch_create_initial_state.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc),
+                                                       C.c_int, C.POINTER(CstrDesc), C.POINTER(InitialStateDesc)]
+        L.copra_batch_set_initial_state_bounds.restype = C.c_int
+        L.copra_batch_set_initial_state_bounds.argtypes = [vp, vp, vp, C.c_int]
+        L.copra_batch_get_initial_state.restype = C.c_int
+        L.copra_batch_get_initial_state.argtypes = [vp, vp]
         L.copra_batch_destroy.restype = None
         L.copra_batch_destroy.argtypes = [vp]
         L.copra_batch_set_system.restype = C.c_int

@@ -29,7 +29,9 @@ def _is_torch(t):
 
 
 class BatchLMPC:
-    def __init__(self, nx, nu, N, batch, costs, cstrs):
+    def __init__(self, nx, nu, N, batch, costs, cstrs, initial_state=None):
+        """initial_state = dict(R=(nx,nx), r=(nx,)) turns the controller into a batched InitialStateLMPC
+        (include/InitialStateLMPC.h): decision vector [x0; U], see set_initial_state_bounds / initial_state."""
         self._lib = _capi.lib()
         self.nx, self.nu, self.N, self.batch = int(nx), int(nu), int(N), int(batch)
         self.n = self.nu * self.N
@@ -39,7 +41,15 @@ class BatchLMPC:
         kk = _capi.pack_cstrs(cstrs, self._keep)
         dims = _capi.Dims(self.nx, self.nu, self.N, self.batch)
         self._h = C.c_void_p()
-        _capi.check(self._lib.copra_batch_create(C.byref(self._h), C.byref(dims), len(costs), cc, len(cstrs), kk))
+        self.is_initial_state = initial_state is not None
+        if self.is_initial_state:
+            Rm, rv = _capi.fcol(initial_state["R"]), _capi.fcol(initial_state["r"])
+            self._keep.extend([Rm, rv])
+            isd = _capi.InitialStateDesc(_capi.dptr(Rm), _capi.dptr(rv))
+            _capi.check(self._lib.copra_batch_create_initial_state(C.byref(self._h), C.byref(dims), len(costs), cc,
+                                                                   len(cstrs), kk, C.byref(isd)))
+        else:
+            _capi.check(self._lib.copra_batch_create(C.byref(self._h), C.byref(dims), len(costs), cc, len(cstrs), kk))
         self._sys = None
         self._outs = None
 
@@ -77,6 +87,18 @@ class BatchLMPC:
         else:
             xb = np.ascontiguousarray(x0, dtype=np.float64)
             _capi.check(self._lib.copra_batch_set_x0(self._h, xb.ctypes.data, 0))
+
+    # InitialStateLMPC::resetInitialStateBounds, per instance
+    def set_initial_state_bounds(self, x0lb, x0ub):
+        lo = np.ascontiguousarray(np.broadcast_to(x0lb, (self.batch, self.nx)), dtype=np.float64)
+        up = np.ascontiguousarray(np.broadcast_to(x0ub, (self.batch, self.nx)), dtype=np.float64)
+        _capi.check(self._lib.copra_batch_set_initial_state_bounds(self._h, lo.ctypes.data, up.ctypes.data, 0))
+
+    # InitialStateLMPC::initialState()
+    def initial_state(self):
+        out = np.empty((self.batch, self.nx))
+        _capi.check(self._lib.copra_batch_get_initial_state(self._h, out.ctypes.data))
+        return out
 
     def set_outputs(self, control, trajectory, status, iters):
         """torch CUDA tensors (float64 [b,n], float64 [b,X], int32 [b], int32 [b,2]) that receive the results"""

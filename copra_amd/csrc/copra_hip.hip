@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/copra_hip.h"
+#include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
 #include "plan_builder.hpp"
 #include "qp_dense.hpp"
@@ -45,6 +46,11 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;
 }
 } // namespace
+
+__global__ __launch_bounds__(64) void copra_islmpc_fused_kernel(const FusedPlan P)
+{
+    islmpc_fused_body(P, P.inst_offset + (int)blockIdx.x);
+}
 
 __global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
 
@@ -95,6 +101,9 @@ struct copra_batch {
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
     int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
+    // InitialStateLMPC variant
+    double *d_isR = nullptr, *d_isr = nullptr, *d_x0opt = nullptr, *own_x0lb = nullptr, *own_x0ub = nullptr;
+    const double *x0lb = nullptr, *x0ub = nullptr;
     long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -129,6 +138,11 @@ static FusedPlan device_plan(const copra_batch* h)
     P.dumpQ = P.dumpc = P.dumpA = P.dumpb = nullptr;
     P.prof = h->d_prof;
     P.prof_fine = h->d_prof_fine;
+    P.is_R = h->d_isR;
+    P.is_r = h->d_isr;
+    P.x0lb = h->x0lb;
+    P.x0ub = h->x0ub;
+    P.x0_opt = h->d_x0opt;
     P.ovf_count = h->d_ovf_count;
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
@@ -139,8 +153,9 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
 {
     const size_t need = h->hp.lds_full_bytes > h->hp.lds_bytes ? h->hp.lds_full_bytes : h->hp.lds_bytes;
     if (!h->lds_attr_set && need > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_fused_kernel(h->hp.plan)),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+        const void* fn = h->hp.plan.initial_state ? reinterpret_cast<const void*>(copra_islmpc_fused_kernel)
+                                                  : reinterpret_cast<const void*>(select_fused_kernel(h->hp.plan));
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     h->lds_attr_set = true;
     return COPRA_OK;
@@ -171,14 +186,30 @@ copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name,
     return COPRA_OK;
 }
 
+static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is);
+
 copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs)
+{
+    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, nullptr);
+}
+
+copra_status_t copra_batch_create_initial_state(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
+{
+    if (!is) return fail(COPRA_ERR_ARG, "copra_batch_create_initial_state: null descriptor");
+    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, is);
+}
+
+static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
 {
     if (!out || !dims || n_costs < 0 || n_cstrs < 0 || (n_costs > 0 && !costs) || (n_cstrs > 0 && !cstrs))
         return fail(COPRA_ERR_ARG, "copra_batch_create: null / negative argument");
     *out = nullptr;
     copra_batch* h = new copra_batch();
-    copra_status_t rc = build_plan(h->hp, *dims, n_costs, costs, n_cstrs, cstrs);
+    copra_status_t rc = build_plan(h->hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) {
         g_err = h->hp.error;
         delete h;
@@ -203,6 +234,11 @@ copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims,
     chk(hipMalloc((void**)&h->d_traj, b * P.X * sizeof(double)));
     chk(hipMalloc((void**)&h->d_status, b * sizeof(int)));
     chk(hipMalloc((void**)&h->d_iter, b * 2 * sizeof(int)));
+    if (is) {
+        chk(upload(&h->d_isR, h->hp.isR));
+        chk(upload(&h->d_isr, h->hp.isr));
+        chk(hipMalloc((void**)&h->d_x0opt, b * P.nx * sizeof(double)));
+    }
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
@@ -237,6 +273,11 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_iter);
     (void)hipFree(h->d_prof);
+    (void)hipFree(h->d_isR);
+    (void)hipFree(h->d_isr);
+    (void)hipFree(h->d_x0opt);
+    (void)hipFree(h->own_x0lb);
+    (void)hipFree(h->own_x0ub);
     (void)hipFree(h->d_ovf_count);
     (void)hipFree(h->d_ovf_list);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -313,6 +354,13 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
+    if (P.initial_state) {
+        hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+        return COPRA_OK;
+    }
     if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
     hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
     HIP_TRY(hipGetLastError());
@@ -367,10 +415,41 @@ copra_status_t copra_batch_get_results(copra_batch_t* h, double* control, double
     return COPRA_OK;
 }
 
+copra_status_t copra_batch_set_initial_state_bounds(copra_batch_t* h, const double* x0lb, const double* x0ub,
+    int on_device)
+{
+    if (!h || !x0lb || !x0ub) return fail(COPRA_ERR_ARG, "copra_batch_set_initial_state_bounds: null argument");
+    if (!h->hp.plan.initial_state) return fail(COPRA_ERR_RUNTIME, "not an InitialStateLMPC controller");
+    const size_t nd = (size_t)h->hp.plan.batch * h->hp.plan.nx;
+    if (on_device) {
+        h->x0lb = x0lb;
+        h->x0ub = x0ub;
+        return COPRA_OK;
+    }
+    if (!h->own_x0lb) {
+        HIP_TRY(hipMalloc((void**)&h->own_x0lb, (nd ? nd : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->own_x0ub, (nd ? nd : 1) * sizeof(double)));
+    }
+    HIP_TRY(hipMemcpy(h->own_x0lb, x0lb, nd * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->own_x0ub, x0ub, nd * sizeof(double), hipMemcpyHostToDevice));
+    h->x0lb = h->own_x0lb;
+    h->x0ub = h->own_x0ub;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_get_initial_state(copra_batch_t* h, double* x0_opt)
+{
+    if (!h || !x0_opt) return fail(COPRA_ERR_ARG, "copra_batch_get_initial_state: null argument");
+    if (!h->hp.plan.initial_state) return fail(COPRA_ERR_RUNTIME, "not an InitialStateLMPC controller");
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(x0_opt, h->d_x0opt, (size_t)h->hp.plan.batch * h->hp.plan.nx * sizeof(double), hipMemcpyDeviceToHost));
+    return COPRA_OK;
+}
+
 copra_status_t copra_batch_qp_sizes(const copra_batch_t* h, int* nvar, int* neq, int* nineq)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_qp_sizes: null handle");
-    if (nvar) *nvar = h->hp.plan.n;
+    if (nvar) *nvar = h->hp.plan.initial_state ? h->hp.plan.nx + h->hp.plan.n : h->hp.plan.n;
     if (neq) *neq = h->hp.plan.meq;
     if (nineq) *nineq = h->hp.plan.mineq;
     return COPRA_OK;
@@ -383,7 +462,7 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     const FusedPlan& HP = h->hp.plan;
     if (instance < 0 || instance >= HP.batch) return fail(COPRA_ERR_ARG, "copra_batch_dump_qp: bad instance");
     if (!h->A) return fail(COPRA_ERR_RUNTIME, "copra_batch_dump_qp: no preview system set");
-    const int n = HP.n, mg = HP.mgen;
+    const int n = HP.initial_state ? HP.nx + HP.n : HP.n, mg = HP.mgen;
     double *dQ = nullptr, *dc = nullptr, *dA = nullptr, *db = nullptr;
     HIP_TRY(hipMalloc((void**)&dQ, (size_t)n * n * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&dc, (size_t)n * sizeof(double)));
@@ -400,7 +479,10 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     P.lds = h->hp.lds_full;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
+    if (P.initial_state)
+        hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
+    else
+        hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     std::vector<double> hA((size_t)(mg ? mg : 1) * n), hb((size_t)(mg ? mg : 1));
@@ -419,8 +501,18 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
         if (beq) beq[i] = hb[(size_t)i];
     for (int i = 0; i < HP.mineq; ++i)
         if (bineq) bineq[i] = hb[(size_t)HP.meq + i];
-    if (lb) memcpy(lb, h->hp.lb.data(), (size_t)n * sizeof(double));
-    if (ub) memcpy(ub, h->hp.ub.data(), (size_t)n * sizeof(double));
+    { // bounds of the decision vector: [x0lb; lb], [x0ub; ub] for the InitialStateLMPC variant
+        const int off = HP.initial_state ? HP.nx : 0;
+        std::vector<double> l0((size_t)(off ? off : 1)), u0((size_t)(off ? off : 1));
+        if (off) {
+            HIP_TRY(hipMemcpy(l0.data(), (h->x0lb ? h->x0lb : h->x0) + (size_t)instance * off, off * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(u0.data(), (h->x0ub ? h->x0ub : h->x0) + (size_t)instance * off, off * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        for (int i = 0; i < n; ++i) {
+            if (lb) lb[i] = (i < off) ? l0[(size_t)i] : h->hp.lb[(size_t)(i - off)];
+            if (ub) ub[i] = (i < off) ? u0[(size_t)i] : h->hp.ub[(size_t)(i - off)];
+        }
+    }
     (void)hipFree(dQ);
     (void)hipFree(dc);
     (void)hipFree(dA);

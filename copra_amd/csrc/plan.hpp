@@ -82,6 +82,13 @@ struct LdsLayout {
     int total; // total doubles
 };
 
+// extra LDS regions of the InitialStateLMPC variant (islmpc_fused.hpp)
+struct IsLayout {
+    int Jq, ldq; // n x ldq: Hessian of the U block -> its Cholesky factor -> inverse factor
+    int E; // nx x n: top-right block of the Hessian
+    int MPhi; // (N+1) blocks r x nx
+};
+
 struct FusedPlan {
     // dimensions
     int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
@@ -115,6 +122,14 @@ struct FusedPlan {
     double* trajectory; // [batch][X]
     int* status; // [batch]
     int* iter; // [batch][2]
+    // InitialStateLMPC variant (include/InitialStateLMPC.h): decision vector [x0; U]
+    int initial_state; // 0: LMPC, 1: InitialStateLMPC
+    const double* is_R; // nx x nx  (resetInitialStateCost, InitialStateLMPC.cpp:35-40)
+    const double* is_r; // nx
+    const double* x0lb; // [batch][nx] or nullptr = ps->x0 (InitialStateLMPC.cpp:20-28, 42-46)
+    const double* x0ub;
+    double* x0_opt; // [batch][nx]  (InitialStateLMPC::initialState())
+    IsLayout isl;
     int inst_offset; // instance handled by workgroup 0 (normally 0)
     // optional parity dump (dump_instance >= 0): the dense QP of ONE instance written by the condense code
     int dump_instance;

@@ -22,6 +22,7 @@ struct HostPlan {
     std::vector<int> row_step, row_ekind, row_eoff, row_gkind, row_goff;
     std::vector<double> row_f;
     std::vector<double> lb, ub;
+    std::vector<double> isR, isr; // InitialStateLMPC: R (nx x nx), r (nx)
     std::string error;
     size_t lds_bytes = 0; // of plan.lds (the layout of the first launch)
     // two-tier execution: plan.lds is the compact layout (4 waves per CU) when it fits, lds_full the always-sufficient
@@ -131,7 +132,7 @@ inline bool is_neg_inf(double v) { return std::isinf(v) && v < 0; }
 inline bool is_pos_inf(double v) { return std::isinf(v) && v > 0; }
 
 inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_costs, const copra_cost_desc_t* costs,
-    int n_cstrs, const copra_cstr_desc_t* cstrs)
+    int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is = nullptr)
 {
     FusedPlan& P = hp.plan;
     const int nx = dims.nx, nu = dims.nu, N = dims.N;
@@ -147,6 +148,12 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     P.X = X;
     P.batch = dims.batch;
     P.dump_instance = -1;
+    P.initial_state = is ? 1 : 0;
+    if (is) {
+        if (!is->R || !is->r) return hp.error = "InitialStateLMPC: R / r missing", COPRA_ERR_DOMAIN;
+        hp.isR.assign(is->R, is->R + (size_t)nx * nx);
+        hp.isr.assign(is->r, is->r + nx);
+    }
     if (n_costs > kMaxCosts) {
         hp.error = "too many cost functions for the fused kernel";
         return COPRA_ERR_UNSUPPORTED;
@@ -209,6 +216,10 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
         }
         t.full = full ? 1 : 0;
+        if (full && is) {
+            hp.error = "InitialStateLMPC with full-size cost entries is not covered by the HIP path yet";
+            return COPRA_ERR_UNSUPPORTED;
+        }
         if (full) {
             // full-size entry: keep M (rows x fullXDim) and N (rows x fullUDim) ROW-major, one contiguous row per cost row
             auto push_rowmajor = [&](const double* Mx, int rows, int cols) {
@@ -365,16 +376,34 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         }
     }
     P.mgen = P.meq + P.mineq;
-    P.mtotal = P.mgen + 2 * U; // QuadProgSolver.cpp:51
+    const int nvar = is ? nx + U : U; // InitialStateLMPC optimises [x0; U] (InitialStateLMPC.cpp:52-75)
+    P.mtotal = P.mgen + 2 * nvar; // QuadProgSolver.cpp:51
     if (hp.params.empty()) hp.params.assign(2, 0.0);
 
     P.vsmall = qpgen2_vsmall();
-    P.max_iter = 50 * (U + P.mtotal) + 100;
+    P.max_iter = 50 * (nvar + P.mtotal) + 100;
 
     // fused-kernel limits
-    if (U > kWave) {
-        hp.error = "fullUDim > 64 is not covered by the one-wave fused kernel";
+    if (nvar > kWave) {
+        hp.error = "more than 64 decision variables are not covered by the one-wave fused kernel";
         return COPRA_ERR_UNSUPPORTED;
+    }
+    if (is) {
+        if (nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;
+        layout_lds(hp.lds_full, nx, nu, N, nvar, X, P.rmax, P.mgen, P.meq, P.mtotal, true);
+        LdsLayout& L = hp.lds_full;
+        int o = L.total;
+        P.isl.ldq = (U % 2 == 0) ? U + 1 : U;
+        P.isl.Jq = o, o += align2(U * P.isl.ldq);
+        P.isl.E = o, o += align2(nx * U);
+        P.isl.MPhi = o, o += align2((N + 1) * P.rmax * nx);
+        L.total = o;
+        hp.lds_full_bytes = (size_t)o * sizeof(double);
+        if (hp.lds_full_bytes > 160u * 1024u) return hp.error = "problem does not fit the 160 KiB LDS of one CU", COPRA_ERR_UNSUPPORTED;
+        hp.two_tier = false;
+        P.lds = hp.lds_full;
+        hp.lds_bytes = hp.lds_full_bytes;
+        return COPRA_OK;
     }
     if (nu > kMaxNu) {
         hp.error = "uDim > 8 is not covered by the one-wave fused kernel";
@@ -419,6 +448,8 @@ inline void point_plan_to_host(HostPlan& hp)
     P.params = hp.params.data();
     P.lb = hp.lb.data();
     P.ub = hp.ub.data();
+    P.is_R = hp.isR.empty() ? nullptr : hp.isR.data();
+    P.is_r = hp.isr.empty() ? nullptr : hp.isr.data();
 }
 
 } // namespace copra_hip

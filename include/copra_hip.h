@@ -90,6 +90,13 @@ typedef struct {
     int batch; /* number of independent preview systems (instances) */
 } copra_dims_t;
 
+/* InitialStateLMPC::resetInitialStateCost(R, r) (src/InitialStateLMPC.cpp:35-40): R [nx x nx] positive definite, r [nx];
+ * shared by the batch. */
+typedef struct {
+    const double* R;
+    const double* r;
+} copra_initial_state_desc_t;
+
 typedef struct copra_batch copra_batch_t; /* opaque handle == one batched LMPC controller */
 
 /* ---- controller life cycle (replaces LMPC::LMPC / initializeController / addCost / addConstraint,
@@ -98,6 +105,18 @@ typedef struct copra_batch copra_batch_t; /* opaque handle == one batched LMPC c
 copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs);
 void copra_batch_destroy(copra_batch_t* h);
+
+/* ---- InitialStateLMPC variant (include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp): the decision vector is
+ *      [x0; U]; costs contribute E and f, the Hessian is [[R + E Q^-1 E', E], [E', Q]] (InitialStateLMPC.cpp:77-122).
+ *      Covered on the device for xDim + fullUDim <= 64 and per-step cost entries; other shapes COPRA_ERR_UNSUPPORTED.
+ *      Initial-state bounds (resetInitialStateBounds, :42-46) are per instance, [batch][nx]; when they are never set
+ *      both default to the x0 handed to copra_batch_set_system (InitialStateLMPC.cpp:20-28).
+ *      copra_batch_get_initial_state == InitialStateLMPC::initialState() (:30-33), [batch][nx]. ---- */
+copra_status_t copra_batch_create_initial_state(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is);
+copra_status_t copra_batch_set_initial_state_bounds(copra_batch_t* h, const double* x0lb, const double* x0ub,
+    int on_device);
+copra_status_t copra_batch_get_initial_state(copra_batch_t* h, double* x0_opt);
 
 /* ---- PreviewSystem::system / xInit for every instance (src/PreviewSystem.cpp:16-55, include/PreviewSystem.h:52).
  *      A [batch][nx x nx], B [batch][nx x nu], d [batch][nx], x0 [batch][nx].

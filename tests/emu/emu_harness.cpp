@@ -2,6 +2,7 @@
 // See wave_prims.hpp in this directory.  Exposes a tiny C interface for ctypes.
 #include "wave_prims.hpp" // must come first: shadows copra_amd/csrc/wave_prims.hpp (same include guard name)
 
+#include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
@@ -89,10 +90,11 @@ extern "C" {
 int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
     const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
     double* control, double* trajectory, int* status, int* iter, int dump_instance, double* dumpQ, double* dumpc,
-    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes, overflowed, rcap */, int use_specialised)
+    double* dumpA, double* dumpb, int* sizes /* nvar, neq, nineq, lds_bytes, overflowed, rcap */, int use_specialised,
+    const copra_initial_state_desc_t* is, const double* x0lb, const double* x0ub, double* x0_opt)
 {
     HostPlan hp;
-    copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs);
+    copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) {
         fprintf(stderr, "emu: %s\n", hp.error.c_str());
         return (int)rc;
@@ -112,8 +114,11 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.dumpc = dumpc;
     P.dumpA = dumpA;
     P.dumpb = dumpb;
+    P.x0lb = x0lb;
+    P.x0ub = x0ub;
+    P.x0_opt = x0_opt;
     if (sizes) {
-        sizes[0] = P.n;
+        sizes[0] = P.initial_state ? P.nx + P.n : P.n;
         sizes[1] = P.meq;
         sizes[2] = P.mineq;
         sizes[3] = (int)hp.lds_bytes;
@@ -121,6 +126,13 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[5] = P.lds.rcap;
     }
     if (!A) return 0; // size query only
+    if (P.initial_state) {
+        for (int b = 0; b < dims->batch; ++b) {
+            int r = emu::run_wave([&]() { islmpc_fused_body(P, b); }, hp.lds_bytes, b, dims->batch);
+            if (r != 0) return -100;
+        }
+        return 0;
+    }
     // same dispatch as the HIP launcher (select_fused_kernel): compile-time shapes for the BASELINE configs
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const bool s6 = use_specialised && P.nx == 6 && rp == 6;

@@ -39,7 +39,7 @@ def _batchify(A, B, d, x0):
     return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
 
 
-def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True):
+def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True, initial_state=None):
     Ab, Bb, db, xb = _batchify(A, B, d, x0)
     batch, nu, nx = Bb.shape[0], Bb.shape[1], Bb.shape[2]
     keep = []
@@ -48,18 +48,29 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True)
     dims = _capi.Dims(nx, nu, N, batch)
     sizes = (C.c_int * 6)()
     vp = C.c_void_p
+    isd, x0lb, x0ub, x0o = vp(), None, None, None
+    if initial_state is not None:
+        Rm = _capi.fcol(initial_state["R"])
+        rv = _capi.fcol(initial_state["r"])
+        keep.extend([Rm, rv])
+        isd = _capi.InitialStateDesc(_capi.dptr(Rm), _capi.dptr(rv))
+        if initial_state.get("x0lb") is not None:
+            x0lb = np.ascontiguousarray(np.broadcast_to(initial_state["x0lb"], (batch, nx)), dtype=np.float64)
+            x0ub = np.ascontiguousarray(np.broadcast_to(initial_state["x0ub"], (batch, nx)), dtype=np.float64)
+        x0o = np.full((batch, nx), np.nan)
+        isd = C.byref(isd)
     rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, vp(), vp(), vp(), vp(), vp(), vp(), vp(),
-                              vp(), -1, vp(), vp(), vp(), vp(), sizes, 0)
+                              vp(), -1, vp(), vp(), vp(), vp(), sizes, 0, isd, vp(), vp(), vp())
     if rc == _capi.COPRA_ERR_DOMAIN:
         raise _capi.CopraDomainError("emu")
     if rc == _capi.COPRA_ERR_RUNTIME:
         raise _capi.CopraRuntimeError("emu")
     if rc == _capi.COPRA_ERR_UNSUPPORTED:
         raise _capi.CopraUnsupported("emu")
-    n, neq, nineq = sizes[0], sizes[1], sizes[2]
+    n, neq, nineq = sizes[0], sizes[1], sizes[2]  # n = number of decision variables of the QP
     mgen = neq + nineq
     X = nx * (N + 1)
-    u = np.full((batch, n), np.nan)
+    u = np.full((batch, nu * N), np.nan)
     tr = np.full((batch, X), np.nan)
     st = np.full(batch, -1, dtype=np.int32)
     it = np.zeros((batch, 2), dtype=np.int32)
@@ -70,10 +81,14 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True)
     p = _capi.dptr
     rc = lib().emu_lmpc_solve(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ab), p(Bb), p(db), p(xb), p(u), p(tr),
                               st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)),
-                              dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes, 1 if specialised else 0)
+                              dump_instance, p(dQ), p(dc), p(dA), p(db_), sizes, 1 if specialised else 0, isd,
+                              p(x0lb) if x0lb is not None else vp(), p(x0ub) if x0ub is not None else vp(),
+                              p(x0o) if x0o is not None else vp())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
     out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3], overflowed=sizes[4], rcap=sizes[5])
+    if x0o is not None:
+        out["x0_opt"] = x0o
     if dump_instance >= 0:
         out.update(Q=np.array(dQ), c=dc, Aeq=np.array(dA[:neq]), beq=db_[:neq], Aineq=np.array(dA[neq:mgen]),
                    bineq=db_[neq:mgen])

@@ -199,3 +199,59 @@ def test_dense_mfma_hessian_equals_structured_path(emu, oracle):
     assert np.abs(rd["Q"] - rs["Q"]).max() <= 1e-12 * scale
     assert np.abs(rd["c"] - qp["c"]).max() <= 1e-11 * max(1.0, np.abs(qp["c"]).max())
     assert _rel(rd["control"], rs["control"]) <= 1e-9
+
+
+def _is_problem_batch(b=5):
+    pb = F.bounded_system("trajectory", N=12)
+    rng = np.random.default_rng(1)
+    x0 = np.tile(pb["x0"], (b, 1))
+    x0[:, 1] += rng.uniform(-0.5, 0.5, b)
+    A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=x0 - 0.05, x0ub=x0 + 0.05)
+    return pb, A, B, d, x0, ist
+
+
+def test_initial_state_lmpc_batch(emu, oracle):
+    """InitialStateLMPC (src/InitialStateLMPC.cpp:77-128) on the device: decision vector [x0; U], per-instance x0
+    bounds; control, trajectory and x0* against the oracle"""
+    pb, A, B, d, x0, ist = _is_problem_batch()
+    re = emu.lmpc_solve(A, B, d, x0, 12, pb["costs"], pb["cstrs"], initial_state=ist)
+    for k in range(len(x0)):
+        ro = oracle.lmpc_solve(A[k], B[k], d[k], x0[k], 12, pb["costs"], pb["cstrs"],
+                               initial_state=dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k]))
+        assert ro["status"] == re["status"][k] == 0
+        assert _rel(re["control"][k], ro["control"]) <= RTOL
+        assert _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+        assert _rel(re["x0_opt"][k], ro["x0_opt"]) <= RTOL
+        assert (re["x0_opt"][k] <= ist["x0ub"][k] + 1e-6).all() and (re["x0_opt"][k] >= ist["x0lb"][k] - 1e-6).all()
+
+
+def test_initial_state_lmpc_reference_test_problem(emu, oracle):
+    """tests/TestLMPC_InitialState.cpp:266-403 (all nine classes, x0 free in [-1,1], R = 1e-6 I) and :29-260 (trailing
+    blocks of the InitialStateLMPC QP equal the LMPC QP).  With R = 1e-6 the Hessian's Schur complement is 1e-6
+    against blocks of 1e6, so U itself is not determined to 1e-6 by ANY arithmetic; like the reference's test we check
+    solve() == true and x0* within its bounds, plus x0* and the QP against the oracle."""
+    pb = F.initial_state_problem(False)
+    ist = dict(R=1e-6 * np.eye(2), r=np.zeros(2), x0lb=-np.ones(2), x0ub=np.ones(2))
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist,
+                        dump_instance=0)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist)
+    assert re["status"][0] == ro["status"] == 0
+    x0s = re["x0_opt"][0]
+    assert (x0s <= 1 + 1e-6).all() and (x0s >= -1 - 1e-6).all()
+    assert np.abs(x0s - ro["x0_opt"]).max() <= 1e-6
+    qb = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist)
+    qa = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    scale = np.abs(qb["Q"]).max()
+    assert np.abs(re["Q"] - qb["Q"]).max() <= 1e-9 * scale
+    assert np.abs(re["c"] - qb["c"]).max() <= 1e-9 * max(1.0, np.abs(qb["c"]).max())
+    assert np.abs(re["Aineq"] - qb["Aineq"]).max() <= 1e-10 * max(1.0, np.abs(qb["Aineq"]).max())
+    assert np.abs(re["bineq"] - qb["bineq"]).max() <= 1e-10
+    # TestLMPC_InitialState.cpp:212-226 on the device-built matrices
+    assert np.abs(re["Q"][2:, 2:] - qa["Q"]).max() <= 1e-6
+    assert np.abs(re["Aineq"][:, 2:] - qa["Aineq"]).max() <= 1e-6
+    # better conditioned variant: U must match too
+    ist2 = dict(R=np.eye(2), r=np.array([0.3, -0.2]), x0lb=-np.ones(2), x0ub=np.ones(2))
+    re2 = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist2)
+    ro2 = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist2)
+    assert re2["status"][0] == ro2["status"] == 0 and _rel(re2["control"][0], ro2["control"]) <= RTOL

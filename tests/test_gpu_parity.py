@@ -274,3 +274,50 @@ def test_full_size_cost_entries_mfma_contraction(oracle):
     got = e1.dump_qp(5)
     qp = oracle.lmpc_build(wl["A"][5], wl["B"][5], wl["d"][5], wl["x0"][5], 20, wl["costs"], wl["cstrs"])
     assert np.abs(got["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+
+
+def test_initial_state_lmpc_on_gpu(oracle):
+    """InitialStateLMPC (src/InitialStateLMPC.cpp) through the C ABI: (a) batch with per-instance x0 boxes,
+    (b) the reference's own test problem (TestLMPC_InitialState.cpp:266-403: all nine classes, R = 1e-6 I)."""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    pb = F.bounded_system("trajectory", N=12)
+    b = 257
+    rng = np.random.default_rng(1)
+    x0 = np.tile(pb["x0"], (b, 1))
+    x0[:, 1] += rng.uniform(-0.5, 0.5, b)
+    A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))
+    eng = BatchLMPC(2, 1, 12, b, pb["costs"], pb["cstrs"], initial_state=ist)
+    eng.set_system(A, B, d, x0)
+    eng.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
+    eng.solve()
+    res = eng.results()
+    x0s = eng.initial_state()
+    assert (res["status"] == 0).all()
+    assert (x0s <= x0 + 0.05 + 1e-6).all() and (x0s >= x0 - 0.05 - 1e-6).all()
+    for k in range(0, b, 16):
+        ro = oracle.lmpc_solve(A[k], B[k], d[k], x0[k], 12, pb["costs"], pb["cstrs"],
+                               initial_state=dict(R=ist["R"], r=ist["r"], x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05))
+        assert ro["status"] == 0
+        assert _rel(res["control"][k], ro["control"]) <= RTOL
+        assert _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+        assert _rel(x0s[k], ro["x0_opt"]) <= RTOL
+    pb = F.initial_state_problem(False)
+    ist = dict(R=1e-6 * np.eye(2), r=np.zeros(2))
+    eng = BatchLMPC(2, 1, pb["N"], 1, pb["costs"], pb["cstrs"], initial_state=ist)
+    eng.set_system(pb["A"][None], pb["B"][None], pb["d"][None], pb["x0"][None])
+    eng.set_initial_state_bounds(-np.ones((1, 2)), np.ones((1, 2)))
+    eng.solve()
+    res = eng.results()
+    x0s = eng.initial_state()[0]
+    assert res["status"][0] == 0  # REQUIRE(lmpc.solve())
+    assert (x0s <= 1 + 1e-6).all() and (x0s >= -1 - 1e-6).all()  # TestLMPC_InitialState.cpp:390-395
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"],
+                           initial_state=dict(R=ist["R"], r=ist["r"], x0lb=-np.ones(2), x0ub=np.ones(2)))
+    assert np.abs(x0s - ro["x0_opt"]).max() <= 1e-6
+    got = eng.dump_qp(0)
+    qb = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"],
+                           initial_state=dict(R=ist["R"], r=ist["r"], x0lb=-np.ones(2), x0ub=np.ones(2)))
+    assert np.abs(got["Q"] - qb["Q"]).max() <= 1e-9 * np.abs(qb["Q"]).max()
+    assert np.array_equal(got["lb"], qb["lb"]) and np.array_equal(got["ub"], qb["ub"])
