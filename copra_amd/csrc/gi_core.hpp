@@ -238,7 +238,7 @@ COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
 // ------------------------------------------------------------------------------------------------
 template <int NV, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
-    int& iter_main, int& iter_drop)
+    int& iter_main, int& iter_drop COPRA_FINE_ARGS)
 {
     const int lane = lane_id();
     const int n = NV ? NV : n_rt;
@@ -305,6 +305,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             }
         }
         wave_argmin(best, best_i, best_s);
+        if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
         double sv_nvl = best_s;
@@ -334,6 +335,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             }
             if (lane < n) S.dv[lane] = (lane >= nact) ? dj : 0.0; // d2 (d1 stays in registers)
             wave_sync();
+            if (iter_main <= 1) COPRA_FINE("as:d");
             // z = J2 d2   (lane = row; the d1 part of dv is zero)
             double zi;
             {
@@ -346,6 +348,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if (j < n) z0 += J[lj * ld + j] * S.dv[j];
                 zi = (lane < n) ? z0 + z1 : 0.0;
             }
+            if (iter_main <= 1) COPRA_FINE("as:z");
             // r = R^-1 d1 : column-oriented back substitution, r_c broadcast from lane c
             double acc = (lane < nact) ? dj : 0.0;
             double ri = 0.0;
@@ -368,6 +371,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 wave_argmin(t1, it1, dummy);
             }
             const bool t1inf = (it1 < 0);
+            if (iter_main <= 1) COPRA_FINE("as:t1");
             const double zz = wave_sum(zi * zi);
             bool drop = false;
             if (fabs(zz) <= vsmall) {
@@ -387,6 +391,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if (lane < n) S.xs[lane] += tt * zi;
                 if (lane < nact) S.uv[lane] -= tt * ri;
                 if (lane == 0) S.uv[nact] += tt;
+                if (iter_main <= 1) COPRA_FINE("as:step");
                 if (t2min) {
                     // ---- full step: constraint nvl becomes active; update R and J ----
                     if (nact >= S.rcap) return 4; // compact layout: R is full -> the instance is redone with the full one
@@ -428,11 +433,34 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         S.act[nvl] = 1;
                     }
                     wave_sync();
+                    if (iter_main <= 1) COPRA_FINE("as:coef");
                     if (nact + 1 < n) {
                         double carry = J[lj * ld + (n - 1)];
                         const int qlo = NV ? 0 : nact; // compile-time shape: sweep everything (identity below nact)
-#pragma unroll 4
-                        for (int q = n - 1; q > qlo; --q) {
+                        int q = n - 1;
+                        // four rotations per round trip: all LDS reads of a group are issued before its first store
+                        // (the compiler cannot move loads across the stores by itself: everything aliases in LDS)
+                        for (; q - 3 > qlo; q -= 4) {
+                            double a[4], c[4][4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                a[u] = J[lj * ld + q - 1 - u];
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) c[u][v] = S.coef[4 * (q - u) + v];
+                            }
+                            double w[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double t = c[u][0] * a[u] + c[u][1] * carry;
+                                w[u] = c[u][2] * a[u] + c[u][3] * carry;
+                                carry = t;
+                            }
+                            if (lane < n) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) J[lane * ld + q - u] = w[u];
+                            }
+                        }
+                        for (; q > qlo; --q) {
                             const double a = J[lj * ld + q - 1];
                             const double c0 = S.coef[4 * q + 0], c1 = S.coef[4 * q + 1];
                             const double c2 = S.coef[4 * q + 2], c3 = S.coef[4 * q + 3];
@@ -445,6 +473,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     }
                     nact += 1;
                     wave_sync();
+                    if (iter_main <= 1) COPRA_FINE("as:givens");
                     break; // back to step 1
                 } else {
                     // ---- partial step: recompute the slack of nvl, then drop the blocking constraint ----

@@ -335,7 +335,7 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
     if (P.dump_only) return;
     int it_main = 0, it_drop = 0;
     if (status == 0) status = gi_factorize<0>(S, nv, nullptr COPRA_FINE_PASS);
-    if (status == 0) status = gi_active_set<0>(S, nv, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
+    if (status == 0) status = gi_active_set<0>(S, nv, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     // ---- results (InitialStateLMPC.cpp:124-128) ----
     if (status == 0) {

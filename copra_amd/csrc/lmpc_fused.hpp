@@ -621,7 +621,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
+        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     stamp[6] = cycle_counter();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else

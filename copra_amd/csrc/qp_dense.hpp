@@ -78,7 +78,7 @@ COPRA_DEV void qp_dense_body(const DensePlan& P, int inst)
     COPRA_FINE_DECL;
     int status = gi_factorize<0>(S, n, nullptr COPRA_FINE_PASS);
     int it_main = 0, it_drop = 0;
-    if (status == 0) status = gi_active_set<0>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
+    if (status == 0) status = gi_active_set<0>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     const double qnan = __builtin_nan("");
     for (int e = lane; e < n; e += kWave) P.x[(size_t)inst * n + e] = (status == 0) ? S.xs[e] : qnan;

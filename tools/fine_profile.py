@@ -29,9 +29,10 @@ eng.solve()
 out = np.zeros((batch, 32), dtype=np.int64)
 _capi.check(L.copra_batch_fine_profile(eng._h, out.ctypes.data))
 it = eng.results()["iter"][:, 0]
-sel = it == np.bincount(it).argmax()
+want = int(sys.argv[2]) if len(sys.argv) > 2 else int(np.bincount(it).argmax())
+sel = it == want
 m = out[sel].mean(axis=0)
-print("kernel ms", eng.last_solve_seconds() * 1e3, "instances with iters ==", np.bincount(it).argmax(), sel.sum())
+print("kernel ms", eng.last_solve_seconds() * 1e3, "instances with iters ==", want, sel.sum())
 prev = 0.0
 for k in range(32):
     if m[k] < 0:
