@@ -85,8 +85,8 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
 
 // ------------------------------------------------------------------------------------------------
 // Factorisation: S.J holds the Hessian (upper triangle), S.cvec the linear term c.
-// On exit S.J = J = R^-1 (upper triangular, strict lower part zero), S.xs = -Q^-1 c.  Returns 0 or 2.
-// S.coef is used as scratch (1/R(i,i)).
+// On exit the upper triangle of S.J holds the Cholesky factor R (Q = R'R), S.coef holds 1/R(i,i) and S.xs = -Q^-1 c.
+// Returns 0 or 2.  gi_invert() then turns R into J = R^-1 when (and only when) the active-set loop needs it.
 // ------------------------------------------------------------------------------------------------
 template <int NV>
 COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA_FINE_ARGS)
@@ -157,6 +157,69 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
         if (k0 == 24 || k0 == 28 || k0 == 52 || k0 == 56) COPRA_FINE("chol:panel");
     }
     if (t_chol) *t_chol = cycle_counter();
+    // ---- unconstrained minimiser: R'R x = -c by two substitutions (qpgen2: dposl).  J = R^-1 is NOT formed here:
+    //      an instance whose unconstrained minimiser violates nothing never needs it (gi_invert is called lazily). ----
+    {
+        // forward  R' y = -c :  y_k = acc_k / R(k,k),  acc_j -= R(k,j) y_k  (j > k), lane = column
+        double acc = (lane < n) ? -S.cvec[lj] : 0.0;
+        double yk = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 4) {
+            double row[4], ri[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = (k0 + u < n) ? k0 + u : n - 1;
+                row[u] = J[k * ld + lj]; // R(k, lane)
+                ri[u] = rinvd[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k < n) {
+                    const double y = bcast_f64(acc, k) * ri[u];
+                    if (lane == k) yk = y;
+                    if (lane > k) acc -= row[u] * y;
+                }
+            }
+        }
+        // backward  R x = y :  x_k = acc_k / R(k,k),  acc_i -= R(i,k) x_k  (i < k), lane = row
+        acc = yk;
+        double xk = 0.0;
+        for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
+            double colv[4], ri[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = (k0 - u >= 0) ? k0 - u : 0;
+                colv[u] = J[lj * ld + k]; // R(lane, k)
+                ri[u] = rinvd[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 - u;
+                if (k >= 0) {
+                    const double x = bcast_f64(acc, k) * ri[u];
+                    if (lane == k) xk = x;
+                    if (lane < k) acc -= colv[u] * x;
+                }
+            }
+        }
+        if (lane < n) S.xs[lane] = xk;
+        wave_sync();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// J = R^-1 in place (upper triangular, strict lower part zero).  S.coef still holds 1/R(i,i) from gi_factorize.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
+{
+    const int lane = lane_id();
+    const int n = NV ? NV : n_rt;
+    const int ld = NV ? (NV | 1) : S.ldj;
+    const int lj = (lane < n) ? lane : n - 1;
+    double* J = S.J;
+    const double* rinvd = S.coef;
     // zero the strict lower triangle (qpgen2 does the same before the first rotation)
     for (int i = 1; i < n; ++i)
         if (i > lane) J[i * ld + lane] = 0.0;
@@ -206,28 +269,6 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
             if (p < pw && lane < n) J[(i0 + p) * ld + lane] = v[p];
         wave_sync();
     }
-    // ---- unconstrained minimiser x = -J J' c   (qpgen2: dposl on dvec = -c) ----
-    {
-        double t0 = 0.0, t1 = 0.0;
-        int i = 0;
-        for (; i + 1 < n; i += 2) {
-            t0 += J[i * ld + lj] * S.cvec[i];
-            t1 += J[(i + 1) * ld + lj] * S.cvec[i + 1];
-        }
-        if (i < n) t0 += J[i * ld + lj] * S.cvec[i];
-        if (lane < n) S.dv[lane] = t0 + t1;
-        wave_sync();
-        double x0 = 0.0, x1 = 0.0;
-        int j = 0;
-        for (; j + 1 < n; j += 2) {
-            x0 += J[lj * ld + j] * S.dv[j];
-            x1 += J[lj * ld + j + 1] * S.dv[j + 1];
-        }
-        if (j < n) x0 += J[lj * ld + j] * S.dv[j];
-        if (lane < n) S.xs[lane] = -(x0 + x1);
-        wave_sync();
-    }
-    return 0;
 }
 
 COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
@@ -247,6 +288,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     const int mtotal = mgen + 2 * n; // QuadProgSolver.cpp:51: the bounds are 2n more inequality rows
     double* J = S.J;
     int nact = 0;
+    bool have_J = false;
     iter_main = 0;
     iter_drop = 0;
     for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;
@@ -308,6 +350,10 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
+        if (!have_J) { // first violated constraint: only now is J = R^-1 needed
+            gi_invert<NV>(S, n);
+            have_J = true;
+        }
         double sv_nvl = best_s;
         wave_sync(); // eqsgn updates visible
 

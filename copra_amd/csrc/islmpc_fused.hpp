@@ -288,6 +288,7 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
         if (lane < n) S.ap[lane] = 0.0;
         wave_sync();
         status = gi_factorize<0>(Sq, n, nullptr COPRA_FINE_PASS);
+        if (status == 0) gi_invert<0>(Sq, n);
         if (status == 0) {
             // T = E Jq (nx x n): lane j holds column j;  top-left = R + T T'
             double Tj[16];
