@@ -24,14 +24,18 @@ using namespace copra_hip;
 template <int NX, int NU, int NH, int RP>
 __global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
 {
-    if (!P.from_list) {
-        lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
-    } else { // second tier: the instances the compact layout could not finish
-        const int count = *P.ovf_count;
-        for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-            lmpc_fused_body<NX, NU, NH, RP>(P, P.ovf_list[k]);
-            __syncthreads();
-        }
+    lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
+}
+
+// Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
+// layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
+template <int NX, int NU, int NH, int RP>
+__global__ __launch_bounds__(64) void copra_lmpc_fused_tier2_kernel(const FusedPlan P)
+{
+    const int count = *P.ovf_count;
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        lmpc_fused_body<NX, NU, NH, RP>(P, P.ovf_list[k]);
+        __syncthreads();
     }
 }
 
@@ -44,6 +48,13 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;
+}
+fused_kernel_t select_tier2_kernel(const FusedPlan& P)
+{
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
+    if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tier2_kernel<6, 3, 20, 6>;
+    if (P.nx == 2 && rp == 2) return copra_lmpc_fused_tier2_kernel<2, 1, 10, 2>;
+    return copra_lmpc_fused_tier2_kernel<0, 0, 0, 0>;
 }
 } // namespace
 
@@ -156,6 +167,9 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
         const void* fn = h->hp.plan.initial_state ? reinterpret_cast<const void*>(copra_islmpc_fused_kernel)
                                                   : reinterpret_cast<const void*>(select_fused_kernel(h->hp.plan));
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+        if (!h->hp.plan.initial_state && h->hp.two_tier)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_tier2_kernel(h->hp.plan)),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     h->lds_attr_set = true;
     return COPRA_OK;
@@ -370,7 +384,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P2.lds = h->hp.lds_full;
         P2.from_list = 1;
         const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
-        hipLaunchKernelGGL(select_fused_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+        hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(h->ev1, s));
