@@ -136,21 +136,34 @@ def source_hash():
 def build_library(force=False):
     """(Re)build libcopra_hip.so with hipcc when the sources changed since the last build.  Never falls back to
     anything else: without hipcc a stale or missing library is an error the caller sees."""
+    import fcntl
     import subprocess
     stamp = LIB_PATH + ".srchash"
     want = source_hash()
-    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
-    if os.path.exists(LIB_PATH) and have == want and not force:
+
+    def current():
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        return os.path.exists(LIB_PATH) and have == want
+
+    if current() and not force:
         return False
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         if os.path.exists(LIB_PATH):
             raise ImportError("copra_amd: libcopra_hip.so is older than its sources and hipcc is not available")
         raise ImportError("copra_amd: libcopra_hip.so has not been built and hipcc is not available")
-    subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
-                          stdout=subprocess.DEVNULL)
-    with open(stamp, "w") as fh:
-        fh.write(want + "\n")
+    # several ranks of one job may get here at once: build under an exclusive lock, re-check after acquiring it
+    with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if current() and not force:
+                return False
+            subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
+                                  stdout=subprocess.DEVNULL)
+            with open(stamp, "w") as fh:
+                fh.write(want + "\n")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return True
 
 
