@@ -43,6 +43,11 @@ def main():
                     help="hand the TrajectoryCost over as a full-size entry (126x126 M): the Hessian is then built by "
                          "the dense v_mfma_f64_16x16x4 Psi'WPsi contraction instead of the block-diagonal prefix sums")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: gather synchronously on the compute stream instead of overlapping it with the next solve")
+    ap.add_argument("--selftest-overlap", action="store_true",
+                    help="(single GPU) exercise the double-buffer / side-stream plumbing of the N > 1 path with a "
+                         "device copy standing in for the RCCL gather")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,20 +83,54 @@ def main():
     Ab, Bb, db, xb = to_abi_layout(wl["A"], wl["B"], wl["d"], wl["x0"])
     tA, tB = torch.from_numpy(Ab).to(dev), torch.from_numpy(Bb).to(dev)
     td, tx0 = torch.from_numpy(db).to(dev), torch.from_numpy(xb).to(dev)
-    slab, views = alloc_result_slab(batch, n, X, dev)  # the engine writes straight into the gather payload
+    # The engine writes straight into the gather payload.  N > 1: two slabs, so that the RCCL gather of step k (on a
+    # side stream, over xGMI) overlaps the solve of step k+1; the timed region ends only when both streams are idle.
+    comm_path = world > 1 or args.selftest_overlap
+    overlap = comm_path and not args.no_overlap
+    n_slabs = 2 if overlap else 1
+    slabs = [alloc_result_slab(batch, n, X, dev) for _ in range(n_slabs)]
+    slab, views = slabs[0]
     out_u, out_x, out_s, out_i = views["control"], views["trajectory"], views["status"], views["iter"]
 
     eng = BatchLMPC(nx, nu, N, batch, wl["costs"], wl["cstrs"])
     eng.set_system(tA, tB, td, tx0)
     eng.set_outputs(out_u, out_x, out_s, out_i)
-    stream = torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_stream()
+    stream = cur.cuda_stream
 
-    gather_bufs = alloc_gather_buffers(slab, rank, world) if world > 1 else None
+    if world > 1:
+        gather_bufs = [alloc_gather_buffers(sl[0], rank, world) for sl in slabs]
+    else:
+        gather_bufs = [[torch.empty_like(sl[0])] for sl in slabs]  # self-test stand-in
+    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+    ev_solved = [torch.cuda.Event() for _ in range(n_slabs)]
+    ev_sent = [torch.cuda.Event() for _ in range(n_slabs)]
+    step_no = [0]
+
+    def send(k):
+        if world > 1:
+            gather_results(slabs[k][0], rank, world, gather_bufs[k])
+        else:
+            gather_bufs[k][0].copy_(slabs[k][0], non_blocking=True)
 
     def step():
+        k = step_no[0] % n_slabs
+        step_no[0] += 1
+        if overlap:
+            v = slabs[k][1]
+            if step_no[0] > n_slabs:
+                cur.wait_event(ev_sent[k])  # this slab's previous gather must be done before it is overwritten
+            eng.set_outputs(v["control"], v["trajectory"], v["status"], v["iter"])
         eng.solve(stream)
-        if world > 1:
-            gather_results(slab, rank, world, gather_bufs)
+        if comm_path:
+            if overlap:
+                ev_solved[k].record(cur)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ev_solved[k])
+                    send(k)
+                    ev_sent[k].record(comm_stream)
+            else:
+                send(k)
 
     for _ in range(args.warmup):
         step()
@@ -110,6 +149,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # device time of the dominant kernel: HIP events recorded by the C ABI around the launch on `stream`
     # (measured in a separate short loop so that the event sync does not perturb the timed region)
+    eng.set_outputs(out_u, out_x, out_s, out_i)
     for _ in range(min(args.steps, 10)):
         eng.solve(stream)
         kernel_s.append(eng.last_solve_seconds())
@@ -152,7 +192,9 @@ def main():
                        "hessian": "dense MFMA f64 contraction (full-size cost entry)" if args.dense_hessian
                        else "block-diagonal prefix sums (per-step cost entry)",
                        "batch_per_gpu": batch, "global_batch": batch * world, "nvar": n, "ineq_rows": 63,
-                       "bound_rows": 2 * n, "parallelism": "batch-shard x%d + 1 RCCL gather/step" % world
+                       "bound_rows": 2 * n,
+                       "parallelism": ("batch-shard x%d + 1 RCCL gather/step (%s)"
+                                       % (world, "overlapped with the next solve" if overlap else "synchronous"))
                        if world > 1 else "single GPU"},
             "solved_ok": n_ok,
             "mean_active_set_iters": float(iters[:, 0].mean()),
