@@ -7,6 +7,7 @@
 #include "lmpc_fused.hpp"
 #include "plan_builder.hpp"
 #include "qp_dense.hpp"
+#include "qp_dense_large.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -65,12 +66,31 @@ __global__ __launch_bounds__(64) void copra_islmpc_fused_kernel(const FusedPlan 
 
 __global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
 
+// n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
+__global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
 
 thread_local std::string g_err;
+
+// persistent grid of the workgroup-per-instance kernels: as many workgroups as the device keeps resident
+int large_grid(int batch, int threads, size_t lds_bytes)
+{
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    int per_cu = (int)((160u * 1024u) / (lds_bytes ? lds_bytes : 1));
+    const int by_threads = 2048 / threads;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    const long long g = (long long)cus * per_cu;
+    return (int)(g < batch ? g : batch);
+}
 
 copra_status_t fail(copra_status_t code, const std::string& msg)
 {
@@ -591,8 +611,9 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         return fail(COPRA_ERR_DOMAIN, "copra_qp_solve_dense_batch: bad problem sizes");
     if (!Q || !c || !XL || !XU || !x || !failv || (neq > 0 && (!Aeq || !beq)) || (nineq > 0 && (!Aineq || !bineq)))
         return fail(COPRA_ERR_ARG, "copra_qp_solve_dense_batch: null argument");
-    if (n > kWave) return fail(COPRA_ERR_UNSUPPORTED, "dense QP with more than 64 variables is not covered yet");
+    if (n > kLargeMaxN) return fail(COPRA_ERR_UNSUPPORTED, "dense QP with more than 512 variables is not covered yet");
     if (batch == 0) return COPRA_OK;
+    const bool large = n > kWave;
     hipStream_t s = (hipStream_t)hip_stream;
     DensePlan P {};
     P.n = n;
@@ -603,11 +624,18 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.batch = batch;
     P.vsmall = qpgen2_vsmall();
     P.max_iter = 50 * (n + P.mtotal) + 100;
-    (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
-    const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
+    size_t lds_bytes;
+    if (large) {
+        layout_large_solver(P.llds, 0, n, P.mgen, P.meq, P.mtotal);
+        lds_bytes = (size_t)P.llds.total * sizeof(double);
+    } else {
+        (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
+        lds_bytes = (size_t)P.lds.total * sizeof(double);
+    }
     if (lds_bytes > 160u * 1024u) return fail(COPRA_ERR_UNSUPPORTED, "dense QP does not fit LDS");
     if (lds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_qp_dense_kernel),
+        HIP_TRY(hipFuncSetAttribute(large ? reinterpret_cast<const void*>(copra_qp_dense_large_kernel)
+                                          : reinterpret_cast<const void*>(copra_qp_dense_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const size_t b = (size_t)batch;
     std::vector<void*> owned;
@@ -654,7 +682,21 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.x = dx;
     P.fail = dfail;
     P.iter = diter;
-    hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
+    if (large) {
+        const int threads = (n + kWave - 1) & ~(kWave - 1);
+        const int grid = large_grid(batch, threads, lds_bytes);
+        double* ws = nullptr;
+        e = hipMalloc((void**)&ws, (size_t)grid * 2 * n * large_ld(n) * sizeof(double));
+        if (e != hipSuccess) {
+            release();
+            return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
+        }
+        owned.push_back(ws);
+        P.ws = ws;
+        hipLaunchKernelGGL(copra_qp_dense_large_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
+    } else {
+        hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
+    }
     e = hipGetLastError();
     if (e == hipSuccess && !on_device) {
         e = hipMemcpyAsync(x, dx, b * n * sizeof(double), hipMemcpyDeviceToHost, s);

@@ -149,6 +149,11 @@ struct FusedPlan {
     LdsLayout lds;
 };
 
+// LDS regions of the workgroup-per-instance solver (gi_large.hpp), offsets in doubles
+struct LargeLds {
+    int xs, cv, np, dv, rv, uv, hv, coef, nb, eqsgn, red, stage, dblk, act, iact, total;
+};
+
 // dense batched QP kernel (plug-in point 1): plain SolverInterface::SI_solve arguments, batch-major
 struct DensePlan {
     int n, meq, mineq, mgen, mtotal, batch;
@@ -159,6 +164,9 @@ struct DensePlan {
     double vsmall;
     int max_iter;
     LdsLayout lds;
+    // n > 64: workgroup-per-problem kernel (qp_dense_large.hpp); J and the factor live in `ws`
+    LargeLds llds;
+    double* ws; // [gridDim.x][2][n * ld] doubles
 };
 
 } // namespace copra_hip

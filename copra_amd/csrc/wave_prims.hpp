@@ -34,13 +34,13 @@ COPRA_DEV int shfl_i32(int v, int src) { return __shfl(v, src, 64); }
 COPRA_DEV double shfl_down0_f64(double v, int delta)
 {
     const double t = __shfl_down(v, (unsigned)delta, 64);
-    return ((int)threadIdx.x + delta < 64) ? t : 0.0;
+    return ((int)(threadIdx.x & 63u) + delta < 64) ? t : 0.0;
 }
 // value of lane (lane-delta), 0 before the start of the wave
 COPRA_DEV double shfl_up0_f64(double v, int delta)
 {
     const double t = __shfl_up(v, (unsigned)delta, 64);
-    return ((int)threadIdx.x - delta >= 0) ? t : 0.0;
+    return ((int)(threadIdx.x & 63u) - delta >= 0) ? t : 0.0;
 }
 
 // value of lane `src` (src wave-uniform): v_readlane_b32 x2, no LDS round trip

@@ -6,6 +6,7 @@
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
+#include "../../copra_amd/csrc/qp_dense_large.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -17,67 +18,111 @@
 namespace copra_hip {
 namespace emu {
     WaveState g_wave;
-    double g_mfma_a[64], g_mfma_b[64];
+    double g_mfma_a[kMaxThreads], g_mfma_b[kMaxThreads];
     static ucontext_t g_sched;
-    static ucontext_t g_fiber[64];
-    static bool g_done[64];
+    static ucontext_t g_fiber[kMaxThreads];
+    static bool g_done[kMaxThreads];
     static std::function<void()>* g_body;
+    // barriers: a waiting fiber records which generation it waits for; the scheduler skips it until that generation
+    // has passed (so a blocked thread costs a comparison, not a context switch)
+    static int g_blk_count;
+    static unsigned g_blk_gen;
+    static int g_wv_count[kMaxThreads / 64];
+    static unsigned g_wv_gen[kMaxThreads / 64];
+    static int g_wait_kind[kMaxThreads]; // 0 runnable, 1 block barrier, 2 wave barrier
+    static unsigned g_wait_gen[kMaxThreads];
+    static unsigned long g_progress;
 
-    void yield() { swapcontext(&g_fiber[g_wave.lane], &g_sched); }
+    static void yield() { swapcontext(&g_fiber[g_wave.lane], &g_sched); }
+
+    void barrier_block()
+    {
+        const int me = g_wave.lane;
+        const unsigned g = g_blk_gen;
+        if (++g_blk_count == g_wave.nthreads) {
+            g_blk_count = 0;
+            ++g_blk_gen;
+            ++g_progress;
+            return;
+        }
+        g_wait_kind[me] = 1;
+        g_wait_gen[me] = g;
+        yield();
+    }
+    void barrier_wave()
+    {
+        const int me = g_wave.lane, w = me >> 6;
+        const unsigned g = g_wv_gen[w];
+        if (++g_wv_count[w] == 64) {
+            g_wv_count[w] = 0;
+            ++g_wv_gen[w];
+            ++g_progress;
+            return;
+        }
+        g_wait_kind[me] = 2;
+        g_wait_gen[me] = g;
+        yield();
+    }
 
     static void fiber_main()
     {
         (*g_body)();
         g_done[g_wave.lane] = true;
+        ++g_progress;
         swapcontext(&g_fiber[g_wave.lane], &g_sched);
     }
 
-    // run one 64-lane wave to completion
-    static int run_wave(std::function<void()> body, size_t lds_bytes, int inst, int ninst)
+    // run one workgroup of `nthreads` threads to completion
+    static int run_block(std::function<void()> body, size_t lds_bytes, int inst, int ninst, int nthreads)
     {
         static std::vector<char> stacks;
         const size_t stack_sz = 256 * 1024;
-        if (stacks.size() < 64 * stack_sz) stacks.resize(64 * stack_sz);
+        if (nthreads % 64 != 0 || nthreads > kMaxThreads) return -1;
+        if (stacks.size() < (size_t)nthreads * stack_sz) stacks.resize((size_t)nthreads * stack_sz);
         std::vector<double> lds(lds_bytes / sizeof(double) + 2, __builtin_nan(""));
         g_wave.lds = lds.data();
         g_wave.inst = inst;
         g_wave.ninst = ninst;
+        g_wave.nthreads = nthreads;
         g_body = &body;
-        for (int l = 0; l < 64; ++l) {
+        g_blk_count = 0;
+        for (int w = 0; w < nthreads / 64; ++w) g_wv_count[w] = 0;
+        for (int l = 0; l < nthreads; ++l) {
             g_done[l] = false;
+            g_wait_kind[l] = 0;
             getcontext(&g_fiber[l]);
-            g_fiber[l].uc_stack.ss_sp = stacks.data() + l * stack_sz;
+            g_fiber[l].uc_stack.ss_sp = stacks.data() + (size_t)l * stack_sz;
             g_fiber[l].uc_stack.ss_size = stack_sz;
             g_fiber[l].uc_link = &g_sched;
             makecontext(&g_fiber[l], fiber_main, 0);
         }
         for (;;) {
+            const unsigned long before = g_progress;
             int ndone = 0;
-            for (int l = 0; l < 64; ++l) {
+            for (int l = 0; l < nthreads; ++l) {
                 if (g_done[l]) {
                     ++ndone;
                     continue;
                 }
+                if (g_wait_kind[l] == 1 && g_wait_gen[l] == g_blk_gen) continue;
+                if (g_wait_kind[l] == 2 && g_wait_gen[l] == g_wv_gen[l >> 6]) continue;
+                g_wait_kind[l] = 0;
                 g_wave.lane = l;
                 swapcontext(&g_sched, &g_fiber[l]);
             }
-            int after = 0;
-            for (int l = 0; l < 64; ++l) after += g_done[l] ? 1 : 0;
-            if (after == 64) return 0;
-            if (after != 0 && after != ndone && after != 64) {
-                // some lanes finished while others wait at a barrier: divergent exit
-                bool all = true;
-                for (int l = 0; l < 64; ++l) all = all && g_done[l];
-                if (!all && after > 0) {
-                    // allow: lanes finish in the same round only
-                    int pending = 64 - after;
-                    if (pending > 0 && ndone == 0) {
-                        fprintf(stderr, "emu: divergent wave exit (%d lanes done, %d waiting)\n", after, pending);
-                        return -1;
-                    }
-                }
+            if (ndone == nthreads) return 0;
+            if (g_progress == before) {
+                int waiting = 0;
+                for (int l = 0; l < nthreads; ++l) waiting += g_done[l] ? 0 : 1;
+                fprintf(stderr, "emu: deadlock -- %d threads wait at a barrier the rest of the workgroup never reaches\n",
+                    waiting);
+                return -1;
             }
         }
+    }
+    static int run_wave(std::function<void()> body, size_t lds_bytes, int inst, int ninst)
+    {
+        return run_block(body, lds_bytes, inst, ninst, 64);
     }
 } // namespace emu
 } // namespace copra_hip
@@ -194,7 +239,17 @@ int emu_qp_dense(int batch, int n, int neq, int nineq, const double* Q, const do
     P.iter = iter;
     P.vsmall = qpgen2_vsmall();
     P.max_iter = 50 * (n + P.mtotal) + 100;
-    if (n > 64) return (int)COPRA_ERR_UNSUPPORTED;
+    if (n > kLargeMaxN) return (int)COPRA_ERR_UNSUPPORTED;
+    if (n > 64) { // workgroup-per-problem kernel, same launch geometry as copra_qp_solve_dense_batch
+        layout_large_solver(P.llds, 0, n, P.mgen, P.meq, P.mtotal);
+        const int threads = (n + 63) & ~63;
+        const int ld = large_ld(n);
+        std::vector<double> ws((size_t)2 * n * ld, __builtin_nan(""));
+        P.ws = ws.data();
+        // one resident workgroup walking the batch (the persistent-grid loop of the kernel)
+        int r = emu::run_block([&]() { qp_dense_large_body(P); }, (size_t)P.llds.total * sizeof(double), 0, 1, threads);
+        return r != 0 ? -100 : 0;
+    }
     (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
     const size_t lds_bytes = (size_t)P.lds.total * sizeof(double);
     for (int b = 0; b < batch; ++b) {

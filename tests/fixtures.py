@@ -143,3 +143,15 @@ def com_walk_problem():
     costs = [dict(kind="target", M=np.eye(6), p=-x_goal)]  # pyTests.py:436 (sic: -x_goal)
     cstrs = [dict(kind="control", G=G, f=h)]
     return dict(A=A, B=B, d=np.zeros(6), x0=x_init, N=N, costs=costs, cstrs=cstrs)
+
+
+def random_dense_qp(rng, n, meq, mineq, tight=0.3):
+    """strictly convex QP around a feasible point: equalities, inequalities (some active) and box bounds"""
+    M = rng.standard_normal((n, n))
+    Q = M @ M.T / n + 0.5 * np.eye(n)
+    c = rng.standard_normal(n)
+    xf = 0.2 * rng.standard_normal(n)
+    Aeq = rng.standard_normal((meq, n))
+    Ain = rng.standard_normal((mineq, n))
+    return dict(Q=Q, c=c, Aeq=Aeq, beq=Aeq @ xf, Aineq=Ain, bineq=Ain @ xf + tight * rng.random(mineq),
+                XL=xf - 0.5 * rng.random(n) - 0.05, XU=xf + 0.5 * rng.random(n) + 0.05)

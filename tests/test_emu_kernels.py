@@ -146,6 +146,29 @@ def test_dense_qp_kernel_body(emu, oracle):
             assert np.abs(x[0] - xo).max() <= 1e-8 * (1 + np.abs(xo).max())
 
 
+def test_dense_qp_large_kernel_body(emu, oracle):
+    """qp_dense_large.hpp / gi_large.hpp (n > 64: one problem per workgroup, J and R in the HBM workspace) takes the same
+    decisions as the oracle's qpgen2 restatement: same iteration counts, same solution; plus the status codes"""
+    rng = np.random.default_rng(11)
+    for n, meq, mi in [(65, 3, 20), (100, 10, 120)]:
+        P = F.random_dense_qp(rng, n, meq, mi)
+        xo, fo, ito = oracle.quadprog_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+        x, fail, it = emu.qp_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+        assert fo == 0 and fail[0] == 0 and tuple(it[0]) == tuple(ito)
+        assert np.abs(x[0] - xo).max() <= 1e-10 * (1 + np.abs(xo).max())
+    # not positive definite -> 2 ; infeasible (contradictory bounds through an equality) -> 1
+    P = F.random_dense_qp(rng, 70, 0, 4)
+    Qbad = P["Q"].copy()
+    Qbad[40, 40] = -1.0
+    _, fail, _ = emu.qp_dense(Qbad, P["c"], None, None, P["Aineq"], P["bineq"], P["XL"], P["XU"])
+    assert fail[0] == 2 and oracle.quadprog_dense(Qbad, P["c"], None, None, P["Aineq"], P["bineq"], P["XL"], P["XU"])[1] == 2
+    Aeq = np.zeros((1, 70))
+    Aeq[0, 0] = 1.0
+    beq = np.array([P["XU"][0] + 1.0])
+    _, fail, _ = emu.qp_dense(P["Q"], P["c"], Aeq, beq, None, None, P["XL"], P["XU"])
+    assert fail[0] == 1 and oracle.quadprog_dense(P["Q"], P["c"], Aeq, beq, None, None, P["XL"], P["XU"])[1] == 1
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi

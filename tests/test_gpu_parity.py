@@ -126,6 +126,23 @@ def test_dense_qp_plugin_point(oracle):
         assert fo == 0 and np.abs(x[k] - xo).max() < 1e-9
 
 
+@pytest.mark.parametrize("n,meq,mi,b", [(65, 3, 20, 9), (130, 10, 150, 5), (312, 50, 300, 3), (512, 0, 200, 2)])
+def test_dense_qp_large_n(oracle, n, meq, mi, b):
+    """n > 64 runs the workgroup-per-problem kernel (gi_large.hpp): same iteration counts and solution as the oracle"""
+    import fixtures as F
+    from copra_amd import qp_solve_dense_batch
+    rng = np.random.default_rng(n)
+    Ps = [F.random_dense_qp(rng, n, meq, mi) for _ in range(b)]
+    st = lambda k: np.stack([P[k] for P in Ps])
+    x, fail, it = qp_solve_dense_batch(st("Q"), st("c"), st("Aeq") if meq else None, st("beq") if meq else None,
+                                       st("Aineq"), st("bineq"), st("XL"), st("XU"))
+    for k, P in enumerate(Ps):
+        xo, fo, ito = oracle.quadprog_dense(P["Q"], P["c"], P["Aeq"] if meq else None, P["beq"] if meq else None,
+                                            P["Aineq"], P["bineq"], P["XL"], P["XU"])
+        assert fo == 0 and fail[k] == 0 and tuple(it[k]) == tuple(ito)
+        assert np.abs(x[k] - xo).max() <= 1e-9 * (1 + np.abs(xo).max())
+
+
 def test_status_codes_infeasible_and_not_pd(oracle):
     """SI_fail codes (QuadProgSolver.h:21-27): 1 when x0 violates a trajectory bound at step 0 (reference quirk Q5),
     2 when the Hessian is not positive definite (negative weights)."""
