@@ -5,6 +5,7 @@
 #include "../../include/copra_hip.h"
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
+#include "lmpc_large.hpp"
 #include "plan_builder.hpp"
 #include "qp_dense.hpp"
 #include "qp_dense_large.hpp"
@@ -65,6 +66,9 @@ __global__ __launch_bounds__(64) void copra_islmpc_fused_kernel(const FusedPlan 
 }
 
 __global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
+
+// more than 64 decision variables: one MPC instance per workgroup (lmpc_large.hpp), persistent grid over the batch
+__global__ __launch_bounds__(kLargeMaxN) void copra_lmpc_large_kernel(const FusedPlan P) { lmpc_large_body(P); }
 
 // n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
@@ -132,6 +136,8 @@ struct copra_batch {
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
     int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
+    double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
+    int large_grid = 0;
     // InitialStateLMPC variant
     double *d_isR = nullptr, *d_isr = nullptr, *d_x0opt = nullptr, *own_x0lb = nullptr, *own_x0ub = nullptr;
     const double *x0lb = nullptr, *x0ub = nullptr;
@@ -177,11 +183,19 @@ static FusedPlan device_plan(const copra_batch* h)
     P.ovf_count = h->d_ovf_count;
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
+    P.ws = h->d_ws;
     return P;
 }
 
 static copra_status_t ensure_lds_attr(copra_batch* h)
 {
+    if (h->hp.large) {
+        if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_lmpc_large_kernel),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
+        h->lds_attr_set = true;
+        return COPRA_OK;
+    }
     const size_t need = h->hp.lds_full_bytes > h->hp.lds_bytes ? h->hp.lds_full_bytes : h->hp.lds_bytes;
     if (!h->lds_attr_set && need > 48 * 1024) {
         const void* fn = h->hp.plan.initial_state ? reinterpret_cast<const void*>(copra_islmpc_fused_kernel)
@@ -273,6 +287,10 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         chk(upload(&h->d_isr, h->hp.isr));
         chk(hipMalloc((void**)&h->d_x0opt, b * P.nx * sizeof(double)));
     }
+    if (h->hp.large) {
+        h->large_grid = large_grid(P.batch > 0 ? P.batch : 1, P.large.threads, h->hp.lds_bytes);
+        chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
+    }
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
@@ -312,6 +330,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_x0opt);
     (void)hipFree(h->own_x0lb);
     (void)hipFree(h->own_x0ub);
+    (void)hipFree(h->d_ws);
     (void)hipFree(h->d_ovf_count);
     (void)hipFree(h->d_ovf_list);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -388,6 +407,14 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
+    if (h->hp.large) {
+        hipLaunchKernelGGL(copra_lmpc_large_kernel, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+            h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+        return COPRA_OK;
+    }
     if (P.initial_state) {
         hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
@@ -513,7 +540,10 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     P.lds = h->hp.lds_full;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    if (P.initial_state)
+    if (h->hp.large)
+        hipLaunchKernelGGL(copra_lmpc_large_kernel, dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
+            h->last_stream, P);
+    else if (P.initial_state)
         hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
     else
         hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);

@@ -20,12 +20,6 @@
 
 namespace copra_hip {
 
-constexpr int kNB = 8; // panel width of the blocked Cholesky factorisation / triangular inversion
-constexpr int kLargeMaxN = 512; // thread = row: workgroup size = n rounded up to a wave, at most 512 threads
-constexpr int kLargeMaxWaves = kLargeMaxN / kWave;
-
-inline int large_ld(int n) { return (n + 7) & ~7; }
-
 struct LargeSolver {
     int n, ld;
     double* J; // global, n x ld
@@ -35,34 +29,6 @@ struct LargeSolver {
     int *act, *iact;
 };
 
-// `o` = first free double; returns the first free double after the solver regions
-inline int layout_large_solver(LargeLds& L, int o, int n, int mgen, int meq, int mtotal)
-{
-    auto take = [&](int count) {
-        int at = o;
-        o += (count + 1) & ~1;
-        return at;
-    };
-    L.xs = take(n);
-    L.cv = take(n);
-    L.np = take(n);
-    L.dv = take(n);
-    L.rv = take(n);
-    L.uv = take(n + 2);
-    L.hv = take(n);
-    L.coef = take(4 * n);
-    L.nb = take(mgen > 0 ? mgen : 1);
-    L.eqsgn = take(meq > 0 ? meq : 1);
-    L.red = take(4 * kLargeMaxWaves + 4);
-    L.stage = take(kNB * n);
-    L.dblk = take(kNB * kNB);
-    L.act = take((mtotal + 1) / 2 + 1);
-    L.iact = take((n + 2) / 2 + 1);
-    L.total = o;
-    return o;
-}
-
-#ifdef COPRA_DEV
 COPRA_DEV LargeSolver carve_large(double* lds, const LargeLds& L, int n, double* J, double* F)
 {
     LargeSolver S;
@@ -549,55 +515,128 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             }
             if (drop) {
                 bt_sync();
-                // ---- drop the it1-th active constraint ----
+                // ---- drop the it1-th active constraint: columns it1+1 .. last of R move one place to the left after
+                // the Givens rotations q = it1 .. last-1 on rows (q, q+1) of R / columns (q, q+1) of J.  Only the
+                // rotation COEFFICIENTS are sequential (rotation q is defined by column q+1 after rotation q-1), so:
+                //   1. rows < it1 of R just shift (thread = row);
+                //   2. thread = column keeps the running row-q element of its column in a register, prefetches the
+                //      next 8 rows of its column per HBM round trip, and column q+1 publishes (a, b) through LDS:
+                //      one barrier per rotation, no memory round trip; the coefficients are kept in LDS;
+                //   3. J is updated in ONE coalesced sweep over columns it1 .. last (thread = row), like an add step.
+                const int last = nact - 1;
                 if (tid == 0) S.act[S.iact[it1]] = 0;
-                for (int q = it1; q < nact - 1; ++q) {
-                    bt_sync();
-                    const double a = R[(size_t)(q + 1) * ld + q]; // R(q, q+1)
-                    const double b = R[(size_t)(q + 1) * ld + q + 1]; // R(q+1, q+1)
-                    bool rot = false;
-                    double gc = 1.0, gs = 0.0, nu_ = 0.0;
-                    if (b != 0.0) {
-                        const double big = fmax(fabs(a), fabs(b)), small = fmin(fabs(a), fabs(b));
-                        const double tg = copysign(big * sqrt(1.0 + (small / big) * (small / big)), a);
-                        gc = a / tg;
-                        gs = b / tg;
-                        if (gc != 1.0) {
-                            rot = true;
-                            nu_ = gs / (1.0 + gc);
-                        }
+                if (tid < it1) {
+                    int c = it1 + 1;
+                    for (; c + 3 <= last; c += 4) {
+                        double v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = R[(size_t)(c + u) * ld + tid];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) R[(size_t)(c + u - 1) * ld + tid] = v[u];
                     }
-                    bt_sync();
-                    if (rot) {
-                        // rows q, q+1 of R for columns q+1 .. nact-1 (thread = column)
-                        const int c = q + 1 + tid;
-                        if (c < nact) {
-                            const double x = R[(size_t)c * ld + q], y = R[(size_t)c * ld + q + 1];
-                            const double t = gc * x + gs * y;
-                            R[(size_t)c * ld + q + 1] = nu_ * (x + t) - y;
-                            R[(size_t)c * ld + q] = t;
+                    for (; c <= last; ++c) R[(size_t)(c - 1) * ld + tid] = R[(size_t)c * ld + tid];
+                }
+                {
+                    const int c = tid;
+                    const bool colact = (c > it1 && c <= last);
+                    double x = colact ? R[(size_t)c * ld + it1] : 0.0;
+                    for (int q0 = it1; q0 < last; q0 += 8) {
+                        double yb[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int row = q0 + 1 + u;
+                            yb[u] = (colact && row <= c) ? R[(size_t)c * ld + row] : 0.0;
                         }
-                        // columns q, q+1 of J (thread = row)
-                        if (own) {
-                            const double x = J[(size_t)q * ld + tid], y = J[(size_t)(q + 1) * ld + tid];
-                            const double t = gc * x + gs * y;
-                            J[(size_t)(q + 1) * ld + tid] = nu_ * (x + t) - y;
-                            J[(size_t)q * ld + tid] = t;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int q = q0 + u;
+                            if (q < last) {
+                                const double y = yb[u];
+                                double* slot = S.red + 2 * (q & 1);
+                                if (c == q + 1) {
+                                    slot[0] = x; // R(q, q+1) after the previous rotation
+                                    slot[1] = y; // R(q+1, q+1)
+                                }
+                                bt_sync();
+                                const double a = slot[0], b = slot[1];
+                                bool rot = false;
+                                double gc = 1.0, gs = 0.0, nu_ = 0.0;
+                                if (b != 0.0) {
+                                    const double big = fmax(fabs(a), fabs(b)), small = fmin(fabs(a), fabs(b));
+                                    const double tg = copysign(big * sqrt(1.0 + (small / big) * (small / big)), a);
+                                    gc = a / tg;
+                                    gs = b / tg;
+                                    if (gc != 1.0) {
+                                        rot = true;
+                                        nu_ = gs / (1.0 + gc);
+                                    }
+                                }
+                                if (tid == 0) {
+                                    S.coef[4 * q + 0] = gc;
+                                    S.coef[4 * q + 1] = gs;
+                                    S.coef[4 * q + 2] = nu_;
+                                    S.coef[4 * q + 3] = rot ? 1.0 : 0.0;
+                                }
+                                if (colact && c >= q + 1) {
+                                    double t = x, yn = y;
+                                    if (rot) {
+                                        t = gc * x + gs * y;
+                                        yn = nu_ * (x + t) - y;
+                                    }
+                                    R[(size_t)(c - 1) * ld + q] = t;
+                                    x = yn;
+                                }
+                            }
                         }
-                    }
-                    bt_sync();
-                    // shift column q+1 (rows 0..q) into column q
-                    if (tid <= q) R[(size_t)q * ld + tid] = R[(size_t)(q + 1) * ld + tid];
-                    if (tid == 0) {
-                        S.uv[q] = S.uv[q + 1];
-                        S.iact[q] = S.iact[q + 1];
                     }
                 }
-                bt_sync();
-                if (tid == 0) {
-                    S.uv[nact - 1] = S.uv[nact];
-                    S.uv[nact] = 0.0;
-                    S.iact[nact - 1] = 0;
+                // multipliers and the index list move with their columns
+                double uvn = 0.0;
+                int ian = 0;
+                if (tid >= it1 && tid <= last) {
+                    uvn = S.uv[tid + 1];
+                    ian = (tid < last) ? S.iact[tid + 1] : 0;
+                }
+                bt_sync(); // also publishes the rotation coefficients
+                if (tid >= it1 && tid <= last) {
+                    S.uv[tid] = uvn;
+                    S.iact[tid] = ian;
+                }
+                if (tid == 0) S.uv[nact] = 0.0;
+                if (own && it1 < last) {
+                    double x = J[(size_t)it1 * ld + tid];
+                    int q = it1;
+                    for (; q + 3 < last; q += 4) {
+                        double yv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) yv[u] = J[(size_t)(q + 1 + u) * ld + tid];
+                        double tv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double* cf = S.coef + 4 * (q + u);
+                            double t = x, yn = yv[u];
+                            if (cf[3] != 0.0) {
+                                t = cf[0] * x + cf[1] * yv[u];
+                                yn = cf[2] * (x + t) - yv[u];
+                            }
+                            tv[u] = t;
+                            x = yn;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) J[(size_t)(q + u) * ld + tid] = tv[u];
+                    }
+                    for (; q < last; ++q) {
+                        const double y = J[(size_t)(q + 1) * ld + tid];
+                        const double* cf = S.coef + 4 * q;
+                        double t = x, yn = y;
+                        if (cf[3] != 0.0) {
+                            t = cf[0] * x + cf[1] * y;
+                            yn = cf[2] * (x + t) - y;
+                        }
+                        J[(size_t)q * ld + tid] = t;
+                        x = yn;
+                    }
+                    J[(size_t)last * ld + tid] = x;
                 }
                 nact -= 1;
                 iter_drop += 1;
@@ -607,6 +646,5 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
         }
     }
 }
-#endif // COPRA_DEV
 
 } // namespace copra_hip

@@ -1,0 +1,430 @@
+// lmpc_large.hpp -- "condense + solve" for problems with more than 64 decision variables (up to 512): one MPC
+// instance per WORKGROUP, thread = row of J, persistent grid over the batch.  Covers LMPC (src/LMPC.cpp:79-101) and
+// InitialStateLMPC (src/InitialStateLMPC.cpp:52-128), e.g. BASELINE config 5 (xDim 12, uDim 6, 50 steps: 312
+// variables) and the 300-step fixtures of the reference's tests (tests/systems.h).
+//
+// Same construction as lmpc_fused.hpp / islmpc_fused.hpp -- Psi stays implicit (first block column G_k = A^k B in
+// LDS), the Hessian is built by prefix sums along its block diagonals, constraints stay implicit rows -- but
+//   * the n x n matrices (Hessian -> factor -> R, and J) live in the workgroup's HBM workspace (gi_large.hpp);
+//   * Phi_k (and M Phi_k, E, E Jq of the InitialStateLMPC variant) live there too: they are touched once per instance
+//     or with workgroup-uniform addresses, LDS keeps what every iteration gathers from (G, the trajectory, vectors);
+//   * InitialStateLMPC: Q is built twice (once alone for E Q^-1 E' = (E Jq)(E Jq)', once at its place in the
+//     (nx + n)^2 Hessian) instead of being copied inside the workspace.
+// Full-size COST entries are not covered here (plan_builder.hpp rejects them); full-size constraint entries are.
+#pragma once
+
+#include "gi_large.hpp"
+#include "lmpc_fused.hpp"
+
+namespace copra_hip {
+
+// Implicit rows at workgroup level; the coefficient algebra is StageRows<0,0,0>'s (thread-level functions only).
+struct LargeRows {
+    const FusedPlan& P;
+    StageRows<0, 0, 0> base;
+    const double* Phi; // HBM: (N+1) blocks nx x nx
+    const double* Xi; // LDS
+    const double* x0ub; // this instance (InitialStateLMPC)
+    const double* x0lb;
+    int off; // nx for InitialStateLMPC (decision vector [x0; U]), else 0
+
+    COPRA_DEV int nx() const { return P.nx; }
+    COPRA_DEV int nvar() const { return off + P.n; }
+
+    COPRA_DEV double coeff(const RowDesc& d, int j) const
+    {
+        if (j >= off) return base.coeff(d, j - off);
+        const int a = j, k = d.k, eo = d.eo, nPhi = nx() * nx(); // x0 part: Y_row = E_row Phi_k
+        double v = 0.0;
+        if (d.ek == kEOneHot) {
+            v = Phi[k * nPhi + eo + nx() * a];
+        } else if (d.ek == kEDense) {
+            for (int c = 0; c < nx(); ++c) v += P.params[eo + c] * Phi[k * nPhi + c + nx() * a];
+        } else if (d.ek == kEFull) {
+            for (int s = 0; s <= P.N; ++s)
+                for (int c = 0; c < nx(); ++c) v += P.params[eo + s * nx() + c] * Phi[s * nPhi + c + nx() * a];
+        }
+        return v;
+    }
+    COPRA_DEV double norm2(const RowDesc& d) const
+    {
+        if (off == 0) return base.norm2(d);
+        double s = 0.0;
+        for (int j = 0; j < nvar(); ++j) {
+            const double a = coeff(d, j);
+            s += a * a;
+        }
+        return s;
+    }
+    // X = Phi x0 + xi + Psi U at the current iterate (x0 = the variable for InitialStateLMPC, folded in Xbar otherwise)
+    COPRA_DEV void refresh_trajectory(const double* xs) const
+    {
+        const int nPhi = nx() * nx(), nu = P.nu, T = bt_size();
+        for (int row = bt_tid(); row < P.X; row += T) {
+            const int k = row / nx(), comp = row - k * nx();
+            double a0;
+            if (off) {
+                a0 = Xi[row];
+                for (int a = 0; a < nx(); ++a) a0 += Phi[k * nPhi + comp + nx() * a] * xs[a];
+            } else {
+                a0 = base.Xbar[row];
+            }
+            const double* g = base.G + comp + (k - 1) * nx() * nu;
+            for (int jb = 0; jb < k; ++jb)
+                for (int jc = 0; jc < nu; ++jc) a0 += g[-jb * nx() * nu + nx() * jc] * xs[off + jb * nu + jc];
+            base.Xcur[row] = a0;
+        }
+    }
+    COPRA_DEV void begin_scan(const double* xs) const
+    {
+        if (P.any_state_rows || off) refresh_trajectory(xs);
+        bt_sync();
+    }
+    COPRA_DEV double slack(int i, const double* xs) const
+    {
+        const RowDesc d = base.load_desc(i);
+        const double ax = base.lhs(d, base.Xcur, xs + off);
+        return (i < P.meq) ? (ax - d.f) : (d.f - ax);
+    }
+    COPRA_DEV double slack_uniform(int p, const double* xs) const { return slack(uniform_i32(p), xs); }
+    COPRA_DEV double norm(int i) const { return base.nb[i]; }
+    COPRA_DEV double ub(int j) const { return (j < off) ? x0ub[j] : P.ub[j - off]; }
+    COPRA_DEV double lb(int j) const { return (j < off) ? x0lb[j] : P.lb[j - off]; }
+    COPRA_DEV void load_normal(int p, double sgn, double* np) const
+    {
+        const int j = bt_tid();
+        if (j >= nvar()) return;
+        const RowDesc d = base.load_desc(uniform_i32(p));
+        const double v = coeff(d, j);
+        np[j] = (p < P.meq) ? sgn * v : -v;
+    }
+};
+
+// Hessian of the U block (lower triangle, placed at rows / columns qoff.. of F) and, when `linear`, the linear terms:
+//   LMPC:              cj += c_j                                   (costFunctions.cpp:78-80, 106, 152-155, 211-213)
+//   InitialStateLMPC:  cj += f_j and Ecol[a] += E(a, j)            (InitialStateLMPC.cpp:82-83)
+// thread j < n owns column j = (block, component) of the linear terms and walks block diagonal `block` of Q.
+COPRA_DEV void large_costs(const FusedPlan& P, double* lds, double* F, int ld, int qoff, bool linear, const double* G,
+    const double* Xbar, const double* Xi, const double* Phi, double* MPhi, double& cj, double* Ecol)
+{
+    const LargeLayout& L = P.large;
+    const int tid = bt_tid(), T = bt_size();
+    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n;
+    const bool is = P.initial_state != 0;
+    const int nPhi = nx * nx;
+    double* Y = lds + L.Y;
+    double* We = lds + L.We;
+    double* Cp = lds + L.Cp;
+    const int blk = tid / nu, sub = tid - blk * nu;
+    double* Q = F + (size_t)qoff * ld + qoff;
+    if (tid < n) {
+        double one = 1.0;
+        one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;  (LMPC.cpp:228-229)
+        Q[(size_t)tid * ld + tid] = one;
+    }
+    for (int t = 0; t < P.ncost; ++t) {
+        const CostTerm& ct = P.cost[t];
+        const int r = ct.rows;
+        bt_sync();
+        double* Mx = Cp;
+        double* Nm = Cp + r * nx;
+        double* p = Nm + r * nu;
+        double* w = p + r;
+        for (int e = tid; e < r * nx; e += T) Mx[e] = (ct.offM >= 0) ? P.params[ct.offM + e] : 0.0;
+        for (int e = tid; e < r * nu; e += T) Nm[e] = (ct.offN >= 0) ? P.params[ct.offN + e] : 0.0;
+        for (int e = tid; e < r; e += T) {
+            p[e] = P.params[ct.offP + e];
+            w[e] = P.params[ct.offW + e];
+        }
+        bt_sync();
+        if (ct.kind == kCostControl) { // ControlCost::update (costFunctions.cpp:148-156): block-diagonal N'WN
+            if (tid < n) {
+                for (int i2 = 0; i2 < nu; ++i2) {
+                    double acc = 0.0;
+                    for (int k = 0; k < r; ++k) acc += (Nm[k + r * i2] * w[k]) * Nm[k + r * sub];
+                    Q[(size_t)(blk * nu + i2) * ld + tid] += acc;
+                }
+                if (linear) {
+                    double acc = 0.0;
+                    for (int k = 0; k < r; ++k) acc += ((-p[k]) * w[k]) * Nm[k + r * sub];
+                    cj += acc;
+                }
+            }
+            continue;
+        }
+        const bool mixed = (ct.kind == kCostMixed);
+        for (int e = tid; e < N * r * nu; e += T) { // Y_k = M G_k
+            const int k = e / (r * nu), rem = e - k * r * nu;
+            const int jc = rem / r, row = rem - jc * r;
+            const double* Gk = G + k * nx * nu + nx * jc;
+            double acc = 0.0;
+            for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Gk[c];
+            Y[e] = acc;
+        }
+        if (linear) {
+            const double* xfree = is ? Xi : Xbar; // We_k = w .* (M xbar_k - p), InitialStateLMPC: w .* (M xi_k - p)
+            for (int e = tid; e < (N + 1) * r; e += T) {
+                const int k = e / r, row = e - k * r;
+                double acc = 0.0;
+                for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * xfree[k * nx + c];
+                We[e] = (acc - p[row]) * w[row];
+            }
+            if (is) {
+                for (int e = tid; e < (N + 1) * r * nx; e += T) { // MPhi_k = M Phi_k (costFunctions.cpp:77)
+                    const int k = e / (r * nx), rem = e - k * r * nx;
+                    const int a = rem / r, row = rem - a * r;
+                    double acc = 0.0;
+                    for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Phi[k * nPhi + c + nx * a];
+                    MPhi[e] = acc;
+                }
+            }
+        }
+        bt_sync();
+        const int K = mixed ? N - 1 : N; // last state index that enters the sum (target: only K = N)
+        const bool accumulate = (ct.kind != kCostTarget);
+        if (tid < n) {
+            const int delta = blk, ic = sub;
+            double val[kMaxNu], cross[kMaxNu];
+#pragma unroll
+            for (int jc = 0; jc < kMaxNu; ++jc) val[jc] = cross[jc] = 0.0;
+            if (mixed) { // step k = b of MixedCost (costFunctions.cpp:207)
+                for (int jc = 0; jc < nu; ++jc) {
+                    double acc = 0.0;
+                    if (delta > 0) {
+                        const double* Ya = Y + (delta - 1) * r * nu + r * ic;
+                        for (int k = 0; k < r; ++k) acc += (Ya[k] * w[k]) * Nm[k + r * jc];
+                    } else {
+                        for (int k = 0; k < r; ++k) acc += (Nm[k + r * ic] * w[k]) * Nm[k + r * jc];
+                    }
+                    cross[jc] = acc;
+                }
+            }
+            for (int b = N - 1; b >= delta; --b) {
+                const int a = b - delta, m = K - 1 - b;
+#pragma unroll
+                for (int jc = 0; jc < kMaxNu; ++jc) {
+                    if (jc < nu) {
+                        double pterm = 0.0;
+                        if (m >= 0) {
+                            const double* Ya = Y + (m + delta) * r * nu + r * ic;
+                            const double* Yb = Y + m * r * nu + r * jc;
+                            for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
+                        }
+                        val[jc] = accumulate ? val[jc] + pterm : pterm;
+                        Q[(size_t)(a * nu + ic) * ld + b * nu + jc] += mixed ? val[jc] + cross[jc] : val[jc];
+                    }
+                }
+            }
+            if (linear) {
+                // column j = (b, jc): steps in ascending order; tmp_k(:, j) = N (k == b, mixed) or Y_{k-1-b}
+                const int b = blk, jc = sub;
+                const int k_lo = (ct.kind == kCostTarget) ? N : (mixed ? b : b + 1);
+                for (int k = k_lo; k <= K; ++k) {
+                    const double* tk = (k == b) ? (Nm + r * jc) : (Y + (k - 1 - b) * r * nu + r * jc);
+                    double sf = 0.0;
+                    for (int q = 0; q < r; ++q) sf += We[k * r + q] * tk[q];
+                    cj += sf;
+                    if (is) {
+                        for (int a = 0; a < nx; ++a) {
+                            double se = 0.0;
+                            for (int q = 0; q < r; ++q) se += (MPhi[k * r * nx + q + r * a] * w[q]) * tk[q];
+                            Ecol[a] += se;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    bt_sync();
+}
+
+COPRA_DEV void lmpc_large_body(const FusedPlan& P)
+{
+    double* lds = lds_base();
+    const LargeLayout& L = P.large;
+    const int tid = bt_tid(), T = bt_size();
+    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X;
+    const bool is = P.initial_state != 0;
+    const int off = is ? nx : 0, nv = n + off;
+    const int ld = L.ld;
+    double* ws = P.ws + (size_t)instance_id() * L.ws_total;
+    double* F = ws + L.wsF;
+    double* Jg = ws + L.wsJ;
+    double* Phi = ws + L.wsPhi;
+    double* MPhi = ws + L.wsMPhi;
+    double* Eg = ws + L.wsE;
+    double* Tg = ws + L.wsT;
+    double* A = lds + L.A;
+    double* B = lds + L.B;
+    double* D = lds + L.D;
+    double* X0 = lds + L.X0;
+    double* G = lds + L.G;
+    double* Xi = lds + L.Xi;
+    double* Xbar = lds + L.Xbar;
+    double* Xcur = lds + L.Xcur;
+    double* PP = lds + L.PhiPP;
+    double* TL = lds + L.TL;
+    LargeSolver S = carve_large(lds, L.sol, nv, Jg, F);
+    const int nPhi = nx * nx, nG = nx * nu;
+
+    for (int inst = P.inst_offset + instance_id(); inst < P.batch; inst += instance_stride()) {
+        // ---- 0. this instance's system ----
+        for (int e = tid; e < nPhi; e += T) A[e] = P.A[(size_t)inst * nPhi + e];
+        for (int e = tid; e < nG; e += T) B[e] = P.B[(size_t)inst * nG + e];
+        for (int e = tid; e < nx; e += T) {
+            D[e] = P.d[(size_t)inst * nx + e];
+            X0[e] = P.x0[(size_t)inst * nx + e];
+        }
+        bt_sync();
+        // ---- 1. preview recursion (PreviewSystem.cpp:57-74): G_s = A G_{s-1}, Phi_s = A Phi_{s-1}, xi_s = A xi_{s-1} + d
+        for (int e = tid; e < nPhi; e += T) {
+            const double v = (e % nx == e / nx) ? 1.0 : 0.0; // Phi_0 = I (:51)
+            PP[e] = v;
+            Phi[e] = v;
+        }
+        for (int e = tid; e < nG; e += T) G[e] = B[e]; // Psi_{1,0} = B (:60)
+        for (int e = tid; e < nx; e += T) {
+            Xi[e] = 0.0;
+            Xbar[e] = X0[e];
+        }
+        bt_sync();
+        const int per_step = nx * (nx + nu + 1);
+        for (int s = 1; s <= N; ++s) {
+            const double* Pprev = PP + ((s - 1) & 1) * nPhi;
+            double* Pcur = PP + (s & 1) * nPhi;
+            for (int e = tid; e < per_step; e += T) {
+                const int c = e / nx, r = e - c * nx;
+                if (c < nx) { // Phi_s (:59, :64)
+                    double acc = 0.0;
+                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * Pprev[c * nx + t];
+                    Pcur[c * nx + r] = acc;
+                    Phi[(size_t)s * nPhi + c * nx + r] = acc;
+                } else if (c < nx + nu) { // G_s = A G_{s-1} (:65); G_{N} is not needed
+                    if (s < N) {
+                        const double* src = G + (s - 1) * nG + (c - nx) * nx;
+                        double acc = 0.0;
+                        for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * src[t];
+                        G[s * nG + (c - nx) * nx + r] = acc;
+                    }
+                } else { // xi_s = A xi_{s-1} + d (:61, :70)
+                    const double* src = Xi + (s - 1) * nx;
+                    double acc = 0.0;
+                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * src[t];
+                    Xi[s * nx + r] = acc + D[r];
+                }
+            }
+            bt_sync();
+            for (int r = tid; r < nx; r += T) { // free response  xbar_s = Phi_s x0 + xi_s
+                double acc = 0.0;
+                for (int c = 0; c < nx; ++c) acc += Pcur[r + nx * c] * X0[c];
+                Xbar[s * nx + r] = acc + Xi[s * nx + r];
+            }
+        }
+        bt_sync();
+        // ---- 2. Hessian and linear term (LMPC.cpp:228-230, 252-255; InitialStateLMPC.cpp:77-122) ----
+        if (tid < ld)
+            for (int c = 0; c < nv; ++c) F[(size_t)c * ld + tid] = 0.0;
+        bt_sync();
+        double cj = 0.0;
+        double Ecol[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) Ecol[a] = 0.0;
+        large_costs(P, lds, F, ld, 0, true, G, Xbar, Xi, Phi, MPhi, cj, Ecol);
+        int status = 0;
+        if (is) {
+            // E -> HBM; Q = Lq Lq', Jq = Lq^-T; T = E Jq; top-left = R + T T'
+            if (tid < n)
+                for (int a = 0; a < nx; ++a) Eg[(size_t)a * n + tid] = Ecol[a];
+            bt_sync();
+            LargeSolver Sq = S;
+            Sq.n = n;
+            status = gl_factorize(Sq);
+            if (status == 0) {
+                gl_invert(Sq);
+                for (int a = 0; a < nx; ++a) {
+                    if (tid < n) S.np[tid] = Eg[(size_t)a * n + tid];
+                    bt_sync();
+                    gl_matvec_t(Sq, Jg, S.np, Tg + (size_t)a * n);
+                    bt_sync();
+                }
+                double Tj[16];
+#pragma unroll
+                for (int a = 0; a < 16; ++a) Tj[a] = (a < nx && tid < n) ? Tg[(size_t)a * n + tid] : 0.0;
+                for (int a = 0; a < nx; ++a)
+                    for (int b2 = a; b2 < nx; ++b2) {
+                        const double sab = block_sum(Tj[a] * Tj[b2], S.red);
+                        if (tid == 0) TL[a + nx * b2] = P.is_R[a + nx * b2] + sab;
+                    }
+            }
+            bt_sync();
+            // the (nx + n)^2 Hessian: Q again at its place, E' below the top-left block
+            if (tid < ld)
+                for (int c = 0; c < nv; ++c) F[(size_t)c * ld + tid] = 0.0;
+            bt_sync();
+            double dummy = 0.0;
+            large_costs(P, lds, F, ld, nx, false, G, Xbar, Xi, Phi, MPhi, dummy, Ecol);
+            if (tid < n)
+                for (int a = 0; a < nx; ++a) F[(size_t)a * ld + nx + tid] = Ecol[a]; // row nx + j, column a
+            if (tid < nx)
+                for (int b2 = tid; b2 < nx; ++b2) F[(size_t)tid * ld + b2] = TL[tid + nx * b2]; // row b2 >= column tid
+            bt_sync();
+            if (tid < nx) S.cv[tid] = P.is_r[tid];
+            if (tid < n) S.cv[nx + tid] = cj;
+        } else {
+            if (tid < n) S.cv[tid] = cj;
+        }
+        bt_sync();
+        // ---- 3. implicit rows: norms; parity hook ----
+        StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0 };
+        LargeRows rows { P, base, Phi, Xi,
+            is ? (P.x0ub ? P.x0ub + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr,
+            is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off };
+        for (int i = tid; i < P.mgen; i += T) S.nb[i] = sqrt(rows.norm2(base.load_desc(i)));
+        if (inst == P.dump_instance && P.dumpQ) { // LMPC::Q() c() Aeq() ... (LMPC.h:112-127)
+            if (tid < nv) {
+                for (int i = 0; i < nv; ++i)
+                    P.dumpQ[(size_t)tid * nv + i] = (i >= tid) ? F[(size_t)tid * ld + i] : F[(size_t)i * ld + tid];
+                P.dumpc[tid] = S.cv[tid];
+            }
+            for (int i = tid; i < P.mgen; i += T) {
+                const RowDesc d = base.load_desc(i);
+                for (int j = 0; j < nv; ++j) P.dumpA[(size_t)j * P.mgen + i] = rows.coeff(d, j);
+                P.dumpb[i] = d.f - base.lhs(d, is ? Xi : Xbar, nullptr); // b = z - Y x0 (constraints.cpp:80-81)
+            }
+        }
+        bt_sync();
+        if (P.dump_only) return; // copra_batch_dump_qp: one workgroup, one instance
+        // ---- 4. + 5. solve ----
+        int it_main = 0, it_drop = 0;
+        if (status == 0) status = gl_factorize(S);
+        if (status == 0) {
+            gl_invert(S);
+            gl_unconstrained(S);
+            status = gl_active_set(S, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
+        }
+        bt_sync();
+        // ---- 6. results (LMPC.cpp:95-97, 282-286; InitialStateLMPC.cpp:124-128) ----
+        if (status == 0) {
+            rows.refresh_trajectory(S.xs);
+            bt_sync();
+            for (int e = tid; e < n; e += T) P.control[(size_t)inst * n + e] = S.xs[off + e];
+            for (int e = tid; e < X; e += T) P.trajectory[(size_t)inst * X + e] = Xcur[e];
+            if (is)
+                for (int e = tid; e < nx; e += T) P.x0_opt[(size_t)inst * nx + e] = S.xs[e];
+        } else {
+            const double qnan = __builtin_nan("");
+            for (int e = tid; e < n; e += T) P.control[(size_t)inst * n + e] = qnan;
+            for (int e = tid; e < X; e += T) P.trajectory[(size_t)inst * X + e] = qnan;
+            if (is)
+                for (int e = tid; e < nx; e += T) P.x0_opt[(size_t)inst * nx + e] = qnan;
+        }
+        if (tid == 0) {
+            P.status[inst] = status;
+            P.iter[2 * (size_t)inst] = it_main;
+            P.iter[2 * (size_t)inst + 1] = it_drop;
+        }
+        bt_sync();
+    }
+}
+
+} // namespace copra_hip

@@ -89,6 +89,65 @@ struct IsLayout {
     int MPhi; // (N+1) blocks r x nx
 };
 
+// LDS regions of the workgroup-per-instance solver (gi_large.hpp), offsets in doubles
+struct LargeLds {
+    int xs, cv, np, dv, rv, uv, hv, coef, nb, eqsgn, red, stage, dblk, act, iact, total;
+};
+
+constexpr int kNB = 8; // panel width of the blocked Cholesky factorisation / triangular inversion
+constexpr int kLargeMaxN = 512; // thread = row: workgroup size = n rounded up to a wave, at most 512 threads
+constexpr int kLargeMaxWaves = kLargeMaxN / kWave;
+
+inline int large_ld(int n) { return (n + 7) & ~7; }
+
+// `o` = first free double; returns the first free double after the solver regions
+inline int layout_large_solver(LargeLds& L, int o, int n, int mgen, int meq, int mtotal)
+{
+    auto take = [&](int count) {
+        int at = o;
+        o += (count + 1) & ~1;
+        return at;
+    };
+    L.xs = take(n);
+    L.cv = take(n);
+    L.np = take(n);
+    L.dv = take(n);
+    L.rv = take(n);
+    L.uv = take(n + 2);
+    L.hv = take(n);
+    L.coef = take(4 * n);
+    L.nb = take(mgen > 0 ? mgen : 1);
+    L.eqsgn = take(meq > 0 ? meq : 1);
+    L.red = take(4 * kLargeMaxWaves + 4);
+    L.stage = take(kNB * n);
+    L.dblk = take(kNB * kNB);
+    L.act = take((mtotal + 1) / 2 + 1);
+    L.iact = take((n + 2) / 2 + 1);
+    L.total = o;
+    return o;
+}
+
+// Workgroup-per-instance LMPC / InitialStateLMPC kernel (lmpc_large.hpp; 64 < decision variables <= 512).
+// LDS offsets in doubles; the cost-phase tables (Y, We, Cp) alias the solver regions, which are not live yet.
+struct LargeLayout {
+    int A, B, D, X0; // system matrices of this instance
+    int G; // N blocks G_k = A^k B
+    int Xi, Xbar, Xcur; // fullXDim each
+    int PhiPP; // two nx x nx blocks: Phi_{s-1}, Phi_s of the preview recursion
+    int TL; // nx x nx: top-left Hessian block of the InitialStateLMPC variant
+    int Y, We, Cp; // cost tables (see LdsLayout)
+    LargeLds sol;
+    int total; // LDS doubles
+    int threads; // workgroup size: number of QP variables rounded up to a wave
+    int ld; // leading dimension of F / J
+    // per-workgroup HBM workspace, offsets in doubles
+    long long wsF, wsJ; // nv x ld each
+    long long wsPhi; // (N+1) blocks nx x nx
+    long long wsMPhi; // (N+1) blocks rmax x nx   (InitialStateLMPC)
+    long long wsE, wsT; // nx x n each              (InitialStateLMPC)
+    long long ws_total;
+};
+
 struct FusedPlan {
     // dimensions
     int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
@@ -144,14 +203,13 @@ struct FusedPlan {
     int* ovf_count; // device counter (reset before every solve)
     int* ovf_list; // [batch] instance ids
     int from_list; // ... and the second launch (full layout) takes its instances from that queue
+    // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
+    int use_large;
+    LargeLayout large;
+    double* ws; // [resident workgroups][large.ws_total]
     long long* prof;
     long long* prof_fine; // profiling builds only (-DCOPRA_FINE_PROFILE): 32 raw stamps per instance
     LdsLayout lds;
-};
-
-// LDS regions of the workgroup-per-instance solver (gi_large.hpp), offsets in doubles
-struct LargeLds {
-    int xs, cv, np, dv, rv, uv, hv, coef, nb, eqsgn, red, stage, dblk, act, iact, total;
 };
 
 // dense batched QP kernel (plug-in point 1): plain SolverInterface::SI_solve arguments, batch-major

@@ -30,6 +30,7 @@ struct HostPlan {
     bool two_tier = false;
     LdsLayout lds_full {};
     size_t lds_full_bytes = 0;
+    bool large = false; // more than 64 decision variables: workgroup-per-instance kernel (lmpc_large.hpp)
 };
 
 // qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
@@ -384,9 +385,58 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     P.max_iter = 50 * (nvar + P.mtotal) + 100;
 
     // fused-kernel limits
-    if (nvar > kWave) {
-        hp.error = "more than 64 decision variables are not covered by the one-wave fused kernel";
-        return COPRA_ERR_UNSUPPORTED;
+    P.use_large = 0;
+    if (nvar > kWave) { // workgroup-per-instance kernel: J / R in HBM (lmpc_large.hpp)
+        if (nvar > kLargeMaxN) return hp.error = "more than 512 decision variables are not covered", COPRA_ERR_UNSUPPORTED;
+        if (nu > kMaxNu) return hp.error = "uDim > 8 is not covered", COPRA_ERR_UNSUPPORTED;
+        if (is && nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;
+        if (P.rfull > 0)
+            return hp.error = "full-size cost entries with more than 64 decision variables are not covered", COPRA_ERR_UNSUPPORTED;
+        LargeLayout& L = P.large;
+        int o = 0;
+        auto take = [&](int count) {
+            int at = o;
+            o += align2(count);
+            return at;
+        };
+        L.A = take(nx * nx);
+        L.B = take(nx * nu);
+        L.D = take(nx);
+        L.X0 = take(nx);
+        L.G = take(N * nx * nu);
+        L.Xi = take(X);
+        L.Xbar = take(X);
+        L.Xcur = take(X);
+        L.PhiPP = take(2 * nx * nx);
+        L.TL = take(nx * nx);
+        const int sol0 = o;
+        const int sol_end = layout_large_solver(L.sol, sol0, nvar, P.mgen, P.meq, P.mtotal);
+        o = sol0; // the cost tables alias the solver regions
+        L.Y = take(N * P.rmax * nu);
+        L.We = take((N + 1) * P.rmax);
+        L.Cp = take(P.rmax * (nx + nu + 2));
+        L.total = o > sol_end ? o : sol_end;
+        L.threads = (nvar + kWave - 1) & ~(kWave - 1);
+        L.ld = large_ld(nvar);
+        long long w = 0;
+        auto wtake = [&](long long count) {
+            long long at = w;
+            w += (count + 7) & ~7LL;
+            return at;
+        };
+        L.wsF = wtake((long long)nvar * L.ld);
+        L.wsJ = wtake((long long)nvar * L.ld);
+        L.wsPhi = wtake((long long)(N + 1) * nx * nx);
+        L.wsMPhi = wtake(is ? (long long)(N + 1) * P.rmax * nx : 0);
+        L.wsE = wtake(is ? (long long)nx * U : 0);
+        L.wsT = wtake(is ? (long long)nx * U : 0);
+        L.ws_total = w;
+        hp.lds_bytes = hp.lds_full_bytes = (size_t)L.total * sizeof(double);
+        if (hp.lds_bytes > 160u * 1024u) return hp.error = "problem does not fit the 160 KiB LDS of one CU", COPRA_ERR_UNSUPPORTED;
+        hp.two_tier = false;
+        hp.large = true;
+        P.use_large = 1;
+        return COPRA_OK;
     }
     if (is) {
         if (nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;

@@ -4,6 +4,7 @@
 
 #include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
+#include "../../copra_amd/csrc/lmpc_large.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
 #include "../../copra_amd/csrc/qp_dense_large.hpp"
@@ -171,6 +172,22 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[5] = P.lds.rcap;
     }
     if (!A) return 0; // size query only
+    if (P.use_large) { // workgroup-per-instance kernel: one resident workgroup walks the batch (persistent grid)
+        std::vector<double> ws((size_t)P.large.ws_total + 8, __builtin_nan(""));
+        P.ws = ws.data();
+        if (dump_instance >= 0) {
+            P.inst_offset = dump_instance; // as copra_batch_dump_qp launches it
+            P.dump_only = 1;
+        }
+        int r = emu::run_block([&]() { lmpc_large_body(P); }, hp.lds_bytes, 0, 1, P.large.threads);
+        if (r == 0 && dump_instance >= 0) { // ... followed by the ordinary solve
+            P.inst_offset = 0;
+            P.dump_only = 0;
+            P.dump_instance = -1;
+            r = emu::run_block([&]() { lmpc_large_body(P); }, hp.lds_bytes, 0, 1, P.large.threads);
+        }
+        return r != 0 ? -100 : 0;
+    }
     if (P.initial_state) {
         for (int b = 0; b < dims->batch; ++b) {
             int r = emu::run_wave([&]() { islmpc_fused_body(P, b); }, hp.lds_bytes, b, dims->batch);

@@ -155,3 +155,19 @@ def random_dense_qp(rng, n, meq, mineq, tight=0.3):
     Ain = rng.standard_normal((mineq, n))
     return dict(Q=Q, c=c, Aeq=Aeq, beq=Aeq @ xf, Aineq=Ain, bineq=Ain @ xf + tight * rng.random(mineq),
                 XL=xf - 0.5 * rng.random(n) - 0.05, XU=xf + 0.5 * rng.random(n) + 0.05)
+
+
+def nine_class_problem(N):
+    """All four cost classes and all five constraint classes (per-step entries) on the falling-mass system of
+    systems.h:42-90 -- a well-conditioned counterpart of initial_state_problem() for long horizons"""
+    T, mass, A, B, d = _falling_mass(N)
+    costs = [dict(kind="trajectory", M=np.eye(2), p=[0.0, -1.0], weights=[10.0, 100.0]),
+             dict(kind="target", M=[[1.0, 0.5]], p=[0.2], weights=[50.0]),
+             dict(kind="control", N=[[1.0]], p=[2.0], weights=[1e-3]),
+             dict(kind="mixed", M=[[0.0, 1.0]], N=[[0.01]], p=[-0.5], weights=[2.0])]
+    cstrs = [dict(kind="trajectory", E=[[1.0, 0.2]], f=[0.05]),
+             dict(kind="control", G=[[1.0]], f=[150.0]),
+             dict(kind="mixed", E=[[0.0, 1.0]], G=[[0.002]], f=[0.1]),
+             dict(kind="trajectory_bound", lower=[-INF, -INF], upper=[0.02, 0.5]),  # (reference quirk Q1: no lower rows)
+             dict(kind="control_bound", lower=[-20.0], upper=[200.0])]
+    return dict(A=A, B=B, d=d, x0=np.array([0.0, -5.0]), N=N, costs=costs, cstrs=cstrs)

@@ -169,6 +169,41 @@ def test_dense_qp_large_kernel_body(emu, oracle):
     assert fail[0] == 1 and oracle.quadprog_dense(P["Q"], P["c"], Aeq, beq, None, None, P["XL"], P["XU"])[1] == 1
 
 
+@pytest.mark.parametrize("system,xcost", [("bounded", "trajectory"), ("ineq", "mixed"), ("mixed", "trajectory"),
+                                          ("eq", "target")])
+def test_large_lmpc_reference_fixtures(emu, oracle, system, xcost):
+    """More than 64 decision variables (N = 70 on the systems.h fixtures): the workgroup-per-instance kernel body
+    (lmpc_large.hpp + gi_large.hpp) builds the same QP and takes the same active-set path as the oracle"""
+    pb = getattr(F, system + "_system")(xcost, N=70)
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], dump_instance=0)
+    qp = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert np.abs(re["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+    assert np.abs(re["c"] - qp["c"]).max() <= 1e-11 * max(1.0, np.abs(qp["c"]).max())
+    for k in ("Aeq", "Aineq", "beq", "bineq"):
+        if qp[k].size:
+            assert np.abs(re[k] - qp[k]).max() <= 1e-10 * max(1.0, np.abs(qp[k]).max())
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    assert re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+    assert _rel(re["trajectory"][0], ro["trajectory"]) <= RTOL
+
+
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_large_nine_classes(emu, oracle, initial_state):
+    """All nine cost / constraint classes at N = 70 through the workgroup-per-instance body, as LMPC and as
+    InitialStateLMPC (72 variables [x0; U]: Q is factorised for E Q^-1 E', then the full Hessian)"""
+    pb = F.nine_class_problem(70)
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"] - 0.05, x0ub=pb["x0"] + 0.05) \
+        if initial_state else None
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist)
+    assert re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+    assert _rel(re["trajectory"][0], ro["trajectory"]) <= RTOL
+    if initial_state:
+        assert _rel(re["x0_opt"][0], ro["x0_opt"]) <= RTOL
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi

@@ -338,3 +338,92 @@ def test_initial_state_lmpc_on_gpu(oracle):
                            initial_state=dict(R=ist["R"], r=ist["r"], x0lb=-np.ones(2), x0ub=np.ones(2)))
     assert np.abs(got["Q"] - qb["Q"]).max() <= 1e-9 * np.abs(qb["Q"]).max()
     assert np.array_equal(got["lb"], qb["lb"]) and np.array_equal(got["ub"], qb["ub"])
+
+
+@pytest.mark.parametrize("system", ["bounded", "ineq", "mixed", "eq"])
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_reference_fixtures_full_horizon(oracle, system, xcost):
+    """The twelve {cost} x {constraint} combinations of tests/TestLMPC.cpp at the reference's OWN horizon (nbStep = 300,
+    systems.h:45): 300 decision variables -> the workgroup-per-instance kernel.  Solution vs the oracle, and the
+    reference's own acceptance checks (TestLMPC.cpp:60-78 etc.: bounds respected, target reached)."""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    pb = getattr(F, system + "_system")(xcost, N=300)
+    b = 3
+    eng = BatchLMPC(2, 1, 300, b, pb["costs"], pb["cstrs"])
+    x0 = np.tile(pb["x0"], (b, 1))
+    if system != "eq":
+        x0[1:, 1] += [0.5, -0.5]
+    eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0)
+    eng.solve()
+    res = eng.results()
+    for k in range(b):
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 300, pb["costs"], pb["cstrs"])
+        assert res["status"][k] == ro["status"] == 0
+        assert tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert _rel(res["control"][k], ro["control"]) <= 1e-6
+        assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
+    u, tr = res["control"][0], res["trajectory"][0].reshape(301, 2)
+    if system in ("bounded", "ineq"):
+        assert tr[:, 1].max() <= pb["v_upper"] + 1e-6 and u.max() <= pb["u_upper"] + 1e-6
+    if system == "eq":
+        assert np.abs(tr[:, 0]).max() <= 1e-6 and np.abs(u[:-1] - pb["u_expected"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_nine_classes_long_horizon(oracle, initial_state):
+    """All nine cost / constraint classes at N = 150 (LMPC: 150 variables, InitialStateLMPC: 152) vs the oracle"""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    pb = F.nine_class_problem(150)
+    b = 4
+    rng = np.random.default_rng(5)
+    x0 = np.tile(pb["x0"], (b, 1)) + 0.1 * rng.standard_normal((b, 2))
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2])) if initial_state else None
+    eng = BatchLMPC(2, 1, 150, b, pb["costs"], pb["cstrs"], initial_state=ist)
+    eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0)
+    if initial_state:
+        eng.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
+    eng.solve()
+    res = eng.results()
+    for k in range(b):
+        io = dict(ist, x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05) if initial_state else None
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 150, pb["costs"], pb["cstrs"], initial_state=io)
+        assert res["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(res["iter"][k]) == tuple(ro["iter"])
+            assert _rel(res["control"][k], ro["control"]) <= 1e-6
+            assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
+            if initial_state:
+                assert _rel(eng.initial_state()[k], ro["x0_opt"]) <= 1e-6
+
+
+def test_config5_long_horizon_initial_state(oracle):
+    """BASELINE config 5: InitialStateLMPC (nx=12, nu=6, N=50; 312 variables, 50 equality + 456 inequality rows + 624
+    bound rows) -- a few instances against the oracle, and the QP matrices of one of them"""
+    from copra_amd import BatchLMPC, workloads
+    b = 6
+    wl = workloads.long_horizon_initial_state(b)
+    ist = wl["initial_state"]
+    eng = BatchLMPC(12, 6, wl["N"], b, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
+    eng.solve()
+    res = eng.results()
+    x0o = eng.initial_state()
+    for k in range(b):
+        io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"],
+                               initial_state=io)
+        assert res["status"][k] == ro["status"] == 0
+        assert _rel(res["control"][k], ro["control"]) <= 1e-6
+        assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
+        assert _rel(x0o[k], ro["x0_opt"]) <= 1e-6
+    qp = eng.dump_qp(2)
+    io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][2], x0ub=ist["x0ub"][2])
+    qo = oracle.lmpc_build(wl["A"][2], wl["B"][2], wl["d"][2], wl["x0"][2], wl["N"], wl["costs"], wl["cstrs"],
+                           initial_state=io)
+    assert np.abs(qp["Q"] - qo["Q"]).max() <= 1e-9 * np.abs(qo["Q"]).max()
+    assert np.abs(qp["c"] - qo["c"]).max() <= 1e-9 * max(1.0, np.abs(qo["c"]).max())
+    for key in ("Aeq", "Aineq", "beq", "bineq"):
+        assert np.abs(qp[key] - qo[key]).max() <= 1e-10 * max(1.0, np.abs(qo[key]).max())
