@@ -11,6 +11,7 @@
 #include "qp_dense_large.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,19 +82,32 @@ namespace {
 thread_local std::string g_err;
 
 // persistent grid of the workgroup-per-instance kernels: as many workgroups as the device keeps resident
-int large_grid(int batch, int threads, size_t lds_bytes)
+int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
 {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    int per_cu = (int)((160u * 1024u) / (lds_bytes ? lds_bytes : 1));
-    const int by_threads = 2048 / threads;
-    if (per_cu > by_threads) per_cu = by_threads;
-    if (per_cu < 1) per_cu = 1;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
     if (per_cu > 4) per_cu = 4;
+    if (const char* force = std::getenv("COPRA_LARGE_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
+    if (std::getenv("COPRA_DEBUG"))
+        fprintf(stderr, "[copra] large grid: %d CUs x %d workgroups of %d threads, %zu B LDS\n", cus, per_cu, threads, lds_bytes);
     const long long g = (long long)cus * per_cu;
     return (int)(g < batch ? g : batch);
+}
+
+typedef void (*large_kernel_t)(const FusedPlan);
+large_kernel_t select_large_kernel(const HostPlan& hp)
+{
+    // (one variant today.  Measured on MI355X: a second resident workgroup per CU -- a 168-VGPR build -- leaves the
+    //  throughput unchanged: with every CU streaming its own J the kernel is bound by HBM bandwidth, not by latency.)
+    (void)hp;
+    return copra_lmpc_large_kernel;
 }
 
 copra_status_t fail(copra_status_t code, const std::string& msg)
@@ -191,7 +205,7 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
 {
     if (h->hp.large) {
         if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_lmpc_large_kernel),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_large_kernel(h->hp)),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
         h->lds_attr_set = true;
         return COPRA_OK;
@@ -288,7 +302,11 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         chk(hipMalloc((void**)&h->d_x0opt, b * P.nx * sizeof(double)));
     }
     if (h->hp.large) {
-        h->large_grid = large_grid(P.batch > 0 ? P.batch : 1, P.large.threads, h->hp.lds_bytes);
+        if (h->hp.lds_bytes > 48 * 1024) // (the occupancy query below needs the attribute as well)
+            chk(hipFuncSetAttribute(reinterpret_cast<const void*>(select_large_kernel(h->hp)),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
+        h->large_grid = large_grid(reinterpret_cast<const void*>(select_large_kernel(h->hp)), P.batch > 0 ? P.batch : 1,
+            P.large.threads, h->hp.lds_bytes);
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
@@ -408,7 +426,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
-        hipLaunchKernelGGL(copra_lmpc_large_kernel, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+        hipLaunchKernelGGL(select_large_kernel(h->hp), dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
             h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev1, s));
@@ -541,7 +559,7 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     if (h->hp.large)
-        hipLaunchKernelGGL(copra_lmpc_large_kernel, dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
+        hipLaunchKernelGGL(select_large_kernel(h->hp), dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
             h->last_stream, P);
     else if (P.initial_state)
         hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
@@ -714,7 +732,7 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.iter = diter;
     if (large) {
         const int threads = (n + kWave - 1) & ~(kWave - 1);
-        const int grid = large_grid(batch, threads, lds_bytes);
+        const int grid = large_grid(reinterpret_cast<const void*>(copra_qp_dense_large_kernel), batch, threads, lds_bytes);
         double* ws = nullptr;
         e = hipMalloc((void**)&ws, (size_t)grid * 2 * n * large_ld(n) * sizeof(double));
         if (e != hipSuccess) {

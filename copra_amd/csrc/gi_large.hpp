@@ -26,8 +26,34 @@ struct LargeSolver {
     double* F; // global, n x ld
     // LDS
     double *xs, *cv, *np, *dv, *rv, *uv, *hv, *coef, *nb, *eqsgn, *red, *stage, *dblk;
-    int *act, *iact;
+    unsigned char* act; // one flag per constraint row
+    int* iact;
+    long long* fine; // profiling builds: 16 accumulated shader-clock counters of this instance (or nullptr)
 };
+
+// sub-phases of the active-set loop, accumulated over the iterations (profiling builds only)
+enum { kLpScan = 0, kLpNormal, kLpD, kLpZ, kLpTri, kLpStep, kLpAdd, kLpDrop, kLpPartial, kLpCount };
+#ifdef COPRA_FINE_PROFILE
+#define COPRA_LPROF_DECL                                                                                              \
+    long long lprof[kLpCount];                                                                                        \
+    for (int k_ = 0; k_ < kLpCount; ++k_) lprof[k_] = 0;                                                               \
+    long long lprof_last = cycle_counter()
+#define COPRA_LPROF(k)                                                                                                \
+    do {                                                                                                              \
+        const long long now_ = cycle_counter();                                                                       \
+        lprof[k] += now_ - lprof_last;                                                                                \
+        lprof_last = now_;                                                                                            \
+    } while (0)
+#define COPRA_LPROF_FLUSH                                                                                             \
+    do {                                                                                                              \
+        if (S.fine && bt_tid() == 0)                                                                                  \
+            for (int k_ = 0; k_ < kLpCount; ++k_) S.fine[k_] = lprof[k_];                                              \
+    } while (0)
+#else
+#define COPRA_LPROF_DECL
+#define COPRA_LPROF(k)
+#define COPRA_LPROF_FLUSH
+#endif
 
 COPRA_DEV LargeSolver carve_large(double* lds, const LargeLds& L, int n, double* J, double* F)
 {
@@ -49,8 +75,9 @@ COPRA_DEV LargeSolver carve_large(double* lds, const LargeLds& L, int n, double*
     S.red = lds + L.red;
     S.stage = lds + L.stage;
     S.dblk = lds + L.dblk;
-    S.act = (int*)(lds + L.act);
+    S.act = (unsigned char*)(lds + L.act);
     S.iact = (int*)(lds + L.iact);
+    S.fine = nullptr;
     return S;
 }
 
@@ -118,39 +145,66 @@ COPRA_DEV double block_suffix_sum(double v, double* red)
     return v + add;
 }
 
-// out[c] = sum_r J[r, c] v[r] for c in [0, n): one wave per group of four columns, lanes stride the rows
-COPRA_DEV void gl_matvec_t(const LargeSolver& S, const double* M, const double* v, double* out)
+// out[c] = sum_{r < rlim} M[r, c] v[r] for c in [0, n): one wave per group of four columns, lanes stride the rows.
+// All loads of a group (4 columns x up to 8 row chunks) are issued before the first FMA: the passes over J are
+// latency-bound with the few waves a workgroup has unless many loads are in flight per lane.
+COPRA_DEV void gl_matvec_t(const LargeSolver& S, const double* M, const double* v, double* out, int rlim)
 {
     const int n = S.n, ld = S.ld, lane = bt_lane();
     const int nw = bt_nwaves();
-    for (int c0 = 4 * bt_wave(); c0 < n; c0 += 4 * nw) {
-        double p[4] = { 0.0, 0.0, 0.0, 0.0 };
-        const int cn = (n - c0 < 4) ? n - c0 : 4;
-        for (int r = lane; r < n; r += kWave) {
-            const double a = v[r];
+    const int nch = (rlim + kWave - 1) / kWave; // <= 8 (n <= 512)
+    double vr[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < cn) p[u] += M[(size_t)(c0 + u) * ld + r] * a;
+    for (int ch = 0; ch < 8; ++ch) {
+        const int r = lane + kWave * ch;
+        vr[ch] = (ch < nch && r < rlim) ? v[r] : 0.0;
+    }
+    for (int c0 = 4 * bt_wave(); c0 < n; c0 += 4 * nw) {
+        const int cn = (n - c0 < 4) ? n - c0 : 4;
+        double a[4][8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int r = lane + kWave * ch;
+            const bool live = (ch < nch) && (r < rlim);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u][ch] = (live && u < cn) ? M[(size_t)(c0 + u) * ld + r] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double s = wave_sum(p[u]);
-            if (lane == 0 && u < cn) out[c0 + u] = s;
+            double p = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) p += a[u][ch] * vr[ch];
+            p = wave_sum(p);
+            if (lane == 0 && u < cn) out[c0 + u] = p;
         }
     }
 }
-// sum_{c in [c0, n)} J[row, c] v[c] for the calling thread's row (0 for threads beyond n)
+// sum_{c in [c0, n)} M[row, c] v[c] for the calling thread's row (0 for threads beyond n); 16 loads in flight
 COPRA_DEV double gl_matvec_n(const LargeSolver& S, const double* M, const double* v, int c0)
 {
     const int n = S.n, ld = S.ld, row = bt_tid();
     if (row >= n) return 0.0;
     double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
     int c = c0;
+    for (; c + 15 < n; c += 16) {
+        double a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = M[(size_t)(c + u) * ld + row];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            z0 += a[u] * v[c + u];
+            z1 += a[u + 1] * v[c + u + 1];
+            z2 += a[u + 2] * v[c + u + 2];
+            z3 += a[u + 3] * v[c + u + 3];
+        }
+    }
     for (; c + 3 < n; c += 4) {
-        z0 += M[(size_t)c * ld + row] * v[c];
-        z1 += M[(size_t)(c + 1) * ld + row] * v[c + 1];
-        z2 += M[(size_t)(c + 2) * ld + row] * v[c + 2];
-        z3 += M[(size_t)(c + 3) * ld + row] * v[c + 3];
+        const double a0 = M[(size_t)c * ld + row], a1 = M[(size_t)(c + 1) * ld + row];
+        const double a2 = M[(size_t)(c + 2) * ld + row], a3 = M[(size_t)(c + 3) * ld + row];
+        z0 += a0 * v[c];
+        z1 += a1 * v[c + 1];
+        z2 += a2 * v[c + 2];
+        z3 += a3 * v[c + 3];
     }
     for (; c < n; ++c) z0 += M[(size_t)c * ld + row] * v[c];
     return (z0 + z1) + (z2 + z3);
@@ -271,7 +325,7 @@ COPRA_DEV void gl_invert(const LargeSolver& S)
 // Unconstrained minimiser xs = -Q^-1 c = -J (J' c); c in S.cv.  Leaves the workgroup synchronised.
 COPRA_DEV void gl_unconstrained(const LargeSolver& S)
 {
-    gl_matvec_t(S, S.J, S.cv, S.dv);
+    gl_matvec_t(S, S.J, S.cv, S.dv, S.n);
     bt_sync();
     const double x = gl_matvec_n(S, S.J, S.dv, 0);
     if (bt_tid() < S.n) S.xs[bt_tid()] = -x;
@@ -280,10 +334,12 @@ COPRA_DEV void gl_unconstrained(const LargeSolver& S)
 
 // ---- the active-set iteration.  Rows policy (workgroup-level):
 //   void   begin_scan(const double* xs)                 cooperative; may synchronise
-//   double slack(int i, const double* xs)               thread-level: row i (stacking order, equalities first)
+//   double slack_at(int pass, int i, const double* xs)  thread-level: row i = tid + pass * T (stacking order, equalities
+//                                                       first); `pass` lets the policy keep its first rows in registers
 //   double slack_uniform(int i, const double* xs)       cooperative, uniform result
 //   double norm(int i)
 //   void   load_normal(int i, double sgn, double* np)   cooperative: np[0..n) = sgn * row (eq) / -row (ineq); caller syncs
+//   int    normal_extent(int i)                         uniform: entries of that normal at or past it are zero
 //   double ub(int j), lb(int j)
 // Returns 0 optimal, 1 infeasible, 3 iteration limit.
 template <class Rows>
@@ -303,16 +359,20 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
     for (int i = tid; i <= n + 1; i += T) S.uv[i] = 0.0;
     const double ubj = own ? rows.ub(tid) : 0.0, lbj = own ? rows.lb(tid) : 0.0;
     bt_sync();
+    COPRA_LPROF_DECL;
 
     for (;;) {
-        if (iter_main >= max_iter) return 3;
+        if (iter_main >= max_iter) {
+            COPRA_LPROF_FLUSH;
+            return 3;
+        }
         iter_main += 1;
         // ---------------- step 1: most violated constraint ----------------
         rows.begin_scan(S.xs);
         double best = 0.0, best_s = 0.0;
         int best_i = -1;
-        for (int i = tid; i < mgen; i += T) { // general rows (equalities first)
-            double s = rows.slack(i, S.xs);
+        for (int i = tid, pass = 0; i < mgen; i += T, ++pass) { // general rows (equalities first)
+            double s = rows.slack_at(pass, i, S.xs);
             if (i < meq) {
                 const double sg = S.eqsgn[i];
                 s = sg * s;
@@ -350,8 +410,12 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             }
         }
         block_argmin(best, best_i, best_s, S.red);
+        COPRA_LPROF(kLpScan);
         const int nvl = best_i;
-        if (nvl < 0) return 0; // optimal
+        if (nvl < 0) {
+            COPRA_LPROF_FLUSH;
+            return 0; // optimal
+        }
         double sv_nvl = best_s;
 
         // ---------------- step 2 ----------------
@@ -359,15 +423,24 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             if (nvl < mgen) {
                 const double sgn = (nvl < meq) ? S.eqsgn[nvl] : 1.0;
                 rows.load_normal(nvl, sgn, S.np);
-            } else if (own) { // rows of -[I; -I]: -e_j for an upper bound, +e_j for a lower bound
+                bt_sync();
+                COPRA_LPROF(kLpNormal);
+                gl_matvec_t(S, J, S.np, S.dv, rows.normal_extent(nvl)); // d = J' n+ (rows past the extent are zero)
+            } else { // rows of -[I; -I]: -e_j for an upper bound, +e_j for a lower bound -> d = -/+ row j of J
                 const int q = nvl - mgen;
-                S.np[tid] = (q < n) ? ((tid == q) ? -1.0 : 0.0) : ((tid == q - n) ? 1.0 : 0.0);
+                const int jq = (q < n) ? q : q - n;
+                const double sg = (q < n) ? -1.0 : 1.0;
+                if (own) {
+                    S.np[tid] = (tid == jq) ? sg : 0.0;
+                    S.dv[tid] = sg * J[(size_t)tid * ld + jq];
+                }
+                COPRA_LPROF(kLpNormal);
             }
             bt_sync();
-            gl_matvec_t(S, J, S.np, S.dv); // d = J' n+
-            bt_sync();
+            COPRA_LPROF(kLpD);
             const double dj = own ? S.dv[tid] : 0.0;
             const double zi = gl_matvec_n(S, J, S.dv, nact); // z = J2 d2
+            COPRA_LPROF(kLpZ);
             // r = R^-1 d1: 64-row diagonal blocks are solved inside the wave that owns them (readlane broadcasts),
             // the off-diagonal part is a coalesced column sweep by the rows above
             double acc = (tid < nact) ? dj : 0.0;
@@ -376,20 +449,41 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                 const int lo = blk * kWave;
                 const int hi = (nact < lo + kWave) ? nact : lo + kWave;
                 if (wave == blk) {
-                    for (int c = hi - 1; c >= lo; --c) {
-                        double rc = 0.0;
-                        if (tid == c) rc = acc / R[(size_t)c * ld + c];
-                        rc = bcast_f64(rc, c - lo);
-                        if (tid == c) ri = rc;
-                        if (tid < c) acc -= R[(size_t)c * ld + tid] * rc;
+                    for (int c1 = hi; c1 > lo; c1 -= 16) { // columns c1-1 .. c1-16: one HBM round trip per 16 steps
+                        double col[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int c = c1 - 1 - u;
+                            col[u] = (c >= lo && tid <= c) ? R[(size_t)c * ld + tid] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int c = c1 - 1 - u;
+                            if (c >= lo) {
+                                double rc = 0.0;
+                                if (tid == c) rc = acc / col[u];
+                                rc = bcast_f64(rc, c - lo);
+                                if (tid == c) ri = rc;
+                                if (tid < c) acc -= col[u] * rc;
+                            }
+                        }
                     }
                     if (tid < hi) S.rv[tid] = ri;
                 }
                 bt_sync();
                 if (tid < lo) {
-                    for (int c = lo; c < hi; ++c) acc -= R[(size_t)c * ld + tid] * S.rv[c];
+                    int c = lo;
+                    for (; c + 15 < hi; c += 16) {
+                        double col[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) col[u] = R[(size_t)(c + u) * ld + tid];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc -= col[u] * S.rv[c + u];
+                    }
+                    for (; c < hi; ++c) acc -= R[(size_t)c * ld + tid] * S.rv[c];
                 }
             }
+            COPRA_LPROF(kLpTri);
             // t1 = min u_i / r_i over active inequalities with r_i > 0 (lowest position wins ties)
             double t1 = 0.0;
             int it1 = -1;
@@ -406,7 +500,10 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             bool drop = false;
             if (fabs(zz) <= vsmall) {
                 // no step in primal space
-                if (t1inf) return 1; // infeasible
+                if (t1inf) {
+                    COPRA_LPROF_FLUSH;
+                    return 1; // infeasible
+                }
                 if (tid < nact) S.uv[tid] -= t1 * ri;
                 if (tid == 0) S.uv[nact] += t1;
                 drop = true;
@@ -421,6 +518,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                 if (own) S.xs[tid] += tt * zi;
                 if (tid < nact) S.uv[tid] -= tt * ri;
                 if (tid == 0) S.uv[nact] += tt;
+                COPRA_LPROF(kLpStep);
                 if (t2min) {
                     // ---- full step: constraint nvl becomes active; update R and J ----
                     if (tid < nact) R[(size_t)nact * ld + tid] = dj;
@@ -463,21 +561,21 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                     if (nact + 1 < n && own) {
                         double carry = J[(size_t)(n - 1) * ld + tid];
                         int q = n - 1;
-                        // four rotations per round trip: the loads of a group are issued before its first store
-                        for (; q - 3 > nact; q -= 4) {
-                            double a[4];
+                        // sixteen rotations per round trip: the loads of a group are issued before its first store
+                        for (; q - 15 > nact; q -= 16) {
+                            double a[16];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) a[u] = J[(size_t)(q - 1 - u) * ld + tid];
-                            double wv[4];
+                            for (int u = 0; u < 16; ++u) a[u] = J[(size_t)(q - 1 - u) * ld + tid];
+                            double wv[16];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < 16; ++u) {
                                 const double* cf = S.coef + 4 * (q - u);
                                 const double t = cf[0] * a[u] + cf[1] * carry;
                                 wv[u] = cf[2] * a[u] + cf[3] * carry;
                                 carry = t;
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) J[(size_t)(q - u) * ld + tid] = wv[u];
+                            for (int u = 0; u < 16; ++u) J[(size_t)(q - u) * ld + tid] = wv[u];
                         }
                         for (; q > nact; --q) {
                             const double a = J[(size_t)(q - 1) * ld + tid];
@@ -490,6 +588,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                     }
                     nact += 1;
                     bt_sync();
+                    COPRA_LPROF(kLpAdd);
                     break; // back to step 1
                 } else {
                     // ---- partial step: recompute the slack of nvl, then drop the blocking constraint ----
@@ -511,6 +610,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                     }
                     sv_nvl = s;
                     drop = true;
+                    COPRA_LPROF(kLpPartial);
                 }
             }
             if (drop) {
@@ -527,12 +627,12 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                 if (tid == 0) S.act[S.iact[it1]] = 0;
                 if (tid < it1) {
                     int c = it1 + 1;
-                    for (; c + 3 <= last; c += 4) {
-                        double v[4];
+                    for (; c + 15 <= last; c += 16) {
+                        double v[16];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = R[(size_t)(c + u) * ld + tid];
+                        for (int u = 0; u < 16; ++u) v[u] = R[(size_t)(c + u) * ld + tid];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) R[(size_t)(c + u - 1) * ld + tid] = v[u];
+                        for (int u = 0; u < 16; ++u) R[(size_t)(c + u - 1) * ld + tid] = v[u];
                     }
                     for (; c <= last; ++c) R[(size_t)(c - 1) * ld + tid] = R[(size_t)c * ld + tid];
                 }
@@ -606,13 +706,13 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                 if (own && it1 < last) {
                     double x = J[(size_t)it1 * ld + tid];
                     int q = it1;
-                    for (; q + 3 < last; q += 4) {
-                        double yv[4];
+                    for (; q + 15 < last; q += 16) {
+                        double yv[16];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) yv[u] = J[(size_t)(q + 1 + u) * ld + tid];
-                        double tv[4];
+                        for (int u = 0; u < 16; ++u) yv[u] = J[(size_t)(q + 1 + u) * ld + tid];
+                        double tv[16];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < 16; ++u) {
                             const double* cf = S.coef + 4 * (q + u);
                             double t = x, yn = yv[u];
                             if (cf[3] != 0.0) {
@@ -623,7 +723,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                             x = yn;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) J[(size_t)(q + u) * ld + tid] = tv[u];
+                        for (int u = 0; u < 16; ++u) J[(size_t)(q + u) * ld + tid] = tv[u];
                     }
                     for (; q < last; ++q) {
                         const double y = J[(size_t)(q + 1) * ld + tid];
@@ -641,7 +741,11 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                 nact -= 1;
                 iter_drop += 1;
                 bt_sync();
-                if (iter_drop > max_iter) return 3;
+                COPRA_LPROF(kLpDrop);
+                if (iter_drop > max_iter) {
+                    COPRA_LPROF_FLUSH;
+                    return 3;
+                }
             }
         }
     }

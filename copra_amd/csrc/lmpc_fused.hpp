@@ -41,6 +41,9 @@ struct StageRows {
     const double* nb; // LDS
     RowDesc mine; // descriptor of row `lane` (rows 0..63 are scanned as i == lane): no table look-ups in the loop
     double ub_mine, lb_mine; // XU_lane, XL_lane
+    const double* prm = nullptr; // optional LDS copy of the parameter blob (workgroup-per-instance kernel)
+
+    COPRA_DEV const double* params() const { return prm ? prm : P.params; }
 
     COPRA_DEV int nx() const { return NX_ ? NX_ : P.nx; }
     COPRA_DEV int nu() const { return NU_ ? NU_ : P.nu; }
@@ -83,18 +86,18 @@ struct StageRows {
         } else if (d.ek == kEDense) {
             if (jb < k) {
                 const double* Gk = G + (k - 1 - jb) * nx() * nu() + nx() * jc;
-                for (int c = 0; c < nx(); ++c) v += P.params[eo + c] * Gk[c];
+                for (int c = 0; c < nx(); ++c) v += params()[eo + c] * Gk[c];
             }
         } else if (d.ek == kEFull) {
             for (int s = jb + 1; s <= nh(); ++s) {
                 const double* Gk = G + (s - 1 - jb) * nx() * nu() + nx() * jc;
-                for (int c = 0; c < nx(); ++c) v += P.params[eo + s * nx() + c] * Gk[c];
+                for (int c = 0; c < nx(); ++c) v += params()[eo + s * nx() + c] * Gk[c];
             }
         }
         if (d.gk == kGStep) {
-            if (jb == k) v += P.params[go + jc];
+            if (jb == k) v += params()[go + jc];
         } else if (d.gk == kGFull) {
-            v += P.params[go + j];
+            v += params()[go + j];
         }
         return v;
     }
@@ -129,15 +132,15 @@ struct StageRows {
         if (d.ek == kEOneHot) {
             ax = Xv[k * nx() + eo];
         } else if (d.ek == kEDense) {
-            for (int c = 0; c < nx(); ++c) ax += P.params[eo + c] * Xv[k * nx() + c];
+            for (int c = 0; c < nx(); ++c) ax += params()[eo + c] * Xv[k * nx() + c];
         } else if (d.ek == kEFull) {
-            for (int r = 0; r < xdim(); ++r) ax += P.params[eo + r] * Xv[r];
+            for (int r = 0; r < xdim(); ++r) ax += params()[eo + r] * Xv[r];
         }
         if (u) {
             if (d.gk == kGStep) {
-                for (int c = 0; c < nu(); ++c) ax += P.params[go + c] * u[k * nu() + c];
+                for (int c = 0; c < nu(); ++c) ax += params()[go + c] * u[k * nu() + c];
             } else if (d.gk == kGFull) {
-                for (int j = 0; j < nvar(); ++j) ax += P.params[go + j] * u[j];
+                for (int j = 0; j < nvar(); ++j) ax += params()[go + j] * u[j];
             }
         }
         return ax;

@@ -27,6 +27,7 @@ struct LargeRows {
     const double* x0ub; // this instance (InitialStateLMPC)
     const double* x0lb;
     int off; // nx for InitialStateLMPC (decision vector [x0; U]), else 0
+    RowDesc mine0, mine1; // descriptors of rows tid and tid + T: the scan does not go back to the plan tables for them
 
     COPRA_DEV int nx() const { return P.nx; }
     COPRA_DEV int nvar() const { return off + P.n; }
@@ -39,10 +40,10 @@ struct LargeRows {
         if (d.ek == kEOneHot) {
             v = Phi[k * nPhi + eo + nx() * a];
         } else if (d.ek == kEDense) {
-            for (int c = 0; c < nx(); ++c) v += P.params[eo + c] * Phi[k * nPhi + c + nx() * a];
+            for (int c = 0; c < nx(); ++c) v += base.params()[eo + c] * Phi[k * nPhi + c + nx() * a];
         } else if (d.ek == kEFull) {
             for (int s = 0; s <= P.N; ++s)
-                for (int c = 0; c < nx(); ++c) v += P.params[eo + s * nx() + c] * Phi[s * nPhi + c + nx() * a];
+                for (int c = 0; c < nx(); ++c) v += base.params()[eo + s * nx() + c] * Phi[s * nPhi + c + nx() * a];
         }
         return v;
     }
@@ -80,14 +81,36 @@ struct LargeRows {
         if (P.any_state_rows || off) refresh_trajectory(xs);
         bt_sync();
     }
-    COPRA_DEV double slack(int i, const double* xs) const
+    COPRA_DEV void cache_own_rows()
     {
-        const RowDesc d = base.load_desc(i);
+        const RowDesc none { 0, kENone, 0, kGNone, 0, 0.0 };
+        const int i0 = bt_tid(), i1 = bt_tid() + bt_size();
+        mine0 = (i0 < P.mgen) ? base.load_desc(i0) : none;
+        mine1 = (i1 < P.mgen) ? base.load_desc(i1) : none;
+    }
+    COPRA_DEV double slack_of(const RowDesc& d, int i, const double* xs) const
+    {
         const double ax = base.lhs(d, base.Xcur, xs + off);
         return (i < P.meq) ? (ax - d.f) : (d.f - ax);
     }
+    COPRA_DEV double slack(int i, const double* xs) const { return slack_of(base.load_desc(i), i, xs); }
+    COPRA_DEV double slack_at(int pass, int i, const double* xs) const
+    {
+        if (pass == 0) return slack_of(mine0, i, xs);
+        if (pass == 1) return slack_of(mine1, i, xs);
+        return slack(i, xs);
+    }
     COPRA_DEV double slack_uniform(int p, const double* xs) const { return slack(uniform_i32(p), xs); }
     COPRA_DEV double norm(int i) const { return base.nb[i]; }
+    // a row at step k involves x0 and u_0 .. u_k only (Psi is block lower triangular): its normal ends there
+    COPRA_DEV int normal_extent(int p) const
+    {
+        const int i = uniform_i32(p);
+        if (P.row_ekind[i] == kEFull || P.row_gkind[i] == kGFull) return nvar();
+        const int k = P.row_step[i];
+        const int blocks = (k + 1 < P.N) ? k + 1 : P.N;
+        return off + blocks * P.nu;
+    }
     COPRA_DEV double ub(int j) const { return (j < off) ? x0ub[j] : P.ub[j - off]; }
     COPRA_DEV double lb(int j) const { return (j < off) ? x0lb[j] : P.lb[j - off]; }
     COPRA_DEV void load_normal(int p, double sgn, double* np) const
@@ -242,6 +265,14 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
 {
     double* lds = lds_base();
     const LargeLayout& L = P.large;
+    // the parameter blob (E, G of every constraint) is read in every scan: the row algebra reads an LDS copy of it
+    const double* prm = nullptr;
+    if (L.nparams > 0) {
+        double* pl = lds + L.Params;
+        for (int e = bt_tid(); e < L.nparams; e += bt_size()) pl[e] = P.params[e];
+        prm = pl;
+        bt_sync();
+    }
     const int tid = bt_tid(), T = bt_size();
     const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X;
     const bool is = P.initial_state != 0;
@@ -268,6 +299,11 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
     const int nPhi = nx * nx, nG = nx * nu;
 
     for (int inst = P.inst_offset + instance_id(); inst < P.batch; inst += instance_stride()) {
+        long long stamp[8];
+        stamp[0] = cycle_counter();
+#ifdef COPRA_FINE_PROFILE
+        S.fine = P.prof_fine ? P.prof_fine + 32 * (size_t)inst : nullptr;
+#endif
         // ---- 0. this instance's system ----
         for (int e = tid; e < nPhi; e += T) A[e] = P.A[(size_t)inst * nPhi + e];
         for (int e = tid; e < nG; e += T) B[e] = P.B[(size_t)inst * nG + e];
@@ -285,7 +321,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         for (int e = tid; e < nG; e += T) G[e] = B[e]; // Psi_{1,0} = B (:60)
         for (int e = tid; e < nx; e += T) {
             Xi[e] = 0.0;
-            Xbar[e] = X0[e];
+            if (!is) Xbar[e] = X0[e];
         }
         bt_sync();
         const int per_step = nx * (nx + nu + 1);
@@ -314,13 +350,16 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
                 }
             }
             bt_sync();
-            for (int r = tid; r < nx; r += T) { // free response  xbar_s = Phi_s x0 + xi_s
-                double acc = 0.0;
-                for (int c = 0; c < nx; ++c) acc += Pcur[r + nx * c] * X0[c];
-                Xbar[s * nx + r] = acc + Xi[s * nx + r];
+            if (!is) {
+                for (int r = tid; r < nx; r += T) { // free response  xbar_s = Phi_s x0 + xi_s
+                    double acc = 0.0;
+                    for (int c = 0; c < nx; ++c) acc += Pcur[r + nx * c] * X0[c];
+                    Xbar[s * nx + r] = acc + Xi[s * nx + r];
+                }
             }
         }
         bt_sync();
+        stamp[1] = cycle_counter();
         // ---- 2. Hessian and linear term (LMPC.cpp:228-230, 252-255; InitialStateLMPC.cpp:77-122) ----
         if (tid < ld)
             for (int c = 0; c < nv; ++c) F[(size_t)c * ld + tid] = 0.0;
@@ -344,7 +383,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
                 for (int a = 0; a < nx; ++a) {
                     if (tid < n) S.np[tid] = Eg[(size_t)a * n + tid];
                     bt_sync();
-                    gl_matvec_t(Sq, Jg, S.np, Tg + (size_t)a * n);
+                    gl_matvec_t(Sq, Jg, S.np, Tg + (size_t)a * n, n);
                     bt_sync();
                 }
                 double Tj[16];
@@ -361,24 +400,25 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
             if (tid < ld)
                 for (int c = 0; c < nv; ++c) F[(size_t)c * ld + tid] = 0.0;
             bt_sync();
-            double dummy = 0.0;
-            large_costs(P, lds, F, ld, nx, false, G, Xbar, Xi, Phi, MPhi, dummy, Ecol);
             if (tid < n)
                 for (int a = 0; a < nx; ++a) F[(size_t)a * ld + nx + tid] = Ecol[a]; // row nx + j, column a
-            if (tid < nx)
+            if (tid < nx) // (TL shares LDS with the cost tables: consume it before they are rebuilt)
                 for (int b2 = tid; b2 < nx; ++b2) F[(size_t)tid * ld + b2] = TL[tid + nx * b2]; // row b2 >= column tid
-            bt_sync();
+            double dummy = 0.0;
+            large_costs(P, lds, F, ld, nx, false, G, Xbar, Xi, Phi, MPhi, dummy, Ecol);
             if (tid < nx) S.cv[tid] = P.is_r[tid];
             if (tid < n) S.cv[nx + tid] = cj;
         } else {
             if (tid < n) S.cv[tid] = cj;
         }
         bt_sync();
+        stamp[2] = cycle_counter();
         // ---- 3. implicit rows: norms; parity hook ----
-        StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0 };
+        StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0, prm };
         LargeRows rows { P, base, Phi, Xi,
             is ? (P.x0ub ? P.x0ub + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr,
-            is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off };
+            is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off, RowDesc {}, RowDesc {} };
+        rows.cache_own_rows();
         for (int i = tid; i < P.mgen; i += T) S.nb[i] = sqrt(rows.norm2(base.load_desc(i)));
         if (inst == P.dump_instance && P.dumpQ) { // LMPC::Q() c() Aeq() ... (LMPC.h:112-127)
             if (tid < nv) {
@@ -395,14 +435,19 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         bt_sync();
         if (P.dump_only) return; // copra_batch_dump_qp: one workgroup, one instance
         // ---- 4. + 5. solve ----
+        stamp[3] = cycle_counter();
         int it_main = 0, it_drop = 0;
         if (status == 0) status = gl_factorize(S);
+        stamp[4] = cycle_counter();
+        stamp[5] = stamp[4];
         if (status == 0) {
             gl_invert(S);
             gl_unconstrained(S);
+            stamp[5] = cycle_counter();
             status = gl_active_set(S, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop);
         }
         bt_sync();
+        stamp[6] = cycle_counter();
         // ---- 6. results (LMPC.cpp:95-97, 282-286; InitialStateLMPC.cpp:124-128) ----
         if (status == 0) {
             rows.refresh_trajectory(S.xs);
@@ -422,6 +467,12 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
             P.status[inst] = status;
             P.iter[2 * (size_t)inst] = it_main;
             P.iter[2 * (size_t)inst + 1] = it_drop;
+            if (P.prof) { // preview, costs, norms, cholesky, inverse + x0, active set, results, total
+                stamp[7] = cycle_counter();
+                long long* pr = P.prof + 8 * (size_t)inst;
+                for (int k = 0; k < 7; ++k) pr[k] = stamp[k + 1] - stamp[k];
+                pr[7] = stamp[7] - stamp[0];
+            }
         }
         bt_sync();
     }

@@ -119,9 +119,9 @@ inline int layout_large_solver(LargeLds& L, int o, int n, int mgen, int meq, int
     L.nb = take(mgen > 0 ? mgen : 1);
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.red = take(4 * kLargeMaxWaves + 4);
-    L.stage = take(kNB * n);
+    L.stage = L.np; // kNB * n doubles over np | dv | rv | uv | hv | coef (9n + 2): dead while a factorisation runs
     L.dblk = take(kNB * kNB);
-    L.act = take((mtotal + 1) / 2 + 1);
+    L.act = take((mtotal + 7) / 8 + 1); // one byte per row
     L.iact = take((n + 2) / 2 + 1);
     L.total = o;
     return o;
@@ -133,8 +133,9 @@ struct LargeLayout {
     int A, B, D, X0; // system matrices of this instance
     int G; // N blocks G_k = A^k B
     int Xi, Xbar, Xcur; // fullXDim each
-    int PhiPP; // two nx x nx blocks: Phi_{s-1}, Phi_s of the preview recursion
-    int TL; // nx x nx: top-left Hessian block of the InitialStateLMPC variant
+    int PhiPP; // two nx x nx blocks: Phi_{s-1}, Phi_s of the preview recursion (aliases the solver regions)
+    int TL; // nx x nx: top-left Hessian block of the InitialStateLMPC variant (aliases sol.coef)
+    int Params, nparams; // LDS copy of the parameter blob (nparams == 0: too large, stays in HBM)
     int Y, We, Cp; // cost tables (see LdsLayout)
     LargeLds sol;
     int total; // LDS doubles

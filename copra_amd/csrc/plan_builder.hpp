@@ -405,13 +405,16 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.X0 = take(nx);
         L.G = take(N * nx * nu);
         L.Xi = take(X);
-        L.Xbar = take(X);
+        L.Xbar = is ? L.Xi : take(X); // InitialStateLMPC never uses the free response Phi x0 + xi
         L.Xcur = take(X);
-        L.PhiPP = take(2 * nx * nx);
-        L.TL = take(nx * nx);
+        L.nparams = (hp.params.size() <= 1024) ? (int)hp.params.size() : 0;
+        L.Params = take(L.nparams);
         const int sol0 = o;
         const int sol_end = layout_large_solver(L.sol, sol0, nvar, P.mgen, P.meq, P.mtotal);
-        o = sol0; // the cost tables alias the solver regions
+        L.TL = L.sol.coef; // 4 nvar >= 256 >= nx^2 doubles; free between the two factorisations
+        o = sol0; // the preview ping-pong blocks and the cost tables alias the solver regions
+        L.PhiPP = take(2 * nx * nx);
+        o = sol0;
         L.Y = take(N * P.rmax * nu);
         L.We = take((N + 1) * P.rmax);
         L.Cp = take(P.rmax * (nx + nu + 2));

@@ -27,6 +27,7 @@ struct DenseRowsLarge {
         for (int j = 0; j < n; ++j) ax += coeff(i, j) * xs[j];
         return (i < P.meq) ? ax - beq[i] : bineq[i - P.meq] - ax;
     }
+    COPRA_DEV double slack_at(int, int i, const double* xs) const { return slack(i, xs); }
     COPRA_DEV double slack_uniform(int p, const double* xs) const
     {
         const int j = bt_tid();
@@ -34,6 +35,7 @@ struct DenseRowsLarge {
         return (p < P.meq) ? ax - beq[p] : bineq[p - P.meq] - ax;
     }
     COPRA_DEV double norm(int i) const { return nb[i]; }
+    COPRA_DEV int normal_extent(int) const { return P.n; }
     COPRA_DEV double ub(int j) const { return XU[j]; }
     COPRA_DEV double lb(int j) const { return XL[j]; }
     COPRA_DEV void load_normal(int p, double sgn, double* np) const
