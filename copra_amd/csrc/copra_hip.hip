@@ -104,8 +104,8 @@ int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
 typedef void (*large_kernel_t)(const FusedPlan);
 large_kernel_t select_large_kernel(const HostPlan& hp)
 {
-    // (one variant today.  Measured on MI355X: a second resident workgroup per CU -- a 168-VGPR build -- leaves the
-    //  throughput unchanged: with every CU streaming its own J the kernel is bound by HBM bandwidth, not by latency.)
+    // One variant.  A 168-VGPR build (three waves per SIMD, i.e. two five-wave workgroups per CU) was measured on
+    // MI355X and is not faster (config 5: 2011 vs 2048 solves/s): it pays for the occupancy with scratch spills.
     (void)hp;
     return copra_lmpc_large_kernel;
 }

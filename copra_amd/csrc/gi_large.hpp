@@ -145,8 +145,8 @@ COPRA_DEV double block_suffix_sum(double v, double* red)
     return v + add;
 }
 
-// out[c] = sum_{r < rlim} M[r, c] v[r] for c in [0, n): one wave per group of four columns, lanes stride the rows.
-// All loads of a group (4 columns x up to 8 row chunks) are issued before the first FMA: the passes over J are
+// out[c] = sum_{r < rlim} M[r, c] v[r] for c in [0, n): one wave per pair of columns, lanes stride the rows.
+// All loads of a group (2 columns x up to 8 row chunks) are issued before the first FMA: the passes over J are
 // latency-bound with the few waves a workgroup has unless many loads are in flight per lane.
 COPRA_DEV void gl_matvec_t(const LargeSolver& S, const double* M, const double* v, double* out, int rlim)
 {
@@ -159,23 +159,27 @@ COPRA_DEV void gl_matvec_t(const LargeSolver& S, const double* M, const double* 
         const int r = lane + kWave * ch;
         vr[ch] = (ch < nch && r < rlim) ? v[r] : 0.0;
     }
-    for (int c0 = 4 * bt_wave(); c0 < n; c0 += 4 * nw) {
-        const int cn = (n - c0 < 4) ? n - c0 : 4;
-        double a[4][8];
+    for (int c0 = 2 * bt_wave(); c0 < n; c0 += 2 * nw) {
+        const bool two = (c0 + 1 < n);
+        double a0[8], a1[8];
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             const int r = lane + kWave * ch;
             const bool live = (ch < nch) && (r < rlim);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u][ch] = (live && u < cn) ? M[(size_t)(c0 + u) * ld + r] : 0.0;
+            a0[ch] = live ? M[(size_t)c0 * ld + r] : 0.0;
+            a1[ch] = (live && two) ? M[(size_t)(c0 + 1) * ld + r] : 0.0;
         }
+        double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double p = 0.0;
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) p += a[u][ch] * vr[ch];
-            p = wave_sum(p);
-            if (lane == 0 && u < cn) out[c0 + u] = p;
+        for (int ch = 0; ch < 8; ++ch) {
+            p0 += a0[ch] * vr[ch];
+            p1 += a1[ch] * vr[ch];
+        }
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
+        if (lane == 0) {
+            out[c0] = p0;
+            if (two) out[c0 + 1] = p1;
         }
     }
 }
@@ -241,34 +245,33 @@ COPRA_DEV int gl_factorize(const LargeSolver& S)
             }
         }
         bt_sync();
-        // every thread factorises the kNB x kNB diagonal block (same data -> same result, no broadcast needed)
-        double Ld[kNB][kNB];
-        bool bad = false;
-#pragma unroll
+        // the kNB x kNB diagonal block is factorised in place in LDS: thread i < kNB owns row i; column c is final
+        // after step c (one barrier per column).  dblk[kNB * kNB] flags a non-positive pivot.
+        if (tid == 0) S.dblk[kNB * kNB] = 0.0;
         for (int c = 0; c < kNB; ++c) {
-            double dsum = (c < w) ? S.dblk[c * kNB + c] : 1.0;
-#pragma unroll
-            for (int t = 0; t < c; ++t) dsum -= Ld[c][t] * Ld[c][t];
-            if (!(dsum > 0.0)) bad = true;
-            const double dd = sqrt(dsum);
-            Ld[c][c] = dd;
-#pragma unroll
-            for (int i = c + 1; i < kNB; ++i) {
-                double v = (i < w) ? S.dblk[i * kNB + c] : 0.0;
-#pragma unroll
-                for (int t = 0; t < c; ++t) v -= Ld[i][t] * Ld[c][t];
-                Ld[i][c] = v / dd;
+            if (tid >= c && tid < kNB && c < w && tid < w) {
+                double v = S.dblk[tid * kNB + c];
+                for (int t = 0; t < c; ++t) v -= S.dblk[tid * kNB + t] * S.dblk[c * kNB + t];
+                if (tid == c) {
+                    if (!(v > 0.0)) S.dblk[kNB * kNB] = 1.0;
+                    S.dblk[c * kNB + c] = sqrt(v);
+                } else {
+                    S.dblk[tid * kNB + c] = v; // divided by the pivot after the barrier
+                }
             }
+            bt_sync();
+            if (tid > c && tid < kNB && c < w && tid < w) S.dblk[tid * kNB + c] /= S.dblk[c * kNB + c];
+            bt_sync();
         }
-        if (bad) return 2;
+        if (S.dblk[kNB * kNB] != 0.0) return 2;
         if (mine) {
             double out[kNB];
 #pragma unroll
             for (int c = 0; c < kNB; ++c) {
                 double v = acc[c];
 #pragma unroll
-                for (int t = 0; t < c; ++t) v -= out[t] * Ld[c][t];
-                out[c] = v / Ld[c][c];
+                for (int t = 0; t < c; ++t) v -= out[t] * S.dblk[c * kNB + t];
+                out[c] = (c < w) ? v / S.dblk[c * kNB + c] : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < kNB; ++c)
@@ -566,16 +569,15 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                             double a[16];
 #pragma unroll
                             for (int u = 0; u < 16; ++u) a[u] = J[(size_t)(q - 1 - u) * ld + tid];
-                            double wv[16];
 #pragma unroll
                             for (int u = 0; u < 16; ++u) {
                                 const double* cf = S.coef + 4 * (q - u);
                                 const double t = cf[0] * a[u] + cf[1] * carry;
-                                wv[u] = cf[2] * a[u] + cf[3] * carry;
+                                a[u] = cf[2] * a[u] + cf[3] * carry;
                                 carry = t;
                             }
 #pragma unroll
-                            for (int u = 0; u < 16; ++u) J[(size_t)(q - u) * ld + tid] = wv[u];
+                            for (int u = 0; u < 16; ++u) J[(size_t)(q - u) * ld + tid] = a[u];
                         }
                         for (; q > nact; --q) {
                             const double a = J[(size_t)(q - 1) * ld + tid];
@@ -710,7 +712,6 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                         double yv[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) yv[u] = J[(size_t)(q + 1 + u) * ld + tid];
-                        double tv[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
                             const double* cf = S.coef + 4 * (q + u);
@@ -719,11 +720,11 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
                                 t = cf[0] * x + cf[1] * yv[u];
                                 yn = cf[2] * (x + t) - yv[u];
                             }
-                            tv[u] = t;
+                            yv[u] = t;
                             x = yn;
                         }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) J[(size_t)(q + u) * ld + tid] = tv[u];
+                        for (int u = 0; u < 16; ++u) J[(size_t)(q + u) * ld + tid] = yv[u];
                     }
                     for (; q < last; ++q) {
                         const double y = J[(size_t)(q + 1) * ld + tid];

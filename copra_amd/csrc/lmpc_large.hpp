@@ -401,7 +401,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
                 for (int c = 0; c < nv; ++c) F[(size_t)c * ld + tid] = 0.0;
             bt_sync();
             if (tid < n)
-                for (int a = 0; a < nx; ++a) F[(size_t)a * ld + nx + tid] = Ecol[a]; // row nx + j, column a
+                for (int a = 0; a < nx; ++a) F[(size_t)a * ld + nx + tid] = Eg[(size_t)a * n + tid]; // row nx + j, column a
             if (tid < nx) // (TL shares LDS with the cost tables: consume it before they are rebuilt)
                 for (int b2 = tid; b2 < nx; ++b2) F[(size_t)tid * ld + b2] = TL[tid + nx * b2]; // row b2 >= column tid
             double dummy = 0.0;

@@ -120,7 +120,7 @@ inline int layout_large_solver(LargeLds& L, int o, int n, int mgen, int meq, int
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.red = take(4 * kLargeMaxWaves + 4);
     L.stage = L.np; // kNB * n doubles over np | dv | rv | uv | hv | coef (9n + 2): dead while a factorisation runs
-    L.dblk = take(kNB * kNB);
+    L.dblk = take(kNB * kNB + 2); // + the "pivot not positive" flag
     L.act = take((mtotal + 7) / 8 + 1); // one byte per row
     L.iact = take((n + 2) / 2 + 1);
     L.total = o;
