@@ -56,8 +56,8 @@ COPRA_DEV void qp_dense_large_body(const DensePlan& P)
     LargeSolver S = carve_large(lds, P.llds, n, wsJ, wsF);
     for (int inst = instance_id(); inst < P.batch; inst += instance_stride()) {
         const double* Q = P.Q + (size_t)inst * n * n;
-        if (tid < n) {
-            for (int c = 0; c < n; ++c) S.F[(size_t)c * ld + tid] = Q[(size_t)c * n + tid];
+        if (tid < n) { // only the UPPER triangle of Q is read (as by qp_dense.hpp / qpgen2): L(r, c) <- Q(c, r), c <= r
+            for (int c = 0; c <= tid; ++c) S.F[(size_t)c * ld + tid] = Q[(size_t)tid * n + c];
             S.cv[tid] = P.c[(size_t)inst * n + tid];
         }
         DenseRowsLarge rows { P, P.Aeq + (size_t)inst * P.meq * n, P.beq + (size_t)inst * P.meq,

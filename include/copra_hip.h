@@ -108,7 +108,7 @@ void copra_batch_destroy(copra_batch_t* h);
 
 /* ---- InitialStateLMPC variant (include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp): the decision vector is
  *      [x0; U]; costs contribute E and f, the Hessian is [[R + E Q^-1 E', E], [E', Q]] (InitialStateLMPC.cpp:77-122).
- *      Covered on the device for xDim + fullUDim <= 64 and per-step cost entries; other shapes COPRA_ERR_UNSUPPORTED.
+ *      Covered on the device for xDim + fullUDim <= 512 and per-step cost entries; other shapes COPRA_ERR_UNSUPPORTED.
  *      Initial-state bounds (resetInitialStateBounds, :42-46) are per instance, [batch][nx]; when they are never set
  *      both default to the x0 handed to copra_batch_set_system (InitialStateLMPC.cpp:20-28).
  *      copra_batch_get_initial_state == InitialStateLMPC::initialState() (:30-33), [batch][nx]. ---- */
@@ -165,7 +165,9 @@ copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long
  *      `batch` independent dense QPs  min 1/2 x'Qx + c'x  s.t. Aeq x = beq, Aineq x <= bineq, XL <= x <= XU.
  *      Q [batch][n x n] (upper triangle read), c [batch][n], Aeq [batch][neq x n], beq [batch][neq],
  *      Aineq [batch][nineq x n], bineq [batch][nineq], XL/XU [batch][n]; outputs x [batch][n], fail [batch]
- *      (SI_fail), iter [batch][2].  on_device selects host or device pointers for ALL arrays. ---- */
+ *      (SI_fail), iter [batch][2].  on_device selects host or device pointers for ALL arrays.
+ *      n <= 64: one QP per wavefront, Q/J/R in LDS; 64 < n <= 512: one QP per workgroup, J/R in an HBM workspace
+ *      (the call then allocates that workspace and synchronises the stream); n > 512: COPRA_ERR_UNSUPPORTED. ---- */
 copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, const double* Q, const double* c,
     const double* Aeq, const double* beq, const double* Aineq, const double* bineq, const double* XL,
     const double* XU, double* x, int* fail, int* iter, int on_device, void* hip_stream);

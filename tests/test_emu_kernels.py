@@ -153,7 +153,8 @@ def test_dense_qp_large_kernel_body(emu, oracle):
     for n, meq, mi in [(65, 3, 20), (100, 10, 120)]:
         P = F.random_dense_qp(rng, n, meq, mi)
         xo, fo, ito = oracle.quadprog_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
-        x, fail, it = emu.qp_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+        Qu = np.triu(P["Q"]) + np.tril(np.full_like(P["Q"], np.nan), -1)  # only the upper triangle may be read
+        x, fail, it = emu.qp_dense(Qu, P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
         assert fo == 0 and fail[0] == 0 and tuple(it[0]) == tuple(ito)
         assert np.abs(x[0] - xo).max() <= 1e-10 * (1 + np.abs(xo).max())
     # not positive definite -> 2 ; infeasible (contradictory bounds through an equality) -> 1
