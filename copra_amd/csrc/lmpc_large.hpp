@@ -28,6 +28,8 @@ struct LargeRows {
     const double* x0lb;
     int off; // nx for InitialStateLMPC (decision vector [x0; U]), else 0
     RowDesc mine0, mine1; // descriptors of rows tid and tid + T: the scan does not go back to the plan tables for them
+    double* fulls; // LDS: left-hand sides of the (few) full-size rows, evaluated by the whole workgroup
+    double* red; // LDS scratch of the workgroup reductions
 
     COPRA_DEV int nx() const { return P.nx; }
     COPRA_DEV int nvar() const { return off + P.n; }
@@ -76,10 +78,42 @@ struct LargeRows {
             base.Xcur[row] = a0;
         }
     }
+    COPRA_DEV static bool is_full(const RowDesc& d) { return d.ek == kEFull || d.gk == kGFull; }
+    // E_row . X + G_row . U of a full-size row: a fullXDim (+ fullUDim) long inner product, strided over the workgroup
+    COPRA_DEV double lhs_cooperative(const RowDesc& d, const double* Xv, const double* u) const
+    {
+        const int T = bt_size();
+        double part = 0.0;
+        if (d.ek == kEFull) {
+            for (int r = bt_tid(); r < P.X; r += T) part += base.params()[d.eo + r] * Xv[r];
+        } else if (bt_tid() == 0) {
+            part += base.lhs(RowDesc { d.k, d.ek, d.eo, kGNone, 0, 0.0 }, Xv, nullptr);
+        }
+        if (u) {
+            if (d.gk == kGFull) {
+                for (int j = bt_tid(); j < P.n; j += T) part += base.params()[d.go + j] * u[j];
+            } else if (d.gk == kGStep && bt_tid() == 0) {
+                for (int c = 0; c < P.nu; ++c) part += base.params()[d.go + c] * u[d.k * P.nu + c];
+            }
+        }
+        return block_sum(part, red);
+    }
+    COPRA_DEV int full_slot(int i) const
+    {
+        for (int f = 0; f < kMaxFullRows; ++f)
+            if (f < P.n_full_rows && P.full_row[f] == i) return f;
+        return -1;
+    }
     COPRA_DEV void begin_scan(const double* xs) const
     {
         if (P.any_state_rows || off) refresh_trajectory(xs);
         bt_sync();
+        for (int f = 0; f < P.n_full_rows; ++f) { // (n_full_rows < 0: too many, they stay thread-level)
+            const RowDesc d = base.load_desc(P.full_row[f]);
+            const double ax = lhs_cooperative(d, base.Xcur, xs + off);
+            if (bt_tid() == 0) fulls[f] = ax;
+        }
+        if (P.n_full_rows > 0) bt_sync();
     }
     COPRA_DEV void cache_own_rows()
     {
@@ -90,7 +124,11 @@ struct LargeRows {
     }
     COPRA_DEV double slack_of(const RowDesc& d, int i, const double* xs) const
     {
-        const double ax = base.lhs(d, base.Xcur, xs + off);
+        double ax;
+        if (P.n_full_rows > 0 && is_full(d))
+            ax = fulls[full_slot(i)];
+        else
+            ax = base.lhs(d, base.Xcur, xs + off);
         return (i < P.meq) ? (ax - d.f) : (d.f - ax);
     }
     COPRA_DEV double slack(int i, const double* xs) const { return slack_of(base.load_desc(i), i, xs); }
@@ -100,7 +138,14 @@ struct LargeRows {
         if (pass == 1) return slack_of(mine1, i, xs);
         return slack(i, xs);
     }
-    COPRA_DEV double slack_uniform(int p, const double* xs) const { return slack(uniform_i32(p), xs); }
+    COPRA_DEV double slack_uniform(int p, const double* xs) const // cooperative (the trajectory is current)
+    {
+        const int i = uniform_i32(p);
+        const RowDesc d = base.load_desc(i);
+        if (!is_full(d)) return slack_of(d, i, xs);
+        const double ax = lhs_cooperative(d, base.Xcur, xs + off);
+        return (i < P.meq) ? (ax - d.f) : (d.f - ax);
+    }
     COPRA_DEV double norm(int i) const { return base.nb[i]; }
     // a row at step k involves x0 and u_0 .. u_k only (Psi is block lower triangular): its normal ends there
     COPRA_DEV int normal_extent(int p) const
@@ -417,9 +462,20 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0, prm };
         LargeRows rows { P, base, Phi, Xi,
             is ? (P.x0ub ? P.x0ub + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr,
-            is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off, RowDesc {}, RowDesc {} };
+            is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off, RowDesc {}, RowDesc {},
+            lds + L.FullS, S.red };
         rows.cache_own_rows();
-        for (int i = tid; i < P.mgen; i += T) S.nb[i] = sqrt(rows.norm2(base.load_desc(i)));
+        for (int i = tid; i < P.mgen; i += T) {
+            const RowDesc d = base.load_desc(i);
+            if (P.n_full_rows > 0 && LargeRows::is_full(d)) continue; // below, by the whole workgroup
+            S.nb[i] = sqrt(rows.norm2(d));
+        }
+        for (int f = 0; f < P.n_full_rows; ++f) { // a full-size row: thread j squares its own coefficient
+            const RowDesc d = base.load_desc(P.full_row[f]);
+            const double a = (tid < nv) ? rows.coeff(d, tid) : 0.0;
+            const double s2 = block_sum(a * a, S.red);
+            if (tid == 0) S.nb[P.full_row[f]] = sqrt(s2);
+        }
         if (inst == P.dump_instance && P.dumpQ) { // LMPC::Q() c() Aeq() ... (LMPC.h:112-127)
             if (tid < nv) {
                 for (int i = 0; i < nv; ++i)

@@ -16,6 +16,7 @@
 namespace copra_hip {
 
 constexpr int kMaxCosts = 8;
+constexpr int kMaxFullRows = 16; // full-size constraint rows the workgroup-per-instance kernel evaluates cooperatively
 constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
 constexpr int kWave = 64;
 
@@ -135,6 +136,7 @@ struct LargeLayout {
     int Xi, Xbar, Xcur; // fullXDim each
     int PhiPP; // two nx x nx blocks: Phi_{s-1}, Phi_s of the preview recursion (aliases the solver regions)
     int TL; // nx x nx: top-left Hessian block of the InitialStateLMPC variant (aliases sol.coef)
+    int FullS; // kMaxFullRows doubles: left-hand sides of the full-size rows at the current iterate
     int Params, nparams; // LDS copy of the parameter blob (nparams == 0: too large, stays in HBM)
     int Y, We, Cp; // cost tables (see LdsLayout)
     LargeLds sol;
@@ -161,6 +163,8 @@ struct FusedPlan {
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)
+    int n_full_rows; // rows with a full-size entry (kEFull / kGFull), listed below; -1: more than kMaxFullRows
+    int full_row[kMaxFullRows];
     const int* row_step; // [mgen]
     const int* row_ekind; // [mgen]
     const int* row_eoff; // [mgen]

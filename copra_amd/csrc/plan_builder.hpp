@@ -377,6 +377,16 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         }
     }
     P.mgen = P.meq + P.mineq;
+    P.n_full_rows = 0;
+    for (int i = 0; i < kMaxFullRows; ++i) P.full_row[i] = -1;
+    for (int i = 0; i < P.mgen && P.n_full_rows >= 0; ++i) {
+        if (hp.row_ekind[(size_t)i] == kEFull || hp.row_gkind[(size_t)i] == kGFull) {
+            if (P.n_full_rows == kMaxFullRows)
+                P.n_full_rows = -1;
+            else
+                P.full_row[P.n_full_rows++] = i;
+        }
+    }
     const int nvar = is ? nx + U : U; // InitialStateLMPC optimises [x0; U] (InitialStateLMPC.cpp:52-75)
     P.mtotal = P.mgen + 2 * nvar; // QuadProgSolver.cpp:51
     if (hp.params.empty()) hp.params.assign(2, 0.0);
@@ -407,8 +417,9 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.Xi = take(X);
         L.Xbar = is ? L.Xi : take(X); // InitialStateLMPC never uses the free response Phi x0 + xi
         L.Xcur = take(X);
-        L.nparams = (hp.params.size() <= 1024) ? (int)hp.params.size() : 0;
+        L.nparams = (hp.params.size() <= 6144) ? (int)hp.params.size() : 0; // (dropped below if LDS gets too tight)
         L.Params = take(L.nparams);
+        L.FullS = take(kMaxFullRows);
         const int sol0 = o;
         const int sol_end = layout_large_solver(L.sol, sol0, nvar, P.mgen, P.meq, P.mtotal);
         L.TL = L.sol.coef; // 4 nvar >= 256 >= nx^2 doubles; free between the two factorisations
@@ -434,6 +445,16 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.wsE = wtake(is ? (long long)nx * U : 0);
         L.wsT = wtake(is ? (long long)nx * U : 0);
         L.ws_total = w;
+        if ((size_t)L.total * sizeof(double) > 160u * 1024u && L.nparams > 0) { // parameters stay in HBM instead
+            L.total -= align2(L.nparams);
+            L.nparams = 0;
+            const int shift = align2((int)hp.params.size());
+            L.sol.xs -= shift, L.sol.cv -= shift, L.sol.np -= shift, L.sol.dv -= shift, L.sol.rv -= shift;
+            L.sol.uv -= shift, L.sol.hv -= shift, L.sol.coef -= shift, L.sol.nb -= shift, L.sol.eqsgn -= shift;
+            L.sol.red -= shift, L.sol.stage -= shift, L.sol.dblk -= shift, L.sol.act -= shift, L.sol.iact -= shift;
+            L.sol.total -= shift;
+            L.TL -= shift, L.PhiPP -= shift, L.Y -= shift, L.We -= shift, L.Cp -= shift, L.FullS -= shift;
+        }
         hp.lds_bytes = hp.lds_full_bytes = (size_t)L.total * sizeof(double);
         if (hp.lds_bytes > 160u * 1024u) return hp.error = "problem does not fit the 160 KiB LDS of one CU", COPRA_ERR_UNSUPPORTED;
         hp.two_tier = false;

@@ -92,54 +92,41 @@ def com_preview(batch, N=20, seed=1, v_max=0.6, u_max=3.0):
                 costs=costs, cstrs=cstrs)
 
 
-def long_horizon_initial_state(batch, N=50, seed=2, v_max=0.5, u_max=2.0):
-    """BASELINE config 5: InitialStateLMPC with nx=12, nu=6, N=50 (312 decision variables [x0; U]) and mixed
-    equality / inequality constraints -- the long-horizon case that does not fit the LDS of a CU.
-    Six double-integrator axes (two CoM-like triples), per-instance sampling period T ~ U(0.04, 0.06) and velocity
-    damping, x = [p(6); v(6)].  Costs: trajectory cost on positions towards a goal, target cost on the terminal
-    velocity, control cost.  Constraints:
-      * MixedConstraint (equality):   u_5 + 2 v_5 = 0 at every step (axis 5 runs a fixed damping law)   -> N rows
-      * MixedConstraint (inequality): v_i + 0.1 u_i <= 0.55 for the first three axes                    -> 3 N rows
-      * TrajectoryBoundConstraint: v <= v_max (upper only, reference quirk Q1)                          -> 6 (N+1) rows
-      * ControlBoundConstraint: |u| <= u_max
-    Initial state: cost (x0 - x_meas)' R (x0 - x_meas) with R = 50 I, bounds x_meas +- 0.05."""
+def long_horizon_initial_state(batch, N=50, seed=3, v_max=0.5, u_max=2.0, R_diag=1e-6, T=0.05):
+    """BASELINE config 5 as SURVEY.md section 8(d) specifies it: InitialStateLMPC on a 6-DoF double integrator
+    (nx=12, nu=6, N=50, T=0.05; 312 decision variables [x0; U]) -- the long-horizon case that does not fit the LDS.
+      x = [p(6); v(6)];  TrajectoryCost towards a goal + ControlCost;
+      * MixedConstraint (inequality, r=6):  v_k + T u_k <= v_max                            -> 300 rows
+      * one FULL-SIZE TrajectoryConstraint (equality): terminal velocity = 0 (6 rows x 612 columns)
+      * ControlBoundConstraint |u| <= u_max
+      * resetInitialStateCost(R = 1e-6 I, r = 0), x0 bounds = x0_nom +- 0.05 (cf. TestLMPC_InitialState.cpp:356-361)
+    Per instance: x0_nom (positions N(0, 0.05), velocities U(-0.3, 0.3)); A, B are shared in value but still handed over
+    per instance, as everywhere in this engine."""
     rng = SplitMix64(seed)
-    T = rng.uniform(batch, 0.04, 0.06)
-    damp = rng.uniform(batch, 0.0, 0.02)
     I6 = np.eye(6)
-    A = np.zeros((batch, 12, 12))
-    B = np.zeros((batch, 12, 6))
-    A[:, :6, :6] = I6
-    A[:, :6, 6:] = T[:, None, None] * I6
-    A[:, 6:, 6:] = (1.0 - damp)[:, None, None] * I6
-    B[:, :6, :] = (0.5 * T * T)[:, None, None] * I6
-    B[:, 6:, :] = T[:, None, None] * I6
+    A1 = np.zeros((12, 12))
+    B1 = np.zeros((12, 6))
+    A1[:6, :6] = I6
+    A1[:6, 6:] = T * I6
+    A1[6:, 6:] = I6
+    B1[:6, :] = 0.5 * T * T * I6
+    B1[6:, :] = T * I6
+    A = np.tile(A1, (batch, 1, 1))
+    B = np.tile(B1, (batch, 1, 1))
     d = np.zeros((batch, 12))
     x0 = np.zeros((batch, 12))
     x0[:, :6] = rng.normal(batch * 6, 0.05).reshape(batch, 6)
     x0[:, 6:] = rng.uniform(batch * 6, -0.3, 0.3).reshape(batch, 6)
     goal = np.array([0.8, -0.6, 0.5, 0.7, -0.4, 0.3])
-    inf = np.inf
     Mpos = np.hstack([I6, np.zeros((6, 6))])
-    Mvel = np.hstack([np.zeros((6, 6)), I6])
     costs = [dict(kind="trajectory", M=Mpos, p=goal, weights=[10.0] * 6),
-             dict(kind="target", M=Mvel, p=np.zeros(6), weights=[5.0] * 6),
              dict(kind="control", N=I6, p=np.zeros(6), weights=[1e-2] * 6)]
-    Eeq = np.zeros((1, 12))
-    Eeq[0, 11] = 2.0
-    Geq = np.zeros((1, 6))
-    Geq[0, 5] = 1.0
-    Ein = np.zeros((3, 12))
-    Gin = np.zeros((3, 6))
-    for i in range(3):
-        Ein[i, 6 + i] = 1.0
-        Gin[i, i] = 0.1
-    cstrs = [dict(kind="mixed", E=Eeq, G=Geq, f=[0.0], ineq=False),
-             dict(kind="mixed", E=Ein, G=Gin, f=[0.55] * 3),
-             dict(kind="trajectory_bound", lower=[-inf] * 12, upper=[inf] * 6 + [v_max] * 6),
+    X = 12 * (N + 1)
+    Eterm = np.zeros((6, X))
+    Eterm[:, X - 6:] = I6  # velocity block of x_N
+    cstrs = [dict(kind="mixed", E=np.hstack([np.zeros((6, 6)), I6]), G=T * I6, f=[v_max] * 6),
+             dict(kind="trajectory", E=Eterm, f=np.zeros(6), ineq=False),
              dict(kind="control_bound", lower=[-u_max] * 6, upper=[u_max] * 6)]
-    # the measured state itself: R (x0 - x_meas)^2 = x0' R x0 - 2 x_meas' R x0 -> r = -R x_meas is per instance in
-    # general; the engine takes one (R, r) per controller, so the workload centres the measurement on r's optimum
-    ist = dict(R=50.0 * np.eye(12), r=np.zeros(12), x0lb=x0 - 0.05, x0ub=x0 + 0.05)
-    return dict(name="InitialStateLMPC (nx=12,nu=6,N=%d) mixed eq/ineq constraints" % N, A=A, B=B, d=d, x0=x0, N=N,
-                costs=costs, cstrs=cstrs, initial_state=ist)
+    ist = dict(R=R_diag * np.eye(12), r=np.zeros(12), x0lb=x0 - 0.05, x0ub=x0 + 0.05)
+    return dict(name="InitialStateLMPC (nx=12,nu=6,N=%d): mixed ineq + full-size terminal equality + control bounds" % N,
+                A=A, B=B, d=d, x0=x0, N=N, costs=costs, cstrs=cstrs, initial_state=ist)

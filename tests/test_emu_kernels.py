@@ -205,6 +205,31 @@ def test_large_nine_classes(emu, oracle, initial_state):
         assert _rel(re["x0_opt"][0], ro["x0_opt"]) <= RTOL
 
 
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_large_full_size_constraint_rows(emu, oracle, initial_state):
+    """Full-size constraint entries with more than 64 variables: a terminal-velocity equality (1 x fullXDim) and a
+    budget on a weighted sum of the controls (1 x fullUDim), both active at the optimum.  The workgroup evaluates such rows
+    cooperatively (lmpc_large.hpp: lhs_cooperative)."""
+    N = 70
+    pb = F.bounded_system("trajectory", N=N)
+    X = 2 * (N + 1)
+    E = np.zeros((1, X))
+    E[0, X - 1] = 1.0
+    cstrs = pb["cstrs"] + [dict(kind="trajectory", E=E, f=[-1.0], ineq=False),
+                           dict(kind="control", G=(0.02 * np.arange(N) / N)[None], f=[47.0])]
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"] - 0.05, x0ub=pb["x0"] + 0.05) \
+        if initial_state else None
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], N, pb["costs"], cstrs, initial_state=ist, dump_instance=0)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], N, pb["costs"], cstrs, initial_state=ist)
+    qp = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], N, pb["costs"], cstrs, initial_state=ist)
+    for k in ("Aeq", "Aineq", "beq", "bineq"):
+        assert np.abs(re[k] - qp[k]).max() <= 1e-10 * max(1.0, np.abs(qp[k]).max())
+    assert re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+    assert abs((0.02 * np.arange(N) / N) @ re["control"][0] - 47.0) <= 1e-6  # the budget row is active (48.4 without it)
+    assert abs(re["trajectory"][0][-1] + 1.0) <= 1e-9  # the terminal equality holds
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi
