@@ -174,6 +174,55 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
         const CostTerm& ct = P.cost[t];
         const int r = ct.rows;
         wave_sync();
+        if (ct.full) {
+            // Full-size entry (costFunctions.cpp:65-71, 141-146, 197-203): tmp = M Psi (+ N) is R x n and dense;
+            //   Q += tmp' W tmp,  E += (M Phi)' W tmp,  f += (M xi - p)' W tmp        (one cost row at a time:
+            // row `rr` of tmp goes through LDS, every lane adds its column of the rank-1 update).  API-completeness
+            // path (TestLMPC_InitialState.cpp runs all nine classes with full-size entries), not a fast one.
+            const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
+            const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
+            const double* pp = P.params + ct.offP;
+            const double* ww = P.params + ct.offW;
+            double* rowbuf = S.dv; // n doubles (the solver vectors are not live yet)
+            double* mphi = S.xs; // (M Phi)(rr, 0..nx-1) and the residual (M xi - p)(rr)
+            const int jb = lane / nu, jc = lane - jb * nu;
+            for (int rr = 0; rr < r; ++rr) {
+                wave_sync();
+                double tv = 0.0;
+                if (lane < n) {
+                    if (Mr) { // row rr of M times column `lane` of Psi: Psi_{s, jb} = G_{s-1-jb} for s > jb
+                        const double* mrow = Mr + (size_t)rr * X;
+                        for (int s2 = jb + 1; s2 <= N; ++s2) {
+                            const double* Gk = G + (s2 - 1 - jb) * nx * nu + nx * jc;
+                            for (int c = 0; c < nx; ++c) tv += mrow[s2 * nx + c] * Gk[c];
+                        }
+                    }
+                    if (Nr) tv += Nr[(size_t)rr * n + lane];
+                    rowbuf[lane] = tv;
+                }
+                if (lane <= nx) {
+                    double acc = 0.0;
+                    if (Mr) {
+                        const double* mrow = Mr + (size_t)rr * X;
+                        if (lane < nx) {
+                            for (int s2 = 0; s2 <= N; ++s2)
+                                for (int c = 0; c < nx; ++c) acc += mrow[s2 * nx + c] * Phi[s2 * nPhi + c + nx * lane];
+                        } else {
+                            for (int col = 0; col < X; ++col) acc += mrow[col] * Xi[col];
+                        }
+                    }
+                    mphi[lane] = (lane < nx) ? acc : acc - pp[rr];
+                }
+                wave_sync();
+                const double wr = ww[rr];
+                if (lane < n) {
+                    for (int i = 0; i <= lane; ++i) Jq[i * ldq + lane] += (rowbuf[i] * wr) * tv;
+                    fj += (mphi[nx] * wr) * tv;
+                    for (int a = 0; a < nx; ++a) Eb[a + nx * lane] += (mphi[a] * wr) * tv;
+                }
+            }
+            continue;
+        }
         double* Mx = Cp;
         double* Nm = Cp + r * nx;
         double* p = Nm + r * nu;

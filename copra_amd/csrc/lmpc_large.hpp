@@ -194,6 +194,81 @@ COPRA_DEV void large_costs(const FusedPlan& P, double* lds, double* F, int ld, i
         const CostTerm& ct = P.cost[t];
         const int r = ct.rows;
         bt_sync();
+        if (ct.full) {
+            // Full-size entry (costFunctions.cpp:65-71, 141-146, 197-203): tmp = M Psi (+ N), R x n and dense.
+            //   Q += tmp' W tmp,  c += (M xbar - p)' W tmp   |   InitialStateLMPC: E += (M Phi)' W tmp, f += (M xi - p)' W tmp
+            // Four rows of tmp per pass over the lower triangle of Q (thread j owns row j of Q: coalesced RMW).
+            // Completeness path: R n^2 / 8 read-modify-writes per cost, no structure exploited.
+            const int X = P.X;
+            const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
+            const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
+            const double* pp = P.params + ct.offP;
+            const double* ww = P.params + ct.offW;
+            double* rowbuf = lds + L.sol.stage; // 4 x n
+            double* mphi = lds + L.sol.xs; // 4 x (nx + 1): (M Phi)(row, :) and the residual of the row
+            const double* xfree = is ? Xi : Xbar;
+            const int jb = tid / nu, jc = tid - jb * nu;
+            for (int r0 = 0; r0 < r; r0 += 4) {
+                bt_sync();
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r0 + u;
+                    double v = 0.0;
+                    if (rr < r && tid < n) {
+                        if (Mr) { // row rr of M times column tid of Psi: Psi_{s, jb} = G_{s-1-jb} for s > jb
+                            const double* mrow = Mr + (size_t)rr * X;
+                            for (int s2 = jb + 1; s2 <= N; ++s2) {
+                                const double* Gk = G + (s2 - 1 - jb) * nx * nu + nx * jc;
+                                for (int c = 0; c < nx; ++c) v += mrow[s2 * nx + c] * Gk[c];
+                            }
+                        }
+                        if (Nr) v += Nr[(size_t)rr * n + tid];
+                    }
+                    tv[u] = v;
+                    if (tid < n) rowbuf[u * n + tid] = v;
+                }
+                if (linear) { // thread (u, a): a < nx -> (M Phi)(rr, a) (InitialStateLMPC), a == nx -> residual of row rr
+                    for (int e = tid; e < 4 * (nx + 1); e += T) {
+                        const int u = e / (nx + 1), a = e - u * (nx + 1);
+                        const int rr = r0 + u;
+                        double acc = 0.0;
+                        if (rr < r && Mr) {
+                            const double* mrow = Mr + (size_t)rr * X;
+                            if (a < nx) {
+                                if (is)
+                                    for (int s2 = 0; s2 <= N; ++s2)
+                                        for (int c = 0; c < nx; ++c) acc += mrow[s2 * nx + c] * Phi[s2 * nPhi + c + nx * a];
+                            } else {
+                                for (int col = 0; col < X; ++col) acc += mrow[col] * xfree[col];
+                            }
+                        }
+                        mphi[e] = (a < nx) ? acc : ((rr < r) ? acc - pp[rr] : 0.0);
+                    }
+                }
+                bt_sync();
+                if (tid < n) {
+                    double tw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) tw[u] = (r0 + u < r) ? tv[u] * ww[r0 + u] : 0.0;
+                    for (int i = 0; i <= tid; ++i) { // Q(tid, i), i <= tid: lower triangle, column i
+                        double acc = 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc += rowbuf[u * n + i] * tw[u];
+                        Q[(size_t)i * ld + tid] += acc;
+                    }
+                    if (linear) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            cj += mphi[u * (nx + 1) + nx] * tw[u];
+                            if (is)
+                                for (int a = 0; a < nx; ++a) Ecol[a] += mphi[u * (nx + 1) + a] * tw[u];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         double* Mx = Cp;
         double* Nm = Cp + r * nx;
         double* p = Nm + r * nu;

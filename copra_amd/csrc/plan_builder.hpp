@@ -217,10 +217,6 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
         }
         t.full = full ? 1 : 0;
-        if (full && is) {
-            hp.error = "InitialStateLMPC with full-size cost entries is not covered by the HIP path yet";
-            return COPRA_ERR_UNSUPPORTED;
-        }
         if (full) {
             // full-size entry: keep M (rows x fullXDim) and N (rows x fullUDim) ROW-major, one contiguous row per cost row
             auto push_rowmajor = [&](const double* Mx, int rows, int cols) {
@@ -400,8 +396,6 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         if (nvar > kLargeMaxN) return hp.error = "more than 512 decision variables are not covered", COPRA_ERR_UNSUPPORTED;
         if (nu > kMaxNu) return hp.error = "uDim > 8 is not covered", COPRA_ERR_UNSUPPORTED;
         if (is && nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;
-        if (P.rfull > 0)
-            return hp.error = "full-size cost entries with more than 64 decision variables are not covered", COPRA_ERR_UNSUPPORTED;
         LargeLayout& L = P.large;
         int o = 0;
         auto take = [&](int count) {

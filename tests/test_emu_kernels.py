@@ -230,6 +230,36 @@ def test_large_full_size_constraint_rows(emu, oracle, initial_state):
     assert abs(re["trajectory"][0][-1] + 1.0) <= 1e-9  # the terminal equality holds
 
 
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_large_full_size_cost_entries(emu, oracle, initial_state):
+    """Full-size COST entries (time-varying references: p and weights of size r (N+1), M spanned by autoSpan) with
+    more than 64 variables: rank-4 updates of the Hessian in the HBM workspace (lmpc_large.hpp)"""
+    from copra_amd.autospan import autospan_cost
+    N = 70
+    pb = F.nine_class_problem(N)
+
+    def span(c):
+        c = dict(c)
+        if c["kind"] == "target":
+            return c
+        reps = N + 1 if c["kind"] == "trajectory" else N
+        ramp = np.linspace(1.0, 0.5, reps)  # genuinely time-varying reference and weights
+        c["p"] = (np.atleast_1d(c["p"])[None, :] * ramp[:, None]).ravel()
+        c["weights"] = (np.atleast_1d(c["weights"])[None, :] * (2.0 - ramp[:, None])).ravel()
+        return autospan_cost(c)
+
+    costs = [span(c) for c in pb["costs"]]
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"] - 0.05, x0ub=pb["x0"] + 0.05) \
+        if initial_state else None
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], N, costs, pb["cstrs"], initial_state=ist, dump_instance=0)
+    qp = oracle.lmpc_build(pb["A"], pb["B"], pb["d"], pb["x0"], N, costs, pb["cstrs"], initial_state=ist)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], N, costs, pb["cstrs"], initial_state=ist)
+    assert np.abs(re["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+    assert np.abs(re["c"] - qp["c"]).max() <= 1e-11 * max(1.0, np.abs(qp["c"]).max())
+    assert re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi
@@ -310,12 +340,14 @@ def test_initial_state_lmpc_batch(emu, oracle):
         assert (re["x0_opt"][k] <= ist["x0ub"][k] + 1e-6).all() and (re["x0_opt"][k] >= ist["x0lb"][k] - 1e-6).all()
 
 
-def test_initial_state_lmpc_reference_test_problem(emu, oracle):
-    """tests/TestLMPC_InitialState.cpp:266-403 (all nine classes, x0 free in [-1,1], R = 1e-6 I) and :29-260 (trailing
+@pytest.mark.parametrize("full_size", [False, True])
+def test_initial_state_lmpc_reference_test_problem(emu, oracle, full_size):
+    """tests/TestLMPC_InitialState.cpp:266-403 (all nine classes, x0 free in [-1,1], R = 1e-6 I; run_optimization_test
+    with per-step and with full-size entries) and :29-260 (trailing
     blocks of the InitialStateLMPC QP equal the LMPC QP).  With R = 1e-6 the Hessian's Schur complement is 1e-6
     against blocks of 1e6, so U itself is not determined to 1e-6 by ANY arithmetic; like the reference's test we check
     solve() == true and x0* within its bounds, plus x0* and the QP against the oracle."""
-    pb = F.initial_state_problem(False)
+    pb = F.initial_state_problem(full_size)
     ist = dict(R=1e-6 * np.eye(2), r=np.zeros(2), x0lb=-np.ones(2), x0ub=np.ones(2))
     re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist,
                         dump_instance=0)

@@ -320,7 +320,14 @@ def test_initial_state_lmpc_on_gpu(oracle):
         assert _rel(res["control"][k], ro["control"]) <= RTOL
         assert _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
         assert _rel(x0s[k], ro["x0_opt"]) <= RTOL
-    pb = F.initial_state_problem(False)
+    for full_size in (False, True):  # run_optimization_test(false / true), TestLMPC_InitialState.cpp:398-403
+        _initial_state_optimization_case(oracle, full_size)
+
+
+def _initial_state_optimization_case(oracle, full_size):
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    pb = F.initial_state_problem(full_size)
     ist = dict(R=1e-6 * np.eye(2), r=np.zeros(2))
     eng = BatchLMPC(2, 1, pb["N"], 1, pb["costs"], pb["cstrs"], initial_state=ist)
     eng.set_system(pb["A"][None], pb["B"][None], pb["d"][None], pb["x0"][None])
@@ -435,3 +442,41 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, tol):
     assert np.abs(qp["c"] - qo["c"]).max() <= 1e-9 * max(1.0, np.abs(qo["c"]).max())
     for key in ("Aeq", "Aineq", "beq", "bineq"):
         assert np.abs(qp[key] - qo[key]).max() <= 1e-10 * max(1.0, np.abs(qo[key]).max())
+
+
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_full_size_cost_entries_long_horizon(oracle, initial_state):
+    """Full-size cost entries (time-varying reference and weights over the horizon) with 150 decision variables: the
+    workgroup-per-instance kernel's rank-4 Hessian updates vs the oracle"""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    from copra_amd.autospan import autospan_cost
+    N, b = 150, 3
+    pb = F.nine_class_problem(N)
+
+    def span(c):
+        c = dict(c)
+        if c["kind"] == "target":
+            return c
+        reps = N + 1 if c["kind"] == "trajectory" else N
+        ramp = np.linspace(1.0, 0.5, reps)
+        c["p"] = (np.atleast_1d(c["p"])[None, :] * ramp[:, None]).ravel()
+        c["weights"] = (np.atleast_1d(c["weights"])[None, :] * (2.0 - ramp[:, None])).ravel()
+        return autospan_cost(c)
+
+    costs = [span(c) for c in pb["costs"]]
+    rng = np.random.default_rng(7)
+    x0 = np.tile(pb["x0"], (b, 1)) + 0.1 * rng.standard_normal((b, 2))
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2])) if initial_state else None
+    eng = BatchLMPC(2, 1, N, b, costs, pb["cstrs"], initial_state=ist)
+    eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0)
+    if initial_state:
+        eng.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
+    eng.solve()
+    res = eng.results()
+    for k in range(b):
+        io = dict(ist, x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05) if initial_state else None
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, costs, pb["cstrs"], initial_state=io)
+        assert res["status"][k] == ro["status"] == 0 and tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert _rel(res["control"][k], ro["control"]) <= 1e-6
+        assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
