@@ -500,12 +500,15 @@ public:
         const auto t0 = clock::now();
         rebuild();
         throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
+        beforeSolve();
         ps_->isUpdated = true;
+        qpValid_ = false;
         const auto t1 = clock::now();
         throw_status(copra_batch_solve(h_, nullptr));
         Eigen::VectorXd u(ps_->fullUDim), x(ps_->fullXDim);
         int it[2];
         throw_status(copra_batch_get_results(h_, u.data(), x.data(), &fail_, it));
+        afterSolve(fail_ == 0);
         double dev = 0.0;
         copra_batch_last_solve_seconds(h_, &dev);
         solveTime_ = dev;
@@ -554,6 +557,7 @@ public:
     {
         rebuild();
         throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
+        beforeSolve();
         int n, e, i;
         copra_batch_qp_sizes(h_, &n, &e, &i);
         DenseQP q;
@@ -570,7 +574,34 @@ public:
         return q;
     }
 
+    // the accessors of LMPC.h:112-127 (matrices of the last problem handed to the solver), fetched from the device on
+    // first use after a solve
+    const Eigen::MatrixXd& Q() { return qp().Q; }
+    const Eigen::VectorXd& c() { return qp().c; }
+    const Eigen::MatrixXd& Aeq() { return qp().Aeq; }
+    const Eigen::VectorXd& beq() { return qp().beq; }
+    const Eigen::MatrixXd& Aineq() { return qp().Aineq; }
+    const Eigen::VectorXd& bineq() { return qp().bineq; }
+    const Eigen::VectorXd& lb() { return qp().lb; }
+    const Eigen::VectorXd& ub() { return qp().ub; }
+
 protected:
+    const DenseQP& qp()
+    {
+        if (!qpValid_) {
+            qp_ = denseQP();
+            qpValid_ = true;
+        }
+        return qp_;
+    }
+    // hooks of the InitialStateLMPC variant
+    virtual copra_status_t createHandle(const copra_dims_t& dims, const std::vector<copra_cost_desc_t>& cd,
+        const std::vector<copra_cstr_desc_t>& kd)
+    {
+        return copra_batch_create(&h_, &dims, (int)cd.size(), cd.data(), (int)kd.size(), kd.data());
+    }
+    virtual void beforeSolve() {}
+    virtual void afterSolve(bool) {}
     void validate(const std::vector<copra_cost_desc_t>& costs, const std::vector<copra_cstr_desc_t>& cstrs) const
     {
         // the same host-side checks copra_batch_create runs (plan_builder.hpp), without touching the device
@@ -589,8 +620,9 @@ protected:
         for (auto& c : spCost_) cd.push_back(c->desc());
         for (auto& c : spConstr_) kd.push_back(c->desc());
         copra_dims_t dims { ps_->xDim, ps_->uDim, ps_->nrUStep, 1 };
-        throw_status(copra_batch_create(&h_, &dims, (int)cd.size(), cd.data(), (int)kd.size(), kd.data()));
+        throw_status(createHandle(dims, cd, kd));
         dirty_ = false;
+        qpValid_ = false;
     }
     void release()
     {
@@ -606,6 +638,58 @@ protected:
     Eigen::VectorXd control_, trajectory_;
     int fail_ = 0, iter_ = 0;
     double solveTime_ = 0.0, solveAndBuildTime_ = 0.0;
+    DenseQP qp_;
+    bool qpValid_ = false;
+};
+
+// include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp: the initial state is a decision variable too
+class InitialStateLMPC : public LMPC {
+public:
+    InitialStateLMPC(SolverFlag f = SolverFlag::DEFAULT)
+        : LMPC(f)
+    {
+    }
+    InitialStateLMPC(const std::shared_ptr<PreviewSystem>& ps, SolverFlag f = SolverFlag::DEFAULT)
+        : LMPC(ps, f)
+    {
+        // InitialStateLMPC.cpp:20-28: R = 0, r = 0, both bounds = ps->x0
+        R_ = Eigen::MatrixXd::Zero(ps->xDim, ps->xDim);
+        r_ = Eigen::VectorXd::Zero(ps->xDim);
+        x0lb_ = ps->x0;
+        x0ub_ = ps->x0;
+    }
+    Eigen::VectorXd initialState() const noexcept { return x0opt_; } // :30-33
+    void resetInitialStateCost(const Eigen::MatrixXd& R, const Eigen::VectorXd& r) // :35-40
+    {
+        R_ = R;
+        r_ = r;
+        dirty_ = true;
+    }
+    void resetInitialStateBounds(const Eigen::VectorXd& l, const Eigen::VectorXd& u) // :42-46
+    {
+        x0lb_ = l;
+        x0ub_ = u;
+    }
+
+protected:
+    copra_status_t createHandle(const copra_dims_t& dims, const std::vector<copra_cost_desc_t>& cd,
+        const std::vector<copra_cstr_desc_t>& kd) override
+    {
+        copra_initial_state_desc_t is { R_.data(), r_.data() };
+        return copra_batch_create_initial_state(&h_, &dims, (int)cd.size(), cd.data(), (int)kd.size(), kd.data(), &is);
+    }
+    void beforeSolve() override
+    {
+        throw_status(copra_batch_set_initial_state_bounds(h_, x0lb_.data(), x0ub_.data(), 0));
+    }
+    void afterSolve(bool ok) override
+    {
+        if (!ok) return;
+        x0opt_.resize(ps_->xDim);
+        throw_status(copra_batch_get_initial_state(h_, x0opt_.data()));
+    }
+    Eigen::MatrixXd R_;
+    Eigen::VectorXd r_, x0lb_, x0ub_, x0opt_;
 };
 
 } // namespace copra

@@ -108,7 +108,8 @@ void copra_batch_destroy(copra_batch_t* h);
 
 /* ---- InitialStateLMPC variant (include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp): the decision vector is
  *      [x0; U]; costs contribute E and f, the Hessian is [[R + E Q^-1 E', E], [E', Q]] (InitialStateLMPC.cpp:77-122).
- *      Covered on the device for xDim + fullUDim <= 512 and per-step cost entries; other shapes COPRA_ERR_UNSUPPORTED.
+ *      Covered on the device for xDim + fullUDim <= 512 (xDim <= 16), per-step and full-size entries; other shapes
+ *      COPRA_ERR_UNSUPPORTED.
  *      Initial-state bounds (resetInitialStateBounds, :42-46) are per instance, [batch][nx]; when they are never set
  *      both default to the x0 handed to copra_batch_set_system (InitialStateLMPC.cpp:20-28).
  *      copra_batch_get_initial_state == InitialStateLMPC::initialState() (:30-33), [batch][nx]. ---- */

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 static int failures = 0;
@@ -40,10 +41,10 @@ static int failures = 0;
         }                                                                                                             \
     } while (0)
 
-// tests/systems.h:94-137 (IneqSystem) with a shorter horizon
+// tests/systems.h:42-229: the falling-mass fixture all four reference systems share (nbStep = 300 there)
 struct IneqSystem {
-    IneqSystem()
-        : T(0.005), mass(5), nbStep(12), A(2, 2), B(2, 1), G(1, 1), E(1, 2), M(2, 2), N(1, 1), c(2), h(1), p(1), x0(2), xd(2), ud(1), wx(2), wu(1)
+    explicit IneqSystem(int steps = 12)
+        : T(0.005), mass(5), nbStep(steps), A(2, 2), B(2, 1), G(1, 1), E(1, 2), M(2, 2), N(1, 1), c(2), h(1), p(1), x0(2), xd(2), ud(1), wx(2), wu(1)
     {
         A << 1, T, 0, 1;
         B << 0.5 * T * T / mass, T / mass;
@@ -134,82 +135,119 @@ static void error_handlers()
     }
 }
 
-static void solve_cases()
+// Largest velocity / position over a trajectory vector [p0, v0, p1, v1, ...]
+static void extrema(const Eigen::VectorXd& traj, double& posMax, double& velMax)
 {
-    IneqSystem s;
+    posMax = velMax = -std::numeric_limits<double>::infinity();
+    for (Eigen::Index i = 0; i < traj.rows() / 2; ++i) {
+        posMax = std::max(posMax, traj(2 * i));
+        velMax = std::max(velMax, traj(2 * i + 1));
+    }
+}
+
+// The state cost of one of the reference's test cases: TargetCost, TrajectoryCost, or the MixedCost pair of
+// TestLMPC.cpp:182-183 (MixedCost(M, 0, xd) + MixedCost(0, N, ud)); always followed by the control cost.
+static void add_costs(copra::LMPC& controller, const IneqSystem& s, const Eigen::VectorXd& xd, int kind)
+{
+    if (kind == 2) {
+        auto xCost = std::make_shared<copra::MixedCost>(s.M, Eigen::MatrixXd::Zero(2, 1), xd);
+        auto uCost = std::make_shared<copra::MixedCost>(Eigen::MatrixXd::Zero(1, 2), s.N, s.ud);
+        xCost->weights(s.wx);
+        uCost->weights(s.wu);
+        controller.addCost(xCost);
+        controller.addCost(uCost);
+        return;
+    }
+    std::shared_ptr<copra::CostFunction> xCost;
+    if (kind == 0)
+        xCost = std::make_shared<copra::TargetCost>(s.M, xd);
+    else
+        xCost = std::make_shared<copra::TrajectoryCost>(s.M, xd);
+    auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
+    xCost->weights(s.wx);
+    uCost->weights(s.wu);
+    controller.addCost(xCost);
+    controller.addCost(uCost);
+}
+
+// TestLMPC.cpp:36-771 at the reference's own horizon (nbStep = 300 -> 300 decision variables): every
+// {Target, Trajectory, Mixed cost} x {bound, inequality, mixed, equality constraint} case with its acceptance checks.
+static void solve_cases(int nbStep)
+{
+    IneqSystem s(nbStep);
     const double inf = std::numeric_limits<double>::infinity();
-    { // MPC_TARGET_COST_WITH_BOUND_CONSTRAINTS (TestLMPC.cpp:36-97)
-        Eigen::VectorXd uLower(1), uUpper(1), xLower(2), xUpper(2);
-        uLower.setConstant(-inf);
-        uUpper.setConstant(200);
-        xLower.setConstant(-inf);
-        xUpper << inf, 0;
-        auto ps = std::make_shared<copra::PreviewSystem>();
-        ps->system(s.A, s.B, s.c, s.x0, s.nbStep);
-        auto controller = copra::LMPC(ps);
-        auto xCost = std::make_shared<copra::TargetCost>(s.M, s.xd);
-        auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
-        auto trajConstr = std::make_shared<copra::TrajectoryBoundConstraint>(xLower, xUpper);
-        auto contConstr = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
-        xCost->weights(s.wx);
-        uCost->weights(s.wu);
-        controller.addCost(xCost);
-        controller.addCost(uCost);
-        controller.addConstraint(trajConstr);
-        controller.addConstraint(contConstr);
-        CHECK(controller.solve());
-        Eigen::VectorXd fullTraj = controller.trajectory();
-        Eigen::VectorXd control = controller.control();
-        double posMax = -inf, velMax = -inf;
-        for (Eigen::Index i = 0; i < fullTraj.rows() / 2; ++i) {
-            posMax = std::max(posMax, fullTraj(2 * i));
-            velMax = std::max(velMax, fullTraj(2 * i + 1));
+    const char* costName[3] = { "TARGET", "TRAJECTORY", "MIXED" };
+    for (int kind = 0; kind < 3; ++kind) {
+        { // MPC_<cost>_COST_WITH_BOUND_CONSTRAINTS
+            Eigen::VectorXd uLower(1), uUpper(1), xLower(2), xUpper(2);
+            uLower.setConstant(-inf);
+            uUpper.setConstant(200);
+            xLower.setConstant(-inf);
+            xUpper << inf, 0;
+            auto ps = std::make_shared<copra::PreviewSystem>();
+            ps->system(s.A, s.B, s.c, s.x0, s.nbStep);
+            auto controller = copra::LMPC(ps);
+            add_costs(controller, s, s.xd, kind);
+            controller.addConstraint(std::make_shared<copra::TrajectoryBoundConstraint>(xLower, xUpper));
+            controller.addConstraint(std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper));
+            CHECK(controller.solve());
+            double posMax, velMax;
+            extrema(controller.trajectory(), posMax, velMax);
+            CHECK(posMax <= s.x0(0) + 1e-9);
+            CHECK(velMax <= 0 + 1e-6);
+            CHECK(controller.control().maxCoeff() <= 200 + 1e-6);
+            if (kind == 0 && nbStep >= 300) // the target is reachable over the full horizon (TestLMPC.cpp:78-83)
+                CHECK(std::fabs(controller.trajectory()(2 * s.nbStep + 1) - s.xd(1)) <= 1e-3);
+            CHECK(controller.solveTime() > 0 && controller.solveAndBuildTime() >= controller.solveTime());
+            if (kind == 0) { // receding horizon: xInit without re-creating anything (PreviewSystem.h:52)
+                Eigen::VectorXd x1(2);
+                x1 << controller.trajectory()(2), controller.trajectory()(3);
+                ps->xInit(x1);
+                CHECK(controller.solve());
+                CHECK(std::fabs(controller.trajectory()(0) - x1(0)) < 1e-12);
+            }
         }
-        CHECK(posMax <= s.x0(0));
-        CHECK(velMax <= 0 + 1e-6);
-        CHECK(control.maxCoeff() <= 200 + 1e-6);
-        CHECK(controller.solveTime() > 0 && controller.solveAndBuildTime() >= controller.solveTime());
-        // receding horizon: xInit without re-creating anything (PreviewSystem.h:52)
-        Eigen::VectorXd x1(2);
-        x1 << fullTraj(2), fullTraj(3);
-        ps->xInit(x1);
-        CHECK(controller.solve());
-        CHECK(std::fabs(controller.trajectory()(0) - x1(0)) < 1e-12);
-    }
-    { // MPC_TARGET_COST_WITH_MIXED_CONSTRAINTS (TestLMPC.cpp:415-479), p = 200
-        Eigen::VectorXd p(1);
-        p << 200;
-        auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
-        auto controller = copra::LMPC(ps);
-        auto xCost = std::make_shared<copra::TargetCost>(s.M, s.xd);
-        auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
-        auto mixedConstr = std::make_shared<copra::MixedConstraint>(s.E, s.G, p);
-        xCost->weights(s.wx);
-        uCost->weights(s.wu);
-        controller.addCost(xCost);
-        controller.addCost(uCost);
-        controller.addConstraint(mixedConstr);
-        CHECK(controller.solve());
-        Eigen::VectorXd fullTraj = controller.trajectory(), control = controller.control();
-        for (int i = 0; i < s.nbStep; ++i) CHECK(fullTraj(2 * i + 1) + control(i) <= 200 + 1e-6);
-    }
-    { // MPC_TARGET_COST_WITH_EQUALITY_CONSTRAINTS (TestLMPC.cpp:593-670) -> u_k = m g
-        Eigen::MatrixXd E = Eigen::MatrixXd::Zero(2, 2);
-        E(0, 0) = 1;
-        Eigen::VectorXd x0 = Eigen::VectorXd::Zero(2), xd = Eigen::VectorXd::Zero(2);
-        auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, x0, s.nbStep);
-        auto controller = copra::LMPC(ps);
-        auto xCost = std::make_shared<copra::TargetCost>(s.M, xd);
-        auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
-        auto trajConstr = std::make_shared<copra::TrajectoryConstraint>(E, x0, false);
-        xCost->weights(s.wx);
-        uCost->weights(s.wu);
-        controller.addCost(xCost);
-        controller.addCost(uCost);
-        controller.addConstraint(trajConstr);
-        CHECK(controller.solve());
-        for (int i = 0; i < s.nbStep; ++i) CHECK(std::fabs(controller.control()(i) - 49.05) < 1e-5);
-        CHECK(controller.nrEqConstr() == 2 * (s.nbStep + 1));
+        { // MPC_<cost>_COST_WITH_INEQUALITY_CONSTRAINTS: E x <= f (velocity <= 0), G u <= h
+            Eigen::VectorXd f(1);
+            f << 0;
+            auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+            auto controller = copra::LMPC(ps);
+            add_costs(controller, s, s.xd, kind);
+            controller.addConstraint(std::make_shared<copra::TrajectoryConstraint>(s.E, f));
+            controller.addConstraint(std::make_shared<copra::ControlConstraint>(s.G, s.h));
+            CHECK(controller.solve());
+            double posMax, velMax;
+            extrema(controller.trajectory(), posMax, velMax);
+            CHECK(velMax <= 0 + 1e-6);
+            CHECK(controller.control().maxCoeff() <= 200 + 1e-6);
+            CHECK(controller.nrIneqConstr() == (s.nbStep + 1) + s.nbStep);
+        }
+        { // MPC_<cost>_COST_WITH_MIXED_CONSTRAINTS: v_k + u_k <= 200
+            Eigen::VectorXd p(1);
+            p << 200;
+            auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+            auto controller = copra::LMPC(ps);
+            add_costs(controller, s, s.xd, kind);
+            controller.addConstraint(std::make_shared<copra::MixedConstraint>(s.E, s.G, p));
+            CHECK(controller.solve());
+            Eigen::VectorXd fullTraj = controller.trajectory(), control = controller.control();
+            for (int i = 0; i < s.nbStep; ++i) CHECK(fullTraj(2 * i + 1) + control(i) <= 200 + 1e-6);
+        }
+        { // MPC_<cost>_COST_WITH_EQUALITY_CONSTRAINTS: position pinned to 0 -> u_k = m g
+            Eigen::MatrixXd E = Eigen::MatrixXd::Zero(2, 2);
+            E(0, 0) = 1;
+            Eigen::VectorXd x0 = Eigen::VectorXd::Zero(2), xd = Eigen::VectorXd::Zero(2);
+            auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, x0, s.nbStep);
+            auto controller = copra::LMPC(ps);
+            add_costs(controller, s, xd, kind);
+            controller.addConstraint(std::make_shared<copra::TrajectoryConstraint>(E, x0, false));
+            CHECK(controller.solve());
+            // the last control has no effect on the pinned positions (x_N depends on u_0 .. u_{N-2} only)
+            for (int i = 0; i + 1 < s.nbStep; ++i) CHECK(std::fabs(controller.control()(i) - 49.05) < 1e-4);
+            for (int i = 0; i <= s.nbStep; ++i) CHECK(std::fabs(controller.trajectory()(2 * i)) < 1e-6);
+            CHECK(controller.nrEqConstr() == 2 * (s.nbStep + 1));
+        }
+        std::printf("  %s cost: bound / inequality / mixed / equality cases done (%d failure(s) so far)\n", costName[kind], failures);
     }
     { // TestSolvers.cpp:25-33 through plug-in point 1 on the GPU
         Eigen::MatrixXd Q = Eigen::MatrixXd::Identity(6, 6), Aeq(3, 6), Aineq(2, 6);
@@ -230,12 +268,126 @@ static void solve_cases()
     }
 }
 
+// TestLMPC_InitialState.cpp: all nine cost / constraint classes on A = ones(2,2), B = ones(2,1), 10 steps, with
+// per-step entries and with the full-size entries autoSpan() produces.
+struct NineClasses {
+    std::vector<std::shared_ptr<copra::CostFunction>> costs;
+    std::vector<std::shared_ptr<copra::Constraint>> cstrs;
+    NineClasses(bool fullSize, int steps)
+    {
+        using namespace Eigen;
+        const int U = fullSize ? steps : 1, X = fullSize ? steps + 1 : 1;
+        const double factor = 10, inf = std::numeric_limits<double>::infinity();
+        auto tc = std::make_shared<copra::TrajectoryCost>(MatrixXd::Ones(1, 2), factor * VectorXd::Ones(X));
+        auto tac = std::make_shared<copra::TargetCost>(MatrixXd::Ones(1, 2), factor * VectorXd::Ones(1));
+        auto cc = std::make_shared<copra::ControlCost>(MatrixXd::Ones(1, 1), factor * VectorXd::Ones(U));
+        auto mc = std::make_shared<copra::MixedCost>(MatrixXd::Ones(1, 2), MatrixXd::Ones(1, 1), factor * VectorXd::Ones(U));
+        auto tk = std::make_shared<copra::TrajectoryConstraint>(MatrixXd::Ones(1, 2), factor * VectorXd::Ones(X), true);
+        auto ck = std::make_shared<copra::ControlConstraint>(MatrixXd::Ones(1, 1), factor * VectorXd::Ones(U), true);
+        auto mk = std::make_shared<copra::MixedConstraint>(MatrixXd::Ones(1, 2), MatrixXd::Ones(1, 1), factor * VectorXd::Ones(U), true);
+        auto tb = std::make_shared<copra::TrajectoryBoundConstraint>(-inf * VectorXd::Ones(2 * X), inf * VectorXd::Ones(2 * X));
+        auto cb = std::make_shared<copra::ControlBoundConstraint>(-3.0 * VectorXd::Ones(U), 3.0 * VectorXd::Ones(U));
+        for (auto& c : { std::static_pointer_cast<copra::CostFunction>(tc), std::static_pointer_cast<copra::CostFunction>(tac),
+                 std::static_pointer_cast<copra::CostFunction>(cc), std::static_pointer_cast<copra::CostFunction>(mc) }) {
+            c->autoSpan();
+            c->weight(1);
+            costs.push_back(c);
+        }
+        for (auto& c : { std::static_pointer_cast<copra::Constraint>(tk), std::static_pointer_cast<copra::Constraint>(ck),
+                 std::static_pointer_cast<copra::Constraint>(mk), std::static_pointer_cast<copra::Constraint>(tb),
+                 std::static_pointer_cast<copra::Constraint>(cb) }) {
+            c->autoSpan();
+            cstrs.push_back(c);
+        }
+    }
+};
+
+static double max_abs_diff(const Eigen::MatrixXd& a, const Eigen::MatrixXd& b, Eigen::Index r0, Eigen::Index c0)
+{
+    double m = 0.0; // || a - b[r0.., c0..] ||_max
+    for (Eigen::Index i = 0; i < a.rows(); ++i)
+        for (Eigen::Index j = 0; j < a.cols(); ++j) m = std::max(m, std::fabs(a(i, j) - b(r0 + i, c0 + j)));
+    return m;
+}
+
+static void initial_state_cases()
+{
+    using namespace Eigen;
+    const int steps = 10;
+    MatrixXd combi = MatrixXd::Ones(3, 3), A(2, 2), B(2, 1);
+    A << 1, 1, 1, 1;
+    B << 1, 1;
+    const VectorXd bias = VectorXd::Zero(2), s_init = VectorXd::Zero(2);
+    for (int fullSize = 0; fullSize < 2; ++fullSize) {
+        { // INITIAL-STATE-OPTIMIZATION (TestLMPC_InitialState.cpp:266-403)
+            NineClasses nc(fullSize != 0, steps);
+            auto ps = std::make_shared<copra::PreviewSystem>();
+            ps->system(A, B, bias, s_init, steps);
+            copra::InitialStateLMPC lmpc(ps);
+            const VectorXd lo = -1.0 * VectorXd::Ones(2), up = VectorXd::Ones(2);
+            lmpc.resetInitialStateBounds(lo, up);
+            lmpc.resetInitialStateCost(1e-6 * MatrixXd::Identity(2, 2), VectorXd::Zero(2));
+            for (auto& c : nc.costs) lmpc.addCost(c);
+            for (auto& c : nc.cstrs) lmpc.addConstraint(c);
+            CHECK(lmpc.solve());
+            if (lmpc.fail() != 0) {
+                std::printf("InitialStateLMPC::solve failed with status %d (fullSize = %d)\n", lmpc.fail(), fullSize);
+                continue;
+            }
+            const VectorXd x0s = lmpc.trajectory().head(2);
+            for (int i = 0; i < 2; ++i) {
+                CHECK(x0s(i) <= up(i) + 1e-6);
+                CHECK(lo(i) <= x0s(i) + 1e-6);
+                CHECK(std::fabs(x0s(i) - lmpc.initialState()(i)) < 1e-12);
+            }
+        }
+        { // LMPC_AND_INITIAL-STATE-LMPC_COMPARISON (:29-253): the trailing blocks of the InitialStateLMPC QP are the LMPC QP
+            NineClasses a(fullSize != 0, steps), b(fullSize != 0, steps);
+            auto ps = std::make_shared<copra::PreviewSystem>();
+            ps->system(A, B, bias, s_init, steps);
+            copra::LMPC lmpcA(ps);
+            for (auto& c : a.costs) lmpcA.addCost(c);
+            for (auto& c : a.cstrs) lmpcA.addConstraint(c);
+            CHECK(lmpcA.solve());
+            copra::InitialStateLMPC lmpcB(ps);
+            // (the reference runs this case on QLD with the default R = 0, which no Cholesky-based solver -- QuadProgDense
+            //  included -- can factorise, reference quirk Q6; with x0lb == x0ub and a tiny R the dual active-set method
+            //  -- the CPU oracle's as well -- reports "no solution" on this badly scaled problem, so R = I here: the
+            //  identities checked below do not depend on R)
+            lmpcB.resetInitialStateCost(MatrixXd::Identity(2, 2), VectorXd::Zero(2));
+            for (auto& c : b.costs) lmpcB.addCost(c);
+            for (auto& c : b.cstrs) lmpcB.addConstraint(c);
+            CHECK(lmpcB.solve());
+            if (lmpcA.fail() != 0 || lmpcB.fail() != 0) {
+                std::printf("comparison case: solve failed (LMPC %d, InitialStateLMPC %d, fullSize = %d)\n", lmpcA.fail(), lmpcB.fail(), fullSize);
+                continue;
+            }
+            CHECK(lmpcA.nrEqConstr() == lmpcB.nrEqConstr());
+            CHECK(lmpcA.nrIneqConstr() == lmpcB.nrIneqConstr());
+            const int n = ps->fullUDim;
+            CHECK(max_abs_diff(lmpcA.Q(), lmpcB.Q(), 2, 2) <= 1e-6);
+            CHECK(max_abs_diff(lmpcA.Aineq(), lmpcB.Aineq(), 0, 2) <= 1e-6);
+            for (int i = 0; i < n; ++i) {
+                CHECK(std::fabs(lmpcA.lb()(i) - lmpcB.lb()(2 + i)) <= 1e-6);
+                CHECK(std::fabs(lmpcA.ub()(i) - lmpcB.ub()(2 + i)) <= 1e-6);
+            }
+            // bounds default to ps->x0 on both sides: the initial state cannot move (:236-252)
+            for (int i = 0; i < 2; ++i) {
+                CHECK(std::fabs(lmpcA.trajectory()(i) - s_init(i)) <= 1e-6);
+                CHECK(std::fabs(lmpcB.trajectory()(i) - s_init(i)) <= 1e-6);
+            }
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);
     const char* mode = argc > 1 ? argv[1] : "errors";
     try {
         if (!std::strcmp(mode, "errors")) error_handlers();
-        if (!std::strcmp(mode, "solve")) solve_cases();
+        if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
+        if (!std::strcmp(mode, "initial_state")) initial_state_cases();
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());
         return 2;

@@ -31,7 +31,19 @@ def test_error_handlers_like_TestLMPC():
 
 
 @pytest.mark.gpu
-def test_solve_cases_like_TestLMPC():
+@pytest.mark.parametrize("steps", [12, 300])
+def test_solve_cases_like_TestLMPC(steps):
+    """TestLMPC.cpp:36-771: the twelve {cost} x {constraint} cases with the reference's acceptance checks, through the
+    C++ mirror of copra's classes; 12 steps = one-wave kernel, 300 steps (the reference's nbStep) = workgroup kernel"""
     _build()
-    r = subprocess.run([EXE, "solve"], capture_output=True, text=True)
+    r = subprocess.run([EXE, "solve", str(steps)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_initial_state_cases_like_TestLMPC_InitialState():
+    """TestLMPC_InitialState.cpp: INITIAL-STATE-OPTIMIZATION and LMPC_AND_INITIAL-STATE-LMPC_COMPARISON, per-step and
+    full-size entries, through copra::InitialStateLMPC of the C++ mirror"""
+    _build()
+    r = subprocess.run([EXE, "initial_state"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
