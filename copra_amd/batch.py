@@ -80,6 +80,14 @@ class BatchLMPC:
                                                          xb.ctypes.data, 0))
 
     # PreviewSystem::xInit for every instance
+    def set_shared_system(self, A, B, d):
+        """Shared-model receding-horizon fast path: ONE system (A (nx,nx), B (nx,nu), d (nx)) for the whole batch;
+        the per-instance initial states come from set_x0.  The factorisation is done once, at the next solve()."""
+        Ac = np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)  # column-major
+        Bc = np.ascontiguousarray(np.asarray(B, dtype=np.float64).T)
+        dc = np.ascontiguousarray(d, dtype=np.float64)
+        _capi.check(self._lib.copra_batch_set_shared_system(self._h, Ac.ctypes.data, Bc.ctypes.data, dc.ctypes.data, 0))
+
     def set_x0(self, x0):
         if _is_torch(x0):
             self._x0 = x0

@@ -6,10 +6,12 @@
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
 #include "lmpc_large.hpp"
+#include "lmpc_shared.hpp"
 #include "plan_builder.hpp"
 #include "qp_dense.hpp"
 #include "qp_dense_large.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,8 +44,33 @@ __global__ __launch_bounds__(64) void copra_lmpc_fused_tier2_kernel(const FusedP
     }
 }
 
+// Shared-model fast path (lmpc_shared.hpp): the factorisation comes from a one-workgroup prepare launch of the fused
+// kernel; same two-tier scheme (own symbols so that profiles keep the kernels apart).
+template <int NX, int NU, int NH>
+__global__ __launch_bounds__(64) void copra_lmpc_shared_kernel(const FusedPlan P)
+{
+    lmpc_shared_body<NX, NU, NH>(P, (int)blockIdx.x);
+}
+template <int NX, int NU, int NH>
+__global__ __launch_bounds__(64) void copra_lmpc_shared_tier2_kernel(const FusedPlan P)
+{
+    const int count = *P.ovf_count;
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        lmpc_shared_body<NX, NU, NH>(P, P.ovf_list[k]);
+        __syncthreads();
+    }
+}
+
 namespace {
 using fused_kernel_t = void (*)(const FusedPlan);
+fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
+{
+    if (P.nx == 6 && P.nu == 3 && P.N == 20)
+        return tier2 ? copra_lmpc_shared_tier2_kernel<6, 3, 20> : copra_lmpc_shared_kernel<6, 3, 20>;
+    if (P.nx == 2 && P.nu == 1 && P.N == 10)
+        return tier2 ? copra_lmpc_shared_tier2_kernel<2, 1, 10> : copra_lmpc_shared_kernel<2, 1, 10>;
+    return tier2 ? copra_lmpc_shared_tier2_kernel<0, 0, 0> : copra_lmpc_shared_kernel<0, 0, 0>;
+}
 // the BASELINE.json shapes get their own instantiation
 fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
@@ -150,6 +177,10 @@ struct copra_batch {
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
     int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
+    // shared-model fast path: one (A, B, d) for the whole batch, factorised once (copra_batch_set_shared_system)
+    bool shared = false, model_dirty = true, shared_attr_set = false;
+    double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
+    std::vector<double> shA, shB, shd;
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
     int large_grid = 0;
     // InitialStateLMPC variant
@@ -198,6 +229,8 @@ static FusedPlan device_plan(const copra_batch* h)
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
     P.ws = h->d_ws;
+    P.model_out = nullptr;
+    P.model = nullptr;
     return P;
 }
 
@@ -349,6 +382,10 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->own_x0lb);
     (void)hipFree(h->own_x0ub);
     (void)hipFree(h->d_ws);
+    (void)hipFree(h->d_shA);
+    (void)hipFree(h->d_shB);
+    (void)hipFree(h->d_shd);
+    (void)hipFree(h->d_model);
     (void)hipFree(h->d_ovf_count);
     (void)hipFree(h->d_ovf_list);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -387,6 +424,99 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     return COPRA_OK;
 }
 
+copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, const double* B, const double* d,
+    int on_device)
+{
+    if (!h || !A || !B || !d) return fail(COPRA_ERR_ARG, "copra_batch_set_shared_system: null argument");
+    const FusedPlan& P = h->hp.plan;
+    if (P.initial_state || h->hp.large)
+        return fail(COPRA_ERR_UNSUPPORTED, "the shared-model fast path covers LMPC with at most 64 decision variables");
+    const size_t nA = (size_t)P.nx * P.nx, nB = (size_t)P.nx * P.nu, nd = (size_t)P.nx;
+    h->shA.resize(nA), h->shB.resize(nB), h->shd.resize(nd);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+    HIP_TRY(hipMemcpy(h->shA.data(), A, nA * sizeof(double), kind));
+    HIP_TRY(hipMemcpy(h->shB.data(), B, nB * sizeof(double), kind));
+    HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
+    h->shared = true;
+    h->model_dirty = true;
+    return COPRA_OK;
+}
+
+// One-off work of the shared-model path: nx + 1 probe instances (x0 = 0, e_0 .. e_{nx-1}) of the ordinary fused kernel
+// give c(x0) = c0 + C1 x0; one more launch stores J = R^-1, G, Phi, xi and the row norms (FusedPlan::model_out).
+static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
+{
+    const FusedPlan& HP = h->hp.plan;
+    const int nx = HP.nx, nu = HP.nu, N = HP.N, n = HP.n, X = HP.X, np1 = nx + 1;
+    const ModelLayout m = model_layout(nx, nu, N, n, X, h->hp.lds_full.ldj, HP.mgen);
+    if (!h->d_model) HIP_TRY(hipMalloc((void**)&h->d_model, (size_t)m.total * sizeof(double)));
+    const size_t nA = (size_t)nx * nx, nB = (size_t)nx * nu;
+    std::vector<double> Ap(nA * np1), Bp(nB * np1), dp((size_t)nx * np1), xp((size_t)nx * np1, 0.0);
+    for (int a = 0; a < np1; ++a) {
+        std::copy(h->shA.begin(), h->shA.end(), Ap.begin() + (size_t)a * nA);
+        std::copy(h->shB.begin(), h->shB.end(), Bp.begin() + (size_t)a * nB);
+        std::copy(h->shd.begin(), h->shd.end(), dp.begin() + (size_t)a * nx);
+        if (a > 0) xp[(size_t)a * nx + (a - 1)] = 1.0;
+    }
+    double *dA = nullptr, *dB = nullptr, *dd = nullptr, *dx = nullptr, *dQ = nullptr, *dC = nullptr;
+    hipError_t e = hipSuccess;
+    auto up = [&](double** dst, const std::vector<double>& src) {
+        hipError_t r = hipMalloc((void**)dst, src.size() * sizeof(double));
+        if (r == hipSuccess) r = hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (r != hipSuccess && e == hipSuccess) e = r;
+    };
+    up(&dA, Ap), up(&dB, Bp), up(&dd, dp), up(&dx, xp);
+    if (e == hipSuccess) e = hipMalloc((void**)&dQ, (size_t)n * n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dC, (size_t)n * np1 * sizeof(double));
+    auto release = [&]() {
+        (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dd), (void)hipFree(dx), (void)hipFree(dQ), (void)hipFree(dC);
+    };
+    if (e != hipSuccess) {
+        release();
+        return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
+    }
+    FusedPlan P = device_plan(h);
+    P.A = dA, P.B = dB, P.d = dd, P.x0 = dx;
+    P.batch = np1;
+    P.lds = h->hp.lds_full;
+    P.prof = nullptr;
+    P.prof_fine = nullptr;
+    for (int a = 0; a < np1 && e == hipSuccess; ++a) { // c(x0 = probe a) through the parity hook of the fused kernel
+        P.inst_offset = a;
+        P.dump_instance = a;
+        P.dump_only = 1;
+        P.dumpQ = dQ;
+        P.dumpc = dC + (size_t)a * n;
+        hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, s, P);
+        e = hipGetLastError();
+    }
+    P.inst_offset = 0;
+    P.dump_instance = 0;
+    P.dump_only = 0;
+    P.dumpQ = P.dumpc = nullptr;
+    P.model_out = h->d_model;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, s, P);
+        e = hipGetLastError();
+    }
+    std::vector<double> C((size_t)n * np1);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(C.data(), dC, C.size() * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        std::vector<double> lin((size_t)n * np1); // c0 | C1 (n x nx, column-major)
+        for (int j = 0; j < n; ++j) lin[(size_t)j] = C[(size_t)j];
+        for (int a = 0; a < nx; ++a)
+            for (int j = 0; j < n; ++j) lin[(size_t)n + (size_t)a * n + j] = C[(size_t)(a + 1) * n + j] - C[(size_t)j];
+        e = hipMemcpy(h->d_model + m.c0, lin.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(h->d_model + m.C1, lin.data() + n, (size_t)n * nx * sizeof(double), hipMemcpyHostToDevice);
+    }
+    release();
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
+    h->model_dirty = false;
+    return COPRA_OK;
+}
+
 copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device)
 {
     if (!h || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_x0: null argument");
@@ -416,6 +546,42 @@ copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double
 copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
+    if (h->shared) {
+        if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
+        hipStream_t s = (hipStream_t)hip_stream;
+        h->last_stream = s;
+        if (h->hp.plan.batch == 0) return COPRA_OK;
+        copra_status_t rc = ensure_lds_attr(h);
+        if (rc != COPRA_OK) return rc;
+        if (!h->shared_attr_set && h->hp.lds_full_bytes > 48 * 1024) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, false)),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, true)),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
+        }
+        h->shared_attr_set = true;
+        if (h->model_dirty) {
+            rc = prepare_shared_model(h, s);
+            if (rc != COPRA_OK) return rc;
+        }
+        FusedPlan P = device_plan(h);
+        P.model = h->d_model;
+        HIP_TRY(hipEventRecord(h->ev0, s));
+        if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
+        hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
+        if (h->hp.two_tier) {
+            FusedPlan P2 = P;
+            P2.lds = h->hp.lds_full;
+            P2.from_list = 1;
+            const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+            hipLaunchKernelGGL(select_shared_kernel(P2, true), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->timed = true;
+        return COPRA_OK;
+    }
     if (!h->A || !h->B || !h->d || !h->x0)
         return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
     const FusedPlan P = device_plan(h);

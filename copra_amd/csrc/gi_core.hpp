@@ -279,7 +279,7 @@ COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
 // ------------------------------------------------------------------------------------------------
 template <int NV, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
-    int& iter_main, int& iter_drop COPRA_FINE_ARGS)
+    int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false)
 {
     const int lane = lane_id();
     const int n = NV ? NV : n_rt;
@@ -288,7 +288,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     const int mtotal = mgen + 2 * n; // QuadProgSolver.cpp:51: the bounds are 2n more inequality rows
     double* J = S.J;
     int nact = 0;
-    bool have_J = false;
+    bool have_J = j_ready; // the shared-model path arrives with J = R^-1 in place
     iter_main = 0;
     iter_drop = 0;
     for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;

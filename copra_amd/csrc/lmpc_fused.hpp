@@ -621,6 +621,20 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     // ---- 4. + 5. solve ----
     stamp[4] = stamp[3];
     int status = gi_factorize<NV>(S, n, &stamp[4] COPRA_FINE_PASS);
+    if (P.model_out) { // "prepare" launch of the shared-model fast path (lmpc_shared.hpp); runs with the full layout
+        if (inst != P.dump_instance) return;
+        if (status == 0) gi_invert<NV>(S, n);
+        wave_sync();
+        const ModelLayout m = model_layout(nx, nu, N, n, X, ld, P.mgen);
+        double* out = P.model_out;
+        if (lane == 0) out[m.status] = (double)status;
+        for (int e = lane; e < n * ld; e += kWave) out[m.J + e] = S.J[e];
+        for (int e = lane; e < N * nx * nu; e += kWave) out[m.G + e] = G[e];
+        for (int e = lane; e < (N + 1) * nx * nx; e += kWave) out[m.Phi + e] = Phi[e];
+        for (int e = lane; e < X; e += kWave) out[m.Xi + e] = Xi[e];
+        for (int e = lane; e < P.mgen; e += kWave) out[m.nb + e] = nb[e];
+        return;
+    }
     stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
     if (status == 0)

@@ -1,0 +1,106 @@
+// lmpc_shared.hpp -- shared-model receding-horizon fast path: every instance of the batch has the
+// SAME preview system (A, B, d) and the same costs / constraints; only x0 differs (PreviewSystem::xInit between
+// solves, include/PreviewSystem.h:52-54, with isUpdated left true so that LMPC::updateSystem does not rebuild Psi,
+// src/LMPC.cpp:233).  Then Psi, the Hessian, its Cholesky factor and J = R^-1 are the same for the whole batch: a
+// one-workgroup "prepare" launch of the fused kernel computes them once (lmpc_fused.hpp, model_out) and each wave here
+// only
+//   * forms the free response  xbar = Phi x0 + xi  and the gradient  c = c0 + C1 x0  (the reference factors the
+//     x0-dependence the same way: c = E' x0 + f, costFunctions.cpp:80; b = z - Y x0, constraints.cpp:81),
+//   * copies J into its LDS (the active-set updates rotate it per instance), takes x = -J J' c,
+//   * runs the same Goldfarb-Idnani loop (gi_core.hpp) and writes the results.
+// Same LDS layouts and the same two-tier overflow scheme as the fused kernel.
+#pragma once
+
+#include "lmpc_fused.hpp"
+
+namespace copra_hip {
+
+template <int NX_, int NU_, int NH_>
+COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
+{
+    double* lds = lds_base();
+    const LdsLayout& L = P.lds;
+    const int lane = lane_id();
+    const int nx = NX_ ? NX_ : P.nx, nu = NU_ ? NU_ : P.nu, N = NH_ ? NH_ : P.N;
+    const int n = nu * N, X = nx * (N + 1);
+    constexpr int NV = NU_ * NH_;
+    double* G = lds + L.G;
+    double* Xbar = lds + L.Xbar;
+    double* Xcur = lds + L.Xcur;
+    double* nb = lds + L.nb;
+    SolverLds S = carve_solver(lds, L);
+    const int ld = NV ? (NV | 1) : S.ldj;
+    const ModelLayout m = model_layout(nx, nu, N, n, X, ld, P.mgen);
+    const double* M = P.model;
+    COPRA_FINE_DECL;
+
+    StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
+    rows.cache_own_row();
+    int status = (int)M[m.status];
+    // ---- this instance's x0; shared tables -> LDS ----
+    const double* x0 = P.x0 + (size_t)inst * nx;
+    double x0r[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x0r[c] = (c < nx) ? x0[c] : 0.0;
+    for (int e = lane; e < n * ld; e += kWave) S.J[e] = M[m.J + e];
+    for (int e = lane; e < N * nx * nu; e += kWave) G[e] = M[m.G + e];
+    for (int e = lane; e < P.mgen; e += kWave) nb[e] = M[m.nb + e];
+    for (int row = lane; row < X; row += kWave) { // free response  xbar = Phi x0 + xi
+        const int k = row / nx, r = row - k * nx;
+        const double* Pk = M + m.Phi + k * nx * nx + r;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < nx) acc += Pk[nx * c] * x0r[c];
+        Xbar[row] = acc + M[m.Xi + row];
+    }
+    if (lane < n) { // c = c0 + C1 x0
+        double acc = M[m.c0 + lane];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < nx) acc += M[m.C1 + (size_t)c * n + lane] * x0r[c];
+        S.cvec[lane] = acc;
+    }
+    wave_sync();
+    // ---- unconstrained minimiser x = -J (J' c) ----
+    {
+        const int lj = (lane < n) ? lane : n - 1;
+        double t = 0.0; // t_j = sum_i J(i, j) c_i : column j of the upper-triangular J
+        for (int i = 0; i <= lj; ++i) t += S.J[i * ld + lj] * S.cvec[i];
+        if (lane < n) S.dv[lane] = t;
+        wave_sync();
+        double x = 0.0; // x_i = -sum_{j >= i} J(i, j) t_j
+        for (int j = lj; j < n; ++j) x += S.J[lj * ld + j] * S.dv[j];
+        if (lane < n) S.xs[lane] = -x;
+        wave_sync();
+    }
+    int it_main = 0, it_drop = 0;
+    if (status == 0)
+        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS, true);
+    wave_sync();
+    if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch
+        if (lane == 0) {
+            const int slot = atomic_append(P.ovf_count);
+            P.ovf_list[slot] = inst;
+            P.status[inst] = 4;
+        }
+        return;
+    }
+    if (status == 0) {
+        rows.refresh_trajectory(S.xs);
+        wave_sync();
+        for (int e = lane; e < n; e += kWave) P.control[(size_t)inst * n + e] = S.xs[e];
+        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = Xcur[e];
+    } else {
+        const double qnan = __builtin_nan("");
+        for (int e = lane; e < n; e += kWave) P.control[(size_t)inst * n + e] = qnan;
+        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = qnan;
+    }
+    if (lane == 0) {
+        P.status[inst] = status;
+        P.iter[2 * (size_t)inst] = it_main;
+        P.iter[2 * (size_t)inst + 1] = it_drop;
+    }
+}
+
+} // namespace copra_hip

@@ -208,6 +208,13 @@ struct FusedPlan {
     int* ovf_count; // device counter (reset before every solve)
     int* ovf_list; // [batch] instance ids
     int from_list; // ... and the second launch (full layout) takes its instances from that queue
+    // shared-model fast path (lmpc_shared.hpp): the whole batch shares (A, B, d), only x0 differs per instance.
+    //   model_out != nullptr : "prepare" launch of the fused kernel -- after the factorisation instance
+    //                          `dump_instance` stores J = R^-1, G, Phi, xi and the row norms there and stops
+    //   model     != nullptr : lmpc_shared_body reads them (+ c0, C1: c = c0 + C1 x0) instead of rebuilding
+    // layout (doubles): status | J [n * ldj] | G [N nx nu] | Phi [(N+1) nx nx] | xi [X] | nb [mgen] | c0 [n] | C1 [n x nx]
+    double* model_out;
+    const double* model;
     // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
     int use_large;
     LargeLayout large;
@@ -216,6 +223,35 @@ struct FusedPlan {
     long long* prof_fine; // profiling builds only (-DCOPRA_FINE_PROFILE): 32 raw stamps per instance
     LdsLayout lds;
 };
+
+// offsets (doubles) into the shared-model buffer, see FusedPlan::model
+struct ModelLayout {
+    long long status, J, G, Phi, Xi, nb, c0, C1, total;
+};
+#ifdef __HIPCC__
+#define COPRA_HOST_DEVICE __host__ __device__
+#else
+#define COPRA_HOST_DEVICE
+#endif
+COPRA_HOST_DEVICE inline ModelLayout model_layout(int nx, int nu, int N, int n, int X, int ldj, int mgen)
+{
+    ModelLayout m;
+    long long o = 0;
+#define COPRA_TAKE(field, count)                                                                                      \
+    m.field = o;                                                                                                      \
+    o += ((long long)(count) + 1) & ~1LL
+    COPRA_TAKE(status, 2);
+    COPRA_TAKE(J, (long long)n * ldj);
+    COPRA_TAKE(G, (long long)N * nx * nu);
+    COPRA_TAKE(Phi, (long long)(N + 1) * nx * nx);
+    COPRA_TAKE(Xi, X);
+    COPRA_TAKE(nb, mgen > 0 ? mgen : 1);
+    COPRA_TAKE(c0, n);
+    COPRA_TAKE(C1, (long long)n * nx);
+#undef COPRA_TAKE
+    m.total = o;
+    return m;
+}
 
 // dense batched QP kernel (plug-in point 1): plain SolverInterface::SI_solve arguments, batch-major
 struct DensePlan {

@@ -127,6 +127,18 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     const double* x0, int on_device);
 copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device);
 
+/* ---- shared-model receding-horizon fast path: ONE preview system (A [nx x nx], B [nx x nu], d [nx], column-major) for
+ *      the whole batch; only x0 differs per instance (copra_batch_set_x0, [batch][nx]).  This is the reference's own
+ *      receding-horizon use: PreviewSystem::xInit between solves with isUpdated left true (include/PreviewSystem.h:
+ *      52-54, src/LMPC.cpp:233), where c = E'x0 + f and b = z - Y x0 carry the whole x0-dependence
+ *      (src/costFunctions.cpp:80, src/constraints.cpp:81).  The preview matrices, the Hessian, its Cholesky factor and
+ *      J = R^-1 are then computed ONCE (at the first copra_batch_solve after this call) and every solve only forms the
+ *      free response and the gradient, copies J and runs the active-set loop.  LMPC with at most 64 decision variables;
+ *      InitialStateLMPC / larger problems: COPRA_ERR_UNSUPPORTED.  Results are those of copra_batch_set_system with the
+ *      same system replicated. ---- */
+copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, const double* B, const double* d,
+    int on_device);
+
 /* ---- optional: let the caller own the result buffers (device pointers, e.g. torch tensors that are later handed to
  *      an RCCL gather); must be called before copra_batch_solve and stay valid.  Sizes as in the results block. ---- */
 copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter);

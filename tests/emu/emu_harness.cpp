@@ -5,6 +5,7 @@
 #include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
+#include "../../copra_amd/csrc/lmpc_shared.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
 #include "../../copra_amd/csrc/qp_dense_large.hpp"
@@ -227,6 +228,94 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             const int b = ovf_list[(size_t)k];
             int r = emu::run_wave([&]() { body(P2, b); }, hp.lds_full_bytes, b, dims->batch);
             if (r != 0) return -100;
+        }
+    }
+    return 0;
+}
+
+// Shared-model fast path exactly as copra_batch_set_shared_system + copra_batch_solve run it: nx + 1 probe instances of
+// the fused body give c(x0) = c0 + C1 x0, one "prepare" run stores the factorisation, then lmpc_shared_body per
+// instance (compact layout first, overflow queue, full layout).  A, B, d: ONE system; x0: [batch][nx].
+int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
+    const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
+    double* control, double* trajectory, int* status, int* iter, int* sizes /* overflowed */)
+{
+    HostPlan hp;
+    copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, nullptr);
+    if (rc != COPRA_OK) {
+        fprintf(stderr, "emu: %s\n", hp.error.c_str());
+        return (int)rc;
+    }
+    if (hp.large) return (int)COPRA_ERR_UNSUPPORTED;
+    point_plan_to_host(hp);
+    FusedPlan P = hp.plan;
+    const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X, np1 = nx + 1;
+    const ModelLayout m = model_layout(nx, nu, N, n, X, hp.lds_full.ldj, P.mgen);
+    std::vector<double> model((size_t)m.total, 0.0);
+    std::vector<double> Ap((size_t)nx * nx * np1), Bp((size_t)nx * nu * np1), dp((size_t)nx * np1), xp((size_t)nx * np1, 0.0);
+    for (int a = 0; a < np1; ++a) {
+        memcpy(&Ap[(size_t)a * nx * nx], A, sizeof(double) * nx * nx);
+        memcpy(&Bp[(size_t)a * nx * nu], B, sizeof(double) * nx * nu);
+        memcpy(&dp[(size_t)a * nx], d, sizeof(double) * nx);
+        if (a > 0) xp[(size_t)a * nx + (a - 1)] = 1.0;
+    }
+    std::vector<double> dQ((size_t)n * n), dC((size_t)n * np1);
+    int ovf_count = 0;
+    std::vector<int> ovf_list((size_t)(dims->batch > 0 ? dims->batch : 1));
+    P.ovf_count = &ovf_count;
+    P.ovf_list = ovf_list.data();
+    P.from_list = 0;
+    P.control = control;
+    P.trajectory = trajectory;
+    P.status = status;
+    P.iter = iter;
+    FusedPlan Q = P; // prepare launches
+    Q.A = Ap.data(), Q.B = Bp.data(), Q.d = dp.data(), Q.x0 = xp.data();
+    Q.batch = np1;
+    Q.lds = hp.lds_full;
+    auto fused = [&](const FusedPlan& PP, int b) {
+        const int rp = specialised_cost_rows(PP.nx, PP.nu, PP.N, PP.rmax, PP.rfull);
+        if (PP.nx == 6 && rp == 6)
+            lmpc_fused_body<6, 3, 20, 6>(PP, b);
+        else if (PP.nx == 2 && rp == 2)
+            lmpc_fused_body<2, 1, 10, 2>(PP, b);
+        else
+            lmpc_fused_body<0, 0, 0, 0>(PP, b);
+    };
+    for (int a = 0; a < np1; ++a) {
+        Q.dump_instance = a;
+        Q.dump_only = 1;
+        Q.dumpQ = dQ.data();
+        Q.dumpc = dC.data() + (size_t)a * n;
+        if (emu::run_wave([&]() { fused(Q, a); }, hp.lds_full_bytes, a, np1) != 0) return -100;
+    }
+    Q.dump_instance = 0;
+    Q.dump_only = 0;
+    Q.dumpQ = Q.dumpc = nullptr;
+    Q.model_out = model.data();
+    if (emu::run_wave([&]() { fused(Q, 0); }, hp.lds_full_bytes, 0, np1) != 0) return -100;
+    for (int j = 0; j < n; ++j) model[(size_t)m.c0 + j] = dC[(size_t)j];
+    for (int a = 0; a < nx; ++a)
+        for (int j = 0; j < n; ++j) model[(size_t)m.C1 + (size_t)a * n + j] = dC[(size_t)(a + 1) * n + j] - dC[(size_t)j];
+    P.model = model.data();
+    P.x0 = x0;
+    auto shared = [&](const FusedPlan& PP, int b) {
+        if (PP.nx == 6 && PP.nu == 3 && PP.N == 20)
+            lmpc_shared_body<6, 3, 20>(PP, b);
+        else if (PP.nx == 2 && PP.nu == 1 && PP.N == 10)
+            lmpc_shared_body<2, 1, 10>(PP, b);
+        else
+            lmpc_shared_body<0, 0, 0>(PP, b);
+    };
+    for (int b = 0; b < dims->batch; ++b)
+        if (emu::run_wave([&]() { shared(P, b); }, hp.lds_bytes, b, dims->batch) != 0) return -100;
+    if (sizes) sizes[0] = ovf_count;
+    if (ovf_count > 0) {
+        FusedPlan P2 = P;
+        P2.lds = hp.lds_full;
+        for (int k = 0; k < ovf_count; ++k) {
+            const int b = ovf_list[(size_t)k];
+            if (emu::run_wave([&]() { shared(P2, b); }, hp.lds_full_bytes, b, dims->batch) != 0) return -100;
         }
     }
     return 0;

@@ -24,6 +24,7 @@ def lib():
         _lib = C.CDLL(os.path.join(_HERE, "libcopra_emu.so"))
         _lib.emu_lmpc_solve.restype = C.c_int
         _lib.emu_qp_dense.restype = C.c_int
+        _lib.emu_lmpc_solve_shared.restype = C.c_int
     return _lib
 
 
@@ -93,6 +94,32 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
         out.update(Q=np.array(dQ), c=dc, Aeq=np.array(dA[:neq]), beq=db_[:neq], Aineq=np.array(dA[neq:mgen]),
                    bineq=db_[neq:mgen])
     return out
+
+
+def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs):
+    """shared-model fast path: ONE system (A, B, d), x0 of shape (batch, nx)"""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+    batch, nx, nu = x0.shape[0], A.shape[0], B.shape[1]
+    keep = []
+    cc = _capi.pack_costs(costs, keep)
+    kk = _capi.pack_cstrs(cstrs, keep)
+    dims = _capi.Dims(nx, nu, N, batch)
+    Ac, Bc = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)  # column-major
+    dc = np.ascontiguousarray(d, dtype=np.float64)
+    u = np.full((batch, nu * N), np.nan)
+    tr = np.full((batch, nx * (N + 1)), np.nan)
+    st = np.full(batch, -1, dtype=np.int32)
+    it = np.zeros((batch, 2), dtype=np.int32)
+    sizes = (C.c_int * 2)()
+    p = _capi.dptr
+    rc = lib().emu_lmpc_solve_shared(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ac), p(Bc), p(dc), p(x0), p(u),
+                                     p(tr), st.ctypes.data_as(C.POINTER(C.c_int)),
+                                     it.ctypes.data_as(C.POINTER(C.c_int)), sizes)
+    if rc != 0:
+        raise RuntimeError("emulator failed rc=%d" % rc)
+    return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0])
 
 
 def qp_dense(Q, c, Aeq, beq, Aineq, bineq, XL, XU):

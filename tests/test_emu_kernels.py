@@ -260,6 +260,28 @@ def test_large_full_size_cost_entries(emu, oracle, initial_state):
     assert _rel(re["control"][0], ro["control"]) <= RTOL
 
 
+def test_shared_model_fast_path(emu, oracle):
+    """lmpc_shared.hpp: one (A, B, d) for the whole batch, factorised once by a prepare run of the fused body;
+    per instance only xbar = Phi x0 + xi, c = c0 + C1 x0, x = -J J'c and the active-set loop.  Same decisions and the
+    same solution as a fresh controller per instance (the oracle), for the compile-time and the generic shapes."""
+    from copra_amd import workloads
+    wl = workloads.com_preview(10, v_max=0.25, u_max=1.2)
+    A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
+    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    for k in range(10):
+        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+    pb = F.mixed_system("mixed", N=12)
+    x0 = np.tile(pb["x0"], (4, 1))
+    x0[:, 1] += np.linspace(-0.5, 0.5, 4)
+    re = emu.lmpc_solve_shared(pb["A"], pb["B"], pb["d"], x0, 12, pb["costs"], pb["cstrs"])
+    for k in range(4):
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 12, pb["costs"], pb["cstrs"])
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
+        assert _rel(re["control"][k], ro["control"]) <= RTOL
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi

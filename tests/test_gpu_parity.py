@@ -480,3 +480,45 @@ def test_full_size_cost_entries_long_horizon(oracle, initial_state):
         assert res["status"][k] == ro["status"] == 0 and tuple(res["iter"][k]) == tuple(ro["iter"])
         assert _rel(res["control"][k], ro["control"]) <= 1e-6
         assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
+
+
+def test_shared_model_fast_path(oracle):
+    """copra_batch_set_shared_system: the batch shares (A, B, d); the factorisation is done once, every solve only
+    forms c(x0), copies J and runs the active-set loop.  Must reproduce the ordinary path (same system replicated)
+    on every instance -- including those that overflow the compact layout into the second tier -- and the oracle;
+    then a receding-horizon tick: new x0, no re-factorisation."""
+    from copra_amd import BatchLMPC, workloads
+    b = 4096
+    wl = workloads.com_preview(b, v_max=0.15, u_max=0.8)  # tight: up to ~28 iterations, ~1/3 infeasible (status 1)
+    A, B, d = wl["A"][5], wl["B"][5], wl["d"][5]
+    ref_eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    ref_eng.set_system(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), wl["x0"])
+    ref_eng.solve()
+    ref = ref_eng.results()
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_shared_system(A, B, d)
+    eng.set_x0(wl["x0"])
+    eng.solve()
+    res = eng.results()
+    assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
+    ok = ref["status"] == 0
+    # some instances hold more than 17 active constraints: they go through the second tier (full LDS layout)
+    assert ok.sum() > 0.5 * b and (res["iter"][ok, 0] - res["iter"][ok, 1]).max() > 17
+    assert _rel(res["control"][ok], ref["control"][ok]) <= 1e-9
+    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= 1e-9
+    for k in range(0, b, 512):
+        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        assert ro["status"] == res["status"][k]
+        if ro["status"] == 0:
+            assert _rel(res["control"][k], ro["control"]) <= 1e-6
+    # next tick: every instance moves to the state it predicted for step 1
+    x1 = res["trajectory"][:, 6:12].copy()
+    x1[~ok] = wl["x0"][~ok]
+    eng.set_x0(x1)
+    eng.solve()
+    res1 = eng.results()
+    for k in range(0, b, 1024):
+        ro = oracle.lmpc_solve(A, B, d, x1[k], wl["N"], wl["costs"], wl["cstrs"])
+        assert ro["status"] == res1["status"][k]
+        if ro["status"] == 0:
+            assert _rel(res1["control"][k], ro["control"]) <= 1e-6
