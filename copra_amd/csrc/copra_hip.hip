@@ -424,6 +424,16 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     return COPRA_OK;
 }
 
+copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
+    const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
+{
+    if (!dims) return fail(COPRA_ERR_ARG, "copra_plan_check: null dims");
+    HostPlan hp;
+    const copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
+    if (rc != COPRA_OK) g_err = hp.error;
+    return rc;
+}
+
 copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, const double* B, const double* d,
     int on_device)
 {

@@ -106,6 +106,12 @@ copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs);
 void copra_batch_destroy(copra_batch_t* h);
 
+/* ---- the checks of copra_batch_create / copra_batch_create_initial_state WITHOUT touching the device: what
+ *      LMPC::addCost / addConstraint do when they call initializeCost / initializeConstraint (src/LMPC.cpp:118-128).
+ *      `is` may be NULL.  Returns COPRA_OK, COPRA_ERR_DOMAIN, COPRA_ERR_RUNTIME or COPRA_ERR_UNSUPPORTED. ---- */
+copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
+    const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is);
+
 /* ---- InitialStateLMPC variant (include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp): the decision vector is
  *      [x0; U]; costs contribute E and f, the Hessian is [[R + E Q^-1 E', E], [E', Q]] (InitialStateLMPC.cpp:77-122).
  *      Covered on the device for xDim + fullUDim <= 512 (xDim <= 16), per-step and full-size entries; other shapes

@@ -1,0 +1,212 @@
+"""The reference's Python surface (binding/python/CopraBindings.cpp, `import pyCopra as copra`) over the HIP engine:
+binding/python/tests/pyTests.py restated against copra_amd.pycopra with the reference's own setUp values
+(pyTests.py:12-56: falling mass, nbStep = 300 -> the workgroup-per-instance kernel) and acceptance checks."""
+import numpy as np
+import pytest
+
+import fixtures as F
+
+
+@pytest.fixture()
+def S():
+    class Setup:
+        timestep, mass, nbStep = 0.005, 5, 300
+        A = np.array([[1.0, timestep], [0.0, 1.0]])
+        B = np.array([[0.5 * timestep * timestep / mass], [timestep / mass]])
+        c = np.array([(-9.81 / 2.0) * timestep ** 2, -9.81 * timestep])
+        x0 = np.array([0.0, -5.0])
+        wu, wx = np.array([1e-4]), np.array([10.0, 10000.0])
+        xd, ud = np.zeros(2), np.zeros(1)
+        M, N = np.identity(2), np.ones((1, 1))
+        Gineq, hineq = np.ones((1, 1)), np.array([200.0])
+        Eineq, fineq = np.array([[0.0, 1.0]]), np.zeros(1)
+        uLower, uUpper = np.array([-np.inf]), np.array([200.0])
+        xLower, xUpper = np.array([-np.inf, -np.inf]), np.array([np.inf, 0.0])
+        x0Eq, xdEq = np.zeros(2), np.zeros(2)
+        Geq, heq = np.ones((1, 1)), np.array([200.0])
+        Eeq, feq = np.array([[1.0, 0.0], [0.0, 0.0]]), np.zeros(2)
+    return Setup
+
+
+def _controller(copra, S, x0=None):
+    ps = copra.PreviewSystem()
+    ps.system(S.A, S.B, S.c, S.x0 if x0 is None else x0, S.nbStep)
+    controller = copra.LMPC(ps)
+    xCost = copra.TargetCost(S.M, -S.xd)
+    uCost = copra.ControlCost(S.N, -S.ud)
+    xCost.weights(S.wx)
+    uCost.weights(S.wu)
+    controller.add_cost(xCost)
+    controller.add_cost(uCost)
+    return ps, controller, (xCost, uCost)
+
+
+def _split(traj):
+    return traj[0::2], traj[1::2]
+
+
+@pytest.mark.gpu
+def test_lmpc_ineq(S):  # pyTests.py:58-92
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S)
+    trajConstr = copra.TrajectoryConstraint(S.Eineq, S.fineq)
+    contConstr = copra.ControlConstraint(S.Gineq, S.hineq)
+    controller.add_constraint(trajConstr)
+    controller.add_constraint(contConstr)
+    assert controller.solve()
+    pos, vel = _split(controller.trajectory())
+    assert abs(S.xd[1] - vel[-1]) < 5e-4  # assertAlmostEqual(places=3)
+    assert pos.max() <= S.x0[0] + 1e-9
+    assert controller.control().max() <= S.hineq[0] + 1e-6
+    assert controller.solve_time() > 0 and controller.solve_and_build_time() >= controller.solve_time()
+
+
+@pytest.mark.gpu
+def test_lmpc_mixed(S):  # pyTests.py:94-132
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S)
+    mixedConstr = copra.MixedConstraint(S.Eineq, S.Gineq, S.hineq)
+    controller.add_constraint(mixedConstr)
+    assert controller.solve()
+    control, traj = controller.control(), controller.trajectory()
+    pos, vel = _split(traj)
+    assert abs(S.xd[1] - vel[-1]) < 5e-4 and pos.max() <= S.x0[0] + 1e-9
+    assert (vel[:-1] + control <= S.hineq[0] + 1e-6).all()
+
+
+@pytest.mark.gpu
+def test_lmpc_bound(S):  # pyTests.py:134-169
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S)
+    trajConstr = copra.TrajectoryBoundConstraint(S.xLower, S.xUpper)
+    contConstr = copra.ControlBoundConstraint(S.uLower, S.uUpper)
+    controller.add_constraint(trajConstr)
+    controller.add_constraint(contConstr)
+    assert controller.solve()
+    pos, vel = _split(controller.trajectory())
+    assert abs(S.xd[1] - vel[-1]) < 5e-4 and pos.max() <= S.x0[0] + 1e-9
+    assert vel.max() <= S.xUpper[1] + 1e-6 and controller.control().max() <= S.uUpper[0] + 1e-6
+
+
+@pytest.mark.gpu
+def test_lmpc_eq(S):  # pyTests.py:171-203
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S, x0=S.x0Eq)
+    trajConstr = copra.TrajectoryConstraint(S.Eeq, S.feq, False)
+    controller.add_constraint(trajConstr)
+    assert controller.solve()
+    pos, vel = _split(controller.trajectory())
+    assert abs(S.xdEq[1] - vel[-1]) < 5e-4
+    assert np.abs(pos).max() <= 1e-6 and np.abs(vel).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_constraint_and_cost_deletion(S):  # pyTests.py:233-277: dropped pieces leave the controller after a solve
+    import copra_amd.pycopra as copra
+    ps = copra.PreviewSystem()
+    ps.system(S.A, S.B, S.c, S.x0, S.nbStep)
+    controller = copra.LMPC(ps)
+    trajConstr = copra.TrajectoryConstraint(S.Eineq, S.fineq)
+    contConstr = copra.ControlConstraint(S.Gineq, S.hineq)
+    trajEqConstr = copra.TrajectoryConstraint(S.Eeq, S.feq, False)
+    contEqConstr = copra.ControlConstraint(S.Geq, S.heq, False)
+    trajBdConstr = copra.TrajectoryBoundConstraint(S.xLower, S.xUpper)
+    contBdConstr = copra.ControlBoundConstraint(S.uLower, S.uUpper)
+    targetCost = copra.TargetCost(S.M, -S.xd)
+    trajectoryCost = copra.TrajectoryCost(S.M, -S.xd)
+    controlCost = copra.ControlCost(S.N, -S.ud)
+    mixedCost = copra.MixedCost(np.ones((1, 2)), S.N, -S.ud)
+    for c in (trajConstr, contConstr, trajEqConstr, contEqConstr, trajBdConstr, contBdConstr):
+        controller.add_constraint(c)
+    for c in (targetCost, trajectoryCost, controlCost, mixedCost):
+        controller.add_cost(c)
+    del c
+    del trajConstr
+    targetCost.weights(S.wx)
+    controlCost.weights(S.wu)
+    del trajEqConstr, contEqConstr, trajBdConstr, contBdConstr, trajectoryCost, mixedCost
+    assert not controller.solve()  # contradictory equalities are still in
+    assert controller.solve()  # "Has kept the contConstr only"
+
+
+@pytest.mark.gpu
+def test_preview_system_still_exists_and_receding_horizon(S):  # pyTests.py:279-309 + PreviewSystem::xInit
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S)
+    trajConstr = copra.TrajectoryConstraint(S.Eineq, S.fineq)
+    contConstr = copra.ControlConstraint(S.Gineq, S.hineq)
+    controller.add_constraint(trajConstr)
+    controller.add_constraint(contConstr)
+    del ps
+    assert controller.solve()
+    traj = controller.trajectory()
+    pos, vel = _split(traj)
+    assert abs(S.xd[1] - vel[-1]) < 5e-4 and pos.max() <= S.x0[0] + 1e-9
+    controller._ps.x_init(traj[2:4])
+    assert controller.solve() and np.abs(controller.trajectory()[:2] - traj[2:4]).max() < 1e-12
+
+
+def test_constructors_and_throw_handler(S):  # pyTests.py:205-216, 311-339 (no GPU needed)
+    import copra_amd.pycopra as copra
+    ps = copra.PreviewSystem()
+    ps.system(S.A, S.B, S.c, S.x0, S.nbStep)
+    controller = copra.LMPC(ps)
+    copra.LMPC()
+    copra.LMPC(copra.SolverFlag.QuadProgDense)
+    copra.LMPC(ps, copra.SolverFlag.QuadProgDense)
+    controller.initialize_controller(ps)
+    for bad in (lambda: copra.TrajectoryConstraint(np.identity(5), np.ones(2)),
+                lambda: copra.ControlConstraint(np.identity(5), np.ones(2)),
+                lambda: copra.MixedConstraint(np.identity(5), np.identity(5), np.ones(2)),
+                lambda: copra.TrajectoryBoundConstraint(np.ones(3), np.ones(2)),
+                lambda: copra.ControlBoundConstraint(np.ones(3), np.ones(2))):
+        with pytest.raises(RuntimeError):
+            controller.add_constraint(bad())
+    with pytest.raises(RuntimeError):
+        copra.PreviewSystem().system(np.ones((5, 2)), S.B, S.c, S.x0, S.nbStep)
+    with pytest.raises(TypeError):
+        copra.TrajectoryConstraint()  # pyTests.py:218-231: no default constructors
+    assert copra.AutoSpan.span_matrix(np.ones((1, 2)), 3).shape == (3, 6)
+    assert copra.AutoSpan.span_vector(np.ones(2), 6).shape == (6,)
+    with pytest.raises(RuntimeError):
+        copra.AutoSpan.span_vector(np.ones(4), 6)
+
+
+@pytest.mark.gpu
+def test_dynamic_walk():  # pyTests.py:341-443: CoM system, full-size 66 x 30 ControlConstraint, TargetCost
+    import copra_amd.pycopra as copra
+    pb = F.com_walk_problem()
+    ps = copra.PreviewSystem()
+    ps.system(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"])
+    controller = copra.LMPC(ps)
+    c0 = pb["cstrs"][0]
+    contConstr = copra.ControlConstraint(c0["G"], c0["f"])
+    k0 = pb["costs"][0]
+    targetCost = copra.TargetCost(k0["M"], k0["p"])
+    controller.add_constraint(contConstr)
+    controller.add_cost(targetCost)
+    assert controller.solve()
+    assert (np.asarray(c0["G"]) @ controller.control() <= np.asarray(c0["f"]) + 1e-6).all()
+    assert controller.solve_time() > 0
+
+
+@pytest.mark.gpu
+def test_initial_state_lmpc(S):  # include/InitialStateLMPC.h through the Python surface
+    import copra_amd.pycopra as copra
+    ps = copra.PreviewSystem()
+    ps.system(S.A, S.B, S.c, S.x0, 40)
+    controller = copra.InitialStateLMPC(ps)
+    controller.reset_initial_state_cost(10.0 * np.eye(2), np.zeros(2))
+    controller.reset_initial_state_bounds(S.x0 - 0.05, S.x0 + 0.05)
+    xCost = copra.TrajectoryCost(S.M, -S.xd)
+    uCost = copra.ControlCost(S.N, -S.ud)
+    xCost.weights(S.wx)
+    uCost.weights(S.wu)
+    bound = copra.ControlBoundConstraint(S.uLower, S.uUpper)
+    controller.add_cost(xCost)
+    controller.add_cost(uCost)
+    controller.add_constraint(bound)
+    assert controller.solve()
+    x0s = controller.initial_state()
+    assert (x0s <= S.x0 + 0.05 + 1e-6).all() and (x0s >= S.x0 - 0.05 - 1e-6).all()
+    assert np.abs(controller.trajectory()[:2] - x0s).max() < 1e-12
