@@ -124,15 +124,17 @@ int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
     if (const char* force = std::getenv("COPRA_LARGE_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
     if (std::getenv("COPRA_DEBUG"))
         fprintf(stderr, "[copra] large grid: %d CUs x %d workgroups of %d threads, %zu B LDS\n", cus, per_cu, threads, lds_bytes);
-    const long long g = (long long)cus * per_cu;
+    long long g = (long long)cus * per_cu;
+    if (const char* force = std::getenv("COPRA_LARGE_GRID")) g = std::atoi(force) > 0 ? std::atoi(force) : g; // (tuning aid)
     return (int)(g < batch ? g : batch);
 }
 
 typedef void (*large_kernel_t)(const FusedPlan);
 large_kernel_t select_large_kernel(const HostPlan& hp)
 {
-    // One variant.  A 168-VGPR build (three waves per SIMD, i.e. two five-wave workgroups per CU) was measured on
-    // MI355X and is not faster (config 5: 2011 vs 2048 solves/s): it pays for the occupancy with scratch spills.
+    // One variant.  Measured on MI355X (config 5): throughput grows linearly with the number of resident workgroups
+    // (128 -> 1.13 k, 256 -> 2.17 k solves/s), i.e. each workgroup is latency-bound and HBM is far from saturated, yet a
+    // 168-VGPR build (three waves per SIMD, two five-wave workgroups per CU by every documented limit) gains nothing.
     (void)hp;
     return copra_lmpc_large_kernel;
 }
