@@ -174,6 +174,18 @@ def main():
         m_rows = 63 + 2 * n
         flops = 2 * n * n * X + 2 * (nx ** 3 + nx * nx * nu) * (N - 1) + 2 * n ** 3 / 3.0 \
             + float(iters[:, 0].mean()) * (2 * m_rows * n + 4 * n * n)
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE + WRITE_SIZE,
+        # KB units; 8-byte-per-lane accesses calibrate at x1.0 on gfx950) -- not re-measured live
+        traffic, traffic_src = None, None
+        prof = os.path.join(ROOT, "profiles", "r01", "headline_rocprof_summary_final.json")
+        if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
+            try:
+                ctr = json.load(open(prof))["counters"]
+                kname = [k for k in ctr if "copra_lmpc_fused_kernel" in k][0]
+                traffic = 1024.0 * (ctr[kname]["FETCH_SIZE"]["mean_per_launch"] + ctr[kname]["WRITE_SIZE"]["mean_per_launch"])
+                traffic_src = "profiles/r01/headline_rocprof_summary_final.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except Exception:
+                traffic = None
         line = {
             "metric": "MPC solves/sec (batched) at (nx=6,nu=3,N=20); max |u-u_ref|",
             "value": value,
@@ -202,7 +214,8 @@ def main():
             "kernel_ms": kern * 1e3,
             "kernel_solves_per_s": batch / kern,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "kernel": "copra_lmpc_fused_kernel", "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "
                                  "construction",
