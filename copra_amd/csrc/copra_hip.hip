@@ -97,9 +97,18 @@ __global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) {
 
 // more than 64 decision variables: one MPC instance per workgroup (lmpc_large.hpp), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_lmpc_large_kernel(const FusedPlan P) { lmpc_large_body(P); }
+// Same body with the register budget of FOUR waves per SIMD (128 VGPRs, some spilling): on gfx950 a second five- to
+// eight-wave workgroup is only placed on a CU when every SIMD still has room for its share of the waves, which in
+// practice needs four wave slots per SIMD (tools/exp/coresidency.hip: 168 VGPRs = three slots never co-schedules
+// two five-wave workgroups although the occupancy API reports two).  Each workgroup is a chain of HBM round trips, so
+// two resident workgroups per CU win despite the spills: config 5 2.18 k -> 2.76 k solves/s, 300-step fixture
+// 35.0 k -> 41.2 k solves/s.  Used whenever the LDS footprint lets two workgroups share a CU.
+__global__ __launch_bounds__(kLargeMaxN, 4) void copra_lmpc_large_kernel_w4(const FusedPlan P) { lmpc_large_body(P); }
 
 // n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
+// more than four waves per workgroup: 128-VGPR build so that two workgroups share a CU (see copra_lmpc_large_kernel_w4)
+__global__ __launch_bounds__(kLargeMaxN, 4) void copra_qp_dense_large_kernel_w4(const DensePlan P) { qp_dense_large_body(P); }
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -108,6 +117,17 @@ namespace {
 
 thread_local std::string g_err;
 
+// resident workgroups per CU the runtime reports for a kernel variant (at least 1, at most 8)
+int large_per_cu(const void* kernel, int threads, size_t lds_bytes)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    return per_cu > 8 ? 8 : per_cu;
+}
+
 // persistent grid of the workgroup-per-instance kernels: as many workgroups as the device keeps resident
 int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
 {
@@ -115,12 +135,7 @@ int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 1;
-    }
-    if (per_cu > 4) per_cu = 4;
+    int per_cu = large_per_cu(kernel, threads, lds_bytes);
     if (const char* force = std::getenv("COPRA_LARGE_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
     if (std::getenv("COPRA_DEBUG"))
         fprintf(stderr, "[copra] large grid: %d CUs x %d workgroups of %d threads, %zu B LDS\n", cus, per_cu, threads, lds_bytes);
@@ -129,13 +144,25 @@ int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
     return (int)(g < batch ? g : batch);
 }
 
-typedef void (*large_kernel_t)(const FusedPlan);
-large_kernel_t select_large_kernel(const HostPlan& hp)
+// The 128-VGPR build of a kernel is worth its spills only where it puts MORE workgroups on a CU than the full-budget
+// build.  (The occupancy API is trusted for one to four waves per SIMD; for five- to eight-wave workgroups at THREE
+// waves per SIMD it over-reports, tools/exp/coresidency.hip -- that budget is not used.)
+bool prefer_w4(const void* full, const void* w4, int threads, size_t lds_bytes)
 {
-    // One variant.  Measured on MI355X (config 5): throughput grows linearly with the number of resident workgroups
-    // (128 -> 1.13 k, 256 -> 2.17 k solves/s), i.e. each workgroup is latency-bound and HBM is far from saturated, yet a
-    // 168-VGPR build (three waves per SIMD, two five-wave workgroups per CU by every documented limit) gains nothing.
-    (void)hp;
+    if (lds_bytes > 48 * 1024) { // the occupancy query honours the opt-in limit of each symbol
+        (void)hipFuncSetAttribute(full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    }
+    if (std::getenv("COPRA_LARGE_NO_W4")) return false; // (tuning aid)
+    return large_per_cu(w4, threads, lds_bytes) > large_per_cu(full, threads, lds_bytes);
+}
+
+typedef void (*large_kernel_t)(const FusedPlan);
+large_kernel_t choose_large_kernel(const HostPlan& hp)
+{
+    if (prefer_w4(reinterpret_cast<const void*>(copra_lmpc_large_kernel), reinterpret_cast<const void*>(copra_lmpc_large_kernel_w4),
+            hp.plan.large.threads, hp.lds_bytes))
+        return copra_lmpc_large_kernel_w4;
     return copra_lmpc_large_kernel;
 }
 
@@ -183,6 +210,7 @@ struct copra_batch {
     bool shared = false, model_dirty = true, shared_attr_set = false;
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
+    void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
     int large_grid = 0;
     // InitialStateLMPC variant
@@ -240,7 +268,7 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
 {
     if (h->hp.large) {
         if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_large_kernel(h->hp)),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->large_fn),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
         h->lds_attr_set = true;
         return COPRA_OK;
@@ -337,10 +365,11 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         chk(hipMalloc((void**)&h->d_x0opt, b * P.nx * sizeof(double)));
     }
     if (h->hp.large) {
+        h->large_fn = choose_large_kernel(h->hp);
         if (h->hp.lds_bytes > 48 * 1024) // (the occupancy query below needs the attribute as well)
-            chk(hipFuncSetAttribute(reinterpret_cast<const void*>(select_large_kernel(h->hp)),
+            chk(hipFuncSetAttribute(reinterpret_cast<const void*>(h->large_fn),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
-        h->large_grid = large_grid(reinterpret_cast<const void*>(select_large_kernel(h->hp)), P.batch > 0 ? P.batch : 1,
+        h->large_grid = large_grid(reinterpret_cast<const void*>(h->large_fn), P.batch > 0 ? P.batch : 1,
             P.large.threads, h->hp.lds_bytes);
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
@@ -604,7 +633,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
-        hipLaunchKernelGGL(select_large_kernel(h->hp), dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+        hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
             h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev1, s));
@@ -737,7 +766,7 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
     if (h->hp.large)
-        hipLaunchKernelGGL(select_large_kernel(h->hp), dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
+        hipLaunchKernelGGL(h->large_fn, dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
             h->last_stream, P);
     else if (P.initial_state)
         hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
@@ -859,10 +888,14 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         lds_bytes = (size_t)P.lds.total * sizeof(double);
     }
     if (lds_bytes > 160u * 1024u) return fail(COPRA_ERR_UNSUPPORTED, "dense QP does not fit LDS");
-    if (lds_bytes > 48 * 1024)
+    if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute(large ? reinterpret_cast<const void*>(copra_qp_dense_large_kernel)
                                           : reinterpret_cast<const void*>(copra_qp_dense_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (large)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_qp_dense_large_kernel_w4),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
     const size_t b = (size_t)batch;
     std::vector<void*> owned;
     auto release = [&]() {
@@ -910,7 +943,10 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.iter = diter;
     if (large) {
         const int threads = (n + kWave - 1) & ~(kWave - 1);
-        const int grid = large_grid(reinterpret_cast<const void*>(copra_qp_dense_large_kernel), batch, threads, lds_bytes);
+        const bool w4 = prefer_w4(reinterpret_cast<const void*>(copra_qp_dense_large_kernel),
+            reinterpret_cast<const void*>(copra_qp_dense_large_kernel_w4), threads, lds_bytes);
+        auto dense_kernel = w4 ? copra_qp_dense_large_kernel_w4 : copra_qp_dense_large_kernel;
+        const int grid = large_grid(reinterpret_cast<const void*>(dense_kernel), batch, threads, lds_bytes);
         double* ws = nullptr;
         e = hipMalloc((void**)&ws, (size_t)grid * 2 * n * large_ld(n) * sizeof(double));
         if (e != hipSuccess) {
@@ -919,7 +955,7 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         }
         owned.push_back(ws);
         P.ws = ws;
-        hipLaunchKernelGGL(copra_qp_dense_large_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
+        hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
     } else {
         hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
     }

@@ -422,6 +422,9 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         long long stamp[8];
         stamp[0] = cycle_counter();
 #ifdef COPRA_FINE_PROFILE
+        const long long wall0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef COPRA_FINE_PROFILE
         S.fine = P.prof_fine ? P.prof_fine + 32 * (size_t)inst : nullptr;
 #endif
         // ---- 0. this instance's system ----
@@ -598,6 +601,15 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
             P.status[inst] = status;
             P.iter[2 * (size_t)inst] = it_main;
             P.iter[2 * (size_t)inst + 1] = it_drop;
+#ifdef COPRA_FINE_PROFILE
+            if (P.prof_fine) { // where and when did this instance run (co-residency studies)
+                long long* pf = P.prof_fine + 32 * (size_t)inst;
+                pf[28] = (long long)__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+                pf[29] = wall0;
+                pf[30] = (long long)__builtin_amdgcn_s_memrealtime();
+                pf[31] = (long long)instance_id();
+            }
+#endif
             if (P.prof) { // preview, costs, norms, cholesky, inverse + x0, active set, results, total
                 stamp[7] = cycle_counter();
                 long long* pr = P.prof + 8 * (size_t)inst;

@@ -10,6 +10,7 @@
 #include "plan.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -411,7 +412,9 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.Xi = take(X);
         L.Xbar = is ? L.Xi : take(X); // InitialStateLMPC never uses the free response Phi x0 + xi
         L.Xcur = take(X);
-        L.nparams = (hp.params.size() <= 6144) ? (int)hp.params.size() : 0; // (dropped below if LDS gets too tight)
+        int plimit = 6144;
+        if (const char* e = std::getenv("COPRA_LARGE_PARAMS_LDS")) plimit = std::atoi(e); // (tuning aid)
+        L.nparams = ((int)hp.params.size() <= plimit) ? (int)hp.params.size() : 0; // (dropped below if LDS gets too tight)
         L.Params = take(L.nparams);
         L.FullS = take(kMaxFullRows);
         const int sol0 = o;
@@ -439,7 +442,11 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.wsE = wtake(is ? (long long)nx * U : 0);
         L.wsT = wtake(is ? (long long)nx * U : 0);
         L.ws_total = w;
-        if ((size_t)L.total * sizeof(double) > 160u * 1024u && L.nparams > 0) { // parameters stay in HBM instead
+        // the LDS copy of the parameters goes first when LDS is tight: when the layout does not fit at all, and when
+        // dropping it brings the footprint under 80 KiB, i.e. lets a second workgroup share the CU
+        const size_t with_p = (size_t)L.total * sizeof(double);
+        const size_t without_p = (size_t)(L.total - align2(L.nparams)) * sizeof(double);
+        if (L.nparams > 0 && (with_p > 160u * 1024u || (with_p > 80u * 1024u && without_p <= 80u * 1024u))) {
             L.total -= align2(L.nparams);
             L.nparams = 0;
             const int shift = align2((int)hp.params.size());
