@@ -10,7 +10,8 @@
 //     or with workgroup-uniform addresses, LDS keeps what every iteration gathers from (G, the trajectory, vectors);
 //   * InitialStateLMPC: Q is built twice (once alone for E Q^-1 E' = (E Jq)(E Jq)', once at its place in the
 //     (nx + n)^2 Hessian) instead of being copied inside the workspace.
-// Full-size COST entries are not covered here (plan_builder.hpp rejects them); full-size constraint entries are.
+// Full-size constraint rows are evaluated cooperatively by the workgroup (lhs_cooperative); full-size COST entries run
+// as rank-4 updates of the Hessian in the workspace (a completeness path: no structure is exploited there).
 #pragma once
 
 #include "gi_large.hpp"
