@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: gather synchronously on the compute stream instead of overlapping it with the next solve")
+    ap.add_argument("--selftest-rccl", action="store_true",
+                    help="(single GPU) run the N > 1 code path for real with a one-rank RCCL process group: "
+                         "init_process_group('nccl'), dist.gather of the result slab on the side stream, barrier, "
+                         "all_reduce of the timing")
     ap.add_argument("--selftest-overlap", action="store_true",
                     help="(single GPU) exercise the double-buffer / side-stream plumbing of the N > 1 path with a "
                          "device copy standing in for the RCCL gather")
@@ -63,8 +67,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.selftest_rccl
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from copra_amd import BatchLMPC, workloads
@@ -85,7 +93,7 @@ def main():
     td, tx0 = torch.from_numpy(db).to(dev), torch.from_numpy(xb).to(dev)
     # The engine writes straight into the gather payload.  N > 1: two slabs, so that the RCCL gather of step k (on a
     # side stream, over xGMI) overlaps the solve of step k+1; the timed region ends only when both streams are idle.
-    comm_path = world > 1 or args.selftest_overlap
+    comm_path = use_dist or args.selftest_overlap
     overlap = comm_path and not args.no_overlap
     n_slabs = 2 if overlap else 1
     slabs = [alloc_result_slab(batch, n, X, dev) for _ in range(n_slabs)]
@@ -98,7 +106,7 @@ def main():
     cur = torch.cuda.current_stream()
     stream = cur.cuda_stream
 
-    if world > 1:
+    if use_dist:
         gather_bufs = [alloc_gather_buffers(sl[0], rank, world) for sl in slabs]
     else:
         gather_bufs = [[torch.empty_like(sl[0])] for sl in slabs]  # self-test stand-in
@@ -108,8 +116,8 @@ def main():
     step_no = [0]
 
     def send(k):
-        if world > 1:
-            gather_results(slabs[k][0], rank, world, gather_bufs[k])
+        if use_dist:
+            gather_results(slabs[k][0], rank, world, gather_bufs[k], force=True)
         else:
             gather_bufs[k][0].copy_(slabs[k][0], non_blocking=True)
 
@@ -135,7 +143,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_s = []
@@ -143,7 +151,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -154,7 +162,7 @@ def main():
         eng.solve(stream)
         kernel_s.append(eng.last_solve_seconds())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -256,9 +264,20 @@ def main():
         line["max_abs_u_err"] = err
         line["max_rel_u_err"] = rel
         line["status_agree"] = bool((ref["status"] == status[:sample]).all())
+    if use_dist:
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which is block-buffered on a pipe and
+        # would otherwise land AFTER the JSON line at exit: flush it now so that the JSON line stays the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        dist.barrier()  # every rank has flushed before rank 0 prints
     if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        if rank == 0 and args.selftest_rccl:  # the gathered copy of this rank's slab must equal the slab
+            assert all(torch.equal(gather_bufs[k][0], slabs[k][0]) for k in range(n_slabs)), "RCCL gather mismatch"
         dist.destroy_process_group()
 
 

@@ -54,9 +54,9 @@ def alloc_gather_buffers(slab, rank, world):
     return [torch.empty_like(slab) for _ in range(world)]
 
 
-def gather_results(slab, rank, world, bufs, dst=0):
-    """the single collective of the path: every rank's slab -> rank `dst`"""
-    if world == 1:
+def gather_results(slab, rank, world, bufs, dst=0, force=False):
+    """the single collective of the path: every rank's slab -> rank `dst` (force: also with a one-rank group)"""
+    if world == 1 and not force:
         return [slab]
     dist.gather(slab, gather_list=bufs if rank == dst else None, dst=dst)
     return bufs
