@@ -430,6 +430,7 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     if (!h || !A || !B || !d || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_system: null argument");
     const FusedPlan& P = h->hp.plan;
     const size_t b = (size_t)P.batch;
+    h->shared = false; // per-instance systems again (leaves the shared-model fast path)
     if (on_device) {
         h->A = A;
         h->B = B;
