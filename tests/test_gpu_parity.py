@@ -522,3 +522,23 @@ def test_shared_model_fast_path(oracle):
         assert ro["status"] == res1["status"][k]
         if ro["status"] == 0:
             assert _rel(res1["control"][k], ro["control"]) <= 1e-6
+
+
+def test_receding_horizon_example_runs_on_device():
+    """examples/receding_horizon.py: closed loop on the shared-model path with x0 handed over as a device pointer every
+    tick; the CoM moves towards the goal and every tick's QP is solved.  (Own process: the example imports torch, which
+    must load its HIP runtime before libcopra_hip.so does.)"""
+    import ast
+    import os
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "receding_horizon.py")
+
+    def run(ticks):
+        r = subprocess.run([sys.executable, exe, "2048", str(ticks)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return ast.literal_eval(r.stdout.strip().splitlines()[-1])
+
+    first, last = run(1), run(25)
+    assert last["solved_last_tick"] >= 0.99 * 2048
+    assert last["mean_distance_to_goal"] < 0.5 * first["mean_distance_to_goal"]
