@@ -60,12 +60,14 @@ struct SolverLds {
     int rcap; // columns R has room for (LdsLayout::rcap)
     double *xs, *dv, *zv, *uv, *ap, *coef, *cvec, *eqsgn, *scal;
     int *act, *iact;
+    const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr)
 };
 
 COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
 {
     SolverLds S;
     S.J = lds + L.J;
+    S.Jsrc = nullptr;
     S.ldj = L.ldj;
     S.R = lds + L.R;
     S.rcap = L.rcap;
@@ -351,7 +353,13 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
         if (!have_J) { // first violated constraint: only now is J = R^-1 needed
-            gi_invert<NV>(S, n);
+            if (S.Jsrc) { // shared model: the batch-wide J is in HBM / L2, take a private copy (the updates rotate it)
+                wave_sync();
+                for (int e = lane; e < n * ld; e += kWave) S.J[e] = S.Jsrc[e];
+                wave_sync();
+            } else {
+                gi_invert<NV>(S, n);
+            }
             have_J = true;
         }
         double sv_nvl = best_s;

@@ -629,6 +629,13 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         double* out = P.model_out;
         if (lane == 0) out[m.status] = (double)status;
         for (int e = lane; e < n * ld; e += kWave) out[m.J + e] = S.J[e];
+        if (lane < n) { // Qinv(i, lane) = sum_{k >= max(i, lane)} J(i, k) J(lane, k)   (J upper triangular)
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int k = (i > lane ? i : lane); k < n; ++k) acc += S.J[i * ld + k] * S.J[lane * ld + k];
+                out[m.Qinv + (size_t)i * ld + lane] = acc;
+            }
+        }
         for (int e = lane; e < N * nx * nu; e += kWave) out[m.G + e] = G[e];
         for (int e = lane; e < (N + 1) * nx * nx; e += kWave) out[m.Phi + e] = Phi[e];
         for (int e = lane; e < X; e += kWave) out[m.Xi + e] = Xi[e];

@@ -6,7 +6,8 @@
 // only
 //   * forms the free response  xbar = Phi x0 + xi  and the gradient  c = c0 + C1 x0  (the reference factors the
 //     x0-dependence the same way: c = E' x0 + f, costFunctions.cpp:80; b = z - Y x0, constraints.cpp:81),
-//   * copies J into its LDS (the active-set updates rotate it per instance), takes x = -J J' c,
+//   * takes x = -Qinv c (Qinv = J J' precomputed) and copies J into its LDS only if a constraint is violated (the
+//     active-set updates rotate it per instance),
 //   * runs the same Goldfarb-Idnani loop (gi_core.hpp) and writes the results.
 // Same LDS layouts and the same two-tier overflow scheme as the fused kernel.
 #pragma once
@@ -42,7 +43,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
     double x0r[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x0r[c] = (c < nx) ? x0[c] : 0.0;
-    for (int e = lane; e < n * ld; e += kWave) S.J[e] = M[m.J + e];
+    S.Jsrc = M + m.J; // copied into LDS only if a constraint turns out to be violated (gi_active_set)
     for (int e = lane; e < N * nx * nu; e += kWave) G[e] = M[m.G + e];
     for (int e = lane; e < P.mgen; e += kWave) nb[e] = M[m.nb + e];
     for (int row = lane; row < X; row += kWave) { // free response  xbar = Phi x0 + xi
@@ -62,21 +63,24 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
         S.cvec[lane] = acc;
     }
     wave_sync();
-    // ---- unconstrained minimiser x = -J (J' c) ----
+    // ---- unconstrained minimiser x = -Qinv c, Qinv = J J' precomputed for the whole batch (symmetric: row i is read
+    // as column i, i.e. coalesced across the lanes; L2-resident) ----
     {
         const int lj = (lane < n) ? lane : n - 1;
-        double t = 0.0; // t_j = sum_i J(i, j) c_i : column j of the upper-triangular J
-        for (int i = 0; i <= lj; ++i) t += S.J[i * ld + lj] * S.cvec[i];
-        if (lane < n) S.dv[lane] = t;
-        wave_sync();
-        double x = 0.0; // x_i = -sum_{j >= i} J(i, j) t_j
-        for (int j = lj; j < n; ++j) x += S.J[lj * ld + j] * S.dv[j];
-        if (lane < n) S.xs[lane] = -x;
+        const double* Qi = M + m.Qinv;
+        double x0a = 0.0, x1a = 0.0;
+        int j = 0;
+        for (; j + 1 < n; j += 2) {
+            x0a += Qi[(size_t)j * ld + lj] * S.cvec[j];
+            x1a += Qi[(size_t)(j + 1) * ld + lj] * S.cvec[j + 1];
+        }
+        if (j < n) x0a += Qi[(size_t)j * ld + lj] * S.cvec[j];
+        if (lane < n) S.xs[lane] = -(x0a + x1a);
         wave_sync();
     }
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS, true);
+        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch
         if (lane == 0) {

@@ -213,6 +213,7 @@ struct FusedPlan {
     //                          `dump_instance` stores J = R^-1, G, Phi, xi and the row norms there and stops
     //   model     != nullptr : lmpc_shared_body reads them (+ c0, C1: c = c0 + C1 x0) instead of rebuilding
     // layout (doubles): status | J [n * ldj] | G [N nx nu] | Phi [(N+1) nx nx] | xi [X] | nb [mgen] | c0 [n] | C1 [n x nx]
+    //                   | Qinv [n * ldj] (= J J', symmetric: the unconstrained minimiser is -Qinv c without touching J)
     double* model_out;
     const double* model;
     // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
@@ -226,7 +227,7 @@ struct FusedPlan {
 
 // offsets (doubles) into the shared-model buffer, see FusedPlan::model
 struct ModelLayout {
-    long long status, J, G, Phi, Xi, nb, c0, C1, total;
+    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, total;
 };
 #ifdef __HIPCC__
 #define COPRA_HOST_DEVICE __host__ __device__
@@ -248,6 +249,7 @@ COPRA_HOST_DEVICE inline ModelLayout model_layout(int nx, int nu, int N, int n, 
     COPRA_TAKE(nb, mgen > 0 ? mgen : 1);
     COPRA_TAKE(c0, n);
     COPRA_TAKE(C1, (long long)n * nx);
+    COPRA_TAKE(Qinv, (long long)n * ldj);
 #undef COPRA_TAKE
     m.total = o;
     return m;
