@@ -233,7 +233,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        cores = os.cpu_count() or 1
+        # threads actually available to this process: hardware threads, affinity mask and the cgroup CPU quota
+        hw = os.cpu_count() or 1
+        cores = min(hw, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else hw
+        quota_note = ""
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                lim = max(1, int(round(float(q) / float(per))))
+                if lim < cores:
+                    quota_note = "; cgroup CPU quota %d of %d hardware threads" % (lim, hw)
+                    cores = lim
+        except Exception:
+            pass
         probe = min(batch, 64 * cores)
         sl = slice(0, probe)
         t = time.perf_counter()
@@ -258,8 +270,8 @@ def main():
         rel = float(np.nanmax(np.abs(u[ok] - ref["control"][ok]) / (1.0 + np.abs(ref["control"][ok]))))
         line["cpu_baseline"] = {"value": sample / cpu_t, "unit": "solves/s", "cores": cores, "kind": "port",
                                 "sample": "first %d of the %d instances of this run, one oracle controller per "
-                                          "instance, static partition over %d pthreads, gcc -O3 -march=native"
-                                          % (sample, batch, cores),
+                                          "instance, static partition over %d pthreads, gcc -O3 -march=native%s"
+                                          % (sample, batch, cores, quota_note),
                                 "single_thread_solves_per_s": cpu1}
         line["max_abs_u_err"] = err
         line["max_rel_u_err"] = rel
