@@ -116,7 +116,7 @@ def pack_cstrs(cstrs, keep):
 
 
 _lib = None
-_SRC_EXT = (".hip", ".hpp", ".h")
+_SRC_EXT = (".hip", ".hpp", ".h", ".inc")
 
 
 def source_hash():
@@ -194,6 +194,8 @@ def lib():
         L.copra_batch_set_system.argtypes = [vp, vp, vp, vp, vp, C.c_int]
         L.copra_batch_set_x0.restype = C.c_int
         L.copra_batch_set_x0.argtypes = [vp, vp, C.c_int]
+        L.copra_batch_lanes_per_instance.restype = C.c_int
+        L.copra_batch_lanes_per_instance.argtypes = [vp]
         L.copra_plan_check.restype = C.c_int
         L.copra_plan_check.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.copra_batch_set_shared_system.restype = C.c_int

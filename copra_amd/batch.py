@@ -53,6 +53,10 @@ class BatchLMPC:
         self._sys = None
         self._outs = None
 
+    def lanes_per_instance(self):
+        """16 / 32: several small problems per wavefront; 64: one wavefront each; > 64: one workgroup each"""
+        return int(self._lib.copra_batch_lanes_per_instance(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.copra_batch_destroy(self._h)

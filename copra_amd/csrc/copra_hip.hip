@@ -7,6 +7,7 @@
 #include "lmpc_fused.hpp"
 #include "lmpc_large.hpp"
 #include "lmpc_shared.hpp"
+#include "packed_launch.hpp"
 #include "plan_builder.hpp"
 #include "qp_dense.hpp"
 #include "qp_dense_large.hpp"
@@ -210,6 +211,7 @@ struct copra_batch {
     bool shared = false, model_dirty = true, shared_attr_set = false;
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
+    int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
     void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
     int large_grid = 0;
@@ -373,6 +375,8 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
             P.large.threads, h->hp.lds_bytes);
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
+    h->packed = (h->hp.large || std::getenv("COPRA_NO_PACKED")) ? 0
+        : packed_width(is ? P.nx + P.n : P.n, P.rfull > 0, h->hp.lds_bytes);
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
@@ -454,6 +458,13 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     h->d = h->own_d;
     h->x0 = h->own_x0;
     return COPRA_OK;
+}
+
+int copra_batch_lanes_per_instance(const copra_batch_t* h)
+{
+    if (!h) return 0;
+    if (h->hp.large) return h->hp.plan.large.threads;
+    return h->packed ? h->packed : kWave;
 }
 
 copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
@@ -610,8 +621,12 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.model = h->d_model;
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-        hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
-        HIP_TRY(hipGetLastError());
+        if (h->packed) {
+            HIP_TRY(h->packed == 16 ? packed_launch_w16(P, true, h->hp.lds_bytes, s) : packed_launch_w32(P, true, h->hp.lds_bytes, s));
+        } else {
+            hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+            HIP_TRY(hipGetLastError());
+        }
         if (h->hp.two_tier) {
             FusedPlan P2 = P;
             P2.lds = h->hp.lds_full;
@@ -642,15 +657,23 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         return COPRA_OK;
     }
     if (P.initial_state) {
-        hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
-        HIP_TRY(hipGetLastError());
+        if (h->packed) {
+            HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
+        } else {
+            hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed = true;
         return COPRA_OK;
     }
     if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-    hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
-    HIP_TRY(hipGetLastError());
+    if (h->packed) {
+        HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
+    } else {
+        hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
+    }
     if (h->hp.two_tier) {
         // second tier: same kernel, full LDS layout, instances taken from the overflow queue (usually empty)
         FusedPlan P2 = P;
@@ -958,9 +981,15 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         P.ws = ws;
         hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
     } else {
-        hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
+        const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, false, lds_bytes);
+        if (pw == 16)
+            e = packed_dense_launch_w16(P, lds_bytes, s);
+        else if (pw == 32)
+            e = packed_dense_launch_w32(P, lds_bytes, s);
+        else
+            hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
     }
-    e = hipGetLastError();
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && !on_device) {
         e = hipMemcpyAsync(x, dx, b * n * sizeof(double), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipMemcpyAsync(failv, dfail, b * sizeof(int), hipMemcpyDeviceToHost, s);

@@ -18,7 +18,12 @@ namespace copra_hip {
 constexpr int kMaxCosts = 8;
 constexpr int kMaxFullRows = 16; // full-size constraint rows the workgroup-per-instance kernel evaluates cooperatively
 constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
-constexpr int kWave = 64;
+// lanes one instance works with: the 64-lane wavefront, or a 16-lane DPP row of it in the packed small-problem build
+// (copra_hip_packed.hip compiles the same kernel bodies with COPRA_WAVE_WIDTH = 16: four instances per wavefront)
+#ifndef COPRA_WAVE_WIDTH
+#define COPRA_WAVE_WIDTH 64
+#endif
+constexpr int kWave = COPRA_WAVE_WIDTH;
 
 // cost kinds (== copra_cost_kind_t)
 enum { kCostTrajectory = 0, kCostTarget = 1, kCostControl = 2, kCostMixed = 3 };
@@ -97,7 +102,7 @@ struct LargeLds {
 
 constexpr int kNB = 8; // panel width of the blocked Cholesky factorisation / triangular inversion
 constexpr int kLargeMaxN = 512; // thread = row: workgroup size = n rounded up to a wave, at most 512 threads
-constexpr int kLargeMaxWaves = kLargeMaxN / kWave;
+constexpr int kLargeMaxWaves = kLargeMaxN / 64;
 
 inline int large_ld(int n) { return (n + 7) & ~7; }
 

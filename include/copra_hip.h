@@ -106,6 +106,11 @@ copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs);
 void copra_batch_destroy(copra_batch_t* h);
 
+/* ---- how the controller is mapped onto the device: lanes that work on ONE instance -- 16 or 32 (several small
+ *      problems share a 64-lane wavefront), 64 (one wavefront per instance) or the workgroup size of the
+ *      workgroup-per-instance kernel (64 < decision variables <= 512). ---- */
+int copra_batch_lanes_per_instance(const copra_batch_t* h);
+
 /* ---- the checks of copra_batch_create / copra_batch_create_initial_state WITHOUT touching the device: what
  *      LMPC::addCost / addConstraint do when they call initializeCost / initializeConstraint (src/LMPC.cpp:118-128).
  *      `is` may be NULL.  Returns COPRA_OK, COPRA_ERR_DOMAIN, COPRA_ERR_RUNTIME or COPRA_ERR_UNSUPPORTED. ---- */

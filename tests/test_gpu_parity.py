@@ -542,3 +542,67 @@ def test_receding_horizon_example_runs_on_device():
     first, last = run(1), run(25)
     assert last["solved_last_tick"] >= 0.99 * 2048
     assert last["mean_distance_to_goal"] < 0.5 * first["mean_distance_to_goal"]
+
+
+@pytest.mark.parametrize("N,lanes", [(10, 16), (16, 16), (20, 32), (40, 64)])
+def test_packed_small_problems(oracle, N, lanes):
+    """Several small problems per wavefront (packed_impl.inc: the same kernel bodies on 16- / 32-lane groups): every
+    instance of a batch that is not a multiple of the group count matches the oracle, with per-instance iteration
+    counts that differ inside one wavefront (rows diverge) -- LMPC, the shared-model path and InitialStateLMPC."""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    b = 203
+    pb = F.ineq_system("trajectory", N=N)
+    rng = np.random.default_rng(N)
+    x0 = np.tile(pb["x0"], (b, 1))
+    # the target velocity is -1; the control bound allows +0.15 per step: anything from 0 to N active constraints
+    x0[:, 1] = -1.0 - rng.uniform(0.0, 0.17 * N, b)
+    A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+    eng = BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"])
+    assert eng.lanes_per_instance() == lanes
+    eng.set_system(A, B, d, x0)
+    eng.solve()
+    res = eng.results()
+    sh = BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"])
+    sh.set_shared_system(pb["A"], pb["B"], pb["d"])
+    sh.set_x0(x0)
+    sh.solve()
+    rsh = sh.results()
+    its = set()
+    for k in range(b):
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, pb["costs"], pb["cstrs"])
+        assert res["status"][k] == ro["status"] == rsh["status"][k]
+        if ro["status"] == 0:
+            assert tuple(res["iter"][k]) == tuple(ro["iter"]) == tuple(rsh["iter"][k])
+            assert _rel(res["control"][k], ro["control"]) <= 1e-6 and _rel(rsh["control"][k], ro["control"]) <= 1e-6
+            its.add(int(ro["iter"][0]))
+    assert len(its) >= 3  # genuinely different paths inside a wavefront
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))
+    ise = BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"], initial_state=ist)
+    ise.set_system(A, B, d, x0)
+    ise.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
+    ise.solve()
+    ri = ise.results()
+    for k in range(0, b, 7):
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, pb["costs"], pb["cstrs"],
+                               initial_state=dict(ist, x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05))
+        assert ri["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert _rel(ri["control"][k], ro["control"]) <= 1e-6
+
+
+def test_packed_dense_qps(oracle):
+    """copra_qp_solve_dense_batch with n <= 16: four QPs per wavefront; random strictly convex QPs of different
+    difficulty in one batch"""
+    import fixtures as F
+    from copra_amd import qp_solve_dense_batch
+    rng = np.random.default_rng(4)
+    n, meq, mi, b = 12, 2, 9, 101
+    Ps = [F.random_dense_qp(rng, n, meq, mi, tight=0.05 + 0.5 * rng.random()) for _ in range(b)]
+    st = lambda k: np.stack([P[k] for P in Ps])
+    x, fail, it = qp_solve_dense_batch(st("Q"), st("c"), st("Aeq"), st("beq"), st("Aineq"), st("bineq"), st("XL"), st("XU"))
+    for k, P in enumerate(Ps):
+        xo, fo, ito = oracle.quadprog_dense(P["Q"], P["c"], P["Aeq"], P["beq"], P["Aineq"], P["bineq"], P["XL"], P["XU"])
+        assert fail[k] == fo
+        if fo == 0:
+            assert tuple(it[k]) == tuple(ito) and np.abs(x[k] - xo).max() <= 1e-9 * (1 + np.abs(xo).max())
