@@ -92,6 +92,19 @@ class BatchLMPC:
         dc = np.ascontiguousarray(d, dtype=np.float64)
         _capi.check(self._lib.copra_batch_set_shared_system(self._h, Ac.ctypes.data, Bc.ctypes.data, dc.ctypes.data, 0))
 
+    def set_cost_reference(self, cost_index, p):
+        """per-instance reference of cost `cost_index`: p of shape (batch, rows) (numpy, or a torch CUDA tensor used in
+        place); None restores the controller-wide reference"""
+        if p is None:
+            _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), None, 0))
+        elif _is_torch(p):
+            self._keep.append(p)
+            _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), p.data_ptr(), 1))
+        else:
+            pb = np.ascontiguousarray(p, dtype=np.float64)
+            assert pb.shape[0] == self.batch
+            _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), pb.ctypes.data, 0))
+
     def set_x0(self, x0):
         if _is_torch(x0):
             self._x0 = x0

@@ -211,6 +211,8 @@ struct copra_batch {
     bool shared = false, model_dirty = true, shared_attr_set = false;
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
+    double* d_cost_p[kMaxCosts] = {}; // per-instance cost references (owned copies) ...
+    const double* cost_p[kMaxCosts] = {}; // ... or borrowed device pointers (copra_batch_set_cost_reference)
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
     void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
@@ -263,6 +265,7 @@ static FusedPlan device_plan(const copra_batch* h)
     P.ws = h->d_ws;
     P.model_out = nullptr;
     P.model = nullptr;
+    for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = h->cost_p[k];
     return P;
 }
 
@@ -416,6 +419,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_x0opt);
     (void)hipFree(h->own_x0lb);
     (void)hipFree(h->own_x0ub);
+    for (int k = 0; k < kMaxCosts; ++k) (void)hipFree(h->d_cost_p[k]);
     (void)hipFree(h->d_ws);
     (void)hipFree(h->d_shA);
     (void)hipFree(h->d_shB);
@@ -570,6 +574,26 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     return COPRA_OK;
 }
 
+copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: null handle");
+    const FusedPlan& P = h->hp.plan;
+    if (cost_index < 0 || cost_index >= P.ncost) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: no such cost");
+    if (!p) { // back to the controller-wide reference given at creation
+        h->cost_p[cost_index] = nullptr;
+        return COPRA_OK;
+    }
+    if (on_device) {
+        h->cost_p[cost_index] = p;
+        return COPRA_OK;
+    }
+    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.cost[cost_index].rows;
+    if (!h->d_cost_p[cost_index]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[cost_index], count * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_cost_p[cost_index], p, count * sizeof(double), hipMemcpyHostToDevice));
+    h->cost_p[cost_index] = h->d_cost_p[cost_index];
+    return COPRA_OK;
+}
+
 copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device)
 {
     if (!h || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_x0: null argument");
@@ -601,6 +625,9 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
+        for (int k = 0; k < kMaxCosts; ++k)
+            if (h->cost_p[k])
+                return fail(COPRA_ERR_UNSUPPORTED, "per-instance cost references are not covered by the shared-model fast path");
         hipStream_t s = (hipStream_t)hip_stream;
         h->last_stream = s;
         if (h->hp.plan.batch == 0) return COPRA_OK;

@@ -181,7 +181,7 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
             // path (TestLMPC_InitialState.cpp runs all nine classes with full-size entries), not a fast one.
             const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
             const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
-            const double* pp = P.params + ct.offP;
+            const double* pp = cost_reference(P, t, inst);
             const double* ww = P.params + ct.offW;
             double* rowbuf = S.dv; // n doubles (the solver vectors are not live yet)
             double* mphi = S.xs; // (M Phi)(rr, 0..nx-1) and the residual (M xi - p)(rr)
@@ -230,7 +230,7 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
         for (int e = lane; e < r * nx; e += kWave) Mx[e] = (ct.offM >= 0) ? P.params[ct.offM + e] : 0.0;
         for (int e = lane; e < r * nu; e += kWave) Nm[e] = (ct.offN >= 0) ? P.params[ct.offN + e] : 0.0;
         for (int e = lane; e < r; e += kWave) {
-            p[e] = P.params[ct.offP + e];
+            p[e] = cost_reference(P, t, inst)[e];
             w[e] = P.params[ct.offW + e];
         }
         wave_sync();

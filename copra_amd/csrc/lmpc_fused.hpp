@@ -25,6 +25,14 @@
 
 namespace copra_hip {
 
+// reference vector p of cost term t for this instance: the controller-wide one from the parameter blob, or the
+// per-instance one handed over by copra_batch_set_cost_reference (each instance tracks its own goal)
+COPRA_DEV const double* cost_reference(const FusedPlan& P, int t, int inst)
+{
+    const CostTerm& ct = P.cost[t];
+    return P.cost_p[t] ? P.cost_p[t] + (size_t)inst * ct.rows : P.params + ct.offP;
+}
+
 // One constraint row of the plan (see plan.hpp), held in registers.
 struct RowDesc {
     int k, ek, eo, gk, go;
@@ -202,8 +210,8 @@ struct StageRows {
 // and accumulated into the 10 upper 16x16 tiles of Q; the weights ride on the A operand ((tmp' W) tmp as in Eigen).
 // ------------------------------------------------------------------------------------------------
 template <int NX_, int NU_, int NH_>
-COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const double* G, const double* Xbar,
-    double* Q, int ld, double* scratch, double& cj)
+COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const double* p, const double* G,
+    const double* Xbar, double* Q, int ld, double* scratch, double& cj)
 {
     const int lane = lane_id();
     const int nx = NX_ ? NX_ : P.nx, nu = NU_ ? NU_ : P.nu, N = NH_ ? NH_ : P.N;
@@ -211,7 +219,6 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     const int R = ct.rows;
     const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
     const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
-    const double* p = P.params + ct.offP;
     const double* w = P.params + ct.offW;
     double* We = scratch; // R weighted residuals
     double* stage = scratch + ((R + 1) & ~1); // 4 x 64 tile of tmp rows
@@ -421,7 +428,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             if constexpr (RP_ == 0) { // plans with full-size entries always run the generic instantiation (plan.hpp)
                 if (ct.full) {
                     wave_sync();
-                    full_size_cost_term<NX_, NU_, NH_>(P, ct, G, Xbar, Q, ld, lds + L.BldFull, cj);
+                    full_size_cost_term<NX_, NU_, NH_>(P, ct, cost_reference(P, t, inst), G, Xbar, Q, ld, lds + L.BldFull, cj);
                     continue;
                 }
             }
@@ -440,8 +447,9 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                 const int row = e % r, c = e / r;
                 Nm[e] = (ct.offN >= 0 && row < rc) ? P.params[ct.offN + row + rc * c] : 0.0;
             }
+            const double* pref = cost_reference(P, t, inst);
             for (int e = lane; e < r; e += kWave) {
-                p[e] = (e < rc) ? P.params[ct.offP + e] : 0.0;
+                p[e] = (e < rc) ? pref[e] : 0.0;
                 w[e] = (e < rc) ? P.params[ct.offW + e] : 0.0;
             }
             wave_sync();

@@ -173,7 +173,7 @@ struct LargeRows {
 //   LMPC:              cj += c_j                                   (costFunctions.cpp:78-80, 106, 152-155, 211-213)
 //   InitialStateLMPC:  cj += f_j and Ecol[a] += E(a, j)            (InitialStateLMPC.cpp:82-83)
 // thread j < n owns column j = (block, component) of the linear terms and walks block diagonal `block` of Q.
-COPRA_DEV void large_costs(const FusedPlan& P, double* lds, double* F, int ld, int qoff, bool linear, const double* G,
+COPRA_DEV void large_costs(const FusedPlan& P, int inst, double* lds, double* F, int ld, int qoff, bool linear, const double* G,
     const double* Xbar, const double* Xi, const double* Phi, double* MPhi, double& cj, double* Ecol)
 {
     const LargeLayout& L = P.large;
@@ -203,7 +203,7 @@ COPRA_DEV void large_costs(const FusedPlan& P, double* lds, double* F, int ld, i
             const int X = P.X;
             const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
             const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
-            const double* pp = P.params + ct.offP;
+            const double* pp = cost_reference(P, t, inst);
             const double* ww = P.params + ct.offW;
             double* rowbuf = lds + L.sol.stage; // 4 x n
             double* mphi = lds + L.sol.xs; // 4 x (nx + 1): (M Phi)(row, :) and the residual of the row
@@ -277,7 +277,7 @@ COPRA_DEV void large_costs(const FusedPlan& P, double* lds, double* F, int ld, i
         for (int e = tid; e < r * nx; e += T) Mx[e] = (ct.offM >= 0) ? P.params[ct.offM + e] : 0.0;
         for (int e = tid; e < r * nu; e += T) Nm[e] = (ct.offN >= 0) ? P.params[ct.offN + e] : 0.0;
         for (int e = tid; e < r; e += T) {
-            p[e] = P.params[ct.offP + e];
+            p[e] = cost_reference(P, t, inst)[e];
             w[e] = P.params[ct.offW + e];
         }
         bt_sync();
@@ -492,7 +492,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         double Ecol[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) Ecol[a] = 0.0;
-        large_costs(P, lds, F, ld, 0, true, G, Xbar, Xi, Phi, MPhi, cj, Ecol);
+        large_costs(P, inst, lds, F, ld, 0, true, G, Xbar, Xi, Phi, MPhi, cj, Ecol);
         int status = 0;
         if (is) {
             // E -> HBM; Q = Lq Lq', Jq = Lq^-T; T = E Jq; top-left = R + T T'
@@ -529,7 +529,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
             if (tid < nx) // (TL shares LDS with the cost tables: consume it before they are rebuilt)
                 for (int b2 = tid; b2 < nx; ++b2) F[(size_t)tid * ld + b2] = TL[tid + nx * b2]; // row b2 >= column tid
             double dummy = 0.0;
-            large_costs(P, lds, F, ld, nx, false, G, Xbar, Xi, Phi, MPhi, dummy, Ecol);
+            large_costs(P, inst, lds, F, ld, nx, false, G, Xbar, Xi, Phi, MPhi, dummy, Ecol);
             if (tid < nx) S.cv[tid] = P.is_r[tid];
             if (tid < n) S.cv[nx + tid] = cj;
         } else {

@@ -163,6 +163,7 @@ struct FusedPlan {
     // costs
     int ncost;
     CostTerm cost[kMaxCosts];
+    const double* cost_p[kMaxCosts]; // per-instance references p of cost t: [batch][rows], or nullptr = the shared one
     int rmax; // max rows over the per-step costs
     int rfull; // max rows over the full-size costs (0 if none)
     // constraint rows

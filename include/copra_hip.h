@@ -138,6 +138,14 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     const double* x0, int on_device);
 copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device);
 
+/* ---- per-instance references: p of cost `cost_index` (the order of the `costs` array given at creation) for EVERY
+ *      instance, [batch][rows] with the rows of that cost as created (per-step entry: r, full-size entry: r (N+1) or
+ *      r N) -- each instance of the batch tracks its own goal / reference trajectory; in the reference this is one
+ *      TrajectoryCost(M, p_b) / TargetCost / ControlCost / MixedCost object per LMPC (include/costFunctions.h:103-219).
+ *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Not combinable with
+ *      copra_batch_set_shared_system (COPRA_ERR_UNSUPPORTED at solve). ---- */
+copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);
+
 /* ---- shared-model receding-horizon fast path: ONE preview system (A [nx x nx], B [nx x nu], d [nx], column-major) for
  *      the whole batch; only x0 differs per instance (copra_batch_set_x0, [batch][nx]).  This is the reference's own
  *      receding-horizon use: PreviewSystem::xInit between solves with isUpdated left true (include/PreviewSystem.h:

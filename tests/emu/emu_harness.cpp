@@ -131,7 +131,11 @@ namespace emu {
 
 using namespace copra_hip;
 
+static const double* g_cost_p[copra_hip::kMaxCosts]; // per-instance cost references for the next emu_lmpc_solve
+
 extern "C" {
+
+void emu_set_cost_reference(int cost_index, const double* p) { g_cost_p[cost_index] = p; }
 
 // Build the plan exactly as copra_batch_create does and run the fused kernel body for every instance.
 int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
@@ -164,6 +168,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.x0lb = x0lb;
     P.x0ub = x0ub;
     P.x0_opt = x0_opt;
+    for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = g_cost_p[k];
     if (sizes) {
         sizes[0] = P.initial_state ? P.nx + P.n : P.n;
         sizes[1] = P.meq;

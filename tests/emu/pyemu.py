@@ -40,8 +40,12 @@ def _batchify(A, B, d, x0):
     return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
 
 
-def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True, initial_state=None):
+def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True, initial_state=None, cost_refs=None):
+    """cost_refs: {cost_index: array (batch, rows)} per-instance references (copra_batch_set_cost_reference)"""
     Ab, Bb, db, xb = _batchify(A, B, d, x0)
+    refs = {int(k): np.ascontiguousarray(v, dtype=np.float64) for k, v in (cost_refs or {}).items()}
+    for k in range(8):
+        lib().emu_set_cost_reference(k, _capi.dptr(refs[k]) if k in refs else C.c_void_p())
     batch, nu, nx = Bb.shape[0], Bb.shape[1], Bb.shape[2]
     keep = []
     cc = _capi.pack_costs(costs, keep)

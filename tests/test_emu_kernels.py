@@ -282,6 +282,35 @@ def test_shared_model_fast_path(emu, oracle):
         assert _rel(re["control"][k], ro["control"]) <= RTOL
 
 
+def test_per_instance_cost_references(emu, oracle):
+    """copra_batch_set_cost_reference: every instance tracks its own goal (one TrajectoryCost(M, p_b) per LMPC in the
+    reference).  One-wave kernel (compile-time and generic shape), InitialStateLMPC, and the workgroup kernel."""
+    from copra_amd import workloads
+    rng = np.random.default_rng(9)
+    b = 6
+    wl = workloads.com_preview(b)
+    goals = wl["costs"][0]["p"][None, :] + 0.2 * rng.standard_normal((b, 6))
+    for spec in (True, False):
+        re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], specialised=spec,
+                            cost_refs={0: goals})
+        for k in range(b):
+            costs = [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]]
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"])
+            assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
+    for N, ist in ((12, dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))), (70, None), (70, dict(R=10.0 * np.eye(2), r=np.zeros(2)))):
+        pb = F.nine_class_problem(N)
+        x0 = np.tile(pb["x0"], (3, 1))
+        refs = np.array([[0.0, -1.0], [0.01, -0.8], [-0.01, -1.3]])
+        io = None if ist is None else dict(ist, x0lb=x0 - 0.05, x0ub=x0 + 0.05)
+        re = emu.lmpc_solve(np.tile(pb["A"], (3, 1, 1)), np.tile(pb["B"], (3, 1, 1)), np.tile(pb["d"], (3, 1)), x0, N,
+                            pb["costs"], pb["cstrs"], initial_state=io, cost_refs={0: refs})
+        for k in range(3):
+            costs = [dict(pb["costs"][0], p=refs[k])] + pb["costs"][1:]
+            iok = None if ist is None else dict(ist, x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05)
+            ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, costs, pb["cstrs"], initial_state=iok)
+            assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi

@@ -606,3 +606,35 @@ def test_packed_dense_qps(oracle):
         assert fail[k] == fo
         if fo == 0:
             assert tuple(it[k]) == tuple(ito) and np.abs(x[k] - xo).max() <= 1e-9 * (1 + np.abs(xo).max())
+
+
+def test_per_instance_cost_references(oracle):
+    """copra_batch_set_cost_reference on the headline shape: every instance has its own goal; back to the shared goal
+    with None; refused on the shared-model path"""
+    from copra_amd import BatchLMPC, CopraUnsupported, workloads
+    b = 1024
+    wl = workloads.com_preview(b)
+    rng = np.random.default_rng(2)
+    goals = wl["costs"][0]["p"][None, :] + 0.2 * rng.standard_normal((b, 6))
+    eng, base = _solve_gpu(wl, b)
+    eng.set_cost_reference(0, goals)
+    eng.solve()
+    res = eng.results()
+    for k in range(0, b, 64):
+        costs = [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"])
+        assert res["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert _rel(res["control"][k], ro["control"]) <= RTOL
+    assert np.nanmax(np.abs(res["control"] - base["control"])) > 1e-3  # the goals matter
+    eng.set_cost_reference(0, None)
+    eng.solve()
+    again = eng.results()
+    ok = base["status"] == 0
+    assert np.array_equal(again["status"], base["status"]) and np.abs(again["control"][ok] - base["control"][ok]).max() <= 1e-12
+    sh = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    sh.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    sh.set_x0(wl["x0"])
+    sh.set_cost_reference(0, goals)
+    with pytest.raises(CopraUnsupported):
+        sh.solve()
