@@ -198,6 +198,10 @@ def lib():
         L.copra_batch_lanes_per_instance.argtypes = [vp]
         L.copra_plan_check.restype = C.c_int
         L.copra_plan_check.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.copra_batch_set_constraint_rhs.restype = C.c_int
+        L.copra_batch_set_constraint_rhs.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.copra_batch_set_control_bounds.restype = C.c_int
+        L.copra_batch_set_control_bounds.argtypes = [vp, vp, vp, C.c_int]
         L.copra_batch_set_cost_reference.restype = C.c_int
         L.copra_batch_set_cost_reference.argtypes = [vp, C.c_int, vp, C.c_int]
         L.copra_batch_set_shared_system.restype = C.c_int

@@ -105,6 +105,18 @@ class BatchLMPC:
             assert pb.shape[0] == self.batch
             _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), pb.ctypes.data, 0))
 
+    def set_constraint_rhs(self, cstr_index, f):
+        """per-instance right-hand side f (batch, rows) of the Trajectory / Control / Mixed constraint `cstr_index`"""
+        fb = np.ascontiguousarray(f, dtype=np.float64)
+        assert fb.shape[0] == self.batch
+        _capi.check(self._lib.copra_batch_set_constraint_rhs(self._h, int(cstr_index), fb.ctypes.data, 0))
+
+    def set_control_bounds(self, lower, upper):
+        """per-instance ControlBoundConstraint: lower / upper broadcastable to (batch, nu * N)"""
+        lo = np.ascontiguousarray(np.broadcast_to(lower, (self.batch, self.n)), dtype=np.float64)
+        up = np.ascontiguousarray(np.broadcast_to(upper, (self.batch, self.n)), dtype=np.float64)
+        _capi.check(self._lib.copra_batch_set_control_bounds(self._h, lo.ctypes.data, up.ctypes.data, 0))
+
     def set_x0(self, x0):
         if _is_torch(x0):
             self._x0 = x0

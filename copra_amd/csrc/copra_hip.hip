@@ -62,6 +62,16 @@ __global__ __launch_bounds__(64) void copra_lmpc_shared_tier2_kernel(const Fused
     }
 }
 
+// out[b][row0 + s * r + i] = f[b][i] for the steps s of one constraint (copra_batch_set_constraint_rhs)
+__global__ void copra_scatter_rhs_kernel(const double* f, double* out, int batch, int r, int steps, int row0, int mgen)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)r * steps;
+    if (e >= per * batch) return;
+    const long long b = e / per, rem = e - b * per;
+    out[b * mgen + row0 + rem] = f[b * r + rem % r];
+}
+
 namespace {
 using fused_kernel_t = void (*)(const FusedPlan);
 fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
@@ -211,6 +221,7 @@ struct copra_batch {
     bool shared = false, model_dirty = true, shared_attr_set = false;
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
+    double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
     double* d_cost_p[kMaxCosts] = {}; // per-instance cost references (owned copies) ...
     const double* cost_p[kMaxCosts] = {}; // ... or borrowed device pointers (copra_batch_set_cost_reference)
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
@@ -266,6 +277,9 @@ static FusedPlan device_plan(const copra_batch* h)
     P.model_out = nullptr;
     P.model = nullptr;
     for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = h->cost_p[k];
+    P.row_f_inst = h->d_row_f_inst;
+    P.lb_inst = h->d_lb_inst;
+    P.ub_inst = h->d_ub_inst;
     return P;
 }
 
@@ -420,6 +434,9 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->own_x0lb);
     (void)hipFree(h->own_x0ub);
     for (int k = 0; k < kMaxCosts; ++k) (void)hipFree(h->d_cost_p[k]);
+    (void)hipFree(h->d_row_f_inst);
+    (void)hipFree(h->d_lb_inst);
+    (void)hipFree(h->d_ub_inst);
     (void)hipFree(h->d_ws);
     (void)hipFree(h->d_shA);
     (void)hipFree(h->d_shB);
@@ -591,6 +608,59 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
     if (!h->d_cost_p[cost_index]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[cost_index], count * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_cost_p[cost_index], p, count * sizeof(double), hipMemcpyHostToDevice));
     h->cost_p[cost_index] = h->d_cost_p[cost_index];
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_set_constraint_rhs(copra_batch_t* h, int cstr_index, const double* f, int on_device)
+{
+    if (!h || !f) return fail(COPRA_ERR_ARG, "copra_batch_set_constraint_rhs: null argument");
+    const FusedPlan& P = h->hp.plan;
+    if (cstr_index < 0 || cstr_index >= (int)h->hp.cstr_row0.size() || h->hp.cstr_row0[(size_t)cstr_index] < 0)
+        return fail(COPRA_ERR_UNSUPPORTED,
+            "copra_batch_set_constraint_rhs: not a Trajectory / Control / Mixed constraint of this controller "
+            "(bound constraints: copra_batch_set_control_bounds)");
+    const int r = h->hp.cstr_per_step[(size_t)cstr_index], steps = h->hp.cstr_steps[(size_t)cstr_index];
+    const int row0 = h->hp.cstr_row0[(size_t)cstr_index];
+    const size_t b = (size_t)(P.batch > 0 ? P.batch : 1);
+    if (!h->d_row_f_inst) { // first use: every instance starts from the controller-wide right-hand sides
+        HIP_TRY(hipMalloc((void**)&h->d_row_f_inst, b * (size_t)P.mgen * sizeof(double)));
+        std::vector<double> rep(b * (size_t)P.mgen);
+        for (size_t i = 0; i < b; ++i) std::copy(h->hp.row_f.begin(), h->hp.row_f.begin() + P.mgen, rep.begin() + i * P.mgen);
+        HIP_TRY(hipMemcpy(h->d_row_f_inst, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const double* src = f;
+    double* tmp = nullptr;
+    if (!on_device) {
+        HIP_TRY(hipMalloc((void**)&tmp, b * (size_t)r * sizeof(double)));
+        hipError_t e = hipMemcpy(tmp, f, b * (size_t)r * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            return fail(COPRA_ERR_HIP, std::string("copra_batch_set_constraint_rhs: ") + hipGetErrorString(e));
+        }
+        src = tmp;
+    }
+    const long long total = (long long)P.batch * r * steps;
+    if (total > 0) {
+        hipLaunchKernelGGL(copra_scatter_rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->last_stream, src,
+            h->d_row_f_inst, P.batch, r, steps, row0, P.mgen);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->last_stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_batch_set_constraint_rhs: ") + hipGetErrorString(e));
+    return COPRA_OK; // (the shared-model factorisation does not depend on right-hand sides)
+}
+
+copra_status_t copra_batch_set_control_bounds(copra_batch_t* h, const double* lower, const double* upper, int on_device)
+{
+    if (!h || !lower || !upper) return fail(COPRA_ERR_ARG, "copra_batch_set_control_bounds: null argument");
+    const FusedPlan& P = h->hp.plan;
+    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.n;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (!h->d_lb_inst) HIP_TRY(hipMalloc((void**)&h->d_lb_inst, count * sizeof(double)));
+    if (!h->d_ub_inst) HIP_TRY(hipMalloc((void**)&h->d_ub_inst, count * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_lb_inst, lower, count * sizeof(double), kind));
+    HIP_TRY(hipMemcpy(h->d_ub_inst, upper, count * sizeof(double), kind));
     return COPRA_OK;
 }
 

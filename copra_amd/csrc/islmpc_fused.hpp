@@ -357,6 +357,7 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
     }
     // parity hook: the dense QP of this instance (LMPC.h:112-127 on the InitialStateLMPC object)
     StageRows<0, 0, 0> base { P, G, Xcur, Xcur, nb, RowDesc {}, 0.0, 0.0 };
+    base.inst = inst;
     StageRowsIS rows { P, base, Phi, Xi, 0.0, 0.0 };
     {
         const int lv = (lane < nv) ? lane : nv - 1;
@@ -364,8 +365,8 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
             rows.ubv = P.x0ub ? P.x0ub[(size_t)inst * nx + lv] : P.x0[(size_t)inst * nx + lv];
             rows.lbv = P.x0lb ? P.x0lb[(size_t)inst * nx + lv] : P.x0[(size_t)inst * nx + lv];
         } else {
-            rows.ubv = P.ub[lv - nx];
-            rows.lbv = P.lb[lv - nx];
+            rows.ubv = base.bound_ub(lv - nx);
+            rows.lbv = base.bound_lb(lv - nx);
         }
     }
     for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(base.load_desc(i)));

@@ -50,6 +50,7 @@ struct StageRows {
     RowDesc mine; // descriptor of row `lane` (rows 0..63 are scanned as i == lane): no table look-ups in the loop
     double ub_mine, lb_mine; // XU_lane, XL_lane
     const double* prm = nullptr; // optional LDS copy of the parameter blob (workgroup-per-instance kernel)
+    int inst = 0; // instance this wave / workgroup works on (per-instance right-hand sides and bounds)
 
     COPRA_DEV const double* params() const { return prm ? prm : P.params; }
 
@@ -59,6 +60,8 @@ struct StageRows {
     COPRA_DEV int nvar() const { return (NU_ && NH_) ? NU_ * NH_ : P.n; }
     COPRA_DEV int xdim() const { return (NX_ && NH_) ? NX_ * (NH_ + 1) : P.X; }
 
+    COPRA_DEV double bound_ub(int j) const { return P.ub_inst ? P.ub_inst[(size_t)inst * nvar() + j] : P.ub[j]; }
+    COPRA_DEV double bound_lb(int j) const { return P.lb_inst ? P.lb_inst[(size_t)inst * nvar() + j] : P.lb[j]; }
     COPRA_DEV RowDesc load_desc(int i) const
     {
         RowDesc d;
@@ -67,7 +70,7 @@ struct StageRows {
         d.eo = P.row_eoff[i];
         d.gk = P.row_gkind[i];
         d.go = P.row_goff[i];
-        d.f = P.row_f[i];
+        d.f = P.row_f_inst ? P.row_f_inst[(size_t)inst * P.mgen + i] : P.row_f[i];
         return d;
     }
     COPRA_DEV void cache_own_row()
@@ -78,8 +81,8 @@ struct StageRows {
         else
             mine = RowDesc { 0, kENone, 0, kGNone, 0, 0.0 };
         const int j = (i < nvar()) ? i : nvar() - 1;
-        ub_mine = P.ub[j];
-        lb_mine = P.lb[j];
+        ub_mine = bound_ub(j);
+        lb_mine = bound_lb(j);
     }
     COPRA_DEV RowDesc desc(int i) const { return (i < kWave) ? mine : load_desc(i); }
 
@@ -317,6 +320,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     // plan look-ups this lane needs much later (its constraint row, its bounds): issue the global loads now so that
     // their latency hides under the preview / cost phases
     StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
+    rows.inst = inst;
     rows.cache_own_row();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];

@@ -157,8 +157,8 @@ struct LargeRows {
         const int blocks = (k + 1 < P.N) ? k + 1 : P.N;
         return off + blocks * P.nu;
     }
-    COPRA_DEV double ub(int j) const { return (j < off) ? x0ub[j] : P.ub[j - off]; }
-    COPRA_DEV double lb(int j) const { return (j < off) ? x0lb[j] : P.lb[j - off]; }
+    COPRA_DEV double ub(int j) const { return (j < off) ? x0ub[j] : base.bound_ub(j - off); }
+    COPRA_DEV double lb(int j) const { return (j < off) ? x0lb[j] : base.bound_lb(j - off); }
     COPRA_DEV void load_normal(int p, double sgn, double* np) const
     {
         const int j = bt_tid();
@@ -538,7 +538,7 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
         bt_sync();
         stamp[2] = cycle_counter();
         // ---- 3. implicit rows: norms; parity hook ----
-        StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0, prm };
+        StageRows<0, 0, 0> base { P, G, Xbar, Xcur, S.nb, RowDesc {}, 0.0, 0.0, prm, inst };
         LargeRows rows { P, base, Phi, Xi,
             is ? (P.x0ub ? P.x0ub + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr,
             is ? (P.x0lb ? P.x0lb + (size_t)inst * nx : P.x0 + (size_t)inst * nx) : nullptr, off, RowDesc {}, RowDesc {},

@@ -177,6 +177,9 @@ struct FusedPlan {
     const int* row_gkind; // [mgen]
     const int* row_goff; // [mgen]
     const double* row_f; // [mgen]
+    const double* row_f_inst; // per-instance right-hand sides [batch][mgen] (copra_batch_set_constraint_rhs) or nullptr
+    const double* lb_inst; // per-instance control bounds [batch][n] (copra_batch_set_control_bounds) or nullptr
+    const double* ub_inst;
     const double* params; // blob
     const double* lb; // [n]
     const double* ub; // [n]

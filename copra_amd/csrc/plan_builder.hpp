@@ -32,6 +32,9 @@ struct HostPlan {
     LdsLayout lds_full {};
     size_t lds_full_bytes = 0;
     bool large = false; // more than 64 decision variables: workgroup-per-instance kernel (lmpc_large.hpp)
+    // where the rows of constraint k (position in the user's array) sit in the stacked order: row = row0 + s * per_step
+    // + i for its steps s and lines i (steps == 1 for a full-size entry); row0 < 0: bound constraint, no rows
+    std::vector<int> cstr_row0, cstr_per_step, cstr_steps;
 };
 
 // qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
@@ -305,6 +308,11 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         return push(tmp.data(), cols);
     };
     P.meq = P.mineq = 0;
+    P.row_f_inst = nullptr;
+    P.lb_inst = P.ub_inst = nullptr;
+    hp.cstr_row0.assign((size_t)(n_cstrs > 0 ? n_cstrs : 1), -1);
+    hp.cstr_per_step.assign((size_t)(n_cstrs > 0 ? n_cstrs : 1), 0);
+    hp.cstr_steps.assign((size_t)(n_cstrs > 0 ? n_cstrs : 1), 0);
     for (int pass = 0; pass < 2; ++pass) { // pass 0: equalities, pass 1: inequalities (LMPC.cpp:257-271)
         for (int k = 0; k < n_cstrs; ++k) {
             const copra_cstr_desc_t& c = cstrs[k];
@@ -368,6 +376,11 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 break;
             }
             const int added = (int)hp.row_f.size() - before;
+            if (c.kind != COPRA_CSTR_TRAJECTORY_BOUND && r > 0) { // (bound rows skip infinite components: no map)
+                hp.cstr_row0[(size_t)k] = before;
+                hp.cstr_per_step[(size_t)k] = r;
+                hp.cstr_steps[(size_t)k] = added / r;
+            }
             if (ineq)
                 P.mineq += added;
             else

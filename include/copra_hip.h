@@ -146,6 +146,16 @@ copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_dev
  *      copra_batch_set_shared_system (COPRA_ERR_UNSUPPORTED at solve). ---- */
 copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);
 
+/* ---- per-instance constraint data.  copra_batch_set_constraint_rhs: f of the Trajectory / Control / Mixed constraint
+ *      `cstr_index` (position in the `cstrs` array given at creation) for every instance, [batch][rows] with the rows
+ *      of that constraint as created (per-step entry: r values used at every step; full-size entry: all of them) -- in
+ *      the reference one TrajectoryConstraint(E, f_b) ... object per LMPC (include/constraints.h:114-226).
+ *      copra_batch_set_control_bounds: lower / upper of the ControlBoundConstraint for every instance, [batch][fullUDim]
+ *      (include/constraints.h:284-308).  TrajectoryBoundConstraint stays controller-wide (its infinite components
+ *      are dropped at creation, src/constraints.cpp:263-282).  Both copy their input. ---- */
+copra_status_t copra_batch_set_constraint_rhs(copra_batch_t* h, int cstr_index, const double* f, int on_device);
+copra_status_t copra_batch_set_control_bounds(copra_batch_t* h, const double* lower, const double* upper, int on_device);
+
 /* ---- shared-model receding-horizon fast path: ONE preview system (A [nx x nx], B [nx x nu], d [nx], column-major) for
  *      the whole batch; only x0 differs per instance (copra_batch_set_x0, [batch][nx]).  This is the reference's own
  *      receding-horizon use: PreviewSystem::xInit between solves with isUpdated left true (include/PreviewSystem.h:

@@ -136,6 +136,14 @@ static const double* g_cost_p[copra_hip::kMaxCosts]; // per-instance cost refere
 extern "C" {
 
 void emu_set_cost_reference(int cost_index, const double* p) { g_cost_p[cost_index] = p; }
+// per-instance right-hand sides in STACKED row order [batch][mgen] and control bounds [batch][n] for the next solve
+static const double *g_row_f_inst, *g_lb_inst, *g_ub_inst;
+void emu_set_instance_rows(const double* row_f, const double* lb, const double* ub)
+{
+    g_row_f_inst = row_f;
+    g_lb_inst = lb;
+    g_ub_inst = ub;
+}
 
 // Build the plan exactly as copra_batch_create does and run the fused kernel body for every instance.
 int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
@@ -169,6 +177,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.x0ub = x0ub;
     P.x0_opt = x0_opt;
     for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = g_cost_p[k];
+    P.row_f_inst = g_row_f_inst;
+    P.lb_inst = g_lb_inst;
+    P.ub_inst = g_ub_inst;
     if (sizes) {
         sizes[0] = P.initial_state ? P.nx + P.n : P.n;
         sizes[1] = P.meq;

@@ -40,8 +40,16 @@ def _batchify(A, B, d, x0):
     return Ab, Bb, np.ascontiguousarray(d, dtype=np.float64), np.ascontiguousarray(x0, dtype=np.float64)
 
 
-def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True, initial_state=None, cost_refs=None):
-    """cost_refs: {cost_index: array (batch, rows)} per-instance references (copra_batch_set_cost_reference)"""
+def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True, initial_state=None, cost_refs=None,
+               row_rhs=None, bounds=None):
+    """cost_refs: {cost_index: array (batch, rows)} per-instance references (copra_batch_set_cost_reference);
+    row_rhs: (batch, mgen) per-instance right-hand sides in stacked row order; bounds: (lower, upper) each (batch, n)"""
+    rr = None if row_rhs is None else np.ascontiguousarray(row_rhs, dtype=np.float64)
+    lo = None if bounds is None else np.ascontiguousarray(bounds[0], dtype=np.float64)
+    up = None if bounds is None else np.ascontiguousarray(bounds[1], dtype=np.float64)
+    lib().emu_set_instance_rows(_capi.dptr(rr) if rr is not None else C.c_void_p(),
+                                _capi.dptr(lo) if lo is not None else C.c_void_p(),
+                                _capi.dptr(up) if up is not None else C.c_void_p())
     Ab, Bb, db, xb = _batchify(A, B, d, x0)
     refs = {int(k): np.ascontiguousarray(v, dtype=np.float64) for k, v in (cost_refs or {}).items()}
     for k in range(8):

@@ -311,6 +311,36 @@ def test_per_instance_cost_references(emu, oracle):
             assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
 
 
+def test_per_instance_constraint_rhs_and_bounds(emu, oracle):
+    """Per-instance right-hand sides (stacked row order) and control bounds: one-wave kernel and workgroup kernel"""
+    rng = np.random.default_rng(13)
+    for N in (12, 70):
+        pb = F.ineq_system("trajectory", N=N)  # rows: E x_k <= f (N+1 rows), then G u_k <= h (N rows)
+        b = 4
+        x0 = np.tile(pb["x0"], (b, 1))
+        fv = np.array([0.0, -0.2, 0.3, -0.05])  # velocity limit per instance
+        hv = np.array([200.0, 150.0, 120.0, 180.0])  # force limit per instance
+        rhs = np.hstack([np.repeat(fv[:, None], N + 1, axis=1), np.repeat(hv[:, None], N, axis=1)])
+        re = emu.lmpc_solve(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0, N,
+                            pb["costs"], pb["cstrs"], row_rhs=rhs)
+        for k in range(b):
+            cs = [dict(pb["cstrs"][0], f=[fv[k]]), dict(pb["cstrs"][1], f=[hv[k]])]
+            ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, pb["costs"], cs)
+            assert re["status"][k] == ro["status"]
+            if ro["status"] == 0:
+                assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= RTOL
+        pbb = F.bounded_system("trajectory", N=N)
+        up = np.repeat(np.array([200.0, 90.0, 140.0, 60.0])[:, None], N, axis=1)
+        lo = np.full((b, N), -np.inf)
+        re = emu.lmpc_solve(np.tile(pbb["A"], (b, 1, 1)), np.tile(pbb["B"], (b, 1, 1)), np.tile(pbb["d"], (b, 1)), x0, N,
+                            pbb["costs"], pbb["cstrs"], bounds=(lo, up))
+        for k in range(b):
+            cs = [pbb["cstrs"][0], dict(pbb["cstrs"][1], upper=[up[k, 0]])]
+            ro = oracle.lmpc_solve(pbb["A"], pbb["B"], pbb["d"], x0[k], N, pbb["costs"], cs)
+            assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
+            assert re["control"][k].max() <= up[k, 0] + 1e-6
+
+
 def test_host_plan_errors(emu):
     """copra_batch_create's dimension checks (plan_builder.hpp) == std::domain_error of TestLMPC.cpp:949-1087"""
     from copra_amd import _capi

@@ -638,3 +638,53 @@ def test_per_instance_cost_references(oracle):
     sh.set_cost_reference(0, goals)
     with pytest.raises(CopraUnsupported):
         sh.solve()
+
+
+def test_per_instance_constraint_rhs_and_bounds(oracle):
+    """copra_batch_set_constraint_rhs / copra_batch_set_control_bounds: per-instance limits on the ordinary and on the
+    shared-model path (one-wave kernels) and with 150 steps (workgroup kernel)"""
+    import fixtures as F
+    from copra_amd import BatchLMPC
+    rng = np.random.default_rng(21)
+    for N in (12, 150):
+        pb = F.ineq_system("trajectory", N=N)
+        b = 64
+        x0 = np.tile(pb["x0"], (b, 1))
+        x0[:, 1] = -1.0 - rng.uniform(0.0, 0.1 * N, b)
+        fv = rng.uniform(-0.2, 0.3, (b, 1))
+        hv = rng.uniform(100.0, 200.0, (b, 1))
+        A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+        engines = [BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"])]
+        engines[0].set_system(A, B, d, x0)
+        if N <= 64:
+            sh = BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"])
+            sh.set_shared_system(pb["A"], pb["B"], pb["d"])
+            sh.set_x0(x0)
+            engines.append(sh)
+        for eng in engines:
+            eng.set_constraint_rhs(0, fv)
+            eng.set_constraint_rhs(1, hv)
+            eng.solve()
+            res = eng.results()
+            for k in range(0, b, 4):
+                cs = [dict(pb["cstrs"][0], f=fv[k]), dict(pb["cstrs"][1], f=hv[k])]
+                ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, pb["costs"], cs)
+                assert res["status"][k] == ro["status"]
+                if ro["status"] == 0:
+                    assert _rel(res["control"][k], ro["control"]) <= RTOL
+                    assert res["control"][k].max() <= hv[k, 0] + 1e-5
+        pbb = F.bounded_system("trajectory", N=N)
+        up = rng.uniform(60.0, 200.0, (b, 1))
+        eng = BatchLMPC(2, 1, N, b, pbb["costs"], pbb["cstrs"])
+        eng.set_system(A, B, d, x0)
+        eng.set_control_bounds(-np.inf, np.repeat(up, N, axis=1))
+        eng.solve()
+        res = eng.results()
+        for k in range(0, b, 8):
+            cs = [pbb["cstrs"][0], dict(pbb["cstrs"][1], upper=up[k])]
+            ro = oracle.lmpc_solve(pbb["A"], pbb["B"], pbb["d"], x0[k], N, pbb["costs"], cs)
+            assert res["status"][k] == ro["status"]
+            if ro["status"] == 0:
+                assert _rel(res["control"][k], ro["control"]) <= RTOL and res["control"][k].max() <= up[k, 0] + 1e-5
+    with pytest.raises(Exception):
+        eng.set_constraint_rhs(0, np.zeros((b, 2)))  # a TrajectoryBoundConstraint has no per-instance right-hand side
