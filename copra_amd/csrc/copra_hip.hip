@@ -219,6 +219,8 @@ struct copra_batch {
     int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
     // shared-model fast path: one (A, B, d) for the whole batch, factorised once (copra_batch_set_shared_system)
     bool shared = false, model_dirty = true, shared_attr_set = false;
+    int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)
+    size_t model_doubles = 0; // allocated size of d_model
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
     double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
@@ -521,41 +523,70 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
 static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
 {
     const FusedPlan& HP = h->hp.plan;
-    const int nx = HP.nx, nu = HP.nu, N = HP.N, n = HP.n, X = HP.X, np1 = nx + 1;
+    const int nx = HP.nx, nu = HP.nu, N = HP.N, n = HP.n, X = HP.X;
+    // c is affine in (x0, p of the costs with per-instance references): probe 0 = everything zero, then one unit probe
+    // per component of x0 and per row of every such cost
+    int rtot = 0;
+    for (int t = 0; t < kMaxCosts; ++t) {
+        h->model_ref_off[t] = -1;
+        if (t < HP.ncost && h->cost_p[t]) {
+            h->model_ref_off[t] = rtot;
+            rtot += HP.cost[t].rows;
+        }
+    }
+    const int np = 1 + nx + rtot;
     const ModelLayout m = model_layout(nx, nu, N, n, X, h->hp.lds_full.ldj, HP.mgen);
-    if (!h->d_model) HIP_TRY(hipMalloc((void**)&h->d_model, (size_t)m.total * sizeof(double)));
+    const size_t need = (size_t)m.C2 + (size_t)n * (rtot > 0 ? rtot : 1);
+    if (!h->d_model || h->model_doubles < need) {
+        (void)hipFree(h->d_model);
+        h->d_model = nullptr;
+        HIP_TRY(hipMalloc((void**)&h->d_model, need * sizeof(double)));
+        h->model_doubles = need;
+    }
     const size_t nA = (size_t)nx * nx, nB = (size_t)nx * nu;
-    std::vector<double> Ap(nA * np1), Bp(nB * np1), dp((size_t)nx * np1), xp((size_t)nx * np1, 0.0);
-    for (int a = 0; a < np1; ++a) {
+    std::vector<double> Ap(nA * np), Bp(nB * np), dp((size_t)nx * np), xp((size_t)nx * np, 0.0);
+    for (int a = 0; a < np; ++a) {
         std::copy(h->shA.begin(), h->shA.end(), Ap.begin() + (size_t)a * nA);
         std::copy(h->shB.begin(), h->shB.end(), Bp.begin() + (size_t)a * nB);
         std::copy(h->shd.begin(), h->shd.end(), dp.begin() + (size_t)a * nx);
-        if (a > 0) xp[(size_t)a * nx + (a - 1)] = 1.0;
+        if (a >= 1 && a <= nx) xp[(size_t)a * nx + (a - 1)] = 1.0;
     }
-    double *dA = nullptr, *dB = nullptr, *dd = nullptr, *dx = nullptr, *dQ = nullptr, *dC = nullptr;
+    std::vector<void*> owned;
     hipError_t e = hipSuccess;
-    auto up = [&](double** dst, const std::vector<double>& src) {
-        hipError_t r = hipMalloc((void**)dst, src.size() * sizeof(double));
-        if (r == hipSuccess) r = hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice);
+    auto up = [&](const std::vector<double>& src) -> double* {
+        double* dst = nullptr;
+        hipError_t r = hipMalloc((void**)&dst, (src.empty() ? 1 : src.size()) * sizeof(double));
+        if (r == hipSuccess && !src.empty()) r = hipMemcpy(dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice);
         if (r != hipSuccess && e == hipSuccess) e = r;
+        owned.push_back(dst);
+        return dst;
     };
-    up(&dA, Ap), up(&dB, Bp), up(&dd, dp), up(&dx, xp);
-    if (e == hipSuccess) e = hipMalloc((void**)&dQ, (size_t)n * n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dC, (size_t)n * np1 * sizeof(double));
     auto release = [&]() {
-        (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dd), (void)hipFree(dx), (void)hipFree(dQ), (void)hipFree(dC);
+        for (void* q : owned) (void)hipFree(q);
     };
+    FusedPlan P = device_plan(h);
+    P.A = up(Ap), P.B = up(Bp), P.d = up(dp), P.x0 = up(xp);
+    for (int t = 0; t < HP.ncost; ++t) { // probe references of the costs that have per-instance ones
+        P.cost_p[t] = nullptr;
+        if (h->model_ref_off[t] < 0) continue;
+        const int r = HP.cost[t].rows;
+        std::vector<double> pp((size_t)np * r, 0.0);
+        for (int i = 0; i < r; ++i) pp[(size_t)(1 + nx + h->model_ref_off[t] + i) * r + i] = 1.0;
+        P.cost_p[t] = up(pp);
+    }
+    P.row_f_inst = nullptr; // (c, J and the norms do not depend on right-hand sides or bounds)
+    P.lb_inst = P.ub_inst = nullptr;
+    double* dQ = up(std::vector<double>((size_t)n * n));
+    double* dC = up(std::vector<double>((size_t)n * np));
     if (e != hipSuccess) {
         release();
         return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
     }
-    FusedPlan P = device_plan(h);
-    P.A = dA, P.B = dB, P.d = dd, P.x0 = dx;
-    P.batch = np1;
+    P.batch = np;
     P.lds = h->hp.lds_full;
     P.prof = nullptr;
     P.prof_fine = nullptr;
-    for (int a = 0; a < np1 && e == hipSuccess; ++a) { // c(x0 = probe a) through the parity hook of the fused kernel
+    for (int a = 0; a < np && e == hipSuccess; ++a) { // c(probe a) through the parity hook of the fused kernel
         P.inst_offset = a;
         P.dump_instance = a;
         P.dump_only = 1;
@@ -573,17 +604,19 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
         hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, s, P);
         e = hipGetLastError();
     }
-    std::vector<double> C((size_t)n * np1);
+    std::vector<double> C((size_t)n * np);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipMemcpy(C.data(), dC, C.size() * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
-        std::vector<double> lin((size_t)n * np1); // c0 | C1 (n x nx, column-major)
+        std::vector<double> lin((size_t)n * np); // c0 | C1 (n x nx) | C2 (n x rtot), column-major
         for (int j = 0; j < n; ++j) lin[(size_t)j] = C[(size_t)j];
-        for (int a = 0; a < nx; ++a)
-            for (int j = 0; j < n; ++j) lin[(size_t)n + (size_t)a * n + j] = C[(size_t)(a + 1) * n + j] - C[(size_t)j];
+        for (int a = 1; a < np; ++a)
+            for (int j = 0; j < n; ++j) lin[(size_t)a * n + j] = C[(size_t)a * n + j] - C[(size_t)j];
         e = hipMemcpy(h->d_model + m.c0, lin.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess)
             e = hipMemcpy(h->d_model + m.C1, lin.data() + n, (size_t)n * nx * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess && rtot > 0)
+            e = hipMemcpy(h->d_model + m.C2, lin.data() + (size_t)n * (1 + nx), (size_t)n * rtot * sizeof(double), hipMemcpyHostToDevice);
     }
     release();
     if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
@@ -596,6 +629,7 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: null handle");
     const FusedPlan& P = h->hp.plan;
     if (cost_index < 0 || cost_index >= P.ncost) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: no such cost");
+    if ((p != nullptr) != (h->cost_p[cost_index] != nullptr)) h->model_dirty = true; // shared model: c0 / C2 change
     if (!p) { // back to the controller-wide reference given at creation
         h->cost_p[cost_index] = nullptr;
         return COPRA_OK;
@@ -695,9 +729,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
-        for (int k = 0; k < kMaxCosts; ++k)
-            if (h->cost_p[k])
-                return fail(COPRA_ERR_UNSUPPORTED, "per-instance cost references are not covered by the shared-model fast path");
+
         hipStream_t s = (hipStream_t)hip_stream;
         h->last_stream = s;
         if (h->hp.plan.batch == 0) return COPRA_OK;
@@ -716,6 +748,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         }
         FusedPlan P = device_plan(h);
         P.model = h->d_model;
+        for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
         if (h->packed) {

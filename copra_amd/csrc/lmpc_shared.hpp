@@ -61,6 +61,13 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (c < nx) acc += M[m.C1 + (size_t)c * n + lane] * x0r[c];
+        for (int t = 0; t < P.ncost; ++t) { // costs with per-instance references: c += C2_t p_t
+            if (P.cost_p[t] && P.model_ref_off[t] >= 0) {
+                const double* pt = P.cost_p[t] + (size_t)inst * P.cost[t].rows;
+                const double* C2 = M + m.C2 + (size_t)P.model_ref_off[t] * n;
+                for (int i = 0; i < P.cost[t].rows; ++i) acc += C2[(size_t)i * n + lane] * pt[i];
+            }
+        }
         S.cvec[lane] = acc;
     }
     wave_sync();

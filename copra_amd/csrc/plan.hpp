@@ -223,6 +223,9 @@ struct FusedPlan {
     //   model     != nullptr : lmpc_shared_body reads them (+ c0, C1: c = c0 + C1 x0) instead of rebuilding
     // layout (doubles): status | J [n * ldj] | G [N nx nu] | Phi [(N+1) nx nx] | xi [X] | nb [mgen] | c0 [n] | C1 [n x nx]
     //                   | Qinv [n * ldj] (= J J', symmetric: the unconstrained minimiser is -Qinv c without touching J)
+    //                   | C2 [n x R] : dc/dp of the costs that have per-instance references (model_ref_off[t] = first
+    //                     column of cost t, -1 = controller-wide reference already folded into c0)
+    int model_ref_off[kMaxCosts];
     double* model_out;
     const double* model;
     // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
@@ -236,7 +239,7 @@ struct FusedPlan {
 
 // offsets (doubles) into the shared-model buffer, see FusedPlan::model
 struct ModelLayout {
-    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, total;
+    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, C2, total; // (C2 has no fixed size: it ends the buffer)
 };
 #ifdef __HIPCC__
 #define COPRA_HOST_DEVICE __host__ __device__
@@ -259,6 +262,7 @@ COPRA_HOST_DEVICE inline ModelLayout model_layout(int nx, int nu, int N, int n, 
     COPRA_TAKE(c0, n);
     COPRA_TAKE(C1, (long long)n * nx);
     COPRA_TAKE(Qinv, (long long)n * ldj);
+    m.C2 = o;
 #undef COPRA_TAKE
     m.total = o;
     return m;

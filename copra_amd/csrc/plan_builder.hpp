@@ -172,7 +172,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
 
     // ---------------- costs ----------------
     P.ncost = n_costs;
-    for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = nullptr;
+    for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = nullptr, P.model_ref_off[k] = -1;
     P.rmax = 1;
     P.rfull = 0;
     for (int k = 0; k < n_costs; ++k) {

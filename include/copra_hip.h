@@ -142,8 +142,8 @@ copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_dev
  *      instance, [batch][rows] with the rows of that cost as created (per-step entry: r, full-size entry: r (N+1) or
  *      r N) -- each instance of the batch tracks its own goal / reference trajectory; in the reference this is one
  *      TrajectoryCost(M, p_b) / TargetCost / ControlCost / MixedCost object per LMPC (include/costFunctions.h:103-219).
- *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Not combinable with
- *      copra_batch_set_shared_system (COPRA_ERR_UNSUPPORTED at solve). ---- */
+ *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Works on the shared-model fast path
+ *      too (the gradient is affine in p: c = c0 + C1 x0 + C2 p, probed once). ---- */
 copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);
 
 /* ---- per-instance constraint data.  copra_batch_set_constraint_rhs: f of the Trajectory / Control / Mixed constraint

@@ -610,8 +610,8 @@ def test_packed_dense_qps(oracle):
 
 def test_per_instance_cost_references(oracle):
     """copra_batch_set_cost_reference on the headline shape: every instance has its own goal; back to the shared goal
-    with None; refused on the shared-model path"""
-    from copra_amd import BatchLMPC, CopraUnsupported, workloads
+    with None; the same on the shared-model path"""
+    from copra_amd import BatchLMPC, workloads
     b = 1024
     wl = workloads.com_preview(b)
     rng = np.random.default_rng(2)
@@ -632,12 +632,25 @@ def test_per_instance_cost_references(oracle):
     again = eng.results()
     ok = base["status"] == 0
     assert np.array_equal(again["status"], base["status"]) and np.abs(again["control"][ok] - base["control"][ok]).max() <= 1e-12
+    # shared-model path: c = c0 + C1 x0 + C2 p, probed once; goals of a second tick reuse the factorisation
     sh = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     sh.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
     sh.set_x0(wl["x0"])
-    sh.set_cost_reference(0, goals)
-    with pytest.raises(CopraUnsupported):
+    for tick_goals in (goals, goals[::-1].copy()):
+        sh.set_cost_reference(0, tick_goals)
         sh.solve()
+        rs = sh.results()
+        for k in range(0, b, 64):
+            costs = [dict(wl["costs"][0], p=tick_goals[k]), wl["costs"][1]]
+            ro = oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][k], wl["N"], costs, wl["cstrs"])
+            assert rs["status"][k] == ro["status"]
+            if ro["status"] == 0:
+                assert _rel(rs["control"][k], ro["control"]) <= RTOL
+    sh.set_cost_reference(0, None)  # back to the controller-wide goal: re-probed
+    sh.solve()
+    rs = sh.results()
+    ro = oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][5], wl["N"], wl["costs"], wl["cstrs"])
+    assert rs["status"][5] == ro["status"] == 0 and _rel(rs["control"][5], ro["control"]) <= RTOL
 
 
 def test_per_instance_constraint_rhs_and_bounds(oracle):
