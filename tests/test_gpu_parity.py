@@ -544,7 +544,7 @@ def test_receding_horizon_example_runs_on_device():
     assert last["mean_distance_to_goal"] < 0.5 * first["mean_distance_to_goal"]
 
 
-@pytest.mark.parametrize("N,lanes", [(10, 16), (16, 16), (20, 32), (40, 64)])
+@pytest.mark.parametrize("N,lanes", [(1, 16), (3, 16), (10, 16), (16, 16), (20, 32), (40, 64)])
 def test_packed_small_problems(oracle, N, lanes):
     """Several small problems per wavefront (packed_impl.inc: the same kernel bodies on 16- / 32-lane groups): every
     instance of a batch that is not a multiple of the group count matches the oracle, with per-instance iteration
@@ -576,7 +576,7 @@ def test_packed_small_problems(oracle, N, lanes):
             assert tuple(res["iter"][k]) == tuple(ro["iter"]) == tuple(rsh["iter"][k])
             assert _rel(res["control"][k], ro["control"]) <= 1e-6 and _rel(rsh["control"][k], ro["control"]) <= 1e-6
             its.add(int(ro["iter"][0]))
-    assert len(its) >= 3  # genuinely different paths inside a wavefront
+    assert len(its) >= min(3, N)  # genuinely different paths inside a wavefront
     ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))
     ise = BatchLMPC(2, 1, N, b, pb["costs"], pb["cstrs"], initial_state=ist)
     ise.set_system(A, B, d, x0)
