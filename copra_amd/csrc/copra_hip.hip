@@ -33,6 +33,17 @@ __global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
     lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
 }
 
+// Run-time shapes whose (compact) LDS layout lets more than 8 instances share a CU: the same bodies at four waves per
+// SIMD (128 VGPRs) -- at the 256-VGPR budget of the kernels above a CU holds 8 waves, whatever the LDS would allow.
+__global__ __launch_bounds__(64, 4) void copra_lmpc_fused_kernel_w4(const FusedPlan P)
+{
+    lmpc_fused_body<0, 0, 0, 0>(P, P.inst_offset + (int)blockIdx.x);
+}
+__global__ __launch_bounds__(64, 4) void copra_lmpc_shared_kernel_w4(const FusedPlan P)
+{
+    lmpc_shared_body<0, 0, 0>(P, (int)blockIdx.x);
+}
+
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
 template <int NX, int NU, int NH, int RP>
@@ -80,6 +91,7 @@ fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
         return tier2 ? copra_lmpc_shared_tier2_kernel<6, 3, 20> : copra_lmpc_shared_kernel<6, 3, 20>;
     if (P.nx == 2 && P.nu == 1 && P.N == 10)
         return tier2 ? copra_lmpc_shared_tier2_kernel<2, 1, 10> : copra_lmpc_shared_kernel<2, 1, 10>;
+    if (!tier2 && (size_t)P.lds.total * sizeof(double) * 9 <= 160u * 1024u) return copra_lmpc_shared_kernel_w4;
     return tier2 ? copra_lmpc_shared_tier2_kernel<0, 0, 0> : copra_lmpc_shared_kernel<0, 0, 0>;
 }
 // the BASELINE.json shapes get their own instantiation
@@ -88,6 +100,7 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
+    if ((size_t)P.lds.total * sizeof(double) * 9 <= 160u * 1024u) return copra_lmpc_fused_kernel_w4; // > 8 per CU
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;
 }
 fused_kernel_t select_tier2_kernel(const FusedPlan& P)
@@ -226,6 +239,8 @@ struct copra_batch {
     double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
     double* d_cost_p[kMaxCosts] = {}; // per-instance cost references (owned copies) ...
     const double* cost_p[kMaxCosts] = {}; // ... or borrowed device pointers (copra_batch_set_cost_reference)
+    int adapt_left = 2; // solves after which the overflow count of a dense layout is still checked
+    bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
     void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
@@ -283,6 +298,30 @@ static FusedPlan device_plan(const copra_batch* h)
     P.lb_inst = h->d_lb_inst;
     P.ub_inst = h->d_ub_inst;
     return P;
+}
+
+// Dense compact layouts bet on small active sets.  After each of the first solves the overflow queue tells whether the
+// bet holds; if more than one instance in eight had to be redone by the second tier, go back to the safe layout.
+static copra_status_t adapt_layout(copra_batch* h)
+{
+    if (!h->hp.dense || h->adapt_left <= 0 || !h->solved_once) return COPRA_OK;
+    h->adapt_left -= 1;
+    int count = 0;
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(&count, h->d_ovf_count, sizeof(int), hipMemcpyDeviceToHost));
+    if ((long long)count * 8 > (long long)h->hp.plan.batch) {
+        h->hp.plan.lds = h->hp.lds_safe;
+        h->hp.two_tier = h->hp.safe_two_tier;
+        h->hp.lds_bytes = (size_t)h->hp.lds_safe.total * sizeof(double);
+        h->hp.dense = false;
+        h->lds_attr_set = false;
+        h->shared_attr_set = false;
+        const FusedPlan& P = h->hp.plan;
+        h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.rfull > 0, h->hp.lds_bytes);
+        if (std::getenv("COPRA_DEBUG"))
+            fprintf(stderr, "[copra] %d of %d instances overflowed the dense LDS layout: back to the safe one\n", count, P.batch);
+    }
+    return COPRA_OK;
 }
 
 static copra_status_t ensure_lds_attr(copra_batch* h)
@@ -727,6 +766,11 @@ copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double
 copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
+    {
+        const copra_status_t rca = adapt_layout(h);
+        if (rca != COPRA_OK) return rca;
+        h->solved_once = true;
+    }
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
 

@@ -31,6 +31,11 @@ struct HostPlan {
     bool two_tier = false;
     LdsLayout lds_full {};
     size_t lds_full_bytes = 0;
+    // run-time shapes: plan.lds may be a DENSER compact layout than the safe choice below; copra_batch_solve falls back
+    // to the safe one when too many instances of the first solves overflow into the second tier
+    bool dense = false;
+    LdsLayout lds_safe {};
+    bool safe_two_tier = false;
     bool large = false; // more than 64 decision variables: workgroup-per-instance kernel (lmpc_large.hpp)
     // where the rows of constraint k (position in the user's array) sit in the stacked order: row = row0 + s * per_step
     // + i for its steps s and lines i (steps == 1 for a full-size entry); row0 < 0: bound constraint, no rows
@@ -518,6 +523,28 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             && compact.total <= quarter && compact.rcap >= 8 && compact.rcap < U) {
             hp.two_tier = true;
             P.lds = compact;
+        }
+        // Run-time shapes (no compile-time instantiation): the same trade at finer grain -- the densest compact layout
+        // (160 KiB / k per instance) that still leaves R room for a quarter of the variables (at least 8 columns);
+        // instances that need more finish in the second tier.  Measured at 30 variables (CoM preview, N = 10):
+        // 7 instances per CU in the full layout 17.4 M solves/s, k = 12 with the 128-VGPR build of the kernel 28.8 M.
+        hp.lds_safe = P.lds;
+        hp.safe_two_tier = hp.two_tier;
+        if (rp == 0 && !std::getenv("COPRA_NO_DENSE_LAYOUT")) {
+            static const int ks[] = { 16, 14, 12, 10, 8, 7, 6, 5 };
+            const int need = U < 8 ? U : ((U + 3) / 4 > 8 ? (U + 3) / 4 : 8);
+            for (int k : ks) {
+                const int budget = (160 * 1024 / k) / (int)sizeof(double);
+                if (budget >= P.lds.total) continue; // no denser than what is already chosen
+                LdsLayout c2 {};
+                if (layout_lds(c2, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, P.rfull)
+                    && c2.total <= budget && c2.rcap >= need) {
+                    hp.two_tier = c2.rcap < U;
+                    hp.dense = hp.two_tier; // (with room for every column there is nothing to fall back from)
+                    P.lds = c2;
+                    break;
+                }
+            }
         }
         hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
     }
