@@ -317,7 +317,7 @@ static copra_status_t adapt_layout(copra_batch* h)
         h->lds_attr_set = false;
         h->shared_attr_set = false;
         const FusedPlan& P = h->hp.plan;
-        h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.rfull > 0, h->hp.lds_bytes);
+        h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
         if (std::getenv("COPRA_DEBUG"))
             fprintf(stderr, "[copra] %d of %d instances overflowed the dense LDS layout: back to the safe one\n", count, P.batch);
     }
@@ -434,7 +434,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
     h->packed = (h->hp.large || std::getenv("COPRA_NO_PACKED")) ? 0
-        : packed_width(is ? P.nx + P.n : P.n, P.rfull > 0, h->hp.lds_bytes);
+        : packed_width(is ? P.nx + P.n : P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
@@ -1155,7 +1155,7 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         P.ws = ws;
         hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
     } else {
-        const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, false, lds_bytes);
+        const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, 0, false, lds_bytes);
         if (pw == 16)
             e = packed_dense_launch_w16(P, lds_bytes, s);
         else if (pw == 32)

@@ -21,10 +21,17 @@ hipError_t packed_dense_launch_w32(const DensePlan& P, size_t lds_bytes_per_inst
 // lds 3 KB, w = 16: 35 -> 150 M solves/s; n = 30, lds 14 KB, w = 32: 11 vs 8 instances per CU and rows that diverge
 // -> 18.1 -> 15.4 M solves/s, hence the threshold).  Full-size COST entries need the 64-lane MFMA operand layout and
 // stay on the one-wave kernels.
-inline int packed_width(int nvar, bool has_full_size_costs, size_t lds_bytes_per_instance)
+// `build_width` = elements one step of the preview recursion produces, xDim (xDim + uDim + 1) (0 for a dense QP): the
+// condense phase is lane-parallel over those, so a group should not be much narrower (CoM system, xDim 6, uDim 3, 15
+// variables: 73 M solves/s on 64 lanes, 60 M on 16 -- the recursion then takes four rounds per step).
+inline int packed_width(int nvar, int build_width, bool has_full_size_costs, size_t lds_bytes_per_instance)
 {
     if (has_full_size_costs || lds_bytes_per_instance == 0) return 0;
-    const int w = nvar <= 16 ? 16 : (nvar <= 32 ? 32 : 0);
+    int w = 0;
+    if (nvar <= 16 && build_width <= 32)
+        w = 16;
+    else if (nvar <= 32 && build_width <= 64)
+        w = 32;
     if (w == 0) return 0;
     const long long by_lds = (long long)(160u * 1024u / lds_bytes_per_instance);
     const long long unpacked = by_lds < 8 ? by_lds : 8;

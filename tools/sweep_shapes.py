@@ -1,0 +1,37 @@
+"""Kernel rate over problem sizes (dev / report tool; GPU box only): double integrator (nx=2, nu=1) and CoM preview
+(nx=6, nu=3) at several horizons.  Env: COPRA_NO_PACKED=1, COPRA_NO_DENSE_LAYOUT=1 switch the small / mid-size
+mappings off for comparison."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+from copra_amd import BatchLMPC, workloads  # noqa: E402
+
+
+def rate(eng, batch):
+    ts = []
+    for _ in range(7):
+        eng.solve()
+        eng.synchronize()
+        ts.append(eng.last_solve_seconds())
+    return batch / float(np.mean(ts[3:])) / 1e6
+
+
+rows = []
+for N in (5, 10, 16, 20, 32, 48, 64):
+    b = 131072
+    wl = workloads.double_integrator(b, N=N)
+    eng = BatchLMPC(2, 1, N, b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    rows.append(("double integrator N=%d" % N, N, eng.lanes_per_instance(), rate(eng, b)))
+for N in (5, 10, 15, 20):
+    b = 65536
+    wl = workloads.com_preview(b, N=N)
+    eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    rows.append(("CoM preview N=%d" % N, 3 * N, eng.lanes_per_instance(), rate(eng, b)))
+for name, n, lanes, r in rows:
+    print("%-26s n=%3d  lanes/instance %3d  %8.2f M solves/s" % (name, n, lanes, r))
