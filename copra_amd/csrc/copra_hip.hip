@@ -239,7 +239,7 @@ struct copra_batch {
     double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
     double* d_cost_p[kMaxCosts] = {}; // per-instance cost references (owned copies) ...
     const double* cost_p[kMaxCosts] = {}; // ... or borrowed device pointers (copra_batch_set_cost_reference)
-    int adapt_left = 2; // solves after which the overflow count of a dense layout is still checked
+    int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
     bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
     void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
@@ -300,27 +300,33 @@ static FusedPlan device_plan(const copra_batch* h)
     return P;
 }
 
-// Dense compact layouts bet on small active sets.  After each of the first solves the overflow queue tells whether the
-// bet holds; if more than one instance in eight had to be redone by the second tier, go back to the safe layout.
+// Compact LDS layouts (R capped, overflow finished by the second tier) bet on small active sets.  After each of the
+// first solves the overflow queue tells whether the bet holds; if more than one instance in eight had to be redone by
+// the second tier, step to the next safer layout: dense -> safe (quarter-CU compact or full) -> full.
 static copra_status_t adapt_layout(copra_batch* h)
 {
-    if (!h->hp.dense || h->adapt_left <= 0 || !h->solved_once) return COPRA_OK;
+    if (!h->hp.two_tier || h->hp.large || h->adapt_left <= 0 || !h->solved_once) return COPRA_OK;
     h->adapt_left -= 1;
     int count = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&count, h->d_ovf_count, sizeof(int), hipMemcpyDeviceToHost));
-    if ((long long)count * 8 > (long long)h->hp.plan.batch) {
+    if ((long long)count * 8 <= (long long)h->hp.plan.batch) return COPRA_OK;
+    if (h->hp.dense && h->hp.safe_two_tier) { // dense -> quarter-CU compact
         h->hp.plan.lds = h->hp.lds_safe;
-        h->hp.two_tier = h->hp.safe_two_tier;
-        h->hp.lds_bytes = (size_t)h->hp.lds_safe.total * sizeof(double);
-        h->hp.dense = false;
-        h->lds_attr_set = false;
-        h->shared_attr_set = false;
-        const FusedPlan& P = h->hp.plan;
-        h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
-        if (std::getenv("COPRA_DEBUG"))
-            fprintf(stderr, "[copra] %d of %d instances overflowed the dense LDS layout: back to the safe one\n", count, P.batch);
+        h->hp.two_tier = true;
+    } else { // -> full layout, single tier
+        h->hp.plan.lds = h->hp.lds_full;
+        h->hp.two_tier = false;
     }
+    h->hp.dense = false;
+    h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
+    h->lds_attr_set = false;
+    h->shared_attr_set = false;
+    const FusedPlan& P = h->hp.plan;
+    h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
+    if (std::getenv("COPRA_DEBUG"))
+        fprintf(stderr, "[copra] %d of %d instances overflowed the compact LDS layout: next layout %zu B, %s\n", count, P.batch,
+            h->hp.lds_bytes, h->hp.two_tier ? "two-tier" : "single tier");
     return COPRA_OK;
 }
 
