@@ -196,6 +196,8 @@ def lib():
         L.copra_batch_set_x0.argtypes = [vp, vp, C.c_int]
         L.copra_batch_lanes_per_instance.restype = C.c_int
         L.copra_batch_lanes_per_instance.argtypes = [vp]
+        L.copra_batch_specialise.restype = C.c_int
+        L.copra_batch_specialise.argtypes = [vp, C.c_char_p]
         L.copra_plan_check.restype = C.c_int
         L.copra_plan_check.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.copra_batch_set_constraint_rhs.restype = C.c_int

@@ -53,6 +53,10 @@ class BatchLMPC:
         self._sys = None
         self._outs = None
 
+    def specialise(self, cache_dir=None):
+        """compile this controller's shape into its own kernels (hipcc --genco, cached); see copra_batch_specialise"""
+        _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
+
     def lanes_per_instance(self):
         """16 / 32: several small problems per wavefront; 64: one wavefront each; > 64: one workgroup each"""
         return int(self._lib.copra_batch_lanes_per_instance(self._h))

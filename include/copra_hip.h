@@ -111,6 +111,15 @@ void copra_batch_destroy(copra_batch_t* h);
  *      workgroup-per-instance kernel (64 < decision variables <= 512). ---- */
 int copra_batch_lanes_per_instance(const copra_batch_t* h);
 
+/* ---- run-time specialisation: compile the kernels for THIS controller's (xDim, uDim, nrStep, cost rows) with
+ *      `hipcc --genco` from the headers next to libcopra_hip.so (about 20-40 s, once per shape: the code object is kept in
+ *      cache_dir, or $COPRA_JIT_CACHE, or ~/.cache/copra_amd when NULL) and use them from the next solve on.  The library
+ *      ships such instantiations for the BASELINE shapes only; every other shape otherwise runs on the run-time-shape
+ *      kernel, which is ~2.5x slower on the same problem.  A no-op (COPRA_OK) for shapes that already have dedicated
+ *      kernels (BASELINE shapes, packed small problems, InitialStateLMPC, more than 64 variables).  Results are the
+ *      same either way; COPRA_ERR_RUNTIME if hipcc is not available. ---- */
+copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir);
+
 /* ---- the checks of copra_batch_create / copra_batch_create_initial_state WITHOUT touching the device: what
  *      LMPC::addCost / addConstraint do when they call initializeCost / initializeConstraint (src/LMPC.cpp:118-128).
  *      `is` may be NULL.  Returns COPRA_OK, COPRA_ERR_DOMAIN, COPRA_ERR_RUNTIME or COPRA_ERR_UNSUPPORTED. ---- */

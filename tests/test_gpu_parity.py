@@ -701,3 +701,47 @@ def test_per_instance_constraint_rhs_and_bounds(oracle):
                 assert _rel(res["control"][k], ro["control"]) <= RTOL and res["control"][k].max() <= up[k, 0] + 1e-5
     with pytest.raises(Exception):
         eng.set_constraint_rhs(0, np.zeros((b, 2)))  # a TrajectoryBoundConstraint has no per-instance right-hand side
+
+
+def test_run_time_specialisation(oracle, tmp_path):
+    """copra_batch_specialise: the controller's shape compiled into its own kernels (hipcc --genco, cached) gives the
+    same results as the run-time-shape kernel, on the ordinary and on the shared-model path, and is reused from the
+    cache by the next controller of that shape"""
+    import time
+    from copra_amd import BatchLMPC, workloads
+    b, N = 2048, 15
+    wl = workloads.com_preview(b, N=N, v_max=0.3, u_max=1.5)
+    ref = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
+    ref.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    ref.solve()
+    r0 = ref.results()
+    eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.specialise(str(tmp_path))
+    assert any(f.name.endswith(".hsaco") for f in tmp_path.iterdir())
+    eng.solve()
+    r1 = eng.results()
+    assert np.array_equal(r0["status"], r1["status"]) and np.array_equal(r0["iter"], r1["iter"])
+    ok = r0["status"] == 0
+    assert ok.sum() > 0.9 * b and np.abs(r0["control"][ok] - r1["control"][ok]).max() <= 1e-9
+    for k in range(0, b, 256):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+        assert ro["status"] == r1["status"][k]
+        if ro["status"] == 0:
+            assert _rel(r1["control"][k], ro["control"]) <= RTOL
+    t0 = time.time()
+    sh = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
+    sh.specialise(str(tmp_path))  # cached code object
+    assert time.time() - t0 < 5.0
+    sh.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    sh.set_x0(wl["x0"])
+    sh.solve()
+    rs = sh.results()
+    for k in range(0, b, 256):
+        ro = oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+        assert ro["status"] == rs["status"][k]
+        if ro["status"] == 0:
+            assert _rel(rs["control"][k], ro["control"]) <= RTOL
+    # shapes that already have dedicated kernels: a no-op
+    small = BatchLMPC(2, 1, 10, 8, *[workloads.double_integrator(8)[k] for k in ("costs", "cstrs")])
+    small.specialise(str(tmp_path))

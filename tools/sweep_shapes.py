@@ -20,18 +20,23 @@ def rate(eng, batch):
     return batch / float(np.mean(ts[3:])) / 1e6
 
 
+JIT = "--specialise" in sys.argv  # copra_batch_specialise for every shape (about 20 s each, cached)
 rows = []
 for N in (5, 10, 16, 20, 32, 48, 64):
     b = 131072
     wl = workloads.double_integrator(b, N=N)
     eng = BatchLMPC(2, 1, N, b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    if JIT:
+        eng.specialise()
     rows.append(("double integrator N=%d" % N, N, eng.lanes_per_instance(), rate(eng, b)))
 for N in (5, 10, 15, 20):
     b = 65536
     wl = workloads.com_preview(b, N=N)
     eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    if JIT:
+        eng.specialise()
     rows.append(("CoM preview N=%d" % N, 3 * N, eng.lanes_per_instance(), rate(eng, b)))
 for name, n, lanes, r in rows:
     print("%-26s n=%3d  lanes/instance %3d  %8.2f M solves/s" % (name, n, lanes, r))
