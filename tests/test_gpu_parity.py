@@ -745,3 +745,17 @@ def test_run_time_specialisation(oracle, tmp_path):
     # shapes that already have dedicated kernels: a no-op
     small = BatchLMPC(2, 1, 10, 8, *[workloads.double_integrator(8)[k] for k in ("costs", "cstrs")])
     small.specialise(str(tmp_path))
+    # a packed shape (16 variables, four instances per wavefront): specialised on the group-wide primitives
+    w16 = workloads.double_integrator(203, N=16)
+    pk = BatchLMPC(2, 1, 16, 203, w16["costs"], w16["cstrs"])
+    assert pk.lanes_per_instance() == 16
+    pk.set_system(w16["A"], w16["B"], w16["d"], w16["x0"])
+    pk.solve()
+    before = pk.results()
+    pk.specialise(str(tmp_path))
+    pk.solve()
+    after = pk.results()
+    assert np.array_equal(before["status"], after["status"]) and np.array_equal(before["iter"], after["iter"])
+    assert np.abs(before["control"] - after["control"]).max() <= 1e-9
+    ro = oracle.lmpc_solve(w16["A"][7], w16["B"][7], w16["d"][7], w16["x0"][7], 16, w16["costs"], w16["cstrs"])
+    assert ro["status"] == after["status"][7] == 0 and _rel(after["control"][7], ro["control"]) <= RTOL

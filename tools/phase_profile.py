@@ -9,6 +9,10 @@ from copra_amd import BatchLMPC, workloads  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 wl = workloads.com_preview(batch)
+if "--generic" in sys.argv:  # a zero-weight seventh cost row keeps the shape off the compile-time instantiation
+    c0 = wl["costs"][0]
+    wl["costs"] = [dict(kind="trajectory", M=np.vstack([c0["M"], np.zeros((1, 6))]), p=np.append(c0["p"], 0.0),
+                        weights=np.append(c0["weights"], 0.0)), wl["costs"][1]]
 eng = BatchLMPC(6, 3, wl["N"], batch, wl["costs"], wl["cstrs"])
 eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
 eng.enable_phase_profile(True)
