@@ -198,6 +198,8 @@ def lib():
         L.copra_batch_lanes_per_instance.argtypes = [vp]
         L.copra_batch_specialise.restype = C.c_int
         L.copra_batch_specialise.argtypes = [vp, C.c_char_p]
+        L.copra_qp_dense_specialise.restype = C.c_int
+        L.copra_qp_dense_specialise.argtypes = [C.c_int, C.c_char_p]
         L.copra_plan_check.restype = C.c_int
         L.copra_plan_check.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.copra_batch_set_constraint_rhs.restype = C.c_int

@@ -200,6 +200,12 @@ class BatchLMPC:
         return dict(Q=np.array(Q), c=c, Aeq=np.array(Aeq), beq=beq, Aineq=np.array(Aineq), bineq=bineq, lb=lb, ub=ub)
 
 
+def qp_dense_specialise(n, cache_dir=None):
+    """Compile the dense-QP kernels for problems with `n` variables (copra_qp_dense_specialise): later
+    qp_solve_dense_batch calls with that n run on them.  Needs hipcc on the machine; cached on disk."""
+    _capi.check(_capi.lib().copra_qp_dense_specialise(int(n), cache_dir.encode() if cache_dir else None))
+
+
 def qp_solve_dense_batch(Q, c, Aeq, beq, Aineq, bineq, XL, XU):
     """Batched QuadProgDenseSolver::SI_solve (src/QuadProgSolver.cpp:54-72) on the GPU; numpy, natural indexing:
     Q (b,n,n), c (b,n), Aeq (b,meq,n) or None, ...  Returns x (b,n), fail (b,), iter (b,2)."""

@@ -768,14 +768,10 @@ static std::string library_dir()
     return ".";
 }
 
-copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
+// compile `source` (a translation unit that includes headers from the library's directory) into a code object named
+// `key` in the cache directory, unless it is already there; returns its path in `obj`
+static copra_status_t jit_compile(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj)
 {
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_specialise: null handle");
-    const FusedPlan& P = h->hp.plan;
-    if (h->jit_fused) return COPRA_OK;
-    const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
-    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu)
-        return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
     const std::string src_dir = library_dir();
     std::string dir = cache_dir ? cache_dir : "";
     if (dir.empty()) {
@@ -785,54 +781,102 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     }
     (void)mkdir((dir.substr(0, dir.find_last_of('/'))).c_str(), 0755);
     (void)mkdir(dir.c_str(), 0755);
-    // the code object depends on the shape, the register budget and the exact sources it was compiled from
+    std::string stamp = "nostamp"; // the code object depends on the exact sources it was compiled from
+    if (FILE* f = fopen((src_dir + "/libcopra_hip.so.srchash").c_str(), "r")) {
+        char buf[64] = { 0 };
+        if (fgets(buf, sizeof buf, f)) stamp = std::string(buf).substr(0, 12);
+        fclose(f);
+    }
+    obj = dir + "/" + key + "_" + stamp + ".hsaco";
+    if (access(obj.c_str(), R_OK) == 0) return COPRA_OK;
+    const std::string src = obj + "." + std::to_string((long)getpid()) + ".hip";
+    FILE* f = fopen(src.c_str(), "w");
+    if (!f) return fail(COPRA_ERR_RUNTIME, "run-time specialisation: cannot write to the cache directory " + dir);
+    fputs(source.c_str(), f);
+    fclose(f);
+    const char* hipcc = std::getenv("HIPCC");
+    const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
+    const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 --genco -I'" + src_dir
+        + "' -o '" + tmp + "' '" + src + "' > '" + src + ".log' 2>&1";
+    const int rc = std::system(cmd.c_str());
+    (void)unlink(src.c_str());
+    if (rc != 0 || rename(tmp.c_str(), obj.c_str()) != 0)
+        return fail(COPRA_ERR_RUNTIME, "run-time specialisation: hipcc --genco failed (see " + src + ".log)");
+    (void)unlink((src + ".log").c_str());
+    return COPRA_OK;
+}
+
+// dense-QP kernels compiled for a fixed number of variables (copra_qp_dense_specialise): (n, lanes per QP) -> kernel
+struct DenseJit {
+    int n, lanes;
+    hipFunction_t fn;
+};
+static std::vector<DenseJit> g_dense_jit;
+
+copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir)
+{
+    if (n <= 0 || n > kWave) return COPRA_OK; // (the workgroup-per-problem kernel has no shape parameters)
+    for (int lanes : { 64, 32, 16 }) {
+        if (lanes < n) continue;
+        bool have = false;
+        for (const DenseJit& d : g_dense_jit) have = have || (d.n == n && d.lanes == lanes);
+        if (have) continue;
+        char key[96], source[1024];
+        snprintf(key, sizeof key, "copra_jit_dense_%d_l%d", n, lanes);
+        if (lanes == 64)
+            snprintf(source, sizeof source,
+                "#include <hip/hip_runtime.h>\n#include \"qp_dense.hpp\"\nusing namespace copra_hip;\n"
+                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_dense(const DensePlan P)\n"
+                "{ qp_dense_body<%d>(P, (int)blockIdx.x); }\n", n);
+        else
+            snprintf(source, sizeof source,
+                "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
+                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_dense(const DensePlan P)\n"
+                "{ const int inst = instance_id(); if (inst < P.batch) qp_dense_body<%d>(P, inst); }\n", lanes, n);
+        std::string obj;
+        const copra_status_t rc = jit_compile(key, source, cache_dir, obj);
+        if (rc != COPRA_OK) return rc;
+        hipModule_t mod = nullptr;
+        HIP_TRY(hipModuleLoad(&mod, obj.c_str()));
+        hipFunction_t fn = nullptr;
+        HIP_TRY(hipModuleGetFunction(&fn, mod, "copra_jit_dense"));
+        g_dense_jit.push_back(DenseJit { n, lanes, fn }); // (modules stay loaded for the life of the process)
+    }
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_specialise: null handle");
+    const FusedPlan& P = h->hp.plan;
+    if (h->jit_fused) return COPRA_OK;
+    const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
+    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu)
+        return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
     // (always the full register budget: with compile-time trip counts the unrolled bodies spill at 128 VGPRs -- double
     //  integrator N = 32: 9.2 M solves/s at four waves per SIMD, 15.6 M at two, 11.8 M for the run-time-shape kernel)
-    const bool w4 = false;
-    std::string stamp;
+    char key[128], source[1536];
+    snprintf(key, sizeof key, "copra_jit_%d_%d_%d_%d_l%d", P.nx, P.nu, P.N, P.rmax, h->packed ? h->packed : 64);
+    if (h->packed) // several small instances per wavefront: the same bodies on the group-wide primitives
+        snprintf(source, sizeof source,
+            "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
+            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
+            "{ const int inst = P.inst_offset + instance_id(); if (inst < P.batch) lmpc_fused_body<%d, %d, %d, %d>(P, inst); }\n"
+            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
+            "{ const int inst = instance_id(); if (inst < P.batch) lmpc_shared_body<%d, %d, %d>(P, inst); }\n",
+            h->packed, P.nx, P.nu, P.N, P.rmax, P.nx, P.nu, P.N);
+    else
+        snprintf(source, sizeof source,
+            "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
+            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
+            "{ lmpc_fused_body<%d, %d, %d, %d>(P, P.inst_offset + (int)blockIdx.x); }\n"
+            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
+            "{ lmpc_shared_body<%d, %d, %d>(P, (int)blockIdx.x); }\n",
+            P.nx, P.nu, P.N, P.rmax, P.nx, P.nu, P.N);
+    std::string obj;
     {
-        FILE* f = fopen((src_dir + "/libcopra_hip.so.srchash").c_str(), "r");
-        char buf[64] = { 0 };
-        if (f) {
-            if (fgets(buf, sizeof buf, f)) stamp = std::string(buf).substr(0, 12);
-            fclose(f);
-        }
-    }
-    char key[160];
-    snprintf(key, sizeof key, "copra_jit_%d_%d_%d_%d_%s_l%d_%s", P.nx, P.nu, P.N, P.rmax, w4 ? "w4" : "w2", h->packed ? h->packed : 64,
-        stamp.empty() ? "nostamp" : stamp.c_str());
-    const std::string obj = dir + "/" + key + ".hsaco";
-    if (access(obj.c_str(), R_OK) != 0) {
-        const std::string src = dir + "/" + key + "." + std::to_string((long)getpid()) + ".hip";
-        FILE* f = fopen(src.c_str(), "w");
-        if (!f) return fail(COPRA_ERR_RUNTIME, "copra_batch_specialise: cannot write to the cache directory " + dir);
-        if (h->packed) { // several small instances per wavefront: the same bodies on the group-wide primitives
-            fprintf(f,
-                "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
-                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
-                "{ const int inst = P.inst_offset + instance_id(); if (inst < P.batch) lmpc_fused_body<%d, %d, %d, %d>(P, inst); }\n"
-                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
-                "{ const int inst = instance_id(); if (inst < P.batch) lmpc_shared_body<%d, %d, %d>(P, inst); }\n",
-                h->packed, P.nx, P.nu, P.N, P.rmax, P.nx, P.nu, P.N);
-        } else {
-            fprintf(f,
-                "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
-                "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_fused(const FusedPlan P)\n"
-                "{ lmpc_fused_body<%d, %d, %d, %d>(P, P.inst_offset + (int)blockIdx.x); }\n"
-                "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_shared(const FusedPlan P)\n"
-                "{ lmpc_shared_body<%d, %d, %d>(P, (int)blockIdx.x); }\n",
-                w4 ? ", 4" : "", P.nx, P.nu, P.N, P.rmax, w4 ? ", 4" : "", P.nx, P.nu, P.N);
-        }
-        fclose(f);
-        const char* hipcc = std::getenv("HIPCC");
-        const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
-        const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 --genco -I'" + src_dir
-            + "' -o '" + tmp + "' '" + src + "' > '" + src + ".log' 2>&1";
-        const int rc = std::system(cmd.c_str());
-        (void)unlink(src.c_str());
-        if (rc != 0 || rename(tmp.c_str(), obj.c_str()) != 0)
-            return fail(COPRA_ERR_RUNTIME, "copra_batch_specialise: hipcc --genco failed (see " + src + ".log)");
-        (void)unlink((src + ".log").c_str());
+        const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);
+        if (rcj != COPRA_OK) return rcj;
     }
     hipModule_t mod = nullptr;
     HIP_TRY(hipModuleLoad(&mod, obj.c_str()));
@@ -1287,7 +1331,15 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
     } else {
         const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, 0, false, lds_bytes);
-        if (pw == 16)
+        hipFunction_t jit = nullptr;
+        for (const DenseJit& d : g_dense_jit)
+            if (d.n == n && d.lanes == (pw ? pw : 64)) jit = d.fn;
+        const unsigned per = pw ? 64u / (unsigned)pw : 1u;
+        if (jit && (size_t)per * lds_bytes <= 48 * 1024) {
+            DensePlan Pj = P;
+            void* args[] = { &Pj };
+            e = hipModuleLaunchKernel(jit, ((unsigned)batch + per - 1) / per, 1, 1, 64, 1, 1, per * (unsigned)lds_bytes, s, args, nullptr);
+        } else if (pw == 16)
             e = packed_dense_launch_w16(P, lds_bytes, s);
         else if (pw == 32)
             e = packed_dense_launch_w32(P, lds_bytes, s);

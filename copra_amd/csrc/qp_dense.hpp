@@ -48,14 +48,16 @@ struct DenseRows {
     }
 };
 
+// NV > 0: number of variables fixed at compile time (copra_qp_dense_specialise), 0: taken from the plan
+template <int NV = 0>
 COPRA_DEV void qp_dense_body(const DensePlan& P, int inst)
 {
     double* lds = lds_base();
     const LdsLayout& L = P.lds;
     const int lane = lane_id();
-    const int n = P.n;
+    const int n = NV ? NV : P.n;
     SolverLds S = carve_solver(lds, L);
-    const int ld = S.ldj;
+    const int ld = NV ? (NV | 1) : S.ldj;
     double* nb = lds + L.nb;
     const double* Q = P.Q + (size_t)inst * n * n;
     for (int e = lane; e < n * n; e += kWave) {
@@ -76,9 +78,9 @@ COPRA_DEV void qp_dense_body(const DensePlan& P, int inst)
     }
     wave_sync();
     COPRA_FINE_DECL;
-    int status = gi_factorize<0>(S, n, nullptr COPRA_FINE_PASS);
+    int status = gi_factorize<NV>(S, n, nullptr COPRA_FINE_PASS);
     int it_main = 0, it_drop = 0;
-    if (status == 0) status = gi_active_set<0>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+    if (status == 0) status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     const double qnan = __builtin_nan("");
     for (int e = lane; e < n; e += kWave) P.x[(size_t)inst * n + e] = (status == 0) ? S.xs[e] : qnan;

@@ -224,6 +224,10 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     const double* XU, double* x, int* fail, int* iter, int on_device, void* hip_stream);
 
 /* ---- misc ---- */
+/* ---- run-time specialisation of the dense-QP kernel for problems with `n` variables (n <= 64): as
+ *      copra_batch_specialise; later copra_qp_solve_dense_batch calls with that n use the compiled kernels. ---- */
+copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir);
+
 const char* copra_last_error(void);
 copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len);
 int copra_abi_version(void);

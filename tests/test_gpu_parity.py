@@ -3,6 +3,8 @@
 Tolerance: BASELINE.json north_star -- controls / trajectories within 1e-6 relative of the CPU QuadProgDense path.
 We assert  max |u - u_ref| / (1 + |u_ref|) <= 1e-6  (and the same for the trajectory) plus identical status codes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -606,6 +608,29 @@ def test_packed_dense_qps(oracle):
         assert fail[k] == fo
         if fo == 0:
             assert tuple(it[k]) == tuple(ito) and np.abs(x[k] - xo).max() <= 1e-9 * (1 + np.abs(xo).max())
+
+
+def test_dense_qp_specialised_for_n(oracle, tmp_path):
+    """copra_qp_dense_specialise: kernels compiled for a fixed number of variables give the results of the run-time-n
+    kernels bit for bit, for one QP per wavefront (n = 40) and for packed QPs (n = 12)"""
+    import shutil
+    import fixtures as F
+    from copra_amd import qp_dense_specialise, qp_solve_dense_batch
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this machine")
+    rng = np.random.default_rng(14)
+    for n, meq, mi, b in ((40, 3, 25, 67), (12, 2, 9, 101)):
+        Ps = [F.random_dense_qp(rng, n, meq, mi, tight=0.05 + 0.5 * rng.random()) for _ in range(b)]
+        st = lambda k: np.stack([P[k] for P in Ps])
+        args = (st("Q"), st("c"), st("Aeq"), st("beq"), st("Aineq"), st("bineq"), st("XL"), st("XU"))
+        x0, f0, it0 = qp_solve_dense_batch(*args)
+        qp_dense_specialise(n, str(tmp_path))
+        x1, f1, it1 = qp_solve_dense_batch(*args)
+        assert np.array_equal(f0, f1) and np.array_equal(it0, it1) and (f0 == 0).sum() > b // 2
+        assert np.array_equal(x0[f0 == 0], x1[f0 == 0])
+        xo, fo, ito = oracle.quadprog_dense(*[a[5] for a in args])
+        assert f1[5] == fo and (fo != 0 or np.abs(x1[5] - xo).max() <= 1e-9 * (1 + np.abs(xo).max()))
+    assert len(list(tmp_path.glob("copra_jit_dense_*.hsaco"))) >= 3  # 40: one build; 12: 64-, 32- and 16-lane builds
 
 
 def test_per_instance_cost_references(oracle):
