@@ -48,6 +48,14 @@ __global__ __launch_bounds__(64, 4) void copra_lmpc_shared_kernel_w4(const Fused
     lmpc_shared_body<0, 0, 0>(P, (int)blockIdx.x);
 }
 
+// Factor-only first tier (LdsLayout::tri): the packed Cholesky factor is the only O(n^2) object in LDS, so six instances
+// share a CU at the headline shape (two waves on two of the four SIMDs: 256 VGPRs each) instead of four.
+template <int NX, int NU, int NH, int RP>
+__global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const FusedPlan P)
+{
+    lmpc_fused_body<NX, NU, NH, RP, true>(P, P.inst_offset + (int)blockIdx.x);
+}
+
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
 template <int NX, int NU, int NH, int RP>
@@ -102,6 +110,10 @@ fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
 fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
+    if (P.lds.tri) {
+        if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
+        return copra_lmpc_fused_tri_kernel<0, 0, 0, 0>;
+    }
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
     if ((size_t)P.lds.total * sizeof(double) * 9 <= 160u * 1024u) return copra_lmpc_fused_kernel_w4; // > 8 per CU
@@ -247,6 +259,7 @@ struct copra_batch {
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_fused = nullptr, jit_shared = nullptr;
     int jit_lanes = 64; // lanes per instance the code object was compiled for
+    int jit_tri = 0; // ... and whether for the factor-only layout
     int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
     bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
@@ -567,6 +580,14 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shA.data(), A, nA * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shB.data(), B, nB * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
+    if (h->hp.plan.lds.tri) { // the shared-model kernel works on the batch-wide J = R^-1: back to the layout that holds it
+        h->hp.plan.lds = h->hp.lds_safe;
+        h->hp.two_tier = h->hp.safe_two_tier;
+        h->hp.dense = false;
+        h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
+        h->lds_attr_set = false;
+        h->shared_attr_set = false;
+    }
     h->shared = true;
     h->model_dirty = true;
     return COPRA_OK;
@@ -856,7 +877,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     // (always the full register budget: with compile-time trip counts the unrolled bodies spill at 128 VGPRs -- double
     //  integrator N = 32: 9.2 M solves/s at four waves per SIMD, 15.6 M at two, 11.8 M for the run-time-shape kernel)
     char key[128], source[1536];
-    snprintf(key, sizeof key, "copra_jit_%d_%d_%d_%d_l%d", P.nx, P.nu, P.N, P.rmax, h->packed ? h->packed : 64);
+    snprintf(key, sizeof key, "copra_jit_%d_%d_%d_%d_l%d%s", P.nx, P.nu, P.N, P.rmax, h->packed ? h->packed : 64, P.lds.tri ? "t" : "");
     if (h->packed) // several small instances per wavefront: the same bodies on the group-wide primitives
         snprintf(source, sizeof source,
             "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
@@ -869,10 +890,10 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
         snprintf(source, sizeof source,
             "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
             "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
-            "{ lmpc_fused_body<%d, %d, %d, %d>(P, P.inst_offset + (int)blockIdx.x); }\n"
+            "{ lmpc_fused_body<%d, %d, %d, %d, %s>(P, P.inst_offset + (int)blockIdx.x); }\n"
             "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
             "{ lmpc_shared_body<%d, %d, %d>(P, (int)blockIdx.x); }\n",
-            P.nx, P.nu, P.N, P.rmax, P.nx, P.nu, P.N);
+            P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.nx, P.nu, P.N);
     std::string obj;
     {
         const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);
@@ -895,6 +916,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     }
     h->jit_module = mod;
     h->jit_lanes = h->packed ? h->packed : 64;
+    h->jit_tri = P.lds.tri;
     h->jit_fused = f1;
     h->jit_shared = f2;
     return COPRA_OK;
@@ -1011,7 +1033,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         return COPRA_OK;
     }
     if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-    if (h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64)) {
+    if (h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
         FusedPlan Pj = P;
         void* args[] = { &Pj };
         const unsigned per = 64u / (unsigned)h->jit_lanes;

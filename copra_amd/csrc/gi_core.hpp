@@ -56,6 +56,7 @@ struct alignas(16) f64x2 { // one 16-byte LDS access
 struct SolverLds {
     double* J;
     int ldj;
+    double* Q1; // factor-only layout: column k of the orthonormal basis of R^-T N at Q1[64 k + lane] (else unused)
     double* R; // packed upper triangular: R(i,c) at R[c(c+1)/2 + i]
     int rcap; // columns R has room for (LdsLayout::rcap)
     double *xs, *dv, *zv, *uv, *ap, *coef, *cvec, *eqsgn, *scal;
@@ -69,6 +70,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.J = lds + L.J;
     S.Jsrc = nullptr;
     S.ldj = L.ldj;
+    S.Q1 = lds + L.Q1;
     S.R = lds + L.R;
     S.rcap = L.rcap;
     S.xs = lds + L.xs;
@@ -90,7 +92,19 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
 // On exit the upper triangle of S.J holds the Cholesky factor R (Q = R'R), S.coef holds 1/R(i,i) and S.xs = -Q^-1 c.
 // Returns 0 or 2.  gi_invert() then turns R into J = R^-1 when (and only when) the active-set loop needs it.
 // ------------------------------------------------------------------------------------------------
-template <int NV>
+COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
+
+// where entry (i, j) of the factor lives: square storage with leading dimension ld, or (TRI) the packed upper triangle.
+// Both are bank-conflict free for "lane = column" and "lane = row" accesses (c -> c (c + 1) / 2 is a bijection modulo
+// 32 on any 32 consecutive columns).  In the packed form an (i, j) below the diagonal names some other entry of the
+// triangle: the factorisation loops read such entries on lanes whose result is discarded, never write them.
+template <bool TRI>
+COPRA_DEV int fidx(int i, int j, int ld)
+{
+    return TRI ? rcol(j) + i : i * ld + j;
+}
+
+template <int NV, bool TRI = false>
 COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA_FINE_ARGS)
 {
     const int lane = lane_id();
@@ -106,15 +120,15 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
         const int pw = (n - k0 < 4) ? n - k0 : 4;
         double acc[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = (p < pw) ? J[(k0 + p) * ld + lj] : 0.0;
+        for (int p = 0; p < 4; ++p) acc[p] = (p < pw) ? J[fidx<TRI>(k0 + p, lj, ld)] : 0.0;
 #pragma unroll 2
         for (int t = 0; t < k0; t += 4) { // k0 is a multiple of 4: no remainder
             double rt[4], bb[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                rt[u] = J[(t + u) * ld + lj]; // R(t+u, lane)
+                rt[u] = J[fidx<TRI>(t + u, lj, ld)]; // R(t+u, lane)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) bb[u][p] = (p < pw) ? J[(t + u) * ld + k0 + p] : 0.0; // wave-uniform address
+                for (int p = 0; p < 4; ++p) bb[u][p] = (p < pw) ? J[fidx<TRI>(t + u, k0 + p, ld)] : 0.0; // wave-uniform address
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -152,7 +166,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 #pragma unroll
             for (int t = 0; t < p; ++t) v -= Rd[t][p] * rp[t];
             rp[p] = v * ri[p]; // R(k0+p, lane); the diagonal lane gets sqrt(pivot)
-            if (p < pw && lane >= k0 + p && lane < n) J[(k0 + p) * ld + lane] = rp[p];
+            if (p < pw && lane >= k0 + p && lane < n) J[fidx<TRI>(k0 + p, lane, ld)] = rp[p];
             if (p < pw && lane == 0) rinvd[k0 + p] = ri[p];
         }
         wave_sync();
@@ -170,7 +184,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = (k0 + u < n) ? k0 + u : n - 1;
-                row[u] = J[k * ld + lj]; // R(k, lane)
+                row[u] = J[fidx<TRI>(k, lj, ld)]; // R(k, lane)
                 ri[u] = rinvd[k];
             }
 #pragma unroll
@@ -191,7 +205,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = (k0 - u >= 0) ? k0 - u : 0;
-                colv[u] = J[lj * ld + k]; // R(lane, k)
+                colv[u] = J[fidx<TRI>(lj, k, ld)]; // R(lane, k)
                 ri[u] = rinvd[k];
             }
 #pragma unroll
@@ -273,13 +287,19 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
     }
 }
 
-COPRA_DEV int rcol(int c) { return c * (c + 1) / 2; }
-
 // ------------------------------------------------------------------------------------------------
 // Active-set iterations.  Returns qpgen2's ierr (0 ok, 1 infeasible), 3 (iteration cap) or 4 (internal: the
 // compact layout's R is full; the caller queues the instance for the full-layout launch).
 // ------------------------------------------------------------------------------------------------
-template <int NV, class Rows>
+//
+// TRI (factor-only layout): J = R^-1 is never formed.  With N the active normals, R^-T N = Q1 Rq (Q1 orthonormal, n x
+// nact; Rq is S.R) replaces the first nact columns of qpgen2's J = R^-1 [Q1 Q2]:
+//     d1 = Q1' w,  w = R^-T n+ (forward substitution);   z = J2 J2' n+ = R^-1 (w - Q1 d1) (back substitution);
+//     adding a constraint appends (w - Q1 d1) / |.| to Q1 and [d1; |.|] to Rq -- no sweep over an n x n matrix;
+//     dropping one rotates columns of Q1 exactly as it rotates those of J.
+// Same pivoting rule, same steps, the same iterates up to rounding; 15 KB of LDS per instance instead of 29 KB at
+// n = 60 and no triangular inverse (48 k cycles) for the instances that activate a constraint.
+template <int NV, bool TRI = false, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
     int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false)
 {
@@ -352,7 +372,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
-        if (!have_J) { // first violated constraint: only now is J = R^-1 needed
+        if (!TRI && !have_J) { // first violated constraint: only now is J = R^-1 needed
             if (S.Jsrc) { // shared model: the batch-wide J is in HBM / L2, take a private copy (the updates rotate it)
                 wave_sync();
                 for (int e = lane; e < n * ld; e += kWave) S.J[e] = S.Jsrc[e];
@@ -375,8 +395,75 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 S.ap[lane] = (q < n) ? ((lane == q) ? -1.0 : 0.0) : ((lane == q - n) ? 1.0 : 0.0);
             }
             wave_sync();
+            double dj, zi;
+            double vj = 0.0; // TRI: component `lane` of w - Q1 d1
+            if constexpr (TRI) {
+                // w = R^-T n+ : forward substitution, lane = column; a bound row's normal starts at its own index
+                const double* rinvd = S.coef;
+                double acc = (lane < n) ? S.ap[lj] : 0.0;
+                double wk = 0.0;
+                auto forward = [&](int kfirst) {
+                    for (int k0 = kfirst; k0 < n; k0 += 4) {
+                        double row[4], ri4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = (k0 + u < n) ? k0 + u : n - 1;
+                            row[u] = J[fidx<true>(k, lj, ld)];
+                            ri4[u] = rinvd[k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int k = k0 + u;
+                            if (k < n) {
+                                const double y = bcast_f64(acc, k) * ri4[u];
+                                if (lane == k) wk = y;
+                                if (lane > k) acc -= row[u] * y;
+                            }
+                        }
+                    }
+                };
+                if (nvl < mgen)
+                    forward(0); // (compile-time trip count when the shape is: the loads of the whole sweep batch)
+                else
+                    forward(((nvl - mgen) % n) & ~3);
+                if (lane >= n) wk = 0.0;
+                // d1 = Q1' w and v = w - Q1 d1, by modified Gram-Schmidt, twice (keeps Q1 orthonormal to rounding)
+                vj = wk;
+                dj = 0.0;
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int k = 0; k < nact; ++k) {
+                        const double qk = S.Q1[k * kWave + lane];
+                        const double e = wave_sum(qk * vj);
+                        vj -= e * qk;
+                        if (lane == k) dj += e;
+                    }
+                }
+                if (iter_main <= 1) COPRA_FINE("as:d");
+                // z = R^-1 v : back substitution, lane = row
+                acc = vj;
+                double zk = 0.0;
+                for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
+                    double colv[4], ri4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = (k0 - u >= 0) ? k0 - u : 0;
+                        colv[u] = J[fidx<true>(lj, k, ld)];
+                        ri4[u] = rinvd[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 - u;
+                        if (k >= 0) {
+                            const double x = bcast_f64(acc, k) * ri4[u];
+                            if (lane == k) zk = x;
+                            if (lane < k) acc -= colv[u] * x;
+                        }
+                    }
+                }
+                zi = (lane < n) ? zk : 0.0;
+                if (iter_main <= 1) COPRA_FINE("as:z");
+            } else {
             // d = J' n+   (lane = column)
-            double dj;
             {
                 double d0 = 0.0, d1 = 0.0;
                 int i = 0;
@@ -391,7 +478,6 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             wave_sync();
             if (iter_main <= 1) COPRA_FINE("as:d");
             // z = J2 d2   (lane = row; the d1 part of dv is zero)
-            double zi;
             {
                 double z0 = 0.0, z1 = 0.0;
                 int j = 0;
@@ -403,6 +489,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 zi = (lane < n) ? z0 + z1 : 0.0;
             }
             if (iter_main <= 1) COPRA_FINE("as:z");
+            }
             // r = R^-1 d1 : column-oriented back substitution, r_c broadcast from lane c
             double acc = (lane < nact) ? dj : 0.0;
             double ri = 0.0;
@@ -450,6 +537,19 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     // ---- full step: constraint nvl becomes active; update R and J ----
                     if (nact >= S.rcap) return 4; // compact layout: R is full -> the instance is redone with the full one
                     if (lane < nact) S.R[rcol(nact) + lane] = dj;
+                    if constexpr (TRI) {
+                        const double h = sqrt(wave_sum(vj * vj));
+                        S.Q1[nact * kWave + lane] = vj / h; // (lanes >= n hold 0)
+                        if (lane == nact) {
+                            S.R[rcol(nact) + nact] = h;
+                            S.iact[nact] = nvl;
+                            S.act[nvl] = 1;
+                        }
+                        nact += 1;
+                        wave_sync();
+                        if (iter_main <= 1) COPRA_FINE("as:givens");
+                        break; // back to step 1
+                    }
                     const bool in_tail = (lane >= nact && lane < n);
                     // |h_q| = sqrt(sum_{k>=q} d_k^2) by a suffix scan, scaled by max|d| against under/overflow
                     const double dmax = wave_max(in_tail ? fabs(dj) : 0.0);
@@ -583,7 +683,12 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                             S.R[rcol(c) + q] = t;
                         }
                         // columns q, q+1 of J (lane = row)
-                        if (lane < n) {
+                        if constexpr (TRI) {
+                            const double x = S.Q1[q * kWave + lane], y = S.Q1[(q + 1) * kWave + lane];
+                            const double t = gc * x + gs * y;
+                            S.Q1[(q + 1) * kWave + lane] = nu_ * (x + t) - y;
+                            S.Q1[q * kWave + lane] = t;
+                        } else if (lane < n) {
                             const double x = J[lane * ld + q], y = J[lane * ld + q + 1];
                             const double t = gc * x + gs * y;
                             J[lane * ld + q + 1] = nu_ * (x + t) - y;

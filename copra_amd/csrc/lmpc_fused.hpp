@@ -171,9 +171,48 @@ struct StageRows {
         }
     }
 
+    // component eo of state k at the iterate xs, straight from G (FusedPlan::rows_direct): the same sum in the same
+    // order as refresh_trajectory().  With a compile-time horizon every lane runs all steps (the blocks past its own
+    // step enter with a zero factor), so the loop unrolls and its LDS reads are issued back to back.
+    COPRA_DEV double state_component(int k, int eo, const double* xs) const
+    {
+        double a0 = 0.0;
+        if constexpr (NH_ > 0 && NU_ > 0 && NX_ > 0) {
+#pragma unroll
+            for (int jb = 0; jb < NH_; ++jb) {
+                const int t = k - 1 - jb;
+                const bool on = t >= 0;
+                const double* g = G + eo + (on ? t : 0) * NX_ * NU_;
+#pragma unroll
+                for (int jc = 0; jc < NU_; ++jc) {
+                    const double gv = g[NX_ * jc];
+                    a0 += (on ? gv : 0.0) * xs[jb * NU_ + jc];
+                }
+            }
+        } else {
+            const double* g = G + eo + (k - 1) * nx() * nu();
+            for (int jb = 0; jb < k; ++jb)
+                for (int jc = 0; jc < nu(); ++jc) a0 += g[-jb * nx() * nu() + nx() * jc] * xs[jb * nu() + jc];
+        }
+        return Xbar[k * nx() + eo] + a0;
+    }
+
+    // E_row . X(xs) + G_row . xs at the current iterate
+    COPRA_DEV double lhs_now(const RowDesc& d, const double* xs) const
+    {
+        if (!P.rows_direct) return lhs(d, Xcur, xs);
+        double ax = (d.ek == kEOneHot) ? state_component(d.k, d.eo, xs) : 0.0;
+        if (d.gk == kGStep) {
+            for (int c = 0; c < nu(); ++c) ax += params()[d.go + c] * xs[d.k * nu() + c];
+        } else if (d.gk == kGFull) {
+            for (int j = 0; j < nvar(); ++j) ax += params()[d.go + j] * xs[j];
+        }
+        return ax;
+    }
+
     COPRA_DEV void begin_scan(const double* xs) const
     {
-        if (P.any_state_rows) refresh_trajectory(xs);
+        if (P.any_state_rows && !P.rows_direct) refresh_trajectory(xs);
         wave_sync();
     }
 
@@ -181,13 +220,13 @@ struct StageRows {
     COPRA_DEV double slack(int i, const double* xs) const
     {
         const RowDesc d = desc(i);
-        const double ax = lhs(d, Xcur, xs);
+        const double ax = lhs_now(d, xs);
         return (i < P.meq) ? (ax - d.f) : (d.f - ax);
     }
     COPRA_DEV double slack_uniform(int p, const double* xs) const
     {
         const RowDesc d = load_desc(uniform_i32(p));
-        const double ax = lhs(d, Xcur, xs);
+        const double ax = lhs_now(d, xs);
         return (p < P.meq) ? (ax - d.f) : (d.f - ax);
     }
 
@@ -294,7 +333,9 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
 
 // RP_ > 0: every cost term is padded to RP_ rows (zero M / N / p / w rows add exact zeros), so the inner products
 // over the cost rows unroll; RP_ == 0 uses the run-time row count of each term.
-template <int NX_, int NU_, int NH_, int RP_>
+// TRI_: factor-only layout (LdsLayout::tri; gi_core.hpp) -- the Hessian is built straight into the packed upper triangle
+// (each entry has ONE writer: the lanes of a diagonal block skip its lower half), plans without full-size costs only.
+template <int NX_, int NU_, int NH_, int RP_, bool TRI_ = false>
 COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
 {
     double* lds = lds_base();
@@ -411,7 +452,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         COPRA_FINE("costs:start");
         { // the J region starts 16-byte aligned (plan_builder.hpp: even offsets): clear two doubles per store
             f64x2* Q2 = reinterpret_cast<f64x2*>(Q);
-            const int n2 = (n * ld + 1) / 2;
+            const int n2 = TRI_ ? (n * (n + 1) / 2 + 1) / 2 : (n * ld + 1) / 2;
 #pragma unroll 8
             for (int e = lane; e < n2; e += kWave) Q2[e] = f64x2 { 0.0, 0.0 };
         }
@@ -420,7 +461,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         if (lane < n) {
             double one = 1.0;
             one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;
-            Q[lane * ld + lane] = one;
+            Q[fidx<TRI_>(lane, lane, ld)] = one;
         }
         double cj = 0.0; // lane j accumulates c_j
         double* Y = lds + L.BldY;
@@ -429,7 +470,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         const int blk = lane / nu, sub = lane - blk * nu; // lane as (block, component)
         for (int t = 0; t < P.ncost; ++t) {
             const CostTerm& ct = P.cost[t];
-            if constexpr (RP_ == 0) { // plans with full-size entries always run the generic instantiation (plan.hpp)
+            if constexpr (RP_ == 0 && !TRI_) { // plans with full-size entries always run the generic instantiation (plan.hpp)
                 if (ct.full) {
                     wave_sync();
                     full_size_cost_term<NX_, NU_, NH_>(P, ct, cost_reference(P, t, inst), G, Xbar, Q, ld, lds + L.BldFull, cj);
@@ -461,10 +502,10 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             if (ct.kind == kCostControl) {
                 // ControlCost::update (costFunctions.cpp:148-156): block-diagonal N'WN, c = -p'WN
                 if (lane < n) {
-                    for (int i2 = 0; i2 < nu; ++i2) {
+                    for (int i2 = 0; i2 < (TRI_ ? sub + 1 : nu); ++i2) {
                         double acc = 0.0;
                         for (int k = 0; k < r; ++k) acc += (Nm[k + r * i2] * w[k]) * Nm[k + r * sub];
-                        Q[(blk * nu + i2) * ld + lane] += acc;
+                        Q[fidx<TRI_>(blk * nu + i2, lane, ld)] += acc;
                     }
                     double acc = 0.0;
                     for (int k = 0; k < r; ++k) acc += ((-p[k]) * w[k]) * Nm[k + r * sub];
@@ -534,7 +575,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
 #pragma unroll
                             for (int k = 0; k < RP_; ++k) yb[jc][k] = Y[mb * RP_ * NU_ + RP_ * jc + k];
 #pragma unroll
-                        for (int jc = 0; jc < NU_; ++jc) qv[jc] = Q[(a * NU_ + ic) * ld + b * NU_ + jc];
+                        for (int jc = 0; jc < NU_; ++jc) qv[jc] = Q[fidx<TRI_>(a * NU_ + ic, b * NU_ + jc, ld)];
 #pragma unroll
                         for (int jc = 0; jc < NU_; ++jc) {
                             double pterm = 0.0;
@@ -542,7 +583,8 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                             for (int k = 0; k < RP_; ++k) pterm += ya[k] * yb[jc][k];
                             if (m < 0) pterm = 0.0;
                             val[jc] = accumulate ? val[jc] + pterm : pterm;
-                            Q[(a * NU_ + ic) * ld + b * NU_ + jc] = qv[jc] + (mixed ? val[jc] + cross[jc] : val[jc]);
+                            if (!TRI_ || delta > 0 || jc >= ic)
+                                Q[fidx<TRI_>(a * NU_ + ic, b * NU_ + jc, ld)] = qv[jc] + (mixed ? val[jc] + cross[jc] : val[jc]);
                         }
                     }
                 } else {
@@ -559,7 +601,8 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                                     for (int k = 0; k < r; ++k) pterm += (Ya[k] * w[k]) * Yb[k];
                                 }
                                 val[jc] = accumulate ? val[jc] + pterm : pterm;
-                                Q[(a * nu + ic) * ld + b * nu + jc] += mixed ? val[jc] + cross[jc] : val[jc];
+                                if (!TRI_ || delta > 0 || jc >= ic)
+                                    Q[fidx<TRI_>(a * nu + ic, b * nu + jc, ld)] += mixed ? val[jc] + cross[jc] : val[jc];
                             }
                         }
                     }
@@ -610,7 +653,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         if (inst == P.dump_instance && P.dumpQ) { // parity hook (LMPC::Q(), LMPC::c(); LMPC.h:113-115)
             if (lane < n) {
                 for (int i = 0; i < n; ++i) {
-                    const double v = (i <= lane) ? Q[i * ld + lane] : Q[lane * ld + i];
+                    const double v = (i <= lane) ? Q[fidx<TRI_>(i, lane, ld)] : Q[fidx<TRI_>(lane, i, ld)];
                     P.dumpQ[(size_t)lane * n + i] = v;
                 }
                 P.dumpc[lane] = cj;
@@ -632,8 +675,8 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     stamp[3] = cycle_counter();
     // ---- 4. + 5. solve ----
     stamp[4] = stamp[3];
-    int status = gi_factorize<NV>(S, n, &stamp[4] COPRA_FINE_PASS);
-    if (P.model_out) { // "prepare" launch of the shared-model fast path (lmpc_shared.hpp); runs with the full layout
+    int status = gi_factorize<NV, TRI_>(S, n, &stamp[4] COPRA_FINE_PASS);
+    if (!TRI_ && P.model_out) { // "prepare" launch of the shared-model fast path (lmpc_shared.hpp); runs with the full layout
         if (inst != P.dump_instance) return;
         if (status == 0) gi_invert<NV>(S, n);
         wave_sync();
@@ -657,7 +700,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+        status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     stamp[6] = cycle_counter();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else

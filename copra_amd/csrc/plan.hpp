@@ -70,6 +70,10 @@ struct LdsLayout {
     int Xbar; // free response  Phi x0 + xi               (fullXDim)
     int Xcur; // current trajectory Xbar + Psi U          (fullXDim)
     int J, ldj; // n x ldj: Hessian (upper) -> Cholesky factor -> J = R^-1 (row i at J + i*ldj)
+    int tri; // 1: factor-only layout (gi_core.hpp, TRI): J holds the PACKED upper triangle (entry (i, c), i <= c, at
+             // c (c + 1) / 2 + i) of the Hessian -> its Cholesky factor, J = R^-1 is never formed, Q1 holds the
+             // orthonormal basis of the active normals (rcap columns of 64), dv / the 4n coefficients do not exist
+    int Q1;
     int R; // packed upper-triangular R of the active set (rcap columns)
     int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one
     int xs, dv, zv, uv, ap, coef, cvec; // solver vectors (n; uv n+1; coef 4n)
@@ -169,6 +173,8 @@ struct FusedPlan {
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)
+    int rows_direct; // 1 if every state term is one component of one state (bounds on the trajectory): such a slack is
+                     // evaluated straight from G and the iterate, without refreshing the whole trajectory first
     int n_full_rows; // rows with a full-size entry (kEFull / kGFull), listed below; -1: more than kMaxFullRows
     int full_row[kMaxFullRows];
     const int* row_step; // [mgen]

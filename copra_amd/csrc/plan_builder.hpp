@@ -61,8 +61,11 @@ inline int align2(int v) { return (v + 1) & ~1; }
 //   compact == true : the preview-phase tables (A, B, d, x0, Phi, xi) borrow the not-yet-used J region, the cost-phase
 //                     tables (Y, We, cost parameters) borrow the not-yet-used solver vectors, and R gets whatever is
 //                     left of `budget` doubles (at least 1 column).  Returns false if even that does not fit.
+//   tri (with compact): factor-only layout (LdsLayout::tri) -- the packed triangle instead of the n x ldj square, no
+//                     dv / Givens coefficients, and rcap columns of Q1 (64 doubles each) next to R; the cost-phase
+//                     tables may run over Q1 / R as well (nothing of the active set exists yet).
 inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused, bool compact = false, int budget = 0, int rfull = 0)
+    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false)
 {
     int o = 0;
     auto take = [&](int count) {
@@ -71,7 +74,9 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
         return at;
     };
     L.ldj = (n % 2 == 0) ? n + 1 : n; // odd leading dimension: row-per-lane and column-per-lane reads conflict-free
-    const int sizeJ = align2(n * L.ldj);
+    const int sizeJ = tri ? align2(n * (n + 1) / 2) : align2(n * L.ldj);
+    L.tri = tri ? 1 : 0;
+    L.Q1 = 0;
     const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
     const int sizeFull = rfull > 0 ? align2(rfull) + 4 * kWave : 0;
     const int sizeCost
@@ -101,18 +106,18 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     // solver vectors (the cost tables alias them in the compact layout)
     const int vec0 = o;
     L.xs = take(n);
-    L.dv = take(n);
+    L.dv = tri ? L.xs : take(n);
     L.zv = L.dv; // (unused scratch name kept for the carve helper)
     L.uv = take(n + 2);
     L.ap = take(n);
     L.cvec = compact ? L.ap : take(n); // c is consumed by the factorisation before ap is first written
-    L.coef = take(4 * n);
+    L.coef = take(tri ? n : 4 * n);
     L.nb = take(mgen > 0 ? mgen : 1);
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
     L.act = take((mtotal + 1) / 2 + 1);
     L.iact = take((n + 2) / 2 + 1);
-    if (compact && sizeCost > o - vec0) take(sizeCost - (o - vec0));
+    if (compact && !tri && sizeCost > o - vec0) take(sizeCost - (o - vec0));
     int cost0 = vec0;
     if (fused && !compact) cost0 = take(sizeCost);
     if (fused) {
@@ -128,12 +133,15 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     int rcap = n;
     if (compact) {
         const int left = budget - o - 2;
+        const int per_col = tri ? kWave : 0;
         rcap = 0;
-        while (rcap < n && (rcap + 1) * (rcap + 2) / 2 <= left) ++rcap;
+        while (rcap < n && (rcap + 1) * per_col + (rcap + 1) * (rcap + 2) / 2 <= left) ++rcap;
         if (rcap < 1) return false;
     }
     L.rcap = rcap;
+    if (tri) L.Q1 = take(rcap * kWave);
     L.R = take(rcap * (rcap + 1) / 2 + 2);
+    if (tri && o < vec0 + sizeCost) o = vec0 + sizeCost;
     L.total = o;
     return true;
 }
@@ -252,6 +260,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     hp.ub.assign(U, DBL_MAX);
     int bound_line = 0;
     P.any_state_rows = 0;
+    P.rows_direct = 1;
     // validate + bounds
     for (int k = 0; k < n_cstrs; ++k) {
         const copra_cstr_desc_t& c = cstrs[k];
@@ -305,6 +314,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.row_goff.push_back(goff);
         hp.row_f.push_back(f);
         if (ekind != kENone) P.any_state_rows = 1;
+        if (ekind != kENone && ekind != kEOneHot) P.rows_direct = 0;
     };
     // row-major copy of one row of a column-major (rows x cols) matrix into the blob
     auto push_row = [&](const double* Mx, int rows, int cols, int r) {
@@ -544,6 +554,29 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     P.lds = c2;
                     break;
                 }
+            }
+        }
+        // Factor-only first tier (LdsLayout::tri): without the n x n inverse factor the instance is about half the
+        // size.  Taken when it lets more instances share a CU than the layout chosen so far and still leaves the
+        // active set `need` columns; the instances that outgrow them finish in the second tier as above.
+        const bool tri_wanted = std::getenv("COPRA_FORCE_TRI") || (rp > 0 && U > 32);
+        if (tri_wanted && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
+            const char* kenv = std::getenv("COPRA_TRI_K");
+            const int need = U < 5 ? U : 5;
+            for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
+                const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
+                if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
+                LdsLayout t {};
+                if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true)
+                    && t.total <= budget && t.rcap >= need) {
+                    hp.lds_safe = P.lds; // what the adaptive fall-back steps to
+                    hp.safe_two_tier = hp.two_tier;
+                    hp.two_tier = true;
+                    hp.dense = true;
+                    P.lds = t;
+                    break;
+                }
+                if (kenv) break;
             }
         }
         hp.lds_bytes = (size_t)P.lds.total * sizeof(double);

@@ -224,7 +224,11 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.from_list = 0;
     if (dump_instance >= 0) P.lds = hp.lds_full;
     auto body = [&](const FusedPlan& PP, int b) {
-        if (s6)
+        if (PP.lds.tri && s6) // (select_fused_kernel: the factor-only first tier)
+            lmpc_fused_body<6, 3, 20, 6, true>(PP, b);
+        else if (PP.lds.tri)
+            lmpc_fused_body<0, 0, 0, 0, true>(PP, b);
+        else if (s6)
             lmpc_fused_body<6, 3, 20, 6>(PP, b);
         else if (s2)
             lmpc_fused_body<2, 1, 10, 2>(PP, b);
@@ -264,6 +268,10 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     }
     if (hp.large) return (int)COPRA_ERR_UNSUPPORTED;
     point_plan_to_host(hp);
+    if (hp.plan.lds.tri) { // copra_batch_set_shared_system: the shared-model kernel needs the layout that holds J
+        hp.plan.lds = hp.lds_safe;
+        hp.lds_bytes = (size_t)hp.plan.lds.total * sizeof(double);
+    }
     FusedPlan P = hp.plan;
     const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X, np1 = nx + 1;
     const ModelLayout m = model_layout(nx, nu, N, n, X, hp.lds_full.ldj, P.mgen);
