@@ -889,11 +889,11 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     else
         snprintf(source, sizeof source,
             "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
-            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
+            "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_fused(const FusedPlan P)\n"
             "{ lmpc_fused_body<%d, %d, %d, %d, %s>(P, P.inst_offset + (int)blockIdx.x); }\n"
             "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
             "{ lmpc_shared_body<%d, %d, %d>(P, (int)blockIdx.x); }\n",
-            P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.nx, P.nu, P.N);
+            P.lds.tri ? ", 2" : "", P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.nx, P.nu, P.N);
     std::string obj;
     {
         const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);

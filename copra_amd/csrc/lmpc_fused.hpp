@@ -23,6 +23,13 @@
 
 #include "gi_core.hpp"
 
+#ifndef COPRA_CHAIN_GROUP
+#define COPRA_CHAIN_GROUP 2
+#endif
+#ifndef COPRA_GRAD_UNROLL
+#define COPRA_GRAD_UNROLL 4
+#endif
+
 namespace copra_hip {
 
 // reference vector p of cost term t for this instance: the controller-wide one from the parameter blob, or the
@@ -85,6 +92,20 @@ struct StageRows {
         lb_mine = bound_lb(j);
     }
     COPRA_DEV RowDesc desc(int i) const { return (i < kWave) ? mine : load_desc(i); }
+    // descriptor of a wave-uniform row: rows 0..63 sit in the registers of their lane (no trip to the plan tables)
+    COPRA_DEV RowDesc desc_uniform(int p) const
+    {
+        p = uniform_i32(p);
+        if (p >= kWave) return load_desc(p);
+        RowDesc d;
+        d.k = bcast_i32(mine.k, p);
+        d.ek = bcast_i32(mine.ek, p);
+        d.eo = bcast_i32(mine.eo, p);
+        d.gk = bcast_i32(mine.gk, p);
+        d.go = bcast_i32(mine.go, p);
+        d.f = bcast_f64(mine.f, p);
+        return d;
+    }
 
     // coefficient j of a row in the reference's orientation (row of Aeq / Aineq)
     COPRA_DEV double coeff(const RowDesc& d, int j) const
@@ -160,6 +181,13 @@ struct StageRows {
     // trajectory at the current iterate: Xcur = Xbar + Psi U  (Psi implicit)
     COPRA_DEV void refresh_trajectory(const double* xs) const
     {
+        if constexpr (NH_ > 0 && NU_ > 0 && NX_ > 0) { // (the same sums, unrolled: see state_component)
+            for (int row = lane_id(); row < xdim(); row += kWave) {
+                const int k = row / NX_, comp = row - k * NX_;
+                Xcur[row] = state_component(k, comp, xs);
+            }
+            return;
+        }
         for (int row = lane_id(); row < xdim(); row += kWave) {
             const int k = row / nx(), comp = row - k * nx();
             double a0 = 0.0;
@@ -225,7 +253,7 @@ struct StageRows {
     }
     COPRA_DEV double slack_uniform(int p, const double* xs) const
     {
-        const RowDesc d = load_desc(uniform_i32(p));
+        const RowDesc d = desc_uniform(p);
         const double ax = lhs_now(d, xs);
         return (p < P.meq) ? (ax - d.f) : (d.f - ax);
     }
@@ -237,8 +265,8 @@ struct StageRows {
     COPRA_DEV void load_normal(int p, double sgn, double* ap) const
     {
         const int j = lane_id();
+        const RowDesc d = desc_uniform(p); // (every lane takes part in the broadcast)
         if (j >= nvar()) return;
-        const RowDesc d = load_desc(uniform_i32(p));
         const double v = coeff(d, j);
         ap[j] = (p < P.meq) ? sgn * v : -v;
     }
@@ -450,7 +478,10 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     {
         double* Q = S.J;
         COPRA_FINE("costs:start");
-        { // the J region starts 16-byte aligned (plan_builder.hpp: even offsets): clear two doubles per store
+        // Compile-time shapes whose first cost is a per-step state cost: its block-diagonal walk below writes every
+        // entry of the upper triangle, so it stores 1e-6 I + Q_0 outright instead of clearing Q and adding to it.
+        const bool fresh0 = RP_ > 0 && NU_ > 0 && NH_ > 0 && P.ncost > 0 && P.cost[0].kind != kCostControl;
+        if (!fresh0) { // the J region starts 16-byte aligned (plan_builder.hpp: even offsets): clear two doubles per store
             f64x2* Q2 = reinterpret_cast<f64x2*>(Q);
             const int n2 = TRI_ ? (n * (n + 1) / 2 + 1) / 2 : (n * ld + 1) / 2;
 #pragma unroll 8
@@ -458,7 +489,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         }
         wave_sync();
         COPRA_FINE("costs:zeroed");
-        if (lane < n) {
+        if (lane < n && !fresh0) {
             double one = 1.0;
             one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;
             Q[fidx<TRI_>(lane, lane, ld)] = one;
@@ -558,7 +589,57 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                         }
                     }
                 }
-                if constexpr (RP_ > 0 && NU_ > 0) {
+                if constexpr (RP_ > 0 && NU_ > 0 && NH_ > 0) {
+                    // Compile-time shape: the walk runs in groups of four steps.  The products P_{m+delta,m} of a group
+                    // are formed first (no store in between, so the LDS reads of the group are issued back to back),
+                    // then the running sums are stored.  Every lane runs all NH_ steps; the ones past the end of its
+                    // diagonal are switched off.  Same additions in the same order as the step-by-step loop below.
+                    double wr[RP_];
+#pragma unroll
+                    for (int k = 0; k < RP_; ++k) wr[k] = w[k];
+                    const bool fresh = fresh0 && t == 0;
+                    const int last = NH_ - 1 - delta; // this lane's steps: i = N-1-b = 0 .. last
+                    const int shift = NH_ - K; // m = i - shift
+                    constexpr int CH = COPRA_CHAIN_GROUP;
+#pragma unroll
+                    for (int i0 = 0; i0 < NH_; i0 += CH) {
+                        double pt[CH][NU_], qv[CH][NU_];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int i = i0 + u;
+                            const int m = i - shift;
+                            const bool on = (i <= last) && (m >= 0);
+                            const int ma = on ? m + delta : 0, mb = on ? m : 0;
+                            double ya[RP_];
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) ya[k] = Y[ma * RP_ * NU_ + RP_ * ic + k] * wr[k];
+#pragma unroll
+                            for (int jc = 0; jc < NU_; ++jc) {
+                                double pterm = 0.0;
+#pragma unroll
+                                for (int k = 0; k < RP_; ++k) pterm += ya[k] * Y[mb * RP_ * NU_ + RP_ * jc + k];
+                                pt[u][jc] = on ? pterm : 0.0;
+                                const int b = (i <= last) ? NH_ - 1 - i : delta; // (an idle step re-reads the lane's last block)
+                                qv[u][jc] = fresh ? ((delta == 0 && jc == ic) ? 1e-6 : 0.0)
+                                                  : Q[fidx<TRI_>((b - delta) * NU_ + ic, b * NU_ + jc, ld)];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int i = i0 + u;
+                            if (i <= last) {
+                                const int b = NH_ - 1 - i, a = b - delta;
+#pragma unroll
+                                for (int jc = 0; jc < NU_; ++jc) {
+                                    val[jc] = accumulate ? val[jc] + pt[u][jc] : pt[u][jc];
+                                    if (!TRI_ || delta > 0 || jc >= ic)
+                                        Q[fidx<TRI_>(a * NU_ + ic, b * NU_ + jc, ld)]
+                                            = qv[u][jc] + (mixed ? val[jc] + cross[jc] : val[jc]);
+                                }
+                            }
+                        }
+                    }
+                } else if constexpr (RP_ > 0 && NU_ > 0) {
                     // compile-time rows: every operand of a step is loaded before the first FMA so the LDS reads batch
                     double wr[RP_];
 #pragma unroll
@@ -620,7 +701,24 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                         for (int k = 0; k < r; ++k) s0 += We[b * r + k] * Nm[k + r * jc];
                         acc += s0;
                     }
-                    if constexpr (RP_ > 0 && NU_ > 0) {
+                    if constexpr (RP_ > 0 && NU_ > 0 && NH_ > 0) {
+                        // every lane runs all steps (the ones outside b < s <= K add an exact zero): the loop unrolls
+#pragma unroll COPRA_GRAD_UNROLL
+                        for (int s = 1; s <= NH_; ++s) {
+                            const bool on = (s > b) && (s <= K);
+                            const int yi = on ? s - 1 - b : 0;
+                            double yv[RP_], wv[RP_];
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) {
+                                yv[k] = Y[yi * RP_ * NU_ + RP_ * jc + k];
+                                wv[k] = We[s * RP_ + k];
+                            }
+                            double sk = 0.0;
+#pragma unroll
+                            for (int k = 0; k < RP_; ++k) sk += wv[k] * yv[k];
+                            acc += on ? sk : 0.0;
+                        }
+                    } else if constexpr (RP_ > 0 && NU_ > 0) {
                         for (int s = b + 1; s <= K; ++s) {
                             double yv[RP_], wv[RP_];
 #pragma unroll

@@ -559,10 +559,12 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // Factor-only first tier (LdsLayout::tri): without the n x n inverse factor the instance is about half the
         // size.  Taken when it lets more instances share a CU than the layout chosen so far and still leaves the
         // active set `need` columns; the instances that outgrow them finish in the second tier as above.
-        const bool tri_wanted = std::getenv("COPRA_FORCE_TRI") || (rp > 0 && U > 32);
-        if (tri_wanted && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
+        // Measured (M solves/s, square layout -> factor-only): headline shape 13.4 -> 21.3; run-time shapes with 45
+        // variables 10.0 -> 19.0, 48: 10.1 -> 13.9, 64: 4.1 -> 9.8.  Up to 32 variables the packed kernels and the dense
+        // square layouts already fill the wave slots, so those shapes stay as they are.
+        if (U > 32 && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
-            const int need = U < 5 ? U : 5;
+            const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen

@@ -50,6 +50,7 @@ COPRA_DEV double bcast_f64(double v, int src)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+COPRA_DEV int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 // 1/sqrt(x): v_rsq_f64 seed + two Newton steps (full double precision to ~1 ulp, no divide)
 COPRA_DEV double fast_rsqrt(double x)
 {

@@ -187,6 +187,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[3] = (int)hp.lds_bytes;
         sizes[4] = 0;
         sizes[5] = P.lds.rcap;
+        sizes[6] = P.lds.tri;
     }
     if (!A) return 0; // size query only
     if (P.use_large) { // workgroup-per-instance kernel: one resident workgroup walks the batch (persistent grid)

@@ -51,6 +51,30 @@ def test_config3_com_preview(emu, oracle, specialised, vmax, umax):
     _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], specialised)
 
 
+@pytest.mark.parametrize("case", ["bounded", "ineq", "mixed", "eq", "nine", "com15", "di48"])
+def test_factor_only_layout(emu, oracle, case):
+    """More than 32 decision variables: the first tier keeps only the packed Cholesky factor in LDS and runs the active
+    set on R^-T N = Q1 Rq (gi_core.hpp, TRI); same statuses, iterates and iteration counts as the oracle, with
+    equality rows, every cost / constraint class, and instances that overflow into the square-layout second tier"""
+    import fixtures as F
+    from copra_amd import workloads
+    if case == "nine":
+        pb = F.nine_class_problem(44)
+    elif case == "com15":
+        wl = workloads.com_preview(12, N=15, v_max=0.2, u_max=1.0, seed=3)
+        pb = dict(wl, x0=wl["x0"])
+    elif case == "di48":
+        wl = workloads.double_integrator(8, N=48)
+        pb = dict(wl)
+    else:
+        pb = getattr(F, case + "_system")("trajectory" if case != "eq" else "target", N=50)
+    re, ro = _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"],
+                      specialised=False)
+    assert re["factor_only"] and re["rcap"] < 40
+    if case == "com15":
+        assert re["overflowed"] > 0 and ro["iter"][:, 0].max() > re["rcap"] + 1  # the second tier finished some
+
+
 def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
     """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
     from copra_amd import workloads
