@@ -189,7 +189,7 @@ def main():
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
                 ctr = json.load(open(prof))["counters"]
-                kname = [k for k in ctr if "copra_lmpc_fused_kernel" in k][0]
+                kname = [k for k in ctr if "copra_lmpc_fused_tri_kernel" in k][0]
                 traffic = 1024.0 * (ctr[kname]["FETCH_SIZE"]["mean_per_launch"] + ctr[kname]["WRITE_SIZE"]["mean_per_launch"])
                 traffic_src = "profiles/r01/headline_rocprof_summary_final.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             except Exception:
@@ -224,7 +224,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
-                         "kernel": "copra_lmpc_fused_kernel", "algorithmic_bytes_per_solve": alg_bytes,
+                         "kernel": "copra_lmpc_fused_tri_kernel", "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "
                                  "construction",
                          "fp64_model_tflops": flops * batch / kern / 1e12, "fp64_peak_tflops": FP64_PEAK_TFLOPS},
