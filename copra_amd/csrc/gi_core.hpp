@@ -104,6 +104,62 @@ COPRA_DEV int fidx(int i, int j, int ld)
     return TRI ? rcol(j) + i : i * ld + j;
 }
 
+// Two-level left-looking Cholesky: before the first 4-row panel of every 16-row super-panel, rows [k0, k0+16) x
+// columns [k0, n) of the Hessian receive the contribution of ALL finished rows 0..k0-1 at once,
+//     H(k0+i, c) -= sum_{t<k0} R(t, k0+i) R(t, c),
+// as 16x16x4 FP64 matrix-core products: per four rows t one lane-private LDS read feeds the A operand and one per column
+// tile the B operand -- no wave-uniform (broadcast) reads at all, which is what the one-level loop spends its time on
+// (5 LDS reads per 4 FMAs; 105 of its 4-row blocks at n = 60 become 24, plus 40 MFMAs).  The panels of the super-panel
+// then only sweep the rows of their own super-panel.  (MI355X: the FP64 MFMA rate equals the VALU FMA rate; the gain
+// is the operand traffic, not the arithmetic.)
+#ifndef COPRA_CHOL_SUPER
+#define COPRA_CHOL_SUPER 1
+#endif
+template <int NV, bool TRI>
+COPRA_DEV void chol_super_update(double* J, int n, int ld, int k0)
+{
+    const int lane = lane_id();
+    const int kk = lane >> 4, col = lane & 15;
+    const int ra = k0 + col; // the row of the super-panel this lane feeds into the A operand
+    const int rac = (ra < n) ? ra : n - 1;
+    const int tile0 = k0 >> 4;
+    constexpr int kMaxTiles = 3; // k0 >= 16 and n <= 64: at most the column tiles 1..3
+    const int ntile = ((n + 15) >> 4) - tile0;
+    mfma_acc acc[kMaxTiles];
+#pragma unroll
+    for (int c = 0; c < kMaxTiles; ++c) acc[c].v[0] = acc[c].v[1] = acc[c].v[2] = acc[c].v[3] = 0.0;
+    int cb[kMaxTiles];
+    bool cin[kMaxTiles];
+#pragma unroll
+    for (int c = 0; c < kMaxTiles; ++c) {
+        const int cc = 16 * (tile0 + c) + col;
+        cin[c] = (c < ntile) && (cc < n);
+        cb[c] = cin[c] ? cc : n - 1;
+    }
+    for (int t0 = 0; t0 < k0; t0 += 4) {
+        double a = J[fidx<TRI>(t0 + kk, rac, ld)];
+        if (ra >= n) a = 0.0;
+        double b[kMaxTiles];
+#pragma unroll
+        for (int c = 0; c < kMaxTiles; ++c) {
+            b[c] = J[fidx<TRI>(t0 + kk, cb[c], ld)];
+            if (!cin[c]) b[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxTiles; ++c)
+            if (c < ntile) mfma_f64_16x16x4(a, b[c], acc[c]); // (ntile is wave-uniform)
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxTiles; ++c) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = k0 + kk + 4 * reg, cc = 16 * (tile0 + c) + col;
+            if (c < ntile && i < n && cc < n && cc >= i) J[fidx<TRI>(i, cc, ld)] -= acc[c].v[reg];
+        }
+    }
+    wave_sync();
+}
+
 template <int NV, bool TRI = false>
 COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA_FINE_ARGS)
 {
@@ -118,11 +174,18 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 #pragma unroll 1
     for (int k0 = 0; k0 < n; k0 += 4) {
         const int pw = (n - k0 < 4) ? n - k0 : 4;
+        int tfirst = 0;
+        if constexpr (COPRA_CHOL_SUPER && kWave == 64) { // (the packed builds have no 64-lane matrix-core operand)
+            if (n > 16) {
+                tfirst = k0 & ~15;
+                if (k0 > 0 && k0 == tfirst) chol_super_update<NV, TRI>(J, n, ld, k0);
+            }
+        }
         double acc[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[p] = (p < pw) ? J[fidx<TRI>(k0 + p, lj, ld)] : 0.0;
 #pragma unroll 2
-        for (int t = 0; t < k0; t += 4) { // k0 is a multiple of 4: no remainder
+        for (int t = tfirst; t < k0; t += 4) { // k0 is a multiple of 4: no remainder
             double rt[4], bb[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
