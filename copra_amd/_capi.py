@@ -198,6 +198,8 @@ def lib():
         L.copra_batch_lanes_per_instance.argtypes = [vp]
         L.copra_batch_specialise.restype = C.c_int
         L.copra_batch_specialise.argtypes = [vp, C.c_char_p]
+        L.copra_batch_layout_info.restype = C.c_int
+        L.copra_batch_layout_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         L.copra_qp_dense_specialise.restype = C.c_int
         L.copra_qp_dense_specialise.argtypes = [C.c_int, C.c_char_p]
         L.copra_plan_check.restype = C.c_int

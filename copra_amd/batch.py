@@ -57,6 +57,12 @@ class BatchLMPC:
         """compile this controller's shape into its own kernels (hipcc --genco, cached); see copra_batch_specialise"""
         _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
 
+    def layout_info(self):
+        """dict(lds_bytes, active_capacity, factor_only, two_tier) of the next solve (copra_batch_layout_info)"""
+        v = [C.c_int() for _ in range(4)]
+        _capi.check(self._lib.copra_batch_layout_info(self._h, *[C.byref(x) for x in v]))
+        return dict(lds_bytes=v[0].value, active_capacity=v[1].value, factor_only=bool(v[2].value), two_tier=bool(v[3].value))
+
     def lanes_per_instance(self):
         """16 / 32: several small problems per wavefront; 64: one wavefront each; > 64: one workgroup each"""
         return int(self._lib.copra_batch_lanes_per_instance(self._h))

@@ -332,6 +332,17 @@ static copra_status_t adapt_layout(copra_batch* h)
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&count, h->d_ovf_count, sizeof(int), hipMemcpyDeviceToHost));
     if ((long long)count * 8 <= (long long)h->hp.plan.batch) return COPRA_OK;
+    LdsLayout roomier {};
+    if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) { // factor-only: one instance per CU fewer, more columns
+        h->hp.plan.lds = roomier;
+        h->hp.lds_bytes = (size_t)roomier.total * sizeof(double);
+        h->lds_attr_set = false;
+        h->adapt_left += 1; // (a step down the ladder does not use up the budget of attempts)
+        if (std::getenv("COPRA_DEBUG"))
+            fprintf(stderr, "[copra] %d of %d instances overflowed the factor-only layout: next %zu B, %d columns\n", count,
+                h->hp.plan.batch, h->hp.lds_bytes, roomier.rcap);
+        return COPRA_OK;
+    }
     if (h->hp.dense && h->hp.safe_two_tier) { // dense -> quarter-CU compact
         h->hp.plan.lds = h->hp.lds_safe;
         h->hp.two_tier = true;
@@ -945,6 +956,17 @@ copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double
     h->ext_traj = trajectory;
     h->ext_status = status;
     h->ext_iter = iter;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_layout_info(const copra_batch_t* h, int* lds_bytes, int* active_capacity, int* factor_only,
+    int* two_tier)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_layout_info: null handle");
+    if (lds_bytes) *lds_bytes = (int)h->hp.lds_bytes;
+    if (active_capacity) *active_capacity = h->hp.large ? h->hp.plan.n : h->hp.plan.lds.rcap;
+    if (factor_only) *factor_only = h->hp.large ? 0 : h->hp.plan.lds.tri;
+    if (two_tier) *two_tier = h->hp.two_tier ? 1 : 0;
     return COPRA_OK;
 }
 

@@ -60,7 +60,8 @@ struct SolverLds {
     double* R; // packed upper triangular: R(i,c) at R[c(c+1)/2 + i]
     int rcap; // columns R has room for (LdsLayout::rcap)
     double *xs, *dv, *zv, *uv, *ap, *coef, *cvec, *eqsgn, *scal;
-    int *act, *iact;
+    unsigned char* act; // one flag per row
+    int* iact;
     const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr)
 };
 
@@ -82,7 +83,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.cvec = lds + L.cvec;
     S.eqsgn = lds + L.eqsgn;
     S.scal = lds + L.scal;
-    S.act = reinterpret_cast<int*>(lds + L.act);
+    S.act = reinterpret_cast<unsigned char*>(lds + L.act);
     S.iact = reinterpret_cast<int*>(lds + L.iact);
     return S;
 }
@@ -149,12 +150,23 @@ COPRA_DEV void chol_super_update(double* J, int n, int ld, int k0)
         for (int c = 0; c < kMaxTiles; ++c)
             if (c < ntile) mfma_f64_16x16x4(a, b[c], acc[c]); // (ntile is wave-uniform)
     }
+    // every entry has one owner: all reads first, then all writes (the LDS reads batch)
+    double h[kMaxTiles][4];
 #pragma unroll
     for (int c = 0; c < kMaxTiles; ++c) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int i = k0 + kk + 4 * reg, cc = 16 * (tile0 + c) + col;
-            if (c < ntile && i < n && cc < n && cc >= i) J[fidx<TRI>(i, cc, ld)] -= acc[c].v[reg];
+            const bool mine = c < ntile && i < n && cc < n && cc >= i;
+            h[c][reg] = J[fidx<TRI>(mine ? i : 0, mine ? cc : 0, ld)];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxTiles; ++c) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = k0 + kk + 4 * reg, cc = 16 * (tile0 + c) + col;
+            if (c < ntile && i < n && cc < n && cc >= i) J[fidx<TRI>(i, cc, ld)] = h[c][reg] - acc[c].v[reg];
         }
     }
     wave_sync();
@@ -378,7 +390,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     iter_drop = 0;
     for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;
     for (int i = lane; i < meq; i += kWave) S.eqsgn[i] = 1.0;
-    for (int i = lane; i <= n + 1; i += kWave) S.uv[i] = 0.0;
+    for (int i = lane; i <= S.rcap + 1 && i <= n + 1; i += kWave) S.uv[i] = 0.0;
     // rows [I; -I] with right-hand sides [XU; -XL] (QuadProgSolver.cpp:61-69): lane j keeps XU_j, XL_j
     const double ubj = rows.ub(lj), lbj = rows.lb(lj);
     wave_sync();

@@ -80,7 +80,7 @@ struct LdsLayout {
     int nb; // norms of the general rows (m_gen)
     int eqsgn; // current orientation of each equality row (meq)
     int scal; // 8 scalars
-    int act; // int[m_total] active flags   (offset in doubles; cast to int*)
+    int act; // unsigned char[m_total] active flags   (offset in doubles)
     int iact; // int[n+1]
     // build-phase scratch (aliases R and beyond; sized on the host)
     int BldPhi; // (N+1) blocks nx x nx

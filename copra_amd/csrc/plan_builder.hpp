@@ -64,8 +64,10 @@ inline int align2(int v) { return (v + 1) & ~1; }
 //   tri (with compact): factor-only layout (LdsLayout::tri) -- the packed triangle instead of the n x ldj square, no
 //                     dv / Givens coefficients, and rcap columns of Q1 (64 doubles each) next to R; the cost-phase
 //                     tables may run over Q1 / R as well (nothing of the active set exists yet).
+//   xcur_late (with tri): the plan never reads the trajectory during the active-set loop (FusedPlan::rows_direct), so
+//                     the trajectory written at the very end takes the place of the then dead factor.
 inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false)
+    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false, bool xcur_late = false)
 {
     int o = 0;
     auto take = [&](int count) {
@@ -84,11 +86,12 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     if (fused) {
         L.G = take(N * nx * nu);
         L.Xbar = take(X);
-        L.Xcur = take(X);
+        L.Xcur = (tri && xcur_late) ? -1 : take(X);
     } else {
         L.G = L.Xbar = L.Xcur = 0;
     }
     L.J = take(sizeJ > 0 ? sizeJ : 2);
+    if (L.Xcur < 0) L.Xcur = L.J;
     if (compact && sizePrev > sizeJ) take(sizePrev - sizeJ); // (never for the shapes of interest)
     int prev0 = L.J; // preview tables alias J in the compact layout
     if (fused && !compact) prev0 = take(sizePrev);
@@ -108,15 +111,15 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     L.xs = take(n);
     L.dv = tri ? L.xs : take(n);
     L.zv = L.dv; // (unused scratch name kept for the carve helper)
-    L.uv = take(n + 2);
+    if (!compact) L.uv = take(n + 2); // (compact: sized by rcap, below)
     L.ap = take(n);
     L.cvec = compact ? L.ap : take(n); // c is consumed by the factorisation before ap is first written
     L.coef = take(tri ? n : 4 * n);
     L.nb = take(mgen > 0 ? mgen : 1);
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
-    L.act = take((mtotal + 1) / 2 + 1);
-    L.iact = take((n + 2) / 2 + 1);
+    L.act = take((mtotal + 7) / 8 + 1); // one byte per row
+    if (!compact) L.iact = take((n + 2) / 2 + 1);
     if (compact && !tri && sizeCost > o - vec0) take(sizeCost - (o - vec0));
     int cost0 = vec0;
     if (fused && !compact) cost0 = take(sizeCost);
@@ -134,9 +137,13 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     if (compact) {
         const int left = budget - o - 2;
         const int per_col = tri ? kWave : 0;
+        // a column of R, its multiplier (uv), its row index (iact) and, factor-only, its column of Q1
+        auto need = [&](int r) { return r * per_col + r * (r + 1) / 2 + align2(r + 2) + align2((r + 2) / 2 + 1); };
         rcap = 0;
-        while (rcap < n && (rcap + 1) * per_col + (rcap + 1) * (rcap + 2) / 2 <= left) ++rcap;
+        while (rcap < n && need(rcap + 1) <= left) ++rcap;
         if (rcap < 1) return false;
+        L.uv = take(rcap + 2);
+        L.iact = take((rcap + 2) / 2 + 1);
     }
     L.rcap = rcap;
     if (tri) L.Q1 = take(rcap * kWave);
@@ -144,6 +151,26 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     if (tri && o < vec0 + sizeCost) o = vec0 + sizeCost;
     L.total = o;
     return true;
+}
+
+// Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
+// instance per CU fewer (at least four) and more room for active constraints; false when there is none.
+inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
+{
+    if (!cur.tri) return false;
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
+    const int rows = rp > P.rmax ? rp : P.rmax;
+    const int kcur = (160 * 1024) / (cur.total * (int)sizeof(double));
+    for (int k = kcur - 1; k >= 4; --k) {
+        const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
+        LdsLayout t {};
+        if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
+            && t.total <= budget && t.rcap > cur.rcap) {
+            out = t;
+            return true;
+        }
+    }
+    return false;
 }
 
 inline bool is_neg_inf(double v) { return std::isinf(v) && v < 0; }
@@ -564,12 +591,12 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // square layouts already fill the wave slots, so those shapes stay as they are.
         if (U > 32 && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
-            const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
+            const int need = rp > 0 ? 4 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
-                if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true)
+                if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
                     && t.total <= budget && t.rcap >= need) {
                     hp.lds_safe = P.lds; // what the adaptive fall-back steps to
                     hp.safe_two_tier = hp.two_tier;

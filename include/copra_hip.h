@@ -203,6 +203,13 @@ copra_status_t copra_batch_qp_sizes(const copra_batch_t* h, int* nvar, int* neq,
 copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, double* c, double* Aeq, double* beq,
     double* Aineq, double* bineq, double* lb, double* ub);
 
+/* ---- how the next copra_batch_solve maps instances to the GPU (no reference counterpart; for tests and tuning):
+ *      LDS bytes per instance of the first launch, number of active constraints that launch has room for (instances
+ *      that need more finish in a second launch), 1 if it keeps only the Cholesky factor (no inverse factor),
+ *      1 if a second launch exists.  The first solves of a controller may step to a roomier layout. ---- */
+copra_status_t copra_batch_layout_info(const copra_batch_t* h, int* lds_bytes, int* active_capacity, int* factor_only,
+    int* two_tier);
+
 /* ---- timing contract of LMPC::solveTime()/solveAndBuildTime() (src/LMPC.cpp:82-99, 108-116): device time of the
  *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch. ---- */
 copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds);

@@ -260,6 +260,33 @@ def test_two_tier_overflow_on_gpu(oracle):
     assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
 
 
+def test_factor_only_layout_steps_down_its_ladder(oracle):
+    """headline shape, tighter bounds: the seven-per-CU factor-only layout has room for four active constraints, half of
+    the instances need more; after the first solves the controller takes a roomier factor-only layout.  Every solve --
+    before, while and after stepping -- agrees with the CPU path."""
+    from copra_amd import BatchLMPC, workloads
+    b = 2048
+    wl = workloads.com_preview(b, v_max=0.25, u_max=1.2, seed=7)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    assert ok.sum() > b // 2 and (ref["iter"][:, 0] > 6).sum() > b // 8
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    first = eng.layout_info()
+    assert first["factor_only"] and first["two_tier"] and first["active_capacity"] <= 5
+    seen = [first["active_capacity"]]
+    for _ in range(6):
+        eng.solve()
+        res = eng.results()
+        assert (res["status"] == ref["status"]).all()
+        assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
+        assert (res["iter"][ok] == ref["iter"][ok]).all()
+        seen.append(eng.layout_info()["active_capacity"])
+    last = eng.layout_info()
+    assert last["factor_only"] and last["active_capacity"] > first["active_capacity"] and last["lds_bytes"] > first["lds_bytes"]
+    assert seen == sorted(seen)
+
+
 def test_full_size_cost_entries_mfma_contraction(oracle):
     """Full-size cost entries (costFunctions.cpp:65-71,141-146,197-203) run the dense Psi' W Psi contraction on
     v_mfma_f64_16x16x4_f64: (a) all nine classes with autoSpan'ed full-size entries (TestLMPC_InitialState.cpp,
