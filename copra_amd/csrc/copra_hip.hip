@@ -76,6 +76,11 @@ __global__ __launch_bounds__(64) void copra_lmpc_shared_kernel(const FusedPlan P
     lmpc_shared_body<NX, NU, NH>(P, (int)blockIdx.x);
 }
 template <int NX, int NU, int NH>
+__global__ __launch_bounds__(64, 2) void copra_lmpc_shared_tri_kernel(const FusedPlan P) // factor-only first tier
+{
+    lmpc_shared_body<NX, NU, NH, true>(P, (int)blockIdx.x);
+}
+template <int NX, int NU, int NH>
 __global__ __launch_bounds__(64) void copra_lmpc_shared_tier2_kernel(const FusedPlan P)
 {
     const int count = *P.ovf_count;
@@ -99,6 +104,10 @@ namespace {
 using fused_kernel_t = void (*)(const FusedPlan);
 fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
 {
+    if (P.lds.tri && !tier2) {
+        if (P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_shared_tri_kernel<6, 3, 20>;
+        return copra_lmpc_shared_tri_kernel<0, 0, 0>;
+    }
     if (P.nx == 6 && P.nu == 3 && P.N == 20)
         return tier2 ? copra_lmpc_shared_tier2_kernel<6, 3, 20> : copra_lmpc_shared_kernel<6, 3, 20>;
     if (P.nx == 2 && P.nu == 1 && P.N == 10)
@@ -591,14 +600,6 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shA.data(), A, nA * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shB.data(), B, nB * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
-    if (h->hp.plan.lds.tri) { // the shared-model kernel works on the batch-wide J = R^-1: back to the layout that holds it
-        h->hp.plan.lds = h->hp.lds_safe;
-        h->hp.two_tier = h->hp.safe_two_tier;
-        h->hp.dense = false;
-        h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
-        h->lds_attr_set = false;
-        h->shared_attr_set = false;
-    }
     h->shared = true;
     h->model_dirty = true;
     return COPRA_OK;
@@ -902,9 +903,10 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
             "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
             "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_fused(const FusedPlan P)\n"
             "{ lmpc_fused_body<%d, %d, %d, %d, %s>(P, P.inst_offset + (int)blockIdx.x); }\n"
-            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
-            "{ lmpc_shared_body<%d, %d, %d>(P, (int)blockIdx.x); }\n",
-            P.lds.tri ? ", 2" : "", P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.nx, P.nu, P.N);
+            "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_shared(const FusedPlan P)\n"
+            "{ lmpc_shared_body<%d, %d, %d, %s>(P, (int)blockIdx.x); }\n",
+            P.lds.tri ? ", 2" : "", P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.lds.tri ? ", 2" : "", P.nx, P.nu,
+            P.N, P.lds.tri ? "true" : "false");
     std::string obj;
     {
         const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);
@@ -1002,7 +1004,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-        if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64)) {
+        if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
             FusedPlan Pj = P;
             void* args[] = { &Pj };
             const unsigned per = 64u / (unsigned)h->jit_lanes;

@@ -62,7 +62,9 @@ struct SolverLds {
     double *xs, *dv, *zv, *uv, *ap, *coef, *cvec, *eqsgn, *scal;
     unsigned char* act; // one flag per row
     int* iact;
-    const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr)
+    const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr);
+                        // factor-only layout: the packed factor R instead, and ...
+    const double* rinv_src; // ... 1 / R(i,i)
 };
 
 COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
@@ -70,6 +72,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     SolverLds S;
     S.J = lds + L.J;
     S.Jsrc = nullptr;
+    S.rinv_src = nullptr;
     S.ldj = L.ldj;
     S.Q1 = lds + L.Q1;
     S.R = lds + L.R;
@@ -447,6 +450,13 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
         if (nvl < 0) return 0; // optimal
+        if (TRI && !have_J && S.Jsrc) { // shared model, factor-only: the batch-wide factor comes into LDS on first need
+            wave_sync();
+            for (int e = lane; e < n * (n + 1) / 2; e += kWave) S.J[e] = S.Jsrc[e];
+            if (lane < n) S.coef[lane] = S.rinv_src[lane];
+            have_J = true;
+            wave_sync();
+        }
         if (!TRI && !have_J) { // first violated constraint: only now is J = R^-1 needed
             if (S.Jsrc) { // shared model: the batch-wide J is in HBM / L2, take a private copy (the updates rotate it)
                 wave_sync();

@@ -776,10 +776,15 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     int status = gi_factorize<NV, TRI_>(S, n, &stamp[4] COPRA_FINE_PASS);
     if (!TRI_ && P.model_out) { // "prepare" launch of the shared-model fast path (lmpc_shared.hpp); runs with the full layout
         if (inst != P.dump_instance) return;
-        if (status == 0) gi_invert<NV>(S, n);
-        wave_sync();
         const ModelLayout m = model_layout(nx, nu, N, n, X, ld, P.mgen);
         double* out = P.model_out;
+        if (lane < n) { // the factor as the factor-only tier wants it: packed columns, and the reciprocal pivots
+            for (int i = 0; i <= lane; ++i) out[m.Rtri + rcol(lane) + i] = S.J[i * ld + lane];
+            out[m.rinv + lane] = S.coef[lane];
+        }
+        wave_sync();
+        if (status == 0) gi_invert<NV>(S, n);
+        wave_sync();
         if (lane == 0) out[m.status] = (double)status;
         for (int e = lane; e < n * ld; e += kWave) out[m.J + e] = S.J[e];
         if (lane < n) { // Qinv(i, lane) = sum_{k >= max(i, lane)} J(i, k) J(lane, k)   (J upper triangular)

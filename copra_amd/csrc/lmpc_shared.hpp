@@ -16,7 +16,9 @@
 
 namespace copra_hip {
 
-template <int NX_, int NU_, int NH_>
+// TRI_: factor-only first tier (LdsLayout::tri) -- the instance never owns an n x n matrix: the batch-wide Cholesky
+// factor is copied (packed, half the size of J) on first need and stays read-only; Q1 / Rq carry the active set.
+template <int NX_, int NU_, int NH_, bool TRI_ = false>
 COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
 {
     double* lds = lds_base();
@@ -44,7 +46,8 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
     double x0r[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x0r[c] = (c < nx) ? x0[c] : 0.0;
-    S.Jsrc = M + m.J; // copied into LDS only if a constraint turns out to be violated (gi_active_set)
+    S.Jsrc = TRI_ ? M + m.Rtri : M + m.J; // copied into LDS only if a constraint turns out to be violated (gi_active_set)
+    S.rinv_src = M + m.rinv;
     for (int e = lane; e < N * nx * nu; e += kWave) G[e] = M[m.G + e];
     for (int e = lane; e < P.mgen; e += kWave) nb[e] = M[m.nb + e];
     for (int row = lane; row < X; row += kWave) { // free response  xbar = Phi x0 + xi
@@ -88,7 +91,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
     }
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+        status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch
         if (lane == 0) {

@@ -229,6 +229,7 @@ struct FusedPlan {
     //   model     != nullptr : lmpc_shared_body reads them (+ c0, C1: c = c0 + C1 x0) instead of rebuilding
     // layout (doubles): status | J [n * ldj] | G [N nx nu] | Phi [(N+1) nx nx] | xi [X] | nb [mgen] | c0 [n] | C1 [n x nx]
     //                   | Qinv [n * ldj] (= J J', symmetric: the unconstrained minimiser is -Qinv c without touching J)
+    //                   | Rtri [n (n + 1) / 2], rinv [n] : the packed Cholesky factor and 1 / R(i,i) (factor-only tier)
     //                   | C2 [n x R] : dc/dp of the costs that have per-instance references (model_ref_off[t] = first
     //                     column of cost t, -1 = controller-wide reference already folded into c0)
     int model_ref_off[kMaxCosts];
@@ -245,7 +246,7 @@ struct FusedPlan {
 
 // offsets (doubles) into the shared-model buffer, see FusedPlan::model
 struct ModelLayout {
-    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, C2, total; // (C2 has no fixed size: it ends the buffer)
+    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, Rtri, rinv, C2, total; // (C2 has no fixed size: it ends the buffer)
 };
 #ifdef __HIPCC__
 #define COPRA_HOST_DEVICE __host__ __device__
@@ -268,6 +269,8 @@ COPRA_HOST_DEVICE inline ModelLayout model_layout(int nx, int nu, int N, int n, 
     COPRA_TAKE(c0, n);
     COPRA_TAKE(C1, (long long)n * nx);
     COPRA_TAKE(Qinv, (long long)n * ldj);
+    COPRA_TAKE(Rtri, (long long)n * (n + 1) / 2); // the Cholesky factor itself, packed (factor-only first tier)
+    COPRA_TAKE(rinv, n); // 1 / R(i, i)
     m.C2 = o;
 #undef COPRA_TAKE
     m.total = o;

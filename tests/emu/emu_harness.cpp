@@ -269,10 +269,6 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     }
     if (hp.large) return (int)COPRA_ERR_UNSUPPORTED;
     point_plan_to_host(hp);
-    if (hp.plan.lds.tri) { // copra_batch_set_shared_system: the shared-model kernel needs the layout that holds J
-        hp.plan.lds = hp.lds_safe;
-        hp.lds_bytes = (size_t)hp.plan.lds.total * sizeof(double);
-    }
     FusedPlan P = hp.plan;
     const int nx = P.nx, nu = P.nu, N = P.N, n = P.n, X = P.X, np1 = nx + 1;
     const ModelLayout m = model_layout(nx, nu, N, n, X, hp.lds_full.ldj, P.mgen);
@@ -325,7 +321,11 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     P.model = model.data();
     P.x0 = x0;
     auto shared = [&](const FusedPlan& PP, int b) {
-        if (PP.nx == 6 && PP.nu == 3 && PP.N == 20)
+        if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
+            lmpc_shared_body<6, 3, 20, true>(PP, b);
+        else if (PP.lds.tri)
+            lmpc_shared_body<0, 0, 0, true>(PP, b);
+        else if (PP.nx == 6 && PP.nu == 3 && PP.N == 20)
             lmpc_shared_body<6, 3, 20>(PP, b);
         else if (PP.nx == 2 && PP.nu == 1 && PP.N == 10)
             lmpc_shared_body<2, 1, 10>(PP, b);

@@ -296,6 +296,13 @@ def test_shared_model_fast_path(emu, oracle):
         ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
         assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
         assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+    wl = workloads.com_preview(8, N=15, v_max=0.2, u_max=1.0, seed=3)  # 45 variables: factor-only tier, run-time shape
+    A, B, d = wl["A"][1], wl["B"][1], wl["d"][1]
+    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    for k in range(8):
+        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        assert re["status"][k] == ro["status"] and (ro["status"] != 0 or tuple(re["iter"][k]) == tuple(ro["iter"]))
+        assert ro["status"] != 0 or _rel(re["control"][k], ro["control"]) <= RTOL
     pb = F.mixed_system("mixed", N=12)
     x0 = np.tile(pb["x0"], (4, 1))
     x0[:, 1] += np.linspace(-0.5, 0.5, 4)
