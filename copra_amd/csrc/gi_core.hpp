@@ -56,6 +56,7 @@ struct alignas(16) f64x2 { // one 16-byte LDS access
 struct SolverLds {
     double* J;
     int ldj;
+    // (factor-only layout: coef does not exist, 1 / R(i,i) sits on the diagonal of the packed factor)
     double* Q1; // factor-only layout: column k of the orthonormal basis of R^-T N at Q1[64 k + lane] (else unused)
     double* R; // packed upper triangular: R(i,c) at R[c(c+1)/2 + i]
     int rcap; // columns R has room for (LdsLayout::rcap)
@@ -244,8 +245,9 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
 #pragma unroll
             for (int t = 0; t < p; ++t) v -= Rd[t][p] * rp[t];
             rp[p] = v * ri[p]; // R(k0+p, lane); the diagonal lane gets sqrt(pivot)
-            if (p < pw && lane >= k0 + p && lane < n) J[fidx<TRI>(k0 + p, lane, ld)] = rp[p];
-            if (p < pw && lane == 0) rinvd[k0 + p] = ri[p];
+            // (factor-only layout: nothing ever reads the diagonal of R itself, so its slot carries 1 / R(i,i))
+            if (p < pw && lane >= k0 + p && lane < n) J[fidx<TRI>(k0 + p, lane, ld)] = (TRI && lane == k0 + p) ? ri[p] : rp[p];
+            if (!TRI && p < pw && lane == 0) rinvd[k0 + p] = ri[p];
         }
         wave_sync();
         if (k0 == 24 || k0 == 28 || k0 == 52 || k0 == 56) COPRA_FINE("chol:panel");
@@ -263,7 +265,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
             for (int u = 0; u < 4; ++u) {
                 const int k = (k0 + u < n) ? k0 + u : n - 1;
                 row[u] = J[fidx<TRI>(k, lj, ld)]; // R(k, lane)
-                ri[u] = rinvd[k];
+                ri[u] = TRI ? J[fidx<true>(k, k, ld)] : rinvd[k];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -284,7 +286,7 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
             for (int u = 0; u < 4; ++u) {
                 const int k = (k0 - u >= 0) ? k0 - u : 0;
                 colv[u] = J[fidx<TRI>(lj, k, ld)]; // R(lane, k)
-                ri[u] = rinvd[k];
+                ri[u] = TRI ? J[fidx<true>(k, k, ld)] : rinvd[k];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -453,7 +455,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         if (TRI && !have_J && S.Jsrc) { // shared model, factor-only: the batch-wide factor comes into LDS on first need
             wave_sync();
             for (int e = lane; e < n * (n + 1) / 2; e += kWave) S.J[e] = S.Jsrc[e];
-            if (lane < n) S.coef[lane] = S.rinv_src[lane];
+            wave_sync();
+            if (lane < n) S.J[fidx<true>(lane, lane, ld)] = S.rinv_src[lane]; // (the diagonal slots carry 1 / R(i,i))
             have_J = true;
             wave_sync();
         }
@@ -484,7 +487,6 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             double vj = 0.0; // TRI: component `lane` of w - Q1 d1
             if constexpr (TRI) {
                 // w = R^-T n+ : forward substitution, lane = column; a bound row's normal starts at its own index
-                const double* rinvd = S.coef;
                 double acc = (lane < n) ? S.ap[lj] : 0.0;
                 double wk = 0.0;
                 auto forward = [&](int kfirst) {
@@ -494,7 +496,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         for (int u = 0; u < 4; ++u) {
                             const int k = (k0 + u < n) ? k0 + u : n - 1;
                             row[u] = J[fidx<true>(k, lj, ld)];
-                            ri4[u] = rinvd[k];
+                            ri4[u] = J[fidx<true>(k, k, ld)];
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -533,7 +535,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     for (int u = 0; u < 4; ++u) {
                         const int k = (k0 - u >= 0) ? k0 - u : 0;
                         colv[u] = J[fidx<true>(lj, k, ld)];
-                        ri4[u] = rinvd[k];
+                        ri4[u] = J[fidx<true>(k, k, ld)];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

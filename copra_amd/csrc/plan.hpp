@@ -72,7 +72,8 @@ struct LdsLayout {
     int J, ldj; // n x ldj: Hessian (upper) -> Cholesky factor -> J = R^-1 (row i at J + i*ldj)
     int tri; // 1: factor-only layout (gi_core.hpp, TRI): J holds the PACKED upper triangle (entry (i, c), i <= c, at
              // c (c + 1) / 2 + i) of the Hessian -> its Cholesky factor, J = R^-1 is never formed, Q1 holds the
-             // orthonormal basis of the active normals (rcap columns of 64), dv / the 4n coefficients do not exist
+             // orthonormal basis of the active normals (rcap columns of 64), dv / the 4n coefficients do not exist and
+             // the diagonal slots of the factor carry 1 / R(i,i)
     int Q1;
     int R; // packed upper-triangular R of the active set (rcap columns)
     int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one

@@ -114,7 +114,7 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     if (!compact) L.uv = take(n + 2); // (compact: sized by rcap, below)
     L.ap = take(n);
     L.cvec = compact ? L.ap : take(n); // c is consumed by the factorisation before ap is first written
-    L.coef = take(tri ? n : 4 * n);
+    L.coef = tri ? L.xs : take(4 * n); // (factor-only: 1 / R(i,i) sits on the diagonal of the packed factor; never touched)
     L.nb = take(mgen > 0 ? mgen : 1);
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
@@ -591,7 +591,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // square layouts already fill the wave slots, so those shapes stay as they are.
         if (U > 32 && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
-            const int need = rp > 0 ? 4 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
+            const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
