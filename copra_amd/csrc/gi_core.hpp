@@ -272,11 +272,13 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
                 const int k = k0 + u;
                 if (k < n) {
                     const double y = bcast_f64(acc, k) * ri[u];
-                    if (lane == k) yk = y;
                     if (lane > k) acc -= row[u] * y;
                 }
             }
         }
+        // (lane k's accumulator is final once step k-1 is done: y_k = acc_k / R(k,k), no select inside the loop)
+        const double rinv_own = TRI ? J[fidx<true>(lj, lj, ld)] : rinvd[lj];
+        yk = acc * rinv_own;
         // backward  R x = y :  x_k = acc_k / R(k,k),  acc_i -= R(i,k) x_k  (i < k), lane = row
         acc = yk;
         double xk = 0.0;
@@ -293,11 +295,11 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
                 const int k = k0 - u;
                 if (k >= 0) {
                     const double x = bcast_f64(acc, k) * ri[u];
-                    if (lane == k) xk = x;
                     if (lane < k) acc -= colv[u] * x;
                 }
             }
         }
+        xk = acc * rinv_own;
         if (lane < n) S.xs[lane] = xk;
         wave_sync();
     }
@@ -503,7 +505,6 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                             const int k = k0 + u;
                             if (k < n) {
                                 const double y = bcast_f64(acc, k) * ri4[u];
-                                if (lane == k) wk = y;
                                 if (lane > k) acc -= row[u] * y;
                             }
                         }
@@ -513,7 +514,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     forward(0); // (compile-time trip count when the shape is: the loads of the whole sweep batch)
                 else
                     forward(((nvl - mgen) % n) & ~3);
-                if (lane >= n) wk = 0.0;
+                const double rinv_own = J[fidx<true>(lj, lj, ld)];
+                wk = (lane < n) ? acc * rinv_own : 0.0; // (lane k's accumulator is final once step k-1 is done)
                 // d1 = Q1' w and v = w - Q1 d1, by modified Gram-Schmidt, twice (keeps Q1 orthonormal to rounding)
                 vj = wk;
                 dj = 0.0;
@@ -542,11 +544,11 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         const int k = k0 - u;
                         if (k >= 0) {
                             const double x = bcast_f64(acc, k) * ri4[u];
-                            if (lane == k) zk = x;
                             if (lane < k) acc -= colv[u] * x;
                         }
                     }
                 }
+                zk = acc * rinv_own;
                 zi = (lane < n) ? zk : 0.0;
                 if (iter_main <= 1) COPRA_FINE("as:z");
             } else {
