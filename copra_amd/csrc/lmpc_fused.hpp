@@ -58,6 +58,7 @@ struct StageRows {
     double ub_mine, lb_mine; // XU_lane, XL_lane
     const double* prm = nullptr; // optional LDS copy of the parameter blob (workgroup-per-instance kernel)
     int inst = 0; // instance this wave / workgroup works on (per-instance right-hand sides and bounds)
+    const double* zero = nullptr; // an LDS double that holds 0.0 (compile-time shapes: switched-off terms read it)
 
     COPRA_DEV const double* params() const { return prm ? prm : P.params; }
 
@@ -210,12 +211,11 @@ struct StageRows {
             for (int jb = 0; jb < NH_; ++jb) {
                 const int t = k - 1 - jb;
                 const bool on = t >= 0;
-                const double* g = G + eo + (on ? t : 0) * NX_ * NU_;
+                // a block past the lane's own step reads the zero slot: one address select instead of a value select
+                const double* g = on ? G + eo + t * NX_ * NU_ : zero;
+                const int st = on ? NX_ : 0;
 #pragma unroll
-                for (int jc = 0; jc < NU_; ++jc) {
-                    const double gv = g[NX_ * jc];
-                    a0 += (on ? gv : 0.0) * xs[jb * NU_ + jc];
-                }
+                for (int jc = 0; jc < NU_; ++jc) a0 += g[st * jc] * xs[jb * NU_ + jc];
             }
         } else {
             const double* g = G + eo + (k - 1) * nx() * nu();
@@ -390,6 +390,8 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     // their latency hides under the preview / cost phases
     StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
+    rows.zero = S.scal;
+    if (lane == 0) S.scal[0] = 0.0;
     rows.cache_own_row();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];

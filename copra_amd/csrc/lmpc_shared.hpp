@@ -39,6 +39,8 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
 
     StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
+    rows.zero = S.scal;
+    if (lane == 0) S.scal[0] = 0.0;
     rows.cache_own_row();
     int status = (int)M[m.status];
     // ---- this instance's x0; shared tables -> LDS ----
