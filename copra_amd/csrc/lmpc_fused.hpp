@@ -207,15 +207,16 @@ struct StageRows {
     {
         double a0 = 0.0;
         if constexpr (NH_ > 0 && NU_ > 0 && NX_ > 0) {
+            const int zoff = (int)(zero - G);
 #pragma unroll
             for (int jb = 0; jb < NH_; ++jb) {
                 const int t = k - 1 - jb;
                 const bool on = t >= 0;
                 // a block past the lane's own step reads the zero slot: one address select instead of a value select
-                const double* g = on ? G + eo + t * NX_ * NU_ : zero;
+                const int off = on ? eo + t * NX_ * NU_ : zoff; // (an index relative to G, not a second pointer: 32 bits)
                 const int st = on ? NX_ : 0;
 #pragma unroll
-                for (int jc = 0; jc < NU_; ++jc) a0 += g[st * jc] * xs[jb * NU_ + jc];
+                for (int jc = 0; jc < NU_; ++jc) a0 += G[off + st * jc] * xs[jb * NU_ + jc];
             }
         } else {
             const double* g = G + eo + (k - 1) * nx() * nu();
