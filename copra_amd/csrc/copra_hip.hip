@@ -364,7 +364,8 @@ static copra_status_t adapt_layout(copra_batch* h)
     h->lds_attr_set = false;
     h->shared_attr_set = false;
     const FusedPlan& P = h->hp.plan;
-    h->packed = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
+    h->packed = (P.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0
+        : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
     if (std::getenv("COPRA_DEBUG"))
         fprintf(stderr, "[copra] %d of %d instances overflowed the compact LDS layout: next layout %zu B, %s\n", count, P.batch,
             h->hp.lds_bytes, h->hp.two_tier ? "two-tier" : "single tier");
@@ -480,7 +481,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
             P.large.threads, h->hp.lds_bytes);
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
-    h->packed = (h->hp.large || std::getenv("COPRA_NO_PACKED")) ? 0
+    h->packed = (h->hp.large || h->hp.plan.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0 // (the packed bodies are square-layout)
         : packed_width(is ? P.nx + P.n : P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
     chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));

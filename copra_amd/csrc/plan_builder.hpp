@@ -589,7 +589,8 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // Measured (M solves/s, square layout -> factor-only): headline shape 13.4 -> 21.3; run-time shapes with 45
         // variables 10.0 -> 19.0, 48: 10.1 -> 13.9, 64: 4.1 -> 9.8.  Up to 32 variables the packed kernels and the dense
         // square layouts already fill the wave slots, so those shapes stay as they are.
-        if (U > 32 && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
+        const char* tmin = std::getenv("COPRA_TRI_MIN"); // (experiments: smallest number of variables that takes the tier)
+        if (U > (tmin ? std::atoi(tmin) : 32) && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
