@@ -498,7 +498,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             Q[fidx<TRI_>(lane, lane, ld)] = one;
         }
         double cj = 0.0; // lane j accumulates c_j
-        double* Y = lds + L.BldY;
+        double* Ybuf = lds + L.BldY;
         double* We = lds + L.BldWe;
         double* Cp = lds + L.BldCp; // this cost's parameters: M (r x nx) | N (r x nu) | p (r) | w (r)
         const int blk = lane / nu, sub = lane - blk * nu; // lane as (block, component)
@@ -549,13 +549,16 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             }
             const bool mixed = (ct.kind == kCostMixed);
             // Y_k = M G_k (the block  M * Psi_{i, j}  with k = i-1-j), We_k = w .* (M xbar_k - p)
+            const bool ident = ct.ident && r == nx; // M = I: the blocks G_k themselves (same layout when r == nx)
+            const double* Y = ident ? G : Ybuf;
+            if (!ident)
             for (int e = lane; e < N * r * nu; e += kWave) {
                 const int k = e / (r * nu), rem = e - k * r * nu;
                 const int jc = rem / r, row = rem - jc * r;
                 const double* Gk = G + k * nx * nu + nx * jc;
                 double acc = 0.0;
                 for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Gk[c];
-                Y[e] = acc; // Y[k][row + r*jc]
+                Ybuf[e] = acc; // Y[k][row + r*jc]
             }
             for (int e = lane; e < (N + 1) * r; e += kWave) {
                 const int k = e / r, row = e - k * r;

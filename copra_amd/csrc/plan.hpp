@@ -61,6 +61,8 @@ struct CostTerm {
     int offP; // r
     int offW; // r
     int full; // 1: full-size entry (costFunctions.cpp:65-71, 141-146, 197-203) -> dense MFMA contraction
+    int ident; // 1: per-step entry whose M is the xDim x xDim identity (the usual "track the whole state" cost): the
+               // products M G_k ARE the blocks G_k, bit for bit, so the cost phase reads G instead of forming them
 };
 
 // LDS carve-up, offsets in doubles from the dynamic-LDS base (all multiples of 2 doubles = 16 bytes)

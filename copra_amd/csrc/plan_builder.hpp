@@ -262,6 +262,13 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
         }
         t.full = full ? 1 : 0;
+        t.ident = 0;
+        if (!full && c.kind != COPRA_COST_CONTROL && c.rows == nx) {
+            bool id = true;
+            for (int j = 0; j < nx && id; ++j)
+                for (int i = 0; i < nx && id; ++i) id = c.M[(size_t)j * nx + i] == ((i == j) ? 1.0 : 0.0);
+            t.ident = id ? 1 : 0;
+        }
         if (full) {
             // full-size entry: keep M (rows x fullXDim) and N (rows x fullUDim) ROW-major, one contiguous row per cost row
             auto push_rowmajor = [&](const double* Mx, int rows, int cols) {

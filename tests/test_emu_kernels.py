@@ -75,6 +75,20 @@ def test_factor_only_layout(emu, oracle, case):
         assert re["overflowed"] > 0 and ro["iter"][:, 0].max() > re["rcap"] + 1  # the second tier finished some
 
 
+@pytest.mark.parametrize("specialised", [True, False])
+def test_headline_shape_with_a_general_output_map(emu, oracle, specialised):
+    """the cost phase reads G instead of forming M G_k when M is the identity (CostTerm::ident); a general 6 x 6 M and a
+    5-row selection (padded to the six rows of the compile-time shape) take the ordinary route"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.3, u_max=1.5, seed=5)
+    rng = np.random.default_rng(2)
+    c0 = wl["costs"][0]
+    Mg = np.eye(6) + 0.2 * rng.standard_normal((6, 6))
+    for M, p, w in ((Mg, Mg @ c0["p"], c0["weights"]), (np.eye(6)[:5], c0["p"][:5], c0["weights"][:5])):
+        costs = [dict(kind="trajectory", M=M, p=p, weights=w), wl["costs"][1]]
+        _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], specialised)
+
+
 def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
     """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
     from copra_amd import workloads
