@@ -391,8 +391,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     // their latency hides under the preview / cost phases
     StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
-    rows.zero = S.scal;
-    if (lane == 0) S.scal[0] = 0.0;
+    rows.zero = S.scal; // (written after the cost phase: its tables borrow the solver vectors in the compact layouts)
     rows.cache_own_row();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];
@@ -765,6 +764,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         }
     }
     stamp[2] = cycle_counter();
+    if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component (synchronised by the norms phase's barrier)
     // ---- 3. implicit rows: norms (qpgen2: column norms of amat) ----
     for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(rows.desc(i)));
     if (inst == P.dump_instance && P.dumpA) { // parity hook (LMPC::Aeq/beq/Aineq/bineq; LMPC.h:116-123)

@@ -260,6 +260,26 @@ def test_two_tier_overflow_on_gpu(oracle):
     assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
 
 
+def test_headline_shape_with_a_general_output_map(oracle):
+    """compile-time headline shape, TrajectoryCost with a general 6 x 6 M and with a 5-row selection (the identity M of
+    the bench workload takes a shortcut in the cost phase: CostTerm::ident)"""
+    from copra_amd import workloads
+    b = 512
+    wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=5)
+    rng = np.random.default_rng(2)
+    c0 = wl["costs"][0]
+    Mg = np.eye(6) + 0.2 * rng.standard_normal((6, 6))
+    for M, p, w in ((Mg, Mg @ c0["p"], c0["weights"]), (np.eye(6)[:5], c0["p"][:5], c0["weights"][:5])):
+        wl2 = dict(wl, costs=[dict(kind="trajectory", M=M, p=p, weights=w), wl["costs"][1]])
+        eng, res = _solve_gpu(wl2, b)
+        assert eng.layout_info()["factor_only"]
+        ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl2["costs"], wl["cstrs"], nthreads=8)
+        assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
+        ok = ref["status"] == 0
+        assert ok.sum() > b // 2 and _rel(res["control"][ok], ref["control"][ok]) <= RTOL
+        assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+
+
 def test_factor_only_layout_steps_down_its_ladder(oracle):
     """headline shape, tighter bounds: the seven-per-CU factor-only layout has room for four active constraints, half of
     the instances need more; after the first solves the controller takes a roomier factor-only layout.  Every solve --
