@@ -89,6 +89,28 @@ def test_headline_shape_with_a_general_output_map(emu, oracle, specialised):
         _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], specialised)
 
 
+@pytest.mark.parametrize("order", ["target-first", "control-first", "mixed-first", "trajectory-mixed-target"])
+def test_headline_shape_every_per_step_cost_kind(emu, oracle, order):
+    """compile-time (6, 3, 20) instantiation: the grouped walk along the block diagonals with a TargetCost (no running
+    sum), a MixedCost (cross terms, one step shorter) and a ControlCost in first position (then the Hessian is cleared
+    and added to instead of stored outright); Hessian / gradient dump and solution against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(4, v_max=0.4, u_max=2.0, seed=11)
+    rng = np.random.default_rng(5)
+    traj, ctrl = wl["costs"]
+    target = dict(kind="target", M=np.eye(6)[[0, 2, 4]], p=traj["p"][[0, 2, 4]], weights=[40.0, 40.0, 10.0])
+    mixed = dict(kind="mixed", M=0.3 * rng.standard_normal((2, 6)), N=0.1 * rng.standard_normal((2, 3)), p=[0.1, -0.2],
+                 weights=[3.0, 5.0])
+    costs = {"target-first": [target, ctrl], "control-first": [ctrl, traj, target], "mixed-first": [mixed, ctrl, traj],
+             "trajectory-mixed-target": [traj, mixed, target, ctrl]}[order]
+    for spec in (True, False):
+        re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], dump_instance=1, specialised=spec)
+        qp = oracle.lmpc_build(wl["A"][1], wl["B"][1], wl["d"][1], wl["x0"][1], wl["N"], costs, wl["cstrs"])
+        assert np.abs(re["Q"] - qp["Q"]).max() <= 1e-12 * np.abs(qp["Q"]).max()
+        assert np.abs(re["c"] - qp["c"]).max() <= 1e-12 * max(1.0, np.abs(qp["c"]).max())
+        _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], spec)
+
+
 def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
     """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
     from copra_amd import workloads
