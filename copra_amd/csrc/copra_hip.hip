@@ -259,6 +259,7 @@ struct copra_batch {
     bool shared = false, model_dirty = true, shared_attr_set = false;
     int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)
     size_t model_doubles = 0; // allocated size of d_model
+    int model_rtot = 0; // columns of C2 / K2 as prepared
     double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
     std::vector<double> shA, shB, shd;
     double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
@@ -624,7 +625,7 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     }
     const int np = 1 + nx + rtot;
     const ModelLayout m = model_layout(nx, nu, N, n, X, h->hp.lds_full.ldj, HP.mgen);
-    const size_t need = (size_t)m.C2 + (size_t)n * (rtot > 0 ? rtot : 1);
+    const size_t need = (size_t)m.C2 + 2 * (size_t)n * (rtot > 0 ? rtot : 1);
     if (!h->d_model || h->model_doubles < need) {
         (void)hipFree(h->d_model);
         h->d_model = nullptr;
@@ -705,6 +706,24 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
             e = hipMemcpy(h->d_model + m.C1, lin.data() + n, (size_t)n * nx * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess && rtot > 0)
             e = hipMemcpy(h->d_model + m.C2, lin.data() + (size_t)n * (1 + nx), (size_t)n * rtot * sizeof(double), hipMemcpyHostToDevice);
+        // the unconstrained minimiser x = -Qinv (c0 + C1 x0 + C2 p) as an affine map of (x0, p): one n x (1 + nx + R)
+        // product here instead of an n x n one in every instance
+        const int ld = h->hp.lds_full.ldj;
+        std::vector<double> Qi((size_t)n * ld), K((size_t)n * np);
+        if (e == hipSuccess) e = hipMemcpy(Qi.data(), h->d_model + m.Qinv, Qi.size() * sizeof(double), hipMemcpyDeviceToHost);
+        for (int a = 0; a < np; ++a)
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j) acc += Qi[(size_t)j * ld + i] * lin[(size_t)a * n + j]; // (same order as the kernel had)
+                K[(size_t)a * n + i] = -acc;
+            }
+        if (e == hipSuccess) e = hipMemcpy(h->d_model + m.xu0, K.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(h->d_model + m.K1, K.data() + n, (size_t)n * nx * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess && rtot > 0)
+            e = hipMemcpy(h->d_model + m.C2 + (size_t)n * rtot, K.data() + (size_t)n * (1 + nx), (size_t)n * rtot * sizeof(double),
+                hipMemcpyHostToDevice);
+        h->model_rtot = rtot;
     }
     release();
     if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
@@ -1003,6 +1022,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         FusedPlan P = device_plan(h);
         P.model = h->d_model;
         for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
+        P.model_rtot = h->model_rtot;
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
         if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {

@@ -4,10 +4,10 @@
 // src/LMPC.cpp:233).  Then Psi, the Hessian, its Cholesky factor and J = R^-1 are the same for the whole batch: a
 // one-workgroup "prepare" launch of the fused kernel computes them once (lmpc_fused.hpp, model_out) and each wave here
 // only
-//   * forms the free response  xbar = Phi x0 + xi  and the gradient  c = c0 + C1 x0  (the reference factors the
-//     x0-dependence the same way: c = E' x0 + f, costFunctions.cpp:80; b = z - Y x0, constraints.cpp:81),
-//   * takes x = -Qinv c (Qinv = J J' precomputed) and copies J into its LDS only if a constraint is violated (the
-//     active-set updates rotate it per instance),
+//   * forms the free response  xbar = Phi x0 + xi  (the reference factors the x0-dependence the same way: c = E' x0 + f,
+//     costFunctions.cpp:80; b = z - Y x0, constraints.cpp:81),
+//   * takes the unconstrained minimiser x = -Qinv (c0 + C1 x0 + C2 p) = xu0 + K1 x0 + K2 p (multiplied out once per
+//     batch) and copies the factor into its LDS only if a constraint is violated,
 //   * runs the same Goldfarb-Idnani loop (gi_core.hpp) and writes the results.
 // Same LDS layouts and the same two-tier overflow scheme as the fused kernel.
 #pragma once
@@ -61,36 +61,24 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
             if (c < nx) acc += Pk[nx * c] * x0r[c];
         Xbar[row] = acc + M[m.Xi + row];
     }
-    if (lane < n) { // c = c0 + C1 x0
-        double acc = M[m.c0 + lane];
+    // ---- unconstrained minimiser: x = -Qinv (c0 + C1 x0 + C2 p) is affine in (x0, p); the prepare step multiplied it
+    //      out once for the batch (xu0, K1, K2: nx + R terms per lane instead of an n x n product; c itself is not
+    //      needed any more -- the active-set loop works from x and the constraint rows) ----
+    if (lane < n) {
+        double acc = M[m.xu0 + lane];
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c < nx) acc += M[m.C1 + (size_t)c * n + lane] * x0r[c];
-        for (int t = 0; t < P.ncost; ++t) { // costs with per-instance references: c += C2_t p_t
+            if (c < nx) acc += M[m.K1 + (size_t)c * n + lane] * x0r[c];
+        for (int t = 0; t < P.ncost; ++t) { // costs with per-instance references
             if (P.cost_p[t] && P.model_ref_off[t] >= 0) {
                 const double* pt = P.cost_p[t] + (size_t)inst * P.cost[t].rows;
-                const double* C2 = M + m.C2 + (size_t)P.model_ref_off[t] * n;
-                for (int i = 0; i < P.cost[t].rows; ++i) acc += C2[(size_t)i * n + lane] * pt[i];
+                const double* K2 = M + m.C2 + (size_t)(P.model_rtot + P.model_ref_off[t]) * n;
+                for (int i = 0; i < P.cost[t].rows; ++i) acc += K2[(size_t)i * n + lane] * pt[i];
             }
         }
-        S.cvec[lane] = acc;
+        S.xs[lane] = acc;
     }
     wave_sync();
-    // ---- unconstrained minimiser x = -Qinv c, Qinv = J J' precomputed for the whole batch (symmetric: row i is read
-    // as column i, i.e. coalesced across the lanes; L2-resident) ----
-    {
-        const int lj = (lane < n) ? lane : n - 1;
-        const double* Qi = M + m.Qinv;
-        double x0a = 0.0, x1a = 0.0;
-        int j = 0;
-        for (; j + 1 < n; j += 2) {
-            x0a += Qi[(size_t)j * ld + lj] * S.cvec[j];
-            x1a += Qi[(size_t)(j + 1) * ld + lj] * S.cvec[j + 1];
-        }
-        if (j < n) x0a += Qi[(size_t)j * ld + lj] * S.cvec[j];
-        if (lane < n) S.xs[lane] = -(x0a + x1a);
-        wave_sync();
-    }
     int it_main = 0, it_drop = 0;
     if (status == 0)
         status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);

@@ -233,9 +233,11 @@ struct FusedPlan {
     // layout (doubles): status | J [n * ldj] | G [N nx nu] | Phi [(N+1) nx nx] | xi [X] | nb [mgen] | c0 [n] | C1 [n x nx]
     //                   | Qinv [n * ldj] (= J J', symmetric: the unconstrained minimiser is -Qinv c without touching J)
     //                   | Rtri [n (n + 1) / 2], rinv [n] : the packed Cholesky factor and 1 / R(i,i) (factor-only tier)
+    //                   | xu0 [n], K1 [n x nx] (and K2 [n x R] after C2): the unconstrained minimiser xu0 + K1 x0 + K2 p
     //                   | C2 [n x R] : dc/dp of the costs that have per-instance references (model_ref_off[t] = first
     //                     column of cost t, -1 = controller-wide reference already folded into c0)
     int model_ref_off[kMaxCosts];
+    int model_rtot; // columns of C2 (and of K2, which follows it)
     double* model_out;
     const double* model;
     // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
@@ -249,7 +251,7 @@ struct FusedPlan {
 
 // offsets (doubles) into the shared-model buffer, see FusedPlan::model
 struct ModelLayout {
-    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, Rtri, rinv, C2, total; // (C2 has no fixed size: it ends the buffer)
+    long long status, J, G, Phi, Xi, nb, c0, C1, Qinv, Rtri, rinv, xu0, K1, C2, total; // (C2, then K2 of the same size, end the buffer)
 };
 #ifdef __HIPCC__
 #define COPRA_HOST_DEVICE __host__ __device__
@@ -274,6 +276,8 @@ COPRA_HOST_DEVICE inline ModelLayout model_layout(int nx, int nu, int N, int n, 
     COPRA_TAKE(Qinv, (long long)n * ldj);
     COPRA_TAKE(Rtri, (long long)n * (n + 1) / 2); // the Cholesky factor itself, packed (factor-only first tier)
     COPRA_TAKE(rinv, n); // 1 / R(i, i)
+    COPRA_TAKE(xu0, n); // the unconstrained minimiser is affine in (x0, p): x = xu0 + K1 x0 + K2 p with
+    COPRA_TAKE(K1, (long long)n * nx); // xu0 = -Qinv c0, K1 = -Qinv C1, K2 = -Qinv C2 (K2 follows C2, same shape)
     m.C2 = o;
 #undef COPRA_TAKE
     m.total = o;

@@ -318,7 +318,21 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     for (int j = 0; j < n; ++j) model[(size_t)m.c0 + j] = dC[(size_t)j];
     for (int a = 0; a < nx; ++a)
         for (int j = 0; j < n; ++j) model[(size_t)m.C1 + (size_t)a * n + j] = dC[(size_t)(a + 1) * n + j] - dC[(size_t)j];
+    { // x = -Qinv (c0 + C1 x0) multiplied out once (prepare_shared_model in copra_hip.hip)
+        const int ld = hp.lds_full.ldj;
+        for (int a = 0; a < np1; ++a)
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                const double* col = (a == 0) ? &model[(size_t)m.c0] : &model[(size_t)m.C1 + (size_t)(a - 1) * n];
+                for (int j = 0; j < n; ++j) acc += model[(size_t)m.Qinv + (size_t)j * ld + i] * col[j];
+                if (a == 0)
+                    model[(size_t)m.xu0 + i] = -acc;
+                else
+                    model[(size_t)m.K1 + (size_t)(a - 1) * n + i] = -acc;
+            }
+    }
     P.model = model.data();
+    P.model_rtot = 0;
     P.x0 = x0;
     auto shared = [&](const FusedPlan& PP, int b) {
         if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
