@@ -120,15 +120,19 @@ COPRA_DEV int fidx(int i, int j, int ld)
 #ifndef COPRA_CHOL_SUPER
 #define COPRA_CHOL_SUPER 1
 #endif
-template <int NV, bool TRI>
-COPRA_DEV void chol_super_update(double* J, int n, int ld, int k0)
+// K0 > 0 (with NV > 0): the super-panel's first row at compile time -- trip count and tile count are constants, the
+// loop unrolls and every operand is on its way before the first product issues.
+template <int NV, bool TRI, int K0 = 0>
+COPRA_DEV void chol_super_update(double* J, int n, int ld, int k0_rt)
 {
     const int lane = lane_id();
+    const int k0 = K0 ? K0 : k0_rt;
     const int kk = lane >> 4, col = lane & 15;
     const int ra = k0 + col; // the row of the super-panel this lane feeds into the A operand
     const int rac = (ra < n) ? ra : n - 1;
     const int tile0 = k0 >> 4;
-    constexpr int kMaxTiles = 3; // k0 >= 16 and n <= 64: at most the column tiles 1..3
+    // k0 >= 16 and n <= 64: at most the column tiles 1..3
+    constexpr int kMaxTiles = (NV > 0 && K0 > 0) ? ((NV + 15) / 16 - K0 / 16) : 3;
     const int ntile = ((n + 15) >> 4) - tile0;
     mfma_acc acc[kMaxTiles];
 #pragma unroll
@@ -141,6 +145,7 @@ COPRA_DEV void chol_super_update(double* J, int n, int ld, int k0)
         cin[c] = (c < ntile) && (cc < n);
         cb[c] = cin[c] ? cc : n - 1;
     }
+#pragma unroll(K0 > 0 ? 16 : 1)
     for (int t0 = 0; t0 < k0; t0 += 4) {
         double a = J[fidx<TRI>(t0 + kk, rac, ld)];
         if (ra >= n) a = 0.0;
@@ -194,7 +199,18 @@ COPRA_DEV int gi_factorize(const SolverLds& S, int n_rt, long long* t_chol COPRA
         if constexpr (COPRA_CHOL_SUPER && kWave == 64) { // (the packed builds have no 64-lane matrix-core operand)
             if (n > 16) {
                 tfirst = k0 & ~15;
-                if (k0 > 0 && k0 == tfirst) chol_super_update<NV, TRI>(J, n, ld, k0);
+                if (k0 > 0 && k0 == tfirst) {
+                    if constexpr (NV > 16) { // (compile-time shapes: one instantiation per super-panel)
+                        if (k0 == 16)
+                            chol_super_update<NV, TRI, 16>(J, n, ld, k0);
+                        else if (k0 == 32)
+                            chol_super_update<NV, TRI, (NV > 32 ? 32 : 0)>(J, n, ld, k0);
+                        else
+                            chol_super_update<NV, TRI, (NV > 48 ? 48 : 0)>(J, n, ld, k0);
+                    } else {
+                        chol_super_update<NV, TRI>(J, n, ld, k0);
+                    }
+                }
             }
         }
         double acc[4];
