@@ -424,6 +424,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         if (iter_main >= max_iter) return 3;
         iter_main += 1;
         // ---------------- step 1: most violated constraint ----------------
+        if (iter_main <= 1) COPRA_FINE("as:init");
         rows.begin_scan(S.xs);
         double best = 0.0, best_s = 0.0;
         int best_i = -1;
@@ -449,6 +450,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 }
             }
         }
+        if (iter_main <= 1) COPRA_FINE("as:rows");
         if (lane < n) { // bound rows: unit norm; an infinite / DBL_MAX bound gives a slack that is never negative
             const double xj = S.xs[lane];
             double s = ubj - xj; // row mgen + j of [I]
@@ -468,6 +470,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 best_s = s;
             }
         }
+        if (iter_main <= 1) COPRA_FINE("as:bounds");
         wave_argmin(best, best_i, best_s);
         if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
