@@ -23,6 +23,9 @@
 
 #include "gi_core.hpp"
 
+#ifndef COPRA_LATE_ROW_CACHE
+#define COPRA_LATE_ROW_CACHE 1
+#endif
 #ifndef COPRA_CHAIN_GROUP
 #define COPRA_CHAIN_GROUP 2
 #endif
@@ -392,7 +395,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     StageRows<NX_, NU_, NH_> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
     rows.zero = S.scal; // (written after the cost phase: its tables borrow the solver vectors in the compact layouts)
-    rows.cache_own_row();
+    if (!COPRA_LATE_ROW_CACHE) rows.cache_own_row();
     // ---- 0. coalesced loads of this instance's system ----
     for (int e = lane; e < nx * nx; e += kWave) A[e] = P.A[(size_t)inst * nx * nx + e];
     for (int e = lane; e < nx * nu; e += kWave) B[e] = P.B[(size_t)inst * nx * nu + e];
@@ -750,6 +753,9 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
             }
         }
         COPRA_FINE("costs:grad");
+        // this lane's row descriptor and bounds: first needed by the norms below; fetched here rather than at kernel
+        // start so that eleven registers are not carried (and spilled) across the preview and cost phases
+        if (COPRA_LATE_ROW_CACHE) rows.cache_own_row();
         wave_sync();
         if (lane < n) S.cvec[lane] = cj;
         wave_sync();
