@@ -506,6 +506,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 S.ap[lane] = (q < n) ? ((lane == q) ? -1.0 : 0.0) : ((lane == q - n) ? 1.0 : 0.0);
             }
             wave_sync();
+            if (iter_main <= 1) COPRA_FINE("as:normal");
             double dj, zi;
             double vj = 0.0; // TRI: component `lane` of w - Q1 d1
             if constexpr (TRI) {
@@ -531,12 +532,16 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         }
                     }
                 };
-                if (nvl < mgen)
-                    forward(0); // (compile-time trip count when the shape is: the loads of the whole sweep batch)
+                // A bound row's normal starts at its own index, so its sweep could start there -- but a run-time start
+                // keeps the loop from unrolling, and the unrolled sweep (offsets folded, loads batched) is twice as
+                // fast as the rolled one (5.5 k vs 10.4 k cycles at n = 60): compile-time shapes always sweep from 0.
+                if (NV > 0 || nvl < mgen)
+                    forward(0);
                 else
                     forward(((nvl - mgen) % n) & ~3);
                 const double rinv_own = J[fidx<true>(lj, lj, ld)];
                 wk = (lane < n) ? acc * rinv_own : 0.0; // (lane k's accumulator is final once step k-1 is done)
+                if (iter_main <= 1) COPRA_FINE("as:w");
                 // d1 = Q1' w and v = w - Q1 d1, by modified Gram-Schmidt, twice (keeps Q1 orthonormal to rounding)
                 vj = wk;
                 dj = 0.0;
