@@ -26,6 +26,9 @@
 #ifndef COPRA_LATE_ROW_CACHE
 #define COPRA_LATE_ROW_CACHE 1
 #endif
+#ifndef COPRA_STATE_GROUP
+#define COPRA_STATE_GROUP 4
+#endif
 #ifndef COPRA_CHAIN_GROUP
 #define COPRA_CHAIN_GROUP 2
 #endif
@@ -211,15 +214,33 @@ struct StageRows {
         double a0 = 0.0;
         if constexpr (NH_ > 0 && NU_ > 0 && NX_ > 0) {
             const int zoff = (int)(zero - G);
+            // groups of COPRA_STATE_GROUP blocks: all operands of a group are read before its first multiply-add (left
+            // to itself the compiler waits for every single LDS read -- 60 exposed latencies -- to save registers)
+            constexpr int GB = COPRA_STATE_GROUP;
 #pragma unroll
-            for (int jb = 0; jb < NH_; ++jb) {
-                const int t = k - 1 - jb;
-                const bool on = t >= 0;
-                // a block past the lane's own step reads the zero slot: one address select instead of a value select
-                const int off = on ? eo + t * NX_ * NU_ : zoff; // (an index relative to G, not a second pointer: 32 bits)
-                const int st = on ? NX_ : 0;
+            for (int j0 = 0; j0 < NH_; j0 += GB) {
+                double gv[GB][NU_], xv[GB][NU_];
 #pragma unroll
-                for (int jc = 0; jc < NU_; ++jc) a0 += G[off + st * jc] * xs[jb * NU_ + jc];
+                for (int u = 0; u < GB; ++u) {
+                    const int jb = j0 + u;
+                    if (jb < NH_) {
+                        const int t = k - 1 - jb;
+                        const bool on = t >= 0;
+                        // a block past the lane's own step reads the zero slot: one address select, no value select
+                        const int off = on ? eo + t * NX_ * NU_ : zoff; // (an index relative to G: 32 bits)
+                        const int st = on ? NX_ : 0;
+#pragma unroll
+                        for (int jc = 0; jc < NU_; ++jc) {
+                            gv[u][jc] = G[off + st * jc];
+                            xv[u][jc] = xs[jb * NU_ + jc];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GB; ++u)
+#pragma unroll
+                    for (int jc = 0; jc < NU_; ++jc)
+                        if (j0 + u < NH_) a0 += gv[u][jc] * xv[u][jc];
             }
         } else {
             const double* g = G + eo + (k - 1) * nx() * nu();
