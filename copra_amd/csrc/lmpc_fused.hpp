@@ -27,7 +27,7 @@
 #define COPRA_LATE_ROW_CACHE 1
 #endif
 #ifndef COPRA_STATE_GROUP
-#define COPRA_STATE_GROUP 4
+#define COPRA_STATE_GROUP 5
 #endif
 #ifndef COPRA_CHAIN_GROUP
 #define COPRA_CHAIN_GROUP 2
@@ -215,9 +215,11 @@ struct StageRows {
         if constexpr (NH_ > 0 && NU_ > 0 && NX_ > 0) {
             const int zoff = (int)(zero - G);
             // groups of COPRA_STATE_GROUP blocks: all operands of a group are read before its first multiply-add (left
-            // to itself the compiler waits for every single LDS read -- 60 exposed latencies -- to save registers)
+            // to itself the compiler waits for every single LDS read -- 60 exposed latencies -- to save registers).
+            // The loop over the groups stays rolled: unrolled, all 120 reads are hoisted to the front and ~50 registers
+            // spill (705 MB of scratch traffic per launch of 65536 instances, and slower).
             constexpr int GB = COPRA_STATE_GROUP;
-#pragma unroll
+#pragma clang loop unroll(disable)
             for (int j0 = 0; j0 < NH_; j0 += GB) {
                 double gv[GB][NU_], xv[GB][NU_];
 #pragma unroll

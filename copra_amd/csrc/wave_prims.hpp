@@ -51,6 +51,8 @@ COPRA_DEV double bcast_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 COPRA_DEV int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// the instruction scheduler moves nothing across this point (bounds how far ahead it hoists the loads of unrolled code)
+COPRA_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // 1/sqrt(x): v_rsq_f64 seed + two Newton steps (full double precision to ~1 ulp, no divide)
 COPRA_DEV double fast_rsqrt(double x)
 {

@@ -90,6 +90,7 @@ COPRA_DEV double shfl_up0_f64(double v, int delta)
 }
 COPRA_DEV double bcast_f64(double v, int src) { return emu_xchg_f64(v, src); }
 COPRA_DEV int bcast_i32(int v, int src) { return (int)emu_xchg_f64((double)v, src); }
+COPRA_DEV void sched_fence() { }
 COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 COPRA_DEV int uniform_i32(int v) { return v; }
