@@ -147,8 +147,14 @@ def build_library(force=False):
 
     if current() and not force:
         return False
+    if os.environ.get("COPRA_NO_BUILD"):
+        # profilers preload a library that initialises the GPU in every child: never spawn make -> hipcc from there
+        raise ImportError("copra_amd: libcopra_hip.so is missing or older than its sources and COPRA_NO_BUILD is set "
+                          "(build first: python -c 'import __graft_entry__ as g; g.build()')")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
+        if os.path.exists(LIB_PATH) and not os.path.exists(stamp):
+            return False  # a prebuilt library without its stamp on a box that cannot rebuild it: used as it is
         if os.path.exists(LIB_PATH):
             raise ImportError("copra_amd: libcopra_hip.so is older than its sources and hipcc is not available")
         raise ImportError("copra_amd: libcopra_hip.so has not been built and hipcc is not available")
@@ -159,9 +165,10 @@ def build_library(force=False):
             if current() and not force:
                 return False
             subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
-                                  stdout=subprocess.DEVNULL)
-            with open(stamp, "w") as fh:
-                fh.write(want + "\n")
+                                  stdout=subprocess.DEVNULL)  # (the Makefile writes the stamp, same hash formula)
+            have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+            if have != want:
+                raise ImportError("copra_amd: Makefile and _capi.source_hash() disagree on the source hash")
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return True

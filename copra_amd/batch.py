@@ -37,6 +37,7 @@ class BatchLMPC:
         self.n = self.nu * self.N
         self.X = self.nx * (self.N + 1)
         self._keep = []
+        self._ref_keep = {}  # torch tensors used in place as per-instance cost references, by cost index
         cc = _capi.pack_costs(costs, self._keep)
         kk = _capi.pack_cstrs(cstrs, self._keep)
         dims = _capi.Dims(self.nx, self.nu, self.N, self.batch)
@@ -105,10 +106,11 @@ class BatchLMPC:
     def set_cost_reference(self, cost_index, p):
         """per-instance reference of cost `cost_index`: p of shape (batch, rows) (numpy, or a torch CUDA tensor used in
         place); None restores the controller-wide reference"""
+        self._ref_keep.pop(int(cost_index), None)  # one slot per cost: the previous tensor is released
         if p is None:
             _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), None, 0))
         elif _is_torch(p):
-            self._keep.append(p)
+            self._ref_keep[int(cost_index)] = p
             _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), p.data_ptr(), 1))
         else:
             pb = np.ascontiguousarray(p, dtype=np.float64)

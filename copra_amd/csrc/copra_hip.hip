@@ -13,10 +13,17 @@
 #include "qp_dense_large.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+extern char** environ;
+
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -226,6 +233,23 @@ copra_status_t fail(copra_status_t code, const std::string& msg)
         hipError_t e_ = (expr);                                                                                       \
         if (e_ != hipSuccess) return fail(COPRA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
+
+// Dynamic LDS beyond 48 KiB is an opt-in PER KERNEL SYMBOL: raise the limit of exactly the function that is about to be
+// launched, to the size it is launched with (several symbols -- first tier, second tier, parity dump, shared-model
+// prepare, run-time-compiled kernels -- run with different layouts of the same controller).  Remembered per function.
+hipError_t lds_opt_in(const void* fn, size_t bytes)
+{
+    if (bytes <= 48u * 1024u) return hipSuccess;
+    static std::mutex mu;
+    static std::map<const void*, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(fn);
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[fn] = bytes;
+    return e;
+}
+#define LDS_OPT_IN(fn, bytes) HIP_TRY(lds_opt_in(reinterpret_cast<const void*>(fn), (bytes)))
 
 template <class T>
 hipError_t upload(T** dst, const std::vector<T>& src)
@@ -681,6 +705,8 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
         P.dump_only = 1;
         P.dumpQ = dQ;
         P.dumpc = dC + (size_t)a * n;
+        e = lds_opt_in(reinterpret_cast<const void*>(select_fused_kernel(P)), h->hp.lds_full_bytes);
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, s, P);
         e = hipGetLastError();
     }
@@ -689,6 +715,7 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     P.dump_only = 0;
     P.dumpQ = P.dumpc = nullptr;
     P.model_out = h->d_model;
+    if (e == hipSuccess) e = lds_opt_in(reinterpret_cast<const void*>(select_fused_kernel(P)), h->hp.lds_full_bytes);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, s, P);
         e = hipGetLastError();
@@ -834,12 +861,12 @@ static copra_status_t jit_compile(const std::string& key, const std::string& sou
     }
     (void)mkdir((dir.substr(0, dir.find_last_of('/'))).c_str(), 0755);
     (void)mkdir(dir.c_str(), 0755);
-    std::string stamp = "nostamp"; // the code object depends on the exact sources it was compiled from
-    if (FILE* f = fopen((src_dir + "/libcopra_hip.so.srchash").c_str(), "r")) {
-        char buf[64] = { 0 };
-        if (fgets(buf, sizeof buf, f)) stamp = std::string(buf).substr(0, 12);
-        fclose(f);
-    }
+    // the code object depends on the exact sources it was compiled from: the hash of those sources is compiled into this
+    // library (Makefile: COPRA_SRC_HASH), so a cache left by another build of the library is never picked up
+#ifndef COPRA_SRC_HASH
+#error "build through copra_amd/csrc/Makefile (it defines COPRA_SRC_HASH, the key of the run-time-compilation cache)"
+#endif
+    const std::string stamp = std::string(COPRA_SRC_HASH).substr(0, 12);
     obj = dir + "/" + key + "_" + stamp + ".hsaco";
     if (access(obj.c_str(), R_OK) == 0) return COPRA_OK;
     const std::string src = obj + "." + std::to_string((long)getpid()) + ".hip";
@@ -847,15 +874,31 @@ static copra_status_t jit_compile(const std::string& key, const std::string& sou
     if (!f) return fail(COPRA_ERR_RUNTIME, "run-time specialisation: cannot write to the cache directory " + dir);
     fputs(source.c_str(), f);
     fclose(f);
-    const char* hipcc = std::getenv("HIPCC");
+    const char* hipcc_env = std::getenv("HIPCC");
+    const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
     const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
-    const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 --genco -I'" + src_dir
-        + "' -o '" + tmp + "' '" + src + "' > '" + src + ".log' 2>&1";
-    const int rc = std::system(cmd.c_str());
+    const std::string log = src + ".log";
+    const std::string inc = "-I" + src_dir;
+    // argv, no shell: paths with quotes or spaces cannot break (or inject into) the command
+    const char* argv[] = { hipcc.c_str(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", inc.c_str(), "-o", tmp.c_str(),
+        src.c_str(), nullptr };
+    int rc = -1;
+    {
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        posix_spawn_file_actions_adddup2(&fa, 1, 2);
+        pid_t pid = 0;
+        if (posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, const_cast<char* const*>(argv), environ) == 0) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) == pid && WIFEXITED(st)) rc = WEXITSTATUS(st);
+        }
+        posix_spawn_file_actions_destroy(&fa);
+    }
     (void)unlink(src.c_str());
     if (rc != 0 || rename(tmp.c_str(), obj.c_str()) != 0)
-        return fail(COPRA_ERR_RUNTIME, "run-time specialisation: hipcc --genco failed (see " + src + ".log)");
-    (void)unlink((src + ".log").c_str());
+        return fail(COPRA_ERR_RUNTIME, "run-time specialisation: hipcc --genco failed (see " + log + ")");
+    (void)unlink(log.c_str());
     return COPRA_OK;
 }
 
@@ -864,11 +907,13 @@ struct DenseJit {
     int n, lanes;
     hipFunction_t fn;
 };
-static std::vector<DenseJit> g_dense_jit;
+static std::vector<DenseJit> g_dense_jit; // guarded by g_dense_jit_mu
+static std::mutex g_dense_jit_mu;
 
 copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir)
 {
     if (n <= 0 || n > kWave) return COPRA_OK; // (the workgroup-per-problem kernel has no shape parameters)
+    std::lock_guard<std::mutex> lock(g_dense_jit_mu);
     for (int lanes : { 64, 32, 16 }) {
         if (lanes < n) continue;
         bool have = false;
@@ -1029,11 +1074,13 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             FusedPlan Pj = P;
             void* args[] = { &Pj };
             const unsigned per = 64u / (unsigned)h->jit_lanes;
+            LDS_OPT_IN(h->jit_shared, (size_t)per * h->hp.lds_bytes);
             HIP_TRY(hipModuleLaunchKernel(h->jit_shared, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
                 per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
         } else if (h->packed) {
             HIP_TRY(h->packed == 16 ? packed_launch_w16(P, true, h->hp.lds_bytes, s) : packed_launch_w32(P, true, h->hp.lds_bytes, s));
         } else {
+            LDS_OPT_IN(select_shared_kernel(P, false), h->hp.lds_bytes);
             hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
             HIP_TRY(hipGetLastError());
         }
@@ -1042,6 +1089,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             P2.lds = h->hp.lds_full;
             P2.from_list = 1;
             const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+            LDS_OPT_IN(select_shared_kernel(P2, true), h->hp.lds_full_bytes);
             hipLaunchKernelGGL(select_shared_kernel(P2, true), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
             HIP_TRY(hipGetLastError());
         }
@@ -1059,6 +1107,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
+        LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
         hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
             h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
@@ -1070,6 +1119,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         if (h->packed) {
             HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
         } else {
+            LDS_OPT_IN(copra_islmpc_fused_kernel, h->hp.lds_bytes);
             hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
             HIP_TRY(hipGetLastError());
         }
@@ -1082,11 +1132,13 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         FusedPlan Pj = P;
         void* args[] = { &Pj };
         const unsigned per = 64u / (unsigned)h->jit_lanes;
+        LDS_OPT_IN(h->jit_fused, (size_t)per * h->hp.lds_bytes);
         HIP_TRY(hipModuleLaunchKernel(h->jit_fused, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
             per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
     } else if (h->packed) {
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
     } else {
+        LDS_OPT_IN(select_fused_kernel(P), h->hp.lds_bytes);
         hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
     }
@@ -1096,6 +1148,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P2.lds = h->hp.lds_full;
         P2.from_list = 1;
         const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+        LDS_OPT_IN(select_tier2_kernel(P2), h->hp.lds_full_bytes);
         hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
         HIP_TRY(hipGetLastError());
     }
@@ -1205,13 +1258,17 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     P.lds = h->hp.lds_full;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    if (h->hp.large)
+    if (h->hp.large) {
+        LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
         hipLaunchKernelGGL(h->large_fn, dim3(1), dim3((unsigned)P.large.threads), h->hp.lds_bytes,
             h->last_stream, P);
-    else if (P.initial_state)
+    } else if (P.initial_state) {
+        LDS_OPT_IN(copra_islmpc_fused_kernel, h->hp.lds_full_bytes);
         hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
-    else
+    } else { // (P.lds is the full layout here: NOT the symbol the solve launches when that runs the factor-only tier)
+        LDS_OPT_IN(select_fused_kernel(P), h->hp.lds_full_bytes);
         hipLaunchKernelGGL(select_fused_kernel(P), dim3(1), dim3(64), h->hp.lds_full_bytes, h->last_stream, P);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     std::vector<double> hA((size_t)(mg ? mg : 1) * n), hb((size_t)(mg ? mg : 1));
@@ -1399,8 +1456,11 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     } else {
         const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, 0, false, lds_bytes);
         hipFunction_t jit = nullptr;
-        for (const DenseJit& d : g_dense_jit)
-            if (d.n == n && d.lanes == (pw ? pw : 64)) jit = d.fn;
+        {
+            std::lock_guard<std::mutex> lock(g_dense_jit_mu);
+            for (const DenseJit& d : g_dense_jit)
+                if (d.n == n && d.lanes == (pw ? pw : 64)) jit = d.fn;
+        }
         const unsigned per = pw ? 64u / (unsigned)pw : 1u;
         if (jit && (size_t)per * lds_bytes <= 48 * 1024) {
             DensePlan Pj = P;

@@ -418,6 +418,10 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     for (int i = lane; i <= S.rcap + 1 && i <= n + 1; i += kWave) S.uv[i] = 0.0;
     // rows [I; -I] with right-hand sides [XU; -XL] (QuadProgSolver.cpp:61-69): lane j keeps XU_j, XL_j
     const double ubj = rows.ub(lj), lbj = rows.lb(lj);
+    // XL_j == XU_j (the default x0 bounds of InitialStateLMPC, InitialStateLMPC.cpp:20-28): once one row of the pair is
+    // active the other one is its negative -- linearly dependent, its slack is rounding noise and never a violation
+    // (qpgen2 would otherwise try to add it, find no step and report "no solution" whenever the noise is negative)
+    const bool pinned = (ubj - lbj) <= 1e-12 * fmax(1.0, fabs(ubj)); // (an interval narrower than the noise counts as one)
     wave_sync();
 
     for (;;) {
@@ -455,7 +459,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             const double xj = S.xs[lane];
             double s = ubj - xj; // row mgen + j of [I]
             if (fabs(s) < vsmall) s = 0.0;
-            if (S.act[mgen + lane]) s = 0.0;
+            if (S.act[mgen + lane] || (pinned && S.act[mgen + n + lane])) s = 0.0;
             if (s < best) {
                 best = s;
                 best_i = mgen + lane;
@@ -463,7 +467,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             }
             s = xj - lbj; // row mgen + n + j of [-I]
             if (fabs(s) < vsmall) s = 0.0;
-            if (S.act[mgen + n + lane]) s = 0.0;
+            if (S.act[mgen + n + lane] || (pinned && S.act[mgen + lane])) s = 0.0;
             if (s < best) {
                 best = s;
                 best_i = mgen + n + lane;

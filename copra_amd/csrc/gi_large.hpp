@@ -361,6 +361,10 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
     for (int i = tid; i < meq; i += T) S.eqsgn[i] = 1.0;
     for (int i = tid; i <= n + 1; i += T) S.uv[i] = 0.0;
     const double ubj = own ? rows.ub(tid) : 0.0, lbj = own ? rows.lb(tid) : 0.0;
+    // XL_j == XU_j (the default x0 bounds of InitialStateLMPC, InitialStateLMPC.cpp:20-28): once one row of the pair is
+    // active the other one is its negative -- linearly dependent, its slack is rounding noise and never a violation
+    // (qpgen2 would otherwise try to add it, find no step and report "no solution" whenever the noise is negative)
+    const bool pinned = (ubj - lbj) <= 1e-12 * fmax(1.0, fabs(ubj)); // (an interval narrower than the noise counts as one)
     bt_sync();
     COPRA_LPROF_DECL;
 
@@ -397,7 +401,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             const double xj = S.xs[tid];
             double s = ubj - xj; // row mgen + j of [I]
             if (fabs(s) < vsmall) s = 0.0;
-            if (S.act[mgen + tid]) s = 0.0;
+            if (S.act[mgen + tid] || (pinned && S.act[mgen + n + tid])) s = 0.0;
             if (s < best) {
                 best = s;
                 best_i = mgen + tid;
@@ -405,7 +409,7 @@ COPRA_DEV int gl_active_set(const LargeSolver& S, int meq, int mgen, Rows& rows,
             }
             s = xj - lbj; // row mgen + n + j of [-I]
             if (fabs(s) < vsmall) s = 0.0;
-            if (S.act[mgen + n + tid]) s = 0.0;
+            if (S.act[mgen + n + tid] || (pinned && S.act[mgen + tid])) s = 0.0;
             if (s < best) {
                 best = s;
                 best_i = mgen + n + tid;

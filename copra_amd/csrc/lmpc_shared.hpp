@@ -59,6 +59,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (c < nx) acc += Pk[nx * c] * x0r[c];
+        for (int c = 16; c < nx; ++c) acc += Pk[nx * c] * x0[c]; // (xDim > 16: the tail straight from HBM)
         Xbar[row] = acc + M[m.Xi + row];
     }
     // ---- unconstrained minimiser: x = -Qinv (c0 + C1 x0 + C2 p) is affine in (x0, p); the prepare step multiplied it
@@ -69,6 +70,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (c < nx) acc += M[m.K1 + (size_t)c * n + lane] * x0r[c];
+        for (int c = 16; c < nx; ++c) acc += M[m.K1 + (size_t)c * n + lane] * x0[c];
         for (int t = 0; t < P.ncost; ++t) { // costs with per-instance references
             if (P.cost_p[t] && P.model_ref_off[t] >= 0) {
                 const double* pt = P.cost_p[t] + (size_t)inst * P.cost[t].rows;

@@ -351,7 +351,9 @@ class InitialStateLMPC(LMPC):
         super().__init__(ps_or_flag, flag)
         nx = self._ps.x_dim if self._ps is not None else 0
         self._R, self._r = np.zeros((nx, nx)), np.zeros(nx)  # InitialStateLMPC.cpp:20-28
-        self._x0lb = self._x0ub = None
+        # x0lb_ = x0ub_ = ps->x0 captured ONCE, at construction (InitialStateLMPC.cpp:20-28): a later x_init() does not
+        # move the default bounds
+        self._x0lb = self._x0ub = (np.array(self._ps.x0, dtype=np.float64) if self._ps is not None else None)
         self._x0_opt = np.zeros(0)
 
     def _initial_state_desc(self):

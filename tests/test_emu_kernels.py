@@ -349,6 +349,25 @@ def test_shared_model_fast_path(emu, oracle):
         assert _rel(re["control"][k], ro["control"]) <= RTOL
 
 
+def test_shared_model_fast_path_more_than_16_states(emu, oracle):
+    """xDim = 18 on the shared-model path (the x0 register cache of lmpc_shared.hpp holds 16 components; the tail is
+    read from memory): same answer as a fresh controller per instance"""
+    rng = np.random.default_rng(18)
+    nx, nu, N, b = 18, 1, 8, 4
+    A = np.eye(nx) + 0.05 * rng.standard_normal((nx, nx))
+    B = 0.3 * rng.standard_normal((nx, nu))
+    d = 0.01 * rng.standard_normal(nx)
+    x0 = rng.standard_normal((b, nx))
+    costs = [dict(kind="trajectory", M=np.eye(nx), p=np.zeros(nx), weights=np.ones(nx)),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-2])]
+    cstrs = [dict(kind="control_bound", lower=[-0.5], upper=[0.5])]
+    re = emu.lmpc_solve_shared(A, B, d, x0, N, costs, cstrs)
+    for k in range(b):
+        ro = oracle.lmpc_solve(A, B, d, x0[k], N, costs, cstrs)
+        assert re["status"][k] == ro["status"] == 0
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_per_instance_cost_references(emu, oracle):
     """copra_batch_set_cost_reference: every instance tracks its own goal (one TrajectoryCost(M, p_b) per LMPC in the
     reference).  One-wave kernel (compile-time and generic shape), InitialStateLMPC, and the workgroup kernel."""
@@ -519,3 +538,26 @@ def test_initial_state_lmpc_reference_test_problem(emu, oracle, full_size):
     re2 = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist2)
     ro2 = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"], initial_state=ist2)
     assert re2["status"][0] == ro2["status"] == 0 and _rel(re2["control"][0], ro2["control"]) <= RTOL
+
+
+def test_edge_cases_of_the_reference_path(emu, oracle):
+    """tests/edge_cases.py on the kernel bodies: quirk Q1 with a finite lower bound, duplicate rows, the linearly
+    dependent opposite pair (status parity), opposite state rows that x0 violates, default x0 bounds (x0lb == x0ub)"""
+    import edge_cases as E
+    pb, quirk, _ = E.finite_lower_trajectory_bound()
+    re, ro = _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], quirk)
+    assert ro["status"][0] == 0 and re["trajectory"][0].reshape(-1, 2)[:, 1].max() <= -4.0 + 1e-9
+    dup, opp = E.duplicate_and_opposite_rows()
+    _compare(emu, oracle, dup["A"], dup["B"], dup["d"], dup["x0"], dup["N"], dup["costs"], dup["cstrs"], same_iters=False)
+    re, ro = _compare(emu, oracle, opp["A"], opp["B"], opp["d"], opp["x0"], opp["N"], opp["costs"], opp["cstrs"],
+                      same_iters=False)
+    assert ro["status"][0] == 1
+    q = E.opposite_state_rows_infeasible()
+    re, ro = _compare(emu, oracle, q["A"], q["B"], q["d"], q["x0"], q["N"], q["costs"], q["cstrs"], same_iters=False)
+    assert ro["status"][0] == 1
+    pb = F.bounded_system("trajectory", N=12)
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"][None], x0ub=pb["x0"][None])
+    re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 12, pb["costs"], pb["cstrs"], initial_state=ist)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 12, pb["costs"], pb["cstrs"])  # the plain LMPC
+    assert re["status"][0] == 0 and np.abs(re["x0_opt"][0] - pb["x0"]).max() < 1e-12
+    assert _rel(re["control"][0], ro["control"]) <= RTOL

@@ -833,3 +833,94 @@ def test_run_time_specialisation(oracle, tmp_path):
     assert np.abs(before["control"] - after["control"]).max() <= 1e-9
     ro = oracle.lmpc_solve(w16["A"][7], w16["B"][7], w16["d"][7], w16["x0"][7], 16, w16["costs"], w16["cstrs"])
     assert ro["status"] == after["status"][7] == 0 and _rel(after["control"][7], ro["control"]) <= RTOL
+
+
+def test_r_quadprog_published_example_on_gpu():
+    """copra_qp_solve_dense_batch on the published example of R's quadprog::solve.QP (the qpgen2 code eigen-quadprog
+    wraps): solution 0.4761905 1.0476190 2.0952381, value -2.380952, iterations 3 0 -- third-party published vector"""
+    import edge_cases as E
+    from copra_amd import qp_solve_dense_batch
+    ex = E.R_QUADPROG_EXAMPLE
+    b = 5
+    x, fail, it = qp_solve_dense_batch(np.tile(ex["Q"], (b, 1, 1)), np.tile(ex["c"], (b, 1)), None, None,
+                                       np.tile(ex["Aineq"], (b, 1, 1)), np.tile(ex["bineq"], (b, 1)),
+                                       np.tile(ex["XL"], (b, 1)), np.tile(ex["XU"], (b, 1)))
+    assert (fail == 0).all() and (it == np.array(ex["iterations"])).all()
+    assert np.abs(x - ex["x_star"]).max() < 1e-13
+
+
+def test_edge_cases_of_the_reference_path_on_gpu(oracle):
+    """tests/edge_cases.py through the C ABI: quirk Q1 with a FINITE lower trajectory bound (constraints.cpp:289-296),
+    duplicate rows, the linearly dependent opposite pair (status parity), opposite state rows violated by x0 (status 1),
+    and the default x0 bounds of InitialStateLMPC (x0lb == x0ub, InitialStateLMPC.cpp:20-28)"""
+    import edge_cases as E
+    import fixtures as F
+    from copra_amd import BatchLMPC
+
+    def run(pb, cstrs, b=3, initial_state=None, bounds=None):
+        eng = BatchLMPC(2, 1, pb["N"], b, pb["costs"], cstrs, initial_state=initial_state)
+        eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)),
+                       np.tile(pb["x0"], (b, 1)))
+        if bounds is not None:
+            eng.set_initial_state_bounds(*bounds)
+        eng.solve()
+        return eng, eng.results()
+
+    pb, quirk, explicit = E.finite_lower_trajectory_bound()
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"])
+    eng, res = run(pb, quirk)
+    ro = oracle.lmpc_solve(*args, quirk)
+    assert (res["status"] == 0).all() and ro["status"] == 0
+    assert _rel(res["control"][1], ro["control"]) <= RTOL and _rel(res["trajectory"][1], ro["trajectory"]) <= RTOL
+    assert res["trajectory"][1].reshape(-1, 2)[:, 1].max() <= -4.0 + 1e-9  # "lower" acts as an upper limit
+    qp, qo = eng.dump_qp(0), oracle.lmpc_build(*args, quirk)
+    assert np.abs(qp["Aineq"] - qo["Aineq"]).max() <= 1e-12 and np.abs(qp["bineq"] - qo["bineq"]).max() <= 1e-12
+
+    dup, opp = E.duplicate_and_opposite_rows()
+    _, res = run(dup, dup["cstrs"])
+    ro = oracle.lmpc_solve(dup["A"], dup["B"], dup["d"], dup["x0"], dup["N"], dup["costs"], dup["cstrs"])
+    assert (res["status"] == 0).all() and _rel(res["control"][2], ro["control"]) <= RTOL
+    _, res = run(opp, opp["cstrs"])
+    ro = oracle.lmpc_solve(opp["A"], opp["B"], opp["d"], opp["x0"], opp["N"], opp["costs"], opp["cstrs"])
+    assert ro["status"] == 1 and (res["status"] == 1).all()
+    q = E.opposite_state_rows_infeasible()
+    _, res = run(q, q["cstrs"])
+    assert (res["status"] == 1).all()
+
+    pb = F.bounded_system("trajectory", N=12)
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))
+    eng, res = run(pb, pb["cstrs"], initial_state=ist)  # bounds never set: x0lb = x0ub = x0
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 12, pb["costs"], pb["cstrs"])  # == the plain LMPC
+    assert (res["status"] == 0).all()
+    assert np.abs(eng.initial_state() - pb["x0"]).max() < 1e-12
+    assert _rel(res["control"][0], ro["control"]) <= RTOL
+    # the same at 152 variables (workgroup-per-instance kernel)
+    pl = F.bounded_system("trajectory", N=150)
+    eng, res = run(pl, pl["cstrs"], b=2, initial_state=ist)
+    ro = oracle.lmpc_solve(pl["A"], pl["B"], pl["d"], pl["x0"], 150, pl["costs"], pl["cstrs"])
+    assert (res["status"] == 0).all() and np.abs(eng.initial_state() - pl["x0"]).max() < 1e-12
+    assert _rel(res["control"][0], ro["control"]) <= RTOL
+
+
+def test_shared_model_more_than_16_states(oracle):
+    """xDim = 18 on the shared-model path (lmpc_shared.hpp keeps 16 components of x0 in registers, the tail comes from
+    memory) against a fresh controller per instance"""
+    from copra_amd import BatchLMPC
+    rng = np.random.default_rng(18)
+    nx, nu, N, b = 18, 1, 8, 6
+    A = np.eye(nx) + 0.05 * rng.standard_normal((nx, nx))
+    B = 0.3 * rng.standard_normal((nx, nu))
+    d = 0.01 * rng.standard_normal(nx)
+    x0 = rng.standard_normal((b, nx))
+    costs = [dict(kind="trajectory", M=np.eye(nx), p=np.zeros(nx), weights=np.ones(nx)),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-2])]
+    cstrs = [dict(kind="control_bound", lower=[-0.5], upper=[0.5])]
+    eng = BatchLMPC(nx, nu, N, b, costs, cstrs)
+    eng.set_shared_system(A, B, d)
+    eng.set_x0(x0)
+    eng.solve()
+    res = eng.results()
+    for k in range(b):
+        ro = oracle.lmpc_solve(A, B, d, x0[k], N, costs, cstrs)
+        assert res["status"][k] == ro["status"] == 0
+        assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL

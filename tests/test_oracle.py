@@ -179,3 +179,54 @@ def test_status_codes(oracle):
     pb = F.bounded_system("target", N=10)
     pb["costs"][0]["weights"] = [-1e9, -1e9]
     assert _solve(oracle, pb)["status"] == 2
+
+
+def test_r_quadprog_published_example(oracle):
+    """The published example of R's quadprog::solve.QP -- the qpgen2 code that eigen-quadprog wraps (third-party,
+    published: solution 0.4761905 1.0476190 2.0952381, value -2.380952, iterations 3 0): pins the Goldfarb-Idnani
+    restatement of the oracle including its iteration count"""
+    import edge_cases as E
+    ex = E.R_QUADPROG_EXAMPLE
+    x, fail, it = oracle.quadprog_dense(ex["Q"], ex["c"], None, None, ex["Aineq"], ex["bineq"], ex["XL"], ex["XU"])
+    assert fail == 0 and tuple(it) == ex["iterations"]
+    assert np.abs(x - ex["x_star"]).max() < 1e-14
+    assert abs(0.5 * x @ ex["Q"] @ x + ex["c"] @ x - ex["f_star"]) < 1e-14
+
+
+def test_finite_lower_trajectory_bound_quirk_q1(oracle):
+    """src/constraints.cpp:289-296: a finite LOWER trajectory bound is stacked as x <= lower.  The oracle's rows equal the
+    same constraint written as explicit TrajectoryConstraint objects, bit for bit, and the rows are active"""
+    import edge_cases as E
+    pb, quirk, explicit = E.finite_lower_trajectory_bound()
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"])
+    a, b = oracle.lmpc_build(*args, quirk), oracle.lmpc_build(*args, explicit)
+    assert a["nineq"] == b["nineq"] == 3 * (pb["N"] + 1)
+    assert np.array_equal(a["Aineq"], b["Aineq"]) and np.array_equal(a["bineq"], b["bineq"])
+    ra, rb = oracle.lmpc_solve(*args, quirk), oracle.lmpc_solve(*args, explicit)
+    assert ra["status"] == rb["status"] == 0 and np.array_equal(ra["control"], rb["control"])
+    v = ra["trajectory"].reshape(-1, 2)[:, 1]
+    assert v.max() <= -4.0 + 1e-9 and (np.abs(v + 4.0) < 1e-9).sum() >= 3  # "lower" acts as an upper limit
+
+
+def test_degenerate_rows(oracle):
+    import edge_cases as E
+    dup, opp = E.duplicate_and_opposite_rows()
+    r = oracle.lmpc_solve(dup["A"], dup["B"], dup["d"], dup["x0"], dup["N"], dup["costs"], dup["cstrs"])
+    ref = oracle.lmpc_solve(dup["A"], dup["B"], dup["d"], dup["x0"], dup["N"], dup["costs"], dup["cstrs"][1:])
+    assert r["status"] == ref["status"] == 0 and np.abs(r["control"] - ref["control"]).max() < 1e-9
+    r = oracle.lmpc_solve(opp["A"], opp["B"], opp["d"], opp["x0"], opp["N"], opp["costs"], opp["cstrs"])
+    assert r["status"] == 1  # qpgen2 semantics on the linearly dependent pair (see edge_cases.py)
+    q = E.opposite_state_rows_infeasible()
+    assert oracle.lmpc_solve(q["A"], q["B"], q["d"], q["x0"], q["N"], q["costs"], q["cstrs"])["status"] == 1
+
+
+def test_initial_state_default_bounds_pin_x0(oracle):
+    """InitialStateLMPC.cpp:20-28: without resetInitialStateBounds x0lb = x0ub = ps->x0, i.e. x0 is pinned and the
+    controls are those of the plain LMPC (c = E'x0 + f, costFunctions.cpp:80)"""
+    pb = F.bounded_system("trajectory", N=12)
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"], x0ub=pb["x0"])
+    a, b = oracle.lmpc_solve(*args, initial_state=ist), oracle.lmpc_solve(*args)
+    assert a["status"] == b["status"] == 0
+    assert np.abs(a["x0_opt"] - pb["x0"]).max() < 1e-12
+    assert np.abs(a["control"] - b["control"]).max() < 1e-7 * (1 + np.abs(b["control"]).max())
