@@ -245,6 +245,10 @@ def lib():
         L.copra_device_info.restype = C.c_int
         L.copra_device_info.argtypes = [_ip, _ip, C.c_char_p, C.c_int]
         L.copra_abi_version.restype = C.c_int
+        L.copra_batch_select_solver.restype = C.c_int
+        L.copra_batch_select_solver.argtypes = [vp, C.c_int]
+        L.copra_batch_solver_info.restype = C.c_int
+        L.copra_batch_solver_info.argtypes = [vp]
         _lib = L
     return _lib
 

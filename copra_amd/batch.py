@@ -155,6 +155,19 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_set_outputs(self._h, control.data_ptr(), trajectory.data_ptr(),
                                                       status.data_ptr(), iters.data_ptr()))
 
+    SOLVERS = {"default": 0, "quadprog_dense": 1, "riccati_ipm": 2}
+
+    def select_solver(self, solver):
+        """LMPC::selectQPSolver (src/LMPC.cpp:62-65) for the batch: "default" (the engine picks: condensed
+        Goldfarb-Idnani up to 64 variables, the stage-wise Riccati interior-point kernel for long horizons when the
+        controller is stage-wise), "quadprog_dense" (always Goldfarb-Idnani: the reference's QuadProgDense arithmetic and
+        iteration counts) or "riccati_ipm" (CopraUnsupported when the controller is not stage-wise)."""
+        _capi.check(self._lib.copra_batch_select_solver(self._h, self.SOLVERS[solver] if isinstance(solver, str) else int(solver)))
+
+    def solver(self):
+        """the solver the next solve() runs: 'quadprog_dense' or 'riccati_ipm'"""
+        return {1: "quadprog_dense", 2: "riccati_ipm"}[self._lib.copra_batch_solver_info(self._h)]
+
     def solve(self, stream=None):
         """LMPC::solve for the whole batch; asynchronous on `stream` (an integer hipStream_t handle or None)"""
         _capi.check(self._lib.copra_batch_solve(self._h, C.c_void_p(stream or 0)))

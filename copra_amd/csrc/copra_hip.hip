@@ -6,6 +6,7 @@
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
 #include "lmpc_large.hpp"
+#include "lmpc_riccati.hpp"
 #include "lmpc_shared.hpp"
 #include "packed_launch.hpp"
 #include "plan_builder.hpp"
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(kLargeMaxN) void copra_lmpc_large_kernel(const Fuse
 // 35.0 k -> 41.2 k solves/s.  Used whenever the LDS footprint lets two workgroups share a CU.
 __global__ __launch_bounds__(kLargeMaxN, 4) void copra_lmpc_large_kernel_w4(const FusedPlan P) { lmpc_large_body(P); }
 
+// Long horizons whose pieces are all stage-wise (stage_plan.hpp): Riccati interior-point method, one instance per
+// wavefront, persistent grid (lmpc_riccati.hpp); the instances it does not converge on are queued for the kernel above.
+__global__ __launch_bounds__(64, 4) void copra_lmpc_riccati_kernel(const FusedPlan P, const StagePlan S) { lmpc_riccati_body(P, S); }
+
 // n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
 // more than four waves per workgroup: 128-VGPR build so that two workgroups share a CU (see copra_lmpc_large_kernel_w4)
@@ -303,6 +308,14 @@ struct copra_batch {
     // InitialStateLMPC variant
     double *d_isR = nullptr, *d_isr = nullptr, *d_x0opt = nullptr, *own_x0lb = nullptr, *own_x0ub = nullptr;
     const double *x0lb = nullptr, *x0ub = nullptr;
+    // stage-wise Riccati interior-point path (copra_batch_select_solver; lmpc_riccati.hpp)
+    int solver = COPRA_SOLVER_DEFAULT;
+    HostStagePlan hs;
+    bool ric_built = false; // hs describes this controller (eligible or not) ...
+    bool ric_all_bounds = false; // ... with bound rows for every control
+    std::vector<void*> ric_dev; // device copies of its tables
+    double* d_ric_ws = nullptr;
+    int ric_grid = 0;
     long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -419,9 +432,116 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
     return COPRA_OK;
 }
 
+// (Re)build the stage plan of a controller and put its tables on the device.  The plan depends on whether per-instance
+// control bounds exist (then every control gets both bound rows, infinite ones are switched off per instance).
+static copra_status_t prepare_riccati(copra_batch* h)
+{
+    const bool all_bounds = h->d_lb_inst != nullptr;
+    if (h->ric_built && h->ric_all_bounds == all_bounds) return COPRA_OK;
+    for (void* q : h->ric_dev) (void)hipFree(q);
+    h->ric_dev.clear();
+    (void)hipFree(h->d_ric_ws);
+    h->d_ric_ws = nullptr;
+    build_stage_plan(h->hp, h->hs, all_bounds);
+    h->ric_built = true;
+    h->ric_all_bounds = all_bounds;
+    if (!h->hs.eligible) return COPRA_OK;
+    HostStagePlan& hs = h->hs;
+    hipError_t e = hipSuccess;
+    auto upi = [&](const std::vector<int>& v) -> const int* {
+        int* dptr = nullptr;
+        hipError_t r = upload(&dptr, v);
+        if (r != hipSuccess && e == hipSuccess) e = r;
+        h->ric_dev.push_back(dptr);
+        return dptr;
+    };
+    auto upd = [&](const std::vector<double>& v) -> const double* {
+        double* dptr = nullptr;
+        hipError_t r = upload(&dptr, v);
+        if (r != hipSuccess && e == hipSuccess) e = r;
+        h->ric_dev.push_back(dptr);
+        return dptr;
+    };
+    StagePlan& sp = hs.sp;
+    sp.cls_of_stage = upi(hs.cls_of_stage);
+    sp.stage_row0 = upi(hs.stage_row0);
+    sp.cls_W = upi(hs.cls_W);
+    sp.cls_crow0 = upi(hs.cls_crow0);
+    sp.cls_row0 = upi(hs.cls_row0);
+    sp.cls_ndense = upi(hs.cls_ndense);
+    sp.cr_aoff = upi(hs.cr_aoff);
+    sp.cr_cost = upi(hs.cr_cost);
+    sp.cr_pidx = upi(hs.cr_pidx);
+    sp.cr_w = upd(hs.cr_w);
+    sp.r_kind = upi(hs.r_kind);
+    sp.r_aoff = upi(hs.r_aoff);
+    sp.r_sign = upd(hs.r_sign);
+    sp.r_eq = upi(hs.r_eq);
+    sp.r_src = upi(hs.r_src);
+    sp.r_sidx = upi(hs.r_sidx);
+    sp.r_sstride = upi(hs.r_sstride);
+    sp.blob = upd(hs.blob);
+    // persistent grid: as many one-wave workgroups as the device keeps resident
+    const size_t lds_bytes = (size_t)sp.lds_doubles * sizeof(double);
+    if (e == hipSuccess) e = lds_opt_in(reinterpret_cast<const void*>(copra_lmpc_riccati_kernel), lds_bytes);
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(copra_lmpc_riccati_kernel), 64, lds_bytes)
+            != hipSuccess
+        || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    if (const char* force = std::getenv("COPRA_RICCATI_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
+    long long g = (long long)cus * per_cu;
+    const int batch = h->hp.plan.batch > 0 ? h->hp.plan.batch : 1;
+    h->ric_grid = (int)(g < batch ? g : batch);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (size_t)sp.ws_total * sizeof(double));
+    sp.ws = h->d_ric_ws;
+    if (std::getenv("COPRA_DEBUG"))
+        fprintf(stderr, "[copra] riccati path: %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n", sp.ncls,
+            sp.m, h->ric_grid, per_cu, lds_bytes, sp.ws_total * 8LL);
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("riccati path: ") + hipGetErrorString(e));
+    return COPRA_OK;
+}
+
+// does the next solve of this controller run the Riccati interior-point kernel?
+static bool use_riccati(copra_batch* h)
+{
+    if (h->solver == COPRA_SOLVER_QUADPROG_DENSE || h->shared) return false;
+    if (h->solver == COPRA_SOLVER_DEFAULT && (!h->hp.large || std::getenv("COPRA_NO_RICCATI"))) return false;
+    if (prepare_riccati(h) != COPRA_OK) return false;
+    return h->hs.eligible;
+}
+
 extern "C" {
 
-int copra_abi_version(void) { return 1; }
+int copra_abi_version(void) { return 2; }
+
+copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_select_solver: null handle");
+    if (solver != COPRA_SOLVER_DEFAULT && solver != COPRA_SOLVER_QUADPROG_DENSE && solver != COPRA_SOLVER_RICCATI_IPM)
+        return fail(COPRA_ERR_ARG, "copra_batch_select_solver: unknown solver flag");
+    if (solver == COPRA_SOLVER_RICCATI_IPM) {
+        const copra_status_t rc = prepare_riccati(h);
+        if (rc != COPRA_OK) return rc;
+        if (!h->hs.eligible)
+            return fail(COPRA_ERR_UNSUPPORTED, "the Riccati interior-point solver needs a stage-wise controller: " + h->hs.why);
+        if (!h->hp.large) // the queue of non-converged instances is finished by the workgroup-per-instance kernel
+            return fail(COPRA_ERR_UNSUPPORTED, "the Riccati interior-point solver covers controllers with more than 64 decision variables");
+    }
+    h->solver = solver;
+    return COPRA_OK;
+}
+
+int copra_batch_solver_info(const copra_batch_t* h)
+{
+    if (!h) return -1;
+    return use_riccati(const_cast<copra_batch_t*>(h)) ? COPRA_SOLVER_RICCATI_IPM : COPRA_SOLVER_QUADPROG_DENSE;
+}
 
 const char* copra_last_error(void) { return g_err.c_str(); }
 
@@ -553,6 +673,8 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_lb_inst);
     (void)hipFree(h->d_ub_inst);
     (void)hipFree(h->d_ws);
+    for (void* q : h->ric_dev) (void)hipFree(q);
+    (void)hipFree(h->d_ric_ws);
     (void)hipFree(h->d_shA);
     (void)hipFree(h->d_shB);
     (void)hipFree(h->d_shd);
@@ -1107,6 +1229,23 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (rc != COPRA_OK) return rc;
     HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
+        if (use_riccati(h)) {
+            // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
+            const size_t ric_lds = (size_t)h->hs.sp.lds_doubles * sizeof(double);
+            HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
+            LDS_OPT_IN(copra_lmpc_riccati_kernel, ric_lds);
+            hipLaunchKernelGGL(copra_lmpc_riccati_kernel, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
+            HIP_TRY(hipGetLastError());
+            FusedPlan P2 = P;
+            P2.from_list = 1;
+            LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
+            hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+                h->hp.lds_bytes, s, P2);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(h->ev1, s));
+            h->timed = true;
+            return COPRA_OK;
+        }
         LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
         hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
             h->hp.lds_bytes, s, P);

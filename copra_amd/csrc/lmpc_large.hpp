@@ -419,7 +419,10 @@ COPRA_DEV void lmpc_large_body(const FusedPlan& P)
     LargeSolver S = carve_large(lds, L.sol, nv, Jg, F);
     const int nPhi = nx * nx, nG = nx * nu;
 
-    for (int inst = P.inst_offset + instance_id(); inst < P.batch; inst += instance_stride()) {
+    // (second tier of the Riccati interior-point path: the instances it queued, P.from_list)
+    const int work = P.from_list ? *P.ovf_count : P.batch;
+    for (int witem = P.inst_offset + instance_id(); witem < work; witem += instance_stride()) {
+        const int inst = P.from_list ? P.ovf_list[witem] : witem;
         long long stamp[8];
         stamp[0] = cycle_counter();
 #ifdef COPRA_FINE_PROFILE

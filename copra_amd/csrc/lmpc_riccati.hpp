@@ -1,0 +1,647 @@
+// lmpc_riccati.hpp -- long-horizon LMPC / InitialStateLMPC WITHOUT condensing: a primal-dual interior-point method whose
+// Newton systems are solved by a Riccati recursion over the stages.  ONE instance per 64-lane
+// wavefront, persistent grid over the batch; the stage plan (stage_plan.hpp) is shared by the batch.
+//
+// What it replaces, for controllers with more than 64 decision variables whose pieces are all stage-wise
+// (stage_plan.hpp): the whole call stack of LMPC::solve (src/LMPC.cpp:79-101) --
+//   PreviewSystem::updateSystem + every cost->update / constraint->update + makeQPForm + QuadProgDense
+// The reference builds Psi (X x n), the n x n Hessian and hands the dense QP to Goldfarb-Idnani: at BASELINE config 5
+// (nx=12, nu=6, N=50, InitialStateLMPC) that is a 312 x 312 inverse factor swept ~1000 times per solve (600 additions,
+// 440 drops).  Here the same optimum is the fixed point of ~20 Newton steps, each ONE backward factorisation sweep over
+// the 50 stages (18 x 18 blocks) plus three vector sweeps: O(N (nx+nu)^3) per step, nothing of size n x n exists.
+// The QP is strictly convex, so the optimum is unique: U, X, x0* equal the reference's to solver accuracy (measured
+// against 60-digit truth vectors, tests/golden/config5_truth.npz: 5e-15 in the numpy prototype of this algorithm, where
+// the CPU Goldfarb-Idnani path is 1e-5 away); iteration counts are NOT comparable (status: 0, iter = (Newton steps, 0)).
+// An instance that does not converge (infeasible problems make an interior-point method stall) is queued for the
+// condensed Goldfarb-Idnani kernel, which reports the reference's status code for it.
+//
+// Algorithm (Mehrotra predictor-corrector on  min sum_k 1/2 z_k'W_k z_k + q_k'z_k  s.t. dynamics, rows a_i'z <= f_i):
+//   slacks s, multipliers lam per inequality row; D = lam / s; equality rows by a proximal multiplier iteration
+//   (weight 1/delta on the row, nu += residual / delta);
+//   stage Hessian  H_k = W_k + sum_i D_i a_i a_i',  gradient  g_k = W_k z_k + q_k + sum_i a_i c_i;
+//   backward:  M = H_k + [A B]' P_{k+1} [A B],  h = g_k + [A B]' p_{k+1};   K = -Muu^-1 Mux,  kv = -Muu^-1 hu;
+//              P_k = Mxx + Mux' K,  p_k = hx + Mux' kv;     forward:  du = K dx + kv,  dx+ = A dx + B du.
+//   The iterate always satisfies the dynamics (the steps do), so no costates are carried.
+// InitialStateLMPC (src/InitialStateLMPC.cpp:77-122): the reference's objective is
+//   1/2 U'QU + x0'E U + f'U + 1/2 x0'(R + E Q^-1 E')x0 + r'x0,  while the stage-wise cost is
+//   1/2 U'QU + (E'x0 + f)'U + 1/2 x0'S x0 + g0'x0;  the difference  1/2 x0'(R - P0) x0 + (r - g0)'x0  with
+//   P0 = S - E Q^-1 E' (the UNCONSTRAINED cost-to-go Hessian: one Riccati sweep without rows) and g0 (one adjoint sweep)
+//   is added at stage 0.
+#pragma once
+
+#include "plan.hpp"
+#include "stage_plan.hpp"
+#include "wave_prims.hpp"
+
+namespace copra_hip {
+
+struct RicLds {
+    double *AB, *Pm, *T, *M, *pv, *h, *g, *zk, *dzk, *dxn, *dv, *Kl, *Mi, *rowD, *rowC;
+};
+
+COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S)
+{
+    const int nx = S.nx, nu = S.nu, nz = S.nz;
+    auto a2 = [](int v) { return (v + 1) & ~1; };
+    RicLds L;
+    double* p = lds;
+    L.AB = p, p += a2(nx * nz);
+    L.Pm = p, p += a2(nx * nx);
+    L.T = p, p += a2(nx * nz > 2 * nu * nu ? nx * nz : 2 * nu * nu); // (also the Gauss-Jordan scratch, nu x 2 nu)
+    L.M = p, p += a2(nz * nz);
+    L.pv = p, p += a2(nz);
+    L.h = p, p += a2(nz);
+    L.g = p, p += a2(nz);
+    L.zk = p, p += a2(nz);
+    L.dzk = p, p += a2(nz);
+    L.dxn = p, p += a2(nz);
+    L.dv = p, p += a2(nz);
+    L.Kl = p, p += a2(nu * nx);
+    L.Mi = p, p += a2(nu * nu);
+    const int mr = S.max_stage_rows > 0 ? S.max_stage_rows : 1;
+    L.rowD = p, p += a2(mr);
+    L.rowC = p, p += a2(mr);
+    return L;
+}
+
+// flags of a row of ONE instance
+enum { kRowIneq = 0, kRowEq = 1, kRowOff = 2 };
+
+COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
+{
+    const int lane = lane_id();
+    const int nx = S.nx, nu = S.nu, nz = S.nz, N = S.N, m = S.m;
+    const int NZ = (N + 1) * nz;
+    double* lds = lds_base();
+    const RicLds L = carve_riccati(lds, S);
+    double* ws = S.ws + (size_t)instance_id() * (size_t)S.ws_total;
+    double *Z = ws + S.oZ, *DZ = ws + S.oDZ, *Q = ws + S.oQ, *GB = ws + S.oGB;
+    double *F = ws + S.oF, *Sv = ws + S.oS, *Lam = ws + S.oLam, *DS = ws + S.oDS, *DL = ws + S.oDL, *RP = ws + S.oRP;
+    double* Flag = ws + S.oFlag;
+    double *Kg = ws + S.oK, *Mig = ws + S.oMi, *Kvg = ws + S.oKv, *H0 = ws + S.oH0, *G0 = ws + S.oG0;
+    const double* blob = S.blob;
+    const double delta = S.delta;
+    const double BIGF = 1e299;
+
+    for (int inst = instance_id(); inst < P.batch; inst += instance_stride()) {
+        // ------------------------------------------------------------------ 0. this instance's data
+        const bool x0_free = S.x0_free && P.x0lb && P.x0ub; // (bounds never set: x0lb = x0ub = ps->x0, i.e. x0 is fixed)
+        for (int e = lane; e < nx * nx; e += kWave) L.AB[e] = P.A[(size_t)inst * nx * nx + e];
+        for (int e = lane; e < nx * nu; e += kWave) L.AB[nx * nx + e] = P.B[(size_t)inst * nx * nu + e];
+        double* dvec = L.dv;
+        // right-hand sides and row states
+        for (int k = 0; k <= N; ++k) {
+            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+            for (int r = lane; r < nr; r += kWave) {
+                const int t = r0 + r, idx = S.r_sidx[t] + S.r_sstride[t] * k;
+                double f;
+                switch (S.r_src[t]) {
+                case kSrcRowF: f = P.row_f_inst ? P.row_f_inst[(size_t)inst * P.mgen + idx] : P.row_f[idx]; break;
+                case kSrcUb: f = P.ub_inst ? P.ub_inst[(size_t)inst * P.n + idx] : P.ub[idx]; break;
+                case kSrcNegLb: f = -(P.lb_inst ? P.lb_inst[(size_t)inst * P.n + idx] : P.lb[idx]); break;
+                case kSrcX0Ub: f = x0_free ? P.x0ub[(size_t)inst * nx + idx] : BIGF; break;
+                default: f = x0_free ? -P.x0lb[(size_t)inst * nx + idx] : BIGF; break;
+                }
+                F[gi0 + r] = f;
+                Flag[gi0 + r] = (f >= BIGF) ? (double)kRowOff : (S.r_eq[t] ? (double)kRowEq : (double)kRowIneq);
+            }
+        }
+        wave_sync();
+        // a bound pair  lb == ub  (up to rounding) is one equality row: the upper row becomes it, the lower row is off
+        for (int k = 0; k <= N; ++k) {
+            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+            for (int r = lane; r < nr; r += kWave) {
+                const int t = r0 + r;
+                if (r == 0 || S.r_kind[t] != 1 || S.r_kind[t - 1] != 1 || S.r_aoff[t] != S.r_aoff[t - 1]) continue;
+                if (!(S.r_sign[t - 1] == 1.0 && S.r_sign[t] == -1.0)) continue;
+                if (Flag[gi0 + r] != (double)kRowIneq || Flag[gi0 + r - 1] != (double)kRowIneq) continue;
+                const double up = F[gi0 + r - 1], lo = -F[gi0 + r];
+                if (up - lo <= 1e-12 * fmax(1.0, fabs(up))) {
+                    Flag[gi0 + r - 1] = (double)kRowEq;
+                    Flag[gi0 + r] = (double)kRowOff;
+                }
+            }
+        }
+        // q_k = - sum_rows w p a  (costFunctions.cpp: the p-dependent part of the gradient)
+        for (int e = lane; e < NZ; e += kWave) {
+            const int k = e / nz, i = e - k * nz;
+            const int c = S.cls_of_stage[k];
+            double acc = 0.0;
+            for (int t = S.cls_crow0[c]; t < S.cls_crow0[c + 1]; ++t) {
+                const int ct = S.cr_cost[t];
+                const double pv = P.cost_p[ct] ? P.cost_p[ct][(size_t)inst * P.cost[ct].rows + S.cr_pidx[t]]
+                                               : P.params[P.cost[ct].offP + S.cr_pidx[t]];
+                acc -= S.cr_w[t] * pv * blob[S.cr_aoff[t] + i];
+            }
+            Q[e] = acc;
+        }
+        for (int e = lane; e < nx; e += kWave) dvec[e] = P.d[(size_t)inst * nx + e];
+        wave_sync();
+
+        // ---- helpers -------------------------------------------------------------------------------------------
+        // a_t' v for row template t (v: nz values in LDS)
+        auto row_dot = [&](int t, const double* v) -> double {
+            if (S.r_kind[t] == 1) return S.r_sign[t] * v[S.r_aoff[t]];
+            const double* a = blob + S.r_aoff[t];
+            double acc = 0.0;
+            for (int j = 0; j < nz; ++j) acc += a[j] * v[j];
+            return acc;
+        };
+        // x_{k+1} = A x_k + B u_k + d along Z (u as stored), from Z[0..nx)
+        auto rollout = [&]() {
+            for (int k = 0; k < N; ++k) {
+                for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
+                wave_sync();
+                for (int i = lane; i < nx; i += kWave) {
+                    double acc = dvec[i];
+                    for (int j = 0; j < nz; ++j) acc += L.AB[i + nx * j] * L.zk[j];
+                    Z[(k + 1) * nz + i] = acc;
+                }
+                wave_sync();
+            }
+        };
+        // One stage of the backward factorisation.  Before: zk holds z_k (u-part 0 at k = N), rowD / rowC the weights and
+        // gradient coefficients of the stage's rows, Pm / pv the cost-to-go of stage k + 1.  After: Pm / pv of stage k;
+        // K, Muu^-1, kv stored for the forward sweeps.  Returns false when Muu is not positive definite.
+        auto stage_gradient = [&](int k, bool with_rows, bool store_gb) {
+            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
+            const double* Wk = blob + S.cls_W[c];
+            for (int i = lane; i < nz; i += kWave) {
+                double gb;
+                if (store_gb) {
+                    gb = Q[k * nz + i];
+                    for (int j = 0; j < nz; ++j) gb += Wk[i + nz * j] * L.zk[j];
+                    if (k == 0 && x0_free && i < nx) { // InitialStateLMPC: + (R - P0) x0 + (r - g0)
+                        gb += G0[i];
+                        for (int j = 0; j < nx; ++j) gb += H0[i + nx * j] * L.zk[j];
+                    }
+                    GB[k * nz + i] = gb;
+                } else {
+                    gb = GB[k * nz + i];
+                }
+                if (with_rows) {
+                    for (int r = 0; r < nd; ++r) gb += L.rowC[r] * blob[S.r_aoff[r0 + r] + i];
+                    for (int r = nd; r < nr; ++r)
+                        if (S.r_aoff[r0 + r] == i) gb += S.r_sign[r0 + r] * L.rowC[r];
+                }
+                L.g[i] = gb;
+            }
+        };
+        auto stage_factor = [&](int k, bool with_rows) -> bool {
+            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
+            const double* Wk = blob + S.cls_W[c];
+            // H = W + sum D a a'
+            for (int e = lane; e < nz * nz; e += kWave) {
+                const int j = e / nz, i = e - j * nz;
+                double acc = Wk[e];
+                if (with_rows) {
+                    for (int r = 0; r < nd; ++r) {
+                        const double* a = blob + S.r_aoff[r0 + r];
+                        acc += L.rowD[r] * a[i] * a[j];
+                    }
+                    if (i == j)
+                        for (int r = nd; r < nr; ++r)
+                            if (S.r_aoff[r0 + r] == i) acc += L.rowD[r];
+                }
+                L.M[e] = acc;
+            }
+            if (k == N) { // P_N = Hxx, p_N = g_x
+                wave_sync();
+                for (int e = lane; e < nx * nx; e += kWave) {
+                    const int j = e / nx, i = e - j * nx;
+                    L.Pm[e] = L.M[i + nz * j];
+                }
+                for (int i = lane; i < nx; i += kWave) L.pv[i] = L.g[i];
+                wave_sync();
+                return true;
+            }
+            // T = P [A B]
+            for (int e = lane; e < nx * nz; e += kWave) {
+                const int j = e / nx, i = e - j * nx;
+                double acc = 0.0;
+                for (int l = 0; l < nx; ++l) acc += L.Pm[i + nx * l] * L.AB[l + nx * j];
+                L.T[e] = acc;
+            }
+            wave_sync();
+            // M = H + [A B]' T ;  h = g + [A B]' p
+            for (int e = lane; e < nz * nz; e += kWave) {
+                const int b = e / nz, a = e - b * nz;
+                double acc = L.M[e];
+                for (int l = 0; l < nx; ++l) acc += L.AB[l + nx * a] * L.T[l + nx * b];
+                L.M[e] = acc;
+            }
+            for (int a = lane; a < nz; a += kWave) {
+                double acc = L.g[a];
+                for (int l = 0; l < nx; ++l) acc += L.AB[l + nx * a] * L.pv[l];
+                L.h[a] = acc;
+            }
+            wave_sync();
+            // Muu^-1 by Gauss-Jordan on [Muu | I] (Muu is symmetric positive definite: no pivoting); Kl is the scratch
+            // (nu x 2 nu <= nu x nx is not guaranteed: use T, which is free again)
+            double* GJ = L.T; // nu x 2nu, row-major with leading dimension 2 nu
+            const int w2 = 2 * nu;
+            for (int e = lane; e < nu * w2; e += kWave) {
+                const int r = e / w2, cc = e - r * w2;
+                GJ[e] = (cc < nu) ? L.M[(nx + r) + nz * (nx + cc)] : ((cc - nu == r) ? 1.0 : 0.0);
+            }
+            wave_sync();
+            bool ok = true;
+            for (int p = 0; p < nu; ++p) {
+                const double piv = GJ[p * w2 + p];
+                if (!(piv > 0.0)) ok = false;
+                const double ip = 1.0 / piv;
+                wave_sync();
+                // eliminate column p from every other row; scale row p
+                for (int e = lane; e < nu * w2; e += kWave) {
+                    const int r = e / w2, cc = e - r * w2;
+                    if (r == p) continue;
+                    const double fct = GJ[r * w2 + p] * ip;
+                    if (cc != p) GJ[e] -= fct * GJ[p * w2 + cc];
+                }
+                wave_sync();
+                for (int e = lane; e < nu * w2; e += kWave) {
+                    const int r = e / w2, cc = e - r * w2;
+                    if (r == p)
+                        GJ[e] *= ip;
+                    else if (cc == p)
+                        GJ[e] = 0.0;
+                }
+                wave_sync();
+            }
+            for (int e = lane; e < nu * nu; e += kWave) {
+                const int cc = e / nu, r = e - cc * nu;
+                const double v = 0.5 * (GJ[r * w2 + nu + cc] + GJ[cc * w2 + nu + r]);
+                L.Mi[e] = v;
+                Mig[(size_t)k * nu * nu + e] = v;
+            }
+            wave_sync();
+            // K = -Muu^-1 Mux (nu x nx), kv = -Muu^-1 hu
+            for (int e = lane; e < nu * nx; e += kWave) {
+                const int j = e / nu, i = e - j * nu;
+                double acc = 0.0;
+                for (int l = 0; l < nu; ++l) acc += L.Mi[i + nu * l] * L.M[(nx + l) + nz * j];
+                L.Kl[e] = -acc;
+                Kg[(size_t)k * nu * nx + e] = -acc;
+            }
+            for (int i = lane; i < nu; i += kWave) {
+                double acc = 0.0;
+                for (int l = 0; l < nu; ++l) acc += L.Mi[i + nu * l] * L.h[nx + l];
+                L.dxn[i] = -acc; // kv
+                Kvg[(size_t)k * nu + i] = -acc;
+            }
+            wave_sync();
+            // P = Mxx + Mux' K (symmetrised), p = hx + Mux' kv
+            for (int e = lane; e < nx * nx; e += kWave) {
+                const int j = e / nx, i = e - j * nx;
+                double a1 = L.M[i + nz * j], a2 = a1;
+                for (int l = 0; l < nu; ++l) {
+                    a1 += L.M[(nx + l) + nz * i] * L.Kl[l + nu * j];
+                    a2 += L.M[(nx + l) + nz * j] * L.Kl[l + nu * i];
+                }
+                L.Pm[e] = 0.5 * (a1 + a2);
+            }
+            for (int i = lane; i < nx; i += kWave) {
+                double acc = L.h[i];
+                for (int l = 0; l < nu; ++l) acc += L.M[(nx + l) + nz * i] * L.dxn[l];
+                L.pv[i] = acc;
+            }
+            wave_sync();
+            return ok;
+        };
+        // dx_0 = -(P_0 + R - P0)^-1 p_0  (InitialStateLMPC) into dzk[0..nx); Gauss-Jordan on [P | -p] in M (nx x (nx+1))
+        auto solve_x0 = [&]() -> bool {
+            double* GJ = L.M;
+            const int w1 = nx + 1;
+            for (int e = lane; e < nx * w1; e += kWave) {
+                const int r = e / w1, cc = e - r * w1;
+                GJ[e] = (cc < nx) ? L.Pm[r + nx * cc] + H0[r + nx * cc] : -L.pv[r];
+            }
+            wave_sync();
+            bool ok = true;
+            for (int p = 0; p < nx; ++p) {
+                const double piv = GJ[p * w1 + p];
+                if (!(piv > 0.0)) ok = false;
+                const double ip = 1.0 / piv;
+                wave_sync();
+                for (int e = lane; e < nx * w1; e += kWave) {
+                    const int r = e / w1, cc = e - r * w1;
+                    if (r == p || cc == p) continue;
+                    GJ[e] -= GJ[r * w1 + p] * ip * GJ[p * w1 + cc];
+                }
+                wave_sync();
+                for (int e = lane; e < nx * w1; e += kWave) {
+                    const int r = e / w1, cc = e - r * w1;
+                    if (r == p)
+                        GJ[e] *= ip;
+                    else if (cc == p)
+                        GJ[e] = 0.0;
+                }
+                wave_sync();
+            }
+            for (int i = lane; i < nx; i += kWave) L.dzk[i] = GJ[i * w1 + nx];
+            wave_sync();
+            return ok;
+        };
+
+        // ------------------------------------------------------------------ 1. starting point
+        for (int e = lane; e < NZ; e += kWave) Z[e] = 0.0;
+        wave_sync();
+        bool good = true;
+        if (x0_free) {
+            // P0 (unconstrained cost-to-go Hessian) and g0 = dJ/dx0 at (x0, U) = 0
+            for (int e = lane; e < nx * nx; e += kWave) H0[e] = 0.0;
+            for (int e = lane; e < nx; e += kWave) G0[e] = 0.0;
+            wave_sync();
+            rollout(); // x0 = 0, U = 0
+            for (int k = N; k >= 0; --k) {
+                for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
+                wave_sync();
+                stage_gradient(k, false, true); // g = W z + q  (H0 = G0 = 0 for now), stored in GB
+                wave_sync();
+                good = stage_factor(k, false) && good;
+            }
+            // adjoint sweep for g0: lam_N = g_N,x ; lam_k = g_k,x + A' lam_{k+1}
+            for (int i = lane; i < nx; i += kWave) L.h[i] = GB[N * nz + i];
+            wave_sync();
+            for (int k = N - 1; k >= 0; --k) {
+                for (int i = lane; i < nx; i += kWave) {
+                    double acc = GB[k * nz + i];
+                    for (int l = 0; l < nx; ++l) acc += L.AB[l + nx * i] * L.h[l];
+                    L.g[i] = acc;
+                }
+                wave_sync();
+                for (int i = lane; i < nx; i += kWave) L.h[i] = L.g[i];
+                wave_sync();
+            }
+            for (int e = lane; e < nx * nx; e += kWave) H0[e] = P.is_R[e] - L.Pm[e];
+            for (int i = lane; i < nx; i += kWave) G0[i] = P.is_r[i] - L.h[i];
+            wave_sync();
+        }
+        for (int i = lane; i < nx; i += kWave) {
+            double v = P.x0[(size_t)inst * nx + i];
+            if (x0_free) v = fmin(fmax(v, P.x0lb[(size_t)inst * nx + i]), P.x0ub[(size_t)inst * nx + i]);
+            Z[i] = v;
+        }
+        wave_sync();
+        rollout();
+        int n_ineq = 0;
+        for (int k = 0; k <= N; ++k) {
+            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+            for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
+            wave_sync();
+            for (int r = lane; r < nr; r += kWave) {
+                const int gi = gi0 + r;
+                const int fl = (int)Flag[gi];
+                double sv = 1.0, lv = 0.0;
+                if (fl == kRowIneq) {
+                    sv = fmax(F[gi] - row_dot(r0 + r, L.zk), 1.0);
+                    lv = 1.0;
+                    n_ineq += 1;
+                }
+                Sv[gi] = sv;
+                Lam[gi] = lv;
+            }
+            wave_sync();
+        }
+        n_ineq = (int)(wave_sum((double)n_ineq) + 0.5);
+        const double inv_mi = n_ineq > 0 ? 1.0 / (double)n_ineq : 0.0;
+
+        // ------------------------------------------------------------------ 2. Newton iterations
+        int it = 0;
+        bool converged = false;
+        for (it = 1; it <= S.max_iter && good; ++it) {
+            // ---- sweep 1 (backward): residuals, barrier weights, factorisation, predictor right-hand side
+            double musum = 0.0, maxr = 0.0;
+            for (int k = N; k >= 0; --k) {
+                const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
+                wave_sync();
+                for (int r = lane; r < nr; r += kWave) {
+                    const int gi = gi0 + r;
+                    const int fl = (int)Flag[gi];
+                    double Dv = 0.0, Cv = 0.0;
+                    if (fl != kRowOff) {
+                        const double az = row_dot(r0 + r, L.zk);
+                        if (fl == kRowEq) {
+                            const double re = az - F[gi];
+                            Dv = 1.0 / delta;
+                            Cv = Lam[gi] + re / delta;
+                            RP[gi] = re;
+                        } else {
+                            const double sv = Sv[gi], lv = Lam[gi];
+                            const double rp = az + sv - F[gi];
+                            Dv = lv / sv;
+                            Cv = Dv * rp;
+                            RP[gi] = rp;
+                            maxr = fmax(maxr, fabs(rp));
+                            musum += sv * lv;
+                        }
+                    }
+                    L.rowD[r] = Dv;
+                    L.rowC[r] = Cv;
+                }
+                wave_sync();
+                stage_gradient(k, true, true);
+                wave_sync();
+                good = stage_factor(k, true) && good;
+            }
+            const double mu = wave_sum(musum) * inv_mi;
+            const double maxres = wave_max(maxr);
+            if (!good) break;
+            // ---- two forward sweeps (predictor, corrector) with one backward vector sweep in between
+            double alpha = 1.0, sigma_mu = 0.0, step_inf = 0.0, z_inf = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) { // ---- sweep 3 (backward): corrector right-hand side through the stored factors
+                    for (int k = N; k >= 0; --k) {
+                        const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                        for (int r = lane; r < nr; r += kWave) {
+                            const int gi = gi0 + r;
+                            const int fl = (int)Flag[gi];
+                            double Cv = 0.0;
+                            if (fl == kRowEq)
+                                Cv = Lam[gi] + RP[gi] / delta;
+                            else if (fl == kRowIneq) {
+                                const double sv = Sv[gi];
+                                Cv = (sigma_mu - DS[gi] * DL[gi]) / sv + (Lam[gi] / sv) * RP[gi];
+                            }
+                            L.rowC[r] = Cv;
+                        }
+                        wave_sync();
+                        stage_gradient(k, true, false);
+                        wave_sync();
+                        if (k == N) {
+                            for (int i = lane; i < nx; i += kWave) L.pv[i] = L.g[i];
+                            wave_sync();
+                            continue;
+                        }
+                        for (int a = lane; a < nz; a += kWave) { // h = g + [A B]' p
+                            double acc = L.g[a];
+                            for (int l = 0; l < nx; ++l) acc += L.AB[l + nx * a] * L.pv[l];
+                            L.h[a] = acc;
+                        }
+                        wave_sync();
+                        for (int i = lane; i < nu; i += kWave) { // kv = -Muu^-1 hu
+                            double acc = 0.0;
+                            for (int l = 0; l < nu; ++l) acc += Mig[(size_t)k * nu * nu + i + nu * l] * L.h[nx + l];
+                            Kvg[(size_t)k * nu + i] = -acc;
+                        }
+                        for (int i = lane; i < nx; i += kWave) { // p = hx + K' hu
+                            double acc = L.h[i];
+                            for (int l = 0; l < nu; ++l) acc += Kg[(size_t)k * nu * nx + l + nu * i] * L.h[nx + l];
+                            L.dxn[i] = acc;
+                        }
+                        wave_sync();
+                        for (int i = lane; i < nx; i += kWave) L.pv[i] = L.dxn[i];
+                        wave_sync();
+                    }
+                }
+                // dx_0
+                if (x0_free) {
+                    good = solve_x0() && good;
+                } else {
+                    for (int i = lane; i < nx; i += kWave) L.dzk[i] = 0.0;
+                    wave_sync();
+                }
+                double amin = 1.0e300;
+                step_inf = 0.0;
+                z_inf = 0.0;
+                for (int k = 0; k <= N; ++k) {
+                    const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                    if (k < N) {
+                        for (int i = lane; i < nu; i += kWave) { // du = K dx + kv
+                            double acc = Kvg[(size_t)k * nu + i];
+                            for (int j = 0; j < nx; ++j) acc += Kg[(size_t)k * nu * nx + i + nu * j] * L.dzk[j];
+                            L.dzk[nx + i] = acc;
+                        }
+                    } else {
+                        for (int i = lane; i < nu; i += kWave) L.dzk[nx + i] = 0.0;
+                    }
+                    wave_sync();
+                    for (int e = lane; e < nz; e += kWave) {
+                        DZ[k * nz + e] = L.dzk[e];
+                        step_inf = fmax(step_inf, fabs(L.dzk[e]));
+                        z_inf = fmax(z_inf, fabs(Z[k * nz + e]));
+                    }
+                    for (int r = lane; r < nr; r += kWave) {
+                        const int gi = gi0 + r;
+                        const int fl = (int)Flag[gi];
+                        if (fl == kRowOff) continue;
+                        const double adz = row_dot(r0 + r, L.dzk);
+                        if (fl == kRowEq) {
+                            DS[gi] = adz; // (kept for the multiplier update)
+                            continue;
+                        }
+                        const double sv = Sv[gi], lv = Lam[gi];
+                        const double ds = -RP[gi] - adz;
+                        const double corr = (pass == 1) ? (sigma_mu - DS[gi] * DL[gi]) : 0.0;
+                        const double dl = (corr - lv * sv - lv * ds) / sv;
+                        if (pass == 1) { // final direction: overwrite the predictor's
+                            L.rowD[r] = ds;
+                            L.rowC[r] = dl;
+                        } else {
+                            DS[gi] = ds;
+                            DL[gi] = dl;
+                        }
+                        if (ds < 0.0) amin = fmin(amin, -sv / ds);
+                        if (dl < 0.0) amin = fmin(amin, -lv / dl);
+                    }
+                    wave_sync();
+                    if (pass == 1) // (the corrector's own DS * DL product was read above: now the direction can be stored)
+                        for (int r = lane; r < nr; r += kWave) {
+                            const int gi = gi0 + r;
+                            if ((int)Flag[gi] == kRowIneq) {
+                                DS[gi] = L.rowD[r];
+                                DL[gi] = L.rowC[r];
+                            }
+                        }
+                    if (k < N) {
+                        for (int i = lane; i < nx; i += kWave) { // dx+ = A dx + B du
+                            double acc = 0.0;
+                            for (int j = 0; j < nz; ++j) acc += L.AB[i + nx * j] * L.dzk[j];
+                            L.dxn[i] = acc;
+                        }
+                        wave_sync();
+                        for (int i = lane; i < nx; i += kWave) L.dzk[i] = L.dxn[i];
+                    }
+                    wave_sync();
+                }
+                amin = -wave_max(-amin);
+                if (pass == 0) { // Mehrotra's centring parameter from the affine step
+                    const double aaff = fmin(1.0, amin);
+                    double acc = 0.0;
+                    for (int gi = lane; gi < m; gi += kWave)
+                        if ((int)Flag[gi] == kRowIneq) acc += (Sv[gi] + aaff * DS[gi]) * (Lam[gi] + aaff * DL[gi]);
+                    const double mu_aff = wave_sum(acc) * inv_mi;
+                    const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
+                    sigma_mu = ratio * ratio * ratio * mu;
+                } else {
+                    const double tau = mu > 1e-10 ? 0.995 : 0.9999;
+                    alpha = amin < 1.0 ? fmin(1.0, tau * amin) : 1.0;
+                }
+            }
+            step_inf = wave_max(step_inf) * alpha;
+            z_inf = wave_max(z_inf);
+            if (!good) break;
+            // ---- update
+            for (int e = lane; e < NZ; e += kWave) Z[e] += alpha * DZ[e];
+            double musum2 = 0.0, maxe = 0.0;
+            for (int gi = lane; gi < m; gi += kWave) {
+                const int fl = (int)Flag[gi];
+                if (fl == kRowIneq) {
+                    const double sv = Sv[gi] + alpha * DS[gi], lv = Lam[gi] + alpha * DL[gi];
+                    Sv[gi] = sv;
+                    Lam[gi] = lv;
+                    musum2 += sv * lv;
+                } else if (fl == kRowEq) {
+                    const double re = RP[gi] + alpha * DS[gi]; // residual of the row at the new point
+                    Lam[gi] += re / delta;
+                    maxe = fmax(maxe, fabs(re));
+                }
+            }
+            wave_sync();
+            const double mu_new = wave_sum(musum2) * inv_mi;
+            // inequality rows carry slacks, so their residuals shrink by exactly 1 - alpha; equality rows are only
+            // penalised: their residual is what the new point leaves
+            const double res_new = fmax((1.0 - alpha) * maxres, wave_max(maxe));
+            if (!(mu_new == mu_new) || !(step_inf == step_inf)) {
+                good = false;
+                break;
+            }
+            if (res_new <= 1e-9 && ((step_inf <= 1e-10 * (1.0 + z_inf) && mu_new <= 1e-8) || mu_new <= 1e-15)) {
+                converged = true;
+                break;
+            }
+        }
+
+        // ------------------------------------------------------------------ 3. results (LMPC.cpp:282-286)
+        if (converged) {
+            rollout(); // trajectory = Phi x0 + Psi U + xi, recomputed from the final x0 and U
+            for (int e = lane; e < N * nu; e += kWave) {
+                const int k = e / nu, i = e - k * nu;
+                P.control[(size_t)inst * P.n + e] = Z[k * nz + nx + i];
+            }
+            for (int e = lane; e < P.X; e += kWave) {
+                const int k = e / nx, i = e - k * nx;
+                P.trajectory[(size_t)inst * P.X + e] = Z[k * nz + i];
+            }
+            if (P.initial_state && P.x0_opt)
+                for (int e = lane; e < nx; e += kWave) P.x0_opt[(size_t)inst * nx + e] = Z[e];
+            if (lane == 0) {
+                P.status[inst] = 0;
+                P.iter[2 * (size_t)inst] = it;
+                P.iter[2 * (size_t)inst + 1] = 0;
+            }
+        } else {
+            // not converged (infeasible / degenerate): the condensed Goldfarb-Idnani kernel decides its status
+            if (lane == 0) {
+                P.status[inst] = 3;
+                P.iter[2 * (size_t)inst] = it;
+                P.iter[2 * (size_t)inst + 1] = 0;
+                if (P.ovf_count) P.ovf_list[atomic_append(P.ovf_count)] = inst;
+            }
+        }
+        wave_sync();
+    }
+}
+
+} // namespace copra_hip

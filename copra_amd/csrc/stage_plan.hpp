@@ -1,0 +1,394 @@
+// stage_plan.hpp -- the UNCONDENSED (stage-wise) form of one LMPC / InitialStateLMPC controller, for the Riccati
+// interior-point kernel (lmpc_riccati.hpp): SURVEY.md 8(f) rank 3, "structure-exploiting long-horizon solver".
+//
+// The reference condenses the optimal-control problem into a dense QP in U (src/LMPC.cpp:225-280: n = N nu variables,
+// Hessian N nu x N nu) and hands it to a dense active-set solver: O(N^3 nu^3) to factorise, O(N^2 nu^2) per active-set
+// iteration.  The SAME problem written over the stage variables z_k = (x_k, u_k) with the dynamics
+// x_{k+1} = A x_k + B u_k + d as equality constraints is block-banded:
+//
+//     min  sum_k  1/2 z_k' W_k z_k + q_k' z_k      s.t.  rows of stage k:  a_i' z_k  <= | =  f_i
+//
+// and every cost / constraint class of the reference with a per-step entry is exactly of this form:
+//   TrajectoryCost / TargetCost / ControlCost / MixedCost  (src/costFunctions.cpp:63-82, 100-108, 139-158, 195-215):
+//       1/2 || M x_k + N u_k - p ||^2_W  at the steps the class sums over  ->  cost ROWS  a = [M_i, N_i], weight w_i, target p_i
+//   LMPC::updateSystem's 1e-6 I (src/LMPC.cpp:228-230)  ->  1e-6 on the u-u diagonal of every W_k
+//   Trajectory / Control / Mixed constraints, TrajectoryBoundConstraint (src/constraints.cpp:66-84, 137-148, 197-226,
+//       284-315, quirk Q1 included: the plan's rows are taken as they are)  ->  constraint rows  a = [E_i, G_i]
+//   ControlBoundConstraint and the [I; -I] rows of QuadProgSolver.cpp:59-69  ->  unit rows on u_k
+//   InitialStateLMPC (src/InitialStateLMPC.cpp:77-122): x_0 is a variable with unit rows x0lb <= x_0 <= x0ub; its
+//       objective differs from the stage-wise one only in x_0 (lmpc_riccati.hpp works that term out per instance).
+// Full-size entries are stage-wise when every row touches ONE step only (block-diagonal M / E / G: what AutoSpan
+// produces, and e.g. a terminal constraint); a row that couples several steps makes the controller ineligible, and so do
+// more than kRicMaxEq equality rows (they are handled by a proximal multiplier iteration that suits a few
+// well-posed rows, not the hundreds of redundant ones of the reference's EqSystem fixture).  Ineligible controllers
+// stay on the condensed Goldfarb-Idnani path.
+//
+// Pure C++ (no HIP): shared by the C-ABI library and the CPU emulator harness.
+#pragma once
+
+#include "plan_builder.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace copra_hip {
+
+constexpr int kRicMaxNz = 32; // xDim + uDim the Riccati kernel covers
+constexpr int kRicMaxEq = 32; // equality rows (proximal multiplier iteration)
+constexpr int kRicMaxStageRows = 192; // rows of one stage (LDS staging of their weights)
+
+// where the right-hand side of a constraint row comes from (per instance when the caller set per-instance data)
+enum { kSrcRowF = 0, kSrcUb = 1, kSrcNegLb = 2, kSrcX0Ub = 3, kSrcNegX0Lb = 4 };
+
+// device view (all pointers into HBM copies, or host vectors in the emulator)
+struct StagePlan {
+    int nx, nu, N, nz; // nz = nx + nu
+    int m; // constraint rows of one instance (all stages)
+    int ncls; // stage classes (stages with identical W and row templates share one)
+    int max_stage_rows;
+    int x0_free; // InitialStateLMPC
+    const int* cls_of_stage; // [N + 1]
+    const int* stage_row0; // [N + 2] first row of stage k in the per-instance row arrays
+    // per class
+    const int* cls_W; // [ncls] offset of W (nz x nz, column-major, symmetric) in `blob`
+    const int* cls_crow0; // [ncls + 1] cost rows of the class
+    const int* cls_row0; // [ncls + 1] constraint-row templates of the class: dense rows first ...
+    const int* cls_ndense; // [ncls] ... this many, unit rows after them
+    // cost rows (for q_k = - sum w p a)
+    const int* cr_aoff; // offset of a (nz doubles) in `blob`
+    const int* cr_cost; // index of the cost (FusedPlan::cost / cost_p)
+    const int* cr_pidx; // index into that cost's p vector
+    const double* cr_w;
+    // constraint-row templates
+    const int* r_kind; // 0: dense (nz coefficients at blob[r_aoff]), 1: unit (coefficient r_sign on component r_aoff)
+    const int* r_aoff;
+    const double* r_sign;
+    const int* r_eq; // 1: equality
+    const int* r_src; // kSrc*
+    const int* r_sidx; // index into the source array ...
+    const int* r_sstride; // ... + r_sstride * step
+    const double* blob;
+    // per-resident-wave workspace
+    double* ws;
+    long long ws_total; // doubles per wave
+    // workspace offsets (doubles)
+    long long oZ, oDZ, oQ, oGB, oF, oS, oLam, oDS, oDL, oRP, oFlag, oK, oMi, oKv, oH0, oG0;
+    int lds_doubles;
+    int max_iter;
+    double delta; // proximal weight of the equality rows
+};
+
+struct HostStagePlan {
+    bool eligible = false;
+    std::string why; // reason when not eligible
+    StagePlan sp {};
+    std::vector<int> cls_of_stage, stage_row0, cls_W, cls_crow0, cls_row0, cls_ndense;
+    std::vector<int> cr_aoff, cr_cost, cr_pidx;
+    std::vector<double> cr_w;
+    std::vector<int> r_kind, r_aoff, r_eq, r_src, r_sidx, r_sstride;
+    std::vector<double> r_sign;
+    std::vector<double> blob;
+    bool all_bounds = false; // bound rows for every control (per-instance bounds may make any of them finite)
+};
+
+namespace stage_detail {
+    struct CostRow {
+        std::vector<double> a;
+        double w;
+        int cost, pidx;
+    };
+    struct Row {
+        int kind; // 0 dense, 1 unit
+        std::vector<double> a; // dense
+        int comp;
+        double sign;
+        int eq, src, sidx, sstride;
+    };
+    struct StageDesc {
+        std::vector<CostRow> crows;
+        std::vector<Row> rows;
+        bool last;
+    };
+    inline bool same(const StageDesc& x, const StageDesc& y)
+    {
+        if (x.last != y.last || x.crows.size() != y.crows.size() || x.rows.size() != y.rows.size()) return false;
+        for (size_t i = 0; i < x.crows.size(); ++i) {
+            const CostRow &a = x.crows[i], &b = y.crows[i];
+            if (a.a != b.a || a.w != b.w || a.cost != b.cost || a.pidx != b.pidx) return false;
+        }
+        for (size_t i = 0; i < x.rows.size(); ++i) {
+            const Row &a = x.rows[i], &b = y.rows[i];
+            // (sidx may differ between stages of one class: it advances by sstride per step from the class's first stage)
+            if (a.kind != b.kind || a.a != b.a || a.comp != b.comp || a.sign != b.sign || a.eq != b.eq || a.src != b.src
+                || (a.src != kSrcRowF && a.sstride != b.sstride))
+                return false;
+        }
+        return true;
+    }
+} // namespace stage_detail
+
+// Build the stage plan of the controller `hp` (after build_plan).  all_bounds: emit both bound rows of every control
+// even where the controller-wide bound is infinite (needed once per-instance bounds are set).
+inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bounds)
+{
+    using namespace stage_detail;
+    const FusedPlan& P = hp.plan;
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, X = P.X, U = P.n;
+    out = HostStagePlan();
+    out.all_bounds = all_bounds;
+    auto no = [&](const char* why) {
+        out.eligible = false;
+        out.why = why;
+    };
+    if (nz > kRicMaxNz) return no("xDim + uDim too large for the Riccati kernel");
+    if (nu > 8) return no("uDim > 8");
+    if (P.meq > kRicMaxEq) return no("too many equality rows for the proximal multiplier iteration");
+    std::vector<StageDesc> st((size_t)N + 1);
+    for (int k = 0; k <= N; ++k) st[(size_t)k].last = (k == N);
+    const std::vector<double>& prm = hp.params;
+    // a full-size coefficient row touches at most one step?  -> (step, per-step slice); nothing set: step -1
+    auto one_step = [&](const double* row, int per, int steps, int& step) {
+        step = -1;
+        for (int s = 0; s < steps; ++s)
+            for (int j = 0; j < per; ++j)
+                if (row[(size_t)s * per + j] != 0.0) {
+                    if (step >= 0 && step != s) return false;
+                    step = s;
+                }
+        return true;
+    };
+    // ---- costs ----
+    for (int t = 0; t < P.ncost; ++t) {
+        const CostTerm& c = P.cost[t];
+        const bool hasM = c.offM >= 0, hasN = c.offN >= 0;
+        if (!c.full) {
+            int k0 = 0, k1 = N; // steps the class sums over
+            if (c.kind == kCostTarget) k0 = N; // costFunctions.cpp:100-108
+            if (c.kind == kCostControl || c.kind == kCostMixed) k1 = N - 1; // :139-158, :195-215
+            for (int k = k0; k <= k1; ++k)
+                for (int i = 0; i < c.rows; ++i) {
+                    CostRow r { std::vector<double>((size_t)nz, 0.0), prm[(size_t)c.offW + i], t, i };
+                    if (hasM && c.kind != kCostControl)
+                        for (int j = 0; j < nx; ++j) r.a[(size_t)j] = prm[(size_t)c.offM + (size_t)j * c.rows + i];
+                    if (hasN && (c.kind == kCostControl || c.kind == kCostMixed))
+                        for (int j = 0; j < nu; ++j) r.a[(size_t)nx + j] = prm[(size_t)c.offN + (size_t)j * c.rows + i];
+                    st[(size_t)k].crows.push_back(r);
+                }
+        } else { // full-size entry: row-major M (rows x X), N (rows x U)
+            for (int i = 0; i < c.rows; ++i) {
+                int sx = -1, su = -1;
+                if (hasM && !one_step(&prm[(size_t)c.offM + (size_t)i * X], nx, N + 1, sx))
+                    return no("a full-size cost row couples several steps");
+                if (hasN && !one_step(&prm[(size_t)c.offN + (size_t)i * U], nu, N, su))
+                    return no("a full-size cost row couples several steps");
+                if (sx >= 0 && su >= 0 && sx != su) return no("a full-size cost row couples several steps");
+                const int s = sx >= 0 ? sx : su;
+                CostRow r { std::vector<double>((size_t)nz, 0.0), prm[(size_t)c.offW + i], t, i };
+                if (sx >= 0)
+                    for (int j = 0; j < nx; ++j) r.a[(size_t)j] = prm[(size_t)c.offM + (size_t)i * X + (size_t)sx * nx + j];
+                if (su >= 0)
+                    for (int j = 0; j < nu; ++j) r.a[(size_t)nx + j] = prm[(size_t)c.offN + (size_t)i * U + (size_t)su * nu + j];
+                // (an all-zero row still carries  1/2 w p^2 : a constant, dropped)
+                if (s >= 0) st[(size_t)s].crows.push_back(r);
+            }
+        }
+    }
+    // ---- general constraint rows, in the plan's stacked order ----
+    for (int i = 0; i < P.mgen; ++i) {
+        const int ek = hp.row_ekind[(size_t)i], gk = hp.row_gkind[(size_t)i];
+        Row r { 0, std::vector<double>((size_t)nz, 0.0), 0, 1.0, i < P.meq ? 1 : 0, kSrcRowF, i, 0 };
+        int step = hp.row_step[(size_t)i];
+        int sx = -1, su = -1;
+        if (ek == kEDense)
+            for (int j = 0; j < nx; ++j) r.a[(size_t)j] = prm[(size_t)hp.row_eoff[(size_t)i] + j];
+        else if (ek == kEOneHot)
+            r.a[(size_t)hp.row_eoff[(size_t)i]] = 1.0;
+        else if (ek == kEFull) {
+            const double* row = &prm[(size_t)hp.row_eoff[(size_t)i]];
+            if (!one_step(row, nx, N + 1, sx)) return no("a full-size constraint row couples several steps");
+            if (sx >= 0)
+                for (int j = 0; j < nx; ++j) r.a[(size_t)j] = row[(size_t)sx * nx + j];
+        }
+        if (gk == kGStep)
+            for (int j = 0; j < nu; ++j) r.a[(size_t)nx + j] = prm[(size_t)hp.row_goff[(size_t)i] + j];
+        else if (gk == kGFull) {
+            const double* row = &prm[(size_t)hp.row_goff[(size_t)i]];
+            if (!one_step(row, nu, N, su)) return no("a full-size constraint row couples several steps");
+            if (su >= 0)
+                for (int j = 0; j < nu; ++j) r.a[(size_t)nx + j] = row[(size_t)su * nu + j];
+        }
+        if (ek == kEFull || gk == kGFull) {
+            if (sx >= 0 && su >= 0 && sx != su) return no("a full-size constraint row couples several steps");
+            step = sx >= 0 ? sx : (su >= 0 ? su : 0);
+        }
+        if (step == N) // no u_N: a control term there cannot exist (the reference's classes never produce one)
+            for (int j = 0; j < nu; ++j)
+                if (r.a[(size_t)nx + j] != 0.0) return no("constraint row on u_N");
+        // a row with exactly one coefficient of +-1 is a unit row (bounds on a state / control component)
+        int nnz = 0, comp = -1;
+        for (int j = 0; j < nz; ++j)
+            if (r.a[(size_t)j] != 0.0) ++nnz, comp = j;
+        if (nnz == 1 && (r.a[(size_t)comp] == 1.0 || r.a[(size_t)comp] == -1.0)) {
+            r.kind = 1;
+            r.comp = comp;
+            r.sign = r.a[(size_t)comp];
+            r.a.clear();
+        }
+        st[(size_t)step].rows.push_back(r);
+    }
+    // ---- bounds on U: rows [I; -I] with [XU; -XL] (QuadProgSolver.cpp:59-69) ----
+    for (int k = 0; k < N; ++k)
+        for (int j = 0; j < nu; ++j) {
+            const double lo = hp.lb[(size_t)k * nu + j], up = hp.ub[(size_t)k * nu + j];
+            if (all_bounds || (up < DBL_MAX && !is_pos_inf(up)))
+                st[(size_t)k].rows.push_back(Row { 1, {}, nx + j, 1.0, 0, kSrcUb, j, nu });
+            if (all_bounds || (lo > -DBL_MAX && !is_neg_inf(lo)))
+                st[(size_t)k].rows.push_back(Row { 1, {}, nx + j, -1.0, 0, kSrcNegLb, j, nu });
+        }
+    // ---- InitialStateLMPC: bounds on x_0 (InitialStateLMPC.cpp:119-121) ----
+    if (P.initial_state)
+        for (int j = 0; j < nx; ++j) {
+            st[0].rows.push_back(Row { 1, {}, j, 1.0, 0, kSrcX0Ub, j, 0 });
+            st[0].rows.push_back(Row { 1, {}, j, -1.0, 0, kSrcNegX0Lb, j, 0 });
+        }
+    // dense rows first, unit rows after (the kernel treats the two groups in separate loops)
+    for (int k = 0; k <= N; ++k)
+        std::stable_partition(st[(size_t)k].rows.begin(), st[(size_t)k].rows.end(), [](const Row& r) { return r.kind == 0; });
+    // ---- classes: stages with the same cost rows and the same row templates share one.  The right-hand sides of the
+    //      general rows are addressed by their position in the plan's stacked order, which advances by a fixed stride
+    //      from stage to stage inside a class (fixed when the class gets its second member) ----
+    std::vector<int> first_stage; // of each class
+    std::vector<char> stride_set;
+    out.cls_of_stage.assign((size_t)N + 1, -1);
+    for (int k = 0; k <= N; ++k) {
+        int c = -1;
+        for (size_t q = 0; q < first_stage.size() && c < 0; ++q) {
+            const int k0 = first_stage[q];
+            if (!same(st[(size_t)k0], st[(size_t)k])) continue;
+            bool ok = true;
+            for (size_t i = 0; i < st[(size_t)k].rows.size() && ok; ++i) {
+                const Row &a = st[(size_t)k0].rows[i], &b = st[(size_t)k].rows[i];
+                if (a.src != kSrcRowF) {
+                    ok = a.sidx == b.sidx;
+                    continue;
+                }
+                const int dd = b.sidx - a.sidx;
+                ok = stride_set[q] ? (dd == a.sstride * (k - k0)) : (dd % (k - k0) == 0);
+            }
+            if (!ok) continue;
+            if (!stride_set[q]) {
+                for (size_t i = 0; i < st[(size_t)k].rows.size(); ++i) {
+                    Row& a = st[(size_t)k0].rows[i];
+                    if (a.src == kSrcRowF) a.sstride = (st[(size_t)k].rows[i].sidx - a.sidx) / (k - k0);
+                }
+                stride_set[q] = 1;
+            }
+            c = (int)q;
+        }
+        if (c < 0) {
+            c = (int)first_stage.size();
+            first_stage.push_back(k);
+            stride_set.push_back(0);
+        }
+        out.cls_of_stage[(size_t)k] = c;
+    }
+    const int ncls = (int)first_stage.size();
+    auto push_blob = [&](const std::vector<double>& v) {
+        const int at = (int)out.blob.size();
+        out.blob.insert(out.blob.end(), v.begin(), v.end());
+        if (out.blob.size() & 1) out.blob.push_back(0.0);
+        return at;
+    };
+    int max_rows = 0;
+    out.cls_crow0.push_back(0);
+    out.cls_row0.push_back(0);
+    for (int c = 0; c < ncls; ++c) {
+        const int k0 = first_stage[(size_t)c];
+        const StageDesc& S = st[(size_t)k0];
+        std::vector<double> W((size_t)nz * nz, 0.0);
+        for (const CostRow& r : S.crows)
+            for (int j = 0; j < nz; ++j)
+                for (int i = 0; i < nz; ++i) W[(size_t)j * nz + i] += r.w * r.a[(size_t)i] * r.a[(size_t)j];
+        if (!S.last)
+            for (int j = nx; j < nz; ++j) W[(size_t)j * nz + j] += 1e-6; // LMPC.cpp:228-230
+        out.cls_W.push_back(push_blob(W));
+        for (const CostRow& r : S.crows) {
+            out.cr_aoff.push_back(push_blob(r.a));
+            out.cr_cost.push_back(r.cost);
+            out.cr_pidx.push_back(r.pidx);
+            out.cr_w.push_back(r.w);
+        }
+        out.cls_crow0.push_back((int)out.cr_aoff.size());
+        for (const Row& r : S.rows) {
+            out.r_kind.push_back(r.kind);
+            out.r_aoff.push_back(r.kind == 0 ? push_blob(r.a) : r.comp);
+            out.r_sign.push_back(r.sign);
+            out.r_eq.push_back(r.eq);
+            out.r_src.push_back(r.src);
+            // index of the class's FIRST stage minus stride * k0, so that the kernel computes sidx + sstride * k
+            out.r_sidx.push_back(r.sidx - r.sstride * (r.src == kSrcRowF ? k0 : 0));
+            out.r_sstride.push_back(r.sstride);
+        }
+        out.cls_row0.push_back((int)out.r_kind.size());
+        {
+            int nd = 0;
+            for (const Row& r : S.rows) nd += r.kind == 0 ? 1 : 0;
+            out.cls_ndense.push_back(nd);
+        }
+        if ((int)S.rows.size() > max_rows) max_rows = (int)S.rows.size();
+    }
+    if (max_rows > kRicMaxStageRows) return no("too many constraint rows in one stage");
+    out.stage_row0.assign((size_t)N + 2, 0);
+    for (int k = 0; k <= N; ++k)
+        out.stage_row0[(size_t)k + 1] = out.stage_row0[(size_t)k] + (int)st[(size_t)k].rows.size();
+    StagePlan& sp = out.sp;
+    sp.nx = nx, sp.nu = nu, sp.N = N, sp.nz = nz;
+    sp.m = out.stage_row0[(size_t)N + 1];
+    sp.ncls = ncls;
+    sp.max_stage_rows = max_rows;
+    sp.x0_free = P.initial_state;
+    sp.max_iter = 60;
+    sp.delta = 1e-9;
+    // workspace of one resident wave
+    long long o = 0;
+    auto take = [&](long long count) {
+        const long long at = o;
+        o += (count + 7) & ~7LL;
+        return at;
+    };
+    const long long NZ = (long long)(N + 1) * nz, m = sp.m > 0 ? sp.m : 1;
+    sp.oZ = take(NZ), sp.oDZ = take(NZ), sp.oQ = take(NZ), sp.oGB = take(NZ);
+    sp.oF = take(m), sp.oS = take(m), sp.oLam = take(m), sp.oDS = take(m), sp.oDL = take(m), sp.oRP = take(m), sp.oFlag = take(m);
+    sp.oK = take((long long)N * nu * nx), sp.oMi = take((long long)N * nu * nu), sp.oKv = take((long long)N * nu);
+    sp.oH0 = take((long long)nx * nx), sp.oG0 = take(nx);
+    sp.ws_total = o;
+    // LDS of one wave (doubles): AB | P | T | M | pv, h, g, zk, dzk, dxn, d | K | Mi | row weights / coefficients
+    sp.lds_doubles = align2(nx * nz) + align2(nx * nx) + align2(nx * nz > 2 * nu * nu ? nx * nz : 2 * nu * nu) + align2(nz * nz)
+        + 7 * align2(nz) + align2(nu * nx) + align2(nu * nu) + 2 * align2(max_rows > 0 ? max_rows : 1) + 2; // == carve_riccati
+    out.eligible = true;
+}
+
+inline void point_stage_plan_to_host(HostStagePlan& h)
+{
+    StagePlan& sp = h.sp;
+    sp.cls_of_stage = h.cls_of_stage.data();
+    sp.stage_row0 = h.stage_row0.data();
+    sp.cls_W = h.cls_W.data();
+    sp.cls_crow0 = h.cls_crow0.data();
+    sp.cls_row0 = h.cls_row0.data();
+    sp.cls_ndense = h.cls_ndense.data();
+    sp.cr_aoff = h.cr_aoff.data();
+    sp.cr_cost = h.cr_cost.data();
+    sp.cr_pidx = h.cr_pidx.data();
+    sp.cr_w = h.cr_w.data();
+    sp.r_kind = h.r_kind.data();
+    sp.r_aoff = h.r_aoff.data();
+    sp.r_sign = h.r_sign.data();
+    sp.r_eq = h.r_eq.data();
+    sp.r_src = h.r_src.data();
+    sp.r_sidx = h.r_sidx.data();
+    sp.r_sstride = h.r_sstride.data();
+    sp.blob = h.blob.data();
+}
+
+} // namespace copra_hip

@@ -177,6 +177,23 @@ copra_status_t copra_batch_set_control_bounds(copra_batch_t* h, const double* lo
 copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, const double* B, const double* d,
     int on_device);
 
+/* ---- LMPC::selectQPSolver(SolverFlag) (src/LMPC.cpp:62-65, include/solverUtils.h:34-50) for the batched controller.
+ *      COPRA_SOLVER_DEFAULT (SolverFlag::DEFAULT): the engine picks -- the condensed Goldfarb-Idnani kernels up to 64
+ *        decision variables, and for longer horizons the stage-wise Riccati interior-point kernel when every cost /
+ *        constraint of the controller is stage-wise (per-step entries, block-diagonal full-size entries, at most 32
+ *        equality rows), else the condensed workgroup-per-instance Goldfarb-Idnani kernel; instances the interior-point
+ *        kernel does not converge on (infeasible ones) are finished by Goldfarb-Idnani, which sets their status.
+ *      COPRA_SOLVER_QUADPROG_DENSE (SolverFlag::QuadProgDense): always the Goldfarb-Idnani kernels -- the arithmetic of
+ *        the reference's QuadProgDense path, same active-set iteration counts as the CPU path.
+ *      COPRA_SOLVER_RICCATI_IPM: force the interior-point kernel; COPRA_ERR_UNSUPPORTED when the controller is not
+ *        stage-wise.
+ *      Both solvers return the unique optimum of the same strictly convex QP: controls / trajectories agree to solver
+ *      accuracy; status codes agree; iter[0] counts active-set iterations or Newton steps respectively.
+ *      copra_batch_solver_info: which one the next copra_batch_solve runs (a copra_solver_t). ---- */
+typedef enum { COPRA_SOLVER_DEFAULT = 0, COPRA_SOLVER_QUADPROG_DENSE = 1, COPRA_SOLVER_RICCATI_IPM = 2 } copra_solver_t;
+copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver);
+int copra_batch_solver_info(const copra_batch_t* h);
+
 /* ---- optional: let the caller own the result buffers (device pointers, e.g. torch tensors that are later handed to
  *      an RCCL gather); must be called before copra_batch_solve and stay valid.  Sizes as in the results block. ---- */
 copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter);

@@ -5,6 +5,7 @@
 #include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
+#include "../../copra_amd/csrc/lmpc_riccati.hpp"
 #include "../../copra_amd/csrc/lmpc_shared.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
@@ -252,6 +253,47 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         }
     }
     return 0;
+}
+
+// The stage-wise Riccati interior-point body (lmpc_riccati.hpp) for every instance; returns -200 when the controller is
+// not stage-wise (stage_plan.hpp), else 0.  not_converged[0] = number of instances it queued for the Goldfarb-Idnani path.
+int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
+    const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0, double* control,
+    double* trajectory, int* status, int* iter, const copra_initial_state_desc_t* is, const double* x0lb, const double* x0ub,
+    double* x0_opt, int* not_converged)
+{
+    HostPlan hp;
+    copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
+    if (rc != COPRA_OK) {
+        fprintf(stderr, "emu: %s\n", hp.error.c_str());
+        return (int)rc;
+    }
+    point_plan_to_host(hp);
+    FusedPlan& P = hp.plan;
+    HostStagePlan hs;
+    build_stage_plan(hp, hs, g_lb_inst != nullptr);
+    if (!hs.eligible) {
+        fprintf(stderr, "emu: not stage-wise: %s\n", hs.why.c_str());
+        return -200;
+    }
+    point_stage_plan_to_host(hs);
+    P.A = A, P.B = B, P.d = d, P.x0 = x0;
+    P.control = control, P.trajectory = trajectory, P.status = status, P.iter = iter;
+    P.x0lb = x0lb, P.x0ub = x0ub, P.x0_opt = x0_opt;
+    for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = g_cost_p[k];
+    P.row_f_inst = g_row_f_inst;
+    P.lb_inst = g_lb_inst;
+    P.ub_inst = g_ub_inst;
+    int ovf_count = 0;
+    std::vector<int> ovf_list((size_t)(dims->batch > 0 ? dims->batch : 1));
+    P.ovf_count = &ovf_count;
+    P.ovf_list = ovf_list.data();
+    std::vector<double> ws((size_t)hs.sp.ws_total + 8, __builtin_nan(""));
+    hs.sp.ws = ws.data();
+    const StagePlan& S = hs.sp;
+    int r = emu::run_wave([&]() { lmpc_riccati_body(P, S); }, (size_t)S.lds_doubles * sizeof(double), 0, 1);
+    if (not_converged) not_converged[0] = ovf_count;
+    return r != 0 ? -100 : 0;
 }
 
 // Shared-model fast path exactly as copra_batch_set_shared_system + copra_batch_solve run it: nx + 1 probe instances of

@@ -25,6 +25,7 @@ def lib():
         _lib.emu_lmpc_solve.restype = C.c_int
         _lib.emu_qp_dense.restype = C.c_int
         _lib.emu_lmpc_solve_shared.restype = C.c_int
+        _lib.emu_lmpc_solve_riccati.restype = C.c_int
     return _lib
 
 
@@ -105,6 +106,54 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
     if dump_instance >= 0:
         out.update(Q=np.array(dQ), c=dc, Aeq=np.array(dA[:neq]), beq=db_[:neq], Aineq=np.array(dA[neq:mgen]),
                    bineq=db_[neq:mgen])
+    return out
+
+
+def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_refs=None, row_rhs=None, bounds=None):
+    """lmpc_riccati.hpp (stage-wise interior-point body) for every instance; returns None when the controller is not
+    stage-wise.  Arguments as lmpc_solve."""
+    rr = None if row_rhs is None else np.ascontiguousarray(row_rhs, dtype=np.float64)
+    lo = None if bounds is None else np.ascontiguousarray(bounds[0], dtype=np.float64)
+    up = None if bounds is None else np.ascontiguousarray(bounds[1], dtype=np.float64)
+    vp = C.c_void_p
+    p = _capi.dptr
+    lib().emu_set_instance_rows(p(rr) if rr is not None else vp(), p(lo) if lo is not None else vp(),
+                                p(up) if up is not None else vp())
+    Ab, Bb, db, xb = _batchify(A, B, d, x0)
+    refs = {int(k): np.ascontiguousarray(v, dtype=np.float64) for k, v in (cost_refs or {}).items()}
+    for k in range(8):
+        lib().emu_set_cost_reference(k, p(refs[k]) if k in refs else vp())
+    batch, nu, nx = Bb.shape[0], Bb.shape[1], Bb.shape[2]
+    keep = []
+    cc = _capi.pack_costs(costs, keep)
+    kk = _capi.pack_cstrs(cstrs, keep)
+    dims = _capi.Dims(nx, nu, N, batch)
+    isd, x0lb, x0ub, x0o = vp(), None, None, None
+    if initial_state is not None:
+        Rm = _capi.fcol(initial_state["R"])
+        rv = _capi.fcol(initial_state["r"])
+        keep.extend([Rm, rv])
+        isd = C.byref(_capi.InitialStateDesc(p(Rm), p(rv)))
+        if initial_state.get("x0lb") is not None:
+            x0lb = np.ascontiguousarray(np.broadcast_to(initial_state["x0lb"], (batch, nx)), dtype=np.float64)
+            x0ub = np.ascontiguousarray(np.broadcast_to(initial_state["x0ub"], (batch, nx)), dtype=np.float64)
+        x0o = np.full((batch, nx), np.nan)
+    u = np.full((batch, nu * N), np.nan)
+    tr = np.full((batch, nx * (N + 1)), np.nan)
+    st = np.full(batch, -1, dtype=np.int32)
+    it = np.zeros((batch, 2), dtype=np.int32)
+    nc = (C.c_int * 1)()
+    rc = lib().emu_lmpc_solve_riccati(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ab), p(Bb), p(db), p(xb), p(u),
+                                      p(tr), st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)),
+                                      isd, p(x0lb) if x0lb is not None else vp(), p(x0ub) if x0ub is not None else vp(),
+                                      p(x0o) if x0o is not None else vp(), nc)
+    if rc == -200:
+        return None
+    if rc != 0:
+        raise RuntimeError("emulator failed rc=%d" % rc)
+    out = dict(control=u, trajectory=tr, status=st, iter=it, not_converged=nc[0])
+    if x0o is not None:
+        out["x0_opt"] = x0o
     return out
 
 

@@ -396,17 +396,32 @@ def _initial_state_optimization_case(oracle, full_size):
     assert np.array_equal(got["lb"], qb["lb"]) and np.array_equal(got["ub"], qb["ub"])
 
 
+SOLVERS = ["quadprog_dense", "default"]  # copra_batch_select_solver: condensed Goldfarb-Idnani / what the engine picks
+
+
+def _select(eng, solver, expect_riccati=True):
+    """returns True when the active-set iteration counts are comparable with the oracle's (Goldfarb-Idnani runs)"""
+    eng.select_solver(solver)
+    if solver == "default" and expect_riccati:
+        assert eng.solver() == "riccati_ipm"
+    return eng.solver() == "quadprog_dense"
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("system", ["bounded", "ineq", "mixed", "eq"])
 @pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
-def test_reference_fixtures_full_horizon(oracle, system, xcost):
+def test_reference_fixtures_full_horizon(oracle, system, xcost, solver):
     """The twelve {cost} x {constraint} combinations of tests/TestLMPC.cpp at the reference's OWN horizon (nbStep = 300,
-    systems.h:45): 300 decision variables -> the workgroup-per-instance kernel.  Solution vs the oracle, and the
-    reference's own acceptance checks (TestLMPC.cpp:60-78 etc.: bounds respected, target reached)."""
+    systems.h:45): 300 decision variables -> the workgroup-per-instance Goldfarb-Idnani kernel ("quadprog_dense") and
+    the stage-wise Riccati interior-point kernel (what "default" picks; the EqSystem's 602 equality rows keep that one
+    on Goldfarb-Idnani).  Solution vs the oracle, and the reference's own acceptance checks (TestLMPC.cpp:60-78 etc.:
+    bounds respected, target reached)."""
     import fixtures as F
     from copra_amd import BatchLMPC
     pb = getattr(F, system + "_system")(xcost, N=300)
     b = 3
     eng = BatchLMPC(2, 1, 300, b, pb["costs"], pb["cstrs"])
+    same_iters = _select(eng, solver, expect_riccati=(system != "eq"))
     x0 = np.tile(pb["x0"], (b, 1))
     if system != "eq":
         x0[1:, 1] += [0.5, -0.5]
@@ -416,7 +431,7 @@ def test_reference_fixtures_full_horizon(oracle, system, xcost):
     for k in range(b):
         ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 300, pb["costs"], pb["cstrs"])
         assert res["status"][k] == ro["status"] == 0
-        assert tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert (not same_iters) or tuple(res["iter"][k]) == tuple(ro["iter"])
         assert _rel(res["control"][k], ro["control"]) <= 1e-6
         assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
     u, tr = res["control"][0], res["trajectory"][0].reshape(301, 2)
@@ -426,9 +441,11 @@ def test_reference_fixtures_full_horizon(oracle, system, xcost):
         assert np.abs(tr[:, 0]).max() <= 1e-6 and np.abs(u[:-1] - pb["u_expected"]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("initial_state", [False, True])
-def test_nine_classes_long_horizon(oracle, initial_state):
-    """All nine cost / constraint classes at N = 150 (LMPC: 150 variables, InitialStateLMPC: 152) vs the oracle"""
+def test_nine_classes_long_horizon(oracle, initial_state, solver):
+    """All nine cost / constraint classes at N = 150 (LMPC: 150 variables, InitialStateLMPC: 152) vs the oracle, on both
+    long-horizon solvers"""
     import fixtures as F
     from copra_amd import BatchLMPC
     pb = F.nine_class_problem(150)
@@ -437,6 +454,7 @@ def test_nine_classes_long_horizon(oracle, initial_state):
     x0 = np.tile(pb["x0"], (b, 1)) + 0.1 * rng.standard_normal((b, 2))
     ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2])) if initial_state else None
     eng = BatchLMPC(2, 1, 150, b, pb["costs"], pb["cstrs"], initial_state=ist)
+    same_iters = _select(eng, solver)
     eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0)
     if initial_state:
         eng.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
@@ -447,42 +465,60 @@ def test_nine_classes_long_horizon(oracle, initial_state):
         ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 150, pb["costs"], pb["cstrs"], initial_state=io)
         assert res["status"][k] == ro["status"]
         if ro["status"] == 0:
-            assert tuple(res["iter"][k]) == tuple(ro["iter"])
+            assert (not same_iters) or tuple(res["iter"][k]) == tuple(ro["iter"])
             assert _rel(res["control"][k], ro["control"]) <= 1e-6
             assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
             if initial_state:
                 assert _rel(eng.initial_state()[k], ro["x0_opt"]) <= 1e-6
 
 
-@pytest.mark.parametrize("r_diag,tol", [(1e-2, 1e-6), (1e-6, 1e-4)])
-def test_config5_long_horizon_initial_state(oracle, r_diag, tol):
+@pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("r_diag", [1e-2, 1e-6])
+def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
     """BASELINE config 5: InitialStateLMPC (nx=12, nu=6, N=50; 312 variables; 300 mixed inequality rows,
     a full-size terminal equality, control bounds) -- a few instances against the oracle, and the QP matrices of one.
-    With the specified R = 1e-6 I the Schur complement of the Hessian is 1e-6 against Hessian entries of 1e2: two valid
-    FP64 evaluation orders differ by ~1e-5 in U (cond ~ 1e10), so that case asserts 1e-4 on U plus identical
-    status / iteration counts / x0*; R = 1e-2 I is the well-conditioned twin held to the 1e-6 bar."""
+
+    With the SPECIFIED R = 1e-6 I the Hessian [[R + E Q^-1 E', E], [E', Q]] has cond 2e12 and the Goldfarb-Idnani
+    arithmetic of the CPU path is itself 1.1e-5 .. 1.3e-5 away from the certified optimum (60-digit truth vectors,
+    tests/golden/gen_truth_config5.py; tests/test_golden.py::test_oracle_vs_config5_truth).  So at R = 1e-6 the bar is
+    the TRUTH: the default solver (stage-wise Riccati interior-point kernel) must be within 1e-6 of it -- i.e. nearer
+    the optimum than the CPU path is -- and within 1e-4 of the oracle; the condensed Goldfarb-Idnani kernel
+    ("quadprog_dense": same arithmetic family as the oracle, same iteration counts) is held to 1e-4 of both.
+    R = 1e-2 I is the well-conditioned twin where everything meets 1e-6 against the oracle."""
     from copra_amd import BatchLMPC, workloads
     b = 6
     wl = workloads.long_horizon_initial_state(b, R_diag=r_diag)
     ist = wl["initial_state"]
     eng = BatchLMPC(12, 6, wl["N"], b, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+    same_iters = _select(eng, solver)
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
     eng.solve()
     res = eng.results()
     x0o = eng.initial_state()
+    tol = 1e-6 if r_diag == 1e-2 else 1e-4
     for k in range(b):
         io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
         ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"],
                                initial_state=io)
         assert res["status"][k] == ro["status"] == 0
-        assert tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert (not same_iters) or tuple(res["iter"][k]) == tuple(ro["iter"])
         assert _rel(res["control"][k], ro["control"]) <= tol
         assert _rel(res["trajectory"][k], ro["trajectory"]) <= tol
         assert _rel(x0o[k], ro["x0_opt"]) <= 1e-6
         tr = res["trajectory"][k].reshape(wl["N"] + 1, 12)
         assert np.abs(tr[-1, 6:]).max() <= 1e-8  # the full-size terminal equality
         assert np.abs(res["control"][k]).max() <= 2.0 + 1e-6
+    if r_diag == 1e-6:  # the certified optimum
+        import test_golden as G
+        twl, picks = G.config5_truth_cases()
+        assert np.array_equal(twl["x0"], wl["x0"])
+        for k in picks:
+            ut, xt = G.TRUTH5["control_%d" % k], G.TRUTH5["trajectory_%d" % k]
+            ttol = 1e-4 if same_iters else 1e-6
+            assert _rel(res["control"][k], ut) <= ttol
+            assert _rel(res["trajectory"][k], xt) <= ttol
+            assert np.abs(x0o[k] - G.TRUTH5["x0_opt_%d" % k]).max() <= 1e-9
     qp = eng.dump_qp(2)
     io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][2], x0ub=ist["x0ub"][2])
     qo = oracle.lmpc_build(wl["A"][2], wl["B"][2], wl["d"][2], wl["x0"][2], wl["N"], wl["costs"], wl["cstrs"],
@@ -493,8 +529,9 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, tol):
         assert np.abs(qp[key] - qo[key]).max() <= 1e-10 * max(1.0, np.abs(qo[key]).max())
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("initial_state", [False, True])
-def test_full_size_cost_entries_long_horizon(oracle, initial_state):
+def test_full_size_cost_entries_long_horizon(oracle, initial_state, solver):
     """Full-size cost entries (time-varying reference and weights over the horizon) with 150 decision variables: the
     workgroup-per-instance kernel's rank-4 Hessian updates vs the oracle"""
     import fixtures as F
@@ -518,6 +555,7 @@ def test_full_size_cost_entries_long_horizon(oracle, initial_state):
     x0 = np.tile(pb["x0"], (b, 1)) + 0.1 * rng.standard_normal((b, 2))
     ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2])) if initial_state else None
     eng = BatchLMPC(2, 1, N, b, costs, pb["cstrs"], initial_state=ist)
+    same_iters = _select(eng, solver)  # (autospanned full-size entries are block-diagonal: stage-wise)
     eng.set_system(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0)
     if initial_state:
         eng.set_initial_state_bounds(x0 - 0.05, x0 + 0.05)
@@ -526,7 +564,8 @@ def test_full_size_cost_entries_long_horizon(oracle, initial_state):
     for k in range(b):
         io = dict(ist, x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05) if initial_state else None
         ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], N, costs, pb["cstrs"], initial_state=io)
-        assert res["status"][k] == ro["status"] == 0 and tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert res["status"][k] == ro["status"] == 0
+        assert (not same_iters) or tuple(res["iter"][k]) == tuple(ro["iter"])
         assert _rel(res["control"][k], ro["control"]) <= 1e-6
         assert _rel(res["trajectory"][k], ro["trajectory"]) <= 1e-6
 

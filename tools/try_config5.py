@@ -13,9 +13,12 @@ from copra_amd import BatchLMPC, workloads  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ncheck = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+solver = sys.argv[3] if len(sys.argv) > 3 else "default"  # default | quadprog_dense | riccati_ipm
 wl = workloads.long_horizon_initial_state(batch)
 ist = wl["initial_state"]
 eng = BatchLMPC(12, 6, wl["N"], batch, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+eng.select_solver(solver)
+print("solver:", eng.solver())
 eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
 eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
 for rep in range(3):
