@@ -37,6 +37,8 @@ namespace copra_hip {
 
 struct RicLds {
     double *AB, *Pm, *T, *M, *pv, *h, *g, *zk, *dzk, *dxn, *dv, *Kl, *Mi, *rowD, *rowC;
+    double *Wc, *Ad, *Us; // tables of the current stage class: W, dense row coefficients (row-major), unit-row signs
+    int* Uc; // ... and unit-row components
 };
 
 COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S)
@@ -61,6 +63,10 @@ COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S)
     const int mr = S.max_stage_rows > 0 ? S.max_stage_rows : 1;
     L.rowD = p, p += a2(mr);
     L.rowC = p, p += a2(mr);
+    L.Wc = p, p += a2(nz * nz);
+    L.Ad = p, p += a2((S.max_dense > 0 ? S.max_dense : 1) * nz);
+    L.Us = p, p += a2(mr);
+    L.Uc = reinterpret_cast<int*>(p), p += a2((mr + 1) / 2);
     return L;
 }
 
@@ -106,7 +112,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 Flag[gi0 + r] = (f >= BIGF) ? (double)kRowOff : (S.r_eq[t] ? (double)kRowEq : (double)kRowIneq);
             }
         }
-        wave_sync();
+        wave_sync_full(); // (F / Flag are read across lanes below)
         // a bound pair  lb == ub  (up to rounding) is one equality row: the upper row becomes it, the lower row is off
         for (int k = 0; k <= N; ++k) {
             const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
@@ -136,36 +142,60 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             Q[e] = acc;
         }
         for (int e = lane; e < nx; e += kWave) dvec[e] = P.d[(size_t)inst * nx + e];
-        wave_sync();
+        wave_sync_full();
 
         // ---- helpers -------------------------------------------------------------------------------------------
-        // a_t' v for row template t (v: nz values in LDS)
-        auto row_dot = [&](int t, const double* v) -> double {
-            if (S.r_kind[t] == 1) return S.r_sign[t] * v[S.r_aoff[t]];
-            const double* a = blob + S.r_aoff[t];
+        // tables of stage class c -> LDS (W, the dense rows' coefficients, the unit rows' component and sign); stages of
+        // one class are mostly consecutive, so this happens a few times per sweep
+        int cur_cls = -1;
+        auto load_class = [&](int c) {
+            if (c == cur_cls) return;
+            cur_cls = c;
+            const int r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
+            wave_sync(); // (readers of the previous class's tables are done)
+            for (int e = lane; e < nz * nz; e += kWave) L.Wc[e] = blob[S.cls_W[c] + e];
+            for (int e = lane; e < nd * nz; e += kWave) {
+                const int r = e / nz, j = e - r * nz;
+                L.Ad[e] = blob[S.r_aoff[r0 + r] + j];
+            }
+            for (int r = nd + lane; r < nr; r += kWave) {
+                L.Uc[r] = S.r_aoff[r0 + r];
+                L.Us[r] = S.r_sign[r0 + r];
+            }
+            wave_sync();
+        };
+        // a_r' v for row r of the CURRENT class (v: nz values in LDS)
+        auto row_dot = [&](int r, int nd, const double* v) -> double {
+            if (r >= nd) return L.Us[r] * v[L.Uc[r]];
+            const double* a = L.Ad + r * nz;
             double acc = 0.0;
             for (int j = 0; j < nz; ++j) acc += a[j] * v[j];
             return acc;
         };
-        // x_{k+1} = A x_k + B u_k + d along Z (u as stored), from Z[0..nx)
+        // x_{k+1} = A x_k + B u_k + d along Z (the controls as stored in Z), from the x_0 stored in Z[0..nx)
         auto rollout = [&]() {
+            wave_sync_full();
+            for (int i = lane; i < nx; i += kWave) L.zk[i] = Z[i];
             for (int k = 0; k < N; ++k) {
-                for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
+                for (int i = nx + lane; i < nz; i += kWave) L.zk[i] = Z[k * nz + i];
                 wave_sync();
                 for (int i = lane; i < nx; i += kWave) {
                     double acc = dvec[i];
                     for (int j = 0; j < nz; ++j) acc += L.AB[i + nx * j] * L.zk[j];
+                    L.dxn[i] = acc;
                     Z[(k + 1) * nz + i] = acc;
                 }
                 wave_sync();
+                for (int i = lane; i < nx; i += kWave) L.zk[i] = L.dxn[i];
             }
+            wave_sync_full();
         };
         // One stage of the backward factorisation.  Before: zk holds z_k (u-part 0 at k = N), rowD / rowC the weights and
         // gradient coefficients of the stage's rows, Pm / pv the cost-to-go of stage k + 1.  After: Pm / pv of stage k;
         // K, Muu^-1, kv stored for the forward sweeps.  Returns false when Muu is not positive definite.
         auto stage_gradient = [&](int k, bool with_rows, bool store_gb) {
-            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
-            const double* Wk = blob + S.cls_W[c];
+            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c];
+            const double* Wk = L.Wc;
             for (int i = lane; i < nz; i += kWave) {
                 double gb;
                 if (store_gb) {
@@ -180,28 +210,25 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     gb = GB[k * nz + i];
                 }
                 if (with_rows) {
-                    for (int r = 0; r < nd; ++r) gb += L.rowC[r] * blob[S.r_aoff[r0 + r] + i];
+                    for (int r = 0; r < nd; ++r) gb += L.rowC[r] * L.Ad[r * nz + i];
                     for (int r = nd; r < nr; ++r)
-                        if (S.r_aoff[r0 + r] == i) gb += S.r_sign[r0 + r] * L.rowC[r];
+                        if (L.Uc[r] == i) gb += L.Us[r] * L.rowC[r];
                 }
                 L.g[i] = gb;
             }
         };
         auto stage_factor = [&](int k, bool with_rows) -> bool {
-            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
-            const double* Wk = blob + S.cls_W[c];
+            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c];
+            const double* Wk = L.Wc;
             // H = W + sum D a a'
             for (int e = lane; e < nz * nz; e += kWave) {
                 const int j = e / nz, i = e - j * nz;
                 double acc = Wk[e];
                 if (with_rows) {
-                    for (int r = 0; r < nd; ++r) {
-                        const double* a = blob + S.r_aoff[r0 + r];
-                        acc += L.rowD[r] * a[i] * a[j];
-                    }
+                    for (int r = 0; r < nd; ++r) acc += L.rowD[r] * L.Ad[r * nz + i] * L.Ad[r * nz + j];
                     if (i == j)
                         for (int r = nd; r < nr; ++r)
-                            if (S.r_aoff[r0 + r] == i) acc += L.rowD[r];
+                            if (L.Uc[r] == i) acc += L.rowD[r];
                 }
                 L.M[e] = acc;
             }
@@ -345,15 +372,14 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
 
         // ------------------------------------------------------------------ 1. starting point
         for (int e = lane; e < NZ; e += kWave) Z[e] = 0.0;
-        wave_sync();
         bool good = true;
         if (x0_free) {
             // P0 (unconstrained cost-to-go Hessian) and g0 = dJ/dx0 at (x0, U) = 0
             for (int e = lane; e < nx * nx; e += kWave) H0[e] = 0.0;
             for (int e = lane; e < nx; e += kWave) G0[e] = 0.0;
-            wave_sync();
             rollout(); // x0 = 0, U = 0
             for (int k = N; k >= 0; --k) {
+                load_class(S.cls_of_stage[k]);
                 for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
                 wave_sync();
                 stage_gradient(k, false, true); // g = W z + q  (H0 = G0 = 0 for now), stored in GB
@@ -375,18 +401,18 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             }
             for (int e = lane; e < nx * nx; e += kWave) H0[e] = P.is_R[e] - L.Pm[e];
             for (int i = lane; i < nx; i += kWave) G0[i] = P.is_r[i] - L.h[i];
-            wave_sync();
         }
+        wave_sync_full();
         for (int i = lane; i < nx; i += kWave) {
             double v = P.x0[(size_t)inst * nx + i];
             if (x0_free) v = fmin(fmax(v, P.x0lb[(size_t)inst * nx + i]), P.x0ub[(size_t)inst * nx + i]);
             Z[i] = v;
         }
-        wave_sync();
         rollout();
         int n_ineq = 0;
         for (int k = 0; k <= N; ++k) {
-            const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
+            load_class(c);
             for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
             wave_sync();
             for (int r = lane; r < nr; r += kWave) {
@@ -394,7 +420,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 const int fl = (int)Flag[gi];
                 double sv = 1.0, lv = 0.0;
                 if (fl == kRowIneq) {
-                    sv = fmax(F[gi] - row_dot(r0 + r, L.zk), 1.0);
+                    sv = fmax(F[gi] - row_dot(r, nd, L.zk), 1.0);
                     lv = 1.0;
                     n_ineq += 1;
                 }
@@ -404,6 +430,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             wave_sync();
         }
         n_ineq = (int)(wave_sum((double)n_ineq) + 0.5);
+        wave_sync_full();
         const double inv_mi = n_ineq > 0 ? 1.0 / (double)n_ineq : 0.0;
 
         // ------------------------------------------------------------------ 2. Newton iterations
@@ -413,7 +440,8 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             // ---- sweep 1 (backward): residuals, barrier weights, factorisation, predictor right-hand side
             double musum = 0.0, maxr = 0.0;
             for (int k = N; k >= 0; --k) {
-                const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
+                load_class(c);
                 for (int e = lane; e < nz; e += kWave) L.zk[e] = Z[k * nz + e];
                 wave_sync();
                 for (int r = lane; r < nr; r += kWave) {
@@ -421,7 +449,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     const int fl = (int)Flag[gi];
                     double Dv = 0.0, Cv = 0.0;
                     if (fl != kRowOff) {
-                        const double az = row_dot(r0 + r, L.zk);
+                        const double az = row_dot(r, nd, L.zk);
                         if (fl == kRowEq) {
                             const double re = az - F[gi];
                             Dv = 1.0 / delta;
@@ -448,12 +476,14 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             const double mu = wave_sum(musum) * inv_mi;
             const double maxres = wave_max(maxr);
             if (!good) break;
+            wave_sync_full(); // (K, Muu^-1, kv of this sweep are read across lanes from here on)
             // ---- two forward sweeps (predictor, corrector) with one backward vector sweep in between
             double alpha = 1.0, sigma_mu = 0.0, step_inf = 0.0, z_inf = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) { // ---- sweep 3 (backward): corrector right-hand side through the stored factors
                     for (int k = N; k >= 0; --k) {
-                        const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                        const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi0 = S.stage_row0[k];
+                        load_class(c);
                         for (int r = lane; r < nr; r += kWave) {
                             const int gi = gi0 + r;
                             const int fl = (int)Flag[gi];
@@ -494,6 +524,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                         for (int i = lane; i < nx; i += kWave) L.pv[i] = L.dxn[i];
                         wave_sync();
                     }
+                    wave_sync_full();
                 }
                 // dx_0
                 if (x0_free) {
@@ -506,7 +537,8 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 step_inf = 0.0;
                 z_inf = 0.0;
                 for (int k = 0; k <= N; ++k) {
-                    const int c = S.cls_of_stage[k], r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, gi0 = S.stage_row0[k];
+                    const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
+                    load_class(c);
                     if (k < N) {
                         for (int i = lane; i < nu; i += kWave) { // du = K dx + kv
                             double acc = Kvg[(size_t)k * nu + i];
@@ -526,7 +558,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                         const int gi = gi0 + r;
                         const int fl = (int)Flag[gi];
                         if (fl == kRowOff) continue;
-                        const double adz = row_dot(r0 + r, L.dzk);
+                        const double adz = row_dot(r, nd, L.dzk);
                         if (fl == kRowEq) {
                             DS[gi] = adz; // (kept for the multiplier update)
                             continue;
@@ -566,6 +598,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     wave_sync();
                 }
                 amin = -wave_max(-amin);
+                wave_sync_full(); // (DS / DL / DZ are read across lanes below)
                 if (pass == 0) { // Mehrotra's centring parameter from the affine step
                     const double aaff = fmin(1.0, amin);
                     double acc = 0.0;
@@ -598,7 +631,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     maxe = fmax(maxe, fabs(re));
                 }
             }
-            wave_sync();
+            wave_sync_full();
             const double mu_new = wave_sum(musum2) * inv_mi;
             // inequality rows carry slacks, so their residuals shrink by exactly 1 - alpha; equality rows are only
             // penalised: their residual is what the new point leaves

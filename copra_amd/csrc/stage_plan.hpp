@@ -46,6 +46,7 @@ struct StagePlan {
     int m; // constraint rows of one instance (all stages)
     int ncls; // stage classes (stages with identical W and row templates share one)
     int max_stage_rows;
+    int max_dense; // most dense rows of one stage
     int x0_free; // InitialStateLMPC
     const int* cls_of_stage; // [N + 1]
     const int* stage_row0; // [N + 2] first row of stage k in the per-instance row arrays
@@ -299,7 +300,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
         if (out.blob.size() & 1) out.blob.push_back(0.0);
         return at;
     };
-    int max_rows = 0;
+    int max_rows = 0, max_dense = 0;
     out.cls_crow0.push_back(0);
     out.cls_row0.push_back(0);
     for (int c = 0; c < ncls; ++c) {
@@ -336,6 +337,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
             out.cls_ndense.push_back(nd);
         }
         if ((int)S.rows.size() > max_rows) max_rows = (int)S.rows.size();
+        if (out.cls_ndense.back() > max_dense) max_dense = out.cls_ndense.back();
     }
     if (max_rows > kRicMaxStageRows) return no("too many constraint rows in one stage");
     out.stage_row0.assign((size_t)N + 2, 0);
@@ -346,6 +348,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.m = out.stage_row0[(size_t)N + 1];
     sp.ncls = ncls;
     sp.max_stage_rows = max_rows;
+    sp.max_dense = max_dense;
     sp.x0_free = P.initial_state;
     sp.max_iter = 60;
     sp.delta = 1e-9;
@@ -364,7 +367,8 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.ws_total = o;
     // LDS of one wave (doubles): AB | P | T | M | pv, h, g, zk, dzk, dxn, d | K | Mi | row weights / coefficients
     sp.lds_doubles = align2(nx * nz) + align2(nx * nx) + align2(nx * nz > 2 * nu * nu ? nx * nz : 2 * nu * nu) + align2(nz * nz)
-        + 7 * align2(nz) + align2(nu * nx) + align2(nu * nu) + 2 * align2(max_rows > 0 ? max_rows : 1) + 2; // == carve_riccati
+        + 7 * align2(nz) + align2(nu * nx) + align2(nu * nu) + 3 * align2(max_rows > 0 ? max_rows : 1)
+        + align2(((max_rows > 0 ? max_rows : 1) + 1) / 2) + align2(nz * nz) + align2((max_dense > 0 ? max_dense : 1) * nz) + 2; // == carve_riccati
     out.eligible = true;
 }
 

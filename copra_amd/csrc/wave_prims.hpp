@@ -14,8 +14,24 @@ COPRA_DEV int lane_id() { return (int)threadIdx.x; }
 COPRA_DEV int instance_id() { return (int)blockIdx.x; }
 COPRA_DEV int instance_stride() { return (int)gridDim.x; }
 
-// workgroup == one wave: the barrier only has to order LDS traffic
+// workgroup == one wave.  wave_sync() orders the LDS traffic between the lanes of that wave: a wave's LDS instructions
+// execute in issue order, so a later ds_read sees an earlier ds_write of ANY lane of the same wave without waiting for
+// anything -- only the compiler must not move accesses across the point (fences at wavefront scope + a scheduling
+// barrier: no instruction is emitted).  __syncthreads() here used to cost an `s_waitcnt vmcnt(0) lgkmcnt(0)` per call --
+// every outstanding load, store and LDS access drained -- although the s_barrier itself is dropped for one-wave groups.
+// wave_sync_full() is that heavier form: it also makes the wave's global-memory stores visible to its other lanes'
+// later loads (cross-lane traffic through HBM workspaces).
+#ifndef COPRA_HEAVY_SYNC
+COPRA_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#else
 COPRA_DEV void wave_sync() { __syncthreads(); }
+#endif
+COPRA_DEV void wave_sync_full() { __syncthreads(); }
 
 COPRA_DEV int atomic_append(int* counter) { return atomicAdd(counter, 1); }
 COPRA_DEV long long cycle_counter() { return (long long)__builtin_readcyclecounter(); } // s_memtime

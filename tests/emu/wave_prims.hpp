@@ -41,6 +41,7 @@ COPRA_DEV int lane_id() { return emu::g_wave.lane; } // wave-per-instance kernel
 COPRA_DEV int instance_id() { return emu::g_wave.inst; }
 COPRA_DEV int instance_stride() { return emu::g_wave.ninst; }
 COPRA_DEV void wave_sync() { emu::barrier_block(); }
+COPRA_DEV void wave_sync_full() { emu::barrier_block(); }
 // workgroup-per-instance kernels (block_prims.hpp)
 COPRA_DEV int bt_tid() { return emu::g_wave.lane; }
 COPRA_DEV int bt_size() { return emu::g_wave.nthreads; }

@@ -1,0 +1,137 @@
+"""The stage-wise Riccati interior-point body (copra_amd/csrc/lmpc_riccati.hpp + stage_plan.hpp) on the CPU wave
+emulator, against the oracle and the 60-digit truth vectors of config 5.  The same body, compiled by hipcc, is what
+`-m gpu` tests run on the MI355X (tests/test_gpu_parity.py, solver "default" at long horizons).
+
+It is a different ALGORITHM from the reference's Goldfarb-Idnani path (interior point on the uncondensed problem); the
+QP is strictly convex, so what is compared is the unique optimum: U, X, x0*, status.  Iteration counts are Newton steps."""
+import numpy as np
+import pytest
+
+import fixtures as F
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import pyemu
+    pyemu.lib()
+    return pyemu
+
+
+def _rel(a, b):
+    return np.nanmax(np.abs(a - b) / (1.0 + np.abs(b)))
+
+
+@pytest.mark.parametrize("system", ["bounded", "ineq", "mixed"])
+@pytest.mark.parametrize("xcost", ["target", "trajectory", "mixed"])
+def test_reference_fixtures(emu, oracle, system, xcost):
+    """the nine {cost} x {inequality constraint} combinations of tests/TestLMPC.cpp, 40 steps"""
+    pb = getattr(F, system + "_system")(xcost, N=40)
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    re, ro = emu.lmpc_solve_riccati(*args), oracle.lmpc_solve(*args)
+    assert re["status"][0] == ro["status"] == 0 and re["not_converged"] == 0
+    assert _rel(re["control"][0], ro["control"]) <= RTOL and _rel(re["trajectory"][0], ro["trajectory"]) <= RTOL
+    assert re["iter"][0, 0] <= 30
+
+
+def test_config5_against_the_truth_vectors(emu, oracle):
+    """BASELINE config 5 at the specified R = 1e-6 I: within 1e-8 of the certified optimum (the CPU Goldfarb-Idnani path
+    is 1.3e-5 away from it, tests/test_golden.py::test_oracle_vs_config5_truth)"""
+    import test_golden as G
+    wl, picks = G.config5_truth_cases()
+    ist = wl["initial_state"]
+    ks = picks[:2]
+    re = emu.lmpc_solve_riccati(wl["A"][ks], wl["B"][ks], wl["d"][ks], wl["x0"][ks], wl["N"], wl["costs"], wl["cstrs"],
+                                initial_state=dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][ks], x0ub=ist["x0ub"][ks]))
+    assert (re["status"] == 0).all() and re["not_converged"] == 0
+    for j, k in enumerate(ks):
+        assert _rel(re["control"][j], G.TRUTH5["control_%d" % k]) <= 1e-8
+        assert _rel(re["trajectory"][j], G.TRUTH5["trajectory_%d" % k]) <= 1e-8
+        assert np.abs(re["x0_opt"][j] - G.TRUTH5["x0_opt_%d" % k]).max() <= 1e-12
+        assert np.abs(re["trajectory"][j].reshape(-1, 12)[-1, 6:]).max() <= 1e-9  # the terminal equality
+
+
+@pytest.mark.parametrize("initial_state", [False, True])
+def test_all_nine_classes_long_horizon(emu, oracle, initial_state):
+    pb = F.nine_class_problem(100)
+    b = 2
+    rng = np.random.default_rng(5)
+    x0 = np.tile(pb["x0"], (b, 1)) + 0.1 * rng.standard_normal((b, 2))
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=x0 - 0.05, x0ub=x0 + 0.05) if initial_state else None
+    re = emu.lmpc_solve_riccati(np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1)), x0,
+                                100, pb["costs"], pb["cstrs"], initial_state=ist)
+    for k in range(b):
+        io = dict(R=ist["R"], r=ist["r"], x0lb=x0[k] - 0.05, x0ub=x0[k] + 0.05) if initial_state else None
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 100, pb["costs"], pb["cstrs"], initial_state=io)
+        assert re["status"][k] == ro["status"] == 0
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+        if initial_state:
+            assert np.abs(re["x0_opt"][k] - ro["x0_opt"]).max() <= 1e-9
+
+
+def test_block_diagonal_full_size_entries_are_stage_wise(emu, oracle):
+    """full-size entries built by AutoSpan (block-diagonal M / E / G, time-varying p / weights / f) are stage-wise"""
+    pb = F.initial_state_problem(True)
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+    re, ro = emu.lmpc_solve_riccati(*args), oracle.lmpc_solve(*args)
+    assert re is not None and re["status"][0] == ro["status"] == 0
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+
+
+def test_controllers_that_are_not_stage_wise_are_refused(emu):
+    """EqSystem (602 equality rows, most of them redundant) and a full-size row that couples two steps stay on the
+    Goldfarb-Idnani path"""
+    pb = F.eq_system("target", N=40)
+    assert emu.lmpc_solve_riccati(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"]) is None
+    pb = F.ineq_system("target", N=20)
+    E = np.zeros((1, 2 * 21))
+    E[0, 3], E[0, 2 * 9 + 1] = 1.0, -1.0  # v_1 - v_9 <= 1
+    cstrs = pb["cstrs"] + [dict(kind="trajectory", E=E, f=[1.0])]
+    assert emu.lmpc_solve_riccati(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], cstrs) is None
+
+
+def test_infeasible_instances_are_queued_for_goldfarb_idnani(emu, oracle):
+    import edge_cases as E
+    q = E.opposite_state_rows_infeasible(30)
+    re = emu.lmpc_solve_riccati(q["A"], q["B"], q["d"], q["x0"], q["N"], q["costs"], q["cstrs"])
+    assert re["not_converged"] == 1 and re["status"][0] == 3  # (status 3 = provisional: the second tier overwrites it)
+    assert oracle.lmpc_solve(q["A"], q["B"], q["d"], q["x0"], q["N"], q["costs"], q["cstrs"])["status"] == 1
+
+
+def test_per_instance_data_and_pinned_bounds(emu, oracle):
+    """per-instance cost references, right-hand sides and control bounds (an infinite bound switches the row off, equal
+    bounds make it an equality), default x0 bounds of InitialStateLMPC (x0 fixed)"""
+    pb = F.ineq_system("trajectory", N=30)
+    b = 3
+    rng = np.random.default_rng(3)
+    x0 = np.tile(pb["x0"], (b, 1))
+    x0[:, 1] = -1.0 - rng.uniform(0.0, 2.0, b)
+    A, B, d = np.tile(pb["A"], (b, 1, 1)), np.tile(pb["B"], (b, 1, 1)), np.tile(pb["d"], (b, 1))
+    refs = {0: np.array([[0.0, -1.0], [0.0, -0.5], [0.1, -1.5]])}
+    hv = rng.uniform(100.0, 200.0, (b, 1))
+    mgen = 31 + 30
+    row_rhs = np.zeros((b, mgen))
+    row_rhs[:, 31:] = hv
+    re = emu.lmpc_solve_riccati(A, B, d, x0, 30, pb["costs"], pb["cstrs"], cost_refs=refs, row_rhs=row_rhs)
+    for k in range(b):
+        costs = [dict(pb["costs"][0], p=refs[0][k]), pb["costs"][1]]
+        cs = [pb["cstrs"][0], dict(pb["cstrs"][1], f=hv[k])]
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], x0[k], 30, costs, cs)
+        assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
+    pbb = F.bounded_system("trajectory", N=30)
+    lo = np.full((b, 30), -np.inf)
+    up = np.repeat(rng.uniform(60.0, 200.0, (b, 1)), 30, axis=1)
+    lo[2, 5], up[2, 5] = 120.0, 120.0  # a pinned control
+    up[1, 7] = np.inf  # a bound switched off
+    re = emu.lmpc_solve_riccati(A, B, d, x0, 30, pbb["costs"], pbb["cstrs"], bounds=(lo, up))
+    for k in range(b):
+        cs = [pbb["cstrs"][0], dict(kind="control_bound", lower=lo[k], upper=up[k])]
+        ro = oracle.lmpc_solve(pbb["A"], pbb["B"], pbb["d"], x0[k], 30, pbb["costs"], cs)
+        assert re["status"][k] == ro["status"] == 0 and _rel(re["control"][k], ro["control"]) <= RTOL
+    pb = F.bounded_system("trajectory", N=30)
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))  # bounds never set
+    re = emu.lmpc_solve_riccati(pb["A"], pb["B"], pb["d"], pb["x0"], 30, pb["costs"], pb["cstrs"], initial_state=ist)
+    ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 30, pb["costs"], pb["cstrs"])
+    assert re["status"][0] == 0 and np.abs(re["x0_opt"][0] - pb["x0"]).max() == 0.0
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
