@@ -164,7 +164,19 @@ __global__ __launch_bounds__(kLargeMaxN, 4) void copra_lmpc_large_kernel_w4(cons
 
 // Long horizons whose pieces are all stage-wise (stage_plan.hpp): Riccati interior-point method, one instance per
 // wavefront, persistent grid (lmpc_riccati.hpp); the instances it does not converge on are queued for the kernel above.
-__global__ __launch_bounds__(64, 4) void copra_lmpc_riccati_kernel(const FusedPlan P, const StagePlan S) { lmpc_riccati_body(P, S); }
+template <int NXT, int NUT>
+__global__ __launch_bounds__(64, 4) void copra_lmpc_riccati_kernel(const FusedPlan P, const StagePlan S)
+{
+    lmpc_riccati_body<NXT, NUT>(P, S);
+}
+typedef void (*riccati_kernel_t)(const FusedPlan, const StagePlan);
+// shapes with their own instantiation: BASELINE config 5 (12, 6) and the reference's test fixtures (2, 1)
+static riccati_kernel_t select_riccati_kernel(int nx, int nu)
+{
+    if (nx == 12 && nu == 6) return copra_lmpc_riccati_kernel<12, 6>;
+    if (nx == 2 && nu == 1) return copra_lmpc_riccati_kernel<2, 1>;
+    return copra_lmpc_riccati_kernel<0, 0>;
+}
 
 // n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
@@ -483,12 +495,13 @@ static copra_status_t prepare_riccati(copra_batch* h)
     sp.blob = upd(hs.blob);
     // persistent grid: as many one-wave workgroups as the device keeps resident
     const size_t lds_bytes = (size_t)sp.lds_doubles * sizeof(double);
-    if (e == hipSuccess) e = lds_opt_in(reinterpret_cast<const void*>(copra_lmpc_riccati_kernel), lds_bytes);
+    const void* ric_fn = reinterpret_cast<const void*>(select_riccati_kernel(sp.nx, sp.nu));
+    if (e == hipSuccess) e = lds_opt_in(ric_fn, lds_bytes);
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(copra_lmpc_riccati_kernel), 64, lds_bytes)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ric_fn, 64, lds_bytes)
             != hipSuccess
         || per_cu < 1) {
         (void)hipGetLastError();
@@ -1233,8 +1246,9 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
             const size_t ric_lds = (size_t)h->hs.sp.lds_doubles * sizeof(double);
             HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-            LDS_OPT_IN(copra_lmpc_riccati_kernel, ric_lds);
-            hipLaunchKernelGGL(copra_lmpc_riccati_kernel, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
+            const riccati_kernel_t ric_fn = select_riccati_kernel(P.nx, P.nu);
+            LDS_OPT_IN(ric_fn, ric_lds);
+            hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
             HIP_TRY(hipGetLastError());
             FusedPlan P2 = P;
             P2.from_list = 1;

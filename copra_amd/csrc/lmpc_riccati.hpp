@@ -41,9 +41,9 @@ struct RicLds {
     int* Uc; // ... and unit-row components
 };
 
-COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S)
+COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S, int nx, int nu)
 {
-    const int nx = S.nx, nu = S.nu, nz = S.nz;
+    const int nz = nx + nu;
     auto a2 = [](int v) { return (v + 1) & ~1; };
     RicLds L;
     double* p = lds;
@@ -73,13 +73,16 @@ COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S)
 // flags of a row of ONE instance
 enum { kRowIneq = 0, kRowEq = 1, kRowOff = 2 };
 
+// <NXT, NUT> = compile-time (xDim, uDim): index arithmetic folds and the small loops unroll; <0, 0> is the run-time-shape
+// instantiation (every `e / nz` is then an integer division, ~40 instructions: several times slower on the same problem)
+template <int NXT, int NUT>
 COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
 {
     const int lane = lane_id();
-    const int nx = S.nx, nu = S.nu, nz = S.nz, N = S.N, m = S.m;
+    const int nx = NXT ? NXT : S.nx, nu = NUT ? NUT : S.nu, nz = nx + nu, N = S.N, m = S.m;
     const int NZ = (N + 1) * nz;
     double* lds = lds_base();
-    const RicLds L = carve_riccati(lds, S);
+    const RicLds L = carve_riccati(lds, S, nx, nu);
     double* ws = S.ws + (size_t)instance_id() * (size_t)S.ws_total;
     double *Z = ws + S.oZ, *DZ = ws + S.oDZ, *Q = ws + S.oQ, *GB = ws + S.oGB;
     double *F = ws + S.oF, *Sv = ws + S.oS, *Lam = ws + S.oLam, *DS = ws + S.oDS, *DL = ws + S.oDL, *RP = ws + S.oRP;

@@ -291,7 +291,17 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
     std::vector<double> ws((size_t)hs.sp.ws_total + 8, __builtin_nan(""));
     hs.sp.ws = ws.data();
     const StagePlan& S = hs.sp;
-    int r = emu::run_wave([&]() { lmpc_riccati_body(P, S); }, (size_t)S.lds_doubles * sizeof(double), 0, 1);
+    // same dispatch as the HIP launcher (select_riccati_kernel)
+    int r = emu::run_wave(
+        [&]() {
+            if (S.nx == 12 && S.nu == 6)
+                lmpc_riccati_body<12, 6>(P, S);
+            else if (S.nx == 2 && S.nu == 1 && !std::getenv("COPRA_EMU_GENERIC"))
+                lmpc_riccati_body<2, 1>(P, S);
+            else
+                lmpc_riccati_body<0, 0>(P, S);
+        },
+        (size_t)S.lds_doubles * sizeof(double), 0, 1);
     if (not_converged) not_converged[0] = ovf_count;
     return r != 0 ? -100 : 0;
 }
