@@ -93,6 +93,18 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
     const double BIGF = 1e299;
 
     for (int inst = instance_id(); inst < P.batch; inst += instance_stride()) {
+        // optional phase profile (copra_batch_phase_profile): set-up | sweep 1 rows | sweep 1 gradient | sweep 1 factor |
+        // forward sweeps | sweep 3 | update + results | total, shader-clock cycles of this instance
+        long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        long long tprev = P.prof ? cycle_counter() : 0;
+        const long long tstart = tprev;
+        auto stamp = [&](int slot) {
+            if (P.prof) {
+                const long long t = cycle_counter();
+                prof[slot] += t - tprev;
+                tprev = t;
+            }
+        };
         // ------------------------------------------------------------------ 0. this instance's data
         const bool x0_free = S.x0_free && P.x0lb && P.x0ub; // (bounds never set: x0lb = x0ub = ps->x0, i.e. x0 is fixed)
         for (int e = lane; e < nx * nx; e += kWave) L.AB[e] = P.A[(size_t)inst * nx * nx + e];
@@ -436,6 +448,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         wave_sync_full();
         const double inv_mi = n_ineq > 0 ? 1.0 / (double)n_ineq : 0.0;
 
+        stamp(0);
         // ------------------------------------------------------------------ 2. Newton iterations
         int it = 0;
         bool converged = false;
@@ -472,9 +485,12 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     L.rowC[r] = Cv;
                 }
                 wave_sync();
+                stamp(1);
                 stage_gradient(k, true, true);
                 wave_sync();
+                stamp(2);
                 good = stage_factor(k, true) && good;
+                stamp(3);
             }
             const double mu = wave_sum(musum) * inv_mi;
             const double maxres = wave_max(maxr);
@@ -528,6 +544,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                         wave_sync();
                     }
                     wave_sync_full();
+                    stamp(5);
                 }
                 // dx_0
                 if (x0_free) {
@@ -602,6 +619,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 }
                 amin = -wave_max(-amin);
                 wave_sync_full(); // (DS / DL / DZ are read across lanes below)
+                stamp(4);
                 if (pass == 0) { // Mehrotra's centring parameter from the affine step
                     const double aaff = fmin(1.0, amin);
                     double acc = 0.0;
@@ -643,6 +661,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 good = false;
                 break;
             }
+            stamp(6);
             if (res_new <= 1e-9 && ((step_inf <= 1e-10 * (1.0 + z_inf) && mu_new <= 1e-8) || mu_new <= 1e-15)) {
                 converged = true;
                 break;
@@ -675,6 +694,11 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 P.iter[2 * (size_t)inst + 1] = 0;
                 if (P.ovf_count) P.ovf_list[atomic_append(P.ovf_count)] = inst;
             }
+        }
+        if (P.prof && lane == 0) {
+            stamp(6);
+            prof[7] = cycle_counter() - tstart;
+            for (int q = 0; q < 8; ++q) P.prof[8 * (size_t)inst + q] = prof[q];
         }
         wave_sync();
     }
