@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcopra_hip.so")
 
 COPRA_OK, COPRA_ERR_DOMAIN, COPRA_ERR_RUNTIME, COPRA_ERR_HIP, COPRA_ERR_UNSUPPORTED, COPRA_ERR_ARG = range(6)
 
-COST_KINDS = {"trajectory": 0, "target": 1, "control": 2, "mixed": 3}
-CSTR_KINDS = {"trajectory": 0, "control": 1, "mixed": 2, "trajectory_bound": 3, "control_bound": 4}
+COST_KINDS = {"trajectory": 0, "target": 1, "control": 2, "mixed": 3, "dense": 4}
+CSTR_KINDS = {"trajectory": 0, "control": 1, "mixed": 2, "trajectory_bound": 3, "control_bound": 4, "dense": 5}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -22,12 +22,14 @@ _ip = C.POINTER(C.c_int)
 
 class CostDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("m_cols", C.c_int), ("n_cols", C.c_int),
-                ("M", _dp), ("N", _dp), ("p", _dp), ("weights", _dp)]
+                ("M", _dp), ("N", _dp), ("p", _dp), ("weights", _dp),
+                ("Q", _dp), ("c", _dp), ("E", _dp), ("f", _dp)]  # COPRA_COST_DENSE
 
 
 class CstrDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("rows", C.c_int), ("e_cols", C.c_int), ("g_cols", C.c_int),
-                ("is_inequality", C.c_int), ("E", _dp), ("G", _dp), ("f", _dp), ("lower", _dp), ("upper", _dp)]
+                ("is_inequality", C.c_int), ("E", _dp), ("G", _dp), ("f", _dp), ("lower", _dp), ("upper", _dp),
+                ("A", _dp), ("b", _dp), ("Y", _dp), ("z", _dp)]  # COPRA_CSTR_DENSE
 
 
 class Dims(C.Structure):
@@ -63,6 +65,12 @@ def pack_costs(costs, keep):
     """costs: list of dicts {kind, M, N, p, weights}.  `keep` collects the numpy buffers the structs point into."""
     arr = (CostDesc * max(1, len(costs)))()
     for i, c in enumerate(costs):
+        if c["kind"] == "dense":  # a host-evaluated user cost function: Q, c (LMPC) / Q, E, f (InitialStateLMPC)
+            bufs = {k: (fcol(c[k]) if c.get(k) is not None else None) for k in ("Q", "c", "E", "f")}
+            keep.extend(bufs.values())
+            arr[i].kind = COST_KINDS["dense"]
+            arr[i].Q, arr[i].c, arr[i].E, arr[i].f = (dptr(bufs[k]) for k in ("Q", "c", "E", "f"))
+            continue
         M = fcol(np.atleast_2d(c["M"])) if c.get("M") is not None else None
         Nm = fcol(np.atleast_2d(c["N"])) if c.get("N") is not None else None
         p = fcol(np.atleast_1d(c["p"]))
@@ -92,6 +100,13 @@ def pack_cstrs(cstrs, keep):
         kind = CSTR_KINDS[c["kind"]]
         arr[i].kind = kind
         arr[i].is_inequality = 1 if c.get("ineq", True) else 0
+        if kind == 5:  # a host-evaluated user constraint: A, b (LMPC) / Y, A, z (InitialStateLMPC)
+            bufs = {k: (fcol(np.atleast_2d(c[k]) if k in ("A", "Y") else np.atleast_1d(c[k])) if c.get(k) is not None else None)
+                    for k in ("A", "b", "Y", "z")}
+            keep.extend(bufs.values())
+            arr[i].rows = bufs["A"].shape[0]
+            arr[i].A, arr[i].b, arr[i].Y, arr[i].z = (dptr(bufs[k]) for k in ("A", "b", "Y", "z"))
+            continue
         if kind in (3, 4):
             lo = fcol(np.atleast_1d(c["lower"]))
             up = fcol(np.atleast_1d(c["upper"]))
@@ -245,6 +260,8 @@ def lib():
         L.copra_device_info.restype = C.c_int
         L.copra_device_info.argtypes = [_ip, _ip, C.c_char_p, C.c_int]
         L.copra_abi_version.restype = C.c_int
+        L.copra_preview_update.restype = C.c_int
+        L.copra_preview_update.argtypes = [C.c_int] * 3 + [vp] * 6
         L.copra_batch_select_solver.restype = C.c_int
         L.copra_batch_select_solver.argtypes = [vp, C.c_int]
         L.copra_batch_solver_info.restype = C.c_int

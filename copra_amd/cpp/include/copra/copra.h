@@ -4,11 +4,17 @@
 //   include/PreviewSystem.h, costFunctions.h, constraints.h, LMPC.h, SolverInterface.h, solverUtils.h, AutoSpan.h
 // so that code (and tests) written against copra compile against this header; all arithmetic of LMPC::solve runs on
 // the GPU (one fused launch), nothing is computed on the host.  Differences, all documented in DESIGN.md:
-//   * the cost / constraint classes are DESCRIPTORS (the built-in nine); user subclasses of CostFunction / Constraint
-//     with their own update() are not supported on this path -- plug a custom QP pipeline in through
-//     SolverInterface (HipQuadProgSolver) instead;
-//   * every solve() has fresh-controller semantics (reference quirk Q2 -- accumulation across solves -- is not kept);
-//   * PreviewSystem has no public Phi / Psi / xi: the preview matrices only ever exist in LDS.
+//   * the nine built-in cost / constraint classes hand the device a DESCRIPTOR (their constructor arguments): the
+//     kernels evaluate them, nothing of them is computed on the host.  Their update() / Q() c() E() f() / A() b() Y() z()
+//     exist with the reference's signatures and, when a caller asks for them, are evaluated ON THE DEVICE as well;
+//   * user subclasses of CostFunction / EqIneqConstraint / ControlBoundConstraint (plug-in point 2) are supported the way
+//     the reference runs them: LMPC::solve calls their update(const PreviewSystem&) on the host, then hands the resulting
+//     dense Q c E f / A b Y z to the device (COPRA_COST_DENSE / COPRA_CSTR_DENSE), where they join the same fused solve;
+//   * LMPC::useSolver installs a user SolverInterface (plug-in point 1): the QP is then condensed on the device, copied
+//     out and handed to SI_problem / SI_solve / SI_result exactly as src/LMPC.cpp:79-101 does;
+//   * PreviewSystem::updateSystem() computes Phi / Psi / xi on the device (copra_preview_update); the solve path itself
+//     never materialises them;
+//   * every solve() has fresh-controller semantics (reference quirk Q2 -- accumulation across solves -- is not kept).
 #pragma once
 
 #include "../../../../include/copra_hip.h"
@@ -87,6 +93,7 @@ struct PreviewSystem {
         if (xInit.rows() != bias.rows()) COPRA_DOMAIN_ERROR("xInit and bias should have the same number of rows");
         if (numberOfSteps <= 0) COPRA_DOMAIN_ERROR("The number of step sould be a positive number! ");
         isUpdated = false;
+        previewOnHost = false;
         nrUStep = numberOfSteps;
         nrXStep = numberOfSteps + 1;
         xDim = (int)state.cols();
@@ -98,26 +105,132 @@ struct PreviewSystem {
         B = control;
         d = bias;
     }
-    void updateSystem() noexcept { isUpdated = true; } // Phi / Psi / xi are built on the device inside LMPC::solve
+    // src/PreviewSystem.cpp:57-74 -- Phi, Psi, xi through the device (copra_preview_update).  LMPC::solve only calls this
+    // when a host-evaluated user cost / constraint / solver needs the matrices.
+    void updateSystem() noexcept
+    {
+        Phi.resize(fullXDim, xDim);
+        Psi.resize(fullXDim, fullUDim);
+        xi.resize(fullXDim);
+        if (copra_preview_update(xDim, uDim, nrUStep, A.data(), B.data(), d.data(), Phi.data(), Psi.data(), xi.data()) == COPRA_OK) {
+            isUpdated = true;
+            previewOnHost = true;
+        }
+    }
     void xInit(const Eigen::VectorXd& xInit) { x0 = xInit; }
 
     bool isUpdated = false;
+    bool previewOnHost = false; // Phi / Psi / xi below hold the matrices of the current (A, B, d)
     int nrUStep = 0, nrXStep = 0, xDim = 0, uDim = 0, fullXDim = 0, fullUDim = 0;
     Eigen::VectorXd x0;
     Eigen::MatrixXd A, B;
     Eigen::VectorXd d;
+    Eigen::VectorXd xi; // include/PreviewSystem.h:58-60
+    Eigen::MatrixXd Phi, Psi;
 };
 
+namespace detail {
+    struct HandleGuard {
+        copra_batch_t* h = nullptr;
+        ~HandleGuard()
+        {
+            if (h) copra_batch_destroy(h);
+        }
+    };
+    inline copra_dims_t dims_of(const PreviewSystem& ps) { return copra_dims_t { ps.xDim, ps.uDim, ps.nrUStep, 1 }; }
+    // the checks of initializeCost / initializeConstraint (plan_builder.hpp == copra_batch_create), without the device
+    inline void check_pieces(const PreviewSystem& ps, const std::vector<copra_cost_desc_t>& costs,
+        const std::vector<copra_cstr_desc_t>& cstrs, copra_hip::HostPlan* out = nullptr)
+    {
+        copra_hip::HostPlan hp;
+        const copra_dims_t dims = dims_of(ps);
+        const copra_status_t rc = copra_hip::build_plan(hp, dims, (int)costs.size(), costs.data(), (int)cstrs.size(), cstrs.data());
+        if (rc == COPRA_ERR_DOMAIN) throw std::domain_error(hp.error);
+        if (rc == COPRA_ERR_RUNTIME) throw std::runtime_error(hp.error);
+        if (out) *out = hp;
+    }
+    // Q_, c_, E_, f_ of ONE built-in cost, evaluated by the device's condense code (the parity hook copra_batch_dump_qp):
+    // the LMPC form gives Q (minus LMPC::updateSystem's 1e-6 I, src/LMPC.cpp:228-230) and c, the InitialStateLMPC form
+    // gives E (top-right block of its Hessian) and f (tail of its linear term), src/InitialStateLMPC.cpp:80-84
+    inline void evaluate_cost_on_device(const PreviewSystem& ps, const copra_cost_desc_t& d, Eigen::MatrixXd& Q,
+        Eigen::VectorXd& c, Eigen::MatrixXd& E, Eigen::VectorXd& f)
+    {
+        const int n = ps.fullUDim, nx = ps.xDim;
+        const copra_dims_t dims = dims_of(ps);
+        Q.resize(n, n), c.resize(n), E.resize(nx, n), f.resize(n);
+        {
+            HandleGuard g;
+            throw_status(copra_batch_create(&g.h, &dims, 1, &d, 0, nullptr));
+            throw_status(copra_batch_set_system(g.h, ps.A.data(), ps.B.data(), ps.d.data(), ps.x0.data(), 0));
+            throw_status(copra_batch_dump_qp(g.h, 0, Q.data(), c.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+            for (int i = 0; i < n; ++i) Q(i, i) -= 1e-6;
+        }
+        Eigen::MatrixXd R = Eigen::MatrixXd::Identity(nx, nx), H(nx + n, nx + n);
+        Eigen::VectorXd r = Eigen::VectorXd::Zero(nx), g2(nx + n);
+        copra_initial_state_desc_t is { R.data(), r.data() };
+        HandleGuard g;
+        if (copra_batch_create_initial_state(&g.h, &dims, 1, &d, 0, nullptr, &is) != COPRA_OK) return; // (xDim > 16: E, f stay zero)
+        throw_status(copra_batch_set_system(g.h, ps.A.data(), ps.B.data(), ps.d.data(), ps.x0.data(), 0));
+        throw_status(copra_batch_dump_qp(g.h, 0, H.data(), g2.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        for (int j = 0; j < n; ++j) {
+            f(j) = g2(nx + j);
+            for (int a = 0; a < nx; ++a) E(a, j) = H(a, nx + j);
+        }
+    }
+    // A_, b_, Y_, z_ of ONE built-in equality / inequality constraint, the same way: [A | b] from the LMPC form
+    // (src/LMPC.cpp:257-271), [Y, A | z] from the InitialStateLMPC form (src/InitialStateLMPC.cpp:88-102)
+    inline void evaluate_constraint_on_device(const PreviewSystem& ps, const copra_cstr_desc_t& d, bool ineq, Eigen::MatrixXd& A,
+        Eigen::VectorXd& b, Eigen::MatrixXd& Y, Eigen::VectorXd& z)
+    {
+        const int n = ps.fullUDim, nx = ps.xDim;
+        const copra_dims_t dims = dims_of(ps);
+        int rows = 0;
+        {
+            HandleGuard g;
+            throw_status(copra_batch_create(&g.h, &dims, 0, nullptr, 1, &d));
+            int nv, ne, ni;
+            throw_status(copra_batch_qp_sizes(g.h, &nv, &ne, &ni));
+            rows = ineq ? ni : ne;
+            A.resize(rows, n), b.resize(rows), Y.resize(rows, nx), z.resize(rows);
+            throw_status(copra_batch_set_system(g.h, ps.A.data(), ps.B.data(), ps.d.data(), ps.x0.data(), 0));
+            throw_status(copra_batch_dump_qp(g.h, 0, nullptr, nullptr, ineq ? nullptr : A.data(), ineq ? nullptr : b.data(),
+                ineq ? A.data() : nullptr, ineq ? b.data() : nullptr, nullptr, nullptr));
+        }
+        Eigen::MatrixXd R = Eigen::MatrixXd::Identity(nx, nx), YA(rows, nx + n);
+        Eigen::VectorXd r = Eigen::VectorXd::Zero(nx);
+        copra_initial_state_desc_t is { R.data(), r.data() };
+        HandleGuard g;
+        if (copra_batch_create_initial_state(&g.h, &dims, 0, nullptr, 1, &d, &is) != COPRA_OK) return;
+        throw_status(copra_batch_set_system(g.h, ps.A.data(), ps.B.data(), ps.d.data(), ps.x0.data(), 0));
+        throw_status(copra_batch_dump_qp(g.h, 0, nullptr, nullptr, ineq ? nullptr : YA.data(), ineq ? nullptr : z.data(),
+            ineq ? YA.data() : nullptr, ineq ? z.data() : nullptr, nullptr, nullptr));
+        for (int i = 0; i < rows; ++i)
+            for (int a = 0; a < nx; ++a) Y(i, a) = YA(i, a);
+    }
+} // namespace detail
+
 // ---------------------------------------------------------------------------------------------- costFunctions.h
+// include/costFunctions.h:22-97.  A user subclass overrides autoSpan / initializeCost / update and fills Q_, c_ (read by
+// LMPC) and E_, f_ (read by InitialStateLMPC) in update(); the nine built-in classes instead describe themselves to the
+// device (deviceDescriptor) and are evaluated there.
 class CostFunction {
 public:
-    explicit CostFunction(std::string&& name, int kind)
+    explicit CostFunction(std::string&& name)
         : name_(std::move(name))
-        , kind_(kind)
     {
     }
     virtual ~CostFunction() = default;
     virtual void autoSpan() {}
+    virtual void initializeCost(const PreviewSystem& ps) // costFunctions.cpp:24-30
+    {
+        Q_.resize(ps.fullUDim, ps.fullUDim);
+        c_.resize(ps.fullUDim);
+        E_.resize(ps.xDim, ps.fullUDim);
+        f_.resize(ps.fullUDim);
+    }
+    virtual void update(const PreviewSystem& ps) = 0;
+    // engine hook: true + the constructor arguments when the device evaluates this cost itself (built-in classes)
+    virtual bool deviceDescriptor(copra_cost_desc_t&) const { return false; }
     // costFunctions.h:54-67
     void weights(const Eigen::VectorXd& w)
     {
@@ -133,6 +246,26 @@ public:
     }
     void weight(double w) { weights_.setConstant(w); } // costFunctions.h:72-76
     const std::string& name() const noexcept { return name_; }
+    const Eigen::MatrixXd& Q() const noexcept { return Q_; } // costFunctions.h:79-90
+    const Eigen::VectorXd& c() const noexcept { return c_; }
+    const Eigen::MatrixXd& E() const noexcept { return E_; }
+    const Eigen::VectorXd& f() const noexcept { return f_; }
+
+protected:
+    std::string name_;
+    bool fullSizeEntry_ = false;
+    Eigen::MatrixXd Q_, E_;
+    Eigen::VectorXd c_, f_, weights_;
+};
+
+// the four built-in classes: M / N / p / weights are the descriptor the kernels read
+class BuiltinCost : public CostFunction {
+public:
+    BuiltinCost(std::string&& name, int kind)
+        : CostFunction(std::move(name))
+        , kind_(kind)
+    {
+    }
     copra_cost_desc_t desc() const
     {
         copra_cost_desc_t d {};
@@ -146,23 +279,34 @@ public:
         d.weights = weights_.data();
         return d;
     }
-    void checkRows() const
-    { // costFunctions.cpp:47-49, 91-93, 125-127, 176-181
+    bool deviceDescriptor(copra_cost_desc_t& d) const override
+    {
+        d = desc();
+        return true;
+    }
+    void initializeCost(const PreviewSystem& ps) override // costFunctions.cpp:44-61, 88-98, 122-137, 173-193
+    {
         if (M_.size() && M_.rows() != p_.rows()) COPRA_DOMAIN_ERROR("M and p should have the same number of rows (try autoSpan)");
         if (N_.size() && N_.rows() != p_.rows()) COPRA_DOMAIN_ERROR("N and p should have the same number of rows (try autoSpan)");
+        detail::check_pieces(ps, { desc() }, {});
+        fullSizeEntry_ = (M_.size() && M_.cols() == ps.fullXDim && ps.fullXDim != ps.xDim)
+            || (N_.size() && N_.cols() == ps.fullUDim && ps.fullUDim != ps.uDim);
+        CostFunction::initializeCost(ps);
     }
+    // Q_, c_, E_, f_ as the reference's update() leaves them -- evaluated by the device, on request only (LMPC::solve
+    // never needs them for a built-in class)
+    void update(const PreviewSystem& ps) override { detail::evaluate_cost_on_device(ps, desc(), Q_, c_, E_, f_); }
 
 protected:
-    std::string name_;
     int kind_;
     Eigen::MatrixXd M_, N_;
-    Eigen::VectorXd p_, weights_;
+    Eigen::VectorXd p_;
 };
 
-class TrajectoryCost final : public CostFunction { // costFunctions.h:103-126
+class TrajectoryCost : public BuiltinCost { // costFunctions.h:103-126
 public:
     TrajectoryCost(const Eigen::MatrixXd& M, const Eigen::VectorXd& p)
-        : CostFunction("TrajectoryCost", COPRA_COST_TRAJECTORY)
+        : BuiltinCost("TrajectoryCost", COPRA_COST_TRAJECTORY)
     {
         M_ = M;
         p_ = p;
@@ -176,20 +320,20 @@ public:
         AutoSpan::spanVector(weights_, m);
     }
 };
-class TargetCost final : public CostFunction { // costFunctions.h:134-155
+class TargetCost : public BuiltinCost { // costFunctions.h:134-155
 public:
     TargetCost(const Eigen::MatrixXd& M, const Eigen::VectorXd& p)
-        : CostFunction("TargetCost", COPRA_COST_TARGET)
+        : BuiltinCost("TargetCost", COPRA_COST_TARGET)
     {
         M_ = M;
         p_ = p;
         weights_ = Eigen::VectorXd::Ones(p_.rows());
     }
 };
-class ControlCost final : public CostFunction { // costFunctions.h:163-186
+class ControlCost : public BuiltinCost { // costFunctions.h:163-186
 public:
     ControlCost(const Eigen::MatrixXd& N, const Eigen::VectorXd& p)
-        : CostFunction("ControlCost", COPRA_COST_CONTROL)
+        : BuiltinCost("ControlCost", COPRA_COST_CONTROL)
     {
         N_ = N;
         p_ = p;
@@ -203,10 +347,10 @@ public:
         AutoSpan::spanVector(weights_, m);
     }
 };
-class MixedCost final : public CostFunction { // costFunctions.h:194-219
+class MixedCost : public BuiltinCost { // costFunctions.h:194-219
 public:
     MixedCost(const Eigen::MatrixXd& M, const Eigen::MatrixXd& N, const Eigen::VectorXd& p)
-        : CostFunction("MixedCost", COPRA_COST_MIXED)
+        : BuiltinCost("MixedCost", COPRA_COST_MIXED)
     {
         M_ = M;
         N_ = N;
@@ -224,71 +368,105 @@ public:
 };
 
 // ---------------------------------------------------------------------------------------------- constraints.h
-enum class ConstraintFlag { Constraint, EqualityConstraint, InequalityConstraint, BoundConstraint };
+enum class ConstraintFlag { Constraint, EqualityConstraint, InequalityConstraint, BoundConstraint }; // constraints.h:28-33
 
-class Constraint {
+class Constraint { // constraints.h:42-79
 public:
-    Constraint(std::string&& name, int kind, bool ineq)
+    explicit Constraint(std::string&& name)
         : name_(std::move(name))
-        , kind_(kind)
-        , isIneq_(ineq)
     {
     }
     virtual ~Constraint() = default;
     virtual void autoSpan() = 0;
-    virtual ConstraintFlag constraintType() const noexcept
+    virtual void initializeConstraint(const PreviewSystem& ps) = 0;
+    virtual void update(const PreviewSystem& ps) = 0;
+    virtual ConstraintFlag constraintType() const noexcept = 0;
+    // engine hook: true + the constructor arguments when the device evaluates this constraint itself (built-in classes)
+    virtual bool deviceDescriptor(copra_cstr_desc_t&) const { return false; }
+    const std::string& name() const noexcept { return name_; }
+    int nrConstr() noexcept { return nrConstr_; }
+
+protected:
+    std::string name_;
+    int nrConstr_ = 0;
+    bool fullSizeEntry_ = false;
+    bool hasBeenInitialized_ = false;
+};
+
+class EqIneqConstraint : public Constraint { // constraints.h:84-107
+public:
+    EqIneqConstraint(const std::string& name, bool isInequalityConstraint)
+        : Constraint(name + (isInequalityConstraint ? " inequality constraint" : " equality constraint")) // constraints.cpp:22-32
+        , isIneq_(isInequalityConstraint)
+    {
+    }
+    const Eigen::MatrixXd& A() const noexcept { return A_; }
+    const Eigen::VectorXd& b() const noexcept { return b_; }
+    const Eigen::MatrixXd& Y() const noexcept { return Y_; }
+    const Eigen::VectorXd& z() const noexcept { return z_; }
+    ConstraintFlag constraintType() const noexcept override
     {
         return isIneq_ ? ConstraintFlag::InequalityConstraint : ConstraintFlag::EqualityConstraint;
     }
-    const std::string& name() const noexcept { return name_; }
-    int nrConstr() noexcept { return nrConstr_; }
+
+protected:
+    Eigen::MatrixXd A_, Y_;
+    Eigen::VectorXd b_, z_;
+    bool isIneq_;
+};
+
+// the three built-in equality / inequality classes: E / G / f are the descriptor the kernels read
+class BuiltinEqIneq : public EqIneqConstraint {
+public:
+    BuiltinEqIneq(const std::string& name, int kind, bool ineq)
+        : EqIneqConstraint(name, ineq)
+        , kind_(kind)
+    {
+    }
     copra_cstr_desc_t desc() const
     {
         copra_cstr_desc_t d {};
         d.kind = kind_;
         d.is_inequality = isIneq_ ? 1 : 0;
-        if (kind_ == COPRA_CSTR_TRAJECTORY_BOUND || kind_ == COPRA_CSTR_CONTROL_BOUND) {
-            d.rows = (int)lower_.rows();
-            d.lower = lower_.data();
-            d.upper = upper_.data();
-        } else {
-            d.rows = (int)f_.rows();
-            d.e_cols = (int)E_.cols();
-            d.g_cols = (int)G_.cols();
-            d.E = E_.size() ? E_.data() : nullptr;
-            d.G = G_.size() ? G_.data() : nullptr;
-            d.f = f_.data();
-        }
+        d.rows = (int)f_.rows();
+        d.e_cols = (int)E_.cols();
+        d.g_cols = (int)G_.cols();
+        d.E = E_.size() ? E_.data() : nullptr;
+        d.G = G_.size() ? G_.data() : nullptr;
+        d.f = f_.data();
         return d;
     }
-    void checkRows() const
+    bool deviceDescriptor(copra_cstr_desc_t& d) const override
     {
-        if (kind_ == COPRA_CSTR_TRAJECTORY_BOUND || kind_ == COPRA_CSTR_CONTROL_BOUND) {
-            if (lower_.rows() != upper_.rows()) COPRA_DOMAIN_ERROR("lower and upper should have the same number of rows (try autoSpan)");
-        } else {
-            if (E_.size() && E_.rows() != f_.rows()) COPRA_DOMAIN_ERROR("E and f should have the same number of rows (try autoSpan)");
-            if (G_.size() && G_.rows() != f_.rows()) COPRA_DOMAIN_ERROR("G and f should have the same number of rows (try autoSpan)");
-        }
+        d = desc();
+        return true;
     }
-    // move-consuming classes may be initialised once (constraints.cpp:108-110, 335-337)
-    bool consumesOnInit() const { return kind_ == COPRA_CSTR_CONTROL || kind_ == COPRA_CSTR_CONTROL_BOUND; }
-    bool hasBeenInitialized_ = false;
-    void setNrConstr(int n) { nrConstr_ = n; }
+    void initializeConstraint(const PreviewSystem& ps) override // constraints.cpp:45-64, 106-135, 171-195
+    {
+        if (kind_ == COPRA_CSTR_CONTROL && hasBeenInitialized_) // move semantics of the reference (constraints.cpp:108-110)
+            COPRA_RUNTIME_ERROR("You have initialized a " + name_ + " twice. As move semantics are used, you can't do so.");
+        if (E_.size() && E_.rows() != f_.rows()) COPRA_DOMAIN_ERROR("E and f should have the same number of rows (try autoSpan)");
+        if (G_.size() && G_.rows() != f_.rows()) COPRA_DOMAIN_ERROR("G and f should have the same number of rows (try autoSpan)");
+        copra_hip::HostPlan hp;
+        detail::check_pieces(ps, {}, { desc() }, &hp);
+        nrConstr_ = hp.plan.meq + hp.plan.mineq;
+        fullSizeEntry_ = (E_.size() && E_.cols() == ps.fullXDim && ps.fullXDim != ps.xDim)
+            || (G_.size() && G_.cols() == ps.fullUDim && ps.fullUDim != ps.uDim);
+        hasBeenInitialized_ = true;
+    }
+    // A_, b_, Y_, z_ as the reference's update() leaves them -- evaluated by the device, on request only
+    void update(const PreviewSystem& ps) override { detail::evaluate_constraint_on_device(ps, desc(), isIneq_, A_, b_, Y_, z_); }
 
 protected:
-    std::string name_;
     int kind_;
-    bool isIneq_;
-    int nrConstr_ = 0;
     Eigen::MatrixXd E_, G_;
-    Eigen::VectorXd f_, lower_, upper_;
+    Eigen::VectorXd f_;
 };
 
-class TrajectoryConstraint final : public Constraint { // constraints.h:114-145
+class TrajectoryConstraint : public BuiltinEqIneq { // constraints.h:114-145
 public:
     TrajectoryConstraint(const Eigen::MatrixXd& E, const Eigen::VectorXd& f, bool isInequalityConstraint = true)
-        : Constraint(std::string("Trajectory") + (isInequalityConstraint ? " inequality constraint" : " equality constraint"),
-            COPRA_CSTR_TRAJECTORY, isInequalityConstraint)
+        : BuiltinEqIneq("Trajectory", COPRA_CSTR_TRAJECTORY, isInequalityConstraint)
     {
         E_ = E;
         f_ = f;
@@ -300,11 +478,10 @@ public:
         AutoSpan::spanVector(f_, m);
     }
 };
-class ControlConstraint final : public Constraint { // constraints.h:153-185
+class ControlConstraint : public BuiltinEqIneq { // constraints.h:153-185
 public:
     ControlConstraint(const Eigen::MatrixXd& G, const Eigen::VectorXd& f, bool isInequalityConstraint = true)
-        : Constraint(std::string("Control") + (isInequalityConstraint ? " inequality constraint" : " equality constraint"),
-            COPRA_CSTR_CONTROL, isInequalityConstraint)
+        : BuiltinEqIneq("Control", COPRA_CSTR_CONTROL, isInequalityConstraint)
     {
         G_ = G;
         f_ = f;
@@ -316,12 +493,11 @@ public:
         AutoSpan::spanVector(f_, m);
     }
 };
-class MixedConstraint final : public Constraint { // constraints.h:193-226
+class MixedConstraint : public BuiltinEqIneq { // constraints.h:193-226
 public:
     MixedConstraint(const Eigen::MatrixXd& E, const Eigen::MatrixXd& G, const Eigen::VectorXd& f,
         bool isInequalityConstraint = true)
-        : Constraint(std::string("Control") + (isInequalityConstraint ? " inequality constraint" : " equality constraint"),
-            COPRA_CSTR_MIXED, isInequalityConstraint) // name quirk Q4 kept (constraints.h:204)
+        : BuiltinEqIneq("Control", COPRA_CSTR_MIXED, isInequalityConstraint) // name quirk Q4 kept (constraints.h:204)
     {
         E_ = E;
         G_ = G;
@@ -335,13 +511,13 @@ public:
         AutoSpan::spanVector(f_, m);
     }
 };
-class TrajectoryBoundConstraint final : public Constraint { // constraints.h:234-276
+class TrajectoryBoundConstraint : public EqIneqConstraint { // constraints.h:234-276
 public:
     TrajectoryBoundConstraint(const Eigen::VectorXd& lower, const Eigen::VectorXd& upper)
-        : Constraint("Trajectory bound inequality constraint", COPRA_CSTR_TRAJECTORY_BOUND, true)
+        : EqIneqConstraint("Trajectory bound", true)
+        , lower_(lower)
+        , upper_(upper)
     {
-        lower_ = lower;
-        upper_ = upper;
     }
     void autoSpan() override // constraints.cpp:232-261
     {
@@ -349,15 +525,41 @@ public:
         AutoSpan::spanVector(lower_, m);
         AutoSpan::spanVector(upper_, m);
     }
-    ConstraintFlag constraintType() const noexcept override { return ConstraintFlag::InequalityConstraint; }
+    copra_cstr_desc_t desc() const
+    {
+        copra_cstr_desc_t d {};
+        d.kind = COPRA_CSTR_TRAJECTORY_BOUND;
+        d.is_inequality = 1;
+        d.rows = (int)lower_.rows();
+        d.lower = lower_.data();
+        d.upper = upper_.data();
+        return d;
+    }
+    bool deviceDescriptor(copra_cstr_desc_t& d) const override
+    {
+        d = desc();
+        return true;
+    }
+    void initializeConstraint(const PreviewSystem& ps) override // constraints.cpp:263-282
+    {
+        if (lower_.rows() != upper_.rows()) COPRA_DOMAIN_ERROR("lower and upper should have the same number of rows (try autoSpan)");
+        copra_hip::HostPlan hp;
+        detail::check_pieces(ps, {}, { desc() }, &hp);
+        nrConstr_ = hp.plan.mineq;
+        hasBeenInitialized_ = true;
+    }
+    void update(const PreviewSystem& ps) override { detail::evaluate_constraint_on_device(ps, desc(), true, A_, b_, Y_, z_); }
+
+protected:
+    Eigen::VectorXd lower_, upper_;
 };
-class ControlBoundConstraint final : public Constraint { // constraints.h:284-308
+class ControlBoundConstraint : public Constraint { // constraints.h:284-308
 public:
     ControlBoundConstraint(const Eigen::VectorXd& lower, const Eigen::VectorXd& upper)
-        : Constraint("Control bound constraint", COPRA_CSTR_CONTROL_BOUND, true)
+        : Constraint("Control bound constraint")
+        , lower_(lower)
+        , upper_(upper)
     {
-        lower_ = lower;
-        upper_ = upper;
     }
     void autoSpan() override // constraints.cpp:326-331
     {
@@ -365,11 +567,51 @@ public:
         AutoSpan::spanVector(lower_, m);
         AutoSpan::spanVector(upper_, m);
     }
+    copra_cstr_desc_t desc() const
+    {
+        copra_cstr_desc_t d {};
+        d.kind = COPRA_CSTR_CONTROL_BOUND;
+        d.is_inequality = 1;
+        d.rows = (int)lower_.rows();
+        d.lower = lower_.data();
+        d.upper = upper_.data();
+        return d;
+    }
+    bool deviceDescriptor(copra_cstr_desc_t& d) const override
+    {
+        d = desc();
+        return true;
+    }
+    void initializeConstraint(const PreviewSystem& ps) override // constraints.cpp:333-357
+    {
+        if (hasBeenInitialized_) // constraints.cpp:335-337
+            COPRA_RUNTIME_ERROR("You have initialized a " + name_ + " twice. As move semantics are used, you can't do so.");
+        if (lower_.rows() != upper_.rows()) COPRA_DOMAIN_ERROR("lower and upper should have the same number of rows (try autoSpan)");
+        detail::check_pieces(ps, {}, { desc() });
+        nrConstr_ = ps.fullUDim;
+        hasBeenInitialized_ = true;
+        lb_.resize(ps.fullUDim), ub_.resize(ps.fullUDim);
+        update(ps);
+    }
+    void update(const PreviewSystem& ps) override // constraints.cpp:359-367: tile the per-step bounds over the horizon
+    {
+        lb_.resize(ps.fullUDim), ub_.resize(ps.fullUDim);
+        for (int i = 0; i < ps.fullUDim; ++i) {
+            const Eigen::Index src = (lower_.rows() == ps.uDim) ? (i % ps.uDim) : i;
+            lb_(i) = lower_(src);
+            ub_(i) = upper_(src);
+        }
+    }
     ConstraintFlag constraintType() const noexcept override { return ConstraintFlag::BoundConstraint; }
+    const Eigen::VectorXd& lower() noexcept { return lb_; } // constraints.h:298-300
+    const Eigen::VectorXd& upper() noexcept { return ub_; }
+
+protected:
+    Eigen::VectorXd lower_, upper_, lb_, ub_;
 };
 
 // ---------------------------------------------------------------------------------------------- SolverInterface.h
-class SolverInterface { // include/SolverInterface.h:19-81
+class SolverInterface { // include/SolverInterface.h:19-81; defaults of the optional members: src/SolverInterface.cpp:15-56
 public:
     SolverInterface() = default;
     virtual ~SolverInterface() = default;
@@ -377,9 +619,28 @@ public:
     virtual void SI_inform() const = 0;
     virtual int SI_iter() const
     {
-        std::printf("No iter() function for this qp\n"); // SolverInterface.cpp:15-19
+        std::printf("No iter() function for this qp\n");
         return 0;
     }
+    virtual int SI_maxIter() const
+    {
+        std::printf("No maxIter() function for this qp\n");
+        return 0;
+    }
+    virtual void SI_maxIter(int) { std::printf("No maxIter(int) function for this qp\n"); }
+    virtual void SI_printLevel(int) { std::printf("No printLevel(int) function for this qp\n"); }
+    virtual double SI_feasibilityTolerance() const
+    {
+        std::printf("No feasibilityTolerance() function for this qp\n");
+        return 0.;
+    }
+    virtual void SI_feasibilityTolerance(double) { std::printf("No feasibilityTolerance(double) function for this qp\n"); }
+    virtual bool SI_warmStart() const
+    {
+        std::printf("No warmStart() function for this qp\n");
+        return false;
+    }
+    virtual void SI_warmStart(bool) { std::printf("No warmStart(bool) function for this qp\n"); }
     virtual const Eigen::VectorXd& SI_result() const = 0;
     virtual void SI_problem(int nrVar, int nrEq, int nrInEq) = 0;
     virtual bool SI_solve(const Eigen::MatrixXd& Q, const Eigen::VectorXd& c, const Eigen::MatrixXd& Aeq,
@@ -424,7 +685,10 @@ private:
     Eigen::VectorXd x_;
 };
 
-enum class SolverFlag { DEFAULT, QuadProgDense, HipQuadProg }; // include/solverUtils.h:34-50 (+ the HIP back-end)
+// include/solverUtils.h:34-50.  DEFAULT: the engine's own choice inside the fused device solve (Goldfarb-Idnani up to 64
+// variables, the stage-wise Riccati interior-point kernel for long stage-wise horizons); QuadProgDense: always the
+// Goldfarb-Idnani kernels (the reference's QuadProgDense arithmetic); HipQuadProg: the same through plug-in point 1.
+enum class SolverFlag { DEFAULT, QuadProgDense, HipQuadProg };
 inline std::unique_ptr<SolverInterface> solverFactory(SolverFlag) // src/solverUtils.cpp:9-34
 {
     return std::unique_ptr<SolverInterface>(new HipQuadProgSolver());
@@ -433,8 +697,12 @@ inline std::unique_ptr<SolverInterface> solverFactory(SolverFlag) // src/solverU
 // ---------------------------------------------------------------------------------------------- LMPC.h
 class LMPC { // include/LMPC.h:36-191, src/LMPC.cpp
 public:
-    LMPC(SolverFlag = SolverFlag::DEFAULT) {}
-    LMPC(const std::shared_ptr<PreviewSystem>& ps, SolverFlag = SolverFlag::DEFAULT) { initializeController(ps); }
+    LMPC(SolverFlag flag = SolverFlag::DEFAULT) { selectQPSolver(flag); }
+    LMPC(const std::shared_ptr<PreviewSystem>& ps, SolverFlag flag = SolverFlag::DEFAULT)
+    {
+        selectQPSolver(flag);
+        initializeController(ps);
+    }
     virtual ~LMPC() { release(); }
     LMPC(LMPC&& o) noexcept { *this = std::move(o); }
     LMPC& operator=(LMPC&& o) noexcept
@@ -443,6 +711,8 @@ public:
         ps_ = std::move(o.ps_);
         spCost_ = std::move(o.spCost_);
         spConstr_ = std::move(o.spConstr_);
+        sol_ = std::move(o.sol_);
+        flag_ = o.flag_;
         h_ = o.h_;
         o.h_ = nullptr;
         dirty_ = o.dirty_;
@@ -450,26 +720,32 @@ public:
         trajectory_ = std::move(o.trajectory_);
         return *this;
     }
-    void selectQPSolver(SolverFlag) {} // the fused kernel is the solver on this path
+    // LMPC.cpp:62-65.  The fused device solve is the solver behind every flag; the flag picks its algorithm
+    // (copra_batch_select_solver) and drops a solver installed by useSolver.
+    void selectQPSolver(SolverFlag flag)
+    {
+        flag_ = flag;
+        sol_.reset();
+        if (h_) throw_status(copra_batch_select_solver(h_, flag_ == SolverFlag::DEFAULT ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE));
+    }
+    // LMPC.cpp:67-70: plug-in point 1.  With a user solver the QP is condensed on the device, copied out and handed to
+    // SI_problem / SI_solve / SI_result in the reference's order (LMPC.cpp:88-97, 284).
+    void useSolver(std::unique_ptr<SolverInterface>&& solver) { sol_ = std::move(solver); }
     void initializeController(const std::shared_ptr<PreviewSystem>& ps)
     {
         ps_ = ps;
         dirty_ = true;
     }
-    void addCost(const std::shared_ptr<CostFunction>& cost) // LMPC.cpp:118-122 -> initializeCost
+    void addCost(const std::shared_ptr<CostFunction>& cost) // LMPC.cpp:118-122
     {
-        cost->checkRows();
-        validate({ cost->desc() }, {});
+        cost->initializeCost(*ps_);
         spCost_.push_back(cost);
         dirty_ = true;
     }
-    void addConstraint(const std::shared_ptr<Constraint>& c) // LMPC.cpp:124-128 -> initializeConstraint
+    void addConstraint(const std::shared_ptr<Constraint>& c) // LMPC.cpp:124-128, 173-197
     {
-        if (c->consumesOnInit() && c->hasBeenInitialized_)
-            COPRA_RUNTIME_ERROR("You have initialized a " + c->name() + " twice. As move semantics are used, you can't do so.");
-        c->checkRows();
-        validate({}, { c->desc() });
-        c->hasBeenInitialized_ = true;
+        c->initializeConstraint(*ps_);
+        if (c->constraintType() == ConstraintFlag::Constraint) return; // (LMPC.cpp:192-193: unknown type, not stored)
         spConstr_.push_back(c);
         dirty_ = true;
     }
@@ -498,37 +774,52 @@ public:
     {
         using clock = std::chrono::high_resolution_clock;
         const auto t0 = clock::now();
-        rebuild();
-        throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
-        beforeSolve();
-        ps_->isUpdated = true;
-        qpValid_ = false;
-        const auto t1 = clock::now();
-        throw_status(copra_batch_solve(h_, nullptr));
-        Eigen::VectorXd u(ps_->fullUDim), x(ps_->fullXDim);
-        int it[2];
-        throw_status(copra_batch_get_results(h_, u.data(), x.data(), &fail_, it));
-        afterSolve(fail_ == 0);
-        double dev = 0.0;
-        copra_batch_last_solve_seconds(h_, &dev);
-        solveTime_ = dev;
-        iter_ = it[0];
-        if (fail_ == 0) { // LMPC.cpp:95-97: outputs only updated on success
-            control_ = u;
-            trajectory_ = x;
+        prepare();
+        bool ok;
+        if (sol_) {
+            // ---- user SolverInterface: the device condenses, the user's solver solves (LMPC.cpp:88-97) ----
+            qp_ = fetchQP();
+            qpValid_ = true;
+            const int nvar = (int)qp_.c.rows();
+            sol_->SI_problem(nvar, (int)qp_.beq.rows(), (int)qp_.bineq.rows());
+            const auto t1 = clock::now();
+            ok = sol_->SI_solve(qp_.Q, qp_.c, qp_.Aeq, qp_.beq, qp_.Aineq, qp_.bineq, qp_.lb, qp_.ub);
+            solveTime_ = std::chrono::duration<double>(clock::now() - t1).count();
+            fail_ = sol_->SI_fail();
+            checkDeleteCostsAndConstraints();
+            if (ok) updateResultsFrom(sol_->SI_result());
+        } else {
+            qpValid_ = false;
+            throw_status(copra_batch_solve(h_, nullptr));
+            Eigen::VectorXd u(ps_->fullUDim), x(ps_->fullXDim);
+            int it[2];
+            throw_status(copra_batch_get_results(h_, u.data(), x.data(), &fail_, it));
+            ok = fail_ == 0;
+            afterSolve(ok);
+            double dev = 0.0;
+            copra_batch_last_solve_seconds(h_, &dev);
+            solveTime_ = dev; // device time of the launch
+            iter_ = it[0];
+            checkDeleteCostsAndConstraints();
+            if (ok) { // LMPC.cpp:95-97: outputs only updated on success
+                control_ = u;
+                trajectory_ = x;
+            }
         }
-        (void)t1;
+        ps_->isUpdated = true;
         solveAndBuildTime_ = std::chrono::duration<double>(clock::now() - t0).count();
-        return fail_ == 0;
+        return ok;
     }
     void inform() const noexcept
     {
-        HipQuadProgSolver s;
-        (void)s;
+        if (sol_) {
+            sol_->SI_inform();
+            return;
+        }
         std::printf("%s\n", fail_ == 0 ? "No problems" : fail_ == 1 ? "The minimization problem has no solution"
                                                                     : "Problems with the decomposition of Q (Is it symmetric?)");
     }
-    double solveTime() const noexcept { return solveTime_; } // device time of the fused launch
+    double solveTime() const noexcept { return solveTime_; }
     double solveAndBuildTime() const noexcept { return solveAndBuildTime_; }
     const Eigen::VectorXd& control() const noexcept { return control_; }
     const Eigen::VectorXd& trajectory() const noexcept { return trajectory_; }
@@ -536,14 +827,14 @@ public:
     int iter() const noexcept { return iter_; }
     int nrEqConstr()
     {
-        rebuild();
+        prepare();
         int n, e, i;
         copra_batch_qp_sizes(h_, &n, &e, &i);
         return e;
     }
     int nrIneqConstr()
     {
-        rebuild();
+        prepare();
         int n, e, i;
         copra_batch_qp_sizes(h_, &n, &e, &i);
         return i;
@@ -555,23 +846,8 @@ public:
     };
     DenseQP denseQP()
     {
-        rebuild();
-        throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
-        beforeSolve();
-        int n, e, i;
-        copra_batch_qp_sizes(h_, &n, &e, &i);
-        DenseQP q;
-        q.Q.resize(n, n);
-        q.c.resize(n);
-        q.Aeq.resize(e, n);
-        q.beq.resize(e);
-        q.Aineq.resize(i, n);
-        q.bineq.resize(i);
-        q.lb.resize(n);
-        q.ub.resize(n);
-        throw_status(copra_batch_dump_qp(h_, 0, q.Q.data(), q.c.data(), q.Aeq.data(), q.beq.data(), q.Aineq.data(),
-            q.bineq.data(), q.lb.data(), q.ub.data()));
-        return q;
+        prepare();
+        return fetchQP();
     }
 
     // the accessors of LMPC.h:112-127 (matrices of the last problem handed to the solver), fetched from the device on
@@ -602,14 +878,65 @@ protected:
     }
     virtual void beforeSolve() {}
     virtual void afterSolve(bool) {}
-    void validate(const std::vector<copra_cost_desc_t>& costs, const std::vector<copra_cstr_desc_t>& cstrs) const
+    // LMPC.cpp:282-286 with a user solver's result: control = U, trajectory = Phi x0 + Psi U + xi on the host
+    virtual void updateResultsFrom(const Eigen::VectorXd& result)
     {
-        // the same host-side checks copra_batch_create runs (plan_builder.hpp), without touching the device
-        copra_hip::HostPlan hp;
-        copra_dims_t dims { ps_->xDim, ps_->uDim, ps_->nrUStep, 1 };
-        const copra_status_t rc = copra_hip::build_plan(hp, dims, (int)costs.size(), costs.data(), (int)cstrs.size(), cstrs.data());
-        if (rc == COPRA_ERR_DOMAIN) throw std::domain_error(hp.error);
-        if (rc == COPRA_ERR_RUNTIME) throw std::runtime_error(hp.error);
+        control_ = result;
+        hostTrajectory(ps_->x0, control_);
+    }
+    void hostTrajectory(const Eigen::VectorXd& x0, const Eigen::VectorXd& U)
+    {
+        needPreview();
+        trajectory_.resize(ps_->fullXDim);
+        for (int i = 0; i < ps_->fullXDim; ++i) {
+            double acc = ps_->xi(i);
+            for (int a = 0; a < ps_->xDim; ++a) acc += ps_->Phi(i, a) * x0(a);
+            for (int j = 0; j < ps_->fullUDim; ++j) acc += ps_->Psi(i, j) * U(j);
+            trajectory_(i) = acc;
+        }
+    }
+    void needPreview()
+    {
+        if (!ps_->previewOnHost) ps_->updateSystem(); // LMPC.cpp:233
+        if (!ps_->previewOnHost) throw std::runtime_error(std::string("PreviewSystem::updateSystem: ") + copra_last_error());
+    }
+    // everything of LMPC::updateSystem + makeQPForm that is not the device's job: host-evaluated user pieces are updated,
+    // the controller handle is (re)built from the descriptors, the system and x0 go to the device
+    void prepare()
+    {
+        bool custom = false;
+        copra_cost_desc_t cdesc;
+        copra_cstr_desc_t kdesc;
+        for (auto& c : spCost_) custom = custom || !c->deviceDescriptor(cdesc);
+        for (auto& c : spConstr_) custom = custom || !c->deviceDescriptor(kdesc);
+        if (custom) { // LMPC.cpp:233-247: constraints first, then costs
+            needPreview();
+            for (auto& c : spConstr_)
+                if (!c->deviceDescriptor(kdesc)) c->update(*ps_);
+            for (auto& c : spCost_)
+                if (!c->deviceDescriptor(cdesc)) c->update(*ps_);
+            dirty_ = true; // their matrices are part of the plan
+        }
+        rebuild();
+        throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
+        beforeSolve();
+    }
+    DenseQP fetchQP()
+    {
+        int n, e, i;
+        copra_batch_qp_sizes(h_, &n, &e, &i);
+        DenseQP q;
+        q.Q.resize(n, n);
+        q.c.resize(n);
+        q.Aeq.resize(e, n);
+        q.beq.resize(e);
+        q.Aineq.resize(i, n);
+        q.bineq.resize(i);
+        q.lb.resize(n);
+        q.ub.resize(n);
+        throw_status(copra_batch_dump_qp(h_, 0, q.Q.data(), q.c.data(), q.Aeq.data(), q.beq.data(), q.Aineq.data(),
+            q.bineq.data(), q.lb.data(), q.ub.data()));
+        return q;
     }
     void rebuild()
     {
@@ -617,12 +944,69 @@ protected:
         release();
         std::vector<copra_cost_desc_t> cd;
         std::vector<copra_cstr_desc_t> kd;
-        for (auto& c : spCost_) cd.push_back(c->desc());
-        for (auto& c : spConstr_) kd.push_back(c->desc());
-        copra_dims_t dims { ps_->xDim, ps_->uDim, ps_->nrUStep, 1 };
+        for (auto& c : spCost_) {
+            copra_cost_desc_t d {};
+            if (!c->deviceDescriptor(d)) { // host-evaluated user cost (LMPC.cpp:252-255 / InitialStateLMPC.cpp:80-84)
+                d = copra_cost_desc_t {};
+                d.kind = COPRA_COST_DENSE;
+                if (c->Q().rows() != ps_->fullUDim || c->Q().cols() != ps_->fullUDim || c->c().rows() != ps_->fullUDim
+                    || c->E().rows() != ps_->xDim || c->E().cols() != ps_->fullUDim || c->f().rows() != ps_->fullUDim)
+                    COPRA_DOMAIN_ERROR("cost '" + c->name() + "': Q / c / E / f do not have the sizes initializeCost gives them");
+                d.Q = c->Q().data(), d.c = c->c().data(), d.E = c->E().data(), d.f = c->f().data();
+            }
+            cd.push_back(d);
+        }
+        for (auto& c : spConstr_) {
+            copra_cstr_desc_t d {};
+            if (!c->deviceDescriptor(d)) {
+                d = copra_cstr_desc_t {};
+                if (c->constraintType() == ConstraintFlag::BoundConstraint) { // LMPC.cpp:274-279: lower() / upper()
+                    auto b = std::static_pointer_cast<ControlBoundConstraint>(c);
+                    d.kind = COPRA_CSTR_CONTROL_BOUND;
+                    d.rows = (int)b->lower().rows();
+                    d.lower = b->lower().data();
+                    d.upper = b->upper().data();
+                } else { // LMPC.cpp:257-271 / InitialStateLMPC.cpp:88-102: A b Y z
+                    auto q = std::static_pointer_cast<EqIneqConstraint>(c);
+                    d.kind = COPRA_CSTR_DENSE;
+                    d.is_inequality = c->constraintType() == ConstraintFlag::InequalityConstraint ? 1 : 0;
+                    d.rows = (int)q->A().rows();
+                    if (q->A().cols() != ps_->fullUDim || q->b().rows() != d.rows || q->Y().rows() != d.rows
+                        || q->Y().cols() != ps_->xDim || q->z().rows() != d.rows)
+                        COPRA_DOMAIN_ERROR("constraint '" + c->name() + "': A / b / Y / z sizes do not match");
+                    d.A = q->A().data(), d.b = q->b().data(), d.Y = q->Y().data(), d.z = q->z().data();
+                }
+            }
+            kd.push_back(d);
+        }
+        const copra_dims_t dims = detail::dims_of(*ps_);
         throw_status(createHandle(dims, cd, kd));
+        throw_status(copra_batch_select_solver(h_, flag_ == SolverFlag::DEFAULT ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE));
         dirty_ = false;
         qpValid_ = false;
+    }
+    // LMPC.cpp:288-307: a cost / constraint the caller has released is dropped after the solve (the controller's own
+    // reference is then the only one: one list here, where the reference keeps a master and a typed list)
+    void checkDeleteCostsAndConstraints()
+    {
+        for (auto it = spConstr_.begin(); it != spConstr_.end();) {
+            if (it->use_count() <= 1) {
+                std::fprintf(stderr, "A '%s' has been destroyed.\nIt has been removed from the controller\n", (*it)->name().c_str());
+                it = spConstr_.erase(it);
+                dirty_ = true;
+            } else {
+                ++it;
+            }
+        }
+        for (auto it = spCost_.begin(); it != spCost_.end();) {
+            if (it->use_count() <= 1) {
+                std::fprintf(stderr, "A '%s' has been destroyed.\nIt has been removed from the controller\n", (*it)->name().c_str());
+                it = spCost_.erase(it);
+                dirty_ = true;
+            } else {
+                ++it;
+            }
+        }
     }
     void release()
     {
@@ -633,6 +1017,8 @@ protected:
     std::shared_ptr<PreviewSystem> ps_;
     std::vector<std::shared_ptr<CostFunction>> spCost_;
     std::vector<std::shared_ptr<Constraint>> spConstr_;
+    std::unique_ptr<SolverInterface> sol_; // a user solver (useSolver); null: the fused device solve
+    SolverFlag flag_ = SolverFlag::DEFAULT;
     copra_batch_t* h_ = nullptr;
     bool dirty_ = true;
     Eigen::VectorXd control_, trajectory_;
@@ -687,6 +1073,12 @@ protected:
         if (!ok) return;
         x0opt_.resize(ps_->xDim);
         throw_status(copra_batch_get_initial_state(h_, x0opt_.data()));
+    }
+    void updateResultsFrom(const Eigen::VectorXd& result) override // InitialStateLMPC.cpp:124-128
+    {
+        x0opt_ = result.head(ps_->xDim);
+        control_ = result.tail(ps_->fullUDim);
+        hostTrajectory(x0opt_, control_);
     }
     Eigen::MatrixXd R_;
     Eigen::VectorXd r_, x0lb_, x0ub_, x0opt_;

@@ -98,6 +98,49 @@ __global__ __launch_bounds__(64) void copra_lmpc_shared_tier2_kernel(const Fused
     }
 }
 
+// PreviewSystem::updateSystem (src/PreviewSystem.cpp:57-74) as matrices, for host-evaluated user subclasses of Constraint /
+// CostFunction (copra_preview_update).  One workgroup runs the recursion Phi_i = A Phi_{i-1}, G_i = A G_{i-1} (G_0 = B),
+// xi_i = A xi_{i-1} + d; a second launch spreads the first block column over Psi_{i,j} = G_{i-1-j}.
+__global__ __launch_bounds__(256) void copra_preview_recursion_kernel(int nx, int nu, int N, const double* A, const double* B,
+    const double* d, double* Phi, double* G, double* xi)
+{
+    const int X = nx * (N + 1), tid = (int)threadIdx.x, T = (int)blockDim.x;
+    for (int e = tid; e < nx * nx; e += T) Phi[(e % nx) + (size_t)X * (e / nx)] = (e % nx == e / nx) ? 1.0 : 0.0; // Phi_0 = I (:51)
+    for (int e = tid; e < nx * nu; e += T) G[e] = B[e]; // Psi_{1,0} = B (:60)
+    for (int e = tid; e < nx; e += T) xi[e] = 0.0;
+    __syncthreads();
+    for (int i = 1; i <= N; ++i) {
+        for (int e = tid; e < nx * (nx + nu + 1); e += T) {
+            const int c = e / nx, r = e - c * nx;
+            double acc = 0.0;
+            if (c < nx) { // Phi_i = A Phi_{i-1} (:59, :64)
+                for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * Phi[((i - 1) * nx + t) + (size_t)X * c];
+                Phi[(i * nx + r) + (size_t)X * c] = acc;
+            } else if (c < nx + nu) { // G_i = A G_{i-1} (:65); G_N is not part of Psi
+                if (i < N) {
+                    const int cc = c - nx;
+                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * G[(size_t)(i - 1) * nx * nu + t + nx * cc];
+                    G[(size_t)i * nx * nu + r + nx * cc] = acc;
+                }
+            } else { // xi_i = A xi_{i-1} + d (:61, :70)
+                acc = d[r];
+                for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * xi[(i - 1) * nx + t];
+                xi[i * nx + r] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void copra_preview_fill_kernel(int nx, int nu, int N, const double* G, double* Psi)
+{
+    const size_t X = (size_t)nx * (N + 1), U = (size_t)nu * N;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= X * U) return;
+    const size_t col = e / X, row = e - col * X;
+    const int i = (int)(row / nx), r = (int)(row - (size_t)i * nx), j = (int)(col / nu), c = (int)(col - (size_t)j * nu);
+    Psi[e] = (j < i) ? G[(size_t)(i - 1 - j) * nx * nu + r + nx * c] : 0.0; // Psi_{i,j} = A^(i-1-j) B (:66-69), row block 0 is zero
+}
+
 // out[b][row0 + s * r + i] = f[b][i] for the steps s of one constraint (copra_batch_set_constraint_rhs)
 __global__ void copra_scatter_rhs_kernel(const double* f, double* out, int batch, int r, int steps, int row0, int mgen)
 {
@@ -533,6 +576,40 @@ extern "C" {
 
 int copra_abi_version(void) { return 2; }
 
+copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
+    double* Psi, double* xi)
+{
+    if (nx <= 0 || nu <= 0 || N <= 0) return fail(COPRA_ERR_DOMAIN, "copra_preview_update: dimensions and number of steps must be positive");
+    if (!A || !B || !d || !Phi || !Psi || !xi) return fail(COPRA_ERR_ARG, "copra_preview_update: null argument");
+    const size_t X = (size_t)nx * (N + 1), U = (size_t)nu * N;
+    double *dA = nullptr, *dB = nullptr, *dd = nullptr, *dPhi = nullptr, *dPsi = nullptr, *dxi = nullptr, *dG = nullptr;
+    hipError_t e = hipMalloc((void**)&dA, (size_t)nx * nx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dB, (size_t)nx * nu * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)nx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dPhi, X * nx * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dPsi, X * U * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dxi, X * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dG, (size_t)N * nx * nu * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dA, A, (size_t)nx * nx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, B, (size_t)nx * nu * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dd, d, (size_t)nx * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(copra_preview_recursion_kernel, dim3(1), dim3(256), 0, nullptr, nx, nu, N, dA, dB, dd, dPhi, dG, dxi);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        const size_t total = X * U;
+        hipLaunchKernelGGL(copra_preview_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, nx, nu, N, dG, dPsi);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(Phi, dPhi, X * nx * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(Psi, dPsi, X * U * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(xi, dxi, X * sizeof(double), hipMemcpyDeviceToHost);
+    for (double* q : { dA, dB, dd, dPhi, dPsi, dxi, dG }) (void)hipFree(q);
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_preview_update: ") + hipGetErrorString(e));
+    return COPRA_OK;
+}
+
 copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_select_solver: null handle");
@@ -897,7 +974,9 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: null handle");
     const FusedPlan& P = h->hp.plan;
-    if (cost_index < 0 || cost_index >= P.ncost) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: no such cost");
+    if (cost_index < 0 || cost_index >= (int)h->hp.cost_slot.size()) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: no such cost");
+    cost_index = h->hp.cost_slot[(size_t)cost_index]; // (dense costs are not among the kernel-evaluated terms)
+    if (cost_index < 0) return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference: a dense (host-evaluated) cost has no reference p");
     if ((p != nullptr) != (h->cost_p[cost_index] != nullptr)) h->model_dirty = true; // shared model: c0 / C2 change
     if (!p) { // back to the controller-wide reference given at creation
         h->cost_p[cost_index] = nullptr;

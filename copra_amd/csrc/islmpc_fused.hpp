@@ -319,6 +319,12 @@ COPRA_DEV void islmpc_fused_body(const FusedPlan& P, int inst)
         }
     }
     wave_sync();
+    if (P.denseQ >= 0 && lane < n) { // host-evaluated user cost functions: Q += Q_, E += E_, f += f_ (InitialStateLMPC.cpp:80-84)
+        const double* Qd = P.params + P.denseQ + (size_t)n * lane;
+        for (int i = 0; i <= lane; ++i) Jq[i * ldq + lane] += Qd[i];
+        for (int a = 0; a < nx; ++a) Eb[a + nx * lane] += P.params[P.denseE + a + nx * lane];
+        fj += P.params[P.densef + lane];
+    }
     // ---- assemble [[R + E Q^-1 E', E], [E', Q]] (upper triangle) and [r; f] ----
     if (lane < n) {
         for (int i = 0; i <= lane; ++i) S.J[(nx + i) * ld + nx + lane] = Jq[i * ldq + lane];

@@ -780,6 +780,11 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         // start so that eleven registers are not carried (and spilled) across the preview and cost phases
         if (COPRA_LATE_ROW_CACHE) rows.cache_own_row();
         wave_sync();
+        if (P.denseQ >= 0 && lane < n) { // host-evaluated user cost functions (COPRA_COST_DENSE): Q += Q_, c += c_ (LMPC.cpp:252-255)
+            const double* Qd = P.params + P.denseQ + (size_t)n * lane;
+            for (int i = 0; i <= lane; ++i) Q[fidx<TRI_>(i, lane, ld)] += Qd[i];
+            cj += P.params[P.densec + lane];
+        }
         if (lane < n) S.cvec[lane] = cj;
         wave_sync();
         if (inst == P.dump_instance && P.dumpQ) { // parity hook (LMPC::Q(), LMPC::c(); LMPC.h:113-115)

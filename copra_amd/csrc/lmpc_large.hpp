@@ -380,6 +380,16 @@ COPRA_DEV void large_costs(const FusedPlan& P, int inst, double* lds, double* F,
         }
     }
     bt_sync();
+    if (P.denseQ >= 0 && tid < n) { // host-evaluated user cost functions (COPRA_COST_DENSE), lower triangle: row tid
+        const double* Qd = P.params + P.denseQ;
+        for (int c = 0; c <= tid; ++c) Q[(size_t)c * ld + tid] += Qd[(size_t)n * c + tid];
+        if (linear) {
+            cj += is ? P.params[P.densef + tid] : P.params[P.densec + tid]; // InitialStateLMPC.cpp:84 / LMPC.cpp:254
+            if (is)
+                for (int a = 0; a < nx; ++a) Ecol[a] += P.params[P.denseE + a + nx * tid];
+        }
+    }
+    bt_sync();
 }
 
 COPRA_DEV void lmpc_large_body(const FusedPlan& P)

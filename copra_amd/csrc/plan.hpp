@@ -171,6 +171,9 @@ struct FusedPlan {
     int ncost;
     CostTerm cost[kMaxCosts];
     const double* cost_p[kMaxCosts]; // per-instance references p of cost t: [batch][rows], or nullptr = the shared one
+    // sum of the COPRA_COST_DENSE terms (host-evaluated user cost functions): offsets into `params`, -1 = none.
+    // Q (n x n, column-major, both triangles), c (n), E (nx x n), f (n)
+    int denseQ, densec, denseE, densef;
     int rmax; // max rows over the per-step costs
     int rfull; // max rows over the full-size costs (0 if none)
     // constraint rows

@@ -40,6 +40,7 @@ struct HostPlan {
     // where the rows of constraint k (position in the user's array) sit in the stacked order: row = row0 + s * per_step
     // + i for its steps s and lines i (steps == 1 for a full-size entry); row0 < 0: bound constraint, no rows
     std::vector<int> cstr_row0, cstr_per_step, cstr_steps;
+    std::vector<int> cost_slot; // position of the user's cost k among the kernel-evaluated cost terms, -1: a dense cost
 };
 
 // qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
@@ -199,10 +200,6 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.isR.assign(is->R, is->R + (size_t)nx * nx);
         hp.isr.assign(is->r, is->r + nx);
     }
-    if (n_costs > kMaxCosts) {
-        hp.error = "too many cost functions for the fused kernel";
-        return COPRA_ERR_UNSUPPORTED;
-    }
     auto push = [&](const double* src, int count) {
         int at = (int)hp.params.size();
         hp.params.insert(hp.params.end(), src, src + count);
@@ -211,6 +208,41 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     };
 
     // ---------------- costs ----------------
+    // COPRA_COST_DENSE terms (host-evaluated user cost functions) are summed into one dense block; the others become
+    // cost terms the kernels evaluate
+    std::vector<double> dQ, dc, dE, df;
+    std::vector<copra_cost_desc_t> builtin;
+    for (int k = 0; k < n_costs; ++k) {
+        const copra_cost_desc_t& c = costs[k];
+        hp.cost_slot.push_back(c.kind != COPRA_COST_DENSE ? (int)builtin.size() : -1);
+        if (c.kind != COPRA_COST_DENSE) {
+            builtin.push_back(c);
+            continue;
+        }
+        if (!c.Q || (!is && !c.c) || (is && (!c.E || !c.f))) // LMPC.cpp:252-255 / InitialStateLMPC.cpp:80-84
+            return hp.error = "dense cost: Q and c (LMPC) or Q, E and f (InitialStateLMPC) are needed", COPRA_ERR_DOMAIN;
+        if (dQ.empty()) dQ.assign((size_t)U * U, 0.0), dc.assign((size_t)U, 0.0), dE.assign((size_t)nx * U, 0.0), df.assign((size_t)U, 0.0);
+        for (size_t e = 0; e < (size_t)U * U; ++e) dQ[e] += c.Q[e];
+        if (c.c)
+            for (int e = 0; e < U; ++e) dc[(size_t)e] += c.c[e];
+        if (c.E)
+            for (size_t e = 0; e < (size_t)nx * U; ++e) dE[e] += c.E[e];
+        if (c.f)
+            for (int e = 0; e < U; ++e) df[(size_t)e] += c.f[e];
+    }
+    P.denseQ = P.densec = P.denseE = P.densef = -1;
+    if (!dQ.empty()) {
+        P.denseQ = push(dQ.data(), U * U);
+        P.densec = push(dc.data(), U);
+        P.denseE = push(dE.data(), nx * U);
+        P.densef = push(df.data(), U);
+    }
+    n_costs = (int)builtin.size();
+    costs = builtin.data();
+    if (n_costs > kMaxCosts) {
+        hp.error = "too many cost functions for the fused kernel";
+        return COPRA_ERR_UNSUPPORTED;
+    }
     P.ncost = n_costs;
     for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = nullptr, P.model_ref_off[k] = -1;
     P.rmax = 1;
@@ -321,6 +353,10 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 return hp.error = "TrajectoryBoundConstraint: bounds have neither xDim nor fullXDim rows",
                        COPRA_ERR_DOMAIN;
             break;
+        case COPRA_CSTR_DENSE:
+            if (!c.A || (!is && !c.b) || (is && (!c.Y || !c.z)))
+                return hp.error = "dense constraint: A and b (LMPC) or Y, A and z (InitialStateLMPC) are needed", COPRA_ERR_DOMAIN;
+            break;
         case COPRA_CSTR_CONTROL_BOUND: {
             if (!c.lower || !c.upper) return hp.error = "ControlBoundConstraint: bounds missing", COPRA_ERR_DOMAIN;
             if (c.rows != nu && c.rows != U)
@@ -403,6 +439,16 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 } else {
                     for (int i = 0; i < r; ++i)
                         add_row(0, kEFull, push_row(c.E, r, X, i), kGFull, push_row(c.G, r, U, i), c.f[i]);
+                }
+                break;
+            case COPRA_CSTR_DENSE:
+                // row i:  Y_i x_0 + A_i U  <=|=  z_i  (InitialStateLMPC.cpp:88-102), or  A_i U <=|= b_i  with the
+                // host-evaluated b = z - Y x0 (LMPC.cpp:257-271)
+                for (int i = 0; i < r; ++i) {
+                    if (is)
+                        add_row(0, kEDense, push_row(c.Y, r, nx, i), kGFull, push_row(c.A, r, U, i), c.z[i]);
+                    else
+                        add_row(0, kENone, -1, kGFull, push_row(c.A, r, U, i), c.b[i]);
                 }
                 break;
             case COPRA_CSTR_TRAJECTORY_BOUND: { // constraints.h:248-255, constraints.cpp:284-315

@@ -144,6 +144,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     if (nz > kRicMaxNz) return no("xDim + uDim too large for the Riccati kernel");
     if (nu > 8) return no("uDim > 8");
     if (P.meq > kRicMaxEq) return no("too many equality rows for the proximal multiplier iteration");
+    if (P.denseQ >= 0) return no("a dense (host-evaluated) cost couples all steps");
     std::vector<StageDesc> st((size_t)N + 1);
     for (int k = 0; k <= N; ++k) st[(size_t)k].last = (k == N);
     const std::vector<double>& prm = hp.params;

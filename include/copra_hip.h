@@ -31,8 +31,18 @@ typedef enum {
     COPRA_ERR_ARG = 5 /* NULL / negative argument */
 } copra_status_t;
 
-/* Cost kinds: include/costFunctions.h:103 (TrajectoryCost), :134 (TargetCost), :165 (ControlCost), :196 (MixedCost) */
-typedef enum { COPRA_COST_TRAJECTORY = 0, COPRA_COST_TARGET = 1, COPRA_COST_CONTROL = 2, COPRA_COST_MIXED = 3 } copra_cost_kind_t;
+/* Cost kinds: include/costFunctions.h:103 (TrajectoryCost), :134 (TargetCost), :165 (ControlCost), :196 (MixedCost).
+ * COPRA_COST_DENSE: a user-defined CostFunction subclass (plug-in point 2, include/costFunctions.h:22-97) whose update()
+ * ran on the host: the base-class members Q_ (fullUDim x fullUDim), c_ (fullUDim), E_ (xDim x fullUDim), f_ (fullUDim)
+ * as LMPC::makeQPForm (src/LMPC.cpp:252-255: Q += Q_, c += c_) and InitialStateLMPC::makeQPForm
+ * (src/InitialStateLMPC.cpp:80-84: Q += Q_, E += E_, tail of c += f_) consume them. */
+typedef enum {
+    COPRA_COST_TRAJECTORY = 0,
+    COPRA_COST_TARGET = 1,
+    COPRA_COST_CONTROL = 2,
+    COPRA_COST_MIXED = 3,
+    COPRA_COST_DENSE = 4
+} copra_cost_kind_t;
 
 /* Constraint kinds: include/constraints.h:114, :153, :193, :234, :284 */
 typedef enum {
@@ -40,7 +50,11 @@ typedef enum {
     COPRA_CSTR_CONTROL = 1,
     COPRA_CSTR_MIXED = 2,
     COPRA_CSTR_TRAJECTORY_BOUND = 3,
-    COPRA_CSTR_CONTROL_BOUND = 4
+    COPRA_CSTR_CONTROL_BOUND = 4,
+    /* a user-defined EqIneqConstraint subclass (plug-in point 2, include/constraints.h:42-107) whose update() ran on the
+     * host: A_ (rows x fullUDim), b_ (rows), Y_ (rows x xDim), z_ (rows) with b = z - Y x0.  LMPC stacks [A | b]
+     * (src/LMPC.cpp:257-271), InitialStateLMPC stacks [Y, A | z] (src/InitialStateLMPC.cpp:88-102). */
+    COPRA_CSTR_DENSE = 5
 } copra_cstr_kind_t;
 
 /* Per-instance solver status == SolverInterface::SI_fail() of QuadProgDenseSolver (include/QuadProgSolver.h:21-27),
@@ -64,6 +78,12 @@ typedef struct {
     const double* N; /* rows x n_cols */
     const double* p; /* rows */
     const double* weights; /* rows */
+    /* COPRA_COST_DENSE only (column-major; rows / M / N / p / weights unused): LMPC reads Q and c, InitialStateLMPC reads
+     * Q, E and f; a pointer the variant does not read may be NULL */
+    const double* Q; /* fullUDim x fullUDim, symmetric */
+    const double* c; /* fullUDim */
+    const double* E; /* xDim x fullUDim */
+    const double* f; /* fullUDim */
 } copra_cost_desc_t;
 
 /* A constraint exactly as handed to LMPC::addConstraint (src/LMPC.cpp:124-128): constructor arguments of
@@ -79,6 +99,12 @@ typedef struct {
     const double* f;
     const double* lower;
     const double* upper;
+    /* COPRA_CSTR_DENSE only (column-major, `rows` rows, is_inequality as above): LMPC reads A and b, InitialStateLMPC
+     * reads Y, A and z */
+    const double* A; /* rows x fullUDim */
+    const double* b; /* rows */
+    const double* Y; /* rows x xDim */
+    const double* z; /* rows */
 } copra_cstr_desc_t;
 
 /* Dimensions of the preview systems of one batch: PreviewSystem::system(state, control, bias, xInit, numberOfSteps)
@@ -246,6 +272,13 @@ copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long
 copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, const double* Q, const double* c,
     const double* Aeq, const double* beq, const double* Aineq, const double* bineq, const double* XL,
     const double* XU, double* x, int* fail, int* iter, int on_device, void* hip_stream);
+
+/* ---- PreviewSystem::updateSystem (src/PreviewSystem.cpp:57-74) for ONE system, on the device: Phi [fullXDim x xDim],
+ *      Psi [fullXDim x fullUDim], xi [fullXDim], column-major host buffers.  The solve path never materialises them (they
+ *      only exist block-wise in LDS); this entry point serves host-evaluated user subclasses of Constraint / CostFunction,
+ *      whose update(const PreviewSystem&) reads ps.Phi / ps.Psi / ps.xi. ---- */
+copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
+    double* Psi, double* xi);
 
 /* ---- misc ---- */
 /* ---- run-time specialisation of the dense-QP kernel for problems with `n` variables (n <= 64): as

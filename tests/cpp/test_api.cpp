@@ -380,6 +380,288 @@ static void initial_state_cases()
     }
 }
 
+// ---- plug-in point 2: user-defined subclasses with their own update() (include/constraints.h:42-107, costFunctions.h:22-97)
+// The same velocity limit as TrajectoryConstraint(E = [0 1], f = 0) and the same tracking cost as TrajectoryCost(M, xd),
+// written by a "user" against ps.Phi / ps.Psi / ps.xi exactly as the reference's classes are (constraints.cpp:66-84,
+// costFunctions.cpp:63-82) -- LMPC::solve runs these update() on the host and the device solves with the results.
+class UserVelocityLimit : public copra::EqIneqConstraint {
+public:
+    explicit UserVelocityLimit(double vmax)
+        : EqIneqConstraint("User velocity", true)
+        , vmax_(vmax)
+    {
+    }
+    void autoSpan() override {}
+    void initializeConstraint(const copra::PreviewSystem& ps) override
+    {
+        nrConstr_ = ps.nrXStep;
+        A_.resize(nrConstr_, ps.fullUDim);
+        Y_.resize(nrConstr_, ps.xDim);
+        b_.resize(nrConstr_);
+        z_.resize(nrConstr_);
+        ++initialised;
+    }
+    void update(const copra::PreviewSystem& ps) override
+    {
+        for (int i = 0; i < ps.nrXStep; ++i) { // row i: velocity of step i  (E = [0 1])
+            const int row = i * ps.xDim + 1;
+            for (int j = 0; j < ps.fullUDim; ++j) A_(i, j) = ps.Psi(row, j);
+            for (int a = 0; a < ps.xDim; ++a) Y_(i, a) = ps.Phi(row, a);
+            z_(i) = vmax_ - ps.xi(row);
+            double yx = 0.0;
+            for (int a = 0; a < ps.xDim; ++a) yx += Y_(i, a) * ps.x0(a);
+            b_(i) = z_(i) - yx;
+        }
+        ++updated;
+    }
+    int initialised = 0, updated = 0;
+
+private:
+    double vmax_;
+};
+class UserTrackingCost : public copra::CostFunction {
+public:
+    UserTrackingCost(const Eigen::VectorXd& xd, const Eigen::VectorXd& w)
+        : CostFunction("User tracking cost")
+        , xd_(xd)
+        , w_(w)
+    {
+    }
+    void update(const copra::PreviewSystem& ps) override
+    {
+        Q_.setZero(), E_.setZero(), f_.setZero();
+        const int nx = ps.xDim, n = ps.fullUDim;
+        for (int i = 0; i < ps.nrXStep; ++i) // sum over the steps of Psi_i' W Psi_i etc. (M = I)
+            for (int k = 0; k < nx; ++k) {
+                const int row = i * nx + k;
+                for (int j = 0; j < n; ++j) {
+                    const double t = w_(k) * ps.Psi(row, j);
+                    if (t == 0.0) continue;
+                    for (int l = 0; l < n; ++l) Q_(l, j) += ps.Psi(row, l) * t;
+                    for (int a = 0; a < nx; ++a) E_(a, j) += ps.Phi(row, a) * t;
+                    f_(j) += (ps.xi(row) - xd_(k)) * t;
+                }
+            }
+        for (int j = 0; j < n; ++j) {
+            double acc = f_(j);
+            for (int a = 0; a < nx; ++a) acc += E_(a, j) * ps.x0(a);
+            c_(j) = acc;
+        }
+    }
+
+private:
+    Eigen::VectorXd xd_, w_;
+};
+
+// ---- plug-in point 1: a user SolverInterface handed to LMPC::useSolver.  This one runs the CPU oracle's restatement of
+// the reference's QuadProgDenseSolver (oracle/copra_oracle.c::or_quadprog_dense -- test infrastructure), so the check is
+// "device-condensed QP + CPU QuadProgDense == fused device solve".
+extern "C" int or_quadprog_dense(int n, int meq, int mineq, const double* Q, const double* c, const double* Aeq,
+    const double* beq, const double* Aineq, const double* bineq, const double* XL, const double* XU, double* x, int* iter);
+class OracleQuadProgSolver : public copra::SolverInterface {
+public:
+    int SI_fail() const override { return fail_; }
+    void SI_inform() const override { std::printf("oracle QuadProgDense: fail = %d\n", fail_); }
+    int SI_iter() const override { return iter_[0]; }
+    const Eigen::VectorXd& SI_result() const override { return x_; }
+    void SI_problem(int nrVar, int nrEq, int nrInEq) override
+    {
+        n_ = nrVar, neq_ = nrEq, nin_ = nrInEq;
+        x_.resize(nrVar);
+        ++problems;
+    }
+    bool SI_solve(const Eigen::MatrixXd& Q, const Eigen::VectorXd& c, const Eigen::MatrixXd& Aeq, const Eigen::VectorXd& beq,
+        const Eigen::MatrixXd& Aineq, const Eigen::VectorXd& bineq, const Eigen::VectorXd& XL, const Eigen::VectorXd& XU) override
+    {
+        fail_ = or_quadprog_dense(n_, neq_, nin_, Q.data(), c.data(), Aeq.data(), beq.data(), Aineq.data(), bineq.data(),
+            XL.data(), XU.data(), x_.data(), iter_);
+        ++solves;
+        return fail_ == 0;
+    }
+    int problems = 0, solves = 0;
+
+private:
+    int n_ = 0, neq_ = 0, nin_ = 0, fail_ = 0, iter_[2] = { 0, 0 };
+    Eigen::VectorXd x_;
+};
+
+static double max_rel(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
+{
+    double m = 0.0;
+    for (Eigen::Index i = 0; i < a.rows(); ++i) m = std::fmax(m, std::fabs(a(i) - b(i)) / (1.0 + std::fabs(b(i))));
+    return a.rows() == b.rows() ? m : 1e300;
+}
+
+static void plugin_cases(int nbStep)
+{
+    using namespace Eigen;
+    std::vector<std::shared_ptr<copra::CostFunction>> keep, keepc;
+    std::vector<std::shared_ptr<copra::Constraint>> keepk;
+    IneqSystem s(nbStep);
+    VectorXd uLower(1), uUpper(1);
+    uLower.setConstant(-std::numeric_limits<double>::infinity());
+    uUpper.setConstant(200);
+    // reference: the built-in classes only
+    auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+    copra::LMPC ref(ps);
+    auto xCost = std::make_shared<copra::TrajectoryCost>(s.M, s.xd);
+    auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
+    xCost->weights(s.wx);
+    uCost->weights(s.wu);
+    VectorXd f0(1);
+    f0 << 0;
+    auto vCstr = std::make_shared<copra::TrajectoryConstraint>(s.E, f0);
+    auto uBound = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+    ref.addCost(xCost), ref.addCost(uCost), ref.addConstraint(vCstr), ref.addConstraint(uBound);
+    CHECK(ref.solve());
+
+    { // a user-defined constraint subclass and a user-defined cost subclass ride the fused device solve
+        auto ps2 = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+        copra::LMPC mpc(ps2);
+        auto userCost = std::make_shared<UserTrackingCost>(s.xd, s.wx);
+        auto uCost2 = std::make_shared<copra::ControlCost>(s.N, s.ud);
+        uCost2->weights(s.wu);
+        auto userCstr = std::make_shared<UserVelocityLimit>(0.0);
+        auto uBound2 = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        mpc.addCost(userCost), mpc.addCost(uCost2), mpc.addConstraint(userCstr), mpc.addConstraint(uBound2);
+        CHECK(userCstr->initialised == 1 && userCstr->nrConstr() == s.nbStep + 1);
+        CHECK(mpc.solve());
+        CHECK(userCstr->updated == 1 && ps2->previewOnHost);
+        CHECK(mpc.nrIneqConstr() == s.nbStep + 1);
+        CHECK(max_rel(mpc.control(), ref.control()) <= 1e-6);
+        CHECK(max_rel(mpc.trajectory(), ref.trajectory()) <= 1e-6);
+        // receding horizon: a new x0 reaches the user pieces through their update() (b = z - Y x0, c = E'x0 + f)
+        VectorXd x1(2);
+        x1 << 0.01, -4.5;
+        ps->xInit(x1), ps2->xInit(x1);
+        CHECK(ref.solve() && mpc.solve());
+        CHECK(userCstr->updated >= 2);
+        CHECK(max_rel(mpc.control(), ref.control()) <= 1e-6);
+        ps->xInit(s.x0);
+        CHECK(ref.solve());
+        // ... and the InitialStateLMPC form reads Y, z, E, f of the same user pieces
+        copra::InitialStateLMPC isRef(ps), isUser(ps2);
+        ps2->xInit(s.x0);
+        auto mk = [&](copra::InitialStateLMPC& c, bool user) {
+            MatrixXd R = MatrixXd::Identity(2, 2) * 10.0;
+            VectorXd r(2), lo(2), hi(2);
+            r << 0.1, -0.2;
+            lo << s.x0(0) - 0.05, s.x0(1) - 0.05;
+            hi << s.x0(0) + 0.05, s.x0(1) + 0.05;
+            c.resetInitialStateCost(R, r);
+            c.resetInitialStateBounds(lo, hi);
+            auto uc = std::make_shared<copra::ControlCost>(s.N, s.ud);
+            uc->weights(s.wu);
+            keep.push_back(uc);
+            c.addCost(uc);
+            if (user) {
+                auto a = std::make_shared<UserTrackingCost>(s.xd, s.wx);
+                auto b = std::make_shared<UserVelocityLimit>(0.0);
+                keepc.push_back(a), keepk.push_back(b);
+                c.addCost(a), c.addConstraint(b);
+            } else {
+                auto a = std::make_shared<copra::TrajectoryCost>(s.M, s.xd);
+                a->weights(s.wx);
+                auto b = std::make_shared<copra::TrajectoryConstraint>(s.E, f0);
+                keepc.push_back(a), keepk.push_back(b);
+                c.addCost(a), c.addConstraint(b);
+            }
+            auto bd = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+            keepk.push_back(bd);
+            c.addConstraint(bd);
+        };
+        mk(isRef, false), mk(isUser, true);
+        CHECK(isRef.solve() && isUser.solve());
+        CHECK(max_rel(isUser.control(), isRef.control()) <= 1e-6);
+        CHECK(max_rel(isUser.initialState(), isRef.initialState()) <= 1e-6);
+    }
+    { // LMPC::useSolver: a user SolverInterface gets the device-condensed QP (LMPC.cpp:67-70, 88-97)
+        copra::LMPC mpc(ps);
+        mpc.addCost(xCost), mpc.addCost(uCost), mpc.addConstraint(vCstr);
+        auto uBound3 = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        mpc.addConstraint(uBound3);
+        auto user = new OracleQuadProgSolver();
+        mpc.useSolver(std::unique_ptr<copra::SolverInterface>(user));
+        CHECK(mpc.solve());
+        CHECK(user->problems == 1 && user->solves == 1);
+        CHECK(max_rel(mpc.control(), ref.control()) <= 1e-6);
+        CHECK(max_rel(mpc.trajectory(), ref.trajectory()) <= 1e-6);
+        CHECK(mpc.Q().rows() == s.nbStep && mpc.ub()(0) == 200);
+        mpc.selectQPSolver(copra::SolverFlag::QuadProgDense); // back to the fused device solve (drops the user solver)
+        CHECK(mpc.solve());
+        CHECK(max_rel(mpc.control(), ref.control()) <= 1e-6);
+        // the same for InitialStateLMPC: result = [x0*; U] (InitialStateLMPC.cpp:124-128)
+        copra::InitialStateLMPC isA(ps), isB(ps);
+        for (copra::InitialStateLMPC* c : { &isA, &isB }) {
+            MatrixXd R = MatrixXd::Identity(2, 2) * 10.0;
+            VectorXd r(2), lo(2), hi(2);
+            r << 0.1, -0.2;
+            lo << s.x0(0) - 0.05, s.x0(1) - 0.05;
+            hi << s.x0(0) + 0.05, s.x0(1) + 0.05;
+            c->resetInitialStateCost(R, r);
+            c->resetInitialStateBounds(lo, hi);
+            c->addCost(xCost), c->addCost(uCost), c->addConstraint(vCstr);
+        }
+        isB.useSolver(std::unique_ptr<copra::SolverInterface>(new OracleQuadProgSolver()));
+        CHECK(isA.solve() && isB.solve());
+        CHECK(max_rel(isB.control(), isA.control()) <= 1e-6);
+        CHECK(max_rel(isB.initialState(), isA.initialState()) <= 1e-6);
+        CHECK(max_rel(isB.trajectory(), isA.trajectory()) <= 1e-6);
+    }
+    { // LMPC::checkDeleteCostsAndConstraints (LMPC.cpp:288-307): a piece the caller released is dropped after the solve
+        copra::LMPC mpc(ps);
+        auto extra = std::make_shared<copra::TrajectoryConstraint>(s.E, f0);
+        auto uBound4 = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        mpc.addCost(xCost), mpc.addCost(uCost), mpc.addConstraint(extra), mpc.addConstraint(uBound4);
+        CHECK(mpc.nrIneqConstr() == s.nbStep + 1);
+        extra.reset(); // only the controller refers to it now
+        CHECK(mpc.solve()); // this solve still honours it ...
+        CHECK(max_rel(mpc.control(), ref.control()) <= 1e-6);
+        CHECK(mpc.nrIneqConstr() == 0); // ... and drops it afterwards
+        CHECK(mpc.solve());
+        double pm, vm;
+        extrema(mpc.trajectory(), pm, vm);
+        CHECK(nbStep < 100 || vm > 1e-3); // without the limit the velocity overshoots (long horizon only)
+    }
+    { // the accessors of the built-in classes (costFunctions.h:79-90, constraints.h:93-99), evaluated on the device
+        auto ps3 = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+        copra::LMPC only(ps3);
+        auto cst = std::make_shared<copra::TrajectoryCost>(s.M, s.xd);
+        cst->weights(s.wx);
+        only.addCost(cst);
+        cst->update(*ps3);
+        CHECK(cst->Q().rows() == s.nbStep && cst->E().rows() == 2 && cst->f().rows() == s.nbStep);
+        double dq = 0.0, dc = 0.0;
+        for (int j = 0; j < s.nbStep; ++j) {
+            dc = std::fmax(dc, std::fabs(only.c()(j) - cst->c()(j)));
+            for (int i = 0; i < s.nbStep; ++i)
+                dq = std::fmax(dq, std::fabs(only.Q()(i, j) - cst->Q()(i, j) - (i == j ? 1e-6 : 0.0)));
+        }
+        CHECK(dq <= 1e-9 && dc <= 1e-9);
+        UserTrackingCost mine(s.xd, s.wx); // the user restatement above agrees with the device's evaluation
+        mine.initializeCost(*ps3);
+        ps3->updateSystem();
+        mine.update(*ps3);
+        double de = 0.0;
+        for (int j = 0; j < s.nbStep; ++j)
+            for (int a = 0; a < 2; ++a) de = std::fmax(de, std::fabs(mine.E()(a, j) - cst->E()(a, j)) / (1.0 + std::fabs(cst->E()(a, j))));
+        CHECK(de <= 1e-9);
+        auto lim = std::make_shared<copra::TrajectoryConstraint>(s.E, f0);
+        lim->initializeConstraint(*ps3);
+        lim->update(*ps3);
+        UserVelocityLimit ul(0.0);
+        ul.initializeConstraint(*ps3);
+        ul.update(*ps3);
+        CHECK(lim->A().rows() == s.nbStep + 1 && lim->Y().cols() == 2);
+        double da = 0.0;
+        for (int i = 0; i <= s.nbStep; ++i) {
+            da = std::fmax(da, std::fabs(lim->b()(i) - ul.b()(i)) + std::fabs(lim->z()(i) - ul.z()(i)));
+            for (int j = 0; j < s.nbStep; ++j) da = std::fmax(da, std::fabs(lim->A()(i, j) - ul.A()(i, j)));
+        }
+        CHECK(da <= 1e-12);
+    }
+}
+
 int main(int argc, char** argv)
 {
     std::setvbuf(stdout, nullptr, _IONBF, 0);
@@ -388,6 +670,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "errors")) error_handlers();
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
+        if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());
         return 2;

@@ -18,9 +18,11 @@ def _build():
     if os.path.exists(EXE) and os.path.getmtime(EXE) >= newest:
         return
     libdir = os.path.dirname(_capi.LIB_PATH)
+    import pyoracle  # the user SolverInterface of the plug-in test runs the oracle's QuadProgDense restatement
+    oracle_so = pyoracle.build()
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "copra_amd", "cpp", "include"),
-                           src, "-o", EXE, "-L", libdir, "-lcopra_hip", "-Wl,-rpath," + libdir,
-                           "-Wl,-rpath,/opt/rocm/lib"])
+                           src, "-o", EXE, "-L", libdir, "-lcopra_hip", oracle_so, "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath," + os.path.dirname(oracle_so), "-Wl,-rpath,/opt/rocm/lib"])
 
 
 def test_error_handlers_like_TestLMPC():
@@ -46,4 +48,18 @@ def test_initial_state_cases_like_TestLMPC_InitialState():
     full-size entries, through copra::InitialStateLMPC of the C++ mirror"""
     _build()
     r = subprocess.run([EXE, "initial_state"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps", [12, 150])
+def test_plugin_surface_user_subclasses_and_user_solver(steps):
+    """north_star "constraint/cost plugin surface as a drop-in": a user-defined EqIneqConstraint subclass and a
+    user-defined CostFunction subclass (their update() runs on the host against ps.Phi / Psi / xi, the results join the
+    fused device solve as COPRA_CSTR_DENSE / COPRA_COST_DENSE), a user SolverInterface installed with LMPC::useSolver
+    (device-condensed QP -> the CPU QuadProgDense restatement), LMPC::checkDeleteCostsAndConstraints, and the
+    Q() c() E() f() / A() b() Y() z() accessors of the built-in classes; LMPC and InitialStateLMPC, 12 steps (one-wave
+    kernels) and 150 steps (workgroup kernel)"""
+    _build()
+    r = subprocess.run([EXE, "plugins", str(steps)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

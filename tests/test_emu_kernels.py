@@ -561,3 +561,47 @@ def test_edge_cases_of_the_reference_path(emu, oracle):
     ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 12, pb["costs"], pb["cstrs"])  # the plain LMPC
     assert re["status"][0] == 0 and np.abs(re["x0_opt"][0] - pb["x0"]).max() < 1e-12
     assert _rel(re["control"][0], ro["control"]) <= RTOL
+
+
+def _dense_twins(oracle, N):
+    """a TrajectoryCost and a TrajectoryConstraint of the falling-mass fixture evaluated on the host (what a user
+    subclass's update() does, costFunctions.cpp:63-82 / constraints.cpp:66-84) -> COPRA_COST_DENSE / COPRA_CSTR_DENSE"""
+    pb = F.ineq_system("trajectory", N=N)
+    A, B, d, x0 = pb["A"], pb["B"], pb["d"], pb["x0"]
+    Phi, Psi, xi = oracle.preview(A, B, d, N)
+    c0, k0 = pb["costs"][0], pb["cstrs"][0]
+    M, p, w = np.atleast_2d(c0["M"]), np.asarray(c0["p"], float), np.asarray(c0["weights"], float)
+    Q, E, f = np.zeros((N, N)), np.zeros((2, N)), np.zeros(N)
+    for i in range(N + 1):
+        tmp = M @ Psi[2 * i:2 * i + 2]
+        Q += tmp.T @ (w[:, None] * tmp)
+        E += (M @ Phi[2 * i:2 * i + 2]).T @ (w[:, None] * tmp)
+        f += (M @ xi[2 * i:2 * i + 2] - p) @ (w[:, None] * tmp)
+    Em, fm = np.atleast_2d(k0["E"]), np.asarray(k0["f"], float)
+    Ar = np.vstack([Em @ Psi[2 * i:2 * i + 2] for i in range(N + 1)])
+    Y = np.vstack([Em @ Phi[2 * i:2 * i + 2] for i in range(N + 1)])
+    z = np.concatenate([fm - Em @ xi[2 * i:2 * i + 2] for i in range(N + 1)])
+    costs = [dict(kind="dense", Q=Q, c=E.T @ x0 + f, E=E, f=f), pb["costs"][1]]
+    cstrs = [dict(kind="dense", A=Ar, b=z - Y @ x0, Y=Y, z=z), pb["cstrs"][1]]
+    return pb, costs, cstrs
+
+
+@pytest.mark.parametrize("N", [12, 80])
+def test_host_evaluated_user_pieces_dense_kinds(emu, oracle, N):
+    """COPRA_COST_DENSE / COPRA_CSTR_DENSE (plug-in point 2: a user subclass evaluated on the host) in the one-wave kernels
+    (N = 12) and the workgroup kernel (N = 80), LMPC and InitialStateLMPC: same QP and same solution as the built-in twin"""
+    pb, costs, cstrs = _dense_twins(oracle, N)
+    args = (pb["A"], pb["B"], pb["d"], pb["x0"], N)
+    ro = oracle.lmpc_solve(*args, pb["costs"], pb["cstrs"])
+    qo = oracle.lmpc_build(*args, pb["costs"], pb["cstrs"])
+    re = emu.lmpc_solve(*args, costs, cstrs, dump_instance=0)
+    assert re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+    assert _rel(re["control"][0], ro["control"]) <= RTOL
+    assert np.abs(re["Q"] - qo["Q"]).max() <= 1e-12 * np.abs(qo["Q"]).max()
+    assert np.abs(re["c"] - qo["c"]).max() <= 1e-10 and np.abs(re["Aineq"] - qo["Aineq"]).max() <= 1e-12
+    ist = dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]), x0lb=pb["x0"] - 0.05, x0ub=pb["x0"] + 0.05)
+    ro = oracle.lmpc_solve(*args, pb["costs"], pb["cstrs"], initial_state=ist)
+    re = emu.lmpc_solve(*args, costs, cstrs, initial_state=ist)
+    assert re["status"][0] == ro["status"] == 0
+    assert _rel(re["control"][0], ro["control"]) <= RTOL and np.abs(re["x0_opt"][0] - ro["x0_opt"]).max() <= 1e-9
+    assert emu.lmpc_solve_riccati(*args, costs, cstrs) is None  # dense pieces couple all steps: not stage-wise

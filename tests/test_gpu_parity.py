@@ -963,3 +963,43 @@ def test_shared_model_more_than_16_states(oracle):
         ro = oracle.lmpc_solve(A, B, d, x0[k], N, costs, cstrs)
         assert res["status"][k] == ro["status"] == 0
         assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
+@pytest.mark.parametrize("N", [12, 80])
+def test_host_evaluated_user_pieces_dense_kinds_on_gpu(oracle, N):
+    """COPRA_COST_DENSE / COPRA_CSTR_DENSE (plug-in point 2) and copra_preview_update through the C ABI: a TrajectoryCost
+    and a TrajectoryConstraint evaluated on the host from the DEVICE-built Phi / Psi / xi ride the fused solve -- same QP
+    and same answer as the built-in classes; per-instance x0 reaches the dense rows (b = z - Y x0 on the device)"""
+    import ctypes as C
+    import test_emu_kernels as T
+    from copra_amd import BatchLMPC, _capi
+    pb, costs, cstrs = T._dense_twins(oracle, N)
+    A, B, d, x0 = pb["A"], pb["B"], pb["d"], pb["x0"]
+    # PreviewSystem::updateSystem on the device vs the oracle's
+    X, U = 2 * (N + 1), N
+    Phi, Psi, xi = np.zeros((X, 2), order="F"), np.zeros((X, U), order="F"), np.zeros(X)
+    Ac, Bc = np.asfortranarray(A), np.asfortranarray(B)
+    _capi.check(_capi.lib().copra_preview_update(2, 1, N, Ac.ctypes.data, Bc.ctypes.data, d.ctypes.data, Phi.ctypes.data,
+                                                 Psi.ctypes.data, xi.ctypes.data))
+    Po, So, xo = oracle.preview(A, B, d, N)
+    assert np.abs(Phi - Po).max() <= 1e-13 and np.abs(Psi - So).max() <= 1e-13 and np.abs(xi - xo).max() <= 1e-13
+    b = 5
+    x0b = np.tile(x0, (b, 1))
+    x0b[1:, 1] += np.linspace(-0.4, 0.4, b - 1)
+    for ist in (None, dict(R=10.0 * np.eye(2), r=np.array([0.1, -0.2]))):
+        eng = BatchLMPC(2, 1, N, b, costs, cstrs, initial_state=ist)
+        eng.set_system(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), x0b)
+        if ist:
+            eng.set_initial_state_bounds(x0b - 0.05, x0b + 0.05)
+        assert eng.solver() == "quadprog_dense"  # dense pieces couple all steps: never the stage-wise solver
+        eng.solve()
+        res = eng.results()
+        for k in range(b):
+            if ist is None and k > 0:
+                continue  # (the dense c of the LMPC form was evaluated for instance 0's x0: LMPC.cpp:252-255 reads c_, not E_, f_)
+            io = dict(ist, x0lb=x0b[k] - 0.05, x0ub=x0b[k] + 0.05) if ist else None
+            ro = oracle.lmpc_solve(A, B, d, x0b[k], N, pb["costs"], pb["cstrs"], initial_state=io)
+            assert res["status"][k] == ro["status"] == 0
+            assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+    with pytest.raises(Exception):  # LMPC form without c
+        BatchLMPC(2, 1, N, 1, [dict(kind="dense", Q=costs[0]["Q"], E=costs[0]["E"], f=costs[0]["f"])], [])
