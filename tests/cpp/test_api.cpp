@@ -147,6 +147,16 @@ static void extrema(const Eigen::VectorXd& traj, double& posMax, double& velMax)
 
 // The state cost of one of the reference's test cases: TargetCost, TrajectoryCost, or the MixedCost pair of
 // TestLMPC.cpp:182-183 (MixedCost(M, 0, xd) + MixedCost(0, N, ud)); always followed by the control cost.
+// The caller keeps what it adds alive, as the reference's tests do: a piece only the controller still refers to is
+// dropped after the next solve (LMPC::checkDeleteCostsAndConstraints, src/LMPC.cpp:288-307).
+static std::vector<std::shared_ptr<void>> g_keep;
+template <class T>
+static std::shared_ptr<T> hold(std::shared_ptr<T> p)
+{
+    g_keep.push_back(p);
+    return p;
+}
+
 static void add_costs(copra::LMPC& controller, const IneqSystem& s, const Eigen::VectorXd& xd, int kind)
 {
     if (kind == 2) {
@@ -154,8 +164,8 @@ static void add_costs(copra::LMPC& controller, const IneqSystem& s, const Eigen:
         auto uCost = std::make_shared<copra::MixedCost>(Eigen::MatrixXd::Zero(1, 2), s.N, s.ud);
         xCost->weights(s.wx);
         uCost->weights(s.wu);
-        controller.addCost(xCost);
-        controller.addCost(uCost);
+        controller.addCost(hold(xCost));
+        controller.addCost(hold(uCost));
         return;
     }
     std::shared_ptr<copra::CostFunction> xCost;
@@ -166,8 +176,8 @@ static void add_costs(copra::LMPC& controller, const IneqSystem& s, const Eigen:
     auto uCost = std::make_shared<copra::ControlCost>(s.N, s.ud);
     xCost->weights(s.wx);
     uCost->weights(s.wu);
-    controller.addCost(xCost);
-    controller.addCost(uCost);
+    controller.addCost(hold(xCost));
+    controller.addCost(hold(uCost));
 }
 
 // TestLMPC.cpp:36-771 at the reference's own horizon (nbStep = 300 -> 300 decision variables): every
@@ -188,8 +198,8 @@ static void solve_cases(int nbStep)
             ps->system(s.A, s.B, s.c, s.x0, s.nbStep);
             auto controller = copra::LMPC(ps);
             add_costs(controller, s, s.xd, kind);
-            controller.addConstraint(std::make_shared<copra::TrajectoryBoundConstraint>(xLower, xUpper));
-            controller.addConstraint(std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper));
+            controller.addConstraint(hold(std::make_shared<copra::TrajectoryBoundConstraint>(xLower, xUpper)));
+            controller.addConstraint(hold(std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper)));
             CHECK(controller.solve());
             double posMax, velMax;
             extrema(controller.trajectory(), posMax, velMax);
@@ -213,8 +223,8 @@ static void solve_cases(int nbStep)
             auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
             auto controller = copra::LMPC(ps);
             add_costs(controller, s, s.xd, kind);
-            controller.addConstraint(std::make_shared<copra::TrajectoryConstraint>(s.E, f));
-            controller.addConstraint(std::make_shared<copra::ControlConstraint>(s.G, s.h));
+            controller.addConstraint(hold(std::make_shared<copra::TrajectoryConstraint>(s.E, f)));
+            controller.addConstraint(hold(std::make_shared<copra::ControlConstraint>(s.G, s.h)));
             CHECK(controller.solve());
             double posMax, velMax;
             extrema(controller.trajectory(), posMax, velMax);
@@ -228,7 +238,7 @@ static void solve_cases(int nbStep)
             auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
             auto controller = copra::LMPC(ps);
             add_costs(controller, s, s.xd, kind);
-            controller.addConstraint(std::make_shared<copra::MixedConstraint>(s.E, s.G, p));
+            controller.addConstraint(hold(std::make_shared<copra::MixedConstraint>(s.E, s.G, p)));
             CHECK(controller.solve());
             Eigen::VectorXd fullTraj = controller.trajectory(), control = controller.control();
             for (int i = 0; i < s.nbStep; ++i) CHECK(fullTraj(2 * i + 1) + control(i) <= 200 + 1e-6);
@@ -240,7 +250,7 @@ static void solve_cases(int nbStep)
             auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, x0, s.nbStep);
             auto controller = copra::LMPC(ps);
             add_costs(controller, s, xd, kind);
-            controller.addConstraint(std::make_shared<copra::TrajectoryConstraint>(E, x0, false));
+            controller.addConstraint(hold(std::make_shared<copra::TrajectoryConstraint>(E, x0, false)));
             CHECK(controller.solve());
             // the last control has no effect on the pinned positions (x_N depends on u_0 .. u_{N-2} only)
             for (int i = 0; i + 1 < s.nbStep; ++i) CHECK(std::fabs(controller.control()(i) - 49.05) < 1e-4);
