@@ -6,18 +6,26 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (copra_batch_solve: condense + Goldfarb-Idnani + results) over one batch of
-synthetic CoM preview systems (BASELINE.json configs[2]: batch=65536 per GPU, inputs already resident in HBM).
-N > 1: the batch of independent preview systems is sharded, one process per GPU, weak scaling (65536 per GPU);
-the only data-path collective is ONE RCCL gather of the [U | X | status] slabs to rank 0 per step, inside the
-timed region.  Rank 0 prints ONE JSON line.
+synthetic CoM preview systems, inputs already resident in HBM.
+  N = 1 : BASELINE.json configs[2] -- batch 65536, seed 1 (the configuration the metric is quoted on).
+  N > 1 : the batch of independent preview systems is sharded contiguously, one process per GPU, 32768 instances per GPU
+          of ONE seed-2 batch of 32768 N instances -- at N = 8 exactly BASELINE.json configs[3] (262144 = 8 x 32768):
+          rank g owns [g B / N, (g + 1) B / N).  The only data-path collective is ONE RCCL gather of the
+          [U | X | status | iter] slabs to rank 0 per step, inside the timed region; after the timed region rank 0
+          VERIFIES what it gathered (per-rank checksums + an oracle sample of every shard).
+          `--scaling weak` instead keeps 65536 instances per GPU with per-rank seeds (rank 0 = configs[2]).
+Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- dominant kernel (copra_lmpc_fused_kernel): algorithmic bytes per launch (2016 B/solve: A,B,d,x0 in,
+  roofline     -- dominant kernel (copra_lmpc_fused_tri_kernel): algorithmic bytes per launch (2016 B/solve: A,B,d,x0 in,
                   U,X out) / average launch duration from HIP events recorded by the C ABI on the launch
-                  stream, against the 8 TB/s HBM peak.  The path is FP64-latency/LDS bound, not HBM bound (see
-                  DESIGN.md), so the fraction is small by construction; fp64 figures are reported next to it.
+                  stream, against the 8 TB/s HBM peak.  The path is FP64-latency/LDS bound, not HBM bound,
+                  so the fraction is small by construction; executed-FP64 and VALU-issue figures next to it.
   cpu_baseline -- the oracle (C port of the reference's CPU QuadProgDense path) timed on this host's cores on a
                   bounded sample of the same workload, rank 0, N=1 only.
+  extra        -- N=1 only, measured OUTSIDE the timed region (SURVEY.md 8d asks for them next to the headline):
+                  the other BASELINE configs (2 and 5), the shared-model tick, the tight-workload sensitivity point,
+                  the host-inclusive rate, the iteration histogram and the host's CPU model.
 """
 import argparse
 import json
@@ -30,6 +38,122 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector = matrix FP64
+PMC_SUMMARY = os.path.join("profiles", "r02", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    """threads actually available to this process: hardware threads, affinity mask and the cgroup CPU quota"""
+    hw = os.cpu_count() or 1
+    cores = min(hw, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else hw
+    note = ""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            lim = max(1, int(round(float(q) / float(per))))
+            if lim < cores:
+                note = "; cgroup CPU quota %d of %d hardware threads" % (lim, hw)
+                cores = lim
+    except Exception:
+        pass
+    return cores, hw, note
+
+
+def timed_rate(eng, batch, reps=5):
+    """solves/s of copra_batch_solve from the C ABI's HIP events (best of `reps` after one warm-up)"""
+    eng.solve()
+    eng.synchronize()
+    best = None
+    for _ in range(reps):
+        eng.solve()
+        s = eng.last_solve_seconds()
+        best = s if best is None else min(best, s)
+    return batch / best, best
+
+
+def extra_measurements(np, torch, dev):
+    """The other BASELINE configs and SURVEY 8(d)'s side figures; every number is a device-resident kernel rate unless
+    its name says otherwise."""
+    from copra_amd import BatchLMPC, workloads
+    from copra_amd.batch import to_abi_layout
+    out = {}
+
+    def on_device(wl):
+        Ab, Bb, db, xb = to_abi_layout(wl["A"], wl["B"], wl["d"], wl["x0"])
+        return [torch.from_numpy(a).to(dev) for a in (Ab, Bb, db, xb)]
+
+    # BASELINE configs[1]: double integrator (nx=2, nu=1, N=10) + control bound, batch 4096 and a saturating batch
+    for b in (4096, 262144):
+        wl = workloads.double_integrator(b)
+        eng = BatchLMPC(2, 1, wl["N"], b, wl["costs"], wl["cstrs"])
+        t = on_device(wl)
+        eng.set_system(*t)
+        rate, sec = timed_rate(eng, b)
+        out["config2_double_integrator_batch%d" % b] = {"solves_per_s": rate, "kernel_ms": sec * 1e3,
+                                                        "lanes_per_instance": eng.lanes_per_instance()}
+        eng.close()
+    # BASELINE configs[4]: InitialStateLMPC (12, 6, 50) at its full batch, on both long-horizon solvers
+    b5 = 16384
+    wl = workloads.long_horizon_initial_state(b5)
+    ist = wl["initial_state"]
+    for solver, bb in (("default", b5), ("quadprog_dense", 2048)):
+        eng = BatchLMPC(12, 6, wl["N"], bb, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+        eng.select_solver(solver)
+        eng.set_system(wl["A"][:bb], wl["B"][:bb], wl["d"][:bb], wl["x0"][:bb])
+        eng.set_initial_state_bounds(ist["x0lb"][:bb], ist["x0ub"][:bb])
+        rate, sec = timed_rate(eng, bb, reps=2)
+        res = eng.results()
+        out["config5_initial_state_12_6_50_%s" % eng.solver()] = {
+            "batch": bb, "solves_per_s": rate, "kernel_ms": sec * 1e3, "solved_ok": int((res["status"] == 0).sum()),
+            "mean_iterations": float(res["iter"][:, 0].mean()),
+            "algorithmic_GBps": 9216.0 * rate / 1e9}  # 1920 B in + 7296 B out per solve (SURVEY.md 8d)
+        eng.close()
+    # headline shape, shared model (receding-horizon tick: one (A, B, d) for the batch, only x0 differs)
+    b = 65536
+    wl = workloads.com_preview(b)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
+    rate, sec = timed_rate(eng, b)
+    out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3}
+    eng.close()
+    # sensitivity: the tight workload (v_max 0.25 / u_max 1.2: every instance activates 3..22 constraints; the factor-only
+    # layout steps down its ladder) -- the headline number depends on <= 5 active constraints per instance
+    wl = workloads.com_preview(b, v_max=0.25, u_max=1.2)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    t = on_device(wl)
+    eng.set_system(*t)
+    for _ in range(4):  # (the layout controller adapts over the first solves)
+        eng.solve()
+    rate, sec = timed_rate(eng, b)
+    it = eng.results()["iter"][:, 0]
+    out["tight_workload_vmax0.25_umax1.2"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3,
+                                              "mean_active_set_iters": float(it.mean()), "max_active_set_iters": int(it.max())}
+    eng.close()
+    # host-inclusive: numpy inputs -> layout conversion -> pageable H2D -> solve -> D2H of U, X, status
+    wl = workloads.com_preview(b)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    eng.results()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        eng.results()
+    out["host_inclusive_numpy_in_numpy_out"] = {"solves_per_s": 3 * b / (time.perf_counter() - t0),
+                                                "note": "2016 B/solve over PCIe (pageable) + layout conversion on the host"}
+    eng.close()
+    return out
 
 
 def main():
@@ -37,8 +161,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: 65536 at N = 1, 32768 at N > 1)")
+    ap.add_argument("--scaling", choices=["auto", "weak"], default="auto",
+                    help="auto: N > 1 shards ONE seed-2 batch of 32768 N instances (N = 8: BASELINE configs[3]); "
+                         "weak: 65536 instances per GPU with per-rank seeds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the measurements outside the timed region")
     ap.add_argument("--dense-hessian", action="store_true",
                     help="hand the TrajectoryCost over as a full-size entry (126x126 M): the Hessian is then built by "
                          "the dense v_mfma_f64_16x16x4 Psi'WPsi contraction instead of the block-diagonal prefix sums")
@@ -48,7 +176,7 @@ def main():
     ap.add_argument("--selftest-rccl", action="store_true",
                     help="(single GPU) run the N > 1 code path for real with a one-rank RCCL process group: "
                          "init_process_group('nccl'), dist.gather of the result slab on the side stream, barrier, "
-                         "all_reduce of the timing")
+                         "all_reduce of the timing, verification of the gathered slab")
     ap.add_argument("--selftest-overlap", action="store_true",
                     help="(single GPU) exercise the double-buffer / side-stream plumbing of the N > 1 path with a "
                          "device copy standing in for the RCCL gather")
@@ -77,13 +205,31 @@ def main():
 
     from copra_amd import BatchLMPC, workloads
     from copra_amd.batch import to_abi_layout
-    from copra_amd.sharding import alloc_gather_buffers, alloc_result_slab, gather_results
+    from copra_amd.sharding import GatherLoop, alloc_result_slab, shard_range, split_slab
 
     nx, nu, N = 6, 3, 20
-    batch = args.batch
     n, X = nu * N, nx * (N + 1)
-    # weak scaling: every rank owns `batch` instances; seeds differ per rank (rank 0 == BASELINE config 3, seed 1)
-    wl = workloads.com_preview(batch, N=N, seed=1 + rank)
+    sharded = world > 1 and args.scaling == "auto"
+    if sharded:
+        # ONE batch for the whole job, contiguous shards: at 8 ranks BASELINE.json configs[3]
+        per_gpu = args.batch or 32768
+        global_batch = per_gpu * world
+        wl_all = workloads.com_preview(global_batch, N=N, seed=2)
+        lo, hi = shard_range(global_batch, rank, world)
+        wl = dict(wl_all, A=wl_all["A"][lo:hi], B=wl_all["B"][lo:hi], d=wl_all["d"][lo:hi], x0=wl_all["x0"][lo:hi])
+        batch = hi - lo
+        workload_name = ("CoM preview LMPC nx=6 nu=3 N=20, TrajectoryCost+ControlCost, TrajectoryBound(63 rows)+ControlBound: "
+                         "one seed-2 batch of %d sharded contiguously over %d GPUs%s"
+                         % (global_batch, world, " (BASELINE configs[3])" if global_batch == 262144 and world == 8 else ""))
+    else:
+        # every rank owns `batch` instances; seeds differ per rank (rank 0 == BASELINE configs[2], seed 1)
+        batch = args.batch or 65536
+        global_batch = batch * world
+        lo, hi = 0, batch
+        wl_all = None
+        wl = workloads.com_preview(batch, N=N, seed=1 + rank)
+        workload_name = ("CoM preview LMPC nx=6 nu=3 N=20, TrajectoryCost+ControlCost, "
+                         "TrajectoryBound(63 rows)+ControlBound (BASELINE configs[2])")
     if args.dense_hessian:
         from copra_amd.autospan import autospan_cost
         c0 = wl["costs"][0]
@@ -97,51 +243,20 @@ def main():
     overlap = comm_path and not args.no_overlap
     n_slabs = 2 if overlap else 1
     slabs = [alloc_result_slab(batch, n, X, dev) for _ in range(n_slabs)]
-    slab, views = slabs[0]
-    out_u, out_x, out_s, out_i = views["control"], views["trajectory"], views["status"], views["iter"]
+    views0 = slabs[0][1]
 
     eng = BatchLMPC(nx, nu, N, batch, wl["costs"], wl["cstrs"])
     eng.set_system(tA, tB, td, tx0)
-    eng.set_outputs(out_u, out_x, out_s, out_i)
-    cur = torch.cuda.current_stream()
-    stream = cur.cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream
 
-    if use_dist:
-        gather_bufs = [alloc_gather_buffers(sl[0], rank, world) for sl in slabs]
-    else:
-        gather_bufs = [[torch.empty_like(sl[0])] for sl in slabs]  # self-test stand-in
-    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
-    ev_solved = [torch.cuda.Event() for _ in range(n_slabs)]
-    ev_sent = [torch.cuda.Event() for _ in range(n_slabs)]
-    step_no = [0]
-
-    def send(k):
-        if use_dist:
-            gather_results(slabs[k][0], rank, world, gather_bufs[k], force=True)
-        else:
-            gather_bufs[k][0].copy_(slabs[k][0], non_blocking=True)
-
-    def step():
-        k = step_no[0] % n_slabs
-        step_no[0] += 1
-        if overlap:
-            v = slabs[k][1]
-            if step_no[0] > n_slabs:
-                cur.wait_event(ev_sent[k])  # this slab's previous gather must be done before it is overwritten
-            eng.set_outputs(v["control"], v["trajectory"], v["status"], v["iter"])
+    def solve_into(v, k):
+        eng.set_outputs(v["control"], v["trajectory"], v["status"], v["iter"])
         eng.solve(stream)
-        if comm_path:
-            if overlap:
-                ev_solved[k].record(cur)
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ev_solved[k])
-                    send(k)
-                    ev_sent[k].record(comm_stream)
-            else:
-                send(k)
+
+    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=use_dist, overlap=overlap, force_gather=args.selftest_rccl)
 
     for _ in range(args.warmup):
-        step()
+        loop.step(communicate=comm_path)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -149,51 +264,86 @@ def main():
     kernel_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        loop.step(communicate=comm_path)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # device time of the dominant kernel: HIP events recorded by the C ABI around the launch on `stream`
-    # (measured in a separate short loop so that the event sync does not perturb the timed region)
-    eng.set_outputs(out_u, out_x, out_s, out_i)
-    for _ in range(min(args.steps, 10)):
-        eng.solve(stream)
-        kernel_s.append(eng.last_solve_seconds())
-    torch.cuda.synchronize()
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- N > 1: rank 0 verifies what it gathered (after the timed region) ----
+    multi = None
+    if comm_path:
+        ok_sum, sums = loop.verify()
+        if rank == 0:
+            multi = {"gathered_slabs_match_per_rank_checksums": bool(ok_sum), "ranks": world}
+            if use_dist and not args.dense_hessian:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import pyoracle
+                worst, agree, checked = 0.0, True, 0
+                for g, buf in enumerate(loop.gathered()):
+                    glo, ghi = shard_range(global_batch, g, world) if sharded else (0, batch)
+                    gw = wl_all if sharded else workloads.com_preview(batch, N=N, seed=1 + g)
+                    part = split_slab(buf, ghi - glo, n, X)
+                    pick = np.linspace(0, ghi - glo - 1, 16).astype(int)
+                    ref = pyoracle.lmpc_solve_batch(gw["A"][glo:ghi][pick], gw["B"][glo:ghi][pick], gw["d"][glo:ghi][pick],
+                                                    gw["x0"][glo:ghi][pick], N, gw["costs"], gw["cstrs"])
+                    u = part["control"].cpu().numpy()[pick]
+                    st = part["status"].cpu().numpy()[pick]
+                    agree = agree and bool((st == ref["status"]).all())
+                    okm = ref["status"] == 0
+                    worst = max(worst, float(np.nanmax(np.abs(u[okm] - ref["control"][okm]) / (1.0 + np.abs(ref["control"][okm])))))
+                    checked += len(pick)
+                multi.update({"oracle_sample_per_shard": 16, "instances_checked": checked, "max_rel_u_err": worst,
+                              "status_agree": agree})
+
+    # device time of the dominant kernel: HIP events recorded by the C ABI around the launch on `stream`
+    # (measured in a separate short loop so that the event sync does not perturb the timed region)
+    eng.set_outputs(views0["control"], views0["trajectory"], views0["status"], views0["iter"])
+    for _ in range(min(args.steps, 10)):
+        eng.solve(stream)
+        kernel_s.append(eng.last_solve_seconds())
+    torch.cuda.synchronize()
+    out_u, out_s, out_i = views0["control"], views0["status"], views0["iter"]
     status = out_s.cpu().numpy()
     iters = out_i.cpu().numpy()
     n_ok = int((status == 0).sum())
 
     line = None
     if rank == 0:
-        total = batch * world * args.steps
+        total = global_batch * args.steps
         value = total / elapsed
         kern = float(np.mean(kernel_s))
         alg_bytes = 8 * (nx * nx + nx * nu + 2 * nx) + 8 * (n + X)  # 528 in + 1488 out = 2016 B / solve
         achieved = alg_bytes * batch / kern / 1e9
-        # dense-as-the-reference flop model: 2 n^2 X build + 2 n^3/3 factor + k (2 m n + 4 n^2)
-        m_rows = 63 + 2 * n
-        flops = 2 * n * n * X + 2 * (nx ** 3 + nx * nx * nu) * (N - 1) + 2 * n ** 3 / 3.0 \
-            + float(iters[:, 0].mean()) * (2 * m_rows * n + 4 * n * n)
-        # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE + WRITE_SIZE,
-        # KB units; 8-byte-per-lane accesses calibrate at x1.0 on gfx950) -- not re-measured live
-        traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles", "r01", "headline_rocprof_summary_final.json")
+        # HBM traffic per launch and the issue figures from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE + WRITE_SIZE in KB; 8-byte-per-lane accesses calibrate at x1.0 on gfx950) -- not
+        # re-measured live
+        traffic, traffic_src, issue = None, None, {}
+        prof = os.path.join(ROOT, PMC_SUMMARY)
+        if not os.path.exists(prof):
+            prof = os.path.join(ROOT, "profiles", "r01", "headline_rocprof_summary_final.json")
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
                 ctr = json.load(open(prof))["counters"]
                 kname = [k for k in ctr if "copra_lmpc_fused_tri_kernel" in k][0]
-                traffic = 1024.0 * (ctr[kname]["FETCH_SIZE"]["mean_per_launch"] + ctr[kname]["WRITE_SIZE"]["mean_per_launch"])
-                traffic_src = "profiles/r01/headline_rocprof_summary_final.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                c = {k: v["mean_per_launch"] for k, v in ctr[kname].items()}
+                traffic = 1024.0 * (c["FETCH_SIZE"] + c["WRITE_SIZE"])
+                traffic_src = os.path.relpath(prof, ROOT) + " (rocprofv3 --pmc, separate passes)"
+                issue = {"valu_instructions_per_solve": c["SQ_INSTS_VALU"] / batch,
+                         "lds_instructions_per_solve": c["SQ_INSTS_LDS"] / batch,
+                         "valu_issue_share_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                         "fp64_mfma_per_solve": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / batch / 4.0,
+                         # ~22 % of the wave instructions are FP64 arithmetic (static count in the disassembly, DESIGN.md
+                         # 3.9): executed flops = that share x 64 lanes x 2 per FMA
+                         "executed_fp64_tflops_estimate": 0.22 * c["SQ_INSTS_VALU"] * 64 * 2 / kern / 1e12}
             except Exception:
                 traffic = None
+        hist = np.bincount(np.minimum(iters[:, 0], 15), minlength=16)
         line = {
             "metric": "MPC solves/sec (batched) at (nx=6,nu=3,N=20); max |u-u_ref|",
             "value": value,
@@ -207,18 +357,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "CoM preview LMPC nx=6 nu=3 N=20, TrajectoryCost+ControlCost, "
-                                   "TrajectoryBound(63 rows)+ControlBound (BASELINE configs[2])",
+            "config": {"workload": workload_name,
                        "hessian": "dense MFMA f64 contraction (full-size cost entry)" if args.dense_hessian
                        else "block-diagonal prefix sums (per-step cost entry)",
-                       "batch_per_gpu": batch, "global_batch": batch * world, "nvar": n, "ineq_rows": 63,
+                       "batch_per_gpu": batch, "global_batch": global_batch, "nvar": n, "ineq_rows": 63,
                        "bound_rows": 2 * n,
-                       "parallelism": ("batch-shard x%d + 1 RCCL gather/step (%s)"
+                       "parallelism": ("contiguous batch shards x%d + 1 RCCL gather/step (%s)"
                                        % (world, "overlapped with the next solve" if overlap else "synchronous"))
                        if world > 1 else "single GPU"},
             "solved_ok": n_ok,
             "mean_active_set_iters": float(iters[:, 0].mean()),
             "max_active_set_iters": int(iters[:, 0].max()),
+            "active_set_iteration_histogram": {("%d" % k if k < 15 else "15+"): int(v) for k, v in enumerate(hist) if v},
             "kernel_ms": kern * 1e3,
             "kernel_solves_per_s": batch / kern,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -226,27 +376,20 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "kernel": "copra_lmpc_fused_tri_kernel", "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "
-                                 "construction",
-                         "fp64_model_tflops": flops * batch / kern / 1e12, "fp64_peak_tflops": FP64_PEAK_TFLOPS},
+                                 "construction; what it does with the machine is in `issue`",
+                         "issue": issue, "fp64_peak_tflops": FP64_PEAK_TFLOPS},
         }
+        if multi is not None:
+            line["multi_gpu_check"] = multi
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        # threads actually available to this process: hardware threads, affinity mask and the cgroup CPU quota
-        hw = os.cpu_count() or 1
-        cores = min(hw, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else hw
-        quota_note = ""
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                lim = max(1, int(round(float(q) / float(per))))
-                if lim < cores:
-                    quota_note = "; cgroup CPU quota %d of %d hardware threads" % (lim, hw)
-                    cores = lim
-        except Exception:
-            pass
-        probe = min(batch, 64 * cores)
+        cores, hw, quota_note = host_cores()
+        # warm the -O3 -march=native build of the oracle (compiled on first use on a new host) before anything is timed
+        pyoracle.lmpc_solve_batch(wl["A"][:8], wl["B"][:8], wl["d"][:8], wl["x0"][:8], N, wl["costs"], wl["cstrs"],
+                                  nthreads=1, native=True)
+        probe = min(batch, 256 * cores)
         sl = slice(0, probe)
         t = time.perf_counter()
         ref = pyoracle.lmpc_solve_batch(wl["A"][sl], wl["B"][sl], wl["d"][sl], wl["x0"][sl], N, wl["costs"],
@@ -269,13 +412,19 @@ def main():
         err = float(np.nanmax(np.abs(u[ok] - ref["control"][ok])))
         rel = float(np.nanmax(np.abs(u[ok] - ref["control"][ok]) / (1.0 + np.abs(ref["control"][ok]))))
         line["cpu_baseline"] = {"value": sample / cpu_t, "unit": "solves/s", "cores": cores, "kind": "port",
-                                "sample": "first %d of the %d instances of this run, one oracle controller per "
-                                          "instance, static partition over %d pthreads, gcc -O3 -march=native%s"
-                                          % (sample, batch, cores, quota_note),
-                                "single_thread_solves_per_s": cpu1}
+                                "sample": "first %d of the %d instances of this run (%.1f s of CPU work), one oracle "
+                                          "controller per instance, static partition over %d pthreads, gcc -O3 "
+                                          "-march=native%s" % (sample, batch, cpu_t, cores, quota_note),
+                                "single_thread_solves_per_s": cpu1, "cpu_model": cpu_model(), "hardware_threads": hw}
         line["max_abs_u_err"] = err
         line["max_rel_u_err"] = rel
         line["status_agree"] = bool((ref["status"] == status[:sample]).all())
+    if rank == 0 and world == 1 and not args.no_extra and not comm_path and not args.dense_hessian:
+        eng.close()
+        try:
+            line["extra"] = extra_measurements(np, torch, dev)
+        except Exception as e:  # the headline line must not be lost to a side measurement
+            line["extra"] = {"error": repr(e)}
     if use_dist:
         # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which is block-buffered on a pipe and
         # would otherwise land AFTER the JSON line at exit: flush it now so that the JSON line stays the last line
@@ -288,8 +437,8 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
-        if rank == 0 and args.selftest_rccl:  # the gathered copy of this rank's slab must equal the slab
-            assert all(torch.equal(gather_bufs[k][0], slabs[k][0]) for k in range(n_slabs)), "RCCL gather mismatch"
+        if rank == 0 and multi is not None:
+            assert multi["gathered_slabs_match_per_rank_checksums"], "RCCL gather mismatch"
         dist.destroy_process_group()
 
 

@@ -35,8 +35,9 @@ def _guard(fn):
 
 
 class SolverFlag:
-    DEFAULT = 0
-    QuadProgDense = 1  # the only back-end of this engine: hand-written Goldfarb-Idnani on the GPU
+    # include/solverUtils.h:34-50 -> copra_batch_select_solver
+    DEFAULT = 0  # the engine picks: Goldfarb-Idnani kernels, the stage-wise Riccati interior-point kernel for long horizons
+    QuadProgDense = 1  # always the hand-written Goldfarb-Idnani kernels (the reference's QuadProgDense arithmetic)
 
 
 class AutoSpan:
@@ -226,6 +227,7 @@ class LMPC:
         self._ps = ps_or_flag if isinstance(ps_or_flag, PreviewSystem) else None
         self._costs, self._cstrs = [], []
         self._eng = None
+        self._flag = ps_or_flag if (ps_or_flag is not None and not isinstance(ps_or_flag, PreviewSystem)) else flag
         self._dirty = True
         self._control = np.zeros(0)
         self._trajectory = np.zeros(0)
@@ -288,8 +290,15 @@ class LMPC:
             ist = self._initial_state_desc() if self._initial_state else None
             self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, [c._dict() for c in self._costs],
                                   [c._dict() for c in self._cstrs], initial_state=ist)
+            self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
             self._dirty = False
         return self._eng
+
+    def select_qp_solver(self, flag):
+        """LMPC::selectQPSolver (src/LMPC.cpp:62-65)"""
+        self._flag = flag
+        if self._eng is not None:
+            self._eng.select_solver("quadprog_dense" if flag == SolverFlag.QuadProgDense else "default")
 
     @_guard
     def solve(self):

@@ -60,3 +60,92 @@ def gather_results(slab, rank, world, bufs, dst=0, force=False):
         return [slab]
     dist.gather(slab, gather_list=bufs if rank == dst else None, dst=dst)
     return bufs
+
+
+class _HostStream:
+    """stand-in for a HIP stream where there is none (gloo ranks on CPU in the tests): everything is synchronous"""
+
+    def wait_event(self, ev):
+        pass
+
+
+class _HostEvent:
+    def record(self, stream=None):
+        pass
+
+
+class GatherLoop:
+    """The N > 1 step loop of bench.py: every step solves the rank's shard into result slab k and sends that slab to rank
+    0 with the ONE collective of the path.  With `overlap` (two slabs) the gather of step k runs on a side stream, ordered
+    after the solve that filled its slab, and overlaps the solve of step k + 1; a slab is not overwritten before its
+    previous gather has finished.  `solve(views, k)` fills the four typed views of slab k (the engine writes straight
+    into them); on a CUDA device it must launch on the current stream.  verify() is the end-to-end check of the path."""
+
+    def __init__(self, slabs, rank, world, solve, device, use_dist=True, overlap=False, force_gather=False):
+        self.slabs, self.rank, self.world, self.solve = slabs, rank, world, solve
+        self.use_dist, self.force = use_dist, force_gather
+        self.n_slabs = len(slabs)
+        self.cuda = device.type == "cuda"
+        self.overlap = overlap and self.n_slabs > 1
+        if use_dist:
+            self.gather_bufs = [alloc_gather_buffers(sl[0], rank, world) for sl in slabs]
+        else:
+            self.gather_bufs = [[torch.empty_like(sl[0])] for sl in slabs]  # single-GPU self-test: a device copy stands in
+        if self.cuda:
+            self.cur = torch.cuda.current_stream()
+            self.comm = torch.cuda.Stream(device=device) if self.overlap else None
+            self.ev_solved = [torch.cuda.Event() for _ in slabs]
+            self.ev_sent = [torch.cuda.Event() for _ in slabs]
+        else:
+            self.cur, self.comm = _HostStream(), (_HostStream() if self.overlap else None)
+            self.ev_solved = [_HostEvent() for _ in slabs]
+            self.ev_sent = [_HostEvent() for _ in slabs]
+        self.step_no = 0
+        self.last = 0  # slab of the most recent step
+
+    def send(self, k):
+        if self.use_dist:
+            gather_results(self.slabs[k][0], self.rank, self.world, self.gather_bufs[k], force=self.force)
+        else:
+            self.gather_bufs[k][0].copy_(self.slabs[k][0], non_blocking=True)
+
+    def step(self, communicate=True):
+        k = self.step_no % self.n_slabs
+        self.step_no += 1
+        self.last = k
+        if self.overlap and self.step_no > self.n_slabs:
+            self.cur.wait_event(self.ev_sent[k])  # this slab's previous gather must be done before it is overwritten
+        self.solve(self.slabs[k][1], k)
+        if not communicate:
+            return
+        if self.overlap:
+            self.ev_solved[k].record(self.cur)
+            if self.cuda:
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(self.ev_solved[k])
+                    self.send(k)
+                    self.ev_sent[k].record(self.comm)
+            else:
+                self.send(k)
+        else:
+            self.send(k)
+
+    def verify(self):
+        """After the loop has drained: every rank checksums the slab it sent last (exact: int64 wrap-around sum of the
+        raw bytes), the checksums are all-gathered, and rank 0 compares them with the checksums of what it received.
+        Returns (ok, per-rank checksums) on rank 0, (True, None) elsewhere."""
+        k = self.last
+        mine = self.slabs[k][0].view(torch.int64).sum().reshape(1)
+        if not self.use_dist:
+            return bool(torch.equal(self.gather_bufs[k][0], self.slabs[k][0])), [int(mine.item())]
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        if self.rank != 0:
+            return True, None
+        got = [int(b.view(torch.int64).sum().item()) for b in self.gather_bufs[k]]
+        sent = [int(t.item()) for t in every]
+        return got == sent, sent
+
+    def gathered(self):
+        """rank 0: the slabs received by the most recent gather, in rank order"""
+        return self.gather_bufs[self.last]

@@ -28,13 +28,30 @@ def _run(*extra):
 
 @pytest.mark.gpu
 def test_single_gpu_line_with_cpu_baseline():
-    out = _run("--cpu-seconds", "1")
+    out = _run("--cpu-seconds", "1", "--no-extra")
     cb = out["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cpu_model"]
     assert out["max_rel_u_err"] <= 1e-6 and out["status_agree"]
+    assert sum(out["active_set_iteration_histogram"].values()) == 4096
+
+
+@pytest.mark.gpu
+def test_extra_measurements_outside_the_timed_region():
+    """configs 2 and 5, the shared-model tick, the tight-workload point and the host-inclusive rate ride
+    along in `extra`"""
+    out = _run("--no-cpu-baseline")
+    ex = out["extra"]
+    assert "error" not in ex, ex
+    for key in ("config2_double_integrator_batch4096", "config5_initial_state_12_6_50_riccati_ipm",
+                "config5_initial_state_12_6_50_quadprog_dense", "shared_model_tick_batch65536",
+                "tight_workload_vmax0.25_umax1.2", "host_inclusive_numpy_in_numpy_out"):
+        assert ex[key]["solves_per_s"] > 0, key
+    assert ex["config5_initial_state_12_6_50_riccati_ipm"]["solved_ok"] == 16384
 
 
 @pytest.mark.gpu
 def test_multi_gpu_code_path_with_one_rank_rccl():
     out = _run("--no-cpu-baseline", "--selftest-rccl")
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    mg = out["multi_gpu_check"]  # rank 0 verified what it gathered: checksums + an oracle sample of the shard
+    assert mg["gathered_slabs_match_per_rank_checksums"] and mg["status_agree"] and mg["max_rel_u_err"] <= 1e-6

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks shard a batch, fill their result slabs and gather them on rank 0 exactly as
-bench.py does with RCCL (backend "nccl") on the GPUs.  The per-rank "solve" is the CPU oracle here (no GPU in this
-container); what is under test is the partitioning, the slab layout and the single gather."""
+"""N > 1 path on CPU: two gloo ranks run the step loop bench.py runs with RCCL (backend "nccl") on the GPUs -- the SAME
+code (copra_amd.sharding.GatherLoop) -- with the CPU oracle standing in for the per-rank solve (no GPU in this
+container); under test: the partitioning, the slab layout, the single gather per step, the double-buffer rotation and
+the verification of what rank 0 received."""
 import os
 import socket
 import sys
@@ -22,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, out_path):
+def _worker(rank, world, port, total, out_path, overlap):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -30,25 +31,42 @@ def _worker(rank, world, port, total, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import pyoracle
     from copra_amd import workloads
-    from copra_amd.sharding import alloc_gather_buffers, alloc_result_slab, gather_results, shard_range, split_slab
+    from copra_amd.sharding import GatherLoop, alloc_result_slab, shard_range, split_slab
     wl = workloads.double_integrator(total, seed=11)
-    lo, hi = shard_range(total, rank, world)
+    lo, hi = shard_range(total, rank, world)  # contiguous shards of ONE batch, as bench.py --gpus N does
     b = hi - lo
     n, X = 10, 22
-    slab, v = alloc_result_slab(b, n, X, torch.device("cpu"))
-    ref = pyoracle.lmpc_solve_batch(wl["A"][lo:hi], wl["B"][lo:hi], wl["d"][lo:hi], wl["x0"][lo:hi], wl["N"],
-                                    wl["costs"], wl["cstrs"])
-    v["control"].copy_(torch.from_numpy(ref["control"]))
-    v["trajectory"].copy_(torch.from_numpy(ref["trajectory"]))
-    v["status"].copy_(torch.from_numpy(ref["status"]))
-    v["iter"].copy_(torch.from_numpy(ref["iter"]))
-    bufs = alloc_gather_buffers(slab, rank, world)
-    got = gather_results(slab, rank, world, bufs)
+    dev = torch.device("cpu")
+    slabs = [alloc_result_slab(b, n, X, dev) for _ in range(2 if overlap else 1)]
+    calls = []
+
+    def solve_into(v, k):  # stand-in for eng.set_outputs + eng.solve: the CPU oracle fills the slab the gather sends
+        x0 = wl["x0"][lo:hi] + 0.01 * len(calls)  # (every step solves something else: a stale slab would be noticed)
+        ref = pyoracle.lmpc_solve_batch(wl["A"][lo:hi], wl["B"][lo:hi], wl["d"][lo:hi], x0, wl["N"], wl["costs"], wl["cstrs"])
+        v["control"].copy_(torch.from_numpy(ref["control"]))
+        v["trajectory"].copy_(torch.from_numpy(ref["trajectory"]))
+        v["status"].copy_(torch.from_numpy(ref["status"]))
+        v["iter"].copy_(torch.from_numpy(ref["iter"]))
+        calls.append(k)
+
+    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=True, overlap=overlap)
+    for _ in range(3):
+        loop.step()
+    dist.barrier()
+    ok, sums = loop.verify()
+    assert ok
     if rank == 0:
-        parts = [split_slab(g, b, n, X) for g in got]
+        assert len(sums) == world
+        parts = [split_slab(g, b, n, X) for g in loop.gathered()]
         u = torch.cat([p["control"] for p in parts]).numpy()
         st = torch.cat([p["status"] for p in parts]).numpy()
-        np.savez(out_path, control=u, status=st)
+        np.savez(out_path, control=u, status=st, slabs_used=np.array(calls))
+    # a corrupted payload must be caught
+    if rank == 0:
+        loop.gathered()[1].view(torch.int64)[3] += 1
+    ok2, _ = loop.verify()
+    if rank == 0:
+        assert not ok2
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,16 +82,21 @@ def test_shard_range_covers_everything():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_gather(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_gloo_gather(tmp_path, overlap):
+    """bench.py's own step loop (copra_amd.sharding.GatherLoop: step / send / verify, one or two result slabs) with two
+    gloo ranks on CPU and the oracle standing in for the solve: contiguous shards, ONE gather per step, rank 0 ends up with
+    every shard of the LAST step and the checksum verification notices a corrupted payload"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     from copra_amd import workloads
-    total, world = 32, 2  # equal shards (weak-scaling layout of bench.py)
+    total, world = 32, 2
     out = str(tmp_path / "gathered.npz")
     pyoracle.lib()
-    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     wl = workloads.double_integrator(total, seed=11)
-    ref = pyoracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    ref = pyoracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"] + 0.02, wl["N"], wl["costs"], wl["cstrs"])  # step 3
     assert (got["status"] == ref["status"]).all()
     assert np.array_equal(got["control"], ref["control"])
+    assert list(got["slabs_used"]) == ([0, 1, 0] if overlap else [0, 0, 0])
