@@ -58,10 +58,10 @@ __global__ __launch_bounds__(64, 4) void copra_lmpc_shared_kernel_w4(const Fused
 
 // Factor-only first tier (LdsLayout::tri): the packed Cholesky factor is the only O(n^2) object in LDS, so six instances
 // share a CU at the headline shape (two waves on two of the four SIMDs: 256 VGPRs each) instead of four.
-template <int NX, int NU, int NH, int RP>
+template <int NX, int NU, int NH, int RP, int QR = 0>
 __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const FusedPlan P)
 {
-    lmpc_fused_body<NX, NU, NH, RP, true>(P, P.inst_offset + (int)blockIdx.x);
+    lmpc_fused_body<NX, NU, NH, RP, true, QR>(P, P.inst_offset + (int)blockIdx.x);
 }
 
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
@@ -171,6 +171,7 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
+        if (P.nx == 6 && rp == 6 && P.lds.q1regs == kFusedQ1Regs) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6, kFusedQ1Regs>;
         if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
         return copra_lmpc_fused_tri_kernel<0, 0, 0, 0>;
     }
@@ -840,6 +841,13 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared = true;
     h->model_dirty = true;
+    LdsLayout lq {};
+    if (tri_layout_with_lds_q1(h->hp.plan, h->hp.plan.lds, lq)) { // the shared-model kernels keep Q1 in LDS
+        h->hp.plan.lds = lq;
+        h->hp.lds_bytes = (size_t)lq.total * sizeof(double);
+        h->lds_attr_set = false;
+        h->shared_attr_set = false;
+    }
     return COPRA_OK;
 }
 

@@ -399,10 +399,34 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
 //     dropping one rotates columns of Q1 exactly as it rotates those of J.
 // Same pivoting rule, same steps, the same iterates up to rounding; 15 KB of LDS per instance instead of 29 KB at
 // n = 60 and no triangular inverse (48 k cycles) for the instances that activate a constraint.
-template <int NV, bool TRI = false, class Rows>
+// QR > 0 (with TRI): the columns of Q1 live in REGISTERS -- every access to Q1 is lane-private (lane j holds row j of each
+// column), so QR columns cost 2 QR VGPRs per lane and no LDS: 320 doubles less per instance at QR = 5, which is what lets
+// an eighth instance share a CU at the headline shape (LdsLayout::q1regs).  S.rcap <= QR then.
+template <int NV, bool TRI = false, int QR = 0, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
     int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false)
 {
+    double q1r[QR > 0 ? QR : 1]; // this lane's element of every Q1 column (QR > 0)
+#pragma unroll
+    for (int u = 0; u < (QR > 0 ? QR : 1); ++u) q1r[u] = 0.0;
+    auto q1_get = [&](int k) -> double {
+        if constexpr (QR > 0) {
+            double v = q1r[0];
+#pragma unroll
+            for (int u = 1; u < QR; ++u) v = (u == k) ? q1r[u] : v;
+            return v;
+        } else {
+            return S.Q1[k * kWave + lane_id()];
+        }
+    };
+    auto q1_set = [&](int k, double v) {
+        if constexpr (QR > 0) {
+#pragma unroll
+            for (int u = 0; u < QR; ++u) q1r[u] = (u == k) ? v : q1r[u];
+        } else {
+            S.Q1[k * kWave + lane_id()] = v;
+        }
+    };
     const int lane = lane_id();
     const int n = NV ? NV : n_rt;
     const int ld = NV ? (NV | 1) : S.ldj;
@@ -550,11 +574,23 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 vj = wk;
                 dj = 0.0;
                 for (int pass = 0; pass < 2; ++pass) {
-                    for (int k = 0; k < nact; ++k) {
-                        const double qk = S.Q1[k * kWave + lane];
-                        const double e = wave_sum(qk * vj);
-                        vj -= e * qk;
-                        if (lane == k) dj += e;
+                    if constexpr (QR > 0) {
+#pragma unroll
+                        for (int k = 0; k < QR; ++k) {
+                            if (k < nact) {
+                                const double qk = q1r[k];
+                                const double e = wave_sum(qk * vj);
+                                vj -= e * qk;
+                                if (lane == k) dj += e;
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < nact; ++k) {
+                            const double qk = S.Q1[k * kWave + lane];
+                            const double e = wave_sum(qk * vj);
+                            vj -= e * qk;
+                            if (lane == k) dj += e;
+                        }
                     }
                 }
                 if (iter_main <= 1) COPRA_FINE("as:d");
@@ -658,7 +694,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     if (lane < nact) S.R[rcol(nact) + lane] = dj;
                     if constexpr (TRI) {
                         const double h = sqrt(wave_sum(vj * vj));
-                        S.Q1[nact * kWave + lane] = vj / h; // (lanes >= n hold 0)
+                        q1_set(nact, vj / h); // (lanes >= n hold 0)
                         if (lane == nact) {
                             S.R[rcol(nact) + nact] = h;
                             S.iact[nact] = nvl;
@@ -803,10 +839,10 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         }
                         // columns q, q+1 of J (lane = row)
                         if constexpr (TRI) {
-                            const double x = S.Q1[q * kWave + lane], y = S.Q1[(q + 1) * kWave + lane];
+                            const double x = q1_get(q), y = q1_get(q + 1);
                             const double t = gc * x + gs * y;
-                            S.Q1[(q + 1) * kWave + lane] = nu_ * (x + t) - y;
-                            S.Q1[q * kWave + lane] = t;
+                            q1_set(q + 1, nu_ * (x + t) - y);
+                            q1_set(q, t);
                         } else if (lane < n) {
                             const double x = J[lane * ld + q], y = J[lane * ld + q + 1];
                             const double t = gc * x + gs * y;

@@ -390,7 +390,7 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
 // over the cost rows unroll; RP_ == 0 uses the run-time row count of each term.
 // TRI_: factor-only layout (LdsLayout::tri; gi_core.hpp) -- the Hessian is built straight into the packed upper triangle
 // (each entry has ONE writer: the lanes of a diagonal block skip its lower half), plans without full-size costs only.
-template <int NX_, int NU_, int NH_, int RP_, bool TRI_ = false>
+template <int NX_, int NU_, int NH_, int RP_, bool TRI_ = false, int QR_ = 0>
 COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
 {
     double* lds = lds_base();
@@ -843,7 +843,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
     stamp[5] = cycle_counter();
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+        status = gi_active_set<NV, TRI_, QR_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     stamp[6] = cycle_counter();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else

@@ -18,6 +18,7 @@ namespace copra_hip {
 constexpr int kMaxCosts = 8;
 constexpr int kMaxFullRows = 16; // full-size constraint rows the workgroup-per-instance kernel evaluates cooperatively
 constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
+constexpr int kFusedQ1Regs = 5; // columns of Q1 the headline first-tier kernel keeps in registers (gi_core.hpp, QR)
 // lanes one instance works with: the 64-lane wavefront, or a 16-lane DPP row of it in the packed small-problem build
 // (copra_hip_packed.hip compiles the same kernel bodies with COPRA_WAVE_WIDTH = 16: four instances per wavefront)
 #ifndef COPRA_WAVE_WIDTH
@@ -77,6 +78,7 @@ struct LdsLayout {
              // orthonormal basis of the active normals (rcap columns of 64), dv / the 4n coefficients do not exist and
              // the diagonal slots of the factor carry 1 / R(i,i)
     int Q1;
+    int q1regs; // > 0 (factor-only layout): that many columns of Q1 live in registers, there is no Q1 region in LDS
     int R; // packed upper-triangular R of the active set (rcap columns)
     int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one
     int xs, dv, zv, uv, ap, coef, cvec; // solver vectors (n; uv n+1; coef 4n)

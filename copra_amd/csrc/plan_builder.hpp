@@ -67,8 +67,10 @@ inline int align2(int v) { return (v + 1) & ~1; }
 //                     tables may run over Q1 / R as well (nothing of the active set exists yet).
 //   xcur_late (with tri): the plan never reads the trajectory during the active-set loop (FusedPlan::rows_direct), so
 //                     the trajectory written at the very end takes the place of the then dead factor.
+//   q1regs (with tri): the first-tier kernel keeps that many columns of Q1 in registers (gi_core.hpp, QR): no Q1 region,
+//                     rcap = q1regs.
 inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false, bool xcur_late = false)
+    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false, bool xcur_late = false, int q1regs = 0)
 {
     int o = 0;
     auto take = [&](int count) {
@@ -80,6 +82,7 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     const int sizeJ = tri ? align2(n * (n + 1) / 2) : align2(n * L.ldj);
     L.tri = tri ? 1 : 0;
     L.Q1 = 0;
+    L.q1regs = (tri && q1regs > 0) ? q1regs : 0;
     const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
     const int sizeFull = rfull > 0 ? align2(rfull) + 4 * kWave : 0;
     const int sizeCost
@@ -137,17 +140,21 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     int rcap = n;
     if (compact) {
         const int left = budget - o - 2;
-        const int per_col = tri ? kWave : 0;
+        const int per_col = (tri && q1regs == 0) ? kWave : 0;
         // a column of R, its multiplier (uv), its row index (iact) and, factor-only, its column of Q1
         auto need = [&](int r) { return r * per_col + r * (r + 1) / 2 + align2(r + 2) + align2((r + 2) / 2 + 1); };
         rcap = 0;
         while (rcap < n && need(rcap + 1) <= left) ++rcap;
+        if (q1regs > 0) {
+            if (rcap < q1regs) return false;
+            rcap = q1regs;
+        }
         if (rcap < 1) return false;
         L.uv = take(rcap + 2);
         L.iact = take((rcap + 2) / 2 + 1);
     }
     L.rcap = rcap;
-    if (tri) L.Q1 = take(rcap * kWave);
+    if (tri && q1regs == 0) L.Q1 = take(rcap * kWave);
     L.R = take(rcap * (rcap + 1) / 2 + 2);
     if (tri && o < vec0 + sizeCost) o = vec0 + sizeCost;
     L.total = o;
@@ -167,6 +174,25 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
         LdsLayout t {};
         if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
             && t.total <= budget && t.rcap > cur.rcap) {
+            out = t;
+            return true;
+        }
+    }
+    return false;
+}
+
+// The layout with Q1 in LDS that is closest to a register-Q1 layout (kernels without the QR instantiation -- the
+// shared-model path -- cannot run the latter)
+inline bool tri_layout_with_lds_q1(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
+{
+    if (!cur.tri || cur.q1regs == 0) return false;
+    const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
+    const int rows = rp > P.rmax ? rp : P.rmax;
+    for (int k = 8; k >= 4; --k) {
+        const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
+        LdsLayout t {};
+        if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
+            && t.total <= budget && t.rcap >= cur.rcap) {
             out = t;
             return true;
         }
@@ -646,10 +672,22 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         if (U > (tmin ? std::atoi(tmin) : 32) && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
+            // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU
+            const int qregs = (nx == 6 && rp == 6 && !std::getenv("COPRA_NO_Q1REGS")) ? kFusedQ1Regs : 0;
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
+                if (qregs > 0
+                    && layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0, qregs)
+                    && t.total <= budget) {
+                    hp.lds_safe = P.lds;
+                    hp.safe_two_tier = hp.two_tier;
+                    hp.two_tier = true;
+                    hp.dense = true;
+                    P.lds = t;
+                    break;
+                }
                 if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
                     && t.total <= budget && t.rcap >= need) {
                     hp.lds_safe = P.lds; // what the adaptive fall-back steps to

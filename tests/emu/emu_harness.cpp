@@ -225,8 +225,14 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.ovf_list = ovf_list.data();
     P.from_list = 0;
     if (dump_instance >= 0) P.lds = hp.lds_full;
+    if (!s6 && P.lds.q1regs > 0) { // the run-time-shape body keeps Q1 in LDS (it never meets a register-Q1 layout in the library)
+        LdsLayout lq {};
+        if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
+    }
     auto body = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && s6) // (select_fused_kernel: the factor-only first tier)
+        if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
+            lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
+        else if (PP.lds.tri && s6)
             lmpc_fused_body<6, 3, 20, 6, true>(PP, b);
         else if (PP.lds.tri)
             lmpc_fused_body<0, 0, 0, 0, true>(PP, b);
@@ -386,6 +392,13 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     P.model = model.data();
     P.model_rtot = 0;
     P.x0 = x0;
+    { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
+        LdsLayout lq {};
+        if (tri_layout_with_lds_q1(P, P.lds, lq)) {
+            P.lds = lq;
+            hp.lds_bytes = (size_t)lq.total * sizeof(double);
+        }
+    }
     auto shared = [&](const FusedPlan& PP, int b) {
         if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
             lmpc_shared_body<6, 3, 20, true>(PP, b);
