@@ -1379,6 +1379,12 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
     } else {
         LDS_OPT_IN(select_fused_kernel(P), h->hp.lds_bytes);
+        if (std::getenv("COPRA_DEBUG")) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(select_fused_kernel(P)), 64, h->hp.lds_bytes);
+            fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
+                h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
+        }
         hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
     }

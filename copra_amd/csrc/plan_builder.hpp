@@ -70,8 +70,11 @@ inline int align2(int v) { return (v + 1) & ~1; }
 //   q1regs (with tri): the first-tier kernel keeps that many columns of Q1 in registers (gi_core.hpp, QR): no Q1 region,
 //                     rcap = q1regs.
 inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rmax, int mgen, int meq, int mtotal,
-    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false, bool xcur_late = false, int q1regs = 0)
+    bool fused, bool compact = false, int budget = 0, int rfull = 0, bool tri = false, bool xcur_late = false, int q1regs = 0,
+    bool no_y = false)
 {
+    // no_y: every state cost of the controller has M = I (CostTerm::ident): the cost phase reads the blocks G_k instead of
+    // forming Y_k = M G_k, so the Y table does not exist (the high-water mark of the factor-only layout is the cost phase)
     int o = 0;
     auto take = [&](int count) {
         int at = o;
@@ -85,8 +88,8 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     L.q1regs = (tri && q1regs > 0) ? q1regs : 0;
     const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
     const int sizeFull = rfull > 0 ? align2(rfull) + 4 * kWave : 0;
-    const int sizeCost
-        = fused ? align2(N * rmax * nu) + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) + sizeFull : 0;
+    const int sizeY = no_y ? 0 : align2(N * rmax * nu);
+    const int sizeCost = fused ? sizeY + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) + sizeFull : 0;
     if (fused) {
         L.G = take(N * nx * nu);
         L.Xbar = take(X);
@@ -129,7 +132,7 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     if (fused && !compact) cost0 = take(sizeCost);
     if (fused) {
         int q = cost0;
-        L.BldY = q, q += align2(N * rmax * nu);
+        L.BldY = q, q += sizeY;
         L.BldWe = q, q += align2((N + 1) * rmax);
         L.BldCp = q, q += align2(rmax * (nx + nu + 2));
         L.BldFull = q;
@@ -674,12 +677,16 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU
             const int qregs = (nx == 6 && rp == 6 && !std::getenv("COPRA_NO_Q1REGS")) ? kFusedQ1Regs : 0;
+            bool all_ident = true; // (state costs with M = I padded to nx rows: lmpc_fused.hpp reads G instead of Y)
+            for (int t = 0; t < P.ncost; ++t)
+                all_ident = all_ident && (P.cost[t].kind == kCostControl || (P.cost[t].ident && rows == nx));
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
                 if (qregs > 0
-                    && layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0, qregs)
+                    && layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0, qregs,
+                        all_ident)
                     && t.total <= budget) {
                     hp.lds_safe = P.lds;
                     hp.safe_two_tier = hp.two_tier;
