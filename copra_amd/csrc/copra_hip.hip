@@ -177,6 +177,7 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
     }
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_kernel<2, 1, 10, 2>;
+    if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_kernel<6, 3, 20, 0>; // headline shape, full-size costs
     if ((size_t)P.lds.total * sizeof(double) * 9 <= 160u * 1024u) return copra_lmpc_fused_kernel_w4; // > 8 per CU
     return copra_lmpc_fused_kernel<0, 0, 0, 0>;
 }
@@ -185,6 +186,7 @@ fused_kernel_t select_tier2_kernel(const FusedPlan& P)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tier2_kernel<6, 3, 20, 6>;
     if (P.nx == 2 && rp == 2) return copra_lmpc_fused_tier2_kernel<2, 1, 10, 2>;
+    if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tier2_kernel<6, 3, 20, 0>;
     return copra_lmpc_fused_tier2_kernel<0, 0, 0, 0>;
 }
 } // namespace

@@ -301,10 +301,17 @@ struct StageRows {
 
 // ------------------------------------------------------------------------------------------------
 // Full-size cost entry (costFunctions.cpp:65-71 TrajectoryCost, :141-146 ControlCost, :197-203 MixedCost):
-//     tmp = M Psi (+ N)   (R x n, dense, no Toeplitz structure),   Q += tmp' W tmp,   c += tmp' W (M xbar - p).
-// This is the dense Psi' W Psi contraction of the reference.  It runs on the matrix cores: four rows of tmp at a
-// time are staged through LDS into the operand layout of v_mfma_f64_16x16x4_f64 (K = 4 cost rows per instruction)
-// and accumulated into the 10 upper 16x16 tiles of Q; the weights ride on the A operand ((tmp' W) tmp as in Eigen).
+//     tmp = M Psi (+ N)   (R x n, dense),   Q += tmp' W tmp,   c += tmp' W (M xbar - p).
+// This is the dense Psi' W Psi contraction of the reference, and BOTH products run on the matrix cores
+// (v_mfma_f64_16x16x4_f64), sixteen rows of tmp at a time:
+//   * tmp(16 x 64) = M(16 x X) Psi(X x 64): K = 4 columns of M per instruction, A operand = M straight from HBM / L2 (the
+//     matrix is shared by the batch), B operand = Psi built on the fly from the blocks G_k in LDS (Psi_{s,j} = G_{s-1-j}
+//     for s > j, else 0); a K-step whose four rows of Psi are zero for a whole 16-column tile is skipped (Psi is block
+//     lower triangular: about 45 % of the tile products);
+//   * the tile goes to LDS once (16 x 64 doubles) and from there feeds (a) the gradient c_j += sum_r We_r tmp(r, j), lane =
+//     column, and (b) the ten upper 16x16 tiles of Q += (tmp' W) tmp, four K-steps of four rows, weights on the A operand
+//     as Eigen evaluates it.
+// Round 1 formed tmp row by row on the VALU (0.83 M solves/s at the headline shape, the matrix cores 0.7 % busy).
 // ------------------------------------------------------------------------------------------------
 template <int NX_, int NU_, int NH_>
 COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const double* p, const double* G,
@@ -318,7 +325,7 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
     const double* w = P.params + ct.offW;
     double* We = scratch; // R weighted residuals
-    double* stage = scratch + ((R + 1) & ~1); // 4 x 64 tile of tmp rows
+    double* stage = scratch + ((R + 1) & ~1); // 16 x 64 tile of tmp rows
     // weighted residuals  We_r = (M_r . xbar - p_r) w_r   (ControlCost: -p_r w_r)
     for (int r = lane; r < R; r += kWave) {
         double acc = 0.0;
@@ -330,45 +337,72 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     mfma_acc acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t].v[0] = acc[t].v[1] = acc[t].v[2] = acc[t].v[3] = 0.0;
-    const int jb = lane / nu, jc = lane - jb * nu;
     const int kk = lane >> 4, col = lane & 15;
-    for (int r0 = 0; r0 < R; r0 += 4) {
-        double y[4];
+    // this lane's column of every 16-column tile of Psi: j = 16 tj + col = (jb, jc)
+    int jbv[4], goff[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + u;
-            double v = 0.0;
-            if (r < R && lane < n) {
-                if (Mr) { // row r of M times column `lane` of Psi: Psi_{s, jb} = G_{s-1-jb} for s > jb
-                    const double* mrow = Mr + (size_t)r * X;
-                    for (int s = jb + 1; s <= N; ++s) {
-                        const double* Gk = G + (s - 1 - jb) * nx * nu + nx * jc;
-                        for (int c = 0; c < nx; ++c) v += mrow[s * nx + c] * Gk[c];
-                    }
+    for (int tj = 0; tj < 4; ++tj) {
+        const int j = 16 * tj + col;
+        jbv[tj] = (j < n) ? j / nu : (1 << 20); // (a column beyond n never sees s > jb)
+        goff[tj] = (j < n) ? nx * (j - (j / nu) * nu) - (j / nu) * nx * nu : 0; // G[(s-1-jb) nx nu + c + nx jc] = G[(s-1) nx nu + c + goff]
+    }
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        mfma_acc tt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tt[t].v[0] = tt[t].v[1] = tt[t].v[2] = tt[t].v[3] = 0.0;
+        if (Mr) {
+            const int ra = r0 + col; // A operand: M(ra, k0 + kk)
+            const double* mrow = Mr + (size_t)(ra < R ? ra : 0) * X;
+            for (int k0 = 0; k0 < X; k0 += 4) {
+                const int k = k0 + kk;
+                const double a = (ra < R && k < X) ? mrow[k] : 0.0;
+                const int s = k / nx, c = k - s * nx; // row k of Psi = (step s, component c)
+                const int smax = (k0 + 3 < X ? k0 + 3 : X - 1) / nx; // wave-uniform: the last step this K-step touches
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    if (smax <= (16 * tj) / nu) continue; // the whole tile of Psi is zero (s <= jb for every column)
+                    const double b = (k < X && s > jbv[tj]) ? G[(s - 1) * nx * nu + c + goff[tj]] : 0.0;
+                    mfma_f64_16x16x4(a, b, tt[tj]);
                 }
-                if (Nr) v += Nr[(size_t)r * n + lane];
             }
-            y[u] = v;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (r0 + u < R) cj += We[r0 + u] * y[u]; // c += (resid' W) tmp, rows in ascending order
+        // tile -> LDS (+ N): element `reg` of tile tj is tmp(r0 + kk + 4 reg, 16 tj + col)
         wave_sync();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) stage[u * kWave + lane] = y[u];
-        wave_sync();
-        const double wk = (r0 + kk < R) ? w[r0 + kk] : 0.0;
-        double a[4];
+        for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = stage[kk * kWave + 16 * t + col]; // tmp(r0 + kk, 16 t + col)
-        int idx = 0;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = ti; tj < 4; ++tj) {
-                mfma_f64_16x16x4(a[ti] * wk, a[tj], acc[idx]); // (tmp' W) tmp
-                ++idx;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = r0 + kk + 4 * reg, j = 16 * tj + col;
+                double v = tt[tj].v[reg];
+                if (Nr && r < R && j < n) v += Nr[(size_t)r * n + j];
+                stage[(kk + 4 * reg) * kWave + j] = (r < R && j < n) ? v : 0.0;
             }
+        wave_sync();
+        // c += (resid' W) tmp, rows in ascending order (lane = column)
+        {
+            double g = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (r0 + i < R) g += We[r0 + i] * stage[i * kWave + lane];
+            cj += g;
+        }
+        // Q += (tmp' W) tmp : four K-steps of four rows
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int r = r0 + 4 * ks + kk;
+            const double wk = (r < R) ? w[r] : 0.0;
+            double a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = stage[(4 * ks + kk) * kWave + 16 * t + col]; // tmp(r, 16 t + col)
+            int idx = 0;
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < 4; ++tj) {
+                    mfma_f64_16x16x4(a[ti] * wk, a[tj], acc[idx]);
+                    ++idx;
+                }
+        }
     }
     wave_sync();
     int idx = 0;

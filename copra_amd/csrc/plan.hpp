@@ -93,7 +93,7 @@ struct LdsLayout {
     int BldY; // N blocks r x nu   (M G_k)
     int BldWe; // (N+1) blocks r    (w .* (M xbar_k - p))
     int BldCp; // parameters of the cost being processed: M (r x nx) | N (r x nu) | p (r) | w (r)
-    int BldFull; // full-size costs: weighted residuals (rfull) | 4 x 64 staging tile of Y rows for the MFMA operands
+    int BldFull; // full-size costs: weighted residuals (rfull) | 16 x 64 tile of tmp = M Psi + N for the MFMA operands
     int total; // total doubles
 };
 

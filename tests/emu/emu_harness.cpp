@@ -240,6 +240,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             lmpc_fused_body<6, 3, 20, 6>(PP, b);
         else if (s2)
             lmpc_fused_body<2, 1, 10, 2>(PP, b);
+        else if (use_specialised && PP.rfull > 0 && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // headline shape, full-size costs
+            lmpc_fused_body<6, 3, 20, 0>(PP, b);
         else
             lmpc_fused_body<0, 0, 0, 0>(PP, b);
     };
