@@ -313,7 +313,7 @@ struct StageRows {
 //     as Eigen evaluates it.
 // Round 1 formed tmp row by row on the VALU (0.83 M solves/s at the headline shape, the matrix cores 0.7 % busy).
 // ------------------------------------------------------------------------------------------------
-template <int NX_, int NU_, int NH_>
+template <int NX_, int NU_, int NH_, bool TRI_ = false>
 COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const double* p, const double* G,
     const double* Xbar, double* Q, int ld, double* scratch, double& cj)
 {
@@ -413,7 +413,7 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int i = 16 * ti + kk + 4 * reg, j = 16 * tj + col;
-                if (i < n && j < n) Q[i * ld + j] += acc[idx].v[reg];
+                if (i < n && j < n && (!TRI_ || i <= j)) Q[fidx<TRI_>(i, j, ld)] += acc[idx].v[reg]; // (factor-only: the packed upper triangle)
             }
             ++idx;
         }
@@ -563,10 +563,10 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
         const int blk = lane / nu, sub = lane - blk * nu; // lane as (block, component)
         for (int t = 0; t < P.ncost; ++t) {
             const CostTerm& ct = P.cost[t];
-            if constexpr (RP_ == 0 && !TRI_) { // plans with full-size entries always run the generic instantiation (plan.hpp)
+            if constexpr (RP_ == 0) { // plans with full-size entries run the instantiations without padded cost rows (plan.hpp)
                 if (ct.full) {
                     wave_sync();
-                    full_size_cost_term<NX_, NU_, NH_>(P, ct, cost_reference(P, t, inst), G, Xbar, Q, ld, lds + L.BldFull, cj);
+                    full_size_cost_term<NX_, NU_, NH_, TRI_>(P, ct, cost_reference(P, t, inst), G, Xbar, Q, ld, lds + L.BldFull, cj);
                     continue;
                 }
             }

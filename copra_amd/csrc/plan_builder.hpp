@@ -175,7 +175,7 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
     for (int k = kcur - 1; k >= 4; --k) {
         const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
         LdsLayout t {};
-        if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
+        if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, P.rfull, true, P.rows_direct != 0)
             && t.total <= budget && t.rcap > cur.rcap) {
             out = t;
             return true;
@@ -672,7 +672,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // variables 10.0 -> 19.0, 48: 10.1 -> 13.9, 64: 4.1 -> 9.8.  Up to 32 variables the packed kernels and the dense
         // square layouts already fill the wave slots, so those shapes stay as they are.
         const char* tmin = std::getenv("COPRA_TRI_MIN"); // (experiments: smallest number of variables that takes the tier)
-        if (U > (tmin ? std::atoi(tmin) : 32) && P.rfull == 0 && !std::getenv("COPRA_NO_TRI")) {
+        if (U > (tmin ? std::atoi(tmin) : 32) && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU
@@ -695,7 +695,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     P.lds = t;
                     break;
                 }
-                if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
+                if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, P.rfull, true, P.rows_direct != 0)
                     && t.total <= budget && t.rcap >= need) {
                     hp.lds_safe = P.lds; // what the adaptive fall-back steps to
                     hp.safe_two_tier = hp.two_tier;

@@ -234,6 +234,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)
             lmpc_fused_body<6, 3, 20, 6, true>(PP, b);
+        else if (PP.lds.tri && use_specialised && PP.rfull > 0 && PP.nx == 6 && PP.nu == 3 && PP.N == 20)
+            lmpc_fused_body<6, 3, 20, 0, true>(PP, b);
         else if (PP.lds.tri)
             lmpc_fused_body<0, 0, 0, 0, true>(PP, b);
         else if (s6)
