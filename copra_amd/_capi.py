@@ -262,6 +262,8 @@ def lib():
         L.copra_abi_version.restype = C.c_int
         L.copra_preview_update.restype = C.c_int
         L.copra_preview_update.argtypes = [C.c_int] * 3 + [vp] * 6
+        L.copra_batch_set_warm_start.restype = C.c_int
+        L.copra_batch_set_warm_start.argtypes = [vp, C.c_int]
         L.copra_batch_select_solver.restype = C.c_int
         L.copra_batch_select_solver.argtypes = [vp, C.c_int]
         L.copra_batch_solver_info.restype = C.c_int

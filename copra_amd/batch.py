@@ -155,6 +155,11 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_set_outputs(self._h, control.data_ptr(), trajectory.data_ptr(),
                                                       status.data_ptr(), iters.data_ptr()))
 
+    def set_warm_start(self, on=True):
+        """shared-model path: start every solve from the previous solve's active set, moved one step towards the present
+        (receding horizon); instances where that set is not dual feasible restart cold.  Same results either way."""
+        _capi.check(self._lib.copra_batch_set_warm_start(self._h, 1 if on else 0))
+
     SOLVERS = {"default": 0, "quadprog_dense": 1, "riccati_ipm": 2}
 
     def select_solver(self, solver):

@@ -333,6 +333,7 @@ struct copra_batch {
     int *d_row_step = nullptr, *d_row_ekind = nullptr, *d_row_eoff = nullptr, *d_row_gkind = nullptr,
         *d_row_goff = nullptr;
     double *d_row_f = nullptr, *d_params = nullptr, *d_lb = nullptr, *d_ub = nullptr;
+    int *d_row_prev = nullptr, *d_warm = nullptr; // warm start of the shared-model path (copra_batch_set_warm_start)
     // system (owned copies, or borrowed device pointers)
     double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
     const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
@@ -392,6 +393,8 @@ static FusedPlan device_plan(const copra_batch* h)
     P.row_gkind = h->d_row_gkind;
     P.row_goff = h->d_row_goff;
     P.row_f = h->d_row_f;
+    P.row_prev = h->d_row_prev;
+    P.warm_set = h->shared ? h->d_warm : nullptr;
     P.params = h->d_params;
     P.lb = h->d_lb;
     P.ub = h->d_ub;
@@ -614,6 +617,22 @@ copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, cons
     return COPRA_OK;
 }
 
+copra_status_t copra_batch_set_warm_start(copra_batch_t* h, int enable)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_warm_start: null handle");
+    if (h->hp.plan.initial_state || h->hp.large)
+        return fail(COPRA_ERR_UNSUPPORTED, "the warm start belongs to the shared-model path (LMPC, at most 64 decision variables)");
+    if (!enable) {
+        (void)hipFree(h->d_warm);
+        h->d_warm = nullptr;
+        return COPRA_OK;
+    }
+    const size_t count = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1) * kWarmCap;
+    if (!h->d_warm) HIP_TRY(hipMalloc((void**)&h->d_warm, count * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_warm, 0xff, count * sizeof(int))); // every entry -1: the first solve starts cold
+    return COPRA_OK;
+}
+
 copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_select_solver: null handle");
@@ -698,6 +717,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     chk(upload(&h->d_row_gkind, h->hp.row_gkind));
     chk(upload(&h->d_row_goff, h->hp.row_goff));
     chk(upload(&h->d_row_f, h->hp.row_f));
+    chk(upload(&h->d_row_prev, h->hp.row_prev));
     chk(upload(&h->d_params, h->hp.params));
     chk(upload(&h->d_lb, h->hp.lb));
     chk(upload(&h->d_ub, h->hp.ub));
@@ -744,6 +764,8 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_row_gkind);
     (void)hipFree(h->d_row_goff);
     (void)hipFree(h->d_row_f);
+    (void)hipFree(h->d_row_prev);
+    (void)hipFree(h->d_warm);
     (void)hipFree(h->d_params);
     (void)hipFree(h->d_lb);
     (void)hipFree(h->d_ub);

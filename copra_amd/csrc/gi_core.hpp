@@ -402,9 +402,16 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
 // QR > 0 (with TRI): the columns of Q1 live in REGISTERS -- every access to Q1 is lane-private (lane j holds row j of each
 // column), so QR columns cost 2 QR VGPRs per lane and no LDS: 320 doubles less per instance at QR = 5, which is what lets
 // an eighth instance share a CU at the headline shape (LdsLayout::q1regs).  S.rcap <= QR then.
+// Warm start (warm_list != nullptr; receding-horizon ticks of the shared-model path): the rows of warm_list -- the active
+// set of the previous tick, shifted by one step -- are the FIRST CANDIDATES of step 1.  The dual method may pick any violated
+// constraint (qpgen2 takes the most violated one, a heuristic), so while the list lasts the next candidate is simply its next
+// row that is violated at the current iterate: ONE slack evaluation instead of a scan over all rows, then the ordinary
+// iteration (dual blocking test, drops) -- every invariant of the method holds throughout, nothing is ever restarted.
+// After the list the ordinary scans take over and finish.  Same optimum as a cold start; the iterates differ.
 template <int NV, bool TRI = false, int QR = 0, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
-    int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false)
+    int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false, const int* warm_list = nullptr, int warm_n = 0,
+    int* nact_out = nullptr)
 {
     double q1r[QR > 0 ? QR : 1]; // this lane's element of every Q1 column (QR > 0)
 #pragma unroll
@@ -448,6 +455,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     const bool pinned = (ubj - lbj) <= 1e-12 * fmax(1.0, fabs(ubj)); // (an interval narrower than the noise counts as one)
     wave_sync();
 
+    int warm_i = 0; // next entry of warm_list
+    bool forced = false; // the current candidate comes from the warm list (no scan needed)
     for (;;) {
         if (iter_main >= max_iter) return 3;
         iter_main += 1;
@@ -456,6 +465,25 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         rows.begin_scan(S.xs);
         double best = 0.0, best_s = 0.0;
         int best_i = -1;
+        forced = false;
+        while (warm_list && warm_i < warm_n && best_i < 0) { // the next row of the warm list that is violated here
+            const int p = warm_list[warm_i++];
+            if (p < meq || p >= mtotal || S.act[p]) continue; // (equality rows are left to the ordinary scans)
+            double s;
+            if (p < mgen) {
+                s = rows.slack_uniform(p, S.xs);
+            } else {
+                const int q = p - mgen;
+                const double sl = (q < n) ? ubj - S.xs[lj] : S.xs[lj] - lbj;
+                s = bcast_f64(sl, (q < n) ? q : q - n);
+            }
+            if (fabs(s) < vsmall) s = 0.0;
+            if (!(s < 0.0)) continue; // satisfied at the current iterate: not a candidate
+            best_i = p;
+            best_s = s;
+            forced = true;
+        }
+        if (!forced) {
         for (int base = 0; base < mgen; base += kWave) { // general rows (equalities first)
             const int i = base + lane;
             if (i < mgen) {
@@ -500,9 +528,13 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         }
         if (iter_main <= 1) COPRA_FINE("as:bounds");
         wave_argmin(best, best_i, best_s);
+        } // (!forced)
         if (iter_main <= 2) COPRA_FINE("as:scan");
         const int nvl = best_i;
-        if (nvl < 0) return 0; // optimal
+        if (nvl < 0) { // optimal
+            if (nact_out) *nact_out = nact;
+            return 0;
+        }
         if (TRI && !have_J && S.Jsrc) { // shared model, factor-only: the batch-wide factor comes into LDS on first need
             wave_sync();
             for (int e = lane; e < n * (n + 1) / 2; e += kWave) S.J[e] = S.Jsrc[e];

@@ -65,6 +65,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
     // ---- unconstrained minimiser: x = -Qinv (c0 + C1 x0 + C2 p) is affine in (x0, p); the prepare step multiplied it
     //      out once for the batch (xu0, K1, K2: nx + R terms per lane instead of an n x n product; c itself is not
     //      needed any more -- the active-set loop works from x and the constraint rows) ----
+    auto unconstrained = [&]() {
     if (lane < n) {
         double acc = M[m.xu0 + lane];
 #pragma unroll
@@ -80,11 +81,45 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
         }
         S.xs[lane] = acc;
     }
+    };
+    unconstrained();
     wave_sync();
     int it_main = 0, it_drop = 0;
-    if (status == 0)
-        status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+    int* wset = P.warm_set ? P.warm_set + (size_t)inst * kWarmCap : nullptr; // previous tick's active set, shifted
+    int nact = 0;
+    if (status == 0) {
+        int wn = 0;
+        if (wset)
+            while (wn < kWarmCap && wset[wn] >= 0) ++wn;
+        status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS,
+            false, wn > 0 ? wset : nullptr, wn, &nact);
+    }
     wave_sync();
+    if (wset && status == 0) { // remember the active set, moved one step towards the present (step 0 rows leave)
+        for (int k = lane; k < kWarmCap; k += kWave) {
+            int nw = -1;
+            if (k < nact) {
+                const int idx = S.iact[k];
+                if (idx < P.mgen) {
+                    nw = P.row_prev[idx];
+                } else {
+                    const int q = idx - P.mgen, side = q / n, j = q - side * n;
+                    nw = (j >= nu) ? P.mgen + side * n + (j - nu) : -1;
+                }
+            }
+            wset[k] = nw;
+        }
+        // (gaps left by rows that moved out are closed by the reader: it stops at the first -1, so compact them)
+        wave_sync_full();
+        if (lane == 0) {
+            int w = 0;
+            for (int k = 0; k < kWarmCap; ++k) {
+                const int v = wset[k];
+                if (v >= 0) wset[w++] = v;
+            }
+            for (; w < kWarmCap; ++w) wset[w] = -1;
+        }
+    }
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch
         if (lane == 0) {
             const int slot = atomic_append(P.ovf_count);

@@ -18,6 +18,7 @@ namespace copra_hip {
 constexpr int kMaxCosts = 8;
 constexpr int kMaxFullRows = 16; // full-size constraint rows the workgroup-per-instance kernel evaluates cooperatively
 constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
+constexpr int kWarmCap = 32; // active rows remembered per instance for the warm start
 constexpr int kFusedQ1Regs = 5; // columns of Q1 the headline first-tier kernel keeps in registers (gi_core.hpp, QR)
 // lanes one instance works with: the 64-lane wavefront, or a 16-lane DPP row of it in the packed small-problem build
 // (copra_hip_packed.hip compiles the same kernel bodies with COPRA_WAVE_WIDTH = 16: four instances per wavefront)
@@ -245,6 +246,11 @@ struct FusedPlan {
     int model_rtot; // columns of C2 (and of K2, which follows it)
     double* model_out;
     const double* model;
+    // warm start of the shared-model path (copra_batch_set_warm_start): the active set each instance ended its previous
+    // solve with, already shifted by one step -- [batch][kWarmCap] row indices, -1 = none -- and for every general row the
+    // same row one step earlier (-1: none)
+    int* warm_set;
+    const int* row_prev;
     // more than 64 decision variables: workgroup-per-instance kernel, J / R in the per-workgroup HBM workspace `ws`
     int use_large;
     LargeLayout large;

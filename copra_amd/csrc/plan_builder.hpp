@@ -22,6 +22,7 @@ struct HostPlan {
     std::vector<double> params;
     std::vector<int> row_step, row_ekind, row_eoff, row_gkind, row_goff;
     std::vector<double> row_f;
+    std::vector<int> row_prev; // the same row one step earlier, -1: none (warm start of the receding-horizon path)
     std::vector<double> lb, ub;
     std::vector<double> isR, isr; // InitialStateLMPC: R (nx x nx), r (nx)
     std::string error;
@@ -512,6 +513,21 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         }
     }
     P.mgen = P.meq + P.mineq;
+    { // row i one step earlier: same coefficients, row_step - 1 (per-step entries only)
+        hp.row_prev.assign((size_t)(P.mgen > 0 ? P.mgen : 1), -1);
+        for (int i = 0; i < P.mgen; ++i) {
+            if (hp.row_ekind[(size_t)i] == kEFull || hp.row_gkind[(size_t)i] == kGFull) continue;
+            for (int j = i - 1; j >= 0; --j) // (rows of one constraint are stacked step-major: the match is close by)
+                if (hp.row_step[(size_t)j] == hp.row_step[(size_t)i] - 1 && hp.row_ekind[(size_t)j] == hp.row_ekind[(size_t)i]
+                    && hp.row_eoff[(size_t)j] == hp.row_eoff[(size_t)i] && hp.row_gkind[(size_t)j] == hp.row_gkind[(size_t)i]
+                    && hp.row_goff[(size_t)j] == hp.row_goff[(size_t)i] && (i < P.meq) == (j < P.meq)) {
+                    hp.row_prev[(size_t)i] = j;
+                    break;
+                }
+        }
+    }
+    P.warm_set = nullptr;
+    P.row_prev = nullptr;
     P.n_full_rows = 0;
     for (int i = 0; i < kMaxFullRows; ++i) P.full_row[i] = -1;
     for (int i = 0; i < P.mgen && P.n_full_rows >= 0; ++i) {
@@ -722,6 +738,7 @@ inline void point_plan_to_host(HostPlan& hp)
     P.row_gkind = hp.row_gkind.data();
     P.row_goff = hp.row_goff.data();
     P.row_f = hp.row_f.data();
+    P.row_prev = hp.row_prev.data();
     P.params = hp.params.data();
     P.lb = hp.lb.data();
     P.ub = hp.ub.data();

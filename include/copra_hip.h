@@ -220,6 +220,14 @@ typedef enum { COPRA_SOLVER_DEFAULT = 0, COPRA_SOLVER_QUADPROG_DENSE = 1, COPRA_
 copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver);
 int copra_batch_solver_info(const copra_batch_t* h);
 
+/* ---- warm start of the active set across receding-horizon ticks on the shared-model path: with
+ *      enable != 0 every instance remembers the active set it ended with, moved one step towards the present (the rows of
+ *      step 0 leave), and its next solve takes those rows as the first candidates of the dual active-set method: while the
+ *      list lasts, the next constraint to activate is the list's next row that is violated at the current iterate (one slack
+ *      evaluation instead of a scan over all rows; the method may pick ANY violated constraint, its invariants hold
+ *      throughout).  Same optimum and status as a cold start.  enable == 0 forgets the stored sets. ---- */
+copra_status_t copra_batch_set_warm_start(copra_batch_t* h, int enable);
+
 /* ---- optional: let the caller own the result buffers (device pointers, e.g. torch tensors that are later handed to
  *      an RCCL gather); must be called before copra_batch_solve and stay valid.  Sizes as in the results block. ---- */
 copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter);

@@ -321,7 +321,8 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
 // instance (compact layout first, overflow queue, full layout).  A, B, d: ONE system; x0: [batch][nx].
 int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
     const copra_cstr_desc_t* cstrs, const double* A, const double* B, const double* d, const double* x0,
-    double* control, double* trajectory, int* status, int* iter, int* sizes /* overflowed */)
+    double* control, double* trajectory, int* status, int* iter, int* sizes /* overflowed */,
+    int* warm_set /* [batch][kWarmCap], kept by the caller across ticks; nullptr: cold starts */)
 {
     HostPlan hp;
     copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, nullptr);
@@ -396,6 +397,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     P.model = model.data();
     P.model_rtot = 0;
     P.x0 = x0;
+    P.warm_set = warm_set;
     { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
         LdsLayout lq {};
         if (tri_layout_with_lds_q1(P, P.lds, lq)) {

@@ -157,8 +157,12 @@ def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_re
     return out
 
 
-def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs):
-    """shared-model fast path: ONE system (A, B, d), x0 of shape (batch, nx)"""
+WARM_CAP = 32  # plan.hpp::kWarmCap
+
+
+def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
+    """shared-model fast path: ONE system (A, B, d), x0 of shape (batch, nx).  warm: int32 array (batch, WARM_CAP) kept by
+    the caller across receding-horizon ticks (initialised to -1): the active set of the previous tick, shifted by one step"""
     A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
@@ -177,7 +181,8 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs):
     p = _capi.dptr
     rc = lib().emu_lmpc_solve_shared(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ac), p(Bc), p(dc), p(x0), p(u),
                                      p(tr), st.ctypes.data_as(C.POINTER(C.c_int)),
-                                     it.ctypes.data_as(C.POINTER(C.c_int)), sizes)
+                                     it.ctypes.data_as(C.POINTER(C.c_int)), sizes,
+                                     warm.ctypes.data_as(C.POINTER(C.c_int)) if warm is not None else C.c_void_p())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
     return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0])

@@ -605,3 +605,34 @@ def test_host_evaluated_user_pieces_dense_kinds(emu, oracle, N):
     assert re["status"][0] == ro["status"] == 0
     assert _rel(re["control"][0], ro["control"]) <= RTOL and np.abs(re["x0_opt"][0] - ro["x0_opt"]).max() <= 1e-9
     assert emu.lmpc_solve_riccati(*args, costs, cstrs) is None  # dense pieces couple all steps: not stage-wise
+
+
+def test_warm_start_across_receding_horizon_ticks(emu, oracle):
+    """copra_batch_set_warm_start (lmpc_shared.hpp + gi_core.hpp): the previous tick's active set, moved one step towards
+    the present, is activated first.  Same U / status as a cold start and as the oracle on every tick; fewer constraint
+    scans (iterations count forced activations + ONE closing scan instead of one scan per activation)"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.25, u_max=1.2, seed=4)
+    A, B, d = wl["A"][2], wl["B"][2], wl["d"][2]
+    x = wl["x0"].copy()
+    warm = np.full((6, emu.WARM_CAP), -1, dtype=np.int32)
+    rng = np.random.default_rng(0)
+    it_cold = it_warm = 0
+    reused = 0
+    for tick in range(6):
+        rw = emu.lmpc_solve_shared(A, B, d, x, wl["N"], wl["costs"], wl["cstrs"], warm=warm)
+        rc = emu.lmpc_solve_shared(A, B, d, x, wl["N"], wl["costs"], wl["cstrs"])
+        for k in range(6):
+            ro = oracle.lmpc_solve(A, B, d, x[k], wl["N"], wl["costs"], wl["cstrs"])
+            assert rw["status"][k] == rc["status"][k] == ro["status"]
+            if ro["status"] == 0:
+                assert _rel(rw["control"][k], ro["control"]) <= RTOL and _rel(rc["control"][k], ro["control"]) <= RTOL
+        ok = rw["status"] == 0
+        it_cold += int(rc["iter"][ok, 0].sum())
+        it_warm += int(rw["iter"][ok, 0].sum())
+        reused += int((warm >= 0).sum())
+        nxt = rw["trajectory"][:, 6:12].copy()
+        nxt[:, :3] += 0.002 * rng.standard_normal((6, 3))
+        x = np.where(ok[:, None], nxt, x)
+    assert reused > 0  # active sets were carried over ...
+    assert it_warm <= it_cold + 6 * 6  # ... and never cost more than the closing scan per solve

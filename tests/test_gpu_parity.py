@@ -1003,3 +1003,31 @@ def test_host_evaluated_user_pieces_dense_kinds_on_gpu(oracle, N):
             assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
     with pytest.raises(Exception):  # LMPC form without c
         BatchLMPC(2, 1, N, 1, [dict(kind="dense", Q=costs[0]["Q"], E=costs[0]["E"], f=costs[0]["f"])], [])
+
+
+def test_warm_start_over_25_receding_horizon_ticks(oracle):
+    """copra_batch_set_warm_start on the shared-model path, examples/receding_horizon.py for 25 ticks on the tight workload
+    (every instance has active constraints): on every tick a sample of instances equals the oracle (U, status) to 1e-6,
+    with and without the warm start; mean iterations / kernel time of both are printed by the example"""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("receding_horizon", os.path.join(sys_path, "receding_horizon.py"))
+    rh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rh)
+    stats = {}
+
+    def check(tick, wl, x, out):
+        xs = x.cpu().numpy()
+        u = out["control"].cpu().numpy()
+        st = out["status"].cpu().numpy()
+        for k in (0, 7, 100, 511):
+            ro = oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], xs[k], wl["N"], wl["costs"], wl["cstrs"])
+            assert st[k] == ro["status"], (tick, k)
+            if ro["status"] == 0:
+                assert _rel(u[k], ro["control"]) <= RTOL, (tick, k)
+
+    for warm in (False, True):
+        stats[warm] = rh.run(batch=512, ticks=25, warm=warm, v_max=0.25, u_max=1.2, noise=0.002, check=check)
+        assert stats[warm]["solved_last_tick"] >= 500
+    print("cold:", stats[False]["mean_iterations"], stats[False]["mean_kernel_ms"], "warm:", stats[True]["mean_iterations"],
+          stats[True]["mean_kernel_ms"])
