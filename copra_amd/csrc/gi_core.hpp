@@ -410,9 +410,10 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
 // After the list the ordinary scans take over and finish.  Same optimum as a cold start; the iterates differ.
 template <int NV, bool TRI = false, int QR = 0, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
-    int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false, const int* warm_list = nullptr, int warm_n = 0,
+    int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false, int warm_mine = -1, int warm_n = 0,
     int* nact_out = nullptr)
 {
+    // warm_mine: lane k holds entry k of the warm list (-1: none), warm_n entries in all (0: cold start)
     double q1r[QR > 0 ? QR : 1]; // this lane's element of every Q1 column (QR > 0)
 #pragma unroll
     for (int u = 0; u < (QR > 0 ? QR : 1); ++u) q1r[u] = 0.0;
@@ -466,9 +467,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
         double best = 0.0, best_s = 0.0;
         int best_i = -1;
         forced = false;
-        while (warm_list && warm_i < warm_n && best_i < 0) { // the next row of the warm list that is violated here
-            const int p = warm_list[warm_i++];
-            if (p < meq || p >= mtotal || S.act[p]) continue; // (equality rows are left to the ordinary scans)
+        while (warm_i < warm_n && best_i < 0) { // the next row of the warm list that is violated here
+            const int p = bcast_i32(warm_mine, warm_i++);
+            if (p < meq || p >= mtotal || S.act[p]) continue; // (gaps are -1; equality rows are left to the ordinary scans)
             double s;
             if (p < mgen) {
                 s = rows.slack_uniform(p, S.xs);

@@ -88,11 +88,9 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
     int* wset = P.warm_set ? P.warm_set + (size_t)inst * kWarmCap : nullptr; // previous tick's active set, shifted
     int nact = 0;
     if (status == 0) {
-        int wn = 0;
-        if (wset)
-            while (wn < kWarmCap && wset[wn] >= 0) ++wn;
+        const int wmine = (wset && lane < kWarmCap) ? wset[lane] : -1; // one coalesced load; read back with v_readlane
         status = gi_active_set<NV, TRI_>(S, n, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS,
-            false, wn > 0 ? wset : nullptr, wn, &nact);
+            false, wmine, wset ? kWarmCap : 0, &nact);
     }
     wave_sync();
     if (wset && status == 0) { // remember the active set, moved one step towards the present (step 0 rows leave)
@@ -107,17 +105,7 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
                     nw = (j >= nu) ? P.mgen + side * n + (j - nu) : -1;
                 }
             }
-            wset[k] = nw;
-        }
-        // (gaps left by rows that moved out are closed by the reader: it stops at the first -1, so compact them)
-        wave_sync_full();
-        if (lane == 0) {
-            int w = 0;
-            for (int k = 0; k < kWarmCap; ++k) {
-                const int v = wset[k];
-                if (v >= 0) wset[w++] = v;
-            }
-            for (; w < kWarmCap; ++w) wset[w] = -1;
+            wset[k] = nw; // (rows that moved out of the horizon leave -1 gaps: the reader skips them)
         }
     }
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch
