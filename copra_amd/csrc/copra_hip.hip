@@ -543,6 +543,10 @@ static copra_status_t prepare_riccati(copra_batch* h)
     sp.r_sidx = upi(hs.r_sidx);
     sp.r_sstride = upi(hs.r_sstride);
     sp.blob = upd(hs.blob);
+    sp.iblob = upi(hs.iblob);
+    sp.cls_rptr = upi(hs.cls_rptr), sp.cls_rcol = upi(hs.cls_rcol), sp.cls_gptr = upi(hs.cls_gptr), sp.cls_grow = upi(hs.cls_grow);
+    sp.cls_eptr = upi(hs.cls_eptr), sp.cls_erow = upi(hs.cls_erow);
+    sp.cls_rval = upi(hs.cls_rval), sp.cls_gval = upi(hs.cls_gval), sp.cls_eval = upi(hs.cls_eval);
     // persistent grid: as many one-wave workgroups as the device keeps resident
     const size_t lds_bytes = (size_t)sp.lds_doubles * sizeof(double);
     const void* ric_fn = reinterpret_cast<const void*>(select_riccati_kernel(sp.nx, sp.nu));

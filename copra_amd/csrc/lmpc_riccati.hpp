@@ -37,8 +37,9 @@ namespace copra_hip {
 
 struct RicLds {
     double *AB, *Pm, *T, *M, *pv, *h, *g, *zk, *dzk, *dxn, *dv, *Kl, *Mi, *rowD, *rowC;
-    double *Wc, *Ad, *Us; // tables of the current stage class: W, dense row coefficients (row-major), unit-row signs
-    int* Uc; // ... and unit-row components
+    // tables of the current stage class: W and the three sparse views of its rows (stage_plan.hpp)
+    double *Wc, *rval, *gval, *eval;
+    int *rptr, *rcol, *gptr, *grow, *eptr, *erow;
 };
 
 COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S, int nx, int nu)
@@ -63,10 +64,18 @@ COPRA_DEV RicLds carve_riccati(double* lds, const StagePlan& S, int nx, int nu)
     const int mr = S.max_stage_rows > 0 ? S.max_stage_rows : 1;
     L.rowD = p, p += a2(mr);
     L.rowC = p, p += a2(mr);
+    const int nn = S.max_nnz > 0 ? S.max_nnz : 1, ne = S.max_nnze > 0 ? S.max_nnze : 1;
     L.Wc = p, p += a2(nz * nz);
-    L.Ad = p, p += a2((S.max_dense > 0 ? S.max_dense : 1) * nz);
-    L.Us = p, p += a2(mr);
-    L.Uc = reinterpret_cast<int*>(p), p += a2((mr + 1) / 2);
+    L.rval = p, p += a2(nn);
+    L.gval = p, p += a2(nn);
+    L.eval = p, p += a2(ne);
+    int* q = reinterpret_cast<int*>(p);
+    L.rptr = q, q += mr + 1;
+    L.rcol = q, q += nn;
+    L.gptr = q, q += nz + 1;
+    L.grow = q, q += nn;
+    L.eptr = q, q += nz * nz + 1;
+    L.erow = q, q += ne;
     return L;
 }
 
@@ -166,25 +175,30 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         auto load_class = [&](int c) {
             if (c == cur_cls) return;
             cur_cls = c;
-            const int r0 = S.cls_row0[c], nr = S.cls_row0[c + 1] - r0, nd = S.cls_ndense[c];
+            const int nr = S.cls_row0[c + 1] - S.cls_row0[c];
+            const int* ib = S.iblob;
             wave_sync(); // (readers of the previous class's tables are done)
             for (int e = lane; e < nz * nz; e += kWave) L.Wc[e] = blob[S.cls_W[c] + e];
-            for (int e = lane; e < nd * nz; e += kWave) {
-                const int r = e / nz, j = e - r * nz;
-                L.Ad[e] = blob[S.r_aoff[r0 + r] + j];
+            for (int e = lane; e <= nr; e += kWave) L.rptr[e] = ib[S.cls_rptr[c] + e];
+            for (int e = lane; e <= nz; e += kWave) L.gptr[e] = ib[S.cls_gptr[c] + e];
+            for (int e = lane; e <= nz * nz; e += kWave) L.eptr[e] = ib[S.cls_eptr[c] + e];
+            const int nnz = ib[S.cls_rptr[c] + nr], nnze = ib[S.cls_eptr[c] + nz * nz];
+            for (int e = lane; e < nnz; e += kWave) {
+                L.rcol[e] = ib[S.cls_rcol[c] + e];
+                L.rval[e] = blob[S.cls_rval[c] + e];
+                L.grow[e] = ib[S.cls_grow[c] + e];
+                L.gval[e] = blob[S.cls_gval[c] + e];
             }
-            for (int r = nd + lane; r < nr; r += kWave) {
-                L.Uc[r] = S.r_aoff[r0 + r];
-                L.Us[r] = S.r_sign[r0 + r];
+            for (int e = lane; e < nnze; e += kWave) {
+                L.erow[e] = ib[S.cls_erow[c] + e];
+                L.eval[e] = blob[S.cls_eval[c] + e];
             }
             wave_sync();
         };
-        // a_r' v for row r of the CURRENT class (v: nz values in LDS)
-        auto row_dot = [&](int r, int nd, const double* v) -> double {
-            if (r >= nd) return L.Us[r] * v[L.Uc[r]];
-            const double* a = L.Ad + r * nz;
+        // a_r' v for row r of the CURRENT class (v: nz values in LDS); bound rows have one term, mixed rows two
+        auto row_dot = [&](int r, int, const double* v) -> double {
             double acc = 0.0;
-            for (int j = 0; j < nz; ++j) acc += a[j] * v[j];
+            for (int q = L.rptr[r]; q < L.rptr[r + 1]; ++q) acc += L.rval[q] * v[L.rcol[q]];
             return acc;
         };
         // x_{k+1} = A x_k + B u_k + d along Z (the controls as stored in Z), from the x_0 stored in Z[0..nx)
@@ -209,7 +223,6 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         // gradient coefficients of the stage's rows, Pm / pv the cost-to-go of stage k + 1.  After: Pm / pv of stage k;
         // K, Muu^-1, kv stored for the forward sweeps.  Returns false when Muu is not positive definite.
         auto stage_gradient = [&](int k, bool with_rows, bool store_gb) {
-            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c];
             const double* Wk = L.Wc;
             for (int i = lane; i < nz; i += kWave) {
                 double gb;
@@ -224,27 +237,18 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 } else {
                     gb = GB[k * nz + i];
                 }
-                if (with_rows) {
-                    for (int r = 0; r < nd; ++r) gb += L.rowC[r] * L.Ad[r * nz + i];
-                    for (int r = nd; r < nr; ++r)
-                        if (L.Uc[r] == i) gb += L.Us[r] * L.rowC[r];
-                }
+                if (with_rows)
+                    for (int q = L.gptr[i]; q < L.gptr[i + 1]; ++q) gb += L.gval[q] * L.rowC[L.grow[q]];
                 L.g[i] = gb;
             }
         };
         auto stage_factor = [&](int k, bool with_rows) -> bool {
-            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c];
             const double* Wk = L.Wc;
             // H = W + sum D a a'
-            for (int e = lane; e < nz * nz; e += kWave) {
-                const int j = e / nz, i = e - j * nz;
+            for (int e = lane; e < nz * nz; e += kWave) { // entry e = i + nz j
                 double acc = Wk[e];
-                if (with_rows) {
-                    for (int r = 0; r < nd; ++r) acc += L.rowD[r] * L.Ad[r * nz + i] * L.Ad[r * nz + j];
-                    if (i == j)
-                        for (int r = nd; r < nr; ++r)
-                            if (L.Uc[r] == i) acc += L.rowD[r];
-                }
+                if (with_rows)
+                    for (int q = L.eptr[e]; q < L.eptr[e + 1]; ++q) acc += L.eval[q] * L.rowD[L.erow[q]];
                 L.M[e] = acc;
             }
             if (k == N) { // P_N = Hxx, p_N = g_x
@@ -278,6 +282,57 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 L.h[a] = acc;
             }
             wave_sync();
+            bool ok = true;
+            if constexpr (NUT > 0) {
+                // Muu^-1 from a Cholesky factor held in registers: every lane factorises the nu x nu block redundantly
+                // (NUT (NUT + 1) / 2 broadcast LDS reads, no round trips through LDS in between), then lane c solves for
+                // column c of the inverse
+                double Lc[NUT][NUT];
+#pragma unroll
+                for (int i = 0; i < NUT; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Lc[i][j] = L.M[(nx + i) + nz * (nx + j)];
+#pragma unroll
+                for (int j = 0; j < NUT; ++j) {
+                    double dg = Lc[j][j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) dg -= Lc[j][t] * Lc[j][t];
+                    if (!(dg > 0.0)) ok = false;
+                    const double inv = 1.0 / sqrt(dg);
+                    Lc[j][j] = inv; // (the diagonal holds 1 / L_jj)
+#pragma unroll
+                    for (int i = j + 1; i < NUT; ++i) {
+                        double v = Lc[i][j];
+#pragma unroll
+                        for (int t = 0; t < j; ++t) v -= Lc[i][t] * Lc[j][t];
+                        Lc[i][j] = v * inv;
+                    }
+                }
+                const int cc = lane % NUT;
+                double y[NUT];
+#pragma unroll
+                for (int i = 0; i < NUT; ++i) { // L y = e_cc
+                    double v = (i == cc) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int t = 0; t < i; ++t) v -= Lc[i][t] * y[t];
+                    y[i] = v * Lc[i][i];
+                }
+#pragma unroll
+                for (int i = NUT - 1; i >= 0; --i) { // L' x = y
+                    double v = y[i];
+#pragma unroll
+                    for (int t = i + 1; t < NUT; ++t) v -= Lc[t][i] * y[t];
+                    y[i] = v * Lc[i][i];
+                }
+                if (lane < NUT) {
+#pragma unroll
+                    for (int i = 0; i < NUT; ++i) {
+                        L.Mi[i + NUT * lane] = y[i];
+                        Mig[(size_t)k * nu * nu + i + NUT * lane] = y[i];
+                    }
+                }
+                wave_sync();
+            } else {
             // Muu^-1 by Gauss-Jordan on [Muu | I] (Muu is symmetric positive definite: no pivoting); Kl is the scratch
             // (nu x 2 nu <= nu x nx is not guaranteed: use T, which is free again)
             double* GJ = L.T; // nu x 2nu, row-major with leading dimension 2 nu
@@ -287,7 +342,6 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 GJ[e] = (cc < nu) ? L.M[(nx + r) + nz * (nx + cc)] : ((cc - nu == r) ? 1.0 : 0.0);
             }
             wave_sync();
-            bool ok = true;
             for (int p = 0; p < nu; ++p) {
                 const double piv = GJ[p * w2 + p];
                 if (!(piv > 0.0)) ok = false;
@@ -317,6 +371,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 Mig[(size_t)k * nu * nu + e] = v;
             }
             wave_sync();
+            }
             // K = -Muu^-1 Mux (nu x nx), kv = -Muu^-1 hu
             for (int e = lane; e < nu * nx; e += kWave) {
                 const int j = e / nu, i = e - j * nu;

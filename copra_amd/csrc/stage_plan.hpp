@@ -36,6 +36,8 @@ namespace copra_hip {
 constexpr int kRicMaxNz = 32; // xDim + uDim the Riccati kernel covers
 constexpr int kRicMaxEq = 32; // equality rows (proximal multiplier iteration)
 constexpr int kRicMaxStageRows = 192; // rows of one stage (LDS staging of their weights)
+constexpr int kRicMaxNnz = 512; // non-zero coefficients of the rows of one stage ...
+constexpr int kRicMaxNnzE = 1024; // ... and non-zero products a_i a_j over all its rows (LDS tables of the kernel)
 
 // where the right-hand side of a constraint row comes from (per instance when the caller set per-instance data)
 enum { kSrcRowF = 0, kSrcUb = 1, kSrcNegLb = 2, kSrcX0Ub = 3, kSrcNegX0Lb = 4 };
@@ -69,6 +71,15 @@ struct StagePlan {
     const int* r_sidx; // index into the source array ...
     const int* r_sstride; // ... + r_sstride * step
     const double* blob;
+    // the rows of a stage class as a sparse matrix A (rows x nz), three ways (offsets into iblob / blob per class):
+    //   by row     : a_r' v          = sum_{q in [rptr[r], rptr[r+1])} rval[q] v[rcol[q]]
+    //   by column  : (A' c)_i        = sum_{q in [gptr[i], gptr[i+1])} gval[q] c[grow[q]]
+    //   by entry   : (A' D A)_(i,j)  = sum_{q in [eptr[e], eptr[e+1])} eval[q] D[erow[q]],  e = i + nz j, eval = a_i a_j
+    // bound rows have one coefficient, the reference's mixed rows two: the loops over them have 0 - 3 iterations
+    const int* iblob;
+    const int *cls_rptr, *cls_rcol, *cls_gptr, *cls_grow, *cls_eptr, *cls_erow; // [ncls] offsets into iblob
+    const int *cls_rval, *cls_gval, *cls_eval; // [ncls] offsets into blob
+    int max_nnz, max_nnze;
     // per-resident-wave workspace
     double* ws;
     long long ws_total; // doubles per wave
@@ -89,6 +100,7 @@ struct HostStagePlan {
     std::vector<int> r_kind, r_aoff, r_eq, r_src, r_sidx, r_sstride;
     std::vector<double> r_sign;
     std::vector<double> blob;
+    std::vector<int> iblob, cls_rptr, cls_rcol, cls_gptr, cls_grow, cls_eptr, cls_erow, cls_rval, cls_gval, cls_eval;
     bool all_bounds = false; // bound rows for every control (per-instance bounds may make any of them finite)
 };
 
@@ -301,7 +313,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
         if (out.blob.size() & 1) out.blob.push_back(0.0);
         return at;
     };
-    int max_rows = 0, max_dense = 0;
+    int max_rows = 0, max_dense = 0, max_nnz = 0, max_nnze = 0;
     out.cls_crow0.push_back(0);
     out.cls_row0.push_back(0);
     for (int c = 0; c < ncls; ++c) {
@@ -339,7 +351,48 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
         }
         if ((int)S.rows.size() > max_rows) max_rows = (int)S.rows.size();
         if (out.cls_ndense.back() > max_dense) max_dense = out.cls_ndense.back();
+        { // the three sparse views of the class's rows
+            const int nr = (int)S.rows.size();
+            std::vector<std::vector<std::pair<int, double>>> byrow((size_t)nr), bycol((size_t)nz);
+            std::vector<std::vector<std::pair<int, double>>> byent((size_t)nz * nz);
+            for (int r = 0; r < nr; ++r) {
+                const Row& R = S.rows[(size_t)r];
+                for (int j = 0; j < nz; ++j) {
+                    const double v = R.kind == 0 ? R.a[(size_t)j] : (j == R.comp ? R.sign : 0.0);
+                    if (v == 0.0) continue;
+                    byrow[(size_t)r].push_back({ j, v });
+                    bycol[(size_t)j].push_back({ r, v });
+                }
+                for (auto& a : byrow[(size_t)r])
+                    for (auto& b : byrow[(size_t)r]) byent[(size_t)a.first + (size_t)nz * b.first].push_back({ r, a.second * b.second });
+            }
+            auto emit = [&](const std::vector<std::vector<std::pair<int, double>>>& lists, std::vector<int>& cptr,
+                            std::vector<int>& cidx, std::vector<int>& cval) {
+                cptr.push_back((int)out.iblob.size());
+                int run = 0;
+                for (auto& l : lists) {
+                    out.iblob.push_back(run);
+                    run += (int)l.size();
+                }
+                out.iblob.push_back(run);
+                cidx.push_back((int)out.iblob.size());
+                cval.push_back((int)out.blob.size());
+                for (auto& l : lists)
+                    for (auto& e : l) {
+                        out.iblob.push_back(e.first);
+                        out.blob.push_back(e.second);
+                    }
+                if (out.blob.size() & 1) out.blob.push_back(0.0);
+                return run;
+            };
+            const int nnz = emit(byrow, out.cls_rptr, out.cls_rcol, out.cls_rval);
+            emit(bycol, out.cls_gptr, out.cls_grow, out.cls_gval);
+            const int nnze = emit(byent, out.cls_eptr, out.cls_erow, out.cls_eval);
+            if (nnz > max_nnz) max_nnz = nnz;
+            if (nnze > max_nnze) max_nnze = nnze;
+        }
     }
+    if (max_nnz > kRicMaxNnz || max_nnze > kRicMaxNnzE) return no("the rows of one stage are too dense for the kernel's LDS tables");
     if (max_rows > kRicMaxStageRows) return no("too many constraint rows in one stage");
     out.stage_row0.assign((size_t)N + 2, 0);
     for (int k = 0; k <= N; ++k)
@@ -350,6 +403,8 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.ncls = ncls;
     sp.max_stage_rows = max_rows;
     sp.max_dense = max_dense;
+    sp.max_nnz = max_nnz;
+    sp.max_nnze = max_nnze;
     sp.x0_free = P.initial_state;
     sp.max_iter = 60;
     sp.delta = 1e-9;
@@ -367,9 +422,13 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.oH0 = take((long long)nx * nx), sp.oG0 = take(nx);
     sp.ws_total = o;
     // LDS of one wave (doubles): AB | P | T | M | pv, h, g, zk, dzk, dxn, d | K | Mi | row weights / coefficients
-    sp.lds_doubles = align2(nx * nz) + align2(nx * nx) + align2(nx * nz > 2 * nu * nu ? nx * nz : 2 * nu * nu) + align2(nz * nz)
-        + 7 * align2(nz) + align2(nu * nx) + align2(nu * nu) + 3 * align2(max_rows > 0 ? max_rows : 1)
-        + align2(((max_rows > 0 ? max_rows : 1) + 1) / 2) + align2(nz * nz) + align2((max_dense > 0 ? max_dense : 1) * nz) + 2; // == carve_riccati
+    {
+        const int mr = max_rows > 0 ? max_rows : 1, nn = max_nnz > 0 ? max_nnz : 1, ne = max_nnze > 0 ? max_nnze : 1;
+        const int ints = (mr + 1) + nn + (nz + 1) + nn + (nz * nz + 1) + ne; // rptr rcol gptr grow eptr erow
+        sp.lds_doubles = align2(nx * nz) + align2(nx * nx) + align2(nx * nz > 2 * nu * nu ? nx * nz : 2 * nu * nu) + align2(nz * nz)
+            + 7 * align2(nz) + align2(nu * nx) + align2(nu * nu) + 2 * align2(mr) + align2(nz * nz) + 2 * align2(nn) + align2(ne)
+            + align2((ints + 1) / 2) + 2;
+    } // == carve_riccati
     out.eligible = true;
 }
 
@@ -394,6 +453,10 @@ inline void point_stage_plan_to_host(HostStagePlan& h)
     sp.r_sidx = h.r_sidx.data();
     sp.r_sstride = h.r_sstride.data();
     sp.blob = h.blob.data();
+    sp.iblob = h.iblob.data();
+    sp.cls_rptr = h.cls_rptr.data(), sp.cls_rcol = h.cls_rcol.data(), sp.cls_gptr = h.cls_gptr.data(), sp.cls_grow = h.cls_grow.data();
+    sp.cls_eptr = h.cls_eptr.data(), sp.cls_erow = h.cls_erow.data();
+    sp.cls_rval = h.cls_rval.data(), sp.cls_gval = h.cls_gval.data(), sp.cls_eval = h.cls_eval.data();
 }
 
 } // namespace copra_hip
