@@ -375,6 +375,7 @@ struct copra_batch {
     bool ric_all_bounds = false; // ... with bound rows for every control
     std::vector<void*> ric_dev; // device copies of its tables
     double* d_ric_ws = nullptr;
+    int* d_ric_next = nullptr; // work-queue counter of the Riccati kernel
     int ric_grid = 0;
     long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
@@ -567,6 +568,8 @@ static copra_status_t prepare_riccati(copra_batch* h)
     h->ric_grid = (int)(g < batch ? g : batch);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (size_t)sp.ws_total * sizeof(double));
     sp.ws = h->d_ric_ws;
+    if (e == hipSuccess && !h->d_ric_next) e = hipMalloc((void**)&h->d_ric_next, sizeof(int));
+    sp.next_instance = h->d_ric_next;
     if (std::getenv("COPRA_DEBUG"))
         fprintf(stderr, "[copra] riccati path: %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n", sp.ncls,
             sp.m, h->ric_grid, per_cu, lds_bytes, sp.ws_total * 8LL);
@@ -795,6 +798,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_ws);
     for (void* q : h->ric_dev) (void)hipFree(q);
     (void)hipFree(h->d_ric_ws);
+    (void)hipFree(h->d_ric_next);
     (void)hipFree(h->d_shA);
     (void)hipFree(h->d_shB);
     (void)hipFree(h->d_shd);
@@ -1362,6 +1366,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
             const size_t ric_lds = (size_t)h->hs.sp.lds_doubles * sizeof(double);
             HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
+            HIP_TRY(hipMemsetAsync(h->d_ric_next, 0, sizeof(int), s));
             const riccati_kernel_t ric_fn = select_riccati_kernel(P.nx, P.nu);
             LDS_OPT_IN(ric_fn, ric_lds);
             hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);

@@ -101,7 +101,16 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
     const double delta = S.delta;
     const double BIGF = 1e299;
 
-    for (int inst = instance_id(); inst < P.batch; inst += instance_stride()) {
+    for (int witem = instance_id();; witem += instance_stride()) {
+        // the batch is a queue: a wave that finishes early (fewer Newton steps) takes the next instance (S.next_instance
+        // counts them; without it each wave walks its own arithmetic progression)
+        int inst = witem;
+        if (S.next_instance) {
+            int v = 0;
+            if (lane == 0) v = atomic_append(S.next_instance);
+            inst = bcast_i32(v, 0);
+        }
+        if (inst >= P.batch) break;
         // optional phase profile (copra_batch_phase_profile): set-up | sweep 1 rows | sweep 1 gradient | sweep 1 factor |
         // forward sweeps | sweep 3 | update + results | total, shader-clock cycles of this instance
         long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -510,6 +519,78 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         for (it = 1; it <= S.max_iter && good; ++it) {
             // ---- sweep 1 (backward): residuals, barrier weights, factorisation, predictor right-hand side
             double musum = 0.0, maxr = 0.0;
+            bool done1 = false;
+            if constexpr (NXT > 0 && NUT > 0) {
+                if (S.max_stage_rows <= kWave) { // operands of stage k - 1 requested before stage k is computed (see sweep 3)
+                    struct Regs1 {
+                        int fl;
+                        double f, sv, lv, z, q;
+                    };
+                    auto issue1 = [&](int k, Regs1& R) {
+                        const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi = S.stage_row0[k] + lane;
+                        R.fl = kRowOff;
+                        R.f = R.sv = R.lv = R.z = R.q = 0.0;
+                        if (lane < nr) {
+                            R.fl = (int)Flag[gi];
+                            R.f = F[gi], R.sv = Sv[gi], R.lv = Lam[gi];
+                        }
+                        if (lane < nz) R.z = Z[k * nz + lane], R.q = Q[k * nz + lane];
+                    };
+                    Regs1 cur, nxt;
+                    issue1(N, cur);
+                    for (int k = N; k >= 0; --k) {
+                        if (k > 0) issue1(k - 1, nxt);
+                        load_class(S.cls_of_stage[k]);
+                        if (lane < nz) L.zk[lane] = cur.z;
+                        wave_sync();
+                        {
+                            double Dv = 0.0, Cv = 0.0;
+                            if (cur.fl != kRowOff) {
+                                const int gi = S.stage_row0[k] + lane;
+                                const double az = row_dot(lane, 0, L.zk);
+                                if (cur.fl == kRowEq) {
+                                    const double re = az - cur.f;
+                                    Dv = 1.0 / delta;
+                                    Cv = cur.lv + re / delta;
+                                    RP[gi] = re;
+                                } else {
+                                    const double rp = az + cur.sv - cur.f;
+                                    Dv = cur.lv / cur.sv;
+                                    Cv = Dv * rp;
+                                    RP[gi] = rp;
+                                    maxr = fmax(maxr, fabs(rp));
+                                    musum += cur.sv * cur.lv;
+                                }
+                            }
+                            if (lane < S.max_stage_rows) {
+                                L.rowD[lane] = Dv;
+                                L.rowC[lane] = Cv;
+                            }
+                        }
+                        wave_sync();
+                        stamp(1);
+                        if (lane < nz) { // g = W z + q (+ the InitialStateLMPC terms at stage 0) + A' c
+                            double gb = cur.q;
+#pragma unroll
+                            for (int j = 0; j < NXT + NUT; ++j) gb += L.Wc[lane + nz * j] * L.zk[j];
+                            if (k == 0 && x0_free && lane < nx) {
+                                gb += G0[lane];
+                                for (int j = 0; j < nx; ++j) gb += H0[lane + nx * j] * L.zk[j];
+                            }
+                            GB[k * nz + lane] = gb;
+                            for (int q = L.gptr[lane]; q < L.gptr[lane + 1]; ++q) gb += L.gval[q] * L.rowC[L.grow[q]];
+                            L.g[lane] = gb;
+                        }
+                        wave_sync();
+                        stamp(2);
+                        good = stage_factor(k, true) && good;
+                        stamp(3);
+                        cur = nxt;
+                    }
+                    done1 = true;
+                }
+            }
+            if (!done1)
             for (int k = N; k >= 0; --k) {
                 const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
                 load_class(c);
@@ -555,6 +636,82 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             double alpha = 1.0, sigma_mu = 0.0, step_inf = 0.0, z_inf = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 if (pass == 1) { // ---- sweep 3 (backward): corrector right-hand side through the stored factors
+                    bool done3 = false;
+                    if constexpr (NXT > 0 && NUT > 0) {
+                        if (S.max_stage_rows <= kWave) {
+                            // compile-time shape, at most one row per lane: every operand of stage k - 1 is requested from
+                            // the workspace BEFORE stage k is computed, so its HBM / L2 round trip runs underneath
+                            struct Regs3 {
+                                int fl;
+                                double sv, lv, rp, ds, dl, gb, mi[NUT], kc[NUT];
+                            };
+                            auto issue3 = [&](int k, Regs3& R) {
+                                const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi = S.stage_row0[k] + lane;
+                                R.fl = kRowOff;
+                                if (lane < nr) {
+                                    R.fl = (int)Flag[gi];
+                                    R.sv = Sv[gi], R.lv = Lam[gi], R.rp = RP[gi], R.ds = DS[gi], R.dl = DL[gi];
+                                }
+                                if (lane < nz) R.gb = GB[k * nz + lane];
+                                if (k < N) {
+#pragma unroll
+                                    for (int l = 0; l < NUT; ++l) {
+                                        if (lane < nu) R.mi[l] = Mig[(size_t)k * nu * nu + lane + nu * l];
+                                        if (lane < nx) R.kc[l] = Kg[(size_t)k * nu * nx + l + nu * lane];
+                                    }
+                                }
+                            };
+                            Regs3 cur, nxt;
+                            issue3(N, cur);
+                            for (int k = N; k >= 0; --k) {
+                                if (k > 0) issue3(k - 1, nxt);
+                                load_class(S.cls_of_stage[k]);
+                                {
+                                    double Cv = 0.0;
+                                    if (cur.fl == kRowEq)
+                                        Cv = cur.lv + cur.rp / delta;
+                                    else if (cur.fl == kRowIneq)
+                                        Cv = (sigma_mu - cur.ds * cur.dl) / cur.sv + (cur.lv / cur.sv) * cur.rp;
+                                    if (lane < S.max_stage_rows) L.rowC[lane] = Cv;
+                                }
+                                wave_sync();
+                                if (lane < nz) {
+                                    double gb = cur.gb;
+                                    for (int q = L.gptr[lane]; q < L.gptr[lane + 1]; ++q) gb += L.gval[q] * L.rowC[L.grow[q]];
+                                    L.g[lane] = gb;
+                                }
+                                wave_sync();
+                                if (k == N) {
+                                    if (lane < nx) L.pv[lane] = L.g[lane];
+                                } else {
+                                    if (lane < nz) { // h = g + [A B]' p
+                                        double acc = L.g[lane];
+#pragma unroll
+                                        for (int l = 0; l < NXT; ++l) acc += L.AB[l + nx * lane] * L.pv[l];
+                                        L.h[lane] = acc;
+                                    }
+                                    wave_sync();
+                                    double kvv = 0.0, pn = 0.0;
+                                    if (lane < nu) { // kv = -Muu^-1 hu
+#pragma unroll
+                                        for (int l = 0; l < NUT; ++l) kvv += cur.mi[l] * L.h[nx + l];
+                                        Kvg[(size_t)k * nu + lane] = -kvv;
+                                    }
+                                    if (lane < nx) { // p = hx + K' hu
+                                        pn = L.h[lane];
+#pragma unroll
+                                        for (int l = 0; l < NUT; ++l) pn += cur.kc[l] * L.h[nx + l];
+                                    }
+                                    wave_sync();
+                                    if (lane < nx) L.pv[lane] = pn;
+                                }
+                                wave_sync();
+                                cur = nxt;
+                            }
+                            done3 = true;
+                        }
+                    }
+                    if (!done3)
                     for (int k = N; k >= 0; --k) {
                         const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi0 = S.stage_row0[k];
                         load_class(c);
@@ -610,7 +767,77 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 }
                 double amin = 1.0e300;
                 step_inf = 0.0;
-                z_inf = 0.0;
+                bool donef = false;
+                if constexpr (NXT > 0 && NUT > 0) {
+                    if (S.max_stage_rows <= kWave) {
+                        struct RegsF {
+                            int fl;
+                            double sv, lv, rp, ds, dl, kv, kc[NXT];
+                        };
+                        auto issuef = [&](int k, RegsF& R) {
+                            const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi = S.stage_row0[k] + lane;
+                            R.fl = kRowOff;
+                            if (lane < nr) {
+                                R.fl = (int)Flag[gi];
+                                R.sv = Sv[gi], R.lv = Lam[gi], R.rp = RP[gi], R.ds = DS[gi], R.dl = DL[gi];
+                            }
+                            if (k < N && lane < nu) {
+                                R.kv = Kvg[(size_t)k * nu + lane];
+#pragma unroll
+                                for (int j = 0; j < NXT; ++j) R.kc[j] = Kg[(size_t)k * nu * nx + lane + nu * j];
+                            }
+                        };
+                        RegsF cur, nxt;
+                        issuef(0, cur);
+                        for (int k = 0; k <= N; ++k) {
+                            if (k < N) issuef(k + 1, nxt);
+                            load_class(S.cls_of_stage[k]);
+                            if (lane < nu) { // du = K dx + kv
+                                double acc = 0.0;
+                                if (k < N) {
+                                    acc = cur.kv;
+#pragma unroll
+                                    for (int j = 0; j < NXT; ++j) acc += cur.kc[j] * L.dzk[j];
+                                }
+                                L.dzk[nx + lane] = acc;
+                            }
+                            wave_sync();
+                            if (lane < nz) {
+                                const double v = L.dzk[lane];
+                                DZ[k * nz + lane] = v;
+                                step_inf = fmax(step_inf, fabs(v));
+                            }
+                            if (cur.fl != kRowOff) {
+                                const int gi = S.stage_row0[k] + lane;
+                                const double adz = row_dot(lane, 0, L.dzk);
+                                if (cur.fl == kRowEq) {
+                                    DS[gi] = adz; // (kept for the multiplier update)
+                                } else {
+                                    const double ds = -cur.rp - adz;
+                                    const double corr = (pass == 1) ? (sigma_mu - cur.ds * cur.dl) : 0.0;
+                                    const double dl = (corr - cur.lv * cur.sv - cur.lv * ds) / cur.sv;
+                                    DS[gi] = ds; // (pass 1 overwrites the predictor's direction, which this lane holds in cur)
+                                    DL[gi] = dl;
+                                    if (ds < 0.0) amin = fmin(amin, -cur.sv / ds);
+                                    if (dl < 0.0) amin = fmin(amin, -cur.lv / dl);
+                                }
+                            }
+                            if (k < N) {
+                                double acc = 0.0;
+                                if (lane < nx) { // dx+ = A dx + B du
+#pragma unroll
+                                    for (int j = 0; j < NXT + NUT; ++j) acc += L.AB[lane + nx * j] * L.dzk[j];
+                                }
+                                wave_sync();
+                                if (lane < nx) L.dzk[lane] = acc;
+                            }
+                            wave_sync();
+                            cur = nxt;
+                        }
+                        donef = true;
+                    }
+                }
+                if (!donef)
                 for (int k = 0; k <= N; ++k) {
                     const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
                     load_class(c);
@@ -627,7 +854,6 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                     for (int e = lane; e < nz; e += kWave) {
                         DZ[k * nz + e] = L.dzk[e];
                         step_inf = fmax(step_inf, fabs(L.dzk[e]));
-                        z_inf = fmax(z_inf, fabs(Z[k * nz + e]));
                     }
                     for (int r = lane; r < nr; r += kWave) {
                         const int gi = gi0 + r;
@@ -689,10 +915,15 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 }
             }
             step_inf = wave_max(step_inf) * alpha;
-            z_inf = wave_max(z_inf);
             if (!good) break;
             // ---- update
-            for (int e = lane; e < NZ; e += kWave) Z[e] += alpha * DZ[e];
+            z_inf = 0.0;
+            for (int e = lane; e < NZ; e += kWave) {
+                const double v = Z[e] + alpha * DZ[e];
+                Z[e] = v;
+                z_inf = fmax(z_inf, fabs(v));
+            }
+            z_inf = wave_max(z_inf);
             double musum2 = 0.0, maxe = 0.0;
             for (int gi = lane; gi < m; gi += kWave) {
                 const int fl = (int)Flag[gi];

@@ -80,6 +80,7 @@ struct StagePlan {
     const int *cls_rptr, *cls_rcol, *cls_gptr, *cls_grow, *cls_eptr, *cls_erow; // [ncls] offsets into iblob
     const int *cls_rval, *cls_gval, *cls_eval; // [ncls] offsets into blob
     int max_nnz, max_nnze;
+    int* next_instance; // device counter of the work queue (reset before every launch), or nullptr
     // per-resident-wave workspace
     double* ws;
     long long ws_total; // doubles per wave

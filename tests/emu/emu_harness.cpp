@@ -300,6 +300,8 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
     P.ovf_list = ovf_list.data();
     std::vector<double> ws((size_t)hs.sp.ws_total + 8, __builtin_nan(""));
     hs.sp.ws = ws.data();
+    int next_instance = 0; // the work queue of the kernel
+    hs.sp.next_instance = &next_instance;
     const StagePlan& S = hs.sp;
     // same dispatch as the HIP launcher (select_riccati_kernel)
     int r = emu::run_wave(
