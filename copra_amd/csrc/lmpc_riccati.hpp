@@ -638,12 +638,14 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 if (pass == 1) { // ---- sweep 3 (backward): corrector right-hand side through the stored factors
                     bool done3 = false;
                     if constexpr (NXT > 0 && NUT > 0) {
-                        if (S.max_stage_rows <= kWave) {
+                        if (S.max_stage_rows <= kWave && NXT * NUT <= 2 * kWave) {
                             // compile-time shape, at most one row per lane: every operand of stage k - 1 is requested from
                             // the workspace BEFORE stage k is computed, so its HBM / L2 round trip runs underneath
+                            // (K and Muu^-1 travel ONE or TWO elements per lane -- element e of the nu x nx block in lane
+                            //  e % 64 -- and are put into LDS when their stage starts: two registers instead of nu + nu)
                             struct Regs3 {
                                 int fl;
-                                double sv, lv, rp, ds, dl, gb, mi[NUT], kc[NUT];
+                                double sv, lv, rp, ds, dl, gb, mi, k0, k1;
                             };
                             auto issue3 = [&](int k, Regs3& R) {
                                 const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi = S.stage_row0[k] + lane;
@@ -653,12 +655,11 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                                     R.sv = Sv[gi], R.lv = Lam[gi], R.rp = RP[gi], R.ds = DS[gi], R.dl = DL[gi];
                                 }
                                 if (lane < nz) R.gb = GB[k * nz + lane];
+                                R.mi = R.k0 = R.k1 = 0.0;
                                 if (k < N) {
-#pragma unroll
-                                    for (int l = 0; l < NUT; ++l) {
-                                        if (lane < nu) R.mi[l] = Mig[(size_t)k * nu * nu + lane + nu * l];
-                                        if (lane < nx) R.kc[l] = Kg[(size_t)k * nu * nx + l + nu * lane];
-                                    }
+                                    if (lane < nu * nu) R.mi = Mig[(size_t)k * nu * nu + lane];
+                                    if (lane < nu * nx) R.k0 = Kg[(size_t)k * nu * nx + lane];
+                                    if (lane + kWave < nu * nx) R.k1 = Kg[(size_t)k * nu * nx + lane + kWave];
                                 }
                             };
                             Regs3 cur, nxt;
@@ -666,6 +667,11 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                             for (int k = N; k >= 0; --k) {
                                 if (k > 0) issue3(k - 1, nxt);
                                 load_class(S.cls_of_stage[k]);
+                                if (k < N) {
+                                    if (lane < nu * nu) L.Mi[lane] = cur.mi;
+                                    if (lane < nu * nx) L.Kl[lane] = cur.k0;
+                                    if (lane + kWave < nu * nx) L.Kl[lane + kWave] = cur.k1;
+                                }
                                 {
                                     double Cv = 0.0;
                                     if (cur.fl == kRowEq)
@@ -694,13 +700,13 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                                     double kvv = 0.0, pn = 0.0;
                                     if (lane < nu) { // kv = -Muu^-1 hu
 #pragma unroll
-                                        for (int l = 0; l < NUT; ++l) kvv += cur.mi[l] * L.h[nx + l];
+                                        for (int l = 0; l < NUT; ++l) kvv += L.Mi[lane + nu * l] * L.h[nx + l];
                                         Kvg[(size_t)k * nu + lane] = -kvv;
                                     }
                                     if (lane < nx) { // p = hx + K' hu
                                         pn = L.h[lane];
 #pragma unroll
-                                        for (int l = 0; l < NUT; ++l) pn += cur.kc[l] * L.h[nx + l];
+                                        for (int l = 0; l < NUT; ++l) pn += L.Kl[l + nu * lane] * L.h[nx + l];
                                     }
                                     wave_sync();
                                     if (lane < nx) L.pv[lane] = pn;
@@ -769,10 +775,10 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 step_inf = 0.0;
                 bool donef = false;
                 if constexpr (NXT > 0 && NUT > 0) {
-                    if (S.max_stage_rows <= kWave) {
+                    if (S.max_stage_rows <= kWave && NXT * NUT <= 2 * kWave) {
                         struct RegsF {
                             int fl;
-                            double sv, lv, rp, ds, dl, kv, kc[NXT];
+                            double sv, lv, rp, ds, dl, kv, k0, k1;
                         };
                         auto issuef = [&](int k, RegsF& R) {
                             const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], gi = S.stage_row0[k] + lane;
@@ -781,10 +787,11 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                                 R.fl = (int)Flag[gi];
                                 R.sv = Sv[gi], R.lv = Lam[gi], R.rp = RP[gi], R.ds = DS[gi], R.dl = DL[gi];
                             }
-                            if (k < N && lane < nu) {
-                                R.kv = Kvg[(size_t)k * nu + lane];
-#pragma unroll
-                                for (int j = 0; j < NXT; ++j) R.kc[j] = Kg[(size_t)k * nu * nx + lane + nu * j];
+                            R.kv = R.k0 = R.k1 = 0.0;
+                            if (k < N) {
+                                if (lane < nu) R.kv = Kvg[(size_t)k * nu + lane];
+                                if (lane < nu * nx) R.k0 = Kg[(size_t)k * nu * nx + lane];
+                                if (lane + kWave < nu * nx) R.k1 = Kg[(size_t)k * nu * nx + lane + kWave];
                             }
                         };
                         RegsF cur, nxt;
@@ -792,12 +799,17 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                         for (int k = 0; k <= N; ++k) {
                             if (k < N) issuef(k + 1, nxt);
                             load_class(S.cls_of_stage[k]);
+                            if (k < N) {
+                                if (lane < nu * nx) L.Kl[lane] = cur.k0;
+                                if (lane + kWave < nu * nx) L.Kl[lane + kWave] = cur.k1;
+                            }
+                            wave_sync();
                             if (lane < nu) { // du = K dx + kv
                                 double acc = 0.0;
                                 if (k < N) {
                                     acc = cur.kv;
 #pragma unroll
-                                    for (int j = 0; j < NXT; ++j) acc += cur.kc[j] * L.dzk[j];
+                                    for (int j = 0; j < NXT; ++j) acc += L.Kl[lane + nu * j] * L.dzk[j];
                                 }
                                 L.dzk[nx + lane] = acc;
                             }
