@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kLargeMaxN, 4) void copra_lmpc_large_kernel_w4(cons
 // Long horizons whose pieces are all stage-wise (stage_plan.hpp): Riccati interior-point method, one instance per
 // wavefront, persistent grid (lmpc_riccati.hpp); the instances it does not converge on are queued for the kernel above.
 template <int NXT, int NUT>
-__global__ __launch_bounds__(64, 3) void copra_lmpc_riccati_kernel(const FusedPlan P, const StagePlan S) // (LDS admits ~10 waves per CU: 168 VGPRs, no spills)
+__global__ __launch_bounds__(64, 2) void copra_lmpc_riccati_kernel(const FusedPlan P, const StagePlan S) // (256 VGPRs: the prefetched operands of the next stage and the register-resident factorisation spill below that; LDS admits 10 waves per CU, this gives 8)
 {
     lmpc_riccati_body<NXT, NUT>(P, S);
 }
