@@ -417,24 +417,27 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     double q1r[QR > 0 ? QR : 1]; // this lane's element of every Q1 column (QR > 0)
 #pragma unroll
     for (int u = 0; u < (QR > 0 ? QR : 1); ++u) q1r[u] = 0.0;
-    auto q1_get = [&](int k) -> double {
-        if constexpr (QR > 0) {
-            double v = q1r[0];
-#pragma unroll
-            for (int u = 1; u < QR; ++u) v = (u == k) ? q1r[u] : v;
-            return v;
-        } else {
-            return S.Q1[k * kWave + lane_id()];
-        }
-    };
-    auto q1_set = [&](int k, double v) {
-        if constexpr (QR > 0) {
-#pragma unroll
-            for (int u = 0; u < QR; ++u) q1r[u] = (u == k) ? v : q1r[u];
-        } else {
-            S.Q1[k * kWave + lane_id()] = v;
-        }
-    };
+    // (accessed only through fully unrolled, compile-time-indexed code below -- no lambdas, no address taken -- so that the
+    //  array stays in registers: a first version went through closures and the compiler kept it in scratch memory, 24 MB of
+    //  extra HBM writes per launch)
+#define COPRA_Q1_GET(dst, kk)                                                                                         \
+    do {                                                                                                              \
+        if constexpr (QR > 0) {                                                                                       \
+            dst = q1r[0];                                                                                             \
+            _Pragma("unroll") for (int u_ = 1; u_ < QR; ++u_) dst = (u_ == (kk)) ? q1r[u_] : dst;                    \
+        } else {                                                                                                      \
+            dst = S.Q1[(kk) * kWave + lane_id()];                                                                     \
+        }                                                                                                             \
+    } while (0)
+#define COPRA_Q1_SET(kk, val)                                                                                         \
+    do {                                                                                                              \
+        if constexpr (QR > 0) {                                                                                       \
+            const double v_ = (val);                                                                                  \
+            _Pragma("unroll") for (int u_ = 0; u_ < QR; ++u_) q1r[u_] = (u_ == (kk)) ? v_ : q1r[u_];                 \
+        } else {                                                                                                      \
+            S.Q1[(kk) * kWave + lane_id()] = (val);                                                                   \
+        }                                                                                                             \
+    } while (0)
     const int lane = lane_id();
     const int n = NV ? NV : n_rt;
     const int ld = NV ? (NV | 1) : S.ldj;
@@ -727,7 +730,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     if (lane < nact) S.R[rcol(nact) + lane] = dj;
                     if constexpr (TRI) {
                         const double h = sqrt(wave_sum(vj * vj));
-                        q1_set(nact, vj / h); // (lanes >= n hold 0)
+                        COPRA_Q1_SET(nact, vj / h); // (lanes >= n hold 0)
                         if (lane == nact) {
                             S.R[rcol(nact) + nact] = h;
                             S.iact[nact] = nvl;
@@ -872,10 +875,12 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         }
                         // columns q, q+1 of J (lane = row)
                         if constexpr (TRI) {
-                            const double x = q1_get(q), y = q1_get(q + 1);
+                            double x, y;
+                            COPRA_Q1_GET(x, q);
+                            COPRA_Q1_GET(y, q + 1);
                             const double t = gc * x + gs * y;
-                            q1_set(q + 1, nu_ * (x + t) - y);
-                            q1_set(q, t);
+                            COPRA_Q1_SET(q + 1, nu_ * (x + t) - y);
+                            COPRA_Q1_SET(q, t);
                         } else if (lane < n) {
                             const double x = J[lane * ld + q], y = J[lane * ld + q + 1];
                             const double t = gc * x + gs * y;
