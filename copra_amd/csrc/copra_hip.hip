@@ -5,6 +5,7 @@
 #include "../../include/copra_hip.h"
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
+#include "lmpc_fused_ric.hpp"
 #include "lmpc_large.hpp"
 #include "lmpc_riccati.hpp"
 #include "lmpc_shared.hpp"
@@ -62,6 +63,13 @@ template <int NX, int NU, int NH, int RP, int QR = 0>
 __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const FusedPlan P)
 {
     lmpc_fused_body<NX, NU, NH, RP, true, QR>(P, P.inst_offset + (int)blockIdx.x);
+}
+
+// The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
+template <int NX, int NU, int NH, int QR>
+__global__ __launch_bounds__(64, 2) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
+{
+    lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, P.inst_offset + (int)blockIdx.x);
 }
 
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
@@ -171,6 +179,7 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
+        if (P.lds.ric) return copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs>; // (plan_builder.hpp: only this shape gets the layout)
         if (P.nx == 6 && rp == 6 && P.lds.q1regs == kFusedQ1Regs) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6, kFusedQ1Regs>;
         if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
         if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tri_kernel<6, 3, 20, 0>; // headline shape, full-size costs

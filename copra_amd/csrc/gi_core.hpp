@@ -30,6 +30,7 @@
 
 #include "plan.hpp"
 #include "wave_prims.hpp"
+#include "ric_factor.hpp"
 
 // Fine-grained stamps for profiling builds (make libcopra_hip_prof.so); compiled out of the product library.
 #ifdef COPRA_FINE_PROFILE
@@ -408,7 +409,9 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
 // row that is violated at the current iterate: ONE slack evaluation instead of a scan over all rows, then the ordinary
 // iteration (dual blocking test, drops) -- every invariant of the method holds throughout, nothing is ever restarted.
 // After the list the ordinary scans take over and finish.  Same optimum as a cold start; the iterates differ.
-template <int NV, bool TRI = false, int QR = 0, class Rows>
+// RNX, RNU > 0 (with TRI and a compile-time shape): the factor in S.J is in Riccati form (ric_factor.hpp) -- the two
+// substitutions become the closed-loop recursions over the NV / RNU stages; everything else is unchanged.
+template <int NV, bool TRI = false, int QR = 0, int RNX = 0, int RNU = 0, class Rows>
 COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Rows& rows, double vsmall, int max_iter,
     int& iter_main, int& iter_drop COPRA_FINE_ARGS, bool j_ready = false, int warm_mine = -1, int warm_n = 0,
     int* nact_out = nullptr)
@@ -577,6 +580,10 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 // w = R^-T n+ : forward substitution, lane = column; a bound row's normal starts at its own index
                 double acc = (lane < n) ? S.ap[lj] : 0.0;
                 double wk = 0.0;
+                double rinv_own = 0.0;
+                if constexpr (RNX > 0) {
+                    wk = ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
+                } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
                         double row[4], ri4[4];
@@ -603,8 +610,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     forward(0);
                 else
                     forward(((nvl - mgen) % n) & ~3);
-                const double rinv_own = J[fidx<true>(lj, lj, ld)];
+                rinv_own = J[fidx<true>(lj, lj, ld)];
                 wk = (lane < n) ? acc * rinv_own : 0.0; // (lane k's accumulator is final once step k-1 is done)
+                }
                 if (iter_main <= 1) COPRA_FINE("as:w");
                 // d1 = Q1' w and v = w - Q1 d1, by modified Gram-Schmidt, twice (keeps Q1 orthonormal to rounding)
                 vj = wk;
@@ -633,6 +641,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 // z = R^-1 v : back substitution, lane = row
                 acc = vj;
                 double zk = 0.0;
+                if constexpr (RNX > 0) {
+                    zk = ric_apply<RNX, RNU, NV / RNU>(J, vj);
+                } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];
 #pragma unroll
@@ -651,6 +662,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     }
                 }
                 zk = acc * rinv_own;
+                }
                 zi = (lane < n) ? zk : 0.0;
                 if (iter_main <= 1) COPRA_FINE("as:z");
             } else {

@@ -1,0 +1,483 @@
+// LMPC::solve() for one instance per wavefront, factor-only tier with the factor in RICCATI form.
+//
+// Same call stack as lmpc_fused.hpp (LMPC.cpp:79-101: updateSystem, makeQPForm, SI_solve, updateResults) and the same
+// Goldfarb-Idnani iteration (gi_core.hpp, TRI), but the condensed Hessian  Q = 1e-6 I + sum Q_k  (LMPC.cpp:228-230,
+// 252-255) is never formed and never factorised as an n x n matrix: for a controller whose costs are all per-step entries
+// (TrajectoryCost / TargetCost / ControlCost / MixedCost without full-size weights, costFunctions.cpp:63-215) Q is the
+// Hessian of a stage-wise LQ problem, and ONE backward Riccati sweep over the N stages yields a factor of Q^-1 whose two
+// products are closed-loop recursions (ric_factor.hpp).  O(N (nx+nu)^3) = 15 k multiply-adds at the headline shape
+// instead of 11 k (cost phase) + 72 k (Cholesky) + 7 k (two substitutions), and -- what matters on a latency-bound wave --
+// 60 dependent steps of three LDS round trips instead of the 35 k + 32 k + 8 k cycles those three phases take.
+//     stage k < N:   l_k(x, u) = 1/2 [x; u]' Hin [x; u] + hin' [x; u],   Hin = sum_t [M_t N_t]' W_t [M_t N_t] (+ 1e-6 I on u),
+//                                                                       hin = -sum_t [M_t N_t]' W_t p_t
+//     stage N:       l_N(x) = 1/2 x' HN x + hN' x                        (TrajectoryCost and TargetCost terms)
+// The unconstrained minimiser -Q^-1 c (qpgen2's starting point) is the LQ roll-out u_k = K_k x_k + kv_k from x_0.
+// Constraint rows, bounds, status codes, iteration counts, results: exactly the fused body's (StageRows, gi_active_set).
+// Shapes: compile-time (NX, NU, NH) with NX (NX + NU + 1) <= 64 (one element of P [A B d] per lane).
+#pragma once
+#include "lmpc_fused.hpp"
+
+namespace copra_hip {
+
+template <int NX, int NU, int NH, int RP, int QR>
+COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
+{
+    constexpr int NZ = NX + NU, NV = NU * NH, X = NX * (NH + 1);
+    constexpr int nxx = NX * (NX + 1) / 2, nux = NU * NX, nuu = NU * (NU + 1) / 2;
+    static_assert(NX * (NZ + 1) <= kWave && nxx + nux + nuu + NZ <= kWave && NV <= kWave, "one element per lane");
+    using RR = RicRec<NX, NU>;
+    double* lds = lds_base();
+    const LdsLayout& L = P.lds;
+    const int lane = lane_id();
+    double* A = lds + L.A;
+    double* B = lds + L.B;
+    double* D = lds + L.D;
+    double* X0 = lds + L.X0;
+    double* G = lds + L.G;
+    double* Xbar = lds + L.Xbar;
+    double* Xcur = lds + L.Xcur;
+    double* nb = lds + L.nb;
+    SolverLds S = carve_solver(lds, L);
+    double* F = S.J; // NH stage records
+    // scratch of the sweep (aliases the solver vectors: first written by the roll-out / the norms phase)
+    double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
+    double* pv = Pm + NX * NX; // NX
+    double* T = pv + ((NX + 1) & ~1); // NX x (NZ + 1):  P [A B d] (+ p in the last column)
+    double* Mu = T + NX * (NZ + 1); // NU x (NX + 1):  [M_ux | h_u]
+    double* Zs = Mu + ((NU * (NX + 1) + 1) & ~1); // two doubles that hold 0.0 during the sweep
+    double* Bk = Zs + 2; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
+
+    long long stamp[8];
+    COPRA_FINE_DECL;
+    stamp[0] = cycle_counter();
+    StageRows<NX, NU, NH> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
+    rows.inst = inst;
+    rows.zero = S.scal;
+    // ---- 0. coalesced loads of this instance's system ----
+    for (int e = lane; e < NX * NX; e += kWave) A[e] = P.A[(size_t)inst * NX * NX + e];
+    for (int e = lane; e < NX * NU; e += kWave) B[e] = P.B[(size_t)inst * NX * NU + e];
+    for (int e = lane; e < NX; e += kWave) {
+        D[e] = P.d[(size_t)inst * NX + e];
+        X0[e] = P.x0[(size_t)inst * NX + e];
+    }
+    // ---- 0b. stage costs (they do not depend on the system: their loads overlap the ones above) ----
+    // lane -> entry (a, b) of M = Hin + [A B]' P+ [A B] that it owns in the sweep:  x-x upper triangle | u-x | u-u upper
+    // triangle | the affine column (b == NZ)
+    int ma = 0, mb = 0;
+    bool m_on = true;
+    if (lane < nxx) {
+        int b = 0;
+        while ((b + 1) * (b + 2) / 2 <= lane) ++b;
+        mb = b;
+        ma = lane - b * (b + 1) / 2;
+    } else if (lane < nxx + nux) {
+        const int t = lane - nxx;
+        ma = NX + t % NU;
+        mb = t / NU;
+    } else if (lane < nxx + nux + nuu) {
+        const int t = lane - nxx - nux;
+        int b = 0;
+        while ((b + 1) * (b + 2) / 2 <= t) ++b;
+        mb = NX + b;
+        ma = NX + t - b * (b + 1) / 2;
+    } else if (lane < nxx + nux + nuu + NZ) {
+        ma = lane - nxx - nux - nuu;
+        mb = NZ;
+    } else {
+        m_on = false;
+    }
+    // Branch-free: every lane loads from a valid address and switches its term off by a select, the rows of a term are
+    // padded to RP (clamped index, masked), so that the 4 RP loads of a term are in flight together.
+    double hreg = 0.0; // Hin(ma, mb), or hin(ma) in the affine column
+    double term = 0.0; // lanes e < NX NX: HN(e % NX, e / NX);  the next NX lanes: hN
+    const int pi = lane % NX, pj = lane / NX; // element (pi, pj) of an NX x (NZ + 1) table: [A B d] layout
+    {
+        const int ti = pi, tj = pj; // tj == NX: hN
+        // (all terms unrolled, a missing one clamped to the last and masked: the loads of every term are issued before the
+        //  first multiply-add waits for any of them -- one round trip to L2 instead of one per term)
+        double va[kRicMaxCosts][RP], vb[kRicMaxCosts][RP], vc[kRicMaxCosts][RP], vd[kRicMaxCosts][RP], vw[kRicMaxCosts][RP];
+        bool on_s[kRicMaxCosts], on_t[kRicMaxCosts];
+        double sb = (mb < NZ) ? 1.0 : -1.0, sd = (tj < NX) ? 1.0 : -1.0; // (the affine column pairs with -p)
+#pragma unroll
+        for (int t = 0; t < kRicMaxCosts; ++t) {
+            const bool live = t < P.ncost;
+            const CostTerm& ct = P.cost[live ? t : 0];
+            const int rc = ct.rows;
+            const double* pref = cost_reference(P, live ? t : 0, inst);
+            const bool in_stage = ct.kind != kCostTarget; // TargetCost: the last state only (costFunctions.cpp:107-120)
+            const bool in_term = ct.kind == kCostTrajectory || ct.kind == kCostTarget; // MixedCost stops at x_{N-1} (:207)
+            const bool useM = ct.offM >= 0 && ct.kind != kCostControl;
+            const bool useN = ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed);
+            // offset of column `a` of [M_t N_t] in the blob, or -1
+            auto col_off = [&](int a) { return a < NX ? (useM ? ct.offM + rc * a : -1) : (useN ? ct.offN + rc * (a - NX) : -1); };
+            const int oa = col_off(ma), ob = (mb < NZ) ? col_off(mb) : 0;
+            const int oc = col_off(ti), od = (tj < NX) ? col_off(tj) : 0;
+            on_s[t] = live && in_stage && m_on && oa >= 0 && ob >= 0;
+            on_t[t] = live && in_term && tj <= NX && oc >= 0 && od >= 0;
+            const double* pa = P.params + (oa >= 0 ? oa : ct.offW);
+            const double* pb = (mb < NZ) ? P.params + (ob >= 0 ? ob : ct.offW) : pref;
+            const double* pc = P.params + (oc >= 0 ? oc : ct.offW);
+            const double* pd = (tj < NX) ? P.params + (od >= 0 ? od : ct.offW) : pref;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const int rr = r < rc ? r : rc - 1;
+                vw[t][r] = (r < rc) ? P.params[ct.offW + rr] : 0.0; // (a padded row has weight zero)
+                va[t][r] = pa[rr];
+                vb[t][r] = pb[rr];
+                vc[t][r] = pc[rr];
+                vd[t][r] = pd[rr];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kRicMaxCosts; ++t) {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) {
+                const double hs = (va[t][r] * vw[t][r]) * (sb * vb[t][r]);
+                const double ht = (vc[t][r] * vw[t][r]) * (sd * vd[t][r]);
+                hreg += on_s[t] ? hs : 0.0;
+                term += on_t[t] ? ht : 0.0;
+            }
+        }
+        if (m_on && ma == mb && ma >= NX) {
+            double one = 1.0;
+            one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;  (LMPC.cpp:228-229)
+            hreg += one;
+        }
+        if (tj < NX)
+            Pm[lane] = term;
+        else if (tj == NX)
+            pv[ti] = term;
+    }
+    COPRA_FINE("ric:costs");
+    // ---- 1. preview: G_s = A G_{s-1} (G_0 = B), xbar_s = A xbar_{s-1} + d (PreviewSystem.cpp:57-74 applied to x0).  One step
+    //      per stage of the sweep below, inside its synchronisation intervals: the two recursions are independent, the
+    //      preview's LDS round trips hide under the sweep's. ----
+    wave_sync();
+    double ar[NX]; // row pi of A
+#pragma unroll
+    for (int t = 0; t < NX; ++t) ar[t] = A[pi + NX * t];
+    const bool isx = (pj == NU);
+    const double padd = isx ? D[pi] : 0.0;
+    if (lane < NX * NU) G[lane] = B[lane];
+    if (lane < NX) Xbar[lane] = X0[lane];
+    stamp[1] = cycle_counter();
+    // ---- 2. backward Riccati sweep: stage records into F ----
+    // Per stage k (three synchronisation intervals):
+    //   (e) of stage k + 1: Acl = A + B K, bkd = d + B kv          | (a) T = P+ [A B d] (+ p+ in the affine column)
+    //   one preview step | (b) this lane's entry of M = Hin + [A B]' T; M_ux, h_u to LDS, M_uu to the record; M_uu^-1 in
+    //                          every lane from an LDL' factorisation of the broadcast M_uu (no square roots here)
+    //   (cd) P = M_xx - M_ux' M_uu^-1 M_ux, p = h_x - M_ux' M_uu^-1 h_u, K = -M_uu^-1 M_ux, kv = -M_uu^-1 h_u: ONE code
+    //        path, v = base - sum_c2 (sum_c M_uu^-1(c, c2) mine(c)) col(c2), with mine = column a of M_ux for the x rows and a
+    //        unit vector for the u rows.
+    // Lam^-1 (the Cholesky factor of M_uu, inverted) and Bt = B Lam^-T are only used by the active-set iteration: they are
+    // formed after the sweep for all stages at once (lane = stage), not twenty times inside it.
+    int status = 0;
+    {
+        double abr[NX]; // column pj of [A B d]
+        double aba[NX]; // column ma of [A B]
+        double brow[NU]; // row pi of B
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+            abr[t] = (pj < NX) ? A[t + NX * pj] : (pj < NZ) ? B[t + NX * (pj - NX)] : (pj == NZ) ? D[t] : 0.0;
+            aba[t] = (ma < NX) ? A[t + NX * ma] : B[t + NX * (ma - NX)];
+        }
+#pragma unroll
+        for (int c = 0; c < NU; ++c) brow[c] = B[pi + NX * c];
+        const bool e_on = pj < NX || pj == NZ; // (e): Acl columns and bkd
+        const double eadd = (pj < NX) ? A[pi + NX * pj] : (pj == NZ) ? D[pi] : 0.0;
+        const int esrc = (pj < NX) ? RR::oK + NU * pj : RR::oKv; // column pj of K, or kv
+        double* const edst = (pj < NX) ? F + lane : Bk + pi; // (Acl is the head of the record, in this lane order)
+        const int estride = (pj < NX) ? RR::SZ : NX;
+        const bool a_on = lane < NX * (NZ + 1);
+        const double* apv = (pj == NZ) ? pv + pi : Zs;
+        const int mbc = (mb == NZ) ? NX : mb; // column of Mu / T this lane pairs with (h_u is column NX of Mu)
+        const int tcol = (mb == NZ) ? NZ : mb;
+        const bool is_x = ma < NX; // rows of P / p;  else rows of K / kv (u-x and affine lanes) or M_uu lanes
+        const bool is_uu = m_on && ma >= NX && mb >= NX && mb < NZ;
+        const bool is_k = m_on && ma >= NX && !is_uu;
+        const int uu_t = lane - nxx - nux; // position in the packed upper triangle of M_uu
+        double unit[NU]; // u rows: the unit vector that picks row (ma - NX) of M_uu^-1
+#pragma unroll
+        for (int c = 0; c < NU; ++c) unit[c] = (ma - NX == c) ? 1.0 : 0.0;
+        const double* minep = Mu + NU * (is_x ? ma : 0);
+        // where (cd) stores: x rows into P (both halves) or p; u rows into the record (K, kv)
+        const int w1 = is_x ? (mb < NX ? ma + NX * mb : NX * NX + ma) : (mb < NX ? RR::oK + (ma - NX) + NU * mb : RR::oKv + (ma - NX));
+        const int w2 = (is_x && mb < NX) ? mb + NX * ma : w1;
+        if (lane == 0) Zs[0] = 0.0;
+        bool bad = false;
+        wave_sync();
+        for (int k = NH - 1; k >= -1; --k) {
+            if (k < NH - 1 && e_on) {
+                double* Fe = F + (k + 1) * RR::SZ;
+                double acc = eadd;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) acc += brow[c] * Fe[esrc + c];
+                edst[(k + 1) * estride] = acc;
+            }
+            if (k < 0) break;
+            if (a_on) {
+                double acc = *apv;
+#pragma unroll
+                for (int t = 0; t < NX; ++t) acc += Pm[t + NX * pi] * abr[t];
+                T[pi + NX * pj] = acc;
+            }
+            wave_sync();
+            if (k == NH - 2) COPRA_FINE("sweep:e+a");
+            { // preview step s = NH - k (reads what step s - 1 wrote one iteration ago)
+                const int s = NH - k;
+                const double* src = isx ? Xbar + (s - 1) * NX : G + (s - 1) * NX * NU + NX * (pj < NU ? pj : 0);
+                double sv[NX];
+#pragma unroll
+                for (int t = 0; t < NX; ++t) sv[t] = src[t];
+                double acc = padd;
+#pragma unroll
+                for (int t = 0; t < NX; ++t) acc += ar[t] * sv[t];
+                if (isx)
+                    Xbar[s * NX + pi] = acc;
+                else if (pj < NU && s < NH)
+                    G[s * NX * NU + NX * pj + pi] = acc;
+            }
+            if (k == NH - 2) COPRA_FINE("sweep:preview");
+            double* Fk = F + k * RR::SZ;
+            double mval = hreg;
+#pragma unroll
+            for (int t = 0; t < NX; ++t) mval += aba[t] * T[t + NX * tcol];
+            if (is_k) Mu[(ma - NX) + NU * mbc] = mval;
+            if (is_uu) Fk[RR::oLi + uu_t] = mval; // (packed upper triangle; replaced by Lam^-1 after the sweep)
+            double mi[NU][NU]; // M_uu^-1 (symmetric)
+            {
+                double lm[NU][NU]; // M_uu (lower part) -> unit lower L of M_uu = L D L'
+                double rd[NU]; // 1 / D(c)
+#pragma unroll
+                for (int cb = 0; cb < NU; ++cb)
+#pragma unroll
+                    for (int ca = 0; ca <= cb; ++ca) lm[cb][ca] = bcast_f64(mval, nxx + nux + cb * (cb + 1) / 2 + ca); // M_uu(ca, cb)
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    // column c:  v_r = M(r, c) - sum_q L(r, q) D(q) L(c, q);  D(c) = v_c;  L(r, c) = v_r / D(c)
+                    double dl[NU]; // D(q) L(c, q)
+#pragma unroll
+                    for (int q = 0; q < c; ++q) dl[q] = lm[c][q]; // (still D(q) L(c, q): scaled below)
+                    double dc = lm[c][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) {
+                        const double lcq = dl[q] * rd[q];
+                        dc -= lcq * dl[q];
+                        lm[c][q] = lcq;
+                    }
+                    bad = bad || !(dc > 0.0);
+                    rd[c] = ric_rcp(dc);
+#pragma unroll
+                    for (int r2 = c + 1; r2 < NU; ++r2) {
+                        double v = lm[r2][c];
+#pragma unroll
+                        for (int q = 0; q < c; ++q) v -= lm[r2][q] * lm[c][q]; // lm[r2][q] = D(q) L(r2, q), lm[c][q] = L(c, q)
+                        lm[r2][c] = v; // D(c) L(r2, c)
+                    }
+                }
+                // L^-1 (unit lower) by forward substitution
+                double li[NU][NU];
+#pragma unroll
+                for (int c = 0; c < NU; ++c)
+#pragma unroll
+                    for (int r2 = c; r2 < NU; ++r2) {
+                        double v = (r2 == c) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int q = c; q < r2; ++q) v -= lm[r2][q] * li[q][c];
+                        li[r2][c] = v;
+                    }
+#pragma unroll
+                for (int r2 = 0; r2 < NU; ++r2)
+#pragma unroll
+                    for (int c = r2; c < NU; ++c) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = c; q < NU; ++q) v += (li[q][r2] * rd[q]) * li[q][c];
+                        mi[r2][c] = v;
+                        mi[c][r2] = v;
+                    }
+            }
+            wave_sync();
+            if (k == NH - 2) COPRA_FINE("sweep:b+ldl");
+            if (m_on && !is_uu) {
+                double col[NU], mine[NU];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    col[c] = Mu[c + NU * mbc];
+                    const double mv = minep[c];
+                    mine[c] = is_x ? mv : unit[c];
+                }
+                double v = is_x ? mval : 0.0;
+#pragma unroll
+                for (int c2 = 0; c2 < NU; ++c2) {
+                    double ta = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) ta += mi[c][c2] * mine[c];
+                    v -= ta * col[c2];
+                }
+                double* base = is_x ? Pm : Fk;
+                base[w1] = v;
+                base[w2] = v;
+            }
+            wave_sync();
+            if (k == NH - 2) COPRA_FINE("sweep:cd");
+            if (k == NH - 1) COPRA_FINE("sweep:first");
+        }
+        COPRA_FINE("sweep:loop");
+        if (bad) status = 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
+        // Lam^-1 of every stage (lane = stage): Cholesky of the stored M_uu, inverted in place of it
+        if (lane < NH) {
+            double* Fk = F + lane * RR::SZ;
+            double lm[NU][NU], rd[NU], li[NU][NU];
+#pragma unroll
+            for (int cb = 0; cb < NU; ++cb)
+#pragma unroll
+                for (int ca = 0; ca <= cb; ++ca) lm[cb][ca] = Fk[RR::oLi + cb * (cb + 1) / 2 + ca];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double dpp = lm[c][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) dpp -= lm[c][q] * lm[c][q];
+                rd[c] = fast_rsqrt(dpp);
+#pragma unroll
+                for (int r2 = c + 1; r2 < NU; ++r2) {
+                    double v = lm[r2][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= lm[r2][q] * lm[c][q];
+                    lm[r2][c] = v * rd[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NU; ++c)
+#pragma unroll
+                for (int r2 = 0; r2 < NU; ++r2) {
+                    if (r2 < c) {
+                        li[r2][c] = 0.0;
+                    } else if (r2 == c) {
+                        li[r2][c] = rd[c];
+                    } else {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = c; q < r2; ++q) v -= lm[r2][q] * li[q][c];
+                        li[r2][c] = v * rd[r2];
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < NU; ++c)
+#pragma unroll
+                for (int r2 = 0; r2 < NU; ++r2) Fk[RR::oLi + r2 + NU * c] = li[r2][c];
+        }
+        wave_sync();
+        COPRA_FINE("sweep:Li");
+        // Bt = B Lam^-T of every stage
+        for (int e = lane; e < NH * NX * NU; e += kWave) {
+            const int k = e / (NX * NU), rem = e - k * NX * NU;
+            const int c = rem / NX, j = rem - c * NX;
+            const double* Lk = F + k * RR::SZ + RR::oLi;
+            double acc = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < NU; ++c2) acc += B[j + NX * c2] * Lk[c + NU * c2];
+            F[k * RR::SZ + RR::oBt + rem] = acc;
+        }
+    }
+    wave_sync();
+    COPRA_FINE("sweep:Bt");
+    stamp[2] = cycle_counter();
+    // ---- 3. unconstrained minimiser: roll-out u_k = K_k x_k + kv_k, x_{k+1} = Acl_k x_k + bkd_k ----
+    {
+        const int li = lane < NX ? lane : NX - 1;
+        const int kq = lane / NU, cq = lane - kq * NU;
+        struct Ops {
+            double kr[NX], ar[NX], kv, bk;
+        };
+        auto fetch = [&](int k, Ops& o) {
+            const double* Fk = F + k * RR::SZ;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                o.kr[j] = Fk[RR::oK + cq + NU * j];
+                o.ar[j] = Fk[RR::oAcl + li + NX * j];
+            }
+            o.kv = Fk[RR::oKv + cq];
+            o.bk = Bk[k * NX + li];
+        };
+        double xr = X0[li], u = 0.0;
+        Ops cur, nxt;
+        fetch(0, cur);
+#pragma unroll COPRA_RIC_UNROLL
+        for (int k = 0; k < NH; ++k) {
+            fetch(k + 1 < NH ? k + 1 : NH - 1, nxt);
+            double m[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) m[j] = bcast_f64(xr, j);
+            double u0 = cur.kv, u1 = 0.0, a0 = cur.bk, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; j += 2) {
+                u0 += cur.kr[j] * m[j];
+                a0 += cur.ar[j] * m[j];
+                if (j + 1 < NX) {
+                    u1 += cur.kr[j + 1] * m[j + 1];
+                    a1 += cur.ar[j + 1] * m[j + 1];
+                }
+            }
+            u = (kq == k) ? u0 + u1 : u;
+            xr = a0 + a1;
+            cur = nxt;
+        }
+        if (lane < NV) S.xs[lane] = u;
+    }
+    COPRA_FINE("rollout");
+    rows.cache_own_row();
+    if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component
+    wave_sync();
+    stamp[3] = cycle_counter();
+    // ---- 4. implicit rows: norms (qpgen2: column norms of amat) ----
+    for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(rows.desc(i)));
+    wave_sync();
+    COPRA_FINE("norms");
+    stamp[4] = cycle_counter();
+    stamp[5] = stamp[4];
+    // ---- 5. active set ----
+    int it_main = 0, it_drop = 0;
+    if (status == 0)
+        status = gi_active_set<NV, true, QR, NX, NU>(S, NV, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+    wave_sync();
+    stamp[6] = cycle_counter();
+    if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else
+        if (lane == 0) {
+            const int slot = atomic_append(P.ovf_count);
+            P.ovf_list[slot] = inst;
+            P.status[inst] = 4;
+        }
+        return;
+    }
+    // ---- 6. results (LMPC.cpp:95-97: outputs only on success; failures are flagged with NaN) ----
+    if (status == 0) {
+        rows.refresh_trajectory(S.xs);
+        wave_sync();
+        for (int e = lane; e < NV; e += kWave) P.control[(size_t)inst * NV + e] = S.xs[e];
+        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = Xcur[e];
+    } else {
+        const double qnan = __builtin_nan("");
+        for (int e = lane; e < NV; e += kWave) P.control[(size_t)inst * NV + e] = qnan;
+        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = qnan;
+    }
+    if (lane == 0) {
+        P.status[inst] = status;
+        P.iter[2 * (size_t)inst] = it_main;
+        P.iter[2 * (size_t)inst + 1] = it_drop;
+#ifdef COPRA_FINE_PROFILE
+        if (P.prof_fine) {
+            long long* pf = P.prof_fine + 32 * (size_t)inst;
+            for (int k = 0; k < 32; ++k) pf[k] = (k < copra_fine_n) ? copra_fine[k] - stamp[0] : -1;
+        }
+#endif
+        if (P.prof) { // preview | Riccati sweep | roll-out | norms | - | active set | results | total
+            stamp[7] = cycle_counter();
+            long long* pr = P.prof + 8 * (size_t)inst;
+            for (int k = 0; k < 7; ++k) pr[k] = stamp[k + 1] - stamp[k];
+            pr[7] = stamp[7] - stamp[0];
+        }
+    }
+}
+
+} // namespace copra_hip

@@ -19,6 +19,7 @@ constexpr int kMaxCosts = 8;
 constexpr int kMaxFullRows = 16; // full-size constraint rows the workgroup-per-instance kernel evaluates cooperatively
 constexpr int kMaxNu = 8; // register arrays in the Hessian recursion (uDim <= 8 on the fused path)
 constexpr int kWarmCap = 32; // active rows remembered per instance for the warm start
+constexpr int kRicMaxCosts = 3; // cost terms the Riccati-factor tier takes (lmpc_fused_ric.hpp keeps the loads of all of them in flight)
 constexpr int kFusedQ1Regs = 5; // columns of Q1 the headline first-tier kernel keeps in registers (gi_core.hpp, QR)
 // lanes one instance works with: the 64-lane wavefront, or a 16-lane DPP row of it in the packed small-problem build
 // (copra_hip_packed.hip compiles the same kernel bodies with COPRA_WAVE_WIDTH = 16: four instances per wavefront)
@@ -80,6 +81,9 @@ struct LdsLayout {
              // the diagonal slots of the factor carry 1 / R(i,i)
     int Q1;
     int q1regs; // > 0 (factor-only layout): that many columns of Q1 live in registers, there is no Q1 region in LDS
+    int ric; // 1 (with tri and q1regs): the J region holds the RICCATI form of the factor (ric_factor.hpp: N stage records
+             // instead of the packed triangle), A / B / d / x0 keep their own slots and there are no cost tables
+    int ricS; // scratch of the Riccati sweep (aliases the solver vectors, which are written after it)
     int R; // packed upper-triangular R of the active set (rcap columns)
     int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one
     int xs, dv, zv, uv, ap, coef, cvec; // solver vectors (n; uv n+1; coef 4n)

@@ -165,6 +165,54 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     return true;
 }
 
+// Layout of the Riccati-factor tier (lmpc_fused_ric.hpp): the J region holds N stage records (ric_factor.hpp) and, before
+// them, nothing (the lean preview of that body writes G and Xbar in place); A / B / d / x0 keep their own slots because the
+// sweep reads them while it fills the records; no cost tables; the sweep's scratch aliases the solver vectors.
+inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, int mgen, int meq, int mtotal, bool xcur_late,
+    int q1regs, int budget)
+{
+    int o = 0;
+    auto take = [&](int count) {
+        int at = o;
+        o += align2(count);
+        return at;
+    };
+    L = LdsLayout {};
+    const int rec = (nx * nx + 2 * nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    L.ldj = (n % 2 == 0) ? n + 1 : n;
+    L.tri = 1;
+    L.ric = 1;
+    L.q1regs = q1regs;
+    L.rcap = q1regs;
+    L.G = take(N * nx * nu);
+    L.Xbar = take(X);
+    L.J = take(N * rec > X ? N * rec : X);
+    L.Xcur = xcur_late ? L.J : take(X);
+    L.A = take(nx * nx);
+    L.B = take(nx * nu);
+    L.D = take(nx);
+    L.X0 = take(nx);
+    L.BldPhi = L.BldXi = L.J; // (unused by the body)
+    const int vec0 = o;
+    L.ricS = vec0;
+    L.xs = take(n);
+    L.dv = L.zv = L.coef = L.xs;
+    L.ap = take(n);
+    L.cvec = L.ap;
+    L.nb = take(mgen > 0 ? mgen : 1);
+    L.eqsgn = take(meq > 0 ? meq : 1);
+    L.scal = take(2);
+    L.act = take((mtotal + 7) / 8 + 1);
+    L.uv = take(L.rcap + 2);
+    L.iact = take((L.rcap + 2) / 2 + 1);
+    L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
+    const int scratch = align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + align2(nu * (nx + 1)) + 2 + align2(N * nx);
+    if (o < vec0 + scratch) o = vec0 + scratch;
+    L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
+    L.total = o;
+    return o <= budget;
+}
+
 // Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
 // instance per CU fewer (at least four) and more room for active constraints; false when there is none.
 inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
@@ -696,10 +744,24 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             bool all_ident = true; // (state costs with M = I padded to nx rows: lmpc_fused.hpp reads G instead of Y)
             for (int t = 0; t < P.ncost; ++t)
                 all_ident = all_ident && (P.cost[t].kind == kCostControl || (P.cost[t].ident && rows == nx));
+            // Riccati form of the factor (lmpc_fused_ric.hpp): every cost a per-step entry, the headline instantiation
+            bool ric_ok = qregs > 0 && nu == 3 && N == 20 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state && P.ncost <= kRicMaxCosts
+                && !std::getenv("COPRA_NO_RIC");
+            for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full;
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
+                if (ric_ok && k == 8
+                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, qregs, budget)) {
+                    hp.lds_safe = P.lds;
+                    hp.safe_two_tier = hp.two_tier;
+                    hp.two_tier = true;
+                    hp.dense = true;
+                    P.lds = t;
+                    break;
+                }
+                t = LdsLayout {};
                 if (qregs > 0
                     && layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0, qregs,
                         all_ident)

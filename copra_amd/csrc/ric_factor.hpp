@@ -1,0 +1,172 @@
+// Riccati form of the factor of the condensed LMPC Hessian (factor-only tier of the fused kernel, lmpc_fused_ric.hpp).
+//
+// The condensed Hessian Q = Psi' W Psi + N'WN + 1e-6 I (LMPC.cpp:228-230, 252-255 after costFunctions.cpp:63-215) of a
+// controller whose costs are all per-step entries is the Hessian of a stage-wise LQ problem.  One backward Riccati sweep
+// over the N stages (O(N nx^3) instead of the O(n^3) Cholesky of the n x n matrix) gives, per stage k,
+//     Lam_k Lam_k' = M_uu,k            (Cholesky of the nu x nu control block)
+//     K_k = -M_uu,k^-1 M_ux,k ,  Acl_k = A + B K_k ,  Bt_k = B Lam_k^-T
+// and with them a factor Q^-1 = Rinv Rinv' whose two products are closed-loop recursions over the stages:
+//     z = Rinv v   :  xi_0 = 0;   z_k = K_k xi_k + Lam_k^-T v_k;   xi_{k+1} = Acl_k xi_k + Bt_k v_k          (forward)
+//     w = Rinv' n  :  mu_N = 0;   w_k = Lam_k^-1 n_k + Bt_k' mu_{k+1};   mu_k = Acl_k' mu_{k+1} + K_k' n_k   (backward)
+// These are the ONLY two operations the factor-only Goldfarb-Idnani iteration applies to the factor (gi_core.hpp, TRI:
+// w = R^-T n+, z = R^-1 (w - Q1 d1)); qpgen2's J = R^-1 [Q1 Q2] differs from this choice of R by an orthogonal factor that
+// cancels in every quantity the method looks at, so the steps, the active sets and the iterates are the same up to rounding.
+// (Check of the algebra in numpy: tools/exp/ric_factor_proto.py.)
+//
+// Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
+//     Acl (NX x NX, column-major) | Bt (NX x NU, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (NU x NU, column-major,
+//     lower triangular, the upper part stored as zeros) | kv (NU: feed-forward of the unconstrained minimiser)
+#pragma once
+
+#ifndef COPRA_RIC_UNROLL
+#define COPRA_RIC_UNROLL 2 // stages per loop body of the recursions (fully unrolled they spill 800 SGPRs: every broadcast is hoisted)
+#endif
+
+namespace copra_hip {
+
+// 1 / x: v_rcp_f64 seed + two Newton steps
+COPRA_DEV double ric_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
+
+template <int NX, int NU>
+struct RicRec {
+    static constexpr int oAcl = 0;
+    static constexpr int oBt = oAcl + NX * NX;
+    static constexpr int oK = oBt + NX * NU;
+    static constexpr int oLi = oK + NU * NX;
+    static constexpr int oKv = oLi + NU * NU;
+    static constexpr int SZ = (oKv + NU + 1) & ~1;
+};
+
+// Both recursions keep the operands of the NEXT stage in registers while the current one is evaluated (the loads do not
+// depend on the recursion's state, so their LDS latency hides under the dependent multiply-adds), and split every inner
+// product into two or three independent partial sums.
+
+// w = Rinv' n.  Lane 3k + c holds component c of n_k in `nl` and receives component c of w_k (lanes >= NU NH: 0).
+template <int NX, int NU, int NH>
+COPRA_DEV double ric_apply_transposed(const double* F, double nl)
+{
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id();
+    const int li = lane < NX ? lane : NX - 1;
+    const int kq = lane / NU, cq = lane - kq * NU;
+    struct Ops {
+        double lr[NU], bt[NX], kc[NU], ac[NX];
+    };
+    auto fetch = [&](int k, Ops& o) {
+        const double* Fk = F + k * RR::SZ;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            o.lr[c] = Fk[RR::oLi + cq + NU * c]; // row cq of Lam^-1
+            o.kc[c] = Fk[RR::oK + c + NU * li]; // column li of K
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            o.bt[j] = Fk[RR::oBt + j + NX * cq]; // column cq of Bt
+            o.ac[j] = Fk[RR::oAcl + j + NX * li]; // column li of Acl
+        }
+    };
+    double mu = 0.0, w = 0.0;
+    Ops cur, nxt;
+    fetch(NH - 1, cur);
+#pragma unroll COPRA_RIC_UNROLL
+    for (int k = NH - 1; k >= 0; --k) {
+        fetch(k > 0 ? k - 1 : 0, nxt);
+        double m[NX], nk[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) nk[c] = bcast_f64(nl, NU * k + c);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) m[j] = bcast_f64(mu, j); // (mu_N = 0)
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            w0 += cur.lr[c] * nk[c];
+            a0 += cur.kc[c] * nk[c];
+        }
+#pragma unroll
+        for (int j = 0; j < NX; j += 2) {
+            w1 += cur.bt[j] * m[j];
+            a1 += cur.ac[j] * m[j];
+            if (j + 1 < NX) {
+                w2 += cur.bt[j + 1] * m[j + 1];
+                a2 += cur.ac[j + 1] * m[j + 1];
+            }
+        }
+        w = (kq == k) ? w0 + (w1 + w2) : w;
+        mu = a0 + (a1 + a2);
+        cur = nxt;
+    }
+    return w;
+}
+
+// z = Rinv v.  Lane 3k + c holds component c of v_k in `vl` and receives component c of z_k (lanes >= NU NH: 0).
+// XI != nullptr: the closed-loop states xi_k (k = 0 .. NH) -- the response Psi z of the state trajectory to z -- are stored
+// there, NX per stage.
+template <int NX, int NU, int NH>
+COPRA_DEV double ric_apply(const double* F, double vl, double* XI = nullptr)
+{
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id();
+    const int li = lane < NX ? lane : NX - 1;
+    const int kq = lane / NU, cq = lane - kq * NU;
+    struct Ops {
+        double lc[NU], kr[NX], br[NU], ar[NX];
+    };
+    auto fetch = [&](int k, Ops& o) {
+        const double* Fk = F + k * RR::SZ;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            o.lc[c] = Fk[RR::oLi + c + NU * cq]; // row cq of Lam^-T
+            o.br[c] = Fk[RR::oBt + li + NX * c]; // row li of Bt
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            o.kr[j] = Fk[RR::oK + cq + NU * j]; // row cq of K
+            o.ar[j] = Fk[RR::oAcl + li + NX * j]; // row li of Acl
+        }
+    };
+    double xi = 0.0, z = 0.0;
+    Ops cur, nxt;
+    fetch(0, cur);
+#pragma unroll COPRA_RIC_UNROLL
+    for (int k = 0; k < NH; ++k) {
+        fetch(k + 1 < NH ? k + 1 : NH - 1, nxt);
+        if (XI && lane < NX) XI[k * NX + lane] = xi;
+        double m[NX], vk[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) vk[c] = bcast_f64(vl, NU * k + c);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) m[j] = bcast_f64(xi, j); // (xi_0 = 0)
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            z0 += cur.lc[c] * vk[c];
+            a0 += cur.br[c] * vk[c];
+        }
+#pragma unroll
+        for (int j = 0; j < NX; j += 2) {
+            z1 += cur.kr[j] * m[j];
+            a1 += cur.ar[j] * m[j];
+            if (j + 1 < NX) {
+                z2 += cur.kr[j + 1] * m[j + 1];
+                a2 += cur.ar[j + 1] * m[j + 1];
+            }
+        }
+        z = (kq == k) ? z0 + (z1 + z2) : z;
+        xi = a0 + (a1 + a2);
+        cur = nxt;
+    }
+    if (XI && lane < NX) XI[NH * NX + lane] = xi;
+    return z;
+}
+
+} // namespace copra_hip

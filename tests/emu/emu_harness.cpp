@@ -4,6 +4,7 @@
 
 #include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
+#include "../../copra_amd/csrc/lmpc_fused_ric.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati.hpp"
 #include "../../copra_amd/csrc/lmpc_shared.hpp"
@@ -189,6 +190,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[4] = 0;
         sizes[5] = P.lds.rcap;
         sizes[6] = P.lds.tri;
+        sizes[7] = P.lds.ric;
     }
     if (!A) return 0; // size query only
     if (P.use_large) { // workgroup-per-instance kernel: one resident workgroup walks the batch (persistent grid)
@@ -230,7 +232,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
     auto body = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
+        if (PP.lds.tri && PP.lds.ric) // (select_fused_kernel: the factor in Riccati form)
+            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
+        else if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)
             lmpc_fused_body<6, 3, 20, 6, true>(PP, b);

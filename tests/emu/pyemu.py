@@ -100,7 +100,8 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
                               p(x0o) if x0o is not None else vp())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
-    out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3], overflowed=sizes[4], rcap=sizes[5], factor_only=bool(sizes[6]))
+    out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3], overflowed=sizes[4], rcap=sizes[5], factor_only=bool(sizes[6]),
+               riccati_factor=bool(sizes[7]))
     if x0o is not None:
         out["x0_opt"] = x0o
     if dump_instance >= 0:

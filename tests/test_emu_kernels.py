@@ -111,6 +111,33 @@ def test_headline_shape_every_per_step_cost_kind(emu, oracle, order):
         _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], spec)
 
 
+def test_riccati_factor_tier_selection_and_parity(emu, oracle):
+    """lmpc_fused_ric.hpp (the factor of the condensed Hessian in Riccati form): what the plan builder picks for the headline
+    shape when every cost is a per-step entry (at most kRicMaxCosts of them); statuses, iteration counts and controls
+    against the oracle on the tight workload (instances that overflow the five register columns finish in the second
+    tier), with per-instance references, and with an instance whose QP is infeasible (reference quirk Q5)"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(12, v_max=0.25, u_max=1.2, seed=4)
+    x0 = wl["x0"].copy()
+    x0[3, 3] = 0.9  # velocity beyond the bound at step 0: infeasible
+    goals = wl["costs"][0]["p"][None, :] + 0.2 * np.random.default_rng(3).standard_normal((12, 6))
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], wl["costs"], wl["cstrs"], cost_refs={0: goals})
+    assert re["riccati_factor"] and re["factor_only"] and re["overflowed"] > 0
+    for k in range(12):
+        costs = [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], x0[k], wl["N"], costs, wl["cstrs"])
+        assert re["status"][k] == ro["status"], k
+        if ro["status"] == 0:
+            assert tuple(re["iter"][k]) == tuple(ro["iter"])
+            assert np.abs(re["control"][k] - ro["control"]).max() <= 1e-9 * (1 + np.abs(ro["control"]).max())
+            assert np.abs(re["trajectory"][k] - ro["trajectory"]).max() <= 1e-9 * (1 + np.abs(ro["trajectory"]).max())
+    assert re["status"][3] == 1
+    traj, ctrl = wl["costs"]
+    four = [traj, ctrl, dict(kind="target", M=np.eye(6)[:2], p=traj["p"][:2], weights=[1.0, 1.0]),
+            dict(kind="control", N=np.eye(3), p=np.zeros(3), weights=[1e-4] * 3)]
+    assert not emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], four, wl["cstrs"])["riccati_factor"]
+
+
 def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
     """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
     from copra_amd import workloads

@@ -744,7 +744,9 @@ def test_per_instance_cost_references(oracle):
     eng.solve()
     again = eng.results()
     ok = base["status"] == 0
-    assert np.array_equal(again["status"], base["status"]) and np.abs(again["control"][ok] - base["control"][ok]).max() <= 1e-12
+    # (not bit-identical: the solve with the scattered goals overflowed the first tier often enough for the engine to step
+    #  down its layout ladder, so this third solve may run a different kernel -- other factorisation, same optimum)
+    assert np.array_equal(again["status"], base["status"]) and np.abs(again["control"][ok] - base["control"][ok]).max() <= 1e-10
     # shared-model path: c = c0 + C1 x0 + C2 p, probed once; goals of a second tick reuse the factorisation
     sh = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     sh.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
