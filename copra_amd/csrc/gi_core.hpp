@@ -67,6 +67,7 @@ struct SolverLds {
     const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr);
                         // factor-only layout: the packed factor R instead, and ...
     const double* rinv_src; // ... 1 / R(i,i)
+    double* ricx; // Riccati-factor tier: 64 doubles for the hand-over of the MFMA recursions (ric_factor.hpp)
 };
 
 COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
@@ -90,6 +91,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.scal = lds + L.scal;
     S.act = reinterpret_cast<unsigned char*>(lds + L.act);
     S.iact = reinterpret_cast<int*>(lds + L.iact);
+    S.ricx = lds + L.ricX;
     return S;
 }
 
@@ -582,7 +584,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 double wk = 0.0;
                 double rinv_own = 0.0;
                 if constexpr (RNX > 0) {
-                    wk = ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
+                    wk = COPRA_RIC_MFMA ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
+                                        : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
                 } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
@@ -642,7 +645,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 acc = vj;
                 double zk = 0.0;
                 if constexpr (RNX > 0) {
-                    zk = ric_apply<RNX, RNU, NV / RNU>(J, vj);
+                    zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
                 } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];

@@ -22,6 +22,10 @@
 #define COPRA_RIC_UNROLL 2 // stages per loop body of the recursions (fully unrolled they spill 800 SGPRs: every broadcast is hoisted)
 #endif
 
+#ifndef COPRA_RIC_MFMA
+#define COPRA_RIC_MFMA 1 // the recursions of the active-set iteration on the matrix cores (0: v_readlane + vector-ALU version)
+#endif
+
 namespace copra_hip {
 
 // 1 / x: v_rcp_f64 seed + two Newton steps
@@ -167,6 +171,84 @@ COPRA_DEV double ric_apply(const double* F, double vl, double* XI = nullptr)
     }
     if (XI && lane < NX) XI[NH * NX + lane] = xi;
     return z;
+}
+
+// ---- the same two products on the matrix cores -------------------------------------------------------------------
+// One stage of either recursion is a small matrix-vector product,  [xi+; z_k] = [Acl Bt; K Lam^-T] [xi; v_k]  (and its
+// transpose for w), and v_mfma_f64_16x16x4_f64 has the property that makes a CHAIN of them free of data movement: the
+// result D(row = (lane >> 4) + 4 reg, col = lane & 15) of one product is laid out exactly as the B operand (k = lane >> 4,
+// col = lane & 15) of the next one, K-block `reg`.  So the recursion state never leaves the accumulator registers -- no
+// v_readlane broadcasts (18 per stage in the plain version), no multiply-adds on the vector ALU (18 per stage): three
+// MFMAs, three LDS reads of matrix elements and one of the input per stage.  All 16 columns carry the same vector.
+// Stacked index s = 4 blk + (lane >> 4):  0 .. NX-1 state components (NX <= 8) | 8 .. 8+NU-1 input / output components.
+template <int NX, int NU>
+COPRA_DEV int ric_stack_offset(int s_out, int s_in)
+{
+    using RR = RicRec<NX, NU>;
+    static_assert(NX <= 8 && NU >= 2 && NU <= 4, "stacked layout of the MFMA recursions");
+    const int zero = RR::oLi + NU; // Lam^-1(0, 1): stored as zero in every record
+    const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
+    const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
+    if (to == 2 || ti == 2) return zero;
+    const int a = to == 0 ? s_out : s_out - 8, b = ti == 0 ? s_in : s_in - 8;
+    if (to == 0) return ti == 0 ? RR::oAcl + a + NX * b : RR::oBt + a + NX * b; // Acl(a, b) | Bt(a, b)
+    return ti == 0 ? RR::oK + a + NU * b : RR::oLi + b + NU * a; // K(a, b) | Lam^-T(a, b) = Lam^-1(b, a)
+}
+
+// w = Rinv' n with n in LDS (nvec[0 .. NU NH)); X: NU NH doubles of LDS for the hand-over.  Returns component `lane` of w.
+template <int NX, int NU, int NH>
+COPRA_DEV double ric_apply_transposed_mfma(const double* F, const double* nvec, double* X)
+{
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15;
+    int off[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) off[b] = ric_stack_offset<NX, NU>(4 * b + g, j); // element (row j, column 4 b + g) of the TRANSPOSE
+    const double* np = nvec + (g < NU ? g : 0);
+    mfma_acc prev = { { 0.0, 0.0, 0.0, 0.0 } };
+#pragma unroll COPRA_RIC_UNROLL
+    for (int k = NH - 1; k >= 0; --k) {
+        const double* Fk = F + k * RR::SZ;
+        const double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]];
+        const double nk = np[NU * k];
+        mfma_acc y = { { 0.0, 0.0, 0.0, 0.0 } };
+        mfma_f64_16x16x4(a2, nk, y); // (does not wait for the previous stage)
+        mfma_f64_16x16x4(a0, prev.v[0], y);
+        mfma_f64_16x16x4(a1, prev.v[1], y);
+        if (g < NU) X[NU * k + g] = y.v[2];
+        prev = y;
+    }
+    wave_sync();
+    return lane < NU * NH ? X[lane] : 0.0;
+}
+
+// z = Rinv v; lane 3k + c holds component c of v_k in `vl`.  Returns component `lane` of z.
+template <int NX, int NU, int NH>
+COPRA_DEV double ric_apply_mfma(const double* F, double vl, double* X)
+{
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15;
+    int off[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) off[b] = ric_stack_offset<NX, NU>(j, 4 * b + g);
+    if (lane < NU * NH) X[lane] = vl;
+    wave_sync();
+    double* xp = X + (g < NU ? g : 0);
+    mfma_acc prev = { { 0.0, 0.0, 0.0, 0.0 } };
+#pragma unroll COPRA_RIC_UNROLL
+    for (int k = 0; k < NH; ++k) {
+        const double* Fk = F + k * RR::SZ;
+        const double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]];
+        const double vk = xp[NU * k];
+        mfma_acc y = { { 0.0, 0.0, 0.0, 0.0 } };
+        mfma_f64_16x16x4(a2, vk, y);
+        mfma_f64_16x16x4(a0, prev.v[0], y);
+        mfma_f64_16x16x4(a1, prev.v[1], y);
+        if (g < NU) xp[NU * k] = y.v[2]; // (in place: every lane has read v_k)
+        prev = y;
+    }
+    wave_sync();
+    return lane < NU * NH ? X[lane] : 0.0;
 }
 
 } // namespace copra_hip

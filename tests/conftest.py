@@ -18,3 +18,17 @@ def oracle():
     import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: bring torch's HIP runtime up BEFORE the first test drives the device through libcopra_hip.so.  A test that
+    is the first to touch torch.cuda late in a session (after hundreds of launches through the C ABI in the same process)
+    has been seen to fail with "No HIP GPUs are available" on the GPU box; with the runtime initialised first it never does."""
+    if not any(item.get_closest_marker("gpu") for item in items):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:  # no torch / no GPU: the tests that need them say so themselves
+        pass
