@@ -584,8 +584,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 double wk = 0.0;
                 double rinv_own = 0.0;
                 if constexpr (RNX > 0) {
-                    wk = COPRA_RIC_MFMA ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
-                                        : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
+                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ricx)
+                        : COPRA_RIC_MFMA   ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
+                                           : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
                 } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
@@ -645,7 +646,13 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 acc = vj;
                 double zk = 0.0;
                 if constexpr (RNX > 0) {
-                    zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
+                    if (COPRA_RIC_MFMA == 2) {
+                        if (lane < n) S.ricx[lane] = vj;
+                        wave_sync();
+                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ricx, S.ricx);
+                    } else {
+                        zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
+                    }
                 } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];

@@ -60,6 +60,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         D[e] = P.d[(size_t)inst * NX + e];
         X0[e] = P.x0[(size_t)inst * NX + e];
     }
+    COPRA_FINE("ric:sys");
     // ---- 0b. stage costs (they do not depend on the system: their loads overlap the ones above) ----
     // lane -> entry (a, b) of M = Hin + [A B]' P+ [A B] that it owns in the sweep:  x-x upper triangle | u-x | u-u upper
     // triangle | the affine column (b == NZ)
@@ -86,63 +87,36 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     } else {
         m_on = false;
     }
-    // Branch-free: every lane loads from a valid address and switches its term off by a select, the rows of a term are
-    // padded to RP (clamped index, masked), so that the 4 RP loads of a term are in flight together.
-    double hreg = 0.0; // Hin(ma, mb), or hin(ma) in the affine column
-    double term = 0.0; // lanes e < NX NX: HN(e % NX, e / NX);  the next NX lanes: hN
+    // The plan builder has evaluated them per lane (plan_builder.hpp, build_ric_tables): entry of Hin / HN, and for the
+    // affine lanes the coefficients of the references p_t, which may be per-instance -- 2 + 4 RP coalesced loads per cost.
     const int pi = lane % NX, pj = lane / NX; // element (pi, pj) of an NX x (NZ + 1) table: [A B d] layout
+    double hreg, term; // Hin(ma, mb) or hin(ma) in the affine column | lanes e < NX NX: HN(e % NX, e / NX), the next NX: hN
     {
         const int ti = pi, tj = pj; // tj == NX: hN
-        // (all terms unrolled, a missing one clamped to the last and masked: the loads of every term are issued before the
-        //  first multiply-add waits for any of them -- one round trip to L2 instead of one per term)
-        double va[kRicMaxCosts][RP], vb[kRicMaxCosts][RP], vc[kRicMaxCosts][RP], vd[kRicMaxCosts][RP], vw[kRicMaxCosts][RP];
-        bool on_s[kRicMaxCosts], on_t[kRicMaxCosts];
-        double sb = (mb < NZ) ? 1.0 : -1.0, sd = (tj < NX) ? 1.0 : -1.0; // (the affine column pairs with -p)
+        const double* tab = P.params + P.ric_tab;
+        hreg = tab[lane];
+        term = tab[kWave + lane];
+        double cw[kRicMaxCosts][RP], ct2[kRicMaxCosts][RP], pr[kRicMaxCosts][RP];
 #pragma unroll
         for (int t = 0; t < kRicMaxCosts; ++t) {
             const bool live = t < P.ncost;
-            const CostTerm& ct = P.cost[live ? t : 0];
-            const int rc = ct.rows;
-            const double* pref = cost_reference(P, live ? t : 0, inst);
-            const bool in_stage = ct.kind != kCostTarget; // TargetCost: the last state only (costFunctions.cpp:107-120)
-            const bool in_term = ct.kind == kCostTrajectory || ct.kind == kCostTarget; // MixedCost stops at x_{N-1} (:207)
-            const bool useM = ct.offM >= 0 && ct.kind != kCostControl;
-            const bool useN = ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed);
-            // offset of column `a` of [M_t N_t] in the blob, or -1
-            auto col_off = [&](int a) { return a < NX ? (useM ? ct.offM + rc * a : -1) : (useN ? ct.offN + rc * (a - NX) : -1); };
-            const int oa = col_off(ma), ob = (mb < NZ) ? col_off(mb) : 0;
-            const int oc = col_off(ti), od = (tj < NX) ? col_off(tj) : 0;
-            on_s[t] = live && in_stage && m_on && oa >= 0 && ob >= 0;
-            on_t[t] = live && in_term && tj <= NX && oc >= 0 && od >= 0;
-            const double* pa = P.params + (oa >= 0 ? oa : ct.offW);
-            const double* pb = (mb < NZ) ? P.params + (ob >= 0 ? ob : ct.offW) : pref;
-            const double* pc = P.params + (oc >= 0 ? oc : ct.offW);
-            const double* pd = (tj < NX) ? P.params + (od >= 0 ? od : ct.offW) : pref;
+            const int tt = live ? t : 0;
+            const int rc = P.cost[tt].rows;
+            const double* pref = cost_reference(P, tt, inst);
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
-                const int rr = r < rc ? r : rc - 1;
-                vw[t][r] = (r < rc) ? P.params[ct.offW + rr] : 0.0; // (a padded row has weight zero)
-                va[t][r] = pa[rr];
-                vb[t][r] = pb[rr];
-                vc[t][r] = pc[rr];
-                vd[t][r] = pd[rr];
+                cw[t][r] = tab[kWave * (2 + 2 * (tt * RP + r)) + lane];
+                ct2[t][r] = tab[kWave * (2 + 2 * (tt * RP + r) + 1) + lane];
+                pr[t][r] = live ? pref[r < rc ? r : rc - 1] : 0.0; // (rows past the term's have zero coefficients)
             }
         }
 #pragma unroll
-        for (int t = 0; t < kRicMaxCosts; ++t) {
+        for (int t = 0; t < kRicMaxCosts; ++t)
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
-                const double hs = (va[t][r] * vw[t][r]) * (sb * vb[t][r]);
-                const double ht = (vc[t][r] * vw[t][r]) * (sd * vd[t][r]);
-                hreg += on_s[t] ? hs : 0.0;
-                term += on_t[t] ? ht : 0.0;
+                hreg += cw[t][r] * pr[t][r];
+                term += ct2[t][r] * pr[t][r];
             }
-        }
-        if (m_on && ma == mb && ma >= NX) {
-            double one = 1.0;
-            one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;  (LMPC.cpp:228-229)
-            hreg += one;
-        }
         if (tj < NX)
             Pm[lane] = term;
         else if (tj == NX)
@@ -325,6 +299,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         }
         COPRA_FINE("sweep:loop");
         if (bad) status = 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
+        rows.cache_own_row(); // (global loads of this lane's row descriptor and bounds: their latency hides under the passes below)
         // Lam^-1 of every stage (lane = stage): Cholesky of the stored M_uu, inverted in place of it
         if (lane < NH) {
             double* Fk = F + lane * RR::SZ;
@@ -384,37 +359,43 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     COPRA_FINE("sweep:Bt");
     stamp[2] = cycle_counter();
     // ---- 3. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k bkd_k; K_k kv_k] [x_k; 1] from x_0, on the matrix
-    //      cores like the recursions of ric_factor.hpp (the state stays in the accumulator layout) ----
+    //      cores like the recursions of ric_factor.hpp (v_mfma_f64_4x4x4: block b of the lane = rows 4b .. 4b+3 of the
+    //      stacked matrix, the state handed on by a DPP row broadcast) ----
     {
-        const int g = lane >> 4, j = lane & 15;
+        const int q = lane >> 4, b4 = (lane >> 2) & 3, r = lane & 3, row = 4 * b4 + r;
         int off[2];
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) off[b2] = ric_stack_offset<NX, NU>(j, 4 * b2 + g);
-        // K-block 2: the constant 1 at stacked index 8 (g == 0) times the column [bkd; kv]
+        for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU>(row, 4 * J + q);
+        // K-block 2: the constant 1 at stacked component 8 (lane row q == 0) times the column [bkd; kv]
         const double* p2 = F + RR::oLi + NU; // (a zero of every record)
         int st2 = RR::SZ;
-        if (g == 0 && j < NX) {
-            p2 = Bk + j;
+        if (q == 0 && row < NX) {
+            p2 = Bk + row;
             st2 = NX;
-        } else if (g == 0 && j >= 8 && j < 8 + NU) {
-            p2 = F + RR::oKv + (j - 8);
+        } else if (q == 0 && row >= 8 && row < 8 + NU) {
+            p2 = F + RR::oKv + (row - 8);
         }
-        const double one = (g == 0) ? 1.0 : 0.0;
-        mfma_acc prev = { { X0[g < NX ? g : 0], (4 + g < NX) ? X0[4 + g < NX ? 4 + g : 0] : 0.0, 0.0, 0.0 } };
+        const double one = (q == 0) ? 1.0 : 0.0;
+        const bool writer = q < NU && b4 == 2 && r == 0;
+        double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
+        double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0];
 #pragma unroll COPRA_RIC_UNROLL
         for (int k = 0; k < NH; ++k) {
-            const double* Fk = F + k * RR::SZ;
-            const double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = p2[k * st2];
-            mfma_acc y = { { 0.0, 0.0, 0.0, 0.0 } };
-            mfma_f64_16x16x4(a2, one, y);
-            mfma_f64_16x16x4(a0, prev.v[0], y);
-            mfma_f64_16x16x4(a1, prev.v[1], y);
-            if (g < NU) S.xs[NU * k + g] = y.v[2];
-            prev = y;
+            const int kn = k + 1 < NH ? k + 1 : k;
+            const double* Fn = F + kn * RR::SZ;
+            const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = p2[kn * st2];
+            double y = mfma_f64_4x4x4(a2, one, 0.0);
+            y = mfma_f64_4x4x4(a0, s0, y);
+            y = mfma_f64_4x4x4(a1, s1, y);
+            if (writer) S.xs[NU * k + q] = y;
+            s0 = row_bcast_f64<0>(y);
+            s1 = row_bcast_f64<4>(y);
+            a0 = n0;
+            a1 = n1;
+            a2 = n2;
         }
     }
     COPRA_FINE("rollout");
-    rows.cache_own_row();
     if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component
     wave_sync();
     stamp[3] = cycle_counter();

@@ -183,6 +183,10 @@ struct FusedPlan {
     // Q (n x n, column-major, both triangles), c (n), E (nx x n), f (n)
     int denseQ, densec, denseE, densef;
     int rmax; // max rows over the per-step costs
+    // Riccati-factor tier (lmpc_fused_ric.hpp): per-lane stage-cost tables in `params`, built by the plan builder --
+    //   [0, 64): Hin entry of the lane | [64, 128): HN entry | then per cost t and row r < 6 two vectors of 64: the
+    //   coefficient of p_t[r] in the lane's Hin / HN entry (non-zero on the affine lanes only).  -1: no tables.
+    int ric_tab;
     int rfull; // max rows over the full-size costs (0 if none)
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)

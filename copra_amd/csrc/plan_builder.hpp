@@ -214,6 +214,79 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     return o <= budget;
 }
 
+// Stage-cost tables of the Riccati-factor tier (FusedPlan::ric_tab): what lane `l` of lmpc_fused_ric_body owns in the sweep
+// is entry (a, b) of  M = Hin + [A B]' P+ [A B]  over z = (x, u) -- x-x upper triangle | u-x | u-u upper triangle | the affine
+// column b == nz -- and entry (l % nx, l / nx) of the terminal [HN | hN].  Hin = sum_t [M_t N_t]' W_t [M_t N_t] (+ 1e-6 I on
+// u: LMPC.cpp:228-229) does not depend on the instance; the affine entries are linear in the references p_t, which may be
+// per-instance (copra_batch_set_cost_reference): the tables hold their coefficients.
+inline int build_ric_tables(HostPlan& hp, int rp)
+{
+    FusedPlan& P = hp.plan;
+    const int nx = P.nx, nu = P.nu, nz = nx + nu;
+    const int nxx = nx * (nx + 1) / 2, nux = nu * nx, nuu = nu * (nu + 1) / 2;
+    std::vector<double> tab((size_t)kWave * (2 + 2 * kRicMaxCosts * rp), 0.0);
+    auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]
+        if (a < nx) return (ct.offM >= 0 && ct.kind != kCostControl) ? hp.params[(size_t)ct.offM + r + ct.rows * a] : 0.0;
+        return (ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed)) ? hp.params[(size_t)ct.offN + r + ct.rows * (a - nx)] : 0.0;
+    };
+    for (int lane = 0; lane < kWave; ++lane) {
+        int ma = 0, mb = 0;
+        bool on = true;
+        auto tri = [](int t, int& lo, int& hi) {
+            hi = 0;
+            while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+            lo = t - hi * (hi + 1) / 2;
+        };
+        if (lane < nxx) {
+            tri(lane, ma, mb);
+        } else if (lane < nxx + nux) {
+            ma = nx + (lane - nxx) % nu;
+            mb = (lane - nxx) / nu;
+        } else if (lane < nxx + nux + nuu) {
+            tri(lane - nxx - nux, ma, mb);
+            ma += nx;
+            mb += nx;
+        } else if (lane < nxx + nux + nuu + nz) {
+            ma = lane - nxx - nux - nuu;
+            mb = nz;
+        } else {
+            on = false;
+        }
+        const int ti = lane % nx, tj = lane / nx; // terminal: tj < nx entry of HN, tj == nx entry ti of hN
+        double h0 = 0.0, t0 = 0.0;
+        for (int t = 0; t < P.ncost; ++t) {
+            const CostTerm& ct = P.cost[t];
+            const bool in_stage = ct.kind != kCostTarget; // TargetCost: the last state only (costFunctions.cpp:107-120)
+            const bool in_term = ct.kind == kCostTrajectory || ct.kind == kCostTarget; // MixedCost stops at x_{N-1} (:207)
+            for (int r = 0; r < ct.rows && r < rp; ++r) {
+                const double w = hp.params[(size_t)ct.offW + r];
+                if (on && in_stage) {
+                    if (mb < nz)
+                        h0 += (coef(ct, r, ma) * w) * coef(ct, r, mb);
+                    else
+                        tab[(size_t)kWave * (2 + 2 * (t * rp + r)) + lane] = -(coef(ct, r, ma) * w);
+                }
+                if (in_term && tj <= nx) {
+                    if (tj < nx)
+                        t0 += (coef(ct, r, ti) * w) * coef(ct, r, tj);
+                    else
+                        tab[(size_t)kWave * (2 + 2 * (t * rp + r) + 1) + lane] = -(coef(ct, r, ti) * w);
+                }
+            }
+        }
+        if (on && ma == mb && ma >= nx) {
+            double one = 1.0;
+            one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;  (LMPC.cpp:228-229)
+            h0 += one;
+        }
+        tab[lane] = h0;
+        tab[kWave + lane] = t0;
+    }
+    const int at = (int)hp.params.size();
+    hp.params.insert(hp.params.end(), tab.begin(), tab.end());
+    return at;
+}
+
 // Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
 // instance per CU fewer (at least four) and more room for active constraints; false when there is none.
 inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
@@ -310,6 +383,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             for (int e = 0; e < U; ++e) df[(size_t)e] += c.f[e];
     }
     P.denseQ = P.densec = P.denseE = P.densef = -1;
+    P.ric_tab = -1;
     if (!dQ.empty()) {
         P.denseQ = push(dQ.data(), U * U);
         P.densec = push(dc.data(), U);
@@ -760,6 +834,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     hp.two_tier = true;
                     hp.dense = true;
                     P.lds = t;
+                    P.ric_tab = build_ric_tables(hp, rp);
                     break;
                 }
                 t = LdsLayout {};

@@ -23,7 +23,7 @@
 #endif
 
 #ifndef COPRA_RIC_MFMA
-#define COPRA_RIC_MFMA 1 // the recursions of the active-set iteration on the matrix cores (0: v_readlane + vector-ALU version)
+#define COPRA_RIC_MFMA 2 // the recursions of the active-set iteration: 2 = v_mfma_f64_4x4x4 (+ DPP row broadcasts), 1 = v_mfma_f64_16x16x4, 0 = v_readlane + vector ALU
 #endif
 
 namespace copra_hip {
@@ -246,6 +246,51 @@ COPRA_DEV double ric_apply_mfma(const double* F, double vl, double* X)
         mfma_f64_16x16x4(a1, prev.v[1], y);
         if (g < NU) xp[NU * k] = y.v[2]; // (in place: every lane has read v_k)
         prev = y;
+    }
+    wave_sync();
+    return lane < NU * NH ? X[lane] : 0.0;
+}
+
+// ---- the same on v_mfma_f64_4x4x4_4b_f64 -------------------------------------------------------------------------
+// A 16 x 16 x 4 FP64 MFMA occupies the matrix pipe of its SIMD for 64 cycles, and with two waves per SIMD the three of a
+// stage cost ~400 cycles (measured; profiles/r02/mfma_f64_4x4x4_probe.txt).  The 4 x 4 x 4 instruction computes four
+// independent 4 x 4 blocks in 16 cycles: block b of instruction J multiplies rows 4b .. 4b+3 of the stacked matrix by K-block
+// J of the stacked vector, the three instructions of a stage accumulate in place.  Result rows 4b + i sit in quad b of lane
+// row i; the next stage needs K-block J in EVERY quad of row k -- one DPP row broadcast of lane 4 J per block.
+// lane = 16 q + 4 b + r:  A operand (row 4b + r, column 4J + q), B operand: component 4J + q of the vector in all lanes of row q.
+template <int NX, int NU, int NH, bool TR>
+COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X)
+{
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
+    int off[3];
+#pragma unroll
+    for (int J = 0; J < 3; ++J)
+        off[J] = TR ? ric_stack_offset<NX, NU>(4 * J + q, 4 * b + r) : ric_stack_offset<NX, NU>(4 * b + r, 4 * J + q);
+    const double* ip = in + (q < NU ? q : 0);
+    double* const op = X + (q < NU ? q : 0);
+    const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
+    double s0 = 0.0, s1 = 0.0; // K-blocks 0 and 1 of the state (stacked components 0..3 and 4..7), one per lane row
+    // (the operands of the next stage are fetched while the current one runs: their LDS latency is off the chain)
+    const int kfirst = TR ? NH - 1 : 0, kstep = TR ? -1 : 1;
+    const double* Fk = F + kfirst * RR::SZ;
+    double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]], vk = ip[NU * kfirst];
+#pragma unroll COPRA_RIC_UNROLL
+    for (int t = 0; t < NH; ++t) {
+        const int k = kfirst + kstep * t;
+        const int kn = (t + 1 < NH) ? k + kstep : k;
+        const double* Fn = F + kn * RR::SZ;
+        const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = Fn[off[2]], nv = ip[NU * kn];
+        double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
+        y = mfma_f64_4x4x4(a0, s0, y);
+        y = mfma_f64_4x4x4(a1, s1, y);
+        if (writer) op[NU * k] = y;
+        s0 = row_bcast_f64<0>(y);
+        s1 = row_bcast_f64<4>(y);
+        a0 = n0;
+        a1 = n1;
+        a2 = n2;
+        vk = nv;
     }
     wave_sync();
     return lane < NU * NH ? X[lane] : 0.0;

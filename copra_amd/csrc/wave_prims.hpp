@@ -97,6 +97,21 @@ COPRA_DEV void mfma_f64_16x16x4(double a, double b, mfma_acc& c)
     c.v[3] = cc[3];
 }
 
+// v_mfma_f64_4x4x4_4b_f64: FOUR independent products D_b = A_b (4 x 4) B_b (4 x 4) + C_b, one double per lane everywhere.
+// Layout (found by one-hot probing, tools/exp/mfma444_probe.hip; profiles/r02/mfma_f64_4x4x4_probe.txt), lane = 16 q + 4 b + r:
+//     A_b[i = r][k = q],   B_b[k = q][j = r],   C_b / D_b[i = q][j = r]
+// so that, as with the 16 x 16 x 4 instruction, a result is laid out like the B operand of the next product.  16 cycles of
+// the matrix pipe instead of 64.
+COPRA_DEV double mfma_f64_4x4x4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// lane N of every row of 16 lanes, to all lanes of that row (DPP row_newbcast)
+template <int N>
+COPRA_DEV double row_bcast_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // make a wave-uniform value provably uniform (SGPR) so that table look-ups become scalar loads
 COPRA_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

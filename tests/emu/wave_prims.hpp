@@ -118,6 +118,21 @@ COPRA_DEV void mfma_f64_16x16x4(double a, double b, mfma_acc& c)
     }
     emu::barrier_wave();
 }
+// v_mfma_f64_4x4x4_4b_f64 stand-in: lane = 16 q + 4 b + r;  A_b[i = r][k = q], B_b[k = q][j = r], C_b / D_b[i = q][j = r]
+COPRA_DEV double mfma_f64_4x4x4(double a, double b, double c)
+{
+    const int l = emu::g_wave.lane & 63, base = emu::g_wave.lane & ~63;
+    emu::g_mfma_a[base + l] = a;
+    emu::g_mfma_b[base + l] = b;
+    emu::barrier_wave();
+    const int i = l >> 4, blk = (l >> 2) & 3, j = l & 3;
+    double acc = c;
+    for (int k = 0; k < 4; ++k) acc += emu::g_mfma_a[base + 16 * k + 4 * blk + i] * emu::g_mfma_b[base + 16 * k + 4 * blk + j];
+    emu::barrier_wave();
+    return acc;
+}
+template <int N>
+COPRA_DEV double row_bcast_f64(double v) { return shfl_f64(v, (lane_id() & ~15) + N); }
 COPRA_DEV void wave_argmin(double& key, int& idx, double& payload)
 {
     for (int m = 32; m >= 1; m >>= 1) {
