@@ -17,7 +17,7 @@ synthetic CoM preview systems, inputs already resident in HBM.
 Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- dominant kernel (copra_lmpc_fused_tri_kernel): algorithmic bytes per launch (2016 B/solve: A,B,d,x0 in,
+  roofline     -- dominant kernel (copra_lmpc_fused_ric_kernel): algorithmic bytes per launch (2016 B/solve: A,B,d,x0 in,
                   U,X out) / average launch duration from HIP events recorded by the C ABI on the launch
                   stream, against the 8 TB/s HBM peak.  The path is FP64-latency/LDS bound, not HBM bound,
                   so the fraction is small by construction; executed-FP64 and VALU-issue figures next to it.
@@ -324,23 +324,31 @@ def main():
         # (FETCH_SIZE + WRITE_SIZE in KB; 8-byte-per-lane accesses calibrate at x1.0 on gfx950) -- not
         # re-measured live
         traffic, traffic_src, issue = None, None, {}
+        dominant = "copra_lmpc_fused_ric_kernel"  # (plan_builder.hpp: what the headline controller runs on)
         prof = os.path.join(ROOT, PMC_SUMMARY)
         if not os.path.exists(prof):
             prof = os.path.join(ROOT, "profiles", "r01", "headline_rocprof_summary_final.json")
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
                 ctr = json.load(open(prof))["counters"]
-                kname = [k for k in ctr if "copra_lmpc_fused_tri_kernel" in k][0]
+                # the dominant kernel: the first-tier fused kernel (Riccati-factor tier `copra_lmpc_fused_ric_kernel` since
+                # round 2; `copra_lmpc_fused_tri_kernel` before) -- the one with the most wave cycles in the profile
+                cands = [k for k in ctr if "copra_lmpc_fused_ric_kernel" in k or "copra_lmpc_fused_tri_kernel" in k]
+                kname = max(cands, key=lambda k: ctr[k].get("SQ_WAVE_CYCLES", {}).get("mean_per_launch", 0.0))
+                dominant = kname.split("<")[0].replace("void ", "")
                 c = {k: v["mean_per_launch"] for k, v in ctr[kname].items()}
                 traffic = 1024.0 * (c["FETCH_SIZE"] + c["WRITE_SIZE"])
                 traffic_src = os.path.relpath(prof, ROOT) + " (rocprofv3 --pmc, separate passes)"
                 issue = {"valu_instructions_per_solve": c["SQ_INSTS_VALU"] / batch,
                          "lds_instructions_per_solve": c["SQ_INSTS_LDS"] / batch,
                          "valu_issue_share_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
-                         "fp64_mfma_per_solve": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / batch / 4.0,
-                         # ~22 % of the wave instructions are FP64 arithmetic (static count in the disassembly, DESIGN.md
-                         # 3.9): executed flops = that share x 64 lanes x 2 per FMA
-                         "executed_fp64_tflops_estimate": 0.22 * c["SQ_INSTS_VALU"] * 64 * 2 / kern / 1e12}
+                         "fp64_mfma_mops_per_solve": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / batch}
+                if "SQ_INSTS_VALU_FMA_F64" in c:  # executed FP64 wave-instructions by class (their own --pmc pass)
+                    fma, add, mul = c["SQ_INSTS_VALU_FMA_F64"], c.get("SQ_INSTS_VALU_ADD_F64", 0.0), c.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                    issue["fp64_valu_instructions_per_solve"] = (fma + add + mul + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) / batch
+                    # 64 lanes x (2 per FMA, 1 per add / mul) + 512 per MFMA "MOP" unit, over the kernel time of THIS run
+                    issue["executed_fp64_tflops"] = (64 * (2 * fma + add + mul)
+                                                     + 512 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)) / kern / 1e12
             except Exception:
                 traffic = None
         hist = np.bincount(np.minimum(iters[:, 0], 15), minlength=16)
@@ -374,7 +382,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
-                         "kernel": "copra_lmpc_fused_tri_kernel", "algorithmic_bytes_per_solve": alg_bytes,
+                         "kernel": dominant, "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "
                                  "construction; what it does with the machine is in `issue`",
                          "issue": issue, "fp64_peak_tflops": FP64_PEAK_TFLOPS},

@@ -123,15 +123,29 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             pv[ti] = term;
     }
     COPRA_FINE("ric:costs");
-    // ---- 1. preview: G_s = A G_{s-1} (G_0 = B), xbar_s = A xbar_{s-1} + d (PreviewSystem.cpp:57-74 applied to x0).  One step
-    //      per stage of the sweep below, inside its synchronisation intervals: the two recursions are independent, the
-    //      preview's LDS round trips hide under the sweep's. ----
+    // ---- 1. preview: [G_s | xbar_s] = A [G_{s-1} | xbar_{s-1}] + [0 | d]  (G_0 = B, xbar_0 = x0; PreviewSystem.cpp:57-74
+    //      applied to x0).  One step per stage of the sweep below, on v_mfma_f64_4x4x4: the NU + 1 columns are the four
+    //      columns of a block, the two row blocks (x_0..3 | x_4..) are two accumulators, and an accumulator is laid out like
+    //      the B operand of the next step -- no LDS reads, no waiting: the recursion runs in the shadow of the sweep. ----
+    static_assert(NU + 1 <= 4 && NX <= 8, "preview recursion on 4 x 4 blocks");
     wave_sync();
-    double ar[NX]; // row pi of A
+    const int q4 = lane >> 4, r4 = lane & 3; // lane = 16 q + 4 b + r
+    double pa[2][2]; // A operand (row 4 I + r, column 4 K + q) of A
 #pragma unroll
-    for (int t = 0; t < NX; ++t) ar[t] = A[pi + NX * t];
-    const bool isx = (pj == NU);
-    const double padd = isx ? D[pi] : 0.0;
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) pa[I][K] = (4 * I + r4 < NX && 4 * K + q4 < NX) ? A[(4 * I + r4) + NX * (4 * K + q4)] : 0.0;
+    const bool pw = ((lane >> 2) & 3) == 0 && r4 <= NU; // lanes of block 0 store
+    const bool pgc = r4 < NU; // a column of G (else xbar)
+    double pc[2], px[2]; // [0 | d] and the state, rows q and 4 + q, column r
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        const int row = 4 * I + q4, rw = row < NX ? row : 0;
+        pc[I] = (row < NX && r4 == NU) ? D[rw] : 0.0;
+        px[I] = row < NX ? (pgc ? B[rw + NX * (pgc ? r4 : 0)] : (r4 == NU ? X0[rw] : 0.0)) : 0.0;
+    }
+    double* const pdst = pgc ? G + NX * r4 + q4 : Xbar + q4; // row q of step 0 (row 4 + q: + 4)
+    const int pst = pgc ? NX * NU : NX;
     if (lane < NX * NU) G[lane] = B[lane];
     if (lane < NX) Xbar[lane] = X0[lane];
     stamp[1] = cycle_counter();
@@ -197,19 +211,20 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             }
             wave_sync();
             if (k == NH - 2) COPRA_FINE("sweep:e+a");
-            { // preview step s = NH - k (reads what step s - 1 wrote one iteration ago)
+            { // preview step s = NH - k
                 const int s = NH - k;
-                const double* src = isx ? Xbar + (s - 1) * NX : G + (s - 1) * NX * NU + NX * (pj < NU ? pj : 0);
-                double sv[NX];
-#pragma unroll
-                for (int t = 0; t < NX; ++t) sv[t] = src[t];
-                double acc = padd;
-#pragma unroll
-                for (int t = 0; t < NX; ++t) acc += ar[t] * sv[t];
-                if (isx)
-                    Xbar[s * NX + pi] = acc;
-                else if (pj < NU && s < NH)
-                    G[s * NX * NU + NX * pj + pi] = acc;
+                double n0 = mfma_f64_4x4x4(pa[0][0], px[0], pc[0]);
+                double n1 = mfma_f64_4x4x4(pa[1][0], px[0], pc[1]);
+                if (NX > 4) {
+                    n0 = mfma_f64_4x4x4(pa[0][1], px[1], n0);
+                    n1 = mfma_f64_4x4x4(pa[1][1], px[1], n1);
+                }
+                px[0] = n0;
+                px[1] = n1;
+                if (pw && (s < NH || !pgc)) {
+                    pdst[s * pst] = n0;
+                    if (4 + q4 < NX) pdst[s * pst + 4] = n1;
+                }
             }
             if (k == NH - 2) COPRA_FINE("sweep:preview");
             double* Fk = F + k * RR::SZ;

@@ -15,7 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/hl_fetch -- $BENCH --steps 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/hl_write -- $BENCH --steps 5 --warmup 1 >> $O/hl_run.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/hl_sq -- $BENCH --steps 5 --warmup 1 >> $O/hl_run.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/hl_sq2 -- $BENCH --steps 5 --warmup 1 >> $O/hl_run.log 2>&1
-python tools/pmc_summary.py $O/hl_stats $O/hl_fetch $O/hl_write $O/hl_sq $O/hl_sq2 > profiles/r02/headline_rocprof_summary.json
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/hl_sq3 -- $BENCH --steps 5 --warmup 1 >> $O/hl_run.log 2>&1 || echo "(FP64 class counters not available)"
+python tools/pmc_summary.py $O/hl_stats $O/hl_fetch $O/hl_write $O/hl_sq $O/hl_sq2 $O/hl_sq3 > profiles/r02/headline_rocprof_summary.json
 find $O/hl_stats -name "*kernel_stats.csv" -exec cp {} profiles/r02/headline_kernel_stats.csv \;
 # ---- config 5 (InitialStateLMPC 12/6/50, batch 16384, Riccati interior-point kernel) ----
 C5="python3 tools/try_config5.py 16384 0"
