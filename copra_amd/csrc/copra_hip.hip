@@ -179,7 +179,8 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
-        if (P.lds.ric) return copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs>; // (plan_builder.hpp: only this shape gets the layout)
+        if (P.lds.ric) // (plan_builder.hpp: only this shape gets the layout; Q1 in registers, or in LDS further down the ladder)
+            return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 20, 0>;
         if (P.nx == 6 && rp == 6 && P.lds.q1regs == kFusedQ1Regs) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6, kFusedQ1Regs>;
         if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
         if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tri_kernel<6, 3, 20, 0>; // headline shape, full-size costs

@@ -53,14 +53,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     StageRows<NX, NU, NH> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
     rows.zero = S.scal;
-    // ---- 0. coalesced loads of this instance's system ----
-    for (int e = lane; e < NX * NX; e += kWave) A[e] = P.A[(size_t)inst * NX * NX + e];
-    for (int e = lane; e < NX * NU; e += kWave) B[e] = P.B[(size_t)inst * NX * NU + e];
-    for (int e = lane; e < NX; e += kWave) {
-        D[e] = P.d[(size_t)inst * NX + e];
-        X0[e] = P.x0[(size_t)inst * NX + e];
-    }
-    COPRA_FINE("ric:sys");
+    // ---- 0. coalesced loads of this instance's system: into registers now, into LDS after the loads of the cost tables
+    //      below have been issued as well (one trip to memory for both, not two) ----
+    static_assert(NX * NX <= kWave, "one element of A per lane");
+    const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
+    const double sysB = lane < NX * NU ? P.B[(size_t)inst * NX * NU + lane] : 0.0;
+    const double sysD = lane < NX ? P.d[(size_t)inst * NX + lane] : 0.0;
+    const double sysX = lane < NX ? P.x0[(size_t)inst * NX + lane] : 0.0;
     // ---- 0b. stage costs (they do not depend on the system: their loads overlap the ones above) ----
     // lane -> entry (a, b) of M = Hin + [A B]' P+ [A B] that it owns in the sweep:  x-x upper triangle | u-x | u-u upper
     // triangle | the affine column (b == NZ)
@@ -121,6 +120,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             Pm[lane] = term;
         else if (tj == NX)
             pv[ti] = term;
+    }
+    if (lane < NX * NX) A[lane] = sysA;
+    if (lane < NX * NU) B[lane] = sysB;
+    if (lane < NX) {
+        D[lane] = sysD;
+        X0[lane] = sysX;
     }
     COPRA_FINE("ric:costs");
     // ---- 1. preview: [G_s | xbar_s] = A [G_{s-1} | xbar_{s-1}] + [0 | d]  (G_0 = B, xbar_0 = x0; PreviewSystem.cpp:57-74

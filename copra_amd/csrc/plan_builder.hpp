@@ -168,6 +168,7 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
 // Layout of the Riccati-factor tier (lmpc_fused_ric.hpp): the J region holds N stage records (ric_factor.hpp) and, before
 // them, nothing (the lean preview of that body writes G and Xbar in place); A / B / d / x0 keep their own slots because the
 // sweep reads them while it fills the records; no cost tables; the sweep's scratch aliases the solver vectors.
+// q1regs > 0: that many columns of Q1 in registers (rcap = q1regs);  q1regs == 0: Q1 in LDS, as many columns as `budget` leaves.
 inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, int mgen, int meq, int mtotal, bool xcur_late,
     int q1regs, int budget)
 {
@@ -203,10 +204,18 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
     L.act = take((mtotal + 7) / 8 + 1);
+    L.ricX = take(kWave);
+    if (q1regs == 0) { // a column of Q1, its column of R, its multiplier and its row index per active constraint
+        auto need = [&](int r) { return r * kWave + align2(r * (r + 1) / 2 + 2) + align2(r + 2) + align2((r + 2) / 2 + 1); };
+        int rcap = 0;
+        while (rcap < n && o + need(rcap + 1) <= budget) ++rcap;
+        if (rcap < 1) return false;
+        L.rcap = rcap;
+        L.Q1 = take(rcap * kWave);
+    }
     L.uv = take(L.rcap + 2);
     L.iact = take((L.rcap + 2) / 2 + 1);
     L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
-    L.ricX = take(kWave);
     const int scratch = align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + align2(nu * (nx + 1)) + 2 + align2(N * nx);
     if (o < vec0 + scratch) o = vec0 + scratch;
     L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
@@ -295,6 +304,17 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const int rows = rp > P.rmax ? rp : P.rmax;
     const int kcur = (160 * 1024) / (cur.total * (int)sizeof(double));
+    if (cur.ric) { // the Riccati-factor tier keeps its factor: Q1 moves to LDS, one instance per CU fewer per step
+        for (int k = kcur - 1; k >= 4; --k) {
+            const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
+            LdsLayout t {};
+            if (layout_lds_ric(t, P.nx, P.nu, P.N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, 0, budget) && t.rcap > cur.rcap) {
+                out = t;
+                return true;
+            }
+        }
+        return false;
+    }
     for (int k = kcur - 1; k >= 4; --k) {
         const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
         LdsLayout t {};
@@ -311,14 +331,15 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
 // shared-model path -- cannot run the latter)
 inline bool tri_layout_with_lds_q1(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
 {
-    if (!cur.tri || cur.q1regs == 0) return false;
+    if (!cur.tri || (cur.q1regs == 0 && !cur.ric)) return false; // (a Riccati-factor layout is never run by those kernels)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const int rows = rp > P.rmax ? rp : P.rmax;
-    for (int k = 8; k >= 4; --k) {
+    const int kfirst = (160 * 1024) / (cur.total * (int)sizeof(double)) < 8 ? (160 * 1024) / (cur.total * (int)sizeof(double)) : 8;
+    for (int k = kfirst; k >= 4; --k) {
         const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
         LdsLayout t {};
         if (layout_lds(t, P.nx, P.nu, P.N, P.n, P.X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, 0, true, P.rows_direct != 0)
-            && t.total <= budget && t.rcap >= cur.rcap) {
+            && t.total <= budget && (t.rcap >= cur.rcap || k == 4)) {
             out = t;
             return true;
         }
@@ -827,8 +848,11 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
+                // (COPRA_RIC_K = instances per CU: start on the LDS-Q1 step of the ladder that adapt_layout would reach -- experiments, tests)
+                const char* rk = std::getenv("COPRA_RIC_K");
+                const int rbudget = rk ? ((160 * 1024 / std::atoi(rk)) & ~511) / (int)sizeof(double) : budget;
                 if (ric_ok && k == 8
-                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, qregs, budget)) {
+                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, rk ? 0 : qregs, rbudget)) {
                     hp.lds_safe = P.lds;
                     hp.safe_two_tier = hp.two_tier;
                     hp.two_tier = true;

@@ -232,8 +232,10 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
     auto body = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && PP.lds.ric) // (select_fused_kernel: the factor in Riccati form)
+        if (PP.lds.tri && PP.lds.ric && PP.lds.q1regs) // (select_fused_kernel: the factor in Riccati form)
             lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric)
+            lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b);
         else if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)

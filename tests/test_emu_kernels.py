@@ -138,6 +138,22 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert not emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], four, wl["cstrs"])["riccati_factor"]
 
 
+def test_riccati_factor_tier_with_q1_in_lds(emu, oracle, monkeypatch):
+    """the steps of the layout ladder below the register-Q1 one (what copra_batch_solve moves to when more than an eighth of
+    the batch overflows five columns): the same body with Q1 in LDS and as many columns as five instances per CU leave --
+    the tight workload then finishes in the first tier; COPRA_RIC_K starts the plan there"""
+    from copra_amd import workloads
+    monkeypatch.setenv("COPRA_RIC_K", "5")
+    wl = workloads.com_preview(10, v_max=0.25, u_max=1.2, seed=9)
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert re["riccati_factor"] and re["rcap"] >= 16 and re["overflowed"] == 0
+    for k in range(10):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        assert re["status"][k] == ro["status"] and tuple(re["iter"][k]) == tuple(ro["iter"])
+        assert np.abs(re["control"][k] - ro["control"]).max() <= 1e-9 * (1 + np.abs(ro["control"]).max())
+    assert re["iter"][:, 0].max() > 6
+
+
 def test_condensed_qp_dump_matches_oracle_build(emu, oracle):
     """Q, c, Aineq, bineq written by the device condense code == LMPC::Q() c() Aineq() bineq() of the oracle"""
     from copra_amd import workloads
