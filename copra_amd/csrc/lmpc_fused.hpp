@@ -65,6 +65,11 @@ struct StageRows {
     const double* prm = nullptr; // optional LDS copy of the parameter blob (workgroup-per-instance kernel)
     int inst = 0; // instance this wave / workgroup works on (per-instance right-hand sides and bounds)
     const double* zero = nullptr; // an LDS double that holds 0.0 (compile-time shapes: switched-off terms read it)
+    // Riccati-factor tier: the state trajectory AT THE UNCONSTRAINED MINIMISER (a by-product of its roll-out), nx (N + 1)
+    // doubles.  The first scan of the active-set iteration happens at exactly that iterate, so a one-hot state row reads its
+    // left-hand side there instead of summing over the blocks G (3 k of the 6.5 k cycles of a first scan).
+    const double* xu = nullptr;
+    mutable int scans = 0; // begin_scan() calls so far
 
     COPRA_DEV const double* params() const { return prm ? prm : P.params; }
 
@@ -256,7 +261,8 @@ struct StageRows {
     COPRA_DEV double lhs_now(const RowDesc& d, const double* xs) const
     {
         if (!P.rows_direct) return lhs(d, Xcur, xs);
-        double ax = (d.ek == kEOneHot) ? state_component(d.k, d.eo, xs) : 0.0;
+        double ax = 0.0;
+        if (d.ek == kEOneHot) ax = (xu && scans <= 1) ? xu[d.k * nx() + d.eo] : state_component(d.k, d.eo, xs);
         if (d.gk == kGStep) {
             for (int c = 0; c < nu(); ++c) ax += params()[d.go + c] * xs[d.k * nu() + c];
         } else if (d.gk == kGFull) {
@@ -267,6 +273,7 @@ struct StageRows {
 
     COPRA_DEV void begin_scan(const double* xs) const
     {
+        scans += 1;
         if (P.any_state_rows && !P.rows_direct) refresh_trajectory(xs);
         wave_sync();
     }

@@ -40,6 +40,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     SolverLds S = carve_solver(lds, L);
     double* F = S.J; // NH stage records
     // scratch of the sweep (aliases the solver vectors: first written by the roll-out / the norms phase)
+    // A | B | d | x0 | ricX are contiguous (layout_lds_ric): once the sweep is done they hold the trajectory of the roll-out
+    double* XU = A;
+    const bool xu_ok = P.rows_direct && (L.ricX + kWave - L.A) >= X && L.ricX > L.X0;
     double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
     double* T = pv + ((NX + 1) & ~1); // NX x (NZ + 1):  P [A B d] (+ p in the last column)
@@ -397,8 +400,15 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         }
         const double one = (q == 0) ? 1.0 : 0.0;
         const bool writer = q < NU && b4 == 2 && r == 0;
+        // the states of the roll-out (rows 0 .. NX-1 of the stacked result: blocks 0 and 1) are the trajectory at the
+        // unconstrained minimiser: kept for the first scan and, if that finds nothing violated, for the results
+        const int yrow = 4 * b4 + q; // (the RESULT of lane 16 q + 4 b + r is row 4 b + q of the stacked product)
+        const bool xwriter = xu_ok && b4 < 2 && r == 0 && yrow < NX;
+        const double x0r = X0[yrow < NX ? yrow : 0];
         double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
         double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0];
+        wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
+        if (xwriter) XU[yrow] = x0r;
 #pragma unroll COPRA_RIC_UNROLL
         for (int k = 0; k < NH; ++k) {
             const int kn = k + 1 < NH ? k + 1 : k;
@@ -408,6 +418,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             y = mfma_f64_4x4x4(a0, s0, y);
             y = mfma_f64_4x4x4(a1, s1, y);
             if (writer) S.xs[NU * k + q] = y;
+            if (xwriter) XU[(k + 1) * NX + yrow] = y;
             s0 = row_bcast_f64<0>(y);
             s1 = row_bcast_f64<4>(y);
             a0 = n0;
@@ -415,6 +426,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             a2 = n2;
         }
     }
+    if (xu_ok) rows.xu = XU;
     COPRA_FINE("rollout");
     if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component
     wave_sync();
@@ -441,10 +453,15 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     }
     // ---- 6. results (LMPC.cpp:95-97: outputs only on success; failures are flagged with NaN) ----
     if (status == 0) {
-        rows.refresh_trajectory(S.xs);
-        wave_sync();
+        const double* Xres = Xcur;
+        if (it_main == 1 && rows.xu) { // nothing was violated at the unconstrained minimiser: its trajectory is the result
+            Xres = rows.xu;
+        } else {
+            rows.refresh_trajectory(S.xs);
+            wave_sync();
+        }
         for (int e = lane; e < NV; e += kWave) P.control[(size_t)inst * NV + e] = S.xs[e];
-        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = Xcur[e];
+        for (int e = lane; e < X; e += kWave) P.trajectory[(size_t)inst * X + e] = Xres[e];
     } else {
         const double qnan = __builtin_nan("");
         for (int e = lane; e < NV; e += kWave) P.control[(size_t)inst * NV + e] = qnan;

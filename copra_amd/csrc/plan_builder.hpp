@@ -193,6 +193,8 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.B = take(nx * nu);
     L.D = take(nx);
     L.X0 = take(nx);
+    L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out and
+                          //  the first scan -- lmpc_fused_ric.hpp, StageRows::xu)
     L.BldPhi = L.BldXi = L.J; // (unused by the body)
     const int vec0 = o;
     L.ricS = vec0;
@@ -204,7 +206,6 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
     L.act = take((mtotal + 7) / 8 + 1);
-    L.ricX = take(kWave);
     if (q1regs == 0) { // a column of Q1, its column of R, its multiplier and its row index per active constraint
         auto need = [&](int r) { return r * kWave + align2(r * (r + 1) / 2 + 2) + align2(r + 2) + align2((r + 2) / 2 + 1); };
         int rcap = 0;
