@@ -212,10 +212,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             }
             if (k < 0) break;
             if (a_on) {
-                double acc = *apv;
+                double acc = *apv, acc2 = 0.0; // (two partial sums: half the dependent chain)
 #pragma unroll
-                for (int t = 0; t < NX; ++t) acc += Pm[t + NX * pi] * abr[t];
-                T[pi + NX * pj] = acc;
+                for (int t = 0; t < NX; t += 2) {
+                    acc += Pm[t + NX * pi] * abr[t];
+                    if (t + 1 < NX) acc2 += Pm[t + 1 + NX * pi] * abr[t + 1];
+                }
+                T[pi + NX * pj] = acc + acc2;
             }
             wave_sync();
             if (k == NH - 2) COPRA_FINE("sweep:e+a");
@@ -236,12 +239,35 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             }
             if (k == NH - 2) COPRA_FINE("sweep:preview");
             double* Fk = F + k * RR::SZ;
-            double mval = hreg;
+            double mval = hreg, mval2 = 0.0;
 #pragma unroll
-            for (int t = 0; t < NX; ++t) mval += aba[t] * T[t + NX * tcol];
+            for (int t = 0; t < NX; t += 2) {
+                mval += aba[t] * T[t + NX * tcol];
+                if (t + 1 < NX) mval2 += aba[t + 1] * T[t + 1 + NX * tcol];
+            }
+            mval += mval2;
             if (is_k) Mu[(ma - NX) + NU * mbc] = mval;
             if (is_uu) Fk[RR::oLi + uu_t] = mval; // (packed upper triangle; replaced by Lam^-1 after the sweep)
             double mi[NU][NU]; // M_uu^-1 (symmetric)
+            if constexpr (NU == 3) {
+                // 3 x 3: adjugate over determinant -- ONE reciprocal and a dependent chain of 11 operations (cofactor, determinant,
+                // reciprocal + two Newton steps, scaling) where the LDL' below has three reciprocals in sequence (26); positive
+                // definite <=> the leading minors m00, C22, det are positive (Sylvester)
+                const int ub = nxx + nux; // lanes of the packed upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
+                const double m00 = bcast_f64(mval, ub + 0), m01 = bcast_f64(mval, ub + 1), m11 = bcast_f64(mval, ub + 2);
+                const double m02 = bcast_f64(mval, ub + 3), m12 = bcast_f64(mval, ub + 4), m22 = bcast_f64(mval, ub + 5);
+                const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+                const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+                const double det = m00 * c00 + (m01 * c01 + m02 * c02);
+                bad = bad || !(m00 > 0.0) || !(c22 > 0.0) || !(det > 0.0);
+                const double rdet = ric_rcp(det);
+                mi[0][0] = c00 * rdet;
+                mi[0][1] = mi[1][0] = c01 * rdet;
+                mi[0][2] = mi[2][0] = c02 * rdet;
+                mi[1][1] = c11 * rdet;
+                mi[1][2] = mi[2][1] = c12 * rdet;
+                mi[2][2] = c22 * rdet;
+            } else
             {
                 double lm[NU][NU]; // M_uu (lower part) -> unit lower L of M_uu = L D L'
                 double rd[NU]; // 1 / D(c)
