@@ -584,7 +584,14 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 double wk = 0.0;
                 double rinv_own = 0.0;
                 if constexpr (RNX > 0) {
-                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ricx)
+                    int nst = NV / RNU;
+                    if (COPRA_RIC_MFMA == 2) { // stages past the last non-zero of the normal contribute nothing: skip them
+                        const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
+                        nst = (int)last / RNU + 1;
+                        nst = uniform_i32(nst);
+                        if (lane < kWave) S.ricx[lane] = 0.0;
+                    }
+                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ricx, nst)
                         : COPRA_RIC_MFMA   ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
                                            : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
                 } else {

@@ -258,8 +258,10 @@ COPRA_DEV double ric_apply_mfma(const double* F, double vl, double* X)
 // J of the stacked vector, the three instructions of a stage accumulate in place.  Result rows 4b + i sit in quad b of lane
 // row i; the next stage needs K-block J in EVERY quad of row k -- one DPP row broadcast of lane 4 J per block.
 // lane = 16 q + 4 b + r:  A operand (row 4b + r, column 4J + q), B operand: component 4J + q of the vector in all lanes of row q.
+// nstages (TR only): the backward recursion starts at stage nstages - 1 -- the normal of a constraint at step k has no
+// component beyond stage k - 1, mu is zero until then and so is w beyond it (X must hold zeros there: see the caller).
 template <int NX, int NU, int NH, bool TR>
-COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X)
+COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, int nstages = NH)
 {
     using RR = RicRec<NX, NU>;
     const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
@@ -272,13 +274,14 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X)
     const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
     double s0 = 0.0, s1 = 0.0; // K-blocks 0 and 1 of the state (stacked components 0..3 and 4..7), one per lane row
     // (the operands of the next stage are fetched while the current one runs: their LDS latency is off the chain)
-    const int kfirst = TR ? NH - 1 : 0, kstep = TR ? -1 : 1;
+    const int kfirst = TR ? nstages - 1 : 0, kstep = TR ? -1 : 1;
+    const int count = TR ? nstages : NH;
     const double* Fk = F + kfirst * RR::SZ;
     double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]], vk = ip[NU * kfirst];
 #pragma unroll COPRA_RIC_UNROLL
-    for (int t = 0; t < NH; ++t) {
+    for (int t = 0; t < count; ++t) {
         const int k = kfirst + kstep * t;
-        const int kn = (t + 1 < NH) ? k + kstep : k;
+        const int kn = (t + 1 < count) ? k + kstep : k;
         const double* Fn = F + kn * RR::SZ;
         const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = Fn[off[2]], nv = ip[NU * kn];
         double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
