@@ -68,6 +68,7 @@ struct SolverLds {
                         // factor-only layout: the packed factor R instead, and ...
     const double* rinv_src; // ... 1 / R(i,i)
     double* ricx; // Riccati-factor tier: 64 doubles for the hand-over of the MFMA recursions (ric_factor.hpp)
+    double* ricxi; // ... and, if set, where z = R^-1 v leaves its closed-loop states (nx (N + 1) doubles; StageRows::xi)
 };
 
 COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
@@ -92,6 +93,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.act = reinterpret_cast<unsigned char*>(lds + L.act);
     S.iact = reinterpret_cast<int*>(lds + L.iact);
     S.ricx = lds + L.ricX;
+    S.ricxi = nullptr;
     return S;
 }
 
@@ -411,6 +413,12 @@ COPRA_DEV void gi_invert(const SolverLds& S, int n_rt)
 // row that is violated at the current iterate: ONE slack evaluation instead of a scan over all rows, then the ordinary
 // iteration (dual blocking test, drops) -- every invariant of the method holds throughout, nothing is ever restarted.
 // After the list the ordinary scans take over and finish.  Same optimum as a cold start; the iterates differ.
+// a row policy may want to know that the iterate moved by t z (StageRows::moved); the others do not have the member
+template <class R>
+COPRA_DEV auto rows_moved(const R& r, double t, int) -> decltype(r.moved(t), void()) { r.moved(t); }
+template <class R>
+COPRA_DEV void rows_moved(const R&, double, long) { }
+
 // RNX, RNU > 0 (with TRI and a compile-time shape): the factor in S.J is in Riccati form (ric_factor.hpp) -- the two
 // substitutions become the closed-loop recursions over the NV / RNU stages; everything else is unchanged.
 template <int NV, bool TRI = false, int QR = 0, int RNX = 0, int RNU = 0, class Rows>
@@ -578,10 +586,12 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
             if (iter_main <= 1) COPRA_FINE("as:normal");
             double dj, zi;
             double vj = 0.0; // TRI: component `lane` of w - Q1 d1
+            double napl = 0.0; // TRI, Riccati form: component `lane` of n+
             if constexpr (TRI) {
                 // w = R^-T n+ : forward substitution, lane = column; a bound row's normal starts at its own index
                 double acc = (lane < n) ? S.ap[lj] : 0.0;
                 double wk = 0.0;
+                napl = acc;
                 double rinv_own = 0.0;
                 if constexpr (RNX > 0) {
                     int nst = NV / RNU;
@@ -589,9 +599,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
                         nst = (int)last / RNU + 1;
                         nst = uniform_i32(nst);
-                        if (lane < kWave) S.ricx[lane] = 0.0;
                     }
-                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ricx, nst)
+                    // (in place: the normal is zero past stage nst - 1, and so is w; this lane's n is in `acc`)
+                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, nst)
                         : COPRA_RIC_MFMA   ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
                                            : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
                 } else {
@@ -654,9 +664,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 double zk = 0.0;
                 if constexpr (RNX > 0) {
                     if (COPRA_RIC_MFMA == 2) {
-                        if (lane < n) S.ricx[lane] = vj;
+                        if (lane < n) S.ap[lane] = vj;
                         wave_sync();
-                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ricx, S.ricx);
+                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, NV / RNU, S.ricxi);
                     } else {
                         zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
                     }
@@ -742,7 +752,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if (lane == 0) S.uv[nact] += t1;
                 drop = true;
             } else {
-                const double zn = wave_sum((lane < n) ? zi * S.ap[lane] : 0.0);
+                // (Riccati-factor tier on v_mfma_f64_4x4x4: S.ap was the hand-over buffer of the two recursions; n+ is in `napl`)
+                const double zn = wave_sum((lane < n) ? zi * ((RNX > 0 && COPRA_RIC_MFMA == 2) ? napl : S.ap[lane]) : 0.0);
                 double tt = -sv_nvl / zn;
                 bool t2min = true;
                 if (!t1inf && t1 < tt) {
@@ -750,6 +761,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     t2min = false;
                 }
                 if (lane < n) S.xs[lane] += tt * zi;
+                rows_moved(rows, tt, 0);
                 if (lane < nact) S.uv[lane] -= tt * ri;
                 if (lane == 0) S.uv[nact] += tt;
                 if (iter_main <= 1) COPRA_FINE("as:step");

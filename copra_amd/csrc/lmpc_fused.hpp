@@ -68,8 +68,17 @@ struct StageRows {
     // Riccati-factor tier: the state trajectory AT THE UNCONSTRAINED MINIMISER (a by-product of its roll-out), nx (N + 1)
     // doubles.  The first scan of the active-set iteration happens at exactly that iterate, so a one-hot state row reads its
     // left-hand side there instead of summing over the blocks G (3 k of the 6.5 k cycles of a first scan).
-    const double* xu = nullptr;
+    double* xu = nullptr;
     mutable int scans = 0; // begin_scan() calls so far
+    // ... and with `xi` set the tier MAINTAINS that trajectory: z = R^-1 v is a closed-loop recursion whose states ARE the
+    // response Psi z of the trajectory to the step direction (ric_factor.hpp writes them to xi), so a step x += t z is
+    // followed by xu += t xi (moved()) -- every scan and the results read the trajectory, nothing sums over G any more.
+    const double* xi = nullptr;
+    COPRA_DEV void moved(double t) const
+    {
+        if (!xi) return;
+        for (int e = lane_id(); e < xdim(); e += kWave) xu[e] += t * xi[e];
+    }
 
     COPRA_DEV const double* params() const { return prm ? prm : P.params; }
 
@@ -262,7 +271,7 @@ struct StageRows {
     {
         if (!P.rows_direct) return lhs(d, Xcur, xs);
         double ax = 0.0;
-        if (d.ek == kEOneHot) ax = (xu && scans <= 1) ? xu[d.k * nx() + d.eo] : state_component(d.k, d.eo, xs);
+        if (d.ek == kEOneHot) ax = (xu && (scans <= 1 || xi)) ? xu[d.k * nx() + d.eo] : state_component(d.k, d.eo, xs);
         if (d.gk == kGStep) {
             for (int c = 0; c < nu(); ++c) ax += params()[d.go + c] * xs[d.k * nu() + c];
         } else if (d.gk == kGFull) {

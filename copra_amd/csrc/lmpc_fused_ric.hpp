@@ -452,7 +452,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             a2 = n2;
         }
     }
-    if (xu_ok) rows.xu = XU;
+    if (xu_ok) {
+        rows.xu = XU;
+        if (COPRA_RIC_MFMA == 2) { // the trajectory is maintained from here on (StageRows::xi): the free response is not needed any more
+            rows.xi = Xbar;
+            S.ricxi = Xbar;
+        }
+    }
     COPRA_FINE("rollout");
     if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component
     wave_sync();
@@ -480,7 +486,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // ---- 6. results (LMPC.cpp:95-97: outputs only on success; failures are flagged with NaN) ----
     if (status == 0) {
         const double* Xres = Xcur;
-        if (it_main == 1 && rows.xu) { // nothing was violated at the unconstrained minimiser: its trajectory is the result
+        if (rows.xu && (it_main == 1 || rows.xi)) { // the trajectory at the final iterate is there already (nothing was violated at the
+                                                      // unconstrained minimiser, or every step has been applied to it)
             Xres = rows.xu;
         } else {
             rows.refresh_trajectory(S.xs);
