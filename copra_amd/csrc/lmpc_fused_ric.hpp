@@ -464,7 +464,41 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     wave_sync();
     stamp[3] = cycle_counter();
     // ---- 4. implicit rows: norms (qpgen2: column norms of amat) ----
-    for (int i = lane; i < P.mgen; i += kWave) nb[i] = sqrt(rows.norm2(rows.desc(i)));
+    // A row of Psi (one component of one state, no control term: TrajectoryBoundConstraint) has the squared norm
+    // sum_{t < k} |row eo of G_t|^2: the NH NX block-row norms once (two per lane), then at most NH additions per row --
+    // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.
+    {
+        double* NB2 = Xbar; // (free: the trajectory lives in XU; the closed-loop states come here only during z = R^-1 v)
+        const bool fast = rows.xu != nullptr;
+        if (fast) {
+            for (int e = lane; e < NH * NX; e += kWave) {
+                const int t = e / NX, comp = e - t * NX;
+                double s2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    const double a = G[t * NX * NU + comp + NX * c];
+                    s2 += a * a;
+                }
+                NB2[e] = s2;
+            }
+            wave_sync();
+        }
+        for (int i = lane; i < P.mgen; i += kWave) {
+            const RowDesc d = rows.desc(i);
+            double s2;
+            if (fast && d.ek == kEOneHot && d.gk == kGNone) {
+                double part[NH];
+#pragma unroll
+                for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * NX + d.eo];
+                s2 = 0.0;
+#pragma unroll
+                for (int t = 0; t < NH; ++t) s2 += (t < d.k) ? part[t] : 0.0;
+            } else {
+                s2 = rows.norm2(d);
+            }
+            nb[i] = sqrt(s2);
+        }
+    }
     wave_sync();
     COPRA_FINE("norms");
     stamp[4] = cycle_counter();

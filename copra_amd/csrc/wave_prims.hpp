@@ -107,8 +107,9 @@ COPRA_DEV double mfma_f64_4x4x4(double a, double b, double c) { return __builtin
 template <int N>
 COPRA_DEV double row_bcast_f64(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xF, 0xF, false);
+    // (every lane is written: no `old` operand to initialise -- mov_dpp instead of update_dpp saves two v_mov per call)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + N, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
