@@ -601,7 +601,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                         nst = uniform_i32(nst);
                     }
                     // (in place: the normal is zero past stage nst - 1, and so is w; this lane's n is in `acc`)
-                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, nst)
+                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricx + kWave - 2, nst)
                         : COPRA_RIC_MFMA   ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
                                            : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
                 } else {
@@ -666,7 +666,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     if (COPRA_RIC_MFMA == 2) {
                         if (lane < n) S.ap[lane] = vj;
                         wave_sync();
-                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, NV / RNU, S.ricxi);
+                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricx + kWave - 2, NV / RNU, S.ricxi);
                     } else {
                         zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
                     }

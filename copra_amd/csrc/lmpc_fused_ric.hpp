@@ -42,7 +42,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // scratch of the sweep (aliases the solver vectors: first written by the roll-out / the norms phase)
     // A | B | d | x0 | ricX are contiguous (layout_lds_ric): once the sweep is done they hold the trajectory of the roll-out
     double* XU = A;
-    const bool xu_ok = P.rows_direct && (L.ricX + kWave - L.A) >= X && L.ricX > L.X0;
+    const bool xu_ok = P.rows_direct && (L.ricX + kWave - 2 - L.A) >= X && L.ricX > L.X0; // (the last two doubles of ricX: the spare
+                                                                                         //  target of the lanes that store nothing)
     double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
     double* T = pv + ((NX + 1) & ~1); // NX x (NZ + 1):  P [A B d] (+ p in the last column)
@@ -431,6 +432,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const int yrow = 4 * b4 + q; // (the RESULT of lane 16 q + 4 b + r is row 4 b + q of the stacked product)
         const bool xwriter = xu_ok && b4 < 2 && r == 0 && yrow < NX;
         const double x0r = X0[yrow < NX ? yrow : 0];
+        // (lanes with nothing to store write to a spare double: no branches in the loop, see ric_apply_mfma4)
+        double* const up = writer ? S.xs + q : S.ricx + kWave - 2;
+        const int ust = writer ? NU : 0;
+        double* const xwp = xwriter ? XU + NX + yrow : S.ricx + kWave - 2;
+        const int xwst = xwriter ? NX : 0;
         double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
         double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0];
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
@@ -443,8 +449,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             double y = mfma_f64_4x4x4(a2, one, 0.0);
             y = mfma_f64_4x4x4(a0, s0, y);
             y = mfma_f64_4x4x4(a1, s1, y);
-            if (writer) S.xs[NU * k + q] = y;
-            if (xwriter) XU[(k + 1) * NX + yrow] = y;
+            up[ust * k] = y;
+            xwp[xwst * k] = y;
             s0 = row_bcast_f64<0>(y);
             s1 = row_bcast_f64<4>(y);
             a0 = n0;

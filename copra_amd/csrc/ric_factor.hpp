@@ -262,7 +262,10 @@ COPRA_DEV double ric_apply_mfma(const double* F, double vl, double* X)
 // component beyond stage k - 1, mu is zero until then and so is w beyond it (X must hold zeros there: see the caller).
 template <int NX, int NU, int NH, bool TR>
 // XI (forward recursion only): the closed-loop states xi_0 .. xi_NH are stored there, NX per stage.
-COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, int nstages = NH, double* XI = nullptr)
+// dummy: one double of LDS nobody reads -- the lanes that have nothing to store write there, so that the loop body has no
+// branches (with the stores in exec-masked blocks the compiler waits for ALL outstanding LDS operations at every stage,
+// stores included, instead of just for the prefetched operands).
+COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, double* dummy, int nstages = NH, double* XI = nullptr)
 {
     using RR = RicRec<NX, NU>;
     const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
@@ -271,9 +274,13 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, i
     for (int J = 0; J < 3; ++J)
         off[J] = TR ? ric_stack_offset<NX, NU>(4 * J + q, 4 * b + r) : ric_stack_offset<NX, NU>(4 * b + r, 4 * J + q);
     const double* ip = in + (q < NU ? q : 0);
-    double* const op = X + (q < NU ? q : 0);
     const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
     const bool xwriter = !TR && XI && r == 0 && b < 2 && 4 * b + q < NX; // the state: component 4 b + q sits in lane row q
+    double* const op = writer ? X + q : dummy;
+    const int ost = writer ? NU : 0;
+    double* const xp = xwriter ? XI + 4 * b + q : dummy;
+    const int xst = xwriter ? NX : 0;
+    const bool xany = !TR && XI;
     double s0 = 0.0, s1 = 0.0; // K-blocks 0 and 1 of the state (stacked components 0..3 and 4..7), one per lane row
     // (the operands of the next stage are fetched while the current one runs: their LDS latency is off the chain)
     const int kfirst = TR ? nstages - 1 : 0, kstep = TR ? -1 : 1;
@@ -286,11 +293,11 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, i
         const int kn = (t + 1 < count) ? k + kstep : k;
         const double* Fn = F + kn * RR::SZ;
         const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = Fn[off[2]], nv = ip[NU * kn];
-        if (xwriter) XI[k * NX + 4 * b + q] = (b == 0) ? s0 : s1;
+        if (xany) xp[k * xst] = (b == 0) ? s0 : s1;
         double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
         y = mfma_f64_4x4x4(a0, s0, y);
         y = mfma_f64_4x4x4(a1, s1, y);
-        if (writer) op[NU * k] = y;
+        op[ost * k] = y;
         s0 = row_bcast_f64<0>(y);
         s1 = row_bcast_f64<4>(y);
         a0 = n0;
@@ -298,7 +305,7 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, i
         a2 = n2;
         vk = nv;
     }
-    if (xwriter) XI[NH * NX + 4 * b + q] = (b == 0) ? s0 : s1;
+    if (xany) xp[NH * xst] = (b == 0) ? s0 : s1;
     wave_sync();
     return lane < NU * NH ? X[lane] : 0.0;
 }
