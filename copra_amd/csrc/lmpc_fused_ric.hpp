@@ -47,8 +47,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
     double* T = pv + ((NX + 1) & ~1); // NX x (NZ + 1):  P [A B d] (+ p in the last column)
-    double* Mu = T + NX * (NZ + 1); // NU x (NX + 1):  [M_ux | h_u]
-    double* Zs = Mu + ((NU * (NX + 1) + 1) & ~1); // two doubles that hold 0.0 during the sweep
+    double* Mu = T + NX * (NZ + 1); // NU x (NX + 1 + NU):  [M_ux | h_u | I]  (the unit columns: what a row of K multiplies M_uu^-1 with)
+    double* Zs = Mu + ((NU * (NX + 1 + NU) + 1) & ~1); // two doubles that hold 0.0 during the sweep
     double* Bk = Zs + 2; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
 
     long long stamp[8];
@@ -193,10 +193,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const bool is_uu = m_on && ma >= NX && mb >= NX && mb < NZ;
         const bool is_k = m_on && ma >= NX && !is_uu;
         const int uu_t = lane - nxx - nux; // position in the packed upper triangle of M_uu
-        double unit[NU]; // u rows: the unit vector that picks row (ma - NX) of M_uu^-1
-#pragma unroll
-        for (int c = 0; c < NU; ++c) unit[c] = (ma - NX == c) ? 1.0 : 0.0;
-        const double* minep = Mu + NU * (is_x ? ma : 0);
+        // u rows: the unit vector that picks row (ma - NX) of M_uu^-1 -- a column of the table like the others (no select)
+        if (lane < NU * NU) Mu[NU * (NX + 1) + lane] = (lane % NU == lane / NU) ? 1.0 : 0.0;
+        const double* minep = Mu + NU * (is_x ? ma : NX + 1 + (ma - NX));
         // where (cd) stores: x rows into P (both halves) or p; u rows into the record (K, kv)
         const int w1 = is_x ? (mb < NX ? ma + NX * mb : NX * NX + ma) : (mb < NX ? RR::oK + (ma - NX) + NU * mb : RR::oKv + (ma - NX));
         const int w2 = (is_x && mb < NX) ? mb + NX * ma : w1;
@@ -328,8 +327,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
                     col[c] = Mu[c + NU * mbc];
-                    const double mv = minep[c];
-                    mine[c] = is_x ? mv : unit[c];
+                    mine[c] = minep[c];
                 }
                 double v = is_x ? mval : 0.0;
 #pragma unroll

@@ -217,7 +217,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.uv = take(L.rcap + 2);
     L.iact = take((L.rcap + 2) / 2 + 1);
     L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
-    const int scratch = align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + align2(nu * (nx + 1)) + 2 + align2(N * nx);
+    const int scratch = align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + align2(nu * (nx + 1 + nu)) + 2 + align2(N * nx);
     if (o < vec0 + scratch) o = vec0 + scratch;
     L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
     L.total = o;
