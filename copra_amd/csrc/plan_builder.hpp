@@ -852,7 +852,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 // (COPRA_RIC_K = instances per CU: start on the LDS-Q1 step of the ladder that adapt_layout would reach -- experiments, tests)
                 const char* rk = std::getenv("COPRA_RIC_K");
                 const int rbudget = rk ? ((160 * 1024 / std::atoi(rk)) & ~511) / (int)sizeof(double) : budget;
-                if (ric_ok && k == 8
+                if (ric_ok && k >= 6 // (general state rows keep their own trajectory buffer: seven instances per CU)
                     && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, rk ? 0 : qregs, rbudget)) {
                     hp.lds_safe = P.lds;
                     hp.safe_two_tier = hp.two_tier;

@@ -138,6 +138,34 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert not emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], four, wl["cstrs"])["riccati_factor"]
 
 
+def test_riccati_factor_tier_with_general_rows(emu, oracle):
+    """the Riccati-factor tier with rows that are NOT one component of one state: a dense TrajectoryConstraint (velocity
+    sum), a MixedConstraint (state + control at the same step), a ControlConstraint and an equality on the first control --
+    the row policy then has no maintained trajectory to read (StageRows::xu stays null: every scan refreshes the trajectory
+    from G) and the equality goes through the eqsgn path; statuses, iteration counts, U and X against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.4, u_max=2.0, seed=21)
+    E1 = np.zeros((1, 6)); E1[0, 3:] = 1.0           # vx + vy + vz <= 0.8
+    Em = np.zeros((1, 6)); Em[0, 3] = 1.0            # vx_k + 0.05 ux_k <= 0.45
+    Gm = np.array([[0.05, 0.0, 0.0]])
+    cstrs = [dict(kind="trajectory", E=E1, f=[0.8]),
+             dict(kind="mixed", E=Em, G=Gm, f=[0.45]),
+             dict(kind="control", G=[[0.0, 1.0, 1.0]], f=[2.5]),
+             dict(kind="control_bound", lower=[-2.0] * 3, upper=[2.0] * 3)]
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+    assert re["riccati_factor"]
+    seen = 0
+    for k in range(6):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cstrs)
+        assert re["status"][k] == ro["status"], k
+        if ro["status"] == 0:
+            assert tuple(re["iter"][k]) == tuple(ro["iter"])
+            assert np.abs(re["control"][k] - ro["control"]).max() <= 1e-9 * (1 + np.abs(ro["control"]).max())
+            assert np.abs(re["trajectory"][k] - ro["trajectory"]).max() <= 1e-9 * (1 + np.abs(ro["trajectory"]).max())
+            seen += int(ro["iter"][0] > 1)
+    assert seen >= 3  # (constraints are active in most instances)
+
+
 def test_riccati_factor_tier_with_q1_in_lds(emu, oracle, monkeypatch):
     """the steps of the layout ladder below the register-Q1 one (what copra_batch_solve moves to when more than an eighth of
     the batch overflows five columns): the same body with Q1 in LDS and as many columns as five instances per CU leave --

@@ -1033,3 +1033,33 @@ def test_warm_start_over_25_receding_horizon_ticks(oracle):
         assert stats[warm]["solved_last_tick"] >= 500
     print("cold:", stats[False]["mean_iterations"], stats[False]["mean_kernel_ms"], "warm:", stats[True]["mean_iterations"],
           stats[True]["mean_kernel_ms"])
+
+
+def test_riccati_factor_tier_general_rows_and_ladder(oracle):
+    """the headline's Riccati-factor tier (lmpc_fused_ric.hpp) away from its benchmark configuration: (a) rows that are not
+    one component of one state (dense TrajectoryConstraint, MixedConstraint, ControlConstraint) -- no maintained trajectory,
+    seven instances per CU; (b) the tight workload, whose second solve runs on the LDS-Q1 step of the layout ladder:
+    statuses, iteration counts, U and X against the oracle both times, and the ladder actually moved"""
+    from copra_amd import BatchLMPC, workloads
+    b = 512
+    wl = workloads.com_preview(b, v_max=0.4, u_max=2.0, seed=21)
+    E1 = np.zeros((1, 6)); E1[0, 3:] = 1.0
+    Em = np.zeros((1, 6)); Em[0, 3] = 1.0
+    wl["cstrs"] = [dict(kind="trajectory", E=E1, f=[0.8]), dict(kind="mixed", E=Em, G=np.array([[0.05, 0.0, 0.0]]), f=[0.45]),
+                   dict(kind="control", G=[[0.0, 1.0, 1.0]], f=[2.5]), dict(kind="control_bound", lower=[-2.0] * 3, upper=[2.0] * 3)]
+    eng, res, ref = _check(wl, b, oracle)
+    assert (res["iter"][ref["status"] == 0] == ref["iter"][ref["status"] == 0]).all()
+    eng.close()
+    wt = workloads.com_preview(4096, v_max=0.25, u_max=1.2, seed=5)
+    eng = BatchLMPC(6, 3, wt["N"], 4096, wt["costs"], wt["cstrs"])
+    eng.set_system(wt["A"], wt["B"], wt["d"], wt["x0"])
+    eng.solve()
+    first, cap0 = eng.results(), eng.layout_info()["active_capacity"]
+    eng.solve()
+    second, cap1 = eng.results(), eng.layout_info()["active_capacity"]
+    assert cap1 > cap0  # more than an eighth of the batch overflowed five columns: the next solve has more
+    ref = oracle.lmpc_solve_batch(wt["A"][:256], wt["B"][:256], wt["d"][:256], wt["x0"][:256], wt["N"], wt["costs"], wt["cstrs"], nthreads=8)
+    for res in (first, second):
+        assert (res["status"][:256] == ref["status"]).all() and (res["iter"][:256] == ref["iter"]).all()
+        assert _rel(res["control"][:256], ref["control"]) <= RTOL and _rel(res["trajectory"][:256], ref["trajectory"]) <= RTOL
+    eng.close()
