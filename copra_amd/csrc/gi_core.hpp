@@ -594,16 +594,11 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 napl = acc;
                 double rinv_own = 0.0;
                 if constexpr (RNX > 0) {
-                    int nst = NV / RNU;
-                    if (COPRA_RIC_MFMA == 2) { // stages past the last non-zero of the normal contribute nothing: skip them
-                        const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
-                        nst = (int)last / RNU + 1;
-                        nst = uniform_i32(nst);
-                    }
-                    // (in place: the normal is zero past stage nst - 1, and so is w; this lane's n is in `acc`)
-                    wk = COPRA_RIC_MFMA == 2 ? ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricx + kWave - 2, nst)
-                        : COPRA_RIC_MFMA   ? ric_apply_transposed_mfma<RNX, RNU, NV / RNU>(J, S.ap, S.ricx)
-                                           : ric_apply_transposed<RNX, RNU, NV / RNU>(J, acc);
+                    // stages past the last non-zero of the normal contribute nothing (a row at step k has no component beyond
+                    // stage k - 1): the backward recursion starts there.  In place: this lane's n is in `acc` / `napl`.
+                    const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
+                    const int nst = uniform_i32((int)last / RNU + 1);
+                    wk = ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricx + kWave - 2, nst);
                 } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
@@ -663,13 +658,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 acc = vj;
                 double zk = 0.0;
                 if constexpr (RNX > 0) {
-                    if (COPRA_RIC_MFMA == 2) {
-                        if (lane < n) S.ap[lane] = vj;
-                        wave_sync();
-                        zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricx + kWave - 2, NV / RNU, S.ricxi);
-                    } else {
-                        zk = COPRA_RIC_MFMA ? ric_apply_mfma<RNX, RNU, NV / RNU>(J, vj, S.ricx) : ric_apply<RNX, RNU, NV / RNU>(J, vj);
-                    }
+                    if (lane < n) S.ap[lane] = vj;
+                    wave_sync();
+                    zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricx + kWave - 2, NV / RNU, S.ricxi);
                 } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];
@@ -752,8 +743,8 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if (lane == 0) S.uv[nact] += t1;
                 drop = true;
             } else {
-                // (Riccati-factor tier on v_mfma_f64_4x4x4: S.ap was the hand-over buffer of the two recursions; n+ is in `napl`)
-                const double zn = wave_sum((lane < n) ? zi * ((RNX > 0 && COPRA_RIC_MFMA == 2) ? napl : S.ap[lane]) : 0.0);
+                // (Riccati-factor tier: S.ap was the hand-over buffer of the two recursions; n+ is in `napl`)
+                const double zn = wave_sum((lane < n) ? zi * (RNX > 0 ? napl : S.ap[lane]) : 0.0);
                 double tt = -sv_nvl / zn;
                 bool t2min = true;
                 if (!t1inf && t1 < tt) {

@@ -458,10 +458,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     }
     if (xu_ok) {
         rows.xu = XU;
-        if (COPRA_RIC_MFMA == 2) { // the trajectory is maintained from here on (StageRows::xi): the free response is not needed any more
-            rows.xi = Xbar;
-            S.ricxi = Xbar;
-        }
+        rows.xi = Xbar; // the trajectory is maintained from here on (StageRows::moved): the free response is not needed any more
+        S.ricxi = Xbar;
     }
     COPRA_FINE("rollout");
     if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component

@@ -19,11 +19,7 @@
 #pragma once
 
 #ifndef COPRA_RIC_UNROLL
-#define COPRA_RIC_UNROLL 2 // stages per loop body of the recursions (fully unrolled they spill 800 SGPRs: every broadcast is hoisted)
-#endif
-
-#ifndef COPRA_RIC_MFMA
-#define COPRA_RIC_MFMA 2 // the recursions of the active-set iteration: 2 = v_mfma_f64_4x4x4 (+ DPP row broadcasts), 1 = v_mfma_f64_16x16x4, 0 = v_readlane + vector ALU
+#define COPRA_RIC_UNROLL 2 // stages per loop body of the recursions (two: the prefetch registers of stage k + 1 become those of stage k without moves)
 #endif
 
 namespace copra_hip {
@@ -51,136 +47,14 @@ struct RicRec {
     static constexpr int SZ = (oKv + NU + 1) & ~1;
 };
 
-// Both recursions keep the operands of the NEXT stage in registers while the current one is evaluated (the loads do not
-// depend on the recursion's state, so their LDS latency hides under the dependent multiply-adds), and split every inner
-// product into two or three independent partial sums.
-
-// w = Rinv' n.  Lane 3k + c holds component c of n_k in `nl` and receives component c of w_k (lanes >= NU NH: 0).
-template <int NX, int NU, int NH>
-COPRA_DEV double ric_apply_transposed(const double* F, double nl)
-{
-    using RR = RicRec<NX, NU>;
-    const int lane = lane_id();
-    const int li = lane < NX ? lane : NX - 1;
-    const int kq = lane / NU, cq = lane - kq * NU;
-    struct Ops {
-        double lr[NU], bt[NX], kc[NU], ac[NX];
-    };
-    auto fetch = [&](int k, Ops& o) {
-        const double* Fk = F + k * RR::SZ;
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            o.lr[c] = Fk[RR::oLi + cq + NU * c]; // row cq of Lam^-1
-            o.kc[c] = Fk[RR::oK + c + NU * li]; // column li of K
-        }
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            o.bt[j] = Fk[RR::oBt + j + NX * cq]; // column cq of Bt
-            o.ac[j] = Fk[RR::oAcl + j + NX * li]; // column li of Acl
-        }
-    };
-    double mu = 0.0, w = 0.0;
-    Ops cur, nxt;
-    fetch(NH - 1, cur);
-#pragma unroll COPRA_RIC_UNROLL
-    for (int k = NH - 1; k >= 0; --k) {
-        fetch(k > 0 ? k - 1 : 0, nxt);
-        double m[NX], nk[NU];
-#pragma unroll
-        for (int c = 0; c < NU; ++c) nk[c] = bcast_f64(nl, NU * k + c);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) m[j] = bcast_f64(mu, j); // (mu_N = 0)
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            w0 += cur.lr[c] * nk[c];
-            a0 += cur.kc[c] * nk[c];
-        }
-#pragma unroll
-        for (int j = 0; j < NX; j += 2) {
-            w1 += cur.bt[j] * m[j];
-            a1 += cur.ac[j] * m[j];
-            if (j + 1 < NX) {
-                w2 += cur.bt[j + 1] * m[j + 1];
-                a2 += cur.ac[j + 1] * m[j + 1];
-            }
-        }
-        w = (kq == k) ? w0 + (w1 + w2) : w;
-        mu = a0 + (a1 + a2);
-        cur = nxt;
-    }
-    return w;
-}
-
-// z = Rinv v.  Lane 3k + c holds component c of v_k in `vl` and receives component c of z_k (lanes >= NU NH: 0).
-// XI != nullptr: the closed-loop states xi_k (k = 0 .. NH) -- the response Psi z of the state trajectory to z -- are stored
-// there, NX per stage.
-template <int NX, int NU, int NH>
-COPRA_DEV double ric_apply(const double* F, double vl, double* XI = nullptr)
-{
-    using RR = RicRec<NX, NU>;
-    const int lane = lane_id();
-    const int li = lane < NX ? lane : NX - 1;
-    const int kq = lane / NU, cq = lane - kq * NU;
-    struct Ops {
-        double lc[NU], kr[NX], br[NU], ar[NX];
-    };
-    auto fetch = [&](int k, Ops& o) {
-        const double* Fk = F + k * RR::SZ;
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            o.lc[c] = Fk[RR::oLi + c + NU * cq]; // row cq of Lam^-T
-            o.br[c] = Fk[RR::oBt + li + NX * c]; // row li of Bt
-        }
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            o.kr[j] = Fk[RR::oK + cq + NU * j]; // row cq of K
-            o.ar[j] = Fk[RR::oAcl + li + NX * j]; // row li of Acl
-        }
-    };
-    double xi = 0.0, z = 0.0;
-    Ops cur, nxt;
-    fetch(0, cur);
-#pragma unroll COPRA_RIC_UNROLL
-    for (int k = 0; k < NH; ++k) {
-        fetch(k + 1 < NH ? k + 1 : NH - 1, nxt);
-        if (XI && lane < NX) XI[k * NX + lane] = xi;
-        double m[NX], vk[NU];
-#pragma unroll
-        for (int c = 0; c < NU; ++c) vk[c] = bcast_f64(vl, NU * k + c);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) m[j] = bcast_f64(xi, j); // (xi_0 = 0)
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            z0 += cur.lc[c] * vk[c];
-            a0 += cur.br[c] * vk[c];
-        }
-#pragma unroll
-        for (int j = 0; j < NX; j += 2) {
-            z1 += cur.kr[j] * m[j];
-            a1 += cur.ar[j] * m[j];
-            if (j + 1 < NX) {
-                z2 += cur.kr[j + 1] * m[j + 1];
-                a2 += cur.ar[j + 1] * m[j + 1];
-            }
-        }
-        z = (kq == k) ? z0 + (z1 + z2) : z;
-        xi = a0 + (a1 + a2);
-        cur = nxt;
-    }
-    if (XI && lane < NX) XI[NH * NX + lane] = xi;
-    return z;
-}
-
-// ---- the same two products on the matrix cores -------------------------------------------------------------------
+// ---- the two products on the matrix cores ------------------------------------------------------------------------
 // One stage of either recursion is a small matrix-vector product,  [xi+; z_k] = [Acl Bt; K Lam^-T] [xi; v_k]  (and its
-// transpose for w), and v_mfma_f64_16x16x4_f64 has the property that makes a CHAIN of them free of data movement: the
-// result D(row = (lane >> 4) + 4 reg, col = lane & 15) of one product is laid out exactly as the B operand (k = lane >> 4,
-// col = lane & 15) of the next one, K-block `reg`.  So the recursion state never leaves the accumulator registers -- no
-// v_readlane broadcasts (18 per stage in the plain version), no multiply-adds on the vector ALU (18 per stage): three
-// MFMAs, three LDS reads of matrix elements and one of the input per stage.  All 16 columns carry the same vector.
-// Stacked index s = 4 blk + (lane >> 4):  0 .. NX-1 state components (NX <= 8) | 8 .. 8+NU-1 input / output components.
+// transpose for w), and the MFMA instructions have the property that makes a CHAIN of them free of data movement: the
+// result of one product is laid out exactly as the B operand of the next one.  So the recursion state never leaves the
+// accumulator registers -- no v_readlane broadcasts (18 per stage in a vector-ALU version), no multiply-adds on the vector
+// ALU (18 per stage).  (History: a vector-ALU version and one on v_mfma_f64_16x16x4 -- 64 cycles of the matrix pipe per
+// instruction on MI355X, no faster than the vector ALU -- preceded the one below; DESIGN.md 3.9b has their numbers.)
+// Stacked index:  0 .. NX-1 state components (NX <= 8) | 8 .. 8+NU-1 input / output components.
 template <int NX, int NU>
 COPRA_DEV int ric_stack_offset(int s_out, int s_in)
 {
@@ -195,66 +69,9 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in)
     return ti == 0 ? RR::oK + a + NU * b : RR::oLi + b + NU * a; // K(a, b) | Lam^-T(a, b) = Lam^-1(b, a)
 }
 
-// w = Rinv' n with n in LDS (nvec[0 .. NU NH)); X: NU NH doubles of LDS for the hand-over.  Returns component `lane` of w.
-template <int NX, int NU, int NH>
-COPRA_DEV double ric_apply_transposed_mfma(const double* F, const double* nvec, double* X)
-{
-    using RR = RicRec<NX, NU>;
-    const int lane = lane_id(), g = lane >> 4, j = lane & 15;
-    int off[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) off[b] = ric_stack_offset<NX, NU>(4 * b + g, j); // element (row j, column 4 b + g) of the TRANSPOSE
-    const double* np = nvec + (g < NU ? g : 0);
-    mfma_acc prev = { { 0.0, 0.0, 0.0, 0.0 } };
-#pragma unroll COPRA_RIC_UNROLL
-    for (int k = NH - 1; k >= 0; --k) {
-        const double* Fk = F + k * RR::SZ;
-        const double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]];
-        const double nk = np[NU * k];
-        mfma_acc y = { { 0.0, 0.0, 0.0, 0.0 } };
-        mfma_f64_16x16x4(a2, nk, y); // (does not wait for the previous stage)
-        mfma_f64_16x16x4(a0, prev.v[0], y);
-        mfma_f64_16x16x4(a1, prev.v[1], y);
-        if (g < NU) X[NU * k + g] = y.v[2];
-        prev = y;
-    }
-    wave_sync();
-    return lane < NU * NH ? X[lane] : 0.0;
-}
-
-// z = Rinv v; lane 3k + c holds component c of v_k in `vl`.  Returns component `lane` of z.
-template <int NX, int NU, int NH>
-COPRA_DEV double ric_apply_mfma(const double* F, double vl, double* X)
-{
-    using RR = RicRec<NX, NU>;
-    const int lane = lane_id(), g = lane >> 4, j = lane & 15;
-    int off[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) off[b] = ric_stack_offset<NX, NU>(j, 4 * b + g);
-    if (lane < NU * NH) X[lane] = vl;
-    wave_sync();
-    double* xp = X + (g < NU ? g : 0);
-    mfma_acc prev = { { 0.0, 0.0, 0.0, 0.0 } };
-#pragma unroll COPRA_RIC_UNROLL
-    for (int k = 0; k < NH; ++k) {
-        const double* Fk = F + k * RR::SZ;
-        const double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]];
-        const double vk = xp[NU * k];
-        mfma_acc y = { { 0.0, 0.0, 0.0, 0.0 } };
-        mfma_f64_16x16x4(a2, vk, y);
-        mfma_f64_16x16x4(a0, prev.v[0], y);
-        mfma_f64_16x16x4(a1, prev.v[1], y);
-        if (g < NU) xp[NU * k] = y.v[2]; // (in place: every lane has read v_k)
-        prev = y;
-    }
-    wave_sync();
-    return lane < NU * NH ? X[lane] : 0.0;
-}
-
-// ---- the same on v_mfma_f64_4x4x4_4b_f64 -------------------------------------------------------------------------
-// A 16 x 16 x 4 FP64 MFMA occupies the matrix pipe of its SIMD for 64 cycles, and with two waves per SIMD the three of a
-// stage cost ~400 cycles (measured; profiles/r02/mfma_f64_4x4x4_probe.txt).  The 4 x 4 x 4 instruction computes four
-// independent 4 x 4 blocks in 16 cycles: block b of instruction J multiplies rows 4b .. 4b+3 of the stacked matrix by K-block
+// ---- on v_mfma_f64_4x4x4_4b_f64 ----------------------------------------------------------------------------------
+// (A 16 x 16 x 4 FP64 MFMA occupies the matrix pipe of its SIMD for 64 cycles: profiles/r02/mfma_f64_4x4x4_probe.txt.)  The
+// 4 x 4 x 4 instruction computes four independent 4 x 4 blocks in 16 cycles: block b of instruction J multiplies rows 4b .. 4b+3 of the stacked matrix by K-block
 // J of the stacked vector, the three instructions of a stage accumulate in place.  Result rows 4b + i sit in quad b of lane
 // row i; the next stage needs K-block J in EVERY quad of row k -- one DPP row broadcast of lane 4 J per block.
 // lane = 16 q + 4 b + r:  A operand (row 4b + r, column 4J + q), B operand: component 4J + q of the vector in all lanes of row q.
