@@ -356,6 +356,12 @@ struct copra_batch {
     int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
     // shared-model fast path: one (A, B, d) for the whole batch, factorised once (copra_batch_set_shared_system)
     bool shared = false, model_dirty = true, shared_attr_set = false;
+    // shared-model mode of the Riccati-factor tier (lmpc_fused_ric.hpp, FusedPlan::ric_model): the layout the plan builder chose
+    // for that tier (kept when copra_batch_set_shared_system moves the plan to an LDS-Q1 layout), whether the next solve uses it,
+    // and the batch-wide records
+    bool has_lds_ric = false, shared_ric = false;
+    LdsLayout lds_ric {};
+    double* d_ric_model = nullptr;
     int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)
     size_t model_doubles = 0; // allocated size of d_model
     int model_rtot = 0; // columns of C2 / K2 as prepared
@@ -809,6 +815,7 @@ void copra_batch_destroy(copra_batch_t* h)
     for (void* q : h->ric_dev) (void)hipFree(q);
     (void)hipFree(h->d_ric_ws);
     (void)hipFree(h->d_ric_next);
+    (void)hipFree(h->d_ric_model);
     (void)hipFree(h->d_shA);
     (void)hipFree(h->d_shB);
     (void)hipFree(h->d_shd);
@@ -884,6 +891,11 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared = true;
     h->model_dirty = true;
+    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve)
+        h->has_lds_ric = true;
+        h->lds_ric = h->hp.plan.lds;
+    }
+    h->shared_ric = false;
     LdsLayout lq {};
     if (tri_layout_with_lds_q1(h->hp.plan, h->hp.plan.lds, lq)) { // the shared-model kernels keep Q1 in LDS
         h->hp.plan.lds = lq;
@@ -1017,6 +1029,41 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     }
     release();
     if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("shared-model prepare: ") + hipGetErrorString(e));
+    if (h->shared_ric) { // the stage records of the shared system: one run of the Riccati-factor body (FusedPlan::ric_model_out)
+        int oBk, oG, oNb;
+        const size_t count = (size_t)ric_model_offsets(nx, nu, N, HP.mgen, oBk, oG, oNb);
+        if (!h->d_ric_model) HIP_TRY(hipMalloc((void**)&h->d_ric_model, count * sizeof(double)));
+        std::vector<void*> own2;
+        hipError_t e2 = hipSuccess;
+        auto up2 = [&](const std::vector<double>& src) -> double* {
+            double* dst = nullptr;
+            hipError_t r = hipMalloc((void**)&dst, src.size() * sizeof(double));
+            if (r == hipSuccess) r = hipMemcpy(dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (r != hipSuccess && e2 == hipSuccess) e2 = r;
+            own2.push_back(dst);
+            return dst;
+        };
+        FusedPlan R = device_plan(h);
+        R.A = up2(h->shA), R.B = up2(h->shB), R.d = up2(h->shd), R.x0 = up2(std::vector<double>((size_t)nx, 0.0));
+        for (int t = 0; t < kMaxCosts; ++t) R.cost_p[t] = nullptr;
+        R.row_f_inst = nullptr;
+        R.lb_inst = R.ub_inst = nullptr;
+        R.batch = 1;
+        R.dump_instance = 0;
+        R.lds = h->lds_ric;
+        R.prof = nullptr;
+        R.prof_fine = nullptr;
+        R.ric_model_out = h->d_ric_model;
+        const size_t lb = (size_t)h->lds_ric.total * sizeof(double);
+        if (e2 == hipSuccess) e2 = lds_opt_in(reinterpret_cast<const void*>(select_fused_kernel(R)), lb);
+        if (e2 == hipSuccess) {
+            hipLaunchKernelGGL(select_fused_kernel(R), dim3(1), dim3(64), lb, s, R);
+            e2 = hipGetLastError();
+        }
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+        for (void* q : own2) (void)hipFree(q);
+        if (e2 != hipSuccess) return fail(COPRA_ERR_HIP, std::string("shared-model prepare (Riccati records): ") + hipGetErrorString(e2));
+    }
     h->model_dirty = false;
     return COPRA_OK;
 }
@@ -1316,6 +1363,24 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         hipStream_t s = (hipStream_t)hip_stream;
         h->last_stream = s;
         if (h->hp.plan.batch == 0) return COPRA_OK;
+        { // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
+            bool want = h->has_lds_ric && !h->d_warm && !std::getenv("COPRA_NO_RIC_SHARED");
+            for (int t = 0; t < kMaxCosts; ++t) want = want && !h->cost_p[t];
+            if (want != h->shared_ric) {
+                LdsLayout lq {};
+                if (want) {
+                    h->hp.plan.lds = h->lds_ric;
+                } else if (tri_layout_with_lds_q1(h->hp.plan, h->lds_ric, lq)) {
+                    h->hp.plan.lds = lq;
+                }
+                h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
+                h->hp.two_tier = true;
+                h->lds_attr_set = false;
+                h->shared_attr_set = false;
+                h->shared_ric = want;
+                h->model_dirty = true;
+            }
+        }
         copra_status_t rc = ensure_lds_attr(h);
         if (rc != COPRA_OK) return rc;
         if (!h->shared_attr_set && h->hp.lds_full_bytes > 48 * 1024) {
@@ -1335,7 +1400,13 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.model_rtot = h->model_rtot;
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-        if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
+        if (h->shared_ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
+            FusedPlan Pr = P;
+            Pr.ric_model = h->d_ric_model;
+            LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
+            hipLaunchKernelGGL(select_fused_kernel(Pr), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, Pr);
+            HIP_TRY(hipGetLastError());
+        } else if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
             FusedPlan Pj = P;
             void* args[] = { &Pj };
             const unsigned per = 64u / (unsigned)h->jit_lanes;

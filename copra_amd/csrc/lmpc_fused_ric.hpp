@@ -57,6 +57,19 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     StageRows<NX, NU, NH> rows { P, G, Xbar, Xcur, nb, RowDesc {}, 0.0, 0.0 };
     rows.inst = inst;
     rows.zero = S.scal;
+    int status = 0;
+    // shared-model mode: the records, bkd, G (and later the row norms) of the whole batch come from the prepare launch
+    int mBk = 0, mG = 0, mNb = 0;
+    ric_model_offsets(NX, NU, NH, P.mgen, mBk, mG, mNb);
+    const bool from_model = P.ric_model != nullptr;
+    if (from_model) {
+        if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
+        rows.cache_own_row();
+        for (int e = lane; e < NH * RR::SZ; e += kWave) F[e] = P.ric_model[e];
+        for (int e = lane; e < NH * NX; e += kWave) Bk[e] = P.ric_model[mBk + e];
+        for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
+        stamp[1] = cycle_counter();
+    } else {
     // ---- 0. coalesced loads of this instance's system: into registers now, into LDS after the loads of the cost tables
     //      below have been issued as well (one trip to memory for both, not two) ----
     static_assert(NX * NX <= kWave, "one element of A per lane");
@@ -168,7 +181,6 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     //        unit vector for the u rows.
     // Lam^-1 (the Cholesky factor of M_uu, inverted) and Bt = B Lam^-T are only used by the active-set iteration: they are
     // formed after the sweep for all stages at once (lane = stage), not twenty times inside it.
-    int status = 0;
     {
         double abr[NX]; // column pj of [A B d]
         double aba[NX]; // column ma of [A B]
@@ -403,7 +415,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             F[k * RR::SZ + RR::oBt + rem] = acc;
         }
     }
+    } // (!from_model)
     wave_sync();
+    if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
+        for (int e = lane; e < NH * RR::SZ; e += kWave) P.ric_model_out[e] = F[e];
+        for (int e = lane; e < NH * NX; e += kWave) P.ric_model_out[mBk + e] = Bk[e];
+        for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
+    }
     COPRA_FINE("sweep:Bt");
     stamp[2] = cycle_counter();
     // ---- 3. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k bkd_k; K_k kv_k] [x_k; 1] from x_0, on the matrix
@@ -469,7 +487,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // A row of Psi (one component of one state, no control term: TrajectoryBoundConstraint) has the squared norm
     // sum_{t < k} |row eo of G_t|^2: the NH NX block-row norms once (two per lane), then at most NH additions per row --
     // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.
-    {
+    if (from_model) {
+        for (int i = lane; i < P.mgen; i += kWave) nb[i] = P.ric_model[mNb + i];
+    } else {
         double* NB2 = Xbar; // (free: the trajectory lives in XU; the closed-loop states come here only during z = R^-1 v)
         const bool fast = rows.xu != nullptr;
         if (fast) {
@@ -502,6 +522,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         }
     }
     wave_sync();
+    if (P.ric_model_out) { // prepare launch, second half: the row norms; nothing is solved
+        if (inst == P.dump_instance)
+            for (int i = lane; i < P.mgen; i += kWave) P.ric_model_out[mNb + i] = nb[i];
+        return;
+    }
     COPRA_FINE("norms");
     stamp[4] = cycle_counter();
     stamp[5] = stamp[4];

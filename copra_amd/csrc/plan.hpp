@@ -171,6 +171,21 @@ struct LargeLayout {
     long long ws_total;
 };
 
+#if defined(__HIPCC__)
+#define COPRA_HD __host__ __device__
+#else
+#define COPRA_HD
+#endif
+// offsets (doubles) of the four parts of FusedPlan::ric_model; returns the total
+COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
+{
+    const int rec = (nx * nx + 2 * nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    oBk = N * rec;
+    oG = oBk + N * nx;
+    oNb = oG + N * nx * nu;
+    return oNb + ((mgen + 1) & ~1);
+}
+
 struct FusedPlan {
     // dimensions
     int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
@@ -187,6 +202,11 @@ struct FusedPlan {
     //   [0, 64): Hin entry of the lane | [64, 128): HN entry | then per cost t and row r < 6 two vectors of 64: the
     //   coefficient of p_t[r] in the lane's Hin / HN entry (non-zero on the affine lanes only).  -1: no tables.
     int ric_tab;
+    // Shared-model mode of that tier (copra_batch_set_shared_system): the stage records do not depend on x0, so ONE prepare
+    // launch sweeps (ric_model_out, instance dump_instance) and every instance of the batch copies the result (ric_model):
+    //   records [N x RicRec::SZ] | bkd [N x nx] | G [N x nx x nu] | row norms [mgen]      (ric_model_offsets below)
+    const double* ric_model;
+    double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)

@@ -406,7 +406,21 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     P.model_rtot = 0;
     P.x0 = x0;
     P.warm_set = warm_set;
-    { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
+    // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, no per-instance references): one prepare
+    // run of the body leaves the stage records, bkd, G and the row norms; the first tier copies them instead of sweeping
+    std::vector<double> ric_model;
+    const bool ric_shared = P.lds.ric && P.lds.q1regs == kFusedQ1Regs && !warm_set && !std::getenv("COPRA_NO_RIC_SHARED");
+    if (ric_shared) {
+        int oBk, oG, oNb;
+        ric_model.assign((size_t)ric_model_offsets(nx, nu, N, P.mgen, oBk, oG, oNb), 0.0);
+        FusedPlan R = P;
+        R.A = A, R.B = B, R.d = d, R.x0 = xp.data(); // (x0 = 0: the records do not depend on it)
+        R.batch = 1;
+        R.dump_instance = 0;
+        R.ric_model_out = ric_model.data();
+        if (emu::run_wave([&]() { lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(R, 0); }, hp.lds_bytes, 0, 1) != 0) return -100;
+        P.ric_model = ric_model.data();
+    } else { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
         LdsLayout lq {};
         if (tri_layout_with_lds_q1(P, P.lds, lq)) {
             P.lds = lq;
@@ -414,7 +428,9 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         }
     }
     auto shared = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
+        if (PP.lds.ric && PP.ric_model)
+            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
+        else if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
             lmpc_shared_body<6, 3, 20, true>(PP, b);
         else if (PP.lds.tri)
             lmpc_shared_body<0, 0, 0, true>(PP, b);
@@ -428,9 +444,11 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     for (int b = 0; b < dims->batch; ++b)
         if (emu::run_wave([&]() { shared(P, b); }, hp.lds_bytes, b, dims->batch) != 0) return -100;
     if (sizes) sizes[0] = ovf_count;
+    if (sizes) sizes[1] = ric_shared ? 1 : 0;
     if (ovf_count > 0) {
         FusedPlan P2 = P;
         P2.lds = hp.lds_full;
+        P2.ric_model = nullptr;
         for (int k = 0; k < ovf_count; ++k) {
             const int b = ovf_list[(size_t)k];
             if (emu::run_wave([&]() { shared(P2, b); }, hp.lds_full_bytes, b, dims->batch) != 0) return -100;

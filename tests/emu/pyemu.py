@@ -186,7 +186,7 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
                                      warm.ctypes.data_as(C.POINTER(C.c_int)) if warm is not None else C.c_void_p())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
-    return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0])
+    return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0], riccati_factor=bool(sizes[1]))
 
 
 def qp_dense(Q, c, Aeq, beq, Aineq, bineq, XL, XU):

@@ -2,6 +2,8 @@
 tests/emu/ and compared with the oracle.  This is how the kernel logic is covered without a GPU; the same bodies,
 compiled by hipcc, are what `-m gpu` tests run on the MI355X.  (The emulator is test infrastructure: see
 tests/emu/wave_prims.hpp.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -398,11 +400,20 @@ def test_shared_model_fast_path(emu, oracle):
     from copra_amd import workloads
     wl = workloads.com_preview(10, v_max=0.25, u_max=1.2)
     A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
-    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
-    for k in range(10):
-        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
-        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
-        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+    # the headline shape runs it twice: on the Riccati-factor tier in shared-model mode (stage records swept once by a prepare
+    # run, copied by every instance: what copra_batch_solve picks for cold starts) and on lmpc_shared.hpp (COPRA_NO_RIC_SHARED)
+    for ric in (True, False):
+        if not ric:
+            os.environ["COPRA_NO_RIC_SHARED"] = "1"
+        try:
+            re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+        finally:
+            os.environ.pop("COPRA_NO_RIC_SHARED", None)
+        assert re["riccati_factor"] == ric and re["overflowed"] > 0
+        for k in range(10):
+            ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+            assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
+            assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
     wl = workloads.com_preview(8, N=15, v_max=0.2, u_max=1.0, seed=3)  # 45 variables: factor-only tier, run-time shape
     A, B, d = wl["A"][1], wl["B"][1], wl["d"][1]
     re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])

@@ -1063,3 +1063,35 @@ def test_riccati_factor_tier_general_rows_and_ladder(oracle):
         assert (res["status"][:256] == ref["status"]).all() and (res["iter"][:256] == ref["iter"]).all()
         assert _rel(res["control"][:256], ref["control"]) <= RTOL and _rel(res["trajectory"][:256], ref["trajectory"]) <= RTOL
     eng.close()
+
+
+def test_shared_model_both_first_tiers(oracle, monkeypatch):
+    """copra_batch_set_shared_system on the headline shape: the first solve runs the Riccati-factor tier in shared-model mode
+    (stage records swept once), the second one -- COPRA_NO_RIC_SHARED is read at every solve -- lmpc_shared.hpp; a third one
+    with the warm start enabled must move to lmpc_shared.hpp by itself.  Same statuses and iteration counts as the oracle
+    each time, U and X within the tolerance, the two cold solves equal to rounding"""
+    from copra_amd import BatchLMPC, workloads
+    b = 2048
+    wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=13)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(wl["x0"])
+    eng.solve()
+    r1 = eng.results()
+    monkeypatch.setenv("COPRA_NO_RIC_SHARED", "1")
+    eng.solve()
+    r2 = eng.results()
+    monkeypatch.delenv("COPRA_NO_RIC_SHARED")
+    eng.set_warm_start(True)
+    eng.solve()
+    r3 = eng.results()
+    ref = oracle.lmpc_solve_batch(np.repeat(wl["A"][:1], 128, 0), np.repeat(wl["B"][:1], 128, 0), np.repeat(wl["d"][:1], 128, 0),
+                                  wl["x0"][:128], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    for r in (r1, r2, r3):
+        assert (r["status"][:128] == ref["status"]).all() and (r["iter"][:128][ok] == ref["iter"][ok]).all()
+        assert _rel(r["control"][:128][ok], ref["control"][ok]) <= RTOL and _rel(r["trajectory"][:128][ok], ref["trajectory"][ok]) <= RTOL
+    good = (r1["status"] == 0) & (r2["status"] == 0)
+    assert (r1["status"] == r2["status"]).all() and np.abs(r1["control"][good] - r2["control"][good]).max() <= 1e-9
+    assert (r1["iter"][:, 0] > 1).mean() > 0.3
+    eng.close()
