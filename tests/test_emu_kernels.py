@@ -138,6 +138,12 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     four = [traj, ctrl, dict(kind="target", M=np.eye(6)[:2], p=traj["p"][:2], weights=[1.0, 1.0]),
             dict(kind="control", N=np.eye(3), p=np.zeros(3), weights=[1e-4] * 3)]
     assert not emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], four, wl["cstrs"])["riccati_factor"]
+    # an indefinite Hessian (negative weight): the condensed Q is positive definite <=> every stage's control block is, so the
+    # sweep reports "Problems with the decomposition of Q" (status 2) exactly where the reference's Cholesky fails
+    bad = [dict(traj, weights=[10.0, 10.0, -50.0, 1.0, 1.0, 1.0]), ctrl]
+    rb = emu.lmpc_solve(wl["A"][:3], wl["B"][:3], wl["d"][:3], wl["x0"][:3], wl["N"], bad, wl["cstrs"])
+    assert rb["riccati_factor"] and (rb["status"] == 2).all() and np.isnan(rb["control"]).all()
+    assert oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][0], wl["N"], bad, wl["cstrs"])["status"] == 2
 
 
 def test_riccati_factor_tier_with_general_rows(emu, oracle):
