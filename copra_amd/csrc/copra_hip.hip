@@ -179,8 +179,11 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
-        if (P.lds.ric) // (plan_builder.hpp: only this shape gets the layout; Q1 in registers, or in LDS further down the ladder)
+        if (P.lds.ric) { // (plan_builder.hpp: only these shapes get the layout; Q1 in registers, or in LDS further down the ladder)
+            if (P.N == 10) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 10, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 10, 0>;
+            if (P.N == 15) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 15, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 15, 0>;
             return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 20, 0>;
+        }
         if (P.nx == 6 && rp == 6 && P.lds.q1regs == kFusedQ1Regs) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6, kFusedQ1Regs>;
         if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
         if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tri_kernel<6, 3, 20, 0>; // headline shape, full-size costs
@@ -1261,7 +1264,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     const FusedPlan& P = h->hp.plan;
     if (h->jit_fused) return COPRA_OK;
     const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
-    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu)
+    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu || P.lds.ric)
         return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
     // (always the full register budget: with compile-time trip counts the unrolled bodies spill at 128 VGPRs -- double
     //  integrator N = 32: 9.2 M solves/s at four waves per SIMD, 15.6 M at two, 11.8 M for the run-time-shape kernel)

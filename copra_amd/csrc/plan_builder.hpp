@@ -832,8 +832,28 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // Measured (M solves/s, square layout -> factor-only): headline shape 13.4 -> 21.3; run-time shapes with 45
         // variables 10.0 -> 19.0, 48: 10.1 -> 13.9, 64: 4.1 -> 9.8.  Up to 32 variables the packed kernels and the dense
         // square layouts already fill the wave slots, so those shapes stay as they are.
+        // The Riccati-factor tier (lmpc_fused_ric.hpp) is instantiated for the CoM shape at three horizons; N = 20 is chosen
+        // inside the factor-only block below (it competes with the layouts there), the shorter ones here -- they would
+        // otherwise run on the square layouts (30 variables) or the run-time-shape factor-only kernel (45)
+        bool ric_short = nx == 6 && nu == 3 && (N == 10 || N == 15) && P.rmax <= 6 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state
+            && P.ncost <= kRicMaxCosts && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI");
+        for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full;
+        bool ric_taken = false;
+        for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {
+            const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
+            LdsLayout t {};
+            if (layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, kFusedQ1Regs, budget)) {
+                hp.lds_safe = P.lds;
+                hp.safe_two_tier = hp.two_tier;
+                hp.two_tier = true;
+                hp.dense = true;
+                P.lds = t;
+                P.ric_tab = build_ric_tables(hp, 6);
+                ric_taken = true;
+            }
+        }
         const char* tmin = std::getenv("COPRA_TRI_MIN"); // (experiments: smallest number of variables that takes the tier)
-        if (U > (tmin ? std::atoi(tmin) : 32) && !std::getenv("COPRA_NO_TRI")) {
+        if (!ric_taken && U > (tmin ? std::atoi(tmin) : 32) && !std::getenv("COPRA_NO_TRI")) {
             const char* kenv = std::getenv("COPRA_TRI_K");
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU

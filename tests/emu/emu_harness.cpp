@@ -227,12 +227,16 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.ovf_list = ovf_list.data();
     P.from_list = 0;
     if (dump_instance >= 0) P.lds = hp.lds_full;
-    if (!s6 && P.lds.q1regs > 0) { // the run-time-shape body keeps Q1 in LDS (it never meets a register-Q1 layout in the library)
+    if (!s6 && !(use_specialised && P.lds.ric) && P.lds.q1regs > 0) { // the run-time-shape body keeps Q1 in LDS (it never meets a register-Q1 layout in the library)
         LdsLayout lq {};
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
     auto body = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && PP.lds.ric && PP.lds.q1regs) // (select_fused_kernel: the factor in Riccati form)
+        if (PP.lds.tri && PP.lds.ric && PP.N == 10) // (select_fused_kernel: the factor in Riccati form)
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.N == 15)
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.lds.q1regs)
             lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && PP.lds.ric)
             lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b);
@@ -409,7 +413,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, no per-instance references): one prepare
     // run of the body leaves the stage records, bkd, G and the row norms; the first tier copies them instead of sweeping
     std::vector<double> ric_model;
-    const bool ric_shared = P.lds.ric && P.lds.q1regs == kFusedQ1Regs && !warm_set && !std::getenv("COPRA_NO_RIC_SHARED");
+    const bool ric_shared = P.lds.ric && P.N == 20 && P.lds.q1regs == kFusedQ1Regs && !warm_set && !std::getenv("COPRA_NO_RIC_SHARED");
     if (ric_shared) {
         int oBk, oG, oNb;
         ric_model.assign((size_t)ric_model_offsets(nx, nu, N, P.mgen, oBk, oG, oNb), 0.0);

@@ -146,6 +146,23 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][0], wl["N"], bad, wl["cstrs"])["status"] == 2
 
 
+@pytest.mark.parametrize("N", [10, 15])
+def test_riccati_factor_tier_shorter_horizons(emu, oracle, N):
+    """the other two instantiated horizons of the CoM shape (30 and 45 variables; the body is generic in the horizon): selected
+    by the plan builder, statuses / iteration counts / U / X against the oracle on the default and the tight workload"""
+    from copra_amd import workloads
+    for kw in (dict(), dict(v_max=0.25, u_max=1.2)):
+        wl = workloads.com_preview(8, N=N, seed=6, **kw)
+        re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], N, wl["costs"], wl["cstrs"])
+        assert re["riccati_factor"]
+        for k in range(8):
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+            assert re["status"][k] == ro["status"]
+            if ro["status"] == 0:
+                assert tuple(re["iter"][k]) == tuple(ro["iter"])
+                assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_riccati_factor_tier_with_general_rows(emu, oracle):
     """the Riccati-factor tier with rows that are NOT one component of one state: a dense TrajectoryConstraint (velocity
     sum), a MixedConstraint (state + control at the same step), a ControlConstraint and an equality on the first control --

@@ -824,7 +824,7 @@ def test_run_time_specialisation(oracle, tmp_path):
     cache by the next controller of that shape"""
     import time
     from copra_amd import BatchLMPC, workloads
-    b, N = 2048, 15
+    b, N = 2048, 14  # (42 variables: a horizon without an instantiation of its own -- N = 10, 15, 20 run the Riccati-factor tier)
     wl = workloads.com_preview(b, N=N, v_max=0.3, u_max=1.5)
     ref = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
     ref.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
@@ -1094,4 +1094,15 @@ def test_shared_model_both_first_tiers(oracle, monkeypatch):
     good = (r1["status"] == 0) & (r2["status"] == 0)
     assert (r1["status"] == r2["status"]).all() and np.abs(r1["control"][good] - r2["control"][good]).max() <= 1e-9
     assert (r1["iter"][:, 0] > 1).mean() > 0.3
+    eng.close()
+
+
+@pytest.mark.parametrize("N", [10, 15])
+def test_riccati_factor_tier_shorter_horizons(oracle, N):
+    """CoM shape at the two shorter instantiated horizons (lmpc_fused_ric.hpp for N = 10, 15): whole batch against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(1024, N=N, v_max=0.3, u_max=1.5, seed=N)
+    eng, res, ref = _check(wl, 1024, oracle)
+    ok = ref["status"] == 0
+    assert (res["iter"][ok] == ref["iter"][ok]).all() and (res["iter"][:, 0] > 1).mean() > 0.2
     eng.close()
