@@ -25,6 +25,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     constexpr int NZ = NX + NU, NV = NU * NH, X = NX * (NH + 1);
     constexpr int nxx = NX * (NX + 1) / 2, nux = NU * NX, nuu = NU * (NU + 1) / 2;
     static_assert(NX * (NZ + 1) <= kWave && nxx + nux + nuu + NZ <= kWave && NV <= kWave, "one element per lane");
+    static_assert(nxx + nux + nuu >= NX * (NX + 1), "affine lanes of the stage cost and of the terminal cost are disjoint (ric_tab)");
     using RR = RicRec<NX, NU>;
     double* lds = lds_base();
     const LdsLayout& L = P.lds;
@@ -104,7 +105,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         m_on = false;
     }
     // The plan builder has evaluated them per lane (plan_builder.hpp, build_ric_tables): entry of Hin / HN, and for the
-    // affine lanes the coefficients of the references p_t, which may be per-instance -- 2 + 4 RP coalesced loads per cost.
+    // affine lanes the coefficients of the references p_t, which may be per-instance -- 2 + RP coalesced loads per cost.
     const int pi = lane % NX, pj = lane / NX; // element (pi, pj) of an NX x (NZ + 1) table: [A B d] layout
     double hreg, term; // Hin(ma, mb) or hin(ma) in the affine column | lanes e < NX NX: HN(e % NX, e / NX), the next NX: hN
     {
@@ -112,7 +113,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const double* tab = P.params + P.ric_tab;
         hreg = tab[lane];
         term = tab[kWave + lane];
-        double cw[kRicMaxCosts][RP], ct2[kRicMaxCosts][RP], pr[kRicMaxCosts][RP];
+        double cw[kRicMaxCosts][RP], pr[kRicMaxCosts][RP];
 #pragma unroll
         for (int t = 0; t < kRicMaxCosts; ++t) {
             const bool live = t < P.ncost;
@@ -121,18 +122,18 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             const double* pref = cost_reference(P, tt, inst);
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
-                cw[t][r] = tab[kWave * (2 + 2 * (tt * RP + r)) + lane];
-                ct2[t][r] = tab[kWave * (2 + 2 * (tt * RP + r) + 1) + lane];
+                cw[t][r] = tab[kWave * (2 + tt * RP + r) + lane];
                 pr[t][r] = live ? pref[r < rc ? r : rc - 1] : 0.0; // (rows past the term's have zero coefficients)
             }
         }
+        double aff = 0.0;
 #pragma unroll
         for (int t = 0; t < kRicMaxCosts; ++t)
 #pragma unroll
-            for (int r = 0; r < RP; ++r) {
-                hreg += cw[t][r] * pr[t][r];
-                term += ct2[t][r] * pr[t][r];
-            }
+            for (int r = 0; r < RP; ++r) aff += cw[t][r] * pr[t][r];
+        // (no lane owns an affine entry of the stage AND one of the terminal cost: the table holds whichever it has)
+        hreg += (m_on && mb == NZ) ? aff : 0.0;
+        term += (tj == NX) ? aff : 0.0;
         if (tj < NX)
             Pm[lane] = term;
         else if (tj == NX)

@@ -234,7 +234,7 @@ inline int build_ric_tables(HostPlan& hp, int rp)
     FusedPlan& P = hp.plan;
     const int nx = P.nx, nu = P.nu, nz = nx + nu;
     const int nxx = nx * (nx + 1) / 2, nux = nu * nx, nuu = nu * (nu + 1) / 2;
-    std::vector<double> tab((size_t)kWave * (2 + 2 * kRicMaxCosts * rp), 0.0);
+    std::vector<double> tab((size_t)kWave * (2 + kRicMaxCosts * rp), 0.0);
     auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]
         if (a < nx) return (ct.offM >= 0 && ct.kind != kCostControl) ? hp.params[(size_t)ct.offM + r + ct.rows * a] : 0.0;
         return (ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed)) ? hp.params[(size_t)ct.offN + r + ct.rows * (a - nx)] : 0.0;
@@ -274,13 +274,13 @@ inline int build_ric_tables(HostPlan& hp, int rp)
                     if (mb < nz)
                         h0 += (coef(ct, r, ma) * w) * coef(ct, r, mb);
                     else
-                        tab[(size_t)kWave * (2 + 2 * (t * rp + r)) + lane] = -(coef(ct, r, ma) * w);
+                        tab[(size_t)kWave * (2 + t * rp + r) + lane] = -(coef(ct, r, ma) * w);
                 }
                 if (in_term && tj <= nx) {
                     if (tj < nx)
                         t0 += (coef(ct, r, ti) * w) * coef(ct, r, tj);
                     else
-                        tab[(size_t)kWave * (2 + 2 * (t * rp + r) + 1) + lane] = -(coef(ct, r, ti) * w);
+                        tab[(size_t)kWave * (2 + t * rp + r) + lane] = -(coef(ct, r, ti) * w); // (lanes nx nx .. nx nx + nx - 1: never an affine stage lane)
                 }
             }
         }
