@@ -83,9 +83,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // triangle | the affine column (b == NZ)
     int ma = 0, mb = 0;
     bool m_on = true;
+    // (position t of a packed upper triangle -> column b = floor((sqrt(8 t + 1) - 1) / 2): sqrtf is exact on the perfect squares
+    //  8 t + 1 = (2 b + 1)^2 at which b steps)
+    auto tri_col = [](int t) { return (int)((sqrtf(8.0f * (float)t + 1.0f) - 0.999f) * 0.5f); }; // (0.001 of slack: the next smaller
+                                                                                                // radicand is 0.19 below for t < 64)
     if (lane < nxx) {
-        int b = 0;
-        while ((b + 1) * (b + 2) / 2 <= lane) ++b;
+        const int b = tri_col(lane);
         mb = b;
         ma = lane - b * (b + 1) / 2;
     } else if (lane < nxx + nux) {
@@ -94,8 +97,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         mb = t / NU;
     } else if (lane < nxx + nux + nuu) {
         const int t = lane - nxx - nux;
-        int b = 0;
-        while ((b + 1) * (b + 2) / 2 <= t) ++b;
+        const int b = tri_col(t);
         mb = NX + b;
         ma = NX + t - b * (b + 1) / 2;
     } else if (lane < nxx + nux + nuu + NZ) {
