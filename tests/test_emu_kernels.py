@@ -165,9 +165,9 @@ def test_riccati_factor_tier_shorter_horizons(emu, oracle, N):
 
 def test_riccati_factor_tier_with_general_rows(emu, oracle):
     """the Riccati-factor tier with rows that are NOT one component of one state: a dense TrajectoryConstraint (velocity
-    sum), a MixedConstraint (state + control at the same step), a ControlConstraint and an equality on the first control --
-    the row policy then has no maintained trajectory to read (StageRows::xu stays null: every scan refreshes the trajectory
-    from G) and the equality goes through the eqsgn path; statuses, iteration counts, U and X against the oracle"""
+    sum), a MixedConstraint (state + control at the same step) and a ControlConstraint -- the row policy then has no
+    maintained trajectory to read (StageRows::xu stays null: every scan refreshes the trajectory from G); statuses,
+    iteration counts, U and X against the oracle"""
     from copra_amd import workloads
     wl = workloads.com_preview(6, v_max=0.4, u_max=2.0, seed=21)
     E1 = np.zeros((1, 6)); E1[0, 3:] = 1.0           # vx + vy + vz <= 0.8
