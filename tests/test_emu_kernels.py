@@ -146,6 +146,25 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][0], wl["N"], bad, wl["cstrs"])["status"] == 2
 
 
+def test_riccati_factor_tier_with_equality_rows(emu, oracle):
+    """the Riccati-factor tier with a full-size equality entry (two rows: terminal velocities prescribed) next to the bounds:
+    the equality rows go through the orientation logic of the active-set loop (eqsgn), the full-size rows keep the trajectory
+    buffer of their own (seven instances per CU); statuses, iteration counts, U and X against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.5, u_max=2.5, seed=3)
+    E = np.zeros((2, 6 * 21))
+    E[0, 6 * 20 + 3] = 1.0
+    E[1, 6 * 20 + 4] = 1.0
+    cstrs = wl["cstrs"] + [dict(kind="trajectory", E=E, f=[0.05, -0.05], ineq=False)]
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+    assert re["riccati_factor"]
+    for k in range(6):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cstrs)
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"]) and ro["iter"][0] >= 3
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+        assert abs(re["trajectory"][k][6 * 20 + 3] - 0.05) <= 1e-9 and abs(re["trajectory"][k][6 * 20 + 4] + 0.05) <= 1e-9
+
+
 @pytest.mark.parametrize("N", [10, 15])
 def test_riccati_factor_tier_shorter_horizons(emu, oracle, N):
     """the other two instantiated horizons of the CoM shape (30 and 45 variables; the body is generic in the horizon): selected
