@@ -175,68 +175,100 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     if (lane < NX) Xbar[lane] = X0[lane];
     stamp[1] = cycle_counter();
     // ---- 2. backward Riccati sweep: stage records into F ----
-    // Per stage k (three synchronisation intervals):
-    //   (e) of stage k + 1: Acl = A + B K, bkd = d + B kv          | (a) T = P+ [A B d] (+ p+ in the affine column)
-    //   one preview step | (b) this lane's entry of M = Hin + [A B]' T; M_ux, h_u to LDS, M_uu to the record; M_uu^-1 in
-    //                          every lane from an LDL' factorisation of the broadcast M_uu (no square roots here)
-    //   (cd) P = M_xx - M_ux' M_uu^-1 M_ux, p = h_x - M_ux' M_uu^-1 h_u, K = -M_uu^-1 M_ux, kv = -M_uu^-1 h_u: ONE code
-    //        path, v = base - sum_c2 (sum_c M_uu^-1(c, c2) mine(c)) col(c2), with mine = column a of M_ux for the x rows and a
-    //        unit vector for the u rows.
+    // Every matrix product of a stage runs on v_mfma_f64_4x4x4 in a stacked index space of three blocks of four,
+    //     sigma:  0 .. NU-1 = u (block 0) | 4 .. 4+NX-1 = x (blocks 1, 2) | 4+NX = the affine column (d, p, h) | padding,
+    // hardware block b of the instruction = COLUMN block b of the result, one accumulator per ROW block; lane 16 q + 4 b + r
+    // then holds element (row q of the row block, column r of column block b) -- the layout of the B operand of the next
+    // product, so T and M and K chain through registers.  A operands that are results themselves (P+ as the left factor of T,
+    // M_ux' as the left factor of the update of P) go through LDS, which replicates them over the hardware blocks for free.
+    //     T_I  = P+_{I,.} [B A d]  (+ p+ in the affine column)                 I = 1, 2       4 MFMAs   (A operand: P+ from LDS)
+    //     M_I  = Hin_I + [B A]'_{I,.} T                                          I = 0, 1, 2    6 MFMAs   (B operand: T)
+    //     M_uu by v_readlane, adjugate / determinant, each lane keeps its element of -M_uu^-1
+    //     K    = -M_uu^-1 M_0                                                                    1 MFMA    (B operand: M_0)
+    //     P_I  = M_I + M_{0,I}' K                                                I = 1, 2       2 MFMAs   (A operand: M_0 from LDS)
+    //     [Acl | bkd]_I = [A | d]_I + B_I K                                      I = 1, 2       2 MFMAs   (off the chain)
+    // Two LDS hand-overs per stage (P+, M_0) instead of three, ~60 vector-ALU instructions instead of ~110.
     // Lam^-1 (the Cholesky factor of M_uu, inverted) and Bt = B Lam^-T are only used by the active-set iteration: they are
     // formed after the sweep for all stages at once (lane = stage), not twenty times inside it.
+    static_assert(NX <= 7 && NU <= 3, "stacked blocks of the MFMA sweep: u + pad | x_0..3 | x_4.., affine");
     {
-        double abr[NX]; // column pj of [A B d]
-        double aba[NX]; // column ma of [A B]
-        double brow[NU]; // row pi of B
-#pragma unroll
-        for (int t = 0; t < NX; ++t) {
-            abr[t] = (pj < NX) ? A[t + NX * pj] : (pj < NZ) ? B[t + NX * (pj - NX)] : (pj == NZ) ? D[t] : 0.0;
-            aba[t] = (ma < NX) ? A[t + NX * ma] : B[t + NX * (ma - NX)];
-        }
-#pragma unroll
-        for (int c = 0; c < NU; ++c) brow[c] = B[pi + NX * c];
-        const bool e_on = pj < NX || pj == NZ; // (e): Acl columns and bkd
-        const double eadd = (pj < NX) ? A[pi + NX * pj] : (pj == NZ) ? D[pi] : 0.0;
-        const int esrc = (pj < NX) ? RR::oK + NU * pj : RR::oKv; // column pj of K, or kv
-        double* const edst = (pj < NX) ? F + lane : Bk + pi; // (Acl is the head of the record, in this lane order)
-        const int estride = (pj < NX) ? RR::SZ : NX;
-        const bool a_on = lane < NX * (NZ + 1);
-        const double* apv = (pj == NZ) ? pv + pi : Zs;
-        const int mbc = (mb == NZ) ? NX : mb; // column of Mu / T this lane pairs with (h_u is column NX of Mu)
-        const int tcol = (mb == NZ) ? NZ : mb;
-        const bool is_x = ma < NX; // rows of P / p;  else rows of K / kv (u-x and affine lanes) or M_uu lanes
-        const bool is_uu = m_on && ma >= NX && mb >= NX && mb < NZ;
-        const bool is_k = m_on && ma >= NX && !is_uu;
-        const int uu_t = lane - nxx - nux; // position in the packed upper triangle of M_uu
-        // u rows: the unit vector that picks row (ma - NX) of M_uu^-1 -- a column of the table like the others (no select)
-        if (lane < NU * NU) Mu[NU * (NX + 1) + lane] = (lane % NU == lane / NU) ? 1.0 : 0.0;
-        const double* minep = Mu + NU * (is_x ? ma : NX + 1 + (ma - NX));
-        // where (cd) stores: x rows into P (both halves) or p; u rows into the record (K, kv)
-        const int w1 = is_x ? (mb < NX ? ma + NX * mb : NX * NX + ma) : (mb < NX ? RR::oK + (ma - NX) + NU * mb : RR::oKv + (ma - NX));
-        const int w2 = (is_x && mb < NX) ? mb + NX * ma : w1;
-        if (lane == 0) Zs[0] = 0.0;
-        bool bad = false;
-        wave_sync();
-        for (int k = NH - 1; k >= -1; --k) {
-            if (k < NH - 1 && e_on) {
-                double* Fe = F + (k + 1) * RR::SZ;
-                double acc = eadd;
-#pragma unroll
-                for (int c = 0; c < NU; ++c) acc += brow[c] * Fe[esrc + c];
-                edst[(k + 1) * estride] = acc;
-            }
-            if (k < 0) break;
-            if (a_on) {
-                double acc = *apv, acc2 = 0.0; // (two partial sums: half the dependent chain)
-#pragma unroll
-                for (int t = 0; t < NX; t += 2) {
-                    acc += Pm[t + NX * pi] * abr[t];
-                    if (t + 1 < NX) acc2 += Pm[t + 1 + NX * pi] * abr[t + 1];
-                }
-                T[pi + NX * pj] = acc + acc2;
+        constexpr int SAFF = 4 + NX; // stacked index of the affine column
+        const int q = lane >> 4, hb = (lane >> 2) & 3, r = lane & 3;
+        const int scol = 4 * hb + r; // stacked column of this lane's results
+        const bool col_x = scol >= 4 && scol < 4 + NX, col_aff = scol == SAFF;
+        double* const Mu2 = T; // NU x 12: rows u of M (every stacked column), the A operand of the update of P
+        double* const dummy = Zs + 1; // (lanes with nothing to store write here: no branches in the loop)
+        // Hin in result layout, through a 12 x (SAFF + 1) table in LDS (the lanes above hold one entry each: hreg)
+        {
+            double* HS = T; // (over T, Mu, Zs and the head of Bk: all written later)
+            constexpr int HSN = 12 * (SAFF + 1);
+            static_assert(HSN <= NX * (NZ + 1) + ((NU * (NX + 1 + NU) + 1) & ~1) + 2 + NH * NX, "table of Hin fits the scratch");
+            for (int e = lane; e < HSN; e += kWave) HS[e] = 0.0;
+            wave_sync();
+            if (m_on) {
+                const int sa = (ma < NX) ? 4 + ma : ma - NX;
+                const int sb = (mb == NZ) ? SAFF : (mb < NX) ? 4 + mb : mb - NX;
+                HS[sa + 12 * sb] = hreg;
+                if (mb != NZ) HS[sb + 12 * sa] = hreg;
             }
             wave_sync();
-            if (k == NH - 2) COPRA_FINE("sweep:e+a");
+        }
+        double Hacc[3];
+#pragma unroll
+        for (int I = 0; I < 3; ++I) Hacc[I] = (scol <= SAFF) ? T[(4 * I + q) + 12 * (scol <= SAFF ? scol : 0)] : 0.0;
+        wave_sync();
+        if (lane < 2) Zs[lane] = 0.0;
+        // row t of [B A d] at stacked column sc
+        auto abd = [&](int t, int sc) -> double {
+            if (t < 0 || t >= NX) return 0.0;
+            if (sc < NU) return B[t + NX * sc];
+            if (sc >= 4 && sc < 4 + NX) return A[t + NX * (sc - 4)];
+            return sc == SAFF ? D[t] : 0.0;
+        };
+        double bK[3], aM[3][3], aB[3]; // (index 0 unused: K-blocks / row blocks 1 and 2 are the x blocks)
+        const double* pA[3][3];
+        const double* pC[3];
+        const double* muA[3];
+#pragma unroll
+        for (int K = 1; K <= 2; ++K) {
+            bK[K] = abd(4 * (K - 1) + q, scol); // B operand (row x_t of K-block K, column scol); also C of the closed loop
+#pragma unroll
+            for (int I = 0; I < 3; ++I) aM[I][K] = (4 * I + r == SAFF) ? 0.0 : abd(4 * (K - 1) + q, 4 * I + r); // A operand of M
+        }
+#pragma unroll
+        for (int I = 1; I <= 2; ++I) {
+            const int ir = 4 * (I - 1) + r, iq = 4 * (I - 1) + q; // x row as A-operand row / as result row
+            aB[I] = (ir < NX && q < NU) ? B[ir + NX * q] : 0.0;
+#pragma unroll
+            for (int K = 1; K <= 2; ++K) {
+                const int kq = 4 * (K - 1) + q;
+                pA[I][K] = (ir < NX && kq < NX) ? Pm + ir + NX * kq : Zs;
+            }
+            pC[I] = (col_aff && iq < NX) ? pv + iq : Zs;
+            muA[I] = (ir < NX && q < NU) ? Mu2 + q + NU * (4 + ir) : Zs;
+        }
+        // where results go
+        double* const wMu = (q < NU && hb < 3) ? Mu2 + q + NU * scol : dummy;
+        const bool uu_on = q < NU && hb == 0 && r <= q;
+        const int uu_off = RR::oLi + q * (q + 1) / 2 + r;
+        const bool k_on = q < NU && (col_x || col_aff);
+        const int k_off = col_x ? RR::oK + q + NU * (scol - 4) : RR::oKv + q;
+        double* wP[3];
+        double* wA[3];
+        int wAst[3];
+#pragma unroll
+        for (int I = 1; I <= 2; ++I) {
+            const int iq = 4 * (I - 1) + q;
+            const bool on = iq < NX && (col_x || col_aff);
+            wP[I] = !on ? dummy : col_x ? Pm + iq + NX * (scol - 4) : pv + iq;
+            wA[I] = !on ? dummy : col_x ? F + RR::oAcl + iq + NX * (scol - 4) : Bk + iq;
+            wAst[I] = !on ? 0 : col_x ? RR::SZ : NX;
+        }
+        const bool my_minv = r < NU && q < NU; // A operand of K: element (row r, k = q) of -M_uu^-1
+        bool bad = false;
+        wave_sync();
+        for (int k = NH - 1; k >= 0; --k) {
+            double* Fk = F + k * RR::SZ;
             { // preview step s = NH - k
                 const int s = NH - k;
                 double n0 = mfma_f64_4x4x4(pa[0][0], px[0], pc[0]);
@@ -252,56 +284,63 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                     if (4 + q4 < NX) pdst[s * pst + 4] = n1;
                 }
             }
-            if (k == NH - 2) COPRA_FINE("sweep:preview");
-            double* Fk = F + k * RR::SZ;
-            double mval = hreg, mval2 = 0.0;
-#pragma unroll
-            for (int t = 0; t < NX; t += 2) {
-                mval += aba[t] * T[t + NX * tcol];
-                if (t + 1 < NX) mval2 += aba[t + 1] * T[t + 1 + NX * tcol];
+            // T_I = P+_{I,.} [B A d] + [0 | p+]
+            double T1 = mfma_f64_4x4x4(*pA[1][1], bK[1], *pC[1]);
+            double T2 = mfma_f64_4x4x4(*pA[2][1], bK[1], *pC[2]);
+            if (NX > 4) {
+                T1 = mfma_f64_4x4x4(*pA[1][2], bK[2], T1);
+                T2 = mfma_f64_4x4x4(*pA[2][2], bK[2], T2);
             }
-            mval += mval2;
-            if (is_k) Mu[(ma - NX) + NU * mbc] = mval;
-            if (is_uu) Fk[RR::oLi + uu_t] = mval; // (packed upper triangle; replaced by Lam^-1 after the sweep)
-            double mi[NU][NU]; // M_uu^-1 (symmetric)
+            // M_I = Hin_I + [B A]'_{I,.} T
+            double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hacc[0]);
+            double M1 = mfma_f64_4x4x4(aM[1][1], T1, Hacc[1]);
+            double M2 = mfma_f64_4x4x4(aM[2][1], T1, Hacc[2]);
+            if (NX > 4) {
+                M0 = mfma_f64_4x4x4(aM[0][2], T2, M0);
+                M1 = mfma_f64_4x4x4(aM[1][2], T2, M1);
+                M2 = mfma_f64_4x4x4(aM[2][2], T2, M2);
+            }
+            *wMu = M0;
+            if (uu_on) Fk[uu_off] = M0; // (packed upper triangle; replaced by Lam^-1 after the sweep)
+            wave_sync();
+            const double mu1 = *muA[1], mu2 = *muA[2]; // (read back now: the latency hides under the inversion of M_uu below)
+            // M_uu(c, c') sits in lane 16 c + c' of M0
+            double mine = 0.0; // element (r, q) of -M_uu^-1
             if constexpr (NU == 3) {
-                // 3 x 3: adjugate over determinant -- ONE reciprocal and a dependent chain of 11 operations (cofactor, determinant,
-                // reciprocal + two Newton steps, scaling) where the LDL' below has three reciprocals in sequence (26); positive
-                // definite <=> the leading minors m00, C22, det are positive (Sylvester)
-                const int ub = nxx + nux; // lanes of the packed upper triangle: (0,0) (0,1) (1,1) (0,2) (1,2) (2,2)
-                const double m00 = bcast_f64(mval, ub + 0), m01 = bcast_f64(mval, ub + 1), m11 = bcast_f64(mval, ub + 2);
-                const double m02 = bcast_f64(mval, ub + 3), m12 = bcast_f64(mval, ub + 4), m22 = bcast_f64(mval, ub + 5);
+                // 3 x 3: adjugate over determinant -- ONE reciprocal and a dependent chain of 11 operations; positive definite
+                // <=> the leading minors m00, C22, det are positive (Sylvester)
+                const double m00 = bcast_f64(M0, 0), m01 = bcast_f64(M0, 1), m02 = bcast_f64(M0, 2);
+                const double m11 = bcast_f64(M0, 17), m12 = bcast_f64(M0, 18), m22 = bcast_f64(M0, 34);
                 const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
                 const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
                 const double det = m00 * c00 + (m01 * c01 + m02 * c02);
                 bad = bad || !(m00 > 0.0) || !(c22 > 0.0) || !(det > 0.0);
-                const double rdet = ric_rcp(det);
-                mi[0][0] = c00 * rdet;
-                mi[0][1] = mi[1][0] = c01 * rdet;
-                mi[0][2] = mi[2][0] = c02 * rdet;
-                mi[1][1] = c11 * rdet;
-                mi[1][2] = mi[2][1] = c12 * rdet;
-                mi[2][2] = c22 * rdet;
-            } else
-            {
-                double lm[NU][NU]; // M_uu (lower part) -> unit lower L of M_uu = L D L'
-                double rd[NU]; // 1 / D(c)
+                const double nrdet = -ric_rcp(det);
+                // this lane's cofactor: (r, q) symmetric
+                double cf = c00;
+                cf = ((r == 0 && q == 1) || (r == 1 && q == 0)) ? c01 : cf;
+                cf = ((r == 0 && q == 2) || (r == 2 && q == 0)) ? c02 : cf;
+                cf = (r == 1 && q == 1) ? c11 : cf;
+                cf = ((r == 1 && q == 2) || (r == 2 && q == 1)) ? c12 : cf;
+                cf = (r == 2 && q == 2) ? c22 : cf;
+                mine = my_minv ? cf * nrdet : 0.0;
+            } else {
+                double lm[NU][NU], rd[NU], li[NU][NU];
 #pragma unroll
                 for (int cb = 0; cb < NU; ++cb)
 #pragma unroll
-                    for (int ca = 0; ca <= cb; ++ca) lm[cb][ca] = bcast_f64(mval, nxx + nux + cb * (cb + 1) / 2 + ca); // M_uu(ca, cb)
+                    for (int ca = 0; ca <= cb; ++ca) lm[cb][ca] = bcast_f64(M0, 16 * cb + ca);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    // column c:  v_r = M(r, c) - sum_q L(r, q) D(q) L(c, q);  D(c) = v_c;  L(r, c) = v_r / D(c)
-                    double dl[NU]; // D(q) L(c, q)
+                    double dl[NU];
 #pragma unroll
-                    for (int q = 0; q < c; ++q) dl[q] = lm[c][q]; // (still D(q) L(c, q): scaled below)
+                    for (int t = 0; t < c; ++t) dl[t] = lm[c][t];
                     double dc = lm[c][c];
 #pragma unroll
-                    for (int q = 0; q < c; ++q) {
-                        const double lcq = dl[q] * rd[q];
-                        dc -= lcq * dl[q];
-                        lm[c][q] = lcq;
+                    for (int t = 0; t < c; ++t) {
+                        const double lct = dl[t] * rd[t];
+                        dc -= lct * dl[t];
+                        lm[c][t] = lct;
                     }
                     bad = bad || !(dc > 0.0);
                     rd[c] = ric_rcp(dc);
@@ -309,19 +348,17 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                     for (int r2 = c + 1; r2 < NU; ++r2) {
                         double v = lm[r2][c];
 #pragma unroll
-                        for (int q = 0; q < c; ++q) v -= lm[r2][q] * lm[c][q]; // lm[r2][q] = D(q) L(r2, q), lm[c][q] = L(c, q)
-                        lm[r2][c] = v; // D(c) L(r2, c)
+                        for (int t = 0; t < c; ++t) v -= lm[r2][t] * lm[c][t];
+                        lm[r2][c] = v;
                     }
                 }
-                // L^-1 (unit lower) by forward substitution
-                double li[NU][NU];
 #pragma unroll
                 for (int c = 0; c < NU; ++c)
 #pragma unroll
                     for (int r2 = c; r2 < NU; ++r2) {
                         double v = (r2 == c) ? 1.0 : 0.0;
 #pragma unroll
-                        for (int q = c; q < r2; ++q) v -= lm[r2][q] * li[q][c];
+                        for (int t = c; t < r2; ++t) v -= lm[r2][t] * li[t][c];
                         li[r2][c] = v;
                     }
 #pragma unroll
@@ -330,34 +367,26 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                     for (int c = r2; c < NU; ++c) {
                         double v = 0.0;
 #pragma unroll
-                        for (int q = c; q < NU; ++q) v += (li[q][r2] * rd[q]) * li[q][c];
-                        mi[r2][c] = v;
-                        mi[c][r2] = v;
+                        for (int t = c; t < NU; ++t) v += (li[t][r2] * rd[t]) * li[t][c];
+                        mine = ((r == r2 && q == c) || (r == c && q == r2)) ? -v : mine;
                     }
+                mine = my_minv ? mine : 0.0;
             }
+            // K = -M_uu^-1 M_0  (rows u: K | kv in the affine column)
+            const double Kr = mfma_f64_4x4x4(mine, M0, 0.0);
+            if (k_on) Fk[k_off] = Kr;
+            // P_I = M_I + M_{0,I}' K   (rows / columns x: the new cost-to-go; affine column: p)
+            const double P1 = mfma_f64_4x4x4(mu1, Kr, M1);
+            const double P2 = mfma_f64_4x4x4(mu2, Kr, M2);
+            *wP[1] = P1;
+            if (NX > 4) *wP[2] = P2;
+            // [Acl | bkd]_I = [A | d]_I + B_I K
+            const double A1 = mfma_f64_4x4x4(aB[1], Kr, bK[1]);
+            const double A2 = mfma_f64_4x4x4(aB[2], Kr, bK[2]);
+            wA[1][k * wAst[1]] = A1;
+            if (NX > 4) wA[2][k * wAst[2]] = A2;
             wave_sync();
-            if (k == NH - 2) COPRA_FINE("sweep:b+ldl");
-            if (m_on && !is_uu) {
-                double col[NU], mine[NU];
-#pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    col[c] = Mu[c + NU * mbc];
-                    mine[c] = minep[c];
-                }
-                double v = is_x ? mval : 0.0;
-#pragma unroll
-                for (int c2 = 0; c2 < NU; ++c2) {
-                    double ta = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NU; ++c) ta += mi[c][c2] * mine[c];
-                    v -= ta * col[c2];
-                }
-                double* base = is_x ? Pm : Fk;
-                base[w1] = v;
-                base[w2] = v;
-            }
-            wave_sync();
-            if (k == NH - 2) COPRA_FINE("sweep:cd");
+            if (k == NH - 2) COPRA_FINE("sweep:stage");
             if (k == NH - 1) COPRA_FINE("sweep:first");
         }
         COPRA_FINE("sweep:loop");
