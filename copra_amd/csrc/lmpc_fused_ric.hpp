@@ -198,25 +198,24 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const bool col_x = scol >= 4 && scol < 4 + NX, col_aff = scol == SAFF;
         double* const Mu2 = T; // NU x 12: rows u of M (every stacked column), the A operand of the update of P
         double* const dummy = Zs + 1; // (lanes with nothing to store write here: no branches in the loop)
-        // Hin in result layout, through a 12 x (SAFF + 1) table in LDS (the lanes above hold one entry each: hreg)
+        // Hin in result layout: the quadratic part straight from the plan builder's table (second view), the affine column from
+        // the lanes that hold hin(a) in `hreg`, through NZ doubles of LDS
+        double Hacc[3];
         {
-            double* HS = T; // (over T, Mu, Zs and the head of Bk: all written later)
-            constexpr int HSN = 12 * (SAFF + 1);
-            static_assert(HSN <= NX * (NZ + 1) + ((NU * (NX + 1 + NU) + 1) & ~1) + 2 + NH * NX, "table of Hin fits the scratch");
-            for (int e = lane; e < HSN; e += kWave) HS[e] = 0.0;
+            const double* tabq = P.params + P.ric_tab + kWave * (2 + kRicMaxCosts * RP);
+#pragma unroll
+            for (int I = 0; I < 3; ++I) Hacc[I] = tabq[kWave * I + lane];
+            double* AF = T; // [stacked row]: 12 doubles
+            if (lane < 12) AF[lane] = 0.0;
             wave_sync();
-            if (m_on) {
-                const int sa = (ma < NX) ? 4 + ma : ma - NX;
-                const int sb = (mb == NZ) ? SAFF : (mb < NX) ? 4 + mb : mb - NX;
-                HS[sa + 12 * sb] = hreg;
-                if (mb != NZ) HS[sb + 12 * sa] = hreg;
+            if (m_on && mb == NZ) AF[(ma < NX) ? 4 + ma : ma - NX] = hreg;
+            wave_sync();
+            if (col_aff) {
+#pragma unroll
+                for (int I = 0; I < 3; ++I) Hacc[I] += AF[4 * I + q];
             }
             wave_sync();
         }
-        double Hacc[3];
-#pragma unroll
-        for (int I = 0; I < 3; ++I) Hacc[I] = (scol <= SAFF) ? T[(4 * I + q) + 12 * (scol <= SAFF ? scol : 0)] : 0.0;
-        wave_sync();
         if (lane < 2) Zs[lane] = 0.0;
         // row t of [B A d] at stacked column sc
         auto abd = [&](int t, int sc) -> double {

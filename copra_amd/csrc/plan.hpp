@@ -200,7 +200,8 @@ struct FusedPlan {
     int rmax; // max rows over the per-step costs
     // Riccati-factor tier (lmpc_fused_ric.hpp): per-lane stage-cost tables in `params`, built by the plan builder --
     //   [0, 64): Hin entry of the lane | [64, 128): HN entry | then per cost t and row r < 6 one vector of 64: the
-    //   coefficient of p_t[r] in the lane's affine entry (of the stage cost OR of the terminal cost: no lane has both).  -1: none.
+    //   coefficient of p_t[r] in the lane's affine entry (of the stage cost OR of the terminal cost: no lane has both) | then
+    //   three vectors of 64: Hin again, in the accumulator layout of the MFMA sweep (row blocks 0, 1, 2).  -1: none.
     int ric_tab;
     // Shared-model mode of that tier (copra_batch_set_shared_system): the stage records do not depend on x0, so ONE prepare
     // launch sweeps (ric_model_out, instance dump_instance) and every instance of the batch copies the result (ric_model):

@@ -234,7 +234,8 @@ inline int build_ric_tables(HostPlan& hp, int rp)
     FusedPlan& P = hp.plan;
     const int nx = P.nx, nu = P.nu, nz = nx + nu;
     const int nxx = nx * (nx + 1) / 2, nux = nu * nx, nuu = nu * (nu + 1) / 2;
-    std::vector<double> tab((size_t)kWave * (2 + kRicMaxCosts * rp), 0.0);
+    std::vector<double> tab((size_t)kWave * (2 + kRicMaxCosts * rp + 3), 0.0);
+    std::vector<double> Hin((size_t)nz * nz, 0.0); // the quadratic part, for the second view below
     auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]
         if (a < nx) return (ct.offM >= 0 && ct.kind != kCostControl) ? hp.params[(size_t)ct.offM + r + ct.rows * a] : 0.0;
         return (ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed)) ? hp.params[(size_t)ct.offN + r + ct.rows * (a - nx)] : 0.0;
@@ -291,7 +292,16 @@ inline int build_ric_tables(HostPlan& hp, int rp)
         }
         tab[lane] = h0;
         tab[kWave + lane] = t0;
+        if (on && mb < nz) Hin[(size_t)ma + nz * mb] = Hin[(size_t)mb + nz * ma] = h0;
     }
+    // second view of Hin for the MFMA sweep: accumulator layout -- lane 16 q + 4 b + r of row block I holds the entry (stacked row
+    // 4 I + q, stacked column 4 b + r), stacked index: 0 .. nu-1 = u | 4 .. 4+nx-1 = x (the affine column comes from the lanes above)
+    auto unstack = [&](int s) { return s < nu ? nx + s : (s >= 4 && s < 4 + nx) ? s - 4 : -1; }; // -> index in z = (x, u)
+    for (int I = 0; I < 3; ++I)
+        for (int lane = 0; lane < kWave; ++lane) {
+            const int a = unstack(4 * I + (lane >> 4)), b = unstack(4 * ((lane >> 2) & 3) + (lane & 3));
+            tab[(size_t)kWave * (2 + kRicMaxCosts * rp + I) + lane] = (a >= 0 && b >= 0) ? Hin[(size_t)a + nz * b] : 0.0;
+        }
     const int at = (int)hp.params.size();
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
     return at;
