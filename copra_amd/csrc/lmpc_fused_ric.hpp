@@ -110,6 +110,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // affine lanes the coefficients of the references p_t, which may be per-instance -- 2 + RP coalesced loads per cost.
     const int pi = lane % NX, pj = lane / NX; // element (pi, pj) of an NX x (NZ + 1) table: [A B d] layout
     double hreg, term; // Hin(ma, mb) or hin(ma) in the affine column | lanes e < NX NX: HN(e % NX, e / NX), the next NX: hN
+    double Hacc[3]; // Hin in the accumulator layout of the MFMA sweep (row blocks 0, 1, 2): fetched here, with the other tables
+    {
+        const double* tabq = P.params + P.ric_tab + kWave * (2 + kRicMaxCosts * RP);
+#pragma unroll
+        for (int I = 0; I < 3; ++I) Hacc[I] = tabq[kWave * I + lane];
+    }
     {
         const int ti = pi, tj = pj; // tj == NX: hN
         const double* tab = P.params + P.ric_tab;
@@ -200,11 +206,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         double* const dummy = Zs + 1; // (lanes with nothing to store write here: no branches in the loop)
         // Hin in result layout: the quadratic part straight from the plan builder's table (second view), the affine column from
         // the lanes that hold hin(a) in `hreg`, through NZ doubles of LDS
-        double Hacc[3];
         {
-            const double* tabq = P.params + P.ric_tab + kWave * (2 + kRicMaxCosts * RP);
-#pragma unroll
-            for (int I = 0; I < 3; ++I) Hacc[I] = tabq[kWave * I + lane];
             double* AF = T; // [stacked row]: 12 doubles
             if (lane < 12) AF[lane] = 0.0;
             wave_sync();
