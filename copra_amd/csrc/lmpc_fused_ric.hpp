@@ -7,13 +7,17 @@
 // Hessian of a stage-wise LQ problem, and ONE backward Riccati sweep over the N stages yields a factor of Q^-1 whose two
 // products are closed-loop recursions (ric_factor.hpp).  O(N (nx+nu)^3) = 15 k multiply-adds at the headline shape
 // instead of 11 k (cost phase) + 72 k (Cholesky) + 7 k (two substitutions), and -- what matters on a latency-bound wave --
-// 60 dependent steps of three LDS round trips instead of the 35 k + 32 k + 8 k cycles those three phases take.
+// twenty stages of small chained block products instead of the 35 k + 32 k + 8 k cycles those three phases take.
+// Every matrix product of the body (sweep, preview recursion, roll-out, the two recursions of the active-set iteration) runs
+// on v_mfma_f64_4x4x4 with results chained as the B operands of the next product; the trajectory is MAINTAINED (the closed-loop
+// states of a step direction are its effect on the trajectory), so nothing sums over the blocks G after the row norms.
 //     stage k < N:   l_k(x, u) = 1/2 [x; u]' Hin [x; u] + hin' [x; u],   Hin = sum_t [M_t N_t]' W_t [M_t N_t] (+ 1e-6 I on u),
 //                                                                       hin = -sum_t [M_t N_t]' W_t p_t
 //     stage N:       l_N(x) = 1/2 x' HN x + hN' x                        (TrajectoryCost and TargetCost terms)
 // The unconstrained minimiser -Q^-1 c (qpgen2's starting point) is the LQ roll-out u_k = K_k x_k + kv_k from x_0.
 // Constraint rows, bounds, status codes, iteration counts, results: exactly the fused body's (StageRows, gi_active_set).
-// Shapes: compile-time (NX, NU, NH) with NX (NX + NU + 1) <= 64 (one element of P [A B d] per lane).
+// Shapes: compile-time (NX, NU, NH) with NX <= 7, 2 <= NU <= 3, NU NH <= 64 (the static_asserts below); instantiated for the CoM
+// shape (6, 3) at N = 10, 15, 20.  Shared-model mode: FusedPlan::ric_model (the records come from one prepare run).
 #pragma once
 #include "lmpc_fused.hpp"
 
@@ -47,9 +51,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                                                                                          //  target of the lanes that store nothing)
     double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
-    double* T = pv + ((NX + 1) & ~1); // NX x (NZ + 1):  P [A B d] (+ p in the last column)
-    double* Mu = T + NX * (NZ + 1); // NU x (NX + 1 + NU):  [M_ux | h_u | I]  (the unit columns: what a row of K multiplies M_uu^-1 with)
-    double* Zs = Mu + ((NU * (NX + 1 + NU) + 1) & ~1); // two doubles that hold 0.0 during the sweep
+    double* T = pv + ((NX + 1) & ~1); // NX (NZ + 1) doubles: the rows u of M (NU x 12, A operand of the update of P); 12 doubles of hand-over before the sweep
+    double* Mu = T + NX * (NZ + 1); // (spare)
+    double* Zs = Mu + ((NU * (NX + 1 + NU) + 1) & ~1); // [0]: holds 0.0 during the sweep (operands that are structurally zero); [1]: write-only spare
     double* Bk = Zs + 2; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
 
     long long stamp[8];
