@@ -66,8 +66,9 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 }
 
 // The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
+// (three waves per SIMD: 161 VGPRs; with 17.7 KB of LDS per instance nine instances share a CU)
 template <int NX, int NU, int NH, int QR>
-__global__ __launch_bounds__(64, 2) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
+__global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {
     lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, P.inst_offset + (int)blockIdx.x);
 }

@@ -70,7 +70,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     if (from_model) {
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
-        for (int e = lane; e < NH * RR::SZ; e += kWave) F[e] = P.ric_model[e];
+        for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
         for (int e = lane; e < NH * NX; e += kWave) Bk[e] = P.ric_model[mBk + e];
         for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         stamp[1] = cycle_counter();
@@ -441,21 +441,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         }
         wave_sync();
         COPRA_FINE("sweep:Li");
-        // Bt = B Lam^-T of every stage
-        for (int e = lane; e < NH * NX * NU; e += kWave) {
-            const int k = e / (NX * NU), rem = e - k * NX * NU;
-            const int c = rem / NX, j = rem - c * NX;
-            const double* Lk = F + k * RR::SZ + RR::oLi;
-            double acc = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < NU; ++c2) acc += B[j + NX * c2] * Lk[c + NU * c2];
-            F[k * RR::SZ + RR::oBt + rem] = acc;
-        }
+        // the constant block behind the records: B (it takes the place of every Bt_k, ric_factor.hpp) and the identity
+        if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
+        if (lane < NU * NU) F[NH * RR::SZ + RR::cI + lane] = (lane % NU == lane / NU) ? 1.0 : 0.0;
     }
     } // (!from_model)
     wave_sync();
     if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
-        for (int e = lane; e < NH * RR::SZ; e += kWave) P.ric_model_out[e] = F[e];
+        for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
         for (int e = lane; e < NH * NX; e += kWave) P.ric_model_out[mBk + e] = Bk[e];
         for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
     }
@@ -466,17 +459,18 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     //      stacked matrix, the state handed on by a DPP row broadcast) ----
     {
         const int q = lane >> 4, b4 = (lane >> 2) & 3, r = lane & 3, row = 4 * b4 + r;
-        int off[2];
+        int off[2], km[2];
 #pragma unroll
-        for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU>(row, 4 * J + q);
+        for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU, NH>(row, 4 * J + q, km[J]);
         // K-block 2: the constant 1 at stacked component 8 (lane row q == 0) times the column [bkd; kv]
-        const double* p2 = F + RR::oLi + NU; // (a zero of every record)
-        int st2 = RR::SZ;
+        const double* p2 = F + NH * RR::SZ + RR::cI + NU; // (I(0, 1): a zero)
+        int st2 = 0;
         if (q == 0 && row < NX) {
             p2 = Bk + row;
             st2 = NX;
         } else if (q == 0 && row >= 8 && row < 8 + NU) {
             p2 = F + RR::oKv + (row - 8);
+            st2 = RR::SZ;
         }
         const double one = (q == 0) ? 1.0 : 0.0;
         const bool writer = q < NU && b4 == 2 && r == 0;
@@ -491,14 +485,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         double* const xwp = xwriter ? XU + NX + yrow : S.ricx + kWave - 2;
         const int xwst = xwriter ? NX : 0;
         double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
-        double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0];
+        double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0]; // (stage 0)
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
         if (xwriter) XU[yrow] = x0r;
 #pragma unroll COPRA_RIC_UNROLL
         for (int k = 0; k < NH; ++k) {
             const int kn = k + 1 < NH ? k + 1 : k;
-            const double* Fn = F + kn * RR::SZ;
-            const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = p2[kn * st2];
+            const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], n2 = p2[kn * st2];
             double y = mfma_f64_4x4x4(a2, one, 0.0);
             y = mfma_f64_4x4x4(a0, s0, y);
             y = mfma_f64_4x4x4(a1, s1, y);

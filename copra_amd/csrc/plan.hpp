@@ -179,8 +179,9 @@ struct LargeLayout {
 // offsets (doubles) of the four parts of FusedPlan::ric_model; returns the total
 COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
 {
-    const int rec = (nx * nx + 2 * nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
-    oBk = N * rec;
+    const int rec = (nx * nx + nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int cst = (nx * nu + nu * nu + 1) & ~1; // RicRec<NX, NU>::CST (B | I behind the records)
+    oBk = N * rec + cst;
     oG = oBk + N * nx;
     oNb = oG + N * nx * nu;
     return oNb + ((mgen + 1) & ~1);
@@ -205,7 +206,7 @@ struct FusedPlan {
     int ric_tab;
     // Shared-model mode of that tier (copra_batch_set_shared_system): the stage records do not depend on x0, so ONE prepare
     // launch sweeps (ric_model_out, instance dump_instance) and every instance of the batch copies the result (ric_model):
-    //   records [N x RicRec::SZ] | bkd [N x nx] | G [N x nx x nu] | row norms [mgen]      (ric_model_offsets below)
+    //   records [N x RicRec::SZ] + constant block | bkd [N x nx] | G [N x nx x nu] | row norms [mgen]      (ric_model_offsets below)
     const double* ric_model;
     double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)

@@ -179,7 +179,8 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
         return at;
     };
     L = LdsLayout {};
-    const int rec = (nx * nx + 2 * nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int rec = (nx * nx + nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int cst = (nx * nu + nu * nu + 1) & ~1; // RicRec<NX, NU>::CST
     L.ldj = (n % 2 == 0) ? n + 1 : n;
     L.tri = 1;
     L.ric = 1;
@@ -187,7 +188,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.rcap = q1regs;
     L.G = take(N * nx * nu);
     L.Xbar = take(X);
-    L.J = take(N * rec > X ? N * rec : X);
+    L.J = take(N * rec + cst > X ? N * rec + cst : X);
     L.Xcur = xcur_late ? L.J : take(X);
     L.A = take(nx * nx);
     L.B = take(nx * nu);

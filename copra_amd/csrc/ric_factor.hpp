@@ -13,9 +13,14 @@
 // cancels in every quantity the method looks at, so the steps, the active sets and the iterates are the same up to rounding.
 // (Check of the algebra in numpy: tools/exp/ric_factor_proto.py.)
 //
+// Bt is never stored: with t_k = Lam_k^-T v_k formed beforehand the forward recursion is  z_k = K_k xi_k + t_k,
+// xi_{k+1} = Acl_k xi_k + B t_k  (the CONSTANT B in place of Bt_k), and the backward one yields s_k = n_k + B' mu_{k+1} with
+// w_k = Lam_k^-1 s_k afterwards -- 18 doubles less per stage, which is what lets a ninth instance share a CU.
+//
 // Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
-//     Acl (NX x NX, column-major) | Bt (NX x NU, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (NU x NU, column-major,
-//     lower triangular, the upper part stored as zeros) | kv (NU: feed-forward of the unconstrained minimiser)
+//     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (NU x NU, column-major, lower triangular, the upper
+//     part stored as zeros) | kv (NU: feed-forward of the unconstrained minimiser)
+// followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | I (NU x NU)
 #pragma once
 
 #ifndef COPRA_RIC_UNROLL
@@ -40,11 +45,14 @@ COPRA_DEV double ric_rcp(double x)
 template <int NX, int NU>
 struct RicRec {
     static constexpr int oAcl = 0;
-    static constexpr int oBt = oAcl + NX * NX;
-    static constexpr int oK = oBt + NX * NU;
+    static constexpr int oK = oAcl + NX * NX;
     static constexpr int oLi = oK + NU * NX;
     static constexpr int oKv = oLi + NU * NU;
     static constexpr int SZ = (oKv + NU + 1) & ~1;
+    // the constant block behind the N records
+    static constexpr int cB = 0;
+    static constexpr int cI = cB + NX * NU;
+    static constexpr int CST = (cI + NU * NU + 1) & ~1;
 };
 
 // ---- the two products on the matrix cores ------------------------------------------------------------------------
@@ -55,18 +63,22 @@ struct RicRec {
 // ALU (18 per stage).  (History: a vector-ALU version and one on v_mfma_f64_16x16x4 -- 64 cycles of the matrix pipe per
 // instruction on MI355X, no faster than the vector ALU -- preceded the one below; DESIGN.md 3.9b has their numbers.)
 // Stacked index:  0 .. NX-1 state components (NX <= 8) | 8 .. 8+NU-1 input / output components.
-template <int NX, int NU>
-COPRA_DEV int ric_stack_offset(int s_out, int s_in)
+// -> offset (doubles from the first record) of element (s_out, s_in) of the stacked matrix [Acl B; K I] of the forward
+// recursion; kmul = RicRec::SZ if the element belongs to the stage record (add kmul * stage), 0 for the constant block.
+template <int NX, int NU, int NH>
+COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
 {
     using RR = RicRec<NX, NU>;
     static_assert(NX <= 8 && NU >= 2 && NU <= 4, "stacked layout of the MFMA recursions");
-    const int zero = RR::oLi + NU; // Lam^-1(0, 1): stored as zero in every record
+    constexpr int cbase = NH * RR::SZ;
+    kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
     const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
-    if (to == 2 || ti == 2) return zero;
+    if (to == 2 || ti == 2) return cbase + RR::cI + NU; // I(0, 1) = 0
     const int a = to == 0 ? s_out : s_out - 8, b = ti == 0 ? s_in : s_in - 8;
-    if (to == 0) return ti == 0 ? RR::oAcl + a + NX * b : RR::oBt + a + NX * b; // Acl(a, b) | Bt(a, b)
-    return ti == 0 ? RR::oK + a + NU * b : RR::oLi + b + NU * a; // K(a, b) | Lam^-T(a, b) = Lam^-1(b, a)
+    if (ti == 1) return cbase + (to == 0 ? RR::cB + a + NX * b : RR::cI + a + NU * b); // B(a, b) | I(a, b)
+    kmul = RR::SZ;
+    return to == 0 ? RR::oAcl + a + NX * b : RR::oK + a + NU * b; // Acl(a, b) | K(a, b)
 }
 
 // ---- on v_mfma_f64_4x4x4_4b_f64 ----------------------------------------------------------------------------------
@@ -77,19 +89,34 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in)
 // lane = 16 q + 4 b + r:  A operand (row 4b + r, column 4J + q), B operand: component 4J + q of the vector in all lanes of row q.
 // nstages (TR only): the backward recursion starts at stage nstages - 1 -- the normal of a constraint at step k has no
 // component beyond stage k - 1, mu is zero until then and so is w beyond it (X must hold zeros there: see the caller).
-template <int NX, int NU, int NH, bool TR>
+// in / X (may be the same NU NH doubles of LDS): the input vector (v for the forward recursion, n for the backward one) and
+// the hand-over buffer; returns component `lane` of z = Rinv v (TR = false) or of w = Rinv' n (TR = true).
 // XI (forward recursion only): the closed-loop states xi_0 .. xi_NH are stored there, NX per stage.
 // dummy: one double of LDS nobody reads -- the lanes that have nothing to store write there, so that the loop body has no
 // branches (with the stores in exec-masked blocks the compiler waits for ALL outstanding LDS operations at every stage,
 // stores included, instead of just for the prefetched operands).
+template <int NX, int NU, int NH, bool TR>
 COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, double* dummy, int nstages = NH, double* XI = nullptr)
 {
     using RR = RicRec<NX, NU>;
     const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
-    int off[3];
+    const int kl = lane / NU, cl = lane - kl * NU; // this lane's (stage, component) of the NU NH vectors
+    const bool mine = lane < NU * NH;
+    if (!TR) { // t_k = Lam_k^-T v_k, in place of v
+        double t = 0.0;
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) t += F[kl * RR::SZ + RR::oLi + c + NU * cl] * in[NU * kl + c];
+        }
+        wave_sync();
+        if (mine) X[lane] = t;
+        wave_sync();
+        in = X;
+    }
+    int off[3], km[3];
 #pragma unroll
     for (int J = 0; J < 3; ++J)
-        off[J] = TR ? ric_stack_offset<NX, NU>(4 * J + q, 4 * b + r) : ric_stack_offset<NX, NU>(4 * b + r, 4 * J + q);
+        off[J] = TR ? ric_stack_offset<NX, NU, NH>(4 * J + q, 4 * b + r, km[J]) : ric_stack_offset<NX, NU, NH>(4 * b + r, 4 * J + q, km[J]);
     const double* ip = in + (q < NU ? q : 0);
     const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
     const bool xwriter = !TR && XI && r == 0 && b < 2 && 4 * b + q < NX; // the state: component 4 b + q sits in lane row q
@@ -102,14 +129,12 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
     // (the operands of the next stage are fetched while the current one runs: their LDS latency is off the chain)
     const int kfirst = TR ? nstages - 1 : 0, kstep = TR ? -1 : 1;
     const int count = TR ? nstages : NH;
-    const double* Fk = F + kfirst * RR::SZ;
-    double a0 = Fk[off[0]], a1 = Fk[off[1]], a2 = Fk[off[2]], vk = ip[NU * kfirst];
+    double a0 = F[off[0] + km[0] * kfirst], a1 = F[off[1] + km[1] * kfirst], a2 = F[off[2] + km[2] * kfirst], vk = ip[NU * kfirst];
 #pragma unroll COPRA_RIC_UNROLL
     for (int t = 0; t < count; ++t) {
         const int k = kfirst + kstep * t;
         const int kn = (t + 1 < count) ? k + kstep : k;
-        const double* Fn = F + kn * RR::SZ;
-        const double n0 = Fn[off[0]], n1 = Fn[off[1]], n2 = Fn[off[2]], nv = ip[NU * kn];
+        const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], n2 = F[off[2] + km[2] * kn], nv = ip[NU * kn];
         if (xany) xp[k * xst] = (b == 0) ? s0 : s1;
         double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
         y = mfma_f64_4x4x4(a0, s0, y);
@@ -124,7 +149,14 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
     }
     if (xany) xp[NH * xst] = (b == 0) ? s0 : s1;
     wave_sync();
-    return lane < NU * NH ? X[lane] : 0.0;
+    if (!TR) return mine ? X[lane] : 0.0;
+    // w_k = Lam_k^-1 s_k  (s = n where the recursion did not go: zero there, and so is w)
+    double w = 0.0;
+    if (mine) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) w += F[kl * RR::SZ + RR::oLi + cl + NU * c] * X[NU * kl + c];
+    }
+    return w;
 }
 
 } // namespace copra_hip
