@@ -156,6 +156,7 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
 #pragma unroll
         for (int c = 0; c < NU; ++c) w += F[kl * RR::SZ + RR::oLi + cl + NU * c] * X[NU * kl + c];
     }
+    wave_sync(); // (every lane has read s before the caller reuses the buffer)
     return w;
 }
 
