@@ -461,7 +461,10 @@ static copra_status_t adapt_layout(copra_batch* h)
     int count = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&count, h->d_ovf_count, sizeof(int), hipMemcpyDeviceToHost));
-    if ((long long)count * 8 <= (long long)h->hp.plan.batch) return COPRA_OK;
+    // (the Riccati-factor tier is so much faster than its second tier -- the square-layout kernel -- that it pays to step down
+    //  the ladder until only one instance in 32 is left over; the other first tiers keep the round-1 threshold of one in 8)
+    const long long share = h->hp.plan.lds.ric ? 32 : 8;
+    if ((long long)count * share <= (long long)h->hp.plan.batch) return COPRA_OK;
     LdsLayout roomier {};
     if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) { // factor-only: one instance per CU fewer, more columns
         h->hp.plan.lds = roomier;
