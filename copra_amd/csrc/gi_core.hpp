@@ -67,7 +67,7 @@ struct SolverLds {
     const double* Jsrc; // shared-model path: J = R^-1 of the whole batch in HBM, copied on first need (else nullptr);
                         // factor-only layout: the packed factor R instead, and ...
     const double* rinv_src; // ... 1 / R(i,i)
-    double* ricx; // Riccati-factor tier: 64 doubles for the hand-over of the MFMA recursions (ric_factor.hpp)
+    double* ricd; // Riccati-factor tier: a double nobody reads (the lanes with nothing to store write there)
     double* ricxi; // ... and, if set, where z = R^-1 v leaves its closed-loop states (nx (N + 1) doubles; StageRows::xi)
 };
 
@@ -92,7 +92,7 @@ COPRA_DEV SolverLds carve_solver(double* lds, const LdsLayout& L)
     S.scal = lds + L.scal;
     S.act = reinterpret_cast<unsigned char*>(lds + L.act);
     S.iact = reinterpret_cast<int*>(lds + L.iact);
-    S.ricx = lds + L.ricX;
+    S.ricd = lds + L.ricD;
     S.ricxi = nullptr;
     return S;
 }
@@ -575,9 +575,14 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
 
         // ---------------- step 2 ----------------
         for (;;) {
+            int inj_stage = 0, inj_comp = 0; // Riccati form, compact variant: the state part of the normal as  inj_val e_comp  at stage inj_stage
+            double inj_val = 0.0;
             if (nvl < mgen) {
                 const double sgn = (nvl < meq) ? S.eqsgn[nvl] : 1.0;
-                rows.load_normal(nvl, sgn, S.ap);
+                if constexpr (RNX > 0)
+                    rows.load_normal_split(nvl, sgn, S.ap, inj_stage, inj_comp, inj_val);
+                else
+                    rows.load_normal(nvl, sgn, S.ap);
             } else if (lane < n) { // rows of -[I; -I]: -e_j for an upper bound, +e_j for a lower bound
                 const int q = nvl - mgen;
                 S.ap[lane] = (q < n) ? ((lane == q) ? -1.0 : 0.0) : ((lane == q - n) ? 1.0 : 0.0);
@@ -598,7 +603,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     // stage k - 1): the backward recursion starts there.  In place: this lane's n is in `acc` / `napl`.
                     const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
                     const int nst = uniform_i32((int)last / RNU + 1);
-                    wk = ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricx + kWave - 2, nst);
+                    wk = ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricd, nst > inj_stage ? nst : inj_stage, nullptr, inj_stage, inj_comp, inj_val);
                 } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
@@ -660,7 +665,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if constexpr (RNX > 0) {
                     if (lane < n) S.ap[lane] = vj;
                     wave_sync();
-                    zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricx + kWave - 2, NV / RNU, S.ricxi);
+                    zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricd, NV / RNU, S.ricxi);
                 } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];
@@ -744,7 +749,10 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 drop = true;
             } else {
                 // (Riccati-factor tier: S.ap was the hand-over buffer of the two recursions; n+ is in `napl`)
-                const double zn = wave_sum((lane < n) ? zi * (RNX > 0 ? napl : S.ap[lane]) : 0.0);
+                double zn = wave_sum((lane < n) ? zi * (RNX > 0 ? napl : S.ap[lane]) : 0.0);
+                if constexpr (RNX > 0) { // the state part of the normal did not go through S.ap: n'z = (Psi z)(row) = a closed-loop state of z
+                    if (inj_stage > 0) zn += inj_val * S.ricxi[inj_stage * RNX + inj_comp];
+                }
                 double tt = -sv_nvl / zn;
                 bool t2min = true;
                 if (!t1inf && t1 < tt) {

@@ -305,6 +305,36 @@ struct StageRows {
     COPRA_DEV double ub(int) const { return ub_mine; } // asked for j == min(lane, n-1) only
     COPRA_DEV double lb(int) const { return lb_mine; }
 
+    // Riccati-factor tier: with g_dead the blocks G are gone (lmpc_fused_ric.hpp, compact variant) and the state part of a row --
+    // one component of one state -- is handed back as a unit injection (ric_factor.hpp) instead of being spread over ap;
+    // without g_dead this is load_normal
+    bool g_dead = false;
+    COPRA_DEV void load_normal_split(int p, double sgn, double* ap, int& inj_stage, int& inj_comp, double& inj_val) const
+    {
+        inj_stage = 0;
+        if (!g_dead) {
+            load_normal(p, sgn, ap);
+            return;
+        }
+        const int j = lane_id();
+        const RowDesc d = desc_uniform(p); // (every lane takes part in the broadcast)
+        const double sign = (p < P.meq) ? sgn : -1.0;
+        if (d.ek == kEOneHot && d.k > 0) {
+            inj_stage = d.k;
+            inj_comp = d.eo;
+            inj_val = sign;
+        }
+        if (j >= nvar()) return;
+        const int jb = j / nu(), jc = j - jb * nu();
+        double v = 0.0;
+        if (d.gk == kGStep) {
+            if (jb == d.k) v = params()[d.go + jc];
+        } else if (d.gk == kGFull) {
+            v = params()[d.go + j];
+        }
+        ap[j] = sign * v;
+    }
+
     COPRA_DEV void load_normal(int p, double sgn, double* ap) const
     {
         const int j = lane_id();

@@ -44,17 +44,20 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     double* nb = lds + L.nb;
     SolverLds S = carve_solver(lds, L);
     double* F = S.J; // NH stage records
-    // scratch of the sweep (aliases the solver vectors: first written by the roll-out / the norms phase)
-    // A | B | d | x0 | ricX are contiguous (layout_lds_ric): once the sweep is done they hold the trajectory of the roll-out
-    double* XU = A;
-    const bool xu_ok = P.rows_direct && (L.ricX + kWave - 2 - L.A) >= X && L.ricX > L.X0; // (the last two doubles of ricX: the spare
-                                                                                         //  target of the lanes that store nothing)
-    double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
+    // Where the trajectory lives once the roll-out has produced it.  Compact variant (LdsLayout::ricC: every state term of a row
+    // is one component of one state): in the region of the blocks G, which are dead by then -- the row norms are taken before
+    // the roll-out, and the normal of a state row enters w = R^-T n as a unit injection (ric_factor.hpp) -- with the
+    // closed-loop states of z = R^-1 v behind it (L.Xbar points there).  General variant: over A | B | d | x0 | ricX.
+    const bool compact = L.ricC != 0;
+    double* XU = compact ? G : A;
+    const bool xu_ok = compact || (P.rows_direct && (L.ricX + kWave - 2 - L.A) >= X && L.ricX > L.X0);
+    // scratch of the sweep (aliases the solver vectors).  bkd first: it is read by the roll-out, which writes xs behind its own
+    // reads only; the rest is dead after the sweep and lies where the row norms go
+    double* Bk = lds + L.ricS; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
+    double* Pm = Bk + NH * NX; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
     double* T = pv + ((NX + 1) & ~1); // NX (NZ + 1) doubles: the rows u of M (NU x 12, A operand of the update of P); 12 doubles of hand-over before the sweep
-    double* Mu = T + NX * (NZ + 1); // (spare)
-    double* Zs = Mu + ((NU * (NX + 1 + NU) + 1) & ~1); // [0]: holds 0.0 during the sweep (operands that are structurally zero); [1]: write-only spare
-    double* Bk = Zs + 2; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
+    double* Zs = T + NX * (NZ + 1); // [0]: holds 0.0 during the sweep (operands that are structurally zero); [1]: write-only spare
 
     long long stamp[8];
     COPRA_FINE_DECL;
@@ -72,7 +75,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         rows.cache_own_row();
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
         for (int e = lane; e < NH * NX; e += kWave) Bk[e] = P.ric_model[mBk + e];
-        for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
+        if (!compact) // (compact variant: nothing reads the blocks G once the row norms are known -- and those come from the model too)
+            for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         stamp[1] = cycle_counter();
     } else {
     // ---- 0. coalesced loads of this instance's system: into registers now, into LDS after the loads of the cost tables
@@ -170,7 +174,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     for (int I = 0; I < 2; ++I)
 #pragma unroll
         for (int K = 0; K < 2; ++K) pa[I][K] = (4 * I + r4 < NX && 4 * K + q4 < NX) ? A[(4 * I + r4) + NX * (4 * K + q4)] : 0.0;
-    const bool pw = ((lane >> 2) & 3) == 0 && r4 <= NU; // lanes of block 0 store
+    const bool pw = ((lane >> 2) & 3) == 0 && (compact ? r4 < NU : r4 <= NU); // lanes of block 0 store (compact variant: not the
+                                                                              // free response, which nobody reads -- its place is inside G)
     const bool pgc = r4 < NU; // a column of G (else xbar)
     double pc[2], px[2]; // [0 | d] and the state, rows q and 4 + q, column r
 #pragma unroll
@@ -182,7 +187,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     double* const pdst = pgc ? G + NX * r4 + q4 : Xbar + q4; // row q of step 0 (row 4 + q: + 4)
     const int pst = pgc ? NX * NU : NX;
     if (lane < NX * NU) G[lane] = B[lane];
-    if (lane < NX) Xbar[lane] = X0[lane];
+    if (lane < NX && !compact) Xbar[lane] = X0[lane];
     stamp[1] = cycle_counter();
     // ---- 2. backward Riccati sweep: stage records into F ----
     // Every matrix product of a stage runs on v_mfma_f64_4x4x4 in a stacked index space of three blocks of four,
@@ -454,7 +459,69 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     }
     COPRA_FINE("sweep:Bt");
     stamp[2] = cycle_counter();
-    // ---- 3. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k bkd_k; K_k kv_k] [x_k; 1] from x_0, on the matrix
+    // ---- 3. implicit rows: norms (qpgen2: column norms of amat).  Before the roll-out: in the compact variant the trajectory
+    //      will take the place of the blocks G. ----
+    // A row of Psi (one component of one state, no control term: TrajectoryBoundConstraint) has the squared norm
+    // sum_{t < k} |row eo of G_t|^2: the NH NX block-row norms once (two per lane), then at most NH additions per row --
+    // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.  The block-row norms go
+    // to Xbar (free: the preview's free response is not used) or, compact variant, into the blocks themselves (G is dead after
+    // this phase; the rows that need all of it are done first).
+    if (from_model) {
+        for (int i = lane; i < P.mgen; i += kWave) nb[i] = P.ric_model[mNb + i];
+    } else {
+        const bool fast = xu_ok;
+        for (int i = lane; i < P.mgen; i += kWave) {
+            const RowDesc d = rows.desc(i);
+            if (!(fast && d.ek == kEOneHot && d.gk == kGNone)) nb[i] = sqrt(rows.norm2(d));
+        }
+        if (fast) {
+            double* NB2 = compact ? G : Xbar;
+            const int tst = compact ? NX * NU : NX; // stride between the blocks
+            wave_sync();
+            double s2[(NH * NX + kWave - 1) / kWave];
+#pragma unroll
+            for (int u = 0; u < (NH * NX + kWave - 1) / kWave; ++u) {
+                const int e = lane + kWave * u, t = e / NX, comp = e - t * NX;
+                s2[u] = 0.0;
+                if (e < NH * NX) {
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) {
+                        const double a = G[t * NX * NU + comp + NX * c];
+                        s2[u] += a * a;
+                    }
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < (NH * NX + kWave - 1) / kWave; ++u) {
+                const int e = lane + kWave * u, t = e / NX, comp = e - t * NX;
+                if (e < NH * NX) NB2[t * tst + comp] = s2[u];
+            }
+            wave_sync();
+            for (int i = lane; i < P.mgen; i += kWave) {
+                const RowDesc d = rows.desc(i);
+                if (d.ek == kEOneHot && d.gk == kGNone) {
+                    double part[NH];
+#pragma unroll
+                    for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * tst + d.eo];
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NH; ++t) acc += (t < d.k) ? part[t] : 0.0;
+                    nb[i] = sqrt(acc);
+                }
+            }
+        }
+    }
+    wave_sync();
+    if (P.ric_model_out) { // prepare launch, second half: the row norms; nothing is solved
+        if (inst == P.dump_instance)
+            for (int i = lane; i < P.mgen; i += kWave) P.ric_model_out[mNb + i] = nb[i];
+        return;
+    }
+    rows.g_dead = compact; // (from here on nothing reads the blocks G: StageRows::load_normal_split)
+    COPRA_FINE("norms");
+    stamp[3] = cycle_counter();
+    // ---- 4. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k bkd_k; K_k kv_k] [x_k; 1] from x_0, on the matrix
     //      cores like the recursions of ric_factor.hpp (v_mfma_f64_4x4x4: block b of the lane = rows 4b .. 4b+3 of the
     //      stacked matrix, the state handed on by a DPP row broadcast) ----
     {
@@ -480,9 +547,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const bool xwriter = xu_ok && b4 < 2 && r == 0 && yrow < NX;
         const double x0r = X0[yrow < NX ? yrow : 0];
         // (lanes with nothing to store write to a spare double: no branches in the loop, see ric_apply_mfma4)
-        double* const up = writer ? S.xs + q : S.ricx + kWave - 2;
+        double* const up = writer ? S.xs + q : S.ricd;
         const int ust = writer ? NU : 0;
-        double* const xwp = xwriter ? XU + NX + yrow : S.ricx + kWave - 2;
+        double* const xwp = xwriter ? XU + NX + yrow : S.ricd;
         const int xwst = xwriter ? NX : 0;
         double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
         double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0]; // (stage 0)
@@ -512,52 +579,6 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     COPRA_FINE("rollout");
     if (lane == 0) S.scal[0] = 0.0; // the zero slot of StageRows::state_component
     wave_sync();
-    stamp[3] = cycle_counter();
-    // ---- 4. implicit rows: norms (qpgen2: column norms of amat) ----
-    // A row of Psi (one component of one state, no control term: TrajectoryBoundConstraint) has the squared norm
-    // sum_{t < k} |row eo of G_t|^2: the NH NX block-row norms once (two per lane), then at most NH additions per row --
-    // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.
-    if (from_model) {
-        for (int i = lane; i < P.mgen; i += kWave) nb[i] = P.ric_model[mNb + i];
-    } else {
-        double* NB2 = Xbar; // (free: the trajectory lives in XU; the closed-loop states come here only during z = R^-1 v)
-        const bool fast = rows.xu != nullptr;
-        if (fast) {
-            for (int e = lane; e < NH * NX; e += kWave) {
-                const int t = e / NX, comp = e - t * NX;
-                double s2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    const double a = G[t * NX * NU + comp + NX * c];
-                    s2 += a * a;
-                }
-                NB2[e] = s2;
-            }
-            wave_sync();
-        }
-        for (int i = lane; i < P.mgen; i += kWave) {
-            const RowDesc d = rows.desc(i);
-            double s2;
-            if (fast && d.ek == kEOneHot && d.gk == kGNone) {
-                double part[NH];
-#pragma unroll
-                for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * NX + d.eo];
-                s2 = 0.0;
-#pragma unroll
-                for (int t = 0; t < NH; ++t) s2 += (t < d.k) ? part[t] : 0.0;
-            } else {
-                s2 = rows.norm2(d);
-            }
-            nb[i] = sqrt(s2);
-        }
-    }
-    wave_sync();
-    if (P.ric_model_out) { // prepare launch, second half: the row norms; nothing is solved
-        if (inst == P.dump_instance)
-            for (int i = lane; i < P.mgen; i += kWave) P.ric_model_out[mNb + i] = nb[i];
-        return;
-    }
-    COPRA_FINE("norms");
     stamp[4] = cycle_counter();
     stamp[5] = stamp[4];
     // ---- 5. active set ----
@@ -601,7 +622,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             for (int k = 0; k < 32; ++k) pf[k] = (k < copra_fine_n) ? copra_fine[k] - stamp[0] : -1;
         }
 #endif
-        if (P.prof) { // preview | Riccati sweep | roll-out | norms | - | active set | results | total
+        if (P.prof) { // set-up | Riccati sweep (+ preview) | row norms | roll-out | - | active set | results | total
             stamp[7] = cycle_counter();
             long long* pr = P.prof + 8 * (size_t)inst;
             for (int k = 0; k < 7; ++k) pr[k] = stamp[k + 1] - stamp[k];

@@ -83,7 +83,11 @@ struct LdsLayout {
     int q1regs; // > 0 (factor-only layout): that many columns of Q1 live in registers, there is no Q1 region in LDS
     int ric; // 1 (with tri and q1regs): the J region holds the RICCATI form of the factor (ric_factor.hpp: N stage records
              // instead of the packed triangle), A / B / d / x0 keep their own slots and there are no cost tables
-    int ricX; // 64 doubles: hand-over buffer of the MFMA recursions (ric_factor.hpp)
+    int ricX; // general variant: 64 doubles behind A | B | d | x0 -- together the trajectory of the roll-out (lmpc_fused_ric.hpp)
+    int ricD; // two doubles nobody reads (what the lanes with nothing to store write to)
+    int ricC; // 1: compact variant (every state term of a row is one component of one state): once the row norms are known the
+              // blocks G are dead -- the normal of a state row enters w = R^-T n as a unit injection into the recursion's state --
+              // and their region holds the maintained trajectory (at G) and the closed-loop states of z = R^-1 v (at Xbar)
     int ricS; // scratch of the Riccati sweep (aliases the solver vectors, which are written after it)
     int R; // packed upper-triangular R of the active set (rcap columns)
     int rcap; // number of active constraints R has room for: n in the full layout, fewer in the compact (tier-1) one

@@ -186,16 +186,25 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.ric = 1;
     L.q1regs = q1regs;
     L.rcap = q1regs;
+    // compact variant (xcur_late <=> FusedPlan::rows_direct): trajectory and closed-loop states inside the G region (LdsLayout::ricC)
+    const bool compact = xcur_late && N * nx * nu >= 2 * align2(X) && !std::getenv("COPRA_RIC_GENERAL");
+    L.ricC = compact ? 1 : 0;
     L.G = take(N * nx * nu);
-    L.Xbar = take(X);
+    L.Xbar = compact ? L.G + align2(X) : take(X);
     L.J = take(N * rec + cst > X ? N * rec + cst : X);
     L.Xcur = xcur_late ? L.J : take(X);
     L.A = take(nx * nx);
     L.B = take(nx * nu);
     L.D = take(nx);
     L.X0 = take(nx);
-    L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out and
-                          //  the first scan -- lmpc_fused_ric.hpp, StageRows::xu)
+    if (compact) {
+        L.ricX = L.G;
+        L.ricD = take(2);
+    } else {
+        L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out
+                              //  and the first scan -- lmpc_fused_ric.hpp, StageRows::xu)
+        L.ricD = L.ricX + kWave - 2;
+    }
     L.BldPhi = L.BldXi = L.J; // (unused by the body)
     const int vec0 = o;
     L.ricS = vec0;
@@ -218,7 +227,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.uv = take(L.rcap + 2);
     L.iact = take((L.rcap + 2) / 2 + 1);
     L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
-    const int scratch = align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + align2(nu * (nx + 1 + nu)) + 2 + align2(N * nx);
+    const int scratch = align2(N * nx) + align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + 2; // bkd | P | p | T | zero, spare
     if (o < vec0 + scratch) o = vec0 + scratch;
     L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
     L.total = o;

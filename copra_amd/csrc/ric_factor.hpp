@@ -96,7 +96,12 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
 // branches (with the stores in exec-masked blocks the compiler waits for ALL outstanding LDS operations at every stage,
 // stores included, instead of just for the prefetched operands).
 template <int NX, int NU, int NH, bool TR>
-COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, double* dummy, int nstages = NH, double* XI = nullptr)
+// inj_stage > 0 (backward recursion only): the normal has a state part  inj_val e_comp  at step inj_stage -- a row of Psi.  Its
+// Psi' e is never formed: with lambda the adjoint of the OPEN loop (lambda_k = e, lambda_j = A' lambda_{j+1}, n_j = B' lambda_{j+1})
+// the sums nu = mu + lambda obey the same recursion, nu_j = Acl_j' nu_{j+1}, s_j = B' nu_{j+1}: the unit vector simply joins the
+// state that enters stage inj_stage - 1 (the caller makes nstages >= inj_stage).
+COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, double* dummy, int nstages = NH, double* XI = nullptr,
+    int inj_stage = 0, int inj_comp = 0, double inj_val = 0.0)
 {
     using RR = RicRec<NX, NU>;
     const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
@@ -136,6 +141,11 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
         const int kn = (t + 1 < count) ? k + kstep : k;
         const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], n2 = F[off[2] + km[2] * kn], nv = ip[NU * kn];
         if (xany) xp[k * xst] = (b == 0) ? s0 : s1;
+        if (TR) { // (branch-free: the comparison is wave-uniform, the selects are per lane row)
+            const double add = (k == inj_stage - 1) ? inj_val : 0.0;
+            s0 += (q == inj_comp) ? add : 0.0;
+            s1 += (4 + q == inj_comp) ? add : 0.0;
+        }
         double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
         y = mfma_f64_4x4x4(a0, s0, y);
         y = mfma_f64_4x4x4(a1, s1, y);

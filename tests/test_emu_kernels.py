@@ -146,6 +146,22 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][0], wl["N"], bad, wl["cstrs"])["status"] == 2
 
 
+def test_riccati_factor_tier_compact_variant_with_control_rows(emu, oracle):
+    """compact variant of the Riccati-factor tier (every state term of a row is one component of one state: the blocks G are
+    dead after the row norms, the normal of a state row enters w = R^-T n as a unit injection into the recursion, the
+    trajectory takes G's place) together with ControlConstraint rows, whose normals DO go through the vector: statuses,
+    iteration counts, U and X against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(8, v_max=0.3, u_max=1.5, seed=8)
+    cstrs = wl["cstrs"] + [dict(kind="control", G=[[0.0, 1.0, 1.0], [1.0, -1.0, 0.0]], f=[1.2, 0.9])]
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+    assert re["riccati_factor"] and re["lds_bytes"] < 17000  # (the general variant needs 17.7 KB + the extra rows)
+    for k in range(8):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cstrs)
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"]) and ro["iter"][0] >= 4
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_riccati_factor_tier_with_equality_rows(emu, oracle):
     """the Riccati-factor tier with a full-size equality entry (two rows: terminal velocities prescribed) next to the bounds:
     the equality rows go through the orientation logic of the active-set loop (eqsgn), the full-size rows keep the trajectory
