@@ -301,7 +301,10 @@ struct StageRows {
         return (p < P.meq) ? (ax - d.f) : (d.f - ax);
     }
 
-    COPRA_DEV double norm(int i) const { return nb[i]; }
+    // (Riccati-factor tier, compact variant: the norm of row `lane` sits in a register, nb holds the rows from 64 on)
+    bool nb_split = false;
+    double nb_mine = 0.0;
+    COPRA_DEV double norm(int i) const { return nb_split ? (i < kWave ? nb_mine : nb[i - kWave]) : nb[i]; }
     COPRA_DEV double ub(int) const { return ub_mine; } // asked for j == min(lane, n-1) only
     COPRA_DEV double lb(int) const { return lb_mine; }
 

@@ -442,7 +442,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
             for (int c = 0; c < NU; ++c)
 #pragma unroll
-                for (int r2 = 0; r2 < NU; ++r2) Fk[RR::oLi + r2 + NU * c] = li[r2][c];
+                for (int r2 = c; r2 < NU; ++r2) Fk[RR::oLi + r2 * (r2 + 1) / 2 + c] = li[r2][c];
         }
         wave_sync();
         COPRA_FINE("sweep:Li");
@@ -466,13 +466,23 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.  The block-row norms go
     // to Xbar (free: the preview's free response is not used) or, compact variant, into the blocks themselves (G is dead after
     // this phase; the rows that need all of it are done first).
+    // (compact variant: the norm of row `lane` stays in a register -- StageRows::nb_mine --, only rows 64.. go to LDS)
+    rows.nb_split = compact;
+    auto put_norm = [&](int i, double v) {
+        if (!compact)
+            nb[i] = v;
+        else if (i < kWave)
+            rows.nb_mine = v;
+        else
+            nb[i - kWave] = v;
+    };
     if (from_model) {
-        for (int i = lane; i < P.mgen; i += kWave) nb[i] = P.ric_model[mNb + i];
+        for (int i = lane; i < P.mgen; i += kWave) put_norm(i, P.ric_model[mNb + i]);
     } else {
         const bool fast = xu_ok;
         for (int i = lane; i < P.mgen; i += kWave) {
             const RowDesc d = rows.desc(i);
-            if (!(fast && d.ek == kEOneHot && d.gk == kGNone)) nb[i] = sqrt(rows.norm2(d));
+            if (!(fast && d.ek == kEOneHot && d.gk == kGNone)) put_norm(i, sqrt(rows.norm2(d)));
         }
         if (fast) {
             double* NB2 = compact ? G : Xbar;
@@ -507,7 +517,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                     double acc = 0.0;
 #pragma unroll
                     for (int t = 0; t < NH; ++t) acc += (t < d.k) ? part[t] : 0.0;
-                    nb[i] = sqrt(acc);
+                    put_norm(i, sqrt(acc));
                 }
             }
         }
@@ -515,7 +525,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     wave_sync();
     if (P.ric_model_out) { // prepare launch, second half: the row norms; nothing is solved
         if (inst == P.dump_instance)
-            for (int i = lane; i < P.mgen; i += kWave) P.ric_model_out[mNb + i] = nb[i];
+            for (int i = lane; i < P.mgen; i += kWave) P.ric_model_out[mNb + i] = rows.norm(i);
         return;
     }
     rows.g_dead = compact; // (from here on nothing reads the blocks G: StageRows::load_normal_split)

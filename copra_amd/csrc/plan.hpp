@@ -183,7 +183,7 @@ struct LargeLayout {
 // offsets (doubles) of the four parts of FusedPlan::ric_model; returns the total
 COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
 {
-    const int rec = (nx * nx + nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
     const int cst = (nx * nu + nu * nu + 1) & ~1; // RicRec<NX, NU>::CST (B | I behind the records)
     oBk = N * rec + cst;
     oG = oBk + N * nx;

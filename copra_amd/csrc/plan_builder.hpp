@@ -179,7 +179,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
         return at;
     };
     L = LdsLayout {};
-    const int rec = (nx * nx + nx * nu + nu * nu + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
     const int cst = (nx * nu + nu * nu + 1) & ~1; // RicRec<NX, NU>::CST
     L.ldj = (n % 2 == 0) ? n + 1 : n;
     L.tri = 1;
@@ -212,7 +212,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.dv = L.zv = L.coef = L.xs;
     L.ap = take(n);
     L.cvec = L.ap;
-    L.nb = take(mgen > 0 ? mgen : 1);
+    L.nb = take(compact ? (mgen > kWave ? mgen - kWave : 1) : (mgen > 0 ? mgen : 1)); // (compact: the first 64 norms live in registers)
     L.eqsgn = take(meq > 0 ? meq : 1);
     L.scal = take(2);
     L.act = take((mtotal + 7) / 8 + 1);

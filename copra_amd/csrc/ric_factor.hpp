@@ -18,8 +18,8 @@
 // w_k = Lam_k^-1 s_k afterwards -- 18 doubles less per stage, which is what lets a ninth instance share a CU.
 //
 // Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
-//     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (NU x NU, column-major, lower triangular, the upper
-//     part stored as zeros) | kv (NU: feed-forward of the unconstrained minimiser)
+//     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows) | kv (NU: feed-forward
+//     of the unconstrained minimiser)
 // followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | I (NU x NU)
 #pragma once
 
@@ -47,7 +47,7 @@ struct RicRec {
     static constexpr int oAcl = 0;
     static constexpr int oK = oAcl + NX * NX;
     static constexpr int oLi = oK + NU * NX;
-    static constexpr int oKv = oLi + NU * NU;
+    static constexpr int oKv = oLi + NU * (NU + 1) / 2; // (Lam^-1 packed: entry (r, c), c <= r, at r (r + 1) / 2 + c)
     static constexpr int SZ = (oKv + NU + 1) & ~1;
     // the constant block behind the N records
     static constexpr int cB = 0;
@@ -111,7 +111,8 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
         double t = 0.0;
         if (mine) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) t += F[kl * RR::SZ + RR::oLi + c + NU * cl] * in[NU * kl + c];
+            for (int c = 0; c < NU; ++c) // (Lam^-T)(cl, c) = Lam^-1(c, cl): zero above the diagonal
+                t += (c >= cl ? F[kl * RR::SZ + RR::oLi + c * (c + 1) / 2 + (c >= cl ? cl : 0)] : 0.0) * in[NU * kl + c];
         }
         wave_sync();
         if (mine) X[lane] = t;
@@ -164,7 +165,7 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
     double w = 0.0;
     if (mine) {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) w += F[kl * RR::SZ + RR::oLi + cl + NU * c] * X[NU * kl + c];
+        for (int c = 0; c < NU; ++c) w += (c <= cl ? F[kl * RR::SZ + RR::oLi + cl * (cl + 1) / 2 + (c <= cl ? c : 0)] : 0.0) * X[NU * kl + c];
     }
     wave_sync(); // (every lane has read s before the caller reuses the buffer)
     return w;
