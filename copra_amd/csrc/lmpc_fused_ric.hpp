@@ -51,13 +51,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     const bool compact = L.ricC != 0;
     double* XU = compact ? G : A;
     const bool xu_ok = compact || (P.rows_direct && (L.ricX + kWave - 2 - L.A) >= X && L.ricX > L.X0);
-    // scratch of the sweep (aliases the solver vectors).  bkd first: it is read by the roll-out, which writes xs behind its own
-    // reads only; the rest is dead after the sweep and lies where the row norms go
-    double* Bk = lds + L.ricS; // NH x NX:  bkd_k = B kv_k + d (only the roll-out needs it)
-    double* Pm = Bk + NH * NX; // NX x NX cost-to-go Hessian (symmetric, both halves)
+    // scratch of the sweep (aliases the solver vectors, which are written after it)
+    double* Pm = lds + L.ricS; // NX x NX cost-to-go Hessian (symmetric, both halves)
     double* pv = Pm + NX * NX; // NX
-    double* T = pv + ((NX + 1) & ~1); // NX (NZ + 1) doubles: the rows u of M (NU x 12, A operand of the update of P); 12 doubles of hand-over before the sweep
-    double* Zs = T + NX * (NZ + 1); // [0]: holds 0.0 during the sweep (operands that are structurally zero); [1]: write-only spare
+    double* T = pv + ((NX + 1) & ~1); // NU x 12: the rows u of M (A operand of the update of P); 12 doubles of hand-over before the sweep
+    double* Zs = T + ((NU * 12 + 1) & ~1); // [0]: holds 0.0 during the sweep (operands that are structurally zero); [1]: write-only spare
 
     long long stamp[8];
     COPRA_FINE_DECL;
@@ -74,7 +72,6 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
-        for (int e = lane; e < NH * NX; e += kWave) Bk[e] = P.ric_model[mBk + e];
         if (!compact) // (compact variant: nothing reads the blocks G once the row norms are known -- and those come from the model too)
             for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         stamp[1] = cycle_counter();
@@ -271,8 +268,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             const int iq = 4 * (I - 1) + q;
             const bool on = iq < NX && (col_x || col_aff);
             wP[I] = !on ? dummy : col_x ? Pm + iq + NX * (scol - 4) : pv + iq;
-            wA[I] = !on ? dummy : col_x ? F + RR::oAcl + iq + NX * (scol - 4) : Bk + iq;
-            wAst[I] = !on ? 0 : col_x ? RR::SZ : NX;
+            wA[I] = (on && col_x) ? F + RR::oAcl + iq + NX * (scol - 4) : dummy; // (the affine column, d + B kv, is formed by the roll-out)
+            wAst[I] = (on && col_x) ? RR::SZ : 0;
         }
         const bool my_minv = r < NU && q < NU; // A operand of K: element (row r, k = q) of -M_uu^-1
         bool bad = false;
@@ -446,15 +443,15 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         }
         wave_sync();
         COPRA_FINE("sweep:Li");
-        // the constant block behind the records: B (it takes the place of every Bt_k, ric_factor.hpp) and the identity
+        // the constant block behind the records: B (it takes the place of every Bt_k, ric_factor.hpp), d and a zero
         if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
-        if (lane < NU * NU) F[NH * RR::SZ + RR::cI + lane] = (lane % NU == lane / NU) ? 1.0 : 0.0;
+        if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
+        if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
     }
     } // (!from_model)
     wave_sync();
     if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
-        for (int e = lane; e < NH * NX; e += kWave) P.ric_model_out[mBk + e] = Bk[e];
         for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
     }
     COPRA_FINE("sweep:Bt");
@@ -531,7 +528,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     rows.g_dead = compact; // (from here on nothing reads the blocks G: StageRows::load_normal_split)
     COPRA_FINE("norms");
     stamp[3] = cycle_counter();
-    // ---- 4. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k bkd_k; K_k kv_k] [x_k; 1] from x_0, on the matrix
+    // ---- 4. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k B d; K_k I 0] [x_k; kv_k; 1] from x_0, on the matrix
     //      cores like the recursions of ric_factor.hpp (v_mfma_f64_4x4x4: block b of the lane = rows 4b .. 4b+3 of the
     //      stacked matrix, the state handed on by a DPP row broadcast) ----
     {
@@ -539,17 +536,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         int off[2], km[2];
 #pragma unroll
         for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU, NH>(row, 4 * J + q, km[J]);
-        // K-block 2: the constant 1 at stacked component 8 (lane row q == 0) times the column [bkd; kv]
-        const double* p2 = F + NH * RR::SZ + RR::cI + NU; // (I(0, 1): a zero)
-        int st2 = 0;
-        if (q == 0 && row < NX) {
-            p2 = Bk + row;
-            st2 = NX;
-        } else if (q == 0 && row >= 8 && row < 8 + NU) {
-            p2 = F + RR::oKv + (row - 8);
-            st2 = RR::SZ;
-        }
-        const double one = (q == 0) ? 1.0 : 0.0;
+        // K-block 2: the stacked input is (kv_k, 1) -- lane row q holds kv_k(q), lane row NU the constant 1 -- and the matrix
+        // [B d] for the state rows (B kv + d = bkd_k: never stored), the identity for the rows u (through the C operand)
+        const double a2 = (row < NX && q <= NU) ? F[NH * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)] : 0.0;
+        const double* kvp = (q < NU) ? F + RR::oKv + q : F + NH * RR::SZ + RR::cZ;
+        const int kvst = (q < NU) ? RR::SZ : 0;
+        const double one = (q == NU) ? 1.0 : 0.0;
         const bool writer = q < NU && b4 == 2 && r == 0;
         // the states of the roll-out (rows 0 .. NX-1 of the stacked result: blocks 0 and 1) are the trajectory at the
         // unconstrained minimiser: kept for the first scan and, if that finds nothing violated, for the results
@@ -562,14 +554,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         double* const xwp = xwriter ? XU + NX + yrow : S.ricd;
         const int xwst = xwriter ? NX : 0;
         double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
-        double a0 = F[off[0]], a1 = F[off[1]], a2 = p2[0]; // (stage 0)
+        double a0 = F[off[0]], a1 = F[off[1]], kv = kvp[0]; // (stage 0)
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
         if (xwriter) XU[yrow] = x0r;
 #pragma unroll COPRA_RIC_UNROLL
         for (int k = 0; k < NH; ++k) {
             const int kn = k + 1 < NH ? k + 1 : k;
-            const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], n2 = p2[kn * st2];
-            double y = mfma_f64_4x4x4(a2, one, 0.0);
+            const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], nkv = kvp[kn * kvst];
+            double y = mfma_f64_4x4x4(a2, kv + one, b4 == 2 ? kv : 0.0); // (kv is 0 in lane rows >= NU: kv + one is the stacked input)
             y = mfma_f64_4x4x4(a0, s0, y);
             y = mfma_f64_4x4x4(a1, s1, y);
             up[ust * k] = y;
@@ -578,7 +570,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             s1 = row_bcast_f64<4>(y);
             a0 = n0;
             a1 = n1;
-            a2 = n2;
+            kv = nkv;
         }
     }
     if (xu_ok) {

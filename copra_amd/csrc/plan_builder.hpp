@@ -180,7 +180,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     };
     L = LdsLayout {};
     const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
-    const int cst = (nx * nu + nu * nu + 1) & ~1; // RicRec<NX, NU>::CST
+    const int cst = (nx * nu + nx + 2 + 1) & ~1; // RicRec<NX, NU>::CST
     L.ldj = (n % 2 == 0) ? n + 1 : n;
     L.tri = 1;
     L.ric = 1;
@@ -199,7 +199,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.X0 = take(nx);
     if (compact) {
         L.ricX = L.G;
-        L.ricD = take(2);
+        L.ricD = L.J + N * rec + cst - 1; // (RicRec::cS: the spare double of the constant block)
     } else {
         L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out
                               //  and the first scan -- lmpc_fused_ric.hpp, StageRows::xu)
@@ -227,7 +227,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.uv = take(L.rcap + 2);
     L.iact = take((L.rcap + 2) / 2 + 1);
     L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
-    const int scratch = align2(N * nx) + align2(nx * nx) + align2(nx) + align2(nx * (nx + nu + 1)) + 2; // bkd | P | p | T | zero, spare
+    const int scratch = align2(nx * nx) + align2(nx) + align2(nu * 12) + 2; // P | p | rows u of M | zero, spare
     if (o < vec0 + scratch) o = vec0 + scratch;
     L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
     L.total = o;

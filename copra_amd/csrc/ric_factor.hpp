@@ -20,7 +20,8 @@
 // Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
 //     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows) | kv (NU: feed-forward
 //     of the unconstrained minimiser)
-// followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | I (NU x NU)
+// followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | d (NX) | a zero | a spare double
+// (the identity that passes t_k / n_k / kv_k through to the output rows is the C operand of the first MFMA of a stage)
 #pragma once
 
 #ifndef COPRA_RIC_UNROLL
@@ -51,8 +52,10 @@ struct RicRec {
     static constexpr int SZ = (oKv + NU + 1) & ~1;
     // the constant block behind the N records
     static constexpr int cB = 0;
-    static constexpr int cI = cB + NX * NU;
-    static constexpr int CST = (cI + NU * NU + 1) & ~1;
+    static constexpr int cD = cB + NX * NU;
+    static constexpr int cZ = cD + NX; // holds 0.0: what structurally zero operands read
+    static constexpr int cS = cZ + 1; // nobody reads it: what lanes with nothing to store write
+    static constexpr int CST = (cS + 1 + 1) & ~1;
 };
 
 // ---- the two products on the matrix cores ------------------------------------------------------------------------
@@ -64,7 +67,8 @@ struct RicRec {
 // instruction on MI355X, no faster than the vector ALU -- preceded the one below; DESIGN.md 3.9b has their numbers.)
 // Stacked index:  0 .. NX-1 state components (NX <= 8) | 8 .. 8+NU-1 input / output components.
 // -> offset (doubles from the first record) of element (s_out, s_in) of the stacked matrix [Acl B; K I] of the forward
-// recursion; kmul = RicRec::SZ if the element belongs to the stage record (add kmul * stage), 0 for the constant block.
+// recursion (its identity block excepted); kmul = RicRec::SZ if the element belongs to the stage record (add kmul * stage),
+// 0 for the constant block.
 template <int NX, int NU, int NH>
 COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
 {
@@ -74,9 +78,9 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
     kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
     const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
-    if (to == 2 || ti == 2) return cbase + RR::cI + NU; // I(0, 1) = 0
+    if (to == 2 || ti == 2 || (to == 1 && ti == 1)) return cbase + RR::cZ; // (the identity block goes through the C operand)
     const int a = to == 0 ? s_out : s_out - 8, b = ti == 0 ? s_in : s_in - 8;
-    if (ti == 1) return cbase + (to == 0 ? RR::cB + a + NX * b : RR::cI + a + NU * b); // B(a, b) | I(a, b)
+    if (ti == 1) return cbase + RR::cB + a + NX * b; // B(a, b)
     kmul = RR::SZ;
     return to == 0 ? RR::oAcl + a + NX * b : RR::oK + a + NU * b; // Acl(a, b) | K(a, b)
 }
@@ -147,7 +151,8 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
             s0 += (q == inj_comp) ? add : 0.0;
             s1 += (4 + q == inj_comp) ? add : 0.0;
         }
-        double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
+        double y = mfma_f64_4x4x4(a2, vk, b == 2 ? vk : 0.0); // (does not wait for the previous stage; C: the identity block -- lane row
+                                                              //  q of block 2 is output row 8 + q and holds input component q)
         y = mfma_f64_4x4x4(a0, s0, y);
         y = mfma_f64_4x4x4(a1, s1, y);
         op[ost * k] = y;
