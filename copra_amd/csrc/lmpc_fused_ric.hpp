@@ -44,10 +44,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     double* nb = lds + L.nb;
     SolverLds S = carve_solver(lds, L);
     double* F = S.J; // NH stage records
-    // Where the trajectory lives once the roll-out has produced it.  Compact variant (LdsLayout::ricC: every state term of a row
-    // is one component of one state): in the region of the blocks G, which are dead by then -- the row norms are taken before
-    // the roll-out, and the normal of a state row enters w = R^-T n as a unit injection (ric_factor.hpp) -- with the
-    // closed-loop states of z = R^-1 v behind it (L.Xbar points there).  General variant: over A | B | d | x0 | ricX.
+    // Where the trajectory lives once the roll-out has produced it.  Compact variant (LdsLayout::ricC: a row has a state term --
+    // one component of one state -- or a control term, not both): the blocks G are NEVER STORED.  Their block-row norms, which is
+    // all the row norms need, are taken by the preview steps; the normal of a state row enters w = R^-T n as a unit injection
+    // (ric_factor.hpp); scans and results read the maintained trajectory.  `G` is then the trajectory's place, L.Xbar (behind
+    // it) that of the closed-loop states of z = R^-1 v.  General variant: G as in lmpc_fused.hpp, the trajectory over A | B | d |
+    // x0 | ricX.
     const bool compact = L.ricC != 0;
     double* XU = compact ? G : A;
     const bool xu_ok = compact || (P.rows_direct && (L.ricX + kWave - 2 - L.A) >= X && L.ricX > L.X0);
@@ -72,7 +74,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
-        if (!compact) // (compact variant: nothing reads the blocks G once the row norms are known -- and those come from the model too)
+        if (!compact) // (compact variant: the blocks G are not kept at all -- the row norms come from the model too)
             for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         stamp[1] = cycle_counter();
     } else {
@@ -183,8 +185,21 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     }
     double* const pdst = pgc ? G + NX * r4 + q4 : Xbar + q4; // row q of step 0 (row 4 + q: + 4)
     const int pst = pgc ? NX * NU : NX;
-    if (lane < NX * NU) G[lane] = B[lane];
-    if (lane < NX && !compact) Xbar[lane] = X0[lane];
+    if (!compact) {
+        if (lane < NX * NU) G[lane] = B[lane];
+        if (lane < NX) Xbar[lane] = X0[lane];
+    }
+    // compact variant: the blocks G are not stored -- only |row i of G_s|^2, s = 0 .. NH-1, for the row norms (NB2 = Xbar's place:
+    // free until z = R^-1 v first leaves its states there); lane r = 0 of block 0 writes rows q and 4 + q, the others a spare
+    const bool nb2w = compact && ((lane >> 2) & 3) == 0 && r4 == 0;
+    double* const nb2p = nb2w ? Xbar + q4 : Zs + 1;
+    double* const nb2q = (nb2w && 4 + q4 < NX) ? Xbar + 4 + q4 : Zs + 1;
+    const int nb2st = nb2w ? NX : 0, nb2qst = (nb2w && 4 + q4 < NX) ? NX : 0;
+    if (compact) {
+        const double g0 = quad_sum(pgc ? px[0] * px[0] : 0.0), g1 = quad_sum(pgc ? px[1] * px[1] : 0.0);
+        nb2p[0] = g0; // (block 0: G_0 = B)
+        nb2q[0] = g1;
+    }
     stamp[1] = cycle_counter();
     // ---- 2. backward Riccati sweep: stage records into F ----
     // Every matrix product of a stage runs on v_mfma_f64_4x4x4 in a stacked index space of three blocks of four,
@@ -286,9 +301,15 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                 }
                 px[0] = n0;
                 px[1] = n1;
-                if (pw && (s < NH || !pgc)) {
-                    pdst[s * pst] = n0;
-                    if (4 + q4 < NX) pdst[s * pst + 4] = n1;
+                if (!compact) {
+                    if (pw && (s < NH || !pgc)) {
+                        pdst[s * pst] = n0;
+                        if (4 + q4 < NX) pdst[s * pst + 4] = n1;
+                    }
+                } else if (s < NH) { // block-row norms of G_s (all the compact variant keeps of it)
+                    const double g0 = quad_sum(pgc ? n0 * n0 : 0.0), g1 = quad_sum(pgc ? n1 * n1 : 0.0);
+                    nb2p[s * nb2st] = g0;
+                    nb2q[s * nb2qst] = g1;
                 }
             }
             // T_I = P+_{I,.} [B A d] + [0 | p+]
@@ -452,7 +473,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     wave_sync();
     if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
-        for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
+        if (!compact)
+            for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
     }
     COPRA_FINE("sweep:Bt");
     stamp[2] = cycle_counter();
@@ -460,10 +482,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     //      will take the place of the blocks G. ----
     // A row of Psi (one component of one state, no control term: TrajectoryBoundConstraint) has the squared norm
     // sum_{t < k} |row eo of G_t|^2: the NH NX block-row norms once (two per lane), then at most NH additions per row --
-    // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.  The block-row norms go
-    // to Xbar (free: the preview's free response is not used) or, compact variant, into the blocks themselves (G is dead after
-    // this phase; the rows that need all of it are done first).
+    // instead of 3 k multiply-adds behind as many dependent LDS reads for the row of the last step.  The block-row norms sit
+    // at Xbar's place (free: the preview's free response is not used); in the compact variant the preview steps wrote them.
     // (compact variant: the norm of row `lane` stays in a register -- StageRows::nb_mine --, only rows 64.. go to LDS)
+    const double* const X0r = compact ? XU : X0; // (compact variant: the norms of rows 64.. overwrite the system's slots)
+    if (compact) {
+        if (lane < NX) XU[lane] = X0[lane];
+        wave_sync();
+    }
     rows.nb_split = compact;
     auto put_norm = [&](int i, double v) {
         if (!compact)
@@ -482,9 +508,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             if (!(fast && d.ek == kEOneHot && d.gk == kGNone)) put_norm(i, sqrt(rows.norm2(d)));
         }
         if (fast) {
-            double* NB2 = compact ? G : Xbar;
-            const int tst = compact ? NX * NU : NX; // stride between the blocks
+            double* NB2 = Xbar;
+            const int tst = NX; // stride between the blocks
             wave_sync();
+            if (!compact) { // (compact variant: the preview steps have left the block-row norms there)
             double s2[(NH * NX + kWave - 1) / kWave];
 #pragma unroll
             for (int u = 0; u < (NH * NX + kWave - 1) / kWave; ++u) {
@@ -505,6 +532,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                 if (e < NH * NX) NB2[t * tst + comp] = s2[u];
             }
             wave_sync();
+            }
             for (int i = lane; i < P.mgen; i += kWave) {
                 const RowDesc d = rows.desc(i);
                 if (d.ek == kEOneHot && d.gk == kGNone) {
@@ -547,13 +575,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         // unconstrained minimiser: kept for the first scan and, if that finds nothing violated, for the results
         const int yrow = 4 * b4 + q; // (the RESULT of lane 16 q + 4 b + r is row 4 b + q of the stacked product)
         const bool xwriter = xu_ok && b4 < 2 && r == 0 && yrow < NX;
-        const double x0r = X0[yrow < NX ? yrow : 0];
+        const double x0r = X0r[yrow < NX ? yrow : 0];
         // (lanes with nothing to store write to a spare double: no branches in the loop, see ric_apply_mfma4)
         double* const up = writer ? S.xs + q : S.ricd;
         const int ust = writer ? NU : 0;
         double* const xwp = xwriter ? XU + NX + yrow : S.ricd;
         const int xwst = xwriter ? NX : 0;
-        double s0 = X0[q < NX ? q : 0], s1 = (4 + q < NX) ? X0[4 + q < NX ? 4 + q : 0] : 0.0;
+        double s0 = X0r[q < NX ? q : 0], s1 = (4 + q < NX) ? X0r[4 + q < NX ? 4 + q : 0] : 0.0;
         double a0 = F[off[0]], a1 = F[off[1]], kv = kvp[0]; // (stage 0)
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
         if (xwriter) XU[yrow] = x0r;

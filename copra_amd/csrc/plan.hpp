@@ -217,6 +217,7 @@ struct FusedPlan {
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)
+    int rows_pure; // 1 if, on top of rows_direct, no row has both a state term and a control term (lmpc_fused_ric.hpp, compact variant)
     int rows_direct; // 1 if every state term is one component of one state (bounds on the trajectory): such a slack is
                      // evaluated straight from G and the iterate, without refreshing the whole trajectory first
     int n_full_rows; // rows with a full-size entry (kEFull / kGFull), listed below; -1: more than kMaxFullRows

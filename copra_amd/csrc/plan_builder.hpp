@@ -187,16 +187,21 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.q1regs = q1regs;
     L.rcap = q1regs;
     // compact variant (xcur_late <=> FusedPlan::rows_direct): trajectory and closed-loop states inside the G region (LdsLayout::ricC)
-    const bool compact = xcur_late && N * nx * nu >= 2 * align2(X) && !std::getenv("COPRA_RIC_GENERAL");
+    // (there the blocks G are never stored: their block-row norms are taken by the preview steps, nothing else needs them;
+    //  and A | B | d | x0 share the solver vectors' place behind the sweep's scratch -- they are dead before those are written)
+    const bool compact = xcur_late && !std::getenv("COPRA_RIC_GENERAL");
+    const int scratch = align2(nx * nx) + align2(nx) + align2(nu * 12) + 2; // P | p | rows u of M | zero, spare
     L.ricC = compact ? 1 : 0;
-    L.G = take(N * nx * nu);
+    L.G = take(compact ? 2 * align2(X) : N * nx * nu);
     L.Xbar = compact ? L.G + align2(X) : take(X);
     L.J = take(N * rec + cst > X ? N * rec + cst : X);
     L.Xcur = xcur_late ? L.J : take(X);
-    L.A = take(nx * nx);
-    L.B = take(nx * nu);
-    L.D = take(nx);
-    L.X0 = take(nx);
+    if (!compact) {
+        L.A = take(nx * nx);
+        L.B = take(nx * nu);
+        L.D = take(nx);
+        L.X0 = take(nx);
+    }
     if (compact) {
         L.ricX = L.G;
         L.ricD = L.J + N * rec + cst - 1; // (RicRec::cS: the spare double of the constant block)
@@ -208,6 +213,13 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.BldPhi = L.BldXi = L.J; // (unused by the body)
     const int vec0 = o;
     L.ricS = vec0;
+    int sys_end = vec0 + scratch;
+    if (compact) {
+        L.A = sys_end, sys_end += align2(nx * nx);
+        L.B = sys_end, sys_end += align2(nx * nu);
+        L.D = sys_end, sys_end += align2(nx);
+        L.X0 = sys_end, sys_end += align2(nx);
+    }
     L.xs = take(n);
     L.dv = L.zv = L.coef = L.xs;
     L.ap = take(n);
@@ -227,8 +239,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     L.uv = take(L.rcap + 2);
     L.iact = take((L.rcap + 2) / 2 + 1);
     L.R = take(L.rcap * (L.rcap + 1) / 2 + 2);
-    const int scratch = align2(nx * nx) + align2(nx) + align2(nu * 12) + 2; // P | p | rows u of M | zero, spare
-    if (o < vec0 + scratch) o = vec0 + scratch;
+    if (o < sys_end) o = sys_end;
     L.BldY = L.BldWe = L.BldCp = L.BldFull = vec0;
     L.total = o;
     return o <= budget;
@@ -329,7 +340,7 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
         for (int k = kcur - 1; k >= 4; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
             LdsLayout t {};
-            if (layout_lds_ric(t, P.nx, P.nu, P.N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, 0, budget) && t.rcap > cur.rcap) {
+            if (layout_lds_ric(t, P.nx, P.nu, P.N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, 0, budget) && t.rcap > cur.rcap) {
                 out = t;
                 return true;
             }
@@ -522,6 +533,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     int bound_line = 0;
     P.any_state_rows = 0;
     P.rows_direct = 1;
+    P.rows_pure = 1;
     // validate + bounds
     for (int k = 0; k < n_cstrs; ++k) {
         const copra_cstr_desc_t& c = cstrs[k];
@@ -580,6 +592,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.row_f.push_back(f);
         if (ekind != kENone) P.any_state_rows = 1;
         if (ekind != kENone && ekind != kEOneHot) P.rows_direct = 0;
+        if (ekind != kENone && (ekind != kEOneHot || gkind != kGNone)) P.rows_pure = 0;
     };
     // row-major copy of one row of a column-major (rows x cols) matrix into the blob
     auto push_row = [&](const double* Mx, int rows, int cols, int r) {
@@ -862,7 +875,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
             LdsLayout t {};
-            if (layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, kFusedQ1Regs, budget)) {
+            if (layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, kFusedQ1Regs, budget)) {
                 hp.lds_safe = P.lds;
                 hp.safe_two_tier = hp.two_tier;
                 hp.two_tier = true;
@@ -893,7 +906,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 const char* rk = std::getenv("COPRA_RIC_K");
                 const int rbudget = rk ? ((160 * 1024 / std::atoi(rk)) & ~511) / (int)sizeof(double) : budget;
                 if (ric_ok && k >= 6 // (general state rows keep their own trajectory buffer: seven instances per CU)
-                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_direct != 0, rk ? 0 : qregs, rbudget)) {
+                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, rk ? 0 : qregs, rbudget)) {
                     hp.lds_safe = P.lds;
                     hp.safe_two_tier = hp.two_tier;
                     hp.two_tier = true;

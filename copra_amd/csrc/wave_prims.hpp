@@ -137,6 +137,13 @@ COPRA_DEV int dpp_i32(int v)
 #define COPRA_DPP_HMIRROR 0x141
 #define COPRA_DPP_MIRROR 0x140
 
+// sum over the four lanes of a quad (two DPP quad_perm steps), in every lane of the quad
+COPRA_DEV double quad_sum(double v)
+{
+    v += dpp_f64<COPRA_DPP_XOR1>(v);
+    v += dpp_f64<COPRA_DPP_XOR2>(v);
+    return v;
+}
 COPRA_DEV double wave_sum(double v)
 {
     v += dpp_f64<COPRA_DPP_XOR1>(v);

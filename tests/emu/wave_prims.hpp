@@ -148,6 +148,12 @@ COPRA_DEV void wave_argmin(double& key, int& idx, double& payload)
     }
 }
 
+COPRA_DEV double quad_sum(double v)
+{
+    v += shfl_xor_f64(v, 1);
+    v += shfl_xor_f64(v, 2);
+    return v;
+}
 COPRA_DEV double wave_sum(double v)
 {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
