@@ -468,6 +468,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
         if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
         if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
+        if (lane == 1) F[NH * RR::SZ + RR::cO] = 1.0;
     }
     } // (!from_model)
     wave_sync();
@@ -565,40 +566,42 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
         for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU, NH>(row, 4 * J + q, km[J]);
         // K-block 2: the stacked input is (kv_k, 1) -- lane row q holds kv_k(q), lane row NU the constant 1 -- and the matrix
-        // [B d] for the state rows (B kv + d = bkd_k: never stored), the identity for the rows u (through the C operand)
-        const double a2 = (row < NX && q <= NU) ? F[NH * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)] : 0.0;
-        const double* kvp = (q < NU) ? F + RR::oKv + q : F + NH * RR::SZ + RR::cZ;
+        // [B d] for the state rows (B kv + d = bkd_k: never stored), the identity for the rows u: the same at every stage
+        const double a2 = (row < NX && q <= NU) ? F[NH * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)]
+                                                : (b4 == 2 && r == q && q < NU) ? 1.0 : 0.0;
+        const double* kvp = (q < NU) ? F + RR::oKv + q : F + NH * RR::SZ + (q == NU ? RR::cO : RR::cZ);
         const int kvst = (q < NU) ? RR::SZ : 0;
-        const double one = (q == NU) ? 1.0 : 0.0;
         const bool writer = q < NU && b4 == 2 && r == 0;
         // the states of the roll-out (rows 0 .. NX-1 of the stacked result: blocks 0 and 1) are the trajectory at the
         // unconstrained minimiser: kept for the first scan and, if that finds nothing violated, for the results
         const int yrow = 4 * b4 + q; // (the RESULT of lane 16 q + 4 b + r is row 4 b + q of the stacked product)
         const bool xwriter = xu_ok && b4 < 2 && r == 0 && yrow < NX;
         const double x0r = X0r[yrow < NX ? yrow : 0];
-        // (lanes with nothing to store write to a spare double: no branches in the loop, see ric_apply_mfma4)
-        double* const up = writer ? S.xs + q : S.ricd;
-        const int ust = writer ? NU : 0;
-        double* const xwp = xwriter ? XU + NX + yrow : S.ricd;
-        const int xwst = xwriter ? NX : 0;
+        // (one store per stage: the lanes that own an output row or a state row; the others write to a spare double -- no
+        //  branches in the loop; operand pointers with per-lane strides, fetched right after their last use: ric_apply_mfma4)
+        double* sp = writer ? S.xs + q : xwriter ? XU + NX + yrow : S.ricd;
+        const int sst = writer ? NU : xwriter ? NX : 0;
         double s0 = X0r[q < NX ? q : 0], s1 = (4 + q < NX) ? X0r[4 + q < NX ? 4 + q : 0] : 0.0;
-        double a0 = F[off[0]], a1 = F[off[1]], kv = kvp[0]; // (stage 0)
+        const double* p0 = F + off[0];
+        const double* p1 = F + off[1];
+        double a0 = *p0, a1 = *p1, kv = *kvp; // (stage 0)
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
         if (xwriter) XU[yrow] = x0r;
 #pragma unroll COPRA_RIC_UNROLL
         for (int k = 0; k < NH; ++k) {
-            const int kn = k + 1 < NH ? k + 1 : k;
-            const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], nkv = kvp[kn * kvst];
-            double y = mfma_f64_4x4x4(a2, kv + one, b4 == 2 ? kv : 0.0); // (kv is 0 in lane rows >= NU: kv + one is the stacked input)
+            double y = mfma_f64_4x4x4(a2, kv, 0.0);
+            kvp += kvst; // (behind the last stage: one record past the end, unused)
+            kv = *kvp;
             y = mfma_f64_4x4x4(a0, s0, y);
+            p0 += km[0];
+            a0 = *p0;
             y = mfma_f64_4x4x4(a1, s1, y);
-            up[ust * k] = y;
-            xwp[xwst * k] = y;
+            p1 += km[1];
+            a1 = *p1;
+            *sp = y;
+            sp += sst;
             s0 = row_bcast_f64<0>(y);
             s1 = row_bcast_f64<4>(y);
-            a0 = n0;
-            a1 = n1;
-            kv = nkv;
         }
     }
     if (xu_ok) {

@@ -184,7 +184,7 @@ struct LargeLayout {
 COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
 {
     const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
-    const int cst = (nx * nu + nx + 2 + 1) & ~1; // RicRec<NX, NU>::CST (B | d | zero | spare behind the records)
+    const int cst = (nx * nu + nx + 3 + 1) & ~1; // RicRec<NX, NU>::CST (B | d | zero | spare | one behind the records)
     oBk = N * rec + cst; // (formerly bkd: nothing there any more)
     oG = oBk;
     oNb = oG + N * nx * nu;

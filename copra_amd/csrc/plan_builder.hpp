@@ -180,7 +180,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     };
     L = LdsLayout {};
     const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
-    const int cst = (nx * nu + nx + 2 + 1) & ~1; // RicRec<NX, NU>::CST
+    const int cst = (nx * nu + nx + 3 + 1) & ~1; // RicRec<NX, NU>::CST
     L.ldj = (n % 2 == 0) ? n + 1 : n;
     L.tri = 1;
     L.ric = 1;
@@ -204,7 +204,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     }
     if (compact) {
         L.ricX = L.G;
-        L.ricD = L.J + N * rec + cst - 1; // (RicRec::cS: the spare double of the constant block)
+        L.ricD = L.J + N * rec + nx * nu + nx + 1; // (RicRec::cS: the spare double of the constant block)
     } else {
         L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out
                               //  and the first scan -- lmpc_fused_ric.hpp, StageRows::xu)

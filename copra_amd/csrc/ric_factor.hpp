@@ -20,8 +20,8 @@
 // Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
 //     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows) | kv (NU: feed-forward
 //     of the unconstrained minimiser)
-// followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | d (NX) | a zero | a spare double
-// (the identity that passes t_k / n_k / kv_k through to the output rows is the C operand of the first MFMA of a stage)
+// followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | d (NX) | a zero | a spare double | a one
+// (the one: the identity block that passes t_k / n_k through to the output rows; the roll-out's goes through the C operand)
 #pragma once
 
 #ifndef COPRA_RIC_UNROLL
@@ -55,7 +55,8 @@ struct RicRec {
     static constexpr int cD = cB + NX * NU;
     static constexpr int cZ = cD + NX; // holds 0.0: what structurally zero operands read
     static constexpr int cS = cZ + 1; // nobody reads it: what lanes with nothing to store write
-    static constexpr int CST = (cS + 1 + 1) & ~1;
+    static constexpr int cO = cS + 1; // holds 1.0: the identity block of the stacked matrix
+    static constexpr int CST = (cO + 1 + 1) & ~1;
 };
 
 // ---- the two products on the matrix cores ------------------------------------------------------------------------
@@ -69,7 +70,7 @@ struct RicRec {
 // -> offset (doubles from the first record) of element (s_out, s_in) of the stacked matrix [Acl B; K I] of the forward
 // recursion (its identity block excepted); kmul = RicRec::SZ if the element belongs to the stage record (add kmul * stage),
 // 0 for the constant block.
-template <int NX, int NU, int NH>
+template <int NX, int NU, int NH, bool IDENT = false>
 COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
 {
     using RR = RicRec<NX, NU>;
@@ -78,7 +79,8 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
     kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
     const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
-    if (to == 2 || ti == 2 || (to == 1 && ti == 1)) return cbase + RR::cZ; // (the identity block goes through the C operand)
+    if (IDENT && to == 1 && s_out == s_in) return cbase + RR::cO; // the identity block: a constant 1.0 (roll-out: through the C operand)
+    if (to == 2 || ti == 2 || (to == 1 && ti == 1)) return cbase + RR::cZ;
     const int a = to == 0 ? s_out : s_out - 8, b = ti == 0 ? s_in : s_in - 8;
     if (ti == 1) return cbase + RR::cB + a + NX * b; // B(a, b)
     kmul = RR::SZ;
@@ -126,44 +128,59 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
     int off[3], km[3];
 #pragma unroll
     for (int J = 0; J < 3; ++J)
-        off[J] = TR ? ric_stack_offset<NX, NU, NH>(4 * J + q, 4 * b + r, km[J]) : ric_stack_offset<NX, NU, NH>(4 * b + r, 4 * J + q, km[J]);
-    const double* ip = in + (q < NU ? q : 0);
+        off[J] = TR ? ric_stack_offset<NX, NU, NH, true>(4 * J + q, 4 * b + r, km[J]) : ric_stack_offset<NX, NU, NH, true>(4 * b + r, 4 * J + q, km[J]);
+    // The loop is bound by instruction ISSUE, not latency (several instances share a SIMD): every operand has a pointer of its
+    // own that moves by a per-lane stride (one addition per stage; a constant operand has stride 0), the outputs of a stage --
+    // rows 8.. (block 2) and, for the forward recursion, the new state (blocks 0 and 1: the lanes that own a result row hold it
+    // before the broadcast) -- leave through ONE store, the injection is a wave-uniform branch, and the operands of the next
+    // stage are fetched into the registers of the current one right after their last use (no copies).  The fetches behind the
+    // last stage read one record past the end (inside the instance's LDS; unused).
+    const int count = TR ? uniform_i32(nstages) : NH;
+    const int kfirst = TR ? count - 1 : 0;
     const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
     const bool xwriter = !TR && XI && r == 0 && b < 2 && 4 * b + q < NX; // the state: component 4 b + q sits in lane row q
-    double* const op = writer ? X + q : dummy;
-    const int ost = writer ? NU : 0;
-    double* const xp = xwriter ? XI + 4 * b + q : dummy;
-    const int xst = xwriter ? NX : 0;
-    const bool xany = !TR && XI;
+    const double* p0 = F + off[0] + km[0] * kfirst;
+    const double* p1 = F + off[1] + km[1] * kfirst;
+    const double* p2 = F + off[2] + km[2] * kfirst;
+    const double* pv = in + (q < NU ? q : 0) + NU * kfirst;
+    const int d0 = TR ? -km[0] : km[0], d1 = TR ? -km[1] : km[1], d2 = TR ? -km[2] : km[2], dv = TR ? -NU : NU;
+    double* sp = writer ? X + q + NU * kfirst : xwriter ? XI + NX + 4 * b + q : dummy;
+    const int sst = writer ? dv : xwriter ? NX : 0;
+    if (xwriter) XI[4 * b + q] = 0.0; // xi_0
     double s0 = 0.0, s1 = 0.0; // K-blocks 0 and 1 of the state (stacked components 0..3 and 4..7), one per lane row
-    // (the operands of the next stage are fetched while the current one runs: their LDS latency is off the chain)
-    const int kfirst = TR ? nstages - 1 : 0, kstep = TR ? -1 : 1;
-    const int count = TR ? nstages : NH;
-    double a0 = F[off[0] + km[0] * kfirst], a1 = F[off[1] + km[1] * kfirst], a2 = F[off[2] + km[2] * kfirst], vk = ip[NU * kfirst];
-#pragma unroll COPRA_RIC_UNROLL
-    for (int t = 0; t < count; ++t) {
-        const int k = kfirst + kstep * t;
-        const int kn = (t + 1 < count) ? k + kstep : k;
-        const double n0 = F[off[0] + km[0] * kn], n1 = F[off[1] + km[1] * kn], n2 = F[off[2] + km[2] * kn], nv = ip[NU * kn];
-        if (xany) xp[k * xst] = (b == 0) ? s0 : s1;
-        if (TR) { // (branch-free: the comparison is wave-uniform, the selects are per lane row)
-            const double add = (k == inj_stage - 1) ? inj_val : 0.0;
-            s0 += (q == inj_comp) ? add : 0.0;
-            s1 += (4 + q == inj_comp) ? add : 0.0;
+    const double inj0 = (q == inj_comp) ? inj_val : 0.0, inj1 = (4 + q == inj_comp) ? inj_val : 0.0;
+    const int tinj = TR ? count - uniform_i32(inj_stage) : -1; // (stage inj_stage - 1)
+    double a0 = *p0, a1 = *p1, a2 = *p2, vk = *pv;
+    auto stage = [&]() {
+        double y = mfma_f64_4x4x4(a2, vk, 0.0); // (does not wait for the previous stage)
+        pv += dv;
+        vk = *pv;
+        if (TR) { // (forward recursion: K-block 2 of the matrix is [B; I], the same at every stage)
+            p2 += d2;
+            a2 = *p2;
         }
-        double y = mfma_f64_4x4x4(a2, vk, b == 2 ? vk : 0.0); // (does not wait for the previous stage; C: the identity block -- lane row
-                                                              //  q of block 2 is output row 8 + q and holds input component q)
         y = mfma_f64_4x4x4(a0, s0, y);
+        p0 += d0;
+        a0 = *p0;
         y = mfma_f64_4x4x4(a1, s1, y);
-        op[ost * k] = y;
+        p1 += d1;
+        a1 = *p1;
+        *sp = y;
+        sp += sst;
         s0 = row_bcast_f64<0>(y);
         s1 = row_bcast_f64<4>(y);
-        a0 = n0;
-        a1 = n1;
-        a2 = n2;
-        vk = nv;
+    };
+    if (TR) { // two loops around the injection: nothing of it inside them
+        for (int t = 0; t < tinj; ++t) stage();
+        if (tinj < count) {
+            s0 += inj0;
+            s1 += inj1;
+        }
+        for (int t = tinj; t < count; ++t) stage();
+    } else {
+#pragma unroll COPRA_RIC_UNROLL
+        for (int t = 0; t < count; ++t) stage();
     }
-    if (xany) xp[NH * xst] = (b == 0) ? s0 : s1;
     wave_sync();
     if (!TR) return mine ? X[lane] : 0.0;
     // w_k = Lam_k^-1 s_k  (s = n where the recursion did not go: zero there, and so is w)
