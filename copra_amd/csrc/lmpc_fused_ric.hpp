@@ -180,8 +180,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
         const int row = 4 * I + q4, rw = row < NX ? row : 0;
-        pc[I] = (row < NX && r4 == NU) ? D[rw] : 0.0;
-        px[I] = row < NX ? (pgc ? B[rw + NX * (pgc ? r4 : 0)] : (r4 == NU ? X0[rw] : 0.0)) : 0.0;
+        // (compact variant: no free response -- its lanes carry zeros, so that the squares below need no mask)
+        pc[I] = (!compact && row < NX && r4 == NU) ? D[rw] : 0.0;
+        px[I] = row < NX ? (pgc ? B[rw + NX * (pgc ? r4 : 0)] : (!compact && r4 == NU ? X0[rw] : 0.0)) : 0.0;
     }
     double* const pdst = pgc ? G + NX * r4 + q4 : Xbar + q4; // row q of step 0 (row 4 + q: + 4)
     const int pst = pgc ? NX * NU : NX;
@@ -192,13 +193,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // compact variant: the blocks G are not stored -- only |row i of G_s|^2, s = 0 .. NH-1, for the row norms (NB2 = Xbar's place:
     // free until z = R^-1 v first leaves its states there); lane r = 0 of block 0 writes rows q and 4 + q, the others a spare
     const bool nb2w = compact && ((lane >> 2) & 3) == 0 && r4 == 0;
-    double* const nb2p = nb2w ? Xbar + q4 : Zs + 1;
-    double* const nb2q = (nb2w && 4 + q4 < NX) ? Xbar + 4 + q4 : Zs + 1;
+    double* nb2p = nb2w ? Xbar + q4 : Zs + 1;
+    double* nb2q = (nb2w && 4 + q4 < NX) ? Xbar + 4 + q4 : Zs + 1;
     const int nb2st = nb2w ? NX : 0, nb2qst = (nb2w && 4 + q4 < NX) ? NX : 0;
     if (compact) {
-        const double g0 = quad_sum(pgc ? px[0] * px[0] : 0.0), g1 = quad_sum(pgc ? px[1] * px[1] : 0.0);
-        nb2p[0] = g0; // (block 0: G_0 = B)
-        nb2q[0] = g1;
+        const double g0 = quad_sum(px[0] * px[0]), g1 = quad_sum(px[1] * px[1]);
+        *nb2p = g0; // (block 0: G_0 = B)
+        *nb2q = g1;
     }
     stamp[1] = cycle_counter();
     // ---- 2. backward Riccati sweep: stage records into F ----
@@ -283,10 +284,22 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             const int iq = 4 * (I - 1) + q;
             const bool on = iq < NX && (col_x || col_aff);
             wP[I] = !on ? dummy : col_x ? Pm + iq + NX * (scol - 4) : pv + iq;
-            wA[I] = (on && col_x) ? F + RR::oAcl + iq + NX * (scol - 4) : dummy; // (the affine column, d + B kv, is formed by the roll-out)
             wAst[I] = (on && col_x) ? RR::SZ : 0;
+            // (the affine column, d + B kv, is formed by the roll-out; the pointer walks down with the stages)
+            wA[I] = (on && col_x) ? F + RR::oAcl + iq + NX * (scol - 4) + (NH - 1) * RR::SZ : dummy;
         }
         const bool my_minv = r < NU && q < NU; // A operand of K: element (row r, k = q) of -M_uu^-1
+        // (NU == 3) this lane's cofactor of M_uu = x1 x2 - x3 x4, operands by their offsets in the rows-u buffer (M_uu(a, b) at a + NU b)
+        const double *adj1 = Zs, *adj2 = Zs, *adj3 = Zs, *adj4 = Zs;
+        if (NU == 3 && my_minv) {
+            const int lo = r < q ? r : q, hi = r < q ? q : r, pr = 3 * lo + hi; // (symmetric: pair (lo, hi))
+            // pairs: 00 -> 0, 01 -> 1, 02 -> 2, 11 -> 4, 12 -> 5, 22 -> 8;  entries (a, b) as a + 3 b
+            const int e1 = pr == 0 ? 4 : pr == 1 ? 2 : pr == 2 ? 1 : pr == 4 ? 0 : pr == 5 ? 1 : 0;
+            const int e2 = pr == 0 ? 8 : pr == 1 ? 5 : pr == 2 ? 5 : pr == 4 ? 8 : pr == 5 ? 2 : 4;
+            const int e3 = pr == 0 ? 5 : pr == 1 ? 1 : pr == 2 ? 2 : pr == 4 ? 2 : pr == 5 ? 0 : 1;
+            const int e4 = pr == 0 ? 5 : pr == 1 ? 8 : pr == 2 ? 4 : pr == 4 ? 2 : pr == 5 ? 5 : 1;
+            adj1 = Mu2 + e1, adj2 = Mu2 + e2, adj3 = Mu2 + e3, adj4 = Mu2 + e4;
+        }
         bool bad = false;
         wave_sync();
         for (int k = NH - 1; k >= 0; --k) {
@@ -307,9 +320,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                         if (4 + q4 < NX) pdst[s * pst + 4] = n1;
                     }
                 } else if (s < NH) { // block-row norms of G_s (all the compact variant keeps of it)
-                    const double g0 = quad_sum(pgc ? n0 * n0 : 0.0), g1 = quad_sum(pgc ? n1 * n1 : 0.0);
-                    nb2p[s * nb2st] = g0;
-                    nb2q[s * nb2qst] = g1;
+                    const double g0 = quad_sum(n0 * n0), g1 = quad_sum(n1 * n1);
+                    nb2p += nb2st;
+                    nb2q += nb2qst;
+                    *nb2p = g0;
+                    *nb2q = g1;
                 }
             }
             // T_I = P+_{I,.} [B A d] + [0 | p+]
@@ -335,23 +350,18 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             // M_uu(c, c') sits in lane 16 c + c' of M0
             double mine = 0.0; // element (r, q) of -M_uu^-1
             if constexpr (NU == 3) {
-                // 3 x 3: adjugate over determinant -- ONE reciprocal and a dependent chain of 11 operations; positive definite
-                // <=> the leading minors m00, C22, det are positive (Sylvester)
-                const double m00 = bcast_f64(M0, 0), m01 = bcast_f64(M0, 1), m02 = bcast_f64(M0, 2);
-                const double m11 = bcast_f64(M0, 17), m12 = bcast_f64(M0, 18), m22 = bcast_f64(M0, 34);
+                // 3 x 3: adjugate over determinant -- ONE reciprocal.  The loop is bound by instruction issue, so the block is
+                // taken from LDS (the rows u of M were written there above for the update of P): six reads at wave-uniform
+                // addresses for the determinant, four at this lane's own addresses for ITS cofactor (element (r, q) of the
+                // adjugate) -- instead of six v_readlane pairs and a chain of selects.  Positive definite <=> the trailing
+                // minors m22, C00, det are positive (Sylvester)
+                const double m00 = Mu2[0], m01 = Mu2[1], m02 = Mu2[2], m11 = Mu2[1 + NU], m12 = Mu2[2 + NU], m22 = Mu2[2 + 2 * NU];
+                const double x1 = *adj1, x2 = *adj2, x3 = *adj3, x4 = *adj4;
                 const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-                const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
                 const double det = m00 * c00 + (m01 * c01 + m02 * c02);
-                bad = bad || !(m00 > 0.0) || !(c22 > 0.0) || !(det > 0.0);
+                bad = bad || !(m22 > 0.0) || !(c00 > 0.0) || !(det > 0.0);
                 const double nrdet = -ric_rcp(det);
-                // this lane's cofactor: (r, q) symmetric
-                double cf = c00;
-                cf = ((r == 0 && q == 1) || (r == 1 && q == 0)) ? c01 : cf;
-                cf = ((r == 0 && q == 2) || (r == 2 && q == 0)) ? c02 : cf;
-                cf = (r == 1 && q == 1) ? c11 : cf;
-                cf = ((r == 1 && q == 2) || (r == 2 && q == 1)) ? c12 : cf;
-                cf = (r == 2 && q == 2) ? c22 : cf;
-                mine = my_minv ? cf * nrdet : 0.0;
+                mine = (x1 * x2 - x3 * x4) * nrdet; // (lanes outside the block read zeros)
             } else {
                 double lm[NU][NU], rd[NU], li[NU][NU];
 #pragma unroll
@@ -411,8 +421,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             // [Acl | bkd]_I = [A | d]_I + B_I K
             const double A1 = mfma_f64_4x4x4(aB[1], Kr, bK[1]);
             const double A2 = mfma_f64_4x4x4(aB[2], Kr, bK[2]);
-            wA[1][k * wAst[1]] = A1;
-            if (NX > 4) wA[2][k * wAst[2]] = A2;
+            *wA[1] = A1;
+            if (NX > 4) *wA[2] = A2;
+            wA[1] -= wAst[1];
+            wA[2] -= wAst[2];
             wave_sync();
             if (k == NH - 2) COPRA_FINE("sweep:stage");
             if (k == NH - 1) COPRA_FINE("sweep:first");

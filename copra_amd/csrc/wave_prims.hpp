@@ -120,14 +120,15 @@ COPRA_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <int CTRL>
 COPRA_DEV double dpp_f64(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    // (the controls used here are permutations inside a row with every lane written: mov_dpp, no `old` operand to initialise)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 COPRA_DEV int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
 }
 // Butterfly inside each 16-lane row: xor 1, xor 2 (quad_perm), then mirror inside 8 and inside 16 (valid for
 // commutative reductions once the smaller groups already agree).  Afterwards every lane of a row holds the row
