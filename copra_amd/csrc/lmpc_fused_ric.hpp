@@ -192,7 +192,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     }
     // compact variant: the blocks G are not stored -- only |row i of G_s|^2, s = 0 .. NH-1, for the row norms (NB2 = Xbar's place:
     // free until z = R^-1 v first leaves its states there); lane r = 0 of block 0 writes rows q and 4 + q, the others a spare
-    const bool nb2w = compact && ((lane >> 2) & 3) == 0 && r4 == 0;
+    const bool nb2w = compact && ((lane >> 2) & 3) == 3 && r4 == 0; // (hardware block 3: where the preview rides, see the sweep)
     double* nb2p = nb2w ? Xbar + q4 : Zs + 1;
     double* nb2q = (nb2w && 4 + q4 < NX) ? Xbar + 4 + q4 : Zs + 1;
     const int nb2st = nb2w ? NX : 0, nb2qst = (nb2w && 4 + q4 < NX) ? NX : 0;
@@ -252,9 +252,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         const double* pA[3][3];
         const double* pC[3];
         const double* muA[3];
+        // Compact variant: the preview recursion G_s = A G_{s-1} RIDES in hardware block 3 of the products T_I -- its columns (12..)
+        // are padding there, and T_I = sum_K P+_{I,K} [B A d]_K has the shape of G_I = sum_K A_{I,K} G_K: the lanes of block 3 hand
+        // in A instead of P+ and the previous G instead of [B A d], and take the new G out of T (four MFMAs less per stage).
+        const bool ride = compact && hb == 3;
 #pragma unroll
         for (int K = 1; K <= 2; ++K) {
-            bK[K] = abd(4 * (K - 1) + q, scol); // B operand (row x_t of K-block K, column scol); also C of the closed loop
+            bK[K] = ride ? px[K - 1] : abd(4 * (K - 1) + q, scol); // B operand (row x_t of K-block K, column scol); also C of the closed loop
 #pragma unroll
             for (int I = 0; I < 3; ++I) aM[I][K] = (4 * I + r == SAFF) ? 0.0 : abd(4 * (K - 1) + q, 4 * I + r); // A operand of M
         }
@@ -265,7 +269,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
             for (int K = 1; K <= 2; ++K) {
                 const int kq = 4 * (K - 1) + q;
-                pA[I][K] = (ir < NX && kq < NX) ? Pm + ir + NX * kq : Zs;
+                pA[I][K] = (ir < NX && kq < NX) ? (ride ? A : Pm) + ir + NX * kq : Zs;
             }
             pC[I] = (col_aff && iq < NX) ? pv + iq : Zs;
             muA[I] = (ir < NX && q < NU) ? Mu2 + q + NU * (4 + ir) : Zs;
@@ -304,7 +308,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
         wave_sync();
         for (int k = NH - 1; k >= 0; --k) {
             double* Fk = F + k * RR::SZ;
-            { // preview step s = NH - k
+            if (!compact) { // preview step s = NH - k
                 const int s = NH - k;
                 double n0 = mfma_f64_4x4x4(pa[0][0], px[0], pc[0]);
                 double n1 = mfma_f64_4x4x4(pa[1][0], px[0], pc[1]);
@@ -314,17 +318,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
                 }
                 px[0] = n0;
                 px[1] = n1;
-                if (!compact) {
-                    if (pw && (s < NH || !pgc)) {
-                        pdst[s * pst] = n0;
-                        if (4 + q4 < NX) pdst[s * pst + 4] = n1;
-                    }
-                } else if (s < NH) { // block-row norms of G_s (all the compact variant keeps of it)
-                    const double g0 = quad_sum(n0 * n0), g1 = quad_sum(n1 * n1);
-                    nb2p += nb2st;
-                    nb2q += nb2qst;
-                    *nb2p = g0;
-                    *nb2q = g1;
+                if (pw && (s < NH || !pgc)) {
+                    pdst[s * pst] = n0;
+                    if (4 + q4 < NX) pdst[s * pst + 4] = n1;
                 }
             }
             // T_I = P+_{I,.} [B A d] + [0 | p+]
@@ -333,6 +329,17 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             if (NX > 4) {
                 T1 = mfma_f64_4x4x4(*pA[1][2], bK[2], T1);
                 T2 = mfma_f64_4x4x4(*pA[2][2], bK[2], T2);
+            }
+            if (compact) { // block 3 of T: G_s, s = NH - k -- its block-row norms are all that is kept (the other blocks' sums go nowhere)
+                if (k > 0) {
+                    const double g0 = quad_sum(T1 * T1), g1 = quad_sum(T2 * T2);
+                    nb2p += nb2st;
+                    nb2q += nb2qst;
+                    *nb2p = g0;
+                    *nb2q = g1;
+                }
+                bK[1] = ride ? T1 : bK[1];
+                bK[2] = ride ? T2 : bK[2];
             }
             // M_I = Hin_I + [B A]'_{I,.} T
             double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hacc[0]);
