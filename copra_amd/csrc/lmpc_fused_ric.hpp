@@ -196,10 +196,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     double* nb2p = nb2w ? Xbar + q4 : Zs + 1;
     double* nb2q = (nb2w && 4 + q4 < NX) ? Xbar + 4 + q4 : Zs + 1;
     const int nb2st = nb2w ? NX : 0, nb2qst = (nb2w && 4 + q4 < NX) ? NX : 0;
+    double ncum0 = 0.0, ncum1 = 0.0; // running sums over the steps: a row at step k needs sum_{t < k}, ONE read later
     if (compact) {
-        const double g0 = quad_sum(px[0] * px[0]), g1 = quad_sum(px[1] * px[1]);
-        *nb2p = g0; // (block 0: G_0 = B)
-        *nb2q = g1;
+        ncum0 = quad_sum(px[0] * px[0]), ncum1 = quad_sum(px[1] * px[1]);
+        *nb2p = ncum0; // (block 0: G_0 = B)
+        *nb2q = ncum1;
     }
     stamp[1] = cycle_counter();
     // ---- 2. backward Riccati sweep: stage records into F ----
@@ -332,11 +333,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             }
             if (compact) { // block 3 of T: G_s, s = NH - k -- its block-row norms are all that is kept (the other blocks' sums go nowhere)
                 if (k > 0) {
-                    const double g0 = quad_sum(T1 * T1), g1 = quad_sum(T2 * T2);
+                    ncum0 += quad_sum(T1 * T1);
+                    ncum1 += quad_sum(T2 * T2);
                     nb2p += nb2st;
                     nb2q += nb2qst;
-                    *nb2p = g0;
-                    *nb2q = g1;
+                    *nb2p = ncum0;
+                    *nb2q = ncum1;
                 }
                 bK[1] = ride ? T1 : bK[1];
                 bK[2] = ride ? T2 : bK[2];
@@ -555,7 +557,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             }
             for (int i = lane; i < P.mgen; i += kWave) {
                 const RowDesc d = rows.desc(i);
-                if (d.ek == kEOneHot && d.gk == kGNone) {
+                if (compact && d.ek == kEOneHot && d.gk == kGNone) { // (the preview steps left RUNNING sums)
+                    put_norm(i, d.k > 0 ? sqrt(NB2[(d.k - 1) * tst + d.eo]) : 0.0);
+                } else if (d.ek == kEOneHot && d.gk == kGNone) {
                     double part[NH];
 #pragma unroll
                     for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * tst + d.eo];

@@ -162,6 +162,21 @@ def test_riccati_factor_tier_compact_variant_with_control_rows(emu, oracle):
         assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
+def test_riccati_factor_tier_compact_variant_shared_model_more_than_64_rows(emu, oracle):
+    """the compact variant in shared-model mode with 103 rows: stage records and row norms come from the model, the norms of
+    rows 64.. are written over the system's slots (x0 has moved into the trajectory buffer by then); against the oracle"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.3, u_max=1.5, seed=9)
+    cstrs = wl["cstrs"] + [dict(kind="control", G=[[0.0, 1.0, 1.0], [1.0, -1.0, 0.0]], f=[1.2, 0.9])]
+    A, B, d = wl["A"][0], wl["B"][0], wl["d"][0]
+    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], cstrs)
+    assert re["riccati_factor"]
+    for k in range(6):
+        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], cstrs)
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
+        assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_riccati_factor_tier_with_equality_rows(emu, oracle):
     """the Riccati-factor tier with a full-size equality entry (two rows: terminal velocities prescribed) next to the bounds:
     the equality rows go through the orientation logic of the active-set loop (eqsgn), the full-size rows keep the trajectory

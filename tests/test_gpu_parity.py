@@ -1097,6 +1097,33 @@ def test_shared_model_both_first_tiers(oracle, monkeypatch):
     eng.close()
 
 
+def test_riccati_factor_tier_compact_variant_more_than_64_rows(oracle):
+    """compact variant of the Riccati-factor tier (G never stored, A | B | d | x0 in the solver vectors' place, the first 64 row
+    norms in registers) with ControlConstraint rows on top of the bounds: 103 rows, so the norms of rows 64.. go to LDS -- over
+    the system's slots, which is why x0 moves into the trajectory buffer first.  Per-instance systems and the shared-model
+    mode (stage records and norms from the model), whole batch against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 512
+    wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=31)
+    wl["cstrs"] = wl["cstrs"] + [dict(kind="control", G=[[0.0, 1.0, 1.0], [1.0, -1.0, 0.0]], f=[1.2, 0.9])]
+    eng, res, ref = _check(wl, b, oracle)
+    ok = ref["status"] == 0
+    assert (res["iter"][ok] == ref["iter"][ok]).all() and (res["iter"][:, 0] > 2).mean() > 0.2
+    assert eng.layout_info()["lds_bytes"] < 15360  # (ten or more instances per CU: the compact variant, not the general one)
+    eng.close()
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(wl["x0"])
+    eng.solve()
+    rs = eng.results()
+    ref = oracle.lmpc_solve_batch(np.repeat(wl["A"][:1], b, 0), np.repeat(wl["B"][:1], b, 0), np.repeat(wl["d"][:1], b, 0),
+                                  wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    assert (rs["status"] == ref["status"]).all() and (rs["iter"][ok] == ref["iter"][ok]).all()
+    assert _rel(rs["control"][ok], ref["control"][ok]) <= RTOL and _rel(rs["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+    eng.close()
+
+
 @pytest.mark.parametrize("N", [10, 15])
 def test_riccati_factor_tier_shorter_horizons(oracle, N):
     """CoM shape at the two shorter instantiated horizons (lmpc_fused_ric.hpp for N = 10, 15): whole batch against the oracle"""
