@@ -1,6 +1,7 @@
 // copra_hip.hip -- kernels + C ABI (include/copra_hip.h) of the MI355X-native batched linear-MPC engine.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared copra_hip.hip -o libcopra_hip.so  (see Makefile)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "../../include/copra_hip.h"
 #include "islmpc_fused.hpp"
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 template <int NX, int NU, int NH, int QR>
 __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {
+    if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
     lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, P.inst_offset + (int)blockIdx.x);
 }
 
@@ -357,7 +359,9 @@ struct copra_batch {
     // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
-    int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue
+    int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue (TWO counters, used in turn: begin_overflow_queue)
+    int ovf_cur = 0; // the counter the last solve appended to
+    bool ovf_clean[2] = { false, false }; // known to hold zero on the device
     // shared-model fast path: one (A, B, d) for the whole batch, factorised once (copra_batch_set_shared_system)
     bool shared = false, model_dirty = true, shared_attr_set = false;
     // shared-model mode of the Riccati-factor tier (lmpc_fused_ric.hpp, FusedPlan::ric_model): the layout the plan builder chose
@@ -438,7 +442,8 @@ static FusedPlan device_plan(const copra_batch* h)
     P.x0lb = h->x0lb;
     P.x0ub = h->x0ub;
     P.x0_opt = h->d_x0opt;
-    P.ovf_count = h->d_ovf_count;
+    P.ovf_count = h->d_ovf_count + h->ovf_cur;
+    P.ovf_zero = nullptr;
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
     P.ws = h->d_ws;
@@ -451,6 +456,30 @@ static FusedPlan device_plan(const copra_batch* h)
     return P;
 }
 
+// The overflow queue of a two-tier solve needs a counter that is zero when the first tier starts.  There are two, used in
+// turn: a first-tier kernel that can do so (`self_reset`: the Riccati-factor tier) zeroes the OTHER one while it runs -- nobody
+// reads it then (the second tier of the previous solve, which did, is behind in the stream) --, so that the next solve finds
+// a clean counter and no hipMemsetAsync has to sit in the stream between two solves (a dispatch of its own: ~ 6 us with its
+// gap, 1 % of the headline step).  Otherwise: one memset, as before.
+static hipError_t begin_overflow_queue(copra_batch* h, hipStream_t s, bool self_reset, FusedPlan& P)
+{
+    int cur = h->ovf_clean[0] ? 0 : h->ovf_clean[1] ? 1 : -1;
+    if (cur < 0) {
+        cur = 0;
+        const hipError_t e = hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
+    h->ovf_clean[cur] = false; // (appended to from now on)
+    h->ovf_cur = cur;
+    P.ovf_count = h->d_ovf_count + cur;
+    P.ovf_zero = nullptr;
+    if (self_reset) {
+        P.ovf_zero = h->d_ovf_count + (cur ^ 1);
+        h->ovf_clean[cur ^ 1] = true;
+    }
+    return hipSuccess;
+}
+
 // Compact LDS layouts (R capped, overflow finished by the second tier) bet on small active sets.  After each of the
 // first solves the overflow queue tells whether the bet holds; if more than one instance in eight had to be redone by
 // the second tier, step to the next safer layout: dense -> safe (quarter-CU compact or full) -> full.
@@ -460,7 +489,7 @@ static copra_status_t adapt_layout(copra_batch* h)
     h->adapt_left -= 1;
     int count = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
-    HIP_TRY(hipMemcpy(&count, h->d_ovf_count, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&count, h->d_ovf_count + h->ovf_cur, sizeof(int), hipMemcpyDeviceToHost));
     // (the Riccati-factor tier is so much faster than its second tier -- the square-layout kernel -- that it pays to step down
     //  the ladder until only one instance in 32 is left over; the other first tiers keep the round-1 threshold of one in 8)
     const long long share = h->hp.plan.lds.ric ? 32 : 8;
@@ -772,7 +801,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     }
     h->packed = (h->hp.large || h->hp.plan.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0 // (the packed bodies are square-layout)
         : packed_width(is ? P.nx + P.n : P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
-    chk(hipMalloc((void**)&h->d_ovf_count, sizeof(int)));
+    chk(hipMalloc((void**)&h->d_ovf_count, 2 * sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
     chk(hipEventCreate(&h->ev1));
@@ -1406,7 +1435,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
         P.model_rtot = h->model_rtot;
         HIP_TRY(hipEventRecord(h->ev0, s));
-        if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
+        if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, false, P));
         if (h->shared_ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
             FusedPlan Pr = P;
             Pr.ric_model = h->d_ric_model;
@@ -1442,18 +1471,24 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     }
     if (!h->A || !h->B || !h->d || !h->x0)
         return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
-    const FusedPlan P = device_plan(h);
+    FusedPlan P = device_plan(h);
     hipStream_t s = (hipStream_t)hip_stream;
     h->last_stream = s;
     if (P.batch == 0) return COPRA_OK;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    HIP_TRY(hipEventRecord(h->ev0, s));
+    // Timing (copra_batch_last_solve_seconds).  The plain one-wave launch carries its two events IN its dispatch packet
+    // (hipExtLaunchKernelGGL): the first-tier kernel's own start and end, no barrier packets in the stream -- two
+    // hipEventRecord per solve cost ~ 20 us between consecutive solves, 3 % of the headline step.  The other paths bracket
+    // their launches with recorded events as before.
+    const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri;
+    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed && !std::getenv("COPRA_RECORDED_EVENTS");
+    if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
         if (use_riccati(h)) {
             // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
             const size_t ric_lds = (size_t)h->hs.sp.lds_doubles * sizeof(double);
-            HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
+            HIP_TRY(begin_overflow_queue(h, s, false, P));
             HIP_TRY(hipMemsetAsync(h->d_ric_next, 0, sizeof(int), s));
             const riccati_kernel_t ric_fn = select_riccati_kernel(P.nx, P.nu);
             LDS_OPT_IN(ric_fn, ric_lds);
@@ -1489,8 +1524,8 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->timed = true;
         return COPRA_OK;
     }
-    if (h->hp.two_tier) HIP_TRY(hipMemsetAsync(h->d_ovf_count, 0, sizeof(int), s));
-    if (h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
+    if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && !jit_launch && !h->packed, P));
+    if (jit_launch) {
         FusedPlan Pj = P;
         void* args[] = { &Pj };
         const unsigned per = 64u / (unsigned)h->jit_lanes;
@@ -1507,7 +1542,10 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
                 h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
         }
-        hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        if (ext_timed)
+            hipExtLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, h->ev0, h->ev1, 0, P);
+        else
+            hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
     }
     if (h->hp.two_tier) {
@@ -1520,7 +1558,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(h->ev1, s));
+    if (!ext_timed) HIP_TRY(hipEventRecord(h->ev1, s));
     h->timed = true;
     return COPRA_OK;
 }

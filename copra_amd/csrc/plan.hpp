@@ -265,7 +265,8 @@ struct FusedPlan {
     // optional phase profile: 8 shader-clock stamps per instance (preview, costs, norms, cholesky, inverse+x0,
     // active set, results, total) -- the device-side analogue of LMPC::solveTime()/solveAndBuildTime()
     // two-tier execution: instances whose active set outgrows lds.rcap in the compact layout are queued ...
-    int* ovf_count; // device counter (reset before every solve)
+    int* ovf_count; // device counter (zero when the first tier starts)
+    int* ovf_zero; // != nullptr: the first tier zeroes this one -- the next solve's counter (copra_hip.hip: begin_overflow_queue)
     int* ovf_list; // [batch] instance ids
     int from_list; // ... and the second launch (full layout) takes its instances from that queue
     // shared-model fast path (lmpc_shared.hpp): the whole batch shares (A, B, d), only x0 differs per instance.
