@@ -71,14 +71,20 @@ def host_cores():
 
 
 def timed_rate(eng, batch, reps=5):
-    """solves/s of copra_batch_solve from the C ABI's HIP events (best of `reps` after one warm-up)"""
-    eng.solve()
-    eng.synchronize()
-    best = None
-    for _ in range(reps):
+    """solves/s of copra_batch_solve from the C ABI's HIP events (best of `reps` after one warm-up).  WHOLE solve: events
+    recorded around both launches (COPRA_RECORDED_EVENTS; the default event pair of the one-wave path times the first
+    launch alone, which is what the roofline of the headline wants but would leave out the second tier's share here)"""
+    os.environ["COPRA_RECORDED_EVENTS"] = "1"
+    try:
         eng.solve()
-        s = eng.last_solve_seconds()
-        best = s if best is None else min(best, s)
+        eng.synchronize()
+        best = None
+        for _ in range(reps):
+            eng.solve()
+            s = eng.last_solve_seconds()
+            best = s if best is None else min(best, s)
+    finally:
+        os.environ.pop("COPRA_RECORDED_EVENTS", None)
     return batch / best, best
 
 
