@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 }
 
 // The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
-// (three waves per SIMD: 161 VGPRs; with 17.7 KB of LDS per instance nine instances share a CU)
+// (three waves per SIMD: 168 VGPRs; compact variant: 13.9 KB of LDS per instance, eleven instances share a CU; general
+//  variant: 17.7 KB + the rows' share, seven to nine -- the LDS allocation granule is 1280 B, profiles/r02/lds_granule_probe.txt)
 template <int NX, int NU, int NH, int QR>
 __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {

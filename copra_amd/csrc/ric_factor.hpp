@@ -21,11 +21,12 @@
 //     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows) | kv (NU: feed-forward
 //     of the unconstrained minimiser)
 // followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | d (NX) | a zero | a spare double | a one
-// (the one: the identity block that passes t_k / n_k through to the output rows; the roll-out's goes through the C operand)
+// (the one: the identity block that passes t_k / n_k through to the output rows of the backward recursion; the forward one and
+//  the roll-out keep their whole K-block 2, [B; I] resp. [B d; I 0], in a register -- it is the same at every stage)
 #pragma once
 
 #ifndef COPRA_RIC_UNROLL
-#define COPRA_RIC_UNROLL 2 // stages per loop body of the recursions (two: the prefetch registers of stage k + 1 become those of stage k without moves)
+#define COPRA_RIC_UNROLL 2 // stages per loop body of the fixed-length recursions (forward, roll-out)
 #endif
 
 namespace copra_hip {
@@ -79,7 +80,7 @@ COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
     kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
     const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
-    if (IDENT && to == 1 && s_out == s_in) return cbase + RR::cO; // the identity block: a constant 1.0 (roll-out: through the C operand)
+    if (IDENT && to == 1 && s_out == s_in) return cbase + RR::cO; // the identity block: a constant 1.0
     if (to == 2 || ti == 2 || (to == 1 && ti == 1)) return cbase + RR::cZ;
     const int a = to == 0 ? s_out : s_out - 8, b = ti == 0 ? s_in : s_in - 8;
     if (ti == 1) return cbase + RR::cB + a + NX * b; // B(a, b)
