@@ -88,31 +88,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     // ---- 0b. stage costs (they do not depend on the system: their loads overlap the ones above) ----
     // lane -> entry (a, b) of M = Hin + [A B]' P+ [A B] that it owns in the sweep:  x-x upper triangle | u-x | u-u upper
     // triangle | the affine column (b == NZ)
-    int ma = 0, mb = 0;
-    bool m_on = true;
-    // (position t of a packed upper triangle -> column b = floor((sqrt(8 t + 1) - 1) / 2): sqrtf is exact on the perfect squares
-    //  8 t + 1 = (2 b + 1)^2 at which b steps)
-    auto tri_col = [](int t) { return (int)((sqrtf(8.0f * (float)t + 1.0f) - 0.999f) * 0.5f); }; // (0.001 of slack: the next smaller
-                                                                                                // radicand is 0.19 below for t < 64)
-    if (lane < nxx) {
-        const int b = tri_col(lane);
-        mb = b;
-        ma = lane - b * (b + 1) / 2;
-    } else if (lane < nxx + nux) {
-        const int t = lane - nxx;
-        ma = NX + t % NU;
-        mb = t / NU;
-    } else if (lane < nxx + nux + nuu) {
-        const int t = lane - nxx - nux;
-        const int b = tri_col(t);
-        mb = NX + b;
-        ma = NX + t - b * (b + 1) / 2;
-    } else if (lane < nxx + nux + nuu + NZ) {
-        ma = lane - nxx - nux - nuu;
-        mb = NZ;
-    } else {
-        m_on = false;
-    }
+    // (the sweep takes Hin in accumulator layout from the plan builder's tables; of this lane layout only the affine lanes
+    //  are still decoded: lane base + a owns hin(a), which may depend on per-instance references)
+    const bool aff_lane = lane >= nxx + nux + nuu && lane < nxx + nux + nuu + NZ;
+    const int ma = lane - (nxx + nux + nuu);
     // The plan builder has evaluated them per lane (plan_builder.hpp, build_ric_tables): entry of Hin / HN, and for the
     // affine lanes the coefficients of the references p_t, which may be per-instance -- 2 + RP coalesced loads per cost.
     const int pi = lane % NX, pj = lane / NX; // element (pi, pj) of an NX x (NZ + 1) table: [A B d] layout
@@ -147,7 +126,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
             for (int r = 0; r < RP; ++r) aff += cw[t][r] * pr[t][r];
         // (no lane owns an affine entry of the stage AND one of the terminal cost: the table holds whichever it has)
-        hreg += (m_on && mb == NZ) ? aff : 0.0;
+        hreg += aff_lane ? aff : 0.0;
         term += (tj == NX) ? aff : 0.0;
         if (tj < NX)
             Pm[lane] = term;
@@ -233,7 +212,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             double* AF = T; // [stacked row]: 12 doubles
             if (lane < 12) AF[lane] = 0.0;
             wave_sync();
-            if (m_on && mb == NZ) AF[(ma < NX) ? 4 + ma : ma - NX] = hreg;
+            if (aff_lane) AF[(ma < NX) ? 4 + ma : ma - NX] = hreg;
             wave_sync();
             if (col_aff) {
 #pragma unroll
