@@ -147,11 +147,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     static_assert(NU + 1 <= 4 && NX <= 8, "preview recursion on 4 x 4 blocks");
     wave_sync();
     const int q4 = lane >> 4, r4 = lane & 3; // lane = 16 q + 4 b + r
-    double pa[2][2]; // A operand (row 4 I + r, column 4 K + q) of A
+    double pa[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } }; // A operand (row 4 I + r, column 4 K + q) of A
+    if (!compact) { // (compact variant: the recursion rides in the sweep's products, which read A themselves)
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < 2; ++I)
 #pragma unroll
-        for (int K = 0; K < 2; ++K) pa[I][K] = (4 * I + r4 < NX && 4 * K + q4 < NX) ? A[(4 * I + r4) + NX * (4 * K + q4)] : 0.0;
+            for (int K = 0; K < 2; ++K) pa[I][K] = (4 * I + r4 < NX && 4 * K + q4 < NX) ? A[(4 * I + r4) + NX * (4 * K + q4)] : 0.0;
+    }
     const bool pw = ((lane >> 2) & 3) == 0 && (compact ? r4 < NU : r4 <= NU); // lanes of block 0 store (compact variant: not the
                                                                               // free response, which nobody reads -- its place is inside G)
     const bool pgc = r4 < NU; // a column of G (else xbar)
@@ -160,8 +162,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     for (int I = 0; I < 2; ++I) {
         const int row = 4 * I + q4, rw = row < NX ? row : 0;
         // (compact variant: no free response -- its lanes carry zeros, so that the squares below need no mask)
-        pc[I] = (!compact && row < NX && r4 == NU) ? D[rw] : 0.0;
-        px[I] = row < NX ? (pgc ? B[rw + NX * (pgc ? r4 : 0)] : (!compact && r4 == NU ? X0[rw] : 0.0)) : 0.0;
+        pc[I] = 0.0;
+        px[I] = (row < NX && pgc) ? B[rw + NX * (pgc ? r4 : 0)] : 0.0;
+        if (!compact) {
+            pc[I] = (row < NX && r4 == NU) ? D[rw] : 0.0;
+            px[I] = (row < NX && r4 == NU) ? X0[rw] : px[I];
+        }
     }
     double* const pdst = pgc ? G + NX * r4 + q4 : Xbar + q4; // row q of step 0 (row 4 + q: + 4)
     const int pst = pgc ? NX * NU : NX;
@@ -221,12 +227,17 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
             wave_sync();
         }
         if (lane < 2) Zs[lane] = 0.0;
+        wave_sync(); // (the zero is read below, by other lanes)
         // row t of [B A d] at stacked column sc
+        // (ONE unconditional read through a selected address -- LDS addresses are 32 bits -- instead of three masked reads and
+        //  64-bit selects: this is straight-line set-up that every instance pays)
         auto abd = [&](int t, int sc) -> double {
-            if (t < 0 || t >= NX) return 0.0;
-            if (sc < NU) return B[t + NX * sc];
-            if (sc >= 4 && sc < 4 + NX) return A[t + NX * (sc - 4)];
-            return sc == SAFF ? D[t] : 0.0;
+            const bool tv = t >= 0 && t < NX;
+            const double* p = Zs;
+            p = (tv && sc < NU) ? B + t + NX * sc : p;
+            p = (tv && sc >= 4 && sc < 4 + NX) ? A + t + NX * (sc - 4) : p;
+            p = (tv && sc == SAFF) ? D + t : p;
+            return *p;
         };
         double bK[3], aM[3][3], aB[3]; // (index 0 unused: K-blocks / row blocks 1 and 2 are the x blocks)
         const double* pA[3][3];
