@@ -461,7 +461,12 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
     bool have_J = j_ready; // the shared-model path arrives with J = R^-1 in place
     iter_main = 0;
     iter_drop = 0;
-    for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;
+    if constexpr (RNX > 0) { // (layout_lds_ric: the flags start on a double and own whole doubles -- eight rows per store)
+        double* const act8 = reinterpret_cast<double*>(S.act);
+        for (int i = lane; i < (mtotal + 7) / 8; i += kWave) act8[i] = 0.0;
+    } else {
+        for (int i = lane; i < mtotal; i += kWave) S.act[i] = 0;
+    }
     for (int i = lane; i < meq; i += kWave) S.eqsgn[i] = 1.0;
     for (int i = lane; i <= S.rcap + 1 && i <= n + 1; i += kWave) S.uv[i] = 0.0;
     // rows [I; -I] with right-hand sides [XU; -XL] (QuadProgSolver.cpp:61-69): lane j keeps XU_j, XL_j

@@ -256,7 +256,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
         for (int I = 1; I <= 2; ++I) {
             const int ir = 4 * (I - 1) + r, iq = 4 * (I - 1) + q; // x row as A-operand row / as result row
-            aB[I] = (ir < NX && q < NU) ? B[ir + NX * q] : 0.0;
+            aB[I] = *((ir < NX && q < NU) ? B + ir + NX * q : Zs);
 #pragma unroll
             for (int K = 1; K <= 2; ++K) {
                 const int kq = 4 * (K - 1) + q;
