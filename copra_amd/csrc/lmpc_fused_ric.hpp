@@ -117,14 +117,19 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
                 cw[t][r] = tab[kWave * (2 + tt * RP + r) + lane];
-                pr[t][r] = live ? pref[r < rc ? r : rc - 1] : 0.0; // (rows past the term's have zero coefficients)
+                pr[t][r] = pref[r < rc ? r : rc - 1]; // (rows past the term's have zero coefficients; a cost that is not there reads
+                                                      //  cost 0's -- every load unconditional: no branches in this prologue, whose
+                                                      //  loads are all in flight together -- and is left out of the sum below)
             }
         }
         double aff = 0.0;
 #pragma unroll
-        for (int t = 0; t < kRicMaxCosts; ++t)
+        for (int t = 0; t < kRicMaxCosts; ++t) {
+            double at = 0.0;
 #pragma unroll
-            for (int r = 0; r < RP; ++r) aff += cw[t][r] * pr[t][r];
+            for (int r = 0; r < RP; ++r) at += cw[t][r] * pr[t][r];
+            aff += (t < P.ncost) ? at : 0.0;
+        }
         // (no lane owns an affine entry of the stage AND one of the terminal cost: the table holds whichever it has)
         hreg += aff_lane ? aff : 0.0;
         term += (tj == NX) ? aff : 0.0;
