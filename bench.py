@@ -71,21 +71,20 @@ def host_cores():
 
 
 def timed_rate(eng, batch, reps=5):
-    """solves/s of copra_batch_solve from the C ABI's HIP events (best of `reps` after one warm-up).  WHOLE solve: events
-    recorded around both launches (COPRA_RECORDED_EVENTS; the default event pair of the one-wave path times the first
-    launch alone, which is what the roofline of the headline wants but would leave out the second tier's share here)"""
-    os.environ["COPRA_RECORDED_EVENTS"] = "1"
-    try:
+    """solves/s of copra_batch_solve from the C ABI's HIP events: BEST of `reps` solves after one warm-up, device time of the
+    WHOLE solve (every launch of it: copra_batch_last_solve_seconds).  These are kernel-event rates of single solves -- the
+    headline `value` is the mean over wall-clock steps -- and every `extra` entry made from them says so in `timing`."""
+    eng.solve()
+    eng.synchronize()
+    best = None
+    for _ in range(reps):
         eng.solve()
-        eng.synchronize()
-        best = None
-        for _ in range(reps):
-            eng.solve()
-            s = eng.last_solve_seconds()
-            best = s if best is None else min(best, s)
-    finally:
-        os.environ.pop("COPRA_RECORDED_EVENTS", None)
+        s = eng.last_solve_seconds()
+        best = s if best is None else min(best, s)
     return batch / best, best
+
+
+EVENT_TIMING = "best of %d solves, HIP events around the whole solve (device time, inputs resident in HBM)"
 
 
 def extra_measurements(np, torch, dev):
@@ -320,7 +319,7 @@ def main():
     eng.set_outputs(views0["control"], views0["trajectory"], views0["status"], views0["iter"])
     for _ in range(min(args.steps, 10)):
         eng.solve(stream)
-        kernel_s.append(eng.last_solve_seconds())
+        kernel_s.append(eng.last_first_tier_seconds())  # (the dominant kernel alone: what rocprofv3's kernel trace shows)
     torch.cuda.synchronize()
     out_u, out_s, out_i = views0["control"], views0["status"], views0["iter"]
     status = out_s.cpu().numpy()

@@ -252,6 +252,8 @@ def lib():
         L.copra_batch_dump_qp.argtypes = [vp, C.c_int] + [vp] * 8
         L.copra_batch_last_solve_seconds.restype = C.c_int
         L.copra_batch_last_solve_seconds.argtypes = [vp, _dp]
+        L.copra_batch_last_first_tier_seconds.restype = C.c_int
+        L.copra_batch_last_first_tier_seconds.argtypes = [vp, _dp]
         L.copra_batch_phase_profile.restype = C.c_int
         L.copra_batch_phase_profile.argtypes = [vp, C.c_int, vp]
         L.copra_qp_solve_dense_batch.restype = C.c_int

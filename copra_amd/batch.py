@@ -185,6 +185,12 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_last_solve_seconds(self._h, C.byref(s)))
         return s.value
 
+    def last_first_tier_seconds(self):
+        """device time of the FIRST launch of the last solve (the dominant kernel; what a rocprofv3 kernel trace shows)"""
+        s = C.c_double()
+        _capi.check(self._lib.copra_batch_last_first_tier_seconds(self._h, C.byref(s)))
+        return s.value
+
     PHASES = ("preview", "costs", "norms", "cholesky", "inverse_x0", "active_set", "results", "total")
 
     def enable_phase_profile(self, on=True):

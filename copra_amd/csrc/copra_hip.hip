@@ -404,7 +404,8 @@ struct copra_batch {
     int ric_grid = 0;
     long long* d_prof_fine = nullptr; // profiling builds only
     long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr; // start | end of the solve | end of its first launch (packet-borne timing)
+    bool tier_timed = false; // evm was written by the last solve
     hipStream_t last_stream = nullptr;
     bool timed = false;
     bool lds_attr_set = false;
@@ -517,6 +518,13 @@ static copra_status_t adapt_layout(copra_batch* h)
     h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
     h->lds_attr_set = false;
     h->shared_attr_set = false;
+    if (h->shared_ric || h->has_lds_ric) {
+        // the ladder of Riccati-factor layouts is exhausted: a shared-model controller leaves that tier for good (its first
+        // tier is lmpc_shared.hpp from now on, whose model -- J, G, Phi, xi -- has to be prepared again for the new layout)
+        h->shared_ric = false;
+        h->has_lds_ric = false;
+        h->model_dirty = true;
+    }
     const FusedPlan& P = h->hp.plan;
     h->packed = (P.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0
         : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
@@ -559,9 +567,12 @@ static copra_status_t prepare_riccati(copra_batch* h)
     (void)hipFree(h->d_ric_ws);
     h->d_ric_ws = nullptr;
     build_stage_plan(h->hp, h->hs, all_bounds);
-    h->ric_built = true;
+    h->ric_built = false; // (set once every table and the workspace are on the device: a failed attempt must not look prepared)
     h->ric_all_bounds = all_bounds;
-    if (!h->hs.eligible) return COPRA_OK;
+    if (!h->hs.eligible) {
+        h->ric_built = true;
+        return COPRA_OK;
+    }
     HostStagePlan& hs = h->hs;
     hipError_t e = hipSuccess;
     auto upi = [&](const std::vector<int>& v) -> const int* {
@@ -626,7 +637,17 @@ static copra_status_t prepare_riccati(copra_batch* h)
     if (std::getenv("COPRA_DEBUG"))
         fprintf(stderr, "[copra] riccati path: %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n", sp.ncls,
             sp.m, h->ric_grid, per_cu, lds_bytes, sp.ws_total * 8LL);
-    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("riccati path: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        for (void* q : h->ric_dev) (void)hipFree(q);
+        h->ric_dev.clear();
+        (void)hipFree(h->d_ric_ws);
+        h->d_ric_ws = nullptr;
+        h->hs.eligible = false;
+        h->hs.why = "device tables of the stage plan could not be allocated";
+        (void)hipGetLastError();
+        return fail(COPRA_ERR_HIP, std::string("riccati path: ") + hipGetErrorString(e));
+    }
+    h->ric_built = true;
     return COPRA_OK;
 }
 
@@ -806,6 +827,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
     chk(hipEventCreate(&h->ev0));
     chk(hipEventCreate(&h->ev1));
+    chk(hipEventCreate(&h->evm));
     if (e != hipSuccess) {
         g_err = std::string("copra_batch_create: ") + hipGetErrorString(e);
         copra_batch_destroy(h);
@@ -861,6 +883,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_ovf_list);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->evm) (void)hipEventDestroy(h->evm);
     delete h;
 }
 
@@ -1437,7 +1460,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.model_rtot = h->model_rtot;
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, false, P));
-        if (h->shared_ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
+        if (h->shared_ric && P.lds.ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
             FusedPlan Pr = P;
             Pr.ric_model = h->d_ric_model;
             LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
@@ -1468,6 +1491,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         }
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed = true;
+        h->tier_timed = false;
         return COPRA_OK;
     }
     if (!h->A || !h->B || !h->d || !h->x0)
@@ -1478,8 +1502,9 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (P.batch == 0) return COPRA_OK;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    // Timing (copra_batch_last_solve_seconds).  The plain one-wave launch carries its two events IN its dispatch packet
-    // (hipExtLaunchKernelGGL): the first-tier kernel's own start and end, no barrier packets in the stream -- two
+    // Timing (copra_batch_last_solve_seconds).  The plain one-wave launches carry their events IN their dispatch packets
+    // (hipExtLaunchKernelGGL): start of the first launch, end of the first launch (copra_batch_last_first_tier_seconds) and end
+    // of the second one (the whole solve, what LMPC::solveTime() reports) -- no barrier packets in the stream: two
     // hipEventRecord per solve cost ~ 20 us between consecutive solves, 3 % of the headline step.  The other paths bracket
     // their launches with recorded events as before.
     const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri;
@@ -1503,6 +1528,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(h->ev1, s));
             h->timed = true;
+            h->tier_timed = false;
             return COPRA_OK;
         }
         LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
@@ -1511,6 +1537,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed = true;
+        h->tier_timed = false;
         return COPRA_OK;
     }
     if (P.initial_state) {
@@ -1523,6 +1550,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         }
         HIP_TRY(hipEventRecord(h->ev1, s));
         h->timed = true;
+        h->tier_timed = false;
         return COPRA_OK;
     }
     if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && !jit_launch && !h->packed, P));
@@ -1543,8 +1571,9 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
                 h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
         }
-        if (ext_timed)
-            hipExtLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, h->ev0, h->ev1, 0, P);
+        if (ext_timed) // (start | end of the first launch; with a second launch the solve ends with THAT kernel's packet)
+            hipExtLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, h->ev0,
+                h->hp.two_tier ? h->evm : h->ev1, 0, P);
         else
             hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
@@ -1556,10 +1585,14 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P2.from_list = 1;
         const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
         LDS_OPT_IN(select_tier2_kernel(P2), h->hp.lds_full_bytes);
-        hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+        if (ext_timed)
+            hipExtLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, nullptr, h->ev1, 0, P2);
+        else
+            hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
         HIP_TRY(hipGetLastError());
     }
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev1, s));
+    h->tier_timed = ext_timed && h->hp.two_tier;
     h->timed = true;
     return COPRA_OK;
 }
@@ -1758,6 +1791,18 @@ copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds)
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *seconds = (double)ms * 1e-3;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* seconds)
+{
+    if (!h || !seconds) return fail(COPRA_ERR_ARG, "copra_batch_last_first_tier_seconds: null argument");
+    if (!h->timed) return fail(COPRA_ERR_RUNTIME, "copra_batch_last_first_tier_seconds: no solve has been launched");
+    if (!h->tier_timed) return copra_batch_last_solve_seconds(h, seconds);
+    HIP_TRY(hipEventSynchronize(h->evm));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->evm));
     *seconds = (double)ms * 1e-3;
     return COPRA_OK;
 }

@@ -117,7 +117,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
                 cw[t][r] = tab[kWave * (2 + tt * RP + r) + lane];
-                pr[t][r] = pref[r < rc ? r : rc - 1]; // (rows past the term's have zero coefficients; a cost that is not there reads
+                pr[t][r] = pref[r < rc ? r : (rc > 0 ? rc - 1 : 0)]; // (rows past the term's have zero coefficients; a cost that is not there reads
                                                       //  cost 0's -- every load unconditional: no branches in this prologue, whose
                                                       //  loads are all in flight together -- and is left out of the sum below)
             }

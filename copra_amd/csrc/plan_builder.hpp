@@ -333,6 +333,7 @@ inline int build_ric_tables(HostPlan& hp, int rp)
 inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
 {
     if (!cur.tri) return false;
+    if (std::getenv("COPRA_NO_LADDER")) return false; // (tests: the fall-back that follows an exhausted ladder, reachable at once)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const int rows = rp > P.rmax ? rp : P.rmax;
     const int kcur = (160 * 1024) / (cur.total * (int)sizeof(double));

@@ -262,11 +262,14 @@ copra_status_t copra_batch_layout_info(const copra_batch_t* h, int* lds_bytes, i
     int* two_tier);
 
 /* ---- timing contract of LMPC::solveTime()/solveAndBuildTime() (src/LMPC.cpp:82-99, 108-116): device time of the
- *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch.  For the one-wave kernels the
- *      pair rides in the first launch's dispatch packet (its own start and end; the second launch, which only sees the
- *      instances whose active set outgrew the first one's layout, is not inside it); COPRA_RECORDED_EVENTS=1 brackets the
- *      whole solve with recorded events instead. ---- */
+ *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch, EVERY launch of the solve (the
+ *      second launch, which only sees the instances whose active set outgrew the first one's layout, included).  For the
+ *      one-wave kernels the events ride in the dispatch packets of the launches themselves; COPRA_RECORDED_EVENTS=1 brackets
+ *      the solve with recorded events instead. ---- */
 copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds);
+/* ---- the first launch of that solve alone (no reference counterpart: the figure a kernel profile -- rocprofv3 -- of the
+ *      dominant kernel is compared with); equals copra_batch_last_solve_seconds where the solve is not timed per launch. ---- */
+copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* seconds);
 
 /* ---- device-side split of that time: per-instance shader-clock cycles of the 7 phases of the fused kernel
  *      (preview, costs, norms, cholesky, inverse+x0, active set, result stores) + total; 8 values per instance.

@@ -146,6 +146,23 @@ def test_riccati_factor_tier_selection_and_parity(emu, oracle):
     assert oracle.lmpc_solve(wl["A"][0], wl["B"][0], wl["d"][0], wl["x0"][0], wl["N"], bad, wl["cstrs"])["status"] == 2
 
 
+def test_riccati_factor_tier_without_any_cost(emu, oracle):
+    """round-2 advisor finding: an LMPC with an EMPTY cost list (valid in the reference: Q = 1e-6 I, src/LMPC.cpp:228-230) is
+    eligible for the Riccati-factor tier, whose branch-free prologue then evaluates the absent cost 0 -- the reference index
+    must stay inside the parameter blob.  U = argmin 1e-6/2 |U|^2 under the bounds: zero where the velocity rows allow it"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(6, v_max=0.25, u_max=1.2, seed=9)
+    x0 = wl["x0"].copy()
+    x0[:, 3:] = 0.3  # above the velocity bound... 
+    x0[:3, 3:] = 0.2  # ... for the last three instances only (quirk Q5: those are infeasible at step 0)
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], x0, wl["N"], [], wl["cstrs"])
+    assert re["riccati_factor"]
+    ro = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], x0, wl["N"], [], wl["cstrs"])
+    assert (re["status"] == ro["status"]).all() and (ro["status"][:3] == 0).all()
+    ok = ro["status"] == 0
+    assert _rel(re["control"][ok], ro["control"][ok]) <= RTOL and (re["iter"][ok] == ro["iter"][ok]).all()
+
+
 def test_riccati_factor_tier_compact_variant_with_control_rows(emu, oracle):
     """compact variant of the Riccati-factor tier (every state term of a row is one component of one state: the blocks G are
     dead after the row norms, the normal of a state row enters w = R^-T n as a unit injection into the recursion, the

@@ -1,7 +1,9 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 
 Tolerance: BASELINE.json north_star -- controls / trajectories within 1e-6 relative of the CPU QuadProgDense path.
-We assert  max |u - u_ref| / (1 + |u_ref|) <= 1e-6  (and the same for the trajectory) plus identical status codes.
+We assert  max_i |u_i - u_ref,i| / max(|u_ref,i|, ABS_FLOOR) <= 1e-6  (and the same for the trajectory) plus identical
+status codes: the true relative error of every entry larger than ABS_FLOOR = 1e-3 in magnitude; entries below it (controls
+and states that vanish at the optimum) are held to the ABSOLUTE error 1e-3 * 1e-6 = 1e-9.
 """
 import os
 
@@ -13,8 +15,19 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6
 
 
-def _rel(a, b):
-    return np.nanmax(np.abs(a - b) / (1.0 + np.abs(b)))
+ABS_FLOOR = 1e-3
+
+
+def _rel(a, b, floor=ABS_FLOOR):
+    """entry-wise relative error with an absolute floor: max_i |a_i - b_i| / max(|b_i|, floor)"""
+    return np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+def _rel_vec(a, b, floor=ABS_FLOOR):
+    """norm-wise relative error, max_i |a_i - b_i| / max(max_i |b_i|, floor) -- for the comparisons whose error is set by the
+    conditioning of the whole problem rather than entry by entry (config 5 at R = 1e-6 I: cond 2e12, where the CPU path is itself
+    1e-5 of the solution's scale away from the certified optimum)"""
+    return np.nanmax(np.abs(a - b)) / max(np.nanmax(np.abs(b)), floor)
 
 
 def _solve_gpu(wl, batch):
@@ -60,8 +73,9 @@ def test_config3_com_preview_batch2048(oracle, vmax, umax):
     from copra_amd import workloads
     wl = workloads.com_preview(2048, v_max=vmax, u_max=umax)
     eng, res, ref = _check(wl, 2048, oracle)
-    # same active-set path as the scalar restatement on well-separated problems
-    assert (res["iter"][:, 0] == ref["iter"][:, 0]).mean() > 0.95
+    # same active-set path as the scalar restatement: identical iteration counts (additions, drops) on every solved instance
+    ok = ref["status"] == 0
+    assert (res["iter"][ok] == ref["iter"][ok]).all()
 
 
 def test_condensed_qp_matches_reference_build(oracle):
@@ -81,14 +95,22 @@ def test_condensed_qp_matches_reference_build(oracle):
         assert (got["lb"] == qp["lb"]).all() and (got["ub"] == qp["ub"]).all()
 
 
-def test_headline_full_size_properties():
-    """BASELINE config 3 at full size (65536): size-independent properties instead of a 65536-instance oracle run:
-    every instance solved, bounds respected to the reference's own slack (TestLMPC.cpp:82-83: +1e-6), trajectory is
-    the rollout of the returned controls, and a sampled subset matches the oracle."""
+def test_headline_full_size_properties(oracle):
+    """BASELINE config 3 at full size (65536): size-independent properties -- every instance solved, bounds respected to the
+    reference's own slack (TestLMPC.cpp:82-83: +1e-6), trajectory is the rollout of the returned controls -- AND the oracle on
+    a stratified sample: every instance that needed four or more active-set iterations plus an evenly spaced 4096 of the
+    rest; U, X, status and both iteration counters."""
     from copra_amd import workloads
     batch = 65536
     wl = workloads.com_preview(batch)
     eng, res = _solve_gpu(wl, batch)
+    pick = np.union1d(np.nonzero(res["iter"][:, 0] >= 4)[0], np.linspace(0, batch - 1, 4096).astype(int))
+    assert len(pick) >= 2048 and (res["iter"][pick, 0] >= 4).sum() > 100
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], wl["cstrs"],
+                                  nthreads=8)
+    assert (res["status"][pick] == ref["status"]).all() and (res["iter"][pick] == ref["iter"]).all()
+    assert _rel(res["control"][pick], ref["control"]) <= RTOL
+    assert _rel(res["trajectory"][pick], ref["trajectory"]) <= RTOL
     assert (res["status"] == 0).all()
     u = res["control"].reshape(batch, wl["N"], 3)
     x = res["trajectory"].reshape(batch, wl["N"] + 1, 6)
@@ -484,7 +506,8 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
     the TRUTH: the default solver (stage-wise Riccati interior-point kernel) must be within 1e-6 of it -- i.e. nearer
     the optimum than the CPU path is -- and within 1e-4 of the oracle; the condensed Goldfarb-Idnani kernel
     ("quadprog_dense": same arithmetic family as the oracle, same iteration counts) is held to 1e-4 of both.
-    R = 1e-2 I is the well-conditioned twin where everything meets 1e-6 against the oracle."""
+    R = 1e-2 I is the well-conditioned twin where everything meets 1e-6 against the oracle.
+    Errors are norm-wise here (_rel_vec: the conditioning of the whole problem sets them, not the size of the single entry)."""
     from copra_amd import BatchLMPC, workloads
     b = 6
     wl = workloads.long_horizon_initial_state(b, R_diag=r_diag)
@@ -503,9 +526,9 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
                                initial_state=io)
         assert res["status"][k] == ro["status"] == 0
         assert (not same_iters) or tuple(res["iter"][k]) == tuple(ro["iter"])
-        assert _rel(res["control"][k], ro["control"]) <= tol
-        assert _rel(res["trajectory"][k], ro["trajectory"]) <= tol
-        assert _rel(x0o[k], ro["x0_opt"]) <= 1e-6
+        assert _rel_vec(res["control"][k], ro["control"]) <= tol
+        assert _rel_vec(res["trajectory"][k], ro["trajectory"]) <= tol
+        assert _rel_vec(x0o[k], ro["x0_opt"]) <= 1e-6
         tr = res["trajectory"][k].reshape(wl["N"] + 1, 12)
         assert np.abs(tr[-1, 6:]).max() <= 1e-8  # the full-size terminal equality
         assert np.abs(res["control"][k]).max() <= 2.0 + 1e-6
@@ -516,8 +539,8 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
         for k in picks:
             ut, xt = G.TRUTH5["control_%d" % k], G.TRUTH5["trajectory_%d" % k]
             ttol = 1e-4 if same_iters else 1e-6
-            assert _rel(res["control"][k], ut) <= ttol
-            assert _rel(res["trajectory"][k], xt) <= ttol
+            assert _rel_vec(res["control"][k], ut) <= ttol
+            assert _rel_vec(res["trajectory"][k], xt) <= ttol
             assert np.abs(x0o[k] - G.TRUTH5["x0_opt_%d" % k]).max() <= 1e-9
     qp = eng.dump_qp(2)
     io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][2], x0ub=ist["x0ub"][2])
@@ -527,6 +550,48 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
     assert np.abs(qp["c"] - qo["c"]).max() <= 1e-9 * max(1.0, np.abs(qo["c"]).max())
     for key in ("Aeq", "Aineq", "beq", "bineq"):
         assert np.abs(qp[key] - qo[key]).max() <= 1e-10 * max(1.0, np.abs(qo[key]).max())
+
+
+def test_config5_full_batch_default_solver():
+    """BASELINE config 5 at its FULL batch (16384) on the default solver: size-independent properties of every instance --
+    solved (status 0), the full-size terminal equality (velocity of x_N = 0) to 1e-8, control bounds and the mixed rows
+    v_k + T u_k <= v_max to the reference's own slack (TestLMPC.cpp:82-83: +1e-6), x0* inside its bounds (TestLMPC_InitialState
+    .cpp:242-252: +-1e-6), the trajectory the rollout of (x0*, U) -- and the six instances of the 60-digit certified truth set
+    (tests/golden/config5_truth.npz), embedded at the head of the batch, within 1e-6 of the truth."""
+    import test_golden as G
+    from copra_amd import BatchLMPC, workloads
+    b = 16384
+    wl = workloads.long_horizon_initial_state(b)
+    ist = wl["initial_state"]
+    twl, picks = G.config5_truth_cases()
+    nt = twl["x0"].shape[0]
+    tist = twl["initial_state"]
+    wl["x0"][:nt] = twl["x0"]
+    ist["x0lb"][:nt], ist["x0ub"][:nt] = tist["x0lb"], tist["x0ub"]
+    assert np.array_equal(ist["R"], tist["R"]) and np.array_equal(wl["A"][0], twl["A"][0])
+    eng = BatchLMPC(12, 6, wl["N"], b, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
+    eng.solve()
+    res = eng.results()
+    x0o = eng.initial_state()
+    assert eng.solver() == "riccati_ipm"
+    assert (res["status"] == 0).all()
+    N, T = wl["N"], 0.05
+    u = res["control"].reshape(b, N, 6)
+    x = res["trajectory"].reshape(b, N + 1, 12)
+    assert np.abs(x[:, -1, 6:]).max() <= 1e-8
+    assert np.abs(u).max() <= 2.0 + 1e-6
+    assert (x[:, :-1, 6:] + T * u).max() <= 0.5 + 1e-6
+    assert (x0o >= ist["x0lb"] - 1e-6).all() and (x0o <= ist["x0ub"] + 1e-6).all()
+    assert np.abs(x[:, 0] - x0o).max() <= 1e-12
+    xr = np.einsum("ij,bkj->bki", wl["A"][0], x[:, :-1]) + np.einsum("ij,bkj->bki", wl["B"][0], u)
+    assert np.abs(xr - x[:, 1:]).max() <= 1e-9
+    for k in picks:
+        assert _rel_vec(res["control"][k], G.TRUTH5["control_%d" % k]) <= 1e-6
+        assert _rel_vec(res["trajectory"][k], G.TRUTH5["trajectory_%d" % k]) <= 1e-6
+        assert np.abs(x0o[k] - G.TRUTH5["x0_opt_%d" % k]).max() <= 1e-9
+    eng.close()
 
 
 @pytest.mark.parametrize("solver", SOLVERS)
@@ -1094,6 +1159,33 @@ def test_shared_model_both_first_tiers(oracle, monkeypatch):
     good = (r1["status"] == 0) & (r2["status"] == 0)
     assert (r1["status"] == r2["status"]).all() and np.abs(r1["control"][good] - r2["control"][good]).max() <= 1e-9
     assert (r1["iter"][:, 0] > 1).mean() > 0.3
+    eng.close()
+
+
+def test_shared_model_leaves_riccati_tier_when_ladder_is_exhausted(oracle, monkeypatch):
+    """round-2 advisor finding: a shared-model controller whose layout ladder has nothing roomier left falls back to the
+    square layouts -- and must then leave the Riccati-factor tier's shared mode as well (its kernel would read per-instance A / B / d
+    that a shared-model controller never set).  COPRA_NO_LADDER makes the ladder empty, the tight workload overflows five
+    columns on far more than one instance in 32: the second and third solves run lmpc_shared.hpp; all three agree with the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    monkeypatch.setenv("COPRA_NO_LADDER", "1")
+    b = 1024
+    wl = workloads.com_preview(b, v_max=0.25, u_max=1.2, seed=17)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(wl["x0"])
+    ref = oracle.lmpc_solve_batch(np.repeat(wl["A"][:1], 256, 0), np.repeat(wl["B"][:1], 256, 0), np.repeat(wl["d"][:1], 256, 0),
+                                  wl["x0"][:256], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    assert (ref["iter"][:, 0] > 6).mean() > 1.0 / 32
+    layouts = []
+    for _ in range(3):
+        eng.solve()
+        r = eng.results()
+        layouts.append(eng.layout_info()["lds_bytes"])
+        assert (r["status"][:256] == ref["status"]).all() and (r["iter"][:256][ok] == ref["iter"][ok]).all()
+        assert _rel(r["control"][:256][ok], ref["control"][ok]) <= RTOL and _rel(r["trajectory"][:256][ok], ref["trajectory"][ok]) <= RTOL
+    assert layouts[-1] > layouts[0]  # the fall-back layout was taken
     eng.close()
 
 
