@@ -9,6 +9,7 @@
 #include "lmpc_fused_ric.hpp"
 #include "lmpc_large.hpp"
 #include "lmpc_riccati.hpp"
+#include "lmpc_riccati_mfma.hpp"
 #include "lmpc_shared.hpp"
 #include "packed_launch.hpp"
 #include "plan_builder.hpp"
@@ -233,6 +234,12 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_riccati_kernel(const FusedPl
 {
     lmpc_riccati_body<NXT, NUT>(P, S);
 }
+// The same method with the iterate resident on the CU and the stage algebra on the matrix cores (lmpc_riccati_mfma.hpp): what
+// BASELINE config 5 runs on.  512 VGPRs (the per-row state of the instance lives in registers), <= 80 KB of LDS: two per CU.
+__global__ __launch_bounds__(64, 1) void copra_lmpc_riccati_mfma_kernel(const FusedPlan P, const StagePlan S)
+{
+    lmpc_riccati_mfma_body(P, S);
+}
 typedef void (*riccati_kernel_t)(const FusedPlan, const StagePlan);
 // shapes with their own instantiation: BASELINE config 5 (12, 6) and the reference's test fixtures (2, 1)
 static riccati_kernel_t select_riccati_kernel(int nx, int nu)
@@ -396,6 +403,8 @@ struct copra_batch {
     // stage-wise Riccati interior-point path (copra_batch_select_solver; lmpc_riccati.hpp)
     int solver = COPRA_SOLVER_DEFAULT;
     HostStagePlan hs;
+    bool ric_fast = false; // the LDS-resident kernel (lmpc_riccati_mfma.hpp) runs it
+    bool ric_refs = false; // ... decided for this state of the per-instance cost references
     bool ric_built = false; // hs describes this controller (eligible or not) ...
     bool ric_all_bounds = false; // ... with bound rows for every control
     std::vector<void*> ric_dev; // device copies of its tables
@@ -561,7 +570,10 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
 static copra_status_t prepare_riccati(copra_batch* h)
 {
     const bool all_bounds = h->d_lb_inst != nullptr;
-    if (h->ric_built && h->ric_all_bounds == all_bounds) return COPRA_OK;
+    bool refs = false; // per-instance cost references: q_k differs per instance, which only the streaming kernel evaluates
+    for (int t = 0; t < kMaxCosts; ++t) refs = refs || h->cost_p[t] != nullptr;
+    if (h->ric_built && h->ric_all_bounds == all_bounds && h->ric_refs == refs) return COPRA_OK;
+    h->ric_refs = refs;
     for (void* q : h->ric_dev) (void)hipFree(q);
     h->ric_dev.clear();
     (void)hipFree(h->d_ric_ws);
@@ -612,9 +624,18 @@ static copra_status_t prepare_riccati(copra_batch* h)
     sp.cls_rptr = upi(hs.cls_rptr), sp.cls_rcol = upi(hs.cls_rcol), sp.cls_gptr = upi(hs.cls_gptr), sp.cls_grow = upi(hs.cls_grow);
     sp.cls_eptr = upi(hs.cls_eptr), sp.cls_erow = upi(hs.cls_erow);
     sp.cls_rval = upi(hs.cls_rval), sp.cls_gval = upi(hs.cls_gval), sp.cls_eval = upi(hs.cls_eval);
+    h->ric_fast = sp.fast_ok && !refs && !std::getenv("COPRA_NO_RIC_FAST");
+    if (h->ric_fast) { // fixed-width tables of the LDS-resident kernel
+        sp.f_rinfo = upi(hs.f_rinfo), sp.f_rcomp = upi(hs.f_rcomp), sp.f_rval = upd(hs.f_rval);
+        sp.f_gcnt = upi(hs.f_gcnt), sp.f_grow = upi(hs.f_grow), sp.f_gval = upd(hs.f_gval);
+        sp.f_wcol = upi(hs.f_wcol), sp.f_wval = upd(hs.f_wval), sp.f_Wp = upi(hs.f_Wp);
+        sp.f_tptr = upi(hs.f_tptr), sp.f_tent = upi(hs.f_tent), sp.f_trow = upi(hs.f_trow), sp.f_tval = upd(hs.f_tval);
+        sp.f_qcnt = upi(hs.f_qcnt), sp.f_qoff = upi(hs.f_qoff), sp.f_qa = upd(hs.f_qa), sp.f_q = upd(hs.f_q);
+    }
     // persistent grid: as many one-wave workgroups as the device keeps resident
-    const size_t lds_bytes = (size_t)sp.lds_doubles * sizeof(double);
-    const void* ric_fn = reinterpret_cast<const void*>(select_riccati_kernel(sp.nx, sp.nu));
+    const size_t lds_bytes = (size_t)(h->ric_fast ? sp.fast_lds_doubles : sp.lds_doubles) * sizeof(double);
+    const void* ric_fn = h->ric_fast ? reinterpret_cast<const void*>(copra_lmpc_riccati_mfma_kernel)
+                                     : reinterpret_cast<const void*>(select_riccati_kernel(sp.nx, sp.nu));
     if (e == hipSuccess) e = lds_opt_in(ric_fn, lds_bytes);
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
@@ -630,13 +651,15 @@ static copra_status_t prepare_riccati(copra_batch* h)
     long long g = (long long)cus * per_cu;
     const int batch = h->hp.plan.batch > 0 ? h->hp.plan.batch : 1;
     h->ric_grid = (int)(g < batch ? g : batch);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (size_t)sp.ws_total * sizeof(double));
+    if (e == hipSuccess && !h->ric_fast) // (the LDS-resident kernel has no workspace in HBM)
+        e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (size_t)sp.ws_total * sizeof(double));
     sp.ws = h->d_ric_ws;
     if (e == hipSuccess && !h->d_ric_next) e = hipMalloc((void**)&h->d_ric_next, sizeof(int));
     sp.next_instance = h->d_ric_next;
     if (std::getenv("COPRA_DEBUG"))
-        fprintf(stderr, "[copra] riccati path: %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n", sp.ncls,
-            sp.m, h->ric_grid, per_cu, lds_bytes, sp.ws_total * 8LL);
+        fprintf(stderr, "[copra] riccati path (%s): %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n",
+            h->ric_fast ? "LDS-resident, MFMA" : hs.fast_why.c_str(), sp.ncls, sp.m, h->ric_grid, per_cu, lds_bytes,
+            h->ric_fast ? 0LL : sp.ws_total * 8LL);
     if (e != hipSuccess) {
         for (void* q : h->ric_dev) (void)hipFree(q);
         h->ric_dev.clear();
@@ -1513,10 +1536,10 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     if (h->hp.large) {
         if (use_riccati(h)) {
             // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
-            const size_t ric_lds = (size_t)h->hs.sp.lds_doubles * sizeof(double);
+            const size_t ric_lds = (size_t)(h->ric_fast ? h->hs.sp.fast_lds_doubles : h->hs.sp.lds_doubles) * sizeof(double);
             HIP_TRY(begin_overflow_queue(h, s, false, P));
             HIP_TRY(hipMemsetAsync(h->d_ric_next, 0, sizeof(int), s));
-            const riccati_kernel_t ric_fn = select_riccati_kernel(P.nx, P.nu);
+            const riccati_kernel_t ric_fn = h->ric_fast ? copra_lmpc_riccati_mfma_kernel : select_riccati_kernel(P.nx, P.nu);
             LDS_OPT_IN(ric_fn, ric_lds);
             hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
             HIP_TRY(hipGetLastError());

@@ -38,6 +38,12 @@ constexpr int kRicMaxEq = 32; // equality rows (proximal multiplier iteration)
 constexpr int kRicMaxStageRows = 192; // rows of one stage (LDS staging of their weights)
 constexpr int kRicMaxNnz = 512; // non-zero coefficients of the rows of one stage ...
 constexpr int kRicMaxNnzE = 1024; // ... and non-zero products a_i a_j over all its rows (LDS tables of the kernel)
+// LDS-resident kernel (lmpc_riccati_mfma.hpp): blocks of the v_mfma_f64_4x4x4 products and the widths of its fixed tables
+constexpr int kRfNX = 12, kRfNU = 6, kRfNZ = 18; // padded xDim / uDim: three blocks of four states, two blocks of three controls
+constexpr int kRfMR = 15; // 64-lane registers of per-row state: at most 960 rows
+constexpr int kRfZR = 15; // 64-lane registers of the stage vectors: (N + 1) 18 <= 960
+constexpr int kRfGTerms = 4, kRfWTerms = 4, kRfTTerms = 4, kRfMaxTouched = 64;
+constexpr int kRfKStride = 100; // stage record: Ka 3 x 12 | Kb 3 x 12 | Kba 3 x 3 | -Mbb^-1 3 x 3 | -M'aa^-1 3 x 3
 
 // where the right-hand side of a constraint row comes from (per instance when the caller set per-instance data)
 enum { kSrcRowF = 0, kSrcUb = 1, kSrcNegLb = 2, kSrcX0Ub = 3, kSrcNegX0Lb = 4 };
@@ -89,6 +95,28 @@ struct StagePlan {
     int lds_doubles;
     int max_iter;
     double delta; // proximal weight of the equality rows
+    // ---- LDS-resident kernel (lmpc_riccati_mfma.hpp): fixed-width views over the PADDED stage vector z_k = (x: 12 | u: 6),
+    //      entry (k, i) at k * kRfNZ + i; usable when fast_ok (else the streaming kernel of lmpc_riccati.hpp runs) ----
+    int fast_ok;
+    int fast_lds_doubles;
+    const int* f_rinfo; // [m] stage | template << 8 (template: index into the r_* arrays)
+    const int* f_rcomp; // [templates][2] padded components of the (at most two) coefficients of a row template, -1: none
+    const double* f_rval; // [templates][2]
+    const int* f_gcnt; // per (class, padded component): rows of the stage that touch it, at most kRfGTerms ...
+    const int* f_grow; // [ncls][kRfNZ][kRfGTerms] ... as row offsets inside the stage
+    const double* f_gval; // [ncls][kRfNZ][kRfGTerms]
+    const int* f_wcol; // [ncls][kRfNZ][kRfWTerms] non-zeros of row i of the padded W (column, -1: none)
+    const double* f_wval;
+    const int* f_Wp; // [ncls] offset in `blob` of the padded dense W (18 x 18 column-major, unit diagonal on padded controls)
+    const int* f_tptr; // [ncls + 1] touched entries of H = W + A' D A
+    const int* f_tent; // entry i + kRfNZ j (padded)
+    const int* f_trow; // [touched][kRfTTerms] row offsets inside the stage (-1: none)
+    const double* f_tval; // [touched][kRfTTerms] a_i a_j
+    const int* f_qcnt; // [ncls] cost rows (for q_k) -- padded coefficient vectors:
+    const int* f_qoff; // [ncls] first cost row of the class in cr_*
+    const double* f_qa; // [cost rows][kRfNZ] padded coefficient vectors a
+    const double* f_q; // [(N + 1) kRfNZ] q_k = - sum_rows w p a with the controller-wide references p (per-instance references: streaming kernel)
+    int fast_ntmpl; // row templates (their coefficient pairs sit in LDS)
 };
 
 struct HostStagePlan {
@@ -103,6 +131,10 @@ struct HostStagePlan {
     std::vector<double> blob;
     std::vector<int> iblob, cls_rptr, cls_rcol, cls_gptr, cls_grow, cls_eptr, cls_erow, cls_rval, cls_gval, cls_eval;
     bool all_bounds = false; // bound rows for every control (per-instance bounds may make any of them finite)
+    // LDS-resident kernel
+    std::string fast_why; // reason when not fast_ok
+    std::vector<int> f_rinfo, f_rcomp, f_gcnt, f_grow, f_wcol, f_Wp, f_tptr, f_tent, f_trow, f_qcnt, f_qoff;
+    std::vector<double> f_rval, f_gval, f_wval, f_tval, f_qa, f_q;
 };
 
 namespace stage_detail {
@@ -431,6 +463,112 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
             + align2((ints + 1) / 2) + 2;
     } // == carve_riccati
     out.eligible = true;
+    // ---- fixed-width tables of the LDS-resident kernel ----
+    sp.fast_ok = 0;
+    auto slow = [&](const char* why) { out.fast_why = why; };
+    if (nx > kRfNX || nu > kRfNU) return slow("xDim > 12 or uDim > 6");
+    if (sp.m > 64 * kRfMR) return slow("more than 960 constraint rows");
+    if ((N + 1) * kRfNZ > 64 * kRfZR) return slow("more than 52 steps");
+    auto pad = [&](int j) { return j < nx ? j : kRfNX + (j - nx); };
+    const int ntmpl = (int)out.r_kind.size();
+    out.f_rcomp.assign((size_t)ntmpl * 2, -1);
+    out.f_rval.assign((size_t)ntmpl * 2, 0.0);
+    out.f_gcnt.assign((size_t)ncls * kRfNZ, 0);
+    out.f_grow.assign((size_t)ncls * kRfNZ * kRfGTerms, 0);
+    out.f_gval.assign((size_t)ncls * kRfNZ * kRfGTerms, 0.0);
+    out.f_wcol.assign((size_t)ncls * kRfNZ * kRfWTerms, -1);
+    out.f_wval.assign((size_t)ncls * kRfNZ * kRfWTerms, 0.0);
+    out.f_tptr.assign(1, 0);
+    for (int c = 0; c < ncls; ++c) {
+        const StageDesc& Sd = st[(size_t)first_stage[(size_t)c]];
+        const int nr = (int)Sd.rows.size();
+        std::vector<std::vector<std::pair<int, double>>> coef((size_t)nr); // padded (component, value) of every row
+        for (int r = 0; r < nr; ++r) {
+            const Row& R = Sd.rows[(size_t)r];
+            for (int j = 0; j < nz; ++j) {
+                const double v = R.kind == 0 ? R.a[(size_t)j] : (j == R.comp ? R.sign : 0.0);
+                if (v != 0.0) coef[(size_t)r].push_back({ pad(j), v });
+            }
+            if (coef[(size_t)r].size() > 2) return slow("a constraint row with more than two coefficients");
+            const int t = out.cls_row0[(size_t)c] + r;
+            for (size_t q = 0; q < coef[(size_t)r].size(); ++q) {
+                out.f_rcomp[(size_t)t * 2 + q] = coef[(size_t)r][q].first;
+                out.f_rval[(size_t)t * 2 + q] = coef[(size_t)r][q].second;
+                int& cnt = out.f_gcnt[(size_t)c * kRfNZ + coef[(size_t)r][q].first];
+                if (cnt >= kRfGTerms) return slow("a component with more than four constraint rows in one stage");
+                const size_t at = ((size_t)c * kRfNZ + coef[(size_t)r][q].first) * kRfGTerms + cnt;
+                out.f_grow[at] = r;
+                out.f_gval[at] = coef[(size_t)r][q].second;
+                cnt += 1;
+            }
+        }
+        // padded dense W (the kernel's copy of the stage Hessian starts from it) and its non-zeros row by row
+        std::vector<double> Wp((size_t)kRfNZ * kRfNZ, 0.0);
+        const double* Wc = &out.blob[(size_t)out.cls_W[(size_t)c]];
+        for (int j = 0; j < nz; ++j)
+            for (int i = 0; i < nz; ++i) Wp[(size_t)pad(j) * kRfNZ + pad(i)] = Wc[(size_t)j * nz + i];
+        for (int j = nu; j < kRfNU; ++j) Wp[(size_t)(kRfNX + j) * kRfNZ + kRfNX + j] = 1.0; // (controls that do not exist stay zero)
+        for (int i = 0; i < kRfNZ; ++i) {
+            int cnt = 0;
+            for (int j = 0; j < kRfNZ; ++j) {
+                const double v = Wp[(size_t)j * kRfNZ + i];
+                if (v == 0.0 || (i >= kRfNX + nu && i == j)) continue; // (the padded unit diagonal multiplies zeros)
+                if (cnt >= kRfWTerms) return slow("a stage cost with more than four entries per row");
+                out.f_wcol[((size_t)c * kRfNZ + i) * kRfWTerms + cnt] = j;
+                out.f_wval[((size_t)c * kRfNZ + i) * kRfWTerms + cnt] = v;
+                cnt += 1;
+            }
+        }
+        out.f_Wp.push_back(push_blob(Wp));
+        // entries of H = W + sum_r D_r a_r a_r' that the rows touch
+        std::vector<std::vector<std::pair<int, double>>> ent((size_t)kRfNZ * kRfNZ);
+        for (int r = 0; r < nr; ++r)
+            for (auto& a : coef[(size_t)r])
+                for (auto& b : coef[(size_t)r]) ent[(size_t)a.first + (size_t)kRfNZ * b.first].push_back({ r, a.second * b.second });
+        int touched = 0;
+        for (int e = 0; e < kRfNZ * kRfNZ; ++e) {
+            if (ent[(size_t)e].empty()) continue;
+            if ((int)ent[(size_t)e].size() > kRfTTerms) return slow("an entry of the stage Hessian with more than four row products");
+            out.f_tent.push_back(e);
+            for (int q = 0; q < kRfTTerms; ++q) {
+                const bool on = q < (int)ent[(size_t)e].size();
+                out.f_trow.push_back(on ? ent[(size_t)e][(size_t)q].first : -1);
+                out.f_tval.push_back(on ? ent[(size_t)e][(size_t)q].second : 0.0);
+            }
+            touched += 1;
+        }
+        if (touched > kRfMaxTouched) return slow("the rows of one stage touch more than 64 entries of the stage Hessian");
+        out.f_tptr.push_back((int)out.f_tent.size());
+        // cost rows with padded coefficient vectors
+        out.f_qoff.push_back(out.cls_crow0[(size_t)c]);
+        out.f_qcnt.push_back(out.cls_crow0[(size_t)c + 1] - out.cls_crow0[(size_t)c]);
+    }
+    out.f_qa.assign(out.cr_aoff.size() * (size_t)kRfNZ, 0.0);
+    for (size_t t = 0; t < out.cr_aoff.size(); ++t)
+        for (int j = 0; j < nz; ++j) out.f_qa[t * kRfNZ + (size_t)pad(j)] = out.blob[(size_t)out.cr_aoff[t] + j];
+    out.f_rinfo.assign((size_t)(sp.m > 0 ? sp.m : 1), 0);
+    for (int k = 0; k <= N; ++k) {
+        const int c = out.cls_of_stage[(size_t)k];
+        for (int r = 0; r < (int)st[(size_t)k].rows.size(); ++r)
+            out.f_rinfo[(size_t)out.stage_row0[(size_t)k] + r] = k | ((out.cls_row0[(size_t)c] + r) << 8);
+    }
+    if (N > 255) return slow("more than 255 steps");
+    out.f_q.assign((size_t)(N + 1) * kRfNZ, 0.0);
+    for (int k = 0; k <= N; ++k) {
+        const int c = out.cls_of_stage[(size_t)k];
+        for (int t = out.cls_crow0[(size_t)c]; t < out.cls_crow0[(size_t)c + 1]; ++t) {
+            const int ct = out.cr_cost[(size_t)t];
+            const double pv = prm[(size_t)P.cost[ct].offP + out.cr_pidx[(size_t)t]];
+            for (int i = 0; i < kRfNZ; ++i) out.f_q[(size_t)k * kRfNZ + i] -= out.cr_w[(size_t)t] * pv * out.f_qa[(size_t)t * kRfNZ + i];
+        }
+    }
+    sp.fast_ntmpl = ntmpl > 0 ? ntmpl : 1;
+    if (ntmpl > 128) return slow("more than 128 row templates");
+    // LDS of one instance (doubles): X | Y | F (64 kRfMR each) | stage records | kv | H | P | Rb | Ra | H0 | G0 | A B | d | Gauss-Jordan
+    sp.fast_lds_doubles = 3 * 64 * kRfMR + N * kRfKStride + N * 8 + kRfNZ * kRfNZ + kRfNX * kRfNX + 64 + 64 + kRfNX * kRfNX + 16
+        + kRfNX * kRfNZ + 16 + kRfNX * (kRfNX + 1) + 12 + 12 + 4 + 20 + 2 * sp.fast_ntmpl; // == carve_rf
+    if ((size_t)sp.fast_lds_doubles * sizeof(double) > 80 * 1024) return slow("LDS footprint above 80 KiB (two instances per CU)");
+    sp.fast_ok = 1;
 }
 
 inline void point_stage_plan_to_host(HostStagePlan& h)
@@ -458,6 +596,11 @@ inline void point_stage_plan_to_host(HostStagePlan& h)
     sp.cls_rptr = h.cls_rptr.data(), sp.cls_rcol = h.cls_rcol.data(), sp.cls_gptr = h.cls_gptr.data(), sp.cls_grow = h.cls_grow.data();
     sp.cls_eptr = h.cls_eptr.data(), sp.cls_erow = h.cls_erow.data();
     sp.cls_rval = h.cls_rval.data(), sp.cls_gval = h.cls_gval.data(), sp.cls_eval = h.cls_eval.data();
+    sp.f_rinfo = h.f_rinfo.data(), sp.f_rcomp = h.f_rcomp.data(), sp.f_rval = h.f_rval.data();
+    sp.f_gcnt = h.f_gcnt.data(), sp.f_grow = h.f_grow.data(), sp.f_gval = h.f_gval.data();
+    sp.f_wcol = h.f_wcol.data(), sp.f_wval = h.f_wval.data(), sp.f_Wp = h.f_Wp.data();
+    sp.f_tptr = h.f_tptr.data(), sp.f_tent = h.f_tent.data(), sp.f_trow = h.f_trow.data(), sp.f_tval = h.f_tval.data();
+    sp.f_qcnt = h.f_qcnt.data(), sp.f_qoff = h.f_qoff.data(), sp.f_qa = h.f_qa.data(), sp.f_q = h.f_q.data();
 }
 
 } // namespace copra_hip

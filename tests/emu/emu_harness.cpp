@@ -7,6 +7,7 @@
 #include "../../copra_amd/csrc/lmpc_fused_ric.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati.hpp"
+#include "../../copra_amd/csrc/lmpc_riccati_mfma.hpp"
 #include "../../copra_amd/csrc/lmpc_shared.hpp"
 #include "../../copra_amd/csrc/plan_builder.hpp"
 #include "../../copra_amd/csrc/qp_dense.hpp"
@@ -313,7 +314,17 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
     int next_instance = 0; // the work queue of the kernel
     hs.sp.next_instance = &next_instance;
     const StagePlan& S = hs.sp;
-    // same dispatch as the HIP launcher (select_riccati_kernel)
+    // same dispatch as the HIP launcher: the LDS-resident kernel (lmpc_riccati_mfma.hpp) where the plan fits it ...
+    if (not_converged) not_converged[1] = 0;
+    bool refs = false;
+    for (int k = 0; k < kMaxCosts; ++k) refs = refs || g_cost_p[k] != nullptr;
+    if (S.fast_ok && !refs && !std::getenv("COPRA_NO_RIC_FAST")) {
+        int rf = emu::run_wave([&]() { lmpc_riccati_mfma_body(P, S); }, (size_t)S.fast_lds_doubles * sizeof(double), 0, 1);
+        if (not_converged) not_converged[0] = ovf_count, not_converged[1] = 1;
+        return rf != 0 ? -100 : 0;
+    }
+    if (std::getenv("COPRA_EMU_DEBUG")) fprintf(stderr, "emu: streaming Riccati kernel (%s)\n", hs.fast_why.c_str());
+    // ... else the streaming one (select_riccati_kernel)
     int r = emu::run_wave(
         [&]() {
             if (S.nx == 12 && S.nu == 6)

@@ -143,7 +143,7 @@ def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_re
     tr = np.full((batch, nx * (N + 1)), np.nan)
     st = np.full(batch, -1, dtype=np.int32)
     it = np.zeros((batch, 2), dtype=np.int32)
-    nc = (C.c_int * 1)()
+    nc = (C.c_int * 2)()
     rc = lib().emu_lmpc_solve_riccati(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ab), p(Bb), p(db), p(xb), p(u),
                                       p(tr), st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)),
                                       isd, p(x0lb) if x0lb is not None else vp(), p(x0ub) if x0ub is not None else vp(),
@@ -152,7 +152,7 @@ def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_re
         return None
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
-    out = dict(control=u, trajectory=tr, status=st, iter=it, not_converged=nc[0])
+    out = dict(control=u, trajectory=tr, status=st, iter=it, not_converged=nc[0], lds_resident=bool(nc[1]))
     if x0o is not None:
         out["x0_opt"] = x0o
     return out
