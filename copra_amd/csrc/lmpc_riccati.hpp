@@ -498,9 +498,9 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 const int gi = gi0 + r;
                 const int fl = (int)Flag[gi];
                 double sv = 1.0, lv = 0.0;
-                if (fl == kRowIneq) {
-                    sv = fmax(F[gi] - row_dot(r, nd, L.zk), 1.0);
-                    lv = 1.0;
+                if (fl == kRowIneq) { // (centred start: stage_plan.hpp, s_floor / lam0)
+                    sv = fmax(F[gi] - row_dot(r, nd, L.zk), S.s_floor);
+                    lv = S.lam0 > 0.0 ? S.lam0 : -S.lam0 / sv;
                     n_ineq += 1;
                 }
                 Sv[gi] = sv;

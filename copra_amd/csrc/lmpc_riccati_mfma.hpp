@@ -37,8 +37,10 @@
 namespace copra_hip {
 
 struct RfLds {
-    double *X, *Y, *Cb, *KF, *KV, *Hb, *Pb, *Rb, *Ra, *H0, *G0, *AB, *dv, *GJ, *pv0, *dx0, *Zs, *gk, *TT;
+    double *X, *Y, *Cb, *KF, *Hb, *Pb, *Rb, *Ra, *H0, *G0, *AB, *dv, *GJ, *pv0, *dx0, *Zs, *gk, *TT;
 };
+
+constexpr int kRfHStride = kRfNZ * kRfNZ + 2; // one copy of the stage Hessian + a zero pad (what lanes without an entry read)
 
 COPRA_DEV RfLds carve_rf(double* lds, int N, int ntmpl)
 {
@@ -47,9 +49,8 @@ COPRA_DEV RfLds carve_rf(double* lds, int N, int ntmpl)
     L.X = p, p += 64 * kRfZR; // the iterate z = (x_k, u_k)_k, padded
     L.Y = p, p += 64 * kRfMR; // row weights D (backward factorisation) | the step dz (forward sweeps)
     L.Cb = p, p += 64 * kRfMR; // gradient coefficients c of the rows (g_k += A_k' c)
-    L.KF = p, p += N * kRfKStride;
-    L.KV = p, p += N * 8;
-    L.Hb = p, p += kRfNZ * kRfNZ;
+    L.KF = p, p += N * kRfKStride; // stage records
+    L.Hb = p, p += 2 * kRfHStride; // stage Hessian H = W + A' D A of the stage in flight | of the next one (being assembled)
     L.Pb = p, p += kRfNX * kRfNX;
     L.Rb = p, p += 64;
     L.Ra = p, p += 64;
@@ -60,8 +61,8 @@ COPRA_DEV RfLds carve_rf(double* lds, int N, int ntmpl)
     L.GJ = p, p += kRfNX * (kRfNX + 1);
     L.pv0 = p, p += 12;
     L.dx0 = p, p += 12;
-    L.Zs = p, p += 4;
-    L.gk = p, p += 20; // gradient of the stage in flight
+    L.Zs = p, p += 32; // 16 zeros (absent operands) | 16 doubles nobody reads (stores of lanes with nothing to store)
+    L.gk = p, p += 2 * 20; // gradient of the stage in flight | of the next one (18 entries + a zero pad each)
     L.TT = p, p += 2 * ntmpl; // the (at most two) coefficients of every row template
     return L; // (stage_plan.hpp: fast_lds_doubles)
 }
@@ -83,15 +84,16 @@ enum { kRfIneq = 0, kRfEq = 1, kRfOff = 2 };
 COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 {
     constexpr int NX = kRfNX, NZ = kRfNZ, MR = kRfMR, KS = kRfKStride;
-    constexpr int oKa = 0, oKb = 36, oKba = 72, oNb = 81, oNa = 90;
+    // stage record: K_a 3 x 12 | K_b 3 x 12 | K_ba 3 x 3 | -M_bb^-1 | -M'_aa^-1 | kv_a | kv_b | spare (dummy stores) | zero (absent operands)
+    constexpr int oKa = 0, oKb = 36, oKba = 72, oNb = 81, oNa = 90, oKva = 99, oKvb = 102, oSpare = 105, oZero = 106;
     const int lane = lane_id();
     const int nx = S.nx, nu = S.nu, N = S.N, m = S.m;
     const int NE = (N + 1) * NZ; // entries of the padded stage vectors
     const RfLds L = carve_rf(lds_base(), N, S.fast_ntmpl);
-    const int q4 = lane >> 4, hb = (lane >> 2) & 3, r4 = lane & 3; // lane = 16 q + 4 b + r
     const double delta = S.delta;
     const double BIGF = 1e299;
-    const bool qr3 = q4 < 3 && r4 < 3;
+    // class and first row of stage `lane` (N + 1 <= 53 stages): one v_readlane per stage instead of two scalar loads from memory
+    const int stinfo = lane <= N ? (S.cls_of_stage[lane] | (S.stage_row0[lane] << 8)) : 0;
 
     for (int witem = instance_id();; witem += instance_stride()) {
         int inst = witem;
@@ -112,6 +114,20 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             }
         };
         const bool x0_free = S.x0_free && P.x0lb && P.x0ub;
+#ifdef COPRA_RF_FINE // (development: the stamps go INSIDE the stage of sweep 1 -- slot s = time up to stamp s of a stage, summed)
+#if COPRA_RF_FINE == 2 // ... or inside prepare_stage: slot 0 = the stage up to it, 1 = class check / refill, 2 = touched entries, 3 = gradient, 4 = rest
+#define COPRA_RF_STAMP(s) ((s) == 2 ? stamp(0) : (s) == 6 ? stamp(4) : (void)0)
+#define COPRA_RF_PSTAMP(s) stamp(s)
+#else
+#define COPRA_RF_STAMP(s) stamp(s)
+#define COPRA_RF_PSTAMP(s) ((void)0)
+#endif
+#define stamp_outer(s) ((void)0)
+#else
+#define COPRA_RF_STAMP(s) ((void)0)
+#define COPRA_RF_PSTAMP(s) ((void)0)
+#define stamp_outer(s) stamp(s)
+#endif
         // ------------------------------------------------------------------ 0. this instance's system, padded
         for (int e = lane; e < NX * NZ; e += kWave) {
             const int j = e / NX, i = e - j * NX;
@@ -124,37 +140,23 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             L.AB[e] = v;
         }
         if (lane < 16) L.dv[lane] = lane < nx ? P.d[(size_t)inst * nx + lane] : 0.0;
-        if (lane < 4) L.Zs[lane] = 0.0;
+        if (lane < 32) L.Zs[lane] = 0.0;
+        if (lane < 4) L.Hb[NZ * NZ + (lane & 1) + kRfHStride * (lane >> 1)] = 0.0, L.gk[18 + (lane & 1) + 20 * (lane >> 1)] = 0.0;
+        for (int k = lane; k < N; k += kWave) L.KF[k * KS + oSpare] = 0.0, L.KF[k * KS + oZero] = 0.0;
         for (int e = lane; e < 2 * S.fast_ntmpl; e += kWave) L.TT[e] = S.f_rval[e];
         wave_sync();
         const double* const AB = L.AB;
-        // operands of the matrix products that are constants of the instance (element of [A B] each lane hands in)
-        double bA[3], bBu[3], aMx[3][3], aMu[2][3], fA[5], hM[3], hMb[3];
-#pragma unroll
-        for (int K = 0; K < 3; ++K) {
-            const int row = 4 * K + q4;
-            bA[K] = hb < 3 ? AB[row + NX * (4 * hb + r4)] : 0.0;
-            bBu[K] = (hb < 2 && r4 < 3) ? AB[row + NX * (NX + 3 * hb + r4)] : 0.0;
-#pragma unroll
-            for (int I = 0; I < 3; ++I) aMx[I][K] = AB[row + NX * (4 * I + r4)];
-#pragma unroll
-            for (int J = 0; J < 2; ++J) aMu[J][K] = r4 < 3 ? AB[row + NX * (NX + 3 * J + r4)] : 0.0;
-            fA[K] = hb < 3 ? AB[(4 * hb + r4) + NX * row] : 0.0;
-            hM[K] = hb < 3 ? AB[row + NX * (4 * hb + r4)] : (r4 < 3 ? AB[row + NX * (NX + r4)] : 0.0);
-            hMb[K] = r4 < 3 ? AB[row + NX * (NX + 3 + r4)] : 0.0;
-        }
-        fA[3] = (hb < 3 && q4 < 3) ? AB[(4 * hb + r4) + NX * (NX + q4)] : 0.0;
-        fA[4] = (hb < 3 && q4 < 3) ? AB[(4 * hb + r4) + NX * (NX + 3 + q4)] : 0.0;
+        // (the operands of the matrix products that are constants of the instance -- the element of [A B] each lane hands in -- are
+        //  read from this copy at the head of every sweep: registers are what limits this kernel)
 
         // ------------------------------------------------------------------ per-row state (registers: row 64 j + lane in element j)
-        int rinf[MR]; // stage | template << 8 | flag << 28
-        int roff[MR]; // entries of the padded stage vectors the row's two coefficients multiply: o0 | o1 << 16
-        double Fr[MR], Sv[MR], Lam[MR], Rp[MR], Dd[MR];
+        int rinf[MR]; // stage | template << 6 | components of its two coefficients << 15, << 20 | flag << 28
+        double Fr[MR], Sv[MR], Lam[MR], Dd[MR];
         // right-hand sides (Cb serves as the exchange buffer for the flags below)
 #pragma unroll
         for (int j = 0; j < MR; ++j) {
             const int gi = 64 * j + lane;
-            int info = 0, off = 0;
+            int info = 0;
             double f = BIGF;
             if (gi < m) {
                 info = S.f_rinfo[gi];
@@ -168,10 +170,10 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 }
                 L.Cb[gi] = f;
                 const int c0 = S.f_rcomp[2 * t], c1 = S.f_rcomp[2 * t + 1];
-                off = (k * NZ + (c0 < 0 ? 0 : c0)) | ((k * NZ + (c1 < 0 ? 0 : c1)) << 16);
+                info = k | (t << 6) | ((c0 < 0 ? 0 : c0) << 15) | ((c1 < 0 ? 0 : c1) << 20);
             }
-            rinf[j] = info, roff[j] = off;
-            Fr[j] = f, Sv[j] = 1.0, Lam[j] = 0.0, Rp[j] = 0.0, Dd[j] = 0.0;
+            rinf[j] = info;
+            Fr[j] = f, Sv[j] = 1.0, Lam[j] = 0.0, Dd[j] = 0.0;
             if (j % 5 == 4) sched_fence();
         }
         wave_sync();
@@ -212,9 +214,10 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 
         // ---- helpers ------------------------------------------------------------------------------------------------
         // a_gi' v for this lane's row (v: a padded stage-vector buffer in LDS)
-        auto row_dot = [&](int info, int off, const double* v) -> double {
-            const int t = (info >> 8) & 0xFFFFF;
-            return L.TT[2 * t] * v[off & 0xFFFF] + L.TT[2 * t + 1] * v[(off >> 16) & 0xFFFF]; // (absent coefficients carry value 0)
+        auto row_dot = [&](int info, const double* v) -> double {
+            const int t = (info >> 6) & 511;
+            const double* vk = v + (info & 63) * NZ;
+            return L.TT[2 * t] * vk[(info >> 15) & 31] + L.TT[2 * t + 1] * vk[(info >> 20) & 31]; // (absent coefficients carry value 0)
         };
         // x_{k+1} = A x_k + B u_k + d along X (the controls as stored in X), from the x_0 stored in X[0 .. 12)
         auto rollout = [&]() {
@@ -230,36 +233,49 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             }
             wave_sync();
         };
+        // ---- the sweeps.  Every address a lane uses in their stage loops is an OFFSET from the LDS base, worked out at the head of the
+        //      sweep from the lane's position (q, b, r) in the v_mfma_f64_4x4x4 layout -- no selects, no predicates in the loops: a
+        //      lane with nothing to read reads the zero pad, a lane with nothing to write writes the spare slot.
+        //      (The first version of this kernel selected pointers inside the loops: ~ 50 lane predicates alive at once = 100 scalar
+        //       registers, which the compiler spilled and reloaded, 51 v_readlane per stage.)
+        double* const lds = lds_base();
+        const int oY = (int)(L.Y - lds), oHb = (int)(L.Hb - lds);
+        const int oPb = (int)(L.Pb - lds), oRb = (int)(L.Rb - lds), oRa = (int)(L.Ra - lds), oGk = (int)(L.gk - lds);
+        const int oZ0 = (int)(L.Zs - lds), oDU = oZ0 + 16, oPv0 = (int)(L.pv0 - lds);
+        auto lane_qbr = [&](int& q, int& b, int& r) { // (opaque: what is derived from it is worked out HERE, not ahead of the Newton loop)
+            int ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(ln));
+#endif
+            q = ln >> 4, b = (ln >> 2) & 3, r = ln & 3;
+        };
         // this lane's element (r, q) of -inverse of the symmetric 3 x 3 block m(a, b) = base[20 a + b]: adjugate over determinant,
         // ONE reciprocal (every lane computes the determinant from six wave-uniform reads and ITS cofactor from four reads at its
-        // own addresses); lanes outside the block return 0.  Positive definite <=> m22, C00, det > 0 (Sylvester).
-        const int ai1 = (r4 + 1) % 3, ai2 = (r4 + 2) % 3, aj1 = (q4 + 1) % 3, aj2 = (q4 + 2) % 3;
-        const int ad1 = qr3 ? 20 * ai1 + aj1 : 0, ad2 = qr3 ? 20 * ai2 + aj2 : 0, ad3 = qr3 ? 20 * ai1 + aj2 : 0, ad4 = qr3 ? 20 * ai2 + aj1 : 0;
-        auto neg_inv3 = [&](const double* base, bool& bad) -> double {
+        // own offsets a1 .. a4 -- all zero outside the block, which makes the result zero there).  Positive definite <=> m22, C00,
+        // det > 0 (Sylvester).
+        auto neg_inv3 = [&](const double* base, int a1, int a2, int a3, int a4, bool& bad) -> double {
             const double m00 = base[0], m01 = base[1], m02 = base[2], m11 = base[21], m12 = base[22], m22 = base[42];
-            const double x1 = base[ad1], x2 = base[ad2], x3 = base[ad3], x4 = base[ad4];
+            const double x1 = base[a1], x2 = base[a2], x3 = base[a3], x4 = base[a4];
             const double c00 = m11 * m22 - m12 * m12, c01 = m12 * m02 - m01 * m22, c02 = m01 * m12 - m11 * m02;
             const double det = m00 * c00 + (m01 * c01 + m02 * c02);
             bad = bad || !(m22 > 0.0) || !(c00 > 0.0) || !(det > 0.0);
-            const double v = (x1 * x2 - x3 * x4) * (-rf_rcp(det));
-            return qr3 ? v : 0.0;
+            return (x1 * x2 - x3 * x4) * (-rf_rcp(det));
         };
 
-        // ---- tables of the stage class in flight (registers): the entries of H = W + A' D A the rows touch (one per lane), and for
-        //      the lanes 0 .. 17 the non-zeros of row `lane` of W and the rows that touch component `lane`
-        int cur_cls = -1;
+        // ---- tables of the stage class being PREPARED (registers): the entries of H = W + A' D A the rows touch (one per lane), and
+        //      for the lanes 0 .. 17 the non-zeros of row `lane` of W and the rows that touch component `lane`.  The stage loops run
+        //      class by class (inner loops over the stages of one class), so that these are loop constants there.
         int t_ent = 0, t_r0 = 0, t_r1 = 0, t_r2 = 0, t_r3 = 0, t_cnt = 0;
         double t_w = 0.0, t_v0 = 0.0, t_v1 = 0.0, t_v2 = 0.0, t_v3 = 0.0;
         int w_c0 = 0, w_c1 = 0, w_c2 = 0, w_c3 = 0, g_r0 = 0, g_r1 = 0, g_r2 = 0, g_r3 = 0;
         double w_v0 = 0.0, w_v1 = 0.0, w_v2 = 0.0, w_v3 = 0.0, g_v0 = 0.0, g_v1 = 0.0, g_v2 = 0.0, g_v3 = 0.0;
-        auto load_class = [&](int c) {
-            if (c == cur_cls) return;
-            cur_cls = c;
-            wave_sync();
+        int hb_cls0 = -1, hb_cls1 = -1; // class whose padded W the two copies of the stage Hessian start from
+        double q_cls = 0.0;
+        auto load_class = [&](int c, int kfirst) { // kfirst: any stage of the class (where its q is read from)
             const double* Wp = S.blob + S.f_Wp[c];
-            for (int e = lane; e < NZ * NZ; e += kWave) L.Hb[e] = Wp[e];
             const int t0 = S.f_tptr[c];
             t_cnt = S.f_tptr[c + 1] - t0;
+            t_ent = 0, t_w = 0.0;
             if (lane < t_cnt) {
                 const int t = t0 + lane;
                 t_ent = S.f_tent[t];
@@ -269,6 +285,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 t_r0 = t_r0 < 0 ? 0 : t_r0, t_r1 = t_r1 < 0 ? 0 : t_r1, t_r2 = t_r2 < 0 ? 0 : t_r2, t_r3 = t_r3 < 0 ? 0 : t_r3;
             }
             if (lane < NZ) {
+                q_cls = S.f_q[kfirst * NZ + lane];
                 const size_t at = ((size_t)c * NZ + lane) * 4;
                 w_c0 = S.f_wcol[at], w_c1 = S.f_wcol[at + 1], w_c2 = S.f_wcol[at + 2], w_c3 = S.f_wcol[at + 3];
                 w_v0 = S.f_wval[at], w_v1 = S.f_wval[at + 1], w_v2 = S.f_wval[at + 2], w_v3 = S.f_wval[at + 3];
@@ -276,17 +293,39 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 g_r0 = S.f_grow[at], g_r1 = S.f_grow[at + 1], g_r2 = S.f_grow[at + 2], g_r3 = S.f_grow[at + 3];
                 g_v0 = S.f_gval[at], g_v1 = S.f_gval[at + 1], g_v2 = S.f_gval[at + 2], g_v3 = S.f_gval[at + 3];
             }
-            wave_sync();
         };
-        // gradient of stage k at the z in X:  g = W z + q (+ the InitialStateLMPC terms at stage 0) (+ A' c, c in Cb) -> gk.
-        // q_k = - sum_rows w p a (costFunctions.cpp: the p-dependent part of the gradient; references shared by the batch) comes
-        // from the plan's table, one stage ahead (`qn`: this stage's, fetched while the previous one ran)
-        auto stage_gradient = [&](int k, double qk, bool with_rows, bool with_x0_terms) {
+        // everything of stage k that does not depend on the cost-to-go: its Hessian H = W + A' D A (the entries the rows touch; the
+        // copy of the stage's parity starts from the padded W of the class) and its gradient
+        //     g = W z + q (+ the InitialStateLMPC terms at stage 0) (+ A' c, c in Cb)  ->  gk[k & 1],
+        // q_k = - sum_rows w p a (costFunctions.cpp: the p-dependent part of the gradient; references shared by the batch) from the
+        // plan's table, fetched one stage ahead.  Runs one stage AHEAD of the sweep, in the shadow of its matrix products; the
+        // class tables above must be those of stage k's class `c`.
+        double qnext = 0.0;
+        const bool q_uniform = S.f_q_uniform != 0; // (per-step references: q is a constant of the class, held with its tables)
+        auto prepare_stage = [&](int k, int c, int gi0, bool hessian, bool with_rows, bool with_x0_terms) {
+            const double qk = q_uniform ? q_cls : qnext;
+            if (!q_uniform) qnext = (lane < NZ && k > 0) ? S.f_q[(k - 1) * NZ + lane] : 0.0;
+            if (hessian) {
+                double* Hk = L.Hb + kRfHStride * (k & 1);
+                int& have = (k & 1) ? hb_cls1 : hb_cls0;
+                if (have != c) {
+                    have = c;
+                    const double* Wp = S.blob + S.f_Wp[c];
+                    for (int e = lane; e < NZ * NZ; e += kWave) Hk[e] = Wp[e];
+                    wave_sync();
+                }
+                COPRA_RF_PSTAMP(1);
+                if (with_rows && lane < t_cnt) {
+                    const double* Yk = L.Y + gi0;
+                    Hk[t_ent] = t_w + ((t_v0 * Yk[t_r0] + t_v1 * Yk[t_r1]) + (t_v2 * Yk[t_r2] + t_v3 * Yk[t_r3]));
+                }
+                COPRA_RF_PSTAMP(2);
+            }
             if (lane < NZ) {
                 const double* Xk = L.X + k * NZ;
                 double g = qk + ((w_v0 * Xk[w_c0] + w_v1 * Xk[w_c1]) + (w_v2 * Xk[w_c2] + w_v3 * Xk[w_c3]));
                 if (with_rows) {
-                    const double* Ck = L.Cb + S.stage_row0[k];
+                    const double* Ck = L.Cb + gi0;
                     g += (g_v0 * Ck[g_r0] + g_v1 * Ck[g_r1]) + (g_v2 * Ck[g_r2] + g_v3 * Ck[g_r3]);
                 }
                 if (with_x0_terms && k == 0 && lane < NX) {
@@ -294,206 +333,282 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 #pragma unroll
                     for (int l = 0; l < NX; ++l) g += L.H0[lane + NX * l] * L.X[l];
                 }
-                L.gk[lane] = g;
+                L.gk[20 * (k & 1) + lane] = g;
             }
+            COPRA_RF_PSTAMP(3);
         };
-        auto fetch_q = [&](int k) -> double { return (lane < NZ && k >= 0) ? S.f_q[k * NZ + lane] : 0.0; };
+        auto stage_cls = [&](int k) -> int { return bcast_i32(stinfo, k) & 255; };
+        auto stage_row0 = [&](int k) -> int { return bcast_i32(stinfo, k) >> 8; };
 
         // ---- sweep 1: backward factorisation.  Before: X holds z, Cb the rows' gradient coefficients, Y their weights D (with_rows).
-        //      After: stage records in KF / KV, P_0 in Pb, p_0 in pv0.  Returns false when a control block is not positive definite.
-        // where this lane's initial values of the accumulators come from: an entry of H, the gradient of the stage, or zero
-        const double* hxp[5];
-        const double* hup[2];
-#pragma unroll
-        for (int I = 0; I < 5; ++I) {
-            const int row = I < 3 ? 4 * I + q4 : (q4 < 3 ? NX + 3 * (I - 3) + q4 : -1);
-            hxp[I] = L.Zs;
-            if (row >= 0) {
-                if (hb < 3)
-                    hxp[I] = L.Hb + row + NZ * (4 * hb + r4);
-                else if (r4 == 0)
-                    hxp[I] = L.gk + row;
-            }
-        }
-#pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            hup[J] = L.Zs;
-            if (qr3 && hb < 2) hup[J] = L.Hb + (NX + 3 * J + q4) + NZ * (NX + 3 * hb + r4);
-        }
-        double* const dummy = L.Zs + 2;
+        //      After: stage records in KF, P_0 in Pb, p_0 in pv0.  Returns false when a control block is not positive definite.
         auto sweep1 = [&](bool with_rows, bool with_x0_terms) -> bool {
+            int q, b, r;
+            lane_qbr(q, b, r);
+            const bool v3 = q < 3 && r < 3;
             bool bad = false;
             double PX[3] = { 0.0, 0.0, 0.0 };
-            double qn = fetch_q(N);
-            for (int k = N; k >= 0; --k) {
-                const int gi0 = S.stage_row0[k];
-                load_class(S.cls_of_stage[k]); // (the stage Hessian starts from the padded W of its class; the entries the rows touch are rebuilt per stage)
-                const double qk = qn;
-                qn = fetch_q(k - 1);
-                if (with_rows && lane < t_cnt) {
-                    const double* Yk = L.Y + gi0;
-                    L.Hb[t_ent] = t_w + ((t_v0 * Yk[t_r0] + t_v1 * Yk[t_r1]) + (t_v2 * Yk[t_r2] + t_v3 * Yk[t_r3]));
-                }
-                stage_gradient(k, qk, with_rows, with_x0_terms);
-                wave_sync();
+            double bA[3], bBu[3], aMx[3][3], aMu[2][3]; // B operands of T = P [A | B], A operands of M = H + [A B]' T
+#pragma unroll
+            for (int K = 0; K < 3; ++K) {
+                const int row = 4 * K + q;
+                bA[K] = *(b < 3 ? AB + row + NX * (4 * b + r) : L.Zs);
+                bBu[K] = *((b < 2 && r < 3) ? AB + row + NX * (NX + 3 * b + r) : L.Zs);
+#pragma unroll
+                for (int I = 0; I < 3; ++I) aMx[I][K] = AB[row + NX * (4 * I + r)];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) aMu[J][K] = *(r < 3 ? AB + row + NX * (NX + 3 * J + r) : L.Zs);
+            }
+            // offsets (doubles from the LDS base) of what this lane reads and writes
+            int hx[5], hu[2];
+            const int hstr = b < 3 ? kRfHStride : 20; // the accumulators start from an entry of H (copy of the stage's parity) | the gradient
+#pragma unroll
+            for (int I = 0; I < 5; ++I) {
+                const int row = I < 3 ? 4 * I + q : (q < 3 ? NX + 3 * (I - 3) + q : -1);
+                if (b < 3)
+                    hx[I] = row >= 0 ? oHb + row + NZ * (4 * b + r) : oHb + NZ * NZ;
+                else
+                    hx[I] = (row >= 0 && r == 0) ? oGk + row : oGk + 18;
+            }
+#pragma unroll
+            for (int J = 0; J < 2; ++J) hu[J] = (v3 && b < 2) ? oHb + (NX + 3 * J + q) + NZ * (NX + 3 * b + r) : oHb + NZ * NZ;
+            const double m3 = b == 3 ? 1.0 : 0.0; // (the gradient column of T starts from p)
+            const int wP = b < 3 ? oPb + q + NX * (4 * b + r) : oDU, rP = oPb + r + NX * q;
+            const int wPend = b < 3 ? wP : (r == 0 ? oPv0 + q : oDU);
+            const int wRb1 = q < 3 ? (b < 3 ? oRb + 20 * q + 4 * b + r : (r == 0 ? oRb + 20 * q + 18 : oDU)) : oDU;
+            const int wRb2 = (v3 && b < 2) ? oRb + 20 * q + NX + 3 * b + r : oDU;
+            const int wRa1 = q < 3 ? (b < 3 ? oRa + 20 * q + 4 * b + r : (r == 0 ? oRa + 20 * q + 18 : oDU)) : oDU;
+            const int wRa2 = (v3 && b == 0) ? oRa + 20 * q + NX + r : oDU;
+            const int rRb = q < 3 ? oRb + 20 * q + r : oZ0, rRb3 = v3 ? oRb + 20 * q + NX + r : oZ0;
+            const int rRa = q < 3 ? oRa + 20 * q + r : oZ0;
+            const int i1 = (r + 1) % 3, i2 = (r + 2) % 3, j1 = (q + 1) % 3, j2 = (q + 2) % 3;
+            const int a1 = v3 ? 20 * i1 + j1 : 0, a2 = v3 ? 20 * i2 + j2 : 0, a3 = v3 ? 20 * i1 + j2 : 0, a4 = v3 ? 20 * i2 + j1 : 0;
+            const int kKb = q < 3 ? (b < 3 ? oKb + 12 * q + 4 * b + r : (r == 0 ? oKvb + q : oSpare)) : oSpare;
+            const int kKa = q < 3 ? (b < 3 ? oKa + 12 * q + 4 * b + r : (r == 0 ? oKva + q : oSpare)) : oSpare;
+            const int kKba = (v3 && b == 0) ? oKba + 3 * q + r : oSpare;
+            const int kNb = (v3 && b == 0) ? oNb + 3 * r + q : oSpare, kNa = (v3 && b == 0) ? oNa + 3 * r + q : oSpare;
+            // one stage; `prep`: prepare stage k - 1 (class cn, rows from gn) in the shadow of the products
+            auto stage = [&](int k, bool prep, int cn, int gn) {
+                const int par = k & 1;
                 double HX[5], HU[2];
-#pragma unroll
-                for (int I = 0; I < 5; ++I) HX[I] = *hxp[I];
-#pragma unroll
-                for (int J = 0; J < 2; ++J) HU[J] = *hup[J];
                 if (k == N) { // P_N = H_xx, p_N = g_x
+                    wave_sync(); // (what prepare_stage(N) wrote is read below)
 #pragma unroll
-                    for (int I = 0; I < 3; ++I) PX[I] = HX[I];
-                } else {
-                    // P as the left factor: through LDS, which replicates it over the hardware blocks
-#pragma unroll
-                    for (int I = 0; I < 3; ++I) *(hb < 3 ? L.Pb + (4 * I + q4) + NX * (4 * hb + r4) : dummy) = PX[I];
-                    wave_sync();
-                    double aP[3][3];
-#pragma unroll
-                    for (int I = 0; I < 3; ++I)
-#pragma unroll
-                        for (int K = 0; K < 3; ++K) aP[I][K] = L.Pb[(4 * I + r4) + NX * (4 * K + q4)];
-                    // T = P [A B]  (+ p in the gradient column)
-                    double TX[3], TU[3];
-#pragma unroll
-                    for (int I = 0; I < 3; ++I) TX[I] = hb == 3 ? PX[I] : 0.0, TU[I] = 0.0;
-#pragma unroll
-                    for (int K = 0; K < 3; ++K)
-#pragma unroll
-                        for (int I = 0; I < 3; ++I) {
-                            TX[I] = mfma_f64_4x4x4(aP[I][K], bA[K], TX[I]);
-                            TU[I] = mfma_f64_4x4x4(aP[I][K], bBu[K], TU[I]);
-                        }
-                    // M = H + [A B]' T
-                    double MX[5], MU[2];
-#pragma unroll
-                    for (int I = 0; I < 5; ++I) MX[I] = HX[I];
-                    MU[0] = HU[0], MU[1] = HU[1];
-#pragma unroll
-                    for (int K = 0; K < 3; ++K) {
-#pragma unroll
-                        for (int I = 0; I < 3; ++I) MX[I] = mfma_f64_4x4x4(aMx[I][K], TX[K], MX[I]);
-                        MX[3] = mfma_f64_4x4x4(aMu[0][K], TX[K], MX[3]);
-                        MX[4] = mfma_f64_4x4x4(aMu[1][K], TX[K], MX[4]);
-                        MU[0] = mfma_f64_4x4x4(aMu[0][K], TU[K], MU[0]);
-                        MU[1] = mfma_f64_4x4x4(aMu[1][K], TU[K], MU[1]);
-                    }
-                    // ---- eliminate u_b (controls 3 .. 5): rows u_b of M -> LDS (left factor of the Schur update, the 3 x 3 block)
-                    {
-                        double* w1 = dummy;
-                        if (q4 < 3) w1 = hb < 3 ? L.Rb + 20 * q4 + 4 * hb + r4 : (r4 == 0 ? L.Rb + 20 * q4 + 18 : dummy);
-                        *w1 = MX[4];
-                        double* w2 = dummy;
-                        if (qr3 && hb < 2) w2 = L.Rb + 20 * q4 + NX + 3 * hb + r4;
-                        *w2 = MU[1];
-                    }
-                    wave_sync();
-                    double aRb[4];
-#pragma unroll
-                    for (int I = 0; I < 3; ++I) aRb[I] = *(q4 < 3 ? L.Rb + 20 * q4 + 4 * I + r4 : L.Zs);
-                    aRb[3] = *(qr3 ? L.Rb + 20 * q4 + NX + r4 : L.Zs);
-                    const double nB = neg_inv3(L.Rb + NX + 3, bad);
-                    const double KbX = mfma_f64_4x4x4(nB, MX[4], 0.0);
-                    const double KbU = mfma_f64_4x4x4(nB, MU[1], 0.0);
-#pragma unroll
-                    for (int I = 0; I < 4; ++I) MX[I] = mfma_f64_4x4x4(aRb[I], KbX, MX[I]);
-                    MU[0] = mfma_f64_4x4x4(aRb[3], KbU, MU[0]);
-                    double* const Fk = L.KF + k * KS;
-                    {
-                        double* w1 = dummy;
-                        if (q4 < 3) w1 = hb < 3 ? Fk + oKb + 12 * q4 + 4 * hb + r4 : (r4 == 0 ? L.KV + 8 * k + 4 + q4 : dummy);
-                        *w1 = KbX;
-                        *((qr3 && hb == 0) ? Fk + oKba + 3 * q4 + r4 : dummy) = KbU;
-                        *((qr3 && hb == 0) ? Fk + oNb + 3 * r4 + q4 : dummy) = nB;
-                    }
-                    // ---- eliminate u_a (controls 0 .. 2)
-                    {
-                        double* w1 = dummy;
-                        if (q4 < 3) w1 = hb < 3 ? L.Ra + 20 * q4 + 4 * hb + r4 : (r4 == 0 ? L.Ra + 20 * q4 + 18 : dummy);
-                        *w1 = MX[3];
-                        *((qr3 && hb == 0) ? L.Ra + 20 * q4 + NX + r4 : dummy) = MU[0];
-                    }
-                    wave_sync();
-                    double aRa[3];
-#pragma unroll
-                    for (int I = 0; I < 3; ++I) aRa[I] = *(q4 < 3 ? L.Ra + 20 * q4 + 4 * I + r4 : L.Zs);
-                    const double nA = neg_inv3(L.Ra + NX, bad);
-                    const double KaX = mfma_f64_4x4x4(nA, MX[3], 0.0);
-#pragma unroll
-                    for (int I = 0; I < 3; ++I) PX[I] = mfma_f64_4x4x4(aRa[I], KaX, MX[I]);
-                    {
-                        double* w1 = dummy;
-                        if (q4 < 3) w1 = hb < 3 ? Fk + oKa + 12 * q4 + 4 * hb + r4 : (r4 == 0 ? L.KV + 8 * k + q4 : dummy);
-                        *w1 = KaX;
-                        *((qr3 && hb == 0) ? Fk + oNa + 3 * r4 + q4 : dummy) = nA;
-                    }
+                    for (int I = 0; I < 3; ++I) PX[I] = lds[hx[I] + hstr * par];
+                    if (prep) prepare_stage(k - 1, cn, gn, true, with_rows, with_x0_terms);
+                    return;
                 }
+                // P as the left factor: through LDS, which replicates it over the hardware blocks; the stage's own H and gradient
+                // (written one stage ago by prepare_stage) come back in the same round trip
+#pragma unroll
+                for (int I = 0; I < 3; ++I) lds[wP + 4 * I] = PX[I];
+                wave_sync();
+                COPRA_RF_STAMP(0);
+                double aP[3][3];
+#pragma unroll
+                for (int I = 0; I < 3; ++I)
+#pragma unroll
+                    for (int K = 0; K < 3; ++K) aP[I][K] = lds[rP + 4 * I + 4 * NX * K];
+#pragma unroll
+                for (int I = 0; I < 5; ++I) HX[I] = lds[hx[I] + hstr * par];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) HU[J] = lds[hu[J] + kRfHStride * par];
+                COPRA_RF_STAMP(1);
+                // T = P [A B]  (+ p in the gradient column)
+                double TX[3], TU[3];
+#pragma unroll
+                for (int I = 0; I < 3; ++I) TX[I] = PX[I] * m3, TU[I] = 0.0;
+#pragma unroll
+                for (int K = 0; K < 3; ++K)
+#pragma unroll
+                    for (int I = 0; I < 3; ++I) {
+                        TX[I] = mfma_f64_4x4x4(aP[I][K], bA[K], TX[I]);
+                        TU[I] = mfma_f64_4x4x4(aP[I][K], bBu[K], TU[I]);
+                    }
+                COPRA_RF_STAMP(2);
+                // (the next stage's Hessian and gradient, in the shadow of these products)
+                if (prep) prepare_stage(k - 1, cn, gn, true, with_rows, with_x0_terms);
+                COPRA_RF_STAMP(3);
+                // M = H + [A B]' T : the rows u_b FIRST -- they go to LDS (left factor of the first Schur update, the 3 x 3 block to
+                // invert), and that round trip runs in the shadow of the other fifteen products
+                double MX[5], MU[2];
+#pragma unroll
+                for (int I = 0; I < 5; ++I) MX[I] = HX[I];
+                MU[0] = HU[0], MU[1] = HU[1];
+#pragma unroll
+                for (int K = 0; K < 3; ++K) {
+                    MX[4] = mfma_f64_4x4x4(aMu[1][K], TX[K], MX[4]);
+                    MU[1] = mfma_f64_4x4x4(aMu[1][K], TU[K], MU[1]);
+                }
+                lds[wRb1] = MX[4];
+                lds[wRb2] = MU[1];
+#pragma unroll
+                for (int K = 0; K < 3; ++K) {
+                    MX[3] = mfma_f64_4x4x4(aMu[0][K], TX[K], MX[3]);
+                    MU[0] = mfma_f64_4x4x4(aMu[0][K], TU[K], MU[0]);
+#pragma unroll
+                    for (int I = 0; I < 3; ++I) MX[I] = mfma_f64_4x4x4(aMx[I][K], TX[K], MX[I]);
+                }
+                COPRA_RF_STAMP(4);
+                // ---- eliminate u_b (controls 3 .. 5)
+                wave_sync();
+                double aRb[4];
+#pragma unroll
+                for (int I = 0; I < 3; ++I) aRb[I] = lds[rRb + 4 * I];
+                aRb[3] = lds[rRb3];
+                const double nB = neg_inv3(L.Rb + NX + 3, a1, a2, a3, a4, bad);
+                const double KbX = mfma_f64_4x4x4(nB, MX[4], 0.0);
+                const double KbU = mfma_f64_4x4x4(nB, MU[1], 0.0);
+                // (the rows u_a first: they are the next ones to go through LDS)
+                MX[3] = mfma_f64_4x4x4(aRb[3], KbX, MX[3]);
+                MU[0] = mfma_f64_4x4x4(aRb[3], KbU, MU[0]);
+                lds[wRa1] = MX[3];
+                lds[wRa2] = MU[0];
+#pragma unroll
+                for (int I = 0; I < 3; ++I) MX[I] = mfma_f64_4x4x4(aRb[I], KbX, MX[I]);
+                double* const Fk = L.KF + k * KS;
+                Fk[kKb] = KbX;
+                Fk[kKba] = KbU;
+                Fk[kNb] = nB;
+                COPRA_RF_STAMP(5);
+                // ---- eliminate u_a (controls 0 .. 2)
+                wave_sync();
+                double aRa[3];
+#pragma unroll
+                for (int I = 0; I < 3; ++I) aRa[I] = lds[rRa + 4 * I];
+                const double nA = neg_inv3(L.Ra + NX, a1, a2, a3, a4, bad);
+                const double KaX = mfma_f64_4x4x4(nA, MX[3], 0.0);
+#pragma unroll
+                for (int I = 0; I < 3; ++I) PX[I] = mfma_f64_4x4x4(aRa[I], KaX, MX[I]);
+                Fk[kKa] = KaX;
+                Fk[kNa] = nA;
+                COPRA_RF_STAMP(6);
+            };
+            qnext = lane < NZ ? S.f_q[N * NZ + lane] : 0.0;
+            load_class(stage_cls(N), N);
+            prepare_stage(N, stage_cls(N), stage_row0(N), true, with_rows, with_x0_terms);
+            int k = N;
+            while (k >= 0) { // runs of stages whose NEXT stage (the one being prepared) is of one class: its tables are loop constants
+                const int cn = stage_cls(k > 0 ? k - 1 : 0);
+                load_class(cn, k > 0 ? k - 1 : 0);
+                do {
+                    stage(k, k > 0, cn, k > 0 ? stage_row0(k - 1) : 0);
+                    --k;
+                } while (k >= 0 && (k == 0 || stage_cls(k - 1) == cn));
             }
             // P_0, p_0 for the step in x_0
             wave_sync();
 #pragma unroll
-            for (int I = 0; I < 3; ++I) *(hb < 3 ? L.Pb + (4 * I + q4) + NX * (4 * hb + r4) : (r4 == 0 ? L.pv0 + 4 * I + q4 : dummy)) = PX[I];
+            for (int I = 0; I < 3; ++I) lds[wPend + 4 * I] = PX[I];
             wave_sync();
             return !bad;
         };
         // ---- sweep 3: backward VECTOR sweep through the stored factors.  Before: X holds z, Cb the rows' gradient coefficients.
-        //      After: kv in KV, p_0 in pv0.
+        //      After: kv in the stage records, p_0 in pv0.
         auto sweep3 = [&]() {
+            int q, b, r;
+            lane_qbr(q, b, r);
+            const bool v3 = q < 3 && r < 3;
             double pB[3] = { 0.0, 0.0, 0.0 };
-            double qn = fetch_q(N);
-            for (int k = N; k >= 0; --k) {
-                load_class(S.cls_of_stage[k]);
-                const double qk = qn;
-                qn = fetch_q(k - 1);
-                stage_gradient(k, qk, true, x0_free);
-                wave_sync();
+            double hM[3], hMb[3]; // A operands of h = g + [A B]' p: row block = hardware block (x | x | x | u_a), and u_b
+#pragma unroll
+            for (int K = 0; K < 3; ++K) {
+                const int row = 4 * K + q;
+                hM[K] = *(b < 3 ? AB + row + NX * (4 * b + r) : (r < 3 ? AB + row + NX * (NX + r) : L.Zs));
+                hMb[K] = *(r < 3 ? AB + row + NX * (NX + 3 + r) : L.Zs);
+            }
+            // operands of a stage from its record: -M_bb^-1, -M'_aa^-1 (element (r, q)), K_b' | K_ba' and K_a' (row block = hardware
+            // block); absent ones read the record's zero slot
+            const int oN1 = v3 ? oNb + 3 * r + q : oZero, oN2 = v3 ? oNa + 3 * r + q : oZero;
+            const int oB = q < 3 ? (b < 3 ? oKb + 12 * q + 4 * b + r : (r < 3 ? oKba + 3 * q + r : oZero)) : oZero;
+            const int oA = (q < 3 && b < 3) ? oKa + 12 * q + 4 * b + r : oZero;
+            const int gh = r == 0 ? (b < 3 ? 4 * b + q : (q < 3 ? NX + q : 18)) : 18, ghb = (r == 0 && q < 3) ? NX + 3 + q : 18;
+            const int wkv = (r == 0 && q < 3 && b < 2) ? (b == 0 ? oKva + q : oKvb + q) : oSpare;
+            const double sel = b == 0 ? 1.0 : 0.0;
+            double nBop = 0.0, nAop = 0.0, aKbT = 0.0, aKaT = 0.0;
+            auto fetch = [&](int k) {
+                const double* Fk = L.KF + k * KS;
+                nBop = Fk[oN1], nAop = Fk[oN2], aKbT = Fk[oB], aKaT = Fk[oA];
+            };
+            auto stage = [&](int k, bool prep, int cn, int gn) {
+                wave_sync(); // (the gradient prepare_stage(k) wrote)
+                const double* gk = L.gk + 20 * (k & 1);
                 if (k == N) {
 #pragma unroll
-                    for (int K = 0; K < 3; ++K) pB[K] = L.gk[4 * K + q4];
-                    continue;
+                    for (int K = 0; K < 3; ++K) pB[K] = gk[4 * K + q];
+                    if (prep) fetch(k - 1), prepare_stage(k - 1, cn, gn, false, true, x0_free);
+                    return;
                 }
-                const double* Fk = L.KF + k * KS;
                 // h = g + [A B]' p : hardware block b = row block (x_0..3 | x_4..7 | x_8..11 | u_a), u_b on its own (replicated)
-                double hv = r4 == 0 ? *(hb < 3 ? L.gk + 4 * hb + q4 : (q4 < 3 ? L.gk + NX + q4 : L.Zs)) : 0.0;
-                double hbv = (r4 == 0 && q4 < 3) ? L.gk[NX + 3 + q4] : 0.0;
-                const double nBop = qr3 ? Fk[oNb + 3 * r4 + q4] : 0.0, nAop = qr3 ? Fk[oNa + 3 * r4 + q4] : 0.0;
-                const double aKbT = *(q4 < 3 ? (hb < 3 ? Fk + oKb + 12 * q4 + 4 * hb + r4 : (r4 < 3 ? Fk + oKba + 3 * q4 + r4 : L.Zs)) : L.Zs);
-                const double aKaT = *((q4 < 3 && hb < 3) ? Fk + oKa + 12 * q4 + 4 * hb + r4 : L.Zs);
+                double hv = gk[gh], hbv = gk[ghb];
+                const double c_nB = nBop, c_nA = nAop, c_KbT = aKbT, c_KaT = aKaT;
+                if (prep) fetch(k - 1), prepare_stage(k - 1, cn, gn, false, true, x0_free); // (on their way while this stage computes)
 #pragma unroll
                 for (int K = 0; K < 3; ++K) {
                     hv = mfma_f64_4x4x4(hM[K], pB[K], hv);
                     hbv = mfma_f64_4x4x4(hMb[K], pB[K], hbv);
                 }
-                const double kvb = mfma_f64_4x4x4(nBop, hbv, 0.0); // kv_b = -M_bb^-1 h_b
-                const double hp = mfma_f64_4x4x4(aKbT, hbv, hv); // h' = h + K_b' h_b  (x and u_a)
+                const double kvb = mfma_f64_4x4x4(c_nB, hbv, 0.0); // kv_b = -M_bb^-1 h_b
+                const double hp = mfma_f64_4x4x4(c_KbT, hbv, hv); // h' = h + K_b' h_b  (x and u_a)
                 const double ha = row_bcast_f64<12>(hp); // h'_a to every hardware block
-                const double kva = mfma_f64_4x4x4(nAop, ha, 0.0); // kv_a = -M'_aa^-1 h'_a
-                const double pn = mfma_f64_4x4x4(aKaT, ha, hp); // p = h'_x + K_a' h'_a
-                if (r4 == 0 && q4 < 3 && hb < 2) L.KV[8 * k + 4 * hb + q4] = hb == 0 ? kva : kvb;
+                const double kva = mfma_f64_4x4x4(c_nA, ha, 0.0); // kv_a = -M'_aa^-1 h'_a
+                const double pn = mfma_f64_4x4x4(c_KaT, ha, hp); // p = h'_x + K_a' h'_a
+                L.KF[k * KS + wkv] = sel * kva + (1.0 - sel) * kvb;
                 pB[0] = row_bcast_f64<0>(pn), pB[1] = row_bcast_f64<4>(pn), pB[2] = row_bcast_f64<8>(pn);
+            };
+            qnext = lane < NZ ? S.f_q[N * NZ + lane] : 0.0;
+            load_class(stage_cls(N), N);
+            prepare_stage(N, stage_cls(N), stage_row0(N), false, true, x0_free);
+            int k = N;
+            while (k >= 0) {
+                const int cn = stage_cls(k > 0 ? k - 1 : 0);
+                load_class(cn, k > 0 ? k - 1 : 0);
+                do {
+                    stage(k, k > 0, cn, k > 0 ? stage_row0(k - 1) : 0);
+                    --k;
+                } while (k >= 0 && (k == 0 || stage_cls(k - 1) == cn));
             }
             wave_sync();
-            if (r4 == 0 && hb < 3) L.pv0[4 * hb + q4] = hb == 0 ? pB[0] : hb == 1 ? pB[1] : pB[2];
+            if (r == 0 && b < 3) L.pv0[4 * b + q] = b == 0 ? pB[0] : b == 1 ? pB[1] : pB[2];
             wave_sync();
         };
         // ---- forward sweep: dz_k into Y, from dx_0 in dx0[]; the controls through the stored gains, the states through [A B]
         auto forward = [&]() {
-            double xB[3];
+            int q, b, r;
+            lane_qbr(q, b, r);
+            const bool v3 = q < 3 && r < 3;
+            double xB[3], fA[5]; // A operands of x+ = [A B] (x, u_a, u_b): row block = hardware block
 #pragma unroll
-            for (int K = 0; K < 3; ++K) xB[K] = L.dx0[4 * K + q4];
-            if (r4 == 0 && hb < 3) L.Y[4 * hb + q4] = hb == 0 ? xB[0] : hb == 1 ? xB[1] : xB[2];
-            for (int k = 0; k < N; ++k) {
+            for (int K = 0; K < 3; ++K) fA[K] = *(b < 3 ? AB + (4 * b + r) + NX * (4 * K + q) : L.Zs);
+            fA[3] = *((b < 3 && q < 3) ? AB + (4 * b + r) + NX * (NX + q) : L.Zs);
+            fA[4] = *((b < 3 && q < 3) ? AB + (4 * b + r) + NX * (NX + 3 + q) : L.Zs);
+#pragma unroll
+            for (int K = 0; K < 3; ++K) xB[K] = L.dx0[4 * K + q];
+            if (r == 0 && b < 3) L.Y[4 * b + q] = b == 0 ? xB[0] : b == 1 ? xB[1] : xB[2];
+            // operands of a stage from its record (fetched one stage ahead): rows of K_a, K_b (A operand: row r, column 4 K + q), K_ba, kv
+            int oRa_[3], oRb_[3];
+#pragma unroll
+            for (int K = 0; K < 3; ++K) oRa_[K] = r < 3 ? oKa + 12 * r + 4 * K + q : oZero, oRb_[K] = r < 3 ? oKb + 12 * r + 4 * K + q : oZero;
+            const int oBa = v3 ? oKba + 3 * r + q : oZero;
+            const int oVa = (r == 0 && q < 3) ? oKva + q : oZero, oVb = (r == 0 && q < 3) ? oKvb + q : oZero;
+            const int wu = (r == 0 && q < 3 && b < 2) ? oY + NX + 3 * b + q : oDU, wus = (r == 0 && q < 3 && b < 2) ? NZ : 0;
+            const int wx = (r == 0 && b < 3) ? oY + NZ + 4 * b + q : oDU, wxs = (r == 0 && b < 3) ? NZ : 0;
+            const double sel = b == 0 ? 1.0 : 0.0;
+            double nKa[3], nKb[3], nKba, nva, nvb;
+            auto fetch = [&](int k) {
                 const double* Fk = L.KF + k * KS;
+#pragma unroll
+                for (int K = 0; K < 3; ++K) nKa[K] = Fk[oRa_[K]], nKb[K] = Fk[oRb_[K]];
+                nKba = Fk[oBa], nva = Fk[oVa], nvb = Fk[oVb];
+            };
+            if (N > 0) fetch(0);
+            for (int k = 0; k < N; ++k) {
                 double fKa[3], fKb[3];
 #pragma unroll
-                for (int K = 0; K < 3; ++K) {
-                    fKa[K] = *(r4 < 3 ? Fk + oKa + 12 * r4 + 4 * K + q4 : L.Zs);
-                    fKb[K] = *(r4 < 3 ? Fk + oKb + 12 * r4 + 4 * K + q4 : L.Zs);
-                }
-                const double fKba = *(qr3 ? Fk + oKba + 3 * r4 + q4 : L.Zs);
-                double ua = (r4 == 0 && q4 < 3) ? L.KV[8 * k + q4] : 0.0;
-                double ub = (r4 == 0 && q4 < 3) ? L.KV[8 * k + 4 + q4] : 0.0;
+                for (int K = 0; K < 3; ++K) fKa[K] = nKa[K], fKb[K] = nKb[K];
+                const double fKba = nKba;
+                double ua = nva, ub = nvb;
+                if (k + 1 < N) fetch(k + 1);
                 double xn = 0.0;
 #pragma unroll
                 for (int K = 0; K < 3; ++K) {
@@ -504,8 +619,8 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 ub = mfma_f64_4x4x4(fKba, ua, ub);
                 xn = mfma_f64_4x4x4(fA[3], ua, xn);
                 xn = mfma_f64_4x4x4(fA[4], ub, xn);
-                if (r4 == 0 && q4 < 3 && hb < 2) L.Y[k * NZ + NX + 3 * hb + q4] = hb == 0 ? ua : ub;
-                if (r4 == 0 && hb < 3) L.Y[(k + 1) * NZ + 4 * hb + q4] = xn;
+                lds[wu + wus * k] = sel * ua + (1.0 - sel) * ub;
+                lds[wx + wxs * k] = xn;
                 xB[0] = row_bcast_f64<0>(xn), xB[1] = row_bcast_f64<4>(xn), xB[2] = row_bcast_f64<8>(xn);
             }
             if (lane < kRfNU) L.Y[N * NZ + NX + lane] = 0.0;
@@ -518,35 +633,41 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 wave_sync();
                 return true;
             }
+            // Gaussian elimination without pivoting (the matrix is symmetric positive definite) on the padded 12 x 13 system [P | -p]:
+            // entry (r, cc) = e / 13, e % 13 of lane + 64 i; ONE pass per pivot -- it reads column p and row p, and writes the columns
+            // beyond p of the other rows --, the solution is rhs / diagonal at the end
+            constexpr int W1 = NX + 1;
             double* GJ = L.GJ;
-            const int w1 = nx + 1;
-            for (int e = lane; e < nx * w1; e += kWave) {
-                const int r = e / w1, cc = e - r * w1;
-                GJ[e] = (cc < nx) ? L.Pb[r + NX * cc] + L.H0[r + NX * cc] : -L.pv0[r];
+            int er[3], ec[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = lane + 64 * i;
+                er[i] = e / W1, ec[i] = e - er[i] * W1;
+                if (e < NX * W1) {
+                    const int r = er[i], cc = ec[i];
+                    double v;
+                    if (cc < NX)
+                        v = (r < nx && cc < nx) ? L.Pb[r + NX * cc] + L.H0[r + NX * cc] : (r == cc ? 1.0 : 0.0);
+                    else
+                        v = r < nx ? -L.pv0[r] : 0.0;
+                    GJ[e] = v;
+                }
             }
             wave_sync();
             bool ok = true;
-            for (int p = 0; p < nx; ++p) {
-                const double piv = GJ[p * w1 + p];
-                if (!(piv > 0.0)) ok = false;
-                const double ip = 1.0 / piv;
-                wave_sync();
-                for (int e = lane; e < nx * w1; e += kWave) {
-                    const int r = e / w1, cc = e - r * w1;
-                    if (r == p || cc == p) continue;
-                    GJ[e] -= GJ[r * w1 + p] * ip * GJ[p * w1 + cc];
-                }
-                wave_sync();
-                for (int e = lane; e < nx * w1; e += kWave) {
-                    const int r = e / w1, cc = e - r * w1;
-                    if (r == p)
-                        GJ[e] *= ip;
-                    else if (cc == p)
-                        GJ[e] = 0.0;
+#pragma unroll
+            for (int p = 0; p < NX; ++p) {
+                const double piv = GJ[p * W1 + p];
+                ok = ok && (piv > 0.0);
+                const double ip = rf_rcp(piv);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int e = lane + 64 * i;
+                    if (e < NX * W1 && er[i] != p && ec[i] > p) GJ[e] -= (GJ[er[i] * W1 + p] * ip) * GJ[p * W1 + ec[i]];
                 }
                 wave_sync();
             }
-            if (lane < NX) L.dx0[lane] = lane < nx ? GJ[lane * w1 + nx] : 0.0;
+            if (lane < NX) L.dx0[lane] = GJ[lane * W1 + NX] * rf_rcp(GJ[lane * W1 + lane]);
             wave_sync();
             return ok;
         };
@@ -563,16 +684,14 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             rollout(); // x0 = 0, U = 0
             good = sweep1(false, false) && good;
             // adjoint sweep for g0: lam_N = g_N,x ; lam_k = g_k,x + A' lam_{k+1}   (g = W z + q)
-            double qn = fetch_q(N);
+            qnext = lane < NZ ? S.f_q[N * NZ + lane] : 0.0;
             for (int k = N; k >= 0; --k) {
-                load_class(S.cls_of_stage[k]);
-                const double qk = qn;
-                qn = fetch_q(k - 1);
-                stage_gradient(k, qk, false, false);
+                load_class(stage_cls(k), k); // (one-off sweep: the class tables are simply reloaded per stage)
+                prepare_stage(k, stage_cls(k), stage_row0(k), false, false, false);
                 wave_sync();
                 double acc = 0.0;
                 if (lane < NX) {
-                    acc = L.gk[lane];
+                    acc = L.gk[20 * (k & 1) + lane];
                     if (k < N) {
 #pragma unroll
                         for (int l = 0; l < NX; ++l) acc += AB[l + NX * lane] * L.dx0[l];
@@ -604,64 +723,76 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
         for (int j = 0; j < MR; ++j) {
             const int gi = 64 * j + lane;
             if (gi < m && (rinf[j] >> 28) == kRfIneq) {
-                Sv[j] = fmax(Fr[j] - row_dot(rinf[j], roff[j], L.X), 1.0);
-                Lam[j] = 1.0;
+                Sv[j] = fmax(Fr[j] - row_dot(rinf[j], L.X), S.s_floor);
+                Lam[j] = S.lam0 > 0.0 ? S.lam0 : -S.lam0 / Sv[j]; // (negative: every complementarity product s * lam starts at |lam0|)
             }
         }
-        stamp(0);
+        stamp_outer(0);
         // ------------------------------------------------------------------ 2. Newton iterations
+        // Per row only the slack, the multiplier, the right-hand side and the predictor's ds * dl live in registers; the residual
+        // rp = a' z + s - f  is formed again from the iterate (which never leaves LDS) wherever it is needed: three LDS reads
+        // instead of two registers per row.
+        auto residual = [&](int j, int fl) -> double { // of an inequality row (with its slack) or an equality row
+            const double az = row_dot(rinf[j], L.X);
+            return fl == kRfEq ? az - Fr[j] : az + Sv[j] - Fr[j];
+        };
         int it = 0;
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // (the row descriptors never change, so the compiler would decode all fifteen of them -- stage offset, template, two
+            //  components, flag -- ONCE, ahead of this loop, and keep ~ 90 registers live across it: make them opaque per iteration)
+#pragma unroll
+            for (int j = 0; j < MR; ++j) asm volatile("" : "+v"(rinf[j]));
+#endif
             // ---- bulk phase: residuals, barrier weights D (-> Y) and gradient coefficients c (-> Cb) of every row
             double musum = 0.0, maxr = 0.0;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
+                if (j % 3 == 0) sched_fence(); // (bounds how many rows' operands the scheduler keeps in flight: registers)
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
-                double Dv = 0.0, Cv = 0.0, rp = 0.0;
+                double Dv = 0.0, Cv = 0.0;
                 if (gi < m && fl != kRfOff) {
-                    const double az = row_dot(rinf[j], roff[j], L.X);
+                    const double rp = residual(j, fl);
                     if (fl == kRfEq) {
-                        rp = az - Fr[j];
                         Dv = 1.0 / delta;
                         Cv = Lam[j] + rp / delta;
                     } else {
-                        rp = az + Sv[j] - Fr[j];
-                        Dv = Lam[j] / Sv[j];
+                        Dv = Lam[j] * rf_rcp(Sv[j]);
                         Cv = Dv * rp;
                         maxr = fmax(maxr, fabs(rp));
                         musum += Sv[j] * Lam[j];
                     }
                 }
-                Rp[j] = rp;
                 if (gi < m) L.Y[gi] = Dv, L.Cb[gi] = Cv;
             }
             wave_sync();
             const double mu = wave_sum(musum) * inv_mi;
             const double maxres = wave_max(maxr);
-            stamp(1);
+            stamp_outer(1);
             // ---- sweep 1 (backward): factorisation and the predictor's right-hand side
             good = sweep1(true, x0_free) && good;
-            stamp(2);
+            stamp_outer(2);
             if (!good) break;
             // ---- predictor: forward sweep, then the rows in bulk
             good = solve_x0() && good;
+            stamp_outer(3);
             forward();
-            stamp(3);
+            stamp_outer(4);
             double amin = 1.0e300;
             // mu_aff = sum (s + a ds)(lam + a dl) / n  needs the step length a of the whole wave first: its three coefficients in a
             // are summed in the same pass (no second pass over the directions, no registers to keep them in)
             double q0 = 0.0, q1 = 0.0, q2 = 0.0;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
+                if (j % 3 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 double dsdl = 0.0;
                 if (gi < m && fl == kRfIneq) {
-                    const double adz = row_dot(rinf[j], roff[j], L.Y);
-                    const double ds = -Rp[j] - adz;
-                    const double dl = (-Lam[j] * Sv[j] - Lam[j] * ds) / Sv[j];
-                    if (ds < 0.0) amin = fmin(amin, -Sv[j] / ds);
-                    if (dl < 0.0) amin = fmin(amin, -Lam[j] / dl);
+                    const double ds = -residual(j, fl) - row_dot(rinf[j], L.Y);
+                    const double dl = (-Lam[j] * Sv[j] - Lam[j] * ds) * rf_rcp(Sv[j]);
+                    if (ds < 0.0) amin = fmin(amin, -Sv[j] * rf_rcp(ds));
+                    if (dl < 0.0) amin = fmin(amin, -Lam[j] * rf_rcp(dl));
                     dsdl = ds * dl;
                     q0 += Sv[j] * Lam[j], q1 += Sv[j] * dl + Lam[j] * ds, q2 += dsdl;
                 }
@@ -678,42 +809,63 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             // ---- corrector right-hand side: gradient coefficients of the rows
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
+                if (j % 3 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 double Cv = 0.0;
-                if (fl == kRfEq)
-                    Cv = Lam[j] + Rp[j] / delta; // as in the predictor
-                else if (fl == kRfIneq)
-                    Cv = (sigma_mu - Dd[j]) / Sv[j] + (Lam[j] / Sv[j]) * Rp[j];
+                if (gi < m && fl != kRfOff) {
+                    const double rp = residual(j, fl);
+                    if (fl == kRfEq)
+                        Cv = Lam[j] + rp / delta; // as in the predictor
+                    else
+                        Cv = ((sigma_mu - Dd[j]) + Lam[j] * rp) * rf_rcp(Sv[j]);
+                }
                 if (gi < m) L.Cb[gi] = Cv;
             }
             wave_sync();
-            stamp(4);
+            stamp_outer(6);
             sweep3();
+            stamp_outer(5);
             good = solve_x0() && good;
+            stamp_outer(3);
             forward();
-            stamp(5);
-            // ---- final direction of the rows, step length, update.  The direction takes the place of values that are dead by now:
-            //      inequality rows ds -> Rp, dl -> Dd; equality rows keep their residual in Rp, a' dz -> Dd
+            stamp_outer(4);
+            // ---- final direction of the rows: the step length first, then (the direction formed once more) the update
             amin = 1.0e300;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
+                if (j % 3 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
-                if (gi < m && fl != kRfOff) {
-                    const double adz = row_dot(rinf[j], roff[j], L.Y);
-                    if (fl == kRfEq) {
-                        Dd[j] = adz;
-                    } else {
-                        const double ds = -Rp[j] - adz;
-                        const double dl = ((sigma_mu - Dd[j]) - Lam[j] * Sv[j] - Lam[j] * ds) / Sv[j];
-                        if (ds < 0.0) amin = fmin(amin, -Sv[j] / ds);
-                        if (dl < 0.0) amin = fmin(amin, -Lam[j] / dl);
-                        Rp[j] = ds, Dd[j] = dl;
-                    }
+                if (gi < m && fl == kRfIneq) {
+                    const double ds = -residual(j, fl) - row_dot(rinf[j], L.Y);
+                    const double dl = ((sigma_mu - Dd[j]) - Lam[j] * Sv[j] - Lam[j] * ds) * rf_rcp(Sv[j]);
+                    if (ds < 0.0) amin = fmin(amin, -Sv[j] * rf_rcp(ds));
+                    if (dl < 0.0) amin = fmin(amin, -Lam[j] * rf_rcp(dl));
                 }
             }
             amin = -wave_max(-amin);
             const double tau = mu > 1e-10 ? 0.995 : 0.9999;
             const double alpha = amin < 1.0 ? fmin(1.0, tau * amin) : 1.0;
+            double musum2 = 0.0, maxe = 0.0;
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                if (j % 3 == 0) sched_fence();
+                const int gi = 64 * j + lane, fl = rinf[j] >> 28;
+                if (gi < m && fl != kRfOff) {
+                    const double rp = residual(j, fl), adz = row_dot(rinf[j], L.Y);
+                    if (fl == kRfIneq) {
+                        const double ds = -rp - adz;
+                        const double dl = ((sigma_mu - Dd[j]) - Lam[j] * Sv[j] - Lam[j] * ds) * rf_rcp(Sv[j]);
+                        Sv[j] += alpha * ds;
+                        Lam[j] += alpha * dl;
+                        musum2 += Sv[j] * Lam[j];
+                    } else {
+                        const double re = rp + alpha * adz; // residual of the row at the new point
+                        Lam[j] += re / delta;
+                        maxe = fmax(maxe, fabs(re));
+                    }
+                }
+            }
+            wave_sync(); // (every row has read the old iterate)
             double z_inf = 0.0, step_inf = 0.0;
             for (int e = lane; e < NE; e += kWave) {
                 const double dz = L.Y[e];
@@ -724,22 +876,6 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             }
             step_inf = wave_max(step_inf) * alpha;
             z_inf = wave_max(z_inf);
-            double musum2 = 0.0, maxe = 0.0;
-#pragma unroll
-            for (int j = 0; j < MR; ++j) {
-                const int fl = rinf[j] >> 28;
-                if (64 * j + lane < m) {
-                    if (fl == kRfIneq) {
-                        Sv[j] += alpha * Rp[j];
-                        Lam[j] += alpha * Dd[j];
-                        musum2 += Sv[j] * Lam[j];
-                    } else if (fl == kRfEq) {
-                        const double re = Rp[j] + alpha * Dd[j]; // residual of the row at the new point
-                        Lam[j] += re / delta;
-                        maxe = fmax(maxe, fabs(re));
-                    }
-                }
-            }
             wave_sync();
             const double mu_new = wave_sum(musum2) * inv_mi;
             const double res_new = fmax((1.0 - alpha) * maxres, wave_max(maxe));
@@ -747,8 +883,11 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 good = false;
                 break;
             }
-            stamp(6);
-            if (res_new <= 1e-9 && ((step_inf <= 1e-10 * (1.0 + z_inf) && mu_new <= 1e-8) || mu_new <= 1e-15)) {
+            stamp_outer(6);
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(COPRA_EMU_TRACE)
+            if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e eq %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, maxe, step_inf, z_inf);
+#endif
+            if (res_new <= 1e-9 && ((step_inf <= S.step_tol * (1.0 + z_inf) && mu_new <= S.mu_tol) || mu_new <= 1e-15)) {
                 converged = true;
                 break;
             }
@@ -782,12 +921,15 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             }
         }
         if (P.prof && lane == 0) {
-            stamp(6);
+            stamp_outer(6);
             prof[7] = cycle_counter() - tstart;
             for (int q = 0; q < 8; ++q) P.prof[8 * (size_t)inst + q] = prof[q];
         }
         wave_sync();
     }
+#undef COPRA_RF_STAMP
+#undef COPRA_RF_PSTAMP
+#undef stamp_outer
 }
 
 } // namespace copra_hip

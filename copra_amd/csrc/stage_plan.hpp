@@ -43,7 +43,7 @@ constexpr int kRfNX = 12, kRfNU = 6, kRfNZ = 18; // padded xDim / uDim: three bl
 constexpr int kRfMR = 15; // 64-lane registers of per-row state: at most 960 rows
 constexpr int kRfZR = 15; // 64-lane registers of the stage vectors: (N + 1) 18 <= 960
 constexpr int kRfGTerms = 4, kRfWTerms = 4, kRfTTerms = 4, kRfMaxTouched = 64;
-constexpr int kRfKStride = 100; // stage record: Ka 3 x 12 | Kb 3 x 12 | Kba 3 x 3 | -Mbb^-1 3 x 3 | -M'aa^-1 3 x 3
+constexpr int kRfKStride = 107; // stage record: Ka 3 x 12 | Kb 3 x 12 | Kba 3 x 3 | -Mbb^-1 3 x 3 | -M'aa^-1 3 x 3 | kv_a | kv_b | spare | zero
 
 // where the right-hand side of a constraint row comes from (per instance when the caller set per-instance data)
 enum { kSrcRowF = 0, kSrcUb = 1, kSrcNegLb = 2, kSrcX0Ub = 3, kSrcNegX0Lb = 4 };
@@ -94,6 +94,8 @@ struct StagePlan {
     long long oZ, oDZ, oQ, oGB, oF, oS, oLam, oDS, oDL, oRP, oFlag, oK, oMi, oKv, oH0, oG0;
     int lds_doubles;
     int max_iter;
+    double step_tol, mu_tol; // convergence: step <= step_tol (1 + |z|) and mu <= mu_tol (or mu <= 1e-15), residuals <= 1e-9
+    double s_floor, lam0; // starting point of the interior-point iteration: slacks max(f - a'z, s_floor), multipliers lam0
     double delta; // proximal weight of the equality rows
     // ---- LDS-resident kernel (lmpc_riccati_mfma.hpp): fixed-width views over the PADDED stage vector z_k = (x: 12 | u: 6),
     //      entry (k, i) at k * kRfNZ + i; usable when fast_ok (else the streaming kernel of lmpc_riccati.hpp runs) ----
@@ -117,6 +119,7 @@ struct StagePlan {
     const double* f_qa; // [cost rows][kRfNZ] padded coefficient vectors a
     const double* f_q; // [(N + 1) kRfNZ] q_k = - sum_rows w p a with the controller-wide references p (per-instance references: streaming kernel)
     int fast_ntmpl; // row templates (their coefficient pairs sit in LDS)
+    int f_q_uniform; // q_k is the same at every stage of a class (per-step references): one load per class instead of one per stage
 };
 
 struct HostStagePlan {
@@ -440,6 +443,15 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.max_nnze = max_nnze;
     sp.x0_free = P.initial_state;
     sp.max_iter = 60;
+    // starting point: slacks s = max(f - a'z_0, 0.05) at the roll-out z_0 of u = 0 and multipliers lam = 1 / s -- every complementarity
+    // product starts at 1 (a CENTRED start).  The first version (s = max(., 1), lam = 1) made every row with a slack below 1
+    // start with a primal residual, and the first five Newton steps were spent recovering from that: 19 -> 14 steps on config 5.
+    sp.s_floor = 0.05, sp.lam0 = -1.0;
+    sp.step_tol = 1e-10, sp.mu_tol = 1e-8;
+    if (const char* e = std::getenv("COPRA_RIC_STEP_TOL")) sp.step_tol = std::atof(e); // (experiments)
+    if (const char* e = std::getenv("COPRA_RIC_MU_TOL")) sp.mu_tol = std::atof(e);
+    if (const char* e = std::getenv("COPRA_RIC_S0")) sp.s_floor = std::atof(e); // (experiments)
+    if (const char* e = std::getenv("COPRA_RIC_LAM0")) sp.lam0 = std::atof(e);
     sp.delta = 1e-9;
     // workspace of one resident wave
     long long o = 0;
@@ -469,6 +481,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     if (nx > kRfNX || nu > kRfNU) return slow("xDim > 12 or uDim > 6");
     if (sp.m > 64 * kRfMR) return slow("more than 960 constraint rows");
     if ((N + 1) * kRfNZ > 64 * kRfZR) return slow("more than 52 steps");
+    if ((int)out.r_kind.size() > 128) return slow("more than 128 row templates");
     auto pad = [&](int j) { return j < nx ? j : kRfNX + (j - nx); };
     const int ntmpl = (int)out.r_kind.size();
     out.f_rcomp.assign((size_t)ntmpl * 2, -1);
@@ -562,11 +575,17 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
             for (int i = 0; i < kRfNZ; ++i) out.f_q[(size_t)k * kRfNZ + i] -= out.cr_w[(size_t)t] * pv * out.f_qa[(size_t)t * kRfNZ + i];
         }
     }
+    sp.f_q_uniform = 1;
+    for (int k = 0; k <= N && sp.f_q_uniform; ++k) {
+        const int k0 = first_stage[(size_t)out.cls_of_stage[(size_t)k]];
+        for (int i = 0; i < kRfNZ; ++i)
+            if (out.f_q[(size_t)k * kRfNZ + i] != out.f_q[(size_t)k0 * kRfNZ + i]) sp.f_q_uniform = 0;
+    }
     sp.fast_ntmpl = ntmpl > 0 ? ntmpl : 1;
     if (ntmpl > 128) return slow("more than 128 row templates");
     // LDS of one instance (doubles): X | Y | F (64 kRfMR each) | stage records | kv | H | P | Rb | Ra | H0 | G0 | A B | d | Gauss-Jordan
-    sp.fast_lds_doubles = 3 * 64 * kRfMR + N * kRfKStride + N * 8 + kRfNZ * kRfNZ + kRfNX * kRfNX + 64 + 64 + kRfNX * kRfNX + 16
-        + kRfNX * kRfNZ + 16 + kRfNX * (kRfNX + 1) + 12 + 12 + 4 + 20 + 2 * sp.fast_ntmpl; // == carve_rf
+    sp.fast_lds_doubles = 3 * 64 * kRfMR + N * kRfKStride + 2 * (kRfNZ * kRfNZ + 2) + kRfNX * kRfNX + 64 + 64 + kRfNX * kRfNX + 16
+        + kRfNX * kRfNZ + 16 + kRfNX * (kRfNX + 1) + 12 + 12 + 32 + 40 + 2 * sp.fast_ntmpl; // == carve_rf
     if ((size_t)sp.fast_lds_doubles * sizeof(double) > 80 * 1024) return slow("LDS footprint above 80 KiB (two instances per CU)");
     sp.fast_ok = 1;
 }
