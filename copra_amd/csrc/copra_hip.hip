@@ -545,6 +545,7 @@ static copra_status_t adapt_layout(copra_batch* h)
 
 static copra_status_t ensure_lds_attr(copra_batch* h)
 {
+    if (h->hp.ric_only) return COPRA_OK; // (the Riccati kernels opt in to their LDS where they are launched)
     if (h->hp.large) {
         if (!h->lds_attr_set && h->hp.lds_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->large_fn),
@@ -677,6 +678,7 @@ static copra_status_t prepare_riccati(copra_batch* h)
 // does the next solve of this controller run the Riccati interior-point kernel?
 static bool use_riccati(copra_batch* h)
 {
+    if (h->hp.ric_only) return prepare_riccati(h) == COPRA_OK && h->hs.eligible;
     if (h->solver == COPRA_SOLVER_QUADPROG_DENSE || h->shared) return false;
     if (h->solver == COPRA_SOLVER_DEFAULT && (!h->hp.large || std::getenv("COPRA_NO_RICCATI"))) return false;
     if (prepare_riccati(h) != COPRA_OK) return false;
@@ -742,6 +744,8 @@ copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver)
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_select_solver: null handle");
     if (solver != COPRA_SOLVER_DEFAULT && solver != COPRA_SOLVER_QUADPROG_DENSE && solver != COPRA_SOLVER_RICCATI_IPM)
         return fail(COPRA_ERR_ARG, "copra_batch_select_solver: unknown solver flag");
+    if (h->hp.ric_only && solver == COPRA_SOLVER_QUADPROG_DENSE)
+        return fail(COPRA_ERR_UNSUPPORTED, "the condensed Goldfarb-Idnani kernels cover at most 512 decision variables (InitialStateLMPC: xDim <= 16)");
     if (solver == COPRA_SOLVER_RICCATI_IPM) {
         const copra_status_t rc = prepare_riccati(h);
         if (rc != COPRA_OK) return rc;
@@ -835,7 +839,16 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         chk(upload(&h->d_isr, h->hp.isr));
         chk(hipMalloc((void**)&h->d_x0opt, b * P.nx * sizeof(double)));
     }
-    if (h->hp.large) {
+    if (h->hp.ric_only) { // only the Riccati interior-point kernels cover this size: the controller must be stage-wise
+        const copra_status_t rr = prepare_riccati(h);
+        if (rr != COPRA_OK || !h->hs.eligible) {
+            const std::string why = rr != COPRA_OK ? g_err : h->hs.why;
+            copra_batch_destroy(h);
+            *out = nullptr;
+            fail(COPRA_ERR_UNSUPPORTED, "more than 512 decision variables (or InitialStateLMPC with xDim > 16) need a stage-wise controller for the Riccati interior-point kernel: " + why);
+            return COPRA_ERR_UNSUPPORTED;
+        }
+    } else if (h->hp.large) {
         h->large_fn = choose_large_kernel(h->hp);
         if (h->hp.lds_bytes > 48 * 1024) // (the occupancy query below needs the attribute as well)
             chk(hipFuncSetAttribute(reinterpret_cast<const void*>(h->large_fn),
@@ -945,6 +958,7 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
 int copra_batch_lanes_per_instance(const copra_batch_t* h)
 {
     if (!h) return 0;
+    if (h->hp.ric_only) return kWave;
     if (h->hp.large) return h->hp.plan.large.threads;
     return h->packed ? h->packed : kWave;
 }
@@ -956,6 +970,12 @@ copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const cop
     HostPlan hp;
     const copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) g_err = hp.error;
+    if (rc == COPRA_OK && hp.ric_only) { // beyond the condensed kernels' sizes: covered if (and only if) the controller is stage-wise
+        HostStagePlan hs;
+        build_stage_plan(hp, hs, false);
+        if (!hs.eligible)
+            return fail(COPRA_ERR_UNSUPPORTED, "more than 512 decision variables (or InitialStateLMPC with xDim > 16) need a stage-wise controller for the Riccati interior-point kernel: " + hs.why);
+    }
     return rc;
 }
 
@@ -1543,12 +1563,14 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             LDS_OPT_IN(ric_fn, ric_lds);
             hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
             HIP_TRY(hipGetLastError());
-            FusedPlan P2 = P;
-            P2.from_list = 1;
-            LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
-            hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
-                h->hp.lds_bytes, s, P2);
-            HIP_TRY(hipGetLastError());
+            if (!h->hp.ric_only) { // (beyond the condensed kernels' sizes the instances that did not converge keep status 3)
+                FusedPlan P2 = P;
+                P2.from_list = 1;
+                LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
+                hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+                    h->hp.lds_bytes, s, P2);
+                HIP_TRY(hipGetLastError());
+            }
             HIP_TRY(hipEventRecord(h->ev1, s));
             h->timed = true;
             h->tier_timed = false;
@@ -1704,6 +1726,8 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     const FusedPlan& HP = h->hp.plan;
     if (instance < 0 || instance >= HP.batch) return fail(COPRA_ERR_ARG, "copra_batch_dump_qp: bad instance");
     if (!h->A) return fail(COPRA_ERR_RUNTIME, "copra_batch_dump_qp: no preview system set");
+    if (h->hp.ric_only)
+        return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_dump_qp: the condensed QP of a controller this size is never formed on the device (stage-wise Riccati path)");
     const int n = HP.initial_state ? HP.nx + HP.n : HP.n, mg = HP.mgen;
     double *dQ = nullptr, *dc = nullptr, *dA = nullptr, *db = nullptr;
     HIP_TRY(hipMalloc((void**)&dQ, (size_t)n * n * sizeof(double)));

@@ -38,6 +38,8 @@ struct HostPlan {
     LdsLayout lds_safe {};
     bool safe_two_tier = false;
     bool large = false; // more than 64 decision variables: workgroup-per-instance kernel (lmpc_large.hpp)
+    bool ric_only = false; // beyond the condensed kernels' sizes (more than 512 decision variables; InitialStateLMPC with xDim > 16):
+                           // only the stage-wise Riccati interior-point kernels cover it, and only if the controller is stage-wise
     // where the rows of constraint k (position in the user's array) sit in the stacked order: row = row0 + s * per_step
     // + i for its steps s and lines i (steps == 1 for a full-size entry); row0 < 0: bound constraint, no rows
     std::vector<int> cstr_row0, cstr_per_step, cstr_steps;
@@ -726,10 +728,19 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
 
     // fused-kernel limits
     P.use_large = 0;
-    if (nvar > kWave) { // workgroup-per-instance kernel: J / R in HBM (lmpc_large.hpp)
-        if (nvar > kLargeMaxN) return hp.error = "more than 512 decision variables are not covered", COPRA_ERR_UNSUPPORTED;
+    if (nvar > kLargeMaxN || (is && nx > 16)) {
+        // The condensed Goldfarb-Idnani kernels stop here (one thread per row of a 512 x 512 inverse factor; xDim x xDim scratch of
+        // InitialStateLMPC).  The stage-wise Riccati interior-point method has no object of that size: such a controller is
+        // accepted if it is stage-wise (stage_plan.hpp decides when the handle is created) and then runs on that path alone --
+        // instances it does not converge on keep status 3 instead of being re-queued.
         if (nu > kMaxNu) return hp.error = "uDim > 8 is not covered", COPRA_ERR_UNSUPPORTED;
-        if (is && nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;
+        hp.large = true;
+        hp.ric_only = true;
+        P.use_large = 0;
+        return COPRA_OK;
+    }
+    if (nvar > kWave) { // workgroup-per-instance kernel: J / R in HBM (lmpc_large.hpp)
+        if (nu > kMaxNu) return hp.error = "uDim > 8 is not covered", COPRA_ERR_UNSUPPORTED;
         LargeLayout& L = P.large;
         int o = 0;
         auto take = [&](int count) {
@@ -797,7 +808,6 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         return COPRA_OK;
     }
     if (is) {
-        if (nx > 16) return hp.error = "InitialStateLMPC: xDim > 16 not covered", COPRA_ERR_UNSUPPORTED;
         layout_lds(hp.lds_full, nx, nu, N, nvar, X, P.rmax, P.mgen, P.meq, P.mtotal, true);
         LdsLayout& L = hp.lds_full;
         int o = L.total;

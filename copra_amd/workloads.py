@@ -130,3 +130,28 @@ def long_horizon_initial_state(batch, N=50, seed=3, v_max=0.5, u_max=2.0, R_diag
     ist = dict(R=R_diag * np.eye(12), r=np.zeros(12), x0lb=x0 - 0.05, x0ub=x0 + 0.05)
     return dict(name="InitialStateLMPC (nx=12,nu=6,N=%d): mixed ineq + full-size terminal equality + control bounds" % N,
                 A=A, B=B, d=d, x0=x0, N=N, costs=costs, cstrs=cstrs, initial_state=ist)
+
+
+def wide_state_initial_state(batch, nx=18, nu=2, N=40, seed=11, u_max=1.5):
+    """InitialStateLMPC with MORE than 16 states (the condensed kernels' limit; stage-wise, so the Riccati interior-point kernel
+    takes it): a stable random system shared in value by the batch, TrajectoryCost on the first six states + ControlCost,
+    control bounds, one upper TrajectoryBound on state 0, x0 bounds +- 0.05, R = 1e-2 I."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+    A1 = 0.97 * Q
+    B1 = 0.3 * rng.standard_normal((nx, nu))
+    d1 = 0.01 * rng.standard_normal(nx)
+    A = np.tile(A1, (batch, 1, 1))
+    B = np.tile(B1, (batch, 1, 1))
+    d = np.tile(d1, (batch, 1))
+    x0 = 0.5 * rng.standard_normal((batch, nx))
+    M = np.eye(nx)[:6]
+    upper = np.full(nx, np.inf)
+    upper[0] = 1.5
+    costs = [dict(kind="trajectory", M=M, p=np.zeros(6), weights=[5.0] * 6),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-2] * nu)]
+    cstrs = [dict(kind="trajectory_bound", lower=[-np.inf] * nx, upper=list(upper)),
+             dict(kind="control_bound", lower=[-u_max] * nu, upper=[u_max] * nu)]
+    ist = dict(R=1e-2 * np.eye(nx), r=np.zeros(nx), x0lb=x0 - 0.05, x0ub=x0 + 0.05)
+    return dict(name="InitialStateLMPC (nx=%d,nu=%d,N=%d): more than 16 states" % (nx, nu, N), A=A, B=B, d=d, x0=x0, N=N,
+                costs=costs, cstrs=cstrs, initial_state=ist)

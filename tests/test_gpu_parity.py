@@ -1227,3 +1227,40 @@ def test_riccati_factor_tier_shorter_horizons(oracle, N):
     ok = ref["status"] == 0
     assert (res["iter"][ok] == ref["iter"][ok]).all() and (res["iter"][:, 0] > 1).mean() > 0.2
     eng.close()
+
+
+def test_sizes_beyond_the_condensed_kernels(oracle):
+    """round-2 verdict item 8: more than 512 decision variables, and InitialStateLMPC with more than 16 states, are accepted when
+    the controller is stage-wise: the Riccati interior-point kernel has no n x n object.  (12, 6, 120) = 732 variables (the
+    config-5 controller on a longer horizon, R = 1e-2 I) and (18, 2, 40) InitialStateLMPC, a few instances against the oracle;
+    the condensed solver cannot be selected for them, and a controller of that size that is NOT stage-wise is refused."""
+    from copra_amd import BatchLMPC, workloads
+    from copra_amd import _capi
+    for wl, b in ((workloads.long_horizon_initial_state(3, N=120, R_diag=1e-2), 3), (workloads.wide_state_initial_state(8), 8)):
+        ist = wl["initial_state"]
+        nx, nu = wl["B"].shape[1], wl["B"].shape[2]
+        eng = BatchLMPC(nx, nu, wl["N"], b, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+        assert eng.solver() == "riccati_ipm"
+        with pytest.raises(Exception):
+            eng.select_solver("quadprog_dense")
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
+        eng.solve()
+        res, x0o = eng.results(), eng.initial_state()
+        assert (res["status"] == 0).all()
+        for k in range(min(b, 3)):
+            io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
+            assert ro["status"] == 0
+            assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+            assert np.abs(x0o[k] - ro["x0_opt"]).max() <= 1e-7
+        with pytest.raises(Exception):
+            eng.dump_qp(0)
+        eng.close()
+    # 200 steps x 3 controls = 600 variables with a full-size cost row that couples two steps: not stage-wise -> refused
+    wl = workloads.com_preview(1, N=200)
+    M = np.zeros((1, 6 * 201))
+    M[0, 0], M[0, 6] = 1.0, -1.0
+    costs = wl["costs"] + [dict(kind="trajectory", M=M, p=[0.0], weights=[1.0])]
+    with pytest.raises(Exception):
+        BatchLMPC(6, 3, 200, 1, costs, wl["cstrs"])

@@ -145,3 +145,22 @@ def test_per_instance_data_and_pinned_bounds(emu, oracle):
     ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], 30, pb["costs"], pb["cstrs"])
     assert re["status"][0] == 0 and np.abs(re["x0_opt"][0] - pb["x0"]).max() == 0.0
     assert _rel(re["control"][0], ro["control"]) <= RTOL
+
+
+def test_beyond_the_condensed_kernels_sizes(emu, oracle):
+    """round-2 verdict item 8: sizes the condensed Goldfarb-Idnani kernels refuse (more than 512 decision variables;
+    InitialStateLMPC with more than 16 states) are accepted when the controller is stage-wise -- the Riccati interior-point
+    method has no object of that size.  (nx, nu, N) = (12, 6, 120): 732 variables, the config-5 controller on a longer horizon
+    (R = 1e-2 I: the well-conditioned twin, 1e-6 against the oracle);  (18, 2, 40) InitialStateLMPC: 98 variables."""
+    from copra_amd import workloads
+    for wl, b in ((workloads.long_horizon_initial_state(1, N=120, R_diag=1e-2), 1), (workloads.wide_state_initial_state(2), 2)):
+        ist = wl["initial_state"]
+        re = emu.lmpc_solve_riccati(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"],
+                                    initial_state=dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"], x0ub=ist["x0ub"]))
+        assert re is not None and (re["status"] == 0).all() and re["not_converged"] == 0 and not re["lds_resident"]
+        for k in range(b):
+            io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
+            assert ro["status"] == 0
+            assert _rel(re["control"][k], ro["control"]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"]) <= RTOL
+            assert np.abs(re["x0_opt"][k] - ro["x0_opt"]).max() <= 1e-7
