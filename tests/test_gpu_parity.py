@@ -1252,7 +1252,9 @@ def test_sizes_beyond_the_condensed_kernels(oracle):
             io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
             ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
             assert ro["status"] == 0
-            assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+            # (norm-wise, as for config 5: 732 variables through the CPU path's dense Goldfarb-Idnani leave ~ 1e-8 absolute on entries
+            #  that vanish at the optimum)
+            assert _rel_vec(res["control"][k], ro["control"]) <= RTOL and _rel_vec(res["trajectory"][k], ro["trajectory"]) <= RTOL
             assert np.abs(x0o[k] - ro["x0_opt"]).max() <= 1e-7
         with pytest.raises(Exception):
             eng.dump_qp(0)
