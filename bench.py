@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector = matrix FP64
-PMC_SUMMARY = os.path.join("profiles", "r02", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r03", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
 
 
 SPIN_UP_SOLVES = 40  # untimed solves before the warm-up steps (clock ramp; see main)
@@ -87,9 +87,79 @@ def timed_rate(eng, batch, reps=5):
 EVENT_TIMING = "best of %d solves, HIP events around the whole solve (device time, inputs resident in HBM)"
 
 
+def cpp_single_solve_latency():
+    """What a drop-in user of ONE controller sees: copra::LMPC::solve() of the C++ mirror (copra_amd/cpp/include/copra/copra.h) on
+    the headline controller, batch 1 -- launch + synchronisation + result copy per call (tests/cpp/test_api.cpp: latency_case)."""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import test_cpp_api
+    test_cpp_api._build()
+    r = subprocess.run([test_cpp_api.EXE, "latency", "1000"], capture_output=True, text=True, timeout=300)
+    m = re.search(r"latency_us median ([0-9.]+) mean ([0-9.]+) min ([0-9.]+) p95 ([0-9.]+) solveTime_us ([0-9.]+) solveAndBuildTime_us ([0-9.]+)",
+                  r.stdout)
+    if r.returncode != 0 or not m:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    med, mean, mn, p95, st, sbt = (float(v) for v in m.groups())
+    return {"median_us": med, "mean_us": mean, "min_us": mn, "p95_us": p95, "device_solveTime_us": st,
+            "solves_per_s": 1e6 / med, "calls": 1000,
+            "what": "wall time of copra::LMPC::solve() (C++ mirror, batch 1, CoM nx=6 nu=3 N=20 with both bound constraints): "
+                    "xInit -> H2D of x0, two launches, one synchronisation, one pinned copy of [U | X | status | iter]"}
+
+
+def host_inclusive_pipelined(np, torch, dev, b=65536, chunks=4, passes=6):
+    """numpy in, numpy out over PCIe with PINNED staging: the caller's numpy arrays are views of pinned buffers (inputs in numpy's
+    row-major indexing, results as [U | X | status | iter] slabs); the batch goes through `chunks` engines on their own streams --
+    H2D of chunk k + 1, layout conversion (a kernel of the library: copra_batch_set_system_rowmajor_async) and solve of chunk k
+    and D2H of chunk k - 1 overlap.  Whole-job wall time, every pass moves every byte."""
+    from copra_amd import BatchLMPC, workloads
+    from copra_amd.sharding import alloc_result_slab
+    wl = workloads.com_preview(b)
+    N, per = wl["N"], b // chunks
+    n, X = 3 * N, 6 * (N + 1)
+    eng, streams, hin, din, slabs, hout = [], [], [], [], [], []
+    for c in range(chunks):
+        lo, hi = c * per, (c + 1) * per
+        eng.append(BatchLMPC(6, 3, N, per, wl["costs"], wl["cstrs"]))
+        streams.append(torch.cuda.Stream(device=dev))
+        h = [torch.from_numpy(np.ascontiguousarray(wl[k][lo:hi])).pin_memory() for k in ("A", "B", "d", "x0")]
+        hin.append(h)
+        din.append([torch.empty_like(t, device=dev) for t in h])
+        slab, views = alloc_result_slab(per, n, X, dev)
+        slabs.append((slab, views))
+        hout.append(torch.empty(slab.shape, dtype=slab.dtype).pin_memory())
+        eng[c].set_outputs(views["control"], views["trajectory"], views["status"], views["iter"])
+
+    def one_pass():
+        for c in range(chunks):
+            with torch.cuda.stream(streams[c]):
+                for t_h, t_d in zip(hin[c], din[c]):
+                    t_d.copy_(t_h, non_blocking=True)
+                eng[c].set_system_rowmajor_async(*din[c], stream=streams[c].cuda_stream)
+                eng[c].solve(streams[c].cuda_stream)
+                hout[c].copy_(slabs[c][0], non_blocking=True)
+    one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    from copra_amd.sharding import split_slab
+    st = split_slab(hout[0], per, n, X)["status"].numpy()
+    for e in eng:
+        e.close()
+    return {"solves_per_s": passes * b / dt, "ms_per_batch": dt / passes * 1e3, "batch": b, "chunks": chunks,
+            "solved_ok_first_chunk": int((st == 0).sum()),
+            "note": "2028 B/solve over PCIe through pinned buffers, %d chunks on their own streams (copies, layout kernel and "
+                    "solves overlap), wall time of %d passes" % (chunks, passes)}
+
+
 def extra_measurements(np, torch, dev):
-    """The other BASELINE configs and SURVEY 8(d)'s side figures; every number is a device-resident kernel rate unless
-    its name says otherwise."""
+    """The other BASELINE configs and SURVEY 8(d)'s side figures.  Every `solves_per_s` here that carries `timing: EVENT_TIMING`
+    is a device-resident rate of a single solve from HIP events (best of a few) -- not comparable digit for digit with the
+    headline `value`, which is the mean over wall-clock steps; the host-inclusive and latency entries are wall-clock."""
     from copra_amd import BatchLMPC, workloads
     from copra_amd.batch import to_abi_layout
     out = {}
@@ -105,7 +175,7 @@ def extra_measurements(np, torch, dev):
         t = on_device(wl)
         eng.set_system(*t)
         rate, sec = timed_rate(eng, b)
-        out["config2_double_integrator_batch%d" % b] = {"solves_per_s": rate, "kernel_ms": sec * 1e3,
+        out["config2_double_integrator_batch%d" % b] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5,
                                                         "lanes_per_instance": eng.lanes_per_instance()}
         eng.close()
     # BASELINE configs[4]: InitialStateLMPC (12, 6, 50) at its full batch, on both long-horizon solvers
@@ -120,8 +190,8 @@ def extra_measurements(np, torch, dev):
         rate, sec = timed_rate(eng, bb, reps=2)
         res = eng.results()
         out["config5_initial_state_12_6_50_%s" % eng.solver()] = {
-            "batch": bb, "solves_per_s": rate, "kernel_ms": sec * 1e3, "solved_ok": int((res["status"] == 0).sum()),
-            "mean_iterations": float(res["iter"][:, 0].mean()),
+            "batch": bb, "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 2,
+            "solved_ok": int((res["status"] == 0).sum()), "mean_iterations": float(res["iter"][:, 0].mean()),
             "algorithmic_GBps": 9216.0 * rate / 1e9}  # 1920 B in + 7296 B out per solve
         eng.close()
     # headline shape, shared model (receding-horizon tick: one (A, B, d) for the batch, only x0 differs)
@@ -131,7 +201,7 @@ def extra_measurements(np, torch, dev):
     eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
     eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
     rate, sec = timed_rate(eng, b)
-    out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3}
+    out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5}
     eng.close()
     # sensitivity: the tight workload (v_max 0.25 / u_max 1.2: every instance activates 3..22 constraints; the factor-only
     # layout steps down its ladder) -- the headline number depends on <= 5 active constraints per instance
@@ -143,8 +213,23 @@ def extra_measurements(np, torch, dev):
         eng.solve()
     rate, sec = timed_rate(eng, b)
     it = eng.results()["iter"][:, 0]
-    out["tight_workload_vmax0.25_umax1.2"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3,
+    out["tight_workload_vmax0.25_umax1.2"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5,
                                               "mean_active_set_iters": float(it.mean()), "max_active_set_iters": int(it.max())}
+    eng.close()
+    # the dense Psi' W Psi contraction on v_mfma_f64_16x16x4 (north star: "MFMA used only for the dense contraction"): the
+    # TrajectoryCost handed over as a full-size entry (126 x 126 M) -- MFMA-busy share of that path: profiles/ (rocprofv3 --pmc)
+    from copra_amd.autospan import autospan_cost
+    wl = workloads.com_preview(b)
+    c0 = wl["costs"][0]
+    dense_costs = [autospan_cost(dict(c0, p=np.tile(c0["p"], wl["N"] + 1))), wl["costs"][1]]
+    eng = BatchLMPC(6, 3, wl["N"], b, dense_costs, wl["cstrs"])
+    t = on_device(wl)
+    eng.set_system(*t)
+    rate, sec = timed_rate(eng, b, reps=3)
+    out["dense_hessian_mfma_f64_16x16x4_batch65536"] = {
+        "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3,
+        "mfma_flops_per_solve": 976 * 2048,  # 976 v_mfma_f64_16x16x4 per solve (profiles/r02/pmc_dense_mfma_path.json)
+        "executed_mfma_tflops": 976 * 2048 * rate / 1e12}
     eng.close()
     # host-inclusive: numpy inputs -> layout conversion -> pageable H2D -> solve -> D2H of U, X, status
     wl = workloads.com_preview(b)
@@ -158,8 +243,16 @@ def extra_measurements(np, torch, dev):
         eng.solve()
         eng.results()
     out["host_inclusive_numpy_in_numpy_out"] = {"solves_per_s": 3 * b / (time.perf_counter() - t0),
-                                                "note": "2016 B/solve over PCIe (pageable) + layout conversion on the host"}
+                                                "note": "2016 B/solve over PCIe (pageable) + layout conversion on the host; wall clock"}
     eng.close()
+    try:
+        out["host_inclusive_pinned_pipelined"] = host_inclusive_pipelined(np, torch, dev)
+    except Exception as e:
+        out["host_inclusive_pinned_pipelined"] = {"error": repr(e)}
+    try:
+        out["single_problem_latency_cpp_mirror"] = cpp_single_solve_latency()
+    except Exception as e:
+        out["single_problem_latency_cpp_mirror"] = {"error": repr(e)}
     return out
 
 
@@ -184,6 +277,14 @@ def main():
                     help="(single GPU) run the N > 1 code path for real with a one-rank RCCL process group: "
                          "init_process_group('nccl'), dist.gather of the result slab on the side stream, barrier, "
                          "all_reduce of the timing, verification of the gathered slab")
+    ap.add_argument("--payload", choices=["full", "controls"], default="full",
+                    help="N > 1: what the one gather per step carries: the whole result [U | status | iter | X] (default: what the "
+                         "north star asks for, 1500 B per instance) or only [U | status | iter] (492 B; X is the roll-out of U and "
+                         "rank 0 reproduces it) -- for nodes whose xGMI links, not the kernel, bound the step")
+    ap.add_argument("--selftest-rccl2", action="store_true",
+                    help="(two or more GPUs visible) spawn a world-2 RCCL run of this benchmark -- one process per GPU -- and fail "
+                         "unless both ranks took part (dist.get_world_size() == 2), the gathered slabs match their checksums and an "
+                         "oracle sample of every shard agrees; the first thing to run on a multi-GPU box")
     ap.add_argument("--selftest-overlap", action="store_true",
                     help="(single GPU) exercise the double-buffer / side-stream plumbing of the N > 1 path with a "
                          "device copy standing in for the RCCL gather")
@@ -192,6 +293,22 @@ def main():
     import numpy as np
     import torch  # first: libcopra_hip.so then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
+
+    if args.selftest_rccl2:
+        # (counting devices does not initialise the GPU: the two ranks are CHILD processes, started before anything here touches it)
+        import subprocess
+        if torch.cuda.device_count() < 2:
+            raise SystemExit("--selftest-rccl2 needs two visible GPUs (found %d)" % torch.cuda.device_count())
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29531", os.path.abspath(__file__), "--gpus", "2", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--payload", args.payload, "--no-extra"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+        line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+        mg = (line or {}).get("multi_gpu_check", {})
+        ok = (line is not None and line["n_gpus"] == 2 and mg.get("ranks") == 2 and mg.get("rccl_world_size") == 2
+              and mg.get("gathered_slabs_match_per_rank_checksums") and mg.get("status_agree") and mg.get("max_rel_u_err", 1.0) <= 1e-6)
+        print(json.dumps({"selftest_rccl2": bool(ok), "line": line, "stderr_tail": r.stderr[-800:] if not ok else ""}), flush=True)
+        raise SystemExit(0 if ok else 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +329,7 @@ def main():
 
     from copra_amd import BatchLMPC, workloads
     from copra_amd.batch import to_abi_layout
-    from copra_amd.sharding import GatherLoop, alloc_result_slab, shard_range, split_slab
+    from copra_amd.sharding import GatherLoop, alloc_result_slab, head_bytes, rollout_trajectory, shard_range, split_slab
 
     nx, nu, N = 6, 3, 20
     n, X = nu * N, nx * (N + 1)
@@ -260,7 +377,20 @@ def main():
         eng.set_outputs(v["control"], v["trajectory"], v["status"], v["iter"])
         eng.solve(stream)
 
-    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=use_dist, overlap=overlap, force_gather=args.selftest_rccl)
+    payload_bytes = head_bytes(batch, n, X) if args.payload == "controls" else None
+    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=use_dist, overlap=overlap, force_gather=args.selftest_rccl,
+                      payload_bytes=payload_bytes)
+    # the device at the clock it has when work arrives after an idle period (see below): a few timed steps BEFORE the spin-up
+    cold_ms = None
+    if world == 1 and not comm_path:
+        solve_into(views0, 0)  # (module load, LDS opt-in, layout controller)
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+        t0c = time.perf_counter()
+        for _ in range(5):
+            solve_into(views0, 0)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - t0c) / 5 * 1e3
 
     # Clock ramp: the first ~25 launches after an idle period run at a lower shader clock (kernel 751 us -> 690 us over them,
     # profiles/r02/dispatch_timeline.txt).  A fixed number of untimed solves -- about 30 ms -- gets the device to its steady
@@ -293,7 +423,15 @@ def main():
     if comm_path:
         ok_sum, sums = loop.verify()
         if rank == 0:
-            multi = {"gathered_slabs_match_per_rank_checksums": bool(ok_sum), "ranks": world}
+            sent = payload_bytes if payload_bytes is not None else slabs[0][0].numel()
+            step_s = elapsed / args.steps
+            multi = {"gathered_slabs_match_per_rank_checksums": bool(ok_sum), "ranks": world,
+                     "rccl_world_size": dist.get_world_size() if use_dist else 1, "payload": args.payload,
+                     "payload_bytes_per_rank_per_step": int(sent),
+                     # each peer reaches rank 0 over its own xGMI link (7 links x ~153 GB/s per GPU): what the measured step asks of one
+                     # link if the gather fills it, and what the gather alone would take at the nominal link rate
+                     "per_link_GBps_if_gather_filled_the_step": sent / step_s / 1e9,
+                     "gather_ms_at_nominal_153_GBps_per_link": sent / 153e9 * 1e3, "measured_ms_per_step": step_s * 1e3}
             if use_dist and not args.dense_hessian:
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))
                 import pyoracle
@@ -307,6 +445,12 @@ def main():
                                                     gw["x0"][glo:ghi][pick], N, gw["costs"], gw["cstrs"])
                     u = part["control"].cpu().numpy()[pick]
                     st = part["status"].cpu().numpy()[pick]
+                    if args.payload == "controls":  # X did not travel: rank 0 reproduces it by the roll-out and it must be the oracle's
+                        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                        xr = rollout_trajectory(tt(gw["A"][glo:ghi][pick]), tt(gw["B"][glo:ghi][pick]), tt(gw["d"][glo:ghi][pick]),
+                                                tt(gw["x0"][glo:ghi][pick]), part["control"][torch.from_numpy(pick).to(dev)]).cpu().numpy()
+                        okx = ref["status"] == 0
+                        worst = max(worst, float(np.nanmax(np.abs(xr[okx] - ref["trajectory"][okx]) / (1.0 + np.abs(ref["trajectory"][okx])))))
                     agree = agree and bool((st == ref["status"]).all())
                     okm = ref["status"] == 0
                     worst = max(worst, float(np.nanmax(np.abs(u[okm] - ref["control"][okm]) / (1.0 + np.abs(ref["control"][okm])))))
@@ -340,7 +484,7 @@ def main():
         dominant = "copra_lmpc_fused_ric_kernel"  # (plan_builder.hpp: what the headline controller runs on)
         prof = os.path.join(ROOT, PMC_SUMMARY)
         if not os.path.exists(prof):
-            prof = os.path.join(ROOT, "profiles", "r01", "headline_rocprof_summary_final.json")
+            prof = os.path.join(ROOT, "profiles", "r02", "headline_rocprof_summary.json")
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
                 ctr = json.load(open(prof))["counters"]
@@ -373,6 +517,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "spin_up_solves": SPIN_UP_SOLVES,
+            "cold_clock_ms_per_step": cold_ms,  # five steps after half a second of idle, before the spin-up: the clock a sporadic caller gets
+            "cold_clock_solves_per_s": (batch / (cold_ms * 1e-3)) if cold_ms else None,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

@@ -250,6 +250,8 @@ def lib():
         L.copra_batch_qp_sizes.argtypes = [vp, _ip, _ip, _ip]
         L.copra_batch_dump_qp.restype = C.c_int
         L.copra_batch_dump_qp.argtypes = [vp, C.c_int] + [vp] * 8
+        L.copra_batch_set_system_rowmajor_async.restype = C.c_int
+        L.copra_batch_set_system_rowmajor_async.argtypes = [vp, vp, vp, vp, vp, vp]
         L.copra_batch_last_solve_seconds.restype = C.c_int
         L.copra_batch_last_solve_seconds.argtypes = [vp, _dp]
         L.copra_batch_last_first_tier_seconds.restype = C.c_int

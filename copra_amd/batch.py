@@ -94,6 +94,15 @@ class BatchLMPC:
             _capi.check(self._lib.copra_batch_set_system(self._h, Ab.ctypes.data, Bb.ctypes.data, db.ctypes.data,
                                                          xb.ctypes.data, 0))
 
+    def set_system_rowmajor_async(self, A, B, d, x0, stream=None):
+        """torch CUDA tensors in numpy's natural (row-major) indexing, (b,nx,nx), (b,nx,nu), (b,nx), (b,nx): the library
+        transposes A and B on `stream` (an integer hipStream_t handle); nothing blocks the host"""
+        self._sys = (A, B, d, x0)
+        for t in self._sys:
+            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float64"
+        _capi.check(self._lib.copra_batch_set_system_rowmajor_async(self._h, A.data_ptr(), B.data_ptr(), d.data_ptr(), x0.data_ptr(),
+                                                                    C.c_void_p(stream or 0)))
+
     # PreviewSystem::xInit for every instance
     def set_shared_system(self, A, B, d):
         """Shared-model receding-horizon fast path: ONE system (A (nx,nx), B (nx,nu), d (nx)) for the whole batch;

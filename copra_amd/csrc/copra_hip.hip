@@ -351,6 +351,8 @@ hipError_t upload(T** dst, const std::vector<T>& src)
 
 } // namespace
 
+constexpr size_t kSmallSlab = 1u << 20; // result slabs up to this size are fetched with one copy through pinned memory
+
 struct copra_batch {
     HostPlan hp;
     // device copies of the plan tables
@@ -362,8 +364,11 @@ struct copra_batch {
     double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
     const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
     // results
-    double *d_control = nullptr, *d_traj = nullptr;
+    double *d_control = nullptr, *d_traj = nullptr; // (carved from ONE allocation, d_results: small batches fetch it with one copy)
     int *d_status = nullptr, *d_iter = nullptr;
+    unsigned char* d_results = nullptr;
+    size_t results_bytes = 0, off_traj = 0, off_status = 0, off_iter = 0;
+    unsigned char* h_results = nullptr; // pinned staging copy of the slab (batches whose slab is at most kSmallSlab bytes)
     // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
     double *ext_control = nullptr, *ext_traj = nullptr;
     int *ext_status = nullptr, *ext_iter = nullptr;
@@ -687,7 +692,7 @@ static bool use_riccati(copra_batch* h)
 
 extern "C" {
 
-int copra_abi_version(void) { return 2; }
+int copra_abi_version(void) { return 3; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async
 
 copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
     double* Psi, double* xi)
@@ -830,10 +835,21 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     chk(upload(&h->d_lb, h->hp.lb));
     chk(upload(&h->d_ub, h->hp.ub));
     const size_t b = (size_t)(P.batch > 0 ? P.batch : 1);
-    chk(hipMalloc((void**)&h->d_control, b * P.n * sizeof(double)));
-    chk(hipMalloc((void**)&h->d_traj, b * P.X * sizeof(double)));
-    chk(hipMalloc((void**)&h->d_status, b * sizeof(int)));
-    chk(hipMalloc((void**)&h->d_iter, b * 2 * sizeof(int)));
+    { // result slab [U | X | status | iter], every part 256-byte aligned
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        h->off_traj = up(b * P.n * sizeof(double));
+        h->off_status = h->off_traj + up(b * P.X * sizeof(double));
+        h->off_iter = h->off_status + up(b * sizeof(int));
+        h->results_bytes = h->off_iter + up(b * 2 * sizeof(int));
+        chk(hipMalloc((void**)&h->d_results, h->results_bytes));
+        if (h->d_results) {
+            h->d_control = reinterpret_cast<double*>(h->d_results);
+            h->d_traj = reinterpret_cast<double*>(h->d_results + h->off_traj);
+            h->d_status = reinterpret_cast<int*>(h->d_results + h->off_status);
+            h->d_iter = reinterpret_cast<int*>(h->d_results + h->off_iter);
+        }
+        if (h->results_bytes <= kSmallSlab) chk(hipHostMalloc((void**)&h->h_results, h->results_bytes, hipHostMallocDefault));
+    }
     if (is) {
         chk(upload(&h->d_isR, h->hp.isR));
         chk(upload(&h->d_isr, h->hp.isr));
@@ -891,10 +907,8 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->own_B);
     (void)hipFree(h->own_d);
     (void)hipFree(h->own_x0);
-    (void)hipFree(h->d_control);
-    (void)hipFree(h->d_traj);
-    (void)hipFree(h->d_status);
-    (void)hipFree(h->d_iter);
+    (void)hipFree(h->d_results);
+    if (h->h_results) (void)hipHostFree(h->h_results);
     (void)hipFree(h->d_prof);
     (void)hipFree(h->d_isR);
     (void)hipFree(h->d_isr);
@@ -952,6 +966,42 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     h->B = h->own_B;
     h->d = h->own_d;
     h->x0 = h->own_x0;
+    return COPRA_OK;
+}
+
+// [batch][rows x cols] row-major -> per-instance column-major (what Eigen holds and every kernel here reads)
+__global__ void copra_rowmajor_to_colmajor_kernel(const double* __restrict__ src, double* __restrict__ dst, int rows, int cols,
+    long long total)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int per = rows * cols;
+    const long long inst = e / per;
+    const int w = (int)(e - inst * per), j = w / rows, i = w - j * rows; // destination: column j, row i
+    dst[e] = src[inst * per + (long long)i * cols + j];
+}
+
+copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const double* A, const double* B, const double* d,
+    const double* x0, void* hip_stream)
+{
+    if (!h || !A || !B || !d || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_system_rowmajor_async: null argument");
+    const FusedPlan& P = h->hp.plan;
+    const size_t b = (size_t)P.batch;
+    const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
+    h->shared = false;
+    if (!h->own_A) {
+        HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&h->own_d, (nd ? nd : 1) * sizeof(double)));
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (nA) hipLaunchKernelGGL(copra_rowmajor_to_colmajor_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, A, h->own_A, P.nx, P.nx, (long long)nA);
+    if (nB) hipLaunchKernelGGL(copra_rowmajor_to_colmajor_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, s, B, h->own_B, P.nx, P.nu, (long long)nB);
+    HIP_TRY(hipGetLastError());
+    h->A = h->own_A;
+    h->B = h->own_B;
+    h->d = d; // (vectors have no layout: used in place)
+    h->x0 = x0;
     return COPRA_OK;
 }
 
@@ -1671,6 +1721,17 @@ copra_status_t copra_batch_get_results(copra_batch_t* h, double* control, double
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_get_results: null handle");
     const FusedPlan& P = h->hp.plan;
     const size_t b = (size_t)P.batch;
+    if (h->h_results && !h->ext_control && !h->ext_traj && !h->ext_status && !h->ext_iter) {
+        // small batch (the single-problem use of copra::LMPC::solve() above all): ONE asynchronous copy of the whole slab into
+        // pinned memory behind the solve, one synchronisation -- instead of a stream synchronisation and four blocking copies
+        HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, h->results_bytes, hipMemcpyDeviceToHost, h->last_stream));
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+        if (control) std::memcpy(control, h->h_results, b * P.n * sizeof(double));
+        if (trajectory) std::memcpy(trajectory, h->h_results + h->off_traj, b * P.X * sizeof(double));
+        if (status) std::memcpy(status, h->h_results + h->off_status, b * sizeof(int));
+        if (iter) std::memcpy(iter, h->h_results + h->off_iter, b * 2 * sizeof(int));
+        return COPRA_OK;
+    }
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     if (control) HIP_TRY(hipMemcpy(control, copra_batch_control_device(h), b * P.n * sizeof(double), hipMemcpyDeviceToHost));
     if (trajectory) HIP_TRY(hipMemcpy(trajectory, copra_batch_trajectory_device(h), b * P.X * sizeof(double), hipMemcpyDeviceToHost));

@@ -14,38 +14,58 @@ def shard_range(total, rank, world):
 
 
 def slab_layout(batch, n, X):
-    """byte offsets of the four result arrays inside one flat slab (all 8-byte aligned)"""
+    """byte offsets of the four result arrays inside one flat slab (all 8-byte aligned): [U | status | iter | X].  The
+    trajectory comes LAST so that the head of the slab -- controls, status, iteration counts: 492 of the 1500 bytes per instance at
+    the headline shape -- is a contiguous prefix: the payload a caller may choose to gather instead of the whole slab (X is the
+    roll-out of U, `rollout_trajectory` reproduces it on the receiving side)."""
     off_u = 0
-    off_x = off_u + batch * n * 8
-    off_s = off_x + batch * X * 8
+    off_s = off_u + batch * n * 8
     off_i = off_s + ((batch * 4 + 7) // 8) * 8
-    total = off_i + batch * 2 * 4
-    total = ((total + 7) // 8) * 8
+    off_x = off_i + batch * 2 * 4
+    off_x = ((off_x + 7) // 8) * 8
+    total = off_x + batch * X * 8
     return off_u, off_x, off_s, off_i, total
 
 
-def alloc_result_slab(batch, n, X, device):
-    """One flat byte buffer holding control [b,n] f64, trajectory [b,X] f64, status [b] i32, iter [b,2] i32.
-    The typed views alias the slab, so the engine writes straight into what the gather sends (no packing copy)."""
+def head_bytes(batch, n, X):
+    """bytes of the [U | status | iter] prefix of a slab"""
+    return slab_layout(batch, n, X)[1]
+
+
+def _views(slab, batch, n, X):
     off_u, off_x, off_s, off_i, total = slab_layout(batch, n, X)
-    slab = torch.zeros(total, dtype=torch.uint8, device=device)
-    views = dict(
-        control=slab[off_u:off_x].view(torch.float64).view(batch, n),
-        trajectory=slab[off_x:off_s].view(torch.float64).view(batch, X),
+    return dict(
+        control=slab[off_u:off_u + batch * n * 8].view(torch.float64).view(batch, n),
+        trajectory=slab[off_x:off_x + batch * X * 8].view(torch.float64).view(batch, X),
         status=slab[off_s:off_s + batch * 4].view(torch.int32),
         iter=slab[off_i:off_i + batch * 8].view(torch.int32).view(batch, 2),
     )
-    return slab, views
+
+
+def alloc_result_slab(batch, n, X, device):
+    """One flat byte buffer holding control [b,n] f64, status [b] i32, iter [b,2] i32, trajectory [b,X] f64.
+    The typed views alias the slab, so the engine writes straight into what the gather sends (no packing copy)."""
+    total = slab_layout(batch, n, X)[4]
+    slab = torch.zeros(total, dtype=torch.uint8, device=device)
+    return slab, _views(slab, batch, n, X)
 
 
 def split_slab(slab, batch, n, X):
-    off_u, off_x, off_s, off_i, total = slab_layout(batch, n, X)
-    return dict(
-        control=slab[off_u:off_x].view(torch.float64).view(batch, n),
-        trajectory=slab[off_x:off_s].view(torch.float64).view(batch, X),
-        status=slab[off_s:off_s + batch * 4].view(torch.int32),
-        iter=slab[off_i:off_i + batch * 8].view(torch.int32).view(batch, 2),
-    )
+    return _views(slab, batch, n, X)
+
+
+def rollout_trajectory(A, B, d, x0, control):
+    """X = Phi x0 + Psi U + xi as the roll-out x_{k+1} = A x_k + B u_k + d (src/LMPC.cpp:282-286) for a batch, torch tensors in natural
+    indexing: A (b,nx,nx), B (b,nx,nu), d (b,nx), x0 (b,nx), control (b, N nu) -> (b, (N+1) nx).  What rank 0 runs when only
+    the [U | status | iter] head of the slabs was gathered."""
+    b, nx = x0.shape
+    nu = B.shape[2]
+    N = control.shape[1] // nu
+    u = control.view(b, N, nu)
+    xs = [x0]
+    for k in range(N):
+        xs.append(torch.bmm(A, xs[-1].unsqueeze(2)).squeeze(2) + torch.bmm(B, u[:, k].unsqueeze(2)).squeeze(2) + d)
+    return torch.stack(xs, dim=1).reshape(b, (N + 1) * nx)
 
 
 def alloc_gather_buffers(slab, rank, world):
@@ -54,11 +74,15 @@ def alloc_gather_buffers(slab, rank, world):
     return [torch.empty_like(slab) for _ in range(world)]
 
 
-def gather_results(slab, rank, world, bufs, dst=0, force=False):
-    """the single collective of the path: every rank's slab -> rank `dst` (force: also with a one-rank group)"""
+def gather_results(slab, rank, world, bufs, dst=0, force=False, nbytes=None):
+    """the single collective of the path: every rank's slab -> rank `dst` (force: also with a one-rank group); nbytes: only that
+    prefix of the slab travels (head_bytes: [U | status | iter])"""
     if world == 1 and not force:
         return [slab]
-    dist.gather(slab, gather_list=bufs if rank == dst else None, dst=dst)
+    if nbytes is None:
+        dist.gather(slab, gather_list=bufs if rank == dst else None, dst=dst)
+    else:
+        dist.gather(slab[:nbytes], gather_list=[t[:nbytes] for t in bufs] if rank == dst else None, dst=dst)
     return bufs
 
 
@@ -81,9 +105,10 @@ class GatherLoop:
     previous gather has finished.  `solve(views, k)` fills the four typed views of slab k (the engine writes straight
     into them); on a CUDA device it must launch on the current stream.  verify() is the end-to-end check of the path."""
 
-    def __init__(self, slabs, rank, world, solve, device, use_dist=True, overlap=False, force_gather=False):
+    def __init__(self, slabs, rank, world, solve, device, use_dist=True, overlap=False, force_gather=False, payload_bytes=None):
         self.slabs, self.rank, self.world, self.solve = slabs, rank, world, solve
         self.use_dist, self.force = use_dist, force_gather
+        self.payload_bytes = payload_bytes  # None: the whole slab [U | status | iter | X]; head_bytes(...): without X
         self.n_slabs = len(slabs)
         self.cuda = device.type == "cuda"
         self.overlap = overlap and self.n_slabs > 1
@@ -105,9 +130,10 @@ class GatherLoop:
 
     def send(self, k):
         if self.use_dist:
-            gather_results(self.slabs[k][0], self.rank, self.world, self.gather_bufs[k], force=self.force)
+            gather_results(self.slabs[k][0], self.rank, self.world, self.gather_bufs[k], force=self.force, nbytes=self.payload_bytes)
         else:
-            self.gather_bufs[k][0].copy_(self.slabs[k][0], non_blocking=True)
+            nb = self.payload_bytes if self.payload_bytes is not None else self.slabs[k][0].numel()
+            self.gather_bufs[k][0][:nb].copy_(self.slabs[k][0][:nb], non_blocking=True)
 
     def step(self, communicate=True):
         k = self.step_no % self.n_slabs
@@ -135,14 +161,15 @@ class GatherLoop:
         raw bytes), the checksums are all-gathered, and rank 0 compares them with the checksums of what it received.
         Returns (ok, per-rank checksums) on rank 0, (True, None) elsewhere."""
         k = self.last
-        mine = self.slabs[k][0].view(torch.int64).sum().reshape(1)
+        nb = self.payload_bytes if self.payload_bytes is not None else self.slabs[k][0].numel()
+        mine = self.slabs[k][0][:nb].view(torch.int64).sum().reshape(1)
         if not self.use_dist:
-            return bool(torch.equal(self.gather_bufs[k][0], self.slabs[k][0])), [int(mine.item())]
+            return bool(torch.equal(self.gather_bufs[k][0][:nb], self.slabs[k][0][:nb])), [int(mine.item())]
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(every, mine)
         if self.rank != 0:
             return True, None
-        got = [int(b.view(torch.int64).sum().item()) for b in self.gather_bufs[k]]
+        got = [int(b[:nb].view(torch.int64).sum().item()) for b in self.gather_bufs[k]]
         sent = [int(t.item()) for t in every]
         return got == sent, sent
 

@@ -172,6 +172,12 @@ copra_status_t copra_batch_get_initial_state(copra_batch_t* h, double* x0_opt);
 copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const double* B, const double* d,
     const double* x0, int on_device);
 copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device);
+/* ---- the same from ROW-major per-instance matrices that are already on the device (what C arrays and numpy hold; Eigen --
+ *      src/PreviewSystem.cpp:16-55 takes Eigen matrices -- and every other entry point here are column-major): the library
+ *      transposes A and B into buffers of its own with a kernel on `hip_stream` (no host-side layout conversion, nothing
+ *      blocks); d and x0 are used in place.  For host pipelines that stage pinned buffers asynchronously. ---- */
+copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const double* A, const double* B, const double* d,
+    const double* x0, void* hip_stream);
 
 /* ---- per-instance references: p of cost `cost_index` (the order of the `costs` array given at creation) for EVERY
  *      instance, [batch][rows] with the rows of that cost as created (per-step entry: r, full-size entry: r (N+1) or

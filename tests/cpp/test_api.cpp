@@ -669,6 +669,68 @@ static void plugin_cases(int nbStep)
     }
 }
 
+// What a drop-in user sees for ONE problem: the headline controller (CoM preview, nx = 6, nu = 3, N = 20, TrajectoryCost +
+// ControlCost, 63 velocity rows + control bounds; binding/python/tests/pyTests.py:342-359 constants) built through the mirror's
+// classes and solved with copra::LMPC::solve() -- one launch, one synchronisation, two result copies per call -- `reps` times
+// with a new measured state each time (ps->xInit, PreviewSystem.h:52).  Prints wall microseconds per solve() (median, mean) and
+// the mirror's own solveTime() / solveAndBuildTime() of the last call: the figure to put next to the CPU path's.
+#include <algorithm>
+#include <chrono>
+static void latency_case(int reps)
+{
+    using namespace Eigen;
+    const int nbStep = 20;
+    const double T = 0.117;
+    MatrixXd A = MatrixXd::Identity(6, 6), B = MatrixXd::Zero(6, 3);
+    for (int i = 0; i < 3; ++i) {
+        A(i, 3 + i) = T;
+        B(i, i) = 0.5 * T * T;
+        B(3 + i, i) = T;
+    }
+    VectorXd d = VectorXd::Zero(6), x0(6), goal(6), wx(6), wu(3), lo(6), up(6), ulo(3), uup(3);
+    x0 << 0.2, 0.1, 0.8, 0.05, -0.1, 0.0;
+    goal << 1.0, 0.6, 0.8, 0.0, 0.0, 0.0;
+    wx << 10, 10, 10, 1, 1, 1;
+    wu << 1e-3, 1e-3, 1e-3;
+    const double inf = std::numeric_limits<double>::infinity();
+    lo << -inf, -inf, -inf, -inf, -inf, -inf;
+    up << inf, inf, inf, 0.6, 0.6, 0.6;
+    ulo << -3, -3, -3;
+    uup << 3, 3, 3;
+    auto ps = std::make_shared<copra::PreviewSystem>();
+    ps->system(A, B, d, x0, nbStep);
+    copra::LMPC controller(ps);
+    auto xCost = std::make_shared<copra::TrajectoryCost>(MatrixXd::Identity(6, 6), goal);
+    xCost->weights(wx);
+    auto uCost = std::make_shared<copra::ControlCost>(MatrixXd::Identity(3, 3), VectorXd::Zero(3));
+    uCost->weights(wu);
+    auto xBound = std::make_shared<copra::TrajectoryBoundConstraint>(lo, up);
+    auto uBound = std::make_shared<copra::ControlBoundConstraint>(ulo, uup);
+    controller.addCost(xCost);
+    controller.addCost(uCost);
+    controller.addConstraint(xBound);
+    controller.addConstraint(uBound);
+    for (int i = 0; i < 20; ++i) CHECK(controller.solve()); // (first calls: plan, handle, module load)
+    std::vector<double> us;
+    VectorXd x = x0;
+    for (int i = 0; i < reps; ++i) {
+        x(0) = 0.2 + 0.001 * (i % 17);
+        ps->xInit(x);
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool ok = controller.solve();
+        const auto t1 = std::chrono::steady_clock::now();
+        CHECK(ok);
+        us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+    }
+    std::sort(us.begin(), us.end());
+    double mean = 0.0;
+    for (double v : us) mean += v;
+    mean /= (double)us.size();
+    std::printf("latency_us median %.2f mean %.2f min %.2f p95 %.2f solveTime_us %.2f solveAndBuildTime_us %.2f control0 %.9f\n",
+        us[us.size() / 2], mean, us.front(), us[(size_t)(0.95 * us.size())], controller.solveTime() * 1e6,
+        controller.solveAndBuildTime() * 1e6, controller.control()(0));
+}
+
 int main(int argc, char** argv)
 {
     std::setvbuf(stdout, nullptr, _IONBF, 0);
@@ -678,6 +740,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
         if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
+        if (!std::strcmp(mode, "latency")) latency_case(argc > 2 ? std::atoi(argv[2]) : 500);
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());
         return 2;

@@ -44,8 +44,11 @@ def test_extra_measurements_outside_the_timed_region():
     assert "error" not in ex, ex
     for key in ("config2_double_integrator_batch4096", "config5_initial_state_12_6_50_riccati_ipm",
                 "config5_initial_state_12_6_50_quadprog_dense", "shared_model_tick_batch65536",
-                "tight_workload_vmax0.25_umax1.2", "host_inclusive_numpy_in_numpy_out"):
+                "tight_workload_vmax0.25_umax1.2", "host_inclusive_numpy_in_numpy_out", "host_inclusive_pinned_pipelined",
+                "dense_hessian_mfma_f64_16x16x4_batch65536", "single_problem_latency_cpp_mirror"):
+        assert "error" not in ex[key], (key, ex[key])
         assert ex[key]["solves_per_s"] > 0, key
+    assert ex["single_problem_latency_cpp_mirror"]["median_us"] > 0 and out["cold_clock_ms_per_step"] > 0
     assert ex["config5_initial_state_12_6_50_riccati_ipm"]["solved_ok"] == 16384
 
 
@@ -55,3 +58,27 @@ def test_multi_gpu_code_path_with_one_rank_rccl():
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
     mg = out["multi_gpu_check"]  # rank 0 verified what it gathered: checksums + an oracle sample of the shard
     assert mg["gathered_slabs_match_per_rank_checksums"] and mg["status_agree"] and mg["max_rel_u_err"] <= 1e-6
+
+
+@pytest.mark.gpu
+def test_multi_gpu_code_path_controls_only_payload():
+    """--payload controls: the gather carries [U | status | iter] (492 of 1500 bytes per instance), rank 0 reproduces X by the
+    roll-out and the oracle sample checks BOTH; the line says what travelled and what it asks of one xGMI link"""
+    out = _run("--no-cpu-baseline", "--selftest-rccl", "--payload", "controls")
+    mg = out["multi_gpu_check"]
+    assert mg["payload"] == "controls" and mg["payload_bytes_per_rank_per_step"] < 4096 * 500
+    assert mg["gathered_slabs_match_per_rank_checksums"] and mg["status_agree"] and mg["max_rel_u_err"] <= 1e-6
+    assert mg["rccl_world_size"] == 1 and mg["gather_ms_at_nominal_153_GBps_per_link"] > 0
+
+
+@pytest.mark.gpu
+def test_world_2_rccl_selftest_when_two_gpus_are_visible():
+    """the first thing to run on a multi-GPU box: two processes, one per GPU, RCCL gather; fails unless RCCL really saw two
+    ranks and rank 0 verified both shards (skipped on the single-GPU boxes this repo is developed on)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-rccl2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["selftest_rccl2"] is True

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, out_path, overlap):
+def _worker(rank, world, port, total, out_path, overlap, payload):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -31,7 +31,7 @@ def _worker(rank, world, port, total, out_path, overlap):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import pyoracle
     from copra_amd import workloads
-    from copra_amd.sharding import GatherLoop, alloc_result_slab, shard_range, split_slab
+    from copra_amd.sharding import GatherLoop, alloc_result_slab, head_bytes, rollout_trajectory, shard_range, split_slab
     wl = workloads.double_integrator(total, seed=11)
     lo, hi = shard_range(total, rank, world)  # contiguous shards of ONE batch, as bench.py --gpus N does
     b = hi - lo
@@ -49,7 +49,8 @@ def _worker(rank, world, port, total, out_path, overlap):
         v["iter"].copy_(torch.from_numpy(ref["iter"]))
         calls.append(k)
 
-    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=True, overlap=overlap)
+    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=True, overlap=overlap,
+                      payload_bytes=head_bytes(b, n, X) if payload == "controls" else None)
     for _ in range(3):
         loop.step()
     dist.barrier()
@@ -60,7 +61,12 @@ def _worker(rank, world, port, total, out_path, overlap):
         parts = [split_slab(g, b, n, X) for g in loop.gathered()]
         u = torch.cat([p["control"] for p in parts]).numpy()
         st = torch.cat([p["status"] for p in parts]).numpy()
-        np.savez(out_path, control=u, status=st, slabs_used=np.array(calls))
+        if payload == "controls":  # X did not travel: rank 0 rolls the gathered controls out (x0 of the LAST step)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            xt = rollout_trajectory(t(wl["A"]), t(wl["B"]), t(wl["d"]), t(wl["x0"] + 0.01 * (len(calls) - 1)), torch.from_numpy(u)).numpy()
+        else:
+            xt = torch.cat([p["trajectory"] for p in parts]).numpy()
+        np.savez(out_path, control=u, status=st, trajectory=xt, slabs_used=np.array(calls))
     # a corrupted payload must be caught
     if rank == 0:
         loop.gathered()[1].view(torch.int64)[3] += 1
@@ -82,21 +88,24 @@ def test_shard_range_covers_everything():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_rank_gloo_gather(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,payload", [(False, "full"), (True, "full"), (True, "controls")])
+def test_two_rank_gloo_gather(tmp_path, overlap, payload):
     """bench.py's own step loop (copra_amd.sharding.GatherLoop: step / send / verify, one or two result slabs) with two
     gloo ranks on CPU and the oracle standing in for the solve: contiguous shards, ONE gather per step, rank 0 ends up with
-    every shard of the LAST step and the checksum verification notices a corrupted payload"""
+    every shard of the LAST step and the checksum verification notices a corrupted payload; payload "controls": only the
+    [U | status | iter] head of the slabs travels and rank 0 reproduces X by the roll-out"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     from copra_amd import workloads
     total, world = 32, 2
     out = str(tmp_path / "gathered.npz")
     pyoracle.lib()
-    mp.spawn(_worker, args=(world, _free_port(), total, out, overlap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, out, overlap, payload), nprocs=world, join=True)
     got = np.load(out)
     wl = workloads.double_integrator(total, seed=11)
     ref = pyoracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"] + 0.02, wl["N"], wl["costs"], wl["cstrs"])  # step 3
     assert (got["status"] == ref["status"]).all()
     assert np.array_equal(got["control"], ref["control"])
+    ok = ref["status"] == 0  # (payload "controls": the trajectory is the receiving side's roll-out of the gathered controls)
+    assert np.abs(got["trajectory"][ok] - ref["trajectory"][ok]).max() <= (0.0 if payload == "full" else 1e-9)
     assert list(got["slabs_used"]) == ([0, 1, 0] if overlap else [0, 0, 0])
