@@ -81,6 +81,14 @@ COPRA_DEV double rf_rcp(double x)
 
 enum { kRfIneq = 0, kRfEq = 1, kRfOff = 2 };
 
+// the four values are needed at this point TOGETHER: the compiler then issues their loads back to back and waits once (left to
+// itself it interleaved every pair of LDS reads of the stage gradient with a full wait: four round trips instead of one)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define COPRA_RF_TOGETHER4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#else
+#define COPRA_RF_TOGETHER4(a, b, c, d) ((void)0)
+#endif
+
 COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 {
     constexpr int NX = kRfNX, NZ = kRfNZ, MR = kRfMR, KS = kRfKStride;
@@ -317,17 +325,21 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 COPRA_RF_PSTAMP(1);
                 if (with_rows && lane < t_cnt) {
                     const double* Yk = L.Y + gi0;
-                    Hk[t_ent] = t_w + ((t_v0 * Yk[t_r0] + t_v1 * Yk[t_r1]) + (t_v2 * Yk[t_r2] + t_v3 * Yk[t_r3]));
+                    double y0 = Yk[t_r0], y1 = Yk[t_r1], y2 = Yk[t_r2], y3 = Yk[t_r3];
+                    COPRA_RF_TOGETHER4(y0, y1, y2, y3); // (ONE round trip: all four reads in flight before the first is used)
+                    Hk[t_ent] = t_w + ((t_v0 * y0 + t_v1 * y1) + (t_v2 * y2 + t_v3 * y3));
                 }
                 COPRA_RF_PSTAMP(2);
             }
             if (lane < NZ) {
                 const double* Xk = L.X + k * NZ;
-                double g = qk + ((w_v0 * Xk[w_c0] + w_v1 * Xk[w_c1]) + (w_v2 * Xk[w_c2] + w_v3 * Xk[w_c3]));
-                if (with_rows) {
-                    const double* Ck = L.Cb + gi0;
-                    g += (g_v0 * Ck[g_r0] + g_v1 * Ck[g_r1]) + (g_v2 * Ck[g_r2] + g_v3 * Ck[g_r3]);
-                }
+                const double* Ck = L.Cb + (with_rows ? gi0 : 0);
+                double x0v = Xk[w_c0], x1v = Xk[w_c1], x2v = Xk[w_c2], x3v = Xk[w_c3];
+                double c0v = Ck[g_r0], c1v = Ck[g_r1], c2v = Ck[g_r2], c3v = Ck[g_r3];
+                COPRA_RF_TOGETHER4(x0v, x1v, x2v, x3v);
+                COPRA_RF_TOGETHER4(c0v, c1v, c2v, c3v);
+                double g = qk + ((w_v0 * x0v + w_v1 * x1v) + (w_v2 * x2v + w_v3 * x3v));
+                if (with_rows) g += (g_v0 * c0v + g_v1 * c1v) + (g_v2 * c2v + g_v3 * c3v);
                 if (with_x0_terms && k == 0 && lane < NX) {
                     g += L.G0[lane];
 #pragma unroll
@@ -539,15 +551,18 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                     if (prep) fetch(k - 1), prepare_stage(k - 1, cn, gn, false, true, x0_free);
                     return;
                 }
-                // h = g + [A B]' p : hardware block b = row block (x_0..3 | x_4..7 | x_8..11 | u_a), u_b on its own (replicated)
-                double hv = gk[gh], hbv = gk[ghb];
+                // h = g + [A B]' p : hardware block b = row block (x_0..3 | x_4..7 | x_8..11 | u_a), u_b on its own (replicated).  The
+                // products start from zero and g is added afterwards: its way back from LDS runs under them
+                const double gv = gk[gh], gbv = gk[ghb];
                 const double c_nB = nBop, c_nA = nAop, c_KbT = aKbT, c_KaT = aKaT;
-                if (prep) fetch(k - 1), prepare_stage(k - 1, cn, gn, false, true, x0_free); // (on their way while this stage computes)
+                double hv = 0.0, hbv = 0.0;
 #pragma unroll
                 for (int K = 0; K < 3; ++K) {
                     hv = mfma_f64_4x4x4(hM[K], pB[K], hv);
                     hbv = mfma_f64_4x4x4(hMb[K], pB[K], hbv);
                 }
+                if (prep) fetch(k - 1), prepare_stage(k - 1, cn, gn, false, true, x0_free); // (in the shadow of the products)
+                hv += gv, hbv += gbv;
                 const double kvb = mfma_f64_4x4x4(c_nB, hbv, 0.0); // kv_b = -M_bb^-1 h_b
                 const double hp = mfma_f64_4x4x4(c_KbT, hbv, hv); // h' = h + K_b' h_b  (x and u_a)
                 const double ha = row_bcast_f64<12>(hp); // h'_a to every hardware block
@@ -608,7 +623,6 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 for (int K = 0; K < 3; ++K) fKa[K] = nKa[K], fKb[K] = nKb[K];
                 const double fKba = nKba;
                 double ua = nva, ub = nvb;
-                if (k + 1 < N) fetch(k + 1);
                 double xn = 0.0;
 #pragma unroll
                 for (int K = 0; K < 3; ++K) {
@@ -616,6 +630,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                     ub = mfma_f64_4x4x4(fKb[K], xB[K], ub);
                     xn = mfma_f64_4x4x4(fA[K], xB[K], xn);
                 }
+                if (k + 1 < N) fetch(k + 1); // (the next stage's operands: requested in the shadow of the products)
                 ub = mfma_f64_4x4x4(fKba, ua, ub);
                 xn = mfma_f64_4x4x4(fA[3], ua, xn);
                 xn = mfma_f64_4x4x4(fA[4], ub, xn);

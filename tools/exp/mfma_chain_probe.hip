@@ -44,6 +44,35 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, int mod
             r = mf(a, c, r), r = mf(b, c, r), r = mf(a, c, r);
             c = r;
         }
+    } else if (mode == 8) { // one stage of the backward vector sweep of lmpc_riccati_mfma.hpp (10 MFMAs, 4 row broadcasts), registers only
+        double p0 = c, p1 = d, p2 = e;
+        for (int i = 0; i < N_STEPS; ++i) {
+            double hv = a, hbv = b;
+            hv = mf(a, p0, hv), hbv = mf(b, p0, hbv);
+            hv = mf(a, p1, hv), hbv = mf(b, p1, hbv);
+            hv = mf(a, p2, hv), hbv = mf(b, p2, hbv);
+            const double kvb = mf(a, hbv, 0.0);
+            const double hp = mf(b, hbv, hv);
+            const double ha = bc0(hp);
+            const double kva = mf(a, ha, 0.0);
+            const double pn = mf(b, ha, hp);
+            d += kva + kvb;
+            p0 = bc0(pn), p1 = bc0(pn + 1.0), p2 = bc0(pn - 1.0);
+        }
+        c = p0 + p1 + p2;
+    } else if (mode == 9) { // one stage of the forward sweep (12 MFMAs, 3 row broadcasts)
+        double x0 = c, x1 = d, x2 = e;
+        for (int i = 0; i < N_STEPS; ++i) {
+            double ua = a, ub = b, xn = 0.0;
+            ua = mf(a, x0, ua), ub = mf(b, x0, ub), xn = mf(a, x0, xn);
+            ua = mf(a, x1, ua), ub = mf(b, x1, ub), xn = mf(a, x1, xn);
+            ua = mf(a, x2, ua), ub = mf(b, x2, ub), xn = mf(a, x2, xn);
+            ub = mf(a, ua, ub);
+            xn = mf(b, ua, xn);
+            xn = mf(a, ub, xn);
+            x0 = bc0(xn), x1 = bc0(xn + 1.0), x2 = bc0(xn - 1.0);
+        }
+        c = x0 + x1 + x2;
     } else if (mode == 7) { // v_fma_f64 dependent (reference)
         for (int i = 0; i < N_STEPS; ++i) c = fma(a, c, d);
     }
@@ -60,10 +89,11 @@ int main()
     hipMalloc(&cyc, maxg * sizeof(long long));
     const char* names[] = { "accumulator chain", "result -> B operand", "result -> A operand", "3 independent accumulator chains (per MFMA)",
         "MFMA -> row_bcast (2 DPP) -> B operand", "MFMA -> LDS write -> read -> A operand", "group of 3 accumulating MFMAs on the previous result (per group)",
-        "dependent v_fma_f64" };
-    for (int grid : { 1, 512, 1024, 2048 }) {
+        "dependent v_fma_f64", "backward vector sweep stage: 10 MFMAs + 4 row broadcasts (registers only)",
+        "forward sweep stage: 12 MFMAs + 3 row broadcasts (registers only)" };
+    for (int grid : { 1, 512 }) {
         printf("---- %d workgroups of one wave ----\n", grid);
-        for (int mode = 0; mode < 8; ++mode) {
+        for (int mode = 0; mode < 10; ++mode) {
             std::vector<long long> h(grid);
             probe<<<grid, 64, 1024>>>(out, cyc, mode);
             probe<<<grid, 64, 1024>>>(out, cyc, mode);
