@@ -764,7 +764,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             double musum = 0.0, maxr = 0.0;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
-                if (j % 3 == 0) sched_fence(); // (bounds how many rows' operands the scheduler keeps in flight: registers)
+                if (j % 5 == 0) sched_fence(); // (bounds how many rows' operands the scheduler keeps in flight: registers)
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 double Dv = 0.0, Cv = 0.0;
                 if (gi < m && fl != kRfOff) {
@@ -800,7 +800,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             double q0 = 0.0, q1 = 0.0, q2 = 0.0;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
-                if (j % 3 == 0) sched_fence();
+                if (j % 5 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 double dsdl = 0.0;
                 if (gi < m && fl == kRfIneq) {
@@ -824,7 +824,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             // ---- corrector right-hand side: gradient coefficients of the rows
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
-                if (j % 3 == 0) sched_fence();
+                if (j % 5 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 double Cv = 0.0;
                 if (gi < m && fl != kRfOff) {
@@ -848,7 +848,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             amin = 1.0e300;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
-                if (j % 3 == 0) sched_fence();
+                if (j % 5 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 if (gi < m && fl == kRfIneq) {
                     const double ds = -residual(j, fl) - row_dot(rinf[j], L.Y);
@@ -863,7 +863,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             double musum2 = 0.0, maxe = 0.0;
 #pragma unroll
             for (int j = 0; j < MR; ++j) {
-                if (j % 3 == 0) sched_fence();
+                if (j % 5 == 0) sched_fence();
                 const int gi = 64 * j + lane, fl = rinf[j] >> 28;
                 if (gi < m && fl != kRfOff) {
                     const double rp = residual(j, fl), adz = row_dot(rinf[j], L.Y);
