@@ -394,6 +394,8 @@ struct copra_batch {
     // copra_batch_specialise: this controller's shape compiled into its own kernels (hipcc --genco, cached on disk)
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_fused = nullptr, jit_shared = nullptr;
+    hipFunction_t jit_fused_q0 = nullptr; // Riccati-factor tier compiled for this shape: Q1 in LDS (further down the layout ladder)
+    bool jit_ric = false; // the code object holds the Riccati-factor tier (lmpc_fused_ric.hpp) of this controller's shape
     int jit_lanes = 64; // lanes per instance the code object was compiled for
     int jit_tri = 0; // ... and whether for the factor-only layout
     int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
@@ -1044,7 +1046,8 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared = true;
     h->model_dirty = true;
-    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve)
+    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
+                                                                        //  only the library's instantiations: a run-time-compiled one has no prepare kernel)
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;
     }
@@ -1416,6 +1419,59 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu || P.lds.ric)
         return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
+    // ---- the Riccati-factor tier (lmpc_fused_ric.hpp; what the headline runs on) for THIS shape: per-step costs, xDim (xDim + uDim + 1)
+    //      <= 64, two or three controls, at most 64 decision variables.  Compiled with Q1 in registers and in LDS (the layout ladder
+    //      moves between the two); the controller takes the tier's layout once the kernels exist.
+    // Single-control systems with fewer than 48 variables stay on the packed / factor-only kernels: the reference's falling-mass
+    // problems hold most of their control bounds active, far beyond this tier's five register columns (measured, M solves/s,
+    // this tier vs the others compiled for the shape: N = 5: 94 vs 339, 16: 6.8 vs 55, 32: 7.2 vs 16, 48: 29 vs 22, 64: 75 vs 29).
+    const bool ric_pays = P.nu >= 2 || P.n >= 48 || std::getenv("COPRA_RIC_ANY_SHAPE");
+    if (!h->shared && ric_pays && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI")) {
+        HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
+        if (take_ric_layout(trial)) {
+            char keyr[128], srcr[2048];
+            snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d", P.nx, P.nu, P.N);
+            snprintf(srcr, sizeof srcr,
+                "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\nusing namespace copra_hip;\n"
+                "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
+                "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d>(P, P.inst_offset + (int)blockIdx.x); }\n"
+                "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused_q0(const FusedPlan P)\n"
+                "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, P.inst_offset + (int)blockIdx.x); }\n",
+                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N);
+            std::string objr;
+            const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
+            if (rcr != COPRA_OK) return rcr;
+            hipModule_t modr = nullptr;
+            HIP_TRY(hipModuleLoad(&modr, objr.c_str()));
+            hipFunction_t fr = nullptr, fq = nullptr;
+            hipError_t er = hipModuleGetFunction(&fr, modr, "copra_jit_fused");
+            if (er == hipSuccess) er = hipModuleGetFunction(&fq, modr, "copra_jit_fused_q0");
+            double* dparams = nullptr;
+            if (er == hipSuccess) er = upload(&dparams, trial.params); // (the stage-cost tables were appended)
+            if (er != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipModuleUnload(modr);
+                (void)hipFree(dparams);
+                return fail(COPRA_ERR_HIP, std::string("copra_batch_specialise (Riccati-factor tier): ") + hipGetErrorString(er));
+            }
+            (void)hipFree(h->d_params);
+            h->d_params = dparams;
+            h->hp = trial;
+            h->packed = 0; // (one instance per wavefront on this tier)
+            h->lds_attr_set = false;
+            h->adapt_left = h->adapt_left > 4 ? h->adapt_left : 4;
+            h->jit_module = modr;
+            h->jit_lanes = 64;
+            h->jit_tri = 1;
+            h->jit_ric = true;
+            h->jit_fused = fr;
+            h->jit_fused_q0 = fq;
+            h->jit_shared = nullptr;
+            return COPRA_OK;
+        }
+    }
     // (always the full register budget: with compile-time trip counts the unrolled bodies spill at 128 VGPRs -- double
     //  integrator N = 32: 9.2 M solves/s at four waves per SIMD, 15.6 M at two, 11.8 M for the run-time-shape kernel)
     char key[128], source[1536];
@@ -1600,7 +1656,8 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     // of the second one (the whole solve, what LMPC::solveTime() reports) -- no barrier packets in the stream: two
     // hipEventRecord per solve cost ~ 20 us between consecutive solves, 3 % of the headline step.  The other paths bracket
     // their launches with recorded events as before.
-    const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri;
+    const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri
+        && h->jit_ric == (P.lds.ric != 0);
     const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed && !std::getenv("COPRA_RECORDED_EVENTS");
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
@@ -1648,13 +1705,14 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->tier_timed = false;
         return COPRA_OK;
     }
-    if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && !jit_launch && !h->packed, P));
+    if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && (!jit_launch || h->jit_ric) && !h->packed, P));
     if (jit_launch) {
         FusedPlan Pj = P;
         void* args[] = { &Pj };
         const unsigned per = 64u / (unsigned)h->jit_lanes;
-        LDS_OPT_IN(h->jit_fused, (size_t)per * h->hp.lds_bytes);
-        HIP_TRY(hipModuleLaunchKernel(h->jit_fused, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
+        const hipFunction_t jfn = (h->jit_ric && P.lds.q1regs == 0) ? h->jit_fused_q0 : h->jit_fused;
+        LDS_OPT_IN(jfn, (size_t)per * h->hp.lds_bytes);
+        HIP_TRY(hipModuleLaunchKernel(jfn, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
             per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
     } else if (h->packed) {
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));

@@ -171,6 +171,14 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
 // them, nothing (the lean preview of that body writes G and Xbar in place); A / B / d / x0 keep their own slots because the
 // sweep reads them while it fills the records; no cost tables; the sweep's scratch aliases the solver vectors.
 // q1regs > 0: that many columns of Q1 in registers (rcap = q1regs);  q1regs == 0: Q1 in LDS, as many columns as `budget` leaves.
+// shapes lmpc_fused_ric_body<NX, NU, NH> can be instantiated for (its static_asserts)
+inline bool ric_shape_ok(int nx, int nu, int N)
+{
+    const int nz = nx + nu, nxx = nx * (nx + 1) / 2, nux = nu * nx, nuu = nu * (nu + 1) / 2;
+    return nu >= 1 && nu <= 3 && nx >= 1 && nx <= 7 && nx * (nz + 1) <= kWave && nxx + nux + nuu + nz <= kWave && nu * N <= kWave
+        && nxx + nux + nuu >= nx * (nx + 1) && N >= 2;
+}
+
 inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, int mgen, int meq, int mtotal, bool xcur_late,
     int q1regs, int budget)
 {
@@ -384,6 +392,36 @@ inline bool tri_layout_with_lds_q1(const FusedPlan& P, const LdsLayout& cur, Lds
 
 inline bool is_neg_inf(double v) { return std::isinf(v) && v < 0; }
 inline bool is_pos_inf(double v) { return std::isinf(v) && v > 0; }
+
+// Move a controller that build_plan has laid out onto the Riccati-factor tier (lmpc_fused_ric.hpp) if its shape and its costs allow:
+// the layout with the stage records in the factor's place, Q1 in registers, and the stage-cost tables (appended to hp.params: the
+// caller uploads them again).  What build_plan does itself for the shapes the library instantiates; copra_batch_specialise calls it
+// for every other shape once the kernel for it is compiled.
+inline bool take_ric_layout(HostPlan& hp)
+{
+    FusedPlan& P = hp.plan;
+    const int nx = P.nx, nu = P.nu, N = P.N;
+    if (P.lds.ric) return true;
+    if (hp.large || P.initial_state || !ric_shape_ok(nx, nu, N)) return false;
+    if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts) return false;
+    for (int t = 0; t < P.ncost; ++t)
+        if (P.cost[t].full) return false;
+    for (int k = 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
+        const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
+        LdsLayout t {};
+        if (layout_lds_ric(t, nx, nu, N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, kFusedQ1Regs, budget)) {
+            hp.lds_safe = P.lds; // (what the controller falls back to when the tier's layout ladder is exhausted: adapt_layout)
+            hp.safe_two_tier = hp.two_tier;
+            hp.two_tier = true;
+            hp.dense = true;
+            P.lds = t;
+            P.ric_tab = build_ric_tables(hp, 6);
+            hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
+            return true;
+        }
+    }
+    return false;
+}
 
 inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_costs, const copra_cost_desc_t* costs,
     int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is = nullptr)
@@ -881,6 +919,8 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // otherwise run on the square layouts (30 variables) or the run-time-shape factor-only kernel (45)
         bool ric_short = nx == 6 && nu == 3 && (N == 10 || N == 15) && P.rmax <= 6 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state
             && P.ncost <= kRicMaxCosts && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI");
+        // (every other shape the body of that tier can be instantiated for gets there through copra_batch_specialise, which
+        //  compiles the kernel and calls take_ric_layout)
         for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full;
         bool ric_taken = false;
         for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {

@@ -75,7 +75,7 @@ template <int NX, int NU, int NH, bool IDENT = false>
 COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
 {
     using RR = RicRec<NX, NU>;
-    static_assert(NX <= 8 && NU >= 2 && NU <= 4, "stacked layout of the MFMA recursions");
+    static_assert(NX <= 8 && NU >= 1 && NU <= 4, "stacked layout of the MFMA recursions");
     constexpr int cbase = NH * RR::SZ;
     kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;

@@ -161,6 +161,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         fprintf(stderr, "emu: %s\n", hp.error.c_str());
         return (int)rc;
     }
+    if (std::getenv("COPRA_EMU_WANT_RIC")) (void)take_ric_layout(hp); // (what copra_batch_specialise does once the shape's kernel is compiled)
     point_plan_to_host(hp);
     FusedPlan& P = hp.plan;
     P.A = A;
@@ -233,7 +234,18 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
     auto body = [&](const FusedPlan& PP, int b) {
-        if (PP.lds.tri && PP.lds.ric && PP.N == 10) // (select_fused_kernel: the factor in Riccati form)
+        // (shapes beyond the library's instantiations: what copra_batch_specialise compiles at run time)
+        if (PP.lds.tri && PP.lds.ric && PP.nx == 6 && PP.nu == 3 && PP.N == 12)
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.nx == 4 && PP.nu == 2 && PP.N == 16)
+            PP.lds.q1regs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.nx == 5 && PP.nu == 3 && PP.N == 12)
+            PP.lds.q1regs ? lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<5, 3, 12, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 10)
+            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<2, 1, 10, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 40)
+            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<2, 1, 40, 6, 0>(PP, b);
+        else if (PP.lds.tri && PP.lds.ric && PP.N == 10) // (select_fused_kernel: the factor in Riccati form)
             PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b);
         else if (PP.lds.tri && PP.lds.ric && PP.N == 15)
             PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b);

@@ -808,3 +808,59 @@ def test_warm_start_across_receding_horizon_ticks(emu, oracle):
         x = np.where(ok[:, None], nxt, x)
     assert reused > 0  # active sets were carried over ...
     assert it_warm <= it_cold + 6 * 6  # ... and never cost more than the closing scan per solve
+
+
+def test_riccati_factor_tier_body_with_one_control(emu, oracle, monkeypatch):
+    """... and with ONE control (the reference's falling-mass fixtures, tests/systems.h: 40 steps; BASELINE configs[1]'s shape
+    (2, 1, 10)): the stacked layout of the recursions and the 1 x 1 control block work as they are"""
+    from copra_amd import workloads
+    monkeypatch.setenv("COPRA_EMU_WANT_RIC", "1")
+    wl = workloads.double_integrator(6)
+    _, _ = _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    for system, xcost in (("bounded", "trajectory"), ("ineq", "mixed"), ("mixed", "target")):
+        pb = getattr(F, system + "_system")(xcost, N=40)
+        re = emu.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+        ro = oracle.lmpc_solve(pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
+        assert re["riccati_factor"] and re["status"][0] == ro["status"] == 0 and tuple(re["iter"][0]) == tuple(ro["iter"])
+        assert _rel(re["control"][0], ro["control"]) <= RTOL
+
+
+@pytest.mark.parametrize("shape", ["com12", "planar16", "five_states"])
+def test_riccati_factor_tier_body_on_other_shapes(emu, oracle, shape, monkeypatch):
+    """the body of the Riccati-factor tier instantiated for shapes beyond the library's three CoM horizons -- what
+    copra_batch_specialise compiles at run time: (6, 3, 12), (4, 2, 16), (5, 3, 12); the emulator takes the tier's layout the
+    way the library does after the compilation (take_ric_layout).  Same statuses, iteration counts and controls as the oracle,
+    through the overflow tier where the active set outgrows the five register columns"""
+    from copra_amd import workloads
+    monkeypatch.setenv("COPRA_EMU_WANT_RIC", "1")
+    rng = np.random.default_rng(1)
+    b = 6
+    if shape == "com12":
+        wl = workloads.com_preview(b, N=12, v_max=0.3, u_max=1.5, seed=3)
+        args = (wl["A"], wl["B"], wl["d"], wl["x0"], 12, wl["costs"], wl["cstrs"])
+    elif shape == "planar16":
+        T = 0.1
+        A = np.tile(np.block([[np.eye(2), T * np.eye(2)], [np.zeros((2, 2)), np.eye(2)]]), (b, 1, 1))
+        B = np.tile(np.vstack([0.5 * T * T * np.eye(2), T * np.eye(2)]), (b, 1, 1))
+        x0 = np.hstack([rng.normal(0, 0.3, (b, 2)), rng.uniform(-0.2, 0.2, (b, 2))])
+        costs = [dict(kind="trajectory", M=np.eye(4), p=np.array([1.0, 0.5, 0.0, 0.0]), weights=[10, 10, 1, 1]),
+                 dict(kind="control", N=np.eye(2), p=np.zeros(2), weights=[1e-3] * 2)]
+        cstrs = [dict(kind="trajectory_bound", lower=[-np.inf] * 4, upper=[np.inf, np.inf, 0.4, 0.4]),
+                 dict(kind="control_bound", lower=[-1.5] * 2, upper=[1.5] * 2)]
+        args = (A, B, np.zeros((b, 4)), x0, 16, costs, cstrs)
+    else:
+        Q, _ = np.linalg.qr(rng.standard_normal((5, 5)))
+        A = np.tile(0.95 * Q, (b, 1, 1))
+        B = np.tile(0.4 * rng.standard_normal((5, 3)), (b, 1, 1))
+        x0 = rng.standard_normal((b, 5))
+        costs = [dict(kind="trajectory", M=np.eye(5), p=np.zeros(5), weights=[5.0] * 5),
+                 dict(kind="control", N=np.eye(3), p=np.zeros(3), weights=[1e-2] * 3)]
+        cstrs = [dict(kind="control_bound", lower=[-0.4] * 3, upper=[0.4] * 3)]
+        args = (A, B, 0.01 * rng.standard_normal((b, 5)), x0, 12, costs, cstrs)
+    re = emu.lmpc_solve(*args)
+    assert re["riccati_factor"]
+    ro = oracle.lmpc_solve_batch(*args)
+    assert (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
+    ok = ro["status"] == 0
+    assert ok.any() and _rel(re["control"][ok], ro["control"][ok]) <= RTOL and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= RTOL
+    assert (re["iter"][:, 0] > 1).any()

@@ -41,7 +41,8 @@ python tools/pmc_summary.py $O/hl_dense > $R/pmc_dense_mfma_path.json
 tools/exp/mfma_chain_probe > $R/mfma_chain_probe.txt 2>&1 || true
 python tools/pcie_probe.py 2>&1 | grep -v amdgpu.ids > $R/pcie_probe.txt
 python tools/host_pipeline.py 2>&1 | grep -v amdgpu.ids > $R/host_pipeline.txt
-python tools/sweep_shapes.py > $R/shape_sweep.txt 2>&1 || true
+python tools/sweep_shapes.py 2>&1 | grep -v amdgpu.ids > $R/shape_sweep.txt || true
+python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_sweep_specialised.txt || true
 cp $R/*.json $R/*.csv $R/*.txt $O/ 2>/dev/null || true
 # ---- the bench line itself (with cpu_baseline and extra) ----
 python bench.py --steps 20 --warmup 3 > $O/bench_r03.json 2> $O/bench_r03.err

@@ -30,7 +30,7 @@ for N in (5, 10, 16, 20, 32, 48, 64):
     if JIT:
         eng.specialise()
     rows.append(("double integrator N=%d" % N, N, eng.lanes_per_instance(), rate(eng, b)))
-for N in (5, 10, 15, 20):
+for N in (5, 8, 10, 12, 15, 18, 20, 21):
     b = 65536
     wl = workloads.com_preview(b, N=N)
     eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
@@ -40,3 +40,17 @@ for N in (5, 10, 15, 20):
     rows.append(("CoM preview N=%d" % N, 3 * N, eng.lanes_per_instance(), rate(eng, b)))
 for name, n, lanes, r in rows:
     print("%-26s n=%3d  lanes/instance %3d  %8.2f M solves/s" % (name, n, lanes, r))
+# (nx, nu) = (4, 2): the planar point mass of tests/test_gpu_parity.py
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+try:
+    import test_gpu_parity as T
+    for N in (16, 24, 32):
+        b = 65536
+        wl = T._planar_integrator(b, N)
+        eng = BatchLMPC(4, 2, N, b, wl["costs"], wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        if JIT:
+            eng.specialise()
+        print("%-26s n=%3d  lanes/instance %3d  %8.2f M solves/s" % ("planar point mass N=%d" % N, 2 * N, eng.lanes_per_instance(), rate(eng, b)))
+except Exception as e:  # (the sweep itself must not be lost)
+    print("planar cases skipped:", repr(e))
