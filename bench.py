@@ -87,25 +87,50 @@ def timed_rate(eng, batch, reps=5):
 EVENT_TIMING = "best of %d solves, HIP events around the whole solve (device time, inputs resident in HBM)"
 
 
-def cpp_single_solve_latency():
+def cpp_single_solve_latency(np):
     """What a drop-in user of ONE controller sees: copra::LMPC::solve() of the C++ mirror (copra_amd/cpp/include/copra/copra.h) on
-    the headline controller, batch 1 -- launch + synchronisation + result copy per call (tests/cpp/test_api.cpp: latency_case)."""
+    the headline controller, batch 1 -- xInit, launch, synchronisation, result copy per call (tests/cpp/test_api.cpp:
+    latency_case) -- for the benchmark's own instance (x_init -> x_goal of pyTests.py:358-359: one active-set iteration) and for a
+    constraint-heavy one (start far from the goal), each next to the CPU path (oracle, one thread) on THE SAME instance."""
     import re
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
     import test_cpp_api
+    from copra_amd import workloads
     test_cpp_api._build()
-    r = subprocess.run([test_cpp_api.EXE, "latency", "1000"], capture_output=True, text=True, timeout=300)
-    m = re.search(r"latency_us median ([0-9.]+) mean ([0-9.]+) min ([0-9.]+) p95 ([0-9.]+) solveTime_us ([0-9.]+) solveAndBuildTime_us ([0-9.]+)",
-                  r.stdout)
-    if r.returncode != 0 or not m:
-        return {"error": (r.stdout + r.stderr)[-400:]}
-    med, mean, mn, p95, st, sbt = (float(v) for v in m.groups())
-    return {"median_us": med, "mean_us": mean, "min_us": mn, "p95_us": p95, "device_solveTime_us": st,
-            "solves_per_s": 1e6 / med, "calls": 1000,
-            "what": "wall time of copra::LMPC::solve() (C++ mirror, batch 1, CoM nx=6 nu=3 N=20 with both bound constraints): "
-                    "xInit -> H2D of x0, two launches, one synchronisation, one pinned copy of [U | X | status | iter]"}
+    out = {}
+    wl = workloads.com_preview(1)
+    T = 0.117
+    A = np.eye(6)
+    A[:3, 3:] = T * np.eye(3)
+    B = np.vstack([0.5 * T * T * np.eye(3), T * np.eye(3)])
+    for name, extra, x0, goal in (("benchmark_instance", [], workloads.COM_X_INIT, workloads.COM_X_GOAL),
+                                  ("constraint_heavy_instance", ["hard"], np.array([0.2, 0.1, 0.8, 0.05, -0.1, 0.0]),
+                                   np.array([1.0, 0.6, 0.8, 0.0, 0.0, 0.0]))):
+        r = subprocess.run([test_cpp_api.EXE, "latency", "1000"] + extra, capture_output=True, text=True, timeout=300)
+        m = re.search(r"latency_us median ([0-9.]+) mean ([0-9.]+) min ([0-9.]+) p95 ([0-9.]+) solveTime_us ([0-9.]+) "
+                      r"solveAndBuildTime_us ([0-9.]+) control0 \S+ iter (\d+)", r.stdout)
+        if r.returncode != 0 or not m:
+            out[name] = {"error": (r.stdout + r.stderr)[-400:]}
+            continue
+        med, mean, mn, p95, st, sbt = (float(v) for v in m.groups()[:6])
+        costs = [dict(wl["costs"][0], p=goal), wl["costs"][1]]
+        reps = 256
+        t0 = time.perf_counter()
+        ro = pyoracle.lmpc_solve_batch(np.tile(A, (reps, 1, 1)), np.tile(B, (reps, 1, 1)), np.zeros((reps, 6)), np.tile(x0, (reps, 1)),
+                                       wl["N"], costs, wl["cstrs"], nthreads=1, native=True)
+        cpu_us = (time.perf_counter() - t0) / reps * 1e6
+        out[name] = {"median_us": med, "mean_us": mean, "min_us": mn, "p95_us": p95, "device_solveTime_us": st,
+                     "active_set_iterations": int(m.group(7)), "cpu_path_one_thread_us": cpu_us,
+                     "cpu_path_iterations": int(ro["iter"][0, 0])}
+    ok = out.get("benchmark_instance", {})
+    out["solves_per_s"] = 1e6 / ok["median_us"] if "median_us" in ok else 0.0
+    out["median_us"] = ok.get("median_us", 0.0)
+    out["what"] = ("wall time of copra::LMPC::solve() (C++ mirror, batch 1, CoM nx=6 nu=3 N=20 with both bound constraints), 1000 calls "
+                   "with a new measured state each: H2D of x0, two launches, one synchronisation, one pinned copy of [U | X | status | iter]")
+    return out
 
 
 def host_inclusive_pipelined(np, torch, dev, b=65536, chunks=4, passes=6, warm=10, controls_only=False):
@@ -258,7 +283,7 @@ def extra_measurements(np, torch, dev):
         except Exception as e:
             out[key] = {"error": repr(e)}
     try:
-        out["single_problem_latency_cpp_mirror"] = cpp_single_solve_latency()
+        out["single_problem_latency_cpp_mirror"] = cpp_single_solve_latency(np)
     except Exception as e:
         out["single_problem_latency_cpp_mirror"] = {"error": repr(e)}
     return out

@@ -917,8 +917,21 @@ protected:
                 if (!c->deviceDescriptor(cdesc)) c->update(*ps_);
             dirty_ = true; // their matrices are part of the plan
         }
+        const bool fresh = dirty_ || !h_;
         rebuild();
-        throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
+        // The receding-horizon tick of the reference is ps->xInit(x) between solves (PreviewSystem.h:52): only x0 has changed then,
+        // and only x0 crosses PCIe again (one 48-byte copy instead of four blocking ones).  The fields of PreviewSystem are public, so
+        // what was sent last is compared rather than trusted.
+        auto same = [](const double* a, Eigen::Index na, const double* b, Eigen::Index nb) { return na == nb && std::equal(a, a + na, b); };
+        const bool same_system = !fresh && same(sentA_.data(), sentA_.rows() * sentA_.cols(), ps_->A.data(), ps_->A.rows() * ps_->A.cols())
+            && same(sentB_.data(), sentB_.rows() * sentB_.cols(), ps_->B.data(), ps_->B.rows() * ps_->B.cols())
+            && same(sentd_.data(), sentd_.rows(), ps_->d.data(), ps_->d.rows());
+        if (same_system) {
+            throw_status(copra_batch_set_x0(h_, ps_->x0.data(), 0));
+        } else {
+            throw_status(copra_batch_set_system(h_, ps_->A.data(), ps_->B.data(), ps_->d.data(), ps_->x0.data(), 0));
+            sentA_ = ps_->A, sentB_ = ps_->B, sentd_ = ps_->d;
+        }
         beforeSolve();
     }
     DenseQP fetchQP()
@@ -1026,6 +1039,8 @@ protected:
     double solveTime_ = 0.0, solveAndBuildTime_ = 0.0;
     DenseQP qp_;
     bool qpValid_ = false;
+    Eigen::MatrixXd sentA_, sentB_; // the system the device holds (prepare)
+    Eigen::VectorXd sentd_;
 };
 
 // include/InitialStateLMPC.h:18-42, src/InitialStateLMPC.cpp: the initial state is a decision variable too

@@ -76,7 +76,6 @@ __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const Fused
     if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
     lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, P.inst_offset + (int)blockIdx.x);
 }
-
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
 template <int NX, int NU, int NH, int RP>
@@ -509,8 +508,11 @@ static copra_status_t adapt_layout(copra_batch* h)
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&count, h->d_ovf_count + h->ovf_cur, sizeof(int), hipMemcpyDeviceToHost));
     // (the Riccati-factor tier is so much faster than its second tier -- the square-layout kernel -- that it pays to step down
-    //  the ladder until only one instance in 32 is left over; the other first tiers keep the round-1 threshold of one in 8)
-    const long long share = h->hp.plan.lds.ric ? 32 : 8;
+    //  the ladder until only one instance in 64 is left over -- measured in round 3 over five constraint levels: 64 and 128 equal, 32
+    //  leaves a mid-constrained workload on five columns at 42.8 instead of 50.4 M solves/s, 512 goes too far; the other first tiers
+    //  keep the round-1 threshold of one in 8)
+    long long share = h->hp.plan.lds.ric ? 64 : 8;
+    if (const char* e = std::getenv("COPRA_OVERFLOW_SHARE")) share = std::atoll(e) > 0 ? std::atoll(e) : share; // (experiments)
     if ((long long)count * share <= (long long)h->hp.plan.batch) return COPRA_OK;
     LdsLayout roomier {};
     if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) { // factor-only: one instance per CU fewer, more columns

@@ -347,7 +347,10 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const int rows = rp > P.rmax ? rp : P.rmax;
     const int kcur = (160 * 1024) / (cur.total * (int)sizeof(double));
-    if (cur.ric) { // the Riccati-factor tier keeps its factor: Q1 moves to LDS, one instance per CU fewer per step
+    if (cur.ric) { // the Riccati-factor tier keeps its factor
+        // Q1 moves to LDS, one instance per CU fewer per step.  (A first step with TEN register columns on a 256-VGPR build of the kernel,
+        //  eight instances per CU, was measured in round 3 and dropped: 1.39 ms against 1.30 ms for seven LDS columns at nine per CU on a
+        //  mid-constrained workload, no better anywhere: profiles/r03/README.md)
         for (int k = kcur - 1; k >= 4; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
             LdsLayout t {};

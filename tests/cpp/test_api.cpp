@@ -676,7 +676,7 @@ static void plugin_cases(int nbStep)
 // the mirror's own solveTime() / solveAndBuildTime() of the last call: the figure to put next to the CPU path's.
 #include <algorithm>
 #include <chrono>
-static void latency_case(int reps)
+static void latency_case(int reps, bool hard)
 {
     using namespace Eigen;
     const int nbStep = 20;
@@ -688,8 +688,8 @@ static void latency_case(int reps)
         B(3 + i, i) = T;
     }
     VectorXd d = VectorXd::Zero(6), x0(6), goal(6), wx(6), wu(3), lo(6), up(6), ulo(3), uup(3);
-    x0 << 0.2, 0.1, 0.8, 0.05, -0.1, 0.0;
-    goal << 1.0, 0.6, 0.8, 0.0, 0.0, 0.0;
+    x0 << 1.5842778860957882, 0.3422260214935311, 2.289067474385933, 0.0, 0.0, 0.0; // x_init, x_goal of pyTests.py:358-359: the
+    goal << 1.627772868473883, 0.4156386515475985, 2.3984423755527136, 0.06745225960685897, 0.3882830795737303, 0.06845759848745198; // benchmark's instances
     wx << 10, 10, 10, 1, 1, 1;
     wu << 1e-3, 1e-3, 1e-3;
     const double inf = std::numeric_limits<double>::infinity();
@@ -697,6 +697,11 @@ static void latency_case(int reps)
     up << inf, inf, inf, 0.6, 0.6, 0.6;
     ulo << -3, -3, -3;
     uup << 3, 3, 3;
+    if (hard) { // a start far from the goal: velocity and control bounds active over much of the horizon -- more active constraints than the
+                // first launch's five register columns, so every solve also goes through the second launch
+        x0 << 0.2, 0.1, 0.8, 0.05, -0.1, 0.0;
+        goal << 1.0, 0.6, 0.8, 0.0, 0.0, 0.0;
+    }
     auto ps = std::make_shared<copra::PreviewSystem>();
     ps->system(A, B, d, x0, nbStep);
     copra::LMPC controller(ps);
@@ -714,7 +719,7 @@ static void latency_case(int reps)
     std::vector<double> us;
     VectorXd x = x0;
     for (int i = 0; i < reps; ++i) {
-        x(0) = 0.2 + 0.001 * (i % 17);
+        x(0) = x0(0) + 0.002 * (i % 17), x(4) = 0.01 * (i % 5); // (a new measured state every call)
         ps->xInit(x);
         const auto t0 = std::chrono::steady_clock::now();
         const bool ok = controller.solve();
@@ -726,9 +731,9 @@ static void latency_case(int reps)
     double mean = 0.0;
     for (double v : us) mean += v;
     mean /= (double)us.size();
-    std::printf("latency_us median %.2f mean %.2f min %.2f p95 %.2f solveTime_us %.2f solveAndBuildTime_us %.2f control0 %.9f\n",
+    std::printf("latency_us median %.2f mean %.2f min %.2f p95 %.2f solveTime_us %.2f solveAndBuildTime_us %.2f control0 %.9f iter %d\n",
         us[us.size() / 2], mean, us.front(), us[(size_t)(0.95 * us.size())], controller.solveTime() * 1e6,
-        controller.solveAndBuildTime() * 1e6, controller.control()(0));
+        controller.solveAndBuildTime() * 1e6, controller.control()(0), controller.iter());
 }
 
 int main(int argc, char** argv)
@@ -740,7 +745,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
         if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
-        if (!std::strcmp(mode, "latency")) latency_case(argc > 2 ? std::atoi(argv[2]) : 500);
+        if (!std::strcmp(mode, "latency")) latency_case(argc > 2 ? std::atoi(argv[2]) : 500, argc > 3 && !std::strcmp(argv[3], "hard"));
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());
         return 2;

@@ -162,6 +162,14 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         return (int)rc;
     }
     if (std::getenv("COPRA_EMU_WANT_RIC")) (void)take_ric_layout(hp); // (what copra_batch_specialise does once the shape's kernel is compiled)
+    if (const char* steps = std::getenv("COPRA_EMU_LADDER_STEPS")) { // (what adapt_layout does after solves that overflowed: steps down the tier's ladder)
+        for (int q = 0; q < std::atoi(steps); ++q) {
+            LdsLayout roomier {};
+            if (!next_tri_layout(hp.plan, hp.plan.lds, roomier)) break;
+            hp.plan.lds = roomier;
+            hp.lds_bytes = (size_t)roomier.total * sizeof(double);
+        }
+    }
     point_plan_to_host(hp);
     FusedPlan& P = hp.plan;
     P.A = A;

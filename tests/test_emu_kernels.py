@@ -864,3 +864,15 @@ def test_riccati_factor_tier_body_on_other_shapes(emu, oracle, shape, monkeypatc
     ok = ro["status"] == 0
     assert ok.any() and _rel(re["control"][ok], ro["control"][ok]) <= RTOL and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= RTOL
     assert (re["iter"][:, 0] > 1).any()
+
+
+@pytest.mark.parametrize("steps", [1, 2])
+def test_riccati_factor_tier_ladder_steps(emu, oracle, steps, monkeypatch):
+    """the layout ladder of the headline's tier (Q1 moves to LDS, more columns per step: what adapt_layout does after solves that
+    overflowed): the tight workload (3 .. 22 active constraints) on its first two steps, against the oracle incl. iteration counts"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(10, v_max=0.25, u_max=1.2, seed=4)
+    base = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    monkeypatch.setenv("COPRA_EMU_LADDER_STEPS", str(steps))
+    re, ro = _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert re["riccati_factor"] and re["rcap"] > base["rcap"] and re["overflowed"] <= base["overflowed"]
