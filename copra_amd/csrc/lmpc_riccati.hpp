@@ -498,9 +498,9 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
                 const int gi = gi0 + r;
                 const int fl = (int)Flag[gi];
                 double sv = 1.0, lv = 0.0;
-                if (fl == kRowIneq) { // (centred start: stage_plan.hpp, s_floor / lam0)
+                if (fl == kRowIneq) { // (centred start: stage_plan.hpp, s_floor / lam0; the multipliers follow below)
                     sv = fmax(F[gi] - row_dot(r, nd, L.zk), S.s_floor);
-                    lv = S.lam0 > 0.0 ? S.lam0 : -S.lam0 / sv;
+                    lv = S.lam0 > 0.0 ? S.lam0 : 1.0;
                     n_ineq += 1;
                 }
                 Sv[gi] = sv;
@@ -511,6 +511,15 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         n_ineq = (int)(wave_sum((double)n_ineq) + 0.5);
         wave_sync_full();
         const double inv_mi = n_ineq > 0 ? 1.0 / (double)n_ineq : 0.0;
+        if (!(S.lam0 > 0.0)) { // every complementarity product s lam starts at |lam0| x the mean slack (lmpc_riccati_mfma.hpp)
+            double ssum = 0.0;
+            for (int gi = lane; gi < m; gi += kWave)
+                if ((int)Flag[gi] == kRowIneq) ssum += Sv[gi];
+            const double mu0 = -S.lam0 * wave_sum(ssum) * inv_mi;
+            for (int gi = lane; gi < m; gi += kWave)
+                if ((int)Flag[gi] == kRowIneq) Lam[gi] = mu0 / Sv[gi];
+            wave_sync_full();
+        }
 
         stamp(0);
         // ------------------------------------------------------------------ 2. Newton iterations

@@ -737,10 +737,18 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 #pragma unroll
         for (int j = 0; j < MR; ++j) {
             const int gi = 64 * j + lane;
-            if (gi < m && (rinf[j] >> 28) == kRfIneq) {
-                Sv[j] = fmax(Fr[j] - row_dot(rinf[j], L.X), S.s_floor);
-                Lam[j] = S.lam0 > 0.0 ? S.lam0 : -S.lam0 / Sv[j]; // (negative: every complementarity product s * lam starts at |lam0|)
-            }
+            if (gi < m && (rinf[j] >> 28) == kRfIneq) Sv[j] = fmax(Fr[j] - row_dot(rinf[j], L.X), S.s_floor);
+        }
+        { // multipliers: lam0 > 0: that value; lam0 < 0 (the default): every complementarity product s lam starts at |lam0| x the MEAN
+          // slack -- a centred start at the problem's own scale (bounds of 200 and bounds of 0.5 both start with lam ~ 1 on a typical row)
+            double ssum = 0.0;
+#pragma unroll
+            for (int j = 0; j < MR; ++j)
+                if (64 * j + lane < m && (rinf[j] >> 28) == kRfIneq) ssum += Sv[j];
+            const double mu0 = S.lam0 > 0.0 ? 0.0 : -S.lam0 * wave_sum(ssum) * inv_mi;
+#pragma unroll
+            for (int j = 0; j < MR; ++j)
+                if (64 * j + lane < m && (rinf[j] >> 28) == kRfIneq) Lam[j] = S.lam0 > 0.0 ? S.lam0 : mu0 / Sv[j];
         }
         stamp_outer(0);
         // ------------------------------------------------------------------ 2. Newton iterations

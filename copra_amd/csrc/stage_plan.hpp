@@ -443,10 +443,14 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.max_nnze = max_nnze;
     sp.x0_free = P.initial_state;
     sp.max_iter = 60;
-    // starting point: slacks s = max(f - a'z_0, 0.05) at the roll-out z_0 of u = 0 and multipliers lam = 1 / s -- every complementarity
-    // product starts at 1 (a CENTRED start).  The first version (s = max(., 1), lam = 1) made every row with a slack below 1
-    // start with a primal residual, and the first five Newton steps were spent recovering from that: 19 -> 14 steps on config 5.
-    sp.s_floor = 0.05, sp.lam0 = -1.0;
+    // starting point: slacks s = max(f - a'z_0, 0.05) at the roll-out z_0 of u = 0 and multipliers lam = mean(s) / s -- every
+    // complementarity product starts at the mean slack (a CENTRED start at the problem's own scale).  The first version
+    // (s = max(., 1), lam = 1) made every row with a slack below 1 start with a primal residual, and the first five Newton steps were
+    // spent recovering from that: 19 -> 14 steps on config 5.  (lam = 1 / s -- products of 1 whatever the scale -- does the same for
+    // config 5 but takes 27 steps instead of 8 on the reference's falling-mass fixtures, whose bounds are 200.)  The factor on the mean
+    // slack, |lam0| = 10: config 5 takes 13.3 / 13.5 / 13.4 / 13.6 steps at 1 / 3 / 10 / 30 (full batch, profiles/r03/lam0_scan.log);
+    // the trajectory-cost fixtures (weights of 1e4 -- large multipliers at the optimum) 22 / 19 / 15 / 12.
+    sp.s_floor = 0.05, sp.lam0 = -10.0;
     sp.step_tol = 1e-10, sp.mu_tol = 1e-8;
     if (const char* e = std::getenv("COPRA_RIC_STEP_TOL")) sp.step_tol = std::atof(e); // (experiments)
     if (const char* e = std::getenv("COPRA_RIC_MU_TOL")) sp.mu_tol = std::atof(e);

@@ -41,6 +41,8 @@ python tools/pmc_summary.py $O/hl_dense > $R/pmc_dense_mfma_path.json
 tools/exp/mfma_chain_probe > $R/mfma_chain_probe.txt 2>&1 || true
 python tools/pcie_probe.py 2>&1 | grep -v amdgpu.ids > $R/pcie_probe.txt
 python tools/host_pipeline.py 2>&1 | grep -v amdgpu.ids > $R/host_pipeline.txt
+python tools/tight_ladder_rates.py 2>&1 | grep -v amdgpu.ids > $R/tight_ladder_rates.txt || true
+python tools/latency_small_batches.py 2>&1 | grep -v amdgpu.ids > $R/latency_small_batches.txt || true
 python tools/sweep_shapes.py 2>&1 | grep -v amdgpu.ids > $R/shape_sweep.txt || true
 python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_sweep_specialised.txt || true
 cp $R/*.json $R/*.csv $R/*.txt $O/ 2>/dev/null || true
