@@ -7,6 +7,7 @@
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
 #include "lmpc_fused_ric.hpp"
+#include "lmpc_lane.hpp"
 #include "lmpc_large.hpp"
 #include "lmpc_riccati.hpp"
 #include "lmpc_riccati_mfma.hpp"
@@ -74,7 +75,27 @@ template <int NX, int NU, int NH, int QR>
 __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {
     if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
-    lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, P.inst_offset + (int)blockIdx.x);
+    int inst = P.inst_offset + (int)blockIdx.x;
+    bool lane_failed = false;
+    if (P.lane_from_list) { // behind the one-instance-per-lane pass: only the instances it left over
+        // Workgroups go to the eight XCDs in turn (each has its own L2), and the gather of the stage records reads 64-byte sectors
+        // that eight neighbouring instances share: entry (w % 8) * per + w / 8 of the list gives every XCD a CONTIGUOUS eighth of it,
+        // so that the neighbours run on one XCD at about the same time and seven of their eight reads hit its L2.
+        const int cnt = *P.lane_count, per = (cnt + 7) >> 3, w = (int)blockIdx.x;
+        const int idx = (w & 7) * per + (w >> 3);
+        if ((w >> 3) >= per || idx >= cnt) return;
+        inst = P.lane_list[idx];
+        lane_failed = inst < 0; // (top bit: its factorisation failed)
+        inst &= 0x7fffffff;
+    }
+    lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, inst, lane_failed);
+}
+// One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
+// instance; those that violate nothing are finished here.  One wave per SIMD: the lane's matrices live in up to 512 registers.
+template <int NX, int NU>
+__global__ __launch_bounds__(64, 1) void copra_lmpc_lane_kernel(const FusedPlan P)
+{
+    lmpc_lane_body<NX, NU>(P, (int)blockIdx.x);
 }
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
@@ -397,6 +418,13 @@ struct copra_batch {
     bool jit_ric = false; // the code object holds the Riccati-factor tier (lmpc_fused_ric.hpp) of this controller's shape
     int jit_lanes = 64; // lanes per instance the code object was compiled for
     int jit_tri = 0; // ... and whether for the factor-only layout
+    // one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp)
+    int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
+    double* d_lane_ws = nullptr;
+    int lane_cur = 0; // the counter the last solve appended to
+    bool lane_ran = false; // the last solve ran the pass
+    bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass)
+    int lane_adapt_left = 2;
     int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
     bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
@@ -463,6 +491,13 @@ static FusedPlan device_plan(const copra_batch* h)
     P.ovf_zero = nullptr;
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
+    P.lane_from_list = 0;
+    P.lane_handover = 0;
+    P.lane_dbg = 0;
+    P.lane_ws = nullptr;
+    P.lane_list = nullptr;
+    P.lane_count = P.lane_zero = nullptr;
+    P.lane_bp = 0;
     P.ws = h->d_ws;
     P.model_out = nullptr;
     P.model = nullptr;
@@ -495,6 +530,62 @@ static hipError_t begin_overflow_queue(copra_batch* h, hipStream_t s, bool self_
         h->ovf_clean[cur ^ 1] = true;
     }
     return hipSuccess;
+}
+
+// ---- the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp) ----
+static fused_kernel_t select_lane_kernel(const FusedPlan& P)
+{
+    if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_kernel<6, 3>;
+    return nullptr;
+}
+static size_t lane_lds_bytes(const FusedPlan& P)
+{
+    int oH = 0;
+    return (size_t)lane_lds_doubles(P.nx, P.nu, oH) * sizeof(double);
+}
+// does the next solve run it?  (the per-instance references and right-hand sides can be set at any time: checked per solve)
+static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_launch)
+{
+    if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS")) return false;
+    const char* dbg = std::getenv("COPRA_LANE_DBG");
+    if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
+    if (!P.lds.ric || P.lane_tab < 0 || jit_launch || h->packed || h->shared || P.row_f_inst) return false;
+    for (int t = 0; t < kMaxCosts; ++t)
+        if (h->cost_p[t]) return false;
+    return select_lane_kernel(P) != nullptr;
+}
+static copra_status_t ensure_lane_buffers(copra_batch* h)
+{
+    if (h->d_lane_ws) return COPRA_OK;
+    const FusedPlan& P = h->hp.plan;
+    const size_t bp = ((size_t)P.batch + kWave - 1) / kWave * kWave;
+    HIP_TRY(hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_lane_count, 0, 2 * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_lane_list, bp * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double)));
+    h->lane_cur = 1;
+    return COPRA_OK;
+}
+// The pass pays when a fair share of the batch ends in it.  After each of the first solves that ran it: if fewer than one instance in
+// eight did, it is switched off for this controller (it costs about a tenth of the first tier per instance).
+static copra_status_t adapt_lane_pass(copra_batch* h)
+{
+    if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
+    // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
+    //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
+    if (h->hp.plan.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) return COPRA_OK;
+    h->lane_adapt_left -= 1;
+    int left = 0;
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+    const long long done = (long long)h->hp.plan.batch - left;
+    long long share = 8;
+    if (const char* e = std::getenv("COPRA_LANE_SHARE")) share = std::atoll(e) > 0 ? std::atoll(e) : share; // (experiments)
+    if (done * share < (long long)h->hp.plan.batch && !std::getenv("COPRA_LANE_KEEP")) h->lane_off = true;
+    if (std::getenv("COPRA_DEBUG"))
+        fprintf(stderr, "[copra] one-instance-per-lane pass: %lld of %d instances ended in it%s\n", done, h->hp.plan.batch,
+            h->lane_off ? " -- switched off" : "");
+    return COPRA_OK;
 }
 
 // Compact LDS layouts (R capped, overflow finished by the second tier) bet on small active sets.  After each of the
@@ -935,6 +1026,9 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_model);
     (void)hipFree(h->d_ovf_count);
     (void)hipFree(h->d_ovf_list);
+    (void)hipFree(h->d_lane_count);
+    (void)hipFree(h->d_lane_list);
+    (void)hipFree(h->d_lane_ws);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evm) (void)hipEventDestroy(h->evm);
@@ -1564,9 +1658,12 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
     {
-        const copra_status_t rca = adapt_layout(h);
+        copra_status_t rca = adapt_lane_pass(h);
+        if (rca != COPRA_OK) return rca;
+        rca = adapt_layout(h);
         if (rca != COPRA_OK) return rca;
         h->solved_once = true;
+        h->lane_ran = false;
     }
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
@@ -1707,6 +1804,31 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->tier_timed = false;
         return COPRA_OK;
     }
+    // the one-instance-per-lane pass (lmpc_lane.hpp): every instance whose unconstrained minimiser violates nothing ends in it, the
+    // first tier below runs for the others only
+    bool lane_pass = lane_pass_wanted(h, P, jit_launch);
+    if (lane_pass) {
+        rc = ensure_lane_buffers(h);
+        if (rc != COPRA_OK) return rc;
+        h->lane_cur ^= 1;
+        h->lane_ran = true;
+        P.lane_ws = h->d_lane_ws;
+        P.lane_list = h->d_lane_list;
+        P.lane_count = h->d_lane_count + h->lane_cur;
+        P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
+        P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
+        const unsigned g0 = (unsigned)(P.lane_bp / kWave);
+        if (const char* e = std::getenv("COPRA_LANE_DBG")) P.lane_dbg = std::atoi(e);
+        LDS_OPT_IN(select_lane_kernel(P), lane_lds_bytes(P));
+        if (ext_timed)
+            hipExtLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, h->ev0, nullptr, 0, P);
+        else
+            hipLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, P);
+        HIP_TRY(hipGetLastError());
+        P.lane_from_list = 1;
+        P.lane_handover = (P.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) ? 1 : 0;
+        P.lane_zero = nullptr;
+    }
     if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && (!jit_launch || h->jit_ric) && !h->packed, P));
     if (jit_launch) {
         FusedPlan Pj = P;
@@ -1726,11 +1848,12 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
                 h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
         }
+        const unsigned g1 = lane_pass ? (((unsigned)P.batch + 7u) & ~7u) : (unsigned)P.batch; // (the list is dealt out in eighths)
         if (ext_timed) // (start | end of the first launch; with a second launch the solve ends with THAT kernel's packet)
-            hipExtLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, h->ev0,
-                h->hp.two_tier ? h->evm : h->ev1, 0, P);
+            hipExtLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s,
+                lane_pass ? nullptr : h->ev0, h->hp.two_tier ? h->evm : h->ev1, 0, P);
         else
-            hipLaunchKernelGGL(select_fused_kernel(P), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+            hipLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
     }
     if (h->hp.two_tier) {

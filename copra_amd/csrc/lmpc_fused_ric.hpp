@@ -24,7 +24,7 @@
 namespace copra_hip {
 
 template <int NX, int NU, int NH, int RP, int QR>
-COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
+COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_failed = false)
 {
     constexpr int NZ = NX + NU, NV = NU * NH, X = NX * (NH + 1);
     constexpr int nxx = NX * (NX + 1) / 2, nux = NU * NX, nuu = NU * (NU + 1) / 2;
@@ -70,7 +70,59 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst)
     int mBk = 0, mG = 0, mNb = 0;
     ric_model_offsets(NX, NU, NH, P.mgen, mBk, mG, mNb);
     const bool from_model = P.ric_model != nullptr;
-    if (from_model) {
+    // behind the one-instance-per-lane pass (lmpc_lane.hpp) the sweep has been done already: K | kv | Lam^-1 of every stage and the running
+    // block-row norms sit in its lane-major workspace, element (k, e) of this instance at lane_ws[(k WR + e) lane_bp + inst] -- a gather
+    // of NH WR doubles (eleven loads per lane at the headline shape) and Acl = A + B K instead of the 32 k cycles of the sweep
+    const bool from_lane = !from_model && compact && P.lane_from_list && P.lane_handover && !P.ric_model_out;
+    if (lane_failed) status = 2; // (its factorisation met a control block that is not positive definite)
+    if (from_lane) {
+        constexpr int KWl = NU * NX, WR = KWl + NU + NU * (NU + 1) / 2 + NX; // (plan.hpp: lane_ws_rows)
+        const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
+        const double sysB = lane < NX * NU ? P.B[(size_t)inst * NX * NU + lane] : 0.0;
+        const double sysD = lane < NX ? P.d[(size_t)inst * NX + lane] : 0.0;
+        const double sysX = lane < NX ? P.x0[(size_t)inst * NX + lane] : 0.0;
+        constexpr int NG = (NH * WR + kWave - 1) / kWave;
+        double gv[NG];
+        const double* const wsb = P.lane_ws + (size_t)inst;
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int idx = lane + kWave * u;
+            gv[u] = wsb[(size_t)(idx < NH * WR ? idx : 0) * (size_t)P.lane_bp];
+        }
+        rows.cache_own_row();
+        if (lane < NX * NX) A[lane] = sysA;
+        if (lane < NX * NU) B[lane] = sysB;
+        if (lane < NX) {
+            D[lane] = sysD;
+            X0[lane] = sysX;
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int idx = lane + kWave * u, k = idx / WR, e = idx - k * WR;
+            if (idx < NH * WR) {
+                double* dst = e < KWl        ? F + k * RR::SZ + RR::oK + e
+                    : e < KWl + NU           ? F + k * RR::SZ + RR::oKv + (e - KWl)
+                    : e < WR - NX            ? F + k * RR::SZ + RR::oLi + (e - KWl - NU)
+                                             : Xbar + k * NX + (e - (WR - NX)); // (NB2: the running block-row norms)
+                *dst = gv[u];
+            }
+        }
+        wave_sync();
+        // Acl_k = A + B K_k, every stage: element (i, j) of stage k
+        for (int idx = lane; idx < NH * NX * NX; idx += kWave) {
+            const int k = idx / (NX * NX), r = idx - k * (NX * NX), i = r % NX, j = r / NX;
+            double acc = A[r];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) acc += B[i + NX * c] * F[k * RR::SZ + RR::oK + c + NU * j];
+            F[k * RR::SZ + RR::oAcl + r] = acc;
+        }
+        // the constant block behind the records (as after the sweep below)
+        if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
+        if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
+        if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
+        if (lane == 1) F[NH * RR::SZ + RR::cO] = 1.0;
+        stamp[1] = cycle_counter();
+    } else if (from_model) {
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];

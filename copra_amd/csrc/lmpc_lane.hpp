@@ -1,0 +1,444 @@
+// LMPC::solve() with ONE INSTANCE PER LANE: the pass in front of the Riccati-factor tier (lmpc_fused_ric.hpp).
+//
+// qpgen2 starts at the unconstrained minimiser -Q^-1 c and is finished at once when no constraint is violated there
+// (QuadProgSolver.cpp:45-72 -> qpgen2: the first scan finds nothing).  For a controller whose costs are all per-step entries
+// (costFunctions.cpp:63-215) that minimiser is the LQ roll-out u_k = K_k x_k + kv_k of ONE backward Riccati sweep -- N small dense
+// steps without any search, the same work for every instance: data-parallel over the BATCH, not over the matrix.  So this pass
+// gives every instance one lane: the lane keeps its own A, B, d, the cost-to-go P and the stage matrix M in registers, every
+// multiply-add is a full-rate v_fma_f64 on 64 instances at once (no padding of 6 x 6 blocks to MFMA tiles, no cross-lane
+// traffic, no LDS hand-overs), the feedback gains K_k | kv_k go through a lane-major HBM workspace (coalesced: 512 B per
+// store), and the roll-out checks every constraint row and bound with qpgen2's own test (slack <= -vsmall).  An instance that
+// violates nothing is DONE: U, X, status 0, iteration counts (1, 0) -- exactly what the first tier reports for it.  Every other
+// instance is appended to a list, and the first tier (wave per instance, active-set iteration) runs for those only.
+// At the headline workload 47 % of the instances end here, at about a tenth of the first tier's cost per instance.
+//     stage k < N:   l_k(x, u) = 1/2 [x; u]' H [x; u] + h' [x; u]          (H, h, HN, hN: plan_builder.hpp, build_lane_tables)
+//     stage N:       l_N(x)    = 1/2 x' HN x + hN' x
+//     M = H + [A B]' P+ [A B],  m = h + [A B]' (P+ d + p+),  K = -M_uu^-1 M_ux,  kv = -M_uu^-1 m_u,
+//     P = M_xx + M_xu K,  p = m_x + M_xu kv                                  (the recursion of lmpc_fused_ric.hpp, dense per lane)
+// Shapes: compile-time (NX, NU) with NU <= 3 (the Riccati-factor tier's), the horizon is a run-time value.
+#pragma once
+#include "lmpc_fused.hpp"
+
+namespace copra_hip {
+
+// W doubles per instance, [batch][W] in HBM: the 64 instances of this wave are one contiguous block -- coalesced loads (ALL arrays
+// are requested before the first one is used: one trip to memory), transposed through LDS (odd stride: no bank conflicts) so that
+// every lane ends up with its own instance in registers
+template <int W>
+COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)[W])
+{
+    const int lane = lane_id();
+    const size_t base = (size_t)group * kWave * W;
+    const int left = batch - group * kWave;
+    const int count = (left < kWave ? left : kWave) * W;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int e = j * kWave + lane;
+        raw[j] = src[base + (e < count ? e : 0)];
+    }
+}
+template <int W>
+COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, double* lds, double (&out)[W])
+{
+    constexpr int ST = W | 1;
+    const int lane = lane_id();
+    const int left = batch - group * kWave;
+    const int count = (left < kWave ? left : kWave) * W;
+    wave_sync(); // (the previous array has left the staging area)
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int e = j * kWave + lane;
+        lds[e + (ST - W) * (e / W)] = raw[j];
+    }
+    wave_sync();
+    const int ln = (lane * W < count) ? lane : 0; // (lanes past the end of the batch compute on a copy of the first instance)
+#pragma unroll
+    for (int c = 0; c < W; ++c) out[c] = lds[ln * ST + c];
+}
+// element `lane index` of a wave-uniform row: the row pointer is pinned to scalar registers (opaque to the optimiser, which would fold the
+// row offsets into one 64-bit address PER ACCESS otherwise), so that the access is `global_load/store v_index, s[row]`: one index
+// register for the whole kernel instead of an address pair per access in flight
+COPRA_DEV double& lane_at(double* row, unsigned byte_off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(row));
+#endif
+    return *(double*)((char*)row + byte_off); // (a 32-bit BYTE offset: what the scalar-base addressing mode takes)
+}
+COPRA_DEV const double& lane_at(const double* row, unsigned byte_off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(row));
+#endif
+    return *(const double*)((const char*)row + byte_off);
+}
+
+template <int NX, int NU>
+COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
+{
+    constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 1;
+    constexpr int oLiW = KW, oNbW = KW + NU * (NU + 1) / 2, WR = oNbW + NX; // rows of the workspace per stage (plan.hpp: lane_ws_rows)
+    static_assert(NU >= 1 && NU <= 3, "the control block is eliminated in closed form");
+    const int lane = lane_id();
+    const int inst = group * kWave + lane;
+    const bool valid = inst < P.batch;
+    const int NH = P.N;
+    const double* tab = P.params + P.lane_tab;
+    int oh_, oHN_, ohN_, oRows_;
+    lane_tab_offsets(NX, NU, oh_, oHN_, ohN_, oRows_);
+    const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
+    double* lds = lds_base();
+    if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0; // (the NEXT solve's counter: nobody reads it now)
+
+    long long stamp[5];
+    stamp[0] = cycle_counter();
+    // ---- 0. this lane's system ----
+    double A[NX * NX], B[NX * NU], d[NX], x[NX];
+    {
+        double rA[NX * NX], rB[NX * NU], rd[NX], rx[NX];
+        lane_fetch<NX * NX>(P.A, group, P.batch, rA);
+        lane_fetch<NX * NU>(P.B, group, P.batch, rB);
+        lane_fetch<NX>(P.d, group, P.batch, rd);
+        lane_fetch<NX>(P.x0, group, P.batch, rx);
+        lane_transpose_in<NX * NX>(rA, group, P.batch, lds, A);
+        lane_transpose_in<NX * NU>(rB, group, P.batch, lds, B);
+        lane_transpose_in<NX>(rd, group, P.batch, lds, d);
+        lane_transpose_in<NX>(rx, group, P.batch, lds, x);
+    }
+    // the stage cost H | h into LDS, behind the staging area: read there by every stage of the sweep (a wave-uniform address: one
+    // broadcast read per entry, in order -- scalar loads come back out of order and every use waited for all of them)
+    int oHl_ = 0;
+    (void)lane_lds_doubles(NX, NU, oHl_);
+    double* Hl = lds + oHl_;
+    for (int e = lane; e < NZ * NZ + NZ; e += kWave) Hl[e] = tab[e];
+    wave_sync();
+    auto AB = [&](int l, int a) -> double { return a < NX ? A[l + NX * a] : B[l + NX * (a - NX)]; }; // [A B](l, a)
+
+    stamp[1] = cycle_counter();
+    // ---- 1. backward Riccati sweep; K_k | kv_k to the workspace, lane-major: element e of stage k at ws[(k KW + e) bp + inst] ----
+    double* const ws = P.lane_ws;
+    const size_t bp = (size_t)P.lane_bp;
+    const unsigned ioff = (unsigned)inst * 8u; // this lane's byte offset in a workspace row
+    double Pm[NX * NX], pv[NX]; // cost-to-go (symmetric, both halves)
+#pragma unroll
+    for (int e = 0; e < NX * NX; ++e) Pm[e] = uniform_load(tab, oHN + e);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) pv[i] = uniform_load(tab, ohN + i);
+    bool bad = false;
+    for (int k = NH - 1; k >= 0; --k) {
+        int hoff = oHl_;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(hoff)); // (opaque per stage: the reads stay inside the loop -- hoisted, they would cost 180 registers)
+#endif
+        const double* const Hk = lds + hoff;
+        double M[NZ][NZ], mz[NZ]; // upper triangle (a <= b)
+        {
+            double tq[NX]; // P+ d + p+
+#pragma unroll
+            for (int l = 0; l < NX; ++l) {
+                double s = pv[l];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s += Pm[l + NX * i] * d[i];
+                tq[l] = s;
+            }
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) {
+                double s = Hk[oh + a];
+#pragma unroll
+                for (int l = 0; l < NX; ++l) s += AB(l, a) * tq[l];
+                mz[a] = s;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NZ; ++b) {
+            double Tb[NX]; // column b of P+ [A B]
+#pragma unroll
+            for (int l = 0; l < NX; ++l) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s += Pm[l + NX * i] * AB(i, b);
+                Tb[l] = s;
+            }
+#pragma unroll
+            for (int a = 0; a <= b; ++a) {
+                double s = Hk[a + NZ * b];
+#pragma unroll
+                for (int l = 0; l < NX; ++l) s += AB(l, a) * Tb[l];
+                M[a][b] = s;
+            }
+        }
+        // -M_uu^-1 (symmetric; positive definite <=> the trailing minors are positive)
+        double Ni[NU][NU];
+        if constexpr (NU == 1) {
+            const double m00 = M[NX][NX];
+            bad = bad || !(m00 > 0.0);
+            Ni[0][0] = -1.0 / m00;
+        } else if constexpr (NU == 2) {
+            const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m11 = M[NX + 1][NX + 1];
+            const double det = m00 * m11 - m01 * m01;
+            bad = bad || !(m11 > 0.0) || !(det > 0.0);
+            const double nr = -1.0 / det;
+            Ni[0][0] = m11 * nr;
+            Ni[0][1] = Ni[1][0] = -m01 * nr;
+            Ni[1][1] = m00 * nr;
+        } else {
+            const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m02 = M[NX][NX + 2], m11 = M[NX + 1][NX + 1], m12 = M[NX + 1][NX + 2],
+                         m22 = M[NX + 2][NX + 2];
+            const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+            const double det = m00 * c00 + (m01 * c01 + m02 * c02);
+            bad = bad || !(m22 > 0.0) || !(c00 > 0.0) || !(det > 0.0);
+            const double nr = -1.0 / det;
+            Ni[0][0] = c00 * nr;
+            Ni[0][1] = Ni[1][0] = c01 * nr;
+            Ni[0][2] = Ni[2][0] = c02 * nr;
+            Ni[1][1] = (m00 * m22 - m02 * m02) * nr;
+            Ni[1][2] = Ni[2][1] = (m01 * m02 - m00 * m12) * nr;
+            Ni[2][2] = (m00 * m11 - m01 * m01) * nr;
+        }
+        double K[NU][NX], kv[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int e = 0; e < NU; ++e) s += Ni[c][e] * M[j][NX + e];
+                K[c][j] = s;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < NU; ++e) s += Ni[c][e] * mz[NX + e];
+            kv[c] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+#pragma unroll
+            for (int i = 0; i <= j; ++i) {
+                double s = M[i][j];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) s += M[i][NX + c] * K[c][j];
+                Pm[i + NX * j] = s;
+                Pm[j + NX * i] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double s = mz[i];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) s += M[i][NX + c] * kv[c];
+            pv[i] = s;
+        }
+        // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
+        double* const wk = ws + ((size_t)k * WR) * bp;
+        if (!(P.lane_dbg & 2)) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) lane_at(wk + (size_t)(c + NU * j) * bp, ioff) = K[c][j];
+                lane_at(wk + (size_t)(NU * NX + c) * bp, ioff) = kv[c];
+            }
+            // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier
+            double lm[NU][NU], rd[NU], lid[NU][NU];
+#pragma unroll
+            for (int cb = 0; cb < NU; ++cb)
+#pragma unroll
+                for (int ca = 0; ca <= cb; ++ca) lm[cb][ca] = M[NX + ca][NX + cb];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double dpp = lm[c][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) dpp -= lm[c][q] * lm[c][q];
+                rd[c] = fast_rsqrt(dpp);
+#pragma unroll
+                for (int r2 = c + 1; r2 < NU; ++r2) {
+                    double v = lm[r2][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= lm[r2][q] * lm[c][q];
+                    lm[r2][c] = v * rd[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NU; ++c)
+#pragma unroll
+                for (int r2 = c; r2 < NU; ++r2) {
+                    double li;
+                    if (r2 == c) {
+                        li = rd[c];
+                    } else {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = c; q < r2; ++q) v -= lm[r2][q] * lid[q][c];
+                        li = v * rd[r2];
+                    }
+                    lid[r2][c] = li;
+                    lane_at(wk + (size_t)(oLiW + r2 * (r2 + 1) / 2 + c) * bp, ioff) = li;
+                }
+        }
+    }
+
+    stamp[2] = cycle_counter();
+    // ---- 2. roll-out from x0 with qpgen2's first scan inside: rows of step k on (x_k, u_k), the bounds of u_k ----
+    const double vsmall = P.vsmall;
+    const int rps = P.lane_rps;
+    bool viol = bad;
+    const int li = valid ? inst : 0;
+    const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
+    const double* const ubp = P.ub_inst ? P.ub_inst + (size_t)li * P.n : P.ub;
+    const bool own_bounds = P.lb_inst != nullptr;
+    // Stages in groups of GS.  One wave per SIMD: nothing else hides a trip to memory, so the gains of a stage are requested kLaneAhead stages
+    // ahead -- rotating buffers, each refilled as soon as its stage has used it.  The group's states and controls are collected in
+    // LDS and leave as contiguous segments per instance.  Everything is written for every instance -- the verdict comes last --, the
+    // first tier overwrites what it solves again.
+    constexpr int GS = kLaneGroup, SX = (GS * NX) | 1, SU = (GS * NU) | 1;
+    double* const ldx = lds; // [lane][SX]
+    double* const ldu = lds + kWave * SX; // [lane][SU]
+    auto fetch_stage = [&](double (&buf)[KW], int k) {
+        const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
+        const double* const wk = ws + ((size_t)kk * WR) * bp;
+#pragma unroll
+        for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_at(wk + (size_t)e * bp, ioff);
+    };
+    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) { // E x_k + G u_k <= f
+        for (int r = 0; r < rps; ++r) {
+            const int ro = oRows + (k * rps + r) * RW;
+            double ax = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ax += uniform_load(tab, ro + c) * xk[c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
+            const double s = uniform_load(tab, ro + NZ) - ax;
+            viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+        }
+    };
+    constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
+    static_assert(GS % KB == 0, "the buffers rotate inside a group");
+    // block-row norms of the preview blocks G_s = A^s B as running sums over s (one stage of the roll-out = one block): what the row norms
+    // of the first tier's compact variant are read from (lmpc_fused_ric.hpp: NB2)
+    double Gp[NX * NU], ncum[NX];
+#pragma unroll
+    for (int e = 0; e < NX * NU; ++e) Gp[e] = B[e];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ncum[i] = 0.0;
+    double Kq[KB][KW];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) fetch_stage(Kq[q], q);
+    const int left = P.batch - group * kWave;
+    const int ninst = left < kWave ? left : kWave;
+    for (int k0 = 0; k0 < NH; k0 += GS) {
+        wave_sync(); // (the previous group has left the staging area)
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            const int k = k0 + q;
+            const bool on = k < NH;
+            double u[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double s = Kq[q % KB][NU * NX + c];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) s += Kq[q % KB][c + NU * j] * x[j];
+                u[c] = s;
+            }
+            fetch_stage(Kq[q % KB], k + KB);
+            if (on && !(P.lane_dbg & 2)) { // |row i of G_k|^2 added, stored, and the next block
+                double* const wn = ws + ((size_t)k * WR + oNbW) * bp;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double sq = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) sq += Gp[i + NX * c] * Gp[i + NX * c];
+                    ncum[i] += sq;
+                    lane_at(wn + (size_t)i * bp, ioff) = ncum[i];
+                }
+                double Gn[NX * NU];
+#pragma unroll
+                for (int c = 0; c < NU; ++c)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int l = 0; l < NX; ++l) acc += A[i + NX * l] * Gp[l + NX * c];
+                        Gn[i + NX * c] = acc;
+                    }
+#pragma unroll
+                for (int e = 0; e < NX * NU; ++e) Gp[e] = Gn[e];
+            }
+            if (on) {
+                check_rows(k, x, u);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    const double ub = own_bounds ? ubp[k * NU + c] : uniform_load(ubp, k * NU + c);
+                    const double lb = own_bounds ? lbp[k * NU + c] : uniform_load(lbp, k * NU + c);
+                    viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = x[c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = u[c];
+            double xn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double s = d[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) s += A[i + NX * j] * x[j];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) s += B[i + NX * c] * u[c];
+                xn[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = on ? xn[i] : x[i];
+            sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
+        }
+        wave_sync();
+        if (!(P.lane_dbg & 1)) { // consecutive lanes write consecutive doubles of an instance's segment
+            const int nst = NH - k0 < GS ? NH - k0 : GS; // stages of this group
+            double* const xg = P.trajectory + (size_t)(group * kWave) * P.X + (size_t)k0 * NX;
+            double* const ug = P.control + (size_t)(group * kWave) * P.n + (size_t)k0 * NU;
+#pragma unroll 4
+            for (int j = 0; j < GS * NX; ++j) { // (four stores in flight at a time: each has its own address pair)
+                const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
+                if (il < ninst && c < nst * NX) xg[(size_t)il * P.X + c] = ldx[il * SX + c];
+            }
+#pragma unroll 4
+            for (int j = 0; j < GS * NU; ++j) {
+                const int e = j * kWave + lane, il = e / (GS * NU), c = e - il * (GS * NU);
+                if (il < ninst && c < nst * NU) ug[(size_t)il * P.n + c] = ldu[il * SU + c];
+            }
+        }
+    }
+    { // the last state: its rows, and out
+        double u0[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) u0[c] = 0.0;
+        check_rows(NH, x, u0);
+        if (valid && !(P.lane_dbg & 1)) {
+            double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xo[c] = x[c];
+        }
+    }
+
+    stamp[3] = cycle_counter();
+    // ---- 3. verdict: done, or one more entry of the first tier's list (one atomic per wave) ----
+    const bool more = valid && viol;
+    int total = 0;
+    const int before = wave_prefix_count(more, total);
+    if (total > 0) {
+        int base = 0;
+        if (lane == 0) base = atomic_add_i32(P.lane_count, total);
+        base = bcast_i32(base, 0);
+        if (more) P.lane_list[base + before] = bad ? (inst | (int)0x80000000) : inst; // (top bit: the factorisation failed -- status 2)
+    }
+    if (valid && !viol) {
+        P.status[inst] = 0;
+        P.iter[2 * (size_t)inst] = 1;
+        P.iter[2 * (size_t)inst + 1] = 0;
+    }
+    if ((P.lane_dbg & 8) && P.prof && lane == 0) { // (experiments: staging | sweep | roll-out | verdict, in row `group` of the profile)
+        stamp[4] = cycle_counter();
+        long long* pr = P.prof + 8 * (size_t)group;
+        for (int q = 0; q < 4; ++q) pr[q] = stamp[q + 1] - stamp[q];
+        pr[7] = stamp[4] - stamp[0];
+    }
+}
+
+} // namespace copra_hip

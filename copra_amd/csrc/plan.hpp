@@ -191,6 +191,33 @@ COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk,
     return oNb + ((mgen + 1) & ~1);
 }
 
+// offsets (doubles) of the tables at FusedPlan::lane_tab:  H (nz x nz, column-major, z = (x, u)) | h (nz) | HN (nx x nx) | hN (nx) |
+// rows: (N + 1) steps x lane_rps rows of [E (nx) | G (nu) | f]  (a row that is not there: zeros and f = +inf)
+COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& ohN, int& oRows)
+{
+    const int nz = nx + nu;
+    oh = nz * nz;
+    oHN = oh + nz;
+    ohN = oHN + nx * nx;
+    oRows = (ohN + nx + 1) & ~1;
+}
+
+// rows of its workspace per stage: K (nu x nx, column-major) | kv (nu) | Lam^-1 (packed by rows, as RicRec) | running sums of the squared
+// block-row norms of G_s = A^s B (nx) -- the first two are what its own roll-out reads back, all four are what the first tier takes
+// over instead of sweeping again (lmpc_fused_ric.hpp, from_lane)
+COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu + nu * (nu + 1) / 2 + nx; }
+// LDS of that pass (doubles): the staging area of the transpositions (64 lanes x the widest array, odd stride), then H | h
+constexpr int kLaneGroup = 4; // stages per group of its roll-out (results leave through LDS once per group)
+constexpr int kLaneAhead = 4; // stages whose gains are in flight
+COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
+{
+    int w = (nx * nx) | 1;
+    if (((nx * nu) | 1) > w) w = (nx * nu) | 1;
+    if (((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1) > w) w = ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1); // (both at once)
+    oH = 64 * w;
+    const int nz = nx + nu;
+    return (oH + nz * nz + nz + 1) & ~1;
+}
 struct FusedPlan {
     // dimensions
     int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
@@ -214,6 +241,19 @@ struct FusedPlan {
     const double* ric_model;
     double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)
+    // One-instance-per-LANE pass in front of the Riccati-factor tier (lmpc_lane.hpp): tables in `params` (-1: the controller is not
+    // eligible): H | h | HN | hN | (N + 1) x lane_rps rows [E | G | f], offsets from lane_tab_offsets().  The pass appends every instance
+    // it does not finish to lane_list (lane_count entries; lane_zero: the next solve's counter, zeroed on the way); the first tier
+    // then runs with lane_from_list = 1: workgroup w takes instance lane_list[w], workgroups beyond the count leave at once.
+    int lane_tab, lane_rps;
+    int lane_bp; // instances per workspace row (the batch rounded up to whole waves)
+    int lane_from_list;
+    int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)
+    int lane_dbg; // experiments (COPRA_LANE_DBG): 1 = no result stores, 2 = no workspace traffic, 4 = no input staging through LDS
+    double* lane_ws; // [N][lane_ws_rows][lane_bp]: what the sweep leaves per stage, lane-major
+    int* lane_list;
+    int* lane_count;
+    int* lane_zero;
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)

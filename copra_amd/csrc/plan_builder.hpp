@@ -260,6 +260,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
 // column b == nz -- and entry (l % nx, l / nx) of the terminal [HN | hN].  Hin = sum_t [M_t N_t]' W_t [M_t N_t] (+ 1e-6 I on
 // u: LMPC.cpp:228-229) does not depend on the instance; the affine entries are linear in the references p_t, which may be
 // per-instance (copra_batch_set_cost_reference): the tables hold their coefficients.
+inline void build_lane_tables(HostPlan& hp);
 inline int build_ric_tables(HostPlan& hp, int rp)
 {
     FusedPlan& P = hp.plan;
@@ -335,7 +336,79 @@ inline int build_ric_tables(HostPlan& hp, int rp)
         }
     const int at = (int)hp.params.size();
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
+    build_lane_tables(hp); // (behind the tier's own tables: the pass in front of it, lmpc_lane.hpp)
     return at;
+}
+
+// Tables of the one-instance-per-lane pass (lmpc_lane.hpp) for a controller on the Riccati-factor tier: the stage cost as plain dense
+// matrices and the constraint rows grouped by step.  Eligible: inequality rows only, every row a per-step entry (state part on x_k,
+// control part on u_k of the same step).  Per-instance cost references and right-hand sides are checked when a solve is launched
+// (they can be set at any time).  Sets P.lane_tab (-1: not eligible) and P.lane_rps.
+inline void build_lane_tables(HostPlan& hp)
+{
+    FusedPlan& P = hp.plan;
+    P.lane_tab = -1;
+    P.lane_rps = 0;
+    const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
+    if (P.meq > 0 || P.initial_state || nu > 3 || P.denseQ >= 0 || P.rfull > 0) return;
+    std::vector<int> per_step((size_t)N + 1, 0);
+    for (int i = 0; i < P.mgen; ++i) {
+        const int k = hp.row_step[i], ek = hp.row_ekind[i], gk = hp.row_gkind[i];
+        if (ek == kEFull || gk == kGFull || k < 0 || k > N || (k == N && gk != kGNone)) return;
+        per_step[k] += 1;
+    }
+    int rps = 0;
+    for (int k = 0; k <= N; ++k) rps = per_step[k] > rps ? per_step[k] : rps;
+    if (rps > 32) return;
+    int oh, oHN, ohN, oRows;
+    lane_tab_offsets(nx, nu, oh, oHN, ohN, oRows);
+    const int rw = nz + 1;
+    std::vector<double> tab((size_t)oRows + (size_t)(N + 1) * rps * rw, 0.0);
+    auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]  (as build_ric_tables)
+        if (a < nx) return (ct.offM >= 0 && ct.kind != kCostControl) ? hp.params[(size_t)ct.offM + r + ct.rows * a] : 0.0;
+        return (ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed)) ? hp.params[(size_t)ct.offN + r + ct.rows * (a - nx)] : 0.0;
+    };
+    for (int t = 0; t < P.ncost; ++t) {
+        const CostTerm& ct = P.cost[t];
+        if (ct.full) return;
+        const bool in_stage = ct.kind != kCostTarget; // TargetCost: the last state only (costFunctions.cpp:107-120)
+        const bool in_term = ct.kind == kCostTrajectory || ct.kind == kCostTarget; // MixedCost stops at x_{N-1} (:207)
+        for (int r = 0; r < ct.rows; ++r) {
+            const double w = hp.params[(size_t)ct.offW + r], pr = hp.params[(size_t)ct.offP + r];
+            for (int a = 0; a < nz; ++a) {
+                if (in_stage) {
+                    for (int b = 0; b < nz; ++b) tab[(size_t)a + nz * b] += (coef(ct, r, a) * w) * coef(ct, r, b);
+                    tab[(size_t)oh + a] += -(coef(ct, r, a) * w) * pr;
+                }
+                if (in_term && a < nx) {
+                    for (int b = 0; b < nx; ++b) tab[(size_t)oHN + a + nx * b] += (coef(ct, r, a) * w) * coef(ct, r, b);
+                    tab[(size_t)ohN + a] += -(coef(ct, r, a) * w) * pr;
+                }
+            }
+        }
+    }
+    for (int c = nx; c < nz; ++c) {
+        double one = 1.0;
+        one *= 1e-6; // Q_.setIdentity(); Q_ *= 1e-6;  (LMPC.cpp:228-229)
+        tab[(size_t)c + nz * c] += one;
+    }
+    std::vector<int> filled((size_t)N + 1, 0);
+    for (int k = 0; k <= N; ++k)
+        for (int r = 0; r < rps; ++r) tab[(size_t)oRows + ((size_t)k * rps + r) * rw + nz] = HUGE_VAL;
+    for (int i = 0; i < P.mgen; ++i) {
+        const int k = hp.row_step[i];
+        double* row = tab.data() + oRows + ((size_t)k * rps + filled[k]++) * rw;
+        if (hp.row_ekind[i] == kEOneHot) row[hp.row_eoff[i]] = 1.0;
+        if (hp.row_ekind[i] == kEDense)
+            for (int c = 0; c < nx; ++c) row[c] = hp.params[(size_t)hp.row_eoff[i] + c];
+        if (hp.row_gkind[i] == kGStep)
+            for (int c = 0; c < nu; ++c) row[nx + c] = hp.params[(size_t)hp.row_goff[i] + c];
+        row[nz] = hp.row_f[i];
+    }
+    if (hp.params.size() & 1) hp.params.push_back(0.0);
+    P.lane_tab = (int)hp.params.size();
+    P.lane_rps = rps;
+    hp.params.insert(hp.params.end(), tab.begin(), tab.end());
 }
 
 // Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
@@ -481,6 +554,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     }
     P.denseQ = P.densec = P.denseE = P.densef = -1;
     P.ric_tab = -1;
+    P.lane_tab = -1;
     if (!dQ.empty()) {
         P.denseQ = push(dQ.data(), U * U);
         P.densec = push(dc.data(), U);

@@ -35,6 +35,21 @@ COPRA_DEV void wave_sync_full() { __syncthreads(); }
 
 COPRA_DEV int atomic_append(int* counter) { return atomicAdd(counter, 1); }
 COPRA_DEV long long cycle_counter() { return (long long)__builtin_readcyclecounter(); } // s_memtime
+COPRA_DEV int atomic_add_i32(int* counter, int v) { return atomicAdd(counter, v); }
+// number of lanes below this one whose flag is set (and the wave's total): one ballot, no LDS
+COPRA_DEV int wave_prefix_count(bool flag, int& total)
+{
+    const unsigned long long m = __ballot(flag);
+    total = __popcll(m);
+    return __popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
+}
+// a table entry at a wave-uniform index: read through the constant address space, so that it is a scalar load (s_load, SGPR operand
+// of the multiply-add that uses it) whatever the kernel stores elsewhere
+COPRA_DEV double uniform_load(const double* p, int idx)
+{
+    typedef const double __attribute__((address_space(4))) * cptr_t;
+    return ((cptr_t)(unsigned long long)p)[idx];
+}
 
 COPRA_DEV double* lds_base()
 {

@@ -5,6 +5,7 @@
 #include "../../copra_amd/csrc/islmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused_ric.hpp"
+#include "../../copra_amd/csrc/lmpc_lane.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati_mfma.hpp"
@@ -201,6 +202,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         sizes[5] = P.lds.rcap;
         sizes[6] = P.lds.tri;
         sizes[7] = P.lds.ric;
+        sizes[8] = -1; // instances finished by the one-instance-per-lane pass (-1: it did not run)
     }
     if (!A) return 0; // size query only
     if (P.use_large) { // workgroup-per-instance kernel: one resident workgroup walks the batch (persistent grid)
@@ -241,26 +243,27 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         LdsLayout lq {};
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
+    bool lane_failed = false; // (the instance comes from the one-instance-per-lane pass with a failed factorisation)
     auto body = [&](const FusedPlan& PP, int b) {
         // (shapes beyond the library's instantiations: what copra_batch_specialise compiles at run time)
         if (PP.lds.tri && PP.lds.ric && PP.nx == 6 && PP.nu == 3 && PP.N == 12)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 4 && PP.nu == 2 && PP.N == 16)
-            PP.lds.q1regs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 5 && PP.nu == 3 && PP.N == 12)
-            PP.lds.q1regs ? lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<5, 3, 12, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<5, 3, 12, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 10)
-            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<2, 1, 10, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 10, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 40)
-            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<2, 1, 40, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 40, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.N == 10) // (select_fused_kernel: the factor in Riccati form)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.N == 15)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b);
+            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric && PP.lds.q1regs)
-            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
+            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b, lane_failed);
         else if (PP.lds.tri && PP.lds.ric)
-            lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b);
+            lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b, lane_failed);
         else if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)
@@ -279,9 +282,49 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             lmpc_fused_body<0, 0, 0, 0>(PP, b);
     };
     const size_t bytes1 = (size_t)P.lds.total * sizeof(double);
+    // the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp), as copra_batch_solve runs it
+    // (copra_hip.hip: lane_pass_wanted): the instances it does not finish go through the first tier
+    bool lane_pass = P.lds.ric && P.lane_tab >= 0 && !P.row_f_inst && dump_instance < 0 && !std::getenv("COPRA_NO_LANE_PASS")
+        && ((P.nx == 6 && P.nu == 3) || (P.nx == 4 && P.nu == 2) || (P.nx == 5 && P.nu == 3) || (P.nx == 2 && P.nu == 1));
+    for (int k = 0; k < kMaxCosts; ++k) lane_pass = lane_pass && !P.cost_p[k];
+    std::vector<int> lane_list((size_t)dims->batch + 64, -1);
+    std::vector<double> lane_ws;
+    int lane_count = 0, lane_other = 0;
+    if (lane_pass) {
+        const int groups = (dims->batch + 63) / 64;
+        P.lane_bp = groups * 64;
+        lane_ws.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * P.lane_bp, 0.0);
+        P.lane_ws = lane_ws.data();
+        P.lane_list = lane_list.data();
+        P.lane_count = &lane_count;
+        P.lane_zero = &lane_other;
+        for (int g = 0; g < groups; ++g) {
+            int oHl = 0;
+            const size_t lbytes = (size_t)lane_lds_doubles(P.nx, P.nu, oHl) * sizeof(double);
+            int r = emu::run_wave([&]() {
+                if (P.nx == 6) lmpc_lane_body<6, 3>(P, g);
+                else if (P.nx == 4) lmpc_lane_body<4, 2>(P, g);
+                else if (P.nx == 5) lmpc_lane_body<5, 3>(P, g);
+                else lmpc_lane_body<2, 1>(P, g);
+            }, lbytes, g, groups);
+            if (r != 0) return -100;
+        }
+        P.lane_from_list = 1;
+        P.lane_handover = (P.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) ? 1 : 0;
+        for (int k = 0; k < lane_count; ++k) {
+            const int raw = lane_list[(size_t)k], b = raw & 0x7fffffff;
+            lane_failed = raw < 0;
+            int r = emu::run_wave([&]() { body(P, b); }, bytes1, b, dims->batch);
+            if (r != 0) return -100;
+        }
+        lane_failed = false;
+        P.lane_from_list = 0;
+        if (sizes) sizes[8] = dims->batch - lane_count;
+    } else {
     for (int b = 0; b < dims->batch; ++b) {
         int r = emu::run_wave([&]() { body(P, b); }, bytes1, b, dims->batch);
         if (r != 0) return -100;
+    }
     }
     if (sizes) sizes[4] = ovf_count;
     if (ovf_count > 0) {

@@ -60,7 +60,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
     cc = _capi.pack_costs(costs, keep)
     kk = _capi.pack_cstrs(cstrs, keep)
     dims = _capi.Dims(nx, nu, N, batch)
-    sizes = (C.c_int * 8)()
+    sizes = (C.c_int * 9)()
     vp = C.c_void_p
     isd, x0lb, x0ub, x0o = vp(), None, None, None
     if initial_state is not None:
@@ -101,7 +101,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
     out = dict(control=u, trajectory=tr, status=st, iter=it, lds_bytes=sizes[3], overflowed=sizes[4], rcap=sizes[5], factor_only=bool(sizes[6]),
-               riccati_factor=bool(sizes[7]))
+               riccati_factor=bool(sizes[7]), lane_pass_finished=sizes[8])
     if x0o is not None:
         out["x0_opt"] = x0o
     if dump_instance >= 0:

@@ -52,6 +52,13 @@ COPRA_DEV void bt_sync() { emu::barrier_block(); }
 COPRA_DEV double* lds_base() { return emu::g_wave.lds; }
 COPRA_DEV long long cycle_counter() { return 0; }
 COPRA_DEV int atomic_append(int* counter) { return (*counter)++; }
+COPRA_DEV int atomic_add_i32(int* counter, int v)
+{
+    const int o = *counter;
+    *counter += v;
+    return o;
+}
+COPRA_DEV double uniform_load(const double* p, int idx) { return p[idx]; }
 
 // `src` is a lane of the caller's own wave
 COPRA_DEV double emu_xchg_f64(double v, int src)
@@ -91,6 +98,20 @@ COPRA_DEV double shfl_up0_f64(double v, int delta)
 }
 COPRA_DEV double bcast_f64(double v, int src) { return emu_xchg_f64(v, src); }
 COPRA_DEV int bcast_i32(int v, int src) { return (int)emu_xchg_f64((double)v, src); }
+COPRA_DEV int wave_prefix_count(bool flag, int& total)
+{
+    const int me = emu::g_wave.lane, base = me & ~63;
+    emu::g_wave.xi[me] = flag ? 1 : 0;
+    emu::barrier_wave();
+    int before = 0;
+    total = 0;
+    for (int l = 0; l < 64; ++l) {
+        total += emu::g_wave.xi[base + l];
+        if (l < (me & 63)) before += emu::g_wave.xi[base + l];
+    }
+    emu::barrier_wave();
+    return before;
+}
 COPRA_DEV void sched_fence() { }
 COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
