@@ -80,22 +80,22 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
         const double sysB = lane < NX * NU ? P.B[(size_t)inst * NX * NU + lane] : 0.0;
         const double sysD = lane < NX ? P.d[(size_t)inst * NX + lane] : 0.0;
-        const double sysX = lane < NX ? P.x0[(size_t)inst * NX + lane] : 0.0;
-        constexpr int NG = (NH * WR + kWave - 1) / kWave;
-        double gv[NG];
+        constexpr int NG = (NH * WR + kWave - 1) / kWave, NT = (X + kWave - 1) / kWave;
+        double gv[NG], gx[NT];
         const double* const wsb = P.lane_ws + (size_t)inst;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int idx = lane + kWave * u;
             gv[u] = wsb[(size_t)(idx < NH * WR ? idx : 0) * (size_t)P.lane_bp];
         }
+        // the pass has also left the unconstrained minimiser (U in `control`, its trajectory in `trajectory`): no roll-out below
+        const double gu = P.control[(size_t)inst * NV + (lane < NV ? lane : 0)];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) gx[u] = P.trajectory[(size_t)inst * X + ((lane + kWave * u < X) ? lane + kWave * u : 0)];
         rows.cache_own_row();
         if (lane < NX * NX) A[lane] = sysA;
         if (lane < NX * NU) B[lane] = sysB;
-        if (lane < NX) {
-            D[lane] = sysD;
-            X0[lane] = sysX;
-        }
+        if (lane < NX) D[lane] = sysD;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int idx = lane + kWave * u, k = idx / WR, e = idx - k * WR;
@@ -121,6 +121,11 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
         if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
         if (lane == 1) F[NH * RR::SZ + RR::cO] = 1.0;
+        wave_sync(); // (A, B, d have been read: the solver vectors share their place)
+        if (lane < NV) S.xs[lane] = gu;
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+            if (lane + kWave * u < X) XU[lane + kWave * u] = gx[u];
         stamp[1] = cycle_counter();
     } else if (from_model) {
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
@@ -555,7 +560,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // at Xbar's place (free: the preview's free response is not used); in the compact variant the preview steps wrote them.
     // (compact variant: the norm of row `lane` stays in a register -- StageRows::nb_mine --, only rows 64.. go to LDS)
     const double* const X0r = compact ? XU : X0; // (compact variant: the norms of rows 64.. overwrite the system's slots)
-    if (compact) {
+    if (compact && !from_lane) { // (from_lane: the whole trajectory is there already)
         if (lane < NX) XU[lane] = X0[lane];
         wave_sync();
     }
@@ -630,7 +635,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // ---- 4. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k B d; K_k I 0] [x_k; kv_k; 1] from x_0, on the matrix
     //      cores like the recursions of ric_factor.hpp (v_mfma_f64_4x4x4: block b of the lane = rows 4b .. 4b+3 of the
     //      stacked matrix, the state handed on by a DPP row broadcast) ----
-    {
+    if (!from_lane) { // (from_lane: U and its trajectory came from the pass in front)
         const int q = lane >> 4, b4 = (lane >> 2) & 3, r = lane & 3, row = 4 * b4 + r;
         int off[2], km[2];
 #pragma unroll
