@@ -75,19 +75,9 @@ template <int NX, int NU, int NH, int QR>
 __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {
     if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
-    int inst = P.inst_offset + (int)blockIdx.x;
-    bool lane_failed = false;
-    if (P.lane_from_list) { // behind the one-instance-per-lane pass: only the instances it left over
-        // Workgroups go to the eight XCDs in turn (each has its own L2), and the gather of the stage records reads 64-byte sectors
-        // that eight neighbouring instances share: entry (w % 8) * per + w / 8 of the list gives every XCD a CONTIGUOUS eighth of it,
-        // so that the neighbours run on one XCD at about the same time and seven of their eight reads hit its L2.
-        const int cnt = *P.lane_count, per = (cnt + 7) >> 3, w = (int)blockIdx.x;
-        const int idx = (w & 7) * per + (w >> 3);
-        if ((w >> 3) >= per || idx >= cnt) return;
-        inst = P.lane_list[idx];
-        lane_failed = inst < 0; // (top bit: its factorisation failed)
-        inst &= 0x7fffffff;
-    }
+    int inst;
+    bool lane_failed;
+    if (!ric_tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
     lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, inst, lane_failed);
 }
 // One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
@@ -415,6 +405,7 @@ struct copra_batch {
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_fused = nullptr, jit_shared = nullptr;
     hipFunction_t jit_fused_q0 = nullptr; // Riccati-factor tier compiled for this shape: Q1 in LDS (further down the layout ladder)
+    hipFunction_t jit_lane = nullptr; // ... and the one-instance-per-lane pass in front of it (lmpc_lane.hpp)
     bool jit_ric = false; // the code object holds the Riccati-factor tier (lmpc_fused_ric.hpp) of this controller's shape
     int jit_lanes = 64; // lanes per instance the code object was compiled for
     int jit_tri = 0; // ... and whether for the factor-only layout
@@ -549,10 +540,10 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
     if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS")) return false;
     const char* dbg = std::getenv("COPRA_LANE_DBG");
     if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
-    if (!P.lds.ric || P.lane_tab < 0 || jit_launch || h->packed || h->shared || P.row_f_inst) return false;
+    if (!P.lds.ric || P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || P.row_f_inst) return false;
     for (int t = 0; t < kMaxCosts; ++t)
         if (h->cost_p[t]) return false;
-    return select_lane_kernel(P) != nullptr;
+    return (jit_launch ? h->jit_lane != nullptr : select_lane_kernel(P) != nullptr);
 }
 static copra_status_t ensure_lane_buffers(copra_batch* h)
 {
@@ -1525,25 +1516,30 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     if (!h->shared && ric_pays && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI")) {
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {
-            char keyr[128], srcr[2048];
+            char keyr[128], srcr[3072];
             snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d", P.nx, P.nu, P.N);
             snprintf(srcr, sizeof srcr,
-                "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\nusing namespace copra_hip;\n"
+                "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\n#include \"lmpc_lane.hpp\"\nusing namespace copra_hip;\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d>(P, P.inst_offset + (int)blockIdx.x); }\n"
+                "  int inst; bool failed; if (!ric_tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused_q0(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, P.inst_offset + (int)blockIdx.x); }\n",
-                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N);
+                "  int inst; bool failed; if (!ric_tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, inst, failed); }\n"
+                "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
+                "{ lmpc_lane_body<%d, %d>(P, (int)blockIdx.x); }\n",
+                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N, P.nx, P.nu);
             std::string objr;
             const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
             if (rcr != COPRA_OK) return rcr;
             hipModule_t modr = nullptr;
             HIP_TRY(hipModuleLoad(&modr, objr.c_str()));
-            hipFunction_t fr = nullptr, fq = nullptr;
+            hipFunction_t fr = nullptr, fq = nullptr, fl = nullptr;
             hipError_t er = hipModuleGetFunction(&fr, modr, "copra_jit_fused");
             if (er == hipSuccess) er = hipModuleGetFunction(&fq, modr, "copra_jit_fused_q0");
+            if (er == hipSuccess) er = hipModuleGetFunction(&fl, modr, "copra_jit_lane");
             double* dparams = nullptr;
             if (er == hipSuccess) er = upload(&dparams, trial.params); // (the stage-cost tables were appended)
             if (er != hipSuccess) {
@@ -1564,6 +1560,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
             h->jit_ric = true;
             h->jit_fused = fr;
             h->jit_fused_q0 = fq;
+            h->jit_lane = fl;
             h->jit_shared = nullptr;
             return COPRA_OK;
         }
@@ -1819,12 +1816,19 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
         const unsigned g0 = (unsigned)(P.lane_bp / kWave);
         if (const char* e = std::getenv("COPRA_LANE_DBG")) P.lane_dbg = std::atoi(e);
-        LDS_OPT_IN(select_lane_kernel(P), lane_lds_bytes(P));
-        if (ext_timed)
-            hipExtLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, h->ev0, nullptr, 0, P);
-        else
-            hipLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, P);
-        HIP_TRY(hipGetLastError());
+        if (jit_launch) {
+            FusedPlan Pl = P;
+            void* largs[] = { &Pl };
+            LDS_OPT_IN(h->jit_lane, lane_lds_bytes(P));
+            HIP_TRY(hipModuleLaunchKernel(h->jit_lane, g0, 1, 1, 64, 1, 1, (unsigned)lane_lds_bytes(P), s, largs, nullptr));
+        } else {
+            LDS_OPT_IN(select_lane_kernel(P), lane_lds_bytes(P));
+            if (ext_timed)
+                hipExtLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, h->ev0, nullptr, 0, P);
+            else
+                hipLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, P);
+            HIP_TRY(hipGetLastError());
+        }
         P.lane_from_list = 1;
         P.lane_handover = (P.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) ? 1 : 0;
         P.lane_zero = nullptr;
@@ -1836,8 +1840,8 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         const unsigned per = 64u / (unsigned)h->jit_lanes;
         const hipFunction_t jfn = (h->jit_ric && P.lds.q1regs == 0) ? h->jit_fused_q0 : h->jit_fused;
         LDS_OPT_IN(jfn, (size_t)per * h->hp.lds_bytes);
-        HIP_TRY(hipModuleLaunchKernel(jfn, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
-            per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
+        const unsigned gj = lane_pass ? (((unsigned)P.batch + 7u) & ~7u) : ((unsigned)P.batch + per - 1) / per; // (the list is dealt out in eighths)
+        HIP_TRY(hipModuleLaunchKernel(jfn, gj, 1, 1, 64, 1, 1, per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
     } else if (h->packed) {
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
     } else {
