@@ -17,9 +17,10 @@ synthetic CoM preview systems, inputs already resident in HBM.
 Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- dominant kernel (copra_lmpc_fused_ric_kernel): algorithmic bytes per launch (2016 B/solve: A,B,d,x0 in,
-                  U,X out) / average launch duration from HIP events recorded by the C ABI on the launch
-                  stream, against the 8 TB/s HBM peak.  The path is FP64-latency/LDS bound, not HBM bound,
+  roofline     -- the pair of launches that is the hot path (copra_lmpc_lane_kernel: LQ sweep + roll-out for every instance, one
+                  per lane; copra_lmpc_fused_ric_kernel: the active-set iteration for the instances that need it): algorithmic
+                  bytes per launch (2016 B/solve: A,B,d,x0 in, U,X out) / duration of the pair from HIP events
+                  carried in their dispatch packets on the launch stream, against the 8 TB/s HBM peak.  The path is FP64-latency/LDS bound, not HBM bound,
                   so the fraction is small by construction; executed-FP64 and VALU-issue figures next to it.
   cpu_baseline -- the oracle (C port of the reference's CPU QuadProgDense path) timed on this host's cores on a
                   bounded sample of the same workload, rank 0, N=1 only.
@@ -527,6 +528,14 @@ def main():
                 kname = max(cands, key=lambda k: ctr[k].get("SQ_WAVE_CYCLES", {}).get("mean_per_launch", 0.0))
                 dominant = kname.split("<")[0].replace("void ", "")
                 c = {k: v["mean_per_launch"] for k, v in ctr[kname].items()}
+                # since round 3 the hot path is a PAIR of launches: the one-instance-per-lane pass (LQ sweep + roll-out for the whole
+                # batch, lmpc_lane.hpp) and the first tier for the instances it leaves over -- `kernel_ms` spans both (events in
+                # their dispatch packets), so the counters are those of both, per launch of the pair
+                lane = [k for k in ctr if "copra_lmpc_lane_kernel" in k]
+                if lane:
+                    dominant = "copra_lmpc_lane_kernel + " + dominant
+                    for k, v in ctr[lane[0]].items():
+                        c[k] = c.get(k, 0.0) + v["mean_per_launch"]
                 traffic = 1024.0 * (c["FETCH_SIZE"] + c["WRITE_SIZE"])
                 traffic_src = os.path.relpath(prof, ROOT) + " (rocprofv3 --pmc, separate passes)"
                 issue = {"valu_instructions_per_solve": c["SQ_INSTS_VALU"] / batch,

@@ -256,6 +256,8 @@ def lib():
         L.copra_batch_last_solve_seconds.argtypes = [vp, _dp]
         L.copra_batch_last_first_tier_seconds.restype = C.c_int
         L.copra_batch_last_first_tier_seconds.argtypes = [vp, _dp]
+        L.copra_batch_lane_pass_info.restype = C.c_int
+        L.copra_batch_lane_pass_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.copra_batch_phase_profile.restype = C.c_int
         L.copra_batch_phase_profile.argtypes = [vp, C.c_int, vp]
         L.copra_qp_solve_dense_batch.restype = C.c_int

@@ -200,6 +200,13 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_last_first_tier_seconds(self._h, C.byref(s)))
         return s.value
 
+    def lane_pass_info(self):
+        """(ran, finished): whether the last solve ran the one-instance-per-lane pass in front of the first tier, and how many
+        instances ended in it (their unconstrained minimiser violates nothing); waits for the solve"""
+        ran, fin = C.c_int(), C.c_int()
+        _capi.check(self._lib.copra_batch_lane_pass_info(self._h, C.byref(ran), C.byref(fin)))
+        return bool(ran.value), fin.value
+
     PHASES = ("preview", "costs", "norms", "cholesky", "inverse_x0", "active_set", "results", "total")
 
     def enable_phase_profile(self, on=True):

@@ -778,7 +778,7 @@ static bool use_riccati(copra_batch* h)
 
 extern "C" {
 
-int copra_abi_version(void) { return 3; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async
+int copra_abi_version(void) { return 4; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info
 
 copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
     double* Psi, double* xi)
@@ -2099,6 +2099,22 @@ copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* sec
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->evm));
     *seconds = (double)ms * 1e-3;
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_lane_pass_info: null handle");
+    if (ran) *ran = h->lane_ran ? 1 : 0;
+    if (finished) {
+        *finished = 0;
+        if (h->lane_ran) {
+            int left = 0;
+            HIP_TRY(hipStreamSynchronize(h->last_stream));
+            HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+            *finished = h->hp.plan.batch - left;
+        }
+    }
     return COPRA_OK;
 }
 

@@ -276,6 +276,13 @@ copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds)
 /* ---- the first launch of that solve alone (no reference counterpart: the figure a kernel profile -- rocprofv3 -- of the
  *      dominant kernel is compared with); equals copra_batch_last_solve_seconds where the solve is not timed per launch. ---- */
 copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* seconds);
+/* ---- the one-instance-per-lane pass of the last solve (no reference counterpart; for tests, tuning and the bench line).  For a
+ *      controller whose costs are all per-step entries (src/costFunctions.cpp:63-215) the unconstrained minimiser qpgen2 starts from
+ *      is the LQ roll-out of one Riccati sweep; a pass in front of the first tier does that sweep and roll-out for the whole batch
+ *      with one instance per LANE, finishes every instance whose minimiser violates no constraint (what QuadProgDense::solve returns
+ *      after its first scan, src/QuadProgSolver.cpp:45-72) and hands the factor of the others to the first tier.
+ *      ran: 1 if the last solve ran it; finished: the instances that ended in it (waits for the solve). ---- */
+copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished);
 
 /* ---- device-side split of that time: per-instance shader-clock cycles of the 7 phases of the fused kernel
  *      (preview, costs, norms, cholesky, inverse+x0, active set, result stores) + total; 8 values per instance.

@@ -876,3 +876,57 @@ def test_riccati_factor_tier_ladder_steps(emu, oracle, steps, monkeypatch):
     monkeypatch.setenv("COPRA_EMU_LADDER_STEPS", str(steps))
     re, ro = _compare(emu, oracle, wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     assert re["riccati_factor"] and re["rcap"] > base["rcap"] and re["overflowed"] <= base["overflowed"]
+
+
+@pytest.mark.parametrize("mode", ["handover", "filter_only", "off"])
+@pytest.mark.parametrize("batch,N,vmax,umax", [(150, 20, 0.6, 3.0), (70, 15, 0.3, 1.5), (64, 10, 0.6, 3.0)])
+def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vmax, umax):
+    """lmpc_lane.hpp in front of the Riccati-factor tier: LQ sweep + roll-out with one instance per LANE (64 instances per wave; the last
+    wave of the batch is ragged).  It must finish EXACTLY the instances whose unconstrained minimiser violates nothing (the oracle's
+    iteration count (1, 0): qpgen2's first scan finds nothing) and leave the others to the first tier, which takes the factor over
+    (`handover`: K | kv | Lam^-1 and the row-norm sums come from the pass, no sweep and no roll-out there) or sweeps itself
+    (`filter_only`); `off`: the tier alone.  Statuses, BOTH iteration counters, U and X against the oracle in all three."""
+    from copra_amd import workloads
+    if mode == "off":
+        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+    if mode == "filter_only":
+        monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+    wl = workloads.com_preview(batch, N=N, v_max=vmax, u_max=umax, seed=9)
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    re = emu.lmpc_solve(*args)
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    assert re["riccati_factor"]
+    assert (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
+    ok = ro["status"] == 0
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
+    assert re["lane_pass_finished"] == (-1 if mode == "off" else at_minimiser)
+    if vmax == 0.6:
+        assert 0 < at_minimiser < batch  # (both kinds of instance in the batch)
+
+
+def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
+    """per-instance control bounds go through the pass (every lane reads its own); per-instance cost references and right-hand sides
+    are not its business -- the solve must not run it then (and still agree with the oracle, on the tier alone)"""
+    from copra_amd import workloads
+    b = 24
+    wl = workloads.com_preview(b, v_max=0.6, u_max=3.0, seed=12)
+    rng = np.random.default_rng(3)
+    n = 3 * wl["N"]
+    umax = 3.0 * rng.uniform(0.3, 1.2, b)
+    ub = np.repeat(umax[:, None], n, axis=1)
+    lb = -0.8 * ub
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    re = emu.lmpc_solve(*args, bounds=(lb, ub))
+    finished = 0
+    for k in range(b):
+        cs = [wl["cstrs"][0], dict(wl["cstrs"][1], lower=[-0.8 * umax[k]] * 3, upper=[umax[k]] * 3)]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
+        assert re["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-9
+            finished += int(ro["iter"][0] == 1)
+    assert re["lane_pass_finished"] == finished > 0
+    refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.01 * rng.standard_normal((b, 6))}
+    re2 = emu.lmpc_solve(*args, cost_refs=refs)
+    assert re2["lane_pass_finished"] == -1 and (re2["status"] == 0).all()

@@ -1319,3 +1319,48 @@ def test_riccati_factor_tier_compiled_for_other_shapes(oracle, tmp_path, shape):
         assert (res["status"] == ref["status"]).all() and (res["iter"][ok] == ref["iter"][ok]).all()
         assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     eng.close()
+
+
+@pytest.mark.parametrize("vmax,umax", [(0.6, 3.0), (0.35, 1.8), (0.25, 1.2)])
+def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
+    """lmpc_lane.hpp (round 3): LQ sweep + roll-out with one instance per lane in front of the headline's tier, at the full batch of
+    BASELINE configs[2] (and a ragged one).  Against the tier alone (COPRA_NO_LANE_PASS): same statuses, BOTH iteration counters
+    equal, U and X to 1e-11; the pass finishes exactly the instances that report the iteration count (1, 0) -- their unconstrained
+    minimiser violates nothing; a stratified sample (every iteration count) against the oracle."""
+    from copra_amd import BatchLMPC, workloads
+    for b in (65536, 65536 - 37):
+        wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
+        out = {}
+        for mode in ("off", "filter_only", "on"):
+            monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+            monkeypatch.delenv("COPRA_NO_LANE_HANDOVER", raising=False)
+            if mode == "off":
+                monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+            if mode == "filter_only":
+                monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+            eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+            eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+            for _ in range(3):  # (the layout controller may step down the tier's ladder between solves)
+                eng.solve()
+            out[mode] = (eng.results(), eng.lane_pass_info())
+            eng.close()
+        r0 = out["off"][0]
+        assert out["off"][1] == (False, 0)
+        ok = r0["status"] == 0
+        for mode in ("filter_only", "on"):
+            r1, (ran, finished) = out[mode]
+            assert (r1["status"] == r0["status"]).all() and (r1["iter"] == r0["iter"]).all()
+            assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-11
+            at_minimiser = int(((r0["iter"][:, 0] == 1) & ok).sum())
+            if mode == "on":  # (with the hand-over of the factor the pass always runs)
+                assert ran and finished == at_minimiser
+            else:  # (filter only: switched off after the first solves when fewer than one instance in eight ends in it)
+                assert (ran and finished == at_minimiser) if at_minimiser * 8 >= b else not ran
+        if b == 65536:
+            r1 = out["on"][0]
+            pick = np.concatenate([np.flatnonzero(r1["iter"][:, 0] == v)[:96] for v in range(1, int(r1["iter"][:, 0].max()) + 1)])
+            ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], wl["cstrs"],
+                                          nthreads=8)
+            assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick] == ref["iter"]).all()
+            okp = ref["status"] == 0
+            assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL and _rel(r1["trajectory"][pick][okp], ref["trajectory"][okp]) <= RTOL
