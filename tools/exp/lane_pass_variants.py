@@ -11,7 +11,7 @@ from copra_amd import BatchLMPC, workloads  # noqa: E402
 b = 65536
 wl = workloads.com_preview(b, v_max=50.0, u_max=500.0)
 os.environ["COPRA_LANE_KEEP"] = "1"
-for dbg in (0, 1, 2, 3):
+for dbg in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]:
     os.environ["COPRA_LANE_DBG"] = str(dbg)
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
