@@ -87,6 +87,13 @@ __global__ __launch_bounds__(64, 1) void copra_lmpc_lane_kernel(const FusedPlan 
 {
     lmpc_lane_body<NX, NU>(P, (int)blockIdx.x);
 }
+// ... and its shared-model form: the stage records are those of the whole batch (wave-uniform: scalar operands), only the roll-out
+// from each instance's x0 is left
+template <int NX, int NU>
+__global__ __launch_bounds__(64, 4) void copra_lmpc_lane_shared_kernel(const FusedPlan P)
+{
+    lmpc_lane_shared_body<NX, NU>(P, (int)blockIdx.x);
+}
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
 template <int NX, int NU, int NH, int RP>
@@ -529,6 +536,11 @@ static fused_kernel_t select_lane_kernel(const FusedPlan& P)
     if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_kernel<6, 3>;
     return nullptr;
 }
+static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
+{
+    if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_shared_kernel<6, 3>;
+    return nullptr;
+}
 static size_t lane_lds_bytes(const FusedPlan& P)
 {
     int oH = 0;
@@ -545,16 +557,18 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
         if (h->cost_p[t]) return false;
     return (jit_launch ? h->jit_lane != nullptr : select_lane_kernel(P) != nullptr);
 }
-static copra_status_t ensure_lane_buffers(copra_batch* h)
+static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
 {
-    if (h->d_lane_ws) return COPRA_OK;
     const FusedPlan& P = h->hp.plan;
     const size_t bp = ((size_t)P.batch + kWave - 1) / kWave * kWave;
-    HIP_TRY(hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int)));
-    HIP_TRY(hipMemset(h->d_lane_count, 0, 2 * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&h->d_lane_list, bp * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double)));
-    h->lane_cur = 1;
+    if (!h->d_lane_count) {
+        HIP_TRY(hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int)));
+        HIP_TRY(hipMemset(h->d_lane_count, 0, 2 * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&h->d_lane_list, bp * sizeof(int)));
+        h->lane_cur = 1;
+    }
+    if (need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
+        HIP_TRY(hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double)));
     return COPRA_OK;
 }
 // The pass pays when a fair share of the batch ends in it.  After each of the first solves that ran it: if fewer than one instance in
@@ -1708,8 +1722,28 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         if (h->shared_ric && P.lds.ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
             FusedPlan Pr = P;
             Pr.ric_model = h->d_ric_model;
+            // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
+            // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
+            unsigned g1 = (unsigned)P.batch;
+            if (!h->lane_off && !std::getenv("COPRA_NO_LANE_PASS") && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
+                && !P.row_f_inst && select_lane_shared_kernel(P)) {
+                rc = ensure_lane_buffers(h, false);
+                if (rc != COPRA_OK) return rc;
+                h->lane_cur ^= 1;
+                h->lane_ran = true;
+                Pr.lane_list = h->d_lane_list;
+                Pr.lane_count = h->d_lane_count + h->lane_cur;
+                Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
+                Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
+                hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
+                HIP_TRY(hipGetLastError());
+                Pr.lane_from_list = 1;
+                Pr.lane_handover = 1;
+                Pr.lane_zero = nullptr;
+                g1 = ((unsigned)P.batch + 7u) & ~7u; // (the list is dealt out in eighths: ric_tier_instance)
+            }
             LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
-            hipLaunchKernelGGL(select_fused_kernel(Pr), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, Pr);
+            hipLaunchKernelGGL(select_fused_kernel(Pr), dim3(g1), dim3(64), h->hp.lds_bytes, s, Pr);
             HIP_TRY(hipGetLastError());
         } else if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
             FusedPlan Pj = P;
@@ -1805,7 +1839,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     // first tier below runs for the others only
     bool lane_pass = lane_pass_wanted(h, P, jit_launch);
     if (lane_pass) {
-        rc = ensure_lane_buffers(h);
+        rc = ensure_lane_buffers(h, true);
         if (rc != COPRA_OK) return rc;
         h->lane_cur ^= 1;
         h->lane_ran = true;

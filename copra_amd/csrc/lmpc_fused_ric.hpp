@@ -94,6 +94,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // of NH WR doubles (eleven loads per lane at the headline shape) and Acl = A + B K instead of the 32 k cycles of the sweep
     const bool from_lane = !from_model && compact && P.lane_from_list && P.lane_handover && !P.ric_model_out;
     if (lane_failed) status = 2; // (its factorisation met a control block that is not positive definite)
+    // the unconstrained minimiser and its trajectory came from the pass in front (either form of it): no roll-out below
+    const bool have_ux = from_lane || (from_model && compact && P.lane_from_list && P.lane_handover);
     if (from_lane) {
         constexpr int KWl = NU * NX, WR = KWl + NU + NU * (NU + 1) / 2 + NX; // (plan.hpp: lane_ws_rows)
         const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
@@ -152,6 +154,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
         if (!compact) // (compact variant: the blocks G are not kept at all -- the row norms come from the model too)
             for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
+        if (have_ux) { // (behind the shared-model lane pass, lmpc_lane_shared_body: U and its trajectory are there already)
+            if (lane < NV) S.xs[lane] = P.control[(size_t)inst * NV + lane];
+            for (int e = lane; e < X; e += kWave) XU[e] = P.trajectory[(size_t)inst * X + e];
+        }
         stamp[1] = cycle_counter();
     } else {
     // ---- 0. coalesced loads of this instance's system: into registers now, into LDS after the loads of the cost tables
@@ -579,7 +585,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // at Xbar's place (free: the preview's free response is not used); in the compact variant the preview steps wrote them.
     // (compact variant: the norm of row `lane` stays in a register -- StageRows::nb_mine --, only rows 64.. go to LDS)
     const double* const X0r = compact ? XU : X0; // (compact variant: the norms of rows 64.. overwrite the system's slots)
-    if (compact && !from_lane) { // (from_lane: the whole trajectory is there already)
+    if (compact && !have_ux) { // (have_ux: the whole trajectory is there already)
         if (lane < NX) XU[lane] = X0[lane];
         wave_sync();
     }
@@ -654,7 +660,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // ---- 4. unconstrained minimiser: roll-out [x_{k+1}; u_k] = [Acl_k B d; K_k I 0] [x_k; kv_k; 1] from x_0, on the matrix
     //      cores like the recursions of ric_factor.hpp (v_mfma_f64_4x4x4: block b of the lane = rows 4b .. 4b+3 of the
     //      stacked matrix, the state handed on by a DPP row broadcast) ----
-    if (!from_lane) { // (from_lane: U and its trajectory came from the pass in front)
+    if (!have_ux) { // (have_ux: U and its trajectory came from the pass in front)
         const int q = lane >> 4, b4 = (lane >> 2) & 3, r = lane & 3, row = 4 * b4 + r;
         int off[2], km[2];
 #pragma unroll

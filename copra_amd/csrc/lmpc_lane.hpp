@@ -456,4 +456,137 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     }
 }
 
+// The same pass for the SHARED-MODEL path (copra_batch_set_shared_system; receding-horizon ticks): the batch shares (A, B, d), so the
+// sweep was done once by the prepare launch (FusedPlan::ric_model: the stage records of lmpc_fused_ric.hpp) and every instance only
+// rolls out from its own x0 -- with one instance per lane the records are WAVE-UNIFORM: every matrix entry is a scalar operand of the
+// multiply-add (s_load, no vector registers, no LDS), a stage is 80 v_fma_f64 for 64 instances.  Rows, bounds, verdict and the
+// hand-over of U and X to the first tier exactly as above.
+template <int NX, int NU>
+COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
+{
+    constexpr int NZ = NX + NU, RW = NZ + 1;
+    using RR = RicRec<NX, NU>;
+    const int lane = lane_id();
+    const int inst = group * kWave + lane;
+    const bool valid = inst < P.batch;
+    const int NH = P.N;
+    const double* tab = P.params + P.lane_tab;
+    int oh_, oHN_, ohN_, oRows_;
+    lane_tab_offsets(NX, NU, oh_, oHN_, ohN_, oRows_);
+    const int oRows = oRows_;
+    double* lds = lds_base();
+    if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0;
+    const double* const F = P.ric_model; // N stage records + the constant block (B | d | ...)
+    const int li = valid ? inst : 0;
+    double x[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) x[c] = P.x0[(size_t)li * NX + c];
+    const double vsmall = P.vsmall;
+    const int rps = P.lane_rps;
+    bool viol = false;
+    const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
+    const double* const ubp = P.ub_inst ? P.ub_inst + (size_t)li * P.n : P.ub;
+    const bool own_bounds = P.lb_inst != nullptr;
+    constexpr int GS = kLaneGroup, SX = (GS * NX) | 1, SU = (GS * NU) | 1;
+    double* const ldx = lds;
+    double* const ldu = lds + kWave * SX;
+    const int left = P.batch - group * kWave;
+    const int ninst = left < kWave ? left : kWave;
+    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) {
+        for (int r = 0; r < rps; ++r) {
+            const int ro = oRows + (k * rps + r) * RW;
+            double ax = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ax += uniform_load(tab, ro + c) * xk[c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
+            const double s = uniform_load(tab, ro + NZ) - ax;
+            viol = viol || (s <= -vsmall);
+        }
+    };
+    for (int k0 = 0; k0 < NH; k0 += GS) {
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            const int k = k0 + q;
+            const bool on = k < NH;
+            const int kk = on ? k : NH - 1;
+            const int rb = kk * RR::SZ;
+            double u[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double s = uniform_load(F, rb + RR::oKv + c);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oK + c + NU * j) * x[j];
+                u[c] = s;
+            }
+            if (on) {
+                check_rows(k, x, u);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    const double ub = own_bounds ? ubp[k * NU + c] : uniform_load(ubp, k * NU + c);
+                    const double lb = own_bounds ? lbp[k * NU + c] : uniform_load(lbp, k * NU + c);
+                    viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = x[c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = u[c];
+            // x+ = Acl x + B kv + d  (= A x + B u + d: the tier's own roll-out, ric_factor.hpp)
+            double xn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double s = uniform_load(F, NH * RR::SZ + RR::cD + i);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oAcl + i + NX * j) * x[j];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) s += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * uniform_load(F, rb + RR::oKv + c);
+                xn[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = on ? xn[i] : x[i];
+        }
+        wave_sync();
+        const int nst = NH - k0 < GS ? NH - k0 : GS;
+        double* const xg = P.trajectory + (size_t)(group * kWave) * P.X + (size_t)k0 * NX;
+        double* const ug = P.control + (size_t)(group * kWave) * P.n + (size_t)k0 * NU;
+#pragma unroll 4
+        for (int j = 0; j < GS * NX; ++j) {
+            const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
+            if (il < ninst && c < nst * NX) xg[(size_t)il * P.X + c] = ldx[il * SX + c];
+        }
+#pragma unroll 4
+        for (int j = 0; j < GS * NU; ++j) {
+            const int e = j * kWave + lane, il = e / (GS * NU), c = e - il * (GS * NU);
+            if (il < ninst && c < nst * NU) ug[(size_t)il * P.n + c] = ldu[il * SU + c];
+        }
+    }
+    {
+        double u0[NU];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) u0[c] = 0.0;
+        check_rows(NH, x, u0);
+        if (valid) {
+            double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xo[c] = x[c];
+        }
+    }
+    const bool more = valid && viol;
+    int total = 0;
+    const int before = wave_prefix_count(more, total);
+    if (total > 0) {
+        int base = 0;
+        if (lane == 0) base = atomic_add_i32(P.lane_count, total);
+        base = bcast_i32(base, 0);
+        if (more) P.lane_list[base + before] = inst;
+    }
+    if (valid && !viol) {
+        P.status[inst] = 0;
+        P.iter[2 * (size_t)inst] = 1;
+        P.iter[2 * (size_t)inst + 1] = 0;
+    }
+}
+
 } // namespace copra_hip

@@ -519,10 +519,34 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         else
             lmpc_shared_body<0, 0, 0>(PP, b);
     };
+    // in front of the Riccati-factor tier in shared-model mode: the one-instance-per-lane pass in its shared-model form (as copra_batch_solve)
+    std::vector<int> lane_list((size_t)dims->batch + 64, -1);
+    int lane_count = 0, lane_other = 0, lane_finished = -1;
+    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !std::getenv("COPRA_NO_LANE_PASS")) {
+        const int groups = (dims->batch + 63) / 64;
+        P.lane_bp = groups * 64;
+        P.lane_list = lane_list.data();
+        P.lane_count = &lane_count;
+        P.lane_zero = &lane_other;
+        int oHl = 0;
+        const size_t lbytes = (size_t)lane_lds_doubles(P.nx, P.nu, oHl) * sizeof(double);
+        for (int g = 0; g < groups; ++g)
+            if (emu::run_wave([&]() { lmpc_lane_shared_body<6, 3>(P, g); }, lbytes, g, groups) != 0) return -100;
+        P.lane_from_list = 1;
+        P.lane_handover = 1;
+        for (int k = 0; k < lane_count; ++k) {
+            const int b = lane_list[(size_t)k];
+            if (emu::run_wave([&]() { shared(P, b); }, hp.lds_bytes, b, dims->batch) != 0) return -100;
+        }
+        P.lane_from_list = 0;
+        lane_finished = dims->batch - lane_count;
+    } else {
     for (int b = 0; b < dims->batch; ++b)
         if (emu::run_wave([&]() { shared(P, b); }, hp.lds_bytes, b, dims->batch) != 0) return -100;
+    }
     if (sizes) sizes[0] = ovf_count;
     if (sizes) sizes[1] = ric_shared ? 1 : 0;
+    if (sizes) sizes[2] = lane_finished;
     if (ovf_count > 0) {
         FusedPlan P2 = P;
         P2.lds = hp.lds_full;

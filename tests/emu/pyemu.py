@@ -178,7 +178,7 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
     tr = np.full((batch, nx * (N + 1)), np.nan)
     st = np.full(batch, -1, dtype=np.int32)
     it = np.zeros((batch, 2), dtype=np.int32)
-    sizes = (C.c_int * 2)()
+    sizes = (C.c_int * 3)()
     p = _capi.dptr
     rc = lib().emu_lmpc_solve_shared(C.byref(dims), len(costs), cc, len(cstrs), kk, p(Ac), p(Bc), p(dc), p(x0), p(u),
                                      p(tr), st.ctypes.data_as(C.POINTER(C.c_int)),
@@ -186,7 +186,7 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
                                      warm.ctypes.data_as(C.POINTER(C.c_int)) if warm is not None else C.c_void_p())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
-    return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0], riccati_factor=bool(sizes[1]))
+    return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0], riccati_factor=bool(sizes[1]), lane_pass_finished=sizes[2])
 
 
 def qp_dense(Q, c, Aeq, beq, Aineq, bineq, XL, XU):

@@ -930,3 +930,24 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.01 * rng.standard_normal((b, 6))}
     re2 = emu.lmpc_solve(*args, cost_refs=refs)
     assert re2["lane_pass_finished"] == -1 and (re2["status"] == 0).all()
+
+
+def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
+    """the shared-model form of the pass (lmpc_lane_shared_body: the batch-wide stage records as scalar operands, only the roll-out from
+    each x0 is left) in front of the Riccati-factor tier in shared-model mode: it finishes exactly the instances at their unconstrained
+    minimiser, the tier starts the others from the U and X it left; against the oracle and against the tier alone"""
+    from copra_amd import workloads
+    b = 70
+    wl = workloads.com_preview(b, seed=21)
+    A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
+    ro = oracle.lmpc_solve_batch(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), wl["x0"], wl["N"], wl["costs"], wl["cstrs"],
+                                 nthreads=8)
+    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    ok = ro["status"] == 0
+    assert re["riccati_factor"] and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    assert 0 < re["lane_pass_finished"] == int(((ro["iter"][:, 0] == 1) & ok).sum()) < b
+    monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+    r0 = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert r0["lane_pass_finished"] == -1 and (r0["status"] == re["status"]).all() and (r0["iter"] == re["iter"]).all()
+    assert _rel(r0["control"][ok], re["control"][ok]) <= 1e-11

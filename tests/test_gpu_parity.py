@@ -1364,3 +1364,37 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
             assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick] == ref["iter"]).all()
             okp = ref["status"] == 0
             assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL and _rel(r1["trajectory"][pick][okp], ref["trajectory"][okp]) <= RTOL
+
+
+def test_one_instance_per_lane_pass_shared_model_tick(oracle, monkeypatch):
+    """... and its shared-model form in front of the tier in shared-model mode (copra_batch_set_shared_system, a tick with new x0):
+    against the tier alone at the full batch, and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 65536 - 11
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=4)
+    A, B, d = wl["A"][7], wl["B"][7], wl["d"][7]
+    out = {}
+    for mode in ("off", "on"):
+        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        if mode == "off":
+            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+        eng.set_shared_system(A, B, d)
+        eng.set_x0(wl["x0"][::-1].copy())
+        eng.solve()
+        eng.set_x0(wl["x0"])  # (the tick: new states, same model)
+        eng.solve()
+        out[mode] = (eng.results(), eng.lane_pass_info())
+        eng.close()
+    r0, r1 = out["off"][0], out["on"][0]
+    ok = r0["status"] == 0
+    assert not out["off"][1][0] and out["on"][1][0]
+    assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-11
+    assert out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > b // 8
+    pick = np.arange(0, b, 257)
+    ref = oracle.lmpc_solve_batch(np.tile(A, (len(pick), 1, 1)), np.tile(B, (len(pick), 1, 1)), np.tile(d, (len(pick), 1)), wl["x0"][pick],
+                                  wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    okp = ref["status"] == 0
+    assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
+    assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL
