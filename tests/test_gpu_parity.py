@@ -1398,3 +1398,23 @@ def test_one_instance_per_lane_pass_shared_model_tick(oracle, monkeypatch):
     okp = ref["status"] == 0
     assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
     assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL
+
+
+@pytest.mark.parametrize("N", [20, 10, 15])
+def test_one_instance_per_lane_pass_small_ragged_batch(oracle, monkeypatch, N):
+    """the pass is only taken from 20480 instances on (a wave of it runs ~ 90 us whatever the batch); forced on a small ragged batch
+    (COPRA_LANE_MIN_BATCH), every instance against the oracle at the three horizons the library instantiates"""
+    from copra_amd import BatchLMPC, workloads
+    b = 333
+    wl = workloads.com_preview(b, N=N, seed=17)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    eng, res = _solve_gpu(wl, b)
+    assert eng.lane_pass_info() == (False, 0)
+    eng.close()
+    monkeypatch.setenv("COPRA_LANE_MIN_BATCH", "1")
+    eng, res = _solve_gpu(wl, b)
+    ok = ref["status"] == 0
+    assert eng.lane_pass_info() == (True, int(((ref["iter"][:, 0] == 1) & ok).sum()))
+    assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+    eng.close()
