@@ -5,6 +5,12 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if "--lib" in sys.argv:  # an experimental build of the library (copra_amd/csrc/variants/*.so)
+    from copra_amd import _capi  # noqa: E402
+
+    _capi.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    _capi.build_library = lambda force=False: False
+    del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 from copra_amd import BatchLMPC, workloads  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
