@@ -503,6 +503,7 @@ def main():
     status = out_s.cpu().numpy()
     iters = out_i.cpu().numpy()
     n_ok = int((status == 0).sum())
+    lane_ran, lane_done = eng.lane_pass_info()  # (the one-instance-per-lane pass in front of the first tier, lmpc_lane.hpp)
 
     line = None
     if rank == 0:
@@ -576,6 +577,9 @@ def main():
                                        % (world, "overlapped with the next solve" if overlap else "synchronous"))
                        if world > 1 else "single GPU"},
             "solved_ok": n_ok,
+            "lane_pass": {"ran": lane_ran, "finished_at_unconstrained_minimiser": lane_done,
+                          "what": "LQ sweep + roll-out with one instance per lane in front of the first tier: instances whose unconstrained "
+                                  "minimiser violates nothing end there, the others hand K, kv, Lam^-1, U, X to the active-set kernel"},
             "mean_active_set_iters": float(iters[:, 0].mean()),
             "max_active_set_iters": int(iters[:, 0].max()),
             "active_set_iteration_histogram": {("%d" % k if k < 15 else "15+"): int(v) for k, v in enumerate(hist) if v},

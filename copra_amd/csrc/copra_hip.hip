@@ -544,7 +544,7 @@ static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 static size_t lane_lds_bytes(const FusedPlan& P)
 {
     int oH = 0;
-    return (size_t)lane_lds_doubles(P.nx, P.nu, oH) * sizeof(double);
+    return (size_t)(lane_lds_doubles(P.nx, P.nu, oH) + P.lane_tlds) * sizeof(double);
 }
 // does the next solve run it?  (the per-instance references and right-hand sides can be set at any time: checked per solve)
 // The pass holds 64 instances per wave at ONE wave per SIMD, and a wave of it runs ~ 90 us whatever the batch: it pays from about a third

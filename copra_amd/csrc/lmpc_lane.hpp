@@ -126,6 +126,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     (void)lane_lds_doubles(NX, NU, oHl_);
     double* Hl = lds + oHl_;
     for (int e = lane; e < NZ * NZ + NZ; e += kWave) Hl[e] = tab[e];
+    // ... and behind it, when they fit (FusedPlan::lane_tlds), the rows of every step and the bounds: the roll-out reads them there
+    double* const Tl = Hl + ((NZ * NZ + NZ + 1) & ~1);
+    const int tl_rows = (NH + 1) * P.lane_rps * RW;
+    const bool tlds = P.lane_tlds > 0;
+    if (tlds) {
+        for (int e = lane; e < tl_rows; e += kWave) Tl[e] = tab[oRows + e];
+        for (int e = lane; e < P.n; e += kWave) {
+            Tl[tl_rows + e] = P.ub[e];
+            Tl[tl_rows + P.n + e] = P.lb[e];
+        }
+    }
     wave_sync();
     auto AB = [&](int l, int a) -> double { return a < NX ? A[l + NX * a] : B[l + NX * (a - NX)]; }; // [A B](l, a)
 
@@ -313,6 +324,19 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_at(wk + (size_t)e * bp, ioff);
     };
     auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) { // E x_k + G u_k <= f
+        if (tlds) {
+            for (int r = 0; r < rps; ++r) {
+                const double* const rt = Tl + (k * rps + r) * RW;
+                double ax = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) ax += rt[c] * xk[c];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
+                const double s = rt[NZ] - ax;
+                viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+            }
+            return;
+        }
         for (int r = 0; r < rps; ++r) {
             const int ro = oRows + (k * rps + r) * RW;
             double ax = 0.0;
@@ -321,7 +345,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
             for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
             const double s = uniform_load(tab, ro + NZ) - ax;
-            viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+            viol = viol || (s <= -vsmall);
         }
     };
     constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
@@ -380,8 +404,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 check_rows(k, x, u);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    const double ub = own_bounds ? ubp[k * NU + c] : uniform_load(ubp, k * NU + c);
-                    const double lb = own_bounds ? lbp[k * NU + c] : uniform_load(lbp, k * NU + c);
+                    const double ub = own_bounds ? ubp[k * NU + c] : tlds ? Tl[tl_rows + k * NU + c] : uniform_load(ubp, k * NU + c);
+                    const double lb = own_bounds ? lbp[k * NU + c] : tlds ? Tl[tl_rows + P.n + k * NU + c] : uniform_load(lbp, k * NU + c);
                     viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
                 }
             }
@@ -492,7 +516,33 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
     double* const ldu = lds + kWave * SX;
     const int left = P.batch - group * kWave;
     const int ninst = left < kWave ? left : kWave;
+    int oHl_ = 0;
+    (void)lane_lds_doubles(NX, NU, oHl_);
+    double* const Tl = lds + oHl_ + ((NZ * NZ + NZ + 1) & ~1); // (the same place as in lmpc_lane_body: the rows of every step and the bounds)
+    const int tl_rows = (NH + 1) * P.lane_rps * RW;
+    const bool tlds = P.lane_tlds > 0;
+    if (tlds) {
+        for (int e = lane; e < tl_rows; e += kWave) Tl[e] = tab[oRows + e];
+        for (int e = lane; e < P.n; e += kWave) {
+            Tl[tl_rows + e] = P.ub[e];
+            Tl[tl_rows + P.n + e] = P.lb[e];
+        }
+    }
+    wave_sync();
     auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) {
+        if (tlds) {
+            for (int r = 0; r < rps; ++r) {
+                const double* const rt = Tl + (k * rps + r) * RW;
+                double ax = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) ax += rt[c] * xk[c];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
+                const double s = rt[NZ] - ax;
+                viol = viol || (s <= -vsmall);
+            }
+            return;
+        }
         for (int r = 0; r < rps; ++r) {
             const int ro = oRows + (k * rps + r) * RW;
             double ax = 0.0;
@@ -524,8 +574,8 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
                 check_rows(k, x, u);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    const double ub = own_bounds ? ubp[k * NU + c] : uniform_load(ubp, k * NU + c);
-                    const double lb = own_bounds ? lbp[k * NU + c] : uniform_load(lbp, k * NU + c);
+                    const double ub = own_bounds ? ubp[k * NU + c] : tlds ? Tl[tl_rows + k * NU + c] : uniform_load(ubp, k * NU + c);
+                    const double lb = own_bounds ? lbp[k * NU + c] : tlds ? Tl[tl_rows + P.n + k * NU + c] : uniform_load(lbp, k * NU + c);
                     viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
                 }
             }

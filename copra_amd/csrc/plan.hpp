@@ -246,6 +246,8 @@ struct FusedPlan {
     // it does not finish to lane_list (lane_count entries; lane_zero: the next solve's counter, zeroed on the way); the first tier
     // then runs with lane_from_list = 1: workgroup w takes instance lane_list[w], workgroups beyond the count leave at once.
     int lane_tab, lane_rps;
+    int lane_tlds; // > 0: that many doubles of tables -- the rows of every step, then ub and lb -- sit in LDS behind H | h (the pass reads them there
+                   // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // instances per workspace row (the batch rounded up to whole waves)
     int lane_from_list;
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)

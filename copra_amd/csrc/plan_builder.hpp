@@ -349,6 +349,7 @@ inline void build_lane_tables(HostPlan& hp)
     FusedPlan& P = hp.plan;
     P.lane_tab = -1;
     P.lane_rps = 0;
+    P.lane_tlds = 0;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
     if (P.meq > 0 || P.initial_state || nu > 3 || P.denseQ >= 0 || P.rfull > 0) return;
     std::vector<int> per_step((size_t)N + 1, 0);
@@ -408,6 +409,11 @@ inline void build_lane_tables(HostPlan& hp)
     if (hp.params.size() & 1) hp.params.push_back(0.0);
     P.lane_tab = (int)hp.params.size();
     P.lane_rps = rps;
+    {
+        int oHl = 0;
+        const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;
+        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u && !std::getenv("COPRA_LANE_TABLES_IN_MEMORY")) ? tl : 0; // (four waves per CU)
+    }
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
 }
 

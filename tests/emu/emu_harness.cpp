@@ -300,7 +300,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         P.lane_zero = &lane_other;
         for (int g = 0; g < groups; ++g) {
             int oHl = 0;
-            const size_t lbytes = (size_t)lane_lds_doubles(P.nx, P.nu, oHl) * sizeof(double);
+            const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
             int r = emu::run_wave([&]() {
                 if (P.nx == 6) lmpc_lane_body<6, 3>(P, g);
                 else if (P.nx == 4) lmpc_lane_body<4, 2>(P, g);
@@ -529,7 +529,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
         int oHl = 0;
-        const size_t lbytes = (size_t)lane_lds_doubles(P.nx, P.nu, oHl) * sizeof(double);
+        const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
         for (int g = 0; g < groups; ++g)
             if (emu::run_wave([&]() { lmpc_lane_shared_body<6, 3>(P, g); }, lbytes, g, groups) != 0) return -100;
         P.lane_from_list = 1;

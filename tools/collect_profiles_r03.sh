@@ -37,6 +37,12 @@ COPRA_NO_RIC_FAST=1 python tools/try_config5.py 16384 0 2>&1 | grep -E "solver|b
 # ---- dense-Hessian (MFMA 16x16x4) path: MFMA-busy share ----
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/hl_dense -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/hl_run.log 2>&1
 python tools/pmc_summary.py $O/hl_dense > $R/pmc_dense_mfma_path.json
+# ---- the one-instance-per-lane pass (lmpc_lane.hpp): with / without it, its parts, the first tier behind it, the shared-model tick, batch sizes ----
+python tools/exp/lane_pass_check.py 2>&1 | grep -v amdgpu.ids > $R/lane_pass_check.txt || true
+VARIANTS=0,1,2,3 PHASE_DBG=8,9,10,11 python tools/exp/lane_pass_variants.py 2>&1 | grep -v amdgpu.ids > $R/lane_pass_parts.txt || true
+python tools/exp/lane_tier1_phases.py 2>&1 | grep -v amdgpu.ids > $R/lane_tier1_phases.txt || true
+python tools/exp/lane_shared_check.py 2>&1 | grep -v amdgpu.ids > $R/lane_shared_tick.txt || true
+for b in 2048 8192 16384 24576 32768; do echo "batch $b"; COPRA_LANE_MIN_BATCH=1 python tools/exp/lane_pass_check.py $b 2>&1 | grep -v amdgpu.ids | head -1; done > $R/lane_batch_sweep.txt || true
 # ---- probes and side measurements ----
 tools/exp/mfma_chain_probe > $R/mfma_chain_probe.txt 2>&1 || true
 python tools/pcie_probe.py 2>&1 | grep -v amdgpu.ids > $R/pcie_probe.txt

@@ -24,13 +24,17 @@ for dbg in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]:
     print("dbg %d: solve %.4f ms (best %.4f), finished at the minimiser %d of %d" % (dbg, np.mean(ts[6:]) * 1e3, np.min(ts) * 1e3, (res["iter"][:, 0] == 1).sum(), b))
     eng.close()
 # phase stamps of the pass (lane 0 of every wave): staging | sweep | roll-out | verdict
-os.environ["COPRA_LANE_DBG"] = "8"
-eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
-eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
-for _ in range(4):
+for pdbg in os.environ.get("PHASE_DBG", "8").split(","):
+  os.environ["COPRA_LANE_DBG"] = pdbg
+  print("phase stamps with COPRA_LANE_DBG =", pdbg)
+  if True:
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    for _ in range(4):
+        eng.solve()
+    eng.enable_phase_profile(True)
     eng.solve()
-eng.enable_phase_profile(True)
-eng.solve()
-pr = eng.phase_profile()[: b // 64]
-print("cycles per wave: staging %.0f, sweep %.0f (per stage %.0f), roll-out %.0f (per stage %.0f), verdict %.0f, total %.0f"
-      % (pr[:, 0].mean(), pr[:, 1].mean(), pr[:, 1].mean() / 20, pr[:, 2].mean(), pr[:, 2].mean() / 21, pr[:, 3].mean(), pr[:, 7].mean()))
+    pr = eng.phase_profile()[: b // 64]
+    print("cycles per wave: staging %.0f, sweep %.0f (per stage %.0f), roll-out %.0f (per stage %.0f), verdict %.0f, total %.0f"
+          % (pr[:, 0].mean(), pr[:, 1].mean(), pr[:, 1].mean() / 20, pr[:, 2].mean(), pr[:, 2].mean() / 21, pr[:, 3].mean(), pr[:, 7].mean()))
+
