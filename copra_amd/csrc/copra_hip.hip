@@ -588,13 +588,14 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
     // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
-    if (h->hp.plan.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) return COPRA_OK;
+    //  -- except in shared-model mode, where there is no sweep to take over: there the pass must finish one instance in four to pay, measured)
+    if (!h->shared && h->hp.plan.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) return COPRA_OK;
     h->lane_adapt_left -= 1;
     int left = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
     const long long done = (long long)h->hp.plan.batch - left;
-    long long share = 8;
+    long long share = h->shared ? 4 : 8;
     if (const char* e = std::getenv("COPRA_LANE_SHARE")) share = std::atoll(e) > 0 ? std::atoll(e) : share; // (experiments)
     if (done * share < (long long)h->hp.plan.batch && !std::getenv("COPRA_LANE_KEEP")) h->lane_off = true;
     if (std::getenv("COPRA_DEBUG"))
