@@ -141,6 +141,39 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     auto AB = [&](int l, int a) -> double { return a < NX ? A[l + NX * a] : B[l + NX * (a - NX)]; }; // [A B](l, a)
 
     stamp[1] = cycle_counter();
+    // Per-instance cost references (copra_batch_set_cost_reference: every instance tracks its own goal): the affine terms h = -sum_t
+    // [M N]_t' W_t p_t and hN differ per lane then.  They are rebuilt from the coefficient table of the plan builder (lane_cref), this
+    // lane's references where a cost has them and the controller-wide ones elsewhere, and h waits in the (idle) staging area for the sweep.
+    bool own_refs = false;
+    for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
+    double hNl[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) hNl[i] = uniform_load(tab, ohN + i);
+    constexpr int HS = NZ | 1;
+    if (own_refs) {
+        double hl[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) hl[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hNl[i] = 0.0;
+        const int li0 = valid ? inst : 0;
+        for (int t = 0; t < P.ncost; ++t) {
+            const int rows_t = P.cost[t].rows;
+            const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)li0 * rows_t : P.params + P.cost[t].offP;
+            for (int r = 0; r < rows_t; ++r) {
+                const double pv_r = pr[r];
+                const int co = P.lane_cref + (t * 6 + r) * (NZ + NX);
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) hl[a] += uniform_load(tab, co + a) * pv_r;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) hNl[i] += uniform_load(tab, co + NZ + i) * pv_r;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hl[a];
+        wave_sync();
+    }
     // ---- 1. backward Riccati sweep; K_k | kv_k to the workspace, lane-major: element e of stage k at ws[(k KW + e) bp + inst] ----
     double* const ws = P.lane_ws;
     const size_t bp = (size_t)P.lane_bp;
@@ -149,7 +182,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
     for (int e = 0; e < NX * NX; ++e) Pm[e] = uniform_load(tab, oHN + e);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) pv[i] = uniform_load(tab, ohN + i);
+    for (int i = 0; i < NX; ++i) pv[i] = hNl[i];
     bool bad = false;
     for (int k = NH - 1; k >= 0; --k) {
         int hoff = oHl_;
@@ -169,7 +202,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             }
 #pragma unroll
             for (int a = 0; a < NZ; ++a) {
-                double s = Hk[oh + a];
+                double s = own_refs ? lds[lane * HS + a] : Hk[oh + a];
 #pragma unroll
                 for (int l = 0; l < NX; ++l) s += AB(l, a) * tq[l];
                 mz[a] = s;

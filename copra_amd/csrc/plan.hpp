@@ -192,7 +192,9 @@ COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk,
 }
 
 // offsets (doubles) of the tables at FusedPlan::lane_tab:  H (nz x nz, column-major, z = (x, u)) | h (nz) | HN (nx x nx) | hN (nx) |
-// rows: (N + 1) steps x lane_rps rows of [E (nx) | G (nu) | f]  (a row that is not there: zeros and f = +inf)
+// rows: (N + 1) steps x lane_rps rows of [E (nx) | G (nu) | f]  (a row that is not there: zeros and f = +inf) |
+// per cost t < kRicMaxCosts and row r < 6: the coefficients of the reference p_t[r] in h (nz) and in hN (nx) -- lane_cref: what h and hN are
+// rebuilt from, per lane, when a cost has per-instance references (copra_batch_set_cost_reference)
 COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& ohN, int& oRows)
 {
     const int nz = nx + nu;
@@ -246,6 +248,7 @@ struct FusedPlan {
     // it does not finish to lane_list (lane_count entries; lane_zero: the next solve's counter, zeroed on the way); the first tier
     // then runs with lane_from_list = 1: workgroup w takes instance lane_list[w], workgroups beyond the count leave at once.
     int lane_tab, lane_rps;
+    int lane_cref; // offset (doubles from lane_tab) of the reference coefficients: [cost][row (6)][nz + nx]
     int lane_tlds; // > 0: that many doubles of tables -- the rows of every step, then ub and lb -- sit in LDS behind H | h (the pass reads them there
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // instances per workspace row (the batch rounded up to whole waves)

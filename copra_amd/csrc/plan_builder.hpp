@@ -350,6 +350,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_tab = -1;
     P.lane_rps = 0;
     P.lane_tlds = 0;
+    P.lane_cref = -1;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
     if (P.meq > 0 || P.initial_state || nu > 3 || P.denseQ >= 0 || P.rfull > 0) return;
     std::vector<int> per_step((size_t)N + 1, 0);
@@ -364,7 +365,8 @@ inline void build_lane_tables(HostPlan& hp)
     int oh, oHN, ohN, oRows;
     lane_tab_offsets(nx, nu, oh, oHN, ohN, oRows);
     const int rw = nz + 1;
-    std::vector<double> tab((size_t)oRows + (size_t)(N + 1) * rps * rw, 0.0);
+    const int oCref = (oRows + (N + 1) * rps * rw + 1) & ~1, crw = nz + nx; // reference coefficients: [cost][row (6)][nz | nx]
+    std::vector<double> tab((size_t)oCref + (size_t)kRicMaxCosts * 6 * crw, 0.0);
     auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]  (as build_ric_tables)
         if (a < nx) return (ct.offM >= 0 && ct.kind != kCostControl) ? hp.params[(size_t)ct.offM + r + ct.rows * a] : 0.0;
         return (ct.offN >= 0 && (ct.kind == kCostControl || ct.kind == kCostMixed)) ? hp.params[(size_t)ct.offN + r + ct.rows * (a - nx)] : 0.0;
@@ -380,10 +382,12 @@ inline void build_lane_tables(HostPlan& hp)
                 if (in_stage) {
                     for (int b = 0; b < nz; ++b) tab[(size_t)a + nz * b] += (coef(ct, r, a) * w) * coef(ct, r, b);
                     tab[(size_t)oh + a] += -(coef(ct, r, a) * w) * pr;
+                    if (t < kRicMaxCosts && r < 6) tab[(size_t)oCref + ((size_t)t * 6 + r) * crw + a] = -(coef(ct, r, a) * w);
                 }
                 if (in_term && a < nx) {
                     for (int b = 0; b < nx; ++b) tab[(size_t)oHN + a + nx * b] += (coef(ct, r, a) * w) * coef(ct, r, b);
                     tab[(size_t)ohN + a] += -(coef(ct, r, a) * w) * pr;
+                    if (t < kRicMaxCosts && r < 6) tab[(size_t)oCref + ((size_t)t * 6 + r) * crw + nz + a] = -(coef(ct, r, a) * w);
                 }
             }
         }
@@ -409,6 +413,7 @@ inline void build_lane_tables(HostPlan& hp)
     if (hp.params.size() & 1) hp.params.push_back(0.0);
     P.lane_tab = (int)hp.params.size();
     P.lane_rps = rps;
+    P.lane_cref = (P.ncost <= kRicMaxCosts && P.rmax <= 6) ? oCref : -1; // (-1: per-instance references keep the first tier alone)
     {
         int oHl = 0;
         const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;

@@ -906,8 +906,8 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
 
 
 def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
-    """per-instance control bounds go through the pass (every lane reads its own); per-instance cost references and right-hand sides
-    are not its business -- the solve must not run it then (and still agree with the oracle, on the tier alone)"""
+    """per-instance control bounds and per-instance cost references go through the pass (every lane reads its own bounds, rebuilds its
+    own affine cost terms); per-instance right-hand sides are not its business -- the solve must not run it then"""
     from copra_amd import workloads
     b = 24
     wl = workloads.com_preview(b, v_max=0.6, u_max=3.0, seed=12)
@@ -927,9 +927,22 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
             assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
     assert re["lane_pass_finished"] == finished > 0
-    refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.01 * rng.standard_normal((b, 6))}
+    # per-instance cost references (every instance its own goal): the pass rebuilds its affine terms per lane from the plan's coefficient
+    # table; per-instance right-hand sides keep the tier alone
+    refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.03 * rng.standard_normal((b, 6))}
     re2 = emu.lmpc_solve(*args, cost_refs=refs)
-    assert re2["lane_pass_finished"] == -1 and (re2["status"] == 0).all()
+    finished = 0
+    for k in range(b):
+        cs = [dict(wl["costs"][0], p=refs[0][k]), wl["costs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], cs, wl["cstrs"])
+        assert re2["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(re2["iter"][k]) == tuple(ro["iter"]) and _rel(re2["control"][k], ro["control"]) <= 1e-9
+            finished += int(ro["iter"][0] == 1)
+    assert re2["lane_pass_finished"] == finished > 0
+    rhs = np.tile(np.full(63, 0.6), (b, 1)) * rng.uniform(0.8, 1.2, (b, 1))
+    re3 = emu.lmpc_solve(*args, row_rhs=rhs)
+    assert re3["lane_pass_finished"] == -1
 
 
 def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):

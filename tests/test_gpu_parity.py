@@ -1418,3 +1418,35 @@ def test_one_instance_per_lane_pass_small_ragged_batch(oracle, monkeypatch, N):
     assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     eng.close()
+
+
+def test_one_instance_per_lane_pass_per_instance_references(oracle, monkeypatch):
+    """every instance tracks its own goal (copra_batch_set_cost_reference): the pass rebuilds its affine cost terms per lane from the
+    plan's coefficient table; against the tier alone at 32768 instances and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 32768
+    wl = workloads.com_preview(b, seed=6)
+    rng = np.random.default_rng(8)
+    refs = np.tile(wl["costs"][0]["p"], (b, 1)) + 0.03 * rng.standard_normal((b, 6))
+    out = {}
+    for mode in ("off", "on"):
+        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        if mode == "off":
+            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.set_cost_reference(0, refs)
+        eng.solve()
+        out[mode] = (eng.results(), eng.lane_pass_info())
+        eng.close()
+    r0, r1 = out["off"][0], out["on"][0]
+    ok = r0["status"] == 0
+    assert out["on"][1][0] and out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > 0
+    assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-11
+    for k in range(0, b, 1021):
+        cs = [dict(wl["costs"][0], p=refs[k]), wl["costs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], cs, wl["cstrs"])
+        assert r1["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(r1["iter"][k]) == tuple(ro["iter"]) and _rel(r1["control"][k], ro["control"]) <= RTOL
