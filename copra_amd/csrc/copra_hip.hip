@@ -562,7 +562,7 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
     if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS") || !lane_batch_ok(P.batch)) return false;
     const char* dbg = std::getenv("COPRA_LANE_DBG");
     if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
-    if (!P.lds.ric || P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || P.row_f_inst) return false;
+    if (!P.lds.ric || P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared) return false;
     for (int t = 0; t < kMaxCosts; ++t)
         if (h->cost_p[t] && P.lane_cref < 0) return false; // (per-instance references: the pass rebuilds its affine terms per lane)
     return (jit_launch ? h->jit_lane != nullptr : select_lane_kernel(P) != nullptr);

@@ -91,7 +91,7 @@ COPRA_DEV void stream_store(double* p, double v, bool streaming)
 template <int NX, int NU>
 COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 {
-    constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 1;
+    constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 2; // (a row of the table: E | G | f | its index)
     constexpr int oLiW = KW, oNbW = KW + NU * (NU + 1) / 2, WR = oNbW + NX; // rows of the workspace per stage (plan.hpp: lane_ws_rows)
     static_assert(NU >= 1 && NU <= 3, "the control block is eliminated in closed form");
     const int lane = lane_id();
@@ -356,6 +356,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
         for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_at(wk + (size_t)e * bp, ioff);
     };
+    // the right-hand side of a row: the controller's, or this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the
+    // stacked order; a row of the table that is not there keeps +inf)
+    const double* const rhs_mine = P.row_f_inst ? P.row_f_inst + (size_t)li * P.mgen : nullptr;
+    auto row_rhs = [&](double f_shared, int idx) -> double { return (rhs_mine && idx >= 0) ? rhs_mine[idx] : f_shared; };
     auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) { // E x_k + G u_k <= f
         if (tlds) {
             for (int r = 0; r < rps; ++r) {
@@ -365,7 +369,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int c = 0; c < NX; ++c) ax += rt[c] * xk[c];
 #pragma unroll
                 for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
-                const double s = rt[NZ] - ax;
+                const double s = row_rhs(rt[NZ], (int)rt[NZ + 1]) - ax;
                 viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
             }
             return;
@@ -377,7 +381,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int c = 0; c < NX; ++c) ax += uniform_load(tab, ro + c) * xk[c];
 #pragma unroll
             for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
-            const double s = uniform_load(tab, ro + NZ) - ax;
+            const double s = row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)) - ax;
             viol = viol || (s <= -vsmall);
         }
     };
@@ -521,7 +525,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 template <int NX, int NU>
 COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
 {
-    constexpr int NZ = NX + NU, RW = NZ + 1;
+    constexpr int NZ = NX + NU, RW = NZ + 2;
     using RR = RicRec<NX, NU>;
     const int lane = lane_id();
     const int inst = group * kWave + lane;

@@ -192,7 +192,8 @@ COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk,
 }
 
 // offsets (doubles) of the tables at FusedPlan::lane_tab:  H (nz x nz, column-major, z = (x, u)) | h (nz) | HN (nx x nx) | hN (nx) |
-// rows: (N + 1) steps x lane_rps rows of [E (nx) | G (nu) | f]  (a row that is not there: zeros and f = +inf) |
+// rows: (N + 1) steps x lane_rps rows of [E (nx) | G (nu) | f | index of the row in the stacked order]  (a row that is not there: zeros,
+// f = +inf, index -1) |
 // per cost t < kRicMaxCosts and row r < 6: the coefficients of the reference p_t[r] in h (nz) and in hN (nx) -- lane_cref: what h and hN are
 // rebuilt from, per lane, when a cost has per-instance references (copra_batch_set_cost_reference)
 COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& ohN, int& oRows)

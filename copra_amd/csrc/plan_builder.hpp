@@ -364,7 +364,7 @@ inline void build_lane_tables(HostPlan& hp)
     if (rps > 32) return;
     int oh, oHN, ohN, oRows;
     lane_tab_offsets(nx, nu, oh, oHN, ohN, oRows);
-    const int rw = nz + 1;
+    const int rw = nz + 2; // E | G | f | index
     const int oCref = (oRows + (N + 1) * rps * rw + 1) & ~1, crw = nz + nx; // reference coefficients: [cost][row (6)][nz | nx]
     std::vector<double> tab((size_t)oCref + (size_t)kRicMaxCosts * 6 * crw, 0.0);
     auto coef = [&](const CostTerm& ct, int r, int a) -> double { // entry (r, a) of [M_t N_t]  (as build_ric_tables)
@@ -399,7 +399,10 @@ inline void build_lane_tables(HostPlan& hp)
     }
     std::vector<int> filled((size_t)N + 1, 0);
     for (int k = 0; k <= N; ++k)
-        for (int r = 0; r < rps; ++r) tab[(size_t)oRows + ((size_t)k * rps + r) * rw + nz] = HUGE_VAL;
+        for (int r = 0; r < rps; ++r) {
+            tab[(size_t)oRows + ((size_t)k * rps + r) * rw + nz] = HUGE_VAL;
+            tab[(size_t)oRows + ((size_t)k * rps + r) * rw + nz + 1] = -1.0;
+        }
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i];
         double* row = tab.data() + oRows + ((size_t)k * rps + filled[k]++) * rw;
@@ -409,6 +412,7 @@ inline void build_lane_tables(HostPlan& hp)
         if (hp.row_gkind[i] == kGStep)
             for (int c = 0; c < nu; ++c) row[nx + c] = hp.params[(size_t)hp.row_goff[i] + c];
         row[nz] = hp.row_f[i];
+        row[nz + 1] = (double)i;
     }
     if (hp.params.size() & 1) hp.params.push_back(0.0);
     P.lane_tab = (int)hp.params.size();

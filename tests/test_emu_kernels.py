@@ -906,8 +906,8 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
 
 
 def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
-    """per-instance control bounds and per-instance cost references go through the pass (every lane reads its own bounds, rebuilds its
-    own affine cost terms); per-instance right-hand sides are not its business -- the solve must not run it then"""
+    """per-instance control bounds, cost references and right-hand sides all go through the pass (every lane reads its own bounds and
+    its own row of right-hand sides, rebuilds its own affine cost terms)"""
     from copra_amd import workloads
     b = 24
     wl = workloads.com_preview(b, v_max=0.6, u_max=3.0, seed=12)
@@ -928,7 +928,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
             finished += int(ro["iter"][0] == 1)
     assert re["lane_pass_finished"] == finished > 0
     # per-instance cost references (every instance its own goal): the pass rebuilds its affine terms per lane from the plan's coefficient
-    # table; per-instance right-hand sides keep the tier alone
+    # table
     refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.03 * rng.standard_normal((b, 6))}
     re2 = emu.lmpc_solve(*args, cost_refs=refs)
     finished = 0
@@ -940,9 +940,19 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
             assert tuple(re2["iter"][k]) == tuple(ro["iter"]) and _rel(re2["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
     assert re2["lane_pass_finished"] == finished > 0
-    rhs = np.tile(np.full(63, 0.6), (b, 1)) * rng.uniform(0.8, 1.2, (b, 1))
-    re3 = emu.lmpc_solve(*args, row_rhs=rhs)
-    assert re3["lane_pass_finished"] == -1
+    # ... and per-instance right-hand sides (every instance its own velocity limit): every lane reads its own row of the table
+    vlim = 0.6 * rng.uniform(0.7, 1.2, b)
+    re3 = emu.lmpc_solve(*args, row_rhs=np.repeat(vlim[:, None], 63, axis=1))
+    finished = 0
+    inf = np.inf
+    for k in range(b):
+        cs = [dict(wl["cstrs"][0], upper=[inf, inf, inf, vlim[k], vlim[k], vlim[k]]), wl["cstrs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
+        assert re3["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(re3["iter"][k]) == tuple(ro["iter"]) and _rel(re3["control"][k], ro["control"]) <= 1e-9
+            finished += int(ro["iter"][0] == 1)
+    assert re3["lane_pass_finished"] == finished > 0
 
 
 def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):

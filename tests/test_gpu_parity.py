@@ -1450,3 +1450,37 @@ def test_one_instance_per_lane_pass_per_instance_references(oracle, monkeypatch)
         assert r1["status"][k] == ro["status"]
         if ro["status"] == 0:
             assert tuple(r1["iter"][k]) == tuple(ro["iter"]) and _rel(r1["control"][k], ro["control"]) <= RTOL
+
+
+def test_one_instance_per_lane_pass_per_instance_rhs(oracle, monkeypatch):
+    """every instance its own velocity limit (copra_batch_set_constraint_rhs) through the pass: against the tier alone at 32768
+    instances and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 32768
+    wl = workloads.com_preview(b, seed=16)
+    rng = np.random.default_rng(2)
+    vlim = 0.6 * rng.uniform(0.7, 1.2, b)
+    Ev = np.hstack([np.zeros((3, 3)), np.eye(3)])  # the velocity limit as a TrajectoryConstraint E x_k <= f (a TrajectoryBound has no f)
+    wl["cstrs"] = [dict(kind="trajectory", E=Ev, f=[0.6] * 3, ineq=True), wl["cstrs"][1]]
+    out = {}
+    for mode in ("off", "on"):
+        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        if mode == "off":
+            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.set_constraint_rhs(0, np.repeat(vlim[:, None], 3, axis=1))
+        eng.solve()
+        out[mode] = (eng.results(), eng.lane_pass_info())
+        eng.close()
+    r0, r1 = out["off"][0], out["on"][0]
+    ok = r0["status"] == 0
+    assert out["on"][1][0] and out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > 0
+    assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11
+    for k in range(0, b, 1021):
+        cs = [dict(wl["cstrs"][0], f=[vlim[k]] * 3), wl["cstrs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
+        assert r1["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(r1["iter"][k]) == tuple(ro["iter"]) and _rel(r1["control"][k], ro["control"]) <= RTOL
