@@ -6,11 +6,12 @@
 // steps without any search, the same work for every instance: data-parallel over the BATCH, not over the matrix.  So this pass
 // gives every instance one lane: the lane keeps its own A, B, d, the cost-to-go P and the stage matrix M in registers, every
 // multiply-add is a full-rate v_fma_f64 on 64 instances at once (no padding of 6 x 6 blocks to MFMA tiles, no cross-lane
-// traffic, no LDS hand-overs), the feedback gains K_k | kv_k go through a lane-major HBM workspace (coalesced: 512 B per
+// traffic, no LDS hand-overs), the stage records K_k | kv_k | Lam_k^-1 go to a lane-major HBM workspace (coalesced: 512 B per
 // store), and the roll-out checks every constraint row and bound with qpgen2's own test (slack <= -vsmall).  An instance that
 // violates nothing is DONE: U, X, status 0, iteration counts (1, 0) -- exactly what the first tier reports for it.  Every other
-// instance is appended to a list, and the first tier (wave per instance, active-set iteration) runs for those only.
-// At the headline workload 47 % of the instances end here, at about a tenth of the first tier's cost per instance.
+// instance is appended to a list, and the first tier (wave per instance) runs for those only -- and only its active-set iteration:
+// it takes the stage records, the row-norm sums, U and X over from here instead of sweeping and rolling out again
+// (lmpc_fused_ric.hpp, from_lane).  At the headline workload 47 % of the instances end here; DESIGN.md 3.12 has the measurements.
 //     stage k < N:   l_k(x, u) = 1/2 [x; u]' H [x; u] + h' [x; u]          (H, h, HN, hN: plan_builder.hpp, build_lane_tables)
 //     stage N:       l_N(x)    = 1/2 x' HN x + hN' x
 //     M = H + [A B]' P+ [A B],  m = h + [A B]' (P+ d + p+),  K = -M_uu^-1 M_ux,  kv = -M_uu^-1 m_u,
@@ -55,15 +56,15 @@ COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, d
 #pragma unroll
     for (int c = 0; c < W; ++c) out[c] = lds[ln * ST + c];
 }
-// element `lane index` of a wave-uniform row: the row pointer is pinned to scalar registers (opaque to the optimiser, which would fold the
-// row offsets into one 64-bit address PER ACCESS otherwise), so that the access is `global_load/store v_index, s[row]`: one index
-// register for the whole kernel instead of an address pair per access in flight
+// this lane's element of a wave-uniform workspace row, by a 32-bit byte offset from the row pointer.  (The row pointer is made opaque to
+// the optimiser: left to itself it folds row and lane offsets into a fresh 64-bit address computation per access and keeps all of them
+// live across the unrolled stage.)
 COPRA_DEV double& lane_at(double* row, unsigned byte_off)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(row));
 #endif
-    return *(double*)((char*)row + byte_off); // (a 32-bit BYTE offset: what the scalar-base addressing mode takes)
+    return *(double*)((char*)row + byte_off);
 }
 COPRA_DEV const double& lane_at(const double* row, unsigned byte_off)
 {
