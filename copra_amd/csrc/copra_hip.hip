@@ -46,14 +46,20 @@ using namespace copra_hip;
 template <int NX, int NU, int NH, int RP>
 __global__ __launch_bounds__(64) void copra_lmpc_fused_kernel(const FusedPlan P)
 {
-    lmpc_fused_body<NX, NU, NH, RP>(P, P.inst_offset + (int)blockIdx.x);
+    int inst;
+    bool lane_failed; // (a first tier that does not take the pass's factor over finds a failed factorisation itself)
+    if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
+    lmpc_fused_body<NX, NU, NH, RP>(P, inst);
 }
 
 // Run-time shapes whose (compact) LDS layout lets more than 8 instances share a CU: the same bodies at four waves per
 // SIMD (128 VGPRs) -- at the 256-VGPR budget of the kernels above a CU holds 8 waves, whatever the LDS would allow.
 __global__ __launch_bounds__(64, 4) void copra_lmpc_fused_kernel_w4(const FusedPlan P)
 {
-    lmpc_fused_body<0, 0, 0, 0>(P, P.inst_offset + (int)blockIdx.x);
+    int inst;
+    bool lane_failed;
+    if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
+    lmpc_fused_body<0, 0, 0, 0>(P, inst);
 }
 __global__ __launch_bounds__(64, 4) void copra_lmpc_shared_kernel_w4(const FusedPlan P)
 {
@@ -65,7 +71,10 @@ __global__ __launch_bounds__(64, 4) void copra_lmpc_shared_kernel_w4(const Fused
 template <int NX, int NU, int NH, int RP, int QR = 0>
 __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const FusedPlan P)
 {
-    lmpc_fused_body<NX, NU, NH, RP, true, QR>(P, P.inst_offset + (int)blockIdx.x);
+    int inst;
+    bool lane_failed;
+    if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
+    lmpc_fused_body<NX, NU, NH, RP, true, QR>(P, inst);
 }
 
 // The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const Fused
     if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
     int inst;
     bool lane_failed;
-    if (!ric_tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
+    if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
     lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, inst, lane_failed);
 }
 // One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
@@ -534,6 +543,7 @@ static hipError_t begin_overflow_queue(copra_batch* h, hipStream_t s, bool self_
 static fused_kernel_t select_lane_kernel(const FusedPlan& P)
 {
     if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_kernel<6, 3>;
+    if (P.nx == 2 && P.nu == 1) return copra_lmpc_lane_kernel<2, 1>; // (the reference's falling-mass system: BASELINE configs[1])
     return nullptr;
 }
 static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
@@ -562,7 +572,8 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
     if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS") || !lane_batch_ok(P.batch)) return false;
     const char* dbg = std::getenv("COPRA_LANE_DBG");
     if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
-    if (!P.lds.ric || P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared) return false;
+    // (in front of the Riccati-factor tier, which takes the factor over, or of any other one-wave first tier, where it only filters)
+    if (P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || h->hp.large || P.initial_state) return false;
     for (int t = 0; t < kMaxCosts; ++t)
         if (h->cost_p[t] && P.lane_cref < 0) return false; // (per-instance references: the pass rebuilds its affine terms per lane)
     return (jit_launch ? h->jit_lane != nullptr : select_lane_kernel(P) != nullptr);
@@ -1547,11 +1558,11 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
                 "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\n#include \"lmpc_lane.hpp\"\nusing namespace copra_hip;\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  int inst; bool failed; if (!ric_tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
+                "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
                 "  lmpc_fused_ric_body<%d, %d, %d, 6, %d>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused_q0(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  int inst; bool failed; if (!ric_tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
+                "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
                 "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
                 "{ lmpc_lane_body<%d, %d>(P, (int)blockIdx.x); }\n",

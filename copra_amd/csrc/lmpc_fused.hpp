@@ -46,6 +46,25 @@ COPRA_DEV const double* cost_reference(const FusedPlan& P, int t, int inst)
     return P.cost_p[t] ? P.cost_p[t] + (size_t)inst * ct.rows : P.params + ct.offP;
 }
 
+// Which instance does workgroup w of a first tier solve?  Without the one-instance-per-lane pass in front (lmpc_lane.hpp): instance w.  Behind
+// it: an entry of the list the pass left -- false when there is none for this workgroup.
+// Workgroups go to the eight XCDs in turn (each has its own L2), and the gather of the stage records reads 64-byte sectors that eight
+// neighbouring instances share: entry (w % 8) per + w / 8 of the list gives every XCD a CONTIGUOUS eighth of it, so that the neighbours
+// run on one XCD at about the same time and seven of their eight reads hit its L2 (HBM fetches of the tier: 1.32 GB -> 0.18 GB).
+COPRA_DEV bool tier_instance(const FusedPlan& P, int w, int& inst, bool& lane_failed)
+{
+    inst = P.inst_offset + w;
+    lane_failed = false;
+    if (!P.lane_from_list) return true;
+    const int cnt = *P.lane_count, per = (cnt + 7) >> 3;
+    const int idx = (w & 7) * per + (w >> 3);
+    if ((w >> 3) >= per || idx >= cnt) return false;
+    inst = P.lane_list[idx];
+    lane_failed = inst < 0; // (top bit: the pass's factorisation failed -- status 2)
+    inst &= 0x7fffffff;
+    return true;
+}
+
 // One constraint row of the plan (see plan.hpp), held in registers.
 struct RowDesc {
     int k, ek, eo, gk, go;

@@ -23,25 +23,6 @@
 
 namespace copra_hip {
 
-// Which instance does workgroup w of this tier solve?  Without the one-instance-per-lane pass in front (lmpc_lane.hpp): instance w.  Behind
-// it: an entry of the list the pass left -- false when there is none for this workgroup.
-// Workgroups go to the eight XCDs in turn (each has its own L2), and the gather of the stage records reads 64-byte sectors that eight
-// neighbouring instances share: entry (w % 8) per + w / 8 of the list gives every XCD a CONTIGUOUS eighth of it, so that the neighbours
-// run on one XCD at about the same time and seven of their eight reads hit its L2 (HBM fetches of the tier: 1.32 GB -> 0.18 GB).
-COPRA_DEV bool ric_tier_instance(const FusedPlan& P, int w, int& inst, bool& lane_failed)
-{
-    inst = P.inst_offset + w;
-    lane_failed = false;
-    if (!P.lane_from_list) return true;
-    const int cnt = *P.lane_count, per = (cnt + 7) >> 3;
-    const int idx = (w & 7) * per + (w >> 3);
-    if ((w >> 3) >= per || idx >= cnt) return false;
-    inst = P.lane_list[idx];
-    lane_failed = inst < 0; // (top bit: the pass's factorisation failed -- status 2)
-    inst &= 0x7fffffff;
-    return true;
-}
-
 template <int NX, int NU, int NH, int RP, int QR>
 COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_failed = false)
 {

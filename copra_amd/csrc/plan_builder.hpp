@@ -352,7 +352,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_tlds = 0;
     P.lane_cref = -1;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
-    if (P.meq > 0 || P.initial_state || nu > 3 || P.denseQ >= 0 || P.rfull > 0) return;
+    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
     std::vector<int> per_step((size_t)N + 1, 0);
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i], ek = hp.row_ekind[i], gk = hp.row_gkind[i];
@@ -1084,6 +1084,9 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         }
         hp.lds_bytes = (size_t)P.lds.total * sizeof(double);
     }
+    // the tables of the one-instance-per-lane pass (lmpc_lane.hpp) for a controller that did not get them with the Riccati-factor tier:
+    // in front of the other one-wave first tiers the pass only filters (the instances at their unconstrained minimiser end in it)
+    if (P.lane_tab < 0 && !hp.large && !P.initial_state) build_lane_tables(hp);
     return COPRA_OK;
 }
 

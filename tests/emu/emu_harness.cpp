@@ -284,7 +284,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     const size_t bytes1 = (size_t)P.lds.total * sizeof(double);
     // the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp), as copra_batch_solve runs it
     // (copra_hip.hip: lane_pass_wanted): the instances it does not finish go through the first tier
-    bool lane_pass = P.lds.ric && P.lane_tab >= 0 && dump_instance < 0 && !std::getenv("COPRA_NO_LANE_PASS")
+    bool lane_pass = P.lane_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && (P.lds.ric || std::getenv("COPRA_EMU_LANE_FILTER")) && !std::getenv("COPRA_NO_LANE_PASS")
         && ((P.nx == 6 && P.nu == 3) || (P.nx == 4 && P.nu == 2) || (P.nx == 5 && P.nu == 3) || (P.nx == 2 && P.nu == 1));
     for (int k = 0; k < kMaxCosts; ++k) lane_pass = lane_pass && (!P.cost_p[k] || P.lane_cref >= 0);
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);

@@ -974,3 +974,23 @@ def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
     r0 = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     assert r0["lane_pass_finished"] == -1 and (r0["status"] == re["status"]).all() and (r0["iter"] == re["iter"]).all()
     assert _rel(r0["control"][ok], re["control"][ok]) <= 1e-11
+
+
+@pytest.mark.parametrize("case", ["falling_mass_32", "falling_mass_20", "com_12", "com_20_generic"])
+def test_one_instance_per_lane_pass_filters_for_the_other_tiers(emu, oracle, monkeypatch, case):
+    """in front of a first tier that is not the Riccati-factor tier (shapes the library has no instantiation of it for: the run-time-shape
+    and factor-only kernels) the pass only FILTERS: the instances at their unconstrained minimiser end in it, the tier solves the others
+    from scratch.  (2, 1) and (6, 3) lanes, against the oracle."""
+    from copra_amd import workloads
+    monkeypatch.setenv("COPRA_EMU_LANE_FILTER", "1")
+    b = 70
+    wl = {"falling_mass_32": lambda: workloads.double_integrator(b, N=32), "falling_mass_20": lambda: workloads.double_integrator(b, N=20),
+          "com_12": lambda: workloads.com_preview(b, N=12, seed=5), "com_20_generic": lambda: workloads.com_preview(b, N=20, seed=5)}[case]()
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    re = emu.lmpc_solve(*args, specialised=(case != "com_20_generic"))
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    ok = ro["status"] == 0
+    assert (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9
+    assert re["lane_pass_finished"] == int(((ro["iter"][:, 0] == 1) & ok).sum()) > 0
+    assert re["riccati_factor"] == (case == "com_20_generic")

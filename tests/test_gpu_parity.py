@@ -1484,3 +1484,25 @@ def test_one_instance_per_lane_pass_per_instance_rhs(oracle, monkeypatch):
         assert r1["status"][k] == ro["status"]
         if ro["status"] == 0:
             assert tuple(r1["iter"][k]) == tuple(ro["iter"]) and _rel(r1["control"][k], ro["control"]) <= RTOL
+
+
+@pytest.mark.parametrize("case", ["falling_mass_32", "com_12"])
+def test_one_instance_per_lane_pass_filters_for_the_other_tiers(oracle, monkeypatch, case):
+    """the pass in front of a first tier that is NOT the Riccati-factor tier (shapes without a library instantiation of it, not
+    specialised): it only filters -- against the tier alone and the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 3000
+    wl = workloads.double_integrator(b, N=32) if case == "falling_mass_32" else workloads.com_preview(b, N=12, seed=5)
+    nx, nu = wl["B"].shape[1], wl["B"].shape[2]
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    monkeypatch.setenv("COPRA_LANE_MIN_BATCH", "1")
+    eng = BatchLMPC(nx, nu, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    res = eng.results()
+    assert not eng.layout_info().get("riccati_factor", False)
+    assert eng.lane_pass_info() == (True, int(((ref["iter"][:, 0] == 1) & ok).sum()))
+    assert (res["status"] == ref["status"]).all() and (res["iter"][ok] == ref["iter"][ok]).all()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+    eng.close()
