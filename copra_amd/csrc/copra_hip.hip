@@ -561,15 +561,17 @@ static size_t lane_lds_bytes(const FusedPlan& P)
 // of the machine's SIMDs on (measured at the headline shape, first tier alone -> with the pass: batch 2048: 0.051 -> 0.174 ms, 8192: 0.125 ->
 // 0.212, 16384: 0.208 -> 0.241, 24576: 0.293 -> 0.276, 32768: 0.383 -> 0.309, 65536: 0.71 -> 0.49).  Smaller batches -- the single problem of
 // copra::LMPC::solve() above all -- keep the wave-per-instance tier alone.
-static bool lane_batch_ok(int batch)
+// In front of the OTHER one-wave first tiers (ten times slower per instance than the Riccati-factor tier) it pays from a few thousand
+// instances on (tools/exp/lane_threshold.py: falling mass N = 32: 2048: 0.49 -> 0.38 ms, 16384: 2.78 -> 2.06; N = 64: 1.27 -> 0.08 ms).
+static bool lane_batch_ok(int batch, bool ric_tier)
 {
-    int least = 20480;
+    int least = ric_tier ? 20480 : 4096;
     if (const char* e = std::getenv("COPRA_LANE_MIN_BATCH")) least = std::atoi(e);
     return batch >= least;
 }
 static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_launch)
 {
-    if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS") || !lane_batch_ok(P.batch)) return false;
+    if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS") || !lane_batch_ok(P.batch, P.lds.ric != 0)) return false;
     const char* dbg = std::getenv("COPRA_LANE_DBG");
     if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
     // (in front of the Riccati-factor tier, which takes the factor over, or of any other one-wave first tier, where it only filters)
@@ -1747,7 +1749,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
             // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
             unsigned g1 = (unsigned)P.batch;
-            if (!h->lane_off && !std::getenv("COPRA_NO_LANE_PASS") && lane_batch_ok(P.batch) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
+            if (!h->lane_off && !std::getenv("COPRA_NO_LANE_PASS") && lane_batch_ok(P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
                 && !P.row_f_inst && select_lane_shared_kernel(P)) {
                 rc = ensure_lane_buffers(h, false);
                 if (rc != COPRA_OK) return rc;
