@@ -1751,8 +1751,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             unsigned g1 = (unsigned)P.batch;
             if (!h->lane_off && !std::getenv("COPRA_NO_LANE_PASS") && lane_batch_ok(P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
                 && !P.row_f_inst && select_lane_shared_kernel(P)) {
-                rc = ensure_lane_buffers(h, false);
-                if (rc != COPRA_OK) return rc;
+                if (ensure_lane_buffers(h, false) != COPRA_OK) return fail(COPRA_ERR_HIP, "copra_batch_solve: no memory for the lane pass's list");
                 h->lane_cur ^= 1;
                 h->lane_ran = true;
                 Pr.lane_list = h->d_lane_list;
@@ -1862,9 +1861,12 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     // the one-instance-per-lane pass (lmpc_lane.hpp): every instance whose unconstrained minimiser violates nothing ends in it, the
     // first tier below runs for the others only
     bool lane_pass = lane_pass_wanted(h, P, jit_launch);
+    if (lane_pass && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for its workspace: the tier alone, from now on)
+        (void)hipGetLastError();
+        h->lane_off = true;
+        lane_pass = false;
+    }
     if (lane_pass) {
-        rc = ensure_lane_buffers(h, true);
-        if (rc != COPRA_OK) return rc;
         h->lane_cur ^= 1;
         h->lane_ran = true;
         P.lane_ws = h->d_lane_ws;
