@@ -151,8 +151,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
     for (int i = 0; i < NX; ++i) hNl[i] = uniform_load(tab, ohN + i);
     constexpr int HS = NZ | 1;
+    double hl[NZ]; // (the sweep reads h from this lane's slot of the staging area either way: no branch per use in its loop)
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) hl[a] = uniform_load(tab, oh + a);
     if (own_refs) {
-        double hl[NZ];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) hl[a] = 0.0;
 #pragma unroll
@@ -170,11 +172,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NX; ++i) hNl[i] += uniform_load(tab, co + NZ + i) * pv_r;
             }
         }
-        wave_sync();
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hl[a];
-        wave_sync();
     }
+    wave_sync();
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hl[a];
+    wave_sync();
     // ---- 1. backward Riccati sweep; K_k | kv_k to the workspace, lane-major: element e of stage k at ws[(k KW + e) bp + inst] ----
     double* const ws = P.lane_ws;
     const size_t bp = (size_t)P.lane_bp;
@@ -203,7 +205,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             }
 #pragma unroll
             for (int a = 0; a < NZ; ++a) {
-                double s = own_refs ? lds[lane * HS + a] : Hk[oh + a];
+                double s = lds[lane * HS + a];
 #pragma unroll
                 for (int l = 0; l < NX; ++l) s += AB(l, a) * tq[l];
                 mz[a] = s;
