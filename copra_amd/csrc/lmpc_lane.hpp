@@ -181,9 +181,13 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double* const ws = P.lane_ws;
     const size_t bp = (size_t)P.lane_bp;
     const unsigned ioff = (unsigned)inst * 8u; // this lane's byte offset in a workspace row
-    double Pm[NX * NX], pv[NX]; // cost-to-go (symmetric, both halves)
+    // cost-to-go: the upper triangle only ((i, l), i <= l, at i + NX l) -- both halves would be 15 more doubles carried around the loop
+    double Pm[NX * NX], pv[NX];
 #pragma unroll
-    for (int e = 0; e < NX * NX; ++e) Pm[e] = uniform_load(tab, oHN + e);
+    for (int l = 0; l < NX; ++l)
+#pragma unroll
+        for (int i = 0; i <= l; ++i) Pm[i + NX * l] = uniform_load(tab, oHN + i + NX * l);
+    auto Ps = [&](int i, int l) -> double { return i <= l ? Pm[i + NX * l] : Pm[l + NX * i]; };
 #pragma unroll
     for (int i = 0; i < NX; ++i) pv[i] = hNl[i];
     bool bad = false;
@@ -200,7 +204,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int l = 0; l < NX; ++l) {
                 double s = pv[l];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s += Pm[l + NX * i] * d[i];
+                for (int i = 0; i < NX; ++i) s += Ps(l, i) * d[i];
                 tq[l] = s;
             }
 #pragma unroll
@@ -218,7 +222,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int l = 0; l < NX; ++l) {
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s += Pm[l + NX * i] * AB(i, b);
+                for (int i = 0; i < NX; ++i) s += Ps(l, i) * AB(i, b);
                 Tb[l] = s;
             }
 #pragma unroll
@@ -279,8 +283,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 double s = M[i][j];
 #pragma unroll
                 for (int c = 0; c < NU; ++c) s += M[i][NX + c] * K[c][j];
-                Pm[i + NX * j] = s;
-                Pm[j + NX * i] = s;
+                Pm[i + NX * j] = s; // (i <= j)
             }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
