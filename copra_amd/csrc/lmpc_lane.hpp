@@ -59,35 +59,37 @@ COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, d
 // this lane's element of a wave-uniform workspace row, by a 32-bit byte offset from the row pointer.  (The row pointer is made opaque to
 // the optimiser: left to itself it folds row and lane offsets into a fresh 64-bit address computation per access and keeps all of them
 // live across the unrolled stage.)
-COPRA_DEV double& lane_at(double* row, unsigned byte_off)
+// (The accesses go through the GLOBAL address space explicitly: behind the opaque pointer the compiler would fall back to flat loads and
+//  stores, which probe the LDS aperture as well and count against both wait counters.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double __attribute__((address_space(1))) lane_gdouble;
+#endif
+COPRA_DEV void lane_put(double* row, unsigned byte_off, double v, bool streaming = false)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(row));
-#endif
-    return *(double*)((char*)row + byte_off);
-}
-COPRA_DEV const double& lane_at(const double* row, unsigned byte_off)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(row));
-#endif
-    return *(const double*)((const char*)row + byte_off);
-}
-
-// a store that does not claim cache space: what is written once and read, if at all, by a later kernel (measured: 226 -> 220 us for the
-// pass when Lam^-1 and the norm sums leave this way; no difference for U and X)
-COPRA_DEV void stream_store(double* p, double v, bool streaming)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
+    lane_gdouble* const g = (lane_gdouble*)((unsigned long long)row + byte_off);
     if (streaming)
-        __builtin_nontemporal_store(v, p);
+        __builtin_nontemporal_store(v, g);
     else
-        *p = v;
+        *g = v;
 #else
     (void)streaming;
-    *p = v;
+    *(double*)((char*)row + byte_off) = v;
 #endif
 }
+COPRA_DEV double lane_get(const double* row, unsigned byte_off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(row));
+    return *(const lane_gdouble*)((unsigned long long)row + byte_off);
+#else
+    return *(const double*)((const char*)row + byte_off);
+#endif
+}
+
+// (streaming: a store that does not claim cache space -- what is written once and read, if at all, by a later kernel; measured: 226 -> 220 us
+//  for the pass when Lam^-1 and the norm sums leave this way, no difference for U and X)
 
 template <int NX, int NU>
 COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
@@ -298,8 +300,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) lane_at(wk + (size_t)(c + NU * j) * bp, ioff) = K[c][j];
-                lane_at(wk + (size_t)(NU * NX + c) * bp, ioff) = kv[c];
+                for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
+                lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
             }
             // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier
             double lm[NU][NU], rd[NU], lid[NU][NU];
@@ -335,7 +337,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                         li = v * rd[r2];
                     }
                     lid[r2][c] = li;
-                    stream_store(&lane_at(wk + (size_t)(oLiW + r2 * (r2 + 1) / 2 + c) * bp, ioff), li, true); // (for the first tier only)
+                    lane_put(wk + (size_t)(oLiW + r2 * (r2 + 1) / 2 + c) * bp, ioff, li, true); // (streaming: for the first tier only)
                 }
         }
     }
@@ -360,12 +362,21 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
-        for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_at(wk + (size_t)e * bp, ioff);
+        for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_get(wk + (size_t)e * bp, ioff);
     };
     // the right-hand side of a row: the controller's, or this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the
     // stacked order; a row of the table that is not there keeps +inf)
     const double* const rhs_mine = P.row_f_inst ? P.row_f_inst + (size_t)li * P.mgen : nullptr;
-    auto row_rhs = [&](double f_shared, int idx) -> double { return (rhs_mine && idx >= 0) ? rhs_mine[idx] : f_shared; };
+    auto row_rhs = [&](double f_shared, int idx) -> double {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(f_shared)); // (the table entry is READ: folded into a choice between two addresses it would be a flat load)
+#endif
+        double f = f_shared;
+        if (rhs_mine) {
+            if (idx >= 0) f = rhs_mine[idx];
+        }
+        return f;
+    };
     auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) { // E x_k + G u_k <= f
         if (tlds) {
             for (int r = 0; r < rps; ++r) {
@@ -428,7 +439,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
                     for (int c = 0; c < NU; ++c) sq += Gp[i + NX * c] * Gp[i + NX * c];
                     ncum[i] += sq;
-                    stream_store(&lane_at(wn + (size_t)i * bp, ioff), ncum[i], true);
+                    lane_put(wn + (size_t)i * bp, ioff, ncum[i], true);
                 }
                 double Gn[NX * NU];
 #pragma unroll
@@ -447,8 +458,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 check_rows(k, x, u);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    const double ub = own_bounds ? ubp[k * NU + c] : tlds ? Tl[tl_rows + k * NU + c] : uniform_load(ubp, k * NU + c);
-                    const double lb = own_bounds ? lbp[k * NU + c] : tlds ? Tl[tl_rows + P.n + k * NU + c] : uniform_load(lbp, k * NU + c);
+                    double ub, lb; // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
+                    if (own_bounds) {
+                        ub = ubp[k * NU + c];
+                        lb = lbp[k * NU + c];
+                    } else if (tlds) {
+                        ub = Tl[tl_rows + k * NU + c];
+                        lb = Tl[tl_rows + P.n + k * NU + c];
+                    } else {
+                        ub = uniform_load(ubp, k * NU + c);
+                        lb = uniform_load(lbp, k * NU + c);
+                    }
                     viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
                 }
             }
@@ -617,8 +637,17 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
                 check_rows(k, x, u);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    const double ub = own_bounds ? ubp[k * NU + c] : tlds ? Tl[tl_rows + k * NU + c] : uniform_load(ubp, k * NU + c);
-                    const double lb = own_bounds ? lbp[k * NU + c] : tlds ? Tl[tl_rows + P.n + k * NU + c] : uniform_load(lbp, k * NU + c);
+                    double ub, lb; // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
+                    if (own_bounds) {
+                        ub = ubp[k * NU + c];
+                        lb = lbp[k * NU + c];
+                    } else if (tlds) {
+                        ub = Tl[tl_rows + k * NU + c];
+                        lb = Tl[tl_rows + P.n + k * NU + c];
+                    } else {
+                        ub = uniform_load(ubp, k * NU + c);
+                        lb = uniform_load(lbp, k * NU + c);
+                    }
                     viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
                 }
             }
