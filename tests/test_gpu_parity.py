@@ -1506,3 +1506,33 @@ def test_one_instance_per_lane_pass_filters_for_the_other_tiers(oracle, monkeypa
     assert (res["status"] == ref["status"]).all() and (res["iter"][ok] == ref["iter"][ok]).all()
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     eng.close()
+
+
+@pytest.mark.parametrize("violators", [0, 1, 3, 8, 13])
+def test_one_instance_per_lane_pass_short_lists(oracle, violators):
+    """the list the pass leaves to the first tier is dealt to the eight XCDs in contiguous eighths (tier_instance): empty list, fewer
+    entries than XCDs, exactly eight, a ragged count -- every listed instance must be solved exactly once, nothing else touched.
+    Loose bounds for everyone (all end at their unconstrained minimiser) except `violators` instances with tight control bounds of
+    their own."""
+    from copra_amd import BatchLMPC, workloads
+    b = 20480 + 77
+    wl = workloads.com_preview(b, v_max=50.0, u_max=500.0, seed=23)
+    pick = np.linspace(5, b - 9, violators).astype(int) if violators else np.zeros(0, dtype=int)
+    n = 3 * wl["N"]
+    ub = np.full((b, n), 500.0)
+    ub[pick] = 0.5
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.set_control_bounds(-ub, ub)
+    eng.solve()
+    res = eng.results()
+    ran, finished = eng.lane_pass_info()
+    assert ran and finished == b - violators and (res["status"] == 0).all()
+    assert (res["iter"][pick, 0] > 1).all() and (np.delete(res["iter"][:, 0], pick) == 1).all()
+    sample = np.unique(np.concatenate([pick, np.arange(0, b, 997)]))
+    for k in sample:
+        cs = [wl["cstrs"][0], dict(wl["cstrs"][1], lower=[-ub[k, 0]] * 3, upper=[ub[k, 0]] * 3)]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
+        assert ro["status"] == 0 and tuple(res["iter"][k]) == tuple(ro["iter"])
+        assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
+    eng.close()
