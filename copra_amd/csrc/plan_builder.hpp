@@ -750,10 +750,24 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             switch (c.kind) {
             case COPRA_CSTR_TRAJECTORY: // constraints.cpp:66-84
                 if (c.e_cols == nx) {
-                    std::vector<int> eo((size_t)r);
-                    for (int i = 0; i < r; ++i) eo[(size_t)i] = push_row(c.E, r, nx, i);
+                    std::vector<int> eo((size_t)r), hot((size_t)r, -1);
+                    for (int i = 0; i < r; ++i) {
+                        eo[(size_t)i] = push_row(c.E, r, nx, i);
+                        // a row of E that SELECTS one component (one entry, equal to 1: a velocity limit written as E x <= f) is the
+                        // row of Psi a TrajectoryBoundConstraint would give -- the same arithmetic (1 x_c, sums of zeros), and the
+                        // controller keeps the compact variant of the Riccati-factor tier and the hand-over from the lane pass
+                        int nnz = 0, at = -1;
+                        for (int j = 0; j < nx; ++j)
+                            if (c.E[(size_t)j * r + i] != 0.0) ++nnz, at = j;
+                        if (nnz == 1 && c.E[(size_t)at * r + i] == 1.0 && c.is_inequality && !std::getenv("COPRA_NO_SELECTION_ROWS")) hot[(size_t)i] = at;
+                    }
                     for (int s = 0; s <= N; ++s)
-                        for (int i = 0; i < r; ++i) add_row(s, kEDense, eo[(size_t)i], kGNone, -1, c.f[i]);
+                        for (int i = 0; i < r; ++i) {
+                            if (hot[(size_t)i] >= 0)
+                                add_row(s, kEOneHot, hot[(size_t)i], kGNone, -1, c.f[i]);
+                            else
+                                add_row(s, kEDense, eo[(size_t)i], kGNone, -1, c.f[i]);
+                        }
                 } else {
                     for (int i = 0; i < r; ++i) add_row(0, kEFull, push_row(c.E, r, X, i), kGNone, -1, c.f[i]);
                 }
