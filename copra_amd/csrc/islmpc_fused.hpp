@@ -32,8 +32,8 @@ struct StageRowsIS {
         if (j >= nx()) return base.coeff(d, j - nx());
         const int a = j, k = d.k, eo = d.eo, nPhi = nx() * nx();
         double v = 0.0;
-        if (d.ek == kEOneHot) {
-            v = Phi[k * nPhi + eo + nx() * a];
+        if (e_onehot(d.ek)) {
+            v = e_sign(d.ek) * Phi[k * nPhi + eo + nx() * a];
         } else if (d.ek == kEDense) {
             for (int c = 0; c < nx(); ++c) v += P.params[eo + c] * Phi[k * nPhi + c + nx() * a];
         } else if (d.ek == kEFull) {

@@ -153,8 +153,8 @@ struct StageRows {
         const int k = d.k, eo = d.eo, go = d.go;
         const int jb = j / nu(), jc = j - jb * nu();
         double v = 0.0;
-        if (d.ek == kEOneHot) {
-            if (jb < k) v = G[(k - 1 - jb) * nx() * nu() + nx() * jc + eo];
+        if (e_onehot(d.ek)) {
+            if (jb < k) v = e_sign(d.ek) * G[(k - 1 - jb) * nx() * nu() + nx() * jc + eo];
         } else if (d.ek == kEDense) {
             if (jb < k) {
                 const double* Gk = G + (k - 1 - jb) * nx() * nu() + nx() * jc;
@@ -177,7 +177,7 @@ struct StageRows {
     // squared norm of a row: sum_j coeff(j)^2
     COPRA_DEV double norm2(const RowDesc& d) const
     {
-        if (d.ek == kEOneHot && d.gk == kGNone) { // rows of Psi: sum over the blocks G_0 .. G_{k-1}
+        if (e_onehot(d.ek) && d.gk == kGNone) { // rows of +-Psi: sum over the blocks G_0 .. G_{k-1}
             double s0 = 0.0;
             const double* g = G + d.eo;
             for (int t = 0; t < d.k; ++t) {
@@ -201,8 +201,8 @@ struct StageRows {
     {
         const int k = d.k, eo = d.eo, go = d.go;
         double ax = 0.0;
-        if (d.ek == kEOneHot) {
-            ax = Xv[k * nx() + eo];
+        if (e_onehot(d.ek)) {
+            ax = e_sign(d.ek) * Xv[k * nx() + eo];
         } else if (d.ek == kEDense) {
             for (int c = 0; c < nx(); ++c) ax += params()[eo + c] * Xv[k * nx() + c];
         } else if (d.ek == kEFull) {
@@ -290,7 +290,7 @@ struct StageRows {
     {
         if (!P.rows_direct) return lhs(d, Xcur, xs);
         double ax = 0.0;
-        if (d.ek == kEOneHot) ax = (xu && (scans <= 1 || xi)) ? xu[d.k * nx() + d.eo] : state_component(d.k, d.eo, xs);
+        if (e_onehot(d.ek)) ax = e_sign(d.ek) * ((xu && (scans <= 1 || xi)) ? xu[d.k * nx() + d.eo] : state_component(d.k, d.eo, xs));
         if (d.gk == kGStep) {
             for (int c = 0; c < nu(); ++c) ax += params()[d.go + c] * xs[d.k * nu() + c];
         } else if (d.gk == kGFull) {
@@ -341,10 +341,10 @@ struct StageRows {
         const int j = lane_id();
         const RowDesc d = desc_uniform(p); // (every lane takes part in the broadcast)
         const double sign = (p < P.meq) ? sgn : -1.0;
-        if (d.ek == kEOneHot && d.k > 0) {
+        if (e_onehot(d.ek) && d.k > 0) {
             inj_stage = d.k;
             inj_comp = d.eo;
-            inj_val = sign;
+            inj_val = sign * e_sign(d.ek);
         }
         if (j >= nvar()) return;
         const int jb = j / nu(), jc = j - jb * nu();

@@ -587,7 +587,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         const bool fast = xu_ok;
         for (int i = lane; i < P.mgen; i += kWave) {
             const RowDesc d = rows.desc(i);
-            if (!(fast && d.ek == kEOneHot && d.gk == kGNone)) put_norm(i, sqrt(rows.norm2(d)));
+            if (!(fast && e_onehot(d.ek) && d.gk == kGNone)) put_norm(i, sqrt(rows.norm2(d)));
         }
         if (fast) {
             double* NB2 = Xbar;
@@ -617,9 +617,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             }
             for (int i = lane; i < P.mgen; i += kWave) {
                 const RowDesc d = rows.desc(i);
-                if (compact && d.ek == kEOneHot && d.gk == kGNone) { // (the preview steps left RUNNING sums)
+                if (compact && e_onehot(d.ek) && d.gk == kGNone) { // (the preview steps left RUNNING sums)
                     put_norm(i, d.k > 0 ? sqrt(NB2[(d.k - 1) * tst + d.eo]) : 0.0);
-                } else if (d.ek == kEOneHot && d.gk == kGNone) {
+                } else if (e_onehot(d.ek) && d.gk == kGNone) {
                     double part[NH];
 #pragma unroll
                     for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * tst + d.eo];

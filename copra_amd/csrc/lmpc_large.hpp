@@ -40,8 +40,8 @@ struct LargeRows {
         if (j >= off) return base.coeff(d, j - off);
         const int a = j, k = d.k, eo = d.eo, nPhi = nx() * nx(); // x0 part: Y_row = E_row Phi_k
         double v = 0.0;
-        if (d.ek == kEOneHot) {
-            v = Phi[k * nPhi + eo + nx() * a];
+        if (e_onehot(d.ek)) {
+            v = e_sign(d.ek) * Phi[k * nPhi + eo + nx() * a];
         } else if (d.ek == kEDense) {
             for (int c = 0; c < nx(); ++c) v += base.params()[eo + c] * Phi[k * nPhi + c + nx() * a];
         } else if (d.ek == kEFull) {

@@ -36,8 +36,18 @@ enum {
     kENone = 0, // no state term
     kEDense = 1, // nx coefficients at params[eoff..] applied to x_step
     kEOneHot = 2, // coefficient 1 on component `eoff` of x_step (rows of Psi: TrajectoryBoundConstraint)
-    kEFull = 3 // fullXDim coefficients at params[eoff..] applied to the whole trajectory X (full-size entry)
+    kEFull = 3, // fullXDim coefficients at params[eoff..] applied to the whole trajectory X (full-size entry)
+    kEOneHotNeg = 4 // coefficient -1 on component `eoff` of x_step (a lower limit written as -x_c <= -l: TrajectoryConstraint with E = -e_c')
 };
+// a row whose state part is +- one component of one state, and that sign
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool e_onehot(int ek) { return ek == kEOneHot || ek == kEOneHotNeg; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline double e_sign(int ek) { return ek == kEOneHotNeg ? -1.0 : 1.0; }
 // control part of a constraint row
 enum {
     kGNone = 0,

@@ -406,7 +406,7 @@ inline void build_lane_tables(HostPlan& hp)
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i];
         double* row = tab.data() + oRows + ((size_t)k * rps + filled[k]++) * rw;
-        if (hp.row_ekind[i] == kEOneHot) row[hp.row_eoff[i]] = 1.0;
+        if (e_onehot(hp.row_ekind[i])) row[hp.row_eoff[i]] = e_sign(hp.row_ekind[i]);
         if (hp.row_ekind[i] == kEDense)
             for (int c = 0; c < nx; ++c) row[c] = hp.params[(size_t)hp.row_eoff[i] + c];
         if (hp.row_gkind[i] == kGStep)
@@ -724,8 +724,8 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         hp.row_goff.push_back(goff);
         hp.row_f.push_back(f);
         if (ekind != kENone) P.any_state_rows = 1;
-        if (ekind != kENone && ekind != kEOneHot) P.rows_direct = 0;
-        if (ekind != kENone && (ekind != kEOneHot || gkind != kGNone)) P.rows_pure = 0;
+        if (ekind != kENone && !e_onehot(ekind)) P.rows_direct = 0;
+        if (ekind != kENone && (!e_onehot(ekind) || gkind != kGNone)) P.rows_pure = 0;
     };
     // row-major copy of one row of a column-major (rows x cols) matrix into the blob
     auto push_row = [&](const double* Mx, int rows, int cols, int r) {
@@ -750,21 +750,25 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             switch (c.kind) {
             case COPRA_CSTR_TRAJECTORY: // constraints.cpp:66-84
                 if (c.e_cols == nx) {
-                    std::vector<int> eo((size_t)r), hot((size_t)r, -1);
+                    std::vector<int> eo((size_t)r), hot((size_t)r, -1), neg((size_t)r, 0);
                     for (int i = 0; i < r; ++i) {
                         eo[(size_t)i] = push_row(c.E, r, nx, i);
-                        // a row of E that SELECTS one component (one entry, equal to 1: a velocity limit written as E x <= f) is the
+                        // a row of E that SELECTS one component (one entry, equal to 1 or -1: a velocity limit written as +-x_c <= f) is, up to its sign, the
                         // row of Psi a TrajectoryBoundConstraint would give -- the same arithmetic (1 x_c, sums of zeros), and the
                         // controller keeps the compact variant of the Riccati-factor tier and the hand-over from the lane pass
                         int nnz = 0, at = -1;
                         for (int j = 0; j < nx; ++j)
                             if (c.E[(size_t)j * r + i] != 0.0) ++nnz, at = j;
-                        if (nnz == 1 && c.E[(size_t)at * r + i] == 1.0 && c.is_inequality && !std::getenv("COPRA_NO_SELECTION_ROWS")) hot[(size_t)i] = at;
+                        const double ev = nnz == 1 ? c.E[(size_t)at * r + i] : 0.0;
+                        if ((ev == 1.0 || ev == -1.0) && c.is_inequality && !std::getenv("COPRA_NO_SELECTION_ROWS")) {
+                            hot[(size_t)i] = at;
+                            neg[(size_t)i] = ev < 0.0; // (-x_c <= -l: a lower limit)
+                        }
                     }
                     for (int s = 0; s <= N; ++s)
                         for (int i = 0; i < r; ++i) {
                             if (hot[(size_t)i] >= 0)
-                                add_row(s, kEOneHot, hot[(size_t)i], kGNone, -1, c.f[i]);
+                                add_row(s, neg[(size_t)i] ? kEOneHotNeg : kEOneHot, hot[(size_t)i], kGNone, -1, c.f[i]);
                             else
                                 add_row(s, kEDense, eo[(size_t)i], kGNone, -1, c.f[i]);
                         }

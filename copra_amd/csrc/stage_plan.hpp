@@ -251,8 +251,8 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
         int sx = -1, su = -1;
         if (ek == kEDense)
             for (int j = 0; j < nx; ++j) r.a[(size_t)j] = prm[(size_t)hp.row_eoff[(size_t)i] + j];
-        else if (ek == kEOneHot)
-            r.a[(size_t)hp.row_eoff[(size_t)i]] = 1.0;
+        else if (e_onehot(ek))
+            r.a[(size_t)hp.row_eoff[(size_t)i]] = e_sign(ek);
         else if (ek == kEFull) {
             const double* row = &prm[(size_t)hp.row_eoff[(size_t)i]];
             if (!one_step(row, nx, N + 1, sx)) return no("a full-size constraint row couples several steps");

@@ -994,3 +994,29 @@ def test_one_instance_per_lane_pass_filters_for_the_other_tiers(emu, oracle, mon
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9
     assert re["lane_pass_finished"] == int(((ro["iter"][:, 0] == 1) & ok).sum()) > 0
     assert re["riccati_factor"] == (case == "com_20_generic")
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+def test_selection_rows_of_a_trajectory_constraint(emu, oracle, monkeypatch, specialised):
+    """|v| <= v_max written as TrajectoryConstraint(E = [S; -S], f) with S a selection matrix: the plan builder classifies such rows as
+    +- one component of one state (the rows of +-Psi, like TrajectoryBoundConstraint's), the controller keeps the compact variant of the
+    Riccati-factor tier; against the oracle, and identical to the dense-row classification (COPRA_NO_SELECTION_ROWS)"""
+    from copra_amd import workloads
+    b = 40
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=41)
+    S3 = np.hstack([np.zeros((3, 3)), np.eye(3)])
+    cstrs = [dict(kind="trajectory", E=np.vstack([S3, -S3]), f=[0.5, 0.5, 0.5, 0.12, 0.12, 0.12], ineq=True), wl["cstrs"][1]]
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+    re = emu.lmpc_solve(*args, specialised=specialised)
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    ok = ro["status"] == 0
+    # (initial velocities lie in [-0.2, 0.2]: some instances start below the lower limit -- infeasible, status 1 --, in others it binds)
+    assert ok.sum() >= 8 and (~ok).sum() >= 3 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    assert (ro["iter"][ok, 0] > 1).any()
+    monkeypatch.setenv("COPRA_NO_SELECTION_ROWS", "1")
+    rd = emu.lmpc_solve(*args, specialised=specialised)
+    assert (rd["status"] == re["status"]).all() and (rd["iter"][ok] == re["iter"][ok]).all()
+    assert _rel(rd["control"][ok], re["control"][ok]) <= 1e-10
+    if specialised:
+        assert re["lds_bytes"] < rd["lds_bytes"]  # (compact variant of the tier against its general one)

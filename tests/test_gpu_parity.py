@@ -1536,3 +1536,34 @@ def test_one_instance_per_lane_pass_short_lists(oracle, violators):
         assert ro["status"] == 0 and tuple(res["iter"][k]) == tuple(ro["iter"])
         assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL
     eng.close()
+
+
+def test_selection_rows_two_sided_velocity_limits(oracle, monkeypatch):
+    """|v| <= v_max as TrajectoryConstraint(E = [S; -S], f): rows that select +- one state component keep the compact variant of the
+    Riccati-factor tier and the lane pass's hand-over; against the dense-row classification (COPRA_NO_SELECTION_ROWS) at 32768
+    instances and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 32768
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=41)
+    S3 = np.hstack([np.zeros((3, 3)), np.eye(3)])
+    cstrs = [dict(kind="trajectory", E=np.vstack([S3, -S3]), f=[0.5, 0.5, 0.5, 0.25, 0.25, 0.25], ineq=True), wl["cstrs"][1]]
+    out = {}
+    for mode in ("dense", "selection"):
+        monkeypatch.delenv("COPRA_NO_SELECTION_ROWS", raising=False)
+        if mode == "dense":
+            monkeypatch.setenv("COPRA_NO_SELECTION_ROWS", "1")
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], cstrs)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        out[mode] = (eng.results(), eng.layout_info(), eng.lane_pass_info())
+        eng.close()
+    r0, r1 = out["dense"][0], out["selection"][0]
+    ok = r0["status"] == 0
+    assert out["selection"][1]["lds_bytes"] < out["dense"][1]["lds_bytes"] and out["selection"][2][0]
+    assert ok.sum() > b // 2 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).all()
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-10
+    pick = np.arange(0, b, 509)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], cstrs, nthreads=8)
+    okp = ref["status"] == 0
+    assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
+    assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL
