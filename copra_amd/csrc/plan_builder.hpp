@@ -733,6 +733,39 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         for (int j = 0; j < cols; ++j) tmp[(size_t)j] = Mx[(size_t)j * rows + r];
         return push(tmp.data(), cols);
     };
+    // A row of a FULL-SIZE entry (E over the whole trajectory, G over all controls: constraints.cpp:66-84, 137-148, 197-226) whose
+    // non-zeros lie inside ONE step -- a terminal constraint written as a full-size matrix, the usual way to get one from the reference --
+    // is a per-step row of that step: the same coefficients, the same arithmetic over them, none of the full-row machinery (sums over
+    // the whole trajectory at every slack evaluation, the general variants of the tiers, no lane pass).
+    const bool step_rows = !std::getenv("COPRA_NO_STEP_ROWS");
+    auto single_block = [&](const double* Mx, int rows, int blk, int nblk, int i, int& at) { // false: more than one block of row i is non-zero
+        at = -1;
+        for (int b = 0; b < nblk; ++b)
+            for (int j = 0; j < blk; ++j)
+                if (Mx[(size_t)(b * blk + j) * rows + i] != 0.0) {
+                    if (at >= 0 && at != b) return false;
+                    at = b;
+                }
+        return true;
+    };
+    auto push_block = [&](const double* Mx, int rows, int blk, int b, int i) {
+        std::vector<double> tmp((size_t)blk);
+        for (int j = 0; j < blk; ++j) tmp[(size_t)j] = Mx[(size_t)(b * blk + j) * rows + i];
+        return push(tmp.data(), blk);
+    };
+    // state part of a per-step row from nx coefficients: +- one component (selection row) or dense
+    auto state_kind = [&](const double* coef, bool ineq, int& eoff_or_comp) {
+        int nnz = 0, at = -1;
+        for (int j = 0; j < nx; ++j)
+            if (coef[j] != 0.0) ++nnz, at = j;
+        const double ev = nnz == 1 ? coef[at] : 0.0;
+        if ((ev == 1.0 || ev == -1.0) && ineq && !std::getenv("COPRA_NO_SELECTION_ROWS")) {
+            eoff_or_comp = at;
+            return ev < 0.0 ? (int)kEOneHotNeg : (int)kEOneHot;
+        }
+        eoff_or_comp = push(coef, nx);
+        return (int)kEDense;
+    };
     P.meq = P.mineq = 0;
     P.row_f_inst = nullptr;
     P.lb_inst = P.ub_inst = nullptr;
@@ -773,7 +806,18 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                                 add_row(s, kEDense, eo[(size_t)i], kGNone, -1, c.f[i]);
                         }
                 } else {
-                    for (int i = 0; i < r; ++i) add_row(0, kEFull, push_row(c.E, r, X, i), kGNone, -1, c.f[i]);
+                    for (int i = 0; i < r; ++i) {
+                        int sx = -1;
+                        if (step_rows && single_block(c.E, r, nx, N + 1, i, sx) && sx >= 0) {
+                            std::vector<double> coef((size_t)nx);
+                            for (int j = 0; j < nx; ++j) coef[(size_t)j] = c.E[(size_t)(sx * nx + j) * r + i];
+                            int eoc = -1;
+                            const int ek = state_kind(coef.data(), c.is_inequality != 0, eoc);
+                            add_row(sx, ek, eoc, kGNone, -1, c.f[i]);
+                        } else {
+                            add_row(0, kEFull, push_row(c.E, r, X, i), kGNone, -1, c.f[i]);
+                        }
+                    }
                 }
                 break;
             case COPRA_CSTR_CONTROL: // constraints.cpp:137-148
@@ -783,7 +827,13 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     for (int s = 0; s < N; ++s)
                         for (int i = 0; i < r; ++i) add_row(s, kENone, -1, kGStep, go[(size_t)i], c.f[i]);
                 } else {
-                    for (int i = 0; i < r; ++i) add_row(0, kENone, -1, kGFull, push_row(c.G, r, U, i), c.f[i]);
+                    for (int i = 0; i < r; ++i) {
+                        int su = -1;
+                        if (step_rows && single_block(c.G, r, nu, N, i, su) && su >= 0)
+                            add_row(su, kENone, -1, kGStep, push_block(c.G, r, nu, su, i), c.f[i]);
+                        else
+                            add_row(0, kENone, -1, kGFull, push_row(c.G, r, U, i), c.f[i]);
+                    }
                 }
                 break;
             case COPRA_CSTR_MIXED: // constraints.cpp:197-226
@@ -796,8 +846,23 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     for (int s = 0; s < N; ++s)
                         for (int i = 0; i < r; ++i) add_row(s, kEDense, eo[(size_t)i], kGStep, go[(size_t)i], c.f[i]);
                 } else {
-                    for (int i = 0; i < r; ++i)
-                        add_row(0, kEFull, push_row(c.E, r, X, i), kGFull, push_row(c.G, r, U, i), c.f[i]);
+                    for (int i = 0; i < r; ++i) {
+                        int sx = -1, su = -1;
+                        const bool one = step_rows && single_block(c.E, r, nx, N + 1, i, sx) && single_block(c.G, r, nu, N, i, su);
+                        if (one && sx >= 0 && su >= 0 && sx == su) { // E x_s + G u_s: a per-step mixed row
+                            add_row(sx, kEDense, push_block(c.E, r, nx, sx, i), kGStep, push_block(c.G, r, nu, su, i), c.f[i]);
+                        } else if (one && sx >= 0 && su < 0) { // no control part at all
+                            std::vector<double> coef((size_t)nx);
+                            for (int j = 0; j < nx; ++j) coef[(size_t)j] = c.E[(size_t)(sx * nx + j) * r + i];
+                            int eoc = -1;
+                            const int ek = state_kind(coef.data(), c.is_inequality != 0, eoc);
+                            add_row(sx, ek, eoc, kGNone, -1, c.f[i]);
+                        } else if (one && sx < 0 && su >= 0) { // no state part at all
+                            add_row(su, kENone, -1, kGStep, push_block(c.G, r, nu, su, i), c.f[i]);
+                        } else {
+                            add_row(0, kEFull, push_row(c.E, r, X, i), kGFull, push_row(c.G, r, U, i), c.f[i]);
+                        }
+                    }
                 }
                 break;
             case COPRA_CSTR_DENSE:

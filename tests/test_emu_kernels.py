@@ -1020,3 +1020,46 @@ def test_selection_rows_of_a_trajectory_constraint(emu, oracle, monkeypatch, spe
     assert _rel(rd["control"][ok], re["control"][ok]) <= 1e-10
     if specialised:
         assert re["lds_bytes"] < rd["lds_bytes"]  # (compact variant of the tier against its general one)
+
+
+@pytest.mark.parametrize("kind", ["terminal_velocity", "terminal_box_and_first_control", "mixed_one_step"])
+def test_full_size_rows_that_touch_one_step(emu, oracle, monkeypatch, kind):
+    """a terminal constraint written the reference's way -- a FULL-SIZE E (rows over the whole trajectory) that is non-zero in the last
+    state only -- is classified as a per-step row of that step (selection rows as +- one component); likewise full-size G / mixed rows
+    inside one step.  Against the oracle and against the full-row classification (COPRA_NO_STEP_ROWS)."""
+    from copra_amd import workloads
+    b = 24
+    wl = workloads.com_preview(b, v_max=0.6, u_max=3.0, seed=51)
+    N, nx, nu = wl["N"], 6, 3
+    X, U = nx * (N + 1), nu * N
+    rng = np.random.default_rng(5)
+    if kind == "terminal_velocity":  # |v_N| <= 0.02: six selection rows in the last block
+        E = np.zeros((6, X))
+        E[:3, X - 3:] = np.eye(3)
+        E[3:, X - 3:] = -np.eye(3)
+        extra = [dict(kind="trajectory", E=E, f=[0.02] * 6, ineq=True)]
+    elif kind == "terminal_box_and_first_control":  # a dense terminal row + a full-size control row inside step 0
+        E = np.zeros((2, X))
+        E[:, X - 6:] = rng.standard_normal((2, 6))
+        G = np.zeros((1, U))
+        G[0, :3] = [1.0, -0.5, 0.25]
+        extra = [dict(kind="trajectory", E=E, f=[2.0, 2.5], ineq=True), dict(kind="control", G=G, f=[0.4], ineq=True)]
+    else:  # mixed row inside step 3
+        E = np.zeros((1, X))
+        G = np.zeros((1, U))
+        E[0, 3 * nx + 3: 3 * nx + 6] = [1.0, 1.0, 1.0]
+        G[0, 3 * nu: 3 * nu + 3] = [0.1, 0.1, 0.1]
+        extra = [dict(kind="mixed", E=E, G=G, f=[0.5], ineq=True)]
+    cstrs = wl["cstrs"] + extra
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, wl["costs"], cstrs)
+    re = emu.lmpc_solve(*args)
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    ok = ro["status"] == 0
+    assert ok.sum() >= b // 2 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    assert (ro["iter"][ok, 0] > 1).any()
+    monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")
+    rf = emu.lmpc_solve(*args)
+    assert (rf["status"] == re["status"]).all() and (rf["iter"][ok] == re["iter"][ok]).all() and _rel(rf["control"][ok], re["control"][ok]) <= 1e-9
+    if kind == "terminal_velocity":
+        assert re["riccati_factor"] and re["lds_bytes"] < rf["lds_bytes"]  # (the compact variant of the headline's tier is kept)
