@@ -1567,3 +1567,36 @@ def test_selection_rows_two_sided_velocity_limits(oracle, monkeypatch):
     okp = ref["status"] == 0
     assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
     assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL
+
+
+def test_full_size_rows_that_touch_one_step(oracle, monkeypatch):
+    """a terminal velocity limit written as a full-size E (non-zero in the last state only): per-step rows of step N (the compact
+    variant of the headline's tier, the lane pass in front) against the full-row classification (COPRA_NO_STEP_ROWS) and the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 24576
+    wl = workloads.com_preview(b, seed=61)
+    N, nx = wl["N"], 6
+    X = nx * (N + 1)
+    E = np.zeros((6, X))
+    E[:3, X - 3:] = np.eye(3)
+    E[3:, X - 3:] = -np.eye(3)
+    cstrs = wl["cstrs"] + [dict(kind="trajectory", E=E, f=[0.3] * 6, ineq=True)]
+    out = {}
+    for mode in ("full", "step"):
+        monkeypatch.delenv("COPRA_NO_STEP_ROWS", raising=False)
+        if mode == "full":
+            monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")
+        eng = BatchLMPC(6, 3, N, b, wl["costs"], cstrs)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        out[mode] = (eng.results(), eng.layout_info(), eng.lane_pass_info())
+        eng.close()
+    r0, r1 = out["full"][0], out["step"][0]
+    ok = r0["status"] == 0
+    assert out["step"][1]["lds_bytes"] < out["full"][1]["lds_bytes"] and out["step"][2][0] and not out["full"][2][0]
+    assert ok.all() and (r1["status"] == 0).all() and (r0["iter"] == r1["iter"]).all()
+    assert _rel_vec(r1["control"], r0["control"]) <= 1e-10 and (r1["iter"][:, 0] > 1).all()  # (the terminal limit binds everywhere)
+    pick = np.arange(0, b, 401)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], N, wl["costs"], cstrs, nthreads=8)
+    assert (ref["status"] == 0).all() and (r1["iter"][pick] == ref["iter"]).all()
+    assert _rel(r1["control"][pick], ref["control"]) <= RTOL and _rel(r1["trajectory"][pick], ref["trajectory"]) <= RTOL
