@@ -1365,7 +1365,7 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
         h->cost_p[cost_index] = p;
         return COPRA_OK;
     }
-    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.cost[cost_index].rows;
+    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.cost[cost_index].prows; // (a reference trajectory: rows x steps per instance)
     if (!h->d_cost_p[cost_index]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[cost_index], count * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_cost_p[cost_index], p, count * sizeof(double), hipMemcpyHostToDevice));
     h->cost_p[cost_index] = h->d_cost_p[cost_index];
@@ -1702,6 +1702,10 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     }
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
+        if (h->hp.plan.stage_refs) // (the model's dc/dp holds one column per cost row, not per row and step)
+            for (int t = 0; t < kMaxCosts; ++t)
+                if (h->cost_p[t] && h->hp.plan.cost[t].pstride)
+                    return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_solve: per-instance reference trajectories are not available in shared-model mode");
 
         hipStream_t s = (hipStream_t)hip_stream;
         h->last_stream = s;

@@ -43,7 +43,7 @@ namespace copra_hip {
 COPRA_DEV const double* cost_reference(const FusedPlan& P, int t, int inst)
 {
     const CostTerm& ct = P.cost[t];
-    return P.cost_p[t] ? P.cost_p[t] + (size_t)inst * ct.rows : P.params + ct.offP;
+    return P.cost_p[t] ? P.cost_p[t] + (size_t)inst * ct.prows : P.params + ct.offP;
 }
 
 // Which instance does workgroup w of a first tier solve?  Without the one-instance-per-lane pass in front (lmpc_lane.hpp): instance w.  Behind
@@ -669,7 +669,8 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                         Q[fidx<TRI_>(blk * nu + i2, lane, ld)] += acc;
                     }
                     double acc = 0.0;
-                    for (int k = 0; k < r; ++k) acc += ((-p[k]) * w[k]) * Nm[k + r * sub];
+                    for (int k = 0; k < r; ++k) // (reference trajectory: the reference of this lane's step)
+                        acc += ((-(ct.pstride ? (k < rc ? pref[blk * ct.pstride + k] : 0.0) : p[k])) * w[k]) * Nm[k + r * sub];
                     cj += acc;
                 }
                 continue;
@@ -691,7 +692,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                 const int k = e / r, row = e - k * r;
                 double acc = 0.0;
                 for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Xbar[k * nx + c];
-                We[e] = (acc - p[row]) * w[row];
+                We[e] = (acc - (ct.pstride ? (row < rc ? pref[k * ct.pstride + row] : 0.0) : p[row])) * w[row]; // (reference trajectory: p_k)
             }
             wave_sync();
             COPRA_FINE("cost:YWe");

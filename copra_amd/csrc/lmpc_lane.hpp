@@ -164,7 +164,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         const int li0 = valid ? inst : 0;
         for (int t = 0; t < P.ncost; ++t) {
             const int rows_t = P.cost[t].rows;
-            const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)li0 * rows_t : P.params + P.cost[t].offP;
+            const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)li0 * P.cost[t].prows : P.params + P.cost[t].offP;
             for (int r = 0; r < rows_t; ++r) {
                 const double pv_r = pr[r];
                 const int co = P.lane_cref + (t * 6 + r) * (NZ + NX);

@@ -168,7 +168,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             double acc = 0.0;
             for (int t = S.cls_crow0[c]; t < S.cls_crow0[c + 1]; ++t) {
                 const int ct = S.cr_cost[t];
-                const double pv = P.cost_p[ct] ? P.cost_p[ct][(size_t)inst * P.cost[ct].rows + S.cr_pidx[t]]
+                const double pv = P.cost_p[ct] ? P.cost_p[ct][(size_t)inst * P.cost[ct].prows + S.cr_pidx[t]]
                                                : P.params[P.cost[ct].offP + S.cr_pidx[t]];
                 acc -= S.cr_w[t] * pv * blob[S.cr_aoff[t] + i];
             }

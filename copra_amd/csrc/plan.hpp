@@ -74,6 +74,11 @@ struct CostTerm {
     int offP; // r
     int offW; // r
     int full; // 1: full-size entry (costFunctions.cpp:65-71, 141-146, 197-203) -> dense MFMA contraction
+    int pstride; // 0: one reference p for every step.  r (= rows): a REFERENCE TRAJECTORY -- the reference of step k sits at offP + k r.
+                 // (A full-size entry whose M / N is block-diagonal with identical blocks and identical weights per step -- the only way the
+                 // reference's API can express a reference that changes along the horizon, costFunctions.cpp:63-82, 139-156 -- is such a
+                 // per-step entry: plan_builder.hpp.)
+    int prows; // length of the whole reference: rows, or rows x steps with pstride (what a per-instance reference holds per instance)
     int ident; // 1: per-step entry whose M is the xDim x xDim identity (the usual "track the whole state" cost): the
                // products M G_k ARE the blocks G_k, bit for bit, so the cost phase reads G instead of forming them
 };
@@ -254,6 +259,8 @@ struct FusedPlan {
     const double* ric_model;
     double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)
+    int stage_refs; // 1: some cost follows a reference trajectory (CostTerm::pstride): only the kernels that evaluate costs step by step
+                    // with the reference of the step (lmpc_fused.hpp and its packed builds) take the controller
     // One-instance-per-LANE pass in front of the Riccati-factor tier (lmpc_lane.hpp): tables in `params` (-1: the controller is not
     // eligible): H | h | HN | hN | (N + 1) x lane_rps rows [E | G | f], offsets from lane_tab_offsets().  The pass appends every instance
     // it does not finish to lane_list (lane_count entries; lane_zero: the next solve's counter, zeroed on the way); the first tier

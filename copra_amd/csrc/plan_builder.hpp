@@ -352,7 +352,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_tlds = 0;
     P.lane_cref = -1;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
-    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
+    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave || P.stage_refs) return; // (nx: the lane's registers)
     std::vector<int> per_step((size_t)N + 1, 0);
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i], ek = hp.row_ekind[i], gk = hp.row_gkind[i];
@@ -494,7 +494,7 @@ inline bool take_ric_layout(HostPlan& hp)
     const int nx = P.nx, nu = P.nu, N = P.N;
     if (P.lds.ric) return true;
     if (hp.large || P.initial_state || !ric_shape_ok(nx, nu, N)) return false;
-    if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts) return false;
+    if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts || P.stage_refs) return false;
     for (int t = 0; t < P.ncost; ++t)
         if (P.cost[t].full) return false;
     for (int k = 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
@@ -586,6 +586,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = nullptr, P.model_ref_off[k] = -1;
     P.rmax = 1;
     P.rfull = 0;
+    P.stage_refs = 0;
     for (int k = 0; k < n_costs; ++k) {
         const copra_cost_desc_t& c = costs[k];
         CostTerm& t = P.cost[k];
@@ -631,6 +632,57 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             break;
         default:
             return hp.error = "unknown cost kind", COPRA_ERR_DOMAIN;
+        }
+        t.pstride = 0;
+        t.prows = c.rows;
+        // A REFERENCE TRAJECTORY: the reference's API can only express a reference that changes along the horizon as a full-size entry
+        // (costFunctions.cpp:63-82, 139-156): M = blkdiag(M0, .., M0) over the N + 1 states (N = blkdiag(N0, .., N0) over the N
+        // controls), the same weights in every block, p the stacked references.  That is a PER-STEP entry whose reference is that of
+        // the step -- the same sums over the same blocks in the same order, without the dense contraction of a full-size entry
+        // (lmpc_fused.hpp: 7.6 M solves/s at the headline shape).  One-wave LMPC controllers only; the kernels that do not evaluate
+        // costs step by step with the step's reference refuse such a controller (FusedPlan::stage_refs).
+        if (full && !is && U <= kWave && (c.kind == COPRA_COST_TRAJECTORY || c.kind == COPRA_COST_CONTROL) && !std::getenv("COPRA_NO_STAGE_REFS")) {
+            const bool traj = c.kind == COPRA_COST_TRAJECTORY;
+            const int S = traj ? N + 1 : N, cwd = traj ? nx : nu, R = c.rows;
+            const double* Mx = traj ? c.M : c.N; // column-major, R x (S cwd)
+            if (R % S == 0 && R / S <= 6) {
+                const int r = R / S;
+                bool ok = true;
+                for (int sblk = 0; sblk < S && ok; ++sblk)
+                    for (int i = 0; i < r && ok; ++i) {
+                        ok = c.weights[(size_t)sblk * r + i] == c.weights[i];
+                        for (int j = 0; j < S * cwd && ok; ++j) {
+                            const double v = Mx[(size_t)j * R + (size_t)sblk * r + i];
+                            const int jb = j / cwd, jc = j - jb * cwd;
+                            ok = v == (jb == sblk ? Mx[(size_t)jc * R + i] : 0.0);
+                        }
+                    }
+                if (ok) {
+                    std::vector<double> blk((size_t)r * cwd);
+                    for (int j = 0; j < cwd; ++j)
+                        for (int i = 0; i < r; ++i) blk[(size_t)i + (size_t)r * j] = Mx[(size_t)j * R + i];
+                    t.rows = r;
+                    t.full = 0;
+                    t.ident = 0;
+                    if (traj && r == nx) {
+                        bool id = true;
+                        for (int j = 0; j < nx && id; ++j)
+                            for (int i = 0; i < nx && id; ++i) id = blk[(size_t)j * nx + i] == ((i == j) ? 1.0 : 0.0);
+                        t.ident = id ? 1 : 0;
+                    }
+                    if (traj)
+                        t.offM = push(blk.data(), r * nx);
+                    else
+                        t.offN = push(blk.data(), r * nu);
+                    if (r > P.rmax) P.rmax = r;
+                    t.offP = push(c.p, R);
+                    t.offW = push(c.weights, r);
+                    t.pstride = r;
+                    t.prows = R;
+                    P.stage_refs = 1;
+                    continue;
+                }
+            }
         }
         t.full = full ? 1 : 0;
         t.ident = 0;
@@ -1096,7 +1148,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             && P.ncost <= kRicMaxCosts && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI");
         // (every other shape the body of that tier can be instantiated for gets there through copra_batch_specialise, which
         //  compiles the kernel and calls take_ric_layout)
-        for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full;
+        for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full && !P.cost[t].pstride;
         bool ric_taken = false;
         for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
@@ -1123,7 +1175,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             // Riccati form of the factor (lmpc_fused_ric.hpp): every cost a per-step entry, the headline instantiation
             bool ric_ok = qregs > 0 && nu == 3 && N == 20 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state && P.ncost <= kRicMaxCosts
                 && !std::getenv("COPRA_NO_RIC");
-            for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full;
+            for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full && !P.cost[t].pstride;
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen

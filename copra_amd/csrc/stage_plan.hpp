@@ -217,7 +217,7 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
             if (c.kind == kCostControl || c.kind == kCostMixed) k1 = N - 1; // :139-158, :195-215
             for (int k = k0; k <= k1; ++k)
                 for (int i = 0; i < c.rows; ++i) {
-                    CostRow r { std::vector<double>((size_t)nz, 0.0), prm[(size_t)c.offW + i], t, i };
+                    CostRow r { std::vector<double>((size_t)nz, 0.0), prm[(size_t)c.offW + i], t, (c.pstride ? k * c.pstride : 0) + i }; // (a reference trajectory: the reference of step k)
                     if (hasM && c.kind != kCostControl)
                         for (int j = 0; j < nx; ++j) r.a[(size_t)j] = prm[(size_t)c.offM + (size_t)j * c.rows + i];
                     if (hasN && (c.kind == kCostControl || c.kind == kCostMixed))

@@ -1063,3 +1063,46 @@ def test_full_size_rows_that_touch_one_step(emu, oracle, monkeypatch, kind):
     assert (rf["status"] == re["status"]).all() and (rf["iter"][ok] == re["iter"][ok]).all() and _rel(rf["control"][ok], re["control"][ok]) <= 1e-9
     if kind == "terminal_velocity":
         assert re["riccati_factor"] and re["lds_bytes"] < rf["lds_bytes"]  # (the compact variant of the headline's tier is kept)
+
+
+@pytest.mark.parametrize("specialised", [True, False])
+@pytest.mark.parametrize("what", ["state_reference", "state_and_control_reference"])
+def test_reference_trajectory_costs(emu, oracle, monkeypatch, specialised, what):
+    """a reference that changes along the horizon -- the reference's API can only express it as a FULL-SIZE entry, M = blkdiag(M0 .. M0),
+    stacked p (costFunctions.cpp:63-82) -- is classified as a per-step entry with the reference of the step (CostTerm::pstride) and runs on
+    the step-by-step cost phase instead of the dense contraction; against the oracle (which takes the full-size entry as it is) and
+    against the dense path (COPRA_NO_STAGE_REFS), with controller-wide and with per-instance reference trajectories"""
+    from copra_amd import workloads
+    b = 12
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=71)
+    N, nx, nu = wl["N"], 6, 3
+    rng = np.random.default_rng(9)
+    M0 = np.eye(6) if what == "state_reference" else np.eye(6)[:4] + 0.1 * rng.standard_normal((4, 6))
+    r = M0.shape[0]
+    Mf = np.kron(np.eye(N + 1), M0)
+    ts = np.linspace(0.0, 1.0, N + 1)
+    pos = workloads.COM_X_INIT[:3][None, :] + ts[:, None] * (workloads.COM_X_GOAL[:3] - workloads.COM_X_INIT[:3])[None, :]
+    xref = np.hstack([pos, 0.05 * np.ones((N + 1, 3))])  # a straight-line reference with a constant velocity
+    pf = (xref @ M0.T).reshape(-1)
+    wf = np.tile(np.array([10.0, 10.0, 10.0, 1.0, 1.0, 1.0])[:r], N + 1)
+    costs = [dict(kind="trajectory", M=Mf, p=pf, weights=wf)]
+    if what == "state_and_control_reference":
+        uref = 0.2 * np.sin(np.arange(N))[:, None] * np.ones((1, nu))
+        costs.append(dict(kind="control", N=np.kron(np.eye(N), np.eye(nu)), p=uref.reshape(-1), weights=np.full(nu * N, 1e-2)))
+    else:
+        costs.append(wl["costs"][1])
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, costs, wl["cstrs"])
+    re = emu.lmpc_solve(*args, specialised=specialised)
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    ok = ro["status"] == 0
+    assert ok.sum() >= b - 2 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-8 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-8
+    refs = {0: np.tile(pf, (b, 1)) + 0.02 * rng.standard_normal((b, pf.size))}  # every instance its own reference trajectory
+    re2 = emu.lmpc_solve(*args, specialised=specialised, cost_refs=refs)
+    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+    rd = emu.lmpc_solve(*args, specialised=specialised)
+    rd2 = emu.lmpc_solve(*args, specialised=specialised, cost_refs=refs)
+    assert (rd["status"] == re["status"]).all() and _rel(rd["control"][ok], re["control"][ok]) <= 1e-8
+    ok2 = rd2["status"] == 0
+    assert (rd2["status"] == re2["status"]).all() and ok2.sum() >= b - 3 and _rel(rd2["control"][ok2], re2["control"][ok2]) <= 1e-8
+    assert np.abs(re2["control"][ok2 & ok] - re["control"][ok2 & ok]).max() > 1e-4  # (the per-instance references did something)

@@ -1600,3 +1600,46 @@ def test_full_size_rows_that_touch_one_step(oracle, monkeypatch):
     ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], N, wl["costs"], cstrs, nthreads=8)
     assert (ref["status"] == 0).all() and (r1["iter"][pick] == ref["iter"]).all()
     assert _rel(r1["control"][pick], ref["control"]) <= RTOL and _rel(r1["trajectory"][pick], ref["trajectory"]) <= RTOL
+
+
+def test_reference_trajectory_costs(oracle, monkeypatch):
+    """a full-size TrajectoryCost / ControlCost with identical blocks and a stacked reference -- the reference's way to track a
+    reference TRAJECTORY -- runs as a per-step entry with the reference of the step (CostTerm::pstride); against the dense path
+    (COPRA_NO_STAGE_REFS), with per-instance reference trajectories, and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 8192
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=81)
+    N, nu = wl["N"], 3
+    rng = np.random.default_rng(4)
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    uref = 0.2 * np.sin(np.arange(N))[:, None] * np.ones((1, nu))
+    costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)),
+             dict(kind="control", N=np.kron(np.eye(N), np.eye(nu)), p=uref.reshape(-1), weights=np.full(nu * N, 1e-2))]
+    refs = np.tile(xref.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, 6 * (N + 1)))
+    out = {}
+    for mode in ("dense", "steps"):
+        monkeypatch.delenv("COPRA_NO_STAGE_REFS", raising=False)
+        if mode == "dense":
+            monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        ra = eng.results()
+        eng.set_cost_reference(0, refs)  # every instance its own reference trajectory
+        eng.solve()
+        out[mode] = (ra, eng.results(), eng.layout_info())
+        eng.close()
+    assert out["steps"][2]["lds_bytes"] < out["dense"][2]["lds_bytes"]
+    for which in (0, 1):
+        r0, r1 = out["dense"][which], out["steps"][which]
+        ok = r0["status"] == 0
+        assert ok.sum() > b // 2 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).all()
+        assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9
+    assert np.abs(out["steps"][1]["control"] - out["steps"][0]["control"]).max() > 1e-3
+    pick = np.arange(0, b, 331)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], N, costs, wl["cstrs"], nthreads=8)
+    okp = ref["status"] == 0
+    r1 = out["steps"][0]
+    assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
+    assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL

@@ -46,6 +46,7 @@ for b in 2048 8192 16384 24576 32768; do echo "batch $b"; COPRA_LANE_MIN_BATCH=1
 python tools/exp/lane_threshold.py 2>&1 | grep -v amdgpu.ids > $R/lane_threshold.txt || true
 python tools/exp/selection_rows.py 2>&1 | grep -v amdgpu.ids > $R/selection_rows.txt || true
 python tools/exp/terminal_rows.py 2>&1 | grep -v amdgpu.ids > $R/terminal_rows.txt || true
+python tools/exp/reference_trajectory.py 2>&1 | grep -v amdgpu.ids > $R/reference_trajectory.txt || true
 # ---- probes and side measurements ----
 tools/exp/mfma_chain_probe > $R/mfma_chain_probe.txt 2>&1 || true
 python tools/pcie_probe.py 2>&1 | grep -v amdgpu.ids > $R/pcie_probe.txt
