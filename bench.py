@@ -253,7 +253,11 @@ def extra_measurements(np, torch, dev):
     wl = workloads.com_preview(b)
     c0 = wl["costs"][0]
     dense_costs = [autospan_cost(dict(c0, p=np.tile(c0["p"], wl["N"] + 1))), wl["costs"][1]]
+    # (such a block-diagonal entry is what the plan builder recognises as a per-step cost with the reference of the step -- see the next
+    #  entry; this one measures the dense contraction itself, so the classification is switched off while its plan is built)
+    os.environ["COPRA_NO_STAGE_REFS"] = "1"
     eng = BatchLMPC(6, 3, wl["N"], b, dense_costs, wl["cstrs"])
+    os.environ.pop("COPRA_NO_STAGE_REFS", None)
     t = on_device(wl)
     eng.set_system(*t)
     rate, sec = timed_rate(eng, b, reps=3)
@@ -261,6 +265,19 @@ def extra_measurements(np, torch, dev):
         "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3,
         "mfma_flops_per_solve": 976 * 2048,  # 976 v_mfma_f64_16x16x4 per solve (profiles/r02/pmc_dense_mfma_path.json)
         "executed_mfma_tflops": 976 * 2048 * rate / 1e12}
+    eng.close()
+    # the same full-size entry as the plan builder takes it by default: a REFERENCE TRAJECTORY (here a straight line from x_init to x_goal)
+    # -- a per-step cost with the reference of the step, on the factor-only tier
+    ts_ref = np.linspace(0.0, 1.0, wl["N"] + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts_ref[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    track_costs = [autospan_cost(dict(c0, p=xref.reshape(-1))), wl["costs"][1]]
+    eng = BatchLMPC(6, 3, wl["N"], b, track_costs, wl["cstrs"])
+    eng.set_system(*t)
+    rate, sec = timed_rate(eng, b, reps=3)
+    out["reference_trajectory_tracking_batch65536"] = {
+        "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3,
+        "what": "TrajectoryCost as a full-size entry with a reference that changes along the horizon (the only form the reference's API has "
+                "for it), recognised as a per-step cost with the reference of the step"}
     eng.close()
     # host-inclusive: numpy inputs -> layout conversion -> pageable H2D -> solve -> D2H of U, X, status
     wl = workloads.com_preview(b)
@@ -390,6 +407,7 @@ def main():
                          "TrajectoryBound(63 rows)+ControlBound (BASELINE configs[2])")
     if args.dense_hessian:
         from copra_amd.autospan import autospan_cost
+        os.environ["COPRA_NO_STAGE_REFS"] = "1"  # (measure the dense contraction, not the per-step form the plan builder would recognise)
         c0 = wl["costs"][0]
         wl["costs"] = [autospan_cost(dict(c0, p=np.tile(c0["p"], N + 1))), wl["costs"][1]]
     Ab, Bb, db, xb = to_abi_layout(wl["A"], wl["B"], wl["d"], wl["x0"])

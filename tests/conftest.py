@@ -32,3 +32,13 @@ def pytest_collection_modifyitems(config, items):
             torch.cuda.init()
     except Exception:  # no torch / no GPU: the tests that need them say so themselves
         pass
+
+
+@pytest.fixture
+def full_size_paths(monkeypatch):
+    """the plan builder classifies full-size entries with a per-step structure (block-diagonal costs with repeating blocks: reference
+    trajectories; constraint rows inside one step) as per-step entries.  Tests that are ABOUT the full-size machinery -- the dense
+    Psi' W Psi contraction on the matrix cores, the full-row slack evaluation -- build their inputs with AutoSpan, which produces exactly
+    that structure: they switch the classification off, so that they keep covering what they were written for."""
+    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+    monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")

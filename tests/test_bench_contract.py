@@ -45,7 +45,8 @@ def test_extra_measurements_outside_the_timed_region():
     for key in ("config2_double_integrator_batch4096", "config5_initial_state_12_6_50_riccati_ipm",
                 "config5_initial_state_12_6_50_quadprog_dense", "shared_model_tick_batch65536",
                 "tight_workload_vmax0.25_umax1.2", "host_inclusive_numpy_in_numpy_out", "host_inclusive_pinned_pipelined",
-                "dense_hessian_mfma_f64_16x16x4_batch65536", "single_problem_latency_cpp_mirror"):
+                "dense_hessian_mfma_f64_16x16x4_batch65536", "reference_trajectory_tracking_batch65536",
+                "single_problem_latency_cpp_mirror"):
         assert "error" not in ex[key], (key, ex[key])
         assert ex[key]["solves_per_s"] > 0, key
     assert ex["single_problem_latency_cpp_mirror"]["median_us"] > 0 and out["cold_clock_ms_per_step"] > 0

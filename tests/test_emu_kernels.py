@@ -322,7 +322,7 @@ def test_all_nine_classes_at_once(emu, oracle, full_size):
     _compare(emu, oracle, pb["A"], pb["B"], pb["d"], pb["x0"], pb["N"], pb["costs"], pb["cstrs"])
 
 
-def test_full_size_constraint_entries(emu, oracle):
+def test_full_size_constraint_entries(emu, oracle, full_size_paths):
     """full-size (autoSpan'ed) constraint entries run on the fused path: E (R x fullXDim), G (R x fullUDim)"""
     from copra_amd.autospan import autospan_cstr
     pb = F.ineq_system("target", N=12)
@@ -454,7 +454,7 @@ def test_large_full_size_constraint_rows(emu, oracle, initial_state):
 
 
 @pytest.mark.parametrize("initial_state", [False, True])
-def test_large_full_size_cost_entries(emu, oracle, initial_state):
+def test_large_full_size_cost_entries(emu, oracle, initial_state, full_size_paths):
     """Full-size COST entries (time-varying references: p and weights of size r (N+1), M spanned by autoSpan) with
     more than 64 variables: rank-4 updates of the Hessian in the HBM workspace (lmpc_large.hpp)"""
     from copra_amd.autospan import autospan_cost
@@ -637,7 +637,7 @@ def test_two_tier_execution_overflow_queue(emu, oracle):
     assert ok.any() and _rel(re["control"][ok], ro["control"][ok]) <= RTOL
 
 
-def test_dense_mfma_hessian_equals_structured_path(emu, oracle):
+def test_dense_mfma_hessian_equals_structured_path(emu, oracle, full_size_paths):
     """The headline TrajectoryCost handed over as a full-size entry (M = blockdiag, 126 x 126) must give the same QP
     as the per-step entry: dense v_mfma_f64_16x16x4 contraction vs block-diagonal prefix sums vs the oracle."""
     from copra_amd import workloads

@@ -213,7 +213,7 @@ def test_reference_fixtures_on_the_generic_kernel(oracle, system, xcost):
     assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
 
 
-def test_all_nine_classes_and_full_size_constraints(oracle):
+def test_all_nine_classes_and_full_size_constraints(oracle, full_size_paths):
     import fixtures as F
     from copra_amd import BatchLMPC
     from copra_amd.autospan import autospan_cstr
@@ -331,7 +331,7 @@ def test_factor_only_layout_steps_down_its_ladder(oracle):
     assert seen == sorted(seen)
 
 
-def test_full_size_cost_entries_mfma_contraction(oracle):
+def test_full_size_cost_entries_mfma_contraction(oracle, full_size_paths):
     """Full-size cost entries (costFunctions.cpp:65-71,141-146,197-203) run the dense Psi' W Psi contraction on
     v_mfma_f64_16x16x4_f64: (a) all nine classes with autoSpan'ed full-size entries (TestLMPC_InitialState.cpp,
     fullSizeEntry = true), (b) the headline cost as a 126 x 126 full-size entry vs the structured path."""
@@ -598,7 +598,7 @@ def test_config5_full_batch_default_solver():
 
 @pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("initial_state", [False, True])
-def test_full_size_cost_entries_long_horizon(oracle, initial_state, solver):
+def test_full_size_cost_entries_long_horizon(oracle, initial_state, solver, full_size_paths):
     """Full-size cost entries (time-varying reference and weights over the horizon) with 150 decision variables: the
     workgroup-per-instance kernel's rank-4 Hessian updates vs the oracle"""
     import fixtures as F
