@@ -91,10 +91,10 @@ __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const Fused
 }
 // One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
 // instance; those that violate nothing are finished here.  One wave per SIMD: the lane's matrices live in up to 512 registers.
-template <int NX, int NU>
+template <int NX, int NU, bool SREFS = false>
 __global__ __launch_bounds__(64, 1) void copra_lmpc_lane_kernel(const FusedPlan P)
 {
-    lmpc_lane_body<NX, NU>(P, (int)blockIdx.x);
+    lmpc_lane_body<NX, NU, SREFS>(P, (int)blockIdx.x);
 }
 // ... and its shared-model form: the stage records are those of the whole batch (wave-uniform: scalar operands), only the roll-out
 // from each instance's x0 is left
@@ -542,8 +542,8 @@ static hipError_t begin_overflow_queue(copra_batch* h, hipStream_t s, bool self_
 // ---- the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp) ----
 static fused_kernel_t select_lane_kernel(const FusedPlan& P)
 {
-    if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_kernel<6, 3>;
-    if (P.nx == 2 && P.nu == 1) return copra_lmpc_lane_kernel<2, 1>; // (the reference's falling-mass system: BASELINE configs[1])
+    if (P.nx == 6 && P.nu == 3) return P.stage_refs ? copra_lmpc_lane_kernel<6, 3, true> : copra_lmpc_lane_kernel<6, 3>; // (reference trajectories)
+    if (P.nx == 2 && P.nu == 1) return P.stage_refs ? copra_lmpc_lane_kernel<2, 1, true> : copra_lmpc_lane_kernel<2, 1>; // (the reference's falling-mass system: BASELINE configs[1])
     return nullptr;
 }
 static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
@@ -578,6 +578,7 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
     if (P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || h->hp.large || P.initial_state) return false;
     for (int t = 0; t < kMaxCosts; ++t)
         if (h->cost_p[t] && P.lane_cref < 0) return false; // (per-instance references: the pass rebuilds its affine terms per lane)
+    if (P.stage_refs && P.lane_cref < 0) return false; // (reference trajectories: ... per lane and stage)
     return (jit_launch ? h->jit_lane != nullptr : select_lane_kernel(P) != nullptr);
 }
 static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
@@ -1555,7 +1556,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {
             char keyr[128], srcr[3072];
-            snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d", P.nx, P.nu, P.N);
+            snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d%s", P.nx, P.nu, P.N, P.stage_refs ? "_srefs" : "");
             snprintf(srcr, sizeof srcr,
                 "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\n#include \"lmpc_lane.hpp\"\nusing namespace copra_hip;\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
@@ -1567,8 +1568,8 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
                 "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
                 "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
-                "{ lmpc_lane_body<%d, %d>(P, (int)blockIdx.x); }\n",
-                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N, P.nx, P.nu);
+                "{ lmpc_lane_body<%d, %d, %s>(P, (int)blockIdx.x); }\n",
+                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N, P.nx, P.nu, P.stage_refs ? "true" : "false");
             std::string objr;
             const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
             if (rcr != COPRA_OK) return rcr;

@@ -178,7 +178,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             const bool live = t < P.ncost;
             const int tt = live ? t : 0;
             const int rc = P.cost[tt].rows;
-            const double* pref = cost_reference(P, tt, inst);
+            // (a reference trajectory, CostTerm::pstride: the terminal lanes take the reference of the last step here, the affine terms of the
+            //  stages are formed per stage below)
+            const double* pref = cost_reference(P, tt, inst) + (P.cost[tt].pstride ? P.cost[tt].prows - P.cost[tt].pstride : 0);
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
                 cw[t][r] = tab[kWave * (2 + tt * RP + r) + lane];
@@ -196,7 +198,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             aff += (t < P.ncost) ? at : 0.0;
         }
         // (no lane owns an affine entry of the stage AND one of the terminal cost: the table holds whichever it has)
-        hreg += aff_lane ? aff : 0.0;
+        hreg += (aff_lane && !P.stage_refs) ? aff : 0.0;
         term += (tj == NX) ? aff : 0.0;
         if (tj < NX)
             Pm[lane] = term;
@@ -208,6 +210,32 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     if (lane < NX) {
         D[lane] = sysD;
         X0[lane] = sysX;
+    }
+    // Reference trajectories (FusedPlan::stage_refs): the affine term of the stage cost changes along the horizon,
+    //     h_k(a) = sum_t sum_r c_t(r, a) p_t[k r_t + r]     (c_t: the coefficients of the affine lanes in the table above),
+    // NH NZ values, each formed once: entry a of stage k waits in the place of record k (where Acl_k goes at the END of stage k of the
+    // sweep, which reads it at its start).
+    if (P.stage_refs) {
+        const double* tab = P.params + P.ric_tab;
+        for (int e = lane; e < NH * NZ; e += kWave) {
+            const int k = e / NZ, a = e - k * NZ;
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < kRicMaxCosts; ++t) {
+                const bool live = t < P.ncost;
+                const int tt = live ? t : 0;
+                const CostTerm& ct = P.cost[tt];
+                const int rc = ct.rows, ps = ct.pstride;
+                const int kk = (ps && (k + 1) * ps > ct.prows) ? ct.prows / ps - 1 : k; // (a cost without a step k has zero coefficients there)
+                const double* pref = cost_reference(P, tt, inst) + kk * ps;
+                double at = 0.0;
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
+                    at += tab[kWave * (2 + tt * RP + r) + nxx + nux + nuu + a] * pref[r < rc ? r : (rc > 0 ? rc - 1 : 0)];
+                acc += live ? at : 0.0;
+            }
+            F[k * RR::SZ + RR::oAcl + a] = acc;
+        }
     }
     COPRA_FINE("ric:costs");
     // ---- 1. preview: [G_s | xbar_s] = A [G_{s-1} | xbar_{s-1}] + [0 | d]  (G_0 = B, xbar_0 = x0; PreviewSystem.cpp:57-74
@@ -365,10 +393,29 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             const int e4 = pr == 0 ? 5 : pr == 1 ? 8 : pr == 2 ? 4 : pr == 4 ? 2 : pr == 5 ? 5 : 1;
             adj1 = Mu2 + e1, adj2 = Mu2 + e2, adj3 = Mu2 + e3, adj4 = Mu2 + e4;
         }
+        // reference trajectories: the affine column of Hin of stage k, from the place of record k (see above); everybody else reads a zero
+        const bool srefs = P.stage_refs != 0;
+        const double* hkp[3];
+        int hkst[3];
+#pragma unroll
+        for (int I = 0; I < 3; ++I) {
+            const int sr = 4 * I + q, a = sr < NU ? NX + sr : (sr >= 4 && sr < 4 + NX) ? sr - 4 : -1; // stacked row -> index in z = (x, u)
+            const bool on = srefs && col_aff && a >= 0;
+            hkp[I] = on ? F + (NH - 1) * RR::SZ + RR::oAcl + a : Zs;
+            hkst[I] = on ? RR::SZ : 0;
+        }
         bool bad = false;
         wave_sync();
         for (int k = NH - 1; k >= 0; --k) {
             double* Fk = F + k * RR::SZ;
+            double Hk[3] = { Hacc[0], Hacc[1], Hacc[2] };
+            if (srefs) {
+#pragma unroll
+                for (int I = 0; I < 3; ++I) {
+                    Hk[I] += *hkp[I];
+                    hkp[I] -= hkst[I];
+                }
+            }
             if (!compact) { // preview step s = NH - k
                 const int s = NH - k;
                 double n0 = mfma_f64_4x4x4(pa[0][0], px[0], pc[0]);
@@ -404,9 +451,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 bK[2] = ride ? T2 : bK[2];
             }
             // M_I = Hin_I + [B A]'_{I,.} T
-            double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hacc[0]);
-            double M1 = mfma_f64_4x4x4(aM[1][1], T1, Hacc[1]);
-            double M2 = mfma_f64_4x4x4(aM[2][1], T1, Hacc[2]);
+            double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hk[0]);
+            double M1 = mfma_f64_4x4x4(aM[1][1], T1, Hk[1]);
+            double M2 = mfma_f64_4x4x4(aM[2][1], T1, Hk[2]);
             if (NX > 4) {
                 M0 = mfma_f64_4x4x4(aM[0][2], T2, M0);
                 M1 = mfma_f64_4x4x4(aM[1][2], T2, M1);

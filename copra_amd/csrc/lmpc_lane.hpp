@@ -91,7 +91,9 @@ COPRA_DEV double lane_get(const double* row, unsigned byte_off)
 // (streaming: a store that does not claim cache space -- what is written once and read, if at all, by a later kernel; measured: 226 -> 220 us
 //  for the pass when Lam^-1 and the norm sums leave this way, no difference for U and X)
 
-template <int NX, int NU>
+// SREFS: the build for controllers with reference trajectories (FusedPlan::stage_refs) -- its own instantiation, so that the registers of
+// stage_h below are not the headline's (measured on the one build for both: 3 VGPRs of the sweep in scratch memory)
+template <int NX, int NU, bool SREFS = false>
 COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 {
     constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 2; // (a row of the table: E | G | f | its index)
@@ -156,15 +158,19 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double hl[NZ]; // (the sweep reads h from this lane's slot of the staging area either way: no branch per use in its loop)
 #pragma unroll
     for (int a = 0; a < NZ; ++a) hl[a] = uniform_load(tab, oh + a);
-    if (own_refs) {
+    // Reference TRAJECTORIES (FusedPlan::stage_refs, CostTerm::pstride): the reference changes along the horizon, h is rebuilt the same way
+    // before every stage of the sweep (stage_h below); the terminal term takes the reference of the last step.
+    constexpr bool srefs = SREFS;
+    const int li0 = valid ? inst : 0;
+    if (own_refs || srefs) {
 #pragma unroll
         for (int a = 0; a < NZ; ++a) hl[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) hNl[i] = 0.0;
-        const int li0 = valid ? inst : 0;
         for (int t = 0; t < P.ncost; ++t) {
             const int rows_t = P.cost[t].rows;
-            const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)li0 * P.cost[t].prows : P.params + P.cost[t].offP;
+            const double* const pr = (P.cost_p[t] ? P.cost_p[t] + (size_t)li0 * P.cost[t].prows : P.params + P.cost[t].offP)
+                + (P.cost[t].pstride ? P.cost[t].prows - P.cost[t].pstride : 0);
             for (int r = 0; r < rows_t; ++r) {
                 const double pv_r = pr[r];
                 const int co = P.lane_cref + (t * 6 + r) * (NZ + NX);
@@ -192,8 +198,39 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     auto Ps = [&](int i, int l) -> double { return i <= l ? Pm[i + NX * l] : Pm[l + NX * i]; };
 #pragma unroll
     for (int i = 0; i < NX; ++i) pv[i] = hNl[i];
+    // h of stage k into this lane's slot (reference trajectories): every load of the stage is issued before the first is used
+    auto stage_h = [&](int k) {
+        double pvk[kRicMaxCosts][6];
+#pragma unroll
+        for (int t = 0; t < kRicMaxCosts; ++t) {
+            const int tt = t < P.ncost ? t : 0;
+            const CostTerm& ct = P.cost[tt];
+            const int ps = ct.pstride, rc = ct.rows;
+            const int kk = (ps && (k + 1) * ps > ct.prows) ? ct.prows / ps - 1 : k; // (a cost without a step k: zero coefficients)
+            const double* const pr = (P.cost_p[tt] ? P.cost_p[tt] + (size_t)li0 * ct.prows : P.params + ct.offP) + kk * ps;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) pvk[t][r] = pr[r < rc ? r : (rc > 0 ? rc - 1 : 0)]; // (rows past the term's: zero coefficients)
+        }
+        double hk[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) hk[a] = 0.0;
+#pragma unroll
+        for (int t = 0; t < kRicMaxCosts; ++t) {
+            if (t < P.ncost) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const int co = P.lane_cref + (t * 6 + r) * (NZ + NX);
+#pragma unroll
+                    for (int a = 0; a < NZ; ++a) hk[a] += uniform_load(tab, co + a) * pvk[t][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hk[a];
+    };
     bool bad = false;
     for (int k = NH - 1; k >= 0; --k) {
+        if constexpr (SREFS) stage_h(k);
         int hoff = oHl_;
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(hoff)); // (opaque per stage: the reads stay inside the loop -- hoisted, they would cost 180 registers)

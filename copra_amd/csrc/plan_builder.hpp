@@ -352,7 +352,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_tlds = 0;
     P.lane_cref = -1;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
-    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave || P.stage_refs) return; // (nx: the lane's registers)
+    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
     std::vector<int> per_step((size_t)N + 1, 0);
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i], ek = hp.row_ekind[i], gk = hp.row_gkind[i];
@@ -494,7 +494,7 @@ inline bool take_ric_layout(HostPlan& hp)
     const int nx = P.nx, nu = P.nu, N = P.N;
     if (P.lds.ric) return true;
     if (hp.large || P.initial_state || !ric_shape_ok(nx, nu, N)) return false;
-    if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts || P.stage_refs) return false;
+    if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts) return false;
     for (int t = 0; t < P.ncost; ++t)
         if (P.cost[t].full) return false;
     for (int k = 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
@@ -1148,7 +1148,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             && P.ncost <= kRicMaxCosts && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI");
         // (every other shape the body of that tier can be instantiated for gets there through copra_batch_specialise, which
         //  compiles the kernel and calls take_ric_layout)
-        for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full && !P.cost[t].pstride;
+        for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full;
         bool ric_taken = false;
         for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
@@ -1175,7 +1175,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             // Riccati form of the factor (lmpc_fused_ric.hpp): every cost a per-step entry, the headline instantiation
             bool ric_ok = qregs > 0 && nu == 3 && N == 20 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state && P.ncost <= kRicMaxCosts
                 && !std::getenv("COPRA_NO_RIC");
-            for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full && !P.cost[t].pstride;
+            for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full;
             for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen

@@ -302,10 +302,10 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             int oHl = 0;
             const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
             int r = emu::run_wave([&]() {
-                if (P.nx == 6) lmpc_lane_body<6, 3>(P, g);
-                else if (P.nx == 4) lmpc_lane_body<4, 2>(P, g);
-                else if (P.nx == 5) lmpc_lane_body<5, 3>(P, g);
-                else lmpc_lane_body<2, 1>(P, g);
+                if (P.nx == 6) P.stage_refs ? lmpc_lane_body<6, 3, true>(P, g) : lmpc_lane_body<6, 3>(P, g);
+                else if (P.nx == 4) P.stage_refs ? lmpc_lane_body<4, 2, true>(P, g) : lmpc_lane_body<4, 2>(P, g);
+                else if (P.nx == 5) P.stage_refs ? lmpc_lane_body<5, 3, true>(P, g) : lmpc_lane_body<5, 3>(P, g);
+                else P.stage_refs ? lmpc_lane_body<2, 1, true>(P, g) : lmpc_lane_body<2, 1>(P, g);
             }, lbytes, g, groups);
             if (r != 0) return -100;
         }

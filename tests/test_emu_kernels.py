@@ -1106,3 +1106,66 @@ def test_reference_trajectory_costs(emu, oracle, monkeypatch, specialised, what)
     ok2 = rd2["status"] == 0
     assert (rd2["status"] == re2["status"]).all() and ok2.sum() >= b - 3 and _rel(rd2["control"][ok2], re2["control"][ok2]) <= 1e-8
     assert np.abs(re2["control"][ok2 & ok] - re["control"][ok2 & ok]).max() > 1e-4  # (the per-instance references did something)
+
+
+@pytest.mark.parametrize("mode", ["lane_pass_and_handover", "own_sweep", "lane_pass_filter_only"])
+def test_reference_trajectory_on_the_riccati_factor_tier(emu, oracle, monkeypatch, mode):
+    """reference trajectories keep the headline's kernels: the affine term of the stage cost, h_k = -sum_t [M N]_t' W_t p_t[k], changes
+    along the horizon -- rebuilt per stage by the one-instance-per-lane pass (lmpc_lane.hpp: stage_h), formed once per instance by the
+    tier's own sweep (lmpc_fused_ric.hpp, in the place of record k) -- with controller-wide and per-instance references, a state reference
+    alone and together with a control reference"""
+    from copra_amd import workloads
+    b = 70
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=71)
+    N, nu = wl["N"], 3
+    rng = np.random.default_rng(9)
+    ts = np.linspace(0.0, 1.0, N + 1)
+    pos = workloads.COM_X_INIT[:3][None, :] + ts[:, None] * (workloads.COM_X_GOAL[:3] - workloads.COM_X_INIT[:3])[None, :]
+    xref = np.hstack([pos, 0.05 * np.ones((N + 1, 3))])
+    pf = xref.reshape(-1)
+    uref = 0.2 * np.sin(np.arange(N))[:, None] * np.ones((1, nu))
+    track = dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=pf, weights=np.tile([10.0, 10.0, 10.0, 1.0, 1.0, 1.0], N + 1))
+    if mode == "own_sweep":
+        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+    if mode == "lane_pass_filter_only":
+        monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+    for second in (wl["costs"][1], dict(kind="control", N=np.kron(np.eye(N), np.eye(nu)), p=uref.reshape(-1), weights=np.full(nu * N, 1e-2))):
+        args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, [track, second], wl["cstrs"])
+        ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+        ok = ro["status"] == 0
+        re = emu.lmpc_solve(*args)
+        assert re["riccati_factor"] and (re["lane_pass_finished"] > 0) == (mode != "own_sweep")
+        assert ok.sum() >= b - 4 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+        assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+        refs = {0: np.tile(pf, (b, 1)) + 0.02 * rng.standard_normal((b, pf.size))}  # every instance its own reference trajectory
+        re2 = emu.lmpc_solve(*args, cost_refs=refs)
+        monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+        rd2 = emu.lmpc_solve(*args, cost_refs=refs)  # (the full-size entry as it is: dense contraction)
+        monkeypatch.delenv("COPRA_NO_STAGE_REFS")
+        ok2 = rd2["status"] == 0
+        assert re2["riccati_factor"] and not rd2["riccati_factor"]
+        assert ok2.sum() >= b - 6 and (re2["status"] == rd2["status"]).all() and (re2["iter"][ok2] == rd2["iter"][ok2]).all()
+        assert _rel(re2["control"][ok2], rd2["control"][ok2]) <= 1e-9
+        assert np.abs(re2["control"][ok2 & ok] - re["control"][ok2 & ok]).max() > 1e-4
+
+
+def test_reference_trajectory_shared_model(emu, oracle, monkeypatch):
+    """one model, one reference trajectory, a batch of measured states: the prepare run of the shared-model mode does the sweep with the
+    stage-varying affine term once, the lane pass and the tier read its records"""
+    from copra_amd import workloads
+    b = 70
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=23)
+    A, B, d, N = wl["A"][3], wl["B"][3], wl["d"][3], wl["N"]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10.0, 10.0, 1.0, 1.0, 1.0], N + 1)),
+             wl["costs"][1]]
+    ro = oracle.lmpc_solve_batch(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), wl["x0"], N, costs, wl["cstrs"], nthreads=8)
+    ok = ro["status"] == 0
+    for no_pass in (False, True):
+        if no_pass:
+            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        re = emu.lmpc_solve_shared(A, B, d, wl["x0"], N, costs, wl["cstrs"])
+        assert re["riccati_factor"] and ok.sum() >= b - 4 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+        assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+        assert (re["lane_pass_finished"] > 0) == (not no_pass)

@@ -1602,12 +1602,14 @@ def test_full_size_rows_that_touch_one_step(oracle, monkeypatch):
     assert _rel(r1["control"][pick], ref["control"]) <= RTOL and _rel(r1["trajectory"][pick], ref["trajectory"]) <= RTOL
 
 
-def test_reference_trajectory_costs(oracle, monkeypatch):
+@pytest.mark.parametrize("b", [8192, 24576])
+def test_reference_trajectory_costs(oracle, monkeypatch, b):
     """a full-size TrajectoryCost / ControlCost with identical blocks and a stacked reference -- the reference's way to track a
-    reference TRAJECTORY -- runs as a per-step entry with the reference of the step (CostTerm::pstride); against the dense path
-    (COPRA_NO_STAGE_REFS), with per-instance reference trajectories, and a sample against the oracle"""
+    reference TRAJECTORY -- runs as a per-step entry with the reference of the step (CostTerm::pstride) on the Riccati-factor tier, whose
+    affine term h_k then changes along the horizon: in the tier's own sweep (batch 8192) and in the one-instance-per-lane pass in front
+    of it (batch 24576); against the dense path (COPRA_NO_STAGE_REFS), with per-instance reference trajectories, and a sample against
+    the oracle"""
     from copra_amd import BatchLMPC, workloads
-    b = 8192
     wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=81)
     N, nu = wl["N"], 3
     rng = np.random.default_rng(4)
@@ -1628,9 +1630,12 @@ def test_reference_trajectory_costs(oracle, monkeypatch):
         ra = eng.results()
         eng.set_cost_reference(0, refs)  # every instance its own reference trajectory
         eng.solve()
-        out[mode] = (ra, eng.results(), eng.layout_info())
+        out[mode] = (ra, eng.results(), eng.layout_info(), eng.lane_pass_info())
         eng.close()
     assert out["steps"][2]["lds_bytes"] < out["dense"][2]["lds_bytes"]
+    assert out["steps"][3][0] == (b >= 20480) and not out["dense"][3][0]  # (the pass in front runs from 20480 instances)
+    if b >= 20480:
+        assert 0 < out["steps"][3][1] < b
     for which in (0, 1):
         r0, r1 = out["dense"][which], out["steps"][which]
         ok = r0["status"] == 0
@@ -1643,3 +1648,74 @@ def test_reference_trajectory_costs(oracle, monkeypatch):
     r1 = out["steps"][0]
     assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
     assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL
+
+
+@pytest.mark.gpu
+def test_reference_trajectory_shared_model_tick(oracle):
+    """one model and one reference trajectory for the whole batch (copra_batch_set_shared_system): the prepare launch runs the sweep with
+    the stage-varying affine term once, the lane pass and the tier read its records; two reference trajectories, a tick with new states
+    each; samples against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 32768
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=14)
+    A, B, d, N = wl["A"][7], wl["B"][7], wl["d"][7], wl["N"]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    pick = np.arange(0, b, 509)
+    tile = lambda M: np.tile(M, (len(pick),) + (1,) * M.ndim)
+    res = []
+    for xr in (xref, xref + 0.02 * np.sin(3.0 * ts)[:, None]):
+        costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xr.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)),
+                 wl["costs"][1]]
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_shared_system(A, B, d)
+        eng.set_x0(wl["x0"][::-1].copy())
+        eng.solve()
+        eng.set_x0(wl["x0"])  # (the tick: new states, same model)
+        eng.solve()
+        r = eng.results()
+        assert eng.lane_pass_info()[0]
+        eng.close()
+        ref = oracle.lmpc_solve_batch(tile(A), tile(B), tile(d), wl["x0"][pick], N, costs, wl["cstrs"], nthreads=8)
+        okp = ref["status"] == 0
+        assert okp.sum() > len(pick) // 2 and (r["status"][pick] == ref["status"]).all() and (r["iter"][pick][okp] == ref["iter"][okp]).all()
+        assert _rel(r["control"][pick][okp], ref["control"][okp]) <= RTOL
+        res.append(r)
+    assert np.abs(res[1]["control"] - res[0]["control"]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_reference_trajectory_compiled_shape(oracle, tmp_path):
+    """reference trajectories on a shape the library holds no instantiation for: copra_batch_specialise compiles the Riccati-factor tier
+    AND the one-instance-per-lane pass (its reference-trajectory build) for (4, 2, 16); a circle to follow, every instance its own phase
+    (per-instance reference trajectories), at a batch the pass runs on; against the oracle before (library kernels) and after"""
+    from copra_amd import BatchLMPC
+    b, N = 24576, 16
+    wl = _planar_integrator(b, N, v_max=0.6)
+    rng = np.random.default_rng(12)
+    ang = 0.15 * np.arange(N + 1)[None, :] + rng.uniform(0, 0.5, (b, 1))
+    xref = np.stack([0.3 * np.cos(ang), 0.3 * np.sin(ang), -0.3 * 1.5 * np.sin(ang), 0.3 * 1.5 * np.cos(ang)], axis=2)  # (b, N + 1, 4)
+    costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(4)), p=xref[0].reshape(-1), weights=np.tile([10.0, 7, 1, 1.5], N + 1)),
+             wl["costs"][1]]
+    eng = BatchLMPC(4, 2, N, b, costs, wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.set_cost_reference(0, xref.reshape(b, -1))
+    pick = np.arange(0, b, 97)
+    ref = {"status": [], "iter": [], "control": []}
+    for i in pick:  # (the CPU path takes one reference per call)
+        ci = [dict(costs[0], p=xref[i].reshape(-1)), costs[1]]
+        r = oracle.lmpc_solve(wl["A"][i], wl["B"][i], wl["d"][i], wl["x0"][i], N, ci, wl["cstrs"])
+        ref["status"].append(r["status"]), ref["iter"].append(r["iter"]), ref["control"].append(r["control"])
+    ref = {k: np.array(v) for k, v in ref.items()}
+    okp = ref["status"] == 0
+    assert okp.sum() > len(pick) // 2
+    for compiled in (False, True):
+        if compiled:
+            eng.specialise(str(tmp_path))
+            assert eng.layout_info()["factor_only"]
+        eng.solve()
+        res = eng.results()
+        assert (res["status"][pick] == ref["status"]).all() and (res["iter"][pick][okp].reshape(ref["iter"][okp].shape) == ref["iter"][okp]).all()
+        assert _rel(res["control"][pick][okp], ref["control"][okp]) <= RTOL
+    assert eng.lane_pass_info()[0]
+    eng.close()

@@ -16,23 +16,27 @@ ts = np.linspace(0.0, 1.0, N + 1)
 xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
 costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)), wl["costs"][1]]
 out = {}
-for mode in ("dense contraction", "per-step with p_k"):
-    if mode == "dense contraction":
-        os.environ["COPRA_NO_STAGE_REFS"] = "1"
-    else:
-        os.environ.pop("COPRA_NO_STAGE_REFS", None)
+MODES = {"dense contraction": {"COPRA_NO_STAGE_REFS": "1"}, "per-step, factor-only tier": {"COPRA_NO_RIC": "1"},
+         "per-step, tier's own sweep": {"COPRA_NO_LANE_PASS": "1"}, "per-step with p_k": {}, "own reference per instance": {}}
+rng = np.random.default_rng(4)
+for mode, env in MODES.items():
+    for k in ("COPRA_NO_STAGE_REFS", "COPRA_NO_RIC", "COPRA_NO_LANE_PASS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
     eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    if mode == "own reference per instance":
+        eng.set_cost_reference(0, np.tile(xref.reshape(-1), (b, 1)) + 0.002 * rng.standard_normal((b, 6 * (N + 1))))
     ts_ = []
     for _ in range(10):
         eng.solve()
         eng.synchronize()
         ts_.append(eng.last_solve_seconds())
-    out[mode] = (eng.results(), float(np.mean(ts_[5:])), eng.layout_info())
+    out[mode] = (eng.results(), float(np.mean(ts_[5:])), dict(eng.layout_info(), lane_pass=eng.lane_pass_info()))
     eng.close()
 r0, r1 = out["dense contraction"][0], out["per-step with p_k"][0]
 ok = r0["status"] == 0
 for mode in out:
-    print("%-20s %.4f ms (%.1f M solves/s), layout %s" % (mode, out[mode][1] * 1e3, b / out[mode][1] / 1e6, out[mode][2]))
+    print("%-28s %.4f ms (%.1f M solves/s), layout %s" % (mode, out[mode][1] * 1e3, b / out[mode][1] / 1e6, out[mode][2]))
 print("status equal", (r0["status"] == r1["status"]).all(), "iter equal", (r0["iter"][ok] == r1["iter"][ok]).all(), "max rel |dU|",
       np.abs(r0["control"][ok] - r1["control"][ok]).max() / np.abs(r0["control"][ok]).max(), "mean iterations", r1["iter"][:, 0].mean())
