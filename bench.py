@@ -126,6 +126,12 @@ def cpp_single_solve_latency(np):
         out[name] = {"median_us": med, "mean_us": mean, "min_us": mn, "p95_us": p95, "device_solveTime_us": st,
                      "active_set_iterations": int(m.group(7)), "cpu_path_one_thread_us": cpu_us,
                      "cpu_path_iterations": int(ro["iter"][0, 0])}
+    # a tracking controller's tick: the TrajectoryCost replaced by a new one with the moved reference trajectory, then solve()
+    # (tests/cpp/test_api.cpp: tracking_case) -- on the handle that exists, and with a new handle per tick (what a swapped cost cost before)
+    for name, env in (("tracking_tick", {}), ("tracking_tick_new_handle_per_tick", {"COPRA_MIRROR_NEW_HANDLE_PER_COST_CHANGE": "1"})):
+        r = subprocess.run([test_cpp_api.EXE, "tracking", "300"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        m = re.search(r"tracking_tick_us median ([0-9.]+) mean ([0-9.]+) min ([0-9.]+) p95 ([0-9.]+)", r.stdout)
+        out[name] = {"median_us": float(m.group(1)), "p95_us": float(m.group(4))} if m else {"error": (r.stdout + r.stderr)[-300:]}
     ok = out.get("benchmark_instance", {})
     out["solves_per_s"] = 1e6 / ok["median_us"] if "median_us" in ok else 0.0
     out["median_us"] = ok.get("median_us", 0.0)

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cstdio>
 #include <limits>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -716,6 +717,9 @@ public:
         h_ = o.h_;
         o.h_ = nullptr;
         dirty_ = o.dirty_;
+        costsDirty_ = o.costsDirty_;
+        builtCosts_ = std::move(o.builtCosts_);
+        builtCostsKnown_ = o.builtCostsKnown_;
         control_ = std::move(o.control_);
         trajectory_ = std::move(o.trajectory_);
         return *this;
@@ -740,7 +744,7 @@ public:
     {
         cost->initializeCost(*ps_);
         spCost_.push_back(cost);
-        dirty_ = true;
+        costsDirty_ = true; // (the list of costs has changed: rebuild() looks at what has changed in it)
     }
     void addConstraint(const std::shared_ptr<Constraint>& c) // LMPC.cpp:124-128, 173-197
     {
@@ -752,7 +756,7 @@ public:
     void clearCosts() noexcept
     {
         spCost_.clear();
-        dirty_ = true;
+        costsDirty_ = true;
     }
     void clearConstraints() noexcept
     {
@@ -762,7 +766,7 @@ public:
     void removeCost(const std::shared_ptr<CostFunction>& c)
     {
         auto it = std::find(spCost_.begin(), spCost_.end(), c);
-        if (it != spCost_.end()) spCost_.erase(it), dirty_ = true;
+        if (it != spCost_.end()) spCost_.erase(it), costsDirty_ = true;
     }
     void removeConstraint(const std::shared_ptr<Constraint>& c)
     {
@@ -825,6 +829,7 @@ public:
     const Eigen::VectorXd& trajectory() const noexcept { return trajectory_; }
     int fail() const noexcept { return fail_; }
     int iter() const noexcept { return iter_; }
+    int handleBuilds() const noexcept { return handleBuilds_; } // (not in the reference: how often the device-side controller was built)
     int nrEqConstr()
     {
         prepare();
@@ -917,8 +922,7 @@ protected:
                 if (!c->deviceDescriptor(cdesc)) c->update(*ps_);
             dirty_ = true; // their matrices are part of the plan
         }
-        const bool fresh = dirty_ || !h_;
-        rebuild();
+        const bool fresh = rebuild(); // (a new handle: the system has to be sent to it)
         // The receding-horizon tick of the reference is ps->xInit(x) between solves (PreviewSystem.h:52): only x0 has changed then,
         // and only x0 crosses PCIe again (one 48-byte copy instead of four blocking ones).  The fields of PreviewSystem are public, so
         // what was sent last is compared rather than trusted.
@@ -951,10 +955,63 @@ protected:
             q.bineq.data(), q.lb.data(), q.ub.data()));
         return q;
     }
-    void rebuild()
+    // What the handle was built from, cost by cost (built-in classes): the reference evaluates every cost anew in every solve
+    // (LMPC.cpp:233-247), so a caller may change weights between solves, or -- the only way its API has to move a reference -- replace a
+    // cost by a new one that differs in p alone (costFunctions.h: M, N, p are constructor arguments).  The first needs a new plan; the
+    // second is copra_batch_set_cost_reference on the handle that exists: a tracking controller's tick costs a copy of p, not a new handle.
+    struct CostSnapshot {
+        int kind = 0, rows = 0, m_cols = 0, n_cols = 0;
+        std::vector<double> M, N, p, w;
+    };
+    static CostSnapshot snapshot(const copra_cost_desc_t& d)
     {
-        if (!dirty_ && h_) return;
+        CostSnapshot c;
+        c.kind = d.kind, c.rows = d.rows, c.m_cols = d.m_cols, c.n_cols = d.n_cols;
+        if (d.M) c.M.assign(d.M, d.M + (size_t)d.rows * d.m_cols);
+        if (d.N) c.N.assign(d.N, d.N + (size_t)d.rows * d.n_cols);
+        if (d.p) c.p.assign(d.p, d.p + d.rows);
+        if (d.weights) c.w.assign(d.weights, d.weights + d.rows);
+        return c;
+    }
+    // 0: the costs are what the handle was built from; 1: so they are up to the references p (pushed to the handle); 2: anything else
+    int costsAgainstHandle()
+    {
+        if (!builtCostsKnown_ || spCost_.size() != builtCosts_.size()) return 2;
+        if (costsDirty_ && std::getenv("COPRA_MIRROR_NEW_HANDLE_PER_COST_CHANGE")) return 2; // (measurements: what a swapped cost cost before)
+        auto same = [](const double* a, const std::vector<double>& b, size_t n) { return (a ? n : 0) == b.size() && (!a || std::equal(a, a + n, b.begin())); };
+        std::vector<copra_cost_desc_t> now(spCost_.size());
+        for (size_t t = 0; t < spCost_.size(); ++t) {
+            const CostSnapshot& b = builtCosts_[t];
+            copra_cost_desc_t& d = now[t];
+            if (!spCost_[t]->deviceDescriptor(d)) return 2;
+            if (d.kind != b.kind || d.rows != b.rows || d.m_cols != b.m_cols || d.n_cols != b.n_cols) return 2;
+            if (!same(d.weights, b.w, (size_t)d.rows)) return 2;
+            // (M and N are constructor arguments: the same object still has the ones the handle was built from)
+            if (costsDirty_ && (!same(d.M, b.M, (size_t)d.rows * d.m_cols) || !same(d.N, b.N, (size_t)d.rows * d.n_cols))) return 2;
+        }
+        int rc = 0;
+        for (size_t t = 0; t < spCost_.size(); ++t) {
+            if (same(now[t].p, builtCosts_[t].p, (size_t)now[t].rows)) continue;
+            if (copra_batch_set_cost_reference(h_, (int)t, now[t].p, 0) != COPRA_OK) return 2; // (a kernel that cannot: a new handle can)
+            builtCosts_[t].p.assign(now[t].p, now[t].p + now[t].rows);
+            rc = 1;
+        }
+        return rc;
+    }
+    bool rebuild() // true: the handle is a new one
+    {
+        if (h_ && !dirty_) {
+            const int c = costsAgainstHandle();
+            if (c < 2) {
+                costsDirty_ = false;
+                if (c == 1) qpValid_ = false;
+                return false;
+            }
+        }
         release();
+        ++handleBuilds_;
+        builtCosts_.clear();
+        builtCostsKnown_ = true;
         std::vector<copra_cost_desc_t> cd;
         std::vector<copra_cstr_desc_t> kd;
         for (auto& c : spCost_) {
@@ -966,6 +1023,9 @@ protected:
                     || c->E().rows() != ps_->xDim || c->E().cols() != ps_->fullUDim || c->f().rows() != ps_->fullUDim)
                     COPRA_DOMAIN_ERROR("cost '" + c->name() + "': Q / c / E / f do not have the sizes initializeCost gives them");
                 d.Q = c->Q().data(), d.c = c->c().data(), d.E = c->E().data(), d.f = c->f().data();
+                builtCostsKnown_ = false; // (a host-evaluated cost: the handle is rebuilt for every solve anyway, prepare())
+            } else {
+                builtCosts_.push_back(snapshot(d));
             }
             cd.push_back(d);
         }
@@ -996,7 +1056,9 @@ protected:
         throw_status(createHandle(dims, cd, kd));
         throw_status(copra_batch_select_solver(h_, flag_ == SolverFlag::DEFAULT ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE));
         dirty_ = false;
+        costsDirty_ = false;
         qpValid_ = false;
+        return true;
     }
     // LMPC.cpp:288-307: a cost / constraint the caller has released is dropped after the solve (the controller's own
     // reference is then the only one: one list here, where the reference keeps a master and a typed list)
@@ -1015,7 +1077,7 @@ protected:
             if (it->use_count() <= 1) {
                 std::fprintf(stderr, "A '%s' has been destroyed.\nIt has been removed from the controller\n", (*it)->name().c_str());
                 it = spCost_.erase(it);
-                dirty_ = true;
+                costsDirty_ = true;
             } else {
                 ++it;
             }
@@ -1033,7 +1095,11 @@ protected:
     std::unique_ptr<SolverInterface> sol_; // a user solver (useSolver); null: the fused device solve
     SolverFlag flag_ = SolverFlag::DEFAULT;
     copra_batch_t* h_ = nullptr;
-    bool dirty_ = true;
+    bool dirty_ = true; // the handle has to be built anew
+    bool costsDirty_ = false; // the list of costs has changed since the handle was built (rebuild() decides what that needs)
+    std::vector<CostSnapshot> builtCosts_;
+    bool builtCostsKnown_ = false;
+    int handleBuilds_ = 0;
     Eigen::VectorXd control_, trajectory_;
     int fail_ = 0, iter_ = 0;
     double solveTime_ = 0.0, solveAndBuildTime_ = 0.0;

@@ -229,6 +229,9 @@ class LMPC:
         self._eng = None
         self._flag = ps_or_flag if (ps_or_flag is not None and not isinstance(ps_or_flag, PreviewSystem)) else flag
         self._dirty = True
+        self._costs_dirty = False
+        self._built_costs = None
+        self.handle_builds = 0  # (not in the reference: how often the device-side controller was built)
         self._control = np.zeros(0)
         self._trajectory = np.zeros(0)
         self._solve_time = self._solve_and_build_time = 0.0
@@ -255,7 +258,7 @@ class LMPC:
     def add_cost(self, cost):
         self._check([cost], [])
         self._costs.append(cost)
-        self._dirty = True
+        self._costs_dirty = True  # (_engine() looks at what has changed in the list)
 
     @_guard
     def add_constraint(self, constr):
@@ -267,14 +270,14 @@ class LMPC:
 
     def remove_cost(self, cost):
         self._costs = [c for c in self._costs if c is not cost]
-        self._dirty = True
+        self._costs_dirty = True
 
     def remove_constraint(self, constr):
         self._cstrs = [c for c in self._cstrs if c is not constr]
         self._dirty = True
 
     def clear_costs(self):
-        self._costs, self._dirty = [], True
+        self._costs, self._costs_dirty = [], True
 
     def clear_constraints(self):
         self._cstrs, self._dirty = [], True
@@ -282,16 +285,44 @@ class LMPC:
     reset_constraints = clear_constraints  # (the binding's stale name, CopraBindings.cpp:286)
 
     # ---- LMPC::solve (src/LMPC.cpp:79-101) ----
+    def _costs_against_engine(self):
+        """The reference evaluates every cost anew in every solve (LMPC.cpp:233-247): weights changed on a cost that is inside the
+        controller, or a cost replaced by a new one, take effect at the next solve.  0: the costs are what the engine was built from;
+        1: they are up to the references p -- the only way the reference's API has to move a reference trajectory is a NEW cost object
+        (M, N, p are constructor arguments) --, which go to the engine that exists (copra_batch_set_cost_reference); 2: anything else"""
+        built = self._built_costs
+        if built is None or len(built) != len(self._costs):
+            return 2
+        same = lambda a, b: (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and np.array_equal(a, b))
+        for c, (kind, M, N, w, _) in zip(self._costs, built):
+            if c.kind != kind or not same(c._w, w) or not same(c._M, M) or not same(c._N, N):
+                return 2
+        rc = 0
+        for t, c in enumerate(self._costs):
+            if not same(c._p, built[t][4]):
+                try:
+                    self._eng.set_cost_reference(t, c._p[None])
+                except Exception:
+                    return 2  # (a kernel that cannot: a new engine can)
+                built[t] = built[t][:4] + (c._p.copy(),)
+                rc = 1
+        return rc
+
     def _engine(self):
         from .batch import BatchLMPC
-        if self._eng is None or self._dirty:
-            if self._eng is not None:
-                self._eng.close()
-            ist = self._initial_state_desc() if self._initial_state else None
-            self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, [c._dict() for c in self._costs],
-                                  [c._dict() for c in self._cstrs], initial_state=ist)
-            self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
-            self._dirty = False
+        if self._eng is not None and not self._dirty and self._costs_against_engine() < 2:
+            self._costs_dirty = False
+            return self._eng
+        if self._eng is not None:
+            self._eng.close()
+        ist = self._initial_state_desc() if self._initial_state else None
+        self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, [c._dict() for c in self._costs],
+                              [c._dict() for c in self._cstrs], initial_state=ist)
+        self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
+        self._dirty = self._costs_dirty = False
+        self.handle_builds += 1
+        cp = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)
+        self._built_costs = [(c.kind, cp(c._M), cp(c._N), cp(c._w), cp(c._p)) for c in self._costs]
         return self._eng
 
     def select_qp_solver(self, flag):

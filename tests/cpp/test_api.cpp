@@ -736,6 +736,111 @@ static void latency_case(int reps, bool hard)
         controller.solveAndBuildTime() * 1e6, controller.control()(0), controller.iter());
 }
 
+// A tracking controller's tick through the reference's API: the reference trajectory moves, and the only way to tell the controller is a
+// NEW TrajectoryCost (M, N, p are constructor arguments, costFunctions.h:103-131) in place of the old one.  The reference evaluates every
+// cost anew in every solve anyway; the mirror recognises a cost list that differs from the handle's in p alone and sends p
+// (copra_batch_set_cost_reference) instead of building a new handle.  Checked against a controller built from scratch with the same
+// costs at every tick; a weights() call on a cost that is already in the controller must be seen as well (LMPC.cpp:233-247).
+static double max_abs_diff(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
+{
+    double m = a.rows() == b.rows() ? 0.0 : 1e300;
+    for (Eigen::Index i = 0; i < a.rows() && i < b.rows(); ++i) m = std::max(m, std::fabs(a(i) - b(i)));
+    return m;
+}
+static void tracking_case(int reps)
+{
+    using namespace Eigen;
+    const int N = 20;
+    const double T = 0.117, inf = std::numeric_limits<double>::infinity();
+    MatrixXd A = MatrixXd::Identity(6, 6), B = MatrixXd::Zero(6, 3);
+    for (int i = 0; i < 3; ++i) A(i, 3 + i) = T, B(i, i) = 0.5 * T * T, B(3 + i, i) = T;
+    VectorXd d = VectorXd::Zero(6), x0(6), goal(6), wx(6), wu(3), lo(6), up(6), ulo(3), uup(3);
+    x0 << 1.5842778860957882, 0.3422260214935311, 2.289067474385933, 0.0, 0.0, 0.0;
+    goal << 1.627772868473883, 0.4156386515475985, 2.3984423755527136, 0.06745225960685897, 0.3882830795737303, 0.06845759848745198;
+    wx << 10, 10, 10, 1, 1, 1;
+    wu << 1e-3, 1e-3, 1e-3;
+    lo << -inf, -inf, -inf, -inf, -inf, -inf;
+    up << inf, inf, inf, 0.6, 0.6, 0.6;
+    ulo << -3, -3, -3;
+    uup << 3, 3, 3;
+    MatrixXd Mfull = MatrixXd::Identity(6 * (N + 1), 6 * (N + 1));
+    auto reference = [&](int tick) { // a straight line towards the goal that moves on with the ticks
+        VectorXd p(6 * (N + 1));
+        for (int k = 0; k <= N; ++k) {
+            const double s = std::min(1.0, (k + 0.05 * tick) / (double)N);
+            for (int i = 0; i < 6; ++i) p(6 * k + i) = x0(i) + s * (goal(i) - x0(i));
+        }
+        return p;
+    };
+    auto make = [&](copra::LMPC& c, const std::shared_ptr<copra::PreviewSystem>& ps, const VectorXd& p, const VectorXd& w) {
+        auto xc = std::make_shared<copra::TrajectoryCost>(Mfull, p);
+        xc->weights(w);
+        auto uc = std::make_shared<copra::ControlCost>(MatrixXd::Identity(3, 3), VectorXd::Zero(3));
+        uc->weights(wu);
+        auto xb = std::make_shared<copra::TrajectoryBoundConstraint>(lo, up);
+        auto ub = std::make_shared<copra::ControlBoundConstraint>(ulo, uup);
+        c.addCost(xc), c.addCost(uc), c.addConstraint(xb), c.addConstraint(ub);
+        return std::make_tuple(xc, uc, xb, ub);
+    };
+    auto ps = std::make_shared<copra::PreviewSystem>();
+    ps->system(A, B, d, x0, N);
+    copra::LMPC controller(ps);
+    auto held = make(controller, ps, reference(0), wx);
+    auto xCost = std::get<0>(held);
+    for (int i = 0; i < 10; ++i) CHECK(controller.solve());
+    int builds0 = 0; // (after the first tick: removeCost + addCost moves the cost to the end of the list -- once a new order, then the same)
+    std::vector<double> us;
+    VectorXd x = x0;
+    double worst = 0.0;
+    for (int i = 1; i <= reps; ++i) {
+        x(0) = x0(0) + 0.002 * (i % 17), x(4) = 0.01 * (i % 5);
+        ps->xInit(x);
+        const VectorXd p = reference(i);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto next = std::make_shared<copra::TrajectoryCost>(Mfull, p);
+        next->weights(wx);
+        controller.removeCost(xCost);
+        controller.addCost(next);
+        xCost = next;
+        const bool ok = controller.solve();
+        const auto t1 = std::chrono::steady_clock::now();
+        CHECK(ok);
+        if (i == 1) builds0 = controller.handleBuilds();
+        if (i > 1) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        if (i % 50 == 1) { // against a controller built from scratch with the same costs
+            auto ps2 = std::make_shared<copra::PreviewSystem>();
+            ps2->system(A, B, d, x, N);
+            copra::LMPC fresh(ps2);
+            auto h2 = make(fresh, ps2, p, wx);
+            CHECK(fresh.solve());
+            worst = std::max(worst, max_abs_diff(fresh.control(), controller.control()));
+            CHECK(fresh.iter() == controller.iter());
+        }
+    }
+    CHECK(worst <= 1e-10);
+    CHECK(controller.handleBuilds() == builds0); // (not one new handle for all these ticks)
+    // weights changed on a cost that is in the controller: seen by the next solve (a new plan)
+    VectorXd w2 = wx;
+    w2(0) = 3.0, w2(4) = 2.5;
+    xCost->weights(w2);
+    CHECK(controller.solve());
+    {
+        auto ps2 = std::make_shared<copra::PreviewSystem>();
+        ps2->system(A, B, d, x, N);
+        copra::LMPC fresh(ps2);
+        auto h2 = make(fresh, ps2, reference(reps), w2);
+        CHECK(fresh.solve());
+        CHECK(max_abs_diff(fresh.control(), controller.control()) <= 1e-10);
+        CHECK(controller.handleBuilds() == builds0 + 1);
+    }
+    std::sort(us.begin(), us.end());
+    double mean = 0.0;
+    for (double v : us) mean += v;
+    mean /= (double)us.size();
+    std::printf("tracking_tick_us median %.2f mean %.2f min %.2f p95 %.2f solveTime_us %.2f builds %d worst %.3e\n", us[us.size() / 2], mean,
+        us.front(), us[(size_t)(0.95 * us.size())], controller.solveTime() * 1e6, controller.handleBuilds(), worst);
+}
+
 int main(int argc, char** argv)
 {
     std::setvbuf(stdout, nullptr, _IONBF, 0);
@@ -745,6 +850,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
         if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
+        if (!std::strcmp(mode, "tracking")) tracking_case(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "latency")) latency_case(argc > 2 ? std::atoi(argv[2]) : 500, argc > 3 && !std::strcmp(argv[3], "hard"));
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());

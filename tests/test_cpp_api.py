@@ -63,3 +63,15 @@ def test_plugin_surface_user_subclasses_and_user_solver(steps):
     _build()
     r = subprocess.run([EXE, "plugins", str(steps)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_tracking_tick_reuses_the_device_controller():
+    """a tracking controller through the reference's API: every tick REPLACES the TrajectoryCost by a new one with the moved reference
+    trajectory (the reference has no setter for p, costFunctions.h:103-131).  The mirror sees that the cost list differs from the handle's
+    in p alone and sends p (copra_batch_set_cost_reference): 300 ticks on ONE handle, each equal to a controller built from scratch
+    with the same costs; a weights() call on a cost inside the controller is seen by the next solve (LMPC.cpp:233-247 evaluates every
+    cost anew)"""
+    _build()
+    r = subprocess.run([EXE, "tracking", "300"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

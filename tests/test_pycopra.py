@@ -210,3 +210,60 @@ def test_initial_state_lmpc(S):  # include/InitialStateLMPC.h through the Python
     x0s = controller.initial_state()
     assert (x0s <= S.x0 + 0.05 + 1e-6).all() and (x0s >= S.x0 - 0.05 - 1e-6).all()
     assert np.abs(controller.trajectory()[:2] - x0s).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_cost_changes_between_solves_like_the_reference():
+    """the reference evaluates every cost anew in every solve (LMPC.cpp:233-247): weights() on a cost that is inside the controller takes
+    effect at the next solve (a new plan), and a cost REPLACED by one that differs in p alone -- the reference's only way to move a
+    reference trajectory -- is sent to the engine that exists (copra_batch_set_cost_reference) instead of building a new one; every state
+    against a controller built from scratch"""
+    import copra_amd.pycopra as copra
+    from copra_amd import workloads
+    wl = workloads.com_preview(1)
+    N, A, B, d = wl["N"], wl["A"][0], wl["B"][0], wl["d"][0]
+    x0, goal = workloads.COM_X_INIT, workloads.COM_X_GOAL
+    wx, inf = np.array([10.0, 10, 10, 1, 1, 1]), np.inf
+
+    def reference(tick):
+        s = np.minimum(1.0, (np.arange(N + 1) + 0.3 * tick) / N)
+        return (x0[None, :] + s[:, None] * (goal - x0)[None, :]).reshape(-1)
+
+    def build(p, w, x):
+        ps = copra.PreviewSystem(A, B, d, x, N)
+        c = copra.LMPC(ps)
+        xc = copra.TrajectoryCost(np.eye(6 * (N + 1)), p)
+        xc.weights(w)
+        uc = copra.ControlCost(np.eye(3), np.zeros(3))
+        uc.weights(np.full(3, 1e-3))
+        keep = (xc, uc, copra.TrajectoryBoundConstraint(np.full(6, -inf), np.array([inf, inf, inf, 0.6, 0.6, 0.6])),
+                copra.ControlBoundConstraint(np.full(3, -3.0), np.full(3, 3.0)))
+        c.add_cost(xc), c.add_cost(uc), c.add_constraint(keep[2]), c.add_constraint(keep[3])
+        return ps, c, keep
+
+    ps, ctl, keep = build(reference(0), wx, x0)
+    xc = keep[0]
+    assert ctl.solve()
+    builds = None
+    for tick in range(1, 8):
+        x = x0 + 0.002 * tick
+        ps.x_init(x)
+        nxt = copra.TrajectoryCost(np.eye(6 * (N + 1)), reference(tick))
+        nxt.weights(wx)
+        ctl.remove_cost(xc)
+        ctl.add_cost(nxt)
+        xc = nxt
+        assert ctl.solve()
+        if tick == 1:
+            builds = ctl.handle_builds  # (remove + add moved the cost to the end of the list: a new order once, the same from then on)
+        _, fresh, keep2 = build(reference(tick), wx, x)
+        assert fresh.solve() and np.abs(fresh.control() - ctl.control()).max() <= 1e-10
+    assert ctl.handle_builds == builds
+    w2 = wx.copy()
+    w2[0], w2[4] = 3.0, 2.5
+    xc.weights(w2)
+    assert ctl.solve() and ctl.handle_builds == builds + 1
+    _, fresh, keep2 = build(reference(7), w2, x)
+    assert fresh.solve() and np.abs(fresh.control() - ctl.control()).max() <= 1e-10
+    _, stale, keep3 = build(reference(7), wx, x)
+    assert stale.solve() and np.abs(stale.control() - ctl.control()).max() > 1e-6  # (the weights did something)
