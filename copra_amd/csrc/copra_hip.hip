@@ -80,14 +80,14 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 // The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
 // (three waves per SIMD: 168 VGPRs; compact variant: 13.9 KB of LDS per instance, eleven instances share a CU; general
 //  variant: 17.7 KB + the rows' share, seven to nine -- the LDS allocation granule is 1280 B, profiles/r02/lds_granule_probe.txt)
-template <int NX, int NU, int NH, int QR>
+template <int NX, int NU, int NH, int QR, bool SREFS = false>
 __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
 {
     if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
     int inst;
     bool lane_failed;
     if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
-    lmpc_fused_ric_body<NX, NU, NH, 6, QR>(P, inst, lane_failed);
+    lmpc_fused_ric_body<NX, NU, NH, 6, QR, SREFS>(P, inst, lane_failed);
 }
 // One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
 // instance; those that violate nothing are finished here.  One wave per SIMD: the lane's matrices live in up to 512 registers.
@@ -211,6 +211,11 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
         if (P.lds.ric) { // (plan_builder.hpp: only these shapes get the layout; Q1 in registers, or in LDS further down the ladder)
+            if (P.stage_refs) { // (reference trajectories: the builds with the stage-varying affine term)
+                if (P.N == 10) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 10, kFusedQ1Regs, true> : copra_lmpc_fused_ric_kernel<6, 3, 10, 0, true>;
+                if (P.N == 15) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 15, kFusedQ1Regs, true> : copra_lmpc_fused_ric_kernel<6, 3, 15, 0, true>;
+                return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs, true> : copra_lmpc_fused_ric_kernel<6, 3, 20, 0, true>;
+            }
             if (P.N == 10) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 10, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 10, 0>;
             if (P.N == 15) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 15, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 15, 0>;
             return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 20, kFusedQ1Regs> : copra_lmpc_fused_ric_kernel<6, 3, 20, 0>;
@@ -1556,20 +1561,21 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {
             char keyr[128], srcr[3072];
+            const char* const sr = P.stage_refs ? "true" : "false"; // (reference trajectories: the builds with the stage-varying affine term)
             snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d%s", P.nx, P.nu, P.N, P.stage_refs ? "_srefs" : "");
             snprintf(srcr, sizeof srcr,
                 "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\n#include \"lmpc_lane.hpp\"\nusing namespace copra_hip;\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
                 "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d>(P, inst, failed); }\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d, %s>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused_q0(const FusedPlan P)\n"
                 "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
                 "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0>(P, inst, failed); }\n"
+                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0, %s>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
                 "{ lmpc_lane_body<%d, %d, %s>(P, (int)blockIdx.x); }\n",
-                P.nx, P.nu, P.N, kFusedQ1Regs, P.nx, P.nu, P.N, P.nx, P.nu, P.stage_refs ? "true" : "false");
+                P.nx, P.nu, P.N, kFusedQ1Regs, sr, P.nx, P.nu, P.N, sr, P.nx, P.nu, sr);
             std::string objr;
             const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
             if (rcr != COPRA_OK) return rcr;

@@ -23,7 +23,9 @@
 
 namespace copra_hip {
 
-template <int NX, int NU, int NH, int RP, int QR>
+// SREFS: the build for controllers with reference trajectories (FusedPlan::stage_refs): the stage-varying affine term of the sweep in its
+// own instantiation (in one build for both, the headline's kernel ran 3 % slower: 281 -> 290 us, twice the scalar-register spills)
+template <int NX, int NU, int NH, int RP, int QR, bool SREFS = false>
 COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_failed = false)
 {
     constexpr int NZ = NX + NU, NV = NU * NH, X = NX * (NH + 1);
@@ -180,7 +182,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             const int rc = P.cost[tt].rows;
             // (a reference trajectory, CostTerm::pstride: the terminal lanes take the reference of the last step here, the affine terms of the
             //  stages are formed per stage below)
-            const double* pref = cost_reference(P, tt, inst) + (P.cost[tt].pstride ? P.cost[tt].prows - P.cost[tt].pstride : 0);
+            const double* pref = cost_reference(P, tt, inst) + ((SREFS && P.cost[tt].pstride) ? P.cost[tt].prows - P.cost[tt].pstride : 0);
 #pragma unroll
             for (int r = 0; r < RP; ++r) {
                 cw[t][r] = tab[kWave * (2 + tt * RP + r) + lane];
@@ -198,7 +200,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             aff += (t < P.ncost) ? at : 0.0;
         }
         // (no lane owns an affine entry of the stage AND one of the terminal cost: the table holds whichever it has)
-        hreg += (aff_lane && !P.stage_refs) ? aff : 0.0;
+        hreg += (aff_lane && !SREFS) ? aff : 0.0;
         term += (tj == NX) ? aff : 0.0;
         if (tj < NX)
             Pm[lane] = term;
@@ -215,7 +217,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     //     h_k(a) = sum_t sum_r c_t(r, a) p_t[k r_t + r]     (c_t: the coefficients of the affine lanes in the table above),
     // NH NZ values, each formed once: entry a of stage k waits in the place of record k (where Acl_k goes at the END of stage k of the
     // sweep, which reads it at its start).
-    if (P.stage_refs) {
+    if constexpr (SREFS) {
         const double* tab = P.params + P.ric_tab;
         for (int e = lane; e < NH * NZ; e += kWave) {
             const int k = e / NZ, a = e - k * NZ;
@@ -394,7 +396,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             adj1 = Mu2 + e1, adj2 = Mu2 + e2, adj3 = Mu2 + e3, adj4 = Mu2 + e4;
         }
         // reference trajectories: the affine column of Hin of stage k, from the place of record k (see above); everybody else reads a zero
-        const bool srefs = P.stage_refs != 0;
+        constexpr bool srefs = SREFS;
         const double* hkp[3];
         int hkst[3];
 #pragma unroll
@@ -409,7 +411,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         for (int k = NH - 1; k >= 0; --k) {
             double* Fk = F + k * RR::SZ;
             double Hk[3] = { Hacc[0], Hacc[1], Hacc[2] };
-            if (srefs) {
+            if constexpr (SREFS) {
 #pragma unroll
                 for (int I = 0; I < 3; ++I) {
                     Hk[I] += *hkp[I];

@@ -247,23 +247,23 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     auto body = [&](const FusedPlan& PP, int b) {
         // (shapes beyond the library's instantiations: what copra_batch_specialise compiles at run time)
         if (PP.lds.tri && PP.lds.ric && PP.nx == 6 && PP.nu == 3 && PP.N == 12)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 12, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 4 && PP.nu == 2 && PP.N == 16)
-            PP.lds.q1regs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<4, 2, 16, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 5 && PP.nu == 3 && PP.N == 12)
-            PP.lds.q1regs ? lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<5, 3, 12, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<5, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<5, 3, 12, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<5, 3, 12, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 10)
-            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 10, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 10, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<2, 1, 10, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 10, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 2 && PP.nu == 1 && PP.N == 40)
-            PP.lds.q1regs ? lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 40, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 40, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<2, 1, 40, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<2, 1, 40, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.N == 10) // (select_fused_kernel: the factor in Riccati form)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 10, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 10, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 10, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.N == 15)
-            PP.lds.q1regs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b, lane_failed);
+            PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 15, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 15, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 15, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.lds.q1regs)
-            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b, lane_failed);
+            (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric)
-            lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b, lane_failed);
+            (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 20, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && s6 && PP.lds.q1regs == kFusedQ1Regs) // (select_fused_kernel: the factor-only first tier, Q1 in registers)
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)
@@ -496,7 +496,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         R.batch = 1;
         R.dump_instance = 0;
         R.ric_model_out = ric_model.data();
-        if (emu::run_wave([&]() { lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(R, 0); }, hp.lds_bytes, 0, 1) != 0) return -100;
+        if (emu::run_wave([&]() { (R.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs, true>(R, 0) : lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(R, 0)); }, hp.lds_bytes, 0, 1) != 0) return -100;
         P.ric_model = ric_model.data();
     } else { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
         LdsLayout lq {};
@@ -507,7 +507,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     }
     auto shared = [&](const FusedPlan& PP, int b) {
         if (PP.lds.ric && PP.ric_model)
-            lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b);
+            (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs, true>(PP, b) : lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b));
         else if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
             lmpc_shared_body<6, 3, 20, true>(PP, b);
         else if (PP.lds.tri)

@@ -1,6 +1,8 @@
 """Differential fuzz of this round's plan-builder classifications and of the lane pass (GPU box): random controllers on the (6, 3) and
 (2, 1) systems with random mixes of constraint forms; the default build of the plan (selection rows, step rows, lane pass) against the
-previous classification (COPRA_NO_SELECTION_ROWS, COPRA_NO_STEP_ROWS, COPRA_NO_LANE_PASS) -- statuses, iteration counts, U."""
+previous classification (COPRA_NO_SELECTION_ROWS, COPRA_NO_STEP_ROWS, COPRA_NO_LANE_PASS, COPRA_NO_STAGE_REFS) -- statuses, iteration
+counts, U.  Half of the controllers track a reference TRAJECTORY (a full-size TrajectoryCost and / or ControlCost with repeating blocks),
+controller-wide or one per instance."""
 import os
 import sys
 
@@ -9,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
 
-OLD = ("COPRA_NO_SELECTION_ROWS", "COPRA_NO_STEP_ROWS", "COPRA_NO_LANE_PASS")
+OLD = ("COPRA_NO_SELECTION_ROWS", "COPRA_NO_STEP_ROWS", "COPRA_NO_LANE_PASS", "COPRA_NO_STAGE_REFS")
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 bad = 0
 for seed in range(nseeds):
@@ -58,6 +60,24 @@ for seed in range(nseeds):
     if not cstrs:
         cstrs = [wl["cstrs"][-1]]
         forms = ["ubound"]
+    costs = list(wl["costs"])
+    own_ref = None
+    if rng.random() < 0.5:  # a reference trajectory: the state cost as a full-size entry with a stacked reference
+        c0 = costs[0]
+        M0 = np.atleast_2d(c0["M"])
+        r = M0.shape[0]
+        pk = np.asarray(c0["p"])[None, :] * np.linspace(0.6, 1.0, N + 1)[:, None] + 0.01 * rng.standard_normal((N + 1, r))
+        costs[0] = dict(kind="trajectory", M=np.kron(np.eye(N + 1), M0), p=pk.reshape(-1), weights=np.tile(np.asarray(c0["weights"], dtype=float), N + 1))
+        forms.append("xref")
+        if rng.random() < 0.5:
+            own_ref = np.tile(pk.reshape(-1), (b, 1)) + 0.01 * rng.standard_normal((b, pk.size))
+            forms.append("own")
+        if rng.random() < 0.4:
+            c1 = costs[1]
+            uk = 0.1 * rng.standard_normal((N, nu))
+            costs[1] = dict(kind="control", N=np.kron(np.eye(N), np.atleast_2d(c1["N"])), p=uk.reshape(-1),
+                            weights=np.tile(np.asarray(c1["weights"], dtype=float), N))
+            forms.append("uref")
     out = {}
     for mode in ("old", "new"):
         for e in OLD:
@@ -65,8 +85,10 @@ for seed in range(nseeds):
             if mode == "old":
                 os.environ[e] = "1"
         os.environ["COPRA_LANE_MIN_BATCH"] = "1"
-        eng = BatchLMPC(nx, nu, N, b, wl["costs"], cstrs)
+        eng = BatchLMPC(nx, nu, N, b, costs, cstrs)
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        if own_ref is not None:
+            eng.set_cost_reference(0, own_ref)
         eng.solve()
         eng.solve()
         out[mode] = (eng.results(), eng.lane_pass_info(), eng.layout_info())
