@@ -232,6 +232,8 @@ def lib():
         L.copra_batch_set_control_bounds.argtypes = [vp, vp, vp, C.c_int]
         L.copra_batch_set_cost_reference.restype = C.c_int
         L.copra_batch_set_cost_reference.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.copra_batch_set_cost_reference_all.restype = C.c_int
+        L.copra_batch_set_cost_reference_all.argtypes = [vp, C.c_int, vp, C.c_int]
         L.copra_batch_set_shared_system.restype = C.c_int
         L.copra_batch_set_shared_system.argtypes = [vp, vp, vp, vp, C.c_int]
         L.copra_batch_set_outputs.restype = C.c_int

@@ -114,8 +114,17 @@ class BatchLMPC:
 
     def set_cost_reference(self, cost_index, p):
         """per-instance reference of cost `cost_index`: p of shape (batch, rows) (numpy, or a torch CUDA tensor used in
-        place); None restores the controller-wide reference"""
+        place); p of shape (rows,): ONE new reference for every instance (copra_batch_set_cost_reference_all: copied); None
+        restores the controller-wide reference given at creation"""
         self._ref_keep.pop(int(cost_index), None)  # one slot per cost: the previous tensor is released
+        if p is not None and getattr(p, "ndim", np.ndim(p)) == 1:
+            if _is_torch(p):
+                assert p.is_cuda and p.is_contiguous() and str(p.dtype) == "torch.float64"
+                _capi.check(self._lib.copra_batch_set_cost_reference_all(self._h, int(cost_index), p.data_ptr(), 1))
+            else:
+                pb = np.ascontiguousarray(p, dtype=np.float64)
+                _capi.check(self._lib.copra_batch_set_cost_reference_all(self._h, int(cost_index), pb.ctypes.data, 0))
+            return
         if p is None:
             _capi.check(self._lib.copra_batch_set_cost_reference(self._h, int(cost_index), None, 0))
         elif _is_torch(p):

@@ -180,6 +180,13 @@ __global__ void copra_preview_fill_kernel(int nx, int nu, int N, const double* G
     Psi[e] = (j < i) ? G[(size_t)(i - 1 - j) * nx * nu + r + nx * c] : 0.0; // Psi_{i,j} = A^(i-1-j) B (:66-69), row block 0 is zero
 }
 
+// out[b][i] = out[0][i], b >= 1: one reference for every instance (copra_batch_set_cost_reference_all)
+__global__ void copra_broadcast_reference_kernel(const double* p, double* out, int rows, long long total)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) out[e] = p[e % rows];
+}
+
 // out[b][row0 + s * r + i] = f[b][i] for the steps s of one constraint (copra_batch_set_constraint_rhs)
 __global__ void copra_scatter_rhs_kernel(const double* f, double* out, int batch, int r, int steps, int row0, int mgen)
 {
@@ -822,7 +829,7 @@ static bool use_riccati(copra_batch* h)
 
 extern "C" {
 
-int copra_abi_version(void) { return 4; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info
+int copra_abi_version(void) { return 4; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info, copra_batch_set_cost_reference_all
 
 copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
     double* Psi, double* xi)
@@ -1375,6 +1382,40 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
     if (!h->d_cost_p[cost_index]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[cost_index], count * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_cost_p[cost_index], p, count * sizeof(double), hipMemcpyHostToDevice));
     h->cost_p[cost_index] = h->d_cost_p[cost_index];
+    return COPRA_OK;
+}
+
+copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_index, const double* p, int on_device)
+{
+    if (!h || !p) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: null argument");
+    const FusedPlan& P = h->hp.plan;
+    if (cost_index < 0 || cost_index >= (int)h->hp.cost_slot.size()) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: no such cost");
+    const int t = h->hp.cost_slot[(size_t)cost_index];
+    if (t < 0) return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a dense (host-evaluated) cost has no reference p");
+    if (h->shared && P.cost[t].pstride)
+        return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a new reference trajectory in shared-model mode needs a new controller");
+    // Every kernel already reads a per-instance reference where one is set: the new reference is written once per instance into the
+    // library's own buffer (a broadcast on the device: 66 MB at the headline's batch for a reference trajectory, ~ 10 us) and that
+    // path is taken -- nothing that was derived from the creation-time p (tables of the plan builder, the shared model's c0) can go stale.
+    const size_t b = (size_t)(P.batch > 0 ? P.batch : 1), rows = (size_t)P.cost[t].prows;
+    if (!h->d_cost_p[t]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[t], b * rows * sizeof(double)));
+    double* const out = h->d_cost_p[t];
+    if (p == out) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: p aliases the library's buffer");
+    HIP_TRY(hipStreamSynchronize(h->last_stream)); // (a solve that still reads the buffer)
+    const double* src = p;
+    if (!on_device) {
+        HIP_TRY(hipMemcpy(out, p, rows * sizeof(double), hipMemcpyHostToDevice)); // instance 0's slot, then read from there
+        src = out;
+    }
+    const long long first = on_device ? 0 : (long long)rows, total = (long long)(b * rows) - first;
+    if (total > 0)
+        hipLaunchKernelGGL(copra_broadcast_reference_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->last_stream, src, out + first,
+            (int)rows, total);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->last_stream);
+    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_batch_set_cost_reference_all: ") + hipGetErrorString(e));
+    if (!h->cost_p[t]) h->model_dirty = true; // shared model: c0 / C2 change
+    h->cost_p[t] = out;
     return COPRA_OK;
 }
 

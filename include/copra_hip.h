@@ -186,6 +186,12 @@ copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const dou
  *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Works on the shared-model fast path
  *      too (the gradient is affine in p: c = c0 + C1 x0 + C2 p, probed once). ---- */
 copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);
+/* ... and ONE new reference for every instance: p[rows] (rows as above -- a reference trajectory: r (N+1) or r N), host or device.
+ *      The reference's API has no setter for p (include/costFunctions.h:103-219: a constructor argument): a tracking controller
+ *      replaces the cost object and the next solve evaluates the new one (src/LMPC.cpp:233-247).  Here the new reference is written
+ *      once per instance into the library's buffer (a broadcast on the device) and the per-instance path above is taken: no new
+ *      plan, no new handle.  Not for a reference TRAJECTORY in shared-model mode (COPRA_ERR_UNSUPPORTED: build a new controller). */
+copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_index, const double* p, int on_device);
 
 /* ---- per-instance constraint data.  copra_batch_set_constraint_rhs: f of the Trajectory / Control / Mixed constraint
  *      `cstr_index` (position in the `cstrs` array given at creation) for every instance, [batch][rows] with the rows

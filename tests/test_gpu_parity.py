@@ -1719,3 +1719,62 @@ def test_reference_trajectory_compiled_shape(oracle, tmp_path):
         assert _rel(res["control"][pick][okp], ref["control"][okp]) <= RTOL
     assert eng.lane_pass_info()[0]
     eng.close()
+
+
+@pytest.mark.gpu
+def test_one_new_reference_for_every_instance(oracle):
+    """copra_batch_set_cost_reference_all: a new goal / a new reference trajectory for the whole batch without a new controller (the
+    reference replaces the cost object, costFunctions.h:103-219 has no setter) -- equal to a controller built with that reference; host
+    and device pointers; shared-model mode takes a new goal and refuses a new reference trajectory"""
+    import torch
+    from copra_amd import BatchLMPC, workloads
+    b = 24576
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=31)
+    N = wl["N"]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    xref2 = xref + 0.02 * np.sin(3.0 * ts)[:, None]
+    goal2 = workloads.COM_X_GOAL + np.array([0.02, -0.03, 0.01, 0.0, 0.0, 0.0])
+    track = lambda xr: [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xr.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)),
+                        wl["costs"][1]]
+    to_goal = lambda g: [dict(wl["costs"][0], p=g), wl["costs"][1]]
+
+    def solve(costs, new=None, device=False):
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        if new is not None:
+            eng.set_cost_reference(0, torch.tensor(new, dtype=torch.float64, device="cuda") if device else new)
+            eng.solve()
+        r = eng.results()
+        eng.close()
+        return r
+
+    for first, second, mk in ((xref.reshape(-1), xref2.reshape(-1), track), (workloads.COM_X_GOAL, goal2, to_goal)):
+        want = solve(mk(second.reshape(xref.shape) if mk is track else second))
+        ok = want["status"] == 0
+        assert ok.sum() > b // 2
+        for device in (False, True):
+            got = solve(mk(first.reshape(xref.shape) if mk is track else first), new=second, device=device)
+            assert (got["status"] == want["status"]).all() and (got["iter"][ok] == want["iter"][ok]).all()
+            assert _rel_vec(got["control"][ok], want["control"][ok]) <= 1e-10
+    # shared-model mode
+    A, B, d = wl["A"][7], wl["B"][7], wl["d"][7]
+    res = []
+    for costs, new in ((to_goal(goal2), None), (to_goal(workloads.COM_X_GOAL), goal2)):
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_shared_system(A, B, d)
+        eng.set_x0(wl["x0"])
+        eng.solve()
+        if new is not None:
+            eng.set_cost_reference(0, new)
+            eng.solve()
+        res.append(eng.results())
+        eng.close()
+    ok = res[0]["status"] == 0
+    assert (res[0]["status"] == res[1]["status"]).all() and _rel_vec(res[1]["control"][ok], res[0]["control"][ok]) <= 1e-9
+    eng = BatchLMPC(6, 3, N, b, track(xref), wl["cstrs"])
+    eng.set_shared_system(A, B, d)
+    with pytest.raises(Exception):
+        eng.set_cost_reference(0, xref2.reshape(-1))
+    eng.close()
