@@ -20,7 +20,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", _HERE, "libcopra_emu.so"], stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # (pytest -n: one worker builds, the others wait for it)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE, "libcopra_emu.so"], stdout=subprocess.DEVNULL)
         _lib = C.CDLL(os.path.join(_HERE, "libcopra_emu.so"))
         _lib.emu_lmpc_solve.restype = C.c_int
         _lib.emu_qp_dense.restype = C.c_int
