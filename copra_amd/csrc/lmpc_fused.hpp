@@ -692,7 +692,7 @@ COPRA_DEV void lmpc_fused_body(const FusedPlan& P, int inst)
                 const int k = e / r, row = e - k * r;
                 double acc = 0.0;
                 for (int c = 0; c < nx; ++c) acc += Mx[row + r * c] * Xbar[k * nx + c];
-                We[e] = (acc - (ct.pstride ? (row < rc ? pref[k * ct.pstride + row] : 0.0) : p[row])) * w[row]; // (reference trajectory: p_k)
+                We[e] = (acc - (ct.pstride ? ((row < rc && (k + 1) * ct.pstride <= ct.prows) ? pref[k * ct.pstride + row] : 0.0) : p[row])) * w[row]; // (reference trajectory: p_k; MixedCost has none for x_N)
             }
             wave_sync();
             COPRA_FINE("cost:YWe");

@@ -641,39 +641,55 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // the step -- the same sums over the same blocks in the same order, without the dense contraction of a full-size entry
         // (lmpc_fused.hpp: 7.6 M solves/s at the headline shape).  One-wave LMPC controllers only; the kernels that do not evaluate
         // costs step by step with the step's reference refuse such a controller (FusedPlan::stage_refs).
-        if (full && !is && U <= kWave && (c.kind == COPRA_COST_TRAJECTORY || c.kind == COPRA_COST_CONTROL) && !std::getenv("COPRA_NO_STAGE_REFS")) {
-            const bool traj = c.kind == COPRA_COST_TRAJECTORY;
-            const int S = traj ? N + 1 : N, cwd = traj ? nx : nu, R = c.rows;
-            const double* Mx = traj ? c.M : c.N; // column-major, R x (S cwd)
+        if (full && !is && U <= kWave && (c.kind == COPRA_COST_TRAJECTORY || c.kind == COPRA_COST_CONTROL || c.kind == COPRA_COST_MIXED)
+            && !std::getenv("COPRA_NO_STAGE_REFS")) {
+            // (MixedCost, costFunctions.cpp:173-210: M x_k + N u_k - p_k over the N steps with a control -- M has fullXDim columns, the
+            //  ones of x_N zero; both matrices must repeat their block)
+            const bool traj = c.kind == COPRA_COST_TRAJECTORY, mixed = c.kind == COPRA_COST_MIXED;
+            const int S = traj ? N + 1 : N, R = c.rows;
+            // `Mx`, column-major R x (cols), is blkdiag(its first block, ...) over S row blocks of r rows and column blocks of cwd (columns
+            // past the S-th block: zero)
+            auto repeats = [&](const double* Mx, int cols, int cwd, int r) {
+                for (int sblk = 0; sblk < S; ++sblk)
+                    for (int i = 0; i < r; ++i)
+                        for (int j = 0; j < cols; ++j) {
+                            const double v = Mx[(size_t)j * R + (size_t)sblk * r + i];
+                            const int jb = j / cwd, jc = j - jb * cwd;
+                            if (v != (jb == sblk ? Mx[(size_t)jc * R + i] : 0.0)) return false;
+                        }
+                return true;
+            };
             if (R % S == 0 && R / S <= 6) {
                 const int r = R / S;
                 bool ok = true;
                 for (int sblk = 0; sblk < S && ok; ++sblk)
-                    for (int i = 0; i < r && ok; ++i) {
-                        ok = c.weights[(size_t)sblk * r + i] == c.weights[i];
-                        for (int j = 0; j < S * cwd && ok; ++j) {
-                            const double v = Mx[(size_t)j * R + (size_t)sblk * r + i];
-                            const int jb = j / cwd, jc = j - jb * cwd;
-                            ok = v == (jb == sblk ? Mx[(size_t)jc * R + i] : 0.0);
-                        }
-                    }
+                    for (int i = 0; i < r && ok; ++i) ok = c.weights[(size_t)sblk * r + i] == c.weights[i];
+                if (ok && (traj || mixed)) ok = repeats(c.M, X, nx, r);
+                if (ok && (!traj)) ok = repeats(c.N, U, nu, r);
                 if (ok) {
-                    std::vector<double> blk((size_t)r * cwd);
-                    for (int j = 0; j < cwd; ++j)
-                        for (int i = 0; i < r; ++i) blk[(size_t)i + (size_t)r * j] = Mx[(size_t)j * R + i];
+                    auto block = [&](const double* Mx, int cwd) {
+                        std::vector<double> blk((size_t)r * cwd);
+                        for (int j = 0; j < cwd; ++j)
+                            for (int i = 0; i < r; ++i) blk[(size_t)i + (size_t)r * j] = Mx[(size_t)j * R + i];
+                        return blk;
+                    };
                     t.rows = r;
                     t.full = 0;
                     t.ident = 0;
-                    if (traj && r == nx) {
-                        bool id = true;
-                        for (int j = 0; j < nx && id; ++j)
-                            for (int i = 0; i < nx && id; ++i) id = blk[(size_t)j * nx + i] == ((i == j) ? 1.0 : 0.0);
-                        t.ident = id ? 1 : 0;
-                    }
-                    if (traj)
+                    if (traj || mixed) {
+                        const std::vector<double> blk = block(c.M, nx);
+                        if (traj && r == nx) {
+                            bool id = true;
+                            for (int j = 0; j < nx && id; ++j)
+                                for (int i = 0; i < nx && id; ++i) id = blk[(size_t)j * nx + i] == ((i == j) ? 1.0 : 0.0);
+                            t.ident = id ? 1 : 0;
+                        }
                         t.offM = push(blk.data(), r * nx);
-                    else
+                    }
+                    if (!traj) {
+                        const std::vector<double> blk = block(c.N, nu);
                         t.offN = push(blk.data(), r * nu);
+                    }
                     if (r > P.rmax) P.rmax = r;
                     t.offP = push(c.p, R);
                     t.offW = push(c.weights, r);

@@ -1169,3 +1169,44 @@ def test_reference_trajectory_shared_model(emu, oracle, monkeypatch):
         assert re["riccati_factor"] and ok.sum() >= b - 4 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
         assert (re["lane_pass_finished"] > 0) == (not no_pass)
+
+
+@pytest.mark.parametrize("mode", ["lane_pass_and_handover", "own_sweep", "factor_only_tier"])
+def test_mixed_cost_reference_trajectory(emu, oracle, monkeypatch, mode):
+    """MixedCost with a reference that changes along the horizon: the full-size entry of costFunctions.cpp:173-210 -- M with fullXDim
+    columns (those of x_N zero), N with fullUDim, both repeating their block over the N steps that have a control -- is a per-step entry
+    with the reference of the step too; on the Riccati-factor tier behind the lane pass, on its own sweep and on the factor-only tier's
+    step-by-step cost phase, controller-wide and per-instance references; against the oracle, which takes the full-size entry as it is"""
+    from copra_amd import workloads
+    b = 70
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=33)
+    N, nx, nu = wl["N"], 6, 3
+    rng = np.random.default_rng(2)
+    M0 = np.hstack([np.zeros((3, 3)), np.eye(3)])  # the velocity ...
+    N0 = 0.05 * np.eye(3)  # ... plus a share of the control follows a reference
+    Mf = np.hstack([np.kron(np.eye(N), M0), np.zeros((3 * N, nx))])
+    Nf = np.kron(np.eye(N), N0)
+    pk = 0.05 * np.sin(0.4 * np.arange(N))[:, None] * np.array([1.0, -0.5, 0.3])[None, :]
+    mixed = dict(kind="mixed", M=Mf, N=Nf, p=pk.reshape(-1), weights=np.tile([2.0, 3.0, 1.5], N))
+    costs = [wl["costs"][0], mixed, wl["costs"][1]]
+    if mode == "own_sweep":
+        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+    if mode == "factor_only_tier":
+        monkeypatch.setenv("COPRA_NO_RIC", "1")
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, costs, wl["cstrs"])
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    ok = ro["status"] == 0
+    re = emu.lmpc_solve(*args)
+    assert re["riccati_factor"] == (mode != "factor_only_tier")
+    assert ok.sum() >= b - 4 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    refs = {1: np.tile(pk.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, pk.size))}
+    re2 = emu.lmpc_solve(*args, cost_refs=refs)
+    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+    rd = emu.lmpc_solve(*args)
+    rd2 = emu.lmpc_solve(*args, cost_refs=refs)  # (the full-size entry as it is: dense contraction)
+    assert not rd["riccati_factor"] and (rd["status"] == re["status"]).all() and _rel(rd["control"][ok], re["control"][ok]) <= 1e-9
+    ok2 = rd2["status"] == 0
+    assert ok2.sum() >= b - 6 and (re2["status"] == rd2["status"]).all() and (re2["iter"][ok2] == rd2["iter"][ok2]).all()
+    assert _rel(re2["control"][ok2], rd2["control"][ok2]) <= 1e-9
+    assert np.abs(re2["control"][ok2 & ok] - re["control"][ok2 & ok]).max() > 1e-5

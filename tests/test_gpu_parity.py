@@ -1778,3 +1778,46 @@ def test_one_new_reference_for_every_instance(oracle):
     with pytest.raises(Exception):
         eng.set_cost_reference(0, xref2.reshape(-1))
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b", [4096, 24576])
+def test_mixed_cost_reference_trajectory(oracle, monkeypatch, b):
+    """a full-size MixedCost with repeating blocks (costFunctions.cpp:173-210; the columns of x_N zero) as a per-step entry with the
+    reference of the step: on the tier's own sweep (batch 4096) and behind the lane pass (24576); against the dense path, with
+    per-instance references, and a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=35)
+    N, nx = wl["N"], 6
+    rng = np.random.default_rng(6)
+    M0, N0 = np.hstack([np.zeros((3, 3)), np.eye(3)]), 0.05 * np.eye(3)
+    pk = 0.05 * np.sin(0.4 * np.arange(N))[:, None] * np.array([1.0, -0.5, 0.3])[None, :]
+    mixed = dict(kind="mixed", M=np.hstack([np.kron(np.eye(N), M0), np.zeros((3 * N, nx))]), N=np.kron(np.eye(N), N0), p=pk.reshape(-1),
+                 weights=np.tile([2.0, 3.0, 1.5], N))
+    costs = [wl["costs"][0], mixed, wl["costs"][1]]
+    refs = np.tile(pk.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, pk.size))
+    out = {}
+    for mode in ("dense", "steps"):
+        monkeypatch.delenv("COPRA_NO_STAGE_REFS", raising=False)
+        if mode == "dense":
+            monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        ra = eng.results()
+        eng.set_cost_reference(1, refs)
+        eng.solve()
+        out[mode] = (ra, eng.results(), eng.layout_info(), eng.lane_pass_info())
+        eng.close()
+    assert out["steps"][2]["lds_bytes"] < out["dense"][2]["lds_bytes"] and out["steps"][3][0] == (b >= 20480)
+    for which in (0, 1):
+        r0, r1 = out["dense"][which], out["steps"][which]
+        ok = r0["status"] == 0
+        assert ok.sum() > b // 2 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).all()
+        assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9
+    pick = np.arange(0, b, 211)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], N, costs, wl["cstrs"], nthreads=8)
+    okp = ref["status"] == 0
+    r1 = out["steps"][0]
+    assert (r1["status"][pick] == ref["status"]).all() and (r1["iter"][pick][okp] == ref["iter"][okp]).all()
+    assert _rel(r1["control"][pick][okp], ref["control"][okp]) <= RTOL

@@ -78,6 +78,12 @@ for seed in range(nseeds):
             costs[1] = dict(kind="control", N=np.kron(np.eye(N), np.atleast_2d(c1["N"])), p=uk.reshape(-1),
                             weights=np.tile(np.asarray(c1["weights"], dtype=float), N))
             forms.append("uref")
+    if com and rng.random() < 0.25:  # a MixedCost reference trajectory (velocity + a share of the control)
+        M0, N0 = np.hstack([np.zeros((3, 3)), np.eye(3)]), 0.05 * np.eye(3)
+        pm = 0.05 * rng.standard_normal((N, 3))
+        costs.append(dict(kind="mixed", M=np.hstack([np.kron(np.eye(N), M0), np.zeros((3 * N, nx))]), N=np.kron(np.eye(N), N0), p=pm.reshape(-1),
+                          weights=np.tile([2.0, 3.0, 1.5], N)))
+        forms.append("mref")
     out = {}
     for mode in ("old", "new"):
         for e in OLD:
