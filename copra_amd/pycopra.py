@@ -291,10 +291,14 @@ class LMPC:
         1: they are up to the references p -- the only way the reference's API has to move a reference trajectory is a NEW cost object
         (M, N, p are constructor arguments) --, which go to the engine that exists (copra_batch_set_cost_reference); 2: anything else"""
         built = self._built_costs
-        if built is None or len(built) != len(self._costs):
+        if built is None:  # (costs that are not the built-in classes: the list alone decides, as before)
+            return 2 if self._costs_dirty else 0
+        if len(built) != len(self._costs):
             return 2
         same = lambda a, b: (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and np.array_equal(a, b))
         for c, (kind, M, N, w, _) in zip(self._costs, built):
+            if not all(hasattr(c, a) for a in ("_M", "_N", "_p", "_w")):  # (not one of the built-in classes)
+                return 2
             if c.kind != kind or not same(c._w, w) or not same(c._M, M) or not same(c._N, N):
                 return 2
         rc = 0
@@ -322,7 +326,8 @@ class LMPC:
         self._dirty = self._costs_dirty = False
         self.handle_builds += 1
         cp = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)
-        self._built_costs = [(c.kind, cp(c._M), cp(c._N), cp(c._w), cp(c._p)) for c in self._costs]
+        builtin = all(hasattr(c, a) for c in self._costs for a in ("_M", "_N", "_p", "_w"))
+        self._built_costs = [(c.kind, cp(c._M), cp(c._N), cp(c._w), cp(c._p)) for c in self._costs] if builtin else None
         return self._eng
 
     def select_qp_solver(self, flag):
