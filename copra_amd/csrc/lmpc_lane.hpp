@@ -210,6 +210,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             const double* const pr = (P.cost_p[tt] ? P.cost_p[tt] + (size_t)li0 * ct.prows : P.params + ct.offP) + kk * ps;
 #pragma unroll
             for (int r = 0; r < 6; ++r) pvk[t][r] = pr[r < rc ? r : (rc > 0 ? rc - 1 : 0)]; // (rows past the term's: zero coefficients)
+            // (Measured and dropped: scalar loads for a controller-wide reference -- the same value for every lane --: the step 0.360 ->
+            //  0.370 ms, they come back out of order and every wait for one of them is a wait for the LDS traffic of the sweep as well;
+            //  the loads requested at the top of the stage and h added to the affine column behind the products of M: 0.360 -> 0.361 ms.)
         }
         double hk[NZ];
 #pragma unroll

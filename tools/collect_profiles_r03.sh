@@ -47,6 +47,9 @@ python tools/exp/lane_threshold.py 2>&1 | grep -v amdgpu.ids > $R/lane_threshold
 python tools/exp/selection_rows.py 2>&1 | grep -v amdgpu.ids > $R/selection_rows.txt || true
 python tools/exp/terminal_rows.py 2>&1 | grep -v amdgpu.ids > $R/terminal_rows.txt || true
 python tools/exp/reference_trajectory.py 2>&1 | grep -v amdgpu.ids > $R/reference_trajectory.txt || true
+rm -rf $O/rt_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rt_stats -- python3 tools/exp/reference_trajectory.py profile > $O/rt_run.log 2>&1 || true
+find $O/rt_stats -name "*kernel_stats.csv" -exec cp {} $R/reference_trajectory_kernel_stats.csv \;
 # ---- probes and side measurements ----
 tools/exp/mfma_chain_probe > $R/mfma_chain_probe.txt 2>&1 || true
 python tools/pcie_probe.py 2>&1 | grep -v amdgpu.ids > $R/pcie_probe.txt

@@ -15,6 +15,15 @@ N = wl["N"]
 ts = np.linspace(0.0, 1.0, N + 1)
 xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
 costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)), wl["costs"][1]]
+if len(sys.argv) > 1 and sys.argv[1] == "profile":  # rocprofv3 --kernel-trace --stats -- python3 tools/exp/reference_trajectory.py profile
+    eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    for _ in range(25):
+        eng.solve()
+    eng.synchronize()
+    print("lane pass", eng.lane_pass_info())
+    eng.close()
+    sys.exit(0)
 out = {}
 MODES = {"dense contraction": {"COPRA_NO_STAGE_REFS": "1"}, "per-step, factor-only tier": {"COPRA_NO_RIC": "1"},
          "per-step, tier's own sweep": {"COPRA_NO_LANE_PASS": "1"}, "per-step with p_k": {}, "own reference per instance": {}}
