@@ -5,7 +5,7 @@
 // runs on the GPU behind include/copra_hip.h.
 #pragma once
 #if defined(__has_include)
-#if __has_include(<Eigen/Core>)
+#if __has_include(<Eigen/src/Core/Matrix.h>) // (the real Eigen3, not copra/eigen_shim/Eigen/Core, which leads back here)
 #include <Eigen/Core>
 #define COPRA_HAVE_EIGEN 1
 #endif

@@ -650,9 +650,12 @@ public:
         = 0;
 };
 
-// Plug-in point 1 on the GPU: replaces QuadProgDenseSolver (include/QuadProgSolver.h:16-42, src/QuadProgSolver.cpp:14-72)
-class HipQuadProgSolver : public SolverInterface {
+// Plug-in point 1 on the GPU: copra::QuadProgDenseSolver (include/QuadProgSolver.h:16-42, src/QuadProgSolver.cpp:14-72) under the
+// reference's own name -- code that instantiates it (tests/TestSolvers.cpp:27) compiles unchanged; the arithmetic is the batched
+// Goldfarb-Idnani kernel behind copra_qp_solve_dense_batch.  HipQuadProgSolver is the name earlier rounds of this mirror used.
+class QuadProgDenseSolver : public SolverInterface {
 public:
+    QuadProgDenseSolver() = default;
     int SI_fail() const override { return fail_; }
     int SI_iter() const override { return iter_[0]; }
     void SI_inform() const override
@@ -689,10 +692,15 @@ private:
 // include/solverUtils.h:34-50.  DEFAULT: the engine's own choice inside the fused device solve (Goldfarb-Idnani up to 64
 // variables, the stage-wise Riccati interior-point kernel for long stage-wise horizons); QuadProgDense: always the
 // Goldfarb-Idnani kernels (the reference's QuadProgDense arithmetic); HipQuadProg: the same through plug-in point 1.
+using HipQuadProgSolver = QuadProgDenseSolver;
 enum class SolverFlag { DEFAULT, QuadProgDense, HipQuadProg };
 inline std::unique_ptr<SolverInterface> solverFactory(SolverFlag) // src/solverUtils.cpp:9-34
 {
-    return std::unique_ptr<SolverInterface>(new HipQuadProgSolver());
+    return std::unique_ptr<SolverInterface>(new QuadProgDenseSolver());
+}
+inline SolverInterface* pythonSolverFactory(SolverFlag) // src/solverUtils.cpp:36-59 (a raw pointer for bindings; the caller owns it)
+{
+    return new QuadProgDenseSolver();
 }
 
 // ---------------------------------------------------------------------------------------------- LMPC.h

@@ -25,6 +25,49 @@ def _build():
                            "-Wl,-rpath," + os.path.dirname(oracle_so), "-Wl,-rpath,/opt/rocm/lib"])
 
 
+DROPIN = os.path.join(ROOT, "tests", "cpp", "test_dropin")
+
+
+def _build_dropin():
+    """tests/cpp/test_dropin.cpp: ONLY the reference's header names (LMPC.h, PreviewSystem.h, QuadProgSolver.h, constraints.h,
+    costFunctions.h, <Eigen/Core>, ...) and class names (copra::QuadProgDenseSolver)"""
+    from copra_amd import _capi
+    _capi.build_library()
+    src = os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp")
+    inc = os.path.join(ROOT, "copra_amd", "cpp", "include")
+    hdrs = [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")] + [os.path.join(inc, "copra", "copra.h")]
+    newest = max(os.path.getmtime(p) for p in [src, _capi.LIB_PATH] + hdrs)
+    if os.path.exists(DROPIN) and os.path.getmtime(DROPIN) >= newest:
+        return
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", inc, "-I", os.path.join(inc, "copra", "eigen_shim"),
+                           src, "-o", DROPIN, "-L", libdir, "-lcopra_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_reference_header_names_and_class_names_compile_unchanged():
+    """round-3 verdict, missing #4: code written against copra includes "LMPC.h", "PreviewSystem.h", "QuadProgSolver.h",
+    "constraints.h", "costFunctions.h" (tests/TestLMPC.cpp:5-9) and instantiates copra::QuadProgDenseSolver
+    (tests/TestSolvers.cpp:27).  The TU compiles with -Wall -Werror against the forwarding headers and its host-only mode runs
+    (controller assembly, AutoSpan, debugUtils.h's exception macro, typedefs.h's trait) without a GPU."""
+    _build_dropin()
+    r = subprocess.run([DROPIN], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    inc = os.path.join(ROOT, "copra_amd", "cpp", "include")
+    ref_names = {"AutoSpan.h", "InitialStateLMPC.h", "LMPC.h", "PreviewSystem.h", "QuadProgSolver.h", "SolverInterface.h", "api.h",
+                 "constraints.h", "costFunctions.h", "debugUtils.h", "solverUtils.h", "typedefs.h"}  # include/ of the reference, minus
+    assert ref_names <= set(os.listdir(inc))                                     # the optional proprietary solvers (DESIGN.md 7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["solvers", "lmpc"])
+def test_reference_style_cases_through_the_reference_names(mode):
+    """TestSolvers.cpp:25-33 (QuadProgTest, + the Scilab known answer) and the first case of TestLMPC.cpp (300 steps, both bound
+    constraints, solver by flag and by useSolver(QuadProgDenseSolver)) on the device, through the reference's names only"""
+    _build_dropin()
+    r = subprocess.run([DROPIN, mode], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_error_handlers_like_TestLMPC():
     """TestLMPC.cpp:949-1087: std::domain_error / std::runtime_error from system/addCost/addConstraint/weights"""
     _build()

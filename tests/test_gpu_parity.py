@@ -2,10 +2,14 @@
 
 Tolerance: BASELINE.json north_star -- controls / trajectories within 1e-6 relative of the CPU QuadProgDense path.
 We assert  max_i |u_i - u_ref,i| / max(|u_ref,i|, ABS_FLOOR) <= 1e-6  (and the same for the trajectory) plus identical
-status codes: the true relative error of every entry larger than ABS_FLOOR = 1e-2 in magnitude (the bounds of these problems
-are O(1)); entries below it (controls and states that vanish at the optimum) are held to the ABSOLUTE error 1e-2 * 1e-6 = 1e-8.
-(With a floor of 1e-3 two of 94 tests miss the bar by entries of size ~1e-3 whose absolute error, 1e-9, is what the condition
-number ~1e6 of those Hessians allows EITHER side in FP64 -- measured in round 3, gpurun_out/r03_gputest_all.log.)
+status codes: the true relative error of every entry larger than ABS_FLOOR = 1e-3 in magnitude (the bounds of these problems
+are O(1)); entries below it (controls and states that vanish at the optimum) are held to the ABSOLUTE error 1e-3 * 1e-6 = 1e-9.
+
+Where the ORACLE itself is further than that from the optimum (ill-conditioned Hessians: the CPU path's Goldfarb-Idnani arithmetic
+rotates J = L^-T once per added constraint) the device is held to 1e-6 of the extended-precision CERTIFIED optimum instead
+(tests/truth.py: the reference's QP evaluated in 80-bit arithmetic from the primary data, KKT solve on the active set, optimality
+certificate) and the oracle's own distance from it is measured in the same test -- `_check_against_truth`; each such test states
+both distances in its docstring.  (Round 3 ran with a floor of 1e-2 instead.)
 """
 import os
 
@@ -17,7 +21,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6
 
 
-ABS_FLOOR = 1e-2
+ABS_FLOOR = 1e-3
 
 
 def _rel(a, b, floor=ABS_FLOOR):
@@ -51,6 +55,35 @@ def _check(wl, batch, oracle):
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL
     assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     return eng, res, ref
+
+
+def _check_against_truth(wl, costs, res, ref, initial_state=None, x0_opt=None, picks=None, oracle_bar=None):
+    """every solved instance (or `picks`) against the certified extended-precision optimum (tests/truth.py), entry by entry with
+    the floor of this file: the DEVICE must be within RTOL; the oracle's distance is returned (and held to `oracle_bar` when given,
+    so that a docstring's figure cannot rot).  The active set is identified from the ORACLE's solution -- the certificate makes the
+    result independent of the guess."""
+    import truth
+    ist = initial_state
+    dev_u = dev_x = ora_u = ora_x = 0.0
+    ks = range(len(res["status"])) if picks is None else picks
+    for k in ks:
+        if ref["status"][k] != 0:
+            continue
+        io = None if ist is None else dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+        zg = ref["control"][k] if ist is None else np.concatenate([ref["x0_opt"][k], ref["control"][k]])
+        t = truth.solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"], zg, initial_state=io)
+        dev_u = max(dev_u, _rel(res["control"][k], t["control"]))
+        dev_x = max(dev_x, _rel(res["trajectory"][k], t["trajectory"]))
+        ora_u = max(ora_u, _rel(ref["control"][k], t["control"]))
+        ora_x = max(ora_x, _rel(ref["trajectory"][k], t["trajectory"]))
+        if x0_opt is not None:
+            assert np.abs(x0_opt[k] - t["x0_opt"]).max() <= 1e-9
+    print("   distance from the certified optimum (floor %g): device U %.2e X %.2e | oracle U %.2e X %.2e"
+          % (ABS_FLOOR, dev_u, dev_x, ora_u, ora_x))
+    assert dev_u <= RTOL and dev_x <= RTOL, (dev_u, dev_x, ora_u, ora_x)
+    if oracle_bar is not None:
+        assert max(ora_u, ora_x) <= oracle_bar, (ora_u, ora_x)
+    return dict(device=(dev_u, dev_x), oracle=(ora_u, ora_x))
 
 
 def test_library_is_native_and_sees_gfx950():
@@ -124,6 +157,30 @@ def test_headline_full_size_properties(oracle):
     xr = np.einsum("bij,bkj->bki", wl["A"], x[:, :-1]) + np.einsum("bij,bkj->bki", wl["B"], u) + wl["d"][:, None, :]
     assert np.abs(xr - x[:, 1:]).max() <= 1e-9
     assert np.abs(x[:, 0] - wl["x0"]).max() <= 1e-12
+
+
+def test_config4_seed2_batch_as_eight_shards_on_one_gpu():
+    """BASELINE.json configs[3] (batch 262144, seed 2, 8 x 32768 contiguous shards, one RCCL gather per step) has no 8-GPU box in
+    this pool: its eight shards run here one after the other on ONE GPU through the very step loop a rank of `bench.py --gpus 8`
+    runs (sharding.GatherLoop) with a one-rank RCCL group doing the gather.  Per shard: rank 0's checksum verification and 17
+    instances against the CPU oracle (U, X, status, both iteration counters); over all 262144: every instance solved, control and
+    velocity bounds (TestLMPC.cpp:82-83 slack), x_{k+1} = A x_k + B u_k + d.  (tests/run_config4_single_gpu.py, a child process.)"""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "run_config4_single_gpu.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["instances"] == 262144 and out["solved_ok"] == 262144 and len(out["shards"]) == 8 and out["rccl_world_size"] == 1
+    for sh in out["shards"]:
+        assert sh["range"] == [sh["shard"] * 32768, (sh["shard"] + 1) * 32768]
+        for key in ("gathered_matches_checksum", "status_agree", "iterations_agree", "all_solved", "control_bounds_hold",
+                    "velocity_bounds_hold", "x0_is_first_state"):
+            assert sh[key], (sh["shard"], key)
+        assert sh["max_rel_u_err"] <= RTOL and sh["max_rel_x_err"] <= RTOL and sh["rollout_residual"] <= 1e-9
+        assert sh["lane_pass"][0]  # (a shard of 32768 runs the one-instance-per-lane pass in front of the tier)
+    assert sum(out["active_set_iteration_histogram"].values()) == 262144
 
 
 def test_dense_qp_plugin_point(oracle):
@@ -286,7 +343,11 @@ def test_two_tier_overflow_on_gpu(oracle):
 
 def test_headline_shape_with_a_general_output_map(oracle):
     """compile-time headline shape, TrajectoryCost with a general 6 x 6 M and with a 5-row selection (the identity M of
-    the bench workload takes a shortcut in the cost phase: CostTerm::ident)"""
+    the bench workload takes a shortcut in the cost phase: CostTerm::ident).
+    Status codes and both iteration counters equal the oracle's on every instance.  Values: the general M gives Hessians of
+    condition ~1e6, and on 15 of the 512 instances the ORACLE is more than 1e-7 (worst: 2.1e-6, instance 105) away from the certified
+    optimum on controls of size ~1e-3 -- so the device is held to 1e-6 of the CERTIFIED optimum on all 512 (tests/truth.py) and to
+    (oracle's distance + 1e-6) of the oracle; the selection variant is benign (oracle 1.1e-8 from the optimum)."""
     from copra_amd import workloads
     b = 512
     wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=5)
@@ -300,8 +361,10 @@ def test_headline_shape_with_a_general_output_map(oracle):
         ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl2["costs"], wl["cstrs"], nthreads=8)
         assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
         ok = ref["status"] == 0
-        assert ok.sum() > b // 2 and _rel(res["control"][ok], ref["control"][ok]) <= RTOL
-        assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+        assert ok.sum() > b // 2
+        dist = _check_against_truth(wl, wl2["costs"], res, ref, oracle_bar=5e-6)
+        assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL + dist["oracle"][0]
+        assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL + dist["oracle"][1]
 
 
 def test_factor_only_layout_steps_down_its_ladder(oracle):
@@ -1232,7 +1295,9 @@ def test_riccati_factor_tier_shorter_horizons(oracle, N):
 def test_sizes_beyond_the_condensed_kernels(oracle):
     """round-2 verdict item 8: more than 512 decision variables, and InitialStateLMPC with more than 16 states, are accepted when
     the controller is stage-wise: the Riccati interior-point kernel has no n x n object.  (12, 6, 120) = 732 variables (the
-    config-5 controller on a longer horizon, R = 1e-2 I) and (18, 2, 40) InitialStateLMPC, a few instances against the oracle;
+    config-5 controller on a longer horizon, R = 1e-2 I) and (18, 2, 40) InitialStateLMPC, a few instances against the oracle
+    (norm-wise) and against the certified extended-precision optimum (entry-wise, floor 1e-3: device <= 1e-6; the oracle is
+    2.6e-5 ... 3.7e-5 away on the 732-variable case, 3e-12 on the other);
     the condensed solver cannot be selected for them, and a controller of that size that is NOT stage-wise is refused."""
     from copra_amd import BatchLMPC, workloads
     from copra_amd import _capi
@@ -1248,14 +1313,21 @@ def test_sizes_beyond_the_condensed_kernels(oracle):
         eng.solve()
         res, x0o = eng.results(), eng.initial_state()
         assert (res["status"] == 0).all()
-        for k in range(min(b, 3)):
+        nk = min(b, 3)
+        ros = []
+        for k in range(nk):
             io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
             ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
             assert ro["status"] == 0
-            # (norm-wise, as for config 5: 732 variables through the CPU path's dense Goldfarb-Idnani leave ~ 1e-8 absolute on entries
-            #  that vanish at the optimum)
+            ros.append(ro)
+            # against the CPU path norm-wise (as for config 5): 732 variables through its dense Goldfarb-Idnani leave it 3.7e-5
+            # (entry-wise, floor 1e-3) away from the certified optimum on controls that vanish there -- measured below
             assert _rel_vec(res["control"][k], ro["control"]) <= RTOL and _rel_vec(res["trajectory"][k], ro["trajectory"]) <= RTOL
             assert np.abs(x0o[k] - ro["x0_opt"]).max() <= 1e-7
+        # ... and ENTRY-WISE against the certified optimum (tests/truth.py): the device within 1e-6, the oracle within 1e-4
+        refd = dict(status=np.zeros(nk, dtype=int), control=np.array([r["control"] for r in ros]),
+                    trajectory=np.array([r["trajectory"] for r in ros]), x0_opt=np.array([r["x0_opt"] for r in ros]))
+        _check_against_truth(wl, wl["costs"], res, refd, initial_state=ist, x0_opt=x0o, picks=range(nk), oracle_bar=1e-4)
         with pytest.raises(Exception):
             eng.dump_qp(0)
         eng.close()

@@ -230,3 +230,56 @@ def test_initial_state_default_bounds_pin_x0(oracle):
     assert a["status"] == b["status"] == 0
     assert np.abs(a["x0_opt"] - pb["x0"]).max() < 1e-12
     assert np.abs(a["control"] - b["control"]).max() < 1e-7 * (1 + np.abs(b["control"]).max())
+
+
+# ---- tests/truth.py: the extended-precision certified optimum the GPU parity tests hold the device to where the oracle is the
+# ---- side that is off.  Pinned here: its two arithmetics against each other, and against the 60-digit config-5 fixtures.
+def test_truth_longdouble_agrees_with_50_digit_arithmetic(oracle):
+    import truth
+    from copra_amd import workloads
+    wl = workloads.com_preview(4, v_max=0.3, u_max=1.5, seed=5)
+    ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    for k in (1, 3):
+        args = (wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], ref["control"][k])
+        tl, tm = truth.solve(*args), truth.solve(*args, arith="mp")
+        assert tm["stationarity"] <= 1e-40 and tl["stationarity"] <= 1e-15 and tm["min_mult"] > 0 and tm["min_inactive_slack"] > 0
+        assert tl["n_active"] == tm["n_active"] and sum(tl["n_active"]) > 0
+        assert np.abs(tl["control"] - tm["control"]).max() <= 1e-15 and np.abs(tl["trajectory"] - tm["trajectory"]).max() <= 1e-15
+        assert truth.rel(ref["control"][k], tl["control"]) <= 1e-6  # (a benign Hessian: the oracle is at the optimum)
+
+
+def test_truth_reproduces_the_60_digit_config5_fixture():
+    """the certified optimum of BASELINE config 5 at R = 1e-6 I (cond 2e12) from tests/golden/gen_truth_config5.py (mpmath, 60 digits,
+    its own builder) against truth.py's 80-bit evaluation of the same problem, started from a deliberately rough guess"""
+    import test_golden as G
+    import truth
+    wl, picks = G.config5_truth_cases()
+    ist = wl["initial_state"]
+    k = picks[0]
+    io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+    zg = np.concatenate([G.TRUTH5["x0_opt_%d" % k], G.TRUTH5["control_%d" % k]])
+    zg = zg + 1e-7 * np.cos(np.arange(zg.size))
+    t = truth.solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], zg, initial_state=io)
+    assert truth.rel(t["control"], G.TRUTH5["control_%d" % k]) <= 1e-9
+    assert truth.rel(t["trajectory"], G.TRUTH5["trajectory_%d" % k]) <= 1e-9
+    assert np.abs(t["x0_opt"] - G.TRUTH5["x0_opt_%d" % k]).max() <= 1e-12
+
+
+def test_where_the_oracle_is_the_side_that_is_off(oracle):
+    """the figure in test_headline_shape_with_a_general_output_map's docstring: with a general 6 x 6 output map the CPU path ends
+    2.1e-6 (entry-wise, floor 1e-3) away from the certified optimum on instance 105 of that batch -- more than the 1e-6 the device
+    is held to.  If the oracle ever gets better than documented this fails, and the GPU test's bars should be tightened."""
+    import truth
+    from copra_amd import workloads
+    wl = workloads.com_preview(512, v_max=0.3, u_max=1.5, seed=5)
+    rng = np.random.default_rng(2)
+    c0 = wl["costs"][0]
+    Mg = np.eye(6) + 0.2 * rng.standard_normal((6, 6))
+    costs = [dict(kind="trajectory", M=Mg, p=Mg @ c0["p"], weights=c0["weights"]), wl["costs"][1]]
+    ks = [105, 3, 200]
+    ref = oracle.lmpc_solve_batch(wl["A"][ks], wl["B"][ks], wl["d"][ks], wl["x0"][ks], wl["N"], costs, wl["cstrs"])
+    e = []
+    for i, k in enumerate(ks):
+        t = truth.solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"], ref["control"][i])
+        e.append(truth.rel(ref["control"][i], t["control"]))
+    assert 1e-6 < e[0] <= 5e-6 and max(e[1:]) <= 1e-6
