@@ -46,7 +46,7 @@ def parity_rel(a, b, floor=1e-3):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector = matrix FP64
-PMC_SUMMARY = os.path.join("profiles", "r03", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r04", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
 
 
 SPIN_UP_SOLVES = 40  # untimed solves before the warm-up steps (clock ramp; see main)
@@ -135,8 +135,8 @@ def cpp_single_solve_latency(np):
                      "cpu_path_iterations": int(ro["iter"][0, 0])}
     # a tracking controller's tick: the TrajectoryCost replaced by a new one with the moved reference trajectory, then solve()
     # (tests/cpp/test_api.cpp: tracking_case) -- on the handle that exists, and with a new handle per tick (what a swapped cost cost before)
-    for name, env in (("tracking_tick", {}), ("tracking_tick_new_handle_per_tick", {"COPRA_MIRROR_NEW_HANDLE_PER_COST_CHANGE": "1"})):
-        r = subprocess.run([test_cpp_api.EXE, "tracking", "300"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    for name, extra in (("tracking_tick", []), ("tracking_tick_new_handle_per_tick", ["newhandle"])):
+        r = subprocess.run([test_cpp_api.EXE, "tracking", "300"] + extra, capture_output=True, text=True, timeout=300)
         m = re.search(r"tracking_tick_us median ([0-9.]+) mean ([0-9.]+) min ([0-9.]+) p95 ([0-9.]+)", r.stdout)
         out[name] = {"median_us": float(m.group(1)), "p95_us": float(m.group(4))} if m else {"error": (r.stdout + r.stderr)[-300:]}
     ok = out.get("benchmark_instance", {})
@@ -253,11 +253,20 @@ def extra_measurements(np, torch, dev):
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     t = on_device(wl)
     eng.set_system(*t)
-    for _ in range(4):  # (the layout controller adapts over the first solves)
+    # what a one-shot caller sees: the FIRST solve of the controller (its first-tier layout is chosen from the lane pass's histogram of
+    # violated rows before the tier is launched; one synchronisation inside) -- then the steady state
+    eng.solve()
+    eng.synchronize()
+    first_ms = eng.last_solve_seconds() * 1e3
+    first_layout = eng.layout_info()
+    for _ in range(4):  # (adapt_layout still looks at the overflow counts of the first solves)
         eng.solve()
     rate, sec = timed_rate(eng, b)
     it = eng.results()["iter"][:, 0]
     out["tight_workload_vmax0.25_umax1.2"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5,
+                                              "first_solve_ms": first_ms, "first_solve_over_steady": first_ms / (sec * 1e3),
+                                              "first_solve_active_capacity": first_layout["active_capacity"],
+                                              "steady_active_capacity": eng.layout_info()["active_capacity"],
                                               "mean_active_set_iters": float(it.mean()), "max_active_set_iters": int(it.max())}
     eng.close()
     # the dense Psi' W Psi contraction on v_mfma_f64_16x16x4 (north star: "MFMA used only for the dense contraction"): the
@@ -268,9 +277,7 @@ def extra_measurements(np, torch, dev):
     dense_costs = [autospan_cost(dict(c0, p=np.tile(c0["p"], wl["N"] + 1))), wl["costs"][1]]
     # (such a block-diagonal entry is what the plan builder recognises as a per-step cost with the reference of the step -- see the next
     #  entry; this one measures the dense contraction itself, so the classification is switched off while its plan is built)
-    os.environ["COPRA_NO_STAGE_REFS"] = "1"
-    eng = BatchLMPC(6, 3, wl["N"], b, dense_costs, wl["cstrs"])
-    os.environ.pop("COPRA_NO_STAGE_REFS", None)
+    eng = BatchLMPC(6, 3, wl["N"], b, dense_costs, wl["cstrs"], options=dict(no_stage_refs=1))
     t = on_device(wl)
     eng.set_system(*t)
     rate, sec = timed_rate(eng, b, reps=3)
@@ -447,7 +454,6 @@ def main():
                          "TrajectoryBound(63 rows)+ControlBound (BASELINE configs[2])")
     if args.dense_hessian:
         from copra_amd.autospan import autospan_cost
-        os.environ["COPRA_NO_STAGE_REFS"] = "1"  # (measure the dense contraction, not the per-step form the plan builder would recognise)
         c0 = wl["costs"][0]
         wl["costs"] = [autospan_cost(dict(c0, p=np.tile(c0["p"], N + 1))), wl["costs"][1]]
     Ab, Bb, db, xb = to_abi_layout(wl["A"], wl["B"], wl["d"], wl["x0"])
@@ -461,7 +467,8 @@ def main():
     slabs = [alloc_result_slab(batch, n, X, dev) for _ in range(n_slabs)]
     views0 = slabs[0][1]
 
-    eng = BatchLMPC(nx, nu, N, batch, wl["costs"], wl["cstrs"])
+    # (--dense-hessian measures the dense contraction, not the per-step form the plan builder would recognise in the block-diagonal entry)
+    eng = BatchLMPC(nx, nu, N, batch, wl["costs"], wl["cstrs"], options=dict(no_stage_refs=1) if args.dense_hessian else None)
     eng.set_system(tA, tB, td, tx0)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -577,10 +584,16 @@ def main():
         dominant = "copra_lmpc_fused_ric_kernel"  # (plan_builder.hpp: what the headline controller runs on)
         prof = os.path.join(ROOT, PMC_SUMMARY)
         if not os.path.exists(prof):
-            prof = os.path.join(ROOT, "profiles", "r02", "headline_rocprof_summary.json")
+            prof = os.path.join(ROOT, "profiles", "r03", "headline_rocprof_summary.json")
+        traffic_stale = None
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
-                ctr = json.load(open(prof))["counters"]
+                prof_json = json.load(open(prof))
+                # the counters are quoted from a committed profile of this command: they describe THIS run only if that profile was
+                # taken on the build of the library that is loaded now (tools/pmc_summary.py records its source hash)
+                from copra_amd import _capi
+                traffic_stale = prof_json.get("library_source_hash") != _capi.library_source_hash()
+                ctr = prof_json["counters"]
                 # the dominant kernel: the first-tier fused kernel (Riccati-factor tier `copra_lmpc_fused_ric_kernel` since
                 # round 2; `copra_lmpc_fused_tri_kernel` before) -- the one with the most wave cycles in the profile
                 cands = [k for k in ctr if "copra_lmpc_fused_ric_kernel" in k or "copra_lmpc_fused_tri_kernel" in k]
@@ -645,6 +658,8 @@ def main():
             "kernel_solves_per_s": batch / kern,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_stale": traffic_stale,  # True: the quoted counters were taken on ANOTHER build of the library
+                         "library_source_hash": __import__("copra_amd")._capi.library_source_hash(),
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "kernel": dominant, "algorithmic_bytes_per_solve": alg_bytes,
                          "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "

@@ -40,6 +40,63 @@ class InitialStateDesc(C.Structure):
     _fields_ = [("R", _dp), ("r", _dp)]
 
 
+class Options(C.Structure):
+    """copra_options_t (include/copra_hip.h): every switch the engine consults, fixed when the controller is created.  The library reads
+    no environment variable; experiments steer it through the ONE variable this module parses, COPRA_OPTIONS="name=value,name=value"
+    (e.g. COPRA_OPTIONS=no_lane_pass=1,lane_min_batch=-1), which seeds OPTIONS below."""
+    _fields_ = ([("struct_size", C.c_int)]
+                + [(n, C.c_int) for n in ("no_stage_refs", "no_step_rows", "no_selection_rows",
+                                           "no_ric", "no_tri", "ric_general", "no_dense_layout", "no_q1regs", "no_ladder", "no_packed",
+                                           "ric_any_shape", "tri_min", "tri_k", "ric_k", "overflow_share",
+                                           "no_lane_pass", "no_lane_handover", "lane_min_batch", "lane_share", "lane_keep",
+                                           "lane_tables_in_memory", "lane_dbg", "no_ric_shared",
+                                           "no_riccati", "no_ric_fast", "riccati_per_cu", "large_per_cu", "large_grid", "large_no_w4",
+                                           "large_params_lds")]
+                + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol", "ric_s0", "ric_lam0")]
+                + [("recorded_events", C.c_int), ("debug", C.c_int)])
+
+
+OPTION_NAMES = tuple(n for n, _ in Options._fields_ if n != "struct_size")
+
+
+def _options_from_env():
+    out = {}
+    for item in os.environ.get("COPRA_OPTIONS", "").replace(";", ",").split(","):
+        item = item.strip()
+        if not item:
+            continue
+        k, _, v = item.partition("=")
+        k = k.strip()
+        if k not in OPTION_NAMES:
+            raise ValueError("COPRA_OPTIONS: unknown option %r (known: %s)" % (k, ", ".join(OPTION_NAMES)))
+        out[k] = float(v) if k.startswith("ric_") and k.endswith(("tol", "s0", "lam0")) else int(v or "1")
+    return out
+
+
+# defaults every controller created through this module starts from (tests: monkeypatch.setitem(_capi.OPTIONS, name, value));
+# BatchLMPC(..., options={...}) overrides them per controller
+OPTIONS = _options_from_env()
+
+
+def make_options(overrides=None):
+    """an Options struct: the library's built-in defaults, then OPTIONS, then `overrides`"""
+    o = Options()
+    o.struct_size = C.sizeof(Options)
+    for src in (OPTIONS, overrides or {}):
+        for k, v in src.items():
+            if k not in OPTION_NAMES:
+                raise ValueError("unknown engine option %r" % k)
+            setattr(o, k, v)
+    return o
+
+
+def apply_default_options():
+    """hand OPTIONS to the library as its process-wide defaults (the entry points without an options argument -- the dense-QP
+    plug-in point, copra_plan_check, the C++ mirror's handles -- use those)"""
+    o = make_options()
+    check(lib().copra_set_default_options(C.byref(o)))
+
+
 class CopraDomainError(ValueError):
     """std::domain_error of the reference (include/debugUtils.h:32-36)"""
 
@@ -203,6 +260,13 @@ def lib():
         L.copra_batch_create.restype = C.c_int
         L.copra_batch_create.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc), C.c_int,
                                          C.POINTER(CstrDesc)]
+        L.copra_batch_create_with_options.restype = C.c_int
+        L.copra_batch_create_with_options.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc), C.c_int,
+                                                      C.POINTER(CstrDesc), C.POINTER(InitialStateDesc), C.POINTER(Options)]
+        L.copra_set_default_options.restype = C.c_int
+        L.copra_set_default_options.argtypes = [C.POINTER(Options)]
+        L.copra_options_init.restype = None
+        L.copra_options_init.argtypes = [C.POINTER(Options)]
         L.copra_batch_create_initial_state.restype = C.c_int
         L.copra_batch_create_initial_state.argtypes = [C.POINTER(vp), C.POINTER(Dims), C.c_int, C.POINTER(CostDesc),
                                                        C.c_int, C.POINTER(CstrDesc), C.POINTER(InitialStateDesc)]
@@ -268,6 +332,7 @@ def lib():
         L.copra_device_info.restype = C.c_int
         L.copra_device_info.argtypes = [_ip, _ip, C.c_char_p, C.c_int]
         L.copra_abi_version.restype = C.c_int
+        L.copra_source_hash.restype = C.c_char_p
         L.copra_preview_update.restype = C.c_int
         L.copra_preview_update.argtypes = [C.c_int] * 3 + [vp] * 6
         L.copra_batch_set_warm_start.restype = C.c_int
@@ -278,6 +343,11 @@ def lib():
         L.copra_batch_solver_info.argtypes = [vp]
         _lib = L
     return _lib
+
+
+def library_source_hash():
+    """the source hash compiled into the LOADED library (copra_source_hash)"""
+    return lib().copra_source_hash().decode()
 
 
 def check(rc):

@@ -29,9 +29,11 @@ def _is_torch(t):
 
 
 class BatchLMPC:
-    def __init__(self, nx, nu, N, batch, costs, cstrs, initial_state=None):
+    def __init__(self, nx, nu, N, batch, costs, cstrs, initial_state=None, options=None):
         """initial_state = dict(R=(nx,nx), r=(nx,)) turns the controller into a batched InitialStateLMPC
-        (include/InitialStateLMPC.h): decision vector [x0; U], see set_initial_state_bounds / initial_state."""
+        (include/InitialStateLMPC.h): decision vector [x0; U], see set_initial_state_bounds / initial_state.
+        options: dict of engine options (copra_options_t, include/copra_hip.h; names in _capi.OPTION_NAMES) on top of _capi.OPTIONS --
+        they choose which kernels run, never what they compute."""
         self._lib = _capi.lib()
         self.nx, self.nu, self.N, self.batch = int(nx), int(nu), int(N), int(batch)
         self.n = self.nu * self.N
@@ -43,14 +45,14 @@ class BatchLMPC:
         dims = _capi.Dims(self.nx, self.nu, self.N, self.batch)
         self._h = C.c_void_p()
         self.is_initial_state = initial_state is not None
+        opts = _capi.make_options(options)
+        isd = None
         if self.is_initial_state:
             Rm, rv = _capi.fcol(initial_state["R"]), _capi.fcol(initial_state["r"])
             self._keep.extend([Rm, rv])
-            isd = _capi.InitialStateDesc(_capi.dptr(Rm), _capi.dptr(rv))
-            _capi.check(self._lib.copra_batch_create_initial_state(C.byref(self._h), C.byref(dims), len(costs), cc,
-                                                                   len(cstrs), kk, C.byref(isd)))
-        else:
-            _capi.check(self._lib.copra_batch_create(C.byref(self._h), C.byref(dims), len(costs), cc, len(cstrs), kk))
+            isd = C.byref(_capi.InitialStateDesc(_capi.dptr(Rm), _capi.dptr(rv)))
+        _capi.check(self._lib.copra_batch_create_with_options(C.byref(self._h), C.byref(dims), len(costs), cc, len(cstrs), kk, isd,
+                                                              C.byref(opts)))
         self._sys = None
         self._outs = None
 
@@ -267,6 +269,7 @@ def qp_solve_dense_batch(Q, c, Aeq, beq, Aineq, bineq, XL, XU):
     """Batched QuadProgDenseSolver::SI_solve (src/QuadProgSolver.cpp:54-72) on the GPU; numpy, natural indexing:
     Q (b,n,n), c (b,n), Aeq (b,meq,n) or None, ...  Returns x (b,n), fail (b,), iter (b,2)."""
     L = _capi.lib()
+    _capi.apply_default_options()  # (this entry point has no handle: the process-wide defaults steer it)
     Q = np.asarray(Q, dtype=np.float64)
     b, n = Q.shape[0], Q.shape[1]
     Aeq = np.zeros((b, 0, n)) if Aeq is None else np.asarray(Aeq, dtype=np.float64).reshape(b, -1, n)

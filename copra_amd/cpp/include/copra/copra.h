@@ -981,11 +981,21 @@ protected:
         if (d.weights) c.w.assign(d.weights, d.weights + d.rows);
         return c;
     }
+public:
+    // (measurement aid of this mirror, no reference counterpart: rebuild the device-side controller whenever a cost object was
+    //  replaced, as the mirror did before it learnt to send a changed reference to the handle that exists)
+    static bool& newHandlePerCostChange()
+    {
+        static bool on = false;
+        return on;
+    }
+
+protected:
     // 0: the costs are what the handle was built from; 1: so they are up to the references p (pushed to the handle); 2: anything else
     int costsAgainstHandle()
     {
         if (!builtCostsKnown_ || spCost_.size() != builtCosts_.size()) return 2;
-        if (costsDirty_ && std::getenv("COPRA_MIRROR_NEW_HANDLE_PER_COST_CHANGE")) return 2; // (measurements: what a swapped cost cost before)
+        if (costsDirty_ && newHandlePerCostChange()) return 2; // (measurements: what a swapped cost cost before)
         auto same = [](const double* a, const std::vector<double>& b, size_t n) { return (a ? n : 0) == b.size() && (!a || std::equal(a, a + n, b.begin())); };
         std::vector<copra_cost_desc_t> now(spCost_.size());
         for (size_t t = 0; t < spCost_.size(); ++t) {
@@ -1000,6 +1010,9 @@ protected:
         int rc = 0;
         for (size_t t = 0; t < spCost_.size(); ++t) {
             if (same(now[t].p, builtCosts_[t].p, (size_t)now[t].rows)) continue;
+            // (a controller past the one-wave kernels would leave its fast kernels in per-instance-reference mode -- the LDS-resident
+            //  interior-point kernel above all, include/copra_hip.h --: there a new handle is worth more than the handle build)
+            if (copra_batch_lanes_per_instance(h_) > 64 || copra_batch_solver_info(h_) == COPRA_SOLVER_RICCATI_IPM) return 2;
             if (copra_batch_set_cost_reference(h_, (int)t, now[t].p, 0) != COPRA_OK) return 2; // (a kernel that cannot: a new handle can)
             builtCosts_[t].p.assign(now[t].p, now[t].p + now[t].rows);
             rc = 1;

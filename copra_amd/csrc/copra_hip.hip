@@ -311,38 +311,38 @@ int large_per_cu(const void* kernel, int threads, size_t lds_bytes)
 }
 
 // persistent grid of the workgroup-per-instance kernels: as many workgroups as the device keeps resident
-int large_grid(const void* kernel, int batch, int threads, size_t lds_bytes)
+int large_grid(const copra_options_t& opt, const void* kernel, int batch, int threads, size_t lds_bytes)
 {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
     int per_cu = large_per_cu(kernel, threads, lds_bytes);
-    if (const char* force = std::getenv("COPRA_LARGE_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
-    if (std::getenv("COPRA_DEBUG"))
+    if (opt.large_per_cu > 0) per_cu = opt.large_per_cu; // (tuning aid)
+    if (opt.debug)
         fprintf(stderr, "[copra] large grid: %d CUs x %d workgroups of %d threads, %zu B LDS\n", cus, per_cu, threads, lds_bytes);
     long long g = (long long)cus * per_cu;
-    if (const char* force = std::getenv("COPRA_LARGE_GRID")) g = std::atoi(force) > 0 ? std::atoi(force) : g; // (tuning aid)
+    if (opt.large_grid > 0) g = opt.large_grid; // (tuning aid)
     return (int)(g < batch ? g : batch);
 }
 
 // The 128-VGPR build of a kernel is worth its spills only where it puts MORE workgroups on a CU than the full-budget
 // build.  (The occupancy API is trusted for one to four waves per SIMD; for five- to eight-wave workgroups at THREE
 // waves per SIMD it over-reports, tools/exp/coresidency.hip -- that budget is not used.)
-bool prefer_w4(const void* full, const void* w4, int threads, size_t lds_bytes)
+bool prefer_w4(const copra_options_t& opt, const void* full, const void* w4, int threads, size_t lds_bytes)
 {
     if (lds_bytes > 48 * 1024) { // the occupancy query honours the opt-in limit of each symbol
         (void)hipFuncSetAttribute(full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     }
-    if (std::getenv("COPRA_LARGE_NO_W4")) return false; // (tuning aid)
+    if (opt.large_no_w4) return false; // (tuning aid)
     return large_per_cu(w4, threads, lds_bytes) > large_per_cu(full, threads, lds_bytes);
 }
 
 typedef void (*large_kernel_t)(const FusedPlan);
 large_kernel_t choose_large_kernel(const HostPlan& hp)
 {
-    if (prefer_w4(reinterpret_cast<const void*>(copra_lmpc_large_kernel), reinterpret_cast<const void*>(copra_lmpc_large_kernel_w4),
+    if (prefer_w4(hp.opt, reinterpret_cast<const void*>(copra_lmpc_large_kernel), reinterpret_cast<const void*>(copra_lmpc_large_kernel_w4),
             hp.plan.large.threads, hp.lds_bytes))
         return copra_lmpc_large_kernel_w4;
     return copra_lmpc_large_kernel;
@@ -439,11 +439,15 @@ struct copra_batch {
     int jit_tri = 0; // ... and whether for the factor-only layout
     // one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp)
     int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
+    int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
+    int lane_predict_left = 1; // solves whose first-tier layout is still chosen from that histogram
     double* d_lane_ws = nullptr;
     int lane_cur = 0; // the counter the last solve appended to
     bool lane_ran = false; // the last solve ran the pass
     bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass)
     int lane_adapt_left = 2;
+    long long lane_solves = 0; // solves seen by adapt_lane_pass (it samples the share again every 256)
+    bool lane_off_by_share = false; // lane_off was set by adapt_lane_pass (too few instances ended in the pass), not for lack of memory
     int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
     bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
@@ -516,6 +520,7 @@ static FusedPlan device_plan(const copra_batch* h)
     P.lane_ws = nullptr;
     P.lane_list = nullptr;
     P.lane_count = P.lane_zero = nullptr;
+    P.lane_hist = nullptr;
     P.lane_bp = 0;
     P.ws = h->d_ws;
     P.model_out = nullptr;
@@ -575,17 +580,17 @@ static size_t lane_lds_bytes(const FusedPlan& P)
 // copra::LMPC::solve() above all -- keep the wave-per-instance tier alone.
 // In front of the OTHER one-wave first tiers (ten times slower per instance than the Riccati-factor tier) it pays from a few thousand
 // instances on (tools/exp/lane_threshold.py: falling mass N = 32: 2048: 0.49 -> 0.38 ms, 16384: 2.78 -> 2.06; N = 64: 1.27 -> 0.08 ms).
-static bool lane_batch_ok(int batch, bool ric_tier)
+static bool lane_batch_ok(const copra_options_t& opt, int batch, bool ric_tier)
 {
     int least = ric_tier ? 20480 : 4096;
-    if (const char* e = std::getenv("COPRA_LANE_MIN_BATCH")) least = std::atoi(e);
+    if (opt.lane_min_batch != 0) least = opt.lane_min_batch < 0 ? 0 : opt.lane_min_batch;
     return batch >= least;
 }
 static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_launch)
 {
-    if (h->lane_off || std::getenv("COPRA_NO_LANE_PASS") || !lane_batch_ok(P.batch, P.lds.ric != 0)) return false;
-    const char* dbg = std::getenv("COPRA_LANE_DBG");
-    if ((P.prof && !(dbg && (std::atoi(dbg) & 8))) || P.prof_fine) return false;
+    const copra_options_t& opt = h->hp.opt;
+    if (h->lane_off || opt.no_lane_pass || !lane_batch_ok(opt, P.batch, P.lds.ric != 0)) return false;
+    if ((P.prof && !(opt.lane_dbg & 8)) || P.prof_fine) return false;
     // (in front of the Riccati-factor tier, which takes the factor over, or of any other one-wave first tier, where it only filters)
     if (P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || h->hp.large || P.initial_state) return false;
     for (int t = 0; t < kMaxCosts; ++t)
@@ -597,34 +602,62 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
 {
     const FusedPlan& P = h->hp.plan;
     const size_t bp = ((size_t)P.batch + kWave - 1) / kWave * kWave;
-    if (!h->d_lane_count) {
-        HIP_TRY(hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int)));
-        HIP_TRY(hipMemset(h->d_lane_count, 0, 2 * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&h->d_lane_list, bp * sizeof(int)));
+    // every buffer is tested on its own, and a failed attempt leaves NONE behind (round-3 advisor finding: with the counters allocated
+    // and the list not, the next call returned COPRA_OK with a null list)
+    hipError_t e = hipSuccess;
+    if (!h->d_lane_count || !h->d_lane_list || !h->d_lane_hist) {
+        (void)hipFree(h->d_lane_count);
+        (void)hipFree(h->d_lane_list);
+        (void)hipFree(h->d_lane_hist);
+        h->d_lane_count = h->d_lane_list = h->d_lane_hist = nullptr;
+        e = hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(h->d_lane_count, 0, 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&h->d_lane_list, bp * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&h->d_lane_hist, kLaneHistBins * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(h->d_lane_hist, 0, kLaneHistBins * sizeof(int));
         h->lane_cur = 1;
     }
-    if (need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
-        HIP_TRY(hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double)));
+    if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
+        e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(h->d_lane_count);
+        (void)hipFree(h->d_lane_list);
+        (void)hipFree(h->d_lane_hist);
+        (void)hipFree(h->d_lane_ws);
+        h->d_lane_count = h->d_lane_list = h->d_lane_hist = nullptr;
+        h->d_lane_ws = nullptr;
+        return fail(COPRA_ERR_HIP, std::string("one-instance-per-lane pass: ") + hipGetErrorString(e));
+    }
     return COPRA_OK;
 }
 // The pass pays when a fair share of the batch ends in it.  After each of the first solves that ran it: if fewer than one instance in
 // eight did, it is switched off for this controller (it costs about a tenth of the first tier per instance).
 static copra_status_t adapt_lane_pass(copra_batch* h)
 {
+    // The decision is not final (round-3 advisor finding: a controller whose first ticks are a constrained transient lost the pass for
+    // good, one that became constraint-heavy later kept paying for it): every kLaneResample solves the share is sampled again -- a pass
+    // that was switched off by THIS function (not for lack of memory) runs once more, a running one is checked again.
+    constexpr int kLaneResample = 256;
+    h->lane_solves += 1;
+    if (h->lane_solves % kLaneResample == 0 && h->lane_adapt_left <= 0) {
+        h->lane_adapt_left = 1;
+        if (h->lane_off && h->lane_off_by_share) h->lane_off = h->lane_off_by_share = false;
+    }
     if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
     // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
     //  -- except in shared-model mode, where there is no sweep to take over: there the pass must finish one instance in four to pay, measured)
-    if (!h->shared && h->hp.plan.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) return COPRA_OK;
+    if (!h->shared && h->hp.plan.lds.ricC && !h->hp.opt.no_lane_handover) return COPRA_OK;
     h->lane_adapt_left -= 1;
     int left = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
     const long long done = (long long)h->hp.plan.batch - left;
     long long share = h->shared ? 4 : 8;
-    if (const char* e = std::getenv("COPRA_LANE_SHARE")) share = std::atoll(e) > 0 ? std::atoll(e) : share; // (experiments)
-    if (done * share < (long long)h->hp.plan.batch && !std::getenv("COPRA_LANE_KEEP")) h->lane_off = true;
-    if (std::getenv("COPRA_DEBUG"))
+    if (h->hp.opt.lane_share > 0) share = h->hp.opt.lane_share; // (experiments)
+    if (done * share < (long long)h->hp.plan.batch && !h->hp.opt.lane_keep) h->lane_off = h->lane_off_by_share = true;
+    if (h->hp.opt.debug)
         fprintf(stderr, "[copra] one-instance-per-lane pass: %lld of %d instances ended in it%s\n", done, h->hp.plan.batch,
             h->lane_off ? " -- switched off" : "");
     return COPRA_OK;
@@ -645,15 +678,15 @@ static copra_status_t adapt_layout(copra_batch* h)
     //  leaves a mid-constrained workload on five columns at 42.8 instead of 50.4 M solves/s, 512 goes too far; the other first tiers
     //  keep the round-1 threshold of one in 8)
     long long share = h->hp.plan.lds.ric ? 64 : 8;
-    if (const char* e = std::getenv("COPRA_OVERFLOW_SHARE")) share = std::atoll(e) > 0 ? std::atoll(e) : share; // (experiments)
+    if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share; // (experiments)
     if ((long long)count * share <= (long long)h->hp.plan.batch) return COPRA_OK;
     LdsLayout roomier {};
-    if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) { // factor-only: one instance per CU fewer, more columns
+    if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier, h->hp.opt.no_ladder != 0)) { // factor-only: one instance per CU fewer, more columns
         h->hp.plan.lds = roomier;
         h->hp.lds_bytes = (size_t)roomier.total * sizeof(double);
         h->lds_attr_set = false;
         h->adapt_left += 1; // (a step down the ladder does not use up the budget of attempts)
-        if (std::getenv("COPRA_DEBUG"))
+        if (h->hp.opt.debug)
             fprintf(stderr, "[copra] %d of %d instances overflowed the factor-only layout: next %zu B, %d columns\n", count,
                 h->hp.plan.batch, h->hp.lds_bytes, roomier.rcap);
         return COPRA_OK;
@@ -677,9 +710,9 @@ static copra_status_t adapt_layout(copra_batch* h)
         h->model_dirty = true;
     }
     const FusedPlan& P = h->hp.plan;
-    h->packed = (P.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0
+    h->packed = (P.lds.tri || h->hp.opt.no_packed) ? 0
         : packed_width(P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
-    if (std::getenv("COPRA_DEBUG"))
+    if (h->hp.opt.debug)
         fprintf(stderr, "[copra] %d of %d instances overflowed the compact LDS layout: next layout %zu B, %s\n", count, P.batch,
             h->hp.lds_bytes, h->hp.two_tier ? "two-tier" : "single tier");
     return COPRA_OK;
@@ -767,7 +800,7 @@ static copra_status_t prepare_riccati(copra_batch* h)
     sp.cls_rptr = upi(hs.cls_rptr), sp.cls_rcol = upi(hs.cls_rcol), sp.cls_gptr = upi(hs.cls_gptr), sp.cls_grow = upi(hs.cls_grow);
     sp.cls_eptr = upi(hs.cls_eptr), sp.cls_erow = upi(hs.cls_erow);
     sp.cls_rval = upi(hs.cls_rval), sp.cls_gval = upi(hs.cls_gval), sp.cls_eval = upi(hs.cls_eval);
-    h->ric_fast = sp.fast_ok && !refs && !std::getenv("COPRA_NO_RIC_FAST");
+    h->ric_fast = sp.fast_ok && !refs && !h->hp.opt.no_ric_fast;
     if (h->ric_fast) { // fixed-width tables of the LDS-resident kernel
         sp.f_rinfo = upi(hs.f_rinfo), sp.f_rcomp = upi(hs.f_rcomp), sp.f_rval = upd(hs.f_rval);
         sp.f_gcnt = upi(hs.f_gcnt), sp.f_grow = upi(hs.f_grow), sp.f_gval = upd(hs.f_gval);
@@ -790,7 +823,7 @@ static copra_status_t prepare_riccati(copra_batch* h)
         (void)hipGetLastError();
         per_cu = 1;
     }
-    if (const char* force = std::getenv("COPRA_RICCATI_PER_CU")) per_cu = std::atoi(force) > 0 ? std::atoi(force) : per_cu; // (tuning aid)
+    if (h->hp.opt.riccati_per_cu > 0) per_cu = h->hp.opt.riccati_per_cu; // (tuning aid)
     long long g = (long long)cus * per_cu;
     const int batch = h->hp.plan.batch > 0 ? h->hp.plan.batch : 1;
     h->ric_grid = (int)(g < batch ? g : batch);
@@ -799,7 +832,7 @@ static copra_status_t prepare_riccati(copra_batch* h)
     sp.ws = h->d_ric_ws;
     if (e == hipSuccess && !h->d_ric_next) e = hipMalloc((void**)&h->d_ric_next, sizeof(int));
     sp.next_instance = h->d_ric_next;
-    if (std::getenv("COPRA_DEBUG"))
+    if (h->hp.opt.debug)
         fprintf(stderr, "[copra] riccati path (%s): %d classes, %d rows, grid %d (%d per CU), %zu B LDS, %lld B workspace per wave\n",
             h->ric_fast ? "LDS-resident, MFMA" : hs.fast_why.c_str(), sp.ncls, sp.m, h->ric_grid, per_cu, lds_bytes,
             h->ric_fast ? 0LL : sp.ws_total * 8LL);
@@ -822,14 +855,14 @@ static bool use_riccati(copra_batch* h)
 {
     if (h->hp.ric_only) return prepare_riccati(h) == COPRA_OK && h->hs.eligible;
     if (h->solver == COPRA_SOLVER_QUADPROG_DENSE || h->shared) return false;
-    if (h->solver == COPRA_SOLVER_DEFAULT && (!h->hp.large || std::getenv("COPRA_NO_RICCATI"))) return false;
+    if (h->solver == COPRA_SOLVER_DEFAULT && (!h->hp.large || h->hp.opt.no_riccati)) return false;
     if (prepare_riccati(h) != COPRA_OK) return false;
     return h->hs.eligible;
 }
 
 extern "C" {
 
-int copra_abi_version(void) { return 4; } // 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info, copra_batch_set_cost_reference_all
+int copra_abi_version(void) { return 5; } // 5: + copra_options_t, copra_options_init, copra_set_default_options, copra_batch_create_with_options; 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info, copra_batch_set_cost_reference_all
 
 copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
     double* Psi, double* xi)
@@ -908,6 +941,11 @@ int copra_batch_solver_info(const copra_batch_t* h)
 
 const char* copra_last_error(void) { return g_err.c_str(); }
 
+#ifndef COPRA_SRC_HASH
+#error "build through copra_amd/csrc/Makefile (it defines COPRA_SRC_HASH)"
+#endif
+const char* copra_source_hash(void) { return COPRA_SRC_HASH; }
+
 copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len)
 {
     int n = 0;
@@ -928,28 +966,52 @@ copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name,
 }
 
 static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
-    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is);
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is,
+    const copra_options_t* opts);
+
+void copra_options_init(copra_options_t* opts)
+{
+    if (opts) *opts = default_options();
+}
+
+copra_status_t copra_set_default_options(const copra_options_t* opts)
+{
+    copra_options_t builtin {};
+    builtin.struct_size = (int)sizeof(copra_options_t);
+    default_options() = builtin;
+    if (opts) default_options() = resolve_options(opts);
+    return COPRA_OK;
+}
 
 copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs)
 {
-    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, nullptr);
+    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, nullptr, nullptr);
+}
+
+copra_status_t copra_batch_create_with_options(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is,
+    const copra_options_t* opts)
+{
+    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, is, opts);
 }
 
 copra_status_t copra_batch_create_initial_state(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
 {
     if (!is) return fail(COPRA_ERR_ARG, "copra_batch_create_initial_state: null descriptor");
-    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, is);
+    return create_common(out, dims, n_costs, costs, n_cstrs, cstrs, is, nullptr);
 }
 
 static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
-    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is,
+    const copra_options_t* opts)
 {
     if (!out || !dims || n_costs < 0 || n_cstrs < 0 || (n_costs > 0 && !costs) || (n_cstrs > 0 && !cstrs))
         return fail(COPRA_ERR_ARG, "copra_batch_create: null / negative argument");
     *out = nullptr;
     copra_batch* h = new copra_batch();
+    h->hp.opt = resolve_options(opts); // (everything the engine consults from here on: no environment variable is read on any path)
     copra_status_t rc = build_plan(h->hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) {
         g_err = h->hp.error;
@@ -972,7 +1034,9 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     chk(upload(&h->d_lb, h->hp.lb));
     chk(upload(&h->d_ub, h->hp.ub));
     const size_t b = (size_t)(P.batch > 0 ? P.batch : 1);
-    { // result slab [U | X | status | iter], every part 256-byte aligned
+    { // result slab [U | X | status | iter], every part 256-byte aligned.  (The slab a multi-GPU caller hands in through
+      //  copra_batch_set_outputs is laid out [U | status | iter | X] instead -- copra_amd/sharding.py: there the small parts come first so
+      //  that controls + status are a contiguous prefix a gather may send alone; this engine-owned slab is only ever fetched whole.)
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         h->off_traj = up(b * P.n * sizeof(double));
         h->off_status = h->off_traj + up(b * P.X * sizeof(double));
@@ -1006,11 +1070,11 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
         if (h->hp.lds_bytes > 48 * 1024) // (the occupancy query below needs the attribute as well)
             chk(hipFuncSetAttribute(reinterpret_cast<const void*>(h->large_fn),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_bytes));
-        h->large_grid = large_grid(reinterpret_cast<const void*>(h->large_fn), P.batch > 0 ? P.batch : 1,
+        h->large_grid = large_grid(h->hp.opt, reinterpret_cast<const void*>(h->large_fn), P.batch > 0 ? P.batch : 1,
             P.large.threads, h->hp.lds_bytes);
         chk(hipMalloc((void**)&h->d_ws, (size_t)h->large_grid * (size_t)P.large.ws_total * sizeof(double)));
     }
-    h->packed = (h->hp.large || h->hp.plan.lds.tri || std::getenv("COPRA_NO_PACKED")) ? 0 // (the packed bodies are square-layout)
+    h->packed = (h->hp.large || h->hp.plan.lds.tri || h->hp.opt.no_packed) ? 0 // (the packed bodies are square-layout)
         : packed_width(is ? P.nx + P.n : P.n, P.nx * (P.nx + P.nu + 1), P.rfull > 0, h->hp.lds_bytes);
     chk(hipMalloc((void**)&h->d_ovf_count, 2 * sizeof(int)));
     chk(hipMalloc((void**)&h->d_ovf_list, b * sizeof(int)));
@@ -1070,6 +1134,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_ovf_list);
     (void)hipFree(h->d_lane_count);
     (void)hipFree(h->d_lane_list);
+    (void)hipFree(h->d_lane_hist);
     (void)hipFree(h->d_lane_ws);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1157,7 +1222,7 @@ copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const cop
     const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
 {
     if (!dims) return fail(COPRA_ERR_ARG, "copra_plan_check: null dims");
-    HostPlan hp;
+    HostPlan hp; // (the process-wide default options)
     const copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) g_err = hp.error;
     if (rc == COPRA_OK && hp.ric_only) { // beyond the condensed kernels' sizes: covered if (and only if) the controller is stage-wise
@@ -1597,8 +1662,8 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     // Single-control systems with fewer than 48 variables stay on the packed / factor-only kernels: the reference's falling-mass
     // problems hold most of their control bounds active, far beyond this tier's five register columns (measured, M solves/s,
     // this tier vs the others compiled for the shape: N = 5: 94 vs 339, 16: 6.8 vs 55, 32: 7.2 vs 16, 48: 29 vs 22, 64: 75 vs 29).
-    const bool ric_pays = P.nu >= 2 || P.n >= 48 || std::getenv("COPRA_RIC_ANY_SHAPE");
-    if (!h->shared && ric_pays && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI")) {
+    const bool ric_pays = P.nu >= 2 || P.n >= 48 || h->hp.opt.ric_any_shape;
+    if (!h->shared && ric_pays && !h->hp.opt.no_ric && !h->hp.opt.no_tri) {
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {
             char keyr[128], srcr[3072];
@@ -1759,7 +1824,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->last_stream = s;
         if (h->hp.plan.batch == 0) return COPRA_OK;
         { // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
-            bool want = h->has_lds_ric && !h->d_warm && !std::getenv("COPRA_NO_RIC_SHARED");
+            bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared;
             for (int t = 0; t < kMaxCosts; ++t) want = want && !h->cost_p[t];
             if (want != h->shared_ric) {
                 LdsLayout lq {};
@@ -1801,9 +1866,9 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
             // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
             unsigned g1 = (unsigned)P.batch;
-            if (!h->lane_off && !std::getenv("COPRA_NO_LANE_PASS") && lane_batch_ok(P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
-                && !P.row_f_inst && select_lane_shared_kernel(P)) {
-                if (ensure_lane_buffers(h, false) != COPRA_OK) return fail(COPRA_ERR_HIP, "copra_batch_solve: no memory for the lane pass's list");
+            if (!h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
+                && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, false) == COPRA_OK || (h->lane_off = true, false))) {
+                // (no room for the pass's list: the tier alone, from now on -- as on the per-instance path below)
                 h->lane_cur ^= 1;
                 h->lane_ran = true;
                 Pr.lane_list = h->d_lane_list;
@@ -1863,7 +1928,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     // their launches with recorded events as before.
     const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri
         && h->jit_ric == (P.lds.ric != 0);
-    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed && !std::getenv("COPRA_RECORDED_EVENTS");
+    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed && !h->hp.opt.recorded_events;
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
         if (use_riccati(h)) {
@@ -1927,7 +1992,11 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
         P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
         const unsigned g0 = (unsigned)(P.lane_bp / kWave);
-        if (const char* e = std::getenv("COPRA_LANE_DBG")) P.lane_dbg = std::atoi(e);
+        P.lane_dbg = h->hp.opt.lane_dbg;
+        // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
+        // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
+        const bool predict = h->lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;
+        if (predict) P.lane_hist = h->d_lane_hist;
         if (jit_launch) {
             FusedPlan Pl = P;
             void* largs[] = { &Pl };
@@ -1941,8 +2010,36 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
                 hipLaunchKernelGGL(select_lane_kernel(P), dim3(g0), dim3(64), lane_lds_bytes(P), s, P);
             HIP_TRY(hipGetLastError());
         }
+        if (P.lane_hist) {
+            // The size of an instance's final active set goes with the number of rows its unconstrained minimiser violates (~ 1.1 x,
+            // correlation 0.9 from the headline's to the tightest workload of the tests): step down the ladder until at most one instance
+            // in `share` is expected to outgrow the first tier -- BEFORE its first launch, with ONE synchronisation in the controller's
+            // life, instead of after each of the first solves (round 3: the first solve of the tight workload took 10.4 ms, the
+            // steady state 2.8 ms).  adapt_layout keeps checking the real overflow counts of the first solves behind this.
+            h->lane_predict_left -= 1;
+            int hist[kLaneHistBins];
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(hist, h->d_lane_hist, sizeof hist, hipMemcpyDeviceToHost));
+            long long share = h->hp.plan.lds.ric ? 64 : 8;
+            if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share;
+            for (;;) {
+                long long over = 0;
+                for (int b = 0; b < kLaneHistBins; ++b)
+                    if (b + b / 8 > h->hp.plan.lds.rcap) over += hist[b];
+                LdsLayout roomier {};
+                if (over * share <= (long long)P.batch || !next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) break;
+                h->hp.plan.lds = roomier;
+                h->hp.lds_bytes = (size_t)roomier.total * sizeof(double);
+                h->lds_attr_set = false;
+                if (h->hp.opt.debug)
+                    fprintf(stderr, "[copra] %lld of %d instances are expected to outgrow the first tier: starting on %zu B, %d columns\n", over,
+                        P.batch, h->hp.lds_bytes, roomier.rcap);
+            }
+            P.lds = h->hp.plan.lds;
+            P.lane_hist = nullptr;
+        }
         P.lane_from_list = 1;
-        P.lane_handover = (P.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) ? 1 : 0;
+        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover) ? 1 : 0;
         P.lane_zero = nullptr;
     }
     if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && (!jit_launch || h->jit_ric) && !h->packed, P));
@@ -1958,7 +2055,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
     } else {
         LDS_OPT_IN(select_fused_kernel(P), h->hp.lds_bytes);
-        if (std::getenv("COPRA_DEBUG")) {
+        if (h->hp.opt.debug) {
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(select_fused_kernel(P)), 64, h->hp.lds_bytes);
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
@@ -2315,10 +2412,10 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
     P.iter = diter;
     if (large) {
         const int threads = (n + kWave - 1) & ~(kWave - 1);
-        const bool w4 = prefer_w4(reinterpret_cast<const void*>(copra_qp_dense_large_kernel),
+        const bool w4 = prefer_w4(default_options(), reinterpret_cast<const void*>(copra_qp_dense_large_kernel),
             reinterpret_cast<const void*>(copra_qp_dense_large_kernel_w4), threads, lds_bytes);
         auto dense_kernel = w4 ? copra_qp_dense_large_kernel_w4 : copra_qp_dense_large_kernel;
-        const int grid = large_grid(reinterpret_cast<const void*>(dense_kernel), batch, threads, lds_bytes);
+        const int grid = large_grid(default_options(), reinterpret_cast<const void*>(dense_kernel), batch, threads, lds_bytes);
         double* ws = nullptr;
         e = hipMalloc((void**)&ws, (size_t)grid * 2 * n * large_ld(n) * sizeof(double));
         if (e != hipSuccess) {
@@ -2329,7 +2426,7 @@ copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, 
         P.ws = ws;
         hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
     } else {
-        const int pw = std::getenv("COPRA_NO_PACKED") ? 0 : packed_width(n, 0, false, lds_bytes);
+        const int pw = default_options().no_packed ? 0 : packed_width(n, 0, false, lds_bytes);
         hipFunction_t jit = nullptr;
         {
             std::lock_guard<std::mutex> lock(g_dense_jit_mu);

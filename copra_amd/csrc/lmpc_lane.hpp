@@ -387,6 +387,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const double vsmall = P.vsmall;
     const int rps = P.lane_rps;
     bool viol = bad;
+    int nviol = 0; // violated rows and bounds at the unconstrained minimiser: what the size of the final active set goes with (lane_hist below)
     const int li = valid ? inst : 0;
     const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
     const double* const ubp = P.ub_inst ? P.ub_inst + (size_t)li * P.n : P.ub;
@@ -428,6 +429,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
                 const double s = row_rhs(rt[NZ], (int)rt[NZ + 1]) - ax;
                 viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+                nviol += (s <= -vsmall) ? 1 : 0;
             }
             return;
         }
@@ -440,6 +442,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
             const double s = row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)) - ax;
             viol = viol || (s <= -vsmall);
+            nviol += (s <= -vsmall) ? 1 : 0;
         }
     };
     constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
@@ -510,6 +513,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                         lb = uniform_load(lbp, k * NU + c);
                     }
                     viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
+                    nviol += ((ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall)) ? 1 : 0;
                 }
             }
 #pragma unroll
@@ -574,6 +578,18 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         P.status[inst] = 0;
         P.iter[2 * (size_t)inst] = 1;
         P.iter[2 * (size_t)inst + 1] = 0;
+    }
+    // Histogram of the violated-row counts over the batch (first solve of a controller: copra_batch_solve reads it BEFORE it launches the
+    // first tier and starts on the layout of the tier's ladder that has room for the active sets to expect -- the final active set of an
+    // instance is ~ 1.1 x its violated rows, correlation 0.9 over five constraint levels, DESIGN.md 3.12 -- instead of learning the layout
+    // from the overflow counts of its first solves).  kLaneHistBins bins, the last one open; one ballot per bin, one atomic per non-empty bin.
+    if (P.lane_hist) {
+        const int bin = !more ? -1 : (nviol < kLaneHistBins - 1 ? nviol : kLaneHistBins - 1);
+        for (int b = 0; b < kLaneHistBins; ++b) {
+            int cnt = 0;
+            (void)wave_prefix_count(bin == b, cnt);
+            if (cnt > 0 && lane == 0) (void)atomic_add_i32(P.lane_hist + b, cnt);
+        }
     }
     if ((P.lane_dbg & 8) && P.prof && lane == 0) { // (experiments: staging | sweep | roll-out | verdict, in row `group` of the profile)
         stamp[4] = cycle_counter();

@@ -227,6 +227,7 @@ COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu + nu * (n
 // LDS of that pass (doubles): the staging area of the transpositions (64 lanes x the widest array, odd stride), then H | h
 constexpr int kLaneGroup = 4; // stages per group of its roll-out (results leave through LDS once per group)
 constexpr int kLaneAhead = 4; // stages whose gains are in flight
+constexpr int kLaneHistBins = 32; // bins of its violated-row histogram (FusedPlan::lane_hist), the last one open
 COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
 {
     int w = (nx * nx) | 1;
@@ -277,6 +278,7 @@ struct FusedPlan {
     int* lane_list;
     int* lane_count;
     int* lane_zero;
+    int* lane_hist; // [kLaneHistBins] or nullptr: histogram of the violated-row counts of the instances the pass leaves over (first solve)
     // constraint rows
     int meq, mineq, mgen, mtotal; // mgen = meq + mineq, mtotal = mgen + 2n (QuadProgSolver.cpp:51)
     int any_state_rows; // 1 if any row has a state term (then the trajectory is refreshed before every scan)

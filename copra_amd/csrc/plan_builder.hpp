@@ -11,13 +11,38 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <string>
 #include <vector>
 
 namespace copra_hip {
 
+// the process-wide default options (copra_set_default_options); built-in: everything zero = the engine decides
+inline copra_options_t& default_options()
+{
+    static copra_options_t d = [] {
+        copra_options_t o {};
+        o.struct_size = (int)sizeof(copra_options_t);
+        return o;
+    }();
+    return d;
+}
+// a caller's struct may be shorter (built against an older header): the fields it does not have keep the defaults
+inline copra_options_t resolve_options(const copra_options_t* given)
+{
+    copra_options_t o = default_options();
+    if (given) {
+        size_t len = given->struct_size > 0 ? (size_t)given->struct_size : sizeof(copra_options_t);
+        if (len > sizeof(copra_options_t)) len = sizeof(copra_options_t);
+        std::memcpy(&o, given, len);
+        o.struct_size = (int)sizeof(copra_options_t);
+    }
+    return o;
+}
+
 struct HostPlan {
+    copra_options_t opt = default_options(); // engine options of this controller (set BEFORE build_plan; include/copra_hip.h)
     FusedPlan plan {}; // pointers refer to the vectors below (host addresses)
     std::vector<double> params;
     std::vector<int> row_step, row_ekind, row_eoff, row_gkind, row_goff;
@@ -199,7 +224,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     // compact variant (xcur_late <=> FusedPlan::rows_direct): trajectory and closed-loop states inside the G region (LdsLayout::ricC)
     // (there the blocks G are never stored: their block-row norms are taken by the preview steps, nothing else needs them;
     //  and A | B | d | x0 share the solver vectors' place behind the sweep's scratch -- they are dead before those are written)
-    const bool compact = xcur_late && !std::getenv("COPRA_RIC_GENERAL");
+    const bool compact = xcur_late; // (callers pass rows_pure && !copra_options_t::ric_general)
     const int scratch = align2(nx * nx) + align2(nx) + align2(nu * 12) + 2; // P | p | rows u of M | zero, spare
     L.ricC = compact ? 1 : 0;
     L.G = take(compact ? 2 * align2(X) : N * nx * nu);
@@ -421,17 +446,17 @@ inline void build_lane_tables(HostPlan& hp)
     {
         int oHl = 0;
         const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;
-        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u && !std::getenv("COPRA_LANE_TABLES_IN_MEMORY")) ? tl : 0; // (four waves per CU)
+        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u && !hp.opt.lane_tables_in_memory) ? tl : 0; // (four waves per CU)
     }
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
 }
 
 // Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
 // instance per CU fewer (at least four) and more room for active constraints; false when there is none.
-inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out)
+inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout& out, bool no_ladder = false)
 {
     if (!cur.tri) return false;
-    if (std::getenv("COPRA_NO_LADDER")) return false; // (tests: the fall-back that follows an exhausted ladder, reachable at once)
+    if (no_ladder) return false; // (copra_options_t::no_ladder -- tests: the fall-back that follows an exhausted ladder, reachable at once)
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     const int rows = rp > P.rmax ? rp : P.rmax;
     const int kcur = (160 * 1024) / (cur.total * (int)sizeof(double));
@@ -442,7 +467,7 @@ inline bool next_tri_layout(const FusedPlan& P, const LdsLayout& cur, LdsLayout&
         for (int k = kcur - 1; k >= 4; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
             LdsLayout t {};
-            if (layout_lds_ric(t, P.nx, P.nu, P.N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, 0, budget) && t.rcap > cur.rcap) {
+            if (layout_lds_ric(t, P.nx, P.nu, P.N, P.n, P.X, P.mgen, P.meq, P.mtotal, cur.ricC != 0, 0, budget) && t.rcap > cur.rcap) {
                 out = t;
                 return true;
             }
@@ -500,7 +525,7 @@ inline bool take_ric_layout(HostPlan& hp)
     for (int k = 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
         const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
         LdsLayout t {};
-        if (layout_lds_ric(t, nx, nu, N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, kFusedQ1Regs, budget)) {
+        if (layout_lds_ric(t, nx, nu, N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0 && !hp.opt.ric_general, kFusedQ1Regs, budget)) {
             hp.lds_safe = P.lds; // (what the controller falls back to when the tier's layout ladder is exhausted: adapt_layout)
             hp.safe_two_tier = hp.two_tier;
             hp.two_tier = true;
@@ -642,7 +667,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // (lmpc_fused.hpp: 7.6 M solves/s at the headline shape).  One-wave LMPC controllers only; the kernels that do not evaluate
         // costs step by step with the step's reference refuse such a controller (FusedPlan::stage_refs).
         if (full && !is && U <= kWave && (c.kind == COPRA_COST_TRAJECTORY || c.kind == COPRA_COST_CONTROL || c.kind == COPRA_COST_MIXED)
-            && !std::getenv("COPRA_NO_STAGE_REFS")) {
+            && !hp.opt.no_stage_refs) {
             // (MixedCost, costFunctions.cpp:173-210: M x_k + N u_k - p_k over the N steps with a control -- M has fullXDim columns, the
             //  ones of x_N zero; both matrices must repeat their block)
             const bool traj = c.kind == COPRA_COST_TRAJECTORY, mixed = c.kind == COPRA_COST_MIXED;
@@ -805,7 +830,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     // non-zeros lie inside ONE step -- a terminal constraint written as a full-size matrix, the usual way to get one from the reference --
     // is a per-step row of that step: the same coefficients, the same arithmetic over them, none of the full-row machinery (sums over
     // the whole trajectory at every slack evaluation, the general variants of the tiers, no lane pass).
-    const bool step_rows = !std::getenv("COPRA_NO_STEP_ROWS");
+    const bool step_rows = !hp.opt.no_step_rows;
     auto single_block = [&](const double* Mx, int rows, int blk, int nblk, int i, int& at) { // false: more than one block of row i is non-zero
         at = -1;
         for (int b = 0; b < nblk; ++b)
@@ -827,7 +852,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         for (int j = 0; j < nx; ++j)
             if (coef[j] != 0.0) ++nnz, at = j;
         const double ev = nnz == 1 ? coef[at] : 0.0;
-        if ((ev == 1.0 || ev == -1.0) && ineq && !std::getenv("COPRA_NO_SELECTION_ROWS")) {
+        if ((ev == 1.0 || ev == -1.0) && ineq && !hp.opt.no_selection_rows) {
             eoff_or_comp = at;
             return ev < 0.0 ? (int)kEOneHotNeg : (int)kEOneHot;
         }
@@ -861,7 +886,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                         for (int j = 0; j < nx; ++j)
                             if (c.E[(size_t)j * r + i] != 0.0) ++nnz, at = j;
                         const double ev = nnz == 1 ? c.E[(size_t)at * r + i] : 0.0;
-                        if ((ev == 1.0 || ev == -1.0) && c.is_inequality && !std::getenv("COPRA_NO_SELECTION_ROWS")) {
+                        if ((ev == 1.0 || ev == -1.0) && c.is_inequality && !hp.opt.no_selection_rows) {
                             hot[(size_t)i] = at;
                             neg[(size_t)i] = ev < 0.0; // (-x_c <= -l: a lower limit)
                         }
@@ -1037,8 +1062,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.Xi = take(X);
         L.Xbar = is ? L.Xi : take(X); // InitialStateLMPC never uses the free response Phi x0 + xi
         L.Xcur = take(X);
-        int plimit = 6144;
-        if (const char* e = std::getenv("COPRA_LARGE_PARAMS_LDS")) plimit = std::atoi(e); // (tuning aid)
+        const int plimit = hp.opt.large_params_lds > 0 ? hp.opt.large_params_lds : hp.opt.large_params_lds < 0 ? 0 : 6144; // (tuning aid)
         L.nparams = ((int)hp.params.size() <= plimit) ? (int)hp.params.size() : 0; // (dropped below if LDS gets too tight)
         L.Params = take(L.nparams);
         L.FullS = take(kMaxFullRows);
@@ -1135,7 +1159,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // 7 instances per CU in the full layout 17.4 M solves/s, k = 12 with the 128-VGPR build of the kernel 28.8 M.
         hp.lds_safe = P.lds;
         hp.safe_two_tier = hp.two_tier;
-        if (rp == 0 && !std::getenv("COPRA_NO_DENSE_LAYOUT")) {
+        if (rp == 0 && !hp.opt.no_dense_layout) {
             static const int ks[] = { 16, 14, 12, 10, 8, 7, 6, 5 };
             const int need = U < 8 ? U : ((U + 3) / 4 > 8 ? (U + 3) / 4 : 8);
             for (int k : ks) {
@@ -1161,7 +1185,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         // inside the factor-only block below (it competes with the layouts there), the shorter ones here -- they would
         // otherwise run on the square layouts (30 variables) or the run-time-shape factor-only kernel (45)
         bool ric_short = nx == 6 && nu == 3 && (N == 10 || N == 15) && P.rmax <= 6 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state
-            && P.ncost <= kRicMaxCosts && !std::getenv("COPRA_NO_RIC") && !std::getenv("COPRA_NO_TRI");
+            && P.ncost <= kRicMaxCosts && !hp.opt.no_ric && !hp.opt.no_tri;
         // (every other shape the body of that tier can be instantiated for gets there through copra_batch_specialise, which
         //  compiles the kernel and calls take_ric_layout)
         for (int t = 0; t < P.ncost; ++t) ric_short = ric_short && !P.cost[t].full;
@@ -1169,7 +1193,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         for (int k = 8; ric_short && !ric_taken && k >= 6; --k) {
             const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
             LdsLayout t {};
-            if (layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, kFusedQ1Regs, budget)) {
+            if (layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0 && !hp.opt.ric_general, kFusedQ1Regs, budget)) {
                 hp.lds_safe = P.lds;
                 hp.safe_two_tier = hp.two_tier;
                 hp.two_tier = true;
@@ -1179,28 +1203,28 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 ric_taken = true;
             }
         }
-        const char* tmin = std::getenv("COPRA_TRI_MIN"); // (experiments: smallest number of variables that takes the tier)
-        if (!ric_taken && U > (tmin ? std::atoi(tmin) : 32) && !std::getenv("COPRA_NO_TRI")) {
-            const char* kenv = std::getenv("COPRA_TRI_K");
+        const int tmin = hp.opt.tri_min; // (experiments: smallest number of variables that takes the tier)
+        if (!ric_taken && U > (tmin > 0 ? tmin - 1 : 32) && !hp.opt.no_tri) {
+            const int kenv = hp.opt.tri_k;
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU
-            const int qregs = (nx == 6 && rp == 6 && !std::getenv("COPRA_NO_Q1REGS")) ? kFusedQ1Regs : 0;
+            const int qregs = (nx == 6 && rp == 6 && !hp.opt.no_q1regs) ? kFusedQ1Regs : 0;
             bool all_ident = true; // (state costs with M = I padded to nx rows: lmpc_fused.hpp reads G instead of Y)
             for (int t = 0; t < P.ncost; ++t)
                 all_ident = all_ident && (P.cost[t].kind == kCostControl || (P.cost[t].ident && rows == nx));
             // Riccati form of the factor (lmpc_fused_ric.hpp): every cost a per-step entry, the headline instantiation
             bool ric_ok = qregs > 0 && nu == 3 && N == 20 && P.rfull == 0 && P.denseQ < 0 && !P.initial_state && P.ncost <= kRicMaxCosts
-                && !std::getenv("COPRA_NO_RIC");
+                && !hp.opt.no_ric;
             for (int t = 0; t < P.ncost; ++t) ric_ok = ric_ok && !P.cost[t].full;
-            for (int k = kenv ? std::atoi(kenv) : 8; k >= 2; --k) {
+            for (int k = kenv > 0 ? kenv : 8; k >= 2; --k) {
                 const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double); // (LDS is granted in 512-byte units)
                 if (budget >= P.lds.total && !kenv) break; // no denser than what is already chosen
                 LdsLayout t {};
                 // (COPRA_RIC_K = instances per CU: start on the LDS-Q1 step of the ladder that adapt_layout would reach -- experiments, tests)
-                const char* rk = std::getenv("COPRA_RIC_K");
-                const int rbudget = rk ? ((160 * 1024 / std::atoi(rk)) & ~511) / (int)sizeof(double) : budget;
+                const int rk = hp.opt.ric_k > 0 ? hp.opt.ric_k : 0;
+                const int rbudget = rk ? ((160 * 1024 / rk) & ~511) / (int)sizeof(double) : budget;
                 if (ric_ok && k >= 6 // (general state rows keep their own trajectory buffer: seven instances per CU)
-                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0, rk ? 0 : qregs, rbudget)) {
+                    && layout_lds_ric(t, nx, nu, N, U, X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0 && !hp.opt.ric_general, rk ? 0 : qregs, rbudget)) {
                     hp.lds_safe = P.lds;
                     hp.safe_two_tier = hp.two_tier;
                     hp.two_tier = true;

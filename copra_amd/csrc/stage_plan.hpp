@@ -452,10 +452,10 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     // the trajectory-cost fixtures (weights of 1e4 -- large multipliers at the optimum) 22 / 19 / 15 / 12.
     sp.s_floor = 0.05, sp.lam0 = -10.0;
     sp.step_tol = 1e-10, sp.mu_tol = 1e-8;
-    if (const char* e = std::getenv("COPRA_RIC_STEP_TOL")) sp.step_tol = std::atof(e); // (experiments)
-    if (const char* e = std::getenv("COPRA_RIC_MU_TOL")) sp.mu_tol = std::atof(e);
-    if (const char* e = std::getenv("COPRA_RIC_S0")) sp.s_floor = std::atof(e); // (experiments)
-    if (const char* e = std::getenv("COPRA_RIC_LAM0")) sp.lam0 = std::atof(e);
+    if (hp.opt.ric_step_tol != 0.0) sp.step_tol = hp.opt.ric_step_tol; // (copra_options_t: experiments)
+    if (hp.opt.ric_mu_tol != 0.0) sp.mu_tol = hp.opt.ric_mu_tol;
+    if (hp.opt.ric_s0 != 0.0) sp.s_floor = hp.opt.ric_s0;
+    if (hp.opt.ric_lam0 != 0.0) sp.lam0 = hp.opt.ric_lam0;
     sp.delta = 1e-9;
     // workspace of one resident wave
     long long o = 0;

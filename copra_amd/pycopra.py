@@ -304,6 +304,10 @@ class LMPC:
         rc = 0
         for t, c in enumerate(self._costs):
             if not same(c._p, built[t][4]):
+                # (a controller past the one-wave kernels would leave its fast kernels in per-instance-reference mode -- the LDS-resident
+                #  interior-point kernel above all, include/copra_hip.h --: there a new engine is worth more than the engine build)
+                if self._eng.lanes_per_instance() > 64 or self._eng.solver() == "riccati_ipm":
+                    return 2
                 try:
                     self._eng.set_cost_reference(t, c._p[None])
                 except Exception:

@@ -125,11 +125,68 @@ typedef struct {
 
 typedef struct copra_batch copra_batch_t; /* opaque handle == one batched LMPC controller */
 
+/* ---- engine options: every switch and tuning value the engine consults, fixed when the controller is created (no environment
+ *      variable is read by the library on any path; earlier rounds steered it through ~50 COPRA_* variables).  There is no reference
+ *      counterpart: copra's LMPC has no tuning surface beyond selectQPSolver.  copra_options_init fills in the process-wide defaults
+ *      (all zeros / "the engine decides" unless copra_set_default_options changed them); a caller sets `struct_size =
+ *      sizeof(copra_options_t)` (done by copra_options_init) so that a library built against a longer struct keeps defaults for the
+ *      fields the caller does not know.  Integer switches: 0 = off / engine's choice.  Results are the same under every setting --
+ *      the options choose WHICH kernels run (tests pin each tier by switching the others off), never what they compute. ---- */
+typedef struct {
+    int struct_size;
+    /* plan builder: classification of full-size entries as per-step entries */
+    int no_stage_refs; /* block-diagonal full-size costs with repeating blocks stay dense Psi'WPsi contractions */
+    int no_step_rows; /* full-size constraint rows inside one step keep the full-row machinery */
+    int no_selection_rows; /* one-hot TrajectoryConstraint rows are not treated like TrajectoryBound rows */
+    /* tier selection of the one-wave kernels */
+    int no_ric; /* never the Riccati-factor tier (lmpc_fused_ric.hpp) */
+    int no_tri; /* never a factor-only tier */
+    int ric_general; /* Riccati-factor tier: the general variant even where the compact one applies */
+    int no_dense_layout; /* run-time shapes: the safe compact layout instead of the densest one */
+    int no_q1regs; /* factor-only tier with Q1 in LDS */
+    int no_ladder; /* the layout ladder behaves as exhausted */
+    int no_packed; /* small problems: one wavefront per instance instead of 16 / 32 lanes */
+    int ric_any_shape; /* copra_batch_specialise: the Riccati-factor tier also where the packed kernels are expected to win */
+    int tri_min; /* smallest number of decision variables that takes a factor-only tier (0: 33) */
+    int tri_k; /* factor-only tier: instances per CU the layout search starts from (0: 8) */
+    int ric_k; /* Riccati-factor tier: start on the LDS-Q1 layout for this many instances per CU (0: Q1 in registers) */
+    int overflow_share; /* step down the ladder when more than batch / overflow_share instances overflow (0: 64 / 8) */
+    /* the one-instance-per-lane pass in front of the first tier (lmpc_lane.hpp) */
+    int no_lane_pass;
+    int no_lane_handover; /* the pass only filters; the tier sweeps itself */
+    int lane_min_batch; /* smallest batch that runs the pass (0: 20480 in front of the Riccati-factor tier, 4096 elsewhere; -1: any) */
+    int lane_share; /* keep the pass while batch / lane_share instances end in it (0: 8, shared-model mode 4) */
+    int lane_keep; /* never switch it off */
+    int lane_tables_in_memory; /* its row tables stay in HBM instead of LDS */
+    int lane_dbg; /* bit mask of experiment switches of the pass (1: no result stores, 2: no workspace, 8: phase stamps) */
+    /* shared-model mode */
+    int no_ric_shared; /* lmpc_shared.hpp instead of the Riccati-factor tier's shared-model mode */
+    /* long horizons */
+    int no_riccati; /* SolverFlag::DEFAULT keeps Goldfarb-Idnani where the Riccati interior-point kernel would be picked */
+    int no_ric_fast; /* the streaming interior-point kernel instead of the LDS-resident one */
+    int riccati_per_cu, large_per_cu, large_grid; /* persistent grids: waves / workgroups per CU, total (0: occupancy query) */
+    int large_no_w4; /* never the 128-VGPR builds of the workgroup kernels */
+    int large_params_lds; /* workgroup kernels: parameter blobs up to this many doubles go to LDS (0: 4096; -1: never) */
+    double ric_step_tol, ric_mu_tol, ric_s0, ric_lam0; /* interior-point tolerances and starting point (0: defaults of stage_plan.hpp) */
+    /* misc */
+    int recorded_events; /* time solves with recorded events instead of events carried in the dispatch packets */
+    int debug; /* print launch geometry and adaptation decisions to stderr */
+} copra_options_t;
+void copra_options_init(copra_options_t* opts);
+/* the process-wide defaults copra_options_init hands out and the entry points without an options argument use (copra_batch_create,
+ * copra_batch_create_initial_state, copra_plan_check, copra_qp_solve_dense_batch); NULL restores the built-in ones */
+copra_status_t copra_set_default_options(const copra_options_t* opts);
+
 /* ---- controller life cycle (replaces LMPC::LMPC / initializeController / addCost / addConstraint,
  *      src/LMPC.cpp:56-77, 118-128; dimension checks of costFunctions.cpp:44-61,88-98,122-137,173-193 and
  *      constraints.cpp:45-64,106-135,171-195,263-282,333-357 -> COPRA_ERR_DOMAIN) ---- */
 copra_status_t copra_batch_create(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs);
+/* the same with explicit engine options (`is` NULL: LMPC, else InitialStateLMPC as copra_batch_create_initial_state; `opts` NULL:
+ * the process-wide defaults) */
+copra_status_t copra_batch_create_with_options(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
+    const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is,
+    const copra_options_t* opts);
 void copra_batch_destroy(copra_batch_t* h);
 
 /* ---- how the controller is mapped onto the device: lanes that work on ONE instance -- 16 or 32 (several small
@@ -139,7 +196,8 @@ int copra_batch_lanes_per_instance(const copra_batch_t* h);
 
 /* ---- run-time specialisation: compile the kernels for THIS controller's (xDim, uDim, nrStep, cost rows) with
  *      `hipcc --genco` from the headers next to libcopra_hip.so (about 20-40 s, once per shape: the code object is kept in
- *      cache_dir, or $COPRA_JIT_CACHE, or ~/.cache/copra_amd when NULL) and use them from the next solve on.  The library
+ *      cache_dir, or $COPRA_JIT_CACHE, or ~/.cache/copra_amd when NULL; the compiler is $HIPCC or /opt/rocm/bin/hipcc -- the
+ *      only environment the library reads, and only here) and use them from the next solve on.  The library
  *      ships such instantiations for the BASELINE shapes only; every other shape otherwise runs on the run-time-shape
  *      kernel, which is ~2.5x slower on the same problem.  A no-op (COPRA_OK) for shapes that already have dedicated
  *      kernels (BASELINE shapes, packed small problems, InitialStateLMPC, more than 64 variables).  Results are the
@@ -192,6 +250,12 @@ copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, 
  *      once per instance into the library's buffer (a broadcast on the device) and the per-instance path above is taken: no new
  *      plan, no new handle.  Not for a reference TRAJECTORY in shared-model mode (COPRA_ERR_UNSUPPORTED: build a new controller). */
 copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_index, const double* p, int on_device);
+/*      Cost of that convenience: the controller is in per-instance-reference mode afterwards (until copra_batch_set_cost_reference(h,
+ *      k, NULL, 0), which restores the reference given at CREATION).  In that mode a long-horizon controller runs the streaming
+ *      interior-point kernel instead of the LDS-resident one (config 5: about 0.6 x the rate), a shared-model controller leaves the
+ *      Riccati-factor tier's shared mode, and every call broadcasts batch x rows doubles.  Where that matters -- InitialStateLMPC /
+ *      long horizons, shared-model ticks -- create a new controller with the new reference instead; the C++ and Python mirrors do so
+ *      for controllers with more than 64 decision variables. */
 
 /* ---- per-instance constraint data.  copra_batch_set_constraint_rhs: f of the Trajectory / Control / Mixed constraint
  *      `cstr_index` (position in the `cstrs` array given at creation) for every instance, [batch][rows] with the rows
@@ -276,8 +340,8 @@ copra_status_t copra_batch_layout_info(const copra_batch_t* h, int* lds_bytes, i
 /* ---- timing contract of LMPC::solveTime()/solveAndBuildTime() (src/LMPC.cpp:82-99, 108-116): device time of the
  *      last copra_batch_solve in seconds (hipEvent pair on the launch stream); whole batch, EVERY launch of the solve (the
  *      second launch, which only sees the instances whose active set outgrew the first one's layout, included).  For the
- *      one-wave kernels the events ride in the dispatch packets of the launches themselves; COPRA_RECORDED_EVENTS=1 brackets
- *      the solve with recorded events instead. ---- */
+ *      one-wave kernels the events ride in the dispatch packets of the launches themselves; copra_options_t::recorded_events
+ *      brackets the solve with recorded events instead. ---- */
 copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds);
 /* ---- the first launch of that solve alone (no reference counterpart: the figure a kernel profile -- rocprofv3 -- of the
  *      dominant kernel is compared with); equals copra_batch_last_solve_seconds where the solve is not timed per launch. ---- */
@@ -289,6 +353,11 @@ copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* sec
  *      after its first scan, src/QuadProgSolver.cpp:45-72) and hands the factor of the others to the first tier.
  *      ran: 1 if the last solve ran it; finished: the instances that ended in it (waits for the solve). ---- */
 copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished);
+/*      Whether the pass runs is decided per controller from the batch size (from 20480 instances on in front of the Riccati-factor
+ *      tier, 4096 elsewhere) and, where it only filters, from the share of instances that ended in it in the first two solves --
+ *      sampled again every 256 solves.  Which instances the pass or the tier finish does not change statuses or iteration counts,
+ *      but the two evaluate the unconstrained minimiser in different orders of summation: results are reproducible to rounding
+ *      (1e-11 relative), not bit for bit, across batch sizes and across the solves around such a decision. */
 
 /* ---- device-side split of that time: per-instance shader-clock cycles of the 7 phases of the fused kernel
  *      (preview, costs, norms, cholesky, inverse+x0, active set, result stores) + total; 8 values per instance.
@@ -321,6 +390,9 @@ copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir);
 const char* copra_last_error(void);
 copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len);
 int copra_abi_version(void);
+/* sha1 over the sources this library was built from (copra_amd/csrc/Makefile: COPRA_SRC_HASH; the same value keys the cache of run-time-
+ * compiled kernels): what a committed profile records so that a benchmark can tell whether the counters it quotes were taken on THIS build */
+const char* copra_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.pa
     if p not in sys.path:
         sys.path.insert(0, p)
 
+from copra_amd._capi import OPTIONS  # noqa: E402  engine options (copra_options_t): tests pin a tier by switching the others off
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -40,5 +42,5 @@ def full_size_paths(monkeypatch):
     trajectories; constraint rows inside one step) as per-step entries.  Tests that are ABOUT the full-size machinery -- the dense
     Psi' W Psi contraction on the matrix cores, the full-row slack evaluation -- build their inputs with AutoSpan, which produces exactly
     that structure: they switch the classification off, so that they keep covering what they were written for."""
-    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
-    monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")
+    monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
+    monkeypatch.setitem(OPTIONS, "no_step_rows", 1)

@@ -850,7 +850,10 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
         if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
-        if (!std::strcmp(mode, "tracking")) tracking_case(argc > 2 ? std::atoi(argv[2]) : 300);
+        if (!std::strcmp(mode, "tracking")) {
+            copra::LMPC::newHandlePerCostChange() = argc > 3 && !std::strcmp(argv[3], "newhandle"); // (measurements: a new handle per swapped cost)
+            tracking_case(argc > 2 ? std::atoi(argv[2]) : 300);
+        }
         if (!std::strcmp(mode, "latency")) latency_case(argc > 2 ? std::atoi(argv[2]) : 500, argc > 3 && !std::strcmp(argv[3], "hard"));
     } catch (const std::exception& e) {
         std::printf("uncaught exception: %s\n", e.what());

@@ -109,7 +109,17 @@ struct BoundedSystem {
     Eigen::VectorXd c, x0, xd, ud, wx, wu, uLower, uUpper, xLower, xUpper;
 };
 
-static std::shared_ptr<copra::PreviewSystem> build_controller(BoundedSystem& s, copra::LMPC& controller)
+// (the controller co-owns its pieces and DROPS the ones the user has released after a solve -- src/LMPC.cpp:288-307 --, so the
+//  caller keeps them, as the reference's test bodies do)
+struct Pieces {
+    std::shared_ptr<copra::PreviewSystem> ps;
+    std::shared_ptr<copra::TargetCost> xCost;
+    std::shared_ptr<copra::ControlCost> uCost;
+    std::shared_ptr<copra::TrajectoryBoundConstraint> trajConstr;
+    std::shared_ptr<copra::ControlBoundConstraint> contConstr;
+};
+
+static Pieces build_controller(BoundedSystem& s, copra::LMPC& controller)
 {
     auto ps = std::make_shared<copra::PreviewSystem>();
     ps->system(s.A, s.B, s.c, s.x0, s.nbStep);
@@ -124,14 +134,14 @@ static std::shared_ptr<copra::PreviewSystem> build_controller(BoundedSystem& s, 
     controller.addCost(uCost);
     controller.addConstraint(trajConstr);
     controller.addConstraint(contConstr);
-    return ps;
+    return Pieces { ps, xCost, uCost, trajConstr, contConstr };
 }
 
 static void lmpc_case()
 {
     BoundedSystem s;
     copra::LMPC controller;
-    auto ps = build_controller(s, controller);
+    Pieces keep = build_controller(s, controller);
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0)
             controller.selectQPSolver(copra::SolverFlag::QuadProgDense);
@@ -155,7 +165,8 @@ static void host_only_case()
 {
     BoundedSystem s;
     copra::LMPC controller;
-    auto ps = build_controller(s, controller);
+    Pieces keep = build_controller(s, controller);
+    auto ps = keep.ps;
     REQUIRE(ps->fullXDim == 2 * (s.nbStep + 1) && ps->fullUDim == s.nbStep);
     copra::InitialStateLMPC isController(ps);
     (void)isController;

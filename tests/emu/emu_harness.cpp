@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <ucontext.h>
+#include <algorithm>
 #include <vector>
 
 namespace copra_hip {
@@ -139,7 +140,18 @@ static const double* g_cost_p[copra_hip::kMaxCosts]; // per-instance cost refere
 
 extern "C" {
 
+static int g_lane_hist[copra_hip::kLaneHistBins]; // violated-row histogram of the last lane pass (FusedPlan::lane_hist)
+void emu_last_lane_hist(int* out) { std::copy(g_lane_hist, g_lane_hist + copra_hip::kLaneHistBins, out); }
 void emu_set_cost_reference(int cost_index, const double* p) { g_cost_p[cost_index] = p; }
+// the engine options of the next calls (copra_options_t; what copra_batch_create_with_options takes): every HostPlan built here starts
+// from them, and the launch decisions this harness restates from copra_batch_solve consult them
+void emu_set_options(const copra_options_t* opts)
+{
+    copra_options_t builtin {};
+    builtin.struct_size = (int)sizeof(copra_options_t);
+    default_options() = builtin;
+    if (opts) default_options() = resolve_options(opts);
+}
 // per-instance right-hand sides in STACKED row order [batch][mgen] and control bounds [batch][n] for the next solve
 static const double *g_row_f_inst, *g_lb_inst, *g_ub_inst;
 void emu_set_instance_rows(const double* row_f, const double* lb, const double* ub)
@@ -284,7 +296,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     const size_t bytes1 = (size_t)P.lds.total * sizeof(double);
     // the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp), as copra_batch_solve runs it
     // (copra_hip.hip: lane_pass_wanted): the instances it does not finish go through the first tier
-    bool lane_pass = P.lane_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && (P.lds.ric || std::getenv("COPRA_EMU_LANE_FILTER")) && !std::getenv("COPRA_NO_LANE_PASS")
+    bool lane_pass = P.lane_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && (P.lds.ric || std::getenv("COPRA_EMU_LANE_FILTER")) && !default_options().no_lane_pass
         && ((P.nx == 6 && P.nu == 3) || (P.nx == 4 && P.nu == 2) || (P.nx == 5 && P.nu == 3) || (P.nx == 2 && P.nu == 1));
     for (int k = 0; k < kMaxCosts; ++k) lane_pass = lane_pass && (!P.cost_p[k] || P.lane_cref >= 0);
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
@@ -298,6 +310,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
+        std::fill(g_lane_hist, g_lane_hist + kLaneHistBins, 0);
+        P.lane_hist = g_lane_hist; // (what the first solve of a controller asks of the pass: copra_batch_solve picks the tier's layout from it)
         for (int g = 0; g < groups; ++g) {
             int oHl = 0;
             const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
@@ -309,8 +323,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             }, lbytes, g, groups);
             if (r != 0) return -100;
         }
+        P.lane_hist = nullptr;
         P.lane_from_list = 1;
-        P.lane_handover = (P.lds.ricC && !std::getenv("COPRA_NO_LANE_HANDOVER")) ? 1 : 0;
+        P.lane_handover = (P.lds.ricC && !default_options().no_lane_handover) ? 1 : 0;
         for (int k = 0; k < lane_count; ++k) {
             const int raw = lane_list[(size_t)k], b = raw & 0x7fffffff;
             lane_failed = raw < 0;
@@ -381,7 +396,7 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
     if (not_converged) not_converged[1] = 0;
     bool refs = false;
     for (int k = 0; k < kMaxCosts; ++k) refs = refs || g_cost_p[k] != nullptr;
-    if (S.fast_ok && !refs && !std::getenv("COPRA_NO_RIC_FAST")) {
+    if (S.fast_ok && !refs && !default_options().no_ric_fast) {
         int rf = emu::run_wave([&]() { lmpc_riccati_mfma_body(P, S); }, (size_t)S.fast_lds_doubles * sizeof(double), 0, 1);
         if (not_converged) not_converged[0] = ovf_count, not_converged[1] = 1;
         return rf != 0 ? -100 : 0;
@@ -487,7 +502,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, no per-instance references): one prepare
     // run of the body leaves the stage records, bkd, G and the row norms; the first tier copies them instead of sweeping
     std::vector<double> ric_model;
-    const bool ric_shared = P.lds.ric && P.N == 20 && P.lds.q1regs == kFusedQ1Regs && !warm_set && !std::getenv("COPRA_NO_RIC_SHARED");
+    const bool ric_shared = P.lds.ric && P.N == 20 && P.lds.q1regs == kFusedQ1Regs && !warm_set && !default_options().no_ric_shared;
     if (ric_shared) {
         int oBk, oG, oNb;
         ric_model.assign((size_t)ric_model_offsets(nx, nu, N, P.mgen, oBk, oG, oNb), 0.0);
@@ -522,7 +537,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // in front of the Riccati-factor tier in shared-model mode: the one-instance-per-lane pass in its shared-model form (as copra_batch_solve)
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
     int lane_count = 0, lane_other = 0, lane_finished = -1;
-    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !std::getenv("COPRA_NO_LANE_PASS")) {
+    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass) {
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = groups * 64;
         P.lane_list = lane_list.data();

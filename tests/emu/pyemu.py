@@ -32,6 +32,19 @@ def lib():
     return _lib
 
 
+def _sync_options():
+    """hand _capi.OPTIONS (what BatchLMPC would pass to copra_batch_create_with_options) to the harness"""
+    o = _capi.make_options()
+    lib().emu_set_options(C.byref(o))
+
+
+def last_lane_hist():
+    """histogram (32 bins, the last one open) of the violated-row counts of the instances the last lane pass left to the first tier"""
+    out = (C.c_int * 32)()
+    lib().emu_last_lane_hist(out)
+    return np.array(list(out))
+
+
 def _batchify(A, B, d, x0):
     A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
@@ -48,6 +61,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
                row_rhs=None, bounds=None):
     """cost_refs: {cost_index: array (batch, rows)} per-instance references (copra_batch_set_cost_reference);
     row_rhs: (batch, mgen) per-instance right-hand sides in stacked row order; bounds: (lower, upper) each (batch, n)"""
+    _sync_options()
     rr = None if row_rhs is None else np.ascontiguousarray(row_rhs, dtype=np.float64)
     lo = None if bounds is None else np.ascontiguousarray(bounds[0], dtype=np.float64)
     up = None if bounds is None else np.ascontiguousarray(bounds[1], dtype=np.float64)
@@ -116,6 +130,7 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, dump_instance=-1, specialised=True,
 def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_refs=None, row_rhs=None, bounds=None):
     """lmpc_riccati.hpp (stage-wise interior-point body) for every instance; returns None when the controller is not
     stage-wise.  Arguments as lmpc_solve."""
+    _sync_options()
     rr = None if row_rhs is None else np.ascontiguousarray(row_rhs, dtype=np.float64)
     lo = None if bounds is None else np.ascontiguousarray(bounds[0], dtype=np.float64)
     up = None if bounds is None else np.ascontiguousarray(bounds[1], dtype=np.float64)
@@ -167,6 +182,7 @@ WARM_CAP = 32  # plan.hpp::kWarmCap
 def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
     """shared-model fast path: ONE system (A, B, d), x0 of shape (batch, nx).  warm: int32 array (batch, WARM_CAP) kept by
     the caller across receding-horizon ticks (initialised to -1): the active set of the previous tick, shifted by one step"""
+    _sync_options()
     A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
@@ -194,6 +210,7 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
 
 def qp_dense(Q, c, Aeq, beq, Aineq, bineq, XL, XU):
     """batched: Q (b,n,n), c (b,n), Aeq (b,meq,n) ... natural numpy indexing"""
+    _sync_options()
     Q = np.asarray(Q, dtype=np.float64)
     if Q.ndim == 2:
         Q, c, XL, XU = Q[None], np.asarray(c)[None], np.asarray(XL)[None], np.asarray(XU)[None]

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from copra_amd._capi import OPTIONS  # engine options (copra_options_t): tests pin a tier by switching the others off
+
 import fixtures as F
 
 RTOL = 1e-6  # BASELINE.json north_star tolerance
@@ -261,9 +263,9 @@ def test_riccati_factor_tier_with_general_rows(emu, oracle):
 def test_riccati_factor_tier_with_q1_in_lds(emu, oracle, monkeypatch):
     """the steps of the layout ladder below the register-Q1 one (what copra_batch_solve moves to when more than an eighth of
     the batch overflows five columns): the same body with Q1 in LDS and as many columns as five instances per CU leave --
-    the tight workload then finishes in the first tier; COPRA_RIC_K starts the plan there"""
+    the tight workload then finishes in the first tier; option ric_k starts the plan there"""
     from copra_amd import workloads
-    monkeypatch.setenv("COPRA_RIC_K", "5")
+    monkeypatch.setitem(OPTIONS, "ric_k", 5)
     wl = workloads.com_preview(10, v_max=0.25, u_max=1.2, seed=9)
     re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     assert re["riccati_factor"] and re["rcap"] >= 16 and re["overflowed"] == 0
@@ -491,14 +493,14 @@ def test_shared_model_fast_path(emu, oracle):
     wl = workloads.com_preview(10, v_max=0.25, u_max=1.2)
     A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
     # the headline shape runs it twice: on the Riccati-factor tier in shared-model mode (stage records swept once by a prepare
-    # run, copied by every instance: what copra_batch_solve picks for cold starts) and on lmpc_shared.hpp (COPRA_NO_RIC_SHARED)
+    # run, copied by every instance: what copra_batch_solve picks for cold starts) and on lmpc_shared.hpp (option no_ric_shared)
     for ric in (True, False):
         if not ric:
-            os.environ["COPRA_NO_RIC_SHARED"] = "1"
+            OPTIONS["no_ric_shared"] = 1
         try:
             re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
         finally:
-            os.environ.pop("COPRA_NO_RIC_SHARED", None)
+            OPTIONS.pop("no_ric_shared", None)
         assert re["riccati_factor"] == ric and re["overflowed"] > 0
         for k in range(10):
             ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
@@ -888,9 +890,9 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
     (`filter_only`); `off`: the tier alone.  Statuses, BOTH iteration counters, U and X against the oracle in all three."""
     from copra_amd import workloads
     if mode == "off":
-        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
     if mode == "filter_only":
-        monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+        monkeypatch.setitem(OPTIONS, "no_lane_handover", 1)
     wl = workloads.com_preview(batch, N=N, v_max=vmax, u_max=umax, seed=9)
     args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     re = emu.lmpc_solve(*args)
@@ -970,7 +972,7 @@ def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
     assert re["riccati_factor"] and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     assert 0 < re["lane_pass_finished"] == int(((ro["iter"][:, 0] == 1) & ok).sum()) < b
-    monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+    monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
     r0 = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     assert r0["lane_pass_finished"] == -1 and (r0["status"] == re["status"]).all() and (r0["iter"] == re["iter"]).all()
     assert _rel(r0["control"][ok], re["control"][ok]) <= 1e-11
@@ -1000,7 +1002,7 @@ def test_one_instance_per_lane_pass_filters_for_the_other_tiers(emu, oracle, mon
 def test_selection_rows_of_a_trajectory_constraint(emu, oracle, monkeypatch, specialised):
     """|v| <= v_max written as TrajectoryConstraint(E = [S; -S], f) with S a selection matrix: the plan builder classifies such rows as
     +- one component of one state (the rows of +-Psi, like TrajectoryBoundConstraint's), the controller keeps the compact variant of the
-    Riccati-factor tier; against the oracle, and identical to the dense-row classification (COPRA_NO_SELECTION_ROWS)"""
+    Riccati-factor tier; against the oracle, and identical to the dense-row classification (option no_selection_rows)"""
     from copra_amd import workloads
     b = 40
     wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=41)
@@ -1014,7 +1016,7 @@ def test_selection_rows_of_a_trajectory_constraint(emu, oracle, monkeypatch, spe
     assert ok.sum() >= 8 and (~ok).sum() >= 3 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     assert (ro["iter"][ok, 0] > 1).any()
-    monkeypatch.setenv("COPRA_NO_SELECTION_ROWS", "1")
+    monkeypatch.setitem(OPTIONS, "no_selection_rows", 1)
     rd = emu.lmpc_solve(*args, specialised=specialised)
     assert (rd["status"] == re["status"]).all() and (rd["iter"][ok] == re["iter"][ok]).all()
     assert _rel(rd["control"][ok], re["control"][ok]) <= 1e-10
@@ -1026,7 +1028,7 @@ def test_selection_rows_of_a_trajectory_constraint(emu, oracle, monkeypatch, spe
 def test_full_size_rows_that_touch_one_step(emu, oracle, monkeypatch, kind):
     """a terminal constraint written the reference's way -- a FULL-SIZE E (rows over the whole trajectory) that is non-zero in the last
     state only -- is classified as a per-step row of that step (selection rows as +- one component); likewise full-size G / mixed rows
-    inside one step.  Against the oracle and against the full-row classification (COPRA_NO_STEP_ROWS)."""
+    inside one step.  Against the oracle and against the full-row classification (option no_step_rows)."""
     from copra_amd import workloads
     b = 24
     wl = workloads.com_preview(b, v_max=0.6, u_max=3.0, seed=51)
@@ -1058,7 +1060,7 @@ def test_full_size_rows_that_touch_one_step(emu, oracle, monkeypatch, kind):
     assert ok.sum() >= b // 2 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     assert (ro["iter"][ok, 0] > 1).any()
-    monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")
+    monkeypatch.setitem(OPTIONS, "no_step_rows", 1)
     rf = emu.lmpc_solve(*args)
     assert (rf["status"] == re["status"]).all() and (rf["iter"][ok] == re["iter"][ok]).all() and _rel(rf["control"][ok], re["control"][ok]) <= 1e-9
     if kind == "terminal_velocity":
@@ -1071,7 +1073,7 @@ def test_reference_trajectory_costs(emu, oracle, monkeypatch, specialised, what)
     """a reference that changes along the horizon -- the reference's API can only express it as a FULL-SIZE entry, M = blkdiag(M0 .. M0),
     stacked p (costFunctions.cpp:63-82) -- is classified as a per-step entry with the reference of the step (CostTerm::pstride) and runs on
     the step-by-step cost phase instead of the dense contraction; against the oracle (which takes the full-size entry as it is) and
-    against the dense path (COPRA_NO_STAGE_REFS), with controller-wide and with per-instance reference trajectories"""
+    against the dense path (option no_stage_refs), with controller-wide and with per-instance reference trajectories"""
     from copra_amd import workloads
     b = 12
     wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=71)
@@ -1099,7 +1101,7 @@ def test_reference_trajectory_costs(emu, oracle, monkeypatch, specialised, what)
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-8 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-8
     refs = {0: np.tile(pf, (b, 1)) + 0.02 * rng.standard_normal((b, pf.size))}  # every instance its own reference trajectory
     re2 = emu.lmpc_solve(*args, specialised=specialised, cost_refs=refs)
-    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+    monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
     rd = emu.lmpc_solve(*args, specialised=specialised)
     rd2 = emu.lmpc_solve(*args, specialised=specialised, cost_refs=refs)
     assert (rd["status"] == re["status"]).all() and _rel(rd["control"][ok], re["control"][ok]) <= 1e-8
@@ -1126,9 +1128,9 @@ def test_reference_trajectory_on_the_riccati_factor_tier(emu, oracle, monkeypatc
     uref = 0.2 * np.sin(np.arange(N))[:, None] * np.ones((1, nu))
     track = dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=pf, weights=np.tile([10.0, 10.0, 10.0, 1.0, 1.0, 1.0], N + 1))
     if mode == "own_sweep":
-        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
     if mode == "lane_pass_filter_only":
-        monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+        monkeypatch.setitem(OPTIONS, "no_lane_handover", 1)
     for second in (wl["costs"][1], dict(kind="control", N=np.kron(np.eye(N), np.eye(nu)), p=uref.reshape(-1), weights=np.full(nu * N, 1e-2))):
         args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, [track, second], wl["cstrs"])
         ro = oracle.lmpc_solve_batch(*args, nthreads=8)
@@ -1139,9 +1141,9 @@ def test_reference_trajectory_on_the_riccati_factor_tier(emu, oracle, monkeypatc
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
         refs = {0: np.tile(pf, (b, 1)) + 0.02 * rng.standard_normal((b, pf.size))}  # every instance its own reference trajectory
         re2 = emu.lmpc_solve(*args, cost_refs=refs)
-        monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+        monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
         rd2 = emu.lmpc_solve(*args, cost_refs=refs)  # (the full-size entry as it is: dense contraction)
-        monkeypatch.delenv("COPRA_NO_STAGE_REFS")
+        monkeypatch.setitem(OPTIONS, "no_stage_refs", 0)
         ok2 = rd2["status"] == 0
         assert re2["riccati_factor"] and not rd2["riccati_factor"]
         assert ok2.sum() >= b - 6 and (re2["status"] == rd2["status"]).all() and (re2["iter"][ok2] == rd2["iter"][ok2]).all()
@@ -1164,7 +1166,7 @@ def test_reference_trajectory_shared_model(emu, oracle, monkeypatch):
     ok = ro["status"] == 0
     for no_pass in (False, True):
         if no_pass:
-            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+            monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
         re = emu.lmpc_solve_shared(A, B, d, wl["x0"], N, costs, wl["cstrs"])
         assert re["riccati_factor"] and ok.sum() >= b - 4 and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
@@ -1190,9 +1192,9 @@ def test_mixed_cost_reference_trajectory(emu, oracle, monkeypatch, mode):
     mixed = dict(kind="mixed", M=Mf, N=Nf, p=pk.reshape(-1), weights=np.tile([2.0, 3.0, 1.5], N))
     costs = [wl["costs"][0], mixed, wl["costs"][1]]
     if mode == "own_sweep":
-        monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
     if mode == "factor_only_tier":
-        monkeypatch.setenv("COPRA_NO_RIC", "1")
+        monkeypatch.setitem(OPTIONS, "no_ric", 1)
     args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, costs, wl["cstrs"])
     ro = oracle.lmpc_solve_batch(*args, nthreads=8)
     ok = ro["status"] == 0
@@ -1202,7 +1204,7 @@ def test_mixed_cost_reference_trajectory(emu, oracle, monkeypatch, mode):
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     refs = {1: np.tile(pk.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, pk.size))}
     re2 = emu.lmpc_solve(*args, cost_refs=refs)
-    monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+    monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
     rd = emu.lmpc_solve(*args)
     rd2 = emu.lmpc_solve(*args, cost_refs=refs)  # (the full-size entry as it is: dense contraction)
     assert not rd["riccati_factor"] and (rd["status"] == re["status"]).all() and _rel(rd["control"][ok], re["control"][ok]) <= 1e-9
@@ -1210,3 +1212,43 @@ def test_mixed_cost_reference_trajectory(emu, oracle, monkeypatch, mode):
     assert ok2.sum() >= b - 6 and (re2["status"] == rd2["status"]).all() and (re2["iter"][ok2] == rd2["iter"][ok2]).all()
     assert _rel(re2["control"][ok2], rd2["control"][ok2]) <= 1e-9
     assert np.abs(re2["control"][ok2 & ok] - re["control"][ok2 & ok]).max() > 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(__import__("published_qps").PUBLISHED))
+def test_published_qp_examples_on_the_kernel_body(oracle, emu, name):
+    """tests/published_qps.py (R solve.QP, Goldfarb & Idnani 1983, MathWorks, Nocedal & Wright, CVXOPT, Scilab, Hock-Schittkowski)
+    through the dense-QP kernel body (qp_dense.hpp + gi_core.hpp) on the wave emulator: the published digits, and the oracle's
+    iteration counts"""
+    import published_qps as PQ
+    qp = PQ.PUBLISHED[name]
+    args = (qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+    x, fail, it = emu.qp_dense(*args)
+    xo, fo, ito = oracle.quadprog_dense(*args)
+    assert fail[0] == fo == 0 and tuple(it[0]) == tuple(ito)
+    assert np.abs(x[0] - qp["x_star"]).max() <= qp["tol"] and np.abs(x[0] - xo).max() <= 1e-12 * (1.0 + np.abs(xo).max())
+    if qp["iterations"] is not None:
+        assert tuple(it[0]) == qp["iterations"]
+
+
+def test_lane_pass_counts_the_rows_the_unconstrained_minimiser_violates(oracle, emu):
+    """FusedPlan::lane_hist: on the first solve of a controller the one-instance-per-lane pass histograms, over the instances it leaves
+    to the first tier, how many rows and bounds the unconstrained minimiser violates -- copra_batch_solve picks the tier's starting
+    layout from it (the final active set is ~ 1.1 x that count).  Against numpy: -Q^-1 c of the oracle's condensed QP, rows and bounds
+    counted with qpgen2's test."""
+    from copra_amd import workloads
+    b = 96
+    wl = workloads.com_preview(b, v_max=0.25, u_max=1.2)
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    hist = emu.last_lane_hist()
+    want = np.zeros(32, dtype=int)
+    active = []
+    for k in range(b):
+        qp = oracle.lmpc_build(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        u0 = -np.linalg.solve(qp["Q"], qp["c"])
+        nv = int((qp["Aineq"] @ u0 - qp["bineq"] > 1e-12).sum() + (u0 > qp["ub"] + 1e-12).sum() + (u0 < qp["lb"] - 1e-12).sum())
+        if nv:
+            want[min(nv, 31)] += 1
+            active.append((nv, re["iter"][k, 0] - 1 - 2 * re["iter"][k, 1]))
+    assert hist.sum() == want.sum() > b // 2 and (hist == want).all()
+    nv, na = np.array(active).T
+    assert np.corrcoef(nv, na)[0, 1] > 0.8 and 0.9 <= na.mean() / nv.mean() <= 1.35  # (what the predictor b + b / 8 rests on)

@@ -16,6 +16,8 @@ import os
 import numpy as np
 import pytest
 
+from copra_amd._capi import OPTIONS  # engine options (copra_options_t): tests pin a tier by switching the others off
+
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
@@ -57,7 +59,7 @@ def _check(wl, batch, oracle):
     return eng, res, ref
 
 
-def _check_against_truth(wl, costs, res, ref, initial_state=None, x0_opt=None, picks=None, oracle_bar=None):
+def _check_against_truth(wl, costs, res, ref, initial_state=None, x0_opt=None, picks=None, oracle_bar=None, no_worse_than_oracle=False):
     """every solved instance (or `picks`) against the certified extended-precision optimum (tests/truth.py), entry by entry with
     the floor of this file: the DEVICE must be within RTOL; the oracle's distance is returned (and held to `oracle_bar` when given,
     so that a docstring's figure cannot rot).  The active set is identified from the ORACLE's solution -- the certificate makes the
@@ -76,11 +78,16 @@ def _check_against_truth(wl, costs, res, ref, initial_state=None, x0_opt=None, p
         dev_x = max(dev_x, _rel(res["trajectory"][k], t["trajectory"]))
         ora_u = max(ora_u, _rel(ref["control"][k], t["control"]))
         ora_x = max(ora_x, _rel(ref["trajectory"][k], t["trajectory"]))
+        # the true relative error of every entry of size >= 1e-2 -- never relaxed
+        assert _rel(res["control"][k], t["control"], floor=1e-2) <= RTOL and _rel(res["trajectory"][k], t["trajectory"], floor=1e-2) <= RTOL
         if x0_opt is not None:
             assert np.abs(x0_opt[k] - t["x0_opt"]).max() <= 1e-9
     print("   distance from the certified optimum (floor %g): device U %.2e X %.2e | oracle U %.2e X %.2e"
           % (ABS_FLOOR, dev_u, dev_x, ora_u, ora_x))
-    assert dev_u <= RTOL and dev_x <= RTOL, (dev_u, dev_x, ora_u, ora_x)
+    if no_worse_than_oracle:  # (the CPU path itself is further than RTOL from the optimum: the device must not be further than IT is)
+        assert dev_u <= max(RTOL, ora_u) and dev_x <= max(RTOL, ora_x), (dev_u, dev_x, ora_u, ora_x)
+    else:
+        assert dev_u <= RTOL and dev_x <= RTOL, (dev_u, dev_x, ora_u, ora_x)
     if oracle_bar is not None:
         assert max(ora_u, ora_x) <= oracle_bar, (ora_u, ora_x)
     return dict(device=(dev_u, dev_x), oracle=(ora_u, ora_x))
@@ -344,10 +351,12 @@ def test_two_tier_overflow_on_gpu(oracle):
 def test_headline_shape_with_a_general_output_map(oracle):
     """compile-time headline shape, TrajectoryCost with a general 6 x 6 M and with a 5-row selection (the identity M of
     the bench workload takes a shortcut in the cost phase: CostTerm::ident).
-    Status codes and both iteration counters equal the oracle's on every instance.  Values: the general M gives Hessians of
-    condition ~1e6, and on 15 of the 512 instances the ORACLE is more than 1e-7 (worst: 2.1e-6, instance 105) away from the certified
-    optimum on controls of size ~1e-3 -- so the device is held to 1e-6 of the CERTIFIED optimum on all 512 (tests/truth.py) and to
-    (oracle's distance + 1e-6) of the oracle; the selection variant is benign (oracle 1.1e-8 from the optimum)."""
+    Status codes and both iteration counters equal the oracle's on every instance.  Values, measured against the CERTIFIED optimum
+    (tests/truth.py; MI355X, round 4): the general M gives Hessians of condition ~1e6, and at the floor of 1e-3 BOTH sides miss 1e-6 on
+    controls of size ~1e-3 -- the CPU path by 2.15e-6 (15 of 512 instances above 1e-7), the device by 1.82e-6, i.e. 2e-9 absolute,
+    which is cond x eps x |U|.  Asserted: on entries of size >= 1e-2 (the true relative error) the device is within 1e-6 of the optimum
+    on all 512; at the floor of 1e-3 it is no further from the optimum than the CPU path itself, and within (CPU path's distance + 1e-6)
+    of the CPU path.  The selection variant is benign: device and oracle within 1e-8 of the optimum, 1e-6 asserted."""
     from copra_amd import workloads
     b = 512
     wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=5)
@@ -362,7 +371,7 @@ def test_headline_shape_with_a_general_output_map(oracle):
         assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
         ok = ref["status"] == 0
         assert ok.sum() > b // 2
-        dist = _check_against_truth(wl, wl2["costs"], res, ref, oracle_bar=5e-6)
+        dist = _check_against_truth(wl, wl2["costs"], res, ref, oracle_bar=5e-6, no_worse_than_oracle=M.shape[0] == 6)
         assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL + dist["oracle"][0]
         assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL + dist["oracle"][1]
 
@@ -597,6 +606,16 @@ def test_config5_long_horizon_initial_state(oracle, r_diag, solver):
         tr = res["trajectory"][k].reshape(wl["N"] + 1, 12)
         assert np.abs(tr[-1, 6:]).max() <= 1e-8  # the full-size terminal equality
         assert np.abs(res["control"][k]).max() <= 2.0 + 1e-6
+    if not same_iters:  # the default solver ENTRY-WISE (floor 1e-3) against the certified optimum of all six instances, at both R
+        # (measured, round 4: device 5.8e-7 at both R; the CPU path 3.1e-7 at R = 1e-2 I and 3.2e-3 at R = 1e-6 I)
+        ros = dict(status=np.zeros(b, dtype=int), control=[], trajectory=[], x0_opt=[])
+        for k in range(b):
+            io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
+            for key in ("control", "trajectory", "x0_opt"):
+                ros[key].append(ro[key])
+        ros = {k: np.array(v) for k, v in ros.items()}
+        _check_against_truth(wl, wl["costs"], res, ros, initial_state=ist, x0_opt=x0o)
     if r_diag == 1e-6:  # the certified optimum
         import test_golden as G
         twl, picks = G.config5_truth_cases()
@@ -722,8 +741,10 @@ def test_shared_model_fast_path(oracle):
     ok = ref["status"] == 0
     # some instances hold more than 17 active constraints: they go through the second tier (full LDS layout)
     assert ok.sum() > 0.5 * b and (res["iter"][ok, 0] - res["iter"][ok, 1]).max() > 17
-    assert _rel(res["control"][ok], ref["control"][ok]) <= 1e-9
-    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= 1e-9
+    # (two device paths, two summation orders, up to 28 iterations: 1e-8 entry-wise at the floor of 1e-3 = 1e-11 absolute on entries that
+    #  vanish; 1e-10 of the solution's scale)
+    assert _rel(res["control"][ok], ref["control"][ok]) <= 1e-8 and _rel_vec(res["control"][ok], ref["control"][ok]) <= 1e-10
+    assert _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= 1e-8 and _rel_vec(res["trajectory"][ok], ref["trajectory"][ok]) <= 1e-10
     for k in range(0, b, 512):
         ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
         assert ro["status"] == res["status"][k]
@@ -1197,7 +1218,7 @@ def test_riccati_factor_tier_general_rows_and_ladder(oracle):
 
 def test_shared_model_both_first_tiers(oracle, monkeypatch):
     """copra_batch_set_shared_system on the headline shape: the first solve runs the Riccati-factor tier in shared-model mode
-    (stage records swept once), the second one -- COPRA_NO_RIC_SHARED is read at every solve -- lmpc_shared.hpp; a third one
+    (stage records swept once), a second controller created with the option no_ric_shared runs lmpc_shared.hpp; a third solve of the first one
     with the warm start enabled must move to lmpc_shared.hpp by itself.  Same statuses and iteration counts as the oracle
     each time, U and X within the tolerance, the two cold solves equal to rounding"""
     from copra_amd import BatchLMPC, workloads
@@ -1208,10 +1229,12 @@ def test_shared_model_both_first_tiers(oracle, monkeypatch):
     eng.set_x0(wl["x0"])
     eng.solve()
     r1 = eng.results()
-    monkeypatch.setenv("COPRA_NO_RIC_SHARED", "1")
-    eng.solve()
-    r2 = eng.results()
-    monkeypatch.delenv("COPRA_NO_RIC_SHARED")
+    eng2 = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=dict(no_ric_shared=1))  # (options are fixed at creation)
+    eng2.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng2.set_x0(wl["x0"])
+    eng2.solve()
+    r2 = eng2.results()
+    eng2.close()
     eng.set_warm_start(True)
     eng.solve()
     r3 = eng.results()
@@ -1230,10 +1253,10 @@ def test_shared_model_both_first_tiers(oracle, monkeypatch):
 def test_shared_model_leaves_riccati_tier_when_ladder_is_exhausted(oracle, monkeypatch):
     """round-2 advisor finding: a shared-model controller whose layout ladder has nothing roomier left falls back to the
     square layouts -- and must then leave the Riccati-factor tier's shared mode as well (its kernel would read per-instance A / B / d
-    that a shared-model controller never set).  COPRA_NO_LADDER makes the ladder empty, the tight workload overflows five
+    that a shared-model controller never set).  option no_ladder makes the ladder empty, the tight workload overflows five
     columns on far more than one instance in 32: the second and third solves run lmpc_shared.hpp; all three agree with the oracle"""
     from copra_amd import BatchLMPC, workloads
-    monkeypatch.setenv("COPRA_NO_LADDER", "1")
+    monkeypatch.setitem(OPTIONS, "no_ladder", 1)
     b = 1024
     wl = workloads.com_preview(b, v_max=0.25, u_max=1.2, seed=17)
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
@@ -1396,7 +1419,7 @@ def test_riccati_factor_tier_compiled_for_other_shapes(oracle, tmp_path, shape):
 @pytest.mark.parametrize("vmax,umax", [(0.6, 3.0), (0.35, 1.8), (0.25, 1.2)])
 def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
     """lmpc_lane.hpp (round 3): LQ sweep + roll-out with one instance per lane in front of the headline's tier, at the full batch of
-    BASELINE configs[2] (and a ragged one).  Against the tier alone (COPRA_NO_LANE_PASS): same statuses, BOTH iteration counters
+    BASELINE configs[2] (and a ragged one).  Against the tier alone (option no_lane_pass): same statuses, BOTH iteration counters
     equal, U and X to 1e-11; the pass finishes exactly the instances that report the iteration count (1, 0) -- their unconstrained
     minimiser violates nothing; a stratified sample (every iteration count) against the oracle."""
     from copra_amd import BatchLMPC, workloads
@@ -1404,12 +1427,12 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
         wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
         out = {}
         for mode in ("off", "filter_only", "on"):
-            monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
-            monkeypatch.delenv("COPRA_NO_LANE_HANDOVER", raising=False)
+            monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
+            monkeypatch.setitem(OPTIONS, "no_lane_handover", 0)
             if mode == "off":
-                monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+                monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
             if mode == "filter_only":
-                monkeypatch.setenv("COPRA_NO_LANE_HANDOVER", "1")
+                monkeypatch.setitem(OPTIONS, "no_lane_handover", 1)
             eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
             eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
             for _ in range(3):  # (the layout controller may step down the tier's ladder between solves)
@@ -1447,9 +1470,9 @@ def test_one_instance_per_lane_pass_shared_model_tick(oracle, monkeypatch):
     A, B, d = wl["A"][7], wl["B"][7], wl["d"][7]
     out = {}
     for mode in ("off", "on"):
-        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
         if mode == "off":
-            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+            monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
         eng.set_shared_system(A, B, d)
         eng.set_x0(wl["x0"][::-1].copy())
@@ -1475,7 +1498,7 @@ def test_one_instance_per_lane_pass_shared_model_tick(oracle, monkeypatch):
 @pytest.mark.parametrize("N", [20, 10, 15])
 def test_one_instance_per_lane_pass_small_ragged_batch(oracle, monkeypatch, N):
     """the pass is only taken from 20480 instances on (a wave of it runs ~ 90 us whatever the batch); forced on a small ragged batch
-    (COPRA_LANE_MIN_BATCH), every instance against the oracle at the three horizons the library instantiates"""
+    (option lane_min_batch), every instance against the oracle at the three horizons the library instantiates"""
     from copra_amd import BatchLMPC, workloads
     b = 333
     wl = workloads.com_preview(b, N=N, seed=17)
@@ -1483,7 +1506,7 @@ def test_one_instance_per_lane_pass_small_ragged_batch(oracle, monkeypatch, N):
     eng, res = _solve_gpu(wl, b)
     assert eng.lane_pass_info() == (False, 0)
     eng.close()
-    monkeypatch.setenv("COPRA_LANE_MIN_BATCH", "1")
+    monkeypatch.setitem(OPTIONS, "lane_min_batch", 1)
     eng, res = _solve_gpu(wl, b)
     ok = ref["status"] == 0
     assert eng.lane_pass_info() == (True, int(((ref["iter"][:, 0] == 1) & ok).sum()))
@@ -1502,9 +1525,9 @@ def test_one_instance_per_lane_pass_per_instance_references(oracle, monkeypatch)
     refs = np.tile(wl["costs"][0]["p"], (b, 1)) + 0.03 * rng.standard_normal((b, 6))
     out = {}
     for mode in ("off", "on"):
-        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
         if mode == "off":
-            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+            monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.set_cost_reference(0, refs)
@@ -1536,9 +1559,9 @@ def test_one_instance_per_lane_pass_per_instance_rhs(oracle, monkeypatch):
     wl["cstrs"] = [dict(kind="trajectory", E=Ev, f=[0.6] * 3, ineq=True), wl["cstrs"][1]]
     out = {}
     for mode in ("off", "on"):
-        monkeypatch.delenv("COPRA_NO_LANE_PASS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
         if mode == "off":
-            monkeypatch.setenv("COPRA_NO_LANE_PASS", "1")
+            monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.set_constraint_rhs(0, np.repeat(vlim[:, None], 3, axis=1))
@@ -1568,7 +1591,7 @@ def test_one_instance_per_lane_pass_filters_for_the_other_tiers(oracle, monkeypa
     nx, nu = wl["B"].shape[1], wl["B"].shape[2]
     ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
     ok = ref["status"] == 0
-    monkeypatch.setenv("COPRA_LANE_MIN_BATCH", "1")
+    monkeypatch.setitem(OPTIONS, "lane_min_batch", 1)
     eng = BatchLMPC(nx, nu, wl["N"], b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     eng.solve()
@@ -1612,7 +1635,7 @@ def test_one_instance_per_lane_pass_short_lists(oracle, violators):
 
 def test_selection_rows_two_sided_velocity_limits(oracle, monkeypatch):
     """|v| <= v_max as TrajectoryConstraint(E = [S; -S], f): rows that select +- one state component keep the compact variant of the
-    Riccati-factor tier and the lane pass's hand-over; against the dense-row classification (COPRA_NO_SELECTION_ROWS) at 32768
+    Riccati-factor tier and the lane pass's hand-over; against the dense-row classification (option no_selection_rows) at 32768
     instances and a sample against the oracle"""
     from copra_amd import BatchLMPC, workloads
     b = 32768
@@ -1621,9 +1644,9 @@ def test_selection_rows_two_sided_velocity_limits(oracle, monkeypatch):
     cstrs = [dict(kind="trajectory", E=np.vstack([S3, -S3]), f=[0.5, 0.5, 0.5, 0.25, 0.25, 0.25], ineq=True), wl["cstrs"][1]]
     out = {}
     for mode in ("dense", "selection"):
-        monkeypatch.delenv("COPRA_NO_SELECTION_ROWS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_selection_rows", 0)
         if mode == "dense":
-            monkeypatch.setenv("COPRA_NO_SELECTION_ROWS", "1")
+            monkeypatch.setitem(OPTIONS, "no_selection_rows", 1)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], cstrs)
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.solve()
@@ -1643,7 +1666,7 @@ def test_selection_rows_two_sided_velocity_limits(oracle, monkeypatch):
 
 def test_full_size_rows_that_touch_one_step(oracle, monkeypatch):
     """a terminal velocity limit written as a full-size E (non-zero in the last state only): per-step rows of step N (the compact
-    variant of the headline's tier, the lane pass in front) against the full-row classification (COPRA_NO_STEP_ROWS) and the oracle"""
+    variant of the headline's tier, the lane pass in front) against the full-row classification (option no_step_rows) and the oracle"""
     from copra_amd import BatchLMPC, workloads
     b = 24576
     wl = workloads.com_preview(b, seed=61)
@@ -1655,9 +1678,9 @@ def test_full_size_rows_that_touch_one_step(oracle, monkeypatch):
     cstrs = wl["cstrs"] + [dict(kind="trajectory", E=E, f=[0.3] * 6, ineq=True)]
     out = {}
     for mode in ("full", "step"):
-        monkeypatch.delenv("COPRA_NO_STEP_ROWS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_step_rows", 0)
         if mode == "full":
-            monkeypatch.setenv("COPRA_NO_STEP_ROWS", "1")
+            monkeypatch.setitem(OPTIONS, "no_step_rows", 1)
         eng = BatchLMPC(6, 3, N, b, wl["costs"], cstrs)
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.solve()
@@ -1679,7 +1702,7 @@ def test_reference_trajectory_costs(oracle, monkeypatch, b):
     """a full-size TrajectoryCost / ControlCost with identical blocks and a stacked reference -- the reference's way to track a
     reference TRAJECTORY -- runs as a per-step entry with the reference of the step (CostTerm::pstride) on the Riccati-factor tier, whose
     affine term h_k then changes along the horizon: in the tier's own sweep (batch 8192) and in the one-instance-per-lane pass in front
-    of it (batch 24576); against the dense path (COPRA_NO_STAGE_REFS), with per-instance reference trajectories, and a sample against
+    of it (batch 24576); against the dense path (option no_stage_refs), with per-instance reference trajectories, and a sample against
     the oracle"""
     from copra_amd import BatchLMPC, workloads
     wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=81)
@@ -1693,9 +1716,9 @@ def test_reference_trajectory_costs(oracle, monkeypatch, b):
     refs = np.tile(xref.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, 6 * (N + 1)))
     out = {}
     for mode in ("dense", "steps"):
-        monkeypatch.delenv("COPRA_NO_STAGE_REFS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_stage_refs", 0)
         if mode == "dense":
-            monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+            monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
         eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.solve()
@@ -1870,9 +1893,9 @@ def test_mixed_cost_reference_trajectory(oracle, monkeypatch, b):
     refs = np.tile(pk.reshape(-1), (b, 1)) + 0.02 * rng.standard_normal((b, pk.size))
     out = {}
     for mode in ("dense", "steps"):
-        monkeypatch.delenv("COPRA_NO_STAGE_REFS", raising=False)
+        monkeypatch.setitem(OPTIONS, "no_stage_refs", 0)
         if mode == "dense":
-            monkeypatch.setenv("COPRA_NO_STAGE_REFS", "1")
+            monkeypatch.setitem(OPTIONS, "no_stage_refs", 1)
         eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         eng.solve()
@@ -1910,3 +1933,96 @@ def test_tracking_example_runs_on_device():
     for line in r.stdout.strip().splitlines()[-2:]:
         res = ast.literal_eval(line)
         assert res["solved_last_tick"] == 24576 and res["lane_pass"][0] and res["mean_position_error_last_tick"] < 0.01
+
+
+@pytest.mark.gpu
+def test_published_qp_examples_on_gpu(oracle):
+    """tests/published_qps.py -- eleven worked examples in print -- through plug-in point 1 on the device, each tiled into a batch of
+    37: the published digits, the oracle's (and, where printed, qpgen2's published) iteration counts, the same answer on every instance"""
+    import published_qps as PQ
+    from copra_amd import qp_solve_dense_batch
+    b = 37
+    for name, qp in sorted(PQ.PUBLISHED.items()):
+        t = lambda a: np.tile(a, (b,) + (1,) * np.ndim(a))
+        x, fail, it = qp_solve_dense_batch(t(qp["Q"]), t(qp["c"]), t(qp["Aeq"]), t(qp["beq"]), t(qp["Aineq"]), t(qp["bineq"]),
+                                           t(qp["XL"]), t(qp["XU"]))
+        xo, fo, ito = oracle.quadprog_dense(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+        assert (fail == 0).all() and fo == 0, name
+        assert (it == np.array(ito)).all(), name
+        if qp["iterations"] is not None:
+            assert tuple(it[0]) == qp["iterations"], name
+        assert np.abs(x - qp["x_star"]).max() <= qp["tol"], name
+        assert np.abs(x - xo).max() <= 1e-12 * (1.0 + np.abs(xo).max()), name
+
+
+@pytest.mark.gpu
+def test_randomized_differential_on_gpu(oracle):
+    """the 1000 random QPs of tests/test_oracle.py::test_randomized_differential_... (generic, degenerate, pinned, equality,
+    infeasible, indefinite) through plug-in point 1 on the device, batched by shape: status codes and BOTH iteration counters equal
+    the oracle's, solutions within 1e-6 (entry-wise, floor 1e-3).  Pinned variables (lb == ub) are the documented exception: the
+    kernels never take the twin of an active bound of a pinned variable for violated (gi_core.hpp), where qpgen2's
+    arithmetic -- the oracle's -- ends "no solution" on a few per cent of such problems: there the device must either agree with the
+    oracle or solve the problem (checked against the independent least-distance solve)."""
+    import test_oracle as TO
+    from golden.gen_golden import solve_qp_ldp
+    from copra_amd import qp_solve_dense_batch
+    cases = TO.random_differential_cases()
+    groups = {}
+    for k, qp in enumerate(cases):
+        groups.setdefault((qp["Q"].shape[0], qp["Aeq"].shape[0], qp["Aineq"].shape[0]), []).append(k)
+    n_cmp = n_pin_solved = 0
+    for key, ks in groups.items():
+        st = lambda f: np.stack([cases[k][f] for k in ks])
+        x, fail, it = qp_solve_dense_batch(st("Q"), st("c"), st("Aeq"), st("beq"), st("Aineq"), st("bineq"), st("XL"), st("XU"))
+        for j, k in enumerate(ks):
+            qp = cases[k]
+            xo, fo, ito = oracle.quadprog_dense(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+            if qp["kind"] == "pinned" and (fail[j] != fo or tuple(it[j]) != tuple(ito)):
+                assert fail[j] == 0  # the device solved what qpgen2's arithmetic gave up on (or took another path to the same optimum)
+                xl, ok = solve_qp_ldp(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+                assert ok and np.abs(x[j] - xl).max() <= 1e-8 * (1.0 + np.abs(xl).max())
+                n_pin_solved += 1
+                continue
+            assert fail[j] == fo, (k, qp["kind"])
+            if fo == 0:
+                assert tuple(it[j]) == tuple(ito), (k, qp["kind"])
+                assert _rel(x[j], xo) <= RTOL, (k, qp["kind"])
+                n_cmp += 1
+    assert n_cmp >= 700 and n_pin_solved <= 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vmax,umax,least", [(0.25, 1.2, 11), (0.30, 1.5, 7), (0.6, 3.0, 5)])
+def test_first_tier_layout_chosen_before_the_first_launch(oracle, vmax, umax, least):
+    """round-3 verdict, weak #9: the first solve of a constraint-heavy controller took 10.4 ms against 2.8 ms in the steady state, because
+    the layout ladder was learnt from the overflow counts of the first eight solves.  The one-instance-per-lane pass now histograms the
+    rows each unconstrained minimiser violates and copra_batch_solve starts the tier on the ladder step that has room for the active
+    sets to expect: after ONE solve the layout already has the capacity the steady state uses (or one step less), that solve costs at
+    most 1.5 x a steady one, and its results are the oracle's (sample) with the same iteration counts."""
+    from copra_amd import BatchLMPC, workloads
+    b = 32768
+    wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    assert eng.layout_info()["active_capacity"] == 5
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    res = eng.results()
+    first_ms, cap1 = eng.last_solve_seconds() * 1e3, eng.layout_info()["active_capacity"]
+    assert cap1 >= least and eng.lane_pass_info()[0]
+    pick = np.linspace(0, b - 1, 256).astype(int)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert (res["status"][pick] == ref["status"]).all() and (res["iter"][pick] == ref["iter"]).all()
+    assert _rel(res["control"][pick], ref["control"]) <= RTOL and _rel(res["trajectory"][pick], ref["trajectory"]) <= RTOL
+    for _ in range(6):
+        eng.solve()
+    eng.synchronize()
+    steady = []
+    for _ in range(5):
+        eng.solve()
+        steady.append(eng.last_solve_seconds() * 1e3)
+    cap2 = eng.layout_info()["active_capacity"]
+    print("   v_max %.2f: first solve %.3f ms on %d columns, steady %.3f ms on %d columns" % (vmax, first_ms, cap1, min(steady), cap2))
+    assert first_ms <= 1.5 * min(steady) + 0.15  # (+ the one synchronisation and histogram copy of the first solve)
+    res2 = eng.results()
+    assert (res2["status"] == res["status"]).all() and (res2["iter"] == res["iter"]).all()
+    eng.close()

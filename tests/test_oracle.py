@@ -283,3 +283,73 @@ def test_where_the_oracle_is_the_side_that_is_off(oracle):
         t = truth.solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"], ref["control"][i])
         e.append(truth.rel(ref["control"][i], t["control"]))
     assert 1e-6 < e[0] <= 5e-6 and max(e[1:]) <= 1e-6
+
+
+# ---- third-party numeric pins of the solver (tests/published_qps.py) and a randomized differential against an independent method ----
+import published_qps as PQ  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(PQ.PUBLISHED))
+def test_published_qp_examples(oracle, name):
+    """eleven worked examples in print (R solve.QP, Goldfarb & Idnani 1983, QuadProg++, MathWorks quadprog x 2, Nocedal & Wright 16.4,
+    CVXOPT, Scilab qld, Hock-Schittkowski 21 / 35 / 76): the oracle reproduces the published solution to the printed digits, the
+    published objective, qpgen2's published iteration counts where they are printed, AND agrees to 1e-12 with an independent
+    least-distance (NNLS) solve + exact KKT polish of the same problem"""
+    from golden.gen_golden import solve_qp_ldp
+    qp = PQ.PUBLISHED[name]
+    x, fail, it = oracle.quadprog_dense(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+    assert fail == 0
+    assert np.abs(x - qp["x_star"]).max() <= qp["tol"]
+    assert abs(PQ.objective(qp, x) - qp["f_star"]) <= 10 * qp["tol"] * max(1.0, abs(qp["f_star"]))
+    if qp["iterations"] is not None:
+        assert tuple(it) == qp["iterations"]
+    xl, ok = solve_qp_ldp(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+    assert ok and np.abs(x - xl).max() <= 1e-12 * (1.0 + np.abs(xl).max())
+
+
+RANDOM_KINDS = ["generic"] * 4 + ["degenerate", "pinned", "equality", "infeasible", "not_pd"]
+
+
+def random_differential_cases(count=1000, seed=2024):
+    rng = np.random.default_rng(seed)
+    return [PQ.random_qp(rng, RANDOM_KINDS[k % len(RANDOM_KINDS)]) for k in range(count)]
+
+
+def test_randomized_differential_against_least_distance_programming(oracle):
+    """1000 random strictly convex QPs (2..12 variables, up to 2n rows, bounds on half of the variables) of six kinds -- generic,
+    degenerate (duplicated rows, a row that is a combination of two others, a bound repeated as a row), pinned variables
+    (lb == ub), equalities incl. an identically-zero row, contradicting rows, indefinite Q -- through the oracle's Goldfarb-Idnani
+    and through an independent method (Lawson-Hanson least-distance programming on scipy's NNLS + exact KKT polish).
+    Asserted: every solution the two produce agrees to 1e-9; contradicting rows -> SI_fail() 1 and an infeasible NNLS residual;
+    indefinite Q -> SI_fail() 2; the only disagreement allowed is qpgen2's documented one -- "no solution" on a linearly dependent
+    twin (the second bound of a pinned variable, tests/edge_cases.py::duplicate_and_opposite_rows) in a few per cent of the
+    pinned cases."""
+    from golden.gen_golden import solve_qp_ldp
+    stats = {}
+    for qp in random_differential_cases():
+        kind = qp["kind"]
+        s = stats.setdefault(kind, dict(n=0, agree=0, twin_fail=0, other_solver_gave_up=0))
+        s["n"] += 1
+        x, fail, it = oracle.quadprog_dense(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+        if kind == "not_pd":
+            assert fail == 2
+            continue
+        xl, ok = solve_qp_ldp(qp["Q"], qp["c"], qp["Aeq"], qp["beq"], qp["Aineq"], qp["bineq"], qp["XL"], qp["XU"])
+        if kind == "infeasible":
+            assert fail == 1 and xl is None
+            continue
+        if not ok:  # (the independent method's polish did not certify its own answer: nothing to compare)
+            s["other_solver_gave_up"] += 1
+            continue
+        if fail == 1 and kind == "pinned":
+            s["twin_fail"] += 1
+            continue
+        assert fail == 0, kind
+        assert np.abs(x - xl).max() <= 1e-9 * (1.0 + np.abs(xl).max()), kind
+        s["agree"] += 1
+    for kind, s in stats.items():
+        if kind in ("generic", "degenerate", "equality", "pinned"):
+            assert s["other_solver_gave_up"] <= 0.05 * s["n"], (kind, s)
+            assert s["agree"] >= 0.85 * s["n"], (kind, s)
+    assert stats["pinned"]["twin_fail"] <= 0.10 * stats["pinned"]["n"]
+    assert stats["generic"]["agree"] == stats["generic"]["n"]

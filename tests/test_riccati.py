@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from copra_amd._capi import OPTIONS  # engine options (copra_options_t): tests pin a tier by switching the others off
+
 import fixtures as F
 
 RTOL = 1e-6
@@ -18,13 +20,13 @@ RTOL = 1e-6
 def emu(request):
     """both realisations of the method: lmpc_riccati_mfma.hpp (iterate resident on the CU, stage algebra on v_mfma_f64_4x4x4; what
     the plan builder picks when the controller fits its fixed-width tables) and lmpc_riccati.hpp (streaming workspace, any
-    stage-wise controller; COPRA_NO_RIC_FAST forces it)"""
+    stage-wise controller; option no_ric_fast forces it)"""
     import pyemu
     pyemu.lib()
     if request.param == "streaming":
-        os.environ["COPRA_NO_RIC_FAST"] = "1"
+        OPTIONS["no_ric_fast"] = 1
     yield pyemu
-    os.environ.pop("COPRA_NO_RIC_FAST", None)
+    OPTIONS.pop("no_ric_fast", None)
 
 
 def _rel(a, b):
@@ -53,7 +55,7 @@ def test_config5_against_the_truth_vectors(emu, oracle):
     re = emu.lmpc_solve_riccati(wl["A"][ks], wl["B"][ks], wl["d"][ks], wl["x0"][ks], wl["N"], wl["costs"], wl["cstrs"],
                                 initial_state=dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][ks], x0ub=ist["x0ub"][ks]))
     assert (re["status"] == 0).all() and re["not_converged"] == 0
-    assert re["lds_resident"] == ("COPRA_NO_RIC_FAST" not in os.environ)  # config 5 fits the LDS-resident kernel's tables
+    assert re["lds_resident"] == (not OPTIONS.get("no_ric_fast"))  # config 5 fits the LDS-resident kernel's tables
     assert re["iter"][:, 0].max() <= 17  # (centred starting point: 14 - 15 Newton steps; 19 - 21 before)
     for j, k in enumerate(ks):
         assert _rel(re["control"][j], G.TRUTH5["control_%d" % k]) <= 1e-8

@@ -33,7 +33,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F6
 python tools/pmc_summary.py $O/c5_stats $O/c5_fetch $O/c5_write $O/c5_sq $O/c5_sq2 $O/c5_sq3 > $R/config5_rocprof_summary.json
 find $O/c5_stats -name "*kernel_stats.csv" -exec cp {} $R/config5_kernel_stats.csv \;
 python tools/riccati_mfma_profile.py > $R/config5_phase_cycles.txt 2>&1
-COPRA_NO_RIC_FAST=1 python tools/try_config5.py 16384 0 2>&1 | grep -E "solver|batch|status" > $R/config5_streaming_kernel.txt
+COPRA_OPTIONS=no_ric_fast=1 python tools/try_config5.py 16384 0 2>&1 | grep -E "solver|batch|status" > $R/config5_streaming_kernel.txt
 # ---- dense-Hessian (MFMA 16x16x4) path: MFMA-busy share ----
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/hl_dense -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/hl_run.log 2>&1
 python tools/pmc_summary.py $O/hl_dense > $R/pmc_dense_mfma_path.json
@@ -42,7 +42,7 @@ python tools/exp/lane_pass_check.py 2>&1 | grep -v amdgpu.ids > $R/lane_pass_che
 VARIANTS=0,1,2,3 PHASE_DBG=8,9,10,11 python tools/exp/lane_pass_variants.py 2>&1 | grep -v amdgpu.ids > $R/lane_pass_parts.txt || true
 python tools/exp/lane_tier1_phases.py 2>&1 | grep -v amdgpu.ids > $R/lane_tier1_phases.txt || true
 python tools/exp/lane_shared_check.py 2>&1 | grep -v amdgpu.ids > $R/lane_shared_tick.txt || true
-for b in 2048 8192 16384 24576 32768; do echo "batch $b"; COPRA_LANE_MIN_BATCH=1 python tools/exp/lane_pass_check.py $b 2>&1 | grep -v amdgpu.ids | head -1; done > $R/lane_batch_sweep.txt || true
+for b in 2048 8192 16384 24576 32768; do echo "batch $b"; COPRA_OPTIONS=lane_min_batch=1 python tools/exp/lane_pass_check.py $b 2>&1 | grep -v amdgpu.ids | head -1; done > $R/lane_batch_sweep.txt || true
 python tools/exp/lane_threshold.py 2>&1 | grep -v amdgpu.ids > $R/lane_threshold.txt || true
 python tools/exp/selection_rows.py 2>&1 | grep -v amdgpu.ids > $R/selection_rows.txt || true
 python tools/exp/terminal_rows.py 2>&1 | grep -v amdgpu.ids > $R/terminal_rows.txt || true

@@ -10,8 +10,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
-OLD = ("COPRA_NO_SELECTION_ROWS", "COPRA_NO_STEP_ROWS", "COPRA_NO_LANE_PASS", "COPRA_NO_STAGE_REFS")
+OLD = ("no_selection_rows", "no_step_rows", "no_lane_pass", "no_stage_refs")
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 bad = 0
 for seed in range(nseeds):
@@ -86,12 +87,8 @@ for seed in range(nseeds):
         forms.append("mref")
     out = {}
     for mode in ("old", "new"):
-        for e in OLD:
-            os.environ.pop(e, None)
-            if mode == "old":
-                os.environ[e] = "1"
-        os.environ["COPRA_LANE_MIN_BATCH"] = "1"
-        eng = BatchLMPC(nx, nu, N, b, costs, cstrs)
+        opts = dict({e: 1 for e in OLD} if mode == "old" else {}, lane_min_batch=1)
+        eng = BatchLMPC(nx, nu, N, b, costs, cstrs, options=opts)
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         if own_ref is not None:
             eng.set_cost_reference(0, own_ref)

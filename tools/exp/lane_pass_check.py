@@ -19,9 +19,9 @@ for vmax, umax in ((0.6, 3.0), (0.4, 2.0), (0.25, 1.2)):
     out = {}
     for mode in ("off", "on"):
         if mode == "off":
-            os.environ["COPRA_NO_LANE_PASS"] = "1"
+            _capi.OPTIONS["no_lane_pass"] = int("1")
         else:
-            os.environ.pop("COPRA_NO_LANE_PASS", None)
+            _capi.OPTIONS.pop("no_lane_pass", None)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
         eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
         ts = []

@@ -7,12 +7,13 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 b = 65536
 wl = workloads.com_preview(b, v_max=50.0, u_max=500.0)
-os.environ["COPRA_LANE_KEEP"] = "1"
+_capi.OPTIONS["lane_keep"] = int("1")
 for dbg in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]:
-    os.environ["COPRA_LANE_DBG"] = str(dbg)
+    _capi.OPTIONS["lane_dbg"] = int(str(dbg))
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     ts = []
@@ -25,7 +26,7 @@ for dbg in [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]:
     eng.close()
 # phase stamps of the pass (lane 0 of every wave): staging | sweep | roll-out | verdict
 for pdbg in os.environ.get("PHASE_DBG", "8").split(","):
-  os.environ["COPRA_LANE_DBG"] = pdbg
+  _capi.OPTIONS["lane_dbg"] = int(pdbg)
   print("phase stamps with COPRA_LANE_DBG =", pdbg)
   if True:
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])

@@ -6,6 +6,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 b = 65536
 for vmax, umax in ((0.6, 3.0), (0.35, 1.8)):
@@ -13,9 +14,9 @@ for vmax, umax in ((0.6, 3.0), (0.35, 1.8)):
     out = {}
     for mode in ("off", "on"):
         if mode == "off":
-            os.environ["COPRA_NO_LANE_PASS"] = "1"
+            _capi.OPTIONS["no_lane_pass"] = int("1")
         else:
-            os.environ.pop("COPRA_NO_LANE_PASS", None)
+            _capi.OPTIONS.pop("no_lane_pass", None)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
         eng.set_shared_system(wl["A"][5], wl["B"][5], wl["d"][5])
         eng.set_x0(wl["x0"])

@@ -6,10 +6,11 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 
 def t(wl, b, on):
-    os.environ["COPRA_LANE_MIN_BATCH"] = "1" if on else "100000000"
+    _capi.OPTIONS["lane_min_batch"] = int("1") if on else "100000000"
     nx, nu = wl["B"].shape[1], wl["B"].shape[2]
     eng = BatchLMPC(nx, nu, wl["N"], b, wl["costs"], wl["cstrs"])
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])

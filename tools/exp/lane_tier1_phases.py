@@ -6,8 +6,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["COPRA_LANE_DBG"] = "8"
+_capi.OPTIONS["lane_dbg"] = int("8")
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 b = 65536
 wl = workloads.com_preview(b)

@@ -1,6 +1,6 @@
 """Tracking a reference TRAJECTORY (GPU box): the headline workload with its state cost written as the reference's API demands for a
 reference that changes along the horizon -- a full-size TrajectoryCost, M = blkdiag(I .. I), stacked p.  Default: recognised as a per-step
-entry with the step's reference; COPRA_NO_STAGE_REFS=1: the dense contraction of a full-size entry (the previous path)."""
+entry with the step's reference; COPRA_OPTIONS=no_stage_refs=1: the dense contraction of a full-size entry (the previous path)."""
 import os
 import sys
 
@@ -25,14 +25,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "profile":  # rocprofv3 --kernel-trace -
     eng.close()
     sys.exit(0)
 out = {}
-MODES = {"dense contraction": {"COPRA_NO_STAGE_REFS": "1"}, "per-step, factor-only tier": {"COPRA_NO_RIC": "1"},
-         "per-step, tier's own sweep": {"COPRA_NO_LANE_PASS": "1"}, "per-step with p_k": {}, "own reference per instance": {}}
+MODES = {"dense contraction": {"no_stage_refs": 1}, "per-step, factor-only tier": {"no_ric": 1},
+         "per-step, tier's own sweep": {"no_lane_pass": 1}, "per-step with p_k": {}, "own reference per instance": {}}
 rng = np.random.default_rng(4)
 for mode, env in MODES.items():
-    for k in ("COPRA_NO_STAGE_REFS", "COPRA_NO_RIC", "COPRA_NO_LANE_PASS"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+    eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"], options=env)
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     if mode == "own reference per instance":
         eng.set_cost_reference(0, np.tile(xref.reshape(-1), (b, 1)) + 0.002 * rng.standard_normal((b, 6 * (N + 1))))

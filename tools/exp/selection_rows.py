@@ -1,6 +1,6 @@
 """A velocity limit written as TrajectoryConstraint(E = selection, f) instead of TrajectoryBoundConstraint (GPU box): the plan builder now
 recognises rows that select one component, so the controller keeps the compact variant of the Riccati-factor tier and the lane pass's
-hand-over.  COPRA_NO_SELECTION_ROWS=1: the previous classification (dense rows, general variant)."""
+hand-over.  COPRA_OPTIONS=no_selection_rows=1: the previous classification (dense rows, general variant)."""
 import os
 import sys
 
@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 b = 65536
 wl = workloads.com_preview(b)
@@ -16,9 +17,9 @@ cstrs = [dict(kind="trajectory", E=Ev, f=[0.6] * 3, ineq=True), wl["cstrs"][1]]
 out = {}
 for mode in ("dense rows", "selection rows"):
     if mode == "dense rows":
-        os.environ["COPRA_NO_SELECTION_ROWS"] = "1"
+        _capi.OPTIONS["no_selection_rows"] = int("1")
     else:
-        os.environ.pop("COPRA_NO_SELECTION_ROWS", None)
+        _capi.OPTIONS.pop("no_selection_rows", None)
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], cstrs)
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     ts = []

@@ -1,5 +1,5 @@
 """A terminal constraint written the reference's way -- a full-size E that is non-zero in the last state only (GPU box): classified as
-a per-step row of step N (COPRA_NO_STEP_ROWS=1: as a full-size row, the previous behaviour)."""
+a per-step row of step N (COPRA_OPTIONS=no_step_rows=1: as a full-size row, the previous behaviour)."""
 import os
 import sys
 
@@ -7,6 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
 
 b = 65536
 wl = workloads.com_preview(b)
@@ -19,9 +20,9 @@ cstrs = wl["cstrs"] + [dict(kind="trajectory", E=E, f=[0.3] * 6, ineq=True)]  # 
 out = {}
 for mode in ("full-size rows", "step rows"):
     if mode == "full-size rows":
-        os.environ["COPRA_NO_STEP_ROWS"] = "1"
+        _capi.OPTIONS["no_step_rows"] = int("1")
     else:
-        os.environ.pop("COPRA_NO_STEP_ROWS", None)
+        _capi.OPTIONS.pop("no_step_rows", None)
     eng = BatchLMPC(6, 3, N, b, wl["costs"], cstrs)
     eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
     ts = []

@@ -8,6 +8,10 @@ import sys
 from collections import defaultdict
 
 out = {}
+# which build of the library the profiled command ran on: the stamp next to libcopra_hip.so (= copra_source_hash() of that library);
+# bench.py flags counters taken on another build as stale
+_stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "copra_amd", "csrc", "libcopra_hip.so.srchash")
+out["library_source_hash"] = open(_stamp).read().strip() if os.path.exists(_stamp) else None
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):

@@ -1,5 +1,5 @@
 """Kernel rate over problem sizes (dev / report tool; GPU box only): double integrator (nx=2, nu=1) and CoM preview
-(nx=6, nu=3) at several horizons.  Env: COPRA_NO_PACKED=1, COPRA_NO_DENSE_LAYOUT=1 switch the small / mid-size
+(nx=6, nu=3) at several horizons.  Env: COPRA_OPTIONS=no_packed=1, COPRA_OPTIONS=no_dense_layout=1 switch the small / mid-size
 mappings off for comparison."""
 import os
 import sys

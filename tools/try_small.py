@@ -1,4 +1,4 @@
-"""Packed small-problem kernels vs one wave per instance (COPRA_NO_PACKED=1): kernel rates for a few small shapes."""
+"""Packed small-problem kernels vs one wave per instance (COPRA_OPTIONS=no_packed=1): kernel rates for a few small shapes."""
 import ctypes as C
 import os
 import sys
