@@ -2025,7 +2025,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             for (;;) {
                 long long over = 0;
                 for (int b = 0; b < kLaneHistBins; ++b)
-                    if (b + b / 8 > h->hp.plan.lds.rcap) over += hist[b];
+                    if (b + (b + 3) / 4 > h->hp.plan.lds.rcap) over += hist[b]; // (a little above the mean: the tail decides)
                 LdsLayout roomier {};
                 if (over * share <= (long long)P.batch || !next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier)) break;
                 h->hp.plan.lds = roomier;
