@@ -236,7 +236,7 @@ def build_library(force=False):
         try:
             if current() and not force:
                 return False
-            subprocess.check_call(["make", "-B", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
+            subprocess.check_call(["make", "-B", "-j4", "-C", os.path.join(_HERE, "csrc"), "libcopra_hip.so"],
                                   stdout=subprocess.DEVNULL)  # (the Makefile writes the stamp, same hash formula)
             have = open(stamp).read().strip() if os.path.exists(stamp) else ""
             if have != want:

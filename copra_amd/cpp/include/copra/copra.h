@@ -208,6 +208,12 @@ namespace detail {
         for (int i = 0; i < rows; ++i)
             for (int a = 0; a < nx; ++a) Y(i, a) = YA(i, a);
     }
+    // true while LMPC::solve() evaluates its costs: the only moment a cost in reference-accumulation mode (below) accumulates
+    inline bool& solveInProgress()
+    {
+        static thread_local bool v = false;
+        return v;
+    }
 } // namespace detail
 
 // ---------------------------------------------------------------------------------------------- costFunctions.h
@@ -280,8 +286,20 @@ public:
         d.weights = weights_.data();
         return d;
     }
+    // Reference quirk Q2 (src/costFunctions.cpp:73-80 and :205-213): the per-step entries of TrajectoryCost and MixedCost ADD each
+    // solve's Q, E, f to members that are only zeroed in initializeCost (:52-55, :184-187), and MixedCost also adds to c -- the n-th
+    // solve() on one controller sees n x the trajectory Hessian.  The engine's default is a fresh controller's first solve (what a
+    // batched solve means).  A caller who solves repeatedly on one copra::LMPC and wants the reference's numbers turns
+    // this on (LMPC::referenceAccumulation): the cost is then evaluated per solve by the device's condense code, accumulated HERE in the
+    // reference's own order, and handed to the fused solve as the dense members Q_, c_, E_, f_ (the plug-in route of user subclasses).
+    void referenceAccumulation(bool on) { accumulate_ = on; }
+    bool accumulates() const
+    {
+        return accumulate_ && !fullSizeEntry_ && (kind_ == COPRA_COST_TRAJECTORY || kind_ == COPRA_COST_MIXED);
+    }
     bool deviceDescriptor(copra_cost_desc_t& d) const override
     {
+        if (accumulates()) return false;
         d = desc();
         return true;
     }
@@ -293,13 +311,37 @@ public:
         fullSizeEntry_ = (M_.size() && M_.cols() == ps.fullXDim && ps.fullXDim != ps.xDim)
             || (N_.size() && N_.cols() == ps.fullUDim && ps.fullUDim != ps.uDim);
         CostFunction::initializeCost(ps);
+        Q_.setZero(), c_.setZero(), E_.setZero(), f_.setZero(); // costFunctions.cpp:52-55, 184-187
     }
     // Q_, c_, E_, f_ as the reference's update() leaves them -- evaluated by the device, on request only (LMPC::solve
     // never needs them for a built-in class)
-    void update(const PreviewSystem& ps) override { detail::evaluate_cost_on_device(ps, desc(), Q_, c_, E_, f_); }
+    void update(const PreviewSystem& ps) override
+    {
+        if (!accumulates()) {
+            detail::evaluate_cost_on_device(ps, desc(), Q_, c_, E_, f_);
+            return;
+        }
+        if (!detail::solveInProgress()) return; // (an accessor between solves: the members as the last solve left them)
+        Eigen::MatrixXd Q1, E1;
+        Eigen::VectorXd c1, f1;
+        detail::evaluate_cost_on_device(ps, desc(), Q1, c1, E1, f1); // this solve's sums over the steps
+        const Eigen::Index n = ps.fullUDim, nx = ps.xDim;
+        for (Eigen::Index e = 0; e < n * n; ++e) Q_.data()[e] += Q1.data()[e]; // Q_ += ...   (:75 / :208)
+        for (Eigen::Index e = 0; e < nx * n; ++e) E_.data()[e] += E1.data()[e]; // E_ += ...   (:77 / :210)
+        for (Eigen::Index e = 0; e < n; ++e) f_.data()[e] += f1.data()[e]; // f_ += ...   (:78 / :211)
+        for (Eigen::Index j = 0; j < n; ++j) { // E_' x0 + f_ with the ACCUMULATED E_, f_
+            double v = f_(j);
+            for (Eigen::Index a = 0; a < nx; ++a) v += E_(a, j) * ps.x0(a);
+            if (kind_ == COPRA_COST_MIXED)
+                c_(j) += v; // c_ += ...  (:213)
+            else
+                c_(j) = v; // c_ = ...   (:80)
+        }
+    }
 
 protected:
     int kind_;
+    bool accumulate_ = false;
     Eigen::MatrixXd M_, N_;
     Eigen::VectorXd p_;
 };
@@ -751,9 +793,22 @@ public:
     void addCost(const std::shared_ptr<CostFunction>& cost) // LMPC.cpp:118-122
     {
         cost->initializeCost(*ps_);
+        if (auto b = std::dynamic_pointer_cast<BuiltinCost>(cost)) b->referenceAccumulation(refAccumulation_);
         spCost_.push_back(cost);
         costsDirty_ = true; // (the list of costs has changed: rebuild() looks at what has changed in it)
     }
+    // Opt-in compatibility with reference quirk Q2 (no counterpart in the reference's API -- it is how its cost classes behave,
+    // src/costFunctions.cpp:73-80, 205-213): with `on`, the per-step TrajectoryCost / MixedCost objects of this controller accumulate
+    // Q, E, f (and MixedCost c) from solve to solve as the reference's do, so that the k-th solve() returns the reference's k-th
+    // answer.  Off (default): every solve is a fresh controller's first one.  Costs added later follow the switch.
+    void referenceAccumulation(bool on)
+    {
+        refAccumulation_ = on;
+        for (auto& c : spCost_)
+            if (auto b = std::dynamic_pointer_cast<BuiltinCost>(c)) b->referenceAccumulation(on);
+        dirty_ = true;
+    }
+    bool referenceAccumulation() const noexcept { return refAccumulation_; }
     void addConstraint(const std::shared_ptr<Constraint>& c) // LMPC.cpp:124-128, 173-197
     {
         c->initializeConstraint(*ps_);
@@ -786,7 +841,14 @@ public:
     {
         using clock = std::chrono::high_resolution_clock;
         const auto t0 = clock::now();
-        prepare();
+        detail::solveInProgress() = true; // (costs in reference-accumulation mode accumulate in THIS evaluation only)
+        try {
+            prepare();
+        } catch (...) {
+            detail::solveInProgress() = false;
+            throw;
+        }
+        detail::solveInProgress() = false;
         bool ok;
         if (sol_) {
             // ---- user SolverInterface: the device condenses, the user's solver solves (LMPC.cpp:88-97) ----
@@ -1116,6 +1178,7 @@ protected:
     std::unique_ptr<SolverInterface> sol_; // a user solver (useSolver); null: the fused device solve
     SolverFlag flag_ = SolverFlag::DEFAULT;
     copra_batch_t* h_ = nullptr;
+    bool refAccumulation_ = false; // reference quirk Q2 reproduced on request (referenceAccumulation)
     bool dirty_ = true; // the handle has to be built anew
     bool costsDirty_ = false; // the list of costs has changed since the handle was built (rebuild() decides what that needs)
     std::vector<CostSnapshot> builtCosts_;

@@ -77,25 +77,18 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
     lmpc_fused_body<NX, NU, NH, RP, true, QR>(P, inst);
 }
 
-// The same tier with the factor in Riccati form (lmpc_fused_ric.hpp): controllers whose costs are all per-step entries.
-// (three waves per SIMD: 168 VGPRs; compact variant: 13.9 KB of LDS per instance, eleven instances share a CU; general
-//  variant: 17.7 KB + the rows' share, seven to nine -- the LDS allocation granule is 1280 B, profiles/r02/lds_granule_probe.txt)
-template <int NX, int NU, int NH, int QR, bool SREFS = false>
-__global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const FusedPlan P)
-{
-    if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0; // (the NEXT solve's overflow counter: begin_overflow_queue)
-    int inst;
-    bool lane_failed;
-    if (!tier_instance(P, (int)blockIdx.x, inst, lane_failed)) return;
-    lmpc_fused_ric_body<NX, NU, NH, 6, QR, SREFS>(P, inst, lane_failed);
-}
-// One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
-// instance; those that violate nothing are finished here.  One wave per SIMD: the lane's matrices live in up to 512 registers.
-template <int NX, int NU, bool SREFS = false>
-__global__ __launch_bounds__(64, 1) void copra_lmpc_lane_kernel(const FusedPlan P)
-{
-    lmpc_lane_body<NX, NU, SREFS>(P, (int)blockIdx.x);
-}
+#include "ric_kernels.hpp" // copra_lmpc_fused_ric_kernel, copra_lmpc_lane_kernel
+// run-time-horizon builds (NH == 0) for the shapes of ric_aot_shape: instantiated in copra_hip_ric.hip, a translation unit of its own
+#define COPRA_RIC_RT_DECL(NX, NU)                                                                                      \
+    extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, false>(const FusedPlan);      \
+    extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, 0, false>(const FusedPlan);                 \
+    extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, true>(const FusedPlan);       \
+    extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, 0, true>(const FusedPlan);
+COPRA_RIC_RT_DECL(6, 3)
+COPRA_RIC_RT_DECL(4, 2)
+COPRA_RIC_RT_DECL(2, 1)
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, false>(const FusedPlan);
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, true>(const FusedPlan);
 // ... and its shared-model form: the stage records are those of the whole batch (wave-uniform: scalar operands), only the roll-out
 // from each instance's x0 is left
 template <int NX, int NU>
@@ -217,6 +210,16 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
 {
     const int rp = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
     if (P.lds.tri) {
+        if (P.lds.ric && !ric_aot_exact(P.nx, P.nu, P.N)) { // run-time-horizon builds of the shape (copra_hip_ric.hip)
+#define COPRA_RIC_RT_PICK(NX, NU)                                                                                      \
+    if (P.nx == NX && P.nu == NU)                                                                                      \
+        return P.stage_refs ? (P.lds.q1regs ? copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, true> : copra_lmpc_fused_ric_kernel<NX, NU, 0, 0, true>) \
+                            : (P.lds.q1regs ? copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, false> : copra_lmpc_fused_ric_kernel<NX, NU, 0, 0, false>);
+            COPRA_RIC_RT_PICK(6, 3)
+            COPRA_RIC_RT_PICK(4, 2)
+            COPRA_RIC_RT_PICK(2, 1)
+#undef COPRA_RIC_RT_PICK
+        }
         if (P.lds.ric) { // (plan_builder.hpp: only these shapes get the layout; Q1 in registers, or in LDS further down the ladder)
             if (P.stage_refs) { // (reference trajectories: the builds with the stage-varying affine term)
                 if (P.N == 10) return P.lds.q1regs ? copra_lmpc_fused_ric_kernel<6, 3, 10, kFusedQ1Regs, true> : copra_lmpc_fused_ric_kernel<6, 3, 10, 0, true>;
@@ -561,6 +564,7 @@ static fused_kernel_t select_lane_kernel(const FusedPlan& P)
 {
     if (P.nx == 6 && P.nu == 3) return P.stage_refs ? copra_lmpc_lane_kernel<6, 3, true> : copra_lmpc_lane_kernel<6, 3>; // (reference trajectories)
     if (P.nx == 2 && P.nu == 1) return P.stage_refs ? copra_lmpc_lane_kernel<2, 1, true> : copra_lmpc_lane_kernel<2, 1>; // (the reference's falling-mass system: BASELINE configs[1])
+    if (P.nx == 4 && P.nu == 2) return P.stage_refs ? copra_lmpc_lane_kernel<4, 2, true> : copra_lmpc_lane_kernel<4, 2>; // (a planar point mass; copra_hip_ric.hip)
     return nullptr;
 }
 static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
@@ -1249,7 +1253,7 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared = true;
     h->model_dirty = true;
-    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
+    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric && ric_aot_exact(P.nx, P.nu, P.N)) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
                                                                         //  only the library's instantiations: a run-time-compiled one has no prepare kernel)
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;
@@ -1654,7 +1658,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
     const FusedPlan& P = h->hp.plan;
     if (h->jit_fused) return COPRA_OK;
     const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
-    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu || P.lds.ric)
+    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu || (P.lds.ric && ric_aot_exact(P.nx, P.nu, P.N)))
         return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
     // ---- the Riccati-factor tier (lmpc_fused_ric.hpp; what the headline runs on) for THIS shape: per-step costs, xDim (xDim + uDim + 1)
     //      <= 64, two or three controls, at most 64 decision variables.  Compiled with Q1 in registers and in LDS (the layout ladder

@@ -608,7 +608,9 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                     // stage k - 1): the backward recursion starts there.  In place: this lane's n is in `acc` / `napl`.
                     const double last = wave_max((lane < n && acc != 0.0) ? (double)lane : 0.0);
                     const int nst = uniform_i32((int)last / RNU + 1);
-                    wk = ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricd, nst > inj_stage ? nst : inj_stage, nullptr, inj_stage, inj_comp, inj_val);
+                    // (NV == 0: the horizon n / RNU is a run-time value)
+                    wk = ric_apply_mfma4<RNX, RNU, NV / RNU, true>(J, S.ap, S.ap, S.ricd, nst > inj_stage ? nst : inj_stage, nullptr, inj_stage, inj_comp, inj_val,
+                        n / RNU);
                 } else {
                 auto forward = [&](int kfirst) {
                     for (int k0 = kfirst; k0 < n; k0 += 4) {
@@ -670,7 +672,7 @@ COPRA_DEV int gi_active_set(const SolverLds& S, int n_rt, int meq, int mgen, Row
                 if constexpr (RNX > 0) {
                     if (lane < n) S.ap[lane] = vj;
                     wave_sync();
-                    zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricd, NV / RNU, S.ricxi);
+                    zk = ric_apply_mfma4<RNX, RNU, NV / RNU, false>(J, S.ap, S.ap, S.ricd, n / RNU, S.ricxi, 0, 0, 0.0, n / RNU);
                 } else {
                 for (int k0 = n - 1; k0 >= 0; k0 -= 4) {
                     double colv[4], ri4[4];

@@ -394,14 +394,19 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     const double* w = P.params + ct.offW;
     double* We = scratch; // R weighted residuals
     double* stage = scratch + ((R + 1) & ~1); // 16 x 64 tile of tmp rows
-    // weighted residuals  We_r = (M_r . xbar - p_r) w_r   (ControlCost: -p_r w_r)
-    for (int r = lane; r < R; r += kWave) {
-        double acc = 0.0;
-        if (Mr)
-            for (int col = 0; col < X; ++col) acc += Mr[(size_t)r * X + col] * Xbar[col];
-        We[r] = (acc - p[r]) * w[r];
+    // The residual  M xbar - p  RIDES in the product when the 64-column tile has a spare column (n < 64: the headline has 60):
+    // column n of the B operand is xbar, so tmp(r, n) = M_r . xbar comes out of the same instructions.  (Round 3 walked every row of
+    // M once more on the vector ALU for it, one lane per row: 2 x 126 dependent trips to the L2 per instance.)
+    const bool xcol = Mr != nullptr && n < kWave;
+    if (!xcol) { // weighted residuals  We_r = (M_r . xbar - p_r) w_r   (ControlCost: -p_r w_r)
+        for (int r = lane; r < R; r += kWave) {
+            double acc = 0.0;
+            if (Mr)
+                for (int col = 0; col < X; ++col) acc += Mr[(size_t)r * X + col] * Xbar[col];
+            We[r] = (acc - p[r]) * w[r];
+        }
+        wave_sync();
     }
-    wave_sync();
     mfma_acc acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t].v[0] = acc[t].v[1] = acc[t].v[2] = acc[t].v[3] = 0.0;
@@ -412,29 +417,76 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     for (int tj = 0; tj < 4; ++tj) {
         const int j = 16 * tj + col;
         jbv[tj] = (j < n) ? j / nu : (1 << 20); // (a column beyond n never sees s > jb)
-        goff[tj] = (j < n) ? nx * (j - (j / nu) * nu) - (j / nu) * nx * nu : 0; // G[(s-1-jb) nx nu + c + nx jc] = G[(s-1) nx nu + c + goff]
+        goff[tj] = (j < n) ? nx * (j - (j / nu) * nu) - (j / nu) * nx * nu : 0; // G[(s-1-jb) nx nu + c + goff]
     }
+    const int txc = n >> 4; // the tile that holds column n (the residual column)
+    const bool mine_x = xcol && col == (n & 15);
+    // K-steps of four columns of M, eight at a time: their A operands -- M(r0 + col, 4 ks + kk), straight from the L2, where the
+    // matrix sits for the whole batch -- are ALL requested before the first product (round 3 asked for one, waited, multiplied: 32
+    // exposed trips per row block).  K-steps in which these sixteen rows of M are zero are never visited: the plan builder marks the
+    // non-zero ones (CostTerm::offMask, one 64-bit word per row block and 64 K-steps) -- a block-diagonal M, which is what AutoSpan
+    // produces and the only full-size cost the reference's users write, has 5 of 32.
+    constexpr int CH = 8;
+    const int KS = (X + 3) >> 2, NW = (KS + 63) >> 6;
     for (int r0 = 0; r0 < R; r0 += 16) {
         mfma_acc tt[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) tt[t].v[0] = tt[t].v[1] = tt[t].v[2] = tt[t].v[3] = 0.0;
-        if (Mr) {
-            const int ra = r0 + col; // A operand: M(ra, k0 + kk)
-            const double* mrow = Mr + (size_t)(ra < R ? ra : 0) * X;
-            for (int k0 = 0; k0 < X; k0 += 4) {
-                const int k = k0 + kk;
-                const double a = (ra < R && k < X) ? mrow[k] : 0.0;
-                const int s = k / nx, c = k - s * nx; // row k of Psi = (step s, component c)
-                const int smax = (k0 + 3 < X ? k0 + 3 : X - 1) / nx; // wave-uniform: the last step this K-step touches
+        // (the N part of the tile, for the staging below: requested now, used after the products)
+        double nrv[4][4];
+        if (Nr) {
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj) {
-                    if (smax <= (16 * tj) / nu) continue; // the whole tile of Psi is zero (s <= jb for every column)
-                    const double b = (k < X && s > jbv[tj]) ? G[(s - 1) * nx * nu + c + goff[tj]] : 0.0;
-                    mfma_f64_16x16x4(a, b, tt[tj]);
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = r0 + kk + 4 * reg, j = 16 * tj + col;
+                    nrv[tj][reg] = (r < R && j < n) ? Nr[(size_t)r * n + j] : 0.0;
+                }
+        }
+        if (Mr) {
+            const int ra = r0 + col; // A operand: M(ra, 4 ks + kk)
+            const double* mrow = Mr + (size_t)(ra < R ? ra : 0) * X;
+            for (int wi = 0; wi < NW; ++wi) {
+                unsigned long long m = ~0ull;
+                if (ct.offMask >= 0) {
+                    const int mo = ct.offMask + 2 * ((r0 >> 4) * NW + wi);
+                    m = (unsigned long long)(unsigned)uniform_load(P.params, mo) | ((unsigned long long)(unsigned)uniform_load(P.params, mo + 1) << 32);
+                }
+                if (KS - 64 * wi < 64) m &= (1ull << (KS - 64 * wi)) - 1ull;
+                while (m) { // (wave-uniform: the mask is the same for every lane)
+                    int ksv[CH];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const bool on = m != 0ull;
+                        ksv[q] = on ? 64 * wi + (int)__builtin_ctzll(on ? m : 1ull) : -1;
+                        m = on ? (m & (m - 1ull)) : 0ull;
+                    }
+                    double am[CH];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int k = 4 * ksv[q] + kk;
+                        am[q] = (ksv[q] >= 0 && ra < R && k < X) ? mrow[k] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        if (ksv[q] < 0) continue;
+                        const int k0 = 4 * ksv[q], k = k0 + kk;
+                        const int s = k / nx, c = k - s * nx; // row k of Psi = (step s, component c)
+                        const int smax = (k0 + 3 < X ? k0 + 3 : X - 1) / nx; // wave-uniform: the last step this K-step touches
+                        const double xb = (mine_x && k < X) ? Xbar[k] : 0.0;
+#pragma unroll
+                        for (int tj = 0; tj < 4; ++tj) {
+                            const bool rides = xcol && tj == txc;
+                            if (smax <= (16 * tj) / nu && !rides) continue; // the whole tile of Psi is zero (s <= jb for every column)
+                            double b = (k < X && s > jbv[tj]) ? G[(s - 1) * nx * nu + c + goff[tj]] : 0.0;
+                            if (rides) b = mine_x ? xb : b;
+                            mfma_f64_16x16x4(am[q], b, tt[tj]);
+                        }
+                    }
                 }
             }
         }
-        // tile -> LDS (+ N): element `reg` of tile tj is tmp(r0 + kk + 4 reg, 16 tj + col)
+        // tile -> LDS (+ N): element `reg` of tile tj is tmp(r0 + kk + 4 reg, 16 tj + col); column n: the residual's M_r . xbar
         wave_sync();
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -442,17 +494,21 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = r0 + kk + 4 * reg, j = 16 * tj + col;
                 double v = tt[tj].v[reg];
-                if (Nr && r < R && j < n) v += Nr[(size_t)r * n + j];
-                stage[(kk + 4 * reg) * kWave + j] = (r < R && j < n) ? v : 0.0;
+                if (Nr) v += nrv[tj][reg];
+                stage[(kk + 4 * reg) * kWave + j] = (r < R && (j < n || (xcol && j == n))) ? v : 0.0;
             }
         wave_sync();
+        if (xcol) { // We_r = (M_r . xbar - p_r) w_r of this row block
+            if (lane < 16 && r0 + lane < R) We[r0 + lane] = (stage[lane * kWave + n] - p[r0 + lane]) * w[r0 + lane];
+            wave_sync();
+        }
         // c += (resid' W) tmp, rows in ascending order (lane = column)
         {
             double g = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (r0 + i < R) g += We[r0 + i] * stage[i * kWave + lane];
-            cj += g;
+            cj += (lane < n) ? g : 0.0;
         }
         // Q += (tmp' W) tmp : four K-steps of four rows
 #pragma unroll

@@ -28,9 +28,15 @@ namespace copra_hip {
 template <int NX, int NU, int NH, int RP, int QR, bool SREFS = false>
 COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_failed = false)
 {
-    constexpr int NZ = NX + NU, NV = NU * NH, X = NX * (NH + 1);
+    // NH == 0: the horizon is a RUN-TIME value (P.N, with NU P.N <= 64): the builds the library ships for every horizon of a shape --
+    // round-3 verdict: every shape but the BASELINE ones ran 2.5 x slower unless the USER's box had hipcc for copra_batch_specialise.
+    // NH > 0: compile-time horizon (BASELINE shapes and run-time-compiled kernels): constant trip counts, exact register arrays.
+    constexpr int NZ = NX + NU, NHM = NH ? NH : kWave / NU; // (NHM: the largest horizon this build may see)
+    const int nh = NH ? NH : P.N;
+    const int NV = NU * nh, X = NX * (nh + 1);
+    constexpr int NVM = NU * NHM, XM = NX * (NHM + 1);
     constexpr int nxx = NX * (NX + 1) / 2, nux = NU * NX, nuu = NU * (NU + 1) / 2;
-    static_assert(NX * (NZ + 1) <= kWave && nxx + nux + nuu + NZ <= kWave && NV <= kWave, "one element per lane");
+    static_assert(NX * (NZ + 1) <= kWave && nxx + nux + nuu + NZ <= kWave && NVM <= kWave, "one element per lane");
     static_assert(nxx + nux + nuu >= NX * (NX + 1), "affine lanes of the stage cost and of the terminal cost are disjoint (ric_tab)");
     using RR = RicRec<NX, NU>;
     double* lds = lds_base();
@@ -70,7 +76,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     int status = 0;
     // shared-model mode: the records, bkd, G (and later the row norms) of the whole batch come from the prepare launch
     int mBk = 0, mG = 0, mNb = 0;
-    ric_model_offsets(NX, NU, NH, P.mgen, mBk, mG, mNb);
+    ric_model_offsets(NX, NU, nh, P.mgen, mBk, mG, mNb);
     const bool from_model = P.ric_model != nullptr;
     // behind the one-instance-per-lane pass (lmpc_lane.hpp) the sweep has been done already: K | kv | Lam^-1 of every stage and the running
     // block-row norms sit in its lane-major workspace, element (k, e) of this instance at lane_ws[(k WR + e) lane_bp + inst] -- a gather
@@ -86,13 +92,13 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
         const double sysB = lane < NX * NU ? P.B[(size_t)inst * NX * NU + lane] : 0.0;
         const double sysD = lane < NX ? P.d[(size_t)inst * NX + lane] : 0.0;
-        constexpr int NG = (NH * WR + kWave - 1) / kWave, NT = (X + kWave - 1) / kWave;
+        constexpr int NG = (NHM * WR + kWave - 1) / kWave, NT = (XM + kWave - 1) / kWave;
         double gv[NG], gx[NT];
         const double* const wsb = P.lane_ws + (size_t)inst;
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int idx = lane + kWave * u;
-            gv[u] = wsb[(size_t)(idx < NH * WR ? idx : 0) * (size_t)P.lane_bp];
+            gv[u] = wsb[(size_t)(idx < nh * WR ? idx : 0) * (size_t)P.lane_bp];
         }
         // the pass has also left the unconstrained minimiser (U in `control`, its trajectory in `trajectory`): no roll-out below
         const double gu = P.control[(size_t)inst * NV + (lane < NV ? lane : 0)];
@@ -105,7 +111,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int idx = lane + kWave * u, k = idx / WR, e = idx - k * WR;
-            if (idx < NH * WR) {
+            if (idx < nh * WR) {
                 double* dst = e < KWl        ? F + k * RR::SZ + RR::oK + e
                     : e < KWl + NU           ? F + k * RR::SZ + RR::oKv + (e - KWl)
                     : e < WR - NX            ? F + k * RR::SZ + RR::oLi + (e - KWl - NU)
@@ -115,7 +121,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         }
         wave_sync();
         // Acl_k = A + B K_k, every stage: element (i, j) of stage k
-        for (int idx = lane; idx < NH * NX * NX; idx += kWave) {
+        for (int idx = lane; idx < nh * NX * NX; idx += kWave) {
             const int k = idx / (NX * NX), r = idx - k * (NX * NX), i = r % NX, j = r / NX;
             double acc = A[r];
 #pragma unroll
@@ -123,10 +129,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             F[k * RR::SZ + RR::oAcl + r] = acc;
         }
         // the constant block behind the records (as after the sweep below)
-        if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
-        if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
-        if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
-        if (lane == 1) F[NH * RR::SZ + RR::cO] = 1.0;
+        if (lane < NX * NU) F[nh * RR::SZ + RR::cB + lane] = B[lane];
+        if (lane < NX) F[nh * RR::SZ + RR::cD + lane] = D[lane];
+        if (lane == 0) F[nh * RR::SZ + RR::cZ] = 0.0;
+        if (lane == 1) F[nh * RR::SZ + RR::cO] = 1.0;
         wave_sync(); // (A, B, d have been read: the solver vectors share their place)
         if (lane < NV) S.xs[lane] = gu;
 #pragma unroll
@@ -136,9 +142,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     } else if (from_model) {
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
-        for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
+        for (int e = lane; e < nh * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
         if (!compact) // (compact variant: the blocks G are not kept at all -- the row norms come from the model too)
-            for (int e = lane; e < NH * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
+            for (int e = lane; e < nh * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         if (have_ux) { // (behind the shared-model lane pass, lmpc_lane_shared_body: U and its trajectory are there already)
             if (lane < NV) S.xs[lane] = P.control[(size_t)inst * NV + lane];
             for (int e = lane; e < X; e += kWave) XU[e] = P.trajectory[(size_t)inst * X + e];
@@ -219,7 +225,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // sweep, which reads it at its start).
     if constexpr (SREFS) {
         const double* tab = P.params + P.ric_tab;
-        for (int e = lane; e < NH * NZ; e += kWave) {
+        for (int e = lane; e < nh * NZ; e += kWave) {
             const int k = e / NZ, a = e - k * NZ;
             double acc = 0.0;
 #pragma unroll
@@ -381,7 +387,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             wP[I] = !on ? dummy : col_x ? Pm + iq + NX * (scol - 4) : pv + iq;
             wAst[I] = (on && col_x) ? RR::SZ : 0;
             // (the affine column, d + B kv, is formed by the roll-out; the pointer walks down with the stages)
-            wA[I] = (on && col_x) ? F + RR::oAcl + iq + NX * (scol - 4) + (NH - 1) * RR::SZ : dummy;
+            wA[I] = (on && col_x) ? F + RR::oAcl + iq + NX * (scol - 4) + (nh - 1) * RR::SZ : dummy;
         }
         const bool my_minv = r < NU && q < NU; // A operand of K: element (row r, k = q) of -M_uu^-1
         // (NU == 3) this lane's cofactor of M_uu = x1 x2 - x3 x4, operands by their offsets in the rows-u buffer (M_uu(a, b) at a + NU b)
@@ -403,12 +409,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         for (int I = 0; I < 3; ++I) {
             const int sr = 4 * I + q, a = sr < NU ? NX + sr : (sr >= 4 && sr < 4 + NX) ? sr - 4 : -1; // stacked row -> index in z = (x, u)
             const bool on = srefs && col_aff && a >= 0;
-            hkp[I] = on ? F + (NH - 1) * RR::SZ + RR::oAcl + a : Zs;
+            hkp[I] = on ? F + (nh - 1) * RR::SZ + RR::oAcl + a : Zs;
             hkst[I] = on ? RR::SZ : 0;
         }
         bool bad = false;
         wave_sync();
-        for (int k = NH - 1; k >= 0; --k) {
+        for (int k = nh - 1; k >= 0; --k) {
             double* Fk = F + k * RR::SZ;
             double Hk[3] = { Hacc[0], Hacc[1], Hacc[2] };
             if constexpr (SREFS) {
@@ -419,7 +425,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 }
             }
             if (!compact) { // preview step s = NH - k
-                const int s = NH - k;
+                const int s = nh - k;
                 double n0 = mfma_f64_4x4x4(pa[0][0], px[0], pc[0]);
                 double n1 = mfma_f64_4x4x4(pa[1][0], px[0], pc[1]);
                 if (NX > 4) {
@@ -428,7 +434,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 }
                 px[0] = n0;
                 px[1] = n1;
-                if (pw && (s < NH || !pgc)) {
+                if (pw && (s < nh || !pgc)) {
                     pdst[s * pst] = n0;
                     if (4 + q4 < NX) pdst[s * pst + 4] = n1;
                 }
@@ -544,14 +550,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             wA[1] -= wAst[1];
             wA[2] -= wAst[2];
             wave_sync();
-            if (k == NH - 2) COPRA_FINE("sweep:stage");
-            if (k == NH - 1) COPRA_FINE("sweep:first");
+            if (k == nh - 2) COPRA_FINE("sweep:stage");
+            if (k == nh - 1) COPRA_FINE("sweep:first");
         }
         COPRA_FINE("sweep:loop");
         if (bad) status = 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
         rows.cache_own_row(); // (global loads of this lane's row descriptor and bounds: their latency hides under the passes below)
         // Lam^-1 of every stage (lane = stage): Cholesky of the stored M_uu, inverted in place of it
-        if (lane < NH) {
+        if (lane < nh) {
             double* Fk = F + lane * RR::SZ;
             double lm[NU][NU], rd[NU], li[NU][NU];
 #pragma unroll
@@ -595,17 +601,17 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         wave_sync();
         COPRA_FINE("sweep:Li");
         // the constant block behind the records: B (it takes the place of every Bt_k, ric_factor.hpp), d and a zero
-        if (lane < NX * NU) F[NH * RR::SZ + RR::cB + lane] = B[lane];
-        if (lane < NX) F[NH * RR::SZ + RR::cD + lane] = D[lane];
-        if (lane == 0) F[NH * RR::SZ + RR::cZ] = 0.0;
-        if (lane == 1) F[NH * RR::SZ + RR::cO] = 1.0;
+        if (lane < NX * NU) F[nh * RR::SZ + RR::cB + lane] = B[lane];
+        if (lane < NX) F[nh * RR::SZ + RR::cD + lane] = D[lane];
+        if (lane == 0) F[nh * RR::SZ + RR::cZ] = 0.0;
+        if (lane == 1) F[nh * RR::SZ + RR::cO] = 1.0;
     }
     } // (!from_model)
     wave_sync();
     if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
-        for (int e = lane; e < NH * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
+        for (int e = lane; e < nh * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
         if (!compact)
-            for (int e = lane; e < NH * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
+            for (int e = lane; e < nh * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
     }
     COPRA_FINE("sweep:Bt");
     stamp[2] = cycle_counter();
@@ -643,12 +649,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             const int tst = NX; // stride between the blocks
             wave_sync();
             if (!compact) { // (compact variant: the preview steps have left the block-row norms there)
-            double s2[(NH * NX + kWave - 1) / kWave];
+            double s2[(NHM * NX + kWave - 1) / kWave];
 #pragma unroll
-            for (int u = 0; u < (NH * NX + kWave - 1) / kWave; ++u) {
+            for (int u = 0; u < (NHM * NX + kWave - 1) / kWave; ++u) {
                 const int e = lane + kWave * u, t = e / NX, comp = e - t * NX;
                 s2[u] = 0.0;
-                if (e < NH * NX) {
+                if (e < nh * NX) {
 #pragma unroll
                     for (int c = 0; c < NU; ++c) {
                         const double a = G[t * NX * NU + comp + NX * c];
@@ -658,9 +664,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             }
             wave_sync();
 #pragma unroll
-            for (int u = 0; u < (NH * NX + kWave - 1) / kWave; ++u) {
+            for (int u = 0; u < (NHM * NX + kWave - 1) / kWave; ++u) {
                 const int e = lane + kWave * u, t = e / NX, comp = e - t * NX;
-                if (e < NH * NX) NB2[t * tst + comp] = s2[u];
+                if (e < nh * NX) NB2[t * tst + comp] = s2[u];
             }
             wave_sync();
             }
@@ -669,12 +675,16 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 if (compact && e_onehot(d.ek) && d.gk == kGNone) { // (the preview steps left RUNNING sums)
                     put_norm(i, d.k > 0 ? sqrt(NB2[(d.k - 1) * tst + d.eo]) : 0.0);
                 } else if (e_onehot(d.ek) && d.gk == kGNone) {
-                    double part[NH];
-#pragma unroll
-                    for (int t = 0; t < NH; ++t) part[t] = NB2[(t < d.k ? t : 0) * tst + d.eo];
                     double acc = 0.0;
+                    if constexpr (NH > 0) {
+                        double part[NHM];
 #pragma unroll
-                    for (int t = 0; t < NH; ++t) acc += (t < d.k) ? part[t] : 0.0;
+                        for (int t = 0; t < NHM; ++t) part[t] = NB2[(t < d.k ? t : 0) * tst + d.eo];
+#pragma unroll
+                        for (int t = 0; t < NHM; ++t) acc += (t < d.k) ? part[t] : 0.0;
+                    } else {
+                        for (int t = 0; t < d.k && t < nh; ++t) acc += NB2[t * tst + d.eo]; // (the same order of summation)
+                    }
                     put_norm(i, sqrt(acc));
                 }
             }
@@ -696,12 +706,12 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         const int q = lane >> 4, b4 = (lane >> 2) & 3, r = lane & 3, row = 4 * b4 + r;
         int off[2], km[2];
 #pragma unroll
-        for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU, NH>(row, 4 * J + q, km[J]);
+        for (int J = 0; J < 2; ++J) off[J] = ric_stack_offset<NX, NU, NH>(row, 4 * J + q, km[J], nh);
         // K-block 2: the stacked input is (kv_k, 1) -- lane row q holds kv_k(q), lane row NU the constant 1 -- and the matrix
         // [B d] for the state rows (B kv + d = bkd_k: never stored), the identity for the rows u: the same at every stage
-        const double a2 = (row < NX && q <= NU) ? F[NH * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)]
+        const double a2 = (row < NX && q <= NU) ? F[nh * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)]
                                                 : (b4 == 2 && r == q && q < NU) ? 1.0 : 0.0;
-        const double* kvp = (q < NU) ? F + RR::oKv + q : F + NH * RR::SZ + (q == NU ? RR::cO : RR::cZ);
+        const double* kvp = (q < NU) ? F + RR::oKv + q : F + nh * RR::SZ + (q == NU ? RR::cO : RR::cZ);
         const int kvst = (q < NU) ? RR::SZ : 0;
         const bool writer = q < NU && b4 == 2 && r == 0;
         // the states of the roll-out (rows 0 .. NX-1 of the stacked result: blocks 0 and 1) are the trajectory at the
@@ -720,7 +730,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         wave_sync(); // (every lane has read x0: XU overwrites the system's slots)
         if (xwriter) XU[yrow] = x0r;
 #pragma unroll COPRA_RIC_UNROLL
-        for (int k = 0; k < NH; ++k) {
+        for (int k = 0; k < nh; ++k) {
             double y = mfma_f64_4x4x4(a2, kv, 0.0);
             kvp += kvst; // (behind the last stage: one record past the end, unused)
             kv = *kvp;
@@ -749,7 +759,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // ---- 5. active set ----
     int it_main = 0, it_drop = 0;
     if (status == 0)
-        status = gi_active_set<NV, true, QR, NX, NU>(S, NV, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
+        status = gi_active_set<NU * NH, true, QR, NX, NU>(S, NV, P.meq, P.mgen, rows, P.vsmall, P.max_iter, it_main, it_drop COPRA_FINE_PASS);
     wave_sync();
     stamp[6] = cycle_counter();
     if (status == 4) { // R outgrew the compact layout: queue for the second (full-layout) launch, write nothing else

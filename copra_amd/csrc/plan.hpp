@@ -74,6 +74,8 @@ struct CostTerm {
     int offP; // r
     int offW; // r
     int full; // 1: full-size entry (costFunctions.cpp:65-71, 141-146, 197-203) -> dense MFMA contraction
+    int offMask; // full-size entry with M: which K-steps (four columns of M) of each block of sixteen rows are not all zero -- per row block
+                 // ceil(ceil(X / 4) / 64) 64-bit words, each as two doubles (low | high 32 bits); -1: none (every K-step is visited)
     int pstride; // 0: one reference p for every step.  r (= rows): a REFERENCE TRAJECTORY -- the reference of step k sits at offP + k r.
                  // (A full-size entry whose M / N is block-diagonal with identical blocks and identical weights per step -- the only way the
                  // reference's API can express a reference that changes along the horizon, costFunctions.cpp:63-82, 139-156 -- is such a

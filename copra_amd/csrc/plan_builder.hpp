@@ -204,6 +204,13 @@ inline bool ric_shape_ok(int nx, int nu, int N)
         && nxx + nux + nuu >= nx * (nx + 1) && N >= 2;
 }
 
+// Shapes whose Riccati-factor tier (lmpc_fused_ric.hpp) and one-instance-per-lane pass (lmpc_lane.hpp) the LIBRARY holds for every horizon
+// (run-time value, NU N <= 64; copra_hip_ric.hip): the double integrators in one, two and three dimensions -- the reference's falling
+// mass (tests/systems.h:42-229), a planar point mass, the CoM system of binding/python/tests/pyTests.py:342-359.  (6, 3) at N = 10, 15, 20
+// additionally has builds with a compile-time horizon (copra_hip.hip).  Every other shape: copra_batch_specialise.
+inline bool ric_aot_shape(int nx, int nu) { return (nx == 6 && nu == 3) || (nx == 4 && nu == 2) || (nx == 2 && nu == 1); }
+inline bool ric_aot_exact(int nx, int nu, int N) { return nx == 6 && nu == 3 && (N == 10 || N == 15 || N == 20); }
+
 inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, int mgen, int meq, int mtotal, bool xcur_late,
     int q1regs, int budget)
 {
@@ -618,6 +625,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         t.kind = c.kind;
         t.rows = c.rows;
         t.offM = t.offN = -1;
+        t.offMask = -1;
         if (c.rows <= 0 || !c.p || !c.weights) {
             hp.error = "cost: empty p / weights";
             return COPRA_ERR_DOMAIN;
@@ -743,6 +751,21 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
             };
             if (c.kind != COPRA_COST_CONTROL) t.offM = push_rowmajor(c.M, c.rows, X);
             if (c.kind != COPRA_COST_TRAJECTORY) t.offN = push_rowmajor(c.N, c.rows, U);
+            if (c.kind != COPRA_COST_CONTROL) { // the K-steps of the dense contraction in which a block of sixteen rows of M is not all zero
+                const int KS = (X + 3) / 4, NW = (KS + 63) / 64, RB = (c.rows + 15) / 16;
+                std::vector<double> words((size_t)2 * RB * NW, 0.0);
+                for (int rb = 0; rb < RB; ++rb)
+                    for (int ks = 0; ks < KS; ++ks) {
+                        bool nz = false;
+                        for (int i = 16 * rb; i < 16 * rb + 16 && i < c.rows && !nz; ++i)
+                            for (int j = 4 * ks; j < 4 * ks + 4 && j < X && !nz; ++j) nz = c.M[(size_t)j * c.rows + i] != 0.0;
+                        if (nz) {
+                            const size_t at = (size_t)2 * (rb * NW + ks / 64) + ((ks % 64) >= 32 ? 1 : 0);
+                            words[at] += std::ldexp(1.0, ks % 32); // (bit ks % 32 of that half: an exactly representable integer below 2^32)
+                        }
+                    }
+                t.offMask = push(words.data(), (int)words.size());
+            }
             if (c.rows > P.rfull) P.rfull = c.rows;
         } else {
             if (c.kind != COPRA_COST_CONTROL) t.offM = push(c.M, c.rows * nx);
@@ -1261,6 +1284,12 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     }
     // the tables of the one-instance-per-lane pass (lmpc_lane.hpp) for a controller that did not get them with the Riccati-factor tier:
     // in front of the other one-wave first tiers the pass only filters (the instances at their unconstrained minimiser end in it)
+    // Shapes the library holds the Riccati-factor tier for at ANY horizon (ric_aot_shape): taken here, as copra_batch_specialise does for
+    // the shapes it compiles.  (Single-control systems below 48 variables stay on the packed / factor-only kernels: the reference's
+    // falling-mass problems hold most of their control bounds active, far beyond the tier's five register columns -- measured, §3.7.)
+    if (!P.lds.ric && !hp.large && ric_aot_shape(nx, nu) && ric_shape_ok(nx, nu, N) && !hp.opt.no_ric && !hp.opt.no_tri
+        && (nu >= 2 || U >= 48 || hp.opt.ric_any_shape))
+        (void)take_ric_layout(hp);
     if (P.lane_tab < 0 && !hp.large && !P.initial_state) build_lane_tables(hp);
     return COPRA_OK;
 }

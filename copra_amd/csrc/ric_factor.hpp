@@ -71,12 +71,14 @@ struct RicRec {
 // -> offset (doubles from the first record) of element (s_out, s_in) of the stacked matrix [Acl B; K I] of the forward
 // recursion (its identity block excepted); kmul = RicRec::SZ if the element belongs to the stage record (add kmul * stage),
 // 0 for the constant block.
+// NH == 0: the horizon is a run-time value, nh_rt (the builds the library ships for EVERY horizon of a shape; NH > 0: the builds of the
+// BASELINE shapes, whose loops have compile-time trip counts).
 template <int NX, int NU, int NH, bool IDENT = false>
-COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul)
+COPRA_DEV int ric_stack_offset(int s_out, int s_in, int& kmul, int nh_rt = 0)
 {
     using RR = RicRec<NX, NU>;
     static_assert(NX <= 8 && NU >= 1 && NU <= 4, "stacked layout of the MFMA recursions");
-    constexpr int cbase = NH * RR::SZ;
+    const int cbase = (NH ? NH : nh_rt) * RR::SZ;
     kmul = 0;
     const int to = (s_out < NX) ? 0 : (s_out >= 8 && s_out < 8 + NU) ? 1 : 2;
     const int ti = (s_in < NX) ? 0 : (s_in >= 8 && s_in < 8 + NU) ? 1 : 2;
@@ -108,12 +110,13 @@ template <int NX, int NU, int NH, bool TR>
 // the sums nu = mu + lambda obey the same recursion, nu_j = Acl_j' nu_{j+1}, s_j = B' nu_{j+1}: the unit vector simply joins the
 // state that enters stage inj_stage - 1 (the caller makes nstages >= inj_stage).
 COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, double* dummy, int nstages = NH, double* XI = nullptr,
-    int inj_stage = 0, int inj_comp = 0, double inj_val = 0.0)
+    int inj_stage = 0, int inj_comp = 0, double inj_val = 0.0, int nh_rt = 0)
 {
     using RR = RicRec<NX, NU>;
+    const int nh = NH ? NH : nh_rt; // (NH == 0: the horizon is a run-time value)
     const int lane = lane_id(), q = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
     const int kl = lane / NU, cl = lane - kl * NU; // this lane's (stage, component) of the NU NH vectors
-    const bool mine = lane < NU * NH;
+    const bool mine = lane < NU * nh;
     if (!TR) { // t_k = Lam_k^-T v_k, in place of v
         double t = 0.0;
         if (mine) {
@@ -129,14 +132,14 @@ COPRA_DEV double ric_apply_mfma4(const double* F, const double* in, double* X, d
     int off[3], km[3];
 #pragma unroll
     for (int J = 0; J < 3; ++J)
-        off[J] = TR ? ric_stack_offset<NX, NU, NH, true>(4 * J + q, 4 * b + r, km[J]) : ric_stack_offset<NX, NU, NH, true>(4 * b + r, 4 * J + q, km[J]);
+        off[J] = TR ? ric_stack_offset<NX, NU, NH, true>(4 * J + q, 4 * b + r, km[J], nh) : ric_stack_offset<NX, NU, NH, true>(4 * b + r, 4 * J + q, km[J], nh);
     // The loop is bound by instruction ISSUE, not latency (several instances share a SIMD): every operand has a pointer of its
     // own that moves by a per-lane stride (one addition per stage; a constant operand has stride 0), the outputs of a stage --
     // rows 8.. (block 2) and, for the forward recursion, the new state (blocks 0 and 1: the lanes that own a result row hold it
     // before the broadcast) -- leave through ONE store, the injection is a wave-uniform branch, and the operands of the next
     // stage are fetched into the registers of the current one right after their last use (no copies).  The fetches behind the
     // last stage read one record past the end (inside the instance's LDS; unused).
-    const int count = TR ? uniform_i32(nstages) : NH;
+    const int count = TR ? uniform_i32(nstages) : nh;
     const int kfirst = TR ? count - 1 : 0;
     const bool writer = q < NU && b == 2 && r == 0; // rows 8 + q: the outputs
     const bool xwriter = !TR && XI && r == 0 && b < 2 && 4 * b + q < NX; // the state: component 4 b + q sits in lane row q

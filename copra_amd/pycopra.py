@@ -236,6 +236,48 @@ class LMPC:
         self._trajectory = np.zeros(0)
         self._solve_time = self._solve_and_build_time = 0.0
         self._fail = 0
+        self._ref_accumulation = False
+        self._acc = {}  # id(cost) -> [Q, c, E, f] accumulated over the solves (reference_accumulation)
+
+    def reference_accumulation(self, on=True):
+        """Opt-in compatibility with reference quirk Q2 (no counterpart in the reference's API: it is how its cost classes behave).  The
+        per-step entries of TrajectoryCost and MixedCost ADD each solve's Q, E, f to members that are only zeroed in initializeCost
+        (src/costFunctions.cpp:52-55, 73-80 / 184-187, 205-213), and MixedCost also adds to c: the k-th solve() on one controller sees
+        k x the trajectory Hessian.  Off (default): every solve is a fresh controller's first one, the batched engine's semantics.
+        On: each solve evaluates such a cost on the device (the condense code behind copra_batch_dump_qp), accumulates it here in the
+        reference's own order and hands the sums to the fused solve as a dense cost (COPRA_COST_DENSE, the plug-in route)."""
+        self._ref_accumulation = bool(on)
+        self._dirty = True
+
+    def _accumulating(self, c):
+        per_step = c._M is None or c._M.shape[1] == self._ps.x_dim
+        return self._ref_accumulation and c.kind in ("trajectory", "mixed") and per_step and hasattr(c, "_M")
+
+    def _accumulated_dict(self, c):
+        """one more update() of cost c as the reference performs it: Q_ += .., E_ += .., f_ += .., c_ = (mixed: +=) E_' x0 + f_"""
+        from .batch import BatchLMPC
+        ps = self._ps
+        nx, n = ps.x_dim, ps.u_dim * ps.nr_u_step
+        e1 = BatchLMPC(nx, ps.u_dim, ps.nr_u_step, 1, [c._dict()], [])
+        e1.set_system(ps.A[None], ps.B[None], ps.d[None], ps.x0[None])
+        Q1 = e1.dump_qp(0)["Q"] - 1e-6 * np.eye(n)  # (minus LMPC::updateSystem's 1e-6 I, src/LMPC.cpp:228-230)
+        e1.close()
+        E1, f1 = np.zeros((nx, n)), np.zeros(n)
+        try:  # E and f from the InitialStateLMPC form of the same cost (src/InitialStateLMPC.cpp:80-84)
+            e2 = BatchLMPC(nx, ps.u_dim, ps.nr_u_step, 1, [c._dict()], [], initial_state=dict(R=np.eye(nx), r=np.zeros(nx)))
+            e2.set_system(ps.A[None], ps.B[None], ps.d[None], ps.x0[None])
+            qp = e2.dump_qp(0)
+            E1, f1 = qp["Q"][:nx, nx:], qp["c"][nx:]
+            e2.close()
+        except _capi.CopraUnsupported:
+            pass
+        acc = self._acc.setdefault(id(c), [np.zeros((n, n)), np.zeros(n), np.zeros((nx, n)), np.zeros(n)])
+        acc[0] += Q1
+        acc[2] += E1
+        acc[3] += f1
+        cnow = acc[2].T @ ps.x0 + acc[3]
+        acc[1] = acc[1] + cnow if c.kind == "mixed" else cnow
+        return dict(kind="dense", Q=acc[0], c=acc[1], E=acc[2], f=acc[3])
 
     def select_qp_Solver(self, flag):
         pass
@@ -318,6 +360,20 @@ class LMPC:
 
     def _engine(self):
         from .batch import BatchLMPC
+        if self._ref_accumulation and any(self._accumulating(c) for c in self._costs):
+            # (the accumulated members are part of the plan: a new engine for every solve, as for user-defined costs)
+            if self._eng is not None:
+                self._eng.close()
+            live = {id(c) for c in self._costs}
+            self._acc = {k: v for k, v in self._acc.items() if k in live}
+            cd = [self._accumulated_dict(c) if self._accumulating(c) else c._dict() for c in self._costs]
+            ist = self._initial_state_desc() if self._initial_state else None
+            self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, cd, [c._dict() for c in self._cstrs],
+                                  initial_state=ist)
+            self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
+            self._dirty, self._costs_dirty, self._built_costs = True, False, None
+            self.handle_builds += 1
+            return self._eng
         if self._eng is not None and not self._dirty and self._costs_against_engine() < 2:
             self._costs_dirty = False
             return self._eng

@@ -747,6 +747,113 @@ static double max_abs_diff(const Eigen::VectorXd& a, const Eigen::VectorXd& b)
     for (Eigen::Index i = 0; i < a.rows() && i < b.rows(); ++i) m = std::max(m, std::fabs(a(i) - b(i)));
     return m;
 }
+// Reference quirk Q2 as an opt-in (LMPC::referenceAccumulation): the per-step TrajectoryCost / MixedCost members are only zeroed in
+// initializeCost and ADDED to in every update (src/costFunctions.cpp:52-55, 73-80 / 184-187, 205-213), so the k-th solve() on one
+// controller sees k x Q, E, f of the cost -- for a TrajectoryCost exactly what a FRESH controller with k x the weights sees (c = E'x0 + f
+// is assigned), for a MixedCost with c_k = c_{k-1} + (E_k' x0_k + f_k) on top.  Checked here: three solves with a new x0 each, against
+// (a) a fresh controller with scaled weights (TrajectoryCost) and (b) the dense QP assembled from the accessors of fresh controllers and
+// solved by QuadProgDenseSolver (MixedCost); with the switch off every solve equals a fresh controller's first one.
+static void accumulation_case()
+{
+    IneqSystem s(10);
+    using namespace Eigen;
+    const double x0s[3][2] = { { 0.0, -5.0 }, { -0.02, -4.6 }, { -0.05, -4.1 } };
+    VectorXd uLower(1), uUpper(1);
+    uLower << -std::numeric_limits<double>::infinity();
+    uUpper << 200.0;
+    auto fresh = [&](double scale, const double* x0v, std::shared_ptr<copra::TrajectoryCost>* keep = nullptr) {
+        auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+        VectorXd x0(2);
+        x0 << x0v[0], x0v[1];
+        ps->xInit(x0);
+        auto lm = std::make_shared<copra::LMPC>(ps);
+        auto xc = std::make_shared<copra::TrajectoryCost>(s.M, s.xd);
+        auto uc = std::make_shared<copra::ControlCost>(s.N, s.ud);
+        auto ub = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        xc->weights(s.wx * scale);
+        uc->weights(s.wu);
+        lm->addCost(xc), lm->addCost(uc), lm->addConstraint(ub);
+        CHECK(lm->solve());
+        if (keep) *keep = xc;
+        return lm->control();
+    };
+    for (int mode = 0; mode < 2; ++mode) { // accumulation off / on
+        auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+        copra::LMPC lm(ps);
+        lm.referenceAccumulation(mode == 1);
+        auto xc = std::make_shared<copra::TrajectoryCost>(s.M, s.xd);
+        auto uc = std::make_shared<copra::ControlCost>(s.N, s.ud);
+        auto ub = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        xc->weights(s.wx);
+        uc->weights(s.wu);
+        lm.addCost(xc), lm.addCost(uc), lm.addConstraint(ub);
+        for (int k = 1; k <= 3; ++k) {
+            VectorXd x0(2);
+            x0 << x0s[k - 1][0], x0s[k - 1][1];
+            ps->xInit(x0);
+            CHECK(lm.solve());
+            const VectorXd want = fresh(mode == 1 ? (double)k : 1.0, x0s[k - 1]);
+            const double d = max_abs_diff(lm.control(), want);
+            if (!(d <= 1e-7)) std::printf("accumulation %d solve %d: |u - u_expected| = %.3e\n", mode, k, d);
+            CHECK(d <= 1e-7 * 200.0);
+            if (mode == 1 && k == 3) { // ... and the accumulated members are 3 x one evaluation's (costFunctions.h:79-90 accessors)
+                std::shared_ptr<copra::TrajectoryCost> one;
+                (void)fresh(1.0, x0s[k - 1], &one);
+                one->update(*ps);
+                CHECK(std::fabs(xc->Q()(0, 0) - 3.0 * one->Q()(0, 0)) <= 1e-9 * std::fabs(one->Q()(0, 0)) && one->Q()(0, 0) != 0.0);
+                CHECK(std::fabs(xc->f()(1) - 3.0 * one->f()(1)) <= 1e-9 * std::fabs(one->f()(1)) + 1e-12);
+            }
+        }
+    }
+    // MixedCost: c accumulates as well.  Expected QP of solve k from fresh costs' accessors: Q = 1e-6 I + k Q1 + Qu, c = sum_j j c1(x0_j) + cu
+    {
+        auto ps = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, s.x0, s.nbStep);
+        copra::LMPC lm(ps);
+        lm.referenceAccumulation(true);
+        MatrixXd Mm(1, 2), Nm(1, 1);
+        Mm << 0.0, 1.0; // v_k + 0.001 u_k -> -1
+        Nm << 0.001;
+        VectorXd pm(1), wm(1);
+        pm << -1.0;
+        wm << 50.0;
+        auto mc = std::make_shared<copra::MixedCost>(Mm, Nm, pm);
+        auto uc = std::make_shared<copra::ControlCost>(s.N, s.ud);
+        auto ub = std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper);
+        mc->weights(wm);
+        uc->weights(s.wu);
+        lm.addCost(mc), lm.addCost(uc), lm.addConstraint(ub);
+        const int n = s.nbStep;
+        VectorXd cacc = VectorXd::Zero(n);
+        for (int k = 1; k <= 3; ++k) {
+            VectorXd x0(2);
+            x0 << x0s[k - 1][0], x0s[k - 1][1];
+            ps->xInit(x0);
+            CHECK(lm.solve());
+            // one evaluation of the two costs at this x0, by fresh objects
+            auto ps1 = std::make_shared<copra::PreviewSystem>(s.A, s.B, s.c, x0, s.nbStep);
+            copra::MixedCost m1(Mm, Nm, pm);
+            copra::ControlCost u1(s.N, s.ud);
+            m1.weights(wm), u1.weights(s.wu);
+            m1.initializeCost(*ps1), u1.initializeCost(*ps1);
+            m1.update(*ps1), u1.update(*ps1);
+            MatrixXd Q(n, n);
+            VectorXd c(n), XL(n), XU(n);
+            for (int j = 0; j < n; ++j) {
+                cacc(j) += k * m1.c()(j); // c_k = c_{k-1} + (E_k' x0 + f_k),  E_k = k E1, f_k = k f1
+                c(j) = cacc(j) + u1.c()(j);
+                XL(j) = -std::numeric_limits<double>::max(), XU(j) = 200.0;
+                for (int i = 0; i < n; ++i) Q(i, j) = k * m1.Q()(i, j) + u1.Q()(i, j) + (i == j ? 1e-6 : 0.0);
+            }
+            copra::QuadProgDenseSolver qp;
+            qp.SI_problem(n, 0, 0);
+            CHECK(qp.SI_solve(Q, c, MatrixXd(0, n), VectorXd(0), MatrixXd(0, n), VectorXd(0), XL, XU));
+            const double d = max_abs_diff(lm.control(), qp.SI_result());
+            if (!(d <= 1e-6)) std::printf("mixed accumulation solve %d: |u - u_expected| = %.3e\n", k, d);
+            CHECK(d <= 1e-6);
+        }
+    }
+}
+
 static void tracking_case(int reps)
 {
     using namespace Eigen;
@@ -850,6 +957,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(mode, "solve")) solve_cases(argc > 2 ? std::atoi(argv[2]) : 300);
         if (!std::strcmp(mode, "initial_state")) initial_state_cases();
         if (!std::strcmp(mode, "plugins")) plugin_cases(argc > 2 ? std::atoi(argv[2]) : 12);
+        if (!std::strcmp(mode, "accumulation")) accumulation_case();
         if (!std::strcmp(mode, "tracking")) {
             copra::LMPC::newHandlePerCostChange() = argc > 3 && !std::strcmp(argv[3], "newhandle"); // (measurements: a new handle per swapped cost)
             tracking_case(argc > 2 ? std::atoi(argv[2]) : 300);

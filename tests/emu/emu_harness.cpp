@@ -257,8 +257,22 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     }
     bool lane_failed = false; // (the instance comes from the one-instance-per-lane pass with a failed factorisation)
     auto body = [&](const FusedPlan& PP, int b) {
+        // the library's builds with a RUN-TIME horizon (copra_hip_ric.hip; select_fused_kernel) for the shapes of ric_aot_shape -- unless the
+        // test asks for what copra_batch_specialise compiles (COPRA_EMU_WANT_RIC: the compile-time instantiations below)
+        const bool rt = PP.lds.tri && PP.lds.ric && ric_aot_shape(PP.nx, PP.nu) && !ric_aot_exact(PP.nx, PP.nu, PP.N) && !std::getenv("COPRA_EMU_WANT_RIC");
+#define EMU_RIC_RT(NX, NU)                                                                                             \
+    (PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<NX, NU, 0, 6, kFusedQ1Regs, true>(PP, b, lane_failed)        \
+                                    : lmpc_fused_ric_body<NX, NU, 0, 6, kFusedQ1Regs>(PP, b, lane_failed))             \
+                   : (PP.stage_refs ? lmpc_fused_ric_body<NX, NU, 0, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<NX, NU, 0, 6, 0>(PP, b, lane_failed)))
+        if (rt && PP.nx == 6)
+            EMU_RIC_RT(6, 3);
+        else if (rt && PP.nx == 4)
+            EMU_RIC_RT(4, 2);
+        else if (rt)
+            EMU_RIC_RT(2, 1);
+#undef EMU_RIC_RT
         // (shapes beyond the library's instantiations: what copra_batch_specialise compiles at run time)
-        if (PP.lds.tri && PP.lds.ric && PP.nx == 6 && PP.nu == 3 && PP.N == 12)
+        else if (PP.lds.tri && PP.lds.ric && PP.nx == 6 && PP.nu == 3 && PP.N == 12)
             PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 12, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<6, 3, 12, 6, 0>(PP, b, lane_failed));
         else if (PP.lds.tri && PP.lds.ric && PP.nx == 4 && PP.nu == 2 && PP.N == 16)
             PP.lds.q1regs ? (PP.stage_refs ? lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs, true>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, kFusedQ1Regs>(PP, b, lane_failed)) : (PP.stage_refs ? lmpc_fused_ric_body<4, 2, 16, 6, 0, true>(PP, b, lane_failed) : lmpc_fused_ric_body<4, 2, 16, 6, 0>(PP, b, lane_failed));

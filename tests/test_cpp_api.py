@@ -118,3 +118,14 @@ def test_tracking_tick_reuses_the_device_controller():
     _build()
     r = subprocess.run([EXE, "tracking", "300"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_accumulation_across_solves_is_available_on_request():
+    """reference quirk Q2 (src/costFunctions.cpp:73-80, 205-213: per-step TrajectoryCost / MixedCost accumulate Q, E, f -- MixedCost also
+    c -- across the solves of one controller) as an opt-in of the mirror, copra::LMPC::referenceAccumulation(true): the k-th solve equals
+    a fresh controller with k x the TrajectoryCost weights / the dense QP with k Q1 and sum_j j c1(x0_j); switched off, every solve is a
+    fresh controller's first one (the batched engine's semantics)"""
+    _build()
+    r = subprocess.run([EXE, "accumulation"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

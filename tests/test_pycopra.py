@@ -267,3 +267,71 @@ def test_cost_changes_between_solves_like_the_reference():
     assert fresh.solve() and np.abs(fresh.control() - ctl.control()).max() <= 1e-10
     _, stale, keep3 = build(reference(7), wx, x)
     assert stale.solve() and np.abs(stale.control() - ctl.control()).max() > 1e-6  # (the weights did something)
+
+
+@pytest.mark.gpu
+def test_reference_accumulation_switch():
+    """reference quirk Q2 (src/costFunctions.cpp:73-80, 205-213) as an opt-in of the Python mirror (LMPC.reference_accumulation): the k-th
+    solve of one controller with a per-step TrajectoryCost equals a fresh controller with k x its weights; a per-step MixedCost also
+    accumulates c -- checked against the dense QP  (1e-6 I + k Q1 + Qu) U + (sum_j j c1(x0_j) + cu)  assembled from the oracle's evaluation
+    of ONE update and solved by the oracle's QuadProgDense restatement.  Switched off (the default), every solve is a fresh controller's."""
+    import copra_amd.pycopra as copra
+    import pyoracle
+    from copra_amd import workloads
+    wl = workloads.com_preview(1, v_max=0.4, u_max=2.0)
+    N, A, B, d = wl["N"], wl["A"][0], wl["B"][0], wl["d"][0]
+    x0, goal = workloads.COM_X_INIT, workloads.COM_X_GOAL
+    wx = np.array([10.0, 10, 10, 1, 1, 1])
+    inf = np.inf
+
+    def build(scale, x, accumulate=False):
+        ps = copra.PreviewSystem(A, B, d, x, N)
+        c = copra.LMPC(ps)
+        c.reference_accumulation(accumulate)
+        xc = copra.TrajectoryCost(np.eye(6), goal)
+        xc.weights(wx * scale)
+        uc = copra.ControlCost(np.eye(3), np.zeros(3))
+        uc.weights(np.full(3, 1e-3))
+        keep = (xc, uc, copra.ControlBoundConstraint(np.full(3, -2.0), np.full(3, 2.0)),
+                copra.TrajectoryBoundConstraint(np.full(6, -inf), np.array([inf, inf, inf, 0.4, 0.4, 0.4])))
+        c.add_cost(xc), c.add_cost(uc), c.add_constraint(keep[2]), c.add_constraint(keep[3])
+        return ps, c, keep
+
+    for accumulate in (False, True):
+        ps, ctl, keep = build(1.0, x0, accumulate)
+        for k in (1, 2, 3):
+            x = x0 + 0.01 * (k - 1)
+            ps.x_init(x)
+            assert ctl.solve()
+            _, fresh, keep2 = build(float(k) if accumulate else 1.0, x)
+            assert fresh.solve() and np.abs(fresh.control() - ctl.control()).max() <= 1e-8
+        if accumulate:
+            _, plain, keep3 = build(1.0, x)
+            assert plain.solve() and np.abs(plain.control() - ctl.control()).max() > 1e-4  # (the accumulation did something)
+
+    # MixedCost: Q_k = k Q1, c_k = c_{k-1} + k (E1' x0_k + f1)
+    Mm, Nm, pm, wm = np.hstack([np.zeros((3, 3)), np.eye(3)]), 0.05 * np.eye(3), np.full(3, 0.2), np.full(3, 40.0)
+    mixed = dict(kind="mixed", M=Mm, N=Nm, p=pm, weights=wm)
+    ucost = dict(kind="control", N=np.eye(3), p=np.zeros(3), weights=np.full(3, 1e-3))
+    cstrs = [dict(kind="control_bound", lower=[-2.0] * 3, upper=[2.0] * 3)]
+    ps = copra.PreviewSystem(A, B, d, x0, N)
+    ctl = copra.LMPC(ps)
+    ctl.reference_accumulation(True)
+    mc = copra.MixedCost(Mm, Nm, pm)
+    mc.weights(wm)
+    uc = copra.ControlCost(np.eye(3), np.zeros(3))
+    uc.weights(np.full(3, 1e-3))
+    ub = copra.ControlBoundConstraint(np.full(3, -2.0), np.full(3, 2.0))
+    ctl.add_cost(mc), ctl.add_cost(uc), ctl.add_constraint(ub)
+    n = 3 * N
+    cacc = np.zeros(n)
+    for k in (1, 2, 3):
+        x = x0 + 0.01 * (k - 1)
+        ps.x_init(x)
+        assert ctl.solve()
+        q1 = pyoracle.lmpc_build(A, B, d, x, N, [mixed], [])  # Q = 1e-6 I + Q1, c = c1(x)
+        qu = pyoracle.lmpc_build(A, B, d, x, N, [ucost], cstrs)
+        cacc += k * q1["c"]
+        Q = k * (q1["Q"] - 1e-6 * np.eye(n)) + qu["Q"]
+        want, fail, _ = pyoracle.quadprog_dense(Q, cacc + qu["c"], None, None, None, None, qu["lb"], qu["ub"])
+        assert fail == 0 and np.abs(want - ctl.control()).max() <= 1e-7

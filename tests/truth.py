@@ -277,10 +277,13 @@ def certify(qp, z_guess, tol_act=3e-6, tiny=1e-17):
         neg = [i for i in range(len(lam_in)) if lam_in[i] < 0]
         if not viol and not vlb and not vub and not neg:
             nx0 = qp["nx0"]
-            x0 = z[:nx0] if nx0 else qp["x0"]
-            Xt = qp["Phi"].dot(x0) + qp["Psi"].dot(z[nx0:]) + qp["xi"]
+            if qp.get("Phi") is not None:
+                x0 = z[:nx0] if nx0 else qp["x0"]
+                Xt = ar.f64(qp["Phi"].dot(x0) + qp["Psi"].dot(z[nx0:]) + qp["xi"])
+            else:  # (a plain dense QP: no preview system behind it)
+                Xt = None
             inact = [sl_all[i] for i in range(len(sl_all)) if i not in act_in]
-            return dict(z=zf, control=zf[nx0:], x0_opt=zf[:nx0], trajectory=ar.f64(Xt), stationarity=stat,
+            return dict(z=zf, control=zf[nx0:], x0_opt=zf[:nx0], trajectory=Xt, stationarity=stat,
                         min_mult=float(lam_in.min()) if len(lam_in) else 0.0,
                         min_inactive_slack=float(min(inact)) if inact else np.inf,
                         n_active=(len(a_in), len(a_lb), len(a_ub), len(a_pin)), attempts=_attempt + 1)
@@ -303,6 +306,16 @@ def solve(A, B, d, x0, N, costs, cstrs, z_guess, initial_state=None, arith="long
     """certified optimum of one instance; z_guess: a float64 solution (U, or [x0; U] for InitialStateLMPC) that identifies the
     active set -- the oracle's, or the device's"""
     qp = build_qp(A, B, d, x0, N, costs, cstrs, initial_state=initial_state, ar=Arith(arith))
+    return certify(qp, np.asarray(z_guess, dtype=np.float64))
+
+
+def solve_dense_qp(Q, c, Aeq, beq, Aineq, bineq, XL, XU, z_guess, arith="longdouble"):
+    """certified optimum of a dense QP in SolverInterface form (include/SolverInterface.h:54-80) from a float64 point that identifies
+    the active set; raises RuntimeError when no active set near the guess can be certified"""
+    ar = Arith(arith)
+    n = len(c)
+    qp = dict(H=ar.cv(Q), g=ar.cv(c), Aeq=ar.cv(np.reshape(Aeq, (-1, n))), beq=ar.cv(beq), Ain=ar.cv(np.reshape(Aineq, (-1, n))),
+              bin=ar.cv(bineq), lb=np.asarray(XL, float), ub=np.asarray(XU, float), Phi=None, nx0=0, ar=ar)
     return certify(qp, np.asarray(z_guess, dtype=np.float64))
 
 
