@@ -53,7 +53,7 @@ class Options(C.Structure):
                                            "no_riccati", "no_ric_fast", "riccati_per_cu", "large_per_cu", "large_grid", "large_no_w4",
                                            "large_params_lds")]
                 + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol", "ric_s0", "ric_lam0")]
-                + [("recorded_events", C.c_int), ("debug", C.c_int)])
+                + [("recorded_events", C.c_int), ("debug", C.c_int), ("lane_group", C.c_int)])
 
 
 OPTION_NAMES = tuple(n for n, _ in Options._fields_ if n != "struct_size")

@@ -525,6 +525,7 @@ static FusedPlan device_plan(const copra_batch* h)
     P.lane_count = P.lane_zero = nullptr;
     P.lane_hist = nullptr;
     P.lane_bp = 0;
+    P.lane_group = 0;
     P.ws = h->d_ws;
     P.model_out = nullptr;
     P.model = nullptr;
@@ -605,7 +606,7 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
 static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
 {
     const FusedPlan& P = h->hp.plan;
-    const size_t bp = ((size_t)P.batch + kWave - 1) / kWave * kWave;
+    const size_t bp = ((size_t)P.batch + kWave - 1) / kWave * kWave + kWave; // (+ 64 spare columns: what lanes without an instance write)
     // every buffer is tested on its own, and a failed attempt leaves NONE behind (round-3 advisor finding: with the counters allocated
     // and the list not, the next call returned COPRA_OK with a null list)
     hipError_t e = hipSuccess;
@@ -1994,8 +1995,13 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.lane_list = h->d_lane_list;
         P.lane_count = h->d_lane_count + h->lane_cur;
         P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
-        P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
-        const unsigned g0 = (unsigned)(P.lane_bp / kWave);
+        P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave) + kWave;
+        // instances per wave: 64.  (copra_options_t::lane_group = 32 runs HALF-WAVES -- twice the waves, lanes 32.. idle -- which was meant
+        // to fill the machine at a shard of BASELINE configs[3], 32 768 instances = 512 full waves on 1024 SIMDs: measured NO faster,
+        // 0.295 vs 0.286 ms per 32 768 and 0.575 vs 0.471 ms per 65 536 -- the pass's wave time is its arithmetic and its own dependent memory
+        // trips, not contention: profiles/r04/lane_half_waves.txt.  Kept as an experiment switch.)
+        P.lane_group = h->hp.opt.lane_group == 32 ? 32 : 64;
+        const unsigned g0 = (unsigned)(((long long)P.batch + P.lane_group - 1) / P.lane_group);
         P.lane_dbg = h->hp.opt.lane_dbg;
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)

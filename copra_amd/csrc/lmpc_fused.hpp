@@ -392,8 +392,7 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
     const double* Mr = (ct.offM >= 0) ? P.params + ct.offM : nullptr; // R x X, row-major
     const double* Nr = (ct.offN >= 0) ? P.params + ct.offN : nullptr; // R x n, row-major
     const double* w = P.params + ct.offW;
-    double* We = scratch; // R weighted residuals
-    double* stage = scratch + ((R + 1) & ~1); // 16 x 64 tile of tmp rows
+    double* We = scratch; // R weighted residuals (only where they cannot ride in the product: ControlCost, or n == 64)
     // The residual  M xbar - p  RIDES in the product when the 64-column tile has a spare column (n < 64: the headline has 60):
     // column n of the B operand is xbar, so tmp(r, n) = M_r . xbar comes out of the same instructions.  (Round 3 walked every row of
     // M once more on the vector ALU for it, one lane per row: 2 x 126 dependent trips to the L2 per instance.)
@@ -486,44 +485,52 @@ COPRA_DEV void full_size_cost_term(const FusedPlan& P, const CostTerm& ct, const
                 }
             }
         }
-        // tile -> LDS (+ N): element `reg` of tile tj is tmp(r0 + kk + 4 reg, 16 tj + col); column n: the residual's M_r . xbar
-        wave_sync();
+        // Element `reg` of tile tj in this lane is tmp(r0 + kk + 4 reg, 16 tj + col) -- and the A / B operands of the second product,
+        // (tmp' W) tmp over four K-steps of four rows, are tmp(r0 + 4 ks + kk, 16 t + col): THE SAME LANE's element ks.  The tile never
+        // leaves the registers (round 3 staged it through 8 KB of LDS per instance: sixteen writes, forty-eight reads and two syncs per
+        // row block, and an LDS footprint that kept the kernel at one wave per SIMD).
+        if (Nr) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = r0 + kk + 4 * reg, j = 16 * tj + col;
-                double v = tt[tj].v[reg];
-                if (Nr) v += nrv[tj][reg];
-                stage[(kk + 4 * reg) * kWave + j] = (r < R && (j < n || (xcol && j == n))) ? v : 0.0;
-            }
-        wave_sync();
-        if (xcol) { // We_r = (M_r . xbar - p_r) w_r of this row block
-            if (lane < 16 && r0 + lane < R) We[r0 + lane] = (stage[lane * kWave + n] - p[r0 + lane]) * w[r0 + lane];
-            wave_sync();
+                for (int reg = 0; reg < 4; ++reg) tt[tj].v[reg] += nrv[tj][reg];
         }
-        // c += (resid' W) tmp, rows in ascending order (lane = column)
-        {
-            double g = 0.0;
+        // this lane's four rows: weights, and the weighted residuals We_r = (M_r . xbar - p_r) w_r -- M_r . xbar from the lane of the
+        // same row group that holds column n of the tile
+        double wv[4], we[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (r0 + i < R) g += We[r0 + i] * stage[i * kWave + lane];
-            cj += (lane < n) ? g : 0.0;
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = r0 + kk + 4 * reg, rc = r < R ? r : 0;
+            wv[reg] = (r < R) ? w[rc] : 0.0;
+            if (xcol) {
+                double mx = tt[0].v[reg];
+#pragma unroll
+                for (int tj = 1; tj < 4; ++tj) mx = (tj == txc) ? tt[tj].v[reg] : mx;
+                mx = shfl_f64(mx, (lane & 48) | (n & 15));
+                we[reg] = (r < R) ? (mx - p[rc]) * wv[reg] : 0.0;
+            } else {
+                we[reg] = (r < R) ? We[rc] : 0.0;
+            }
+        }
+        // c += (resid' W) tmp: four rows per lane, then over the four row groups; lane j = 16 tj + col takes column j
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            double part = 0.0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) part += we[reg] * tt[tj].v[reg];
+            part += shfl_xor_f64(part, 16);
+            part += shfl_xor_f64(part, 32);
+            cj += (kk == tj && lane < n) ? part : 0.0;
         }
         // Q += (tmp' W) tmp : four K-steps of four rows
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int r = r0 + 4 * ks + kk;
-            const double wk = (r < R) ? w[r] : 0.0;
-            double a[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = stage[(4 * ks + kk) * kWave + 16 * t + col]; // tmp(r, 16 t + col)
             int idx = 0;
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
                 for (int tj = ti; tj < 4; ++tj) {
-                    mfma_f64_16x16x4(a[ti] * wk, a[tj], acc[idx]);
+                    mfma_f64_16x16x4(tt[ti].v[ks] * wv[ks], tt[tj].v[ks], acc[idx]);
                     ++idx;
                 }
         }

@@ -25,13 +25,15 @@ namespace copra_hip {
 // W doubles per instance, [batch][W] in HBM: the 64 instances of this wave are one contiguous block -- coalesced loads (ALL arrays
 // are requested before the first one is used: one trip to memory), transposed through LDS (odd stride: no bank conflicts) so that
 // every lane ends up with its own instance in registers
+// grp: instances per wave -- 64, or 32 on the HALF-WAVE form of the pass (FusedPlan::lane_group, an experiment switch: twice as many waves
+// with 32 instances each, lanes 32.. compute on a copy of the wave's first instance; measured no faster, profiles/r04/lane_half_waves.txt)
 template <int W>
-COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)[W])
+COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)[W], int grp = kWave)
 {
     const int lane = lane_id();
-    const size_t base = (size_t)group * kWave * W;
-    const int left = batch - group * kWave;
-    const int count = (left < kWave ? left : kWave) * W;
+    const size_t base = (size_t)group * grp * W;
+    const int left = batch - group * grp;
+    const int count = (left < grp ? left : grp) * W;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int e = j * kWave + lane;
@@ -39,12 +41,12 @@ COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)
     }
 }
 template <int W>
-COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, double* lds, double (&out)[W])
+COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, double* lds, double (&out)[W], int grp = kWave)
 {
     constexpr int ST = W | 1;
     const int lane = lane_id();
-    const int left = batch - group * kWave;
-    const int count = (left < kWave ? left : kWave) * W;
+    const int left = batch - group * grp;
+    const int count = (left < grp ? left : grp) * W;
     wave_sync(); // (the previous array has left the staging area)
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -100,8 +102,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     constexpr int oLiW = KW, oNbW = KW + NU * (NU + 1) / 2, WR = oNbW + NX; // rows of the workspace per stage (plan.hpp: lane_ws_rows)
     static_assert(NU >= 1 && NU <= 3, "the control block is eliminated in closed form");
     const int lane = lane_id();
-    const int inst = group * kWave + lane;
-    const bool valid = inst < P.batch;
+    const int GRP = P.lane_group > 0 ? P.lane_group : kWave; // instances of this wave (64, or 32: the half-wave form for small batches)
+    const int inst = group * GRP + lane;
+    const bool valid = lane < GRP && inst < P.batch;
     const int NH = P.N;
     const double* tab = P.params + P.lane_tab;
     int oh_, oHN_, ohN_, oRows_;
@@ -116,14 +119,14 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double A[NX * NX], B[NX * NU], d[NX], x[NX];
     {
         double rA[NX * NX], rB[NX * NU], rd[NX], rx[NX];
-        lane_fetch<NX * NX>(P.A, group, P.batch, rA);
-        lane_fetch<NX * NU>(P.B, group, P.batch, rB);
-        lane_fetch<NX>(P.d, group, P.batch, rd);
-        lane_fetch<NX>(P.x0, group, P.batch, rx);
-        lane_transpose_in<NX * NX>(rA, group, P.batch, lds, A);
-        lane_transpose_in<NX * NU>(rB, group, P.batch, lds, B);
-        lane_transpose_in<NX>(rd, group, P.batch, lds, d);
-        lane_transpose_in<NX>(rx, group, P.batch, lds, x);
+        lane_fetch<NX * NX>(P.A, group, P.batch, rA, GRP);
+        lane_fetch<NX * NU>(P.B, group, P.batch, rB, GRP);
+        lane_fetch<NX>(P.d, group, P.batch, rd, GRP);
+        lane_fetch<NX>(P.x0, group, P.batch, rx, GRP);
+        lane_transpose_in<NX * NX>(rA, group, P.batch, lds, A, GRP);
+        lane_transpose_in<NX * NU>(rB, group, P.batch, lds, B, GRP);
+        lane_transpose_in<NX>(rd, group, P.batch, lds, d, GRP);
+        lane_transpose_in<NX>(rx, group, P.batch, lds, x, GRP);
     }
     // the stage cost H | h into LDS, behind the staging area: read there by every stage of the sweep (a wave-uniform address: one
     // broadcast read per entry, in order -- scalar loads come back out of order and every use waited for all of them)
@@ -188,7 +191,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     // ---- 1. backward Riccati sweep; K_k | kv_k to the workspace, lane-major: element e of stage k at ws[(k KW + e) bp + inst] ----
     double* const ws = P.lane_ws;
     const size_t bp = (size_t)P.lane_bp;
-    const unsigned ioff = (unsigned)inst * 8u; // this lane's byte offset in a workspace row
+    // this lane's byte offset in a workspace row: its instance's column, or -- lanes without an instance -- one of the 64 spare columns
+    // behind the batch (copra_batch_solve sizes the rows lane_bp = batch rounded up to 64, + 64)
+    const unsigned ioff = (unsigned)(valid ? inst : P.lane_bp - kWave + lane) * 8u;
     // cost-to-go: the upper triangle only ((i, l), i <= l, at i + NX l) -- both halves would be 15 more doubles carried around the loop
     double Pm[NX * NX], pv[NX];
 #pragma unroll
@@ -457,8 +462,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double Kq[KB][KW];
 #pragma unroll
     for (int q = 0; q < KB; ++q) fetch_stage(Kq[q], q);
-    const int left = P.batch - group * kWave;
-    const int ninst = left < kWave ? left : kWave;
+    const int left = P.batch - group * GRP;
+    const int ninst = left < GRP ? left : GRP;
     for (int k0 = 0; k0 < NH; k0 += GS) {
         wave_sync(); // (the previous group has left the staging area)
 #pragma unroll
@@ -537,8 +542,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         wave_sync();
         if (!(P.lane_dbg & 1)) { // consecutive lanes write consecutive doubles of an instance's segment
             const int nst = NH - k0 < GS ? NH - k0 : GS; // stages of this group
-            double* const xg = P.trajectory + (size_t)(group * kWave) * P.X + (size_t)k0 * NX;
-            double* const ug = P.control + (size_t)(group * kWave) * P.n + (size_t)k0 * NU;
+            double* const xg = P.trajectory + (size_t)(group * GRP) * P.X + (size_t)k0 * NX;
+            double* const ug = P.control + (size_t)(group * GRP) * P.n + (size_t)k0 * NU;
 #pragma unroll 4
             for (int j = 0; j < GS * NX; ++j) { // (four stores in flight at a time: each has its own address pair)
                 const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);

@@ -120,7 +120,7 @@ struct LdsLayout {
     int BldY; // N blocks r x nu   (M G_k)
     int BldWe; // (N+1) blocks r    (w .* (M xbar_k - p))
     int BldCp; // parameters of the cost being processed: M (r x nx) | N (r x nu) | p (r) | w (r)
-    int BldFull; // full-size costs: weighted residuals (rfull) | 16 x 64 tile of tmp = M Psi + N for the MFMA operands
+    int BldFull; // full-size costs: weighted residuals (rfull)
     int total; // total doubles
 };
 
@@ -272,7 +272,8 @@ struct FusedPlan {
     int lane_cref; // offset (doubles from lane_tab) of the reference coefficients: [cost][row (6)][nz + nx]
     int lane_tlds; // > 0: that many doubles of tables -- the rows of every step, then ub and lb -- sit in LDS behind H | h (the pass reads them there
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
-    int lane_bp; // instances per workspace row (the batch rounded up to whole waves)
+    int lane_bp; // columns of a workspace row: the batch rounded up to whole waves, + 64 spare ones (what lanes without an instance write)
+    int lane_group; // instances per wave of the pass: 64 (0), or 32 -- half-waves (an experiment switch: measured no faster at any batch)
     int lane_from_list;
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)
     int lane_dbg; // experiments (COPRA_LANE_DBG): 1 = no result stores, 2 = no workspace traffic, 4 = no input staging through LDS

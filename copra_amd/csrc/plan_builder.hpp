@@ -115,7 +115,7 @@ inline bool layout_lds(LdsLayout& L, int nx, int nu, int N, int n, int X, int rm
     L.Q1 = 0;
     L.q1regs = (tri && q1regs > 0) ? q1regs : 0;
     const int sizePrev = fused ? align2(nx * nx) + align2(nx * nu) + 2 * align2(nx) + align2((N + 1) * nx * nx) + align2(X) : 0;
-    const int sizeFull = rfull > 0 ? align2(rfull) + 16 * kWave : 0; // weighted residuals | 16 x 64 tile of tmp
+    const int sizeFull = rfull > 0 ? align2(rfull) : 0; // weighted residuals (the 16 x 64 tile of tmp stays in registers: full_size_cost_term)
     const int sizeY = no_y ? 0 : align2(N * rmax * nu);
     const int sizeCost = fused ? sizeY + align2((N + 1) * rmax) + align2(rmax * (nx + nu + 2)) + sizeFull : 0;
     if (fused) {

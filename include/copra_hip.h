@@ -171,6 +171,7 @@ typedef struct {
     /* misc */
     int recorded_events; /* time solves with recorded events instead of events carried in the dispatch packets */
     int debug; /* print launch geometry and adaptation decisions to stderr */
+    int lane_group; /* instances per wave of the one-instance-per-lane pass: 64 (0), or 32 = half-waves (an experiment: measured no faster) */
 } copra_options_t;
 void copra_options_init(copra_options_t* opts);
 /* the process-wide defaults copra_options_init hands out and the entry points without an options argument use (copra_batch_create,

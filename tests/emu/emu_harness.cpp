@@ -317,8 +317,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     std::vector<double> lane_ws;
     int lane_count = 0, lane_other = 0;
     if (lane_pass) {
-        const int groups = (dims->batch + 63) / 64;
-        P.lane_bp = groups * 64;
+        P.lane_group = default_options().lane_group == 32 ? 32 : 64; // (copra_batch_solve: 32 at batches that leave half of the SIMDs idle)
+        const int groups = (dims->batch + P.lane_group - 1) / P.lane_group;
+        P.lane_bp = (dims->batch + 63) / 64 * 64 + 64;
         lane_ws.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * P.lane_bp, 0.0);
         P.lane_ws = lane_ws.data();
         P.lane_list = lane_list.data();

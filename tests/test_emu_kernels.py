@@ -1284,3 +1284,25 @@ def test_riccati_factor_tier_with_a_run_time_horizon(emu, oracle, shape):
         assert re["riccati_factor"], shape
         assert (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all(), (shape, opts)
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+
+
+@pytest.mark.parametrize("b", [70, 96, 33])
+def test_lane_pass_in_half_waves(emu, oracle, monkeypatch, b):
+    """FusedPlan::lane_group = 32: the one-instance-per-lane pass with 32 instances per wave (lanes 32.. idle, their stores in spare
+    workspace columns) -- what copra_batch_solve launches at batches that would leave half of the machine's SIMDs without a wave (a
+    shard of BASELINE configs[3]).  Ragged last wave, hand-over to the tier, histogram: everything against the oracle and identical
+    to the 64-instance form."""
+    from copra_amd import workloads
+    wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=9)
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+    r64 = emu.lmpc_solve(*args)
+    h64 = emu.last_lane_hist()
+    monkeypatch.setitem(OPTIONS, "lane_group", 32)
+    r32 = emu.lmpc_solve(*args)
+    h32 = emu.last_lane_hist()
+    ok = ro["status"] == 0
+    assert (r32["status"] == ro["status"]).all() and (r32["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(r32["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(r32["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    assert r32["lane_pass_finished"] == r64["lane_pass_finished"] and (h32 == h64).all()
+    assert np.array_equal(r32["control"][ok], r64["control"][ok])  # (the same arithmetic per instance: bit for bit)

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-4 profile collection on the GPU box:  gpurun -- 'bash tools/collect_profiles_r04.sh'
+# Builds first and forbids rebuilding afterwards: rocprofv3 preloads a library that initialises the GPU in every child, so make -> hipcc
+# must never be spawned from a profiled process (COPRA_NO_BUILD makes the loader raise instead).  Counters in their own --pmc passes (never
+# combined with trace domains); every summary records the source hash of the library it was taken on (tools/pmc_summary.py), which
+# bench.py compares with the loaded library (roofline.traffic_stale).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python -c 'import __graft_entry__ as g; g.build()' > /dev/null
+python -c 'import sys; sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); import test_cpp_api; test_cpp_api._build()' > /dev/null 2>&1 || true
+export COPRA_NO_BUILD=1
+O=gpurun_out
+R=profiles/r04
+mkdir -p $R
+rm -rf $O/hl4_* $O/c54_* $O/dn4_*
+BENCH="python3 bench.py --no-cpu-baseline --no-extra"
+# ---- headline (BASELINE configs[2], batch 65536): the pair copra_lmpc_lane_kernel + copra_lmpc_fused_ric_kernel ----
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/hl4_stats -- $BENCH --steps 20 --warmup 2 > $O/hl4_run.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/hl4_fetch -- $BENCH --steps 5 --warmup 1 >> $O/hl4_run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/hl4_write -- $BENCH --steps 5 --warmup 1 >> $O/hl4_run.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/hl4_sq -- $BENCH --steps 5 --warmup 1 >> $O/hl4_run.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/hl4_sq2 -- $BENCH --steps 5 --warmup 1 >> $O/hl4_run.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/hl4_sq3 -- $BENCH --steps 5 --warmup 1 >> $O/hl4_run.log 2>&1 || echo "(FP64 class counters not available)"
+python tools/pmc_summary.py $O/hl4_stats $O/hl4_fetch $O/hl4_write $O/hl4_sq $O/hl4_sq2 $O/hl4_sq3 > $R/headline_rocprof_summary.json
+find $O/hl4_stats -name "*kernel_stats.csv" -exec cp {} $R/headline_kernel_stats.csv \;
+# ---- config 5 (InitialStateLMPC 12/6/50, batch 16384): the LDS-resident Riccati interior-point kernel ----
+C5="python3 tools/try_config5.py 16384 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c54_stats -- $C5 > $O/c54_run.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c54_fetch -- $C5 >> $O/c54_run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c54_write -- $C5 >> $O/c54_run.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/c54_sq -- $C5 >> $O/c54_run.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/c54_sq2 -- $C5 >> $O/c54_run.log 2>&1
+python tools/pmc_summary.py $O/c54_stats $O/c54_fetch $O/c54_write $O/c54_sq $O/c54_sq2 > $R/config5_rocprof_summary.json
+find $O/c54_stats -name "*kernel_stats.csv" -exec cp {} $R/config5_kernel_stats.csv \;
+# ---- the dense Psi' W Psi path (what configs[2] names): kernel stats, MFMA counters, HBM traffic, phase split ----
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/dn4_stats -- $BENCH --dense-hessian --steps 5 --warmup 1 > $O/dn4_run.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/dn4_sq -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/dn4_run.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/dn4_fetch -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/dn4_run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/dn4_write -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/dn4_run.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/dn4_sq2 -- $BENCH --dense-hessian --steps 3 --warmup 1 >> $O/dn4_run.log 2>&1
+python tools/pmc_summary.py $O/dn4_stats $O/dn4_sq $O/dn4_fetch $O/dn4_write $O/dn4_sq2 > $R/dense_path_rocprof_summary.json
+python tools/dense_phase_profile.py 2>&1 | grep -v amdgpu.ids > $R/dense_path_phase_cycles.txt || true
+# ---- side measurements ----
+python tools/exp/lane_tier1_phases.py 2>&1 | grep -v amdgpu.ids > $R/lane_tier1_phases.txt || true
+python tools/tight_ladder_rates.py 2>&1 | grep -v amdgpu.ids > $R/tight_ladder_rates.txt || true
+python tools/exp/truth_distances.py 2>&1 | grep -v amdgpu.ids > $R/truth_distances.txt || true
+for b in 8192 16384 24576 32768; do echo "batch $b"; COPRA_OPTIONS=lane_min_batch=1 python tools/exp/lane_pass_check.py $b 2>&1 | grep -v amdgpu.ids | head -1; done > $R/lane_batch_sweep.txt || true
+python tools/sweep_shapes.py 2>&1 | grep -v amdgpu.ids > $R/shape_sweep.txt || true
+python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_sweep_specialised.txt || true
+# ---- the bench line itself (with cpu_baseline and extra): AFTER the summaries, so that its roofline.traffic is the one just measured ----
+python bench.py --steps 20 --warmup 3 > $O/bench_r04.json 2> $O/bench_r04.err
+cp $O/bench_r04.json $R/bench_line_final.json
+tail -c 1200 $O/bench_r04.json
+head -5 $R/headline_kernel_stats.csv
+head -4 $R/config5_kernel_stats.csv
