@@ -50,6 +50,8 @@ python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_s
 # ---- the bench line itself (with cpu_baseline and extra): AFTER the summaries, so that its roofline.traffic is the one just measured ----
 python bench.py --steps 20 --warmup 3 > $O/bench_r04.json 2> $O/bench_r04.err
 cp $O/bench_r04.json $R/bench_line_final.json
+# (only gpurun_out/ travels back from the box: the summaries go there as well, under their own directory)
+mkdir -p $O/profiles_r04 && cp $R/* $O/profiles_r04/
 tail -c 1200 $O/bench_r04.json
 head -5 $R/headline_kernel_stats.csv
 head -4 $R/config5_kernel_stats.csv
