@@ -2003,6 +2003,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.lane_group = h->hp.opt.lane_group == 32 ? 32 : 64;
         const unsigned g0 = (unsigned)(((long long)P.batch + P.lane_group - 1) / P.lane_group);
         P.lane_dbg = h->hp.opt.lane_dbg;
+        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover) ? 1 : 0; // (the pass leaves Lam^-1 and the norm sums only for a tier that takes them)
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
         const bool predict = h->lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;

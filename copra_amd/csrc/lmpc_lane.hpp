@@ -348,7 +348,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
                 lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
             }
-            // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier
+            // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier,
+            // and only when it takes the factor over (FusedPlan::lane_handover; round-3 advisor finding: in front of the other tiers the
+            // pass only filters, and these six rows and the six norm rows below were dead traffic)
+            if (!P.lane_handover) continue;
             double lm[NU][NU], rd[NU], lid[NU][NU];
 #pragma unroll
             for (int cb = 0; cb < NU; ++cb)
@@ -479,7 +482,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 u[c] = s;
             }
             fetch_stage(Kq[q % KB], k + KB);
-            if (on && !(P.lane_dbg & 2)) { // |row i of G_k|^2 added, stored, and the next block
+            if (on && !(P.lane_dbg & 2) && P.lane_handover) { // |row i of G_k|^2 added, stored, and the next block
                 double* const wn = ws + ((size_t)k * WR + oNbW) * bp;
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
