@@ -1,9 +1,6 @@
 // copra_hip.hip -- kernels + C ABI (include/copra_hip.h) of the MI355X-native batched linear-MPC engine.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared copra_hip.hip -o libcopra_hip.so  (see Makefile)
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include "../../include/copra_hip.h"
+#include "engine.hpp"
 #include "islmpc_fused.hpp"
 #include "lmpc_fused.hpp"
 #include "lmpc_fused_ric.hpp"
@@ -12,30 +9,11 @@
 #include "lmpc_riccati.hpp"
 #include "lmpc_riccati_mfma.hpp"
 #include "lmpc_shared.hpp"
-#include "packed_launch.hpp"
-#include "plan_builder.hpp"
-#include "qp_dense.hpp"
-#include "qp_dense_large.hpp"
-
-#include <dlfcn.h>
-#include <fcntl.h>
-#include <spawn.h>
-#include <sys/stat.h>
-#include <sys/wait.h>
-#include <unistd.h>
-
-extern char** environ;
 
 #include <algorithm>
-#include <map>
-#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <string>
-#include <vector>
-
-using namespace copra_hip;
 
 // ------------------------------------------------------------------------------------------------
 // kernels: one 64-lane wavefront (= one workgroup) per MPC instance.  The hardware workgroup dispatcher is the
@@ -130,69 +108,10 @@ __global__ __launch_bounds__(64) void copra_lmpc_shared_tier2_kernel(const Fused
     }
 }
 
-// PreviewSystem::updateSystem (src/PreviewSystem.cpp:57-74) as matrices, for host-evaluated user subclasses of Constraint /
-// CostFunction (copra_preview_update).  One workgroup runs the recursion Phi_i = A Phi_{i-1}, G_i = A G_{i-1} (G_0 = B),
-// xi_i = A xi_{i-1} + d; a second launch spreads the first block column over Psi_{i,j} = G_{i-1-j}.
-__global__ __launch_bounds__(256) void copra_preview_recursion_kernel(int nx, int nu, int N, const double* A, const double* B,
-    const double* d, double* Phi, double* G, double* xi)
-{
-    const int X = nx * (N + 1), tid = (int)threadIdx.x, T = (int)blockDim.x;
-    for (int e = tid; e < nx * nx; e += T) Phi[(e % nx) + (size_t)X * (e / nx)] = (e % nx == e / nx) ? 1.0 : 0.0; // Phi_0 = I (:51)
-    for (int e = tid; e < nx * nu; e += T) G[e] = B[e]; // Psi_{1,0} = B (:60)
-    for (int e = tid; e < nx; e += T) xi[e] = 0.0;
-    __syncthreads();
-    for (int i = 1; i <= N; ++i) {
-        for (int e = tid; e < nx * (nx + nu + 1); e += T) {
-            const int c = e / nx, r = e - c * nx;
-            double acc = 0.0;
-            if (c < nx) { // Phi_i = A Phi_{i-1} (:59, :64)
-                for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * Phi[((i - 1) * nx + t) + (size_t)X * c];
-                Phi[(i * nx + r) + (size_t)X * c] = acc;
-            } else if (c < nx + nu) { // G_i = A G_{i-1} (:65); G_N is not part of Psi
-                if (i < N) {
-                    const int cc = c - nx;
-                    for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * G[(size_t)(i - 1) * nx * nu + t + nx * cc];
-                    G[(size_t)i * nx * nu + r + nx * cc] = acc;
-                }
-            } else { // xi_i = A xi_{i-1} + d (:61, :70)
-                acc = d[r];
-                for (int t = 0; t < nx; ++t) acc += A[r + nx * t] * xi[(i - 1) * nx + t];
-                xi[i * nx + r] = acc;
-            }
-        }
-        __syncthreads();
-    }
-}
-__global__ void copra_preview_fill_kernel(int nx, int nu, int N, const double* G, double* Psi)
-{
-    const size_t X = (size_t)nx * (N + 1), U = (size_t)nu * N;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= X * U) return;
-    const size_t col = e / X, row = e - col * X;
-    const int i = (int)(row / nx), r = (int)(row - (size_t)i * nx), j = (int)(col / nu), c = (int)(col - (size_t)j * nu);
-    Psi[e] = (j < i) ? G[(size_t)(i - 1 - j) * nx * nu + r + nx * c] : 0.0; // Psi_{i,j} = A^(i-1-j) B (:66-69), row block 0 is zero
-}
 
-// out[b][i] = out[0][i], b >= 1: one reference for every instance (copra_batch_set_cost_reference_all)
-__global__ void copra_broadcast_reference_kernel(const double* p, double* out, int rows, long long total)
-{
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < total) out[e] = p[e % rows];
-}
 
-// out[b][row0 + s * r + i] = f[b][i] for the steps s of one constraint (copra_batch_set_constraint_rhs)
-__global__ void copra_scatter_rhs_kernel(const double* f, double* out, int batch, int r, int steps, int row0, int mgen)
-{
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long per = (long long)r * steps;
-    if (e >= per * batch) return;
-    const long long b = e / per, rem = e - b * per;
-    out[b * mgen + row0 + rem] = f[b * r + rem % r];
-}
 
-namespace {
-using fused_kernel_t = void (*)(const FusedPlan);
-fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
+static fused_kernel_t select_shared_kernel(const FusedPlan& P, bool tier2)
 {
     if (P.lds.tri && !tier2) {
         if (P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_shared_tri_kernel<6, 3, 20>;
@@ -249,14 +168,13 @@ fused_kernel_t select_tier2_kernel(const FusedPlan& P)
     if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tier2_kernel<6, 3, 20, 0>;
     return copra_lmpc_fused_tier2_kernel<0, 0, 0, 0>;
 }
-} // namespace
+
 
 __global__ __launch_bounds__(64) void copra_islmpc_fused_kernel(const FusedPlan P)
 {
     islmpc_fused_body(P, P.inst_offset + (int)blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void copra_qp_dense_kernel(const DensePlan P) { qp_dense_body(P, (int)blockIdx.x); }
 
 // more than 64 decision variables: one MPC instance per workgroup (lmpc_large.hpp), persistent grid over the batch
 __global__ __launch_bounds__(kLargeMaxN) void copra_lmpc_large_kernel(const FusedPlan P) { lmpc_large_body(P); }
@@ -290,17 +208,11 @@ static riccati_kernel_t select_riccati_kernel(int nx, int nu)
     return copra_lmpc_riccati_kernel<0, 0>;
 }
 
-// n > 64: one problem per workgroup (thread = row of J), persistent grid over the batch
-__global__ __launch_bounds__(kLargeMaxN) void copra_qp_dense_large_kernel(const DensePlan P) { qp_dense_large_body(P); }
-// more than four waves per workgroup: 128-VGPR build so that two workgroups share a CU (see copra_lmpc_large_kernel_w4)
-__global__ __launch_bounds__(kLargeMaxN, 4) void copra_qp_dense_large_kernel_w4(const DensePlan P) { qp_dense_large_body(P); }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-namespace {
-
-thread_local std::string g_err;
+thread_local std::string g_copra_err; // copra_last_error()
 
 // resident workgroups per CU the runtime reports for a kernel variant (at least 1, at most 8)
 int large_per_cu(const void* kernel, int threads, size_t lds_bytes)
@@ -343,25 +255,13 @@ bool prefer_w4(const copra_options_t& opt, const void* full, const void* w4, int
 }
 
 typedef void (*large_kernel_t)(const FusedPlan);
-large_kernel_t choose_large_kernel(const HostPlan& hp)
+static large_kernel_t choose_large_kernel(const HostPlan& hp)
 {
     if (prefer_w4(hp.opt, reinterpret_cast<const void*>(copra_lmpc_large_kernel), reinterpret_cast<const void*>(copra_lmpc_large_kernel_w4),
             hp.plan.large.threads, hp.lds_bytes))
         return copra_lmpc_large_kernel_w4;
     return copra_lmpc_large_kernel;
 }
-
-copra_status_t fail(copra_status_t code, const std::string& msg)
-{
-    g_err = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                                 \
-    do {                                                                                                              \
-        hipError_t e_ = (expr);                                                                                       \
-        if (e_ != hipSuccess) return fail(COPRA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
-    } while (0)
 
 // Dynamic LDS beyond 48 KiB is an opt-in PER KERNEL SYMBOL: raise the limit of exactly the function that is about to be
 // launched, to the size it is launched with (several symbols -- first tier, second tier, parity dump, shared-model
@@ -378,109 +278,10 @@ hipError_t lds_opt_in(const void* fn, size_t bytes)
     if (e == hipSuccess) granted[fn] = bytes;
     return e;
 }
-#define LDS_OPT_IN(fn, bytes) HIP_TRY(lds_opt_in(reinterpret_cast<const void*>(fn), (bytes)))
 
-template <class T>
-hipError_t upload(T** dst, const std::vector<T>& src)
-{
-    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
-    hipError_t e = hipMalloc((void**)dst, bytes);
-    if (e != hipSuccess) return e;
-    if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-}
 
-} // namespace
 
-constexpr size_t kSmallSlab = 1u << 20; // result slabs up to this size are fetched with one copy through pinned memory
-
-struct copra_batch {
-    HostPlan hp;
-    // device copies of the plan tables
-    int *d_row_step = nullptr, *d_row_ekind = nullptr, *d_row_eoff = nullptr, *d_row_gkind = nullptr,
-        *d_row_goff = nullptr;
-    double *d_row_f = nullptr, *d_params = nullptr, *d_lb = nullptr, *d_ub = nullptr;
-    int *d_row_prev = nullptr, *d_warm = nullptr; // warm start of the shared-model path (copra_batch_set_warm_start)
-    // system (owned copies, or borrowed device pointers)
-    double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
-    const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
-    // results
-    double *d_control = nullptr, *d_traj = nullptr; // (carved from ONE allocation, d_results: small batches fetch it with one copy)
-    int *d_status = nullptr, *d_iter = nullptr;
-    unsigned char* d_results = nullptr;
-    size_t results_bytes = 0, off_traj = 0, off_status = 0, off_iter = 0;
-    unsigned char* h_results = nullptr; // pinned staging copy of the slab (batches whose slab is at most kSmallSlab bytes)
-    // caller-provided device result buffers (copra_batch_set_outputs); override the engine-owned ones
-    double *ext_control = nullptr, *ext_traj = nullptr;
-    int *ext_status = nullptr, *ext_iter = nullptr;
-    int *d_ovf_count = nullptr, *d_ovf_list = nullptr; // two-tier queue (TWO counters, used in turn: begin_overflow_queue)
-    int ovf_cur = 0; // the counter the last solve appended to
-    bool ovf_clean[2] = { false, false }; // known to hold zero on the device
-    // shared-model fast path: one (A, B, d) for the whole batch, factorised once (copra_batch_set_shared_system)
-    bool shared = false, model_dirty = true, shared_attr_set = false;
-    // shared-model mode of the Riccati-factor tier (lmpc_fused_ric.hpp, FusedPlan::ric_model): the layout the plan builder chose
-    // for that tier (kept when copra_batch_set_shared_system moves the plan to an LDS-Q1 layout), whether the next solve uses it,
-    // and the batch-wide records
-    bool has_lds_ric = false, shared_ric = false;
-    LdsLayout lds_ric {};
-    double* d_ric_model = nullptr;
-    int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)
-    size_t model_doubles = 0; // allocated size of d_model
-    int model_rtot = 0; // columns of C2 / K2 as prepared
-    double *d_shA = nullptr, *d_shB = nullptr, *d_shd = nullptr, *d_model = nullptr;
-    std::vector<double> shA, shB, shd;
-    double *d_row_f_inst = nullptr, *d_lb_inst = nullptr, *d_ub_inst = nullptr; // per-instance rhs / control bounds
-    double* d_cost_p[kMaxCosts] = {}; // per-instance cost references (owned copies) ...
-    const double* cost_p[kMaxCosts] = {}; // ... or borrowed device pointers (copra_batch_set_cost_reference)
-    // copra_batch_specialise: this controller's shape compiled into its own kernels (hipcc --genco, cached on disk)
-    hipModule_t jit_module = nullptr;
-    hipFunction_t jit_fused = nullptr, jit_shared = nullptr;
-    hipFunction_t jit_fused_q0 = nullptr; // Riccati-factor tier compiled for this shape: Q1 in LDS (further down the layout ladder)
-    hipFunction_t jit_lane = nullptr; // ... and the one-instance-per-lane pass in front of it (lmpc_lane.hpp)
-    bool jit_ric = false; // the code object holds the Riccati-factor tier (lmpc_fused_ric.hpp) of this controller's shape
-    int jit_lanes = 64; // lanes per instance the code object was compiled for
-    int jit_tri = 0; // ... and whether for the factor-only layout
-    // one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp)
-    int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
-    int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
-    int lane_predict_left = 1; // solves whose first-tier layout is still chosen from that histogram
-    double* d_lane_ws = nullptr;
-    int lane_cur = 0; // the counter the last solve appended to
-    bool lane_ran = false; // the last solve ran the pass
-    bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass)
-    int lane_adapt_left = 2;
-    long long lane_solves = 0; // solves seen by adapt_lane_pass (it samples the share again every 256)
-    bool lane_off_by_share = false; // lane_off was set by adapt_lane_pass (too few instances ended in the pass), not for lack of memory
-    int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
-    bool solved_once = false;
-    int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
-    void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
-    double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)
-    int large_grid = 0;
-    // InitialStateLMPC variant
-    double *d_isR = nullptr, *d_isr = nullptr, *d_x0opt = nullptr, *own_x0lb = nullptr, *own_x0ub = nullptr;
-    const double *x0lb = nullptr, *x0ub = nullptr;
-    // stage-wise Riccati interior-point path (copra_batch_select_solver; lmpc_riccati.hpp)
-    int solver = COPRA_SOLVER_DEFAULT;
-    HostStagePlan hs;
-    bool ric_fast = false; // the LDS-resident kernel (lmpc_riccati_mfma.hpp) runs it
-    bool ric_refs = false; // ... decided for this state of the per-instance cost references
-    bool ric_built = false; // hs describes this controller (eligible or not) ...
-    bool ric_all_bounds = false; // ... with bound rows for every control
-    std::vector<void*> ric_dev; // device copies of its tables
-    double* d_ric_ws = nullptr;
-    int* d_ric_next = nullptr; // work-queue counter of the Riccati kernel
-    int ric_grid = 0;
-    long long* d_prof_fine = nullptr; // profiling builds only
-    long long* d_prof = nullptr; // optional per-instance phase cycle counts (copra_batch_enable_phase_profile)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr; // start | end of the solve | end of its first launch (packet-borne timing)
-    bool tier_timed = false; // evm was written by the last solve
-    hipStream_t last_stream = nullptr;
-    bool timed = false;
-    bool lds_attr_set = false;
-};
-
-static FusedPlan device_plan(const copra_batch* h)
+FusedPlan device_plan(const copra_batch* h)
 {
     FusedPlan P = h->hp.plan;
     P.row_step = h->d_row_step;
@@ -723,7 +524,7 @@ static copra_status_t adapt_layout(copra_batch* h)
     return COPRA_OK;
 }
 
-static copra_status_t ensure_lds_attr(copra_batch* h)
+copra_status_t ensure_lds_attr(copra_batch* h)
 {
     if (h->hp.ric_only) return COPRA_OK; // (the Riccati kernels opt in to their LDS where they are launched)
     if (h->hp.large) {
@@ -748,7 +549,7 @@ static copra_status_t ensure_lds_attr(copra_batch* h)
 
 // (Re)build the stage plan of a controller and put its tables on the device.  The plan depends on whether per-instance
 // control bounds exist (then every control gets both bound rows, infinite ones are switched off per instance).
-static copra_status_t prepare_riccati(copra_batch* h)
+copra_status_t prepare_riccati(copra_batch* h)
 {
     const bool all_bounds = h->d_lb_inst != nullptr;
     bool refs = false; // per-instance cost references: q_k differs per instance, which only the streaming kernel evaluates
@@ -856,7 +657,7 @@ static copra_status_t prepare_riccati(copra_batch* h)
 }
 
 // does the next solve of this controller run the Riccati interior-point kernel?
-static bool use_riccati(copra_batch* h)
+bool use_riccati(copra_batch* h)
 {
     if (h->hp.ric_only) return prepare_riccati(h) == COPRA_OK && h->hs.eligible;
     if (h->solver == COPRA_SOLVER_QUADPROG_DENSE || h->shared) return false;
@@ -869,106 +670,17 @@ extern "C" {
 
 int copra_abi_version(void) { return 5; } // 5: + copra_options_t, copra_options_init, copra_set_default_options, copra_batch_create_with_options; 3: + copra_batch_last_first_tier_seconds, copra_batch_set_system_rowmajor_async; 4: + copra_batch_lane_pass_info, copra_batch_set_cost_reference_all
 
-copra_status_t copra_preview_update(int nx, int nu, int N, const double* A, const double* B, const double* d, double* Phi,
-    double* Psi, double* xi)
-{
-    if (nx <= 0 || nu <= 0 || N <= 0) return fail(COPRA_ERR_DOMAIN, "copra_preview_update: dimensions and number of steps must be positive");
-    if (!A || !B || !d || !Phi || !Psi || !xi) return fail(COPRA_ERR_ARG, "copra_preview_update: null argument");
-    const size_t X = (size_t)nx * (N + 1), U = (size_t)nu * N;
-    double *dA = nullptr, *dB = nullptr, *dd = nullptr, *dPhi = nullptr, *dPsi = nullptr, *dxi = nullptr, *dG = nullptr;
-    hipError_t e = hipMalloc((void**)&dA, (size_t)nx * nx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dB, (size_t)nx * nu * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)nx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dPhi, X * nx * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dPsi, X * U * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dxi, X * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dG, (size_t)N * nx * nu * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(dA, A, (size_t)nx * nx * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dB, B, (size_t)nx * nu * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dd, d, (size_t)nx * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(copra_preview_recursion_kernel, dim3(1), dim3(256), 0, nullptr, nx, nu, N, dA, dB, dd, dPhi, dG, dxi);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) {
-        const size_t total = X * U;
-        hipLaunchKernelGGL(copra_preview_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, nx, nu, N, dG, dPsi);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(Phi, dPhi, X * nx * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(Psi, dPsi, X * U * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(xi, dxi, X * sizeof(double), hipMemcpyDeviceToHost);
-    for (double* q : { dA, dB, dd, dPhi, dPsi, dxi, dG }) (void)hipFree(q);
-    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_preview_update: ") + hipGetErrorString(e));
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_warm_start(copra_batch_t* h, int enable)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_warm_start: null handle");
-    if (h->hp.plan.initial_state || h->hp.large)
-        return fail(COPRA_ERR_UNSUPPORTED, "the warm start belongs to the shared-model path (LMPC, at most 64 decision variables)");
-    if (!enable) {
-        (void)hipFree(h->d_warm);
-        h->d_warm = nullptr;
-        return COPRA_OK;
-    }
-    const size_t count = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1) * kWarmCap;
-    if (!h->d_warm) HIP_TRY(hipMalloc((void**)&h->d_warm, count * sizeof(int)));
-    HIP_TRY(hipMemset(h->d_warm, 0xff, count * sizeof(int))); // every entry -1: the first solve starts cold
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_select_solver(copra_batch_t* h, int solver)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_select_solver: null handle");
-    if (solver != COPRA_SOLVER_DEFAULT && solver != COPRA_SOLVER_QUADPROG_DENSE && solver != COPRA_SOLVER_RICCATI_IPM)
-        return fail(COPRA_ERR_ARG, "copra_batch_select_solver: unknown solver flag");
-    if (h->hp.ric_only && solver == COPRA_SOLVER_QUADPROG_DENSE)
-        return fail(COPRA_ERR_UNSUPPORTED, "the condensed Goldfarb-Idnani kernels cover at most 512 decision variables (InitialStateLMPC: xDim <= 16)");
-    if (solver == COPRA_SOLVER_RICCATI_IPM) {
-        const copra_status_t rc = prepare_riccati(h);
-        if (rc != COPRA_OK) return rc;
-        if (!h->hs.eligible)
-            return fail(COPRA_ERR_UNSUPPORTED, "the Riccati interior-point solver needs a stage-wise controller: " + h->hs.why);
-        if (!h->hp.large) // the queue of non-converged instances is finished by the workgroup-per-instance kernel
-            return fail(COPRA_ERR_UNSUPPORTED, "the Riccati interior-point solver covers controllers with more than 64 decision variables");
-    }
-    h->solver = solver;
-    return COPRA_OK;
-}
 
-int copra_batch_solver_info(const copra_batch_t* h)
-{
-    if (!h) return -1;
-    return use_riccati(const_cast<copra_batch_t*>(h)) ? COPRA_SOLVER_RICCATI_IPM : COPRA_SOLVER_QUADPROG_DENSE;
-}
 
-const char* copra_last_error(void) { return g_err.c_str(); }
+const char* copra_last_error(void) { return g_copra_err.c_str(); }
 
 #ifndef COPRA_SRC_HASH
 #error "build through copra_amd/csrc/Makefile (it defines COPRA_SRC_HASH)"
 #endif
 const char* copra_source_hash(void) { return COPRA_SRC_HASH; }
 
-copra_status_t copra_device_info(int* n_devices, int* cu_count, char* arch_name, int arch_name_len)
-{
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (n_devices) *n_devices = n;
-    if (n > 0) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        if (cu_count) *cu_count = prop.multiProcessorCount;
-        if (arch_name && arch_name_len > 0) {
-            strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1);
-            arch_name[arch_name_len - 1] = 0;
-        }
-    }
-    return COPRA_OK;
-}
 
 static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dims, int n_costs,
     const copra_cost_desc_t* costs, int n_cstrs, const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is,
@@ -1019,7 +731,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     h->hp.opt = resolve_options(opts); // (everything the engine consults from here on: no environment variable is read on any path)
     copra_status_t rc = build_plan(h->hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
     if (rc != COPRA_OK) {
-        g_err = h->hp.error;
+        g_copra_err = h->hp.error;
         delete h;
         return rc;
     }
@@ -1064,7 +776,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     if (h->hp.ric_only) { // only the Riccati interior-point kernels cover this size: the controller must be stage-wise
         const copra_status_t rr = prepare_riccati(h);
         if (rr != COPRA_OK || !h->hs.eligible) {
-            const std::string why = rr != COPRA_OK ? g_err : h->hs.why;
+            const std::string why = rr != COPRA_OK ? g_copra_err : h->hs.why;
             copra_batch_destroy(h);
             *out = nullptr;
             fail(COPRA_ERR_UNSUPPORTED, "more than 512 decision variables (or InitialStateLMPC with xDim > 16) need a stage-wise controller for the Riccati interior-point kernel: " + why);
@@ -1087,7 +799,7 @@ static copra_status_t create_common(copra_batch_t** out, const copra_dims_t* dim
     chk(hipEventCreate(&h->ev1));
     chk(hipEventCreate(&h->evm));
     if (e != hipSuccess) {
-        g_err = std::string("copra_batch_create: ") + hipGetErrorString(e);
+        g_copra_err = std::string("copra_batch_create: ") + hipGetErrorString(e);
         copra_batch_destroy(h);
         return COPRA_ERR_HIP;
     }
@@ -1147,81 +859,9 @@ void copra_batch_destroy(copra_batch_t* h)
     delete h;
 }
 
-copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const double* B, const double* d,
-    const double* x0, int on_device)
-{
-    if (!h || !A || !B || !d || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_system: null argument");
-    const FusedPlan& P = h->hp.plan;
-    const size_t b = (size_t)P.batch;
-    h->shared = false; // per-instance systems again (leaves the shared-model fast path)
-    if (on_device) {
-        h->A = A;
-        h->B = B;
-        h->d = d;
-        h->x0 = x0;
-        return COPRA_OK;
-    }
-    const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
-    if (!h->own_A) {
-        HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&h->own_d, (nd ? nd : 1) * sizeof(double)));
-    }
-    if (!h->own_x0) HIP_TRY(hipMalloc((void**)&h->own_x0, (nd ? nd : 1) * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->own_A, A, nA * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->own_B, B, nB * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->own_d, d, nd * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->own_x0, x0, nd * sizeof(double), hipMemcpyHostToDevice));
-    h->A = h->own_A;
-    h->B = h->own_B;
-    h->d = h->own_d;
-    h->x0 = h->own_x0;
-    return COPRA_OK;
-}
 
-// [batch][rows x cols] row-major -> per-instance column-major (what Eigen holds and every kernel here reads)
-__global__ void copra_rowmajor_to_colmajor_kernel(const double* __restrict__ src, double* __restrict__ dst, int rows, int cols,
-    long long total)
-{
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int per = rows * cols;
-    const long long inst = e / per;
-    const int w = (int)(e - inst * per), j = w / rows, i = w - j * rows; // destination: column j, row i
-    dst[e] = src[inst * per + (long long)i * cols + j];
-}
 
-copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const double* A, const double* B, const double* d,
-    const double* x0, void* hip_stream)
-{
-    if (!h || !A || !B || !d || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_system_rowmajor_async: null argument");
-    const FusedPlan& P = h->hp.plan;
-    const size_t b = (size_t)P.batch;
-    const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
-    h->shared = false;
-    if (!h->own_A) {
-        HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&h->own_d, (nd ? nd : 1) * sizeof(double)));
-    }
-    hipStream_t s = (hipStream_t)hip_stream;
-    if (nA) hipLaunchKernelGGL(copra_rowmajor_to_colmajor_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, A, h->own_A, P.nx, P.nx, (long long)nA);
-    if (nB) hipLaunchKernelGGL(copra_rowmajor_to_colmajor_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, s, B, h->own_B, P.nx, P.nu, (long long)nB);
-    HIP_TRY(hipGetLastError());
-    h->A = h->own_A;
-    h->B = h->own_B;
-    h->d = d; // (vectors have no layout: used in place)
-    h->x0 = x0;
-    return COPRA_OK;
-}
 
-int copra_batch_lanes_per_instance(const copra_batch_t* h)
-{
-    if (!h) return 0;
-    if (h->hp.ric_only) return kWave;
-    if (h->hp.large) return h->hp.plan.large.threads;
-    return h->packed ? h->packed : kWave;
-}
 
 copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const copra_cost_desc_t* costs, int n_cstrs,
     const copra_cstr_desc_t* cstrs, const copra_initial_state_desc_t* is)
@@ -1229,7 +869,7 @@ copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const cop
     if (!dims) return fail(COPRA_ERR_ARG, "copra_plan_check: null dims");
     HostPlan hp; // (the process-wide default options)
     const copra_status_t rc = build_plan(hp, *dims, n_costs, costs, n_cstrs, cstrs, is);
-    if (rc != COPRA_OK) g_err = hp.error;
+    if (rc != COPRA_OK) g_copra_err = hp.error;
     if (rc == COPRA_OK && hp.ric_only) { // beyond the condensed kernels' sizes: covered if (and only if) the controller is stage-wise
         HostStagePlan hs;
         build_stage_plan(hp, hs, false);
@@ -1432,380 +1072,17 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     return COPRA_OK;
 }
 
-copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: null handle");
-    const FusedPlan& P = h->hp.plan;
-    if (cost_index < 0 || cost_index >= (int)h->hp.cost_slot.size()) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference: no such cost");
-    cost_index = h->hp.cost_slot[(size_t)cost_index]; // (dense costs are not among the kernel-evaluated terms)
-    if (cost_index < 0) return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference: a dense (host-evaluated) cost has no reference p");
-    if ((p != nullptr) != (h->cost_p[cost_index] != nullptr)) h->model_dirty = true; // shared model: c0 / C2 change
-    if (!p) { // back to the controller-wide reference given at creation
-        h->cost_p[cost_index] = nullptr;
-        return COPRA_OK;
-    }
-    if (on_device) {
-        h->cost_p[cost_index] = p;
-        return COPRA_OK;
-    }
-    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.cost[cost_index].prows; // (a reference trajectory: rows x steps per instance)
-    if (!h->d_cost_p[cost_index]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[cost_index], count * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_cost_p[cost_index], p, count * sizeof(double), hipMemcpyHostToDevice));
-    h->cost_p[cost_index] = h->d_cost_p[cost_index];
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_index, const double* p, int on_device)
-{
-    if (!h || !p) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: null argument");
-    const FusedPlan& P = h->hp.plan;
-    if (cost_index < 0 || cost_index >= (int)h->hp.cost_slot.size()) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: no such cost");
-    const int t = h->hp.cost_slot[(size_t)cost_index];
-    if (t < 0) return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a dense (host-evaluated) cost has no reference p");
-    if (h->shared && P.cost[t].pstride)
-        return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a new reference trajectory in shared-model mode needs a new controller");
-    // Every kernel already reads a per-instance reference where one is set: the new reference is written once per instance into the
-    // library's own buffer (a broadcast on the device: 66 MB at the headline's batch for a reference trajectory, ~ 10 us) and that
-    // path is taken -- nothing that was derived from the creation-time p (tables of the plan builder, the shared model's c0) can go stale.
-    const size_t b = (size_t)(P.batch > 0 ? P.batch : 1), rows = (size_t)P.cost[t].prows;
-    if (!h->d_cost_p[t]) HIP_TRY(hipMalloc((void**)&h->d_cost_p[t], b * rows * sizeof(double)));
-    double* const out = h->d_cost_p[t];
-    if (p == out) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: p aliases the library's buffer");
-    HIP_TRY(hipStreamSynchronize(h->last_stream)); // (a solve that still reads the buffer)
-    const double* src = p;
-    if (!on_device) {
-        HIP_TRY(hipMemcpy(out, p, rows * sizeof(double), hipMemcpyHostToDevice)); // instance 0's slot, then read from there
-        src = out;
-    }
-    const long long first = on_device ? 0 : (long long)rows, total = (long long)(b * rows) - first;
-    if (total > 0)
-        hipLaunchKernelGGL(copra_broadcast_reference_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->last_stream, src, out + first,
-            (int)rows, total);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->last_stream);
-    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_batch_set_cost_reference_all: ") + hipGetErrorString(e));
-    if (!h->cost_p[t]) h->model_dirty = true; // shared model: c0 / C2 change
-    h->cost_p[t] = out;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_constraint_rhs(copra_batch_t* h, int cstr_index, const double* f, int on_device)
-{
-    if (!h || !f) return fail(COPRA_ERR_ARG, "copra_batch_set_constraint_rhs: null argument");
-    const FusedPlan& P = h->hp.plan;
-    if (cstr_index < 0 || cstr_index >= (int)h->hp.cstr_row0.size() || h->hp.cstr_row0[(size_t)cstr_index] < 0)
-        return fail(COPRA_ERR_UNSUPPORTED,
-            "copra_batch_set_constraint_rhs: not a Trajectory / Control / Mixed constraint of this controller "
-            "(bound constraints: copra_batch_set_control_bounds)");
-    const int r = h->hp.cstr_per_step[(size_t)cstr_index], steps = h->hp.cstr_steps[(size_t)cstr_index];
-    const int row0 = h->hp.cstr_row0[(size_t)cstr_index];
-    const size_t b = (size_t)(P.batch > 0 ? P.batch : 1);
-    if (!h->d_row_f_inst) { // first use: every instance starts from the controller-wide right-hand sides
-        HIP_TRY(hipMalloc((void**)&h->d_row_f_inst, b * (size_t)P.mgen * sizeof(double)));
-        std::vector<double> rep(b * (size_t)P.mgen);
-        for (size_t i = 0; i < b; ++i) std::copy(h->hp.row_f.begin(), h->hp.row_f.begin() + P.mgen, rep.begin() + i * P.mgen);
-        HIP_TRY(hipMemcpy(h->d_row_f_inst, rep.data(), rep.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    const double* src = f;
-    double* tmp = nullptr;
-    if (!on_device) {
-        HIP_TRY(hipMalloc((void**)&tmp, b * (size_t)r * sizeof(double)));
-        hipError_t e = hipMemcpy(tmp, f, b * (size_t)r * sizeof(double), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(tmp);
-            return fail(COPRA_ERR_HIP, std::string("copra_batch_set_constraint_rhs: ") + hipGetErrorString(e));
-        }
-        src = tmp;
-    }
-    const long long total = (long long)P.batch * r * steps;
-    if (total > 0) {
-        hipLaunchKernelGGL(copra_scatter_rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->last_stream, src,
-            h->d_row_f_inst, P.batch, r, steps, row0, P.mgen);
-    }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->last_stream);
-    if (tmp) (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_batch_set_constraint_rhs: ") + hipGetErrorString(e));
-    return COPRA_OK; // (the shared-model factorisation does not depend on right-hand sides)
-}
 
-copra_status_t copra_batch_set_control_bounds(copra_batch_t* h, const double* lower, const double* upper, int on_device)
-{
-    if (!h || !lower || !upper) return fail(COPRA_ERR_ARG, "copra_batch_set_control_bounds: null argument");
-    const FusedPlan& P = h->hp.plan;
-    const size_t count = (size_t)(P.batch > 0 ? P.batch : 1) * P.n;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (!h->d_lb_inst) HIP_TRY(hipMalloc((void**)&h->d_lb_inst, count * sizeof(double)));
-    if (!h->d_ub_inst) HIP_TRY(hipMalloc((void**)&h->d_ub_inst, count * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_lb_inst, lower, count * sizeof(double), kind));
-    HIP_TRY(hipMemcpy(h->d_ub_inst, upper, count * sizeof(double), kind));
-    return COPRA_OK;
-}
 
-// ---- run-time specialisation ------------------------------------------------------------------------------------
-// The kernel bodies are templates on (xDim, uDim, nrStep, cost rows); the library ships instantiations for the
-// BASELINE shapes and a run-time-shape one that is ~2.5x slower on the same problem (headline shape: 13.4 vs 5.4 M
-// solves/s).  copra_batch_specialise compiles the instantiation for THIS controller's shape with hipcc --genco from the
-// headers next to the library, keeps the code object in a cache directory and launches it through the module API.
-static std::string library_dir()
-{
-    Dl_info info;
-    if (dladdr(reinterpret_cast<const void*>(&copra_abi_version), &info) && info.dli_fname) {
-        std::string p(info.dli_fname);
-        const size_t k = p.find_last_of('/');
-        return k == std::string::npos ? std::string(".") : p.substr(0, k);
-    }
-    return ".";
-}
 
-// compile `source` (a translation unit that includes headers from the library's directory) into a code object named
-// `key` in the cache directory, unless it is already there; returns its path in `obj`
-static copra_status_t jit_compile(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj)
-{
-    const std::string src_dir = library_dir();
-    std::string dir = cache_dir ? cache_dir : "";
-    if (dir.empty()) {
-        const char* e = std::getenv("COPRA_JIT_CACHE");
-        const char* home = std::getenv("HOME");
-        dir = e ? e : (std::string(home ? home : "/tmp") + "/.cache/copra_amd");
-    }
-    (void)mkdir((dir.substr(0, dir.find_last_of('/'))).c_str(), 0755);
-    (void)mkdir(dir.c_str(), 0755);
-    // the code object depends on the exact sources it was compiled from: the hash of those sources is compiled into this
-    // library (Makefile: COPRA_SRC_HASH), so a cache left by another build of the library is never picked up
-#ifndef COPRA_SRC_HASH
-#error "build through copra_amd/csrc/Makefile (it defines COPRA_SRC_HASH, the key of the run-time-compilation cache)"
-#endif
-    const std::string stamp = std::string(COPRA_SRC_HASH).substr(0, 12);
-    obj = dir + "/" + key + "_" + stamp + ".hsaco";
-    if (access(obj.c_str(), R_OK) == 0) return COPRA_OK;
-    const std::string src = obj + "." + std::to_string((long)getpid()) + ".hip";
-    FILE* f = fopen(src.c_str(), "w");
-    if (!f) return fail(COPRA_ERR_RUNTIME, "run-time specialisation: cannot write to the cache directory " + dir);
-    fputs(source.c_str(), f);
-    fclose(f);
-    const char* hipcc_env = std::getenv("HIPCC");
-    const std::string hipcc = hipcc_env ? hipcc_env : "/opt/rocm/bin/hipcc";
-    const std::string tmp = obj + "." + std::to_string((long)getpid()) + ".tmp";
-    const std::string log = src + ".log";
-    const std::string inc = "-I" + src_dir;
-    // argv, no shell: paths with quotes or spaces cannot break (or inject into) the command
-    const char* argv[] = { hipcc.c_str(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", inc.c_str(), "-o", tmp.c_str(),
-        src.c_str(), nullptr };
-    int rc = -1;
-    {
-        posix_spawn_file_actions_t fa;
-        posix_spawn_file_actions_init(&fa);
-        posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        posix_spawn_file_actions_adddup2(&fa, 1, 2);
-        pid_t pid = 0;
-        if (posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, const_cast<char* const*>(argv), environ) == 0) {
-            int st = 0;
-            if (waitpid(pid, &st, 0) == pid && WIFEXITED(st)) rc = WEXITSTATUS(st);
-        }
-        posix_spawn_file_actions_destroy(&fa);
-    }
-    (void)unlink(src.c_str());
-    if (rc != 0 || rename(tmp.c_str(), obj.c_str()) != 0)
-        return fail(COPRA_ERR_RUNTIME, "run-time specialisation: hipcc --genco failed (see " + log + ")");
-    (void)unlink(log.c_str());
-    return COPRA_OK;
-}
 
-// dense-QP kernels compiled for a fixed number of variables (copra_qp_dense_specialise): (n, lanes per QP) -> kernel
-struct DenseJit {
-    int n, lanes;
-    hipFunction_t fn;
-};
-static std::vector<DenseJit> g_dense_jit; // guarded by g_dense_jit_mu
-static std::mutex g_dense_jit_mu;
 
-copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir)
-{
-    if (n <= 0 || n > kWave) return COPRA_OK; // (the workgroup-per-problem kernel has no shape parameters)
-    std::lock_guard<std::mutex> lock(g_dense_jit_mu);
-    for (int lanes : { 64, 32, 16 }) {
-        if (lanes < n) continue;
-        bool have = false;
-        for (const DenseJit& d : g_dense_jit) have = have || (d.n == n && d.lanes == lanes);
-        if (have) continue;
-        char key[96], source[1024];
-        snprintf(key, sizeof key, "copra_jit_dense_%d_l%d", n, lanes);
-        if (lanes == 64)
-            snprintf(source, sizeof source,
-                "#include <hip/hip_runtime.h>\n#include \"qp_dense.hpp\"\nusing namespace copra_hip;\n"
-                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_dense(const DensePlan P)\n"
-                "{ qp_dense_body<%d>(P, (int)blockIdx.x); }\n", n);
-        else
-            snprintf(source, sizeof source,
-                "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
-                "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_dense(const DensePlan P)\n"
-                "{ const int inst = instance_id(); if (inst < P.batch) qp_dense_body<%d>(P, inst); }\n", lanes, n);
-        std::string obj;
-        const copra_status_t rc = jit_compile(key, source, cache_dir, obj);
-        if (rc != COPRA_OK) return rc;
-        hipModule_t mod = nullptr;
-        HIP_TRY(hipModuleLoad(&mod, obj.c_str()));
-        hipFunction_t fn = nullptr;
-        HIP_TRY(hipModuleGetFunction(&fn, mod, "copra_jit_dense"));
-        g_dense_jit.push_back(DenseJit { n, lanes, fn }); // (modules stay loaded for the life of the process)
-    }
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_specialise: null handle");
-    const FusedPlan& P = h->hp.plan;
-    if (h->jit_fused) return COPRA_OK;
-    const int rp0 = specialised_cost_rows(P.nx, P.nu, P.N, P.rmax, P.rfull);
-    if (h->hp.large || P.initial_state || P.rfull > 0 || rp0 > 0 || P.n > kWave || P.nu > kMaxNu || (P.lds.ric && ric_aot_exact(P.nx, P.nu, P.N)))
-        return COPRA_OK; // nothing to gain: the shape already runs on dedicated kernels (or on bodies without shape parameters)
-    // ---- the Riccati-factor tier (lmpc_fused_ric.hpp; what the headline runs on) for THIS shape: per-step costs, xDim (xDim + uDim + 1)
-    //      <= 64, two or three controls, at most 64 decision variables.  Compiled with Q1 in registers and in LDS (the layout ladder
-    //      moves between the two); the controller takes the tier's layout once the kernels exist.
-    // Single-control systems with fewer than 48 variables stay on the packed / factor-only kernels: the reference's falling-mass
-    // problems hold most of their control bounds active, far beyond this tier's five register columns (measured, M solves/s,
-    // this tier vs the others compiled for the shape: N = 5: 94 vs 339, 16: 6.8 vs 55, 32: 7.2 vs 16, 48: 29 vs 22, 64: 75 vs 29).
-    const bool ric_pays = P.nu >= 2 || P.n >= 48 || h->hp.opt.ric_any_shape;
-    if (!h->shared && ric_pays && !h->hp.opt.no_ric && !h->hp.opt.no_tri) {
-        HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
-        if (take_ric_layout(trial)) {
-            char keyr[128], srcr[3072];
-            const char* const sr = P.stage_refs ? "true" : "false"; // (reference trajectories: the builds with the stage-varying affine term)
-            snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d%s", P.nx, P.nu, P.N, P.stage_refs ? "_srefs" : "");
-            snprintf(srcr, sizeof srcr,
-                "#include <hip/hip_runtime.h>\n#include \"lmpc_fused_ric.hpp\"\n#include \"lmpc_lane.hpp\"\nusing namespace copra_hip;\n"
-                "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused(const FusedPlan P)\n"
-                "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, %d, %s>(P, inst, failed); }\n"
-                "extern \"C\" __global__ __launch_bounds__(64, 3) void copra_jit_fused_q0(const FusedPlan P)\n"
-                "{ if (P.ovf_zero && blockIdx.x == 0 && threadIdx.x == 0) *P.ovf_zero = 0;\n"
-                "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
-                "  lmpc_fused_ric_body<%d, %d, %d, 6, 0, %s>(P, inst, failed); }\n"
-                "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
-                "{ lmpc_lane_body<%d, %d, %s>(P, (int)blockIdx.x); }\n",
-                P.nx, P.nu, P.N, kFusedQ1Regs, sr, P.nx, P.nu, P.N, sr, P.nx, P.nu, sr);
-            std::string objr;
-            const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
-            if (rcr != COPRA_OK) return rcr;
-            hipModule_t modr = nullptr;
-            HIP_TRY(hipModuleLoad(&modr, objr.c_str()));
-            hipFunction_t fr = nullptr, fq = nullptr, fl = nullptr;
-            hipError_t er = hipModuleGetFunction(&fr, modr, "copra_jit_fused");
-            if (er == hipSuccess) er = hipModuleGetFunction(&fq, modr, "copra_jit_fused_q0");
-            if (er == hipSuccess) er = hipModuleGetFunction(&fl, modr, "copra_jit_lane");
-            double* dparams = nullptr;
-            if (er == hipSuccess) er = upload(&dparams, trial.params); // (the stage-cost tables were appended)
-            if (er != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipModuleUnload(modr);
-                (void)hipFree(dparams);
-                return fail(COPRA_ERR_HIP, std::string("copra_batch_specialise (Riccati-factor tier): ") + hipGetErrorString(er));
-            }
-            (void)hipFree(h->d_params);
-            h->d_params = dparams;
-            h->hp = trial;
-            h->packed = 0; // (one instance per wavefront on this tier)
-            h->lds_attr_set = false;
-            h->adapt_left = h->adapt_left > 4 ? h->adapt_left : 4;
-            h->jit_module = modr;
-            h->jit_lanes = 64;
-            h->jit_tri = 1;
-            h->jit_ric = true;
-            h->jit_fused = fr;
-            h->jit_fused_q0 = fq;
-            h->jit_lane = fl;
-            h->jit_shared = nullptr;
-            return COPRA_OK;
-        }
-    }
-    // (always the full register budget: with compile-time trip counts the unrolled bodies spill at 128 VGPRs -- double
-    //  integrator N = 32: 9.2 M solves/s at four waves per SIMD, 15.6 M at two, 11.8 M for the run-time-shape kernel)
-    char key[128], source[1536];
-    snprintf(key, sizeof key, "copra_jit_%d_%d_%d_%d_l%d%s", P.nx, P.nu, P.N, P.rmax, h->packed ? h->packed : 64, P.lds.tri ? "t" : "");
-    if (h->packed) // several small instances per wavefront: the same bodies on the group-wide primitives
-        snprintf(source, sizeof source,
-            "#define COPRA_WAVE_WIDTH %d\n#include \"packed_impl.inc\"\n"
-            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_fused(const FusedPlan P)\n"
-            "{ const int inst = P.inst_offset + instance_id(); if (inst < P.batch) lmpc_fused_body<%d, %d, %d, %d>(P, inst); }\n"
-            "extern \"C\" __global__ __launch_bounds__(64) void copra_jit_shared(const FusedPlan P)\n"
-            "{ const int inst = instance_id(); if (inst < P.batch) lmpc_shared_body<%d, %d, %d>(P, inst); }\n",
-            h->packed, P.nx, P.nu, P.N, P.rmax, P.nx, P.nu, P.N);
-    else
-        snprintf(source, sizeof source,
-            "#include <hip/hip_runtime.h>\n#include \"lmpc_fused.hpp\"\n#include \"lmpc_shared.hpp\"\nusing namespace copra_hip;\n"
-            "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_fused(const FusedPlan P)\n"
-            "{ lmpc_fused_body<%d, %d, %d, %d, %s>(P, P.inst_offset + (int)blockIdx.x); }\n"
-            "extern \"C\" __global__ __launch_bounds__(64%s) void copra_jit_shared(const FusedPlan P)\n"
-            "{ lmpc_shared_body<%d, %d, %d, %s>(P, (int)blockIdx.x); }\n",
-            P.lds.tri ? ", 2" : "", P.nx, P.nu, P.N, P.rmax, P.lds.tri ? "true" : "false", P.lds.tri ? ", 2" : "", P.nx, P.nu,
-            P.N, P.lds.tri ? "true" : "false");
-    std::string obj;
-    {
-        const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);
-        if (rcj != COPRA_OK) return rcj;
-    }
-    hipModule_t mod = nullptr;
-    HIP_TRY(hipModuleLoad(&mod, obj.c_str()));
-    hipFunction_t f1 = nullptr, f2 = nullptr;
-    hipError_t e = hipModuleGetFunction(&f1, mod, "copra_jit_fused");
-    if (e == hipSuccess) e = hipModuleGetFunction(&f2, mod, "copra_jit_shared");
-    const size_t jit_lds = (size_t)(h->packed ? 64 / h->packed : 1) * h->hp.lds_bytes;
-    if (e == hipSuccess && jit_lds > 48 * 1024) { // more than the default dynamic-LDS limit
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(f1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jit_lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(f2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)jit_lds);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipModuleUnload(mod);
-        return fail(COPRA_ERR_HIP, std::string("copra_batch_specialise: ") + hipGetErrorString(e));
-    }
-    h->jit_module = mod;
-    h->jit_lanes = h->packed ? h->packed : 64;
-    h->jit_tri = P.lds.tri;
-    h->jit_fused = f1;
-    h->jit_shared = f2;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_x0(copra_batch_t* h, const double* x0, int on_device)
-{
-    if (!h || !x0) return fail(COPRA_ERR_ARG, "copra_batch_set_x0: null argument");
-    const FusedPlan& P = h->hp.plan;
-    if (on_device) {
-        h->x0 = x0;
-        return COPRA_OK;
-    }
-    const size_t nd = (size_t)P.batch * P.nx;
-    if (!h->own_x0) HIP_TRY(hipMalloc((void**)&h->own_x0, (nd ? nd : 1) * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->own_x0, x0, nd * sizeof(double), hipMemcpyHostToDevice));
-    h->x0 = h->own_x0;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter)
-{
-    if (!h || !control || !trajectory || !status || !iter)
-        return fail(COPRA_ERR_ARG, "copra_batch_set_outputs: null argument");
-    h->ext_control = control;
-    h->ext_traj = trajectory;
-    h->ext_status = status;
-    h->ext_iter = iter;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_layout_info(const copra_batch_t* h, int* lds_bytes, int* active_capacity, int* factor_only,
-    int* two_tier)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_layout_info: null handle");
-    if (lds_bytes) *lds_bytes = (int)h->hp.lds_bytes;
-    if (active_capacity) *active_capacity = h->hp.large ? h->hp.plan.n : h->hp.plan.lds.rcap;
-    if (factor_only) *factor_only = h->hp.large ? 0 : h->hp.plan.lds.tri;
-    if (two_tier) *two_tier = h->hp.two_tier ? 1 : 0;
-    return COPRA_OK;
-}
 
 copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
 {
@@ -2099,93 +1376,11 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     return COPRA_OK;
 }
 
-copra_status_t copra_batch_synchronize(copra_batch_t* h)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_synchronize: null handle");
-    HIP_TRY(hipStreamSynchronize(h->last_stream));
-    return COPRA_OK;
-}
 
-const double* copra_batch_control_device(const copra_batch_t* h)
-{
-    return h ? (h->ext_control ? h->ext_control : h->d_control) : nullptr;
-}
-const double* copra_batch_trajectory_device(const copra_batch_t* h)
-{
-    return h ? (h->ext_traj ? h->ext_traj : h->d_traj) : nullptr;
-}
-const int* copra_batch_status_device(const copra_batch_t* h)
-{
-    return h ? (h->ext_status ? h->ext_status : h->d_status) : nullptr;
-}
-const int* copra_batch_iter_device(const copra_batch_t* h)
-{
-    return h ? (h->ext_iter ? h->ext_iter : h->d_iter) : nullptr;
-}
 
-copra_status_t copra_batch_get_results(copra_batch_t* h, double* control, double* trajectory, int* status, int* iter)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_get_results: null handle");
-    const FusedPlan& P = h->hp.plan;
-    const size_t b = (size_t)P.batch;
-    if (h->h_results && !h->ext_control && !h->ext_traj && !h->ext_status && !h->ext_iter) {
-        // small batch (the single-problem use of copra::LMPC::solve() above all): ONE asynchronous copy of the whole slab into
-        // pinned memory behind the solve, one synchronisation -- instead of a stream synchronisation and four blocking copies
-        HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, h->results_bytes, hipMemcpyDeviceToHost, h->last_stream));
-        HIP_TRY(hipStreamSynchronize(h->last_stream));
-        if (control) std::memcpy(control, h->h_results, b * P.n * sizeof(double));
-        if (trajectory) std::memcpy(trajectory, h->h_results + h->off_traj, b * P.X * sizeof(double));
-        if (status) std::memcpy(status, h->h_results + h->off_status, b * sizeof(int));
-        if (iter) std::memcpy(iter, h->h_results + h->off_iter, b * 2 * sizeof(int));
-        return COPRA_OK;
-    }
-    HIP_TRY(hipStreamSynchronize(h->last_stream));
-    if (control) HIP_TRY(hipMemcpy(control, copra_batch_control_device(h), b * P.n * sizeof(double), hipMemcpyDeviceToHost));
-    if (trajectory) HIP_TRY(hipMemcpy(trajectory, copra_batch_trajectory_device(h), b * P.X * sizeof(double), hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, copra_batch_status_device(h), b * sizeof(int), hipMemcpyDeviceToHost));
-    if (iter) HIP_TRY(hipMemcpy(iter, copra_batch_iter_device(h), b * 2 * sizeof(int), hipMemcpyDeviceToHost));
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_set_initial_state_bounds(copra_batch_t* h, const double* x0lb, const double* x0ub,
-    int on_device)
-{
-    if (!h || !x0lb || !x0ub) return fail(COPRA_ERR_ARG, "copra_batch_set_initial_state_bounds: null argument");
-    if (!h->hp.plan.initial_state) return fail(COPRA_ERR_RUNTIME, "not an InitialStateLMPC controller");
-    const size_t nd = (size_t)h->hp.plan.batch * h->hp.plan.nx;
-    if (on_device) {
-        h->x0lb = x0lb;
-        h->x0ub = x0ub;
-        return COPRA_OK;
-    }
-    if (!h->own_x0lb) {
-        HIP_TRY(hipMalloc((void**)&h->own_x0lb, (nd ? nd : 1) * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&h->own_x0ub, (nd ? nd : 1) * sizeof(double)));
-    }
-    HIP_TRY(hipMemcpy(h->own_x0lb, x0lb, nd * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->own_x0ub, x0ub, nd * sizeof(double), hipMemcpyHostToDevice));
-    h->x0lb = h->own_x0lb;
-    h->x0ub = h->own_x0ub;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_get_initial_state(copra_batch_t* h, double* x0_opt)
-{
-    if (!h || !x0_opt) return fail(COPRA_ERR_ARG, "copra_batch_get_initial_state: null argument");
-    if (!h->hp.plan.initial_state) return fail(COPRA_ERR_RUNTIME, "not an InitialStateLMPC controller");
-    HIP_TRY(hipStreamSynchronize(h->last_stream));
-    HIP_TRY(hipMemcpy(x0_opt, h->d_x0opt, (size_t)h->hp.plan.batch * h->hp.plan.nx * sizeof(double), hipMemcpyDeviceToHost));
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_qp_sizes(const copra_batch_t* h, int* nvar, int* neq, int* nineq)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_qp_sizes: null handle");
-    if (nvar) *nvar = h->hp.plan.initial_state ? h->hp.plan.nx + h->hp.plan.n : h->hp.plan.n;
-    if (neq) *neq = h->hp.plan.meq;
-    if (nineq) *nineq = h->hp.plan.mineq;
-    return COPRA_OK;
-}
 
 copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, double* c, double* Aeq, double* beq,
     double* Aineq, double* bineq, double* lb, double* ub)
@@ -2261,211 +1456,10 @@ copra_status_t copra_batch_dump_qp(copra_batch_t* h, int instance, double* Q, do
     return COPRA_OK;
 }
 
-copra_status_t copra_batch_phase_profile(copra_batch_t* h, int enable, long long* cycles_out)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_phase_profile: null handle");
-    const size_t b = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1);
-    if (enable && !h->d_prof) {
-        HIP_TRY(hipMalloc((void**)&h->d_prof, b * 8 * sizeof(long long)));
-        HIP_TRY(hipMemset(h->d_prof, 0, b * 8 * sizeof(long long)));
-    }
-    if (cycles_out) {
-        if (!h->d_prof) return fail(COPRA_ERR_RUNTIME, "copra_batch_phase_profile: profiling was not enabled");
-        HIP_TRY(hipStreamSynchronize(h->last_stream));
-        HIP_TRY(hipMemcpy(cycles_out, h->d_prof, b * 8 * sizeof(long long), hipMemcpyDeviceToHost));
-    }
-    if (!enable && h->d_prof) {
-        (void)hipFree(h->d_prof);
-        h->d_prof = nullptr;
-    }
-    return COPRA_OK;
-}
 
-#ifdef COPRA_FINE_PROFILE
-// profiling builds only (libcopra_hip_prof.so): 32 raw shader-clock stamps per instance, -1 = unused
-copra_status_t copra_batch_fine_profile(copra_batch_t* h, long long* out)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_fine_profile: null handle");
-    const size_t b = (size_t)(h->hp.plan.batch > 0 ? h->hp.plan.batch : 1);
-    if (!h->d_prof_fine) {
-        HIP_TRY(hipMalloc((void**)&h->d_prof_fine, b * 32 * sizeof(long long)));
-        HIP_TRY(hipMemset(h->d_prof_fine, 0xff, b * 32 * sizeof(long long)));
-    }
-    if (out) {
-        HIP_TRY(hipStreamSynchronize(h->last_stream));
-        HIP_TRY(hipMemcpy(out, h->d_prof_fine, b * 32 * sizeof(long long), hipMemcpyDeviceToHost));
-    }
-    return COPRA_OK;
-}
-#endif
 
-copra_status_t copra_batch_last_solve_seconds(copra_batch_t* h, double* seconds)
-{
-    if (!h || !seconds) return fail(COPRA_ERR_ARG, "copra_batch_last_solve_seconds: null argument");
-    if (!h->timed) return fail(COPRA_ERR_RUNTIME, "copra_batch_last_solve_seconds: no solve has been launched");
-    HIP_TRY(hipEventSynchronize(h->ev1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *seconds = (double)ms * 1e-3;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* seconds)
-{
-    if (!h || !seconds) return fail(COPRA_ERR_ARG, "copra_batch_last_first_tier_seconds: null argument");
-    if (!h->timed) return fail(COPRA_ERR_RUNTIME, "copra_batch_last_first_tier_seconds: no solve has been launched");
-    if (!h->tier_timed) return copra_batch_last_solve_seconds(h, seconds);
-    HIP_TRY(hipEventSynchronize(h->evm));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->evm));
-    *seconds = (double)ms * 1e-3;
-    return COPRA_OK;
-}
 
-copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_lane_pass_info: null handle");
-    if (ran) *ran = h->lane_ran ? 1 : 0;
-    if (finished) {
-        *finished = 0;
-        if (h->lane_ran) {
-            int left = 0;
-            HIP_TRY(hipStreamSynchronize(h->last_stream));
-            HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
-            *finished = h->hp.plan.batch - left;
-        }
-    }
-    return COPRA_OK;
-}
 
-copra_status_t copra_qp_solve_dense_batch(int batch, int n, int neq, int nineq, const double* Q, const double* c,
-    const double* Aeq, const double* beq, const double* Aineq, const double* bineq, const double* XL,
-    const double* XU, double* x, int* failv, int* iter, int on_device, void* hip_stream)
-{
-    if (batch < 0 || n <= 0 || neq < 0 || nineq < 0) // SI_problem(nrVar, nrEq, nrInEq)
-        return fail(COPRA_ERR_DOMAIN, "copra_qp_solve_dense_batch: bad problem sizes");
-    if (!Q || !c || !XL || !XU || !x || !failv || (neq > 0 && (!Aeq || !beq)) || (nineq > 0 && (!Aineq || !bineq)))
-        return fail(COPRA_ERR_ARG, "copra_qp_solve_dense_batch: null argument");
-    if (n > kLargeMaxN) return fail(COPRA_ERR_UNSUPPORTED, "dense QP with more than 512 variables is not covered yet");
-    if (batch == 0) return COPRA_OK;
-    const bool large = n > kWave;
-    hipStream_t s = (hipStream_t)hip_stream;
-    DensePlan P {};
-    P.n = n;
-    P.meq = neq;
-    P.mineq = nineq;
-    P.mgen = neq + nineq;
-    P.mtotal = P.mgen + 2 * n; // QuadProgSolver.cpp:51
-    P.batch = batch;
-    P.vsmall = qpgen2_vsmall();
-    P.max_iter = 50 * (n + P.mtotal) + 100;
-    size_t lds_bytes;
-    if (large) {
-        layout_large_solver(P.llds, 0, n, P.mgen, P.meq, P.mtotal);
-        lds_bytes = (size_t)P.llds.total * sizeof(double);
-    } else {
-        (void)layout_lds(P.lds, 0, 0, 0, n, 0, 1, P.mgen, P.meq, P.mtotal, false);
-        lds_bytes = (size_t)P.lds.total * sizeof(double);
-    }
-    if (lds_bytes > 160u * 1024u) return fail(COPRA_ERR_UNSUPPORTED, "dense QP does not fit LDS");
-    if (lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(large ? reinterpret_cast<const void*>(copra_qp_dense_large_kernel)
-                                          : reinterpret_cast<const void*>(copra_qp_dense_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        if (large)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(copra_qp_dense_large_kernel_w4),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    const size_t b = (size_t)batch;
-    std::vector<void*> owned;
-    auto release = [&]() {
-        for (void* p : owned) (void)hipFree(p);
-    };
-    hipError_t e = hipSuccess;
-    auto to_dev = [&](const double* src, size_t count) -> const double* {
-        if (on_device) return src;
-        double* dptr = nullptr;
-        hipError_t r = hipMalloc((void**)&dptr, (count ? count : 1) * sizeof(double));
-        if (r == hipSuccess && count) r = hipMemcpyAsync(dptr, src, count * sizeof(double), hipMemcpyHostToDevice, s);
-        if (r != hipSuccess && e == hipSuccess) e = r;
-        owned.push_back(dptr);
-        return dptr;
-    };
-    P.Q = to_dev(Q, b * n * n);
-    P.c = to_dev(c, b * n);
-    P.Aeq = to_dev(Aeq, b * neq * n);
-    P.beq = to_dev(beq, b * neq);
-    P.Aineq = to_dev(Aineq, b * nineq * n);
-    P.bineq = to_dev(bineq, b * nineq);
-    P.XL = to_dev(XL, b * n);
-    P.XU = to_dev(XU, b * n);
-    double* dx = x;
-    int *dfail = failv, *diter = iter;
-    if (!on_device) {
-        hipError_t r = hipMalloc((void**)&dx, b * n * sizeof(double));
-        if (r == hipSuccess) r = hipMalloc((void**)&dfail, b * sizeof(int));
-        if (r == hipSuccess) r = hipMalloc((void**)&diter, b * 2 * sizeof(int));
-        if (r != hipSuccess && e == hipSuccess) e = r;
-        owned.push_back(dx);
-        owned.push_back(dfail);
-        owned.push_back(diter);
-    } else if (!diter) {
-        hipError_t r = hipMalloc((void**)&diter, b * 2 * sizeof(int));
-        if (r != hipSuccess && e == hipSuccess) e = r;
-        owned.push_back(diter);
-    }
-    if (e != hipSuccess) {
-        release();
-        return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
-    }
-    P.x = dx;
-    P.fail = dfail;
-    P.iter = diter;
-    if (large) {
-        const int threads = (n + kWave - 1) & ~(kWave - 1);
-        const bool w4 = prefer_w4(default_options(), reinterpret_cast<const void*>(copra_qp_dense_large_kernel),
-            reinterpret_cast<const void*>(copra_qp_dense_large_kernel_w4), threads, lds_bytes);
-        auto dense_kernel = w4 ? copra_qp_dense_large_kernel_w4 : copra_qp_dense_large_kernel;
-        const int grid = large_grid(default_options(), reinterpret_cast<const void*>(dense_kernel), batch, threads, lds_bytes);
-        double* ws = nullptr;
-        e = hipMalloc((void**)&ws, (size_t)grid * 2 * n * large_ld(n) * sizeof(double));
-        if (e != hipSuccess) {
-            release();
-            return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
-        }
-        owned.push_back(ws);
-        P.ws = ws;
-        hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3((unsigned)threads), lds_bytes, s, P);
-    } else {
-        const int pw = default_options().no_packed ? 0 : packed_width(n, 0, false, lds_bytes);
-        hipFunction_t jit = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g_dense_jit_mu);
-            for (const DenseJit& d : g_dense_jit)
-                if (d.n == n && d.lanes == (pw ? pw : 64)) jit = d.fn;
-        }
-        const unsigned per = pw ? 64u / (unsigned)pw : 1u;
-        if (jit && (size_t)per * lds_bytes <= 48 * 1024) {
-            DensePlan Pj = P;
-            void* args[] = { &Pj };
-            e = hipModuleLaunchKernel(jit, ((unsigned)batch + per - 1) / per, 1, 1, 64, 1, 1, per * (unsigned)lds_bytes, s, args, nullptr);
-        } else if (pw == 16)
-            e = packed_dense_launch_w16(P, lds_bytes, s);
-        else if (pw == 32)
-            e = packed_dense_launch_w32(P, lds_bytes, s);
-        else
-            hipLaunchKernelGGL(copra_qp_dense_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, P);
-    }
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && !on_device) {
-        e = hipMemcpyAsync(x, dx, b * n * sizeof(double), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(failv, dfail, b * sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && iter) e = hipMemcpyAsync(iter, diter, b * 2 * sizeof(int), hipMemcpyDeviceToHost, s);
-    }
-    if (e == hipSuccess && !owned.empty()) e = hipStreamSynchronize(s);
-    release();
-    if (e != hipSuccess) return fail(COPRA_ERR_HIP, std::string("copra_qp_solve_dense_batch: ") + hipGetErrorString(e));
-    return COPRA_OK;
-}
 
 } // extern "C"
