@@ -283,8 +283,13 @@ def extra_measurements(np, torch, dev):
     rate, sec = timed_rate(eng, b, reps=3)
     out["dense_hessian_mfma_f64_16x16x4_batch65536"] = {
         "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3,
-        "mfma_flops_per_solve": 976 * 2048,  # 976 v_mfma_f64_16x16x4 per solve (profiles/r02/pmc_dense_mfma_path.json)
-        "executed_mfma_tflops": 976 * 2048 * rate / 1e12}
+        # v_mfma_f64_16x16x4 per solve: 976 for the dense contraction as round 2 issued it (profiles/r02/pmc_dense_mfma_path.json); since
+        # round 4 the K-steps in which this M is structurally zero are skipped (a bit mask per tile, built with the plan): 462 are ISSUED
+        # (profiles/r04/dense_path_rocprof_summary.json: SQ_INSTS_VALU_MFMA_MOPS_F64 / 4 / batch) -- the executed rate is the one to hold
+        # against the FP64 matrix peak
+        "mfma_issued_per_solve": 462, "mfma_dense_equivalent_per_solve": 976,
+        "executed_mfma_tflops": 462 * 2048 * rate / 1e12,
+        "dense_equivalent_mfma_tflops": 976 * 2048 * rate / 1e12}
     eng.close()
     # the same full-size entry as the plan builder takes it by default: a REFERENCE TRAJECTORY (here a straight line from x_init to x_goal)
     # -- a per-step cost with the reference of the step, on the factor-only tier

@@ -450,6 +450,8 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
         h->lane_adapt_left = 1;
         if (h->lane_off && h->lane_off_by_share) h->lane_off = h->lane_off_by_share = false;
     }
+    // (the first tier's layout is chosen again with the same period, from the top of its ladder: see the prediction in copra_batch_solve)
+    if (h->lane_solves % kLaneResample == 0 && h->lds_top_set && h->hp.plan.lds.tri) h->lane_predict_left = 1;
     if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
     // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
@@ -1305,6 +1307,18 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // life, instead of after each of the first solves (round 3: the first solve of the tight workload took 10.4 ms, the
             // steady state 2.8 ms).  adapt_layout keeps checking the real overflow counts of the first solves behind this.
             h->lane_predict_left -= 1;
+            if (!h->lds_top_set) {
+                h->lds_top = h->hp.plan.lds;
+                h->lds_top_set = true;
+            } else if (h->lds_top.tri && h->lds_top.ric == h->hp.plan.lds.ric && h->lds_top.ricC == h->hp.plan.lds.ricC
+                && h->lds_top.rcap < h->hp.plan.lds.rcap) {
+                // every 256 solves the choice is made again FROM THE TOP of the ladder: the ladder only leads down, and a controller whose
+                // constraints relaxed (a transient that is over, bounds that were widened) would otherwise stay on few instances per CU
+                h->hp.plan.lds = h->lds_top;
+                h->hp.lds_bytes = (size_t)h->lds_top.total * sizeof(double);
+                h->lds_attr_set = false;
+                if (h->adapt_left < 2) h->adapt_left = 2; // (the overflow counts of the next solves check the new choice, as after the first)
+            }
             int hist[kLaneHistBins];
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(hist, h->d_lane_hist, sizeof hist, hipMemcpyDeviceToHost));

@@ -107,6 +107,8 @@ struct copra_batch {
     int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
     int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
     int lane_predict_left = 1; // solves whose first-tier layout is still chosen from that histogram
+    LdsLayout lds_top {}; // the layout the ladder started on (the choice is made again every 256 solves, from the top: a controller whose
+    bool lds_top_set = false; // constraints relax gets its denser layout back)
     double* d_lane_ws = nullptr;
     int lane_cur = 0; // the counter the last solve appended to
     bool lane_ran = false; // the last solve ran the pass
