@@ -151,7 +151,8 @@ fused_kernel_t select_fused_kernel(const FusedPlan& P)
         }
         if (P.nx == 6 && rp == 6 && P.lds.q1regs == kFusedQ1Regs) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6, kFusedQ1Regs>;
         if (P.nx == 6 && rp == 6) return copra_lmpc_fused_tri_kernel<6, 3, 20, 6>;
-        if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) return copra_lmpc_fused_tri_kernel<6, 3, 20, 0>; // headline shape, full-size costs
+        if (P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20) // headline shape, full-size costs
+            return P.lds.q1regs == kFusedQ1Regs ? copra_lmpc_fused_tri_kernel<6, 3, 20, 0, kFusedQ1Regs> : copra_lmpc_fused_tri_kernel<6, 3, 20, 0>;
         return copra_lmpc_fused_tri_kernel<0, 0, 0, 0>;
     }
     if (P.nx == 6 && rp == 6) return copra_lmpc_fused_kernel<6, 3, 20, 6>;

@@ -1268,6 +1268,20 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                     P.lds = t;
                     break;
                 }
+                // full-size cost entries at the headline shape: the same five register columns (the tile of the dense contraction and
+                // they fit the 256 VGPRs of two waves per SIMD) -- one instance per CU more than with Q1 in LDS
+                if (P.rfull > 0 && nx == 6 && nu == 3 && N == 20 && !hp.opt.no_q1regs
+                    && layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, P.rfull, true, P.rows_direct != 0,
+                        kFusedQ1Regs)
+                    && t.total <= budget) {
+                    hp.lds_safe = P.lds;
+                    hp.safe_two_tier = hp.two_tier;
+                    hp.two_tier = true;
+                    hp.dense = true;
+                    P.lds = t;
+                    break;
+                }
+                t = LdsLayout {};
                 if (layout_lds(t, nx, nu, N, U, X, rows, P.mgen, P.meq, P.mtotal, true, true, budget, P.rfull, true, P.rows_direct != 0)
                     && t.total <= budget && t.rcap >= need) {
                     hp.lds_safe = P.lds; // what the adaptive fall-back steps to

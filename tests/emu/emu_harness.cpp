@@ -251,7 +251,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     P.ovf_list = ovf_list.data();
     P.from_list = 0;
     if (dump_instance >= 0) P.lds = hp.lds_full;
-    if (!s6 && !(use_specialised && P.lds.ric) && P.lds.q1regs > 0) { // the run-time-shape body keeps Q1 in LDS (it never meets a register-Q1 layout in the library)
+    const bool sfull = use_specialised && P.rfull > 0 && P.nx == 6 && P.nu == 3 && P.N == 20; // (headline shape, full-size costs)
+    if (!s6 && !sfull && !(use_specialised && P.lds.ric) && P.lds.q1regs > 0) { // the run-time-shape body keeps Q1 in LDS (it never meets a register-Q1 layout in the library)
         LdsLayout lq {};
         if (tri_layout_with_lds_q1(P, P.lds, lq)) P.lds = lq;
     }
@@ -294,7 +295,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             lmpc_fused_body<6, 3, 20, 6, true, kFusedQ1Regs>(PP, b);
         else if (PP.lds.tri && s6)
             lmpc_fused_body<6, 3, 20, 6, true>(PP, b);
-        else if (PP.lds.tri && use_specialised && PP.rfull > 0 && PP.nx == 6 && PP.nu == 3 && PP.N == 20)
+        else if (PP.lds.tri && sfull && PP.lds.q1regs == kFusedQ1Regs)
+            lmpc_fused_body<6, 3, 20, 0, true, kFusedQ1Regs>(PP, b);
+        else if (PP.lds.tri && sfull)
             lmpc_fused_body<6, 3, 20, 0, true>(PP, b);
         else if (PP.lds.tri)
             lmpc_fused_body<0, 0, 0, 0, true>(PP, b);

@@ -656,6 +656,26 @@ def test_dense_mfma_hessian_equals_structured_path(emu, oracle, full_size_paths)
     assert _rel(rd["control"], rs["control"]) <= 1e-9
 
 
+@pytest.mark.parametrize("q1", ["registers", "lds"])
+def test_dense_mfma_path_first_tier_layouts(emu, oracle, full_size_paths, monkeypatch, q1):
+    """the first tier of that path as copra_batch_solve runs it (no dump): five columns of Q1 in REGISTERS (7 instances per CU; round 4)
+    or eleven in LDS (6 per CU, option no_q1regs) -- a constrained batch, results, statuses and both iteration counters == oracle,
+    instances that outgrow five columns finish in the second tier"""
+    from copra_amd import workloads
+    from copra_amd.autospan import autospan_cost
+    if q1 == "lds":
+        monkeypatch.setitem(OPTIONS, "no_q1regs", 1)
+    wl = workloads.com_preview(20, v_max=0.3, u_max=1.5, seed=9)
+    dense = [autospan_cost(dict(wl["costs"][0], p=np.tile(wl["costs"][0]["p"], 21))), wl["costs"][1]]
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], dense, wl["cstrs"])
+    ro = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], dense, wl["cstrs"])
+    assert re["factor_only"] and re["rcap"] == (5 if q1 == "registers" else 11)
+    assert re["lds_bytes"] * (7 if q1 == "registers" else 6) <= 160 * 1024
+    assert (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
+    assert ro["iter"][:, 0].max() > 6 and (q1 == "lds" or re["overflowed"] > 0)
+    assert _rel(re["control"], ro["control"]) <= RTOL and _rel(re["trajectory"], ro["trajectory"]) <= RTOL
+
+
 def _is_problem_batch(b=5):
     pb = F.bounded_system("trajectory", N=12)
     rng = np.random.default_rng(1)

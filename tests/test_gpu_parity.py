@@ -2064,10 +2064,37 @@ def test_first_tier_layout_chosen_before_the_first_launch(oracle, vmax, umax, le
 
 
 @pytest.mark.gpu
+def test_hundred_iteration_regime_against_the_oracle(oracle):
+    """Far outside the benchmark's regime: initial states far from the goal under tight bounds -- 115 to 135 Goldfarb-Idnani iterations
+    with 63 to 74 DROPS per solve (n = 60).  Statuses equal, U and X within 1e-6 entry-wise on every instance; the iteration counters are
+    equal on nearly all of them -- where a row enters and leaves again with a step length at rounding level the two arithmetics may
+    disagree by such a pair (seen: 1 instance in 48, 116 / 64 against 117 / 65, U equal to 3e-10), which is asserted as what it is."""
+    from copra_amd import BatchLMPC, workloads
+    b = 24576
+    wl = workloads.com_preview(b, v_max=0.25, u_max=1.2)
+    x0 = np.ascontiguousarray(wl["x0"] * 0.05)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], x0)
+    eng.solve()
+    res = eng.results()
+    eng.close()
+    pick = np.linspace(0, b - 1, 256).astype(int)
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], x0[pick], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert ref["iter"][:, 0].min() > 90 and ref["iter"][:, 1].min() > 40
+    assert (res["status"][pick] == ref["status"]).all() and (ref["status"] == 0).all()
+    assert _rel(res["control"][pick], ref["control"]) <= RTOL and _rel(res["trajectory"][pick], ref["trajectory"]) <= RTOL
+    diff = np.abs(res["iter"][pick].astype(int) - ref["iter"].astype(int))
+    same = (diff == 0).all(axis=1)
+    print("   %d of %d instances with equal iteration counters (%.0f iterations, %.0f drops on average), largest difference %d"
+          % (same.sum(), len(pick), ref["iter"][:, 0].mean(), ref["iter"][:, 1].mean(), diff.max()))
+    assert same.mean() >= 0.9 and diff.max() <= 2 and (diff[:, 0] == diff[:, 1]).all()
+
+
+@pytest.mark.gpu
 def test_first_tier_layout_is_chosen_again_when_the_constraints_relax(oracle):
     """The layout ladder only leads down (fewer instances per CU, more columns for the active set).  A controller whose first ticks are a
     constrained transient would stay at the bottom for good: every 256 solves the choice is made again from the TOP of the ladder, from
-    the histogram of the one-instance-per-lane pass of that solve.  Tight start (15 or 11 columns), then initial states near the origin:
+    the histogram of the one-instance-per-lane pass of that solve.  Tight start (15 or 11 columns), then initial states next to the goal:
     within 257 solves the controller is back on 5 columns, results equal to the oracle's before and after the switch."""
     from copra_amd import BatchLMPC, workloads
     b = 32768
@@ -2077,7 +2104,9 @@ def test_first_tier_layout_is_chosen_again_when_the_constraints_relax(oracle):
     eng.solve()
     eng.synchronize()
     assert eng.layout_info()["active_capacity"] >= 11
-    x0 = np.ascontiguousarray(wl["x0"] * 0.05)
+    goal = np.array(wl["costs"][0]["p"], dtype=float)  # (a copy; initial states at the goal's position, at rest: one or two active rows each)
+    goal[3:] = 0.0
+    x0 = np.ascontiguousarray(goal[None, :] + 0.01 * np.random.default_rng(4).standard_normal((b, 6)))
     eng.set_x0(x0)
     pick = np.linspace(0, b - 1, 192).astype(int)
     ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], x0[pick], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
