@@ -451,8 +451,6 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
         h->lane_adapt_left = 1;
         if (h->lane_off && h->lane_off_by_share) h->lane_off = h->lane_off_by_share = false;
     }
-    // (the first tier's layout is chosen again with the same period, from the top of its ladder: see the prediction in copra_batch_solve)
-    if (h->lane_solves % kLaneResample == 0 && h->lds_top_set && h->hp.plan.lds.tri) h->lane_predict_left = 1;
     if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
     // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
@@ -524,6 +522,62 @@ static copra_status_t adapt_layout(copra_batch* h)
     if (h->hp.opt.debug)
         fprintf(stderr, "[copra] %d of %d instances overflowed the compact LDS layout: next layout %zu B, %s\n", count, P.batch,
             h->hp.lds_bytes, h->hp.two_tier ? "two-tier" : "single tier");
+    return COPRA_OK;
+}
+
+// The ladder only leads down, and the first solve's choice rests on a proxy (rows violated by the unconstrained minimiser: an instance
+// that must brake for ten steps violates ten rows and ends with one or two active).  Once a solve is behind the controller the SIZES of
+// the final active sets are known exactly -- adds minus drops, from the iteration counters every instance reports anyway.  After the
+// first solve, and every 256 solves from then on, the first tier's layout is chosen again FROM THE TOP of its ladder: the densest step
+// that leaves at most one instance in `share` to the second tier.  One synchronisation and one copy of 8 B per instance each time;
+// adapt_layout keeps checking the overflow counts of the next solves behind it (an active set can peak above its final size).
+static copra_status_t rechoose_layout(copra_batch* h)
+{
+    constexpr long long kPeriod = 256;
+    const FusedPlan& P = h->hp.plan;
+    if (!h->hp.two_tier || h->hp.large || h->shared || !P.lds.tri || h->hp.opt.no_ladder || P.batch <= 0 || P.initial_state) return COPRA_OK;
+    if (!h->lds_top_set) { // (first solve of this ladder: remember where it starts)
+        h->lds_top = P.lds;
+        h->lds_top_set = true;
+        h->layout_solves = 0;
+        return COPRA_OK;
+    }
+    h->layout_solves += 1; // solves completed on this ladder
+    if (h->layout_solves != 1 && h->layout_solves % kPeriod != 0) return COPRA_OK;
+    if (!(h->lds_top.tri && h->lds_top.ric == P.lds.ric && h->lds_top.ricC == P.lds.ricC)) return COPRA_OK;
+    const int* d_it = h->ext_iter ? h->ext_iter : h->d_iter;
+    const int* d_st = h->ext_status ? h->ext_status : h->d_status;
+    if (!d_it || !d_st) return COPRA_OK;
+    std::vector<int> it((size_t)P.batch * 2), st((size_t)P.batch);
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(it.data(), d_it, it.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<long long> larger((size_t)P.n + 2, 0); // larger[a] = instances whose final active set holds MORE than a rows
+    for (int b = 0; b < P.batch; ++b) {
+        if (st[(size_t)b] != 0) continue;
+        int a = it[2 * (size_t)b] - 1 - it[2 * (size_t)b + 1];
+        a = a < 0 ? 0 : (a > P.n ? P.n : a);
+        if (a > 0) larger[(size_t)a - 1] += 1;
+    }
+    for (int a = P.n - 1; a >= 0; --a) larger[(size_t)a] += larger[(size_t)a + 1];
+    long long share = P.lds.ric ? 64 : 8;
+    if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share;
+    LdsLayout pick = h->lds_top;
+    for (;;) {
+        const int cap = pick.rcap < P.n ? pick.rcap : P.n;
+        LdsLayout roomier {};
+        if (larger[(size_t)cap] * share <= (long long)P.batch || !next_tri_layout(P, pick, roomier)) break;
+        pick = roomier;
+    }
+    if (pick.total != P.lds.total || pick.rcap != P.lds.rcap) {
+        if (h->hp.opt.debug)
+            fprintf(stderr, "[copra] final active sets of the last solve: first tier from %d to %d columns (%zu B)\n", P.lds.rcap, pick.rcap,
+                (size_t)pick.total * sizeof(double));
+        h->hp.plan.lds = pick;
+        h->hp.lds_bytes = (size_t)pick.total * sizeof(double);
+        h->lds_attr_set = false;
+        if (h->adapt_left < 2) h->adapt_left = 2;
+    }
     return COPRA_OK;
 }
 
@@ -1095,6 +1149,8 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         if (rca != COPRA_OK) return rca;
         rca = adapt_layout(h);
         if (rca != COPRA_OK) return rca;
+        rca = rechoose_layout(h);
+        if (rca != COPRA_OK) return rca;
         h->solved_once = true;
         h->lane_ran = false;
     }
@@ -1308,18 +1364,6 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // life, instead of after each of the first solves (round 3: the first solve of the tight workload took 10.4 ms, the
             // steady state 2.8 ms).  adapt_layout keeps checking the real overflow counts of the first solves behind this.
             h->lane_predict_left -= 1;
-            if (!h->lds_top_set) {
-                h->lds_top = h->hp.plan.lds;
-                h->lds_top_set = true;
-            } else if (h->lds_top.tri && h->lds_top.ric == h->hp.plan.lds.ric && h->lds_top.ricC == h->hp.plan.lds.ricC
-                && h->lds_top.rcap < h->hp.plan.lds.rcap) {
-                // every 256 solves the choice is made again FROM THE TOP of the ladder: the ladder only leads down, and a controller whose
-                // constraints relaxed (a transient that is over, bounds that were widened) would otherwise stay on few instances per CU
-                h->hp.plan.lds = h->lds_top;
-                h->hp.lds_bytes = (size_t)h->lds_top.total * sizeof(double);
-                h->lds_attr_set = false;
-                if (h->adapt_left < 2) h->adapt_left = 2; // (the overflow counts of the next solves check the new choice, as after the first)
-            }
             int hist[kLaneHistBins];
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(hist, h->d_lane_hist, sizeof hist, hipMemcpyDeviceToHost));

@@ -108,6 +108,7 @@ struct copra_batch {
     int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
     int lane_predict_left = 1; // solves whose first-tier layout is still chosen from that histogram
     LdsLayout lds_top {}; // the layout the ladder started on (the choice is made again every 256 solves, from the top: a controller whose
+    long long layout_solves = 0; // solves completed on the current ladder (rechoose_layout)
     bool lds_top_set = false; // constraints relax gets its denser layout back)
     double* d_lane_ws = nullptr;
     int lane_cur = 0; // the counter the last solve appended to

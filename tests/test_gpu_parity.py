@@ -2093,8 +2093,8 @@ def test_hundred_iteration_regime_against_the_oracle(oracle):
 @pytest.mark.gpu
 def test_first_tier_layout_is_chosen_again_when_the_constraints_relax(oracle):
     """The layout ladder only leads down (fewer instances per CU, more columns for the active set).  A controller whose first ticks are a
-    constrained transient would stay at the bottom for good: every 256 solves the choice is made again from the TOP of the ladder, from
-    the histogram of the one-instance-per-lane pass of that solve.  Tight start (15 or 11 columns), then initial states next to the goal:
+    constrained transient would stay at the bottom for good: after the first solve and every 256 solves the choice is made again from the
+    TOP of the ladder, from the sizes of the final active sets of the solve before (adds - drops of the iteration counters).  Tight start (15 or 11 columns), then initial states next to the goal:
     within 257 solves the controller is back on 5 columns, results equal to the oracle's before and after the switch."""
     from copra_amd import BatchLMPC, workloads
     b = 32768
