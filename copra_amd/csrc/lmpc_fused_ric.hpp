@@ -260,7 +260,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
 #pragma unroll
             for (int K = 0; K < 2; ++K) pa[I][K] = (4 * I + r4 < NX && 4 * K + q4 < NX) ? A[(4 * I + r4) + NX * (4 * K + q4)] : 0.0;
     }
-    const bool pw = ((lane >> 2) & 3) == 0 && (compact ? r4 < NU : r4 <= NU); // lanes of block 0 store (compact variant: not the
+    const bool pw = ((lane >> 2) & 3) == 0 && q4 < NX && (compact ? r4 < NU : r4 <= NU); // lanes of block 0 store, rows q < NX (compact variant: not the
                                                                               // free response, which nobody reads -- its place is inside G)
     const bool pgc = r4 < NU; // a column of G (else xbar)
     double pc[2], px[2]; // [0 | d] and the state, rows q and 4 + q, column r
@@ -446,6 +446,22 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 T1 = mfma_f64_4x4x4(*pA[1][2], bK[2], T1);
                 T2 = mfma_f64_4x4x4(*pA[2][2], bK[2], T2);
             }
+            // M_I = Hin_I + [B A]'_{I,.} T
+            double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hk[0]);
+            double M1 = mfma_f64_4x4x4(aM[1][1], T1, Hk[1]);
+            double M2 = mfma_f64_4x4x4(aM[2][1], T1, Hk[2]);
+            if (NX > 4) {
+                M0 = mfma_f64_4x4x4(aM[0][2], T2, M0);
+                M1 = mfma_f64_4x4x4(aM[1][2], T2, M1);
+                M2 = mfma_f64_4x4x4(aM[2][2], T2, M2);
+            }
+            // (The compact variant's use of T stands BEHIND the products M on purpose.  Between T and M it was a wave-uniform branch, and on
+            //  its taken side -- the variant with general rows -- the compiler (ROCm 7.2, gfx950) left ONE instruction between the
+            //  v_mfma_f64_4x4x4 that writes T1 and the one that reads it as its B operand: the hazard recogniser had counted the wait states
+            //  of the fall-through side only.  The hardware then multiplies with whatever the register held before; which instantiations
+            //  were hit was a matter of scheduling -- <4, 2> and <2, 1> with Q1 in LDS, found by the random differential test on the device,
+            //  tests/random_controllers.py::make_integrator.  Dependent matrix instructions are kept in straight-line code from here on;
+            //  tools/mfma_hazard_lint.py checks the compiled kernels for the pattern.)
             if (compact) { // block 3 of T: G_s, s = NH - k -- its block-row norms are all that is kept (the other blocks' sums go nowhere)
                 if (k > 0) {
                     ncum0 += quad_sum(T1 * T1);
@@ -458,15 +474,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 bK[1] = ride ? T1 : bK[1];
                 bK[2] = ride ? T2 : bK[2];
             }
-            // M_I = Hin_I + [B A]'_{I,.} T
-            double M0 = mfma_f64_4x4x4(aM[0][1], T1, Hk[0]);
-            double M1 = mfma_f64_4x4x4(aM[1][1], T1, Hk[1]);
-            double M2 = mfma_f64_4x4x4(aM[2][1], T1, Hk[2]);
-            if (NX > 4) {
-                M0 = mfma_f64_4x4x4(aM[0][2], T2, M0);
-                M1 = mfma_f64_4x4x4(aM[1][2], T2, M1);
-                M2 = mfma_f64_4x4x4(aM[2][2], T2, M2);
-            }
+            mfma_settle(); // (the branch above merges here, M0 is stored next)
             *wMu = M0;
             if (uu_on) Fk[uu_off] = M0; // (packed upper triangle; replaced by Lam^-1 after the sweep)
             wave_sync();

@@ -33,6 +33,7 @@
 #include "plan.hpp"
 #include "stage_plan.hpp"
 #include "wave_prims.hpp"
+#include "lmpc_riccati.hpp" // ric_converged
 
 namespace copra_hip {
 
@@ -760,6 +761,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             return fl == kRfEq ? az - Fr[j] : az + Sv[j] - Fr[j];
         };
         int it = 0;
+        double prev_step = 1.0e300; // the step before (ric_converged: contraction of the last two steps)
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -883,7 +885,11 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                         musum2 += Sv[j] * Lam[j];
                     } else {
                         const double re = rp + alpha * adz; // residual of the row at the new point
-                        Lam[j] += re / delta;
+                        // Newton direction of the multiplier of the regularised row (a'dz - delta dnu = -(a'z - f)): dnu = (rp + a'dz) / delta,
+                        // damped like every other unknown.  (Rounds 2-3 added re / delta -- the same after a full step; after a damped one it
+                        // differs by (1 - alpha) rp / delta, 1e9 x a residual that is not small yet: the multiplier was thrown to +-1e7 and took
+                        // the rest of the iterations to come back, lmpc_riccati.hpp.)
+                        Lam[j] += alpha * (rp + adz) / delta;
                         maxe = fmax(maxe, fabs(re));
                     }
                 }
@@ -910,7 +916,9 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(COPRA_EMU_TRACE)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e eq %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, maxe, step_inf, z_inf);
 #endif
-            if (res_new <= 1e-9 && ((step_inf <= S.step_tol * (1.0 + z_inf) && mu_new <= S.mu_tol) || mu_new <= 1e-15)) {
+            const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf);
+            prev_step = step_inf;
+            if (conv) {
                 converged = true;
                 break;
             }

@@ -529,10 +529,12 @@ inline bool take_ric_layout(HostPlan& hp)
     if (P.rmax > 6 || P.rfull != 0 || P.denseQ >= 0 || P.ncost > kRicMaxCosts) return false;
     for (int t = 0; t < P.ncost; ++t)
         if (P.cost[t].full) return false;
-    for (int k = 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
+    // (copra_options_t::ric_k = instances per CU: start on the LDS-Q1 step of the ladder with that budget -- tests pin a ladder level with it)
+    const int rk = hp.opt.ric_k > 0 ? hp.opt.ric_k : 0;
+    for (int k = rk ? rk : 16; k >= 6; --k) { // (small shapes: as many instances per CU as the LDS granule allows)
         const int budget = ((160 * 1024 / k) & ~511) / (int)sizeof(double);
         LdsLayout t {};
-        if (layout_lds_ric(t, nx, nu, N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0 && !hp.opt.ric_general, kFusedQ1Regs, budget)) {
+        if (layout_lds_ric(t, nx, nu, N, P.n, P.X, P.mgen, P.meq, P.mtotal, P.rows_pure != 0 && !hp.opt.ric_general, rk ? 0 : kFusedQ1Regs, budget)) {
             hp.lds_safe = P.lds; // (what the controller falls back to when the tier's layout ladder is exhausted: adapt_layout)
             hp.safe_two_tier = hp.two_tier;
             hp.two_tier = true;

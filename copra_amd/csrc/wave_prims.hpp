@@ -84,6 +84,11 @@ COPRA_DEV double bcast_f64(double v, int src)
 COPRA_DEV int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 // the instruction scheduler moves nothing across this point (bounds how far ahead it hoists the loads of unrolled code)
 COPRA_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Ten wait states, unconditionally.  To be placed where a wave-uniform branch MERGES inside a chain of matrix instructions, in front of
+// the first reader of a v_mfma_f64_4x4x4 result: hipcc of ROCm 7.2 counts the wait states such a reader needs (6 as a matrix or vector
+// operand, 9 as store data) along the fall-through side of the branch only -- on the taken side the hardware, which does not interlock
+// here, reads the register's previous contents (lmpc_fused_ric.hpp, the sweep; tools/mfma_hazard_lint.py finds the pattern in the ISA).
+COPRA_DEV void mfma_settle() { __asm__ volatile("s_nop 7\n\ts_nop 1" ::: "memory"); }
 // 1/sqrt(x): v_rsq_f64 seed + two Newton steps (full double precision to ~1 ulp, no divide)
 COPRA_DEV double fast_rsqrt(double x)
 {

@@ -106,7 +106,11 @@ namespace emu {
         for (;;) {
             const unsigned long before = g_progress;
             int ndone = 0;
-            for (int l = 0; l < nthreads; ++l) {
+            // (COPRA_EMU_REVERSE: the lanes take their turns in descending order -- a result that depends on the order is a missing wave_sync:
+            //  between two syncs the hardware runs the lanes in lockstep, the emulator one after the other)
+            static const bool reverse = std::getenv("COPRA_EMU_REVERSE") != nullptr;
+            for (int li = 0; li < nthreads; ++li) {
+                const int l = reverse ? nthreads - 1 - li : li;
                 if (g_done[l]) {
                     ++ndone;
                     continue;

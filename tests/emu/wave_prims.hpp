@@ -113,6 +113,7 @@ COPRA_DEV int wave_prefix_count(bool flag, int& total)
     return before;
 }
 COPRA_DEV void sched_fence() { }
+COPRA_DEV void mfma_settle() { } // (hardware wait states: nothing to emulate)
 COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 COPRA_DEV int uniform_i32(int v) { return v; }

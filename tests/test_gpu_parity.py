@@ -2064,6 +2064,98 @@ def test_first_tier_layout_chosen_before_the_first_launch(oracle, vmax, umax, le
 
 
 @pytest.mark.gpu
+def test_random_controllers_against_the_oracle(oracle):
+    """tests/random_controllers.py on the device: 240 random controllers -- shapes nx 1..7, nu 1..3, N 2..24 (every fifth up to 72
+    variables: the workgroup-per-instance kernels), per-instance systems, random mixes of the reference's four cost and five constraint
+    classes as per-step and as full-size entries (block-diagonal as AutoSpan builds them, or dense across the steps), equalities, infinite
+    bound components -- 48 instances each against the oracle: statuses equal on every instance (infeasible ones included), U and X within
+    1e-6 entry-wise (floor 1e-3), iteration counters equal except for ties broken at rounding level (counted, at most 1 instance in 100)."""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    import truth
+    ndiff = ninst = ninfeasible = n_is = ntruth = 0
+    shapes = set()
+    for seed in range(240):
+        c = RC.make(seed, batch=48, max_vars=72 if seed % 5 == 0 else 64)
+        ref = oracle.lmpc_solve_batch(c["A"], c["B"], c["d"], c["x0"], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        eng = BatchLMPC(c["nx"], c["nu"], c["N"], 48, c["costs"], c["cstrs"])
+        eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+        eng.solve()
+        res = eng.results()
+        eng.close()
+        what = "seed %d (%d, %d, %d) %s" % (seed, c["nx"], c["nu"], c["N"], c["forms"])
+        assert (res["status"] == ref["status"]).all(), what
+        ok = ref["status"] == 0
+        for k in np.nonzero(ok)[0]:
+            if _rel(res["control"][k], ref["control"][k]) <= RTOL and _rel(res["trajectory"][k], ref["trajectory"][k]) <= RTOL:
+                continue
+            # further than 1e-6 from the CPU path: then the certified optimum decides (seen on 2 of 600 controllers, 4e-6 and 1e-6 apart,
+            # device and oracle each within 1e-6 of the optimum, on either side of it)
+            t = truth.solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], c["N"], c["costs"], c["cstrs"], ref["control"][k])
+            assert _rel(res["control"][k], t["control"]) <= RTOL and _rel(res["trajectory"][k], t["trajectory"]) <= RTOL, what + " instance %d" % k
+            ntruth += 1
+        if c["nu"] * c["N"] <= 64:  # (above 64 variables the default solver is the stage-wise interior-point kernel: its counters mean something else)
+            ndiff += int((res["iter"][ok] != ref["iter"][ok]).any(axis=1).sum())  # (status 0 only: an infeasible exit is reached through
+            ninst += int(ok.sum())  #  multipliers at rounding level -- the drop counters of the two arithmetics differ there)
+        ninfeasible += int((~ok).sum())
+        shapes.add((c["nx"], c["nu"]))
+        ist = c["initial_state"]
+        if ist is not None:  # the same pieces under an InitialStateLMPC (x0 a decision variable in a box): every sixth instance
+            eng = BatchLMPC(c["nx"], c["nu"], c["N"], 48, c["costs"], c["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+            eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+            eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
+            eng.solve()
+            res = eng.results()
+            x0s = eng.initial_state()
+            eng.close()
+            for k in range(0, 48, 6):
+                ro = oracle.lmpc_solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], c["N"], c["costs"], c["cstrs"],
+                                       initial_state=dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k]))
+                assert res["status"][k] == ro["status"], what + " (InitialStateLMPC, instance %d)" % k
+                if ro["status"] == 0:
+                    assert _rel(res["control"][k], ro["control"]) <= RTOL and _rel(res["trajectory"][k], ro["trajectory"]) <= RTOL \
+                        and _rel(x0s[k], ro["x0_opt"]) <= RTOL, what + " (InitialStateLMPC, instance %d)" % k
+                ndiff += int(tuple(res["iter"][k]) != tuple(ro["iter"]))
+                ninst += 1
+            n_is += 1
+    print("   240 random controllers (%d also as InitialStateLMPC), %d (nx, nu) pairs, %d infeasible instances, %d decided by the certified optimum, "
+          "iteration counters differ on %d of %d solved instances" % (n_is, len(shapes), ninfeasible, ntruth, ndiff, ninst))
+    assert ndiff * 100 <= ninst and len(shapes) >= 18 and n_is >= 30 and ntruth <= 8
+
+
+@pytest.mark.gpu
+def test_random_controllers_on_the_headline_kernels(oracle):
+    """tests/random_controllers.py::make_integrator: 32 random controllers on the double integrators in one, two and three dimensions
+    (random horizon, costs with general M, reference trajectories, target and mixed costs, velocity / control bounds, row, mixed and
+    terminal full-size constraints) at batches that run the one-instance-per-lane pass in front of the Riccati-factor tier (24 576: with
+    the hand-over of the factor; 6144 with the pass forced on: as a filter where the tier keeps general rows) and the tier alone (4096):
+    a sample of 160 instances against the oracle -- statuses, both iteration counters, U and X within 1e-6."""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    npass = nric = 0
+    for seed in range(32):
+        b = (24576, 4096, 6144)[seed % 3]
+        c = RC.make_integrator(seed, b)
+        eng = BatchLMPC(c["nx"], c["nu"], c["N"], b, c["costs"], c["cstrs"], options=dict(lane_min_batch=-1) if b == 6144 else None)
+        eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+        eng.solve()
+        res = eng.results()
+        info, lane = eng.layout_info(), eng.lane_pass_info()
+        eng.close()
+        pick = np.linspace(0, b - 1, 160).astype(int)
+        ref = oracle.lmpc_solve_batch(c["A"][pick], c["B"][pick], c["d"][pick], c["x0"][pick], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        what = "seed %d (%d, %d, %d) batch %d %s %s pass %s" % (seed, c["nx"], c["nu"], c["N"], b, c["forms"], info, lane)
+        assert (res["status"][pick] == ref["status"]).all(), what
+        ok = ref["status"] == 0
+        assert (res["iter"][pick][ok] == ref["iter"][ok]).all(), what
+        assert _rel(res["control"][pick][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][pick][ok], ref["trajectory"][ok]) <= RTOL, what
+        npass += bool(lane[0])
+        nric += bool(info.get("factor_only"))
+    print("   32 random controllers on the integrator shapes: %d on a factor-only first tier, %d behind the one-instance-per-lane pass" % (nric, npass))
+    assert npass >= 12 and nric >= 24
+
+
+@pytest.mark.gpu
 def test_hundred_iteration_regime_against_the_oracle(oracle):
     """Far outside the benchmark's regime: initial states far from the goal under tight bounds -- 115 to 135 Goldfarb-Idnani iterations
     with 63 to 74 DROPS per solve (n = 60).  Statuses equal, U and X within 1e-6 entry-wise on every instance; the iteration counters are
