@@ -455,7 +455,8 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.s_floor = 0.05, sp.lam0 = -10.0;
     // (step_tol: 1e-10 until round 4 -- an iterate whose last step was 1e-9 went on, and the next factorisation, at multipliers / slacks
     //  of 1e15, broke down: the instance went to the Goldfarb-Idnani kernel for nothing)
-    sp.step_tol = 1e-8, sp.mu_tol = 1e-8;
+    // (mu_tol: 1e-8 until round 4 -- a weakly active row, multiplier 1e-3, then keeps a slack of 1e-5: 4e-6 in U on a random controller)
+    sp.step_tol = 1e-8, sp.mu_tol = 1e-11;
     if (hp.opt.ric_step_tol != 0.0) sp.step_tol = hp.opt.ric_step_tol; // (copra_options_t: experiments)
     if (hp.opt.ric_mu_tol != 0.0) sp.mu_tol = hp.opt.ric_mu_tol;
     if (hp.opt.ric_s0 != 0.0) sp.s_floor = hp.opt.ric_s0;

@@ -179,6 +179,9 @@ def build_qp(A, B, d, x0, N, costs, cstrs, initial_state=None, ar=None):
                     put(c, ar.zeros(Gm.shape[0], nx), blk, fm)
         elif kind == "mixed":
             Em, Gm, fm = ar.cv(np.atleast_2d(c["E"])), ar.cv(np.atleast_2d(c["G"])), ar.cv(np.atleast_1d(c["f"]))
+            if Em.shape[1] == X:  # full-size entry (constraints.cpp:199-204): E over the whole trajectory, G over all controls
+                put(c, Em.dot(Phi), Em.dot(Psi) + Gm, fm - Em.dot(xiv))
+                continue
             for i in range(N):
                 blk = Em.dot(Psi[i * nx:(i + 1) * nx])
                 blk[:, i * nu:(i + 1) * nu] += Gm
@@ -194,7 +197,9 @@ def build_qp(A, B, d, x0, N, costs, cstrs, initial_state=None, ar=None):
                         r = i * nx + j
                         put(dict(ineq=True), Phi[r:r + 1], Psi[r:r + 1], ar.cv([bound[j]]) - xiv[r:r + 1])
         elif kind == "control_bound":
-            lbU, ubU = np.tile(np.asarray(c["lower"], float), N), np.tile(np.asarray(c["upper"], float), N)
+            lo, hi = np.asarray(c["lower"], float).reshape(-1), np.asarray(c["upper"], float).reshape(-1)
+            # (per-step entry tiled over the steps, or a full-size entry taken as it is: constraints.cpp:333-357)
+            lbU, ubU = (lo, hi) if lo.size == U else (np.tile(lo, N), np.tile(hi, N))
         else:
             raise NotImplementedError(kind)
 
