@@ -16,7 +16,7 @@ def _blockdiag(M, steps, add_cols=0):
     return out
 
 
-def make(seed, batch=48, max_vars=64):
+def make(seed, batch=48, max_vars=64, shape=None):
     """-> dict(nx, nu, N, A, B, d, x0, costs, cstrs, forms, initial_state) -- forms names what was drawn (for failure messages);
     initial_state: None, or dict(R, r, x0lb, x0ub) for an InitialStateLMPC over the same pieces (tests decide whether they use it)"""
     rng = np.random.default_rng(seed)
@@ -25,6 +25,8 @@ def make(seed, batch=48, max_vars=64):
     N = int(rng.integers(2, 25))
     while nu * N > max_vars:
         N -= 1
+    if shape is not None:  # (a given (nx, nu, N): the draws above are made all the same, the structure below does not depend on them)
+        nx, nu, N = shape
     X, U = nx * (N + 1), nu * N
     forms = []
     # systems: per-instance perturbations of a contraction-ish A (spectral radius about 1), B full rank
@@ -141,7 +143,7 @@ def make(seed, batch=48, max_vars=64):
         forms.append("ubound")
     # InitialStateLMPC (drawn last: the controllers above do not depend on it): x0 a decision variable in a box around the nominal state
     ist = None
-    if rng.random() < 0.25 and nx + nu * N <= max_vars:
+    if rng.random() < 0.25 and (shape is not None or nx + nu * N <= max_vars):
         half = rng.uniform(0.05, 0.3, nx)
         ist = dict(R=np.diag(rng.uniform(0.5, 5.0, nx)), r=0.1 * rng.standard_normal(nx), x0lb=x0 - half, x0ub=x0 + half)
     return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms, initial_state=ist)

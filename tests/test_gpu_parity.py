@@ -2124,6 +2124,72 @@ def test_random_controllers_against_the_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_random_controllers_in_every_mode_of_the_engine(oracle):
+    """tools/exp/fuzz_modes.py over 96 random controllers, a sample of 24 instances each against the oracle: the shared-model mode (one
+    system for the batch, cold and warm-started, three receding-horizon ticks), per-instance cost references, per-instance right-hand
+    sides and control bounds, six receding-horizon ticks with per-instance systems (the layouts are chosen again underway) -- no solve
+    with a different status or a result more than 1e-4 away, at most 3 % of the solves between 1e-6 and 1e-4 (conditioning)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp"))
+    import fuzz_modes
+    fuzz_modes.HARD[0] = 0
+    soft = sum(fuzz_modes.run_seed(seed) for seed in range(96))
+    print("   96 controllers over four modes: %d solves beyond 1e-6, %d beyond 1e-4 or with another status" % (soft, fuzz_modes.HARD[0]))
+    assert fuzz_modes.HARD[0] == 0 and soft <= 8
+
+
+@pytest.mark.gpu
+def test_random_controllers_on_the_interior_point_kernel(oracle):
+    """tests/random_controllers.py at (nx, nu) = (12, 6), horizons 11 .. 24 (66 .. 144 variables): the shape of the LDS-resident
+    interior-point kernel on the matrix cores (BASELINE config 5), 36 random mixes of costs and constraints, each also as
+    InitialStateLMPC where the generator draws one -- statuses equal, U and X within 1e-6 of the oracle; where they are further apart
+    the certified optimum decides (for InitialStateLMPC the CPU path inverts Q explicitly and is itself up to 3e-6 away: seen on 3 of
+    150 controllers, the device 1e-11 from the optimum)."""
+    import random_controllers as RC
+    import truth
+    from copra_amd import BatchLMPC
+    ntruth = n_is = 0
+    for seed in range(36):
+        N = 11 + seed % 14
+        c = RC.make(seed, batch=24, shape=(12, 6, N))
+        ist = c["initial_state"]
+        for variant in ("lmpc", "initial-state") if ist is not None else ("lmpc",):
+            what = "seed %d %s N = %d %s" % (seed, variant, N, c["forms"])
+            if variant == "lmpc":
+                ks = np.arange(24)
+                ref = oracle.lmpc_solve_batch(c["A"], c["B"], c["d"], c["x0"], N, c["costs"], c["cstrs"], nthreads=8)
+                refs = [dict(status=ref["status"][k], control=ref["control"][k], trajectory=ref["trajectory"][k]) for k in ks]
+                eng = BatchLMPC(12, 6, N, 24, c["costs"], c["cstrs"])
+                eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+            else:
+                ks = np.arange(0, 24, 8)
+                ios = [dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k]) for k in ks]
+                refs = [oracle.lmpc_solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], N, c["costs"], c["cstrs"], initial_state=io) for k, io in zip(ks, ios)]
+                eng = BatchLMPC(12, 6, N, 24, c["costs"], c["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
+                eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+                eng.set_initial_state_bounds(ist["x0lb"], ist["x0ub"])
+                n_is += 1
+            eng.solve()
+            res = eng.results()
+            eng.close()
+            for j, k in enumerate(ks):
+                r = refs[j]
+                assert res["status"][k] == r["status"], what
+                if r["status"] != 0:
+                    continue
+                if _rel(res["control"][k], r["control"]) <= RTOL and _rel(res["trajectory"][k], r["trajectory"]) <= RTOL:
+                    continue
+                io = None if variant == "lmpc" else ios[j]
+                zg = r["control"] if io is None else np.concatenate([r["x0_opt"], r["control"]])
+                t = truth.solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], N, c["costs"], c["cstrs"], zg, initial_state=io)
+                assert _rel(res["control"][k], t["control"]) <= RTOL and _rel(res["trajectory"][k], t["trajectory"]) <= RTOL, what + " instance %d" % k
+                ntruth += 1
+    print("   36 random (12, 6) controllers, %d also as InitialStateLMPC; %d instances decided by the certified optimum" % (n_is, ntruth))
+    assert n_is >= 5 and ntruth <= 12
+
+
+@pytest.mark.gpu
 def test_random_controllers_on_the_headline_kernels(oracle):
     """tests/random_controllers.py::make_integrator: 32 random controllers on the double integrators in one, two and three dimensions
     (random horizon, costs with general M, reference trajectories, target and mixed costs, velocity / control bounds, row, mixed and
