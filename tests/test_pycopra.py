@@ -335,3 +335,61 @@ def test_reference_accumulation_switch():
         Q = k * (q1["Q"] - 1e-6 * np.eye(n)) + qu["Q"]
         want, fail, _ = pyoracle.quadprog_dense(Q, cacc + qu["c"], None, None, None, None, qu["lb"], qu["ub"])
         assert fail == 0 and np.abs(want - ctl.control()).max() <= 1e-7
+
+
+@pytest.mark.gpu
+def test_random_controllers_through_the_python_surface():
+    """tests/random_controllers.py through copra_amd.pycopra (the reference's Python classes over one-problem controllers): 80 random
+    mixes of the four cost and five constraint classes, per-step and full-size -- solve() returns what the oracle's status says, control()
+    and trajectory() within 1e-6 entry-wise (floor 1e-3); the same LMPC object then solves a second initial state (xInit, the receding-
+    horizon idiom of the reference's tests)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyoracle as oracle
+    import random_controllers as RC
+    from copra_amd import pycopra as P
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3)))
+
+    nsolved = 0
+    for seed in range(80):
+        c = RC.make(seed, batch=2)
+        N = c["N"]
+        ps = P.PreviewSystem(c["A"][0], c["B"][0], c["d"][0], c["x0"][0], N)
+        lmpc = P.LMPC(ps)
+        keep = []
+        for d in c["costs"]:
+            kind = d["kind"]
+            obj = (P.TrajectoryCost(d["M"], d["p"]) if kind == "trajectory" else P.TargetCost(d["M"], d["p"]) if kind == "target"
+                   else P.ControlCost(d["N"], d["p"]) if kind == "control" else P.MixedCost(d["M"], d["N"], d["p"]))
+            obj.weights(np.asarray(d["weights"], dtype=float))
+            lmpc.add_cost(obj)
+            keep.append(obj)
+        for d in c["cstrs"]:
+            kind = d["kind"]
+            if kind == "trajectory":
+                obj = P.TrajectoryConstraint(d["E"], d["f"], d.get("ineq", True))
+            elif kind == "control":
+                obj = P.ControlConstraint(d["G"], d["f"], d.get("ineq", True))
+            elif kind == "mixed":
+                obj = P.MixedConstraint(d["E"], d["G"], d["f"], d.get("ineq", True))
+            elif kind == "trajectory_bound":
+                obj = P.TrajectoryBoundConstraint(d["lower"], d["upper"])
+            else:
+                obj = P.ControlBoundConstraint(d["lower"], d["upper"])
+            lmpc.add_constraint(obj)
+            keep.append(obj)
+        for k in range(2):
+            if k == 1:
+                ps.x_init(c["x0"][1])
+            x0 = c["x0"][k]
+            ref = oracle.lmpc_solve(c["A"][0], c["B"][0], c["d"][0], x0, N, c["costs"], c["cstrs"])
+            ok = lmpc.solve()
+            what = "seed %d (%d, %d, %d) %s solve %d" % (seed, c["nx"], c["nu"], N, c["forms"], k)
+            assert bool(ok) == (ref["status"] == 0), what
+            if ok:
+                assert rel(np.asarray(lmpc.control()), ref["control"]) <= 1e-6 and rel(np.asarray(lmpc.trajectory()), ref["trajectory"]) <= 1e-6, what
+                nsolved += 1
+    assert nsolved >= 120
