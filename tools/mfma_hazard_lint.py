@@ -6,7 +6,8 @@ Why it exists (round 4): hipcc of ROCm 7.2 left one instruction between a v_mfma
 operand on the TAKEN side of a wave-uniform branch (the wait states had been counted on the fall-through side only); the hardware then
 multiplies with the register's previous contents.  The emulator cannot see this, the GPU tests only where scheduling happens to expose it.
 
-    python tools/mfma_hazard_lint.py [file.s ...]      (default: compiles every translation unit of copra_amd/csrc with -S)
+    python tools/mfma_hazard_lint.py --library [libcopra_hip.so]   the SHIPPED binary: code objects extracted and disassembled (seconds)
+    python tools/mfma_hazard_lint.py [file.s ...]                  compiler output (default: compiles every translation unit with -S)
 
 Wait states needed (what the compiler itself leaves in straight-line code of these kernels; s_nop N counts N + 1, every other
 instruction 1):  f64 4x4x4 -> matrix operand A/B or vector ALU read: 6, LDS / memory store data: 9;  f64 16x16x4 -> 11 resp. 18;
@@ -62,6 +63,62 @@ def parse(path):
     return kernels
 
 
+def parse_disassembly(path):
+    """llvm-objdump -d of a gfx950 code object -> the same structure as parse(): branch targets become labels 'L<address>'"""
+    kernels, cur, name = {}, None, None
+    raw = []
+    for ln, line in enumerate(open(path, errors="replace"), 1):
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:\s*$", line)
+        if m:
+            name, cur = m.group(1), ([], {})
+            kernels[name] = cur
+            raw.append((name, []))
+            continue
+        if cur is None or not line.startswith("\t"):
+            continue
+        m = re.match(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if not m:
+            continue
+        op, rest, addr = m.group(1), m.group(2), int(m.group(3), 16)
+        ops = [o.strip() for o in rest.split(",")] if rest else []
+        raw[-1][1].append((op, ops, ln, addr))
+    for name, lst in raw:
+        ins, labels = kernels[name]
+        index = {a: i for i, (_, _, _, a) in enumerate(lst)}
+        for op, ops, ln, addr in lst:
+            if (op.startswith("s_cbranch") or op == "s_branch") and ops:
+                imm = int(ops[0], 0) & 0xFFFF
+                imm -= 0x10000 if imm & 0x8000 else 0
+                tgt = addr + 4 + 4 * imm
+                lab = "L%x" % tgt
+                if tgt in index:
+                    labels[lab] = index[tgt]
+                ops = [lab]
+            ins.append((op, ops, ln))
+    return kernels
+
+
+def lint_library(so_path):
+    """the SHIPPED binary: extract the gfx950 code objects of libcopra_hip.so, disassemble, lint (seconds)"""
+    tmp = tempfile.mkdtemp(prefix="copra_lint_")
+    local = os.path.join(tmp, os.path.basename(so_path))
+    with open(so_path, "rb") as f, open(local, "wb") as g:
+        g.write(f.read())
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", os.path.basename(local)], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    found, nobj, nmfma = [], 0, 0
+    for f in sorted(os.listdir(tmp)):
+        if "amdgcn" not in f:
+            continue
+        nobj += 1
+        dis = os.path.join(tmp, f + ".dis")
+        with open(dis, "w") as out:
+            subprocess.run([objdump, "-d", f], cwd=tmp, stdout=out, stderr=subprocess.DEVNULL, check=True)
+        nmfma += sum(1 for line in open(dis, errors="replace") if "\tv_mfma" in line)
+        found += [(f,) + h for h in lint(dis, disassembly=True)]
+    return found, nobj, nmfma
+
+
 def successors(ins, labels, i):
     op, ops, _ = ins[i]
     if op == "s_endpgm":
@@ -74,9 +131,9 @@ def successors(ins, labels, i):
     return [i + 1] if i + 1 < len(ins) else []
 
 
-def lint(path):
+def lint(path, disassembly=False):
     found = []
-    for name, (ins, labels) in parse(path).items():
+    for name, (ins, labels) in (parse_disassembly(path) if disassembly else parse(path)).items():
         for i, (op, ops, ln) in enumerate(ins):
             if not op.startswith("v_mfma"):
                 continue
@@ -117,6 +174,13 @@ def lint(path):
 def main():
     files = sys.argv[1:]
     tmp = None
+    if files and files[0] == "--library":
+        so = files[1] if len(files) > 1 else os.path.join(CSRC, "libcopra_hip.so")
+        hits, nobj, nmfma = lint_library(so)
+        for f, name, ln, op, ln2, o2, waited, need in hits:
+            print("%s: %s\n    line %d %s -> line %d %s after %d wait state(s) on a path across a branch (needs %d)" % (f, name[:90], ln, op, ln2, o2, waited, need))
+        print("%s: %d code object(s), %d matrix instructions, %d finding(s)" % (os.path.basename(so), nobj, nmfma, len(hits)))
+        return 1 if hits else 0
     if not files:
         tmp = tempfile.mkdtemp(prefix="copra_lint_")
         srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
