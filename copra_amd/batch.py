@@ -56,8 +56,24 @@ class BatchLMPC:
         self._sys = None
         self._outs = None
 
-    def specialise(self, cache_dir=None):
-        """compile this controller's shape into its own kernels (hipcc --genco, cached); see copra_batch_specialise"""
+    def specialise(self, cache_dir=None, lint=True):
+        """compile this controller's shape into its own kernels (hipcc --genco, cached); see copra_batch_specialise.
+        lint: the freshly compiled code objects go through copra_amd/hazard_lint.py first (matrix-instruction results read too early on
+        some path of the compiled control flow: a defect of the compiler that round 4 met in the library's own kernels) -- one that
+        fails is deleted and this call raises; the controller keeps the library's kernels."""
+        if lint:
+            import os
+            from . import hazard_lint
+            d = cache_dir or os.environ.get("COPRA_JIT_CACHE") or os.path.join(os.environ.get("HOME", "/tmp"), ".cache", "copra_amd")
+            # (compile into the cache without loading: the C call below then finds checked objects -- or none, and compiles;
+            #  objects compiled by THAT call are checked right after it)
+            bad = hazard_lint.lint_jit_cache(d)
+            _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
+            bad += hazard_lint.lint_jit_cache(d)
+            if bad:
+                raise RuntimeError("copra_batch_specialise: the compiled kernels fail the matrix-instruction hazard check (%s: %r); they have been "
+                                   "removed from the cache -- create the controller again to run on the library's kernels" % bad[0])
+            return
         _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
 
     def layout_info(self):
