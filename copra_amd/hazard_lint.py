@@ -126,8 +126,16 @@ def lint_code_object(path):
     """one gfx950 code object (e.g. what copra_batch_specialise compiled at run time) -> findings"""
     tmp = tempfile.mkdtemp(prefix="copra_lint_")
     dis = os.path.join(tmp, os.path.basename(path) + ".dis")
+    obj = os.path.abspath(path)
+    with open(obj, "rb") as f:
+        bundled = f.read(24).startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+    if bundled:  # (what hipcc --genco writes: host stub + device code object)
+        raw = os.path.join(tmp, os.path.basename(path) + ".co")
+        subprocess.run([os.path.join(os.path.dirname(OBJDUMP), "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + obj, "--output=" + raw], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        obj = raw
     with open(dis, "w") as out:
-        subprocess.run([OBJDUMP, "-d", os.path.abspath(path)], stdout=out, stderr=subprocess.DEVNULL, check=True)
+        subprocess.run([OBJDUMP, "-d", obj], stdout=out, stderr=subprocess.DEVNULL, check=True)
     return lint(dis, disassembly=True)
 
 
