@@ -3,7 +3,7 @@
    refs      per-instance cost references (copra_batch_set_cost_reference) for every cost that has a per-step p
    rhs       per-instance right-hand sides of the row constraints and per-instance control bounds
    ticks     six receding-horizon ticks (x0 <- x_1 of the previous solution): layouts are re-chosen underway
-python tools/exp/fuzz_modes.py first count"""
+python tests/fuzz/fuzz_modes.py first count"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 """Random controllers with copra_batch_specialise (run-time compiled kernels for the controller's shape: hipcc on this box) against the
 oracle -- shapes the library has no compile-time instantiation for, incl. the Riccati-factor tier where take_ric_layout grants it.
-python tools/exp/fuzz_specialise.py first count"""
+python tests/fuzz/fuzz_specialise.py first count"""
 import os
 import sys
 import tempfile

@@ -1,5 +1,5 @@
 """Random controllers (tests/random_controllers.py) on the device against the oracle: statuses, U, X (entry-wise, floor 1e-3), iteration
-counters.  python tools/exp/fuzz_vs_oracle.py [first_seed] [count] [batch]"""
+counters.  python tests/fuzz/fuzz_vs_oracle.py [first_seed] [count] [batch]"""
 import os
 import sys
 

@@ -2125,13 +2125,13 @@ def test_random_controllers_against_the_oracle(oracle):
 
 @pytest.mark.gpu
 def test_random_controllers_in_every_mode_of_the_engine(oracle):
-    """tools/exp/fuzz_modes.py over 96 random controllers, a sample of 24 instances each against the oracle: the shared-model mode (one
+    """tests/fuzz/fuzz_modes.py over 96 random controllers, a sample of 24 instances each against the oracle: the shared-model mode (one
     system for the batch, cold and warm-started, three receding-horizon ticks), per-instance cost references, per-instance right-hand
     sides and control bounds, six receding-horizon ticks with per-instance systems (the layouts are chosen again underway) -- no solve
     with a different status or a result more than 1e-4 away, at most 3 % of the solves between 1e-6 and 1e-4 (conditioning)."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_modes
     fuzz_modes.HARD[0] = 0
     soft = sum(fuzz_modes.run_seed(seed) for seed in range(96))
