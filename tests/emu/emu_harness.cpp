@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <ucontext.h>
+#include <csetjmp>
 #include <algorithm>
 #include <vector>
 
@@ -40,7 +41,24 @@ namespace emu {
     static unsigned g_wait_gen[kMaxThreads];
     static unsigned long g_progress;
 
-    static void yield() { swapcontext(&g_fiber[g_wave.lane], &g_sched); }
+    // Switching: swapcontext saves and restores the signal mask -- a system call per switch, two thirds of the emulator's run time.  A fiber
+    // is ENTERED once through its ucontext (its own stack); every later switch is _setjmp / _longjmp, which touch registers only.
+    static jmp_buf g_sched_jb;
+    static jmp_buf g_fiber_jb[kMaxThreads];
+    static bool g_started[kMaxThreads];
+    static void yield()
+    {
+        if (!_setjmp(g_fiber_jb[g_wave.lane])) _longjmp(g_sched_jb, 1);
+    }
+    static void resume(int l) // scheduler -> fiber l, back at its next yield
+    {
+        if (_setjmp(g_sched_jb)) return;
+        if (!g_started[l]) {
+            g_started[l] = true;
+            setcontext(&g_fiber[l]);
+        }
+        _longjmp(g_fiber_jb[l], 1);
+    }
 
     void barrier_block()
     {
@@ -76,7 +94,7 @@ namespace emu {
         (*g_body)();
         g_done[g_wave.lane] = true;
         ++g_progress;
-        swapcontext(&g_fiber[g_wave.lane], &g_sched);
+        _longjmp(g_sched_jb, 1);
     }
 
     // run one workgroup of `nthreads` threads to completion
@@ -96,6 +114,7 @@ namespace emu {
         for (int w = 0; w < nthreads / 64; ++w) g_wv_count[w] = 0;
         for (int l = 0; l < nthreads; ++l) {
             g_done[l] = false;
+            g_started[l] = false;
             g_wait_kind[l] = 0;
             getcontext(&g_fiber[l]);
             g_fiber[l].uc_stack.ss_sp = stacks.data() + (size_t)l * stack_sz;
@@ -119,7 +138,7 @@ namespace emu {
                 if (g_wait_kind[l] == 2 && g_wait_gen[l] == g_wv_gen[l >> 6]) continue;
                 g_wait_kind[l] = 0;
                 g_wave.lane = l;
-                swapcontext(&g_sched, &g_fiber[l]);
+                resume(l);
             }
             if (ndone == nthreads) return 0;
             if (g_progress == before) {
