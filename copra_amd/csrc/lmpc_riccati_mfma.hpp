@@ -903,7 +903,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 step_inf = fmax(step_inf, fabs(dz));
                 z_inf = fmax(z_inf, fabs(zn));
             }
-            step_inf = wave_max(step_inf) * alpha;
+            step_inf = wave_max(step_inf); // (the FULL Newton step: lmpc_riccati.hpp)
             z_inf = wave_max(z_inf);
             wave_sync();
             const double mu_new = wave_sum(musum2) * inv_mi;

@@ -1328,7 +1328,7 @@ def test_lane_pass_in_half_waves(emu, oracle, monkeypatch, b):
     assert np.array_equal(r32["control"][ok], r64["control"][ok])  # (the same arithmetic per instance: bit for bit)
 
 
-@pytest.mark.parametrize("first", [0, 12, 24])
+@pytest.mark.parametrize("first", [0, 12, 24, 36, 48, 60, 72, 84])
 def test_random_controllers_against_the_oracle(emu, oracle, first):
     """tests/random_controllers.py: random shapes (nx 1..7, nu 1..3, N 2..24), random per-instance systems and a random mix of the four
     cost classes and five constraint classes as per-step and as full-size entries -- the kernel bodies against the oracle: statuses equal,
@@ -1347,3 +1347,46 @@ def test_random_controllers_against_the_oracle(emu, oracle, first):
         ndiff += int((re["iter"][ok] != ro["iter"][ok]).any(axis=1).sum())  # (status 0: an infeasible exit is reached through multipliers at
         ninst += int(ok.sum())  #  rounding level, where the drop counters of two arithmetics differ)
     assert ndiff <= ninst // 16
+
+
+@pytest.mark.parametrize("first", [0, 6, 12])
+def test_random_integrator_controllers_on_the_headline_kernels(emu, oracle, first):
+    """tests/random_controllers.py::make_integrator in the emulator, 70 instances each (the one-instance-per-lane pass runs in front of the
+    Riccati-factor tier from 64 instances on; general rows take the tier's own sweep): statuses, both iteration counters, U and X."""
+    import random_controllers as RC
+    for seed in range(first, first + 6):
+        c = RC.make_integrator(seed, 70)
+        ro = oracle.lmpc_solve_batch(c["A"], c["B"], c["d"], c["x0"], c["N"], c["costs"], c["cstrs"], nthreads=4)
+        re = emu.lmpc_solve(c["A"], c["B"], c["d"], c["x0"], c["N"], c["costs"], c["cstrs"])
+        what = "seed %d (%d, %d, %d) %s" % (seed, c["nx"], c["nu"], c["N"], c["forms"])
+        ok = ro["status"] == 0
+        assert (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all(), what
+        assert _rel(re["control"][ok], ro["control"][ok]) <= RTOL and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= RTOL, what
+
+
+@pytest.mark.parametrize("shape", [(12, 6), (5, 3), (4, 2)])
+def test_random_controllers_on_the_interior_point_kernels(emu, oracle, shape):
+    """beyond 64 variables: the stage-wise interior-point kernels (lmpc_riccati_mfma.hpp for (12, 6), lmpc_riccati.hpp otherwise) on random
+    controllers -- an instance the kernel accepts (status 0; the others go to the Goldfarb-Idnani kernel on the device) is within 1e-6 of the
+    certified optimum where it is further than that from the oracle"""
+    import random_controllers as RC
+    import truth
+    nx, nu = shape
+    naccepted = 0
+    for seed in range(8):
+        N = 64 // nu + 1 + seed
+        c = RC.make(seed, batch=2, shape=(nx, nu, N))
+        ro = oracle.lmpc_solve_batch(c["A"], c["B"], c["d"], c["x0"], N, c["costs"], c["cstrs"])
+        re = emu.lmpc_solve_riccati(c["A"], c["B"], c["d"], c["x0"], N, c["costs"], c["cstrs"])
+        if re is None:  # (not stage-wise -- a cost row that couples the steps: the controller runs on the Goldfarb-Idnani kernels)
+            continue
+        for k in range(2):
+            if re["status"][k] != 0:
+                continue
+            assert ro["status"][k] == 0, (shape, seed, k)
+            naccepted += 1
+            if _rel(re["control"][k], ro["control"][k]) <= RTOL and _rel(re["trajectory"][k], ro["trajectory"][k]) <= RTOL:
+                continue
+            t = truth.solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], N, c["costs"], c["cstrs"], ro["control"][k])
+            assert _rel(re["control"][k], t["control"]) <= RTOL and _rel(re["trajectory"][k], t["trajectory"]) <= RTOL, (shape, seed, k, c["forms"])
+    assert naccepted >= 2  # (the interior-point iteration breaks down on many RANDOM controllers: those go to the other kernel)
