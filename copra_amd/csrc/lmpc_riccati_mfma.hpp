@@ -761,7 +761,8 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             return fl == kRfEq ? az - Fr[j] : az + Sv[j] - Fr[j];
         };
         int it = 0;
-        double prev_step = 1.0e300; // the step before (ric_converged: contraction of the last two steps)
+        double prev_step = 1.0e300; // the step before
+        bool tail_ok = false; // ric_tail_ok of the iterate the loop stands on (lmpc_riccati.hpp)
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -798,7 +799,10 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             // ---- sweep 1 (backward): factorisation and the predictor's right-hand side
             good = sweep1(true, x0_free) && good;
             stamp_outer(2);
-            if (!good) break;
+            if (!good) { // (the factorisation broke down; the iterate itself is untouched: ric_tail_ok)
+                converged = tail_ok;
+                break;
+            }
             // ---- predictor: forward sweep, then the rows in bulk
             good = solve_x0() && good;
             stamp_outer(3);
@@ -917,6 +921,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e eq %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, maxe, step_inf, z_inf);
 #endif
             const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf);
+            tail_ok = ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
             prev_step = step_inf;
             if (conv) {
                 converged = true;
