@@ -51,6 +51,11 @@ COPRA_DEV bool ric_converged(const StagePlan& S, double res, double mu, double s
 // lost 8 of 16 384 instances to the Goldfarb-Idnani kernel that way, 100 ms for them).  If that happens right after an iterate whose barrier
 // was gone (mu <= 1e-15) and whose last two steps contracted superlinearly (r = step / prev <= 0.05, step r <= 1e-6 (1 + z)), that
 // iterate is taken -- the one case in which the step test above cannot be waited for.
+// Crossover (lmpc_riccati.hpp, the streaming kernel): once mu <= kRicSwitchMu the rows with lam > s become regularised equality rows, the
+// others are switched off, and the iteration finishes as Newton's method on that equality-constrained QP; the result is accepted if the
+// multipliers of the former come out non-negative and the latter come out satisfied (else: the Goldfarb-Idnani kernel).
+constexpr double kRicSwitchMu = 1e-10;
+constexpr double kRicWasActive = -1.0, kRicWasIdle = -2.0; // markers in the slack array of rows that the crossover converted
 COPRA_DEV bool ric_tail_ok(double res, double mu, double step, double prev, double z)
 {
     return res <= 1e-9 && mu <= 1e-15 && step <= 0.05 * prev && step * (step / prev) <= 1e-6 * (1.0 + z);
@@ -547,6 +552,8 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         int it = 0;
         double prev_step = 1.0e300; // the step before
         bool tail_ok = false; // ric_tail_ok of the iterate the loop stands on
+        bool polishing = false; // after the crossover (below): active rows as equalities, the others off
+        int polish_it = 0;
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
             // ---- sweep 1 (backward): residuals, barrier weights, factorisation, predictor right-hand side
@@ -1008,8 +1015,32 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(COPRA_EMU_TRACE)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, step_inf, z_inf);
 #endif
-            const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf);
-            tail_ok = ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
+            if (!polishing && n_ineq > 0 && res_new <= 1e-9 && mu_new <= kRicSwitchMu) {
+                // ---- crossover: the barrier has told which rows are active (lam > s).  From here on those are EQUALITY rows of the
+                // regularised kind (weight 1 / delta, an explicit multiplier), the others are off: Newton's method on an equality-
+                // constrained QP, whose factorisations carry weights of 1e6 instead of the barrier's 1e16 -- see ric_converged.
+                for (int gi = lane; gi < m; gi += kWave)
+                    if ((int)Flag[gi] == kRowIneq) {
+                        if (Lam[gi] > Sv[gi]) {
+                            Flag[gi] = (double)kRowEq;
+                            Sv[gi] = kRicWasActive; // (marker: an inequality row held as an equality -- its multiplier must come out >= 0)
+                        } else {
+                            Flag[gi] = (double)kRowOff;
+                            Sv[gi] = kRicWasIdle; // (marker: an inequality row left out -- it must come out satisfied)
+                            Lam[gi] = 0.0;
+                        }
+                    }
+                wave_sync_full();
+                polishing = true;
+                prev_step = 1.0e300;
+                tail_ok = false;
+                continue;
+            }
+            // (after the crossover at least two steps: the first one removes the residuals of the new equality rows, the multipliers
+            //  they inherited -- right to 1e-5 -- are corrected by the second)
+            polish_it += polishing ? 1 : 0;
+            const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf) && (!polishing || polish_it >= 2);
+            tail_ok = !polishing && ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
             prev_step = step_inf;
             if (conv) {
                 converged = true;
@@ -1017,57 +1048,34 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             }
         }
 
-        // ------------------------------------------------------------------ 2b. the accepted point against the optimality conditions
-        // Rows feasible, multipliers positive and complementary, the Newton step at rounding level: what the iteration still cannot vouch
-        // for is STATIONARITY.  Its Newton systems carry weights lam / s of 1e16 at the end, and a state row with such a weight takes the
-        // curvature of every direction it touches with it in the Riccati recursion: the computed step is zero there whatever the gradient
-        // (random controllers of the differential test: steps down to 4e-13 at a point 3e-4 (entry-wise) from the optimum, a bound that
-        // should be active left 2.6e-5 inside).  The gradient of the Lagrangian is made of O(1) quantities: one adjoint sweep
-        //     gamma_k = W_k z_k + q_k + sum_rows a lam,   r_k = gamma_k,u + B' pi_{k+1},   pi_k = gamma_k,x + A' pi_{k+1}
-        // and the instance goes to the Goldfarb-Idnani kernel unless |r| <= 1e-9 (1 + |gamma|) at every stage (and |pi_0| for a free x0).
-        // The test errs on the safe side: the multipliers of active rows have slacks of 1e-20 behind them and are themselves uncertain
-        // at the 1e-3 level, so it also turns away instances that HAVE converged (one of two of config 5 in this kernel) -- they cost the
-        // other kernel's time, not accuracy.  (lmpc_riccati_mfma.hpp, the kernel config 5 runs on, has no such test: its fixed-width
-        //  tables take controllers whose rows are bounds and two-term rows, and 280 random ones were all within 1e-6 of the certified optimum.)
-        if (converged) {
-            rollout(); // trajectory = Phi x0 + Psi U + xi, recomputed from the final x0 and U
-            double worst = 0.0, gmax = 0.0;
-            for (int i = lane; i < nx; i += kWave) L.pv[i] = 0.0;
-            for (int k = N; k >= 0; --k) {
+        // ------------------------------------------------------------------ 2b. was the crossover's active set the right one?
+        // The iteration has finished as Newton's method on the equality-constrained QP the crossover set up (weights 1e6: the
+        // factorisations are accurate, the steps went to rounding level, the multipliers are explicit).  Its solution is THE optimum iff
+        // every inequality row that was held as an equality pushes (multiplier >= 0) and every one that was left out is satisfied; an
+        // instance that fails goes to the Goldfarb-Idnani kernel.
+        // (Rounds 2-3 let the barrier run to mu = 1e-15 instead; with weights lam / s of 1e16 a state row takes the curvature of every
+        //  direction it touches with it in the Riccati recursion and the computed step is zero there whatever the gradient: the random
+        //  differential tests met iterates whose steps were 4e-13 at a point 3e-4 (entry-wise) from the optimum, a bound that should have
+        //  been active left 2.6e-5 inside.  A check of the stationarity by an adjoint sweep was tried in between: with multipliers that
+        //  sit on slacks of 1e-20, and gradients that unstable dynamics amplify by 2^N, it turned away converged instances.)
+        if (converged && polishing) {
+            double wrong = 0.0;
+            for (int k = 0; k <= N; ++k) {
                 const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
                 load_class(c);
                 for (int e = lane; e < nz; e += kWave) L.zk[e] = (k == N && e >= nx) ? 0.0 : Z[k * nz + e];
                 wave_sync();
                 for (int r = lane; r < nr; r += kWave) {
                     const int gi = gi0 + r, fl = (int)Flag[gi];
-                    double lv = 0.0;
-                    if (fl == kRowIneq) lv = Lam[gi];
-                    if (fl == kRowEq) lv = Lam[gi] + (row_dot(r, nd, L.zk) - F[gi]) / delta; // (the multiplier the regularised row stands for)
-                    L.rowC[r] = lv;
+                    if (fl == kRowEq && Sv[gi] == kRicWasActive) { // held: it must push
+                        const double lv = Lam[gi] + (row_dot(r, nd, L.zk) - F[gi]) / delta; // (the multiplier the regularised row stands for)
+                        if (!(lv >= -1e-9 * (1.0 + fabs(Lam[gi])))) wrong = 1.0;
+                    }
+                    if (fl == kRowOff && Sv[gi] == kRicWasIdle && !(row_dot(r, nd, L.zk) - F[gi] <= 1e-9 * (1.0 + fabs(F[gi])))) wrong = 1.0; // left out: it must hold
                 }
-                wave_sync();
-                stage_gradient(k, true, true);
-                wave_sync();
-                for (int i = lane; i < nz; i += kWave) {
-                    double acc = L.g[i];
-                    gmax = fmax(gmax, fabs(GB[k * nz + i]));
-                    if (k < N)
-                        for (int l = 0; l < nx; ++l) acc += L.AB[l + nx * i] * L.pv[l];
-                    L.h[i] = acc;
-                    if ((i >= nx && k < N) || (i < nx && k == 0 && x0_free)) worst = fmax(worst, fabs(acc));
-                }
-                wave_sync();
-                for (int i = lane; i < nx; i += kWave) L.pv[i] = L.h[i];
                 wave_sync();
             }
-            worst = wave_max(worst);
-            gmax = wave_max(gmax);
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(COPRA_EMU_TRACE)
-            if (lane == 0) fprintf(stderr, "      stationarity %.3e (gradient scale %.3e)\n", worst, gmax);
-#endif
-#if !defined(COPRA_EMU_KEEP_UNCHECKED) // (experiments with the emulator: what would have been accepted without the check)
-            if (!(worst <= 1e-9 * (1.0 + gmax))) converged = false;
-#endif
+            if (wave_max(wrong) > 0.0) converged = false;
         }
         // ------------------------------------------------------------------ 3. results (LMPC.cpp:282-286)
         if (converged) {
