@@ -51,11 +51,15 @@ COPRA_DEV bool ric_converged(const StagePlan& S, double res, double mu, double s
 // lost 8 of 16 384 instances to the Goldfarb-Idnani kernel that way, 100 ms for them).  If that happens right after an iterate whose barrier
 // was gone (mu <= 1e-15) and whose last two steps contracted superlinearly (r = step / prev <= 0.05, step r <= 1e-6 (1 + z)), that
 // iterate is taken -- the one case in which the step test above cannot be waited for.
-// Crossover (lmpc_riccati.hpp, the streaming kernel): once mu <= kRicSwitchMu the rows with lam > s become regularised equality rows, the
-// others are switched off, and the iteration finishes as Newton's method on that equality-constrained QP; the result is accepted if the
-// multipliers of the former come out non-negative and the latter come out satisfied (else: the Goldfarb-Idnani kernel).
+// Crossover (both kernels): once mu <= kRicSwitchMu the rows with lam > s become regularised equality rows, the others are switched off,
+// and the iteration finishes as Newton's method on that equality-constrained QP.  Its solution is the optimum iff every held row pushes
+// (multiplier >= 0) and every row left out is satisfied: a held row that pulls is released, a row left out that is violated is taken, and
+// the iteration goes on on the corrected set -- at most kRicRefinements rounds, then the Goldfarb-Idnani kernel.  The factorisations never
+// see a weight above 1e11 (the barrier's reach 1e16 at mu = 1e-18: a state row with such a weight takes the curvature of every direction
+// it touches with it in the Riccati recursion, and the iteration stalls off the optimum or breaks down).
 constexpr double kRicSwitchMu = 1e-10;
 constexpr double kRicWasActive = -1.0, kRicWasIdle = -2.0; // markers in the slack array of rows that the crossover converted
+constexpr int kRicRefinements = 6; // rounds of "release what pulls, take what is violated" after the crossover before the instance is given up
 COPRA_DEV bool ric_tail_ok(double res, double mu, double step, double prev, double z)
 {
     return res <= 1e-9 && mu <= 1e-15 && step <= 0.05 * prev && step * (step / prev) <= 1e-6 * (1.0 + z);
@@ -553,7 +557,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
         double prev_step = 1.0e300; // the step before
         bool tail_ok = false; // ric_tail_ok of the iterate the loop stands on
         bool polishing = false; // after the crossover (below): active rows as equalities, the others off
-        int polish_it = 0;
+        int polish_it = 0, refinements = 0;
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
             // ---- sweep 1 (backward): residuals, barrier weights, factorisation, predictor right-hand side
@@ -1039,8 +1043,49 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             // (after the crossover at least two steps: the first one removes the residuals of the new equality rows, the multipliers
             //  they inherited -- right to 1e-5 -- are corrected by the second)
             polish_it += polishing ? 1 : 0;
-            const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf) && (!polishing || polish_it >= 2);
+            bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf) && (!polishing || polish_it >= 2);
             tail_ok = !polishing && ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
+            if (conv && polishing) {
+                // ---- was the active set the right one?  The solution of the equality-constrained QP is THE optimum iff every held row pushes
+                // (multiplier >= 0) and every row left out is satisfied.  A held row that pulls is released, a row left out that is violated
+                // is taken, and the iteration goes on on the corrected set -- at most kRicRefinements times, then the Goldfarb-Idnani kernel.
+                double flips = 0.0;
+                for (int k = 0; k <= N; ++k) {
+                    const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
+                    load_class(c);
+                    for (int e = lane; e < nz; e += kWave) L.zk[e] = (k == N && e >= nx) ? 0.0 : Z[k * nz + e];
+                    wave_sync();
+                    for (int r = lane; r < nr; r += kWave) {
+                        const int gi = gi0 + r, fl = (int)Flag[gi];
+                        if (fl == kRowEq && Sv[gi] == kRicWasActive) {
+                            const double lv = Lam[gi] + (row_dot(r, nd, L.zk) - F[gi]) / delta; // (the multiplier the regularised row stands for)
+                            if (!(lv >= -1e-9 * (1.0 + fabs(Lam[gi])))) {
+                                Flag[gi] = (double)kRowOff;
+                                Sv[gi] = kRicWasIdle;
+                                Lam[gi] = 0.0;
+                                flips += 1.0;
+                            }
+                        } else if (fl == kRowOff && Sv[gi] == kRicWasIdle && !(row_dot(r, nd, L.zk) - F[gi] <= 1e-9 * (1.0 + fabs(F[gi])))) {
+                            Flag[gi] = (double)kRowEq;
+                            Sv[gi] = kRicWasActive;
+                            Lam[gi] = 0.0;
+                            flips += 1.0;
+                        }
+                    }
+                    wave_sync();
+                }
+                wave_sync_full();
+                if (wave_sum(flips) > 0.0) {
+                    refinements += 1;
+                    if (refinements > kRicRefinements) {
+                        good = false;
+                        break;
+                    }
+                    polish_it = 0;
+                    prev_step = 1.0e300;
+                    conv = false;
+                }
+            }
             prev_step = step_inf;
             if (conv) {
                 converged = true;
@@ -1048,35 +1093,12 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             }
         }
 
-        // ------------------------------------------------------------------ 2b. was the crossover's active set the right one?
-        // The iteration has finished as Newton's method on the equality-constrained QP the crossover set up (weights 1e6: the
-        // factorisations are accurate, the steps went to rounding level, the multipliers are explicit).  Its solution is THE optimum iff
-        // every inequality row that was held as an equality pushes (multiplier >= 0) and every one that was left out is satisfied; an
-        // instance that fails goes to the Goldfarb-Idnani kernel.
-        // (Rounds 2-3 let the barrier run to mu = 1e-15 instead; with weights lam / s of 1e16 a state row takes the curvature of every
+        // (2b of earlier versions -- the check of the crossover's active set -- now happens inside the loop, where a wrong guess is corrected.
+        //  History: rounds 2-3 let the barrier run to mu = 1e-15; with weights lam / s of 1e16 a state row takes the curvature of every
         //  direction it touches with it in the Riccati recursion and the computed step is zero there whatever the gradient: the random
-        //  differential tests met iterates whose steps were 4e-13 at a point 3e-4 (entry-wise) from the optimum, a bound that should have
-        //  been active left 2.6e-5 inside.  A check of the stationarity by an adjoint sweep was tried in between: with multipliers that
-        //  sit on slacks of 1e-20, and gradients that unstable dynamics amplify by 2^N, it turned away converged instances.)
-        if (converged && polishing) {
-            double wrong = 0.0;
-            for (int k = 0; k <= N; ++k) {
-                const int c = S.cls_of_stage[k], nr = S.cls_row0[c + 1] - S.cls_row0[c], nd = S.cls_ndense[c], gi0 = S.stage_row0[k];
-                load_class(c);
-                for (int e = lane; e < nz; e += kWave) L.zk[e] = (k == N && e >= nx) ? 0.0 : Z[k * nz + e];
-                wave_sync();
-                for (int r = lane; r < nr; r += kWave) {
-                    const int gi = gi0 + r, fl = (int)Flag[gi];
-                    if (fl == kRowEq && Sv[gi] == kRicWasActive) { // held: it must push
-                        const double lv = Lam[gi] + (row_dot(r, nd, L.zk) - F[gi]) / delta; // (the multiplier the regularised row stands for)
-                        if (!(lv >= -1e-9 * (1.0 + fabs(Lam[gi])))) wrong = 1.0;
-                    }
-                    if (fl == kRowOff && Sv[gi] == kRicWasIdle && !(row_dot(r, nd, L.zk) - F[gi] <= 1e-9 * (1.0 + fabs(F[gi])))) wrong = 1.0; // left out: it must hold
-                }
-                wave_sync();
-            }
-            if (wave_max(wrong) > 0.0) converged = false;
-        }
+        //  differential tests met iterates whose steps were 4e-13 at a point 3e-4 (entry-wise) from the optimum, a bound that should have been
+        //  active left 2.6e-5 inside.  A check of the stationarity by an adjoint sweep was tried in between: with multipliers that sit on
+        //  slacks of 1e-20, and gradients that unstable dynamics amplify by 2^N, it turned away converged instances.)
         // ------------------------------------------------------------------ 3. results (LMPC.cpp:282-286)
         if (converged) {
             for (int e = lane; e < N * nu; e += kWave) {

@@ -763,6 +763,8 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
         int it = 0;
         double prev_step = 1.0e300; // the step before
         bool tail_ok = false; // ric_tail_ok of the iterate the loop stands on (lmpc_riccati.hpp)
+        bool polishing = false;
+        int polish_it = 0, refinements = 0;
         bool converged = false;
         for (it = 1; it <= S.max_iter && good; ++it) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -920,8 +922,56 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(COPRA_EMU_TRACE)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e eq %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, maxe, step_inf, z_inf);
 #endif
-            const bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf);
-            tail_ok = ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
+            if (!polishing && n_ineq > 0 && res_new <= 1e-9 && mu_new <= kRicSwitchMu) { // crossover: lmpc_riccati.hpp
+#pragma unroll
+                for (int j = 0; j < MR; ++j) {
+                    const int gi = 64 * j + lane;
+                    if (gi < m && (rinf[j] >> 28) == kRfIneq) {
+                        const bool active = Lam[j] > Sv[j];
+                        rinf[j] = (rinf[j] & 0x0FFFFFFF) | ((active ? kRfEq : kRfOff) << 28);
+                        Sv[j] = active ? kRicWasActive : kRicWasIdle;
+                        Lam[j] = active ? Lam[j] : 0.0;
+                    }
+                }
+                polishing = true;
+                prev_step = 1.0e300;
+                tail_ok = false;
+                continue;
+            }
+            polish_it += polishing ? 1 : 0;
+            bool conv = ric_converged(S, res_new, mu_new, step_inf, prev_step, z_inf) && (!polishing || polish_it >= 2);
+            tail_ok = !polishing && ric_tail_ok(res_new, mu_new, step_inf, prev_step, z_inf);
+            if (conv && polishing) { // was the active set the right one?  A held row that pulls is released, a row left out that is violated is taken
+                double flips = 0.0;
+#pragma unroll
+                for (int j = 0; j < MR; ++j) {
+                    const int gi = 64 * j + lane, fl = rinf[j] >> 28;
+                    if (gi < m && fl == kRfEq && Sv[j] == kRicWasActive) {
+                        const double lv = Lam[j] + (row_dot(rinf[j], L.X) - Fr[j]) / delta;
+                        if (!(lv >= -1e-9 * (1.0 + fabs(Lam[j])))) {
+                            rinf[j] = (rinf[j] & 0x0FFFFFFF) | (kRfOff << 28);
+                            Sv[j] = kRicWasIdle;
+                            Lam[j] = 0.0;
+                            flips += 1.0;
+                        }
+                    } else if (gi < m && fl == kRfOff && Sv[j] == kRicWasIdle && !(row_dot(rinf[j], L.X) - Fr[j] <= 1e-9 * (1.0 + fabs(Fr[j])))) {
+                        rinf[j] = (rinf[j] & 0x0FFFFFFF) | (kRfEq << 28);
+                        Sv[j] = kRicWasActive;
+                        Lam[j] = 0.0;
+                        flips += 1.0;
+                    }
+                }
+                if (wave_sum(flips) > 0.0) { // another round on the corrected set (at most kRicRefinements of them)
+                    refinements += 1;
+                    if (refinements > kRicRefinements) {
+                        good = false;
+                        break;
+                    }
+                    polish_it = 0;
+                    prev_step = 1.0e300;
+                    conv = false;
+                }
+            }
             prev_step = step_inf;
             if (conv) {
                 converged = true;
