@@ -57,6 +57,8 @@ COPRA_DEV bool ric_converged(const StagePlan& S, double res, double mu, double s
 // the iteration goes on on the corrected set -- at most kRicRefinements rounds, then the Goldfarb-Idnani kernel.  The factorisations never
 // see a weight above 1e11 (the barrier's reach 1e16 at mu = 1e-18: a state row with such a weight takes the curvature of every direction
 // it touches with it in the Riccati recursion, and the iteration stalls off the optimum or breaks down).
+// (measured on config 5, 16 384 instances: crossover at 1e-10: 13.97 Newton steps, none given up; at 1e-8: 14.37 and 22 given up -- more
+//  wrong guesses to correct; at 1e-6: 15.11 and 271)
 constexpr double kRicSwitchMu = 1e-10;
 constexpr double kRicWasActive = -1.0, kRicWasIdle = -2.0; // markers in the slack array of rows that the crossover converted
 constexpr int kRicRefinements = 6; // rounds of "release what pulls, take what is violated" after the crossover before the instance is given up
