@@ -60,6 +60,7 @@ COPRA_DEV bool ric_converged(const StagePlan& S, double res, double mu, double s
 // (measured on config 5, 16 384 instances: crossover at 1e-10: 13.97 Newton steps, none given up; at 1e-8: 14.37 and 22 given up -- more
 //  wrong guesses to correct; at 1e-6: 15.11 and 271)
 constexpr double kRicSwitchMu = 1e-10;
+constexpr double kRicEarlySwitchMu = 1e-5; // ... or earlier when the factorisation under the barrier breaks down (both kernels)
 constexpr double kRicWasActive = -1.0, kRicWasIdle = -2.0; // markers in the slack array of rows that the crossover converted
 constexpr int kRicRefinements = 6; // rounds of "release what pulls, take what is violated" after the crossover before the instance is given up
 COPRA_DEV bool ric_tail_ok(double res, double mu, double step, double prev, double z)
@@ -553,6 +554,23 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             wave_sync_full();
         }
 
+        // ---- crossover: the barrier has told which rows are active (lam > s).  From there on those are EQUALITY rows of the regularised
+        // kind (weight 1 / delta, an explicit multiplier), the others are off: Newton's method on an equality-constrained QP, whose
+        // factorisations carry weights of 1e6 instead of the barrier's 1e16 -- see ric_converged.
+        auto cross_over = [&]() {
+            for (int gi = lane; gi < m; gi += kWave)
+                if ((int)Flag[gi] == kRowIneq) {
+                    if (Lam[gi] > Sv[gi]) {
+                        Flag[gi] = (double)kRowEq;
+                        Sv[gi] = kRicWasActive; // (marker: an inequality row held as an equality -- its multiplier must come out >= 0)
+                    } else {
+                        Flag[gi] = (double)kRowOff;
+                        Sv[gi] = kRicWasIdle; // (marker: an inequality row left out -- it must come out satisfied)
+                        Lam[gi] = 0.0;
+                    }
+                }
+            wave_sync_full();
+        };
         stamp(0);
         // ------------------------------------------------------------------ 2. Newton iterations
         int it = 0;
@@ -676,6 +694,16 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             const double mu = wave_sum(musum) * inv_mi;
             const double maxres = wave_max(maxr);
             if (!good) { // (the factorisation broke down; the iterate itself is untouched)
+                // ... under barrier weights that are large already (mu small, rows feasible): cross over HERE instead of giving the
+                // instance up -- wrong guesses about weakly active rows are corrected afterwards like any others
+                if (!polishing && n_ineq > 0 && maxres <= 1e-9 && mu <= kRicEarlySwitchMu && it > 1) {
+                    cross_over();
+                    polishing = true;
+                    good = true;
+                    prev_step = 1.0e300;
+                    tail_ok = false;
+                    continue;
+                }
                 converged = tail_ok;
                 break;
             }
@@ -1022,21 +1050,7 @@ COPRA_DEV void lmpc_riccati_body(const FusedPlan& P, const StagePlan& S)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, step_inf, z_inf);
 #endif
             if (!polishing && n_ineq > 0 && res_new <= 1e-9 && mu_new <= kRicSwitchMu) {
-                // ---- crossover: the barrier has told which rows are active (lam > s).  From here on those are EQUALITY rows of the
-                // regularised kind (weight 1 / delta, an explicit multiplier), the others are off: Newton's method on an equality-
-                // constrained QP, whose factorisations carry weights of 1e6 instead of the barrier's 1e16 -- see ric_converged.
-                for (int gi = lane; gi < m; gi += kWave)
-                    if ((int)Flag[gi] == kRowIneq) {
-                        if (Lam[gi] > Sv[gi]) {
-                            Flag[gi] = (double)kRowEq;
-                            Sv[gi] = kRicWasActive; // (marker: an inequality row held as an equality -- its multiplier must come out >= 0)
-                        } else {
-                            Flag[gi] = (double)kRowOff;
-                            Sv[gi] = kRicWasIdle; // (marker: an inequality row left out -- it must come out satisfied)
-                            Lam[gi] = 0.0;
-                        }
-                    }
-                wave_sync_full();
+                cross_over();
                 polishing = true;
                 prev_step = 1.0e300;
                 tail_ok = false;

@@ -760,6 +760,19 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             const double az = row_dot(rinf[j], L.X);
             return fl == kRfEq ? az - Fr[j] : az + Sv[j] - Fr[j];
         };
+        // crossover (lmpc_riccati.hpp): rows with lam > s become regularised equality rows, the others are switched off
+        auto cross_over = [&]() {
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                const int gi = 64 * j + lane;
+                if (gi < m && (rinf[j] >> 28) == kRfIneq) {
+                    const bool active = Lam[j] > Sv[j];
+                    rinf[j] = (rinf[j] & 0x0FFFFFFF) | ((active ? kRfEq : kRfOff) << 28);
+                    Sv[j] = active ? kRicWasActive : kRicWasIdle;
+                    Lam[j] = active ? Lam[j] : 0.0;
+                }
+            }
+        };
         int it = 0;
         double prev_step = 1.0e300; // the step before
         bool tail_ok = false; // ric_tail_ok of the iterate the loop stands on (lmpc_riccati.hpp)
@@ -802,6 +815,14 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             good = sweep1(true, x0_free) && good;
             stamp_outer(2);
             if (!good) { // (the factorisation broke down; the iterate itself is untouched: ric_tail_ok)
+                if (!polishing && n_ineq > 0 && maxres <= 1e-9 && mu <= kRicEarlySwitchMu && it > 1) { // ... under large barrier weights: cross over here
+                    cross_over();
+                    polishing = true;
+                    good = true;
+                    prev_step = 1.0e300;
+                    tail_ok = false;
+                    continue;
+                }
                 converged = tail_ok;
                 break;
             }
@@ -923,16 +944,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             if (lane == 0) fprintf(stderr, "it %2d alpha %.4f mu %.3e -> %.3e res %.3e (maxres %.3e eq %.3e) step %.3e z %.3e\n", it, alpha, mu, mu_new, res_new, maxres, maxe, step_inf, z_inf);
 #endif
             if (!polishing && n_ineq > 0 && res_new <= 1e-9 && mu_new <= kRicSwitchMu) { // crossover: lmpc_riccati.hpp
-#pragma unroll
-                for (int j = 0; j < MR; ++j) {
-                    const int gi = 64 * j + lane;
-                    if (gi < m && (rinf[j] >> 28) == kRfIneq) {
-                        const bool active = Lam[j] > Sv[j];
-                        rinf[j] = (rinf[j] & 0x0FFFFFFF) | ((active ? kRfEq : kRfOff) << 28);
-                        Sv[j] = active ? kRicWasActive : kRicWasIdle;
-                        Lam[j] = active ? Lam[j] : 0.0;
-                    }
-                }
+                cross_over();
                 polishing = true;
                 prev_step = 1.0e300;
                 tail_ok = false;
