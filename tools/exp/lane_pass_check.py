@@ -5,9 +5,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-if "--lib" in sys.argv:  # an experimental build of the library (copra_amd/csrc/variants/*.so)
-    from copra_amd import _capi  # noqa: E402
+from copra_amd import _capi  # noqa: E402
 
+if "--lib" in sys.argv:  # an experimental build of the library (copra_amd/csrc/variants/*.so)
     _capi.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
     _capi.build_library = lambda force=False: False
     del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
@@ -19,7 +19,7 @@ for vmax, umax in ((0.6, 3.0), (0.4, 2.0), (0.25, 1.2)):
     out = {}
     for mode in ("off", "on"):
         if mode == "off":
-            _capi.OPTIONS["no_lane_pass"] = int("1")
+            _capi.OPTIONS["no_lane_pass"] = 1
         else:
             _capi.OPTIONS.pop("no_lane_pass", None)
         eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])

@@ -6,9 +6,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-_capi.OPTIONS["lane_dbg"] = int("8")
 from copra_amd import BatchLMPC, workloads  # noqa: E402
-from copra_amd import _capi  # engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
+from copra_amd import _capi  # noqa: E402  engine options (copra_options_t) instead of the COPRA_* environment variables of earlier rounds
+
+_capi.OPTIONS["lane_dbg"] = 8
 
 b = 65536
 wl = workloads.com_preview(b)
