@@ -951,9 +951,10 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared = true;
     h->model_dirty = true;
-    // (compact variant only -- bound rows: with general rows the shared-model mode of that tier was never right (the random differential test
-    //  of the engine's modes, tests/fuzz/fuzz_modes.py: statuses and U off on (6, 3) with a dense state row); those controllers take lmpc_shared.hpp)
-    if (h->hp.plan.lds.ric && h->hp.plan.lds.ricC && h->hp.plan.lds.q1regs && !h->jit_ric && ric_aot_exact(P.nx, P.nu, P.N)) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
+    // (general rows as well: an instance whose rows go through the free response of the preview rebuilds it from its own x0 and the model's A,
+    //  lmpc_fused_ric.hpp -- until that was there, the random differential test of the engine's modes, tests/fuzz/fuzz_modes.py, had statuses and
+    //  U off on (6, 3) with a dense state row)
+    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric && ric_aot_exact(P.nx, P.nu, P.N)) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
                                                                         //  only the library's instantiations: a run-time-compiled one has no prepare kernel)
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;

@@ -149,6 +149,28 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             if (lane < NV) S.xs[lane] = P.control[(size_t)inst * NV + lane];
             for (int e = lane; e < X; e += kWave) XU[e] = P.trajectory[(size_t)inst * X + e];
         }
+        if (!xu_ok) {
+            // rows that go through the free response of the preview (a dense state row: StageRows::refresh_trajectory reads Xbar, which the
+            // preview steps of the per-instance path leave there): xbar_0 = x0, xbar_{k+1} = A xbar_k + d from THIS instance's x0 -- lane i owns
+            // row i of the model's A.  (Round 4 had taken general rows out of this mode: the random differential test of the engine's modes
+            // found statuses and U off -- Xbar was simply never written here, every such row's slack was read from stale LDS.)
+            const int li = lane < NX ? lane : 0;
+            const double* const Am = P.ric_model + ric_model_A(NX, NU, nh, P.mgen);
+            double arow[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) arow[j] = Am[li + NX * j];
+            wave_sync(); // (the constant block of the records and X0 are in place)
+            const double di = F[nh * RR::SZ + RR::cD + li];
+            if (lane < NX) Xbar[lane] = X0[lane];
+            wave_sync();
+            for (int k = 0; k < nh; ++k) {
+                double acc = di;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc += arow[j] * Xbar[k * NX + j];
+                if (lane < NX) Xbar[(k + 1) * NX + lane] = acc;
+                wave_sync();
+            }
+        }
         stamp[1] = cycle_counter();
     } else {
     // ---- 0. coalesced loads of this instance's system: into registers now, into LDS after the loads of the cost tables
@@ -219,6 +241,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         D[lane] = sysD;
         X0[lane] = sysX;
     }
+    if (P.ric_model_out && inst == P.dump_instance && lane < NX * NX) // prepare launch of the shared-model mode: the system's A (ric_model_A)
+        P.ric_model_out[ric_model_A(NX, NU, nh, P.mgen) + lane] = sysA;
     // Reference trajectories (FusedPlan::stage_refs): the affine term of the stage cost changes along the horizon,
     //     h_k(a) = sum_t sum_r c_t(r, a) p_t[k r_t + r]     (c_t: the coefficients of the affine lanes in the table above),
     // NH NZ values, each formed once: entry a of stage k waits in the place of record k (where Acl_k goes at the END of stage k of the

@@ -197,7 +197,7 @@ struct LargeLayout {
 #else
 #define COPRA_HD
 #endif
-// offsets (doubles) of the four parts of FusedPlan::ric_model; returns the total
+// offsets (doubles) of the parts of FusedPlan::ric_model; returns the total
 COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
 {
     const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
@@ -205,6 +205,14 @@ COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk,
     oBk = N * rec + cst; // (formerly bkd: nothing there any more)
     oG = oBk;
     oNb = oG + N * nx * nu;
+    return oNb + ((mgen + 1) & ~1) + ((nx * nx + 1) & ~1); // (+ the system's A behind the norms: ric_model_A below)
+}
+// ... and of the fifth: A of the shared system (nx x nx, column-major) -- what an instance whose rows go through the free response of the
+// preview (dense state rows: StageRows::refresh_trajectory) rebuilds  xbar_{k+1} = A xbar_k + d  from its own x0 with
+COPRA_HD inline int ric_model_A(int nx, int nu, int N, int mgen)
+{
+    int a, b, oNb;
+    (void)ric_model_offsets(nx, nu, N, mgen, a, b, oNb);
     return oNb + ((mgen + 1) & ~1);
 }
 
@@ -258,7 +266,7 @@ struct FusedPlan {
     int ric_tab;
     // Shared-model mode of that tier (copra_batch_set_shared_system): the stage records do not depend on x0, so ONE prepare
     // launch sweeps (ric_model_out, instance dump_instance) and every instance of the batch copies the result (ric_model):
-    //   records [N x RicRec::SZ] + constant block | bkd [N x nx] | G [N x nx x nu] | row norms [mgen]      (ric_model_offsets below)
+    //   records [N x RicRec::SZ] + constant block | bkd [N x nx] | G [N x nx x nu] | row norms [mgen] | A [nx x nx]      (ric_model_offsets below)
     const double* ric_model;
     double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)

@@ -223,3 +223,21 @@ def make_integrator(seed, batch):
         cstrs.append(dict(kind="control_bound", lower=[-u_max] * nu, upper=[u_max] * nu))
         forms.append("ubound")
     return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms)
+
+
+def com_preview_with_general_rows(seed, batch):
+    """The CoM preview workload (6, 3, 20) -- the shape whose Riccati-factor tier has a shared-model mode -- with its bounds and one more
+    constraint of general rows: seed % 3 == 0 two DENSE state rows at every step (they go through the free response of the preview),
+    1 a mixed state/control row, 2 a control row.  -> (workload, constraints)"""
+    from copra_amd import workloads
+    rng = np.random.default_rng(seed)
+    wl = workloads.com_preview(batch, seed=seed, v_max=float(rng.uniform(0.25, 0.6)), u_max=float(rng.uniform(1.2, 3.0)))
+    cstrs = list(wl["cstrs"])
+    kind = seed % 3
+    if kind == 0:
+        cstrs.append(dict(kind="trajectory", E=rng.standard_normal((2, 6)) * 0.5, f=np.abs(rng.standard_normal(2)) * 0.3 + 0.2))
+    elif kind == 1:
+        cstrs.append(dict(kind="mixed", E=rng.standard_normal((1, 6)) * 0.5, G=rng.standard_normal((1, 3)) * 0.3, f=[0.8]))
+    else:
+        cstrs.append(dict(kind="control", G=rng.standard_normal((1, 3)), f=[1.0]))
+    return wl, cstrs

@@ -1390,3 +1390,20 @@ def test_random_controllers_on_the_interior_point_kernels(emu, oracle, shape):
             t = truth.solve(c["A"][k], c["B"][k], c["d"][k], c["x0"][k], N, c["costs"], c["cstrs"], ro["control"][k])
             assert _rel(re["control"][k], t["control"]) <= RTOL and _rel(re["trajectory"][k], t["trajectory"]) <= RTOL, (shape, seed, k, c["forms"])
     assert naccepted >= 2  # (the interior-point iteration breaks down on many RANDOM controllers: those go to the other kernel)
+
+
+def test_shared_model_riccati_factor_tier_with_general_rows(emu, oracle):
+    """the Riccati-factor tier in shared-model mode on controllers with GENERAL rows (dense state rows, mixed rows, control rows): the rows
+    that go through the free response of the preview need it rebuilt from each instance's x0 (the stage records come from one prepare run
+    at x0 = 0) -- round 4 had found statuses and U off there and taken general rows out of the mode.  Against the oracle, incl. the
+    iteration counters"""
+    import random_controllers as RC
+    b = 12
+    for seed in (1, 3, 4, 5):  # (1, 3, 4: the seeds that were wrong)
+        wl, cstrs = RC.com_preview_with_general_rows(seed, b)
+        A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
+        ro = oracle.lmpc_solve_batch(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), wl["x0"], wl["N"], wl["costs"], cstrs, nthreads=8)
+        re = emu.lmpc_solve_shared(A, B, d, wl["x0"], wl["N"], wl["costs"], cstrs)
+        ok = ro["status"] == 0
+        assert re["riccati_factor"] and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all(), seed
+        assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-7 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-7, seed

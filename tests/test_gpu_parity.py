@@ -2342,3 +2342,39 @@ def test_riccati_factor_tier_with_a_run_time_horizon(oracle, shape):
     assert (r2["status"] == ref["status"]).all() and (r2["iter"][ok] == ref["iter"][ok]).all()
     assert _rel(r2["control"][ok], ref["control"][ok]) <= RTOL
     e2.close()
+
+
+@pytest.mark.gpu
+def test_shared_model_riccati_factor_tier_with_general_rows(oracle):
+    """copra_batch_set_shared_system on the headline shape with GENERAL rows next to the bounds (dense state rows, a mixed row, a control row;
+    tests/random_controllers.py: com_preview_with_general_rows): the Riccati-factor tier in shared-model mode -- rows that go through the
+    free response of the preview rebuild it from each instance's x0 -- against the oracle (statuses, both iteration counters, U and X), and
+    against lmpc_shared.hpp (option no_ric_shared) on the whole batch.  24 controllers, batch 1536."""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    b, ns = 1536, 48
+    constrained = 0
+    for seed in range(24):
+        wl, cstrs = RC.com_preview_with_general_rows(seed, b)
+        A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
+        out, infos = [], []
+        for opts in (None, dict(no_ric_shared=1)):
+            eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], cstrs, options=opts)
+            eng.set_shared_system(A, B, d)
+            eng.set_x0(wl["x0"])
+            eng.solve()
+            out.append(eng.results())
+            infos.append(eng.layout_info()["lds_bytes"])
+            eng.close()
+        r1, r2 = out
+        assert infos[0] != infos[1], seed  # (two different first tiers have run: the records' layout against the one with Q1 in LDS)
+        ref = oracle.lmpc_solve_batch(np.tile(A, (ns, 1, 1)), np.tile(B, (ns, 1, 1)), np.tile(d, (ns, 1)), wl["x0"][:ns], wl["N"], wl["costs"], cstrs,
+                                      nthreads=8)
+        ok = ref["status"] == 0
+        assert (r1["status"][:ns] == ref["status"]).all() and (r1["iter"][:ns][ok] == ref["iter"][ok]).all(), seed
+        if ok.any():  # (a random dense row can leave every sampled instance infeasible: the statuses above are the comparison then)
+            assert _rel(r1["control"][:ns][ok], ref["control"][ok]) <= RTOL and _rel(r1["trajectory"][:ns][ok], ref["trajectory"][ok]) <= RTOL, seed
+        good = (r1["status"] == 0) & (r2["status"] == 0)
+        assert (r1["status"] == r2["status"]).all() and (not good.any() or _rel(r1["control"][good], r2["control"][good]) <= 1e-6), seed
+        constrained += int((ref["iter"][ok][:, 0] > 1).sum())
+    assert constrained >= 24 * ns // 3
