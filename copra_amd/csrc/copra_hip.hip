@@ -983,7 +983,7 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
         h->model_ref_off[t] = -1;
         if (t < HP.ncost && h->cost_p[t]) {
             h->model_ref_off[t] = rtot;
-            rtot += HP.cost[t].rows;
+            rtot += HP.cost[t].prows; // (a reference trajectory: one column per row AND step -- the gradient is affine in all of them)
         }
     }
     const int np = 1 + nx + rtot;
@@ -1021,7 +1021,7 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
     for (int t = 0; t < HP.ncost; ++t) { // probe references of the costs that have per-instance ones
         P.cost_p[t] = nullptr;
         if (h->model_ref_off[t] < 0) continue;
-        const int r = HP.cost[t].rows;
+        const int r = HP.cost[t].prows;
         std::vector<double> pp((size_t)np * r, 0.0);
         for (int i = 0; i < r; ++i) pp[(size_t)(1 + nx + h->model_ref_off[t] + i) * r + i] = 1.0;
         P.cost_p[t] = up(pp);
@@ -1159,10 +1159,6 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     }
     if (h->shared) {
         if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
-        if (h->hp.plan.stage_refs) // (the model's dc/dp holds one column per cost row, not per row and step)
-            for (int t = 0; t < kMaxCosts; ++t)
-                if (h->cost_p[t] && h->hp.plan.cost[t].pstride)
-                    return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_solve: per-instance reference trajectories are not available in shared-model mode");
 
         hipStream_t s = (hipStream_t)hip_stream;
         h->last_stream = s;

@@ -277,8 +277,6 @@ copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_ind
     if (cost_index < 0 || cost_index >= (int)h->hp.cost_slot.size()) return fail(COPRA_ERR_ARG, "copra_batch_set_cost_reference_all: no such cost");
     const int t = h->hp.cost_slot[(size_t)cost_index];
     if (t < 0) return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a dense (host-evaluated) cost has no reference p");
-    if (h->shared && P.cost[t].pstride)
-        return fail(COPRA_ERR_UNSUPPORTED, "copra_batch_set_cost_reference_all: a new reference trajectory in shared-model mode needs a new controller");
     // Every kernel already reads a per-instance reference where one is set: the new reference is written once per instance into the
     // library's own buffer (a broadcast on the device: 66 MB at the headline's batch for a reference trajectory, ~ 10 us) and that
     // path is taken -- nothing that was derived from the creation-time p (tables of the plan builder, the shared model's c0) can go stale.

@@ -74,9 +74,10 @@ COPRA_DEV void lmpc_shared_body(const FusedPlan& P, int inst)
         for (int c = 16; c < nx; ++c) acc += M[m.K1 + (size_t)c * n + lane] * x0[c];
         for (int t = 0; t < P.ncost; ++t) { // costs with per-instance references
             if (P.cost_p[t] && P.model_ref_off[t] >= 0) {
-                const double* pt = P.cost_p[t] + (size_t)inst * P.cost[t].rows;
+                // (prows: the rows of the cost, or rows x steps for a reference trajectory -- CostTerm::pstride)
+                const double* pt = P.cost_p[t] + (size_t)inst * P.cost[t].prows;
                 const double* K2 = M + m.C2 + (size_t)(P.model_rtot + P.model_ref_off[t]) * n;
-                for (int i = 0; i < P.cost[t].rows; ++i) acc += K2[(size_t)i * n + lane] * pt[i];
+                for (int i = 0; i < P.cost[t].prows; ++i) acc += K2[(size_t)i * n + lane] * pt[i];
             }
         }
         S.xs[lane] = acc;

@@ -243,13 +243,16 @@ copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const dou
  *      r N) -- each instance of the batch tracks its own goal / reference trajectory; in the reference this is one
  *      TrajectoryCost(M, p_b) / TargetCost / ControlCost / MixedCost object per LMPC (include/costFunctions.h:103-219).
  *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Works on the shared-model fast path
- *      too (the gradient is affine in p: c = c0 + C1 x0 + C2 p, probed once). ---- */
+ *      too (the gradient is affine in p: c = c0 + C1 x0 + C2 p, probed once -- one column of C2 per entry of p, reference
+ *      trajectories included.  With per-instance reference TRAJECTORIES the shared-model kernel multiplies r (N+1) columns per
+ *      instance: at the headline shape 70 M solves/s against 198 M for the same problem given as per-instance systems --
+ *      copra_batch_set_system with the one model repeated --, profiles/r04/shared_tracking.txt: prefer that form there). ---- */
 copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);
 /* ... and ONE new reference for every instance: p[rows] (rows as above -- a reference trajectory: r (N+1) or r N), host or device.
  *      The reference's API has no setter for p (include/costFunctions.h:103-219: a constructor argument): a tracking controller
  *      replaces the cost object and the next solve evaluates the new one (src/LMPC.cpp:233-247).  Here the new reference is written
  *      once per instance into the library's buffer (a broadcast on the device) and the per-instance path above is taken: no new
- *      plan, no new handle.  Not for a reference TRAJECTORY in shared-model mode (COPRA_ERR_UNSUPPORTED: build a new controller). */
+ *      plan, no new handle. */
 copra_status_t copra_batch_set_cost_reference_all(copra_batch_t* h, int cost_index, const double* p, int on_device);
 /*      Cost of that convenience: the controller is in per-instance-reference mode afterwards (until copra_batch_set_cost_reference(h,
  *      k, NULL, 0), which restores the reference given at CREATION).  In that mode a long-horizon controller runs the streaming

@@ -1848,7 +1848,7 @@ def test_reference_trajectory_compiled_shape(oracle, tmp_path):
 def test_one_new_reference_for_every_instance(oracle):
     """copra_batch_set_cost_reference_all: a new goal / a new reference trajectory for the whole batch without a new controller (the
     reference replaces the cost object, costFunctions.h:103-219 has no setter) -- equal to a controller built with that reference; host
-    and device pointers; shared-model mode takes a new goal and refuses a new reference trajectory"""
+    and device pointers; shared-model mode takes a new goal and a new reference trajectory"""
     import torch
     from copra_amd import BatchLMPC, workloads
     b = 24576
@@ -1896,11 +1896,21 @@ def test_one_new_reference_for_every_instance(oracle):
         eng.close()
     ok = res[0]["status"] == 0
     assert (res[0]["status"] == res[1]["status"]).all() and _rel_vec(res[1]["control"][ok], res[0]["control"][ok]) <= 1e-9
-    eng = BatchLMPC(6, 3, N, b, track(xref), wl["cstrs"])
-    eng.set_shared_system(A, B, d)
-    with pytest.raises(Exception):
-        eng.set_cost_reference(0, xref2.reshape(-1))
-    eng.close()
+    # ... and a new reference TRAJECTORY as well (refused until round 4: the shared model now holds one probe column per row and step)
+    res = []
+    for costs, new in ((track(xref2), None), (track(xref), xref2.reshape(-1))):
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"])
+        eng.set_shared_system(A, B, d)
+        eng.set_x0(wl["x0"])
+        eng.solve()
+        if new is not None:
+            eng.set_cost_reference(0, new)
+            eng.solve()
+        res.append(eng.results())
+        eng.close()
+    ok = res[0]["status"] == 0
+    assert ok.sum() > b // 2 and (res[0]["status"] == res[1]["status"]).all() and (res[0]["iter"][ok] == res[1]["iter"][ok]).all()
+    assert _rel_vec(res[1]["control"][ok], res[0]["control"][ok]) <= 1e-9
 
 
 @pytest.mark.gpu
@@ -2378,3 +2388,58 @@ def test_shared_model_riccati_factor_tier_with_general_rows(oracle):
         assert (r1["status"] == r2["status"]).all() and (not good.any() or _rel(r1["control"][good], r2["control"][good]) <= 1e-6), seed
         constrained += int((ref["iter"][ok][:, 0] > 1).sum())
     assert constrained >= 24 * ns // 3
+
+
+@pytest.mark.gpu
+def test_per_instance_reference_trajectories_in_shared_model_mode(oracle):
+    """one model for the batch (copra_batch_set_shared_system), every instance ITS OWN reference trajectory (copra_batch_set_cost_reference on
+    a TrajectoryCost whose reference changes along the horizon): the shared model's gradient is affine in every entry of p -- one probe
+    column per row and step.  Until round 4 this combination was refused (COPRA_ERR_UNSUPPORTED).  Against the oracle instance by instance,
+    against the per-instance-system mode on the whole batch; then ONE new trajectory for everybody (copra_batch_set_cost_reference_all)."""
+    from copra_amd import BatchLMPC, workloads
+    b = 4096
+    rng = np.random.default_rng(31)
+    wl = workloads.com_preview(b, v_max=0.45, u_max=2.0, seed=17)
+    A, B, d, N = wl["A"][5], wl["B"][5], wl["d"][5], wl["N"]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    mk = lambda p: [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=np.asarray(p).reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)),
+                    wl["costs"][1]]
+    refs = np.tile(xref.reshape(-1), (b, 1)) + 0.05 * rng.standard_normal((b, 6 * (N + 1)))
+    sh = BatchLMPC(6, 3, N, b, mk(xref), wl["cstrs"])
+    sh.set_shared_system(A, B, d)
+    sh.set_x0(wl["x0"])
+    sh.solve()
+    r0 = sh.results()
+    sh.set_cost_reference(0, refs)
+    sh.solve()
+    r1 = sh.results()
+    pi = BatchLMPC(6, 3, N, b, mk(xref), wl["cstrs"])
+    pi.set_system(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), wl["x0"])
+    pi.set_cost_reference(0, refs)
+    pi.solve()
+    r2 = pi.results()
+    pi.close()
+    ok = (r1["status"] == 0) & (r2["status"] == 0)
+    assert ok.sum() > b // 2 and (r1["status"] == r2["status"]).all() and (r1["iter"][ok] == r2["iter"][ok]).all()
+    assert _rel(r1["control"][ok], r2["control"][ok]) <= 1e-7 and np.abs(r1["control"] - r0["control"]).max() > 1e-2
+    constrained = 0
+    for k in range(0, b, 173):
+        ref = oracle.lmpc_solve_batch(A[None], B[None], d[None], wl["x0"][k:k + 1], N, mk(refs[k]), wl["cstrs"], nthreads=1)
+        assert r1["status"][k] == ref["status"][0]
+        if ref["status"][0] == 0:
+            assert tuple(r1["iter"][k]) == tuple(ref["iter"][0]) and _rel(r1["control"][k], ref["control"][0]) <= RTOL
+            assert _rel(r1["trajectory"][k], ref["trajectory"][0]) <= RTOL
+            constrained += int(ref["iter"][0][0] > 1)
+    assert constrained >= 6
+    new = xref + 0.03 * np.sin(4.0 * ts)[:, None]
+    sh.set_cost_reference(0, new.reshape(-1))  # (one-dimensional p: copra_batch_set_cost_reference_all)
+    sh.solve()
+    r3 = sh.results()
+    sh.close()
+    pick = np.arange(0, b, 257)
+    tile = lambda M: np.tile(M, (len(pick),) + (1,) * M.ndim)
+    ref = oracle.lmpc_solve_batch(tile(A), tile(B), tile(d), wl["x0"][pick], N, mk(new), wl["cstrs"], nthreads=8)
+    okp = ref["status"] == 0
+    assert (r3["status"][pick] == ref["status"]).all() and (r3["iter"][pick][okp] == ref["iter"][okp]).all()
+    assert _rel(r3["control"][pick][okp], ref["control"][okp]) <= RTOL

@@ -53,6 +53,7 @@ python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_s
 (for sh in "12 6" "5 3" "7 2" "3 3" "6 1" "4 2"; do echo "== shape $sh"; python tests/fuzz/fuzz_interior_point.py 0 60 $sh 2>&1 | grep -v amdgpu.ids | grep "certified\|<<<<\|mismatching" | cut -c1-420; done) > $R/fuzz_interior_point_kernels.txt || true
 (python tests/fuzz/fuzz_shared_general_rows.py 0 300 2>&1 | grep -v amdgpu.ids) > $R/fuzz_shared_general_rows.txt || true
 python tools/exp/shared_general_rows.py 2>&1 | grep -v amdgpu.ids > $R/shared_general_rows.txt || true
+python tools/exp/shared_tracking.py 2>&1 | grep -v amdgpu.ids > $R/shared_tracking.txt || true
 (python tests/fuzz/fuzz_modes.py 0 400 2>&1 | grep -v amdgpu.ids | grep " <\|ERROR\|mismatching" | cut -c1-400) > $R/fuzz_engine_modes.txt || true
 # ---- the bench line itself (with cpu_baseline and extra): AFTER the summaries, so that its roofline.traffic is the one just measured ----
 python bench.py --steps 20 --warmup 3 > $O/bench_r04.json 2> $O/bench_r04.err
