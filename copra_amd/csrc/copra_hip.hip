@@ -373,6 +373,8 @@ static fused_kernel_t select_lane_kernel(const FusedPlan& P)
 static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 {
     if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_shared_kernel<6, 3>;
+    if (P.nx == 4 && P.nu == 2) return copra_lmpc_lane_shared_kernel<4, 2>; // (the other shapes of the tier's run-time-horizon builds)
+    if (P.nx == 2 && P.nu == 1) return copra_lmpc_lane_shared_kernel<2, 1>;
     return nullptr;
 }
 static size_t lane_lds_bytes(const FusedPlan& P)
@@ -954,7 +956,7 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     // (general rows as well: an instance whose rows go through the free response of the preview rebuilds it from its own x0 and the model's A,
     //  lmpc_fused_ric.hpp -- until that was there, the random differential test of the engine's modes, tests/fuzz/fuzz_modes.py, had statuses and
     //  U off on (6, 3) with a dense state row)
-    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric && ric_aot_exact(P.nx, P.nu, P.N)) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
+    if (h->hp.plan.lds.ric && h->hp.plan.lds.q1regs && !h->jit_ric && (ric_aot_exact(P.nx, P.nu, P.N) || ric_aot_shape(P.nx, P.nu))) { // (the Riccati-factor tier has a shared-model mode of its own: copra_batch_solve;
                                                                         //  only the library's instantiations: a run-time-compiled one has no prepare kernel)
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;

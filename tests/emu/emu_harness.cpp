@@ -544,7 +544,26 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, no per-instance references): one prepare
     // run of the body leaves the stage records, bkd, G and the row norms; the first tier copies them instead of sweeping
     std::vector<double> ric_model;
-    const bool ric_shared = P.lds.ric && P.N == 20 && P.lds.q1regs == kFusedQ1Regs && !warm_set && !default_options().no_ric_shared;
+    // (as copra_batch_set_shared_system: the library's instantiations of the tier -- the compile-time horizons of (6, 3) and the run-time-horizon
+    //  builds of the integrator shapes)
+    const bool ric_shared = P.lds.ric && (ric_aot_exact(P.nx, P.nu, P.N) || ric_aot_shape(P.nx, P.nu)) && P.lds.q1regs == kFusedQ1Regs && !warm_set
+        && !default_options().no_ric_shared;
+    auto ric_tier = [&](const FusedPlan& PP, int b) {
+#define EMU_RIC_SH(NX, NU, NH) (PP.stage_refs ? lmpc_fused_ric_body<NX, NU, NH, 6, kFusedQ1Regs, true>(PP, b) : lmpc_fused_ric_body<NX, NU, NH, 6, kFusedQ1Regs>(PP, b))
+        if (PP.nx == 6 && PP.N == 20)
+            EMU_RIC_SH(6, 3, 20);
+        else if (PP.nx == 6 && PP.N == 15)
+            EMU_RIC_SH(6, 3, 15);
+        else if (PP.nx == 6 && PP.N == 10)
+            EMU_RIC_SH(6, 3, 10);
+        else if (PP.nx == 6)
+            EMU_RIC_SH(6, 3, 0);
+        else if (PP.nx == 4)
+            EMU_RIC_SH(4, 2, 0);
+        else
+            EMU_RIC_SH(2, 1, 0);
+#undef EMU_RIC_SH
+    };
     if (ric_shared) {
         int oBk, oG, oNb;
         ric_model.assign((size_t)ric_model_offsets(nx, nu, N, P.mgen, oBk, oG, oNb), 0.0);
@@ -553,7 +572,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         R.batch = 1;
         R.dump_instance = 0;
         R.ric_model_out = ric_model.data();
-        if (emu::run_wave([&]() { (R.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs, true>(R, 0) : lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(R, 0)); }, hp.lds_bytes, 0, 1) != 0) return -100;
+        if (emu::run_wave([&]() { ric_tier(R, 0); }, hp.lds_bytes, 0, 1) != 0) return -100;
         P.ric_model = ric_model.data();
     } else { // as copra_batch_set_shared_system: the shared-model kernels keep Q1 in LDS
         LdsLayout lq {};
@@ -564,7 +583,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     }
     auto shared = [&](const FusedPlan& PP, int b) {
         if (PP.lds.ric && PP.ric_model)
-            (PP.stage_refs ? lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs, true>(PP, b) : lmpc_fused_ric_body<6, 3, 20, 6, kFusedQ1Regs>(PP, b));
+            ric_tier(PP, b);
         else if (PP.lds.tri && PP.nx == 6 && PP.nu == 3 && PP.N == 20) // (select_shared_kernel: factor-only first tier)
             lmpc_shared_body<6, 3, 20, true>(PP, b);
         else if (PP.lds.tri)
@@ -579,7 +598,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // in front of the Riccati-factor tier in shared-model mode: the one-instance-per-lane pass in its shared-model form (as copra_batch_solve)
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
     int lane_count = 0, lane_other = 0, lane_finished = -1;
-    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass) {
+    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass) { // (select_lane_shared_kernel: every shape of the tier)
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = groups * 64;
         P.lane_list = lane_list.data();
@@ -588,7 +607,14 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         int oHl = 0;
         const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
         for (int g = 0; g < groups; ++g)
-            if (emu::run_wave([&]() { lmpc_lane_shared_body<6, 3>(P, g); }, lbytes, g, groups) != 0) return -100;
+            if (emu::run_wave([&]() {
+                    if (P.nx == 6)
+                        lmpc_lane_shared_body<6, 3>(P, g);
+                    else if (P.nx == 4)
+                        lmpc_lane_shared_body<4, 2>(P, g);
+                    else
+                        lmpc_lane_shared_body<2, 1>(P, g);
+                }, lbytes, g, groups) != 0) return -100;
         P.lane_from_list = 1;
         P.lane_handover = 1;
         for (int k = 0; k < lane_count; ++k) {

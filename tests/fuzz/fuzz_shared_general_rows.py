@@ -1,6 +1,8 @@
 """Shared-model mode of the Riccati-factor tier on the headline shape with general rows next to the bounds (random_controllers.py:
 com_preview_with_general_rows -- dense state rows, a mixed row, a control row), device against the oracle on a sample and against
-lmpc_shared.hpp (option no_ric_shared) on the whole batch.      python tests/fuzz/fuzz_shared_general_rows.py first count [batch]"""
+lmpc_shared.hpp (option no_ric_shared) on the whole batch.      python tests/fuzz/fuzz_shared_general_rows.py first count [batch [integrators]]
+With `integrators`: the controllers of random_controllers.py: make_integrator instead (double integrators in one to three dimensions, random
+horizon, reference trajectories, every kind of row) -- the tier's run-time-horizon builds in shared-model mode."""
 import os
 import sys
 
@@ -24,13 +26,19 @@ b = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 ns = 32
 bad = 0
 ninst = 0
+integrators = len(sys.argv) > 4 and sys.argv[4] == "integrators"
 for seed in range(first, first + count):
-    wl, cstrs = RC.com_preview_with_general_rows(seed, b)
+    if integrators:
+        wl = RC.make_integrator(seed, b)
+        cstrs = wl["cstrs"]
+    else:
+        wl, cstrs = RC.com_preview_with_general_rows(seed, b)
     k = seed % wl["A"].shape[0]
     A, B, d = wl["A"][k], wl["B"][k], wl["d"][k]
+    nx, nu = A.shape[0], B.shape[1]
     out = []
     for opts in (None, dict(no_ric_shared=1)):
-        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], cstrs, options=opts)
+        eng = BatchLMPC(nx, nu, wl["N"], b, wl["costs"], cstrs, options=opts)
         eng.set_shared_system(A, B, d)
         eng.set_x0(wl["x0"])
         eng.solve()
@@ -48,6 +56,6 @@ for seed in range(first, first + count):
     ninst += b
     if st or st2 or ru > 1e-6 or ru2 > 1e-6 or itd:
         bad += 1
-        print(seed, ("dense state rows", "mixed row", "control row")[seed % 3], "oracle: status differ %d iter differ %d relU %.1e | lmpc_shared.hpp: status differ %d relU %.1e"
+        print(seed, (nx, nu, wl["N"], wl["forms"]) if integrators else ("dense state rows", "mixed row", "control row")[seed % 3], "oracle: status differ %d iter differ %d relU %.1e | lmpc_shared.hpp: status differ %d relU %.1e"
               % (st, itd, ru, st2, ru2), "mean iterations %.1f" % ref["iter"][:, 0].mean(), "  <<<<<<" if (st or st2 or ru > 1e-4 or ru2 > 1e-4) else "", flush=True)
 print("seeds %d..%d: %d mismatching controllers of %d (%d instances)" % (first, first + count - 1, bad, count, ninst))

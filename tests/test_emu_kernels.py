@@ -1407,3 +1407,22 @@ def test_shared_model_riccati_factor_tier_with_general_rows(emu, oracle):
         ok = ro["status"] == 0
         assert re["riccati_factor"] and (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all(), seed
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-7 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-7, seed
+
+
+def test_shared_model_riccati_factor_tier_run_time_horizons(emu, oracle):
+    """the Riccati-factor tier's shared-model mode on its RUN-TIME-horizon builds (random_controllers.py: make_integrator -- (6, 3) and (4, 2)
+    at random horizons, reference trajectories, bound / row / mixed constraints): until round 4 only the compile-time horizons 10, 15, 20 of
+    (6, 3) took the mode.  Against the oracle incl. the iteration counters; at least half of the controllers must have run the tier"""
+    import random_controllers as RC
+    b, nric = 10, 0
+    for seed in range(0, 24):
+        c = RC.make_integrator(seed, b)
+        A, B, d = c["A"][0], c["B"][0], c["d"][0]
+        ro = oracle.lmpc_solve_batch(np.tile(A, (b, 1, 1)), np.tile(B, (b, 1, 1)), np.tile(d, (b, 1)), c["x0"], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        re = emu.lmpc_solve_shared(A, B, d, c["x0"], c["N"], c["costs"], c["cstrs"])
+        ok = ro["status"] == 0
+        nric += int(bool(re["riccati_factor"]))
+        assert (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all(), seed
+        if ok.any():
+            assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-7 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-7, seed
+    assert nric >= 12

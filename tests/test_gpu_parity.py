@@ -2443,3 +2443,37 @@ def test_per_instance_reference_trajectories_in_shared_model_mode(oracle):
     okp = ref["status"] == 0
     assert (r3["status"][pick] == ref["status"]).all() and (r3["iter"][pick][okp] == ref["iter"][okp]).all()
     assert _rel(r3["control"][pick][okp], ref["control"][okp]) <= RTOL
+
+
+@pytest.mark.gpu
+def test_shared_model_tick_on_run_time_horizons(oracle):
+    """copra_batch_set_shared_system on the integrator shapes at RANDOM horizons (random_controllers.py: make_integrator): the Riccati-factor
+    tier's shared-model mode on its run-time-horizon builds (round 3: only (6, 3) at N = 10, 15, 20; the others ran lmpc_shared.hpp, 2.5 - 6 x
+    slower: profiles/r04/shared_tick_shapes.txt) -- against the oracle on a sample (statuses, both iteration counters, U, X) and against
+    lmpc_shared.hpp (option no_ric_shared) on the whole batch.  60 controllers, batch 1024."""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    b, ns, other_tier = 1024, 24, 0
+    for seed in range(60):
+        c = RC.make_integrator(seed, b)
+        k = seed % b
+        A, B, d = c["A"][k], c["B"][k], c["d"][k]
+        out, infos = [], []
+        for opts in (None, dict(no_ric_shared=1)):
+            eng = BatchLMPC(c["nx"], c["nu"], c["N"], b, c["costs"], c["cstrs"], options=opts)
+            eng.set_shared_system(A, B, d)
+            eng.set_x0(c["x0"])
+            eng.solve()
+            out.append(eng.results())
+            infos.append(eng.layout_info()["lds_bytes"])
+            eng.close()
+        r1, r2 = out
+        other_tier += int(infos[0] != infos[1])
+        ref = oracle.lmpc_solve_batch(np.tile(A, (ns, 1, 1)), np.tile(B, (ns, 1, 1)), np.tile(d, (ns, 1)), c["x0"][:ns], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        ok = ref["status"] == 0
+        assert (r1["status"][:ns] == ref["status"]).all() and (r1["iter"][:ns][ok] == ref["iter"][ok]).all(), seed
+        if ok.any():
+            assert _rel(r1["control"][:ns][ok], ref["control"][ok]) <= RTOL and _rel(r1["trajectory"][:ns][ok], ref["trajectory"][ok]) <= RTOL, seed
+        good = (r1["status"] == 0) & (r2["status"] == 0)
+        assert (r1["status"] == r2["status"]).all() and (not good.any() or _rel(r1["control"][good], r2["control"][good]) <= 1e-6), seed
+    assert other_tier >= 30  # (the mode was taken: a different layout than with no_ric_shared)
