@@ -961,6 +961,8 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;
     }
+    h->shared_ric_off = false; // (a new model: the tier is tried again)
+    h->shared_ric_solves = 0;
     h->shared_ric = false;
     LdsLayout lq {};
     if (tri_layout_with_lds_q1(h->hp.plan, h->hp.plan.lds, lq)) { // the shared-model kernels keep Q1 in LDS
@@ -1166,7 +1168,32 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->last_stream = s;
         if (h->hp.plan.batch == 0) return COPRA_OK;
         { // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
-            bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared;
+            // The tier is taken by SHAPE.  Where the condensed problem is small (two controls, at most 32 variables) and the active-set path
+            // long, the dense triangular solves of lmpc_shared.hpp are cheaper than N stages of the recursion per iteration (planar point
+            // mass N = 8, 20 iterations per solve: 6.8 vs 13.5 ms, profiles/r04/tier_choice_map.txt; at 5 iterations the tier is twice as
+            // fast): after the first solve on the tier its iteration counters decide -- one synchronisation in the controller's life.
+            if (h->shared_ric && h->shared_ric_solves == 1 && !h->shared_ric_off && h->hp.plan.nu <= 2 && h->hp.plan.n <= 32) {
+                const int* d_it = h->ext_iter ? h->ext_iter : h->d_iter;
+                const int* d_st = h->ext_status ? h->ext_status : h->d_status;
+                if (d_it && d_st) {
+                    const size_t nb = (size_t)h->hp.plan.batch;
+                    std::vector<int> it(nb * 2), st(nb);
+                    HIP_TRY(hipStreamSynchronize(h->last_stream));
+                    HIP_TRY(hipMemcpy(it.data(), d_it, it.size() * sizeof(int), hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+                    long long sum = 0, cnt = 0;
+                    for (size_t b = 0; b < nb; ++b)
+                        if (st[b] == 0) sum += it[2 * b], cnt += 1;
+                    if (cnt > 0 && sum > 12 * cnt) {
+                        h->shared_ric_off = true;
+                        if (h->hp.opt.debug)
+                            fprintf(stderr, "[copra] shared-model tick: %.1f iterations per solve at %d variables: lmpc_shared.hpp from now on\n",
+                                (double)sum / (double)cnt, h->hp.plan.n);
+                    }
+                }
+                h->shared_ric_solves = 2; // (decided)
+            }
+            bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared && !h->shared_ric_off;
             for (int t = 0; t < kMaxCosts; ++t) want = want && !h->cost_p[t];
             if (want != h->shared_ric) {
                 LdsLayout lq {};
@@ -1203,6 +1230,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         HIP_TRY(hipEventRecord(h->ev0, s));
         if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, false, P));
         if (h->shared_ric && P.lds.ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
+            if (h->shared_ric_solves < 1) h->shared_ric_solves = 1;
             FusedPlan Pr = P;
             Pr.ric_model = h->d_ric_model;
             // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from

@@ -85,6 +85,8 @@ struct copra_batch {
     // for that tier (kept when copra_batch_set_shared_system moves the plan to an LDS-Q1 layout), whether the next solve uses it,
     // and the batch-wide records
     bool has_lds_ric = false, shared_ric = false;
+    long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
+    bool shared_ric_off = false;     // ... which a small, constraint-heavy controller leaves after its first solve (copra_batch_solve)
     LdsLayout lds_ric {};
     double* d_ric_model = nullptr;
     int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)

@@ -2477,3 +2477,30 @@ def test_shared_model_tick_on_run_time_horizons(oracle):
         good = (r1["status"] == 0) & (r2["status"] == 0)
         assert (r1["status"] == r2["status"]).all() and (not good.any() or _rel(r1["control"][good], r2["control"][good]) <= 1e-6), seed
     assert other_tier >= 30  # (the mode was taken: a different layout than with no_ric_shared)
+
+
+@pytest.mark.gpu
+def test_small_constraint_heavy_shared_model_controller_leaves_the_records_tier(oracle):
+    """the shared-model tick takes the Riccati-factor tier by SHAPE; a planar point mass at N = 8 (16 variables) whose active-set path is
+    20 iterations long is twice as fast on lmpc_shared.hpp (profiles/r04/tier_choice_map.txt): after its first solve on the tier the
+    iteration counters move such a controller there (one synchronisation), a relaxed one stays.  Results against the oracle before and after."""
+    from copra_amd import BatchLMPC
+    b = 2048
+    for v_max, u_max, leaves in ((0.2, 0.8, True), (2.0, 8.0, False)):
+        wl = _planar_integrator(b, 8, v_max=v_max, u_max=u_max)
+        A, B, d = wl["A"][0], wl["B"][0], wl["d"][0]
+        eng = BatchLMPC(4, 2, 8, b, wl["costs"], wl["cstrs"])
+        eng.set_shared_system(A, B, d)
+        eng.set_x0(wl["x0"])
+        ref = oracle.lmpc_solve_batch(np.tile(A, (64, 1, 1)), np.tile(B, (64, 1, 1)), np.tile(d, (64, 1)), wl["x0"][:64], 8, wl["costs"], wl["cstrs"], nthreads=8)
+        ok = ref["status"] == 0
+        infos = []
+        for _ in range(3):
+            eng.solve()
+            r = eng.results()
+            infos.append(eng.layout_info()["lds_bytes"])
+            assert (r["status"][:64] == ref["status"]).all() and (r["iter"][:64][ok] == ref["iter"][ok]).all()
+            assert _rel(r["control"][:64][ok], ref["control"][ok]) <= RTOL
+        assert (ref["iter"][ok][:, 0].mean() > 12) == leaves
+        assert (infos[0] != infos[1]) == leaves and infos[1] == infos[2]
+        eng.close()
