@@ -1170,7 +1170,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         { // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
             // The tier is taken by SHAPE.  Where the condensed problem is small (two controls, at most 32 variables) and the active-set path
             // long, the dense triangular solves of lmpc_shared.hpp are cheaper than N stages of the recursion per iteration (planar point
-            // mass N = 8, 20 iterations per solve: 6.8 vs 13.5 ms, profiles/r04/tier_choice_map.txt; at 5 iterations the tier is twice as
+            // mass N = 8, 20 iterations per solve: 6.8 vs 13.5 ms, profiles/r04/tier_choice_map_before_switch.txt; at 5 iterations the tier is twice as
             // fast): after the first solve on the tier its iteration counters decide -- one synchronisation in the controller's life.
             if (h->shared_ric && h->shared_ric_solves == 1 && !h->shared_ric_off && h->hp.plan.nu <= 2 && h->hp.plan.n <= 32) {
                 const int* d_it = h->ext_iter ? h->ext_iter : h->d_iter;

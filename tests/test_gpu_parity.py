@@ -2482,7 +2482,7 @@ def test_shared_model_tick_on_run_time_horizons(oracle):
 @pytest.mark.gpu
 def test_small_constraint_heavy_shared_model_controller_leaves_the_records_tier(oracle):
     """the shared-model tick takes the Riccati-factor tier by SHAPE; a planar point mass at N = 8 (16 variables) whose active-set path is
-    20 iterations long is twice as fast on lmpc_shared.hpp (profiles/r04/tier_choice_map.txt): after its first solve on the tier the
+    20 iterations long is twice as fast on lmpc_shared.hpp (profiles/r04/tier_choice_map_before_switch.txt): after its first solve on the tier the
     iteration counters move such a controller there (one synchronisation), a relaxed one stays.  Results against the oracle before and after."""
     from copra_amd import BatchLMPC
     b = 2048
