@@ -1426,3 +1426,15 @@ def test_shared_model_riccati_factor_tier_run_time_horizons(emu, oracle):
         if ok.any():
             assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-7 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-7, seed
     assert nric >= 12
+
+
+def test_random_dense_qps_with_awkward_cases(emu, oracle):
+    """the dense-QP kernel body (qp_dense.hpp: plug-in point 1) on random problems up to 64 variables with the awkward cases mixed in
+    (tests/fuzz/fuzz_dense_qp.py: contradictions, zero rows, infinite bounds, indefinite Hessians, pinned variables, duplicated rows):
+    statuses, iteration counters and x against the oracle"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "fuzz"))
+    import fuzz_dense_qp as FQ
+    bad, tot, seen = FQ.run(0, 30, emu=True, verbose=True)
+    assert bad == 0 and tot == 480 and len(seen) >= 7

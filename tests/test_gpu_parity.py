@@ -12,6 +12,7 @@ certificate) and the oracle's own distance from it is measured in the same test 
 both distances in its docstring.  (Round 3 ran with a floor of 1e-2 instead.)
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -2504,3 +2505,19 @@ def test_small_constraint_heavy_shared_model_controller_leaves_the_records_tier(
         assert (ref["iter"][ok][:, 0].mean() > 12) == leaves
         assert (infos[0] != infos[1]) == leaves and infos[1] == infos[2]
         eng.close()
+
+
+@pytest.mark.gpu
+def test_random_dense_qps_with_awkward_cases_at_plugin_point_1(oracle):
+    """copra_qp_solve_dense_batch (QuadProgDenseSolver::SI_solve, src/QuadProgSolver.cpp:45-72) on 150 random (n, meq, mineq) up to 200
+    variables, 2200 problems (tests/fuzz/fuzz_dense_qp.py): plain ones and the awkward cases -- contradicting rows, zero-norm rows,
+    infinite / DBL_MAX bounds, a box far from the minimiser, an indefinite Hessian, and the degenerate ones (pinned variables, duplicated
+    rows and equalities) whose status qpgen2's own arithmetic decides by the sign of rounding noise: statuses, both
+    iteration counters and x equal to the oracle's everywhere else"""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "fuzz"))
+    import fuzz_dense_qp as FQ
+    bad, tot, seen = FQ.run(0, 150, emu=False, verbose=True)
+    assert bad == 0 and tot >= 2000
+    assert seen["not-pd"][1].get(2, 0) == seen["not-pd"][0] and seen["contradiction"][1].get(1, 0) == seen["contradiction"][0]
+    assert seen["plain"][1].get(0, 0) == seen["plain"][0] and seen["unbounded"][1].get(0, 0) == seen["unbounded"][0]
+    assert seen["pinned"][1].get("rounding-decided", 0) <= seen["pinned"][0] // 4
