@@ -1194,7 +1194,21 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
                 h->shared_ric_solves = 2; // (decided)
             }
             bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared && !h->shared_ric_off;
-            for (int t = 0; t < kMaxCosts; ++t) want = want && !h->cost_p[t];
+            // Per-instance cost references (one model, every instance its own goal / reference trajectory): the records were swept with the
+            // controller-wide references, an instance's own feed-forward terms come from the DELTA sweep of the shared lane pass
+            // (lmpc_lane_shared_body) -- so the records form takes them where that pass runs; elsewhere lmpc_shared.hpp (reference columns of
+            // the shared model), as for every such controller before round 4 (96 vs 200 M solves/s at the headline shape).
+            bool refs = false;
+            for (int t = 0; t < kMaxCosts; ++t) refs = refs || h->cost_p[t];
+            if (want && refs) {
+                const FusedPlan Pw = device_plan(h);
+                want = !h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, Pw.batch, true) && Pw.lane_tab >= 0 && Pw.lane_cref >= 0
+                    && h->lds_ric.ricC && !Pw.prof && !Pw.prof_fine && !Pw.row_f_inst && select_lane_shared_kernel(Pw) != nullptr;
+                if (want && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for the delta terms: lmpc_shared.hpp)
+                    (void)hipGetLastError();
+                    want = false;
+                }
+            }
             if (want != h->shared_ric) {
                 LdsLayout lq {};
                 if (want) {
@@ -1236,8 +1250,11 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
             // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
             unsigned g1 = (unsigned)P.batch;
+            bool refs_now = false; // (then the pass MUST run: the choice of this tier above has checked that it can)
+            for (int t = 0; t < kMaxCosts; ++t) refs_now = refs_now || h->cost_p[t];
+            bool pass_ran = false;
             if (!h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
-                && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, false) == COPRA_OK || (h->lane_off = true, false))) {
+                && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, refs_now) == COPRA_OK || (h->lane_off = true, false))) {
                 // (no room for the pass's list: the tier alone, from now on -- as on the per-instance path below)
                 h->lane_cur ^= 1;
                 h->lane_ran = true;
@@ -1245,13 +1262,17 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
                 Pr.lane_count = h->d_lane_count + h->lane_cur;
                 Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
                 Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
+                Pr.lane_ws = refs_now ? h->d_lane_ws : nullptr; // (the delta feed-forward terms of instances with their own references)
                 hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
                 HIP_TRY(hipGetLastError());
                 Pr.lane_from_list = 1;
                 Pr.lane_handover = 1;
                 Pr.lane_zero = nullptr;
                 g1 = ((unsigned)P.batch + 7u) & ~7u; // (the list is dealt out in eighths: ric_tier_instance)
+                pass_ran = true;
             }
+            if (refs_now && !pass_ran)
+                return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: per-instance references on the shared-model records tier need the lane pass in front");
             LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
             hipLaunchKernelGGL(select_fused_kernel(Pr), dim3(g1), dim3(64), h->hp.lds_bytes, s, Pr);
             HIP_TRY(hipGetLastError());

@@ -681,6 +681,86 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
             viol = viol || (s <= -vsmall);
         }
     };
+    // Per-instance cost references (copra_batch_set_cost_reference: one model, every instance its own goal or reference trajectory).  The
+    // batch-wide records were swept with the controller-wide references p0; the recursion is AFFINE in the references, so this instance's
+    // feed-forward terms are  kv_k + dkv_k  with the DELTA sweep over the same records, no cost-to-go matrix needed:
+    //     q = dh_u + B' dpv+,   dkv_k = -Lam_k^-1 q  (Lam^-1 = Li' Li, RicRec::oLi),   dpv_k = dh_x + K_k' dh_u + Acl_k' dpv+,   dpv_N = dhN,
+    // dh = sum_t sum_r c_t(r) (p_t[r] - p0_t[r]) from the plan builder's coefficient table (lane_cref, as lmpc_lane_body).  About 80
+    // multiply-adds per stage with scalar operands -- the roll-out's cost once more.  dkv waits in the pass's workspace, lane-major.
+    bool own_refs = false, own_traj = false;
+    for (int t = 0; t < P.ncost; ++t) {
+        own_refs = own_refs || P.cost_p[t] != nullptr;
+        own_traj = own_traj || (P.cost_p[t] != nullptr && P.cost[t].pstride != 0);
+    }
+    own_refs = own_refs && P.lane_ws != nullptr && P.lane_cref >= 0;
+    double* const dkw = P.lane_ws;
+    const size_t dbp = (size_t)P.lane_bp;
+    if (own_refs) {
+        auto delta_h = [&](int k, bool terminal, double (&dh)[NZ], double (&dhN)[NX]) {
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) dh[a] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dhN[i] = 0.0;
+            for (int t = 0; t < P.ncost; ++t) {
+                if (!P.cost_p[t]) continue;
+                const CostTerm& ct = P.cost[t];
+                const int ps = ct.pstride;
+                // (the terminal term takes the reference of the last step; a cost without a step k has zero coefficients there)
+                const int kk = terminal ? (ps ? ct.prows / ps - 1 : 0) : ((ps && (k + 1) * ps > ct.prows) ? ct.prows / ps - 1 : k);
+                const double* const pi = P.cost_p[t] + (size_t)li * ct.prows + kk * ps;
+                const double* const p0 = P.params + ct.offP + kk * ps;
+                for (int r = 0; r < ct.rows; ++r) {
+                    const double dp = pi[r] - uniform_load(p0, r);
+                    const int co = P.lane_cref + (t * 6 + r) * (NZ + NX);
+#pragma unroll
+                    for (int a = 0; a < NZ; ++a) dh[a] += uniform_load(tab, co + a) * dp;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) dhN[i] += uniform_load(tab, co + NZ + i) * dp;
+                }
+            }
+        };
+        double dh[NZ], dpv[NX], unused[NX];
+        delta_h(0, true, dh, dpv); // dpv_N = dhN (dh: the stage term with the last reference -- replaced per stage for trajectories)
+        if (!own_traj) delta_h(0, false, dh, unused);
+        for (int k = NH - 1; k >= 0; --k) {
+            if (own_traj) delta_h(k, false, dh, unused);
+            const int rb = k * RR::SZ;
+            double qu[NU], tt[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double s2 = dh[NX + c];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s2 += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * dpv[i];
+                qu[c] = s2;
+            }
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                double s2 = 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c) s2 += uniform_load(F, rb + RR::oLi + r * (r + 1) / 2 + c) * qu[c];
+                tt[r] = s2;
+            }
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                double s2 = 0.0;
+#pragma unroll
+                for (int r = c; r < NU; ++r) s2 += uniform_load(F, rb + RR::oLi + r * (r + 1) / 2 + c) * tt[r];
+                dkw[((size_t)k * NU + c) * dbp + inst] = -s2;
+            }
+            double dn[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double s2 = dh[j];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) s2 += uniform_load(F, rb + RR::oK + c + NU * j) * dh[NX + c];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s2 += uniform_load(F, rb + RR::oAcl + i + NX * j) * dpv[i];
+                dn[j] = s2;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) dpv[j] = dn[j];
+        }
+    }
     for (int k0 = 0; k0 < NH; k0 += GS) {
         wave_sync();
 #pragma unroll
@@ -689,10 +769,12 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
             const bool on = k < NH;
             const int kk = on ? k : NH - 1;
             const int rb = kk * RR::SZ;
-            double u[NU];
+            double u[NU], kvk[NU]; // kvk: this instance's feed-forward term (the records' + its own delta)
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
-                double s = uniform_load(F, rb + RR::oKv + c);
+                kvk[c] = uniform_load(F, rb + RR::oKv + c);
+                if (own_refs) kvk[c] += dkw[((size_t)kk * NU + c) * dbp + inst];
+                double s = kvk[c];
 #pragma unroll
                 for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oK + c + NU * j) * x[j];
                 u[c] = s;
@@ -727,7 +809,7 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
 #pragma unroll
                 for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oAcl + i + NX * j) * x[j];
 #pragma unroll
-                for (int c = 0; c < NU; ++c) s += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * uniform_load(F, rb + RR::oKv + c);
+                for (int c = 0; c < NU; ++c) s += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * kvk[c];
                 xn[i] = s;
             }
 #pragma unroll

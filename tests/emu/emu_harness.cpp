@@ -541,7 +541,11 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     P.model_rtot = 0;
     P.x0 = x0;
     P.warm_set = warm_set;
-    // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, no per-instance references): one prepare
+    // per-instance cost references (emu_set_cost_reference): only the records form with the pass in front takes them here (the delta sweep of
+    // lmpc_lane_shared_body); the emulated lmpc_shared.hpp path has no reference columns in its model -> refused below
+    bool sh_refs = false;
+    for (int k = 0; k < kMaxCosts; ++k) sh_refs = sh_refs || g_cost_p[k] != nullptr;
+    // Riccati-factor tier in shared-model mode (as copra_batch_solve: cold starts, controller-wide references or the pass's delta sweep): one prepare
     // run of the body leaves the stage records, bkd, G and the row norms; the first tier copies them instead of sweeping
     std::vector<double> ric_model;
     // (as copra_batch_set_shared_system: the library's instantiations of the tier -- the compile-time horizons of (6, 3) and the run-time-horizon
@@ -598,9 +602,20 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     // in front of the Riccati-factor tier in shared-model mode: the one-instance-per-lane pass in its shared-model form (as copra_batch_solve)
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
     int lane_count = 0, lane_other = 0, lane_finished = -1;
-    if (ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass) { // (select_lane_shared_kernel: every shape of the tier)
+    const bool lane_sh = ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass;
+    if (sh_refs && !(lane_sh && P.lane_cref >= 0)) {
+        fprintf(stderr, "emu: shared-model references need the records form with the pass: ric_shared %d lane_tab %d ricC %d lane_cref %d\n", (int)ric_shared, P.lane_tab, (int)P.lds.ricC, P.lane_cref);
+        return (int)COPRA_ERR_UNSUPPORTED;
+    }
+    std::vector<double> lane_ws_sh;
+    if (lane_sh) { // (select_lane_shared_kernel: every shape of the tier)
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = groups * 64;
+        if (sh_refs) {
+            for (int k = 0; k < kMaxCosts; ++k) P.cost_p[k] = g_cost_p[k];
+            lane_ws_sh.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * (P.lane_bp + 64), 0.0);
+            P.lane_ws = lane_ws_sh.data();
+        }
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
@@ -630,6 +645,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     if (sizes) sizes[0] = ovf_count;
     if (sizes) sizes[1] = ric_shared ? 1 : 0;
     if (sizes) sizes[2] = lane_finished;
+    if (ovf_count > 0 && sh_refs) return (int)COPRA_ERR_UNSUPPORTED; // (the emulated second tier has no reference columns in its model)
     if (ovf_count > 0) {
         FusedPlan P2 = P;
         P2.lds = hp.lds_full;

@@ -179,10 +179,14 @@ def lmpc_solve_riccati(A, B, d, x0, N, costs, cstrs, initial_state=None, cost_re
 WARM_CAP = 32  # plan.hpp::kWarmCap
 
 
-def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
+def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None, cost_refs=None):
     """shared-model fast path: ONE system (A, B, d), x0 of shape (batch, nx).  warm: int32 array (batch, WARM_CAP) kept by
-    the caller across receding-horizon ticks (initialised to -1): the active set of the previous tick, shifted by one step"""
+    the caller across receding-horizon ticks (initialised to -1): the active set of the previous tick, shifted by one step.
+    cost_refs: {cost_index: array (batch, rows)} per-instance references -- the records form with the pass in front only"""
     _sync_options()
+    refs = {int(k): np.ascontiguousarray(v, dtype=np.float64) for k, v in (cost_refs or {}).items()}
+    for k in range(8):
+        lib().emu_set_cost_reference(k, _capi.dptr(refs[k]) if k in refs else C.c_void_p())
     A = np.asarray(A, dtype=np.float64)
     B = np.asarray(B, dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
@@ -203,6 +207,8 @@ def lmpc_solve_shared(A, B, d, x0, N, costs, cstrs, warm=None):
                                      p(tr), st.ctypes.data_as(C.POINTER(C.c_int)),
                                      it.ctypes.data_as(C.POINTER(C.c_int)), sizes,
                                      warm.ctypes.data_as(C.POINTER(C.c_int)) if warm is not None else C.c_void_p())
+    for k in range(8):
+        lib().emu_set_cost_reference(k, C.c_void_p())
     if rc != 0:
         raise RuntimeError("emulator failed rc=%d" % rc)
     return dict(control=u, trajectory=tr, status=st, iter=it, overflowed=sizes[0], riccati_factor=bool(sizes[1]), lane_pass_finished=sizes[2])

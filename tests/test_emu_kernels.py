@@ -1438,3 +1438,31 @@ def test_random_dense_qps_with_awkward_cases(emu, oracle):
     import fuzz_dense_qp as FQ
     bad, tot, seen = FQ.run(0, 30, emu=True, verbose=True)
     assert bad == 0 and tot == 480 and len(seen) >= 7
+
+
+@pytest.mark.parametrize("case", ["goals", "trajectories", "goals_N13"])
+def test_shared_model_records_tier_with_per_instance_references(emu, oracle, case):
+    """one model for the batch, every instance its own goal / reference trajectory: the shared lane pass adds the DELTA of the instance's
+    feed-forward terms to the batch-wide records (lmpc_lane_shared_body: dkv_k = -Lam_k^-1 (dh_u + B' dpv+), dpv_k = dh_x + K_k' dh_u +
+    Acl_k' dpv+) and hands U and X to the tier.  Against the oracle instance by instance incl. the iteration counters; compile-time
+    horizon 20 and run-time horizon 13"""
+    from copra_amd import workloads
+    b = 20
+    rng = np.random.default_rng(3)
+    N = 13 if case.endswith("13") else 20
+    wl = workloads.com_preview(b, N=N, seed=5)
+    A, B, d = wl["A"][3], wl["B"][3], wl["d"][3]
+    if case.startswith("goals"):
+        costs = wl["costs"]
+        refs = workloads.COM_X_GOAL[None, :] + 0.08 * rng.standard_normal((b, 6))
+    else:
+        ts = np.linspace(0, 1, N + 1)
+        xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+        costs = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)), wl["costs"][1]]
+        refs = np.tile(xref.reshape(-1), (b, 1)) + 0.05 * rng.standard_normal((b, 6 * (N + 1)))
+    re = emu.lmpc_solve_shared(A, B, d, wl["x0"], N, costs, wl["cstrs"], cost_refs={0: refs})
+    assert re["riccati_factor"] and 0 < re["lane_pass_finished"] < b
+    for k in range(b):
+        ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], N, [dict(costs[0], p=refs[k]), costs[1]], wl["cstrs"])
+        assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
+        assert _rel(re["control"][k], ro["control"]) <= 1e-7 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-7

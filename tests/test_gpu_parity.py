@@ -2521,3 +2521,50 @@ def test_random_dense_qps_with_awkward_cases_at_plugin_point_1(oracle):
     assert seen["not-pd"][1].get(2, 0) == seen["not-pd"][0] and seen["contradiction"][1].get(1, 0) == seen["contradiction"][0]
     assert seen["plain"][1].get(0, 0) == seen["plain"][0] and seen["unbounded"][1].get(0, 0) == seen["unbounded"][0]
     assert seen["pinned"][1].get("rounding-decided", 0) <= seen["pinned"][0] // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [20, 13])
+def test_per_instance_references_on_the_shared_model_records_tier(oracle, N):
+    """one model for the batch, every instance its own goal -- then its own reference trajectory -- at a batch the shared lane pass runs on:
+    the records (swept once with the controller-wide references) stay, each instance adds the DELTA of its feed-forward terms (the delta sweep
+    of lmpc_lane_shared_body: the recursion is affine in the references) and the tier takes U and X over.  Against the oracle instance by
+    instance (statuses, both iteration counters, U, X), against lmpc_shared.hpp (option no_ric_shared: the shared model's reference columns)
+    on the whole batch; compile-time horizon 20 and run-time horizon 13."""
+    from copra_amd import BatchLMPC, workloads
+    b = 24576
+    rng = np.random.default_rng(41)
+    wl = workloads.com_preview(b, N=N, v_max=0.5, u_max=2.5, seed=19)
+    A, B, d = wl["A"][5], wl["B"][5], wl["d"][5]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    track = [dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=xref.reshape(-1), weights=np.tile([10.0, 10, 10, 1, 1, 1], N + 1)), wl["costs"][1]]
+    cases = (("goals", wl["costs"], workloads.COM_X_GOAL[None, :] + 0.08 * rng.standard_normal((b, 6))),
+             ("trajectories", track, np.tile(xref.reshape(-1), (b, 1)) + 0.05 * rng.standard_normal((b, 6 * (N + 1)))))
+    for name, costs, refs in cases:
+        out, infos = [], []
+        for opts in (None, dict(no_ric_shared=1)):
+            eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"], options=opts)
+            eng.set_shared_system(A, B, d)
+            eng.set_x0(wl["x0"])
+            eng.set_cost_reference(0, refs)
+            eng.solve()
+            eng.solve()
+            out.append(eng.results())
+            infos.append((eng.layout_info()["lds_bytes"], eng.lane_pass_info()))
+            eng.close()
+        r1, r2 = out
+        assert infos[0][0] != infos[1][0] and infos[0][1][0] and 0 < infos[0][1][1] < b, (name, infos)  # (the records tier behind the pass ran)
+        good = (r1["status"] == 0) & (r2["status"] == 0)
+        assert good.sum() > b // 2 and (r1["status"] == r2["status"]).all() and (r1["iter"][good] == r2["iter"][good]).all(), name
+        assert _rel(r1["control"][good], r2["control"][good]) <= 1e-7, name
+        constrained = 0
+        for k in range(0, b, 509):
+            ck = [dict(costs[0], p=refs[k]), costs[1]]
+            ref = oracle.lmpc_solve(A, B, d, wl["x0"][k], N, ck, wl["cstrs"])
+            assert r1["status"][k] == ref["status"], (name, k)
+            if ref["status"] == 0:
+                assert tuple(r1["iter"][k]) == tuple(ref["iter"]) and _rel(r1["control"][k], ref["control"]) <= RTOL, (name, k)
+                assert _rel(r1["trajectory"][k], ref["trajectory"]) <= RTOL, (name, k)
+                constrained += int(ref["iter"][0] > 1)
+        assert constrained >= 4, name
