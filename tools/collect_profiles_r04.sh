@@ -59,6 +59,7 @@ python tools/exp/tier_choice_map.py 2>&1 | grep -v amdgpu.ids > $R/tier_choice_m
 python tools/exp/shared_tick_shapes.py 2>&1 | grep -v amdgpu.ids > $R/shared_tick_shapes.txt || true
 (python tests/fuzz/fuzz_shared_general_rows.py 0 300 1024 integrators 2>&1 | grep -v amdgpu.ids) > $R/fuzz_shared_integrators.txt || true
 (python tests/fuzz/fuzz_shared_general_rows.py 300 60 32768 integrators 2>&1 | grep -v amdgpu.ids) > $R/fuzz_shared_integrators_32768.txt || true
+(python tests/fuzz/fuzz_shared_general_rows.py 0 240 24576 integrators-refs 2>&1 | grep -v amdgpu.ids) > $R/fuzz_shared_integrators_refs.txt || true
 (python tests/fuzz/fuzz_dense_qp.py 1000 800 2>&1 | grep -v amdgpu.ids) > $R/fuzz_dense_qp.txt || true
 (python tests/fuzz/fuzz_modes.py 0 400 2>&1 | grep -v amdgpu.ids | grep " <\|ERROR\|mismatching" | cut -c1-400) > $R/fuzz_engine_modes.txt || true
 # ---- the bench line itself (with cpu_baseline and extra): AFTER the summaries, so that its roofline.traffic is the one just measured ----
