@@ -246,6 +246,12 @@ def extra_measurements(np, torch, dev):
     eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
     rate, sec = timed_rate(eng, b)
     out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5}
+    # ... and every instance its own goal (copra_batch_set_cost_reference): the batch-wide records stay, the shared lane pass adds the
+    # delta of each instance's feed-forward terms
+    goals = workloads.COM_X_GOAL[None, :] + 0.05 * np.random.default_rng(5).standard_normal((b, 6))
+    eng.set_cost_reference(0, torch.from_numpy(np.ascontiguousarray(goals)).to(dev))
+    rate, sec = timed_rate(eng, b)
+    out["shared_model_tick_per_instance_goals_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5}
     eng.close()
     # sensitivity: the tight workload (v_max 0.25 / u_max 1.2: every instance activates 3..22 constraints; the factor-only
     # layout steps down its ladder) -- the headline number depends on <= 5 active constraints per instance
