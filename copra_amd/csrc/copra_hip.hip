@@ -389,9 +389,11 @@ static size_t lane_lds_bytes(const FusedPlan& P)
 // copra::LMPC::solve() above all -- keep the wave-per-instance tier alone.
 // In front of the OTHER one-wave first tiers (ten times slower per instance than the Riccati-factor tier) it pays from a few thousand
 // instances on (tools/exp/lane_threshold.py: falling mass N = 32: 2048: 0.49 -> 0.38 ms, 16384: 2.78 -> 2.06; N = 64: 1.27 -> 0.08 ms).
-static bool lane_batch_ok(const copra_options_t& opt, int batch, bool ric_tier)
+// (shared-model controllers with per-instance references, refs: without the pass they run lmpc_shared.hpp, not the tier alone -- the pass
+//  with its delta sweep pays from about 10 k instances on: 8192: 0.129 vs 0.132 ms, 16384: 0.198 vs 0.160, profiles/r04/shared_goals_batches.txt)
+static bool lane_batch_ok(const copra_options_t& opt, int batch, bool ric_tier, bool refs = false)
 {
-    int least = ric_tier ? 20480 : 4096;
+    int least = ric_tier ? (refs ? 10240 : 20480) : 4096;
     if (opt.lane_min_batch != 0) least = opt.lane_min_batch < 0 ? 0 : opt.lane_min_batch;
     return batch >= least;
 }
@@ -458,6 +460,11 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
     //  -- except in shared-model mode, where there is no sweep to take over: there the pass must finish one instance in four to pay, measured)
     if (!h->shared && h->hp.plan.lds.ricC && !h->hp.opt.no_lane_handover) return COPRA_OK;
+    // (... and a shared-model controller with per-instance references: the pass carries their delta sweep, without it the controller runs
+    //  lmpc_shared.hpp, which the tier beats by 2 x whatever the share that ends in the pass)
+    if (h->shared && h->shared_ric)
+        for (int t = 0; t < kMaxCosts; ++t)
+            if (h->cost_p[t]) return COPRA_OK;
     h->lane_adapt_left -= 1;
     int left = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
@@ -1202,7 +1209,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             for (int t = 0; t < kMaxCosts; ++t) refs = refs || h->cost_p[t];
             if (want && refs) {
                 const FusedPlan Pw = device_plan(h);
-                want = !h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, Pw.batch, true) && Pw.lane_tab >= 0 && Pw.lane_cref >= 0
+                want = !h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, Pw.batch, true, true) && Pw.lane_tab >= 0 && Pw.lane_cref >= 0
                     && h->lds_ric.ricC && !Pw.prof && !Pw.prof_fine && !Pw.row_f_inst && select_lane_shared_kernel(Pw) != nullptr;
                 if (want && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for the delta terms: lmpc_shared.hpp)
                     (void)hipGetLastError();
@@ -1253,7 +1260,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             bool refs_now = false; // (then the pass MUST run: the choice of this tier above has checked that it can)
             for (int t = 0; t < kMaxCosts; ++t) refs_now = refs_now || h->cost_p[t];
             bool pass_ran = false;
-            if (!h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
+            if (!h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true, refs_now) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
                 && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, refs_now) == COPRA_OK || (h->lane_off = true, false))) {
                 // (no room for the pass's list: the tier alone, from now on -- as on the per-instance path below)
                 h->lane_cur ^= 1;

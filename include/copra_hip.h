@@ -244,7 +244,7 @@ copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const dou
  *      TrajectoryCost(M, p_b) / TargetCost / ControlCost / MixedCost object per LMPC (include/costFunctions.h:103-219).
  *      p == NULL restores the controller-wide p.  on_device != 0: used in place.  Works on the shared-model fast path
  *      too (the gradient is affine in p: c = c0 + C1 x0 + C2 p, probed once -- one column of C2 per entry of p, reference
- *      trajectories included; from 20 480 instances on, on the shapes of the Riccati-factor tier, the batch-wide stage records stay
+ *      trajectories included; from 10 240 instances on, on the shapes of the Riccati-factor tier, the batch-wide stage records stay
  *      and every instance adds the delta of its feed-forward terms: 193 M solves/s with per-instance goals, 327 M with per-instance
  *      reference trajectories at the headline shape, profiles/r04/shared_goals.txt, shared_tracking.txt). ---- */
 copra_status_t copra_batch_set_cost_reference(copra_batch_t* h, int cost_index, const double* p, int on_device);

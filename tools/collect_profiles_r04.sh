@@ -55,6 +55,7 @@ python tools/sweep_shapes.py --specialise 2>&1 | grep -v amdgpu.ids > $R/shape_s
 python tools/exp/shared_general_rows.py 2>&1 | grep -v amdgpu.ids > $R/shared_general_rows.txt || true
 python tools/exp/shared_tracking.py 2>&1 | grep -v amdgpu.ids > $R/shared_tracking.txt || true
 python tools/exp/shared_goals.py 2>&1 | grep -v amdgpu.ids > $R/shared_goals.txt || true
+python tools/exp/shared_goals_batches.py 2>&1 | grep -v amdgpu.ids > $R/shared_goals_batches.txt || true
 python tools/exp/tier_choice_map.py 2>&1 | grep -v amdgpu.ids > $R/tier_choice_map.txt || true
 python tools/exp/shared_tick_shapes.py 2>&1 | grep -v amdgpu.ids > $R/shared_tick_shapes.txt || true
 (python tests/fuzz/fuzz_shared_general_rows.py 0 300 1024 integrators 2>&1 | grep -v amdgpu.ids) > $R/fuzz_shared_integrators.txt || true
