@@ -310,6 +310,16 @@ def extra_measurements(np, torch, dev):
         "what": "TrajectoryCost as a full-size entry with a reference that changes along the horizon (the only form the reference's API has "
                 "for it), recognised as a per-step cost with the reference of the step"}
     eng.close()
+    # ... one model for the batch, every instance its OWN reference trajectory (a fleet tracking different paths): the batch-wide stage
+    # records + the delta sweep of the shared lane pass
+    eng = BatchLMPC(6, 3, wl["N"], b, track_costs, wl["cstrs"])
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
+    own = np.tile(xref.reshape(-1), (b, 1)) + 0.02 * np.random.default_rng(7).standard_normal((b, xref.size))
+    eng.set_cost_reference(0, torch.from_numpy(np.ascontiguousarray(own)).to(dev))
+    rate, sec = timed_rate(eng, b, reps=3)
+    out["shared_model_tracking_per_instance_trajectories_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3}
+    eng.close()
     # host-inclusive: numpy inputs -> layout conversion -> pageable H2D -> solve -> D2H of U, X, status
     wl = workloads.com_preview(b)
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
