@@ -515,9 +515,25 @@ def main():
     # Clock ramp: the first ~25 launches after an idle period run at a lower shader clock (kernel 751 us -> 690 us over them,
     # profiles/r02/dispatch_timeline.txt).  A fixed number of untimed solves -- about 30 ms -- gets the device to its steady
     # state before the W warm-up steps the contract asks for; reported as `spin_up_solves`.
+    # ... and, since one run in a dozen on this pool was still at the idle clock after them (profiles/r04/README.md: a bench line at the
+    # cold-clock rate, 0.59 ms, behind four minutes of counter passes), further untimed groups of ten until the time per solve has stopped
+    # falling (three groups within 1 %) or one second has passed.  Untimed, like the W warm-up steps; the count is in the line.
+    spin_up_done = 0
     for _ in range(SPIN_UP_SOLVES):
         solve_into(views0, 0)
     torch.cuda.synchronize()
+    spin_up_done += SPIN_UP_SOLVES
+    if world == 1 and not comm_path:
+        t_end, last, steady = time.perf_counter() + 1.0, None, 0
+        while time.perf_counter() < t_end and steady < 3:
+            t1 = time.perf_counter()
+            for _ in range(10):
+                solve_into(views0, 0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            steady = steady + 1 if (last is not None and abs(dt - last) <= 0.01 * last) else 0
+            last = dt
+            spin_up_done += 10
     for _ in range(args.warmup):
         loop.step(communicate=comm_path)
     torch.cuda.synchronize()
@@ -651,7 +667,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "spin_up_solves": SPIN_UP_SOLVES,
+            "spin_up_solves": spin_up_done,
             "cold_clock_ms_per_step": cold_ms,  # five steps after half a second of idle, before the spin-up: the clock a sporadic caller gets
             "cold_clock_solves_per_s": (batch / (cold_ms * 1e-3)) if cold_ms else None,
             "ms_per_step": elapsed / args.steps * 1e3,
