@@ -7,6 +7,9 @@ costFunctions.cpp:63-82) and moves it by replacing the cost object.  Here the co
   * x0 <- the state predicted for step 1 plus a disturbance, copra_batch_set_system with the device pointers, copra_batch_solve.
 The full-size cost is recognised as a per-step cost with the reference of the step and runs on the headline's kernels.
 
+With `shared_model=True` the batch is a fleet of IDENTICAL plants (copra_batch_set_shared_system): the factorisation is done once, every
+instance adds the delta of its own reference to it.
+
     python examples/tracking.py [batch] [ticks]
 """
 import os
@@ -31,7 +34,7 @@ def reference_window(tick, N, T=0.117, speed=0.4):
     return np.hstack([pos, vel])
 
 
-def run(batch=32768, ticks=50, seed=0, noise=0.002, per_instance=False):
+def run(batch=32768, ticks=50, seed=0, noise=0.002, per_instance=False, shared_model=False):
     dev = torch.device("cuda:0")
     wl = workloads.com_preview(batch, v_max=0.6, u_max=3.0)
     nx, nu, N = 6, 3, wl["N"]
@@ -44,6 +47,8 @@ def run(batch=32768, ticks=50, seed=0, noise=0.002, per_instance=False):
     x = torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev)
     gen = torch.Generator(device=dev).manual_seed(seed)
     stream = torch.cuda.current_stream().cuda_stream
+    if shared_model:
+        eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
     own = torch.empty((batch, nx * (N + 1)), dtype=torch.float64, device=dev) if per_instance else None
     phase = torch.rand(batch, 1, device=dev, generator=gen, dtype=torch.float64) * 0.01 if per_instance else None
     torch.cuda.synchronize()
@@ -57,7 +62,10 @@ def run(batch=32768, ticks=50, seed=0, noise=0.002, per_instance=False):
             eng.set_cost_reference(0, own)
         else:
             eng.set_cost_reference(0, ref)  # one new reference for every instance (1-D: copra_batch_set_cost_reference_all)
-        eng.set_system(A, B, d, x)  # device tensors (column-major A, B), used in place
+        if shared_model:  # a fleet of identical plants: ONE model for the batch (copra_batch_set_shared_system, above), only the states move;
+            eng.set_x0(x)  # per-instance references ride on the batch-wide factor (the delta sweep of the shared lane pass)
+        else:
+            eng.set_system(A, B, d, x)  # device tensors (column-major A, B), used in place
         eng.solve(stream)
         pred = out["trajectory"][:, nx:2 * nx].clone()
         pred[:, :3] += noise * torch.randn(batch, 3, device=dev, generator=gen, dtype=torch.float64)
@@ -66,7 +74,7 @@ def run(batch=32768, ticks=50, seed=0, noise=0.002, per_instance=False):
             err = float((x[:, :3] - ref[nx:nx + 3][None, :]).norm(dim=1).mean().item())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(batch=batch, ticks=ticks, per_instance_references=per_instance, seconds=dt, solves_per_s=batch * ticks / dt,
+    return dict(batch=batch, ticks=ticks, per_instance_references=per_instance, shared_model=shared_model, seconds=dt, solves_per_s=batch * ticks / dt,
                 solved_last_tick=int((out["status"] == 0).sum().item()), lane_pass=eng.lane_pass_info(), mean_position_error_last_tick=err)
 
 
@@ -76,3 +84,4 @@ if __name__ == "__main__":
     run(b, 5)  # (module load, LDS opt-in, first-solve set-up: outside the figures below)
     print(run(b, k))
     print(run(b, k, per_instance=True))
+    print(run(b, k, per_instance=True, shared_model=True))  # (a fleet of identical plants, every one on its own path)

@@ -1969,8 +1969,9 @@ def test_tracking_example_runs_on_device():
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "tracking.py")
     r = subprocess.run([sys.executable, exe, "24576", "40"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    for line in r.stdout.strip().splitlines()[-2:]:
-        res = ast.literal_eval(line)
+    lines = [ast.literal_eval(line) for line in r.stdout.strip().splitlines()[-3:]]
+    assert [bool(res["shared_model"]) for res in lines] == [False, False, True]  # (the last: a fleet of identical plants, one model for the batch)
+    for res in lines:
         assert res["solved_last_tick"] == 24576 and res["lane_pass"][0] and res["mean_position_error_last_tick"] < 0.01
 
 
