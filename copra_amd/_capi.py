@@ -8,6 +8,9 @@ import os
 
 import numpy as np
 
+# copra_code_object_check_t (include/copra_hip.h): the gate copra_batch_specialise_checked calls before it loads a code object
+CODE_OBJECT_CHECK = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_void_p)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcopra_hip.so")
 
@@ -284,6 +287,8 @@ def lib():
         L.copra_batch_lanes_per_instance.argtypes = [vp]
         L.copra_batch_specialise.restype = C.c_int
         L.copra_batch_specialise.argtypes = [vp, C.c_char_p]
+        L.copra_batch_specialise_checked.restype = C.c_int
+        L.copra_batch_specialise_checked.argtypes = [vp, C.c_char_p, CODE_OBJECT_CHECK, vp]
         L.copra_batch_layout_info.restype = C.c_int
         L.copra_batch_layout_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         L.copra_qp_dense_specialise.restype = C.c_int

@@ -58,23 +58,40 @@ class BatchLMPC:
 
     def specialise(self, cache_dir=None, lint=True):
         """compile this controller's shape into its own kernels (hipcc --genco, cached); see copra_batch_specialise.
-        lint: the freshly compiled code objects go through copra_amd/hazard_lint.py first (matrix-instruction results read too early on
-        some path of the compiled control flow: a defect of the compiler that round 4 met in the library's own kernels) -- one that
-        fails is deleted and this call raises; the controller keeps the library's kernels."""
-        if lint:
-            import os
-            from . import hazard_lint
-            d = cache_dir or os.environ.get("COPRA_JIT_CACHE") or os.path.join(os.environ.get("HOME", "/tmp"), ".cache", "copra_amd")
-            # (compile into the cache without loading: the C call below then finds checked objects -- or none, and compiles;
-            #  objects compiled by THAT call are checked right after it)
-            bad = hazard_lint.lint_jit_cache(d)
-            _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
-            bad += hazard_lint.lint_jit_cache(d)
-            if bad:
-                raise RuntimeError("copra_batch_specialise: the compiled kernels fail the matrix-instruction hazard check (%s: %r); they have been "
-                                   "removed from the cache -- create the controller again to run on the library's kernels" % bad[0])
+        lint: every code object -- cached or freshly compiled -- goes through copra_amd/hazard_lint.py BEFORE the library loads it
+        (matrix-instruction results read too early on some path of the compiled control flow: a defect of the compiler that round 4
+        met in the library's own kernels).  One that fails is deleted by copra_batch_specialise_checked, never loaded, and this
+        call raises; the handle is untouched and keeps solving on the library's kernels.  Objects that passed carry a `.lint_ok`
+        mark next to them and are not disassembled again."""
+        cdir = cache_dir.encode() if cache_dir else None
+        if not lint:
+            _capi.check(self._lib.copra_batch_specialise(self._h, cdir))
             return
-        _capi.check(self._lib.copra_batch_specialise(self._h, cache_dir.encode() if cache_dir else None))
+        import os
+        from . import hazard_lint
+        turned_away = []
+
+        def gate(path, _user):
+            path = path.decode()
+            mark = path + ".lint_ok"
+            if os.path.exists(mark) or not os.path.exists(hazard_lint.OBJDUMP):
+                return 0
+            try:
+                hits = hazard_lint.lint_code_object(path)
+            except Exception as e:  # (a code object that cannot be disassembled is not loaded either)
+                hits = [repr(e)]
+            if hits:
+                turned_away.append((os.path.basename(path), hits[0]))
+                return 1
+            open(mark, "w").close()
+            return 0
+
+        cb = _capi.CODE_OBJECT_CHECK(gate)
+        rc = self._lib.copra_batch_specialise_checked(self._h, cdir, cb, None)
+        if turned_away:
+            raise RuntimeError("copra_batch_specialise: the compiled kernels fail the matrix-instruction hazard check (%s: %r); the code object "
+                               "was removed without being loaded -- this controller keeps the library's kernels" % turned_away[0])
+        _capi.check(rc)
 
     def layout_info(self):
         """dict(lds_bytes, active_capacity, factor_only, two_tier) of the next solve (copra_batch_layout_info)"""

@@ -731,11 +731,15 @@ private:
     Eigen::VectorXd x_;
 };
 
-// include/solverUtils.h:34-50.  DEFAULT: the engine's own choice inside the fused device solve (Goldfarb-Idnani up to 64
-// variables, the stage-wise Riccati interior-point kernel for long stage-wise horizons); QuadProgDense: always the
-// Goldfarb-Idnani kernels (the reference's QuadProgDense arithmetic); HipQuadProg: the same through plug-in point 1.
+// include/solverUtils.h:34-50.  DEFAULT means what it means in the reference (src/solverUtils.cpp:9-34: DEFAULT -> QuadProgDense):
+// the Goldfarb-Idnani kernels at every size -- the reference's QuadProgDense arithmetic, SI_iter() / iterations = active-set
+// iterations.  HipQuadProg: the same through plug-in point 1.  HipRiccati (no counterpart in the reference): "the engine decides" --
+// the Goldfarb-Idnani kernels up to 64 variables and the stage-wise Riccati interior-point kernel for long stage-wise horizons
+// (COPRA_SOLVER_DEFAULT of the C ABI; its iteration counter counts Newton steps there, and at an ill-conditioned Hessian its result
+// is the optimum to 1e-10 where the QuadProgDense arithmetic carries the conditioning: INTEGRATION.md 1).
 using HipQuadProgSolver = QuadProgDenseSolver;
-enum class SolverFlag { DEFAULT, QuadProgDense, HipQuadProg };
+enum class SolverFlag { DEFAULT, QuadProgDense, HipQuadProg, HipRiccati };
+inline int engineSolver(SolverFlag f) { return f == SolverFlag::HipRiccati ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE; }
 inline std::unique_ptr<SolverInterface> solverFactory(SolverFlag) // src/solverUtils.cpp:9-34
 {
     return std::unique_ptr<SolverInterface>(new QuadProgDenseSolver());
@@ -780,7 +784,7 @@ public:
     {
         flag_ = flag;
         sol_.reset();
-        if (h_) throw_status(copra_batch_select_solver(h_, flag_ == SolverFlag::DEFAULT ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE));
+        if (h_) throw_status(copra_batch_select_solver(h_, engineSolver(flag_)));
     }
     // LMPC.cpp:67-70: plug-in point 1.  With a user solver the QP is condensed on the device, copied out and handed to
     // SI_problem / SI_solve / SI_result in the reference's order (LMPC.cpp:88-97, 284).
@@ -900,6 +904,13 @@ public:
     int fail() const noexcept { return fail_; }
     int iter() const noexcept { return iter_; }
     int handleBuilds() const noexcept { return handleBuilds_; } // (not in the reference: how often the device-side controller was built)
+    // (not in the reference) the algorithm the next solve() runs on the device: COPRA_SOLVER_QUADPROG_DENSE -- Goldfarb-Idnani, what every
+    // flag of the reference means -- or COPRA_SOLVER_RICCATI_IPM, which only SolverFlag::HipRiccati can select
+    int solverKind()
+    {
+        prepare();
+        return copra_batch_solver_info(h_);
+    }
     int nrEqConstr()
     {
         prepare();
@@ -1137,7 +1148,7 @@ protected:
         }
         const copra_dims_t dims = detail::dims_of(*ps_);
         throw_status(createHandle(dims, cd, kd));
-        throw_status(copra_batch_select_solver(h_, flag_ == SolverFlag::DEFAULT ? COPRA_SOLVER_DEFAULT : COPRA_SOLVER_QUADPROG_DENSE));
+        throw_status(copra_batch_select_solver(h_, engineSolver(flag_)));
         dirty_ = false;
         costsDirty_ = false;
         qpValid_ = false;

@@ -33,7 +33,23 @@ static std::string library_dir()
 
 // compile `source` (a translation unit that includes headers from the library's directory) into a code object named
 // `key` in the cache directory, unless it is already there; returns its path in `obj`
-static copra_status_t jit_compile(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj)
+// `check` (may be null) sees every code object BEFORE it is loaded -- cached or freshly compiled; a non-zero answer removes the object
+// from the cache and fails the call, so nothing the caller's check turned away ever reaches a handle.
+static copra_status_t jit_compile_unchecked(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj);
+static copra_status_t jit_compile(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj,
+    copra_code_object_check_t check = nullptr, void* user = nullptr)
+{
+    const copra_status_t rc = jit_compile_unchecked(key, source, cache_dir, obj);
+    if (rc != COPRA_OK || !check) return rc;
+    if (check(obj.c_str(), user) != 0) {
+        (void)unlink(obj.c_str());
+        return fail(COPRA_ERR_RUNTIME, "run-time specialisation: the caller's check turned the compiled code object away (" + obj
+                + " removed; the controller keeps the library's kernels)");
+    }
+    return COPRA_OK;
+}
+
+static copra_status_t jit_compile_unchecked(const std::string& key, const std::string& source, const char* cache_dir, std::string& obj)
 {
     const std::string src_dir = library_dir();
     std::string dir = cache_dir ? cache_dir : "";
@@ -142,6 +158,11 @@ copra_status_t copra_qp_dense_specialise(int n, const char* cache_dir)
 
 copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
 {
+    return copra_batch_specialise_checked(h, cache_dir, nullptr, nullptr);
+}
+
+copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cache_dir, copra_code_object_check_t check, void* user)
+{
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_specialise: null handle");
     const FusedPlan& P = h->hp.plan;
     if (h->jit_fused) return COPRA_OK;
@@ -175,7 +196,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
                 "{ lmpc_lane_body<%d, %d, %s>(P, (int)blockIdx.x); }\n",
                 P.nx, P.nu, P.N, kFusedQ1Regs, sr, P.nx, P.nu, P.N, sr, P.nx, P.nu, sr);
             std::string objr;
-            const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr);
+            const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr, check, user);
             if (rcr != COPRA_OK) return rcr;
             hipModule_t modr = nullptr;
             HIP_TRY(hipModuleLoad(&modr, objr.c_str()));
@@ -233,7 +254,7 @@ copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir)
             P.N, P.lds.tri ? "true" : "false");
     std::string obj;
     {
-        const copra_status_t rcj = jit_compile(key, source, cache_dir, obj);
+        const copra_status_t rcj = jit_compile(key, source, cache_dir, obj, check, user);
         if (rcj != COPRA_OK) return rcj;
     }
     hipModule_t mod = nullptr;

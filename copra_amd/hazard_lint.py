@@ -100,23 +100,24 @@ def parse_disassembly(path):
 
 def lint_library(so_path):
     """the SHIPPED binary: extract the gfx950 code objects of libcopra_hip.so, disassemble, lint (seconds)"""
-    tmp = tempfile.mkdtemp(prefix="copra_lint_")
-    local = os.path.join(tmp, os.path.basename(so_path))
-    with open(so_path, "rb") as f, open(local, "wb") as g:
-        g.write(f.read())
-    objdump = OBJDUMP
-    subprocess.run([objdump, "--offloading", os.path.basename(local)], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-    found, nobj, nmfma = [], 0, 0
-    for f in sorted(os.listdir(tmp)):
-        if "amdgcn" not in f:
-            continue
-        nobj += 1
-        dis = os.path.join(tmp, f + ".dis")
-        with open(dis, "w") as out:
-            subprocess.run([objdump, "-d", f], cwd=tmp, stdout=out, stderr=subprocess.DEVNULL, check=True)
-        nmfma += sum(1 for line in open(dis, errors="replace") if "\tv_mfma" in line)
-        found += [(f,) + h for h in lint(dis, disassembly=True)]
-    return found, nobj, nmfma
+    with tempfile.TemporaryDirectory(prefix="copra_lint_") as tmp:  # (several MB of code objects and listings: removed on the way out)
+        local = os.path.join(tmp, os.path.basename(so_path))
+        with open(so_path, "rb") as f, open(local, "wb") as g:
+            g.write(f.read())
+        objdump = OBJDUMP
+        subprocess.run([objdump, "--offloading", os.path.basename(local)], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        found, nobj, nmfma = [], 0, 0
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            nobj += 1
+            dis = os.path.join(tmp, f + ".dis")
+            with open(dis, "w") as out:
+                subprocess.run([objdump, "-d", f], cwd=tmp, stdout=out, stderr=subprocess.DEVNULL, check=True)
+            with open(dis, errors="replace") as listing:
+                nmfma += sum(1 for line in listing if "\tv_mfma" in line)
+            found += [(f,) + h for h in lint(dis, disassembly=True)]
+        return found, nobj, nmfma
 
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -124,40 +125,19 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 def lint_code_object(path):
     """one gfx950 code object (e.g. what copra_batch_specialise compiled at run time) -> findings"""
-    tmp = tempfile.mkdtemp(prefix="copra_lint_")
-    dis = os.path.join(tmp, os.path.basename(path) + ".dis")
-    obj = os.path.abspath(path)
-    with open(obj, "rb") as f:
-        bundled = f.read(24).startswith(b"__CLANG_OFFLOAD_BUNDLE__")
-    if bundled:  # (what hipcc --genco writes: host stub + device code object)
-        raw = os.path.join(tmp, os.path.basename(path) + ".co")
-        subprocess.run([os.path.join(os.path.dirname(OBJDUMP), "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                        "--input=" + obj, "--output=" + raw], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-        obj = raw
-    with open(dis, "w") as out:
-        subprocess.run([OBJDUMP, "-d", obj], stdout=out, stderr=subprocess.DEVNULL, check=True)
-    return lint(dis, disassembly=True)
-
-
-def lint_jit_cache(cache_dir):
-    """every run-time-compiled code object of the cache that has not been checked yet; one that fails is REMOVED (the controller then
-    keeps the library's kernels) and reported.  Nothing happens where llvm-objdump is not installed."""
-    if not os.path.exists(OBJDUMP) or not os.path.isdir(cache_dir):
-        return []
-    bad = []
-    for f in sorted(os.listdir(cache_dir)):
-        if not f.endswith(".hsaco"):
-            continue
-        full, mark = os.path.join(cache_dir, f), os.path.join(cache_dir, f + ".lint_ok")
-        if os.path.exists(mark):
-            continue
-        hits = lint_code_object(full)
-        if hits:
-            os.remove(full)
-            bad.append((f, hits[0]))
-        else:
-            open(mark, "w").close()
-    return bad
+    with tempfile.TemporaryDirectory(prefix="copra_lint_") as tmp:
+        dis = os.path.join(tmp, os.path.basename(path) + ".dis")
+        obj = os.path.abspath(path)
+        with open(obj, "rb") as f:
+            bundled = f.read(24).startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+        if bundled:  # (what hipcc --genco writes: host stub + device code object)
+            raw = os.path.join(tmp, os.path.basename(path) + ".co")
+            subprocess.run([os.path.join(os.path.dirname(OBJDUMP), "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + obj, "--output=" + raw], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            obj = raw
+        with open(dis, "w") as out:
+            subprocess.run([OBJDUMP, "-d", obj], stdout=out, stderr=subprocess.DEVNULL, check=True)
+        return lint(dis, disassembly=True)
 
 
 def successors(ins, labels, i):
@@ -233,6 +213,9 @@ def main():
                                            "--cuda-device-only", "-S", "-o", out, f], cwd=CSRC, stderr=subprocess.DEVNULL))
         for p in procs:
             p.wait()
+        import atexit
+        import shutil
+        atexit.register(shutil.rmtree, tmp, True)
     total = 0
     for f in files:
         hits = lint(f)

@@ -36,8 +36,15 @@ def _guard(fn):
 
 class SolverFlag:
     # include/solverUtils.h:34-50 -> copra_batch_select_solver
-    DEFAULT = 0  # the engine picks: Goldfarb-Idnani kernels, the stage-wise Riccati interior-point kernel for long horizons
+    DEFAULT = 0  # what it is in the reference (src/solverUtils.cpp:9-34: DEFAULT -> QuadProgDense): Goldfarb-Idnani at every size
     QuadProgDense = 1  # always the hand-written Goldfarb-Idnani kernels (the reference's QuadProgDense arithmetic)
+    HipRiccati = 2  # (no reference counterpart) the engine picks: the stage-wise Riccati interior-point kernel for long stage-wise horizons,
+    #                 Goldfarb-Idnani elsewhere; iteration counts are Newton steps there
+
+    @staticmethod
+    def engine_solver(flag):
+        """name of the engine's solver (BatchLMPC.select_solver) behind a flag"""
+        return "default" if flag == SolverFlag.HipRiccati else "quadprog_dense"
 
 
 class AutoSpan:
@@ -370,7 +377,7 @@ class LMPC:
             ist = self._initial_state_desc() if self._initial_state else None
             self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, cd, [c._dict() for c in self._cstrs],
                                   initial_state=ist)
-            self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
+            self._eng.select_solver(SolverFlag.engine_solver(self._flag))
             self._dirty, self._costs_dirty, self._built_costs = True, False, None
             self.handle_builds += 1
             return self._eng
@@ -382,7 +389,7 @@ class LMPC:
         ist = self._initial_state_desc() if self._initial_state else None
         self._eng = BatchLMPC(self._ps.x_dim, self._ps.u_dim, self._ps.nr_u_step, 1, [c._dict() for c in self._costs],
                               [c._dict() for c in self._cstrs], initial_state=ist)
-        self._eng.select_solver("quadprog_dense" if self._flag == SolverFlag.QuadProgDense else "default")
+        self._eng.select_solver(SolverFlag.engine_solver(self._flag))
         self._dirty = self._costs_dirty = False
         self.handle_builds += 1
         cp = lambda a: None if a is None else np.array(a, dtype=np.float64, copy=True)
@@ -394,7 +401,7 @@ class LMPC:
         """LMPC::selectQPSolver (src/LMPC.cpp:62-65)"""
         self._flag = flag
         if self._eng is not None:
-            self._eng.select_solver("quadprog_dense" if flag == SolverFlag.QuadProgDense else "default")
+            self._eng.select_solver(SolverFlag.engine_solver(flag))
 
     @_guard
     def solve(self):
@@ -434,6 +441,11 @@ class LMPC:
     def inform(self):
         print({0: "No problems", 1: "The minimization problem has no solution"}.get(
             self._fail, "Problems with the decomposition of Q (Is it symmetric?)"))
+
+    def solver_kind(self):
+        """(not in the reference) the algorithm the next solve() runs on the device: 'quadprog_dense' -- Goldfarb-Idnani, what every flag of
+        the reference means -- or 'riccati_ipm', which only SolverFlag.HipRiccati can select"""
+        return self._engine().solver()
 
     def solve_time(self):
         return self._solve_time  # device time of the launch (SI_solve only, LMPC.cpp:88-91)

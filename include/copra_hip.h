@@ -204,6 +204,11 @@ int copra_batch_lanes_per_instance(const copra_batch_t* h);
  *      kernels (BASELINE shapes, packed small problems, InitialStateLMPC, more than 64 variables).  Results are the
  *      same either way; COPRA_ERR_RUNTIME if hipcc is not available. ---- */
 copra_status_t copra_batch_specialise(copra_batch_t* h, const char* cache_dir);
+/* the same with a gate between compiler and loader: `check(path, user)` is called with the code object's path (cached or freshly
+ * compiled) BEFORE hipModuleLoad; a non-zero answer deletes the object, leaves the handle exactly as it was (the library's kernels)
+ * and returns COPRA_ERR_RUNTIME.  copra_amd/batch.py passes the matrix-instruction hazard lint (copra_amd/hazard_lint.py) here. */
+typedef int (*copra_code_object_check_t)(const char* code_object_path, void* user);
+copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cache_dir, copra_code_object_check_t check, void* user);
 
 /* ---- the checks of copra_batch_create / copra_batch_create_initial_state WITHOUT touching the device: what
  *      LMPC::addCost / addConstraint do when they call initializeCost / initializeConstraint (src/LMPC.cpp:118-128).

@@ -209,6 +209,28 @@ static void solve_cases(int nbStep)
             if (kind == 0 && nbStep >= 300) // the target is reachable over the full horizon (TestLMPC.cpp:78-83)
                 CHECK(std::fabs(controller.trajectory()(2 * s.nbStep + 1) - s.xd(1)) <= 1e-3);
             CHECK(controller.solveTime() > 0 && controller.solveAndBuildTime() >= controller.solveTime());
+            // src/solverUtils.cpp:9-34: SolverFlag::DEFAULT IS QuadProgDense -- at every size (round-4 verdict: above 64 variables the
+            // mirror's DEFAULT silently ran the interior-point kernel); that kernel is an explicit opt-in, SolverFlag::HipRiccati
+            CHECK(controller.solverKind() == COPRA_SOLVER_QUADPROG_DENSE);
+            if (kind == 0 && nbStep > 64) {
+                const Eigen::VectorXd uGI = controller.control();
+                const int itGI = controller.iter();
+                auto fast = copra::LMPC(ps, copra::SolverFlag::HipRiccati);
+                add_costs(fast, s, s.xd, kind);
+                fast.addConstraint(hold(std::make_shared<copra::TrajectoryBoundConstraint>(xLower, xUpper)));
+                fast.addConstraint(hold(std::make_shared<copra::ControlBoundConstraint>(uLower, uUpper)));
+                CHECK(fast.solverKind() == COPRA_SOLVER_RICCATI_IPM);
+                CHECK(fast.solve());
+                CHECK(itGI >= 1 && fast.iter() >= 1);
+                double du = 0.0, umax = 1.0;
+                for (int i = 0; i < (int)uGI.rows(); ++i) {
+                    du = std::max(du, std::fabs(fast.control()(i) - uGI(i)));
+                    umax = std::max(umax, std::fabs(uGI(i)));
+                }
+                CHECK(du <= 1e-6 * umax);
+                fast.selectQPSolver(copra::SolverFlag::DEFAULT); // ... and back: the reference's meaning again
+                CHECK(fast.solverKind() == COPRA_SOLVER_QUADPROG_DENSE);
+            }
             if (kind == 0) { // receding horizon: xInit without re-creating anything (PreviewSystem.h:52)
                 Eigen::VectorXd x1(2);
                 x1 << controller.trajectory()(2), controller.trajectory()(3);

@@ -59,12 +59,11 @@ def test_product_package_never_imports_the_oracle_or_emulator():
                     assert "tests.emu" not in src and "emu_harness" not in src, f
 
 
-def test_no_matrix_instruction_hazard_across_a_branch():
+def test_no_matrix_instruction_hazard_across_a_branch(tmp_path):
     """tools/mfma_hazard_lint.py on the SHIPPED binary (its gfx950 code objects extracted and disassembled): no matrix-instruction result
     is read fewer wait states later than the hardware needs on ANY path of the compiled control flow.  Round 4 found the compiler counting
     them on the fall-through side of a wave-uniform branch only -- wrong Riccati factors on the taken side, invisible to the emulator."""
     import sys
-    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import mfma_hazard_lint as lint
@@ -74,7 +73,7 @@ def test_no_matrix_instruction_hazard_across_a_branch():
     assert nobj >= 5 and nmfma > 1500  # (the kernels with matrix instructions were really looked at)
     assert not hits, hits[:5]
     # ... and the lint does find the pattern where it exists (the sweep as it was compiled before the fix, reduced to its skeleton)
-    tmp = tempfile.mkdtemp(prefix="copra_lint_")
+    tmp = str(tmp_path)
     bad = os.path.join(tmp, "synthetic.s")
     with open(bad, "w") as fh:
         fh.write("copra_synthetic_kernel:\n\tv_mfma_f64_4x4x4_4b_f64 v[28:29], v[28:29], v[10:11], v[32:33]\n\ts_cbranch_vccnz .LBB0_2\n"

@@ -1055,6 +1055,35 @@ def test_run_time_specialisation(oracle, tmp_path):
     assert ro["status"] == after["status"][7] == 0 and _rel(after["control"][7], ro["control"]) <= RTOL
 
 
+def test_specialise_gate_turns_a_code_object_away_before_it_is_loaded(oracle, tmp_path, monkeypatch):
+    """the hazard lint used to run AFTER copra_batch_specialise had loaded the new kernels into the handle.
+    copra_batch_specialise_checked calls the gate between compiler and loader: a rejected code object is deleted, never loaded,
+    the call raises -- and the SAME handle keeps solving on the library's kernels with the same results."""
+    from copra_amd import BatchLMPC, workloads, hazard_lint
+    b, N = 512, 14
+    wl = workloads.com_preview(b, N=N, v_max=0.3, u_max=1.5)
+    eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    r0 = eng.results()
+    monkeypatch.setattr(hazard_lint, "lint_code_object", lambda path: [("synthetic_kernel", 1, "v_mfma", 2, "v_mfma", 1, 6)])
+    with pytest.raises(RuntimeError, match="hazard check"):
+        eng.specialise(str(tmp_path))
+    assert not any(f.name.endswith(".hsaco") or f.name.endswith(".lint_ok") for f in tmp_path.iterdir())
+    eng.solve()  # (still the library's kernels: nothing of the rejected object reached the handle)
+    r1 = eng.results()
+    assert np.array_equal(r0["status"], r1["status"]) and np.array_equal(r0["iter"], r1["iter"])
+    ok = r0["status"] == 0  # (failed instances carry NaN; the layout the second solve of a controller runs on may differ: 1e-11)
+    assert ok.sum() > 0.9 * b and np.abs(r0["control"][ok] - r1["control"][ok]).max() <= 1e-9
+    monkeypatch.undo()
+    eng.specialise(str(tmp_path))  # the real lint lets the real kernels through, marks them, and now they are loaded
+    assert any(f.name.endswith(".lint_ok") for f in tmp_path.iterdir())
+    eng.solve()
+    r2 = eng.results()
+    assert np.array_equal(r0["status"], r2["status"]) and np.array_equal(r0["iter"], r2["iter"])
+    assert np.abs(r0["control"][ok] - r2["control"][ok]).max() <= 1e-9
+
+
 def test_r_quadprog_published_example_on_gpu():
     """copra_qp_solve_dense_batch on the published example of R's quadprog::solve.QP (the qpgen2 code eigen-quadprog
     wraps): solution 0.4761905 1.0476190 2.0952381, value -2.380952, iterations 3 0 -- third-party published vector"""

@@ -89,6 +89,34 @@ def test_lmpc_bound(S):  # pyTests.py:134-169
 
 
 @pytest.mark.gpu
+def test_default_solver_flag_is_quadprog_dense(S):
+    """src/solverUtils.cpp:9-34: SolverFlag::DEFAULT -> QuadProgDense, at every size.  (Round-4 verdict: above 64 variables the mirrors'
+    DEFAULT silently ran the interior-point kernel, SI_iter counted Newton steps.)  That kernel is an explicit opt-in: SolverFlag.HipRiccati."""
+    import copra_amd.pycopra as copra
+    ps, controller, keep = _controller(copra, S)  # 300 decision variables, stage-wise: the engine's own choice would be the interior-point kernel
+    cb = copra.ControlBoundConstraint(S.uLower, S.uUpper)
+    controller.add_constraint(cb)
+    assert controller.solver_kind() == "quadprog_dense"
+    assert controller.solve()
+    u_gi = controller.control().copy()
+    fast = copra.LMPC(ps, copra.SolverFlag.HipRiccati)
+    xCost, uCost = copra.TargetCost(S.M, -S.xd), copra.ControlCost(S.N, -S.ud)
+    xCost.weights(S.wx)
+    uCost.weights(S.wu)
+    fast.add_cost(xCost)
+    fast.add_cost(uCost)
+    fast.add_constraint(cb)
+    assert fast.solver_kind() == "riccati_ipm"
+    assert fast.solve()
+    assert np.abs(fast.control() - u_gi).max() <= 1e-6 * max(1.0, np.abs(u_gi).max())
+    fast.select_qp_solver(copra.SolverFlag.DEFAULT)
+    assert fast.solver_kind() == "quadprog_dense"
+    explicit = copra.LMPC(ps, copra.SolverFlag.QuadProgDense)
+    assert copra.SolverFlag.engine_solver(copra.SolverFlag.DEFAULT) == copra.SolverFlag.engine_solver(copra.SolverFlag.QuadProgDense) == "quadprog_dense"
+    del explicit
+
+
+@pytest.mark.gpu
 def test_lmpc_eq(S):  # pyTests.py:171-203
     import copra_amd.pycopra as copra
     ps, controller, keep = _controller(copra, S, x0=S.x0Eq)
