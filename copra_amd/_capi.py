@@ -49,14 +49,11 @@ class Options(C.Structure):
     (e.g. COPRA_OPTIONS=no_lane_pass=1,lane_min_batch=-1), which seeds OPTIONS below."""
     _fields_ = ([("struct_size", C.c_int)]
                 + [(n, C.c_int) for n in ("no_stage_refs", "no_step_rows", "no_selection_rows",
-                                           "no_ric", "no_tri", "ric_general", "no_dense_layout", "no_q1regs", "no_ladder", "no_packed",
-                                           "ric_any_shape", "tri_min", "tri_k", "ric_k", "overflow_share",
-                                           "no_lane_pass", "no_lane_handover", "lane_min_batch", "lane_share", "lane_keep",
-                                           "lane_tables_in_memory", "lane_dbg", "no_ric_shared",
-                                           "no_riccati", "no_ric_fast", "riccati_per_cu", "large_per_cu", "large_grid", "large_no_w4",
-                                           "large_params_lds")]
-                + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol", "ric_s0", "ric_lam0")]
-                + [("recorded_events", C.c_int), ("debug", C.c_int), ("lane_group", C.c_int)])
+                                           "no_ric", "no_tri", "ric_general", "no_dense_layout", "no_q1regs", "no_ladder", "no_packed", "ric_k",
+                                           "no_lane_pass", "no_lane_handover", "no_lane_spec", "lane_min_batch", "no_ric_shared",
+                                           "no_riccati", "no_ric_fast")]
+                + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol")]
+                + [("debug", C.c_int)])
 
 
 OPTION_NAMES = tuple(n for n, _ in Options._fields_ if n != "struct_size")
@@ -72,7 +69,7 @@ def _options_from_env():
         k = k.strip()
         if k not in OPTION_NAMES:
             raise ValueError("COPRA_OPTIONS: unknown option %r (known: %s)" % (k, ", ".join(OPTION_NAMES)))
-        out[k] = float(v) if k.startswith("ric_") and k.endswith(("tol", "s0", "lam0")) else int(v or "1")
+        out[k] = float(v) if k in ("ric_step_tol", "ric_mu_tol") else int(v or "1")
     return out
 
 

@@ -234,11 +234,9 @@ int large_grid(const copra_options_t& opt, const void* kernel, int batch, int th
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
     int per_cu = large_per_cu(kernel, threads, lds_bytes);
-    if (opt.large_per_cu > 0) per_cu = opt.large_per_cu; // (tuning aid)
     if (opt.debug)
         fprintf(stderr, "[copra] large grid: %d CUs x %d workgroups of %d threads, %zu B LDS\n", cus, per_cu, threads, lds_bytes);
     long long g = (long long)cus * per_cu;
-    if (opt.large_grid > 0) g = opt.large_grid; // (tuning aid)
     return (int)(g < batch ? g : batch);
 }
 
@@ -251,7 +249,6 @@ bool prefer_w4(const copra_options_t& opt, const void* full, const void* w4, int
         (void)hipFuncSetAttribute(full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         (void)hipFuncSetAttribute(w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     }
-    if (opt.large_no_w4) return false; // (tuning aid)
     return large_per_cu(w4, threads, lds_bytes) > large_per_cu(full, threads, lds_bytes);
 }
 
@@ -321,13 +318,13 @@ FusedPlan device_plan(const copra_batch* h)
     P.from_list = 0;
     P.lane_from_list = 0;
     P.lane_handover = 0;
-    P.lane_dbg = 0;
+    P.lane_spec = 0;
     P.lane_ws = nullptr;
+    P.lane_ws2 = nullptr;
     P.lane_list = nullptr;
     P.lane_count = P.lane_zero = nullptr;
     P.lane_hist = nullptr;
     P.lane_bp = 0;
-    P.lane_group = 0;
     P.ws = h->d_ws;
     P.model_out = nullptr;
     P.model = nullptr;
@@ -401,7 +398,7 @@ static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_
 {
     const copra_options_t& opt = h->hp.opt;
     if (h->lane_off || opt.no_lane_pass || !lane_batch_ok(opt, P.batch, P.lds.ric != 0)) return false;
-    if ((P.prof && !(opt.lane_dbg & 8)) || P.prof_fine) return false;
+    if (P.prof_fine) return false; // (the fine-grained stamps of the profiling build follow ONE kernel through a whole solve)
     // (in front of the Riccati-factor tier, which takes the factor over, or of any other one-wave first tier, where it only filters)
     if (P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || h->hp.large || P.initial_state) return false;
     for (int t = 0; t < kMaxCosts; ++t)
@@ -430,14 +427,17 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
     }
     if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
         e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
+    if (e == hipSuccess && need_ws && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
+        e = hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(h->d_lane_count);
         (void)hipFree(h->d_lane_list);
         (void)hipFree(h->d_lane_hist);
         (void)hipFree(h->d_lane_ws);
+        (void)hipFree(h->d_lane_ws2);
         h->d_lane_count = h->d_lane_list = h->d_lane_hist = nullptr;
-        h->d_lane_ws = nullptr;
+        h->d_lane_ws = h->d_lane_ws2 = nullptr;
         return fail(COPRA_ERR_HIP, std::string("one-instance-per-lane pass: ") + hipGetErrorString(e));
     }
     return COPRA_OK;
@@ -470,9 +470,8 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
     const long long done = (long long)h->hp.plan.batch - left;
-    long long share = h->shared ? 4 : 8;
-    if (h->hp.opt.lane_share > 0) share = h->hp.opt.lane_share; // (experiments)
-    if (done * share < (long long)h->hp.plan.batch && !h->hp.opt.lane_keep) h->lane_off = h->lane_off_by_share = true;
+    const long long share = h->shared ? 4 : 8;
+    if (done * share < (long long)h->hp.plan.batch) h->lane_off = h->lane_off_by_share = true;
     if (h->hp.opt.debug)
         fprintf(stderr, "[copra] one-instance-per-lane pass: %lld of %d instances ended in it%s\n", done, h->hp.plan.batch,
             h->lane_off ? " -- switched off" : "");
@@ -493,8 +492,7 @@ static copra_status_t adapt_layout(copra_batch* h)
     //  the ladder until only one instance in 64 is left over -- measured in round 3 over five constraint levels: 64 and 128 equal, 32
     //  leaves a mid-constrained workload on five columns at 42.8 instead of 50.4 M solves/s, 512 goes too far; the other first tiers
     //  keep the round-1 threshold of one in 8)
-    long long share = h->hp.plan.lds.ric ? 64 : 8;
-    if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share; // (experiments)
+    const long long share = h->hp.plan.lds.ric ? 64 : 8;
     if ((long long)count * share <= (long long)h->hp.plan.batch) return COPRA_OK;
     LdsLayout roomier {};
     if (next_tri_layout(h->hp.plan, h->hp.plan.lds, roomier, h->hp.opt.no_ladder != 0)) { // factor-only: one instance per CU fewer, more columns
@@ -569,8 +567,7 @@ static copra_status_t rechoose_layout(copra_batch* h)
         if (a > 0) larger[(size_t)a - 1] += 1;
     }
     for (int a = P.n - 1; a >= 0; --a) larger[(size_t)a] += larger[(size_t)a + 1];
-    long long share = P.lds.ric ? 64 : 8;
-    if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share;
+    const long long share = P.lds.ric ? 64 : 8;
     LdsLayout pick = h->lds_top;
     for (;;) {
         const int cap = pick.rcap < P.n ? pick.rcap : P.n;
@@ -695,7 +692,6 @@ copra_status_t prepare_riccati(copra_batch* h)
         (void)hipGetLastError();
         per_cu = 1;
     }
-    if (h->hp.opt.riccati_per_cu > 0) per_cu = h->hp.opt.riccati_per_cu; // (tuning aid)
     long long g = (long long)cus * per_cu;
     const int batch = h->hp.plan.batch > 0 ? h->hp.plan.batch : 1;
     h->ric_grid = (int)(g < batch ? g : batch);
@@ -919,6 +915,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_lane_list);
     (void)hipFree(h->d_lane_hist);
     (void)hipFree(h->d_lane_ws);
+    (void)hipFree(h->d_lane_ws2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evm) (void)hipEventDestroy(h->evm);
@@ -1326,7 +1323,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     // their launches with recorded events as before.
     const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri
         && h->jit_ric == (P.lds.ric != 0);
-    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed && !h->hp.opt.recorded_events;
+    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed;
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
     if (h->hp.large) {
         if (use_riccati(h)) {
@@ -1385,18 +1382,16 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->lane_cur ^= 1;
         h->lane_ran = true;
         P.lane_ws = h->d_lane_ws;
+        P.lane_ws2 = h->d_lane_ws2;
         P.lane_list = h->d_lane_list;
         P.lane_count = h->d_lane_count + h->lane_cur;
         P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
         P.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave) + kWave;
-        // instances per wave: 64.  (copra_options_t::lane_group = 32 runs HALF-WAVES -- twice the waves, lanes 32.. idle -- which was meant
-        // to fill the machine at a shard of BASELINE configs[3], 32 768 instances = 512 full waves on 1024 SIMDs: measured NO faster,
-        // 0.295 vs 0.286 ms per 32 768 and 0.575 vs 0.471 ms per 65 536 -- the pass's wave time is its arithmetic and its own dependent memory
-        // trips, not contention: profiles/r04/lane_half_waves.txt.  Kept as an experiment switch.)
-        P.lane_group = h->hp.opt.lane_group == 32 ? 32 : 64;
-        const unsigned g0 = (unsigned)(((long long)P.batch + P.lane_group - 1) / P.lane_group);
-        P.lane_dbg = h->hp.opt.lane_dbg;
+        // (64 instances per wave.  Half-waves -- twice the waves for a shard of BASELINE configs[3] -- were built in round 4 and measured no
+        //  faster, profiles/r04/lane_half_waves.txt: the switch and its code are gone.)
+        const unsigned g0 = (unsigned)(((long long)P.batch + kWave - 1) / kWave);
         P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover) ? 1 : 0; // (the pass leaves Lam^-1 and the norm sums only for a tier that takes them)
+        P.lane_spec = (P.lane_handover && !h->hp.opt.no_lane_spec) ? 1 : 0; // (... and takes the first step of the iteration itself where a bound on u_0 is the pick)
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
         const bool predict = h->lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;
@@ -1424,8 +1419,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             int hist[kLaneHistBins];
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(hist, h->d_lane_hist, sizeof hist, hipMemcpyDeviceToHost));
-            long long share = h->hp.plan.lds.ric ? 64 : 8;
-            if (h->hp.opt.overflow_share > 0) share = h->hp.opt.overflow_share;
+            const long long share = h->hp.plan.lds.ric ? 64 : 8;
             for (;;) {
                 long long over = 0;
                 for (int b = 0; b < kLaneHistBins; ++b)

@@ -175,7 +175,7 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
     // Single-control systems with fewer than 48 variables stay on the packed / factor-only kernels: the reference's falling-mass
     // problems hold most of their control bounds active, far beyond this tier's five register columns (measured, M solves/s,
     // this tier vs the others compiled for the shape: N = 5: 94 vs 339, 16: 6.8 vs 55, 32: 7.2 vs 16, 48: 29 vs 22, 64: 75 vs 29).
-    const bool ric_pays = P.nu >= 2 || P.n >= 48 || h->hp.opt.ric_any_shape;
+    const bool ric_pays = P.nu >= 2 || P.n >= 48;
     if (!h->shared && ric_pays && !h->hp.opt.no_ric && !h->hp.opt.no_tri) {
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {

@@ -113,6 +113,7 @@ struct copra_batch {
     long long layout_solves = 0; // solves completed on the current ladder (rechoose_layout)
     bool lds_top_set = false; // constraints relax gets its denser layout back)
     double* d_lane_ws = nullptr;
+    double* d_lane_ws2 = nullptr; // the instance-major hand-over blocks of the pass (FusedPlan::lane_ws2)
     int lane_cur = 0; // the counter the last solve appended to
     bool lane_ran = false; // the last solve ran the pass
     bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass)

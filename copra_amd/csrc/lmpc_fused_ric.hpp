@@ -34,7 +34,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     constexpr int NZ = NX + NU, NHM = NH ? NH : kWave / NU; // (NHM: the largest horizon this build may see)
     const int nh = NH ? NH : P.N;
     const int NV = NU * nh, X = NX * (nh + 1);
-    constexpr int NVM = NU * NHM, XM = NX * (NHM + 1);
+    constexpr int NVM = NU * NHM;
     constexpr int nxx = NX * (NX + 1) / 2, nux = NU * NX, nuu = NU * (NU + 1) / 2;
     static_assert(NX * (NZ + 1) <= kWave && nxx + nux + nuu + NZ <= kWave && NVM <= kWave, "one element per lane");
     static_assert(nxx + nux + nuu >= NX * (NX + 1), "affine lanes of the stage cost and of the terminal cost are disjoint (ric_tab)");
@@ -52,6 +52,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     double* nb = lds + L.nb;
     SolverLds S = carve_solver(lds, L);
     double* F = S.J; // NH stage records
+    double* const KV = lds + L.ricKv; // the feed-forward terms kv_k of the unconstrained minimiser, NU per stage (RicRec: not part of the records)
     // Where the trajectory lives once the roll-out has produced it.  Compact variant (LdsLayout::ricC: a row has a state term --
     // one component of one state -- or a control term, not both): the blocks G are NEVER STORED.  Their block-row norms, which is
     // all the row norms need, are taken by the preview steps; the normal of a state row enters w = R^-T n as a unit injection
@@ -85,38 +86,51 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     //  measured and dropped: 0.49 -> 0.53 / 0.54 ms per step.)
     const bool from_lane = !from_model && compact && P.lane_from_list && P.lane_handover && !P.ric_model_out;
     if (lane_failed) status = 2; // (its factorisation met a control block that is not positive definite)
-    // the unconstrained minimiser and its trajectory came from the pass in front (either form of it): no roll-out below
-    const bool have_ux = from_lane || (from_model && compact && P.lane_from_list && P.lane_handover);
+    // the unconstrained minimiser and its trajectory came from the SHARED-MODEL pass in front: no roll-out below.  (Behind the per-instance pass
+    // the tier rolls out for itself since round 5 -- 2 k cycles --: where that pass has taken the first step of the iteration speculatively,
+    // what it left in `control` / `trajectory` is that iterate, not the minimiser: lmpc_lane.hpp.)
+    const bool have_ux = from_model && compact && P.lane_from_list && P.lane_handover;
     if (from_lane) {
-        constexpr int KWl = NU * NX, WR = KWl + NU + NU * (NU + 1) / 2 + NX; // (plan.hpp: lane_ws_rows)
+        // K from the pass's lane-major workspace (rows k (NU NX + NU) + e, e < NU NX: one 64-byte sector per value -- what is left of a gather
+        // that round 4 measured at 16.5 k of the 44 k cycles of a tier instance, bound by the CU's sector requests), Lam^-1, kv and the norm
+        // sums from this instance's hand-over block (FusedPlan::lane_ws2: contiguous).
+        constexpr int KWl = NU * NX, WRK = KWl + NU, NL = NU * (NU + 1) / 2, NLU = NL + NU; // (plan.hpp: lane_ws_rows, lane_ws2_doubles)
         const double sysA = lane < NX * NX ? P.A[(size_t)inst * NX * NX + lane] : 0.0;
         const double sysB = lane < NX * NU ? P.B[(size_t)inst * NX * NU + lane] : 0.0;
         const double sysD = lane < NX ? P.d[(size_t)inst * NX + lane] : 0.0;
-        constexpr int NG = (NHM * WR + kWave - 1) / kWave, NT = (XM + kWave - 1) / kWave;
-        double gv[NG], gx[NT];
+        const double sysX = lane < NX ? P.x0[(size_t)inst * NX + lane] : 0.0;
+        constexpr int NGK = (NHM * KWl + kWave - 1) / kWave, NG2 = (NHM * (NLU + NX) + kWave - 1) / kWave;
+        double gk[NGK], g2[NG2];
         const double* const wsb = P.lane_ws + (size_t)inst;
 #pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const int idx = lane + kWave * u;
-            gv[u] = wsb[(size_t)(idx < nh * WR ? idx : 0) * (size_t)P.lane_bp];
+        for (int u = 0; u < NGK; ++u) {
+            const int idx = lane + kWave * u, k = idx / KWl, e = idx - k * KWl;
+            gk[u] = wsb[(size_t)(idx < nh * KWl ? k * WRK + e : 0) * (size_t)P.lane_bp];
         }
-        // the pass has also left the unconstrained minimiser (U in `control`, its trajectory in `trajectory`): no roll-out below
-        const double gu = P.control[(size_t)inst * NV + (lane < NV ? lane : 0)];
+        const int t2 = nh * (NLU + NX);
+        const double* const w2 = P.lane_ws2 + (size_t)inst * t2;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) gx[u] = P.trajectory[(size_t)inst * X + ((lane + kWave * u < X) ? lane + kWave * u : 0)];
+        for (int u = 0; u < NG2; ++u) g2[u] = w2[lane + kWave * u < t2 ? lane + kWave * u : 0];
         rows.cache_own_row();
         if (lane < NX * NX) A[lane] = sysA;
         if (lane < NX * NU) B[lane] = sysB;
-        if (lane < NX) D[lane] = sysD;
+        if (lane < NX) {
+            D[lane] = sysD;
+            X0[lane] = sysX;
+        }
 #pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const int idx = lane + kWave * u, k = idx / WR, e = idx - k * WR;
-            if (idx < nh * WR) {
-                double* dst = e < KWl        ? F + k * RR::SZ + RR::oK + e
-                    : e < KWl + NU           ? F + k * RR::SZ + RR::oKv + (e - KWl)
-                    : e < WR - NX            ? F + k * RR::SZ + RR::oLi + (e - KWl - NU)
-                                             : Xbar + k * NX + (e - (WR - NX)); // (NB2: the running block-row norms)
-                *dst = gv[u];
+        for (int u = 0; u < NGK; ++u) {
+            const int idx = lane + kWave * u, k = idx / KWl, e = idx - k * KWl;
+            if (idx < nh * KWl) F[k * RR::SZ + RR::oK + e] = gk[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NG2; ++u) {
+            const int idx = lane + kWave * u;
+            if (idx < nh * NLU) {
+                const int k = idx / NLU, e = idx - k * NLU;
+                *(e < NL ? F + k * RR::SZ + RR::oLi + e : KV + k * NU + (e - NL)) = g2[u];
+            } else if (idx < t2) {
+                Xbar[idx - nh * NLU] = g2[u]; // (NB2: the running block-row norms, [stage][NX])
             }
         }
         wave_sync();
@@ -133,16 +147,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         if (lane < NX) F[nh * RR::SZ + RR::cD + lane] = D[lane];
         if (lane == 0) F[nh * RR::SZ + RR::cZ] = 0.0;
         if (lane == 1) F[nh * RR::SZ + RR::cO] = 1.0;
-        wave_sync(); // (A, B, d have been read: the solver vectors share their place)
-        if (lane < NV) S.xs[lane] = gu;
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-            if (lane + kWave * u < X) XU[lane + kWave * u] = gx[u];
+        wave_sync();
         stamp[1] = cycle_counter();
     } else if (from_model) {
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
         for (int e = lane; e < nh * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
+        if (!(compact && P.lane_from_list && P.lane_handover)) // (behind the shared-model lane pass there is no roll-out here)
+            for (int e = lane; e < NV; e += kWave) KV[e] = P.ric_model[mBk + e];
         if (!compact) // (compact variant: the blocks G are not kept at all -- the row norms come from the model too)
             for (int e = lane; e < nh * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         if (have_ux) { // (behind the shared-model lane pass, lmpc_lane_shared_body: U and its trajectory are there already)
@@ -400,7 +412,9 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         const bool uu_on = q < NU && hb == 0 && r <= q;
         const int uu_off = RR::oLi + q * (q + 1) / 2 + r;
         const bool k_on = q < NU && (col_x || col_aff);
-        const int k_off = col_x ? RR::oK + q + NU * (scol - 4) : RR::oKv + q;
+        // (K_k into record k, kv_k into the block of its own: one pointer per lane that walks down with the stages)
+        double* wK = !k_on ? dummy : col_x ? F + (nh - 1) * RR::SZ + RR::oK + q + NU * (scol - 4) : KV + (nh - 1) * NU + q;
+        const int wKst = !k_on ? 0 : col_x ? RR::SZ : NU;
         double* wP[3];
         double* wA[3];
         int wAst[3];
@@ -568,7 +582,8 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
             }
             // K = -M_uu^-1 M_0  (rows u: K | kv in the affine column)
             const double Kr = mfma_f64_4x4x4(mine, M0, 0.0);
-            if (k_on) Fk[k_off] = Kr;
+            *wK = Kr;
+            wK -= wKst;
             // P_I = M_I + M_{0,I}' K   (rows / columns x: the new cost-to-go; affine column: p)
             const double P1 = mfma_f64_4x4x4(mu1, Kr, M1);
             const double P2 = mfma_f64_4x4x4(mu2, Kr, M2);
@@ -642,6 +657,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     wave_sync();
     if (P.ric_model_out && inst == P.dump_instance) { // prepare launch of the shared-model mode, first half
         for (int e = lane; e < nh * RR::SZ + RR::CST; e += kWave) P.ric_model_out[e] = F[e];
+        for (int e = lane; e < NV; e += kWave) P.ric_model_out[mBk + e] = KV[e];
         if (!compact)
             for (int e = lane; e < nh * NX * NU; e += kWave) P.ric_model_out[mG + e] = G[e];
     }
@@ -743,8 +759,10 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         // [B d] for the state rows (B kv + d = bkd_k: never stored), the identity for the rows u: the same at every stage
         const double a2 = (row < NX && q <= NU) ? F[nh * RR::SZ + (q < NU ? RR::cB + row + NX * q : RR::cD + row)]
                                                 : (b4 == 2 && r == q && q < NU) ? 1.0 : 0.0;
-        const double* kvp = (q < NU) ? F + RR::oKv + q : F + nh * RR::SZ + (q == NU ? RR::cO : RR::cZ);
-        const int kvst = (q < NU) ? RR::SZ : 0;
+        // (kv_k from its block -- in the compact variant the tail of XU: the state x_{k+1} this loop stores at NX (k + 1) .. stays below the
+        //  kv_{k+2} .. still to be read because NX >= NU, and kv_{k+1} is in a register by then: layout_lds_ric)
+        const double* kvp = (q < NU) ? KV + q : F + nh * RR::SZ + (q == NU ? RR::cO : RR::cZ);
+        const int kvst = (q < NU) ? NU : 0;
         const bool writer = q < NU && b4 == 2 && r == 0;
         // the states of the roll-out (rows 0 .. NX-1 of the stacked result: blocks 0 and 1) are the trajectory at the
         // unconstrained minimiser: kept for the first scan and, if that finds nothing violated, for the results

@@ -25,15 +25,13 @@ namespace copra_hip {
 // W doubles per instance, [batch][W] in HBM: the 64 instances of this wave are one contiguous block -- coalesced loads (ALL arrays
 // are requested before the first one is used: one trip to memory), transposed through LDS (odd stride: no bank conflicts) so that
 // every lane ends up with its own instance in registers
-// grp: instances per wave -- 64, or 32 on the HALF-WAVE form of the pass (FusedPlan::lane_group, an experiment switch: twice as many waves
-// with 32 instances each, lanes 32.. compute on a copy of the wave's first instance; measured no faster, profiles/r04/lane_half_waves.txt)
 template <int W>
-COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)[W], int grp = kWave)
+COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)[W])
 {
     const int lane = lane_id();
-    const size_t base = (size_t)group * grp * W;
-    const int left = batch - group * grp;
-    const int count = (left < grp ? left : grp) * W;
+    const size_t base = (size_t)group * kWave * W;
+    const int left = batch - group * kWave;
+    const int count = (left < kWave ? left : kWave) * W;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         const int e = j * kWave + lane;
@@ -41,12 +39,12 @@ COPRA_DEV void lane_fetch(const double* src, int group, int batch, double (&raw)
     }
 }
 template <int W>
-COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, double* lds, double (&out)[W], int grp = kWave)
+COPRA_DEV void lane_transpose_in(const double (&raw)[W], int group, int batch, double* lds, double (&out)[W])
 {
     constexpr int ST = W | 1;
     const int lane = lane_id();
-    const int left = batch - group * grp;
-    const int count = (left < grp ? left : grp) * W;
+    const int left = batch - group * kWave;
+    const int count = (left < kWave ? left : kWave) * W;
     wave_sync(); // (the previous array has left the staging area)
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -99,12 +97,15 @@ template <int NX, int NU, bool SREFS = false>
 COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 {
     constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 2; // (a row of the table: E | G | f | its index)
-    constexpr int oLiW = KW, oNbW = KW + NU * (NU + 1) / 2, WR = oNbW + NX; // rows of the workspace per stage (plan.hpp: lane_ws_rows)
+    constexpr int WR = KW; // rows of the lane-major workspace per stage (plan.hpp: lane_ws_rows): K | kv
+    // the instance-major hand-over block (plan.hpp: lane_ws2_doubles): Lam^-1 of every stage, then the norm sums -- staged in LDS per group
+    // of kLaneGroup stages and written as contiguous segments per instance, like U and X
+    constexpr int NL = NU * (NU + 1) / 2, NLU = NL + NU, GL = kLaneGroup; // (per stage of the block: Lam^-1 packed | kv)
     static_assert(NU >= 1 && NU <= 3, "the control block is eliminated in closed form");
     const int lane = lane_id();
-    const int GRP = P.lane_group > 0 ? P.lane_group : kWave; // instances of this wave (64, or 32: the half-wave form for small batches)
+    constexpr int GRP = kWave; // instances of this wave
     const int inst = group * GRP + lane;
-    const bool valid = lane < GRP && inst < P.batch;
+    const bool valid = inst < P.batch;
     const int NH = P.N;
     const double* tab = P.params + P.lane_tab;
     int oh_, oHN_, ohN_, oRows_;
@@ -112,21 +113,24 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
     double* lds = lds_base();
     if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0; // (the NEXT solve's counter: nobody reads it now)
+    const int left = P.batch - group * GRP;
+    const int ninst = left < GRP ? left : GRP; // instances of this wave
+    const int T2 = NH * (NLU + NX); // doubles per instance of the hand-over block
+    const bool handover = P.lane_handover && P.lane_ws2;
+    double* const ws2 = handover ? P.lane_ws2 + (size_t)(group * GRP) * T2 : nullptr;
 
-    long long stamp[5];
-    stamp[0] = cycle_counter();
     // ---- 0. this lane's system ----
     double A[NX * NX], B[NX * NU], d[NX], x[NX];
     {
         double rA[NX * NX], rB[NX * NU], rd[NX], rx[NX];
-        lane_fetch<NX * NX>(P.A, group, P.batch, rA, GRP);
-        lane_fetch<NX * NU>(P.B, group, P.batch, rB, GRP);
-        lane_fetch<NX>(P.d, group, P.batch, rd, GRP);
-        lane_fetch<NX>(P.x0, group, P.batch, rx, GRP);
-        lane_transpose_in<NX * NX>(rA, group, P.batch, lds, A, GRP);
-        lane_transpose_in<NX * NU>(rB, group, P.batch, lds, B, GRP);
-        lane_transpose_in<NX>(rd, group, P.batch, lds, d, GRP);
-        lane_transpose_in<NX>(rx, group, P.batch, lds, x, GRP);
+        lane_fetch<NX * NX>(P.A, group, P.batch, rA);
+        lane_fetch<NX * NU>(P.B, group, P.batch, rB);
+        lane_fetch<NX>(P.d, group, P.batch, rd);
+        lane_fetch<NX>(P.x0, group, P.batch, rx);
+        lane_transpose_in<NX * NX>(rA, group, P.batch, lds, A);
+        lane_transpose_in<NX * NU>(rB, group, P.batch, lds, B);
+        lane_transpose_in<NX>(rd, group, P.batch, lds, d);
+        lane_transpose_in<NX>(rx, group, P.batch, lds, x);
     }
     // the stage cost H | h into LDS, behind the staging area: read there by every stage of the sweep (a wave-uniform address: one
     // broadcast read per entry, in order -- scalar loads come back out of order and every use waited for all of them)
@@ -148,7 +152,6 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     wave_sync();
     auto AB = [&](int l, int a) -> double { return a < NX ? A[l + NX * a] : B[l + NX * (a - NX)]; }; // [A B](l, a)
 
-    stamp[1] = cycle_counter();
     // Per-instance cost references (copra_batch_set_cost_reference: every instance tracks its own goal): the affine terms h = -sum_t
     // [M N]_t' W_t p_t and hN differ per lane then.  They are rebuilt from the coefficient table of the plan builder (lane_cref), this
     // lane's references where a cost has them and the controller-wide ones elsewhere, and h waits in the (idle) staging area for the sweep.
@@ -157,7 +160,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double hNl[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) hNl[i] = uniform_load(tab, ohN + i);
-    constexpr int HS = NZ | 1;
+    constexpr int HS = (NZ + GL * NLU + 2 * NX) | 1; // this lane's slot of the staging area during the sweep: h (NZ) | Lam^-1 of the group's stages |
+                                                    // x0 and d, which wait here for the roll-out -- the sweep reads d from the slot (ONE address
+                                                    // register for all; odd: no bank conflicts)
     double hl[NZ]; // (the sweep reads h from this lane's slot of the staging area either way: no branch per use in its loop)
 #pragma unroll
     for (int a = 0; a < NZ; ++a) hl[a] = uniform_load(tab, oh + a);
@@ -187,6 +192,12 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     wave_sync();
 #pragma unroll
     for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hl[a];
+    // (x0 is not needed before the roll-out: twelve registers the sweep -- at the full register file -- has better use for)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        lds[lane * HS + NZ + GL * NLU + i] = x[i];
+        lds[lane * HS + NZ + GL * NLU + NX + i] = d[i];
+    }
     wave_sync();
     // ---- 1. backward Riccati sweep; K_k | kv_k to the workspace, lane-major: element e of stage k at ws[(k KW + e) bp + inst] ----
     double* const ws = P.lane_ws;
@@ -246,12 +257,14 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         const double* const Hk = lds + hoff;
         double M[NZ][NZ], mz[NZ]; // upper triangle (a <= b)
         {
-            double tq[NX]; // P+ d + p+
+            double tq[NX], dl[NX]; // P+ d + p+  (d from this lane's slot: twelve registers less across the stage)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dl[i] = lds[lane * HS + NZ + GL * NLU + NX + i];
 #pragma unroll
             for (int l = 0; l < NX; ++l) {
                 double s = pv[l];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s += Ps(l, i) * d[i];
+                for (int i = 0; i < NX; ++i) s += Ps(l, i) * dl[i];
                 tq[l] = s;
             }
 #pragma unroll
@@ -341,17 +354,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
         // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
         double* const wk = ws + ((size_t)k * WR) * bp;
-        if (!(P.lane_dbg & 2)) {
 #pragma unroll
-            for (int c = 0; c < NU; ++c) {
+        for (int c = 0; c < NU; ++c) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
-                lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
-            }
-            // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier,
-            // and only when it takes the factor over (FusedPlan::lane_handover; round-3 advisor finding: in front of the other tiers the
-            // pass only filters, and these six rows and the six norm rows below were dead traffic)
-            if (!P.lane_handover) continue;
+            for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
+            lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
+        }
+        // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier,
+        // and only when it takes the factor over (FusedPlan::lane_handover; round-3 advisor finding: in front of the other tiers the
+        // pass only filters, and these values and the norm sums below were dead traffic).  Into this lane's slot of the LDS staging area
+        // (behind h), the group's segment of every instance leaves when its last stage is done.
+        if (handover) {
             double lm[NU][NU], rd[NU], lid[NU][NU];
 #pragma unroll
             for (int cb = 0; cb < NU; ++cb)
@@ -385,12 +398,42 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                         li = v * rd[r2];
                     }
                     lid[r2][c] = li;
-                    lane_put(wk + (size_t)(oLiW + r2 * (r2 + 1) / 2 + c) * bp, ioff, li, true); // (streaming: for the first tier only)
+                    lds[lane * HS + NZ + (k % GL) * NLU + r2 * (r2 + 1) / 2 + c] = li;
                 }
+#pragma unroll
+            for (int c = 0; c < NU; ++c) lds[lane * HS + NZ + (k % GL) * NLU + NL + c] = kv[c]; // (the tier rolls out itself: lmpc_fused_ric.hpp)
+            if (k % GL == 0) { // stages k .. k + GL - 1 (fewer in the group that holds the last stage)
+                const int cnt = NH - k < GL ? NH - k : GL;
+                wave_sync();
+                double* const dst = ws2 + (size_t)k * NLU;
+                int lq = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(lq)); // (opaque per group: the index arithmetic below stays here -- hoisted out of the sweep's loop its
+                                             //  48 lane-dependent values pushed six registers of the sweep into scratch memory)
+#endif
+#pragma unroll 4
+                for (int j = 0; j < GL * NLU; ++j) {
+                    const int e = j * kWave + lq, il = e / (GL * NLU), c = e - il * (GL * NLU);
+                    if (il < ninst && c < cnt * NLU) dst[(size_t)il * T2 + c] = lds[il * HS + NZ + c];
+                }
+                wave_sync(); // (the staging area is written again by the next group)
+            }
         }
     }
 
-    stamp[2] = cycle_counter();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double xi = lds[lane * HS + NZ + GL * NLU + i], di = lds[lane * HS + NZ + GL * NLU + NX + i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(xi), "+v"(di)); // (really read back: the values do not stay in registers across the sweep)
+#endif
+        x[i] = xi;
+        d[i] = di;
+    }
+    // Lam_0^-1 from the slot of stage 0 (still there: the group that holds stage 0 was the last one staged) -- the speculative step below
+    double lam0[NL];
+#pragma unroll
+    for (int e = 0; e < NL; ++e) lam0[e] = handover ? lds[lane * HS + NZ + e] : 0.0;
     // ---- 2. roll-out from x0 with qpgen2's first scan inside: rows of step k on (x_k, u_k), the bounds of u_k ----
     const double vsmall = P.vsmall;
     const int rps = P.lane_rps;
@@ -407,11 +450,12 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     constexpr int GS = kLaneGroup, SX = (GS * NX) | 1, SU = (GS * NU) | 1;
     double* const ldx = lds; // [lane][SX]
     double* const ldu = lds + kWave * SX; // [lane][SU]
+    double* const ldn = lds + kWave * (SX + SU); // [lane][SX]: the norm sums of the group (hand-over block)
     auto fetch_stage = [&](double (&buf)[KW], int k) {
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
-        for (int e = 0; e < KW; ++e) buf[e] = (P.lane_dbg & 2) ? 0.0 : lane_get(wk + (size_t)e * bp, ioff);
+        for (int e = 0; e < KW; ++e) buf[e] = lane_get(wk + (size_t)e * bp, ioff);
     };
     // the right-hand side of a row: the controller's, or this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the
     // stacked order; a row of the table that is not there keeps +inf)
@@ -426,37 +470,81 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
         return f;
     };
-    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) { // E x_k + G u_k <= f
+    // ---- the FIRST STEP of the active-set iteration, speculatively (round 5) ----
+    // Where the unconstrained minimiser saturates an actuator NOW -- a bound on u_0 is its most violated constraint, qpgen2's first pick: on
+    // BASELINE configs[2] that is every one of the 53 % of the instances this pass used to leave to the first tier, and 71 % of them are
+    // finished by that one constraint -- the step the iteration takes has a closed form in the quantities of THIS roll-out.  The normal of
+    // a bound on component c of u_0 is n = -+e_c in stage 0 and zero elsewhere, so w = R^-T n stops at stage 0 (ric_factor.hpp: the backward
+    // recursion never starts), t_0 = Lam_0^-T Lam_0^-1 n, z_0 = t_0, and from stage 1 on z_k = K_k xi_k IS the closed loop: the new iterate
+    // U0 + t z is the roll-out from x0 with  u_0 + t t_0  in front and the same gains behind.  So a second state rides along (x1, u1: one
+    // more K x + kv and A x + B u + d per stage), its rows and bounds are scanned like the first one's, and at the end
+    //     nothing violated at U0                                     -> done, iterations (1, 0)              (as before)
+    //     the bound was the pick (strictly the worst of ALL rows, normalised as qpgen2 does) and U1 violates nothing
+    //                                                                -> done, iterations (2, 0): U1, X1 are the results
+    //     anything else (another pick, a tie, more to do at U1)     -> the first tier, from scratch
+    // Same decisions as the tier (its pick, its step length -s / z'n with z'n = |Lam_0^-1 e_c|^2, its test slack <= -vsmall at the new
+    // iterate with the new active row left out); near-ties (1e-9 relative) go to the tier.  A lane that speculates writes U1, X1 to the
+    // results -- the verdict comes last --, which is why the tier behind this pass rolls out for itself (lmpc_fused_ric.hpp, from_lane).
+    const bool spec_on = handover && P.lane_spec;
+    bool spec = false, uniq = true, viol1 = false;
+    int sc = -1; // component of u_0 whose bound is speculated on
+    double sstar = 0.0, sstar2 = 0.0; // its slack at U0 (negative), squared
+    double x1[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) x1[c] = x[c];
+    // one row  e' x + g' u <= f  at both iterates
+    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[NX], const double (&uk)[NU],
+                        const double (&xk1)[NX], const double (&uk1)[NU], const double (&nc)[NX]) {
+        double ax = 0.0, ax1 = 0.0, n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            ax += e[c] * xk[c];
+            ax1 += e[c] * xk1[c];
+            n2 += (e[c] * e[c]) * nc[c]; // (the compact variant's rows: ONE component of the state, or controls only)
+        }
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            ax += g[c] * uk[c];
+            ax1 += g[c] * uk1[c];
+            n2 += g[c] * g[c];
+        }
+        const double s0 = f - ax, s1 = f - ax1;
+        const bool v0 = s0 <= -vsmall; // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+        viol = viol || v0;
+        nviol += v0 ? 1 : 0;
+        // a row at least as bad as the speculated bound by qpgen2's measure, slack / norm (squared: no root, no division): not our pick
+        uniq = uniq && !(v0 && s0 * s0 >= (sstar2 * n2) * (1.0 - 1e-9));
+        viol1 = viol1 || (s1 <= -vsmall);
+    };
+    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU], const double (&xk1)[NX], const double (&uk1)[NU],
+                          const double (&nc)[NX]) { // E x_k + G u_k <= f
         if (tlds) {
             for (int r = 0; r < rps; ++r) {
                 const double* const rt = Tl + (k * rps + r) * RW;
-                double ax = 0.0;
+                double e[NX], g[NU];
 #pragma unroll
-                for (int c = 0; c < NX; ++c) ax += rt[c] * xk[c];
+                for (int c = 0; c < NX; ++c) e[c] = rt[c];
 #pragma unroll
-                for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
-                const double s = row_rhs(rt[NZ], (int)rt[NZ + 1]) - ax;
-                viol = viol || (s <= -vsmall); // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
-                nviol += (s <= -vsmall) ? 1 : 0;
+                for (int c = 0; c < NU; ++c) g[c] = rt[NX + c];
+                row_eval(e, g, row_rhs(rt[NZ], (int)rt[NZ + 1]), xk, uk, xk1, uk1, nc);
             }
             return;
         }
         for (int r = 0; r < rps; ++r) {
             const int ro = oRows + (k * rps + r) * RW;
-            double ax = 0.0;
+            double e[NX], g[NU];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ax += uniform_load(tab, ro + c) * xk[c];
+            for (int c = 0; c < NX; ++c) e[c] = uniform_load(tab, ro + c);
 #pragma unroll
-            for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
-            const double s = row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)) - ax;
-            viol = viol || (s <= -vsmall);
-            nviol += (s <= -vsmall) ? 1 : 0;
+            for (int c = 0; c < NU; ++c) g[c] = uniform_load(tab, ro + NX + c);
+            row_eval(e, g, row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)), xk, uk, xk1, uk1, nc);
         }
     };
     constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
     static_assert(GS % KB == 0, "the buffers rotate inside a group");
     // block-row norms of the preview blocks G_s = A^s B as running sums over s (one stage of the roll-out = one block): what the row norms
-    // of the first tier's compact variant are read from (lmpc_fused_ric.hpp: NB2)
+    // of the first tier's compact variant are read from (lmpc_fused_ric.hpp: NB2) -- and what the rows of step k are normalised by above
+    // (a row on x_k has the squared norm sum_{t < k} |row of G_t|^2: the sums BEFORE block k joins them)
     double Gp[NX * NU], ncum[NX];
 #pragma unroll
     for (int e = 0; e < NX * NU; ++e) Gp[e] = B[e];
@@ -465,32 +553,114 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double Kq[KB][KW];
 #pragma unroll
     for (int q = 0; q < KB; ++q) fetch_stage(Kq[q], q);
-    const int left = P.batch - group * GRP;
-    const int ninst = left < GRP ? left : GRP;
     for (int k0 = 0; k0 < NH; k0 += GS) {
         wave_sync(); // (the previous group has left the staging area)
 #pragma unroll
         for (int q = 0; q < GS; ++q) {
             const int k = k0 + q;
             const bool on = k < NH;
-            double u[NU];
+            double u[NU], u1[NU];
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
-                double s = Kq[q % KB][NU * NX + c];
+                double s = Kq[q % KB][NU * NX + c], s1 = s;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) s += Kq[q % KB][c + NU * j] * x[j];
+                for (int j = 0; j < NX; ++j) {
+                    s += Kq[q % KB][c + NU * j] * x[j];
+                    s1 += Kq[q % KB][c + NU * j] * x1[j];
+                }
                 u[c] = s;
+                u1[c] = s1;
             }
             fetch_stage(Kq[q % KB], k + KB);
-            if (on && !(P.lane_dbg & 2) && P.lane_handover) { // |row i of G_k|^2 added, stored, and the next block
-                double* const wn = ws + ((size_t)k * WR + oNbW) * bp;
+            // the bounds of u_k
+            double ubk[NU], lbk[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) { // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
+                const int kc = (on ? k : 0) * NU + c;
+                if (own_bounds) {
+                    ubk[c] = ubp[kc];
+                    lbk[c] = lbp[kc];
+                } else if (tlds) {
+                    ubk[c] = Tl[tl_rows + kc];
+                    lbk[c] = Tl[tl_rows + P.n + kc];
+                } else {
+                    ubk[c] = uniform_load(ubp, kc);
+                    lbk[c] = uniform_load(lbp, kc);
+                }
+            }
+            if (q == 0 && k0 == 0 && spec_on) {
+                // the most violated bound of u_0: qpgen2's order -- upper bounds (rows mgen + j) before lower ones (mgen + n + j), the first of
+                // equals wins -- so a tie is not decided here: strictly worse than every other one, or no speculation
+                double best = 0.0, second = 0.0, sig = 0.0;
+#pragma unroll
+                for (int i = 0; i < 2 * NU; ++i) {
+                    const int c = i < NU ? i : i - NU;
+                    const double sl = i < NU ? ubk[c] - u[c] : u[c] - lbk[c];
+                    const bool cand = sl <= -vsmall;
+                    const bool better = cand && sl < best;
+                    second = better ? best : ((cand && sl < second) ? sl : second);
+                    best = better ? sl : best;
+                    sc = better ? c : sc;
+                    sig = better ? (i < NU ? -1.0 : 1.0) : sig;
+                }
+                double ubc = 0.0, lbc = 0.0;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    ubc = (c == sc) ? ubk[c] : ubc;
+                    lbc = (c == sc) ? lbk[c] : lbc;
+                }
+                spec = sc >= 0 && best < second && !bad && !(ubc - lbc <= -vsmall); // (an empty box: the tier reports it)
+                // t_0 = Lam_0^-T (Lam_0^-1 n), n = sig e_c; z'n = sig t_0(c) = |Lam_0^-1 e_c|^2
+                double w[NU], t0[NU];
+#pragma unroll
+                for (int r = 0; r < NU; ++r) {
+                    double lrc = 0.0; // Lam^-1 (r, sc): zero above the diagonal
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) lrc = (c == sc) ? lam0[r * (r + 1) / 2 + c] : lrc;
+                    w[r] = sig * lrc;
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = j; r < NU; ++r) acc += lam0[r * (r + 1) / 2 + j] * w[r];
+                    t0[j] = acc;
+                }
+                double zn = 0.0, zz = 0.0;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    zn = (j == sc) ? sig * t0[j] : zn;
+                    zz += t0[j] * t0[j];
+                }
+                spec = spec && zn > 0.0 && zz > vsmall; // (gi_core.hpp: no step in primal space -- the tier's business)
+                const double tt = spec ? -best / zn : 0.0;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) u1[j] = u[j] + tt * t0[j];
+                sstar = spec ? best : 0.0;
+                sstar2 = sstar * sstar;
+                sc = spec ? sc : -1;
+            }
+            if (on) {
+                check_rows(k, x, u, x1, u1, ncum);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    const double su = ubk[c] - u[c], sl = u[c] - lbk[c];
+                    const bool v0 = (su <= -vsmall) || (sl <= -vsmall);
+                    viol = viol || v0;
+                    nviol += v0 ? 1 : 0;
+                    const bool ours = (q == 0 && k0 == 0) && c == sc; // the speculated bound itself (active at U1: its twin cannot be violated)
+                    uniq = uniq && (ours || !((su <= -vsmall && su <= sstar * (1.0 - 1e-9)) || (sl <= -vsmall && sl <= sstar * (1.0 - 1e-9))));
+                    viol1 = viol1 || (!ours && ((ubk[c] - u1[c] <= -vsmall) || (u1[c] - lbk[c] <= -vsmall)));
+                }
+            }
+            if (on && handover) { // |row i of G_k|^2 added, staged, and the next block
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double sq = 0.0;
 #pragma unroll
                     for (int c = 0; c < NU; ++c) sq += Gp[i + NX * c] * Gp[i + NX * c];
                     ncum[i] += sq;
-                    lane_put(wn + (size_t)i * bp, ioff, ncum[i], true);
+                    ldn[lane * SX + q * NX + i] = ncum[i];
                 }
                 double Gn[NX * NU];
 #pragma unroll
@@ -505,45 +675,36 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
                 for (int e = 0; e < NX * NU; ++e) Gp[e] = Gn[e];
             }
-            if (on) {
-                check_rows(k, x, u);
 #pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    double ub, lb; // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
-                    if (own_bounds) {
-                        ub = ubp[k * NU + c];
-                        lb = lbp[k * NU + c];
-                    } else if (tlds) {
-                        ub = Tl[tl_rows + k * NU + c];
-                        lb = Tl[tl_rows + P.n + k * NU + c];
-                    } else {
-                        ub = uniform_load(ubp, k * NU + c);
-                        lb = uniform_load(lbp, k * NU + c);
-                    }
-                    viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
-                    nviol += ((ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall)) ? 1 : 0;
-                }
-            }
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = spec ? x1[c] : x[c];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = x[c];
-#pragma unroll
-            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = u[c];
-            double xn[NX];
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = spec ? u1[c] : u[c];
+            double xn[NX], xn1[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                double s = d[i];
+                double s = d[i], s1 = d[i];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) s += A[i + NX * j] * x[j];
+                for (int j = 0; j < NX; ++j) {
+                    s += A[i + NX * j] * x[j];
+                    s1 += A[i + NX * j] * x1[j];
+                }
 #pragma unroll
-                for (int c = 0; c < NU; ++c) s += B[i + NX * c] * u[c];
+                for (int c = 0; c < NU; ++c) {
+                    s += B[i + NX * c] * u[c];
+                    s1 += B[i + NX * c] * u1[c];
+                }
                 xn[i] = s;
+                xn1[i] = s1;
             }
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = on ? xn[i] : x[i];
+            for (int i = 0; i < NX; ++i) {
+                x[i] = on ? xn[i] : x[i];
+                x1[i] = on ? xn1[i] : x1[i];
+            }
             sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
         }
         wave_sync();
-        if (!(P.lane_dbg & 1)) { // consecutive lanes write consecutive doubles of an instance's segment
+        { // consecutive lanes write consecutive doubles of an instance's segment
             const int nst = NH - k0 < GS ? NH - k0 : GS; // stages of this group
             double* const xg = P.trajectory + (size_t)(group * GRP) * P.X + (size_t)k0 * NX;
             double* const ug = P.control + (size_t)(group * GRP) * P.n + (size_t)k0 * NU;
@@ -558,22 +719,31 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 if (il < ninst && c < nst * NU) ug[(size_t)il * P.n + c] = ldu[il * SU + c];
             }
         }
+        if (handover) { // the group's norm sums of every instance: one contiguous segment of its hand-over block
+            const int nst = NH - k0 < GS ? NH - k0 : GS;
+            double* const ng = ws2 + (size_t)NH * NLU + (size_t)k0 * NX;
+#pragma unroll 4
+            for (int j = 0; j < GS * NX; ++j) {
+                const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
+                if (il < ninst && c < nst * NX) ng[(size_t)il * T2 + c] = ldn[il * SX + c];
+            }
+        }
     }
     { // the last state: its rows, and out
         double u0[NU];
 #pragma unroll
         for (int c = 0; c < NU; ++c) u0[c] = 0.0;
-        check_rows(NH, x, u0);
-        if (valid && !(P.lane_dbg & 1)) {
+        check_rows(NH, x, u0, x1, u0, ncum);
+        if (valid) {
             double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
 #pragma unroll
-            for (int c = 0; c < NX; ++c) xo[c] = x[c];
+            for (int c = 0; c < NX; ++c) xo[c] = spec ? x1[c] : x[c];
         }
     }
+    const bool done1 = valid && spec && uniq && !viol1; // finished by the one constraint it speculated on
 
-    stamp[3] = cycle_counter();
     // ---- 3. verdict: done, or one more entry of the first tier's list (one atomic per wave) ----
-    const bool more = valid && viol;
+    const bool more = valid && viol && !done1;
     int total = 0;
     const int before = wave_prefix_count(more, total);
     if (total > 0) {
@@ -582,9 +752,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         base = bcast_i32(base, 0);
         if (more) P.lane_list[base + before] = bad ? (inst | (int)0x80000000) : inst; // (top bit: the factorisation failed -- status 2)
     }
-    if (valid && !viol) {
+    if ((valid && !viol) || done1) {
         P.status[inst] = 0;
-        P.iter[2 * (size_t)inst] = 1;
+        P.iter[2 * (size_t)inst] = done1 ? 2 : 1; // (qpgen2's counters: the scan that found nothing counts)
         P.iter[2 * (size_t)inst + 1] = 0;
     }
     // Histogram of the violated-row counts over the batch (first solve of a controller: copra_batch_solve reads it BEFORE it launches the
@@ -598,12 +768,6 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             (void)wave_prefix_count(bin == b, cnt);
             if (cnt > 0 && lane == 0) (void)atomic_add_i32(P.lane_hist + b, cnt);
         }
-    }
-    if ((P.lane_dbg & 8) && P.prof && lane == 0) { // (experiments: staging | sweep | roll-out | verdict, in row `group` of the profile)
-        stamp[4] = cycle_counter();
-        long long* pr = P.prof + 8 * (size_t)group;
-        for (int q = 0; q < 4; ++q) pr[q] = stamp[q + 1] - stamp[q];
-        pr[7] = stamp[4] - stamp[0];
     }
 }
 
@@ -628,6 +792,9 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
     double* lds = lds_base();
     if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0;
     const double* const F = P.ric_model; // N stage records + the constant block (B | d | ...)
+    int oKvB_ = 0, oG_ = 0, oNb_ = 0; // the feed-forward terms kv: a block of their own behind the constant block (RicRec)
+    (void)ric_model_offsets(NX, NU, NH, P.mgen, oKvB_, oG_, oNb_);
+    const int oKvB = oKvB_;
     const int li = valid ? inst : 0;
     double x[NX];
 #pragma unroll
@@ -772,7 +939,7 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
             double u[NU], kvk[NU]; // kvk: this instance's feed-forward term (the records' + its own delta)
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
-                kvk[c] = uniform_load(F, rb + RR::oKv + c);
+                kvk[c] = uniform_load(F, oKvB + kk * NU + c);
                 if (own_refs) kvk[c] += dkw[((size_t)kk * NU + c) * dbp + inst];
                 double s = kvk[c];
 #pragma unroll

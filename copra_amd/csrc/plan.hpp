@@ -102,6 +102,7 @@ struct LdsLayout {
              // instead of the packed triangle), A / B / d / x0 keep their own slots and there are no cost tables
     int ricX; // general variant: 64 doubles behind A | B | d | x0 -- together the trajectory of the roll-out (lmpc_fused_ric.hpp)
     int ricD; // two doubles nobody reads (what the lanes with nothing to store write to)
+    int ricKv; // the feed-forward terms kv of the unconstrained minimiser, nu per stage: written by the sweep, read once by the roll-out (RicRec)
     int ricC; // 1: compact variant (every state term of a row is one component of one state): once the row norms are known the
               // blocks G are dead -- the normal of a state row enters w = R^-T n as a unit injection into the recursion's state --
               // and their region holds the maintained trajectory (at G) and the closed-loop states of z = R^-1 v (at Xbar)
@@ -200,10 +201,10 @@ struct LargeLayout {
 // offsets (doubles) of the parts of FusedPlan::ric_model; returns the total
 COPRA_HD inline int ric_model_offsets(int nx, int nu, int N, int mgen, int& oBk, int& oG, int& oNb)
 {
-    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + 1) & ~1; // RicRec<NX, NU>::SZ
     const int cst = (nx * nu + nx + 3 + 1) & ~1; // RicRec<NX, NU>::CST (B | d | zero | spare | one behind the records)
-    oBk = N * rec + cst; // (formerly bkd: nothing there any more)
-    oG = oBk;
+    oBk = N * rec + cst; // the feed-forward terms kv of the unconstrained minimiser, nu per stage (RicRec: they are not part of the records)
+    oG = oBk + ((N * nu + 1) & ~1);
     oNb = oG + N * nx * nu;
     return oNb + ((mgen + 1) & ~1) + ((nx * nx + 1) & ~1); // (+ the system's A behind the norms: ric_model_A below)
 }
@@ -230,19 +231,27 @@ COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& oh
     oRows = (ohN + nx + 1) & ~1;
 }
 
-// rows of its workspace per stage: K (nu x nx, column-major) | kv (nu) | Lam^-1 (packed by rows, as RicRec) | running sums of the squared
-// block-row norms of G_s = A^s B (nx) -- the first two are what its own roll-out reads back, all four are what the first tier takes
-// over instead of sweeping again (lmpc_fused_ric.hpp, from_lane)
-COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu + nu * (nu + 1) / 2 + nx; }
+// rows of its LANE-MAJOR workspace per stage: K (nu x nx, column-major) | kv (nu) -- what its own roll-out reads back (and the first tier
+// gathers K from: lmpc_fused_ric.hpp, from_lane)
+COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu; }
+// ... and doubles per instance of its INSTANCE-MAJOR hand-over block (FusedPlan::lane_ws2; round 5): what only the first tier reads --
+// Lam^-1 (packed by rows, as RicRec) and kv of every stage ([N][nu (nu + 1) / 2 + nu]), then the running sums of the squared block-row
+// norms of G_s = A^s B ([N][nx]).  Until round 5 these were twelve more lane-major rows per stage: the tier fetched each of the 240 values of an
+// instance from a 64-byte sector of its own (the gather was bound by the sector requests of the CU's address unit: 704 per instance);
+// as one contiguous block they are 30 sectors.
+COPRA_HD inline int lane_ws2_doubles(int nx, int nu, int N) { return N * (nu * (nu + 1) / 2 + nu + nx); }
 // LDS of that pass (doubles): the staging area of the transpositions (64 lanes x the widest array, odd stride), then H | h
 constexpr int kLaneGroup = 4; // stages per group of its roll-out (results leave through LDS once per group)
-constexpr int kLaneAhead = 4; // stages whose gains are in flight
+constexpr int kLaneAhead = 2; // stages whose gains are in flight (round 5: two -- a stage of the roll-out carries two trajectories now and takes twice as long, and the 42 doubles of the other two buffers were what pushed the roll-out into scratch memory)
 constexpr int kLaneHistBins = 32; // bins of its violated-row histogram (FusedPlan::lane_hist), the last one open
 COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
 {
     int w = (nx * nx) | 1;
     if (((nx * nu) | 1) > w) w = (nx * nu) | 1;
-    if (((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1) > w) w = ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1); // (both at once)
+    // the roll-out's group of stages: states | controls | norm sums (the hand-over block), all at once
+    if (2 * ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1) > w) w = 2 * ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1);
+    // the sweep: h of the lane | Lam^-1 of a group of stages (the hand-over block)
+    if (((3 * nx + nu + kLaneGroup * (nu * (nu + 1) / 2 + nu)) | 1) > w) w = (3 * nx + nu + kLaneGroup * (nu * (nu + 1) / 2 + nu)) | 1; // (+ x0 and d, parked)
     oH = 64 * w;
     const int nz = nx + nu;
     return (oH + nz * nz + nz + 1) & ~1;
@@ -266,7 +275,7 @@ struct FusedPlan {
     int ric_tab;
     // Shared-model mode of that tier (copra_batch_set_shared_system): the stage records do not depend on x0, so ONE prepare
     // launch sweeps (ric_model_out, instance dump_instance) and every instance of the batch copies the result (ric_model):
-    //   records [N x RicRec::SZ] + constant block | bkd [N x nx] | G [N x nx x nu] | row norms [mgen] | A [nx x nx]      (ric_model_offsets below)
+    //   records [N x RicRec::SZ] + constant block | kv [N x nu] | G [N x nx x nu] | row norms [mgen] | A [nx x nx]      (ric_model_offsets below)
     const double* ric_model;
     double* ric_model_out;
     int rfull; // max rows over the full-size costs (0 if none)
@@ -281,11 +290,11 @@ struct FusedPlan {
     int lane_tlds; // > 0: that many doubles of tables -- the rows of every step, then ub and lb -- sit in LDS behind H | h (the pass reads them there
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // columns of a workspace row: the batch rounded up to whole waves, + 64 spare ones (what lanes without an instance write)
-    int lane_group; // instances per wave of the pass: 64 (0), or 32 -- half-waves (an experiment switch: measured no faster at any batch)
     int lane_from_list;
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)
-    int lane_dbg; // experiments (COPRA_LANE_DBG): 1 = no result stores, 2 = no workspace traffic, 4 = no input staging through LDS
+    int lane_spec; // 1 (with lane_handover): the pass takes the first step of the active-set iteration itself where a bound on u_0 is the pick (lmpc_lane.hpp)
     double* lane_ws; // [N][lane_ws_rows][lane_bp]: what the sweep leaves per stage, lane-major
+    double* lane_ws2; // [batch][lane_ws2_doubles]: the hand-over block of every instance (Lam^-1 | norm sums), instance-major
     int* lane_list;
     int* lane_count;
     int* lane_zero;

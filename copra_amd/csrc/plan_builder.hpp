@@ -201,7 +201,7 @@ inline bool ric_shape_ok(int nx, int nu, int N)
 {
     const int nz = nx + nu, nxx = nx * (nx + 1) / 2, nux = nu * nx, nuu = nu * (nu + 1) / 2;
     return nu >= 1 && nu <= 3 && nx >= 1 && nx <= 7 && nx * (nz + 1) <= kWave && nxx + nux + nuu + nz <= kWave && nu * N <= kWave
-        && nxx + nux + nuu >= nx * (nx + 1) && N >= 2;
+        && nxx + nux + nuu >= nx * (nx + 1) && N >= 2 && nx >= nu; // (nx >= nu: where the roll-out keeps kv, layout_lds_ric)
 }
 
 // Shapes whose Riccati-factor tier (lmpc_fused_ric.hpp) and one-instance-per-lane pass (lmpc_lane.hpp) the LIBRARY holds for every horizon
@@ -221,7 +221,7 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
         return at;
     };
     L = LdsLayout {};
-    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + nu + 1) & ~1; // RicRec<NX, NU>::SZ
+    const int rec = (nx * nx + nx * nu + nu * (nu + 1) / 2 + 1) & ~1; // RicRec<NX, NU>::SZ
     const int cst = (nx * nu + nx + 3 + 1) & ~1; // RicRec<NX, NU>::CST
     L.ldj = (n % 2 == 0) ? n + 1 : n;
     L.tri = 1;
@@ -247,10 +247,14 @@ inline bool layout_lds_ric(LdsLayout& L, int nx, int nu, int N, int n, int X, in
     if (compact) {
         L.ricX = L.G;
         L.ricD = L.J + N * rec + nx * nu + nx + 1; // (RicRec::cS: the spare double of the constant block)
+        // kv: the tail of the trajectory's place.  The roll-out writes x_{k+1} at nx (k + 1) .. and has read kv_{k+1} at X - n + nu (k + 1) ..
+        // by then: with nx >= nu no state ever lands on a kv that is still to be read (lmpc_fused_ric.hpp, the roll-out).
+        L.ricKv = L.G + X - n;
     } else {
         L.ricX = take(kWave); // (directly after A | B | d | x0: together they hold the unconstrained trajectory between the roll-out
                               //  and the first scan -- lmpc_fused_ric.hpp, StageRows::xu)
         L.ricD = L.ricX + kWave - 2;
+        L.ricKv = take(n);
     }
     L.BldPhi = L.BldXi = L.J; // (unused by the body)
     const int vec0 = o;
@@ -453,7 +457,7 @@ inline void build_lane_tables(HostPlan& hp)
     {
         int oHl = 0;
         const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;
-        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u && !hp.opt.lane_tables_in_memory) ? tl : 0; // (four waves per CU)
+        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u) ? tl : 0; // (four waves per CU)
     }
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
 }
@@ -1087,7 +1091,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
         L.Xi = take(X);
         L.Xbar = is ? L.Xi : take(X); // InitialStateLMPC never uses the free response Phi x0 + xi
         L.Xcur = take(X);
-        const int plimit = hp.opt.large_params_lds > 0 ? hp.opt.large_params_lds : hp.opt.large_params_lds < 0 ? 0 : 6144; // (tuning aid)
+        const int plimit = 6144;
         L.nparams = ((int)hp.params.size() <= plimit) ? (int)hp.params.size() : 0; // (dropped below if LDS gets too tight)
         L.Params = take(L.nparams);
         L.FullS = take(kMaxFullRows);
@@ -1228,9 +1232,8 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                 ric_taken = true;
             }
         }
-        const int tmin = hp.opt.tri_min; // (experiments: smallest number of variables that takes the tier)
-        if (!ric_taken && U > (tmin > 0 ? tmin - 1 : 32) && !hp.opt.no_tri) {
-            const int kenv = hp.opt.tri_k;
+        if (!ric_taken && U > 32 && !hp.opt.no_tri) {
+            const int kenv = 0;
             const int need = rp > 0 ? 5 : ((U + 7) / 8 > 5 ? (U + 7) / 8 : 5);
             // the headline instantiation keeps five columns of Q1 in registers (kFusedQ1Regs): 8 instances per CU
             const int qregs = (nx == 6 && rp == 6 && !hp.opt.no_q1regs) ? kFusedQ1Regs : 0;
@@ -1304,7 +1307,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     // the shapes it compiles.  (Single-control systems below 48 variables stay on the packed / factor-only kernels: the reference's
     // falling-mass problems hold most of their control bounds active, far beyond the tier's five register columns -- measured, §3.7.)
     if (!P.lds.ric && !hp.large && ric_aot_shape(nx, nu) && ric_shape_ok(nx, nu, N) && !hp.opt.no_ric && !hp.opt.no_tri
-        && (nu >= 2 || U >= 48 || hp.opt.ric_any_shape))
+        && (nu >= 2 || U >= 48))
         (void)take_ric_layout(hp);
     if (P.lane_tab < 0 && !hp.large && !P.initial_state) build_lane_tables(hp);
     return COPRA_OK;

@@ -18,8 +18,8 @@
 // w_k = Lam_k^-1 s_k afterwards -- 18 doubles less per stage, which is what lets a ninth instance share a CU.
 //
 // Stage record (RicRec<NX, NU>::SZ doubles, N of them in the J region of the LDS layout):
-//     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows) | kv (NU: feed-forward
-//     of the unconstrained minimiser)
+//     Acl (NX x NX, column-major) | K (NU x NX, column-major) | Li = Lam^-1 (lower triangular, packed by rows)
+//     (the feed-forward terms kv of the unconstrained minimiser: a block of their own, see RicRec)
 // followed, once, by the constant block (RicRec::CST doubles):  B (NX x NU, column-major) | d (NX) | a zero | a spare double | a one
 // (the one: the identity block that passes t_k / n_k through to the output rows of the backward recursion; the forward one and
 //  the roll-out keep their whole K-block 2, [B; I] resp. [B d; I 0], in a register -- it is the same at every stage)
@@ -48,9 +48,12 @@ template <int NX, int NU>
 struct RicRec {
     static constexpr int oAcl = 0;
     static constexpr int oK = oAcl + NX * NX;
-    static constexpr int oLi = oK + NU * NX;
-    static constexpr int oKv = oLi + NU * (NU + 1) / 2; // (Lam^-1 packed: entry (r, c), c <= r, at r (r + 1) / 2 + c)
-    static constexpr int SZ = (oKv + NU + 1) & ~1;
+    static constexpr int oLi = oK + NU * NX; // (Lam^-1 packed: entry (r, c), c <= r, at r (r + 1) / 2 + c)
+    // (Round 5: the feed-forward terms kv left the record -- only the roll-out reads them, ONCE, and behind the one-instance-per-lane pass
+    //  nobody does.  They wait in a block of their own, NU per stage: LdsLayout::ricKv in LDS -- in the compact variant the tail of the
+    //  trajectory's place, which the roll-out overwrites only behind its own reads --, FusedPlan::ric_model + oBk in the shared-model
+    //  buffer.  Four doubles less per stage at the headline shape: 13.3 instead of 13.9 KB of LDS, the twelfth instance per CU.)
+    static constexpr int SZ = (oLi + NU * (NU + 1) / 2 + 1) & ~1;
     // the constant block behind the N records
     static constexpr int cB = 0;
     static constexpr int cD = cB + NX * NU;

@@ -459,8 +459,6 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     sp.step_tol = 1e-8, sp.mu_tol = 1e-11;
     if (hp.opt.ric_step_tol != 0.0) sp.step_tol = hp.opt.ric_step_tol; // (copra_options_t: experiments)
     if (hp.opt.ric_mu_tol != 0.0) sp.mu_tol = hp.opt.ric_mu_tol;
-    if (hp.opt.ric_s0 != 0.0) sp.s_floor = hp.opt.ric_s0;
-    if (hp.opt.ric_lam0 != 0.0) sp.lam0 = hp.opt.ric_lam0;
     // proximal weight of the equality rows.  1e-9 until round 4: the multiplier of such a row is (a'z - f + a'dz) / delta, a difference of
     // O(|z|) quantities -- rounding at 1e-13 divided by 1e-9 left the multiplier, and with it U, uncertain at the 1e-4 level whenever the
     // row's right-hand side is not tiny (config 5 pins terminal velocities to ZERO, where that noise is 1e-18; a random controller pins a

@@ -125,7 +125,7 @@ typedef struct {
 
 typedef struct copra_batch copra_batch_t; /* opaque handle == one batched LMPC controller */
 
-/* ---- engine options: every switch and tuning value the engine consults, fixed when the controller is created (no environment
+/* ---- engine options: every switch the engine consults, fixed when the controller is created (no environment
  *      variable is read by the library on any path; earlier rounds steered it through ~50 COPRA_* variables).  There is no reference
  *      counterpart: copra's LMPC has no tuning surface beyond selectQPSolver.  copra_options_init fills in the process-wide defaults
  *      (all zeros / "the engine decides" unless copra_set_default_options changed them); a caller sets `struct_size =
@@ -146,32 +146,20 @@ typedef struct {
     int no_q1regs; /* factor-only tier with Q1 in LDS */
     int no_ladder; /* the layout ladder behaves as exhausted */
     int no_packed; /* small problems: one wavefront per instance instead of 16 / 32 lanes */
-    int ric_any_shape; /* copra_batch_specialise: the Riccati-factor tier also where the packed kernels are expected to win */
-    int tri_min; /* smallest number of decision variables that takes a factor-only tier (0: 33) */
-    int tri_k; /* factor-only tier: instances per CU the layout search starts from (0: 8) */
     int ric_k; /* Riccati-factor tier: start on the LDS-Q1 layout for this many instances per CU (0: Q1 in registers) */
-    int overflow_share; /* step down the ladder when more than batch / overflow_share instances overflow (0: 64 / 8) */
     /* the one-instance-per-lane pass in front of the first tier (lmpc_lane.hpp) */
     int no_lane_pass;
     int no_lane_handover; /* the pass only filters; the tier sweeps itself */
+    int no_lane_spec; /* the pass does not take the first step of the active-set iteration itself (a bound on u_0 as the first pick) */
     int lane_min_batch; /* smallest batch that runs the pass (0: 20480 in front of the Riccati-factor tier, 4096 elsewhere; -1: any) */
-    int lane_share; /* keep the pass while batch / lane_share instances end in it (0: 8, shared-model mode 4) */
-    int lane_keep; /* never switch it off */
-    int lane_tables_in_memory; /* its row tables stay in HBM instead of LDS */
-    int lane_dbg; /* bit mask of experiment switches of the pass (1: no result stores, 2: no workspace, 8: phase stamps) */
     /* shared-model mode */
     int no_ric_shared; /* lmpc_shared.hpp instead of the Riccati-factor tier's shared-model mode */
     /* long horizons */
-    int no_riccati; /* SolverFlag::DEFAULT keeps Goldfarb-Idnani where the Riccati interior-point kernel would be picked */
+    int no_riccati; /* COPRA_SOLVER_DEFAULT keeps Goldfarb-Idnani where the Riccati interior-point kernel would be picked */
     int no_ric_fast; /* the streaming interior-point kernel instead of the LDS-resident one */
-    int riccati_per_cu, large_per_cu, large_grid; /* persistent grids: waves / workgroups per CU, total (0: occupancy query) */
-    int large_no_w4; /* never the 128-VGPR builds of the workgroup kernels */
-    int large_params_lds; /* workgroup kernels: parameter blobs up to this many doubles go to LDS (0: 4096; -1: never) */
-    double ric_step_tol, ric_mu_tol, ric_s0, ric_lam0; /* interior-point tolerances and starting point (0: defaults of stage_plan.hpp) */
+    double ric_step_tol, ric_mu_tol; /* interior-point tolerances (0: defaults of stage_plan.hpp) */
     /* misc */
-    int recorded_events; /* time solves with recorded events instead of events carried in the dispatch packets */
     int debug; /* print launch geometry and adaptation decisions to stderr */
-    int lane_group; /* instances per wave of the one-instance-per-lane pass: 64 (0), or 32 = half-waves (an experiment: measured no faster) */
 } copra_options_t;
 void copra_options_init(copra_options_t* opts);
 /* the process-wide defaults copra_options_init hands out and the entry points without an options argument use (copra_batch_create,

@@ -340,18 +340,20 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         && ((P.nx == 6 && P.nu == 3) || (P.nx == 4 && P.nu == 2) || (P.nx == 5 && P.nu == 3) || (P.nx == 2 && P.nu == 1));
     for (int k = 0; k < kMaxCosts; ++k) lane_pass = lane_pass && (!P.cost_p[k] || P.lane_cref >= 0);
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
-    std::vector<double> lane_ws;
+    std::vector<double> lane_ws, lane_ws2;
     int lane_count = 0, lane_other = 0;
     if (lane_pass) {
-        P.lane_group = default_options().lane_group == 32 ? 32 : 64; // (copra_batch_solve: 32 at batches that leave half of the SIMDs idle)
-        const int groups = (dims->batch + P.lane_group - 1) / P.lane_group;
+        const int groups = (dims->batch + 63) / 64;
         P.lane_bp = (dims->batch + 63) / 64 * 64 + 64;
         lane_ws.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * P.lane_bp, 0.0);
         P.lane_ws = lane_ws.data();
+        lane_ws2.assign((size_t)P.lane_bp * lane_ws2_doubles(P.nx, P.nu, P.N), 0.0);
+        P.lane_ws2 = lane_ws2.data();
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
         P.lane_handover = (P.lds.ricC && !default_options().no_lane_handover) ? 1 : 0; // (as copra_batch_solve: known before the pass runs)
+        P.lane_spec = (P.lane_handover && !default_options().no_lane_spec) ? 1 : 0;
         std::fill(g_lane_hist, g_lane_hist + kLaneHistBins, 0);
         P.lane_hist = g_lane_hist; // (what the first solve of a controller asks of the pass: copra_batch_solve picks the tier's layout from it)
         for (int g = 0; g < groups; ++g) {

@@ -922,7 +922,11 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
     ok = ro["status"] == 0
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
-    assert re["lane_pass_finished"] == (-1 if mode == "off" else at_minimiser)
+    one_bound = int(((ro["iter"][:, 0] == 2) & (ro["iter"][:, 1] == 0) & ok).sum())
+    if mode == "handover":  # (round 5: the pass also takes the first step of the iteration where a bound on u_0 is the pick)
+        assert at_minimiser <= re["lane_pass_finished"] <= at_minimiser + one_bound
+    else:
+        assert re["lane_pass_finished"] == (-1 if mode == "off" else at_minimiser)
     if vmax == 0.6:
         assert 0 < at_minimiser < batch  # (both kinds of instance in the batch)
 
@@ -940,7 +944,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     lb = -0.8 * ub
     args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     re = emu.lmpc_solve(*args, bounds=(lb, ub))
-    finished = 0
+    finished = one_bound = 0
     for k in range(b):
         cs = [wl["cstrs"][0], dict(wl["cstrs"][1], lower=[-0.8 * umax[k]] * 3, upper=[umax[k]] * 3)]
         ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
@@ -948,12 +952,13 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-    assert re["lane_pass_finished"] == finished > 0
+            one_bound += int(tuple(ro["iter"]) == (2, 0))
+    assert 0 < finished <= re["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # per-instance cost references (every instance its own goal): the pass rebuilds its affine terms per lane from the plan's coefficient
     # table
     refs = {0: np.tile(wl["costs"][0]["p"], (b, 1)) + 0.03 * rng.standard_normal((b, 6))}
     re2 = emu.lmpc_solve(*args, cost_refs=refs)
-    finished = 0
+    finished = one_bound = 0
     for k in range(b):
         cs = [dict(wl["costs"][0], p=refs[0][k]), wl["costs"][1]]
         ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], cs, wl["cstrs"])
@@ -961,11 +966,12 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re2["iter"][k]) == tuple(ro["iter"]) and _rel(re2["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-    assert re2["lane_pass_finished"] == finished > 0
+            one_bound += int(tuple(ro["iter"]) == (2, 0))
+    assert 0 < finished <= re2["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # ... and per-instance right-hand sides (every instance its own velocity limit): every lane reads its own row of the table
     vlim = 0.6 * rng.uniform(0.7, 1.2, b)
     re3 = emu.lmpc_solve(*args, row_rhs=np.repeat(vlim[:, None], 63, axis=1))
-    finished = 0
+    finished = one_bound = 0
     inf = np.inf
     for k in range(b):
         cs = [dict(wl["cstrs"][0], upper=[inf, inf, inf, vlim[k], vlim[k], vlim[k]]), wl["cstrs"][1]]
@@ -974,7 +980,8 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re3["iter"][k]) == tuple(ro["iter"]) and _rel(re3["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-    assert re3["lane_pass_finished"] == finished > 0
+            one_bound += int(tuple(ro["iter"]) == (2, 0))
+    assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
 def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
@@ -1306,26 +1313,29 @@ def test_riccati_factor_tier_with_a_run_time_horizon(emu, oracle, shape):
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
 
 
-@pytest.mark.parametrize("b", [70, 33])
-def test_lane_pass_in_half_waves(emu, oracle, monkeypatch, b):
-    """FusedPlan::lane_group = 32: the one-instance-per-lane pass with 32 instances per wave (lanes 32.. idle, their stores in spare
-    workspace columns) -- what copra_batch_solve launches at batches that would leave half of the machine's SIMDs without a wave (a
-    shard of BASELINE configs[3]).  Ragged last wave, hand-over to the tier, histogram: everything against the oracle and identical
-    to the 64-instance form."""
+@pytest.mark.parametrize("b,vmax,umax", [(70, 0.6, 2.0), (33, 0.3, 1.5), (96, 0.25, 1.0)])
+def test_lane_pass_takes_the_first_step_of_the_iteration(emu, oracle, monkeypatch, b, vmax, umax):
+    """Round 5: where a bound on u_0 is qpgen2's first pick, the one-instance-per-lane pass takes that step itself (closed form in the
+    quantities of its roll-out: lmpc_lane.hpp) and finishes the instance when the new iterate violates nothing -- iterations (2, 0), as
+    the oracle counts them.  With the speculation switched off the same instances go through the first tier: same statuses, same
+    counters, same U and X; with it, strictly more instances end in the pass.  Ragged last wave included."""
     from copra_amd import workloads
-    wl = workloads.com_preview(b, v_max=0.3, u_max=1.5, seed=9)
+    wl = workloads.com_preview(b, v_max=vmax, u_max=umax, seed=9)
     args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
     ro = oracle.lmpc_solve_batch(*args, nthreads=8)
-    r64 = emu.lmpc_solve(*args)
-    h64 = emu.last_lane_hist()
-    monkeypatch.setitem(OPTIONS, "lane_group", 32)
-    r32 = emu.lmpc_solve(*args)
-    h32 = emu.last_lane_hist()
+    rs = emu.lmpc_solve(*args)
+    monkeypatch.setitem(OPTIONS, "no_lane_spec", 1)
+    rn = emu.lmpc_solve(*args)
     ok = ro["status"] == 0
-    assert (r32["status"] == ro["status"]).all() and (r32["iter"][ok] == ro["iter"][ok]).all()
-    assert _rel(r32["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(r32["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
-    assert r32["lane_pass_finished"] == r64["lane_pass_finished"] and (h32 == h64).all()
-    assert np.array_equal(r32["control"][ok], r64["control"][ok])  # (the same arithmetic per instance: bit for bit)
+    for r in (rs, rn):
+        assert (r["status"] == ro["status"]).all() and (r["iter"][ok] == ro["iter"][ok]).all()
+        assert _rel(r["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(r["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
+    assert rn["lane_pass_finished"] == at_minimiser
+    one_bound = int(((ro["iter"][:, 0] == 2) & (ro["iter"][:, 1] == 0) & ok).sum())
+    assert at_minimiser <= rs["lane_pass_finished"] <= at_minimiser + one_bound
+    if vmax >= 0.6:  # (loose velocity rows: every first pick is a bound on u_0 -- every one-constraint instance ends in the pass)
+        assert rs["lane_pass_finished"] == at_minimiser + one_bound and one_bound > 0
 
 
 @pytest.mark.parametrize("first", [0, 12, 24, 36, 48, 60, 72, 84])
