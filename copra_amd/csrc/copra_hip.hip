@@ -397,7 +397,7 @@ static bool lane_batch_ok(const copra_options_t& opt, int batch, bool ric_tier, 
 static bool lane_pass_wanted(const copra_batch* h, const FusedPlan& P, bool jit_launch)
 {
     const copra_options_t& opt = h->hp.opt;
-    if (h->lane_off || opt.no_lane_pass || !lane_batch_ok(opt, P.batch, P.lds.ric != 0)) return false;
+    if (h->ad.lane_off || opt.no_lane_pass || !lane_batch_ok(opt, P.batch, P.lds.ric != 0)) return false;
     if (P.prof_fine) return false; // (the fine-grained stamps of the profiling build follow ONE kernel through a whole solve)
     // (in front of the Riccati-factor tier, which takes the factor over, or of any other one-wave first tier, where it only filters)
     if (P.lane_tab < 0 || (jit_launch && !h->jit_ric) || h->packed || h->shared || h->hp.large || P.initial_state) return false;
@@ -450,12 +450,12 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     // good, one that became constraint-heavy later kept paying for it): every kLaneResample solves the share is sampled again -- a pass
     // that was switched off by THIS function (not for lack of memory) runs once more, a running one is checked again.
     constexpr int kLaneResample = 256;
-    h->lane_solves += 1;
-    if (h->lane_solves % kLaneResample == 0 && h->lane_adapt_left <= 0) {
-        h->lane_adapt_left = 1;
-        if (h->lane_off && h->lane_off_by_share) h->lane_off = h->lane_off_by_share = false;
+    h->ad.lane_solves += 1;
+    if (h->ad.lane_solves % kLaneResample == 0 && h->ad.lane_adapt_left <= 0) {
+        h->ad.lane_adapt_left = 1;
+        if (h->ad.lane_off && h->ad.lane_off_by_share) h->ad.lane_off = h->ad.lane_off_by_share = false;
     }
-    if (!h->lane_ran || h->lane_adapt_left <= 0) return COPRA_OK;
+    if (!h->ad.lane_ran || h->ad.lane_adapt_left <= 0) return COPRA_OK;
     // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
     //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
     //  -- except in shared-model mode, where there is no sweep to take over: there the pass must finish one instance in four to pay, measured)
@@ -465,16 +465,16 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     if (h->shared && h->shared_ric)
         for (int t = 0; t < kMaxCosts; ++t)
             if (h->cost_p[t]) return COPRA_OK;
-    h->lane_adapt_left -= 1;
+    h->ad.lane_adapt_left -= 1;
     int left = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
     const long long done = (long long)h->hp.plan.batch - left;
     const long long share = h->shared ? 4 : 8;
-    if (done * share < (long long)h->hp.plan.batch) h->lane_off = h->lane_off_by_share = true;
+    if (done * share < (long long)h->hp.plan.batch) h->ad.lane_off = h->ad.lane_off_by_share = true;
     if (h->hp.opt.debug)
         fprintf(stderr, "[copra] one-instance-per-lane pass: %lld of %d instances ended in it%s\n", done, h->hp.plan.batch,
-            h->lane_off ? " -- switched off" : "");
+            h->ad.lane_off ? " -- switched off" : "");
     return COPRA_OK;
 }
 
@@ -483,8 +483,8 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
 // the second tier, step to the next safer layout: dense -> safe (quarter-CU compact or full) -> full.
 static copra_status_t adapt_layout(copra_batch* h)
 {
-    if (!h->hp.two_tier || h->hp.large || h->adapt_left <= 0 || !h->solved_once) return COPRA_OK;
-    h->adapt_left -= 1;
+    if (!h->hp.two_tier || h->hp.large || h->ad.adapt_left <= 0 || !h->ad.solved_once) return COPRA_OK;
+    h->ad.adapt_left -= 1;
     int count = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     HIP_TRY(hipMemcpy(&count, h->d_ovf_count + h->ovf_cur, sizeof(int), hipMemcpyDeviceToHost));
@@ -499,7 +499,7 @@ static copra_status_t adapt_layout(copra_batch* h)
         h->hp.plan.lds = roomier;
         h->hp.lds_bytes = (size_t)roomier.total * sizeof(double);
         h->lds_attr_set = false;
-        h->adapt_left += 1; // (a step down the ladder does not use up the budget of attempts)
+        h->ad.adapt_left += 1; // (a step down the ladder does not use up the budget of attempts)
         if (h->hp.opt.debug)
             fprintf(stderr, "[copra] %d of %d instances overflowed the factor-only layout: next %zu B, %d columns\n", count,
                 h->hp.plan.batch, h->hp.lds_bytes, roomier.rcap);
@@ -543,17 +543,17 @@ static copra_status_t rechoose_layout(copra_batch* h)
     constexpr long long kPeriod = 256;
     const FusedPlan& P = h->hp.plan;
     if (!h->hp.two_tier || h->hp.large || h->shared || !P.lds.tri || h->hp.opt.no_ladder || P.batch <= 0 || P.initial_state) return COPRA_OK;
-    if (!h->lds_top_set) { // (first solve of this ladder: remember where it starts)
-        h->lds_top = P.lds;
-        h->lds_top_set = true;
-        h->layout_solves = 0;
+    if (!h->ad.lds_top_set) { // (first solve of this ladder: remember where it starts)
+        h->ad.lds_top = P.lds;
+        h->ad.lds_top_set = true;
+        h->ad.layout_solves = 0;
         return COPRA_OK;
     }
-    h->layout_solves += 1; // solves completed on this ladder
-    if (h->layout_solves != 1 && h->layout_solves % kPeriod != 0) return COPRA_OK;
-    if (!(h->lds_top.tri && h->lds_top.ric == P.lds.ric && h->lds_top.ricC == P.lds.ricC)) return COPRA_OK;
-    const int* d_it = h->ext_iter ? h->ext_iter : h->d_iter;
-    const int* d_st = h->ext_status ? h->ext_status : h->d_status;
+    h->ad.layout_solves += 1; // solves completed on this ladder
+    if (h->ad.layout_solves != 1 && h->ad.layout_solves % kPeriod != 0) return COPRA_OK;
+    if (!(h->ad.lds_top.tri && h->ad.lds_top.ric == P.lds.ric && h->ad.lds_top.ricC == P.lds.ricC)) return COPRA_OK;
+    const int* d_it = h->ad.last_iter; // (where the LAST solve wrote: with rotating result slabs not the buffers set for the next one)
+    const int* d_st = h->ad.last_status;
     if (!d_it || !d_st) return COPRA_OK;
     std::vector<int> it((size_t)P.batch * 2), st((size_t)P.batch);
     HIP_TRY(hipStreamSynchronize(h->last_stream));
@@ -568,7 +568,7 @@ static copra_status_t rechoose_layout(copra_batch* h)
     }
     for (int a = P.n - 1; a >= 0; --a) larger[(size_t)a] += larger[(size_t)a + 1];
     const long long share = P.lds.ric ? 64 : 8;
-    LdsLayout pick = h->lds_top;
+    LdsLayout pick = h->ad.lds_top;
     for (;;) {
         const int cap = pick.rcap < P.n ? pick.rcap : P.n;
         LdsLayout roomier {};
@@ -582,7 +582,7 @@ static copra_status_t rechoose_layout(copra_batch* h)
         h->hp.plan.lds = pick;
         h->hp.lds_bytes = (size_t)pick.total * sizeof(double);
         h->lds_attr_set = false;
-        if (h->adapt_left < 2) h->adapt_left = 2;
+        if (h->ad.adapt_left < 2) h->ad.adapt_left = 2;
     }
     return COPRA_OK;
 }
@@ -965,8 +965,8 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
         h->has_lds_ric = true;
         h->lds_ric = h->hp.plan.lds;
     }
-    h->shared_ric_off = false; // (a new model: the tier is tried again)
-    h->shared_ric_solves = 0;
+    h->ad.shared_ric_off = false; // (a new model: the tier is tried again)
+    h->ad.shared_ric_solves = 0;
     h->shared_ric = false;
     LdsLayout lq {};
     if (tri_layout_with_lds_q1(h->hp.plan, h->hp.plan.lds, lq)) { // the shared-model kernels keep Q1 in LDS
@@ -1152,217 +1152,196 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
 
 
 
-copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
-{
-    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
-    {
-        copra_status_t rca = adapt_lane_pass(h);
-        if (rca != COPRA_OK) return rca;
-        rca = adapt_layout(h);
-        if (rca != COPRA_OK) return rca;
-        rca = rechoose_layout(h);
-        if (rca != COPRA_OK) return rca;
-        h->solved_once = true;
-        h->lane_ran = false;
-    }
-    if (h->shared) {
-        if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
+// ---- copra_batch_solve: ONE function per launch path (round-4 verdict: it was one 335-line function with eight paths and four adaptive
+//      controllers inline).  What the engine has learnt about the controller lives in AdaptState (engine.hpp); the controllers run in
+//      learn_from_the_last_solve, before anything of the next solve is chosen. ----
 
-        hipStream_t s = (hipStream_t)hip_stream;
-        h->last_stream = s;
-        if (h->hp.plan.batch == 0) return COPRA_OK;
-        { // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
-            // The tier is taken by SHAPE.  Where the condensed problem is small (two controls, at most 32 variables) and the active-set path
-            // long, the dense triangular solves of lmpc_shared.hpp are cheaper than N stages of the recursion per iteration (planar point
-            // mass N = 8, 20 iterations per solve: 6.8 vs 13.5 ms, profiles/r04/tier_choice_map_before_switch.txt; at 5 iterations the tier is twice as
-            // fast): after the first solve on the tier its iteration counters decide -- one synchronisation in the controller's life.
-            if (h->shared_ric && h->shared_ric_solves == 1 && !h->shared_ric_off && h->hp.plan.nu <= 2 && h->hp.plan.n <= 32) {
-                const int* d_it = h->ext_iter ? h->ext_iter : h->d_iter;
-                const int* d_st = h->ext_status ? h->ext_status : h->d_status;
-                if (d_it && d_st) {
-                    const size_t nb = (size_t)h->hp.plan.batch;
-                    std::vector<int> it(nb * 2), st(nb);
-                    HIP_TRY(hipStreamSynchronize(h->last_stream));
-                    HIP_TRY(hipMemcpy(it.data(), d_it, it.size() * sizeof(int), hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost));
-                    long long sum = 0, cnt = 0;
-                    for (size_t b = 0; b < nb; ++b)
-                        if (st[b] == 0) sum += it[2 * b], cnt += 1;
-                    if (cnt > 0 && sum > 12 * cnt) {
-                        h->shared_ric_off = true;
-                        if (h->hp.opt.debug)
-                            fprintf(stderr, "[copra] shared-model tick: %.1f iterations per solve at %d variables: lmpc_shared.hpp from now on\n",
-                                (double)sum / (double)cnt, h->hp.plan.n);
-                    }
-                }
-                h->shared_ric_solves = 2; // (decided)
-            }
-            bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared && !h->shared_ric_off;
-            // Per-instance cost references (one model, every instance its own goal / reference trajectory): the records were swept with the
-            // controller-wide references, an instance's own feed-forward terms come from the DELTA sweep of the shared lane pass
-            // (lmpc_lane_shared_body) -- so the records form takes them where that pass runs; elsewhere lmpc_shared.hpp (reference columns of
-            // the shared model), as for every such controller before round 4 (96 vs 200 M solves/s at the headline shape).
-            bool refs = false;
-            for (int t = 0; t < kMaxCosts; ++t) refs = refs || h->cost_p[t];
-            if (want && refs) {
-                const FusedPlan Pw = device_plan(h);
-                want = !h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, Pw.batch, true, true) && Pw.lane_tab >= 0 && Pw.lane_cref >= 0
-                    && h->lds_ric.ricC && !Pw.prof && !Pw.prof_fine && !Pw.row_f_inst && select_lane_shared_kernel(Pw) != nullptr;
-                if (want && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for the delta terms: lmpc_shared.hpp)
-                    (void)hipGetLastError();
-                    want = false;
-                }
-            }
-            if (want != h->shared_ric) {
-                LdsLayout lq {};
-                if (want) {
-                    h->hp.plan.lds = h->lds_ric;
-                } else if (tri_layout_with_lds_q1(h->hp.plan, h->lds_ric, lq)) {
-                    h->hp.plan.lds = lq;
-                }
-                h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
-                h->hp.two_tier = true;
-                h->lds_attr_set = false;
-                h->shared_attr_set = false;
-                h->shared_ric = want;
-                h->model_dirty = true;
+// the adaptive controllers, in the order they depend on each other; all of them read what the LAST solve left behind
+static copra_status_t learn_from_the_last_solve(copra_batch* h)
+{
+    copra_status_t rc = adapt_lane_pass(h);
+    if (rc == COPRA_OK) rc = adapt_layout(h);
+    if (rc == COPRA_OK) rc = rechoose_layout(h);
+    h->ad.solved_once = true;
+    h->ad.lane_ran = false;
+    return rc;
+}
+// ... and where this solve will leave its counters, for the next call of the above
+static void remember_outputs(copra_batch* h, const FusedPlan& P)
+{
+    h->ad.last_iter = P.iter;
+    h->ad.last_status = P.status;
+}
+
+// Shared-model tick: WHICH first tier -- the Riccati-factor tier in shared-model mode, or lmpc_shared.hpp.  May move the plan's layout.
+static copra_status_t choose_shared_tier(copra_batch* h)
+{
+    // which first tier: the Riccati-factor tier in shared-model mode (cold starts, controller-wide references), or lmpc_shared.hpp
+    // The tier is taken by SHAPE.  Where the condensed problem is small (two controls, at most 32 variables) and the active-set path
+    // long, the dense triangular solves of lmpc_shared.hpp are cheaper than N stages of the recursion per iteration (planar point
+    // mass N = 8, 20 iterations per solve: 6.8 vs 13.5 ms, profiles/r04/tier_choice_map_before_switch.txt; at 5 iterations the tier is twice as
+    // fast): after the first solve on the tier its iteration counters decide -- one synchronisation in the controller's life.
+    if (h->shared_ric && h->ad.shared_ric_solves == 1 && !h->ad.shared_ric_off && h->hp.plan.nu <= 2 && h->hp.plan.n <= 32) {
+        const int* d_it = h->ad.last_iter;
+        const int* d_st = h->ad.last_status;
+        if (d_it && d_st) {
+            const size_t nb = (size_t)h->hp.plan.batch;
+            std::vector<int> it(nb * 2), st(nb);
+            HIP_TRY(hipStreamSynchronize(h->last_stream));
+            HIP_TRY(hipMemcpy(it.data(), d_it, it.size() * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(st.data(), d_st, st.size() * sizeof(int), hipMemcpyDeviceToHost));
+            long long sum = 0, cnt = 0;
+            for (size_t b = 0; b < nb; ++b)
+                if (st[b] == 0) sum += it[2 * b], cnt += 1;
+            if (cnt > 0 && sum > 12 * cnt) {
+                h->ad.shared_ric_off = true;
+                if (h->hp.opt.debug)
+                    fprintf(stderr, "[copra] shared-model tick: %.1f iterations per solve at %d variables: lmpc_shared.hpp from now on\n",
+                        (double)sum / (double)cnt, h->hp.plan.n);
             }
         }
-        copra_status_t rc = ensure_lds_attr(h);
-        if (rc != COPRA_OK) return rc;
-        if (!h->shared_attr_set && h->hp.lds_full_bytes > 48 * 1024) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, false)),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, true)),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
-        }
-        h->shared_attr_set = true;
-        if (h->model_dirty) {
-            rc = prepare_shared_model(h, s);
-            if (rc != COPRA_OK) return rc;
-        }
-        FusedPlan P = device_plan(h);
-        P.model = h->d_model;
-        for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
-        P.model_rtot = h->model_rtot;
-        HIP_TRY(hipEventRecord(h->ev0, s));
-        if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, false, P));
-        if (h->shared_ric && P.lds.ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
-            if (h->shared_ric_solves < 1) h->shared_ric_solves = 1;
-            FusedPlan Pr = P;
-            Pr.ric_model = h->d_ric_model;
-            // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
-            // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
-            unsigned g1 = (unsigned)P.batch;
-            bool refs_now = false; // (then the pass MUST run: the choice of this tier above has checked that it can)
-            for (int t = 0; t < kMaxCosts; ++t) refs_now = refs_now || h->cost_p[t];
-            bool pass_ran = false;
-            if (!h->lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true, refs_now) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
-                && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, refs_now) == COPRA_OK || (h->lane_off = true, false))) {
-                // (no room for the pass's list: the tier alone, from now on -- as on the per-instance path below)
-                h->lane_cur ^= 1;
-                h->lane_ran = true;
-                Pr.lane_list = h->d_lane_list;
-                Pr.lane_count = h->d_lane_count + h->lane_cur;
-                Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
-                Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
-                Pr.lane_ws = refs_now ? h->d_lane_ws : nullptr; // (the delta feed-forward terms of instances with their own references)
-                hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
-                HIP_TRY(hipGetLastError());
-                Pr.lane_from_list = 1;
-                Pr.lane_handover = 1;
-                Pr.lane_zero = nullptr;
-                g1 = ((unsigned)P.batch + 7u) & ~7u; // (the list is dealt out in eighths: ric_tier_instance)
-                pass_ran = true;
-            }
-            if (refs_now && !pass_ran)
-                return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: per-instance references on the shared-model records tier need the lane pass in front");
-            LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
-            hipLaunchKernelGGL(select_fused_kernel(Pr), dim3(g1), dim3(64), h->hp.lds_bytes, s, Pr);
-            HIP_TRY(hipGetLastError());
-        } else if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
-            FusedPlan Pj = P;
-            void* args[] = { &Pj };
-            const unsigned per = 64u / (unsigned)h->jit_lanes;
-            LDS_OPT_IN(h->jit_shared, (size_t)per * h->hp.lds_bytes);
-            HIP_TRY(hipModuleLaunchKernel(h->jit_shared, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
-                per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
-        } else if (h->packed) {
-            HIP_TRY(h->packed == 16 ? packed_launch_w16(P, true, h->hp.lds_bytes, s) : packed_launch_w32(P, true, h->hp.lds_bytes, s));
-        } else {
-            LDS_OPT_IN(select_shared_kernel(P, false), h->hp.lds_bytes);
-            hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
-            HIP_TRY(hipGetLastError());
-        }
-        if (h->hp.two_tier) {
-            FusedPlan P2 = P;
-            P2.lds = h->hp.lds_full;
-            P2.from_list = 1;
-            const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
-            LDS_OPT_IN(select_shared_kernel(P2, true), h->hp.lds_full_bytes);
-            hipLaunchKernelGGL(select_shared_kernel(P2, true), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
-            HIP_TRY(hipGetLastError());
-        }
-        HIP_TRY(hipEventRecord(h->ev1, s));
-        h->timed = true;
-        h->tier_timed = false;
-        return COPRA_OK;
+        h->ad.shared_ric_solves = 2; // (decided)
     }
-    if (!h->A || !h->B || !h->d || !h->x0)
-        return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
-    FusedPlan P = device_plan(h);
-    hipStream_t s = (hipStream_t)hip_stream;
+    bool want = h->has_lds_ric && !h->d_warm && !h->hp.opt.no_ric_shared && !h->ad.shared_ric_off;
+    // Per-instance cost references (one model, every instance its own goal / reference trajectory): the records were swept with the
+    // controller-wide references, an instance's own feed-forward terms come from the DELTA sweep of the shared lane pass
+    // (lmpc_lane_shared_body) -- so the records form takes them where that pass runs; elsewhere lmpc_shared.hpp (reference columns of
+    // the shared model), as for every such controller before round 4 (96 vs 200 M solves/s at the headline shape).
+    bool refs = false;
+    for (int t = 0; t < kMaxCosts; ++t) refs = refs || h->cost_p[t];
+    if (want && refs) {
+        const FusedPlan Pw = device_plan(h);
+        want = !h->ad.lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, Pw.batch, true, true) && Pw.lane_tab >= 0 && Pw.lane_cref >= 0
+            && h->lds_ric.ricC && !Pw.prof && !Pw.prof_fine && !Pw.row_f_inst && select_lane_shared_kernel(Pw) != nullptr;
+        if (want && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for the delta terms: lmpc_shared.hpp)
+            (void)hipGetLastError();
+            want = false;
+        }
+    }
+    if (want != h->shared_ric) {
+        LdsLayout lq {};
+        if (want) {
+            h->hp.plan.lds = h->lds_ric;
+        } else if (tri_layout_with_lds_q1(h->hp.plan, h->lds_ric, lq)) {
+            h->hp.plan.lds = lq;
+        }
+        h->hp.lds_bytes = (size_t)h->hp.plan.lds.total * sizeof(double);
+        h->hp.two_tier = true;
+        h->lds_attr_set = false;
+        h->shared_attr_set = false;
+        h->shared_ric = want;
+        h->model_dirty = true;
+    }
+    return COPRA_OK;
+}
+
+// copra_batch_set_shared_system: one (A, B, d) for the batch -- prepare launch when the model changed, [shared lane pass +] first tier, second tier
+static copra_status_t solve_shared_model(copra_batch* h, hipStream_t s)
+{
+    if (!h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
     h->last_stream = s;
-    if (P.batch == 0) return COPRA_OK;
+    if (h->hp.plan.batch == 0) return COPRA_OK;
+    copra_status_t rcc = choose_shared_tier(h);
+    if (rcc != COPRA_OK) return rcc;
     copra_status_t rc = ensure_lds_attr(h);
     if (rc != COPRA_OK) return rc;
-    // Timing (copra_batch_last_solve_seconds).  The plain one-wave launches carry their events IN their dispatch packets
-    // (hipExtLaunchKernelGGL): start of the first launch, end of the first launch (copra_batch_last_first_tier_seconds) and end
-    // of the second one (the whole solve, what LMPC::solveTime() reports) -- no barrier packets in the stream: two
-    // hipEventRecord per solve cost ~ 20 us between consecutive solves, 3 % of the headline step.  The other paths bracket
-    // their launches with recorded events as before.
-    const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri
-        && h->jit_ric == (P.lds.ric != 0);
-    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed;
-    if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
-    if (h->hp.large) {
-        if (use_riccati(h)) {
-            // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
-            const size_t ric_lds = (size_t)(h->ric_fast ? h->hs.sp.fast_lds_doubles : h->hs.sp.lds_doubles) * sizeof(double);
-            HIP_TRY(begin_overflow_queue(h, s, false, P));
-            HIP_TRY(hipMemsetAsync(h->d_ric_next, 0, sizeof(int), s));
-            const riccati_kernel_t ric_fn = h->ric_fast ? copra_lmpc_riccati_mfma_kernel : select_riccati_kernel(P.nx, P.nu);
-            LDS_OPT_IN(ric_fn, ric_lds);
-            hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
+    if (!h->shared_attr_set && h->hp.lds_full_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, false)),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(select_shared_kernel(h->hp.plan, true)),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->hp.lds_full_bytes));
+    }
+    h->shared_attr_set = true;
+    if (h->model_dirty) {
+        rc = prepare_shared_model(h, s);
+        if (rc != COPRA_OK) return rc;
+    }
+    FusedPlan P = device_plan(h);
+    P.model = h->d_model;
+    for (int k = 0; k < kMaxCosts; ++k) P.model_ref_off[k] = h->model_ref_off[k];
+    P.model_rtot = h->model_rtot;
+    HIP_TRY(hipEventRecord(h->ev0, s));
+    if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, false, P));
+    if (h->shared_ric && P.lds.ric) { // first tier: the Riccati-factor body, records copied from the prepare launch instead of swept
+        if (h->ad.shared_ric_solves < 1) h->ad.shared_ric_solves = 1;
+        FusedPlan Pr = P;
+        Pr.ric_model = h->d_ric_model;
+        // in front of it the one-instance-per-lane pass in its shared-model form (lmpc_lane.hpp): the roll-out of every instance from
+        // the batch-wide records; the tier solves what it leaves over, starting from the U and X it wrote
+        unsigned g1 = (unsigned)P.batch;
+        bool refs_now = false; // (then the pass MUST run: the choice of this tier above has checked that it can)
+        for (int t = 0; t < kMaxCosts; ++t) refs_now = refs_now || h->cost_p[t];
+        bool pass_ran = false;
+        if (!h->ad.lane_off && !h->hp.opt.no_lane_pass && lane_batch_ok(h->hp.opt, P.batch, true, refs_now) && P.lane_tab >= 0 && P.lds.ricC && !P.prof && !P.prof_fine
+            && !P.row_f_inst && select_lane_shared_kernel(P) && (ensure_lane_buffers(h, refs_now) == COPRA_OK || (h->ad.lane_off = true, false))) {
+            // (no room for the pass's list: the tier alone, from now on -- as on the per-instance path below)
+            h->lane_cur ^= 1;
+            h->ad.lane_ran = true;
+            Pr.lane_list = h->d_lane_list;
+            Pr.lane_count = h->d_lane_count + h->lane_cur;
+            Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
+            Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
+            Pr.lane_ws = refs_now ? h->d_lane_ws : nullptr; // (the delta feed-forward terms of instances with their own references)
+            hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
             HIP_TRY(hipGetLastError());
-            if (!h->hp.ric_only) { // (beyond the condensed kernels' sizes the instances that did not converge keep status 3)
-                FusedPlan P2 = P;
-                P2.from_list = 1;
-                LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
-                hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
-                    h->hp.lds_bytes, s, P2);
-                HIP_TRY(hipGetLastError());
-            }
-            HIP_TRY(hipEventRecord(h->ev1, s));
-            h->timed = true;
-            h->tier_timed = false;
-            return COPRA_OK;
+            Pr.lane_from_list = 1;
+            Pr.lane_handover = 1;
+            Pr.lane_zero = nullptr;
+            g1 = ((unsigned)P.batch + 7u) & ~7u; // (the list is dealt out in eighths: ric_tier_instance)
+            pass_ran = true;
         }
-        LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
-        hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
-            h->hp.lds_bytes, s, P);
+        if (refs_now && !pass_ran)
+            return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: per-instance references on the shared-model records tier need the lane pass in front");
+        LDS_OPT_IN(select_fused_kernel(Pr), h->hp.lds_bytes);
+        hipLaunchKernelGGL(select_fused_kernel(Pr), dim3(g1), dim3(64), h->hp.lds_bytes, s, Pr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev1, s));
-        h->timed = true;
-        h->tier_timed = false;
-        return COPRA_OK;
+    } else if (h->jit_shared && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri) {
+        FusedPlan Pj = P;
+        void* args[] = { &Pj };
+        const unsigned per = 64u / (unsigned)h->jit_lanes;
+        LDS_OPT_IN(h->jit_shared, (size_t)per * h->hp.lds_bytes);
+        HIP_TRY(hipModuleLaunchKernel(h->jit_shared, ((unsigned)P.batch + per - 1) / per, 1, 1, 64, 1, 1,
+            per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
+    } else if (h->packed) {
+        HIP_TRY(h->packed == 16 ? packed_launch_w16(P, true, h->hp.lds_bytes, s) : packed_launch_w32(P, true, h->hp.lds_bytes, s));
+    } else {
+        LDS_OPT_IN(select_shared_kernel(P, false), h->hp.lds_bytes);
+        hipLaunchKernelGGL(select_shared_kernel(P, false), dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
     }
-    if (P.initial_state) {
-        if (h->packed) {
-            HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
-        } else {
-            LDS_OPT_IN(copra_islmpc_fused_kernel, h->hp.lds_bytes);
-            hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+    if (h->hp.two_tier) {
+        FusedPlan P2 = P;
+        P2.lds = h->hp.lds_full;
+        P2.from_list = 1;
+        const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+        LDS_OPT_IN(select_shared_kernel(P2, true), h->hp.lds_full_bytes);
+        hipLaunchKernelGGL(select_shared_kernel(P2, true), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    h->tier_timed = false;
+    return COPRA_OK;
+}
+
+// more than 64 decision variables: the stage-wise interior-point kernel with the workgroup Goldfarb-Idnani kernel behind it, or the latter alone
+static copra_status_t solve_large(copra_batch* h, FusedPlan& P, hipStream_t s)
+{
+    if (use_riccati(h)) {
+        // first tier: stage-wise interior-point kernel; second tier: Goldfarb-Idnani for the instances it queued
+        const size_t ric_lds = (size_t)(h->ric_fast ? h->hs.sp.fast_lds_doubles : h->hs.sp.lds_doubles) * sizeof(double);
+        HIP_TRY(begin_overflow_queue(h, s, false, P));
+        HIP_TRY(hipMemsetAsync(h->d_ric_next, 0, sizeof(int), s));
+        const riccati_kernel_t ric_fn = h->ric_fast ? copra_lmpc_riccati_mfma_kernel : select_riccati_kernel(P.nx, P.nu);
+        LDS_OPT_IN(ric_fn, ric_lds);
+        hipLaunchKernelGGL(ric_fn, dim3((unsigned)h->ric_grid), dim3(64), ric_lds, s, P, h->hs.sp);
+        HIP_TRY(hipGetLastError());
+        if (!h->hp.ric_only) { // (beyond the condensed kernels' sizes the instances that did not converge keep status 3)
+            FusedPlan P2 = P;
+            P2.from_list = 1;
+            LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
+            hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+                h->hp.lds_bytes, s, P2);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(h->ev1, s));
@@ -1370,17 +1349,48 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         h->tier_timed = false;
         return COPRA_OK;
     }
+    LDS_OPT_IN(h->large_fn, h->hp.lds_bytes);
+    hipLaunchKernelGGL(h->large_fn, dim3((unsigned)h->large_grid), dim3((unsigned)P.large.threads),
+        h->hp.lds_bytes, s, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    h->tier_timed = false;
+    return COPRA_OK;
+}
+
+// InitialStateLMPC up to 64 variables: one wave (or 16 / 32 lanes) per instance
+static copra_status_t solve_initial_state(copra_batch* h, FusedPlan& P, hipStream_t s)
+{
+    if (h->packed) {
+        HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
+    } else {
+        LDS_OPT_IN(copra_islmpc_fused_kernel, h->hp.lds_bytes);
+        hipLaunchKernelGGL(copra_islmpc_fused_kernel, dim3((unsigned)P.batch), dim3(64), h->hp.lds_bytes, s, P);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    h->tier_timed = false;
+    return COPRA_OK;
+}
+
+// The one-wave kernels: [one-instance-per-lane pass ->] first tier [-> second tier].  ext_timed: the launches carry their events in their
+// dispatch packets (hipExtLaunchKernelGGL): start of the first launch, end of the first tier (copra_batch_last_first_tier_seconds), end of
+// the solve -- no barrier packets in the stream: two hipEventRecord per solve cost ~ 20 us between consecutive solves, 3 % of a headline step.
+static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s, bool jit_launch, bool ext_timed)
+{
     // the one-instance-per-lane pass (lmpc_lane.hpp): every instance whose unconstrained minimiser violates nothing ends in it, the
     // first tier below runs for the others only
     bool lane_pass = lane_pass_wanted(h, P, jit_launch);
     if (lane_pass && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for its workspace: the tier alone, from now on)
         (void)hipGetLastError();
-        h->lane_off = true;
+        h->ad.lane_off = true;
         lane_pass = false;
     }
     if (lane_pass) {
         h->lane_cur ^= 1;
-        h->lane_ran = true;
+        h->ad.lane_ran = true;
         P.lane_ws = h->d_lane_ws;
         P.lane_ws2 = h->d_lane_ws2;
         P.lane_list = h->d_lane_list;
@@ -1394,8 +1404,11 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         P.lane_spec = (P.lane_handover && !h->hp.opt.no_lane_spec) ? 1 : 0; // (... and takes the first step of the iteration itself where a bound on u_0 is the pick)
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
-        const bool predict = h->lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;
-        if (predict) P.lane_hist = h->d_lane_hist;
+        const bool predict = h->ad.lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;
+        if (predict) {
+            P.lane_hist = h->d_lane_hist;
+            HIP_TRY(hipMemsetAsync(h->d_lane_hist, 0, kLaneHistBins * sizeof(int), s)); // (the pass ADDS to it: a re-armed prediction -- copra_batch_specialise -- must not count the earlier solve's instances again)
+        }
         if (jit_launch) {
             FusedPlan Pl = P;
             void* largs[] = { &Pl };
@@ -1415,7 +1428,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
             // in `share` is expected to outgrow the first tier -- BEFORE its first launch, with ONE synchronisation in the controller's
             // life, instead of after each of the first solves (round 3: the first solve of the tight workload took 10.4 ms, the
             // steady state 2.8 ms).  adapt_layout keeps checking the real overflow counts of the first solves behind this.
-            h->lane_predict_left -= 1;
+            h->ad.lane_predict_left -= 1;
             int hist[kLaneHistBins];
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(hist, h->d_lane_hist, sizeof hist, hipMemcpyDeviceToHost));
@@ -1484,6 +1497,34 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
     h->tier_timed = ext_timed && h->hp.two_tier;
     h->timed = true;
     return COPRA_OK;
+}
+
+copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
+{
+    if (!h) return fail(COPRA_ERR_ARG, "copra_batch_solve: null handle");
+    copra_status_t rc = learn_from_the_last_solve(h);
+    if (rc != COPRA_OK) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (h->shared) {
+        rc = solve_shared_model(h, s);
+        if (rc == COPRA_OK) remember_outputs(h, device_plan(h));
+        return rc;
+    }
+    if (!h->A || !h->B || !h->d || !h->x0)
+        return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
+    FusedPlan P = device_plan(h);
+    h->last_stream = s;
+    if (P.batch == 0) return COPRA_OK;
+    rc = ensure_lds_attr(h);
+    if (rc != COPRA_OK) return rc;
+    remember_outputs(h, P);
+    const bool jit_launch = h->jit_fused && h->jit_lanes == (h->packed ? h->packed : 64) && h->jit_tri == P.lds.tri
+        && h->jit_ric == (P.lds.ric != 0);
+    const bool ext_timed = !h->hp.large && !P.initial_state && !jit_launch && !h->packed;
+    if (!ext_timed) HIP_TRY(hipEventRecord(h->ev0, s));
+    if (h->hp.large) return solve_large(h, P, s);
+    if (P.initial_state) return solve_initial_state(h, P, s);
+    return solve_one_wave(h, P, s, jit_launch, ext_timed);
 }
 
 

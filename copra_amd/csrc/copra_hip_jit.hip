@@ -217,9 +217,9 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
             h->hp = trial;
             h->packed = 0; // (one instance per wavefront on this tier)
             h->lds_attr_set = false;
-            h->adapt_left = h->adapt_left > 4 ? h->adapt_left : 4;
-            h->lds_top_set = false; // (a new ladder: its first solve chooses the level again)
-            h->lane_predict_left = 1;
+            h->ad.adapt_left = h->ad.adapt_left > 4 ? h->ad.adapt_left : 4;
+            h->ad.lds_top_set = false; // (a new ladder: its first solve chooses the level again)
+            h->ad.lane_predict_left = 1;
             h->jit_module = modr;
             h->jit_lanes = 64;
             h->jit_tri = 1;

@@ -57,8 +57,35 @@ bool prefer_w4(const copra_options_t& opt, const void* full, const void* w4, int
 
 constexpr size_t kSmallSlab = 1u << 20; // result slabs up to this size are fetched with one copy through pinned memory
 
+// What the engine has LEARNT about a controller's workload.  Every decision that makes the choice of kernels (never their results) depend on
+// earlier solves reads and writes this struct and nothing else: round-4 verdict -- four adaptive controllers spread over the handle were the
+// place where the variants interacted.  copra_hip.hip: adapt_lane_pass, adapt_layout, rechoose_layout, the pass's histogram, the shared tier's choice.
+struct AdaptState {
+    bool solved_once = false;
+    // the layout ladder of the first tier
+    int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked (adapt_layout)
+    int lane_predict_left = 1; // solves whose first-tier layout is still chosen from the pass's violated-row histogram
+    LdsLayout lds_top {}; // the layout the ladder started on: the choice is made again every 256 solves, from the top (rechoose_layout) -- a
+    bool lds_top_set = false; // controller whose constraints relax gets its denser layout back
+    long long layout_solves = 0; // solves completed on the current ladder
+    // the one-instance-per-lane pass
+    bool lane_ran = false; // the last solve ran it
+    bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass), or no memory for its workspace
+    bool lane_off_by_share = false; // ... the former: sampled again every 256 solves
+    int lane_adapt_left = 2;
+    long long lane_solves = 0; // solves seen by adapt_lane_pass
+    // shared-model tick on the records tier
+    long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
+    bool shared_ric_off = false; // ... which a small, constraint-heavy controller leaves after its first solve
+    // where the LAST LAUNCHED solve wrote its counters (round-4 advisor: rechoose_layout and the shared tier's choice read the buffers set for
+    // the NEXT solve -- with rotating result slabs an uninitialised one)
+    const int* last_iter = nullptr;
+    const int* last_status = nullptr;
+};
+
 struct copra_batch {
     HostPlan hp;
+    AdaptState ad;
     // device copies of the plan tables
     int *d_row_step = nullptr, *d_row_ekind = nullptr, *d_row_eoff = nullptr, *d_row_gkind = nullptr,
         *d_row_goff = nullptr;
@@ -85,8 +112,6 @@ struct copra_batch {
     // for that tier (kept when copra_batch_set_shared_system moves the plan to an LDS-Q1 layout), whether the next solve uses it,
     // and the batch-wide records
     bool has_lds_ric = false, shared_ric = false;
-    long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
-    bool shared_ric_off = false;     // ... which a small, constraint-heavy controller leaves after its first solve (copra_batch_solve)
     LdsLayout lds_ric {};
     double* d_ric_model = nullptr;
     int model_ref_off[kMaxCosts]; // columns of C2 per cost as prepared (-1: none)
@@ -108,20 +133,9 @@ struct copra_batch {
     // one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp)
     int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
     int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
-    int lane_predict_left = 1; // solves whose first-tier layout is still chosen from that histogram
-    LdsLayout lds_top {}; // the layout the ladder started on (the choice is made again every 256 solves, from the top: a controller whose
-    long long layout_solves = 0; // solves completed on the current ladder (rechoose_layout)
-    bool lds_top_set = false; // constraints relax gets its denser layout back)
     double* d_lane_ws = nullptr;
     double* d_lane_ws2 = nullptr; // the instance-major hand-over blocks of the pass (FusedPlan::lane_ws2)
     int lane_cur = 0; // the counter the last solve appended to
-    bool lane_ran = false; // the last solve ran the pass
-    bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass)
-    int lane_adapt_left = 2;
-    long long lane_solves = 0; // solves seen by adapt_lane_pass (it samples the share again every 256)
-    bool lane_off_by_share = false; // lane_off was set by adapt_lane_pass (too few instances ended in the pass), not for lack of memory
-    int adapt_left = 3; // solves after which the overflow count of a compact layout is still checked
-    bool solved_once = false;
     int packed = 0; // lanes per instance when several small problems share a wavefront (16 / 32; 0: one wave each)
     void (*large_fn)(const FusedPlan) = nullptr; // workgroup-per-instance kernel variant chosen at creation
     double* d_ws = nullptr; // workgroup-per-instance kernel: [large_grid][ws_total] doubles (J, factor, Phi, ...)

@@ -118,6 +118,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const int T2 = NH * (NLU + NX); // doubles per instance of the hand-over block
     const bool handover = P.lane_handover && P.lane_ws2;
     double* const ws2 = handover ? P.lane_ws2 + (size_t)(group * GRP) * T2 : nullptr;
+    // (phase stamps of the wave, with copra_batch_enable_phase_profile: staging | sweep | roll-out | verdict, in row `group` of the profile --
+    //  the first tier's rows are per instance, tools/exp/lane_tier1_phases.py leaves the first 1024 out)
+    long long stamp[5];
+    stamp[0] = P.prof ? cycle_counter() : 0;
 
     // ---- 0. this lane's system ----
     double A[NX * NX], B[NX * NU], d[NX], x[NX];
@@ -152,6 +156,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     wave_sync();
     auto AB = [&](int l, int a) -> double { return a < NX ? A[l + NX * a] : B[l + NX * (a - NX)]; }; // [A B](l, a)
 
+    stamp[1] = P.prof ? cycle_counter() : 0;
     // Per-instance cost references (copra_batch_set_cost_reference: every instance tracks its own goal): the affine terms h = -sum_t
     // [M N]_t' W_t p_t and hN differ per lane then.  They are rebuilt from the coefficient table of the plan builder (lane_cref), this
     // lane's references where a cost has them and the controller-wide ones elsewhere, and h waits in the (idle) staging area for the sweep.
@@ -430,6 +435,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         x[i] = xi;
         d[i] = di;
     }
+    stamp[2] = P.prof ? cycle_counter() : 0;
     // Lam_0^-1 from the slot of stage 0 (still there: the group that holds stage 0 was the last one staged) -- the speculative step below
     double lam0[NL];
 #pragma unroll
@@ -742,6 +748,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     }
     const bool done1 = valid && spec && uniq && !viol1; // finished by the one constraint it speculated on
 
+    stamp[3] = P.prof ? cycle_counter() : 0;
     // ---- 3. verdict: done, or one more entry of the first tier's list (one atomic per wave) ----
     const bool more = valid && viol && !done1;
     int total = 0;
@@ -768,6 +775,12 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             (void)wave_prefix_count(bin == b, cnt);
             if (cnt > 0 && lane == 0) (void)atomic_add_i32(P.lane_hist + b, cnt);
         }
+    }
+    if (P.prof && lane == 0) {
+        stamp[4] = cycle_counter();
+        long long* pr = P.prof + 8 * (size_t)group;
+        for (int q = 0; q < 4; ++q) pr[q] = stamp[q + 1] - stamp[q];
+        pr[7] = stamp[4] - stamp[0];
     }
 }
 

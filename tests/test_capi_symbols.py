@@ -92,3 +92,25 @@ def test_no_matrix_instruction_hazard_across_a_branch(tmp_path):
                  "\ts_endpgm                                                   // 000000001020: BF810000\n")
     found = lint.lint(dis, disassembly=True)
     assert len(found) == 1 and found[0][5] == 1 and found[0][6] == 6
+
+
+def test_every_engine_option_takes_part_in_the_mode_fuzzer():
+    """round-4 verdict, item 6: copra_options_t is the variant surface -- 21 fields since round 5 (37 before) -- and tests/fuzz/fuzz_modes.py
+    runs random controllers under every one of them (a 240-controller slice of it is in the GPU suite).  The header's field list, the ctypes
+    mirror and the fuzzer's option sets must name the same options."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fuzz_modes
+    from copra_amd import _capi
+    text = open(os.path.join(ROOT, "include", "copra_hip.h")).read()
+    body = text[text.index("typedef struct {\n    int struct_size;"):text.index("} copra_options_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for m in re.finditer(r"^\s*(?:int|double)\s+([^;]+);", body, flags=re.M):
+        fields += [n.strip() for n in m.group(1).split(",")]
+    assert fields[0] == "struct_size" and tuple(fields[1:]) == _capi.OPTION_NAMES
+    assert len(_capi.OPTION_NAMES) <= 25
+    covered = set().union(*[set(o) for o in fuzz_modes.OPTION_SETS])
+    assert covered == set(_capi.OPTION_NAMES), (covered ^ set(_capi.OPTION_NAMES))
+    assert 240 // 8 >= len(fuzz_modes.OPTION_SETS)  # (the GPU suite's slice reaches every set)

@@ -1483,9 +1483,10 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
     for b in (65536, 65536 - 37):
         wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
         out = {}
-        for mode in ("off", "filter_only", "on"):
+        for mode in ("off", "filter_only", "on", "on_nospec"):
             monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
             monkeypatch.setitem(OPTIONS, "no_lane_handover", 0)
+            monkeypatch.setitem(OPTIONS, "no_lane_spec", 1 if mode == "on_nospec" else 0)
             if mode == "off":
                 monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
             if mode == "filter_only":
@@ -1499,13 +1500,21 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
         r0 = out["off"][0]
         assert out["off"][1] == (False, 0)
         ok = r0["status"] == 0
-        for mode in ("filter_only", "on"):
+        for mode in ("filter_only", "on", "on_nospec"):
             r1, (ran, finished) = out[mode]
             assert (r1["status"] == r0["status"]).all() and (r1["iter"] == r0["iter"]).all()
             # (two orders of summation of the same unconstrained minimiser, up to 22 active-set iterations behind them: measured 1.1e-11)
             assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-10 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-10
             at_minimiser = int(((r0["iter"][:, 0] == 1) & ok).sum())
-            if mode == "on":  # (with the hand-over of the factor the pass always runs)
+            one_bound = int(((r0["iter"][:, 0] == 2) & (r0["iter"][:, 1] == 0) & ok).sum())
+            if mode == "on":  # (with the hand-over of the factor the pass always runs -- and, since round 5, takes the first step of the
+                #  iteration itself where a bound on u_0 is the pick: at the headline's constraint level that is EVERY first pick, so every
+                #  instance the tier alone reports with the counters (2, 0) ends in the pass)
+                assert ran and at_minimiser <= finished <= at_minimiser + one_bound
+                if vmax >= 0.6:
+                    # (all but the handful it leaves to the tier because another row comes within 1e-9 of the pick: 2 of 24 997 measured)
+                    assert finished >= at_minimiser + one_bound - 16 and one_bound > b // 4
+            elif mode == "on_nospec":
                 assert ran and finished == at_minimiser
             else:  # (filter only: switched off after the first solves when fewer than one instance in eight ends in it)
                 assert (ran and finished == at_minimiser) if at_minimiser * 8 >= b else not ran
@@ -1680,7 +1689,8 @@ def test_one_instance_per_lane_pass_short_lists(oracle, violators):
     eng.solve()
     res = eng.results()
     ran, finished = eng.lane_pass_info()
-    assert ran and finished == b - violators and (res["status"] == 0).all()
+    one_bound = int(((res["iter"][pick, 0] == 2) & (res["iter"][pick, 1] == 0)).sum())  # (the pass may take their one step itself: round 5)
+    assert ran and b - violators <= finished <= b - violators + one_bound and (res["status"] == 0).all()
     assert (res["iter"][pick, 0] > 1).all() and (np.delete(res["iter"][:, 0], pick) == 1).all()
     sample = np.unique(np.concatenate([pick, np.arange(0, b, 997)]))
     for k in sample:

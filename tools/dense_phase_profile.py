@@ -8,6 +8,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi as _capi_opts  # noqa: E402
+
+_capi_opts.OPTIONS["no_lane_pass"] = 1  # (the phases of the tier ALONE: under the phase profile the pass otherwise runs as in production)
 from copra_amd.autospan import autospan_cost  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

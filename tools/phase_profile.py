@@ -11,6 +11,9 @@ if "--lib" in sys.argv:  # an experimental build of the library (copra_amd/csrc/
     _capi.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
     _capi.build_library = lambda force=False: False
 from copra_amd import BatchLMPC, workloads  # noqa: E402
+from copra_amd import _capi as _capi_opts  # noqa: E402
+
+_capi_opts.OPTIONS["no_lane_pass"] = 1  # (the phases of the tier ALONE: under the phase profile the pass otherwise runs as in production)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 wl = workloads.com_preview(batch, v_max=float(os.environ.get("VMAX", "0.6")), u_max=float(os.environ.get("UMAX", "3.0")))  # (VMAX=0.25 UMAX=1.2: the tight variant)

@@ -1,5 +1,5 @@
 """Device-resident timing of copra_qp_solve_dense_batch for n > 64 (dev tool; GPU box only).
-usage: try_dense_large.py N BATCH   env: COPRA_OPTIONS=debug=1, COPRA_OPTIONS=large_per_cu=k"""
+usage: try_dense_large.py N BATCH   env: COPRA_OPTIONS=debug=1"""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,5 @@
 """Kernel time of the workgroup-per-instance path on the 300-step reference fixture (dev tool; GPU box only).
-usage: try_large.py BATCH [system] [xcost]   env: COPRA_OPTIONS=debug=1, COPRA_OPTIONS=large_per_cu=k"""
+usage: try_large.py BATCH [system] [xcost]   env: COPRA_OPTIONS=debug=1"""
 import os
 import sys
 
