@@ -427,7 +427,8 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
     }
     if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
         e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
-    if (e == hipSuccess && need_ws && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
+    const bool hand_over = P.lds.ricC && !h->hp.opt.no_lane_handover && h->hp.opt.no_lane_spec; // (copra_batch_solve: the form of the pass that hands blocks over)
+    if (e == hipSuccess && need_ws && hand_over && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
         e = hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1400,8 +1401,13 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         // (64 instances per wave.  Half-waves -- twice the waves for a shard of BASELINE configs[3] -- were built in round 4 and measured no
         //  faster, profiles/r04/lane_half_waves.txt: the switch and its code are gone.)
         const unsigned g0 = (unsigned)(((long long)P.batch + kWave - 1) / kWave);
-        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover) ? 1 : 0; // (the pass leaves Lam^-1 and the norm sums only for a tier that takes them)
-        P.lane_spec = (P.lane_handover && !h->hp.opt.no_lane_spec) ? 1 : 0; // (... and takes the first step of the iteration itself where a bound on u_0 is the pick)
+        // Two forms of the pass in front of the compact variant of the Riccati-factor tier (results are the same):
+        //   speculation (default): it takes the first steps of the active-set iteration itself where bounds on u_0 are the picks -- at the
+        //     headline's constraint level 96 % of the batch ends in it -- and hands NOTHING over: the few instances it leaves sweep for themselves
+        //     (the hand-over blocks of 65 536 instances were 157 MB of writes for the 2 437 that read them);
+        //   hand-over (copra_options_t::no_lane_spec): Lam^-1 | kv | norm sums of every instance for a tier that takes the factor over.
+        P.lane_spec = (P.lds.ricC && !h->hp.opt.no_lane_spec) ? 1 : 0;
+        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover && !P.lane_spec) ? 1 : 0;
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
         const bool predict = h->ad.lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;
@@ -1450,7 +1456,6 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
             P.lane_hist = nullptr;
         }
         P.lane_from_list = 1;
-        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover) ? 1 : 0;
         P.lane_zero = nullptr;
     }
     if (h->hp.two_tier) HIP_TRY(begin_overflow_queue(h, s, P.lds.ric && (!jit_launch || h->jit_ric) && !h->packed, P));

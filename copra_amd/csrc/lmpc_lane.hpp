@@ -165,7 +165,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double hNl[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) hNl[i] = uniform_load(tab, ohN + i);
-    constexpr int HS = (NZ + GL * NLU + 2 * NX) | 1; // this lane's slot of the staging area during the sweep: h (NZ) | Lam^-1 of the group's stages |
+    constexpr int HS = (NZ + GL * NLU + 2 * NX + NL) | 1; // this lane's slot of the staging area during the sweep: h (NZ) | Lam^-1 of the group's stages |
                                                     // x0 and d, which wait here for the roll-out -- the sweep reads d from the slot (ONE address
                                                     // register for all; odd: no bank conflicts)
     double hl[NZ]; // (the sweep reads h from this lane's slot of the staging area either way: no branch per use in its loop)
@@ -357,6 +357,12 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int c = 0; c < NU; ++c) s += M[i][NX + c] * kv[c];
             pv[i] = s;
         }
+        if (k == 0) { // W = M_uu,0^-1 = -Ni, packed by rows: what the speculative steps of the roll-out compute with (parked in this lane's slot)
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) lds[lane * HS + NZ + GL * NLU + 2 * NX + i * (i + 1) / 2 + j] = -Ni[i][j];
+        }
         // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
         double* const wk = ws + ((size_t)k * WR) * bp;
 #pragma unroll
@@ -436,14 +442,20 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         d[i] = di;
     }
     stamp[2] = P.prof ? cycle_counter() : 0;
-    // Lam_0^-1 from the slot of stage 0 (still there: the group that holds stage 0 was the last one staged) -- the speculative step below
-    double lam0[NL];
+    // W = M_uu,0^-1 from the slot (the sweep's last stage left it there) moves to where the roll-out's staging does not reach -- the place of the
+    // norm sums' staging, which only the hand-over form of the pass uses, and that form does not speculate: the speculative steps below read it
+    // there (in registers it would be live across the whole roll-out loop: that was what pushed the sweep into scratch memory)
+    {
+        double w0[NL];
 #pragma unroll
-    for (int e = 0; e < NL; ++e) lam0[e] = handover ? lds[lane * HS + NZ + e] : 0.0;
+        for (int e = 0; e < NL; ++e) w0[e] = lds[lane * HS + NZ + GL * NLU + 2 * NX + e];
+        wave_sync(); // (every lane has read x0, d and W from its slot)
+#pragma unroll
+        for (int e = 0; e < NL; ++e) lds[kWave * (((kLaneGroup * NX) | 1) + ((kLaneGroup * NU) | 1)) + lane * ((kLaneGroup * NX) | 1) + e] = w0[e];
+    }
     // ---- 2. roll-out from x0 with qpgen2's first scan inside: rows of step k on (x_k, u_k), the bounds of u_k ----
     const double vsmall = P.vsmall;
     const int rps = P.lane_rps;
-    bool viol = bad;
     int nviol = 0; // violated rows and bounds at the unconstrained minimiser: what the size of the final active set goes with (lane_hist below)
     const int li = valid ? inst : 0;
     const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
@@ -476,54 +488,67 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
         return f;
     };
-    // ---- the FIRST STEP of the active-set iteration, speculatively (round 5) ----
+    // ---- the FIRST STEPS of the active-set iteration, speculatively (round 5) ----
     // Where the unconstrained minimiser saturates an actuator NOW -- a bound on u_0 is its most violated constraint, qpgen2's first pick: on
-    // BASELINE configs[2] that is every one of the 53 % of the instances this pass used to leave to the first tier, and 71 % of them are
-    // finished by that one constraint -- the step the iteration takes has a closed form in the quantities of THIS roll-out.  The normal of
-    // a bound on component c of u_0 is n = -+e_c in stage 0 and zero elsewhere, so w = R^-T n stops at stage 0 (ric_factor.hpp: the backward
-    // recursion never starts), t_0 = Lam_0^-T Lam_0^-1 n, z_0 = t_0, and from stage 1 on z_k = K_k xi_k IS the closed loop: the new iterate
-    // U0 + t z is the roll-out from x0 with  u_0 + t t_0  in front and the same gains behind.  So a second state rides along (x1, u1: one
-    // more K x + kv and A x + B u + d per stage), its rows and bounds are scanned like the first one's, and at the end
-    //     nothing violated at U0                                     -> done, iterations (1, 0)              (as before)
-    //     the bound was the pick (strictly the worst of ALL rows, normalised as qpgen2 does) and U1 violates nothing
-    //                                                                -> done, iterations (2, 0): U1, X1 are the results
-    //     anything else (another pick, a tie, more to do at U1)     -> the first tier, from scratch
-    // Same decisions as the tier (its pick, its step length -s / z'n with z'n = |Lam_0^-1 e_c|^2, its test slack <= -vsmall at the new
-    // iterate with the new active row left out); near-ties (1e-9 relative) go to the tier.  A lane that speculates writes U1, X1 to the
-    // results -- the verdict comes last --, which is why the tier behind this pass rolls out for itself (lmpc_fused_ric.hpp, from_lane).
-    const bool spec_on = handover && P.lane_spec;
-    bool spec = false, uniq = true, viol1 = false;
-    int sc = -1; // component of u_0 whose bound is speculated on
-    double sstar = 0.0, sstar2 = 0.0; // its slack at U0 (negative), squared
-    double x1[NX];
+    // BASELINE configs[2] that is every one of the 53 % of the instances this pass used to leave to the first tier, 71 % of them are finished
+    // by that one constraint and most of the rest by a second bound on u_0 -- the steps the iteration takes have a closed form in the
+    // quantities of THIS roll-out.  The normal of a bound on component c of u_0 is n = -+e_c in stage 0 and zero elsewhere, so w = R^-T n
+    // stops at stage 0 (ric_factor.hpp: the backward recursion never starts), everything the method computes with such normals lives in the
+    // NU x NU block W = M_uu,0^-1 = Lam_0^-T Lam_0^-1 (the stage-0 block of Q^-1: M_uu,0 is the Schur complement of the later stages), and
+    // from stage 1 on the step direction z_k = K_k xi_k IS the closed loop: the new iterate is the roll-out from x0 with the new u_0 in front
+    // and the same gains behind.  So kSpec more trajectories ride along (one more K x + kv and A x + B u + d per stage each); trajectory l
+    // is the iterate after l steps, its rows and bounds are scanned like the first one's, and at the end, with l the first level that
+    // violates nothing:
+    //     every pick up to l was a bound on u_0 AND strictly the worst of ALL rows at its iterate, normalised as qpgen2 does
+    //                                              -> done, iterations (l + 1, 0): U_l, X_l are the results
+    //     anything else (another pick, a tie, a constraint to drop, more than kSpec steps)  -> the first tier, from scratch
+    // Same decisions as the tier: its pick, its step lengths t2 = -s / z'n and t1 = lambda / r (a partial step -- the tier's business), its test
+    // slack <= -vsmall with the active rows left out; near-ties (1e-9 relative) go to the tier.  A lane writes its DEEPEST trajectory to
+    // the results -- levels it does not speculate on repeat the one before, the verdict comes last --, which is why the tier behind this
+    // pass rolls out for itself (lmpc_fused_ric.hpp, from_lane).
+    constexpr int kSpec = NU >= 2 ? 2 : 1; // levels: steps taken here at most (a third one on u_0 would fix all of it: 1 % of the headline's batch)
+    const bool spec_on = P.lane_spec != 0; // (the controller's rows are the compact variant's: one component of a state, or controls only)
+    bool specl[kSpec + 1], uniql[kSpec + 1], violl[kSpec + 1]; // [l]: level l was speculated on | its pick was the pick | trajectory l violates something
+    int scl[kSpec + 1]; // component of u_0 whose bound level l >= 1 adds (-1: none)
+    double sst[kSpec + 1], sst2[kSpec + 1]; // the slack of level l's pick at trajectory l - 1 (negative), and its square
 #pragma unroll
-    for (int c = 0; c < NX; ++c) x1[c] = x[c];
-    // one row  e' x + g' u <= f  at both iterates
-    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[NX], const double (&uk)[NU],
-                        const double (&xk1)[NX], const double (&uk1)[NU], const double (&nc)[NX]) {
-        double ax = 0.0, ax1 = 0.0, n2 = 0.0;
+    for (int l = 0; l <= kSpec; ++l) {
+        specl[l] = false;
+        uniql[l] = true;
+        violl[l] = false;
+        scl[l] = -1;
+        sst[l] = sst2[l] = 0.0;
+    }
+    violl[0] = bad;
+    double xs[kSpec + 1][NX]; // xs[0]: the unconstrained minimiser's trajectory (x above)
 #pragma unroll
-        for (int c = 0; c < NX; ++c) {
-            ax += e[c] * xk[c];
-            ax1 += e[c] * xk1[c];
-            n2 += (e[c] * e[c]) * nc[c]; // (the compact variant's rows: ONE component of the state, or controls only)
+    for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
+    // one row  e' x + g' u <= f  at every iterate
+    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU],
+                        const double (&nc)[NX]) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) n2 += (e[c] * e[c]) * nc[c]; // (the compact variant's rows: ONE component of the state, or controls only)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) n2 += g[c] * g[c];
+#pragma unroll
+        for (int l = 0; l <= kSpec; ++l) {
+            double ax = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ax += e[c] * xk[l][c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ax += g[c] * uk[l][c];
+            const double sl = f - ax;
+            const bool v = sl <= -vsmall; // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
+            violl[l] = violl[l] || v;
+            if (l == 0) nviol += v ? 1 : 0;
+            // a row at least as bad as the next level's pick by qpgen2's measure, slack / norm (squared: no root, no division): not the pick
+            if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !(v && sl * sl >= (sst2[l + 1] * n2) * (1.0 - 1e-9));
         }
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-            ax += g[c] * uk[c];
-            ax1 += g[c] * uk1[c];
-            n2 += g[c] * g[c];
-        }
-        const double s0 = f - ax, s1 = f - ax1;
-        const bool v0 = s0 <= -vsmall; // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
-        viol = viol || v0;
-        nviol += v0 ? 1 : 0;
-        // a row at least as bad as the speculated bound by qpgen2's measure, slack / norm (squared: no root, no division): not our pick
-        uniq = uniq && !(v0 && s0 * s0 >= (sstar2 * n2) * (1.0 - 1e-9));
-        viol1 = viol1 || (s1 <= -vsmall);
     };
-    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU], const double (&xk1)[NX], const double (&uk1)[NU],
-                          const double (&nc)[NX]) { // E x_k + G u_k <= f
+    auto check_rows = [&](int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU], const double (&nc)[NX]) { // E x_k + G u_k <= f
         if (tlds) {
             for (int r = 0; r < rps; ++r) {
                 const double* const rt = Tl + (k * rps + r) * RW;
@@ -532,7 +557,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int c = 0; c < NX; ++c) e[c] = rt[c];
 #pragma unroll
                 for (int c = 0; c < NU; ++c) g[c] = rt[NX + c];
-                row_eval(e, g, row_rhs(rt[NZ], (int)rt[NZ + 1]), xk, uk, xk1, uk1, nc);
+                row_eval(e, g, row_rhs(rt[NZ], (int)rt[NZ + 1]), xk, uk, nc);
             }
             return;
         }
@@ -543,7 +568,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int c = 0; c < NX; ++c) e[c] = uniform_load(tab, ro + c);
 #pragma unroll
             for (int c = 0; c < NU; ++c) g[c] = uniform_load(tab, ro + NX + c);
-            row_eval(e, g, row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)), xk, uk, xk1, uk1, nc);
+            row_eval(e, g, row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)), xk, uk, nc);
         }
     };
     constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
@@ -565,18 +590,16 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         for (int q = 0; q < GS; ++q) {
             const int k = k0 + q;
             const bool on = k < NH;
-            double u[NU], u1[NU];
+            double us[kSpec + 1][NU];
 #pragma unroll
-            for (int c = 0; c < NU; ++c) {
-                double s = Kq[q % KB][NU * NX + c], s1 = s;
+            for (int l = 0; l <= kSpec; ++l)
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    s += Kq[q % KB][c + NU * j] * x[j];
-                    s1 += Kq[q % KB][c + NU * j] * x1[j];
+                for (int c = 0; c < NU; ++c) {
+                    double acc = Kq[q % KB][NU * NX + c];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc += Kq[q % KB][c + NU * j] * xs[l][j];
+                    us[l][c] = acc;
                 }
-                u[c] = s;
-                u1[c] = s1;
-            }
             fetch_stage(Kq[q % KB], k + KB);
             // the bounds of u_k
             double ubk[NU], lbk[NU];
@@ -595,78 +618,122 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 }
             }
             if (q == 0 && k0 == 0 && spec_on) {
-                // the most violated bound of u_0: qpgen2's order -- upper bounds (rows mgen + j) before lower ones (mgen + n + j), the first of
-                // equals wins -- so a tie is not decided here: strictly worse than every other one, or no speculation
-                double best = 0.0, second = 0.0, sig = 0.0;
+                // W = M_uu,0^-1 (symmetric, packed by rows)
+                double W[NU][NU];
 #pragma unroll
-                for (int i = 0; i < 2 * NU; ++i) {
-                    const int c = i < NU ? i : i - NU;
-                    const double sl = i < NU ? ubk[c] - u[c] : u[c] - lbk[c];
-                    const bool cand = sl <= -vsmall;
-                    const bool better = cand && sl < best;
-                    second = better ? best : ((cand && sl < second) ? sl : second);
-                    best = better ? sl : best;
-                    sc = better ? c : sc;
-                    sig = better ? (i < NU ? -1.0 : 1.0) : sig;
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) W[i][j] = W[j][i] = ldn[lane * SX + i * (i + 1) / 2 + j];
+                double lam1 = 0.0, sig1 = 0.0; // multiplier and orientation of the first active bound
+#pragma unroll
+                for (int l = 1; l <= kSpec; ++l) {
+                    // the most violated bound of u_0 at iterate l - 1 that is not active: qpgen2's order -- upper bounds (rows mgen + j) before
+                    // lower ones (mgen + n + j), the first of equals wins -- so a tie is not decided here: strictly worse than every other
+                    // one, or no speculation.  (The twin of an active bound cannot be violated: gi_core.hpp, `pinned`.)
+                    double best = 0.0, second = 0.0, sig = 0.0;
+                    int cb = -1;
+#pragma unroll
+                    for (int i = 0; i < 2 * NU; ++i) {
+                        const int c = i < NU ? i : i - NU;
+                        const double sl = i < NU ? ubk[c] - us[l - 1][c] : us[l - 1][c] - lbk[c];
+                        const bool cand = sl <= -vsmall && c != scl[l - 1] && (l < 2 || c != scl[l - 2]);
+                        const bool better = cand && sl < best;
+                        second = better ? best : ((cand && sl < second) ? sl : second);
+                        best = better ? sl : best;
+                        cb = better ? c : cb;
+                        sig = better ? (i < NU ? -1.0 : 1.0) : sig;
+                    }
+                    double ubc = 0.0, lbc = 0.0, wcc = 0.0, w1c = 0.0, w11 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) {
+                        ubc = (c == cb) ? ubk[c] : ubc;
+                        lbc = (c == cb) ? lbk[c] : lbc;
+                        wcc = (c == cb) ? W[c][c] : wcc;
+#pragma unroll
+                        for (int c1 = 0; c1 < NU; ++c1) {
+                            w1c = (c == cb && c1 == scl[1]) ? W[c1][c] : w1c;
+                            w11 = (c1 == scl[1]) ? W[c1][c1] : w11;
+                        }
+                    }
+                    bool go = (l == 1 || specl[l - 1]) && cb >= 0 && best < second && !bad && !(ubc - lbc <= -vsmall); // (an empty box: the tier reports it)
+                    // the step: z = H n, n = sig e_cb; with one active bound (level 2) H = W - W n1 n1' W / (n1' W n1)
+                    double z[NU], zn, r1 = 0.0;
+                    if (l == 1) {
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) {
+                            double wj = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NU; ++c) wj = (c == cb) ? W[j][c] : wj;
+                            z[j] = sig * wj;
+                        }
+                        zn = wcc; // z'n = |Lam^-1 e_c|^2
+                    } else {
+                        r1 = sig1 * sig * w1c / w11; // r = (n1' W n1)^-1 n1' W n
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) {
+                            double wj = 0.0, w1j = 0.0;
+#pragma unroll
+                            for (int c = 0; c < NU; ++c) {
+                                wj = (c == cb) ? W[j][c] : wj;
+                                w1j = (c == scl[1]) ? W[j][c] : w1j;
+                            }
+                            z[j] = sig * (wj - w1j * (w1c / w11));
+                        }
+                        zn = wcc - w1c * (w1c / w11);
+                    }
+                    double zz = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) zz += z[j] * z[j];
+                    go = go && zn > 0.0 && zz > vsmall; // (gi_core.hpp: no step in primal space -- the tier's business)
+                    const double t2 = go ? -best / zn : 0.0;
+                    // the dual step length: an active bound whose multiplier would reach zero first is DROPPED by the iteration -- the tier's business
+                    if (l == 2) go = go && !(r1 > 0.0 && lam1 / r1 <= t2 * (1.0 + 1e-9));
+                    const double tt = go ? t2 : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) us[l][j] = go ? us[l - 1][j] + t2 * z[j] : us[l - 1][j]; // (no step: z may be 0 / 0)
+                    if (l == 1) {
+                        lam1 = tt;
+                        sig1 = sig;
+                    }
+                    specl[l] = go;
+                    scl[l] = go ? cb : -1;
+                    sst[l] = go ? best : 0.0;
+                    sst2[l] = sst[l] * sst[l];
+                    if (l < kSpec) { // (the next level starts from this iterate; without a step it repeats it)
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) us[l + 1][j] = us[l][j];
+                    }
                 }
-                double ubc = 0.0, lbc = 0.0;
-#pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    ubc = (c == sc) ? ubk[c] : ubc;
-                    lbc = (c == sc) ? lbk[c] : lbc;
-                }
-                spec = sc >= 0 && best < second && !bad && !(ubc - lbc <= -vsmall); // (an empty box: the tier reports it)
-                // t_0 = Lam_0^-T (Lam_0^-1 n), n = sig e_c; z'n = sig t_0(c) = |Lam_0^-1 e_c|^2
-                double w[NU], t0[NU];
-#pragma unroll
-                for (int r = 0; r < NU; ++r) {
-                    double lrc = 0.0; // Lam^-1 (r, sc): zero above the diagonal
-#pragma unroll
-                    for (int c = 0; c <= r; ++c) lrc = (c == sc) ? lam0[r * (r + 1) / 2 + c] : lrc;
-                    w[r] = sig * lrc;
-                }
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = j; r < NU; ++r) acc += lam0[r * (r + 1) / 2 + j] * w[r];
-                    t0[j] = acc;
-                }
-                double zn = 0.0, zz = 0.0;
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    zn = (j == sc) ? sig * t0[j] : zn;
-                    zz += t0[j] * t0[j];
-                }
-                spec = spec && zn > 0.0 && zz > vsmall; // (gi_core.hpp: no step in primal space -- the tier's business)
-                const double tt = spec ? -best / zn : 0.0;
-#pragma unroll
-                for (int j = 0; j < NU; ++j) u1[j] = u[j] + tt * t0[j];
-                sstar = spec ? best : 0.0;
-                sstar2 = sstar * sstar;
-                sc = spec ? sc : -1;
             }
             if (on) {
-                check_rows(k, x, u, x1, u1, ncum);
+                check_rows(k, xs, us, ncum);
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    const double su = ubk[c] - u[c], sl = u[c] - lbk[c];
-                    const bool v0 = (su <= -vsmall) || (sl <= -vsmall);
-                    viol = viol || v0;
-                    nviol += v0 ? 1 : 0;
-                    const bool ours = (q == 0 && k0 == 0) && c == sc; // the speculated bound itself (active at U1: its twin cannot be violated)
-                    uniq = uniq && (ours || !((su <= -vsmall && su <= sstar * (1.0 - 1e-9)) || (sl <= -vsmall && sl <= sstar * (1.0 - 1e-9))));
-                    viol1 = viol1 || (!ours && ((ubk[c] - u1[c] <= -vsmall) || (u1[c] - lbk[c] <= -vsmall)));
+#pragma unroll
+                    for (int l = 0; l <= kSpec; ++l) {
+                        const double su = ubk[c] - us[l][c], sl = us[l][c] - lbk[c];
+                        // the bounds level <= l holds active (their twins cannot be violated), and the pick of level l + 1 itself
+                        const bool stage0 = q == 0 && k0 == 0;
+                        const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
+                        const bool v = !active && ((su <= -vsmall) || (sl <= -vsmall));
+                        violl[l] = violl[l] || v;
+                        if (l == 0) nviol += v ? 1 : 0;
+                        if (l < kSpec) {
+                            const bool pick = stage0 && c == scl[l + 1];
+                            uniql[l + 1] = uniql[l + 1]
+                                && (active || pick || !((su <= -vsmall && su <= sst[l + 1] * (1.0 - 1e-9)) || (sl <= -vsmall && sl <= sst[l + 1] * (1.0 - 1e-9))));
+                        }
+                    }
                 }
             }
-            if (on && handover) { // |row i of G_k|^2 added, staged, and the next block
+            if (on && (handover || spec_on)) { // |row i of G_k|^2 added (staged for the hand-over block), and the next block
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double sq = 0.0;
 #pragma unroll
                     for (int c = 0; c < NU; ++c) sq += Gp[i + NX * c] * Gp[i + NX * c];
                     ncum[i] += sq;
-                    ldn[lane * SX + q * NX + i] = ncum[i];
+                    if (handover) ldn[lane * SX + q * NX + i] = ncum[i];
                 }
                 double Gn[NX * NU];
 #pragma unroll
@@ -681,31 +748,25 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
                 for (int e = 0; e < NX * NU; ++e) Gp[e] = Gn[e];
             }
+            // (the deepest trajectory: levels without a step repeat the one before)
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = spec ? x1[c] : x[c];
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = xs[kSpec][c];
 #pragma unroll
-            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = spec ? u1[c] : u[c];
-            double xn[NX], xn1[NX];
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = us[kSpec][c];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double s = d[i], s1 = d[i];
+            for (int l = 0; l <= kSpec; ++l) {
+                double xn[NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    s += A[i + NX * j] * x[j];
-                    s1 += A[i + NX * j] * x1[j];
+                for (int i = 0; i < NX; ++i) {
+                    double acc = d[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc += A[i + NX * j] * xs[l][j];
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) acc += B[i + NX * c] * us[l][c];
+                    xn[i] = acc;
                 }
 #pragma unroll
-                for (int c = 0; c < NU; ++c) {
-                    s += B[i + NX * c] * u[c];
-                    s1 += B[i + NX * c] * u1[c];
-                }
-                xn[i] = s;
-                xn1[i] = s1;
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                x[i] = on ? xn[i] : x[i];
-                x1[i] = on ? xn1[i] : x1[i];
+                for (int i = 0; i < NX; ++i) xs[l][i] = on ? xn[i] : xs[l][i];
             }
             sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
         }
@@ -736,17 +797,31 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
     }
     { // the last state: its rows, and out
-        double u0[NU];
+        double u0[kSpec + 1][NU];
 #pragma unroll
-        for (int c = 0; c < NU; ++c) u0[c] = 0.0;
-        check_rows(NH, x, u0, x1, u0, ncum);
+        for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) u0[l][c] = 0.0;
+        check_rows(NH, xs, u0, ncum);
         if (valid) {
             double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
 #pragma unroll
-            for (int c = 0; c < NX; ++c) xo[c] = spec ? x1[c] : x[c];
+            for (int c = 0; c < NX; ++c) xo[c] = xs[kSpec][c];
         }
     }
-    const bool done1 = valid && spec && uniq && !viol1; // finished by the one constraint it speculated on
+    // the verdict: the first level that violates nothing, if every pick on the way to it was the pick
+    const bool viol = violl[0];
+    int done_iters = 0; // qpgen2's first counter of an instance that ends here (0: it does not)
+    {
+        bool chain = valid && !bad;
+#pragma unroll
+        for (int l = 0; l <= kSpec; ++l) {
+            if (l >= 1) chain = chain && specl[l] && uniql[l];
+            if (chain && !violl[l] && done_iters == 0) done_iters = l + 1;
+            chain = chain && violl[l]; // (a deeper level only exists behind a violated one)
+        }
+    }
+    const bool done1 = done_iters >= 2; // finished by the bounds on u_0 it speculated on
 
     stamp[3] = P.prof ? cycle_counter() : 0;
     // ---- 3. verdict: done, or one more entry of the first tier's list (one atomic per wave) ----
@@ -761,7 +836,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     }
     if ((valid && !viol) || done1) {
         P.status[inst] = 0;
-        P.iter[2 * (size_t)inst] = done1 ? 2 : 1; // (qpgen2's counters: the scan that found nothing counts)
+        P.iter[2 * (size_t)inst] = done1 ? done_iters : 1; // (qpgen2's counters: the scan that found nothing counts)
         P.iter[2 * (size_t)inst + 1] = 0;
     }
     // Histogram of the violated-row counts over the batch (first solve of a controller: copra_batch_solve reads it BEFORE it launches the

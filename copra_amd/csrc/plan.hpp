@@ -242,7 +242,7 @@ COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu; }
 COPRA_HD inline int lane_ws2_doubles(int nx, int nu, int N) { return N * (nu * (nu + 1) / 2 + nu + nx); }
 // LDS of that pass (doubles): the staging area of the transpositions (64 lanes x the widest array, odd stride), then H | h
 constexpr int kLaneGroup = 4; // stages per group of its roll-out (results leave through LDS once per group)
-constexpr int kLaneAhead = 2; // stages whose gains are in flight (round 5: two -- a stage of the roll-out carries two trajectories now and takes twice as long, and the 42 doubles of the other two buffers were what pushed the roll-out into scratch memory)
+constexpr int kLaneAhead = 1; // stages whose gains are in flight (round 5: two -- a stage of the roll-out carries two trajectories now and takes twice as long, and the 42 doubles of the other two buffers were what pushed the roll-out into scratch memory)
 constexpr int kLaneHistBins = 32; // bins of its violated-row histogram (FusedPlan::lane_hist), the last one open
 COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
 {
@@ -251,7 +251,10 @@ COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
     // the roll-out's group of stages: states | controls | norm sums (the hand-over block), all at once
     if (2 * ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1) > w) w = 2 * ((kLaneGroup * nx) | 1) + ((kLaneGroup * nu) | 1);
     // the sweep: h of the lane | Lam^-1 of a group of stages (the hand-over block)
-    if (((3 * nx + nu + kLaneGroup * (nu * (nu + 1) / 2 + nu)) | 1) > w) w = (3 * nx + nu + kLaneGroup * (nu * (nu + 1) / 2 + nu)) | 1; // (+ x0 and d, parked)
+    { // (+ x0, d and M_uu,0^-1, parked)
+        const int nl = nu * (nu + 1) / 2, hs = (3 * nx + nu + kLaneGroup * (nl + nu) + nl) | 1;
+        if (hs > w) w = hs;
+    }
     oH = 64 * w;
     const int nz = nx + nu;
     return (oH + nz * nz + nz + 1) & ~1;

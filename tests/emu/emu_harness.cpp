@@ -352,8 +352,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
-        P.lane_handover = (P.lds.ricC && !default_options().no_lane_handover) ? 1 : 0; // (as copra_batch_solve: known before the pass runs)
-        P.lane_spec = (P.lane_handover && !default_options().no_lane_spec) ? 1 : 0;
+        P.lane_spec = (P.lds.ricC && !default_options().no_lane_spec) ? 1 : 0; // (as copra_batch_solve: the two forms of the pass)
+        P.lane_handover = (P.lds.ricC && !default_options().no_lane_handover && !P.lane_spec) ? 1 : 0;
         std::fill(g_lane_hist, g_lane_hist + kLaneHistBins, 0);
         P.lane_hist = g_lane_hist; // (what the first solve of a controller asks of the pass: copra_batch_solve picks the tier's layout from it)
         for (int g = 0; g < groups; ++g) {
@@ -369,7 +369,6 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         }
         P.lane_hist = nullptr;
         P.lane_from_list = 1;
-        P.lane_handover = (P.lds.ricC && !default_options().no_lane_handover) ? 1 : 0;
         for (int k = 0; k < lane_count; ++k) {
             const int raw = lane_list[(size_t)k], b = raw & 0x7fffffff;
             lane_failed = raw < 0;

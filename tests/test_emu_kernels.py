@@ -900,7 +900,7 @@ def test_riccati_factor_tier_ladder_steps(emu, oracle, steps, monkeypatch):
     assert re["riccati_factor"] and re["rcap"] > base["rcap"] and re["overflowed"] <= base["overflowed"]
 
 
-@pytest.mark.parametrize("mode", ["handover", "filter_only", "off"])
+@pytest.mark.parametrize("mode", ["spec", "handover", "filter_only", "off"])
 @pytest.mark.parametrize("batch,N,vmax,umax", [(150, 20, 0.6, 3.0), (70, 15, 0.3, 1.5), (64, 10, 0.6, 3.0)])
 def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vmax, umax):
     """lmpc_lane.hpp in front of the Riccati-factor tier: LQ sweep + roll-out with one instance per LANE (64 instances per wave; the last
@@ -911,6 +911,8 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
     from copra_amd import workloads
     if mode == "off":
         monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
+    if mode != "spec":  # (round 5: by default the pass takes the first steps of the iteration itself and hands nothing over)
+        monkeypatch.setitem(OPTIONS, "no_lane_spec", 1)
     if mode == "filter_only":
         monkeypatch.setitem(OPTIONS, "no_lane_handover", 1)
     wl = workloads.com_preview(batch, N=N, v_max=vmax, u_max=umax, seed=9)
@@ -922,8 +924,8 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
     ok = ro["status"] == 0
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
-    one_bound = int(((ro["iter"][:, 0] == 2) & (ro["iter"][:, 1] == 0) & ok).sum())
-    if mode == "handover":  # (round 5: the pass also takes the first step of the iteration where a bound on u_0 is the pick)
+    one_bound = int(((ro["iter"][:, 0] >= 2) & (ro["iter"][:, 0] <= 3) & (ro["iter"][:, 1] == 0) & ok).sum())
+    if mode == "spec":  # (round 5: the pass also takes the first TWO steps of the iteration where bounds on u_0 are the picks)
         assert at_minimiser <= re["lane_pass_finished"] <= at_minimiser + one_bound
     else:
         assert re["lane_pass_finished"] == (-1 if mode == "off" else at_minimiser)
@@ -952,7 +954,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) == (2, 0))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
     assert 0 < finished <= re["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # per-instance cost references (every instance its own goal): the pass rebuilds its affine terms per lane from the plan's coefficient
     # table
@@ -966,7 +968,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re2["iter"][k]) == tuple(ro["iter"]) and _rel(re2["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) == (2, 0))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
     assert 0 < finished <= re2["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # ... and per-instance right-hand sides (every instance its own velocity limit): every lane reads its own row of the table
     vlim = 0.6 * rng.uniform(0.7, 1.2, b)
@@ -980,7 +982,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re3["iter"][k]) == tuple(ro["iter"]) and _rel(re3["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) == (2, 0))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
@@ -1333,9 +1335,11 @@ def test_lane_pass_takes_the_first_step_of_the_iteration(emu, oracle, monkeypatc
     at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
     assert rn["lane_pass_finished"] == at_minimiser
     one_bound = int(((ro["iter"][:, 0] == 2) & (ro["iter"][:, 1] == 0) & ok).sum())
-    assert at_minimiser <= rs["lane_pass_finished"] <= at_minimiser + one_bound
-    if vmax >= 0.6:  # (loose velocity rows: every first pick is a bound on u_0 -- every one-constraint instance ends in the pass)
-        assert rs["lane_pass_finished"] == at_minimiser + one_bound and one_bound > 0
+    two_bounds = int(((ro["iter"][:, 0] == 3) & (ro["iter"][:, 1] == 0) & ok).sum())
+    assert at_minimiser <= rs["lane_pass_finished"] <= at_minimiser + one_bound + two_bounds
+    if vmax >= 0.6:  # (loose velocity rows: every first pick is a bound on u_0 -- every one-constraint instance ends in the pass, and
+        #  the two-constraint ones whose second pick is another bound on u_0)
+        assert rs["lane_pass_finished"] >= at_minimiser + one_bound and one_bound > 0
 
 
 @pytest.mark.parametrize("first", [0, 12, 24, 36, 48, 60, 72, 84])

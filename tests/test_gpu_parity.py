@@ -1484,9 +1484,11 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
         wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
         out = {}
         for mode in ("off", "filter_only", "on", "on_nospec"):
+            # on: the pass as it runs by default since round 5 (takes the first steps of the iteration itself, hands nothing over);
+            # on_nospec: the hand-over form of rounds 3-4; filter_only: neither (the pass ends the instances at their minimiser, the tier sweeps)
             monkeypatch.setitem(OPTIONS, "no_lane_pass", 0)
             monkeypatch.setitem(OPTIONS, "no_lane_handover", 0)
-            monkeypatch.setitem(OPTIONS, "no_lane_spec", 1 if mode == "on_nospec" else 0)
+            monkeypatch.setitem(OPTIONS, "no_lane_spec", 0 if mode == "on" else 1)
             if mode == "off":
                 monkeypatch.setitem(OPTIONS, "no_lane_pass", 1)
             if mode == "filter_only":
@@ -1507,13 +1509,15 @@ def test_one_instance_per_lane_pass_full_batch(oracle, monkeypatch, vmax, umax):
             assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-10 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-10
             at_minimiser = int(((r0["iter"][:, 0] == 1) & ok).sum())
             one_bound = int(((r0["iter"][:, 0] == 2) & (r0["iter"][:, 1] == 0) & ok).sum())
+            two_bounds = int(((r0["iter"][:, 0] == 3) & (r0["iter"][:, 1] == 0) & ok).sum())
             if mode == "on":  # (with the hand-over of the factor the pass always runs -- and, since round 5, takes the first step of the
                 #  iteration itself where a bound on u_0 is the pick: at the headline's constraint level that is EVERY first pick, so every
                 #  instance the tier alone reports with the counters (2, 0) ends in the pass)
-                assert ran and at_minimiser <= finished <= at_minimiser + one_bound
+                assert ran and at_minimiser <= finished <= at_minimiser + one_bound + two_bounds
                 if vmax >= 0.6:
-                    # (all but the handful it leaves to the tier because another row comes within 1e-9 of the pick: 2 of 24 997 measured)
-                    assert finished >= at_minimiser + one_bound - 16 and one_bound > b // 4
+                    # (all but the handful it leaves to the tier because another row comes within 1e-9 of the pick: 2 of 24 997 measured;
+                    #  and most of the two-constraint instances: a second bound on u_0)
+                    assert finished >= at_minimiser + one_bound - 16 + two_bounds // 2 and one_bound > b // 4
             elif mode == "on_nospec":
                 assert ran and finished == at_minimiser
             else:  # (filter only: switched off after the first solves when fewer than one instance in eight ends in it)
@@ -1689,7 +1693,7 @@ def test_one_instance_per_lane_pass_short_lists(oracle, violators):
     eng.solve()
     res = eng.results()
     ran, finished = eng.lane_pass_info()
-    one_bound = int(((res["iter"][pick, 0] == 2) & (res["iter"][pick, 1] == 0)).sum())  # (the pass may take their one step itself: round 5)
+    one_bound = int(((res["iter"][pick, 0] <= 3) & (res["iter"][pick, 1] == 0)).sum())  # (the pass may take their first steps itself: round 5)
     assert ran and b - violators <= finished <= b - violators + one_bound and (res["status"] == 0).all()
     assert (res["iter"][pick, 0] > 1).all() and (np.delete(res["iter"][:, 0], pick) == 1).all()
     sample = np.unique(np.concatenate([pick, np.arange(0, b, 997)]))
