@@ -39,6 +39,16 @@ def _rel_vec(a, b, floor=ABS_FLOOR):
     return np.nanmax(np.abs(a - b)) / max(np.nanmax(np.abs(b)), floor)
 
 
+def _pass_count_ok(info, iters, ok):
+    """lane_pass_info() of a solve that ran the one-instance-per-lane pass against the iteration counters: the pass finishes every instance
+    whose unconstrained minimiser violates nothing (counters (1, 0)) and, since round 5, the instances whose first one or two picks are
+    bounds on u_0 and whose iteration ends there ((2, 0) and (3, 0): it takes those steps itself)"""
+    ran, finished = info
+    at_min = int(((iters[:, 0] == 1) & ok).sum())
+    steps = int(((iters[:, 0] >= 2) & (iters[:, 0] <= 3) & (iters[:, 1] == 0) & ok).sum())
+    return bool(ran) and at_min <= finished <= at_min + steps
+
+
 def _solve_gpu(wl, batch):
     from copra_amd import BatchLMPC
     nx, nu = wl["B"].shape[1], wl["B"].shape[2]
@@ -1557,7 +1567,7 @@ def test_one_instance_per_lane_pass_shared_model_tick(oracle, monkeypatch):
     assert not out["off"][1][0] and out["on"][1][0]
     assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
     assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-11
-    assert out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > b // 8
+    assert out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > b // 8  # (the shared-model form of the pass does not speculate)
     pick = np.arange(0, b, 257)
     ref = oracle.lmpc_solve_batch(np.tile(A, (len(pick), 1, 1)), np.tile(B, (len(pick), 1, 1)), np.tile(d, (len(pick), 1)), wl["x0"][pick],
                                   wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
@@ -1580,7 +1590,7 @@ def test_one_instance_per_lane_pass_small_ragged_batch(oracle, monkeypatch, N):
     monkeypatch.setitem(OPTIONS, "lane_min_batch", 1)
     eng, res = _solve_gpu(wl, b)
     ok = ref["status"] == 0
-    assert eng.lane_pass_info() == (True, int(((ref["iter"][:, 0] == 1) & ok).sum()))
+    assert _pass_count_ok(eng.lane_pass_info(), ref["iter"], ok)
     assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     eng.close()
@@ -1607,7 +1617,7 @@ def test_one_instance_per_lane_pass_per_instance_references(oracle, monkeypatch)
         eng.close()
     r0, r1 = out["off"][0], out["on"][0]
     ok = r0["status"] == 0
-    assert out["on"][1][0] and out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > 0
+    assert _pass_count_ok(out["on"][1], r0["iter"], ok) and out["on"][1][1] > 0
     assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
     assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-11
     for k in range(0, b, 1021):
@@ -1641,7 +1651,7 @@ def test_one_instance_per_lane_pass_per_instance_rhs(oracle, monkeypatch):
         eng.close()
     r0, r1 = out["off"][0], out["on"][0]
     ok = r0["status"] == 0
-    assert out["on"][1][0] and out["on"][1][1] == int(((r0["iter"][:, 0] == 1) & ok).sum()) > 0
+    assert _pass_count_ok(out["on"][1], r0["iter"], ok) and out["on"][1][1] > 0
     assert (r0["status"] == r1["status"]).all() and (r0["iter"] == r1["iter"]).all()
     assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-11
     for k in range(0, b, 1021):
@@ -1668,7 +1678,7 @@ def test_one_instance_per_lane_pass_filters_for_the_other_tiers(oracle, monkeypa
     eng.solve()
     res = eng.results()
     assert not eng.layout_info().get("riccati_factor", False)
-    assert eng.lane_pass_info() == (True, int(((ref["iter"][:, 0] == 1) & ok).sum()))
+    assert _pass_count_ok(eng.lane_pass_info(), ref["iter"], ok)
     assert (res["status"] == ref["status"]).all() and (res["iter"][ok] == ref["iter"][ok]).all()
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
     eng.close()
