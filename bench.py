@@ -46,7 +46,7 @@ def parity_rel(a, b, floor=1e-3):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector = matrix FP64
-PMC_SUMMARY = os.path.join("profiles", "r04", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
+PMC_SUMMARY = os.path.join("profiles", "r05", "headline_rocprof_summary.json")  # rocprofv3 passes of this command
 
 
 SPIN_UP_SOLVES = 40  # untimed solves before the warm-up steps (clock ramp; see main)
@@ -226,6 +226,26 @@ def extra_measurements(np, torch, dev):
     b5 = 16384
     wl = workloads.long_horizon_initial_state(b5)
     ist = wl["initial_state"]
+    # ... with the six instances of the certified truth set (tests/golden/config5_truth.npz: optima of the QP the reference defines,
+    # certified at 60 digits -- tests/truth.py) at the head of the batch, as tests/test_gpu_parity.py::test_config5_full_batch_default_solver
+    # embeds them: the line carries, for BOTH solvers, the distance of the device from the CPU path (oracle), of the device from the certified
+    # optimum, and of the CPU path from the certified optimum -- all in the parity suite's measure (entry-wise relative, floor 1e-3).
+    # The north star's "within 1e-6 of the CPU QuadProgDense path" cannot be read literally at this configuration's R = 1e-6 I (cond 2e12):
+    # the CPU path itself is 1e-3 .. 1e-5 from the optimum, so the bar that is asserted is 1e-6 from the CERTIFIED optimum.
+    truth = np.load(os.path.join(ROOT, "tests", "golden", "config5_truth.npz"))
+    twl = workloads.long_horizon_initial_state(int(truth["batch"]), R_diag=float(truth["r_diag"]))
+    picks = [int(k) for k in truth["instances"]]
+    nt = twl["x0"].shape[0]
+    wl["x0"][:nt] = twl["x0"]
+    ist["x0lb"][:nt], ist["x0ub"][:nt] = twl["initial_state"]["x0lb"], twl["initial_state"]["x0ub"]
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle  # (the checker, outside every timed region: never the thing measured)
+    oref = {}
+    for k in picks:
+        io = dict(R=ist["R"], r=ist["r"], x0lb=ist["x0lb"][k], x0ub=ist["x0ub"][k])
+        oref[k] = pyoracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"], initial_state=io)
+    oracle_vs_truth = max(max(parity_rel(oref[k]["control"], truth["control_%d" % k]), parity_rel(oref[k]["trajectory"], truth["trajectory_%d" % k]))
+                          for k in picks)
     for solver, bb in (("default", b5), ("quadprog_dense", 2048)):
         eng = BatchLMPC(12, 6, wl["N"], bb, wl["costs"], wl["cstrs"], initial_state=dict(R=ist["R"], r=ist["r"]))
         eng.select_solver(solver)
@@ -233,9 +253,18 @@ def extra_measurements(np, torch, dev):
         eng.set_initial_state_bounds(ist["x0lb"][:bb], ist["x0ub"][:bb])
         rate, sec = timed_rate(eng, bb, reps=2)
         res = eng.results()
+        dev_vs_truth = max(max(parity_rel(res["control"][k], truth["control_%d" % k]), parity_rel(res["trajectory"][k], truth["trajectory_%d" % k]))
+                           for k in picks)
+        dev_vs_oracle = max(max(parity_rel(res["control"][k], oref[k]["control"]), parity_rel(res["trajectory"][k], oref[k]["trajectory"]))
+                            for k in picks)
         out["config5_initial_state_12_6_50_%s" % eng.solver()] = {
             "batch": bb, "solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 2,
             "solved_ok": int((res["status"] == 0).sum()), "mean_iterations": float(res["iter"][:, 0].mean()),
+            "iterations_are": "Newton steps" if eng.solver() == "riccati_ipm" else "active-set iterations (qpgen2's first counter)",
+            "max_rel_err_vs_oracle": dev_vs_oracle, "max_rel_err_vs_certified_truth": dev_vs_truth, "oracle_err_vs_truth": oracle_vs_truth,
+            "error_measure": "entry-wise relative with an absolute floor of 1e-3 over U and X of the six certified instances embedded at the "
+                             "head of the batch (tests/golden/config5_truth.npz); statuses of the six: %s" % [int(res["status"][k]) for k in picks],
+            "within_1e-6_of_certified_truth": bool(dev_vs_truth <= 1e-6),
             "algorithmic_GBps": 9216.0 * rate / 1e9}  # 1920 B in + 7296 B out per solve
         eng.close()
     # headline shape, shared model (receding-horizon tick: one (A, B, d) for the batch, only x0 differs)
@@ -618,10 +647,10 @@ def main():
         # (FETCH_SIZE + WRITE_SIZE in KB; 8-byte-per-lane accesses calibrate at x1.0 on gfx950) -- not
         # re-measured live
         traffic, traffic_src, issue = None, None, {}
-        dominant = "copra_lmpc_fused_ric_kernel"  # (plan_builder.hpp: what the headline controller runs on)
+        dominant = "copra_lmpc_lane_kernel + copra_lmpc_fused_ric_kernel"  # (plan_builder.hpp: the pair the headline controller runs on)
         prof = os.path.join(ROOT, PMC_SUMMARY)
         if not os.path.exists(prof):
-            prof = os.path.join(ROOT, "profiles", "r03", "headline_rocprof_summary.json")
+            prof = os.path.join(ROOT, "profiles", "r04", "headline_rocprof_summary.json")
         traffic_stale = None
         if batch == 65536 and not args.dense_hessian and os.path.exists(prof):
             try:
@@ -678,16 +707,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_name,
                        "hessian": "dense MFMA f64 contraction (full-size cost entry)" if args.dense_hessian
-                       else "block-diagonal prefix sums (per-step cost entry)",
+                       else "none (Riccati stage form: the condensed Hessian is never built; per-step cost entries)",
                        "batch_per_gpu": batch, "global_batch": global_batch, "nvar": n, "ineq_rows": 63,
                        "bound_rows": 2 * n,
                        "parallelism": ("contiguous batch shards x%d + 1 RCCL gather/step (%s)"
                                        % (world, "overlapped with the next solve" if overlap else "synchronous"))
                        if world > 1 else "single GPU"},
             "solved_ok": n_ok,
-            "lane_pass": {"ran": lane_ran, "finished_at_unconstrained_minimiser": lane_done,
-                          "what": "LQ sweep + roll-out with one instance per lane in front of the first tier: instances whose unconstrained "
-                                  "minimiser violates nothing end there, the others hand K, kv, Lam^-1, U, X to the active-set kernel"},
+            "lane_pass": {"ran": lane_ran, "finished": lane_done,
+                          "finished_at_unconstrained_minimiser": int(((iters[:, 0] == 1) & (status == 0)).sum()),
+                          "what": "LQ sweep + roll-out with one instance per lane in front of the first tier: an instance ends there when its "
+                                  "unconstrained minimiser violates nothing (iterations (1, 0)) or -- round 5 -- when the first one or two picks "
+                                  "of the active-set iteration are bounds on u_0 and the iteration ends with them ((2, 0), (3, 0): the pass takes "
+                                  "those steps itself, in closed form); the others go to the active-set kernel, from scratch"},
             "mean_active_set_iters": float(iters[:, 0].mean()),
             "max_active_set_iters": int(iters[:, 0].max()),
             "active_set_iteration_histogram": {("%d" % k if k < 15 else "15+"): int(v) for k, v in enumerate(hist) if v},
@@ -699,9 +731,15 @@ def main():
                          "library_source_hash": __import__("copra_amd")._capi.library_source_hash(),
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "kernel": dominant, "algorithmic_bytes_per_solve": alg_bytes,
-                         "note": "path is FP64-latency/LDS bound at n=60 (SURVEY 8d): HBM fraction is small by "
-                                 "construction; what it does with the machine is in `issue`",
+                         "note": "algorithmic bytes over the time of the pair; the pass (80 % of it since round 5) is bound by the HBM traffic "
+                                 "of its own stage-record workspace (`traffic` vs algorithmic_bytes_per_launch), the rest by FP64 issue: `roofline_fp64`",
                          "issue": issue, "fp64_peak_tflops": FP64_PEAK_TFLOPS},
+            # the same pair of launches against the FP64 peak (vector and matrix FP64 share one pipe on gfx950: 78.6 TFLOP/s either way):
+            # EXECUTED multiply-adds of the PMC pass over the kernel time of this run -- what DESIGN.md calls the path's real bound
+            "roofline_fp64": {"bound": "fp64 issue (VALU + MFMA share the pipe)", "achieved": issue.get("executed_fp64_tflops"),
+                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": (issue["executed_fp64_tflops"] / FP64_PEAK_TFLOPS) if issue.get("executed_fp64_tflops") else None,
+                              "source": traffic_src, "stale": traffic_stale},
         }
         if multi is not None:
             line["multi_gpu_check"] = multi

@@ -427,7 +427,7 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
     }
     if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
         e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
-    const bool hand_over = P.lds.ricC && !h->hp.opt.no_lane_handover && h->hp.opt.no_lane_spec; // (copra_batch_solve: the form of the pass that hands blocks over)
+    const bool hand_over = P.lds.ricC && !h->hp.opt.no_lane_handover && (h->hp.opt.no_lane_spec || h->ad.lane_form_handover); // (solve_one_wave: the form of the pass that hands blocks over)
     if (e == hipSuccess && need_ws && hand_over && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
         e = hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double));
     if (e != hipSuccess) {
@@ -455,12 +455,28 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     if (h->ad.lane_solves % kLaneResample == 0 && h->ad.lane_adapt_left <= 0) {
         h->ad.lane_adapt_left = 1;
         if (h->ad.lane_off && h->ad.lane_off_by_share) h->ad.lane_off = h->ad.lane_off_by_share = false;
+        h->ad.lane_form_handover = false; // (the speculating form is tried again)
     }
     if (!h->ad.lane_ran || h->ad.lane_adapt_left <= 0) return COPRA_OK;
-    // (when the first tier takes the stage records over from the pass -- compact variant of the tier -- the pass pays for every instance:
-    //  it is the tier's sweep, done at several times the efficiency; nothing to decide)
-    //  -- except in shared-model mode, where there is no sweep to take over: there the pass must finish one instance in four to pay, measured)
-    if (!h->shared && h->hp.plan.lds.ricC && !h->hp.opt.no_lane_handover) return COPRA_OK;
+    // In front of the compact variant of the Riccati-factor tier the pass has two forms (solve_one_wave).  The one that hands the factor
+    // over pays for every instance -- it is the tier's sweep, done at several times the efficiency: nothing to decide.  The speculating form
+    // (the default) hands nothing over: it pays where most instances END in it; where fewer than one in four do -- constraint-heavy
+    // workloads: the first picks are state rows, or the iteration goes on after two bounds on u_0 -- the controller moves to the hand-over
+    // form (measured at v_max 0.25 / u_max 1.2, where nothing ends in the pass: 23.7 M solves/s with the hand-over, 20.2 M with the tier
+    // sweeping for itself).
+    if (!h->shared && h->hp.plan.lds.ricC && !h->hp.opt.no_lane_handover) {
+        if (h->hp.opt.no_lane_spec || h->ad.lane_form_handover) return COPRA_OK;
+        h->ad.lane_adapt_left -= 1;
+        int left_over = 0;
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+        HIP_TRY(hipMemcpy(&left_over, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+        const long long ended = (long long)h->hp.plan.batch - left_over;
+        if (ended * 4 < (long long)h->hp.plan.batch) h->ad.lane_form_handover = true;
+        if (h->hp.opt.debug)
+            fprintf(stderr, "[copra] one-instance-per-lane pass (speculating form): %lld of %d instances ended in it%s\n", ended, h->hp.plan.batch,
+                h->ad.lane_form_handover ? " -- the hand-over form from now on" : "");
+        return COPRA_OK;
+    }
     // (... and a shared-model controller with per-instance references: the pass carries their delta sweep, without it the controller runs
     //  lmpc_shared.hpp, which the tier beats by 2 x whatever the share that ends in the pass)
     if (h->shared && h->shared_ric)
@@ -1406,7 +1422,7 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         //     headline's constraint level 96 % of the batch ends in it -- and hands NOTHING over: the few instances it leaves sweep for themselves
         //     (the hand-over blocks of 65 536 instances were 157 MB of writes for the 2 437 that read them);
         //   hand-over (copra_options_t::no_lane_spec): Lam^-1 | kv | norm sums of every instance for a tier that takes the factor over.
-        P.lane_spec = (P.lds.ricC && !h->hp.opt.no_lane_spec) ? 1 : 0;
+        P.lane_spec = (P.lds.ricC && !h->hp.opt.no_lane_spec && !h->ad.lane_form_handover) ? 1 : 0; // (adapt_lane_pass chooses between them by workload)
         P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover && !P.lane_spec) ? 1 : 0;
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)

@@ -73,6 +73,7 @@ struct AdaptState {
     bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass), or no memory for its workspace
     bool lane_off_by_share = false; // ... the former: sampled again every 256 solves
     int lane_adapt_left = 2;
+    bool lane_form_handover = false; // the pass runs in its hand-over form (too few instances end in the speculating one: adapt_lane_pass)
     long long lane_solves = 0; // solves seen by adapt_lane_pass
     // shared-model tick on the records tier
     long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
