@@ -20,6 +20,12 @@
 #pragma once
 #include "lmpc_fused.hpp"
 
+// (experiments only, never defined in the product build: what a phase costs -- tools/exp/lane_variants.sh builds one library per value.
+//  1: no result stores; 2: the gains are not read back; 4: no norm recursion; 8: no row checks; 16: no bound checks)
+#ifndef COPRA_LANE_EXP
+#define COPRA_LANE_EXP 0
+#endif
+
 namespace copra_hip {
 
 // W doubles per instance, [batch][W] in HBM: the 64 instances of this wave are one contiguous block -- coalesced loads (ALL arrays
@@ -473,7 +479,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
-        for (int e = 0; e < KW; ++e) buf[e] = lane_get(wk + (size_t)e * bp, ioff);
+        for (int e = 0; e < KW; ++e) buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get(wk + (size_t)e * bp, ioff);
     };
     // the right-hand side of a row: the controller's, or this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the
     // stacked order; a row of the table that is not there keeps +inf)
@@ -520,6 +526,9 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         sst[l] = sst2[l] = 0.0;
     }
     violl[0] = bad;
+    double bmin[kSpec + 1], bmin_other[kSpec + 1]; // worst bound slack per level: of all bounds | of those that are not the next level's pick
+#pragma unroll
+    for (int l = 0; l <= kSpec; ++l) bmin[l] = bmin_other[l] = 0.0;
     double xs[kSpec + 1][NX]; // xs[0]: the unconstrained minimiser's trajectory (x above)
 #pragma unroll
     for (int l = 0; l <= kSpec; ++l)
@@ -706,27 +715,29 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 }
             }
             if (on) {
-                check_rows(k, xs, us, ncum);
+                if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, ncum);
+                if (!(COPRA_LANE_EXP & 16)) {
+                    // the bounds of u_k at every iterate: the worst slack per level is all that is kept -- a level violates a bound iff its
+                    // minimum is <= -vsmall, and the next level's pick was not the pick iff the minimum (the active bounds and the pick itself
+                    // left out: they only exist at stage 0) comes within 1e-9 of its slack.  Two subtractions and two minima per bound and level.
+                    const bool stage0 = q == 0 && k0 == 0;
 #pragma unroll
-                for (int c = 0; c < NU; ++c) {
+                    for (int c = 0; c < NU; ++c) {
 #pragma unroll
-                    for (int l = 0; l <= kSpec; ++l) {
-                        const double su = ubk[c] - us[l][c], sl = us[l][c] - lbk[c];
-                        // the bounds level <= l holds active (their twins cannot be violated), and the pick of level l + 1 itself
-                        const bool stage0 = q == 0 && k0 == 0;
-                        const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
-                        const bool v = !active && ((su <= -vsmall) || (sl <= -vsmall));
-                        violl[l] = violl[l] || v;
-                        if (l == 0) nviol += v ? 1 : 0;
-                        if (l < kSpec) {
-                            const bool pick = stage0 && c == scl[l + 1];
-                            uniql[l + 1] = uniql[l + 1]
-                                && (active || pick || !((su <= -vsmall && su <= sst[l + 1] * (1.0 - 1e-9)) || (sl <= -vsmall && sl <= sst[l + 1] * (1.0 - 1e-9))));
+                        for (int l = 0; l <= kSpec; ++l) {
+                            const double m = fmin(ubk[c] - us[l][c], us[l][c] - lbk[c]);
+                            if (l == 0) nviol += (m <= -vsmall) ? 1 : 0;
+                            // (the bounds level <= l holds active -- their twins cannot be violated -- count for nothing; the pick of level l + 1
+                            //  counts as a violation of level l, not against itself)
+                            const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
+                            const bool pick = stage0 && l < kSpec && c == scl[l < kSpec ? l + 1 : kSpec];
+                            bmin[l] = fmin(bmin[l], active ? 0.0 : m);
+                            if (l < kSpec) bmin_other[l] = fmin(bmin_other[l], (active || pick) ? 0.0 : m);
                         }
                     }
                 }
             }
-            if (on && (handover || spec_on)) { // |row i of G_k|^2 added (staged for the hand-over block), and the next block
+            if (on && (handover || spec_on) && !(COPRA_LANE_EXP & 4)) { // |row i of G_k|^2 added (staged for the hand-over block), and the next block
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double sq = 0.0;
@@ -735,18 +746,19 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                     ncum[i] += sq;
                     if (handover) ldn[lane * SX + q * NX + i] = ncum[i];
                 }
-                double Gn[NX * NU];
 #pragma unroll
-                for (int c = 0; c < NU; ++c)
+                for (int c = 0; c < NU; ++c) { // (column by column, in place: NX temporaries instead of a second block)
+                    double gn[NX];
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         double acc = 0.0;
 #pragma unroll
                         for (int l = 0; l < NX; ++l) acc += A[i + NX * l] * Gp[l + NX * c];
-                        Gn[i + NX * c] = acc;
+                        gn[i] = acc;
                     }
 #pragma unroll
-                for (int e = 0; e < NX * NU; ++e) Gp[e] = Gn[e];
+                    for (int i = 0; i < NX; ++i) Gp[i + NX * c] = gn[i];
+                }
             }
             // (the deepest trajectory: levels without a step repeat the one before)
 #pragma unroll
@@ -771,7 +783,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
         }
         wave_sync();
-        { // consecutive lanes write consecutive doubles of an instance's segment
+        if (!(COPRA_LANE_EXP & 1)) { // consecutive lanes write consecutive doubles of an instance's segment
             const int nst = NH - k0 < GS ? NH - k0 : GS; // stages of this group
             double* const xg = P.trajectory + (size_t)(group * GRP) * P.X + (size_t)k0 * NX;
             double* const ug = P.control + (size_t)(group * GRP) * P.n + (size_t)k0 * NU;
@@ -810,6 +822,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
     }
     // the verdict: the first level that violates nothing, if every pick on the way to it was the pick
+#pragma unroll
+    for (int l = 0; l <= kSpec; ++l) {
+        violl[l] = violl[l] || (bmin[l] <= -vsmall);
+        if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !(bmin_other[l] <= -vsmall && bmin_other[l] <= sst[l + 1] * (1.0 - 1e-9));
+    }
     const bool viol = violl[0];
     int done_iters = 0; // qpgen2's first counter of an instance that ends here (0: it does not)
     {
