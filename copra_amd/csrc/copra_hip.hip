@@ -1299,6 +1299,7 @@ static copra_status_t solve_shared_model(copra_batch* h, hipStream_t s)
             Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
             Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
             Pr.lane_ws = refs_now ? h->d_lane_ws : nullptr; // (the delta feed-forward terms of instances with their own references)
+            Pr.lane_spec = h->hp.opt.no_lane_spec ? 0 : 1; // (the first steps of the iteration in the pass, lmpc_lane_shared_body: the tier then rolls out again)
             hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
             HIP_TRY(hipGetLastError());
             Pr.lane_from_list = 1;

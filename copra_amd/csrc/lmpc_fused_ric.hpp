@@ -89,7 +89,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // the unconstrained minimiser and its trajectory came from the SHARED-MODEL pass in front: no roll-out below.  (Behind the per-instance pass
     // the tier rolls out for itself since round 5 -- 2 k cycles --: where that pass has taken the first step of the iteration speculatively,
     // what it left in `control` / `trajectory` is that iterate, not the minimiser: lmpc_lane.hpp.)
-    const bool have_ux = from_model && compact && P.lane_from_list && P.lane_handover;
+    const bool have_ux = from_model && compact && P.lane_from_list && P.lane_handover && !P.lane_spec; // (a speculating pass leaves its deepest iterate, not the minimiser)
     if (from_lane) {
         // K from the pass's lane-major workspace (rows k (NU NX + NU) + e, e < NU NX: one 64-byte sector per value -- what is left of a gather
         // that round 4 measured at 16.5 k of the 44 k cycles of a tier instance, bound by the CU's sector requests), Lam^-1, kv and the norm
@@ -153,8 +153,14 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
         if (lane < NX) X0[lane] = P.x0[(size_t)inst * NX + lane];
         rows.cache_own_row();
         for (int e = lane; e < nh * RR::SZ + RR::CST; e += kWave) F[e] = P.ric_model[e];
-        if (!(compact && P.lane_from_list && P.lane_handover)) // (behind the shared-model lane pass there is no roll-out here)
-            for (int e = lane; e < NV; e += kWave) KV[e] = P.ric_model[mBk + e];
+        if (!have_ux) { // (behind the shared-model lane pass in its plain form there is no roll-out here)
+            // (an instance with references of its own: the pass has left the DELTA of its feed-forward terms, lane-major -- lmpc_lane_shared_body)
+            bool own_refs = false;
+            for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
+            own_refs = own_refs && P.lane_from_list && P.lane_ws != nullptr;
+            for (int e = lane; e < NV; e += kWave)
+                KV[e] = P.ric_model[mBk + e] + (own_refs ? P.lane_ws[(size_t)e * (size_t)P.lane_bp + inst] : 0.0);
+        }
         if (!compact) // (compact variant: the blocks G are not kept at all -- the row norms come from the model too)
             for (int e = lane; e < nh * NX * NU; e += kWave) G[e] = P.ric_model[mG + e];
         if (have_ux) { // (behind the shared-model lane pass, lmpc_lane_shared_body: U and its trajectory are there already)

@@ -97,6 +97,96 @@ COPRA_DEV double lane_get(const double* row, unsigned byte_off)
 // (streaming: a store that does not claim cache space -- what is written once and read, if at all, by a later kernel; measured: 226 -> 220 us
 //  for the pass when Lam^-1 and the norm sums leave this way, no difference for U and X)
 
+// The first steps of the active-set iteration where the picks are bounds on u_0 (see lmpc_lane_body): from the iterate us[0] of stage 0 the
+// iterates us[1 .. KS] after one, two ... steps, with everything the verdict needs about each level.  W = M_uu,0^-1; a level without a step
+// repeats the iterate before it.
+template <int NU, int KS>
+COPRA_DEV void lane_spec_steps(const double (&W)[NU][NU], const double (&ubk)[NU], const double (&lbk)[NU], double (&us)[KS + 1][NU], double vsmall,
+    bool bad, bool (&specl)[KS + 1], int (&scl)[KS + 1], double (&sst)[KS + 1], double (&sst2)[KS + 1])
+{
+    constexpr int kSpec = KS;
+    double lam1 = 0.0, sig1 = 0.0; // multiplier and orientation of the first active bound
+#pragma unroll
+    for (int l = 1; l <= kSpec; ++l) {
+        // the most violated bound of u_0 at iterate l - 1 that is not active: qpgen2's order -- upper bounds (rows mgen + j) before
+        // lower ones (mgen + n + j), the first of equals wins -- so a tie is not decided here: strictly worse than every other
+        // one, or no speculation.  (The twin of an active bound cannot be violated: gi_core.hpp, `pinned`.)
+        double best = 0.0, second = 0.0, sig = 0.0;
+        int cb = -1;
+#pragma unroll
+        for (int i = 0; i < 2 * NU; ++i) {
+            const int c = i < NU ? i : i - NU;
+            const double sl = i < NU ? ubk[c] - us[l - 1][c] : us[l - 1][c] - lbk[c];
+            const bool cand = sl <= -vsmall && c != scl[l - 1] && (l < 2 || c != scl[l - 2]);
+            const bool better = cand && sl < best;
+            second = better ? best : ((cand && sl < second) ? sl : second);
+            best = better ? sl : best;
+            cb = better ? c : cb;
+            sig = better ? (i < NU ? -1.0 : 1.0) : sig;
+        }
+        double ubc = 0.0, lbc = 0.0, wcc = 0.0, w1c = 0.0, w11 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            ubc = (c == cb) ? ubk[c] : ubc;
+            lbc = (c == cb) ? lbk[c] : lbc;
+            wcc = (c == cb) ? W[c][c] : wcc;
+#pragma unroll
+            for (int c1 = 0; c1 < NU; ++c1) {
+                w1c = (c == cb && c1 == scl[1]) ? W[c1][c] : w1c;
+                w11 = (c1 == scl[1]) ? W[c1][c1] : w11;
+            }
+        }
+        bool go = (l == 1 || specl[l - 1]) && cb >= 0 && best < second && !bad && !(ubc - lbc <= -vsmall); // (an empty box: the tier reports it)
+        // the step: z = H n, n = sig e_cb; with one active bound (level 2) H = W - W n1 n1' W / (n1' W n1)
+        double z[NU], zn, r1 = 0.0;
+        if (l == 1) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                double wj = 0.0;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) wj = (c == cb) ? W[j][c] : wj;
+                z[j] = sig * wj;
+            }
+            zn = wcc; // z'n = |Lam^-1 e_c|^2
+        } else {
+            r1 = sig1 * sig * w1c / w11; // r = (n1' W n1)^-1 n1' W n
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                double wj = 0.0, w1j = 0.0;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+                    wj = (c == cb) ? W[j][c] : wj;
+                    w1j = (c == scl[1]) ? W[j][c] : w1j;
+                }
+                z[j] = sig * (wj - w1j * (w1c / w11));
+            }
+            zn = wcc - w1c * (w1c / w11);
+        }
+        double zz = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) zz += z[j] * z[j];
+        go = go && zn > 0.0 && zz > vsmall; // (gi_core.hpp: no step in primal space -- the tier's business)
+        const double t2 = go ? -best / zn : 0.0;
+        // the dual step length: an active bound whose multiplier would reach zero first is DROPPED by the iteration -- the tier's business
+        if (l == 2) go = go && !(r1 > 0.0 && lam1 / r1 <= t2 * (1.0 + 1e-9));
+        const double tt = go ? t2 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) us[l][j] = go ? us[l - 1][j] + t2 * z[j] : us[l - 1][j]; // (no step: z may be 0 / 0)
+        if (l == 1) {
+            lam1 = tt;
+            sig1 = sig;
+        }
+        specl[l] = go;
+        scl[l] = go ? cb : -1;
+        sst[l] = go ? best : 0.0;
+        sst2[l] = sst[l] * sst[l];
+        if (l < kSpec) { // (the next level starts from this iterate; without a step it repeats it)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) us[l + 1][j] = us[l][j];
+        }
+    }
+}
+
 // SREFS: the build for controllers with reference trajectories (FusedPlan::stage_refs) -- its own instantiation, so that the registers of
 // stage_h below are not the headline's (measured on the one build for both: 3 VGPRs of the sweep in scratch memory)
 template <int NX, int NU, bool SREFS = false>
@@ -633,86 +723,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NU; ++i)
 #pragma unroll
                     for (int j = 0; j <= i; ++j) W[i][j] = W[j][i] = ldn[lane * SX + i * (i + 1) / 2 + j];
-                double lam1 = 0.0, sig1 = 0.0; // multiplier and orientation of the first active bound
-#pragma unroll
-                for (int l = 1; l <= kSpec; ++l) {
-                    // the most violated bound of u_0 at iterate l - 1 that is not active: qpgen2's order -- upper bounds (rows mgen + j) before
-                    // lower ones (mgen + n + j), the first of equals wins -- so a tie is not decided here: strictly worse than every other
-                    // one, or no speculation.  (The twin of an active bound cannot be violated: gi_core.hpp, `pinned`.)
-                    double best = 0.0, second = 0.0, sig = 0.0;
-                    int cb = -1;
-#pragma unroll
-                    for (int i = 0; i < 2 * NU; ++i) {
-                        const int c = i < NU ? i : i - NU;
-                        const double sl = i < NU ? ubk[c] - us[l - 1][c] : us[l - 1][c] - lbk[c];
-                        const bool cand = sl <= -vsmall && c != scl[l - 1] && (l < 2 || c != scl[l - 2]);
-                        const bool better = cand && sl < best;
-                        second = better ? best : ((cand && sl < second) ? sl : second);
-                        best = better ? sl : best;
-                        cb = better ? c : cb;
-                        sig = better ? (i < NU ? -1.0 : 1.0) : sig;
-                    }
-                    double ubc = 0.0, lbc = 0.0, wcc = 0.0, w1c = 0.0, w11 = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NU; ++c) {
-                        ubc = (c == cb) ? ubk[c] : ubc;
-                        lbc = (c == cb) ? lbk[c] : lbc;
-                        wcc = (c == cb) ? W[c][c] : wcc;
-#pragma unroll
-                        for (int c1 = 0; c1 < NU; ++c1) {
-                            w1c = (c == cb && c1 == scl[1]) ? W[c1][c] : w1c;
-                            w11 = (c1 == scl[1]) ? W[c1][c1] : w11;
-                        }
-                    }
-                    bool go = (l == 1 || specl[l - 1]) && cb >= 0 && best < second && !bad && !(ubc - lbc <= -vsmall); // (an empty box: the tier reports it)
-                    // the step: z = H n, n = sig e_cb; with one active bound (level 2) H = W - W n1 n1' W / (n1' W n1)
-                    double z[NU], zn, r1 = 0.0;
-                    if (l == 1) {
-#pragma unroll
-                        for (int j = 0; j < NU; ++j) {
-                            double wj = 0.0;
-#pragma unroll
-                            for (int c = 0; c < NU; ++c) wj = (c == cb) ? W[j][c] : wj;
-                            z[j] = sig * wj;
-                        }
-                        zn = wcc; // z'n = |Lam^-1 e_c|^2
-                    } else {
-                        r1 = sig1 * sig * w1c / w11; // r = (n1' W n1)^-1 n1' W n
-#pragma unroll
-                        for (int j = 0; j < NU; ++j) {
-                            double wj = 0.0, w1j = 0.0;
-#pragma unroll
-                            for (int c = 0; c < NU; ++c) {
-                                wj = (c == cb) ? W[j][c] : wj;
-                                w1j = (c == scl[1]) ? W[j][c] : w1j;
-                            }
-                            z[j] = sig * (wj - w1j * (w1c / w11));
-                        }
-                        zn = wcc - w1c * (w1c / w11);
-                    }
-                    double zz = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) zz += z[j] * z[j];
-                    go = go && zn > 0.0 && zz > vsmall; // (gi_core.hpp: no step in primal space -- the tier's business)
-                    const double t2 = go ? -best / zn : 0.0;
-                    // the dual step length: an active bound whose multiplier would reach zero first is DROPPED by the iteration -- the tier's business
-                    if (l == 2) go = go && !(r1 > 0.0 && lam1 / r1 <= t2 * (1.0 + 1e-9));
-                    const double tt = go ? t2 : 0.0;
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) us[l][j] = go ? us[l - 1][j] + t2 * z[j] : us[l - 1][j]; // (no step: z may be 0 / 0)
-                    if (l == 1) {
-                        lam1 = tt;
-                        sig1 = sig;
-                    }
-                    specl[l] = go;
-                    scl[l] = go ? cb : -1;
-                    sst[l] = go ? best : 0.0;
-                    sst2[l] = sst[l] * sst[l];
-                    if (l < kSpec) { // (the next level starts from this iterate; without a step it repeats it)
-#pragma unroll
-                        for (int j = 0; j < NU; ++j) us[l + 1][j] = us[l][j];
-                    }
-                }
+                lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
             }
             if (on) {
                 if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, ncum);
@@ -906,7 +917,6 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
     for (int c = 0; c < NX; ++c) x[c] = P.x0[(size_t)li * NX + c];
     const double vsmall = P.vsmall;
     const int rps = P.lane_rps;
-    bool viol = false;
     const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
     const double* const ubp = P.ub_inst ? P.ub_inst + (size_t)li * P.n : P.ub;
     const bool own_bounds = P.lb_inst != nullptr;
@@ -928,29 +938,65 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
         }
     }
     wave_sync();
-    auto check_rows = [&](int k, const double (&xk)[NX], const double (&uk)[NU]) {
+    // The first steps of the active-set iteration, speculatively -- as in lmpc_lane_body (see there): bounds on u_0 as the first picks have
+    // closed-form steps in W = M_uu,0^-1 = Lam_0^-T Lam_0^-1 (here a wave-uniform block of the batch-wide records), the later stages follow in
+    // closed loop, kSpec more trajectories ride along.  The row norms qpgen2 normalises by are the model's (FusedPlan::ric_model, per row).
+    constexpr int kSpec = NU >= 2 ? 2 : 1;
+    const bool spec_on = P.lane_spec != 0;
+    bool specl[kSpec + 1], uniql[kSpec + 1], violl[kSpec + 1];
+    int scl[kSpec + 1];
+    double sst[kSpec + 1], sst2[kSpec + 1], bmin[kSpec + 1], bmin_other[kSpec + 1];
+#pragma unroll
+    for (int l = 0; l <= kSpec; ++l) {
+        specl[l] = false;
+        uniql[l] = true;
+        violl[l] = false;
+        scl[l] = -1;
+        sst[l] = sst2[l] = bmin[l] = bmin_other[l] = 0.0;
+    }
+    double xs[kSpec + 1][NX];
+#pragma unroll
+    for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
+    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, int idx, const double (&xk)[kSpec + 1][NX],
+                        const double (&uk)[kSpec + 1][NU]) {
+        const double nrm = uniform_load(F, oNb_ + (idx >= 0 ? idx : 0)); // (a row that is not there: f = +inf, never violated)
+        const double n2 = nrm * nrm;
+#pragma unroll
+        for (int l = 0; l <= kSpec; ++l) {
+            double ax = 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) ax += e[c] * xk[l][c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) ax += g[c] * uk[l][c];
+            const double sl = f - ax;
+            const bool v = sl <= -vsmall;
+            violl[l] = violl[l] || v;
+            if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !(v && sl * sl >= (sst2[l + 1] * n2) * (1.0 - 1e-9));
+        }
+    };
+    auto check_rows = [&](int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU]) {
         if (tlds) {
             for (int r = 0; r < rps; ++r) {
                 const double* const rt = Tl + (k * rps + r) * RW;
-                double ax = 0.0;
+                double e[NX], g[NU];
 #pragma unroll
-                for (int c = 0; c < NX; ++c) ax += rt[c] * xk[c];
+                for (int c = 0; c < NX; ++c) e[c] = rt[c];
 #pragma unroll
-                for (int c = 0; c < NU; ++c) ax += rt[NX + c] * uk[c];
-                const double s = rt[NZ] - ax;
-                viol = viol || (s <= -vsmall);
+                for (int c = 0; c < NU; ++c) g[c] = rt[NX + c];
+                row_eval(e, g, rt[NZ], uniform_i32((int)rt[NZ + 1]), xk, uk);
             }
             return;
         }
         for (int r = 0; r < rps; ++r) {
             const int ro = oRows + (k * rps + r) * RW;
-            double ax = 0.0;
+            double e[NX], g[NU];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ax += uniform_load(tab, ro + c) * xk[c];
+            for (int c = 0; c < NX; ++c) e[c] = uniform_load(tab, ro + c);
 #pragma unroll
-            for (int c = 0; c < NU; ++c) ax += uniform_load(tab, ro + NX + c) * uk[c];
-            const double s = uniform_load(tab, ro + NZ) - ax;
-            viol = viol || (s <= -vsmall);
+            for (int c = 0; c < NU; ++c) g[c] = uniform_load(tab, ro + NX + c);
+            row_eval(e, g, uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1), xk, uk);
         }
     };
     // Per-instance cost references (copra_batch_set_cost_reference: one model, every instance its own goal or reference trajectory).  The
@@ -1041,51 +1087,96 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
             const bool on = k < NH;
             const int kk = on ? k : NH - 1;
             const int rb = kk * RR::SZ;
-            double u[NU], kvk[NU]; // kvk: this instance's feed-forward term (the records' + its own delta)
+            double us[kSpec + 1][NU], kvk[NU]; // kvk: this instance's feed-forward term (the records' + its own delta)
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
                 kvk[c] = uniform_load(F, oKvB + kk * NU + c);
                 if (own_refs) kvk[c] += dkw[((size_t)kk * NU + c) * dbp + inst];
-                double s = kvk[c];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oK + c + NU * j) * x[j];
-                u[c] = s;
             }
-            if (on) {
-                check_rows(k, x, u);
+#pragma unroll
+            for (int l = 0; l <= kSpec; ++l)
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
-                    double ub, lb; // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
-                    if (own_bounds) {
-                        ub = ubp[k * NU + c];
-                        lb = lbp[k * NU + c];
-                    } else if (tlds) {
-                        ub = Tl[tl_rows + k * NU + c];
-                        lb = Tl[tl_rows + P.n + k * NU + c];
-                    } else {
-                        ub = uniform_load(ubp, k * NU + c);
-                        lb = uniform_load(lbp, k * NU + c);
+                    double acc = kvk[c];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc += uniform_load(F, rb + RR::oK + c + NU * j) * xs[l][j];
+                    us[l][c] = acc;
+                }
+            double ubk[NU], lbk[NU];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) { // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
+                const int kc = kk * NU + c;
+                if (own_bounds) {
+                    ubk[c] = ubp[kc];
+                    lbk[c] = lbp[kc];
+                } else if (tlds) {
+                    ubk[c] = Tl[tl_rows + kc];
+                    lbk[c] = Tl[tl_rows + P.n + kc];
+                } else {
+                    ubk[c] = uniform_load(ubp, kc);
+                    lbk[c] = uniform_load(lbp, kc);
+                }
+            }
+            double du[kSpec + 1][NU]; // what the speculative steps add to u_0 (zero at every other stage): x+ = Acl x + B (kv + du) + d
+#pragma unroll
+            for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+                for (int c = 0; c < NU; ++c) du[l][c] = 0.0;
+            if (q == 0 && k0 == 0 && spec_on) {
+                double W[NU][NU]; // M_uu,0^-1 = Lam^-T Lam^-1 of the batch-wide records (Lam^-1 lower triangular, packed by rows)
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int r = i; r < NU; ++r) acc += uniform_load(F, RR::oLi + r * (r + 1) / 2 + i) * uniform_load(F, RR::oLi + r * (r + 1) / 2 + j);
+                        W[i][j] = W[j][i] = acc;
                     }
-                    viol = viol || (ub - u[c] <= -vsmall) || (u[c] - lb <= -vsmall);
+                double u00[NU];
+#pragma unroll
+                for (int c = 0; c < NU; ++c) u00[c] = us[0][c];
+                lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, false, specl, scl, sst, sst2);
+#pragma unroll
+                for (int l = 1; l <= kSpec; ++l)
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) du[l][c] = us[l][c] - u00[c];
+            }
+            if (on) {
+                check_rows(k, xs, us);
+                const bool stage0 = q == 0 && k0 == 0;
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+#pragma unroll
+                    for (int l = 0; l <= kSpec; ++l) { // (the worst bound slack per level: see lmpc_lane_body)
+                        const double m = fmin(ubk[c] - us[l][c], us[l][c] - lbk[c]);
+                        const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
+                        const bool pick = stage0 && l < kSpec && c == scl[l < kSpec ? l + 1 : kSpec];
+                        bmin[l] = fmin(bmin[l], active ? 0.0 : m);
+                        if (l < kSpec) bmin_other[l] = fmin(bmin_other[l], (active || pick) ? 0.0 : m);
+                    }
                 }
             }
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = x[c];
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = xs[kSpec][c]; // (the deepest trajectory: levels without a step repeat the one before)
 #pragma unroll
-            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = u[c];
-            // x+ = Acl x + B kv + d  (= A x + B u + d: the tier's own roll-out, ric_factor.hpp)
-            double xn[NX];
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = us[kSpec][c];
+            // x+ = Acl x + B (kv + du) + d  (= A x + B u + d: the tier's own roll-out, ric_factor.hpp)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double s = uniform_load(F, NH * RR::SZ + RR::cD + i);
+            for (int l = 0; l <= kSpec; ++l) {
+                double xn[NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) s += uniform_load(F, rb + RR::oAcl + i + NX * j) * x[j];
+                for (int i = 0; i < NX; ++i) {
+                    double acc = uniform_load(F, NH * RR::SZ + RR::cD + i);
 #pragma unroll
-                for (int c = 0; c < NU; ++c) s += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * kvk[c];
-                xn[i] = s;
+                    for (int j = 0; j < NX; ++j) acc += uniform_load(F, rb + RR::oAcl + i + NX * j) * xs[l][j];
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) acc += uniform_load(F, NH * RR::SZ + RR::cB + i + NX * c) * (kvk[c] + du[l][c]);
+                    xn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[l][i] = on ? xn[i] : xs[l][i];
             }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = on ? xn[i] : x[i];
         }
         wave_sync();
         const int nst = NH - k0 < GS ? NH - k0 : GS;
@@ -1103,17 +1194,35 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
         }
     }
     {
-        double u0[NU];
+        double u0[kSpec + 1][NU];
 #pragma unroll
-        for (int c = 0; c < NU; ++c) u0[c] = 0.0;
-        check_rows(NH, x, u0);
+        for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) u0[l][c] = 0.0;
+        check_rows(NH, xs, u0);
         if (valid) {
             double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
 #pragma unroll
-            for (int c = 0; c < NX; ++c) xo[c] = x[c];
+            for (int c = 0; c < NX; ++c) xo[c] = xs[kSpec][c];
         }
     }
-    const bool more = valid && viol;
+    // the verdict: the first level that violates nothing, if every pick on the way to it was the pick (lmpc_lane_body)
+#pragma unroll
+    for (int l = 0; l <= kSpec; ++l) {
+        violl[l] = violl[l] || (bmin[l] <= -vsmall);
+        if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !(bmin_other[l] <= -vsmall && bmin_other[l] <= sst[l + 1] * (1.0 - 1e-9));
+    }
+    int done_iters = 0;
+    {
+        bool chain = valid;
+#pragma unroll
+        for (int l = 0; l <= kSpec; ++l) {
+            if (l >= 1) chain = chain && specl[l] && uniql[l];
+            if (chain && !violl[l] && done_iters == 0) done_iters = l + 1;
+            chain = chain && violl[l];
+        }
+    }
+    const bool more = valid && done_iters == 0;
     int total = 0;
     const int before = wave_prefix_count(more, total);
     if (total > 0) {
@@ -1122,9 +1231,9 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
         base = bcast_i32(base, 0);
         if (more) P.lane_list[base + before] = inst;
     }
-    if (valid && !viol) {
+    if (done_iters > 0) {
         P.status[inst] = 0;
-        P.iter[2 * (size_t)inst] = 1;
+        P.iter[2 * (size_t)inst] = done_iters; // (qpgen2's counters: the scan that found nothing counts)
         P.iter[2 * (size_t)inst + 1] = 0;
     }
 }

@@ -620,6 +620,7 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
+        P.lane_spec = default_options().no_lane_spec ? 0 : 1; // (copra_batch_solve, solve_shared_model)
         int oHl = 0;
         const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
         for (int g = 0; g < groups; ++g)
