@@ -65,14 +65,16 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 COPRA_RIC_RT_DECL(6, 3)
 COPRA_RIC_RT_DECL(4, 2)
 COPRA_RIC_RT_DECL(2, 1)
-extern template __global__ void copra_lmpc_lane_kernel<4, 2, false>(const FusedPlan);
-extern template __global__ void copra_lmpc_lane_kernel<4, 2, true>(const FusedPlan);
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, false, true>(const FusedPlan);
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, true, true>(const FusedPlan);
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, false, false>(const FusedPlan);
+extern template __global__ void copra_lmpc_lane_kernel<4, 2, true, false>(const FusedPlan);
 // ... and its shared-model form: the stage records are those of the whole batch (wave-uniform: scalar operands), only the roll-out
 // from each instance's x0 is left
-template <int NX, int NU>
+template <int NX, int NU, bool SPEC = true>
 __global__ __launch_bounds__(64, 4) void copra_lmpc_lane_shared_kernel(const FusedPlan P)
 {
-    lmpc_lane_shared_body<NX, NU>(P, (int)blockIdx.x);
+    lmpc_lane_shared_body<NX, NU, SPEC>(P, (int)blockIdx.x);
 }
 // Second tier of the two-tier scheme (own symbol so that profiles keep the two apart): the same body with the full LDS
 // layout, run only for the instances whose active set outgrew the compact layout's R (queue filled by the first tier).
@@ -362,16 +364,22 @@ static hipError_t begin_overflow_queue(copra_batch* h, hipStream_t s, bool self_
 // ---- the one-instance-per-lane pass in front of the Riccati-factor tier (lmpc_lane.hpp) ----
 static fused_kernel_t select_lane_kernel(const FusedPlan& P)
 {
-    if (P.nx == 6 && P.nu == 3) return P.stage_refs ? copra_lmpc_lane_kernel<6, 3, true> : copra_lmpc_lane_kernel<6, 3>; // (reference trajectories)
-    if (P.nx == 2 && P.nu == 1) return P.stage_refs ? copra_lmpc_lane_kernel<2, 1, true> : copra_lmpc_lane_kernel<2, 1>; // (the reference's falling-mass system: BASELINE configs[1])
-    if (P.nx == 4 && P.nu == 2) return P.stage_refs ? copra_lmpc_lane_kernel<4, 2, true> : copra_lmpc_lane_kernel<4, 2>; // (a planar point mass; copra_hip_ric.hip)
+    // <NX, NU, reference trajectories, takes the first steps of the iteration itself (FusedPlan::lane_spec)>
+#define COPRA_LANE_PICK(NX, NU)                                                                                                                   \
+    if (P.nx == NX && P.nu == NU)                                                                                                                  \
+        return P.lane_spec ? (P.stage_refs ? copra_lmpc_lane_kernel<NX, NU, true, true> : copra_lmpc_lane_kernel<NX, NU, false, true>)            \
+                           : (P.stage_refs ? copra_lmpc_lane_kernel<NX, NU, true, false> : copra_lmpc_lane_kernel<NX, NU, false, false>);
+    COPRA_LANE_PICK(6, 3) // (the CoM system)
+    COPRA_LANE_PICK(2, 1) // (the reference's falling-mass system: BASELINE configs[1])
+    COPRA_LANE_PICK(4, 2) // (a planar point mass; copra_hip_ric.hip)
+#undef COPRA_LANE_PICK
     return nullptr;
 }
 static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 {
-    if (P.nx == 6 && P.nu == 3) return copra_lmpc_lane_shared_kernel<6, 3>;
-    if (P.nx == 4 && P.nu == 2) return copra_lmpc_lane_shared_kernel<4, 2>; // (the other shapes of the tier's run-time-horizon builds)
-    if (P.nx == 2 && P.nu == 1) return copra_lmpc_lane_shared_kernel<2, 1>;
+    if (P.nx == 6 && P.nu == 3) return P.lane_spec ? copra_lmpc_lane_shared_kernel<6, 3, true> : copra_lmpc_lane_shared_kernel<6, 3, false>;
+    if (P.nx == 4 && P.nu == 2) return P.lane_spec ? copra_lmpc_lane_shared_kernel<4, 2, true> : copra_lmpc_lane_shared_kernel<4, 2, false>; // (the other shapes of the tier's run-time-horizon builds)
+    if (P.nx == 2 && P.nu == 1) return P.lane_spec ? copra_lmpc_lane_shared_kernel<2, 1, true> : copra_lmpc_lane_shared_kernel<2, 1, false>;
     return nullptr;
 }
 static size_t lane_lds_bytes(const FusedPlan& P)
@@ -418,8 +426,8 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
         (void)hipFree(h->d_lane_list);
         (void)hipFree(h->d_lane_hist);
         h->d_lane_count = h->d_lane_list = h->d_lane_hist = nullptr;
-        e = hipMalloc((void**)&h->d_lane_count, 2 * sizeof(int));
-        if (e == hipSuccess) e = hipMemset(h->d_lane_count, 0, 2 * sizeof(int));
+        e = hipMalloc((void**)&h->d_lane_count, 4 * sizeof(int)); // [cur | other]: instances left to the tier; [2 + cur | 2 + other]: instances ended by the pass's own steps
+        if (e == hipSuccess) e = hipMemset(h->d_lane_count, 0, 4 * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void**)&h->d_lane_list, bp * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void**)&h->d_lane_hist, kLaneHistBins * sizeof(int));
         if (e == hipSuccess) e = hipMemset(h->d_lane_hist, 0, kLaneHistBins * sizeof(int));
@@ -456,6 +464,7 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
         h->ad.lane_adapt_left = 1;
         if (h->ad.lane_off && h->ad.lane_off_by_share) h->ad.lane_off = h->ad.lane_off_by_share = false;
         h->ad.lane_form_handover = false; // (the speculating form is tried again)
+        h->ad.lane_spec_shared_off = false;
     }
     if (!h->ad.lane_ran || h->ad.lane_adapt_left <= 0) return COPRA_OK;
     // In front of the compact variant of the Riccati-factor tier the pass has two forms (solve_one_wave).  The one that hands the factor
@@ -467,21 +476,36 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     if (!h->shared && h->hp.plan.lds.ricC && !h->hp.opt.no_lane_handover) {
         if (h->hp.opt.no_lane_spec || h->ad.lane_form_handover) return COPRA_OK;
         h->ad.lane_adapt_left -= 1;
-        int left_over = 0;
+        int left_over = 0, by_steps = 0;
         HIP_TRY(hipStreamSynchronize(h->last_stream));
         HIP_TRY(hipMemcpy(&left_over, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&by_steps, h->d_lane_count + 2 + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
         const long long ended = (long long)h->hp.plan.batch - left_over;
-        if (ended * 4 < (long long)h->hp.plan.batch) h->ad.lane_form_handover = true;
+        // (... and where the steps it takes itself end fewer than one instance in twelve, they do not pay for the two trajectories that ride
+        //  along -- + 45 us per 65 536 instances against 8 ns per instance the tier is spared: the hand-over form does not carry them)
+        if (ended * 4 < (long long)h->hp.plan.batch || (long long)by_steps * 12 < (long long)h->hp.plan.batch) h->ad.lane_form_handover = true;
         if (h->hp.opt.debug)
-            fprintf(stderr, "[copra] one-instance-per-lane pass (speculating form): %lld of %d instances ended in it%s\n", ended, h->hp.plan.batch,
-                h->ad.lane_form_handover ? " -- the hand-over form from now on" : "");
+            fprintf(stderr, "[copra] one-instance-per-lane pass (speculating form): %lld of %d instances ended in it, %d of them by its own steps%s\n", ended,
+                h->hp.plan.batch, by_steps, h->ad.lane_form_handover ? " -- the hand-over form from now on" : "");
         return COPRA_OK;
+    }
+    if (h->shared && !h->ad.lane_spec_shared_off) { // the shared-model form's own steps: kept while they end one instance in eight (measured: a tracking
+        int by_steps = 0;                           // controller whose instances end at their minimiser ran 0.247 ms with them, 0.200 ms without)
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+        HIP_TRY(hipMemcpy(&by_steps, h->d_lane_count + 2 + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+        if ((long long)by_steps * 8 < (long long)h->hp.plan.batch) h->ad.lane_spec_shared_off = true;
+        if (h->hp.opt.debug)
+            fprintf(stderr, "[copra] shared-model pass: %d of %d instances ended by its own steps%s\n", by_steps, h->hp.plan.batch,
+                h->ad.lane_spec_shared_off ? " -- the plain form from now on" : "");
     }
     // (... and a shared-model controller with per-instance references: the pass carries their delta sweep, without it the controller runs
     //  lmpc_shared.hpp, which the tier beats by 2 x whatever the share that ends in the pass)
     if (h->shared && h->shared_ric)
         for (int t = 0; t < kMaxCosts; ++t)
-            if (h->cost_p[t]) return COPRA_OK;
+            if (h->cost_p[t]) {
+                h->ad.lane_adapt_left -= 1; // (the decision about its own steps above was this sample's)
+                return COPRA_OK;
+            }
     h->ad.lane_adapt_left -= 1;
     int left = 0;
     HIP_TRY(hipStreamSynchronize(h->last_stream));
@@ -1299,7 +1323,7 @@ static copra_status_t solve_shared_model(copra_batch* h, hipStream_t s)
             Pr.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
             Pr.lane_bp = (int)(((size_t)P.batch + kWave - 1) / kWave * kWave);
             Pr.lane_ws = refs_now ? h->d_lane_ws : nullptr; // (the delta feed-forward terms of instances with their own references)
-            Pr.lane_spec = h->hp.opt.no_lane_spec ? 0 : 1; // (the first steps of the iteration in the pass, lmpc_lane_shared_body: the tier then rolls out again)
+            Pr.lane_spec = (h->hp.opt.no_lane_spec || h->ad.lane_spec_shared_off) ? 0 : 1; // (the first steps of the iteration in the pass, lmpc_lane_shared_body: the tier then rolls out again)
             hipLaunchKernelGGL(select_lane_shared_kernel(Pr), dim3((unsigned)(Pr.lane_bp / kWave)), dim3(64), lane_lds_bytes(Pr), s, Pr);
             HIP_TRY(hipGetLastError());
             Pr.lane_from_list = 1;
@@ -1435,8 +1459,9 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         if (jit_launch) {
             FusedPlan Pl = P;
             void* largs[] = { &Pl };
-            LDS_OPT_IN(h->jit_lane, lane_lds_bytes(P));
-            HIP_TRY(hipModuleLaunchKernel(h->jit_lane, g0, 1, 1, 64, 1, 1, (unsigned)lane_lds_bytes(P), s, largs, nullptr));
+            const hipFunction_t jl = (P.lane_spec || !h->jit_lane_plain) ? h->jit_lane : h->jit_lane_plain;
+            LDS_OPT_IN(jl, lane_lds_bytes(P));
+            HIP_TRY(hipModuleLaunchKernel(jl, g0, 1, 1, 64, 1, 1, (unsigned)lane_lds_bytes(P), s, largs, nullptr));
         } else {
             LDS_OPT_IN(select_lane_kernel(P), lane_lds_bytes(P));
             if (ext_timed)

@@ -179,7 +179,7 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
     if (!h->shared && ric_pays && !h->hp.opt.no_ric && !h->hp.opt.no_tri) {
         HostPlan trial = h->hp; // (the layout and the tables are only kept if everything below succeeds)
         if (take_ric_layout(trial)) {
-            char keyr[128], srcr[3072];
+            char keyr[128], srcr[4096];
             const char* const sr = P.stage_refs ? "true" : "false"; // (reference trajectories: the builds with the stage-varying affine term)
             snprintf(keyr, sizeof keyr, "copra_jit_ric_%d_%d_%d%s", P.nx, P.nu, P.N, P.stage_refs ? "_srefs" : "");
             snprintf(srcr, sizeof srcr,
@@ -193,8 +193,10 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
                 "  int inst; bool failed; if (!tier_instance(P, (int)blockIdx.x, inst, failed)) return;\n"
                 "  lmpc_fused_ric_body<%d, %d, %d, 6, 0, %s>(P, inst, failed); }\n"
                 "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane(const FusedPlan P)\n"
-                "{ lmpc_lane_body<%d, %d, %s>(P, (int)blockIdx.x); }\n",
-                P.nx, P.nu, P.N, kFusedQ1Regs, sr, P.nx, P.nu, P.N, sr, P.nx, P.nu, sr);
+                "{ lmpc_lane_body<%d, %d, %s, true>(P, (int)blockIdx.x); }\n"
+                "extern \"C\" __global__ __launch_bounds__(64, 1) void copra_jit_lane_plain(const FusedPlan P)\n"
+                "{ lmpc_lane_body<%d, %d, %s, false>(P, (int)blockIdx.x); }\n",
+                P.nx, P.nu, P.N, kFusedQ1Regs, sr, P.nx, P.nu, P.N, sr, P.nx, P.nu, sr, P.nx, P.nu, sr);
             std::string objr;
             const copra_status_t rcr = jit_compile(keyr, srcr, cache_dir, objr, check, user);
             if (rcr != COPRA_OK) return rcr;
@@ -204,6 +206,8 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
             hipError_t er = hipModuleGetFunction(&fr, modr, "copra_jit_fused");
             if (er == hipSuccess) er = hipModuleGetFunction(&fq, modr, "copra_jit_fused_q0");
             if (er == hipSuccess) er = hipModuleGetFunction(&fl, modr, "copra_jit_lane");
+            hipFunction_t flp = nullptr;
+            if (er == hipSuccess) er = hipModuleGetFunction(&flp, modr, "copra_jit_lane_plain");
             double* dparams = nullptr;
             if (er == hipSuccess) er = upload(&dparams, trial.params); // (the stage-cost tables were appended)
             if (er != hipSuccess) {
@@ -227,6 +231,7 @@ copra_status_t copra_batch_specialise_checked(copra_batch_t* h, const char* cach
             h->jit_fused = fr;
             h->jit_fused_q0 = fq;
             h->jit_lane = fl;
+            h->jit_lane_plain = flp;
             h->jit_shared = nullptr;
             return COPRA_OK;
         }

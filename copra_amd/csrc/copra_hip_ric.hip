@@ -12,5 +12,7 @@
 COPRA_RIC_RT_INST(6, 3)
 COPRA_RIC_RT_INST(4, 2)
 COPRA_RIC_RT_INST(2, 1)
-template __global__ void copra_lmpc_lane_kernel<4, 2, false>(const FusedPlan);
-template __global__ void copra_lmpc_lane_kernel<4, 2, true>(const FusedPlan);
+template __global__ void copra_lmpc_lane_kernel<4, 2, false, true>(const FusedPlan);
+template __global__ void copra_lmpc_lane_kernel<4, 2, true, true>(const FusedPlan);
+template __global__ void copra_lmpc_lane_kernel<4, 2, false, false>(const FusedPlan);
+template __global__ void copra_lmpc_lane_kernel<4, 2, true, false>(const FusedPlan);

@@ -73,6 +73,7 @@ struct AdaptState {
     bool lane_off = false; // switched off for this controller: too few instances end in it (adapt_lane_pass), or no memory for its workspace
     bool lane_off_by_share = false; // ... the former: sampled again every 256 solves
     int lane_adapt_left = 2;
+    bool lane_spec_shared_off = false; // the shared-model form of the pass does not take steps itself (too few instances end by them)
     bool lane_form_handover = false; // the pass runs in its hand-over form (too few instances end in the speculating one: adapt_lane_pass)
     long long lane_solves = 0; // solves seen by adapt_lane_pass
     // shared-model tick on the records tier
@@ -127,7 +128,8 @@ struct copra_batch {
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_fused = nullptr, jit_shared = nullptr;
     hipFunction_t jit_fused_q0 = nullptr; // Riccati-factor tier compiled for this shape: Q1 in LDS (further down the layout ladder)
-    hipFunction_t jit_lane = nullptr; // ... and the one-instance-per-lane pass in front of it (lmpc_lane.hpp)
+    hipFunction_t jit_lane = nullptr; // ... and the one-instance-per-lane pass in front of it (lmpc_lane.hpp),
+    hipFunction_t jit_lane_plain = nullptr; // ... its build without the speculative steps
     bool jit_ric = false; // the code object holds the Riccati-factor tier (lmpc_fused_ric.hpp) of this controller's shape
     int jit_lanes = 64; // lanes per instance the code object was compiled for
     int jit_tri = 0; // ... and whether for the factor-only layout

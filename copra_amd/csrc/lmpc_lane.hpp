@@ -189,7 +189,9 @@ COPRA_DEV void lane_spec_steps(const double (&W)[NU][NU], const double (&ubk)[NU
 
 // SREFS: the build for controllers with reference trajectories (FusedPlan::stage_refs) -- its own instantiation, so that the registers of
 // stage_h below are not the headline's (measured on the one build for both: 3 VGPRs of the sweep in scratch memory)
-template <int NX, int NU, bool SREFS = false>
+// SPEC: the build that takes the first steps of the active-set iteration itself (FusedPlan::lane_spec); without it no trajectory rides along
+// (round 5 measured the hand-over form and tracking controllers whose instances end at their minimiser 45 us per 65 536 slower with them)
+template <int NX, int NU, bool SREFS = false, bool SPEC = true>
 COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 {
     constexpr int NZ = NX + NU, KW = NU * (NX + 1), RW = NZ + 2; // (a row of the table: E | G | f | its index)
@@ -208,7 +210,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     lane_tab_offsets(NX, NU, oh_, oHN_, ohN_, oRows_);
     const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
     double* lds = lds_base();
-    if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0; // (the NEXT solve's counter: nobody reads it now)
+    if (P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
     const int left = P.batch - group * GRP;
     const int ninst = left < GRP ? left : GRP; // instances of this wave
     const int T2 = NH * (NLU + NX); // doubles per instance of the hand-over block
@@ -602,8 +604,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     // slack <= -vsmall with the active rows left out; near-ties (1e-9 relative) go to the tier.  A lane writes its DEEPEST trajectory to
     // the results -- levels it does not speculate on repeat the one before, the verdict comes last --, which is why the tier behind this
     // pass rolls out for itself (lmpc_fused_ric.hpp, from_lane).
-    constexpr int kSpec = NU >= 2 ? 2 : 1; // levels: steps taken here at most (a third one on u_0 would fix all of it: 1 % of the headline's batch)
-    const bool spec_on = P.lane_spec != 0; // (the controller's rows are the compact variant's: one component of a state, or controls only)
+    constexpr int kSpec = !SPEC ? 0 : NU >= 2 ? 2 : 1; // levels: steps taken here at most (a third one on u_0 would fix all of it: 1 % of the headline's batch)
+    const bool spec_on = SPEC && P.lane_spec != 0; // (the controller's rows are the compact variant's: one component of a state, or controls only)
     bool specl[kSpec + 1], uniql[kSpec + 1], violl[kSpec + 1]; // [l]: level l was speculated on | its pick was the pick | trajectory l violates something
     int scl[kSpec + 1]; // component of u_0 whose bound level l >= 1 adds (-1: none)
     double sst[kSpec + 1], sst2[kSpec + 1]; // the slack of level l's pick at trajectory l - 1 (negative), and its square
@@ -723,7 +725,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NU; ++i)
 #pragma unroll
                     for (int j = 0; j <= i; ++j) W[i][j] = W[j][i] = ldn[lane * SX + i * (i + 1) / 2 + j];
-                lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
+                if constexpr (kSpec > 0) lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
             }
             if (on) {
                 if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, ncum);
@@ -740,7 +742,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                             if (l == 0) nviol += (m <= -vsmall) ? 1 : 0;
                             // (the bounds level <= l holds active -- their twins cannot be violated -- count for nothing; the pick of level l + 1
                             //  counts as a violation of level l, not against itself)
-                            const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
+                            const bool active = stage0 && ((l >= 1 && c == scl[kSpec >= 1 ? 1 : 0]) || (l >= 2 && c == scl[kSpec]));
                             const bool pick = stage0 && l < kSpec && c == scl[l < kSpec ? l + 1 : kSpec];
                             bmin[l] = fmin(bmin[l], active ? 0.0 : m);
                             if (l < kSpec) bmin_other[l] = fmin(bmin_other[l], (active || pick) ? 0.0 : m);
@@ -862,6 +864,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         base = bcast_i32(base, 0);
         if (more) P.lane_list[base + before] = bad ? (inst | (int)0x80000000) : inst; // (top bit: the factorisation failed -- status 2)
     }
+    { // instances that ended by the steps taken here: what copra_batch_solve weighs the speculation's cost against (adapt_lane_pass)
+        int nspec = 0;
+        (void)wave_prefix_count(done1, nspec);
+        if (nspec > 0 && lane == 0) (void)atomic_add_i32(P.lane_count + 2, nspec);
+    }
     if ((valid && !viol) || done1) {
         P.status[inst] = 0;
         P.iter[2 * (size_t)inst] = done1 ? done_iters : 1; // (qpgen2's counters: the scan that found nothing counts)
@@ -892,7 +899,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 // rolls out from its own x0 -- with one instance per lane the records are WAVE-UNIFORM: every matrix entry is a scalar operand of the
 // multiply-add (s_load, no vector registers, no LDS), a stage is 80 v_fma_f64 for 64 instances.  Rows, bounds, verdict and the
 // hand-over of U and X to the first tier exactly as above.
-template <int NX, int NU>
+template <int NX, int NU, bool SPEC = true>
 COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
 {
     constexpr int NZ = NX + NU, RW = NZ + 2;
@@ -906,7 +913,7 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
     lane_tab_offsets(NX, NU, oh_, oHN_, ohN_, oRows_);
     const int oRows = oRows_;
     double* lds = lds_base();
-    if (P.lane_zero && group == 0 && lane == 0) *P.lane_zero = 0;
+    if (P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0;
     const double* const F = P.ric_model; // N stage records + the constant block (B | d | ...)
     int oKvB_ = 0, oG_ = 0, oNb_ = 0; // the feed-forward terms kv: a block of their own behind the constant block (RicRec)
     (void)ric_model_offsets(NX, NU, NH, P.mgen, oKvB_, oG_, oNb_);
@@ -941,8 +948,8 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
     // The first steps of the active-set iteration, speculatively -- as in lmpc_lane_body (see there): bounds on u_0 as the first picks have
     // closed-form steps in W = M_uu,0^-1 = Lam_0^-T Lam_0^-1 (here a wave-uniform block of the batch-wide records), the later stages follow in
     // closed loop, kSpec more trajectories ride along.  The row norms qpgen2 normalises by are the model's (FusedPlan::ric_model, per row).
-    constexpr int kSpec = NU >= 2 ? 2 : 1;
-    const bool spec_on = P.lane_spec != 0;
+    constexpr int kSpec = !SPEC ? 0 : NU >= 2 ? 2 : 1;
+    const bool spec_on = SPEC && P.lane_spec != 0;
     bool specl[kSpec + 1], uniql[kSpec + 1], violl[kSpec + 1];
     int scl[kSpec + 1];
     double sst[kSpec + 1], sst2[kSpec + 1], bmin[kSpec + 1], bmin_other[kSpec + 1];
@@ -1136,7 +1143,7 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
                 double u00[NU];
 #pragma unroll
                 for (int c = 0; c < NU; ++c) u00[c] = us[0][c];
-                lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, false, specl, scl, sst, sst2);
+                if constexpr (kSpec > 0) lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, false, specl, scl, sst, sst2);
 #pragma unroll
                 for (int l = 1; l <= kSpec; ++l)
 #pragma unroll
@@ -1150,7 +1157,7 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
 #pragma unroll
                     for (int l = 0; l <= kSpec; ++l) { // (the worst bound slack per level: see lmpc_lane_body)
                         const double m = fmin(ubk[c] - us[l][c], us[l][c] - lbk[c]);
-                        const bool active = stage0 && ((l >= 1 && c == scl[1]) || (l >= 2 && c == scl[kSpec]));
+                        const bool active = stage0 && ((l >= 1 && c == scl[kSpec >= 1 ? 1 : 0]) || (l >= 2 && c == scl[kSpec]));
                         const bool pick = stage0 && l < kSpec && c == scl[l < kSpec ? l + 1 : kSpec];
                         bmin[l] = fmin(bmin[l], active ? 0.0 : m);
                         if (l < kSpec) bmin_other[l] = fmin(bmin_other[l], (active || pick) ? 0.0 : m);
@@ -1230,6 +1237,11 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
         if (lane == 0) base = atomic_add_i32(P.lane_count, total);
         base = bcast_i32(base, 0);
         if (more) P.lane_list[base + before] = inst;
+    }
+    {
+        int nspec = 0;
+        (void)wave_prefix_count(done_iters >= 2, nspec);
+        if (nspec > 0 && lane == 0) (void)atomic_add_i32(P.lane_count + 2, nspec);
     }
     if (done_iters > 0) {
         P.status[inst] = 0;

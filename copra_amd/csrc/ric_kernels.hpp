@@ -23,8 +23,8 @@ __global__ __launch_bounds__(64, 3) void copra_lmpc_fused_ric_kernel(const Fused
 }
 // One instance per LANE (lmpc_lane.hpp): the pass in front of the Riccati-factor tier -- LQ roll-out and qpgen2's first scan for every
 // instance; those that violate nothing are finished here.  One wave per SIMD: the lane's matrices live in up to 512 registers.
-template <int NX, int NU, bool SREFS = false>
+template <int NX, int NU, bool SREFS = false, bool SPEC = true>
 __global__ __launch_bounds__(64, 1) void copra_lmpc_lane_kernel(const FusedPlan P)
 {
-    lmpc_lane_body<NX, NU, SREFS>(P, (int)blockIdx.x);
+    lmpc_lane_body<NX, NU, SREFS, SPEC>(P, (int)blockIdx.x);
 }

@@ -341,7 +341,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     for (int k = 0; k < kMaxCosts; ++k) lane_pass = lane_pass && (!P.cost_p[k] || P.lane_cref >= 0);
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
     std::vector<double> lane_ws, lane_ws2;
-    int lane_count = 0, lane_other = 0;
+    int lane_cnt[4] = { 0, 0, 0, 0 }; // (as the device's: [left over | the next solve's] [+ 2: ended by the pass's own steps])
+    int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
     if (lane_pass) {
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = (dims->batch + 63) / 64 * 64 + 64;
@@ -360,10 +361,14 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             int oHl = 0;
             const size_t lbytes = (size_t)(lane_lds_doubles(P.nx, P.nu, oHl) + P.lane_tlds) * sizeof(double);
             int r = emu::run_wave([&]() {
-                if (P.nx == 6) P.stage_refs ? lmpc_lane_body<6, 3, true>(P, g) : lmpc_lane_body<6, 3>(P, g);
-                else if (P.nx == 4) P.stage_refs ? lmpc_lane_body<4, 2, true>(P, g) : lmpc_lane_body<4, 2>(P, g);
-                else if (P.nx == 5) P.stage_refs ? lmpc_lane_body<5, 3, true>(P, g) : lmpc_lane_body<5, 3>(P, g);
-                else P.stage_refs ? lmpc_lane_body<2, 1, true>(P, g) : lmpc_lane_body<2, 1>(P, g);
+#define COPRA_EMU_LANE(NX, NU)                                                                                                    \
+    (P.lane_spec ? (P.stage_refs ? lmpc_lane_body<NX, NU, true, true>(P, g) : lmpc_lane_body<NX, NU, false, true>(P, g))            \
+                 : (P.stage_refs ? lmpc_lane_body<NX, NU, true, false>(P, g) : lmpc_lane_body<NX, NU, false, false>(P, g)))
+                if (P.nx == 6) COPRA_EMU_LANE(6, 3);
+                else if (P.nx == 4) COPRA_EMU_LANE(4, 2);
+                else if (P.nx == 5) COPRA_EMU_LANE(5, 3);
+                else COPRA_EMU_LANE(2, 1);
+#undef COPRA_EMU_LANE
             }, lbytes, g, groups);
             if (r != 0) return -100;
         }
@@ -602,7 +607,9 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
     };
     // in front of the Riccati-factor tier in shared-model mode: the one-instance-per-lane pass in its shared-model form (as copra_batch_solve)
     std::vector<int> lane_list((size_t)dims->batch + 64, -1);
-    int lane_count = 0, lane_other = 0, lane_finished = -1;
+    int lane_cnt[4] = { 0, 0, 0, 0 };
+    int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
+    int lane_finished = -1;
     const bool lane_sh = ric_shared && P.lane_tab >= 0 && P.lds.ricC && !P.row_f_inst && !default_options().no_lane_pass;
     if (sh_refs && !(lane_sh && P.lane_cref >= 0)) {
         fprintf(stderr, "emu: shared-model references need the records form with the pass: ric_shared %d lane_tab %d ricC %d lane_cref %d\n", (int)ric_shared, P.lane_tab, (int)P.lds.ricC, P.lane_cref);
@@ -626,11 +633,11 @@ int emu_lmpc_solve_shared(const copra_dims_t* dims, int n_costs, const copra_cos
         for (int g = 0; g < groups; ++g)
             if (emu::run_wave([&]() {
                     if (P.nx == 6)
-                        lmpc_lane_shared_body<6, 3>(P, g);
+                        P.lane_spec ? lmpc_lane_shared_body<6, 3, true>(P, g) : lmpc_lane_shared_body<6, 3, false>(P, g);
                     else if (P.nx == 4)
-                        lmpc_lane_shared_body<4, 2>(P, g);
+                        P.lane_spec ? lmpc_lane_shared_body<4, 2, true>(P, g) : lmpc_lane_shared_body<4, 2, false>(P, g);
                     else
-                        lmpc_lane_shared_body<2, 1>(P, g);
+                        P.lane_spec ? lmpc_lane_shared_body<2, 1, true>(P, g) : lmpc_lane_shared_body<2, 1, false>(P, g);
                 }, lbytes, g, groups) != 0) return -100;
         P.lane_from_list = 1;
         P.lane_handover = 1;
