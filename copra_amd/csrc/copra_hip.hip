@@ -736,9 +736,10 @@ copra_status_t prepare_riccati(copra_batch* h)
     long long g = (long long)cus * per_cu;
     const int batch = h->hp.plan.batch > 0 ? h->hp.plan.batch : 1;
     h->ric_grid = (int)(g < batch ? g : batch);
-    if (e == hipSuccess && !h->ric_fast) // (the LDS-resident kernel has no workspace in HBM)
-        e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (size_t)sp.ws_total * sizeof(double));
-    sp.ws = h->d_ric_ws;
+    if (e == hipSuccess) // the streaming kernel's workspace | the LDS-resident kernel's stage records (all but a ring of four wait there: N x 107 doubles per wave)
+        e = hipMalloc((void**)&h->d_ric_ws, (size_t)h->ric_grid * (h->ric_fast ? (size_t)sp.N * kRfKStride : (size_t)sp.ws_total) * sizeof(double));
+    sp.ws = h->ric_fast ? nullptr : h->d_ric_ws;
+    sp.rec_ws = h->ric_fast ? h->d_ric_ws : nullptr;
     if (e == hipSuccess && !h->d_ric_next) e = hipMalloc((void**)&h->d_ric_next, sizeof(int));
     sp.next_instance = h->d_ric_next;
     if (h->hp.opt.debug)

@@ -50,7 +50,7 @@ COPRA_DEV RfLds carve_rf(double* lds, int N, int ntmpl)
     L.X = p, p += 64 * kRfZR; // the iterate z = (x_k, u_k)_k, padded
     L.Y = p, p += 64 * kRfMR; // row weights D (backward factorisation) | the step dz (forward sweeps)
     L.Cb = p, p += 64 * kRfMR; // gradient coefficients c of the rows (g_k += A_k' c)
-    L.KF = p, p += N * kRfKStride; // stage records
+    L.KF = p, p += kRfRing * kRfRingStride; // a ring of kRfRing stage records (record k in slot k % kRfRing while a sweep passes it)
     L.Hb = p, p += 2 * kRfHStride; // stage Hessian H = W + A' D A of the stage in flight | of the next one (being assembled)
     L.Pb = p, p += kRfNX * kRfNX;
     L.Rb = p, p += 64;
@@ -151,10 +151,34 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
         if (lane < 16) L.dv[lane] = lane < nx ? P.d[(size_t)inst * nx + lane] : 0.0;
         if (lane < 32) L.Zs[lane] = 0.0;
         if (lane < 4) L.Hb[NZ * NZ + (lane & 1) + kRfHStride * (lane >> 1)] = 0.0, L.gk[18 + (lane & 1) + 20 * (lane >> 1)] = 0.0;
-        for (int k = lane; k < N; k += kWave) L.KF[k * KS + oSpare] = 0.0, L.KF[k * KS + oZero] = 0.0;
+        if (lane < kRfRing) L.KF[lane * kRfRingStride + oSpare] = 0.0, L.KF[lane * kRfRingStride + oZero] = 0.0; // (... of every slot: they travel with the record)
         for (int e = lane; e < 2 * S.fast_ntmpl; e += kWave) L.TT[e] = S.f_rval[e];
         wave_sync();
         const double* const AB = L.AB;
+        // ---- the stage records (round 5).  N x 107 doubles = 42.8 KB of the 77.6 KB of LDS an instance held -- two instances per CU, two of the
+        //      four SIMDs idle.  Every sweep passes the records strictly in order, so only a ring of kRfRing of them stays in LDS: the
+        //      factorisation writes record k into slot k % 4 and copies it out to this wave's workspace one stage later; the vector sweeps
+        //      request record k -+ 3 (two 8-byte loads per lane) while they work on stage k and drop it into its slot one stage later.
+        //      38.7 KB per instance: FOUR per CU, one per SIMD.
+        double* const rec = S.rec_ws + (size_t)instance_id() * (size_t)N * KS;
+        constexpr int RS = kRfRingStride;
+        auto rec_slot = [&](int k) -> double* { return L.KF + (k & (kRfRing - 1)) * RS; };
+        auto rec_copy_out = [&](int k) { // (after a wave_sync that follows the last write to the slot)
+            const double* const sl = rec_slot(k);
+            rec[(size_t)k * KS + lane] = sl[lane];
+            if (lane < KS - kWave) rec[(size_t)k * KS + kWave + lane] = sl[kWave + lane];
+        };
+        auto rec_request = [&](int k, double& g0, double& g1) { // (no wait: the values are used one stage later)
+            const bool in = k >= 0 && k < N;
+            g0 = in ? rec[(size_t)k * KS + lane] : 0.0;
+            g1 = (in && lane < KS - kWave) ? rec[(size_t)k * KS + kWave + lane] : 0.0;
+        };
+        auto rec_put = [&](int k, double g0, double g1) {
+            if (k < 0 || k >= N) return;
+            double* const sl = rec_slot(k);
+            sl[lane] = g0;
+            if (lane < KS - kWave) sl[kWave + lane] = g1;
+        };
         // (the operands of the matrix products that are constants of the instance -- the element of [A B] each lane hands in -- are
         //  read from this copy at the head of every sweep: registers are what limits this kernel)
 
@@ -416,6 +440,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
 #pragma unroll
                 for (int I = 0; I < 3; ++I) lds[wP + 4 * I] = PX[I];
                 wave_sync();
+                if (k + 1 < N) rec_copy_out(k + 1); // (the record the stage before this one wrote: complete behind the sync)
                 COPRA_RF_STAMP(0);
                 double aP[3][3];
 #pragma unroll
@@ -479,7 +504,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 lds[wRa2] = MU[0];
 #pragma unroll
                 for (int I = 0; I < 3; ++I) MX[I] = mfma_f64_4x4x4(aRb[I], KbX, MX[I]);
-                double* const Fk = L.KF + k * KS;
+                double* const Fk = rec_slot(k);
                 Fk[kKb] = KbX;
                 Fk[kKba] = KbU;
                 Fk[kNb] = nB;
@@ -511,6 +536,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             }
             // P_0, p_0 for the step in x_0
             wave_sync();
+            if (N > 0) rec_copy_out(0);
 #pragma unroll
             for (int I = 0; I < 3; ++I) lds[wPend + 4 * I] = PX[I];
             wave_sync();
@@ -540,11 +566,27 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             const double sel = b == 0 ? 1.0 : 0.0;
             double nBop = 0.0, nAop = 0.0, aKbT = 0.0, aKaT = 0.0;
             auto fetch = [&](int k) {
-                const double* Fk = L.KF + k * KS;
+                const double* Fk = rec_slot(k);
                 nBop = Fk[oN1], nAop = Fk[oN2], aKbT = Fk[oB], aKaT = Fk[oA];
             };
+            // the records come back from the workspace: N - 1 and N - 2 now, k - 3 while stage k runs (dropped into its slot at stage k - 1,
+            // fetched from there at stage k - 2)
+            double rq0, rq1;
+            {
+                wave_sync_full(); // (this wave's copies of the records -- the factorisation's, the last vector sweep's kv -- are behind it)
+                double a0, a1, b0, b1;
+                rec_request(N - 1, a0, a1);
+                rec_request(N - 2, b0, b1);
+                rec_request(N - 3, rq0, rq1);
+                rec_put(N - 1, a0, a1);
+                rec_put(N - 2, b0, b1);
+            }
             auto stage = [&](int k, bool prep, int cn, int gn) {
                 wave_sync(); // (the gradient prepare_stage(k) wrote)
+                if (k < N) { // record k - 2 into its slot (requested one stage ago), k - 3 on its way
+                    rec_put(k - 2, rq0, rq1);
+                    rec_request(k - 3, rq0, rq1);
+                }
                 const double* gk = L.gk + 20 * (k & 1);
                 if (k == N) {
 #pragma unroll
@@ -569,7 +611,7 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
                 const double ha = row_bcast_f64<12>(hp); // h'_a to every hardware block
                 const double kva = mfma_f64_4x4x4(c_nA, ha, 0.0); // kv_a = -M'_aa^-1 h'_a
                 const double pn = mfma_f64_4x4x4(c_KaT, ha, hp); // p = h'_x + K_a' h'_a
-                L.KF[k * KS + wkv] = sel * kva + (1.0 - sel) * kvb;
+                rec[(size_t)k * KS + wkv] = sel * kva + (1.0 - sel) * kvb; // (straight to the workspace: the forward sweep reads it from there)
                 pB[0] = row_bcast_f64<0>(pn), pB[1] = row_bcast_f64<4>(pn), pB[2] = row_bcast_f64<8>(pn);
             };
             qnext = lane < NZ ? S.f_q[N * NZ + lane] : 0.0;
@@ -612,13 +654,28 @@ COPRA_DEV void lmpc_riccati_mfma_body(const FusedPlan& P, const StagePlan& S)
             const double sel = b == 0 ? 1.0 : 0.0;
             double nKa[3], nKb[3], nKba, nva, nvb;
             auto fetch = [&](int k) {
-                const double* Fk = L.KF + k * KS;
+                const double* Fk = rec_slot(k);
 #pragma unroll
                 for (int K = 0; K < 3; ++K) nKa[K] = Fk[oRa_[K]], nKb[K] = Fk[oRb_[K]];
                 nKba = Fk[oBa], nva = Fk[oVa], nvb = Fk[oVb];
             };
+            // the records come back from the workspace: 0 and 1 now, k + 3 while stage k runs (dropped into its slot at stage k + 1)
+            double rq0, rq1;
+            {
+                wave_sync_full(); // (the vector sweep's kv)
+                double a0, a1, b0, b1;
+                rec_request(0, a0, a1);
+                rec_request(1, b0, b1);
+                rec_request(2, rq0, rq1);
+                rec_put(0, a0, a1);
+                rec_put(1, b0, b1);
+                wave_sync();
+            }
             if (N > 0) fetch(0);
             for (int k = 0; k < N; ++k) {
+                rec_put(k + 2, rq0, rq1);
+                rec_request(k + 3, rq0, rq1);
+                wave_sync(); // (record k + 1, put one stage ago, is fetched below: LDS runs in issue order, the compiler must not reorder)
                 double fKa[3], fKb[3];
 #pragma unroll
                 for (int K = 0; K < 3; ++K) fKa[K] = nKa[K], fKb[K] = nKb[K];

@@ -43,6 +43,7 @@ constexpr int kRfNX = 12, kRfNU = 6, kRfNZ = 18; // padded xDim / uDim: three bl
 constexpr int kRfMR = 15; // 64-lane registers of per-row state: at most 960 rows
 constexpr int kRfZR = 15; // 64-lane registers of the stage vectors: (N + 1) 18 <= 960
 constexpr int kRfGTerms = 4, kRfWTerms = 4, kRfTTerms = 4, kRfMaxTouched = 64;
+constexpr int kRfRing = 4, kRfRingStride = 108; // stage records of the LDS-resident kernel that sit in LDS at a time (round 5: the other N - 4 wait in a per-wave workspace)
 constexpr int kRfKStride = 107; // stage record: Ka 3 x 12 | Kb 3 x 12 | Kba 3 x 3 | -Mbb^-1 3 x 3 | -M'aa^-1 3 x 3 | kv_a | kv_b | spare | zero
 
 // where the right-hand side of a constraint row comes from (per instance when the caller set per-instance data)
@@ -91,6 +92,7 @@ struct StagePlan {
     int* next_instance; // device counter of the work queue (reset before every launch), or nullptr
     // per-resident-wave workspace
     double* ws;
+    double* rec_ws; // LDS-resident kernel: [persistent waves][N x kRfKStride] -- the stage records of the instance in flight (lmpc_riccati_mfma.hpp)
     long long ws_total; // doubles per wave
     // workspace offsets (doubles)
     long long oZ, oDZ, oQ, oGB, oF, oS, oLam, oDS, oDL, oRP, oFlag, oK, oMi, oKv, oH0, oG0;
@@ -595,8 +597,8 @@ inline void build_stage_plan(const HostPlan& hp, HostStagePlan& out, bool all_bo
     }
     sp.fast_ntmpl = ntmpl > 0 ? ntmpl : 1;
     if (ntmpl > 128) return slow("more than 128 row templates");
-    // LDS of one instance (doubles): X | Y | F (64 kRfMR each) | stage records | kv | H | P | Rb | Ra | H0 | G0 | A B | d | Gauss-Jordan
-    sp.fast_lds_doubles = 3 * 64 * kRfMR + N * kRfKStride + 2 * (kRfNZ * kRfNZ + 2) + kRfNX * kRfNX + 64 + 64 + kRfNX * kRfNX + 16
+    // LDS of one instance (doubles): X | Y | F (64 kRfMR each) | a ring of kRfRing stage records | kv | H | P | Rb | Ra | H0 | G0 | A B | d | Gauss-Jordan
+    sp.fast_lds_doubles = 3 * 64 * kRfMR + kRfRing * kRfRingStride + 2 * (kRfNZ * kRfNZ + 2) + kRfNX * kRfNX + 64 + 64 + kRfNX * kRfNX + 16
         + kRfNX * kRfNZ + 16 + kRfNX * (kRfNX + 1) + 12 + 12 + 32 + 40 + 2 * sp.fast_ntmpl; // == carve_rf
     if ((size_t)sp.fast_lds_doubles * sizeof(double) > 80 * 1024) return slow("LDS footprint above 80 KiB (two instances per CU)");
     sp.fast_ok = 1;

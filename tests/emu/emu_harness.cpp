@@ -439,6 +439,8 @@ int emu_lmpc_solve_riccati(const copra_dims_t* dims, int n_costs, const copra_co
     hs.sp.ws = ws.data();
     int next_instance = 0; // the work queue of the kernel
     hs.sp.next_instance = &next_instance;
+    std::vector<double> rec_ws((size_t)hs.sp.N * kRfKStride + 8, __builtin_nan("")); // (the LDS-resident kernel's stage records: one wave here)
+    hs.sp.rec_ws = rec_ws.data();
     const StagePlan& S = hs.sp;
     // same dispatch as the HIP launcher: the LDS-resident kernel (lmpc_riccati_mfma.hpp) where the plan fits it ...
     if (not_converged) not_converged[1] = 0;
