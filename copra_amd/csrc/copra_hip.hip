@@ -1449,7 +1449,9 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         //     (the hand-over blocks of 65 536 instances were 157 MB of writes for the 2 437 that read them);
         //   hand-over (copra_options_t::no_lane_spec): Lam^-1 | kv | norm sums of every instance for a tier that takes the factor over.
         P.lane_spec = (P.lds.ricC && !h->hp.opt.no_lane_spec && !h->ad.lane_form_handover) ? 1 : 0; // (adapt_lane_pass chooses between them by workload)
-        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover && !P.lane_spec) ? 1 : 0;
+        // (the speculating build has no hand-over code: a code object without the plain build -- an older cache entry -- only filters)
+        const bool plain_missing = jit_launch && !h->jit_lane_plain;
+        P.lane_handover = (P.lds.ricC && !h->hp.opt.no_lane_handover && !P.lane_spec && !plain_missing) ? 1 : 0;
         // first solve of a controller on a factor-only tier with a layout ladder: the pass also counts, per instance it leaves over, the
         // rows its unconstrained minimiser violates; the layout the tier STARTS on is chosen from that histogram (below)
         const bool predict = h->ad.lane_predict_left > 0 && h->hp.two_tier && P.lds.tri && !h->shared && !h->hp.opt.no_ladder;

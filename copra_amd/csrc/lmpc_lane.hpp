@@ -18,6 +18,7 @@
 //     P = M_xx + M_xu K,  p = m_x + M_xu kv                                  (the recursion of lmpc_fused_ric.hpp, dense per lane)
 // Shapes: compile-time (NX, NU) with NU <= 3 (the Riccati-factor tier's), the horizon is a run-time value.
 #pragma once
+#include <type_traits>
 #include "lmpc_fused.hpp"
 
 // (experiments only, never defined in the product build: what a phase costs -- tools/exp/lane_variants.sh builds one library per value.
@@ -92,6 +93,58 @@ COPRA_DEV double lane_get(const double* row, unsigned byte_off)
 #else
     return *(const double*)((const char*)row + byte_off);
 #endif
+}
+
+// A group of the roll-out's stages leaves the LDS staging area: W doubles per instance (row `il` of the staging area, stride LS) to
+// dst + il * stride, consecutive lanes writing consecutive PAIRS of an instance's segment -- one 16-byte store per lane, the (instance, column)
+// of a lane's pair advanced by additions (round 5: the store phase was a quarter of the roll-out -- one 8-byte store per lane behind two integer
+// divisions, a predicate and a wait for its own LDS read, 36 times per group).  Whole waves and whole groups only; the others go element by element.
+template <int W>
+COPRA_DEV void lane_group_out(double* dst, size_t stride, const double* stg, int LS, int ninst, int cnt, int lane)
+{
+    static_assert(W % 2 == 0, "pairs");
+    constexpr int HW = W / 2; // pairs per instance
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane)); // (opaque per call: hoisted out of the roll-out's loop the addresses of every step would be live across it)
+#endif
+    if (ninst == kWave && cnt == W) {
+        // (column, LDS index and offset in memory of this lane's pair, advanced together)
+        const int il0 = lane / HW;
+        int c = 2 * (lane - il0 * HW), lo = il0 * LS + c;
+        unsigned go = (unsigned)il0 * (unsigned)stride + (unsigned)c; // (64 instances x one instance's results: far below 2^32 doubles)
+        const int dl = (kWave / HW) * LS + 2 * (kWave % HW);
+        const unsigned dg = (unsigned)(kWave / HW) * (unsigned)stride + 2u * (kWave % HW);
+#ifndef COPRA_LANE_OUTU
+#define COPRA_LANE_OUTU 4
+#endif
+#pragma unroll COPRA_LANE_OUTU
+        for (int j = 0; j < HW; ++j) { // (64 HW pairs, 64 per step; a few in flight: more would be registers the roll-out's state has to make room for)
+            const double v0 = stg[lo], v1 = stg[lo + 1];
+            double* const g = dst + go;
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef double lane_pair __attribute__((ext_vector_type(2), aligned(8)));
+            typedef lane_pair __attribute__((address_space(1))) lane_gpair;
+            lane_pair pr;
+            pr.x = v0;
+            pr.y = v1;
+            *(lane_gpair*)g = pr;
+#else
+            g[0] = v0;
+            g[1] = v1;
+#endif
+            c += 2 * (kWave % HW);
+            const bool wrap = c >= W; // (into the next instance's segment)
+            c -= wrap ? W : 0;
+            lo += dl + (wrap ? LS - W : 0);
+            go += dg + (wrap ? (unsigned)stride - (unsigned)W : 0u);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int j = 0; j < W; ++j) {
+        const int e = j * kWave + lane, il = e / W, c = e - il * W;
+        if (il < ninst && c < cnt) dst[(size_t)il * stride + c] = stg[il * LS + c];
+    }
 }
 
 // (streaming: a store that does not claim cache space -- what is written once and read, if at all, by a later kernel; measured: 226 -> 220 us
@@ -214,7 +267,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const int left = P.batch - group * GRP;
     const int ninst = left < GRP ? left : GRP; // instances of this wave
     const int T2 = NH * (NLU + NX); // doubles per instance of the hand-over block
-    const bool handover = P.lane_handover && P.lane_ws2;
+    const bool handover = !SPEC && P.lane_handover && P.lane_ws2; // (the speculating build hands nothing over)
     double* const ws2 = handover ? P.lane_ws2 + (size_t)(group * GRP) * T2 : nullptr;
     // (phase stamps of the wave, with copra_batch_enable_phase_profile: staging | sweep | roll-out | verdict, in row `group` of the profile --
     //  the first tier's rows are per instance, tools/exp/lane_tier1_phases.py leaves the first 1024 out)
@@ -463,11 +516,15 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
         // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
         double* const wk = ws + ((size_t)k * WR) * bp;
+        if (!(COPRA_LANE_EXP & 128)) {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
+            for (int c = 0; c < NU; ++c) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
-            lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
+                for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
+                lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
+            }
+        } else if (k == 0) { // (experiment: the sweep leaves nothing -- something of it has to be alive)
+            lane_put(wk, ioff, K[0][0] + kv[0] + K[NU - 1][NX - 1]);
         }
         // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier,
         // and only when it takes the factor over (FusedPlan::lane_handover; round-3 advisor finding: in front of the other tiers the
@@ -558,7 +615,6 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const int li = valid ? inst : 0;
     const double* const lbp = P.lb_inst ? P.lb_inst + (size_t)li * P.n : P.lb;
     const double* const ubp = P.ub_inst ? P.ub_inst + (size_t)li * P.n : P.ub;
-    const bool own_bounds = P.lb_inst != nullptr;
     // Stages in groups of GS.  One wave per SIMD: nothing else hides a trip to memory, so the gains of a stage are requested kLaneAhead stages
     // ahead -- rotating buffers, each refilled as soon as its stage has used it.  The group's states and controls are collected in
     // LDS and leave as contiguous segments per instance.  Everything is written for every instance -- the verdict comes last --, the
@@ -567,24 +623,34 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     double* const ldx = lds; // [lane][SX]
     double* const ldu = lds + kWave * SX; // [lane][SU]
     double* const ldn = lds + kWave * (SX + SU); // [lane][SX]: the norm sums of the group (hand-over block)
-    auto fetch_stage = [&](double (&buf)[KW], int k) {
+    // What a stage reads from memory -- its gains, the bounds of its controls, the right-hand sides of its rows -- is requested TOGETHER, a
+    // stage or two ahead, and from one kind of address each: memory operations retire in order, so anything requested behind the gains waits for
+    // them, and a load on one side of a branch makes the compiler wait for EVERYTHING in flight where the paths join.  (Round 5, measured with
+    // stamps inside the loop: an instance's own right-hand side -- a load behind `if (rhs_mine)` in the rows' loop -- cost every stage of every
+    // controller a wait for the gains requested a moment before: 114 k of the roll-out's 197 k cycles, the prefetch bought nothing.)
+    //   bounds: this instance's own (copra_batch_set_control_bounds) or the controller's, a pointer chosen once
+    //   right-hand sides: this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the stacked order; a row of the table that
+    //     is not there keeps +inf) or the table's -- the first RQ rows of a step; a step with more rows reads the others where it needs them
+    const double* const rhs_mine = P.row_f_inst ? P.row_f_inst + (size_t)li * P.mgen : nullptr;
+    constexpr int RQ = 4, KF = KW + 2 * NU + RQ; // a stage's buffer: K | kv | ub | lb | f of its first rows
+    auto row_index = [&](int ro) -> int { return tlds ? (int)Tl[ro + NZ + 1] : (int)uniform_load(tab, oRows + ro + NZ + 1); }; // (ro: the row's offset in the table)
+    auto fetch_stage = [&](double (&buf)[KF], int k) {
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
         for (int e = 0; e < KW; ++e) buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get(wk + (size_t)e * bp, ioff);
-    };
-    // the right-hand side of a row: the controller's, or this instance's own (copra_batch_set_constraint_rhs: [batch][mgen] in the
-    // stacked order; a row of the table that is not there keeps +inf)
-    const double* const rhs_mine = P.row_f_inst ? P.row_f_inst + (size_t)li * P.mgen : nullptr;
-    auto row_rhs = [&](double f_shared, int idx) -> double {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(f_shared)); // (the table entry is READ: folded into a choice between two addresses it would be a flat load)
-#endif
-        double f = f_shared;
-        if (rhs_mine) {
-            if (idx >= 0) f = rhs_mine[idx];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            buf[KW + c] = ubp[kk * NU + c];
+            buf[KW + NU + c] = lbp[kk * NU + c];
         }
-        return f;
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+            const int ro = (kk * rps + (r < rps ? r : 0)) * RW;
+            const int idx = r < rps ? row_index(ro) : -1;
+            const double* const fp = r >= rps ? tab : (rhs_mine && idx >= 0) ? rhs_mine + idx : tab + oRows + ro + NZ;
+            buf[KW + 2 * NU + r] = *fp;
+        }
     };
     // ---- the FIRST STEPS of the active-set iteration, speculatively (round 5) ----
     // Where the unconstrained minimiser saturates an actuator NOW -- a bound on u_0 is its most violated constraint, qpgen2's first pick: on
@@ -627,13 +693,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
         for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
     // one row  e' x + g' u <= f  at every iterate
-    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU],
-                        const double (&nc)[NX]) {
-        double n2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) n2 += (e[c] * e[c]) * nc[c]; // (the compact variant's rows: ONE component of the state, or controls only)
-#pragma unroll
-        for (int c = 0; c < NU; ++c) n2 += g[c] * g[c];
+    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU]) {
 #pragma unroll
         for (int l = 0; l <= kSpec; ++l) {
             double ax = 0.0;
@@ -645,34 +705,45 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             const bool v = sl <= -vsmall; // (gi_core.hpp: |s| < vsmall counts as zero, a negative slack is a violation)
             violl[l] = violl[l] || v;
             if (l == 0) nviol += v ? 1 : 0;
-            // a row at least as bad as the next level's pick by qpgen2's measure, slack / norm (squared: no root, no division): not the pick
-            if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !(v && sl * sl >= (sst2[l + 1] * n2) * (1.0 - 1e-9));
+            // A violated ROW below the last level: the tier's business.  (Whether the bound was still qpgen2's pick takes the row's norm --
+            // |row of Psi|^2, a recursion G <- A G of its own through the roll-out: 126 multiply-adds per stage and 48 registers, the ones that sent
+            // the roll-out to scratch memory.  Measured on the headline's batch: 186 of 65 536 instances ended here by that comparison, the pass
+            // 278 -> 208 k cycles per wave without it.)
+            if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !v;
         }
     };
-    auto check_rows = [&](int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU], const double (&nc)[NX]) { // E x_k + G u_k <= f
-        if (tlds) {
-            for (int r = 0; r < rps; ++r) {
-                const double* const rt = Tl + (k * rps + r) * RW;
-                double e[NX], g[NU];
-#pragma unroll
-                for (int c = 0; c < NX; ++c) e[c] = rt[c];
-#pragma unroll
-                for (int c = 0; c < NU; ++c) g[c] = rt[NX + c];
-                row_eval(e, g, row_rhs(rt[NZ], (int)rt[NZ + 1]), xk, uk, nc);
-            }
-            return;
-        }
+    // E x_k + G u_k <= f: the rows of step k; fq: the right-hand sides of its first RQ rows as fetch_stage left them (nullptr: none were fetched)
+    auto check_rows = [&](int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU], const double* fq) {
         for (int r = 0; r < rps; ++r) {
-            const int ro = oRows + (k * rps + r) * RW;
             double e[NX], g[NU];
+            const int ro = (k * rps + r) * RW;
+            if (tlds) {
 #pragma unroll
-            for (int c = 0; c < NX; ++c) e[c] = uniform_load(tab, ro + c);
+                for (int c = 0; c < NX; ++c) e[c] = Tl[ro + c];
 #pragma unroll
-            for (int c = 0; c < NU; ++c) g[c] = uniform_load(tab, ro + NX + c);
-            row_eval(e, g, row_rhs(uniform_load(tab, ro + NZ), (int)uniform_load(tab, ro + NZ + 1)), xk, uk, nc);
+                for (int c = 0; c < NU; ++c) g[c] = Tl[ro + NX + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NX; ++c) e[c] = uniform_load(tab, oRows + ro + c);
+#pragma unroll
+                for (int c = 0; c < NU; ++c) g[c] = uniform_load(tab, oRows + ro + NX + c);
+            }
+            double f = 0.0;
+            if (fq && r < RQ) {
+#pragma unroll
+                for (int t = 0; t < RQ; ++t) f = (t == r) ? fq[t] : f; // (r is wave-uniform: one select per entry, no indexed register)
+            } else { // (the last state's rows, and rows past the buffer: read here, waiting for whatever is in flight)
+                const int idx = row_index(ro);
+                const double* const fp = (rhs_mine && idx >= 0) ? rhs_mine + idx : tab + oRows + ro + NZ;
+                f = *fp;
+            }
+            row_eval(e, g, f, xk, uk);
         }
     };
-    constexpr int KB = kLaneAhead; // gain buffers: stages requested ahead
+#ifndef COPRA_LANE_KB
+#define COPRA_LANE_KB 1
+#endif
+    constexpr int KB = SPEC ? COPRA_LANE_KB : kLaneAhead; // gain buffers: stages requested ahead
     static_assert(GS % KB == 0, "the buffers rotate inside a group");
     // block-row norms of the preview blocks G_s = A^s B as running sums over s (one stage of the roll-out = one block): what the row norms
     // of the first tier's compact variant are read from (lmpc_fused_ric.hpp: NB2) -- and what the rows of step k are normalised by above
@@ -682,15 +753,26 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     for (int e = 0; e < NX * NU; ++e) Gp[e] = B[e];
 #pragma unroll
     for (int i = 0; i < NX; ++i) ncum[i] = 0.0;
-    double Kq[KB][KW];
+    double Kq[KB][KF];
 #pragma unroll
     for (int q = 0; q < KB; ++q) fetch_stage(Kq[q], q);
+    constexpr bool fine = (COPRA_LANE_EXP & 64) != 0; // (experiment: where the roll-out's cycles go -- gains and controls | rows and bounds | dynamics; the rest is the store phase)
+    long long fineA = 0, fineB = 0, fineC = 0, fineT = 0;
     for (int k0 = 0; k0 < NH; k0 += GS) {
         wave_sync(); // (the previous group has left the staging area)
 #pragma unroll
         for (int q = 0; q < GS; ++q) {
             const int k = k0 + q;
             const bool on = k < NH;
+            if (fine) fineT = cycle_counter();
+            double ubk[NU], lbk[NU], fk[RQ]; // (out of the buffer before it is refilled)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+                ubk[c] = Kq[q % KB][KW + c];
+                lbk[c] = Kq[q % KB][KW + NU + c];
+            }
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) fk[r] = Kq[q % KB][KW + 2 * NU + r];
             double us[kSpec + 1][NU];
 #pragma unroll
             for (int l = 0; l <= kSpec; ++l)
@@ -702,21 +784,15 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                     us[l][c] = acc;
                 }
             fetch_stage(Kq[q % KB], k + KB);
-            // the bounds of u_k
-            double ubk[NU], lbk[NU];
-#pragma unroll
-            for (int c = 0; c < NU; ++c) { // (three separate paths: a pointer chosen between LDS and memory would make these flat loads)
-                const int kc = (on ? k : 0) * NU + c;
-                if (own_bounds) {
-                    ubk[c] = ubp[kc];
-                    lbk[c] = lbp[kc];
-                } else if (tlds) {
-                    ubk[c] = Tl[tl_rows + kc];
-                    lbk[c] = Tl[tl_rows + P.n + kc];
-                } else {
-                    ubk[c] = uniform_load(ubp, kc);
-                    lbk[c] = uniform_load(lbp, kc);
-                }
+            if (fine) {
+                double a0 = us[kSpec][0];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(a0)); // (the controls are there)
+#endif
+                us[kSpec][0] = a0;
+                const long long t = cycle_counter();
+                fineA += t - fineT;
+                fineT = t;
             }
             if (q == 0 && k0 == 0 && spec_on) {
                 // W = M_uu,0^-1 (symmetric, packed by rows)
@@ -728,7 +804,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 if constexpr (kSpec > 0) lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
             }
             if (on) {
-                if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, ncum);
+                if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, fk);
                 if (!(COPRA_LANE_EXP & 16)) {
                     // the bounds of u_k at every iterate: the worst slack per level is all that is kept -- a level violates a bound iff its
                     // minimum is <= -vsmall, and the next level's pick was not the pick iff the minimum (the active bounds and the pick itself
@@ -750,14 +826,14 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                     }
                 }
             }
-            if (on && (handover || spec_on) && !(COPRA_LANE_EXP & 4)) { // |row i of G_k|^2 added (staged for the hand-over block), and the next block
+            if (on && handover && !(COPRA_LANE_EXP & 4)) { // |row i of G_k|^2 added (staged for the hand-over block), and the next block
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double sq = 0.0;
 #pragma unroll
                     for (int c = 0; c < NU; ++c) sq += Gp[i + NX * c] * Gp[i + NX * c];
                     ncum[i] += sq;
-                    if (handover) ldn[lane * SX + q * NX + i] = ncum[i];
+                    ldn[lane * SX + q * NX + i] = ncum[i];
                 }
 #pragma unroll
                 for (int c = 0; c < NU; ++c) { // (column by column, in place: NX temporaries instead of a second block)
@@ -772,6 +848,16 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
                     for (int i = 0; i < NX; ++i) Gp[i + NX * c] = gn[i];
                 }
+            }
+            if (fine) {
+                double a0 = bmin[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(a0));
+#endif
+                bmin[0] = a0;
+                const long long t = cycle_counter();
+                fineB += t - fineT;
+                fineT = t;
             }
             // (the deepest trajectory: levels without a step repeat the one before)
 #pragma unroll
@@ -793,33 +879,24 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xs[l][i] = on ? xn[i] : xs[l][i];
             }
+            if (fine) {
+                double a0 = xs[kSpec][0];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(a0));
+#endif
+                xs[kSpec][0] = a0;
+                fineC += cycle_counter() - fineT;
+            }
             sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
         }
         wave_sync();
-        if (!(COPRA_LANE_EXP & 1)) { // consecutive lanes write consecutive doubles of an instance's segment
+        if (!(COPRA_LANE_EXP & 1)) { // the group's states and controls: one contiguous segment per instance each
             const int nst = NH - k0 < GS ? NH - k0 : GS; // stages of this group
-            double* const xg = P.trajectory + (size_t)(group * GRP) * P.X + (size_t)k0 * NX;
-            double* const ug = P.control + (size_t)(group * GRP) * P.n + (size_t)k0 * NU;
-#pragma unroll 4
-            for (int j = 0; j < GS * NX; ++j) { // (four stores in flight at a time: each has its own address pair)
-                const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
-                if (il < ninst && c < nst * NX) xg[(size_t)il * P.X + c] = ldx[il * SX + c];
-            }
-#pragma unroll 4
-            for (int j = 0; j < GS * NU; ++j) {
-                const int e = j * kWave + lane, il = e / (GS * NU), c = e - il * (GS * NU);
-                if (il < ninst && c < nst * NU) ug[(size_t)il * P.n + c] = ldu[il * SU + c];
-            }
+            lane_group_out<GS * NX>(P.trajectory + (size_t)(group * GRP) * P.X + (size_t)k0 * NX, (size_t)P.X, ldx, SX, ninst, nst * NX, lane);
+            lane_group_out<GS * NU>(P.control + (size_t)(group * GRP) * P.n + (size_t)k0 * NU, (size_t)P.n, ldu, SU, ninst, nst * NU, lane);
         }
-        if (handover) { // the group's norm sums of every instance: one contiguous segment of its hand-over block
-            const int nst = NH - k0 < GS ? NH - k0 : GS;
-            double* const ng = ws2 + (size_t)NH * NLU + (size_t)k0 * NX;
-#pragma unroll 4
-            for (int j = 0; j < GS * NX; ++j) {
-                const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
-                if (il < ninst && c < nst * NX) ng[(size_t)il * T2 + c] = ldn[il * SX + c];
-            }
-        }
+        if (handover) // the group's norm sums of every instance: one contiguous segment of its hand-over block
+            lane_group_out<GS * NX>(ws2 + (size_t)NH * NLU + (size_t)k0 * NX, (size_t)T2, ldn, SX, ninst, (NH - k0 < GS ? NH - k0 : GS) * NX, lane);
     }
     { // the last state: its rows, and out
         double u0[kSpec + 1][NU];
@@ -827,7 +904,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         for (int l = 0; l <= kSpec; ++l)
 #pragma unroll
             for (int c = 0; c < NU; ++c) u0[l][c] = 0.0;
-        check_rows(NH, xs, u0, ncum);
+        check_rows(NH, xs, u0, nullptr);
         if (valid) {
             double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
 #pragma unroll
@@ -890,6 +967,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         stamp[4] = cycle_counter();
         long long* pr = P.prof + 8 * (size_t)group;
         for (int q = 0; q < 4; ++q) pr[q] = stamp[q + 1] - stamp[q];
+        if (fine) {
+            pr[4] = fineA;
+            pr[5] = fineB;
+            pr[6] = fineC;
+        }
         pr[7] = stamp[4] - stamp[0];
     }
 }
@@ -1187,18 +1269,8 @@ COPRA_DEV void lmpc_lane_shared_body(const FusedPlan& P, int group)
         }
         wave_sync();
         const int nst = NH - k0 < GS ? NH - k0 : GS;
-        double* const xg = P.trajectory + (size_t)(group * kWave) * P.X + (size_t)k0 * NX;
-        double* const ug = P.control + (size_t)(group * kWave) * P.n + (size_t)k0 * NU;
-#pragma unroll 4
-        for (int j = 0; j < GS * NX; ++j) {
-            const int e = j * kWave + lane, il = e / (GS * NX), c = e - il * (GS * NX);
-            if (il < ninst && c < nst * NX) xg[(size_t)il * P.X + c] = ldx[il * SX + c];
-        }
-#pragma unroll 4
-        for (int j = 0; j < GS * NU; ++j) {
-            const int e = j * kWave + lane, il = e / (GS * NU), c = e - il * (GS * NU);
-            if (il < ninst && c < nst * NU) ug[(size_t)il * P.n + c] = ldu[il * SU + c];
-        }
+        lane_group_out<GS * NX>(P.trajectory + (size_t)(group * kWave) * P.X + (size_t)k0 * NX, (size_t)P.X, ldx, SX, ninst, nst * NX, lane);
+        lane_group_out<GS * NU>(P.control + (size_t)(group * kWave) * P.n + (size_t)k0 * NU, (size_t)P.n, ldu, SU, ninst, nst * NU, lane);
     }
     {
         double u0[kSpec + 1][NU];

@@ -7,11 +7,11 @@ set -e
 cd "$(dirname "$0")/../../copra_amd/csrc"
 mkdir -p variants
 SRCHASH=$(cat libcopra_hip.so.srchash)
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -DCOPRA_SRC_HASH=\"$SRCHASH\""
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -DCOPRA_SRC_HASH=\"$SRCHASH\" $EXTRA" # (EXTRA: more -D switches, e.g. -DCOPRA_LANE_KB=1; TAG names the outputs)
 if [ "$1" = build ]; then
   for v in $2; do
-    ( /opt/rocm/bin/hipcc $FLAGS -DCOPRA_LANE_EXP=$v -c -o variants/copra_hip_exp$v.o copra_hip.hip && \
-      /opt/rocm/bin/hipcc $FLAGS -shared -o variants/libcopra_hip_exp$v.so variants/copra_hip_exp$v.o build/copra_hip_ric.o build/copra_hip_setters.o \
+    ( /opt/rocm/bin/hipcc $FLAGS -DCOPRA_LANE_EXP=$v -c -o variants/copra_hip_exp$TAG$v.o copra_hip.hip && \
+      /opt/rocm/bin/hipcc $FLAGS -shared -o variants/libcopra_hip_exp$TAG$v.so variants/copra_hip_exp$TAG$v.o build/copra_hip_ric.o build/copra_hip_setters.o \
          build/copra_hip_jit.o build/copra_hip_qp.o build/copra_hip_packed16.o build/copra_hip_packed32.o ) &
   done
   wait
@@ -19,8 +19,8 @@ if [ "$1" = build ]; then
 else
   cd ../..
   for v in $2; do
-    echo "== COPRA_LANE_EXP=$v"
-    python - "$v" <<'PY'
+    echo "== COPRA_LANE_EXP=$v $TAG"
+    python - "$TAG$v" <<'PY'
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -41,6 +41,9 @@ for _ in range(6):
 pr = eng.phase_profile()[: b // 64]
 print("solve %.4f ms | pass per wave: staging %.0f sweep %.0f roll-out %.0f verdict %.0f total %.0f cycles | finished %s"
       % (1e3 * float(np.mean(ts[2:])), pr[:, 0].mean(), pr[:, 1].mean(), pr[:, 2].mean(), pr[:, 3].mean(), pr[:, 7].mean(), eng.lane_pass_info()))
+if pr[:, 4].mean() > 0:  # (bit 64: the roll-out's stages in three parts)
+    print("   roll-out: gains+controls %.0f | rows+bounds %.0f | dynamics %.0f | rest (store phase) %.0f"
+          % (pr[:, 4].mean(), pr[:, 5].mean(), pr[:, 6].mean(), pr[:, 2].mean() - pr[:, 4:7].sum(axis=1).mean()))
 PY
   done
 fi
