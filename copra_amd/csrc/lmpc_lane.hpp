@@ -114,29 +114,39 @@ COPRA_DEV void lane_group_out(double* dst, size_t stride, const double* stg, int
         unsigned go = (unsigned)il0 * (unsigned)stride + (unsigned)c; // (64 instances x one instance's results: far below 2^32 doubles)
         const int dl = (kWave / HW) * LS + 2 * (kWave % HW);
         const unsigned dg = (unsigned)(kWave / HW) * (unsigned)stride + 2u * (kWave % HW);
-#ifndef COPRA_LANE_OUTU
-#define COPRA_LANE_OUTU 4
-#endif
-#pragma unroll COPRA_LANE_OUTU
-        for (int j = 0; j < HW; ++j) { // (64 HW pairs, 64 per step; a few in flight: more would be registers the roll-out's state has to make room for)
-            const double v0 = stg[lo], v1 = stg[lo + 1];
-            double* const g = dst + go;
+        // NB pairs at a time: their LDS reads first, then their stores (one at a time, every store waited for its own read: 18 LDS latencies per group)
+        constexpr int NB = HW % 3 == 0 ? 3 : HW % 2 == 0 ? 2 : 1;
+#pragma unroll 1
+        for (int j = 0; j < HW; j += NB) { // (64 HW pairs, 64 per step)
+            double v0[NB], v1[NB];
+            unsigned gq[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                v0[t] = stg[lo];
+                v1[t] = stg[lo + 1];
+                gq[t] = go;
+                c += 2 * (kWave % HW);
+                const bool wrap = c >= W; // (into the next instance's segment)
+                c -= wrap ? W : 0;
+                lo += dl + (wrap ? LS - W : 0);
+                go += dg + (wrap ? (unsigned)stride - (unsigned)W : 0u);
+            }
+            sched_fence();
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                double* const g = dst + gq[t];
 #if defined(__HIP_DEVICE_COMPILE__)
-            typedef double lane_pair __attribute__((ext_vector_type(2), aligned(8)));
-            typedef lane_pair __attribute__((address_space(1))) lane_gpair;
-            lane_pair pr;
-            pr.x = v0;
-            pr.y = v1;
-            *(lane_gpair*)g = pr;
+                typedef double lane_pair __attribute__((ext_vector_type(2), aligned(8)));
+                typedef lane_pair __attribute__((address_space(1))) lane_gpair;
+                lane_pair pr;
+                pr.x = v0[t];
+                pr.y = v1[t];
+                *(lane_gpair*)g = pr;
 #else
-            g[0] = v0;
-            g[1] = v1;
+                g[0] = v0[t];
+                g[1] = v1[t];
 #endif
-            c += 2 * (kWave % HW);
-            const bool wrap = c >= W; // (into the next instance's segment)
-            c -= wrap ? W : 0;
-            lo += dl + (wrap ? LS - W : 0);
-            go += dg + (wrap ? (unsigned)stride - (unsigned)W : 0u);
+            }
         }
         return;
     }

@@ -1,2 +1,2 @@
-# timing of the one-instance-per-lane pass with parts of its memory traffic compiled out (tools/exp/lane_variants.sh build, with TAG / EXTRA)
-TAG=kb1_ bash tools/exp/lane_variants.sh run "0 128 2 130 131"
+# timing of the roll-out's prefetch-depth variants (tools/exp/lane_variants.sh build, with TAG / EXTRA)
+for kb in 1 4; do TAG=kb${kb}_ bash tools/exp/lane_variants.sh run "64 66"; done
