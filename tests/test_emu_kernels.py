@@ -986,6 +986,34 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
+def test_lane_pass_with_more_rows_per_step_than_its_prefetch_buffer_holds(emu, oracle):
+    """six rows per step (upper AND lower velocity limits as rows) in front of the pass, whose stage buffer carries the right-hand sides of
+    the first four (lmpc_lane.hpp: RQ): the others are read in place -- with the controller's right-hand sides and with every instance's own"""
+    from copra_amd import workloads
+    b = 64
+    wl = workloads.com_preview(b, seed=33, v_max=0.45)
+    vsel = np.hstack([np.zeros((3, 3)), np.eye(3)])
+    cstrs = list(wl["cstrs"]) + [dict(kind="trajectory", E=-vsel, f=[0.45] * 3, ineq=True)]
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+    rng = np.random.default_rng(5)
+    for own in (False, True):
+        vup, vlo = (0.45 * rng.uniform(0.8, 1.2, b), 0.45 * rng.uniform(0.8, 1.2, b)) if own else (np.full(b, 0.45), np.full(b, 0.45))
+        # stacked order of the rows: the trajectory bound's (N + 1) x 3, then the row constraint's (N + 1) x 3
+        rhs = np.hstack([np.repeat(vup[:, None], 63, axis=1), np.repeat(vlo[:, None], 63, axis=1)]) if own else None
+        re = emu.lmpc_solve(*args, row_rhs=rhs)
+        nsolved = 0
+        inf = np.inf
+        for k in range(b):
+            cs = [dict(cstrs[0], upper=[inf, inf, inf, vup[k], vup[k], vup[k]]), cstrs[1], dict(cstrs[2], f=[vlo[k]] * 3)]
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], cs)
+            assert re["status"][k] == ro["status"], (own, k)
+            if ro["status"] == 0:
+                nsolved += 1
+                assert tuple(re["iter"][k]) == tuple(ro["iter"]), (own, k)
+                assert _rel(re["control"][k], ro["control"]) <= 1e-9 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-9
+        assert nsolved >= b // 2 and 0 < re["lane_pass_finished"] < b
+
+
 def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
     """the shared-model form of the pass (lmpc_lane_shared_body: the batch-wide stage records as scalar operands, only the roll-out from
     each x0 is left) in front of the Riccati-factor tier in shared-model mode: it finishes exactly the instances at their unconstrained
