@@ -731,8 +731,9 @@ def main():
                          "library_source_hash": __import__("copra_amd")._capi.library_source_hash(),
                          "algorithmic_bytes_per_launch": alg_bytes * batch,
                          "kernel": dominant, "algorithmic_bytes_per_solve": alg_bytes,
-                         "note": "algorithmic bytes over the time of the pair; the pass (80 % of it since round 5) is bound by the HBM traffic "
-                                 "of its own stage-record workspace (`traffic` vs algorithmic_bytes_per_launch), the rest by FP64 issue: `roofline_fp64`",
+                         "note": "algorithmic bytes over the time of the pair; the pass (70 % of it since round 5) is bound by FP64 issue in its sweep and "
+                                 "by the round trip of its own gain workspace in its roll-out (`traffic` vs algorithmic_bytes_per_launch), the tier behind it "
+                                 "by its slowest instance's dependent chains: DESIGN.md 3.2, `roofline_fp64`",
                          "issue": issue, "fp64_peak_tflops": FP64_PEAK_TFLOPS},
             # the same pair of launches against the FP64 peak (vector and matrix FP64 share one pipe on gfx950: 78.6 TFLOP/s either way):
             # EXECUTED multiply-adds of the PMC pass over the kernel time of this run -- what DESIGN.md calls the path's real bound
