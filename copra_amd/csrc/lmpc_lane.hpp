@@ -413,6 +413,31 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
         for (int a = 0; a < NZ; ++a) lds[lane * HS + a] = hk[a];
     };
+    // Decoupled axes (FusedPlan::lane_axes: the costs couple none; here: neither do the systems of this wave): K(c, j) is exactly zero for
+    // j % NU != c at every stage -- the recursion stays axis by axis: sums of products with an exact zero factor -- so those entries are
+    // written to a row nobody reads and read from a row of zeros (two rows behind the workspace's own, each wave its 512 bytes of them,
+    // which never leave the L2): no branch, one scalar select per access.  12 of the 18 gains of the CoM model: what the pass writes and
+    // reads back is what it pays for (round 5: the zeros compiled out, 331 -> 270 k cycles per wave; tested per stage at run time the
+    // masks cost the sweep what they saved the roll-out).  The speculating build only: the hand-over form's tier gathers K from the workspace.
+    bool axes = false;
+    if constexpr (SPEC && NU > 1 && NX % NU == 0) {
+        if (P.lane_axes) {
+            double stray = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (i % NU != j % NU) stray += fabs(A[i + NX * j]);
+#pragma unroll
+            for (int c = 0; c < NU; ++c)
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    if (i % NU != c) stray += fabs(B[i + NX * c]);
+            axes = !wave_any(!(stray == 0.0)); // (a NaN couples)
+        }
+    }
+    double* const wdump = ws + ((size_t)NH * WR) * bp;
+    const double* const wzero = wdump + bp;
     bool bad = false;
     for (int k = NH - 1; k >= 0; --k) {
         if constexpr (SREFS) stage_h(k);
@@ -530,7 +555,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
+                for (int j = 0; j < NX; ++j) lane_put((axes && j % NU != c) ? wdump : wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
                 lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
             }
         } else if (k == 0) { // (experiment: the sweep leaves nothing -- something of it has to be alive)
@@ -648,7 +673,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
-        for (int e = 0; e < KW; ++e) buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get(wk + (size_t)e * bp, ioff);
+        for (int e = 0; e < KW; ++e) // (entry e < NU NX of the gains: K(e % NU, e / NU))
+            buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get((axes && e < NU * NX && (e / NU) % NU != e % NU) ? wzero : wk + (size_t)e * bp, ioff);
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
             buf[KW + c] = ubp[kk * NU + c];

@@ -234,6 +234,7 @@ COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& oh
 // rows of its LANE-MAJOR workspace per stage: K (nu x nx, column-major) | kv (nu) -- what its own roll-out reads back (and the first tier
 // gathers K from: lmpc_fused_ric.hpp, from_lane)
 COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu; }
+constexpr int kLaneWsExtraRows = 2; // behind the N stages' rows: one that takes the stores nobody reads, one of zeros (lmpc_lane.hpp: the gains between decoupled axes)
 // ... and doubles per instance of its INSTANCE-MAJOR hand-over block (FusedPlan::lane_ws2; round 5): what only the first tier reads --
 // Lam^-1 (packed by rows, as RicRec) and kv of every stage ([N][nu (nu + 1) / 2 + nu]), then the running sums of the squared block-row
 // norms of G_s = A^s B ([N][nx]).  Until round 5 these were twelve more lane-major rows per stage: the tier fetched each of the 240 values of an
@@ -289,6 +290,9 @@ struct FusedPlan {
     // it does not finish to lane_list (lane_count entries; lane_zero: the next solve's counter, zeroed on the way); the first tier
     // then runs with lane_from_list = 1: workgroup w takes instance lane_list[w], workgroups beyond the count leave at once.
     int lane_tab, lane_rps;
+    int lane_axes; // 1: the stage and terminal cost couple no two AXES -- state i belongs to axis i % nu, control c to axis c (nx a multiple of nu: the
+                   // double integrators in nu dimensions, the CoM model).  A wave whose systems couple none either (checked by the pass) has gains
+                   // K(c, j) = 0 for j % nu != c at every stage, exactly: the whole recursion stays axis by axis.  Those entries are neither written nor read.
     int lane_cref; // offset (doubles from lane_tab) of the reference coefficients: [cost][row (6)][nz + nx]
     int lane_tlds; // > 0: that many doubles of tables -- the rows of every step, then ub and lb -- sit in LDS behind H | h (the pass reads them there
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas

@@ -387,6 +387,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_rps = 0;
     P.lane_tlds = 0;
     P.lane_cref = -1;
+    P.lane_axes = 0;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
     if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
     std::vector<int> per_step((size_t)N + 1, 0);
@@ -449,6 +450,17 @@ inline void build_lane_tables(HostPlan& hp)
             for (int c = 0; c < nu; ++c) row[nx + c] = hp.params[(size_t)hp.row_goff[i] + c];
         row[nz] = hp.row_f[i];
         row[nz + 1] = (double)i;
+    }
+    { // axis-decoupled costs (FusedPlan::lane_axes): H(a, b) = 0 and HN(a, b) = 0 wherever a and b belong to different axes
+        auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
+        bool ok = nu > 1 && nx % nu == 0;
+        for (int a = 0; a < nz && ok; ++a)
+            for (int b = 0; b < nz && ok; ++b) {
+                if (axis(a) == axis(b)) continue;
+                if (tab[(size_t)a + nz * b] != 0.0) ok = false;
+                if (a < nx && b < nx && tab[(size_t)oHN + a + nx * b] != 0.0) ok = false;
+            }
+        P.lane_axes = ok ? 1 : 0;
     }
     if (hp.params.size() & 1) hp.params.push_back(0.0);
     P.lane_tab = (int)hp.params.size();

@@ -36,6 +36,8 @@ COPRA_DEV void wave_sync_full() { __syncthreads(); }
 COPRA_DEV int atomic_append(int* counter) { return atomicAdd(counter, 1); }
 COPRA_DEV long long cycle_counter() { return (long long)__builtin_readcyclecounter(); } // s_memtime
 COPRA_DEV int atomic_add_i32(int* counter, int v) { return atomicAdd(counter, v); }
+// the flag of any lane of the wave (wave-uniform)
+COPRA_DEV bool wave_any(bool flag) { return __ballot(flag) != 0ull; }
 // number of lanes below this one whose flag is set (and the wave's total): one ballot, no LDS
 COPRA_DEV int wave_prefix_count(bool flag, int& total)
 {

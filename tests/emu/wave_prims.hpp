@@ -112,6 +112,12 @@ COPRA_DEV int wave_prefix_count(bool flag, int& total)
     emu::barrier_wave();
     return before;
 }
+COPRA_DEV bool wave_any(bool flag)
+{
+    int total = 0;
+    (void)wave_prefix_count(flag, total);
+    return total > 0;
+}
 COPRA_DEV void sched_fence() { }
 COPRA_DEV void mfma_settle() { } // (hardware wait states: nothing to emulate)
 COPRA_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
