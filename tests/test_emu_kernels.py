@@ -986,6 +986,39 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
+def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wave_is_decoupled(emu, oracle):
+    """the CoM model is three decoupled double integrators and its costs couple no two axes (FusedPlan::lane_axes): the pass neither writes
+    nor reads the twelve gains K(c, j), j % 3 != c, which are exactly zero then.  The systems are checked per WAVE: with ONE instance whose
+    A or B couples two axes its wave keeps every entry, the other waves do not -- results equal to the oracle's either way, and equal to
+    the decoupled batch's on the instances that were not touched"""
+    from copra_amd import workloads
+    b = 130  # (three waves)
+    wl = workloads.com_preview(b, seed=41)
+    args = lambda A, B: (A, B, wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])  # noqa: E731
+    base = emu.lmpc_solve(*args(wl["A"], wl["B"]))
+    A2, B2 = wl["A"].copy(), wl["B"].copy()
+    A2[5, 0, 4] = 0.03  # (x position picks up y velocity: instance 5, first wave)
+    B2[70, 3, 1] = 0.02  # (x velocity driven by the y control: instance 70, second wave)
+    re = emu.lmpc_solve(*args(A2, B2))
+    ro = oracle.lmpc_solve_batch(A2, B2, wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ro["status"] == 0
+    assert (re["status"] == ro["status"]).all() and ok.sum() >= b - 2
+    assert (re["iter"][ok] == ro["iter"][ok]).all()
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+    same = np.ones(b, dtype=bool)
+    same[[5, 70]] = False
+    assert np.array_equal(re["control"][same], base["control"][same]) and (re["iter"][same] == base["iter"][same]).all()
+    assert not np.allclose(re["control"][5], base["control"][5]) and not np.allclose(re["control"][70], base["control"][70])
+    # ... and a cost that couples the axes (a dense output map): the plan says so, nothing is skipped anywhere
+    rng = np.random.default_rng(3)
+    costs = [dict(wl["costs"][0], M=np.eye(6) + 0.1 * rng.standard_normal((6, 6))), wl["costs"][1]]
+    rc = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"])
+    rco = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], costs, wl["cstrs"], nthreads=8)
+    okc = rco["status"] == 0
+    assert (rc["status"] == rco["status"]).all() and (rc["iter"][okc] == rco["iter"][okc]).all()
+    assert _rel(rc["control"][okc], rco["control"][okc]) <= RTOL  # (a general output map: conditioning, as everywhere in this file)
+
+
 def test_lane_pass_with_more_rows_per_step_than_its_prefetch_buffer_holds(emu, oracle):
     """six rows per step (upper AND lower velocity limits as rows) in front of the pass, whose stage buffer carries the right-hand sides of
     the first four (lmpc_lane.hpp: RQ): the others are read in place -- with the controller's right-hand sides and with every instance's own"""

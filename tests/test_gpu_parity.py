@@ -177,6 +177,41 @@ def test_headline_full_size_properties(oracle):
     assert np.abs(x[:, 0] - wl["x0"]).max() <= 1e-12
 
 
+def test_lane_pass_skips_the_gains_between_decoupled_axes_per_wave(oracle):
+    """the one-instance-per-lane pass neither writes nor reads the gains between decoupled axes (FusedPlan::lane_axes; the systems of a wave
+    are checked by the pass itself): a batch of CoM systems with ONE instance whose A couples two axes and one whose B does -- their waves
+    keep every entry, the others skip twelve of eighteen; statuses, counters, U and X of both waves (and a sample of the rest) equal to the
+    oracle's, everything outside the two instances bit-equal to the decoupled batch's"""
+    from copra_amd import BatchLMPC, workloads
+    batch = 24576
+    wl = workloads.com_preview(batch, seed=43)
+
+    def solve(A, B):
+        eng = BatchLMPC(6, 3, wl["N"], batch, wl["costs"], wl["cstrs"])
+        eng.set_system(A, B, wl["d"], wl["x0"])
+        eng.solve()
+        res = eng.results()
+        assert eng.lane_pass_info()[0]
+        eng.close()
+        return res
+
+    base = solve(wl["A"], wl["B"])
+    A2, B2 = wl["A"].copy(), wl["B"].copy()
+    A2[64 * 3 + 5, 0, 4] = 0.03
+    B2[64 * 200 + 17, 3, 1] = 0.02
+    res = solve(A2, B2)
+    pick = np.unique(np.concatenate([np.arange(64 * 3, 64 * 4), np.arange(64 * 200, 64 * 201), np.linspace(0, batch - 1, 512).astype(int)]))
+    ref = oracle.lmpc_solve_batch(A2[pick], B2[pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    ok = ref["status"] == 0
+    assert (res["status"][pick] == ref["status"]).all() and ok.sum() >= len(pick) - 2
+    assert (res["iter"][pick][ok] == ref["iter"][ok]).all()
+    assert _rel(res["control"][pick][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][pick][ok], ref["trajectory"][ok]) <= RTOL
+    same = np.ones(batch, dtype=bool)
+    same[[64 * 3 + 5, 64 * 200 + 17]] = False
+    assert np.array_equal(res["control"][same], base["control"][same]) and np.array_equal(res["trajectory"][same], base["trajectory"][same])
+    assert (res["iter"][same] == base["iter"][same]).all()
+
+
 def test_config4_seed2_batch_as_eight_shards_on_one_gpu():
     """BASELINE.json configs[3] (batch 262144, seed 2, 8 x 32768 contiguous shards, one RCCL gather per step) has no 8-GPU box in
     this pool: its eight shards run here one after the other on ONE GPU through the very step loop a rank of `bench.py --gpus 8`
