@@ -415,10 +415,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     };
     // Decoupled axes (FusedPlan::lane_axes: the costs couple none; here: neither do the systems of this wave): K(c, j) is exactly zero for
     // j % NU != c at every stage -- the recursion stays axis by axis: sums of products with an exact zero factor -- so those entries are
-    // written to a row nobody reads and read from a row of zeros (two rows behind the workspace's own, each wave its 512 bytes of them,
-    // which never leave the L2): no branch, one scalar select per access.  12 of the 18 gains of the CoM model: what the pass writes and
-    // reads back is what it pays for (round 5: the zeros compiled out, 331 -> 270 k cycles per wave; tested per stage at run time the
-    // masks cost the sweep what they saved the roll-out).  The speculating build only: the hand-over form's tier gathers K from the workspace.
+    // neither formed nor written (stage_core below) and the roll-out reads them from a row of zeros behind the workspace's own (each wave
+    // its 512 bytes of it, which never leave the L1): no branch in its loop, one scalar select per load.  12 of the 18 gains of the CoM
+    // model: what the pass writes and reads back is what it pays for (round 5: tested per stage at run time the masks cost the sweep what
+    // they saved the roll-out; this test is one vote per wave).  The speculating build only: the hand-over form's tier gathers K from the
+    // workspace.
     bool axes = false;
     if constexpr (SPEC && NU > 1 && NX % NU == 0) {
         if (P.lane_axes) {
@@ -436,8 +437,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             axes = !wave_any(!(stray == 0.0)); // (a NaN couples)
         }
     }
-    double* const wdump = ws + ((size_t)NH * WR) * bp;
-    const double* const wzero = wdump + bp;
+    const double* const wzero = ws + ((size_t)NH * WR) * bp; // (plan.hpp: kLaneWsExtraRows)
     bool bad = false;
     for (int k = NH - 1; k >= 0; --k) {
         if constexpr (SREFS) stage_h(k);
@@ -447,119 +447,147 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #endif
         const double* const Hk = lds + hoff;
         double M[NZ][NZ], mz[NZ]; // upper triangle (a <= b)
-        {
-            double tq[NX], dl[NX]; // P+ d + p+  (d from this lane's slot: twelve registers less across the stage)
+        double Ni[NU][NU], K[NU][NX], kv[NU];
+        double* const wk = ws + ((size_t)k * WR) * bp; // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
+        // One stage of the sweep.  AXT: the wave's systems and the controller's costs couple no two axes (`axes` above) -- every matrix of the
+        // recursion is then zero between entries of different axes, exactly, and the products with those entries are left out: the SAME sums in
+        // the same order without the terms that are +-0 (841 -> ~ 190 multiply-adds per stage for three axes of a double integrator), the gains
+        // between axes neither formed nor stored.  `sm(a, b)`: z-indices a and b (states 0 .. NX-1, controls NX ..) belong to one axis.
+        auto stage_core = [&](auto axes_tag) {
+            constexpr bool AXT = decltype(axes_tag)::value;
+            auto sm = [](int a2, int b2) -> bool { return !AXT || (a2 < NX ? a2 % NU : a2 - NX) == (b2 < NX ? b2 % NU : b2 - NX); };
+            {
+                double tq[NX], dl[NX]; // P+ d + p+  (d from this lane's slot: twelve registers less across the stage)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dl[i] = lds[lane * HS + NZ + GL * NLU + NX + i];
+                for (int i = 0; i < NX; ++i) dl[i] = lds[lane * HS + NZ + GL * NLU + NX + i];
 #pragma unroll
-            for (int l = 0; l < NX; ++l) {
-                double s = pv[l];
+                for (int l = 0; l < NX; ++l) {
+                    double s = pv[l];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s += Ps(l, i) * dl[i];
-                tq[l] = s;
+                    for (int i = 0; i < NX; ++i)
+                        if (sm(l, i)) s += Ps(l, i) * dl[i];
+                    tq[l] = s;
+                }
+#pragma unroll
+                for (int a2 = 0; a2 < NZ; ++a2) {
+                    double s = lds[lane * HS + a2];
+#pragma unroll
+                    for (int l = 0; l < NX; ++l)
+                        if (sm(l, a2)) s += AB(l, a2) * tq[l];
+                    mz[a2] = s;
+                }
             }
 #pragma unroll
-            for (int a = 0; a < NZ; ++a) {
-                double s = lds[lane * HS + a];
+            for (int b2 = 0; b2 < NZ; ++b2) {
+                double Tb[NX]; // column b of P+ [A B]
 #pragma unroll
-                for (int l = 0; l < NX; ++l) s += AB(l, a) * tq[l];
-                mz[a] = s;
+                for (int l = 0; l < NX; ++l) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i)
+                        if (sm(l, i) && sm(i, b2)) s += Ps(l, i) * AB(i, b2);
+                    Tb[l] = s;
+                }
+#pragma unroll
+                for (int a2 = 0; a2 <= b2; ++a2) {
+                    if (sm(a2, b2)) {
+                        double s = Hk[a2 + NZ * b2];
+#pragma unroll
+                        for (int l = 0; l < NX; ++l)
+                            if (sm(l, a2)) s += AB(l, a2) * Tb[l];
+                        M[a2][b2] = s;
+                    } else {
+                        M[a2][b2] = 0.0;
+                    }
+                }
             }
-        }
+            // -M_uu^-1 (symmetric; positive definite <=> the trailing minors are positive)
+            if constexpr (NU == 1) {
+                const double m00 = M[NX][NX];
+                bad = bad || !(m00 > 0.0);
+                Ni[0][0] = -1.0 / m00;
+            } else if constexpr (NU == 2) {
+                const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m11 = M[NX + 1][NX + 1];
+                const double det = m00 * m11 - m01 * m01;
+                bad = bad || !(m11 > 0.0) || !(det > 0.0);
+                const double nr = -1.0 / det;
+                Ni[0][0] = m11 * nr;
+                Ni[0][1] = Ni[1][0] = -m01 * nr;
+                Ni[1][1] = m00 * nr;
+            } else {
+                const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m02 = M[NX][NX + 2], m11 = M[NX + 1][NX + 1], m12 = M[NX + 1][NX + 2],
+                             m22 = M[NX + 2][NX + 2];
+                const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+                const double det = m00 * c00 + (m01 * c01 + m02 * c02);
+                bad = bad || !(m22 > 0.0) || !(c00 > 0.0) || !(det > 0.0);
+                const double nr = -1.0 / det;
+                Ni[0][0] = c00 * nr;
+                Ni[0][1] = Ni[1][0] = c01 * nr;
+                Ni[0][2] = Ni[2][0] = c02 * nr;
+                Ni[1][1] = (m00 * m22 - m02 * m02) * nr;
+                Ni[1][2] = Ni[2][1] = (m01 * m02 - m00 * m12) * nr;
+                Ni[2][2] = (m00 * m11 - m01 * m01) * nr;
+            }
 #pragma unroll
-        for (int b = 0; b < NZ; ++b) {
-            double Tb[NX]; // column b of P+ [A B]
+            for (int c = 0; c < NU; ++c) {
 #pragma unroll
-            for (int l = 0; l < NX; ++l) {
+                for (int j = 0; j < NX; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NU; ++e)
+                        if (sm(j, NX + e) && sm(NX + c, NX + e)) s += Ni[c][e] * M[j][NX + e];
+                    K[c][j] = s;
+                }
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s += Ps(l, i) * AB(i, b);
-                Tb[l] = s;
+                for (int e = 0; e < NU; ++e)
+                    if (sm(NX + c, NX + e)) s += Ni[c][e] * mz[NX + e];
+                kv[c] = s;
             }
 #pragma unroll
-            for (int a = 0; a <= b; ++a) {
-                double s = Hk[a + NZ * b];
+            for (int j = 0; j < NX; ++j)
 #pragma unroll
-                for (int l = 0; l < NX; ++l) s += AB(l, a) * Tb[l];
-                M[a][b] = s;
+                for (int i = 0; i <= j; ++i) {
+                    if (!sm(i, j)) continue; // (stays the zero it has been since the terminal cost)
+                    double s = M[i][j];
+#pragma unroll
+                    for (int c = 0; c < NU; ++c)
+                        if (sm(i, NX + c)) s += M[i][NX + c] * K[c][j];
+                    Pm[i + NX * j] = s; // (i <= j)
+                }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double s = mz[i];
+#pragma unroll
+                for (int c = 0; c < NU; ++c)
+                    if (sm(i, NX + c)) s += M[i][NX + c] * kv[c];
+                pv[i] = s;
             }
-        }
-        // -M_uu^-1 (symmetric; positive definite <=> the trailing minors are positive)
-        double Ni[NU][NU];
-        if constexpr (NU == 1) {
-            const double m00 = M[NX][NX];
-            bad = bad || !(m00 > 0.0);
-            Ni[0][0] = -1.0 / m00;
-        } else if constexpr (NU == 2) {
-            const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m11 = M[NX + 1][NX + 1];
-            const double det = m00 * m11 - m01 * m01;
-            bad = bad || !(m11 > 0.0) || !(det > 0.0);
-            const double nr = -1.0 / det;
-            Ni[0][0] = m11 * nr;
-            Ni[0][1] = Ni[1][0] = -m01 * nr;
-            Ni[1][1] = m00 * nr;
+            if (!(COPRA_LANE_EXP & 128)) {
+#pragma unroll
+                for (int c = 0; c < NU; ++c) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j)
+                        if (sm(j, NX + c)) lane_put(wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]); // (between axes: nothing -- the roll-out does not read them)
+                    lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
+                }
+            } else if (k == 0) { // (experiment: the sweep leaves nothing -- something of it has to be alive)
+                lane_put(wk, ioff, K[0][0] + kv[0] + K[NU - 1][NX - 1]);
+            }
+        };
+        if constexpr (SPEC && NU > 1 && NX % NU == 0) {
+            if (axes)
+                stage_core(std::true_type {});
+            else
+                stage_core(std::false_type {});
         } else {
-            const double m00 = M[NX][NX], m01 = M[NX][NX + 1], m02 = M[NX][NX + 2], m11 = M[NX + 1][NX + 1], m12 = M[NX + 1][NX + 2],
-                         m22 = M[NX + 2][NX + 2];
-            const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-            const double det = m00 * c00 + (m01 * c01 + m02 * c02);
-            bad = bad || !(m22 > 0.0) || !(c00 > 0.0) || !(det > 0.0);
-            const double nr = -1.0 / det;
-            Ni[0][0] = c00 * nr;
-            Ni[0][1] = Ni[1][0] = c01 * nr;
-            Ni[0][2] = Ni[2][0] = c02 * nr;
-            Ni[1][1] = (m00 * m22 - m02 * m02) * nr;
-            Ni[1][2] = Ni[2][1] = (m01 * m02 - m00 * m12) * nr;
-            Ni[2][2] = (m00 * m11 - m01 * m01) * nr;
-        }
-        double K[NU][NX], kv[NU];
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                double s = 0.0;
-#pragma unroll
-                for (int e = 0; e < NU; ++e) s += Ni[c][e] * M[j][NX + e];
-                K[c][j] = s;
-            }
-            double s = 0.0;
-#pragma unroll
-            for (int e = 0; e < NU; ++e) s += Ni[c][e] * mz[NX + e];
-            kv[c] = s;
-        }
-#pragma unroll
-        for (int j = 0; j < NX; ++j)
-#pragma unroll
-            for (int i = 0; i <= j; ++i) {
-                double s = M[i][j];
-#pragma unroll
-                for (int c = 0; c < NU; ++c) s += M[i][NX + c] * K[c][j];
-                Pm[i + NX * j] = s; // (i <= j)
-            }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double s = mz[i];
-#pragma unroll
-            for (int c = 0; c < NU; ++c) s += M[i][NX + c] * kv[c];
-            pv[i] = s;
+            stage_core(std::false_type {});
         }
         if (k == 0) { // W = M_uu,0^-1 = -Ni, packed by rows: what the speculative steps of the roll-out compute with (parked in this lane's slot)
 #pragma unroll
             for (int i = 0; i < NU; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) lds[lane * HS + NZ + GL * NLU + 2 * NX + i * (i + 1) / 2 + j] = -Ni[i][j];
-        }
-        // (a wave-uniform row pointer + the lane's 32-bit index: one address register per lane, not one pair per store)
-        double* const wk = ws + ((size_t)k * WR) * bp;
-        if (!(COPRA_LANE_EXP & 128)) {
-#pragma unroll
-            for (int c = 0; c < NU; ++c) {
-#pragma unroll
-                for (int j = 0; j < NX; ++j) lane_put((axes && j % NU != c) ? wdump : wk + (size_t)(c + NU * j) * bp, ioff, K[c][j]);
-                lane_put(wk + (size_t)(NU * NX + c) * bp, ioff, kv[c]);
-            }
-        } else if (k == 0) { // (experiment: the sweep leaves nothing -- something of it has to be alive)
-            lane_put(wk, ioff, K[0][0] + kv[0] + K[NU - 1][NX - 1]);
         }
         // Lam^-1 (Lam Lam' = M_uu), packed by rows: what the two products of the factor use (ric_factor.hpp) -- for the first tier,
         // and only when it takes the factor over (FusedPlan::lane_handover; round-3 advisor finding: in front of the other tiers the
