@@ -434,11 +434,7 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
         h->lane_cur = 1;
     }
     if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
-    {
-        const size_t rows = (size_t)P.N * lane_ws_rows(P.nx, P.nu);
-        e = hipMalloc((void**)&h->d_lane_ws, (rows + kLaneWsExtraRows) * bp * sizeof(double));
-        if (e == hipSuccess) e = hipMemset(h->d_lane_ws + rows * bp, 0, kLaneWsExtraRows * bp * sizeof(double)); // (the row of zeros stays what it is)
-    }
+        e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
     const bool hand_over = P.lds.ricC && !h->hp.opt.no_lane_handover && (h->hp.opt.no_lane_spec || h->ad.lane_form_handover); // (solve_one_wave: the form of the pass that hands blocks over)
     if (e == hipSuccess && need_ws && hand_over && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
         e = hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double));

@@ -415,11 +415,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     };
     // Decoupled axes (FusedPlan::lane_axes: the costs couple none; here: neither do the systems of this wave): K(c, j) is exactly zero for
     // j % NU != c at every stage -- the recursion stays axis by axis: sums of products with an exact zero factor -- so those entries are
-    // neither formed nor written (stage_core below) and the roll-out reads them from a row of zeros behind the workspace's own (each wave
-    // its 512 bytes of it, which never leave the L1): no branch in its loop, one scalar select per load.  12 of the 18 gains of the CoM
-    // model: what the pass writes and reads back is what it pays for (round 5: tested per stage at run time the masks cost the sweep what
-    // they saved the roll-out; this test is one vote per wave).  The speculating build only: the hand-over form's tier gathers K from the
-    // workspace.
+    // neither formed nor written (stage_core below) nor read (roll_groups), and the products with the entries of A, B, P and K between axes
+    // are left out of both phases: the same sums in the same order without the terms that are +-0 -- bit-identical results, 841 -> ~ 190
+    // multiply-adds per stage of the sweep for the CoM model (three double integrators), 12 of its 18 gains never in memory.  ONE vote per
+    // wave decides (round 5 had tried masks tested per stage: they cost the sweep what they saved the roll-out).  The speculating build
+    // only: the hand-over form's tier gathers K from the workspace.
     bool axes = false;
     if constexpr (SPEC && NU > 1 && NX % NU == 0) {
         if (P.lane_axes) {
@@ -437,8 +437,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             axes = !wave_any(!(stray == 0.0)); // (a NaN couples)
         }
     }
-    const double* const wzero = ws + ((size_t)NH * WR) * bp; // (plan.hpp: kLaneWsExtraRows)
     bool bad = false;
+    // (the sweep, the hand-over between the phases and the roll-out are DEFINED in this order and run further down, one build of each per kind of
+    //  wave -- decoupled axes or not: ONE branch around all three; with one branch per phase the register allocator left two values of the
+    //  dense sweep in scratch memory)
+    auto sweep_all = [&](auto axes_tag) {
     for (int k = NH - 1; k >= 0; --k) {
         if constexpr (SREFS) stage_h(k);
         int hoff = oHl_;
@@ -575,14 +578,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 lane_put(wk, ioff, K[0][0] + kv[0] + K[NU - 1][NX - 1]);
             }
         };
-        if constexpr (SPEC && NU > 1 && NX % NU == 0) {
-            if (axes)
-                stage_core(std::true_type {});
-            else
-                stage_core(std::false_type {});
-        } else {
-            stage_core(std::false_type {});
-        }
+        stage_core(axes_tag);
         if (k == 0) { // W = M_uu,0^-1 = -Ni, packed by rows: what the speculative steps of the roll-out compute with (parked in this lane's slot)
 #pragma unroll
             for (int i = 0; i < NU; ++i)
@@ -649,7 +645,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             }
         }
     }
-
+    };
+    auto mid = [&]() {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         double xi = lds[lane * HS + NZ + GL * NLU + i], di = lds[lane * HS + NZ + GL * NLU + NX + i];
@@ -671,6 +668,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
 #pragma unroll
         for (int e = 0; e < NL; ++e) lds[kWave * (((kLaneGroup * NX) | 1) + ((kLaneGroup * NU) | 1)) + lane * ((kLaneGroup * NX) | 1) + e] = w0[e];
     }
+    };
     // ---- 2. roll-out from x0 with qpgen2's first scan inside: rows of step k on (x_k, u_k), the bounds of u_k ----
     const double vsmall = P.vsmall;
     const int rps = P.lane_rps;
@@ -697,12 +695,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     const double* const rhs_mine = P.row_f_inst ? P.row_f_inst + (size_t)li * P.mgen : nullptr;
     constexpr int RQ = 4, KF = KW + 2 * NU + RQ; // a stage's buffer: K | kv | ub | lb | f of its first rows
     auto row_index = [&](int ro) -> int { return tlds ? (int)Tl[ro + NZ + 1] : (int)uniform_load(tab, oRows + ro + NZ + 1); }; // (ro: the row's offset in the table)
-    auto fetch_stage = [&](double (&buf)[KF], int k) {
+    auto fetch_stage = [&](auto axes_tag, double (&buf)[KF], int k) {
+        constexpr bool AXT = decltype(axes_tag)::value; // (decoupled axes: the gains between them are not there -- and not used, roll_groups below)
         const int kk = k < NH ? k : NH - 1; // (past the end: the last stage once more, unused)
         const double* const wk = ws + ((size_t)kk * WR) * bp;
 #pragma unroll
-        for (int e = 0; e < KW; ++e) // (entry e < NU NX of the gains: K(e % NU, e / NU))
-            buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get((axes && e < NU * NX && (e / NU) % NU != e % NU) ? wzero : wk + (size_t)e * bp, ioff);
+        for (int e = 0; e < KW; ++e) { // (entry e < NU NX of the gains: K(e % NU, e / NU))
+            if (AXT && e < NU * NX && (e / NU) % NU != e % NU)
+                buf[e] = 0.0;
+            else
+                buf[e] = (COPRA_LANE_EXP & 2) ? 1e-3 * (e + kk) : lane_get(wk + (size_t)e * bp, ioff);
+        }
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
             buf[KW + c] = ubp[kk * NU + c];
@@ -747,15 +750,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         scl[l] = -1;
         sst[l] = sst2[l] = 0.0;
     }
-    violl[0] = bad;
     double bmin[kSpec + 1], bmin_other[kSpec + 1]; // worst bound slack per level: of all bounds | of those that are not the next level's pick
 #pragma unroll
     for (int l = 0; l <= kSpec; ++l) bmin[l] = bmin_other[l] = 0.0;
     double xs[kSpec + 1][NX]; // xs[0]: the unconstrained minimiser's trajectory (x above)
+    auto mid2 = [&]() { // (what the roll-out starts from, once the sweep is behind it)
+        violl[0] = bad;
 #pragma unroll
-    for (int l = 0; l <= kSpec; ++l)
+        for (int l = 0; l <= kSpec; ++l)
 #pragma unroll
-        for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
+            for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
+    };
     // one row  e' x + g' u <= f  at every iterate
     auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU]) {
 #pragma unroll
@@ -817,11 +822,17 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     for (int e = 0; e < NX * NU; ++e) Gp[e] = B[e];
 #pragma unroll
     for (int i = 0; i < NX; ++i) ncum[i] = 0.0;
-    double Kq[KB][KF];
-#pragma unroll
-    for (int q = 0; q < KB; ++q) fetch_stage(Kq[q], q);
     constexpr bool fine = (COPRA_LANE_EXP & 64) != 0; // (experiment: where the roll-out's cycles go -- gains and controls | rows and bounds | dynamics; the rest is the store phase)
     long long fineA = 0, fineB = 0, fineC = 0, fineT = 0;
+    // The roll-out's loop, in two builds: AXT -- decoupled axes (`axes`, see the sweep): the products with the entries of A, B and K between
+    // axes are left out of u = K x + kv and x+ = A x + B u + d (the same sums without the terms that are exactly zero) and those gains
+    // are not read.
+    auto roll_groups = [&](auto axes_tag) {
+    constexpr bool AXT = decltype(axes_tag)::value;
+    auto sm = [](int a2, int b2) -> bool { return !AXT || (a2 < NX ? a2 % NU : a2 - NX) == (b2 < NX ? b2 % NU : b2 - NX); };
+    double Kq[KB][KF];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) fetch_stage(axes_tag, Kq[q], q);
     for (int k0 = 0; k0 < NH; k0 += GS) {
         wave_sync(); // (the previous group has left the staging area)
 #pragma unroll
@@ -844,10 +855,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int c = 0; c < NU; ++c) {
                     double acc = Kq[q % KB][NU * NX + c];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc += Kq[q % KB][c + NU * j] * xs[l][j];
+                    for (int j = 0; j < NX; ++j)
+                        if (sm(j, NX + c)) acc += Kq[q % KB][c + NU * j] * xs[l][j];
                     us[l][c] = acc;
                 }
-            fetch_stage(Kq[q % KB], k + KB);
+            fetch_stage(axes_tag, Kq[q % KB], k + KB);
             if (fine) {
                 double a0 = us[kSpec][0];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -935,9 +947,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NX; ++i) {
                     double acc = d[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc += A[i + NX * j] * xs[l][j];
+                    for (int j = 0; j < NX; ++j)
+                        if (sm(i, j)) acc += A[i + NX * j] * xs[l][j];
 #pragma unroll
-                    for (int c = 0; c < NU; ++c) acc += B[i + NX * c] * us[l][c];
+                    for (int c = 0; c < NU; ++c)
+                        if (sm(i, NX + c)) acc += B[i + NX * c] * us[l][c];
                     xn[i] = acc;
                 }
 #pragma unroll
@@ -961,6 +975,21 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
         if (handover) // the group's norm sums of every instance: one contiguous segment of its hand-over block
             lane_group_out<GS * NX>(ws2 + (size_t)NH * NLU + (size_t)k0 * NX, (size_t)T2, ldn, SX, ninst, (NH - k0 < GS ? NH - k0 : GS) * NX, lane);
+    }
+    };
+    auto sweep_and_roll_out = [&](auto axes_tag) {
+        sweep_all(axes_tag);
+        mid();
+        mid2();
+        roll_groups(axes_tag);
+    };
+    if constexpr (SPEC && NU > 1 && NX % NU == 0) {
+        if (axes)
+            sweep_and_roll_out(std::true_type {});
+        else
+            sweep_and_roll_out(std::false_type {});
+    } else {
+        sweep_and_roll_out(std::false_type {});
     }
     { // the last state: its rows, and out
         double u0[kSpec + 1][NU];

@@ -234,7 +234,6 @@ COPRA_HD inline void lane_tab_offsets(int nx, int nu, int& oh, int& oHN, int& oh
 // rows of its LANE-MAJOR workspace per stage: K (nu x nx, column-major) | kv (nu) -- what its own roll-out reads back (and the first tier
 // gathers K from: lmpc_fused_ric.hpp, from_lane)
 COPRA_HD inline int lane_ws_rows(int nx, int nu) { return nu * nx + nu; }
-constexpr int kLaneWsExtraRows = 1; // behind the N stages' rows: a row of zeros (lmpc_lane.hpp: what the roll-out reads for the gains between decoupled axes)
 // ... and doubles per instance of its INSTANCE-MAJOR hand-over block (FusedPlan::lane_ws2; round 5): what only the first tier reads --
 // Lam^-1 (packed by rows, as RicRec) and kv of every stage ([N][nu (nu + 1) / 2 + nu]), then the running sums of the squared block-row
 // norms of G_s = A^s B ([N][nx]).  Until round 5 these were twelve more lane-major rows per stage: the tier fetched each of the 240 values of an

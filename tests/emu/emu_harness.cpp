@@ -346,7 +346,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     if (lane_pass) {
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = (dims->batch + 63) / 64 * 64 + 64;
-        lane_ws.assign(((size_t)P.N * lane_ws_rows(P.nx, P.nu) + kLaneWsExtraRows) * P.lane_bp, 0.0);
+        lane_ws.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * P.lane_bp, 0.0);
         P.lane_ws = lane_ws.data();
         lane_ws2.assign((size_t)P.lane_bp * lane_ws2_doubles(P.nx, P.nu, P.N), 0.0);
         P.lane_ws2 = lane_ws2.data();
