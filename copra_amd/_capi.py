@@ -50,7 +50,7 @@ class Options(C.Structure):
     _fields_ = ([("struct_size", C.c_int)]
                 + [(n, C.c_int) for n in ("no_stage_refs", "no_step_rows", "no_selection_rows",
                                            "no_ric", "no_tri", "ric_general", "no_dense_layout", "no_q1regs", "no_ladder", "no_packed", "ric_k",
-                                           "no_lane_pass", "no_lane_handover", "no_lane_spec", "lane_min_batch", "no_ric_shared",
+                                           "no_lane_pass", "no_lane_handover", "no_lane_spec", "no_lane_axes", "lane_min_batch", "no_ric_shared",
                                            "no_riccati", "no_ric_fast")]
                 + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol")]
                 + [("debug", C.c_int)])

@@ -453,7 +453,7 @@ inline void build_lane_tables(HostPlan& hp)
     }
     { // axis-decoupled costs (FusedPlan::lane_axes): H(a, b) = 0 and HN(a, b) = 0 wherever a and b belong to different axes
         auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
-        bool ok = nu > 1 && nx % nu == 0;
+        bool ok = nu > 1 && nx % nu == 0 && !hp.opt.no_lane_axes;
         for (int a = 0; a < nz && ok; ++a)
             for (int b = 0; b < nz && ok; ++b) {
                 if (axis(a) == axis(b)) continue;

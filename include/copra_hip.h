@@ -151,6 +151,8 @@ typedef struct {
     int no_lane_pass;
     int no_lane_handover; /* the pass only filters; the tier sweeps itself */
     int no_lane_spec; /* the pass does not take the first step of the active-set iteration itself (a bound on u_0 as the first pick) */
+    int no_lane_axes; /* the pass treats every system as dense: decoupled axes (FusedPlan::lane_axes -- state i on axis i % nu, control c on axis c, nothing
+                         between them in A, B and the costs: the CoM model) are not looked for, no product is left out */
     int lane_min_batch; /* smallest batch that runs the pass (0: 20480 in front of the Riccati-factor tier, 4096 elsewhere; -1: any) */
     /* shared-model mode */
     int no_ric_shared; /* lmpc_shared.hpp instead of the Riccati-factor tier's shared-model mode */

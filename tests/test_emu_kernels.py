@@ -986,7 +986,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
-def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wave_is_decoupled(emu, oracle):
+def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wave_is_decoupled(emu, oracle, monkeypatch):
     """the CoM model is three decoupled double integrators and its costs couple no two axes (FusedPlan::lane_axes): the pass neither writes
     nor reads the twelve gains K(c, j), j % 3 != c, which are exactly zero then.  The systems are checked per WAVE: with ONE instance whose
     A or B couples two axes its wave keeps every entry, the other waves do not -- results equal to the oracle's either way, and equal to
@@ -996,6 +996,12 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     wl = workloads.com_preview(b, seed=41)
     args = lambda A, B: (A, B, wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])  # noqa: E731
     base = emu.lmpc_solve(*args(wl["A"], wl["B"]))
+    # the structured sweep and roll-out leave out products that are exactly zero, nothing else: bit for bit the dense ones' results
+    monkeypatch.setitem(OPTIONS, "no_lane_axes", 1)
+    dense = emu.lmpc_solve(*args(wl["A"], wl["B"]))
+    monkeypatch.setitem(OPTIONS, "no_lane_axes", 0)
+    assert np.array_equal(dense["control"], base["control"]) and np.array_equal(dense["trajectory"], base["trajectory"])
+    assert (dense["iter"] == base["iter"]).all() and (dense["status"] == base["status"]).all()
     A2, B2 = wl["A"].copy(), wl["B"].copy()
     A2[5, 0, 4] = 0.03  # (x position picks up y velocity: instance 5, first wave)
     B2[70, 3, 1] = 0.02  # (x velocity driven by the y control: instance 70, second wave)
