@@ -713,7 +713,8 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         }
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
-            const int ro = (kk * rps + (r < rps ? r : 0)) * RW;
+            const int kr = k < NH ? k : NH; // (the rows of the LAST STATE ride with the request past the end: read behind the loop, roll_groups)
+            const int ro = (kr * rps + (r < rps ? r : 0)) * RW;
             const int idx = r < rps ? row_index(ro) : -1;
             const double* const fp = r >= rps ? tab : (rhs_mine && idx >= 0) ? rhs_mine + idx : tab + oRows + ro + NZ;
             buf[KW + 2 * NU + r] = *fp;
@@ -976,6 +977,23 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
         if (handover) // the group's norm sums of every instance: one contiguous segment of its hand-over block
             lane_group_out<GS * NX>(ws2 + (size_t)NH * NLU + (size_t)k0 * NX, (size_t)T2, ldn, SX, ninst, (NH - k0 < GS ? NH - k0 : GS) * NX, lane);
     }
+    { // the last state's rows: their right-hand sides came with the last request (stage NH - 1 + KB >= NH: buffer (NH - 1) % KB ... the one
+      // refilled last) -- read in place they waited for the results' stores in flight, three times
+        double u0[kSpec + 1][NU], fl[RQ];
+#pragma unroll
+        for (int l = 0; l <= kSpec; ++l)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) u0[l][c] = 0.0;
+        const int qb = (NH - 1) % KB; // (stage NH - 1 refilled its own buffer last, with the request for stage NH - 1 + KB)
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+            double v = Kq[0][KW + 2 * NU + r];
+#pragma unroll
+            for (int t = 1; t < KB; ++t) v = (t == qb) ? Kq[t][KW + 2 * NU + r] : v;
+            fl[r] = v;
+        }
+        check_rows(NH, xs, u0, fl);
+    }
     };
     auto sweep_and_roll_out = [&](auto axes_tag) {
         sweep_all(axes_tag);
@@ -991,13 +1009,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     } else {
         sweep_and_roll_out(std::false_type {});
     }
-    { // the last state: its rows, and out
-        double u0[kSpec + 1][NU];
-#pragma unroll
-        for (int l = 0; l <= kSpec; ++l)
-#pragma unroll
-            for (int c = 0; c < NU; ++c) u0[l][c] = 0.0;
-        check_rows(NH, xs, u0, nullptr);
+    { // the last state: out
         if (valid) {
             double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
 #pragma unroll
