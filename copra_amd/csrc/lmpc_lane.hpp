@@ -250,6 +250,29 @@ COPRA_DEV void lane_spec_steps(const double (&W)[NU][NU], const double (&ubk)[NU
     }
 }
 
+// The same on DECOUPLED AXES (lmpc_lane_body: `axes`).  The QP separates axis by axis there -- Q^-1 is block diagonal, a bound on a control of
+// axis c touches axis c only -- so the active-set run of the whole problem is an interleaving of the axes' own runs: the picks of different axes
+// do not see each other (no multiplier of one axis moves when another takes a step, nothing is dropped), the counters add up, and the order
+// between axes does not matter.  So EVERY axis whose bound on u_0 is violated takes its step at once -- W is diagonal: the control lands on
+// its bound -- and ONE more trajectory carries all of them: the iterate after as many steps as axes stepped.
+template <int NU>
+COPRA_DEV void lane_spec_axes(const double (&W)[NU][NU], const double (&ubk)[NU], const double (&lbk)[NU], const double (&u0)[NU], double (&u1)[NU],
+    double vsmall, bool bad, bool (&stepped)[NU], double (&sst)[NU])
+{
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+        const double slu = ubk[c] - u0[c], sll = u0[c] - lbk[c];
+        const bool vu = slu <= -vsmall, vl = sll <= -vsmall; // (qpgen2's order: the upper bound before the lower one)
+        const double best = vu ? slu : sll, sig = vu ? -1.0 : 1.0;
+        const double z = sig * W[c][c], zn = W[c][c]; // z = H n, n = sig e_c; z'n = |Lam^-1 e_c|^2
+        const bool go = (vu || vl) && !bad && !(ubk[c] - lbk[c] <= -vsmall) && zn > 0.0 && z * z > vsmall; // (as lane_spec_steps, level 1)
+        const double t2 = go ? -best / zn : 0.0;
+        u1[c] = go ? u0[c] + t2 * z : u0[c];
+        stepped[c] = go;
+        sst[c] = go ? best : 0.0;
+    }
+}
+
 // SREFS: the build for controllers with reference trajectories (FusedPlan::stage_refs) -- its own instantiation, so that the registers of
 // stage_h below are not the headline's (measured on the one build for both: 3 VGPRs of the sweep in scratch memory)
 // SPEC: the build that takes the first steps of the active-set iteration itself (FusedPlan::lane_spec); without it no trajectory rides along
@@ -738,7 +761,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     // slack <= -vsmall with the active rows left out; near-ties (1e-9 relative) go to the tier.  A lane writes its DEEPEST trajectory to
     // the results -- levels it does not speculate on repeat the one before, the verdict comes last --, which is why the tier behind this
     // pass rolls out for itself (lmpc_fused_ric.hpp, from_lane).
-    constexpr int kSpec = !SPEC ? 0 : NU >= 2 ? 2 : 1; // levels: steps taken here at most (a third one on u_0 would fix all of it: 1 % of the headline's batch)
+#ifndef COPRA_LANE_KSPEC
+#define COPRA_LANE_KSPEC 2
+#endif
+    constexpr int kSpec = !SPEC ? 0 : NU >= 2 ? COPRA_LANE_KSPEC : 1; // levels: steps taken here at most (a third one on u_0 would fix all of it: 1 % of the headline's batch)
     const bool spec_on = SPEC && P.lane_spec != 0; // (the controller's rows are the compact variant's: one component of a state, or controls only)
     bool specl[kSpec + 1], uniql[kSpec + 1], violl[kSpec + 1]; // [l]: level l was speculated on | its pick was the pick | trajectory l violates something
     int scl[kSpec + 1]; // component of u_0 whose bound level l >= 1 adds (-1: none)
@@ -763,9 +789,10 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int c = 0; c < NX; ++c) xs[l][c] = x[c];
     };
     // one row  e' x + g' u <= f  at every iterate
-    auto row_eval = [&](const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU]) {
+    auto row_eval = [&](auto levels_tag, const double (&e)[NX], const double (&g)[NU], double f, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU]) {
+        constexpr int KS = decltype(levels_tag)::value; // (levels carried: kSpec, or 1 on decoupled axes)
 #pragma unroll
-        for (int l = 0; l <= kSpec; ++l) {
+        for (int l = 0; l <= KS; ++l) {
             double ax = 0.0;
 #pragma unroll
             for (int c = 0; c < NX; ++c) ax += e[c] * xk[l][c];
@@ -779,11 +806,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             // |row of Psi|^2, a recursion G <- A G of its own through the roll-out: 126 multiply-adds per stage and 48 registers, the ones that sent
             // the roll-out to scratch memory.  Measured on the headline's batch: 186 of 65 536 instances ended here by that comparison, the pass
             // 278 -> 208 k cycles per wave without it.)
-            if (l < kSpec) uniql[l + 1] = uniql[l + 1] && !v;
+            if (l < KS) uniql[l + 1] = uniql[l + 1] && !v;
         }
     };
     // E x_k + G u_k <= f: the rows of step k; fq: the right-hand sides of its first RQ rows as fetch_stage left them (nullptr: none were fetched)
-    auto check_rows = [&](int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU], const double* fq) {
+    auto check_rows = [&](auto levels_tag, int k, const double (&xk)[kSpec + 1][NX], const double (&uk)[kSpec + 1][NU], const double* fq) {
         for (int r = 0; r < rps; ++r) {
             double e[NX], g[NU];
             const int ro = (k * rps + r) * RW;
@@ -807,7 +834,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 const double* const fp = (rhs_mine && idx >= 0) ? rhs_mine + idx : tab + oRows + ro + NZ;
                 f = *fp;
             }
-            row_eval(e, g, f, xk, uk);
+            row_eval(levels_tag, e, g, f, xk, uk);
         }
     };
 #ifndef COPRA_LANE_KB
@@ -828,9 +855,21 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
     // The roll-out's loop, in two builds: AXT -- decoupled axes (`axes`, see the sweep): the products with the entries of A, B and K between
     // axes are left out of u = K x + kv and x+ = A x + B u + d (the same sums without the terms that are exactly zero) and those gains
     // are not read.
+    int axes_iters = -1; // (decoupled axes: qpgen2's first counter of an instance that ends here, 0: it does not -- set by roll_groups)
     auto roll_groups = [&](auto axes_tag) {
     constexpr bool AXT = decltype(axes_tag)::value;
     auto sm = [](int a2, int b2) -> bool { return !AXT || (a2 < NX ? a2 % NU : a2 - NX) == (b2 < NX ? b2 % NU : b2 - NX); };
+    // decoupled axes: ONE more trajectory -- every axis whose bound on u_0 is violated takes its step in it (lane_spec_axes) -- and the
+    // bookkeeping per AXIS: did it step | the slack of its pick | its worst bound slack at the minimiser, the same without the pick, and after the step
+    constexpr int KS = AXT ? (kSpec > 0 ? 1 : 0) : kSpec;
+    using levels_t = std::integral_constant<int, KS>;
+    bool ax_step[NU];
+    double ax_sst[NU], ax_b0[NU], ax_b0o[NU], ax_b1[NU];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) {
+        ax_step[c] = false;
+        ax_sst[c] = ax_b0[c] = ax_b0o[c] = ax_b1[c] = 0.0;
+    }
     double Kq[KB][KF];
 #pragma unroll
     for (int q = 0; q < KB; ++q) fetch_stage(axes_tag, Kq[q], q);
@@ -851,7 +890,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int r = 0; r < RQ; ++r) fk[r] = Kq[q % KB][KW + 2 * NU + r];
             double us[kSpec + 1][NU];
 #pragma unroll
-            for (int l = 0; l <= kSpec; ++l)
+            for (int l = 0; l <= KS; ++l)
 #pragma unroll
                 for (int c = 0; c < NU; ++c) {
                     double acc = Kq[q % KB][NU * NX + c];
@@ -862,11 +901,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 }
             fetch_stage(axes_tag, Kq[q % KB], k + KB);
             if (fine) {
-                double a0 = us[kSpec][0];
+                double a0 = us[KS][0];
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : "+v"(a0)); // (the controls are there)
 #endif
-                us[kSpec][0] = a0;
+                us[KS][0] = a0;
                 const long long t = cycle_counter();
                 fineA += t - fineT;
                 fineT = t;
@@ -878,11 +917,28 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NU; ++i)
 #pragma unroll
                     for (int j = 0; j <= i; ++j) W[i][j] = W[j][i] = ldn[lane * SX + i * (i + 1) / 2 + j];
-                if constexpr (kSpec > 0) lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
+                if constexpr (AXT && kSpec > 0)
+                    lane_spec_axes<NU>(W, ubk, lbk, us[0], us[1], vsmall, bad, ax_step, ax_sst);
+                else if constexpr (kSpec > 0)
+                    lane_spec_steps<NU, kSpec>(W, ubk, lbk, us, vsmall, bad, specl, scl, sst, sst2);
             }
             if (on) {
-                if (!(COPRA_LANE_EXP & 8)) check_rows(k, xs, us, fk);
-                if (!(COPRA_LANE_EXP & 16)) {
+                if (!(COPRA_LANE_EXP & 8)) check_rows(levels_t {}, k, xs, us, fk);
+                if constexpr (AXT) { // the bounds of u_k, axis by axis (the pick and, after the step, the active bound -- stage 0 only -- left out)
+                    const bool stage0 = q == 0 && k0 == 0;
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) {
+                        const double m0 = fmin(ubk[c] - us[0][c], us[0][c] - lbk[c]);
+                        nviol += (m0 <= -vsmall) ? 1 : 0;
+                        const bool mine = stage0 && ax_step[c];
+                        ax_b0[c] = fmin(ax_b0[c], m0);
+                        ax_b0o[c] = fmin(ax_b0o[c], mine ? 0.0 : m0);
+                        if constexpr (KS > 0) {
+                            const double m1 = fmin(ubk[c] - us[1][c], us[1][c] - lbk[c]);
+                            ax_b1[c] = fmin(ax_b1[c], mine ? 0.0 : m1);
+                        }
+                    }
+                } else if (!(COPRA_LANE_EXP & 16)) {
                     // the bounds of u_k at every iterate: the worst slack per level is all that is kept -- a level violates a bound iff its
                     // minimum is <= -vsmall, and the next level's pick was not the pick iff the minimum (the active bounds and the pick itself
                     // left out: they only exist at stage 0) comes within 1e-9 of its slack.  Two subtractions and two minima per bound and level.
@@ -938,11 +994,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             }
             // (the deepest trajectory: levels without a step repeat the one before)
 #pragma unroll
-            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = xs[kSpec][c];
+            for (int c = 0; c < NX; ++c) ldx[lane * SX + q * NX + c] = xs[KS][c];
 #pragma unroll
-            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = us[kSpec][c];
+            for (int c = 0; c < NU; ++c) ldu[lane * SU + q * NU + c] = us[KS][c];
 #pragma unroll
-            for (int l = 0; l <= kSpec; ++l) {
+            for (int l = 0; l <= KS; ++l) {
                 double xn[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -959,11 +1015,11 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
                 for (int i = 0; i < NX; ++i) xs[l][i] = on ? xn[i] : xs[l][i];
             }
             if (fine) {
-                double a0 = xs[kSpec][0];
+                double a0 = xs[KS][0];
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : "+v"(a0));
 #endif
-                xs[kSpec][0] = a0;
+                xs[KS][0] = a0;
                 fineC += cycle_counter() - fineT;
             }
             sched_fence(); // (nothing of the next stage moves up here: its operands would be live twice)
@@ -992,7 +1048,29 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             for (int t = 1; t < KB; ++t) v = (t == qb) ? Kq[t][KW + 2 * NU + r] : v;
             fl[r] = v;
         }
-        check_rows(NH, xs, u0, fl);
+        check_rows(levels_t {}, NH, xs, u0, fl);
+        if (valid) { // the last state: out
+            double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xo[c] = xs[KS][c];
+        }
+    }
+    if constexpr (AXT) {
+        // the verdict on decoupled axes: every axis either violates no bound, or its bound on u_0 was its pick -- strictly its worst, and no ROW is
+        // violated at the minimiser (whose normalised slack would have to be compared) -- and after the step it violates none; the rows hold at the
+        // last iterate.  qpgen2's counters: one iteration per axis that stepped, and the scan that finds nothing; nothing dropped.
+        bool okv = valid && !bad && !violl[KS] && (KS == 0 || uniql[KS]);
+        int steps = 0;
+        bool any0 = violl[0];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+            any0 = any0 || (ax_b0[c] <= -vsmall);
+            const bool st = ax_step[c];
+            steps += st ? 1 : 0;
+            okv = okv && (st ? (!(ax_b0o[c] <= -vsmall && ax_b0o[c] <= ax_sst[c] * (1.0 - 1e-9)) && !(ax_b1[c] <= -vsmall)) : !(ax_b0[c] <= -vsmall));
+        }
+        violl[0] = any0;
+        axes_iters = okv ? 1 + steps : 0;
     }
     };
     auto sweep_and_roll_out = [&](auto axes_tag) {
@@ -1008,13 +1086,6 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             sweep_and_roll_out(std::false_type {});
     } else {
         sweep_and_roll_out(std::false_type {});
-    }
-    { // the last state: out
-        if (valid) {
-            double* const xo = P.trajectory + (size_t)inst * P.X + (size_t)NH * NX;
-#pragma unroll
-            for (int c = 0; c < NX; ++c) xo[c] = xs[kSpec][c];
-        }
     }
     // the verdict: the first level that violates nothing, if every pick on the way to it was the pick
 #pragma unroll
@@ -1033,6 +1104,7 @@ COPRA_DEV void lmpc_lane_body(const FusedPlan& P, int group)
             chain = chain && violl[l]; // (a deeper level only exists behind a violated one)
         }
     }
+    if (axes_iters >= 0) done_iters = axes_iters; // (decoupled axes: the verdict was taken axis by axis, roll_groups)
     const bool done1 = done_iters >= 2; // finished by the bounds on u_0 it speculated on
 
     stamp[3] = P.prof ? cycle_counter() : 0;

@@ -924,7 +924,7 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
     ok = ro["status"] == 0
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
-    one_bound = int(((ro["iter"][:, 0] >= 2) & (ro["iter"][:, 0] <= 3) & (ro["iter"][:, 1] == 0) & ok).sum())
+    one_bound = int(((ro["iter"][:, 0] >= 2) & (ro["iter"][:, 0] <= 4) & (ro["iter"][:, 1] == 0) & ok).sum())  # (up to one bound on u_0 per axis: (2, 0) ... (4, 0))
     if mode == "spec":  # (round 5: the pass also takes the first TWO steps of the iteration where bounds on u_0 are the picks)
         assert at_minimiser <= re["lane_pass_finished"] <= at_minimiser + one_bound
     else:
@@ -954,7 +954,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0), (4, 0)))
     assert 0 < finished <= re["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # per-instance cost references (every instance its own goal): the pass rebuilds its affine terms per lane from the plan's coefficient
     # table
@@ -968,7 +968,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re2["iter"][k]) == tuple(ro["iter"]) and _rel(re2["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0), (4, 0)))
     assert 0 < finished <= re2["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
     # ... and per-instance right-hand sides (every instance its own velocity limit): every lane reads its own row of the table
     vlim = 0.6 * rng.uniform(0.7, 1.2, b)
@@ -982,7 +982,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
         if ro["status"] == 0:
             assert tuple(re3["iter"][k]) == tuple(ro["iter"]) and _rel(re3["control"][k], ro["control"]) <= 1e-9
             finished += int(ro["iter"][0] == 1)
-            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0)))
+            one_bound += int(tuple(ro["iter"]) in ((2, 0), (3, 0), (4, 0)))
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
@@ -1000,8 +1000,13 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     monkeypatch.setitem(OPTIONS, "no_lane_axes", 1)
     dense = emu.lmpc_solve(*args(wl["A"], wl["B"]))
     monkeypatch.setitem(OPTIONS, "no_lane_axes", 0)
-    assert np.array_equal(dense["control"], base["control"]) and np.array_equal(dense["trajectory"], base["trajectory"])
+    # (the instances both end in the pass: up to two bounds on u_0; a third one ends there on decoupled axes only -- one step per axis in ONE more
+    #  trajectory -- and in the tier otherwise: the same result to rounding)
+    both = base["iter"][:, 0] <= 3
+    assert both.sum() > b // 2
+    assert np.array_equal(dense["control"][both], base["control"][both]) and np.array_equal(dense["trajectory"][both], base["trajectory"][both])
     assert (dense["iter"] == base["iter"]).all() and (dense["status"] == base["status"]).all()
+    assert _rel(dense["control"], base["control"]) <= 1e-9 and _rel(dense["trajectory"], base["trajectory"]) <= 1e-9
     A2, B2 = wl["A"].copy(), wl["B"].copy()
     A2[5, 0, 4] = 0.03  # (x position picks up y velocity: instance 5, first wave)
     B2[70, 3, 1] = 0.02  # (x velocity driven by the y control: instance 70, second wave)
@@ -1013,7 +1018,10 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
     same = np.ones(b, dtype=bool)
     same[[5, 70]] = False
-    assert np.array_equal(re["control"][same], base["control"][same]) and (re["iter"][same] == base["iter"][same]).all()
+    third = np.arange(b) >= 128  # (the wave nobody touched: bit for bit; in the two others a third bound on u_0 ends in the tier now)
+    assert np.array_equal(re["control"][third], base["control"][third]) and (re["iter"][same] == base["iter"][same]).all()
+    assert np.array_equal(re["control"][same & both], base["control"][same & both])
+    assert _rel(re["control"][same], base["control"][same]) <= 1e-9
     assert not np.allclose(re["control"][5], base["control"][5]) and not np.allclose(re["control"][70], base["control"][70])
     # ... and a cost that couples the axes (a dense output map): the plan says so, nothing is skipped anywhere
     rng = np.random.default_rng(3)
@@ -1410,7 +1418,7 @@ def test_lane_pass_takes_the_first_step_of_the_iteration(emu, oracle, monkeypatc
     at_minimiser = int(((ro["iter"][:, 0] == 1) & ok).sum())
     assert rn["lane_pass_finished"] == at_minimiser
     one_bound = int(((ro["iter"][:, 0] == 2) & (ro["iter"][:, 1] == 0) & ok).sum())
-    two_bounds = int(((ro["iter"][:, 0] == 3) & (ro["iter"][:, 1] == 0) & ok).sum())
+    two_bounds = int(((ro["iter"][:, 0] >= 3) & (ro["iter"][:, 0] <= 4) & (ro["iter"][:, 1] == 0) & ok).sum())  # (two, on decoupled axes three, bounds on u_0)
     assert at_minimiser <= rs["lane_pass_finished"] <= at_minimiser + one_bound + two_bounds
     if vmax >= 0.6:  # (loose velocity rows: every first pick is a bound on u_0 -- every one-constraint instance ends in the pass, and
         #  the two-constraint ones whose second pick is another bound on u_0)
