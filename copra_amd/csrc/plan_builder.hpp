@@ -460,6 +460,19 @@ inline void build_lane_tables(HostPlan& hp)
                 if (tab[(size_t)a + nz * b] != 0.0) ok = false;
                 if (a < nx && b < nx && tab[(size_t)oHN + a + nx * b] != 0.0) ok = false;
             }
+        // ... and no constraint row does: the pass takes its speculative steps axis by axis there (lmpc_lane.hpp: lane_spec_axes) -- right as long
+        // as the iterates BETWEEN the axes' steps, which it never forms, cannot violate anything, i.e. as long as every row looks at one axis
+        // (a row u_x + u_y <= 1 can hold before and after both steps and fail in between: qpgen2 would add it there)
+        for (int k = 0; k <= N && ok; ++k)
+            for (int r = 0; r < rps && ok; ++r) {
+                const double* row = tab.data() + oRows + ((size_t)k * rps + r) * rw;
+                int ax = -1;
+                for (int a = 0; a < nz; ++a)
+                    if (row[a] != 0.0) {
+                        if (ax >= 0 && ax != axis(a)) ok = false;
+                        ax = axis(a);
+                    }
+            }
         P.lane_axes = ok ? 1 : 0;
     }
     if (hp.params.size() & 1) hp.params.push_back(0.0);

@@ -1033,6 +1033,27 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     assert _rel(rc["control"][okc], rco["control"][okc]) <= RTOL  # (a general output map: conditioning, as everywhere in this file)
 
 
+def test_a_row_that_couples_two_axes_keeps_the_pass_off_the_axis_by_axis_steps(emu, oracle):
+    """on decoupled axes the pass takes its speculative steps axis by axis, all in one trajectory (lane_spec_axes) -- right as long as the iterates
+    BETWEEN the axes' steps cannot violate anything.  A control row u_x + u_y <= c can hold at the minimiser and after both steps and fail in
+    between, where qpgen2 would add it: the plan builder sees the row and the controller runs the dense builds with the step-by-step levels
+    (FusedPlan::lane_axes = 0).  Counters and results against the oracle, with bounds tight enough that two axes saturate at once"""
+    from copra_amd import workloads
+    b = 128
+    wl = workloads.com_preview(b, seed=47, u_max=1.5)
+    ro0 = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert ((ro0["iter"][:, 0] >= 3) & (ro0["iter"][:, 1] == 0)).sum() >= 8  # (instances with bounds on u_0 in two axes)
+    for c in (2.2, 2.6, 2.9):
+        cstrs = list(wl["cstrs"]) + [dict(kind="control", G=[[1.0, 1.0, 0.0]], f=[c]), dict(kind="control", G=[[-1.0, -1.0, 0.0]], f=[c])]
+        args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cstrs)
+        re = emu.lmpc_solve(*args)
+        ro = oracle.lmpc_solve_batch(*args, nthreads=8)
+        ok = ro["status"] == 0
+        assert (re["status"] == ro["status"]).all() and ok.sum() >= b - 2
+        assert (re["iter"][ok] == ro["iter"][ok]).all(), c
+        assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
+
+
 def test_lane_pass_with_more_rows_per_step_than_its_prefetch_buffer_holds(emu, oracle):
     """six rows per step (upper AND lower velocity limits as rows) in front of the pass, whose stage buffer carries the right-hand sides of
     the first four (lmpc_lane.hpp: RQ): the others are read in place -- with the controller's right-hand sides and with every instance's own"""
