@@ -353,7 +353,141 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
     // Lam^-1 (the Cholesky factor of M_uu, inverted) and Bt = B Lam^-T are only used by the active-set iteration: they are
     // formed after the sweep for all stages at once (lane = stage), not twenty times inside it.
     static_assert(NX <= 7 && NU <= 3, "stacked blocks of the MFMA sweep: u + pad | x_0..3 | x_4.., affine");
-    {
+    // DECOUPLED AXES (FusedPlan::lane_axes: costs and rows couple none; here: neither does this instance's system): the recursion is NU
+    // independent ones of NX / NU states and one control -- lane a runs axis a in scalar arithmetic, the sums of the pass's sweep
+    // (lmpc_lane.hpp: stage_core) with the terms between axes left out: ~ 45 dependent multiply-adds per stage instead of fifteen
+    // matrix instructions and two LDS hand-overs (30 k of an instance's cycles on the headline).  Stage costs from the pass's table
+    // (controller-wide references only); the block-row norms of the compact variant by lane shuffles.
+    bool axes_sweep = false;
+    if constexpr (!SREFS && NU > 1 && NX % NU == 0) {
+        bool own_refs = false;
+        for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
+        if (P.lane_axes && P.lane_tab >= 0 && compact && !own_refs && !P.ric_model_out) {
+            const int ei = lane % NX, ej = (lane / NX) % NX, bc = (lane / NX) % NU;
+            const bool strayA = lane < NX * NX && ei % NU != ej % NU && !(sysA == 0.0);
+            const bool strayB = lane < NX * NU && ei % NU != bc && !(sysB == 0.0);
+            axes_sweep = !wave_any(strayA || strayB);
+        }
+    }
+    if (axes_sweep) {
+        if constexpr (!SREFS && NU > 1 && NX % NU == 0) {
+            constexpr int NA = NX / NU, NZA = NA + 1; // states of an axis; its z = (states, control)
+            for (int e = lane; e < nh * RR::SZ; e += kWave) F[e] = 0.0; // (Acl, K and Lam^-1 between axes: zero)
+            const int ax = lane < NU ? lane : 0;
+            auto zi = [&](int m) -> int { return m < NA ? ax + NU * m : NX + ax; }; // z-index of the axis's m-th entry
+            const double* const tab = P.params + P.lane_tab;
+            int oh_, oHN_, ohN_, oRows_;
+            lane_tab_offsets(NX, NU, oh_, oHN_, ohN_, oRows_);
+            double Aa[NA][NA], Ba[NA], da[NA], Ha[NZA][NZA], ha[NZA], Pa[NA][NA], pa_[NA];
+#pragma unroll
+            for (int m = 0; m < NA; ++m) {
+#pragma unroll
+                for (int n = 0; n < NA; ++n) {
+                    Aa[m][n] = A[zi(m) + NX * zi(n)];
+                    Pa[m][n] = Pm[zi(m) + NX * zi(n)];
+                }
+                Ba[m] = B[zi(m) + NX * ax];
+                da[m] = D[zi(m)];
+                pa_[m] = pv[zi(m)];
+            }
+#pragma unroll
+            for (int m = 0; m < NZA; ++m) {
+#pragma unroll
+                for (int n = 0; n < NZA; ++n) Ha[m][n] = tab[zi(m) + (NX + NU) * zi(n)];
+                ha[m] = tab[oh_ + zi(m)];
+            }
+            auto ABa = [&](int l, int z) -> double { return z < NA ? Aa[l][z] : Ba[l]; };
+            wave_sync(); // (the records are zero)
+            bool bad = false;
+            for (int k = nh - 1; k >= 0; --k) {
+                double tq[NA], mz[NZA], M[NZA][NZA];
+#pragma unroll
+                for (int l = 0; l < NA; ++l) {
+                    double sacc = pa_[l];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) sacc += Pa[l][i] * da[i];
+                    tq[l] = sacc;
+                }
+#pragma unroll
+                for (int z = 0; z < NZA; ++z) {
+                    double sacc = ha[z];
+#pragma unroll
+                    for (int l = 0; l < NA; ++l) sacc += ABa(l, z) * tq[l];
+                    mz[z] = sacc;
+                }
+#pragma unroll
+                for (int b2 = 0; b2 < NZA; ++b2) {
+                    double Tb[NA];
+#pragma unroll
+                    for (int l = 0; l < NA; ++l) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) sacc += Pa[l][i] * ABa(i, b2);
+                        Tb[l] = sacc;
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 <= b2; ++a2) {
+                        double sacc = Ha[a2][b2];
+#pragma unroll
+                        for (int l = 0; l < NA; ++l) sacc += ABa(l, a2) * Tb[l];
+                        M[a2][b2] = sacc;
+                    }
+                }
+                const double muu = M[NA][NA];
+                bad = bad || (lane < NU && !(muu > 0.0));
+                const double ni = -1.0 / muu;
+                double Kk[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j) Kk[j] = ni * M[j][NA];
+                const double kvk = ni * mz[NA];
+#pragma unroll
+                for (int j = 0; j < NA; ++j)
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) {
+                        const double v = M[i][j] + M[i][NA] * Kk[j];
+                        Pa[i][j] = v;
+                        Pa[j][i] = v;
+                    }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) pa_[i] = mz[i] + M[i][NA] * kvk;
+                if (lane < NU) {
+                    double* Fk = F + k * RR::SZ;
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        Fk[RR::oK + ax + NU * zi(j)] = Kk[j];
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) Fk[RR::oAcl + zi(i) + NX * zi(j)] = Aa[i][j] + Ba[i] * Kk[j];
+                    }
+                    Fk[RR::oLi + ax * (ax + 1) / 2 + ax] = fast_rsqrt(muu);
+                    KV[k * NU + ax] = kvk;
+                }
+            }
+            if (wave_any(bad)) status = 2; // "Problems with the decomposition of Q" (QuadProgSolver.h:25)
+            rows.cache_own_row();
+            // the constant block behind the records: B (it takes the place of every Bt_k, ric_factor.hpp), d and a zero
+            if (lane < NX * NU) F[nh * RR::SZ + RR::cB + lane] = B[lane];
+            if (lane < NX) F[nh * RR::SZ + RR::cD + lane] = D[lane];
+            if (lane == 0) F[nh * RR::SZ + RR::cZ] = 0.0;
+            if (lane == 1) F[nh * RR::SZ + RR::cO] = 1.0;
+            // the running block-row norms NB2[s][i] = sum_{t <= s} |row i of G_t|^2, G_t = A^t B: row i of G_t has ONE entry that is not zero,
+            // g_i = G_t(i, i % NU), and g_i(t + 1) = sum over the states j of its axis of A(i, j) g_j(t) -- lane i < NX carries g_i
+            {
+                const int gi = lane < NX ? lane : 0;
+                double aax[NA];
+#pragma unroll
+                for (int m = 0; m < NA; ++m) aax[m] = A[gi + NX * (gi % NU + NU * m)];
+                double g = B[gi + NX * (gi % NU)], ncum = 0.0;
+                for (int st = 0; st < nh; ++st) {
+                    ncum += g * g;
+                    if (lane < NX) Xbar[st * NX + lane] = ncum;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NA; ++m) acc += aax[m] * shfl_f64(g, gi % NU + NU * m);
+                    g = acc;
+                }
+            }
+        }
+    } else {
         constexpr int SAFF = 4 + NX; // stacked index of the affine column
         const int q = lane >> 4, hb = (lane >> 2) & 3, r = lane & 3;
         const int scol = 4 * hb + r; // stacked column of this lane's results

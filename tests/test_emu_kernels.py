@@ -1000,11 +1000,11 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     monkeypatch.setitem(OPTIONS, "no_lane_axes", 1)
     dense = emu.lmpc_solve(*args(wl["A"], wl["B"]))
     monkeypatch.setitem(OPTIONS, "no_lane_axes", 0)
-    # (the instances both end in the pass: up to two bounds on u_0; a third one ends there on decoupled axes only -- one step per axis in ONE more
-    #  trajectory -- and in the tier otherwise: the same result to rounding)
-    both = base["iter"][:, 0] <= 3
-    assert both.sum() > b // 2
-    assert np.array_equal(dense["control"][both], base["control"][both]) and np.array_equal(dense["trajectory"][both], base["trajectory"][both])
+    # (what ends in the PASS in both runs: the tier behind it sweeps axis by axis too on decoupled systems -- scalar arithmetic instead of
+    #  matrix instructions, equal to rounding -- and a bound on u_0 in every axis ends in the pass on decoupled axes only)
+    differ = (dense["control"] != base["control"]).any(axis=1) | (dense["trajectory"] != base["trajectory"]).any(axis=1)
+    assert differ.sum() <= b - dense["lane_pass_finished"] and dense["lane_pass_finished"] > b // 2
+    both = ~differ
     assert (dense["iter"] == base["iter"]).all() and (dense["status"] == base["status"]).all()
     assert _rel(dense["control"], base["control"]) <= 1e-9 and _rel(dense["trajectory"], base["trajectory"]) <= 1e-9
     A2, B2 = wl["A"].copy(), wl["B"].copy()
@@ -1020,7 +1020,7 @@ def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wav
     same[[5, 70]] = False
     third = np.arange(b) >= 128  # (the wave nobody touched: bit for bit; in the two others a third bound on u_0 ends in the tier now)
     assert np.array_equal(re["control"][third], base["control"][third]) and (re["iter"][same] == base["iter"][same]).all()
-    assert np.array_equal(re["control"][same & both], base["control"][same & both])
+    assert ((re["control"][same] != base["control"][same]).any(axis=1)).sum() <= b - re["lane_pass_finished"]
     assert _rel(re["control"][same], base["control"][same]) <= 1e-9
     assert not np.allclose(re["control"][5], base["control"][5]) and not np.allclose(re["control"][70], base["control"][70])
     # ... and a cost that couples the axes (a dense output map): the plan says so, nothing is skipped anywhere
