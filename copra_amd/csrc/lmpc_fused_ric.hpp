@@ -435,7 +435,7 @@ COPRA_DEV void lmpc_fused_ric_body(const FusedPlan& P, int inst, bool lane_faile
                 }
                 const double muu = M[NA][NA];
                 bad = bad || (lane < NU && !(muu > 0.0));
-                const double ni = -1.0 / muu;
+                const double ni = -ric_rcp(muu); // (v_rcp_f64 + two Newton steps, as the matrix-instruction sweep below: the division is a third of the stage's chain)
                 double Kk[NA];
 #pragma unroll
                 for (int j = 0; j < NA; ++j) Kk[j] = ni * M[j][NA];
