@@ -53,7 +53,7 @@ class Options(C.Structure):
                                            "no_lane_pass", "no_lane_handover", "no_lane_spec", "no_lane_axes", "lane_min_batch", "no_ric_shared",
                                            "no_riccati", "no_ric_fast")]
                 + [(n, C.c_double) for n in ("ric_step_tol", "ric_mu_tol")]
-                + [("debug", C.c_int)])
+                + [("debug", C.c_int), ("no_axis_solver", C.c_int)])
 
 
 OPTION_NAMES = tuple(n for n, _ in Options._fields_ if n != "struct_size")

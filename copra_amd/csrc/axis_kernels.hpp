@@ -1,0 +1,24 @@
+// axis_kernels.hpp -- the __global__ template of the one-(instance, axis)-per-lane solver (lmpc_axis.hpp), shared by the translation unit that
+// instantiates it (copra_hip_axis.hip) and the one that launches it (copra_hip.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lmpc_axis.hpp"
+
+using namespace copra_hip;
+
+// One wave = 64 / NU instances x NU axes.  K, 1 / M_uu, U and the recursion's t of every stage live in registers (5 NMAX doubles), next to the
+// lane's active set (S: QMAX (QMAX + 1) / 2 doubles).
+#ifndef COPRA_AXIS_WAVES
+#define COPRA_AXIS_WAVES 1 // waves per SIMD the register budget is cut for
+#endif
+template <int NXA, int NU, int NMAX, int QMAX, bool EXACT, bool CT>
+__global__ __launch_bounds__(64, (NMAX <= 20 && QMAX <= 6) ? COPRA_AXIS_WAVES : 1) void copra_lmpc_axis_kernel(const FusedPlan P)
+{
+    lmpc_axis_body<NXA, NU, NMAX, QMAX, EXACT, CT>(P, (int)blockIdx.x);
+}
+// (NXA, NU, NMAX, QMAX, EXACT, CT): the headline's horizon exactly; every horizon up to 20 and up to 31 -- each with the tables in registers
+// (FusedPlan::axis_const) and with the tables read from LDS stage by stage
+#define COPRA_AXIS_KERNELS(X)                                                                                          \
+    X(2, 3, 20, 6, true, true) X(2, 3, 20, 6, false, true) X(2, 2, 20, 6, false, true) X(2, 2, 31, 6, false, true)      \
+    X(2, 3, 20, 6, false, false) X(2, 2, 20, 6, false, false) X(2, 2, 31, 6, false, false)

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 }
 
 #include "ric_kernels.hpp" // copra_lmpc_fused_ric_kernel, copra_lmpc_lane_kernel
+#include "axis_kernels.hpp" // copra_lmpc_axis_kernel: instantiated in copra_hip_axis.hip
+#define COPRA_AXIS_DECL(NXA, NU, NMAX, QMAX, EXACT, CT) extern template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT>(const FusedPlan);
+COPRA_AXIS_KERNELS(COPRA_AXIS_DECL)
 // run-time-horizon builds (NH == 0) for the shapes of ric_aot_shape: instantiated in copra_hip_ric.hip, a translation unit of its own
 #define COPRA_RIC_RT_DECL(NX, NU)                                                                                      \
     extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, false>(const FusedPlan);      \
@@ -381,6 +384,31 @@ static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
     if (P.nx == 4 && P.nu == 2) return P.lane_spec ? copra_lmpc_lane_shared_kernel<4, 2, true> : copra_lmpc_lane_shared_kernel<4, 2, false>; // (the other shapes of the tier's run-time-horizon builds)
     if (P.nx == 2 && P.nu == 1) return P.lane_spec ? copra_lmpc_lane_shared_kernel<2, 1, true> : copra_lmpc_lane_shared_kernel<2, 1, false>;
     return nullptr;
+}
+// ---- the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): the whole solve of a controller whose axes are decoupled ----
+static fused_kernel_t select_axis_kernel(const FusedPlan& P)
+{
+    const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+#define COPRA_AXIS_PICK(NU, NMAX, EXACT) (P.axis_const ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false>)
+    if (nmax == 20) return P.nu == 3 ? (P.N == 20 ? COPRA_AXIS_PICK(3, 20, true) : COPRA_AXIS_PICK(3, 20, false)) : COPRA_AXIS_PICK(2, 20, false);
+    if (nmax == 31) return COPRA_AXIS_PICK(2, 31, false);
+#undef COPRA_AXIS_PICK
+    return nullptr;
+}
+static size_t axis_lds_bytes(const FusedPlan& P)
+{
+    int oB = 0, oR = 0, rcs = 0;
+    return (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, oB, oR, rcs) * sizeof(double);
+}
+static bool axis_solver_wanted(const copra_batch* h, const FusedPlan& P)
+{
+    const copra_options_t& opt = h->hp.opt;
+    if (h->ad.axis_off || opt.no_axis_solver || opt.no_lane_pass || P.axis_tab < 0 || P.prof_fine) return false;
+    if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
+    if (h->packed || h->shared || h->hp.large || P.initial_state || P.stage_refs || P.row_f_inst || P.lb_inst || P.ub_inst) return false;
+    for (int t = 0; t < kMaxCosts; ++t)
+        if (h->cost_p[t]) return false; // (per-instance references: the one-instance-per-lane pass rebuilds its affine terms per lane; this one does not)
+    return select_axis_kernel(P) != nullptr;
 }
 static size_t lane_lds_bytes(const FusedPlan& P)
 {
@@ -1206,6 +1234,7 @@ static copra_status_t learn_from_the_last_solve(copra_batch* h)
     if (rc == COPRA_OK) rc = rechoose_layout(h);
     h->ad.solved_once = true;
     h->ad.lane_ran = false;
+    h->ad.axis_ran = false;
     return rc;
 }
 // ... and where this solve will leave its counters, for the next call of the above
@@ -1426,6 +1455,35 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
     // the one-instance-per-lane pass (lmpc_lane.hpp): every instance whose unconstrained minimiser violates nothing ends in it, the
     // first tier below runs for the others only
     bool lane_pass = lane_pass_wanted(h, P, jit_launch);
+    // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): it finishes every instance
+    // whose axes keep their active sets within its lanes' room; the first tier below runs for what it lists
+    bool axis_pass = axis_solver_wanted(h, P);
+    if (axis_pass && ensure_lane_buffers(h, false) != COPRA_OK) {
+        (void)hipGetLastError();
+        h->ad.axis_off = true;
+        axis_pass = false;
+    }
+    if (axis_pass) {
+        lane_pass = false;
+        h->lane_cur ^= 1;
+        h->ad.axis_ran = true;
+        P.lane_list = h->d_lane_list;
+        P.lane_count = h->d_lane_count + h->lane_cur;
+        P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
+        const unsigned ipw = 64u / (unsigned)P.nu;
+        const unsigned ga = ((unsigned)P.batch + ipw - 1) / ipw;
+        const fused_kernel_t ak = select_axis_kernel(P);
+        LDS_OPT_IN(ak, axis_lds_bytes(P));
+        if (ext_timed)
+            hipExtLaunchKernelGGL(ak, dim3(ga), dim3(64), axis_lds_bytes(P), s, h->ev0, nullptr, 0, P);
+        else
+            hipLaunchKernelGGL(ak, dim3(ga), dim3(64), axis_lds_bytes(P), s, P);
+        HIP_TRY(hipGetLastError());
+        P.lane_from_list = 1;
+        P.lane_handover = 0; // (nothing is handed over: the tier sweeps for itself)
+        P.lane_spec = P.lds.ricC ? 1 : 0;
+        P.lane_zero = nullptr;
+    }
     if (lane_pass && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for its workspace: the tier alone, from now on)
         (void)hipGetLastError();
         h->ad.lane_off = true;
@@ -1510,7 +1568,7 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         const unsigned per = 64u / (unsigned)h->jit_lanes;
         const hipFunction_t jfn = (h->jit_ric && P.lds.q1regs == 0) ? h->jit_fused_q0 : h->jit_fused;
         LDS_OPT_IN(jfn, (size_t)per * h->hp.lds_bytes);
-        const unsigned gj = lane_pass ? (((unsigned)P.batch + 7u) & ~7u) : ((unsigned)P.batch + per - 1) / per; // (the list is dealt out in eighths)
+        const unsigned gj = (lane_pass || axis_pass) ? (((unsigned)P.batch + 7u) & ~7u) : ((unsigned)P.batch + per - 1) / per; // (the list is dealt out in eighths)
         HIP_TRY(hipModuleLaunchKernel(jfn, gj, 1, 1, 64, 1, 1, per * (unsigned)h->hp.lds_bytes, s, args, nullptr));
     } else if (h->packed) {
         HIP_TRY(h->packed == 16 ? packed_launch_w16(P, false, h->hp.lds_bytes, s) : packed_launch_w32(P, false, h->hp.lds_bytes, s));
@@ -1522,10 +1580,10 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
                 h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
         }
-        const unsigned g1 = lane_pass ? (((unsigned)P.batch + 7u) & ~7u) : (unsigned)P.batch; // (the list is dealt out in eighths)
+        const unsigned g1 = (lane_pass || axis_pass) ? (((unsigned)P.batch + 7u) & ~7u) : (unsigned)P.batch; // (the list is dealt out in eighths)
         if (ext_timed) // (start | end of the first launch; with a second launch the solve ends with THAT kernel's packet)
             hipExtLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s,
-                lane_pass ? nullptr : h->ev0, h->hp.two_tier ? h->evm : h->ev1, 0, P);
+                (lane_pass || axis_pass) ? nullptr : h->ev0, h->hp.two_tier ? h->evm : h->ev1, 0, P);
         else
             hipLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());

@@ -547,10 +547,10 @@ copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* sec
 copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished)
 {
     if (!h) return fail(COPRA_ERR_ARG, "copra_batch_lane_pass_info: null handle");
-    if (ran) *ran = h->ad.lane_ran ? 1 : 0;
+    if (ran) *ran = h->ad.axis_ran ? 2 : h->ad.lane_ran ? 1 : 0; // (2: the one-(instance, axis)-per-lane solver, lmpc_axis.hpp)
     if (finished) {
         *finished = 0;
-        if (h->ad.lane_ran) {
+        if (h->ad.lane_ran || h->ad.axis_ran) {
             int left = 0;
             HIP_TRY(hipStreamSynchronize(h->last_stream));
             HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));

@@ -76,6 +76,9 @@ struct AdaptState {
     bool lane_spec_shared_off = false; // the shared-model form of the pass does not take steps itself (too few instances end by them)
     bool lane_form_handover = false; // the pass runs in its hand-over form (too few instances end in the speculating one: adapt_lane_pass)
     long long lane_solves = 0; // solves seen by adapt_lane_pass
+    // the one-(instance, axis)-per-lane solver (lmpc_axis.hpp)
+    bool axis_ran = false; // the last solve ran it
+    bool axis_off = false; // switched off for this controller (no memory for its list)
     // shared-model tick on the records tier
     long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
     bool shared_ric_off = false; // ... which a small, constraint-heavy controller leaves after its first solve

@@ -1,0 +1,848 @@
+// LMPC::solve() with ONE (INSTANCE, AXIS) PER LANE: the whole solve -- LQ sweep, roll-out AND the active-set iteration -- for
+// controllers whose axes are decoupled (round 6).
+//
+// The CoM model of BASELINE configs[2], the point masses, the reference's falling mass: state i belongs to axis i % nu, control c to
+// axis c, and neither A, B, the costs (costFunctions.cpp:63-215) nor any constraint row (constraints.cpp:66-315) couple two axes.  Then
+// the condensed QP of LMPC::makeQPForm (LMPC.cpp:250-280) is block diagonal -- nu independent QPs over one chain each (nxa = nx / nu
+// states, ONE control) -- and qpgen2's run on the whole problem (QuadProgSolver.cpp:45-72) is an INTERLEAVING of the axes' own runs: a
+// step of one axis moves no iterate and no multiplier of another, the pick within an axis is the same whenever it is taken, the
+// counters add up (tools/exp/axis_proto.py replays this against the oracle: status, both counters, U).  So every (instance, axis) gets a
+// lane, and the lane does everything:
+//   * backward Riccati sweep of its chain (the recursion of lmpc_lane.hpp with nu = 1): K_k, 1 / M_uu,k and kv_k stay in REGISTERS
+//     -- no workspace in memory, nothing written but the results;
+//   * roll-out = qpgen2's starting point -Q^-1 c, with the first scan inside;
+//   * the Goldfarb-Idnani iteration in RANGE-SPACE form on the Riccati factor.  With N the active normals, n+ the pick's:
+//         y = Q^-1 n+                        one backward + one forward closed-loop recursion over the stages (ric_factor.hpp, scalar)
+//         g = N' y,   S = N' Q^-1 N          (kept explicitly: QMAX x QMAX, padded with the identity),   r = S^-1 g  (Cholesky, in registers)
+//         z = Q^-1 (n+ - N r)                the same two recursions once more, the new iterate U += t z and the next scan inside
+//         t1 = min lambda_i / r_i (r_i > 0),   t2 = -s / (n+' Q^-1 n+ - g' r)
+//     -- qpgen2's d = J' n+, z = J2 d2, r = R^-1 d1 in another basis: the same pick rule (most violated normalised by the row norm, lowest index
+//     wins), the same step lengths, the same iterates up to rounding.  A lane's active set is at most QMAX constraints.
+// Anything the lane cannot decide exactly as qpgen2 would -- an active set that outgrows QMAX, a pick without a step in primal space
+// (|z|^2 <= vsmall: the infeasible and the degenerate cases), a failed factorisation, systems whose axes ARE coupled -- sends the
+// INSTANCE to the list of the first tier (lmpc_fused_ric.hpp), which solves it from scratch, as it does behind lmpc_lane.hpp.
+//
+// Lane mapping: lane = nu * (instance of the wave) + axis, 64 / nu instances per wave; nothing crosses lanes inside the iteration (a
+// wave leaves the loop when its last lane has).  Per lane in LDS: one sparse array over its constraints (N controls + (N + 1) rpa
+// rows) -- coefficients of the combined normal on the way into a recursion, responses n_i' y on the way out.
+#pragma once
+#include <cstring>
+#include <type_traits>
+#include "lmpc_fused.hpp"
+
+namespace copra_hip {
+
+#ifndef COPRA_AXIS_ITER_CAP
+#define COPRA_AXIS_ITER_CAP 64 // picks + drops of one lane; beyond: the tier
+#endif
+
+// the largest double below x > 0:  s < -axis_pred(x)  <=>  s <= -x  (qpgen2's test "|s| < vsmall counts as zero, a negative slack is a violation")
+COPRA_DEV double axis_pred(double x)
+{
+    long long b;
+    std::memcpy(&b, &x, sizeof b);
+    b -= 1;
+    std::memcpy(&x, &b, sizeof b);
+    return x;
+}
+
+// EXACT: the horizon IS NMAX (the builds of the BASELINE horizons: no stage of the sweep and of the scan is guarded)
+// CT: the tables are the same at every step -- every row of the controller a pure state row present at all N + 1 steps with one E and f, the
+//     bounds of a control the same along the horizon (FusedPlan::axis_const: what TrajectoryBoundConstraint and ControlBoundConstraint produce
+//     from per-step entries, constraints.cpp:284-315, 359-367): they live in registers, nothing but the lane's sparse array is read from LDS
+template <int NXA, int NU, int NMAX, int QMAX, bool EXACT = false, bool CT = false>
+COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
+{
+    constexpr int NX = NXA * NU, NZ = NXA + 1, RW = NXA + 3, RPA = kAxisMaxRpa;
+    constexpr int IPW = kWave / NU; // instances per wave
+    static_assert(NXA >= 1 && NXA <= 3 && QMAX >= 1 && QMAX <= 8 && NMAX <= 31, "registers; the stage masks are 32 bits");
+    const int lane = lane_id();
+    const int il = lane / NU, c = lane - il * NU; // instance of the wave | axis
+    const bool lane_on = il < IPW;
+    const int inst0 = group * IPW;
+    const int left = P.batch - inst0;
+    const int ninst = left < IPW ? left : IPW; // instances of this wave
+    const bool valid = lane_on && il < ninst;
+    const int ilc = valid ? il : 0; // (lanes without an instance compute on a copy of the wave's first one)
+    const int inst = inst0 + ilc;
+    const int NH = EXACT ? NMAX : P.N, rpa = P.axis_rpa;
+    const double vsmall = P.vsmall, thr = -axis_pred(vsmall);
+    double* const lds = lds_base();
+    int oBnd_, oRC_, rcs_;
+    (void)axis_lds_doubles(NX, NU, NH, rpa, oBnd_, oRC_, rcs_);
+    const int RCS = rcs_;
+    int oh_, oHN_, ohN_, oRows_;
+    axis_tab_offsets(NXA, oh_, oHN_, ohN_, oRows_);
+    const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
+    const int TA = axis_tab_doubles(NXA, NH, rpa);
+    if (P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
+    long long stamp[6];
+    stamp[0] = P.prof ? cycle_counter() : 0;
+
+    // ---- 0. this lane's system; the tables of its axis ----
+    if (!CT) { // the tables and bounds of every axis: read stage by stage from LDS
+        const double* const src = P.params + P.axis_tab;
+        for (int e = lane; e < NU * TA; e += kWave) lds[e] = src[e];
+        for (int e = lane; e < NU * NH; e += kWave) { // bounds: [axis][ub (N) | lb (N)]
+            const int k = e / NU, a = e - k * NU;
+            lds[oBnd_ + a * 2 * NH + k] = P.ub[e];
+            lds[oBnd_ + a * 2 * NH + NH + k] = P.lb[e];
+        }
+    }
+    // (the recursions below run inside the iteration's loop and read the tables stage by stage: behind an opaque copy of the OFFSET the
+    //  reads stay where they are -- hoisted out of the loop the tables of all stages would sit in registers, 150 doubles of them -- and stay
+    //  LDS reads: an opaque POINTER would lose its address space)
+    auto opaque = [](int v) __attribute__((always_inline)) -> int {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(v));
+#endif
+        return v;
+    };
+    const int oT = c * TA, oUB = oBnd_ + c * 2 * NH; // this lane's axis in LDS (!CT): tables | bounds (ub_k at [k], lb_k at [NH + k])
+    const double* const Tg = P.params + P.axis_tab + c * TA; // ... and in memory: what is read once
+    double A[NXA][NXA], B[NXA], d[NXA], x0[NXA]; // A[i][j]: entry (i, j) of the axis' block
+    bool giveup = false; // this lane cannot finish its instance: the first tier solves it from scratch
+    {
+        // The columns of A and B that belong to this axis, straight from memory (the three lanes of an instance read neighbouring columns of
+        // the same 288 + 144 bytes: one trip, every load requested before the first is used): the axis' own block, and the entries that would
+        // couple it to another axis -- those must be zero (each entry of A and B between two axes is looked at by exactly one lane of the instance).
+        const double* const sA = P.A + (size_t)inst * NX * NX;
+        const double* const sB = P.B + (size_t)inst * NX * NU;
+        const double* const sd = P.d + (size_t)inst * NX;
+        const double* const sx = P.x0 + (size_t)inst * NX;
+        double vA[NXA][NXA][NU], vB[NXA][NU];
+#pragma unroll
+        for (int jj = 0; jj < NXA; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < NXA; ++ii)
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    int ax = c + a; // a == 0: this axis
+                    ax = ax >= NU ? ax - NU : ax;
+                    vA[jj][ii][a] = sA[(ax + NU * ii) + NX * (c + NU * jj)];
+                }
+#pragma unroll
+        for (int ii = 0; ii < NXA; ++ii) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                int ax = c + a;
+                ax = ax >= NU ? ax - NU : ax;
+                vB[ii][a] = sB[(ax + NU * ii) + NX * c];
+            }
+            d[ii] = sd[c + NU * ii];
+            x0[ii] = sx[c + NU * ii];
+        }
+        double stray = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < NXA; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < NXA; ++ii) {
+                A[ii][jj] = vA[jj][ii][0];
+#pragma unroll
+                for (int a = 1; a < NU; ++a) stray += fabs(vA[jj][ii][a]);
+            }
+#pragma unroll
+        for (int ii = 0; ii < NXA; ++ii) {
+            B[ii] = vB[ii][0];
+#pragma unroll
+            for (int a = 1; a < NU; ++a) stray += fabs(vB[ii][a]);
+        }
+        giveup = !(stray == 0.0); // (a NaN couples)
+    }
+    // CT: the one row set and the one pair of bounds of this axis
+    double ubc = 0.0, lbc = 0.0, re[RPA][NXA], rf[RPA];
+    int ridx0[RPA], ridxd[RPA]; // index of row j in the stacked order: ridx0 + step x ridxd  (-1: the slot is empty)
+#pragma unroll
+    for (int j = 0; j < RPA; ++j) {
+        rf[j] = 0.0;
+        ridx0[j] = -1;
+        ridxd[j] = 0;
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) re[j][i] = 0.0;
+    }
+    if (CT) {
+        ubc = P.ub[c];
+        lbc = P.lb[c];
+#pragma unroll
+        for (int j = 0; j < RPA; ++j) {
+            if (j < rpa) {
+                const double* const r0 = Tg + oRows + j * RW;
+                const double* const r1 = Tg + oRows + (rpa + j) * RW;
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) re[j][i] = r0[i];
+                rf[j] = r0[NXA + 1];
+                ridx0[j] = (int)r0[NXA + 2];
+                ridxd[j] = (int)r1[NXA + 2] - ridx0[j];
+            }
+        }
+    }
+    wave_sync(); // (!CT: the tables are in LDS)
+    // this lane's sparse array: [0, NH) the controls, NH + k rpa + j row j of step k, the last entry a spare (what empty slots point to)
+    double* const RC = lds + oRC_ + lane * RCS;
+    const int posSpare = NH + (NH + 1) * rpa;
+    for (int e = 0; e <= posSpare; ++e) RC[e] = 0.0;
+    stamp[1] = P.prof ? cycle_counter() : 0;
+
+    // ---- 1. backward Riccati sweep of the chain: K_k, 1 / M_uu,k in registers, kv_k parked in U[k] ----
+    double K[NMAX][NXA], MI[NMAX], U[NMAX], Tv[NMAX];
+    bool bad = false;
+    {
+        double H[NZ][NZ], h[NZ]; // (upper triangle used)
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+#pragma unroll
+            for (int b = 0; b < NZ; ++b) H[a][b] = Tg[a + NZ * b];
+            h[a] = Tg[oh + a];
+        }
+        double Pm[NXA][NXA], pv[NXA]; // cost-to-go (symmetric: both halves kept, NXA <= 3)
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) {
+#pragma unroll
+            for (int j = 0; j < NXA; ++j) Pm[i][j] = Tg[oHN + i + NXA * j];
+            pv[i] = Tg[ohN + i];
+        }
+        auto AB = [&](int l, int a) __attribute__((always_inline)) -> double { return a < NXA ? A[l][a] : B[l]; };
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k) {
+            if (EXACT || k < NH) {
+                double tq[NXA], mz[NZ], M[NZ][NZ];
+#pragma unroll
+                for (int l = 0; l < NXA; ++l) {
+                    double s = pv[l];
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) s += Pm[l][i] * d[i];
+                    tq[l] = s;
+                }
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) {
+                    double s = h[a];
+#pragma unroll
+                    for (int l = 0; l < NXA; ++l) s += AB(l, a) * tq[l];
+                    mz[a] = s;
+                }
+#pragma unroll
+                for (int b = 0; b < NZ; ++b) {
+                    double Tb[NXA]; // column b of P+ [A B]
+#pragma unroll
+                    for (int l = 0; l < NXA; ++l) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i) s += Pm[l][i] * AB(i, b);
+                        Tb[l] = s;
+                    }
+#pragma unroll
+                    for (int a = 0; a <= b; ++a) {
+                        double s = H[a][b];
+#pragma unroll
+                        for (int l = 0; l < NXA; ++l) s += AB(l, a) * Tb[l];
+                        M[a][b] = s;
+                    }
+                }
+                const double muu = M[NXA][NXA];
+                bad = bad | !(muu > 0.0);
+                const double mi = ric_rcp(muu); // (v_rcp_f64 + two Newton steps)
+                MI[k] = mi;
+#pragma unroll
+                for (int j = 0; j < NXA; ++j) K[k][j] = -mi * M[j][NXA];
+                const double kvk = -mi * mz[NXA];
+                U[k] = kvk;
+#pragma unroll
+                for (int j = 0; j < NXA; ++j)
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) {
+                        const double s = M[i][j] + M[i][NXA] * K[k][j];
+                        Pm[i][j] = s;
+                        Pm[j][i] = s;
+                    }
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) pv[i] = mz[i] + M[i][NXA] * kvk;
+                sched_fence(); // (nothing of the next stage moves up here: in one basic block of NMAX stages the scheduler would start them all at once)
+            } else {
+                MI[k] = 0.0;
+                U[k] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NXA; ++j) K[k][j] = 0.0;
+            }
+            Tv[k] = 0.0;
+        }
+    }
+    giveup = giveup | bad;
+    stamp[2] = P.prof ? cycle_counter() : 0;
+
+    // ---- the active set of this lane ----
+    // slot a < q: where the constraint lives, packed (aloc: position in RC | step << 8 | kind << 13, kind 0: upper bound of u_step, 1: lower
+    // bound, 2 + j: row j of the step; n+ = sg x (the row as written), sg = +1 for a lower bound, -1 otherwise), its multiplier.
+    // S = N' Q^-1 N, lower triangle, the identity beyond q.
+    constexpr int kEmpty = 1 << 16;
+    auto loc_pos = [](int loc) __attribute__((always_inline)) -> int { return loc & 0xff; };
+    auto loc_step = [](int loc) __attribute__((always_inline)) -> int { return (loc >> 8) & 31; };
+    auto loc_kind = [](int loc) __attribute__((always_inline)) -> int { return (loc >> 13) & 3; };
+    auto loc_sg = [](int loc) __attribute__((always_inline)) -> double { return ((loc >> 13) & 3) == 1 ? 1.0 : -1.0; };
+    int q = 0;
+    int aloc[QMAX];
+    double alam[QMAX], S[QMAX][QMAX];
+#pragma unroll
+    for (int a = 0; a < QMAX; ++a) {
+        aloc[a] = posSpare | kEmpty;
+        alam[a] = 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) S[a][b] = (a == b) ? 1.0 : 0.0;
+    }
+    unsigned mact[2 + RPA]; // [kind] bit k: the upper bound | the lower bound of u_k | row j of step k is active
+#pragma unroll
+    for (int t = 0; t < 2 + RPA; ++t) mact[t] = 0u;
+    // the pick: where it lives, its slack, its multiplier so far; qpgen2's counters of this lane
+    bool have = false;
+    int ploc = posSpare | kEmpty;
+    double psl = 0.0, plam = 0.0;
+    int it_main = 0, it_drop = 0, nviol = 0;
+    const bool count_viol = P.lane_hist != nullptr;
+
+    // the highest STAGE a set of constraints reaches: a bound of u_k stage k, a row of step k stage min(k, NH - 1) (its state part joins the adjoint
+    // that enters stage k - 1, its control part sits in stage k); -1: none
+    auto top_stage = [&](unsigned mbounds, unsigned mrows) __attribute__((always_inline)) -> int {
+        const unsigned m = mbounds | (mrows & ~(1u << NH)) | (((mrows >> NH) & 1u) << (NH - 1));
+        return m ? 31 - __builtin_clz(m) : -1;
+    };
+    auto wave_top = [&](int k) __attribute__((always_inline)) -> int { return (int)wave_max((double)k); };
+
+    // One forward pass over the stages: the roll-out (FIRST: u_k = K_k x_k + kv_k) or the step (U += tt z with z = Q^-1 of the combined normal
+    // whose backward recursion left t_k in Tv), then the trajectory of the new iterate and qpgen2's scan on it: the most violated constraint,
+    // normalised by its row norm, the lowest index among equals.  Bounds have unit norms: the worst upper and the worst lower bound are kept
+    // as plain minima (upper bounds come first in the stacked order: the upper one wins a tie), the worst row by cross-multiplied comparison
+    // (s / |a| < s' / |a'|  <=>  s^2 |a'|^2 > s'^2 |a|^2 for negative slacks), and the three meet at the end.
+    // -> bfound: something is violated; bloc, bs: where it lives and its slack
+    bool bfound = false;
+    int bloc = posSpare | kEmpty;
+    double bs = 0.0, zz = 0.0;
+    auto forward_scan = [&](auto first_tag, double tt) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const double* const T = lds + opaque(oT);
+        const double* const UB = lds + opaque(oUB);
+        zz = 0.0;
+        double sU = thr, sL = thr, sR = 0.0, nR = 1.0; // slack of the worst upper bound | lower bound | row, and that row's squared norm
+        int kU = -1, kL = -1, cR = -1, lR = posSpare | kEmpty; // their stages | the row's index in the stacked order and where it lives
+        const unsigned mb = mact[0] | mact[1]; // (the twin of an active bound is its negative: never a candidate -- boxes are not empty here, see below)
+        double x[NXA], xi[NXA], G[NXA], W[NXA][NXA], nrow[RPA]; // iterate's state | the step's state | A^k B | sum_{t < k} G_t G_t' (row norms; CT: nrow, per row)
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) {
+            x[i] = x0[i];
+            xi[i] = 0.0;
+            G[i] = B[i];
+#pragma unroll
+            for (int j = 0; j < NXA; ++j) W[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < RPA; ++j) nrow[j] = 0.0;
+        auto rows_of = [&](int k, double uk, bool with_u) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < RPA; ++j) {
+                if (j < rpa) {
+                    double e[NXA], gq = 0.0, f, ax = 0.0, n2 = 0.0;
+                    int cid;
+                    if (CT) {
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i) e[i] = re[j][i];
+                        f = rf[j];
+                        cid = ridx0[j] + k * ridxd[j];
+                    } else {
+                        const double* const rw = T + oRows + (k * rpa + j) * RW;
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i) e[i] = rw[i];
+                        gq = with_u ? rw[NXA] : 0.0;
+                        f = rw[NXA + 1];
+                        cid = (int)rw[NXA + 2];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) ax += e[i] * x[i];
+                    if (CT) {
+                        n2 = nrow[j];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i)
+#pragma unroll
+                            for (int i2 = 0; i2 < NXA; ++i2) n2 += (e[i] * e[i2]) * W[i][i2];
+                        ax += gq * uk;
+                        n2 += gq * gq;
+                    }
+                    const double s = f - ax;
+                    const bool neg = (s < thr) & (cid >= 0);
+                    if (FIRST && count_viol) nviol += neg ? 1 : 0;
+                    const bool v = neg & (((mact[2 + j] >> k) & 1u) == 0u);
+                    if (wave_any(v)) { // (a violated row is the exception: nothing below runs where no lane has one at this step)
+                        const double l = s * s * nR, r = sR * sR * n2;
+                        const bool better = v & ((cR < 0) | (l > r) | ((l == r) & (cid < cR)));
+                        sR = better ? s : sR;
+                        nR = better ? n2 : nR;
+                        cR = better ? cid : cR;
+                        lR = better ? ((NH + k * rpa + j) | (k << 8) | ((2 + j) << 13)) : lR;
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            if (EXACT || k < NH) {
+                double u;
+                if (FIRST) {
+                    double acc = U[k];
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) acc += K[k][j] * x[j];
+                    u = acc;
+                } else {
+                    double z = Tv[k];
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) z += K[k][j] * xi[j];
+                    zz += z * z;
+                    u = U[k] + tt * z;
+                    double xn[NXA];
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) {
+                        double acc = B[i] * z;
+#pragma unroll
+                        for (int j = 0; j < NXA; ++j) acc += A[i][j] * xi[j];
+                        xn[i] = acc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) xi[i] = xn[i];
+                }
+                U[k] = u;
+                rows_of(k, u, true);
+                {
+                    const double su = (CT ? ubc : UB[k]) - u, sl = u - (CT ? lbc : UB[NH + k]);
+                    const bool free_k = ((mb >> k) & 1u) == 0u;
+                    if (FIRST && count_viol) nviol += ((su < thr) ? 1 : 0) + ((sl < thr) ? 1 : 0);
+                    const bool tu = free_k & (su < sU), tl = free_k & (sl < sL);
+                    if (wave_any(tu | tl)) {
+                        sU = tu ? su : sU;
+                        kU = tu ? k : kU;
+                        sL = tl ? sl : sL;
+                        kL = tl ? k : kL;
+                    }
+                }
+                double xn[NXA], gn[NXA];
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) {
+                    double acc = d[i] + B[i] * u, ag = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) {
+                        acc += A[i][j] * x[j];
+                        ag += A[i][j] * G[j];
+                    }
+                    xn[i] = acc;
+                    gn[i] = ag;
+                }
+                if (CT) {
+#pragma unroll
+                    for (int j = 0; j < RPA; ++j) {
+                        if (j < rpa) {
+                            double pg = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NXA; ++i) pg += re[j][i] * G[i];
+                            nrow[j] += pg * pg;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NXA; ++j) W[i][j] += G[i] * G[j];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) {
+                    x[i] = xn[i];
+                    G[i] = gn[i];
+                }
+                sched_fence();
+            }
+        }
+        rows_of(NH, 0.0, false);
+        // the worst bound (the upper one among equals), then against the worst row (rows come first in the stacked order: the row among equals)
+        const bool lower = (kL >= 0) & ((kU < 0) | (sL < sU));
+        const bool bnd = (kU >= 0) | (kL >= 0);
+        const double sB = lower ? sL : sU;
+        const int kB = lower ? kL : kU;
+        const bool row = (cR >= 0) & (!bnd | (sR * sR >= sB * sB * nR));
+        bfound = bnd | (cR >= 0);
+        bs = row ? sR : sB;
+        bloc = row ? lR : (kB | (kB << 8) | (lower ? (1 << 13) : 0));
+    };
+    // backward recursion of y = Q^-1 n for the combined normal whose coefficients sit in RC, from stage ktop down: t_k = s_k / M_uu,k into Tv (zero
+    // above ktop), returns n' Q^-1 n.  rows_live: some lane of the wave has a row in its combination (else the rows' coefficients are not even read)
+    auto backward = [&](bool rows_live, int ktop, bool clear_above) __attribute__((always_inline)) -> double {
+        const double* const T = lds + opaque(oT);
+        double mu[NXA], nqn = 0.0;
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) mu[i] = 0.0;
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k) {
+            if (k <= ktop) {
+                double nu = RC[k];
+                if (rows_live) {
+#pragma unroll
+                    for (int j = 0; j < RPA; ++j) {
+                        if (j < rpa) {
+                            const double c1 = RC[NH + (k + 1) * rpa + j];
+                            if (CT) {
+#pragma unroll
+                                for (int i = 0; i < NXA; ++i) mu[i] += c1 * re[j][i];
+                            } else {
+                                const double c0 = RC[NH + k * rpa + j];
+                                const double* const r1 = T + oRows + ((k + 1) * rpa + j) * RW;
+                                const double* const r0 = T + oRows + (k * rpa + j) * RW;
+#pragma unroll
+                                for (int i = 0; i < NXA; ++i) mu[i] += c1 * r1[i]; // the state part of a row at step k + 1 joins the adjoint here
+                                nu += c0 * r0[NXA]; // the control part of a row at step k
+                            }
+                        }
+                    }
+                }
+                double s = nu;
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) s += B[i] * mu[i];
+                const double t = s * MI[k];
+                Tv[k] = t;
+                nqn += s * t;
+                double mn[NXA];
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) { // mu <- Acl' mu + K' nu  =  A' mu + K' s
+                    double acc = K[k][i] * s;
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) acc += A[j][i] * mu[j];
+                    mn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) mu[i] = mn[i];
+                sched_fence();
+            } else if (clear_above) {
+                Tv[k] = 0.0;
+            }
+        }
+        return nqn;
+    };
+    // forward recursion of y = Q^-1 n+ up to stage ktop: the responses n_i' y of the ACTIVE constraints into RC (every other entry keeps its zero)
+    auto forward_resp = [&](bool rows_live, int ktop) __attribute__((always_inline)) {
+        const double* const T = lds + opaque(oT);
+        double xi[NXA];
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) xi[i] = 0.0;
+        const unsigned mbd = mact[0] | mact[1];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            if (k <= ktop) {
+                double y = Tv[k];
+#pragma unroll
+                for (int j = 0; j < NXA; ++j) y += K[k][j] * xi[j];
+                if ((mbd >> k) & 1u) RC[k] = y;
+                if (rows_live) {
+#pragma unroll
+                    for (int j = 0; j < RPA; ++j) {
+                        if (j < rpa && ((mact[2 + j] >> k) & 1u)) {
+                            double acc = 0.0;
+                            if (CT) {
+#pragma unroll
+                                for (int i = 0; i < NXA; ++i) acc += re[j][i] * xi[i];
+                            } else {
+                                const double* const rw = T + oRows + (k * rpa + j) * RW;
+                                acc = rw[NXA] * y;
+#pragma unroll
+                                for (int i = 0; i < NXA; ++i) acc += rw[i] * xi[i];
+                            }
+                            RC[NH + k * rpa + j] = acc;
+                        }
+                    }
+                }
+                double xn[NXA];
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) {
+                    double acc = B[i] * y;
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) acc += A[i][j] * xi[j];
+                    xn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) xi[i] = xn[i];
+                sched_fence();
+            }
+        }
+        if (rows_live && ktop >= NH - 1) {
+#pragma unroll
+            for (int j = 0; j < RPA; ++j) {
+                if (j < rpa && ((mact[2 + j] >> NH) & 1u)) {
+                    double acc = 0.0;
+                    if (CT) {
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i) acc += re[j][i] * xi[i];
+                    } else {
+                        const double* const rw = T + oRows + (NH * rpa + j) * RW;
+#pragma unroll
+                        for (int i = 0; i < NXA; ++i) acc += rw[i] * xi[i];
+                    }
+                    RC[NH + NH * rpa + j] = acc;
+                }
+            }
+        }
+    };
+    // the scan's result becomes this lane's pick (qpgen2: step 1)
+    auto take_pick = [&]() __attribute__((always_inline)) {
+        giveup = giveup | (it_main >= COPRA_AXIS_ITER_CAP);
+        it_main += 1;
+        have = bfound & !giveup;
+        ploc = have ? bloc : (posSpare | kEmpty);
+        psl = bs;
+        plam = 0.0;
+    };
+    // An empty box (or a pinned control, ub = lb: gi_core.hpp, `pinned`) makes the twin of an active bound a candidate of qpgen2's scan; the scan
+    // above never looks at twins: such a lane leaves its instance to the tier at once.
+    if (CT) {
+        giveup = giveup | !(ubc - lbc > 1e-9 * fmax(1.0, fabs(ubc)));
+    } else {
+        const double* const UB = lds + oUB;
+        for (int k = 0; k < NH; ++k) giveup = giveup | !(UB[k] - UB[NH + k] > 1e-9 * fmax(1.0, fabs(UB[k])));
+    }
+
+    // ---- 2. roll-out: the unconstrained minimiser and qpgen2's first scan ----
+    forward_scan(std::true_type {}, 0.0);
+    take_pick();
+    const int nviol0 = nviol;
+    stamp[3] = P.prof ? cycle_counter() : 0;
+
+    // ---- 3. the active-set iteration: every lane that has a pick takes one step per trip ----
+    while (wave_any(have)) {
+        const unsigned mrows_act = mact[2] | mact[2 + RPA - 1];
+        const bool rows_live = wave_any(have & ((loc_kind(ploc) >= 2) | (mrows_act != 0u)));
+        // the stages the recursions have to visit: up to the highest one the active set reaches (responses), ... or the pick (its normal)
+        const int pk_ = loc_kind(ploc);
+        const unsigned pbit = have ? (1u << loc_step(ploc)) : 0u;
+        const int ka = wave_top(have ? top_stage(mact[0] | mact[1], mrows_act) : -1);
+        const int kp = wave_top(have ? top_stage((mact[0] | mact[1]) | (pk_ < 2 ? pbit : 0u), mrows_act | (pk_ >= 2 ? pbit : 0u)) : -1);
+        // y = Q^-1 n+ ;  g = N' y ;  n+' Q^-1 n+
+        const double psg = loc_sg(ploc);
+        RC[loc_pos(ploc)] = have ? psg : 0.0; // (lanes without a pick: the spare entry)
+        const double nqn = backward(rows_live, kp, true);
+        if (ka >= 0) forward_resp(rows_live, ka);
+        double g[QMAX], r[QMAX];
+#pragma unroll
+        for (int a = 0; a < QMAX; ++a) g[a] = r[a] = 0.0;
+        if (ka >= 0) { // (no active constraint among the lanes that have a pick -- the first trip of most waves: r = 0)
+#pragma unroll
+            for (int a = 0; a < QMAX; ++a) {
+                const double v = RC[loc_pos(aloc[a])];
+                g[a] = (a < q) ? loc_sg(aloc[a]) * v : 0.0;
+            }
+            // r = S^-1 g by Cholesky (S is the identity beyond q, g is zero there: so is r)
+            double L[QMAX][QMAX], di[QMAX], w[QMAX];
+#pragma unroll
+            for (int i = 0; i < QMAX; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double s = S[i][j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) s -= L[i][t] * L[j][t];
+                    if (j < i) {
+                        L[i][j] = s * di[j];
+                    } else {
+                        giveup = giveup | (have & !(s > 0.0));
+                        di[i] = fast_rsqrt(s > 0.0 ? s : 1.0);
+                        L[i][i] = s * di[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < QMAX; ++i) {
+                double s = g[i];
+#pragma unroll
+                for (int t = 0; t < i; ++t) s -= L[i][t] * w[t];
+                w[i] = s * di[i];
+            }
+#pragma unroll
+            for (int i = QMAX - 1; i >= 0; --i) {
+                double s = w[i];
+#pragma unroll
+                for (int t = i + 1; t < QMAX; ++t) s -= L[t][i] * r[t];
+                r[i] = s * di[i];
+            }
+        }
+        double zn = nqn;
+#pragma unroll
+        for (int a = 0; a < QMAX; ++a) zn -= g[a] * r[a];
+        // t1 = min lambda_i / r_i over r_i > 0, the lowest position among equals (cross-multiplied: one division)
+        int l1 = -1;
+        double lb_ = 0.0, rb_ = 1.0;
+#pragma unroll
+        for (int a = 0; a < QMAX; ++a) {
+            const bool ok = (a < q) & (r[a] > 0.0);
+            const bool better = ok & ((l1 < 0) | (alam[a] * rb_ < lb_ * r[a]));
+            lb_ = better ? alam[a] : lb_;
+            rb_ = better ? r[a] : rb_;
+            l1 = better ? a : l1;
+        }
+        const double t1 = lb_ / rb_;
+        // t2 = -s / z'n; a direction that is zero (n+ in the span of the active normals: |z|^2 <= vsmall is checked behind the step) or not a
+        // descent direction to rounding: the tier's business
+        const bool zn_ok = (zn > 0.0) & (zn > 1e-13 * nqn);
+        giveup = giveup | (have & !zn_ok);
+        double tt = zn_ok ? -psl / zn : 0.0;
+        const bool full = !((l1 >= 0) & (t1 < tt));
+        tt = full ? tt : t1;
+        tt = (have & !giveup) ? tt : 0.0;
+        // z = Q^-1 (n+ - N r): the coefficients over the responses, the recursions again, U += tt z and the next scan
+        if (ka >= 0) { // (else: the combined normal IS n+, its recursion has been done)
+#pragma unroll
+            for (int a = 0; a < QMAX; ++a) RC[loc_pos(aloc[a])] = -r[a] * loc_sg(aloc[a]); // (empty slots: the spare entry)
+            (void)backward(rows_live, kp, false);
+        }
+        forward_scan(std::false_type {}, tt);
+        if (ka >= 0) {
+#pragma unroll
+            for (int a = 0; a < QMAX; ++a) RC[loc_pos(aloc[a])] = 0.0;
+        }
+        RC[loc_pos(ploc)] = 0.0;
+        giveup = giveup | (have & !(zz > vsmall)); // (qpgen2: no step in primal space -- a dual step, or "no solution")
+        have = have & !giveup;
+        if (have) {
+#pragma unroll
+            for (int a = 0; a < QMAX; ++a) alam[a] -= tt * r[a];
+            plam += tt;
+            if (full) {
+                // the pick joins the active set: slot q, S grows by the row [g' | n+' Q^-1 n+]
+                if (q >= QMAX) {
+                    giveup = true;
+                    have = false;
+                } else {
+#pragma unroll
+                    for (int a = 0; a < QMAX; ++a) {
+                        const bool me = a == q;
+                        aloc[a] = me ? ploc : aloc[a];
+                        alam[a] = me ? plam : alam[a];
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) S[a][b] = me ? (b == a ? nqn : g[b]) : S[a][b];
+                    }
+                    const int pk = loc_kind(ploc);
+                    const unsigned bit = 1u << loc_step(ploc);
+#pragma unroll
+                    for (int t = 0; t < 2 + RPA; ++t) mact[t] |= (t == pk) ? bit : 0u;
+                    q += 1;
+                    take_pick(); // (the scan that came with the step)
+                }
+            } else {
+                // partial step: the blocking constraint l1 leaves the active set, the pick stays (its slack moved with the step)
+                int dloc = 0;
+#pragma unroll
+                for (int a = 0; a < QMAX; ++a) dloc = (a == l1) ? aloc[a] : dloc;
+                const int dk = loc_kind(dloc);
+                const unsigned bit = 1u << loc_step(dloc);
+#pragma unroll
+                for (int t = 0; t < 2 + RPA; ++t) mact[t] &= (t == dk) ? ~bit : ~0u;
+#pragma unroll
+                for (int a = 0; a < QMAX; ++a) {
+                    const bool sh = a >= l1; // slot a takes slot a + 1
+                    const int nl = (a + 1 < QMAX) ? aloc[a + 1 < QMAX ? a + 1 : a] : (posSpare | kEmpty);
+                    const double nm = (a + 1 < QMAX) ? alam[a + 1 < QMAX ? a + 1 : a] : 0.0;
+                    aloc[a] = sh ? nl : aloc[a];
+                    alam[a] = sh ? nm : alam[a];
+                }
+                // S without row and column l1 (rows and columns behind it move up; the last becomes the identity's)
+#pragma unroll
+                for (int a = 0; a < QMAX; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b) {
+                        const double same = S[a][b];
+                        const double down = (a + 1 < QMAX) ? S[a + 1 < QMAX ? a + 1 : a][b] : (a == b ? 1.0 : 0.0);
+                        const double diag = (a + 1 < QMAX) ? S[a + 1 < QMAX ? a + 1 : a][b + 1 < QMAX ? b + 1 : b] : (a == b ? 1.0 : 0.0);
+                        S[a][b] = (b >= l1) ? diag : (a >= l1) ? down : same;
+                    }
+                q -= 1;
+                it_drop += 1;
+                psl += tt * zn;
+                if (it_drop + it_main > COPRA_AXIS_ITER_CAP) {
+                    giveup = true;
+                    have = false;
+                }
+            }
+        }
+    }
+    stamp[4] = P.prof ? cycle_counter() : 0;
+
+    // ---- 4. the instance: qpgen2's counters are the sums over its axes; one lane of it reports ----
+    int fail_i = (giveup ? 1 : 0) | (bad ? 2 : 0), adds_i = it_main - 1, drops_i = it_drop, viol_i = nviol0;
+#pragma unroll
+    for (int a = 1; a < NU; ++a) {
+        const int src = lane + a < kWave ? lane + a : lane;
+        const int f2 = shfl_i32(fail_i, src), a2 = shfl_i32(adds_i, src), d2 = shfl_i32(drops_i, src), v2 = shfl_i32(viol_i, src);
+        if (c == 0 && a < NU) { // (lane of axis 0: its instance's other axes sit in the next lanes)
+            fail_i |= f2;
+            adds_i += a2;
+            drops_i += d2;
+            viol_i += v2;
+        }
+    }
+    const bool head = valid && c == 0;
+    const bool more = head && (fail_i & 1) != 0;
+    {
+        int total = 0;
+        const int before = wave_prefix_count(more, total);
+        if (total > 0) {
+            int base = 0;
+            if (lane == 0) base = atomic_add_i32(P.lane_count, total);
+            base = bcast_i32(base, 0);
+            if (more) P.lane_list[base + before] = (fail_i & 2) ? (inst | (int)0x80000000) : inst; // (top bit: a factorisation failed -- status 2)
+        }
+        int nsteps = 0;
+        (void)wave_prefix_count(head && !more && adds_i > 0, nsteps); // instances the iteration finished here
+        if (nsteps > 0 && lane == 0) (void)atomic_add_i32(P.lane_count + 2, nsteps);
+    }
+    if (head && !more) {
+        P.status[inst] = 0;
+        P.iter[2 * (size_t)inst] = 1 + adds_i; // (qpgen2's counters: the scan that found nothing counts)
+        P.iter[2 * (size_t)inst + 1] = drops_i;
+    }
+    if (P.lane_hist) { // (first solve of a controller: the violated-row counts of the instances left over, lmpc_lane.hpp)
+        const int bin = !more ? -1 : (viol_i < kLaneHistBins - 1 ? viol_i : kLaneHistBins - 1);
+        for (int b = 0; b < kLaneHistBins; ++b) {
+            int cnt = 0;
+            (void)wave_prefix_count(bin == b, cnt);
+            if (cnt > 0 && lane == 0) (void)atomic_add_i32(P.lane_hist + b, cnt);
+        }
+    }
+
+    // ---- 5. results: U and the trajectory of the last iterate, straight from the lanes (the three lanes of an instance write neighbouring
+    //         words: 24 contiguous bytes per instance and store; the L2 of the wave's XCD puts the lines together) ----
+    if (valid) {
+        double* const xo = P.trajectory + (size_t)inst * P.X + c;
+        double* const uo = P.control + (size_t)inst * P.n + c;
+        double x[NXA];
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) x[i] = x0[i];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            if (EXACT || k < NH) {
+                const double u = U[k];
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) xo[k * NX + NU * i] = x[i];
+                uo[k * NU] = u;
+                double xn[NXA];
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) {
+                    double acc = d[i] + B[i] * u;
+#pragma unroll
+                    for (int j = 0; j < NXA; ++j) acc += A[i][j] * x[j];
+                    xn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < NXA; ++i) x[i] = xn[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) xo[NH * NX + NU * i] = x[i];
+    }
+    if (P.prof && lane == 0) {
+        stamp[5] = cycle_counter();
+        long long* pr = P.prof + 8 * (size_t)group;
+        for (int t = 0; t < 5; ++t) pr[t] = stamp[t + 1] - stamp[t];
+        pr[7] = stamp[5] - stamp[0];
+    }
+}
+
+} // namespace copra_hip

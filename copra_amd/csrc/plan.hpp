@@ -259,6 +259,42 @@ COPRA_HD inline int lane_lds_doubles(int nx, int nu, int& oH)
     const int nz = nx + nu;
     return (oH + nz * nz + nz + 1) & ~1;
 }
+// Tables of the one-(instance, AXIS)-per-lane solver (lmpc_axis.hpp; round 6) at FusedPlan::axis_tab, one block of axis_tab_doubles() per
+// axis c -- state i of the system belongs to axis i % nu, control c to axis c; nxa = nx / nu states and ONE control per axis:
+//     H (nz x nz, column-major, z = (x_axis, u_axis)) | h (nz) | HN (nxa x nxa) | hN (nxa) |
+//     rows: (N + 1) steps x axis_rpa rows of [E (nxa) | g | f | index of the row in the stacked order]   (a row that is not there: zeros, f = +inf, index -1)
+COPRA_HD inline void axis_tab_offsets(int nxa, int& oh, int& oHN, int& ohN, int& oRows)
+{
+    const int nz = nxa + 1;
+    oh = nz * nz;
+    oHN = oh + nz;
+    ohN = oHN + nxa * nxa;
+    oRows = (ohN + nxa + 1) & ~1;
+}
+COPRA_HD inline int axis_tab_doubles(int nxa, int N, int rpa)
+{
+    int oh, oHN, ohN, oRows;
+    axis_tab_offsets(nxa, oh, oHN, ohN, oRows);
+    return (oRows + (N + 1) * rpa * (nxa + 3) + 1) & ~1;
+}
+constexpr int kAxisGroup = 4; // steps per group of its result staging (U and X leave through LDS as contiguous segments per instance)
+constexpr int kAxisMaxRpa = 2; // constraint rows per axis and step it takes
+// ... and its LDS (doubles): the tables of every axis | the bounds of every axis (ub, lb: N each) | per lane: the sparse coefficient /
+// response array of the two recursions (N controls + (N + 1) rpa rows + a spare, odd stride) -- which the input staging (A | B | d | x0 of the
+// wave's instances) and the result staging (a group of steps) share
+COPRA_HD inline int axis_lds_doubles(int nx, int nu, int N, int rpa, int& oBnd, int& oRC, int& rcs)
+{
+    const int nxa = nx / nu, ipw = 64 / nu;
+    oBnd = nu * axis_tab_doubles(nxa, N, rpa);
+    oRC = oBnd + nu * 2 * N;
+    rcs = (N + (N + 1) * rpa + 1) | 1;
+    int w = 64 * rcs;
+    const int stage_in = ipw * (nx * nx + nx * nu + 2 * nx);
+    const int stage_out = ipw * (((kAxisGroup * nx) | 1) + ((kAxisGroup * nu) | 1));
+    if (stage_in > w) w = stage_in;
+    if (stage_out > w) w = stage_out;
+    return (oRC + w + 1) & ~1;
+}
 struct FusedPlan {
     // dimensions
     int nx, nu, N, n, X; // n = fullUDim, X = fullXDim
@@ -297,6 +333,8 @@ struct FusedPlan {
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // columns of a workspace row: the batch rounded up to whole waves, + 64 spare ones (what lanes without an instance write)
     int lane_from_list;
+    int axis_const; // 1: its tables are the same at every step (pure state rows present at all N + 1 steps with one E and f and indices affine in the step, one pair of bounds per control): the builds that keep them in registers
+    int axis_tab, axis_rpa; // the (instance, axis)-per-lane solver's tables in `params` (-1: the controller is not eligible) and rows per axis and step (lmpc_axis.hpp)
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)
     int lane_spec; // 1 (with lane_handover): the pass takes the first step of the active-set iteration itself where a bound on u_0 is the pick (lmpc_lane.hpp)
     double* lane_ws; // [N][lane_ws_rows][lane_bp]: what the sweep leaves per stage, lane-major

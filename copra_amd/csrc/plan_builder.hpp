@@ -208,6 +208,15 @@ inline bool ric_shape_ok(int nx, int nu, int N)
 // (run-time value, NU N <= 64; copra_hip_ric.hip): the double integrators in one, two and three dimensions -- the reference's falling
 // mass (tests/systems.h:42-229), a planar point mass, the CoM system of binding/python/tests/pyTests.py:342-359.  (6, 3) at N = 10, 15, 20
 // additionally has builds with a compile-time horizon (copra_hip.hip).  Every other shape: copra_batch_specialise.
+// Shapes and horizons the library holds the one-(instance, axis)-per-lane solver for (lmpc_axis.hpp): chains of two states and one control --
+// the double integrators in two and three dimensions (in ONE dimension the horizons its lanes have registers for are the packed kernels'
+// and the factor-only tiers': 32 variables and fewer).  -> the build's largest horizon, 0: none.
+constexpr int kAxisQmax = 6; // active constraints per (instance, axis) its lanes have room for
+inline int axis_solver_nmax(int nx, int nu, int N)
+{
+    if (nu < 2 || nu > 3 || nx != 2 * nu || N < 1) return 0;
+    return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : 0;
+}
 inline bool ric_aot_shape(int nx, int nu) { return (nx == 6 && nu == 3) || (nx == 4 && nu == 2) || (nx == 2 && nu == 1); }
 inline bool ric_aot_exact(int nx, int nu, int N) { return nx == 6 && nu == 3 && (N == 10 || N == 15 || N == 20); }
 
@@ -388,6 +397,9 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_tlds = 0;
     P.lane_cref = -1;
     P.lane_axes = 0;
+    P.axis_tab = -1;
+    P.axis_rpa = 0;
+    P.axis_const = 0;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
     if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
     std::vector<int> per_step((size_t)N + 1, 0);
@@ -485,6 +497,91 @@ inline void build_lane_tables(HostPlan& hp)
         P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u) ? tl : 0; // (four waves per CU)
     }
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
+    // Tables of the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): the same stage cost and rows, cut up axis by axis.  Eligible: the
+    // costs and every row look at one axis each (lane_axes above; a system with ONE control is one axis), at most kAxisMaxRpa rows per axis
+    // and step, no reference trajectories.  (Whether the SYSTEMS couple two axes is checked per instance by the kernel.)
+    P.axis_tab = -1;
+    P.axis_rpa = 0;
+    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || P.lane_axes) && !P.stage_refs) {
+        const int nxa = nx / nu, nza = nxa + 1, arw = nxa + 3;
+        auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
+        // rows per axis and step
+        int rpa = 0;
+        bool ok = true;
+        std::vector<int> row_axis((size_t)(N + 1) * rps, -1);
+        for (int k = 0; k <= N; ++k) {
+            std::vector<int> cnt((size_t)nu, 0);
+            for (int r = 0; r < rps; ++r) {
+                const double* row = tab.data() + oRows + ((size_t)k * rps + r) * rw;
+                if (row[nz + 1] < 0.0) continue; // (a row that is not there)
+                int ax = 0;
+                for (int a = 0; a < nz; ++a)
+                    if (row[a] != 0.0) ax = axis(a);
+                row_axis[(size_t)k * rps + r] = ax;
+                cnt[(size_t)ax] += 1;
+                if (cnt[(size_t)ax] > rpa) rpa = cnt[(size_t)ax];
+            }
+        }
+        if (rpa > kAxisMaxRpa) ok = false;
+        if (rpa < 1) rpa = 1;
+        if (ok) {
+            int aoh, aoHN, aohN, aoRows;
+            axis_tab_offsets(nxa, aoh, aoHN, aohN, aoRows);
+            const int TA = axis_tab_doubles(nxa, N, rpa);
+            std::vector<double> at((size_t)nu * TA, 0.0);
+            for (int c = 0; c < nu; ++c) {
+                double* t = at.data() + (size_t)c * TA;
+                auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; }; // axis index -> index in z = (x, u) of the system
+                for (int a = 0; a < nza; ++a) {
+                    for (int b = 0; b < nza; ++b) t[a + nza * b] = tab[(size_t)zi(a) + nz * zi(b)];
+                    t[aoh + a] = tab[(size_t)oh + zi(a)];
+                }
+                for (int a = 0; a < nxa; ++a) {
+                    for (int b = 0; b < nxa; ++b) t[aoHN + a + nxa * b] = tab[(size_t)oHN + zi(a) + nx * zi(b)];
+                    t[aohN + a] = tab[(size_t)ohN + zi(a)];
+                }
+                for (int k = 0; k <= N; ++k) {
+                    for (int j = 0; j < rpa; ++j) {
+                        t[aoRows + ((size_t)k * rpa + j) * arw + nxa + 1] = HUGE_VAL;
+                        t[aoRows + ((size_t)k * rpa + j) * arw + nxa + 2] = -1.0;
+                    }
+                    int filled_c = 0;
+                    for (int r = 0; r < rps; ++r) {
+                        if (row_axis[(size_t)k * rps + r] != c) continue;
+                        const double* row = tab.data() + oRows + ((size_t)k * rps + r) * rw;
+                        double* dst = t + aoRows + ((size_t)k * rpa + filled_c++) * arw;
+                        for (int a = 0; a < nxa; ++a) dst[a] = row[zi(a)];
+                        dst[nxa] = row[nx + c];
+                        dst[nxa + 1] = row[nz];
+                        dst[nxa + 2] = row[nz + 1];
+                    }
+                }
+            }
+            // the same tables at every step?  (FusedPlan::axis_const)
+            bool cst = true;
+            for (int c = 0; c < nu && cst; ++c) {
+                const double* t = at.data() + (size_t)c * TA;
+                for (int j = 0; j < rpa && cst; ++j) {
+                    const double* r0 = t + aoRows + (size_t)j * arw;
+                    const double* r1 = t + aoRows + ((size_t)rpa + j) * arw;
+                    const double stride = N >= 1 ? r1[nxa + 2] - r0[nxa + 2] : 0.0;
+                    for (int k = 0; k <= N && cst; ++k) {
+                        const double* rk = t + aoRows + ((size_t)k * rpa + j) * arw;
+                        for (int a = 0; a < nxa; ++a) cst = cst && rk[a] == r0[a];
+                        cst = cst && rk[nxa] == 0.0 && rk[nxa + 1] == r0[nxa + 1];
+                        cst = cst && ((r0[nxa + 2] < 0.0 && rk[nxa + 2] < 0.0) || (r0[nxa + 2] >= 0.0 && rk[nxa + 2] == r0[nxa + 2] + k * stride));
+                    }
+                }
+                for (int k = 0; k < N && cst; ++k)
+                    cst = cst && hp.ub[(size_t)k * nu + c] == hp.ub[(size_t)c] && hp.lb[(size_t)k * nu + c] == hp.lb[(size_t)c];
+            }
+            P.axis_const = cst ? 1 : 0;
+            if (hp.params.size() & 1) hp.params.push_back(0.0);
+            P.axis_tab = (int)hp.params.size();
+            P.axis_rpa = rpa;
+            hp.params.insert(hp.params.end(), at.begin(), at.end());
+        }
+    }
 }
 
 // Factor-only layouts trade columns of Q1 for instances per CU.  The next layout down the ladder from `cur`: one
@@ -633,6 +730,9 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
     P.denseQ = P.densec = P.denseE = P.densef = -1;
     P.ric_tab = -1;
     P.lane_tab = -1;
+    P.axis_tab = -1;
+    P.axis_rpa = 0;
+    P.axis_const = 0;
     if (!dQ.empty()) {
         P.denseQ = push(dQ.data(), U * U);
         P.densec = push(dc.data(), U);

@@ -162,6 +162,9 @@ typedef struct {
     double ric_step_tol, ric_mu_tol; /* interior-point tolerances (0: defaults of stage_plan.hpp) */
     /* misc */
     int debug; /* print launch geometry and adaptation decisions to stderr */
+    /* (fields are only ever APPENDED from here on: a caller built against a shorter struct keeps its meaning, struct_size says how much it knows) */
+    int no_axis_solver; /* never the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; round 6): controllers whose axes are decoupled keep the
+                           one-instance-per-lane pass + first tier */
 } copra_options_t;
 void copra_options_init(copra_options_t* opts);
 /* the process-wide defaults copra_options_init hands out and the entry points without an options argument use (copra_batch_create,

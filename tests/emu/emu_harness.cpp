@@ -6,6 +6,7 @@
 #include "../../copra_amd/csrc/lmpc_fused.hpp"
 #include "../../copra_amd/csrc/lmpc_fused_ric.hpp"
 #include "../../copra_amd/csrc/lmpc_lane.hpp"
+#include "../../copra_amd/csrc/lmpc_axis.hpp"
 #include "../../copra_amd/csrc/lmpc_large.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati.hpp"
 #include "../../copra_amd/csrc/lmpc_riccati_mfma.hpp"
@@ -343,7 +344,47 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     std::vector<double> lane_ws, lane_ws2;
     int lane_cnt[4] = { 0, 0, 0, 0 }; // (as the device's: [left over | the next solve's] [+ 2: ended by the pass's own steps])
     int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
-    if (lane_pass) {
+    // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
+    bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0 && !P.row_f_inst && !P.lb_inst
+        && !P.ub_inst && !P.stage_refs;
+    for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && !P.cost_p[k];
+    if (axis_pass) {
+        const int ipw = 64 / P.nu, groups = (dims->batch + ipw - 1) / ipw;
+        P.lane_list = lane_list.data();
+        P.lane_count = &lane_count;
+        P.lane_zero = &lane_other;
+        std::fill(g_lane_hist, g_lane_hist + kLaneHistBins, 0);
+        P.lane_hist = g_lane_hist;
+        int oB = 0, oR = 0, rcs = 0;
+        const size_t abytes = (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, oB, oR, rcs) * sizeof(double);
+        const bool small_q = std::getenv("COPRA_EMU_AXIS_QMAX2") != nullptr; // (tests: an active set that outgrows the lane -- the hand-over to the tier)
+        for (int g = 0; g < groups; ++g) {
+            int r = emu::run_wave([&]() {
+#define COPRA_EMU_AXIS(NU)                                                                                             \
+    (small_q ? (P.axis_const ? lmpc_axis_body<2, NU, 20, 2, false, true>(P, g) : lmpc_axis_body<2, NU, 20, 2, false, false>(P, g))                   \
+             : P.N == 20 && NU == 3 && P.axis_const ? lmpc_axis_body<2, NU, 20, kAxisQmax, true, true>(P, g)                                          \
+             : P.N <= 20 ? (P.axis_const ? lmpc_axis_body<2, NU, 20, kAxisQmax, false, true>(P, g) : lmpc_axis_body<2, NU, 20, kAxisQmax, false, false>(P, g)) \
+                         : (P.axis_const ? lmpc_axis_body<2, NU, 31, kAxisQmax, false, true>(P, g) : lmpc_axis_body<2, NU, 31, kAxisQmax, false, false>(P, g)))
+                if (P.nu == 3) COPRA_EMU_AXIS(3);
+                else COPRA_EMU_AXIS(2);
+#undef COPRA_EMU_AXIS
+            }, abytes, g, groups);
+            if (r != 0) return -100;
+        }
+        P.lane_hist = nullptr;
+        P.lane_from_list = 1;
+        P.lane_spec = P.lds.ricC ? 1 : 0; // (nothing is handed over: the tier sweeps for itself)
+        P.lane_handover = 0;
+        for (int k = 0; k < lane_count; ++k) {
+            const int raw = lane_list[(size_t)k], b = raw & 0x7fffffff;
+            lane_failed = raw < 0;
+            int r = emu::run_wave([&]() { body(P, b); }, bytes1, b, dims->batch);
+            if (r != 0) return -100;
+        }
+        lane_failed = false;
+        P.lane_from_list = 0;
+        if (sizes) sizes[8] = dims->batch - lane_count;
+    } else if (lane_pass) {
         const int groups = (dims->batch + 63) / 64;
         P.lane_bp = (dims->batch + 63) / 64 * 64 + 64;
         lane_ws.assign((size_t)P.N * lane_ws_rows(P.nx, P.nu) * P.lane_bp, 0.0);

@@ -34,6 +34,7 @@ OPTION_SETS = [
     dict(no_lane_handover=1, lane_min_batch=-1),
     dict(no_lane_spec=1, lane_min_batch=-1),
     dict(no_lane_axes=1, lane_min_batch=-1),
+    dict(no_axis_solver=1, lane_min_batch=-1),
     dict(no_ric=1),
     dict(no_tri=1),
     dict(ric_general=1, lane_min_batch=-1),

@@ -40,6 +40,14 @@ def _compare(emu, oracle, A, B, d, x0, N, costs, cstrs, specialised=True, same_i
     return re, ro
 
 
+
+@pytest.fixture
+def no_axis(monkeypatch):
+    """the tests of the one-instance-per-lane pass (lmpc_lane.hpp) and of what it hands to the tier: without the one-(instance, axis)-per-lane
+    solver (lmpc_axis.hpp, round 6), which takes the same controllers first"""
+    monkeypatch.setitem(OPTIONS, "no_axis_solver", 1)
+
+
 @pytest.mark.parametrize("specialised", [True, False])
 def test_config2_double_integrator(emu, oracle, specialised):
     from copra_amd import workloads
@@ -902,7 +910,7 @@ def test_riccati_factor_tier_ladder_steps(emu, oracle, steps, monkeypatch):
 
 @pytest.mark.parametrize("mode", ["spec", "handover", "filter_only", "off"])
 @pytest.mark.parametrize("batch,N,vmax,umax", [(150, 20, 0.6, 3.0), (70, 15, 0.3, 1.5), (64, 10, 0.6, 3.0)])
-def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vmax, umax):
+def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vmax, umax, no_axis):
     """lmpc_lane.hpp in front of the Riccati-factor tier: LQ sweep + roll-out with one instance per LANE (64 instances per wave; the last
     wave of the batch is ragged).  It must finish EXACTLY the instances whose unconstrained minimiser violates nothing (the oracle's
     iteration count (1, 0): qpgen2's first scan finds nothing) and leave the others to the first tier, which takes the factor over
@@ -986,7 +994,7 @@ def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
     assert 0 < finished <= re3["lane_pass_finished"] <= finished + one_bound  # (+ the first steps the pass takes itself: round 5)
 
 
-def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wave_is_decoupled(emu, oracle, monkeypatch):
+def test_lane_pass_skips_the_gains_between_decoupled_axes_only_where_a_whole_wave_is_decoupled(emu, oracle, monkeypatch, no_axis):
     """the CoM model is three decoupled double integrators and its costs couple no two axes (FusedPlan::lane_axes): the pass neither writes
     nor reads the twelve gains K(c, j), j % 3 != c, which are exactly zero then.  The systems are checked per WAVE: with ONE instance whose
     A or B couples two axes its wave keeps every entry, the other waves do not -- results equal to the oracle's either way, and equal to
@@ -1054,7 +1062,7 @@ def test_a_row_that_couples_two_axes_keeps_the_pass_off_the_axis_by_axis_steps(e
         assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-9 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-9
 
 
-def test_lane_pass_with_more_rows_per_step_than_its_prefetch_buffer_holds(emu, oracle):
+def test_lane_pass_with_more_rows_per_step_than_its_prefetch_buffer_holds(emu, oracle, no_axis):
     """six rows per step (upper AND lower velocity limits as rows) in front of the pass, whose stage buffer carries the right-hand sides of
     the first four (lmpc_lane.hpp: RQ): the others are read in place -- with the controller's right-hand sides and with every instance's own"""
     from copra_amd import workloads
@@ -1112,7 +1120,7 @@ def test_one_instance_per_lane_pass_shared_model(emu, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["falling_mass_32", "falling_mass_20", "com_12", "com_20_generic"])
-def test_one_instance_per_lane_pass_filters_for_the_other_tiers(emu, oracle, monkeypatch, case):
+def test_one_instance_per_lane_pass_filters_for_the_other_tiers(emu, oracle, monkeypatch, case, no_axis):
     """in front of a first tier that is not the Riccati-factor tier (shapes the library has no instantiation of it for: the run-time-shape
     and factor-only kernels) the pass only FILTERS: the instances at their unconstrained minimiser end in it, the tier solves the others
     from scratch.  (2, 1) and (6, 3) lanes, against the oracle."""
@@ -1365,7 +1373,7 @@ def test_published_qp_examples_on_the_kernel_body(oracle, emu, name):
         assert tuple(it[0]) == qp["iterations"]
 
 
-def test_lane_pass_counts_the_rows_the_unconstrained_minimiser_violates(oracle, emu):
+def test_lane_pass_counts_the_rows_the_unconstrained_minimiser_violates(oracle, emu, no_axis):
     """FusedPlan::lane_hist: on the first solve of a controller the one-instance-per-lane pass histograms, over the instances it leaves
     to the first tier, how many rows and bounds the unconstrained minimiser violates -- copra_batch_solve picks the tier's starting
     layout from it (the final active set is ~ 1.1 x that count).  Against numpy: -Q^-1 c of the oracle's condensed QP, rows and bounds
@@ -1420,7 +1428,7 @@ def test_riccati_factor_tier_with_a_run_time_horizon(emu, oracle, shape):
 
 
 @pytest.mark.parametrize("b,vmax,umax", [(70, 0.6, 2.0), (33, 0.3, 1.5), (96, 0.25, 1.0)])
-def test_lane_pass_takes_the_first_step_of_the_iteration(emu, oracle, monkeypatch, b, vmax, umax):
+def test_lane_pass_takes_the_first_step_of_the_iteration(emu, oracle, monkeypatch, b, vmax, umax, no_axis):
     """Round 5: where a bound on u_0 is qpgen2's first pick, the one-instance-per-lane pass takes that step itself (closed form in the
     quantities of its roll-out: lmpc_lane.hpp) and finishes the instance when the new iterate violates nothing -- iterations (2, 0), as
     the oracle counts them.  With the speculation switched off the same instances go through the first tier: same statuses, same
@@ -1584,3 +1592,119 @@ def test_shared_model_records_tier_with_per_instance_references(emu, oracle, cas
         ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], N, [dict(costs[0], p=refs[k]), costs[1]], wl["cstrs"])
         assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"])
         assert _rel(re["control"][k], ro["control"]) <= 1e-7 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-7
+
+
+# ---- the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; round 6) ----
+
+def _axis_case(emu, oracle, wl, cstrs=None, what=""):
+    cs = wl["cstrs"] if cstrs is None else cstrs
+    re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cs)
+    ro = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], cs, nthreads=4)
+    ok = ro["status"] == 0
+    assert (re["status"] == ro["status"]).all(), what
+    assert (re["iter"][ok] == ro["iter"][ok]).all(), what
+    assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-8 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-8, what
+    return re, ro
+
+
+@pytest.mark.parametrize("N,vmax,umax", [(20, 0.6, 3.0), (20, 0.25, 1.2), (15, 0.35, 1.8), (7, 0.3, 1.5)])
+def test_axis_solver_on_the_com_preview(emu, oracle, N, vmax, umax):
+    """BASELINE configs[2]'s model is three decoupled double integrators: every (instance, axis) is solved by ONE lane -- sweep, roll-out and
+    the Goldfarb-Idnani iteration in range-space form on the Riccati factor (lmpc_axis.hpp).  qpgen2's run on the whole problem is an
+    interleaving of the axes' runs: statuses, BOTH iteration counters (the sums over the axes), U and X equal the oracle's.  N = 20: the build
+    with the horizon compiled in; 7, 15: the run-time horizon of the same build.  Batches that are not a
+    multiple of the 21 instances of a wave."""
+    from copra_amd import workloads
+    b = 50 if N != 20 else 85
+    wl = workloads.com_preview(b, N=N, v_max=vmax, u_max=umax, seed=5 + N)
+    re, ro = _axis_case(emu, oracle, wl, what=(N, vmax))
+    # with six active constraints per axis nearly everything ends in it (the others: the first tier, from scratch)
+    assert re["lane_pass_finished"] >= (b - 2 if vmax >= 0.35 else b // 2)
+    assert ro["iter"][:, 0].max() >= 3
+
+
+def test_axis_solver_hands_over_what_outgrows_its_lanes(emu, oracle, monkeypatch):
+    """an axis whose active set outgrows the lane's room (here: a build with room for TWO constraints) sends its INSTANCE to the first tier's
+    list; the tier solves it from scratch -- same results, same counters"""
+    from copra_amd import workloads
+    monkeypatch.setenv("COPRA_EMU_AXIS_QMAX2", "1")
+    wl = workloads.com_preview(64, v_max=0.3, u_max=1.5, seed=9)
+    re, ro = _axis_case(emu, oracle, wl)
+    assert 0 < re["lane_pass_finished"] < 64
+
+
+def test_axis_solver_leaves_coupled_and_infeasible_instances_to_the_tier(emu, oracle):
+    """the SYSTEMS are checked per instance: one whose A or B couples two axes goes to the tier (its neighbours in the wave do not); so does an
+    instance whose x0 violates a state row (qpgen2: no step in primal space, "no solution": status 1 from the tier) and one with an empty box"""
+    from copra_amd import workloads
+    b = 45
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=3)
+    A2, B2, x2 = wl["A"].copy(), wl["B"].copy(), wl["x0"].copy()
+    A2[5, 0, 4] = 0.03  # (x position picks up y velocity)
+    B2[30, 3, 1] = 0.02  # (x velocity driven by the y control)
+    x2[12, 4] = 0.9  # (violates the velocity bound at step 0)
+    wl2 = dict(wl, A=A2, B=B2, x0=x2)
+    re, ro = _axis_case(emu, oracle, wl2)
+    assert ro["status"][12] == 1 and re["lane_pass_finished"] <= b - 3
+    same = np.ones(b, dtype=bool)
+    same[[5, 12, 30]] = False
+    base = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert (re["control"][same] == base["control"][same]).all()  # (nothing of a neighbour's result depends on them)
+
+
+def test_axis_solver_with_rows_that_change_along_the_horizon(emu, oracle):
+    """tables that are NOT the same at every step (FusedPlan::axis_const = 0: the builds that read them from LDS stage by stage): a mixed
+    constraint v_k + 0.1 u_k <= v_max per axis (rows with a control part, none at step N), lower velocity limits as rows (two rows per axis and
+    step), and control bounds that tighten along the horizon (a full-size ControlBoundConstraint)"""
+    from copra_amd import workloads
+    b, N = 40, 12
+    wl = workloads.com_preview(b, N=N, v_max=0.35, u_max=1.8, seed=21)
+    vsel = np.hstack([np.zeros((3, 3)), np.eye(3)])
+    up = np.repeat(np.linspace(2.0, 1.2, N), 3)
+    cs = [dict(kind="mixed", E=vsel, G=0.1 * np.eye(3), f=[0.35] * 3, ineq=True),
+          dict(kind="trajectory", E=-vsel, f=[0.5] * 3, ineq=True),
+          dict(kind="control_bound", lower=-up, upper=up)]
+    re, ro = _axis_case(emu, oracle, wl, cstrs=cs)
+    assert re["lane_pass_finished"] >= b // 2 and ro["iter"][:, 0].max() >= 3
+
+
+@pytest.mark.parametrize("N", [14, 27])
+def test_axis_solver_on_the_planar_point_mass(emu, oracle, N):
+    """two dimensions: 32 instances per wave; N = 27: the build for up to 31 steps.  With a gravity-like bias d and a terminal cost."""
+    rng = np.random.default_rng(N)
+    dim = 2
+    b, nx, nu = 70, 2 * dim, dim
+    T = rng.uniform(0.08, 0.15, b)
+    A = np.zeros((b, nx, nx))
+    B = np.zeros((b, nx, nu))
+    I = np.eye(dim)
+    A[:, :dim, :dim] = I
+    A[:, dim:, dim:] = I
+    A[:, :dim, dim:] = T[:, None, None] * I
+    B[:, :dim, :] = (0.5 * T * T)[:, None, None] * I
+    B[:, dim:, :] = T[:, None, None] * I
+    d = np.tile(0.01 * rng.standard_normal(nx), (b, 1))
+    x0 = np.hstack([0.3 * rng.standard_normal((b, dim)), rng.uniform(-0.25, 0.25, (b, dim))])
+    goal = np.concatenate([rng.uniform(0.5, 1.0, dim), np.zeros(dim)])
+    costs = [dict(kind="trajectory", M=np.eye(nx), p=goal, weights=[10.0] * dim + [1.0] * dim),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-2] * nu),
+             dict(kind="target", M=np.eye(nx), p=goal, weights=[50.0] * nx)]
+    inf = np.inf
+    cstrs = [dict(kind="trajectory_bound", lower=[-inf] * nx, upper=[inf] * dim + [0.9] * dim),
+             dict(kind="control_bound", lower=[-6.0] * nu, upper=[6.0] * nu)]
+    wl = dict(A=A, B=B, d=d, x0=x0, N=N, costs=costs, cstrs=cstrs)
+    re, ro = _axis_case(emu, oracle, wl)
+    assert re["lane_pass_finished"] >= b // 4 and ro["iter"][:, 0].max() >= 3
+
+
+def test_axis_solver_is_a_choice_of_kernels_not_of_results(emu, oracle, monkeypatch):
+    """copra_options_t::no_axis_solver: the same controller on the one-instance-per-lane pass + first tier -- the same statuses and counters,
+    results equal to rounding"""
+    from copra_amd import workloads
+    wl = workloads.com_preview(64, v_max=0.4, u_max=2.0, seed=17)
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    ra = emu.lmpc_solve(*args)
+    monkeypatch.setitem(OPTIONS, "no_axis_solver", 1)
+    rb = emu.lmpc_solve(*args)
+    assert (ra["status"] == rb["status"]).all() and (ra["iter"] == rb["iter"]).all()
+    assert _rel(ra["control"], rb["control"]) <= 1e-9 and _rel(ra["trajectory"], rb["trajectory"]) <= 1e-9

@@ -1,0 +1,31 @@
+"""Phase cycles of the one-(instance, axis)-per-lane solver (lmpc_axis.hpp) on the GPU box, one row per wave:
+load | sweep | roll-out + first scan | active-set iteration | results.   python tools/exp/axis_phases.py [v_max u_max]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from copra_amd import BatchLMPC, workloads  # noqa: E402
+
+b = 65536
+vm = float(sys.argv[1]) if len(sys.argv) > 1 else 0.6
+um = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+wl = workloads.com_preview(b, v_max=vm, u_max=um)
+eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+for _ in range(3):
+    eng.solve()
+eng.synchronize()
+plain = eng.last_solve_seconds() * 1e3
+eng.enable_phase_profile(True)
+eng.solve()
+eng.solve()
+pr = eng.phase_profile()
+ran, finished = eng.lane_pass_info()
+nw = (b + 20) // 21
+pw = pr[:nw]
+print("v_max %.2f: solve %.3f ms (with stamps %.3f), finished here %d of %d, waves %d" % (vm, plain, eng.last_solve_seconds() * 1e3, finished, b, nw))
+for k, name in enumerate(("load", "sweep", "roll-out", "iteration", "results")):
+    print("  %-10s mean %9.0f  min %9.0f  max %9.0f cycles per wave" % (name, pw[:, k].mean(), pw[:, k].min(), pw[:, k].max()))
+print("  %-10s mean %9.0f  min %9.0f  max %9.0f" % ("total", pw[:, 7].mean(), pw[:, 7].min(), pw[:, 7].max()))
