@@ -251,6 +251,13 @@ class BatchLMPC:
         _capi.check(self._lib.copra_batch_lane_pass_info(self._h, C.byref(ran), C.byref(fin)))
         return bool(ran.value), fin.value
 
+    def axis_solver_ran(self):
+        """whether the last solve's first kernel was the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): lane_pass_info() then counts
+        the instances that ended in IT"""
+        ran = C.c_int()
+        _capi.check(self._lib.copra_batch_lane_pass_info(self._h, C.byref(ran), None))
+        return ran.value == 2
+
     PHASES = ("preview", "costs", "norms", "cholesky", "inverse_x0", "active_set", "results", "total")
 
     def enable_phase_profile(self, on=True):

@@ -12,13 +12,14 @@ using namespace copra_hip;
 #ifndef COPRA_AXIS_WAVES
 #define COPRA_AXIS_WAVES 1 // waves per SIMD the register budget is cut for
 #endif
-template <int NXA, int NU, int NMAX, int QMAX, bool EXACT, bool CT>
-__global__ __launch_bounds__(64, (NMAX <= 20 && QMAX <= 6) ? COPRA_AXIS_WAVES : 1) void copra_lmpc_axis_kernel(const FusedPlan P)
+template <int NXA, int NU, int NMAX, int QMAX, bool EXACT, bool CT, int RPA>
+__global__ __launch_bounds__(64, COPRA_AXIS_WAVES) void copra_lmpc_axis_kernel(const FusedPlan P)
 {
-    lmpc_axis_body<NXA, NU, NMAX, QMAX, EXACT, CT>(P, (int)blockIdx.x);
+    lmpc_axis_body<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(P, (int)blockIdx.x);
 }
-// (NXA, NU, NMAX, QMAX, EXACT, CT): the headline's horizon exactly; every horizon up to 20 and up to 31 -- each with the tables in registers
-// (FusedPlan::axis_const) and with the tables read from LDS stage by stage
-#define COPRA_AXIS_KERNELS(X)                                                                                          \
-    X(2, 3, 20, 6, true, true) X(2, 3, 20, 6, false, true) X(2, 2, 20, 6, false, true) X(2, 2, 31, 6, false, true)      \
-    X(2, 3, 20, 6, false, false) X(2, 2, 20, 6, false, false) X(2, 2, 31, 6, false, false)
+// (NXA, NU, NMAX, QMAX, EXACT, CT, RPA): the headline's horizon exactly; every horizon up to 20 and -- two axes -- up to 31.  With the tables in
+// registers (FusedPlan::axis_const) for one and for two rows per axis and step; with the tables read from LDS stage by stage
+#define COPRA_AXIS_KERNELS(X)                                                                                                    \
+    X(2, 3, 20, 6, true, true, 1) X(2, 3, 20, 6, false, true, 1) X(2, 2, 20, 6, false, true, 1) X(2, 2, 31, 6, false, true, 1)    \
+    X(2, 3, 20, 6, true, true, 2) X(2, 3, 20, 6, false, true, 2) X(2, 2, 20, 6, false, true, 2) X(2, 2, 31, 6, false, true, 2)    \
+    X(2, 3, 20, 6, false, false, 2) X(2, 2, 20, 6, false, false, 2) X(2, 2, 31, 6, false, false, 2)

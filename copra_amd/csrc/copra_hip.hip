@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 
 #include "ric_kernels.hpp" // copra_lmpc_fused_ric_kernel, copra_lmpc_lane_kernel
 #include "axis_kernels.hpp" // copra_lmpc_axis_kernel: instantiated in copra_hip_axis.hip
-#define COPRA_AXIS_DECL(NXA, NU, NMAX, QMAX, EXACT, CT) extern template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT>(const FusedPlan);
+#define COPRA_AXIS_DECL(NXA, NU, NMAX, QMAX, EXACT, CT, RPA) extern template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(const FusedPlan);
 COPRA_AXIS_KERNELS(COPRA_AXIS_DECL)
 // run-time-horizon builds (NH == 0) for the shapes of ric_aot_shape: instantiated in copra_hip_ric.hip, a translation unit of its own
 #define COPRA_RIC_RT_DECL(NX, NU)                                                                                      \
@@ -389,7 +389,9 @@ static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 {
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
-#define COPRA_AXIS_PICK(NU, NMAX, EXACT) (P.axis_const ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false>)
+#define COPRA_AXIS_PICK(NU, NMAX, EXACT)                                                                                                     \
+    (P.axis_const ? (P.axis_rpa <= 1 ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 1> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 2>) \
+                  : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false, 2>)
     if (nmax == 20) return P.nu == 3 ? (P.N == 20 ? COPRA_AXIS_PICK(3, 20, true) : COPRA_AXIS_PICK(3, 20, false)) : COPRA_AXIS_PICK(2, 20, false);
     if (nmax == 31) return COPRA_AXIS_PICK(2, 31, false);
 #undef COPRA_AXIS_PICK
@@ -398,7 +400,7 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 static size_t axis_lds_bytes(const FusedPlan& P)
 {
     int oB = 0, oR = 0, rcs = 0;
-    return (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, oB, oR, rcs) * sizeof(double);
+    return (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmax, oB, oR, rcs) * sizeof(double);
 }
 static bool axis_solver_wanted(const copra_batch* h, const FusedPlan& P)
 {
@@ -984,6 +986,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_lane_count);
     (void)hipFree(h->d_lane_list);
     (void)hipFree(h->d_lane_hist);
+    (void)hipFree(h->d_axis_acc);
     (void)hipFree(h->d_lane_ws);
     (void)hipFree(h->d_lane_ws2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1463,6 +1466,20 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         h->ad.axis_off = true;
         axis_pass = false;
     }
+    int axis_spare = 0;
+    const int axis_waves = axis_pass ? axis_grid(P.nu, P.batch, axis_spare) : 0;
+    if (axis_pass && !h->d_axis_acc) { // (one word per instance on spare lanes, at most one per nu waves: sized for the batch once)
+        const size_t words = (size_t)axis_waves / (size_t)P.nu + 2;
+        hipError_t e = hipMalloc((void**)&h->d_axis_acc, words * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(h->d_axis_acc, 0, words * sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(h->d_axis_acc);
+            h->d_axis_acc = nullptr;
+            h->ad.axis_off = true;
+            axis_pass = false;
+        }
+    }
     if (axis_pass) {
         lane_pass = false;
         h->lane_cur ^= 1;
@@ -1470,10 +1487,18 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         P.lane_list = h->d_lane_list;
         P.lane_count = h->d_lane_count + h->lane_cur;
         P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
-        const unsigned ipw = 64u / (unsigned)P.nu;
-        const unsigned ga = ((unsigned)P.batch + ipw - 1) / ipw;
+        const unsigned ga = (unsigned)axis_waves;
+        P.axis_waves = axis_waves;
+        P.axis_pf = axis_waves > 1024 ? 1024 : 0; // (one wave per SIMD, 1024 SIMDs: the wave 1024 further on is the next on this one's SIMD, give or take)
+        P.axis_acc = h->d_axis_acc;
         const fused_kernel_t ak = select_axis_kernel(P);
         LDS_OPT_IN(ak, axis_lds_bytes(P));
+        if (h->hp.opt.debug) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(ak), 64, axis_lds_bytes(P));
+            fprintf(stderr, "[copra] (instance, axis)-per-lane solver: %u waves, %zu B LDS per wave, %d instances on spare lanes, occupancy API: %d waves per CU\n", ga,
+                axis_lds_bytes(P), axis_spare, per_cu);
+        }
         if (ext_timed)
             hipExtLaunchKernelGGL(ak, dim3(ga), dim3(64), axis_lds_bytes(P), s, h->ev0, nullptr, 0, P);
         else

@@ -3,5 +3,5 @@
 // A translation unit of its own: it compiles next to copra_hip.hip (make -j).
 #include "axis_kernels.hpp"
 
-#define COPRA_AXIS_INST(NXA, NU, NMAX, QMAX, EXACT, CT) template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT>(const FusedPlan);
+#define COPRA_AXIS_INST(NXA, NU, NMAX, QMAX, EXACT, CT, RPA) template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(const FusedPlan);
 COPRA_AXIS_KERNELS(COPRA_AXIS_INST)

@@ -50,26 +50,34 @@ COPRA_DEV double axis_pred(double x)
 // CT: the tables are the same at every step -- every row of the controller a pure state row present at all N + 1 steps with one E and f, the
 //     bounds of a control the same along the horizon (FusedPlan::axis_const: what TrajectoryBoundConstraint and ControlBoundConstraint produce
 //     from per-step entries, constraints.cpp:284-315, 359-367): they live in registers, nothing but the lane's sparse array is read from LDS
-template <int NXA, int NU, int NMAX, int QMAX, bool EXACT = false, bool CT = false>
+// RPA_: constraint rows per axis and step the build has registers for (FusedPlan::axis_rpa <= RPA_)
+template <int NXA, int NU, int NMAX, int QMAX, bool EXACT = false, bool CT = false, int RPA_ = kAxisMaxRpa>
 COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
 {
-    constexpr int NX = NXA * NU, NZ = NXA + 1, RW = NXA + 3, RPA = kAxisMaxRpa;
+    constexpr int NX = NXA * NU, NZ = NXA + 1, RW = NXA + 3, RPA = RPA_;
     constexpr int IPW = kWave / NU; // instances per wave
     static_assert(NXA >= 1 && NXA <= 3 && QMAX >= 1 && QMAX <= 8 && NMAX <= 31, "registers; the stage masks are 32 bits");
     const int lane = lane_id();
-    const int il = lane / NU, c = lane - il * NU; // instance of the wave | axis
+    // Lanes: NU consecutive lanes per instance, IPW instances per wave.  Where NU does not divide 64 the SPARE lanes (one per wave for three
+    // axes) take the axes of the instances behind the last wave's, NU spare lanes -- of NU consecutive waves -- per instance: 65 536 instances
+    // x 3 axes are exactly 3072 full waves, three rounds on the chip's 1024 SIMDs (with 21 instances per wave and an idle lane: 3121 waves,
+    // four rounds).  Such an instance's counters meet in a word of FusedPlan::axis_acc (below).
+    constexpr int SP = kWave - IPW * NU; // spare lanes per wave
+    const int il = lane / NU;
     const bool lane_on = il < IPW;
-    const int inst0 = group * IPW;
-    const int left = P.batch - inst0;
-    const int ninst = left < IPW ? left : IPW; // instances of this wave
-    const bool valid = lane_on && il < ninst;
-    const int ilc = valid ? il : 0; // (lanes without an instance compute on a copy of the wave's first one)
-    const int inst = inst0 + ilc;
+    const int nwaves = P.axis_waves;
+    const int nreg = IPW * nwaves < P.batch ? IPW * nwaves : P.batch; // instances on regular lanes
+    const int spare = SP > 0 ? group * SP + (lane - IPW * NU) : 0; // this spare lane's number
+    const int orph_e = SP > 0 ? spare / NU : 0; // ... the instance it works for, counted from nreg
+    const bool orphan = SP > 0 && !lane_on && nreg + orph_e < P.batch;
+    const int c = lane_on ? lane - il * NU : spare - orph_e * NU; // axis
+    const bool valid = (lane_on && group * IPW + il < nreg) || orphan;
+    const int inst = orphan ? nreg + orph_e : (valid ? group * IPW + il : (group * IPW < P.batch ? group * IPW : 0)); // (lanes without an instance compute on a copy of another one)
     const int NH = EXACT ? NMAX : P.N, rpa = P.axis_rpa;
     const double vsmall = P.vsmall, thr = -axis_pred(vsmall);
     double* const lds = lds_base();
     int oBnd_, oRC_, rcs_;
-    (void)axis_lds_doubles(NX, NU, NH, rpa, oBnd_, oRC_, rcs_);
+    (void)axis_lds_doubles(NX, NU, NH, rpa, QMAX, oBnd_, oRC_, rcs_);
     const int RCS = rcs_;
     int oh_, oHN_, ohN_, oRows_;
     axis_tab_offsets(NXA, oh_, oHN_, ohN_, oRows_);
@@ -80,6 +88,15 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     stamp[0] = P.prof ? cycle_counter() : 0;
 
     // ---- 0. this lane's system; the tables of its axis ----
+    // One wave per SIMD: nothing overlaps a wave's trips to memory, and the waves of a round start together -- their 34 MB of systems are one
+    // burst the SIMDs sit through (measured: 20 k ticks per wave alone on its CU, 37 k with every SIMD busy).  So a wave also TOUCHES the systems
+    // of the wave that will follow it on the chip (FusedPlan::axis_pf waves further on: one load per 64 bytes, summed up and looked at once,
+    // at the very end): that wave finds them in the L2 / memory-side cache, and the touch travels while this one computes.
+    constexpr int LA = (IPW * NX * NX + 7) / 8, LB = (IPW * NX * NU + 7) / 8, LV = (IPW * NX + 7) / 8; // 64-byte pieces of the wave's arrays
+    constexpr int NPF = (LA + kWave - 1) / kWave + (LB + kWave - 1) / kWave + 2 * ((LV + kWave - 1) / kWave);
+    double pft[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) pft[j] = 0.0;
     if (!CT) { // the tables and bounds of every axis: read stage by stage from LDS
         const double* const src = P.params + P.axis_tab;
         for (int e = lane; e < NU * TA; e += kWave) lds[e] = src[e];
@@ -202,6 +219,36 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             pv[i] = Tg[ohN + i];
         }
         auto AB = [&](int l, int a) __attribute__((always_inline)) -> double { return a < NXA ? A[l][a] : B[l]; };
+        sched_fence(); // (everything this wave reads for ITSELF has been requested: memory operations return in order -- the touches go last)
+        {
+            // (no branch around the loads: where a branch with a load on one side joins, everything in flight is waited for.  Without a wave to
+            //  touch for, a wave touches its own systems again.)
+            const int gp0 = group + P.axis_pf, gp = (P.axis_pf > 0 && gp0 < nwaves) ? gp0 : group;
+            const size_t i0 = (size_t)gp * IPW;
+            const int ni = (int)i0 + IPW <= P.batch ? IPW : (P.batch > (int)i0 ? P.batch - (int)i0 : 1);
+            const double* const pa = P.A + i0 * NX * NX;
+            const double* const pb = P.B + i0 * NX * NU;
+            const double* const pd = P.d + i0 * NX;
+            const double* const px = P.x0 + i0 * NX;
+            int nt = 0;
+#pragma unroll
+            for (int j = 0; j < (LA + kWave - 1) / kWave; ++j) {
+                const int e = 8 * (j * kWave + lane);
+                pft[nt++] = pa[e < ni * NX * NX ? e : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < (LB + kWave - 1) / kWave; ++j) {
+                const int e = 8 * (j * kWave + lane);
+                pft[nt++] = pb[e < ni * NX * NU ? e : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < (LV + kWave - 1) / kWave; ++j) {
+                const int e = 8 * (j * kWave + lane);
+                pft[nt++] = pd[e < ni * NX ? e : 0];
+                pft[nt++] = px[e < ni * NX ? e : 0];
+            }
+        }
+        sched_fence();
 #pragma unroll
         for (int k = NMAX - 1; k >= 0; --k) {
             if (EXACT || k < NH) {
@@ -280,13 +327,16 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     auto loc_sg = [](int loc) __attribute__((always_inline)) -> double { return ((loc >> 13) & 3) == 1 ? 1.0 : -1.0; };
     int q = 0;
     int aloc[QMAX];
-    double alam[QMAX], S[QMAX][QMAX];
+    // (S and the multipliers: this lane's LDS, behind its sparse array -- 66 registers the recursions have better use for; entry (a, b), b <= a, of S
+    //  at a (a + 1) / 2 + b)
+    double* const Sl = RC + posSpare + 1;
+    double* const alam = Sl + QMAX * (QMAX + 1) / 2;
 #pragma unroll
     for (int a = 0; a < QMAX; ++a) {
         aloc[a] = posSpare | kEmpty;
         alam[a] = 0.0;
 #pragma unroll
-        for (int b = 0; b <= a; ++b) S[a][b] = (a == b) ? 1.0 : 0.0;
+        for (int b = 0; b <= a; ++b) Sl[a * (a + 1) / 2 + b] = (a == b) ? 1.0 : 0.0;
     }
     unsigned mact[2 + RPA]; // [kind] bit k: the upper bound | the lower bound of u_k | row j of step k is active
 #pragma unroll
@@ -637,7 +687,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             for (int i = 0; i < QMAX; ++i) {
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
-                    double s = S[i][j];
+                    double s = Sl[i * (i + 1) / 2 + j];
 #pragma unroll
                     for (int t = 0; t < j; ++t) s -= L[i][t] * L[j][t];
                     if (j < i) {
@@ -673,8 +723,9 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
 #pragma unroll
         for (int a = 0; a < QMAX; ++a) {
             const bool ok = (a < q) & (r[a] > 0.0);
-            const bool better = ok & ((l1 < 0) | (alam[a] * rb_ < lb_ * r[a]));
-            lb_ = better ? alam[a] : lb_;
+            const double la = alam[a];
+            const bool better = ok & ((l1 < 0) | (la * rb_ < lb_ * r[a]));
+            lb_ = better ? la : lb_;
             rb_ = better ? r[a] : rb_;
             l1 = better ? a : l1;
         }
@@ -712,12 +763,13 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                     have = false;
                 } else {
 #pragma unroll
-                    for (int a = 0; a < QMAX; ++a) {
-                        const bool me = a == q;
-                        aloc[a] = me ? ploc : aloc[a];
-                        alam[a] = me ? plam : alam[a];
+                    for (int a = 0; a < QMAX; ++a) aloc[a] = (a == q) ? ploc : aloc[a];
+                    alam[q] = plam;
+                    {
+                        double* const row = Sl + q * (q + 1) / 2;
 #pragma unroll
-                        for (int b = 0; b <= a; ++b) S[a][b] = me ? (b == a ? nqn : g[b]) : S[a][b];
+                        for (int b = 0; b < QMAX; ++b)
+                            if (b <= q) row[b] = (b == q) ? nqn : g[b];
                     }
                     const int pk = loc_kind(ploc);
                     const unsigned bit = 1u << loc_step(ploc);
@@ -739,20 +791,30 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 for (int a = 0; a < QMAX; ++a) {
                     const bool sh = a >= l1; // slot a takes slot a + 1
                     const int nl = (a + 1 < QMAX) ? aloc[a + 1 < QMAX ? a + 1 : a] : (posSpare | kEmpty);
-                    const double nm = (a + 1 < QMAX) ? alam[a + 1 < QMAX ? a + 1 : a] : 0.0;
                     aloc[a] = sh ? nl : aloc[a];
-                    alam[a] = sh ? nm : alam[a];
                 }
-                // S without row and column l1 (rows and columns behind it move up; the last becomes the identity's)
+                {
+                    double lam_[QMAX], Sn[QMAX][QMAX];
 #pragma unroll
-                for (int a = 0; a < QMAX; ++a)
+                    for (int a = 0; a < QMAX; ++a) lam_[a] = alam[a];
+                    // S without row and column l1 (rows and columns behind it move up; the last becomes the identity's)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b) {
-                        const double same = S[a][b];
-                        const double down = (a + 1 < QMAX) ? S[a + 1 < QMAX ? a + 1 : a][b] : (a == b ? 1.0 : 0.0);
-                        const double diag = (a + 1 < QMAX) ? S[a + 1 < QMAX ? a + 1 : a][b + 1 < QMAX ? b + 1 : b] : (a == b ? 1.0 : 0.0);
-                        S[a][b] = (b >= l1) ? diag : (a >= l1) ? down : same;
+                    for (int a = 0; a < QMAX; ++a)
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) Sn[a][b] = Sl[a * (a + 1) / 2 + b];
+#pragma unroll
+                    for (int a = 0; a < QMAX; ++a) {
+                        const double nm = (a + 1 < QMAX) ? lam_[a + 1 < QMAX ? a + 1 : a] : 0.0;
+                        alam[a] = (a >= l1) ? nm : lam_[a];
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) {
+                            const double same = Sn[a][b];
+                            const double down = (a + 1 < QMAX) ? Sn[a + 1 < QMAX ? a + 1 : a][b] : (a == b ? 1.0 : 0.0);
+                            const double diag = (a + 1 < QMAX) ? Sn[a + 1 < QMAX ? a + 1 : a][b + 1 < QMAX ? b + 1 : b] : (a == b ? 1.0 : 0.0);
+                            Sl[a * (a + 1) / 2 + b] = (b >= l1) ? diag : (a >= l1) ? down : same;
+                        }
                     }
+                }
                 q -= 1;
                 it_drop += 1;
                 psl += tt * zn;
@@ -771,14 +833,33 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     for (int a = 1; a < NU; ++a) {
         const int src = lane + a < kWave ? lane + a : lane;
         const int f2 = shfl_i32(fail_i, src), a2 = shfl_i32(adds_i, src), d2 = shfl_i32(drops_i, src), v2 = shfl_i32(viol_i, src);
-        if (c == 0 && a < NU) { // (lane of axis 0: its instance's other axes sit in the next lanes)
+        if (lane_on && c == 0) { // (lane of axis 0: its instance's other axes sit in the next lanes)
             fail_i |= f2;
             adds_i += a2;
             drops_i += d2;
             viol_i += v2;
         }
     }
-    const bool head = valid && c == 0;
+    bool head = valid && lane_on && c == 0;
+    if (SP > 0) {
+        // an instance on spare lanes: its axes sit in NU different waves.  Their counters meet in a word of axis_acc -- adds | drops << 12 |
+        // give-ups << 24 | failed factorisations << 26 | arrivals << 28 --; the lane that arrives last reports and leaves the word zero for the
+        // next solve.
+        bool last = false;
+        if (orphan) {
+            const int mine = adds_i | (drops_i << 12) | ((fail_i & 1) << 24) | (((fail_i >> 1) & 1) << 26) | (1 << 28);
+            const int old = atomic_add_i32(P.axis_acc + orph_e, mine);
+            last = ((old >> 28) & 3) == NU - 1;
+            if (last) {
+                const int tot = old + mine;
+                P.axis_acc[orph_e] = 0;
+                adds_i = tot & 0xfff;
+                drops_i = (tot >> 12) & 0xfff;
+                fail_i = (((tot >> 24) & 3) ? 1 : 0) | (((tot >> 26) & 3) ? 2 : 0);
+            }
+        }
+        head = head || last;
+    }
     const bool more = head && (fail_i & 1) != 0;
     {
         int total = 0;
@@ -807,40 +888,99 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         }
     }
 
-    // ---- 5. results: U and the trajectory of the last iterate, straight from the lanes (the three lanes of an instance write neighbouring
-    //         words: 24 contiguous bytes per instance and store; the L2 of the wave's XCD puts the lines together) ----
-    if (valid) {
-        double* const xo = P.trajectory + (size_t)inst * P.X + c;
-        double* const uo = P.control + (size_t)inst * P.n + c;
-        double x[NXA];
+    // ---- 5. results: U and the trajectory of the last iterate.  The lanes' arrays are dead: their place takes the results of the wave's
+    //         instances exactly as they lie in memory -- [instance][X], then [instance][n] -- and leaves as one flat copy, 16 bytes per lane and
+    //         store.  (Straight from the lanes -- 24 contiguous bytes per instance and store -- the stores were the phase that grew with the
+    //         load on the chip: 6 k ticks for a wave alone on its CU, 14 - 18 k with every SIMD busy; profiles/r06/axis_load_sweep.txt.)  An
+    //         instance on a spare lane has its other axes elsewhere: that lane stores for itself. ----
+    {
+        const int nr = nreg - group * IPW < IPW ? (nreg - group * IPW > 0 ? nreg - group * IPW : 0) : IPW; // instances on this wave's regular lanes
+        const int XI = P.X, UI = P.n;
+        double* const sx_ = lds + oRC_; // [il][X]
+        double* const su_ = sx_ + IPW * XI; // [il][n]
+        double* const so_ = su_ + IPW * UI; // the axis of an instance on a spare lane, packed: x_k(i) at k NXA + i, then u_k
+        wave_sync(); // (every lane is through with its arrays)
+        {
+            // (lanes without an instance write like a spare lane: nobody reads it)
+            double* const xo = lane_on ? sx_ + il * XI + c : so_;
+            double* const uo = lane_on ? su_ + il * UI + c : so_ + (NH + 1) * NXA;
+            const int sxk = lane_on ? NX : NXA, sxi = lane_on ? NU : 1, suk = lane_on ? NU : 1; // strides: step | state of the axis; step
+            double x[NXA];
 #pragma unroll
-        for (int i = 0; i < NXA; ++i) x[i] = x0[i];
+            for (int i = 0; i < NXA; ++i) x[i] = x0[i];
 #pragma unroll
-        for (int k = 0; k < NMAX; ++k) {
-            if (EXACT || k < NH) {
-                const double u = U[k];
+            for (int k = 0; k < NMAX; ++k) {
+                if (EXACT || k < NH) {
+                    const double u = U[k];
 #pragma unroll
-                for (int i = 0; i < NXA; ++i) xo[k * NX + NU * i] = x[i];
-                uo[k * NU] = u;
-                double xn[NXA];
+                    for (int i = 0; i < NXA; ++i) xo[k * sxk + i * sxi] = x[i];
+                    uo[k * suk] = u;
+                    double xn[NXA];
 #pragma unroll
-                for (int i = 0; i < NXA; ++i) {
-                    double acc = d[i] + B[i] * u;
+                    for (int i = 0; i < NXA; ++i) {
+                        double acc = d[i] + B[i] * u;
 #pragma unroll
-                    for (int j = 0; j < NXA; ++j) acc += A[i][j] * x[j];
-                    xn[i] = acc;
+                        for (int j = 0; j < NXA; ++j) acc += A[i][j] * x[j];
+                        xn[i] = acc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) x[i] = xn[i];
                 }
-#pragma unroll
-                for (int i = 0; i < NXA; ++i) x[i] = xn[i];
             }
-        }
 #pragma unroll
-        for (int i = 0; i < NXA; ++i) xo[NH * NX + NU * i] = x[i];
+            for (int i = 0; i < NXA; ++i) xo[NH * sxk + i * sxi] = x[i];
+        }
+        wave_sync();
+        auto flat_out = [&](double* dst, const double* src, int count) __attribute__((always_inline)) {
+            const int even = count & ~1;
+            for (int e = 2 * lane; e < even; e += 2 * kWave) {
+                const double v0 = src[e], v1 = src[e + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef double axis_pair __attribute__((ext_vector_type(2), aligned(8)));
+                axis_pair pr;
+                pr.x = v0;
+                pr.y = v1;
+                *(axis_pair*)(dst + e) = pr;
+#else
+                dst[e] = v0;
+                dst[e + 1] = v1;
+#endif
+            }
+            if ((count & 1) && lane == 0) dst[count - 1] = src[count - 1];
+        };
+        flat_out(P.trajectory + (size_t)group * IPW * XI, sx_, nr * XI);
+        flat_out(P.control + (size_t)group * IPW * UI, su_, nr * UI);
+        if (SP > 0 && wave_any(orphan)) { // the spare lane's axis: its (NH + 1) NXA states and NH controls, one lane each (spare lanes: NU = 3, NH <= 20)
+            static_assert(SP == 0 || ((NMAX + 1) * NXA <= kWave && SP == 1), "one store for the states, one for the controls");
+            const int oi = bcast_i32(inst, kWave - 1), oc = bcast_i32(c, kWave - 1);
+            if (lane < (NH + 1) * NXA) {
+                const int k = lane / NXA, i = lane - k * NXA;
+                P.trajectory[(size_t)oi * XI + k * NX + oc + NU * i] = so_[lane];
+            }
+            if (lane < NH) P.control[(size_t)oi * UI + lane * NU + oc] = so_[(NH + 1) * NXA + lane];
+        }
+    }
+    {
+        double pf_sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(pft[j])); // (not before: the sum must not start -- and wait -- where the touches were issued)
+#endif
+            pf_sum += pft[j];
+        }
+        if (pf_sum == -1.2345678901234567e300) P.status[0] = 5; // (never: the touches above must not be optimised away -- and are waited for HERE)
     }
     if (P.prof && lane == 0) {
         stamp[5] = cycle_counter();
         long long* pr = P.prof + 8 * (size_t)group;
         for (int t = 0; t < 5; ++t) pr[t] = stamp[t + 1] - stamp[t];
+        pr[5] = stamp[0]; // (absolute: which waves ran side by side -- tools/exp/axis_phases.py)
+#if defined(__HIP_DEVICE_COMPILE__)
+        pr[6] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // XCC_ID | HW_ID: where it ran
+#else
+        pr[6] = 0;
+#endif
         pr[7] = stamp[5] - stamp[0];
     }
 }

@@ -279,21 +279,36 @@ COPRA_HD inline int axis_tab_doubles(int nxa, int N, int rpa)
 }
 constexpr int kAxisGroup = 4; // steps per group of its result staging (U and X leave through LDS as contiguous segments per instance)
 constexpr int kAxisMaxRpa = 2; // constraint rows per axis and step it takes
-// ... and its LDS (doubles): the tables of every axis | the bounds of every axis (ub, lb: N each) | per lane: the sparse coefficient /
-// response array of the two recursions (N controls + (N + 1) rpa rows + a spare, odd stride) -- which the input staging (A | B | d | x0 of the
-// wave's instances) and the result staging (a group of steps) share
-COPRA_HD inline int axis_lds_doubles(int nx, int nu, int N, int rpa, int& oBnd, int& oRC, int& rcs)
+// ... and its LDS (doubles): the tables of every axis | the bounds of every axis (ub, lb: N each) -- read there by the builds whose tables change
+// along the horizon -- | per lane (odd stride): the sparse coefficient / response array of the two recursions (N controls + (N + 1) rpa rows + a
+// spare), the matrix S of its active set and the multipliers
+COPRA_HD inline int axis_lds_doubles(int nx, int nu, int N, int rpa, int qmax, int& oBnd, int& oRC, int& rcs)
 {
-    const int nxa = nx / nu, ipw = 64 / nu;
+    const int nxa = nx / nu;
     oBnd = nu * axis_tab_doubles(nxa, N, rpa);
     oRC = oBnd + nu * 2 * N;
-    rcs = (N + (N + 1) * rpa + 1) | 1;
+    // per lane: the sparse array (+ a spare entry) | S = N' Q^-1 N of its active set, lower triangle | the multipliers
+    rcs = (N + (N + 1) * rpa + 1 + qmax * (qmax + 1) / 2 + qmax) | 1;
     int w = 64 * rcs;
-    const int stage_in = ipw * (nx * nx + nx * nu + 2 * nx);
-    const int stage_out = ipw * (((kAxisGroup * nx) | 1) + ((kAxisGroup * nu) | 1));
-    if (stage_in > w) w = stage_in;
+    const int stage_out = (64 / nu) * (nx * (N + 1) + nu * N) + (N + 1) * (nx / nu) + N + 2; // (+ the axis of an instance on a spare lane)
+    // ... whose place the results of the wave's instances take at the end, as they lie in memory
     if (stage_out > w) w = stage_out;
     return (oRC + w + 1) & ~1;
+}
+// ... its launch: waves for `batch` instances of nu axes -- 64 / nu instances per wave on regular lanes, and where nu does not divide 64 one more
+// instance per nu waves on their spare lanes (lmpc_axis.hpp) -- and how many instances sit on spare lanes
+COPRA_HD inline int axis_grid(int nu, int batch, int& on_spare)
+{
+    const int ipw = 64 / nu, sp = 64 - ipw * nu;
+    on_spare = 0;
+    if (batch <= 0) return 0;
+    if (sp == 0) return (batch + ipw - 1) / ipw;
+    // the smallest w with ipw w + floor(w sp / nu) >= batch
+    long long w = ((long long)batch * nu) / ((long long)ipw * nu + sp);
+    while (ipw * w + (w * sp) / nu < batch) ++w;
+    while (w > 0 && ipw * (w - 1) + ((w - 1) * sp) / nu >= batch) --w;
+    on_spare = batch - ipw * (int)w > 0 ? batch - ipw * (int)w : 0;
+    return (int)w;
 }
 struct FusedPlan {
     // dimensions
@@ -333,6 +348,9 @@ struct FusedPlan {
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // columns of a workspace row: the batch rounded up to whole waves, + 64 spare ones (what lanes without an instance write)
     int lane_from_list;
+    int axis_waves; // waves of its launch (axis_grid below)
+    int axis_pf; // > 0: a wave touches the systems of the wave that many further on (the one that follows it on its SIMD): lmpc_axis.hpp
+    int* axis_acc; // [axis_grid's spare instances]: where the counters of an instance on spare lanes meet (zero between solves)
     int axis_const; // 1: its tables are the same at every step (pure state rows present at all N + 1 steps with one E and f and indices affine in the step, one pair of bounds per control): the builds that keep them in registers
     int axis_tab, axis_rpa; // the (instance, axis)-per-lane solver's tables in `params` (-1: the controller is not eligible) and rows per axis and step (lmpc_axis.hpp)
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)

@@ -353,7 +353,9 @@ copra_status_t copra_batch_last_first_tier_seconds(copra_batch_t* h, double* sec
  *      is the LQ roll-out of one Riccati sweep; a pass in front of the first tier does that sweep and roll-out for the whole batch
  *      with one instance per LANE, finishes every instance whose minimiser violates no constraint (what QuadProgDense::solve returns
  *      after its first scan, src/QuadProgSolver.cpp:45-72) and hands the factor of the others to the first tier.
- *      ran: 1 if the last solve ran it; finished: the instances that ended in it (waits for the solve). ---- */
+ *      ran: 1 if the last solve ran it, 2 if it ran the one-(instance, axis)-per-lane solver instead (lmpc_axis.hpp, round 6: controllers whose
+ *      axes are decoupled -- the WHOLE solve per lane; what it cannot finish goes to the first tier the same way); finished: the instances that
+ *      ended in it (waits for the solve; NULL: not asked for). ---- */
 copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finished);
 /*      Whether the pass runs is decided per controller from the batch size (from 20480 instances on in front of the Riccati-factor
  *      tier, 4096 elsewhere) and, where it only filters, from the share of instances that ended in it in the first two solves --

@@ -349,22 +349,29 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         && !P.ub_inst && !P.stage_refs;
     for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && !P.cost_p[k];
     if (axis_pass) {
-        const int ipw = 64 / P.nu, groups = (dims->batch + ipw - 1) / ipw;
+        int on_spare = 0;
+        const int groups = axis_grid(P.nu, dims->batch, on_spare);
+        std::vector<int> axis_acc((size_t)groups / (size_t)P.nu + 2, 0);
+        P.axis_waves = groups;
+        P.axis_pf = groups > 2 ? 2 : 0; // (the touches of a later wave's systems: exercised, without effect here)
+        P.axis_acc = axis_acc.data();
         P.lane_list = lane_list.data();
         P.lane_count = &lane_count;
         P.lane_zero = &lane_other;
         std::fill(g_lane_hist, g_lane_hist + kLaneHistBins, 0);
         P.lane_hist = g_lane_hist;
         int oB = 0, oR = 0, rcs = 0;
-        const size_t abytes = (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, oB, oR, rcs) * sizeof(double);
+        const size_t abytes = (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmax, oB, oR, rcs) * sizeof(double); // (sized for the library's builds; the two-slot test build needs less)
         const bool small_q = std::getenv("COPRA_EMU_AXIS_QMAX2") != nullptr; // (tests: an active set that outgrows the lane -- the hand-over to the tier)
         for (int g = 0; g < groups; ++g) {
             int r = emu::run_wave([&]() {
-#define COPRA_EMU_AXIS(NU)                                                                                             \
-    (small_q ? (P.axis_const ? lmpc_axis_body<2, NU, 20, 2, false, true>(P, g) : lmpc_axis_body<2, NU, 20, 2, false, false>(P, g))                   \
-             : P.N == 20 && NU == 3 && P.axis_const ? lmpc_axis_body<2, NU, 20, kAxisQmax, true, true>(P, g)                                          \
-             : P.N <= 20 ? (P.axis_const ? lmpc_axis_body<2, NU, 20, kAxisQmax, false, true>(P, g) : lmpc_axis_body<2, NU, 20, kAxisQmax, false, false>(P, g)) \
-                         : (P.axis_const ? lmpc_axis_body<2, NU, 31, kAxisQmax, false, true>(P, g) : lmpc_axis_body<2, NU, 31, kAxisQmax, false, false>(P, g)))
+#define COPRA_EMU_AXIS_B(NU, NMAX, Q, EXACT)                                                                                     \
+    (P.axis_const ? (P.axis_rpa <= 1 ? lmpc_axis_body<2, NU, NMAX, Q, EXACT, true, 1>(P, g) : lmpc_axis_body<2, NU, NMAX, Q, EXACT, true, 2>(P, g)) \
+                  : lmpc_axis_body<2, NU, NMAX, Q, false, false, 2>(P, g))
+#define COPRA_EMU_AXIS(NU)                                                                                                       \
+    (small_q ? COPRA_EMU_AXIS_B(NU, 20, 2, false)                                                                                \
+             : P.N == 20 && NU == 3 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                                   \
+             : P.N <= 20 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, false) : COPRA_EMU_AXIS_B(NU, 31, kAxisQmax, false))
                 if (P.nu == 3) COPRA_EMU_AXIS(3);
                 else COPRA_EMU_AXIS(2);
 #undef COPRA_EMU_AXIS

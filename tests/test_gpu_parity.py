@@ -39,6 +39,19 @@ def _rel_vec(a, b, floor=ABS_FLOOR):
     return np.nanmax(np.abs(a - b)) / max(np.nanmax(np.abs(b)), floor)
 
 
+
+# Tests written for the one-instance-per-lane pass + first tier (rounds 3-5) and for the tier's layout ladder: they assert which kernel finished
+# what, so they pin those kernels -- the one-(instance, axis)-per-lane solver (lmpc_axis.hpp, round 6) takes the same controllers first.
+_R05_PAIR = ("test_one_instance_per_lane_pass", "test_first_tier_layout", "test_riccati_factor_tier_with_a_run_time_horizon",
+             "test_lane_pass_skips_the_gains")
+
+
+@pytest.fixture(autouse=True)
+def _pin_the_kernels_a_test_is_about(request, monkeypatch):
+    if request.node.name.startswith(_R05_PAIR):
+        monkeypatch.setitem(OPTIONS, "no_axis_solver", 1)
+
+
 def _pass_count_ok(info, iters, ok):
     """lane_pass_info() of a solve that ran the one-instance-per-lane pass against the iteration counters: the pass finishes every instance
     whose unconstrained minimiser violates nothing (counters (1, 0)) and, since round 5, the instances whose first one or two picks are
@@ -2661,3 +2674,111 @@ def test_per_instance_references_on_the_shared_model_records_tier(oracle, N):
                 assert _rel(r1["trajectory"][k], ref["trajectory"]) <= RTOL, (name, k)
                 constrained += int(ref["iter"][0] > 1)
         assert constrained >= 4, name
+
+
+
+# ---- the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; round 6) ----
+
+@pytest.mark.parametrize("vmax,umax,finished_least", [(0.6, 3.0, 65400), (0.4, 2.0, 64000), (0.25, 1.2, 40000)])
+def test_axis_solver_full_batch(oracle, vmax, umax, finished_least):
+    """BASELINE configs[2] at its batch, and two notches of constraint tightness further: every (instance, axis) on a lane of its own, the whole
+    active-set iteration in it (range-space form on the Riccati factor).  Against the oracle on a sample of 3000: statuses, BOTH iteration
+    counters (the sums over an instance's axes), U and X; over all 65 536: solved, bounds held, x_{k+1} = A x_k + B u_k + d.  Instances on
+    spare lanes (the last 1024 of the batch: their axes sit in three different waves) included in the sample."""
+    from copra_amd import BatchLMPC, workloads
+    b = 65536
+    wl = workloads.com_preview(b, v_max=vmax, u_max=umax)
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    eng.solve()
+    res = eng.results()
+    ran, finished = eng.lane_pass_info()
+    assert ran and finished >= finished_least
+    pick = np.r_[0:1500, b - 1500:b]
+    ref = oracle.lmpc_solve_batch(wl["A"][pick], wl["B"][pick], wl["d"][pick], wl["x0"][pick], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+    assert (res["status"][pick] == ref["status"]).all() and (res["iter"][pick] == ref["iter"]).all()
+    assert _rel(res["control"][pick], ref["control"]) <= RTOL and _rel(res["trajectory"][pick], ref["trajectory"]) <= RTOL
+    assert (res["status"] == 0).all()
+    U = res["control"].reshape(b, wl["N"], 3)
+    X = res["trajectory"].reshape(b, wl["N"] + 1, 6)
+    assert np.abs(U).max() <= umax + 1e-9 and X[:, :, 3:].max() <= vmax + 1e-9
+    nxt = np.einsum("bij,bkj->bki", wl["A"], X[:, :-1]) + np.einsum("bij,bkj->bki", wl["B"], U) + wl["d"][:, None, :]
+    assert np.abs(nxt - X[:, 1:]).max() <= 1e-12
+    # ... and it is a choice of kernels, not of results
+    e2 = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1))
+    e2.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    e2.solve()
+    r2 = e2.results()
+    assert (r2["status"] == res["status"]).all() and (r2["iter"] == res["iter"]).all()
+    assert _rel(r2["control"], res["control"]) <= 1e-7 and _rel(r2["trajectory"], res["trajectory"]) <= 1e-7
+
+
+@pytest.mark.parametrize("batch", [1, 20, 21, 22, 64, 1000])
+def test_axis_solver_ragged_batches(oracle, batch):
+    """batches around the 21 instances of a wave, with and without instances on spare lanes"""
+    from copra_amd import BatchLMPC, workloads
+    wl = workloads.com_preview(batch, v_max=0.4, u_max=2.0, seed=batch)
+    eng = BatchLMPC(6, 3, wl["N"], batch, wl["costs"], wl["cstrs"])
+    eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+    for _ in range(2):  # (twice: the words the counters of spare-lane instances meet in are left zero)
+        eng.solve()
+        res = eng.results()
+        ref = oracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], nthreads=8)
+        assert eng.lane_pass_info()[0]
+        assert (res["status"] == ref["status"]).all() and (res["iter"] == ref["iter"]).all()
+        assert _rel(res["control"], ref["control"]) <= RTOL and _rel(res["trajectory"], ref["trajectory"]) <= RTOL
+
+
+def test_axis_solver_leaves_what_it_cannot_decide_to_the_tier(oracle):
+    """coupled systems, a state row violated by x0 (status 1), tables that change along the horizon with two rows per axis and step: statuses,
+    counters, U and X as the oracle's"""
+    from copra_amd import BatchLMPC, workloads
+    b, N = 4096, 12
+    wl = workloads.com_preview(b, N=N, v_max=0.35, u_max=1.8, seed=21)
+    A2, B2, x2 = wl["A"].copy(), wl["B"].copy(), wl["x0"].copy()
+    A2[5, 0, 4] = 0.03
+    B2[3000, 3, 1] = 0.02
+    x2[12, 4] = 0.9
+    vsel = np.hstack([np.zeros((3, 3)), np.eye(3)])
+    up = np.repeat(np.linspace(2.0, 1.2, N), 3)
+    cs = [dict(kind="mixed", E=vsel, G=0.1 * np.eye(3), f=[0.35] * 3, ineq=True),
+          dict(kind="trajectory", E=-vsel, f=[0.5] * 3, ineq=True),
+          dict(kind="control_bound", lower=-up, upper=up)]
+    eng = BatchLMPC(6, 3, N, b, wl["costs"], cs)
+    eng.set_system(A2, B2, wl["d"], x2)
+    eng.solve()
+    res = eng.results()
+    ran, finished = eng.lane_pass_info()
+    ref = oracle.lmpc_solve_batch(A2, B2, wl["d"], x2, N, wl["costs"], cs, nthreads=8)
+    ok = ref["status"] == 0
+    assert ran and b // 2 <= finished <= b - 3 and ref["status"][12] == 1
+    assert (res["status"] == ref["status"]).all() and (res["iter"][ok] == ref["iter"][ok]).all()
+    assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
+
+
+def test_axis_solver_on_random_integrator_controllers(oracle):
+    """tests/random_controllers.py::make_integrator with two and three axes at a batch of 2048: whatever mix of costs and constraints a seed
+    draws (the eligible ones run the solver, the others the pass and the tiers)"""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    nran = ndiff = ninst = 0
+    for seed in range(300, 340):
+        c = RC.make_integrator(seed, 2048)
+        if c["nu"] == 1:
+            continue
+        eng = BatchLMPC(c["nx"], c["nu"], c["N"], 2048, c["costs"], c["cstrs"])
+        eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+        eng.solve()
+        res = eng.results()
+        axis = eng.lane_pass_info()[0] and eng.axis_solver_ran()
+        nran += 1 if axis else 0
+        pick = np.arange(0, 2048, 16)
+        ref = oracle.lmpc_solve_batch(c["A"][pick], c["B"][pick], c["d"][pick], c["x0"][pick], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        ok = ref["status"] == 0
+        what = "seed %d (%d, %d, %d) %s axis solver %s" % (seed, c["nx"], c["nu"], c["N"], c["forms"], axis)
+        assert (res["status"][pick] == ref["status"]).all(), what
+        ndiff += int((res["iter"][pick][ok] != ref["iter"][ok]).any(axis=1).sum())  # (ties of heavy instances: counted, as in the test of the r05 pair)
+        ninst += int(ok.sum())
+        assert _rel(res["control"][pick][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][pick][ok], ref["trajectory"][ok]) <= RTOL, what
+    print("   random integrator controllers: %d on the (instance, axis)-per-lane solver; iteration counters differ on %d of %d solved instances" % (nran, ndiff, ninst))
+    assert nran >= 5 and ndiff * 500 <= ninst

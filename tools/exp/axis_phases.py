@@ -23,9 +23,20 @@ eng.solve()
 eng.solve()
 pr = eng.phase_profile()
 ran, finished = eng.lane_pass_info()
-nw = (b + 20) // 21
+nw = 3072 if b == 65536 else (b + 20) // 21
 pw = pr[:nw]
 print("v_max %.2f: solve %.3f ms (with stamps %.3f), finished here %d of %d, waves %d" % (vm, plain, eng.last_solve_seconds() * 1e3, finished, b, nw))
 for k, name in enumerate(("load", "sweep", "roll-out", "iteration", "results")):
     print("  %-10s mean %9.0f  min %9.0f  max %9.0f cycles per wave" % (name, pw[:, k].mean(), pw[:, k].min(), pw[:, k].max()))
 print("  %-10s mean %9.0f  min %9.0f  max %9.0f" % ("total", pw[:, 7].mean(), pw[:, 7].min(), pw[:, 7].max()))
+
+hw = pw[:, 6].astype(np.int64)
+xcc = (hw >> 32) & 0xf
+hwid = hw & 0xffffffff
+simd = (hwid >> 4) & 3
+cu = (hwid >> 8) & 0xf
+sh = (hwid >> 12) & 1
+se = (hwid >> 13) & 7
+slot = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+print("  distinct XCCs %d, distinct CUs %d, distinct (CU, SIMD) %d" % (len(np.unique(xcc)), len(np.unique(slot)), len(np.unique(slot * 4 + simd))))
+print("  waves per SIMD id:", np.bincount(simd, minlength=4).tolist(), "| waves per CU: min %d max %d" % (np.bincount(np.unique(slot, return_inverse=True)[1]).min(), np.bincount(np.unique(slot, return_inverse=True)[1]).max()))
