@@ -549,6 +549,29 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
     return COPRA_OK;
 }
 
+// The one-(instance, axis)-per-lane solver pays where it FINISHES instances: what it lists is solved again, from scratch, by the tier.  After
+// each of a controller's first two solves on it: if it left more than half of the batch over (systems whose axes are coupled after all, active
+// sets beyond its lanes' room) the controller goes back to the one-instance-per-lane pass + tier; sampled again every 256 solves.
+static copra_status_t adapt_axis_solver(copra_batch* h)
+{
+    constexpr int kResample = 256;
+    h->ad.axis_solves += 1;
+    if (h->ad.axis_solves % kResample == 0 && h->ad.axis_adapt_left <= 0) {
+        h->ad.axis_adapt_left = 1;
+        if (h->ad.axis_off && h->ad.axis_off_by_share) h->ad.axis_off = h->ad.axis_off_by_share = false;
+    }
+    if (!h->ad.axis_ran || h->ad.axis_adapt_left <= 0) return COPRA_OK;
+    h->ad.axis_adapt_left -= 1;
+    int left = 0;
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    HIP_TRY(hipMemcpy(&left, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost));
+    if ((long long)left * 2 > (long long)h->hp.plan.batch) h->ad.axis_off = h->ad.axis_off_by_share = true;
+    if (h->hp.opt.debug)
+        fprintf(stderr, "[copra] (instance, axis)-per-lane solver: %d of %d instances left to the tier%s\n", left, h->hp.plan.batch,
+            h->ad.axis_off ? " -- switched off" : "");
+    return COPRA_OK;
+}
+
 // Compact LDS layouts (R capped, overflow finished by the second tier) bet on small active sets.  After each of the
 // first solves the overflow queue tells whether the bet holds; if more than one instance in eight had to be redone by
 // the second tier, step to the next safer layout: dense -> safe (quarter-CU compact or full) -> full.
@@ -1233,6 +1256,7 @@ static copra_status_t prepare_shared_model(copra_batch* h, hipStream_t s)
 static copra_status_t learn_from_the_last_solve(copra_batch* h)
 {
     copra_status_t rc = adapt_lane_pass(h);
+    if (rc == COPRA_OK) rc = adapt_axis_solver(h);
     if (rc == COPRA_OK) rc = adapt_layout(h);
     if (rc == COPRA_OK) rc = rechoose_layout(h);
     h->ad.solved_once = true;

@@ -78,7 +78,10 @@ struct AdaptState {
     long long lane_solves = 0; // solves seen by adapt_lane_pass
     // the one-(instance, axis)-per-lane solver (lmpc_axis.hpp)
     bool axis_ran = false; // the last solve ran it
-    bool axis_off = false; // switched off for this controller (no memory for its list)
+    bool axis_off = false; // switched off for this controller: it leaves more than half of the batch to the tier (adapt_axis_solver), or no memory for its list
+    bool axis_off_by_share = false; // ... the former: sampled again every 256 solves
+    int axis_adapt_left = 2; // solves after which its share is still looked at
+    long long axis_solves = 0;
     // shared-model tick on the records tier
     long long shared_ric_solves = 0; // solves launched on the tier's shared-model mode
     bool shared_ric_off = false; // ... which a small, constraint-heavy controller leaves after its first solve
