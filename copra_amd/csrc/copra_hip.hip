@@ -89,6 +89,15 @@ __global__ __launch_bounds__(64) void copra_lmpc_fused_tier2_kernel(const FusedP
         lmpc_fused_body<NX, NU, NH, RP>(P, P.ovf_list[k]);
         __syncthreads();
     }
+    // ... and what the first tier's grid did not reach of the list in front of it (FusedPlan::lane_cap: that grid follows the lengths of the
+    // last solves' lists; a list that grew past it -- the workload changed -- is finished here, from scratch)
+    if (P.lane_cap > 0) {
+        const int total = *P.lane_count;
+        for (int k = P.lane_cap + (int)blockIdx.x; k < total; k += (int)gridDim.x) {
+            lmpc_fused_body<NX, NU, NH, RP>(P, P.lane_list[k] & 0x7fffffff);
+            __syncthreads();
+        }
+    }
 }
 
 // Shared-model fast path (lmpc_shared.hpp): the factorisation comes from a one-workgroup prepare launch of the fused
@@ -322,6 +331,7 @@ FusedPlan device_plan(const copra_batch* h)
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
     P.lane_from_list = 0;
+    P.lane_cap = 0;
     P.lane_handover = 0;
     P.lane_spec = 0;
     P.lane_ws = nullptr;
@@ -1010,6 +1020,7 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_lane_list);
     (void)hipFree(h->d_lane_hist);
     (void)hipFree(h->d_axis_acc);
+    if (h->h_lane_seen) (void)hipHostFree(h->h_lane_seen);
     (void)hipFree(h->d_lane_ws);
     (void)hipFree(h->d_lane_ws2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1532,6 +1543,14 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         P.lane_handover = 0; // (nothing is handed over: the tier sweeps for itself)
         P.lane_spec = P.lds.ricC ? 1 : 0;
         P.lane_zero = nullptr;
+        // The tier's grid: one workgroup per list entry -- and 65 536 workgroups that find none cost 15 us, a sixth of the headline's step.  The
+        // length of a solve's list travels to the host behind it (no synchronisation: the next solve takes whatever has arrived); four times the
+        // longest of the last lists + 256 workgroups are launched, entry w by workgroup w, and the second launch walks whatever lies beyond
+        // (tier-2 kernel: a grid-stride loop -- slow, and only ever busy on the solve in which a workload changes).
+        if (h->hp.two_tier && !jit_launch && !h->packed && h->h_lane_seen) {
+            long long cap = 4LL * h->lane_seen_max + 256;
+            if (h->lane_seen_solves >= 2 && cap < (long long)P.batch) P.lane_cap = (int)((cap + 7) & ~7LL);
+        }
     }
     if (lane_pass && ensure_lane_buffers(h, true) != COPRA_OK) { // (no room for its workspace: the tier alone, from now on)
         (void)hipGetLastError();
@@ -1629,7 +1648,7 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
             fprintf(stderr, "[copra] fused first tier: %zu B LDS per instance, %d columns, q1regs %d, occupancy API: %d instances per CU\n",
                 h->hp.lds_bytes, P.lds.rcap, P.lds.q1regs, per_cu);
         }
-        const unsigned g1 = (lane_pass || axis_pass) ? (((unsigned)P.batch + 7u) & ~7u) : (unsigned)P.batch; // (the list is dealt out in eighths)
+        const unsigned g1 = P.lane_cap > 0 ? (unsigned)P.lane_cap : (lane_pass || axis_pass) ? (((unsigned)P.batch + 7u) & ~7u) : (unsigned)P.batch; // (the list is dealt out in eighths)
         if (ext_timed) // (start | end of the first launch; with a second launch the solve ends with THAT kernel's packet)
             hipExtLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s,
                 (lane_pass || axis_pass) ? nullptr : h->ev0, h->hp.two_tier ? h->evm : h->ev1, 0, P);
@@ -1642,6 +1661,7 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         FusedPlan P2 = P;
         P2.lds = h->hp.lds_full;
         P2.from_list = 1;
+        P2.lane_from_list = 0; // (its body takes the instance it is given)
         const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
         LDS_OPT_IN(select_tier2_kernel(P2), h->hp.lds_full_bytes);
         if (ext_timed)
@@ -1649,6 +1669,23 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         else
             hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
         HIP_TRY(hipGetLastError());
+    }
+    if (axis_pass) { // the length of this solve's list, for the grids of the next ones (pinned host word; nobody waits for it)
+        if (!h->h_lane_seen && hipHostMalloc((void**)&h->h_lane_seen, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->h_lane_seen = nullptr;
+        } else if (h->lane_seen_solves == 0) {
+            h->h_lane_seen[0] = h->h_lane_seen[1] = 0;
+        }
+        if (h->h_lane_seen) {
+            if (h->lane_seen_solves > 0) { // (what the LAST solve left there)
+                const int seen = h->h_lane_seen[h->lane_seen_slot];
+                h->lane_seen_max = h->lane_seen_solves % 64 == 0 ? seen : (seen > h->lane_seen_max ? seen : h->lane_seen_max); // (the window starts again every 64 solves)
+            }
+            h->lane_seen_slot ^= 1;
+            h->lane_seen_solves += 1;
+            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + h->lane_seen_slot, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost, s));
+        }
     }
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev1, s));
     h->tier_timed = ext_timed && h->hp.two_tier;

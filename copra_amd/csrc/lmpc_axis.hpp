@@ -733,11 +733,15 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         // t2 = -s / z'n; a direction that is zero (n+ in the span of the active normals: |z|^2 <= vsmall is checked behind the step) or not a
         // descent direction to rounding: the tier's business
         const bool zn_ok = (zn > 0.0) & (zn > 1e-13 * nqn);
-        giveup = giveup | (have & !zn_ok);
+        // (z'n+ zero to rounding: n+ lies in the span of the active normals -- a velocity row behind the bounds of every control in front of it.
+        //  qpgen2 then takes no step in primal space but a DUAL one -- the multipliers move by t1, the blocking constraint leaves, the pick stays --
+        //  if |z|^2 <= vsmall, which the recursion below tells)
+        const bool nostep = have & !zn_ok;
         double tt = zn_ok ? -psl / zn : 0.0;
-        const bool full = !((l1 >= 0) & (t1 < tt));
+        const bool full = zn_ok & !((l1 >= 0) & (t1 < tt));
         tt = full ? tt : t1;
-        tt = (have & !giveup) ? tt : 0.0;
+        const double tm = (have & !giveup) ? tt : 0.0; // what the multipliers move by
+        tt = nostep ? 0.0 : tm; // ... and the iterate
         // z = Q^-1 (n+ - N r): the coefficients over the responses, the recursions again, U += tt z and the next scan
         if (ka >= 0) { // (else: the combined normal IS n+, its recursion has been done)
 #pragma unroll
@@ -750,12 +754,14 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             for (int a = 0; a < QMAX; ++a) RC[loc_pos(aloc[a])] = 0.0;
         }
         RC[loc_pos(ploc)] = 0.0;
-        giveup = giveup | (have & !(zz > vsmall)); // (qpgen2: no step in primal space -- a dual step, or "no solution")
+        // qpgen2's test: |z|^2 <= vsmall -- no step in primal space.  Where z'n+ said so too and a multiplier blocks: the dual step.  Without one:
+        // "no solution" -- the tier reports it.  Where the two tests disagree: the tier decides.
+        giveup = giveup | (have & !nostep & !(zz > vsmall)) | (nostep & (!(zz <= vsmall) | (l1 < 0)));
         have = have & !giveup;
         if (have) {
 #pragma unroll
-            for (int a = 0; a < QMAX; ++a) alam[a] -= tt * r[a];
-            plam += tt;
+            for (int a = 0; a < QMAX; ++a) alam[a] -= tm * r[a];
+            plam += tm;
             if (full) {
                 // the pick joins the active set: slot q, S grows by the row [g' | n+' Q^-1 n+]
                 if (q >= QMAX) {

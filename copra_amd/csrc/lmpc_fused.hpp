@@ -56,6 +56,13 @@ COPRA_DEV bool tier_instance(const FusedPlan& P, int w, int& inst, bool& lane_fa
     inst = P.inst_offset + w;
     lane_failed = false;
     if (!P.lane_from_list) return true;
+    if (P.lane_cap > 0) { // (a grid sized from the last solves' lists: entry w, no dealing in eighths -- what lies beyond the grid is the second launch's)
+        if (w >= *P.lane_count || w >= P.lane_cap) return false;
+        inst = P.lane_list[w];
+        lane_failed = inst < 0;
+        inst &= 0x7fffffff;
+        return true;
+    }
     const int cnt = *P.lane_count, per = (cnt + 7) >> 3;
     const int idx = (w & 7) * per + (w >> 3);
     if ((w >> 3) >= per || idx >= cnt) return false;

@@ -348,6 +348,8 @@ struct FusedPlan {
                    // instead of through scalar loads: three round trips per stage less); 0: they do not fit next to four waves' staging areas
     int lane_bp; // columns of a workspace row: the batch rounded up to whole waves, + 64 spare ones (what lanes without an instance write)
     int lane_from_list;
+    int lane_cap; // > 0 (with lane_from_list): the first tier was launched for the first lane_cap entries of the list only, entry w by workgroup w; the
+                  // second launch (the tier-2 kernel) walks the rest -- usually none (copra_hip.hip: the grid follows the last solves' list lengths)
     int axis_waves; // waves of its launch (axis_grid below)
     int axis_pf; // > 0: a wave touches the systems of the wave that many further on (the one that follows it on its SIMD): lmpc_axis.hpp
     int* axis_acc; // [axis_grid's spare instances]: where the counters of an instance on spare lanes meet (zero between solves)

@@ -269,6 +269,50 @@ def lmpc_solve(A, B, d, x0, N, costs, cstrs, initial_state=None):
     return out
 
 
+_qlib = None
+
+
+def quad_lib():
+    """libcopra_oracle_quad.so: the same source compiled with `double` meaning __float128 (oracle/copra_oracle_quad.c)"""
+    global _qlib
+    if _qlib is None:
+        path = os.path.join(_HERE, "libcopra_oracle_quad.so")
+        srcs = [os.path.join(_HERE, f) for f in ("copra_oracle_quad.c", "copra_oracle.c", "copra_oracle.h")]
+        if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", _HERE, "libcopra_oracle_quad.so"], stdout=subprocess.DEVNULL)
+        _qlib = C.CDLL(path)
+        _qlib.orq_solve.restype = C.c_int
+    return _qlib
+
+
+def lmpc_solve_quad(A, B, d, x0, N, costs, cstrs, initial_state=None):
+    """LMPC::solve / InitialStateLMPC::solve by the oracle's own statements in IEEE binary128 arithmetic; doubles in, doubles out.
+    Returns dict(control, trajectory, status, iter[, x0_opt])."""
+    keep = _Keep()
+    A, B, d, x0 = _f(A), _f(B), _f(d), _f(x0)
+    nx, nu = B.shape
+    X, U = nx * (N + 1), nu * N
+    cc, kk = _pack_costs(costs, keep), _pack_cstrs(cstrs, keep)
+    u = np.full(U, np.nan)
+    tr = np.full(X, np.nan)
+    x0o = np.full(nx, np.nan)
+    it = (C.c_int * 2)()
+    null = C.c_void_p()
+    if initial_state is None:
+        rc = quad_lib().orq_solve(nx, nu, N, _ptr(A), _ptr(B), _ptr(d), _ptr(x0), len(costs), cc, len(cstrs), kk, null, null, null, null,
+                                  _ptr(u), _ptr(tr), _ptr(x0o), it)
+    else:
+        R, r = _f(initial_state["R"]), _f(initial_state["r"])
+        lo, up = _f(initial_state["x0lb"]), _f(initial_state["x0ub"])
+        rc = quad_lib().orq_solve(nx, nu, N, _ptr(A), _ptr(B), _ptr(d), _ptr(x0), len(costs), cc, len(cstrs), kk, _ptr(R), _ptr(r),
+                                  _ptr(lo), _ptr(up), _ptr(u), _ptr(tr), _ptr(x0o), it)
+    _check(rc)
+    out = dict(control=u, trajectory=tr, status=rc, iter=(it[0], it[1]))
+    if initial_state is not None:
+        out["x0_opt"] = x0o
+    return out
+
+
 def lmpc_solve_batch(A, B, d, x0, N, costs, cstrs, nthreads=1, native=False):
     """Batched CPU driver: A (b,nx,nx), B (b,nx,nu), d (b,nx), x0 (b,nx) in natural numpy (row-major) indexing."""
     keep = _Keep()
