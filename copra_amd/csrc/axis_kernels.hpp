@@ -23,3 +23,17 @@ __global__ __launch_bounds__(64, COPRA_AXIS_WAVES) void copra_lmpc_axis_kernel(c
     X(2, 3, 20, 6, true, true, 1) X(2, 3, 20, 6, false, true, 1) X(2, 2, 20, 6, false, true, 1) X(2, 2, 31, 6, false, true, 1)    \
     X(2, 3, 20, 6, true, true, 2) X(2, 3, 20, 6, false, true, 2) X(2, 2, 20, 6, false, true, 2) X(2, 2, 31, 6, false, true, 2)    \
     X(2, 3, 20, 6, false, false, 2) X(2, 2, 20, 6, false, false, 2) X(2, 2, 31, 6, false, false, 2)
+
+// The second chance of what that launch lists: the same solver with room for kAxisQmaxBig active constraints per lane, instances taken from the
+// list (a grid-stride loop over it: the launch does not know its length).  One wave per CU at most (its lanes' LDS): a handful of waves.
+template <int NXA, int NU, int NMAX, int QMAX, bool CT, int RPA>
+__global__ __launch_bounds__(64, 1) void copra_lmpc_axis_list_kernel(const FusedPlan P)
+{
+    constexpr int IPW = 64 / NU;
+    const int count = *P.axis_list_count;
+    for (int g = (int)blockIdx.x; g * IPW < count; g += (int)gridDim.x) {
+        lmpc_axis_body<NXA, NU, NMAX, QMAX, false, CT, RPA, true>(P, g);
+        __syncthreads();
+    }
+}
+#define COPRA_AXIS_LIST_KERNELS(X) X(2, 3, 20, 16, true, 2) X(2, 2, 20, 16, true, 2) X(2, 2, 31, 16, true, 2) X(2, 3, 20, 16, false, 2) X(2, 2, 20, 16, false, 2) X(2, 2, 31, 16, false, 2)

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 #include "axis_kernels.hpp" // copra_lmpc_axis_kernel: instantiated in copra_hip_axis.hip
 #define COPRA_AXIS_DECL(NXA, NU, NMAX, QMAX, EXACT, CT, RPA) extern template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(const FusedPlan);
 COPRA_AXIS_KERNELS(COPRA_AXIS_DECL)
+#define COPRA_AXIS_LIST_DECL(NXA, NU, NMAX, QMAX, CT, RPA) extern template __global__ void copra_lmpc_axis_list_kernel<NXA, NU, NMAX, QMAX, CT, RPA>(const FusedPlan);
+COPRA_AXIS_LIST_KERNELS(COPRA_AXIS_LIST_DECL)
 // run-time-horizon builds (NH == 0) for the shapes of ric_aot_shape: instantiated in copra_hip_ric.hip, a translation unit of its own
 #define COPRA_RIC_RT_DECL(NX, NU)                                                                                      \
     extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, false>(const FusedPlan);      \
@@ -406,6 +408,21 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
     if (nmax == 31) return COPRA_AXIS_PICK(2, 31, false);
 #undef COPRA_AXIS_PICK
     return nullptr;
+}
+// ... and the second chance of what it lists: room for kAxisQmaxBig active constraints per lane
+static fused_kernel_t select_axis_list_kernel(const FusedPlan& P)
+{
+    const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+#define COPRA_AXIS_LPICK(NU, NMAX) (P.axis_const ? copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, true, 2> : copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, false, 2>)
+    if (nmax == 20) return P.nu == 3 ? COPRA_AXIS_LPICK(3, 20) : COPRA_AXIS_LPICK(2, 20);
+    if (nmax == 31) return COPRA_AXIS_LPICK(2, 31);
+#undef COPRA_AXIS_LPICK
+    return nullptr;
+}
+static size_t axis_list_lds_bytes(const FusedPlan& P)
+{
+    int oB = 0, oR = 0, rcs = 0;
+    return (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmaxBig, oB, oR, rcs) * sizeof(double);
 }
 static size_t axis_lds_bytes(const FusedPlan& P)
 {
@@ -1020,6 +1037,8 @@ void copra_batch_destroy(copra_batch_t* h)
     (void)hipFree(h->d_lane_list);
     (void)hipFree(h->d_lane_hist);
     (void)hipFree(h->d_axis_acc);
+    (void)hipFree(h->d_axis_list2);
+    (void)hipFree(h->d_axis_count2);
     if (h->h_lane_seen) (void)hipHostFree(h->h_lane_seen);
     (void)hipFree(h->d_lane_ws);
     (void)hipFree(h->d_lane_ws2);
@@ -1503,6 +1522,19 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
     }
     int axis_spare = 0;
     const int axis_waves = axis_pass ? axis_grid(P.nu, P.batch, axis_spare) : 0;
+    if (axis_pass && !h->d_axis_list2) { // the second chance's own list (the first tier's, then) and its length
+        hipError_t e = hipMalloc((void**)&h->d_axis_list2, ((size_t)P.batch + 64) * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&h->d_axis_count2, 4 * sizeof(int)); // ([0]: entries; [2]: instances its own steps ended, as d_lane_count)
+        if (e == hipSuccess) e = hipMemset(h->d_axis_count2, 0, 4 * sizeof(int));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(h->d_axis_list2);
+            (void)hipFree(h->d_axis_count2);
+            h->d_axis_list2 = h->d_axis_count2 = nullptr;
+            h->ad.axis_off = true;
+            axis_pass = false;
+        }
+    }
     if (axis_pass && !h->d_axis_acc) { // (one word per instance on spare lanes, at most one per nu waves: sized for the batch once)
         const size_t words = (size_t)axis_waves / (size_t)P.nu + 2;
         hipError_t e = hipMalloc((void**)&h->d_axis_acc, words * sizeof(int));
@@ -1523,6 +1555,9 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         P.lane_count = h->d_lane_count + h->lane_cur;
         P.lane_zero = h->d_lane_count + (h->lane_cur ^ 1);
         const unsigned ga = (unsigned)axis_waves;
+        P.axis_count2 = h->d_axis_count2;
+        P.axis_list_in = nullptr;
+        P.axis_list_count = nullptr;
         P.axis_waves = axis_waves;
         P.axis_pf = axis_waves > 1024 ? 1024 : 0; // (one wave per SIMD, 1024 SIMDs: the wave 1024 further on is the next on this one's SIMD, give or take)
         P.axis_acc = h->d_axis_acc;
@@ -1539,6 +1574,27 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         else
             hipLaunchKernelGGL(ak, dim3(ga), dim3(64), axis_lds_bytes(P), s, P);
         HIP_TRY(hipGetLastError());
+        // the second chance of what it listed (active sets beyond its lanes' six constraints): the same solver with room for sixteen, instances
+        // from the list -- a few waves that walk it, however long it is -- appending what IT cannot finish to the list the first tier takes
+        {
+            FusedPlan Pl = P;
+            Pl.axis_list_in = h->d_lane_list;
+            Pl.axis_list_count = h->d_lane_count + h->lane_cur;
+            Pl.lane_list = h->d_axis_list2;
+            Pl.lane_count = h->d_axis_count2;
+            Pl.lane_zero = nullptr;
+            Pl.lane_hist = nullptr;
+            Pl.axis_pf = 0;
+            Pl.prof = nullptr;
+            const fused_kernel_t lk = select_axis_list_kernel(P);
+            const long long want = (4LL * h->lane_seen_first_max) / (64 / P.nu) + 8;
+            const unsigned gl = (unsigned)(want < 8 ? 8 : want > 512 ? 512 : want); // (one wave per CU at most: 256 CUs)
+            LDS_OPT_IN(lk, axis_list_lds_bytes(P));
+            hipLaunchKernelGGL(lk, dim3(gl), dim3(64), axis_list_lds_bytes(P), s, Pl);
+            HIP_TRY(hipGetLastError());
+        }
+        P.lane_list = h->d_axis_list2;
+        P.lane_count = h->d_axis_count2;
         P.lane_from_list = 1;
         P.lane_handover = 0; // (nothing is handed over: the tier sweeps for itself)
         P.lane_spec = P.lds.ricC ? 1 : 0;
@@ -1671,20 +1727,22 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
         HIP_TRY(hipGetLastError());
     }
     if (axis_pass) { // the length of this solve's list, for the grids of the next ones (pinned host word; nobody waits for it)
-        if (!h->h_lane_seen && hipHostMalloc((void**)&h->h_lane_seen, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        if (!h->h_lane_seen && hipHostMalloc((void**)&h->h_lane_seen, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             h->h_lane_seen = nullptr;
         } else if (h->lane_seen_solves == 0) {
-            h->h_lane_seen[0] = h->h_lane_seen[1] = 0;
+            h->h_lane_seen[0] = h->h_lane_seen[1] = h->h_lane_seen[2] = h->h_lane_seen[3] = 0;
         }
         if (h->h_lane_seen) {
             if (h->lane_seen_solves > 0) { // (what the LAST solve left there)
-                const int seen = h->h_lane_seen[h->lane_seen_slot];
+                const int seen = h->h_lane_seen[h->lane_seen_slot], seen1 = h->h_lane_seen[2 + h->lane_seen_slot];
                 h->lane_seen_max = h->lane_seen_solves % 64 == 0 ? seen : (seen > h->lane_seen_max ? seen : h->lane_seen_max); // (the window starts again every 64 solves)
+                h->lane_seen_first_max = h->lane_seen_solves % 64 == 0 ? seen1 : (seen1 > h->lane_seen_first_max ? seen1 : h->lane_seen_first_max);
             }
             h->lane_seen_slot ^= 1;
             h->lane_seen_solves += 1;
-            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + h->lane_seen_slot, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + h->lane_seen_slot, h->d_axis_count2, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the tier got)
+            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + 2 + h->lane_seen_slot, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the second chance got)
         }
     }
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev1, s));

@@ -5,3 +5,5 @@
 
 #define COPRA_AXIS_INST(NXA, NU, NMAX, QMAX, EXACT, CT, RPA) template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(const FusedPlan);
 COPRA_AXIS_KERNELS(COPRA_AXIS_INST)
+#define COPRA_AXIS_LIST_INST(NXA, NU, NMAX, QMAX, CT, RPA) template __global__ void copra_lmpc_axis_list_kernel<NXA, NU, NMAX, QMAX, CT, RPA>(const FusedPlan);
+COPRA_AXIS_LIST_KERNELS(COPRA_AXIS_LIST_INST)

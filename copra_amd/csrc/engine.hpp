@@ -144,8 +144,9 @@ struct copra_batch {
     int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
     double* d_lane_ws = nullptr;
     int* h_lane_seen = nullptr; // pinned: [2] the lengths of the last solves' first-tier lists as they arrive (solve_one_wave: the tier's grid follows them)
-    int lane_seen_slot = 0, lane_seen_max = 0;
+    int lane_seen_slot = 0, lane_seen_max = 0, lane_seen_first_max = 0; // (of the tier's list | of the first launch's list, which the second chance walks)
     long long lane_seen_solves = 0;
+    int *d_axis_list2 = nullptr, *d_axis_count2 = nullptr; // the list the second chance of the (instance, axis)-per-lane solver appends to (the first tier's, then) and its length
     int* d_axis_acc = nullptr; // lmpc_axis.hpp: the words in which the counters of instances on spare lanes meet (FusedPlan::axis_acc; zero between solves)
     double* d_lane_ws2 = nullptr; // the instance-major hand-over blocks of the pass (FusedPlan::lane_ws2)
     int lane_cur = 0; // the counter the last solve appended to

@@ -51,39 +51,46 @@ COPRA_DEV double axis_pred(double x)
 //     bounds of a control the same along the horizon (FusedPlan::axis_const: what TrajectoryBoundConstraint and ControlBoundConstraint produce
 //     from per-step entries, constraints.cpp:284-315, 359-367): they live in registers, nothing but the lane's sparse array is read from LDS
 // RPA_: constraint rows per axis and step the build has registers for (FusedPlan::axis_rpa <= RPA_)
-template <int NXA, int NU, int NMAX, int QMAX, bool EXACT = false, bool CT = false, int RPA_ = kAxisMaxRpa>
+// LIST: the SECOND CHANCE of the instances the first launch listed (FusedPlan::axis_list_in): the same solver with room for more active
+//       constraints per lane (QMAX > 8: S, its factor and the small vectors in the lane's LDS, loops with run-time trip counts), the wave's
+//       instances taken from the list, loaded and stored lane by lane; what it cannot finish either goes on to the first tier's list
+template <int NXA, int NU, int NMAX, int QMAX, bool EXACT = false, bool CT = false, int RPA_ = kAxisMaxRpa, bool LIST = false>
 COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
 {
     constexpr int NX = NXA * NU, NZ = NXA + 1, RW = NXA + 3, RPA = RPA_;
     constexpr int IPW = kWave / NU; // instances per wave
-    static_assert(NXA >= 1 && NXA <= 3 && QMAX >= 1 && QMAX <= 8 && NMAX <= 31, "registers; the stage masks are 32 bits");
+    static_assert(NXA >= 1 && NXA <= 3 && QMAX >= 1 && QMAX <= 16 && NMAX <= 31, "registers; the stage masks are 32 bits");
     const int lane = lane_id();
     // Lanes: NU consecutive lanes per instance, IPW instances per wave.  Where NU does not divide 64 the SPARE lanes (one per wave for three
     // axes) take the axes of the instances behind the last wave's, NU spare lanes -- of NU consecutive waves -- per instance: 65 536 instances
     // x 3 axes are exactly 3072 full waves, three rounds on the chip's 1024 SIMDs (with 21 instances per wave and an idle lane: 3121 waves,
     // four rounds).  Such an instance's counters meet in a word of FusedPlan::axis_acc (below).
-    constexpr int SP = kWave - IPW * NU; // spare lanes per wave
+    constexpr int SP = LIST ? 0 : kWave - IPW * NU; // spare lanes per wave
     const int il = lane / NU;
     const bool lane_on = il < IPW;
     const int nwaves = P.axis_waves;
-    const int nreg = IPW * nwaves < P.batch ? IPW * nwaves : P.batch; // instances on regular lanes
+    const int list_n = LIST ? *P.axis_list_count : 0; // (second chance: entries of the first launch's list)
+    const int nreg = LIST ? list_n : (IPW * nwaves < P.batch ? IPW * nwaves : P.batch); // instances on regular lanes
     const int spare = SP > 0 ? group * SP + (lane - IPW * NU) : 0; // this spare lane's number
     const int orph_e = SP > 0 ? spare / NU : 0; // ... the instance it works for, counted from nreg
     const bool orphan = SP > 0 && !lane_on && nreg + orph_e < P.batch;
     const int c = lane_on ? lane - il * NU : spare - orph_e * NU; // axis
     const bool valid = (lane_on && group * IPW + il < nreg) || orphan;
-    const int inst = orphan ? nreg + orph_e : (valid ? group * IPW + il : (group * IPW < P.batch ? group * IPW : 0)); // (lanes without an instance compute on a copy of another one)
+    // (lanes without an instance compute on a copy of another one)
+    const int slot = orphan ? nreg + orph_e : (valid ? group * IPW + il : (group * IPW < nreg ? group * IPW : 0));
+    const int inst = LIST ? (list_n > 0 ? (P.axis_list_in[slot] & 0x7fffffff) : 0) : slot;
     const int NH = EXACT ? NMAX : P.N, rpa = P.axis_rpa;
     const double vsmall = P.vsmall, thr = -axis_pred(vsmall);
     double* const lds = lds_base();
     int oBnd_, oRC_, rcs_;
     (void)axis_lds_doubles(NX, NU, NH, rpa, QMAX, oBnd_, oRC_, rcs_);
+    if (!LIST && P.axis_count2 && group == 0 && lane == 0) *P.axis_count2 = 0; // (the second chance's own list: empty before that launch appends to it)
     const int RCS = rcs_;
     int oh_, oHN_, ohN_, oRows_;
     axis_tab_offsets(NXA, oh_, oHN_, ohN_, oRows_);
     const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
     const int TA = axis_tab_doubles(NXA, NH, rpa);
-    if (P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
+    if (!LIST && P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
     long long stamp[6];
     stamp[0] = P.prof ? cycle_counter() : 0;
 
@@ -223,7 +230,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         {
             // (no branch around the loads: where a branch with a load on one side joins, everything in flight is waited for.  Without a wave to
             //  touch for, a wave touches its own systems again.)
-            const int gp0 = group + P.axis_pf, gp = (P.axis_pf > 0 && gp0 < nwaves) ? gp0 : group;
+            const int gp0 = group + P.axis_pf, gp = (!LIST && P.axis_pf > 0 && gp0 < nwaves) ? gp0 : (LIST ? 0 : group);
             const size_t i0 = (size_t)gp * IPW;
             const int ni = (int)i0 + IPW <= P.batch ? IPW : (P.batch > (int)i0 ? P.batch - (int)i0 : 1);
             const double* const pa = P.A + i0 * NX * NX;
@@ -329,14 +336,20 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     int aloc[QMAX];
     // (S and the multipliers: this lane's LDS, behind its sparse array -- 66 registers the recursions have better use for; entry (a, b), b <= a, of S
     //  at a (a + 1) / 2 + b)
+    constexpr bool BIG = QMAX > 8;
     double* const Sl = RC + posSpare + 1;
-    double* const alam = Sl + QMAX * (QMAX + 1) / 2;
+    double* const alam = Sl + (BIG ? 0 : QMAX * (QMAX + 1) / 2);
+    // (QMAX > 8: not S but its FACTOR is kept -- L below the diagonal, 1 / L(i, i) on it: it grows by a row when a constraint joins and is
+    //  brought back to a triangle by plane rotations when one leaves --, and g = N' y and r = S^-1 g live in the lane's LDS too)
+    double* const Ll = alam + QMAX;
+    double* const gl = Ll + QMAX * (QMAX + 1) / 2;
+    double* const rl = gl + QMAX;
 #pragma unroll
     for (int a = 0; a < QMAX; ++a) {
         aloc[a] = posSpare | kEmpty;
         alam[a] = 0.0;
 #pragma unroll
-        for (int b = 0; b <= a; ++b) Sl[a * (a + 1) / 2 + b] = (a == b) ? 1.0 : 0.0;
+        for (int b = 0; b <= a; ++b) (BIG ? Ll : Sl)[a * (a + 1) / 2 + b] = (a == b) ? 1.0 : 0.0; // (S, or its factor: the identity's)
     }
     unsigned mact[2 + RPA]; // [kind] bit k: the upper bound | the lower bound of u_k | row j of step k is active
 #pragma unroll
@@ -672,61 +685,109 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         RC[loc_pos(ploc)] = have ? psg : 0.0; // (lanes without a pick: the spare entry)
         const double nqn = backward(rows_live, kp, true);
         if (ka >= 0) forward_resp(rows_live, ka);
-        double g[QMAX], r[QMAX];
+        double g[BIG ? 1 : QMAX], r[BIG ? 1 : QMAX];
 #pragma unroll
-        for (int a = 0; a < QMAX; ++a) g[a] = r[a] = 0.0;
+        for (int a = 0; a < (BIG ? 1 : QMAX); ++a) g[a] = r[a] = 0.0;
+#define AX_G(a) (BIG ? gl[a] : g[BIG ? 0 : (a)])
+#define AX_R(a) (BIG ? rl[a] : r[BIG ? 0 : (a)])
+        double wbig[BIG ? QMAX : 1]; // (QMAX > 8) w = L^-1 g: the row the factor grows by when the pick joins
+#pragma unroll
+        for (int a = 0; a < (BIG ? QMAX : 1); ++a) wbig[a] = 0.0;
+        if constexpr (BIG) {
+#pragma unroll
+            for (int a = 0; a < QMAX; ++a) gl[a] = rl[a] = 0.0;
+        }
         if (ka >= 0) { // (no active constraint among the lanes that have a pick -- the first trip of most waves: r = 0)
+            if constexpr (BIG) {
 #pragma unroll
-            for (int a = 0; a < QMAX; ++a) {
-                const double v = RC[loc_pos(aloc[a])];
-                g[a] = (a < q) ? loc_sg(aloc[a]) * v : 0.0;
-            }
-            // r = S^-1 g by Cholesky (S is the identity beyond q, g is zero there: so is r)
-            double L[QMAX][QMAX], di[QMAX], w[QMAX];
+                for (int a = 0; a < QMAX; ++a) {
+                    const double v = RC[loc_pos(aloc[a])];
+                    gl[a] = (a < q) ? loc_sg(aloc[a]) * v : 0.0;
+                }
+                // r = S^-1 g from the factor S = L L' the lane KEEPS (L below the diagonal, 1 / L(i, i) on it, the identity beyond q): two
+                // substitutions over the whole padded triangle -- every address a constant, the reads travel together.  (The factor grows by
+                // a row when a constraint joins -- the row IS w = L^-1 g, see below -- and is made again from S when one leaves.)
+                const int qw = wave_top(have ? q : 0); // (the largest active set among the wave's lanes: beyond it every row is the identity's)
 #pragma unroll
-            for (int i = 0; i < QMAX; ++i) {
+                for (int i = 0; i < QMAX; ++i) {
+                    if (i < qw) {
+                        double sacc = gl[i];
 #pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    double s = Sl[i * (i + 1) / 2 + j];
-#pragma unroll
-                    for (int t = 0; t < j; ++t) s -= L[i][t] * L[j][t];
-                    if (j < i) {
-                        L[i][j] = s * di[j];
-                    } else {
-                        giveup = giveup | (have & !(s > 0.0));
-                        di[i] = fast_rsqrt(s > 0.0 ? s : 1.0);
-                        L[i][i] = s * di[i];
+                        for (int t = 0; t < i; ++t) sacc -= Ll[i * (i + 1) / 2 + t] * wbig[t];
+                        wbig[i] = sacc * Ll[i * (i + 1) / 2 + i];
                     }
                 }
-            }
+                {
+                    double rr[QMAX];
 #pragma unroll
-            for (int i = 0; i < QMAX; ++i) {
-                double s = g[i];
+                    for (int i = QMAX - 1; i >= 0; --i) {
+                        rr[i] = 0.0;
+                        if (i < qw) {
+                            double sacc = wbig[i];
 #pragma unroll
-                for (int t = 0; t < i; ++t) s -= L[i][t] * w[t];
-                w[i] = s * di[i];
-            }
+                            for (int t = i + 1; t < QMAX; ++t) sacc -= Ll[t * (t + 1) / 2 + i] * rr[t];
+                            rr[i] = sacc * Ll[i * (i + 1) / 2 + i];
+                        }
+                    }
 #pragma unroll
-            for (int i = QMAX - 1; i >= 0; --i) {
-                double s = w[i];
+                    for (int i = 0; i < QMAX; ++i)
+                        if (i < qw) rl[i] = rr[i];
+                }
+            } else {
 #pragma unroll
-                for (int t = i + 1; t < QMAX; ++t) s -= L[t][i] * r[t];
-                r[i] = s * di[i];
+                for (int a = 0; a < QMAX; ++a) {
+                    const double v = RC[loc_pos(aloc[a])];
+                    g[BIG ? 0 : a] = (a < q) ? loc_sg(aloc[a]) * v : 0.0;
+                }
+                // r = S^-1 g by Cholesky (S is the identity beyond q, g is zero there: so is r)
+                constexpr int QS = BIG ? 1 : QMAX;
+                double L[QS][QS], di[QS], w[QS];
+#pragma unroll
+                for (int i = 0; i < QS; ++i) {
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double sacc = Sl[i * (i + 1) / 2 + j];
+#pragma unroll
+                        for (int t = 0; t < j; ++t) sacc -= L[i][t] * L[j][t];
+                        if (j < i) {
+                            L[i][j] = sacc * di[j];
+                        } else {
+                            giveup = giveup | (have & !(sacc > 0.0));
+                            di[i] = fast_rsqrt(sacc > 0.0 ? sacc : 1.0);
+                            L[i][i] = sacc * di[i];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < QS; ++i) {
+                    double sacc = g[i];
+#pragma unroll
+                    for (int t = 0; t < i; ++t) sacc -= L[i][t] * w[t];
+                    w[i] = sacc * di[i];
+                }
+#pragma unroll
+                for (int i = QS - 1; i >= 0; --i) {
+                    double sacc = w[i];
+#pragma unroll
+                    for (int t = i + 1; t < QS; ++t) sacc -= L[t][i] * r[t];
+                    r[i] = sacc * di[i];
+                }
             }
         }
         double zn = nqn;
 #pragma unroll
-        for (int a = 0; a < QMAX; ++a) zn -= g[a] * r[a];
+        for (int a = 0; a < QMAX; ++a) zn -= AX_G(a) * AX_R(a);
         // t1 = min lambda_i / r_i over r_i > 0, the lowest position among equals (cross-multiplied: one division)
         int l1 = -1;
         double lb_ = 0.0, rb_ = 1.0;
 #pragma unroll
         for (int a = 0; a < QMAX; ++a) {
-            const bool ok = (a < q) & (r[a] > 0.0);
+            const double ra = AX_R(a);
+            const bool ok = (a < q) & (ra > 0.0);
             const double la = alam[a];
-            const bool better = ok & ((l1 < 0) | (la * rb_ < lb_ * r[a]));
+            const bool better = ok & ((l1 < 0) | (la * rb_ < lb_ * ra));
             lb_ = better ? la : lb_;
-            rb_ = better ? r[a] : rb_;
+            rb_ = better ? ra : rb_;
             l1 = better ? a : l1;
         }
         const double t1 = lb_ / rb_;
@@ -745,7 +806,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         // z = Q^-1 (n+ - N r): the coefficients over the responses, the recursions again, U += tt z and the next scan
         if (ka >= 0) { // (else: the combined normal IS n+, its recursion has been done)
 #pragma unroll
-            for (int a = 0; a < QMAX; ++a) RC[loc_pos(aloc[a])] = -r[a] * loc_sg(aloc[a]); // (empty slots: the spare entry)
+            for (int a = 0; a < QMAX; ++a) RC[loc_pos(aloc[a])] = -AX_R(a) * loc_sg(aloc[a]); // (empty slots: the spare entry)
             (void)backward(rows_live, kp, false);
         }
         forward_scan(std::false_type {}, tt);
@@ -760,7 +821,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         have = have & !giveup;
         if (have) {
 #pragma unroll
-            for (int a = 0; a < QMAX; ++a) alam[a] -= tm * r[a];
+            for (int a = 0; a < QMAX; ++a) alam[a] -= tm * AX_R(a);
             plam += tm;
             if (full) {
                 // the pick joins the active set: slot q, S grows by the row [g' | n+' Q^-1 n+]
@@ -771,11 +832,21 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
 #pragma unroll
                     for (int a = 0; a < QMAX; ++a) aloc[a] = (a == q) ? ploc : aloc[a];
                     alam[q] = plam;
-                    {
+                    if constexpr (!BIG) {
                         double* const row = Sl + q * (q + 1) / 2;
 #pragma unroll
                         for (int b = 0; b < QMAX; ++b)
-                            if (b <= q) row[b] = (b == q) ? nqn : g[b];
+                            if (b <= q) row[b] = (b == q) ? nqn : AX_G(b);
+                    }
+                    if constexpr (BIG) { // the factor's new row: [w' | sqrt(n+' Q^-1 n+ - w'w)], its diagonal kept as the reciprocal
+                        double* const lrow = Ll + q * (q + 1) / 2;
+                        double dd = nqn;
+#pragma unroll
+                        for (int b = 0; b < QMAX; ++b) dd -= (b < q) ? wbig[b] * wbig[b] : 0.0;
+                        giveup = giveup | !(dd > 0.0);
+#pragma unroll
+                        for (int b = 0; b < QMAX; ++b)
+                            if (b <= q) lrow[b] = (b == q) ? fast_rsqrt(dd > 0.0 ? dd : 1.0) : wbig[b];
                     }
                     const int pk = loc_kind(ploc);
                     const unsigned bit = 1u << loc_step(ploc);
@@ -799,8 +870,30 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                     const int nl = (a + 1 < QMAX) ? aloc[a + 1 < QMAX ? a + 1 : a] : (posSpare | kEmpty);
                     aloc[a] = sh ? nl : aloc[a];
                 }
-                {
-                    double lam_[QMAX], Sn[QMAX][QMAX];
+                if constexpr (BIG) {
+                    // the factor without row l1 of L: the rows behind it move up, each with one entry beyond its diagonal -- plane rotations of
+                    // the columns (j, j + 1), j = l1 .. q - 2, bring the triangle back (what qpgen2 does to its R when a constraint leaves);
+                    // in place, in the lane's LDS
+                    for (int j = l1; j < q - 1; ++j) {
+                        alam[j] = alam[j + 1];
+                        double* const src = Ll + (j + 1) * (j + 2) / 2; // the row that becomes row j: entries 0 .. j + 1
+                        const double x = src[j], y = 1.0 / src[j + 1];
+                        const double rinv = fast_rsqrt(x * x + y * y), cg = x * rinv, sg2 = y * rinv;
+                        for (int i = j + 2; i < q; ++i) { // the rows behind: their entries in the two columns
+                            double* const row = Ll + i * (i + 1) / 2;
+                            const double xi = row[j], yi = row[j + 1];
+                            row[j] = cg * xi + sg2 * yi;
+                            row[j + 1] = cg * yi - sg2 * xi;
+                        }
+                        double* const dst = Ll + j * (j + 1) / 2;
+                        for (int t = 0; t < j; ++t) dst[t] = src[t];
+                        dst[j] = rinv;
+                    }
+                    alam[q - 1] = 0.0;
+                    for (int b = 0; b < q; ++b) Ll[(q - 1) * q / 2 + b] = (b == q - 1) ? 1.0 : 0.0;
+                } else {
+                    constexpr int QS = BIG ? 1 : QMAX;
+                    double lam_[QS], Sn[QS][QS];
 #pragma unroll
                     for (int a = 0; a < QMAX; ++a) lam_[a] = alam[a];
                     // S without row and column l1 (rows and columns behind it move up; the last becomes the identity's)
@@ -899,7 +992,36 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     //         store.  (Straight from the lanes -- 24 contiguous bytes per instance and store -- the stores were the phase that grew with the
     //         load on the chip: 6 k ticks for a wave alone on its CU, 14 - 18 k with every SIMD busy; profiles/r06/axis_load_sweep.txt.)  An
     //         instance on a spare lane has its other axes elsewhere: that lane stores for itself. ----
-    {
+    if constexpr (LIST) { // (the wave's instances are scattered over the batch: every lane stores for itself)
+        if (valid) {
+            double* const xo = P.trajectory + (size_t)inst * P.X + c;
+            double* const uo = P.control + (size_t)inst * P.n + c;
+            double x[NXA];
+#pragma unroll
+            for (int i = 0; i < NXA; ++i) x[i] = x0[i];
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k) {
+                if (EXACT || k < NH) {
+                    const double u = U[k];
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) xo[k * NX + NU * i] = x[i];
+                    uo[k * NU] = u;
+                    double xn[NXA];
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) {
+                        double acc = d[i] + B[i] * u;
+#pragma unroll
+                        for (int j = 0; j < NXA; ++j) acc += A[i][j] * x[j];
+                        xn[i] = acc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) x[i] = xn[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NXA; ++i) xo[NH * NX + NU * i] = x[i];
+        }
+    } else {
         const int nr = nreg - group * IPW < IPW ? (nreg - group * IPW > 0 ? nreg - group * IPW : 0) : IPW; // instances on this wave's regular lanes
         const int XI = P.X, UI = P.n;
         double* const sx_ = lds + oRC_; // [il][X]

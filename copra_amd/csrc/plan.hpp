@@ -288,7 +288,7 @@ COPRA_HD inline int axis_lds_doubles(int nx, int nu, int N, int rpa, int qmax, i
     oBnd = nu * axis_tab_doubles(nxa, N, rpa);
     oRC = oBnd + nu * 2 * N;
     // per lane: the sparse array (+ a spare entry) | S = N' Q^-1 N of its active set, lower triangle | the multipliers
-    rcs = (N + (N + 1) * rpa + 1 + qmax * (qmax + 1) / 2 + qmax) | 1;
+    rcs = (N + (N + 1) * rpa + 1 + qmax * (qmax + 1) / 2 + qmax + (qmax > 8 ? 2 * qmax : 0)) | 1; // (QMAX > 8: the FACTOR of S instead of S, + g and r)
     int w = 64 * rcs;
     const int stage_out = (64 / nu) * (nx * (N + 1) + nu * N) + (N + 1) * (nx / nu) + N + 2; // (+ the axis of an instance on a spare lane)
     // ... whose place the results of the wave's instances take at the end, as they lie in memory
@@ -353,6 +353,9 @@ struct FusedPlan {
     int axis_waves; // waves of its launch (axis_grid below)
     int axis_pf; // > 0: a wave touches the systems of the wave that many further on (the one that follows it on its SIMD): lmpc_axis.hpp
     int* axis_acc; // [axis_grid's spare instances]: where the counters of an instance on spare lanes meet (zero between solves)
+    const int* axis_list_in; // the second chance (lmpc_axis.hpp, LIST): the list the first launch left, ...
+    const int* axis_list_count; // ... its length, ...
+    int* axis_count2; // ... and (first launch) the counter of the list the second chance appends to: zeroed on the way
     int axis_const; // 1: its tables are the same at every step (pure state rows present at all N + 1 steps with one E and f and indices affine in the step, one pair of bounds per control): the builds that keep them in registers
     int axis_tab, axis_rpa; // the (instance, axis)-per-lane solver's tables in `params` (-1: the controller is not eligible) and rows per axis and step (lmpc_axis.hpp)
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)

@@ -212,6 +212,7 @@ inline bool ric_shape_ok(int nx, int nu, int N)
 // the double integrators in two and three dimensions (in ONE dimension the horizons its lanes have registers for are the packed kernels'
 // and the factor-only tiers': 32 variables and fewer).  -> the build's largest horizon, 0: none.
 constexpr int kAxisQmax = 6; // active constraints per (instance, axis) its lanes have room for
+constexpr int kAxisQmaxBig = 16; // ... and the lanes of the second chance of what it lists (copra_lmpc_axis_list_kernel)
 inline int axis_solver_nmax(int nx, int nu, int N)
 {
     if (nu < 2 || nu > 3 || nx != 2 * nu || N < 1) return 0;

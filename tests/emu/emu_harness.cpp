@@ -102,7 +102,7 @@ namespace emu {
     static int run_block(std::function<void()> body, size_t lds_bytes, int inst, int ninst, int nthreads)
     {
         static std::vector<char> stacks;
-        const size_t stack_sz = 256 * 1024;
+        const size_t stack_sz = 1024 * 1024; // (the unrolled (instance, axis)-per-lane bodies have frames of several hundred KB at -O1)
         if (nthreads % 64 != 0 || nthreads > kMaxThreads) return -1;
         if (stacks.size() < (size_t)nthreads * stack_sz) stacks.resize((size_t)nthreads * stack_sz);
         std::vector<double> lds(lds_bytes / sizeof(double) + 2, __builtin_nan(""));
@@ -379,6 +379,34 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
             if (r != 0) return -100;
         }
         P.lane_hist = nullptr;
+        // the second chance of what it listed (copra_lmpc_axis_list_kernel): room for kAxisQmaxBig active constraints per lane, instances from the list
+        std::vector<int> list2((size_t)dims->batch + 64, -1);
+        int cnt2[4] = { 0, 0, 0, 0 }; // (as the first launch's: [left over | - | ended by its steps | -])
+        int& count2 = cnt2[0];
+        if (!std::getenv("COPRA_EMU_AXIS_NO_SECOND_CHANCE")) {
+            FusedPlan Pl = P;
+            Pl.axis_list_in = lane_list.data();
+            Pl.axis_list_count = &lane_count;
+            Pl.lane_list = list2.data();
+            Pl.lane_count = &count2;
+            Pl.lane_zero = nullptr;
+            Pl.axis_pf = 0;
+            const size_t lbytes = (size_t)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmaxBig, oB, oR, rcs) * sizeof(double);
+            const int ipw = 64 / P.nu;
+            for (int g = 0; g * ipw < lane_count; ++g) {
+                int r = emu::run_wave([&]() {
+#define COPRA_EMU_AXIS_L(NU, NMAX)                                                                                       \
+    (Pl.axis_const ? lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, true, 2, true>(Pl, g) : lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, false, 2, true>(Pl, g))
+                    if (P.nu == 3) COPRA_EMU_AXIS_L(3, 20);
+                    else if (P.N <= 20) COPRA_EMU_AXIS_L(2, 20);
+                    else COPRA_EMU_AXIS_L(2, 31);
+#undef COPRA_EMU_AXIS_L
+                }, lbytes, g, 1);
+                if (r != 0) return -100;
+            }
+            lane_list = list2;
+            lane_count = count2;
+        }
         P.lane_from_list = 1;
         P.lane_spec = P.lds.ricC ? 1 : 0; // (nothing is handed over: the tier sweeps for itself)
         P.lane_handover = 0;

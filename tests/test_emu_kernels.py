@@ -1624,11 +1624,16 @@ def test_axis_solver_on_the_com_preview(emu, oracle, N, vmax, umax):
 
 
 def test_axis_solver_hands_over_what_outgrows_its_lanes(emu, oracle, monkeypatch):
-    """an axis whose active set outgrows the lane's room (here: a build with room for TWO constraints) sends its INSTANCE to the first tier's
-    list; the tier solves it from scratch -- same results, same counters"""
+    """an axis whose active set outgrows the lane's room (here: a build with room for TWO constraints) sends its INSTANCE to a list.  The SECOND
+    CHANCE walks that list: the same solver with room for twelve (S, its factor and the small vectors in the lane's LDS, loops with run-time
+    trip counts), instances taken from the list -- it finishes them all here; without it (and for whatever it lists in turn) the first tier
+    solves them from scratch -- same results, same counters either way"""
     from copra_amd import workloads
     monkeypatch.setenv("COPRA_EMU_AXIS_QMAX2", "1")
     wl = workloads.com_preview(64, v_max=0.3, u_max=1.5, seed=9)
+    re, ro = _axis_case(emu, oracle, wl)
+    assert re["lane_pass_finished"] == 64 and ro["iter"][:, 0].max() >= 8
+    monkeypatch.setenv("COPRA_EMU_AXIS_NO_SECOND_CHANCE", "1")
     re, ro = _axis_case(emu, oracle, wl)
     assert 0 < re["lane_pass_finished"] < 64
 
