@@ -127,10 +127,11 @@ def main():
                     help="(single GPU) run the N > 1 code path for real with a one-rank RCCL process group: "
                          "init_process_group('nccl'), dist.gather of the result slab on the side stream, barrier, "
                          "all_reduce of the timing, verification of the gathered slab")
-    ap.add_argument("--payload", choices=["full", "controls"], default="full",
-                    help="N > 1: what the one gather per step carries: the whole result [U | status | iter | X] (default: what the "
-                         "north star asks for, 1500 B per instance) or only [U | status | iter] (492 B; X is the roll-out of U and "
-                         "rank 0 reproduces it) -- for nodes whose xGMI links, not the kernel, bound the step")
+    ap.add_argument("--payload", choices=["auto", "full", "controls"], default="auto",
+                    help="N > 1: what the one gather per step carries: the whole result [U | status | iter | X] (what the north star asks "
+                         "for, 1500 B per instance) or only [U | status | iter] (492 B; X is the roll-out of U and rank 0 reproduces it) -- "
+                         "for nodes whose xGMI links, not the kernel, bound the step.  auto (default): a probe of a few steps before the timed "
+                         "region -- the whole result unless a step with its gather takes more than 1.5 x a step without; the line says which")
     ap.add_argument("--selftest-rccl2", action="store_true",
                     help="(two or more GPUs visible) spawn a world-2 RCCL run of this benchmark -- one process per GPU -- and fail "
                          "unless both ranks took part (dist.get_world_size() == 2), the gathered slabs match their checksums and an "
@@ -230,6 +231,31 @@ def main():
         eng.set_outputs(v["control"], v["trajectory"], v["status"], v["iter"])
         eng.solve(stream)
 
+    payload_probe = None
+    payload_choice = args.payload
+    if payload_choice == "auto":
+        payload_choice = "full"
+        if use_dist and world > 1:
+            # the solve is 0.1 ms per shard; rank 0 ingests (world - 1) x 48.8 MB per step with the whole result: which of the two bounds the
+            # step depends on the node's links.  Probe: a few steps without and with the (full) gather; every rank takes rank 0's verdict.
+            probe = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=True, overlap=overlap, payload_bytes=None)
+            times = []
+            for comm in (False, True):
+                for _ in range(3):
+                    probe.step(communicate=comm)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0p = time.perf_counter()
+                for _ in range(5):
+                    probe.step(communicate=comm)
+                torch.cuda.synchronize()
+                dist.barrier()
+                times.append((time.perf_counter() - t0p) / 5)
+            verdict = torch.tensor([1 if times[1] > 1.5 * times[0] else 0], device=dev)
+            dist.broadcast(verdict, src=0)
+            payload_choice = "controls" if int(verdict.item()) else "full"
+            payload_probe = {"ms_per_step_without_gather": times[0] * 1e3, "ms_per_step_with_full_gather": times[1] * 1e3}
+    args.payload = payload_choice
     payload_bytes = head_bytes(batch, n, X) if args.payload == "controls" else None
     loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=use_dist, overlap=overlap, force_gather=args.selftest_rccl,
                       payload_bytes=payload_bytes)
@@ -295,7 +321,7 @@ def main():
             sent = payload_bytes if payload_bytes is not None else slabs[0][0].numel()
             step_s = elapsed / args.steps
             multi = {"gathered_slabs_match_per_rank_checksums": bool(ok_sum), "ranks": world,
-                     "rccl_world_size": dist.get_world_size() if use_dist else 1, "payload": args.payload,
+                     "rccl_world_size": dist.get_world_size() if use_dist else 1, "payload": args.payload, "payload_probe": payload_probe,
                      "payload_bytes_per_rank_per_step": int(sent),
                      # each peer reaches rank 0 over its own xGMI link (7 links x ~153 GB/s per GPU): what the measured step asks of one
                      # link if the gather fills it, and what the gather alone would take at the nominal link rate

@@ -71,11 +71,26 @@ class BatchLMPC:
         from . import hazard_lint
         turned_away = []
 
+        def fingerprint(path):
+            import hashlib
+            with open(path, "rb") as fh:
+                return hashlib.sha256(fh.read()).hexdigest()
+
         def gate(path, _user):
             path = path.decode()
             mark = path + ".lint_ok"
-            if os.path.exists(mark) or not os.path.exists(hazard_lint.OBJDUMP):
+            if not os.path.exists(hazard_lint.OBJDUMP):
+                import warnings
+                warnings.warn("copra_batch_specialise: %s is missing, the code object %s is loaded WITHOUT the matrix-instruction hazard check"
+                              % (hazard_lint.OBJDUMP, os.path.basename(path)))
                 return 0
+            # (round-5 advisor: the mark belongs to ONE build of the object -- an object rebuilt under the same name, e.g. by another hipcc, is
+            #  disassembled again: the mark holds the checked object's SHA-256)
+            try:
+                if os.path.exists(mark) and open(mark).read().strip() == fingerprint(path):
+                    return 0
+            except OSError:
+                pass
             try:
                 hits = hazard_lint.lint_code_object(path)
             except Exception as e:  # (a code object that cannot be disassembled is not loaded either)
@@ -83,7 +98,8 @@ class BatchLMPC:
             if hits:
                 turned_away.append((os.path.basename(path), hits[0]))
                 return 1
-            open(mark, "w").close()
+            with open(mark, "w") as fh:
+                fh.write(fingerprint(path))
             return 0
 
         cb = _capi.CODE_OBJECT_CHECK(gate)

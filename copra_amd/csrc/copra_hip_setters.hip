@@ -374,6 +374,13 @@ copra_status_t copra_batch_set_outputs(copra_batch_t* h, double* control, double
 {
     if (!h || !control || !trajectory || !status || !iter)
         return fail(COPRA_ERR_ARG, "copra_batch_set_outputs: null argument");
+    // (round-5 advisor: the adaptive controllers read the counters of the LAST solve through pointers to its output buffers; buffers a caller
+    //  ROTATES may be gone by then -- what was learnt from the old ones stays, nothing is read from them any more.  Setting the same buffers
+    //  again changes nothing.  A caller's buffers must stay valid until the solve that writes them has finished.)
+    if (status != h->ext_status || iter != h->ext_iter) {
+        h->ad.last_iter = nullptr;
+        h->ad.last_status = nullptr;
+    }
     h->ext_control = control;
     h->ext_traj = trajectory;
     h->ext_status = status;

@@ -54,6 +54,28 @@ def split_slab(slab, batch, n, X):
     return _views(slab, batch, n, X)
 
 
+def max_shard(total, world):
+    """instances of the largest shard of shard_range(total, ., world)"""
+    return max(shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world))
+
+
+def alloc_shard_slab(total, rank, world, n, X, device):
+    """The result slab of `rank`'s shard for a batch that the ranks do NOT divide: dist.gather wants equal pieces, so every rank's slab
+    has the layout of the LARGEST shard; the views a rank fills -- and shard_views() reads back on the receiving side -- cover the
+    first hi - lo instances of each array (the tail of a smaller shard's arrays stays zero and travels unused: at most one instance
+    per array).  -> (slab, views of this rank's instances, capacity)"""
+    cap = max_shard(total, world)
+    slab, views = alloc_result_slab(cap, n, X, device)
+    lo, hi = shard_range(total, rank, world)
+    return slab, {k: v[:hi - lo] for k, v in views.items()}, cap
+
+
+def shard_views(slab, total, rank, world, n, X):
+    """the instances of `rank` inside a slab laid out by alloc_shard_slab (receiving side)"""
+    lo, hi = shard_range(total, rank, world)
+    return {k: v[:hi - lo] for k, v in _views(slab, max_shard(total, world), n, X).items()}
+
+
 def rollout_trajectory(A, B, d, x0, control):
     """X = Phi x0 + Psi U + xi as the roll-out x_{k+1} = A x_k + B u_k + d (src/LMPC.cpp:282-286) for a batch, torch tensors in natural
     indexing: A (b,nx,nx), B (b,nx,nu), d (b,nx), x0 (b,nx), control (b, N nu) -> (b, (N+1) nx).  What rank 0 runs when only

@@ -109,3 +109,59 @@ def test_two_rank_gloo_gather(tmp_path, overlap, payload):
     ok = ref["status"] == 0  # (payload "controls": the trajectory is the receiving side's roll-out of the gathered controls)
     assert np.abs(got["trajectory"][ok] - ref["trajectory"][ok]).max() <= (0.0 if payload == "full" else 1e-9)
     assert list(got["slabs_used"]) == ([0, 1, 0] if overlap else [0, 0, 0])
+
+
+def _worker_ragged(rank, world, port, total, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pyoracle
+    from copra_amd import workloads
+    from copra_amd.sharding import GatherLoop, alloc_shard_slab, head_bytes, max_shard, shard_range, shard_views
+    wl = workloads.double_integrator(total, seed=13)
+    lo, hi = shard_range(total, rank, world)
+    n, X = 10, 22
+    dev = torch.device("cpu")
+    made = [alloc_shard_slab(total, rank, world, n, X, dev) for _ in range(2)]
+    slabs = [(m[0], m[1]) for m in made]
+
+    def solve_into(v, k):
+        ref = pyoracle.lmpc_solve_batch(wl["A"][lo:hi], wl["B"][lo:hi], wl["d"][lo:hi], wl["x0"][lo:hi], wl["N"], wl["costs"], wl["cstrs"])
+        for key in ("control", "trajectory", "status", "iter"):
+            v[key].copy_(torch.from_numpy(ref[key]))
+
+    loop = GatherLoop(slabs, rank, world, solve_into, dev, use_dist=True, overlap=True)
+    for _ in range(2):
+        loop.step()
+    dist.barrier()
+    ok, _ = loop.verify()
+    assert ok
+    if rank == 0:
+        parts = [shard_views(g, total, r, world, n, X) for r, g in enumerate(loop.gathered())]
+        assert [p["control"].shape[0] for p in parts] == [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+        np.savez(out_path, control=torch.cat([p["control"] for p in parts]).numpy(), status=torch.cat([p["status"] for p in parts]).numpy(),
+                 trajectory=torch.cat([p["trajectory"] for p in parts]).numpy(), iter=torch.cat([p["iter"] for p in parts]).numpy(),
+                 head=np.array(head_bytes(max_shard(total, world), n, X)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_three_rank_gloo_gather_of_a_batch_the_ranks_do_not_divide(tmp_path):
+    """world = 3, batch = 1000 (shards of 333, 333 and 334 instances; round-5 verdict: dist.gather needs equal slabs and bench.py only avoided
+    the case by construction): every rank's slab is laid out for the LARGEST shard (alloc_shard_slab), rank 0 takes each rank's own count
+    out of what it received (shard_views) -- the whole batch in order, equal to the oracle's"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from copra_amd import workloads
+    total, world = 1000, 3
+    out = str(tmp_path / "ragged.npz")
+    pyoracle.lib()
+    mp.spawn(_worker_ragged, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    got = np.load(out)
+    wl = workloads.double_integrator(total, seed=13)
+    ref = pyoracle.lmpc_solve_batch(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"])
+    assert got["control"].shape == (total, 10) and np.array_equal(got["status"], ref["status"]) and np.array_equal(got["iter"], ref["iter"])
+    assert np.array_equal(got["control"], ref["control"]) and np.array_equal(got["trajectory"], ref["trajectory"])
