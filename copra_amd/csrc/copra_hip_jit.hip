@@ -62,10 +62,7 @@ static copra_status_t jit_compile_unchecked(const std::string& key, const std::s
     (void)mkdir(dir.c_str(), 0755);
     // the code object depends on the exact sources it was compiled from: the hash of those sources is compiled into this
     // library (Makefile: COPRA_SRC_HASH), so a cache left by another build of the library is never picked up
-#ifndef COPRA_SRC_HASH
-#error "build through copra_amd/csrc/Makefile (it defines COPRA_SRC_HASH, the key of the run-time-compilation cache)"
-#endif
-    const std::string stamp = std::string(COPRA_SRC_HASH).substr(0, 12);
+    const std::string stamp = std::string(copra_source_hash()).substr(0, 12);
     obj = dir + "/" + key + "_" + stamp + ".hsaco";
     if (access(obj.c_str(), R_OK) == 0) return COPRA_OK;
     const std::string src = obj + "." + std::to_string((long)getpid()) + ".hip";

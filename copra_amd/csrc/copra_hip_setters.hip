@@ -560,7 +560,7 @@ copra_status_t copra_batch_lane_pass_info(copra_batch_t* h, int* ran, int* finis
         if (h->ad.lane_ran || h->ad.axis_ran) {
             int left = 0;
             HIP_TRY(hipStreamSynchronize(h->last_stream));
-            HIP_TRY(hipMemcpy(&left, h->ad.axis_ran ? h->d_axis_count2 : h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost)); // (the solver's second chance included)
+            HIP_TRY(hipMemcpy(&left, (h->ad.axis_ran && !h->ad.axis_quiet) ? h->d_axis_count2 : h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost)); // (the solver's second chance included)
             *finished = h->hp.plan.batch - left;
         }
     }

@@ -78,6 +78,7 @@ struct AdaptState {
     long long lane_solves = 0; // solves seen by adapt_lane_pass
     // the one-(instance, axis)-per-lane solver (lmpc_axis.hpp)
     bool axis_ran = false; // the last solve ran it
+    bool axis_quiet = false; // ... without a second chance and a first tier behind it (its recent lists were empty: solve_one_wave)
     bool axis_off = false; // switched off for this controller: it leaves more than half of the batch to the tier (adapt_axis_solver), or no memory for its list
     bool axis_off_by_share = false; // ... the former: sampled again every 256 solves
     int axis_adapt_left = 2; // solves after which its share is still looked at

@@ -350,6 +350,7 @@ struct FusedPlan {
     int lane_from_list;
     int lane_cap; // > 0 (with lane_from_list): the first tier was launched for the first lane_cap entries of the list only, entry w by workgroup w; the
                   // second launch (the tier-2 kernel) walks the rest -- usually none (copra_hip.hip: the grid follows the last solves' list lengths)
+    int lane_rest; // >= 0: the tier-2 launch walks the entries of lane_list from this one on (lane_cap, or 0 where no first tier was launched at all); -1: none
     int axis_waves; // waves of its launch (axis_grid below)
     int axis_pf; // > 0: a wave touches the systems of the wave that many further on (the one that follows it on its SIMD): lmpc_axis.hpp
     int* axis_acc; // [axis_grid's spare instances]: where the counters of an instance on spare lanes meet (zero between solves)

