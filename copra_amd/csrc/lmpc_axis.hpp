@@ -1068,7 +1068,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 axis_pair pr;
                 pr.x = v0;
                 pr.y = v1;
-                *(axis_pair*)(dst + e) = pr;
+                __builtin_nontemporal_store(pr, (axis_pair*)(dst + e)); // (written once, read by nobody on the chip: + 2 % on the headline)
 #else
                 dst[e] = v0;
                 dst[e + 1] = v1;

@@ -40,3 +40,23 @@ se = (hwid >> 13) & 7
 slot = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 print("  distinct XCCs %d, distinct CUs %d, distinct (CU, SIMD) %d" % (len(np.unique(xcc)), len(np.unique(slot)), len(np.unique(slot * 4 + simd))))
 print("  waves per SIMD id:", np.bincount(simd, minlength=4).tolist(), "| waves per CU: min %d max %d" % (np.bincount(np.unique(slot, return_inverse=True)[1]).min(), np.bincount(np.unique(slot, return_inverse=True)[1]).max()))
+
+# ---- how full the SIMDs are: per CU (the counters of different CUs do not share a base), the span from its first wave's start to its last
+#      wave's end against the sum of its waves' own times over the four SIMDs ----
+start = pw[:, 5].astype(np.int64)
+total = pw[:, 7].astype(np.int64)
+spans, busys, gaps = [], [], []
+for cu_id in np.unique(slot):
+    m = slot == cu_id
+    t0 = start[m].min()
+    span = (start[m] + total[m]).max() - t0
+    spans.append(span)
+    busys.append(total[m].sum() / float(span * 4))
+    for sd in range(4):  # idle ticks between one wave's end and the next wave's start on the same SIMD
+        ms = m & (simd == sd)
+        o = np.argsort(start[ms])
+        st, en = start[ms][o], (start[ms] + total[ms])[o]
+        gaps.extend((st[1:] - en[:-1]).tolist())
+spans, busys, gaps = np.array(spans), np.array(busys), np.array(gaps)
+print("  per CU: span mean %.0f min %d max %d ticks | SIMDs busy mean %.2f min %.2f | gap between waves on a SIMD: mean %.0f median %.0f max %d ticks"
+      % (spans.mean(), spans.min(), spans.max(), busys.mean(), busys.min(), gaps.mean(), np.median(gaps), gaps.max()))
