@@ -86,6 +86,10 @@ __global__ __launch_bounds__(64, 4) void copra_lmpc_lane_shared_kernel(const Fus
 template <int NX, int NU, int NH, int RP>
 __global__ __launch_bounds__(64) void copra_lmpc_fused_tier2_kernel(const FusedPlan P)
 {
+    if (P.seen_out && blockIdx.x == 0 && threadIdx.x == 0) { // (FusedPlan::seen_out: the lists are complete before this launch starts)
+        P.seen_out[0] = *P.seen_src0;
+        P.seen_out[2] = *P.seen_src1;
+    }
     const int count = *P.ovf_count;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         lmpc_fused_body<NX, NU, NH, RP>(P, P.ovf_list[k]);
@@ -335,6 +339,8 @@ FusedPlan device_plan(const copra_batch* h)
     P.lane_from_list = 0;
     P.lane_cap = 0;
     P.lane_rest = -1;
+    P.seen_out = nullptr;
+    P.seen_src0 = P.seen_src1 = nullptr;
     P.lane_handover = 0;
     P.lane_spec = 0;
     P.lane_ws = nullptr;
@@ -1724,26 +1730,21 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
             hipLaunchKernelGGL(select_fused_kernel(P), dim3(g1), dim3(64), h->hp.lds_bytes, s, P);
         HIP_TRY(hipGetLastError());
     }
-    if (h->hp.two_tier) {
-        // second tier: same kernel, full LDS layout, instances taken from the overflow queue (usually empty)
-        FusedPlan P2 = P;
-        P2.lds = h->hp.lds_full;
-        P2.from_list = 1;
-        P2.lane_from_list = 0; // (its body takes the instance it is given)
-        const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
-        LDS_OPT_IN(select_tier2_kernel(P2), h->hp.lds_full_bytes);
-        if (ext_timed)
-            hipExtLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, nullptr, h->ev1, 0, P2);
-        else
-            hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
-        HIP_TRY(hipGetLastError());
-    }
-    if (axis_pass) { // the length of this solve's list, for the grids of the next ones (pinned host word; nobody waits for it)
-        if (!h->h_lane_seen && hipHostMalloc((void**)&h->h_lane_seen, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            h->h_lane_seen = nullptr;
-        } else if (h->lane_seen_solves == 0) {
-            h->h_lane_seen[0] = h->h_lane_seen[1] = h->h_lane_seen[2] = h->h_lane_seen[3] = 0;
+    // the lengths of this solve's lists, for the grids of the next ones: pinned host words nobody waits for -- written by the tier-2 launch itself
+    // where there is one (two 4-byte copies behind the solve are two dispatches of the runtime's copy kernel, 4 us each: 8 % of the headline's step)
+    bool seen_by_kernel = false;
+    if (axis_pass) {
+        if (!h->h_lane_seen) {
+            if (hipHostMalloc((void**)&h->h_lane_seen, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h->h_lane_seen = nullptr;
+            } else {
+                h->h_lane_seen[0] = h->h_lane_seen[1] = h->h_lane_seen[2] = h->h_lane_seen[3] = 0;
+                if (hipHostGetDevicePointer((void**)&h->d_lane_seen, h->h_lane_seen, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    h->d_lane_seen = nullptr;
+                }
+            }
         }
         if (h->h_lane_seen) {
             if (h->lane_seen_solves > 0) { // (what the LAST solve left there)
@@ -1753,9 +1754,31 @@ static copra_status_t solve_one_wave(copra_batch* h, FusedPlan& P, hipStream_t s
             }
             h->lane_seen_slot ^= 1;
             h->lane_seen_solves += 1;
-            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + h->lane_seen_slot, axis_quiet ? h->d_lane_count + h->lane_cur : h->d_axis_count2, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the tier got)
-            HIP_TRY(hipMemcpyAsync(h->h_lane_seen + 2 + h->lane_seen_slot, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the second chance got)
         }
+    }
+    if (h->hp.two_tier) {
+        // second tier: same kernel, full LDS layout, instances taken from the overflow queue (usually empty)
+        FusedPlan P2 = P;
+        P2.lds = h->hp.lds_full;
+        P2.from_list = 1;
+        P2.lane_from_list = 0; // (its body takes the instance it is given)
+        if (axis_pass && h->h_lane_seen && h->d_lane_seen && !jit_launch) {
+            P2.seen_out = h->d_lane_seen + h->lane_seen_slot;
+            P2.seen_src0 = axis_quiet ? h->d_lane_count + h->lane_cur : h->d_axis_count2; // (what the tier got)
+            P2.seen_src1 = h->d_lane_count + h->lane_cur; // (what the second chance got)
+            seen_by_kernel = true;
+        }
+        const unsigned g2 = (unsigned)(P.batch < 1024 ? P.batch : 1024);
+        LDS_OPT_IN(select_tier2_kernel(P2), h->hp.lds_full_bytes);
+        if (ext_timed)
+            hipExtLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, nullptr, h->ev1, 0, P2);
+        else
+            hipLaunchKernelGGL(select_tier2_kernel(P2), dim3(g2), dim3(64), h->hp.lds_full_bytes, s, P2);
+        HIP_TRY(hipGetLastError());
+    }
+    if (axis_pass && h->h_lane_seen && !seen_by_kernel) {
+        HIP_TRY(hipMemcpyAsync(h->h_lane_seen + h->lane_seen_slot, axis_quiet ? h->d_lane_count + h->lane_cur : h->d_axis_count2, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the tier got)
+        HIP_TRY(hipMemcpyAsync(h->h_lane_seen + 2 + h->lane_seen_slot, h->d_lane_count + h->lane_cur, sizeof(int), hipMemcpyDeviceToHost, s)); // (what the second chance got)
     }
     if (!ext_timed) HIP_TRY(hipEventRecord(h->ev1, s));
     h->tier_timed = ext_timed && h->hp.two_tier;

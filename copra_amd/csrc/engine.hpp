@@ -144,6 +144,7 @@ struct copra_batch {
     int *d_lane_count = nullptr, *d_lane_list = nullptr; // (two counters, used in turn like the overflow queue's)
     int* d_lane_hist = nullptr; // histogram of the violated-row counts the pass leaves (kLaneHistBins; read once, before the first tier launch)
     double* d_lane_ws = nullptr;
+    int* d_lane_seen = nullptr; // ... the same words as the device sees them
     int* h_lane_seen = nullptr; // pinned: [2] the lengths of the last solves' first-tier lists as they arrive (solve_one_wave: the tier's grid follows them)
     int lane_seen_slot = 0, lane_seen_max = 0, lane_seen_first_max = 0; // (of the tier's list | of the first launch's list, which the second chance walks)
     long long lane_seen_solves = 0;

@@ -353,6 +353,8 @@ struct FusedPlan {
     int lane_rest; // >= 0: the tier-2 launch walks the entries of lane_list from this one on (lane_cap, or 0 where no first tier was launched at all); -1: none
     int axis_waves; // waves of its launch (axis_grid below)
     int axis_pf; // > 0: a wave touches the systems of the wave that many further on (the one that follows it on its SIMD): lmpc_axis.hpp
+    int* seen_out; // non-null: the tier-2 launch leaves the lengths of this solve's lists in pinned host memory -- [0] <- *seen_src0, [2] <- *seen_src1
+    const int *seen_src0, *seen_src1; //   (copra_hip.hip: the grids of the next solves follow them; two 4-byte copies in the stream cost 8 us a step)
     int* axis_acc; // [axis_grid's spare instances]: where the counters of an instance on spare lanes meet (zero between solves)
     const int* axis_list_in; // the second chance (lmpc_axis.hpp, LIST): the list the first launch left, ...
     const int* axis_list_count; // ... its length, ...
