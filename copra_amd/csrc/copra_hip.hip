@@ -442,8 +442,8 @@ static bool axis_solver_wanted(const copra_batch* h, const FusedPlan& P)
     if (h->ad.axis_off || opt.no_axis_solver || opt.no_lane_pass || P.axis_tab < 0 || P.prof_fine) return false;
     if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
     if (h->packed || h->shared || h->hp.large || P.initial_state || P.stage_refs || P.row_f_inst || P.lb_inst || P.ub_inst) return false;
-    for (int t = 0; t < kMaxCosts; ++t)
-        if (h->cost_p[t]) return false; // (per-instance references: the one-instance-per-lane pass rebuilds its affine terms per lane; this one does not)
+    for (int t = 0; t < kMaxCosts; ++t) // (per-instance references: a lane rebuilds the affine terms of its axis from them -- FusedPlan::axis_cref)
+        if (h->cost_p[t] && (P.axis_cref < 0 || t >= P.ncost || P.cost[t].pstride != 0)) return false;
     return select_axis_kernel(P) != nullptr;
 }
 static size_t lane_lds_bytes(const FusedPlan& P)

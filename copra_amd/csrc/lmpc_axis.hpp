@@ -90,6 +90,9 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     axis_tab_offsets(NXA, oh_, oHN_, ohN_, oRows_);
     const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
     const int TA = axis_tab_doubles(NXA, NH, rpa);
+    bool own_refs = false;
+    for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
+    own_refs = own_refs && P.axis_cref >= 0;
     if (!LIST && P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
     long long stamp[6];
     stamp[0] = P.prof ? cycle_counter() : 0;
@@ -224,6 +227,29 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
 #pragma unroll
             for (int j = 0; j < NXA; ++j) Pm[i][j] = Tg[oHN + i + NXA * j];
             pv[i] = Tg[ohN + i];
+        }
+        // Per-instance cost references (copra_batch_set_cost_reference: every instance tracks its own goal -- one TrajectoryCost(M, p_b) per
+        // LMPC in the reference, costFunctions.cpp:63-82): the affine terms h = -sum_t [M N]_t' W_t p_t and hN of this lane's axis are rebuilt
+        // from the plan builder's coefficients (FusedPlan::axis_cref; lmpc_lane.hpp does the same for the whole instance), with this instance's
+        // references where a cost has them and the controller-wide ones elsewhere.  (A row of another axis has zero coefficients here.)
+        if (own_refs) {
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) h[a] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NXA; ++i) pv[i] = 0.0;
+            const double* const cf = P.params + P.axis_cref + (size_t)c * kRicMaxCosts * 6 * (NZ + NXA);
+            for (int t = 0; t < P.ncost; ++t) {
+                const int rows_t = P.cost[t].rows;
+                const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)inst * P.cost[t].prows : P.params + P.cost[t].offP;
+                for (int r = 0; r < rows_t; ++r) {
+                    const double pv_r = pr[r];
+                    const double* const co = cf + (t * 6 + r) * (NZ + NXA);
+#pragma unroll
+                    for (int a = 0; a < NZ; ++a) h[a] += co[a] * pv_r;
+#pragma unroll
+                    for (int i = 0; i < NXA; ++i) pv[i] += co[NZ + i] * pv_r;
+                }
+            }
         }
         auto AB = [&](int l, int a) __attribute__((always_inline)) -> double { return a < NXA ? A[l][a] : B[l]; };
         sched_fence(); // (everything this wave reads for ITSELF has been requested: memory operations return in order -- the touches go last)

@@ -399,6 +399,7 @@ inline void build_lane_tables(HostPlan& hp)
     P.lane_cref = -1;
     P.lane_axes = 0;
     P.axis_tab = -1;
+    P.axis_cref = -1;
     P.axis_rpa = 0;
     P.axis_const = 0;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
@@ -502,6 +503,7 @@ inline void build_lane_tables(HostPlan& hp)
     // costs and every row look at one axis each (lane_axes above; a system with ONE control is one axis), at most kAxisMaxRpa rows per axis
     // and step, no reference trajectories.  (Whether the SYSTEMS couple two axes is checked per instance by the kernel.)
     P.axis_tab = -1;
+    P.axis_cref = -1;
     P.axis_rpa = 0;
     if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || P.lane_axes) && !P.stage_refs) {
         const int nxa = nx / nu, nza = nxa + 1, arw = nxa + 3;
@@ -581,6 +583,24 @@ inline void build_lane_tables(HostPlan& hp)
             P.axis_tab = (int)hp.params.size();
             P.axis_rpa = rpa;
             hp.params.insert(hp.params.end(), at.begin(), at.end());
+            // the coefficients of the cost references (oCref above), axis by axis: what a lane whose instance has its OWN references
+            // (copra_batch_set_cost_reference) rebuilds h and hN of its axis from
+            if (P.lane_cref >= 0) {
+                const int acw = nza + nxa;
+                std::vector<double> ac((size_t)nu * kRicMaxCosts * 6 * acw, 0.0);
+                for (int c = 0; c < nu; ++c) {
+                    auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; };
+                    for (int tr = 0; tr < kRicMaxCosts * 6; ++tr) {
+                        double* dst = ac.data() + ((size_t)c * kRicMaxCosts * 6 + tr) * acw;
+                        const double* src = tab.data() + oCref + (size_t)tr * crw;
+                        for (int a = 0; a < nza; ++a) dst[a] = src[zi(a)];
+                        for (int a = 0; a < nxa; ++a) dst[nza + a] = src[nz + zi(a)];
+                    }
+                }
+                P.axis_cref = (int)hp.params.size();
+                hp.params.insert(hp.params.end(), ac.begin(), ac.end());
+                if (hp.params.size() & 1) hp.params.push_back(0.0);
+            }
         }
     }
 }

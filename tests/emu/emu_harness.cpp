@@ -347,7 +347,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
     bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0 && !P.row_f_inst && !P.lb_inst
         && !P.ub_inst && !P.stage_refs;
-    for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && !P.cost_p[k];
+    for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost && P.cost[k].pstride == 0));
     if (axis_pass) {
         int on_spare = 0;
         const int groups = axis_grid(P.nu, dims->batch, on_spare);

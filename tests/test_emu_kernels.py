@@ -1657,6 +1657,25 @@ def test_axis_solver_leaves_coupled_and_infeasible_instances_to_the_tier(emu, or
     assert (re["control"][same] == base["control"][same]).all()  # (nothing of a neighbour's result depends on them)
 
 
+def test_axis_solver_with_per_instance_goals(emu, oracle):
+    """copra_batch_set_cost_reference in front of the (instance, axis)-per-lane solver: every instance tracks its own goal (one
+    TrajectoryCost(M, p_b) per LMPC in the reference, costFunctions.cpp:63-82) -- a lane rebuilds the affine terms of its axis from its
+    instance's reference (FusedPlan::axis_cref).  Statuses, both iteration counters, U and X against the oracle run instance by instance with
+    its own cost; the instances end in the solver, not in the tier"""
+    from copra_amd import workloads
+    rng = np.random.default_rng(21)
+    for N, vmax, umax, b in ((20, 0.5, 2.5, 44), (12, 0.35, 1.8, 30)):
+        wl = workloads.com_preview(b, N=N, v_max=vmax, u_max=umax, seed=11 + N)
+        goals = wl["costs"][0]["p"][None, :] + 0.3 * rng.standard_normal((b, 6))
+        re = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], cost_refs={0: goals})
+        assert re["lane_pass_finished"] >= b - 2
+        for k in range(b):
+            costs = [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]]
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], costs, wl["cstrs"])
+            assert re["status"][k] == ro["status"] == 0 and tuple(re["iter"][k]) == tuple(ro["iter"]), (N, k)
+            assert _rel(re["control"][k], ro["control"]) <= 1e-8 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-8, (N, k)
+
+
 def test_axis_solver_with_rows_that_change_along_the_horizon(emu, oracle):
     """tables that are NOT the same at every step (FusedPlan::axis_const = 0: the builds that read them from LDS stage by stage): a mixed
     constraint v_k + 0.1 u_k <= v_max per axis (rows with a control part, none at step N), lower velocity limits as rows (two rows per axis and

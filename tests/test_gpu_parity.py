@@ -2772,6 +2772,45 @@ def test_axis_solver_leaves_what_it_cannot_decide_to_the_tier(oracle):
     assert _rel(res["control"][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][ok], ref["trajectory"][ok]) <= RTOL
 
 
+def test_axis_solver_with_per_instance_goals(oracle):
+    """every instance tracks its own goal (copra_batch_set_cost_reference; one TrajectoryCost(M, p_b) per LMPC in the reference,
+    costFunctions.cpp:63-82) and the (instance, axis)-per-lane solver still takes the controller: a lane rebuilds the affine terms of its axis
+    from its instance's reference.  Whole batch against the round-5 pair (statuses, counters, 1e-9), a sample against the oracle run with the
+    instance's own cost; then back to the controller-wide goal"""
+    from copra_amd import BatchLMPC, workloads
+    b = 65536 + 37
+    wl = workloads.com_preview(b, seed=26, v_max=0.5, u_max=2.5)
+    rng = np.random.default_rng(4)
+    refs = np.tile(wl["costs"][0]["p"], (b, 1)) + 0.2 * rng.standard_normal((b, 6))
+    out = {}
+    for mode in ("axis", "pair"):
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1) if mode == "pair" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.set_cost_reference(0, refs)
+        eng.solve()
+        out[mode] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        if mode == "axis":
+            eng.set_cost_reference(0, None)
+            eng.solve()
+            out["shared_goal"] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.close()
+    r1, ran, info = out["axis"]
+    r0 = out["pair"][0]
+    assert ran and not out["pair"][1] and info[1] >= b - 64  # (it finishes nearly everything itself)
+    ok = r0["status"] == 0
+    assert (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.9999  # (ties)
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-9
+    for k in list(range(0, b, 2111)) + [b - 1]:
+        cs = [dict(wl["costs"][0], p=refs[k]), wl["costs"][1]]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], cs, wl["cstrs"])
+        assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+        assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+    rs = out["shared_goal"][0]
+    for k in range(0, b, 9973):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+        assert rs["status"][k] == ro["status"] == 0 and _rel(rs["control"][k], ro["control"]) <= RTOL
+
+
 def test_axis_solver_on_random_integrator_controllers(oracle):
     """tests/random_controllers.py::make_integrator with two and three axes at a batch of 2048: whatever mix of costs and constraints a seed
     draws (the eligible ones run the solver, the others the pass and the tiers)"""

@@ -222,6 +222,19 @@ def extra_measurements(np, torch, dev):
                     "note": ("A[0, 4] = 1e-3 in every instance: no wave is decoupled, the dense sweep and roll-out run" if eps
                              else "copra_options_t::no_lane_axes: the decoupled CoM systems through the dense sweep and roll-out")}
         eng.close()
+    # the headline with every instance its OWN goal (copra_batch_set_cost_reference: one TrajectoryCost(M, p_b) per LMPC in the reference) --
+    # per-instance systems, per-instance references: the (instance, axis)-per-lane solver rebuilds the affine terms of a lane's axis from them;
+    # and the same controller on the round-5 pair (what it ran on until this round)
+    goals_pi = workloads.COM_X_GOAL[None, :] + 0.05 * np.random.default_rng(5).standard_normal((b, 6))
+    for key, opts in (("headline_per_instance_goals_batch65536", None), ("headline_per_instance_goals_round5_pair_batch65536", dict(no_axis_solver=1))):
+        eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=opts)
+        eng.set_system(*on_device(wl))
+        eng.set_cost_reference(0, torch.from_numpy(np.ascontiguousarray(goals_pi)).to(dev))
+        for _ in range(6):
+            eng.solve()
+        rate, sec = timed_rate(eng, b)
+        out[key] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5, "axis_solver_ran": bool(eng.axis_solver_ran())}
+        eng.close()
     # headline shape, shared model (receding-horizon tick: one (A, B, d) for the batch, only x0 differs)
     b = 65536
     wl = workloads.com_preview(b)
