@@ -411,7 +411,7 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 #define COPRA_AXIS_PICK(NU, NMAX, EXACT)                                                                                                     \
     (P.axis_const ? (P.axis_rpa <= 1 ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 1> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 2>) \
                   : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false, 2>)
-    if (nmax == 20) return P.nu == 3 ? (P.N == 20 ? COPRA_AXIS_PICK(3, 20, true) : COPRA_AXIS_PICK(3, 20, false)) : COPRA_AXIS_PICK(2, 20, false);
+    if (nmax == 20) return P.nu == 3 ? (P.N == 20 && !P.stage_refs ? COPRA_AXIS_PICK(3, 20, true) : COPRA_AXIS_PICK(3, 20, false)) : COPRA_AXIS_PICK(2, 20, false); // (reference trajectories: the run-time-horizon builds)
     if (nmax == 31) return COPRA_AXIS_PICK(2, 31, false);
 #undef COPRA_AXIS_PICK
     return nullptr;
@@ -441,9 +441,14 @@ static bool axis_solver_wanted(const copra_batch* h, const FusedPlan& P)
     const copra_options_t& opt = h->hp.opt;
     if (h->ad.axis_off || opt.no_axis_solver || opt.no_lane_pass || P.axis_tab < 0 || P.prof_fine) return false;
     if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
-    if (h->packed || h->shared || h->hp.large || P.initial_state || P.stage_refs || P.row_f_inst || P.lb_inst || P.ub_inst) return false;
+    if (h->packed || h->shared || h->hp.large || P.initial_state || P.row_f_inst || P.lb_inst || P.ub_inst) return false;
     for (int t = 0; t < kMaxCosts; ++t) // (per-instance references: a lane rebuilds the affine terms of its axis from them -- FusedPlan::axis_cref)
-        if (h->cost_p[t] && (P.axis_cref < 0 || t >= P.ncost || P.cost[t].pstride != 0)) return false;
+        if (h->cost_p[t] && (P.axis_cref < 0 || t >= P.ncost)) return false;
+    if (P.stage_refs) { // reference trajectories: the stages' h wait in the lane's sparse array for the sweep (lmpc_axis.hpp)
+        int oB = 0, oR = 0, rcs = 0;
+        (void)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmax, oB, oR, rcs);
+        if (P.axis_cref < 0 || P.N * (P.nx / P.nu + 1) > rcs) return false;
+    }
     return select_axis_kernel(P) != nullptr;
 }
 static size_t lane_lds_bytes(const FusedPlan& P)

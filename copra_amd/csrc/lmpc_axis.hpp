@@ -93,6 +93,10 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     bool own_refs = false;
     for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
     own_refs = own_refs && P.axis_cref >= 0;
+    // REFERENCE TRAJECTORIES (FusedPlan::stage_refs, CostTerm::pstride: a TrajectoryCost given as a full-size entry whose reference changes along
+    // the horizon -- the only form the reference's API has for it, costFunctions.cpp:63-82 with AutoSpan): h differs from stage to stage.  The
+    // builds with a run-time horizon rebuild it stage by stage into the lane's (still idle) sparse array before the sweep.
+    const bool srefs = !EXACT && P.stage_refs != 0 && P.axis_cref >= 0;
     if (!LIST && P.lane_zero && group == 0 && lane == 0) P.lane_zero[0] = P.lane_zero[2] = 0; // (the NEXT solve's counters: nobody reads them now)
     long long stamp[6];
     stamp[0] = P.prof ? cycle_counter() : 0;
@@ -207,7 +211,8 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     // this lane's sparse array: [0, NH) the controls, NH + k rpa + j row j of step k, the last entry a spare (what empty slots point to)
     double* const RC = lds + oRC_ + lane * RCS;
     const int posSpare = NH + (NH + 1) * rpa;
-    for (int e = 0; e <= posSpare; ++e) RC[e] = 0.0;
+    if (!srefs)
+        for (int e = 0; e <= posSpare; ++e) RC[e] = 0.0;
     stamp[1] = P.prof ? cycle_counter() : 0;
 
     // ---- 1. backward Riccati sweep of the chain: K_k, 1 / M_uu,k in registers, kv_k parked in U[k] ----
@@ -232,22 +237,70 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         // LMPC in the reference, costFunctions.cpp:63-82): the affine terms h = -sum_t [M N]_t' W_t p_t and hN of this lane's axis are rebuilt
         // from the plan builder's coefficients (FusedPlan::axis_cref; lmpc_lane.hpp does the same for the whole instance), with this instance's
         // references where a cost has them and the controller-wide ones elsewhere.  (A row of another axis has zero coefficients here.)
-        if (own_refs) {
+        // Reference trajectories: hN takes the reference of the last step, h of stage k the reference of step k -- NZ doubles per stage, parked
+        // in the lane's sparse array until the sweep has read them (a cost whose reference has no step k -- the last step of a reference over
+        // N steps -- takes its last).
+        if (own_refs || srefs) {
+            // (the cost rows that look at this axis -- at most kAxisMaxRef, FusedPlan::axis_cref --: where their references lie, their coefficients)
+            constexpr int MR = kAxisMaxRef, EW = 2 + NZ + NXA;
+            const double* const cf = P.params + P.axis_cref + (size_t)c * (1 + MR * EW);
+            const int nref = (int)cf[0];
+            const double* bj[MR];
+            int psj[MR], lastj[MR];
+            double ch[MR][NZ], cN[MR][NXA];
 #pragma unroll
-            for (int a = 0; a < NZ; ++a) h[a] = 0.0;
+            for (int j = 0; j < MR; ++j) {
+                const double* const e = cf + 1 + j * EW;
+                const bool on = j < nref;
+                const int t = on ? (int)e[0] : 0, r = on ? (int)e[1] : 0;
 #pragma unroll
-            for (int i = 0; i < NXA; ++i) pv[i] = 0.0;
-            const double* const cf = P.params + P.axis_cref + (size_t)c * kRicMaxCosts * 6 * (NZ + NXA);
-            for (int t = 0; t < P.ncost; ++t) {
-                const int rows_t = P.cost[t].rows;
-                const double* const pr = P.cost_p[t] ? P.cost_p[t] + (size_t)inst * P.cost[t].prows : P.params + P.cost[t].offP;
-                for (int r = 0; r < rows_t; ++r) {
-                    const double pv_r = pr[r];
-                    const double* const co = cf + (t * 6 + r) * (NZ + NXA);
+                for (int a = 0; a < NZ; ++a) ch[j][a] = on ? e[2 + a] : 0.0;
 #pragma unroll
-                    for (int a = 0; a < NZ; ++a) h[a] += co[a] * pv_r;
+                for (int i = 0; i < NXA; ++i) cN[j][i] = on ? e[2 + NZ + i] : 0.0;
+                const int ps = P.cost[t].pstride, prows = P.cost[t].prows;
+                bj[j] = (P.cost_p[t] ? P.cost_p[t] + (size_t)inst * prows : P.params + P.cost[t].offP) + r;
+                psj[j] = ps;
+                lastj[j] = ps ? prows / ps - 1 : 0; // (the last step the reference has)
+            }
+            double pl[MR];
 #pragma unroll
-                    for (int i = 0; i < NXA; ++i) pv[i] += co[NZ + i] * pv_r;
+            for (int j = 0; j < MR; ++j) pl[j] = bj[j][lastj[j] * psj[j]];
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < MR; ++j) s += ch[j][a] * pl[j];
+                h[a] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < NXA; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < MR; ++j) s += cN[j][i] * pl[j];
+                pv[i] = s;
+            }
+            if (srefs) { // four stages a turn: their references are requested together
+                constexpr int KC = 4;
+                for (int k0 = 0; k0 < NH; k0 += KC) {
+                    double pk[KC][MR];
+#pragma unroll
+                    for (int q = 0; q < KC; ++q) {
+                        const int k = k0 + q < NH ? k0 + q : NH - 1;
+#pragma unroll
+                        for (int j = 0; j < MR; ++j) pk[q][j] = bj[j][(k < lastj[j] ? k : lastj[j]) * psj[j]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < KC; ++q) {
+                        if (k0 + q < NH) {
+#pragma unroll
+                            for (int a = 0; a < NZ; ++a) {
+                                double s = 0.0;
+#pragma unroll
+                                for (int j = 0; j < MR; ++j) s += ch[j][a] * pk[q][j];
+                                RC[(k0 + q) * NZ + a] = s;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -293,9 +346,17 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                     for (int i = 0; i < NXA; ++i) s += Pm[l][i] * d[i];
                     tq[l] = s;
                 }
+                double hk[NZ];
+#pragma unroll
+                for (int a = 0; a < NZ; ++a) hk[a] = h[a];
+                if (!EXACT && srefs) {
+                    const int o = opaque(k * NZ);
+#pragma unroll
+                    for (int a = 0; a < NZ; ++a) hk[a] = RC[o + a];
+                }
 #pragma unroll
                 for (int a = 0; a < NZ; ++a) {
-                    double s = h[a];
+                    double s = hk[a];
 #pragma unroll
                     for (int l = 0; l < NXA; ++l) s += AB(l, a) * tq[l];
                     mz[a] = s;
@@ -346,6 +407,8 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             Tv[k] = 0.0;
         }
     }
+    if (srefs) // (the sweep has read the stages' h from it)
+        for (int e = 0; e <= posSpare; ++e) RC[e] = 0.0;
     giveup = giveup | bad;
     stamp[2] = P.prof ? cycle_counter() : 0;
 

@@ -279,6 +279,7 @@ COPRA_HD inline int axis_tab_doubles(int nxa, int N, int rpa)
 }
 constexpr int kAxisGroup = 4; // steps per group of its result staging (U and X leave through LDS as contiguous segments per instance)
 constexpr int kAxisMaxRpa = 2; // constraint rows per axis and step it takes
+constexpr int kAxisMaxRef = 4; // cost rows with a reference per axis it takes (FusedPlan::axis_cref: the CoM model's TrajectoryCost has two per axis)
 // ... and its LDS (doubles): the tables of every axis | the bounds of every axis (ub, lb: N each) -- read there by the builds whose tables change
 // along the horizon -- | per lane (odd stride): the sparse coefficient / response array of the two recursions (N controls + (N + 1) rpa rows + a
 // spare), the matrix S of its active set and the multipliers
@@ -360,8 +361,9 @@ struct FusedPlan {
     const int* axis_list_count; // ... its length, ...
     int* axis_count2; // ... and (first launch) the counter of the list the second chance appends to: zeroed on the way
     int axis_const; // 1: its tables are the same at every step (pure state rows present at all N + 1 steps with one E and f and indices affine in the step, one pair of bounds per control): the builds that keep them in registers
-    int axis_cref; // ... the coefficients of the cost references in its affine terms, per axis: [cost (kRicMaxCosts)][row (6)][h (nxa + 1) | hN (nxa)] (-1: none --
-                   //     controllers with per-instance references keep the one-instance-per-lane pass)
+    int axis_cref; // ... the coefficients of the cost references in its affine terms, per axis: the number of cost rows that look at the axis, then
+                   //     kAxisMaxRef entries [cost | row | coefficients in h (nxa + 1) | in hN (nxa)] (-1: none, or an axis with more such rows --
+                   //     controllers with per-instance references or reference trajectories keep the one-instance-per-lane pass then)
     int axis_tab, axis_rpa; // the (instance, axis)-per-lane solver's tables in `params` (-1: the controller is not eligible) and rows per axis and step (lmpc_axis.hpp)
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)
     int lane_spec; // 1 (with lane_handover): the pass takes the first step of the active-set iteration itself where a bound on u_0 is the pick (lmpc_lane.hpp)

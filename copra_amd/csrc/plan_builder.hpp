@@ -501,11 +501,11 @@ inline void build_lane_tables(HostPlan& hp)
     hp.params.insert(hp.params.end(), tab.begin(), tab.end());
     // Tables of the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): the same stage cost and rows, cut up axis by axis.  Eligible: the
     // costs and every row look at one axis each (lane_axes above; a system with ONE control is one axis), at most kAxisMaxRpa rows per axis
-    // and step, no reference trajectories.  (Whether the SYSTEMS couple two axes is checked per instance by the kernel.)
+    // and step.  (Whether the SYSTEMS couple two axes is checked per instance by the kernel.)
     P.axis_tab = -1;
     P.axis_cref = -1;
     P.axis_rpa = 0;
-    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || P.lane_axes) && !P.stage_refs) {
+    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || P.lane_axes)) {
         const int nxa = nx / nu, nza = nxa + 1, arw = nxa + 3;
         auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
         // rows per axis and step
@@ -586,20 +586,36 @@ inline void build_lane_tables(HostPlan& hp)
             // the coefficients of the cost references (oCref above), axis by axis: what a lane whose instance has its OWN references
             // (copra_batch_set_cost_reference) rebuilds h and hN of its axis from
             if (P.lane_cref >= 0) {
-                const int acw = nza + nxa;
-                std::vector<double> ac((size_t)nu * kRicMaxCosts * 6 * acw, 0.0);
+                const int ew = 2 + nza + nxa, aw = 1 + kAxisMaxRef * ew;
+                std::vector<double> ac((size_t)nu * aw, 0.0);
+                bool fits = true;
                 for (int c = 0; c < nu; ++c) {
                     auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; };
+                    int nref = 0;
                     for (int tr = 0; tr < kRicMaxCosts * 6; ++tr) {
-                        double* dst = ac.data() + ((size_t)c * kRicMaxCosts * 6 + tr) * acw;
                         const double* src = tab.data() + oCref + (size_t)tr * crw;
-                        for (int a = 0; a < nza; ++a) dst[a] = src[zi(a)];
-                        for (int a = 0; a < nxa; ++a) dst[nza + a] = src[nz + zi(a)];
+                        bool any = false;
+                        for (int a = 0; a < nza; ++a) any = any || src[zi(a)] != 0.0;
+                        for (int a = 0; a < nxa; ++a) any = any || src[nz + zi(a)] != 0.0;
+                        if (!any) continue;
+                        if (nref == kAxisMaxRef) {
+                            fits = false;
+                            break;
+                        }
+                        double* dst = ac.data() + (size_t)c * aw + 1 + (size_t)nref * ew;
+                        dst[0] = (double)(tr / 6);
+                        dst[1] = (double)(tr % 6);
+                        for (int a = 0; a < nza; ++a) dst[2 + a] = src[zi(a)];
+                        for (int a = 0; a < nxa; ++a) dst[2 + nza + a] = src[nz + zi(a)];
+                        nref += 1;
                     }
+                    ac[(size_t)c * aw] = (double)nref;
                 }
-                P.axis_cref = (int)hp.params.size();
-                hp.params.insert(hp.params.end(), ac.begin(), ac.end());
-                if (hp.params.size() & 1) hp.params.push_back(0.0);
+                if (fits) {
+                    P.axis_cref = (int)hp.params.size();
+                    hp.params.insert(hp.params.end(), ac.begin(), ac.end());
+                    if (hp.params.size() & 1) hp.params.push_back(0.0);
+                }
             }
         }
     }

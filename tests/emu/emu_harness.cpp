@@ -346,8 +346,13 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
     // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
     bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0 && !P.row_f_inst && !P.lb_inst
-        && !P.ub_inst && !P.stage_refs;
-    for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost && P.cost[k].pstride == 0));
+        && !P.ub_inst;
+    for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost));
+    if (axis_pass && P.stage_refs) { // (reference trajectories: copra_hip.hip, axis_solver_wanted)
+        int oB = 0, oR = 0, rcs = 0;
+        (void)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmax, oB, oR, rcs);
+        axis_pass = P.axis_cref >= 0 && P.N * (P.nx / P.nu + 1) <= rcs;
+    }
     if (axis_pass) {
         int on_spare = 0;
         const int groups = axis_grid(P.nu, dims->batch, on_spare);
@@ -370,7 +375,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                   : lmpc_axis_body<2, NU, NMAX, Q, false, false, 2>(P, g))
 #define COPRA_EMU_AXIS(NU)                                                                                                       \
     (small_q ? COPRA_EMU_AXIS_B(NU, 20, 2, false)                                                                                \
-             : P.N == 20 && NU == 3 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                                   \
+             : P.N == 20 && NU == 3 && !P.stage_refs ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                  \
              : P.N <= 20 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, false) : COPRA_EMU_AXIS_B(NU, 31, kAxisQmax, false))
                 if (P.nu == 3) COPRA_EMU_AXIS(3);
                 else COPRA_EMU_AXIS(2);

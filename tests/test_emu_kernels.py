@@ -1676,6 +1676,38 @@ def test_axis_solver_with_per_instance_goals(emu, oracle):
             assert _rel(re["control"][k], ro["control"]) <= 1e-8 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-8, (N, k)
 
 
+def test_axis_solver_with_reference_trajectories(emu, oracle):
+    """a TrajectoryCost as a full-size entry whose reference changes along the horizon (the only form the reference's API has for tracking,
+    costFunctions.cpp:63-82 with AutoSpan) in front of the (instance, axis)-per-lane solver: the run-time-horizon builds rebuild h stage by
+    stage from the step's reference -- controller-wide, per instance, and together with a control reference over N steps.  Statuses, both
+    counters, U and X against the oracle; the instances end in the solver"""
+    from copra_amd import workloads
+    rng = np.random.default_rng(19)
+    for N, b in ((20, 43), (11, 30)):
+        wl = workloads.com_preview(b, N=N, v_max=0.5, u_max=2.5, seed=40 + N)
+        ts = np.linspace(0.0, 1.0, N + 1)
+        pos = workloads.COM_X_INIT[:3][None, :] + ts[:, None] * (workloads.COM_X_GOAL[:3] - workloads.COM_X_INIT[:3])[None, :]
+        pf = np.hstack([pos, 0.05 * np.ones((N + 1, 3))]).reshape(-1)
+        uref = 0.2 * np.sin(np.arange(N))[:, None] * np.ones((1, 3))
+        track = dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(6)), p=pf, weights=np.tile([10.0, 10.0, 10.0, 1.0, 1.0, 1.0], N + 1))
+        for second in (wl["costs"][1], dict(kind="control", N=np.kron(np.eye(N), np.eye(3)), p=uref.reshape(-1), weights=np.full(3 * N, 1e-2))):
+            args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, [track, second], wl["cstrs"])
+            ro = oracle.lmpc_solve_batch(*args, nthreads=4)
+            ok = ro["status"] == 0
+            re = emu.lmpc_solve(*args)
+            assert re["lane_pass_finished"] >= b - 2 and ok.sum() >= b - 2
+            assert (re["status"] == ro["status"]).all() and (re["iter"][ok] == ro["iter"][ok]).all()
+            assert _rel(re["control"][ok], ro["control"][ok]) <= 1e-8 and _rel(re["trajectory"][ok], ro["trajectory"][ok]) <= 1e-8
+            own = np.tile(pf, (b, 1)) + 0.05 * rng.standard_normal((b, pf.size))  # every instance its own reference trajectory
+            re2 = emu.lmpc_solve(*args, cost_refs={0: own})
+            assert re2["lane_pass_finished"] >= b - 2
+            for k in range(0, b, 3):
+                rk = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, [dict(track, p=own[k]), second], wl["cstrs"])
+                assert re2["status"][k] == rk["status"]
+                if rk["status"] == 0:
+                    assert tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-8
+
+
 def test_axis_solver_with_rows_that_change_along_the_horizon(emu, oracle):
     """tables that are NOT the same at every step (FusedPlan::axis_const = 0: the builds that read them from LDS stage by stage): a mixed
     constraint v_k + 0.1 u_k <= v_max per axis (rows with a control part, none at step N), lower velocity limits as rows (two rows per axis and

@@ -43,7 +43,7 @@ def _rel_vec(a, b, floor=ABS_FLOOR):
 # Tests written for the one-instance-per-lane pass + first tier (rounds 3-5) and for the tier's layout ladder: they assert which kernel finished
 # what, so they pin those kernels -- the one-(instance, axis)-per-lane solver (lmpc_axis.hpp, round 6) takes the same controllers first.
 _R05_PAIR = ("test_one_instance_per_lane_pass", "test_first_tier_layout", "test_riccati_factor_tier_with_a_run_time_horizon",
-             "test_lane_pass_skips_the_gains")
+             "test_lane_pass_skips_the_gains", "test_reference_trajectory_costs", "test_mixed_cost_reference_trajectory")
 
 
 @pytest.fixture(autouse=True)
@@ -2809,6 +2809,44 @@ def test_axis_solver_with_per_instance_goals(oracle):
     for k in range(0, b, 9973):
         ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
         assert rs["status"][k] == ro["status"] == 0 and _rel(rs["control"][k], ro["control"]) <= RTOL
+
+
+def test_axis_solver_with_reference_trajectories(oracle):
+    """reference trajectories (a TrajectoryCost as a full-size entry with a reference that changes along the horizon: the only form the
+    reference's API has for tracking, costFunctions.cpp:63-82) through the (instance, axis)-per-lane solver's run-time-horizon builds:
+    controller-wide and one per instance; whole batch against the round-5 pair, a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    from copra_amd.autospan import autospan_cost
+    b = 40000
+    wl = workloads.com_preview(b, seed=31, v_max=0.5, u_max=2.5)
+    N = wl["N"]
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = workloads.COM_X_INIT[None, :] + ts[:, None] * (workloads.COM_X_GOAL - workloads.COM_X_INIT)[None, :]
+    costs = [autospan_cost(dict(wl["costs"][0], p=xref.reshape(-1))), wl["costs"][1]]
+    own = np.tile(xref.reshape(-1), (b, 1)) + 0.05 * np.random.default_rng(3).standard_normal((b, xref.size))
+    out = {}
+    for mode in ("axis", "pair"):
+        eng = BatchLMPC(6, 3, N, b, costs, wl["cstrs"], options=dict(no_axis_solver=1) if mode == "pair" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        one = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.set_cost_reference(0, own)
+        eng.solve()
+        out[mode] = (one, (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info()))
+        eng.close()
+    for which in (0, 1):
+        r1, ran, info = out["axis"][which]
+        r0 = out["pair"][which][0]
+        assert ran and not out["pair"][which][1] and info[1] >= b - 64
+        ok = r0["status"] == 0
+        assert ok.sum() >= b - 8 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.9999  # (ties)
+        assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-9
+        for k in range(0, b, 3331):
+            p_k = own[k] if which else xref.reshape(-1)
+            cs = [autospan_cost(dict(wl["costs"][0], p=p_k)), wl["costs"][1]]
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, cs, wl["cstrs"])
+            assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+            assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
 def test_axis_solver_on_random_integrator_controllers(oracle):

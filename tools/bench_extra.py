@@ -327,6 +327,17 @@ def extra_measurements(np, torch, dev):
         "what": "TrajectoryCost as a full-size entry with a reference that changes along the horizon (the only form the reference's API has "
                 "for it), recognised as a per-step cost with the reference of the step"}
     eng.close()
+    # ... every instance its OWN reference trajectory, per-instance systems (a fleet of different robots tracking different paths)
+    own = np.tile(xref.reshape(-1), (b, 1)) + 0.02 * np.random.default_rng(7).standard_normal((b, xref.size))
+    eng = BatchLMPC(6, 3, wl["N"], b, track_costs, wl["cstrs"])
+    eng.set_system(*t)
+    eng.set_cost_reference(0, torch.from_numpy(np.ascontiguousarray(own)).to(dev))
+    for _ in range(6):
+        eng.solve()
+    rate, sec = timed_rate(eng, b, reps=3)
+    out["tracking_per_instance_trajectories_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 3,
+                                                            "axis_solver_ran": bool(eng.axis_solver_ran())}
+    eng.close()
     # ... one model for the batch, every instance its OWN reference trajectory (a fleet tracking different paths): the batch-wide stage
     # records + the delta sweep of the shared lane pass
     eng = BatchLMPC(6, 3, wl["N"], b, track_costs, wl["cstrs"])
