@@ -1078,6 +1078,33 @@ copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const cop
     return rc;
 }
 
+// instance 0 of an array of `batch` blocks of `per` doubles, repeated into every other block
+__global__ void copra_repeat_first_block_kernel(double* __restrict__ a, int per, long long total)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x + per;
+    if (e < total) a[e] = a[e % per];
+}
+
+// One model for the batch on a controller the (instance, axis)-per-lane solver takes: that solver, reading every instance's system from memory,
+// is faster than the shared-model path at EVERY batch size (profiles/r06/shared_model_against_instance_by_instance.txt: 256 instances 21 vs
+// 34 us, 65 536: 0.093 vs 0.191 ms; a goal per instance: 0.107 vs 0.247 ms) -- so the model is written out `batch` times and the controller
+// stays on the per-instance path.  Only where that solver would take every solve: its tables and reference coefficients exist, nothing
+// has switched it off.
+static bool shared_model_runs_as_batch(const copra_batch* h)
+{
+    const copra_options_t& opt = h->hp.opt;
+    const FusedPlan& P = h->hp.plan;
+    if (opt.no_axis_solver || opt.no_lane_pass || h->ad.axis_off || P.axis_tab < 0 || P.axis_cref < 0 || P.batch <= 0) return false;
+    if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
+    if (h->packed || h->hp.large || P.initial_state || h->jit_fused) return false;
+    if (P.stage_refs) {
+        int oB = 0, oR = 0, rcs = 0;
+        (void)axis_lds_doubles(P.nx, P.nu, P.N, P.axis_rpa, kAxisQmax, oB, oR, rcs);
+        if (P.N * (P.nx / P.nu + 1) > rcs) return false;
+    }
+    return select_axis_kernel(P) != nullptr;
+}
+
 copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, const double* B, const double* d,
     int on_device)
 {
@@ -1091,6 +1118,31 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shA.data(), A, nA * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shB.data(), B, nB * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
+    h->shared_as_batch = false;
+    if (!h->shared && shared_model_runs_as_batch(h)) { // (a handle that is in shared-model mode stays there: its layouts have moved)
+        const size_t b = (size_t)P.batch;
+        if (!h->own_A) {
+            HIP_TRY(hipMalloc((void**)&h->own_A, b * nA * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&h->own_B, b * nB * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&h->own_d, b * nd * sizeof(double)));
+        }
+        HIP_TRY(hipMemcpy(h->own_A, h->shA.data(), nA * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->own_B, h->shB.data(), nB * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->own_d, h->shd.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+        double* const arr[3] = { h->own_A, h->own_B, h->own_d };
+        const size_t per[3] = { nA, nB, nd };
+        for (int i = 0; i < 3; ++i) {
+            const long long total = (long long)(b * per[i]), rest = total - (long long)per[i];
+            if (rest > 0) hipLaunchKernelGGL(copra_repeat_first_block_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, 0, arr[i], (int)per[i], total);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(0)); // (the solves run on the caller's stream)
+        h->A = h->own_A;
+        h->B = h->own_B;
+        h->d = h->own_d;
+        h->shared_as_batch = true;
+        return COPRA_OK;
+    }
     h->shared = true;
     h->model_dirty = true;
     // (general rows as well: an instance whose rows go through the free response of the preview rebuilds it from its own x0 and the model's A,
@@ -1802,6 +1854,7 @@ copra_status_t copra_batch_solve(copra_batch_t* h, void* hip_stream)
         if (rc == COPRA_OK) remember_outputs(h, device_plan(h));
         return rc;
     }
+    if (h->shared_as_batch && !h->x0) return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no initial states set (copra_batch_set_x0)");
     if (!h->A || !h->B || !h->d || !h->x0)
         return fail(COPRA_ERR_RUNTIME, "copra_batch_solve: no preview system set (copra_batch_set_system)");
     FusedPlan P = device_plan(h);

@@ -172,6 +172,7 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     const FusedPlan& P = h->hp.plan;
     const size_t b = (size_t)P.batch;
     h->shared = false; // per-instance systems again (leaves the shared-model fast path)
+    h->shared_as_batch = false;
     if (on_device) {
         h->A = A;
         h->B = B;
@@ -223,6 +224,7 @@ copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const dou
     const size_t b = (size_t)P.batch;
     const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
     h->shared = false;
+    h->shared_as_batch = false;
     if (!h->own_A) {
         HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));

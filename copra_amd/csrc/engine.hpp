@@ -102,6 +102,7 @@ struct copra_batch {
     int *d_row_prev = nullptr, *d_warm = nullptr; // warm start of the shared-model path (copra_batch_set_warm_start)
     // system (owned copies, or borrowed device pointers)
     double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
+    bool shared_as_batch = false; // copra_batch_set_shared_system on a controller the (instance, axis)-per-lane solver takes: the model written out per instance (copra_hip.hip)
     const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
     // results
     double *d_control = nullptr, *d_traj = nullptr; // (carved from ONE allocation, d_results: small batches fetch it with one copy)

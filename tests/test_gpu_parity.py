@@ -48,7 +48,9 @@ _R05_PAIR = ("test_one_instance_per_lane_pass", "test_first_tier_layout", "test_
 
 @pytest.fixture(autouse=True)
 def _pin_the_kernels_a_test_is_about(request, monkeypatch):
-    if request.node.name.startswith(_R05_PAIR):
+    # (the shared-model path: since round 6 copra_batch_set_shared_system writes the model out per instance on controllers the (instance, axis)-
+    #  per-lane solver takes -- that solver is faster at every batch size; the tests OF the shared-model kernels keep them)
+    if request.node.name.startswith(_R05_PAIR) or "shared_model" in request.node.name:
         monkeypatch.setitem(OPTIONS, "no_axis_solver", 1)
 
 
@@ -2809,6 +2811,53 @@ def test_axis_solver_with_per_instance_goals(oracle):
     for k in range(0, b, 9973):
         ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
         assert rs["status"][k] == ro["status"] == 0 and _rel(rs["control"][k], ro["control"]) <= RTOL
+
+
+def test_one_model_for_the_batch_on_the_axis_solver(oracle):
+    """copra_batch_set_shared_system on a controller the (instance, axis)-per-lane solver takes: the model is written out per instance and the
+    per-instance path runs (faster than the shared-model kernels at every batch size, profiles/r06/shared_model_against_instance_by_instance.txt).
+    Against the shared-model path (option no_axis_solver) on the whole batch -- statuses, counters, 1e-9 -- and a sample against the oracle;
+    with a goal per instance; a NEW model on the same handle; then per-instance systems again"""
+    from copra_amd import BatchLMPC, workloads
+    for b in (300, 30000):
+        wl = workloads.com_preview(b, seed=51, v_max=0.5, u_max=2.5)
+        A, B, d = wl["A"][7], wl["B"][7], wl["d"][7]
+        goals = workloads.COM_X_GOAL[None, :] + 0.1 * np.random.default_rng(2).standard_normal((b, 6))
+        out = {}
+        for mode in ("axis", "shared"):
+            eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1) if mode == "shared" else None)
+            eng.set_shared_system(A, B, d)
+            eng.set_x0(wl["x0"])
+            eng.solve()
+            r_one, ran_one = eng.results(), eng.axis_solver_ran()
+            eng.set_cost_reference(0, goals)
+            eng.solve()
+            r_own = eng.results()
+            eng.set_cost_reference(0, None)
+            eng.set_shared_system(wl["A"][9], wl["B"][9], wl["d"][9])  # (a new model: the tick of a controller whose model moves)
+            eng.solve()
+            r_new = eng.results()
+            out[mode] = (r_one, r_own, r_new, ran_one)
+            if mode == "axis":
+                eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+                eng.solve()
+                r_pi = eng.results()
+            eng.close()
+        assert out["axis"][3] and not out["shared"][3]
+        for r1, r0 in zip(out["axis"][:3], out["shared"][:3]):
+            ok = r0["status"] == 0
+            assert ok.sum() >= b - 4 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.9999  # (ties)
+            assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-9
+        for k in range(0, b, max(b // 6, 1)):
+            ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+            assert out["axis"][0]["status"][k] == ro["status"] == 0 and tuple(out["axis"][0]["iter"][k]) == tuple(ro["iter"])
+            assert _rel(out["axis"][0]["control"][k], ro["control"]) <= RTOL
+            ro = oracle.lmpc_solve(A, B, d, wl["x0"][k], wl["N"], [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]], wl["cstrs"])
+            assert out["axis"][1]["status"][k] == ro["status"] == 0 and _rel(out["axis"][1]["control"][k], ro["control"]) <= RTOL
+            ro = oracle.lmpc_solve(wl["A"][9], wl["B"][9], wl["d"][9], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+            assert out["axis"][2]["status"][k] == ro["status"] == 0 and _rel(out["axis"][2]["control"][k], ro["control"]) <= RTOL
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], wl["costs"], wl["cstrs"])
+            assert r_pi["status"][k] == ro["status"] == 0 and _rel(r_pi["control"][k], ro["control"]) <= RTOL
 
 
 def test_axis_solver_with_reference_trajectories(oracle):

@@ -241,14 +241,27 @@ def extra_measurements(np, torch, dev):
     eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"])
     eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
     eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
+    for _ in range(6):
+        eng.solve()
     rate, sec = timed_rate(eng, b)
-    out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5}
+    # (since round 6 the engine writes the model out per instance where the (instance, axis)-per-lane solver takes the controller -- faster than
+    #  the shared-model kernels at every batch size, profiles/r06/shared_model_against_instance_by_instance.txt; the shared-model kernels: below)
+    out["shared_model_tick_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5, "axis_solver_ran": bool(eng.axis_solver_ran())}
     # ... and every instance its own goal (copra_batch_set_cost_reference): the batch-wide records stay, the shared lane pass adds the
     # delta of each instance's feed-forward terms
     goals = workloads.COM_X_GOAL[None, :] + 0.05 * np.random.default_rng(5).standard_normal((b, 6))
     eng.set_cost_reference(0, torch.from_numpy(np.ascontiguousarray(goals)).to(dev))
+    for _ in range(6):
+        eng.solve()
     rate, sec = timed_rate(eng, b)
-    out["shared_model_tick_per_instance_goals_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5}
+    out["shared_model_tick_per_instance_goals_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5, "axis_solver_ran": bool(eng.axis_solver_ran())}
+    eng.close()
+    eng = BatchLMPC(6, 3, wl["N"], b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1))
+    eng.set_shared_system(wl["A"][0], wl["B"][0], wl["d"][0])
+    eng.set_x0(torch.from_numpy(np.ascontiguousarray(wl["x0"])).to(dev))
+    rate, sec = timed_rate(eng, b)
+    out["shared_model_tick_shared_model_kernels_batch65536"] = {"solves_per_s": rate, "kernel_ms": sec * 1e3, "timing": EVENT_TIMING % 5,
+                                                               "note": "copra_options_t::no_axis_solver: batch-wide records, shared lane pass, records tier (DESIGN.md 3.6)"}
     eng.close()
     # sensitivity: the tight workload (v_max 0.25 / u_max 1.2: every instance activates 3..22 constraints; the factor-only
     # layout steps down its ladder) -- the headline number depends on <= 5 active constraints per instance
