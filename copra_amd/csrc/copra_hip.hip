@@ -441,7 +441,10 @@ static bool axis_solver_wanted(const copra_batch* h, const FusedPlan& P)
     const copra_options_t& opt = h->hp.opt;
     if (h->ad.axis_off || opt.no_axis_solver || opt.no_lane_pass || P.axis_tab < 0 || P.prof_fine) return false;
     if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
-    if (h->packed || h->shared || h->hp.large || P.initial_state || P.row_f_inst || P.lb_inst || P.ub_inst) return false;
+    if (h->packed || h->shared || h->hp.large || P.initial_state) return false;
+    // (per-instance limits: the builds that keep bounds and right-hand sides in registers take this lane's own -- where they are the same
+    //  along the horizon, else the instance goes to the tier: lmpc_axis.hpp)
+    if ((P.row_f_inst || P.lb_inst || P.ub_inst) && (!P.axis_const || (P.lb_inst == nullptr) != (P.ub_inst == nullptr))) return false;
     for (int t = 0; t < kMaxCosts; ++t) // (per-instance references: a lane rebuilds the affine terms of its axis from them -- FusedPlan::axis_cref)
         if (h->cost_p[t] && (P.axis_cref < 0 || t >= P.ncost)) return false;
     if (P.stage_refs) { // reference trajectories: the stages' h wait in the lane's sparse array for the sweep (lmpc_axis.hpp)

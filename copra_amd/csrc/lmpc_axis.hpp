@@ -206,6 +206,31 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 ridxd[j] = (int)r1[NXA + 2] - ridx0[j];
             }
         }
+        // Per-instance limits (copra_batch_set_control_bounds, copra_batch_set_constraint_rhs: every robot its own actuator and velocity limits):
+        // this lane's own values where they are the same at every step of the horizon -- what these builds keep in registers --; an instance
+        // whose limits change along the horizon goes to the tier.
+        if (P.ub_inst) {
+            const double* const up = P.ub_inst + (size_t)inst * P.n + c;
+            const double* const lp = P.lb_inst + (size_t)inst * P.n + c;
+            ubc = up[0];
+            lbc = lp[0];
+            bool same = true;
+            for (int k = 1; k < NH; ++k) same = same & (up[k * NU] == ubc) & (lp[k * NU] == lbc);
+            giveup = giveup | !same;
+        }
+        if (P.row_f_inst) {
+            const double* const fp = P.row_f_inst + (size_t)inst * P.mgen;
+#pragma unroll
+            for (int j = 0; j < RPA; ++j) {
+                if (j < rpa && ridx0[j] >= 0) {
+                    const double f0 = fp[ridx0[j]];
+                    bool same = true;
+                    for (int k = 1; k <= NH; ++k) same = same & (fp[ridx0[j] + k * ridxd[j]] == f0);
+                    rf[j] = f0;
+                    giveup = giveup | !same;
+                }
+            }
+        }
     }
     wave_sync(); // (!CT: the tables are in LDS)
     // this lane's sparse array: [0, NH) the controls, NH + k rpa + j row j of step k, the last entry a spare (what empty slots point to)
@@ -747,11 +772,12 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     };
     // An empty box (or a pinned control, ub = lb: gi_core.hpp, `pinned`) makes the twin of an active bound a candidate of qpgen2's scan; the scan
     // above never looks at twins: such a lane leaves its instance to the tier at once.
+    // (an infinite bound: never empty -- inf > 1e-9 inf would say otherwise)
     if (CT) {
-        giveup = giveup | !(ubc - lbc > 1e-9 * fmax(1.0, fabs(ubc)));
+        giveup = giveup | !(ubc - lbc > 1e-9 * fmax(1.0, fmin(fabs(ubc), 1e300)));
     } else {
         const double* const UB = lds + oUB;
-        for (int k = 0; k < NH; ++k) giveup = giveup | !(UB[k] - UB[NH + k] > 1e-9 * fmax(1.0, fabs(UB[k])));
+        for (int k = 0; k < NH; ++k) giveup = giveup | !(UB[k] - UB[NH + k] > 1e-9 * fmax(1.0, fmin(fabs(UB[k]), 1e300)));
     }
 
     // ---- 2. roll-out: the unconstrained minimiser and qpgen2's first scan ----

@@ -345,8 +345,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     int lane_cnt[4] = { 0, 0, 0, 0 }; // (as the device's: [left over | the next solve's] [+ 2: ended by the pass's own steps])
     int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
     // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
-    bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0 && !P.row_f_inst && !P.lb_inst
-        && !P.ub_inst;
+    bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0
+        && (!(P.row_f_inst || P.lb_inst || P.ub_inst) || (P.axis_const && (P.lb_inst == nullptr) == (P.ub_inst == nullptr)));
     for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost));
     if (axis_pass && P.stage_refs) { // (reference trajectories: copra_hip.hip, axis_solver_wanted)
         int oB = 0, oR = 0, rcs = 0;

@@ -1676,6 +1676,38 @@ def test_axis_solver_with_per_instance_goals(emu, oracle):
             assert _rel(re["control"][k], ro["control"]) <= 1e-8 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-8, (N, k)
 
 
+def test_axis_solver_with_per_instance_limits(emu, oracle):
+    """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) in front of the
+    (instance, axis)-per-lane solver: the builds that keep bounds and right-hand sides in registers take the lane's own values where they are the
+    same at every step of the horizon; an instance whose limits CHANGE along the horizon goes to the tier (same results).  And a controller
+    without control bounds at all: an infinite box is not an empty one"""
+    from copra_amd import workloads
+    rng = np.random.default_rng(33)
+    b, inf = 47, np.inf
+    wl = workloads.com_preview(b, v_max=0.5, u_max=2.5, seed=13)
+    N = wl["N"]
+    vlim = 0.5 * rng.uniform(0.6, 1.3, b)
+    ulim = 2.5 * rng.uniform(0.6, 1.3, b)
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, wl["costs"], wl["cstrs"])
+    rhs = np.repeat(vlim[:, None], 3 * (N + 1), axis=1)
+    lo, hi = -np.repeat(ulim[:, None], 3 * N, axis=1), np.repeat(ulim[:, None], 3 * N, axis=1)
+    hi[5, 3 * 7 + 1] *= 0.5  # (instance 5: a tighter bound on one control of step 7 -- its limits change along the horizon)
+    rhs[9, 3 * 4 + 2] *= 0.8  # (instance 9: one row of step 4)
+    re = emu.lmpc_solve(*args, row_rhs=rhs, bounds=(lo, hi))
+    assert b - 6 <= re["lane_pass_finished"] <= b - 2
+    for k in range(b):
+        up = np.full((N + 1, 6), inf)
+        up[:, 3:] = rhs[k].reshape(N + 1, 3)
+        cs = [dict(kind="trajectory_bound", lower=np.full(6 * (N + 1), -inf), upper=up.reshape(-1)),
+              dict(kind="control_bound", lower=lo[k], upper=hi[k])]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], cs)
+        assert re["status"][k] == ro["status"], k
+        if ro["status"] == 0:
+            assert tuple(re["iter"][k]) == tuple(ro["iter"]) and _rel(re["control"][k], ro["control"]) <= 1e-8, k
+    re2, ro2 = _axis_case(emu, oracle, wl, cstrs=[wl["cstrs"][0]])  # no control bounds at all
+    assert re2["lane_pass_finished"] >= b - 2
+
+
 def test_axis_solver_with_reference_trajectories(emu, oracle):
     """a TrajectoryCost as a full-size entry whose reference changes along the horizon (the only form the reference's API has for tracking,
     costFunctions.cpp:63-82 with AutoSpan) in front of the (instance, axis)-per-lane solver: the run-time-horizon builds rebuild h stage by

@@ -2860,6 +2860,45 @@ def test_one_model_for_the_batch_on_the_axis_solver(oracle):
             assert r_pi["status"][k] == ro["status"] == 0 and _rel(r_pi["control"][k], ro["control"]) <= RTOL
 
 
+def test_axis_solver_with_per_instance_limits(oracle):
+    """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) through the
+    (instance, axis)-per-lane solver: the lane's own values where they are the same along the horizon, the tier for the instances whose limits
+    change along it.  Whole batch against the round-5 pair, a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b, inf = 50000, np.inf
+    wl = workloads.com_preview(b, seed=61, v_max=0.5, u_max=2.5)
+    N = wl["N"]
+    rng = np.random.default_rng(6)
+    vlim = 0.5 * rng.uniform(0.6, 1.3, b)
+    ulim = 2.5 * rng.uniform(0.6, 1.3, b)
+    Ev = np.hstack([np.zeros((3, 3)), np.eye(3)])  # the velocity limit as a TrajectoryConstraint E x_k <= f (a TrajectoryBound has no f)
+    cstrs = [dict(kind="trajectory", E=Ev, f=[0.5] * 3, ineq=True), wl["cstrs"][1]]
+    rhs = np.repeat(vlim[:, None], 3, axis=1)
+    lo, hi = -np.repeat(ulim[:, None], 3 * N, axis=1), np.repeat(ulim[:, None], 3 * N, axis=1)
+    odd = np.arange(0, b, 997)
+    hi[odd, 3 * 5 + 1] *= 0.5  # (a tighter bound on one control of step 5: limits that change along the horizon)
+    out = {}
+    for mode in ("axis", "pair"):
+        eng = BatchLMPC(6, 3, N, b, wl["costs"], cstrs, options=dict(no_axis_solver=1) if mode == "pair" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.set_constraint_rhs(0, rhs)
+        eng.set_control_bounds(lo, hi)
+        eng.solve()
+        out[mode] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.close()
+    r1, ran, info = out["axis"]
+    r0 = out["pair"][0]
+    assert ran and not out["pair"][1] and b - len(odd) - 64 <= info[1] <= b - len(odd)
+    ok = r0["status"] == 0
+    assert ok.sum() >= b - 8 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.9999  # (ties)
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-9
+    for k in list(range(0, b, 4111)) + [int(odd[3])]:
+        cs = [dict(cstrs[0], f=[vlim[k]] * 3), dict(kind="control_bound", lower=lo[k], upper=hi[k])]
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], cs)
+        assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+        assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_axis_solver_with_reference_trajectories(oracle):
     """reference trajectories (a TrajectoryCost as a full-size entry with a reference that changes along the horizon: the only form the
     reference's API has for tracking, costFunctions.cpp:63-82) through the (instance, axis)-per-lane solver's run-time-horizon builds:
