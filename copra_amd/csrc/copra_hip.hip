@@ -59,8 +59,10 @@ __global__ __launch_bounds__(64, 2) void copra_lmpc_fused_tri_kernel(const Fused
 #include "axis_kernels.hpp" // copra_lmpc_axis_kernel: instantiated in copra_hip_axis.hip
 #define COPRA_AXIS_DECL(NXA, NU, NMAX, QMAX, EXACT, CT, RPA) extern template __global__ void copra_lmpc_axis_kernel<NXA, NU, NMAX, QMAX, EXACT, CT, RPA>(const FusedPlan);
 COPRA_AXIS_KERNELS(COPRA_AXIS_DECL)
+COPRA_AXIS_KERNELS_MORE(COPRA_AXIS_DECL)
 #define COPRA_AXIS_LIST_DECL(NXA, NU, NMAX, QMAX, CT, RPA) extern template __global__ void copra_lmpc_axis_list_kernel<NXA, NU, NMAX, QMAX, CT, RPA>(const FusedPlan);
 COPRA_AXIS_LIST_KERNELS(COPRA_AXIS_LIST_DECL)
+COPRA_AXIS_LIST_KERNELS_MORE(COPRA_AXIS_LIST_DECL)
 // run-time-horizon builds (NH == 0) for the shapes of ric_aot_shape: instantiated in copra_hip_ric.hip, a translation unit of its own
 #define COPRA_RIC_RT_DECL(NX, NU)                                                                                      \
     extern template __global__ void copra_lmpc_fused_ric_kernel<NX, NU, 0, kFusedQ1Regs, false>(const FusedPlan);      \
@@ -408,6 +410,12 @@ static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 {
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+    if (nmax == 20 && P.nx == 3 * P.nu) { // (copra_hip_axis3.hip: tables in registers with one row per axis and step, or read from LDS)
+        const bool ct = P.axis_const && P.axis_rpa <= 1;
+#define COPRA_AXIS_PICK3(NXA, NU) (ct ? copra_lmpc_axis_kernel<NXA, NU, 20, kAxisQmax, false, true, 1> : copra_lmpc_axis_kernel<NXA, NU, 20, kAxisQmax, false, false, 2>)
+        return P.nu == 2 ? COPRA_AXIS_PICK3(3, 2) : COPRA_AXIS_PICK3(3, 3);
+#undef COPRA_AXIS_PICK3
+    }
 #define COPRA_AXIS_PICK(NU, NMAX, EXACT)                                                                                                     \
     (P.axis_const ? (P.axis_rpa <= 1 ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 1> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 2>) \
                   : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false, 2>)
@@ -420,6 +428,8 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 static fused_kernel_t select_axis_list_kernel(const FusedPlan& P)
 {
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+    if (nmax == 20 && P.nx == 3 * P.nu)
+        return P.nu == 2 ? copra_lmpc_axis_list_kernel<3, 2, 20, kAxisQmaxBig, false, 2> : copra_lmpc_axis_list_kernel<3, 3, 20, kAxisQmaxBig, false, 2>;
 #define COPRA_AXIS_LPICK(NU, NMAX) (P.axis_const ? copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, true, 2> : copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, false, 2>)
     if (nmax == 20) return P.nu == 3 ? COPRA_AXIS_LPICK(3, 20) : COPRA_AXIS_LPICK(2, 20);
     if (nmax == 31) return COPRA_AXIS_LPICK(2, 31);

@@ -215,8 +215,14 @@ constexpr int kAxisQmax = 6; // active constraints per (instance, axis) its lane
 constexpr int kAxisQmaxBig = 16; // ... and the lanes of the second chance of what it lists (copra_lmpc_axis_list_kernel)
 inline int axis_solver_nmax(int nx, int nu, int N)
 {
-    if (nu < 2 || nu > 3 || nx != 2 * nu || N < 1) return 0;
-    return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : 0;
+    // chains of two states per control in two and three dimensions (the CoM model, planar point masses) at horizons up to 20 (two dimensions: 31);
+    // since late round 6 also chains of THREE states per control (the jerk-controlled CoM model: position, velocity, acceleration per axis)
+    // in two and three dimensions, up to 20 steps
+    if (nu < 2 || nu > 3 || N < 1 || nx % nu != 0) return 0;
+    const int nxa = nx / nu;
+    if (nxa == 2) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : 0;
+    if (nxa == 3) return N <= 20 ? 20 : 0;
+    return 0;
 }
 inline bool ric_aot_shape(int nx, int nu) { return (nx == 6 && nu == 3) || (nx == 4 && nu == 2) || (nx == 2 && nu == 1); }
 inline bool ric_aot_exact(int nx, int nu, int N) { return nx == 6 && nu == 3 && (N == 10 || N == 15 || N == 20); }
@@ -403,7 +409,8 @@ inline void build_lane_tables(HostPlan& hp)
     P.axis_rpa = 0;
     P.axis_const = 0;
     const int nx = P.nx, nu = P.nu, nz = nx + nu, N = P.N;
-    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 7 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return; // (nx: the lane's registers)
+    const bool lane_ok = nx <= 7; // (the one-instance-per-lane pass: the lane's registers; the (instance, axis)-per-lane solver takes chains of up to 3 states per control)
+    if (P.meq > 0 || P.initial_state || nu > 3 || nx > 9 || P.denseQ >= 0 || P.rfull > 0 || P.n > kWave) return;
     std::vector<int> per_step((size_t)N + 1, 0);
     for (int i = 0; i < P.mgen; ++i) {
         const int k = hp.row_step[i], ek = hp.row_ekind[i], gk = hp.row_gkind[i];
@@ -465,6 +472,7 @@ inline void build_lane_tables(HostPlan& hp)
         row[nz] = hp.row_f[i];
         row[nz + 1] = (double)i;
     }
+    bool axes_decoupled = false;
     { // axis-decoupled costs (FusedPlan::lane_axes): H(a, b) = 0 and HN(a, b) = 0 wherever a and b belong to different axes
         auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
         bool ok = nu > 1 && nx % nu == 0 && !hp.opt.no_lane_axes;
@@ -488,24 +496,30 @@ inline void build_lane_tables(HostPlan& hp)
                     }
             }
         P.lane_axes = ok ? 1 : 0;
+        axes_decoupled = ok;
     }
-    if (hp.params.size() & 1) hp.params.push_back(0.0);
-    P.lane_tab = (int)hp.params.size();
-    P.lane_rps = rps;
-    P.lane_cref = (P.ncost <= kRicMaxCosts && P.rmax <= 6) ? oCref : -1; // (-1: per-instance references keep the first tier alone)
-    {
-        int oHl = 0;
-        const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;
-        P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u) ? tl : 0; // (four waves per CU)
+    const bool cref_ok = P.ncost <= kRicMaxCosts && P.rmax <= 6;
+    if (lane_ok) {
+        if (hp.params.size() & 1) hp.params.push_back(0.0);
+        P.lane_tab = (int)hp.params.size();
+        P.lane_rps = rps;
+        P.lane_cref = cref_ok ? oCref : -1; // (-1: per-instance references keep the first tier alone)
+        {
+            int oHl = 0;
+            const int base = lane_lds_doubles(nx, nu, oHl), tl = (N + 1) * rps * rw + 2 * P.n;
+            P.lane_tlds = ((size_t)(base + tl) * sizeof(double) <= 40u * 1024u) ? tl : 0; // (four waves per CU)
+        }
+        hp.params.insert(hp.params.end(), tab.begin(), tab.end());
+    } else {
+        P.lane_axes = 0; // (what the pass reads; the solver below checks the same on its own)
     }
-    hp.params.insert(hp.params.end(), tab.begin(), tab.end());
     // Tables of the one-(instance, axis)-per-lane solver (lmpc_axis.hpp): the same stage cost and rows, cut up axis by axis.  Eligible: the
     // costs and every row look at one axis each (lane_axes above; a system with ONE control is one axis), at most kAxisMaxRpa rows per axis
     // and step.  (Whether the SYSTEMS couple two axes is checked per instance by the kernel.)
     P.axis_tab = -1;
     P.axis_cref = -1;
     P.axis_rpa = 0;
-    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || P.lane_axes)) {
+    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || axes_decoupled)) {
         const int nxa = nx / nu, nza = nxa + 1, arw = nxa + 3;
         auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
         // rows per axis and step
@@ -585,29 +599,40 @@ inline void build_lane_tables(HostPlan& hp)
             hp.params.insert(hp.params.end(), at.begin(), at.end());
             // the coefficients of the cost references (oCref above), axis by axis: what a lane whose instance has its OWN references
             // (copra_batch_set_cost_reference) rebuilds h and hN of its axis from
-            if (P.lane_cref >= 0) {
+            { // (straight from the costs: any number of rows per cost -- the jerk-controlled CoM model's TrajectoryCost has nine)
                 const int ew = 2 + nza + nxa, aw = 1 + kAxisMaxRef * ew;
                 std::vector<double> ac((size_t)nu * aw, 0.0);
-                bool fits = true;
-                for (int c = 0; c < nu; ++c) {
+                bool fits = P.ncost <= kMaxCosts;
+                for (int c = 0; c < nu && fits; ++c) {
                     auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; };
                     int nref = 0;
-                    for (int tr = 0; tr < kRicMaxCosts * 6; ++tr) {
-                        const double* src = tab.data() + oCref + (size_t)tr * crw;
-                        bool any = false;
-                        for (int a = 0; a < nza; ++a) any = any || src[zi(a)] != 0.0;
-                        for (int a = 0; a < nxa; ++a) any = any || src[nz + zi(a)] != 0.0;
-                        if (!any) continue;
-                        if (nref == kAxisMaxRef) {
-                            fits = false;
-                            break;
+                    for (int t = 0; t < P.ncost && fits; ++t) {
+                        const CostTerm& ct = P.cost[t];
+                        const bool in_stage = ct.kind != kCostTarget, in_term = ct.kind == kCostTrajectory || ct.kind == kCostTarget;
+                        for (int r = 0; r < ct.rows; ++r) {
+                            const double w = hp.params[(size_t)ct.offW + r];
+                            double ch[4] = { 0, 0, 0, 0 }, cn[3] = { 0, 0, 0 };
+                            bool any = false;
+                            for (int a = 0; a < nza; ++a) {
+                                ch[a] = in_stage ? -(coef(ct, r, zi(a)) * w) : 0.0;
+                                any = any || ch[a] != 0.0;
+                            }
+                            for (int a = 0; a < nxa; ++a) {
+                                cn[a] = in_term ? -(coef(ct, r, zi(a)) * w) : 0.0;
+                                any = any || cn[a] != 0.0;
+                            }
+                            if (!any) continue;
+                            if (nref == kAxisMaxRef) {
+                                fits = false;
+                                break;
+                            }
+                            double* dst = ac.data() + (size_t)c * aw + 1 + (size_t)nref * ew;
+                            dst[0] = (double)t;
+                            dst[1] = (double)r;
+                            for (int a = 0; a < nza; ++a) dst[2 + a] = ch[a];
+                            for (int a = 0; a < nxa; ++a) dst[2 + nza + a] = cn[a];
+                            nref += 1;
                         }
-                        double* dst = ac.data() + (size_t)c * aw + 1 + (size_t)nref * ew;
-                        dst[0] = (double)(tr / 6);
-                        dst[1] = (double)(tr % 6);
-                        for (int a = 0; a < nza; ++a) dst[2 + a] = src[zi(a)];
-                        for (int a = 0; a < nxa; ++a) dst[2 + nza + a] = src[nz + zi(a)];
-                        nref += 1;
                     }
                     ac[(size_t)c * aw] = (double)nref;
                 }

@@ -92,6 +92,41 @@ def com_preview(batch, N=20, seed=1, v_max=0.6, u_max=3.0):
                 costs=costs, cstrs=cstrs)
 
 
+def jerk_preview(batch, nu=3, N=20, seed=21, v_max=0.6, j_max=20.0, a_max=None):
+    """The jerk-controlled CoM model (the cart-table / preview-control model: position, velocity, acceleration per axis, the jerk as control)
+    in `nu` dimensions: nx = 3 nu, state i on axis i % nu.  Per-instance sampling period T ~ U(0.08, 0.15); trajectory cost towards a goal +
+    small control cost; an upper velocity bound (TrajectoryBoundConstraint, upper-only: reference quirk Q1), a symmetric bound on the jerk,
+    optionally an upper bound on the acceleration as well (two rows per axis and step)."""
+    rng = SplitMix64(seed)
+    T = rng.uniform(batch, 0.08, 0.15)
+    I = np.eye(nu)
+    nx = 3 * nu
+    A = np.zeros((batch, nx, nx))
+    B = np.zeros((batch, nx, nu))
+    for a in range(3):
+        A[:, a * nu:(a + 1) * nu, a * nu:(a + 1) * nu] = I
+    A[:, :nu, nu:2 * nu] = T[:, None, None] * I
+    A[:, :nu, 2 * nu:] = (0.5 * T * T)[:, None, None] * I
+    A[:, nu:2 * nu, 2 * nu:] = T[:, None, None] * I
+    B[:, :nu, :] = (T ** 3 / 6.0)[:, None, None] * I
+    B[:, nu:2 * nu, :] = (0.5 * T * T)[:, None, None] * I
+    B[:, 2 * nu:, :] = T[:, None, None] * I
+    d = np.zeros((batch, nx))
+    goal = np.concatenate([COM_X_GOAL[:nu], np.zeros(2 * nu)])
+    x0 = np.zeros((batch, nx))
+    x0[:, :nu] = COM_X_INIT[:nu] + rng.normal(batch * nu, 0.05).reshape(batch, nu)
+    x0[:, nu:2 * nu] = rng.uniform(batch * nu, -0.2, 0.2).reshape(batch, nu)
+    x0[:, 2 * nu:] = rng.uniform(batch * nu, -0.5, 0.5).reshape(batch, nu)
+    inf = np.inf
+    costs = [dict(kind="trajectory", M=np.eye(nx), p=goal, weights=[10.0] * nu + [1.0] * nu + [0.1] * nu),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-4] * nu)]
+    upper = [inf] * nu + [v_max] * nu + ([inf] * nu if a_max is None else [a_max] * nu)
+    cstrs = [dict(kind="trajectory_bound", lower=[-inf] * nx, upper=upper),
+             dict(kind="control_bound", lower=[-j_max] * nu, upper=[j_max] * nu)]
+    return dict(name="jerk-controlled CoM preview (nx=%d,nu=%d,N=%d) + trajectory & control bounds" % (nx, nu, N), A=A, B=B, d=d, x0=x0, N=N,
+                costs=costs, cstrs=cstrs)
+
+
 def long_horizon_initial_state(batch, N=50, seed=3, v_max=0.5, u_max=2.0, R_diag=1e-6, T=0.05):
     """BASELINE config 5 as SURVEY.md section 8(d) specifies it: InitialStateLMPC on a 6-DoF double integrator
     (nx=12, nu=6, N=50, T=0.05; 312 decision variables [x0; U]) -- the long-horizon case that does not fit the LDS.

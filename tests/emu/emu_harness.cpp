@@ -345,7 +345,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     int lane_cnt[4] = { 0, 0, 0, 0 }; // (as the device's: [left over | the next solve's] [+ 2: ended by the pass's own steps])
     int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
     // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
-    bool axis_pass = lane_pass && P.axis_tab >= 0 && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0
+    // (independent of the pass: chains of three states per control have no build of it)
+    bool axis_pass = P.axis_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && !default_options().no_lane_pass && (lane_pass || P.nx == 3 * P.nu)
+        && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0
         && (!(P.row_f_inst || P.lb_inst || P.ub_inst) || (P.axis_const && (P.lb_inst == nullptr) == (P.ub_inst == nullptr)));
     for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost));
     if (axis_pass && P.stage_refs) { // (reference trajectories: copra_hip.hip, axis_solver_wanted)
@@ -377,7 +379,11 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     (small_q ? COPRA_EMU_AXIS_B(NU, 20, 2, false)                                                                                \
              : P.N == 20 && NU == 3 && !P.stage_refs ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                  \
              : P.N <= 20 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, false) : COPRA_EMU_AXIS_B(NU, 31, kAxisQmax, false))
-                if (P.nu == 3) COPRA_EMU_AXIS(3);
+                if (P.nx == 3 * P.nu) { // chains of three states per control (copra_hip_axis3.hip)
+                    const bool ct = P.axis_const && P.axis_rpa <= 1;
+                    if (P.nu == 3) (small_q ? lmpc_axis_body<3, 3, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 3, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 3, 20, kAxisQmax, false, false, 2>(P, g));
+                    else (small_q ? lmpc_axis_body<3, 2, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 2, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 2, 20, kAxisQmax, false, false, 2>(P, g));
+                } else if (P.nu == 3) COPRA_EMU_AXIS(3);
                 else COPRA_EMU_AXIS(2);
 #undef COPRA_EMU_AXIS
             }, abytes, g, groups);
@@ -402,7 +408,10 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                 int r = emu::run_wave([&]() {
 #define COPRA_EMU_AXIS_L(NU, NMAX)                                                                                       \
     (Pl.axis_const ? lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, true, 2, true>(Pl, g) : lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, false, 2, true>(Pl, g))
-                    if (P.nu == 3) COPRA_EMU_AXIS_L(3, 20);
+                    if (P.nx == 3 * P.nu) {
+                        if (P.nu == 3) lmpc_axis_body<3, 3, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                        else lmpc_axis_body<3, 2, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                    } else if (P.nu == 3) COPRA_EMU_AXIS_L(3, 20);
                     else if (P.N <= 20) COPRA_EMU_AXIS_L(2, 20);
                     else COPRA_EMU_AXIS_L(2, 31);
 #undef COPRA_EMU_AXIS_L

@@ -1676,6 +1676,19 @@ def test_axis_solver_with_per_instance_goals(emu, oracle):
             assert _rel(re["control"][k], ro["control"]) <= 1e-8 and _rel(re["trajectory"][k], ro["trajectory"]) <= 1e-8, (N, k)
 
 
+@pytest.mark.parametrize("nu,N,amax", [(3, 20, None), (3, 14, 2.0), (2, 20, None), (2, 9, 1.5)])
+def test_axis_solver_on_chains_of_three_states(emu, oracle, nu, N, amax):
+    """the jerk-controlled CoM model (position, velocity, acceleration per axis; the jerk as control: nx = 3 nu) on the (instance, axis)-per-lane
+    solver's builds for chains of three states: tables in registers (one row per axis and step) and read from LDS (a bound on the acceleration
+    as well: two rows).  Statuses, both counters, U and X against the oracle; the instances end in the solver"""
+    from copra_amd import workloads
+    b = 50
+    wl = workloads.jerk_preview(b, nu=nu, N=N, seed=3 + N, v_max=0.3, j_max=6.0, a_max=amax)
+    re, ro = _axis_case(emu, oracle, wl, what=(nu, N, amax))
+    assert re["lane_pass_finished"] >= b - 3
+    assert ro["iter"][:, 0].max() >= 3 and (ro["iter"][:, 0] >= 2).mean() >= 0.2  # (the constraints matter)
+
+
 def test_axis_solver_with_per_instance_limits(emu, oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) in front of the
     (instance, axis)-per-lane solver: the builds that keep bounds and right-hand sides in registers take the lane's own values where they are the

@@ -2860,6 +2860,42 @@ def test_one_model_for_the_batch_on_the_axis_solver(oracle):
             assert r_pi["status"][k] == ro["status"] == 0 and _rel(r_pi["control"][k], ro["control"]) <= RTOL
 
 
+@pytest.mark.parametrize("nu,N,amax", [(3, 20, None), (3, 16, 2.0), (2, 20, None)])
+def test_axis_solver_on_the_jerk_controlled_com_model(oracle, nu, N, amax):
+    """chains of THREE states per control (position, velocity, acceleration per axis, the jerk as control: nx = 3 nu = 9 or 6 -- shapes outside the
+    double-integrator families) on the (instance, axis)-per-lane solver: whole batch against the general one-wave kernels (option
+    no_axis_solver: statuses, counters up to ties, 1e-7), a sample against the oracle (1e-6); with a goal per instance as well"""
+    from copra_amd import BatchLMPC, workloads
+    b = 20000
+    wl = workloads.jerk_preview(b, nu=nu, N=N, seed=77, v_max=0.3, j_max=6.0, a_max=amax)
+    goals = np.tile(wl["costs"][0]["p"], (b, 1))
+    goals[:, :nu] += 0.2 * np.random.default_rng(1).standard_normal((b, nu))
+    out = {}
+    for mode in ("axis", "general"):
+        eng = BatchLMPC(3 * nu, nu, N, b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1) if mode == "general" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        one = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.set_cost_reference(0, goals)
+        eng.solve()
+        out[mode] = (one, (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info()))
+        eng.close()
+    for which in (0, 1):
+        r1, ran, info = out["axis"][which]
+        r0 = out["general"][which][0]
+        assert ran and not out["general"][which][1] and info[1] >= int(0.97 * b)  # (what it lists -- degenerate picks, mostly -- the tiers solve)
+        ok = r0["status"] == 0
+        assert ok.sum() >= b - 8 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.999  # (ties)
+        # (two formulations of the same iteration on systems with T^3 / 6 in B: 1.2e-8 measured between them)
+        assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-7 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-7
+        assert r0["iter"][:, 0].mean() >= 1.2  # (the constraints matter)
+        for k in range(0, b, 2857):
+            cs = wl["costs"] if which == 0 else [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]]
+            ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, cs, wl["cstrs"])
+            assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+            assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_axis_solver_with_per_instance_limits(oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) through the
     (instance, axis)-per-lane solver: the lane's own values where they are the same along the horizon, the tier for the instances whose limits
