@@ -54,3 +54,15 @@ try:
         print("%-26s n=%3d  lanes/instance %3d  %8.2f M solves/s" % ("planar point mass N=%d" % N, 2 * N, eng.lanes_per_instance(), rate(eng, b)))
 except Exception as e:  # (the sweep itself must not be lost)
     print("planar cases skipped:", repr(e))
+# chains of three states per control (the jerk-controlled CoM model): shapes outside the double-integrator families -- the library's own builds
+# (round 6: the (instance, axis)-per-lane solver) and, with --specialise, the run-time-compiled general kernels of the same shape
+for nu, N in ((3, 20), (3, 12), (2, 20), (2, 10)):
+    b = 65536
+    wl = workloads.jerk_preview(b, nu=nu, N=N)
+    for opts, what in ((None, ""), (dict(no_axis_solver=1), " without the axis solver")):
+        eng = BatchLMPC(3 * nu, nu, N, b, wl["costs"], wl["cstrs"], options=opts)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        if JIT and opts:
+            eng.specialise()
+        print("%-46s n=%3d  lanes/instance %3d  %8.2f M solves/s" % ("jerk model (%d, %d) N=%d%s" % (3 * nu, nu, N, what), nu * N, eng.lanes_per_instance(), rate(eng, b)))
+        eng.close()
