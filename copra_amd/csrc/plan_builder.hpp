@@ -885,7 +885,7 @@ inline copra_status_t build_plan(HostPlan& hp, const copra_dims_t& dims, int n_c
                         }
                 return true;
             };
-            if (R % S == 0 && R / S <= 6) {
+            if (R % S == 0 && R / S <= 9) { // (nine: the jerk-controlled CoM model in three dimensions; the Riccati-factor tier and the pass take six, plan checks below)
                 const int r = R / S;
                 bool ok = true;
                 for (int sblk = 0; sblk < S && ok; ++sblk)

@@ -149,6 +149,76 @@ def make(seed, batch=48, max_vars=64, shape=None):
     return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms, initial_state=ist)
 
 
+def make_chain3(seed, batch):
+    """Random controllers on chains of THREE states per control (position, velocity, acceleration per axis, the jerk as control) in two and three
+    dimensions -- the shapes of the (instance, axis)-per-lane solver's late-round-6 builds: random horizon up to 20, per-instance sampling
+    period, a goal or a reference trajectory, optional target cost, random mixes of velocity / acceleration bounds, jerk bounds, rows and
+    mixed rows (everything per axis: the solver takes the controller; a dense state row now and then: it does not)."""
+    rng = np.random.default_rng([seed, 993])
+    dim = int(rng.choice([2, 3], p=[0.4, 0.6]))
+    nx, nu = 3 * dim, dim
+    N = int(rng.integers(4, 21))
+    forms = []
+    T = rng.uniform(0.08, 0.15, batch)
+    I = np.eye(dim)
+    A = np.zeros((batch, nx, nx))
+    B = np.zeros((batch, nx, nu))
+    for a in range(3):
+        A[:, a * dim:(a + 1) * dim, a * dim:(a + 1) * dim] = I
+    A[:, :dim, dim:2 * dim] = T[:, None, None] * I
+    A[:, :dim, 2 * dim:] = (0.5 * T * T)[:, None, None] * I
+    A[:, dim:2 * dim, 2 * dim:] = T[:, None, None] * I
+    B[:, :dim, :] = (T ** 3 / 6.0)[:, None, None] * I
+    B[:, dim:2 * dim, :] = (0.5 * T * T)[:, None, None] * I
+    B[:, 2 * dim:, :] = T[:, None, None] * I
+    d = np.zeros((batch, nx)) if rng.random() < 0.6 else np.tile(0.005 * rng.standard_normal(nx), (batch, 1))
+    v_max = float(rng.uniform(0.25, 0.6))
+    a_max = float(rng.uniform(1.0, 3.0))
+    j_max = float(rng.uniform(5.0, 20.0))
+    x0 = np.zeros((batch, nx))
+    x0[:, :dim] = rng.standard_normal((batch, dim)) * 0.3
+    x0[:, dim:2 * dim] = rng.uniform(-0.7 * v_max, 0.7 * v_max, (batch, dim))
+    x0[:, 2 * dim:] = rng.uniform(-0.5 * a_max, 0.5 * a_max, (batch, dim))
+    goal = np.concatenate([rng.uniform(-1.0, 1.0, dim), np.zeros(2 * dim)])
+    wx = np.concatenate([rng.uniform(5.0, 20.0, dim), rng.uniform(0.5, 2.0, dim), rng.uniform(0.05, 0.2, dim)])
+    costs = []
+    if rng.random() < 0.35:
+        pk = goal[None, :] * np.linspace(0.5, 1.0, N + 1)[:, None] + 0.01 * rng.standard_normal((N + 1, nx))
+        costs.append(dict(kind="trajectory", M=_blockdiag(np.eye(nx), N + 1), p=pk.reshape(-1), weights=np.tile(wx, N + 1)))
+        forms.append("xref")
+    else:
+        costs.append(dict(kind="trajectory", M=np.eye(nx), p=goal, weights=wx))
+        forms.append("xcost")
+    costs.append(dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[float(rng.uniform(1e-4, 1e-2))] * nu))
+    if rng.random() < 0.3:
+        costs.append(dict(kind="target", M=np.eye(nx), p=goal, weights=5.0 * wx))
+        forms.append("target")
+    cstrs = []
+    inf = np.inf
+    two_rows = rng.random() < 0.35
+    if rng.random() < 0.85:
+        cstrs.append(dict(kind="trajectory_bound", lower=[-inf] * nx, upper=[inf] * dim + [v_max] * dim + ([a_max] * dim if two_rows else [inf] * dim)))
+        forms.append("v,a bound" if two_rows else "vbound")
+    if rng.random() < 0.85:
+        cstrs.append(dict(kind="control_bound", lower=[-j_max] * nu, upper=[j_max] * nu))
+        forms.append("jbound")
+    vsel = np.hstack([np.zeros((dim, dim)), np.eye(dim), np.zeros((dim, dim))])
+    if not two_rows and rng.random() < 0.3:
+        cstrs.append(dict(kind="trajectory", E=-vsel, f=[v_max] * dim, ineq=True))  # the lower velocity limit as rows
+        forms.append("-v rows")
+    if not two_rows and rng.random() < 0.2:
+        cstrs.append(dict(kind="mixed", E=vsel, G=0.01 * np.eye(dim), f=[v_max * 1.1] * dim, ineq=True))
+        forms.append("v+Tj")
+    if rng.random() < 0.1:
+        E = rng.standard_normal((1, nx))
+        cstrs.append(dict(kind="trajectory", E=E, f=[float(np.abs(E @ x0.T).max() + rng.uniform(0.5, 1.5))], ineq=True))
+        forms.append("dense-x")
+    if not cstrs:
+        cstrs.append(dict(kind="control_bound", lower=[-j_max] * nu, upper=[j_max] * nu))
+        forms.append("jbound")
+    return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms)
+
+
 def make_integrator(seed, batch):
     """Random controllers on the shapes whose Riccati-factor tier and one-instance-per-lane pass the library ships for every horizon
     (double integrators in one, two and three dimensions, per-instance sampling period): random horizon, random per-step costs (incl.

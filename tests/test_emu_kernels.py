@@ -941,7 +941,7 @@ def test_one_instance_per_lane_pass(emu, oracle, monkeypatch, mode, batch, N, vm
         assert 0 < at_minimiser < batch  # (both kinds of instance in the batch)
 
 
-def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle):
+def test_one_instance_per_lane_pass_own_bounds_and_skips(emu, oracle, no_axis):
     """per-instance control bounds, cost references and right-hand sides all go through the pass (every lane reads its own bounds and
     its own row of right-hand sides, rebuilds its own affine cost terms)"""
     from copra_amd import workloads
@@ -1687,6 +1687,37 @@ def test_axis_solver_on_chains_of_three_states(emu, oracle, nu, N, amax):
     re, ro = _axis_case(emu, oracle, wl, what=(nu, N, amax))
     assert re["lane_pass_finished"] >= b - 3
     assert ro["iter"][:, 0].max() >= 3 and (ro["iter"][:, 0] >= 2).mean() >= 0.2  # (the constraints matter)
+
+
+@pytest.mark.parametrize("axis", [True, False])
+def test_reference_trajectory_on_chains_of_three_states(emu, oracle, monkeypatch, axis):
+    """tracking on the jerk-controlled model: a full-size TrajectoryCost with NINE rows per step, classified as a per-step cost with the step's
+    reference (plan_builder.hpp) -- on the (instance, axis)-per-lane solver, and (option no_axis_solver) on the general one-wave kernel, which
+    evaluates the step's reference in its condense code; controller-wide and one per instance"""
+    from copra_amd import workloads
+    if not axis:
+        monkeypatch.setitem(OPTIONS, "no_axis_solver", 1)
+    rng = np.random.default_rng(41)
+    b, N, nu = 24, 12, 3
+    wl = workloads.jerk_preview(b, nu=nu, N=N, seed=8, v_max=0.35, j_max=8.0)
+    nx = 3 * nu
+    ts = np.linspace(0.0, 1.0, N + 1)
+    xref = np.zeros((N + 1, nx))
+    xref[:, :nu] = workloads.COM_X_INIT[:nu][None, :] + ts[:, None] * (workloads.COM_X_GOAL[:nu] - workloads.COM_X_INIT[:nu])[None, :]
+    xref[:, nu:2 * nu] = 0.05
+    track = dict(kind="trajectory", M=np.kron(np.eye(N + 1), np.eye(nx)), p=xref.reshape(-1), weights=np.tile(wl["costs"][0]["weights"], N + 1))
+    args = (wl["A"], wl["B"], wl["d"], wl["x0"], N, [track, wl["costs"][1]], wl["cstrs"])
+    ro = oracle.lmpc_solve_batch(*args, nthreads=4)
+    ok = ro["status"] == 0
+    re = emu.lmpc_solve(*args)
+    assert ok.all() and (re["status"] == ro["status"]).all() and (re["iter"] == ro["iter"]).all()
+    assert _rel(re["control"], ro["control"]) <= 1e-7 and _rel(re["trajectory"], ro["trajectory"]) <= 1e-7
+    assert (re["lane_pass_finished"] >= b - 2) == axis
+    own = np.tile(xref.reshape(-1), (b, 1)) + 0.03 * rng.standard_normal((b, xref.size))
+    re2 = emu.lmpc_solve(*args, cost_refs={0: own})
+    for k in range(0, b, 2):
+        rk = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, [dict(track, p=own[k]), wl["costs"][1]], wl["cstrs"])
+        assert re2["status"][k] == rk["status"] == 0 and tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-7
 
 
 def test_axis_solver_with_per_instance_limits(emu, oracle):

@@ -3003,6 +3003,37 @@ def test_axis_solver_on_random_integrator_controllers(oracle):
     assert nran >= 5 and ndiff * 500 <= ninst
 
 
+def test_axis_solver_on_random_chains_of_three_states(oracle):
+    """tests/random_controllers.py::make_chain3 -- random controllers on the jerk-controlled model in two and three dimensions, whatever mix of
+    costs and constraints a seed draws (goal / reference trajectory / target cost; velocity, acceleration and jerk bounds; rows; mixed rows;
+    now and then a dense state row, which keeps the general kernels) -- at a batch of 2048: statuses against the oracle on a sample, and
+    where the (instance, axis)-per-lane solver took the controller also U, X and the iteration counters (up to ties)"""
+    import random_controllers as RC
+    from copra_amd import BatchLMPC
+    nran = ndiff = ninst = 0
+    for seed in range(500, 536):
+        c = RC.make_chain3(seed, 2048)
+        eng = BatchLMPC(c["nx"], c["nu"], c["N"], 2048, c["costs"], c["cstrs"])
+        eng.set_system(c["A"], c["B"], c["d"], c["x0"])
+        eng.solve()
+        res = eng.results()
+        axis = bool(eng.lane_pass_info()[0] and eng.axis_solver_ran())
+        eng.close()
+        nran += 1 if axis else 0
+        pick = np.arange(0, 2048, 32)
+        ref = oracle.lmpc_solve_batch(c["A"][pick], c["B"][pick], c["d"][pick], c["x0"][pick], c["N"], c["costs"], c["cstrs"], nthreads=8)
+        ok = ref["status"] == 0
+        what = "seed %d (%d, %d, %d) %s axis solver %s" % (seed, c["nx"], c["nu"], c["N"], c["forms"], axis)
+        assert (res["status"][pick] == ref["status"]).all(), what
+        if not axis:
+            continue
+        ndiff += int((res["iter"][pick][ok] != ref["iter"][ok]).any(axis=1).sum())
+        ninst += int(ok.sum())
+        assert _rel(res["control"][pick][ok], ref["control"][ok]) <= RTOL and _rel(res["trajectory"][pick][ok], ref["trajectory"][ok]) <= RTOL, what
+    print("   random chains of three states: %d of 36 on the (instance, axis)-per-lane solver; iteration counters differ on %d of %d solved instances" % (nran, ndiff, ninst))
+    assert nran >= 20 and ndiff * 200 <= ninst
+
+
 def test_first_tier_grid_follows_the_lists_and_the_second_launch_catches_what_outgrows_it(oracle):
     """behind the (instance, axis)-per-lane solver and its second chance the first tier is launched for four times the longest of the last
     solves' lists + 256 entries (65 536 workgroups that find no entry cost a sixth of the headline's step); a list that outgrows that grid --
