@@ -26,6 +26,8 @@
 // wave leaves the loop when its last lane has).  Per lane in LDS: one sparse array over its constraints (N controls + (N + 1) rpa
 // rows) -- coefficients of the combined normal on the way into a recursion, responses n_i' y on the way out.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include "lmpc_fused.hpp"
@@ -33,6 +35,9 @@
 namespace copra_hip {
 
 #ifndef COPRA_AXIS_ITER_CAP
+#ifndef COPRA_AXIS_ZN_REL
+#define COPRA_AXIS_ZN_REL 1e-13 // z'n+ below this share of n+' Q^-1 n+: the direction counts as zero (checked against |z|^2 behind the step)
+#endif
 #define COPRA_AXIS_ITER_CAP 64 // picks + drops of one lane; beyond: the tier
 #endif
 
@@ -133,6 +138,12 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     const double* const Tg = P.params + P.axis_tab + c * TA; // ... and in memory: what is read once
     double A[NXA][NXA], B[NXA], d[NXA], x0[NXA]; // A[i][j]: entry (i, j) of the axis' block
     bool giveup = false; // this lane cannot finish its instance: the first tier solves it from scratch
+#if !defined(__HIP_DEVICE_COMPILE__)
+    int why = 0; // (emulator, COPRA_EMU_AXIS_REPORT: which test sent it there)
+#define AX_WHY(bit, cond) do { if (cond) why |= (bit); } while (0)
+#else
+#define AX_WHY(bit, cond) do { } while (0)
+#endif
     {
         // The columns of A and B that belong to this axis, straight from memory (the three lanes of an instance read neighbouring columns of
         // the same 288 + 144 bytes: one trip, every load requested before the first is used): the axis' own block, and the entries that would
@@ -763,6 +774,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     };
     // the scan's result becomes this lane's pick (qpgen2: step 1)
     auto take_pick = [&]() __attribute__((always_inline)) {
+        AX_WHY(1, it_main >= COPRA_AXIS_ITER_CAP);
         giveup = giveup | (it_main >= COPRA_AXIS_ITER_CAP);
         it_main += 1;
         have = bfound & !giveup;
@@ -867,6 +879,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                         if (j < i) {
                             L[i][j] = sacc * di[j];
                         } else {
+                            AX_WHY(2, have & !(sacc > 0.0));
                             giveup = giveup | (have & !(sacc > 0.0));
                             di[i] = fast_rsqrt(sacc > 0.0 ? sacc : 1.0);
                             L[i][i] = sacc * di[i];
@@ -907,8 +920,11 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         }
         const double t1 = lb_ / rb_;
         // t2 = -s / z'n; a direction that is zero (n+ in the span of the active normals: |z|^2 <= vsmall is checked behind the step) or not a
-        // descent direction to rounding: the tier's business
-        const bool zn_ok = (zn > 0.0) & (zn > 1e-13 * nqn);
+        // descent direction to rounding: the tier's business.  (z'n+ = n+' Q^-1 n+ - g'r loses its digits where a pick lies next to active rows on
+        // a chain whose control barely moves it -- 1.4 % of a TIGHT workload's instances on the jerk-controlled model go to the tier for it.  The
+        // sum-of-squares form (n+ - N r)' Q^-1 (n+ - N r), which the second backward recursion returns for free, was tried: nothing is listed
+        // any more, but 3 % of those instances take one to three picks more than qpgen2 -- it leaves out r'(g - S r), which is not small there.)
+        const bool zn_ok = (zn > 0.0) & (zn > COPRA_AXIS_ZN_REL * nqn);
         // (z'n+ zero to rounding: n+ lies in the span of the active normals -- a velocity row behind the bounds of every control in front of it.
         //  qpgen2 then takes no step in primal space but a DUAL one -- the multipliers move by t1, the blocking constraint leaves, the pick stays --
         //  if |z|^2 <= vsmall, which the recursion below tells)
@@ -932,6 +948,9 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         RC[loc_pos(ploc)] = 0.0;
         // qpgen2's test: |z|^2 <= vsmall -- no step in primal space.  Where z'n+ said so too and a multiplier blocks: the dual step.  Without one:
         // "no solution" -- the tier reports it.  Where the two tests disagree: the tier decides.
+        AX_WHY(4, have & !nostep & !(zz > vsmall));
+        AX_WHY(8, nostep & !(zz <= vsmall));
+        AX_WHY(16, nostep & (zz <= vsmall) & (l1 < 0));
         giveup = giveup | (have & !nostep & !(zz > vsmall)) | (nostep & (!(zz <= vsmall) | (l1 < 0)));
         have = have & !giveup;
         if (have) {
@@ -941,6 +960,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             if (full) {
                 // the pick joins the active set: slot q, S grows by the row [g' | n+' Q^-1 n+]
                 if (q >= QMAX) {
+                    AX_WHY(64, true);
                     giveup = true;
                     have = false;
                 } else {
@@ -958,6 +978,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                         double dd = nqn;
 #pragma unroll
                         for (int b = 0; b < QMAX; ++b) dd -= (b < q) ? wbig[b] * wbig[b] : 0.0;
+                        AX_WHY(32, !(dd > 0.0));
                         giveup = giveup | !(dd > 0.0);
 #pragma unroll
                         for (int b = 0; b < QMAX; ++b)
@@ -1042,6 +1063,11 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     stamp[4] = P.prof ? cycle_counter() : 0;
 
     // ---- 4. the instance: qpgen2's counters are the sums over its axes; one lane of it reports ----
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (giveup && valid && std::getenv("COPRA_EMU_AXIS_REPORT"))
+        std::fprintf(stderr, "  emu axis solver: instance %d axis %d gives up: reasons %d (1 cap | 2 S not positive | 4 z'n+ > 0 but |z|^2 <= vsmall | 8 z'n+ ~ 0 but |z|^2 > vsmall | 16 dual step without a blocking multiplier | 32 factor row | 64 no room) after %d picks, %d drops, q %d\n",
+            inst, c, why, it_main, it_drop, q);
+#endif
     int fail_i = (giveup ? 1 : 0) | (bad ? 2 : 0), adds_i = it_main - 1, drops_i = it_drop, viol_i = nviol0;
 #pragma unroll
     for (int a = 1; a < NU; ++a) {

@@ -418,6 +418,15 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                 }, lbytes, g, 1);
                 if (r != 0) return -100;
             }
+            if (std::getenv("COPRA_EMU_AXIS_REPORT")) { // (tools: who is listed, and why)
+                int bad1 = 0, bad2 = 0;
+                for (int k = 0; k < lane_count; ++k) bad1 += lane_list[(size_t)k] < 0 ? 1 : 0;
+                for (int k = 0; k < count2; ++k) bad2 += list2[(size_t)k] < 0 ? 1 : 0;
+                std::fprintf(stderr, "emu axis solver: %d of %d instances listed by the first launch (%d with a failed factorisation), %d by the second chance (%d failed):",
+                    lane_count, dims->batch, bad1, count2, bad2);
+                for (int k = 0; k < count2 && k < 24; ++k) std::fprintf(stderr, " %d%s", list2[(size_t)k] & 0x7fffffff, list2[(size_t)k] < 0 ? "!" : "");
+                std::fprintf(stderr, "\n");
+            }
             lane_list = list2;
             lane_count = count2;
         }
