@@ -339,6 +339,13 @@ FusedPlan device_plan(const copra_batch* h)
     P.ovf_list = h->d_ovf_list;
     P.from_list = 0;
     P.lane_from_list = 0;
+    if (h->axis_order == 1) { // (the systems' states are in axis-major order: that order's tables -- plan_builder.hpp)
+        P.axis_order = 1;
+        P.axis_tab = h->hp.axis1_tab;
+        P.axis_cref = h->hp.axis1_cref;
+        P.axis_rpa = h->hp.axis1_rpa;
+        P.axis_const = h->hp.axis1_const;
+    }
     P.lane_cap = 0;
     P.lane_rest = -1;
     P.seen_out = nullptr;
@@ -1091,6 +1098,26 @@ copra_status_t copra_plan_check(const copra_dims_t* dims, int n_costs, const cop
     return rc;
 }
 
+// The order of the states in this controller's systems, for the (instance, axis)-per-lane solver (FusedPlan::axis_order): from the zero pattern of
+// the FIRST system the controller is given (one instance's A and B: 432 bytes from the device where the caller's arrays live there -- once per
+// controller).  Systems in neither order, or that change their order later, are what the solver's per-instance check and the adaptation catch.
+extern "C++" void see_axis_order(copra_batch* h, const double* A, const double* B, bool on_device)
+{
+    const FusedPlan& P = h->hp.plan;
+    if (h->axis_order_seen || P.batch <= 0 || (P.axis_tab < 0 && h->hp.axis1_tab < 0)) return;
+    h->axis_order_seen = true;
+    const size_t nA = (size_t)P.nx * P.nx, nB = (size_t)P.nx * P.nu;
+    std::vector<double> a(nA), b(nB);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+    if (hipMemcpy(a.data(), A, nA * sizeof(double), kind) != hipSuccess || hipMemcpy(b.data(), B, nB * sizeof(double), kind) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    const int ord = axis_order_of(a.data(), b.data(), P.nx, P.nu);
+    if (ord == 1 && h->hp.axis1_tab >= 0) h->axis_order = 1;
+    if (h->hp.opt.debug) fprintf(stderr, "[copra] state order of the first system: %d (0: state i on axis i %% nu, 1: axis-major, -1: neither)\n", ord);
+}
+
 // instance 0 of an array of `batch` blocks of `per` doubles, repeated into every other block
 __global__ void copra_repeat_first_block_kernel(double* __restrict__ a, int per, long long total)
 {
@@ -1106,7 +1133,8 @@ __global__ void copra_repeat_first_block_kernel(double* __restrict__ a, int per,
 static bool shared_model_runs_as_batch(const copra_batch* h)
 {
     const copra_options_t& opt = h->hp.opt;
-    const FusedPlan& P = h->hp.plan;
+    FusedPlan P = h->hp.plan;
+    if (h->axis_order == 1) P.axis_order = 1, P.axis_tab = h->hp.axis1_tab, P.axis_cref = h->hp.axis1_cref, P.axis_rpa = h->hp.axis1_rpa, P.axis_const = h->hp.axis1_const;
     if (opt.no_axis_solver || opt.no_lane_pass || h->ad.axis_off || P.axis_tab < 0 || P.axis_cref < 0 || P.batch <= 0) return false;
     if (opt.lane_min_batch > 0 && P.batch < opt.lane_min_batch) return false;
     if (h->packed || h->hp.large || P.initial_state || h->jit_fused) return false;
@@ -1132,6 +1160,7 @@ copra_status_t copra_batch_set_shared_system(copra_batch_t* h, const double* A, 
     HIP_TRY(hipMemcpy(h->shB.data(), B, nB * sizeof(double), kind));
     HIP_TRY(hipMemcpy(h->shd.data(), d, nd * sizeof(double), kind));
     h->shared_as_batch = false;
+    see_axis_order(h, h->shA.data(), h->shB.data(), false);
     if (!h->shared && shared_model_runs_as_batch(h)) { // (a handle that is in shared-model mode stays there: its layouts have moved)
         const size_t b = (size_t)P.batch;
         if (!h->own_A) {

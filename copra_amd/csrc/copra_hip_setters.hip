@@ -173,6 +173,7 @@ copra_status_t copra_batch_set_system(copra_batch_t* h, const double* A, const d
     const size_t b = (size_t)P.batch;
     h->shared = false; // per-instance systems again (leaves the shared-model fast path)
     h->shared_as_batch = false;
+    see_axis_order(h, A, B, on_device != 0);
     if (on_device) {
         h->A = A;
         h->B = B;

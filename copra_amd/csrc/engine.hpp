@@ -53,6 +53,7 @@ hipError_t upload(T** dst, const std::vector<T>& src)
 // persistent grids of the workgroup-per-instance kernels (copra_hip.hip)
 int large_per_cu(const void* kernel, int threads, size_t lds_bytes);
 int large_grid(const copra_options_t& opt, const void* kernel, int batch, int threads, size_t lds_bytes);
+void see_axis_order(copra_batch* h, const double* A, const double* B, bool on_device);
 bool prefer_w4(const copra_options_t& opt, const void* full, const void* w4, int threads, size_t lds_bytes);
 
 constexpr size_t kSmallSlab = 1u << 20; // result slabs up to this size are fetched with one copy through pinned memory
@@ -102,6 +103,8 @@ struct copra_batch {
     int *d_row_prev = nullptr, *d_warm = nullptr; // warm start of the shared-model path (copra_batch_set_warm_start)
     // system (owned copies, or borrowed device pointers)
     double *own_A = nullptr, *own_B = nullptr, *own_d = nullptr, *own_x0 = nullptr;
+    int axis_order = 0; // the state order of this controller's systems as the (instance, axis)-per-lane solver sees it (FusedPlan::axis_order) ...
+    bool axis_order_seen = false; // ... looked at when the first systems were set (see_axis_order, copra_hip.hip)
     bool shared_as_batch = false; // copra_batch_set_shared_system on a controller the (instance, axis)-per-lane solver takes: the model written out per instance (copra_hip.hip)
     const double *A = nullptr, *B = nullptr, *d = nullptr, *x0 = nullptr;
     // results

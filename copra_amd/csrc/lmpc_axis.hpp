@@ -95,6 +95,10 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     axis_tab_offsets(NXA, oh_, oHN_, ohN_, oRows_);
     const int oh = oh_, oHN = oHN_, ohN = ohN_, oRows = oRows_;
     const int TA = axis_tab_doubles(NXA, NH, rpa);
+    // where the states of this lane's axis sit in the system's state vector (FusedPlan::axis_order): state i of axis c at c + NU i (x = (p, v), what
+    // the benchmark's CoM model uses) or at c NXA + i (x = (p_x, v_x, p_y, v_y, ..)) -- z0 + zs i either way
+    const bool zord = P.axis_order != 0;
+    const int zs = zord ? 1 : NU, z0 = zord ? c * NXA : c;
     bool own_refs = false;
     for (int t = 0; t < P.ncost; ++t) own_refs = own_refs || P.cost_p[t] != nullptr;
     own_refs = own_refs && P.axis_cref >= 0;
@@ -161,7 +165,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 for (int a = 0; a < NU; ++a) {
                     int ax = c + a; // a == 0: this axis
                     ax = ax >= NU ? ax - NU : ax;
-                    vA[jj][ii][a] = sA[(ax + NU * ii) + NX * (c + NU * jj)];
+                    vA[jj][ii][a] = sA[((zord ? ax * NXA : ax) + zs * ii) + NX * (z0 + zs * jj)];
                 }
 #pragma unroll
         for (int ii = 0; ii < NXA; ++ii) {
@@ -169,10 +173,10 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             for (int a = 0; a < NU; ++a) {
                 int ax = c + a;
                 ax = ax >= NU ? ax - NU : ax;
-                vB[ii][a] = sB[(ax + NU * ii) + NX * c];
+                vB[ii][a] = sB[((zord ? ax * NXA : ax) + zs * ii) + NX * c];
             }
-            d[ii] = sd[c + NU * ii];
-            x0[ii] = sx[c + NU * ii];
+            d[ii] = sd[z0 + zs * ii];
+            x0[ii] = sx[z0 + zs * ii];
         }
         double stray = 0.0;
 #pragma unroll
@@ -1135,7 +1139,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     //         instance on a spare lane has its other axes elsewhere: that lane stores for itself. ----
     if constexpr (LIST) { // (the wave's instances are scattered over the batch: every lane stores for itself)
         if (valid) {
-            double* const xo = P.trajectory + (size_t)inst * P.X + c;
+            double* const xo = P.trajectory + (size_t)inst * P.X + z0;
             double* const uo = P.control + (size_t)inst * P.n + c;
             double x[NXA];
 #pragma unroll
@@ -1145,7 +1149,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 if (EXACT || k < NH) {
                     const double u = U[k];
 #pragma unroll
-                    for (int i = 0; i < NXA; ++i) xo[k * NX + NU * i] = x[i];
+                    for (int i = 0; i < NXA; ++i) xo[k * NX + zs * i] = x[i];
                     uo[k * NU] = u;
                     double xn[NXA];
 #pragma unroll
@@ -1160,7 +1164,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NXA; ++i) xo[NH * NX + NU * i] = x[i];
+            for (int i = 0; i < NXA; ++i) xo[NH * NX + zs * i] = x[i];
         }
     } else {
         const int nr = nreg - group * IPW < IPW ? (nreg - group * IPW > 0 ? nreg - group * IPW : 0) : IPW; // instances on this wave's regular lanes
@@ -1171,9 +1175,9 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         wave_sync(); // (every lane is through with its arrays)
         {
             // (lanes without an instance write like a spare lane: nobody reads it)
-            double* const xo = lane_on ? sx_ + il * XI + c : so_;
+            double* const xo = lane_on ? sx_ + il * XI + z0 : so_;
             double* const uo = lane_on ? su_ + il * UI + c : so_ + (NH + 1) * NXA;
-            const int sxk = lane_on ? NX : NXA, sxi = lane_on ? NU : 1, suk = lane_on ? NU : 1; // strides: step | state of the axis; step
+            const int sxk = lane_on ? NX : NXA, sxi = lane_on ? zs : 1, suk = lane_on ? NU : 1; // strides: step | state of the axis; step
             double x[NXA];
 #pragma unroll
             for (int i = 0; i < NXA; ++i) x[i] = x0[i];
@@ -1224,7 +1228,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             const int oi = bcast_i32(inst, kWave - 1), oc = bcast_i32(c, kWave - 1);
             if (lane < (NH + 1) * NXA) {
                 const int k = lane / NXA, i = lane - k * NXA;
-                P.trajectory[(size_t)oi * XI + k * NX + oc + NU * i] = so_[lane];
+                P.trajectory[(size_t)oi * XI + k * NX + (zord ? oc * NXA : oc) + zs * i] = so_[lane];
             }
             if (lane < NH) P.control[(size_t)oi * UI + lane * NU + oc] = so_[(NH + 1) * NXA + lane];
         }

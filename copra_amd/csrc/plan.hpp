@@ -361,6 +361,8 @@ struct FusedPlan {
     const int* axis_list_count; // ... its length, ...
     int* axis_count2; // ... and (first launch) the counter of the list the second chance appends to: zeroed on the way
     int axis_const; // 1: its tables are the same at every step (pure state rows present at all N + 1 steps with one E and f and indices affine in the step, one pair of bounds per control): the builds that keep them in registers
+    int axis_order; // which order its systems' states are in: 0: state i on axis i % nu (x = (p, v): the benchmark's CoM model), 1: state i on axis i / nxa
+                    //   (x = (p_x, v_x, p_y, v_y, ..)) -- seen when the systems are set (plan_builder.hpp: axis_order_of); the tables below are that order's
     int axis_cref; // ... the coefficients of the cost references in its affine terms, per axis: the number of cost rows that look at the axis, then
                    //     kAxisMaxRef entries [cost | row | coefficients in h (nxa + 1) | in hN (nxa)] (-1: none, or an axis with more such rows --
                    //     controllers with per-instance references or reference trajectories keep the one-instance-per-lane pass then)

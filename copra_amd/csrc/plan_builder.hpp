@@ -69,7 +69,30 @@ struct HostPlan {
     // + i for its steps s and lines i (steps == 1 for a full-size entry); row0 < 0: bound constraint, no rows
     std::vector<int> cstr_row0, cstr_per_step, cstr_steps;
     std::vector<int> cost_slot; // position of the user's cost k among the kernel-evaluated cost terms, -1: a dense cost
+    // the (instance, axis)-per-lane solver's tables for AXIS-MAJOR state order (state i on axis i / nxa: x = (p_x, v_x, p_y, v_y, ..)); the plan's
+    // own fields hold the set for component-major order (state i on axis i % nu: x = (p, v)), what FusedPlan::axis_order = 0 means
+    int axis1_tab = -1, axis1_cref = -1, axis1_rpa = 0, axis1_const = 0;
 };
+
+// Which order are the states of a system of decoupled chains in?  0: state i on axis i % nu (the benchmark's CoM model: x = (p, v)), 1: state i on
+// axis i / (nx / nu) (x = (p_x, v_x, p_y, v_y, ..)), -1: neither -- from the zero pattern of ONE system (column-major A: nx x nx, B: nx x nu).
+inline int axis_order_of(const double* A, const double* B, int nx, int nu)
+{
+    if (nu < 1 || nx % nu != 0) return -1;
+    const int nxa = nx / nu;
+    for (int ord = 0; ord < 2; ++ord) {
+        auto axis_of = [&](int i) { return ord ? i / nxa : i % nu; };
+        bool ok = true;
+        for (int j = 0; j < nx && ok; ++j)
+            for (int i = 0; i < nx && ok; ++i)
+                if (A[(size_t)i + (size_t)nx * j] != 0.0 && axis_of(i) != axis_of(j)) ok = false;
+        for (int c = 0; c < nu && ok; ++c)
+            for (int i = 0; i < nx && ok; ++i)
+                if (B[(size_t)i + (size_t)nx * c] != 0.0 && axis_of(i) != c) ok = false;
+        if (ok) return ord;
+    }
+    return -1;
+}
 
 // qpgen2's "vsmall": smallest 1e-60 * 2^k with 1 + 0.1 vsmall > 1 and 1 + 0.2 vsmall > 1
 inline double qpgen2_vsmall()
@@ -472,9 +495,10 @@ inline void build_lane_tables(HostPlan& hp)
         row[nz] = hp.row_f[i];
         row[nz + 1] = (double)i;
     }
-    bool axes_decoupled = false;
-    { // axis-decoupled costs (FusedPlan::lane_axes): H(a, b) = 0 and HN(a, b) = 0 wherever a and b belong to different axes
-        auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
+    // axis-decoupled costs and rows (FusedPlan::lane_axes for order 0): H(a, b) = 0 and HN(a, b) = 0 wherever a and b belong to different axes ...
+    auto decoupled = [&](int ord) {
+        const int nxa_ = nx / nu;
+        auto axis = [&](int a) { return a < nx ? (ord ? a / nxa_ : a % nu) : a - nx; };
         bool ok = nu > 1 && nx % nu == 0 && !hp.opt.no_lane_axes;
         for (int a = 0; a < nz && ok; ++a)
             for (int b = 0; b < nz && ok; ++b) {
@@ -495,9 +519,10 @@ inline void build_lane_tables(HostPlan& hp)
                         ax = axis(a);
                     }
             }
-        P.lane_axes = ok ? 1 : 0;
-        axes_decoupled = ok;
-    }
+        return ok;
+    };
+    const bool axes_decoupled = decoupled(0);
+    P.lane_axes = axes_decoupled ? 1 : 0;
     const bool cref_ok = P.ncost <= kRicMaxCosts && P.rmax <= 6;
     if (lane_ok) {
         if (hp.params.size() & 1) hp.params.push_back(0.0);
@@ -519,9 +544,16 @@ inline void build_lane_tables(HostPlan& hp)
     P.axis_tab = -1;
     P.axis_cref = -1;
     P.axis_rpa = 0;
-    if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && (nu == 1 || axes_decoupled)) {
+    P.axis_order = 0;
+    hp.axis1_tab = hp.axis1_cref = -1;
+    hp.axis1_rpa = hp.axis1_const = 0;
+    // (two sets: for state i on axis i % nu -- the plan's own fields -- and for state i on axis i / nxa -- HostPlan::axis1_*; which one a
+    //  controller's systems are in is seen when they are set, axis_order_of above)
+    for (int ord = 0; ord < 2; ++ord) {
+        int set_tab = -1, set_cref = -1, set_rpa = 0, set_const = 0;
+        if (!hp.opt.no_axis_solver && nx % nu == 0 && nx / nu <= 3 && nu > 1 && (ord == 0 ? axes_decoupled : (nx / nu > 1 && decoupled(1)))) {
         const int nxa = nx / nu, nza = nxa + 1, arw = nxa + 3;
-        auto axis = [&](int a) { return a < nx ? a % nu : a - nx; };
+        auto axis = [&](int a) { return a < nx ? (ord ? a / nxa : a % nu) : a - nx; };
         // rows per axis and step
         int rpa = 0;
         bool ok = true;
@@ -548,7 +580,7 @@ inline void build_lane_tables(HostPlan& hp)
             std::vector<double> at((size_t)nu * TA, 0.0);
             for (int c = 0; c < nu; ++c) {
                 double* t = at.data() + (size_t)c * TA;
-                auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; }; // axis index -> index in z = (x, u) of the system
+                auto zi = [&](int a) { return a < nxa ? (ord ? c * nxa + a : c + nu * a) : nx + c; }; // axis index -> index in z = (x, u) of the system
                 for (int a = 0; a < nza; ++a) {
                     for (int b = 0; b < nza; ++b) t[a + nza * b] = tab[(size_t)zi(a) + nz * zi(b)];
                     t[aoh + a] = tab[(size_t)oh + zi(a)];
@@ -592,10 +624,10 @@ inline void build_lane_tables(HostPlan& hp)
                 for (int k = 0; k < N && cst; ++k)
                     cst = cst && hp.ub[(size_t)k * nu + c] == hp.ub[(size_t)c] && hp.lb[(size_t)k * nu + c] == hp.lb[(size_t)c];
             }
-            P.axis_const = cst ? 1 : 0;
+            set_const = cst ? 1 : 0;
             if (hp.params.size() & 1) hp.params.push_back(0.0);
-            P.axis_tab = (int)hp.params.size();
-            P.axis_rpa = rpa;
+            set_tab = (int)hp.params.size();
+            set_rpa = rpa;
             hp.params.insert(hp.params.end(), at.begin(), at.end());
             // the coefficients of the cost references (oCref above), axis by axis: what a lane whose instance has its OWN references
             // (copra_batch_set_cost_reference) rebuilds h and hN of its axis from
@@ -604,7 +636,7 @@ inline void build_lane_tables(HostPlan& hp)
                 std::vector<double> ac((size_t)nu * aw, 0.0);
                 bool fits = P.ncost <= kMaxCosts;
                 for (int c = 0; c < nu && fits; ++c) {
-                    auto zi = [&](int a) { return a < nxa ? c + nu * a : nx + c; };
+                    auto zi = [&](int a) { return a < nxa ? (ord ? c * nxa + a : c + nu * a) : nx + c; };
                     int nref = 0;
                     for (int t = 0; t < P.ncost && fits; ++t) {
                         const CostTerm& ct = P.cost[t];
@@ -637,12 +669,17 @@ inline void build_lane_tables(HostPlan& hp)
                     ac[(size_t)c * aw] = (double)nref;
                 }
                 if (fits) {
-                    P.axis_cref = (int)hp.params.size();
+                    set_cref = (int)hp.params.size();
                     hp.params.insert(hp.params.end(), ac.begin(), ac.end());
                     if (hp.params.size() & 1) hp.params.push_back(0.0);
                 }
             }
         }
+        }
+        if (ord == 0)
+            P.axis_tab = set_tab, P.axis_cref = set_cref, P.axis_rpa = set_rpa, P.axis_const = set_const;
+        else
+            hp.axis1_tab = set_tab, hp.axis1_cref = set_cref, hp.axis1_rpa = set_rpa, hp.axis1_const = set_const;
     }
 }
 

@@ -127,6 +127,38 @@ def jerk_preview(batch, nu=3, N=20, seed=21, v_max=0.6, j_max=20.0, a_max=None):
                 costs=costs, cstrs=cstrs)
 
 
+def axis_major(wl):
+    """The same controller with its states in AXIS-MAJOR order -- x = (p_x, v_x, p_y, v_y, ..) instead of (p, v) --: a workload of com_preview /
+    jerk_preview (identity M, per-step bounds) with systems, costs and bounds permuted.  The engine sees the order from the first system it is
+    given."""
+    nx, nu = wl["A"].shape[1], wl["B"].shape[2]
+    nxa = nx // nu
+    perm = np.array([c + nu * a for c in range(nu) for a in range(nxa)])  # new state j is old state perm[j]
+    out = dict(wl)
+    out["A"] = np.ascontiguousarray(wl["A"][:, perm][:, :, perm])
+    out["B"] = np.ascontiguousarray(wl["B"][:, perm, :])
+    out["d"] = np.ascontiguousarray(wl["d"][:, perm])
+    out["x0"] = np.ascontiguousarray(wl["x0"][:, perm])
+    costs = []
+    for c in wl["costs"]:
+        c = dict(c)
+        if c["kind"] in ("trajectory", "target"):
+            assert np.array_equal(np.asarray(c["M"]), np.eye(nx))
+            c["p"] = np.asarray(c["p"])[perm]
+            c["weights"] = list(np.asarray(c["weights"])[perm])
+        costs.append(c)
+    cstrs = []
+    for c in wl["cstrs"]:
+        c = dict(c)
+        if c["kind"] == "trajectory_bound":
+            c["lower"] = list(np.asarray(c["lower"])[perm])
+            c["upper"] = list(np.asarray(c["upper"])[perm])
+        cstrs.append(c)
+    out["costs"], out["cstrs"] = costs, cstrs
+    out["name"] = wl["name"] + " (axis-major states)"
+    return out
+
+
 def long_horizon_initial_state(batch, N=50, seed=3, v_max=0.5, u_max=2.0, R_diag=1e-6, T=0.05):
     """BASELINE config 5 as SURVEY.md section 8(d) specifies it: InitialStateLMPC on a 6-DoF double integrator
     (nx=12, nu=6, N=50, T=0.05; 312 decision variables [x0; U]) -- the long-horizon case that does not fit the LDS.

@@ -345,6 +345,14 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     int lane_cnt[4] = { 0, 0, 0, 0 }; // (as the device's: [left over | the next solve's] [+ 2: ended by the pass's own steps])
     int &lane_count = lane_cnt[0], &lane_other = lane_cnt[1];
     // ... or, where the controller's axes are decoupled, the one-(instance, axis)-per-lane solver (lmpc_axis.hpp; copra_hip.hip: axis_solver_wanted)
+    // (the order of the systems' states, from the first one: copra_hip.hip, see_axis_order)
+    if (dims->batch > 0 && P.A && P.B && !hp.large && !P.initial_state && axis_order_of(P.A, P.B, P.nx, P.nu) == 1 && hp.axis1_tab >= 0) {
+        P.axis_order = 1;
+        P.axis_tab = hp.axis1_tab;
+        P.axis_cref = hp.axis1_cref;
+        P.axis_rpa = hp.axis1_rpa;
+        P.axis_const = hp.axis1_const;
+    }
     // (independent of the pass: chains of three states per control have no build of it)
     bool axis_pass = P.axis_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && !default_options().no_lane_pass && (lane_pass || P.nx == 3 * P.nu)
         && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0

@@ -1720,6 +1720,26 @@ def test_reference_trajectory_on_chains_of_three_states(emu, oracle, monkeypatch
         assert re2["status"][k] == rk["status"] == 0 and tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-7
 
 
+@pytest.mark.parametrize("model", ["com", "jerk"])
+def test_axis_solver_with_states_in_axis_major_order(emu, oracle, model):
+    """the same controllers with x = (p_x, v_x, p_y, v_y, ..) instead of (p, v): the engine sees the order of the states from the zero pattern
+    of the first system it is given (plan_builder.hpp: axis_order_of) and the (instance, axis)-per-lane solver reads its lanes' axes through that
+    order's index map and tables -- statuses, counters, U and X against the oracle run on the permuted controller; a goal per instance as well"""
+    from copra_amd import workloads
+    b = 45
+    base = workloads.com_preview(b, v_max=0.4, u_max=2.0, seed=17) if model == "com" else workloads.jerk_preview(b, nu=3, N=16, seed=5, v_max=0.3, j_max=6.0)
+    wl = workloads.axis_major(base)
+    re, ro = _axis_case(emu, oracle, wl, what=model)
+    assert re["lane_pass_finished"] >= b - 3
+    nx = wl["A"].shape[1]
+    goals = np.tile(wl["costs"][0]["p"], (b, 1)) + 0.1 * np.random.default_rng(2).standard_normal((b, nx)) * (np.asarray(wl["costs"][0]["p"]) != 0)
+    re2 = emu.lmpc_solve(wl["A"], wl["B"], wl["d"], wl["x0"], wl["N"], wl["costs"], wl["cstrs"], cost_refs={0: goals})
+    assert re2["lane_pass_finished"] >= b - 3
+    for k in range(0, b, 4):
+        rk = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], wl["N"], [dict(wl["costs"][0], p=goals[k]), wl["costs"][1]], wl["cstrs"])
+        assert re2["status"][k] == rk["status"] == 0 and tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-8
+
+
 def test_axis_solver_with_per_instance_limits(emu, oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) in front of the
     (instance, axis)-per-lane solver: the builds that keep bounds and right-hand sides in registers take the lane's own values where they are the

@@ -2896,6 +2896,48 @@ def test_axis_solver_on_the_jerk_controlled_com_model(oracle, nu, N, amax):
             assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
+@pytest.mark.parametrize("model", ["com", "jerk"])
+def test_axis_solver_with_states_in_axis_major_order(oracle, model):
+    """x = (p_x, v_x, p_y, v_y, ..) instead of (p, v): the order of the states is seen from the first system the controller is given, the
+    (instance, axis)-per-lane solver reads its lanes' axes through that order's index map and tables.  Whole batch: the permuted results of
+    the same controller in the benchmark's order (statuses and counters equal, U equal to 1e-12, X the permuted X); a sample against the
+    oracle run on the permuted controller; device arrays as well as host arrays"""
+    import torch
+    from copra_amd import BatchLMPC, workloads
+    b = 30000
+    base = workloads.com_preview(b, v_max=0.4, u_max=2.0, seed=23) if model == "com" else workloads.jerk_preview(b, nu=3, N=16, seed=9, v_max=0.3, j_max=6.0)
+    wl = workloads.axis_major(base)
+    nx, nu, N = wl["A"].shape[1], wl["B"].shape[2], wl["N"]
+    nxa = nx // nu
+    perm = np.array([c + nu * a for c in range(nu) for a in range(nxa)])
+    res = {}
+    for name, w, dev in (("base", base, False), ("major", wl, False), ("major_dev", wl, True)):
+        eng = BatchLMPC(nx, nu, N, b, w["costs"], w["cstrs"])
+        if dev:
+            # (the ABI's layout -- column-major per instance -- in device memory: copra_batch_set_system(on_device = 1) reads ONE system back)
+            t = [torch.from_numpy(np.ascontiguousarray(np.swapaxes(w[k], 1, 2) if w[k].ndim == 3 else w[k])).cuda() for k in ("A", "B", "d", "x0")]
+            eng.set_system(*t)
+        else:
+            eng.set_system(w["A"], w["B"], w["d"], w["x0"])
+        eng.solve()
+        res[name] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.close()
+    r0 = res["base"][0]
+    for name in ("major", "major_dev"):
+        r1, ran, info = res[name]
+        assert ran and info[1] >= int(0.97 * b), name
+        assert (r1["status"] == r0["status"]).all() and (r1["iter"] == r0["iter"]).all(), name
+        ok = r0["status"] == 0
+        assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-12, name
+        X0 = r0["trajectory"].reshape(b, N + 1, nx)[:, :, perm].reshape(b, -1)
+        assert _rel_vec(r1["trajectory"][ok], X0[ok]) <= 1e-12, name
+    r1 = res["major"][0]
+    for k in range(0, b, 3701):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+        assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+        assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_axis_solver_with_per_instance_limits(oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) through the
     (instance, axis)-per-lane solver: the lane's own values where they are the same along the horizon, the tier for the instances whose limits

@@ -37,6 +37,7 @@ python tools/exp/axis_batches.py 2>&1 | grep -v amdgpu.ids > $R/axis_load_sweep.
 python tools/exp/axis_gpu_check.py 2>&1 | grep -v amdgpu.ids > $R/tight_ladder_rates.txt || true
 PYTHONPATH=. python tools/exp/axis_tracking_rates.py 2>&1 | grep -v amdgpu.ids > $R/references_rates.txt || true
 PYTHONPATH=. python tools/exp/axis_limits_rates.py 2>&1 | grep -v amdgpu.ids >> $R/references_rates.txt || true
+PYTHONPATH=. python tools/exp/axis_major_rates.py 2>&1 | grep -v amdgpu.ids > $R/axis_major_rates.txt || true
 PYTHONPATH=. python tools/exp/jerk_model_rates.py 2>&1 | grep -v amdgpu.ids > $R/jerk_model_rates.txt || true
 PYTHONPATH=. python tools/exp/shared_vs_batch.py 2>&1 | grep -v amdgpu.ids > $R/shared_model_against_instance_by_instance.txt || true
 PYTHONPATH=. python tools/exp/config2_rates.py 2>&1 | grep -v amdgpu.ids > $R/config2_rates.txt || true
