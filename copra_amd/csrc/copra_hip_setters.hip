@@ -1,6 +1,7 @@
 // copra_hip_setters.hip -- everything of the C ABI (include/copra_hip.h) that hands data in or out of a controller: PreviewSystem::system /
 // xInit, per-instance references / right-hand sides / bounds, solver selection, results, timing and profile read-outs, copra_preview_update.
 // The solve path itself is copra_hip.hip.
+#include <vector>
 #include "engine.hpp"
 
 #include <cstdio>
@@ -226,6 +227,19 @@ copra_status_t copra_batch_set_system_rowmajor_async(copra_batch_t* h, const dou
     const size_t nA = b * P.nx * P.nx, nB = b * P.nx * P.nu, nd = b * P.nx;
     h->shared = false;
     h->shared_as_batch = false;
+    if (!h->axis_order_seen && b > 0) { // (the order of the states, from the first system -- once per controller; row-major here: transposed on the host)
+        const size_t a1 = (size_t)P.nx * P.nx, b1 = (size_t)P.nx * P.nu;
+        std::vector<double> ar(a1), br(b1), ac(a1), bc(b1);
+        if (hipMemcpy(ar.data(), A, a1 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(br.data(), B, b1 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int i = 0; i < P.nx; ++i) {
+                for (int j = 0; j < P.nx; ++j) ac[(size_t)i + (size_t)P.nx * j] = ar[(size_t)i * P.nx + j];
+                for (int c = 0; c < P.nu; ++c) bc[(size_t)i + (size_t)P.nx * c] = br[(size_t)i * P.nu + c];
+            }
+            see_axis_order(h, ac.data(), bc.data(), false);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (!h->own_A) {
         HIP_TRY(hipMalloc((void**)&h->own_A, (nA ? nA : 1) * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&h->own_B, (nB ? nB : 1) * sizeof(double)));

@@ -2911,9 +2911,12 @@ def test_axis_solver_with_states_in_axis_major_order(oracle, model):
     nxa = nx // nu
     perm = np.array([c + nu * a for c in range(nu) for a in range(nxa)])
     res = {}
-    for name, w, dev in (("base", base, False), ("major", wl, False), ("major_dev", wl, True)):
+    for name, w, dev in (("base", base, False), ("major", wl, False), ("major_dev", wl, True), ("major_rowmajor", wl, "rm")):
         eng = BatchLMPC(nx, nu, N, b, w["costs"], w["cstrs"])
-        if dev:
+        if dev == "rm":  # (numpy's natural indexing in device memory: the library transposes)
+            t = [torch.from_numpy(np.ascontiguousarray(w[k])).cuda() for k in ("A", "B", "d", "x0")]
+            eng.set_system_rowmajor_async(*t)
+        elif dev:
             # (the ABI's layout -- column-major per instance -- in device memory: copra_batch_set_system(on_device = 1) reads ONE system back)
             t = [torch.from_numpy(np.ascontiguousarray(np.swapaxes(w[k], 1, 2) if w[k].ndim == 3 else w[k])).cuda() for k in ("A", "B", "d", "x0")]
             eng.set_system(*t)
@@ -2923,7 +2926,7 @@ def test_axis_solver_with_states_in_axis_major_order(oracle, model):
         res[name] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
         eng.close()
     r0 = res["base"][0]
-    for name in ("major", "major_dev"):
+    for name in ("major", "major_dev", "major_rowmajor"):
         r1, ran, info = res[name]
         assert ran and info[1] >= int(0.97 * b), name
         assert (r1["status"] == r0["status"]).all() and (r1["iter"] == r0["iter"]).all(), name
