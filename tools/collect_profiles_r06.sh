@@ -12,7 +12,7 @@ export COPRA_NO_BUILD=1
 O=gpurun_out
 R=profiles/r06
 mkdir -p $R
-rm -rf $O/hl6_* $O/tl6_*
+rm -rf $O/hl6_* $O/tl6_* $O/rf6_* $O/jk6_*
 BENCH="python3 bench.py --no-cpu-baseline --no-extra"
 # ---- headline (BASELINE configs[2], batch 65536): copra_lmpc_axis_kernel (+ copra_lmpc_fused_ric_kernel for the handful it leaves) ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hl6_stats -- $BENCH --steps 50 --warmup 2 > $O/hl6_run.log 2>&1
@@ -29,6 +29,12 @@ find $O/hl6_stats_r05pair -name "*kernel_stats.csv" -exec cp {} $R/headline_roun
 # ---- the tight workload (v_max 0.25 / u_max 1.2): kernel trace ----
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tl6_stats -- python3 tools/exp/axis_phases.py 0.25 1.2 > $O/tl6_run.log 2>&1
 find $O/tl6_stats -name "*kernel_stats.csv" -exec cp {} $R/tight_kernel_stats.csv \;
+# ---- the widened solver: kernel traces of the reference / limits workloads and of the jerk-controlled model ----
+export PYTHONPATH=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rf6_stats -- python3 tools/exp/axis_tracking_rates.py > $O/rf6_run.log 2>&1 || true
+find $O/rf6_stats -name "*kernel_stats.csv" -exec cp {} $R/references_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/jk6_stats -- python3 tools/exp/jerk_model_rates.py > $O/jk6_run.log 2>&1 || true
+find $O/jk6_stats -name "*kernel_stats.csv" -exec cp {} $R/jerk_model_kernel_stats.csv \;
 # ---- side measurements ----
 python tools/exp/axis_phases.py 0.6 3.0 2>&1 | grep -v amdgpu.ids > $R/axis_phases_headline.txt || true
 python tools/exp/axis_phases.py 0.4 2.0 2>&1 | grep -v amdgpu.ids > $R/axis_phases_vmax040.txt || true
