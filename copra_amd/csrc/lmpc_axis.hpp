@@ -1,7 +1,8 @@
 // LMPC::solve() with ONE (INSTANCE, AXIS) PER LANE: the whole solve -- LQ sweep, roll-out AND the active-set iteration -- for
 // controllers whose axes are decoupled (round 6).
 //
-// The CoM model of BASELINE configs[2], the point masses, the reference's falling mass: state i belongs to axis i % nu, control c to
+// The CoM model of BASELINE configs[2], the point masses, the reference's falling mass: state i belongs to axis i % nu (x = (p, v)) or to
+// axis i / nxa (x = (p_x, v_x, p_y, ..): FusedPlan::axis_order, seen from the first system a controller is given), control c to
 // axis c, and neither A, B, the costs (costFunctions.cpp:63-215) nor any constraint row (constraints.cpp:66-315) couple two axes.  Then
 // the condensed QP of LMPC::makeQPForm (LMPC.cpp:250-280) is block diagonal -- nu independent QPs over one chain each (nxa = nx / nu
 // states, ONE control) -- and qpgen2's run on the whole problem (QuadProgSolver.cpp:45-72) is an INTERLEAVING of the axes' own runs: a
@@ -21,6 +22,11 @@
 // Anything the lane cannot decide exactly as qpgen2 would -- an active set that outgrows QMAX, a pick without a step in primal space
 // (|z|^2 <= vsmall: the infeasible and the degenerate cases), a failed factorisation, systems whose axes ARE coupled -- sends the
 // INSTANCE to the list of the first tier (lmpc_fused_ric.hpp), which solves it from scratch, as it does behind lmpc_lane.hpp.
+//
+// What a controller may bring besides (each checked where it is set, copra_hip.hip: axis_solver_wanted): chains of two or three states per control;
+// a reference per instance (copra_batch_set_cost_reference) and reference trajectories -- the lane rebuilds the affine terms of its axis from the
+// plan's coefficients (FusedPlan::axis_cref), stage by stage for a trajectory --; limits per instance (copra_batch_set_control_bounds,
+// _set_constraint_rhs) where they are the same along the horizon; one model for the batch (written out per instance: copra_batch_set_shared_system).
 //
 // Lane mapping: lane = nu * (instance of the wave) + axis, 64 / nu instances per wave; nothing crosses lanes inside the iteration (a
 // wave leaves the loop when its last lane has).  Per lane in LDS: one sparse array over its constraints (N controls + (N + 1) rpa
