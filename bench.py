@@ -401,7 +401,12 @@ def main():
                 # batch, lmpc_lane.hpp) and the first tier for the instances it leaves over -- `kernel_ms` spans both (events in
                 # their dispatch packets), so the counters are those of both, per launch of the pair
                 lane = [k for k in ctr if ("copra_lmpc_axis_kernel" if axis_ran else "copra_lmpc_lane_kernel") in k]
-                if lane:
+                if lane and axis_ran and eng.lane_pass_info()[1] == batch:
+                    # (round 6: every instance ends in the (instance, axis)-per-lane solver, and a controller whose lists stay empty launches
+                    #  no first tier at all -- `kernel_ms` is that ONE kernel, the counters are its own)
+                    dominant = "copra_lmpc_axis_kernel"
+                    c = {k: v["mean_per_launch"] for k, v in ctr[lane[0]].items()}
+                elif lane:
                     dominant = ("copra_lmpc_axis_kernel + " if axis_ran else "copra_lmpc_lane_kernel + ") + dominant
                     for k, v in ctr[lane[0]].items():
                         c[k] = c.get(k, 0.0) + v["mean_per_launch"]

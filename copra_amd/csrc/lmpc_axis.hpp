@@ -1175,9 +1175,11 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     } else {
         const int nr = nreg - group * IPW < IPW ? (nreg - group * IPW > 0 ? nreg - group * IPW : 0) : IPW; // instances on this wave's regular lanes
         const int XI = P.X, UI = P.n;
+        // (chains of three states: the controls take the place of the states once those have left -- axis_lds_doubles)
+        constexpr bool TWO = NXA >= 3;
         double* const sx_ = lds + oRC_; // [il][X]
-        double* const su_ = sx_ + IPW * XI; // [il][n]
-        double* const so_ = su_ + IPW * UI; // the axis of an instance on a spare lane, packed: x_k(i) at k NXA + i, then u_k
+        double* const su_ = TWO ? sx_ : sx_ + IPW * XI; // [il][n]
+        double* const so_ = TWO ? sx_ + IPW * XI : su_ + IPW * UI; // the axis of an instance on a spare lane, packed: x_k(i) at k NXA + i, then u_k
         wave_sync(); // (every lane is through with its arrays)
         {
             // (lanes without an instance write like a spare lane: nobody reads it)
@@ -1193,7 +1195,7 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
                     const double u = U[k];
 #pragma unroll
                     for (int i = 0; i < NXA; ++i) xo[k * sxk + i * sxi] = x[i];
-                    uo[k * suk] = u;
+                    if (!TWO || !lane_on) uo[k * suk] = u;
                     double xn[NXA];
 #pragma unroll
                     for (int i = 0; i < NXA; ++i) {
@@ -1228,6 +1230,16 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             if ((count & 1) && lane == 0) dst[count - 1] = src[count - 1];
         };
         flat_out(P.trajectory + (size_t)group * IPW * XI, sx_, nr * XI);
+        if constexpr (TWO) {
+            wave_sync(); // (the states have been read)
+            if (lane_on) {
+                double* const uo2 = su_ + il * UI + c;
+#pragma unroll
+                for (int k = 0; k < NMAX; ++k)
+                    if (EXACT || k < NH) uo2[k * NU] = U[k];
+            }
+            wave_sync();
+        }
         flat_out(P.control + (size_t)group * IPW * UI, su_, nr * UI);
         if (SP > 0 && wave_any(orphan)) { // the spare lane's axis: its (NH + 1) NXA states and NH controls, one lane each (spare lanes: NU = 3, NH <= 20)
             static_assert(SP == 0 || ((NMAX + 1) * NXA <= kWave && SP == 1), "one store for the states, one for the controls");

@@ -291,7 +291,8 @@ COPRA_HD inline int axis_lds_doubles(int nx, int nu, int N, int rpa, int qmax, i
     // per lane: the sparse array (+ a spare entry) | S = N' Q^-1 N of its active set, lower triangle | the multipliers
     rcs = (N + (N + 1) * rpa + 1 + qmax * (qmax + 1) / 2 + qmax + (qmax > 8 ? 2 * qmax : 0)) | 1; // (QMAX > 8: the FACTOR of S instead of S, + g and r)
     int w = 64 * rcs;
-    const int stage_out = (64 / nu) * (nx * (N + 1) + nu * N) + (N + 1) * (nx / nu) + N + 2; // (+ the axis of an instance on a spare lane)
+    // (chains of three states: X and U leave one after the other through the same place -- 21 x 249 doubles would cost the fourth wave of a CU)
+    const int stage_out = (64 / nu) * (nx * (N + 1) + (nxa >= 3 ? 0 : nu * N)) + (N + 1) * (nx / nu) + N + 2; // (+ the axis of an instance on a spare lane)
     // ... whose place the results of the wave's instances take at the end, as they lie in memory
     if (stage_out > w) w = stage_out;
     return (oRC + w + 1) & ~1;
