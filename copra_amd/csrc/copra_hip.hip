@@ -423,6 +423,8 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
         return P.nu == 2 ? COPRA_AXIS_PICK3(3, 2) : COPRA_AXIS_PICK3(3, 3);
 #undef COPRA_AXIS_PICK3
     }
+    if (nmax == 21) // (three axes at the last horizon of the one-wave kernels: tables in registers with one row per axis and step, or read from LDS)
+        return (P.axis_const && P.axis_rpa <= 1) ? copra_lmpc_axis_kernel<2, 3, 21, kAxisQmax, false, true, 1> : copra_lmpc_axis_kernel<2, 3, 21, kAxisQmax, false, false, 2>;
 #define COPRA_AXIS_PICK(NU, NMAX, EXACT)                                                                                                     \
     (P.axis_const ? (P.axis_rpa <= 1 ? copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 1> : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, EXACT, true, 2>) \
                   : copra_lmpc_axis_kernel<2, NU, NMAX, kAxisQmax, false, false, 2>)
@@ -437,6 +439,7 @@ static fused_kernel_t select_axis_list_kernel(const FusedPlan& P)
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
     if (nmax == 20 && P.nx == 3 * P.nu)
         return P.nu == 2 ? copra_lmpc_axis_list_kernel<3, 2, 20, kAxisQmaxBig, false, 2> : copra_lmpc_axis_list_kernel<3, 3, 20, kAxisQmaxBig, false, 2>;
+    if (nmax == 21) return copra_lmpc_axis_list_kernel<2, 3, 21, kAxisQmaxBig, false, 2>;
 #define COPRA_AXIS_LPICK(NU, NMAX) (P.axis_const ? copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, true, 2> : copra_lmpc_axis_list_kernel<2, NU, NMAX, kAxisQmaxBig, false, 2>)
     if (nmax == 20) return P.nu == 3 ? COPRA_AXIS_LPICK(3, 20) : COPRA_AXIS_LPICK(2, 20);
     if (nmax == 31) return COPRA_AXIS_LPICK(2, 31);

@@ -243,7 +243,7 @@ inline int axis_solver_nmax(int nx, int nu, int N)
     // in two and three dimensions, up to 20 steps
     if (nu < 2 || nu > 3 || N < 1 || nx % nu != 0) return 0;
     const int nxa = nx / nu;
-    if (nxa == 2) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : 0;
+    if (nxa == 2) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : (nu == 3 && N == 21) ? 21 : 0; // (three axes: 3 N <= 64 variables -- N = 21 is the last horizon of the one-wave kernels)
     if (nxa == 3) return N <= 20 ? 20 : 0;
     return 0;
 }

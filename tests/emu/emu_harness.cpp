@@ -391,6 +391,9 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                     const bool ct = P.axis_const && P.axis_rpa <= 1;
                     if (P.nu == 3) (small_q ? lmpc_axis_body<3, 3, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 3, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 3, 20, kAxisQmax, false, false, 2>(P, g));
                     else (small_q ? lmpc_axis_body<3, 2, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 2, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 2, 20, kAxisQmax, false, false, 2>(P, g));
+                } else if (P.nu == 3 && P.N == 21) {
+                    const bool ct = P.axis_const && P.axis_rpa <= 1;
+                    (small_q ? lmpc_axis_body<2, 3, 21, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<2, 3, 21, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<2, 3, 21, kAxisQmax, false, false, 2>(P, g));
                 } else if (P.nu == 3) COPRA_EMU_AXIS(3);
                 else COPRA_EMU_AXIS(2);
 #undef COPRA_EMU_AXIS
@@ -419,7 +422,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                     if (P.nx == 3 * P.nu) {
                         if (P.nu == 3) lmpc_axis_body<3, 3, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
                         else lmpc_axis_body<3, 2, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
-                    } else if (P.nu == 3) COPRA_EMU_AXIS_L(3, 20);
+                    } else if (P.nu == 3 && P.N == 21) lmpc_axis_body<2, 3, 21, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                    else if (P.nu == 3) COPRA_EMU_AXIS_L(3, 20);
                     else if (P.N <= 20) COPRA_EMU_AXIS_L(2, 20);
                     else COPRA_EMU_AXIS_L(2, 31);
 #undef COPRA_EMU_AXIS_L

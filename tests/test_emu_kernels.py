@@ -1607,7 +1607,7 @@ def _axis_case(emu, oracle, wl, cstrs=None, what=""):
     return re, ro
 
 
-@pytest.mark.parametrize("N,vmax,umax", [(20, 0.6, 3.0), (20, 0.25, 1.2), (15, 0.35, 1.8), (7, 0.3, 1.5)])
+@pytest.mark.parametrize("N,vmax,umax", [(20, 0.6, 3.0), (20, 0.25, 1.2), (15, 0.35, 1.8), (7, 0.3, 1.5), (21, 0.4, 2.0)])
 def test_axis_solver_on_the_com_preview(emu, oracle, N, vmax, umax):
     """BASELINE configs[2]'s model is three decoupled double integrators: every (instance, axis) is solved by ONE lane -- sweep, roll-out and
     the Goldfarb-Idnani iteration in range-space form on the Riccati factor (lmpc_axis.hpp).  qpgen2's run on the whole problem is an

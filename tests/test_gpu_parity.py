@@ -2941,6 +2941,31 @@ def test_axis_solver_with_states_in_axis_major_order(oracle, model):
         assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
+def test_axis_solver_at_the_last_horizon_of_three_axes(oracle):
+    """N = 21 with three controls: 63 variables, the last horizon the one-wave kernels hold -- its own builds of the (instance, axis)-per-lane
+    solver.  Whole batch against the round-5 pair, a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b, N = 25000, 21
+    wl = workloads.com_preview(b, N=N, v_max=0.4, u_max=2.0, seed=12)
+    out = {}
+    for mode in ("axis", "pair"):
+        eng = BatchLMPC(6, 3, N, b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1) if mode == "pair" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        out[mode] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.close()
+    r1, ran, info = out["axis"]
+    r0 = out["pair"][0]
+    assert ran and not out["pair"][1] and info[1] >= b - 64
+    ok = r0["status"] == 0
+    assert ok.sum() >= b - 8 and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.9999  # (ties)
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-9 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-9
+    for k in range(0, b, 2503):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+        assert r1["status"][k] == ro["status"] == 0 and tuple(r1["iter"][k]) == tuple(ro["iter"])
+        assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_axis_solver_with_per_instance_limits(oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) through the
     (instance, axis)-per-lane solver: the lane's own values where they are the same along the horizon, the tier for the instances whose limits
