@@ -664,7 +664,8 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         const bool row = (cR >= 0) & (!bnd | (sR * sR >= sB * sB * nR));
         bfound = bnd | (cR >= 0);
         bs = row ? sR : sB;
-        bloc = row ? lR : (kB | (kB << 8) | (lower ? (1 << 13) : 0));
+        const int kBs = kB < 0 ? 0 : kB; // (no bound found: the value is not looked at -- and no shift of a negative number)
+        bloc = row ? lR : (kBs | (kBs << 8) | (lower ? (1 << 13) : 0));
     };
     // backward recursion of y = Q^-1 n for the combined normal whose coefficients sit in RC, from stage ktop down: t_k = s_k / M_uu,k into Tv (zero
     // above ktop), returns n' Q^-1 n.  rows_live: some lane of the wave has a row in its combination (else the rows' coefficients are not even read)
