@@ -240,11 +240,11 @@ inline int axis_solver_nmax(int nx, int nu, int N)
 {
     // chains of two states per control in two and three dimensions (the CoM model, planar point masses) at horizons up to 20 (two dimensions: 31);
     // since late round 6 also chains of THREE states per control (the jerk-controlled CoM model: position, velocity, acceleration per axis)
-    // in two and three dimensions, up to 20 steps
+    // and of ONE (kinematic models) in two and three dimensions, up to 20 steps
     if (nu < 2 || nu > 3 || N < 1 || nx % nu != 0) return 0;
     const int nxa = nx / nu;
     if (nxa == 2) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : (nu == 3 && N == 21) ? 21 : 0; // (three axes: 3 N <= 64 variables -- N = 21 is the last horizon of the one-wave kernels)
-    if (nxa == 3) return N <= 20 ? 20 : 0;
+    if (nxa == 3 || nxa == 1) return N <= 20 ? 20 : 0; // (one state per control: kinematic models, x+ = a x + b u per axis)
     return 0;
 }
 inline bool ric_aot_shape(int nx, int nu) { return (nx == 6 && nu == 3) || (nx == 4 && nu == 2) || (nx == 2 && nu == 1); }

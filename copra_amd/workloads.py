@@ -127,6 +127,27 @@ def jerk_preview(batch, nu=3, N=20, seed=21, v_max=0.6, j_max=20.0, a_max=None):
                 costs=costs, cstrs=cstrs)
 
 
+def kinematic_preview(batch, nu=3, N=20, seed=31, p_max=0.55, u_max=1.5):
+    """A velocity-controlled point in `nu` dimensions (the kinematic model of mobile-robot MPC): ONE state per control, x+ = a x + T u + d per axis
+    with a ~ U(0.95, 1.0) and T ~ U(0.08, 0.15) per instance; trajectory cost towards a goal + small control cost; an upper bound on the
+    position (TrajectoryBoundConstraint) and a symmetric bound on the velocity command."""
+    rng = SplitMix64(seed)
+    T = rng.uniform(batch, 0.08, 0.15)
+    a = rng.uniform(batch, 0.95, 1.0)
+    I = np.eye(nu)
+    A = a[:, None, None] * I
+    B = T[:, None, None] * I
+    d = np.tile(0.002 * np.arange(1, nu + 1), (batch, 1))
+    x0 = rng.normal(batch * nu, 0.15).reshape(batch, nu)  # (inside the position bound: a state row violated by x0 itself is "no solution")
+    goal = np.array([0.5, 0.4, 0.45])[:nu]  # (inside the position bound: it is active where the unconstrained response overshoots)
+    costs = [dict(kind="trajectory", M=np.eye(nu), p=goal, weights=[10.0, 8.0, 6.0][:nu]),
+             dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[1e-2] * nu)]
+    cstrs = [dict(kind="trajectory_bound", lower=[-np.inf] * nu, upper=[p_max] * nu),
+             dict(kind="control_bound", lower=[-u_max] * nu, upper=[u_max] * nu)]
+    return dict(name="kinematic point (nx=%d,nu=%d,N=%d) + position & velocity bounds" % (nu, nu, N), A=np.ascontiguousarray(A), B=np.ascontiguousarray(B),
+                d=d, x0=x0, N=N, costs=costs, cstrs=cstrs)
+
+
 def axis_major(wl):
     """The same controller with its states in AXIS-MAJOR order -- x = (p_x, v_x, p_y, v_y, ..) instead of (p, v) --: a workload of com_preview /
     jerk_preview (identity M, per-step bounds) with systems, costs and bounds permuted.  The engine sees the order from the first system it is

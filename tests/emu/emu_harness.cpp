@@ -354,7 +354,7 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
         P.axis_const = hp.axis1_const;
     }
     // (independent of the pass: chains of three states per control have no build of it)
-    bool axis_pass = P.axis_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && !default_options().no_lane_pass && (lane_pass || P.nx == 3 * P.nu)
+    bool axis_pass = P.axis_tab >= 0 && !hp.large && !P.initial_state && dump_instance < 0 && !default_options().no_lane_pass && (lane_pass || P.nx == 3 * P.nu || P.nx == P.nu)
         && !default_options().no_axis_solver && axis_solver_nmax(P.nx, P.nu, P.N) > 0
         && (!(P.row_f_inst || P.lb_inst || P.ub_inst) || (P.axis_const && (P.lb_inst == nullptr) == (P.ub_inst == nullptr)));
     for (int k = 0; k < kMaxCosts; ++k) axis_pass = axis_pass && (!P.cost_p[k] || (P.axis_cref >= 0 && k < P.ncost));
@@ -387,7 +387,11 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     (small_q ? COPRA_EMU_AXIS_B(NU, 20, 2, false)                                                                                \
              : P.N == 20 && NU == 3 && !P.stage_refs ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                  \
              : P.N <= 20 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, false) : COPRA_EMU_AXIS_B(NU, 31, kAxisQmax, false))
-                if (P.nx == 3 * P.nu) { // chains of three states per control (copra_hip_axis3.hip)
+                if (P.nx == P.nu) { // one state per control (copra_hip_axis3.hip)
+                    const bool ct = P.axis_const && P.axis_rpa <= 1;
+                    if (P.nu == 3) (small_q ? lmpc_axis_body<1, 3, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<1, 3, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<1, 3, 20, kAxisQmax, false, false, 2>(P, g));
+                    else (small_q ? lmpc_axis_body<1, 2, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<1, 2, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<1, 2, 20, kAxisQmax, false, false, 2>(P, g));
+                } else if (P.nx == 3 * P.nu) { // chains of three states per control (copra_hip_axis3.hip)
                     const bool ct = P.axis_const && P.axis_rpa <= 1;
                     if (P.nu == 3) (small_q ? lmpc_axis_body<3, 3, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 3, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 3, 20, kAxisQmax, false, false, 2>(P, g));
                     else (small_q ? lmpc_axis_body<3, 2, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<3, 2, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<3, 2, 20, kAxisQmax, false, false, 2>(P, g));
@@ -419,7 +423,10 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                 int r = emu::run_wave([&]() {
 #define COPRA_EMU_AXIS_L(NU, NMAX)                                                                                       \
     (Pl.axis_const ? lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, true, 2, true>(Pl, g) : lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, false, 2, true>(Pl, g))
-                    if (P.nx == 3 * P.nu) {
+                    if (P.nx == P.nu) {
+                        if (P.nu == 3) lmpc_axis_body<1, 3, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                        else lmpc_axis_body<1, 2, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                    } else if (P.nx == 3 * P.nu) {
                         if (P.nu == 3) lmpc_axis_body<3, 3, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
                         else lmpc_axis_body<3, 2, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
                     } else if (P.nu == 3 && P.N == 21) lmpc_axis_body<2, 3, 21, kAxisQmaxBig, false, false, 2, true>(Pl, g);

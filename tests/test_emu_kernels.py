@@ -1740,6 +1740,18 @@ def test_axis_solver_with_states_in_axis_major_order(emu, oracle, model):
         assert re2["status"][k] == rk["status"] == 0 and tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-8
 
 
+@pytest.mark.parametrize("nu,N", [(3, 20), (3, 13), (2, 20)])
+def test_axis_solver_on_one_state_per_control(emu, oracle, nu, N):
+    """a velocity-controlled point (nx = nu: the kinematic model of mobile-robot MPC) on the (instance, axis)-per-lane solver's builds for ONE
+    state per control: statuses, both counters, U and X against the oracle; the instances end in the solver"""
+    from copra_amd import workloads
+    b = 50
+    wl = workloads.kinematic_preview(b, nu=nu, N=N, seed=2 + N)
+    re, ro = _axis_case(emu, oracle, wl, what=(nu, N))
+    assert re["lane_pass_finished"] >= b - 3
+    assert ro["iter"][:, 0].max() >= 3 and (ro["iter"][:, 0] >= 2).mean() >= 0.3  # (the constraints matter)
+
+
 def test_axis_solver_with_per_instance_limits(emu, oracle):
     """every robot its own velocity and actuator limits (copra_batch_set_constraint_rhs, copra_batch_set_control_bounds) in front of the
     (instance, axis)-per-lane solver: the builds that keep bounds and right-hand sides in registers take the lane's own values where they are the

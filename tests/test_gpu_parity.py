@@ -2941,6 +2941,34 @@ def test_axis_solver_with_states_in_axis_major_order(oracle, model):
         assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
+@pytest.mark.parametrize("nu,N", [(3, 20), (2, 20)])
+def test_axis_solver_on_one_state_per_control(oracle, nu, N):
+    """a velocity-controlled point (nx = nu: the kinematic model of mobile-robot MPC) on the (instance, axis)-per-lane solver's builds for ONE
+    state per control: whole batch against the general one-wave kernels (option no_axis_solver), a sample against the oracle"""
+    from copra_amd import BatchLMPC, workloads
+    b = 20000
+    wl = workloads.kinematic_preview(b, nu=nu, N=N, seed=14)
+    out = {}
+    for mode in ("axis", "general"):
+        eng = BatchLMPC(nu, nu, N, b, wl["costs"], wl["cstrs"], options=dict(no_axis_solver=1) if mode == "general" else None)
+        eng.set_system(wl["A"], wl["B"], wl["d"], wl["x0"])
+        eng.solve()
+        out[mode] = (eng.results(), eng.axis_solver_ran(), eng.lane_pass_info())
+        eng.close()
+    r1, ran, info = out["axis"]
+    r0 = out["general"][0]
+    assert ran and not out["general"][1] and info[1] >= int(0.97 * b)
+    ok = r0["status"] == 0
+    assert ok.sum() >= int(0.99 * b) and (r0["status"] == r1["status"]).all() and (r0["iter"][ok] == r1["iter"][ok]).mean() >= 0.999  # (ties)
+    assert _rel_vec(r1["control"][ok], r0["control"][ok]) <= 1e-8 and _rel_vec(r1["trajectory"][ok], r0["trajectory"][ok]) <= 1e-8
+    for k in range(0, b, 2857):
+        ro = oracle.lmpc_solve(wl["A"][k], wl["B"][k], wl["d"][k], wl["x0"][k], N, wl["costs"], wl["cstrs"])
+        assert r1["status"][k] == ro["status"]
+        if ro["status"] == 0:
+            assert tuple(r1["iter"][k]) == tuple(ro["iter"])
+            assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
+
+
 def test_axis_solver_at_the_last_horizon_of_three_axes(oracle):
     """N = 21 with three controls: 63 variables, the last horizon the one-wave kernels hold -- its own builds of the (instance, axis)-per-lane
     solver.  Whole batch against the round-5 pair, a sample against the oracle"""
