@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64, COPRA_AXIS_WAVES) void copra_lmpc_axis_kernel(c
 // ... and chains of THREE states per control (the jerk-controlled CoM model: position, velocity, acceleration per axis) in two and three
 // dimensions: tables in registers with one row per axis and step, or read from LDS  (copra_hip_axis3.hip).  (Single-control systems stay on the
 // packed kernels -- 2 or 4 instances per wave, copra_hip_packed16/32.hip --: BASELINE configs[1]'s workload ends with every bound active.)
-#define COPRA_AXIS_KERNELS_MORE(X) X(1, 2, 20, 6, false, true, 1) X(1, 2, 20, 6, false, false, 2) X(1, 3, 20, 6, false, true, 1) X(1, 3, 20, 6, false, false, 2) X(2, 3, 21, 6, false, true, 1) X(2, 3, 21, 6, false, false, 2) X(3, 2, 20, 6, false, true, 1) X(3, 2, 20, 6, false, false, 2) X(3, 3, 20, 6, false, true, 1) X(3, 3, 20, 6, false, false, 2)
+#define COPRA_AXIS_KERNELS_MORE(X) X(1, 2, 31, 6, false, true, 1) X(1, 2, 31, 6, false, false, 2) X(1, 2, 20, 6, false, true, 1) X(1, 2, 20, 6, false, false, 2) X(1, 3, 20, 6, false, true, 1) X(1, 3, 20, 6, false, false, 2) X(2, 3, 21, 6, false, true, 1) X(2, 3, 21, 6, false, false, 2) X(3, 2, 20, 6, false, true, 1) X(3, 2, 20, 6, false, false, 2) X(3, 3, 20, 6, false, true, 1) X(3, 3, 20, 6, false, false, 2)
 
 // The second chance of what that launch lists: the same solver with room for kAxisQmaxBig active constraints per lane, instances taken from the
 // list (a grid-stride loop over it: the launch does not know its length).  One wave per CU at most (its lanes' LDS): a handful of waves.
@@ -40,5 +40,5 @@ __global__ __launch_bounds__(64, 1) void copra_lmpc_axis_list_kernel(const Fused
         __syncthreads();
     }
 }
-#define COPRA_AXIS_LIST_KERNELS_MORE(X) X(1, 2, 20, 16, false, 2) X(1, 3, 20, 16, false, 2) X(2, 3, 21, 16, false, 2) X(3, 2, 20, 16, false, 2) X(3, 3, 20, 16, false, 2)
+#define COPRA_AXIS_LIST_KERNELS_MORE(X) X(1, 2, 31, 16, false, 2) X(1, 2, 20, 16, false, 2) X(1, 3, 20, 16, false, 2) X(2, 3, 21, 16, false, 2) X(3, 2, 20, 16, false, 2) X(3, 3, 20, 16, false, 2)
 #define COPRA_AXIS_LIST_KERNELS(X) X(2, 3, 20, 16, true, 2) X(2, 2, 20, 16, true, 2) X(2, 2, 31, 16, true, 2) X(2, 3, 20, 16, false, 2) X(2, 2, 20, 16, false, 2) X(2, 2, 31, 16, false, 2)

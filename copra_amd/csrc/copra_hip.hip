@@ -417,6 +417,8 @@ static fused_kernel_t select_lane_shared_kernel(const FusedPlan& P)
 static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 {
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+    if (nmax == 31 && P.nx == P.nu) // (one state per control in the plane, horizons up to 31)
+        return (P.axis_const && P.axis_rpa <= 1) ? copra_lmpc_axis_kernel<1, 2, 31, kAxisQmax, false, true, 1> : copra_lmpc_axis_kernel<1, 2, 31, kAxisQmax, false, false, 2>;
     if (nmax == 20 && (P.nx == 3 * P.nu || P.nx == P.nu)) { // (copra_hip_axis3.hip: tables in registers with one row per axis and step, or read from LDS)
         const bool ct = P.axis_const && P.axis_rpa <= 1;
 #define COPRA_AXIS_PICK3(NXA, NU) (ct ? copra_lmpc_axis_kernel<NXA, NU, 20, kAxisQmax, false, true, 1> : copra_lmpc_axis_kernel<NXA, NU, 20, kAxisQmax, false, false, 2>)
@@ -438,6 +440,7 @@ static fused_kernel_t select_axis_kernel(const FusedPlan& P)
 static fused_kernel_t select_axis_list_kernel(const FusedPlan& P)
 {
     const int nmax = axis_solver_nmax(P.nx, P.nu, P.N);
+    if (nmax == 31 && P.nx == P.nu) return copra_lmpc_axis_list_kernel<1, 2, 31, kAxisQmaxBig, false, 2>;
     if (nmax == 20 && P.nx == P.nu)
         return P.nu == 2 ? copra_lmpc_axis_list_kernel<1, 2, 20, kAxisQmaxBig, false, 2> : copra_lmpc_axis_list_kernel<1, 3, 20, kAxisQmaxBig, false, 2>;
     if (nmax == 20 && P.nx == 3 * P.nu)

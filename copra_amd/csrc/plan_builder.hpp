@@ -244,7 +244,8 @@ inline int axis_solver_nmax(int nx, int nu, int N)
     if (nu < 2 || nu > 3 || N < 1 || nx % nu != 0) return 0;
     const int nxa = nx / nu;
     if (nxa == 2) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : (nu == 3 && N == 21) ? 21 : 0; // (three axes: 3 N <= 64 variables -- N = 21 is the last horizon of the one-wave kernels)
-    if (nxa == 3 || nxa == 1) return N <= 20 ? 20 : 0; // (one state per control: kinematic models, x+ = a x + b u per axis)
+    if (nxa == 1) return N <= 20 ? 20 : (nu == 2 && N <= 31) ? 31 : 0; // (one state per control: kinematic models, x+ = a x + b u per axis)
+    if (nxa == 3) return N <= 20 ? 20 : 0;
     return 0;
 }
 inline bool ric_aot_shape(int nx, int nu) { return (nx == 6 && nu == 3) || (nx == 4 && nu == 2) || (nx == 2 && nu == 1); }

@@ -387,7 +387,10 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
     (small_q ? COPRA_EMU_AXIS_B(NU, 20, 2, false)                                                                                \
              : P.N == 20 && NU == 3 && !P.stage_refs ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, true)                                  \
              : P.N <= 20 ? COPRA_EMU_AXIS_B(NU, 20, kAxisQmax, false) : COPRA_EMU_AXIS_B(NU, 31, kAxisQmax, false))
-                if (P.nx == P.nu) { // one state per control (copra_hip_axis3.hip)
+                if (P.nx == P.nu && P.N > 20) { // one state per control in the plane, horizons up to 31
+                    const bool ct = P.axis_const && P.axis_rpa <= 1;
+                    (small_q ? lmpc_axis_body<1, 2, 31, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<1, 2, 31, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<1, 2, 31, kAxisQmax, false, false, 2>(P, g));
+                } else if (P.nx == P.nu) { // one state per control (copra_hip_axis3.hip)
                     const bool ct = P.axis_const && P.axis_rpa <= 1;
                     if (P.nu == 3) (small_q ? lmpc_axis_body<1, 3, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<1, 3, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<1, 3, 20, kAxisQmax, false, false, 2>(P, g));
                     else (small_q ? lmpc_axis_body<1, 2, 20, 2, false, false, 2>(P, g) : ct ? lmpc_axis_body<1, 2, 20, kAxisQmax, false, true, 1>(P, g) : lmpc_axis_body<1, 2, 20, kAxisQmax, false, false, 2>(P, g));
@@ -423,7 +426,8 @@ int emu_lmpc_solve(const copra_dims_t* dims, int n_costs, const copra_cost_desc_
                 int r = emu::run_wave([&]() {
 #define COPRA_EMU_AXIS_L(NU, NMAX)                                                                                       \
     (Pl.axis_const ? lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, true, 2, true>(Pl, g) : lmpc_axis_body<2, NU, NMAX, kAxisQmaxBig, false, false, 2, true>(Pl, g))
-                    if (P.nx == P.nu) {
+                    if (P.nx == P.nu && P.N > 20) lmpc_axis_body<1, 2, 31, kAxisQmaxBig, false, false, 2, true>(Pl, g);
+                    else if (P.nx == P.nu) {
                         if (P.nu == 3) lmpc_axis_body<1, 3, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
                         else lmpc_axis_body<1, 2, 20, kAxisQmaxBig, false, false, 2, true>(Pl, g);
                     } else if (P.nx == 3 * P.nu) {

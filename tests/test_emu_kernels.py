@@ -1740,7 +1740,7 @@ def test_axis_solver_with_states_in_axis_major_order(emu, oracle, model):
         assert re2["status"][k] == rk["status"] == 0 and tuple(re2["iter"][k]) == tuple(rk["iter"]) and _rel(re2["control"][k], rk["control"]) <= 1e-8
 
 
-@pytest.mark.parametrize("nu,N", [(3, 20), (3, 13), (2, 20)])
+@pytest.mark.parametrize("nu,N", [(3, 20), (3, 13), (2, 20), (2, 29)])
 def test_axis_solver_on_one_state_per_control(emu, oracle, nu, N):
     """a velocity-controlled point (nx = nu: the kinematic model of mobile-robot MPC) on the (instance, axis)-per-lane solver's builds for ONE
     state per control: statuses, both counters, U and X against the oracle; the instances end in the solver"""

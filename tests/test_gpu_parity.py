@@ -2941,7 +2941,7 @@ def test_axis_solver_with_states_in_axis_major_order(oracle, model):
         assert _rel(r1["control"][k], ro["control"]) <= RTOL and _rel(r1["trajectory"][k], ro["trajectory"]) <= RTOL
 
 
-@pytest.mark.parametrize("nu,N", [(3, 20), (2, 20)])
+@pytest.mark.parametrize("nu,N", [(3, 20), (2, 20), (2, 30)])
 def test_axis_solver_on_one_state_per_control(oracle, nu, N):
     """a velocity-controlled point (nx = nu: the kinematic model of mobile-robot MPC) on the (instance, axis)-per-lane solver's builds for ONE
     state per control: whole batch against the general one-wave kernels (option no_axis_solver), a sample against the oracle"""
