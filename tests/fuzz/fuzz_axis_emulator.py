@@ -1,4 +1,4 @@
-"""Random controllers on the shapes of the (instance, axis)-per-lane solver (tests/random_controllers.py: make_integrator, make_chain3; now and then
+"""Random controllers on the shapes of the (instance, axis)-per-lane solver (tests/random_controllers.py: make_integrator, make_chain3, make_chain1; now and then
 in axis-major state order, with a goal per instance) through the CPU wave emulator of the kernel bodies against the oracle: statuses, iteration
 counters, U and X.   python tests/fuzz/fuzz_axis_emulator.py [first_seed [count [batch]]]"""
 import os
@@ -26,7 +26,7 @@ b = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 nbad = ntie = naxis = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng([seed, 5])
-    c = RC.make_chain3(seed, b) if seed % 3 == 0 else RC.make_integrator(seed, b)
+    c = RC.make_chain3(seed, b) if seed % 4 == 0 else RC.make_chain1(seed, b) if seed % 4 == 2 else RC.make_integrator(seed, b)
     if c["nu"] == 1:
         continue
     what = list(c["forms"])

@@ -1,5 +1,5 @@
-"""tests/random_controllers.py::make_integrator (third argument "chain3": make_chain3 -- chains of three states per control) on the device against the
-oracle (sample), over many seeds: which layouts fail?   python tests/fuzz/fuzz_integrators.py first count [chain3]"""
+"""tests/random_controllers.py::make_integrator (third argument "chain3" / "chain1": make_chain3 / make_chain1 -- chains of three states, of one state per control) on the device against the
+oracle (sample), over many seeds: which layouts fail?   python tests/fuzz/fuzz_integrators.py first count [chain3 | chain1]"""
 import os
 import sys
 
@@ -17,7 +17,8 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
     b = (24576, 4096, 6144)[seed % 3]
-    c = RC.make_chain3(seed, b) if len(sys.argv) > 3 and sys.argv[3] == "chain3" else RC.make_integrator(seed, b)
+    gen = sys.argv[3] if len(sys.argv) > 3 else ""
+    c = RC.make_chain3(seed, b) if gen == "chain3" else RC.make_chain1(seed, b) if gen == "chain1" else RC.make_integrator(seed, b)
     eng = BatchLMPC(c["nx"], c["nu"], c["N"], b, c["costs"], c["cstrs"], options=dict(lane_min_batch=-1) if b == 6144 else None)
     eng.set_system(c["A"], c["B"], c["d"], c["x0"])
     pick = np.linspace(0, b - 1, 160).astype(int)

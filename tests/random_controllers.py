@@ -149,6 +149,62 @@ def make(seed, batch=48, max_vars=64, shape=None):
     return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms, initial_state=ist)
 
 
+def make_chain1(seed, batch):
+    """Random controllers with ONE state per control (kinematic models: x+ = a x + T u + d per axis) in two and three dimensions -- the shapes of
+    the (instance, axis)-per-lane solver's builds for nx = nu: random horizon (two dimensions: up to 31), per-instance a and T, a goal or a
+    reference trajectory, optional target cost, position bounds / rows, velocity-command bounds, mixed rows; a dense state row now and then."""
+    rng = np.random.default_rng([seed, 4177])
+    dim = int(rng.choice([2, 3], p=[0.45, 0.55]))
+    nx = nu = dim
+    N = int(rng.integers(4, (31 if dim == 2 else 20) + 1))
+    forms = []
+    T = rng.uniform(0.08, 0.15, batch)
+    a = rng.uniform(0.93, 1.0, batch)
+    I = np.eye(dim)
+    A = np.ascontiguousarray(a[:, None, None] * I)
+    B = np.ascontiguousarray(T[:, None, None] * I)
+    d = np.zeros((batch, nx)) if rng.random() < 0.5 else np.tile(0.004 * rng.standard_normal(nx), (batch, 1))
+    p_max = float(rng.uniform(0.5, 0.9))
+    u_max = float(rng.uniform(0.6, 2.0))
+    x0 = rng.uniform(-0.8 * p_max, 0.8 * p_max, (batch, dim))
+    goal = rng.uniform(-0.45, 0.45, dim)
+    wx = rng.uniform(4.0, 15.0, dim)
+    costs = []
+    if rng.random() < 0.35:
+        pk = goal[None, :] * np.linspace(0.3, 1.0, N + 1)[:, None] + 0.01 * rng.standard_normal((N + 1, nx))
+        costs.append(dict(kind="trajectory", M=_blockdiag(np.eye(nx), N + 1), p=pk.reshape(-1), weights=np.tile(wx, N + 1)))
+        forms.append("xref")
+    else:
+        costs.append(dict(kind="trajectory", M=np.eye(nx), p=goal, weights=wx))
+        forms.append("xcost")
+    costs.append(dict(kind="control", N=np.eye(nu), p=np.zeros(nu), weights=[float(rng.uniform(1e-3, 5e-2))] * nu))
+    if rng.random() < 0.3:
+        costs.append(dict(kind="target", M=np.eye(nx), p=goal, weights=5.0 * wx))
+        forms.append("target")
+    cstrs = []
+    inf = np.inf
+    if rng.random() < 0.8:
+        cstrs.append(dict(kind="trajectory_bound", lower=[-inf] * nx, upper=[p_max] * dim))
+        forms.append("pbound")
+    if rng.random() < 0.85:
+        cstrs.append(dict(kind="control_bound", lower=[-u_max] * nu, upper=[u_max] * nu))
+        forms.append("ubound")
+    if rng.random() < 0.3:
+        cstrs.append(dict(kind="trajectory", E=-np.eye(dim), f=[p_max] * dim, ineq=True))  # the lower position limit as rows
+        forms.append("-p rows")
+    elif rng.random() < 0.2:
+        cstrs.append(dict(kind="mixed", E=np.eye(dim), G=0.05 * np.eye(dim), f=[p_max * 1.05] * dim, ineq=True))
+        forms.append("p+Tu")
+    if rng.random() < 0.1:
+        E = rng.standard_normal((1, nx))
+        cstrs.append(dict(kind="trajectory", E=E, f=[float(np.abs(E @ x0.T).max() + rng.uniform(0.5, 1.5))], ineq=True))
+        forms.append("dense-x")
+    if not cstrs:
+        cstrs.append(dict(kind="control_bound", lower=[-u_max] * nu, upper=[u_max] * nu))
+        forms.append("ubound")
+    return dict(nx=nx, nu=nu, N=N, A=A, B=B, d=d, x0=x0, costs=costs, cstrs=cstrs, forms=forms)
+
+
 def make_chain3(seed, batch):
     """Random controllers on chains of THREE states per control (position, velocity, acceleration per axis, the jerk as control) in two and three
     dimensions -- the shapes of the (instance, axis)-per-lane solver's late-round-6 builds: random horizon up to 20, per-instance sampling

@@ -54,6 +54,7 @@ python tools/exp/truth_distances.py 2>&1 | grep -v amdgpu.ids > $R/truth_distanc
 # ---- the random differential tests that reach the new kernel, at wide settings ----
 (python tests/fuzz/fuzz_integrators.py 0 150 2>&1 | grep -v amdgpu.ids | grep "<<<<\|mismatching" | cut -c1-500) > $R/fuzz_integrator_shapes.txt || true
 (python tests/fuzz/fuzz_integrators.py 1000 90 chain3 2>&1 | grep -v amdgpu.ids | grep "<<<<\|mismatching" | cut -c1-500) > $R/fuzz_chains_of_three_states.txt || true
+(python tests/fuzz/fuzz_integrators.py 3000 90 chain1 2>&1 | grep -v amdgpu.ids | grep "<<<<\|mismatching" | cut -c1-500) > $R/fuzz_one_state_per_control.txt || true
 (python tests/fuzz/fuzz_modes.py 0 420 2>&1 | grep -v amdgpu.ids | grep " <\|ERROR\|mismatching" | cut -c1-400) > $R/fuzz_engine_modes.txt || true
 (python tests/fuzz/fuzz_vs_oracle.py 0 1500 48 2>&1 | grep -v amdgpu.ids | tail -40) > $R/fuzz_random_controllers.txt || true
 # ---- the bench line itself (with cpu_baseline and extra): AFTER the summaries, so that its roofline.traffic is the one just measured ----
