@@ -146,6 +146,44 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
     };
     const int oT = c * TA, oUB = oBnd_ + c * 2 * NH; // this lane's axis in LDS (!CT): tables | bounds (ub_k at [k], lb_k at [NH + k])
     const double* const Tg = P.params + P.axis_tab + c * TA; // ... and in memory: what is read once
+    // Per-instance references / reference trajectories (below, 1.): the cost rows that look at this axis -- at most kAxisMaxRef, FusedPlan::axis_cref --,
+    // where their references lie, their coefficients.  Requested HERE, in front of the systems, and the references themselves right behind the
+    // systems: three dependent trips to memory (entry -> cost -> reference) in front of the sweep cost a wave 8 us -- 0.120 instead of 0.086 ms per
+    // 65 536 solves with a goal per instance.
+    constexpr int MR = kAxisMaxRef, EW = 5 + NZ + NXA;
+    const double* bj[MR];
+    int psj[MR], lastj[MR];
+    double ch[MR][NZ], cN[MR][NXA], pl[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        bj[j] = P.params;
+        psj[j] = lastj[j] = 0;
+        pl[j] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) ch[j][a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NXA; ++i) cN[j][i] = 0.0;
+    }
+    if (own_refs || srefs) {
+        const double* const cf = P.params + P.axis_cref + (size_t)c * (1 + MR * EW);
+        const int nref = (int)cf[0];
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const double* const e = cf + 1 + j * EW;
+            const bool on = j < nref;
+            const int t = on ? (int)e[0] : -1, r = on ? (int)e[1] : 0, prows = on ? (int)e[2] : 0, ps = on ? (int)e[3] : 0, offP = on ? (int)e[4] : 0;
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) ch[j][a] = on ? e[5 + a] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NXA; ++i) cN[j][i] = on ? e[5 + NZ + i] : 0.0;
+            const double* own = nullptr; // (this cost's per-instance references, if it has them: the pointers are the launch's arguments)
+#pragma unroll
+            for (int tt = 0; tt < kMaxCosts; ++tt) own = (t == tt) ? P.cost_p[tt] : own;
+            bj[j] = (own ? own + (size_t)inst * prows : P.params + offP) + r;
+            psj[j] = ps;
+            lastj[j] = ps ? prows / ps - 1 : 0; // (the last step the reference has)
+        }
+    }
     double A[NXA][NXA], B[NXA], d[NXA], x0[NXA]; // A[i][j]: entry (i, j) of the axis' block
     bool giveup = false; // this lane cannot finish its instance: the first tier solves it from scratch
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -183,6 +221,10 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
             }
             d[ii] = sd[z0 + zs * ii];
             x0[ii] = sx[z0 + zs * ii];
+        }
+        if (own_refs || srefs) { // (requested behind the systems, looked at in front of the sweep)
+#pragma unroll
+            for (int j = 0; j < MR; ++j) pl[j] = bj[j][lastj[j] * psj[j]];
         }
         double stray = 0.0;
 #pragma unroll
@@ -287,30 +329,6 @@ COPRA_DEV void lmpc_axis_body(const FusedPlan& P, int group)
         // in the lane's sparse array until the sweep has read them (a cost whose reference has no step k -- the last step of a reference over
         // N steps -- takes its last).
         if (own_refs || srefs) {
-            // (the cost rows that look at this axis -- at most kAxisMaxRef, FusedPlan::axis_cref --: where their references lie, their coefficients)
-            constexpr int MR = kAxisMaxRef, EW = 2 + NZ + NXA;
-            const double* const cf = P.params + P.axis_cref + (size_t)c * (1 + MR * EW);
-            const int nref = (int)cf[0];
-            const double* bj[MR];
-            int psj[MR], lastj[MR];
-            double ch[MR][NZ], cN[MR][NXA];
-#pragma unroll
-            for (int j = 0; j < MR; ++j) {
-                const double* const e = cf + 1 + j * EW;
-                const bool on = j < nref;
-                const int t = on ? (int)e[0] : 0, r = on ? (int)e[1] : 0;
-#pragma unroll
-                for (int a = 0; a < NZ; ++a) ch[j][a] = on ? e[2 + a] : 0.0;
-#pragma unroll
-                for (int i = 0; i < NXA; ++i) cN[j][i] = on ? e[2 + NZ + i] : 0.0;
-                const int ps = P.cost[t].pstride, prows = P.cost[t].prows;
-                bj[j] = (P.cost_p[t] ? P.cost_p[t] + (size_t)inst * prows : P.params + P.cost[t].offP) + r;
-                psj[j] = ps;
-                lastj[j] = ps ? prows / ps - 1 : 0; // (the last step the reference has)
-            }
-            double pl[MR];
-#pragma unroll
-            for (int j = 0; j < MR; ++j) pl[j] = bj[j][lastj[j] * psj[j]];
 #pragma unroll
             for (int a = 0; a < NZ; ++a) {
                 double s = 0.0;

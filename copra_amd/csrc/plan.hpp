@@ -365,7 +365,7 @@ struct FusedPlan {
     int axis_order; // which order its systems' states are in: 0: state i on axis i % nu (x = (p, v): the benchmark's CoM model), 1: state i on axis i / nxa
                     //   (x = (p_x, v_x, p_y, v_y, ..)) -- seen when the systems are set (plan_builder.hpp: axis_order_of); the tables below are that order's
     int axis_cref; // ... the coefficients of the cost references in its affine terms, per axis: the number of cost rows that look at the axis, then
-                   //     kAxisMaxRef entries [cost | row | coefficients in h (nxa + 1) | in hN (nxa)] (-1: none, or an axis with more such rows --
+                   //     kAxisMaxRef entries [cost | row | prows | pstride | offP of the cost | coefficients in h (nxa + 1) | in hN (nxa)] (-1: none, or an axis with more such rows --
                    //     controllers with per-instance references or reference trajectories keep the one-instance-per-lane pass then)
     int axis_tab, axis_rpa; // the (instance, axis)-per-lane solver's tables in `params` (-1: the controller is not eligible) and rows per axis and step (lmpc_axis.hpp)
     int lane_handover; // 1: the first tier takes its stage records from lane_ws instead of sweeping (compact variant of the tier)

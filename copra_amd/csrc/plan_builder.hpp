@@ -633,7 +633,7 @@ inline void build_lane_tables(HostPlan& hp)
             // the coefficients of the cost references (oCref above), axis by axis: what a lane whose instance has its OWN references
             // (copra_batch_set_cost_reference) rebuilds h and hN of its axis from
             { // (straight from the costs: any number of rows per cost -- the jerk-controlled CoM model's TrajectoryCost has nine)
-                const int ew = 2 + nza + nxa, aw = 1 + kAxisMaxRef * ew;
+                const int ew = 5 + nza + nxa, aw = 1 + kAxisMaxRef * ew; // [cost | row | length of its reference | stride per step | where the controller-wide one sits | coefficients]
                 std::vector<double> ac((size_t)nu * aw, 0.0);
                 bool fits = P.ncost <= kMaxCosts;
                 for (int c = 0; c < nu && fits; ++c) {
@@ -662,8 +662,11 @@ inline void build_lane_tables(HostPlan& hp)
                             double* dst = ac.data() + (size_t)c * aw + 1 + (size_t)nref * ew;
                             dst[0] = (double)t;
                             dst[1] = (double)r;
-                            for (int a = 0; a < nza; ++a) dst[2 + a] = ch[a];
-                            for (int a = 0; a < nxa; ++a) dst[2 + nza + a] = cn[a];
+                            dst[2] = (double)ct.prows;
+                            dst[3] = (double)ct.pstride;
+                            dst[4] = (double)ct.offP;
+                            for (int a = 0; a < nza; ++a) dst[5 + a] = ch[a];
+                            for (int a = 0; a < nxa; ++a) dst[5 + nza + a] = cn[a];
                             nref += 1;
                         }
                     }
