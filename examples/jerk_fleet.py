@@ -47,10 +47,12 @@ def run(batch=32768, ticks=40, seed=0, noise=0.002):
     for tick in range(ticks):
         eng.set_system(A, B, d, x)
         eng.solve(stream)
-        x = X[:, nx:2 * nx] + noise * torch.randn((batch, nx), device=dev, generator=gen, dtype=torch.float64)  # the plant: step 1 + a disturbance
+        ok = (status == 0)[:, None]  # (a robot whose state violates its own velocity limit has no solution this tick: it coasts)
+        x = torch.where(ok, X[:, nx:2 * nx], x) + noise * torch.randn((batch, nx), device=dev, generator=gen, dtype=torch.float64)  # the plant: step 1 + a disturbance
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
-    dist = float(np.abs(X[:, nx:nx + 3].cpu().numpy() - goals[:, :3]).mean())
+    solved = (status == 0).cpu().numpy()
+    dist = float(np.abs(X[:, nx:nx + 3].cpu().numpy()[solved] - goals[solved, :3]).mean())
     out = dict(batch=batch, ticks=ticks, seconds=sec, solves_per_s=batch * ticks / sec, solved_last_tick=int((status == 0).sum().item()),
                axis_solver=bool(eng.axis_solver_ran()), lane_pass=eng.lane_pass_info(), mean_distance_to_goal=dist)
     eng.close()
