@@ -534,8 +534,16 @@ static copra_status_t ensure_lane_buffers(copra_batch* h, bool need_ws)
     if (e == hipSuccess && need_ws && !h->d_lane_ws) // (the shared-model form of the pass has no sweep: no workspace)
         e = hipMalloc((void**)&h->d_lane_ws, (size_t)P.N * lane_ws_rows(P.nx, P.nu) * bp * sizeof(double));
     const bool hand_over = P.lds.ricC && !h->hp.opt.no_lane_handover && (h->hp.opt.no_lane_spec || h->ad.lane_form_handover); // (solve_one_wave: the form of the pass that hands blocks over)
-    if (e == hipSuccess && need_ws && hand_over && !h->d_lane_ws2) // (the hand-over blocks: what only the first tier reads, instance-major)
-        e = hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double));
+    if (e == hipSuccess && need_ws && hand_over && !h->d_lane_ws2) { // (the hand-over blocks: what only the first tier reads, instance-major)
+        // (round-5 advisor: 126 MB at 65 536 instances -- without room for them the pass keeps its speculating form, which needs none, instead of
+        //  being switched off for good with everything else freed)
+        if (hipMalloc((void**)&h->d_lane_ws2, bp * (size_t)lane_ws2_doubles(P.nx, P.nu, P.N) * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_lane_ws2 = nullptr;
+            if (h->hp.opt.no_lane_spec) e = hipErrorOutOfMemory; // (no other form allowed: the tier alone)
+            else h->ad.lane_form_handover = false, h->ad.lane_ws2_failed = true;
+        }
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(h->d_lane_count);
@@ -581,7 +589,7 @@ static copra_status_t adapt_lane_pass(copra_batch* h)
         const long long ended = (long long)h->hp.plan.batch - left_over;
         // (... and where the steps it takes itself end fewer than one instance in twelve, they do not pay for the two trajectories that ride
         //  along -- + 45 us per 65 536 instances against 8 ns per instance the tier is spared: the hand-over form does not carry them)
-        if (ended * 4 < (long long)h->hp.plan.batch || (long long)by_steps * 12 < (long long)h->hp.plan.batch) h->ad.lane_form_handover = true;
+        if ((ended * 4 < (long long)h->hp.plan.batch || (long long)by_steps * 12 < (long long)h->hp.plan.batch) && !h->ad.lane_ws2_failed) h->ad.lane_form_handover = true;
         if (h->hp.opt.debug)
             fprintf(stderr, "[copra] one-instance-per-lane pass (speculating form): %lld of %d instances ended in it, %d of them by its own steps%s\n", ended,
                 h->hp.plan.batch, by_steps, h->ad.lane_form_handover ? " -- the hand-over form from now on" : "");

@@ -76,6 +76,7 @@ struct AdaptState {
     int lane_adapt_left = 2;
     bool lane_spec_shared_off = false; // the shared-model form of the pass does not take steps itself (too few instances end by them)
     bool lane_form_handover = false; // the pass runs in its hand-over form (too few instances end in the speculating one: adapt_lane_pass)
+    bool lane_ws2_failed = false; // ... whose blocks found no room once (ensure_lane_buffers): the speculating form stays
     long long lane_solves = 0; // solves seen by adapt_lane_pass
     // the one-(instance, axis)-per-lane solver (lmpc_axis.hpp)
     bool axis_ran = false; // the last solve ran it
